@@ -1,0 +1,473 @@
+/*
+ * bvg_oracle.c -- CPU restatement of the BVGraph decode path of vigna/webgraph.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the parity oracle for the HIP decoder in
+ * webgraph_amd/csrc.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load it, and only as the checker / the timed CPU baseline -- never as a product path.
+ *
+ * Parity status: PINNED for the default coding set (gamma outdegrees/blocks/block counts/intervals/
+ * offsets, unary references, zeta_3 residuals) by the reference's own known-answer fixture
+ * slow/it/unimi/dsi/webgraph/cnr-2000.{graph,offsets,properties,graph-txt.gz}
+ * (BVGraphTest.testLarge, test/it/unimi/dsi/webgraph/BVGraphTest.java:101-119); see
+ * tests/test_oracle_golden.py.  delta / Golomb / nibble / zeta_k (k != 3) codes are restated from the
+ * published dsiutils definitions (it.unimi.dsi:dsiutils, unpinned "latest.release" in ivy.xml:21) and
+ * are "parity unpinned": the reference holds no vector for them.
+ *
+ * Every function cites the reference lines it follows.  "BVG" = src/it/unimi/dsi/webgraph/BVGraph.java.
+ * The restatement is eager (arrays instead of lazy iterator objects) but keeps the reference's
+ * evaluation order and the exact semantics of MaskedIntIterator / MergedIntIterator /
+ * IntIntervalSequenceIterator.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define BVO_OK 0
+#define BVO_EARG -1     /* IllegalArgumentException  (BVG:860, :900, :1037, :1165) */
+#define BVO_ESTATE -2   /* IllegalStateException     (BVG:705 reference > window) */
+#define BVO_EUNSUP -3   /* UnsupportedOperationException (BVG:635 etc., unknown coding) */
+#define BVO_ENOMEM -4
+#define BVO_ECAP -5     /* caller's successor buffer too small */
+
+/* CompressionFlags.java:26-44 */
+enum { C_DELTA = 1, C_GAMMA = 2, C_GOLOMB = 3, C_SKEWED_GOLOMB = 4, C_UNARY = 5, C_ZETA = 6, C_NIBBLE = 7 };
+
+typedef struct {
+	int32_t n;             /* nodes */
+	int32_t window;        /* windowsize */
+	int32_t min_interval;  /* minintervallength, 0 = NO_INTERVALS */
+	int32_t zeta_k;
+	int32_t outdegree_coding, block_coding, residual_coding, reference_coding, block_count_coding, offset_coding;
+} bvo_params;
+
+typedef struct {
+	uint8_t *g;      /* padded copy of the .graph bytes */
+	size_t len;      /* unpadded length */
+	bvo_params p;
+	const int64_t *offsets; /* n+1 bit offsets, borrowed; may be NULL (sequential only) */
+	/* outdegree cache of BVG:443-448 is an optimisation with no visible effect: not restated */
+} bvo_graph;
+
+/* ---------------------------------------------------------------- bit input (dsiutils InputBitStream) */
+
+typedef struct { const uint8_t *b; uint64_t pos; uint64_t limit; int err; } ibs_t;
+
+/* MSB-first: bit i of the stream is bit 7-(i mod 8) of byte i/8. */
+static inline uint64_t peek57(const ibs_t *s) {
+	const uint8_t *p = s->b + (s->pos >> 3);
+	uint64_t w = ((uint64_t)p[0] << 56) | ((uint64_t)p[1] << 48) | ((uint64_t)p[2] << 40) | ((uint64_t)p[3] << 32) |
+	             ((uint64_t)p[4] << 24) | ((uint64_t)p[5] << 16) | ((uint64_t)p[6] << 8) | (uint64_t)p[7];
+	return w << (s->pos & 7); /* at least 57 valid leading bits */
+}
+
+/* InputBitStream.readLong(len), len in 0..64 */
+static inline uint64_t read_bits(ibs_t *s, unsigned len) {
+	uint64_t v = 0;
+	while (len > 32) { /* at most twice */
+		if (s->pos + 32 > s->limit) { s->err = 1; return 0; }
+		v = (v << 32) | (peek57(s) >> 32);
+		s->pos += 32; len -= 32;
+	}
+	if (len == 0) return v;
+	if (s->pos + len > s->limit) { s->err = 1; return 0; }
+	v = (len == 64 ? 0 : (v << len)) | (peek57(s) >> (64 - len));
+	s->pos += len;
+	return v;
+}
+
+/* InputBitStream.readUnary(): number of zeros before the first one. */
+static inline uint64_t read_unary(ibs_t *s) {
+	uint64_t z = 0;
+	for (;;) {
+		if (s->pos >= s->limit) { s->err = 1; return z; }
+		uint64_t w = peek57(s) >> 8 << 8; /* keep 56 bits */
+		if (w) {
+			unsigned c = (unsigned)__builtin_clzll(w);
+			z += c; s->pos += c + 1;
+			if (s->pos > s->limit) s->err = 1;
+			return z;
+		}
+		z += 56; s->pos += 56;
+	}
+}
+
+/* InputBitStream.readLongGamma(): encodes x+1 as unary(msb) + msb low bits. */
+static inline uint64_t read_gamma(ibs_t *s) {
+	uint64_t m = read_unary(s);
+	if (m > 63) { s->err = 1; return 0; }
+	return (((uint64_t)1 << m) | read_bits(s, (unsigned)m)) - 1;
+}
+
+/* InputBitStream.readLongDelta(): gamma-coded length then the low bits. */
+static inline uint64_t read_delta(ibs_t *s) {
+	uint64_t m = read_gamma(s);
+	if (m > 63) { s->err = 1; return 0; }
+	return (((uint64_t)1 << m) | read_bits(s, (unsigned)m)) - 1;
+}
+
+/* InputBitStream.readLongZeta(k): x+1 in minimal binary over [2^{hk}, 2^{(h+1)k}) after unary h. */
+static inline uint64_t read_zeta(ibs_t *s, int k) {
+	uint64_t h = read_unary(s);
+	if (h * (uint64_t)k + (uint64_t)k - 1 > 63) { s->err = 1; return 0; }
+	unsigned hk = (unsigned)(h * k);
+	uint64_t left = (uint64_t)1 << hk;
+	uint64_t m = read_bits(s, hk + k - 1);
+	if (m < left) return m + left - 1;
+	return ((m << 1) | read_bits(s, 1)) - 1;
+}
+
+/* InputBitStream.readLongGolomb(b): unary quotient, minimal-binary remainder; b == 0 reads nothing. */
+static inline uint64_t read_golomb(ibs_t *s, int b) {
+	if (b == 0) return 0;
+	unsigned log2b = 63 - (unsigned)__builtin_clzll((uint64_t)b);
+	uint64_t q = read_unary(s);
+	uint64_t mm = ((uint64_t)1 << (log2b + 1)) - (uint64_t)b;
+	uint64_t x = read_bits(s, log2b);
+	uint64_t r = x < mm ? x : ((x << 1) | read_bits(s, 1)) - mm;
+	return q * (uint64_t)b + r;
+}
+
+/* InputBitStream.readLongNibble(): groups of (stop bit, 3 data bits), most significant group first. */
+static inline uint64_t read_nibble(ibs_t *s) {
+	uint64_t x = 0, stop;
+	do {
+		x <<= 3;
+		stop = read_bits(s, 1);
+		x |= read_bits(s, 3);
+	} while (!stop && !s->err);
+	return x;
+}
+
+/* Fast.nat2int */
+static inline int64_t nat2int(uint64_t v) { return (int64_t)(v >> 1) ^ -(int64_t)(v & 1); }
+
+/* BVG:631-637 / :658-664 / :697-707 / :732-739 / :762-769 / :790-816 -- coding dispatch */
+static uint64_t read_coded(ibs_t *s, int coding, int k, int *unsup) {
+	switch (coding) {
+	case C_GAMMA: return read_gamma(s);
+	case C_DELTA: return read_delta(s);
+	case C_UNARY: return read_unary(s);
+	case C_ZETA: return read_zeta(s, k);
+	case C_GOLOMB: return read_golomb(s, k);
+	case C_NIBBLE: return read_nibble(s);
+	default: *unsup = 1; return 0;
+	}
+}
+
+static int coding_allowed(const bvo_params *p) {
+	/* the switch statements of BVG:631-816 accept exactly these */
+	int c;
+	c = p->offset_coding; if (c != C_GAMMA && c != C_DELTA) return 0;
+	c = p->outdegree_coding; if (c != C_GAMMA && c != C_DELTA) return 0;
+	c = p->reference_coding; if (c != C_UNARY && c != C_GAMMA && c != C_DELTA) return 0;
+	c = p->block_count_coding; if (c != C_UNARY && c != C_GAMMA && c != C_DELTA) return 0;
+	c = p->block_coding; if (c != C_UNARY && c != C_GAMMA && c != C_DELTA) return 0;
+	c = p->residual_coding; if (c != C_GAMMA && c != C_ZETA && c != C_DELTA && c != C_GOLOMB && c != C_NIBBLE) return 0;
+	return 1;
+}
+
+/* ---------------------------------------------------------------- open / close */
+
+bvo_graph *bvo_open(const uint8_t *graph, size_t len, const bvo_params *p, const int64_t *offsets) {
+	if (!coding_allowed(p)) return NULL;
+	bvo_graph *h = (bvo_graph *)calloc(1, sizeof *h);
+	if (!h) return NULL;
+	h->g = (uint8_t *)calloc(len + 16, 1);
+	if (!h->g) { free(h); return NULL; }
+	memcpy(h->g, graph, len);
+	h->len = len; h->p = *p; h->offsets = offsets;
+	return h;
+}
+
+void bvo_close(bvo_graph *h) { if (h) { free(h->g); free(h); } }
+
+/* ---------------------------------------------------------------- offsets: BVG:907-935 OffsetsLongIterator */
+
+int bvo_decode_offsets(const uint8_t *offs, size_t len, int32_t n, int coding, int64_t *out) {
+	if (coding != C_GAMMA && coding != C_DELTA) return BVO_EUNSUP;
+	uint8_t *b = (uint8_t *)calloc(len + 16, 1);
+	if (!b) return BVO_ENOMEM;
+	memcpy(b, offs, len);
+	ibs_t s = { b, 0, (uint64_t)len * 8, 0 };
+	int64_t off = 0;
+	for (int64_t i = 0; i <= n; i++) { /* n+1 values, BVG:1594 */
+		off += (int64_t)(coding == C_GAMMA ? read_gamma(&s) : read_delta(&s)); /* readOffset BVG:631-637 */
+		out[i] = off;
+		if (s.err) { free(b); return BVO_EARG; }
+	}
+	free(b);
+	return BVO_OK;
+}
+
+/* ---------------------------------------------------------------- outdegree: BVG:858-888 */
+
+static int outdegree_at(const bvo_graph *h, int32_t x, int32_t *d, uint64_t *pos_after) {
+	ibs_t s = { h->g, (uint64_t)h->offsets[x], (uint64_t)h->len * 8, 0 };
+	int unsup = 0;
+	*d = (int32_t)read_coded(&s, h->p.outdegree_coding, 0, &unsup);
+	if (pos_after) *pos_after = s.pos;
+	return s.err ? BVO_EARG : BVO_OK;
+}
+
+int bvo_outdegree(const bvo_graph *h, int32_t x, int32_t *d) {
+	if (x < 0 || x >= h->p.n) return BVO_EARG;      /* BVG:860 */
+	if (!h->offsets) return BVO_ESTATE;             /* BVG:869 */
+	return outdegree_at(h, x, d, NULL);
+}
+
+/* ---------------------------------------------------------------- the core: BVG:1032-1133 */
+
+typedef struct { int32_t *v; size_t cap; } ivec;
+static int ivec_need(ivec *a, size_t n) {
+	if (n <= a->cap) return 0;
+	size_t c = a->cap ? a->cap : 16; while (c < n) c *= 2;
+	int32_t *nv = (int32_t *)realloc(a->v, c * sizeof(int32_t));
+	if (!nv) return -1;
+	a->v = nv; a->cap = c; return 0;
+}
+
+/*
+ * Decodes the record of node x at stream position s into out[0..d).
+ * window == NULL  -> random access: outdegree via offsets, referent list by recursion (BVG:1046-1047, :1069, :1120)
+ * window != NULL  -> sequential: s is positioned before the outdegree; window[(x-i) mod (W+1)] / outd[] as BVG:1136-1213
+ * Returns d >= 0 or a negative error.  *outp receives a malloc'ed / reused buffer through `dst`.
+ */
+static int64_t decode_record(const bvo_graph *h, int32_t x, ibs_t *s, int32_t **window, int32_t *outd, ivec *dst) {
+	const bvo_params *p = &h->p;
+	if (x < 0 || x >= p->n) return BVO_EARG; /* BVG:1037 */
+	const int cyc = p->window + 1;           /* cyclicBufferSize BVG:1041 */
+	int unsup = 0;
+	int32_t d;
+
+	if (!window) { /* BVG:1045-1047 */
+		uint64_t after;
+		if (!h->offsets) return BVO_ESTATE;
+		int rc = outdegree_at(h, x, &d, &after); if (rc) return rc;
+		s->pos = after;
+	} else {
+		d = (int32_t)read_coded(s, p->outdegree_coding, 0, &unsup); /* BVG:1048 */
+		outd[x % cyc] = d;
+	}
+	if (s->err || d < 0) return BVO_EARG;
+	if (d == 0) return 0; /* BVG:1049 */
+
+	int32_t ref = -1; /* BVG:1053-1054 */
+	if (p->window > 0) {
+		ref = (int32_t)read_coded(s, p->reference_coding, 0, &unsup);
+		if (ref > p->window) return BVO_ESTATE; /* BVG:705 */
+	}
+	const int refIndex = (int)(((int64_t)x - ref + cyc) % cyc); /* BVG:1056 */
+
+	int32_t blockCount = 0, extraCount;
+	int32_t *block = NULL;
+	int32_t refd = 0;
+	if (ref > 0) { /* BVG:1058-1071 */
+		if (x - ref < 0) return BVO_EARG;
+		blockCount = (int32_t)read_coded(s, p->block_count_coding, 0, &unsup);
+		if (s->err || blockCount < 0) return BVO_EARG;
+		if (blockCount) { block = (int32_t *)malloc(sizeof(int32_t) * (size_t)blockCount); if (!block) return BVO_ENOMEM; }
+		int32_t copied = 0, total = 0;
+		for (int32_t i = 0; i < blockCount; i++) {
+			block[i] = (int32_t)read_coded(s, p->block_coding, 0, &unsup) + (i == 0 ? 0 : 1);
+			total += block[i];
+			if ((i & 1) == 0) copied += block[i];
+			if (s->err) { free(block); return BVO_EARG; }
+		}
+		if (window) refd = outd[refIndex];
+		else { int rc = outdegree_at(h, x - ref, &refd, NULL); if (rc) { free(block); return rc; } }
+		if ((blockCount & 1) == 0) copied += refd - total; /* BVG:1069 */
+		extraCount = d - copied;
+	} else extraCount = d;
+	if (extraCount < 0 || extraCount > d) { free(block); return BVO_EARG; }
+
+	/* intervals: BVG:1073-1096, always gamma */
+	int32_t intervalCount = 0, *left = NULL, *len = NULL;
+	if (extraCount > 0 && p->min_interval != 0 && (intervalCount = (int32_t)read_gamma(s)) != 0) {
+		if (s->err || intervalCount < 0 || intervalCount > extraCount) { free(block); return BVO_EARG; }
+		left = (int32_t *)malloc(sizeof(int32_t) * (size_t)intervalCount);
+		len = (int32_t *)malloc(sizeof(int32_t) * (size_t)intervalCount);
+		if (!left || !len) { free(block); free(left); free(len); return BVO_ENOMEM; }
+		int32_t prev;
+		left[0] = prev = (int32_t)(nat2int(read_gamma(s)) + x); /* readLongGamma, BVG:1084 */
+		len[0] = (int32_t)read_gamma(s) + p->min_interval;
+		prev += len[0]; extraCount -= len[0];
+		for (int32_t i = 1; i < intervalCount; i++) {
+			left[i] = prev = (int32_t)read_gamma(s) + prev + 1;
+			len[i] = (int32_t)read_gamma(s) + p->min_interval;
+			prev += len[i]; extraCount -= len[i];
+			if (s->err) break;
+		}
+		if (s->err || extraCount < 0) { free(block); free(left); free(len); return BVO_EARG; }
+	}
+	const int32_t residualCount = extraCount;
+
+	if (ivec_need(dst, (size_t)d)) { free(block); free(left); free(len); return BVO_ENOMEM; }
+	int32_t *out = dst->v;
+
+	/* Build the three increasing streams eagerly, then merge exactly like
+	 * Merged(Masked(block, referent), Merged(Intervals, Residuals))  (BVG:1103-1126). */
+	size_t nInt = 0; for (int32_t i = 0; i < intervalCount; i++) nInt += (size_t)len[i];
+	size_t nExtra = nInt + (size_t)residualCount;
+	int32_t *extra = (int32_t *)malloc(sizeof(int32_t) * (nExtra ? nExtra : 1));
+	int32_t *ivals = (int32_t *)malloc(sizeof(int32_t) * (nInt ? nInt : 1));
+	int32_t *res = (int32_t *)malloc(sizeof(int32_t) * (residualCount ? (size_t)residualCount : 1));
+	int32_t *masked = NULL; size_t nMasked = 0;
+	int64_t rc = 0;
+	if (!extra || !ivals || !res) { rc = BVO_ENOMEM; goto done; }
+
+	{ /* IntIntervalSequenceIterator.java:64-78 */
+		size_t k = 0;
+		for (int32_t i = 0; i < intervalCount; i++) for (int32_t j = 0; j < len[i]; j++) ivals[k++] = left[i] + j;
+	}
+	if (residualCount) { /* ResidualIntIterator BVG:939-991: first value with the long decoder, eagerly */
+		int32_t next = (int32_t)(x + nat2int(read_coded(s, p->residual_coding, p->zeta_k, &unsup)));
+		res[0] = next;
+		for (int32_t i = 1; i < residualCount; i++) {
+			next += (int32_t)read_coded(s, p->residual_coding, p->zeta_k, &unsup) + 1; /* BVG:966 */
+			res[i] = next;
+		}
+		if (s->err) { rc = BVO_EARG; goto done; }
+	}
+	size_t ne = 0;
+	{ /* MergedIntIterator.java:50-74 over (intervals, residuals): equal heads emitted once */
+		size_t a = 0, b = 0;
+		while (a < nInt || b < (size_t)residualCount) {
+			if (a < nInt && (b >= (size_t)residualCount || ivals[a] < res[b])) extra[ne++] = ivals[a++];
+			else { if (a < nInt && ivals[a] == res[b]) a++; extra[ne++] = res[b++]; }
+		}
+	}
+
+	if (ref > 0) { /* MaskedIntIterator.java:65-97 over the referent list */
+		const int32_t *rl; int32_t rn;
+		ivec sub = { NULL, 0 };
+		if (window) { rl = window[refIndex]; rn = outd[refIndex]; }
+		else { /* the recursive lazy part, BVG:1120 */
+			ibs_t s2 = { h->g, 0, (uint64_t)h->len * 8, 0 };
+			int64_t rd = decode_record(h, x - ref, &s2, NULL, NULL, &sub);
+			if (rd < 0) { free(sub.v); rc = rd; goto done; }
+			rl = sub.v; rn = (int32_t)rd;
+		}
+		masked = (int32_t *)malloc(sizeof(int32_t) * (rn > 0 ? (size_t)rn : 1));
+		if (!masked) { free(sub.v); rc = BVO_ENOMEM; goto done; }
+		int32_t i = 0; int keep = 1;
+		for (int32_t b = 0; b < blockCount; b++) {
+			for (int32_t t = 0; t < block[b] && i < rn; t++, i++) if (keep) masked[nMasked++] = rl[i];
+			keep = !keep;
+		}
+		/* after the mask: keep the rest iff the mask length is even (incl. 0) */
+		if ((blockCount & 1) == 0) while (i < rn) masked[nMasked++] = rl[i++];
+		free(sub.v);
+	}
+
+	{ /* outer MergedIntIterator(blockIterator, extraIterator); BVG:1210 pulls exactly d values, -1 once exhausted */
+		size_t a = 0, b = 0; int32_t k = 0;
+		while (k < d) {
+			if (a < nMasked && (b >= ne || masked[a] < extra[b])) out[k++] = masked[a++];
+			else if (b < ne) { if (a < nMasked && masked[a] == extra[b]) a++; out[k++] = extra[b++]; }
+			else out[k++] = -1;
+		}
+	}
+	rc = unsup ? BVO_EUNSUP : d;
+done:
+	free(block); free(left); free(len); free(extra); free(ivals); free(res); free(masked);
+	return rc;
+}
+
+/* BVGraph.successors(x) + ImmutableGraph.successorArray(x): BVG:897-904, ImmutableGraph.java:329-333 */
+int64_t bvo_successors(const bvo_graph *h, int32_t x, int32_t *out, size_t cap) {
+	if (x < 0 || x >= h->p.n) return BVO_EARG; /* BVG:900 */
+	if (!h->offsets) return BVO_EUNSUP;         /* BVG:901 */
+	ibs_t s = { h->g, 0, (uint64_t)h->len * 8, 0 };
+	ivec dst = { NULL, 0 };
+	int64_t d = decode_record(h, x, &s, NULL, NULL, &dst);
+	if (d > 0) { if ((size_t)d > cap) d = BVO_ECAP; else memcpy(out, dst.v, sizeof(int32_t) * (size_t)d); }
+	free(dst.v);
+	return d;
+}
+
+/*
+ * Sequential scan of nodes [from, to): BVGraphNodeIterator (BVG:1136-1281) driven as
+ * nodeIterator(from).copy(to) -- the split of ImmutableGraph.splitNodeIterators (ImmutableGraph.java:389-393).
+ * For from != 0 the window is refilled by random access exactly as BVG:1173-1183.
+ * rowptr gets to-from+1 entries relative to the range; succ may be NULL (count / hash only).
+ * hash_io, when non-NULL, continues the ImmutableGraph.hashCode recurrence (ImmutableGraph.java:757-770).
+ */
+int bvo_scan(const bvo_graph *h, int32_t from, int32_t to, int64_t *rowptr, int32_t *succ, size_t cap,
+             uint64_t *arcs_out, int32_t *hash_io) {
+	const bvo_params *p = &h->p;
+	if (from < 0 || from > p->n) return BVO_EARG; /* BVG:1165 */
+	if (to > p->n) to = p->n;
+	if (to < from) to = from;
+	const int cyc = p->window + 1;
+	int rc = BVO_OK;
+	ivec *win = (ivec *)calloc((size_t)cyc, sizeof(ivec));
+	int32_t **window = (int32_t **)calloc((size_t)cyc, sizeof(int32_t *));
+	int32_t *outd = (int32_t *)calloc((size_t)cyc, sizeof(int32_t));
+	if (!win || !window || !outd) { rc = BVO_ENOMEM; goto out; }
+	ibs_t s = { h->g, 0, (uint64_t)h->len * 8, 0 };
+	if (from != 0) { /* BVG:1173-1183 */
+		if (!h->offsets) { rc = BVO_ESTATE; goto out; }
+		for (int i = 1; i < (from + 1 < cyc ? from + 1 : cyc); i++) {
+			int pos = (int)(((int64_t)from - i + cyc) % cyc);
+			ibs_t s2 = { h->g, 0, (uint64_t)h->len * 8, 0 };
+			int64_t d = decode_record(h, from - i, &s2, NULL, NULL, &win[pos]);
+			if (d < 0) { rc = (int)d; goto out; }
+			outd[pos] = (int32_t)d;
+		}
+		s.pos = (uint64_t)h->offsets[from];
+	}
+	uint64_t arcs = 0;
+	uint32_t hh = hash_io ? (uint32_t)*hash_io : 0;
+	if (rowptr) rowptr[0] = 0;
+	for (int32_t x = from; x < to; x++) { /* nextInt(), BVG:1201-1213 */
+		const int idx = x % cyc;
+		for (int i = 0; i < cyc; i++) window[i] = win[i].v;
+		int64_t d = decode_record(h, x, &s, window, outd, &win[idx]);
+		if (d < 0) { rc = (int)d; goto out; }
+		if (succ) {
+			if (arcs + (uint64_t)d > cap) { rc = BVO_ECAP; goto out; }
+			memcpy(succ + arcs, win[idx].v, sizeof(int32_t) * (size_t)d);
+		}
+		if (hash_io) { /* ImmutableGraph.java:762-766 */
+			hh = hh * 31u + (uint32_t)x;
+			for (int64_t j = d; j-- != 0;) hh = hh * 31u + (uint32_t)win[idx].v[j];
+		}
+		arcs += (uint64_t)d;
+		if (rowptr) rowptr[x - from + 1] = (int64_t)arcs;
+	}
+	if (arcs_out) *arcs_out = arcs;
+	if (hash_io) *hash_io = (int32_t)hh;
+out:
+	if (win) for (int i = 0; i < cyc; i++) free(win[i].v);
+	free(win); free(window); free(outd);
+	return rc;
+}
+
+/* outdegrees of [from,to) through the random-access path (BVG:858-888) */
+int bvo_outdegrees(const bvo_graph *h, int32_t from, int32_t to, int32_t *out) {
+	if (from < 0 || to > h->p.n || from > to) return BVO_EARG;
+	if (!h->offsets) return BVO_ESTATE;
+	for (int32_t x = from; x < to; x++) { int rc = outdegree_at(h, x, &out[x - from], NULL); if (rc) return rc; }
+	return BVO_OK;
+}
+
+/* batch of random-access successor lists: concatenation of successorArray(nodes[i]) */
+int bvo_successors_batch(const bvo_graph *h, const int32_t *nodes, size_t q, int64_t *rowptr, int32_t *succ, size_t cap) {
+	uint64_t arcs = 0;
+	rowptr[0] = 0;
+	ivec dst = { NULL, 0 };
+	for (size_t i = 0; i < q; i++) {
+		if (nodes[i] < 0 || nodes[i] >= h->p.n) { free(dst.v); return BVO_EARG; }
+		ibs_t s = { h->g, 0, (uint64_t)h->len * 8, 0 };
+		int64_t d = decode_record(h, nodes[i], &s, NULL, NULL, &dst);
+		if (d < 0) { free(dst.v); return (int)d; }
+		if (succ) {
+			if (arcs + (uint64_t)d > cap) { free(dst.v); return BVO_ECAP; }
+			memcpy(succ + arcs, dst.v, sizeof(int32_t) * (size_t)d);
+		}
+		arcs += (uint64_t)d;
+		rowptr[i + 1] = (int64_t)arcs;
+	}
+	free(dst.v);
+	return BVO_OK;
+}

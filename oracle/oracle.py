@@ -1,0 +1,256 @@
+"""ctypes front-end of the CPU parity oracle (oracle/bvg_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg -- never by anything under webgraph_amd/.  See the header of bvg_oracle.c for the parity status
+(pinned by the reference's cnr-2000 fixture for the default codings).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libbvgoracle.so")
+
+# CompressionFlags.java:26-44
+DELTA, GAMMA, GOLOMB, SKEWED_GOLOMB, UNARY, ZETA, NIBBLE = 1, 2, 3, 4, 5, 6, 7
+_CODING = {"DELTA": DELTA, "GAMMA": GAMMA, "GOLOMB": GOLOMB, "SKEWED_GOLOMB": SKEWED_GOLOMB,
+           "UNARY": UNARY, "ZETA": ZETA, "NIBBLE": NIBBLE}
+# BVGraph.java:475-523: field name prefix -> bit shift inside the flag word (BVGraph.java:1317-1325)
+_FIELD_SHIFT = {"OUTDEGREES": 0, "BLOCKS": 4, "RESIDUALS": 8, "REFERENCES": 12, "BLOCK_COUNT": 16, "OFFSETS": 20}
+
+
+class Params(C.Structure):
+    _fields_ = [("n", C.c_int32), ("window", C.c_int32), ("min_interval", C.c_int32), ("zeta_k", C.c_int32),
+                ("outdegree_coding", C.c_int32), ("block_coding", C.c_int32), ("residual_coding", C.c_int32),
+                ("reference_coding", C.c_int32), ("block_count_coding", C.c_int32), ("offset_coding", C.c_int32)]
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_HERE, "bvg_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build())
+        L.bvo_open.restype = C.c_void_p
+        L.bvo_open.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(Params), C.c_void_p]
+        L.bvo_close.argtypes = [C.c_void_p]
+        L.bvo_decode_offsets.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.c_int, C.c_void_p]
+        L.bvo_outdegree.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+        L.bvo_outdegrees.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        L.bvo_successors.restype = C.c_int64
+        L.bvo_successors.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t]
+        L.bvo_scan.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t,
+                               C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
+        L.bvo_successors_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
+        _lib = L
+    return _lib
+
+
+def parse_properties(path):
+    """Minimal java.util.Properties reader (key=value, '#'/'!' comments); enough for BVGraph.java:1528-1543."""
+    props = {}
+    with open(path, "r", encoding="latin-1") as f:
+        for line in f:
+            line = line.strip()
+            if not line or line[0] in "#!":
+                continue
+            for sep in "=:":
+                if sep in line:
+                    k, v = line.split(sep, 1)
+                    props[k.strip()] = v.strip()
+                    break
+    return props
+
+
+def flags_from_string(s):
+    """BVGraph.string2Flags (BVGraph.java:1352-1366): 'A | B' of constant names -> flag word."""
+    flags = 0
+    if s:
+        for tok in s.split("|"):
+            tok = tok.strip()
+            if not tok:
+                continue
+            for prefix, shift in _FIELD_SHIFT.items():
+                if tok.startswith(prefix + "_") and tok[len(prefix) + 1:] in _CODING:
+                    flags |= _CODING[tok[len(prefix) + 1:]] << shift
+                    break
+            else:
+                raise IOError("Compression flag %s unknown." % tok)
+    return flags
+
+
+def params_from_properties(props):
+    """BVGraph.loadInternal (BVGraph.java:1528-1543) + setFlags (:1317-1325)."""
+    gc = props.get("graphclass", "").replace("it.unimi.dsi.big.webgraph", "it.unimi.dsi.webgraph")
+    if gc != "it.unimi.dsi.webgraph.BVGraph":
+        raise IOError("cannot load a graph stored using class " + gc)
+    if "version" not in props:
+        raise IOError("Missing format version information")
+    if int(props["version"]) > 0:
+        raise IOError("unsupported format version")
+    n = int(props["nodes"])
+    if n > 2**31 - 1:
+        raise ValueError("too many nodes")
+    flags = flags_from_string(props.get("compressionflags", ""))
+    p = Params()
+    p.n = n
+    p.window = int(props["windowsize"])
+    p.min_interval = int(props["minintervallength"])
+    p.zeta_k = int(props.get("zetak", 3))
+    p.outdegree_coding = (flags & 0xF) or GAMMA
+    p.block_coding = ((flags >> 4) & 0xF) or GAMMA
+    p.residual_coding = ((flags >> 8) & 0xF) or ZETA
+    p.reference_coding = ((flags >> 12) & 0xF) or UNARY
+    p.block_count_coding = ((flags >> 16) & 0xF) or GAMMA
+    p.offset_coding = ((flags >> 20) & 0xF) or GAMMA
+    return p, int(props["arcs"])
+
+
+class OracleError(Exception):
+    def __init__(self, code):
+        super().__init__("oracle error %d" % code)
+        self.code = code
+
+
+class OracleGraph:
+    """Restatement of an in-memory BVGraph (ImmutableGraph.load(basename))."""
+
+    def __init__(self, graph_bytes, params, offsets=None, arcs=None):
+        self.params = params
+        self.n = params.n
+        self.arcs = arcs
+        self._graph = np.frombuffer(graph_bytes, dtype=np.uint8)
+        self.offsets = None if offsets is None else np.ascontiguousarray(offsets, dtype=np.int64)
+        optr = None if self.offsets is None else self.offsets.ctypes.data
+        self._h = lib().bvo_open(self._graph.ctypes.data, self._graph.size, C.byref(params), optr)
+        if not self._h:
+            raise OracleError(-3)
+
+    @classmethod
+    def load(cls, basename, with_offsets=True):
+        props = parse_properties(basename + ".properties")
+        p, arcs = params_from_properties(props)
+        with open(basename + ".graph", "rb") as f:
+            g = f.read()
+        offs = None
+        if with_offsets:
+            with open(basename + ".offsets", "rb") as f:
+                ob = f.read()
+            offs = decode_offsets(ob, p.n, p.offset_coding)
+        return cls(g, p, offs, arcs)
+
+    def close(self):
+        if self._h:
+            lib().bvo_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def outdegree(self, x):
+        d = C.c_int32()
+        rc = lib().bvo_outdegree(self._h, x, C.byref(d))
+        if rc:
+            raise OracleError(rc)
+        return d.value
+
+    def outdegrees(self, lo=0, hi=None):
+        hi = self.n if hi is None else hi
+        out = np.empty(hi - lo, dtype=np.int32)
+        rc = lib().bvo_outdegrees(self._h, lo, hi, out.ctypes.data)
+        if rc:
+            raise OracleError(rc)
+        return out
+
+    def successors(self, x, cap=None):
+        if cap is None:
+            cap = max(self.outdegree(x), 1) if 0 <= x < self.n and self.offsets is not None else 1
+        out = np.empty(cap, dtype=np.int32)
+        d = lib().bvo_successors(self._h, x, out.ctypes.data, cap)
+        if d < 0:
+            raise OracleError(int(d))
+        return out[:d].copy()
+
+    def scan(self, lo=0, hi=None, want_succ=True, want_hash=False, cap=None):
+        """nodeIterator(lo).copy(hi) drained: returns (rowptr[hi-lo+1], succ, arcs[, hash])."""
+        hi = self.n if hi is None else hi
+        rowptr = np.empty(max(hi - lo, 0) + 1, dtype=np.int64)
+        arcs = C.c_uint64(0)
+        h = C.c_int32(-1)
+        if want_succ:
+            if cap is None:
+                # first a counting pass
+                rc = lib().bvo_scan(self._h, lo, hi, rowptr.ctypes.data, None, 0, C.byref(arcs), None)
+                if rc:
+                    raise OracleError(rc)
+                cap = arcs.value
+            succ = np.empty(max(cap, 1), dtype=np.int32)
+            rc = lib().bvo_scan(self._h, lo, hi, rowptr.ctypes.data, succ.ctypes.data, cap, C.byref(arcs),
+                                C.byref(h) if want_hash else None)
+            if rc:
+                raise OracleError(rc)
+            succ = succ[:arcs.value]
+        else:
+            succ = None
+            rc = lib().bvo_scan(self._h, lo, hi, rowptr.ctypes.data, None, 0, C.byref(arcs),
+                                C.byref(h) if want_hash else None)
+            if rc:
+                raise OracleError(rc)
+        if want_hash:
+            return rowptr, succ, arcs.value, h.value
+        return rowptr, succ, arcs.value
+
+    def hashcode(self):
+        """ImmutableGraph.hashCode() (ImmutableGraph.java:757-770)."""
+        return self.scan(0, self.n, want_succ=False, want_hash=True)[3]
+
+    def successors_batch(self, nodes):
+        nodes = np.ascontiguousarray(nodes, dtype=np.int32)
+        rowptr = np.empty(nodes.size + 1, dtype=np.int64)
+        rc = lib().bvo_successors_batch(self._h, nodes.ctypes.data, nodes.size, rowptr.ctypes.data, None, 0)
+        if rc:
+            raise OracleError(rc)
+        succ = np.empty(max(int(rowptr[-1]), 1), dtype=np.int32)
+        rc = lib().bvo_successors_batch(self._h, nodes.ctypes.data, nodes.size, rowptr.ctypes.data,
+                                        succ.ctypes.data, succ.size)
+        if rc:
+            raise OracleError(rc)
+        return rowptr, succ[:int(rowptr[-1])]
+
+
+def decode_offsets(offset_bytes, n, coding=GAMMA):
+    """OffsetsLongIterator (BVGraph.java:907-935): n+1 running sums of gamma/delta coded gaps."""
+    b = np.frombuffer(offset_bytes, dtype=np.uint8)
+    out = np.empty(n + 1, dtype=np.int64)
+    rc = lib().bvo_decode_offsets(b.ctypes.data, b.size, n, coding, out.ctypes.data)
+    if rc:
+        raise OracleError(rc)
+    return out
+
+
+def read_ascii_graph_gz(path):
+    """ASCIIGraph text format (ASCIIGraph.java:57-61): first line n, then one line of successors per node."""
+    import gzip
+    with gzip.open(path, "rt") as f:
+        n = int(f.readline())
+        rowptr = np.zeros(n + 1, dtype=np.int64)
+        chunks = []
+        for i in range(n):
+            line = f.readline()
+            a = np.array(line.split(), dtype=np.int32) if line.strip() else np.empty(0, dtype=np.int32)
+            chunks.append(a)
+            rowptr[i + 1] = rowptr[i] + a.size
+    succ = np.concatenate(chunks) if chunks else np.empty(0, dtype=np.int32)
+    return n, rowptr, succ
