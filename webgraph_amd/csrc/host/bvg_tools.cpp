@@ -1,0 +1,446 @@
+// bvg_tools.cpp -- CPU-side BVGraph writer + seeded synthetic graph generator (libbvgtools.so).
+//
+// The writer produces files in the reference's on-disk format so that the same .graph/.offsets/
+// .properties load both here and in it.unimi.dsi.webgraph.BVGraph.  It follows the *decisions* of the
+// reference compressor (which candidate reference is chosen, how copy blocks / intervals / residuals are
+// formed: BVGraph.java:2222-2386 `call`, :2049-2219 `diffComp`, :1631-1654 `intervalize`), but is organised
+// differently: candidate costs are computed arithmetically from code lengths instead of writing to a
+// bit-counting stream, per-thread streams live in memory and are spliced bit-exactly at the end.
+#include "../../../include/bvgtools.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cerrno>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+// CompressionFlags.java:26-44
+enum { DELTA = 1, GAMMA = 2, GOLOMB = 3, SKEWED_GOLOMB = 4, UNARY = 5, ZETA = 6, NIBBLE = 7 };
+
+inline int msb64(uint64_t v) { return 63 - __builtin_clzll(v); }
+
+// ---------------------------------------------------------------- code lengths (bits)
+inline uint64_t len_unary(uint64_t x) { return x + 1; }
+inline uint64_t len_gamma(uint64_t x) { return 2 * (uint64_t)msb64(x + 1) + 1; }
+inline uint64_t len_delta(uint64_t x) { int m = msb64(x + 1); return (uint64_t)m + len_gamma((uint64_t)m); }
+inline uint64_t len_zeta(uint64_t x, int k) {
+	uint64_t v = x + 1; int h = msb64(v) / k; uint64_t left = (uint64_t)1 << (h * k);
+	return (uint64_t)h + 1 + (v - left < left ? (uint64_t)(h * k + k - 1) : (uint64_t)(h * k + k));
+}
+inline uint64_t len_golomb(uint64_t x, int b) {
+	if (b == 0) return 0;
+	uint64_t q = x / b, r = x % b; int l2 = msb64((uint64_t)b); uint64_t mm = ((uint64_t)1 << (l2 + 1)) - b;
+	return q + 1 + (r < mm ? l2 : l2 + 1);
+}
+inline uint64_t len_nibble(uint64_t x) { return x == 0 ? 4 : 4 * (uint64_t)(msb64(x) / 3 + 1); }
+
+inline uint64_t code_len(int coding, uint64_t x, int k) {
+	switch (coding) {
+	case GAMMA: return len_gamma(x);
+	case DELTA: return len_delta(x);
+	case UNARY: return len_unary(x);
+	case ZETA: return len_zeta(x, k);
+	case GOLOMB: return len_golomb(x, k);
+	case NIBBLE: return len_nibble(x);
+	default: return 0;
+	}
+}
+
+// ---------------------------------------------------------------- MSB-first bit sink
+struct BitSink {
+	std::vector<uint64_t> w; // big-endian bit order inside each word: first stream bit = bit 63 of w[0]
+	uint64_t acc = 0; int fill = 0; uint64_t bits = 0;
+	void put(uint64_t v, int n) { // appends the low n bits of v, n in 0..64
+		if (n == 0) return;
+		bits += (uint64_t)n;
+		if (n < 64) v &= (((uint64_t)1 << n) - 1);
+		const int room = 64 - fill; // 1..64
+		if (n < room) { acc |= v << (room - n); fill += n; return; }
+		const int rest = n - room;  // 0..63
+		acc |= rest ? v >> rest : v;
+		w.push_back(acc);
+		acc = rest ? v << (64 - rest) : 0; fill = rest;
+	}
+	void zeros(uint64_t n) { while (n >= 64) { put(0, 64); n -= 64; } put(0, (int)n); }
+	void unary(uint64_t x) { zeros(x); put(1, 1); }
+	void gamma(uint64_t x) { int m = msb64(x + 1); zeros((uint64_t)m); put(x + 1, m + 1); }
+	void delta(uint64_t x) { int m = msb64(x + 1); gamma((uint64_t)m); put(x + 1, m); }
+	void zeta(uint64_t x, int k) {
+		uint64_t v = x + 1; int h = msb64(v) / k; unary((uint64_t)h);
+		uint64_t left = (uint64_t)1 << (h * k);
+		if (v - left < left) put(v - left, h * k + k - 1); else put(v, h * k + k);
+	}
+	void golomb(uint64_t x, int b) {
+		if (b == 0) return;
+		uint64_t q = x / b, r = x % b; unary(q);
+		int l2 = msb64((uint64_t)b); uint64_t mm = ((uint64_t)1 << (l2 + 1)) - b;
+		if (r < mm) put(r, l2); else put(r + mm, l2 + 1);
+	}
+	void nibble(uint64_t x) {
+		if (x == 0) { put(8, 4); return; }
+		int h = msb64(x) / 3;
+		do { put(h == 0 ? 1 : 0, 1); put((x >> (h * 3)) & 7, 3); } while (h-- != 0);
+	}
+	void code(int coding, uint64_t x, int k) {
+		switch (coding) {
+		case GAMMA: gamma(x); break;
+		case DELTA: delta(x); break;
+		case UNARY: unary(x); break;
+		case ZETA: zeta(x, k); break;
+		case GOLOMB: golomb(x, k); break;
+		case NIBBLE: nibble(x); break;
+		}
+	}
+	// append all bits of another sink
+	void append(const BitSink &o) {
+		for (uint64_t v : o.w) put(v, 64);
+		if (o.fill) put(o.acc >> (64 - o.fill), o.fill);
+	}
+	bool write_file(const std::string &path) const {
+		FILE *f = fopen(path.c_str(), "wb");
+		if (!f) return false;
+		std::vector<uint8_t> buf; buf.reserve(1 << 20);
+		auto flush = [&]() { if (!buf.empty()) { fwrite(buf.data(), 1, buf.size(), f); buf.clear(); } };
+		for (uint64_t v : w) { for (int s = 56; s >= 0; s -= 8) buf.push_back((uint8_t)(v >> s)); if (buf.size() >= (1 << 20)) flush(); }
+		int nb = (fill + 7) / 8;
+		for (int i = 0; i < nb; i++) buf.push_back((uint8_t)(acc >> (56 - 8 * i)));
+		flush();
+		bool ok = !ferror(f);
+		fclose(f);
+		return ok;
+	}
+};
+
+inline uint64_t int2nat(int64_t x) { return x >= 0 ? (uint64_t)x << 1 : (uint64_t)(-x) * 2 - 1; } // Fast.int2nat
+
+struct Codings { int outdegree = GAMMA, block = GAMMA, residual = ZETA, reference = UNARY, block_count = GAMMA, offset = GAMMA; };
+
+struct Cfg { int W, R, I, K; Codings c; };
+
+// One candidate's differential description (what diffComp builds before writing, BVGraph.java:2049-2172).
+struct Diff {
+	std::vector<int32_t> blocks, extras, left, len, residuals;
+	void build(const int32_t *ref, int refLen, const int32_t *cur, int curLen, int minInterval) {
+		blocks.clear(); extras.clear();
+		int j = 0, k = 0, run = 0; bool copying = true;
+		while (j < curLen && k < refLen) {
+			if (copying) {
+				if (cur[j] > ref[k]) { blocks.push_back(run); copying = false; run = 0; }
+				else if (cur[j] < ref[k]) extras.push_back(cur[j++]);
+				else { j++; k++; run++; }
+			} else if (cur[j] < ref[k]) extras.push_back(cur[j++]);
+			else if (cur[j] > ref[k]) { k++; run++; }
+			else { blocks.push_back(run); copying = true; run = 0; }
+		}
+		if (copying && k < refLen) blocks.push_back(run);
+		while (j < curLen) extras.push_back(cur[j++]);
+		left.clear(); len.clear(); residuals.clear();
+		if (minInterval != 0) { // intervalize, BVGraph.java:1631-1654
+			const int vl = (int)extras.size(); const int32_t *v = extras.data();
+			for (int i = 0; i < vl; i++) {
+				int q = 0;
+				if (i < vl - 1 && v[i] + 1 == v[i + 1]) {
+					do q++; while (i + q < vl - 1 && v[i + q] + 1 == v[i + q + 1]);
+					q++;
+					if (q >= minInterval) { left.push_back(v[i]); len.push_back(q); i += q - 1; }
+				}
+				if (q < minInterval) residuals.push_back(v[i]);
+			}
+		} else residuals = extras;
+	}
+	// bits this description takes (the forReal=false run of diffComp)
+	uint64_t cost(int32_t node, int ref, const Cfg &g) const {
+		uint64_t t = 0;
+		if (g.W > 0) t += code_len(g.c.reference, (uint64_t)ref, 0);
+		if (ref != 0) {
+			t += code_len(g.c.block_count, blocks.size(), 0);
+			for (size_t i = 0; i < blocks.size(); i++) t += code_len(g.c.block, (uint64_t)(i == 0 ? blocks[0] : blocks[i] - 1), 0);
+		}
+		if (!extras.empty()) {
+			if (g.I != 0) {
+				t += len_gamma(left.size());
+				int32_t prev = 0;
+				for (size_t i = 0; i < left.size(); i++) {
+					if (i == 0) t += len_gamma(int2nat((int64_t)left[0] - node));
+					else t += len_gamma((uint64_t)(left[i] - prev - 1));
+					prev = left[i] + len[i];
+					t += len_gamma((uint64_t)(len[i] - g.I));
+				}
+			}
+			if (!residuals.empty()) {
+				t += code_len(g.c.residual, int2nat((int64_t)residuals[0] - node), g.K);
+				for (size_t i = 1; i < residuals.size(); i++) t += code_len(g.c.residual, (uint64_t)(residuals[i] - residuals[i - 1] - 1), g.K);
+			}
+		}
+		return t;
+	}
+	void emit(BitSink &o, int32_t node, int ref, const Cfg &g, bvt_store_stats &st) const {
+		uint64_t b0 = o.bits;
+		if (g.W > 0) { o.code(g.c.reference, (uint64_t)ref, 0); st.bits_references += o.bits - b0; }
+		if (ref != 0) {
+			b0 = o.bits;
+			o.code(g.c.block_count, blocks.size(), 0);
+			for (size_t i = 0; i < blocks.size(); i++) o.code(g.c.block, (uint64_t)(i == 0 ? blocks[0] : blocks[i] - 1), 0);
+			st.bits_blocks += o.bits - b0;
+		}
+		if (!extras.empty()) {
+			if (g.I != 0) {
+				b0 = o.bits;
+				o.gamma(left.size());
+				int32_t prev = 0;
+				for (size_t i = 0; i < left.size(); i++) {
+					if (i == 0) o.gamma(int2nat((int64_t)left[0] - node)); else o.gamma((uint64_t)(left[i] - prev - 1));
+					prev = left[i] + len[i];
+					st.intervalised_arcs += (uint64_t)len[i];
+					o.gamma((uint64_t)(len[i] - g.I));
+				}
+				st.bits_intervals += o.bits - b0;
+			}
+			if (!residuals.empty()) {
+				b0 = o.bits;
+				st.residual_arcs += residuals.size();
+				o.code(g.c.residual, int2nat((int64_t)residuals[0] - node), g.K);
+				for (size_t i = 1; i < residuals.size(); i++) o.code(g.c.residual, (uint64_t)(residuals[i] - residuals[i - 1] - 1), g.K);
+				st.bits_residuals += o.bits - b0;
+			}
+		}
+	}
+};
+
+struct ThreadOut { BitSink graph; std::vector<uint64_t> reclen; bvt_store_stats st{}; int err = 0; };
+
+// CompressionThread.call for nodes [lo, hi): empty window at lo (BVGraph.java:2222-2386).
+void compress_range(int32_t lo, int32_t hi, const int64_t *rowptr, const int32_t *succ, const Cfg &g, ThreadOut &out) {
+	const int cyc = g.W + 1;
+	std::vector<int32_t> refCount(cyc, 0), listNode(cyc, -1);
+	Diff best, cand;
+	out.reclen.reserve((size_t)(hi - lo));
+	for (int32_t x = lo; x < hi; x++) {
+		const uint64_t start = out.graph.bits;
+		const int32_t *cur = succ + rowptr[x]; const int d = (int)(rowptr[x + 1] - rowptr[x]);
+		const int ci = x % cyc;
+		out.graph.code(g.c.outdegree, (uint64_t)d, 0);
+		out.st.bits_outdegrees += out.graph.bits - start;
+		listNode[ci] = x;
+		if (d > 0) {
+			for (int i = 1; i < d; i++) if (cur[i] <= cur[i - 1]) { out.err = -EINVAL; return; } // strictly increasing rows only
+			uint64_t bestCost = UINT64_MAX; int bestRef = -1, bestCand = -1;
+			refCount[ci] = -1;
+			for (int r = 0; r < cyc; r++) {
+				if (x - r < lo) break; // nothing before the range start: window starts empty
+				const int c = (int)(((int64_t)x - r + cyc) % cyc);
+				const int y = x - r; const int yl = (int)(rowptr[y + 1] - rowptr[y]);
+				if (refCount[c] < g.R && yl != 0) {
+					cand.build(succ + rowptr[y], r == 0 ? 0 : yl, cur, d, g.I);
+					uint64_t t = cand.cost(x, r, g);
+					if (t < bestCost) { bestCost = t; bestRef = r; bestCand = c; std::swap(best, cand); }
+				}
+			}
+			refCount[ci] = refCount[bestCand] + 1;
+			best.emit(out.graph, x, bestRef, g, out.st);
+			uint64_t copied = (uint64_t)d - best.extras.size();
+			out.st.copied_arcs += copied;
+			out.st.tot_ref += (uint64_t)refCount[ci];
+			out.st.tot_dist += (uint64_t)bestRef;
+			if (refCount[ci] > out.st.max_ref_chain) out.st.max_ref_chain = refCount[ci];
+		}
+		out.reclen.push_back(out.graph.bits - start);
+	}
+}
+
+std::string flags_to_string(uint32_t flags) { // flags2String, BVGraph.java:1333-1345
+	static const char *names[] = { "DEFAULT", "DELTA", "GAMMA", "GOLOMB", "SKEWED_GOLOMB", "UNARY", "ZETA", "NIBBLE" };
+	static const char *fields[] = { "OUTDEGREES_", "BLOCKS_", "RESIDUALS_", "REFERENCES_", "BLOCK_COUNT_", "OFFSETS_" };
+	std::string s;
+	for (int f = 0; f < 6; f++) {
+		unsigned c = (flags >> (4 * f)) & 0xF;
+		if (c && c < 8) { if (!s.empty()) s += " | "; s += fields[f]; s += names[c]; }
+	}
+	return s;
+}
+
+std::string fmt3(double v) { // DecimalFormat("0.###")
+	char b[64]; snprintf(b, sizeof b, "%.3f", v);
+	std::string s(b);
+	while (!s.empty() && s.back() == '0') s.pop_back();
+	if (!s.empty() && s.back() == '.') s.pop_back();
+	return s;
+}
+
+// ---------------------------------------------------------------- RNG: splitmix64-seeded xoroshiro128+
+struct Rng {
+	uint64_t s0, s1;
+	static uint64_t splitmix(uint64_t &z) { z += 0x9E3779B97F4A7C15ULL; uint64_t r = z; r = (r ^ (r >> 30)) * 0xBF58476D1CE4E5B9ULL; r = (r ^ (r >> 27)) * 0x94D049BB133111EBULL; return r ^ (r >> 31); }
+	explicit Rng(uint64_t seed) { uint64_t z = seed; s0 = splitmix(z); s1 = splitmix(z); if (!(s0 | s1)) s1 = 1; }
+	uint64_t next() { uint64_t a = s0, b = s1, r = a + b; b ^= a; s0 = ((a << 24) | (a >> 40)) ^ b ^ (b << 16); s1 = (b << 37) | (b >> 27); return r; }
+	double unit() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); } // [0,1)
+};
+
+// floor of a Pareto variate on [1, xmax+1) with density ~ x^-(a+1)
+inline int64_t pareto_floor(Rng &r, double a, double xmax) {
+	double u = r.unit();
+	double t = 1.0 - u * (1.0 - std::pow(xmax + 1.0, -a));
+	double x = std::pow(t, -1.0 / a);
+	int64_t v = (int64_t)x;
+	if (v < 1) v = 1;
+	if ((double)v > xmax) v = (int64_t)xmax;
+	return v;
+}
+
+const int GEN_BLOCK = 1 << 16; // nodes per independent generation block
+
+} // namespace
+
+extern "C" int bvt_store(const char *basename, int32_t n, const int64_t *rowptr, const int32_t *succ,
+                         int window, int max_ref_count, int min_interval, int zeta_k, uint32_t flags, int threads,
+                         bvt_store_stats *stats) {
+	if (!basename || n < 0 || !rowptr || window < 0 || min_interval < 0 || zeta_k < 1) return -EINVAL;
+	Cfg g; g.W = window; g.R = max_ref_count; g.I = min_interval; g.K = zeta_k;
+	if (flags & 0xF) g.c.outdegree = flags & 0xF;                 // setFlags, BVGraph.java:1317-1325
+	if ((flags >> 4) & 0xF) g.c.block = (flags >> 4) & 0xF;
+	if ((flags >> 8) & 0xF) g.c.residual = (flags >> 8) & 0xF;
+	if ((flags >> 12) & 0xF) g.c.reference = (flags >> 12) & 0xF;
+	if ((flags >> 16) & 0xF) g.c.block_count = (flags >> 16) & 0xF;
+	if ((flags >> 20) & 0xF) g.c.offset = (flags >> 20) & 0xF;
+	auto in = [](int c, std::initializer_list<int> ok) { for (int v : ok) if (c == v) return true; return false; };
+	if (!in(g.c.outdegree, { GAMMA, DELTA }) || !in(g.c.block, { GAMMA, DELTA, UNARY }) || !in(g.c.block_count, { GAMMA, DELTA, UNARY }) ||
+	    !in(g.c.reference, { UNARY, GAMMA, DELTA }) || !in(g.c.residual, { GAMMA, ZETA, DELTA, GOLOMB, NIBBLE }) || !in(g.c.offset, { GAMMA, DELTA }))
+		return -ENOTSUP;
+	if (threads < 1) threads = 1;
+	if (threads > n) threads = n > 0 ? n : 1;
+
+	std::vector<ThreadOut> outs((size_t)threads);
+	const int32_t per = (int32_t)(((int64_t)n + threads - 1) / threads);
+	std::vector<std::thread> pool;
+	for (int t = 0; t < threads; t++) {
+		int32_t lo = (int32_t)std::min<int64_t>((int64_t)t * per, n), hi = (int32_t)std::min<int64_t>((int64_t)lo + per, n);
+		pool.emplace_back([&, lo, hi, t]() { compress_range(lo, hi, rowptr, succ, g, outs[(size_t)t]); });
+	}
+	for (auto &th : pool) th.join();
+	for (auto &o : outs) if (o.err) return o.err;
+
+	BitSink graph, offs;
+	bvt_store_stats st{};
+	st.threads = threads;
+	offs.code(g.c.offset, 0, 0); // offset of node 0
+	for (auto &o : outs) {
+		if (threads == 1) graph = std::move(o.graph); else graph.append(o.graph);
+		for (uint64_t l : o.reclen) offs.code(g.c.offset, l, 0);
+		st.bits_outdegrees += o.st.bits_outdegrees; st.bits_references += o.st.bits_references; st.bits_blocks += o.st.bits_blocks;
+		st.bits_intervals += o.st.bits_intervals; st.bits_residuals += o.st.bits_residuals;
+		st.copied_arcs += o.st.copied_arcs; st.intervalised_arcs += o.st.intervalised_arcs; st.residual_arcs += o.st.residual_arcs;
+		st.tot_ref += o.st.tot_ref; st.tot_dist += o.st.tot_dist;
+		st.max_ref_chain = std::max(st.max_ref_chain, o.st.max_ref_chain);
+	}
+	st.written_bits = graph.bits; st.offsets_bits = offs.bits;
+	std::string base(basename);
+	if (!graph.write_file(base + ".graph") || !offs.write_file(base + ".offsets")) return -EIO;
+
+	const uint64_t m = n ? (uint64_t)rowptr[n] : 0;
+	FILE *f = fopen((base + ".properties").c_str(), "w");
+	if (!f) return -EIO;
+	fprintf(f, "#BVGraph properties\n");
+	fprintf(f, "nodes=%d\narcs=%llu\nwindowsize=%d\nmaxrefcount=%d\nminintervallength=%d\n", n, (unsigned long long)m, window, max_ref_count, min_interval);
+	if (g.c.residual == ZETA) fprintf(f, "zetak=%d\n", zeta_k);
+	fprintf(f, "compressionflags=%s\n", flags_to_string(flags).c_str());
+	fprintf(f, "avgref=%s\navgdist=%s\n", fmt3(n ? (double)st.tot_ref / n : 0).c_str(), fmt3(n ? (double)st.tot_dist / n : 0).c_str());
+	fprintf(f, "copiedarcs=%llu\nintervalisedarcs=%llu\nresidualarcs=%llu\n", (unsigned long long)st.copied_arcs, (unsigned long long)st.intervalised_arcs, (unsigned long long)st.residual_arcs);
+	fprintf(f, "bitsperlink=%s\nbitspernode=%s\n", fmt3(m ? (double)st.written_bits / m : 0).c_str(), fmt3(n ? (double)st.written_bits / n : 0).c_str());
+	fprintf(f, "bitsforoutdegrees=%llu\nbitsforreferences=%llu\nbitsforblocks=%llu\nbitsforresiduals=%llu\nbitsforintervals=%llu\n",
+	        (unsigned long long)st.bits_outdegrees, (unsigned long long)st.bits_references, (unsigned long long)st.bits_blocks,
+	        (unsigned long long)st.bits_residuals, (unsigned long long)st.bits_intervals);
+	fprintf(f, "graphclass=it.unimi.dsi.webgraph.BVGraph\nversion=0\n");
+	fclose(f);
+	if (stats) *stats = st;
+	return 0;
+}
+
+extern "C" int bvt_generate(int32_t n, int64_t m, uint64_t seed, double p_copy, int threads, int64_t **rowptr_out, int32_t **succ_out) {
+	if (n <= 0 || m < 0 || !rowptr_out || !succ_out) return -EINVAL;
+	if (threads < 1) threads = 1;
+	const int64_t dcap = std::max<int64_t>(1, n / 4);
+	if (m > (int64_t)n * dcap / 2) return -EINVAL;
+	const int nblocks = (n + GEN_BLOCK - 1) / GEN_BLOCK;
+
+	// 1. raw power-law outdegrees: P(d) ~ d^-2.1 on [1, 1e5]; 20% of the nodes forced empty
+	std::vector<int32_t> raw((size_t)n);
+	auto par = [&](auto fn) {
+		std::atomic<int> next{0};
+		std::vector<std::thread> pool;
+		for (int t = 0; t < threads; t++) pool.emplace_back([&]() { for (int b; (b = next.fetch_add(1)) < nblocks;) fn(b); });
+		for (auto &th : pool) th.join();
+	};
+	par([&](int b) {
+		Rng r(seed ^ (0xD1B54A32D192ED03ULL * (uint64_t)(b + 1)));
+		int32_t lo = b * GEN_BLOCK, hi = std::min<int64_t>((int64_t)lo + GEN_BLOCK, n);
+		for (int32_t x = lo; x < hi; x++) raw[(size_t)x] = r.unit() < 0.2 ? 0 : (int32_t)pareto_floor(r, 1.1, 1e5);
+	});
+	// 2. rescale to hit exactly m arcs: d = clamp(round(raw*s), 1, dcap) for raw>0, s by bisection
+	auto total = [&](double s) { int64_t t = 0; for (int32_t x = 0; x < n; x++) if (raw[(size_t)x]) t += std::min<int64_t>(dcap, std::max<int64_t>(1, (int64_t)std::llround(raw[(size_t)x] * s))); return t; };
+	double lo_s = 0, hi_s = 1;
+	while (total(hi_s) < m && hi_s < 1e9) hi_s *= 2;
+	for (int it = 0; it < 60; it++) { double mid = 0.5 * (lo_s + hi_s); if (total(mid) < m) lo_s = mid; else hi_s = mid; }
+	std::vector<int64_t> deg((size_t)n);
+	int64_t tot = 0;
+	for (int32_t x = 0; x < n; x++) { deg[(size_t)x] = raw[(size_t)x] ? std::min<int64_t>(dcap, std::max<int64_t>(1, (int64_t)std::llround(raw[(size_t)x] * hi_s))) : 0; tot += deg[(size_t)x]; }
+	// fix the remainder on a fixed stride of non-empty nodes
+	for (int32_t x = 0; tot != m && x < n; x++) {
+		if (tot > m && deg[(size_t)x] > 1) { deg[(size_t)x]--; tot--; }
+		else if (tot < m && deg[(size_t)x] > 0 && deg[(size_t)x] < dcap) { deg[(size_t)x]++; tot++; }
+	}
+	if (tot != m) { for (int32_t x = 0; tot < m && x < n; x++) if (deg[(size_t)x] < dcap) { int64_t a = std::min<int64_t>(dcap - deg[(size_t)x], m - tot); deg[(size_t)x] += a; tot += a; } }
+	if (tot != m) return -ERANGE;
+
+	int64_t *rowptr = (int64_t *)malloc(sizeof(int64_t) * ((size_t)n + 1));
+	int32_t *succ = (int32_t *)malloc(sizeof(int32_t) * (size_t)std::max<int64_t>(m, 1));
+	if (!rowptr || !succ) { free(rowptr); free(succ); return -ENOMEM; }
+	rowptr[0] = 0;
+	for (int32_t x = 0; x < n; x++) rowptr[x + 1] = rowptr[x] + deg[(size_t)x];
+
+	// 3. successor lists: copy model + power-law signed gaps + runs of consecutive ids
+	par([&](int b) {
+		Rng r(seed ^ (0xA0761D6478BD642FULL * (uint64_t)(b + 1)));
+		int32_t lo = b * GEN_BLOCK, hi = std::min<int64_t>((int64_t)lo + GEN_BLOCK, n);
+		std::vector<int32_t> cur;
+		for (int32_t x = lo; x < hi; x++) {
+			const int64_t d = deg[(size_t)x];
+			if (!d) continue;
+			cur.clear();
+			if (x > lo && r.unit() < p_copy) {
+				int32_t back = 1 + (int32_t)(r.next() % (uint64_t)std::min(7, x - lo));
+				int32_t y = x - back;
+				const int32_t *pl = succ + rowptr[y]; int64_t pd = rowptr[y + 1] - rowptr[y];
+				for (int64_t i = 0; i < pd && (int64_t)cur.size() < d; i++) if (r.unit() < 0.7) cur.push_back(pl[i]);
+			}
+			for (int round = 0; (int64_t)cur.size() < d; round++) {
+				int64_t need = d - (int64_t)cur.size();
+				while (need > 0) {
+					int64_t gmag = pareto_floor(r, 0.5, (double)n);
+					int64_t t = (r.next() & 1) ? (int64_t)x + gmag : (int64_t)x - gmag;
+					if (round > 8) t = (int64_t)(r.next() % (uint64_t)n); // dense rows: fall back to uniform targets
+					if (t < 0 || t >= n) continue;
+					if (r.unit() < 0.1) { // a run of consecutive ids, geometric length >= 3
+						int64_t L = 3; while (r.unit() < 0.5) L++;
+						L = std::min(L, need);
+						for (int64_t i = 0; i < L && t + i < n; i++) { cur.push_back((int32_t)(t + i)); need--; }
+					} else { cur.push_back((int32_t)t); need--; }
+				}
+				std::sort(cur.begin(), cur.end());
+				cur.erase(std::unique(cur.begin(), cur.end()), cur.end());
+			}
+			if ((int64_t)cur.size() > d) cur.resize((size_t)d);
+			memcpy(succ + rowptr[x], cur.data(), sizeof(int32_t) * (size_t)d);
+		}
+	});
+	*rowptr_out = rowptr; *succ_out = succ;
+	return 0;
+}
+
+extern "C" void bvt_free(void *p) { free(p); }

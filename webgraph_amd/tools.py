@@ -1,0 +1,84 @@
+"""ctypes front-end of libbvgtools.so: the CPU BVGraph writer and the seeded synthetic generator.
+
+Host-only (no GPU).  See include/bvgtools.h for the C ABI and the reference lines it follows.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libbvgtools.so")
+_SRC = os.path.join(_HERE, "csrc", "host", "bvg_tools.cpp")
+
+# BVGraph flag constants (BVGraph.java:475-523): coding id << (4 * field)
+DELTA, GAMMA, GOLOMB, SKEWED_GOLOMB, UNARY, ZETA, NIBBLE = 1, 2, 3, 4, 5, 6, 7
+OUTDEGREES, BLOCKS, RESIDUALS, REFERENCES, BLOCK_COUNT, OFFSETS = 0, 4, 8, 12, 16, 20
+
+
+def flag(field_shift, coding):
+    return coding << field_shift
+
+
+class StoreStats(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in (
+        "written_bits", "offsets_bits", "bits_outdegrees", "bits_references", "bits_blocks", "bits_intervals",
+        "bits_residuals", "copied_arcs", "intervalised_arcs", "residual_arcs", "tot_ref", "tot_dist")] + [
+        ("max_ref_chain", C.c_int32), ("threads", C.c_int32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(_SRC):
+        subprocess.check_call(["g++", "-O3", "-std=c++17", "-shared", "-fPIC", "-pthread", "-o", _LIB, _SRC])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            raise RuntimeError("libbvgtools.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(_LIB)
+        L.bvt_store.argtypes = [C.c_char_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                C.c_uint32, C.c_int, C.POINTER(StoreStats)]
+        L.bvt_generate.argtypes = [C.c_int32, C.c_int64, C.c_uint64, C.c_double, C.c_int,
+                                   C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+        L.bvt_free.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def store(basename, rowptr, succ, window=7, max_ref_count=3, min_interval=4, zeta_k=3, flags=0, threads=1):
+    """BVGraph.store(g, basename, window, maxRefCount, minIntervalLength, zetaK, flags) for a CSR graph."""
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+    succ = np.ascontiguousarray(succ, dtype=np.int32)
+    n = rowptr.size - 1
+    st = StoreStats()
+    rc = lib().bvt_store(os.fsencode(basename), n, rowptr.ctypes.data, succ.ctypes.data, window, max_ref_count,
+                         min_interval, zeta_k, flags, threads, C.byref(st))
+    if rc:
+        raise OSError(-rc, "bvt_store failed: %s" % os.strerror(-rc))
+    return st.as_dict()
+
+
+def generate(n, m, seed=0x5EEDB5E70001, p_copy=0.5, threads=None):
+    """Seeded power-law / copy-model graph; returns (rowptr int64[n+1], succ int32[m])."""
+    threads = threads or os.cpu_count() or 1
+    rp, sp = C.c_void_p(), C.c_void_p()
+    rc = lib().bvt_generate(n, m, seed, p_copy, threads, C.byref(rp), C.byref(sp))
+    if rc:
+        raise OSError(-rc, "bvt_generate failed: %s" % os.strerror(-rc))
+    try:
+        rowptr = np.ctypeslib.as_array(C.cast(rp, C.POINTER(C.c_int64)), shape=(n + 1,)).copy()
+        succ = np.ctypeslib.as_array(C.cast(sp, C.POINTER(C.c_int32)), shape=(max(m, 1),))[:m].copy()
+    finally:
+        lib().bvt_free(rp)
+        lib().bvt_free(sp)
+    return rowptr, succ
