@@ -1,0 +1,143 @@
+/*
+ * bvgpu.h -- C ABI of libbvgpu.so, the MI355X-native BVGraph decompressor.
+ *
+ * This is the drop-in boundary for ONE hot path of vigna/webgraph: decoding the .graph bit stream of
+ * it.unimi.dsi.webgraph.BVGraph into successor lists.  The reference has no FFI (it is pure Java); its
+ * plug-in point is the `graphclass` reflection of ImmutableGraph.load (ImmutableGraph.java:647-685).  A Java
+ * class `GpuBVGraph extends ImmutableGraph` binds these entry points through JNI (INTEGRATION.md shows the
+ * stub); each function below names the reference method it stands in for.  "BVG" =
+ * src/it/unimi/dsi/webgraph/BVGraph.java.
+ *
+ * Conventions
+ *   - plain C99 types only; every function returns 0 (BVG_OK) or a negative bvg_status.
+ *   - a handle (bvg_t) is NOT thread-safe; bvg_clone() gives a flyweight sharing the immutable device
+ *     buffers with its own stream + scratch, like BVGraph.copy() (BVG:552-577, ImmutableGraph.java:157-165).
+ *   - output buffers are owned by the caller and may live in host or device memory (BVG_OUT_DEVICE).
+ *   - there is NO CPU fallback: every decoding entry point needs a HIP device and fails with BVG_EHIP
+ *     without one.  Only the functions marked [host-only] run without a GPU.
+ */
+#ifndef BVGPU_H
+#define BVGPU_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bvg_graph bvg_t;
+
+typedef enum bvg_status {
+	BVG_OK = 0,
+	BVG_EARG = -1,         /* IllegalArgumentException: node / range out of bounds (BVG:860, :900, :1037, :1165) */
+	BVG_ESTATE = -2,       /* IllegalStateException: reference > windowsize (BVG:705), no offsets (BVG:869) */
+	BVG_EUNSUPPORTED = -3, /* UnsupportedOperationException / IOException: coding id, version > 0, nodes >= 2^31
+	                          (BVG:635, :1534, :1537), graphclass mismatch (BVG:1528) */
+	BVG_EIO = -4,          /* IOException: missing / short / unreadable files */
+	BVG_ENOMEM = -5,       /* host or device allocation failed */
+	BVG_EHIP = -6,         /* no HIP device / HIP runtime error */
+	BVG_EFORMAT = -7,      /* malformed bit stream detected while decoding (never reads out of bounds) */
+	BVG_ECAP = -8          /* caller-provided successor buffer too small (arcs_out still reports the need) */
+} bvg_status;
+
+/* coding ids, CompressionFlags.java:26-44 */
+enum { BVG_DELTA = 1, BVG_GAMMA = 2, BVG_GOLOMB = 3, BVG_SKEWED_GOLOMB = 4, BVG_UNARY = 5, BVG_ZETA = 6, BVG_NIBBLE = 7 };
+
+/* What BVGraph.loadInternal reads from <basename>.properties (BVG:1528-1543) after setFlags (BVG:1317-1325). */
+typedef struct bvg_info {
+	int32_t  nodes;            /* numNodes() */
+	int64_t  arcs;             /* numArcs() */
+	int32_t  window_size;      /* windowSize()  BVG:610 */
+	int32_t  max_ref_count;    /* maxRefCount() BVG:618 -- metadata only, never trusted while decoding */
+	int32_t  min_interval_length;
+	int32_t  zeta_k;
+	uint32_t flags;            /* packed compression flags, layout BVG:1317-1325 */
+	int32_t  outdegree_coding, block_coding, residual_coding, reference_coding, block_count_coding, offset_coding;
+	uint64_t graph_bytes;      /* size of <basename>.graph */
+	int32_t  device;           /* HIP device ordinal the handle lives on, -1 for a host-only parse */
+} bvg_info_t;
+
+/* flags for the *_range / *_batch calls */
+enum {
+	BVG_OUT_HOST = 0,     /* rowptr / succ / nodes are host pointers (copied through a staging buffer) */
+	BVG_OUT_DEVICE = 1,   /* ... are device pointers on the handle's device */
+	BVG_ASYNC = 2         /* with BVG_OUT_DEVICE: enqueue on the handle's stream and return without synchronising;
+	                         errors and *arcs_out are then delivered by bvg_sync() */
+};
+
+/* ---- lifecycle ------------------------------------------------------------------------------------- */
+
+/* ImmutableGraph.load(basename) -> BVGraph.load -> loadInternal (BVG:1380, :1516-1609): parse .properties,
+ * read .graph and .offsets, stage the bit stream and the decoded int64 offset table in HBM on `device`. */
+int bvg_open(const char *basename, int device, bvg_t **out);
+
+/* BVGraph.copy() (BVG:552-577): flyweight sharing the staged graph; own stream and scratch. */
+int bvg_clone(const bvg_t *g, bvg_t **out);
+
+int bvg_close(bvg_t *g);
+
+/* numNodes / numArcs / windowSize / maxRefCount ... (ImmutableGraph.java:254-260, BVG:610-620) */
+int bvg_info(const bvg_t *g, bvg_info_t *out);
+
+/* message for the last failing call on this handle (never NULL) */
+const char *bvg_last_error(const bvg_t *g);
+
+/* Use the caller's HIP stream (a hipStream_t passed as void*) for every launch of this handle; NULL
+ * restores the handle's own stream. */
+int bvg_set_stream(bvg_t *g, void *hip_stream);
+
+/* Waits for the handle's stream; returns the status of the asynchronous work since the last sync and,
+ * if arcs_out != NULL, the arc count of the last range/batch decode. */
+int bvg_sync(bvg_t *g, uint64_t *arcs_out);
+
+/* ---- the hot path ---------------------------------------------------------------------------------- */
+
+/* outdegree(x) for x in [from, to)  (BVG:858-888).  out has to-from int32. */
+int bvg_outdegrees(bvg_t *g, int32_t from, int32_t to, int32_t *out, int flags);
+
+/*
+ * Sequential scan of nodes [from, to): what draining nodeIterator(from).copy(to) produces
+ * (BVGraphNodeIterator BVG:1136-1281 over successors(x, ibs, window, outd) BVG:1032-1133), in CSR form:
+ *   rowptr[to-from+1]  exclusive prefix sums of the outdegrees, rowptr[0] = 0
+ *   succ[rowptr[to-from]]  the successor lists, each strictly increasing
+ * succ == NULL: count-only (rowptr and *arcs_out).  succ_cap is the capacity of succ in int32 elements.
+ * rowptr may be NULL when only succ is wanted?  No: rowptr is required (it is how rows are found).
+ */
+int bvg_decode_range(bvg_t *g, int32_t from, int32_t to, int64_t *rowptr, int32_t *succ, size_t succ_cap,
+                     uint64_t *arcs_out, int flags);
+
+/*
+ * Random access: concatenation of successorArray(nodes[i]) (BVG:897-904, ImmutableGraph.java:329-333),
+ * reference chains resolved on the device.  rowptr has q+1 entries.
+ */
+int bvg_successors_batch(bvg_t *g, const int32_t *nodes, size_t q, int64_t *rowptr, int32_t *succ, size_t succ_cap,
+                         uint64_t *arcs_out, int flags);
+
+/*
+ * Fingerprint of a scan, computed on the device from an already decoded CSR range (device pointers):
+ * continues ImmutableGraph.hashCode() (ImmutableGraph.java:757-770) from *hash_io over nodes [from, to)
+ * (pass -1 and the whole graph to get hashCode()).
+ */
+int bvg_csr_hashcode(bvg_t *g, int32_t from, int32_t to, const int64_t *rowptr_dev, const int32_t *succ_dev,
+                     int32_t *hash_io);
+
+/* ---- sharding (multi-GPU) -------------------------------------------------- */
+
+/* Splits [0, n) into `parts` contiguous node ranges with balanced compressed bits:
+ * bounds[k] = min{x : off[x] >= k*off[n]/parts}, bounds[0] = 0, bounds[parts] = n.  Uses the staged offsets. */
+int bvg_shard_bounds(const bvg_t *g, int parts, int32_t *bounds);
+
+/* ---- [host-only] helpers (no GPU needed) ----------------------------------------------------------- */
+
+/* Parses <basename>.properties exactly as BVG:1528-1543 does (including the error cases). */
+int bvg_parse_properties(const char *basename, bvg_info_t *out, char *errbuf, size_t errlen);
+
+/* string2Flags (BVG:1352-1366): "A | B" of BVGraph constant names -> flag word; -1 on an unknown name. */
+int64_t bvg_flags_from_string(const char *s);
+
+/* OffsetsLongIterator (BVG:907-935): decodes n+1 gamma/delta coded gaps of a .offsets image into running sums. */
+int bvg_decode_offsets_host(const uint8_t *offsets_file, size_t len, int32_t nodes, int offset_coding, int64_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

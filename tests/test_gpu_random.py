@@ -1,0 +1,62 @@
+"""GPU parity tests of the random-access path (BVGraph.successors(x), BVG:897-904 / :1032-1133 with window == null)."""
+import numpy as np
+import pytest
+
+from conftest import CNR, make_graph
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cnr_gpu():
+    from webgraph_amd.bvgraph import BVGraph
+    g = BVGraph.load(CNR)
+    yield g
+    g.close()
+
+
+def test_every_node_random_access(cnr_gpu, cnr_oracle):
+    """BVGraphTest.testLarge second half: outdegree(i) / successors(i) for every node, incl. the -1 terminator."""
+    _, rowptr, succ = cnr_oracle
+    n = cnr_gpu.numNodes()
+    rp, sc = cnr_gpu.successors_batch(np.arange(n, dtype=np.int32))
+    assert np.array_equal(rp, rowptr) and np.array_equal(sc, succ)
+    it = cnr_gpu.successors(7)
+    assert [it.nextInt() for _ in range(7)] == [6, 18, 218, 285, 296, -1, -1]
+    assert cnr_gpu.successors(5).nextInt() == -1  # empty list
+
+
+def test_random_batch_with_repeats(cnr_gpu, cnr_oracle):
+    og, rowptr, succ = cnr_oracle
+    rng = np.random.default_rng(0x5EED)
+    q = rng.integers(0, cnr_gpu.numNodes(), 50000).astype(np.int32)
+    q[:5] = [46918, 46918, 112690, 0, 325556]  # max outdegree twice, longest record, first, last
+    rp, sc = cnr_gpu.successors_batch(q)
+    orp, osc = og.successors_batch(q)
+    assert np.array_equal(rp, orp) and np.array_equal(sc, osc)
+
+
+def test_empty_batch_and_errors(cnr_gpu):
+    rp, sc = cnr_gpu.successors_batch(np.empty(0, dtype=np.int32))
+    assert list(rp) == [0] and sc.size == 0
+    with pytest.raises(ValueError):
+        cnr_gpu.successors_batch(np.array([1, 325557], dtype=np.int32))
+    with pytest.raises(ValueError):
+        cnr_gpu.successors_batch(np.array([-1], dtype=np.int32))
+    with pytest.raises(ValueError):
+        cnr_gpu.successorArray(325557)
+
+
+def test_deep_chains_random_access(tmp_path_factory):
+    from webgraph_amd.bvgraph import BVGraph
+    from oracle import oracle as O
+    base, rowptr, succ = make_graph(tmp_path_factory, "deepra", 20000, 300000, 31, 0.95, window=7, max_ref_count=50, min_interval=2)
+    g = BVGraph.load(base)
+    q = np.random.default_rng(3).integers(0, 20000, 5000).astype(np.int32)
+    rp, sc = g.successors_batch(q)
+    for j in range(0, len(q), 7):
+        assert np.array_equal(sc[rp[j]:rp[j + 1]], succ[rowptr[q[j]]:rowptr[q[j] + 1]])
+    og = O.OracleGraph.load(base)
+    orp, osc = og.successors_batch(q)
+    assert np.array_equal(rp, orp) and np.array_equal(sc, osc)
+    g.close()

@@ -1,0 +1,187 @@
+"""GPU parity tests of the sequential-scan path: HIP decode (through the C ABI) vs the CPU oracle / golden data.
+
+Modelled on the reference's BVGraphTest.testLarge (test/it/unimi/dsi/webgraph/BVGraphTest.java:101-119) and
+WebGraphTestCase.assertGraph (test/it/unimi/dsi/webgraph/WebGraphTestCase.java:158-260).
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import CNR, make_graph
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cnr_gpu():
+    from webgraph_amd.bvgraph import BVGraph
+    g = BVGraph.load(CNR)
+    yield g
+    g.close()
+
+
+def test_cnr2000_known_answers(cnr_gpu):
+    """the reference's own fixture, bit-exact."""
+    g = cnr_gpu
+    assert g.numNodes() == 325557 and g.numArcs() == 3216152
+    rowptr, succ = g.decode_range()
+    assert rowptr[-1] == 3216152
+    assert hashlib.sha256(succ.astype("<i4").tobytes()).hexdigest() == "f8830e775ef6087997ef5fae21c3f538f0417e555cd420d4527ffcb5aea52b3e"
+    assert hashlib.sha256(rowptr.astype("<i8").tobytes()).hexdigest() == "2b9a18c9ce44dc8bc1d95bee4ed4e3a7625a2167ab12fab6bf50e6d9ea6829a6"
+    assert hashlib.sha256(np.diff(rowptr).astype("<i4").tobytes()).hexdigest() == "b3c76d7541de076cd97fa8c510fb53820008520fb8f9836b52603dbf4ce92815"
+    assert list(succ[rowptr[7]:rowptr[8]]) == [6, 18, 218, 285, 296]
+    assert list(succ[rowptr[100000]:rowptr[100001]]) == [99982, 99984, 99985, 99986, 99987, 99988]
+
+
+def test_cnr2000_equals_ascii_golden(cnr_gpu):
+    """BVGraphTest.testLarge: load(cnr-2000) equals ASCIIGraph(cnr-2000.graph-txt.gz)."""
+    from oracle import oracle as O
+    n, rp, sc = O.read_ascii_graph_gz(CNR + ".graph-txt.gz")
+    rowptr, succ = cnr_gpu.decode_range()
+    assert n == cnr_gpu.numNodes()
+    assert np.array_equal(rowptr, rp) and np.array_equal(succ, sc)
+
+
+def test_cnr2000_hashcode(cnr_gpu):
+    assert cnr_gpu.hashCode() == 1711395807  # ImmutableGraph.hashCode(), SURVEY.md App. C
+
+
+def test_cnr2000_outdegrees(cnr_gpu, cnr_oracle):
+    _, rowptr, _ = cnr_oracle
+    d = cnr_gpu.outdegrees()
+    assert np.array_equal(d, np.diff(rowptr).astype(np.int32))
+    assert cnr_gpu.outdegree(46918) == 2716
+
+
+@pytest.mark.parametrize("lo,hi", [(0, 1), (0, 0), (5, 6), (1, 9), (7, 8), (1000, 21000), (100000, 100064), (325000, 325557), (325556, 325557), (325557, 325557), (46910, 46925), (112680, 112700)])
+def test_cnr2000_subranges_with_halo(cnr_gpu, cnr_oracle, lo, hi):
+    """nodeIterator(lo).copy(hi): referents before lo are resolved through the halo (BVG:1173-1183)."""
+    _, rowptr, succ = cnr_oracle
+    rp, sc = cnr_gpu.decode_range(lo, hi)
+    assert np.array_equal(rp, rowptr[lo:hi + 1] - rowptr[lo])
+    assert np.array_equal(sc, succ[rowptr[lo]:rowptr[hi]])
+
+
+def test_split_iterators(cnr_gpu, cnr_oracle):
+    """WebGraphTestCase.assertSplitIterator: every node exactly once, right successors."""
+    _, rowptr, succ = cnr_oracle
+    for how_many in (1, 4, 7):
+        seen = 0
+        for it in cnr_gpu.splitNodeIterators(how_many):
+            while it.hasNext():
+                x = it.nextInt()
+                assert x == seen
+                if x % 997 == 0:
+                    assert np.array_equal(it.successorArray(), succ[rowptr[x]:rowptr[x + 1]])
+                    assert it.outdegree() == rowptr[x + 1] - rowptr[x]
+                seen += 1
+        assert seen == cnr_gpu.numNodes()
+
+
+def test_range_errors(cnr_gpu):
+    with pytest.raises(ValueError):
+        cnr_gpu.decode_range(-1, 5)
+    with pytest.raises(ValueError):
+        cnr_gpu.decode_range(0, 325558)
+    with pytest.raises(ValueError):
+        cnr_gpu.outdegree(325557)
+    with pytest.raises(ValueError):
+        cnr_gpu.nodeIterator(325558)
+
+
+def test_clone_shares_graph(cnr_gpu, cnr_oracle):
+    _, rowptr, succ = cnr_oracle
+    c = cnr_gpu.copy()
+    rp, sc = c.decode_range(2000, 3000)
+    assert np.array_equal(sc, succ[rowptr[2000]:rowptr[3000]])
+    c.close()
+    rp, sc = cnr_gpu.decode_range(2000, 3000)
+    assert np.array_equal(sc, succ[rowptr[2000]:rowptr[3000]])
+
+
+SYN_CASES = [
+    # name, n, m, seed, p_copy, store kwargs
+    ("default", 20000, 300000, 11, 0.5, dict(window=7, max_ref_count=3, min_interval=4)),
+    ("nowindow", 5000, 60000, 12, 0.5, dict(window=0, max_ref_count=0, min_interval=4)),
+    ("nointervals", 5000, 60000, 13, 0.7, dict(window=7, max_ref_count=3, min_interval=0)),
+    ("deepchains", 20000, 300000, 14, 0.9, dict(window=7, max_ref_count=40, min_interval=2)),
+    ("widewindow", 8000, 100000, 15, 0.9, dict(window=32, max_ref_count=5, min_interval=3, threads=3)),
+    ("zeta1", 5000, 60000, 16, 0.5, dict(window=3, max_ref_count=2, min_interval=3, zeta_k=1)),
+    ("zeta5", 5000, 60000, 17, 0.5, dict(window=3, max_ref_count=2, min_interval=3, zeta_k=5)),
+]
+
+
+@pytest.mark.parametrize("case", SYN_CASES, ids=[c[0] for c in SYN_CASES])
+def test_synthetic_roundtrip(tmp_path_factory, case):
+    """store -> GPU decode == original CSR == oracle (BVGraphTest.testCompression's round trip)."""
+    from webgraph_amd.bvgraph import BVGraph
+    from oracle import oracle as O
+    name, n, m, seed, p_copy, kw = case
+    base, rowptr, succ = make_graph(tmp_path_factory, name, n, m, seed, p_copy, **kw)
+    g = BVGraph.load(base)
+    rp, sc = g.decode_range()
+    assert np.array_equal(rp, rowptr) and np.array_equal(sc, succ)
+    og = O.OracleGraph.load(base)
+    for lo, hi in [(n // 3, n // 3 + 500), (n - 100, n), (1, 2)]:
+        orp, osc, _ = og.scan(lo, hi)
+        rp, sc = g.decode_range(lo, hi)
+        assert np.array_equal(rp, orp) and np.array_equal(sc, osc)
+    assert g.hashCode() == og.hashcode()
+    g.close()
+
+
+FLAG_CASES = [
+    ("RESIDUALS_GAMMA", 3), ("RESIDUALS_DELTA", 3), ("RESIDUALS_NIBBLE", 3), ("RESIDUALS_GOLOMB", 3),
+    ("OUTDEGREES_DELTA | BLOCKS_DELTA | REFERENCES_DELTA | BLOCK_COUNT_DELTA | OFFSETS_DELTA", 3),
+    ("REFERENCES_GAMMA | BLOCK_COUNT_UNARY", 2),
+]
+
+
+@pytest.mark.parametrize("flagstr,k", FLAG_CASES)
+def test_nondefault_codings(tmp_path_factory, flagstr, k):
+    """Codings the reference never tests: own round trip + oracle agreement (parity unpinned)."""
+    from webgraph_amd.bvgraph import BVGraph, flags_from_string
+    from oracle import oracle as O
+    flags = flags_from_string(flagstr)
+    base, rowptr, succ = make_graph(tmp_path_factory, "flags", 4000, 50000, 21, 0.6, window=5, max_ref_count=3, min_interval=3, zeta_k=k, flags=flags)
+    g = BVGraph.load(base)
+    rp, sc = g.decode_range()
+    assert np.array_equal(rp, rowptr) and np.array_equal(sc, succ)
+    og = O.OracleGraph.load(base)
+    orp, osc, _ = og.scan(1500, 2500)
+    rp, sc = g.decode_range(1500, 2500)
+    assert np.array_equal(rp, orp) and np.array_equal(sc, osc)
+    g.close()
+
+
+def test_device_pointers_async(cnr_gpu, cnr_oracle):
+    """The bench path: device outputs on a caller stream, BVG_ASYNC, status at bvg_sync."""
+    import torch
+    _, rowptr, succ = cnr_oracle
+    n = cnr_gpu.numNodes()
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream(device=dev)
+    rp = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    sc = torch.empty(cnr_gpu.numArcs(), dtype=torch.int32, device=dev)
+    cnr_gpu.set_stream(st.cuda_stream)
+    try:
+        for _ in range(3):
+            cnr_gpu.decode_range_device(0, n, rp.data_ptr(), sc.data_ptr(), sc.numel(), asynchronous=True)
+        arcs = cnr_gpu.sync()
+    finally:
+        cnr_gpu.set_stream(None)
+    assert arcs == 3216152
+    assert np.array_equal(rp.cpu().numpy(), rowptr) and np.array_equal(sc.cpu().numpy(), succ)
+
+
+def test_cap_too_small(cnr_gpu):
+    import torch
+    dev = torch.device("cuda", 0)
+    n = 1000
+    rp = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    sc = torch.empty(16, dtype=torch.int32, device=dev)
+    from webgraph_amd.bvgraph import BvgError
+    with pytest.raises(BvgError) as ei:
+        cnr_gpu.decode_range_device(0, n, rp.data_ptr(), sc.data_ptr(), sc.numel())
+    assert ei.value.code == -8

@@ -1,0 +1,373 @@
+"""Host-side mirror of the reference's graph API for the BVGraph decode path, over the libbvgpu C ABI.
+
+Names, argument meaning and error behaviour follow it.unimi.dsi.webgraph.ImmutableGraph / BVGraph /
+NodeIterator / LazyIntIterator (src/it/unimi/dsi/webgraph/ImmutableGraph.java:169-772, BVGraph.java,
+NodeIterator.java:34-107, LazyIntIterator.java:28-43) so that parity tests read like the reference's own
+(WebGraphTestCase.assertGraph).  All decoding happens in the HIP kernels behind include/bvgpu.h; there is no
+CPU fallback here -- without the library or without a GPU, loading raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBPATH = os.path.join(_HERE, "libbvgpu.so")
+
+BVG_OK, BVG_EARG, BVG_ESTATE, BVG_EUNSUPPORTED, BVG_EIO, BVG_ENOMEM, BVG_EHIP, BVG_EFORMAT, BVG_ECAP = 0, -1, -2, -3, -4, -5, -6, -7, -8
+BVG_OUT_HOST, BVG_OUT_DEVICE, BVG_ASYNC = 0, 1, 2
+
+
+class BvgInfo(C.Structure):
+    _fields_ = [("nodes", C.c_int32), ("arcs", C.c_int64), ("window_size", C.c_int32), ("max_ref_count", C.c_int32),
+                ("min_interval_length", C.c_int32), ("zeta_k", C.c_int32), ("flags", C.c_uint32),
+                ("outdegree_coding", C.c_int32), ("block_coding", C.c_int32), ("residual_coding", C.c_int32),
+                ("reference_coding", C.c_int32), ("block_count_coding", C.c_int32), ("offset_coding", C.c_int32),
+                ("graph_bytes", C.c_uint64), ("device", C.c_int32)]
+
+
+EXPORTS = ["bvg_open", "bvg_clone", "bvg_close", "bvg_info", "bvg_last_error", "bvg_set_stream", "bvg_sync",
+           "bvg_outdegrees", "bvg_decode_range", "bvg_successors_batch", "bvg_csr_hashcode", "bvg_shard_bounds",
+           "bvg_parse_properties", "bvg_flags_from_string", "bvg_decode_offsets_host"]
+
+_lib = None
+
+
+def lib():
+    """Loads libbvgpu.so (built in-tree by __graft_entry__.build()); raises if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIBPATH):
+            raise RuntimeError("libbvgpu.so is not built (run __graft_entry__.build()); there is no CPU fallback")
+        # One HIP runtime per process: PyTorch bundles its own libamdhip64.so.7, and a second copy loaded next
+        # to it sees no GPU.  Importing torch first makes libbvgpu's NEEDED libamdhip64.so.7 bind to that copy.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        L = C.CDLL(_LIBPATH)
+        vp, i32, i64, u64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_size_t
+        L.bvg_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+        L.bvg_clone.argtypes = [vp, C.POINTER(vp)]
+        L.bvg_close.argtypes = [vp]
+        L.bvg_info.argtypes = [vp, C.POINTER(BvgInfo)]
+        L.bvg_last_error.argtypes = [vp]
+        L.bvg_last_error.restype = C.c_char_p
+        L.bvg_set_stream.argtypes = [vp, vp]
+        L.bvg_sync.argtypes = [vp, C.POINTER(u64)]
+        L.bvg_outdegrees.argtypes = [vp, i32, i32, vp, C.c_int]
+        L.bvg_decode_range.argtypes = [vp, i32, i32, vp, vp, sz, C.POINTER(u64), C.c_int]
+        L.bvg_successors_batch.argtypes = [vp, vp, sz, vp, vp, sz, C.POINTER(u64), C.c_int]
+        L.bvg_csr_hashcode.argtypes = [vp, i32, i32, vp, vp, C.POINTER(i32)]
+        L.bvg_shard_bounds.argtypes = [vp, C.c_int, vp]
+        L.bvg_parse_properties.argtypes = [C.c_char_p, C.POINTER(BvgInfo), C.c_char_p, sz]
+        L.bvg_flags_from_string.argtypes = [C.c_char_p]
+        L.bvg_flags_from_string.restype = i64
+        L.bvg_decode_offsets_host.argtypes = [vp, sz, i32, C.c_int, vp]
+        _lib = L
+    return _lib
+
+
+class BvgError(Exception):
+    def __init__(self, code, msg=""):
+        super().__init__("bvgpu error %d: %s" % (code, msg))
+        self.code = code
+
+
+def _raise(code, msg):
+    """Maps a bvg_status to the exception class the reference throws at the same place (include/bvgpu.h)."""
+    if code == BVG_EARG:
+        raise ValueError(msg or "Node index out of range")                # IllegalArgumentException
+    if code == BVG_ESTATE:
+        raise RuntimeError(msg or "illegal state")                        # IllegalStateException
+    if code == BVG_EUNSUPPORTED:
+        raise NotImplementedError(msg or "unsupported")                   # UnsupportedOperationException
+    if code == BVG_EIO:
+        raise IOError(msg or "I/O error")                                 # IOException
+    if code == BVG_ENOMEM:
+        raise MemoryError(msg)
+    raise BvgError(code, msg)
+
+
+def parse_properties(basename):
+    """[host-only] BVGraph.loadInternal's property parsing (BVGraph.java:1528-1543)."""
+    info = BvgInfo()
+    buf = C.create_string_buffer(512)
+    rc = lib().bvg_parse_properties(os.fsencode(basename), C.byref(info), buf, 512)
+    if rc:
+        _raise(rc, buf.value.decode("latin-1"))
+    return info
+
+
+def flags_from_string(s):
+    """[host-only] BVGraph.string2Flags (BVGraph.java:1352-1366); IOError on an unknown constant name."""
+    v = lib().bvg_flags_from_string(s.encode("latin-1"))
+    if v < 0:
+        raise IOError("Compression flag unknown in %r" % s)
+    return int(v)
+
+
+def decode_offsets_host(offset_bytes, nodes, coding=2):
+    """[host-only] OffsetsLongIterator (BVGraph.java:907-935)."""
+    b = np.frombuffer(offset_bytes, dtype=np.uint8)
+    out = np.empty(nodes + 1, dtype=np.int64)
+    rc = lib().bvg_decode_offsets_host(b.ctypes.data, b.size, nodes, coding, out.ctypes.data)
+    if rc:
+        _raise(rc, "cannot decode offsets")
+    return out
+
+
+class LazyIntIterator:
+    """LazyIntIterator.java:28-43 over a decoded array: increasing ids, then -1 forever."""
+
+    def __init__(self, arr):
+        self._a = arr
+        self._i = 0
+
+    def nextInt(self):
+        if self._i >= len(self._a):
+            return -1
+        v = int(self._a[self._i])
+        self._i += 1
+        return v
+
+    def skip(self, n):
+        k = min(n, len(self._a) - self._i)
+        self._i += k
+        return k
+
+
+class NodeIterator:
+    """BVGraphNodeIterator (BVGraph.java:1136-1281): sequential scan served from GPU-decoded batches."""
+
+    def __init__(self, graph, from_, upper_bound=2**31 - 1, batch_nodes=1 << 20):
+        n = graph.numNodes()
+        if from_ < 0 or from_ > n:
+            raise ValueError("Node index out of range: %d" % from_)   # BVGraph.java:1165
+        self._g = graph
+        self._from = from_
+        self._curr = from_ - 1
+        self._limit = min(upper_bound, n) - 1                         # hasNextLimit, BVGraph.java:1185
+        self._batch = batch_nodes
+        self._lo = self._hi = from_
+        self._rowptr = None
+        self._succ = None
+
+    def hasNext(self):
+        return self._curr < self._limit                               # BVGraph.java:1216
+
+    def nextInt(self):
+        if not self.hasNext():
+            raise StopIteration                                       # NoSuchElementException
+        self._curr += 1
+        if self._curr >= self._hi:
+            self._lo = self._curr
+            self._hi = min(self._lo + self._batch, self._limit + 1)
+            self._rowptr, self._succ = self._g.decode_range(self._lo, self._hi)
+        return self._curr
+
+    def _row(self):
+        if self._curr == self._from - 1:
+            raise RuntimeError("nextInt() not called yet")            # IllegalStateException, BVGraph.java:1220
+        i = self._curr - self._lo
+        return self._succ[self._rowptr[i]:self._rowptr[i + 1]]
+
+    def outdegree(self):
+        return len(self._row())
+
+    def successorArray(self):
+        return self._row()
+
+    def successors(self):
+        return LazyIntIterator(self._row())
+
+    def copy(self, upper_bound=2**31 - 1):
+        """NodeIterator.copy(upperBound) (BVGraph.java:1253-1260): same position, never returns nodes >= upperBound."""
+        it = NodeIterator(self._g, self._curr + 1, upper_bound, self._batch)
+        return it
+
+
+class _EmptyNodeIterator:
+    """NodeIterator.EMPTY"""
+
+    def hasNext(self):
+        return False
+
+    def nextInt(self):
+        raise StopIteration
+
+
+class BVGraph:
+    """ImmutableGraph / BVGraph surface backed by libbvgpu (one HIP device)."""
+
+    def __init__(self, handle, basename):
+        self._h = handle
+        self._basename = basename
+        info = BvgInfo()
+        rc = lib().bvg_info(self._h, C.byref(info))
+        if rc:
+            _raise(rc, "bvg_info")
+        self.info = info
+
+    # -- loaders (ImmutableGraph.load / loadMapped / loadOffline all stage the graph in HBM here)
+    @classmethod
+    def load(cls, basename, device=0):
+        h = C.c_void_p()
+        rc = lib().bvg_open(os.fsencode(basename), device, C.byref(h))
+        if rc:
+            msg = lib().bvg_last_error(h).decode("latin-1") if h else ""
+            if h:
+                lib().bvg_close(h)
+            _raise(rc, msg)
+        return cls(h, basename)
+
+    loadMapped = load
+    loadOffline = load
+
+    def close(self):
+        if self._h:
+            lib().bvg_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            _raise(rc, lib().bvg_last_error(self._h).decode("latin-1"))
+
+    # -- ImmutableGraph.java:254-268, BVGraph.java:591-620
+    def numNodes(self):
+        return self.info.nodes
+
+    def numArcs(self):
+        return self.info.arcs
+
+    def randomAccess(self):
+        return True
+
+    def hasCopiableIterators(self):
+        return True
+
+    def basename(self):
+        return self._basename
+
+    def windowSize(self):
+        return self.info.window_size
+
+    def maxRefCount(self):
+        return self.info.max_ref_count
+
+    def copy(self):
+        """BVGraph.copy() (BVGraph.java:552-577): flyweight sharing the staged graph."""
+        h = C.c_void_p()
+        rc = lib().bvg_clone(self._h, C.byref(h))
+        if rc:
+            if h:
+                lib().bvg_close(h)
+            _raise(rc, "bvg_clone")
+        return BVGraph(h, self._basename)
+
+    # -- the hot path
+    def outdegrees(self, lo=0, hi=None):
+        hi = self.numNodes() if hi is None else hi
+        out = np.empty(max(hi - lo, 0), dtype=np.int32)
+        self._check(lib().bvg_outdegrees(self._h, lo, hi, out.ctypes.data, BVG_OUT_HOST))
+        return out
+
+    def outdegree(self, x):
+        if x < 0 or x >= self.numNodes():
+            raise ValueError("Node index out of range: %d" % x)       # BVGraph.java:860
+        return int(self.outdegrees(x, x + 1)[0])
+
+    def decode_range(self, lo=0, hi=None):
+        """CSR of nodes [lo,hi): (rowptr int64[hi-lo+1], succ int32[arcs]) in host memory."""
+        hi = self.numNodes() if hi is None else hi
+        rowptr = np.empty(max(hi - lo, 0) + 1, dtype=np.int64)
+        arcs = C.c_uint64(0)
+        self._check(lib().bvg_decode_range(self._h, lo, hi, rowptr.ctypes.data, None, 0, C.byref(arcs), BVG_OUT_HOST))
+        succ = np.empty(max(arcs.value, 1), dtype=np.int32)
+        self._check(lib().bvg_decode_range(self._h, lo, hi, rowptr.ctypes.data, succ.ctypes.data, succ.size, C.byref(arcs), BVG_OUT_HOST))
+        return rowptr, succ[:arcs.value]
+
+    def decode_range_device(self, lo, hi, rowptr_ptr, succ_ptr, succ_cap, asynchronous=False):
+        """Device-pointer form: rowptr_ptr / succ_ptr are raw device addresses (e.g. torch.Tensor.data_ptr())."""
+        arcs = C.c_uint64(0)
+        fl = BVG_OUT_DEVICE | (BVG_ASYNC if asynchronous else 0)
+        self._check(lib().bvg_decode_range(self._h, lo, hi, rowptr_ptr, succ_ptr, succ_cap, C.byref(arcs), fl))
+        return arcs.value
+
+    def sync(self):
+        arcs = C.c_uint64(0)
+        self._check(lib().bvg_sync(self._h, C.byref(arcs)))
+        return arcs.value
+
+    def set_stream(self, hip_stream):
+        self._check(lib().bvg_set_stream(self._h, hip_stream))
+
+    def successors_batch(self, nodes):
+        """Concatenated successorArray(nodes[i]) (random access, BVGraph.java:897-904)."""
+        nodes = np.ascontiguousarray(nodes, dtype=np.int32)
+        rowptr = np.empty(nodes.size + 1, dtype=np.int64)
+        arcs = C.c_uint64(0)
+        self._check(lib().bvg_successors_batch(self._h, nodes.ctypes.data, nodes.size, rowptr.ctypes.data, None, 0, C.byref(arcs), BVG_OUT_HOST))
+        succ = np.empty(max(arcs.value, 1), dtype=np.int32)
+        self._check(lib().bvg_successors_batch(self._h, nodes.ctypes.data, nodes.size, rowptr.ctypes.data, succ.ctypes.data, succ.size, C.byref(arcs), BVG_OUT_HOST))
+        return rowptr, succ[:arcs.value]
+
+    def successorArray(self, x):
+        if x < 0 or x >= self.numNodes():
+            raise ValueError("Node index out of range: %d" % x)       # BVGraph.java:900
+        rp, sc = self.successors_batch(np.array([x], dtype=np.int32))
+        return sc
+
+    def successors(self, x):
+        return LazyIntIterator(self.successorArray(x))
+
+    def nodeIterator(self, from_=0):
+        return NodeIterator(self, from_)
+
+    def splitNodeIterators(self, how_many):
+        """ImmutableGraph.splitNodeIterators (ImmutableGraph.java:379-409), random-access branch."""
+        n = self.numNodes()
+        if n == 0 and how_many == 0:
+            return []
+        if how_many < 1:
+            raise ValueError("howMany < 1")
+        m = -(-n // how_many)
+        res = []
+        f = 0
+        while f < n:
+            res.append(self.nodeIterator(f).copy(f + m))
+            f += m
+        res += [_EmptyNodeIterator()] * (how_many - len(res))
+        return res
+
+    def shard_bounds(self, parts):
+        b = np.empty(parts + 1, dtype=np.int32)
+        self._check(lib().bvg_shard_bounds(self._h, parts, b.ctypes.data))
+        return b
+
+    def csr_hashcode(self, lo, hi, rowptr_ptr, succ_ptr, h=-1):
+        hh = C.c_int32(h)
+        self._check(lib().bvg_csr_hashcode(self._h, lo, hi, rowptr_ptr, succ_ptr, C.byref(hh)))
+        return hh.value
+
+    def hashCode(self):
+        """ImmutableGraph.hashCode() (ImmutableGraph.java:757-770), folded on the device per batch."""
+        import torch
+        n = self.numNodes()
+        dev = torch.device("cuda", self.info.device)
+        h = -1
+        step = 1 << 22
+        for lo in range(0, n, step):
+            hi = min(lo + step, n)
+            rowptr = torch.empty(hi - lo + 1, dtype=torch.int64, device=dev)
+            arcs = self.decode_range_device(lo, hi, rowptr.data_ptr(), None, 0)
+            succ = torch.empty(max(arcs, 1), dtype=torch.int32, device=dev)
+            self.decode_range_device(lo, hi, rowptr.data_ptr(), succ.data_ptr(), succ.numel())
+            h = self.csr_hashcode(lo, hi, rowptr.data_ptr(), succ.data_ptr(), h)
+        return h

@@ -1,0 +1,162 @@
+// bv_device.hpp -- device-side bit reader and universal-code decoders for the BVGraph bit stream (gfx950).
+//
+// The .graph image is staged in HBM byte-for-byte as it is on disk (MSB-first bit order)
+// plus zero padding; kernels view it as 32-bit words and byte-swap on load (one v_perm_b32), so that the
+// first stream bit of a word is its bit 31.  All readers are bounds-guarded: past the padded end they see
+// zeros and raise a sticky error instead of touching memory.
+//
+// Code definitions: dsiutils InputBitStream (not in the reference repo; restated in SURVEY.md App. B, pinned
+// through the cnr-2000 fixture for unary / gamma / zeta_3).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bv {
+
+// CompressionFlags.java:26-44
+enum : int { C_DELTA = 1, C_GAMMA = 2, C_GOLOMB = 3, C_SKEWED_GOLOMB = 4, C_UNARY = 5, C_ZETA = 6, C_NIBBLE = 7 };
+
+// sticky device error bits
+enum : int { E_REF = 1, E_FORMAT = 2, E_CAP = 4, E_UNSUP = 8, E_ESCAPED = 16, E_ARG = 32 };
+
+struct GraphDev {
+	const uint32_t *bits;   // .graph bytes viewed as big-endian 32-bit words
+	uint64_t nwords;        // valid words (file bytes rounded up to 4); the allocation has >= 4 more zero words
+	const int64_t *offsets; // n+1 bit offsets
+	int32_t n;
+	int32_t W, minInt, zetaK;
+	int32_t c_outd, c_ref, c_bc, c_blk, c_res;
+};
+
+// Register-buffered MSB-first reader over global memory: 64-bit window, refilled 32 bits at a time.
+struct BitReader {
+	const uint32_t *__restrict__ w;
+	uint64_t nwords;
+	uint64_t widx;  // next word to load
+	uint64_t buf;   // valid bits are the top `nbits`; everything below is zero
+	uint32_t nbits;
+	int err;
+
+	__device__ __forceinline__ uint32_t ld(uint64_t i) const { return i < nwords ? __builtin_bswap32(w[i]) : 0u; }
+
+	__device__ __forceinline__ void init(const uint32_t *words, uint64_t nw) { w = words; nwords = nw; err = 0; widx = 0; buf = 0; nbits = 0; }
+
+	__device__ __forceinline__ void seek(uint64_t pos) {
+		widx = pos >> 5;
+		const uint32_t s = (uint32_t)pos & 31u;
+		const uint64_t hi = ld(widx), lo = ld(widx + 1);
+		widx += 2;
+		buf = ((hi << 32) | lo) << s;
+		nbits = 64u - s;
+	}
+	__device__ __forceinline__ uint64_t pos() const { return widx * 32u - nbits; }
+
+	// after refill(): nbits >= 33
+	__device__ __forceinline__ void refill() {
+		if (nbits <= 32u) {
+			buf |= (uint64_t)ld(widx) << (32u - nbits);
+			widx++;
+			nbits += 32u;
+		}
+	}
+	// n in 0..32
+	__device__ __forceinline__ uint32_t bits(uint32_t n) {
+		refill();
+		const uint32_t v = n ? (uint32_t)(buf >> (64u - n)) : 0u;
+		buf <<= n;
+		nbits -= n;
+		return v;
+	}
+	// n in 0..64
+	__device__ __forceinline__ uint64_t bits64(uint32_t n) {
+		if (n <= 32u) return bits(n);
+		const uint64_t hi = bits(n - 32u);
+		return (hi << 32) | bits(32u);
+	}
+	// number of zeros before the first one; the one is consumed
+	__device__ __forceinline__ uint64_t unary() {
+		uint64_t z = 0;
+		for (;;) {
+			refill();
+			if (buf) {
+				const uint32_t c = (uint32_t)__clzll((long long)buf);
+				z += c;
+				buf = (buf << c) << 1;
+				nbits -= c + 1u;
+				return z;
+			}
+			z += nbits;
+			nbits = 0;
+			if (widx >= nwords + 2) { err |= E_FORMAT; return z; }
+		}
+	}
+	__device__ __forceinline__ uint64_t gamma() {
+		const uint64_t m = unary();
+		if (m > 63) { err |= E_FORMAT; return 0; }
+		return (((uint64_t)1 << m) | bits64((uint32_t)m)) - 1;
+	}
+	__device__ __forceinline__ uint64_t delta() {
+		const uint64_t m = gamma();
+		if (m > 63) { err |= E_FORMAT; return 0; }
+		return (((uint64_t)1 << m) | bits64((uint32_t)m)) - 1;
+	}
+	template <int K> __device__ __forceinline__ uint64_t zeta_k(int k) {
+		const int kk = K > 0 ? K : k;
+		const uint64_t h = unary();
+		const uint64_t nb = h * (uint64_t)kk + (uint64_t)kk - 1;
+		if (nb > 63) { err |= E_FORMAT; return 0; }
+		const uint32_t hk = (uint32_t)h * (uint32_t)kk;
+		const uint64_t left = (uint64_t)1 << hk;
+		const uint64_t m = bits64((uint32_t)nb);
+		if (m < left) return m + left - 1;
+		return ((m << 1) | bits(1)) - 1;
+	}
+	__device__ __forceinline__ uint64_t golomb(int b) {
+		if (b == 0) return 0;
+		const uint32_t l2 = 31u - (uint32_t)__clz(b);
+		const uint64_t q = unary();
+		const uint64_t mm = ((uint64_t)1 << (l2 + 1)) - (uint64_t)b;
+		const uint64_t x = bits(l2);
+		const uint64_t r = x < mm ? x : ((x << 1) | bits(1)) - mm;
+		return q * (uint64_t)b + r;
+	}
+	__device__ __forceinline__ uint64_t nibble() {
+		uint64_t x = 0;
+		uint32_t stop;
+		int guard = 0;
+		do {
+			x <<= 3;
+			stop = bits(1);
+			x |= bits(3);
+		} while (!stop && ++guard < 22);
+		if (!stop) err |= E_FORMAT;
+		return x;
+	}
+	// run-time dispatch (wave-uniform); DEF folds it at compile time in the callers
+	__device__ __forceinline__ uint64_t coded(int coding, int k) {
+		switch (coding) {
+		case C_GAMMA: return gamma();
+		case C_DELTA: return delta();
+		case C_UNARY: return unary();
+		case C_ZETA: return zeta_k<0>(k);
+		case C_GOLOMB: return golomb(k);
+		case C_NIBBLE: return nibble();
+		default: err |= E_UNSUP; return 0;
+		}
+	}
+};
+
+// Fast.nat2int
+__device__ __forceinline__ int64_t nat2int(uint64_t v) { return (int64_t)(v >> 1) ^ -(int64_t)(v & 1); }
+
+// Field readers.  DEF == true: the default coding set (gamma outdegrees / block counts / blocks, unary
+// references, zeta_3 residuals -- BVG:525-541 and DEFAULT_ZETA_K) is resolved at compile time.
+template <bool DEF> struct Fields {
+	static __device__ __forceinline__ uint64_t outdegree(BitReader &br, const GraphDev &g) { return DEF ? br.gamma() : br.coded(g.c_outd, 0); }
+	static __device__ __forceinline__ uint64_t reference(BitReader &br, const GraphDev &g) { return DEF ? br.unary() : br.coded(g.c_ref, 0); }
+	static __device__ __forceinline__ uint64_t block_count(BitReader &br, const GraphDev &g) { return DEF ? br.gamma() : br.coded(g.c_bc, 0); }
+	static __device__ __forceinline__ uint64_t block(BitReader &br, const GraphDev &g) { return DEF ? br.gamma() : br.coded(g.c_blk, 0); }
+	static __device__ __forceinline__ uint64_t residual(BitReader &br, const GraphDev &g) { return DEF ? br.zeta_k<3>(3) : br.coded(g.c_res, g.zetaK); }
+};
+
+} // namespace bv

@@ -1,0 +1,522 @@
+// bv_kernels.hip -- HIP kernels of the BVGraph decode path for gfx950 (MI355X).
+//
+// Pipeline of one range decode (nodes [from,to), optional halo [lo,from) of referents):
+//   k_headers     one lane per node: outdegree + reference fields              (BVG:1048-1054)
+//   k_mark_halo   transitive closure of the referents that live before `from`  (replaces the random-access
+//                 window refill of BVGraphNodeIterator, BVG:1173-1183)
+//   scan          exclusive prefix sum of the outdegrees -> CSR rowptr
+//   k_depth       length of each node's reference chain (the file never stores it; maxrefcount is not trusted)
+//   k_parse       one lane per node: copy-block totals, intervals, residuals -> the node's "extra" successors,
+//                 written merged and sorted to the TAIL of its CSR row      (BVG:1058-1100, :939-991)
+//   k_copy(l)     for l = 1..maxdepth: nodes whose chain depth is l merge the masked copy of their referent's
+//                 (already final) row with their extras, in place           (MaskedIntIterator / MergedIntIterator)
+// All arithmetic is integer; nothing here is MFMA-shaped.
+#include "bv_device.hpp"
+#include "bv_launch.hpp"
+
+namespace bv {
+
+constexpr int TPB = 256;
+
+// ------------------------------------------------------------------------------------------------ headers
+template <bool DEF>
+__global__ void __launch_bounds__(TPB) k_headers(GraphDev g, int32_t lo, int32_t cnt, int32_t *__restrict__ outd,
+                                                 uint16_t *__restrict__ ref, int *__restrict__ err) {
+	const int32_t s = blockIdx.x * TPB + threadIdx.x;
+	if (s >= cnt) return;
+	const int32_t x = lo + s;
+	BitReader br;
+	br.init(g.bits, g.nwords);
+	br.seek((uint64_t)g.offsets[x]);
+	uint64_t d = Fields<DEF>::outdegree(br, g);
+	uint64_t r = 0;
+	int e = 0;
+	if (d > 0x7fffffffull) { e |= E_FORMAT; d = 0; }
+	if (d > 0 && g.W > 0) {
+		r = Fields<DEF>::reference(br, g);
+		if (r > (uint64_t)g.W) { e |= E_REF; r = 0; }       // BVG:705
+		else if (r > (uint64_t)x) { e |= E_FORMAT; r = 0; } // referent before node 0
+	}
+	e |= br.err;
+	outd[s] = (int32_t)d;
+	ref[s] = (uint16_t)r;
+	if (e) atomicOr(err, e);
+}
+
+// ------------------------------------------------------------------------------------------------ halo closure
+__global__ void k_mark_halo(int32_t nh, int32_t cnt, int32_t W, const int32_t *__restrict__ outd,
+                            const uint16_t *__restrict__ ref, uint8_t *__restrict__ need, int *__restrict__ err) {
+	const int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= W || nh + t >= cnt) return;
+	int32_t y = nh + t;
+	while (outd[y] > 0 && ref[y] > 0) {
+		const int32_t y2 = y - (int32_t)ref[y];
+		if (y2 < 0) { atomicOr(err, E_ESCAPED); break; } // chain leaves the halo window: caller retries with a larger one
+		if (y2 < nh) need[y2] = 1;
+		y = y2;
+	}
+}
+
+__global__ void k_apply_need(int32_t nh, const uint8_t *__restrict__ need, int32_t *__restrict__ outd, uint16_t *__restrict__ ref) {
+	const int32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s < nh && !need[s]) { outd[s] = 0; ref[s] = 0; }
+}
+
+// ------------------------------------------------------------------------------------------------ scan
+// Three-phase exclusive scan int32 -> int64 (block sums, scan of the sums, block scan + carry).
+constexpr int SCAN_ITEMS = 4;
+constexpr int SCAN_TILE = TPB * SCAN_ITEMS;
+
+__device__ __forceinline__ int64_t wave_incl_scan(int64_t v) {
+	const int lane = threadIdx.x & 63;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const int64_t t = __shfl_up(v, o, 64);
+		if (lane >= o) v += t;
+	}
+	return v;
+}
+
+// block-wide exclusive scan of one value per thread; returns the exclusive prefix, *total = block sum
+__device__ __forceinline__ int64_t block_excl_scan(int64_t v, int64_t *total) {
+	__shared__ int64_t wsum[TPB / 64];
+	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+	const int64_t inc = wave_incl_scan(v);
+	if (lane == 63) wsum[wid] = inc;
+	__syncthreads();
+	int64_t base = 0, tot = 0;
+#pragma unroll
+	for (int i = 0; i < TPB / 64; i++) { if (i < wid) base += wsum[i]; tot += wsum[i]; }
+	__syncthreads();
+	*total = tot;
+	return base + inc - v;
+}
+
+__global__ void __launch_bounds__(TPB) k_scan_sums(const int32_t *__restrict__ in, int64_t n, int64_t *__restrict__ sums) {
+	const int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
+	int64_t v = 0;
+#pragma unroll
+	for (int i = 0; i < SCAN_ITEMS; i++) { const int64_t j = base + (int64_t)threadIdx.x * SCAN_ITEMS + i; if (j < n) v += in[j]; }
+	int64_t tot;
+	block_excl_scan(v, &tot);
+	if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+// single block: exclusive scan of nb block sums in place (loops in tiles of TPB with a carry)
+__global__ void __launch_bounds__(TPB) k_scan_top(int64_t *__restrict__ sums, int64_t nb) {
+	int64_t carry = 0;
+	for (int64_t b = 0; b < nb; b += TPB) {
+		const int64_t j = b + threadIdx.x;
+		const int64_t v = j < nb ? sums[j] : 0;
+		int64_t tot;
+		const int64_t ex = block_excl_scan(v, &tot);
+		if (j < nb) sums[j] = carry + ex;
+		carry += tot;
+	}
+}
+
+__global__ void __launch_bounds__(TPB) k_scan_apply(const int32_t *__restrict__ in, int64_t n, const int64_t *__restrict__ sums, int64_t *__restrict__ out) {
+	const int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
+	int64_t vals[SCAN_ITEMS];
+	int64_t v = 0;
+#pragma unroll
+	for (int i = 0; i < SCAN_ITEMS; i++) { const int64_t j = base + (int64_t)threadIdx.x * SCAN_ITEMS + i; vals[i] = j < n ? in[j] : 0; v += vals[i]; }
+	int64_t tot;
+	int64_t ex = block_excl_scan(v, &tot) + sums[blockIdx.x];
+#pragma unroll
+	for (int i = 0; i < SCAN_ITEMS; i++) {
+		const int64_t j = base + (int64_t)threadIdx.x * SCAN_ITEMS + i;
+		if (j < n) out[j] = ex;
+		ex += vals[i];
+		if (j == n - 1) out[n] = ex;
+	}
+	if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) out[0] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------ chain depth
+__global__ void __launch_bounds__(TPB) k_depth(int32_t cnt, const uint16_t *__restrict__ ref, int32_t *__restrict__ depth,
+                                               int32_t *__restrict__ maxdepth) {
+	const int32_t s = blockIdx.x * TPB + threadIdx.x;
+	int32_t dd = 0;
+	if (s < cnt) {
+		int32_t y = s;
+		while (ref[y] > 0) { y -= ref[y]; dd++; } // ref[] is 0 for empty / unneeded nodes; y >= 0 was checked in k_headers / k_mark_halo
+		depth[s] = dd;
+	}
+	// one atomic per wave
+	int32_t m = dd;
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+	if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(maxdepth, m);
+}
+
+__global__ void k_rebase(int32_t nh, int32_t cnt, const int64_t *__restrict__ rowstart, int64_t *__restrict__ out) {
+	const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j <= (int64_t)(cnt - nh)) out[j] = rowstart[nh + j] - rowstart[nh];
+}
+
+// ------------------------------------------------------------------------------------------------ parse
+// One lane per node.  Decodes everything that does not depend on the referent's CONTENT:
+//   copied   = how many successors will come from the referent (needs only the referent's outdegree, BVG:1069)
+//   extras   = intervals U residuals, merged, written to row[copied .. d)
+// Nodes without a reference are final after this kernel.
+template <bool DEF>
+__device__ __forceinline__ void parse_node(const GraphDev &g, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row, int *__restrict__ err) {
+	BitReader br;
+	br.init(g.bits, g.nwords);
+	br.seek((uint64_t)g.offsets[x]);
+	(void)Fields<DEF>::outdegree(br, g);
+	if (g.W > 0) (void)Fields<DEF>::reference(br, g);
+
+	int e = 0;
+	int64_t copied = 0;
+	if (hasRef) {
+		const uint64_t bc = Fields<DEF>::block_count(br, g);
+		int64_t total = 0;
+		if (bc > (uint64_t)dref + 1) e |= E_FORMAT;
+		else {
+			for (uint64_t b = 0; b < bc; b++) {
+				const int64_t len = (int64_t)Fields<DEF>::block(br, g) + (b ? 1 : 0);
+				total += len;
+				if (!(b & 1)) copied += len;
+			}
+			if (total > dref) e |= E_FORMAT;
+			if (!(bc & 1)) copied += dref - total;
+		}
+	}
+	const int64_t extra = (int64_t)d - copied;
+	if (extra < 0 || copied < 0) e |= E_FORMAT;
+	if (e || br.err) { atomicOr(err, e | br.err); return; }
+	if (extra == 0) return;
+
+	// interval section: skip-parse to find the residual section and the number of residuals
+	int64_t nIntervals = 0, intervalArcs = 0;
+	BitReader bi; // second cursor, re-reads the interval section lazily during the merge
+	bi.init(g.bits, g.nwords);
+	if (g.minInt != 0) {
+		nIntervals = (int64_t)br.gamma();
+		if (nIntervals > extra) { atomicOr(err, E_FORMAT); return; }
+		if (nIntervals) {
+			bi.seek(br.pos());
+			for (int64_t i = 0; i < nIntervals; i++) {
+				(void)br.gamma();
+				intervalArcs += (int64_t)br.gamma() + g.minInt;
+			}
+		}
+	}
+	const int64_t nRes = extra - intervalArcs;
+	if (nRes < 0 || br.err) { atomicOr(err, E_FORMAT | br.err); return; }
+
+	// merge(intervals, residuals) -> row[copied ..)
+	int32_t *out = row + copied;
+	int64_t k = 0;
+	int64_t ivLeft = 0, ivRem = 0, ivPrev = 0; // current interval: next value, values left; end of the previous interval
+	int64_t ivTodo = nIntervals;
+	bool firstIv = true;
+	int64_t resTodo = nRes;
+	int64_t resVal = 0;
+	if (resTodo) resVal = (int64_t)(int32_t)((int64_t)x + nat2int(Fields<DEF>::residual(br, g))); // BVG:954
+	while (k < extra) {
+		if (ivRem == 0 && ivTodo) { // load the next interval (BVG:1084-1093)
+			if (firstIv) { ivLeft = (int64_t)(int32_t)((int64_t)x + nat2int(bi.gamma())); firstIv = false; }
+			else ivLeft = ivPrev + (int64_t)bi.gamma() + 1;
+			ivRem = (int64_t)bi.gamma() + g.minInt;
+			ivPrev = ivLeft + ivRem;
+			ivTodo--;
+		}
+		int32_t val;
+		if (ivRem && (!resTodo || ivLeft < resVal)) { val = (int32_t)ivLeft; ivLeft++; ivRem--; }
+		else if (resTodo) {
+			val = (int32_t)resVal;
+			if (ivRem && ivLeft == resVal) { ivLeft++; ivRem--; } // equal heads are emitted once (MergedIntIterator.java:69-72)
+			if (--resTodo) resVal += (int64_t)Fields<DEF>::residual(br, g) + 1; // BVG:966
+		} else val = -1; // malformed: fewer values than the outdegree promises (BVG:1210 would store -1)
+		out[k++] = val;
+	}
+	if (br.err | bi.err) atomicOr(err, br.err | bi.err);
+}
+
+template <bool DEF>
+__global__ void __launch_bounds__(TPB) k_parse(GraphDev g, RangeView v, int *__restrict__ err) {
+	const int32_t s = blockIdx.x * TPB + threadIdx.x;
+	if (s >= v.cnt) return;
+	const int32_t d = v.outd[s];
+	if (d == 0) return;
+	const int32_t r = v.ref[s];
+	if (s >= v.nh && (uint64_t)(v.rowstart[s + 1] - v.rowstart[v.nh]) > v.succ_cap) { atomicOr(err, E_CAP); return; }
+	parse_node<DEF>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), err);
+}
+
+// ------------------------------------------------------------------------------------------------ copy
+// One lane per node of chain depth `level`: merge the masked copy of the referent's final row with the
+// node's extras (sitting at row[copied..d)), forward and in place.  The write index never overtakes the
+// extras read index: k = (#copied so far) + (j - copied) <= j.
+template <bool DEF>
+__device__ __forceinline__ void copy_node(const GraphDev &g, int32_t x, int32_t d, int64_t dref, int32_t *__restrict__ row, const int32_t *__restrict__ src, int *__restrict__ err) {
+	BitReader br;
+	br.init(g.bits, g.nwords);
+	br.seek((uint64_t)g.offsets[x]);
+	(void)Fields<DEF>::outdegree(br, g);
+	(void)Fields<DEF>::reference(br, g);
+	const uint64_t bc = Fields<DEF>::block_count(br, g);
+	if (bc > (uint64_t)dref + 1) return; // flagged in k_parse
+	const uint64_t blocksPos = br.pos();
+	int64_t total = 0, copied = 0;
+	for (uint64_t b = 0; b < bc; b++) {
+		const int64_t len = (int64_t)Fields<DEF>::block(br, g) + (b ? 1 : 0);
+		total += len;
+		if (!(b & 1)) copied += len;
+	}
+	if (total > dref) return; // flagged in k_parse
+	if (!(bc & 1)) copied += dref - total;
+	if (copied > d) return;
+	br.seek(blocksPos);
+
+	int64_t i = 0;      // index in the referent row
+	int64_t k = 0;      // write index
+	int64_t j = copied; // extras read index
+	int32_t ev = j < d ? row[j] : 0;
+	for (uint64_t b = 0; b <= bc; b++) {
+		int64_t len;
+		if (b < bc) len = (int64_t)Fields<DEF>::block(br, g) + (b ? 1 : 0);
+		else len = dref - i; // implicit last block: the rest of the referent
+		if (b & 1) { i += len; continue; } // skip block
+		for (int64_t t = 0; t < len; t++) {
+			const int32_t cv = src[i++];
+			while (j < d && ev < cv) { row[k++] = ev; j++; if (j < d) ev = row[j]; }
+			if (j < d && ev == cv) { j++; if (j < d) ev = row[j]; } // equal heads emitted once (never in a valid file)
+			row[k++] = cv;
+		}
+	}
+	// remaining extras row[j..d) are already in place when k == j; a malformed duplicate leaves a gap: pad with -1
+	if (k != j) { while (j < d) { row[k++] = row[j++]; } while (k < d) row[k++] = -1; }
+	if (br.err) atomicOr(err, br.err);
+}
+
+template <bool DEF>
+__global__ void __launch_bounds__(TPB) k_copy(GraphDev g, RangeView v, const int32_t *__restrict__ depth, int32_t level, int *__restrict__ err) {
+	const int32_t s = blockIdx.x * TPB + threadIdx.x;
+	if (s >= v.cnt) return;
+	if (depth[s] != level) return;
+	const int32_t r = v.ref[s];
+	if (s >= v.nh && (uint64_t)(v.rowstart[s + 1] - v.rowstart[v.nh]) > v.succ_cap) return; // E_CAP already raised by k_parse
+	copy_node<DEF>(g, v.lo + s, v.outd[s], (int64_t)v.outd[s - r], v.row(s), v.row(s - r), err);
+}
+
+// ------------------------------------------------------------------------------------------------ random access
+// bvg_successors_batch: every query node x owns a private chain of slots x, x-r1, x-r1-r2, ... (what the
+// recursion of BVG:1120 would visit); slot t of a chain has depth L-1-t and its referent is slot t+1.
+// Query rows go to the caller's succ at rowptr[query]; ancestor rows go to a scratch arena.
+template <bool DEF>
+__device__ __forceinline__ void read_header(const GraphDev &g, int32_t x, int32_t &d, int32_t &r, int &e) {
+	BitReader br;
+	br.init(g.bits, g.nwords);
+	br.seek((uint64_t)g.offsets[x]);
+	uint64_t dd = Fields<DEF>::outdegree(br, g), rr = 0;
+	if (dd > 0x7fffffffull) { e |= E_FORMAT; dd = 0; }
+	if (dd > 0 && g.W > 0) {
+		rr = Fields<DEF>::reference(br, g);
+		if (rr > (uint64_t)g.W) { e |= E_REF; rr = 0; }
+		else if (rr > (uint64_t)x) { e |= E_FORMAT; rr = 0; }
+	}
+	e |= br.err;
+	d = (int32_t)dd; r = (int32_t)rr;
+}
+
+template <bool DEF>
+__global__ void __launch_bounds__(TPB) k_chain_len(GraphDev g, const int32_t *__restrict__ nodes, int64_t q, int32_t *__restrict__ chainlen,
+                                                   int32_t *__restrict__ maxlen, int *__restrict__ err) {
+	const int64_t j = (int64_t)blockIdx.x * TPB + threadIdx.x;
+	int32_t L = 0;
+	if (j < q) {
+		int32_t y = nodes[j];
+		int e = 0;
+		if (y < 0 || y >= g.n) e |= E_ARG; // BVG:900
+		else for (;;) {
+			int32_t d, r;
+			read_header<DEF>(g, y, d, r, e);
+			L++;
+			if (d == 0 || r == 0) break;
+			y -= r;
+		}
+		chainlen[j] = L;
+		if (e) atomicOr(err, e);
+	}
+	int32_t m = L;
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+	if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(maxlen, m);
+}
+
+template <bool DEF>
+__global__ void __launch_bounds__(TPB) k_chain_fill(GraphDev g, const int32_t *__restrict__ nodes, int64_t q, const int64_t *__restrict__ slotbase,
+                                                    int32_t *__restrict__ snode, int32_t *__restrict__ soutd, int32_t *__restrict__ sdepth,
+                                                    int32_t *__restrict__ sq, int32_t *__restrict__ aoutd, int32_t *__restrict__ qoutd) {
+	const int64_t j = (int64_t)blockIdx.x * TPB + threadIdx.x;
+	if (j >= q) return;
+	const int64_t base = slotbase[j];
+	const int32_t L = (int32_t)(slotbase[j + 1] - base);
+	int32_t y = nodes[j];
+	if (L == 0) { qoutd[j] = 0; return; }
+	for (int32_t t = 0; t < L; t++) {
+		int32_t d, r; int e = 0;
+		read_header<DEF>(g, y, d, r, e);
+		const int64_t s = base + t;
+		snode[s] = y; soutd[s] = d; sdepth[s] = L - 1 - t;
+		sq[s] = t == 0 ? (int32_t)j : -1;
+		aoutd[s] = t == 0 ? 0 : d;
+		if (t == 0) qoutd[j] = d;
+		y -= r;
+	}
+}
+
+template <bool DEF>
+__global__ void __launch_bounds__(TPB) k_bparse(GraphDev g, BatchView v, int *__restrict__ err) {
+	const int64_t s = (int64_t)blockIdx.x * TPB + threadIdx.x;
+	if (s >= v.cnt) return;
+	const int32_t d = v.outd[s];
+	if (d == 0) return;
+	const int32_t qi = v.qidx[s];
+	if (qi >= 0 && (uint64_t)v.rowptr[qi + 1] > v.succ_cap) { atomicOr(err, E_CAP); return; }
+	const bool hasRef = v.depth[s] > 0;
+	parse_node<DEF>(g, v.node[s], d, hasRef, hasRef ? (int64_t)v.outd[s + 1] : 0, v.row(s), err);
+}
+
+template <bool DEF>
+__global__ void __launch_bounds__(TPB) k_bcopy(GraphDev g, BatchView v, int32_t level, int *__restrict__ err) {
+	const int64_t s = (int64_t)blockIdx.x * TPB + threadIdx.x;
+	if (s >= v.cnt) return;
+	if (v.depth[s] != level) return;
+	const int32_t qi = v.qidx[s];
+	if (qi >= 0 && (uint64_t)v.rowptr[qi + 1] > v.succ_cap) return;
+	copy_node<DEF>(g, v.node[s], v.outd[s], (int64_t)v.outd[s + 1], v.row(s), v.row(s + 1), err);
+}
+
+// ------------------------------------------------------------------------------------------------ hashCode
+// ImmutableGraph.hashCode (ImmutableGraph.java:757-770): h = -1; for x: h = 31h + x; for j = d-1..0: h = 31h + s[j].
+// Each step is the affine map h -> 31h + v over Z/2^32; maps compose associatively, so a node contributes
+// (A_x, B_x) = (31^(d+1), ...) and blocks combine in order.  One lane per node, block-level ordered reduce.
+struct Affine { uint32_t a, b; }; // h -> a*h + b
+__device__ __forceinline__ Affine compose(Affine f, Affine g2) { return Affine{ f.a * g2.a, g2.a * f.b + g2.b }; } // g2 after f
+
+__global__ void __launch_bounds__(TPB) k_hash_nodes(int32_t from, int32_t cnt, const int64_t *__restrict__ rowptr,
+                                                    const int32_t *__restrict__ succ, uint32_t *__restrict__ outA, uint32_t *__restrict__ outB) {
+	__shared__ Affine sh[TPB];
+	const int32_t s = blockIdx.x * TPB + threadIdx.x;
+	Affine f{ 1u, 0u };
+	if (s < cnt) {
+		uint32_t a = 31u, b = (uint32_t)(from + s);
+		const int64_t lo = rowptr[s], hi = rowptr[s + 1];
+		for (int64_t j = hi; j-- > lo;) { b = b * 31u + (uint32_t)succ[j]; a *= 31u; }
+		f = Affine{ a, b };
+	}
+	sh[threadIdx.x] = f;
+	__syncthreads();
+	for (int o = 1; o < TPB; o <<= 1) { // ordered tree: element t absorbs t+o
+		if ((threadIdx.x % (2 * o)) == 0 && threadIdx.x + o < TPB) sh[threadIdx.x] = compose(sh[threadIdx.x], sh[threadIdx.x + o]);
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) { outA[blockIdx.x] = sh[0].a; outB[blockIdx.x] = sh[0].b; }
+}
+
+// single block: fold nb block maps in order and apply to *hash
+__global__ void __launch_bounds__(TPB) k_hash_fold(const uint32_t *__restrict__ A, const uint32_t *__restrict__ B, int64_t nb, int32_t *__restrict__ hash) {
+	__shared__ Affine sh[TPB];
+	Affine acc{ 1u, 0u };
+	for (int64_t base = 0; base < nb; base += TPB) {
+		const int64_t j = base + threadIdx.x;
+		sh[threadIdx.x] = j < nb ? Affine{ A[j], B[j] } : Affine{ 1u, 0u };
+		__syncthreads();
+		for (int o = 1; o < TPB; o <<= 1) {
+			if ((threadIdx.x % (2 * o)) == 0 && threadIdx.x + o < TPB) sh[threadIdx.x] = compose(sh[threadIdx.x], sh[threadIdx.x + o]);
+			__syncthreads();
+		}
+		if (threadIdx.x == 0) acc = compose(acc, sh[0]);
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) *hash = (int32_t)(acc.a * (uint32_t)*hash + acc.b);
+}
+
+} // namespace bv
+
+// ------------------------------------------------------------------------------------------------ launchers
+
+namespace bv {
+
+static inline unsigned nblk(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+
+void launch_headers(const GraphDev &g, bool def, int32_t lo, int32_t cnt, int32_t *outd, uint16_t *ref, int *err, hipStream_t st) {
+	if (cnt <= 0) return;
+	if (def) hipLaunchKernelGGL(k_headers<true>, dim3(nblk(cnt, TPB)), dim3(TPB), 0, st, g, lo, cnt, outd, ref, err);
+	else hipLaunchKernelGGL(k_headers<false>, dim3(nblk(cnt, TPB)), dim3(TPB), 0, st, g, lo, cnt, outd, ref, err);
+}
+
+void launch_mark_halo(int32_t nh, int32_t cnt, int32_t W, int32_t *outd, uint16_t *ref, uint8_t *need, int *err, hipStream_t st) {
+	if (nh <= 0 || W <= 0) return;
+	(void)hipMemsetAsync(need, 0, (size_t)nh, st);
+	hipLaunchKernelGGL(k_mark_halo, dim3(nblk(W, 64)), dim3(64), 0, st, nh, cnt, W, outd, ref, need, err);
+	hipLaunchKernelGGL(k_apply_need, dim3(nblk(nh, TPB)), dim3(TPB), 0, st, nh, need, outd, ref);
+}
+
+void launch_scan(const int32_t *in, int64_t n, int64_t *out, int64_t *sums, hipStream_t st) {
+	const int64_t nb = n > 0 ? (n + SCAN_TILE - 1) / SCAN_TILE : 1;
+	hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nb), dim3(TPB), 0, st, in, n, sums);
+	hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(TPB), 0, st, sums, nb);
+	hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(TPB), 0, st, in, n, sums, out);
+}
+int64_t scan_num_sums(int64_t n) { return n > 0 ? (n + SCAN_TILE - 1) / SCAN_TILE : 1; }
+
+void launch_depth(int32_t cnt, const uint16_t *ref, int32_t *depth, int32_t *maxdepth, hipStream_t st) {
+	if (cnt <= 0) return;
+	hipLaunchKernelGGL(k_depth, dim3(nblk(cnt, TPB)), dim3(TPB), 0, st, cnt, ref, depth, maxdepth);
+}
+
+void launch_rebase(int32_t nh, int32_t cnt, const int64_t *rowstart, int64_t *out, hipStream_t st) {
+	hipLaunchKernelGGL(k_rebase, dim3(nblk((int64_t)cnt - nh + 1, TPB)), dim3(TPB), 0, st, nh, cnt, rowstart, out);
+}
+
+void launch_parse(const GraphDev &g, bool def, const RangeView &v, int *err, hipStream_t st) {
+	if (v.cnt <= 0) return;
+	if (def) hipLaunchKernelGGL(k_parse<true>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, err);
+	else hipLaunchKernelGGL(k_parse<false>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, err);
+}
+
+void launch_copy(const GraphDev &g, bool def, const RangeView &v, const int32_t *depth, int32_t level, int *err, hipStream_t st) {
+	if (v.cnt <= 0) return;
+	if (def) hipLaunchKernelGGL(k_copy<true>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, depth, level, err);
+	else hipLaunchKernelGGL(k_copy<false>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, depth, level, err);
+}
+
+void launch_hash(int32_t from, int32_t cnt, const int64_t *rowptr, const int32_t *succ, uint32_t *A, uint32_t *B, int32_t *hash, hipStream_t st) {
+	if (cnt <= 0) return;
+	const int64_t nb = nblk(cnt, TPB);
+	hipLaunchKernelGGL(k_hash_nodes, dim3((unsigned)nb), dim3(TPB), 0, st, from, cnt, rowptr, succ, A, B);
+	hipLaunchKernelGGL(k_hash_fold, dim3(1), dim3(TPB), 0, st, A, B, nb, hash);
+}
+
+void launch_chain_len(const GraphDev &g, bool def, const int32_t *nodes, int64_t q, int32_t *chainlen, int32_t *maxlen, int *err, hipStream_t st) {
+	if (q <= 0) return;
+	if (def) hipLaunchKernelGGL(k_chain_len<true>, dim3(nblk(q, TPB)), dim3(TPB), 0, st, g, nodes, q, chainlen, maxlen, err);
+	else hipLaunchKernelGGL(k_chain_len<false>, dim3(nblk(q, TPB)), dim3(TPB), 0, st, g, nodes, q, chainlen, maxlen, err);
+}
+
+void launch_chain_fill(const GraphDev &g, bool def, const int32_t *nodes, int64_t q, const int64_t *slotbase, int32_t *snode, int32_t *soutd,
+                       int32_t *sdepth, int32_t *sq, int32_t *aoutd, int32_t *qoutd, hipStream_t st) {
+	if (q <= 0) return;
+	if (def) hipLaunchKernelGGL(k_chain_fill<true>, dim3(nblk(q, TPB)), dim3(TPB), 0, st, g, nodes, q, slotbase, snode, soutd, sdepth, sq, aoutd, qoutd);
+	else hipLaunchKernelGGL(k_chain_fill<false>, dim3(nblk(q, TPB)), dim3(TPB), 0, st, g, nodes, q, slotbase, snode, soutd, sdepth, sq, aoutd, qoutd);
+}
+
+void launch_bparse(const GraphDev &g, bool def, const BatchView &v, int *err, hipStream_t st) {
+	if (v.cnt <= 0) return;
+	if (def) hipLaunchKernelGGL(k_bparse<true>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, err);
+	else hipLaunchKernelGGL(k_bparse<false>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, err);
+}
+
+void launch_bcopy(const GraphDev &g, bool def, const BatchView &v, int32_t level, int *err, hipStream_t st) {
+	if (v.cnt <= 0) return;
+	if (def) hipLaunchKernelGGL(k_bcopy<true>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, level, err);
+	else hipLaunchKernelGGL(k_bcopy<false>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, level, err);
+}
+
+} // namespace bv

@@ -1,0 +1,50 @@
+// bv_launch.hpp -- host-visible launch interface of bv_kernels.hip (internal to libbvgpu.so).
+#pragma once
+#include "bv_device.hpp"
+
+namespace bv {
+
+// A decode job over consecutive nodes: slot s <-> node lo+s; slots [0,nh) are halo nodes whose rows live
+// in `halo`, slots [nh,cnt) are the caller's nodes whose rows live in `succ`.
+struct RangeView {
+	int32_t lo, cnt, nh;
+	int32_t *outd;          // [cnt] effective outdegree (0 for halo nodes nobody needs)
+	uint16_t *ref;          // [cnt] reference distance, 0 = none
+	int64_t *rowstart;      // [cnt+1] exclusive scan of outd
+	int32_t *succ;          // caller rows
+	int32_t *halo;          // halo rows
+	uint64_t succ_cap;      // capacity of succ in elements
+	__device__ __forceinline__ int32_t *row(int32_t s) const {
+		const int64_t o = rowstart[s];
+		return s < nh ? halo + o : succ + (o - rowstart[nh]);
+	}
+};
+
+
+// A batch of random-access queries: slot s holds one node of a query's reference chain (see bv_kernels.hip).
+struct BatchView {
+	int64_t cnt;
+	const int32_t *node, *outd, *depth, *qidx; // [cnt]
+	const int64_t *arow;                       // [cnt+1] arena row starts (0-length for query slots)
+	const int64_t *rowptr;                     // [q+1] caller rows
+	int32_t *succ, *arena;
+	uint64_t succ_cap;
+	__device__ __forceinline__ int32_t *row(int64_t s) const { const int32_t qi = qidx[s]; return qi >= 0 ? succ + rowptr[qi] : arena + arow[s]; }
+};
+
+void launch_headers(const GraphDev &g, bool def, int32_t lo, int32_t cnt, int32_t *outd, uint16_t *ref, int *err, hipStream_t st);
+void launch_mark_halo(int32_t nh, int32_t cnt, int32_t W, int32_t *outd, uint16_t *ref, uint8_t *need, int *err, hipStream_t st);
+void launch_scan(const int32_t *in, int64_t n, int64_t *out, int64_t *sums, hipStream_t st);
+int64_t scan_num_sums(int64_t n);
+void launch_depth(int32_t cnt, const uint16_t *ref, int32_t *depth, int32_t *maxdepth, hipStream_t st);
+void launch_rebase(int32_t nh, int32_t cnt, const int64_t *rowstart, int64_t *out, hipStream_t st);
+void launch_parse(const GraphDev &g, bool def, const RangeView &v, int *err, hipStream_t st);
+void launch_copy(const GraphDev &g, bool def, const RangeView &v, const int32_t *depth, int32_t level, int *err, hipStream_t st);
+void launch_chain_len(const GraphDev &g, bool def, const int32_t *nodes, int64_t q, int32_t *chainlen, int32_t *maxlen, int *err, hipStream_t st);
+void launch_chain_fill(const GraphDev &g, bool def, const int32_t *nodes, int64_t q, const int64_t *slotbase, int32_t *snode, int32_t *soutd,
+                       int32_t *sdepth, int32_t *sq, int32_t *aoutd, int32_t *qoutd, hipStream_t st);
+void launch_bparse(const GraphDev &g, bool def, const BatchView &v, int *err, hipStream_t st);
+void launch_bcopy(const GraphDev &g, bool def, const BatchView &v, int32_t level, int *err, hipStream_t st);
+void launch_hash(int32_t from, int32_t cnt, const int64_t *rowptr, const int32_t *succ, uint32_t *A, uint32_t *B, int32_t *hash, hipStream_t st);
+
+} // namespace bv

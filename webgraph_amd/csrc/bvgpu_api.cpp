@@ -1,0 +1,506 @@
+// bvgpu_api.cpp -- the C ABI of libbvgpu.so (include/bvgpu.h): handle management, staging of the graph in HBM,
+// orchestration of the decode pipeline of bv_kernels.hip.  Compiled with hipcc (host side only).
+//
+// No CPU fallback lives here: without a HIP device every decode entry point returns BVG_EHIP.
+#include "../../include/bvgpu.h"
+#include "bv_host.hpp"
+#include "bv_launch.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct DevBuf {
+	void *p = nullptr;
+	size_t cap = 0;
+	// grows (never shrinks); contents are NOT preserved
+	bool need(size_t bytes) {
+		if (bytes <= cap) return true;
+		if (p) (void)hipFree(p);
+		p = nullptr; cap = 0;
+		size_t want = bytes + bytes / 8 + 256;
+		if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return false; }
+		cap = want;
+		return true;
+	}
+	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+	template <class T> T *as() const { return (T *)p; }
+};
+
+// Immutable, shared between a handle and its clones (BVGraph.copy() shares graphMemory / offsets, BVG:552-577).
+struct Staged {
+	int device = -1;
+	bvg_info_t info{};
+	uint32_t *d_bits = nullptr;
+	uint64_t nwords = 0;
+	int64_t *d_offsets = nullptr;
+	std::vector<int64_t> h_offsets; // host copy: shard bounds and halo sizing
+	bool def = false;               // default coding set and zeta_3 -> compile-time specialised kernels
+	std::string basename;
+	~Staged() {
+		if (device >= 0) (void)hipSetDevice(device);
+		if (d_bits) (void)hipFree(d_bits);
+		if (d_offsets) (void)hipFree(d_offsets);
+	}
+};
+
+struct Small { // device <-> host mailbox
+	int err;
+	int32_t maxdepth;
+	int32_t hash;
+	int32_t pad;
+	int64_t total;     // rowstart[cnt] - rowstart[nh]
+	int64_t halo_total;
+};
+
+struct Pending { // an enqueued range decode whose status has not been collected yet
+	bool active = false;
+	bv::RangeView view{};
+	int32_t levels_done = 0;
+	bool want_succ = false;
+};
+
+} // namespace
+
+struct bvg_graph {
+	std::shared_ptr<Staged> st;
+	hipStream_t own = nullptr, stream = nullptr;
+	mutable std::string err;
+	DevBuf outd, ref, rowstart, depth, sums, need, halo, hashA, hashB, stage_rowptr, stage_succ, stage_nodes, small;
+	DevBuf b_chainlen, b_slotbase, b_node, b_qidx, b_aoutd, b_qoutd; // random-access batches
+	Small *h_small = nullptr; // pinned
+	int32_t levels_hint = 1;
+	Pending pend;
+	uint64_t last_arcs = 0;
+};
+
+namespace {
+
+int fail(const bvg_graph *g, int code, const std::string &msg) { if (g) g->err = msg; return code; }
+
+#define HIPCHK(g, call)                                                                                     \
+	do {                                                                                                    \
+		hipError_t e_ = (call);                                                                             \
+		if (e_ != hipSuccess) return fail(g, e_ == hipErrorOutOfMemory ? BVG_ENOMEM : BVG_EHIP, std::string(#call ": ") + hipGetErrorString(e_)); \
+	} while (0)
+
+bv::GraphDev graph_dev(const Staged &s) {
+	bv::GraphDev g{};
+	g.bits = s.d_bits; g.nwords = s.nwords; g.offsets = s.d_offsets; g.n = s.info.nodes;
+	g.W = s.info.window_size; g.minInt = s.info.min_interval_length; g.zetaK = s.info.zeta_k;
+	g.c_outd = s.info.outdegree_coding; g.c_ref = s.info.reference_coding; g.c_bc = s.info.block_count_coding;
+	g.c_blk = s.info.block_coding; g.c_res = s.info.residual_coding;
+	return g;
+}
+
+int dev_err_to_status(int e) {
+	if (e & bv::E_REF) return BVG_ESTATE;
+	if (e & bv::E_UNSUP) return BVG_EUNSUPPORTED;
+	if (e & bv::E_FORMAT) return BVG_EFORMAT;
+	if (e & bv::E_CAP) return BVG_ECAP;
+	if (e & bv::E_ESCAPED) return BVG_EFORMAT;
+	return BVG_OK;
+}
+
+int init_handle(bvg_graph *g) {
+	HIPCHK(g, hipSetDevice(g->st->device));
+	HIPCHK(g, hipStreamCreateWithFlags(&g->own, hipStreamNonBlocking));
+	g->stream = g->own;
+	HIPCHK(g, hipHostMalloc((void **)&g->h_small, sizeof(Small), hipHostMallocDefault));
+	if (!g->small.need(sizeof(Small))) return fail(g, BVG_ENOMEM, "device allocation failed");
+	const int mr = g->st->info.max_ref_count;
+	g->levels_hint = mr < 1 ? 1 : (mr > 8 ? 8 : mr);
+	return BVG_OK;
+}
+
+// Enqueues headers (+halo closure) + scan for nodes [from,to) with a halo of nh nodes before `from`.
+// On return the view describes the job; rowstart lives in scratch.
+int enqueue_structure(bvg_graph *g, int32_t from, int32_t to, int32_t nh, bv::RangeView &v) {
+	const Staged &s = *g->st;
+	const int32_t lo = from - nh, cnt = to - lo;
+	if (!g->outd.need(sizeof(int32_t) * (size_t)cnt) || !g->ref.need(sizeof(uint16_t) * (size_t)cnt) ||
+	    !g->rowstart.need(sizeof(int64_t) * ((size_t)cnt + 1)) || !g->sums.need(sizeof(int64_t) * (size_t)bv::scan_num_sums(cnt)) ||
+	    (nh && !g->need.need((size_t)nh)))
+		return fail(g, BVG_ENOMEM, "device scratch allocation failed");
+	v = bv::RangeView{};
+	v.lo = lo; v.cnt = cnt; v.nh = nh;
+	v.outd = g->outd.as<int32_t>(); v.ref = g->ref.as<uint16_t>(); v.rowstart = g->rowstart.as<int64_t>();
+	int *derr = &g->small.as<Small>()->err;
+	const bv::GraphDev gd = graph_dev(s);
+	bv::launch_headers(gd, s.def, lo, cnt, v.outd, v.ref, derr, g->stream);
+	if (nh) bv::launch_mark_halo(nh, cnt, s.info.window_size, v.outd, v.ref, g->need.as<uint8_t>(), derr, g->stream);
+	bv::launch_scan(v.outd, cnt, v.rowstart, g->sums.as<int64_t>(), g->stream);
+	return BVG_OK;
+}
+
+int fetch_small(bvg_graph *g) {
+	HIPCHK(g, hipMemcpyAsync(g->h_small, g->small.p, sizeof(Small), hipMemcpyDeviceToHost, g->stream));
+	HIPCHK(g, hipStreamSynchronize(g->stream));
+	return BVG_OK;
+}
+
+__global__ void k_totals(const int64_t *rowstart, int32_t nh, int32_t cnt, Small *sm) {
+	sm->total = rowstart[cnt] - rowstart[nh];
+	sm->halo_total = rowstart[nh];
+}
+
+// Collects the status of the pending job: runs the reference-chain levels that the optimistic launch did
+// not cover, then reports errors / arc count.
+int finish_pending(bvg_graph *g, uint64_t *arcs_out) {
+	if (!g->pend.active) { if (arcs_out) *arcs_out = g->last_arcs; return BVG_OK; }
+	const Staged &s = *g->st;
+	int rc = fetch_small(g);
+	if (rc) { g->pend.active = false; return rc; }
+	if (g->pend.want_succ && !g->h_small->err) {
+		const bv::GraphDev gd = graph_dev(s);
+		int *derr = &g->small.as<Small>()->err;
+		while (g->pend.levels_done < g->h_small->maxdepth) {
+			const int32_t upto = g->h_small->maxdepth;
+			for (int32_t l = g->pend.levels_done + 1; l <= upto; l++) bv::launch_copy(gd, s.def, g->pend.view, g->depth.as<int32_t>(), l, derr, g->stream);
+			g->pend.levels_done = upto;
+			rc = fetch_small(g);
+			if (rc) { g->pend.active = false; return rc; }
+		}
+		g->levels_hint = std::max(1, std::min<int32_t>(g->h_small->maxdepth, 64));
+	}
+	g->pend.active = false;
+	g->last_arcs = (uint64_t)g->h_small->total;
+	if (arcs_out) *arcs_out = g->last_arcs;
+	if (g->h_small->err) {
+		const int st = dev_err_to_status(g->h_small->err);
+		return fail(g, st, st == BVG_ECAP ? "successor buffer too small" : st == BVG_ESTATE ? "reference incompatible with the window size" : "malformed or unsupported bit stream");
+	}
+	return BVG_OK;
+}
+
+// Device-pointer core of bvg_decode_range.  rowptr_dev: to-from+1 int64; succ_dev may be NULL (count only).
+int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_dev, int32_t *succ_dev, size_t succ_cap, bool async, uint64_t *arcs_out) {
+	const Staged &s = *g->st;
+	HIPCHK(g, hipSetDevice(s.device));
+	if (g->pend.active) { int rc = finish_pending(g, nullptr); if (rc) return rc; }
+	const int32_t W = s.info.window_size;
+	HIPCHK(g, hipMemsetAsync(g->small.p, 0, sizeof(Small), g->stream));
+	if (to == from) {
+		HIPCHK(g, hipMemsetAsync(rowptr_dev, 0, sizeof(int64_t), g->stream));
+		if (!async) HIPCHK(g, hipStreamSynchronize(g->stream));
+		g->last_arcs = 0;
+		if (arcs_out) *arcs_out = 0;
+		return BVG_OK;
+	}
+	// halo: only needed when successors are wanted and the range does not start at node 0
+	int32_t nh = 0;
+	if (succ_dev && from > 0 && W > 0) {
+		const int64_t mr = s.info.max_ref_count < 1 ? 1 : std::min(s.info.max_ref_count, 64);
+		nh = (int32_t)std::min<int64_t>(from, (int64_t)W * mr);
+	}
+	bv::RangeView v;
+	for (;;) {
+		int rc = enqueue_structure(g, from, to, nh, v);
+		if (rc) return rc;
+		if (nh == 0) break;
+		// the halo buffer size and the "chain escaped the window" flag need a round trip
+		hipLaunchKernelGGL(k_totals, dim3(1), dim3(1), 0, g->stream, v.rowstart, v.nh, v.cnt, g->small.as<Small>());
+		rc = fetch_small(g);
+		if (rc) return rc;
+		if (g->h_small->err & bv::E_ESCAPED) {
+			if (nh == from) return fail(g, BVG_EFORMAT, "reference chain runs before node 0");
+			nh = (int32_t)std::min<int64_t>(from, (int64_t)nh * 8);
+			HIPCHK(g, hipMemsetAsync(g->small.p, 0, sizeof(Small), g->stream));
+			continue;
+		}
+		if (!g->halo.need(sizeof(int32_t) * (size_t)std::max<int64_t>(g->h_small->halo_total, 1))) return fail(g, BVG_ENOMEM, "halo allocation failed");
+		break;
+	}
+	v.succ = succ_dev; v.halo = g->halo.as<int32_t>(); v.succ_cap = succ_cap;
+	int *derr = &g->small.as<Small>()->err;
+	const bv::GraphDev gd = graph_dev(s);
+	int32_t levels = 0;
+	if (succ_dev) {
+		if (!g->depth.need(sizeof(int32_t) * (size_t)v.cnt)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
+		if (W > 0) bv::launch_depth(v.cnt, v.ref, g->depth.as<int32_t>(), &g->small.as<Small>()->maxdepth, g->stream);
+		bv::launch_parse(gd, s.def, v, derr, g->stream);
+		if (W > 0) {
+			levels = g->levels_hint;
+			for (int32_t l = 1; l <= levels; l++) bv::launch_copy(gd, s.def, v, g->depth.as<int32_t>(), l, derr, g->stream);
+		}
+	}
+	bv::launch_rebase(v.nh, v.cnt, v.rowstart, rowptr_dev, g->stream);
+	hipLaunchKernelGGL(k_totals, dim3(1), dim3(1), 0, g->stream, v.rowstart, v.nh, v.cnt, g->small.as<Small>());
+	HIPCHK(g, hipGetLastError());
+	g->pend.active = true; g->pend.view = v; g->pend.levels_done = levels; g->pend.want_succ = succ_dev != nullptr;
+	if (async) return BVG_OK;
+	return finish_pending(g, arcs_out);
+}
+
+} // namespace
+
+// ================================================================================================ C ABI
+
+extern "C" int bvg_parse_properties(const char *basename, bvg_info_t *out, char *errbuf, size_t errlen) {
+	if (!basename || !out) return BVG_EARG;
+	std::string err;
+	int rc = bvh::parse_properties(basename, *out, err);
+	if (errbuf && errlen) { strncpy(errbuf, err.c_str(), errlen - 1); errbuf[errlen - 1] = 0; }
+	return rc;
+}
+
+extern "C" int64_t bvg_flags_from_string(const char *s) { return bvh::flags_from_string(s ? s : ""); }
+
+extern "C" int bvg_decode_offsets_host(const uint8_t *offsets_file, size_t len, int32_t nodes, int offset_coding, int64_t *out) {
+	if (!offsets_file || !out || nodes < 0) return BVG_EARG;
+	return bvh::decode_offsets(offsets_file, len, nodes, offset_coding, out);
+}
+
+extern "C" int bvg_open(const char *basename, int device, bvg_t **out) {
+	if (!basename || !out) return BVG_EARG;
+	*out = nullptr;
+	auto *g = new bvg_graph();
+	*out = g; // returned even on failure so that bvg_last_error works; caller still closes it
+	auto st = std::make_shared<Staged>();
+	std::string err;
+	int rc = bvh::parse_properties(basename, st->info, err);
+	if (rc) return fail(g, rc, err);
+	const bvg_info_t &in = st->info;
+	auto okc = [](int c, std::initializer_list<int> l) { for (int v : l) if (c == v) return true; return false; };
+	// the switch statements of BVG:631-816 accept exactly these
+	if (!okc(in.outdegree_coding, { BVG_GAMMA, BVG_DELTA }) || !okc(in.block_coding, { BVG_UNARY, BVG_GAMMA, BVG_DELTA }) ||
+	    !okc(in.block_count_coding, { BVG_UNARY, BVG_GAMMA, BVG_DELTA }) || !okc(in.reference_coding, { BVG_UNARY, BVG_GAMMA, BVG_DELTA }) ||
+	    !okc(in.residual_coding, { BVG_GAMMA, BVG_ZETA, BVG_DELTA, BVG_GOLOMB, BVG_NIBBLE }) || !okc(in.offset_coding, { BVG_GAMMA, BVG_DELTA }))
+		return fail(g, BVG_EUNSUPPORTED, "The required coding is not supported");
+	st->basename = basename;
+	st->def = in.outdegree_coding == BVG_GAMMA && in.block_coding == BVG_GAMMA && in.block_count_coding == BVG_GAMMA &&
+	          in.reference_coding == BVG_UNARY && in.residual_coding == BVG_ZETA && in.zeta_k == 3;
+
+	std::vector<uint8_t> graph, offs;
+	if (!bvh::read_file(st->basename + ".graph", graph, err)) return fail(g, BVG_EIO, err);
+	if (!bvh::read_file(st->basename + ".offsets", offs, err)) return fail(g, BVG_EIO, err);
+	st->info.graph_bytes = graph.size();
+	st->h_offsets.resize((size_t)in.nodes + 1);
+	rc = bvh::decode_offsets(offs.data(), offs.size(), in.nodes, in.offset_coding, st->h_offsets.data());
+	if (rc) return fail(g, rc, "cannot decode " + st->basename + ".offsets");
+	if ((uint64_t)st->h_offsets.back() > (uint64_t)graph.size() * 8) return fail(g, BVG_EIO, "offsets run past the end of the .graph file");
+	for (size_t i = 1; i < st->h_offsets.size(); i++) if (st->h_offsets[i] < st->h_offsets[i - 1]) return fail(g, BVG_EIO, "offsets are not monotone");
+
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(g, BVG_EHIP, "no HIP device available (libbvgpu has no CPU fallback)");
+	if (device < 0 || device >= ndev) return fail(g, BVG_EARG, "no such HIP device");
+	st->device = device;
+	st->info.device = device;
+	HIPCHK(g, hipSetDevice(device));
+	st->nwords = (graph.size() + 3) / 4;
+	const size_t padded = (size_t)(st->nwords + 8) * 4;
+	HIPCHK(g, hipMalloc((void **)&st->d_bits, padded));
+	HIPCHK(g, hipMemset(st->d_bits, 0, padded));
+	if (!graph.empty()) HIPCHK(g, hipMemcpy(st->d_bits, graph.data(), graph.size(), hipMemcpyHostToDevice));
+	HIPCHK(g, hipMalloc((void **)&st->d_offsets, sizeof(int64_t) * st->h_offsets.size()));
+	HIPCHK(g, hipMemcpy(st->d_offsets, st->h_offsets.data(), sizeof(int64_t) * st->h_offsets.size(), hipMemcpyHostToDevice));
+	g->st = st;
+	return init_handle(g);
+}
+
+extern "C" int bvg_clone(const bvg_t *src, bvg_t **out) {
+	if (!src || !out || !src->st) return BVG_EARG;
+	auto *g = new bvg_graph();
+	*out = g;
+	g->st = src->st;
+	return init_handle(g);
+}
+
+extern "C" int bvg_close(bvg_t *g) {
+	if (!g) return BVG_OK;
+	if (g->st && g->st->device >= 0) {
+		(void)hipSetDevice(g->st->device);
+		if (g->own) { (void)hipStreamSynchronize(g->own); (void)hipStreamDestroy(g->own); }
+		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd }) b->release();
+		if (g->h_small) (void)hipHostFree(g->h_small);
+	}
+	delete g;
+	return BVG_OK;
+}
+
+extern "C" int bvg_info(const bvg_t *g, bvg_info_t *out) {
+	if (!g || !out || !g->st) return BVG_EARG;
+	*out = g->st->info;
+	return BVG_OK;
+}
+
+extern "C" const char *bvg_last_error(const bvg_t *g) { return g ? g->err.c_str() : "null handle"; }
+
+extern "C" int bvg_set_stream(bvg_t *g, void *hip_stream) {
+	if (!g || !g->st) return BVG_EARG;
+	if (g->pend.active) { int rc = finish_pending(g, nullptr); if (rc) return rc; }
+	g->stream = hip_stream ? (hipStream_t)hip_stream : g->own;
+	return BVG_OK;
+}
+
+extern "C" int bvg_sync(bvg_t *g, uint64_t *arcs_out) {
+	if (!g || !g->st) return BVG_EARG;
+	HIPCHK(g, hipSetDevice(g->st->device));
+	if (g->pend.active) return finish_pending(g, arcs_out);
+	HIPCHK(g, hipStreamSynchronize(g->stream));
+	if (arcs_out) *arcs_out = g->last_arcs;
+	return BVG_OK;
+}
+
+extern "C" int bvg_outdegrees(bvg_t *g, int32_t from, int32_t to, int32_t *out, int flags) {
+	if (!g || !g->st) return BVG_EARG;
+	const Staged &s = *g->st;
+	if (from < 0 || to > s.info.nodes || from > to || (!out && to > from)) return fail(g, BVG_EARG, "node range out of bounds"); // BVG:860
+	if (to == from) return BVG_OK;
+	HIPCHK(g, hipSetDevice(s.device));
+	if (g->pend.active) { int rc = finish_pending(g, nullptr); if (rc) return rc; }
+	const int32_t cnt = to - from;
+	if (!g->outd.need(sizeof(int32_t) * (size_t)cnt) || !g->ref.need(sizeof(uint16_t) * (size_t)cnt)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
+	HIPCHK(g, hipMemsetAsync(g->small.p, 0, sizeof(Small), g->stream));
+	bv::launch_headers(graph_dev(s), s.def, from, cnt, g->outd.as<int32_t>(), g->ref.as<uint16_t>(), &g->small.as<Small>()->err, g->stream);
+	HIPCHK(g, hipMemcpyAsync(out, g->outd.p, sizeof(int32_t) * (size_t)cnt, (flags & BVG_OUT_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, g->stream));
+	int rc = fetch_small(g);
+	if (rc) return rc;
+	if (g->h_small->err & ~bv::E_REF) return fail(g, dev_err_to_status(g->h_small->err & ~bv::E_REF), "malformed bit stream");
+	return BVG_OK;
+}
+
+extern "C" int bvg_decode_range(bvg_t *g, int32_t from, int32_t to, int64_t *rowptr, int32_t *succ, size_t succ_cap, uint64_t *arcs_out, int flags) {
+	if (!g || !g->st) return BVG_EARG;
+	const Staged &s = *g->st;
+	if (from < 0 || from > s.info.nodes || to < from || to > s.info.nodes || !rowptr) return fail(g, BVG_EARG, "node range out of bounds"); // BVG:1165
+	if (flags & BVG_OUT_DEVICE) return decode_range_device(g, from, to, rowptr, succ, succ_cap, (flags & BVG_ASYNC) != 0, arcs_out);
+	// host outputs: count first, then decode into staging buffers and copy back
+	HIPCHK(g, hipSetDevice(s.device));
+	const size_t nrow = (size_t)(to - from) + 1;
+	if (!g->stage_rowptr.need(sizeof(int64_t) * nrow)) return fail(g, BVG_ENOMEM, "staging allocation failed");
+	uint64_t arcs = 0;
+	int rc = decode_range_device(g, from, to, g->stage_rowptr.as<int64_t>(), nullptr, 0, false, &arcs);
+	if (rc) return rc;
+	if (arcs_out) *arcs_out = arcs;
+	if (succ) {
+		if (arcs > succ_cap) return fail(g, BVG_ECAP, "successor buffer too small");
+		if (!g->stage_succ.need(sizeof(int32_t) * (size_t)std::max<uint64_t>(arcs, 1))) return fail(g, BVG_ENOMEM, "staging allocation failed");
+		rc = decode_range_device(g, from, to, g->stage_rowptr.as<int64_t>(), g->stage_succ.as<int32_t>(), (size_t)arcs, false, &arcs);
+		if (rc) return rc;
+		if (arcs) HIPCHK(g, hipMemcpy(succ, g->stage_succ.p, sizeof(int32_t) * (size_t)arcs, hipMemcpyDeviceToHost));
+	}
+	HIPCHK(g, hipMemcpy(rowptr, g->stage_rowptr.p, sizeof(int64_t) * nrow, hipMemcpyDeviceToHost));
+	return BVG_OK;
+}
+
+extern "C" int bvg_successors_batch(bvg_t *g, const int32_t *nodes, size_t q, int64_t *rowptr, int32_t *succ, size_t succ_cap, uint64_t *arcs_out, int flags) {
+	if (!g || !g->st) return BVG_EARG;
+	if (!rowptr || (!nodes && q)) return fail(g, BVG_EARG, "null argument");
+	const Staged &s = *g->st;
+	HIPCHK(g, hipSetDevice(s.device));
+	if (g->pend.active) { int rc = finish_pending(g, nullptr); if (rc) return rc; }
+	const bool dev = (flags & BVG_OUT_DEVICE) != 0;
+	const bv::GraphDev gd = graph_dev(s);
+	Small *dsm = g->small.as<Small>();
+	HIPCHK(g, hipMemsetAsync(g->small.p, 0, sizeof(Small), g->stream));
+	// inputs / outputs on the device
+	const int32_t *d_nodes = nodes;
+	int64_t *d_rowptr = rowptr;
+	if (!dev) {
+		if (!g->stage_nodes.need(sizeof(int32_t) * std::max<size_t>(q, 1)) || !g->stage_rowptr.need(sizeof(int64_t) * (q + 1))) return fail(g, BVG_ENOMEM, "staging allocation failed");
+		if (q) HIPCHK(g, hipMemcpyAsync(g->stage_nodes.p, nodes, sizeof(int32_t) * q, hipMemcpyHostToDevice, g->stream));
+		d_nodes = g->stage_nodes.as<int32_t>();
+		d_rowptr = g->stage_rowptr.as<int64_t>();
+	}
+	if (q == 0) {
+		HIPCHK(g, hipMemsetAsync(d_rowptr, 0, sizeof(int64_t), g->stream));
+		if (!dev) HIPCHK(g, hipMemcpyAsync(rowptr, d_rowptr, sizeof(int64_t), hipMemcpyDeviceToHost, g->stream));
+		HIPCHK(g, hipStreamSynchronize(g->stream));
+		if (arcs_out) *arcs_out = 0;
+		return BVG_OK;
+	}
+	// 1. chain lengths -> slot bases
+	if (!g->b_chainlen.need(sizeof(int32_t) * q) || !g->b_slotbase.need(sizeof(int64_t) * (q + 1)) || !g->sums.need(sizeof(int64_t) * (size_t)bv::scan_num_sums((int64_t)q)))
+		return fail(g, BVG_ENOMEM, "device scratch allocation failed");
+	bv::launch_chain_len(gd, s.def, d_nodes, (int64_t)q, g->b_chainlen.as<int32_t>(), &dsm->maxdepth, &dsm->err, g->stream);
+	bv::launch_scan(g->b_chainlen.as<int32_t>(), (int64_t)q, g->b_slotbase.as<int64_t>(), g->sums.as<int64_t>(), g->stream);
+	HIPCHK(g, hipMemcpyAsync(&dsm->total, g->b_slotbase.as<int64_t>() + q, sizeof(int64_t), hipMemcpyDeviceToDevice, g->stream));
+	int rc = fetch_small(g);
+	if (rc) return rc;
+	if (g->h_small->err) {
+		const int e = g->h_small->err;
+		if (e & bv::E_ARG) return fail(g, BVG_EARG, "Node index out of range");
+		return fail(g, dev_err_to_status(e), "malformed bit stream");
+	}
+	const int64_t S = g->h_small->total;
+	const int32_t maxlen = g->h_small->maxdepth;
+	// 2. slots, caller rowptr, arena rows
+	const size_t Sz = (size_t)std::max<int64_t>(S, 1);
+	if (!g->b_node.need(4 * Sz) || !g->outd.need(4 * Sz) || !g->depth.need(4 * Sz) || !g->b_qidx.need(4 * Sz) || !g->b_aoutd.need(4 * Sz) ||
+	    !g->b_qoutd.need(4 * q) || !g->rowstart.need(8 * (Sz + 1)) || !g->sums.need(sizeof(int64_t) * (size_t)bv::scan_num_sums((int64_t)std::max<size_t>(Sz, q))))
+		return fail(g, BVG_ENOMEM, "device scratch allocation failed");
+	bv::launch_chain_fill(gd, s.def, d_nodes, (int64_t)q, g->b_slotbase.as<int64_t>(), g->b_node.as<int32_t>(), g->outd.as<int32_t>(), g->depth.as<int32_t>(),
+	                      g->b_qidx.as<int32_t>(), g->b_aoutd.as<int32_t>(), g->b_qoutd.as<int32_t>(), g->stream);
+	bv::launch_scan(g->b_qoutd.as<int32_t>(), (int64_t)q, d_rowptr, g->sums.as<int64_t>(), g->stream);
+	bv::launch_scan(g->b_aoutd.as<int32_t>(), S, g->rowstart.as<int64_t>(), g->sums.as<int64_t>(), g->stream);
+	HIPCHK(g, hipMemcpyAsync(&dsm->total, d_rowptr + q, sizeof(int64_t), hipMemcpyDeviceToDevice, g->stream));
+	HIPCHK(g, hipMemcpyAsync(&dsm->halo_total, g->rowstart.as<int64_t>() + S, sizeof(int64_t), hipMemcpyDeviceToDevice, g->stream));
+	rc = fetch_small(g);
+	if (rc) return rc;
+	const uint64_t arcs = (uint64_t)g->h_small->total;
+	g->last_arcs = arcs;
+	if (arcs_out) *arcs_out = arcs;
+	if (!dev) HIPCHK(g, hipMemcpyAsync(rowptr, d_rowptr, sizeof(int64_t) * (q + 1), hipMemcpyDeviceToHost, g->stream));
+	if (!succ) { HIPCHK(g, hipStreamSynchronize(g->stream)); return BVG_OK; }
+	if (arcs > succ_cap) { HIPCHK(g, hipStreamSynchronize(g->stream)); return fail(g, BVG_ECAP, "successor buffer too small"); }
+	int32_t *d_succ = succ;
+	if (!dev) {
+		if (!g->stage_succ.need(sizeof(int32_t) * (size_t)std::max<uint64_t>(arcs, 1))) return fail(g, BVG_ENOMEM, "staging allocation failed");
+		d_succ = g->stage_succ.as<int32_t>();
+	}
+	if (!g->halo.need(sizeof(int32_t) * (size_t)std::max<int64_t>(g->h_small->halo_total, 1))) return fail(g, BVG_ENOMEM, "arena allocation failed");
+	// 3. decode: parse every slot, then resolve the chains level by level
+	bv::BatchView v{};
+	v.cnt = S; v.node = g->b_node.as<int32_t>(); v.outd = g->outd.as<int32_t>(); v.depth = g->depth.as<int32_t>(); v.qidx = g->b_qidx.as<int32_t>();
+	v.arow = g->rowstart.as<int64_t>(); v.rowptr = d_rowptr; v.succ = d_succ; v.arena = g->halo.as<int32_t>(); v.succ_cap = succ_cap;
+	bv::launch_bparse(gd, s.def, v, &dsm->err, g->stream);
+	for (int32_t l = 1; l < maxlen; l++) bv::launch_bcopy(gd, s.def, v, l, &dsm->err, g->stream);
+	if (!dev && arcs) HIPCHK(g, hipMemcpyAsync(succ, d_succ, sizeof(int32_t) * (size_t)arcs, hipMemcpyDeviceToHost, g->stream));
+	rc = fetch_small(g);
+	if (rc) return rc;
+	if (g->h_small->err) return fail(g, dev_err_to_status(g->h_small->err), "malformed or unsupported bit stream");
+	return BVG_OK;
+}
+
+extern "C" int bvg_csr_hashcode(bvg_t *g, int32_t from, int32_t to, const int64_t *rowptr_dev, const int32_t *succ_dev, int32_t *hash_io) {
+	if (!g || !g->st || !hash_io || from < 0 || to < from) return BVG_EARG;
+	const Staged &s = *g->st;
+	HIPCHK(g, hipSetDevice(s.device));
+	if (g->pend.active) { int rc = finish_pending(g, nullptr); if (rc) return rc; }
+	const int32_t cnt = to - from;
+	if (cnt == 0) return BVG_OK;
+	const size_t nb = ((size_t)cnt + 255) / 256;
+	if (!g->hashA.need(sizeof(uint32_t) * nb) || !g->hashB.need(sizeof(uint32_t) * nb)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
+	g->h_small->hash = *hash_io;
+	int32_t *dh = &g->small.as<Small>()->hash;
+	HIPCHK(g, hipMemcpyAsync(dh, &g->h_small->hash, sizeof(int32_t), hipMemcpyHostToDevice, g->stream));
+	bv::launch_hash(from, cnt, rowptr_dev, succ_dev, g->hashA.as<uint32_t>(), g->hashB.as<uint32_t>(), dh, g->stream);
+	int rc = fetch_small(g);
+	if (rc) return rc;
+	*hash_io = g->h_small->hash;
+	return BVG_OK;
+}
+
+extern "C" int bvg_shard_bounds(const bvg_t *g, int parts, int32_t *bounds) {
+	if (!g || !g->st || parts < 1 || !bounds) return BVG_EARG;
+	const std::vector<int64_t> &off = g->st->h_offsets;
+	const int32_t n = g->st->info.nodes;
+	const int64_t totalBits = off.back();
+	bounds[0] = 0;
+	for (int k = 1; k < parts; k++) {
+		// bounds[k] = min{x : off[x] >= k*total/parts}
+		const int64_t target = (int64_t)((__int128)totalBits * k / parts);
+		int32_t x = (int32_t)(std::lower_bound(off.begin(), off.begin() + n, target) - off.begin());
+		bounds[k] = std::max(x, bounds[k - 1]);
+	}
+	bounds[parts] = n;
+	return BVG_OK;
+}
