@@ -89,6 +89,16 @@ int bvg_set_stream(bvg_t *g, void *hip_stream);
  * if arcs_out != NULL, the arc count of the last range/batch decode. */
 int bvg_sync(bvg_t *g, uint64_t *arcs_out);
 
+/* ---- measurement ------------------------------------------------------------------------------------ */
+
+/* Phases of one bvg_decode_range, in stream order (HIP events are recorded between them when profiling is on):
+ * headers(+halo closure) | scan | chain depth | parse | copy levels | rowptr rebase + totals */
+#define BVG_NUM_PHASES 6
+/* Enables / disables per-phase HIP-event timing on this handle (off by default; costs a few event records). */
+int bvg_set_profile(bvg_t *g, int enable);
+/* Milliseconds of each phase of the last range decode issued with profiling on; ms has BVG_NUM_PHASES floats. */
+int bvg_get_profile(bvg_t *g, float *ms);
+
 /* ---- the hot path ---------------------------------------------------------------------------------- */
 
 /* outdegree(x) for x in [from, to)  (BVG:858-888).  out has to-from int32. */

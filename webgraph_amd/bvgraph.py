@@ -28,7 +28,7 @@ class BvgInfo(C.Structure):
 
 EXPORTS = ["bvg_open", "bvg_clone", "bvg_close", "bvg_info", "bvg_last_error", "bvg_set_stream", "bvg_sync",
            "bvg_outdegrees", "bvg_decode_range", "bvg_successors_batch", "bvg_csr_hashcode", "bvg_shard_bounds",
-           "bvg_parse_properties", "bvg_flags_from_string", "bvg_decode_offsets_host"]
+           "bvg_parse_properties", "bvg_flags_from_string", "bvg_decode_offsets_host", "bvg_set_profile", "bvg_get_profile"]
 
 _lib = None
 
@@ -64,6 +64,8 @@ def lib():
         L.bvg_flags_from_string.argtypes = [C.c_char_p]
         L.bvg_flags_from_string.restype = i64
         L.bvg_decode_offsets_host.argtypes = [vp, sz, i32, C.c_int, vp]
+        L.bvg_set_profile.argtypes = [vp, C.c_int]
+        L.bvg_get_profile.argtypes = [vp, C.POINTER(C.c_float)]
         _lib = L
     return _lib
 
@@ -307,6 +309,17 @@ class BVGraph:
 
     def set_stream(self, hip_stream):
         self._check(lib().bvg_set_stream(self._h, hip_stream))
+
+    PHASES = ("headers", "scan", "depth", "parse", "copy", "tail")
+
+    def set_profile(self, on):
+        self._check(lib().bvg_set_profile(self._h, 1 if on else 0))
+
+    def get_profile(self):
+        """Per-phase milliseconds of the last profiled range decode (HIP events on the decode stream)."""
+        ms = (C.c_float * len(self.PHASES))()
+        self._check(lib().bvg_get_profile(self._h, ms))
+        return dict(zip(self.PHASES, [float(x) for x in ms]))
 
     def successors_batch(self, nodes):
         """Concatenated successorArray(nodes[i]) (random access, BVGraph.java:897-904)."""

@@ -79,6 +79,10 @@ struct bvg_graph {
 	int32_t levels_hint = 1;
 	Pending pend;
 	uint64_t last_arcs = 0;
+	// optional per-phase timing (bvg_set_profile): events recorded between the phases of a range decode
+	bool profile = false;
+	hipEvent_t ev[BVG_NUM_PHASES + 1] = {};
+	bool ev_valid = false;
 };
 
 namespace {
@@ -120,6 +124,8 @@ int init_handle(bvg_graph *g) {
 	return BVG_OK;
 }
 
+void mark(bvg_graph *g, int i) { if (g->profile) (void)hipEventRecord(g->ev[i], g->stream); }
+
 // Enqueues headers (+halo closure) + scan for nodes [from,to) with a halo of nh nodes before `from`.
 // On return the view describes the job; rowstart lives in scratch.
 int enqueue_structure(bvg_graph *g, int32_t from, int32_t to, int32_t nh, bv::RangeView &v) {
@@ -134,9 +140,12 @@ int enqueue_structure(bvg_graph *g, int32_t from, int32_t to, int32_t nh, bv::Ra
 	v.outd = g->outd.as<int32_t>(); v.ref = g->ref.as<uint16_t>(); v.rowstart = g->rowstart.as<int64_t>();
 	int *derr = &g->small.as<Small>()->err;
 	const bv::GraphDev gd = graph_dev(s);
+	mark(g, 0);
 	bv::launch_headers(gd, s.def, lo, cnt, v.outd, v.ref, derr, g->stream);
 	if (nh) bv::launch_mark_halo(nh, cnt, s.info.window_size, v.outd, v.ref, g->need.as<uint8_t>(), derr, g->stream);
+	mark(g, 1);
 	bv::launch_scan(v.outd, cnt, v.rowstart, g->sums.as<int64_t>(), g->stream);
+	mark(g, 2);
 	return BVG_OK;
 }
 
@@ -225,14 +234,20 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 	if (succ_dev) {
 		if (!g->depth.need(sizeof(int32_t) * (size_t)v.cnt)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
 		if (W > 0) bv::launch_depth(v.cnt, v.ref, g->depth.as<int32_t>(), &g->small.as<Small>()->maxdepth, g->stream);
+		mark(g, 3);
 		bv::launch_parse(gd, s.def, v, derr, g->stream);
+		mark(g, 4);
 		if (W > 0) {
 			levels = g->levels_hint;
 			for (int32_t l = 1; l <= levels; l++) bv::launch_copy(gd, s.def, v, g->depth.as<int32_t>(), l, derr, g->stream);
 		}
 	}
+	if (!succ_dev) { mark(g, 3); mark(g, 4); }
+	mark(g, 5);
 	bv::launch_rebase(v.nh, v.cnt, v.rowstart, rowptr_dev, g->stream);
 	hipLaunchKernelGGL(k_totals, dim3(1), dim3(1), 0, g->stream, v.rowstart, v.nh, v.cnt, g->small.as<Small>());
+	mark(g, 6);
+	g->ev_valid = g->profile;
 	HIPCHK(g, hipGetLastError());
 	g->pend.active = true; g->pend.view = v; g->pend.levels_done = levels; g->pend.want_succ = succ_dev != nullptr;
 	if (async) return BVG_OK;
@@ -320,6 +335,7 @@ extern "C" int bvg_close(bvg_t *g) {
 		if (g->own) { (void)hipStreamSynchronize(g->own); (void)hipStreamDestroy(g->own); }
 		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd }) b->release();
 		if (g->h_small) (void)hipHostFree(g->h_small);
+		for (auto &e : g->ev) if (e) (void)hipEventDestroy(e);
 	}
 	delete g;
 	return BVG_OK;
@@ -337,6 +353,24 @@ extern "C" int bvg_set_stream(bvg_t *g, void *hip_stream) {
 	if (!g || !g->st) return BVG_EARG;
 	if (g->pend.active) { int rc = finish_pending(g, nullptr); if (rc) return rc; }
 	g->stream = hip_stream ? (hipStream_t)hip_stream : g->own;
+	return BVG_OK;
+}
+
+extern "C" int bvg_set_profile(bvg_t *g, int enable) {
+	if (!g || !g->st) return BVG_EARG;
+	HIPCHK(g, hipSetDevice(g->st->device));
+	if (enable && !g->ev[0]) for (auto &e : g->ev) HIPCHK(g, hipEventCreate(&e));
+	g->profile = enable != 0;
+	g->ev_valid = false;
+	return BVG_OK;
+}
+
+extern "C" int bvg_get_profile(bvg_t *g, float *ms) {
+	if (!g || !g->st || !ms) return BVG_EARG;
+	if (!g->ev_valid) return fail(g, BVG_ESTATE, "no profiled range decode has completed");
+	if (g->pend.active) { int rc = finish_pending(g, nullptr); if (rc) return rc; }
+	HIPCHK(g, hipEventSynchronize(g->ev[BVG_NUM_PHASES]));
+	for (int i = 0; i < BVG_NUM_PHASES; i++) HIPCHK(g, hipEventElapsedTime(&ms[i], g->ev[i], g->ev[i + 1]));
 	return BVG_OK;
 }
 
