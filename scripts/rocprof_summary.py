@@ -13,7 +13,7 @@ def main():
     lines = ["%-72s %8s %14s %14s %8s" % ("kernel", "calls", "total_us", "avg_us", "pct")]
     for name, calls, tot, avg, pct in rows:
         short = name if len(name) <= 72 else name[:69] + "..."
-        lines.append("%-72s %8d %14.3f %14.3f %8.3f" % (short, calls, tot / 1e3, avg / 1e3, pct))
+        lines.append("%-72s %8d %14.3f %14.3f %8.3f" % (short, calls, tot, avg, pct))
     text = "\n".join(lines) + "\n"
     if len(sys.argv) > 2:
         with open(sys.argv[2], "w") as f:
