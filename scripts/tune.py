@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Tuning helper (GPU box): times the phases of a full scan and prints the cooperative decoder's counters.
+
+usage: BVGPU_STATS=1 python scripts/tune.py [--nodes N --arcs M] [--graph basename] [--reps R]
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nodes", type=int, default=10_000_000)
+    ap.add_argument("--arcs", type=int, default=200_000_000)
+    ap.add_argument("--graph", default=None)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--check", action="store_true")
+    args = ap.parse_args()
+    import torch
+    import bench
+    import __graft_entry__ as ge
+    ge.build()
+    from webgraph_amd.bvgraph import BVGraph
+    if args.graph:
+        base = args.graph
+    else:
+        base, _ = bench.prepare_graph(args.nodes, args.arcs, bench.SEED, 0.5, "/tmp/bvgpu_cache", os.cpu_count())
+    g = BVGraph.load(base)
+    n, m = g.numNodes(), g.numArcs()
+    dev = torch.device("cuda", 0)
+    rowptr = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    succ = torch.empty(max(m, 1), dtype=torch.int32, device=dev)
+    g.decode_range_device(0, n, rowptr.data_ptr(), succ.data_ptr(), succ.numel())
+    if os.environ.get("BVGPU_STATS"):
+        g.debug_stats(reset=True)
+    g.set_profile(True)
+    acc = {}
+    t0 = time.perf_counter()
+    for _ in range(args.reps):
+        g.decode_range_device(0, n, rowptr.data_ptr(), succ.data_ptr(), succ.numel())
+        for k, v in g.get_profile().items():
+            acc[k] = acc.get(k, 0) + v / args.reps
+    wall = (time.perf_counter() - t0) / args.reps
+    print("phases(ms):", {k: round(v, 3) for k, v in acc.items()}, "sum %.3f wall %.3f" % (sum(acc.values()), wall * 1e3), "Gedges/s %.2f" % (m / sum(acc.values()) / 1e6))
+    if os.environ.get("BVGPU_STATS"):
+        st = g.debug_stats() // args.reps
+        print("res tiles %d rounds/tile %.2f | int tiles %d rounds/tile %.2f | big nodes %d ticks/node %.0f max ticks %d (x reps)" % (
+            st[0], st[1] / max(st[0], 1), st[2], st[3] / max(st[2], 1), st[5], st[6] / max(st[5], 1), st[7] * args.reps))
+        print("residual tile rounds histogram (<=2,<=4,<=8,<=16,<=32,<=64):", [int(v) for v in st[8:14]])
+        ns = max(int(st[13]), 1)
+        print("slow tiles: avg B %.0f avg remaining codes %.0f avg codes in tile %.0f" % (st[15] / ns, st[4] / ns, st[14] / ns))
+    if args.check:
+        from oracle import oracle as O
+        og = O.OracleGraph.load(base)
+        import numpy as np
+        rp, sc, _ = og.scan()
+        print("parity:", np.array_equal(rp, rowptr.cpu().numpy()) and np.array_equal(sc, succ.cpu().numpy()))
+
+
+if __name__ == "__main__":
+    main()

@@ -28,7 +28,7 @@ class BvgInfo(C.Structure):
 
 EXPORTS = ["bvg_open", "bvg_clone", "bvg_close", "bvg_info", "bvg_last_error", "bvg_set_stream", "bvg_sync",
            "bvg_outdegrees", "bvg_decode_range", "bvg_successors_batch", "bvg_csr_hashcode", "bvg_shard_bounds",
-           "bvg_parse_properties", "bvg_flags_from_string", "bvg_decode_offsets_host", "bvg_set_profile", "bvg_get_profile"]
+           "bvg_parse_properties", "bvg_flags_from_string", "bvg_decode_offsets_host", "bvg_set_profile", "bvg_get_profile", "bvg_debug_stats"]
 
 _lib = None
 
@@ -66,6 +66,7 @@ def lib():
         L.bvg_decode_offsets_host.argtypes = [vp, sz, i32, C.c_int, vp]
         L.bvg_set_profile.argtypes = [vp, C.c_int]
         L.bvg_get_profile.argtypes = [vp, C.POINTER(C.c_float)]
+        L.bvg_debug_stats.argtypes = [vp, vp, C.c_int]
         _lib = L
     return _lib
 
@@ -320,6 +321,11 @@ class BVGraph:
         ms = (C.c_float * len(self.PHASES))()
         self._check(lib().bvg_get_profile(self._h, ms))
         return dict(zip(self.PHASES, [float(x) for x in ms]))
+
+    def debug_stats(self, reset=True):
+        out = np.zeros(16, dtype=np.uint64)
+        self._check(lib().bvg_debug_stats(self._h, out.ctypes.data, 1 if reset else 0))
+        return out
 
     def successors_batch(self, nodes):
         """Concatenated successorArray(nodes[i]) (random access, BVGraph.java:897-904)."""

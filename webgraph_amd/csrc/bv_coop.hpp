@@ -1,0 +1,448 @@
+// bv_coop.hpp -- cooperative decoding of ONE long BVGraph record by a group of NW wavefronts (gfx950).
+//
+// Variable-length codes are serial within a record, so a long record cannot simply be split between lanes.
+// The group decodes a section of the bit stream in tiles of N x B bits (N = 64*NW lanes): the tile's words are
+// staged in LDS with coalesced loads, then lane i speculatively parses the codes that START inside its B-bit
+// segment, beginning at a guessed boundary; every lane then adopts its left neighbour's end position as its
+// start and re-parses, until no start changes (fixed point).  Lane 0 always starts on a true boundary, so at
+// the fixed point every lane does (induction); universal codes re-synchronise within a few codes, so the loop
+// usually stops after 2-4 rounds.  Gap sequences then become absolute ids through prefix sums over the group
+// (__shfl_up scans inside a wave, LDS across waves) -- the "ballot/prefix" step of the north star.
+//
+// Record grammar and semantics: BVG:1032-1133.  Layout of the work:
+//   phase A  header + copy-block totals      uniform (every lane computes the same scalars)
+//   phase I  interval section (gamma pairs)  cooperative -> list entries {left, pstart, rank, len} in a scratch arena
+//   phase R  residual section (zeta_k ...)   cooperative -> residual ids written at their final position in the
+//                                            row tail; tells each interval how many residuals precede it
+//   phase X  interval expansion              cooperative -> interval ids written at their final position
+// The result is the same "extras merged into row[copied..d)" that the one-lane parse_node produces
+// (IntIntervalSequenceIterator + ResidualIntIterator under a MergedIntIterator, BVG:1103-1110).
+#pragma once
+#include "bv_device.hpp"
+
+namespace bv {
+
+// A tile is N x B bits of stream, one B-bit segment per lane.  B adapts to the average code length of the
+// section (known from the record's bit length and its code count) so that a segment holds ~COOP_CODES_PER_SEG
+// codes: speculative parses only re-synchronise with the true parse after a handful of codes, and a segment
+// that ends before they did costs one more round of the fixed-point loop per lane it delays.
+constexpr int COOP_B_MIN = 64, COOP_CODES_PER_SEG = 12;
+
+template <int NW> struct CoopCfg;
+template <> struct CoopCfg<1> { static constexpr int N = 64, B_MAX = 512, CAPT = 1024; };
+template <> struct CoopCfg<16> { static constexpr int N = 1024, B_MAX = 128, CAPT = 8192; };
+
+template <int NW> struct CoopLds { // LDS layout of one group, in 32-bit words
+	static constexpr int WIN_WORDS = CoopCfg<NW>::N * CoopCfg<NW>::B_MAX / 32 + 8; // staged tile bits (+ look-ahead slack)
+	static constexpr int XCH_WORDS = 2 * (NW + 8);                                   // int64 exchange slots
+	static constexpr int OFF_WIN = 0, OFF_RESV = WIN_WORDS, OFF_DELTA = OFF_RESV + CoopCfg<NW>::CAPT, OFF_XCH = ((OFF_DELTA + CoopCfg<NW>::CAPT + 1) & ~1);
+	static constexpr int WORDS = OFF_XCH + XCH_WORDS;
+};
+
+struct IvEntry { int32_t left; int32_t pstart; int32_t rank; int32_t len; }; // one interval in the scratch arena
+
+__device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d) { return (uint64_t)__shfl_up((long long)v, d, 64); }
+__device__ __forceinline__ int64_t shfl_i64(int64_t v, int l) { return (int64_t)__shfl((long long)v, l, 64); }
+
+__device__ __forceinline__ int64_t wave_incl_scan_i64(int64_t v) {
+	const int lane = threadIdx.x & 63;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const int64_t t = (int64_t)__shfl_up((long long)v, o, 64);
+		if (lane >= o) v += t;
+	}
+	return v;
+}
+
+// Group-wide primitives.  Every member is a collective: all N threads must call it under uniform control flow.
+template <int NW> struct Grp {
+	static constexpr int N = 64 * NW;
+	int64_t *xch; // LDS, NW + 8 slots
+	__device__ __forceinline__ int tid() const { return threadIdx.x; }
+	__device__ __forceinline__ int lane() const { return threadIdx.x & 63; }
+	__device__ __forceinline__ int wave() const { return threadIdx.x >> 6; }
+	// LDS hand-off inside the group.  One wave: the LDS executes a wave's DS instructions in issue order, so
+	// keeping the program order is enough.  Several waves: a workgroup barrier.
+	__device__ __forceinline__ void sync() const {
+		if (NW == 1) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); }
+		else __syncthreads();
+	}
+	// also orders this group's GLOBAL writes before its later reads (waits for outstanding stores: once per phase)
+	__device__ __forceinline__ void sync_global() const {
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		if (NW == 1) __builtin_amdgcn_wave_barrier(); else __syncthreads();
+	}
+	__device__ __forceinline__ bool any(bool p) const { return NW == 1 ? (bool)__any(p) : (bool)__syncthreads_or(p); }
+	__device__ __forceinline__ int64_t incl_scan(int64_t v, int64_t &total) const {
+		const int64_t inc = wave_incl_scan_i64(v);
+		if (NW == 1) { total = shfl_i64(inc, 63); return inc; }
+		if (lane() == 63) xch[wave()] = inc;
+		__syncthreads();
+		int64_t base = 0, tot = 0;
+#pragma unroll
+		for (int i = 0; i < NW; i++) { const int64_t t = xch[i]; if (i < wave()) base += t; tot += t; }
+		__syncthreads();
+		total = tot;
+		return base + inc;
+	}
+	// the value held by thread tid-1; thread 0 gets `first`
+	__device__ __forceinline__ uint64_t prev(uint64_t e, uint64_t first) const {
+		uint64_t v = shfl_up_u64(e, 1);
+		if (NW > 1) {
+			if (lane() == 63) xch[wave()] = (int64_t)e;
+			__syncthreads();
+			if (lane() == 0 && wave() > 0) v = (uint64_t)xch[wave() - 1];
+			__syncthreads();
+		}
+		return tid() == 0 ? first : v;
+	}
+	__device__ __forceinline__ int64_t bcast(int64_t v, int srcTid) const {
+		if (NW == 1) return shfl_i64(v, srcTid);
+		if (tid() == srcTid) xch[NW] = v;
+		__syncthreads();
+		const int64_t r = xch[NW];
+		__syncthreads();
+		return r;
+	}
+	// largest tid with p set, -1 if none
+	__device__ __forceinline__ int last_set(bool p) const {
+		const unsigned long long m = __ballot(p);
+		int w = m ? wave() * 64 + 63 - __clzll((long long)m) : -1;
+		if (NW == 1) return w;
+		if (lane() == 0) xch[wave()] = w;
+		__syncthreads();
+		int r = -1;
+#pragma unroll
+		for (int i = 0; i < NW; i++) r = max(r, (int)xch[i]);
+		__syncthreads();
+		return r;
+	}
+	// smallest tid with p set, N if none
+	__device__ __forceinline__ int first_set(bool p) const {
+		const unsigned long long m = __ballot(p);
+		int w = m ? wave() * 64 + __ffsll((long long)m) - 1 : N;
+		if (NW == 1) return w;
+		if (lane() == 0) xch[wave()] = w;
+		__syncthreads();
+		int r = N;
+#pragma unroll
+		for (int i = 0; i < NW; i++) r = min(r, (int)xch[i]);
+		__syncthreads();
+		return r;
+	}
+};
+
+__device__ __forceinline__ uint32_t coop_pick_B(uint64_t sectionBits, uint64_t codes, uint32_t bmax) {
+	const uint64_t avg = (sectionBits + codes - 1) / (codes ? codes : 1);
+	uint64_t b = (avg * COOP_CODES_PER_SEG + 31) & ~(uint64_t)31;
+	return (uint32_t)(b < COOP_B_MIN ? COOP_B_MIN : b > bmax ? bmax : b);
+}
+
+// Stages the words of the tile [pos0, pos0 + N*B) (+ slack) into LDS, byte-swapped, with coalesced loads.
+template <int NW>
+__device__ __forceinline__ WindowSrc stage_tile(const Grp<NW> &G, const GraphDev &g, uint32_t *win, uint64_t pos0, uint32_t B) {
+	const uint64_t w0 = pos0 >> 5;
+	const uint32_t nw = (uint32_t)(Grp<NW>::N * (B >> 5)) + 8;
+	G.sync(); // the previous tile's readers are done
+	for (uint32_t i = G.tid(); i < nw; i += Grp<NW>::N) { const uint64_t w = w0 + i; win[i] = w < g.nwords ? __builtin_bswap32(g.bits[w]) : 0u; }
+	G.sync();
+	return WindowSrc{ win, w0, nw, GlobalSrc{ g.bits, g.nwords } };
+}
+
+// One speculative parse of the codes starting in [s, segEnd): end position, count and the sum of the decoded
+// contributions.  KIND 0: residual codes (gap+1 each; the first code of the section is the zig-zag value);
+// KIND 1: gamma codes, positions only.
+template <bool DEF, int KIND>
+__device__ __forceinline__ void spec_parse(const GraphDev &g, const WindowSrc &src, uint64_t s, uint64_t segEnd, bool firstOfSection, uint64_t &e, uint32_t &c, int64_t &sum) {
+	c = 0; sum = 0;
+	if (s >= segEnd) { e = s; return; }
+	WinReader br;
+	br.init_src(src, g.nwords);
+	br.seek(s);
+	while (br.pos() < segEnd && !br.err) { // a speculative parse may run through garbage: errors only stop it
+		if (KIND == 0) {
+			const uint64_t v = Fields<DEF>::residual(br, g);
+			sum += (c == 0 && firstOfSection) ? nat2int(v) : (int64_t)v + 1;
+		} else {
+			(void)br.gamma();
+		}
+		c++;
+	}
+	e = br.pos();
+}
+
+// Fixed-point iteration over one tile starting at the true code boundary pos0.  On return every lane holds
+// the true start `s` of the first code it owns, the number `c` of codes starting in its segment, their
+// contribution sum, and E = end of the tile's last code (uniform).
+template <bool DEF, int KIND, int NW>
+__device__ __forceinline__ void spec_tile(const Grp<NW> &G, const GraphDev &g, const WindowSrc &src, uint64_t pos0, uint64_t secEnd, uint32_t B, bool firstTile,
+                                          int64_t needCodes, uint64_t &s, uint32_t &c, int64_t &sum, uint64_t &E) {
+	const int tid = G.tid();
+	const uint64_t segEnd = min(pos0 + (uint64_t)(tid + 1) * B, secEnd);
+	s = min(pos0 + (uint64_t)tid * B, secEnd);
+	uint64_t e = s;
+	bool dirty = true;
+	for (int round = 0; round < Grp<NW>::N + 2; round++) {
+		if (dirty) {
+			spec_parse<DEF, KIND>(g, src, s, segEnd, firstTile && tid == 0, e, c, sum);
+			// a parse that runs past the section end is wrong anyway; clamping keeps the lanes behind the end
+			// quiet instead of handing the overshoot down one lane per round
+			e = min(e, secEnd);
+		}
+		const uint64_t ns = G.prev(e, pos0);
+		dirty = ns != s;
+		s = ns;
+		bool stop = !G.any(dirty);
+		if (!stop && KIND == 1) {
+			// The section ends after needCodes codes, somewhere inside the tile: lanes past that point parse
+			// the NEXT section's bits as gamma codes and need not converge.  The clean prefix of lanes is
+			// exact, so it suffices that the lanes before the one reaching needCodes are clean.
+			const int firstDirty = G.first_set(dirty); // >= 1: lane 0 is never dirty
+			int64_t tot;
+			const int64_t cincl = G.incl_scan((int64_t)c, tot);
+			const int64_t upto = G.bcast(cincl, firstDirty - 1);
+			stop = upto >= needCodes;
+		}
+		if (stop) {
+			stat_add(g, KIND == 0 ? 1 : 3, (unsigned long long)round + 1);
+			if (g.stats && KIND == 0) { const int rr = round + 1; stat_add(g, 8 + (rr <= 2 ? 0 : rr <= 4 ? 1 : rr <= 8 ? 2 : rr <= 16 ? 3 : rr <= 32 ? 4 : rr <= 64 ? 5 : 6), 1); }
+			break;
+		}
+	}
+	stat_add(g, KIND == 0 ? 0 : 2, 1);
+	E = (uint64_t)G.bcast((int64_t)e, Grp<NW>::N - 1);
+}
+
+// ---------------------------------------------------------------------------------------------- phase I
+// Decodes the 2*ic gamma codes of the interval section starting at `pos` into arena entries (BVG:1077-1095);
+// returns the bit position after them (start of the residual section) and the number of intervalised arcs.
+template <bool DEF, int NW>
+__device__ __forceinline__ void coop_intervals(const Grp<NW> &G, const GraphDev &g, int32_t x, uint64_t pos, uint64_t recEnd, int64_t ic, uint32_t B,
+                                               IvEntry *__restrict__ list, uint32_t *lds, uint64_t &posAfter, int64_t &intervalArcs, int &err) {
+	uint32_t *win = lds + CoopLds<NW>::OFF_WIN;
+	int64_t codesDone = 0;              // uniform
+	const int64_t codesAll = 2 * ic;
+	int64_t cursor = x;                 // end of the previous interval; the first left is x + nat2int(v)
+	int64_t pcount = 0;                 // intervalised arcs so far
+	while (codesDone < codesAll) {
+		const WindowSrc src = stage_tile<NW>(G, g, win, pos, B);
+		uint64_t s, E; uint32_t c; int64_t unused;
+		spec_tile<DEF, 1, NW>(G, g, src, pos, recEnd, B, false, codesAll - codesDone, s, c, unused, E);
+		int64_t tileTotal;
+		const int64_t cincl = G.incl_scan((int64_t)c, tileTotal);
+		const int64_t cb = cincl - c;
+		const int64_t rem = codesAll - codesDone;
+		if (cb >= rem) c = 0; else if (cb + c > rem) c = (uint32_t)(rem - cb);
+		const int64_t total = min(rem, tileTotal); // codes this tile contributes
+		if (total <= 0) { err |= E_FORMAT; break; }
+		// pass 1: what my codes add to the cursor and to the arc count.  Code q of the section is a left gap
+		// (q even) or a length (q odd).
+		int64_t dcur = 0, dp = 0;
+		uint64_t myEnd = s;
+		{
+			WinReader br; br.init_src(src, g.nwords);
+			if (c) br.seek(s);
+			for (uint32_t k = 0; k < c; k++) {
+				const int64_t q = codesDone + cb + k;
+				const uint64_t v = br.gamma();
+				if (q & 1) { const int64_t len = (int64_t)v + g.minInt; dcur += len; dp += len; }
+				else dcur += q == 0 ? nat2int(v) : (int64_t)v + 1;
+			}
+			if (c) myEnd = br.pos();
+			err |= br.err;
+		}
+		int64_t curTot, pTot;
+		const int64_t icur = G.incl_scan(dcur, curTot), ip = G.incl_scan(dp, pTot);
+		int64_t cur = cursor + icur - dcur, pc = pcount + ip - dp;
+		// pass 2: write the entries
+		{
+			WinReader br; br.init_src(src, g.nwords);
+			if (c) br.seek(s);
+			for (uint32_t k = 0; k < c; k++) {
+				const int64_t q = codesDone + cb + k;
+				const uint64_t v = br.gamma();
+				if (q & 1) { const int64_t len = (int64_t)v + g.minInt; list[q >> 1].pstart = (int32_t)pc; list[q >> 1].len = (int32_t)len; cur += len; pc += len; }
+				else { cur += q == 0 ? nat2int(v) : (int64_t)v + 1; list[q >> 1].left = (int32_t)cur; }
+			}
+		}
+		// the lane owning the last contributed code knows where the section really continues
+		const int lastTid = G.last_set(c > 0);
+		const uint64_t endPos = (uint64_t)G.bcast((int64_t)myEnd, lastTid);
+		cursor += curTot;
+		pcount += pTot;
+		codesDone += total;
+		pos = codesDone >= codesAll ? endPos : E;
+	}
+	posAfter = pos;
+	intervalArcs = pcount;
+}
+
+// ---------------------------------------------------------------------------------------------- phases R + X
+// out = row + copied.
+template <bool DEF, int NW>
+__device__ __forceinline__ void coop_residuals(const Grp<NW> &G, const GraphDev &g, int32_t x, uint64_t pos, uint64_t recEnd, int64_t nRes, int64_t ic, int64_t intervalArcs,
+                                               IvEntry *__restrict__ list, int32_t *__restrict__ out, uint32_t *lds, int &err) {
+	constexpr int N = Grp<NW>::N, CAPT = CoopCfg<NW>::CAPT;
+	const int tid = G.tid();
+	uint32_t *win = lds + CoopLds<NW>::OFF_WIN;
+	int32_t *resv = (int32_t *)lds + CoopLds<NW>::OFF_RESV, *delta = (int32_t *)lds + CoopLds<NW>::OFF_DELTA;
+	int64_t resDone = 0;       // residuals written so far (uniform)
+	int64_t baseVal = x;       // previous residual (BVG:954: the first one is x + nat2int(code))
+	int64_t ia = 0;            // first interval not yet ranked
+	int64_t elemsBefore = 0;   // arcs of the intervals [0, ia)
+	bool firstTile = true;
+	const uint32_t B = coop_pick_B(recEnd > pos ? recEnd - pos : 0, (uint64_t)nRes, CoopCfg<NW>::B_MAX); // the residual section ends with the record
+	while (resDone < nRes) {
+		const WindowSrc src = stage_tile<NW>(G, g, win, pos, B);
+		uint64_t s, E; uint32_t c; int64_t sum;
+		spec_tile<DEF, 0, NW>(G, g, src, pos, recEnd, B, firstTile, nRes - resDone, s, c, sum, E);
+		// take at most CAPT residuals, and no more than the section still has
+		int64_t tileTotal;
+		const int64_t cincl = G.incl_scan((int64_t)c, tileTotal);
+		const int64_t cb = cincl - c;
+		const int64_t lim = min<int64_t>(nRes - resDone, CAPT);
+		bool cut = false;
+		if (cb >= lim) { cut = c > 0; c = 0; } else if (cb + c > lim) { c = (uint32_t)(lim - cb); cut = true; }
+		const bool anyCut = G.any(cut);
+		const int64_t T = min(lim, tileTotal);
+		if (T <= 0) { err |= E_FORMAT; break; }
+		// absolute values of my residuals -> LDS
+		int64_t sumTot;
+		const int64_t sincl = G.incl_scan(sum, sumTot);
+		int64_t val = baseVal + sincl - sum;
+		uint64_t myEnd = s;
+		{
+			WinReader br; br.init_src(src, g.nwords);
+			if (c) br.seek(s);
+			for (uint32_t k = 0; k < c; k++) {
+				const uint64_t v = Fields<DEF>::residual(br, g);
+				val += (firstTile && tid == 0 && k == 0) ? nat2int(v) : (int64_t)v + 1; // BVG:954, :966
+				resv[cb + k] = (int32_t)val;
+			}
+			if (c) myEnd = br.pos();
+			err |= br.err;
+		}
+		const int lastTid = G.last_set(c > 0);
+		const int64_t lastVal = G.bcast(val, lastTid);
+		const uint64_t nextPos = anyCut ? (uint64_t)G.bcast((int64_t)myEnd, lastTid) : E;
+		G.sync();
+
+		if (ic > 0) {
+			// Rank the intervals whose left extreme precedes this tile's last residual: interval i sits after
+			// `lo` of the tile's residuals.  delta[lo] collects the arcs inserted in front of residual lo.
+			for (int64_t t = tid; t < T; t += N) delta[t] = 0;
+			G.sync();
+			for (;;) {
+				const int64_t i = ia + tid;
+				bool take = false; int32_t left = 0, len = 0;
+				if (i < ic) { left = list[i].left; len = list[i].len; take = (int64_t)left < lastVal; }
+				if (take) {
+					int64_t lo = 0, hi = T; // lower_bound(resv[0..T), left)
+					while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (resv[mid] < left) lo = mid + 1; else hi = mid; }
+					list[i].rank = (int32_t)(resDone + lo);
+					atomicAdd(&delta[lo], len); // lo < T because left < resv[T-1]
+				}
+				int64_t nt;
+				(void)G.incl_scan(take ? 1 : 0, nt); // lefts increase: the taken ones are a prefix of the group
+				ia += nt;
+				if (nt < N) break;
+			}
+			const int64_t pNow = ia < ic ? (int64_t)list[ia].pstart : intervalArcs;
+			G.sync();
+			// residual t of the tile goes after the arcs of earlier tiles' intervals and after those of this
+			// tile's intervals ranked <= t  (inclusive scan of delta)
+			int64_t carry = 0;
+			for (int64_t t0 = 0; t0 < T; t0 += N) {
+				const int64_t t = t0 + tid;
+				const int64_t dv = t < T ? delta[t] : 0;
+				int64_t tot;
+				const int64_t inc = G.incl_scan(dv, tot);
+				if (t < T) out[resDone + t + elemsBefore + carry + inc] = resv[t];
+				carry += tot;
+			}
+			elemsBefore = pNow;
+		} else {
+			for (int64_t t = tid; t < T; t += N) out[resDone + t] = resv[t];
+		}
+		resDone += T;
+		baseVal = lastVal;
+		pos = nextPos;
+		firstTile = false;
+	}
+	if (ic == 0) return;
+	G.sync_global(); // ranks written above are read by other lanes below
+	// phase X: interval i occupies out[pstart + rank .. + len)  (IntIntervalSequenceIterator.java:64-78)
+	for (int64_t i0 = 0; i0 < ic; i0 += N) {
+		const int64_t i = i0 + tid;
+		int32_t left = 0, len = 0; int64_t p = 0;
+		if (i < ic) { const IvEntry en = list[i]; left = en.left; len = en.len; p = (int64_t)en.pstart + en.rank; }
+		const bool isLong = len > 16;
+		if (!isLong) for (int32_t t = 0; t < len; t++) out[p + t] = left + t;
+		unsigned long long lm = __ballot(isLong);
+		while (lm) { // long intervals: a whole wave fills one at a time
+			const int src = __ffsll((long long)lm) - 1;
+			lm &= lm - 1;
+			const int32_t L = __shfl(left, src, 64), Nn = __shfl(len, src, 64);
+			const int64_t P = shfl_i64(p, src);
+			for (int32_t t = G.lane(); t < Nn; t += 64) out[P + t] = L + t;
+		}
+	}
+}
+
+// The whole record of node x by one group.  Same contract as parse_node: extras merged into row[copied..d).
+template <bool DEF, int NW>
+__device__ __forceinline__ void coop_parse_node(const GraphDev &g, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row,
+                                                IvEntry *__restrict__ list, uint32_t *lds, int *__restrict__ errOut) {
+	Grp<NW> G{ (int64_t *)(lds + CoopLds<NW>::OFF_XCH) };
+	const int tid = G.tid();
+	const uint64_t recEnd = (uint64_t)g.offsets[x + 1];
+	int err = 0;
+	// phase A (uniform): outdegree, reference, copy blocks (BVG:1048-1071)
+	BitReader br;
+	br.init(g.bits, g.nwords);
+	br.seek((uint64_t)g.offsets[x]);
+	(void)Fields<DEF>::outdegree(br, g);
+	if (g.W > 0) (void)Fields<DEF>::reference(br, g);
+	int64_t copied = 0;
+	if (hasRef) {
+		const uint64_t bc = Fields<DEF>::block_count(br, g);
+		int64_t total = 0;
+		if (bc > (uint64_t)dref + 1) err |= E_FORMAT;
+		else {
+			for (uint64_t b = 0; b < bc; b++) {
+				const int64_t len = (int64_t)Fields<DEF>::block(br, g) + (b ? 1 : 0);
+				total += len;
+				if (!(b & 1)) copied += len;
+			}
+			if (total > dref) err |= E_FORMAT;
+			if (!(bc & 1)) copied += dref - total;
+		}
+	}
+	const int64_t extra = (int64_t)d - copied;
+	if (extra < 0 || copied < 0) err |= E_FORMAT;
+	err |= br.err;
+	if (err) { if (tid == 0) atomicOr(errOut, err); return; }
+	if (extra == 0) return;
+	int64_t ic = 0, intervalArcs = 0;
+	uint64_t pos = br.pos();
+	if (g.minInt != 0) {
+		ic = (int64_t)br.gamma();
+		pos = br.pos();
+		if (br.err || ic > extra / g.minInt) { if (tid == 0) atomicOr(errOut, E_FORMAT | br.err); return; }
+		if (ic) {
+			// codes left in the record: 2 per interval + at most extra - ic*minInt residuals -> lower bound of the mean code length
+			const uint32_t B = coop_pick_B(recEnd > pos ? recEnd - pos : 0, (uint64_t)(2 * ic + (extra - ic * g.minInt)), CoopCfg<NW>::B_MAX);
+			coop_intervals<DEF, NW>(G, g, x, pos, recEnd, ic, B, list, lds, pos, intervalArcs, err);
+			if (G.any(err != 0)) { if (err) atomicOr(errOut, err); return; } // group-uniform exit
+		}
+	}
+	const int64_t nRes = extra - intervalArcs;
+	if (nRes < 0) { if (tid == 0) atomicOr(errOut, E_FORMAT); return; }
+	// default rank: the interval follows every residual (phase R fixes up the others)
+	for (int64_t i = tid; i < ic; i += Grp<NW>::N) list[i].rank = (int32_t)nRes;
+	G.sync_global();
+	coop_residuals<DEF, NW>(G, g, x, pos, recEnd, nRes, ic, intervalArcs, list, row + copied, lds, err);
+	if (err) atomicOr(errOut, err);
+}
+
+} // namespace bv

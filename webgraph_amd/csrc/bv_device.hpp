@@ -26,20 +26,41 @@ struct GraphDev {
 	int32_t n;
 	int32_t W, minInt, zetaK;
 	int32_t c_outd, c_ref, c_bc, c_blk, c_res;
+	unsigned long long *stats; // optional tuning counters (BVGPU_STATS=1), NULL otherwise
 };
 
-// Register-buffered MSB-first reader over global memory: 64-bit window, refilled 32 bits at a time.
-struct BitReader {
+// tuning counters: 0 tiles(residual) 1 rounds(residual) 2 tiles(interval) 3 rounds(interval) 4 lane-parses 5 big nodes 6 clock ticks in coop nodes 7 max ticks of one node
+__device__ __forceinline__ void stat_add(const GraphDev &g, int i, unsigned long long v) { if (g.stats && (threadIdx.x & 63) == 0) atomicAdd(&g.stats[i], v); }
+__device__ __forceinline__ void stat_max(const GraphDev &g, int i, unsigned long long v) { if (g.stats && (threadIdx.x & 63) == 0) atomicMax(&g.stats[i], v); }
+
+// Word sources of the bit reader.  Words are indexed from the start of the .graph image and returned with
+// the first stream bit in bit 31.
+struct GlobalSrc { // straight from HBM (cached in L1/L2)
 	const uint32_t *__restrict__ w;
 	uint64_t nwords;
+	__device__ __forceinline__ uint32_t ld(uint64_t i) const { return i < nwords ? __builtin_bswap32(w[i]) : 0u; }
+};
+struct WindowSrc { // a window of the stream staged in LDS (already byte-swapped); reads outside fall back to HBM
+	const uint32_t *win;
+	uint64_t w0;
+	uint32_t nw;
+	GlobalSrc g;
+	__device__ __forceinline__ uint32_t ld(uint64_t i) const { const uint64_t j = i - w0; return j < (uint64_t)nw ? win[j] : g.ld(i); }
+};
+
+// Register-buffered MSB-first reader: 64-bit window, refilled 32 bits at a time.
+template <class Src> struct BitReaderT {
+	Src src;
 	uint64_t widx;  // next word to load
 	uint64_t buf;   // valid bits are the top `nbits`; everything below is zero
 	uint32_t nbits;
 	int err;
+	uint64_t nwords; // words of the image (end-of-stream detection)
 
-	__device__ __forceinline__ uint32_t ld(uint64_t i) const { return i < nwords ? __builtin_bswap32(w[i]) : 0u; }
+	__device__ __forceinline__ uint32_t ld(uint64_t i) const { return src.ld(i); }
 
-	__device__ __forceinline__ void init(const uint32_t *words, uint64_t nw) { w = words; nwords = nw; err = 0; widx = 0; buf = 0; nbits = 0; }
+	__device__ __forceinline__ void init(const uint32_t *words, uint64_t nw) { src = Src{ words, nw }; nwords = nw; err = 0; widx = 0; buf = 0; nbits = 0; }
+	__device__ __forceinline__ void init_src(const Src &s_, uint64_t nw) { src = s_; nwords = nw; err = 0; widx = 0; buf = 0; nbits = 0; }
 
 	__device__ __forceinline__ void seek(uint64_t pos) {
 		widx = pos >> 5;
@@ -149,14 +170,17 @@ struct BitReader {
 // Fast.nat2int
 __device__ __forceinline__ int64_t nat2int(uint64_t v) { return (int64_t)(v >> 1) ^ -(int64_t)(v & 1); }
 
+using BitReader = BitReaderT<GlobalSrc>;
+using WinReader = BitReaderT<WindowSrc>;
+
 // Field readers.  DEF == true: the default coding set (gamma outdegrees / block counts / blocks, unary
 // references, zeta_3 residuals -- BVG:525-541 and DEFAULT_ZETA_K) is resolved at compile time.
 template <bool DEF> struct Fields {
-	static __device__ __forceinline__ uint64_t outdegree(BitReader &br, const GraphDev &g) { return DEF ? br.gamma() : br.coded(g.c_outd, 0); }
-	static __device__ __forceinline__ uint64_t reference(BitReader &br, const GraphDev &g) { return DEF ? br.unary() : br.coded(g.c_ref, 0); }
-	static __device__ __forceinline__ uint64_t block_count(BitReader &br, const GraphDev &g) { return DEF ? br.gamma() : br.coded(g.c_bc, 0); }
-	static __device__ __forceinline__ uint64_t block(BitReader &br, const GraphDev &g) { return DEF ? br.gamma() : br.coded(g.c_blk, 0); }
-	static __device__ __forceinline__ uint64_t residual(BitReader &br, const GraphDev &g) { return DEF ? br.zeta_k<3>(3) : br.coded(g.c_res, g.zetaK); }
+	template <class R> static __device__ __forceinline__ uint64_t outdegree(R &br, const GraphDev &g) { return DEF ? br.gamma() : br.coded(g.c_outd, 0); }
+	template <class R> static __device__ __forceinline__ uint64_t reference(R &br, const GraphDev &g) { return DEF ? br.unary() : br.coded(g.c_ref, 0); }
+	template <class R> static __device__ __forceinline__ uint64_t block_count(R &br, const GraphDev &g) { return DEF ? br.gamma() : br.coded(g.c_bc, 0); }
+	template <class R> static __device__ __forceinline__ uint64_t block(R &br, const GraphDev &g) { return DEF ? br.gamma() : br.coded(g.c_blk, 0); }
+	template <class R> static __device__ __forceinline__ uint64_t residual(R &br, const GraphDev &g) { return DEF ? br.template zeta_k<3>(3) : br.coded(g.c_res, g.zetaK); }
 };
 
 } // namespace bv

@@ -13,6 +13,7 @@
 // All arithmetic is integer; nothing here is MFMA-shaped.
 #include "bv_device.hpp"
 #include "bv_launch.hpp"
+#include "bv_coop.hpp"
 
 namespace bv {
 
@@ -147,7 +148,8 @@ __global__ void __launch_bounds__(TPB) k_depth(int32_t cnt, const uint16_t *__re
 	int32_t m = dd;
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
-	if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(maxdepth, m);
+	// one atomic per wave at most, and none once the maximum is known (a stale read only costs an atomic)
+	if ((threadIdx.x & 63) == 0 && m > 0 && m > __builtin_nontemporal_load(maxdepth)) atomicMax(maxdepth, m);
 }
 
 __global__ void k_rebase(int32_t nh, int32_t cnt, const int64_t *__restrict__ rowstart, int64_t *__restrict__ out) {
@@ -241,10 +243,58 @@ __global__ void __launch_bounds__(TPB) k_parse(GraphDev g, RangeView v, int *__r
 	const int32_t s = blockIdx.x * TPB + threadIdx.x;
 	if (s >= v.cnt) return;
 	const int32_t d = v.outd[s];
-	if (d == 0) return;
+	if (d == 0 || d >= v.coop_min) return; // long records are decoded by whole waves (k_parse_big)
 	const int32_t r = v.ref[s];
 	if (s >= v.nh && (uint64_t)(v.rowstart[s + 1] - v.rowstart[v.nh]) > v.succ_cap) { atomicOr(err, E_CAP); return; }
 	parse_node<DEF>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), err);
+}
+
+// ------------------------------------------------------------------------------------------------ long records
+// ctl[0] = #big, ctl[1] = #giant, ctl[2] / ctl[3] = heads of the two work queues
+__global__ void __launch_bounds__(TPB) k_classify(int32_t cnt, const int32_t *__restrict__ outd, int32_t coopMin, int32_t giantMin,
+                                                  int32_t *__restrict__ biglist, int32_t *__restrict__ giantlist, int32_t giantCap, int32_t *__restrict__ ctl) {
+	// block-aggregated append: one atomic per block and list instead of one per long record
+	__shared__ int32_t s_cnt[2], s_base[2];
+	const int32_t s = blockIdx.x * TPB + threadIdx.x;
+	if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+	__syncthreads();
+	const int32_t d = s < cnt ? outd[s] : 0;
+	const int kind = d >= giantMin ? 1 : d >= coopMin ? 0 : -1;
+	int32_t local = 0;
+	if (kind >= 0) local = atomicAdd(&s_cnt[kind], 1);
+	__syncthreads();
+	if (threadIdx.x < 2 && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&ctl[threadIdx.x], s_cnt[threadIdx.x]);
+	__syncthreads();
+	if (kind == 1) { const int32_t k = s_base[1] + local; if (k < giantCap) giantlist[k] = s; } // giantCap >= arcs / giantMin: always fits
+	else if (kind == 0) biglist[s_base[0] + local] = s;
+}
+
+// One group of NW waves per long record, pulled from a device-side queue.  NW = 1 serves the "big" list,
+// NW = 16 the "giant" list (records so long that a single wave would be the tail of the whole scan).
+template <bool DEF, int NW>
+__global__ void __launch_bounds__(64 * NW) k_parse_big(GraphDev g, RangeView v, const int32_t *__restrict__ list, int32_t *__restrict__ ctl, int which,
+                                                       IvEntry *__restrict__ arena, int64_t arenaCap, int *__restrict__ err) {
+	__shared__ __attribute__((aligned(16))) uint32_t lds[CoopLds<NW>::WORDS];
+	__shared__ int32_t s_idx;
+	const int32_t count = ctl[which]; // (the giant list is sized for arcs / giantMin entries, which bounds their number)
+	for (;;) {
+		if (threadIdx.x == 0) s_idx = atomicAdd(&ctl[2 + which], 1);
+		__syncthreads();
+		const int32_t idx = s_idx;
+		__syncthreads();
+		if (idx >= count) break;
+		const int32_t s = list[idx];
+		const int32_t d = v.outd[s];
+		const int32_t r = v.ref[s];
+		if (s >= v.nh && (uint64_t)(v.rowstart[s + 1] - v.rowstart[v.nh]) > v.succ_cap) { if (threadIdx.x == 0) atomicOr(err, E_CAP); continue; }
+		// arena slice of this node: interval counts are bounded by d / minIntervalLength, and
+		// floor(a/k) + floor(b/k) <= floor((a+b)/k) keeps the slices of different nodes disjoint
+		const int64_t abase = g.minInt > 0 ? v.rowstart[s] / g.minInt : 0;
+		if (g.minInt > 0 && abase + d / g.minInt + 1 > arenaCap) { if (threadIdx.x == 0) atomicOr(err, E_FORMAT); continue; }
+		const unsigned long long t0 = g.stats ? __builtin_readcyclecounter() : 0;
+		coop_parse_node<DEF, NW>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), arena + abase, lds, err);
+		if (g.stats) { const unsigned long long dt = __builtin_readcyclecounter() - t0; stat_add(g, 5, 1); stat_add(g, 6, dt); stat_max(g, 7, dt); }
+	}
 }
 
 // ------------------------------------------------------------------------------------------------ copy
@@ -517,6 +567,21 @@ void launch_bcopy(const GraphDev &g, bool def, const BatchView &v, int32_t level
 	if (v.cnt <= 0) return;
 	if (def) hipLaunchKernelGGL(k_bcopy<true>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, level, err);
 	else hipLaunchKernelGGL(k_bcopy<false>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, level, err);
+}
+
+void launch_classify(int32_t cnt, const int32_t *outd, int32_t coopMin, int32_t giantMin, int32_t *biglist, int32_t *giantlist, int32_t giantCap, int32_t *ctl, hipStream_t st) {
+	if (cnt <= 0) return;
+	hipLaunchKernelGGL(k_classify, dim3(nblk(cnt, TPB)), dim3(TPB), 0, st, cnt, outd, coopMin, giantMin, biglist, giantlist, giantCap, ctl);
+}
+
+void launch_parse_big(const GraphDev &g, bool def, const RangeView &v, const int32_t *biglist, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap,
+                      int waves, int giantGroups, int *err, hipStream_t st) {
+	if (v.cnt <= 0) return;
+	// giants first: they are the long poles
+	if (def) hipLaunchKernelGGL((k_parse_big<true, 16>), dim3(giantGroups), dim3(1024), 0, st, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+	else hipLaunchKernelGGL((k_parse_big<false, 16>), dim3(giantGroups), dim3(1024), 0, st, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+	if (def) hipLaunchKernelGGL((k_parse_big<true, 1>), dim3(waves), dim3(64), 0, st, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
+	else hipLaunchKernelGGL((k_parse_big<false, 1>), dim3(waves), dim3(64), 0, st, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
 }
 
 } // namespace bv

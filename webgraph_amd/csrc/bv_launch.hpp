@@ -14,6 +14,7 @@ struct RangeView {
 	int32_t *succ;          // caller rows
 	int32_t *halo;          // halo rows
 	uint64_t succ_cap;      // capacity of succ in elements
+	int32_t coop_min;       // records with outdegree >= coop_min are decoded by whole waves (k_parse_big)
 	__device__ __forceinline__ int32_t *row(int32_t s) const {
 		const int64_t o = rowstart[s];
 		return s < nh ? halo + o : succ + (o - rowstart[nh]);
@@ -45,6 +46,10 @@ void launch_chain_fill(const GraphDev &g, bool def, const int32_t *nodes, int64_
                        int32_t *sdepth, int32_t *sq, int32_t *aoutd, int32_t *qoutd, hipStream_t st);
 void launch_bparse(const GraphDev &g, bool def, const BatchView &v, int *err, hipStream_t st);
 void launch_bcopy(const GraphDev &g, bool def, const BatchView &v, int32_t level, int *err, hipStream_t st);
+void launch_classify(int32_t cnt, const int32_t *outd, int32_t coopMin, int32_t giantMin, int32_t *biglist, int32_t *giantlist, int32_t giantCap, int32_t *ctl, hipStream_t st);
+void launch_parse_big(const GraphDev &g, bool def, const RangeView &v, const int32_t *biglist, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap,
+                      int waves, int giantGroups, int *err, hipStream_t st);
+constexpr int ARENA_ENTRY_BYTES = 16;
 void launch_hash(int32_t from, int32_t cnt, const int64_t *rowptr, const int32_t *succ, uint32_t *A, uint32_t *B, int32_t *hash, hipStream_t st);
 
 } // namespace bv

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -75,6 +76,10 @@ struct bvg_graph {
 	mutable std::string err;
 	DevBuf outd, ref, rowstart, depth, sums, need, halo, hashA, hashB, stage_rowptr, stage_succ, stage_nodes, small;
 	DevBuf b_chainlen, b_slotbase, b_node, b_qidx, b_aoutd, b_qoutd; // random-access batches
+	DevBuf biglist, giantlist, arena, coopctl;                        // wave-cooperative decode of long records
+	int32_t coop_min = 64, giant_min = 8192;                          // thresholds on the outdegree (BVGPU_COOP_MIN / BVGPU_GIANT_MIN)
+	int coop_waves = 4096, giant_groups = 256;
+	DevBuf stats; // BVGPU_STATS=1: tuning counters
 	Small *h_small = nullptr; // pinned
 	int32_t levels_hint = 1;
 	Pending pend;
@@ -87,6 +92,9 @@ struct bvg_graph {
 
 namespace {
 
+bv::GraphDev graph_dev0(const Staged &s);
+bv::GraphDev graph_dev_h(const bvg_graph *g, const Staged &s) { bv::GraphDev d = graph_dev0(s); d.stats = (unsigned long long *)g->stats.p; return d; }
+
 int fail(const bvg_graph *g, int code, const std::string &msg) { if (g) g->err = msg; return code; }
 
 #define HIPCHK(g, call)                                                                                     \
@@ -95,14 +103,17 @@ int fail(const bvg_graph *g, int code, const std::string &msg) { if (g) g->err =
 		if (e_ != hipSuccess) return fail(g, e_ == hipErrorOutOfMemory ? BVG_ENOMEM : BVG_EHIP, std::string(#call ": ") + hipGetErrorString(e_)); \
 	} while (0)
 
-bv::GraphDev graph_dev(const Staged &s) {
+bv::GraphDev graph_dev0(const Staged &s) {
 	bv::GraphDev g{};
 	g.bits = s.d_bits; g.nwords = s.nwords; g.offsets = s.d_offsets; g.n = s.info.nodes;
 	g.W = s.info.window_size; g.minInt = s.info.min_interval_length; g.zetaK = s.info.zeta_k;
 	g.c_outd = s.info.outdegree_coding; g.c_ref = s.info.reference_coding; g.c_bc = s.info.block_count_coding;
 	g.c_blk = s.info.block_coding; g.c_res = s.info.residual_coding;
+	g.stats = nullptr;
 	return g;
 }
+
+#define graph_dev(S) graph_dev_h(g, S)
 
 int dev_err_to_status(int e) {
 	if (e & bv::E_REF) return BVG_ESTATE;
@@ -121,6 +132,12 @@ int init_handle(bvg_graph *g) {
 	if (!g->small.need(sizeof(Small))) return fail(g, BVG_ENOMEM, "device allocation failed");
 	const int mr = g->st->info.max_ref_count;
 	g->levels_hint = mr < 1 ? 1 : (mr > 8 ? 8 : mr);
+	if (const char *e = getenv("BVGPU_COOP_MIN")) g->coop_min = std::max(1, atoi(e));   // 0x7fffffff disables the cooperative path
+	if (const char *e = getenv("BVGPU_GIANT_MIN")) g->giant_min = std::max(g->coop_min, atoi(e));
+	if (const char *e = getenv("BVGPU_COOP_WAVES")) g->coop_waves = std::max(1, atoi(e));
+	if (const char *e = getenv("BVGPU_GIANT_GROUPS")) g->giant_groups = std::max(1, atoi(e));
+	if (!g->coopctl.need(4 * sizeof(int32_t))) return fail(g, BVG_ENOMEM, "device allocation failed");
+	if (const char *e = getenv("BVGPU_STATS")) if (atoi(e)) { if (!g->stats.need(16 * sizeof(unsigned long long))) return fail(g, BVG_ENOMEM, "device allocation failed"); HIPCHK(g, hipMemset(g->stats.p, 0, 128)); }
 	return BVG_OK;
 }
 
@@ -235,6 +252,20 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 		if (!g->depth.need(sizeof(int32_t) * (size_t)v.cnt)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
 		if (W > 0) bv::launch_depth(v.cnt, v.ref, g->depth.as<int32_t>(), &g->small.as<Small>()->maxdepth, g->stream);
 		mark(g, 3);
+		const bool coop = g->coop_min < 0x7fffffff;
+		v.coop_min = coop ? g->coop_min : 0x7fffffff;
+		if (coop) {
+			// long records: queue them (giants first) and give each a whole wave
+			const int64_t arcsBound = std::max<int64_t>(s.info.arcs, 1);
+			const int32_t giantCap = (int32_t)std::min<int64_t>(arcsBound / g->giant_min + 2, 0x7fffffff);
+			const int64_t arenaCap = s.info.min_interval_length > 0 ? arcsBound / s.info.min_interval_length + 2 : 1;
+			if (!g->biglist.need(sizeof(int32_t) * (size_t)v.cnt) || !g->giantlist.need(sizeof(int32_t) * (size_t)giantCap) ||
+			    !g->arena.need((size_t)bv::ARENA_ENTRY_BYTES * (size_t)arenaCap))
+				return fail(g, BVG_ENOMEM, "device scratch allocation failed");
+			HIPCHK(g, hipMemsetAsync(g->coopctl.p, 0, 4 * sizeof(int32_t), g->stream));
+			bv::launch_classify(v.cnt, v.outd, g->coop_min, g->giant_min, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, g->coopctl.as<int32_t>(), g->stream);
+			bv::launch_parse_big(gd, s.def, v, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), g->coopctl.as<int32_t>(), g->arena.p, arenaCap, g->coop_waves, g->giant_groups, derr, g->stream);
+		}
 		bv::launch_parse(gd, s.def, v, derr, g->stream);
 		mark(g, 4);
 		if (W > 0) {
@@ -333,7 +364,7 @@ extern "C" int bvg_close(bvg_t *g) {
 	if (g->st && g->st->device >= 0) {
 		(void)hipSetDevice(g->st->device);
 		if (g->own) { (void)hipStreamSynchronize(g->own); (void)hipStreamDestroy(g->own); }
-		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd }) b->release();
+		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats }) b->release();
 		if (g->h_small) (void)hipHostFree(g->h_small);
 		for (auto &e : g->ev) if (e) (void)hipEventDestroy(e);
 	}
@@ -371,6 +402,16 @@ extern "C" int bvg_get_profile(bvg_t *g, float *ms) {
 	if (g->pend.active) { int rc = finish_pending(g, nullptr); if (rc) return rc; }
 	HIPCHK(g, hipEventSynchronize(g->ev[BVG_NUM_PHASES]));
 	for (int i = 0; i < BVG_NUM_PHASES; i++) HIPCHK(g, hipEventElapsedTime(&ms[i], g->ev[i], g->ev[i + 1]));
+	return BVG_OK;
+}
+
+extern "C" int bvg_debug_stats(bvg_t *g, uint64_t *out8, int reset) {
+	if (!g || !g->st || !out8) return BVG_EARG;
+	if (!g->stats.p) return fail(g, BVG_ESTATE, "set BVGPU_STATS=1 before opening the graph");
+	HIPCHK(g, hipSetDevice(g->st->device));
+	HIPCHK(g, hipDeviceSynchronize());
+	HIPCHK(g, hipMemcpy(out8, g->stats.p, 128, hipMemcpyDeviceToHost));
+	if (reset) HIPCHK(g, hipMemset(g->stats.p, 0, 128));
 	return BVG_OK;
 }
 
