@@ -99,7 +99,7 @@ int bvg_set_profile(bvg_t *g, int enable);
 /* Milliseconds of each phase of the last range decode issued with profiling on; ms has BVG_NUM_PHASES floats. */
 int bvg_get_profile(bvg_t *g, float *ms);
 
-/* Tuning counters of the cooperative decoder (only when BVGPU_STATS=1 was set at bvg_open): 16 uint64, see bv_device.hpp. */
+/* Tuning counters of the cooperative decoder (only when BVGPU_STATS=1 was set at bvg_open): 32 uint64, see bv_device.hpp. */
 int bvg_debug_stats(bvg_t *g, uint64_t *out16, int reset);
 
 /* ---- the hot path ---------------------------------------------------------------------------------- */

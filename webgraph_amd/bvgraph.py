@@ -323,7 +323,7 @@ class BVGraph:
         return dict(zip(self.PHASES, [float(x) for x in ms]))
 
     def debug_stats(self, reset=True):
-        out = np.zeros(16, dtype=np.uint64)
+        out = np.zeros(32, dtype=np.uint64)
         self._check(lib().bvg_debug_stats(self._h, out.ctypes.data, 1 if reset else 0))
         return out
 

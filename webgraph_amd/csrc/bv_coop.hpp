@@ -30,10 +30,10 @@ constexpr int COOP_B_MIN = 64, COOP_CODES_PER_SEG = 12;
 
 template <int NW> struct CoopCfg;
 template <> struct CoopCfg<1> { static constexpr int N = 64, B_MAX = 512, CAPT = 1024; };
-template <> struct CoopCfg<16> { static constexpr int N = 1024, B_MAX = 128, CAPT = 8192; };
+template <> struct CoopCfg<8> { static constexpr int N = 512, B_MAX = 128, CAPT = 4096; };
 
 template <int NW> struct CoopLds { // LDS layout of one group, in 32-bit words
-	static constexpr int WIN_WORDS = CoopCfg<NW>::N * CoopCfg<NW>::B_MAX / 32 + 8; // staged tile bits (+ look-ahead slack)
+	static constexpr int WIN_WORDS = CoopCfg<NW>::N * CoopCfg<NW>::B_MAX / 32 + 12; // staged tile bits (+ alignment and look-ahead slack), multiple of 4
 	static constexpr int XCH_WORDS = 2 * (NW + 8);                                   // int64 exchange slots
 	static constexpr int OFF_WIN = 0, OFF_RESV = WIN_WORDS, OFF_DELTA = OFF_RESV + CoopCfg<NW>::CAPT, OFF_XCH = ((OFF_DELTA + CoopCfg<NW>::CAPT + 1) & ~1);
 	static constexpr int WORDS = OFF_XCH + XCH_WORDS;
@@ -138,15 +138,30 @@ __device__ __forceinline__ uint32_t coop_pick_B(uint64_t sectionBits, uint64_t c
 	return (uint32_t)(b < COOP_B_MIN ? COOP_B_MIN : b > bmax ? bmax : b);
 }
 
-// Stages the words of the tile [pos0, pos0 + N*B) (+ slack) into LDS, byte-swapped, with coalesced loads.
+// Stages the words of the tile [pos0, pos0 + N*B) (+ slack) into LDS, byte-swapped.  All the 16-byte loads of
+// a lane are issued before the first LDS write, so the tile costs one HBM round trip, not one per iteration.
 template <int NW>
 __device__ __forceinline__ WindowSrc stage_tile(const Grp<NW> &G, const GraphDev &g, uint32_t *win, uint64_t pos0, uint32_t B) {
-	const uint64_t w0 = pos0 >> 5;
-	const uint32_t nw = (uint32_t)(Grp<NW>::N * (B >> 5)) + 8;
+	constexpr int N = Grp<NW>::N;
+	constexpr int MAXIT = (CoopLds<NW>::WIN_WORDS / 4 + N - 1) / N; // uint4 loads per lane for the widest tile
+	const uint64_t w0 = (pos0 >> 5) & ~(uint64_t)3;                // 16-byte aligned window start
+	const uint32_t nw4 = (uint32_t)(N * (B >> 5) + 8 + 3) / 4;     // uint4s to stage (<= WIN_WORDS / 4)
+	const uint4 *src4 = (const uint4 *)(g.bits + w0);
+	const uint64_t lim4 = (g.nwords + 8 - w0) / 4;                 // the image is followed by >= 8 zero words
+	uint4 v[MAXIT];
+#pragma unroll
+	for (int k = 0; k < MAXIT; k++) {
+		const uint32_t i = (uint32_t)G.tid() + (uint32_t)k * N;
+		v[k] = (i < nw4 && i < lim4) ? src4[i] : uint4{ 0u, 0u, 0u, 0u };
+	}
 	G.sync(); // the previous tile's readers are done
-	for (uint32_t i = G.tid(); i < nw; i += Grp<NW>::N) { const uint64_t w = w0 + i; win[i] = w < g.nwords ? __builtin_bswap32(g.bits[w]) : 0u; }
+#pragma unroll
+	for (int k = 0; k < MAXIT; k++) {
+		const uint32_t i = (uint32_t)G.tid() + (uint32_t)k * N;
+		if (i < nw4) ((uint4 *)win)[i] = uint4{ __builtin_bswap32(v[k].x), __builtin_bswap32(v[k].y), __builtin_bswap32(v[k].z), __builtin_bswap32(v[k].w) };
+	}
 	G.sync();
-	return WindowSrc{ win, w0, nw, GlobalSrc{ g.bits, g.nwords } };
+	return WindowSrc{ win, w0, nw4 * 4, GlobalSrc{ g.bits, g.nwords } };
 }
 
 // One speculative parse of the codes starting in [s, segEnd): end position, count and the sum of the decoded
@@ -292,10 +307,15 @@ __device__ __forceinline__ void coop_residuals(const Grp<NW> &G, const GraphDev 
 	int64_t elemsBefore = 0;   // arcs of the intervals [0, ia)
 	bool firstTile = true;
 	const uint32_t B = coop_pick_B(recEnd > pos ? recEnd - pos : 0, (uint64_t)nRes, CoopCfg<NW>::B_MAX); // the residual section ends with the record
+	unsigned long long tk = g.stats ? __builtin_readcyclecounter() : 0;
+#define RT(slot) do { if (g.stats && NW == 1) { const unsigned long long now_ = __builtin_readcyclecounter(); if (tid == 0) atomicAdd(&g.stats[24 + slot], now_ - tk); tk = now_; } } while (0)
 	while (resDone < nRes) {
+		RT(7);
 		const WindowSrc src = stage_tile<NW>(G, g, win, pos, B);
+		RT(0);
 		uint64_t s, E; uint32_t c; int64_t sum;
 		spec_tile<DEF, 0, NW>(G, g, src, pos, recEnd, B, firstTile, nRes - resDone, s, c, sum, E);
+		RT(1);
 		// take at most CAPT residuals, and no more than the section still has
 		int64_t tileTotal;
 		const int64_t cincl = G.incl_scan((int64_t)c, tileTotal);
@@ -326,6 +346,7 @@ __device__ __forceinline__ void coop_residuals(const Grp<NW> &G, const GraphDev 
 		const int64_t lastVal = G.bcast(val, lastTid);
 		const uint64_t nextPos = anyCut ? (uint64_t)G.bcast((int64_t)myEnd, lastTid) : E;
 		G.sync();
+		RT(2);
 
 		if (ic > 0) {
 			// Rank the intervals whose left extreme precedes this tile's last residual: interval i sits after
@@ -349,6 +370,7 @@ __device__ __forceinline__ void coop_residuals(const Grp<NW> &G, const GraphDev 
 			}
 			const int64_t pNow = ia < ic ? (int64_t)list[ia].pstart : intervalArcs;
 			G.sync();
+			RT(3);
 			// residual t of the tile goes after the arcs of earlier tiles' intervals and after those of this
 			// tile's intervals ranked <= t  (inclusive scan of delta)
 			int64_t carry = 0;
@@ -364,6 +386,7 @@ __device__ __forceinline__ void coop_residuals(const Grp<NW> &G, const GraphDev 
 		} else {
 			for (int64_t t = tid; t < T; t += N) out[resDone + t] = resv[t];
 		}
+		RT(4);
 		resDone += T;
 		baseVal = lastVal;
 		pos = nextPos;
@@ -371,6 +394,7 @@ __device__ __forceinline__ void coop_residuals(const Grp<NW> &G, const GraphDev 
 	}
 	if (ic == 0) return;
 	G.sync_global(); // ranks written above are read by other lanes below
+	RT(5);
 	// phase X: interval i occupies out[pstart + rank .. + len)  (IntIntervalSequenceIterator.java:64-78)
 	for (int64_t i0 = 0; i0 < ic; i0 += N) {
 		const int64_t i = i0 + tid;
@@ -387,6 +411,8 @@ __device__ __forceinline__ void coop_residuals(const Grp<NW> &G, const GraphDev 
 			for (int32_t t = G.lane(); t < Nn; t += 64) out[P + t] = L + t;
 		}
 	}
+	RT(6);
+#undef RT
 }
 
 // The whole record of node x by one group.  Same contract as parse_node: extras merged into row[copied..d).
@@ -397,6 +423,9 @@ __device__ __forceinline__ void coop_parse_node(const GraphDev &g, int32_t x, in
 	const int tid = G.tid();
 	const uint64_t recEnd = (uint64_t)g.offsets[x + 1];
 	int err = 0;
+	const int sb = NW == 1 ? 16 : 20; // stats slots: ticks of phase A, I, R, X
+	unsigned long long tk = g.stats ? __builtin_readcyclecounter() : 0;
+#define COOP_TICK(slot) do { if (g.stats) { const unsigned long long now_ = __builtin_readcyclecounter(); if (tid == 0) atomicAdd(&g.stats[sb + slot], now_ - tk); tk = now_; } } while (0)
 	// phase A (uniform): outdegree, reference, copy blocks (BVG:1048-1071)
 	BitReader br;
 	br.init(g.bits, g.nwords);
@@ -422,6 +451,7 @@ __device__ __forceinline__ void coop_parse_node(const GraphDev &g, int32_t x, in
 	if (extra < 0 || copied < 0) err |= E_FORMAT;
 	err |= br.err;
 	if (err) { if (tid == 0) atomicOr(errOut, err); return; }
+	COOP_TICK(0);
 	if (extra == 0) return;
 	int64_t ic = 0, intervalArcs = 0;
 	uint64_t pos = br.pos();
@@ -438,10 +468,13 @@ __device__ __forceinline__ void coop_parse_node(const GraphDev &g, int32_t x, in
 	}
 	const int64_t nRes = extra - intervalArcs;
 	if (nRes < 0) { if (tid == 0) atomicOr(errOut, E_FORMAT); return; }
+	COOP_TICK(1);
 	// default rank: the interval follows every residual (phase R fixes up the others)
 	for (int64_t i = tid; i < ic; i += Grp<NW>::N) list[i].rank = (int32_t)nRes;
 	G.sync_global();
 	coop_residuals<DEF, NW>(G, g, x, pos, recEnd, nRes, ic, intervalArcs, list, row + copied, lds, err);
+	COOP_TICK(2);
+#undef COOP_TICK
 	if (err) atomicOr(errOut, err);
 }
 

@@ -35,16 +35,50 @@ __device__ __forceinline__ void stat_max(const GraphDev &g, int i, unsigned long
 
 // Word sources of the bit reader.  Words are indexed from the start of the .graph image and returned with
 // the first stream bit in bit 31.
-struct GlobalSrc { // straight from HBM (cached in L1/L2)
+struct GlobalSrc { // straight from HBM (cached in L1/L2), one word at a time
 	const uint32_t *__restrict__ w;
 	uint64_t nwords;
+	__device__ __forceinline__ void start(uint64_t) {}
 	__device__ __forceinline__ uint32_t ld(uint64_t i) const { return i < nwords ? __builtin_bswap32(w[i]) : 0u; }
+};
+// Sequential reader over HBM with 16-byte loads and one vector always in flight: the words of the current
+// vector are handed out from registers while the next vector is already on its way, so a lane streaming
+// through a long record waits for memory once per 128 bits instead of once per 32, and mostly not at all.
+// ld(i) must be called with consecutive i after start(i) -- exactly what BitReaderT does.
+struct PrefetchSrc {
+	const uint32_t *__restrict__ w; // image; the allocation is padded to a multiple of 16 bytes plus >= 8 zero words
+	uint64_t nwords;
+	uint64_t vnext;                 // next 16-byte vector to request
+	uint4 pend;                     // the vector in flight
+	uint32_t q0, q1, q2, q3;        // words of the current vector still to hand out
+	int qn;
+	__device__ __forceinline__ uint4 ld4(uint64_t vi) const {
+		return vi * 4 < nwords + 4 ? ((const uint4 *)w)[vi] : uint4{ 0u, 0u, 0u, 0u };
+	}
+	__device__ __forceinline__ void take() {
+		q0 = __builtin_bswap32(pend.x); q1 = __builtin_bswap32(pend.y); q2 = __builtin_bswap32(pend.z); q3 = __builtin_bswap32(pend.w);
+		qn = 4;
+		pend = ld4(vnext++);
+	}
+	__device__ __forceinline__ void start(uint64_t i) {
+		vnext = i >> 2;
+		pend = ld4(vnext++);
+		take();
+		for (uint32_t t = 0; t < (uint32_t)(i & 3); t++) { q0 = q1; q1 = q2; q2 = q3; qn--; }
+	}
+	__device__ __forceinline__ uint32_t ld(uint64_t) {
+		if (qn == 0) take();
+		const uint32_t r = q0;
+		q0 = q1; q1 = q2; q2 = q3; qn--;
+		return r;
+	}
 };
 struct WindowSrc { // a window of the stream staged in LDS (already byte-swapped); reads outside fall back to HBM
 	const uint32_t *win;
 	uint64_t w0;
 	uint32_t nw;
 	GlobalSrc g;
+	__device__ __forceinline__ void start(uint64_t) {}
 	__device__ __forceinline__ uint32_t ld(uint64_t i) const { const uint64_t j = i - w0; return j < (uint64_t)nw ? win[j] : g.ld(i); }
 };
 
@@ -57,15 +91,17 @@ template <class Src> struct BitReaderT {
 	int err;
 	uint64_t nwords; // words of the image (end-of-stream detection)
 
-	__device__ __forceinline__ uint32_t ld(uint64_t i) const { return src.ld(i); }
+	__device__ __forceinline__ uint32_t ld(uint64_t i) { return src.ld(i); }
 
 	__device__ __forceinline__ void init(const uint32_t *words, uint64_t nw) { src = Src{ words, nw }; nwords = nw; err = 0; widx = 0; buf = 0; nbits = 0; }
 	__device__ __forceinline__ void init_src(const Src &s_, uint64_t nw) { src = s_; nwords = nw; err = 0; widx = 0; buf = 0; nbits = 0; }
 
 	__device__ __forceinline__ void seek(uint64_t pos) {
 		widx = pos >> 5;
+		src.start(widx);
 		const uint32_t s = (uint32_t)pos & 31u;
-		const uint64_t hi = ld(widx), lo = ld(widx + 1);
+		const uint64_t hi = ld(widx);
+		const uint64_t lo = ld(widx + 1);
 		widx += 2;
 		buf = ((hi << 32) | lo) << s;
 		nbits = 64u - s;
@@ -172,6 +208,7 @@ __device__ __forceinline__ int64_t nat2int(uint64_t v) { return (int64_t)(v >> 1
 
 using BitReader = BitReaderT<GlobalSrc>;
 using WinReader = BitReaderT<WindowSrc>;
+using PReader = BitReaderT<PrefetchSrc>;
 
 // Field readers.  DEF == true: the default coding set (gamma outdegrees / block counts / blocks, unary
 // references, zeta_3 residuals -- BVG:525-541 and DEFAULT_ZETA_K) is resolved at compile time.

@@ -14,10 +14,14 @@
 #include "bv_device.hpp"
 #include "bv_launch.hpp"
 #include "bv_coop.hpp"
+#include "bv_lane.hpp"
+
+#include <algorithm>
 
 namespace bv {
 
 constexpr int TPB = 256;
+constexpr int GIANT_NW = 8; // waves per giant record
 
 // ------------------------------------------------------------------------------------------------ headers
 template <bool DEF>
@@ -249,6 +253,137 @@ __global__ void __launch_bounds__(TPB) k_parse(GraphDev g, RangeView v, int *__r
 	parse_node<DEF>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), err);
 }
 
+// ------------------------------------------------------------------------------------------------ work lists
+// Records are decoded one reference-chain level at a time, and inside a level in order of their length in bits
+// (known from the offsets, no decoding needed), so that the 64 lanes of a wave get similar amounts of work.
+//   key(s) = level * NBIN + bin,  bin = clamp(floor(log2(bits)) - 5, 0, NBIN-1);  giants go to their own list.
+// Chain levels >= MAXLVL-1 share the last level's buckets and are swept once per level (rare: deep chains).
+__device__ __forceinline__ int32_t record_bin(uint64_t bitsLen) {
+	const int lg = 63 - __clzll((long long)(bitsLen | 1));
+	return lg < 6 ? 0 : lg - 5 >= NBIN ? NBIN - 1 : lg - 5;
+}
+
+constexpr int LIST_ITEMS = 16, LIST_TILE = TPB * LIST_ITEMS; // slots per block: few blocks -> few same-address atomics (~88 M/s each)
+
+__global__ void __launch_bounds__(TPB) k_depth_keys(GraphDev g, int32_t lo, int32_t cnt, const int32_t *__restrict__ outd, const uint16_t *__restrict__ ref,
+                                                    uint64_t giantBits, int32_t noBin, int32_t *__restrict__ depth, uint16_t *__restrict__ key16,
+                                                    int32_t *__restrict__ hist, int32_t *__restrict__ ctl, int32_t *__restrict__ maxdepth) {
+	__shared__ int32_t s_hist[NKEYS + 1];
+	for (int k = threadIdx.x; k <= NKEYS; k += TPB) s_hist[k] = 0;
+	__syncthreads();
+	for (int it = 0; it < LIST_ITEMS; it++) {
+		const int32_t s = blockIdx.x * LIST_TILE + it * TPB + threadIdx.x;
+		if (s >= cnt) break;
+		int32_t dd = 0;
+		int32_t y = s;
+		for (;;) { const int32_t r = ref[y]; if (r == 0) break; y -= r; dd++; } // ref[] is 0 for empty / unneeded nodes
+		depth[s] = dd;
+		uint16_t key = KEY_NONE;
+		if (outd[s] > 0) {
+			// work of a record ~ codes to parse + successors to emit: a short record can still expand to a huge
+			// list through intervals and copy blocks, so weigh the outdegree in (8 bits per successor)
+			const uint64_t bitsLen = (uint64_t)(g.offsets[lo + s + 1] - g.offsets[lo + s]);
+			const uint64_t work = max(bitsLen, (uint64_t)outd[s] * 8);
+			if (work >= giantBits) key = KEY_GIANT;
+			else key = (uint16_t)(min(dd, MAXLVL - 1) * NBIN + (noBin ? 0 : record_bin(work)));
+			atomicAdd(&s_hist[key == KEY_GIANT ? NKEYS : key], 1);
+			if (dd >= MAXLVL - 1 && dd > __builtin_nontemporal_load(maxdepth)) atomicMax(maxdepth, dd); // only very deep chains get here
+		}
+		key16[s] = key;
+	}
+	__syncthreads();
+	for (int k = threadIdx.x; k <= NKEYS; k += TPB) { const int32_t c = s_hist[k]; if (c) atomicAdd(k == NKEYS ? &ctl[1] : &hist[k], c); }
+}
+
+// single block: keyBase = exclusive scan of hist; cursor = keyBase; deepest level present -> maxdepth
+__global__ void __launch_bounds__(TPB) k_key_offsets(const int32_t *__restrict__ hist, int32_t *__restrict__ keyBase, int32_t *__restrict__ cursor, int32_t *__restrict__ maxdepth) {
+	__shared__ int32_t s_top;
+	if (threadIdx.x == 0) s_top = 0;
+	__syncthreads();
+	int64_t carry = 0;
+	for (int base = 0; base < NKEYS; base += TPB) {
+		const int k = base + threadIdx.x;
+		const int64_t v = k < NKEYS ? hist[k] : 0;
+		int64_t tot;
+		const int64_t ex = block_excl_scan(v, &tot);
+		if (k < NKEYS) { keyBase[k] = (int32_t)(carry + ex); cursor[k] = (int32_t)(carry + ex); if (v) atomicMax(&s_top, k / NBIN); }
+		carry += tot;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) { keyBase[NKEYS] = (int32_t)carry; atomicMax(maxdepth, s_top); }
+}
+
+__global__ void __launch_bounds__(TPB) k_scatter_keys(int32_t cnt, const uint16_t *__restrict__ key16, int32_t *__restrict__ cursor, int32_t *__restrict__ list,
+                                                      int32_t *__restrict__ giantlist, int32_t giantCap, int32_t *__restrict__ ctl) {
+	__shared__ int32_t s_cnt[NKEYS + 1], s_base[NKEYS + 1];
+	for (int k = threadIdx.x; k <= NKEYS; k += TPB) s_cnt[k] = 0;
+	__syncthreads();
+	uint16_t keys[LIST_ITEMS];
+	int32_t local[LIST_ITEMS];
+#pragma unroll
+	for (int it = 0; it < LIST_ITEMS; it++) {
+		const int32_t s = blockIdx.x * LIST_TILE + it * TPB + threadIdx.x;
+		keys[it] = s < cnt ? key16[s] : KEY_NONE;
+		local[it] = keys[it] != KEY_NONE ? atomicAdd(&s_cnt[keys[it] == KEY_GIANT ? NKEYS : keys[it]], 1) : 0;
+	}
+	__syncthreads();
+	for (int k = threadIdx.x; k <= NKEYS; k += TPB) { const int32_t c = s_cnt[k]; if (c) s_base[k] = atomicAdd(k == NKEYS ? &ctl[4] : &cursor[k], c); }
+	__syncthreads();
+#pragma unroll
+	for (int it = 0; it < LIST_ITEMS; it++) {
+		const int32_t s = blockIdx.x * LIST_TILE + it * TPB + threadIdx.x;
+		if (keys[it] == KEY_GIANT) { const int32_t k = s_base[NKEYS] + local[it]; if (k < giantCap) giantlist[k] = s; }
+		else if (keys[it] != KEY_NONE) list[s_base[keys[it]] + local[it]] = s;
+	}
+}
+
+// One lane per record of chain level `level`; waves walk the level's slice of the list (sorted by length bin).
+template <bool DEF, bool HAS_REF>
+__global__ void __launch_bounds__(TPB) k_decode_level(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ list,
+                                                      const int32_t *__restrict__ keyBase, int32_t level, int *__restrict__ err) {
+	__shared__ int32_t lds[LANE_LDS_INTS_PER_THREAD * TPB];
+	const int32_t bucket = min(level, MAXLVL - 1);
+	const int32_t lo = keyBase[bucket * NBIN], hi = keyBase[(bucket + 1) * NBIN];
+	// longest records first: the waves that take longest start first
+	for (int32_t idx = hi - 1 - (blockIdx.x * TPB + threadIdx.x); idx >= lo; idx -= gridDim.x * TPB) {
+		const int32_t s = list[idx];
+		if (level >= MAXLVL - 1 && depth[s] != level) continue; // shared overflow bucket
+		const int32_t d = v.outd[s];
+		const int32_t r = v.ref[s];
+		if (s >= v.nh && (uint64_t)(v.rowstart[s + 1] - v.rowstart[v.nh]) > v.succ_cap) { atomicOr(err, E_CAP); continue; }
+		decode_node_full<DEF, HAS_REF>(g, v.lo + s, d, r, r > 0 ? (int64_t)v.outd[s - r] : 0, r > 0 ? v.row(s - r) : nullptr, v.row(s), lds, err);
+	}
+}
+
+// copy pass restricted to the giant list (their extras were written by k_parse_big)
+template <bool DEF>
+__global__ void __launch_bounds__(64) k_copy_giants(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ giantlist,
+                                                    const int32_t *__restrict__ ctl, int32_t level, int *__restrict__ err) {
+	const int32_t idx = blockIdx.x * 64 + threadIdx.x;
+	if (idx >= ctl[1]) return;
+	const int32_t s = giantlist[idx];
+	if (depth[s] != level || v.ref[s] == 0) return;
+	const int32_t r = v.ref[s];
+	if (s >= v.nh && (uint64_t)(v.rowstart[s + 1] - v.rowstart[v.nh]) > v.succ_cap) return;
+	copy_node<DEF>(g, v.lo + s, v.outd[s], (int64_t)v.outd[s - r], v.row(s), v.row(s - r), err);
+}
+
+// copy pass over the compact list of one chain level (longest records first)
+template <bool DEF>
+__global__ void __launch_bounds__(TPB) k_copy_list(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ list,
+                                                   const int32_t *__restrict__ keyBase, int32_t level, int *__restrict__ err) {
+	const int32_t bucket = min(level, MAXLVL - 1);
+	const int32_t lo = keyBase[bucket * NBIN], hi = keyBase[(bucket + 1) * NBIN];
+	for (int32_t idx = hi - 1 - (blockIdx.x * TPB + threadIdx.x); idx >= lo; idx -= gridDim.x * TPB) {
+		const int32_t s = list[idx];
+		if (level >= MAXLVL - 1 && depth[s] != level) continue; // shared overflow bucket
+		const int32_t r = v.ref[s];
+		if (r == 0) continue;
+		if (s >= v.nh && (uint64_t)(v.rowstart[s + 1] - v.rowstart[v.nh]) > v.succ_cap) continue; // E_CAP already raised
+		copy_node<DEF>(g, v.lo + s, v.outd[s], (int64_t)v.outd[s - r], v.row(s), v.row(s - r), err);
+	}
+}
+
 // ------------------------------------------------------------------------------------------------ long records
 // ctl[0] = #big, ctl[1] = #giant, ctl[2] / ctl[3] = heads of the two work queues
 __global__ void __launch_bounds__(TPB) k_classify(int32_t cnt, const int32_t *__restrict__ outd, int32_t coopMin, int32_t giantMin,
@@ -270,7 +405,7 @@ __global__ void __launch_bounds__(TPB) k_classify(int32_t cnt, const int32_t *__
 }
 
 // One group of NW waves per long record, pulled from a device-side queue.  NW = 1 serves the "big" list,
-// NW = 16 the "giant" list (records so long that a single wave would be the tail of the whole scan).
+// NW = GIANT_NW the "giant" list (records so long that a single wave would be the tail of the whole scan).
 template <bool DEF, int NW>
 __global__ void __launch_bounds__(64 * NW) k_parse_big(GraphDev g, RangeView v, const int32_t *__restrict__ list, int32_t *__restrict__ ctl, int which,
                                                        IvEntry *__restrict__ arena, int64_t arenaCap, int *__restrict__ err) {
@@ -575,13 +710,55 @@ void launch_classify(int32_t cnt, const int32_t *outd, int32_t coopMin, int32_t 
 }
 
 void launch_parse_big(const GraphDev &g, bool def, const RangeView &v, const int32_t *biglist, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap,
-                      int waves, int giantGroups, int *err, hipStream_t st) {
+                      int waves, int giantGroups, int *err, hipStream_t stGiant, hipStream_t stBig) {
 	if (v.cnt <= 0) return;
-	// giants first: they are the long poles
-	if (def) hipLaunchKernelGGL((k_parse_big<true, 16>), dim3(giantGroups), dim3(1024), 0, st, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
-	else hipLaunchKernelGGL((k_parse_big<false, 16>), dim3(giantGroups), dim3(1024), 0, st, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
-	if (def) hipLaunchKernelGGL((k_parse_big<true, 1>), dim3(waves), dim3(64), 0, st, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
-	else hipLaunchKernelGGL((k_parse_big<false, 1>), dim3(waves), dim3(64), 0, st, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
+	if (def) hipLaunchKernelGGL((k_parse_big<true, GIANT_NW>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+	else hipLaunchKernelGGL((k_parse_big<false, GIANT_NW>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+	if (def) hipLaunchKernelGGL((k_parse_big<true, 1>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
+	else hipLaunchKernelGGL((k_parse_big<false, 1>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
+}
+
+void launch_build_lists(const GraphDev &g, const RangeView &v, uint64_t giantBits, int32_t noBin, int32_t *depth, uint16_t *key16, int32_t *hist, int32_t *keyBase, int32_t *cursor,
+                        int32_t *list, int32_t *giantlist, int32_t giantCap, int32_t *ctl, int32_t *maxdepth, hipStream_t st) {
+	if (v.cnt <= 0) return;
+	(void)hipMemsetAsync(hist, 0, sizeof(int32_t) * NKEYS, st);
+	hipLaunchKernelGGL(k_depth_keys, dim3(nblk(v.cnt, LIST_TILE)), dim3(TPB), 0, st, g, v.lo, v.cnt, v.outd, v.ref, giantBits, noBin, depth, key16, hist, ctl, maxdepth);
+	hipLaunchKernelGGL(k_key_offsets, dim3(1), dim3(TPB), 0, st, hist, keyBase, cursor, maxdepth);
+	hipLaunchKernelGGL(k_scatter_keys, dim3(nblk(v.cnt, LIST_TILE)), dim3(TPB), 0, st, v.cnt, key16, cursor, list, giantlist, giantCap, ctl);
+}
+
+void launch_decode_level(const GraphDev &g, bool def, const RangeView &v, const int32_t *depth, const int32_t *list, const int32_t *keyBase, int32_t level, int blocks,
+                         int *err, hipStream_t st) {
+	if (v.cnt <= 0) return;
+	// level 0 records have no reference: the copy stream is compiled out
+	if (level == 0) {
+		if (def) hipLaunchKernelGGL((k_decode_level<true, false>), dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, err);
+		else hipLaunchKernelGGL((k_decode_level<false, false>), dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, err);
+	} else {
+		if (def) hipLaunchKernelGGL((k_decode_level<true, true>), dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, err);
+		else hipLaunchKernelGGL((k_decode_level<false, true>), dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, err);
+	}
+}
+
+void launch_copy_giants(const GraphDev &g, bool def, const RangeView &v, const int32_t *depth, const int32_t *giantlist, const int32_t *ctl, int32_t giantCap, int32_t level,
+                        int *err, hipStream_t st) {
+	if (v.cnt <= 0 || giantCap <= 0) return;
+	const int blocks = (int)std::min<int64_t>(((int64_t)giantCap + 63) / 64, 65535);
+	if (def) hipLaunchKernelGGL(k_copy_giants<true>, dim3(blocks), dim3(64), 0, st, g, v, depth, giantlist, ctl, level, err);
+	else hipLaunchKernelGGL(k_copy_giants<false>, dim3(blocks), dim3(64), 0, st, g, v, depth, giantlist, ctl, level, err);
+}
+
+void launch_parse_giants(const GraphDev &g, bool def, const RangeView &v, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap, int giantGroups, int *err, hipStream_t st) {
+	if (v.cnt <= 0) return;
+	if (def) hipLaunchKernelGGL((k_parse_big<true, GIANT_NW>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, st, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+	else hipLaunchKernelGGL((k_parse_big<false, GIANT_NW>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, st, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+}
+
+void launch_copy_list(const GraphDev &g, bool def, const RangeView &v, const int32_t *depth, const int32_t *list, const int32_t *keyBase, int32_t level, int blocks,
+                      int *err, hipStream_t st) {
+	if (v.cnt <= 0) return;
+	if (def) hipLaunchKernelGGL(k_copy_list<true>, dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, err);
+	else hipLaunchKernelGGL(k_copy_list<false>, dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, err);
 }
 
 } // namespace bv

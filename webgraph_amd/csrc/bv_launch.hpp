@@ -4,6 +4,10 @@
 
 namespace bv {
 
+// work-list keys (bv_kernels.hip, "work lists")
+constexpr int NBIN = 11, MAXLVL = 64, NKEYS = NBIN * MAXLVL;
+constexpr uint16_t KEY_NONE = 0xffff, KEY_GIANT = 0xfffe;
+
 // A decode job over consecutive nodes: slot s <-> node lo+s; slots [0,nh) are halo nodes whose rows live
 // in `halo`, slots [nh,cnt) are the caller's nodes whose rows live in `succ`.
 struct RangeView {
@@ -48,8 +52,17 @@ void launch_bparse(const GraphDev &g, bool def, const BatchView &v, int *err, hi
 void launch_bcopy(const GraphDev &g, bool def, const BatchView &v, int32_t level, int *err, hipStream_t st);
 void launch_classify(int32_t cnt, const int32_t *outd, int32_t coopMin, int32_t giantMin, int32_t *biglist, int32_t *giantlist, int32_t giantCap, int32_t *ctl, hipStream_t st);
 void launch_parse_big(const GraphDev &g, bool def, const RangeView &v, const int32_t *biglist, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap,
-                      int waves, int giantGroups, int *err, hipStream_t st);
+                      int waves, int giantGroups, int *err, hipStream_t stGiant, hipStream_t stBig);
 constexpr int ARENA_ENTRY_BYTES = 16;
+void launch_build_lists(const GraphDev &g, const RangeView &v, uint64_t giantBits, int32_t noBin, int32_t *depth, uint16_t *key16, int32_t *hist, int32_t *keyBase, int32_t *cursor,
+                        int32_t *list, int32_t *giantlist, int32_t giantCap, int32_t *ctl, int32_t *maxdepth, hipStream_t st);
+void launch_decode_level(const GraphDev &g, bool def, const RangeView &v, const int32_t *depth, const int32_t *list, const int32_t *keyBase, int32_t level, int blocks,
+                         int *err, hipStream_t st);
+void launch_copy_giants(const GraphDev &g, bool def, const RangeView &v, const int32_t *depth, const int32_t *giantlist, const int32_t *ctl, int32_t giantCap, int32_t level,
+                        int *err, hipStream_t st);
+void launch_copy_list(const GraphDev &g, bool def, const RangeView &v, const int32_t *depth, const int32_t *list, const int32_t *keyBase, int32_t level, int blocks,
+                      int *err, hipStream_t st);
+void launch_parse_giants(const GraphDev &g, bool def, const RangeView &v, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap, int giantGroups, int *err, hipStream_t st);
 void launch_hash(int32_t from, int32_t cnt, const int64_t *rowptr, const int32_t *succ, uint32_t *A, uint32_t *B, int32_t *hash, hipStream_t st);
 
 } // namespace bv

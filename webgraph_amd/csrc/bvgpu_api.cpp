@@ -66,6 +66,7 @@ struct Pending { // an enqueued range decode whose status has not been collected
 	bv::RangeView view{};
 	int32_t levels_done = 0;
 	bool want_succ = false;
+	int32_t giantCap = 0;
 };
 
 } // namespace
@@ -76,10 +77,21 @@ struct bvg_graph {
 	mutable std::string err;
 	DevBuf outd, ref, rowstart, depth, sums, need, halo, hashA, hashB, stage_rowptr, stage_succ, stage_nodes, small;
 	DevBuf b_chainlen, b_slotbase, b_node, b_qidx, b_aoutd, b_qoutd; // random-access batches
-	DevBuf biglist, giantlist, arena, coopctl;                        // wave-cooperative decode of long records
-	int32_t coop_min = 64, giant_min = 8192;                          // thresholds on the outdegree (BVGPU_COOP_MIN / BVGPU_GIANT_MIN)
+	DevBuf biglist, giantlist, arena, coopctl;                        // work lists; cooperative decode of giant records
+	DevBuf key16, keys;                                               // per-slot list key; hist / keyBase / cursor
+	uint64_t giant_bits = 65536;                                      // records at least this long (bits) are decoded cooperatively (BVGPU_GIANT_BITS)
+	int level_blocks = 2048;
+	int no_bin = 0;
+	int fused = 0; // BVGPU_PATH=fused: level-by-level single-pass decode (bv_lane.hpp); default: parse all, then copy level by level
+	DevBuf lvlist;
+	int copy_lists = 0; // BVGPU_COPY_LISTS=1: copy pass over per-level compact lists instead of node-order sweeps
+	int32_t coop_min = 256, giant_min = 8192;                         // thresholds on the outdegree (BVGPU_COOP_MIN / BVGPU_GIANT_MIN)
 	int coop_waves = 4096, giant_groups = 256;
 	DevBuf stats; // BVGPU_STATS=1: tuning counters
+	// the three parse kernels (giant / big / short records) are independent: they run on forked streams
+	hipStream_t sideA = nullptr, sideB = nullptr;
+	hipEvent_t evFork = nullptr, evA = nullptr, evB = nullptr;
+	bool overlap = true;
 	Small *h_small = nullptr; // pinned
 	int32_t levels_hint = 1;
 	Pending pend;
@@ -136,8 +148,19 @@ int init_handle(bvg_graph *g) {
 	if (const char *e = getenv("BVGPU_GIANT_MIN")) g->giant_min = std::max(g->coop_min, atoi(e));
 	if (const char *e = getenv("BVGPU_COOP_WAVES")) g->coop_waves = std::max(1, atoi(e));
 	if (const char *e = getenv("BVGPU_GIANT_GROUPS")) g->giant_groups = std::max(1, atoi(e));
-	if (!g->coopctl.need(4 * sizeof(int32_t))) return fail(g, BVG_ENOMEM, "device allocation failed");
-	if (const char *e = getenv("BVGPU_STATS")) if (atoi(e)) { if (!g->stats.need(16 * sizeof(unsigned long long))) return fail(g, BVG_ENOMEM, "device allocation failed"); HIPCHK(g, hipMemset(g->stats.p, 0, 128)); }
+	if (!g->coopctl.need(8 * sizeof(int32_t)) || !g->keys.need(3 * (bv::NKEYS + 1) * sizeof(int32_t))) return fail(g, BVG_ENOMEM, "device allocation failed");
+	if (const char *e = getenv("BVGPU_GIANT_BITS")) g->giant_bits = strtoull(e, nullptr, 10);
+	if (const char *e = getenv("BVGPU_LEVEL_BLOCKS")) g->level_blocks = std::max(1, atoi(e));
+	if (const char *e = getenv("BVGPU_NOBIN")) g->no_bin = atoi(e);
+	if (const char *e = getenv("BVGPU_PATH")) g->fused = strcmp(e, "fused") == 0;
+	if (const char *e = getenv("BVGPU_COPY_LISTS")) g->copy_lists = atoi(e);
+	if (const char *e = getenv("BVGPU_OVERLAP")) g->overlap = atoi(e) != 0;
+	HIPCHK(g, hipStreamCreateWithFlags(&g->sideA, hipStreamNonBlocking));
+	HIPCHK(g, hipStreamCreateWithFlags(&g->sideB, hipStreamNonBlocking));
+	HIPCHK(g, hipEventCreateWithFlags(&g->evFork, hipEventDisableTiming));
+	HIPCHK(g, hipEventCreateWithFlags(&g->evA, hipEventDisableTiming));
+	HIPCHK(g, hipEventCreateWithFlags(&g->evB, hipEventDisableTiming));
+	if (const char *e = getenv("BVGPU_STATS")) if (atoi(e)) { if (!g->stats.need(32 * sizeof(unsigned long long))) return fail(g, BVG_ENOMEM, "device allocation failed"); HIPCHK(g, hipMemset(g->stats.p, 0, 256)); }
 	return BVG_OK;
 }
 
@@ -189,7 +212,16 @@ int finish_pending(bvg_graph *g, uint64_t *arcs_out) {
 		int *derr = &g->small.as<Small>()->err;
 		while (g->pend.levels_done < g->h_small->maxdepth) {
 			const int32_t upto = g->h_small->maxdepth;
-			for (int32_t l = g->pend.levels_done + 1; l <= upto; l++) bv::launch_copy(gd, s.def, g->pend.view, g->depth.as<int32_t>(), l, derr, g->stream);
+			int32_t *keyBase = g->keys.as<int32_t>() + (bv::NKEYS + 1);
+			for (int32_t l = g->pend.levels_done + 1; l <= upto; l++) {
+				if (!g->fused) {
+					if (g->copy_lists) bv::launch_copy_list(gd, s.def, g->pend.view, g->depth.as<int32_t>(), g->lvlist.as<int32_t>(), keyBase, l, g->level_blocks, derr, g->stream);
+					else bv::launch_copy(gd, s.def, g->pend.view, g->depth.as<int32_t>(), l, derr, g->stream);
+					continue;
+				}
+				bv::launch_copy_giants(gd, s.def, g->pend.view, g->depth.as<int32_t>(), g->giantlist.as<int32_t>(), g->coopctl.as<int32_t>(), g->pend.giantCap, l, derr, g->stream);
+				bv::launch_decode_level(gd, s.def, g->pend.view, g->depth.as<int32_t>(), g->biglist.as<int32_t>(), keyBase, l, g->level_blocks, derr, g->stream);
+			}
 			g->pend.levels_done = upto;
 			rc = fetch_small(g);
 			if (rc) { g->pend.active = false; return rc; }
@@ -248,29 +280,82 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 	int *derr = &g->small.as<Small>()->err;
 	const bv::GraphDev gd = graph_dev(s);
 	int32_t levels = 0;
-	if (succ_dev) {
-		if (!g->depth.need(sizeof(int32_t) * (size_t)v.cnt)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
-		if (W > 0) bv::launch_depth(v.cnt, v.ref, g->depth.as<int32_t>(), &g->small.as<Small>()->maxdepth, g->stream);
+	int32_t giantCap = 0;
+	if (succ_dev && !g->fused) {
+		// default path: depth + per-level lists; cooperative decode of long records (two classes) next to the
+		// one-lane decode of the short ones; then the copy pass level by level over compact lists
+		const int64_t arcsBound = std::max<int64_t>(s.info.arcs, 1);
+		giantCap = (int32_t)std::min<int64_t>(arcsBound / g->giant_min + 2, 0x7fffffff);
+		const int64_t arenaCap = s.info.min_interval_length > 0 ? arcsBound / s.info.min_interval_length + 2 : 1;
+		if (!g->depth.need(sizeof(int32_t) * (size_t)v.cnt) || !g->key16.need(sizeof(uint16_t) * (size_t)v.cnt) || !g->lvlist.need(sizeof(int32_t) * (size_t)v.cnt) ||
+		    !g->biglist.need(sizeof(int32_t) * (size_t)v.cnt) || !g->giantlist.need(sizeof(int32_t) * (size_t)giantCap) || !g->arena.need((size_t)bv::ARENA_ENTRY_BYTES * (size_t)arenaCap))
+			return fail(g, BVG_ENOMEM, "device scratch allocation failed");
+		int32_t *hist = g->keys.as<int32_t>(), *keyBase = hist + (bv::NKEYS + 1), *cursor = keyBase + (bv::NKEYS + 1);
+		int32_t *ctl = g->coopctl.as<int32_t>();
+		HIPCHK(g, hipMemsetAsync(ctl, 0, 8 * sizeof(int32_t), g->stream));
+		if (W > 0) bv::launch_build_lists(gd, v, ~0ull, g->no_bin, g->depth.as<int32_t>(), g->key16.as<uint16_t>(), hist, keyBase, cursor, g->lvlist.as<int32_t>(),
+		                                  g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->maxdepth, g->stream);
 		mark(g, 3);
 		const bool coop = g->coop_min < 0x7fffffff;
 		v.coop_min = coop ? g->coop_min : 0x7fffffff;
 		if (coop) {
-			// long records: queue them (giants first) and give each a whole wave
-			const int64_t arcsBound = std::max<int64_t>(s.info.arcs, 1);
-			const int32_t giantCap = (int32_t)std::min<int64_t>(arcsBound / g->giant_min + 2, 0x7fffffff);
-			const int64_t arenaCap = s.info.min_interval_length > 0 ? arcsBound / s.info.min_interval_length + 2 : 1;
-			if (!g->biglist.need(sizeof(int32_t) * (size_t)v.cnt) || !g->giantlist.need(sizeof(int32_t) * (size_t)giantCap) ||
-			    !g->arena.need((size_t)bv::ARENA_ENTRY_BYTES * (size_t)arenaCap))
-				return fail(g, BVG_ENOMEM, "device scratch allocation failed");
-			HIPCHK(g, hipMemsetAsync(g->coopctl.p, 0, 4 * sizeof(int32_t), g->stream));
-			bv::launch_classify(v.cnt, v.outd, g->coop_min, g->giant_min, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, g->coopctl.as<int32_t>(), g->stream);
-			bv::launch_parse_big(gd, s.def, v, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), g->coopctl.as<int32_t>(), g->arena.p, arenaCap, g->coop_waves, g->giant_groups, derr, g->stream);
+			HIPCHK(g, hipMemsetAsync(ctl, 0, 8 * sizeof(int32_t), g->stream));
+			bv::launch_classify(v.cnt, v.outd, g->coop_min, g->giant_min, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, g->stream);
+			if (g->overlap) {
+				HIPCHK(g, hipEventRecord(g->evFork, g->stream));
+				HIPCHK(g, hipStreamWaitEvent(g->sideA, g->evFork, 0));
+				HIPCHK(g, hipStreamWaitEvent(g->sideB, g->evFork, 0));
+				bv::launch_parse_big(gd, s.def, v, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, g->giant_groups, derr, g->sideA, g->sideB);
+				HIPCHK(g, hipEventRecord(g->evA, g->sideA));
+				HIPCHK(g, hipEventRecord(g->evB, g->sideB));
+			} else
+				bv::launch_parse_big(gd, s.def, v, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, g->giant_groups, derr, g->stream, g->stream);
 		}
 		bv::launch_parse(gd, s.def, v, derr, g->stream);
+		if (coop && g->overlap) {
+			HIPCHK(g, hipStreamWaitEvent(g->stream, g->evA, 0));
+			HIPCHK(g, hipStreamWaitEvent(g->stream, g->evB, 0));
+		}
 		mark(g, 4);
 		if (W > 0) {
 			levels = g->levels_hint;
-			for (int32_t l = 1; l <= levels; l++) bv::launch_copy(gd, s.def, v, g->depth.as<int32_t>(), l, derr, g->stream);
+			for (int32_t l = 1; l <= levels; l++) {
+				if (g->copy_lists) bv::launch_copy_list(gd, s.def, v, g->depth.as<int32_t>(), g->lvlist.as<int32_t>(), keyBase, l, g->level_blocks, derr, g->stream);
+				else bv::launch_copy(gd, s.def, v, g->depth.as<int32_t>(), l, derr, g->stream); // sweep in node order: rows of neighbouring nodes are neighbours in memory
+			}
+		}
+	}
+	if (succ_dev && g->fused) {
+		const int64_t arcsBound = std::max<int64_t>(s.info.arcs, 1);
+		// a giant record has >= giant_bits bits; the whole stream has graph_bytes * 8
+		// a giant record has >= giant_bits bits or >= giant_bits / 8 successors
+		giantCap = (int32_t)std::min<uint64_t>((s.info.graph_bytes * 8 + (uint64_t)arcsBound * 8) / std::max<uint64_t>(g->giant_bits, 1) + 2, 0x7fffffff);
+		const int64_t arenaCap = s.info.min_interval_length > 0 ? arcsBound / s.info.min_interval_length + 2 : 1;
+		if (!g->depth.need(sizeof(int32_t) * (size_t)v.cnt) || !g->key16.need(sizeof(uint16_t) * (size_t)v.cnt) || !g->biglist.need(sizeof(int32_t) * (size_t)v.cnt) ||
+		    !g->giantlist.need(sizeof(int32_t) * (size_t)giantCap) || !g->arena.need((size_t)bv::ARENA_ENTRY_BYTES * (size_t)arenaCap))
+			return fail(g, BVG_ENOMEM, "device scratch allocation failed");
+		int32_t *hist = g->keys.as<int32_t>(), *keyBase = hist + (bv::NKEYS + 1), *cursor = keyBase + (bv::NKEYS + 1);
+		int32_t *ctl = g->coopctl.as<int32_t>();
+		v.coop_min = 0x7fffffff;
+		HIPCHK(g, hipMemsetAsync(ctl, 0, 8 * sizeof(int32_t), g->stream));
+		// chain depth of every record + work lists keyed by (level, length bin); giants apart
+		bv::launch_build_lists(gd, v, g->giant_bits, g->no_bin, g->depth.as<int32_t>(), g->key16.as<uint16_t>(), hist, keyBase, cursor, g->biglist.as<int32_t>(),
+		                       g->giantlist.as<int32_t>(), giantCap, ctl, &g->small.as<Small>()->maxdepth, g->stream);
+		mark(g, 3);
+		// giants: cooperative decode of their intervals + residuals on a side stream, overlapping level 0
+		HIPCHK(g, hipEventRecord(g->evFork, g->stream));
+		HIPCHK(g, hipStreamWaitEvent(g->sideA, g->evFork, 0));
+		bv::launch_parse_giants(gd, s.def, v, g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->giant_groups, derr, g->overlap ? g->sideA : g->stream);
+		if (g->overlap) HIPCHK(g, hipEventRecord(g->evA, g->sideA));
+		bv::launch_decode_level(gd, s.def, v, g->depth.as<int32_t>(), g->biglist.as<int32_t>(), keyBase, 0, g->level_blocks, derr, g->stream);
+		if (g->overlap) HIPCHK(g, hipStreamWaitEvent(g->stream, g->evA, 0));
+		mark(g, 4);
+		if (W > 0) {
+			levels = g->levels_hint;
+			for (int32_t l = 1; l <= levels; l++) {
+				bv::launch_copy_giants(gd, s.def, v, g->depth.as<int32_t>(), g->giantlist.as<int32_t>(), ctl, giantCap, l, derr, g->stream);
+				bv::launch_decode_level(gd, s.def, v, g->depth.as<int32_t>(), g->biglist.as<int32_t>(), keyBase, l, g->level_blocks, derr, g->stream);
+			}
 		}
 	}
 	if (!succ_dev) { mark(g, 3); mark(g, 4); }
@@ -280,7 +365,7 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 	mark(g, 6);
 	g->ev_valid = g->profile;
 	HIPCHK(g, hipGetLastError());
-	g->pend.active = true; g->pend.view = v; g->pend.levels_done = levels; g->pend.want_succ = succ_dev != nullptr;
+	g->pend.active = true; g->pend.view = v; g->pend.levels_done = levels; g->pend.want_succ = succ_dev != nullptr; g->pend.giantCap = giantCap;
 	if (async) return BVG_OK;
 	return finish_pending(g, arcs_out);
 }
@@ -364,9 +449,11 @@ extern "C" int bvg_close(bvg_t *g) {
 	if (g->st && g->st->device >= 0) {
 		(void)hipSetDevice(g->st->device);
 		if (g->own) { (void)hipStreamSynchronize(g->own); (void)hipStreamDestroy(g->own); }
-		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats }) b->release();
+		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist }) b->release();
 		if (g->h_small) (void)hipHostFree(g->h_small);
 		for (auto &e : g->ev) if (e) (void)hipEventDestroy(e);
+		for (hipEvent_t e : { g->evFork, g->evA, g->evB }) if (e) (void)hipEventDestroy(e);
+		for (hipStream_t st : { g->sideA, g->sideB }) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
 	}
 	delete g;
 	return BVG_OK;
@@ -410,8 +497,8 @@ extern "C" int bvg_debug_stats(bvg_t *g, uint64_t *out8, int reset) {
 	if (!g->stats.p) return fail(g, BVG_ESTATE, "set BVGPU_STATS=1 before opening the graph");
 	HIPCHK(g, hipSetDevice(g->st->device));
 	HIPCHK(g, hipDeviceSynchronize());
-	HIPCHK(g, hipMemcpy(out8, g->stats.p, 128, hipMemcpyDeviceToHost));
-	if (reset) HIPCHK(g, hipMemset(g->stats.p, 0, 128));
+	HIPCHK(g, hipMemcpy(out8, g->stats.p, 256, hipMemcpyDeviceToHost));
+	if (reset) HIPCHK(g, hipMemset(g->stats.p, 0, 256));
 	return BVG_OK;
 }
 
