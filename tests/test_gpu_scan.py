@@ -185,3 +185,41 @@ def test_cap_too_small(cnr_gpu):
     with pytest.raises(BvgError) as ei:
         cnr_gpu.decode_range_device(0, n, rp.data_ptr(), sc.data_ptr(), sc.numel())
     assert ei.value.code == -8
+
+
+def test_sharded_scan_equals_whole(cnr_gpu, cnr_oracle):
+    """SURVEY.md section 8(e): bits-balanced shards decoded independently (each with its halo) reassemble the graph;
+    the host-side fold of the shards' (arcs, affine hash) pairs gives numArcs and hashCode()."""
+    import torch
+    from webgraph_amd.parallel import affine_from_two_hashes, fold_affine, shard_bounds_from_offsets
+    g, rowptr, succ = cnr_oracle
+    dev = torch.device("cuda", 0)
+    for parts in (2, 8):
+        b = cnr_gpu.shard_bounds(parts)
+        assert np.array_equal(b, shard_bounds_from_offsets(g.offsets, parts))
+        pairs, arcs = [], 0
+        for k in range(parts):
+            lo, hi = int(b[k]), int(b[k + 1])
+            rp = torch.empty(hi - lo + 1, dtype=torch.int64, device=dev)
+            sc = torch.empty(int(rowptr[hi] - rowptr[lo]) + 1, dtype=torch.int32, device=dev)
+            a = cnr_gpu.decode_range_device(lo, hi, rp.data_ptr(), sc.data_ptr(), sc.numel())
+            assert a == rowptr[hi] - rowptr[lo]
+            assert np.array_equal(sc[:a].cpu().numpy(), succ[rowptr[lo]:rowptr[hi]])
+            h0 = cnr_gpu.csr_hashcode(lo, hi, rp.data_ptr(), sc.data_ptr(), 0)
+            h1 = cnr_gpu.csr_hashcode(lo, hi, rp.data_ptr(), sc.data_ptr(), 1)
+            pairs.append(affine_from_two_hashes(h0, h1))
+            arcs += a
+        assert arcs == 3216152 and fold_affine(pairs) == 1711395807
+
+
+def test_fused_path_matches(tmp_path_factory, cnr_oracle, monkeypatch):
+    """The experimental level-by-level single-pass decoder (BVGPU_PATH=fused) gives the same bits."""
+    from webgraph_amd.bvgraph import BVGraph
+    monkeypatch.setenv("BVGPU_PATH", "fused")
+    _, rowptr, succ = cnr_oracle
+    g = BVGraph.load(CNR)
+    rp, sc = g.decode_range()
+    assert np.array_equal(rp, rowptr) and np.array_equal(sc, succ)
+    rp, sc = g.decode_range(100000, 140000)
+    assert np.array_equal(sc, succ[rowptr[100000]:rowptr[140000]])
+    g.close()

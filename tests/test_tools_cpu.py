@@ -1,0 +1,123 @@
+"""CPU tests of the BVGraph writer / generator (libbvgtools) and of the host-only half of libbvgpu."""
+import filecmp
+import os
+
+import numpy as np
+import pytest
+
+from conftest import CNR, make_graph
+from oracle import oracle as O
+
+
+def test_writer_reproduces_reference_bytes(tmp_path, cnr_oracle):
+    """Recompressing cnr-2000 with its own parameters gives back the reference-produced .graph / .offsets bit for bit."""
+    from webgraph_amd import tools as T
+    _, rowptr, succ = cnr_oracle
+    base = str(tmp_path / "cnr")
+    st = T.store(base, rowptr, succ, window=7, max_ref_count=3, min_interval=3, zeta_k=3)
+    assert filecmp.cmp(base + ".graph", CNR + ".graph", shallow=False)
+    assert filecmp.cmp(base + ".offsets", CNR + ".offsets", shallow=False)
+    # BVGraphTest.testCompression's invariants (test/it/unimi/dsi/webgraph/BVGraphTest.java:59-72)
+    bits = st["bits_outdegrees"] + st["bits_references"] + st["bits_blocks"] + st["bits_intervals"] + st["bits_residuals"]
+    assert os.path.getsize(base + ".graph") == (bits + 7) // 8
+    assert st["copied_arcs"] + st["intervalised_arcs"] + st["residual_arcs"] == rowptr[-1]
+    assert (st["copied_arcs"], st["intervalised_arcs"], st["residual_arcs"]) == (2130833, 361894, 723425)
+    assert st["max_ref_chain"] == 3
+
+
+@pytest.mark.parametrize("w,r,i", [(0, 0, 0), (1, 1, 2), (2, 2, 3), (7, 3, 4), (3, 100, 1)])
+def test_roundtrip_through_oracle(tmp_path_factory, w, r, i):
+    """BVGraphTest.testCompression: store -> load -> equal, for several (window, maxRefCount, minIntervalLength)."""
+    base, rowptr, succ = make_graph(tmp_path_factory, "rt", 3000, 40000, 5 + w, 0.7, window=w, max_ref_count=r, min_interval=i, threads=2)
+    g = O.OracleGraph.load(base)
+    rp, sc, arcs = g.scan()
+    assert np.array_equal(rp, rowptr) and np.array_equal(sc, succ)
+    q = np.arange(0, 3000, 7, dtype=np.int32)
+    brp, bsc = g.successors_batch(q)
+    for j, x in enumerate(q):
+        assert np.array_equal(bsc[brp[j]:brp[j + 1]], succ[rowptr[x]:rowptr[x + 1]])
+
+
+def test_generator_is_deterministic_and_exact():
+    from webgraph_amd import tools as T
+    a = T.generate(20000, 300000, seed=99, threads=1)
+    b = T.generate(20000, 300000, seed=99, threads=4)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])  # independent of the thread count
+    rowptr, succ = a
+    assert rowptr[-1] == 300000 and succ.size == 300000
+    d = np.diff(rowptr)
+    assert 0.15 < (d == 0).mean() < 0.25  # 20 % empty nodes
+    for x in range(0, 20000, 500):
+        row = succ[rowptr[x]:rowptr[x + 1]]
+        assert np.all(np.diff(row) > 0) and (row.size == 0 or (row[0] >= 0 and row[-1] < 20000))
+
+
+def test_library_exports_every_declared_symbol():
+    """include/bvgpu.h <-> libbvgpu.so: every declared entry point is exported; no compute call here."""
+    import re
+    from webgraph_amd import bvgraph as B
+    L = B.lib()
+    hdr = open(os.path.join(os.path.dirname(CNR), "..", "..", "include", "bvgpu.h")).read()
+    declared = set(re.findall(r"\b(bvg_[a-z_]+)\s*\(", hdr))
+    assert declared, "no declarations found"
+    for name in declared:
+        assert hasattr(L, name), name
+    assert declared == set(B.EXPORTS)
+    import ctypes
+    T = ctypes.CDLL(os.path.join(os.path.dirname(B.__file__), "libbvgtools.so"))
+    for name in ("bvt_store", "bvt_generate", "bvt_free"):
+        assert hasattr(T, name)
+
+
+def test_no_gpu_means_loud_failure():
+    """There is no CPU fallback: opening a graph without a HIP device fails (this container has no GPU)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from webgraph_amd.bvgraph import BVGraph, BvgError
+    with pytest.raises(BvgError) as e:
+        BVGraph.load(CNR)
+    assert e.value.code == -6
+
+
+def test_parse_properties_like_the_reference(tmp_path):
+    from webgraph_amd import bvgraph as B
+    info = B.parse_properties(CNR)
+    assert (info.nodes, info.arcs, info.window_size, info.max_ref_count, info.min_interval_length, info.zeta_k) == (325557, 3216152, 7, 3, 3, 3)
+    assert (info.outdegree_coding, info.block_coding, info.residual_coding, info.reference_coding, info.block_count_coding, info.offset_coding) == (2, 2, 6, 5, 2, 2)
+
+    def write(name, text):
+        p = tmp_path / (name + ".properties")
+        p.write_text(text)
+        return str(tmp_path / name)
+
+    ok = "graphclass=it.unimi.dsi.webgraph.BVGraph\nversion=0\nnodes=5\narcs=7\nwindowsize=7\nmaxrefcount=3\nminintervallength=4\n"
+    i2 = B.parse_properties(write("a", ok + "compressionflags=RESIDUALS_GAMMA | OFFSETS_DELTA\n"))
+    assert i2.residual_coding == 2 and i2.offset_coding == 1 and i2.zeta_k == 3
+    # the `big` spelling is accepted (BVG:1528); ':' and blank separators are java.util.Properties syntax
+    i3 = B.parse_properties(write("b", ok.replace("it.unimi.dsi.webgraph", "it.unimi.dsi.big.webgraph").replace("nodes=5", "nodes : 5").replace("arcs=7", "arcs 7")))
+    assert i3.nodes == 5 and i3.arcs == 7
+    with pytest.raises(NotImplementedError):  # version > 0 (BVG:1534)
+        B.parse_properties(write("c", ok.replace("version=0", "version=1")))
+    with pytest.raises(NotImplementedError):  # missing version (BVG:1533)
+        B.parse_properties(write("d", ok.replace("version=0\n", "")))
+    with pytest.raises(NotImplementedError):  # another graph class (BVG:1528)
+        B.parse_properties(write("e", ok.replace("BVGraph", "EFGraph")))
+    with pytest.raises(ValueError):  # nodes >= 2^31 (BVG:1537)
+        B.parse_properties(write("f", ok.replace("nodes=5", "nodes=2147483648")))
+    with pytest.raises(NotImplementedError):  # unknown flag name (BVG:1361)
+        B.parse_properties(write("g", ok + "compressionflags=RESIDUALS_FOO\n"))
+    with pytest.raises(IOError):
+        B.parse_properties(str(tmp_path / "missing"))
+
+
+def test_flags_and_offsets_host_logic(cnr_oracle):
+    from webgraph_amd import bvgraph as B
+    assert B.flags_from_string("") == 0
+    assert B.flags_from_string("OUTDEGREES_DELTA|BLOCKS_DELTA | RESIDUALS_NIBBLE|REFERENCES_GAMMA| BLOCK_COUNT_UNARY |OFFSETS_DELTA") == 1 | 1 << 4 | 7 << 8 | 2 << 12 | 5 << 16 | 1 << 20
+    with pytest.raises(IOError):
+        B.flags_from_string("BLOCKS_UNARY")  # not a public constant of BVGraph (BVG:475-523)
+    g, _, _ = cnr_oracle
+    with open(CNR + ".offsets", "rb") as f:
+        offs = B.decode_offsets_host(f.read(), g.n)
+    assert np.array_equal(offs, g.offsets)  # product's own decoder == oracle's

@@ -23,6 +23,9 @@ namespace bv {
 constexpr int TPB = 256;
 constexpr int GIANT_NW = 8; // waves per giant record
 
+template <bool DEF>
+__device__ __forceinline__ void copy_node(const GraphDev &g, int32_t x, int32_t d, int64_t dref, int32_t *__restrict__ row, const int32_t *__restrict__ src, int *__restrict__ err);
+
 // ------------------------------------------------------------------------------------------------ headers
 template <bool DEF>
 __global__ void __launch_bounds__(TPB) k_headers(GraphDev g, int32_t lo, int32_t cnt, int32_t *__restrict__ outd,
