@@ -1,0 +1,126 @@
+/*
+ * GpuBVGraph -- the reference-side binding of libbvgpu: an ImmutableGraph whose successor lists are decoded on an
+ * MI355X.  Drop-in through the reference's own plug-in mechanism: put
+ *     graphclass=it.unimi.dsi.webgraph.gpu.GpuBVGraph
+ * in <basename>.properties (or pass `-g GpuBVGraph` to the tools that take a graph class), and
+ * ImmutableGraph.load(basename) reflects on the static load methods below (ImmutableGraph.java:647-685; the
+ * required signatures are listed at ImmutableGraph.java:89-104).  Same .graph/.offsets/.properties files.
+ *
+ * NOT COMPILED IN THIS REPOSITORY: the build image has no JDK (no javac, no jni.h) and the reference's
+ * dependencies (dsiutils, fastutil) are not vendored.  Shipped as the source a maintainer would add; the C side
+ * is java/jni/bvgpu_jni.c.  The same surface is exercised here through webgraph_amd/host/bvgraph.hpp (C++) and
+ * webgraph_amd/bvgraph.py (ctypes).
+ */
+package it.unimi.dsi.webgraph.gpu;
+
+import it.unimi.dsi.logging.ProgressLogger;
+import it.unimi.dsi.webgraph.ImmutableGraph;
+import it.unimi.dsi.webgraph.LazyIntIterator;
+import it.unimi.dsi.webgraph.LazyIntIterators;
+import it.unimi.dsi.webgraph.NodeIterator;
+
+import java.io.IOException;
+import java.util.NoSuchElementException;
+
+public class GpuBVGraph extends ImmutableGraph {
+	static { System.loadLibrary("bvgpu_jni"); }
+
+	/** Nodes decoded per GPU call by a sequential iterator. */
+	public static final int BATCH_NODES = 1 << 20;
+
+	private final long handle; // bvg_t*
+	private final CharSequence basename;
+	private final int n, windowSize, maxRefCount;
+	private final long m;
+
+	// ---- natives: one per entry point of include/bvgpu.h; a negative bvg_status becomes the exception the
+	// reference throws at the same place (BVG_EARG -> IllegalArgumentException, BVG_ESTATE -> IllegalStateException,
+	// BVG_EUNSUPPORTED -> UnsupportedOperationException, BVG_EIO -> IOException wrapped in RuntimeException).
+	private static native long open(String basename, int device) throws IOException;           // bvg_open
+	private static native long cloneHandle(long handle);                                        // bvg_clone
+	private static native void close(long handle);                                              // bvg_close
+	private static native long[] info(long handle);                                             // bvg_info: {nodes, arcs, window, maxref}
+	private static native int outdegree(long handle, int x);                                    // bvg_outdegrees(x, x+1)
+	private static native int[] successorArray(long handle, int x);                             // bvg_successors_batch, q = 1
+	/** Fills rowptr[to-from+1]; returns the successors of nodes [from,to) concatenated. */
+	private static native int[] decodeRange(long handle, int from, int to, long[] rowptr);      // bvg_decode_range
+
+	private GpuBVGraph(final long handle, final CharSequence basename) {
+		this.handle = handle;
+		this.basename = basename;
+		final long[] i = info(handle);
+		n = (int)i[0]; m = i[1]; windowSize = (int)i[2]; maxRefCount = (int)i[3];
+	}
+
+	// ---- the loaders ImmutableGraph.load reflects on
+	public static GpuBVGraph load(final CharSequence basename) throws IOException { return new GpuBVGraph(open(basename.toString(), 0), basename); }
+	public static GpuBVGraph load(final CharSequence basename, final ProgressLogger pl) throws IOException { return load(basename); }
+	public static GpuBVGraph loadMapped(final CharSequence basename) throws IOException { return load(basename); }
+	public static GpuBVGraph loadMapped(final CharSequence basename, final ProgressLogger pl) throws IOException { return load(basename); }
+	public static GpuBVGraph loadOffline(final CharSequence basename) throws IOException { return load(basename); }
+	public static GpuBVGraph loadOffline(final CharSequence basename, final ProgressLogger pl) throws IOException { return load(basename); }
+
+	@Override public int numNodes() { return n; }
+	@Override public long numArcs() { return m; }
+	@Override public boolean randomAccess() { return true; }
+	@Override public boolean hasCopiableIterators() { return true; }
+	@Override public CharSequence basename() { return basename; }
+	public int windowSize() { return windowSize; }
+	public int maxRefCount() { return maxRefCount; }
+
+	@Override public int outdegree(final int x) {
+		if (x < 0 || x >= n) throw new IllegalArgumentException("Node index out of range: " + x);
+		return outdegree(handle, x);
+	}
+	@Override public int[] successorArray(final int x) {
+		if (x < 0 || x >= n) throw new IllegalArgumentException("Node index out of range: " + x);
+		return successorArray(handle, x);
+	}
+	@Override public LazyIntIterator successors(final int x) {
+		final int[] a = successorArray(x);
+		return LazyIntIterators.wrap(a, a.length);
+	}
+	/** Flyweight copy sharing the staged graph (BVGraph.copy()). */
+	@Override public GpuBVGraph copy() { return new GpuBVGraph(cloneHandle(handle), basename); }
+
+	@Override public NodeIterator nodeIterator(final int from) { return new BatchIterator(from, Integer.MAX_VALUE); }
+
+	/** Sequential scan served from GPU-decoded batches; same contract as BVGraph's node iterator. */
+	private final class BatchIterator extends NodeIterator {
+		private final int from, limit;
+		private int curr, lo, hi;
+		private long[] rowptr;
+		private int[] succ;
+
+		BatchIterator(final int from, final int upperBound) {
+			if (from < 0 || from > n) throw new IllegalArgumentException("Node index out of range: " + from);
+			this.from = from; curr = from - 1; lo = hi = from;
+			limit = Math.min(upperBound, n) - 1;
+		}
+		@Override public boolean hasNext() { return curr < limit; }
+		@Override public int nextInt() {
+			if (!hasNext()) throw new NoSuchElementException();
+			if (++curr >= hi) {
+				lo = curr; hi = (int)Math.min((long)lo + BATCH_NODES, (long)limit + 1);
+				rowptr = new long[hi - lo + 1];
+				succ = decodeRange(handle, lo, hi, rowptr);
+			}
+			return curr;
+		}
+		@Override public int outdegree() {
+			if (curr == from - 1) throw new IllegalStateException();
+			return (int)(rowptr[curr - lo + 1] - rowptr[curr - lo]);
+		}
+		@Override public int[] successorArray() {
+			final int d = outdegree();
+			final int[] a = new int[d];
+			System.arraycopy(succ, (int)rowptr[curr - lo], a, 0, d);
+			return a;
+		}
+		@Override public LazyIntIterator successors() { final int[] a = successorArray(); return LazyIntIterators.wrap(a, a.length); }
+		@Override public NodeIterator copy(final int upperBound) { return new BatchIterator(curr + 1, upperBound); }
+	}
+
+	@SuppressWarnings("deprecation")
+	@Override protected void finalize() throws Throwable { try { close(handle); } finally { super.finalize(); } }
+}

@@ -1,0 +1,77 @@
+/*
+ * bvgpu_jni.c -- JNI glue between it.unimi.dsi.webgraph.gpu.GpuBVGraph and libbvgpu (include/bvgpu.h).
+ * NOT COMPILED HERE (no jni.h in the build image).  Build where a JDK exists:
+ *   gcc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -I../../include bvgpu_jni.c -L../../webgraph_amd -lbvgpu -o libbvgpu_jni.so
+ */
+#include <jni.h>
+#include <stdlib.h>
+#include "bvgpu.h"
+
+static void throw_status(JNIEnv *env, int rc, const bvg_t *h) {
+	const char *cls = rc == BVG_EARG ? "java/lang/IllegalArgumentException"
+	                : rc == BVG_ESTATE ? "java/lang/IllegalStateException"
+	                : rc == BVG_EUNSUPPORTED ? "java/lang/UnsupportedOperationException"
+	                : rc == BVG_EIO ? "java/io/IOException"
+	                : rc == BVG_ENOMEM ? "java/lang/OutOfMemoryError" : "java/lang/RuntimeException";
+	(*env)->ThrowNew(env, (*env)->FindClass(env, cls), h ? bvg_last_error(h) : "bvgpu error");
+}
+
+JNIEXPORT jlong JNICALL Java_it_unimi_dsi_webgraph_gpu_GpuBVGraph_open(JNIEnv *env, jclass c, jstring basename, jint device) {
+	const char *b = (*env)->GetStringUTFChars(env, basename, NULL);
+	bvg_t *h = NULL;
+	const int rc = bvg_open(b, device, &h);
+	(*env)->ReleaseStringUTFChars(env, basename, b);
+	if (rc) { throw_status(env, rc, h); bvg_close(h); return 0; }
+	return (jlong)(intptr_t)h;
+}
+JNIEXPORT jlong JNICALL Java_it_unimi_dsi_webgraph_gpu_GpuBVGraph_cloneHandle(JNIEnv *env, jclass c, jlong handle) {
+	bvg_t *h = NULL;
+	const int rc = bvg_clone((bvg_t *)(intptr_t)handle, &h);
+	if (rc) { throw_status(env, rc, h); bvg_close(h); return 0; }
+	return (jlong)(intptr_t)h;
+}
+JNIEXPORT void JNICALL Java_it_unimi_dsi_webgraph_gpu_GpuBVGraph_close(JNIEnv *env, jclass c, jlong handle) { bvg_close((bvg_t *)(intptr_t)handle); }
+
+JNIEXPORT jlongArray JNICALL Java_it_unimi_dsi_webgraph_gpu_GpuBVGraph_info(JNIEnv *env, jclass c, jlong handle) {
+	bvg_info_t i;
+	const int rc = bvg_info((bvg_t *)(intptr_t)handle, &i);
+	if (rc) { throw_status(env, rc, (bvg_t *)(intptr_t)handle); return NULL; }
+	jlong v[4] = { i.nodes, i.arcs, i.window_size, i.max_ref_count };
+	jlongArray a = (*env)->NewLongArray(env, 4);
+	(*env)->SetLongArrayRegion(env, a, 0, 4, v);
+	return a;
+}
+JNIEXPORT jint JNICALL Java_it_unimi_dsi_webgraph_gpu_GpuBVGraph_outdegree(JNIEnv *env, jclass c, jlong handle, jint x) {
+	int32_t d = 0;
+	const int rc = bvg_outdegrees((bvg_t *)(intptr_t)handle, x, x + 1, &d, BVG_OUT_HOST);
+	if (rc) throw_status(env, rc, (bvg_t *)(intptr_t)handle);
+	return d;
+}
+JNIEXPORT jintArray JNICALL Java_it_unimi_dsi_webgraph_gpu_GpuBVGraph_successorArray(JNIEnv *env, jclass c, jlong handle, jint x) {
+	bvg_t *h = (bvg_t *)(intptr_t)handle;
+	int64_t rp[2]; uint64_t arcs = 0; int32_t node = x;
+	int rc = bvg_successors_batch(h, &node, 1, rp, NULL, 0, &arcs, BVG_OUT_HOST);
+	if (rc) { throw_status(env, rc, h); return NULL; }
+	jintArray a = (*env)->NewIntArray(env, (jsize)arcs);   /* a fresh exact-length array per call, ImmutableGraph.java:329-333 */
+	jint *p = (*env)->GetPrimitiveArrayCritical(env, a, NULL);
+	rc = bvg_successors_batch(h, &node, 1, rp, (int32_t *)p, arcs, &arcs, BVG_OUT_HOST);
+	(*env)->ReleasePrimitiveArrayCritical(env, a, p, 0);
+	if (rc) { throw_status(env, rc, h); return NULL; }
+	return a;
+}
+JNIEXPORT jintArray JNICALL Java_it_unimi_dsi_webgraph_gpu_GpuBVGraph_decodeRange(JNIEnv *env, jclass c, jlong handle, jint from, jint to, jlongArray rowptr) {
+	bvg_t *h = (bvg_t *)(intptr_t)handle;
+	uint64_t arcs = 0;
+	jlong *rp = (*env)->GetLongArrayElements(env, rowptr, NULL);
+	int rc = bvg_decode_range(h, from, to, (int64_t *)rp, NULL, 0, &arcs, BVG_OUT_HOST);           /* count */
+	jintArray a = NULL;
+	if (!rc) {
+		a = (*env)->NewIntArray(env, (jsize)arcs);
+		jint *p = (*env)->GetPrimitiveArrayCritical(env, a, NULL);
+		rc = bvg_decode_range(h, from, to, (int64_t *)rp, (int32_t *)p, arcs, &arcs, BVG_OUT_HOST);  /* decode */
+		(*env)->ReleasePrimitiveArrayCritical(env, a, p, 0);
+	}
+	(*env)->ReleaseLongArrayElements(env, rowptr, rp, 0);
+	if (rc) { throw_status(env, rc, h); return NULL; }
+	return a;
+}

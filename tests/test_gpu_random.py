@@ -60,3 +60,17 @@ def test_deep_chains_random_access(tmp_path_factory):
     orp, osc = og.successors_batch(q)
     assert np.array_equal(rp, orp) and np.array_equal(sc, osc)
     g.close()
+
+
+def test_cpp_host_mirror_runs(tmp_path):
+    """webgraph_amd/host/bvgraph.hpp driven like WebGraphTestCase.assertGraph, on the GPU."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "host_mirror_test")
+    pkg = os.path.join(ROOT, "webgraph_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(ROOT, "tests", "cpp", "host_mirror_test.cpp"),
+                           "-L" + pkg, "-lbvgpu", "-Wl,-rpath," + pkg, "-L/opt/rocm/lib", "-lamdhip64"])
+    p = subprocess.run([exe, CNR, "1711395807", "3216152"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert "host mirror ok" in p.stdout

@@ -121,3 +121,17 @@ def test_flags_and_offsets_host_logic(cnr_oracle):
     with open(CNR + ".offsets", "rb") as f:
         offs = B.decode_offsets_host(f.read(), g.n)
     assert np.array_equal(offs, g.offsets)  # product's own decoder == oracle's
+
+
+def test_cpp_host_mirror_compiles(tmp_path):
+    """The C++ mirror of the reference API (webgraph_amd/host/bvgraph.hpp) builds against the C ABI; without a GPU it fails loudly."""
+    import subprocess
+    import torch
+    from conftest import ROOT
+    exe = str(tmp_path / "host_mirror_test")
+    pkg = os.path.join(ROOT, "webgraph_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(ROOT, "tests", "cpp", "host_mirror_test.cpp"),
+                           "-L" + pkg, "-lbvgpu", "-Wl,-rpath," + pkg, "-L/opt/rocm/lib", "-lamdhip64"])
+    if not torch.cuda.is_available():
+        p = subprocess.run([exe, CNR, "1711395807", "3216152"], capture_output=True, text=True)
+        assert p.returncode != 0 and "no HIP device" in p.stderr
