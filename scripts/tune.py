@@ -52,7 +52,7 @@ def main():
             st[0], st[1] / max(st[0], 1), st[2], st[3] / max(st[2], 1), st[5], st[6] / max(st[5], 1), st[7] * args.reps))
         print("residual tile rounds histogram (<=2,<=4,<=8,<=16,<=32,<=64):", [int(v) for v in st[8:14]])
         print("ticks (M) NW=1: A %.1f I %.1f R+X %.1f | NW=16: A %.1f I %.1f R+X %.1f" % tuple(float(v) / 1e6 for v in (st[16], st[17], st[18], st[20], st[21], st[22])))
-        print("NW=1 residual ticks (M): stage %.0f rounds %.0f values %.0f rank %.0f flush %.0f fence %.0f expand %.0f loop %.0f" % tuple(float(v) / 1e6 for v in st[24:32]))
+        print("giants residual ticks (M): stage %.0f rounds %.0f values %.0f rank %.0f flush %.0f fence %.0f expand %.0f loop %.0f" % tuple(float(v) / 1e6 for v in st[24:32]))
         ns = max(int(st[13]), 1)
         print("slow tiles: avg B %.0f avg remaining codes %.0f avg codes in tile %.0f" % (st[15] / ns, st[4] / ns, st[14] / ns))
     if args.check:

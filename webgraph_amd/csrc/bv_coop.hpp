@@ -164,26 +164,67 @@ __device__ __forceinline__ WindowSrc stage_tile(const Grp<NW> &G, const GraphDev
 	return WindowSrc{ win, w0, nw4 * 4, GlobalSrc{ g.bits, g.nwords } };
 }
 
+// ---- stateless decoding straight from the staged window --------------------------------------------------
+// With the tile in LDS a code can be decoded from its bit position alone: three LDS words give the 64 bits
+// starting at `pos`, and gamma / zeta_3 codes of up to 64 bits (values < 2^31 resp. < 2^45) decode with a
+// handful of shifts -- no register-buffered reader state, ~5x fewer instructions than the generic reader.
+// Anything longer, or outside the window, takes the generic reader for that one code.
+__device__ __forceinline__ bool win_peek64(const WindowSrc &src, uint64_t pos, uint64_t &W) {
+	const uint64_t j = (pos >> 5) - src.w0;
+	if (j + 2 >= (uint64_t)src.nw) return false;
+	const uint32_t a = src.win[j], b = src.win[j + 1], c = src.win[j + 2];
+	const uint32_t sh = (uint32_t)pos & 31u;
+	const uint64_t ab = ((uint64_t)a << 32) | b;
+	W = sh ? (ab << sh) | ((uint64_t)c >> (32u - sh)) : ab;
+	return true;
+}
+__device__ __forceinline__ bool fast_gamma(uint64_t W, uint64_t &v, uint32_t &len) {
+	if (W == 0) return false;
+	const uint32_t m = (uint32_t)__clzll((long long)W);
+	if (m > 31) return false;
+	v = ((W << m) >> (63u - m)) - 1;
+	len = 2 * m + 1;
+	return true;
+}
+__device__ __forceinline__ bool fast_zeta3(uint64_t W, uint64_t &v, uint32_t &len) {
+	if (W == 0) return false;
+	const uint32_t h = (uint32_t)__clzll((long long)W);
+	if (h > 15) return false;
+	const uint32_t nb = 3 * h + 2;
+	const uint64_t W2 = W << (h + 1);
+	const uint64_t m = W2 >> (64u - nb);
+	const uint64_t left = (uint64_t)1 << (3 * h);
+	if (m < left) { v = m + left - 1; len = h + 1 + nb; }
+	else { v = ((m << 1) | ((W2 >> (63u - nb)) & 1)) - 1; len = h + 2 + nb; }
+	return true;
+}
+// one code at bit position p of the staged window; advances p.  KIND 0: residual code, KIND 1: gamma code
+template <bool DEF, int KIND>
+__device__ __forceinline__ uint64_t win_code(const GraphDev &g, const WindowSrc &src, uint64_t &p, int &err) {
+	uint64_t W, v; uint32_t len;
+	if ((KIND == 1 || DEF) && win_peek64(src, p, W) && (KIND == 1 ? fast_gamma(W, v, len) : fast_zeta3(W, v, len))) { p += len; return v; }
+	WinReader br; br.init_src(src, g.nwords);
+	br.seek(p);
+	v = KIND == 1 ? br.gamma() : Fields<DEF>::residual(br, g);
+	p = br.pos();
+	err |= br.err;
+	return v;
+}
+
 // One speculative parse of the codes starting in [s, segEnd): end position, count and the sum of the decoded
 // contributions.  KIND 0: residual codes (gap+1 each; the first code of the section is the zig-zag value);
 // KIND 1: gamma codes, positions only.
 template <bool DEF, int KIND>
 __device__ __forceinline__ void spec_parse(const GraphDev &g, const WindowSrc &src, uint64_t s, uint64_t segEnd, bool firstOfSection, uint64_t &e, uint32_t &c, int64_t &sum) {
 	c = 0; sum = 0;
-	if (s >= segEnd) { e = s; return; }
-	WinReader br;
-	br.init_src(src, g.nwords);
-	br.seek(s);
-	while (br.pos() < segEnd && !br.err) { // a speculative parse may run through garbage: errors only stop it
-		if (KIND == 0) {
-			const uint64_t v = Fields<DEF>::residual(br, g);
-			sum += (c == 0 && firstOfSection) ? nat2int(v) : (int64_t)v + 1;
-		} else {
-			(void)br.gamma();
-		}
+	uint64_t p = s;
+	int err = 0; // a speculative parse may run through garbage: errors only stop it
+	while (p < segEnd && !err) {
+		const uint64_t v = win_code<DEF, KIND>(g, src, p, err);
+		if (KIND == 0) sum += (c == 0 && firstOfSection) ? nat2int(v) : (int64_t)v + 1;
 		c++;
 	}
-	e = br.pos();
+	e = p;
 }
 
 // Fixed-point iteration over one tile starting at the true code boundary pos0.  On return every lane holds
@@ -192,38 +233,66 @@ __device__ __forceinline__ void spec_parse(const GraphDev &g, const WindowSrc &s
 template <bool DEF, int KIND, int NW>
 __device__ __forceinline__ void spec_tile(const Grp<NW> &G, const GraphDev &g, const WindowSrc &src, uint64_t pos0, uint64_t secEnd, uint32_t B, bool firstTile,
                                           int64_t needCodes, uint64_t &s, uint32_t &c, int64_t &sum, uint64_t &E) {
-	const int tid = G.tid();
+	const int tid = G.tid(), lane = G.lane();
 	const uint64_t segEnd = min(pos0 + (uint64_t)(tid + 1) * B, secEnd);
 	s = min(pos0 + (uint64_t)tid * B, secEnd);
 	uint64_t e = s;
 	bool dirty = true;
-	for (int round = 0; round < Grp<NW>::N + 2; round++) {
-		if (dirty) {
-			spec_parse<DEF, KIND>(g, src, s, segEnd, firstTile && tid == 0, e, c, sum);
-			// a parse that runs past the section end is wrong anyway; clamping keeps the lanes behind the end
-			// quiet instead of handing the overshoot down one lane per round
-			e = min(e, secEnd);
+	int rounds = 0;
+	// Fixed point inside one wave, with `waveStart` as lane 0's start: no barrier, only shuffles.
+	auto wave_rounds = [&](uint64_t waveStart) {
+		for (int round = 0; round < 66; round++) {
+			if (dirty) {
+				spec_parse<DEF, KIND>(g, src, s, segEnd, firstTile && tid == 0, e, c, sum);
+				// a parse that runs past the section end is wrong anyway; clamping keeps the lanes behind the
+				// end quiet instead of handing the overshoot down one lane per round
+				e = min(e, secEnd);
+			}
+			uint64_t ns = shfl_up_u64(e, 1);
+			if (lane == 0) ns = waveStart;
+			dirty = ns != s;
+			s = ns;
+			rounds++;
+			bool stop = !__any(dirty);
+			if (!stop && KIND == 1 && NW == 1) {
+				// The section ends after needCodes codes, somewhere inside the tile: lanes past that point
+				// parse the NEXT section's bits as gamma codes and need not converge.  The clean prefix of
+				// lanes is exact, so it suffices that the lanes before the one reaching needCodes are clean.
+				const int firstDirty = __ffsll((long long)__ballot(dirty)) - 1; // >= 1: lane 0 is never dirty
+				const int64_t cincl = wave_incl_scan_i64((int64_t)c);
+				stop = shfl_i64(cincl, firstDirty - 1) >= needCodes;
+			}
+			if (stop) break;
 		}
-		const uint64_t ns = G.prev(e, pos0);
-		dirty = ns != s;
-		s = ns;
-		bool stop = !G.any(dirty);
-		if (!stop && KIND == 1) {
-			// The section ends after needCodes codes, somewhere inside the tile: lanes past that point parse
-			// the NEXT section's bits as gamma codes and need not converge.  The clean prefix of lanes is
-			// exact, so it suffices that the lanes before the one reaching needCodes are clean.
-			const int firstDirty = G.first_set(dirty); // >= 1: lane 0 is never dirty
-			int64_t tot;
-			const int64_t cincl = G.incl_scan((int64_t)c, tot);
-			const int64_t upto = G.bcast(cincl, firstDirty - 1);
-			stop = upto >= needCodes;
-		}
-		if (stop) {
-			stat_add(g, KIND == 0 ? 1 : 3, (unsigned long long)round + 1);
-			if (g.stats && KIND == 0) { const int rr = round + 1; stat_add(g, 8 + (rr <= 2 ? 0 : rr <= 4 ? 1 : rr <= 8 ? 2 : rr <= 16 ? 3 : rr <= 32 ? 4 : rr <= 64 ? 5 : 6), 1); }
-			break;
+	};
+	if (NW == 1) wave_rounds(pos0);
+	else {
+		// Several waves: every wave first converges on its own from a guessed start (its nominal segment
+		// boundary), then the waves exchange end positions; a wave whose start moved re-converges (usually only
+		// its first lanes re-parse).  Barriers only per exchange, not per round.
+		uint64_t waveStart = G.wave() == 0 ? pos0 : s; // s of lane 0 = nominal boundary
+		waveStart = (uint64_t)__shfl((long long)waveStart, 0, 64);
+		wave_rounds(waveStart);
+		for (int xr = 0; xr < NW + 1; xr++) {
+			if (lane == 63) G.xch[G.wave()] = (int64_t)e;
+			__syncthreads();
+			const uint64_t ns = G.wave() == 0 ? pos0 : (uint64_t)G.xch[G.wave() - 1];
+			const bool changed = ns != waveStart;
+			__syncthreads();
+			bool stop = !__syncthreads_or(changed);
+			if (!stop && KIND == 1) {
+				// waves before the first changed one are final; enough if they already hold needCodes codes
+				const int firstChanged = G.first_set(changed) >> 6; // wave index, >= 1
+				int64_t tot;
+				const int64_t cincl = G.incl_scan((int64_t)c, tot);
+				stop = G.bcast(cincl, firstChanged * 64 - 1) >= needCodes;
+			}
+			if (stop) break;
+			if (changed) { waveStart = ns; if (lane == 0) { dirty = true; s = ns; } wave_rounds(waveStart); }
 		}
 	}
+	stat_add(g, KIND == 0 ? 1 : 3, (unsigned long long)rounds);
+	if (g.stats && KIND == 0) { const int rr = rounds; stat_add(g, 8 + (rr <= 2 ? 0 : rr <= 4 ? 1 : rr <= 8 ? 2 : rr <= 16 ? 3 : rr <= 32 ? 4 : rr <= 64 ? 5 : 6), 1); }
 	stat_add(g, KIND == 0 ? 0 : 2, 1);
 	E = (uint64_t)G.bcast((int64_t)e, Grp<NW>::N - 1);
 }
@@ -255,27 +324,25 @@ __device__ __forceinline__ void coop_intervals(const Grp<NW> &G, const GraphDev 
 		int64_t dcur = 0, dp = 0;
 		uint64_t myEnd = s;
 		{
-			WinReader br; br.init_src(src, g.nwords);
-			if (c) br.seek(s);
+			uint64_t p = s;
 			for (uint32_t k = 0; k < c; k++) {
 				const int64_t q = codesDone + cb + k;
-				const uint64_t v = br.gamma();
+				const uint64_t v = win_code<DEF, 1>(g, src, p, err);
 				if (q & 1) { const int64_t len = (int64_t)v + g.minInt; dcur += len; dp += len; }
 				else dcur += q == 0 ? nat2int(v) : (int64_t)v + 1;
 			}
-			if (c) myEnd = br.pos();
-			err |= br.err;
+			myEnd = p;
 		}
 		int64_t curTot, pTot;
 		const int64_t icur = G.incl_scan(dcur, curTot), ip = G.incl_scan(dp, pTot);
 		int64_t cur = cursor + icur - dcur, pc = pcount + ip - dp;
 		// pass 2: write the entries
 		{
-			WinReader br; br.init_src(src, g.nwords);
-			if (c) br.seek(s);
+			uint64_t p = s;
+			int e2 = 0;
 			for (uint32_t k = 0; k < c; k++) {
 				const int64_t q = codesDone + cb + k;
-				const uint64_t v = br.gamma();
+				const uint64_t v = win_code<DEF, 1>(g, src, p, e2);
 				if (q & 1) { const int64_t len = (int64_t)v + g.minInt; list[q >> 1].pstart = (int32_t)pc; list[q >> 1].len = (int32_t)len; cur += len; pc += len; }
 				else { cur += q == 0 ? nat2int(v) : (int64_t)v + 1; list[q >> 1].left = (int32_t)cur; }
 			}
@@ -308,7 +375,7 @@ __device__ __forceinline__ void coop_residuals(const Grp<NW> &G, const GraphDev 
 	bool firstTile = true;
 	const uint32_t B = coop_pick_B(recEnd > pos ? recEnd - pos : 0, (uint64_t)nRes, CoopCfg<NW>::B_MAX); // the residual section ends with the record
 	unsigned long long tk = g.stats ? __builtin_readcyclecounter() : 0;
-#define RT(slot) do { if (g.stats && NW == 1) { const unsigned long long now_ = __builtin_readcyclecounter(); if (tid == 0) atomicAdd(&g.stats[24 + slot], now_ - tk); tk = now_; } } while (0)
+#define RT(slot) do { if (g.stats && NW != 1) { const unsigned long long now_ = __builtin_readcyclecounter(); if (tid == 0) atomicAdd(&g.stats[24 + slot], now_ - tk); tk = now_; } } while (0)
 	while (resDone < nRes) {
 		RT(7);
 		const WindowSrc src = stage_tile<NW>(G, g, win, pos, B);
@@ -332,15 +399,13 @@ __device__ __forceinline__ void coop_residuals(const Grp<NW> &G, const GraphDev 
 		int64_t val = baseVal + sincl - sum;
 		uint64_t myEnd = s;
 		{
-			WinReader br; br.init_src(src, g.nwords);
-			if (c) br.seek(s);
+			uint64_t p = s;
 			for (uint32_t k = 0; k < c; k++) {
-				const uint64_t v = Fields<DEF>::residual(br, g);
+				const uint64_t v = win_code<DEF, 0>(g, src, p, err);
 				val += (firstTile && tid == 0 && k == 0) ? nat2int(v) : (int64_t)v + 1; // BVG:954, :966
 				resv[cb + k] = (int32_t)val;
 			}
-			if (c) myEnd = br.pos();
-			err |= br.err;
+			myEnd = p;
 		}
 		const int lastTid = G.last_set(c > 0);
 		const int64_t lastVal = G.bcast(val, lastTid);

@@ -25,6 +25,8 @@ constexpr int GIANT_NW = 8; // waves per giant record
 
 template <bool DEF>
 __device__ __forceinline__ void copy_node(const GraphDev &g, int32_t x, int32_t d, int64_t dref, int32_t *__restrict__ row, const int32_t *__restrict__ src, int *__restrict__ err);
+template <bool DEF>
+__device__ __forceinline__ void parse_node(const GraphDev &g, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row, int *__restrict__ err);
 
 // ------------------------------------------------------------------------------------------------ headers
 template <bool DEF>
@@ -288,7 +290,7 @@ __global__ void __launch_bounds__(TPB) k_depth_keys(GraphDev g, int32_t lo, int3
 			const uint64_t bitsLen = (uint64_t)(g.offsets[lo + s + 1] - g.offsets[lo + s]);
 			const uint64_t work = max(bitsLen, (uint64_t)outd[s] * 8);
 			if (work >= giantBits) key = KEY_GIANT;
-			else key = (uint16_t)(min(dd, MAXLVL - 1) * NBIN + (noBin ? 0 : record_bin(work)));
+			else key = (uint16_t)(((noBin & 2) ? 0 : min(dd, MAXLVL - 1)) * NBIN + ((noBin & 1) ? 0 : record_bin(work))); // noBin: bit 0 = ignore the length, bit 1 = ignore the level
 			atomicAdd(&s_hist[key == KEY_GIANT ? NKEYS : key], 1);
 			if (dd >= MAXLVL - 1 && dd > __builtin_nontemporal_load(maxdepth)) atomicMax(maxdepth, dd); // only very deep chains get here
 		}
@@ -384,6 +386,20 @@ __global__ void __launch_bounds__(TPB) k_copy_list(GraphDev g, RangeView v, cons
 		if (r == 0) continue;
 		if (s >= v.nh && (uint64_t)(v.rowstart[s + 1] - v.rowstart[v.nh]) > v.succ_cap) continue; // E_CAP already raised
 		copy_node<DEF>(g, v.lo + s, v.outd[s], (int64_t)v.outd[s - r], v.row(s), v.row(s - r), err);
+	}
+}
+
+// parse pass over a list sorted by work bin only (all chain levels together): 64 records of similar length per wave
+template <bool DEF>
+__global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, const int32_t *__restrict__ list, const int32_t *__restrict__ keyBase, int *__restrict__ err) {
+	const int32_t lo = keyBase[0], hi = keyBase[NBIN];
+	for (int32_t idx = hi - 1 - (blockIdx.x * TPB + threadIdx.x); idx >= lo; idx -= gridDim.x * TPB) {
+		const int32_t s = list[idx];
+		const int32_t d = v.outd[s];
+		if (d >= v.coop_min) continue; // decoded by whole waves (k_parse_big)
+		const int32_t r = v.ref[s];
+		if (s >= v.nh && (uint64_t)(v.rowstart[s + 1] - v.rowstart[v.nh]) > v.succ_cap) { atomicOr(err, E_CAP); continue; }
+		parse_node<DEF>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), err);
 	}
 }
 
@@ -762,6 +778,12 @@ void launch_copy_list(const GraphDev &g, bool def, const RangeView &v, const int
 	if (v.cnt <= 0) return;
 	if (def) hipLaunchKernelGGL(k_copy_list<true>, dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, err);
 	else hipLaunchKernelGGL(k_copy_list<false>, dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, err);
+}
+
+void launch_parse_list(const GraphDev &g, bool def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st) {
+	if (v.cnt <= 0) return;
+	if (def) hipLaunchKernelGGL(k_parse_list<true>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, err);
+	else hipLaunchKernelGGL(k_parse_list<false>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, err);
 }
 
 } // namespace bv

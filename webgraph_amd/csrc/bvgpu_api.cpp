@@ -84,8 +84,10 @@ struct bvg_graph {
 	int no_bin = 0;
 	int fused = 0; // BVGPU_PATH=fused: level-by-level single-pass decode (bv_lane.hpp); default: parse all, then copy level by level
 	DevBuf lvlist;
-	int copy_lists = 0; // BVGPU_COPY_LISTS=1: copy pass over per-level compact lists instead of node-order sweeps
-	int32_t coop_min = 256, giant_min = 8192;                         // thresholds on the outdegree (BVGPU_COOP_MIN / BVGPU_GIANT_MIN)
+	int parse_lists = 1; // BVGPU_PARSE_LISTS=0: short records parsed in node order instead of by work bin
+	DevBuf plist, pkeys, pkey16;
+	int copy_lists = 1; // BVGPU_COPY_LISTS=0: node-order sweeps over all slots instead of per-level compact lists
+	int32_t coop_min = 1024, giant_min = 8192;                         // thresholds on the outdegree (BVGPU_COOP_MIN / BVGPU_GIANT_MIN)
 	int coop_waves = 4096, giant_groups = 256;
 	DevBuf stats; // BVGPU_STATS=1: tuning counters
 	// the three parse kernels (giant / big / short records) are independent: they run on forked streams
@@ -154,6 +156,7 @@ int init_handle(bvg_graph *g) {
 	if (const char *e = getenv("BVGPU_NOBIN")) g->no_bin = atoi(e);
 	if (const char *e = getenv("BVGPU_PATH")) g->fused = strcmp(e, "fused") == 0;
 	if (const char *e = getenv("BVGPU_COPY_LISTS")) g->copy_lists = atoi(e);
+	if (const char *e = getenv("BVGPU_PARSE_LISTS")) g->parse_lists = atoi(e);
 	if (const char *e = getenv("BVGPU_OVERLAP")) g->overlap = atoi(e) != 0;
 	HIPCHK(g, hipStreamCreateWithFlags(&g->sideA, hipStreamNonBlocking));
 	HIPCHK(g, hipStreamCreateWithFlags(&g->sideB, hipStreamNonBlocking));
@@ -293,8 +296,19 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 		int32_t *hist = g->keys.as<int32_t>(), *keyBase = hist + (bv::NKEYS + 1), *cursor = keyBase + (bv::NKEYS + 1);
 		int32_t *ctl = g->coopctl.as<int32_t>();
 		HIPCHK(g, hipMemsetAsync(ctl, 0, 8 * sizeof(int32_t), g->stream));
-		if (W > 0) bv::launch_build_lists(gd, v, ~0ull, g->no_bin, g->depth.as<int32_t>(), g->key16.as<uint16_t>(), hist, keyBase, cursor, g->lvlist.as<int32_t>(),
+		// chain depth of every record (+ per-level lists, node order inside a level)
+		if (W > 0) bv::launch_build_lists(gd, v, ~0ull, 1, g->depth.as<int32_t>(), g->key16.as<uint16_t>(), hist, keyBase, cursor, g->lvlist.as<int32_t>(),
 		                                  g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->maxdepth, g->stream);
+		// parse list: every non-empty record, sorted by work bin only
+		int32_t *pKeyBase = nullptr;
+		if (g->parse_lists) {
+			if (!g->plist.need(sizeof(int32_t) * (size_t)v.cnt) || !g->pkeys.need(3 * (bv::NKEYS + 1) * sizeof(int32_t)) || !g->pkey16.need(sizeof(uint16_t) * (size_t)v.cnt)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
+			int32_t *ph = g->pkeys.as<int32_t>();
+			pKeyBase = ph + (bv::NKEYS + 1);
+			// depth output of this second build is not needed: it goes to the (not yet used) big list buffer
+			bv::launch_build_lists(gd, v, ~0ull, 2, g->biglist.as<int32_t>(), g->pkey16.as<uint16_t>(), ph, pKeyBase, pKeyBase + (bv::NKEYS + 1), g->plist.as<int32_t>(),
+			                       g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->pad, g->stream);
+		}
 		mark(g, 3);
 		const bool coop = g->coop_min < 0x7fffffff;
 		v.coop_min = coop ? g->coop_min : 0x7fffffff;
@@ -311,7 +325,8 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 			} else
 				bv::launch_parse_big(gd, s.def, v, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, g->giant_groups, derr, g->stream, g->stream);
 		}
-		bv::launch_parse(gd, s.def, v, derr, g->stream);
+		if (pKeyBase) bv::launch_parse_list(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, g->level_blocks, derr, g->stream);
+		else bv::launch_parse(gd, s.def, v, derr, g->stream);
 		if (coop && g->overlap) {
 			HIPCHK(g, hipStreamWaitEvent(g->stream, g->evA, 0));
 			HIPCHK(g, hipStreamWaitEvent(g->stream, g->evB, 0));
@@ -449,7 +464,7 @@ extern "C" int bvg_close(bvg_t *g) {
 	if (g->st && g->st->device >= 0) {
 		(void)hipSetDevice(g->st->device);
 		if (g->own) { (void)hipStreamSynchronize(g->own); (void)hipStreamDestroy(g->own); }
-		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist }) b->release();
+		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist, &g->plist, &g->pkeys, &g->pkey16 }) b->release();
 		if (g->h_small) (void)hipHostFree(g->h_small);
 		for (auto &e : g->ev) if (e) (void)hipEventDestroy(e);
 		for (hipEvent_t e : { g->evFork, g->evA, g->evB }) if (e) (void)hipEventDestroy(e);
