@@ -29,13 +29,13 @@ namespace bv {
 constexpr int COOP_B_MIN = 64, COOP_CODES_PER_SEG = 12;
 
 template <int NW> struct CoopCfg;
-template <> struct CoopCfg<1> { static constexpr int N = 64, B_MAX = 512, CAPT = 1024; };
-template <> struct CoopCfg<8> { static constexpr int N = 512, B_MAX = 128, CAPT = 4096; };
+template <> struct CoopCfg<1> { static constexpr int N = 64, B_MAX = 1024, IVCAP = 1024; };
+template <> struct CoopCfg<8> { static constexpr int N = 512, B_MAX = 512, IVCAP = 4096; };
 
 template <int NW> struct CoopLds { // LDS layout of one group, in 32-bit words
 	static constexpr int WIN_WORDS = CoopCfg<NW>::N * CoopCfg<NW>::B_MAX / 32 + 12; // staged tile bits (+ alignment and look-ahead slack), multiple of 4
 	static constexpr int XCH_WORDS = 2 * (NW + 8);                                   // int64 exchange slots
-	static constexpr int OFF_WIN = 0, OFF_RESV = WIN_WORDS, OFF_DELTA = OFF_RESV + CoopCfg<NW>::CAPT, OFF_XCH = ((OFF_DELTA + CoopCfg<NW>::CAPT + 1) & ~1);
+	static constexpr int OFF_WIN = 0, OFF_IVL = WIN_WORDS, OFF_XCH = ((OFF_IVL + 2 * (CoopCfg<NW>::IVCAP + 1) + 1) & ~1); // staged intervals: left[], pstart[]
 	static constexpr int WORDS = OFF_XCH + XCH_WORDS;
 };
 
@@ -132,9 +132,13 @@ template <int NW> struct Grp {
 	}
 };
 
-__device__ __forceinline__ uint32_t coop_pick_B(uint64_t sectionBits, uint64_t codes, uint32_t bmax) {
+// Segment width: at least ~COOP_CODES_PER_SEG codes (so that speculative parses re-synchronise inside their
+// segment), and wide enough to spread the whole section over the group's lanes in one tile when it fits:
+// fewer, longer segments need fewer rounds of the fixed-point loop per code.
+__device__ __forceinline__ uint32_t coop_pick_B(uint64_t sectionBits, uint64_t codes, uint32_t lanes, uint32_t bmax) {
 	const uint64_t avg = (sectionBits + codes - 1) / (codes ? codes : 1);
-	uint64_t b = (avg * COOP_CODES_PER_SEG + 31) & ~(uint64_t)31;
+	uint64_t b = max(avg * COOP_CODES_PER_SEG, (sectionBits + lanes - 1) / lanes);
+	b = (b + 31) & ~(uint64_t)31;
 	return (uint32_t)(b < COOP_B_MIN ? COOP_B_MIN : b > bmax ? bmax : b);
 }
 
@@ -265,6 +269,7 @@ __device__ __forceinline__ void spec_tile(const Grp<NW> &G, const GraphDev &g, c
 			if (stop) break;
 		}
 	};
+	unsigned long long tk0 = (g.stats && NW != 1 && KIND == 0) ? __builtin_readcyclecounter() : 0;
 	if (NW == 1) wave_rounds(pos0);
 	else {
 		// Several waves: every wave first converges on its own from a guessed start (its nominal segment
@@ -273,6 +278,7 @@ __device__ __forceinline__ void spec_tile(const Grp<NW> &G, const GraphDev &g, c
 		uint64_t waveStart = G.wave() == 0 ? pos0 : s; // s of lane 0 = nominal boundary
 		waveStart = (uint64_t)__shfl((long long)waveStart, 0, 64);
 		wave_rounds(waveStart);
+		if (g.stats && KIND == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); if (tid == 0) { atomicAdd(&g.stats[12], now_ - tk0); atomicAdd(&g.stats[13], (unsigned long long)rounds); } tk0 = now_; }
 		for (int xr = 0; xr < NW + 1; xr++) {
 			if (lane == 63) G.xch[G.wave()] = (int64_t)e;
 			__syncthreads();
@@ -289,10 +295,11 @@ __device__ __forceinline__ void spec_tile(const Grp<NW> &G, const GraphDev &g, c
 			}
 			if (stop) break;
 			if (changed) { waveStart = ns; if (lane == 0) { dirty = true; s = ns; } wave_rounds(waveStart); }
+			if (g.stats && KIND == 0 && tid == 0) atomicAdd(&g.stats[10], 1);
 		}
+		if (g.stats && KIND == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); if (tid == 0) { atomicAdd(&g.stats[14], now_ - tk0); atomicAdd(&g.stats[11], 1); } }
 	}
 	stat_add(g, KIND == 0 ? 1 : 3, (unsigned long long)rounds);
-	if (g.stats && KIND == 0) { const int rr = rounds; stat_add(g, 8 + (rr <= 2 ? 0 : rr <= 4 ? 1 : rr <= 8 ? 2 : rr <= 16 ? 3 : rr <= 32 ? 4 : rr <= 64 ? 5 : 6), 1); }
 	stat_add(g, KIND == 0 ? 0 : 2, 1);
 	E = (uint64_t)G.bcast((int64_t)e, Grp<NW>::N - 1);
 }
@@ -360,20 +367,23 @@ __device__ __forceinline__ void coop_intervals(const Grp<NW> &G, const GraphDev 
 }
 
 // ---------------------------------------------------------------------------------------------- phases R + X
-// out = row + copied.
+// out = row + copied.  Residual j (0-based in the section) goes to out[j + (arcs of the intervals whose left
+// extreme is smaller)], interval i to out[pstart_i + rank_i ..) where rank_i = residuals smaller than its left.
+// Every lane decodes the run of residuals it owns and walks the (sorted) interval list alongside: it adds up
+// the arcs of the intervals it passes and tells each of them its rank.  The intervals relevant to a tile are
+// staged in LDS first (they are a contiguous slice of the list).
 template <bool DEF, int NW>
 __device__ __forceinline__ void coop_residuals(const Grp<NW> &G, const GraphDev &g, int32_t x, uint64_t pos, uint64_t recEnd, int64_t nRes, int64_t ic, int64_t intervalArcs,
                                                IvEntry *__restrict__ list, int32_t *__restrict__ out, uint32_t *lds, int &err) {
-	constexpr int N = Grp<NW>::N, CAPT = CoopCfg<NW>::CAPT;
+	constexpr int N = Grp<NW>::N, IVCAP = CoopCfg<NW>::IVCAP;
 	const int tid = G.tid();
 	uint32_t *win = lds + CoopLds<NW>::OFF_WIN;
-	int32_t *resv = (int32_t *)lds + CoopLds<NW>::OFF_RESV, *delta = (int32_t *)lds + CoopLds<NW>::OFF_DELTA;
+	int32_t *ivLeft = (int32_t *)lds + CoopLds<NW>::OFF_IVL, *ivP = ivLeft + (IVCAP + 1);
 	int64_t resDone = 0;       // residuals written so far (uniform)
 	int64_t baseVal = x;       // previous residual (BVG:954: the first one is x + nat2int(code))
-	int64_t ia = 0;            // first interval not yet ranked
-	int64_t elemsBefore = 0;   // arcs of the intervals [0, ia)
+	int64_t ia = 0;            // first interval not yet ranked (uniform)
 	bool firstTile = true;
-	const uint32_t B = coop_pick_B(recEnd > pos ? recEnd - pos : 0, (uint64_t)nRes, CoopCfg<NW>::B_MAX); // the residual section ends with the record
+	const uint32_t B = coop_pick_B(recEnd > pos ? recEnd - pos : 0, (uint64_t)nRes, N, CoopCfg<NW>::B_MAX); // the residual section ends with the record
 	unsigned long long tk = g.stats ? __builtin_readcyclecounter() : 0;
 #define RT(slot) do { if (g.stats && NW != 1) { const unsigned long long now_ = __builtin_readcyclecounter(); if (tid == 0) atomicAdd(&g.stats[24 + slot], now_ - tk); tk = now_; } } while (0)
 	while (resDone < nRes) {
@@ -383,79 +393,73 @@ __device__ __forceinline__ void coop_residuals(const Grp<NW> &G, const GraphDev 
 		uint64_t s, E; uint32_t c; int64_t sum;
 		spec_tile<DEF, 0, NW>(G, g, src, pos, recEnd, B, firstTile, nRes - resDone, s, c, sum, E);
 		RT(1);
-		// take at most CAPT residuals, and no more than the section still has
+		// no more codes than the section still has
 		int64_t tileTotal;
 		const int64_t cincl = G.incl_scan((int64_t)c, tileTotal);
 		const int64_t cb = cincl - c;
-		const int64_t lim = min<int64_t>(nRes - resDone, CAPT);
-		bool cut = false;
-		if (cb >= lim) { cut = c > 0; c = 0; } else if (cb + c > lim) { c = (uint32_t)(lim - cb); cut = true; }
-		const bool anyCut = G.any(cut);
+		const int64_t lim = nRes - resDone;
+		if (cb >= lim) c = 0; else if (cb + c > lim) c = (uint32_t)(lim - cb);
+		const bool lastTile = tileTotal >= lim;
 		const int64_t T = min(lim, tileTotal);
 		if (T <= 0) { err |= E_FORMAT; break; }
-		// absolute values of my residuals -> LDS
 		int64_t sumTot;
 		const int64_t sincl = G.incl_scan(sum, sumTot);
-		int64_t val = baseVal + sincl - sum;
-		uint64_t myEnd = s;
+		int64_t val = baseVal + sincl - sum; // the residual before my first one (x for the very first lane)
+		// ---- stage the intervals that can fall among this tile's residuals: [ia, first left >= last value)
+		int64_t staged = 0;
+		if (ic > ia) {
+			const int64_t hiVal = lastTile ? INT64_MAX : baseVal + sumTot;
+			for (int64_t base = 0; base < IVCAP; base += N) {
+				const int64_t i = ia + base + tid;
+				const bool valid = i < ic && base + tid < IVCAP;
+				int32_t l = 0x7fffffff, pp = (int32_t)intervalArcs;
+				if (valid) { l = list[i].left; pp = list[i].pstart; }
+				if (base + tid < IVCAP) { ivLeft[base + tid] = l; ivP[base + tid] = pp; }
+				int64_t nt;
+				(void)G.incl_scan(valid && (int64_t)l < hiVal ? 1 : 0, nt);
+				staged = min<int64_t>(base + N, IVCAP);
+				if (nt < N) break;
+			}
+			staged = min(staged, ic - ia);
+			G.sync();
+		}
+		auto iv_left = [&](int64_t i) -> int64_t { const int64_t o = i - ia; return o < staged ? (int64_t)ivLeft[o] : (int64_t)list[i].left; };
+		auto iv_p = [&](int64_t i) -> int64_t { if (i >= ic) return intervalArcs; const int64_t o = i - ia; return o < staged ? (int64_t)ivP[o] : (int64_t)list[i].pstart; };
+		RT(2);
+		// ---- my run of residuals, merged with the interval list
+		int64_t i = ia;
+		if (c && ic > ia && !(firstTile && tid == 0)) { // first interval with left > val (the residual before mine)
+			int64_t lo = ia, hi = ic;
+			while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (iv_left(mid) < val) lo = mid + 1; else hi = mid; }
+			i = lo;
+		}
 		{
 			uint64_t p = s;
+			int64_t j = resDone + cb;
+			int64_t arcsBefore = ic ? iv_p(i) : 0;
 			for (uint32_t k = 0; k < c; k++) {
 				const uint64_t v = win_code<DEF, 0>(g, src, p, err);
 				val += (firstTile && tid == 0 && k == 0) ? nat2int(v) : (int64_t)v + 1; // BVG:954, :966
-				resv[cb + k] = (int32_t)val;
+				if (ic) {
+					bool moved = false;
+					while (i < ic && iv_left(i) < val) { list[i].rank = (int32_t)j; i++; moved = true; } // interval i sits after j residuals
+					if (moved) arcsBefore = iv_p(i);
+				}
+				out[j + arcsBefore] = (int32_t)val;
+				j++;
 			}
-			myEnd = p;
+			if (c == 0) i = 0;
 		}
+		RT(3);
 		const int lastTid = G.last_set(c > 0);
 		const int64_t lastVal = G.bcast(val, lastTid);
-		const uint64_t nextPos = anyCut ? (uint64_t)G.bcast((int64_t)myEnd, lastTid) : E;
-		G.sync();
-		RT(2);
-
-		if (ic > 0) {
-			// Rank the intervals whose left extreme precedes this tile's last residual: interval i sits after
-			// `lo` of the tile's residuals.  delta[lo] collects the arcs inserted in front of residual lo.
-			for (int64_t t = tid; t < T; t += N) delta[t] = 0;
-			G.sync();
-			for (;;) {
-				const int64_t i = ia + tid;
-				bool take = false; int32_t left = 0, len = 0;
-				if (i < ic) { left = list[i].left; len = list[i].len; take = (int64_t)left < lastVal; }
-				if (take) {
-					int64_t lo = 0, hi = T; // lower_bound(resv[0..T), left)
-					while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (resv[mid] < left) lo = mid + 1; else hi = mid; }
-					list[i].rank = (int32_t)(resDone + lo);
-					atomicAdd(&delta[lo], len); // lo < T because left < resv[T-1]
-				}
-				int64_t nt;
-				(void)G.incl_scan(take ? 1 : 0, nt); // lefts increase: the taken ones are a prefix of the group
-				ia += nt;
-				if (nt < N) break;
-			}
-			const int64_t pNow = ia < ic ? (int64_t)list[ia].pstart : intervalArcs;
-			G.sync();
-			RT(3);
-			// residual t of the tile goes after the arcs of earlier tiles' intervals and after those of this
-			// tile's intervals ranked <= t  (inclusive scan of delta)
-			int64_t carry = 0;
-			for (int64_t t0 = 0; t0 < T; t0 += N) {
-				const int64_t t = t0 + tid;
-				const int64_t dv = t < T ? delta[t] : 0;
-				int64_t tot;
-				const int64_t inc = G.incl_scan(dv, tot);
-				if (t < T) out[resDone + t + elemsBefore + carry + inc] = resv[t];
-				carry += tot;
-			}
-			elemsBefore = pNow;
-		} else {
-			for (int64_t t = tid; t < T; t += N) out[resDone + t] = resv[t];
-		}
-		RT(4);
+		ia = G.bcast(i, lastTid); // everything before it has been ranked
+		G.sync(); // staged intervals / window are reused by the next tile
 		resDone += T;
 		baseVal = lastVal;
-		pos = nextPos;
+		pos = E; // a cut only happens on the last tile
 		firstTile = false;
+		RT(4);
 	}
 	if (ic == 0) return;
 	G.sync_global(); // ranks written above are read by other lanes below
@@ -469,10 +473,10 @@ __device__ __forceinline__ void coop_residuals(const Grp<NW> &G, const GraphDev 
 		if (!isLong) for (int32_t t = 0; t < len; t++) out[p + t] = left + t;
 		unsigned long long lm = __ballot(isLong);
 		while (lm) { // long intervals: a whole wave fills one at a time
-			const int src = __ffsll((long long)lm) - 1;
+			const int srcl = __ffsll((long long)lm) - 1;
 			lm &= lm - 1;
-			const int32_t L = __shfl(left, src, 64), Nn = __shfl(len, src, 64);
-			const int64_t P = shfl_i64(p, src);
+			const int32_t L = __shfl(left, srcl, 64), Nn = __shfl(len, srcl, 64);
+			const int64_t P = shfl_i64(p, srcl);
 			for (int32_t t = G.lane(); t < Nn; t += 64) out[P + t] = L + t;
 		}
 	}
@@ -525,8 +529,11 @@ __device__ __forceinline__ void coop_parse_node(const GraphDev &g, int32_t x, in
 		pos = br.pos();
 		if (br.err || ic > extra / g.minInt) { if (tid == 0) atomicOr(errOut, E_FORMAT | br.err); return; }
 		if (ic) {
-			// codes left in the record: 2 per interval + at most extra - ic*minInt residuals -> lower bound of the mean code length
-			const uint32_t B = coop_pick_B(recEnd > pos ? recEnd - pos : 0, (uint64_t)(2 * ic + (extra - ic * g.minInt)), CoopCfg<NW>::B_MAX);
+			// codes left in the record: 2 per interval + at most extra - ic*minInt residuals -> lower bound of the
+			// mean code length; the interval section itself is estimated as 2*ic codes of that length
+			const uint64_t restBits = recEnd > pos ? recEnd - pos : 0, restCodes = (uint64_t)(2 * ic + (extra - ic * g.minInt));
+			const uint64_t secEst = min(restBits, (restBits * (uint64_t)(2 * ic) + restCodes - 1) / restCodes * 2); // x2: interval gaps are longer than residual gaps
+			const uint32_t B = coop_pick_B(secEst, (uint64_t)(2 * ic), Grp<NW>::N, CoopCfg<NW>::B_MAX);
 			coop_intervals<DEF, NW>(G, g, x, pos, recEnd, ic, B, list, lds, pos, intervalArcs, err);
 			if (G.any(err != 0)) { if (err) atomicOr(errOut, err); return; } // group-uniform exit
 		}

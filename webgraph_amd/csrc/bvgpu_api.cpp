@@ -87,7 +87,7 @@ struct bvg_graph {
 	int parse_lists = 1; // BVGPU_PARSE_LISTS=0: short records parsed in node order instead of by work bin
 	DevBuf plist, pkeys, pkey16;
 	int copy_lists = 1; // BVGPU_COPY_LISTS=0: node-order sweeps over all slots instead of per-level compact lists
-	int32_t coop_min = 1024, giant_min = 8192;                         // thresholds on the outdegree (BVGPU_COOP_MIN / BVGPU_GIANT_MIN)
+	int32_t coop_min = 2048, giant_min = 8192;                         // thresholds on the outdegree (BVGPU_COOP_MIN / BVGPU_GIANT_MIN)
 	int coop_waves = 4096, giant_groups = 256;
 	DevBuf stats; // BVGPU_STATS=1: tuning counters
 	// the three parse kernels (giant / big / short records) are independent: they run on forked streams
