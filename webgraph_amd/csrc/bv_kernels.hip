@@ -373,10 +373,13 @@ __global__ void __launch_bounds__(64) k_copy_giants(GraphDev g, RangeView v, con
 	copy_node<DEF>(g, v.lo + s, v.outd[s], (int64_t)v.outd[s - r], v.row(s), v.row(s - r), err);
 }
 
-// copy pass over the compact list of one chain level (longest records first)
+// copy pass over the compact list of one chain level.  Rows with >= COPY_BIG_MIN successors are not merged by
+// one lane (that would be the tail of the whole scan): they are queued for k_copy_big.
+constexpr int COPY_BIG_MIN = 1024;
 template <bool DEF>
 __global__ void __launch_bounds__(TPB) k_copy_list(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ list,
-                                                   const int32_t *__restrict__ keyBase, int32_t level, int *__restrict__ err) {
+                                                   const int32_t *__restrict__ keyBase, int32_t level, int32_t *__restrict__ bigQueue, int32_t *__restrict__ bigCount,
+                                                   int32_t bigCap, int *__restrict__ err) {
 	const int32_t bucket = min(level, MAXLVL - 1);
 	const int32_t lo = keyBase[bucket * NBIN], hi = keyBase[(bucket + 1) * NBIN];
 	for (int32_t idx = hi - 1 - (blockIdx.x * TPB + threadIdx.x); idx >= lo; idx -= gridDim.x * TPB) {
@@ -385,7 +388,98 @@ __global__ void __launch_bounds__(TPB) k_copy_list(GraphDev g, RangeView v, cons
 		const int32_t r = v.ref[s];
 		if (r == 0) continue;
 		if (s >= v.nh && (uint64_t)(v.rowstart[s + 1] - v.rowstart[v.nh]) > v.succ_cap) continue; // E_CAP already raised
+		if (bigQueue && v.outd[s] >= COPY_BIG_MIN) {
+			const int32_t q = atomicAdd(bigCount, 1);
+			if (q < bigCap) { bigQueue[q] = s; continue; }
+		}
 		copy_node<DEF>(g, v.lo + s, v.outd[s], (int64_t)v.outd[s - r], v.row(s), v.row(s - r), err);
+	}
+}
+
+// One 1024-thread group per long row with a reference.  The copied ids (<= COPY_BIG_CAP of them) are gathered
+// into LDS and ranked among the row's extras by binary search; then the row is rebuilt in place chunk by chunk:
+// output position k holds copied id t if pos_t == k, else extra number k - #(copied positions before k), which
+// sits at or after k -- so reading a whole chunk before writing it never loses data (MergedIntIterator semantics
+// for the disjoint sets of a valid file).  Rows copying more than COPY_BIG_CAP ids fall back to one lane.
+constexpr int COPY_BIG_THREADS = 1024, COPY_BIG_CAP = 6144, COPY_BIG_ITEMS = 8;
+template <bool DEF>
+__global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, RangeView v, const int32_t *__restrict__ bigQueue, const int32_t *__restrict__ bigCount,
+                                                               int32_t bigCap, int *__restrict__ err) {
+	__shared__ int32_t cval[COPY_BIG_CAP], cpos[COPY_BIG_CAP];
+	const int32_t nq = min(*bigCount, bigCap);
+	for (int32_t qi = blockIdx.x; qi < nq; qi += gridDim.x) {
+		const int32_t s = bigQueue[qi];
+		const int32_t d = v.outd[s], r = v.ref[s];
+		const int64_t dref = v.outd[s - r];
+		int32_t *row = v.row(s);
+		const int32_t *src = v.row(s - r);
+		// header + block totals (uniform)
+		BitReader br;
+		br.init(g.bits, g.nwords);
+		br.seek((uint64_t)g.offsets[v.lo + s]);
+		(void)Fields<DEF>::outdegree(br, g);
+		(void)Fields<DEF>::reference(br, g);
+		const uint64_t bc = Fields<DEF>::block_count(br, g);
+		if (bc > (uint64_t)dref + 1) continue; // flagged by the parse kernel
+		const uint64_t blocksPos = br.pos();
+		int64_t total = 0, copied = 0;
+		for (uint64_t b = 0; b < bc; b++) {
+			const int64_t len = (int64_t)Fields<DEF>::block(br, g) + (b ? 1 : 0);
+			total += len;
+			if (!(b & 1)) copied += len;
+		}
+		if (total > dref) continue;
+		if (!(bc & 1)) copied += dref - total;
+		if (copied > d || copied == 0) continue; // nothing to merge: the extras already fill the row
+		if (copied > COPY_BIG_CAP) { // too many copied ids for the LDS tables: one lane does it
+			if (threadIdx.x == 0) copy_node<DEF>(g, v.lo + s, d, dref, row, src, err);
+			__syncthreads();
+			continue;
+		}
+		// gather the copied ids: blocks are walked by every thread, each thread loads the ids it owns
+		br.seek(blocksPos);
+		{
+			int64_t i = 0, o = 0;
+			for (uint64_t b = 0; b <= bc; b++) {
+				int64_t len;
+				if (b < bc) len = (int64_t)Fields<DEF>::block(br, g) + (b ? 1 : 0);
+				else len = dref - i; // implicit last block
+				if (!(b & 1)) { for (int64_t e = threadIdx.x; e < len; e += COPY_BIG_THREADS) cval[o + e] = src[i + e]; o += len; }
+				i += len;
+			}
+		}
+		__syncthreads();
+		// rank of every copied id among the extras row[copied .. d)
+		const int64_t nExtra = (int64_t)d - copied;
+		for (int64_t t = threadIdx.x; t < copied; t += COPY_BIG_THREADS) {
+			const int32_t cv = cval[t];
+			int64_t lo = 0, hi = nExtra;
+			while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (row[copied + mid] < cv) lo = mid + 1; else hi = mid; }
+			cpos[t] = (int32_t)(t + lo);
+		}
+		__syncthreads();
+		const int64_t lastPos = cpos[copied - 1]; // positions after it keep their extras
+		for (int64_t k0 = 0; k0 <= lastPos; k0 += (int64_t)COPY_BIG_THREADS * COPY_BIG_ITEMS) {
+			int32_t vals[COPY_BIG_ITEMS];
+#pragma unroll
+			for (int u = 0; u < COPY_BIG_ITEMS; u++) {
+				const int64_t k = k0 + (int64_t)u * COPY_BIG_THREADS + threadIdx.x;
+				vals[u] = 0;
+				if (k <= lastPos) {
+					int64_t lo = 0, hi = copied; // copied positions before k
+					while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (cpos[mid] < k) lo = mid + 1; else hi = mid; }
+					vals[u] = (lo < copied && cpos[lo] == k) ? cval[lo] : row[copied + (k - lo)];
+				}
+			}
+			__syncthreads(); // the whole chunk is in registers
+#pragma unroll
+			for (int u = 0; u < COPY_BIG_ITEMS; u++) {
+				const int64_t k = k0 + (int64_t)u * COPY_BIG_THREADS + threadIdx.x;
+				if (k <= lastPos) row[k] = vals[u];
+			}
+			__syncthreads();
+		}
+		if (br.err && threadIdx.x == 0) atomicOr(err, br.err);
 	}
 }
 
@@ -774,10 +868,13 @@ void launch_parse_giants(const GraphDev &g, bool def, const RangeView &v, const 
 }
 
 void launch_copy_list(const GraphDev &g, bool def, const RangeView &v, const int32_t *depth, const int32_t *list, const int32_t *keyBase, int32_t level, int blocks,
-                      int *err, hipStream_t st) {
+                      int32_t *bigQueue, int32_t *bigCount, int32_t bigCap, int *err, hipStream_t st) {
 	if (v.cnt <= 0) return;
-	if (def) hipLaunchKernelGGL(k_copy_list<true>, dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, err);
-	else hipLaunchKernelGGL(k_copy_list<false>, dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, err);
+	if (def) hipLaunchKernelGGL(k_copy_list<true>, dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, bigQueue, bigCount, bigCap, err);
+	else hipLaunchKernelGGL(k_copy_list<false>, dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, bigQueue, bigCount, bigCap, err);
+	if (!bigQueue) return;
+	if (def) hipLaunchKernelGGL(k_copy_big<true>, dim3(128), dim3(COPY_BIG_THREADS), 0, st, g, v, bigQueue, bigCount, bigCap, err);
+	else hipLaunchKernelGGL(k_copy_big<false>, dim3(128), dim3(COPY_BIG_THREADS), 0, st, g, v, bigQueue, bigCount, bigCap, err);
 }
 
 void launch_parse_list(const GraphDev &g, bool def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st) {

@@ -67,6 +67,7 @@ struct Pending { // an enqueued range decode whose status has not been collected
 	int32_t levels_done = 0;
 	bool want_succ = false;
 	int32_t giantCap = 0;
+	int32_t bigCap = 0;
 };
 
 } // namespace
@@ -86,6 +87,8 @@ struct bvg_graph {
 	DevBuf lvlist;
 	int parse_lists = 1; // BVGPU_PARSE_LISTS=0: short records parsed in node order instead of by work bin
 	DevBuf plist, pkeys, pkey16;
+	DevBuf cbigq, cbigc; // per-level queues of long rows for the cooperative copy
+	int copy_big = 1;    // BVGPU_COPY_BIG=0: every row is copied by one lane
 	int copy_lists = 1; // BVGPU_COPY_LISTS=0: node-order sweeps over all slots instead of per-level compact lists
 	int32_t coop_min = 2048, giant_min = 8192;                         // thresholds on the outdegree (BVGPU_COOP_MIN / BVGPU_GIANT_MIN)
 	int coop_waves = 4096, giant_groups = 256;
@@ -157,6 +160,7 @@ int init_handle(bvg_graph *g) {
 	if (const char *e = getenv("BVGPU_PATH")) g->fused = strcmp(e, "fused") == 0;
 	if (const char *e = getenv("BVGPU_COPY_LISTS")) g->copy_lists = atoi(e);
 	if (const char *e = getenv("BVGPU_PARSE_LISTS")) g->parse_lists = atoi(e);
+	if (const char *e = getenv("BVGPU_COPY_BIG")) g->copy_big = atoi(e);
 	if (const char *e = getenv("BVGPU_OVERLAP")) g->overlap = atoi(e) != 0;
 	HIPCHK(g, hipStreamCreateWithFlags(&g->sideA, hipStreamNonBlocking));
 	HIPCHK(g, hipStreamCreateWithFlags(&g->sideB, hipStreamNonBlocking));
@@ -218,7 +222,8 @@ int finish_pending(bvg_graph *g, uint64_t *arcs_out) {
 			int32_t *keyBase = g->keys.as<int32_t>() + (bv::NKEYS + 1);
 			for (int32_t l = g->pend.levels_done + 1; l <= upto; l++) {
 				if (!g->fused) {
-					if (g->copy_lists) bv::launch_copy_list(gd, s.def, g->pend.view, g->depth.as<int32_t>(), g->lvlist.as<int32_t>(), keyBase, l, g->level_blocks, derr, g->stream);
+					if (g->copy_lists) bv::launch_copy_list(gd, s.def, g->pend.view, g->depth.as<int32_t>(), g->lvlist.as<int32_t>(), keyBase, l, g->level_blocks,
+					                                         g->copy_big && l < 1023 ? g->cbigq.as<int32_t>() : nullptr, g->cbigc.as<int32_t>() + std::min(l, 1023), g->pend.bigCap, derr, g->stream);
 					else bv::launch_copy(gd, s.def, g->pend.view, g->depth.as<int32_t>(), l, derr, g->stream);
 					continue;
 				}
@@ -334,8 +339,16 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 		mark(g, 4);
 		if (W > 0) {
 			levels = g->levels_hint;
+			// long rows (>= 1024 successors) with a reference: at most arcs / 1024 of them
+			const int32_t bigCap = (int32_t)std::min<int64_t>(arcsBound / 1024 + 2, 0x7fffffff);
+			g->pend.bigCap = bigCap;
+			if (g->copy_lists && g->copy_big) {
+				if (!g->cbigq.need(sizeof(int32_t) * (size_t)bigCap * 1) || !g->cbigc.need(sizeof(int32_t) * 1024)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
+				HIPCHK(g, hipMemsetAsync(g->cbigc.p, 0, sizeof(int32_t) * 1024, g->stream));
+			}
 			for (int32_t l = 1; l <= levels; l++) {
-				if (g->copy_lists) bv::launch_copy_list(gd, s.def, v, g->depth.as<int32_t>(), g->lvlist.as<int32_t>(), keyBase, l, g->level_blocks, derr, g->stream);
+				if (g->copy_lists) bv::launch_copy_list(gd, s.def, v, g->depth.as<int32_t>(), g->lvlist.as<int32_t>(), keyBase, l, g->level_blocks,
+				                                         g->copy_big ? g->cbigq.as<int32_t>() : nullptr, g->cbigc.as<int32_t>() + std::min(l, 1023), bigCap, derr, g->stream);
 				else bv::launch_copy(gd, s.def, v, g->depth.as<int32_t>(), l, derr, g->stream); // sweep in node order: rows of neighbouring nodes are neighbours in memory
 			}
 		}
@@ -464,7 +477,7 @@ extern "C" int bvg_close(bvg_t *g) {
 	if (g->st && g->st->device >= 0) {
 		(void)hipSetDevice(g->st->device);
 		if (g->own) { (void)hipStreamSynchronize(g->own); (void)hipStreamDestroy(g->own); }
-		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist, &g->plist, &g->pkeys, &g->pkey16 }) b->release();
+		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist, &g->plist, &g->pkeys, &g->pkey16, &g->cbigq, &g->cbigc }) b->release();
 		if (g->h_small) (void)hipHostFree(g->h_small);
 		for (auto &e : g->ev) if (e) (void)hipEventDestroy(e);
 		for (hipEvent_t e : { g->evFork, g->evA, g->evB }) if (e) (void)hipEventDestroy(e);
