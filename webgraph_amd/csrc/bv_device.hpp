@@ -50,13 +50,13 @@ struct PrefetchSrc {
 	uint64_t nwords;
 	uint64_t vnext;                 // next 16-byte vector to request
 	uint4 pend;                     // the vector in flight
-	uint32_t q0, q1, q2, q3;        // words of the current vector still to hand out
-	int qn;
+	uint4 cur;                      // the vector being handed out (already byte-swapped)
+	int qn;                         // words of `cur` still to hand out
 	__device__ __forceinline__ uint4 ld4(uint64_t vi) const {
 		return vi * 4 < nwords + 4 ? ((const uint4 *)w)[vi] : uint4{ 0u, 0u, 0u, 0u };
 	}
 	__device__ __forceinline__ void take() {
-		q0 = __builtin_bswap32(pend.x); q1 = __builtin_bswap32(pend.y); q2 = __builtin_bswap32(pend.z); q3 = __builtin_bswap32(pend.w);
+		cur = uint4{ __builtin_bswap32(pend.x), __builtin_bswap32(pend.y), __builtin_bswap32(pend.z), __builtin_bswap32(pend.w) };
 		qn = 4;
 		pend = ld4(vnext++);
 	}
@@ -64,13 +64,37 @@ struct PrefetchSrc {
 		vnext = i >> 2;
 		pend = ld4(vnext++);
 		take();
-		for (uint32_t t = 0; t < (uint32_t)(i & 3); t++) { q0 = q1; q1 = q2; q2 = q3; qn--; }
+		qn = 4 - (int)(i & 3);
 	}
 	__device__ __forceinline__ uint32_t ld(uint64_t) {
 		if (qn == 0) take();
-		const uint32_t r = q0;
-		q0 = q1; q1 = q2; q2 = q3; qn--;
+		const uint32_t r = qn == 4 ? cur.x : qn == 3 ? cur.y : qn == 2 ? cur.z : cur.w;
+		qn--;
 		return r;
+	}
+};
+// Lighter variant: 8-byte loads, one always in flight (7 registers of state).
+struct Prefetch64Src {
+	const uint32_t *__restrict__ w; // 8-byte aligned image, padded with >= 8 zero words
+	uint64_t nwords;
+	uint64_t vnext;  // next 8-byte pair to request
+	uint64_t pend;   // the pair in flight (raw little-endian load: low 32 bits = first word)
+	uint32_t lo;     // second word of the current pair (byte-swapped), valid when half == 1
+	uint32_t half;
+	__device__ __forceinline__ uint64_t ld8(uint64_t pi) const { return pi * 2 < nwords + 6 ? ((const uint64_t *)w)[pi] : 0ull; }
+	__device__ __forceinline__ void start(uint64_t i) {
+		vnext = i >> 1;
+		pend = ld8(vnext++);
+		half = 0;
+		if (i & 1) { (void)ld(0); }
+	}
+	__device__ __forceinline__ uint32_t ld(uint64_t) {
+		if (half) { half = 0; return lo; }
+		const uint64_t c = pend;
+		pend = ld8(vnext++);
+		lo = __builtin_bswap32((uint32_t)(c >> 32));
+		half = 1;
+		return __builtin_bswap32((uint32_t)c);
 	}
 };
 struct WindowSrc { // a window of the stream staged in LDS (already byte-swapped); reads outside fall back to HBM
@@ -148,6 +172,16 @@ template <class Src> struct BitReaderT {
 		}
 	}
 	__device__ __forceinline__ uint64_t gamma() {
+		// fast path: the whole code (<= 31 bits, values < 2^15) sits in the top word of the window
+		refill();
+		const uint32_t hi = (uint32_t)(buf >> 32);
+		if (hi >= (1u << 16)) {
+			const uint32_t m = (uint32_t)__clz((int)hi);
+			const uint32_t len = 2 * m + 1;
+			const uint32_t v = (hi >> (32u - len)) - 1;
+			buf <<= len; nbits -= len;
+			return v;
+		}
 		const uint64_t m = unary();
 		if (m > 63) { err |= E_FORMAT; return 0; }
 		return (((uint64_t)1 << m) | bits64((uint32_t)m)) - 1;
@@ -159,6 +193,23 @@ template <class Src> struct BitReaderT {
 	}
 	template <int K> __device__ __forceinline__ uint64_t zeta_k(int k) {
 		const int kk = K > 0 ? K : k;
+		if (K == 3) {
+			// fast path for zeta_3: h <= 7, i.e. the whole code (<= 32 bits, values < 2^24 - 1) sits in the top word
+			refill();
+			const uint32_t hi = (uint32_t)(buf >> 32);
+			if (hi >= (1u << 24)) {
+				const uint32_t h = (uint32_t)__clz((int)hi);
+				const uint32_t nb = 3 * h + 2;
+				const uint32_t left = 1u << (3 * h);
+				const uint32_t rest = hi << (h + 1);       // payload at the top
+				const uint32_t m = rest >> (32u - nb);
+				uint32_t v, len;
+				if (m < left) { v = m + left - 1; len = h + 1 + nb; }
+				else { v = ((m << 1) | ((rest >> (31u - nb)) & 1u)) - 1; len = h + 2 + nb; }
+				buf <<= len; nbits -= len;
+				return v;
+			}
+		}
 		const uint64_t h = unary();
 		const uint64_t nb = h * (uint64_t)kk + (uint64_t)kk - 1;
 		if (nb > 63) { err |= E_FORMAT; return 0; }
@@ -209,6 +260,7 @@ __device__ __forceinline__ int64_t nat2int(uint64_t v) { return (int64_t)(v >> 1
 using BitReader = BitReaderT<GlobalSrc>;
 using WinReader = BitReaderT<WindowSrc>;
 using PReader = BitReaderT<PrefetchSrc>;
+using P64Reader = BitReaderT<Prefetch64Src>;
 
 // Field readers.  DEF == true: the default coding set (gamma outdegrees / block counts / blocks, unary
 // references, zeta_3 residuals -- BVG:525-541 and DEFAULT_ZETA_K) is resolved at compile time.

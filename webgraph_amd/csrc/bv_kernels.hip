@@ -17,6 +17,8 @@
 #include "bv_lane.hpp"
 
 #include <algorithm>
+#include <cstdlib>
+#include <type_traits>
 
 namespace bv {
 
@@ -25,7 +27,7 @@ constexpr int GIANT_NW = 8; // waves per giant record
 
 template <bool DEF>
 __device__ __forceinline__ void copy_node(const GraphDev &g, int32_t x, int32_t d, int64_t dref, int32_t *__restrict__ row, const int32_t *__restrict__ src, int *__restrict__ err);
-template <bool DEF>
+template <bool DEF, bool PF = false>
 __device__ __forceinline__ void parse_node(const GraphDev &g, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row, int *__restrict__ err);
 
 // ------------------------------------------------------------------------------------------------ headers
@@ -171,9 +173,10 @@ __global__ void k_rebase(int32_t nh, int32_t cnt, const int64_t *__restrict__ ro
 //   copied   = how many successors will come from the referent (needs only the referent's outdegree, BVG:1069)
 //   extras   = intervals U residuals, merged, written to row[copied .. d)
 // Nodes without a reference are final after this kernel.
-template <bool DEF>
+// PF: the main cursor streams through HBM with 16-byte prefetching loads (one wait per 128 bits, not per 32)
+template <bool DEF, bool PF>
 __device__ __forceinline__ void parse_node(const GraphDev &g, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row, int *__restrict__ err) {
-	BitReader br;
+	typename std::conditional<PF, P64Reader, BitReader>::type br;
 	br.init(g.bits, g.nwords);
 	br.seek((uint64_t)g.offsets[x]);
 	(void)Fields<DEF>::outdegree(br, g);
@@ -186,6 +189,7 @@ __device__ __forceinline__ void parse_node(const GraphDev &g, int32_t x, int32_t
 		int64_t total = 0;
 		if (bc > (uint64_t)dref + 1) e |= E_FORMAT;
 		else {
+#pragma nounroll
 			for (uint64_t b = 0; b < bc; b++) {
 				const int64_t len = (int64_t)Fields<DEF>::block(br, g) + (b ? 1 : 0);
 				total += len;
@@ -209,6 +213,7 @@ __device__ __forceinline__ void parse_node(const GraphDev &g, int32_t x, int32_t
 		if (nIntervals > extra) { atomicOr(err, E_FORMAT); return; }
 		if (nIntervals) {
 			bi.seek(br.pos());
+#pragma nounroll
 			for (int64_t i = 0; i < nIntervals; i++) {
 				(void)br.gamma();
 				intervalArcs += (int64_t)br.gamma() + g.minInt;
@@ -227,6 +232,7 @@ __device__ __forceinline__ void parse_node(const GraphDev &g, int32_t x, int32_t
 	int64_t resTodo = nRes;
 	int64_t resVal = 0;
 	if (resTodo) resVal = (int64_t)(int32_t)((int64_t)x + nat2int(Fields<DEF>::residual(br, g))); // BVG:954
+#pragma nounroll
 	while (k < extra) {
 		if (ivRem == 0 && ivTodo) { // load the next interval (BVG:1084-1093)
 			if (firstIv) { ivLeft = (int64_t)(int32_t)((int64_t)x + nat2int(bi.gamma())); firstIv = false; }
@@ -484,7 +490,7 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 }
 
 // parse pass over a list sorted by work bin only (all chain levels together): 64 records of similar length per wave
-template <bool DEF>
+template <bool DEF, bool PF>
 __global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, const int32_t *__restrict__ list, const int32_t *__restrict__ keyBase, int *__restrict__ err) {
 	const int32_t lo = keyBase[0], hi = keyBase[NBIN];
 	for (int32_t idx = hi - 1 - (blockIdx.x * TPB + threadIdx.x); idx >= lo; idx -= gridDim.x * TPB) {
@@ -493,7 +499,7 @@ __global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, con
 		if (d >= v.coop_min) continue; // decoded by whole waves (k_parse_big)
 		const int32_t r = v.ref[s];
 		if (s >= v.nh && (uint64_t)(v.rowstart[s + 1] - v.rowstart[v.nh]) > v.succ_cap) { atomicOr(err, E_CAP); continue; }
-		parse_node<DEF>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), err);
+		parse_node<DEF, PF>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), err);
 	}
 }
 
@@ -873,14 +879,17 @@ void launch_copy_list(const GraphDev &g, bool def, const RangeView &v, const int
 	if (def) hipLaunchKernelGGL(k_copy_list<true>, dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, bigQueue, bigCount, bigCap, err);
 	else hipLaunchKernelGGL(k_copy_list<false>, dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, bigQueue, bigCount, bigCap, err);
 	if (!bigQueue) return;
-	if (def) hipLaunchKernelGGL(k_copy_big<true>, dim3(128), dim3(COPY_BIG_THREADS), 0, st, g, v, bigQueue, bigCount, bigCap, err);
-	else hipLaunchKernelGGL(k_copy_big<false>, dim3(128), dim3(COPY_BIG_THREADS), 0, st, g, v, bigQueue, bigCount, bigCap, err);
+	if (def) hipLaunchKernelGGL(k_copy_big<true>, dim3(512), dim3(COPY_BIG_THREADS), 0, st, g, v, bigQueue, bigCount, bigCap, err);
+	else hipLaunchKernelGGL(k_copy_big<false>, dim3(512), dim3(COPY_BIG_THREADS), 0, st, g, v, bigQueue, bigCount, bigCap, err);
 }
 
 void launch_parse_list(const GraphDev &g, bool def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st) {
 	if (v.cnt <= 0) return;
-	if (def) hipLaunchKernelGGL(k_parse_list<true>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, err);
-	else hipLaunchKernelGGL(k_parse_list<false>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, err);
+	static const bool pf = getenv("BVGPU_PREFETCH") ? atoi(getenv("BVGPU_PREFETCH")) != 0 : false; // prefetching cursor: fewer waits but ~3x the registers (148 VGPRs), off by default
+	if (def && pf) hipLaunchKernelGGL((k_parse_list<true, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, err);
+	else if (def) hipLaunchKernelGGL((k_parse_list<true, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, err);
+	else if (pf) hipLaunchKernelGGL((k_parse_list<false, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, err);
+	else hipLaunchKernelGGL((k_parse_list<false, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, err);
 }
 
 } // namespace bv
