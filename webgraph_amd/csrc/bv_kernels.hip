@@ -27,8 +27,8 @@ constexpr int GIANT_NW = 8; // waves per giant record
 
 template <bool DEF>
 __device__ __forceinline__ void copy_node(const GraphDev &g, int32_t x, int32_t d, int64_t dref, int32_t *__restrict__ row, const int32_t *__restrict__ src, int *__restrict__ err);
-template <bool DEF, bool PF = false>
-__device__ __forceinline__ void parse_node(const GraphDev &g, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row, int *__restrict__ err);
+template <bool DEF, bool PF = false, bool LW = false>
+__device__ __forceinline__ void parse_node(const GraphDev &g, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row, int *__restrict__ err, uint32_t *lds = nullptr);
 
 // ------------------------------------------------------------------------------------------------ headers
 template <bool DEF>
@@ -174,10 +174,12 @@ __global__ void k_rebase(int32_t nh, int32_t cnt, const int64_t *__restrict__ ro
 //   extras   = intervals U residuals, merged, written to row[copied .. d)
 // Nodes without a reference are final after this kernel.
 // PF: the main cursor streams through HBM with 16-byte prefetching loads (one wait per 128 bits, not per 32)
-template <bool DEF, bool PF>
-__device__ __forceinline__ void parse_node(const GraphDev &g, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row, int *__restrict__ err) {
-	typename std::conditional<PF, P64Reader, BitReader>::type br;
-	br.init(g.bits, g.nwords);
+template <bool DEF, bool PF, bool LW>
+__device__ __forceinline__ void parse_node(const GraphDev &g, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row, int *__restrict__ err, uint32_t *lds) {
+	// LW: both cursors read through private LDS windows (lds: 2 * LANE_WIN_WORDS * blockDim.x words)
+	typename std::conditional<LW, LReader, typename std::conditional<PF, PReader, BitReader>::type>::type br;
+	if constexpr (LW) br.init_src(LaneWindowSrc{ g.bits, g.nwords, lds + threadIdx.x, blockDim.x, ~(uint64_t)0 << 8 }, g.nwords);
+	else br.init(g.bits, g.nwords);
 	br.seek((uint64_t)g.offsets[x]);
 	(void)Fields<DEF>::outdegree(br, g);
 	if (g.W > 0) (void)Fields<DEF>::reference(br, g);
@@ -206,8 +208,9 @@ __device__ __forceinline__ void parse_node(const GraphDev &g, int32_t x, int32_t
 
 	// interval section: skip-parse to find the residual section and the number of residuals
 	int64_t nIntervals = 0, intervalArcs = 0;
-	BitReader bi; // second cursor, re-reads the interval section lazily during the merge
-	bi.init(g.bits, g.nwords);
+	typename std::conditional<LW, LReader, BitReader>::type bi; // second cursor, re-reads the interval section lazily during the merge
+	if constexpr (LW) bi.init_src(LaneWindowSrc{ g.bits, g.nwords, lds + LANE_WIN_WORDS * blockDim.x + threadIdx.x, blockDim.x, ~(uint64_t)0 << 8 }, g.nwords);
+	else bi.init(g.bits, g.nwords);
 	if (g.minInt != 0) {
 		nIntervals = (int64_t)br.gamma();
 		if (nIntervals > extra) { atomicOr(err, E_FORMAT); return; }
@@ -490,16 +493,24 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 }
 
 // parse pass over a list sorted by work bin only (all chain levels together): 64 records of similar length per wave
-template <bool DEF, bool PF>
-__global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, const int32_t *__restrict__ list, const int32_t *__restrict__ keyBase, int *__restrict__ err) {
-	const int32_t lo = keyBase[0], hi = keyBase[NBIN];
-	for (int32_t idx = hi - 1 - (blockIdx.x * TPB + threadIdx.x); idx >= lo; idx -= gridDim.x * TPB) {
+template <bool DEF, bool PF, bool LW>
+__global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, const int32_t *__restrict__ list, const int32_t *__restrict__ keyBase, int32_t binLo, int32_t binHi,
+                                                    int *__restrict__ err) {
+	__shared__ uint32_t lds[LW ? 2 * LANE_WIN_WORDS * TPB : 1];
+	const int32_t lo = keyBase[binLo], hi = keyBase[binHi];
+	// The list is sorted longest first.  Thread T takes entries T, 2G-1-T, 2G+T, 4G-1-T, ... (G = threads in the
+	// grid): a snake, so that the threads that got the longest records of one sweep get the shortest of the next.
+	const int64_t G = (int64_t)gridDim.x * TPB, T = (int64_t)blockIdx.x * TPB + threadIdx.x;
+	for (int64_t sweep = 0; sweep * G < (int64_t)hi - lo; sweep++) {
+		const int64_t off = sweep * G + ((sweep & 1) ? G - 1 - T : T);
+		if (off >= (int64_t)hi - lo) continue;
+		const int32_t idx = (int32_t)(hi - 1 - off);
 		const int32_t s = list[idx];
 		const int32_t d = v.outd[s];
 		if (d >= v.coop_min) continue; // decoded by whole waves (k_parse_big)
 		const int32_t r = v.ref[s];
 		if (s >= v.nh && (uint64_t)(v.rowstart[s + 1] - v.rowstart[v.nh]) > v.succ_cap) { atomicOr(err, E_CAP); continue; }
-		parse_node<DEF, PF>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), err);
+		parse_node<DEF, PF, LW>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), err, lds);
 	}
 }
 
@@ -883,13 +894,21 @@ void launch_copy_list(const GraphDev &g, bool def, const RangeView &v, const int
 	else hipLaunchKernelGGL(k_copy_big<false>, dim3(512), dim3(COPY_BIG_THREADS), 0, st, g, v, bigQueue, bigCount, bigCap, err);
 }
 
-void launch_parse_list(const GraphDev &g, bool def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st) {
+void launch_parse_list(const GraphDev &g, bool def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, hipStream_t stHeavy) {
 	if (v.cnt <= 0) return;
-	static const bool pf = getenv("BVGPU_PREFETCH") ? atoi(getenv("BVGPU_PREFETCH")) != 0 : false; // prefetching cursor: fewer waits but ~3x the registers (148 VGPRs), off by default
-	if (def && pf) hipLaunchKernelGGL((k_parse_list<true, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, err);
-	else if (def) hipLaunchKernelGGL((k_parse_list<true, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, err);
-	else if (pf) hipLaunchKernelGGL((k_parse_list<false, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, err);
-	else hipLaunchKernelGGL((k_parse_list<false, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, err);
+	(void)stHeavy;
+	// BVGPU_CURSOR: 0 = plain 32-bit refills from HBM, 1 = 16-byte prefetching cursor (many registers), 2 = private LDS windows
+	static const int mode = getenv("BVGPU_CURSOR") ? atoi(getenv("BVGPU_CURSOR")) : 0; // measured on C2: 0 is fastest (5.5 ms parse phase vs 6.0 / 9.3)
+	if (mode == 2) {
+		if (def) hipLaunchKernelGGL((k_parse_list<true, false, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NBIN, err);
+		else hipLaunchKernelGGL((k_parse_list<false, false, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NBIN, err);
+	} else if (mode == 1) {
+		if (def) hipLaunchKernelGGL((k_parse_list<true, true, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NBIN, err);
+		else hipLaunchKernelGGL((k_parse_list<false, true, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NBIN, err);
+	} else {
+		if (def) hipLaunchKernelGGL((k_parse_list<true, false, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NBIN, err);
+		else hipLaunchKernelGGL((k_parse_list<false, false, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NBIN, err);
+	}
 }
 
 } // namespace bv

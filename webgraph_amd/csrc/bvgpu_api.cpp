@@ -90,7 +90,7 @@ struct bvg_graph {
 	DevBuf cbigq, cbigc; // per-level queues of long rows for the cooperative copy
 	int copy_big = 1;    // BVGPU_COPY_BIG=0: every row is copied by one lane
 	int copy_lists = 1; // BVGPU_COPY_LISTS=0: node-order sweeps over all slots instead of per-level compact lists
-	int32_t coop_min = 2048, giant_min = 8192;                         // thresholds on the outdegree (BVGPU_COOP_MIN / BVGPU_GIANT_MIN)
+	int32_t coop_min = 2048, giant_min = 65536;                         // thresholds on the outdegree (BVGPU_COOP_MIN / BVGPU_GIANT_MIN)
 	int coop_waves = 4096, giant_groups = 256;
 	DevBuf stats; // BVGPU_STATS=1: tuning counters
 	// the three parse kernels (giant / big / short records) are independent: they run on forked streams
@@ -330,7 +330,9 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 			} else
 				bv::launch_parse_big(gd, s.def, v, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, g->giant_groups, derr, g->stream, g->stream);
 		}
-		if (pKeyBase) bv::launch_parse_list(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, g->level_blocks, derr, g->stream);
+		if (pKeyBase) {
+			bv::launch_parse_list(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, g->level_blocks, derr, g->stream, g->stream);
+		}
 		else bv::launch_parse(gd, s.def, v, derr, g->stream);
 		if (coop && g->overlap) {
 			HIPCHK(g, hipStreamWaitEvent(g->stream, g->evA, 0));
