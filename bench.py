@@ -177,7 +177,8 @@ def main():
         wall = time.perf_counter() - t0
         dev_ms = e0.elapsed_time(e1)
 
-        # ---- per-kernel timing of the same scan with HIP events between the phases (outside the timed region)
+        # ---- per-kernel timing of the same scan with HIP events between the phases (outside the timed region;
+        # with profiling on the library runs its normally overlapping parse kernels one after the other)
         g.set_profile(True)
         phases = {}
         reps = max(3, min(args.steps, 10))
@@ -198,8 +199,11 @@ def main():
     info = g.info
     graph_bytes = int(info.graph_bytes)
     b_alg = graph_bytes + 8 * (n + 1) + 4 * m + 8 * (n + 1)
-    dom = max(phases, key=phases.get)
-    dom_ms = phases[dom]
+    kernel_of = {"headers": "k_headers", "scan": "k_scan_*", "lists": "k_depth_keys+k_scatter_keys", "parse_long": "k_parse_big",
+                 "parse_short": "k_parse_list", "copy": "k_copy_list+k_copy_big", "tail": "k_rebase"}
+    dom_phase = max(phases, key=phases.get)
+    dom = kernel_of.get(dom_phase, dom_phase)
+    dom_ms = phases[dom_phase]
     scan_ms = sum(phases.values())
     achieved = b_alg / (dom_ms * 1e-3) / 1e9
     out = {
@@ -222,8 +226,9 @@ def main():
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_scan": b_alg, "bytes_per_edge": b_alg / max(m, 1),
-                     "kernel_ms": dom_ms, "scan_ms": scan_ms, "scan_achieved": b_alg / (scan_ms * 1e-3) / 1e9,
-                     "scan_frac": b_alg / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                     "kernel_ms": dom_ms, "serial_phase_ms_sum": scan_ms,
+                     "scan_achieved": b_alg / (dev_ms / args.steps * 1e-3) / 1e9,
+                     "scan_frac": b_alg / (dev_ms / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS},
     }
     if cpu is not None:
         out["cpu_baseline"] = cpu

@@ -81,8 +81,9 @@ int bvg_info(const bvg_t *g, bvg_info_t *out);
 /* message for the last failing call on this handle (never NULL) */
 const char *bvg_last_error(const bvg_t *g);
 
-/* Use the caller's HIP stream (a hipStream_t passed as void*) for every launch of this handle; NULL
- * restores the handle's own stream. */
+/* Orders this handle's work with the caller's HIP stream (a hipStream_t passed as void*): every call first waits
+ * for what the caller has enqueued on it, and the stream waits for the call's results.  The kernels themselves run
+ * on the handle's own streams (they overlap better there).  NULL detaches. */
 int bvg_set_stream(bvg_t *g, void *hip_stream);
 
 /* Waits for the handle's stream; returns the status of the asynchronous work since the last sync and,
@@ -91,9 +92,11 @@ int bvg_sync(bvg_t *g, uint64_t *arcs_out);
 
 /* ---- measurement ------------------------------------------------------------------------------------ */
 
-/* Phases of one bvg_decode_range, in stream order (HIP events are recorded between them when profiling is on):
- * headers(+halo closure) | scan | chain depth | parse | copy levels | rowptr rebase + totals */
-#define BVG_NUM_PHASES 6
+/* Phases of one bvg_decode_range, in stream order (HIP events are recorded between them when profiling is on;
+ * the three parse kernels, which normally overlap on forked streams, then run one after the other):
+ * headers(+halo closure) | scan | chain depth + work lists | parse of long records (cooperative kernels) |
+ * parse of short records (one lane per record) | copy levels | rowptr rebase + totals */
+#define BVG_NUM_PHASES 7
 /* Enables / disables per-phase HIP-event timing on this handle (off by default; costs a few event records). */
 int bvg_set_profile(bvg_t *g, int enable);
 /* Milliseconds of each phase of the last range decode issued with profiling on; ms has BVG_NUM_PHASES floats. */

@@ -34,18 +34,26 @@ def main():
     dev = torch.device("cuda", 0)
     rowptr = torch.empty(n + 1, dtype=torch.int64, device=dev)
     succ = torch.empty(max(m, 1), dtype=torch.int32, device=dev)
+    if os.environ.get("TUNE_TORCH_STREAM"):
+        st_ = torch.cuda.Stream(device=dev)
+        g.set_stream(st_.cuda_stream)
     g.decode_range_device(0, n, rowptr.data_ptr(), succ.data_ptr(), succ.numel())
     if os.environ.get("BVGPU_STATS"):
         g.debug_stats(reset=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.reps):
+        g.decode_range_device(0, n, rowptr.data_ptr(), succ.data_ptr(), succ.numel(), asynchronous=True)
+    g.sync()
+    wall = (time.perf_counter() - t0) / args.reps
     g.set_profile(True)
     acc = {}
-    t0 = time.perf_counter()
     for _ in range(args.reps):
         g.decode_range_device(0, n, rowptr.data_ptr(), succ.data_ptr(), succ.numel())
         for k, v in g.get_profile().items():
             acc[k] = acc.get(k, 0) + v / args.reps
-    wall = (time.perf_counter() - t0) / args.reps
-    print("phases(ms):", {k: round(v, 3) for k, v in acc.items()}, "sum %.3f wall %.3f" % (sum(acc.values()), wall * 1e3), "Gedges/s %.2f" % (m / sum(acc.values()) / 1e6))
+    g.set_profile(False)
+    print("scan %.3f ms = %.2f Gedges/s | serial phases(ms): %s sum %.3f" % (wall * 1e3, m / wall / 1e9, {k: round(v, 3) for k, v in acc.items()}, sum(acc.values())))
     if os.environ.get("BVGPU_STATS"):
         st = g.debug_stats() // args.reps
         print("res tiles %d rounds/tile %.2f | int tiles %d rounds/tile %.2f | big nodes %d ticks/node %.0f max ticks %d (x reps)" % (

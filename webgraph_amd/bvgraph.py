@@ -311,7 +311,7 @@ class BVGraph:
     def set_stream(self, hip_stream):
         self._check(lib().bvg_set_stream(self._h, hip_stream))
 
-    PHASES = ("headers", "scan", "depth", "parse", "copy", "tail")
+    PHASES = ("headers", "scan", "lists", "parse_long", "parse_short", "copy", "tail")
 
     def set_profile(self, on):
         self._check(lib().bvg_set_profile(self._h, 1 if on else 0))

@@ -74,7 +74,9 @@ struct Pending { // an enqueued range decode whose status has not been collected
 
 struct bvg_graph {
 	std::shared_ptr<Staged> st;
-	hipStream_t own = nullptr, stream = nullptr;
+	hipStream_t own = nullptr, stream = nullptr; // `stream` is always `own`: the library executes on its own streams
+	hipStream_t user = nullptr;                  // caller's stream (bvg_set_stream): work is ordered after it and it waits for our results
+	hipEvent_t evIn = nullptr, evOut = nullptr;
 	mutable std::string err;
 	DevBuf outd, ref, rowstart, depth, sums, need, halo, hashA, hashB, stage_rowptr, stage_succ, stage_nodes, small;
 	DevBuf b_chainlen, b_slotbase, b_node, b_qidx, b_aoutd, b_qoutd; // random-access batches
@@ -165,6 +167,8 @@ int init_handle(bvg_graph *g) {
 	HIPCHK(g, hipStreamCreateWithFlags(&g->sideA, hipStreamNonBlocking));
 	HIPCHK(g, hipStreamCreateWithFlags(&g->sideB, hipStreamNonBlocking));
 	HIPCHK(g, hipEventCreateWithFlags(&g->evFork, hipEventDisableTiming));
+	HIPCHK(g, hipEventCreateWithFlags(&g->evIn, hipEventDisableTiming));
+	HIPCHK(g, hipEventCreateWithFlags(&g->evOut, hipEventDisableTiming));
 	HIPCHK(g, hipEventCreateWithFlags(&g->evA, hipEventDisableTiming));
 	HIPCHK(g, hipEventCreateWithFlags(&g->evB, hipEventDisableTiming));
 	if (const char *e = getenv("BVGPU_STATS")) if (atoi(e)) { if (!g->stats.need(32 * sizeof(unsigned long long))) return fail(g, BVG_ENOMEM, "device allocation failed"); HIPCHK(g, hipMemset(g->stats.p, 0, 256)); }
@@ -193,6 +197,21 @@ int enqueue_structure(bvg_graph *g, int32_t from, int32_t to, int32_t nh, bv::Ra
 	mark(g, 1);
 	bv::launch_scan(v.outd, cnt, v.rowstart, g->sums.as<int64_t>(), g->stream);
 	mark(g, 2);
+	return BVG_OK;
+}
+
+// The caller's stream (if any) only orders the work: kernels run on the library's own streams, which overlap
+// better than a stream taken from the caller (measured with PyTorch's: 9.3 ms vs 7.7 ms per C2 scan).
+int fork_from_user(bvg_graph *g) {
+	if (!g->user) return BVG_OK;
+	HIPCHK(g, hipEventRecord(g->evIn, g->user));
+	HIPCHK(g, hipStreamWaitEvent(g->stream, g->evIn, 0));
+	return BVG_OK;
+}
+int join_to_user(bvg_graph *g) {
+	if (!g->user) return BVG_OK;
+	HIPCHK(g, hipEventRecord(g->evOut, g->stream));
+	HIPCHK(g, hipStreamWaitEvent(g->user, g->evOut, 0));
 	return BVG_OK;
 }
 
@@ -252,9 +271,11 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 	HIPCHK(g, hipSetDevice(s.device));
 	if (g->pend.active) { int rc = finish_pending(g, nullptr); if (rc) return rc; }
 	const int32_t W = s.info.window_size;
+	{ int rc = fork_from_user(g); if (rc) return rc; }
 	HIPCHK(g, hipMemsetAsync(g->small.p, 0, sizeof(Small), g->stream));
 	if (to == from) {
 		HIPCHK(g, hipMemsetAsync(rowptr_dev, 0, sizeof(int64_t), g->stream));
+		{ int rc = join_to_user(g); if (rc) return rc; }
 		if (!async) HIPCHK(g, hipStreamSynchronize(g->stream));
 		g->last_arcs = 0;
 		if (arcs_out) *arcs_out = 0;
@@ -314,13 +335,16 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 			bv::launch_build_lists(gd, v, ~0ull, 2, g->biglist.as<int32_t>(), g->pkey16.as<uint16_t>(), ph, pKeyBase, pKeyBase + (bv::NKEYS + 1), g->plist.as<int32_t>(),
 			                       g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->pad, g->stream);
 		}
-		mark(g, 3);
 		const bool coop = g->coop_min < 0x7fffffff;
+		const bool ovl = g->overlap && !g->profile; // per-kernel timing needs the kernels one after the other
 		v.coop_min = coop ? g->coop_min : 0x7fffffff;
 		if (coop) {
 			HIPCHK(g, hipMemsetAsync(ctl, 0, 8 * sizeof(int32_t), g->stream));
 			bv::launch_classify(v.cnt, v.outd, g->coop_min, g->giant_min, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, g->stream);
-			if (g->overlap) {
+		}
+		mark(g, 3);
+		if (coop) {
+			if (ovl) {
 				HIPCHK(g, hipEventRecord(g->evFork, g->stream));
 				HIPCHK(g, hipStreamWaitEvent(g->sideA, g->evFork, 0));
 				HIPCHK(g, hipStreamWaitEvent(g->sideB, g->evFork, 0));
@@ -330,15 +354,16 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 			} else
 				bv::launch_parse_big(gd, s.def, v, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, g->giant_groups, derr, g->stream, g->stream);
 		}
+		mark(g, 4);
 		if (pKeyBase) {
 			bv::launch_parse_list(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, g->level_blocks, derr, g->stream, g->stream);
 		}
 		else bv::launch_parse(gd, s.def, v, derr, g->stream);
-		if (coop && g->overlap) {
+		if (coop && ovl) {
 			HIPCHK(g, hipStreamWaitEvent(g->stream, g->evA, 0));
 			HIPCHK(g, hipStreamWaitEvent(g->stream, g->evB, 0));
 		}
-		mark(g, 4);
+		mark(g, 5);
 		if (W > 0) {
 			levels = g->levels_hint;
 			// long rows (>= 1024 successors) with a reference: at most arcs / 1024 of them
@@ -380,6 +405,7 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 		bv::launch_decode_level(gd, s.def, v, g->depth.as<int32_t>(), g->biglist.as<int32_t>(), keyBase, 0, g->level_blocks, derr, g->stream);
 		if (g->overlap) HIPCHK(g, hipStreamWaitEvent(g->stream, g->evA, 0));
 		mark(g, 4);
+		mark(g, 5);
 		if (W > 0) {
 			levels = g->levels_hint;
 			for (int32_t l = 1; l <= levels; l++) {
@@ -388,12 +414,13 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 			}
 		}
 	}
-	if (!succ_dev) { mark(g, 3); mark(g, 4); }
-	mark(g, 5);
+	if (!succ_dev) { mark(g, 3); mark(g, 4); mark(g, 5); }
+	mark(g, 6);
 	bv::launch_rebase(v.nh, v.cnt, v.rowstart, rowptr_dev, g->stream);
 	hipLaunchKernelGGL(k_totals, dim3(1), dim3(1), 0, g->stream, v.rowstart, v.nh, v.cnt, g->small.as<Small>());
-	mark(g, 6);
+	mark(g, 7);
 	g->ev_valid = g->profile;
+	{ int rc = join_to_user(g); if (rc) return rc; }
 	HIPCHK(g, hipGetLastError());
 	g->pend.active = true; g->pend.view = v; g->pend.levels_done = levels; g->pend.want_succ = succ_dev != nullptr; g->pend.giantCap = giantCap;
 	if (async) return BVG_OK;
@@ -482,7 +509,7 @@ extern "C" int bvg_close(bvg_t *g) {
 		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist, &g->plist, &g->pkeys, &g->pkey16, &g->cbigq, &g->cbigc }) b->release();
 		if (g->h_small) (void)hipHostFree(g->h_small);
 		for (auto &e : g->ev) if (e) (void)hipEventDestroy(e);
-		for (hipEvent_t e : { g->evFork, g->evA, g->evB }) if (e) (void)hipEventDestroy(e);
+		for (hipEvent_t e : { g->evFork, g->evA, g->evB, g->evIn, g->evOut }) if (e) (void)hipEventDestroy(e);
 		for (hipStream_t st : { g->sideA, g->sideB }) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
 	}
 	delete g;
@@ -500,7 +527,7 @@ extern "C" const char *bvg_last_error(const bvg_t *g) { return g ? g->err.c_str(
 extern "C" int bvg_set_stream(bvg_t *g, void *hip_stream) {
 	if (!g || !g->st) return BVG_EARG;
 	if (g->pend.active) { int rc = finish_pending(g, nullptr); if (rc) return rc; }
-	g->stream = hip_stream ? (hipStream_t)hip_stream : g->own;
+	g->user = (hipStream_t)hip_stream;
 	return BVG_OK;
 }
 
@@ -548,6 +575,7 @@ extern "C" int bvg_outdegrees(bvg_t *g, int32_t from, int32_t to, int32_t *out, 
 	if (to == from) return BVG_OK;
 	HIPCHK(g, hipSetDevice(s.device));
 	if (g->pend.active) { int rc = finish_pending(g, nullptr); if (rc) return rc; }
+	{ int rc = fork_from_user(g); if (rc) return rc; }
 	const int32_t cnt = to - from;
 	if (!g->outd.need(sizeof(int32_t) * (size_t)cnt) || !g->ref.need(sizeof(uint16_t) * (size_t)cnt)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
 	HIPCHK(g, hipMemsetAsync(g->small.p, 0, sizeof(Small), g->stream));
@@ -589,6 +617,7 @@ extern "C" int bvg_successors_batch(bvg_t *g, const int32_t *nodes, size_t q, in
 	const Staged &s = *g->st;
 	HIPCHK(g, hipSetDevice(s.device));
 	if (g->pend.active) { int rc = finish_pending(g, nullptr); if (rc) return rc; }
+	{ int rc = fork_from_user(g); if (rc) return rc; }
 	const bool dev = (flags & BVG_OUT_DEVICE) != 0;
 	const bv::GraphDev gd = graph_dev(s);
 	Small *dsm = g->small.as<Small>();
@@ -667,6 +696,7 @@ extern "C" int bvg_csr_hashcode(bvg_t *g, int32_t from, int32_t to, const int64_
 	const Staged &s = *g->st;
 	HIPCHK(g, hipSetDevice(s.device));
 	if (g->pend.active) { int rc = finish_pending(g, nullptr); if (rc) return rc; }
+	{ int rc = fork_from_user(g); if (rc) return rc; }
 	const int32_t cnt = to - from;
 	if (cnt == 0) return BVG_OK;
 	const size_t nb = ((size_t)cnt + 255) / 256;
