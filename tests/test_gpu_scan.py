@@ -223,3 +223,25 @@ def test_fused_path_matches(tmp_path_factory, cnr_oracle, monkeypatch):
     rp, sc = g.decode_range(100000, 140000)
     assert np.array_equal(sc, succ[rowptr[100000]:rowptr[140000]])
     g.close()
+
+
+KNOBS = [
+    {"BVGPU_OVERLAP": "0"}, {"BVGPU_COOP_MIN": "16", "BVGPU_GIANT_MIN": "64"}, {"BVGPU_COOP_MIN": "2147483647"},
+    {"BVGPU_PARSE_LISTS": "0", "BVGPU_COPY_LISTS": "0"}, {"BVGPU_COPY_BIG": "0"}, {"BVGPU_PATH": "fused", "BVGPU_GIANT_BITS": "2048"},
+]
+
+
+@pytest.mark.parametrize("env", KNOBS, ids=["-".join(k.split("_", 1)[1] + v for k, v in e.items()) for e in KNOBS])
+def test_tuning_knobs_keep_parity(tmp_path_factory, monkeypatch, env):
+    """Every scheduling / threshold knob of the library is a speed choice only: same bits whatever the setting
+    (thresholds small enough that even this small graph exercises the cooperative kernels)."""
+    from webgraph_amd.bvgraph import BVGraph
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    base, rowptr, succ = make_graph(tmp_path_factory, "knobs", 30000, 600000, 77, 0.8, window=7, max_ref_count=3, min_interval=3)
+    g = BVGraph.load(base)
+    rp, sc = g.decode_range()
+    assert np.array_equal(rp, rowptr) and np.array_equal(sc, succ)
+    rp, sc = g.decode_range(12345, 23456)
+    assert np.array_equal(sc, succ[rowptr[12345]:rowptr[23456]])
+    g.close()

@@ -73,59 +73,6 @@ struct PrefetchSrc {
 		return r;
 	}
 };
-// Lighter variant: 8-byte loads, one always in flight (7 registers of state).
-struct Prefetch64Src {
-	const uint32_t *__restrict__ w; // 8-byte aligned image, padded with >= 8 zero words
-	uint64_t nwords;
-	uint64_t vnext;  // next 8-byte pair to request
-	uint64_t pend;   // the pair in flight (raw little-endian load: low 32 bits = first word)
-	uint32_t lo;     // second word of the current pair (byte-swapped), valid when half == 1
-	uint32_t half;
-	__device__ __forceinline__ uint64_t ld8(uint64_t pi) const { return pi * 2 < nwords + 6 ? ((const uint64_t *)w)[pi] : 0ull; }
-	__device__ __forceinline__ void start(uint64_t i) {
-		vnext = i >> 1;
-		pend = ld8(vnext++);
-		half = 0;
-		if (i & 1) { (void)ld(0); }
-	}
-	__device__ __forceinline__ uint32_t ld(uint64_t) {
-		if (half) { half = 0; return lo; }
-		const uint64_t c = pend;
-		pend = ld8(vnext++);
-		lo = __builtin_bswap32((uint32_t)(c >> 32));
-		half = 1;
-		return __builtin_bswap32((uint32_t)c);
-	}
-};
-// A private window of the stream per lane, kept in LDS: LANE_WIN_WORDS consecutive words, refilled from HBM
-// with 16-byte loads issued together whenever the cursor leaves it.  The decode loop itself then only touches
-// LDS -- on gfx950 every global load that is waited for also drains the lane's outstanding stores (one vmcnt
-// counter), so a cursor that refills 32 bits at a time from HBM pays a store round trip every few codes.
-// Layout: word j of thread t at win[j * stride + t] (stride = threads per block).
-constexpr int LANE_WIN_WORDS = 16;
-struct LaneWindowSrc {
-	const uint32_t *__restrict__ w; // image, 16-byte aligned, padded with >= 8 zero words... (reads stay below nwords + 8)
-	uint64_t nwords;
-	uint32_t *win;                  // this thread's column in LDS
-	uint32_t stride;
-	uint64_t w0;                    // first word held; ~0 = nothing yet
-	__device__ __noinline__ void fill(uint64_t i) {
-		w0 = i & ~(uint64_t)3;
-		uint4 v[LANE_WIN_WORDS / 4];
-#pragma unroll
-		for (int k = 0; k < LANE_WIN_WORDS / 4; k++) v[k] = (w0 + 4 * k) < nwords + 4 ? ((const uint4 *)(w + w0))[k] : uint4{ 0u, 0u, 0u, 0u };
-#pragma unroll
-		for (int k = 0; k < LANE_WIN_WORDS / 4; k++) {
-			win[(4 * k + 0) * stride] = __builtin_bswap32(v[k].x); win[(4 * k + 1) * stride] = __builtin_bswap32(v[k].y);
-			win[(4 * k + 2) * stride] = __builtin_bswap32(v[k].z); win[(4 * k + 3) * stride] = __builtin_bswap32(v[k].w);
-		}
-	}
-	__device__ __forceinline__ void start(uint64_t i) { if (i - w0 >= (uint64_t)LANE_WIN_WORDS - 1) fill(i); }
-	__device__ __forceinline__ uint32_t ld(uint64_t i) {
-		if (i - w0 >= (uint64_t)LANE_WIN_WORDS) fill(i);
-		return win[(i - w0) * stride];
-	}
-};
 struct WindowSrc { // a window of the stream staged in LDS (already byte-swapped); reads outside fall back to HBM
 	const uint32_t *win;
 	uint64_t w0;
@@ -289,8 +236,6 @@ __device__ __forceinline__ int64_t nat2int(uint64_t v) { return (int64_t)(v >> 1
 using BitReader = BitReaderT<GlobalSrc>;
 using WinReader = BitReaderT<WindowSrc>;
 using PReader = BitReaderT<PrefetchSrc>;
-using P64Reader = BitReaderT<Prefetch64Src>;
-using LReader = BitReaderT<LaneWindowSrc>;
 
 // Field readers.  DEF == true: the default coding set (gamma outdegrees / block counts / blocks, unary
 // references, zeta_3 residuals -- BVG:525-541 and DEFAULT_ZETA_K) is resolved at compile time.

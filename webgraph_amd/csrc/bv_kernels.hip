@@ -27,8 +27,8 @@ constexpr int GIANT_NW = 8; // waves per giant record
 
 template <bool DEF>
 __device__ __forceinline__ void copy_node(const GraphDev &g, int32_t x, int32_t d, int64_t dref, int32_t *__restrict__ row, const int32_t *__restrict__ src, int *__restrict__ err);
-template <bool DEF, bool PF = false, bool LW = false>
-__device__ __forceinline__ void parse_node(const GraphDev &g, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row, int *__restrict__ err, uint32_t *lds = nullptr);
+template <bool DEF>
+__device__ __forceinline__ void parse_node(const GraphDev &g, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row, int *__restrict__ err);
 
 // ------------------------------------------------------------------------------------------------ headers
 template <bool DEF>
@@ -173,13 +173,12 @@ __global__ void k_rebase(int32_t nh, int32_t cnt, const int64_t *__restrict__ ro
 //   copied   = how many successors will come from the referent (needs only the referent's outdegree, BVG:1069)
 //   extras   = intervals U residuals, merged, written to row[copied .. d)
 // Nodes without a reference are final after this kernel.
-// PF: the main cursor streams through HBM with 16-byte prefetching loads (one wait per 128 bits, not per 32)
-template <bool DEF, bool PF, bool LW>
-__device__ __forceinline__ void parse_node(const GraphDev &g, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row, int *__restrict__ err, uint32_t *lds) {
-	// LW: both cursors read through private LDS windows (lds: 2 * LANE_WIN_WORDS * blockDim.x words)
-	typename std::conditional<LW, LReader, typename std::conditional<PF, PReader, BitReader>::type>::type br;
-	if constexpr (LW) br.init_src(LaneWindowSrc{ g.bits, g.nwords, lds + threadIdx.x, blockDim.x, ~(uint64_t)0 << 8 }, g.nwords);
-	else br.init(g.bits, g.nwords);
+// Both cursors refill 32 bits at a time straight from HBM (L1/L2-cached).  Measured alternatives on C2 -- a 16-byte
+// prefetching cursor and private per-lane LDS windows -- tripled the register count (148-188 VGPRs) and were slower.
+template <bool DEF>
+__device__ __forceinline__ void parse_node(const GraphDev &g, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row, int *__restrict__ err) {
+	BitReader br;
+	br.init(g.bits, g.nwords);
 	br.seek((uint64_t)g.offsets[x]);
 	(void)Fields<DEF>::outdegree(br, g);
 	if (g.W > 0) (void)Fields<DEF>::reference(br, g);
@@ -191,7 +190,6 @@ __device__ __forceinline__ void parse_node(const GraphDev &g, int32_t x, int32_t
 		int64_t total = 0;
 		if (bc > (uint64_t)dref + 1) e |= E_FORMAT;
 		else {
-#pragma nounroll
 			for (uint64_t b = 0; b < bc; b++) {
 				const int64_t len = (int64_t)Fields<DEF>::block(br, g) + (b ? 1 : 0);
 				total += len;
@@ -208,15 +206,13 @@ __device__ __forceinline__ void parse_node(const GraphDev &g, int32_t x, int32_t
 
 	// interval section: skip-parse to find the residual section and the number of residuals
 	int64_t nIntervals = 0, intervalArcs = 0;
-	typename std::conditional<LW, LReader, BitReader>::type bi; // second cursor, re-reads the interval section lazily during the merge
-	if constexpr (LW) bi.init_src(LaneWindowSrc{ g.bits, g.nwords, lds + LANE_WIN_WORDS * blockDim.x + threadIdx.x, blockDim.x, ~(uint64_t)0 << 8 }, g.nwords);
-	else bi.init(g.bits, g.nwords);
+	BitReader bi; // second cursor, re-reads the interval section lazily during the merge
+	bi.init(g.bits, g.nwords);
 	if (g.minInt != 0) {
 		nIntervals = (int64_t)br.gamma();
 		if (nIntervals > extra) { atomicOr(err, E_FORMAT); return; }
 		if (nIntervals) {
 			bi.seek(br.pos());
-#pragma nounroll
 			for (int64_t i = 0; i < nIntervals; i++) {
 				(void)br.gamma();
 				intervalArcs += (int64_t)br.gamma() + g.minInt;
@@ -235,7 +231,6 @@ __device__ __forceinline__ void parse_node(const GraphDev &g, int32_t x, int32_t
 	int64_t resTodo = nRes;
 	int64_t resVal = 0;
 	if (resTodo) resVal = (int64_t)(int32_t)((int64_t)x + nat2int(Fields<DEF>::residual(br, g))); // BVG:954
-#pragma nounroll
 	while (k < extra) {
 		if (ivRem == 0 && ivTodo) { // load the next interval (BVG:1084-1093)
 			if (firstIv) { ivLeft = (int64_t)(int32_t)((int64_t)x + nat2int(bi.gamma())); firstIv = false; }
@@ -493,10 +488,9 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 }
 
 // parse pass over a list sorted by work bin only (all chain levels together): 64 records of similar length per wave
-template <bool DEF, bool PF, bool LW>
+template <bool DEF>
 __global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, const int32_t *__restrict__ list, const int32_t *__restrict__ keyBase, int32_t binLo, int32_t binHi,
                                                     int *__restrict__ err) {
-	__shared__ uint32_t lds[LW ? 2 * LANE_WIN_WORDS * TPB : 1];
 	const int32_t lo = keyBase[binLo], hi = keyBase[binHi];
 	// The list is sorted longest first.  Thread T takes entries T, 2G-1-T, 2G+T, 4G-1-T, ... (G = threads in the
 	// grid): a snake, so that the threads that got the longest records of one sweep get the shortest of the next.
@@ -510,7 +504,7 @@ __global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, con
 		if (d >= v.coop_min) continue; // decoded by whole waves (k_parse_big)
 		const int32_t r = v.ref[s];
 		if (s >= v.nh && (uint64_t)(v.rowstart[s + 1] - v.rowstart[v.nh]) > v.succ_cap) { atomicOr(err, E_CAP); continue; }
-		parse_node<DEF, PF, LW>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), err, lds);
+		parse_node<DEF>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), err);
 	}
 }
 
@@ -894,21 +888,10 @@ void launch_copy_list(const GraphDev &g, bool def, const RangeView &v, const int
 	else hipLaunchKernelGGL(k_copy_big<false>, dim3(512), dim3(COPY_BIG_THREADS), 0, st, g, v, bigQueue, bigCount, bigCap, err);
 }
 
-void launch_parse_list(const GraphDev &g, bool def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, hipStream_t stHeavy) {
+void launch_parse_list(const GraphDev &g, bool def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st) {
 	if (v.cnt <= 0) return;
-	(void)stHeavy;
-	// BVGPU_CURSOR: 0 = plain 32-bit refills from HBM, 1 = 16-byte prefetching cursor (many registers), 2 = private LDS windows
-	static const int mode = getenv("BVGPU_CURSOR") ? atoi(getenv("BVGPU_CURSOR")) : 0; // measured on C2: 0 is fastest (5.5 ms parse phase vs 6.0 / 9.3)
-	if (mode == 2) {
-		if (def) hipLaunchKernelGGL((k_parse_list<true, false, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NBIN, err);
-		else hipLaunchKernelGGL((k_parse_list<false, false, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NBIN, err);
-	} else if (mode == 1) {
-		if (def) hipLaunchKernelGGL((k_parse_list<true, true, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NBIN, err);
-		else hipLaunchKernelGGL((k_parse_list<false, true, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NBIN, err);
-	} else {
-		if (def) hipLaunchKernelGGL((k_parse_list<true, false, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NBIN, err);
-		else hipLaunchKernelGGL((k_parse_list<false, false, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NBIN, err);
-	}
+	if (def) hipLaunchKernelGGL(k_parse_list<true>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NBIN, err);
+	else hipLaunchKernelGGL(k_parse_list<false>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NBIN, err);
 }
 
 } // namespace bv

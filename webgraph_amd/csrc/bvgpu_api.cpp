@@ -356,7 +356,7 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 		}
 		mark(g, 4);
 		if (pKeyBase) {
-			bv::launch_parse_list(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, g->level_blocks, derr, g->stream, g->stream);
+			bv::launch_parse_list(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, g->level_blocks, derr, g->stream);
 		}
 		else bv::launch_parse(gd, s.def, v, derr, g->stream);
 		if (coop && ovl) {
