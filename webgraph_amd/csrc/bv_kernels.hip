@@ -225,6 +225,8 @@ __device__ __forceinline__ void parse_node(const GraphDev &g, int32_t x, int32_t
 	// merge(intervals, residuals) -> row[copied ..)
 	int32_t *out = row + copied;
 	int64_t k = 0;
+	const int64_t head = min<int64_t>(extra, (int64_t)(((16u - ((uint32_t)(uintptr_t)out & 15u)) & 15u) >> 2)); // scalar stores up to the first 16-byte boundary
+	int32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0, on = 0;
 	int64_t ivLeft = 0, ivRem = 0, ivPrev = 0; // current interval: next value, values left; end of the previous interval
 	int64_t ivTodo = nIntervals;
 	bool firstIv = true;
@@ -246,8 +248,16 @@ __device__ __forceinline__ void parse_node(const GraphDev &g, int32_t x, int32_t
 			if (ivRem && ivLeft == resVal) { ivLeft++; ivRem--; } // equal heads are emitted once (MergedIntIterator.java:69-72)
 			if (--resTodo) resVal += (int64_t)Fields<DEF>::residual(br, g) + 1; // BVG:966
 		} else val = -1; // malformed: fewer values than the outdegree promises (BVG:1210 would store -1)
-		out[k++] = val;
+		// 16-byte stores where the row allows it: the 64 lanes of a wave write 64 different rows, and with half a
+		// million rows in flight a 4-byte store per successor lets the L2 evict every line several times before it
+		// is complete (rocprof: WRITE_SIZE 6x the algorithmic bytes of this kernel)
+		if (k < head) { out[k++] = val; continue; }
+		o0 = o1; o1 = o2; o2 = o3; o3 = val; k++;
+		if (++on == 4) { *(int4 *)(out + k - 4) = int4{ o0, o1, o2, o3 }; on = 0; }
 	}
+	if (on == 3) { out[k - 3] = o1; out[k - 2] = o2; out[k - 1] = o3; }
+	else if (on == 2) { out[k - 2] = o2; out[k - 1] = o3; }
+	else if (on == 1) out[k - 1] = o3;
 	if (br.err | bi.err) atomicOr(err, br.err | bi.err);
 }
 
