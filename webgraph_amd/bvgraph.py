@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIBPATH = os.path.join(_HERE, "libbvgpu.so")
+_LIBPATH = os.environ.get("BVGPU_LIB") or os.path.join(_HERE, "libbvgpu.so")  # BVGPU_LIB: tuning builds
 
 BVG_OK, BVG_EARG, BVG_ESTATE, BVG_EUNSUPPORTED, BVG_EIO, BVG_ENOMEM, BVG_EHIP, BVG_EFORMAT, BVG_ECAP = 0, -1, -2, -3, -4, -5, -6, -7, -8
 BVG_OUT_HOST, BVG_OUT_DEVICE, BVG_ASYNC = 0, 1, 2

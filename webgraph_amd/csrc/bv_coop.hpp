@@ -26,11 +26,26 @@ namespace bv {
 // section (known from the record's bit length and its code count) so that a segment holds ~COOP_CODES_PER_SEG
 // codes: speculative parses only re-synchronise with the true parse after a handful of codes, and a segment
 // that ends before they did costs one more round of the fixed-point loop per lane it delays.
-constexpr int COOP_B_MIN = 64, COOP_CODES_PER_SEG = 12;
+constexpr int COOP_B_MIN = 96, COOP_CODES_PER_SEG = 12;
 
-template <int NW> struct CoopCfg;
-template <> struct CoopCfg<1> { static constexpr int N = 64, B_MAX = 1024, IVCAP = 1024; };
-template <> struct CoopCfg<8> { static constexpr int N = 512, B_MAX = 512, IVCAP = 4096; };
+// Tile geometry (compile-time; -D overrides are for tuning builds).  One wave per "big" record, COOP_GIANT_NW
+// waves per "giant" record.  The LDS footprint (tile + staged intervals) bounds the groups resident per CU.
+#ifndef COOP1_BMAX
+#define COOP1_BMAX 512
+#endif
+#ifndef COOP1_IVCAP
+#define COOP1_IVCAP 512
+#endif
+#ifndef COOPG_BMAX
+#define COOPG_BMAX 512
+#endif
+#ifndef COOPG_IVCAP
+#define COOPG_IVCAP 4096
+#endif
+#ifndef COOP_GIANT_NW
+#define COOP_GIANT_NW 8
+#endif
+template <int NW> struct CoopCfg { static constexpr int N = 64 * NW, B_MAX = NW == 1 ? COOP1_BMAX : COOPG_BMAX, IVCAP = NW == 1 ? COOP1_IVCAP : COOPG_IVCAP; };
 
 template <int NW> struct CoopLds { // LDS layout of one group, in 32-bit words
 	static constexpr int WIN_WORDS = CoopCfg<NW>::N * CoopCfg<NW>::B_MAX / 32 + 12; // staged tile bits (+ alignment and look-ahead slack), multiple of 4
@@ -138,8 +153,12 @@ template <int NW> struct Grp {
 __device__ __forceinline__ uint32_t coop_pick_B(uint64_t sectionBits, uint64_t codes, uint32_t lanes, uint32_t bmax) {
 	const uint64_t avg = (sectionBits + codes - 1) / (codes ? codes : 1);
 	uint64_t b = max(avg * COOP_CODES_PER_SEG, (sectionBits + lanes - 1) / lanes);
-	b = (b + 31) & ~(uint64_t)31;
-	return (uint32_t)(b < COOP_B_MIN ? COOP_B_MIN : b > bmax ? bmax : b);
+	b = b < COOP_B_MIN ? COOP_B_MIN : b > bmax ? bmax : b;
+	// an ODD number of 32-bit words per segment: lane i starts reading at word i * (B/32), and with an even
+	// stride the 64 lanes of a wave would keep hitting the same few LDS banks (16 words -> 4 banks)
+	uint32_t w = (uint32_t)((b + 31) >> 5) | 1u;
+	if (w * 32 > bmax) w -= 2;
+	return w * 32;
 }
 
 // Stages the words of the tile [pos0, pos0 + N*B) (+ slack) into LDS, byte-swapped.  All the 16-byte loads of
@@ -215,47 +234,126 @@ __device__ __forceinline__ uint64_t win_code(const GraphDev &g, const WindowSrc 
 	return v;
 }
 
+// ---- tile-relative decoding ------------------------------------------------------------------------------
+// Inside a tile, positions are bit offsets from the first staged word (`base` = src.w0 * 32): they fit 32 bits,
+// and the short codes that make up almost all of a record (gamma < 2^16, zeta_3 < 2^21) decode from two LDS
+// words with a dozen 32-bit instructions.  Everything else takes the 64-bit path above.
+__device__ __forceinline__ bool fast_gamma32(uint32_t W, uint32_t &v, uint32_t &len) {
+	if (W < (1u << 16)) return false; // more than 15 leading zeros: longer than 31 bits
+	const uint32_t m = (uint32_t)__clz((int)W);
+	len = 2 * m + 1;
+	v = (W >> (31u - 2 * m)) - 1;
+	return true;
+}
+__device__ __forceinline__ bool fast_zeta3_32(uint32_t W, uint32_t &v, uint32_t &len) {
+	if (W < (1u << 25)) return false; // h > 6: longer than 28 bits
+	const uint32_t h = (uint32_t)__clz((int)W);
+	const uint32_t nb = 3 * h + 2;
+	const uint32_t mm = (W << (h + 1)) >> (31u - nb); // the nb bits of the short codeword plus the extra bit of the long one
+	const uint32_t m = mm >> 1, left = 1u << (3 * h);
+	const bool lng = m >= left;
+	v = lng ? mm - 1 : m + left - 1;
+	len = 4 * h + 3 + (lng ? 1u : 0u);
+	return true;
+}
+// the rare long codeword: kept out of line (and fed by value) so that the hot loops stay small
+struct SlowCode { uint64_t v; uint32_t q; int err; };
+template <bool DEF, int KIND>
+__device__ __attribute__((noinline)) SlowCode win_code_slow(const GraphDev *gp, const uint32_t *win, uint64_t w0, uint32_t nw, uint32_t q) {
+	const GraphDev &g = *gp;
+	const WindowSrc src{ win, w0, nw, GlobalSrc{ g.bits, g.nwords } };
+	const uint64_t base = w0 << 5;
+	uint64_t p = base + q;
+	int err = 0;
+	const uint64_t v = win_code<DEF, KIND>(g, src, p, err);
+	return SlowCode{ v, (uint32_t)min(p - base, (uint64_t)0x7fffff00u), err };
+}
+// One code at tile-relative position q, which must lie inside the tile proper (then the two words read here
+// are staged: the window extends 8 words past the tile).  Advances q.
+template <bool DEF, int KIND>
+__device__ __forceinline__ uint64_t win_code_rel(const GraphDev &g, const WindowSrc &src, uint32_t &q, int &err) {
+	if (KIND == 1 || DEF) {
+		const uint32_t j = q >> 5;
+		const uint64_t ab = ((uint64_t)src.win[j] << 32) | src.win[j + 1];
+		const uint32_t W = (uint32_t)((ab << (q & 31u)) >> 32);
+		uint32_t v, len;
+		if (__builtin_expect(KIND == 1 ? fast_gamma32(W, v, len) : fast_zeta3_32(W, v, len), 1)) { q += len; return v; }
+	}
+	const SlowCode sc = win_code_slow<DEF, KIND>(&g, src.win, src.w0, src.nw, q);
+	q = sc.q;
+	err |= sc.err;
+	return sc.v;
+}
+
 // One speculative parse of the codes starting in [s, segEnd): end position, count and the sum of the decoded
 // contributions.  KIND 0: residual codes (gap+1 each; the first code of the section is the zig-zag value);
 // KIND 1: gamma codes, positions only.
 template <bool DEF, int KIND>
-__device__ __forceinline__ void spec_parse(const GraphDev &g, const WindowSrc &src, uint64_t s, uint64_t segEnd, bool firstOfSection, uint64_t &e, uint32_t &c, int64_t &sum) {
+__device__ __forceinline__ void spec_parse(const GraphDev &g, const WindowSrc &src, uint64_t base, uint32_t s, uint32_t segEnd, bool firstOfSection, uint32_t &e, uint32_t &c, int64_t &sum) {
 	c = 0; sum = 0;
-	uint64_t p = s;
+	uint32_t p = s;
 	int err = 0; // a speculative parse may run through garbage: errors only stop it
+	if (KIND == 0 && firstOfSection && p < segEnd) { sum = nat2int(win_code_rel<DEF, KIND>(g, src, p, err)); c = 1; }
 	while (p < segEnd && !err) {
-		const uint64_t v = win_code<DEF, KIND>(g, src, p, err);
-		if (KIND == 0) sum += (c == 0 && firstOfSection) ? nat2int(v) : (int64_t)v + 1;
+		const uint64_t v = win_code_rel<DEF, KIND>(g, src, p, err);
+		if (KIND == 0) sum += (int64_t)v + 1;
 		c++;
 	}
-	e = p;
+	e = err ? 0x7fffff00u : p;
+}
+
+// The lane's start moved from `so` to `sn`.  Universal codes re-synchronise after a few codewords, so instead of
+// parsing the segment again the old and the new chain of codewords are walked in lock step (always the one that
+// is behind) until they meet: from there on they are the same chain, and only the difference of the two
+// prefixes is applied to (c, sum).  If they do not meet inside the segment the new chain defines the end.
+template <bool DEF, int KIND>
+__device__ __forceinline__ void spec_resync(const GraphDev &g, const WindowSrc &src, uint64_t base, uint32_t so, uint32_t sn, uint32_t segEnd, uint32_t &e, uint32_t &c, int64_t &sum) {
+	uint32_t po = so, pn = sn;
+	int32_t dc = 0;
+	int64_t ds = 0;
+	while (po != pn && min(po, pn) < segEnd) {
+		const bool adv = pn < po;
+		uint32_t q = adv ? pn : po;
+		int err = 0;
+		const uint64_t v = win_code_rel<DEF, KIND>(g, src, q, err);
+		if (err) q = 0x7fffff00u; // garbage: this chain ends here (as in spec_parse)
+		if (adv) { pn = q; dc++; if (KIND == 0) ds += (int64_t)v + 1; }
+		else { po = q; dc--; if (KIND == 0) ds -= (int64_t)v + 1; }
+	}
+	c += (uint32_t)dc;
+	sum += ds;
+	if (pn >= segEnd) e = pn;
 }
 
 // Fixed-point iteration over one tile starting at the true code boundary pos0.  On return every lane holds
-// the true start `s` of the first code it owns, the number `c` of codes starting in its segment, their
-// contribution sum, and E = end of the tile's last code (uniform).
+// the true start `s` (tile-relative) of the first code it owns, the number `c` of codes starting in its
+// segment, their contribution sum, and E = end of the tile's last code (absolute, uniform).
 template <bool DEF, int KIND, int NW>
 __device__ __forceinline__ void spec_tile(const Grp<NW> &G, const GraphDev &g, const WindowSrc &src, uint64_t pos0, uint64_t secEnd, uint32_t B, bool firstTile,
-                                          int64_t needCodes, uint64_t &s, uint32_t &c, int64_t &sum, uint64_t &E) {
+                                          int64_t needCodes, uint32_t &s, uint32_t &c, int64_t &sum, uint64_t &E) {
 	const int tid = G.tid(), lane = G.lane();
-	const uint64_t segEnd = min(pos0 + (uint64_t)(tid + 1) * B, secEnd);
-	s = min(pos0 + (uint64_t)tid * B, secEnd);
-	uint64_t e = s;
-	bool dirty = true;
-	int rounds = 0;
+	const uint64_t base = src.w0 << 5;
+	const uint32_t p0 = (uint32_t)(pos0 - base);
+	const uint32_t secEndR = (uint32_t)min(secEnd - base, (uint64_t)0x7fffff00u);
+	const uint32_t segEnd = min(p0 + (uint32_t)(tid + 1) * B, secEndR);
+	s = min(p0 + (uint32_t)tid * B, secEndR);
+	uint32_t e;
+	int rounds = 1;
+	spec_parse<DEF, KIND>(g, src, base, s, segEnd, firstTile && tid == 0, e, c, sum);
+	// a parse that runs past the section end is wrong anyway; clamping keeps the lanes behind the end quiet
+	// instead of handing the overshoot down one lane per round
+	e = min(e, secEndR);
 	// Fixed point inside one wave, with `waveStart` as lane 0's start: no barrier, only shuffles.
-	auto wave_rounds = [&](uint64_t waveStart) {
+	auto wave_rounds = [&](uint32_t waveStart) {
 		for (int round = 0; round < 66; round++) {
-			if (dirty) {
-				spec_parse<DEF, KIND>(g, src, s, segEnd, firstTile && tid == 0, e, c, sum);
-				// a parse that runs past the section end is wrong anyway; clamping keeps the lanes behind the
-				// end quiet instead of handing the overshoot down one lane per round
-				e = min(e, secEnd);
-			}
-			uint64_t ns = shfl_up_u64(e, 1);
+			uint32_t ns = (uint32_t)__shfl_up((int)e, 1, 64);
 			if (lane == 0) ns = waveStart;
-			dirty = ns != s;
-			s = ns;
+			const bool dirty = ns != s;
+			if (dirty) {
+				spec_resync<DEF, KIND>(g, src, base, s, ns, segEnd, e, c, sum);
+				e = min(e, secEndR);
+				s = ns;
+			}
 			rounds++;
 			bool stop = !__any(dirty);
 			if (!stop && KIND == 1 && NW == 1) {
@@ -269,20 +367,18 @@ __device__ __forceinline__ void spec_tile(const Grp<NW> &G, const GraphDev &g, c
 			if (stop) break;
 		}
 	};
-	unsigned long long tk0 = (g.stats && NW != 1 && KIND == 0) ? __builtin_readcyclecounter() : 0;
-	if (NW == 1) wave_rounds(pos0);
+	if (NW == 1) wave_rounds(p0);
 	else {
 		// Several waves: every wave first converges on its own from a guessed start (its nominal segment
-		// boundary), then the waves exchange end positions; a wave whose start moved re-converges (usually only
-		// its first lanes re-parse).  Barriers only per exchange, not per round.
-		uint64_t waveStart = G.wave() == 0 ? pos0 : s; // s of lane 0 = nominal boundary
-		waveStart = (uint64_t)__shfl((long long)waveStart, 0, 64);
+		// boundary), then the waves exchange end positions; a wave whose start moved re-converges (only the
+		// lanes up to the point where the old and the new parse meet do any work).  Barriers only per exchange.
+		uint32_t waveStart = G.wave() == 0 ? p0 : s; // s of lane 0 = nominal boundary
+		waveStart = (uint32_t)__shfl((int)waveStart, 0, 64);
 		wave_rounds(waveStart);
-		if (g.stats && KIND == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); if (tid == 0) { atomicAdd(&g.stats[12], now_ - tk0); atomicAdd(&g.stats[13], (unsigned long long)rounds); } tk0 = now_; }
 		for (int xr = 0; xr < NW + 1; xr++) {
 			if (lane == 63) G.xch[G.wave()] = (int64_t)e;
 			__syncthreads();
-			const uint64_t ns = G.wave() == 0 ? pos0 : (uint64_t)G.xch[G.wave() - 1];
+			const uint32_t ns = G.wave() == 0 ? p0 : (uint32_t)G.xch[G.wave() - 1];
 			const bool changed = ns != waveStart;
 			__syncthreads();
 			bool stop = !__syncthreads_or(changed);
@@ -294,14 +390,14 @@ __device__ __forceinline__ void spec_tile(const Grp<NW> &G, const GraphDev &g, c
 				stop = G.bcast(cincl, firstChanged * 64 - 1) >= needCodes;
 			}
 			if (stop) break;
-			if (changed) { waveStart = ns; if (lane == 0) { dirty = true; s = ns; } wave_rounds(waveStart); }
-			if (g.stats && KIND == 0 && tid == 0) atomicAdd(&g.stats[10], 1);
+			if (changed) { waveStart = ns; wave_rounds(waveStart); }
+			if (KIND == 0) stat_add(g, 10, 1);
 		}
-		if (g.stats && KIND == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); if (tid == 0) { atomicAdd(&g.stats[14], now_ - tk0); atomicAdd(&g.stats[11], 1); } }
+		if (KIND == 0) stat_add(g, 11, 1);
 	}
 	stat_add(g, KIND == 0 ? 1 : 3, (unsigned long long)rounds);
 	stat_add(g, KIND == 0 ? 0 : 2, 1);
-	E = (uint64_t)G.bcast((int64_t)e, Grp<NW>::N - 1);
+	E = base + (uint64_t)G.bcast((int64_t)e, Grp<NW>::N - 1);
 }
 
 // ---------------------------------------------------------------------------------------------- phase I
@@ -317,7 +413,8 @@ __device__ __forceinline__ void coop_intervals(const Grp<NW> &G, const GraphDev 
 	int64_t pcount = 0;                 // intervalised arcs so far
 	while (codesDone < codesAll) {
 		const WindowSrc src = stage_tile<NW>(G, g, win, pos, B);
-		uint64_t s, E; uint32_t c; int64_t unused;
+		uint64_t E; uint32_t s, c; int64_t unused;
+		const uint64_t base = src.w0 << 5;
 		spec_tile<DEF, 1, NW>(G, g, src, pos, recEnd, B, false, codesAll - codesDone, s, c, unused, E);
 		int64_t tileTotal;
 		const int64_t cincl = G.incl_scan((int64_t)c, tileTotal);
@@ -329,12 +426,12 @@ __device__ __forceinline__ void coop_intervals(const Grp<NW> &G, const GraphDev 
 		// pass 1: what my codes add to the cursor and to the arc count.  Code q of the section is a left gap
 		// (q even) or a length (q odd).
 		int64_t dcur = 0, dp = 0;
-		uint64_t myEnd = s;
+		uint32_t myEnd = s;
 		{
-			uint64_t p = s;
+			uint32_t p = s;
 			for (uint32_t k = 0; k < c; k++) {
 				const int64_t q = codesDone + cb + k;
-				const uint64_t v = win_code<DEF, 1>(g, src, p, err);
+				const uint64_t v = win_code_rel<DEF, 1>(g, src, p, err);
 				if (q & 1) { const int64_t len = (int64_t)v + g.minInt; dcur += len; dp += len; }
 				else dcur += q == 0 ? nat2int(v) : (int64_t)v + 1;
 			}
@@ -345,18 +442,18 @@ __device__ __forceinline__ void coop_intervals(const Grp<NW> &G, const GraphDev 
 		int64_t cur = cursor + icur - dcur, pc = pcount + ip - dp;
 		// pass 2: write the entries
 		{
-			uint64_t p = s;
+			uint32_t p = s;
 			int e2 = 0;
 			for (uint32_t k = 0; k < c; k++) {
 				const int64_t q = codesDone + cb + k;
-				const uint64_t v = win_code<DEF, 1>(g, src, p, e2);
+				const uint64_t v = win_code_rel<DEF, 1>(g, src, p, e2);
 				if (q & 1) { const int64_t len = (int64_t)v + g.minInt; list[q >> 1].pstart = (int32_t)pc; list[q >> 1].len = (int32_t)len; cur += len; pc += len; }
 				else { cur += q == 0 ? nat2int(v) : (int64_t)v + 1; list[q >> 1].left = (int32_t)cur; }
 			}
 		}
 		// the lane owning the last contributed code knows where the section really continues
 		const int lastTid = G.last_set(c > 0);
-		const uint64_t endPos = (uint64_t)G.bcast((int64_t)myEnd, lastTid);
+		const uint64_t endPos = base + (uint64_t)G.bcast((int64_t)myEnd, lastTid);
 		cursor += curTot;
 		pcount += pTot;
 		codesDone += total;
@@ -385,12 +482,12 @@ __device__ __forceinline__ void coop_residuals(const Grp<NW> &G, const GraphDev 
 	bool firstTile = true;
 	const uint32_t B = coop_pick_B(recEnd > pos ? recEnd - pos : 0, (uint64_t)nRes, N, CoopCfg<NW>::B_MAX); // the residual section ends with the record
 	unsigned long long tk = g.stats ? __builtin_readcyclecounter() : 0;
-#define RT(slot) do { if (g.stats && NW != 1) { const unsigned long long now_ = __builtin_readcyclecounter(); if (tid == 0) atomicAdd(&g.stats[24 + slot], now_ - tk); tk = now_; } } while (0)
+#define RT(slot) do { if (g.stats && NW == 1) { const unsigned long long now_ = __builtin_readcyclecounter(); if (tid == 0) atomicAdd(&g.stats[24 + slot], now_ - tk); tk = now_; } } while (0)
 	while (resDone < nRes) {
 		RT(7);
 		const WindowSrc src = stage_tile<NW>(G, g, win, pos, B);
 		RT(0);
-		uint64_t s, E; uint32_t c; int64_t sum;
+		uint64_t E; uint32_t s, c; int64_t sum;
 		spec_tile<DEF, 0, NW>(G, g, src, pos, recEnd, B, firstTile, nRes - resDone, s, c, sum, E);
 		RT(1);
 		// no more codes than the section still has
@@ -434,12 +531,13 @@ __device__ __forceinline__ void coop_residuals(const Grp<NW> &G, const GraphDev 
 			i = lo;
 		}
 		{
-			uint64_t p = s;
+			uint32_t p = s;
 			int64_t j = resDone + cb;
 			int64_t arcsBefore = ic ? iv_p(i) : 0;
+			const bool zigzag = firstTile && tid == 0;
 			for (uint32_t k = 0; k < c; k++) {
-				const uint64_t v = win_code<DEF, 0>(g, src, p, err);
-				val += (firstTile && tid == 0 && k == 0) ? nat2int(v) : (int64_t)v + 1; // BVG:954, :966
+				const uint64_t v = win_code_rel<DEF, 0>(g, src, p, err);
+				val += (k == 0 && zigzag) ? nat2int(v) : (int64_t)v + 1; // BVG:954, :966
 				if (ic) {
 					bool moved = false;
 					while (i < ic && iv_left(i) < val) { list[i].rank = (int32_t)j; i++; moved = true; } // interval i sits after j residuals

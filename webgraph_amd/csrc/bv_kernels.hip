@@ -23,7 +23,7 @@
 namespace bv {
 
 constexpr int TPB = 256;
-constexpr int GIANT_NW = 8; // waves per giant record
+constexpr int GIANT_NW = COOP_GIANT_NW; // waves per giant record
 
 template <bool DEF>
 __device__ __forceinline__ void copy_node(const GraphDev &g, int32_t x, int32_t d, int64_t dref, int32_t *__restrict__ row, const int32_t *__restrict__ src, int *__restrict__ err);
@@ -541,7 +541,13 @@ __global__ void __launch_bounds__(TPB) k_classify(int32_t cnt, const int32_t *__
 // One group of NW waves per long record, pulled from a device-side queue.  NW = 1 serves the "big" list,
 // NW = GIANT_NW the "giant" list (records so long that a single wave would be the tail of the whole scan).
 template <bool DEF, int NW>
-__global__ void __launch_bounds__(64 * NW) k_parse_big(GraphDev g, RangeView v, const int32_t *__restrict__ list, int32_t *__restrict__ ctl, int which,
+#ifndef COOP1_MINWAVES
+#define COOP1_MINWAVES 4
+#endif
+#ifndef COOPG_MINWAVES
+#define COOPG_MINWAVES 1
+#endif
+__global__ void __launch_bounds__(64 * NW, NW == 1 ? COOP1_MINWAVES : COOPG_MINWAVES) k_parse_big(GraphDev g, RangeView v, const int32_t *__restrict__ list, int32_t *__restrict__ ctl, int which,
                                                        IvEntry *__restrict__ arena, int64_t arenaCap, int *__restrict__ err) {
 	__shared__ __attribute__((aligned(16))) uint32_t lds[CoopLds<NW>::WORDS];
 	__shared__ int32_t s_idx;
