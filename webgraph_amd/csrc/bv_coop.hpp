@@ -463,6 +463,8 @@ __device__ __forceinline__ void coop_intervals(const Grp<NW> &G, const GraphDev 
 	intervalArcs = pcount;
 }
 
+__device__ __attribute__((noinline)) int32_t iv_field_slow(const IvEntry *__restrict__ list, int64_t i, int which) { return which ? list[i].pstart : list[i].left; }
+
 // ---------------------------------------------------------------------------------------------- phases R + X
 // out = row + copied.  Residual j (0-based in the section) goes to out[j + (arcs of the intervals whose left
 // extreme is smaller)], interval i to out[pstart_i + rank_i ..) where rank_i = residuals smaller than its left.
@@ -520,8 +522,10 @@ __device__ __forceinline__ void coop_residuals(const Grp<NW> &G, const GraphDev 
 			staged = min(staged, ic - ia);
 			G.sync();
 		}
-		auto iv_left = [&](int64_t i) -> int64_t { const int64_t o = i - ia; return o < staged ? (int64_t)ivLeft[o] : (int64_t)list[i].left; };
-		auto iv_p = [&](int64_t i) -> int64_t { if (i >= ic) return intervalArcs; const int64_t o = i - ia; return o < staged ? (int64_t)ivP[o] : (int64_t)list[i].pstart; };
+		// (the un-staged case is out of line on purpose: merged into one load it would become a FLAT load, whose
+		// wait also drains every successor store in flight)
+		auto iv_left = [&](int64_t i) -> int64_t { const int64_t o = i - ia; if (__builtin_expect(o < staged, 1)) return (int64_t)ivLeft[o]; return (int64_t)iv_field_slow(list, i, 0); };
+		auto iv_p = [&](int64_t i) -> int64_t { if (i >= ic) return intervalArcs; const int64_t o = i - ia; if (__builtin_expect(o < staged, 1)) return (int64_t)ivP[o]; return (int64_t)iv_field_slow(list, i, 1); };
 		RT(2);
 		// ---- my run of residuals, merged with the interval list
 		int64_t i = ia;
@@ -535,17 +539,19 @@ __device__ __forceinline__ void coop_residuals(const Grp<NW> &G, const GraphDev 
 			int64_t j = resDone + cb;
 			int64_t arcsBefore = ic ? iv_p(i) : 0;
 			const bool zigzag = firstTile && tid == 0;
-			for (uint32_t k = 0; k < c; k++) {
-				const uint64_t v = win_code_rel<DEF, 0>(g, src, p, err);
-				val += (k == 0 && zigzag) ? nat2int(v) : (int64_t)v + 1; // BVG:954, :966
-				if (ic) {
-					bool moved = false;
-					while (i < ic && iv_left(i) < val) { list[i].rank = (int32_t)j; i++; moved = true; } // interval i sits after j residuals
-					if (moved) arcsBefore = iv_p(i);
+			int64_t nextLeft = (c && i < ic) ? iv_left(i) : INT64_MAX; // left extreme of the next interval not yet passed
+			auto emit = [&](int64_t add) {
+				val += add;
+				if (nextLeft < val) {
+					do { list[i].rank = (int32_t)j; i++; nextLeft = i < ic ? iv_left(i) : INT64_MAX; } while (nextLeft < val); // interval i sits after j residuals
+					arcsBefore = iv_p(i);
 				}
 				out[j + arcsBefore] = (int32_t)val;
 				j++;
-			}
+			};
+			uint32_t k = 0;
+			if (c && zigzag) { emit(nat2int(win_code_rel<DEF, 0>(g, src, p, err))); k = 1; } // BVG:954
+			for (; k < c; k++) emit((int64_t)win_code_rel<DEF, 0>(g, src, p, err) + 1);      // BVG:966
 			if (c == 0) i = 0;
 		}
 		RT(3);

@@ -14,6 +14,7 @@
 #include "bv_device.hpp"
 #include "bv_launch.hpp"
 #include "bv_coop.hpp"
+#include "bv_lanewin.hpp"
 #include "bv_lane.hpp"
 
 #include <algorithm>
@@ -501,6 +502,7 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 template <bool DEF>
 __global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, const int32_t *__restrict__ list, const int32_t *__restrict__ keyBase, int32_t binLo, int32_t binHi,
                                                     int *__restrict__ err) {
+	__shared__ uint32_t lw[DEF ? LW_LDS_WORDS : 1]; // lane-private stream windows (default codings)
 	const int32_t lo = keyBase[binLo], hi = keyBase[binHi];
 	// The list is sorted longest first.  Thread T takes entries T, 2G-1-T, 2G+T, 4G-1-T, ... (G = threads in the
 	// grid): a snake, so that the threads that got the longest records of one sweep get the shortest of the next.
@@ -511,10 +513,11 @@ __global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, con
 		const int32_t idx = (int32_t)(hi - 1 - off);
 		const int32_t s = list[idx];
 		const int32_t d = v.outd[s];
-		if (d >= v.coop_min) continue; // decoded by whole waves (k_parse_big)
+		if (d >= v.coop_min || d == 0) continue; // decoded by whole waves (k_parse_big) / nothing to decode
 		const int32_t r = v.ref[s];
 		if (s >= v.nh && (uint64_t)(v.rowstart[s + 1] - v.rowstart[v.nh]) > v.succ_cap) { atomicOr(err, E_CAP); continue; }
-		parse_node<DEF>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), err);
+		if (DEF) parse_node_lw(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), lw, err);
+		else parse_node<DEF>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), err);
 	}
 }
 

@@ -1,0 +1,183 @@
+// bv_lanewin.hpp -- one lane decodes one record through a lane-private window of the stream in LDS (gfx950).
+//
+// gfx950 counts outstanding global loads AND stores in one counter (vmcnt), so a lane that fetches its next 32
+// bits from HBM waits for every successor store it has in flight: a record of 2000 successors decoded by one lane
+// straight from HBM took ~1.3 us per successor, all of it latency.  Here a lane fetches 64 bytes of its record
+// with four 16-byte loads, parks them in its own LDS column and decodes from there with the stateless 32-bit
+// decoders of bv_coop.hpp: one wait per ~500 bits of stream instead of one per 32.
+// Default codings only (gamma / unary / zeta_3); the generic reader handles the rest (parse_node).
+#pragma once
+#include "bv_coop.hpp"
+
+namespace bv {
+
+constexpr int LW_STRIDE = 256;               // threads per block: word k of lane t lives at lds[k * LW_STRIDE + t] (one bank per lane)
+constexpr int LW_MAIN = 16, LW_SIDE = 16;    // words per lane: main cursor / interval cursor
+constexpr int LW_LDS_WORDS = (LW_MAIN + LW_SIDE) * LW_STRIDE;
+
+struct SlowAbs { uint64_t v, pos; int err; };
+// codewords longer than 64 bits (or garbage): the generic reader, out of line
+template <int KIND>
+__device__ __attribute__((noinline)) SlowAbs lane_code_slow(const uint32_t *bits, uint64_t nwords, uint64_t pos) {
+	BitReader br;
+	br.init(bits, nwords);
+	br.seek(pos);
+	const uint64_t v = KIND == 2 ? br.unary() : KIND == 1 ? br.gamma() : br.template zeta_k<3>(3);
+	return SlowAbs{ v, br.pos(), br.err };
+}
+
+template <int NWORDS> struct LaneWin {
+	uint32_t *col;  // this lane's LDS column
+	uint64_t w0;    // absolute index of window word 0 (multiple of 4: 16-byte loads)
+	uint32_t q;     // bit offset of the cursor from word w0
+	uint64_t vlast; // first word of the last 16-byte vector worth fetching (record end + look-ahead, inside the padded image)
+
+	__device__ __forceinline__ void fill(const GraphDev &g) {
+		constexpr int NV = NWORDS / 4;
+		uint4 v[NV];
+#pragma unroll
+		for (int k = 0; k < NV; k++) {
+			// branch-free (all the loads of a refill must be in flight together): past the record, or past the
+			// padded image (which ends with >= 8 zero words), the last wanted vector is simply read again
+			const uint64_t i = min(w0 + 4 * k, vlast);
+			v[k] = *(const uint4 *)(g.bits + i);
+		}
+#pragma unroll
+		for (int k = 0; k < NV; k++) {
+			col[(4 * k + 0) * LW_STRIDE] = __builtin_bswap32(v[k].x);
+			col[(4 * k + 1) * LW_STRIDE] = __builtin_bswap32(v[k].y);
+			col[(4 * k + 2) * LW_STRIDE] = __builtin_bswap32(v[k].z);
+			col[(4 * k + 3) * LW_STRIDE] = __builtin_bswap32(v[k].w);
+		}
+	}
+	__device__ __forceinline__ void seek(const GraphDev &g, uint64_t pos) {
+		w0 = (pos >> 5) & ~(uint64_t)3;
+		q = (uint32_t)(pos - (w0 << 5));
+		fill(g);
+	}
+	__device__ __forceinline__ uint64_t pos() const { return (w0 << 5) + q; }
+	// Called where the wave is converged: if ANY lane is about to run out of window, ALL lanes move theirs up to
+	// their cursor.  Left to themselves the lanes would each stall the whole wave for a memory round trip at a
+	// different iteration (64 lanes, one refill every ~40 codes each: a stall in almost every iteration).
+	template <int MARGIN> __device__ __forceinline__ void wave_refill(const GraphDev &g) { // MARGIN: words the next step may need
+		if (__any((q >> 5) + MARGIN >= (uint32_t)NWORDS)) {
+			const uint32_t adv = (q >> 5) & ~3u;
+			w0 += adv;
+			q -= adv << 5;
+			fill(g);
+		}
+	}
+	// KIND 0: zeta_3, 1: gamma, 2: unary
+	template <int KIND> __device__ __forceinline__ uint64_t code(const GraphDev &g, int &err) {
+		if (__builtin_expect((q >> 5) + 2 >= (uint32_t)NWORDS, 0)) { // keep three words ahead of the cursor inside the window
+			const uint32_t adv = (q >> 5) & ~3u;
+			w0 += adv;
+			q -= adv << 5;
+			fill(g);
+		}
+		const uint32_t j = q >> 5, sh = q & 31u;
+		const uint64_t ab = ((uint64_t)col[j * LW_STRIDE] << 32) | col[(j + 1) * LW_STRIDE];
+		const uint32_t W = (uint32_t)((ab << sh) >> 32);
+		uint32_t v, len;
+		if (KIND == 2) {
+			if (__builtin_expect(W != 0, 1)) { const uint32_t z = (uint32_t)__clz((int)W); q += z + 1; return z; }
+		} else if (__builtin_expect(KIND == 1 ? fast_gamma32(W, v, len) : fast_zeta3_32(W, v, len), 1)) { q += len; return v; }
+		// up to 64 bits
+		const uint32_t c = col[(j + 2) * LW_STRIDE];
+		const uint64_t W64 = sh ? (ab << sh) | ((uint64_t)c >> (32u - sh)) : ab;
+		uint64_t v64;
+		if (KIND == 2) {
+			if (W64) { const uint32_t z = (uint32_t)__clzll((long long)W64); q += z + 1; return z; }
+		} else if (KIND == 1 ? fast_gamma(W64, v64, len) : fast_zeta3(W64, v64, len)) { q += len; return v64; }
+		const SlowAbs sa = lane_code_slow<KIND>(g.bits, g.nwords, pos());
+		err |= sa.err;
+		seek(g, sa.pos);
+		return sa.v;
+	}
+};
+
+// Same contract as parse_node<true>: the extras (intervals merged with residuals) of node x go to row[copied..d).
+__device__ __forceinline__ void parse_node_lw(const GraphDev &g, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row, uint32_t *lds, int *__restrict__ err) {
+	LaneWin<LW_MAIN> br;
+	LaneWin<LW_SIDE> bi; // second cursor, re-reads the interval section lazily during the merge
+	br.col = lds + threadIdx.x;
+	bi.col = lds + LW_MAIN * LW_STRIDE + threadIdx.x;
+	br.vlast = bi.vlast = min((((uint64_t)g.offsets[x + 1] >> 5) + 2) & ~(uint64_t)3, (g.nwords + 4) & ~(uint64_t)3);
+	br.seek(g, (uint64_t)g.offsets[x]);
+	int e = 0;
+	(void)br.code<1>(g, e);              // outdegree (known from k_headers)
+	if (g.W > 0) (void)br.code<2>(g, e); // reference
+	int64_t copied = 0;
+	if (hasRef) { // BVG:1058-1071
+		const uint64_t bc = br.code<1>(g, e);
+		int64_t total = 0;
+		if (bc > (uint64_t)dref + 1) e |= E_FORMAT;
+		else {
+			for (uint64_t b = 0; b < bc; b++) {
+				const int64_t len = (int64_t)br.code<1>(g, e) + (b ? 1 : 0);
+				total += len;
+				if (!(b & 1)) copied += len;
+			}
+			if (total > dref) e |= E_FORMAT;
+			if (!(bc & 1)) copied += dref - total;
+		}
+	}
+	const int64_t extra = (int64_t)d - copied;
+	if (extra < 0 || copied < 0) e |= E_FORMAT;
+	if (e) { atomicOr(err, e); return; }
+	if (extra == 0) return;
+
+	int64_t nIntervals = 0, intervalArcs = 0;
+	if (g.minInt != 0) { // BVG:1073-1096: skip-parse to find the residual section and the number of residuals
+		nIntervals = (int64_t)br.code<1>(g, e);
+		if (nIntervals > extra) { atomicOr(err, E_FORMAT); return; }
+		if (nIntervals) {
+			bi.seek(g, br.pos());
+			for (int64_t i = 0; i < nIntervals; i++) {
+				(void)br.code<1>(g, e);
+				intervalArcs += (int64_t)br.code<1>(g, e) + g.minInt;
+			}
+		}
+	}
+	const int64_t nRes = extra - intervalArcs;
+	if (nRes < 0 || e) { atomicOr(err, E_FORMAT | e); return; }
+
+	// merge(intervals, residuals) -> row[copied ..), in 16-byte stores where the row allows it
+	int32_t *out = row + copied;
+	int64_t k = 0;
+	const int64_t head = min<int64_t>(extra, (int64_t)(((16u - ((uint32_t)(uintptr_t)out & 15u)) & 15u) >> 2));
+	int32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0, on = 0;
+	int64_t ivLeft = 0, ivRem = 0, ivPrev = 0;
+	int64_t ivTodo = nIntervals;
+	bool firstIv = true;
+	int64_t resTodo = nRes;
+	int64_t resVal = 0;
+	if (resTodo) resVal = (int64_t)(int32_t)((int64_t)x + nat2int(br.code<0>(g, e))); // BVG:954
+	while (k < extra) {
+		br.wave_refill<3>(g);
+		if (ivTodo) bi.wave_refill<6>(g); // an interval is two gamma codes
+		if (ivRem == 0 && ivTodo) { // BVG:1084-1093
+			if (firstIv) { ivLeft = (int64_t)(int32_t)((int64_t)x + nat2int(bi.code<1>(g, e))); firstIv = false; }
+			else ivLeft = ivPrev + (int64_t)bi.code<1>(g, e) + 1;
+			ivRem = (int64_t)bi.code<1>(g, e) + g.minInt;
+			ivPrev = ivLeft + ivRem;
+			ivTodo--;
+		}
+		int32_t val;
+		if (ivRem && (!resTodo || ivLeft < resVal)) { val = (int32_t)ivLeft; ivLeft++; ivRem--; }
+		else if (resTodo) {
+			val = (int32_t)resVal;
+			if (ivRem && ivLeft == resVal) { ivLeft++; ivRem--; } // equal heads are emitted once (MergedIntIterator.java:69-72)
+			if (--resTodo) resVal += (g.dbg & 2) ? 1 : (int64_t)br.code<0>(g, e) + 1; // BVG:966
+		} else val = -1; // malformed: fewer values than the outdegree promises (BVG:1210 would store -1)
+		if (k < head) { if (!(g.dbg & 1)) out[k] = val; k++; continue; }
+		o0 = o1; o1 = o2; o2 = o3; o3 = val; k++;
+		if (++on == 4) { if (!(g.dbg & 1)) *(int4 *)(out + k - 4) = int4{ o0, o1, o2, o3 }; on = 0; }
+	}
+	if (on == 3) { out[k - 3] = o1; out[k - 2] = o2; out[k - 1] = o3; }
+	else if (on == 2) { out[k - 2] = o2; out[k - 1] = o3; }
+	else if (on == 1) out[k - 1] = o3;
+	if (e) atomicOr(err, e);
+}
+
+} // namespace bv

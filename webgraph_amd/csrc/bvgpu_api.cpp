@@ -112,7 +112,7 @@ struct bvg_graph {
 namespace {
 
 bv::GraphDev graph_dev0(const Staged &s);
-bv::GraphDev graph_dev_h(const bvg_graph *g, const Staged &s) { bv::GraphDev d = graph_dev0(s); d.stats = (unsigned long long *)g->stats.p; return d; }
+bv::GraphDev graph_dev_h(const bvg_graph *g, const Staged &s) { bv::GraphDev d = graph_dev0(s); d.stats = (unsigned long long *)g->stats.p; d.dbg = getenv("BVGPU_DBG") ? atoi(getenv("BVGPU_DBG")) : 0; return d; }
 
 int fail(const bvg_graph *g, int code, const std::string &msg) { if (g) g->err = msg; return code; }
 
@@ -129,6 +129,7 @@ bv::GraphDev graph_dev0(const Staged &s) {
 	g.c_outd = s.info.outdegree_coding; g.c_ref = s.info.reference_coding; g.c_bc = s.info.block_count_coding;
 	g.c_blk = s.info.block_coding; g.c_res = s.info.residual_coding;
 	g.stats = nullptr;
+	g.dbg = 0;
 	return g;
 }
 
