@@ -46,9 +46,10 @@ def main():
         g.decode_range_device(0, n, rowptr.data_ptr(), succ.data_ptr(), succ.numel(), asynchronous=True)
     g.sync()
     wall = (time.perf_counter() - t0) / args.reps
-    g.set_profile(True)
     acc = {}
-    for _ in range(args.reps):
+    if not os.environ.get("TUNE_NO_PROFILE"):
+        g.set_profile(True)
+    for _ in range(0 if os.environ.get("TUNE_NO_PROFILE") else args.reps):
         g.decode_range_device(0, n, rowptr.data_ptr(), succ.data_ptr(), succ.numel())
         for k, v in g.get_profile().items():
             acc[k] = acc.get(k, 0) + v / args.reps
@@ -58,6 +59,7 @@ def main():
         st = g.debug_stats() // args.reps
         print("res tiles %d rounds/tile %.2f | int tiles %d rounds/tile %.2f | big nodes %d ticks/node %.0f max ticks %d (x reps)" % (
             st[0], st[1] / max(st[0], 1), st[2], st[3] / max(st[2], 1), st[5], st[6] / max(st[5], 1), st[7] * args.reps))
+        print("copy_big rows %d sum bc %d max bc %d sum d %d max d %d fallback rows %d (x reps; max raw)" % (st[8], st[9], st[15] * args.reps, st[12], st[14] * args.reps, st[13]))
         print("giant residual tiles %d: first local rounds %.1f M ticks (%.1f rounds/tile), exchange phase %.1f M ticks (%.2f exchanges/tile)" % (st[11], st[12] / 1e6, st[13] / max(st[11], 1), st[14] / 1e6, st[10] / max(st[11], 1)))
         print("residual tile rounds histogram (<=2,<=4,<=8,<=16,<=32,<=64):", [int(v) for v in st[8:14]])
         print("ticks (M) NW=1: A %.1f I %.1f R+X %.1f | NW=16: A %.1f I %.1f R+X %.1f" % tuple(float(v) / 1e6 for v in (st[16], st[17], st[18], st[20], st[21], st[22])))

@@ -388,47 +388,70 @@ __global__ void __launch_bounds__(64) k_copy_giants(GraphDev g, RangeView v, con
 	copy_node<DEF>(g, v.lo + s, v.outd[s], (int64_t)v.outd[s - r], v.row(s), v.row(s - r), err);
 }
 
-// copy pass over the compact list of one chain level.  Rows with >= COPY_BIG_MIN successors are not merged by
-// one lane (that would be the tail of the whole scan): they are queued for k_copy_big.
+// copy pass over the compact list of one chain level.  Only short rows are merged by one lane: a lane-serial
+// merge of a long row would be the tail of the whole scan, so rows with >= COPY_BIG_MIN successors are queued for
+// k_copy_big (a 1024-thread group each) and rows with >= midMin successors for k_copy_mid (a wave each).
 constexpr int COPY_BIG_MIN = 1024;
 template <bool DEF>
 __global__ void __launch_bounds__(TPB) k_copy_list(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ list,
                                                    const int32_t *__restrict__ keyBase, int32_t level, int32_t *__restrict__ bigQueue, int32_t *__restrict__ bigCount,
-                                                   int32_t bigCap, int *__restrict__ err) {
+                                                   int32_t bigCap, int32_t *__restrict__ midQueue, int32_t *__restrict__ midCount, int32_t midCap, int32_t midMin,
+                                                   int32_t mode, int *__restrict__ err) { // mode 0: queue + merge short rows; 1: queue only; 2: short rows only
 	const int32_t bucket = min(level, MAXLVL - 1);
 	const int32_t lo = keyBase[bucket * NBIN], hi = keyBase[(bucket + 1) * NBIN];
+	const int lane = threadIdx.x & 63;
 	for (int32_t idx = hi - 1 - (blockIdx.x * TPB + threadIdx.x); idx >= lo; idx -= gridDim.x * TPB) {
 		const int32_t s = list[idx];
-		if (level >= MAXLVL - 1 && depth[s] != level) continue; // shared overflow bucket
-		const int32_t r = v.ref[s];
-		if (r == 0) continue;
-		if (s >= v.nh && (uint64_t)(v.rowstart[s + 1] - v.rowstart[v.nh]) > v.succ_cap) continue; // E_CAP already raised
-		if (bigQueue && v.outd[s] >= COPY_BIG_MIN) {
-			const int32_t q = atomicAdd(bigCount, 1);
-			if (q < bigCap) { bigQueue[q] = s; continue; }
+		int32_t r = 0, d = 0;
+		int kind = 0; // 0 nothing to do, 1 one lane, 2 one wave, 3 one group
+		if (!(level >= MAXLVL - 1 && depth[s] != level)) { // (shared overflow bucket)
+			r = v.ref[s];
+			d = v.outd[s];
+			if (r != 0 && !(s >= v.nh && (uint64_t)(v.rowstart[s + 1] - v.rowstart[v.nh]) > v.succ_cap)) // E_CAP already raised
+				kind = (bigQueue && d >= COPY_BIG_MIN) ? 3 : (midQueue && d >= midMin) ? 2 : 1;
 		}
-		copy_node<DEF>(g, v.lo + s, v.outd[s], (int64_t)v.outd[s - r], v.row(s), v.row(s - r), err);
+		// queue pushes are aggregated per wave (same-address atomics run at ~88 M/s)
+#pragma unroll
+		for (int cls = 2; cls <= 3; cls++) {
+			const unsigned long long m = mode == 2 ? 0ull : __ballot(kind == cls);
+			if (m) {
+				const int leader = __ffsll((long long)m) - 1;
+				int32_t base = 0;
+				if (lane == leader) base = atomicAdd(cls == 3 ? bigCount : midCount, (int32_t)__popcll(m));
+				base = __shfl(base, leader, 64);
+				if (kind == cls) {
+					const int32_t q = base + (int32_t)__popcll(m & ((1ull << lane) - 1ull));
+					if (q < (cls == 3 ? bigCap : midCap)) (cls == 3 ? bigQueue : midQueue)[q] = s;
+					else kind = 1; // queue full (cannot happen with the caps of bvgpu_api.cpp): one lane does it
+				}
+			}
+		}
+		if (kind == 1 && mode != 1) copy_node<DEF>(g, v.lo + s, d, (int64_t)v.outd[s - r], v.row(s), v.row(s - r), err);
 	}
 }
 
-// One 1024-thread group per long row with a reference.  The copied ids (<= COPY_BIG_CAP of them) are gathered
-// into LDS and ranked among the row's extras by binary search; then the row is rebuilt in place chunk by chunk:
-// output position k holds copied id t if pos_t == k, else extra number k - #(copied positions before k), which
-// sits at or after k -- so reading a whole chunk before writing it never loses data (MergedIntIterator semantics
-// for the disjoint sets of a valid file).  Rows copying more than COPY_BIG_CAP ids fall back to one lane.
-constexpr int COPY_BIG_THREADS = 1024, COPY_BIG_CAP = 6144, COPY_BIG_ITEMS = 8;
+// One wave per row of fewer than COPY_BIG_MIN successors with a reference.  The block list is walked once (by
+// every lane: it is short) into two LDS tables -- for the j-th copied block, the number of ids copied up to its
+// end and the offset between an id's index in the referent's row and its index among the copied ids.  Then the
+// copied ids and the row's extras are loaded into LDS with coalesced loads, and every id finds its final
+// position by ONE binary search in the other set (the sets are disjoint in a valid file): copied id t goes to
+// t + #(extras smaller), extra e to e + #(copied ids smaller).
+constexpr int COPY_MID_WAVES = 4;
 template <bool DEF>
-__global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, RangeView v, const int32_t *__restrict__ bigQueue, const int32_t *__restrict__ bigCount,
-                                                               int32_t bigCap, int *__restrict__ err) {
-	__shared__ int32_t cval[COPY_BIG_CAP], cpos[COPY_BIG_CAP];
-	const int32_t nq = min(*bigCount, bigCap);
-	for (int32_t qi = blockIdx.x; qi < nq; qi += gridDim.x) {
-		const int32_t s = bigQueue[qi];
+__global__ void __launch_bounds__(64 * COPY_MID_WAVES) k_copy_mid(GraphDev g, RangeView v, const int32_t *__restrict__ midQueue, const int32_t *__restrict__ midCount,
+                                                                  int32_t midCap, int *__restrict__ err) {
+	__shared__ int32_t s_vals[COPY_MID_WAVES][COPY_BIG_MIN], s_kend[COPY_MID_WAVES][COPY_BIG_MIN + 1], s_delta[COPY_MID_WAVES][COPY_BIG_MIN + 1];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	int32_t *vals = s_vals[wave], *kend = s_kend[wave], *delta = s_delta[wave];
+	auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); };
+	const int32_t nq = min(*midCount, midCap);
+	for (int32_t qi = blockIdx.x * COPY_MID_WAVES + wave; qi < nq; qi += gridDim.x * COPY_MID_WAVES) {
+		const int32_t s = midQueue[qi];
 		const int32_t d = v.outd[s], r = v.ref[s];
 		const int64_t dref = v.outd[s - r];
 		int32_t *row = v.row(s);
 		const int32_t *src = v.row(s - r);
-		// header + block totals (uniform)
+		// header + blocks (uniform)
 		BitReader br;
 		br.init(g.bits, g.nwords);
 		br.seek((uint64_t)g.offsets[v.lo + s]);
@@ -436,65 +459,139 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 		(void)Fields<DEF>::reference(br, g);
 		const uint64_t bc = Fields<DEF>::block_count(br, g);
 		if (bc > (uint64_t)dref + 1) continue; // flagged by the parse kernel
-		const uint64_t blocksPos = br.pos();
 		int64_t total = 0, copied = 0;
-		for (uint64_t b = 0; b < bc; b++) {
-			const int64_t len = (int64_t)Fields<DEF>::block(br, g) + (b ? 1 : 0);
+		int32_t nKept = 0;
+		bool bad = false;
+		for (uint64_t b = 0; b <= bc; b++) {
+			int64_t len;
+			if (b < bc) len = (int64_t)Fields<DEF>::block(br, g) + (b ? 1 : 0);
+			else len = dref - total; // implicit last block (copied when the block count is even)
+			if (len < 0 || total + len > dref) { bad = true; break; }
+			if (!(b & 1)) {
+				if (copied + len > d || nKept > COPY_BIG_MIN) { bad = true; break; }
+				if (lane == (nKept & 63)) { kend[nKept] = (int32_t)(copied + len); delta[nKept] = (int32_t)(total - copied); }
+				nKept++;
+				copied += len;
+			}
 			total += len;
-			if (!(b & 1)) copied += len;
 		}
-		if (total > dref) continue;
-		if (!(bc & 1)) copied += dref - total;
-		if (copied > d || copied == 0) continue; // nothing to merge: the extras already fill the row
+		if (bad || br.err || copied == 0) continue; // malformed (flagged by the parse kernel) or nothing to merge
+		const int32_t nExtra = d - (int32_t)copied, nc = (int32_t)copied;
+		wave_sync();
+		// gather: copied ids -> vals[0 .. nc), extras -> vals[nc .. d)
+		for (int32_t t = lane; t < nc; t += 64) {
+			int32_t lo = 0, hi = nKept; // first kept block with kend > t
+			while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (kend[mid] <= t) lo = mid + 1; else hi = mid; }
+			vals[t] = src[t + delta[lo]];
+		}
+		for (int32_t e = lane; e < nExtra; e += 64) vals[nc + e] = row[nc + e];
+		wave_sync();
+		// final positions
+		for (int32_t t = lane; t < d; t += 64) {
+			const int32_t val = vals[t];
+			int32_t lo, hi;
+			if (t < nc) { lo = nc; hi = d; } // copied id: count the extras below it
+			else { lo = 0; hi = nc; }        // extra: count the copied ids below it
+			while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (vals[mid] < val) lo = mid + 1; else hi = mid; }
+			row[t - nc + lo] = val;
+		}
+		wave_sync(); // the tables are reused by the next row
+	}
+}
+
+// One 1024-thread group per long row with a reference.  The block list is walked once, without memory traffic
+// (it is the serial part of a row with thousands of blocks), into the same two LDS tables as in k_copy_mid; the
+// copied ids (<= COPY_BIG_CAP of them) are then gathered into LDS and ranked among the row's extras
+// row[copied..d) by binary search.  Then the extras move LEFT in place, chunk by chunk: extra e goes to
+// e + #(copied ids smaller than it), which is never to the right of where it sits, and never onto an extra with
+// a larger index -- so a chunk may be written once every extra up to its end has been read, and the NEXT chunk
+// is already being read while this one is written.  The copied ids drop into the gaps at the end
+// (MergedIntIterator semantics for the disjoint sets of a valid file).  Rows copying more than COPY_BIG_CAP ids
+// fall back to one lane.
+constexpr int COPY_BIG_THREADS = 1024, COPY_BIG_CAP = 6144, COPY_BIG_ITEMS = 8;
+template <bool DEF>
+__global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, RangeView v, const int32_t *__restrict__ bigQueue, const int32_t *__restrict__ bigCount,
+                                                               int32_t bigCap, int *__restrict__ err) {
+	__shared__ int32_t cval[COPY_BIG_CAP], cpos[COPY_BIG_CAP + 1], delta[COPY_BIG_CAP + 1];
+	int32_t *kend = cpos; // during the gather: ids copied up to the end of the j-th copied block
+	const int32_t nq = min(*bigCount, bigCap);
+	for (int32_t qi = blockIdx.x; qi < nq; qi += gridDim.x) {
+		const int32_t s = bigQueue[qi];
+		const int32_t d = v.outd[s], r = v.ref[s];
+		const int64_t dref = v.outd[s - r];
+		int32_t *row = v.row(s);
+		const int32_t *src = v.row(s - r);
+		__syncthreads(); // the LDS tables of the previous row are free
+		// header + blocks (uniform)
+		BitReader br;
+		br.init(g.bits, g.nwords);
+		br.seek((uint64_t)g.offsets[v.lo + s]);
+		(void)Fields<DEF>::outdegree(br, g);
+		(void)Fields<DEF>::reference(br, g);
+		const uint64_t bc = Fields<DEF>::block_count(br, g);
+		if (bc > (uint64_t)dref + 1) continue; // flagged by the parse kernel
+		int64_t total = 0, copied = 0;
+		int32_t nKept = 0;
+		bool bad = false;
+		for (uint64_t b = 0; b <= bc; b++) {
+			int64_t len;
+			if (b < bc) len = (int64_t)Fields<DEF>::block(br, g) + (b ? 1 : 0);
+			else len = dref - total; // implicit last block (copied when the block count is even)
+			if (len < 0 || total + len > dref) { bad = true; break; }
+			if (!(b & 1)) {
+				if (nKept <= COPY_BIG_CAP && (int32_t)threadIdx.x == (nKept & (COPY_BIG_THREADS - 1))) { kend[nKept] = (int32_t)min<int64_t>(copied + len, 0x7fffffff); delta[nKept] = (int32_t)(total - copied); }
+				nKept++;
+				copied += len;
+			}
+			total += len;
+		}
+		if (bad || br.err || copied > d || copied == 0) continue; // malformed (flagged by the parse kernel) / nothing to merge: the extras already fill the row
+		if (g.stats && threadIdx.x == 0) { stat_add(g, 8, 1); stat_add(g, 9, bc); stat_max(g, 15, bc); stat_add(g, 12, (unsigned long long)d); stat_max(g, 14, (unsigned long long)d); if (copied > COPY_BIG_CAP) stat_add(g, 13, 1); }
 		if (copied > COPY_BIG_CAP) { // too many copied ids for the LDS tables: one lane does it
 			if (threadIdx.x == 0) copy_node<DEF>(g, v.lo + s, d, dref, row, src, err);
-			__syncthreads();
 			continue;
 		}
-		// gather the copied ids: blocks are walked by every thread, each thread loads the ids it owns
-		br.seek(blocksPos);
-		{
-			int64_t i = 0, o = 0;
-			for (uint64_t b = 0; b <= bc; b++) {
-				int64_t len;
-				if (b < bc) len = (int64_t)Fields<DEF>::block(br, g) + (b ? 1 : 0);
-				else len = dref - i; // implicit last block
-				if (!(b & 1)) { for (int64_t e = threadIdx.x; e < len; e += COPY_BIG_THREADS) cval[o + e] = src[i + e]; o += len; }
-				i += len;
-			}
+		__syncthreads();
+		// gather the copied ids (a block of length 0 is possible only in first position, so nKept <= copied + 1)
+		const int32_t nc = (int32_t)copied, nExtra = d - nc;
+		for (int32_t t = threadIdx.x; t < nc; t += COPY_BIG_THREADS) {
+			int32_t lo = 0, hi = nKept; // first copied block with kend > t
+			while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (kend[mid] <= t) lo = mid + 1; else hi = mid; }
+			cval[t] = src[t + delta[lo]];
 		}
 		__syncthreads();
-		// rank of every copied id among the extras row[copied .. d)
-		const int64_t nExtra = (int64_t)d - copied;
-		for (int64_t t = threadIdx.x; t < copied; t += COPY_BIG_THREADS) {
+		// rank of every copied id among the extras (still at row[copied .. d))
+		for (int32_t t = threadIdx.x; t < nc; t += COPY_BIG_THREADS) {
 			const int32_t cv = cval[t];
-			int64_t lo = 0, hi = nExtra;
-			while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (row[copied + mid] < cv) lo = mid + 1; else hi = mid; }
-			cpos[t] = (int32_t)(t + lo);
+			int32_t lo = 0, hi = nExtra;
+			while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (row[nc + mid] < cv) lo = mid + 1; else hi = mid; }
+			cpos[t] = t + lo;
 		}
 		__syncthreads();
-		const int64_t lastPos = cpos[copied - 1]; // positions after it keep their extras
-		for (int64_t k0 = 0; k0 <= lastPos; k0 += (int64_t)COPY_BIG_THREADS * COPY_BIG_ITEMS) {
-			int32_t vals[COPY_BIG_ITEMS];
+		// extras up to the one following the last copied id move; the rest stay where they are
+		const int32_t nMove = cpos[nc - 1] - (nc - 1);
+		constexpr int32_t CHUNK = COPY_BIG_THREADS * COPY_BIG_ITEMS;
+		int32_t cur[COPY_BIG_ITEMS], nxt[COPY_BIG_ITEMS];
+#pragma unroll
+		for (int u = 0; u < COPY_BIG_ITEMS; u++) { const int32_t e = u * COPY_BIG_THREADS + (int32_t)threadIdx.x; nxt[u] = e < nMove ? row[nc + e] : 0; }
+		for (int32_t e0 = 0; e0 < nMove; e0 += CHUNK) {
+#pragma unroll
+			for (int u = 0; u < COPY_BIG_ITEMS; u++) cur[u] = nxt[u];
+			__syncthreads(); // every extra up to the end of this chunk has been read
+#pragma unroll
+			for (int u = 0; u < COPY_BIG_ITEMS; u++) { const int32_t e = e0 + CHUNK + u * COPY_BIG_THREADS + (int32_t)threadIdx.x; nxt[u] = e < nMove ? row[nc + e] : 0; }
 #pragma unroll
 			for (int u = 0; u < COPY_BIG_ITEMS; u++) {
-				const int64_t k = k0 + (int64_t)u * COPY_BIG_THREADS + threadIdx.x;
-				vals[u] = 0;
-				if (k <= lastPos) {
-					int64_t lo = 0, hi = copied; // copied positions before k
-					while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (cpos[mid] < k) lo = mid + 1; else hi = mid; }
-					vals[u] = (lo < copied && cpos[lo] == k) ? cval[lo] : row[copied + (k - lo)];
+				const int32_t e = e0 + u * COPY_BIG_THREADS + (int32_t)threadIdx.x;
+				if (e < nMove) {
+					int32_t lo = 0, hi = nc; // copied ids smaller than this extra
+					while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (cval[mid] < cur[u]) lo = mid + 1; else hi = mid; }
+					if (lo < nc) row[e + lo] = cur[u];
 				}
 			}
-			__syncthreads(); // the whole chunk is in registers
-#pragma unroll
-			for (int u = 0; u < COPY_BIG_ITEMS; u++) {
-				const int64_t k = k0 + (int64_t)u * COPY_BIG_THREADS + threadIdx.x;
-				if (k <= lastPos) row[k] = vals[u];
-			}
-			__syncthreads();
 		}
-		if (br.err && threadIdx.x == 0) atomicOr(err, br.err);
+		__syncthreads(); // all extras are in place
+		for (int32_t t = threadIdx.x; t < nc; t += COPY_BIG_THREADS) row[cpos[t]] = cval[t];
 	}
 }
 
@@ -897,14 +994,36 @@ void launch_parse_giants(const GraphDev &g, bool def, const RangeView &v, const 
 	else hipLaunchKernelGGL((k_parse_big<false, GIANT_NW>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, st, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
 }
 
+// One chain level of the copy pass.  stBig == st: everything in order on one stream.  Otherwise the long rows
+// (one 1024-thread group each, dominated by the few longest rows) run on stBig next to the short and medium
+// ones; evQ / evBig are the fork and join events.
 void launch_copy_list(const GraphDev &g, bool def, const RangeView &v, const int32_t *depth, const int32_t *list, const int32_t *keyBase, int32_t level, int blocks,
-                      int32_t *bigQueue, int32_t *bigCount, int32_t bigCap, int *err, hipStream_t st) {
+                      int32_t *bigQueue, int32_t *bigCount, int32_t bigCap, int32_t *midQueue, int32_t *midCount, int32_t midCap, int32_t midMin, int *err, hipStream_t st,
+                      hipStream_t stBig, hipEvent_t evQ, hipEvent_t evBig) {
 	if (v.cnt <= 0) return;
-	if (def) hipLaunchKernelGGL(k_copy_list<true>, dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, bigQueue, bigCount, bigCap, err);
-	else hipLaunchKernelGGL(k_copy_list<false>, dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, bigQueue, bigCount, bigCap, err);
-	if (!bigQueue) return;
-	if (def) hipLaunchKernelGGL(k_copy_big<true>, dim3(512), dim3(COPY_BIG_THREADS), 0, st, g, v, bigQueue, bigCount, bigCap, err);
-	else hipLaunchKernelGGL(k_copy_big<false>, dim3(512), dim3(COPY_BIG_THREADS), 0, st, g, v, bigQueue, bigCount, bigCap, err);
+	const bool split = bigQueue && stBig != st;
+	auto list_pass = [&](int mode, int nblocks) {
+		if (def) hipLaunchKernelGGL(k_copy_list<true>, dim3(nblocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, bigQueue, bigCount, bigCap, midQueue, midCount, midCap, midMin, mode, err);
+		else hipLaunchKernelGGL(k_copy_list<false>, dim3(nblocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, bigQueue, bigCount, bigCap, midQueue, midCount, midCap, midMin, mode, err);
+	};
+	auto big_pass = [&](hipStream_t s_) {
+		if (def) hipLaunchKernelGGL(k_copy_big<true>, dim3(512), dim3(COPY_BIG_THREADS), 0, s_, g, v, bigQueue, bigCount, bigCap, err);
+		else hipLaunchKernelGGL(k_copy_big<false>, dim3(512), dim3(COPY_BIG_THREADS), 0, s_, g, v, bigQueue, bigCount, bigCap, err);
+	};
+	if (split) {
+		list_pass(1, blocks);
+		hipEventRecord(evQ, st);
+		hipStreamWaitEvent(stBig, evQ, 0);
+		big_pass(stBig);
+		hipEventRecord(evBig, stBig);
+		list_pass(2, blocks);
+	} else list_pass(0, blocks);
+	if (midQueue) {
+		if (def) hipLaunchKernelGGL(k_copy_mid<true>, dim3(1024), dim3(64 * COPY_MID_WAVES), 0, st, g, v, midQueue, midCount, midCap, err);
+		else hipLaunchKernelGGL(k_copy_mid<false>, dim3(1024), dim3(64 * COPY_MID_WAVES), 0, st, g, v, midQueue, midCount, midCap, err);
+	}
+	if (split) hipStreamWaitEvent(st, evBig, 0);
+	else if (bigQueue) big_pass(st);
 }
 
 void launch_parse_list(const GraphDev &g, bool def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st) {

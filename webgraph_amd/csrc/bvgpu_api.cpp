@@ -67,7 +67,7 @@ struct Pending { // an enqueued range decode whose status has not been collected
 	int32_t levels_done = 0;
 	bool want_succ = false;
 	int32_t giantCap = 0;
-	int32_t bigCap = 0;
+	int32_t bigCap = 0, midCap = 0;
 };
 
 } // namespace
@@ -91,6 +91,7 @@ struct bvg_graph {
 	DevBuf plist, pkeys, pkey16;
 	DevBuf cbigq, cbigc; // per-level queues of long rows for the cooperative copy
 	int copy_big = 1;    // BVGPU_COPY_BIG=0: every row is copied by one lane
+	int copy_mid_min = 64; // rows with at least this many successors (and fewer than 1024) are copied by one wave each
 	int copy_lists = 1; // BVGPU_COPY_LISTS=0: node-order sweeps over all slots instead of per-level compact lists
 	int32_t coop_min = 2048, giant_min = 65536;                         // thresholds on the outdegree (BVGPU_COOP_MIN / BVGPU_GIANT_MIN)
 	int coop_waves = 4096, giant_groups = 256;
@@ -164,6 +165,7 @@ int init_handle(bvg_graph *g) {
 	if (const char *e = getenv("BVGPU_COPY_LISTS")) g->copy_lists = atoi(e);
 	if (const char *e = getenv("BVGPU_PARSE_LISTS")) g->parse_lists = atoi(e);
 	if (const char *e = getenv("BVGPU_COPY_BIG")) g->copy_big = atoi(e);
+	if (const char *e = getenv("BVGPU_COPY_MID_MIN")) g->copy_mid_min = std::min(std::max(0, atoi(e)), 1024); // 0: no wave-per-row copy
 	if (const char *e = getenv("BVGPU_OVERLAP")) g->overlap = atoi(e) != 0;
 	HIPCHK(g, hipStreamCreateWithFlags(&g->sideA, hipStreamNonBlocking));
 	HIPCHK(g, hipStreamCreateWithFlags(&g->sideB, hipStreamNonBlocking));
@@ -243,7 +245,9 @@ int finish_pending(bvg_graph *g, uint64_t *arcs_out) {
 			for (int32_t l = g->pend.levels_done + 1; l <= upto; l++) {
 				if (!g->fused) {
 					if (g->copy_lists) bv::launch_copy_list(gd, s.def, g->pend.view, g->depth.as<int32_t>(), g->lvlist.as<int32_t>(), keyBase, l, g->level_blocks,
-					                                         g->copy_big && l < 1023 ? g->cbigq.as<int32_t>() : nullptr, g->cbigc.as<int32_t>() + std::min(l, 1023), g->pend.bigCap, derr, g->stream);
+					                                         g->copy_big && l < 1023 ? g->cbigq.as<int32_t>() : nullptr, g->cbigc.as<int32_t>() + std::min(l, 1023), g->pend.bigCap,
+					                                         g->copy_big && g->copy_mid_min > 0 && l < 1023 ? g->cbigq.as<int32_t>() + g->pend.bigCap : nullptr, g->cbigc.as<int32_t>() + 1024 + std::min(l, 1023), g->pend.midCap, g->copy_mid_min, derr, g->stream,
+					                                         g->overlap && !g->profile ? g->sideA : g->stream, g->evFork, g->evA);
 					else bv::launch_copy(gd, s.def, g->pend.view, g->depth.as<int32_t>(), l, derr, g->stream);
 					continue;
 				}
@@ -370,13 +374,18 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 			// long rows (>= 1024 successors) with a reference: at most arcs / 1024 of them
 			const int32_t bigCap = (int32_t)std::min<int64_t>(arcsBound / 1024 + 2, 0x7fffffff);
 			g->pend.bigCap = bigCap;
+			// medium rows (>= copy_mid_min successors): at most arcs / copy_mid_min of them
+			const int32_t midCap = g->copy_mid_min > 0 ? (int32_t)std::min<int64_t>(arcsBound / g->copy_mid_min + 2, 0x3fffffff) : 0;
+			g->pend.midCap = midCap;
 			if (g->copy_lists && g->copy_big) {
-				if (!g->cbigq.need(sizeof(int32_t) * (size_t)bigCap * 1) || !g->cbigc.need(sizeof(int32_t) * 1024)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
-				HIPCHK(g, hipMemsetAsync(g->cbigc.p, 0, sizeof(int32_t) * 1024, g->stream));
+				if (!g->cbigq.need(sizeof(int32_t) * ((size_t)bigCap + (size_t)midCap)) || !g->cbigc.need(sizeof(int32_t) * 2048)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
+				HIPCHK(g, hipMemsetAsync(g->cbigc.p, 0, sizeof(int32_t) * 2048, g->stream));
 			}
 			for (int32_t l = 1; l <= levels; l++) {
 				if (g->copy_lists) bv::launch_copy_list(gd, s.def, v, g->depth.as<int32_t>(), g->lvlist.as<int32_t>(), keyBase, l, g->level_blocks,
-				                                         g->copy_big ? g->cbigq.as<int32_t>() : nullptr, g->cbigc.as<int32_t>() + std::min(l, 1023), bigCap, derr, g->stream);
+				                                         g->copy_big ? g->cbigq.as<int32_t>() : nullptr, g->cbigc.as<int32_t>() + std::min(l, 1023), bigCap,
+				                                         g->copy_big && midCap > 0 ? g->cbigq.as<int32_t>() + bigCap : nullptr, g->cbigc.as<int32_t>() + 1024 + std::min(l, 1023), midCap, g->copy_mid_min, derr, g->stream,
+				                                         ovl ? g->sideA : g->stream, g->evFork, g->evA);
 				else bv::launch_copy(gd, s.def, v, g->depth.as<int32_t>(), l, derr, g->stream); // sweep in node order: rows of neighbouring nodes are neighbours in memory
 			}
 		}
