@@ -295,9 +295,11 @@ __global__ void __launch_bounds__(TPB) k_depth_keys(GraphDev g, int32_t lo, int3
 		const int32_t s = blockIdx.x * LIST_TILE + it * TPB + threadIdx.x;
 		if (s >= cnt) break;
 		int32_t dd = 0;
-		int32_t y = s;
-		for (;;) { const int32_t r = ref[y]; if (r == 0) break; y -= r; dd++; } // ref[] is 0 for empty / unneeded nodes
-		depth[s] = dd;
+		if (!(noBin & 2)) { // (a list that ignores the level needs no depth: `depth` may be NULL)
+			int32_t y = s;
+			for (;;) { const int32_t r = ref[y]; if (r == 0) break; y -= r; dd++; } // ref[] is 0 for empty / unneeded nodes
+			depth[s] = dd;
+		}
 		uint16_t key = KEY_NONE;
 		if (outd[s] > 0) {
 			// work of a record ~ codes to parse + successors to emit: a short record can still expand to a huge

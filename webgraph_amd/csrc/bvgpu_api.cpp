@@ -98,7 +98,7 @@ struct bvg_graph {
 	DevBuf stats; // BVGPU_STATS=1: tuning counters
 	// the three parse kernels (giant / big / short records) are independent: they run on forked streams
 	hipStream_t sideA = nullptr, sideB = nullptr;
-	hipEvent_t evFork = nullptr, evA = nullptr, evB = nullptr;
+	hipEvent_t evFork = nullptr, evA = nullptr, evB = nullptr, evC = nullptr;
 	bool overlap = true;
 	Small *h_small = nullptr; // pinned
 	int32_t levels_hint = 1;
@@ -174,6 +174,7 @@ int init_handle(bvg_graph *g) {
 	HIPCHK(g, hipEventCreateWithFlags(&g->evOut, hipEventDisableTiming));
 	HIPCHK(g, hipEventCreateWithFlags(&g->evA, hipEventDisableTiming));
 	HIPCHK(g, hipEventCreateWithFlags(&g->evB, hipEventDisableTiming));
+	HIPCHK(g, hipEventCreateWithFlags(&g->evC, hipEventDisableTiming));
 	if (const char *e = getenv("BVGPU_STATS")) if (atoi(e)) { if (!g->stats.need(32 * sizeof(unsigned long long))) return fail(g, BVG_ENOMEM, "device allocation failed"); HIPCHK(g, hipMemset(g->stats.p, 0, 256)); }
 	return BVG_OK;
 }
@@ -327,46 +328,56 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 		int32_t *hist = g->keys.as<int32_t>(), *keyBase = hist + (bv::NKEYS + 1), *cursor = keyBase + (bv::NKEYS + 1);
 		int32_t *ctl = g->coopctl.as<int32_t>();
 		HIPCHK(g, hipMemsetAsync(ctl, 0, 8 * sizeof(int32_t), g->stream));
+		const bool coop = g->coop_min < 0x7fffffff;
+		const bool ovl = g->overlap && !g->profile; // per-kernel timing needs the kernels one after the other
+		v.coop_min = coop ? g->coop_min : 0x7fffffff;
+		// Three things run next to each other from here on (unless profiling serialises them):
+		//   side B: classification of the long records, then the giant ones (a group of waves each) -- the longest
+		//           dependency chains of the scan, which need nothing but the outdegrees and the row starts;
+		//   side A: chain depths + per-level lists (only the copy pass needs them), then the big records (a wave each);
+		//   here:   the parse list and the one-lane parse of everything else.
+		hipStream_t stLists = g->stream;
+		if (ovl) {
+			HIPCHK(g, hipEventRecord(g->evFork, g->stream));
+			HIPCHK(g, hipStreamWaitEvent(g->sideA, g->evFork, 0));
+			HIPCHK(g, hipStreamWaitEvent(g->sideB, g->evFork, 0));
+			stLists = g->sideA;
+			if (coop) {
+				bv::launch_classify(v.cnt, v.outd, g->coop_min, g->giant_min, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, g->sideB);
+				HIPCHK(g, hipEventRecord(g->evC, g->sideB));
+			}
+		}
 		// chain depth of every record (+ per-level lists, node order inside a level)
 		if (W > 0) bv::launch_build_lists(gd, v, ~0ull, 1, g->depth.as<int32_t>(), g->key16.as<uint16_t>(), hist, keyBase, cursor, g->lvlist.as<int32_t>(),
-		                                  g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->maxdepth, g->stream);
+		                                  g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->maxdepth, stLists);
+		if (ovl) {
+			if (coop) {
+				HIPCHK(g, hipStreamWaitEvent(g->sideA, g->evC, 0));
+				bv::launch_parse_big(gd, s.def, v, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, g->giant_groups, derr, g->sideB, g->sideA); // (giants, big)
+				HIPCHK(g, hipEventRecord(g->evB, g->sideB));
+			}
+			HIPCHK(g, hipEventRecord(g->evA, g->sideA));
+		}
 		// parse list: every non-empty record, sorted by work bin only
 		int32_t *pKeyBase = nullptr;
 		if (g->parse_lists) {
 			if (!g->plist.need(sizeof(int32_t) * (size_t)v.cnt) || !g->pkeys.need(3 * (bv::NKEYS + 1) * sizeof(int32_t)) || !g->pkey16.need(sizeof(uint16_t) * (size_t)v.cnt)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
 			int32_t *ph = g->pkeys.as<int32_t>();
 			pKeyBase = ph + (bv::NKEYS + 1);
-			// depth output of this second build is not needed: it goes to the (not yet used) big list buffer
-			bv::launch_build_lists(gd, v, ~0ull, 2, g->biglist.as<int32_t>(), g->pkey16.as<uint16_t>(), ph, pKeyBase, pKeyBase + (bv::NKEYS + 1), g->plist.as<int32_t>(),
+			bv::launch_build_lists(gd, v, ~0ull, 2, nullptr, g->pkey16.as<uint16_t>(), ph, pKeyBase, pKeyBase + (bv::NKEYS + 1), g->plist.as<int32_t>(),
 			                       g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->pad, g->stream);
 		}
-		const bool coop = g->coop_min < 0x7fffffff;
-		const bool ovl = g->overlap && !g->profile; // per-kernel timing needs the kernels one after the other
-		v.coop_min = coop ? g->coop_min : 0x7fffffff;
-		if (coop) {
-			HIPCHK(g, hipMemsetAsync(ctl, 0, 8 * sizeof(int32_t), g->stream));
-			bv::launch_classify(v.cnt, v.outd, g->coop_min, g->giant_min, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, g->stream);
-		}
+		if (coop && !ovl) bv::launch_classify(v.cnt, v.outd, g->coop_min, g->giant_min, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, g->stream);
 		mark(g, 3);
-		if (coop) {
-			if (ovl) {
-				HIPCHK(g, hipEventRecord(g->evFork, g->stream));
-				HIPCHK(g, hipStreamWaitEvent(g->sideA, g->evFork, 0));
-				HIPCHK(g, hipStreamWaitEvent(g->sideB, g->evFork, 0));
-				bv::launch_parse_big(gd, s.def, v, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, g->giant_groups, derr, g->sideA, g->sideB);
-				HIPCHK(g, hipEventRecord(g->evA, g->sideA));
-				HIPCHK(g, hipEventRecord(g->evB, g->sideB));
-			} else
-				bv::launch_parse_big(gd, s.def, v, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, g->giant_groups, derr, g->stream, g->stream);
-		}
+		if (coop && !ovl) bv::launch_parse_big(gd, s.def, v, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, g->giant_groups, derr, g->stream, g->stream);
 		mark(g, 4);
 		if (pKeyBase) {
 			bv::launch_parse_list(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, g->level_blocks, derr, g->stream);
 		}
 		else bv::launch_parse(gd, s.def, v, derr, g->stream);
-		if (coop && ovl) {
+		if (ovl) {
 			HIPCHK(g, hipStreamWaitEvent(g->stream, g->evA, 0));
-			HIPCHK(g, hipStreamWaitEvent(g->stream, g->evB, 0));
+			if (coop) HIPCHK(g, hipStreamWaitEvent(g->stream, g->evB, 0));
 		}
 		mark(g, 5);
 		if (W > 0) {
@@ -519,7 +530,7 @@ extern "C" int bvg_close(bvg_t *g) {
 		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist, &g->plist, &g->pkeys, &g->pkey16, &g->cbigq, &g->cbigc }) b->release();
 		if (g->h_small) (void)hipHostFree(g->h_small);
 		for (auto &e : g->ev) if (e) (void)hipEventDestroy(e);
-		for (hipEvent_t e : { g->evFork, g->evA, g->evB, g->evIn, g->evOut }) if (e) (void)hipEventDestroy(e);
+		for (hipEvent_t e : { g->evFork, g->evA, g->evB, g->evC, g->evIn, g->evOut }) if (e) (void)hipEventDestroy(e);
 		for (hipStream_t st : { g->sideA, g->sideB }) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
 	}
 	delete g;
