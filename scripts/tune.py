@@ -60,7 +60,7 @@ def main():
         print("res tiles %d rounds/tile %.2f | int tiles %d rounds/tile %.2f | big nodes %d ticks/node %.0f max ticks %d (x reps)" % (
             st[0], st[1] / max(st[0], 1), st[2], st[3] / max(st[2], 1), st[5], st[6] / max(st[5], 1), st[7] * args.reps))
         print("copy_big rows %d sum bc %d max bc %d sum d %d max d %d fallback rows %d (x reps; max raw)" % (st[8], st[9], st[15] * args.reps, st[12], st[14] * args.reps, st[13]))
-        print("giant residual tiles %d: first local rounds %.1f M ticks (%.1f rounds/tile), exchange phase %.1f M ticks (%.2f exchanges/tile)" % (st[11], st[12] / 1e6, st[13] / max(st[11], 1), st[14] / 1e6, st[10] / max(st[11], 1)))
+        print("giant residual tiles %d: first parse %.1f M ticks, local rounds %.1f M ticks, exchange phase %.1f M ticks (%.2f exchanges/tile)" % (st[11], st[12] / 1e6, st[13] / 1e6, st[14] / 1e6, st[10] / max(st[11], 1)))
         print("residual tile rounds histogram (<=2,<=4,<=8,<=16,<=32,<=64):", [int(v) for v in st[8:14]])
         print("ticks (M) NW=1: A %.1f I %.1f R+X %.1f | NW=16: A %.1f I %.1f R+X %.1f" % tuple(float(v) / 1e6 for v in (st[16], st[17], st[18], st[20], st[21], st[22])))
         print("giants residual ticks (M): stage %.0f rounds %.0f values %.0f rank %.0f flush %.0f fence %.0f expand %.0f loop %.0f" % tuple(float(v) / 1e6 for v in st[24:32]))

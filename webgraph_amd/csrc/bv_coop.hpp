@@ -37,10 +37,16 @@ constexpr int COOP_B_MIN = 96, COOP_CODES_PER_SEG = 12;
 #define COOP1_IVCAP 512
 #endif
 #ifndef COOPG_BMAX
-#define COOPG_BMAX 512
+#define COOPG_BMAX 1024
 #endif
 #ifndef COOPG_IVCAP
 #define COOPG_IVCAP 4096
+#endif
+#ifndef COOP_RUNIN_MAX
+#define COOP_RUNIN_MAX 256
+#endif
+#ifndef COOP_RUNIN_SHIFT
+#define COOP_RUNIN_SHIFT 1
 #endif
 #ifndef COOP_GIANT_NW
 #define COOP_GIANT_NW 8
@@ -337,9 +343,23 @@ __device__ __forceinline__ void spec_tile(const Grp<NW> &G, const GraphDev &g, c
 	const uint32_t secEndR = (uint32_t)min(secEnd - base, (uint64_t)0x7fffff00u);
 	const uint32_t segEnd = min(p0 + (uint32_t)(tid + 1) * B, secEndR);
 	s = min(p0 + (uint32_t)tid * B, secEndR);
+	// Run-in: a lane starts a little BEFORE its segment, so that its parse has usually locked onto the true code
+	// boundaries by the time it enters the segment; its start is then the first boundary inside the segment.
+	// Two neighbours that both locked on agree on that boundary at once, and the rounds below only repair the few
+	// that did not (each repair costs the wave the longest resync distance among its lanes).
+	if (COOP_RUNIN_MAX > 0 && tid > 0 && s < secEndR) {
+		const uint32_t R = min((uint32_t)COOP_RUNIN_MAX, B >> COOP_RUNIN_SHIFT);
+		uint32_t p = s - min(R, s - p0);
+		int err = 0;
+		while (p < s && !err) (void)win_code_rel<DEF, KIND>(g, src, p, err);
+		s = err ? s : min(p, secEndR);
+	}
 	uint32_t e;
 	int rounds = 1;
+	unsigned long long tq = (g.stats && NW != 1 && KIND == 0) ? __builtin_readcyclecounter() : 0;
+#define QT(slot) do { if (g.stats && NW != 1 && KIND == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); if (tid == 0) atomicAdd(&g.stats[slot], now_ - tq); tq = now_; } } while (0)
 	spec_parse<DEF, KIND>(g, src, base, s, segEnd, firstTile && tid == 0, e, c, sum);
+	QT(12);
 	// a parse that runs past the section end is wrong anyway; clamping keeps the lanes behind the end quiet
 	// instead of handing the overshoot down one lane per round
 	e = min(e, secEndR);
@@ -375,6 +395,7 @@ __device__ __forceinline__ void spec_tile(const Grp<NW> &G, const GraphDev &g, c
 		uint32_t waveStart = G.wave() == 0 ? p0 : s; // s of lane 0 = nominal boundary
 		waveStart = (uint32_t)__shfl((int)waveStart, 0, 64);
 		wave_rounds(waveStart);
+		QT(13);
 		for (int xr = 0; xr < NW + 1; xr++) {
 			if (lane == 63) G.xch[G.wave()] = (int64_t)e;
 			__syncthreads();
@@ -394,7 +415,9 @@ __device__ __forceinline__ void spec_tile(const Grp<NW> &G, const GraphDev &g, c
 			if (KIND == 0) stat_add(g, 10, 1);
 		}
 		if (KIND == 0) stat_add(g, 11, 1);
+		QT(14);
 	}
+#undef QT
 	stat_add(g, KIND == 0 ? 1 : 3, (unsigned long long)rounds);
 	stat_add(g, KIND == 0 ? 0 : 2, 1);
 	E = base + (uint64_t)G.bcast((int64_t)e, Grp<NW>::N - 1);
@@ -484,7 +507,7 @@ __device__ __forceinline__ void coop_residuals(const Grp<NW> &G, const GraphDev 
 	bool firstTile = true;
 	const uint32_t B = coop_pick_B(recEnd > pos ? recEnd - pos : 0, (uint64_t)nRes, N, CoopCfg<NW>::B_MAX); // the residual section ends with the record
 	unsigned long long tk = g.stats ? __builtin_readcyclecounter() : 0;
-#define RT(slot) do { if (g.stats && NW == 1) { const unsigned long long now_ = __builtin_readcyclecounter(); if (tid == 0) atomicAdd(&g.stats[24 + slot], now_ - tk); tk = now_; } } while (0)
+#define RT(slot) do { if (g.stats && NW != 1 && !(g.dbg & 16)) { const unsigned long long now_ = __builtin_readcyclecounter(); if (tid == 0) atomicAdd(&g.stats[24 + slot], now_ - tk); tk = now_; } } while (0)
 	while (resDone < nRes) {
 		RT(7);
 		const WindowSrc src = stage_tile<NW>(G, g, win, pos, B);

@@ -287,9 +287,12 @@ constexpr int LIST_ITEMS = 16, LIST_TILE = TPB * LIST_ITEMS; // slots per block:
 
 __global__ void __launch_bounds__(TPB) k_depth_keys(GraphDev g, int32_t lo, int32_t cnt, const int32_t *__restrict__ outd, const uint16_t *__restrict__ ref,
                                                     uint64_t giantBits, int32_t noBin, int32_t *__restrict__ depth, uint16_t *__restrict__ key16,
-                                                    int32_t *__restrict__ hist, int32_t *__restrict__ ctl, int32_t *__restrict__ maxdepth) {
+                                                    int32_t *__restrict__ hist, int32_t *__restrict__ ctl, int32_t *__restrict__ maxdepth,
+                                                    int32_t *__restrict__ bigQ, int32_t bigCap, int32_t *__restrict__ midQ, int32_t midCap, int32_t midMin, int32_t bigMin) {
 	__shared__ int32_t s_hist[NKEYS + 1];
+	__shared__ int32_t s_q[LIST_TILE], s_qn[2], s_qbase[2]; // rows for the copy queues: wave class from the front, group class from the back
 	for (int k = threadIdx.x; k <= NKEYS; k += TPB) s_hist[k] = 0;
+	if (threadIdx.x < 2) s_qn[threadIdx.x] = 0;
 	__syncthreads();
 	for (int it = 0; it < LIST_ITEMS; it++) {
 		const int32_t s = blockIdx.x * LIST_TILE + it * TPB + threadIdx.x;
@@ -312,6 +315,20 @@ __global__ void __launch_bounds__(TPB) k_depth_keys(GraphDev g, int32_t lo, int3
 			if (dd >= MAXLVL - 1 && dd > __builtin_nontemporal_load(maxdepth)) atomicMax(maxdepth, dd); // only very deep chains get here
 		}
 		key16[s] = key;
+		// rows with a reference that the copy pass will merge with a wave (ctl[6]) or a whole group (ctl[5]) each are
+		// queued once, for all levels; collected per block first (same-address global atomics run at ~88 M/s)
+		if (bigQ && ref[s]) {
+			const int32_t d = outd[s];
+			if (d >= bigMin) s_q[LIST_TILE - 1 - atomicAdd(&s_qn[1], 1)] = s;
+			else if (d >= midMin) s_q[atomicAdd(&s_qn[0], 1)] = s;
+		}
+	}
+	__syncthreads();
+	if (bigQ) {
+		if (threadIdx.x < 2 && s_qn[threadIdx.x]) s_qbase[threadIdx.x] = atomicAdd(&ctl[threadIdx.x ? 5 : 6], s_qn[threadIdx.x]);
+		__syncthreads();
+		for (int k = threadIdx.x; k < s_qn[0]; k += TPB) if (s_qbase[0] + k < midCap) midQ[s_qbase[0] + k] = s_q[k]; // (the caps of bvgpu_api.cpp cannot be exceeded)
+		for (int k = threadIdx.x; k < s_qn[1]; k += TPB) if (s_qbase[1] + k < bigCap) bigQ[s_qbase[1] + k] = s_q[LIST_TILE - 1 - k];
 	}
 	__syncthreads();
 	for (int k = threadIdx.x; k <= NKEYS; k += TPB) { const int32_t c = s_hist[k]; if (c) atomicAdd(k == NKEYS ? &ctl[1] : &hist[k], c); }
@@ -390,45 +407,29 @@ __global__ void __launch_bounds__(64) k_copy_giants(GraphDev g, RangeView v, con
 	copy_node<DEF>(g, v.lo + s, v.outd[s], (int64_t)v.outd[s - r], v.row(s), v.row(s - r), err);
 }
 
-// copy pass over the compact list of one chain level.  Only short rows are merged by one lane: a lane-serial
-// merge of a long row would be the tail of the whole scan, so rows with >= COPY_BIG_MIN successors are queued for
-// k_copy_big (a 1024-thread group each) and rows with >= midMin successors for k_copy_mid (a wave each).
+// The copy pass of one chain level runs as three kernels side by side over the level's compact list, each picking
+// the rows of its class: rows with fewer than midMin successors are merged by one lane each (k_copy_list), rows
+// with fewer than COPY_BIG_MIN by one wave each (k_copy_mid), longer ones by a 1024-thread group each (k_copy_big).
+// A lane-serial merge of a long row would be the tail of the whole scan.
 constexpr int COPY_BIG_MIN = 1024;
+// class of row s at this level: 0 nothing to do, 1 one lane, 2 one wave, 3 one group
+__device__ __forceinline__ int copy_class(const RangeView &v, const int32_t *__restrict__ depth, int32_t level, int32_t s, int32_t midMin, int32_t bigMin) {
+	if (level >= MAXLVL - 1 && depth[s] != level) return 0; // shared overflow bucket
+	if (v.ref[s] == 0) return 0;
+	if (s >= v.nh && (uint64_t)(v.rowstart[s + 1] - v.rowstart[v.nh]) > v.succ_cap) return 0; // E_CAP already raised
+	const int32_t d = v.outd[s];
+	return d >= bigMin ? 3 : d >= midMin ? 2 : 1;
+}
 template <bool DEF>
 __global__ void __launch_bounds__(TPB) k_copy_list(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ list,
-                                                   const int32_t *__restrict__ keyBase, int32_t level, int32_t *__restrict__ bigQueue, int32_t *__restrict__ bigCount,
-                                                   int32_t bigCap, int32_t *__restrict__ midQueue, int32_t *__restrict__ midCount, int32_t midCap, int32_t midMin,
-                                                   int32_t mode, int *__restrict__ err) { // mode 0: queue + merge short rows; 1: queue only; 2: short rows only
+                                                   const int32_t *__restrict__ keyBase, int32_t level, int32_t midMin, int32_t bigMin, int *__restrict__ err) {
 	const int32_t bucket = min(level, MAXLVL - 1);
 	const int32_t lo = keyBase[bucket * NBIN], hi = keyBase[(bucket + 1) * NBIN];
-	const int lane = threadIdx.x & 63;
 	for (int32_t idx = hi - 1 - (blockIdx.x * TPB + threadIdx.x); idx >= lo; idx -= gridDim.x * TPB) {
 		const int32_t s = list[idx];
-		int32_t r = 0, d = 0;
-		int kind = 0; // 0 nothing to do, 1 one lane, 2 one wave, 3 one group
-		if (!(level >= MAXLVL - 1 && depth[s] != level)) { // (shared overflow bucket)
-			r = v.ref[s];
-			d = v.outd[s];
-			if (r != 0 && !(s >= v.nh && (uint64_t)(v.rowstart[s + 1] - v.rowstart[v.nh]) > v.succ_cap)) // E_CAP already raised
-				kind = (bigQueue && d >= COPY_BIG_MIN) ? 3 : (midQueue && d >= midMin) ? 2 : 1;
-		}
-		// queue pushes are aggregated per wave (same-address atomics run at ~88 M/s)
-#pragma unroll
-		for (int cls = 2; cls <= 3; cls++) {
-			const unsigned long long m = mode == 2 ? 0ull : __ballot(kind == cls);
-			if (m) {
-				const int leader = __ffsll((long long)m) - 1;
-				int32_t base = 0;
-				if (lane == leader) base = atomicAdd(cls == 3 ? bigCount : midCount, (int32_t)__popcll(m));
-				base = __shfl(base, leader, 64);
-				if (kind == cls) {
-					const int32_t q = base + (int32_t)__popcll(m & ((1ull << lane) - 1ull));
-					if (q < (cls == 3 ? bigCap : midCap)) (cls == 3 ? bigQueue : midQueue)[q] = s;
-					else kind = 1; // queue full (cannot happen with the caps of bvgpu_api.cpp): one lane does it
-				}
-			}
-		}
-		if (kind == 1 && mode != 1) copy_node<DEF>(g, v.lo + s, d, (int64_t)v.outd[s - r], v.row(s), v.row(s - r), err);
+		if (copy_class(v, depth, level, s, midMin, bigMin) != 1) continue;
+		const int32_t r = v.ref[s];
+		copy_node<DEF>(g, v.lo + s, v.outd[s], (int64_t)v.outd[s - r], v.row(s), v.row(s - r), err);
 	}
 }
 
@@ -440,15 +441,17 @@ __global__ void __launch_bounds__(TPB) k_copy_list(GraphDev g, RangeView v, cons
 // t + #(extras smaller), extra e to e + #(copied ids smaller).
 constexpr int COPY_MID_WAVES = 4;
 template <bool DEF>
-__global__ void __launch_bounds__(64 * COPY_MID_WAVES) k_copy_mid(GraphDev g, RangeView v, const int32_t *__restrict__ midQueue, const int32_t *__restrict__ midCount,
-                                                                  int32_t midCap, int *__restrict__ err) {
+__global__ void __launch_bounds__(64 * COPY_MID_WAVES) k_copy_mid(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ queue,
+                                                                  const int32_t *__restrict__ count, int32_t cap, int32_t level, int *__restrict__ err) {
 	__shared__ int32_t s_vals[COPY_MID_WAVES][COPY_BIG_MIN], s_kend[COPY_MID_WAVES][COPY_BIG_MIN + 1], s_delta[COPY_MID_WAVES][COPY_BIG_MIN + 1];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	int32_t *vals = s_vals[wave], *kend = s_kend[wave], *delta = s_delta[wave];
 	auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); };
-	const int32_t nq = min(*midCount, midCap);
+	// the queue holds the rows of this class of ALL levels: a wave takes the entries of this level among its share
+	const int32_t nq = min(*count, cap);
 	for (int32_t qi = blockIdx.x * COPY_MID_WAVES + wave; qi < nq; qi += gridDim.x * COPY_MID_WAVES) {
-		const int32_t s = midQueue[qi];
+		const int32_t s = queue[qi];
+		if (depth[s] != level || copy_class(v, depth, level, s, 0, 0x7fffffff) == 0) continue;
 		const int32_t d = v.outd[s], r = v.ref[s];
 		const int64_t dref = v.outd[s - r];
 		int32_t *row = v.row(s);
@@ -512,48 +515,80 @@ __global__ void __launch_bounds__(64 * COPY_MID_WAVES) k_copy_mid(GraphDev g, Ra
 // fall back to one lane.
 constexpr int COPY_BIG_THREADS = 1024, COPY_BIG_CAP = 6144, COPY_BIG_ITEMS = 8;
 template <bool DEF>
-__global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, RangeView v, const int32_t *__restrict__ bigQueue, const int32_t *__restrict__ bigCount,
-                                                               int32_t bigCap, int *__restrict__ err) {
+__global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ queue,
+                                                               const int32_t *__restrict__ count, int32_t cap, int32_t level, int *__restrict__ err) {
 	__shared__ int32_t cval[COPY_BIG_CAP], cpos[COPY_BIG_CAP + 1], delta[COPY_BIG_CAP + 1];
+	__shared__ uint32_t lwin[DEF ? LW_MAIN * LW_STRIDE : 1]; // stream window of the wave that walks the block list
+	__shared__ int64_t s_copied;
+	__shared__ int32_t s_kept, s_bad;
 	int32_t *kend = cpos; // during the gather: ids copied up to the end of the j-th copied block
-	const int32_t nq = min(*bigCount, bigCap);
+	// the queue holds the long rows of ALL levels (a few hundred): a group takes the entries of this level among its share
+	const int32_t nq = min(*count, cap);
 	for (int32_t qi = blockIdx.x; qi < nq; qi += gridDim.x) {
-		const int32_t s = bigQueue[qi];
+		const int32_t s = queue[qi];
+		if (depth[s] != level || copy_class(v, depth, level, s, 0, 0x7fffffff) == 0) continue;
 		const int32_t d = v.outd[s], r = v.ref[s];
 		const int64_t dref = v.outd[s - r];
 		int32_t *row = v.row(s);
 		const int32_t *src = v.row(s - r);
 		__syncthreads(); // the LDS tables of the previous row are free
-		// header + blocks (uniform)
-		BitReader br;
-		br.init(g.bits, g.nwords);
-		br.seek((uint64_t)g.offsets[v.lo + s]);
-		(void)Fields<DEF>::outdegree(br, g);
-		(void)Fields<DEF>::reference(br, g);
-		const uint64_t bc = Fields<DEF>::block_count(br, g);
-		if (bc > (uint64_t)dref + 1) continue; // flagged by the parse kernel
-		int64_t total = 0, copied = 0;
-		int32_t nKept = 0;
-		bool bad = false;
-		for (uint64_t b = 0; b <= bc; b++) {
-			int64_t len;
-			if (b < bc) len = (int64_t)Fields<DEF>::block(br, g) + (b ? 1 : 0);
-			else len = dref - total; // implicit last block (copied when the block count is even)
-			if (len < 0 || total + len > dref) { bad = true; break; }
-			if (!(b & 1)) {
-				if (nKept <= COPY_BIG_CAP && (int32_t)threadIdx.x == (nKept & (COPY_BIG_THREADS - 1))) { kend[nKept] = (int32_t)min<int64_t>(copied + len, 0x7fffffff); delta[nKept] = (int32_t)(total - copied); }
-				nKept++;
-				copied += len;
+		unsigned long long tk = (g.stats && (g.dbg & 16)) ? __builtin_readcyclecounter() : 0;
+#define CT(slot) do { if (g.stats && (g.dbg & 16)) { const unsigned long long now_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g.stats[24 + slot], now_ - tk); tk = now_; } } while (0)
+		// header + blocks, by the first wave only (sixteen waves walking the list side by side would only slow each
+		// other down); default codings read through a lane window in LDS with the short-code decoders
+		if (threadIdx.x < 64) {
+			int64_t total = 0, copied = 0;
+			int32_t nKept = 0;
+			int bad = 0;
+			auto walk = [&](auto &&next_gamma, uint64_t bc) {
+				if (bc > (uint64_t)dref + 1) { bad = 1; return; } // flagged by the parse kernel
+				for (uint64_t b = 0; b <= bc; b++) {
+					int64_t len;
+					if (b < bc) len = (int64_t)next_gamma() + (b ? 1 : 0);
+					else len = dref - total; // implicit last block (copied when the block count is even)
+					if (len < 0 || total + len > dref) { bad = 1; break; }
+					if (!(b & 1)) {
+						if (nKept <= COPY_BIG_CAP && (int32_t)threadIdx.x == (nKept & 63)) { kend[nKept] = (int32_t)min<int64_t>(copied + len, 0x7fffffff); delta[nKept] = (int32_t)(total - copied); }
+						nKept++;
+						copied += len;
+					}
+					total += len;
+				}
+			};
+			if (DEF) {
+				LaneWin<LW_MAIN> lw;
+				lw.col = lwin + threadIdx.x;
+				lw.vlast = min((((uint64_t)g.offsets[v.lo + s + 1] >> 5) + 2) & ~(uint64_t)3, (g.nwords + 4) & ~(uint64_t)3);
+				lw.seek(g, (uint64_t)g.offsets[v.lo + s]);
+				int e = 0;
+				(void)lw.template code<1>(g, e);
+				(void)lw.template code<2>(g, e);
+				const uint64_t bc = lw.template code<1>(g, e);
+				walk([&] { return lw.template code<1>(g, e); }, bc);
+				bad |= e;
+			} else {
+				BitReader br;
+				br.init(g.bits, g.nwords);
+				br.seek((uint64_t)g.offsets[v.lo + s]);
+				(void)Fields<DEF>::outdegree(br, g);
+				(void)Fields<DEF>::reference(br, g);
+				const uint64_t bc = Fields<DEF>::block_count(br, g);
+				walk([&] { return Fields<DEF>::block(br, g); }, bc);
+				bad |= br.err;
 			}
-			total += len;
+			if (threadIdx.x == 0) { s_copied = copied; s_kept = nKept; s_bad = bad; }
 		}
-		if (bad || br.err || copied > d || copied == 0) continue; // malformed (flagged by the parse kernel) / nothing to merge: the extras already fill the row
-		if (g.stats && threadIdx.x == 0) { stat_add(g, 8, 1); stat_add(g, 9, bc); stat_max(g, 15, bc); stat_add(g, 12, (unsigned long long)d); stat_max(g, 14, (unsigned long long)d); if (copied > COPY_BIG_CAP) stat_add(g, 13, 1); }
+		__syncthreads();
+		const int64_t copied = s_copied;
+		const int32_t nKept = s_kept;
+		if (s_bad || copied > d || copied == 0) continue; // malformed (flagged by the parse kernel) / nothing to merge: the extras already fill the row
+		if (g.stats && threadIdx.x == 0) { stat_add(g, 8, 1); stat_add(g, 9, (unsigned long long)nKept); stat_max(g, 15, (unsigned long long)nKept); stat_add(g, 4, (unsigned long long)d); }
 		if (copied > COPY_BIG_CAP) { // too many copied ids for the LDS tables: one lane does it
 			if (threadIdx.x == 0) copy_node<DEF>(g, v.lo + s, d, dref, row, src, err);
 			continue;
 		}
 		__syncthreads();
+		CT(0);
 		// gather the copied ids (a block of length 0 is possible only in first position, so nKept <= copied + 1)
 		const int32_t nc = (int32_t)copied, nExtra = d - nc;
 		for (int32_t t = threadIdx.x; t < nc; t += COPY_BIG_THREADS) {
@@ -562,6 +597,7 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 			cval[t] = src[t + delta[lo]];
 		}
 		__syncthreads();
+		CT(1);
 		// rank of every copied id among the extras (still at row[copied .. d))
 		for (int32_t t = threadIdx.x; t < nc; t += COPY_BIG_THREADS) {
 			const int32_t cv = cval[t];
@@ -570,6 +606,7 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 			cpos[t] = t + lo;
 		}
 		__syncthreads();
+		CT(2);
 		// extras up to the one following the last copied id move; the rest stay where they are
 		const int32_t nMove = cpos[nc - 1] - (nc - 1);
 		constexpr int32_t CHUNK = COPY_BIG_THREADS * COPY_BIG_ITEMS;
@@ -593,7 +630,10 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 			}
 		}
 		__syncthreads(); // all extras are in place
+		CT(3);
 		for (int32_t t = threadIdx.x; t < nc; t += COPY_BIG_THREADS) row[cpos[t]] = cval[t];
+		CT(4);
+#undef CT
 	}
 }
 
@@ -960,11 +1000,16 @@ void launch_parse_big(const GraphDev &g, bool def, const RangeView &v, const int
 	else hipLaunchKernelGGL((k_parse_big<false, 1>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
 }
 
+void copy_thresholds(int32_t midMinKnob, bool bigGroups, int32_t &midMin, int32_t &bigMin);
 void launch_build_lists(const GraphDev &g, const RangeView &v, uint64_t giantBits, int32_t noBin, int32_t *depth, uint16_t *key16, int32_t *hist, int32_t *keyBase, int32_t *cursor,
-                        int32_t *list, int32_t *giantlist, int32_t giantCap, int32_t *ctl, int32_t *maxdepth, hipStream_t st) {
+                        int32_t *list, int32_t *giantlist, int32_t giantCap, int32_t *ctl, int32_t *maxdepth, hipStream_t st,
+                        int32_t *bigQ, int32_t bigCap, int32_t *midQ, int32_t midCap, int32_t midMinKnob, bool bigGroups) {
 	if (v.cnt <= 0) return;
 	(void)hipMemsetAsync(hist, 0, sizeof(int32_t) * NKEYS, st);
-	hipLaunchKernelGGL(k_depth_keys, dim3(nblk(v.cnt, LIST_TILE)), dim3(TPB), 0, st, g, v.lo, v.cnt, v.outd, v.ref, giantBits, noBin, depth, key16, hist, ctl, maxdepth);
+	int32_t midMin, bigMin;
+	copy_thresholds(midMinKnob, bigGroups, midMin, bigMin);
+	hipLaunchKernelGGL(k_depth_keys, dim3(nblk(v.cnt, LIST_TILE)), dim3(TPB), 0, st, g, v.lo, v.cnt, v.outd, v.ref, giantBits, noBin, depth, key16, hist, ctl, maxdepth,
+	                   bigQ, bigCap, midQ, midCap, midMin, bigMin);
 	hipLaunchKernelGGL(k_key_offsets, dim3(1), dim3(TPB), 0, st, hist, keyBase, cursor, maxdepth);
 	hipLaunchKernelGGL(k_scatter_keys, dim3(nblk(v.cnt, LIST_TILE)), dim3(TPB), 0, st, v.cnt, key16, cursor, list, giantlist, giantCap, ctl);
 }
@@ -996,36 +1041,39 @@ void launch_parse_giants(const GraphDev &g, bool def, const RangeView &v, const 
 	else hipLaunchKernelGGL((k_parse_big<false, GIANT_NW>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, st, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
 }
 
-// One chain level of the copy pass.  stBig == st: everything in order on one stream.  Otherwise the long rows
-// (one 1024-thread group each, dominated by the few longest rows) run on stBig next to the short and medium
-// ones; evQ / evBig are the fork and join events.
-void launch_copy_list(const GraphDev &g, bool def, const RangeView &v, const int32_t *depth, const int32_t *list, const int32_t *keyBase, int32_t level, int blocks,
-                      int32_t *bigQueue, int32_t *bigCount, int32_t bigCap, int32_t *midQueue, int32_t *midCount, int32_t midCap, int32_t midMin, int *err, hipStream_t st,
-                      hipStream_t stBig, hipEvent_t evQ, hipEvent_t evBig) {
+// One chain level of the copy pass: three kernels, one per row class.  With side streams they run next to each
+// other (evFork forks, evMid / evBig join back into st); with stMid == stBig == st they run one after the other.
+// class thresholds of the copy pass (shared by the queue builder and the level kernels)
+void copy_thresholds(int32_t midMinKnob, bool bigGroups, int32_t &midMin, int32_t &bigMin) {
+	bigMin = bigGroups ? COPY_BIG_MIN : 0x7fffffff; // !bigGroups: every row is merged by one lane
+	midMin = (midMinKnob <= 0 || midMinKnob > bigMin || !bigGroups) ? bigMin : midMinKnob; // = bigMin: no wave-per-row class
+}
+void launch_copy_level(const GraphDev &g, bool def, const RangeView &v, const int32_t *depth, const int32_t *list, const int32_t *keyBase, int32_t level, int blocks,
+                       int32_t midMinKnob, bool bigGroups, const int32_t *bigQ, int32_t bigCap, const int32_t *midQ, int32_t midCap, const int32_t *ctl, int *err,
+                       hipStream_t st, hipStream_t stMid, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evMid, hipEvent_t evBig) {
 	if (v.cnt <= 0) return;
-	const bool split = bigQueue && stBig != st;
-	auto list_pass = [&](int mode, int nblocks) {
-		if (def) hipLaunchKernelGGL(k_copy_list<true>, dim3(nblocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, bigQueue, bigCount, bigCap, midQueue, midCount, midCap, midMin, mode, err);
-		else hipLaunchKernelGGL(k_copy_list<false>, dim3(nblocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, bigQueue, bigCount, bigCap, midQueue, midCount, midCap, midMin, mode, err);
-	};
-	auto big_pass = [&](hipStream_t s_) {
-		if (def) hipLaunchKernelGGL(k_copy_big<true>, dim3(512), dim3(COPY_BIG_THREADS), 0, s_, g, v, bigQueue, bigCount, bigCap, err);
-		else hipLaunchKernelGGL(k_copy_big<false>, dim3(512), dim3(COPY_BIG_THREADS), 0, s_, g, v, bigQueue, bigCount, bigCap, err);
-	};
+	int32_t midMin, bigMin;
+	copy_thresholds(midMinKnob, bigGroups, midMin, bigMin);
+	const bool split = stMid != st || stBig != st;
 	if (split) {
-		list_pass(1, blocks);
-		hipEventRecord(evQ, st);
-		hipStreamWaitEvent(stBig, evQ, 0);
-		big_pass(stBig);
-		hipEventRecord(evBig, stBig);
-		list_pass(2, blocks);
-	} else list_pass(0, blocks);
-	if (midQueue) {
-		if (def) hipLaunchKernelGGL(k_copy_mid<true>, dim3(1024), dim3(64 * COPY_MID_WAVES), 0, st, g, v, midQueue, midCount, midCap, err);
-		else hipLaunchKernelGGL(k_copy_mid<false>, dim3(1024), dim3(64 * COPY_MID_WAVES), 0, st, g, v, midQueue, midCount, midCap, err);
+		(void)hipEventRecord(evFork, st);
+		if (stMid != st) (void)hipStreamWaitEvent(stMid, evFork, 0);
+		if (stBig != st) (void)hipStreamWaitEvent(stBig, evFork, 0);
 	}
-	if (split) hipStreamWaitEvent(st, evBig, 0);
-	else if (bigQueue) big_pass(st);
+	if (bigGroups) {
+		if (def) hipLaunchKernelGGL(k_copy_big<true>, dim3(512), dim3(COPY_BIG_THREADS), 0, stBig, g, v, depth, bigQ, ctl + 5, bigCap, level, err);
+		else hipLaunchKernelGGL(k_copy_big<false>, dim3(512), dim3(COPY_BIG_THREADS), 0, stBig, g, v, depth, bigQ, ctl + 5, bigCap, level, err);
+		if (stBig != st) (void)hipEventRecord(evBig, stBig);
+	}
+	if (midMin < bigMin) {
+		if (def) hipLaunchKernelGGL(k_copy_mid<true>, dim3(1024), dim3(64 * COPY_MID_WAVES), 0, stMid, g, v, depth, midQ, ctl + 6, midCap, level, err);
+		else hipLaunchKernelGGL(k_copy_mid<false>, dim3(1024), dim3(64 * COPY_MID_WAVES), 0, stMid, g, v, depth, midQ, ctl + 6, midCap, level, err);
+	}
+	if (stMid != st) (void)hipEventRecord(evMid, stMid);
+	if (def) hipLaunchKernelGGL(k_copy_list<true>, dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, midMin, bigMin, err);
+	else hipLaunchKernelGGL(k_copy_list<false>, dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, midMin, bigMin, err);
+	if (stMid != st) (void)hipStreamWaitEvent(st, evMid, 0);
+	if (bigGroups && stBig != st) (void)hipStreamWaitEvent(st, evBig, 0);
 }
 
 void launch_parse_list(const GraphDev &g, bool def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st) {

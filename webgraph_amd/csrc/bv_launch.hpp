@@ -55,14 +55,15 @@ void launch_parse_big(const GraphDev &g, bool def, const RangeView &v, const int
                       int waves, int giantGroups, int *err, hipStream_t stGiant, hipStream_t stBig);
 constexpr int ARENA_ENTRY_BYTES = 16;
 void launch_build_lists(const GraphDev &g, const RangeView &v, uint64_t giantBits, int32_t noBin, int32_t *depth, uint16_t *key16, int32_t *hist, int32_t *keyBase, int32_t *cursor,
-                        int32_t *list, int32_t *giantlist, int32_t giantCap, int32_t *ctl, int32_t *maxdepth, hipStream_t st);
+                        int32_t *list, int32_t *giantlist, int32_t giantCap, int32_t *ctl, int32_t *maxdepth, hipStream_t st,
+                        int32_t *bigQ = nullptr, int32_t bigCap = 0, int32_t *midQ = nullptr, int32_t midCap = 0, int32_t midMinKnob = 0, bool bigGroups = false);
 void launch_decode_level(const GraphDev &g, bool def, const RangeView &v, const int32_t *depth, const int32_t *list, const int32_t *keyBase, int32_t level, int blocks,
                          int *err, hipStream_t st);
 void launch_copy_giants(const GraphDev &g, bool def, const RangeView &v, const int32_t *depth, const int32_t *giantlist, const int32_t *ctl, int32_t giantCap, int32_t level,
                         int *err, hipStream_t st);
-void launch_copy_list(const GraphDev &g, bool def, const RangeView &v, const int32_t *depth, const int32_t *list, const int32_t *keyBase, int32_t level, int blocks,
-                      int32_t *bigQueue, int32_t *bigCount, int32_t bigCap, int32_t *midQueue, int32_t *midCount, int32_t midCap, int32_t midMin, int *err, hipStream_t st,
-                      hipStream_t stBig, hipEvent_t evQ, hipEvent_t evBig);
+void launch_copy_level(const GraphDev &g, bool def, const RangeView &v, const int32_t *depth, const int32_t *list, const int32_t *keyBase, int32_t level, int blocks,
+                       int32_t midMinKnob, bool bigGroups, const int32_t *bigQ, int32_t bigCap, const int32_t *midQ, int32_t midCap, const int32_t *ctl, int *err,
+                       hipStream_t st, hipStream_t stMid, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evMid, hipEvent_t evBig);
 void launch_parse_list(const GraphDev &g, bool def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st);
 void launch_parse_giants(const GraphDev &g, bool def, const RangeView &v, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap, int giantGroups, int *err, hipStream_t st);
 void launch_hash(int32_t from, int32_t cnt, const int64_t *rowptr, const int32_t *succ, uint32_t *A, uint32_t *B, int32_t *hash, hipStream_t st);

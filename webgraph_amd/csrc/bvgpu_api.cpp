@@ -66,8 +66,7 @@ struct Pending { // an enqueued range decode whose status has not been collected
 	bv::RangeView view{};
 	int32_t levels_done = 0;
 	bool want_succ = false;
-	int32_t giantCap = 0;
-	int32_t bigCap = 0, midCap = 0;
+	int32_t giantCap = 0, bigCap = 0, midCap = 0;
 };
 
 } // namespace
@@ -89,15 +88,15 @@ struct bvg_graph {
 	DevBuf lvlist;
 	int parse_lists = 1; // BVGPU_PARSE_LISTS=0: short records parsed in node order instead of by work bin
 	DevBuf plist, pkeys, pkey16;
-	DevBuf cbigq, cbigc; // per-level queues of long rows for the cooperative copy
 	int copy_big = 1;    // BVGPU_COPY_BIG=0: every row is copied by one lane
-	int copy_mid_min = 64; // rows with at least this many successors (and fewer than 1024) are copied by one wave each
+	int copy_mid_min = 128; // rows with at least this many successors (and fewer than 1024) are copied by one wave each
 	int copy_lists = 1; // BVGPU_COPY_LISTS=0: node-order sweeps over all slots instead of per-level compact lists
 	int32_t coop_min = 2048, giant_min = 65536;                         // thresholds on the outdegree (BVGPU_COOP_MIN / BVGPU_GIANT_MIN)
 	int coop_waves = 4096, giant_groups = 256;
+	DevBuf copyq; // rows the copy pass merges with a group / a wave each (all levels), filled while the level lists are built
 	DevBuf stats; // BVGPU_STATS=1: tuning counters
 	// the three parse kernels (giant / big / short records) are independent: they run on forked streams
-	hipStream_t sideA = nullptr, sideB = nullptr;
+	hipStream_t sideA = nullptr, sideB = nullptr; // (more streams than this share hardware queues with each other: they would serialise)
 	hipEvent_t evFork = nullptr, evA = nullptr, evB = nullptr, evC = nullptr;
 	bool overlap = true;
 	Small *h_small = nullptr; // pinned
@@ -168,7 +167,14 @@ int init_handle(bvg_graph *g) {
 	if (const char *e = getenv("BVGPU_COPY_MID_MIN")) g->copy_mid_min = std::min(std::max(0, atoi(e)), 1024); // 0: no wave-per-row copy
 	if (const char *e = getenv("BVGPU_OVERLAP")) g->overlap = atoi(e) != 0;
 	HIPCHK(g, hipStreamCreateWithFlags(&g->sideA, hipStreamNonBlocking));
-	HIPCHK(g, hipStreamCreateWithFlags(&g->sideB, hipStreamNonBlocking));
+	{
+		// side B carries the longest dependency chains (the giant records): highest dispatch priority
+		int prLo = 0, prHi = 0;
+		(void)hipDeviceGetStreamPriorityRange(&prLo, &prHi);
+		const char *e = getenv("BVGPU_GIANT_PRIO");
+		if (!e || atoi(e)) HIPCHK(g, hipStreamCreateWithPriority(&g->sideB, hipStreamNonBlocking, prHi));
+		else HIPCHK(g, hipStreamCreateWithFlags(&g->sideB, hipStreamNonBlocking));
+	}
 	HIPCHK(g, hipEventCreateWithFlags(&g->evFork, hipEventDisableTiming));
 	HIPCHK(g, hipEventCreateWithFlags(&g->evIn, hipEventDisableTiming));
 	HIPCHK(g, hipEventCreateWithFlags(&g->evOut, hipEventDisableTiming));
@@ -245,10 +251,12 @@ int finish_pending(bvg_graph *g, uint64_t *arcs_out) {
 			int32_t *keyBase = g->keys.as<int32_t>() + (bv::NKEYS + 1);
 			for (int32_t l = g->pend.levels_done + 1; l <= upto; l++) {
 				if (!g->fused) {
-					if (g->copy_lists) bv::launch_copy_list(gd, s.def, g->pend.view, g->depth.as<int32_t>(), g->lvlist.as<int32_t>(), keyBase, l, g->level_blocks,
-					                                         g->copy_big && l < 1023 ? g->cbigq.as<int32_t>() : nullptr, g->cbigc.as<int32_t>() + std::min(l, 1023), g->pend.bigCap,
-					                                         g->copy_big && g->copy_mid_min > 0 && l < 1023 ? g->cbigq.as<int32_t>() + g->pend.bigCap : nullptr, g->cbigc.as<int32_t>() + 1024 + std::min(l, 1023), g->pend.midCap, g->copy_mid_min, derr, g->stream,
-					                                         g->overlap && !g->profile ? g->sideA : g->stream, g->evFork, g->evA);
+					if (g->copy_lists) {
+						const bool ov2 = g->overlap && !g->profile;
+						bv::launch_copy_level(gd, s.def, g->pend.view, g->depth.as<int32_t>(), g->lvlist.as<int32_t>(), keyBase, l, g->level_blocks, g->copy_mid_min, g->copy_big != 0,
+						                      g->copyq.as<int32_t>(), g->pend.bigCap, g->copyq.as<int32_t>() + g->pend.bigCap, g->pend.midCap, g->coopctl.as<int32_t>(), derr,
+						                      g->stream, ov2 ? g->sideB : g->stream, ov2 ? g->sideA : g->stream, g->evFork, g->evB, g->evA);
+					}
 					else bv::launch_copy(gd, s.def, g->pend.view, g->depth.as<int32_t>(), l, derr, g->stream);
 					continue;
 				}
@@ -328,13 +336,18 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 		int32_t *hist = g->keys.as<int32_t>(), *keyBase = hist + (bv::NKEYS + 1), *cursor = keyBase + (bv::NKEYS + 1);
 		int32_t *ctl = g->coopctl.as<int32_t>();
 		HIPCHK(g, hipMemsetAsync(ctl, 0, 8 * sizeof(int32_t), g->stream));
+		// rows with a reference and >= 1024 (resp. >= copy_mid_min) successors: at most arcs / 1024 (resp. / copy_mid_min) of them
+		const int32_t bigCap = (int32_t)std::min<int64_t>(arcsBound / 1024 + 2, 0x3fffffff);
+		const int32_t midCap = g->copy_mid_min > 0 ? (int32_t)std::min<int64_t>(arcsBound / g->copy_mid_min + 2, 0x3fffffff) : 0;
+		if (g->copy_lists && !g->copyq.need(sizeof(int32_t) * ((size_t)bigCap + (size_t)midCap))) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
+		g->pend.bigCap = bigCap; g->pend.midCap = midCap;
 		const bool coop = g->coop_min < 0x7fffffff;
 		const bool ovl = g->overlap && !g->profile; // per-kernel timing needs the kernels one after the other
 		v.coop_min = coop ? g->coop_min : 0x7fffffff;
 		// Three things run next to each other from here on (unless profiling serialises them):
 		//   side B: classification of the long records, then the giant ones (a group of waves each) -- the longest
 		//           dependency chains of the scan, which need nothing but the outdegrees and the row starts;
-		//   side A: chain depths + per-level lists (only the copy pass needs them), then the big records (a wave each);
+		//   side A: chain depths + per-level lists + copy queues (only the copy pass needs them), then the big records (a wave each);
 		//   here:   the parse list and the one-lane parse of everything else.
 		hipStream_t stLists = g->stream;
 		if (ovl) {
@@ -349,7 +362,8 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 		}
 		// chain depth of every record (+ per-level lists, node order inside a level)
 		if (W > 0) bv::launch_build_lists(gd, v, ~0ull, 1, g->depth.as<int32_t>(), g->key16.as<uint16_t>(), hist, keyBase, cursor, g->lvlist.as<int32_t>(),
-		                                  g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->maxdepth, stLists);
+		                                  g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->maxdepth, stLists,
+		                                  g->copy_lists ? g->copyq.as<int32_t>() : nullptr, bigCap, g->copyq.as<int32_t>() + bigCap, midCap, g->copy_mid_min, g->copy_big != 0);
 		if (ovl) {
 			if (coop) {
 				HIPCHK(g, hipStreamWaitEvent(g->sideA, g->evC, 0));
@@ -382,21 +396,10 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 		mark(g, 5);
 		if (W > 0) {
 			levels = g->levels_hint;
-			// long rows (>= 1024 successors) with a reference: at most arcs / 1024 of them
-			const int32_t bigCap = (int32_t)std::min<int64_t>(arcsBound / 1024 + 2, 0x7fffffff);
-			g->pend.bigCap = bigCap;
-			// medium rows (>= copy_mid_min successors): at most arcs / copy_mid_min of them
-			const int32_t midCap = g->copy_mid_min > 0 ? (int32_t)std::min<int64_t>(arcsBound / g->copy_mid_min + 2, 0x3fffffff) : 0;
-			g->pend.midCap = midCap;
-			if (g->copy_lists && g->copy_big) {
-				if (!g->cbigq.need(sizeof(int32_t) * ((size_t)bigCap + (size_t)midCap)) || !g->cbigc.need(sizeof(int32_t) * 2048)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
-				HIPCHK(g, hipMemsetAsync(g->cbigc.p, 0, sizeof(int32_t) * 2048, g->stream));
-			}
 			for (int32_t l = 1; l <= levels; l++) {
-				if (g->copy_lists) bv::launch_copy_list(gd, s.def, v, g->depth.as<int32_t>(), g->lvlist.as<int32_t>(), keyBase, l, g->level_blocks,
-				                                         g->copy_big ? g->cbigq.as<int32_t>() : nullptr, g->cbigc.as<int32_t>() + std::min(l, 1023), bigCap,
-				                                         g->copy_big && midCap > 0 ? g->cbigq.as<int32_t>() + bigCap : nullptr, g->cbigc.as<int32_t>() + 1024 + std::min(l, 1023), midCap, g->copy_mid_min, derr, g->stream,
-				                                         ovl ? g->sideA : g->stream, g->evFork, g->evA);
+				if (g->copy_lists) bv::launch_copy_level(gd, s.def, v, g->depth.as<int32_t>(), g->lvlist.as<int32_t>(), keyBase, l, g->level_blocks, g->copy_mid_min, g->copy_big != 0,
+				                                          g->copyq.as<int32_t>(), bigCap, g->copyq.as<int32_t>() + bigCap, midCap, ctl, derr,
+				                                          g->stream, ovl ? g->sideB : g->stream, ovl ? g->sideA : g->stream, g->evFork, g->evB, g->evA);
 				else bv::launch_copy(gd, s.def, v, g->depth.as<int32_t>(), l, derr, g->stream); // sweep in node order: rows of neighbouring nodes are neighbours in memory
 			}
 		}
@@ -527,7 +530,7 @@ extern "C" int bvg_close(bvg_t *g) {
 	if (g->st && g->st->device >= 0) {
 		(void)hipSetDevice(g->st->device);
 		if (g->own) { (void)hipStreamSynchronize(g->own); (void)hipStreamDestroy(g->own); }
-		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist, &g->plist, &g->pkeys, &g->pkey16, &g->cbigq, &g->cbigc }) b->release();
+		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist, &g->plist, &g->pkeys, &g->pkey16, &g->copyq }) b->release();
 		if (g->h_small) (void)hipHostFree(g->h_small);
 		for (auto &e : g->ev) if (e) (void)hipEventDestroy(e);
 		for (hipEvent_t e : { g->evFork, g->evA, g->evB, g->evC, g->evIn, g->evOut }) if (e) (void)hipEventDestroy(e);
