@@ -1,0 +1,27 @@
+#!/bin/bash
+# GPU box: the measurements committed under profiles/ for one round.  usage: scripts/profile_round.sh <tag>
+#   gpurun_out/<tag>_bench.json                  python bench.py (default flags)
+#   gpurun_out/<tag>_kernel_stats_overlapped.txt rocprofv3 --kernel-trace --stats of the same command (streams as in production)
+#   gpurun_out/<tag>_kernel_stats_serial.txt     the same with BVGPU_OVERLAP=0 (one kernel at a time: per-kernel durations)
+#   gpurun_out/<tag>_timeline_overlapped.txt     kernel-by-kernel timeline of the last scan of the overlapped run
+#   gpurun_out/<tag>_pmc/summary.txt             PMC counters, separate passes (scripts/pmc.sh)
+tag=$1
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R
+python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
+tail -c 2500 gpurun_out/${tag}_bench.json
+export TMPDIR=/tmp
+cd /tmp
+for mode in overlapped serial; do
+  rm -rf /tmp/prof_$mode
+  if [ $mode = serial ]; then export BVGPU_OVERLAP=0; else unset BVGPU_OVERLAP; fi
+  rocprofv3 --kernel-trace --stats -d /tmp/prof_$mode -o res -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /tmp/prof_$mode.log 2>&1
+  db=$(find /tmp/prof_$mode -name "*.db" | head -1)
+  python $R/scripts/rocprof_summary.py $db $R/gpurun_out/${tag}_kernel_stats_$mode.txt
+  [ $mode = overlapped ] && python $R/scripts/timeline.py $db $R/gpurun_out/${tag}_timeline_overlapped.txt
+done
+unset BVGPU_OVERLAP
+head -12 $R/gpurun_out/${tag}_kernel_stats_serial.txt | cut -c1-140
+cd $R
+BVGPU_OVERLAP=0 scripts/pmc.sh gpurun_out/${tag}_pmc scripts/tune.py --reps 2 > /dev/null 2>&1
+tail -5 gpurun_out/${tag}_pmc/summary.txt

@@ -167,14 +167,7 @@ int init_handle(bvg_graph *g) {
 	if (const char *e = getenv("BVGPU_COPY_MID_MIN")) g->copy_mid_min = std::min(std::max(0, atoi(e)), 1024); // 0: no wave-per-row copy
 	if (const char *e = getenv("BVGPU_OVERLAP")) g->overlap = atoi(e) != 0;
 	HIPCHK(g, hipStreamCreateWithFlags(&g->sideA, hipStreamNonBlocking));
-	{
-		// side B carries the longest dependency chains (the giant records): highest dispatch priority
-		int prLo = 0, prHi = 0;
-		(void)hipDeviceGetStreamPriorityRange(&prLo, &prHi);
-		const char *e = getenv("BVGPU_GIANT_PRIO");
-		if (!e || atoi(e)) HIPCHK(g, hipStreamCreateWithPriority(&g->sideB, hipStreamNonBlocking, prHi));
-		else HIPCHK(g, hipStreamCreateWithFlags(&g->sideB, hipStreamNonBlocking));
-	}
+	HIPCHK(g, hipStreamCreateWithFlags(&g->sideB, hipStreamNonBlocking));
 	HIPCHK(g, hipEventCreateWithFlags(&g->evFork, hipEventDisableTiming));
 	HIPCHK(g, hipEventCreateWithFlags(&g->evIn, hipEventDisableTiming));
 	HIPCHK(g, hipEventCreateWithFlags(&g->evOut, hipEventDisableTiming));
