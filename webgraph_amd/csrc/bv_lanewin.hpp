@@ -142,33 +142,35 @@ __device__ __forceinline__ void parse_node_lw(const GraphDev &g, int32_t x, int3
 	const int64_t nRes = extra - intervalArcs;
 	if (nRes < 0 || e) { atomicOr(err, E_FORMAT | e); return; }
 
-	// merge(intervals, residuals) -> row[copied ..), in 16-byte stores where the row allows it
+	// merge(intervals, residuals) -> row[copied ..), in 16-byte stores where the row allows it.  Ids are Java ints:
+	// 32-bit wrapping arithmetic throughout (BVG:954, :966, :1084-1093 compute in int).
 	int32_t *out = row + copied;
-	int64_t k = 0;
-	const int64_t head = min<int64_t>(extra, (int64_t)(((16u - ((uint32_t)(uintptr_t)out & 15u)) & 15u) >> 2));
+	const int32_t nExtra = (int32_t)extra;
+	int32_t k = 0;
+	const int32_t head = min(nExtra, (int32_t)(((16u - ((uint32_t)(uintptr_t)out & 15u)) & 15u) >> 2));
 	int32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0, on = 0;
-	int64_t ivLeft = 0, ivRem = 0, ivPrev = 0;
-	int64_t ivTodo = nIntervals;
+	int32_t ivLeft = 0, ivRem = 0, ivPrev = 0; // current interval: next value, values left; end of the previous interval
+	int32_t ivTodo = (int32_t)nIntervals;
 	bool firstIv = true;
-	int64_t resTodo = nRes;
-	int64_t resVal = 0;
-	if (resTodo) resVal = (int64_t)(int32_t)((int64_t)x + nat2int(br.code<0>(g, e))); // BVG:954
-	while (k < extra) {
+	int32_t resTodo = (int32_t)nRes;
+	int32_t resVal = 0;
+	if (resTodo) resVal = (int32_t)((int64_t)x + nat2int(br.code<0>(g, e))); // BVG:954
+	while (k < nExtra) {
 		br.wave_refill<3>(g);
 		if (ivTodo) bi.wave_refill<6>(g); // an interval is two gamma codes
 		if (ivRem == 0 && ivTodo) { // BVG:1084-1093
-			if (firstIv) { ivLeft = (int64_t)(int32_t)((int64_t)x + nat2int(bi.code<1>(g, e))); firstIv = false; }
-			else ivLeft = ivPrev + (int64_t)bi.code<1>(g, e) + 1;
-			ivRem = (int64_t)bi.code<1>(g, e) + g.minInt;
+			if (firstIv) { ivLeft = (int32_t)((int64_t)x + nat2int(bi.code<1>(g, e))); firstIv = false; }
+			else ivLeft = ivPrev + (int32_t)bi.code<1>(g, e) + 1;
+			ivRem = (int32_t)bi.code<1>(g, e) + g.minInt;
 			ivPrev = ivLeft + ivRem;
 			ivTodo--;
 		}
 		int32_t val;
-		if (ivRem && (!resTodo || ivLeft < resVal)) { val = (int32_t)ivLeft; ivLeft++; ivRem--; }
+		if (ivRem && (!resTodo || ivLeft < resVal)) { val = ivLeft; ivLeft++; ivRem--; }
 		else if (resTodo) {
-			val = (int32_t)resVal;
+			val = resVal;
 			if (ivRem && ivLeft == resVal) { ivLeft++; ivRem--; } // equal heads are emitted once (MergedIntIterator.java:69-72)
-			if (--resTodo) resVal += (g.dbg & 2) ? 1 : (int64_t)br.code<0>(g, e) + 1; // BVG:966
+			if (--resTodo) resVal += (g.dbg & 2) ? 1 : (int32_t)br.code<0>(g, e) + 1; // BVG:966
 		} else val = -1; // malformed: fewer values than the outdegree promises (BVG:1210 would store -1)
 		if (k < head) { if (!(g.dbg & 1)) out[k] = val; k++; continue; }
 		o0 = o1; o1 = o2; o2 = o3; o3 = val; k++;
