@@ -54,6 +54,7 @@ typedef struct bvg_info {
 	int32_t  outdegree_coding, block_coding, residual_coding, reference_coding, block_count_coding, offset_coding;
 	uint64_t graph_bytes;      /* size of <basename>.graph */
 	int32_t  device;           /* HIP device ordinal the handle lives on, -1 for a host-only parse */
+	int32_t  offsets_on_device; /* 1: the .offsets stream was decoded by the GPU kernels, 0: by the host decoder */
 } bvg_info_t;
 
 /* flags for the *_range / *_batch calls */
@@ -152,6 +153,11 @@ int64_t bvg_flags_from_string(const char *s);
 
 /* OffsetsLongIterator (BVG:907-935): decodes n+1 gamma/delta coded gaps of a .offsets image into running sums. */
 int bvg_decode_offsets_host(const uint8_t *offsets_file, size_t len, int32_t nodes, int offset_coding, int64_t *out);
+
+/* [device] The same decode on the GPU (bv_offsets.hip; what bvg_open uses for gamma-coded offsets): OffsetsLongIterator
+ * (BVG:907-935) as a grid-wide cooperative decode of the gap stream.  `out` is a HOST array of nodes + 1 values.
+ * BVG_EUNSUPPORTED for delta-coded offsets, BVG_EFORMAT when the stream does not hold exactly nodes + 1 codes. */
+int bvg_decode_offsets_device(int device, const uint8_t *offsets_file, size_t len, int32_t nodes, int offset_coding, int64_t *out);
 
 #ifdef __cplusplus
 }

@@ -23,12 +23,12 @@ class BvgInfo(C.Structure):
                 ("min_interval_length", C.c_int32), ("zeta_k", C.c_int32), ("flags", C.c_uint32),
                 ("outdegree_coding", C.c_int32), ("block_coding", C.c_int32), ("residual_coding", C.c_int32),
                 ("reference_coding", C.c_int32), ("block_count_coding", C.c_int32), ("offset_coding", C.c_int32),
-                ("graph_bytes", C.c_uint64), ("device", C.c_int32)]
+                ("graph_bytes", C.c_uint64), ("device", C.c_int32), ("offsets_on_device", C.c_int32)]
 
 
 EXPORTS = ["bvg_open", "bvg_clone", "bvg_close", "bvg_info", "bvg_last_error", "bvg_set_stream", "bvg_sync",
            "bvg_outdegrees", "bvg_decode_range", "bvg_successors_batch", "bvg_csr_hashcode", "bvg_shard_bounds",
-           "bvg_parse_properties", "bvg_flags_from_string", "bvg_decode_offsets_host", "bvg_set_profile", "bvg_get_profile", "bvg_debug_stats"]
+           "bvg_parse_properties", "bvg_flags_from_string", "bvg_decode_offsets_host", "bvg_decode_offsets_device", "bvg_set_profile", "bvg_get_profile", "bvg_debug_stats"]
 
 _lib = None
 
@@ -64,6 +64,7 @@ def lib():
         L.bvg_flags_from_string.argtypes = [C.c_char_p]
         L.bvg_flags_from_string.restype = i64
         L.bvg_decode_offsets_host.argtypes = [vp, sz, i32, C.c_int, vp]
+        L.bvg_decode_offsets_device.argtypes = [C.c_int, vp, sz, i32, C.c_int, vp]
         L.bvg_set_profile.argtypes = [vp, C.c_int]
         L.bvg_get_profile.argtypes = [vp, C.POINTER(C.c_float)]
         L.bvg_debug_stats.argtypes = [vp, vp, C.c_int]
@@ -117,6 +118,16 @@ def decode_offsets_host(offset_bytes, nodes, coding=2):
     rc = lib().bvg_decode_offsets_host(b.ctypes.data, b.size, nodes, coding, out.ctypes.data)
     if rc:
         _raise(rc, "cannot decode offsets")
+    return out
+
+
+def decode_offsets_device(offset_bytes, nodes, coding=2, device=0):
+    """[device] the same decode by the GPU kernels (what BVGraph.load uses for gamma-coded offsets)."""
+    b = np.frombuffer(offset_bytes, dtype=np.uint8)
+    out = np.empty(nodes + 1, dtype=np.int64)
+    rc = lib().bvg_decode_offsets_device(device, b.ctypes.data, b.size, nodes, coding, out.ctypes.data)
+    if rc:
+        _raise(rc, "cannot decode offsets on the device")
     return out
 
 

@@ -227,14 +227,14 @@ __device__ __forceinline__ bool fast_zeta3(uint64_t W, uint64_t &v, uint32_t &le
 	else { v = ((m << 1) | ((W2 >> (63u - nb)) & 1)) - 1; len = h + 2 + nb; }
 	return true;
 }
-// one code at bit position p of the staged window; advances p.  KIND 0: residual code, KIND 1: gamma code
+// one code at bit position p of the staged window; advances p.  KIND 0: residual code, KIND 1 / 2: gamma code
 template <bool DEF, int KIND>
 __device__ __forceinline__ uint64_t win_code(const GraphDev &g, const WindowSrc &src, uint64_t &p, int &err) {
 	uint64_t W, v; uint32_t len;
-	if ((KIND == 1 || DEF) && win_peek64(src, p, W) && (KIND == 1 ? fast_gamma(W, v, len) : fast_zeta3(W, v, len))) { p += len; return v; }
+	if ((KIND != 0 || DEF) && win_peek64(src, p, W) && (KIND != 0 ? fast_gamma(W, v, len) : fast_zeta3(W, v, len))) { p += len; return v; }
 	WinReader br; br.init_src(src, g.nwords);
 	br.seek(p);
-	v = KIND == 1 ? br.gamma() : Fields<DEF>::residual(br, g);
+	v = KIND != 0 ? br.gamma() : Fields<DEF>::residual(br, g);
 	p = br.pos();
 	err |= br.err;
 	return v;
@@ -278,12 +278,12 @@ __device__ __attribute__((noinline)) SlowCode win_code_slow(const GraphDev *gp, 
 // are staged: the window extends 8 words past the tile).  Advances q.
 template <bool DEF, int KIND>
 __device__ __forceinline__ uint64_t win_code_rel(const GraphDev &g, const WindowSrc &src, uint32_t &q, int &err) {
-	if (KIND == 1 || DEF) {
+	if (KIND != 0 || DEF) {
 		const uint32_t j = q >> 5;
 		const uint64_t ab = ((uint64_t)src.win[j] << 32) | src.win[j + 1];
 		const uint32_t W = (uint32_t)((ab << (q & 31u)) >> 32);
 		uint32_t v, len;
-		if (__builtin_expect(KIND == 1 ? fast_gamma32(W, v, len) : fast_zeta3_32(W, v, len), 1)) { q += len; return v; }
+		if (__builtin_expect(KIND != 0 ? fast_gamma32(W, v, len) : fast_zeta3_32(W, v, len), 1)) { q += len; return v; }
 	}
 	const SlowCode sc = win_code_slow<DEF, KIND>(&g, src.win, src.w0, src.nw, q);
 	q = sc.q;
@@ -293,7 +293,7 @@ __device__ __forceinline__ uint64_t win_code_rel(const GraphDev &g, const Window
 
 // One speculative parse of the codes starting in [s, segEnd): end position, count and the sum of the decoded
 // contributions.  KIND 0: residual codes (gap+1 each; the first code of the section is the zig-zag value);
-// KIND 1: gamma codes, positions only.
+// KIND 1: gamma codes, positions only; KIND 2: gamma codes, the sum of their values (offset gaps, bv_offsets.hip).
 template <bool DEF, int KIND>
 __device__ __forceinline__ void spec_parse(const GraphDev &g, const WindowSrc &src, uint64_t base, uint32_t s, uint32_t segEnd, bool firstOfSection, uint32_t &e, uint32_t &c, int64_t &sum) {
 	c = 0; sum = 0;
@@ -303,6 +303,8 @@ __device__ __forceinline__ void spec_parse(const GraphDev &g, const WindowSrc &s
 	while (p < segEnd && !err) {
 		const uint64_t v = win_code_rel<DEF, KIND>(g, src, p, err);
 		if (KIND == 0) sum += (int64_t)v + 1;
+		if (KIND == 2 && !err) sum += (int64_t)v;
+		if (KIND == 2 && err) break; // (a gap stream ends in zero padding: not a code)
 		c++;
 	}
 	e = err ? 0x7fffff00u : p;
@@ -323,8 +325,10 @@ __device__ __forceinline__ void spec_resync(const GraphDev &g, const WindowSrc &
 		int err = 0;
 		const uint64_t v = win_code_rel<DEF, KIND>(g, src, q, err);
 		if (err) q = 0x7fffff00u; // garbage: this chain ends here (as in spec_parse)
-		if (adv) { pn = q; dc++; if (KIND == 0) ds += (int64_t)v + 1; }
-		else { po = q; dc--; if (KIND == 0) ds -= (int64_t)v + 1; }
+		const int64_t w = KIND == 0 ? (int64_t)v + 1 : KIND == 2 ? (int64_t)v : 0;
+		if (KIND == 2 && err) { if (adv) pn = q; else po = q; continue; } // padding: ends the chain, counts nothing
+		if (adv) { pn = q; dc++; ds += w; }
+		else { po = q; dc--; ds -= w; }
 	}
 	c += (uint32_t)dc;
 	sum += ds;
@@ -336,13 +340,16 @@ __device__ __forceinline__ void spec_resync(const GraphDev &g, const WindowSrc &
 // segment, their contribution sum, and E = end of the tile's last code (absolute, uniform).
 template <bool DEF, int KIND, int NW>
 __device__ __forceinline__ void spec_tile(const Grp<NW> &G, const GraphDev &g, const WindowSrc &src, uint64_t pos0, uint64_t secEnd, uint32_t B, bool firstTile,
-                                          int64_t needCodes, uint32_t &s, uint32_t &c, int64_t &sum, uint64_t &E) {
+                                          int64_t needCodes, uint32_t &s, uint32_t &c, int64_t &sum, uint64_t &E, uint64_t anchor = ~0ull) {
+	// anchor: where the segment grid starts (default: at pos0).  A caller whose tiles have FIXED nominal boundaries
+	// passes the nominal tile start <= pos0 < anchor + B: lane 0 still starts at the true boundary pos0.
 	const int tid = G.tid(), lane = G.lane();
 	const uint64_t base = src.w0 << 5;
 	const uint32_t p0 = (uint32_t)(pos0 - base);
+	const uint32_t a0 = anchor == ~0ull ? p0 : (uint32_t)(anchor - base);
 	const uint32_t secEndR = (uint32_t)min(secEnd - base, (uint64_t)0x7fffff00u);
-	const uint32_t segEnd = min(p0 + (uint32_t)(tid + 1) * B, secEndR);
-	s = min(p0 + (uint32_t)tid * B, secEndR);
+	const uint32_t segEnd = min(a0 + (uint32_t)(tid + 1) * B, secEndR);
+	s = tid == 0 ? min(p0, secEndR) : min(a0 + (uint32_t)tid * B, secEndR);
 	// Run-in: a lane starts a little BEFORE its segment, so that its parse has usually locked onto the true code
 	// boundaries by the time it enters the segment; its start is then the first boundary inside the segment.
 	// Two neighbours that both locked on agree on that boundary at once, and the rounds below only repair the few

@@ -68,4 +68,7 @@ void launch_parse_list(const GraphDev &g, bool def, const RangeView &v, const in
 void launch_parse_giants(const GraphDev &g, bool def, const RangeView &v, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap, int giantGroups, int *err, hipStream_t st);
 void launch_hash(int32_t from, int32_t cnt, const int64_t *rowptr, const int32_t *succ, uint32_t *A, uint32_t *B, int32_t *hash, hipStream_t st);
 
+// bv_offsets.hip: gamma-coded .offsets stream (words + >= 8 zero words in HBM) -> int64 offsets[nodes + 1] in HBM
+int offsets_decode_device(const uint32_t *d_words, uint64_t nwords, uint64_t totalBits, int32_t nodes, int64_t *d_out, hipStream_t st);
+
 } // namespace bv

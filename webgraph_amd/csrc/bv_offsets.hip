@@ -1,0 +1,160 @@
+// bv_offsets.hip -- the .offsets file decoded on the GPU (gfx950): n+1 gamma-coded gaps -> int64 bit offsets.
+//
+// Replaces, at load time, the sequential loop the reference calls "long and tedious" (OffsetsLongIterator,
+// BVG:907-935; the offsets list built at BVG:1577-1601): the file is ONE stream of universal codes, so its decode
+// is the cooperative decode of bv_coop.hpp taken to the whole grid.  The stream is cut into chunks of 64 x 256
+// bits with FIXED nominal boundaries; a wave per chunk stages its chunk in LDS and finds the codeword boundaries
+// by speculation with run-in (spec_tile), starting from a guess of the chunk's first boundary.  Chunk c's true
+// first boundary is the end of chunk c-1's last codeword: the kernel is simply run again, every chunk taking its
+// predecessor's end from the previous round and parsing again only if that moved its start -- universal codes
+// re-synchronise within a few codewords, so round 1 repairs a handful of chunks and round 2 finds nothing to do.
+// Two scans over the chunks (codes, gap sums) and a value pass then write off[i] = sum of the first i+1 gaps.
+// Only gamma-coded offsets (the default, A.4 of SURVEY.md); delta-coded files take the host decoder.
+#include "bv_coop.hpp"
+#include "bv_launch.hpp"
+
+namespace bv {
+
+constexpr int OFF_SEG = 256, OFF_CHUNK = 64 * OFF_SEG, OFF_RUNIN = 128, OFF_STAGE_B = 288; // bits; staging covers run-in + chunk + look-ahead
+
+struct OffLane { uint32_t s, c; int64_t v; }; // per lane of a chunk: first owned code (bits from the chunk's nominal start), codes, sum of gaps
+
+__device__ __forceinline__ GraphDev offsets_stream(const uint32_t *words, uint64_t nwords) {
+	GraphDev g{};
+	g.bits = words; g.nwords = nwords; g.offsets = nullptr; g.stats = nullptr; g.dbg = 0;
+	return g;
+}
+
+// round 0: every chunk guesses its start by run-in; round r > 0: start = end of the previous chunk in round r-1
+__global__ void __launch_bounds__(64) k_off_parse(const uint32_t *__restrict__ words, uint64_t nwords, uint64_t totalBits, int64_t nchunks, int round,
+                                                  const uint64_t *__restrict__ endPrev, uint64_t *__restrict__ endNew, uint64_t *__restrict__ startUsed,
+                                                  uint32_t *__restrict__ cnt, int64_t *__restrict__ gapsum, OffLane *__restrict__ lanes, int *__restrict__ changed) {
+	__shared__ __attribute__((aligned(16))) uint32_t lds[CoopLds<1>::WORDS];
+	const GraphDev g = offsets_stream(words, nwords);
+	Grp<1> G{ (int64_t *)(lds + CoopLds<1>::OFF_XCH) };
+	const int64_t c = blockIdx.x;
+	if (c >= nchunks) return;
+	const uint64_t anchor = (uint64_t)c * OFF_CHUNK;
+	uint64_t start = 0;
+	if (c > 0 && round > 0) {
+		start = endPrev[c - 1];
+		if (start == startUsed[c]) { if (threadIdx.x == 0) endNew[c] = endPrev[c]; return; } // nothing moved
+	}
+	const uint64_t posW = anchor >= OFF_RUNIN ? anchor - OFF_RUNIN : 0;
+	const WindowSrc src = stage_tile<1>(G, g, lds + CoopLds<1>::OFF_WIN, posW, OFF_STAGE_B);
+	if (c > 0 && round == 0) { // guess: the first boundary at or after the nominal start, parsing from a little before it
+		const uint64_t base = src.w0 << 5;
+		uint32_t p = (uint32_t)(posW - base);
+		const uint32_t a0 = (uint32_t)(anchor - base);
+		int err = 0;
+		while (p < a0 && !err) (void)win_code_rel<true, 2>(g, src, p, err);
+		start = err ? anchor : base + p;
+	}
+	// a start that is not in [anchor, anchor + 64 + OFF_SEG) cannot come from a valid stream: keep the lanes in range
+	if (start < anchor) start = anchor;
+	if (start > anchor + OFF_SEG) start = anchor + OFF_SEG;
+	uint32_t s, n; int64_t sum; uint64_t E;
+	spec_tile<true, 2, 1>(G, g, src, start, totalBits, OFF_SEG, false, INT64_MAX, s, n, sum, E, anchor);
+	int64_t ntot, stot;
+	(void)G.incl_scan((int64_t)n, ntot);
+	(void)G.incl_scan(sum, stot);
+	lanes[c * 64 + threadIdx.x] = OffLane{ (uint32_t)(((src.w0 << 5) + s) - anchor), n, sum };
+	if (threadIdx.x == 0) {
+		const bool moved = round == 0 || E != endPrev[c];
+		startUsed[c] = start; endNew[c] = E; cnt[c] = (uint32_t)ntot; gapsum[c] = stot;
+		if (moved && round > 0) atomicOr(changed, 1);
+	}
+}
+
+// exclusive scans over the chunks: code index and gap sum at the start of every chunk; total number of codes
+__global__ void __launch_bounds__(1024) k_off_scan(const uint32_t *__restrict__ cnt, const int64_t *__restrict__ gapsum, int64_t nchunks,
+                                                   int64_t *__restrict__ cntBase, int64_t *__restrict__ sumBase, int64_t *__restrict__ total) {
+	__shared__ int64_t s_c[1024], s_s[1024];
+	int64_t carryC = 0, carryS = 0;
+	for (int64_t b = 0; b < nchunks; b += 1024) {
+		const int64_t i = b + threadIdx.x;
+		const int64_t vc = i < nchunks ? (int64_t)cnt[i] : 0, vs = i < nchunks ? gapsum[i] : 0;
+		s_c[threadIdx.x] = vc; s_s[threadIdx.x] = vs;
+		__syncthreads();
+		for (int o = 1; o < 1024; o <<= 1) { // Hillis-Steele: a few thousand chunks, once per load
+			const int64_t tc = threadIdx.x >= o ? s_c[threadIdx.x - o] : 0, ts = threadIdx.x >= o ? s_s[threadIdx.x - o] : 0;
+			__syncthreads();
+			s_c[threadIdx.x] += tc; s_s[threadIdx.x] += ts;
+			__syncthreads();
+		}
+		if (i < nchunks) { cntBase[i] = carryC + s_c[threadIdx.x] - vc; sumBase[i] = carryS + s_s[threadIdx.x] - vs; }
+		carryC += s_c[1023]; carryS += s_s[1023];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) *total = carryC;
+}
+
+// value pass: every lane decodes the codes it owns again and writes the running sums
+__global__ void __launch_bounds__(64) k_off_values(const uint32_t *__restrict__ words, uint64_t nwords, int64_t nchunks, const OffLane *__restrict__ lanes,
+                                                   const int64_t *__restrict__ cntBase, const int64_t *__restrict__ sumBase, int64_t nOut, int64_t *__restrict__ out) {
+	__shared__ __attribute__((aligned(16))) uint32_t lds[CoopLds<1>::WORDS];
+	const GraphDev g = offsets_stream(words, nwords);
+	Grp<1> G{ (int64_t *)(lds + CoopLds<1>::OFF_XCH) };
+	const int64_t c = blockIdx.x;
+	if (c >= nchunks) return;
+	const uint64_t anchor = (uint64_t)c * OFF_CHUNK;
+	const uint64_t posW = anchor >= OFF_RUNIN ? anchor - OFF_RUNIN : 0;
+	const WindowSrc src = stage_tile<1>(G, g, lds + CoopLds<1>::OFF_WIN, posW, OFF_STAGE_B);
+	const OffLane me = lanes[c * 64 + threadIdx.x];
+	int64_t tot;
+	const int64_t cincl = G.incl_scan((int64_t)me.c, tot), vincl = G.incl_scan(me.v, tot);
+	int64_t idx = cntBase[c] + cincl - me.c, acc = sumBase[c] + vincl - me.v;
+	uint32_t p = (uint32_t)(anchor + me.s - (src.w0 << 5));
+	int err = 0;
+	for (uint32_t k = 0; k < me.c; k++) {
+		acc += (int64_t)win_code_rel<true, 2>(g, src, p, err);
+		if (idx < nOut) out[idx] = acc;
+		idx++;
+	}
+}
+
+// host side -------------------------------------------------------------------------------------------------
+// d_words: the file's bytes as 32-bit words followed by >= 8 zero words; scratch is allocated and freed here
+// (load-time code).  Returns 0, or -1 when the stream does not hold exactly `nodes + 1` codes (caller falls
+// back to the host decoder, which produces the precise error).
+int offsets_decode_device(const uint32_t *d_words, uint64_t nwords, uint64_t totalBits, int32_t nodes, int64_t *d_out, hipStream_t st) {
+	const int64_t nOut = (int64_t)nodes + 1;
+	const int64_t nchunks = (int64_t)((totalBits + OFF_CHUNK - 1) / OFF_CHUNK);
+	if (nchunks <= 0 || nchunks > 0x7fffffff) return -1;
+	uint64_t *ends = nullptr, *startUsed = nullptr;
+	uint32_t *cnt = nullptr;
+	int64_t *gapsum = nullptr, *cntBase = nullptr, *sumBase = nullptr, *total = nullptr;
+	OffLane *lanes = nullptr;
+	int *changed = nullptr;
+	int rc = -1;
+	auto ok = [](hipError_t e) { return e == hipSuccess; };
+	if (ok(hipMalloc((void **)&ends, sizeof(uint64_t) * 2 * nchunks)) && ok(hipMalloc((void **)&startUsed, sizeof(uint64_t) * nchunks)) &&
+	    ok(hipMalloc((void **)&cnt, sizeof(uint32_t) * nchunks)) && ok(hipMalloc((void **)&gapsum, sizeof(int64_t) * nchunks)) &&
+	    ok(hipMalloc((void **)&cntBase, sizeof(int64_t) * nchunks)) && ok(hipMalloc((void **)&sumBase, sizeof(int64_t) * nchunks)) &&
+	    ok(hipMalloc((void **)&total, sizeof(int64_t))) && ok(hipMalloc((void **)&lanes, sizeof(OffLane) * 64 * nchunks)) && ok(hipMalloc((void **)&changed, sizeof(int)))) {
+		int cur = 0;
+		bool fine = true;
+		for (int round = 0; round < 64 && fine; round++) { // (a round only repeats while some chunk's end still moves: 2-3 rounds)
+			fine = ok(hipMemsetAsync(changed, 0, sizeof(int), st));
+			hipLaunchKernelGGL(k_off_parse, dim3((unsigned)nchunks), dim3(64), 0, st, d_words, nwords, totalBits, nchunks, round, ends + (size_t)cur * nchunks,
+			                   ends + (size_t)(cur ^ 1) * nchunks, startUsed, cnt, gapsum, lanes, changed);
+			cur ^= 1;
+			int h = 0;
+			fine = fine && ok(hipMemcpyAsync(&h, changed, sizeof(int), hipMemcpyDeviceToHost, st)) && ok(hipStreamSynchronize(st));
+			if (round > 0 && h == 0) break;
+			if (round == 63) fine = false;
+		}
+		if (fine) {
+			hipLaunchKernelGGL(k_off_scan, dim3(1), dim3(1024), 0, st, cnt, gapsum, nchunks, cntBase, sumBase, total);
+			int64_t h = -1;
+			if (ok(hipMemcpyAsync(&h, total, sizeof(int64_t), hipMemcpyDeviceToHost, st)) && ok(hipStreamSynchronize(st)) && h == nOut) {
+				hipLaunchKernelGGL(k_off_values, dim3((unsigned)nchunks), dim3(64), 0, st, d_words, nwords, nchunks, lanes, cntBase, sumBase, nOut, d_out);
+				if (ok(hipStreamSynchronize(st))) rc = 0;
+			}
+		}
+	}
+	for (void *p : { (void *)ends, (void *)startUsed, (void *)cnt, (void *)gapsum, (void *)cntBase, (void *)sumBase, (void *)total, (void *)lanes, (void *)changed }) if (p) (void)hipFree(p);
+	return rc;
+}
+
+} // namespace bv

@@ -463,6 +463,30 @@ extern "C" int bvg_decode_offsets_host(const uint8_t *offsets_file, size_t len, 
 	return bvh::decode_offsets(offsets_file, len, nodes, offset_coding, out);
 }
 
+extern "C" int bvg_decode_offsets_device(int device, const uint8_t *offsets_file, size_t len, int32_t nodes, int offset_coding, int64_t *out) {
+	if (!offsets_file || !out || nodes < 0) return BVG_EARG;
+	if (offset_coding != BVG_GAMMA) return BVG_EUNSUPPORTED;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return BVG_EHIP;
+	if (device < 0 || device >= ndev) return BVG_EARG;
+	if (hipSetDevice(device) != hipSuccess) return BVG_EHIP;
+	const uint64_t ow = (len + 3) / 4;
+	uint32_t *d_ow = nullptr;
+	int64_t *d_out = nullptr;
+	int rc = BVG_ENOMEM;
+	if (hipMalloc((void **)&d_ow, (size_t)(ow + 8) * 4) == hipSuccess && hipMalloc((void **)&d_out, sizeof(int64_t) * ((size_t)nodes + 1)) == hipSuccess) {
+		rc = BVG_EHIP;
+		if (hipMemset(d_ow, 0, (size_t)(ow + 8) * 4) == hipSuccess && (len == 0 || hipMemcpy(d_ow, offsets_file, len, hipMemcpyHostToDevice) == hipSuccess)) {
+			if (len > 0 && bv::offsets_decode_device(d_ow, ow, (uint64_t)len * 8, nodes, d_out, nullptr) == 0)
+				rc = hipMemcpy(out, d_out, sizeof(int64_t) * ((size_t)nodes + 1), hipMemcpyDeviceToHost) == hipSuccess ? BVG_OK : BVG_EHIP;
+			else rc = BVG_EFORMAT;
+		}
+	}
+	if (d_ow) (void)hipFree(d_ow);
+	if (d_out) (void)hipFree(d_out);
+	return rc;
+}
+
 extern "C" int bvg_open(const char *basename, int device, bvg_t **out) {
 	if (!basename || !out) return BVG_EARG;
 	*out = nullptr;
@@ -488,10 +512,6 @@ extern "C" int bvg_open(const char *basename, int device, bvg_t **out) {
 	if (!bvh::read_file(st->basename + ".offsets", offs, err)) return fail(g, BVG_EIO, err);
 	st->info.graph_bytes = graph.size();
 	st->h_offsets.resize((size_t)in.nodes + 1);
-	rc = bvh::decode_offsets(offs.data(), offs.size(), in.nodes, in.offset_coding, st->h_offsets.data());
-	if (rc) return fail(g, rc, "cannot decode " + st->basename + ".offsets");
-	if ((uint64_t)st->h_offsets.back() > (uint64_t)graph.size() * 8) return fail(g, BVG_EIO, "offsets run past the end of the .graph file");
-	for (size_t i = 1; i < st->h_offsets.size(); i++) if (st->h_offsets[i] < st->h_offsets[i - 1]) return fail(g, BVG_EIO, "offsets are not monotone");
 
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(g, BVG_EHIP, "no HIP device available (libbvgpu has no CPU fallback)");
@@ -505,7 +525,32 @@ extern "C" int bvg_open(const char *basename, int device, bvg_t **out) {
 	HIPCHK(g, hipMemset(st->d_bits, 0, padded));
 	if (!graph.empty()) HIPCHK(g, hipMemcpy(st->d_bits, graph.data(), graph.size(), hipMemcpyHostToDevice));
 	HIPCHK(g, hipMalloc((void **)&st->d_offsets, sizeof(int64_t) * st->h_offsets.size()));
-	HIPCHK(g, hipMemcpy(st->d_offsets, st->h_offsets.data(), sizeof(int64_t) * st->h_offsets.size(), hipMemcpyHostToDevice));
+
+	// offsets: gamma-coded gaps (the default) are decoded on the device (bv_offsets.hip) and copied back for shard
+	// planning; delta-coded ones, BVGPU_OFFSETS=host, or a stream the device decoder rejects take the host decoder
+	// (OffsetsLongIterator, BVG:907-935), which also produces the precise error
+	bool onDevice = false;
+	const char *offEnv = getenv("BVGPU_OFFSETS");
+	if (in.offset_coding == BVG_GAMMA && !offs.empty() && !(offEnv && strcmp(offEnv, "host") == 0)) {
+		const uint64_t ow = (offs.size() + 3) / 4;
+		uint32_t *d_ow = nullptr;
+		if (hipMalloc((void **)&d_ow, (size_t)(ow + 8) * 4) == hipSuccess) {
+			if (hipMemset(d_ow, 0, (size_t)(ow + 8) * 4) == hipSuccess && hipMemcpy(d_ow, offs.data(), offs.size(), hipMemcpyHostToDevice) == hipSuccess &&
+			    bv::offsets_decode_device(d_ow, ow, (uint64_t)offs.size() * 8, in.nodes, st->d_offsets, nullptr) == 0 &&
+			    hipMemcpy(st->h_offsets.data(), st->d_offsets, sizeof(int64_t) * st->h_offsets.size(), hipMemcpyDeviceToHost) == hipSuccess)
+				onDevice = true;
+			(void)hipFree(d_ow);
+		}
+		(void)hipGetLastError();
+	}
+	if (!onDevice) {
+		rc = bvh::decode_offsets(offs.data(), offs.size(), in.nodes, in.offset_coding, st->h_offsets.data());
+		if (rc) return fail(g, rc, "cannot decode " + st->basename + ".offsets");
+		HIPCHK(g, hipMemcpy(st->d_offsets, st->h_offsets.data(), sizeof(int64_t) * st->h_offsets.size(), hipMemcpyHostToDevice));
+	}
+	st->info.offsets_on_device = onDevice ? 1 : 0;
+	if ((uint64_t)st->h_offsets.back() > (uint64_t)graph.size() * 8) return fail(g, BVG_EIO, "offsets run past the end of the .graph file");
+	for (size_t i = 1; i < st->h_offsets.size(); i++) if (st->h_offsets[i] < st->h_offsets[i - 1]) return fail(g, BVG_EIO, "offsets are not monotone");
 	g->st = st;
 	return init_handle(g);
 }
