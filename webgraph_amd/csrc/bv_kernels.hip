@@ -680,6 +680,33 @@ __global__ void __launch_bounds__(TPB) k_classify(int32_t cnt, const int32_t *__
 	else if (kind == 0) biglist[s_base[0] + local] = s;
 }
 
+// Longest first: the work queues of the long records are ordered by outdegree, descending, so that the records that
+// take longest start first and the short ones fill the gaps at the end (the kernel's duration is otherwise the
+// start time of an unlucky long record plus its own length).  One block, counting sort in LDS on the top bits of
+// the outdegree (exponent + 3 mantissa bits: order inside a bin does not matter); a list longer than the LDS
+// table keeps its (node) order.
+constexpr int SORT_CAP = 16384, SORT_BINS = 256;
+__global__ void __launch_bounds__(1024) k_sort_desc(int32_t *__restrict__ list, const int32_t *__restrict__ count, int32_t cap, const int32_t *__restrict__ outd) {
+	__shared__ int32_t s_out[SORT_CAP], s_cur[SORT_BINS];
+	const int32_t n = min(*count, cap);
+	if (n <= 1 || n > SORT_CAP) return;
+	auto key = [](int32_t d) { // larger outdegree -> smaller key
+		const uint32_t u = (uint32_t)max(d, 1);
+		const int lg = 31 - __clz((int)u);
+		const uint32_t m = lg >= 3 ? (u >> (lg - 3)) & 7u : (u << (3 - lg)) & 7u;
+		return SORT_BINS - 1 - (int)((uint32_t)lg * 8u + m);
+	};
+	for (int i = threadIdx.x; i < SORT_BINS; i += 1024) s_cur[i] = 0;
+	__syncthreads();
+	for (int32_t i = threadIdx.x; i < n; i += 1024) atomicAdd(&s_cur[key(outd[list[i]])], 1);
+	__syncthreads();
+	if (threadIdx.x == 0) { int32_t acc = 0; for (int b = 0; b < SORT_BINS; b++) { const int32_t c = s_cur[b]; s_cur[b] = acc; acc += c; } }
+	__syncthreads();
+	for (int32_t i = threadIdx.x; i < n; i += 1024) { const int32_t s = list[i]; s_out[atomicAdd(&s_cur[key(outd[s])], 1)] = s; }
+	__syncthreads();
+	for (int32_t i = threadIdx.x; i < n; i += 1024) list[i] = s_out[i];
+}
+
 // One group of NW waves per long record, pulled from a device-side queue.  NW = 1 serves the "big" list,
 // NW = GIANT_NW the "giant" list (records so long that a single wave would be the tail of the whole scan).
 template <bool DEF, int NW>
@@ -989,6 +1016,8 @@ void launch_bcopy(const GraphDev &g, bool def, const BatchView &v, int32_t level
 void launch_classify(int32_t cnt, const int32_t *outd, int32_t coopMin, int32_t giantMin, int32_t *biglist, int32_t *giantlist, int32_t giantCap, int32_t *ctl, hipStream_t st) {
 	if (cnt <= 0) return;
 	hipLaunchKernelGGL(k_classify, dim3(nblk(cnt, TPB)), dim3(TPB), 0, st, cnt, outd, coopMin, giantMin, biglist, giantlist, giantCap, ctl);
+	hipLaunchKernelGGL(k_sort_desc, dim3(1), dim3(1024), 0, st, giantlist, ctl + 1, giantCap, outd);
+	hipLaunchKernelGGL(k_sort_desc, dim3(1), dim3(1024), 0, st, biglist, ctl + 0, cnt, outd);
 }
 
 void launch_parse_big(const GraphDev &g, bool def, const RangeView &v, const int32_t *biglist, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap,

@@ -91,7 +91,7 @@ struct bvg_graph {
 	int copy_big = 1;    // BVGPU_COPY_BIG=0: every row is copied by one lane
 	int copy_mid_min = 128; // rows with at least this many successors (and fewer than 1024) are copied by one wave each
 	int copy_lists = 1; // BVGPU_COPY_LISTS=0: node-order sweeps over all slots instead of per-level compact lists
-	int32_t coop_min = 2048, giant_min = 65536;                         // thresholds on the outdegree (BVGPU_COOP_MIN / BVGPU_GIANT_MIN)
+	int32_t coop_min = 2048, giant_min = 32768;                         // thresholds on the outdegree (BVGPU_COOP_MIN / BVGPU_GIANT_MIN)
 	int coop_waves = 4096, giant_groups = 256;
 	DevBuf copyq; // rows the copy pass merges with a group / a wave each (all levels), filled while the level lists are built
 	DevBuf stats; // BVGPU_STATS=1: tuning counters
