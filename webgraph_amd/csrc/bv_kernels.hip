@@ -504,6 +504,83 @@ __global__ void __launch_bounds__(64 * COPY_MID_WAVES) k_copy_mid(GraphDev g, Ra
 	}
 }
 
+// A long copy-block list (gamma codes, default coding) walked by ONE wave cooperatively instead of code by code: the
+// same speculative tile decode as an interval section (coop_intervals in bv_coop.hpp), block b playing the part of
+// a (copied, skipped) alternation.  Fills kend[j] / delta[j] for the j-th copied block exactly as the serial walk
+// does, including the implicit last block, and returns the totals.  Called by the 64 lanes of wave 0 only.
+constexpr int COPY_BIG_THREADS = 1024, COPY_BIG_CAP = 6144, COPY_BIG_ITEMS = 8;
+constexpr int COPY_COOP_WALK_MIN = 192; // below this many blocks the serial walk is as fast
+__device__ __forceinline__ void coop_block_walk(const GraphDev &g, uint64_t pos, uint64_t recEnd, int64_t bc, int64_t dref, int32_t d, int32_t *kend, int32_t *delta, uint32_t *lds,
+                                                int64_t &totalOut, int64_t &copiedOut, int32_t &nKeptOut, int &bad) {
+	Grp<1> G{ (int64_t *)(lds + CoopLds<1>::OFF_XCH) };
+	const uint32_t B = coop_pick_B(min<uint64_t>(recEnd > pos ? recEnd - pos : 0, (uint64_t)bc * 8), (uint64_t)bc, 64, CoopCfg<1>::B_MAX);
+	int64_t done = 0, total = 0, copied = 0; // uniform
+	int err = 0;
+	while (done < bc) {
+		const WindowSrc src = stage_tile<1>(G, g, lds + CoopLds<1>::OFF_WIN, pos, B);
+		const uint64_t base = src.w0 << 5;
+		uint64_t E; uint32_t s, c; int64_t unused;
+		spec_tile<true, 1, 1>(G, g, src, pos, recEnd, B, false, bc - done, s, c, unused, E);
+		int64_t tileTotal;
+		const int64_t cincl = G.incl_scan((int64_t)c, tileTotal);
+		const int64_t cb = cincl - c, rem = bc - done;
+		if (cb >= rem) c = 0; else if (cb + c > rem) c = (uint32_t)(rem - cb);
+		const int64_t n = min(rem, tileTotal);
+		if (n <= 0) { err = 1; break; }
+		// pass 1: what my codes add to the referent index and to the number of copied ids
+		int64_t dAll = 0, dEven = 0;
+		uint32_t myEnd = s;
+		{
+			uint32_t p = s;
+			for (uint32_t k = 0; k < c; k++) {
+				const int64_t q = done + cb + k;
+				const int64_t len = (int64_t)win_code_rel<true, 1>(g, src, p, err) + (q ? 1 : 0);
+				dAll += len;
+				if (!(q & 1)) dEven += len;
+			}
+			myEnd = p;
+		}
+		int64_t allTot, evenTot;
+		const int64_t iAll = G.incl_scan(dAll, allTot), iEven = G.incl_scan(dEven, evenTot);
+		int64_t t = total + iAll - dAll, cp = copied + iEven - dEven;
+		// pass 2: the table entries of my copied blocks
+		{
+			uint32_t p = s;
+			int e2 = 0;
+			for (uint32_t k = 0; k < c; k++) {
+				const int64_t q = done + cb + k;
+				const int64_t len = (int64_t)win_code_rel<true, 1>(g, src, p, e2) + (q ? 1 : 0);
+				if (!(q & 1)) {
+					const int64_t j = q >> 1;
+					if (j <= COPY_BIG_CAP) { kend[j] = (int32_t)min<int64_t>(cp + len, 0x7fffffff); delta[j] = (int32_t)(t - cp); }
+					cp += len;
+				}
+				t += len;
+			}
+		}
+		const int lastTid = G.last_set(c > 0);
+		const uint64_t endPos = base + (uint64_t)G.bcast((int64_t)myEnd, lastTid);
+		total += allTot;
+		copied += evenTot;
+		done += n;
+		pos = done >= bc ? endPos : E;
+		if (total > dref || copied > d) { err = 1; break; } // (uniform)
+	}
+	if (G.any(err != 0)) { bad = 1; return; }
+	// implicit last block: the rest of the referent's row, copied when the block count is even
+	const int64_t rest = dref - total;
+	if (rest < 0) { bad = 1; return; }
+	if (!(bc & 1)) {
+		const int64_t j = bc >> 1;
+		if (j <= COPY_BIG_CAP && threadIdx.x == 0) { kend[j] = (int32_t)min<int64_t>(copied + rest, 0x7fffffff); delta[j] = (int32_t)(total - copied); }
+		copied += rest;
+	}
+	total += rest;
+	totalOut = total;
+	copiedOut = copied;
+	nKeptOut = (int32_t)min<int64_t>((bc >> 1) + 1, 0x7fffffff);
+}
+
 // One 1024-thread group per long row with a reference.  The block list is walked once, without memory traffic
 // (it is the serial part of a row with thousands of blocks), into the same two LDS tables as in k_copy_mid; the
 // copied ids (<= COPY_BIG_CAP of them) are then gathered into LDS and ranked among the row's extras
@@ -513,12 +590,12 @@ __global__ void __launch_bounds__(64 * COPY_MID_WAVES) k_copy_mid(GraphDev g, Ra
 // is already being read while this one is written.  The copied ids drop into the gaps at the end
 // (MergedIntIterator semantics for the disjoint sets of a valid file).  Rows copying more than COPY_BIG_CAP ids
 // fall back to one lane.
-constexpr int COPY_BIG_THREADS = 1024, COPY_BIG_CAP = 6144, COPY_BIG_ITEMS = 8;
 template <bool DEF>
 __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ queue,
                                                                const int32_t *__restrict__ count, int32_t cap, int32_t level, int *__restrict__ err) {
 	__shared__ int32_t cval[COPY_BIG_CAP], cpos[COPY_BIG_CAP + 1], delta[COPY_BIG_CAP + 1];
 	__shared__ uint32_t lwin[DEF ? LW_MAIN * LW_STRIDE : 1]; // stream window of the wave that walks the block list
+	__shared__ __attribute__((aligned(16))) uint32_t cwin[DEF ? CoopLds<1>::WORDS : 4]; // tile of the cooperative walk of a long block list
 	__shared__ int64_t s_copied;
 	__shared__ int32_t s_kept, s_bad;
 	int32_t *kend = cpos; // during the gather: ids copied up to the end of the j-th copied block
@@ -564,7 +641,9 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 				(void)lw.template code<1>(g, e);
 				(void)lw.template code<2>(g, e);
 				const uint64_t bc = lw.template code<1>(g, e);
-				walk([&] { return lw.template code<1>(g, e); }, bc);
+				if (bc >= COPY_COOP_WALK_MIN && bc <= (uint64_t)dref + 1 && !e)
+					coop_block_walk(g, lw.pos(), (uint64_t)g.offsets[v.lo + s + 1], (int64_t)bc, dref, d, kend, delta, cwin, total, copied, nKept, bad);
+				else walk([&] { return lw.template code<1>(g, e); }, bc);
 				bad |= e;
 			} else {
 				BitReader br;
