@@ -18,8 +18,11 @@ for mode in overlapped serial; do
   rocprofv3 --kernel-trace --stats -d /tmp/prof_$mode -o res -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /tmp/prof_$mode.log 2>&1
   db=$(find /tmp/prof_$mode -name "*.db" | head -1)
   python $R/scripts/rocprof_summary.py $db $R/gpurun_out/${tag}_kernel_stats_$mode.txt
-  [ $mode = overlapped ] && python $R/scripts/timeline.py $db $R/gpurun_out/${tag}_timeline_overlapped.txt
 done
+# timeline of one production scan (bench.py ends with its serialised profiling passes, so use the tuning driver here)
+rm -rf /tmp/prof_tl
+TUNE_NO_PROFILE=1 rocprofv3 --kernel-trace --stats -d /tmp/prof_tl -o res -- python $R/scripts/tune.py --reps 3 > /tmp/prof_tl.log 2>&1
+python $R/scripts/timeline.py $(find /tmp/prof_tl -name "*.db" | head -1) $R/gpurun_out/${tag}_timeline_overlapped.txt
 unset BVGPU_OVERLAP
 head -12 $R/gpurun_out/${tag}_kernel_stats_serial.txt | cut -c1-140
 cd $R
