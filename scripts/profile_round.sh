@@ -19,6 +19,7 @@ for mode in overlapped serial; do
   db=$(find /tmp/prof_$mode -name "*.db" | head -1)
   python $R/scripts/rocprof_summary.py $db $R/gpurun_out/${tag}_kernel_stats_$mode.txt
 done
+unset BVGPU_OVERLAP
 # timeline of one production scan (bench.py ends with its serialised profiling passes, so use the tuning driver here)
 rm -rf /tmp/prof_tl
 TUNE_NO_PROFILE=1 rocprofv3 --kernel-trace --stats -d /tmp/prof_tl -o res -- python $R/scripts/tune.py --reps 3 > /tmp/prof_tl.log 2>&1
