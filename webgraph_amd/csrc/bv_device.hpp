@@ -27,7 +27,7 @@ struct GraphDev {
 	int32_t W, minInt, zetaK;
 	int32_t c_outd, c_ref, c_bc, c_blk, c_res;
 	unsigned long long *stats; // optional tuning counters (BVGPU_STATS=1), NULL otherwise
-	int32_t dbg;               // tuning experiments (BVGPU_DBG); 0 in production
+	int32_t dbg;               // BVGPU_DBG: selects which tick counters BVGPU_STATS collects (bit 4: copy kernels); never changes results
 };
 
 // tuning counters: 0 tiles(residual) 1 rounds(residual) 2 tiles(interval) 3 rounds(interval) 4 lane-parses 5 big nodes 6 clock ticks in coop nodes 7 max ticks of one node

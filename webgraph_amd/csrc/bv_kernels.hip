@@ -283,6 +283,7 @@ __device__ __forceinline__ int32_t record_bin(uint64_t bitsLen) {
 	return lg < 6 ? 0 : lg - 5 >= NBIN ? NBIN - 1 : lg - 5;
 }
 
+constexpr int WINDOWED_BINS = 6; // work < 2^(5 + WINDOWED_BINS) bits: binned per window of nodes (noBin & 4)
 constexpr int LIST_ITEMS = 16, LIST_TILE = TPB * LIST_ITEMS; // slots per block: few blocks -> few same-address atomics (~88 M/s each)
 
 __global__ void __launch_bounds__(TPB) k_depth_keys(GraphDev g, int32_t lo, int32_t cnt, const int32_t *__restrict__ outd, const uint16_t *__restrict__ ref,
@@ -310,7 +311,14 @@ __global__ void __launch_bounds__(TPB) k_depth_keys(GraphDev g, int32_t lo, int3
 			const uint64_t bitsLen = (uint64_t)(g.offsets[lo + s + 1] - g.offsets[lo + s]);
 			const uint64_t work = max(bitsLen, (uint64_t)outd[s] * 8);
 			if (work >= giantBits) key = KEY_GIANT;
-			else key = (uint16_t)(((noBin & 2) ? 0 : min(dd, MAXLVL - 1)) * NBIN + ((noBin & 1) ? 0 : record_bin(work))); // noBin: bit 0 = ignore the length, bit 1 = ignore the level
+			else if (noBin & 4) {
+				// parse list: short records keep their neighbourhood -- sorted by work bin inside MAXLVL windows of
+				// consecutive nodes (a sweep of the parse kernel then touches a few windows of stream and rows, not
+				// the whole graph); the long ones (bin >= WINDOWED_BINS) stay together at the end: they are swept first
+				const int32_t bin = record_bin(work);
+				const int32_t win = bin >= WINDOWED_BINS ? MAXLVL - 1 : (int32_t)(((int64_t)s * MAXLVL) / cnt);
+				key = (uint16_t)(win * NBIN + bin);
+			} else key = (uint16_t)(((noBin & 2) ? 0 : min(dd, MAXLVL - 1)) * NBIN + ((noBin & 1) ? 0 : record_bin(work))); // noBin: bit 0 = ignore the length, bit 1 = ignore the level
 			atomicAdd(&s_hist[key == KEY_GIANT ? NKEYS : key], 1);
 			if (dd >= MAXLVL - 1 && dd > __builtin_nontemporal_load(maxdepth)) atomicMax(maxdepth, dd); // only very deep chains get here
 		}
@@ -1186,8 +1194,8 @@ void launch_copy_level(const GraphDev &g, bool def, const RangeView &v, const in
 
 void launch_parse_list(const GraphDev &g, bool def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st) {
 	if (v.cnt <= 0) return;
-	if (def) hipLaunchKernelGGL(k_parse_list<true>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NBIN, err);
-	else hipLaunchKernelGGL(k_parse_list<false>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NBIN, err);
+	if (def) hipLaunchKernelGGL(k_parse_list<true>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, err);
+	else hipLaunchKernelGGL(k_parse_list<false>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, err);
 }
 
 } // namespace bv

@@ -170,11 +170,11 @@ __device__ __forceinline__ void parse_node_lw(const GraphDev &g, int32_t x, int3
 		else if (resTodo) {
 			val = resVal;
 			if (ivRem && ivLeft == resVal) { ivLeft++; ivRem--; } // equal heads are emitted once (MergedIntIterator.java:69-72)
-			if (--resTodo) resVal += (g.dbg & 2) ? 1 : (int32_t)br.code<0>(g, e) + 1; // BVG:966
+			if (--resTodo) resVal += (int32_t)br.code<0>(g, e) + 1; // BVG:966
 		} else val = -1; // malformed: fewer values than the outdegree promises (BVG:1210 would store -1)
-		if (k < head) { if (!(g.dbg & 1)) out[k] = val; k++; continue; }
+		if (k < head) { out[k++] = val; continue; }
 		o0 = o1; o1 = o2; o2 = o3; o3 = val; k++;
-		if (++on == 4) { if (!(g.dbg & 1)) *(int4 *)(out + k - 4) = int4{ o0, o1, o2, o3 }; on = 0; }
+		if (++on == 4) { *(int4 *)(out + k - 4) = int4{ o0, o1, o2, o3 }; on = 0; }
 	}
 	if (on == 3) { out[k - 3] = o1; out[k - 2] = o2; out[k - 1] = o3; }
 	else if (on == 2) { out[k - 2] = o2; out[k - 1] = o3; }
