@@ -796,14 +796,30 @@ __global__ void __launch_bounds__(1024) k_sort_desc(int32_t *__restrict__ list, 
 
 // One group of NW waves per long record, pulled from a device-side queue.  NW = 1 serves the "big" list,
 // NW = GIANT_NW the "giant" list (records so long that a single wave would be the tail of the whole scan).
-template <bool DEF, int NW>
+// What the cooperative decoder needs to know about one long record, for a scan (slot of a node range) and for a
+// random-access batch (slot of a query's reference chain).  `prefix` = successors of all the slots before this one in
+// one common numbering: it places the record's slice of the interval arena.
+struct LongRec { int32_t x, d; bool hasRef; int64_t dref; int32_t *row; int64_t prefix; bool capOk; };
+__device__ __forceinline__ LongRec long_rec(const RangeView &v, int32_t s) {
+	const int32_t r = v.ref[s];
+	return LongRec{ v.lo + s, v.outd[s], r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), v.rowstart[s],
+	                !(s >= v.nh && (uint64_t)(v.rowstart[s + 1] - v.rowstart[v.nh]) > v.succ_cap) };
+}
+__device__ __forceinline__ LongRec long_rec(const BatchView &v, int32_t s) {
+	const int32_t qi = v.qidx[s];
+	const bool hasRef = v.depth[s] > 0;
+	return LongRec{ v.node[s], v.outd[s], hasRef, hasRef ? (int64_t)v.outd[s + 1] : 0, v.row(s), qi >= 0 ? v.arow[v.cnt] + v.rowptr[qi] : v.arow[s],
+	                !(qi >= 0 && (uint64_t)v.rowptr[qi + 1] > v.succ_cap) };
+}
+
+template <bool DEF, int NW, class View>
 #ifndef COOP1_MINWAVES
 #define COOP1_MINWAVES 4
 #endif
 #ifndef COOPG_MINWAVES
 #define COOPG_MINWAVES 1
 #endif
-__global__ void __launch_bounds__(64 * NW, NW == 1 ? COOP1_MINWAVES : COOPG_MINWAVES) k_parse_big(GraphDev g, RangeView v, const int32_t *__restrict__ list, int32_t *__restrict__ ctl, int which,
+__global__ void __launch_bounds__(64 * NW, NW == 1 ? COOP1_MINWAVES : COOPG_MINWAVES) k_parse_big(GraphDev g, View v, const int32_t *__restrict__ list, int32_t *__restrict__ ctl, int which,
                                                        IvEntry *__restrict__ arena, int64_t arenaCap, int *__restrict__ err) {
 	__shared__ __attribute__((aligned(16))) uint32_t lds[CoopLds<NW>::WORDS];
 	__shared__ int32_t s_idx;
@@ -814,16 +830,14 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? COOP1_MINWAVES : COOPG_MINW
 		const int32_t idx = s_idx;
 		__syncthreads();
 		if (idx >= count) break;
-		const int32_t s = list[idx];
-		const int32_t d = v.outd[s];
-		const int32_t r = v.ref[s];
-		if (s >= v.nh && (uint64_t)(v.rowstart[s + 1] - v.rowstart[v.nh]) > v.succ_cap) { if (threadIdx.x == 0) atomicOr(err, E_CAP); continue; }
-		// arena slice of this node: interval counts are bounded by d / minIntervalLength, and
-		// floor(a/k) + floor(b/k) <= floor((a+b)/k) keeps the slices of different nodes disjoint
-		const int64_t abase = g.minInt > 0 ? v.rowstart[s] / g.minInt : 0;
-		if (g.minInt > 0 && abase + d / g.minInt + 1 > arenaCap) { if (threadIdx.x == 0) atomicOr(err, E_FORMAT); continue; }
+		const LongRec rec = long_rec(v, list[idx]);
+		if (!rec.capOk) { if (threadIdx.x == 0) atomicOr(err, E_CAP); continue; }
+		// arena slice of this record: interval counts are bounded by d / minIntervalLength, and
+		// floor(a/k) + floor(b/k) <= floor((a+b)/k) keeps the slices of different records disjoint
+		const int64_t abase = g.minInt > 0 ? rec.prefix / g.minInt : 0;
+		if (g.minInt > 0 && abase + rec.d / g.minInt + 1 > arenaCap) { if (threadIdx.x == 0) atomicOr(err, E_FORMAT); continue; }
 		const unsigned long long t0 = g.stats ? __builtin_readcyclecounter() : 0;
-		coop_parse_node<DEF, NW>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), arena + abase, lds, err);
+		coop_parse_node<DEF, NW>(g, rec.x, rec.d, rec.hasRef, rec.dref, rec.row, arena + abase, lds, err);
 		if (g.stats) { const unsigned long long dt = __builtin_readcyclecounter() - t0; stat_add(g, 5, 1); stat_add(g, 6, dt); stat_max(g, 7, dt); }
 	}
 }
@@ -959,6 +973,7 @@ __global__ void __launch_bounds__(TPB) k_bparse(GraphDev g, BatchView v, int *__
 	if (d == 0) return;
 	const int32_t qi = v.qidx[s];
 	if (qi >= 0 && (uint64_t)v.rowptr[qi + 1] > v.succ_cap) { atomicOr(err, E_CAP); return; }
+	if (d >= v.coop_min) return; // decoded by whole waves (k_parse_big over the batch's slots)
 	const bool hasRef = v.depth[s] > 0;
 	parse_node<DEF>(g, v.node[s], d, hasRef, hasRef ? (int64_t)v.outd[s + 1] : 0, v.row(s), err);
 }
@@ -1110,13 +1125,26 @@ void launch_classify(int32_t cnt, const int32_t *outd, int32_t coopMin, int32_t 
 void launch_parse_big(const GraphDev &g, bool def, const RangeView &v, const int32_t *biglist, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap,
                       int waves, int giantGroups, int *err, hipStream_t stGiant, hipStream_t stBig) {
 	if (v.cnt <= 0) return;
-	if (def) hipLaunchKernelGGL((k_parse_big<true, GIANT_NW>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
-	else hipLaunchKernelGGL((k_parse_big<false, GIANT_NW>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
-	if (def) hipLaunchKernelGGL((k_parse_big<true, 1>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
-	else hipLaunchKernelGGL((k_parse_big<false, 1>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
+	if (def) hipLaunchKernelGGL((k_parse_big<true, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+	else hipLaunchKernelGGL((k_parse_big<false, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+	if (def) hipLaunchKernelGGL((k_parse_big<true, 1, RangeView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
+	else hipLaunchKernelGGL((k_parse_big<false, 1, RangeView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
 }
 
 void copy_thresholds(int32_t midMinKnob, bool bigGroups, int32_t &midMin, int32_t &bigMin);
+// long records of a random-access batch: same classification, queues and cooperative kernels as a scan, over slots
+void launch_bparse_big(const GraphDev &g, bool def, const BatchView &v, int32_t coopMin, int32_t giantMin, int32_t *biglist, int32_t *giantlist, int32_t giantCap, int32_t *ctl,
+                       void *arena, int64_t arenaCap, int waves, int giantGroups, int *err, hipStream_t st, hipStream_t stGiant, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evGiant, hipEvent_t evBig) {
+	if (v.cnt <= 0) return;
+	launch_classify((int32_t)v.cnt, v.outd, coopMin, giantMin, biglist, giantlist, giantCap, ctl, st);
+	if (stGiant != st) { (void)hipEventRecord(evFork, st); (void)hipStreamWaitEvent(stGiant, evFork, 0); (void)hipStreamWaitEvent(stBig, evFork, 0); }
+	if (def) hipLaunchKernelGGL((k_parse_big<true, GIANT_NW, BatchView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+	else hipLaunchKernelGGL((k_parse_big<false, GIANT_NW, BatchView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+	if (def) hipLaunchKernelGGL((k_parse_big<true, 1, BatchView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
+	else hipLaunchKernelGGL((k_parse_big<false, 1, BatchView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
+	if (stGiant != st) { (void)hipEventRecord(evGiant, stGiant); (void)hipEventRecord(evBig, stBig); }
+}
+
 void launch_build_lists(const GraphDev &g, const RangeView &v, uint64_t giantBits, int32_t noBin, int32_t *depth, uint16_t *key16, int32_t *hist, int32_t *keyBase, int32_t *cursor,
                         int32_t *list, int32_t *giantlist, int32_t giantCap, int32_t *ctl, int32_t *maxdepth, hipStream_t st,
                         int32_t *bigQ, int32_t bigCap, int32_t *midQ, int32_t midCap, int32_t midMinKnob, bool bigGroups) {
@@ -1153,8 +1181,8 @@ void launch_copy_giants(const GraphDev &g, bool def, const RangeView &v, const i
 
 void launch_parse_giants(const GraphDev &g, bool def, const RangeView &v, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap, int giantGroups, int *err, hipStream_t st) {
 	if (v.cnt <= 0) return;
-	if (def) hipLaunchKernelGGL((k_parse_big<true, GIANT_NW>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, st, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
-	else hipLaunchKernelGGL((k_parse_big<false, GIANT_NW>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, st, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+	if (def) hipLaunchKernelGGL((k_parse_big<true, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, st, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+	else hipLaunchKernelGGL((k_parse_big<false, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, st, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
 }
 
 // One chain level of the copy pass: three kernels, one per row class.  With side streams they run next to each

@@ -746,7 +746,25 @@ extern "C" int bvg_successors_batch(bvg_t *g, const int32_t *nodes, size_t q, in
 	bv::BatchView v{};
 	v.cnt = S; v.node = g->b_node.as<int32_t>(); v.outd = g->outd.as<int32_t>(); v.depth = g->depth.as<int32_t>(); v.qidx = g->b_qidx.as<int32_t>();
 	v.arow = g->rowstart.as<int64_t>(); v.rowptr = d_rowptr; v.succ = d_succ; v.arena = g->halo.as<int32_t>(); v.succ_cap = succ_cap;
+	const bool coop = g->coop_min < 0x7fffffff && S <= 0x7fffffff;
+	v.coop_min = coop ? g->coop_min : 0x7fffffff;
+	const bool ovl = coop && g->overlap && !g->profile;
+	if (coop) { // long records: the cooperative kernels of the scan path, over the batch's slots
+		const int64_t arcsTot = (int64_t)arcs + g->h_small->halo_total;
+		const int32_t giantCap = (int32_t)std::min<int64_t>(arcsTot / g->giant_min + 2, 0x7fffffff);
+		const int64_t arenaCap = s.info.min_interval_length > 0 ? arcsTot / s.info.min_interval_length + 2 : 1;
+		if (!g->biglist.need(4 * Sz) || !g->giantlist.need(sizeof(int32_t) * (size_t)giantCap) || !g->arena.need((size_t)bv::ARENA_ENTRY_BYTES * (size_t)arenaCap))
+			return fail(g, BVG_ENOMEM, "device scratch allocation failed");
+		int32_t *ctl = g->coopctl.as<int32_t>();
+		HIPCHK(g, hipMemsetAsync(ctl, 0, 8 * sizeof(int32_t), g->stream));
+		bv::launch_bparse_big(gd, s.def, v, g->coop_min, g->giant_min, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, g->arena.p, arenaCap,
+		                      g->coop_waves, g->giant_groups, &dsm->err, g->stream, ovl ? g->sideB : g->stream, ovl ? g->sideA : g->stream, g->evFork, g->evB, g->evA);
+	}
 	bv::launch_bparse(gd, s.def, v, &dsm->err, g->stream);
+	if (ovl) {
+		HIPCHK(g, hipStreamWaitEvent(g->stream, g->evA, 0));
+		HIPCHK(g, hipStreamWaitEvent(g->stream, g->evB, 0));
+	}
 	for (int32_t l = 1; l < maxlen; l++) bv::launch_bcopy(gd, s.def, v, l, &dsm->err, g->stream);
 	if (!dev && arcs) HIPCHK(g, hipMemcpyAsync(succ, d_succ, sizeof(int32_t) * (size_t)arcs, hipMemcpyDeviceToHost, g->stream));
 	rc = fetch_small(g);
