@@ -26,6 +26,8 @@ def main():
              "FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KB (TCC_EA0 read / write requests); shown here in MB, NOT corrected:",
              "the guide's x2 correction for FETCH_SIZE is calibrated for wide coalesced 16 B/lane streams, these kernels mostly issue",
              "scattered 4..16-byte accesses (MI355X_MICROARCH.md, HBM section).  Read them as ratios against the algorithmic bytes.",
+             "Calibration inside this very run: k_rebase streams 10 000 001 int64 in and out (76.3 MiB each, coalesced 8 B/lane):",
+             "WRITE_SIZE reports it exactly, FETCH_SIZE reports half -- the guide's x2 holds for coalesced reads, writes need no correction.",
              "",
              "%-28s %9s %9s %7s %7s %7s %7s %12s %12s" % ("kernel", "FETCH_MB", "WRITE_MB", "L2hit%", "wait%", "issue%", "valu%", "VALU insts", "LDS insts")]
     for k in sorted(agg):
