@@ -283,6 +283,14 @@ __device__ __forceinline__ int32_t record_bin(uint64_t bitsLen) {
 	return lg < 6 ? 0 : lg - 5 >= NBIN ? NBIN - 1 : lg - 5;
 }
 
+// A row that copies from a very long referent can have a block list of thousands of codes, whatever its own length:
+// walked by one lane (or one wave) it would be the tail of its kernel, so it goes to the group class, whose walk
+// is cooperative (coop_block_walk).
+constexpr int COPY_REF_BIG = 8192;
+__device__ __forceinline__ int copy_class_of(int32_t d, int32_t dref, int32_t midMin, int32_t bigMin) {
+	if (d >= bigMin || (dref >= COPY_REF_BIG && bigMin != 0x7fffffff)) return 3;
+	return d >= midMin ? 2 : 1;
+}
 constexpr int WINDOWED_BINS = 6; // work < 2^(5 + WINDOWED_BINS) bits: binned per window of nodes (noBin & 4)
 constexpr int LIST_ITEMS = 16, LIST_TILE = TPB * LIST_ITEMS; // slots per block: few blocks -> few same-address atomics (~88 M/s each)
 
@@ -326,9 +334,9 @@ __global__ void __launch_bounds__(TPB) k_depth_keys(GraphDev g, int32_t lo, int3
 		// rows with a reference that the copy pass will merge with a wave (ctl[6]) or a whole group (ctl[5]) each are
 		// queued once, for all levels; collected per block first (same-address global atomics run at ~88 M/s)
 		if (bigQ && ref[s]) {
-			const int32_t d = outd[s];
-			if (d >= bigMin) s_q[LIST_TILE - 1 - atomicAdd(&s_qn[1], 1)] = s;
-			else if (d >= midMin) s_q[atomicAdd(&s_qn[0], 1)] = s;
+			const int cls = copy_class_of(outd[s], outd[s - ref[s]], midMin, bigMin);
+			if (cls == 3) s_q[LIST_TILE - 1 - atomicAdd(&s_qn[1], 1)] = s;
+			else if (cls == 2) s_q[atomicAdd(&s_qn[0], 1)] = s;
 		}
 	}
 	__syncthreads();
@@ -425,8 +433,7 @@ __device__ __forceinline__ int copy_class(const RangeView &v, const int32_t *__r
 	if (level >= MAXLVL - 1 && depth[s] != level) return 0; // shared overflow bucket
 	if (v.ref[s] == 0) return 0;
 	if (s >= v.nh && (uint64_t)(v.rowstart[s + 1] - v.rowstart[v.nh]) > v.succ_cap) return 0; // E_CAP already raised
-	const int32_t d = v.outd[s];
-	return d >= bigMin ? 3 : d >= midMin ? 2 : 1;
+	return copy_class_of(v.outd[s], v.outd[s - v.ref[s]], midMin, bigMin);
 }
 template <bool DEF>
 __global__ void __launch_bounds__(TPB) k_copy_list(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ list,
