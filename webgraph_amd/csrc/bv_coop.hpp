@@ -55,7 +55,7 @@ template <int NW> struct CoopCfg { static constexpr int N = 64 * NW, B_MAX = NW 
 
 template <int NW> struct CoopLds { // LDS layout of one group, in 32-bit words
 	static constexpr int WIN_WORDS = CoopCfg<NW>::N * CoopCfg<NW>::B_MAX / 32 + 12; // staged tile bits (+ alignment and look-ahead slack), multiple of 4
-	static constexpr int XCH_WORDS = 2 * (NW + 8);                                   // int64 exchange slots
+	static constexpr int XCH_WORDS = 2 * (3 * NW + 8);                               // int64 exchange slots
 	static constexpr int OFF_WIN = 0, OFF_IVL = WIN_WORDS, OFF_XCH = ((OFF_IVL + 2 * (CoopCfg<NW>::IVCAP + 1) + 1) & ~1); // staged intervals: left[], pstart[]
 	static constexpr int WORDS = OFF_XCH + XCH_WORDS;
 };
@@ -105,6 +105,30 @@ template <int NW> struct Grp {
 		__syncthreads();
 		total = tot;
 		return base + inc;
+	}
+	// two scans for the price of one (the barriers are what a multi-wave scan costs)
+	__device__ __forceinline__ void incl_scan2(int64_t a, int64_t b, int64_t &ia, int64_t &ib, int64_t &totA, int64_t &totB) const {
+		const int64_t inA = wave_incl_scan_i64(a), inB = wave_incl_scan_i64(b);
+		if (NW == 1) { totA = shfl_i64(inA, 63); totB = shfl_i64(inB, 63); ia = inA; ib = inB; return; }
+		if (lane() == 63) { xch[wave()] = inA; xch[NW + wave()] = inB; }
+		__syncthreads();
+		int64_t baseA = 0, baseB = 0, tA = 0, tB = 0;
+#pragma unroll
+		for (int i = 0; i < NW; i++) { const int64_t x = xch[i], y = xch[NW + i]; if (i < wave()) { baseA += x; baseB += y; } tA += x; tB += y; }
+		__syncthreads();
+		totA = tA; totB = tB; ia = baseA + inA; ib = baseB + inB;
+	}
+	// the values a, b held by the LAST thread with p set (some thread must have it set), in two barriers
+	__device__ __forceinline__ void last2(bool p, int64_t a, int64_t b, int64_t &oa, int64_t &ob) const {
+		const unsigned long long m = __ballot(p);
+		const int l = m ? 63 - __clzll((long long)m) : -1;
+		if (NW == 1) { oa = shfl_i64(a, l); ob = shfl_i64(b, l); return; }
+		if (lane() == (l < 0 ? 0 : l)) { xch[wave()] = l >= 0; xch[NW + wave()] = a; xch[2 * NW + wave()] = b; }
+		__syncthreads();
+		int w = NW - 1;
+		while (w > 0 && xch[w] == 0) w--;
+		oa = xch[NW + w]; ob = xch[2 * NW + w];
+		__syncthreads();
 	}
 	// the value held by thread tid-1; thread 0 gets `first`
 	__device__ __forceinline__ uint64_t prev(uint64_t e, uint64_t first) const {
@@ -468,7 +492,8 @@ __device__ __forceinline__ void coop_intervals(const Grp<NW> &G, const GraphDev 
 			myEnd = p;
 		}
 		int64_t curTot, pTot;
-		const int64_t icur = G.incl_scan(dcur, curTot), ip = G.incl_scan(dp, pTot);
+		int64_t icur, ip;
+		G.incl_scan2(dcur, dp, icur, ip, curTot, pTot);
 		int64_t cur = cursor + icur - dcur, pc = pcount + ip - dp;
 		// pass 2: write the entries
 		{
@@ -482,8 +507,9 @@ __device__ __forceinline__ void coop_intervals(const Grp<NW> &G, const GraphDev 
 			}
 		}
 		// the lane owning the last contributed code knows where the section really continues
-		const int lastTid = G.last_set(c > 0);
-		const uint64_t endPos = base + (uint64_t)G.bcast((int64_t)myEnd, lastTid);
+		int64_t endRel, unused2;
+		G.last2(c > 0, (int64_t)myEnd, 0, endRel, unused2);
+		const uint64_t endPos = base + (uint64_t)endRel;
 		cursor += curTot;
 		pcount += pTot;
 		codesDone += total;
@@ -523,16 +549,14 @@ __device__ __forceinline__ void coop_residuals(const Grp<NW> &G, const GraphDev 
 		spec_tile<DEF, 0, NW>(G, g, src, pos, recEnd, B, firstTile, nRes - resDone, s, c, sum, E);
 		RT(1);
 		// no more codes than the section still has
-		int64_t tileTotal;
-		const int64_t cincl = G.incl_scan((int64_t)c, tileTotal);
+		int64_t tileTotal, sumTot, cincl, sincl;
+		G.incl_scan2((int64_t)c, sum, cincl, sincl, tileTotal, sumTot);
 		const int64_t cb = cincl - c;
 		const int64_t lim = nRes - resDone;
 		if (cb >= lim) c = 0; else if (cb + c > lim) c = (uint32_t)(lim - cb);
 		const bool lastTile = tileTotal >= lim;
 		const int64_t T = min(lim, tileTotal);
 		if (T <= 0) { err |= E_FORMAT; break; }
-		int64_t sumTot;
-		const int64_t sincl = G.incl_scan(sum, sumTot);
 		int64_t val = baseVal + sincl - sum; // the residual before my first one (x for the very first lane)
 		// ---- stage the intervals that can fall among this tile's residuals: [ia, first left >= last value)
 		int64_t staged = 0;
@@ -585,10 +609,9 @@ __device__ __forceinline__ void coop_residuals(const Grp<NW> &G, const GraphDev 
 			if (c == 0) i = 0;
 		}
 		RT(3);
-		const int lastTid = G.last_set(c > 0);
-		const int64_t lastVal = G.bcast(val, lastTid);
-		ia = G.bcast(i, lastTid); // everything before it has been ranked
-		G.sync(); // staged intervals / window are reused by the next tile
+		int64_t lastVal;
+		G.last2(c > 0, val, i, lastVal, ia); // ia: everything before it has been ranked
+		if (NW == 1) G.sync(); // staged intervals / window are reused by the next tile (last2 ends with a barrier)
 		resDone += T;
 		baseVal = lastVal;
 		pos = E; // a cut only happens on the last tile
