@@ -1,16 +1,26 @@
 // bv_kernels.hip -- HIP kernels of the BVGraph decode path for gfx950 (MI355X).
 //
-// Pipeline of one range decode (nodes [from,to), optional halo [lo,from) of referents):
-//   k_headers     one lane per node: outdegree + reference fields              (BVG:1048-1054)
-//   k_mark_halo   transitive closure of the referents that live before `from`  (replaces the random-access
-//                 window refill of BVGraphNodeIterator, BVG:1173-1183)
-//   scan          exclusive prefix sum of the outdegrees -> CSR rowptr
-//   k_depth       length of each node's reference chain (the file never stores it; maxrefcount is not trusted)
-//   k_parse       one lane per node: copy-block totals, intervals, residuals -> the node's "extra" successors,
-//                 written merged and sorted to the TAIL of its CSR row      (BVG:1058-1100, :939-991)
-//   k_copy(l)     for l = 1..maxdepth: nodes whose chain depth is l merge the masked copy of their referent's
-//                 (already final) row with their extras, in place           (MaskedIntIterator / MergedIntIterator)
-// All arithmetic is integer; nothing here is MFMA-shaped.
+// Pipeline of one range decode (nodes [from,to), optional halo [lo,from) of referents); DESIGN.md section 3:
+//   k_headers        one lane per node: outdegree + reference fields                   (BVG:1048-1054)
+//   k_mark_halo      transitive closure of the referents that live before `from`       (replaces the random-access
+//                    window refill of BVGraphNodeIterator, BVG:1173-1183)
+//   k_scan_*         exclusive prefix sum of the outdegrees -> CSR rowptr
+//   k_depth_keys,    chain depth of every node (the file never stores it; maxrefcount is not trusted), compact
+//   k_scatter_keys   work lists (per level for the copy pass, per work bin for the parse) and the copy-pass queues
+//   k_classify,      records with >= coop_min / >= giant_min successors -> two queues, longest first
+//   k_sort_desc
+//   k_parse_list     one lane per record (lane-private LDS stream windows, bv_lanewin.hpp)
+//   k_parse_big<1>   one wave per record   } cooperative decoder, bv_coop.hpp
+//   k_parse_big<8>   eight waves per record}
+//                    every parse kernel writes the record's "extra" successors (intervals + residuals, merged) to
+//                    the TAIL of its CSR row                                            (BVG:1058-1100, :939-991)
+//   k_copy_list,     for l = 1..maxdepth: rows whose chain depth is l merge the masked copy of their referent's
+//   k_copy_mid,      (already final) row with their extras, in place: one lane / one wave / one 1024-thread group
+//   k_copy_big       per row                                                 (MaskedIntIterator / MergedIntIterator)
+//   k_chain_*, k_bparse, k_bcopy   the same for batches of random-access queries (slots of reference chains)
+//   k_hash_*         ImmutableGraph.hashCode of a decoded CSR
+// Older single-purpose variants kept for the tuning knobs and as fallbacks: k_parse, k_copy, k_depth, and the fused
+// single-pass path (k_decode_level, bv_lane.hpp).  All arithmetic is integer; nothing here is MFMA-shaped.
 #include "bv_device.hpp"
 #include "bv_launch.hpp"
 #include "bv_coop.hpp"
