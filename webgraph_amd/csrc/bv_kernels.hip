@@ -759,8 +759,11 @@ __global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, con
 		if (d >= v.coop_min || d == 0) continue; // decoded by whole waves (k_parse_big) / nothing to decode
 		const int32_t r = v.ref[s];
 		if (s >= v.nh && (uint64_t)(v.rowstart[s + 1] - v.rowstart[v.nh]) > v.succ_cap) { atomicOr(err, E_CAP); continue; }
-		if (DEF) parse_node_lw(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), lw, err);
-		else parse_node<DEF>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), err);
+		if (DEF) {
+			// records of at most 64 bits (work bin 0 and a few more) never leave a register
+			if (g.offsets[v.lo + s + 1] - g.offsets[v.lo + s] <= 64) parse_node_r64(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), err);
+			else parse_node_lw(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), lw, err);
+		} else parse_node<DEF>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), err);
 	}
 }
 
