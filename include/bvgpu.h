@@ -159,6 +159,37 @@ int bvg_decode_offsets_host(const uint8_t *offsets_file, size_t len, int32_t nod
  * BVG_EUNSUPPORTED for delta-coded offsets, BVG_EFORMAT when the stream does not hold exactly nodes + 1 codes. */
 int bvg_decode_offsets_device(int device, const uint8_t *offsets_file, size_t len, int32_t nodes, int offset_coding, int64_t *out);
 
+/* ---- arc labels ----------------------------------------------------------------
+ * labelling/BitStreamArcLabelledImmutableGraph.java:60-135: <basename>.properties names the underlying graph and the
+ * label class (`underlyinggraph`, `labelspec`), <basename>.labels holds the labels of all arcs in enumeration order as
+ * one bit stream, <basename>.labeloffsets the gamma-coded lengths of the per-node label lists (:652-671).  Supported
+ * label classes: GammaCodedIntLabel (GammaCodedIntLabel.java:60-64) and FixedWidthIntLabel (FixedWidthIntLabel.java:70-73).
+ * The labels of the arcs of nodes [from, to) come out in the CSR order of bvg_decode_range on the underlying graph. */
+typedef struct bvg_labels bvg_labels_t;
+enum { BVG_LABEL_GAMMA = 1, BVG_LABEL_FIXED = 2 };
+typedef struct bvg_labels_info {
+	int32_t  kind;             /* BVG_LABEL_GAMMA / BVG_LABEL_FIXED */
+	int32_t  width;            /* bits per label (BVG_LABEL_FIXED) */
+	int32_t  nodes;            /* nodes of the underlying graph */
+	int32_t  device;
+	uint64_t labels_bytes;     /* size of <basename>.labels */
+	uint64_t labels_bits;      /* last label offset = bits actually used */
+	char     underlying[1024]; /* resolved basename of the underlying graph (open it with bvg_open) */
+	char     key[128];         /* the label's key (first constructor argument) */
+} bvg_labels_info_t;
+
+/* BitStreamArcLabelledImmutableGraph.load (:383-470): parse the properties, stage .labels and the decoded label offsets
+ * in HBM.  `nodes` must be the underlying graph's node count (the label files do not record it). */
+int bvg_labels_open(const char *basename, int32_t nodes, int device, bvg_labels_t **out);
+void bvg_labels_close(bvg_labels_t *h);
+int bvg_labels_info(const bvg_labels_t *h, bvg_labels_info_t *out);
+const char *bvg_labels_last_error(const bvg_labels_t *h);
+/* [host-only] the properties of a labelled graph without touching a GPU: fills kind / width / underlying / key. */
+int bvg_labels_parse_properties(const char *basename, bvg_labels_info_t *out, char *errbuf, size_t errlen);
+/* Labels of the `arcs` arcs of nodes [from, to) (arcs = rowptr[to] - rowptr[from] of the underlying graph; checked against
+ * the stream: BVG_EFORMAT if the stream holds another number of labels).  flags: BVG_OUT_HOST or BVG_OUT_DEVICE. */
+int bvg_labels_decode_range(bvg_labels_t *h, int32_t from, int32_t to, uint64_t arcs, int32_t *labels, int flags);
+
 #ifdef __cplusplus
 }
 #endif

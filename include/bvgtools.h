@@ -50,6 +50,15 @@ int bvt_generate(int32_t n, int64_t m, uint64_t seed, double p_copy, int threads
 
 void bvt_free(void *p);
 
+/*
+ * Arc labels: writes <basename>.labels / .labeloffsets / .properties as
+ * BitStreamArcLabelledImmutableGraph.store does (labelling/BitStreamArcLabelledImmutableGraph.java:650-695), for int
+ * labels given per arc in CSR order.  kind 1 = GammaCodedIntLabel (labels >= 0), 2 = FixedWidthIntLabel(width).
+ * `underlying` is written verbatim as the `underlyinggraph` property (relative to the property file's directory).
+ */
+int bvt_store_labels(const char *basename, const char *underlying, int32_t n, const int64_t *rowptr, const int32_t *labels,
+                     int kind, int width, const char *key);
+
 #ifdef __cplusplus
 }
 #endif

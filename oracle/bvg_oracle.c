@@ -28,6 +28,7 @@
 #define BVO_EUNSUP -3   /* UnsupportedOperationException (BVG:635 etc., unknown coding) */
 #define BVO_ENOMEM -4
 #define BVO_ECAP -5     /* caller's successor buffer too small */
+#define BVO_EFORMAT -6  /* a label list does not end where the next one starts / truncated label stream */
 
 /* CompressionFlags.java:26-44 */
 enum { C_DELTA = 1, C_GAMMA = 2, C_GOLOMB = 3, C_SKEWED_GOLOMB = 4, C_UNARY = 5, C_ZETA = 6, C_NIBBLE = 7 };
@@ -470,4 +471,35 @@ int bvo_successors_batch(const bvo_graph *h, const int32_t *nodes, size_t q, int
 	}
 	free(dst.v);
 	return BVO_OK;
+}
+
+/* ---- arc labels (labelling/BitStreamArcLabelledImmutableGraph.java).  kind 1: GammaCodedIntLabel.fromBitStream
+ * (GammaCodedIntLabel.java:60-64, readGamma); kind 2: FixedWidthIntLabel.fromBitStream (FixedWidthIntLabel.java:70-73,
+ * readInt(width)).  Label offsets: LabelOffsetsLongIterator (:340-358) = gamma gaps, first one 0.  Decodes the labels
+ * of the arcs of nodes [from, to): `outd` are the outdegrees of those nodes (from the underlying graph). */
+int bvo_labels_decode(const uint8_t *labels, size_t len, const uint8_t *loffs, size_t olen, int32_t n, int kind, int width,
+                      int32_t from, int32_t to, const int32_t *outd, int32_t *out, size_t cap, uint64_t *count) {
+	if ((!labels && len) || !loffs || from < 0 || to < from || to > n || (kind != 1 && kind != 2) || (kind == 2 && (width < 0 || width > 32))) return BVO_EARG;
+	int64_t *off = (int64_t *)malloc(sizeof(int64_t) * ((size_t)n + 1));
+	if (!off) return BVO_ENOMEM;
+	int rc = bvo_decode_offsets(loffs, olen, n, 2 /* gamma */, off);
+	if (rc) { free(off); return rc; }
+	uint8_t *b = (uint8_t *)calloc(len + 16, 1);
+	if (!b) { free(off); return BVO_ENOMEM; }
+	if (len) memcpy(b, labels, len);
+	ibs_t s = { b, 0, (uint64_t)len * 8, 0 };
+	uint64_t k = 0;
+	for (int32_t x = from; x < to && !rc; x++) {
+		s.pos = (uint64_t)off[x]; /* random access through the offsets, as the reference's labelled iterators do */
+		for (int32_t j = 0; j < outd[x - from]; j++) {
+			const uint64_t v = kind == 1 ? read_gamma(&s) : (width ? read_bits(&s, (unsigned)width) : 0);
+			if (s.err) { rc = BVO_EFORMAT; break; }
+			if (out) { if (k >= cap) { rc = BVO_EARG; break; } out[k] = (int32_t)(uint32_t)v; }
+			k++;
+		}
+		if (!rc && s.pos != (uint64_t)off[x + 1]) rc = BVO_EFORMAT; /* the list must end where the next one starts */
+	}
+	if (count) *count = k;
+	free(b); free(off);
+	return rc;
 }

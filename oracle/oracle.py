@@ -44,6 +44,8 @@ def lib():
         L.bvo_open.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(Params), C.c_void_p]
         L.bvo_close.argtypes = [C.c_void_p]
         L.bvo_decode_offsets.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.c_int, C.c_void_p]
+        L.bvo_labels_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int32, C.c_int, C.c_int, C.c_int32, C.c_int32,
+                                        C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
         L.bvo_outdegree.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
         L.bvo_outdegrees.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         L.bvo_successors.restype = C.c_int64
@@ -254,3 +256,32 @@ def read_ascii_graph_gz(path):
             rowptr[i + 1] = rowptr[i] + a.size
     succ = np.concatenate(chunks) if chunks else np.empty(0, dtype=np.int32)
     return n, rowptr, succ
+
+
+def parse_labelspec(spec):
+    """'<class>(KEY[,WIDTH])' -> (kind, width, key): kind 1 = GammaCodedIntLabel, 2 = FixedWidthIntLabel (Label.toSpec())."""
+    cls, args = spec.split("(", 1)
+    args = [a.strip() for a in args.rsplit(")", 1)[0].split(",")]
+    name = cls.strip().rsplit(".", 1)[-1]
+    if name == "GammaCodedIntLabel" and len(args) == 1:
+        return 1, -1, args[0]
+    if name == "FixedWidthIntLabel" and len(args) == 2:
+        return 2, int(args[1]), args[0]
+    raise ValueError("unsupported label class: " + spec)
+
+
+def labels_decode(basename, n, outd, lo=0, hi=None):
+    """Labels of the arcs of nodes [lo, hi) of a BitStreamArcLabelledImmutableGraph (test oracle): `outd` = outdegrees of those nodes."""
+    props = parse_properties(basename + ".properties")
+    kind, width, _ = parse_labelspec(props["labelspec"])
+    hi = n if hi is None else hi
+    lab = np.frombuffer(open(basename + ".labels", "rb").read(), dtype=np.uint8)
+    lof = np.frombuffer(open(basename + ".labeloffsets", "rb").read(), dtype=np.uint8)
+    outd = np.ascontiguousarray(outd, dtype=np.int32)
+    out = np.empty(max(int(outd.sum()), 1), dtype=np.int32)
+    cnt = C.c_uint64(0)
+    rc = lib().bvo_labels_decode(lab.ctypes.data if lab.size else None, lab.size, lof.ctypes.data, lof.size, n, kind, max(width, 0), lo, hi,
+                                 outd.ctypes.data, out.ctypes.data, out.size, C.byref(cnt))
+    if rc:
+        raise OracleError(rc)
+    return out[:cnt.value]

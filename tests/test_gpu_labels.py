@@ -1,0 +1,49 @@
+"""GPU decode of arc labels against the CPU oracle and the labels that were stored:
+BitStreamArcLabelledImmutableGraph with GammaCodedIntLabel / FixedWidthIntLabel, labels in the CSR order of the scan."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("kind,width,n,m", [("gamma", 0, 20000, 400000), ("fixed", 13, 20000, 400000), ("fixed", 32, 500, 4000),
+                                             ("fixed", 0, 500, 4000), ("gamma", 0, 300000, 9000000)])
+def test_labels_match_oracle(tmp_path, kind, width, n, m):
+    from webgraph_amd import tools as T
+    from webgraph_amd.bvgraph import ArcLabelledBVGraph
+    from oracle import oracle as O
+    rowptr, succ = T.generate(n, m, seed=31 + width, p_copy=0.5)
+    T.store(str(tmp_path / "g"), rowptr, succ, window=7, max_ref_count=3, min_interval=4)
+    rng = np.random.Generator(np.random.PCG64(5))
+    if kind == "gamma":
+        labels = (rng.pareto(0.8, size=m) * 2).astype(np.int64).clip(0, 2**31 - 2).astype(np.int32)  # mostly short codes, some > 2^16
+    else:
+        labels = (rng.integers(0, 2**width, size=m, dtype=np.int64) if width else np.zeros(m, dtype=np.int64)).astype(np.uint32).view(np.int32)
+    lbase = str(tmp_path / "lab")
+    T.store_labels(lbase, "g", rowptr, labels, kind=kind, width=width)
+    g = ArcLabelledBVGraph.load(lbase)
+    assert (g.info.kind, g.info.nodes) == (1 if kind == "gamma" else 2, n)
+    rp, sc, lb = g.decode_range()
+    assert np.array_equal(rp, rowptr) and np.array_equal(sc, succ) and np.array_equal(lb, labels)
+    d = np.diff(rowptr).astype(np.int32)
+    for lo, hi in [(0, 1), (n // 3, min(n, n // 3 + 777)), (n - 5, n), (7, 7)]:
+        rp, sc, lb = g.decode_range(lo, hi)
+        assert np.array_equal(lb, O.labels_decode(lbase, n, d[lo:hi], lo, hi))
+        assert np.array_equal(lb, labels[rowptr[lo]:rowptr[hi]])
+    g.close()
+
+
+def test_labels_wrong_arc_count_is_an_error(tmp_path):
+    import ctypes as C
+    from webgraph_amd import tools as T
+    from webgraph_amd.bvgraph import ArcLabelledBVGraph, lib
+    rowptr, succ = T.generate(2000, 30000, seed=2, p_copy=0.5)
+    T.store(str(tmp_path / "g"), rowptr, succ, window=7, max_ref_count=3, min_interval=4)
+    T.store_labels(str(tmp_path / "lab"), "g", rowptr, np.arange(succ.size, dtype=np.int32) % 100, kind="gamma")
+    g = ArcLabelledBVGraph.load(str(tmp_path / "lab"))
+    out = np.empty(succ.size + 10, dtype=np.int32)
+    assert lib().bvg_labels_decode_range(g._h, 0, 2000, succ.size + 3, out.ctypes.data, 0) != 0  # more labels asked than stored
+    assert lib().bvg_labels_decode_range(g._h, 0, 2000, succ.size - 3, out.ctypes.data, 0) != 0
+    assert lib().bvg_labels_decode_range(g._h, 0, 2001, succ.size, out.ctypes.data, 0) != 0      # node range out of bounds
+    assert lib().bvg_labels_decode_range(g._h, 0, 2000, succ.size, out.ctypes.data, 0) == 0
+    g.close()

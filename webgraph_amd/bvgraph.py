@@ -26,9 +26,15 @@ class BvgInfo(C.Structure):
                 ("graph_bytes", C.c_uint64), ("device", C.c_int32), ("offsets_on_device", C.c_int32)]
 
 
+class BvgLabelsInfo(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("width", C.c_int32), ("nodes", C.c_int32), ("device", C.c_int32), ("labels_bytes", C.c_uint64),
+                ("labels_bits", C.c_uint64), ("underlying", C.c_char * 1024), ("key", C.c_char * 128)]
+
+
 EXPORTS = ["bvg_open", "bvg_clone", "bvg_close", "bvg_info", "bvg_last_error", "bvg_set_stream", "bvg_sync",
            "bvg_outdegrees", "bvg_decode_range", "bvg_successors_batch", "bvg_csr_hashcode", "bvg_shard_bounds",
-           "bvg_parse_properties", "bvg_flags_from_string", "bvg_decode_offsets_host", "bvg_decode_offsets_device", "bvg_set_profile", "bvg_get_profile", "bvg_debug_stats"]
+           "bvg_parse_properties", "bvg_flags_from_string", "bvg_decode_offsets_host", "bvg_decode_offsets_device", "bvg_labels_open", "bvg_labels_close", "bvg_labels_info",
+           "bvg_labels_last_error", "bvg_labels_parse_properties", "bvg_labels_decode_range", "bvg_set_profile", "bvg_get_profile", "bvg_debug_stats"]
 
 _lib = None
 
@@ -65,6 +71,14 @@ def lib():
         L.bvg_flags_from_string.restype = i64
         L.bvg_decode_offsets_host.argtypes = [vp, sz, i32, C.c_int, vp]
         L.bvg_decode_offsets_device.argtypes = [C.c_int, vp, sz, i32, C.c_int, vp]
+        L.bvg_labels_open.argtypes = [C.c_char_p, i32, C.c_int, C.POINTER(vp)]
+        L.bvg_labels_close.argtypes = [vp]
+        L.bvg_labels_close.restype = None
+        L.bvg_labels_info.argtypes = [vp, C.POINTER(BvgLabelsInfo)]
+        L.bvg_labels_last_error.argtypes = [vp]
+        L.bvg_labels_last_error.restype = C.c_char_p
+        L.bvg_labels_parse_properties.argtypes = [C.c_char_p, C.POINTER(BvgLabelsInfo), C.c_char_p, sz]
+        L.bvg_labels_decode_range.argtypes = [vp, i32, i32, u64, vp, C.c_int]
         L.bvg_set_profile.argtypes = [vp, C.c_int]
         L.bvg_get_profile.argtypes = [vp, C.POINTER(C.c_float)]
         L.bvg_debug_stats.argtypes = [vp, vp, C.c_int]
@@ -401,3 +415,67 @@ class BVGraph:
             self.decode_range_device(lo, hi, rowptr.data_ptr(), succ.data_ptr(), succ.numel())
             h = self.csr_hashcode(lo, hi, rowptr.data_ptr(), succ.data_ptr(), h)
         return h
+
+
+class ArcLabelledBVGraph:
+    """BitStreamArcLabelledImmutableGraph over a BVGraph (labelling/BitStreamArcLabelledImmutableGraph.java:383-470), int
+    labels only (GammaCodedIntLabel / FixedWidthIntLabel): the underlying graph and the label stream both live in HBM."""
+
+    def __init__(self, graph, handle, basename):
+        self.graph = graph
+        self._h = handle
+        self._basename = basename
+        self.info = BvgLabelsInfo()
+        rc = lib().bvg_labels_info(self._h, C.byref(self.info))
+        if rc:
+            _raise(rc, "bvg_labels_info")
+
+    @classmethod
+    def load(cls, basename, device=0):
+        info = BvgLabelsInfo()
+        err = C.create_string_buffer(512)
+        rc = lib().bvg_labels_parse_properties(os.fsencode(basename), C.byref(info), err, 512)
+        if rc:
+            _raise(rc, err.value.decode("utf-8", "replace"))
+        g = BVGraph.load(os.fsdecode(info.underlying), device=device)
+        h = C.c_void_p()
+        rc = lib().bvg_labels_open(os.fsencode(basename), g.numNodes(), device, C.byref(h))
+        if rc:
+            msg = lib().bvg_labels_last_error(h).decode("utf-8", "replace") if h else ""
+            if h:
+                lib().bvg_labels_close(h)
+            g.close()
+            _raise(rc, msg)
+        return cls(g, h, basename)
+
+    def close(self):
+        if self._h:
+            lib().bvg_labels_close(self._h)
+            self._h = None
+        if self.graph is not None:
+            self.graph.close()
+            self.graph = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def numNodes(self):
+        return self.graph.numNodes()
+
+    def decode_range(self, lo=0, hi=None):
+        """(rowptr, successors, labels) of nodes [lo, hi): labels[k] belongs to arc k of the CSR."""
+        hi = self.numNodes() if hi is None else hi
+        rowptr, succ = self.graph.decode_range(lo, hi)
+        labels = np.empty(max(succ.size, 1), dtype=np.int32)
+        rc = lib().bvg_labels_decode_range(self._h, lo, hi, int(rowptr[-1]), labels.ctypes.data, BVG_OUT_HOST)
+        if rc:
+            _raise(rc, lib().bvg_labels_last_error(self._h).decode("utf-8", "replace"))
+        return rowptr, succ, labels[:succ.size]
+
+    def decode_labels_device(self, lo, hi, arcs, labels_ptr):
+        rc = lib().bvg_labels_decode_range(self._h, lo, hi, int(arcs), labels_ptr, BVG_OUT_DEVICE)
+        if rc:
+            _raise(rc, lib().bvg_labels_last_error(self._h).decode("utf-8", "replace"))

@@ -74,5 +74,8 @@ void launch_bparse_big(const GraphDev &g, bool def, const BatchView &v, int32_t 
 
 // bv_offsets.hip: gamma-coded .offsets stream (words + >= 8 zero words in HBM) -> int64 offsets[nodes + 1] in HBM
 int offsets_decode_device(const uint32_t *d_words, uint64_t nwords, uint64_t totalBits, int32_t nodes, int64_t *d_out, hipStream_t st);
+// arc labels (.labels stream in HBM, same padding): `count` consecutive labels starting at bit `startBit`
+int gamma_labels_decode_device(const uint32_t *d_words, uint64_t nwords, uint64_t startBit, uint64_t endBit, int64_t count, int32_t *d_out, hipStream_t st);
+int fixed_labels_decode_device(const uint32_t *d_words, uint64_t nwords, uint64_t startBit, int32_t width, int64_t count, int32_t *d_out, hipStream_t st);
 
 } // namespace bv

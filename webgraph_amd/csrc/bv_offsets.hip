@@ -26,7 +26,7 @@ __device__ __forceinline__ GraphDev offsets_stream(const uint32_t *words, uint64
 }
 
 // round 0: every chunk guesses its start by run-in; round r > 0: start = end of the previous chunk in round r-1
-__global__ void __launch_bounds__(64) k_off_parse(const uint32_t *__restrict__ words, uint64_t nwords, uint64_t totalBits, int64_t nchunks, int round,
+__global__ void __launch_bounds__(64) k_off_parse(const uint32_t *__restrict__ words, uint64_t nwords, uint64_t startBit, uint64_t totalBits, int64_t nchunks, int round,
                                                   const uint64_t *__restrict__ endPrev, uint64_t *__restrict__ endNew, uint64_t *__restrict__ startUsed,
                                                   uint32_t *__restrict__ cnt, int64_t *__restrict__ gapsum, OffLane *__restrict__ lanes, int *__restrict__ changed) {
 	__shared__ __attribute__((aligned(16))) uint32_t lds[CoopLds<1>::WORDS];
@@ -34,8 +34,8 @@ __global__ void __launch_bounds__(64) k_off_parse(const uint32_t *__restrict__ w
 	Grp<1> G{ (int64_t *)(lds + CoopLds<1>::OFF_XCH) };
 	const int64_t c = blockIdx.x;
 	if (c >= nchunks) return;
-	const uint64_t anchor = (uint64_t)c * OFF_CHUNK;
-	uint64_t start = 0;
+	const uint64_t anchor = startBit + (uint64_t)c * OFF_CHUNK; // (startBit is a true codeword boundary)
+	uint64_t start = startBit;
 	if (c > 0 && round > 0) {
 		start = endPrev[c - 1];
 		if (start == startUsed[c]) { if (threadIdx.x == 0) endNew[c] = endPrev[c]; return; } // nothing moved
@@ -90,14 +90,15 @@ __global__ void __launch_bounds__(1024) k_off_scan(const uint32_t *__restrict__ 
 }
 
 // value pass: every lane decodes the codes it owns again and writes the running sums
-__global__ void __launch_bounds__(64) k_off_values(const uint32_t *__restrict__ words, uint64_t nwords, int64_t nchunks, const OffLane *__restrict__ lanes,
-                                                   const int64_t *__restrict__ cntBase, const int64_t *__restrict__ sumBase, int64_t nOut, int64_t *__restrict__ out) {
+template <bool PREFIX, class T>
+__global__ void __launch_bounds__(64) k_off_values(const uint32_t *__restrict__ words, uint64_t nwords, uint64_t startBit, int64_t nchunks, const OffLane *__restrict__ lanes,
+                                                   const int64_t *__restrict__ cntBase, const int64_t *__restrict__ sumBase, int64_t nOut, T *__restrict__ out) {
 	__shared__ __attribute__((aligned(16))) uint32_t lds[CoopLds<1>::WORDS];
 	const GraphDev g = offsets_stream(words, nwords);
 	Grp<1> G{ (int64_t *)(lds + CoopLds<1>::OFF_XCH) };
 	const int64_t c = blockIdx.x;
 	if (c >= nchunks) return;
-	const uint64_t anchor = (uint64_t)c * OFF_CHUNK;
+	const uint64_t anchor = startBit + (uint64_t)c * OFF_CHUNK;
 	const uint64_t posW = anchor >= OFF_RUNIN ? anchor - OFF_RUNIN : 0;
 	const WindowSrc src = stage_tile<1>(G, g, lds + CoopLds<1>::OFF_WIN, posW, OFF_STAGE_B);
 	const OffLane me = lanes[c * 64 + threadIdx.x];
@@ -107,19 +108,34 @@ __global__ void __launch_bounds__(64) k_off_values(const uint32_t *__restrict__ 
 	uint32_t p = (uint32_t)(anchor + me.s - (src.w0 << 5));
 	int err = 0;
 	for (uint32_t k = 0; k < me.c; k++) {
-		acc += (int64_t)win_code_rel<true, 2>(g, src, p, err);
-		if (idx < nOut) out[idx] = acc;
+		const int64_t v = (int64_t)win_code_rel<true, 2>(g, src, p, err);
+		acc += v;
+		if (idx < nOut) out[idx] = (T)(PREFIX ? acc : v); // offsets: running sum of the gaps; labels: the values themselves
 		idx++;
 	}
+}
+
+// fixed-width labels (FixedWidthIntLabel.java:70-73, readInt(width)): label a of the range sits at startBit + a * width
+__global__ void __launch_bounds__(256) k_fixed_width(const uint32_t *__restrict__ words, uint64_t nwords, uint64_t startBit, int32_t width, int64_t count, int32_t *__restrict__ out) {
+	const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (a >= count) return;
+	const uint64_t pos = startBit + (uint64_t)a * (uint64_t)width;
+	const uint64_t w = pos >> 5;
+	const uint32_t sh = (uint32_t)pos & 31u;
+	const uint64_t ab = ((uint64_t)__builtin_bswap32(words[w]) << 32) | __builtin_bswap32(words[w + 1]); // (the image ends with >= 8 zero words)
+	out[a] = width == 0 ? 0 : (int32_t)(uint32_t)(((ab << sh) >> 32) >> (32u - (uint32_t)width));
 }
 
 // host side -------------------------------------------------------------------------------------------------
 // d_words: the file's bytes as 32-bit words followed by >= 8 zero words; scratch is allocated and freed here
 // (load-time code).  Returns 0, or -1 when the stream does not hold exactly `nodes + 1` codes (caller falls
 // back to the host decoder, which produces the precise error).
-int offsets_decode_device(const uint32_t *d_words, uint64_t nwords, uint64_t totalBits, int32_t nodes, int64_t *d_out, hipStream_t st) {
-	const int64_t nOut = (int64_t)nodes + 1;
-	const int64_t nchunks = (int64_t)((totalBits + OFF_CHUNK - 1) / OFF_CHUNK);
+// One contiguous stream of gamma codes in [startBit, endBit) holding exactly nOut codes: running sums -> int64 (offsets)
+// or the values themselves -> int32 (gamma-coded labels).  startBit must be a codeword boundary.
+template <bool PREFIX, class T>
+static int gamma_stream_decode(const uint32_t *d_words, uint64_t nwords, uint64_t startBit, uint64_t totalBits, int64_t nOut, T *d_out, hipStream_t st) {
+	if (nOut == 0) return totalBits == startBit ? 0 : -1;
+	const int64_t nchunks = totalBits > startBit ? (int64_t)((totalBits - startBit + OFF_CHUNK - 1) / OFF_CHUNK) : 0;
 	if (nchunks <= 0 || nchunks > 0x7fffffff) return -1;
 	uint64_t *ends = nullptr, *startUsed = nullptr;
 	uint32_t *cnt = nullptr;
@@ -136,7 +152,7 @@ int offsets_decode_device(const uint32_t *d_words, uint64_t nwords, uint64_t tot
 		bool fine = true;
 		for (int round = 0; round < 64 && fine; round++) { // (a round only repeats while some chunk's end still moves: 2-3 rounds)
 			fine = ok(hipMemsetAsync(changed, 0, sizeof(int), st));
-			hipLaunchKernelGGL(k_off_parse, dim3((unsigned)nchunks), dim3(64), 0, st, d_words, nwords, totalBits, nchunks, round, ends + (size_t)cur * nchunks,
+			hipLaunchKernelGGL(k_off_parse, dim3((unsigned)nchunks), dim3(64), 0, st, d_words, nwords, startBit, totalBits, nchunks, round, ends + (size_t)cur * nchunks,
 			                   ends + (size_t)(cur ^ 1) * nchunks, startUsed, cnt, gapsum, lanes, changed);
 			cur ^= 1;
 			int h = 0;
@@ -148,13 +164,29 @@ int offsets_decode_device(const uint32_t *d_words, uint64_t nwords, uint64_t tot
 			hipLaunchKernelGGL(k_off_scan, dim3(1), dim3(1024), 0, st, cnt, gapsum, nchunks, cntBase, sumBase, total);
 			int64_t h = -1;
 			if (ok(hipMemcpyAsync(&h, total, sizeof(int64_t), hipMemcpyDeviceToHost, st)) && ok(hipStreamSynchronize(st)) && h == nOut) {
-				hipLaunchKernelGGL(k_off_values, dim3((unsigned)nchunks), dim3(64), 0, st, d_words, nwords, nchunks, lanes, cntBase, sumBase, nOut, d_out);
+				hipLaunchKernelGGL((k_off_values<PREFIX, T>), dim3((unsigned)nchunks), dim3(64), 0, st, d_words, nwords, startBit, nchunks, lanes, cntBase, sumBase, nOut, d_out);
 				if (ok(hipStreamSynchronize(st))) rc = 0;
 			}
 		}
 	}
 	for (void *p : { (void *)ends, (void *)startUsed, (void *)cnt, (void *)gapsum, (void *)cntBase, (void *)sumBase, (void *)total, (void *)lanes, (void *)changed }) if (p) (void)hipFree(p);
 	return rc;
+}
+
+int offsets_decode_device(const uint32_t *d_words, uint64_t nwords, uint64_t totalBits, int32_t nodes, int64_t *d_out, hipStream_t st) {
+	return gamma_stream_decode<true, int64_t>(d_words, nwords, 0, totalBits, (int64_t)nodes + 1, d_out, st);
+}
+
+// labels of `count` consecutive arcs, stored in [startBit, endBit) of the .labels stream (GammaCodedIntLabel.java:60-64)
+int gamma_labels_decode_device(const uint32_t *d_words, uint64_t nwords, uint64_t startBit, uint64_t endBit, int64_t count, int32_t *d_out, hipStream_t st) {
+	return gamma_stream_decode<false, int32_t>(d_words, nwords, startBit, endBit, count, d_out, st);
+}
+
+int fixed_labels_decode_device(const uint32_t *d_words, uint64_t nwords, uint64_t startBit, int32_t width, int64_t count, int32_t *d_out, hipStream_t st) {
+	if (count <= 0) return 0;
+	if (width < 0 || width > 32) return -1;
+	hipLaunchKernelGGL(k_fixed_width, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, d_words, nwords, startBit, width, count, d_out);
+	return hipStreamSynchronize(st) == hipSuccess ? 0 : -1;
 }
 
 } // namespace bv

@@ -444,3 +444,32 @@ extern "C" int bvt_generate(int32_t n, int64_t m, uint64_t seed, double p_copy, 
 }
 
 extern "C" void bvt_free(void *p) { free(p); }
+
+// BitStreamArcLabelledImmutableGraph.store (labelling/BitStreamArcLabelledImmutableGraph.java:650-693): the labels of
+// all arcs in enumeration order as one bit stream, gamma(0) + gamma(bits of every node's list) as offsets, and the
+// three-line property file of saveProperties (:689-695).
+extern "C" int bvt_store_labels(const char *basename, const char *underlying, int32_t n, const int64_t *rowptr, const int32_t *labels,
+                                int kind, int width, const char *key) {
+	if (!basename || !underlying || n < 0 || !rowptr || (kind != 1 && kind != 2) || (kind == 2 && (width < 0 || width > 32))) return -EINVAL;
+	BitSink lab, offs;
+	offs.gamma(0);
+	for (int32_t x = 0; x < n; x++) {
+		const uint64_t before = lab.bits;
+		for (int64_t a = rowptr[x]; a < rowptr[x + 1]; a++) {
+			const uint32_t v = (uint32_t)labels[a];
+			if (kind == 1) { if (labels[a] < 0) return -EINVAL; lab.gamma(v); }            // GammaCodedIntLabel.java:74-76
+			else { if (width < 32 && (v >> width)) return -EINVAL; lab.put(v, width); }     // FixedWidthIntLabel.java:76-78
+		}
+		offs.gamma(lab.bits - before);
+	}
+	std::string base(basename);
+	if (!lab.write_file(base + ".labels") || !offs.write_file(base + ".labeloffsets")) return -EIO;
+	FILE *f = fopen((base + ".properties").c_str(), "w");
+	if (!f) return -EIO;
+	fprintf(f, "graphclass = it.unimi.dsi.webgraph.labelling.BitStreamArcLabelledImmutableGraph\n");
+	fprintf(f, "underlyinggraph = %s\n", underlying);
+	if (kind == 1) fprintf(f, "labelspec = it.unimi.dsi.webgraph.labelling.GammaCodedIntLabel(%s)\n", key ? key : "FOO");
+	else fprintf(f, "labelspec = it.unimi.dsi.webgraph.labelling.FixedWidthIntLabel(%s,%d)\n", key ? key : "FOO", width);
+	fclose(f);
+	return 0;
+}

@@ -82,3 +82,15 @@ def generate(n, m, seed=0x5EEDB5E70001, p_copy=0.5, threads=None):
         lib().bvt_free(rp)
         lib().bvt_free(sp)
     return rowptr, succ
+
+
+def store_labels(basename, underlying, rowptr, labels, kind="gamma", width=0, key="FOO"):
+    """BitStreamArcLabelledImmutableGraph.store for int labels given per arc in CSR order (include/bvgtools.h)."""
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+    labels = np.ascontiguousarray(labels, dtype=np.int32)
+    L = lib()
+    L.bvt_store_labels.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_char_p]
+    rc = L.bvt_store_labels(os.fsencode(basename), os.fsencode(underlying), rowptr.size - 1, rowptr.ctypes.data, labels.ctypes.data,
+                            1 if kind == "gamma" else 2, width, key.encode("ascii"))
+    if rc:
+        raise OSError(-rc, "bvt_store_labels failed: %s" % os.strerror(-rc))
