@@ -317,3 +317,34 @@ def test_long_rows_with_references(tmp_path_factory, monkeypatch, case):
     assert np.array_equal(rp, orp) and np.array_equal(sc, osc)
     assert g.hashCode() == og.hashcode()
     g.close()
+
+
+def test_empty_and_degenerate_graphs(tmp_path):
+    """Edge cases of the reference's own tests (ImmutableGraphTest / BVGraphTest use empty and tiny graphs): no nodes,
+    only empty rows, one full row, a single self-loop."""
+    from webgraph_amd import tools as T
+    from webgraph_amd.bvgraph import BVGraph
+    from oracle import oracle as O
+    cases = {
+        "nonodes": (np.array([0], dtype=np.int64), np.array([], dtype=np.int32)),
+        "allempty": (np.zeros(1001, dtype=np.int64), np.array([], dtype=np.int32)),
+        "selfloop": (np.array([0, 1], dtype=np.int64), np.array([0], dtype=np.int32)),
+        "onefullrow": (np.concatenate([[0], np.full(500, 500)]).astype(np.int64), np.arange(500, dtype=np.int32)),
+        "clique": (np.arange(65, dtype=np.int64) * 64, np.tile(np.arange(64, dtype=np.int32), 64)),  # 64 nodes, each -> all 64
+    }
+    for name, (rowptr, succ) in cases.items():
+        base = str(tmp_path / name)
+        T.store(base, rowptr, succ, window=7, max_ref_count=3, min_interval=4)
+        g = BVGraph.load(base)
+        n = rowptr.size - 1
+        assert g.numNodes() == n and g.numArcs() == succ.size
+        rp, sc = g.decode_range()
+        assert np.array_equal(rp, rowptr) and np.array_equal(sc, succ), name
+        if n:
+            og = O.OracleGraph.load(base)
+            assert g.hashCode() == og.hashcode()
+            q = np.array([0, n - 1], dtype=np.int32)
+            rp, sc = g.successors_batch(q)
+            orp, osc = og.successors_batch(q)
+            assert np.array_equal(rp, orp) and np.array_equal(sc, osc), name
+        g.close()
