@@ -420,53 +420,6 @@ __global__ void __launch_bounds__(TPB) k_decode_level(GraphDev g, RangeView v, c
 	}
 }
 
-// The same merge for the default codings when the whole record fits a 64-bit register (most rows of a web graph):
-// header and copy blocks are peeled off the register (no loads while walking the blocks), and the loads of the merge
-// run one element AHEAD of the stores -- gfx950 retires loads and stores in issue order through one counter, so a load
-// issued after a store waits for that store's round trip, one issued before it does not.
-__device__ __forceinline__ void copy_node_r64(const GraphDev &g, int32_t x, int32_t d, int64_t dref, int32_t *__restrict__ row, const int32_t *__restrict__ src, int *__restrict__ err) {
-	const uint64_t pos = (uint64_t)g.offsets[x];
-	const uint64_t w = pos >> 5;
-	const uint32_t sh = (uint32_t)pos & 31u;
-	const uint32_t w0 = __builtin_bswap32(g.bits[w]), w1 = __builtin_bswap32(g.bits[w + 1]), w2 = __builtin_bswap32(g.bits[w + 2]); // (the image ends with >= 8 zero words)
-	const uint64_t ab = ((uint64_t)w0 << 32) | w1;
-	Reg64 br{ sh ? (ab << sh) | ((uint64_t)w2 >> (32u - sh)) : ab, 0 };
-	(void)br.gamma();
-	(void)br.unary();
-	const uint32_t bc = br.gamma();
-	if (br.err || (uint64_t)bc > (uint64_t)dref + 1) return; // flagged by the parse kernel
-	Reg64 bb = br; // second walk: the merge
-	int64_t total = 0, copied64 = 0;
-	for (uint32_t b = 0; b < bc && !br.err; b++) {
-		const int64_t len = (int64_t)br.gamma() + (b ? 1 : 0);
-		total += len;
-		if (!(b & 1)) copied64 += len;
-	}
-	if (br.err || total > dref) return; // flagged by the parse kernel
-	if (!(bc & 1)) copied64 += dref - total;
-	if (copied64 > d) return;
-	int32_t i = 0, k = 0, j = (int32_t)copied64;
-	int32_t ev = j < d ? row[j] : 0, evN = j + 1 < d ? row[j + 1] : 0; // the next two extras
-	for (uint32_t b = 0; b <= bc; b++) {
-		int32_t len;
-		if (b < bc) len = (int32_t)bb.gamma() + (b ? 1 : 0);
-		else len = (int32_t)dref - i; // implicit last block: the rest of the referent
-		if (b & 1) { i += len; continue; } // skip block
-		if (len <= 0) continue;
-		int32_t cvN = src[i];
-		for (int32_t t = 0; t < len; t++) {
-			const int32_t cv = cvN;
-			i++;
-			if (t + 1 < len) cvN = src[i]; // next copied id: requested before this one is stored
-			while (j < d && ev < cv) { const int32_t e0 = ev; j++; ev = evN; evN = j + 1 < d ? row[j + 1] : 0; row[k++] = e0; }
-			if (j < d && ev == cv) { j++; ev = evN; evN = j + 1 < d ? row[j + 1] : 0; } // equal heads emitted once (never in a valid file)
-			row[k++] = cv;
-		}
-	}
-	// remaining extras row[j..d) are already in place when k == j; a malformed duplicate leaves a gap: pad with -1
-	if (k != j) { while (j < d) { row[k++] = row[j++]; } while (k < d) row[k++] = -1; }
-}
-
 // copy pass restricted to the giant list (their extras were written by k_parse_big)
 template <bool DEF>
 __global__ void __launch_bounds__(64) k_copy_giants(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ giantlist,
@@ -501,8 +454,7 @@ __global__ void __launch_bounds__(TPB) k_copy_list(GraphDev g, RangeView v, cons
 		const int32_t s = list[idx];
 		if (copy_class(v, depth, level, s, midMin, bigMin) != 1) continue;
 		const int32_t r = v.ref[s];
-		if (DEF && g.offsets[v.lo + s + 1] - g.offsets[v.lo + s] <= 64) copy_node_r64(g, v.lo + s, v.outd[s], (int64_t)v.outd[s - r], v.row(s), v.row(s - r), err);
-		else copy_node<DEF>(g, v.lo + s, v.outd[s], (int64_t)v.outd[s - r], v.row(s), v.row(s - r), err);
+		copy_node<DEF>(g, v.lo + s, v.outd[s], (int64_t)v.outd[s - r], v.row(s), v.row(s - r), err);
 	}
 }
 
@@ -807,11 +759,8 @@ __global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, con
 		if (d >= v.coop_min || d == 0) continue; // decoded by whole waves (k_parse_big) / nothing to decode
 		const int32_t r = v.ref[s];
 		if (s >= v.nh && (uint64_t)(v.rowstart[s + 1] - v.rowstart[v.nh]) > v.succ_cap) { atomicOr(err, E_CAP); continue; }
-		if (DEF) {
-			// records of at most 64 bits (work bin 0 and a few more) never leave a register
-			if (g.offsets[v.lo + s + 1] - g.offsets[v.lo + s] <= 64) parse_node_r64(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), err);
-			else parse_node_lw(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), lw, err);
-		} else parse_node<DEF>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), err);
+		if (DEF) parse_node_lw(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), lw, err);
+		else parse_node<DEF>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), err);
 	}
 }
 

@@ -182,98 +182,4 @@ __device__ __forceinline__ void parse_node_lw(const GraphDev &g, int32_t x, int3
 	if (e) atomicOr(err, e);
 }
 
-// ---- records of at most 64 bits (two thirds of the records of a web graph): the whole record sits in one 64-bit
-// register, codes are peeled off its top with shifts -- no window, no refills.  Same contract as parse_node_lw.
-struct Reg64 {
-	uint64_t h; // the stream from the cursor on, first bit in bit 63; zeros shift in behind the record
-	int err;
-	__device__ __forceinline__ uint32_t gamma() {
-		if (h == 0) { err |= E_FORMAT; return 0; }
-		const uint32_t m = (uint32_t)__clzll((long long)h);
-		if (m > 31) { err |= E_FORMAT; h = 0; return 0; }
-		const uint32_t v = (uint32_t)(((h << m) >> (63u - m)) - 1);
-		h <<= 2 * m + 1;
-		return v;
-	}
-	__device__ __forceinline__ uint32_t unary() {
-		if (h == 0) { err |= E_FORMAT; return 0; }
-		const uint32_t z = (uint32_t)__clzll((long long)h);
-		h = z >= 63 ? 0 : h << (z + 1);
-		return z;
-	}
-	__device__ __forceinline__ uint64_t zeta3() {
-		uint64_t v; uint32_t len;
-		if (!fast_zeta3(h, v, len)) { err |= E_FORMAT; h = 0; return 0; }
-		h = len >= 64 ? 0 : h << len;
-		return v;
-	}
-};
-
-__device__ __forceinline__ void parse_node_r64(const GraphDev &g, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row, int *__restrict__ err) {
-	const uint64_t pos = (uint64_t)g.offsets[x];
-	const uint64_t w = pos >> 5;
-	const uint32_t sh = (uint32_t)pos & 31u;
-	const uint32_t w0 = __builtin_bswap32(g.bits[w]), w1 = __builtin_bswap32(g.bits[w + 1]), w2 = __builtin_bswap32(g.bits[w + 2]); // (the image ends with >= 8 zero words)
-	const uint64_t ab = ((uint64_t)w0 << 32) | w1;
-	Reg64 br{ sh ? (ab << sh) | ((uint64_t)w2 >> (32u - sh)) : ab, 0 };
-	(void)br.gamma();              // outdegree (known from k_headers)
-	if (g.W > 0) (void)br.unary(); // reference
-	int32_t copied = 0;
-	if (hasRef) { // BVG:1058-1071
-		const uint32_t bc = br.gamma();
-		int64_t total = 0;
-		if ((uint64_t)bc > (uint64_t)dref + 1) br.err |= E_FORMAT;
-		else {
-			for (uint32_t b = 0; b < bc && !br.err; b++) {
-				const int64_t len = (int64_t)br.gamma() + (b ? 1 : 0);
-				total += len;
-				if (!(b & 1)) copied += (int32_t)len;
-			}
-			if (total > dref) br.err |= E_FORMAT;
-			else if (!(bc & 1)) copied += (int32_t)(dref - total);
-		}
-	}
-	const int32_t nExtra = d - copied;
-	if (nExtra < 0 || copied < 0 || br.err) { atomicOr(err, E_FORMAT | br.err); return; }
-	if (nExtra == 0) return;
-	int32_t ivTodo = 0, intervalArcs = 0;
-	Reg64 bi{ 0, 0 }; // second cursor over the interval section
-	if (g.minInt != 0) { // BVG:1073-1096
-		ivTodo = (int32_t)br.gamma();
-		if (ivTodo > nExtra || br.err) { atomicOr(err, E_FORMAT); return; }
-		bi.h = br.h;
-		for (int32_t i = 0; i < ivTodo && !br.err; i++) {
-			(void)br.gamma();
-			intervalArcs += (int32_t)br.gamma() + g.minInt;
-			if (intervalArcs > nExtra) br.err |= E_FORMAT;
-		}
-	}
-	int32_t resTodo = nExtra - intervalArcs;
-	if (resTodo < 0 || br.err) { atomicOr(err, E_FORMAT | br.err); return; }
-	// merge(intervals, residuals) -> row[copied ..): at most 64 ids (a codeword is at least one bit), plain stores
-	int32_t *out = row + copied;
-	int32_t ivLeft = 0, ivRem = 0, ivPrev = 0;
-	bool firstIv = true;
-	int32_t resVal = 0;
-	if (resTodo) resVal = (int32_t)((int64_t)x + nat2int(br.zeta3())); // BVG:954
-	for (int32_t k = 0; k < nExtra; k++) {
-		if (ivRem == 0 && ivTodo) { // BVG:1084-1093
-			if (firstIv) { ivLeft = (int32_t)((int64_t)x + nat2int((uint64_t)bi.gamma())); firstIv = false; }
-			else ivLeft = ivPrev + (int32_t)bi.gamma() + 1;
-			ivRem = (int32_t)bi.gamma() + g.minInt;
-			ivPrev = ivLeft + ivRem;
-			ivTodo--;
-		}
-		int32_t val;
-		if (ivRem && (!resTodo || ivLeft < resVal)) { val = ivLeft; ivLeft++; ivRem--; }
-		else if (resTodo) {
-			val = resVal;
-			if (ivRem && ivLeft == resVal) { ivLeft++; ivRem--; } // equal heads are emitted once (MergedIntIterator.java:69-72)
-			if (--resTodo) resVal += (int32_t)br.zeta3() + 1; // BVG:966
-		} else val = -1; // malformed: fewer values than the outdegree promises (BVG:1210 would store -1)
-		out[k] = val;
-	}
-	if (br.err | bi.err) atomicOr(err, br.err | bi.err);
-}
-
 } // namespace bv
