@@ -215,23 +215,24 @@ def main():
     info = g.info
     graph_bytes = int(info.graph_bytes)
     b_alg = graph_bytes + 8 * (n + 1) + 4 * m + 8 * (n + 1)
-    kernel_of = {"headers": "k_headers", "scan": "k_scan_*", "lists": "k_depth_keys+k_scatter_keys", "parse_long": "k_parse_big<1>+k_parse_big<8>",
+    kernel_of = {"headers": "k_headers", "scan": "k_scan_*", "lists": "k_depth_keys+k_scatter_keys", "parse_giant": "k_parse_big<8>", "parse_big": "k_parse_big<1>",
                  "parse_short": "k_parse_list", "copy": "k_copy_list+k_copy_mid+k_copy_big", "tail": "k_rebase"}
     # The dominant kernel is priced on the units IT processes (bits/8 + 4 B per successor
     # + 16 B per node of offsets and rowptr), not on the whole scan: the two parse kernels split the records by
     # outdegree at the library's BVGPU_COOP_MIN threshold (default 2048).
     coop_min = int(os.environ.get("BVGPU_COOP_MIN", "2048"))
+    giant_min = max(coop_min, int(os.environ.get("BVGPU_GIANT_MIN", "32768")))
     with open(base + ".offsets", "rb") as f:
         from webgraph_amd.bvgraph import decode_offsets_host
         offs = decode_offsets_host(f.read(), n, 2 if "OFFSETS_DELTA" not in open(base + ".properties").read() else 1)
     import numpy as np
     deg = (rowptr[1:] - rowptr[:-1]).cpu().numpy()
     bits = np.diff(np.asarray(offs, dtype=np.int64))
-    is_long = deg >= coop_min
+    masks = {"parse_giant": deg >= giant_min, "parse_big": (deg >= coop_min) & (deg < giant_min), "parse_short": (deg < coop_min) & (deg > 0)}
     def alg_bytes(mask):
         return float(bits[mask].sum()) / 8.0 + 4.0 * float(deg[mask].sum()) + 16.0 * float(mask.sum())
-    units = {"parse_long": alg_bytes(is_long), "parse_short": alg_bytes(~is_long & (deg > 0))}
-    dom_phase = max(("parse_long", "parse_short"), key=lambda k: phases.get(k, 0.0))
+    units = {k: alg_bytes(mk) for k, mk in masks.items()}
+    dom_phase = max(masks, key=lambda k: phases.get(k, 0.0))
     dom = kernel_of[dom_phase]
     dom_ms = phases[dom_phase]
     dom_bytes = units[dom_phase]
@@ -257,8 +258,9 @@ def main():
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel_algorithmic_bytes": dom_bytes, "kernel_ms": dom_ms,
-                     "kernel_units": "records with outdegree %s %d: %d nodes, %d successors" % (">=" if dom_phase == "parse_long" else "<", coop_min,
-                                     int((is_long if dom_phase == "parse_long" else (~is_long & (deg > 0))).sum()), int(deg[is_long if dom_phase == "parse_long" else ~is_long].sum())),
+                     "kernel_units": "%s: %d records, %d successors" % ({"parse_giant": "outdegree >= %d" % giant_min, "parse_big": "%d <= outdegree < %d" % (coop_min, giant_min),
+                                                                          "parse_short": "0 < outdegree < %d" % coop_min}[dom_phase],
+                                                                         int(masks[dom_phase].sum()), int(deg[masks[dom_phase]].sum())),
                      "algorithmic_bytes_per_scan": b_alg, "bytes_per_edge": b_alg / max(m, 1), "serial_phase_ms_sum": scan_ms,
                      "scan_achieved": b_alg / (dev_ms / args.steps * 1e-3) / 1e9,
                      "scan_frac": b_alg / (dev_ms / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS},

@@ -95,9 +95,10 @@ int bvg_sync(bvg_t *g, uint64_t *arcs_out);
 
 /* Phases of one bvg_decode_range, in stream order (HIP events are recorded between them when profiling is on;
  * the three parse kernels, which normally overlap on forked streams, then run one after the other):
- * headers(+halo closure) | scan | chain depth + work lists | parse of long records (cooperative kernels) |
- * parse of short records (one lane per record) | copy levels | rowptr rebase + totals */
-#define BVG_NUM_PHASES 7
+ * headers(+halo closure) | scan | chain depth + work lists | parse of giant records (a group of waves each) |
+ * parse of big records (a wave each) | parse of short records (one lane per record) | copy levels |
+ * rowptr rebase + totals */
+#define BVG_NUM_PHASES 8
 /* Enables / disables per-phase HIP-event timing on this handle (off by default; costs a few event records). */
 int bvg_set_profile(bvg_t *g, int enable);
 /* Milliseconds of each phase of the last range decode issued with profiling on; ms has BVG_NUM_PHASES floats. */

@@ -336,7 +336,7 @@ class BVGraph:
     def set_stream(self, hip_stream):
         self._check(lib().bvg_set_stream(self._h, hip_stream))
 
-    PHASES = ("headers", "scan", "lists", "parse_long", "parse_short", "copy", "tail")
+    PHASES = ("headers", "scan", "lists", "parse_giant", "parse_big", "parse_short", "copy", "tail")
 
     def set_profile(self, on):
         self._check(lib().bvg_set_profile(self._h, 1 if on else 0))

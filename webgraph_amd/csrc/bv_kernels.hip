@@ -1202,6 +1202,12 @@ void launch_parse_giants(const GraphDev &g, bool def, const RangeView &v, const 
 	else hipLaunchKernelGGL((k_parse_big<false, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, st, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
 }
 
+void launch_parse_waves(const GraphDev &g, bool def, const RangeView &v, const int32_t *biglist, int32_t *ctl, void *arena, int64_t arenaCap, int waves, int *err, hipStream_t st) {
+	if (v.cnt <= 0) return;
+	if (def) hipLaunchKernelGGL((k_parse_big<true, 1, RangeView>), dim3(waves), dim3(64), 0, st, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
+	else hipLaunchKernelGGL((k_parse_big<false, 1, RangeView>), dim3(waves), dim3(64), 0, st, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
+}
+
 // One chain level of the copy pass: three kernels, one per row class.  With side streams they run next to each
 // other (evFork forks, evMid / evBig join back into st); with stMid == stBig == st they run one after the other.
 // class thresholds of the copy pass (shared by the queue builder and the level kernels)

@@ -66,6 +66,7 @@ void launch_copy_level(const GraphDev &g, bool def, const RangeView &v, const in
                        int32_t midMinKnob, bool bigGroups, const int32_t *bigQ, int32_t bigCap, const int32_t *midQ, int32_t midCap, const int32_t *ctl, int *err,
                        hipStream_t st, hipStream_t stMid, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evMid, hipEvent_t evBig);
 void launch_parse_list(const GraphDev &g, bool def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st);
+void launch_parse_waves(const GraphDev &g, bool def, const RangeView &v, const int32_t *biglist, int32_t *ctl, void *arena, int64_t arenaCap, int waves, int *err, hipStream_t st);
 void launch_parse_giants(const GraphDev &g, bool def, const RangeView &v, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap, int giantGroups, int *err, hipStream_t st);
 void launch_hash(int32_t from, int32_t cnt, const int64_t *rowptr, const int32_t *succ, uint32_t *A, uint32_t *B, int32_t *hash, hipStream_t st);
 

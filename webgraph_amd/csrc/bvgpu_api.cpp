@@ -378,8 +378,10 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 		}
 		if (coop && !ovl) bv::launch_classify(v.cnt, v.outd, g->coop_min, g->giant_min, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, g->stream);
 		mark(g, 3);
-		if (coop && !ovl) bv::launch_parse_big(gd, s.def, v, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, g->giant_groups, derr, g->stream, g->stream);
+		if (coop && !ovl) bv::launch_parse_giants(gd, s.def, v, g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->giant_groups, derr, g->stream);
 		mark(g, 4);
+		if (coop && !ovl) bv::launch_parse_waves(gd, s.def, v, g->biglist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, derr, g->stream);
+		mark(g, 5);
 		if (pKeyBase) {
 			bv::launch_parse_list(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, g->level_blocks, derr, g->stream);
 		}
@@ -388,7 +390,7 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 			HIPCHK(g, hipStreamWaitEvent(g->stream, g->evA, 0));
 			if (coop) HIPCHK(g, hipStreamWaitEvent(g->stream, g->evB, 0));
 		}
-		mark(g, 5);
+		mark(g, 6);
 		if (W > 0) {
 			levels = g->levels_hint;
 			for (int32_t l = 1; l <= levels; l++) {
@@ -425,6 +427,7 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 		if (g->overlap) HIPCHK(g, hipStreamWaitEvent(g->stream, g->evA, 0));
 		mark(g, 4);
 		mark(g, 5);
+		mark(g, 6);
 		if (W > 0) {
 			levels = g->levels_hint;
 			for (int32_t l = 1; l <= levels; l++) {
@@ -433,11 +436,11 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 			}
 		}
 	}
-	if (!succ_dev) { mark(g, 3); mark(g, 4); mark(g, 5); }
-	mark(g, 6);
+	if (!succ_dev) { mark(g, 3); mark(g, 4); mark(g, 5); mark(g, 6); }
+	mark(g, 7);
 	bv::launch_rebase(v.nh, v.cnt, v.rowstart, rowptr_dev, g->stream);
 	hipLaunchKernelGGL(k_totals, dim3(1), dim3(1), 0, g->stream, v.rowstart, v.nh, v.cnt, g->small.as<Small>());
-	mark(g, 7);
+	mark(g, 8);
 	g->ev_valid = g->profile;
 	{ int rc = join_to_user(g); if (rc) return rc; }
 	HIPCHK(g, hipGetLastError());
