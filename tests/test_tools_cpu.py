@@ -65,8 +65,11 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(B.EXPORTS)
     import ctypes
     T = ctypes.CDLL(os.path.join(os.path.dirname(B.__file__), "libbvgtools.so"))
-    for name in ("bvt_store", "bvt_generate", "bvt_free"):
-        assert hasattr(T, name)
+    thdr = open(os.path.join(os.path.dirname(CNR), "..", "..", "include", "bvgtools.h")).read()
+    tdecl = set(re.findall(r"\b(bvt_[a-z_]+)\s*\(", thdr))
+    assert {"bvt_store", "bvt_generate", "bvt_free", "bvt_store_labels"} <= tdecl
+    for name in tdecl:
+        assert hasattr(T, name), name
 
 
 def test_no_gpu_means_loud_failure():
