@@ -535,8 +535,8 @@ __global__ void __launch_bounds__(64 * COPY_MID_WAVES) k_copy_mid(GraphDev g, Ra
 // does, including the implicit last block, and returns the totals.  Called by the 64 lanes of wave 0 only.
 constexpr int COPY_BIG_THREADS = 1024, COPY_BIG_CAP = 6144, COPY_BIG_ITEMS = 8;
 constexpr int COPY_COOP_WALK_MIN = 192; // below this many blocks the serial walk is as fast
-__device__ __forceinline__ void coop_block_walk(const GraphDev &g, uint64_t pos, uint64_t recEnd, int64_t bc, int64_t dref, int32_t d, int32_t *kend, int32_t *delta, uint32_t *lds,
-                                                int64_t &totalOut, int64_t &copiedOut, int32_t &nKeptOut, int &bad) {
+__device__ __forceinline__ void coop_block_walk(const GraphDev &g, uint64_t pos, uint64_t recEnd, int64_t bc, int64_t dref, int32_t d, int32_t *kend, int32_t *delta, int32_t tabCap,
+                                                uint32_t *lds, int64_t &totalOut, int64_t &copiedOut, int32_t &nKeptOut, int &bad) {
 	Grp<1> G{ (int64_t *)(lds + CoopLds<1>::OFF_XCH) };
 	const uint32_t B = coop_pick_B(min<uint64_t>(recEnd > pos ? recEnd - pos : 0, (uint64_t)bc * 8), (uint64_t)bc, 64, CoopCfg<1>::B_MAX);
 	int64_t done = 0, total = 0, copied = 0; // uniform
@@ -577,7 +577,7 @@ __device__ __forceinline__ void coop_block_walk(const GraphDev &g, uint64_t pos,
 				const int64_t len = (int64_t)win_code_rel<true, 1>(g, src, p, e2) + (q ? 1 : 0);
 				if (!(q & 1)) {
 					const int64_t j = q >> 1;
-					if (j <= COPY_BIG_CAP) { kend[j] = (int32_t)min<int64_t>(cp + len, 0x7fffffff); delta[j] = (int32_t)(t - cp); }
+					if (j < tabCap) { kend[j] = (int32_t)min<int64_t>(cp + len, 0x7fffffff); delta[j] = (int32_t)(t - cp); }
 					cp += len;
 				}
 				t += len;
@@ -597,7 +597,7 @@ __device__ __forceinline__ void coop_block_walk(const GraphDev &g, uint64_t pos,
 	if (rest < 0) { bad = 1; return; }
 	if (!(bc & 1)) {
 		const int64_t j = bc >> 1;
-		if (j <= COPY_BIG_CAP && threadIdx.x == 0) { kend[j] = (int32_t)min<int64_t>(copied + rest, 0x7fffffff); delta[j] = (int32_t)(total - copied); }
+		if (j < tabCap && threadIdx.x == 0) { kend[j] = (int32_t)min<int64_t>(copied + rest, 0x7fffffff); delta[j] = (int32_t)(total - copied); }
 		copied += rest;
 	}
 	total += rest;
@@ -617,13 +617,13 @@ __device__ __forceinline__ void coop_block_walk(const GraphDev &g, uint64_t pos,
 // fall back to one lane.
 template <bool DEF>
 __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ queue,
-                                                               const int32_t *__restrict__ count, int32_t cap, int32_t level, int *__restrict__ err) {
+                                                               const int32_t *__restrict__ count, int32_t cap, int32_t level, int32_t *__restrict__ tmp, uint32_t tmpCap,
+                                                               uint32_t *__restrict__ tmpCursor, int *__restrict__ err) {
 	__shared__ int32_t cval[COPY_BIG_CAP], cpos[COPY_BIG_CAP + 1], delta[COPY_BIG_CAP + 1];
 	__shared__ uint32_t lwin[DEF ? LW_MAIN * LW_STRIDE : 1]; // stream window of the wave that walks the block list
 	__shared__ __attribute__((aligned(16))) uint32_t cwin[DEF ? CoopLds<1>::WORDS : 4]; // tile of the cooperative walk of a long block list
-	__shared__ int64_t s_copied;
+	__shared__ int64_t s_copied, s_tmp;
 	__shared__ int32_t s_kept, s_bad;
-	int32_t *kend = cpos; // during the gather: ids copied up to the end of the j-th copied block
 	// the queue holds the long rows of ALL levels (a few hundred): a group takes the entries of this level among its share
 	const int32_t nq = min(*count, cap);
 	for (int32_t qi = blockIdx.x; qi < nq; qi += gridDim.x) {
@@ -633,110 +633,129 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 		const int64_t dref = v.outd[s - r];
 		int32_t *row = v.row(s);
 		const int32_t *src = v.row(s - r);
-		__syncthreads(); // the LDS tables of the previous row are free
 		unsigned long long tk = (g.stats && (g.dbg & 16)) ? __builtin_readcyclecounter() : 0;
 #define CT(slot) do { if (g.stats && (g.dbg & 16)) { const unsigned long long now_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g.stats[24 + slot], now_ - tk); tk = now_; } } while (0)
 		// header + blocks, by the first wave only (sixteen waves walking the list side by side would only slow each
-		// other down); default codings read through a lane window in LDS with the short-code decoders
-		if (threadIdx.x < 64) {
-			int64_t total = 0, copied = 0;
-			int32_t nKept = 0;
-			int bad = 0;
-			auto walk = [&](auto &&next_gamma, uint64_t bc) {
-				if (bc > (uint64_t)dref + 1) { bad = 1; return; } // flagged by the parse kernel
-				for (uint64_t b = 0; b <= bc; b++) {
-					int64_t len;
-					if (b < bc) len = (int64_t)next_gamma() + (b ? 1 : 0);
-					else len = dref - total; // implicit last block (copied when the block count is even)
-					if (len < 0 || total + len > dref) { bad = 1; break; }
-					if (!(b & 1)) {
-						if (nKept <= COPY_BIG_CAP && (int32_t)threadIdx.x == (nKept & 63)) { kend[nKept] = (int32_t)min<int64_t>(copied + len, 0x7fffffff); delta[nKept] = (int32_t)(total - copied); }
-						nKept++;
-						copied += len;
+		// other down); default codings read through a lane window in LDS with the short-code decoders.  Fills the
+		// tables (kend, delta) up to tabCap entries and publishes (copied, number of copied blocks, bad).
+		auto walk_row = [&](int32_t *kend, int32_t *dlt, int32_t tabCap) {
+			__syncthreads(); // the tables are free
+			if (threadIdx.x < 64) {
+				int64_t total = 0, copied = 0;
+				int32_t nKept = 0;
+				int bad = 0;
+				auto walk = [&](auto &&next_gamma, uint64_t bc) {
+					if (bc > (uint64_t)dref + 1) { bad = 1; return; } // flagged by the parse kernel
+					for (uint64_t b = 0; b <= bc; b++) {
+						int64_t len;
+						if (b < bc) len = (int64_t)next_gamma() + (b ? 1 : 0);
+						else len = dref - total; // implicit last block (copied when the block count is even)
+						if (len < 0 || total + len > dref) { bad = 1; break; }
+						if (!(b & 1)) {
+							if (nKept < tabCap && (int32_t)threadIdx.x == (nKept & 63)) { kend[nKept] = (int32_t)min<int64_t>(copied + len, 0x7fffffff); dlt[nKept] = (int32_t)(total - copied); }
+							nKept++;
+							copied += len;
+						}
+						total += len;
 					}
-					total += len;
+				};
+				if (DEF) {
+					LaneWin<LW_MAIN> lw;
+					lw.col = lwin + threadIdx.x;
+					lw.vlast = min((((uint64_t)g.offsets[v.lo + s + 1] >> 5) + 2) & ~(uint64_t)3, (g.nwords + 4) & ~(uint64_t)3);
+					lw.seek(g, (uint64_t)g.offsets[v.lo + s]);
+					int e = 0;
+					(void)lw.template code<1>(g, e);
+					(void)lw.template code<2>(g, e);
+					const uint64_t bc = lw.template code<1>(g, e);
+					if (bc >= COPY_COOP_WALK_MIN && bc <= (uint64_t)dref + 1 && !e)
+						coop_block_walk(g, lw.pos(), (uint64_t)g.offsets[v.lo + s + 1], (int64_t)bc, dref, d, kend, dlt, tabCap, cwin, total, copied, nKept, bad);
+					else walk([&] { return lw.template code<1>(g, e); }, bc);
+					bad |= e;
+				} else {
+					BitReader br;
+					br.init(g.bits, g.nwords);
+					br.seek((uint64_t)g.offsets[v.lo + s]);
+					(void)Fields<DEF>::outdegree(br, g);
+					(void)Fields<DEF>::reference(br, g);
+					const uint64_t bc = Fields<DEF>::block_count(br, g);
+					walk([&] { return Fields<DEF>::block(br, g); }, bc);
+					bad |= br.err;
 				}
-			};
-			if (DEF) {
-				LaneWin<LW_MAIN> lw;
-				lw.col = lwin + threadIdx.x;
-				lw.vlast = min((((uint64_t)g.offsets[v.lo + s + 1] >> 5) + 2) & ~(uint64_t)3, (g.nwords + 4) & ~(uint64_t)3);
-				lw.seek(g, (uint64_t)g.offsets[v.lo + s]);
-				int e = 0;
-				(void)lw.template code<1>(g, e);
-				(void)lw.template code<2>(g, e);
-				const uint64_t bc = lw.template code<1>(g, e);
-				if (bc >= COPY_COOP_WALK_MIN && bc <= (uint64_t)dref + 1 && !e)
-					coop_block_walk(g, lw.pos(), (uint64_t)g.offsets[v.lo + s + 1], (int64_t)bc, dref, d, kend, delta, cwin, total, copied, nKept, bad);
-				else walk([&] { return lw.template code<1>(g, e); }, bc);
-				bad |= e;
-			} else {
-				BitReader br;
-				br.init(g.bits, g.nwords);
-				br.seek((uint64_t)g.offsets[v.lo + s]);
-				(void)Fields<DEF>::outdegree(br, g);
-				(void)Fields<DEF>::reference(br, g);
-				const uint64_t bc = Fields<DEF>::block_count(br, g);
-				walk([&] { return Fields<DEF>::block(br, g); }, bc);
-				bad |= br.err;
+				if (threadIdx.x == 0) { s_copied = copied; s_kept = nKept; s_bad = bad; }
 			}
-			if (threadIdx.x == 0) { s_copied = copied; s_kept = nKept; s_bad = bad; }
-		}
-		__syncthreads();
+			__syncthreads();
+		};
+		// The merge proper, on tables that live in LDS (the usual case) or in global scratch (rows copying more ids
+		// than the LDS tables hold): gather the copied ids, rank them among the extras (still at row[nc..d)), move the
+		// extras left chunk by chunk, drop the copied ids into the gaps.  kpos doubles as kend during the gather.
+		auto merge_row = [&](const int32_t *kend, const int32_t *dlt, int32_t *cv_, int32_t *cp_, int32_t nc, int32_t nKept) {
+			const int32_t nExtra = d - nc;
+			for (int32_t t = threadIdx.x; t < nc; t += COPY_BIG_THREADS) {
+				int32_t lo = 0, hi = nKept; // first copied block with kend > t (a block of length 0 is possible only in first position)
+				while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (kend[mid] <= t) lo = mid + 1; else hi = mid; }
+				cv_[t] = src[t + dlt[lo]];
+			}
+			__syncthreads();
+			CT(1);
+			for (int32_t t = threadIdx.x; t < nc; t += COPY_BIG_THREADS) {
+				const int32_t cv = cv_[t];
+				int32_t lo = 0, hi = nExtra;
+				while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (row[nc + mid] < cv) lo = mid + 1; else hi = mid; }
+				cp_[t] = t + lo;
+			}
+			__syncthreads();
+			CT(2);
+			// extras up to the one following the last copied id move; the rest stay where they are
+			const int32_t nMove = cp_[nc - 1] - (nc - 1);
+			constexpr int32_t CHUNK = COPY_BIG_THREADS * COPY_BIG_ITEMS;
+			int32_t cur[COPY_BIG_ITEMS], nxt[COPY_BIG_ITEMS];
+#pragma unroll
+			for (int u = 0; u < COPY_BIG_ITEMS; u++) { const int32_t e = u * COPY_BIG_THREADS + (int32_t)threadIdx.x; nxt[u] = e < nMove ? row[nc + e] : 0; }
+			for (int32_t e0 = 0; e0 < nMove; e0 += CHUNK) {
+#pragma unroll
+				for (int u = 0; u < COPY_BIG_ITEMS; u++) cur[u] = nxt[u];
+				__syncthreads(); // every extra up to the end of this chunk has been read
+#pragma unroll
+				for (int u = 0; u < COPY_BIG_ITEMS; u++) { const int32_t e = e0 + CHUNK + u * COPY_BIG_THREADS + (int32_t)threadIdx.x; nxt[u] = e < nMove ? row[nc + e] : 0; }
+#pragma unroll
+				for (int u = 0; u < COPY_BIG_ITEMS; u++) {
+					const int32_t e = e0 + u * COPY_BIG_THREADS + (int32_t)threadIdx.x;
+					if (e < nMove) {
+						int32_t lo = 0, hi = nc; // copied ids smaller than this extra
+						while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (cv_[mid] < cur[u]) lo = mid + 1; else hi = mid; }
+						if (lo < nc) row[e + lo] = cur[u];
+					}
+				}
+			}
+			__syncthreads(); // all extras are in place
+			CT(3);
+			for (int32_t t = threadIdx.x; t < nc; t += COPY_BIG_THREADS) row[cp_[t]] = cv_[t];
+			CT(4);
+		};
+		walk_row(cpos, delta, COPY_BIG_CAP + 1);
 		const int64_t copied = s_copied;
 		const int32_t nKept = s_kept;
 		if (s_bad || copied > d || copied == 0) continue; // malformed (flagged by the parse kernel) / nothing to merge: the extras already fill the row
 		if (g.stats && threadIdx.x == 0) { stat_add(g, 8, 1); stat_add(g, 9, (unsigned long long)nKept); stat_max(g, 15, (unsigned long long)nKept); stat_add(g, 4, (unsigned long long)d); }
-		if (copied > COPY_BIG_CAP) { // too many copied ids for the LDS tables: one lane does it
+		CT(0);
+		if (copied <= COPY_BIG_CAP && nKept <= COPY_BIG_CAP + 1) { merge_row(cpos, delta, cval, cpos, (int32_t)copied, nKept); continue; }
+		// More copied ids than the LDS tables hold (a long row copying most of a long referent): the same merge on
+		// tables in global scratch, taken from a bump allocator; if that is exhausted, one lane does the row.
+		const uint64_t need = 2ull * (uint64_t)nKept + 2ull * (uint64_t)copied;
+		if (threadIdx.x == 0) {
+			s_tmp = -1;
+			if (tmp && need <= tmpCap) { const uint32_t o = atomicAdd(tmpCursor, (uint32_t)need); if ((uint64_t)o + need <= tmpCap) s_tmp = o; }
+		}
+		__syncthreads();
+		if (s_tmp < 0) {
 			if (threadIdx.x == 0) copy_node<DEF>(g, v.lo + s, d, dref, row, src, err);
 			continue;
 		}
-		__syncthreads();
-		CT(0);
-		// gather the copied ids (a block of length 0 is possible only in first position, so nKept <= copied + 1)
-		const int32_t nc = (int32_t)copied, nExtra = d - nc;
-		for (int32_t t = threadIdx.x; t < nc; t += COPY_BIG_THREADS) {
-			int32_t lo = 0, hi = nKept; // first copied block with kend > t
-			while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (kend[mid] <= t) lo = mid + 1; else hi = mid; }
-			cval[t] = src[t + delta[lo]];
-		}
-		__syncthreads();
-		CT(1);
-		// rank of every copied id among the extras (still at row[copied .. d))
-		for (int32_t t = threadIdx.x; t < nc; t += COPY_BIG_THREADS) {
-			const int32_t cv = cval[t];
-			int32_t lo = 0, hi = nExtra;
-			while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (row[nc + mid] < cv) lo = mid + 1; else hi = mid; }
-			cpos[t] = t + lo;
-		}
-		__syncthreads();
-		CT(2);
-		// extras up to the one following the last copied id move; the rest stay where they are
-		const int32_t nMove = cpos[nc - 1] - (nc - 1);
-		constexpr int32_t CHUNK = COPY_BIG_THREADS * COPY_BIG_ITEMS;
-		int32_t cur[COPY_BIG_ITEMS], nxt[COPY_BIG_ITEMS];
-#pragma unroll
-		for (int u = 0; u < COPY_BIG_ITEMS; u++) { const int32_t e = u * COPY_BIG_THREADS + (int32_t)threadIdx.x; nxt[u] = e < nMove ? row[nc + e] : 0; }
-		for (int32_t e0 = 0; e0 < nMove; e0 += CHUNK) {
-#pragma unroll
-			for (int u = 0; u < COPY_BIG_ITEMS; u++) cur[u] = nxt[u];
-			__syncthreads(); // every extra up to the end of this chunk has been read
-#pragma unroll
-			for (int u = 0; u < COPY_BIG_ITEMS; u++) { const int32_t e = e0 + CHUNK + u * COPY_BIG_THREADS + (int32_t)threadIdx.x; nxt[u] = e < nMove ? row[nc + e] : 0; }
-#pragma unroll
-			for (int u = 0; u < COPY_BIG_ITEMS; u++) {
-				const int32_t e = e0 + u * COPY_BIG_THREADS + (int32_t)threadIdx.x;
-				if (e < nMove) {
-					int32_t lo = 0, hi = nc; // copied ids smaller than this extra
-					while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (cval[mid] < cur[u]) lo = mid + 1; else hi = mid; }
-					if (lo < nc) row[e + lo] = cur[u];
-				}
-			}
-		}
-		__syncthreads(); // all extras are in place
-		CT(3);
-		for (int32_t t = threadIdx.x; t < nc; t += COPY_BIG_THREADS) row[cpos[t]] = cval[t];
-		CT(4);
+		int32_t *gk = tmp + s_tmp, *gd = gk + nKept, *gv = gd + nKept, *gp = gv + copied;
+		walk_row(gk, gd, nKept);
+		if (s_bad || s_copied != copied || s_kept != nKept) continue; // (cannot differ: same stream)
+		merge_row(gk, gd, gv, gp, (int32_t)copied, nKept);
 #undef CT
 	}
 }
@@ -1216,7 +1235,7 @@ void copy_thresholds(int32_t midMinKnob, bool bigGroups, int32_t &midMin, int32_
 	midMin = (midMinKnob <= 0 || midMinKnob > bigMin || !bigGroups) ? bigMin : midMinKnob; // = bigMin: no wave-per-row class
 }
 void launch_copy_level(const GraphDev &g, bool def, const RangeView &v, const int32_t *depth, const int32_t *list, const int32_t *keyBase, int32_t level, int blocks,
-                       int32_t midMinKnob, bool bigGroups, const int32_t *bigQ, int32_t bigCap, const int32_t *midQ, int32_t midCap, const int32_t *ctl, int *err,
+                       int32_t midMinKnob, bool bigGroups, const int32_t *bigQ, int32_t bigCap, const int32_t *midQ, int32_t midCap, int32_t *ctl, int32_t *tmp, uint32_t tmpCap, int *err,
                        hipStream_t st, hipStream_t stMid, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evMid, hipEvent_t evBig) {
 	if (v.cnt <= 0) return;
 	int32_t midMin, bigMin;
@@ -1228,8 +1247,8 @@ void launch_copy_level(const GraphDev &g, bool def, const RangeView &v, const in
 		if (stBig != st) (void)hipStreamWaitEvent(stBig, evFork, 0);
 	}
 	if (bigGroups) {
-		if (def) hipLaunchKernelGGL(k_copy_big<true>, dim3(512), dim3(COPY_BIG_THREADS), 0, stBig, g, v, depth, bigQ, ctl + 5, bigCap, level, err);
-		else hipLaunchKernelGGL(k_copy_big<false>, dim3(512), dim3(COPY_BIG_THREADS), 0, stBig, g, v, depth, bigQ, ctl + 5, bigCap, level, err);
+		if (def) hipLaunchKernelGGL(k_copy_big<true>, dim3(512), dim3(COPY_BIG_THREADS), 0, stBig, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 7), err);
+		else hipLaunchKernelGGL(k_copy_big<false>, dim3(512), dim3(COPY_BIG_THREADS), 0, stBig, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 7), err);
 		if (stBig != st) (void)hipEventRecord(evBig, stBig);
 	}
 	if (midMin < bigMin) {

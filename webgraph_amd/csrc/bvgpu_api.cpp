@@ -67,6 +67,7 @@ struct Pending { // an enqueued range decode whose status has not been collected
 	int32_t levels_done = 0;
 	bool want_succ = false;
 	int32_t giantCap = 0, bigCap = 0, midCap = 0;
+	uint32_t tmpCap = 0;
 };
 
 } // namespace
@@ -95,6 +96,7 @@ struct bvg_graph {
 	int32_t coop_min = 2048, giant_min = 32768;                         // thresholds on the outdegree (BVGPU_COOP_MIN / BVGPU_GIANT_MIN)
 	int coop_waves = 4096, giant_groups = 256;
 	DevBuf copyq; // rows the copy pass merges with a group / a wave each (all levels), filled while the level lists are built
+	DevBuf bigtmp; // global scratch tables for rows that copy more ids than the LDS tables of k_copy_big hold
 	DevBuf stats; // BVGPU_STATS=1: tuning counters
 	// the three parse kernels (giant / big / short records) are independent: they run on forked streams
 	hipStream_t sideA = nullptr, sideB = nullptr; // (more streams than this share hardware queues with each other: they would serialise)
@@ -249,7 +251,7 @@ int finish_pending(bvg_graph *g, uint64_t *arcs_out) {
 					if (g->copy_lists) {
 						const bool ov2 = g->overlap && !g->profile;
 						bv::launch_copy_level(gd, s.def, g->pend.view, g->depth.as<int32_t>(), g->lvlist.as<int32_t>(), keyBase, l, g->level_blocks, g->copy_mid_min, g->copy_big != 0,
-						                      g->copyq.as<int32_t>(), g->pend.bigCap, g->copyq.as<int32_t>() + g->pend.bigCap, g->pend.midCap, g->coopctl.as<int32_t>(), derr,
+						                      g->copyq.as<int32_t>(), g->pend.bigCap, g->copyq.as<int32_t>() + g->pend.bigCap, g->pend.midCap, g->coopctl.as<int32_t>(), g->bigtmp.as<int32_t>(), g->pend.tmpCap, derr,
 						                      g->stream, ov2 ? g->sideB : g->stream, ov2 ? g->sideA : g->stream, g->evFork, g->evB, g->evA);
 					}
 					else bv::launch_copy(gd, s.def, g->pend.view, g->depth.as<int32_t>(), l, derr, g->stream);
@@ -336,6 +338,11 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 		const int32_t midCap = g->copy_mid_min > 0 ? (int32_t)std::min<int64_t>(arcsBound / g->copy_mid_min + 2, 0x3fffffff) : 0;
 		if (g->copy_lists && !g->copyq.need(sizeof(int32_t) * ((size_t)bigCap + (size_t)midCap))) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
 		g->pend.bigCap = bigCap; g->pend.midCap = midCap;
+		// scratch tables of the rows that copy more ids than k_copy_big's LDS tables hold (bump-allocated, ctl[7]): a
+		// quarter of the arcs covers every realistic mix; a row that does not fit falls back to one lane
+		const uint32_t tmpCap = (uint32_t)std::min<int64_t>(std::max<int64_t>(arcsBound / 4, 1 << 22), 0x7fffffff);
+		if (g->copy_lists && g->copy_big && !g->bigtmp.need(sizeof(int32_t) * (size_t)tmpCap)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
+		g->pend.tmpCap = g->copy_lists && g->copy_big ? tmpCap : 0;
 		const bool coop = g->coop_min < 0x7fffffff;
 		const bool ovl = g->overlap && !g->profile; // per-kernel timing needs the kernels one after the other
 		v.coop_min = coop ? g->coop_min : 0x7fffffff;
@@ -395,7 +402,7 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 			levels = g->levels_hint;
 			for (int32_t l = 1; l <= levels; l++) {
 				if (g->copy_lists) bv::launch_copy_level(gd, s.def, v, g->depth.as<int32_t>(), g->lvlist.as<int32_t>(), keyBase, l, g->level_blocks, g->copy_mid_min, g->copy_big != 0,
-				                                          g->copyq.as<int32_t>(), bigCap, g->copyq.as<int32_t>() + bigCap, midCap, ctl, derr,
+				                                          g->copyq.as<int32_t>(), bigCap, g->copyq.as<int32_t>() + bigCap, midCap, ctl, g->bigtmp.as<int32_t>(), g->pend.tmpCap, derr,
 				                                          g->stream, ovl ? g->sideB : g->stream, ovl ? g->sideA : g->stream, g->evFork, g->evB, g->evA);
 				else bv::launch_copy(gd, s.def, v, g->depth.as<int32_t>(), l, derr, g->stream); // sweep in node order: rows of neighbouring nodes are neighbours in memory
 			}
@@ -573,7 +580,7 @@ extern "C" int bvg_close(bvg_t *g) {
 	if (g->st && g->st->device >= 0) {
 		(void)hipSetDevice(g->st->device);
 		if (g->own) { (void)hipStreamSynchronize(g->own); (void)hipStreamDestroy(g->own); }
-		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist, &g->plist, &g->pkeys, &g->pkey16, &g->copyq }) b->release();
+		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist, &g->plist, &g->pkeys, &g->pkey16, &g->copyq, &g->bigtmp }) b->release();
 		if (g->h_small) (void)hipHostFree(g->h_small);
 		for (auto &e : g->ev) if (e) (void)hipEventDestroy(e);
 		for (hipEvent_t e : { g->evFork, g->evA, g->evB, g->evC, g->evIn, g->evOut }) if (e) (void)hipEventDestroy(e);
