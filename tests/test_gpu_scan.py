@@ -288,6 +288,11 @@ LONG_ROW_CASES = [
     ("serial", 0, 3, {"BVGPU_OVERLAP": "0"}),
     ("delta_codes", "RESIDUALS_DELTA | BLOCKS_DELTA | BLOCK_COUNT_DELTA | OUTDEGREES_DELTA", 3, {}),
     ("zeta2", 0, 2, {}),
+    ("zeta1", 0, 1, {}),  # the codeword "1" carries no payload bits
+    ("zeta5", 0, 5, {}),
+    ("zeta7", 0, 7, {}),  # codewords outgrow the 32-bit window early: the 64-bit and generic fallbacks run
+    ("zeta16", 0, 16, {}),
+    ("zeta5_small_thresholds", 0, 5, {"BVGPU_COOP_MIN": "64", "BVGPU_GIANT_MIN": "2000"}),
 ]
 
 

@@ -239,23 +239,39 @@ __device__ __forceinline__ bool fast_gamma(uint64_t W, uint64_t &v, uint32_t &le
 	len = 2 * m + 1;
 	return true;
 }
-__device__ __forceinline__ bool fast_zeta3(uint64_t W, uint64_t &v, uint32_t &len) {
+// zeta_k from a 64-bit window: unary h, then h*k + k - 1 bits, one more if that is not a short codeword (SURVEY.md
+// App. B).  K = 3 (the default, constants folded in) or 0 = the graph's zetak at run time.  Fails (generic reader)
+// when the codeword does not fit the window.
+template <int K>
+__device__ __forceinline__ bool fast_zeta(uint64_t W, uint32_t krt, uint64_t &v, uint32_t &len) {
 	if (W == 0) return false;
 	const uint32_t h = (uint32_t)__clzll((long long)W);
-	if (h > 15) return false;
-	const uint32_t nb = 3 * h + 2;
+	if (K == 3) { // the default: constants folded in
+		if (h > 15) return false;
+		const uint32_t nb = 3 * h + 2;
+		const uint64_t W2 = W << (h + 1);
+		const uint64_t m = W2 >> (64u - nb);
+		const uint64_t left = (uint64_t)1 << (3 * h);
+		if (m < left) { v = m + left - 1; len = h + 1 + nb; }
+		else { v = ((m << 1) | ((W2 >> (63u - nb)) & 1)) - 1; len = h + 2 + nb; }
+		return true;
+	}
+	const uint32_t k = krt;
+	const uint32_t nb = k * h + k - 1;
+	if (nb == 0) { v = 0; len = 1; return true; } // zeta_1, h = 0: the codeword "1" has no payload and means 0
+	if (h + 2 + nb > 64u) return false;
 	const uint64_t W2 = W << (h + 1);
 	const uint64_t m = W2 >> (64u - nb);
-	const uint64_t left = (uint64_t)1 << (3 * h);
+	const uint64_t left = (uint64_t)1 << (k * h);
 	if (m < left) { v = m + left - 1; len = h + 1 + nb; }
 	else { v = ((m << 1) | ((W2 >> (63u - nb)) & 1)) - 1; len = h + 2 + nb; }
 	return true;
 }
 // one code at bit position p of the staged window; advances p.  KIND 0: residual code, KIND 1 / 2: gamma code
-template <bool DEF, int KIND>
+template <int DEF, int KIND>
 __device__ __forceinline__ uint64_t win_code(const GraphDev &g, const WindowSrc &src, uint64_t &p, int &err) {
 	uint64_t W, v; uint32_t len;
-	if ((KIND != 0 || DEF) && win_peek64(src, p, W) && (KIND != 0 ? fast_gamma(W, v, len) : fast_zeta3(W, v, len))) { p += len; return v; }
+	if ((KIND != 0 || DEF) && win_peek64(src, p, W) && (KIND != 0 ? fast_gamma(W, v, len) : fast_zeta<DEF == 1 ? 3 : 0>(W, DEF == 1 ? 3u : (uint32_t)g.zetaK, v, len))) { p += len; return v; }
 	WinReader br; br.init_src(src, g.nwords);
 	br.seek(p);
 	v = KIND != 0 ? br.gamma() : Fields<DEF>::residual(br, g);
@@ -275,20 +291,34 @@ __device__ __forceinline__ bool fast_gamma32(uint32_t W, uint32_t &v, uint32_t &
 	v = (W >> (31u - 2 * m)) - 1;
 	return true;
 }
-__device__ __forceinline__ bool fast_zeta3_32(uint32_t W, uint32_t &v, uint32_t &len) {
-	if (W < (1u << 25)) return false; // h > 6: longer than 28 bits
-	const uint32_t h = (uint32_t)__clz((int)W);
-	const uint32_t nb = 3 * h + 2;
-	const uint32_t mm = (W << (h + 1)) >> (31u - nb); // the nb bits of the short codeword plus the extra bit of the long one
-	const uint32_t m = mm >> 1, left = 1u << (3 * h);
+template <int K>
+__device__ __forceinline__ bool fast_zeta_32(uint32_t W, uint32_t krt, uint32_t &v, uint32_t &len) {
+	if (K == 3) {
+		if (W < (1u << 25)) return false; // h > 6: longer than 28 bits
+		const uint32_t h = (uint32_t)__clz((int)W);
+		const uint32_t nb = 3 * h + 2;
+		const uint32_t mm = (W << (h + 1)) >> (31u - nb); // the nb bits of the short codeword plus the extra bit of the long one
+		const uint32_t m = mm >> 1, left = 1u << (3 * h);
+		const bool lng = m >= left;
+		v = lng ? mm - 1 : m + left - 1;
+		len = 4 * h + 3 + (lng ? 1u : 0u);
+		return true;
+	}
+	const uint32_t k = krt;
+	const uint32_t h = (uint32_t)__clz((int)W); // (32 for W == 0: rejected below)
+	const uint32_t nb = k * h + k - 1;
+	if (h + 2 + nb > 32u) return false; // longer than the window
+	if (nb == 0) { v = 0; len = 1; return true; } // zeta_1, h = 0
+	const uint32_t mm = (W << (h + 1)) >> (31u - nb);
+	const uint32_t m = mm >> 1, left = 1u << (k * h);
 	const bool lng = m >= left;
 	v = lng ? mm - 1 : m + left - 1;
-	len = 4 * h + 3 + (lng ? 1u : 0u);
+	len = h + 1 + nb + (lng ? 1u : 0u);
 	return true;
 }
 // the rare long codeword: kept out of line (and fed by value) so that the hot loops stay small
 struct SlowCode { uint64_t v; uint32_t q; int err; };
-template <bool DEF, int KIND>
+template <int DEF, int KIND>
 __device__ __attribute__((noinline)) SlowCode win_code_slow(const GraphDev *gp, const uint32_t *win, uint64_t w0, uint32_t nw, uint32_t q) {
 	const GraphDev &g = *gp;
 	const WindowSrc src{ win, w0, nw, GlobalSrc{ g.bits, g.nwords } };
@@ -300,14 +330,14 @@ __device__ __attribute__((noinline)) SlowCode win_code_slow(const GraphDev *gp, 
 }
 // One code at tile-relative position q, which must lie inside the tile proper (then the two words read here
 // are staged: the window extends 8 words past the tile).  Advances q.
-template <bool DEF, int KIND>
+template <int DEF, int KIND>
 __device__ __forceinline__ uint64_t win_code_rel(const GraphDev &g, const WindowSrc &src, uint32_t &q, int &err) {
 	if (KIND != 0 || DEF) {
 		const uint32_t j = q >> 5;
 		const uint64_t ab = ((uint64_t)src.win[j] << 32) | src.win[j + 1];
 		const uint32_t W = (uint32_t)((ab << (q & 31u)) >> 32);
 		uint32_t v, len;
-		if (__builtin_expect(KIND != 0 ? fast_gamma32(W, v, len) : fast_zeta3_32(W, v, len), 1)) { q += len; return v; }
+		if (__builtin_expect(KIND != 0 ? fast_gamma32(W, v, len) : fast_zeta_32<DEF == 1 ? 3 : 0>(W, DEF == 1 ? 3u : (uint32_t)g.zetaK, v, len), 1)) { q += len; return v; }
 	}
 	const SlowCode sc = win_code_slow<DEF, KIND>(&g, src.win, src.w0, src.nw, q);
 	q = sc.q;
@@ -318,7 +348,7 @@ __device__ __forceinline__ uint64_t win_code_rel(const GraphDev &g, const Window
 // One speculative parse of the codes starting in [s, segEnd): end position, count and the sum of the decoded
 // contributions.  KIND 0: residual codes (gap+1 each; the first code of the section is the zig-zag value);
 // KIND 1: gamma codes, positions only; KIND 2: gamma codes, the sum of their values (offset gaps, bv_offsets.hip).
-template <bool DEF, int KIND>
+template <int DEF, int KIND>
 __device__ __forceinline__ void spec_parse(const GraphDev &g, const WindowSrc &src, uint64_t base, uint32_t s, uint32_t segEnd, bool firstOfSection, uint32_t &e, uint32_t &c, int64_t &sum) {
 	c = 0; sum = 0;
 	uint32_t p = s;
@@ -338,7 +368,7 @@ __device__ __forceinline__ void spec_parse(const GraphDev &g, const WindowSrc &s
 // parsing the segment again the old and the new chain of codewords are walked in lock step (always the one that
 // is behind) until they meet: from there on they are the same chain, and only the difference of the two
 // prefixes is applied to (c, sum).  If they do not meet inside the segment the new chain defines the end.
-template <bool DEF, int KIND>
+template <int DEF, int KIND>
 __device__ __forceinline__ void spec_resync(const GraphDev &g, const WindowSrc &src, uint64_t base, uint32_t so, uint32_t sn, uint32_t segEnd, uint32_t &e, uint32_t &c, int64_t &sum) {
 	uint32_t po = so, pn = sn;
 	int32_t dc = 0;
@@ -362,7 +392,7 @@ __device__ __forceinline__ void spec_resync(const GraphDev &g, const WindowSrc &
 // Fixed-point iteration over one tile starting at the true code boundary pos0.  On return every lane holds
 // the true start `s` (tile-relative) of the first code it owns, the number `c` of codes starting in its
 // segment, their contribution sum, and E = end of the tile's last code (absolute, uniform).
-template <bool DEF, int KIND, int NW>
+template <int DEF, int KIND, int NW>
 __device__ __forceinline__ void spec_tile(const Grp<NW> &G, const GraphDev &g, const WindowSrc &src, uint64_t pos0, uint64_t secEnd, uint32_t B, bool firstTile,
                                           int64_t needCodes, uint32_t &s, uint32_t &c, int64_t &sum, uint64_t &E, uint64_t anchor = ~0ull) {
 	// anchor: where the segment grid starts (default: at pos0).  A caller whose tiles have FIXED nominal boundaries
@@ -457,7 +487,7 @@ __device__ __forceinline__ void spec_tile(const Grp<NW> &G, const GraphDev &g, c
 // ---------------------------------------------------------------------------------------------- phase I
 // Decodes the 2*ic gamma codes of the interval section starting at `pos` into arena entries (BVG:1077-1095);
 // returns the bit position after them (start of the residual section) and the number of intervalised arcs.
-template <bool DEF, int NW>
+template <int DEF, int NW>
 __device__ __forceinline__ void coop_intervals(const Grp<NW> &G, const GraphDev &g, int32_t x, uint64_t pos, uint64_t recEnd, int64_t ic, uint32_t B,
                                                IvEntry *__restrict__ list, uint32_t *lds, uint64_t &posAfter, int64_t &intervalArcs, int &err) {
 	uint32_t *win = lds + CoopLds<NW>::OFF_WIN;
@@ -527,7 +557,7 @@ __device__ __attribute__((noinline)) int32_t iv_field_slow(const IvEntry *__rest
 // Every lane decodes the run of residuals it owns and walks the (sorted) interval list alongside: it adds up
 // the arcs of the intervals it passes and tells each of them its rank.  The intervals relevant to a tile are
 // staged in LDS first (they are a contiguous slice of the list).
-template <bool DEF, int NW>
+template <int DEF, int NW>
 __device__ __forceinline__ void coop_residuals(const Grp<NW> &G, const GraphDev &g, int32_t x, uint64_t pos, uint64_t recEnd, int64_t nRes, int64_t ic, int64_t intervalArcs,
                                                IvEntry *__restrict__ list, int32_t *__restrict__ out, uint32_t *lds, int &err) {
 	constexpr int N = Grp<NW>::N, IVCAP = CoopCfg<NW>::IVCAP;
@@ -642,7 +672,7 @@ __device__ __forceinline__ void coop_residuals(const Grp<NW> &G, const GraphDev 
 }
 
 // The whole record of node x by one group.  Same contract as parse_node: extras merged into row[copied..d).
-template <bool DEF, int NW>
+template <int DEF, int NW>
 __device__ __forceinline__ void coop_parse_node(const GraphDev &g, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row,
                                                 IvEntry *__restrict__ list, uint32_t *lds, int *__restrict__ errOut) {
 	Grp<NW> G{ (int64_t *)(lds + CoopLds<NW>::OFF_XCH) };

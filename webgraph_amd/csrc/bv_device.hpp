@@ -240,12 +240,12 @@ using PReader = BitReaderT<PrefetchSrc>;
 
 // Field readers.  DEF == true: the default coding set (gamma outdegrees / block counts / blocks, unary
 // references, zeta_3 residuals -- BVG:525-541 and DEFAULT_ZETA_K) is resolved at compile time.
-template <bool DEF> struct Fields {
+template <int DEF> struct Fields {
 	template <class R> static __device__ __forceinline__ uint64_t outdegree(R &br, const GraphDev &g) { return DEF ? br.gamma() : br.coded(g.c_outd, 0); }
 	template <class R> static __device__ __forceinline__ uint64_t reference(R &br, const GraphDev &g) { return DEF ? br.unary() : br.coded(g.c_ref, 0); }
 	template <class R> static __device__ __forceinline__ uint64_t block_count(R &br, const GraphDev &g) { return DEF ? br.gamma() : br.coded(g.c_bc, 0); }
 	template <class R> static __device__ __forceinline__ uint64_t block(R &br, const GraphDev &g) { return DEF ? br.gamma() : br.coded(g.c_blk, 0); }
-	template <class R> static __device__ __forceinline__ uint64_t residual(R &br, const GraphDev &g) { return DEF ? br.template zeta_k<3>(3) : br.coded(g.c_res, g.zetaK); }
+	template <class R> static __device__ __forceinline__ uint64_t residual(R &br, const GraphDev &g) { return DEF == 1 ? br.template zeta_k<3>(3) : DEF == 2 ? br.template zeta_k<0>(g.zetaK) : br.coded(g.c_res, g.zetaK); }
 };
 
 } // namespace bv

@@ -36,13 +36,13 @@ namespace bv {
 constexpr int TPB = 256;
 constexpr int GIANT_NW = COOP_GIANT_NW; // waves per giant record
 
-template <bool DEF>
+template <int DEF>
 __device__ __forceinline__ void copy_node(const GraphDev &g, int32_t x, int32_t d, int64_t dref, int32_t *__restrict__ row, const int32_t *__restrict__ src, int *__restrict__ err);
-template <bool DEF>
+template <int DEF>
 __device__ __forceinline__ void parse_node(const GraphDev &g, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row, int *__restrict__ err);
 
 // ------------------------------------------------------------------------------------------------ headers
-template <bool DEF>
+template <int DEF>
 __global__ void __launch_bounds__(TPB) k_headers(GraphDev g, int32_t lo, int32_t cnt, int32_t *__restrict__ outd,
                                                  uint16_t *__restrict__ ref, int *__restrict__ err) {
 	const int32_t s = blockIdx.x * TPB + threadIdx.x;
@@ -186,7 +186,7 @@ __global__ void k_rebase(int32_t nh, int32_t cnt, const int64_t *__restrict__ ro
 // Nodes without a reference are final after this kernel.
 // Both cursors refill 32 bits at a time straight from HBM (L1/L2-cached).  Measured alternatives on C2 -- a 16-byte
 // prefetching cursor and private per-lane LDS windows -- tripled the register count (148-188 VGPRs) and were slower.
-template <bool DEF>
+template <int DEF>
 __device__ __forceinline__ void parse_node(const GraphDev &g, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row, int *__restrict__ err) {
 	BitReader br;
 	br.init(g.bits, g.nwords);
@@ -272,7 +272,7 @@ __device__ __forceinline__ void parse_node(const GraphDev &g, int32_t x, int32_t
 	if (br.err | bi.err) atomicOr(err, br.err | bi.err);
 }
 
-template <bool DEF>
+template <int DEF>
 __global__ void __launch_bounds__(TPB) k_parse(GraphDev g, RangeView v, int *__restrict__ err) {
 	const int32_t s = blockIdx.x * TPB + threadIdx.x;
 	if (s >= v.cnt) return;
@@ -403,7 +403,7 @@ __global__ void __launch_bounds__(TPB) k_scatter_keys(int32_t cnt, const uint16_
 }
 
 // One lane per record of chain level `level`; waves walk the level's slice of the list (sorted by length bin).
-template <bool DEF, bool HAS_REF>
+template <int DEF, bool HAS_REF>
 __global__ void __launch_bounds__(TPB) k_decode_level(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ list,
                                                       const int32_t *__restrict__ keyBase, int32_t level, int *__restrict__ err) {
 	__shared__ int32_t lds[LANE_LDS_INTS_PER_THREAD * TPB];
@@ -421,7 +421,7 @@ __global__ void __launch_bounds__(TPB) k_decode_level(GraphDev g, RangeView v, c
 }
 
 // copy pass restricted to the giant list (their extras were written by k_parse_big)
-template <bool DEF>
+template <int DEF>
 __global__ void __launch_bounds__(64) k_copy_giants(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ giantlist,
                                                     const int32_t *__restrict__ ctl, int32_t level, int *__restrict__ err) {
 	const int32_t idx = blockIdx.x * 64 + threadIdx.x;
@@ -445,7 +445,7 @@ __device__ __forceinline__ int copy_class(const RangeView &v, const int32_t *__r
 	if (s >= v.nh && (uint64_t)(v.rowstart[s + 1] - v.rowstart[v.nh]) > v.succ_cap) return 0; // E_CAP already raised
 	return copy_class_of(v.outd[s], v.outd[s - v.ref[s]], midMin, bigMin);
 }
-template <bool DEF>
+template <int DEF>
 __global__ void __launch_bounds__(TPB) k_copy_list(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ list,
                                                    const int32_t *__restrict__ keyBase, int32_t level, int32_t midMin, int32_t bigMin, int *__restrict__ err) {
 	const int32_t bucket = min(level, MAXLVL - 1);
@@ -465,7 +465,7 @@ __global__ void __launch_bounds__(TPB) k_copy_list(GraphDev g, RangeView v, cons
 // position by ONE binary search in the other set (the sets are disjoint in a valid file): copied id t goes to
 // t + #(extras smaller), extra e to e + #(copied ids smaller).
 constexpr int COPY_MID_WAVES = 4;
-template <bool DEF>
+template <int DEF>
 __global__ void __launch_bounds__(64 * COPY_MID_WAVES) k_copy_mid(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ queue,
                                                                   const int32_t *__restrict__ count, int32_t cap, int32_t level, int *__restrict__ err) {
 	__shared__ int32_t s_vals[COPY_MID_WAVES][COPY_BIG_MIN], s_kend[COPY_MID_WAVES][COPY_BIG_MIN + 1], s_delta[COPY_MID_WAVES][COPY_BIG_MIN + 1];
@@ -545,7 +545,7 @@ __device__ __forceinline__ void coop_block_walk(const GraphDev &g, uint64_t pos,
 		const WindowSrc src = stage_tile<1>(G, g, lds + CoopLds<1>::OFF_WIN, pos, B);
 		const uint64_t base = src.w0 << 5;
 		uint64_t E; uint32_t s, c; int64_t unused;
-		spec_tile<true, 1, 1>(G, g, src, pos, recEnd, B, false, bc - done, s, c, unused, E);
+		spec_tile<1, 1, 1>(G, g, src, pos, recEnd, B, false, bc - done, s, c, unused, E);
 		int64_t tileTotal;
 		const int64_t cincl = G.incl_scan((int64_t)c, tileTotal);
 		const int64_t cb = cincl - c, rem = bc - done;
@@ -559,7 +559,7 @@ __device__ __forceinline__ void coop_block_walk(const GraphDev &g, uint64_t pos,
 			uint32_t p = s;
 			for (uint32_t k = 0; k < c; k++) {
 				const int64_t q = done + cb + k;
-				const int64_t len = (int64_t)win_code_rel<true, 1>(g, src, p, err) + (q ? 1 : 0);
+				const int64_t len = (int64_t)win_code_rel<1, 1>(g, src, p, err) + (q ? 1 : 0);
 				dAll += len;
 				if (!(q & 1)) dEven += len;
 			}
@@ -574,7 +574,7 @@ __device__ __forceinline__ void coop_block_walk(const GraphDev &g, uint64_t pos,
 			int e2 = 0;
 			for (uint32_t k = 0; k < c; k++) {
 				const int64_t q = done + cb + k;
-				const int64_t len = (int64_t)win_code_rel<true, 1>(g, src, p, e2) + (q ? 1 : 0);
+				const int64_t len = (int64_t)win_code_rel<1, 1>(g, src, p, e2) + (q ? 1 : 0);
 				if (!(q & 1)) {
 					const int64_t j = q >> 1;
 					if (j < tabCap) { kend[j] = (int32_t)min<int64_t>(cp + len, 0x7fffffff); delta[j] = (int32_t)(t - cp); }
@@ -615,7 +615,7 @@ __device__ __forceinline__ void coop_block_walk(const GraphDev &g, uint64_t pos,
 // is already being read while this one is written.  The copied ids drop into the gaps at the end
 // (MergedIntIterator semantics for the disjoint sets of a valid file).  Rows copying more than COPY_BIG_CAP ids
 // fall back to one lane.
-template <bool DEF>
+template <int DEF>
 __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ queue,
                                                                const int32_t *__restrict__ count, int32_t cap, int32_t level, int32_t *__restrict__ tmp, uint32_t tmpCap,
                                                                uint32_t *__restrict__ tmpCursor, int *__restrict__ err) {
@@ -761,7 +761,7 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 }
 
 // parse pass over a list sorted by work bin only (all chain levels together): 64 records of similar length per wave
-template <bool DEF>
+template <int DEF>
 __global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, const int32_t *__restrict__ list, const int32_t *__restrict__ keyBase, int32_t binLo, int32_t binHi,
                                                     int *__restrict__ err) {
 	__shared__ uint32_t lw[DEF ? LW_LDS_WORDS : 1]; // lane-private stream windows (default codings)
@@ -778,7 +778,7 @@ __global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, con
 		if (d >= v.coop_min || d == 0) continue; // decoded by whole waves (k_parse_big) / nothing to decode
 		const int32_t r = v.ref[s];
 		if (s >= v.nh && (uint64_t)(v.rowstart[s + 1] - v.rowstart[v.nh]) > v.succ_cap) { atomicOr(err, E_CAP); continue; }
-		if (DEF) parse_node_lw(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), lw, err);
+		if (DEF) parse_node_lw<DEF == 1 ? 3 : 0>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), lw, err);
 		else parse_node<DEF>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), err);
 	}
 }
@@ -848,7 +848,7 @@ __device__ __forceinline__ LongRec long_rec(const BatchView &v, int32_t s) {
 	                !(qi >= 0 && (uint64_t)v.rowptr[qi + 1] > v.succ_cap) };
 }
 
-template <bool DEF, int NW, class View>
+template <int DEF, int NW, class View>
 #ifndef COOP1_MINWAVES
 #define COOP1_MINWAVES 4
 #endif
@@ -882,7 +882,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? COOP1_MINWAVES : COOPG_MINW
 // One lane per node of chain depth `level`: merge the masked copy of the referent's final row with the
 // node's extras (sitting at row[copied..d)), forward and in place.  The write index never overtakes the
 // extras read index: k = (#copied so far) + (j - copied) <= j.
-template <bool DEF>
+template <int DEF>
 __device__ __forceinline__ void copy_node(const GraphDev &g, int32_t x, int32_t d, int64_t dref, int32_t *__restrict__ row, const int32_t *__restrict__ src, int *__restrict__ err) {
 	BitReader br;
 	br.init(g.bits, g.nwords);
@@ -924,7 +924,7 @@ __device__ __forceinline__ void copy_node(const GraphDev &g, int32_t x, int32_t 
 	if (br.err) atomicOr(err, br.err);
 }
 
-template <bool DEF>
+template <int DEF>
 __global__ void __launch_bounds__(TPB) k_copy(GraphDev g, RangeView v, const int32_t *__restrict__ depth, int32_t level, int *__restrict__ err) {
 	const int32_t s = blockIdx.x * TPB + threadIdx.x;
 	if (s >= v.cnt) return;
@@ -938,7 +938,7 @@ __global__ void __launch_bounds__(TPB) k_copy(GraphDev g, RangeView v, const int
 // bvg_successors_batch: every query node x owns a private chain of slots x, x-r1, x-r1-r2, ... (what the
 // recursion of BVG:1120 would visit); slot t of a chain has depth L-1-t and its referent is slot t+1.
 // Query rows go to the caller's succ at rowptr[query]; ancestor rows go to a scratch arena.
-template <bool DEF>
+template <int DEF>
 __device__ __forceinline__ void read_header(const GraphDev &g, int32_t x, int32_t &d, int32_t &r, int &e) {
 	BitReader br;
 	br.init(g.bits, g.nwords);
@@ -954,7 +954,7 @@ __device__ __forceinline__ void read_header(const GraphDev &g, int32_t x, int32_
 	d = (int32_t)dd; r = (int32_t)rr;
 }
 
-template <bool DEF>
+template <int DEF>
 __global__ void __launch_bounds__(TPB) k_chain_len(GraphDev g, const int32_t *__restrict__ nodes, int64_t q, int32_t *__restrict__ chainlen,
                                                    int32_t *__restrict__ maxlen, int *__restrict__ err) {
 	const int64_t j = (int64_t)blockIdx.x * TPB + threadIdx.x;
@@ -979,7 +979,7 @@ __global__ void __launch_bounds__(TPB) k_chain_len(GraphDev g, const int32_t *__
 	if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(maxlen, m);
 }
 
-template <bool DEF>
+template <int DEF>
 __global__ void __launch_bounds__(TPB) k_chain_fill(GraphDev g, const int32_t *__restrict__ nodes, int64_t q, const int64_t *__restrict__ slotbase,
                                                     int32_t *__restrict__ snode, int32_t *__restrict__ soutd, int32_t *__restrict__ sdepth,
                                                     int32_t *__restrict__ sq, int32_t *__restrict__ aoutd, int32_t *__restrict__ qoutd) {
@@ -1001,7 +1001,7 @@ __global__ void __launch_bounds__(TPB) k_chain_fill(GraphDev g, const int32_t *_
 	}
 }
 
-template <bool DEF>
+template <int DEF>
 __global__ void __launch_bounds__(TPB) k_bparse(GraphDev g, BatchView v, int *__restrict__ err) {
 	const int64_t s = (int64_t)blockIdx.x * TPB + threadIdx.x;
 	if (s >= v.cnt) return;
@@ -1014,7 +1014,7 @@ __global__ void __launch_bounds__(TPB) k_bparse(GraphDev g, BatchView v, int *__
 	parse_node<DEF>(g, v.node[s], d, hasRef, hasRef ? (int64_t)v.outd[s + 1] : 0, v.row(s), err);
 }
 
-template <bool DEF>
+template <int DEF>
 __global__ void __launch_bounds__(TPB) k_bcopy(GraphDev g, BatchView v, int32_t level, int *__restrict__ err) {
 	const int64_t s = (int64_t)blockIdx.x * TPB + threadIdx.x;
 	if (s >= v.cnt) return;
@@ -1077,10 +1077,11 @@ namespace bv {
 
 static inline unsigned nblk(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
-void launch_headers(const GraphDev &g, bool def, int32_t lo, int32_t cnt, int32_t *outd, uint16_t *ref, int *err, hipStream_t st) {
+void launch_headers(const GraphDev &g, int def, int32_t lo, int32_t cnt, int32_t *outd, uint16_t *ref, int *err, hipStream_t st) {
 	if (cnt <= 0) return;
-	if (def) hipLaunchKernelGGL(k_headers<true>, dim3(nblk(cnt, TPB)), dim3(TPB), 0, st, g, lo, cnt, outd, ref, err);
-	else hipLaunchKernelGGL(k_headers<false>, dim3(nblk(cnt, TPB)), dim3(TPB), 0, st, g, lo, cnt, outd, ref, err);
+	if (def == 1) hipLaunchKernelGGL(k_headers<1>, dim3(nblk(cnt, TPB)), dim3(TPB), 0, st, g, lo, cnt, outd, ref, err);
+	else if (def == 2) hipLaunchKernelGGL(k_headers<2>, dim3(nblk(cnt, TPB)), dim3(TPB), 0, st, g, lo, cnt, outd, ref, err);
+	else hipLaunchKernelGGL(k_headers<0>, dim3(nblk(cnt, TPB)), dim3(TPB), 0, st, g, lo, cnt, outd, ref, err);
 }
 
 void launch_mark_halo(int32_t nh, int32_t cnt, int32_t W, int32_t *outd, uint16_t *ref, uint8_t *need, int *err, hipStream_t st) {
@@ -1107,16 +1108,18 @@ void launch_rebase(int32_t nh, int32_t cnt, const int64_t *rowstart, int64_t *ou
 	hipLaunchKernelGGL(k_rebase, dim3(nblk((int64_t)cnt - nh + 1, TPB)), dim3(TPB), 0, st, nh, cnt, rowstart, out);
 }
 
-void launch_parse(const GraphDev &g, bool def, const RangeView &v, int *err, hipStream_t st) {
+void launch_parse(const GraphDev &g, int def, const RangeView &v, int *err, hipStream_t st) {
 	if (v.cnt <= 0) return;
-	if (def) hipLaunchKernelGGL(k_parse<true>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, err);
-	else hipLaunchKernelGGL(k_parse<false>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, err);
+	if (def == 1) hipLaunchKernelGGL(k_parse<1>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, err);
+	else if (def == 2) hipLaunchKernelGGL(k_parse<2>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, err);
+	else hipLaunchKernelGGL(k_parse<0>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, err);
 }
 
-void launch_copy(const GraphDev &g, bool def, const RangeView &v, const int32_t *depth, int32_t level, int *err, hipStream_t st) {
+void launch_copy(const GraphDev &g, int def, const RangeView &v, const int32_t *depth, int32_t level, int *err, hipStream_t st) {
 	if (v.cnt <= 0) return;
-	if (def) hipLaunchKernelGGL(k_copy<true>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, depth, level, err);
-	else hipLaunchKernelGGL(k_copy<false>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, depth, level, err);
+	if (def == 1) hipLaunchKernelGGL(k_copy<1>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, depth, level, err);
+	else if (def == 2) hipLaunchKernelGGL(k_copy<2>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, depth, level, err);
+	else hipLaunchKernelGGL(k_copy<0>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, depth, level, err);
 }
 
 void launch_hash(int32_t from, int32_t cnt, const int64_t *rowptr, const int32_t *succ, uint32_t *A, uint32_t *B, int32_t *hash, hipStream_t st) {
@@ -1126,29 +1129,33 @@ void launch_hash(int32_t from, int32_t cnt, const int64_t *rowptr, const int32_t
 	hipLaunchKernelGGL(k_hash_fold, dim3(1), dim3(TPB), 0, st, A, B, nb, hash);
 }
 
-void launch_chain_len(const GraphDev &g, bool def, const int32_t *nodes, int64_t q, int32_t *chainlen, int32_t *maxlen, int *err, hipStream_t st) {
+void launch_chain_len(const GraphDev &g, int def, const int32_t *nodes, int64_t q, int32_t *chainlen, int32_t *maxlen, int *err, hipStream_t st) {
 	if (q <= 0) return;
-	if (def) hipLaunchKernelGGL(k_chain_len<true>, dim3(nblk(q, TPB)), dim3(TPB), 0, st, g, nodes, q, chainlen, maxlen, err);
-	else hipLaunchKernelGGL(k_chain_len<false>, dim3(nblk(q, TPB)), dim3(TPB), 0, st, g, nodes, q, chainlen, maxlen, err);
+	if (def == 1) hipLaunchKernelGGL(k_chain_len<1>, dim3(nblk(q, TPB)), dim3(TPB), 0, st, g, nodes, q, chainlen, maxlen, err);
+	else if (def == 2) hipLaunchKernelGGL(k_chain_len<2>, dim3(nblk(q, TPB)), dim3(TPB), 0, st, g, nodes, q, chainlen, maxlen, err);
+	else hipLaunchKernelGGL(k_chain_len<0>, dim3(nblk(q, TPB)), dim3(TPB), 0, st, g, nodes, q, chainlen, maxlen, err);
 }
 
-void launch_chain_fill(const GraphDev &g, bool def, const int32_t *nodes, int64_t q, const int64_t *slotbase, int32_t *snode, int32_t *soutd,
+void launch_chain_fill(const GraphDev &g, int def, const int32_t *nodes, int64_t q, const int64_t *slotbase, int32_t *snode, int32_t *soutd,
                        int32_t *sdepth, int32_t *sq, int32_t *aoutd, int32_t *qoutd, hipStream_t st) {
 	if (q <= 0) return;
-	if (def) hipLaunchKernelGGL(k_chain_fill<true>, dim3(nblk(q, TPB)), dim3(TPB), 0, st, g, nodes, q, slotbase, snode, soutd, sdepth, sq, aoutd, qoutd);
-	else hipLaunchKernelGGL(k_chain_fill<false>, dim3(nblk(q, TPB)), dim3(TPB), 0, st, g, nodes, q, slotbase, snode, soutd, sdepth, sq, aoutd, qoutd);
+	if (def == 1) hipLaunchKernelGGL(k_chain_fill<1>, dim3(nblk(q, TPB)), dim3(TPB), 0, st, g, nodes, q, slotbase, snode, soutd, sdepth, sq, aoutd, qoutd);
+	else if (def == 2) hipLaunchKernelGGL(k_chain_fill<2>, dim3(nblk(q, TPB)), dim3(TPB), 0, st, g, nodes, q, slotbase, snode, soutd, sdepth, sq, aoutd, qoutd);
+	else hipLaunchKernelGGL(k_chain_fill<0>, dim3(nblk(q, TPB)), dim3(TPB), 0, st, g, nodes, q, slotbase, snode, soutd, sdepth, sq, aoutd, qoutd);
 }
 
-void launch_bparse(const GraphDev &g, bool def, const BatchView &v, int *err, hipStream_t st) {
+void launch_bparse(const GraphDev &g, int def, const BatchView &v, int *err, hipStream_t st) {
 	if (v.cnt <= 0) return;
-	if (def) hipLaunchKernelGGL(k_bparse<true>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, err);
-	else hipLaunchKernelGGL(k_bparse<false>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, err);
+	if (def == 1) hipLaunchKernelGGL(k_bparse<1>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, err);
+	else if (def == 2) hipLaunchKernelGGL(k_bparse<2>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, err);
+	else hipLaunchKernelGGL(k_bparse<0>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, err);
 }
 
-void launch_bcopy(const GraphDev &g, bool def, const BatchView &v, int32_t level, int *err, hipStream_t st) {
+void launch_bcopy(const GraphDev &g, int def, const BatchView &v, int32_t level, int *err, hipStream_t st) {
 	if (v.cnt <= 0) return;
-	if (def) hipLaunchKernelGGL(k_bcopy<true>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, level, err);
-	else hipLaunchKernelGGL(k_bcopy<false>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, level, err);
+	if (def == 1) hipLaunchKernelGGL(k_bcopy<1>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, level, err);
+	else if (def == 2) hipLaunchKernelGGL(k_bcopy<2>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, level, err);
+	else hipLaunchKernelGGL(k_bcopy<0>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, level, err);
 }
 
 void launch_classify(int32_t cnt, const int32_t *outd, int32_t coopMin, int32_t giantMin, int32_t *biglist, int32_t *giantlist, int32_t giantCap, int32_t *ctl, hipStream_t st) {
@@ -1158,26 +1165,30 @@ void launch_classify(int32_t cnt, const int32_t *outd, int32_t coopMin, int32_t 
 	hipLaunchKernelGGL(k_sort_desc, dim3(1), dim3(1024), 0, st, biglist, ctl + 0, cnt, outd);
 }
 
-void launch_parse_big(const GraphDev &g, bool def, const RangeView &v, const int32_t *biglist, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap,
+void launch_parse_big(const GraphDev &g, int def, const RangeView &v, const int32_t *biglist, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap,
                       int waves, int giantGroups, int *err, hipStream_t stGiant, hipStream_t stBig) {
 	if (v.cnt <= 0) return;
-	if (def) hipLaunchKernelGGL((k_parse_big<true, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
-	else hipLaunchKernelGGL((k_parse_big<false, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
-	if (def) hipLaunchKernelGGL((k_parse_big<true, 1, RangeView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
-	else hipLaunchKernelGGL((k_parse_big<false, 1, RangeView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
+	if (def == 1) hipLaunchKernelGGL((k_parse_big<1, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+	else if (def == 2) hipLaunchKernelGGL((k_parse_big<2, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+	else hipLaunchKernelGGL((k_parse_big<0, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+	if (def == 1) hipLaunchKernelGGL((k_parse_big<1, 1, RangeView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
+	else if (def == 2) hipLaunchKernelGGL((k_parse_big<2, 1, RangeView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
+	else hipLaunchKernelGGL((k_parse_big<0, 1, RangeView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
 }
 
 void copy_thresholds(int32_t midMinKnob, bool bigGroups, int32_t &midMin, int32_t &bigMin);
 // long records of a random-access batch: same classification, queues and cooperative kernels as a scan, over slots
-void launch_bparse_big(const GraphDev &g, bool def, const BatchView &v, int32_t coopMin, int32_t giantMin, int32_t *biglist, int32_t *giantlist, int32_t giantCap, int32_t *ctl,
+void launch_bparse_big(const GraphDev &g, int def, const BatchView &v, int32_t coopMin, int32_t giantMin, int32_t *biglist, int32_t *giantlist, int32_t giantCap, int32_t *ctl,
                        void *arena, int64_t arenaCap, int waves, int giantGroups, int *err, hipStream_t st, hipStream_t stGiant, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evGiant, hipEvent_t evBig) {
 	if (v.cnt <= 0) return;
 	launch_classify((int32_t)v.cnt, v.outd, coopMin, giantMin, biglist, giantlist, giantCap, ctl, st);
 	if (stGiant != st) { (void)hipEventRecord(evFork, st); (void)hipStreamWaitEvent(stGiant, evFork, 0); (void)hipStreamWaitEvent(stBig, evFork, 0); }
-	if (def) hipLaunchKernelGGL((k_parse_big<true, GIANT_NW, BatchView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
-	else hipLaunchKernelGGL((k_parse_big<false, GIANT_NW, BatchView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
-	if (def) hipLaunchKernelGGL((k_parse_big<true, 1, BatchView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
-	else hipLaunchKernelGGL((k_parse_big<false, 1, BatchView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
+	if (def == 1) hipLaunchKernelGGL((k_parse_big<1, GIANT_NW, BatchView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+	else if (def == 2) hipLaunchKernelGGL((k_parse_big<2, GIANT_NW, BatchView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+	else hipLaunchKernelGGL((k_parse_big<0, GIANT_NW, BatchView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+	if (def == 1) hipLaunchKernelGGL((k_parse_big<1, 1, BatchView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
+	else if (def == 2) hipLaunchKernelGGL((k_parse_big<2, 1, BatchView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
+	else hipLaunchKernelGGL((k_parse_big<0, 1, BatchView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
 	if (stGiant != st) { (void)hipEventRecord(evGiant, stGiant); (void)hipEventRecord(evBig, stBig); }
 }
 
@@ -1194,37 +1205,42 @@ void launch_build_lists(const GraphDev &g, const RangeView &v, uint64_t giantBit
 	hipLaunchKernelGGL(k_scatter_keys, dim3(nblk(v.cnt, LIST_TILE)), dim3(TPB), 0, st, v.cnt, key16, cursor, list, giantlist, giantCap, ctl);
 }
 
-void launch_decode_level(const GraphDev &g, bool def, const RangeView &v, const int32_t *depth, const int32_t *list, const int32_t *keyBase, int32_t level, int blocks,
+void launch_decode_level(const GraphDev &g, int def, const RangeView &v, const int32_t *depth, const int32_t *list, const int32_t *keyBase, int32_t level, int blocks,
                          int *err, hipStream_t st) {
 	if (v.cnt <= 0) return;
 	// level 0 records have no reference: the copy stream is compiled out
 	if (level == 0) {
-		if (def) hipLaunchKernelGGL((k_decode_level<true, false>), dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, err);
-		else hipLaunchKernelGGL((k_decode_level<false, false>), dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, err);
+		if (def == 1) hipLaunchKernelGGL((k_decode_level<1, false>), dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, err);
+		else if (def == 2) hipLaunchKernelGGL((k_decode_level<2, false>), dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, err);
+		else hipLaunchKernelGGL((k_decode_level<0, false>), dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, err);
 	} else {
-		if (def) hipLaunchKernelGGL((k_decode_level<true, true>), dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, err);
-		else hipLaunchKernelGGL((k_decode_level<false, true>), dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, err);
+		if (def == 1) hipLaunchKernelGGL((k_decode_level<1, true>), dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, err);
+		else if (def == 2) hipLaunchKernelGGL((k_decode_level<2, true>), dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, err);
+		else hipLaunchKernelGGL((k_decode_level<0, true>), dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, err);
 	}
 }
 
-void launch_copy_giants(const GraphDev &g, bool def, const RangeView &v, const int32_t *depth, const int32_t *giantlist, const int32_t *ctl, int32_t giantCap, int32_t level,
+void launch_copy_giants(const GraphDev &g, int def, const RangeView &v, const int32_t *depth, const int32_t *giantlist, const int32_t *ctl, int32_t giantCap, int32_t level,
                         int *err, hipStream_t st) {
 	if (v.cnt <= 0 || giantCap <= 0) return;
 	const int blocks = (int)std::min<int64_t>(((int64_t)giantCap + 63) / 64, 65535);
-	if (def) hipLaunchKernelGGL(k_copy_giants<true>, dim3(blocks), dim3(64), 0, st, g, v, depth, giantlist, ctl, level, err);
-	else hipLaunchKernelGGL(k_copy_giants<false>, dim3(blocks), dim3(64), 0, st, g, v, depth, giantlist, ctl, level, err);
+	if (def == 1) hipLaunchKernelGGL(k_copy_giants<1>, dim3(blocks), dim3(64), 0, st, g, v, depth, giantlist, ctl, level, err);
+	else if (def == 2) hipLaunchKernelGGL(k_copy_giants<2>, dim3(blocks), dim3(64), 0, st, g, v, depth, giantlist, ctl, level, err);
+	else hipLaunchKernelGGL(k_copy_giants<0>, dim3(blocks), dim3(64), 0, st, g, v, depth, giantlist, ctl, level, err);
 }
 
-void launch_parse_giants(const GraphDev &g, bool def, const RangeView &v, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap, int giantGroups, int *err, hipStream_t st) {
+void launch_parse_giants(const GraphDev &g, int def, const RangeView &v, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap, int giantGroups, int *err, hipStream_t st) {
 	if (v.cnt <= 0) return;
-	if (def) hipLaunchKernelGGL((k_parse_big<true, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, st, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
-	else hipLaunchKernelGGL((k_parse_big<false, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, st, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+	if (def == 1) hipLaunchKernelGGL((k_parse_big<1, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, st, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+	else if (def == 2) hipLaunchKernelGGL((k_parse_big<2, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, st, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+	else hipLaunchKernelGGL((k_parse_big<0, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, st, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
 }
 
-void launch_parse_waves(const GraphDev &g, bool def, const RangeView &v, const int32_t *biglist, int32_t *ctl, void *arena, int64_t arenaCap, int waves, int *err, hipStream_t st) {
+void launch_parse_waves(const GraphDev &g, int def, const RangeView &v, const int32_t *biglist, int32_t *ctl, void *arena, int64_t arenaCap, int waves, int *err, hipStream_t st) {
 	if (v.cnt <= 0) return;
-	if (def) hipLaunchKernelGGL((k_parse_big<true, 1, RangeView>), dim3(waves), dim3(64), 0, st, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
-	else hipLaunchKernelGGL((k_parse_big<false, 1, RangeView>), dim3(waves), dim3(64), 0, st, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
+	if (def == 1) hipLaunchKernelGGL((k_parse_big<1, 1, RangeView>), dim3(waves), dim3(64), 0, st, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
+	else if (def == 2) hipLaunchKernelGGL((k_parse_big<2, 1, RangeView>), dim3(waves), dim3(64), 0, st, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
+	else hipLaunchKernelGGL((k_parse_big<0, 1, RangeView>), dim3(waves), dim3(64), 0, st, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
 }
 
 // One chain level of the copy pass: three kernels, one per row class.  With side streams they run next to each
@@ -1234,7 +1250,7 @@ void copy_thresholds(int32_t midMinKnob, bool bigGroups, int32_t &midMin, int32_
 	bigMin = bigGroups ? COPY_BIG_MIN : 0x7fffffff; // !bigGroups: every row is merged by one lane
 	midMin = (midMinKnob <= 0 || midMinKnob > bigMin || !bigGroups) ? bigMin : midMinKnob; // = bigMin: no wave-per-row class
 }
-void launch_copy_level(const GraphDev &g, bool def, const RangeView &v, const int32_t *depth, const int32_t *list, const int32_t *keyBase, int32_t level, int blocks,
+void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int32_t *depth, const int32_t *list, const int32_t *keyBase, int32_t level, int blocks,
                        int32_t midMinKnob, bool bigGroups, const int32_t *bigQ, int32_t bigCap, const int32_t *midQ, int32_t midCap, int32_t *ctl, int32_t *tmp, uint32_t tmpCap, int *err,
                        hipStream_t st, hipStream_t stMid, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evMid, hipEvent_t evBig) {
 	if (v.cnt <= 0) return;
@@ -1247,25 +1263,29 @@ void launch_copy_level(const GraphDev &g, bool def, const RangeView &v, const in
 		if (stBig != st) (void)hipStreamWaitEvent(stBig, evFork, 0);
 	}
 	if (bigGroups) {
-		if (def) hipLaunchKernelGGL(k_copy_big<true>, dim3(512), dim3(COPY_BIG_THREADS), 0, stBig, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 7), err);
-		else hipLaunchKernelGGL(k_copy_big<false>, dim3(512), dim3(COPY_BIG_THREADS), 0, stBig, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 7), err);
+		if (def == 1) hipLaunchKernelGGL(k_copy_big<1>, dim3(512), dim3(COPY_BIG_THREADS), 0, stBig, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 7), err);
+		else if (def == 2) hipLaunchKernelGGL(k_copy_big<2>, dim3(512), dim3(COPY_BIG_THREADS), 0, stBig, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 7), err);
+		else hipLaunchKernelGGL(k_copy_big<0>, dim3(512), dim3(COPY_BIG_THREADS), 0, stBig, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 7), err);
 		if (stBig != st) (void)hipEventRecord(evBig, stBig);
 	}
 	if (midMin < bigMin) {
-		if (def) hipLaunchKernelGGL(k_copy_mid<true>, dim3(1024), dim3(64 * COPY_MID_WAVES), 0, stMid, g, v, depth, midQ, ctl + 6, midCap, level, err);
-		else hipLaunchKernelGGL(k_copy_mid<false>, dim3(1024), dim3(64 * COPY_MID_WAVES), 0, stMid, g, v, depth, midQ, ctl + 6, midCap, level, err);
+		if (def == 1) hipLaunchKernelGGL(k_copy_mid<1>, dim3(1024), dim3(64 * COPY_MID_WAVES), 0, stMid, g, v, depth, midQ, ctl + 6, midCap, level, err);
+		else if (def == 2) hipLaunchKernelGGL(k_copy_mid<2>, dim3(1024), dim3(64 * COPY_MID_WAVES), 0, stMid, g, v, depth, midQ, ctl + 6, midCap, level, err);
+		else hipLaunchKernelGGL(k_copy_mid<0>, dim3(1024), dim3(64 * COPY_MID_WAVES), 0, stMid, g, v, depth, midQ, ctl + 6, midCap, level, err);
 	}
 	if (stMid != st) (void)hipEventRecord(evMid, stMid);
-	if (def) hipLaunchKernelGGL(k_copy_list<true>, dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, midMin, bigMin, err);
-	else hipLaunchKernelGGL(k_copy_list<false>, dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, midMin, bigMin, err);
+	if (def == 1) hipLaunchKernelGGL(k_copy_list<1>, dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, midMin, bigMin, err);
+	else if (def == 2) hipLaunchKernelGGL(k_copy_list<2>, dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, midMin, bigMin, err);
+	else hipLaunchKernelGGL(k_copy_list<0>, dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, midMin, bigMin, err);
 	if (stMid != st) (void)hipStreamWaitEvent(st, evMid, 0);
 	if (bigGroups && stBig != st) (void)hipStreamWaitEvent(st, evBig, 0);
 }
 
-void launch_parse_list(const GraphDev &g, bool def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st) {
+void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st) {
 	if (v.cnt <= 0) return;
-	if (def) hipLaunchKernelGGL(k_parse_list<true>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, err);
-	else hipLaunchKernelGGL(k_parse_list<false>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, err);
+	if (def == 1) hipLaunchKernelGGL(k_parse_list<1>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, err);
+	else if (def == 2) hipLaunchKernelGGL(k_parse_list<2>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, err);
+	else hipLaunchKernelGGL(k_parse_list<0>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, err);
 }
 
 } // namespace bv

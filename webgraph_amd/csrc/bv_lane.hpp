@@ -22,7 +22,7 @@ namespace bv {
 constexpr int LANE_BURST = 16;
 constexpr int LANE_LDS_INTS_PER_THREAD = 2 * LANE_BURST; // out buffer + copy buffer, laid out [slot][thread]
 
-template <bool DEF, bool HAS_REF>
+template <int DEF, bool HAS_REF>
 __device__ __forceinline__ void decode_node_full(const GraphDev &g, int32_t x, int32_t d, int32_t r, int64_t dref, const int32_t *__restrict__ src,
                                                  int32_t *__restrict__ row, int32_t *lds, int *__restrict__ errOut) {
 	// lds: LANE_LDS_INTS_PER_THREAD * blockDim.x ints; slot j of this thread is lds[j * blockDim.x + threadIdx.x]

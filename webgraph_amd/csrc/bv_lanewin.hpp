@@ -25,6 +25,14 @@ __device__ __attribute__((noinline)) SlowAbs lane_code_slow(const uint32_t *bits
 	const uint64_t v = KIND == 2 ? br.unary() : KIND == 1 ? br.gamma() : br.template zeta_k<3>(3);
 	return SlowAbs{ v, br.pos(), br.err };
 }
+// zeta_k with the graph's k (kept apart: one more live argument across the call costs the zeta_3 kernels registers)
+__device__ __attribute__((noinline)) SlowAbs lane_zeta_slow(const uint32_t *bits, uint64_t nwords, uint64_t pos, int zetaK) {
+	BitReader br;
+	br.init(bits, nwords);
+	br.seek(pos);
+	const uint64_t v = br.template zeta_k<0>(zetaK);
+	return SlowAbs{ v, br.pos(), br.err };
+}
 
 template <int NWORDS> struct LaneWin {
 	uint32_t *col;  // this lane's LDS column
@@ -67,8 +75,8 @@ template <int NWORDS> struct LaneWin {
 			fill(g);
 		}
 	}
-	// KIND 0: zeta_3, 1: gamma, 2: unary
-	template <int KIND> __device__ __forceinline__ uint64_t code(const GraphDev &g, int &err) {
+	// KIND 0: zeta_k (ZK = 3: the default, folded in; 0: the graph's zetak at run time), 1: gamma, 2: unary
+	template <int KIND, int ZK = 3> __device__ __forceinline__ uint64_t code(const GraphDev &g, int &err) {
 		if (__builtin_expect((q >> 5) + 2 >= (uint32_t)NWORDS, 0)) { // keep three words ahead of the cursor inside the window
 			const uint32_t adv = (q >> 5) & ~3u;
 			w0 += adv;
@@ -81,15 +89,15 @@ template <int NWORDS> struct LaneWin {
 		uint32_t v, len;
 		if (KIND == 2) {
 			if (__builtin_expect(W != 0, 1)) { const uint32_t z = (uint32_t)__clz((int)W); q += z + 1; return z; }
-		} else if (__builtin_expect(KIND == 1 ? fast_gamma32(W, v, len) : fast_zeta3_32(W, v, len), 1)) { q += len; return v; }
+		} else if (__builtin_expect(KIND == 1 ? fast_gamma32(W, v, len) : fast_zeta_32<ZK>(W, ZK == 3 ? 3u : (uint32_t)g.zetaK, v, len), 1)) { q += len; return v; }
 		// up to 64 bits
 		const uint32_t c = col[(j + 2) * LW_STRIDE];
 		const uint64_t W64 = sh ? (ab << sh) | ((uint64_t)c >> (32u - sh)) : ab;
 		uint64_t v64;
 		if (KIND == 2) {
 			if (W64) { const uint32_t z = (uint32_t)__clzll((long long)W64); q += z + 1; return z; }
-		} else if (KIND == 1 ? fast_gamma(W64, v64, len) : fast_zeta3(W64, v64, len)) { q += len; return v64; }
-		const SlowAbs sa = lane_code_slow<KIND>(g.bits, g.nwords, pos());
+		} else if (KIND == 1 ? fast_gamma(W64, v64, len) : fast_zeta<ZK>(W64, ZK == 3 ? 3u : (uint32_t)g.zetaK, v64, len)) { q += len; return v64; }
+		const SlowAbs sa = (KIND == 0 && ZK != 3) ? lane_zeta_slow(g.bits, g.nwords, pos(), g.zetaK) : lane_code_slow<KIND>(g.bits, g.nwords, pos());
 		err |= sa.err;
 		seek(g, sa.pos);
 		return sa.v;
@@ -97,6 +105,7 @@ template <int NWORDS> struct LaneWin {
 };
 
 // Same contract as parse_node<true>: the extras (intervals merged with residuals) of node x go to row[copied..d).
+template <int ZK>
 __device__ __forceinline__ void parse_node_lw(const GraphDev &g, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row, uint32_t *lds, int *__restrict__ err) {
 	LaneWin<LW_MAIN> br;
 	LaneWin<LW_SIDE> bi; // second cursor, re-reads the interval section lazily during the merge
@@ -154,7 +163,7 @@ __device__ __forceinline__ void parse_node_lw(const GraphDev &g, int32_t x, int3
 	bool firstIv = true;
 	int32_t resTodo = (int32_t)nRes;
 	int32_t resVal = 0;
-	if (resTodo) resVal = (int32_t)((int64_t)x + nat2int(br.code<0>(g, e))); // BVG:954
+	if (resTodo) resVal = (int32_t)((int64_t)x + nat2int(br.template code<0, ZK>(g, e))); // BVG:954
 	while (k < nExtra) {
 		br.wave_refill<3>(g);
 		if (ivTodo) bi.wave_refill<6>(g); // an interval is two gamma codes
@@ -170,7 +179,7 @@ __device__ __forceinline__ void parse_node_lw(const GraphDev &g, int32_t x, int3
 		else if (resTodo) {
 			val = resVal;
 			if (ivRem && ivLeft == resVal) { ivLeft++; ivRem--; } // equal heads are emitted once (MergedIntIterator.java:69-72)
-			if (--resTodo) resVal += (int32_t)br.code<0>(g, e) + 1; // BVG:966
+			if (--resTodo) resVal += (int32_t)br.template code<0, ZK>(g, e) + 1; // BVG:966
 		} else val = -1; // malformed: fewer values than the outdegree promises (BVG:1210 would store -1)
 		if (k < head) { out[k++] = val; continue; }
 		o0 = o1; o1 = o2; o2 = o3; o3 = val; k++;

@@ -38,39 +38,39 @@ struct BatchView {
 	__device__ __forceinline__ int32_t *row(int64_t s) const { const int32_t qi = qidx[s]; return qi >= 0 ? succ + rowptr[qi] : arena + arow[s]; }
 };
 
-void launch_headers(const GraphDev &g, bool def, int32_t lo, int32_t cnt, int32_t *outd, uint16_t *ref, int *err, hipStream_t st);
+void launch_headers(const GraphDev &g, int def, int32_t lo, int32_t cnt, int32_t *outd, uint16_t *ref, int *err, hipStream_t st);
 void launch_mark_halo(int32_t nh, int32_t cnt, int32_t W, int32_t *outd, uint16_t *ref, uint8_t *need, int *err, hipStream_t st);
 void launch_scan(const int32_t *in, int64_t n, int64_t *out, int64_t *sums, hipStream_t st);
 int64_t scan_num_sums(int64_t n);
 void launch_depth(int32_t cnt, const uint16_t *ref, int32_t *depth, int32_t *maxdepth, hipStream_t st);
 void launch_rebase(int32_t nh, int32_t cnt, const int64_t *rowstart, int64_t *out, hipStream_t st);
-void launch_parse(const GraphDev &g, bool def, const RangeView &v, int *err, hipStream_t st);
-void launch_copy(const GraphDev &g, bool def, const RangeView &v, const int32_t *depth, int32_t level, int *err, hipStream_t st);
-void launch_chain_len(const GraphDev &g, bool def, const int32_t *nodes, int64_t q, int32_t *chainlen, int32_t *maxlen, int *err, hipStream_t st);
-void launch_chain_fill(const GraphDev &g, bool def, const int32_t *nodes, int64_t q, const int64_t *slotbase, int32_t *snode, int32_t *soutd,
+void launch_parse(const GraphDev &g, int def, const RangeView &v, int *err, hipStream_t st);
+void launch_copy(const GraphDev &g, int def, const RangeView &v, const int32_t *depth, int32_t level, int *err, hipStream_t st);
+void launch_chain_len(const GraphDev &g, int def, const int32_t *nodes, int64_t q, int32_t *chainlen, int32_t *maxlen, int *err, hipStream_t st);
+void launch_chain_fill(const GraphDev &g, int def, const int32_t *nodes, int64_t q, const int64_t *slotbase, int32_t *snode, int32_t *soutd,
                        int32_t *sdepth, int32_t *sq, int32_t *aoutd, int32_t *qoutd, hipStream_t st);
-void launch_bparse(const GraphDev &g, bool def, const BatchView &v, int *err, hipStream_t st);
-void launch_bcopy(const GraphDev &g, bool def, const BatchView &v, int32_t level, int *err, hipStream_t st);
+void launch_bparse(const GraphDev &g, int def, const BatchView &v, int *err, hipStream_t st);
+void launch_bcopy(const GraphDev &g, int def, const BatchView &v, int32_t level, int *err, hipStream_t st);
 void launch_classify(int32_t cnt, const int32_t *outd, int32_t coopMin, int32_t giantMin, int32_t *biglist, int32_t *giantlist, int32_t giantCap, int32_t *ctl, hipStream_t st);
-void launch_parse_big(const GraphDev &g, bool def, const RangeView &v, const int32_t *biglist, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap,
+void launch_parse_big(const GraphDev &g, int def, const RangeView &v, const int32_t *biglist, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap,
                       int waves, int giantGroups, int *err, hipStream_t stGiant, hipStream_t stBig);
 constexpr int ARENA_ENTRY_BYTES = 16;
 void launch_build_lists(const GraphDev &g, const RangeView &v, uint64_t giantBits, int32_t noBin, int32_t *depth, uint16_t *key16, int32_t *hist, int32_t *keyBase, int32_t *cursor,
                         int32_t *list, int32_t *giantlist, int32_t giantCap, int32_t *ctl, int32_t *maxdepth, hipStream_t st,
                         int32_t *bigQ = nullptr, int32_t bigCap = 0, int32_t *midQ = nullptr, int32_t midCap = 0, int32_t midMinKnob = 0, bool bigGroups = false);
-void launch_decode_level(const GraphDev &g, bool def, const RangeView &v, const int32_t *depth, const int32_t *list, const int32_t *keyBase, int32_t level, int blocks,
+void launch_decode_level(const GraphDev &g, int def, const RangeView &v, const int32_t *depth, const int32_t *list, const int32_t *keyBase, int32_t level, int blocks,
                          int *err, hipStream_t st);
-void launch_copy_giants(const GraphDev &g, bool def, const RangeView &v, const int32_t *depth, const int32_t *giantlist, const int32_t *ctl, int32_t giantCap, int32_t level,
+void launch_copy_giants(const GraphDev &g, int def, const RangeView &v, const int32_t *depth, const int32_t *giantlist, const int32_t *ctl, int32_t giantCap, int32_t level,
                         int *err, hipStream_t st);
-void launch_copy_level(const GraphDev &g, bool def, const RangeView &v, const int32_t *depth, const int32_t *list, const int32_t *keyBase, int32_t level, int blocks,
+void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int32_t *depth, const int32_t *list, const int32_t *keyBase, int32_t level, int blocks,
                        int32_t midMinKnob, bool bigGroups, const int32_t *bigQ, int32_t bigCap, const int32_t *midQ, int32_t midCap, int32_t *ctl, int32_t *tmp, uint32_t tmpCap, int *err,
                        hipStream_t st, hipStream_t stMid, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evMid, hipEvent_t evBig);
-void launch_parse_list(const GraphDev &g, bool def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st);
-void launch_parse_waves(const GraphDev &g, bool def, const RangeView &v, const int32_t *biglist, int32_t *ctl, void *arena, int64_t arenaCap, int waves, int *err, hipStream_t st);
-void launch_parse_giants(const GraphDev &g, bool def, const RangeView &v, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap, int giantGroups, int *err, hipStream_t st);
+void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st);
+void launch_parse_waves(const GraphDev &g, int def, const RangeView &v, const int32_t *biglist, int32_t *ctl, void *arena, int64_t arenaCap, int waves, int *err, hipStream_t st);
+void launch_parse_giants(const GraphDev &g, int def, const RangeView &v, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap, int giantGroups, int *err, hipStream_t st);
 void launch_hash(int32_t from, int32_t cnt, const int64_t *rowptr, const int32_t *succ, uint32_t *A, uint32_t *B, int32_t *hash, hipStream_t st);
 
-void launch_bparse_big(const GraphDev &g, bool def, const BatchView &v, int32_t coopMin, int32_t giantMin, int32_t *biglist, int32_t *giantlist, int32_t giantCap, int32_t *ctl,
+void launch_bparse_big(const GraphDev &g, int def, const BatchView &v, int32_t coopMin, int32_t giantMin, int32_t *biglist, int32_t *giantlist, int32_t giantCap, int32_t *ctl,
                        void *arena, int64_t arenaCap, int waves, int giantGroups, int *err, hipStream_t st, hipStream_t stGiant, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evGiant, hipEvent_t evBig);
 
 // bv_offsets.hip: gamma-coded .offsets stream (words + >= 8 zero words in HBM) -> int64 offsets[nodes + 1] in HBM

@@ -47,14 +47,14 @@ __global__ void __launch_bounds__(64) k_off_parse(const uint32_t *__restrict__ w
 		uint32_t p = (uint32_t)(posW - base);
 		const uint32_t a0 = (uint32_t)(anchor - base);
 		int err = 0;
-		while (p < a0 && !err) (void)win_code_rel<true, 2>(g, src, p, err);
+		while (p < a0 && !err) (void)win_code_rel<1, 2>(g, src, p, err);
 		start = err ? anchor : base + p;
 	}
 	// a start that is not in [anchor, anchor + 64 + OFF_SEG) cannot come from a valid stream: keep the lanes in range
 	if (start < anchor) start = anchor;
 	if (start > anchor + OFF_SEG) start = anchor + OFF_SEG;
 	uint32_t s, n; int64_t sum; uint64_t E;
-	spec_tile<true, 2, 1>(G, g, src, start, totalBits, OFF_SEG, false, INT64_MAX, s, n, sum, E, anchor);
+	spec_tile<1, 2, 1>(G, g, src, start, totalBits, OFF_SEG, false, INT64_MAX, s, n, sum, E, anchor);
 	int64_t ntot, stot;
 	(void)G.incl_scan((int64_t)n, ntot);
 	(void)G.incl_scan(sum, stot);
@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(64) k_off_values(const uint32_t *__restrict__ 
 	uint32_t p = (uint32_t)(anchor + me.s - (src.w0 << 5));
 	int err = 0;
 	for (uint32_t k = 0; k < me.c; k++) {
-		const int64_t v = (int64_t)win_code_rel<true, 2>(g, src, p, err);
+		const int64_t v = (int64_t)win_code_rel<1, 2>(g, src, p, err);
 		acc += v;
 		if (idx < nOut) out[idx] = (T)(PREFIX ? acc : v); // offsets: running sum of the gaps; labels: the values themselves
 		idx++;

@@ -43,7 +43,7 @@ struct Staged {
 	uint64_t nwords = 0;
 	int64_t *d_offsets = nullptr;
 	std::vector<int64_t> h_offsets; // host copy: shard bounds and halo sizing
-	bool def = false;               // default coding set and zeta_3 -> compile-time specialised kernels
+	int def = 0;                    // kernel variant: 1 default codings with zeta_3, 2 default codings with another zeta_k, 0 generic
 	std::string basename;
 	~Staged() {
 		if (device >= 0) (void)hipSetDevice(device);
@@ -516,8 +516,11 @@ extern "C" int bvg_open(const char *basename, int device, bvg_t **out) {
 	    !okc(in.residual_coding, { BVG_GAMMA, BVG_ZETA, BVG_DELTA, BVG_GOLOMB, BVG_NIBBLE }) || !okc(in.offset_coding, { BVG_GAMMA, BVG_DELTA }))
 		return fail(g, BVG_EUNSUPPORTED, "The required coding is not supported");
 	st->basename = basename;
-	st->def = in.outdegree_coding == BVG_GAMMA && in.block_coding == BVG_GAMMA && in.block_count_coding == BVG_GAMMA &&
-	          in.reference_coding == BVG_UNARY && in.residual_coding == BVG_ZETA && in.zeta_k == 3;
+	// kernel variant: 1 = every coding is the default one and zeta_3 (constants folded in), 2 = the default codings
+	// with another zeta_k (taken at run time), 0 = anything else (generic readers)
+	const bool defaults = in.outdegree_coding == BVG_GAMMA && in.block_coding == BVG_GAMMA && in.block_count_coding == BVG_GAMMA &&
+	                      in.reference_coding == BVG_UNARY && in.residual_coding == BVG_ZETA;
+	st->def = !defaults ? 0 : in.zeta_k == 3 ? 1 : (in.zeta_k >= 1 && in.zeta_k <= 16) ? 2 : 0;
 
 	std::vector<uint8_t> graph, offs;
 	if (!bvh::read_file(st->basename + ".graph", graph, err)) return fail(g, BVG_EIO, err);
