@@ -7,10 +7,19 @@ from conftest import CNR, make_graph
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def cnr_gpu():
+# the two random-access strategies of the library: per-query chains of slots / a masked scan of the graph plus a gather
+BATCH_MODES = {"slots": "0", "dense": "1000000000"}
+
+
+@pytest.fixture(scope="module", params=list(BATCH_MODES))
+def cnr_gpu(request):
+    import os
     from webgraph_amd.bvgraph import BVGraph
-    g = BVGraph.load(CNR)
+    os.environ["BVGPU_BATCH_DENSE"] = BATCH_MODES[request.param]  # read when the handle is made
+    try:
+        g = BVGraph.load(CNR)
+    finally:
+        del os.environ["BVGPU_BATCH_DENSE"]
     yield g
     g.close()
 
@@ -47,9 +56,11 @@ def test_empty_batch_and_errors(cnr_gpu):
         cnr_gpu.successorArray(325557)
 
 
-def test_deep_chains_random_access(tmp_path_factory):
+@pytest.mark.parametrize("mode", list(BATCH_MODES))
+def test_deep_chains_random_access(tmp_path_factory, monkeypatch, mode):
     from webgraph_amd.bvgraph import BVGraph
     from oracle import oracle as O
+    monkeypatch.setenv("BVGPU_BATCH_DENSE", BATCH_MODES[mode])
     base, rowptr, succ = make_graph(tmp_path_factory, "deepra", 20000, 300000, 31, 0.95, window=7, max_ref_count=50, min_interval=2)
     g = BVGraph.load(base)
     q = np.random.default_rng(3).integers(0, 20000, 5000).astype(np.int32)

@@ -293,6 +293,8 @@ LONG_ROW_CASES = [
     ("zeta7", 0, 7, {}),  # codewords outgrow the 32-bit window early: the 64-bit and generic fallbacks run
     ("zeta16", 0, 16, {}),
     ("zeta5_small_thresholds", 0, 5, {"BVGPU_COOP_MIN": "64", "BVGPU_GIANT_MIN": "2000"}),
+    ("batch_dense", 0, 3, {"BVGPU_BATCH_DENSE": "1000000000"}),  # random access as a masked scan + gather
+    ("batch_dense_small_thresholds", 0, 3, {"BVGPU_BATCH_DENSE": "1000000000", "BVGPU_COOP_MIN": "64", "BVGPU_GIANT_MIN": "2000"}),
 ]
 
 

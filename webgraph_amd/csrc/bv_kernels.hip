@@ -85,6 +85,49 @@ __global__ void k_apply_need(int32_t nh, const uint8_t *__restrict__ need, int32
 	if (s < nh && !need[s]) { outd[s] = 0; ref[s] = 0; }
 }
 
+// ------------------------------------------------------------------------------------------------ dense batches
+// A batch of random-access queries that touches a good part of the graph is decoded as a MASKED scan: every queried
+// node and every node on its reference chain is marked, the others get outdegree 0 (k_apply_need) and drop out of
+// the scan; each needed record is then decoded ONCE, however many queries (or chains) want it, and the rows are
+// gathered into the caller's order at the end (k_gather_rows).
+__global__ void k_query_mark(const int32_t *__restrict__ nodes, int64_t q, int32_t n, const int32_t *__restrict__ outd, const uint16_t *__restrict__ ref,
+                             uint8_t *need, int32_t *__restrict__ qoutd, int *__restrict__ err) {
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= q) return;
+	const int32_t x = nodes[i];
+	if ((uint32_t)x >= (uint32_t)n) { atomicOr(err, E_ARG); qoutd[i] = 0; return; } // BVG:900
+	qoutd[i] = outd[x];
+	if (!need) return; // count only
+	// walk the chain; whoever marks a node first goes on from there, so a marked node ends the walk
+	int32_t y = x;
+	while (!need[y]) {
+		need[y] = 1;
+		if (outd[y] <= 0 || ref[y] == 0) break;
+		y -= (int32_t)ref[y]; // >= 0: k_headers drops references before node 0
+	}
+}
+
+constexpr int GATHER_ROWS = 256;
+__global__ __launch_bounds__(GATHER_ROWS) void k_gather_rows(const int32_t *__restrict__ nodes, int64_t q, const int64_t *__restrict__ rowstart, const int32_t *__restrict__ arena,
+                                                             const int64_t *__restrict__ rowptr, int32_t *__restrict__ succ) {
+	__shared__ int64_t src[GATHER_ROWS], dst[GATHER_ROWS + 1];
+	const int64_t base = (int64_t)blockIdx.x * GATHER_ROWS;
+	const int t = threadIdx.x;
+	const int64_t i = min(base + t, q - 1);
+	src[t] = rowstart[nodes[i]];
+	dst[t] = rowptr[min(base + t, q)];
+	if (t == 0) dst[GATHER_ROWS] = rowptr[min(base + GATHER_ROWS, q)];
+	__syncthreads();
+	const int64_t d0 = dst[0], total = dst[GATHER_ROWS] - d0;
+	for (int64_t e = t; e < total; e += GATHER_ROWS) {
+		const int64_t pos = d0 + e;
+		int j = 0; // last row of the block that starts at or before pos
+#pragma unroll
+		for (int step = GATHER_ROWS / 2; step > 0; step >>= 1) if (dst[j + step] <= pos) j += step;
+		succ[pos] = arena[src[j] + (pos - dst[j])];
+	}
+}
+
 // ------------------------------------------------------------------------------------------------ scan
 // Three-phase exclusive scan int32 -> int64 (block sums, scan of the sums, block scan + carry).
 constexpr int SCAN_ITEMS = 4;
@@ -1104,6 +1147,14 @@ void launch_depth(int32_t cnt, const uint16_t *ref, int32_t *depth, int32_t *max
 	hipLaunchKernelGGL(k_depth, dim3(nblk(cnt, TPB)), dim3(TPB), 0, st, cnt, ref, depth, maxdepth);
 }
 
+void launch_query_mark(const int32_t *nodes, int64_t q, int32_t n, int32_t *outd, uint16_t *ref, uint8_t *need, int32_t *qoutd, int *err, hipStream_t st) {
+	if (need) (void)hipMemsetAsync(need, 0, (size_t)n, st);
+	hipLaunchKernelGGL(k_query_mark, dim3(nblk(q, TPB)), dim3(TPB), 0, st, nodes, q, n, outd, ref, need, qoutd, err);
+	if (need) hipLaunchKernelGGL(k_apply_need, dim3(nblk(n, TPB)), dim3(TPB), 0, st, n, need, outd, ref);
+}
+void launch_gather_rows(const int32_t *nodes, int64_t q, const int64_t *rowstart, const int32_t *arena, const int64_t *rowptr, int32_t *succ, hipStream_t st) {
+	if (q > 0) hipLaunchKernelGGL(k_gather_rows, dim3(nblk(q, GATHER_ROWS)), dim3(GATHER_ROWS), 0, st, nodes, q, rowstart, arena, rowptr, succ);
+}
 void launch_rebase(int32_t nh, int32_t cnt, const int64_t *rowstart, int64_t *out, hipStream_t st) {
 	hipLaunchKernelGGL(k_rebase, dim3(nblk((int64_t)cnt - nh + 1, TPB)), dim3(TPB), 0, st, nh, cnt, rowstart, out);
 }

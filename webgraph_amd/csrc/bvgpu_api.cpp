@@ -102,6 +102,7 @@ struct bvg_graph {
 	hipStream_t sideA = nullptr, sideB = nullptr; // (more streams than this share hardware queues with each other: they would serialise)
 	hipEvent_t evFork = nullptr, evA = nullptr, evB = nullptr, evC = nullptr;
 	bool overlap = true;
+	int batch_dense = 16;   // a random-access batch of q nodes with q * batch_dense >= n is decoded as a masked scan of the graph (0: never)
 	Small *h_small = nullptr; // pinned
 	int32_t levels_hint = 1;
 	Pending pend;
@@ -170,6 +171,7 @@ int init_handle(bvg_graph *g) {
 	if (const char *e = getenv("BVGPU_PARSE_WINDOWS")) g->parse_windows = atoi(e);
 	if (const char *e = getenv("BVGPU_COPY_MID_MIN")) g->copy_mid_min = std::min(std::max(0, atoi(e)), 1024); // 0: no wave-per-row copy
 	if (const char *e = getenv("BVGPU_OVERLAP")) g->overlap = atoi(e) != 0;
+	if (const char *e = getenv("BVGPU_BATCH_DENSE")) g->batch_dense = std::max(0, atoi(e));
 	HIPCHK(g, hipStreamCreateWithFlags(&g->sideA, hipStreamNonBlocking));
 	HIPCHK(g, hipStreamCreateWithFlags(&g->sideB, hipStreamNonBlocking));
 	HIPCHK(g, hipEventCreateWithFlags(&g->evFork, hipEventDisableTiming));
@@ -276,52 +278,16 @@ int finish_pending(bvg_graph *g, uint64_t *arcs_out) {
 	return BVG_OK;
 }
 
-// Device-pointer core of bvg_decode_range.  rowptr_dev: to-from+1 int64; succ_dev may be NULL (count only).
-int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_dev, int32_t *succ_dev, size_t succ_cap, bool async, uint64_t *arcs_out) {
+// Enqueues the decode proper for a view whose structure (outdegrees, references, row starts) is in place: parse of
+// every record, then `levels_hint` levels of the copy pass (finish_pending launches the levels still missing).
+int enqueue_decode(bvg_graph *g, bv::RangeView &v, int32_t &levels, int32_t &giantCap) {
 	const Staged &s = *g->st;
-	HIPCHK(g, hipSetDevice(s.device));
-	if (g->pend.active) { int rc = finish_pending(g, nullptr); if (rc) return rc; }
 	const int32_t W = s.info.window_size;
-	{ int rc = fork_from_user(g); if (rc) return rc; }
-	HIPCHK(g, hipMemsetAsync(g->small.p, 0, sizeof(Small), g->stream));
-	if (to == from) {
-		HIPCHK(g, hipMemsetAsync(rowptr_dev, 0, sizeof(int64_t), g->stream));
-		{ int rc = join_to_user(g); if (rc) return rc; }
-		if (!async) HIPCHK(g, hipStreamSynchronize(g->stream));
-		g->last_arcs = 0;
-		if (arcs_out) *arcs_out = 0;
-		return BVG_OK;
-	}
-	// halo: only needed when successors are wanted and the range does not start at node 0
-	int32_t nh = 0;
-	if (succ_dev && from > 0 && W > 0) {
-		const int64_t mr = s.info.max_ref_count < 1 ? 1 : std::min(s.info.max_ref_count, 64);
-		nh = (int32_t)std::min<int64_t>(from, (int64_t)W * mr);
-	}
-	bv::RangeView v;
-	for (;;) {
-		int rc = enqueue_structure(g, from, to, nh, v);
-		if (rc) return rc;
-		if (nh == 0) break;
-		// the halo buffer size and the "chain escaped the window" flag need a round trip
-		hipLaunchKernelGGL(k_totals, dim3(1), dim3(1), 0, g->stream, v.rowstart, v.nh, v.cnt, g->small.as<Small>());
-		rc = fetch_small(g);
-		if (rc) return rc;
-		if (g->h_small->err & bv::E_ESCAPED) {
-			if (nh == from) return fail(g, BVG_EFORMAT, "reference chain runs before node 0");
-			nh = (int32_t)std::min<int64_t>(from, (int64_t)nh * 8);
-			HIPCHK(g, hipMemsetAsync(g->small.p, 0, sizeof(Small), g->stream));
-			continue;
-		}
-		if (!g->halo.need(sizeof(int32_t) * (size_t)std::max<int64_t>(g->h_small->halo_total, 1))) return fail(g, BVG_ENOMEM, "halo allocation failed");
-		break;
-	}
-	v.succ = succ_dev; v.halo = g->halo.as<int32_t>(); v.succ_cap = succ_cap;
 	int *derr = &g->small.as<Small>()->err;
 	const bv::GraphDev gd = graph_dev(s);
-	int32_t levels = 0;
-	int32_t giantCap = 0;
-	if (succ_dev && !g->fused) {
+	levels = 0;
+	giantCap = 0;
+	if (!g->fused) {
 		// default path: depth + per-level lists; cooperative decode of long records (two classes) next to the
 		// one-lane decode of the short ones; then the copy pass level by level over compact lists
 		const int64_t arcsBound = std::max<int64_t>(s.info.arcs, 1);
@@ -408,7 +374,7 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 			}
 		}
 	}
-	if (succ_dev && g->fused) {
+	if (g->fused) {
 		const int64_t arcsBound = std::max<int64_t>(s.info.arcs, 1);
 		// a giant record has >= giant_bits bits; the whole stream has graph_bytes * 8
 		// a giant record has >= giant_bits bits or >= giant_bits / 8 successors
@@ -443,6 +409,53 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 			}
 		}
 	}
+	return BVG_OK;
+}
+
+// Device-pointer core of bvg_decode_range.  rowptr_dev: to-from+1 int64; succ_dev may be NULL (count only).
+int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_dev, int32_t *succ_dev, size_t succ_cap, bool async, uint64_t *arcs_out) {
+	const Staged &s = *g->st;
+	HIPCHK(g, hipSetDevice(s.device));
+	if (g->pend.active) { int rc = finish_pending(g, nullptr); if (rc) return rc; }
+	const int32_t W = s.info.window_size;
+	{ int rc = fork_from_user(g); if (rc) return rc; }
+	HIPCHK(g, hipMemsetAsync(g->small.p, 0, sizeof(Small), g->stream));
+	if (to == from) {
+		HIPCHK(g, hipMemsetAsync(rowptr_dev, 0, sizeof(int64_t), g->stream));
+		{ int rc = join_to_user(g); if (rc) return rc; }
+		if (!async) HIPCHK(g, hipStreamSynchronize(g->stream));
+		g->last_arcs = 0;
+		if (arcs_out) *arcs_out = 0;
+		return BVG_OK;
+	}
+	// halo: only needed when successors are wanted and the range does not start at node 0
+	int32_t nh = 0;
+	if (succ_dev && from > 0 && W > 0) {
+		const int64_t mr = s.info.max_ref_count < 1 ? 1 : std::min(s.info.max_ref_count, 64);
+		nh = (int32_t)std::min<int64_t>(from, (int64_t)W * mr);
+	}
+	bv::RangeView v;
+	for (;;) {
+		int rc = enqueue_structure(g, from, to, nh, v);
+		if (rc) return rc;
+		if (nh == 0) break;
+		// the halo buffer size and the "chain escaped the window" flag need a round trip
+		hipLaunchKernelGGL(k_totals, dim3(1), dim3(1), 0, g->stream, v.rowstart, v.nh, v.cnt, g->small.as<Small>());
+		rc = fetch_small(g);
+		if (rc) return rc;
+		if (g->h_small->err & bv::E_ESCAPED) {
+			if (nh == from) return fail(g, BVG_EFORMAT, "reference chain runs before node 0");
+			nh = (int32_t)std::min<int64_t>(from, (int64_t)nh * 8);
+			HIPCHK(g, hipMemsetAsync(g->small.p, 0, sizeof(Small), g->stream));
+			continue;
+		}
+		if (!g->halo.need(sizeof(int32_t) * (size_t)std::max<int64_t>(g->h_small->halo_total, 1))) return fail(g, BVG_ENOMEM, "halo allocation failed");
+		break;
+	}
+	v.succ = succ_dev; v.halo = g->halo.as<int32_t>(); v.succ_cap = succ_cap;
+	int32_t levels = 0;
+	int32_t giantCap = 0;
+	if (succ_dev) { int rc = enqueue_decode(g, v, levels, giantCap); if (rc) return rc; }
 	if (!succ_dev) { mark(g, 3); mark(g, 4); mark(g, 5); mark(g, 6); }
 	mark(g, 7);
 	bv::launch_rebase(v.nh, v.cnt, v.rowstart, rowptr_dev, g->stream);
@@ -713,6 +726,57 @@ extern "C" int bvg_successors_batch(bvg_t *g, const int32_t *nodes, size_t q, in
 		if (!dev) HIPCHK(g, hipMemcpyAsync(rowptr, d_rowptr, sizeof(int64_t), hipMemcpyDeviceToHost, g->stream));
 		HIPCHK(g, hipStreamSynchronize(g->stream));
 		if (arcs_out) *arcs_out = 0;
+		return BVG_OK;
+	}
+	if (g->batch_dense > 0 && (uint64_t)q * (uint64_t)g->batch_dense >= (uint64_t)s.info.nodes) {
+		// Dense batch: a masked scan of the whole graph (every needed record is decoded once, however many queries or
+		// reference chains want it), then a gather of the rows into the caller's order.
+		const int32_t n = s.info.nodes;
+		if (!g->outd.need(sizeof(int32_t) * (size_t)n) || !g->ref.need(sizeof(uint16_t) * (size_t)n) || !g->rowstart.need(sizeof(int64_t) * ((size_t)n + 1)) ||
+		    !g->sums.need(sizeof(int64_t) * (size_t)bv::scan_num_sums((int64_t)std::max<size_t>((size_t)n, q))) || !g->b_qoutd.need(sizeof(int32_t) * q) || (succ && !g->need.need((size_t)n)))
+			return fail(g, BVG_ENOMEM, "device scratch allocation failed");
+		bv::RangeView v{};
+		v.lo = 0; v.cnt = n; v.nh = n; // every row lives in the arena ("halo" rows of the scan)
+		v.outd = g->outd.as<int32_t>(); v.ref = g->ref.as<uint16_t>(); v.rowstart = g->rowstart.as<int64_t>();
+		bv::launch_headers(gd, s.def, 0, n, v.outd, v.ref, &dsm->err, g->stream);
+		bv::launch_query_mark(d_nodes, (int64_t)q, n, v.outd, v.ref, succ ? g->need.as<uint8_t>() : nullptr, g->b_qoutd.as<int32_t>(), &dsm->err, g->stream);
+		bv::launch_scan(g->b_qoutd.as<int32_t>(), (int64_t)q, d_rowptr, g->sums.as<int64_t>(), g->stream);
+		HIPCHK(g, hipMemcpyAsync(&dsm->total, d_rowptr + q, sizeof(int64_t), hipMemcpyDeviceToDevice, g->stream));
+		if (succ) {
+			bv::launch_scan(v.outd, n, v.rowstart, g->sums.as<int64_t>(), g->stream);
+			HIPCHK(g, hipMemcpyAsync(&dsm->halo_total, v.rowstart + n, sizeof(int64_t), hipMemcpyDeviceToDevice, g->stream));
+		}
+		int rc = fetch_small(g);
+		if (rc) return rc;
+		if (g->h_small->err) {
+			const int e = g->h_small->err;
+			if (e & bv::E_ARG) return fail(g, BVG_EARG, "Node index out of range");
+			return fail(g, dev_err_to_status(e), "malformed bit stream");
+		}
+		const uint64_t arcs = (uint64_t)g->h_small->total;
+		g->last_arcs = arcs;
+		if (arcs_out) *arcs_out = arcs;
+		if (!dev) HIPCHK(g, hipMemcpyAsync(rowptr, d_rowptr, sizeof(int64_t) * (q + 1), hipMemcpyDeviceToHost, g->stream));
+		if (!succ) { HIPCHK(g, hipStreamSynchronize(g->stream)); return BVG_OK; }
+		if (arcs > succ_cap) { HIPCHK(g, hipStreamSynchronize(g->stream)); return fail(g, BVG_ECAP, "successor buffer too small"); }
+		int32_t *d_succ = succ;
+		if (!dev) {
+			if (!g->stage_succ.need(sizeof(int32_t) * (size_t)std::max<uint64_t>(arcs, 1))) return fail(g, BVG_ENOMEM, "staging allocation failed");
+			d_succ = g->stage_succ.as<int32_t>();
+		}
+		if (!g->halo.need(sizeof(int32_t) * (size_t)std::max<int64_t>(g->h_small->halo_total, 1))) return fail(g, BVG_ENOMEM, "arena allocation failed");
+		v.succ = nullptr; v.halo = g->halo.as<int32_t>(); v.succ_cap = 0;
+		int32_t levels = 0, giantCap = 0;
+		rc = enqueue_decode(g, v, levels, giantCap);
+		if (rc) return rc;
+		HIPCHK(g, hipGetLastError());
+		g->pend.active = true; g->pend.view = v; g->pend.levels_done = levels; g->pend.want_succ = true; g->pend.giantCap = giantCap;
+		rc = finish_pending(g, nullptr); // the levels of the copy pass still missing, errors
+		if (rc) return rc;
+		bv::launch_gather_rows(d_nodes, (int64_t)q, v.rowstart, v.halo, d_rowptr, d_succ, g->stream);
+		if (!dev && arcs) HIPCHK(g, hipMemcpyAsync(succ, d_succ, sizeof(int32_t) * (size_t)arcs, hipMemcpyDeviceToHost, g->stream));
+		HIPCHK(g, hipStreamSynchronize(g->stream));
+		HIPCHK(g, hipGetLastError());
 		return BVG_OK;
 	}
 	// 1. chain lengths -> slot bases
