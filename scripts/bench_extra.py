@@ -8,6 +8,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def main():
@@ -63,6 +64,8 @@ def main():
                  "gpu_queries_per_s": q.size / dt, "gpu_edges_per_s": float(rp[-1]) / dt, "parity": "first %d queries bit-exact vs oracle" % k,
                  "cpu_oracle_queries_per_s": k / cdt, "cpu_cores": 1}
     g.close()
+    import c4_time
+    out["C4_device_resident"] = c4_time.run(10_000_000)  # ids and outputs in HBM, one call
     print(json.dumps(out))
 
 

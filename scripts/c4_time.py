@@ -10,14 +10,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main():
+def run(nq=None):
     import numpy as np
     import torch
     import bench
     from webgraph_amd import bvgraph as B
     from oracle import oracle as O
     n, m = 10_000_000, 200_000_000
-    nq = int(os.environ.get("C4_QUERIES", "10000000"))
+    nq = nq or int(os.environ.get("C4_QUERIES", "10000000"))
     base, meta = bench.prepare_graph(n, m, bench.SEED, 0.5, "/tmp/bvgpu_cache", os.cpu_count())
     g = B.BVGraph.load(base)
     rng = np.random.Generator(np.random.PCG64(0x5EEDB5E70004))
@@ -49,6 +49,12 @@ def main():
     print("C4 device-resident: %d queries, %d arcs: %.2f ms = %.1f M queries/s, %.2f G edges/s (all runs ms: %s), first %d bit-exact: %s"
           % (nq, arcs.value, dt * 1e3, nq / dt / 1e6, arcs.value / dt / 1e9, " ".join("%.1f" % (t * 1e3) for t in times), k, ok))
     g.close()
+    return {"queries": nq, "arcs_out": int(arcs.value), "gpu_ms_device_resident": dt * 1e3, "gpu_queries_per_s": nq / dt, "gpu_edges_per_s": arcs.value / dt,
+            "parity": "first %d queries bit-exact vs oracle: %s" % (k, ok)}
+
+
+def main():
+    run()
 
 
 if __name__ == "__main__":

@@ -85,3 +85,25 @@ def test_cpp_host_mirror_runs(tmp_path):
     p = subprocess.run([exe, CNR, "1711395807", "3216152"], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
     assert "host mirror ok" in p.stdout
+
+
+@pytest.mark.parametrize("shift", [1, 2, 3])
+def test_device_buffers_need_not_be_16_byte_aligned(cnr_gpu, cnr_oracle, shift):
+    """Device-pointer form of the batch call with an output buffer that starts `shift` ints past an aligned address."""
+    import ctypes as C
+    import torch
+    from webgraph_amd import bvgraph as B
+    og, rowptr, succ = cnr_oracle
+    q = np.random.default_rng(shift).integers(0, cnr_gpu.numNodes(), 40000).astype(np.int32)
+    q[0] = 46918
+    orp, osc = og.successors_batch(q)
+    dev = torch.device("cuda", 0)
+    d_q = torch.from_numpy(q).to(dev)
+    d_rp = torch.empty(q.size + 1, dtype=torch.int64, device=dev)
+    d_sc = torch.full((osc.size + 8,), -7, dtype=torch.int32, device=dev)
+    arcs = C.c_uint64(0)
+    rc = B.lib().bvg_successors_batch(cnr_gpu._h, d_q.data_ptr(), q.size, d_rp.data_ptr(), d_sc.data_ptr() + 4 * shift, osc.size, C.byref(arcs), B.BVG_OUT_DEVICE)
+    assert rc == 0 and arcs.value == osc.size
+    out = d_sc.cpu().numpy()
+    assert np.array_equal(d_rp.cpu().numpy(), orp) and np.array_equal(out[shift:shift + osc.size], osc)
+    assert (out[:shift] == -7).all() and (out[shift + osc.size:] == -7).all()  # nothing written outside the rows

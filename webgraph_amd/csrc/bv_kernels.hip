@@ -118,13 +118,29 @@ __global__ __launch_bounds__(GATHER_ROWS) void k_gather_rows(const int32_t *__re
 	dst[t] = rowptr[min(base + t, q)];
 	if (t == 0) dst[GATHER_ROWS] = rowptr[min(base + GATHER_ROWS, q)];
 	__syncthreads();
-	const int64_t d0 = dst[0], total = dst[GATHER_ROWS] - d0;
-	for (int64_t e = t; e < total; e += GATHER_ROWS) {
-		const int64_t pos = d0 + e;
-		int j = 0; // last row of the block that starts at or before pos
+	// four consecutive ids per lane and step, on 16-byte boundaries of the output: one search per four ids
+	const int64_t d0 = dst[0], d1 = dst[GATHER_ROWS];
+	const int64_t mis = (int64_t)(((uintptr_t)succ >> 2) & 3); // the caller's buffer need not be 16-byte aligned
+	for (int64_t pos = ((d0 + mis) & ~(int64_t)3) - mis + 4 * (int64_t)t; pos < d1; pos += 4 * GATHER_ROWS) {
+		const int64_t first = max(pos, d0);
+		int j = 0; // last row of the block that starts at or before `first`
 #pragma unroll
-		for (int step = GATHER_ROWS / 2; step > 0; step >>= 1) if (dst[j + step] <= pos) j += step;
-		succ[pos] = arena[src[j] + (pos - dst[j])];
+		for (int step = GATHER_ROWS / 2; step > 0; step >>= 1) if (dst[j + step] <= first) j += step;
+		int32_t val[4];
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const int64_t p = pos + k;
+			val[k] = 0;
+			if (p >= d0 && p < d1) {
+				while (dst[j + 1] <= p) j++; // (dst[GATHER_ROWS] = d1 > p ends it)
+				val[k] = arena[src[j] + (p - dst[j])];
+			}
+		}
+		if (pos >= d0 && pos + 4 <= d1) *(int4 *)(succ + pos) = int4{ val[0], val[1], val[2], val[3] };
+		else {
+#pragma unroll
+			for (int k = 0; k < 4; k++) if (pos + k >= d0 && pos + k < d1) succ[pos + k] = val[k];
+		}
 	}
 }
 
