@@ -94,6 +94,7 @@ struct bvg_graph {
 	int copy_mid_min = 128; // rows with at least this many successors (and fewer than 1024) are copied by one wave each
 	int copy_lists = 1; // BVGPU_COPY_LISTS=0: node-order sweeps over all slots instead of per-level compact lists
 	int32_t coop_min = 2048, giant_min = 32768;                         // thresholds on the outdegree (BVGPU_COOP_MIN / BVGPU_GIANT_MIN)
+	bool adaptive = true;                                               // smaller jobs lower them (pick_thresholds) unless a knob pins them
 	int coop_waves = 4096, giant_groups = 256;
 	DevBuf copyq; // rows the copy pass merges with a group / a wave each (all levels), filled while the level lists are built
 	DevBuf bigtmp; // global scratch tables for rows that copy more ids than the LDS tables of k_copy_big hold
@@ -157,8 +158,8 @@ int init_handle(bvg_graph *g) {
 	if (!g->small.need(sizeof(Small))) return fail(g, BVG_ENOMEM, "device allocation failed");
 	const int mr = g->st->info.max_ref_count;
 	g->levels_hint = mr < 1 ? 1 : (mr > 8 ? 8 : mr);
-	if (const char *e = getenv("BVGPU_COOP_MIN")) g->coop_min = std::max(1, atoi(e));   // 0x7fffffff disables the cooperative path
-	if (const char *e = getenv("BVGPU_GIANT_MIN")) g->giant_min = std::max(g->coop_min, atoi(e));
+	if (const char *e = getenv("BVGPU_COOP_MIN")) { g->coop_min = std::max(1, atoi(e)); g->adaptive = false; }   // 0x7fffffff disables the cooperative path
+	if (const char *e = getenv("BVGPU_GIANT_MIN")) { g->giant_min = std::max(g->coop_min, atoi(e)); g->adaptive = false; }
 	if (const char *e = getenv("BVGPU_COOP_WAVES")) g->coop_waves = std::max(1, atoi(e));
 	if (const char *e = getenv("BVGPU_GIANT_GROUPS")) g->giant_groups = std::max(1, atoi(e));
 	if (!g->coopctl.need(8 * sizeof(int32_t)) || !g->keys.need(3 * (bv::NKEYS + 1) * sizeof(int32_t))) return fail(g, BVG_ENOMEM, "device allocation failed");
@@ -281,8 +282,21 @@ int finish_pending(bvg_graph *g, uint64_t *arcs_out) {
 
 // Enqueues the decode proper for a view whose structure (outdegrees, references, row starts) is in place: parse of
 // every record, then `levels_hint` levels of the copy pass (finish_pending launches the levels still missing).
-int enqueue_decode(bvg_graph *g, bv::RangeView &v, int32_t &levels, int32_t &giantCap) {
+// Which records leave the one-lane decoder for a wave (>= coopMin successors) or a group of waves (>= giantMin).
+// A long record is a serial chain (one lane: ~0.5 us per successor, one wave: ~35 ns, a group: ~5 ns); in a scan of
+// the whole C2 graph there is enough other work to hide chains of 2048 / 32768 successors, a job of a few million
+// arcs ends when its longest chain does.  Steps measured on C2 sub-ranges (scripts/small_range.py).
+void pick_thresholds(const bvg_graph *g, int64_t estArcs, int32_t &coopMin, int32_t &giantMin) {
+	coopMin = g->coop_min; giantMin = g->giant_min;
+	if (!g->adaptive) return;
+	if (estArcs < 32000000) coopMin = 512; else if (estArcs < 80000000) coopMin = 1024;
+	if (estArcs < 150000000) giantMin = 8192;
+}
+
+int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &levels, int32_t &giantCap) {
 	const Staged &s = *g->st;
+	int32_t coopMin, giantMin;
+	pick_thresholds(g, estArcs, coopMin, giantMin);
 	const int32_t W = s.info.window_size;
 	int *derr = &g->small.as<Small>()->err;
 	const bv::GraphDev gd = graph_dev(s);
@@ -292,7 +306,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int32_t &levels, int32_t &gia
 		// default path: depth + per-level lists; cooperative decode of long records (two classes) next to the
 		// one-lane decode of the short ones; then the copy pass level by level over compact lists
 		const int64_t arcsBound = std::max<int64_t>(s.info.arcs, 1);
-		giantCap = (int32_t)std::min<int64_t>(arcsBound / g->giant_min + 2, 0x7fffffff);
+		giantCap = (int32_t)std::min<int64_t>(arcsBound / giantMin + 2, 0x7fffffff);
 		const int64_t arenaCap = s.info.min_interval_length > 0 ? arcsBound / s.info.min_interval_length + 2 : 1;
 		if (!g->depth.need(sizeof(int32_t) * (size_t)v.cnt) || !g->key16.need(sizeof(uint16_t) * (size_t)v.cnt) || !g->lvlist.need(sizeof(int32_t) * (size_t)v.cnt) ||
 		    !g->biglist.need(sizeof(int32_t) * (size_t)v.cnt) || !g->giantlist.need(sizeof(int32_t) * (size_t)giantCap) || !g->arena.need((size_t)bv::ARENA_ENTRY_BYTES * (size_t)arenaCap))
@@ -310,9 +324,9 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int32_t &levels, int32_t &gia
 		const uint32_t tmpCap = (uint32_t)std::min<int64_t>(std::max<int64_t>(arcsBound / 4, 1 << 22), 0x7fffffff);
 		if (g->copy_lists && g->copy_big && !g->bigtmp.need(sizeof(int32_t) * (size_t)tmpCap)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
 		g->pend.tmpCap = g->copy_lists && g->copy_big ? tmpCap : 0;
-		const bool coop = g->coop_min < 0x7fffffff;
+		const bool coop = coopMin < 0x7fffffff;
 		const bool ovl = g->overlap && !g->profile; // per-kernel timing needs the kernels one after the other
-		v.coop_min = coop ? g->coop_min : 0x7fffffff;
+		v.coop_min = coop ? coopMin : 0x7fffffff;
 		// Three things run next to each other from here on (unless profiling serialises them):
 		//   side B: classification of the long records, then the giant ones (a group of waves each) -- the longest
 		//           dependency chains of the scan, which need nothing but the outdegrees and the row starts;
@@ -325,7 +339,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int32_t &levels, int32_t &gia
 			HIPCHK(g, hipStreamWaitEvent(g->sideB, g->evFork, 0));
 			stLists = g->sideA;
 			if (coop) {
-				bv::launch_classify(v.cnt, v.outd, g->coop_min, g->giant_min, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, g->sideB);
+				bv::launch_classify(v.cnt, v.outd, coopMin, giantMin, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, g->sideB);
 				HIPCHK(g, hipEventRecord(g->evC, g->sideB));
 			}
 		}
@@ -350,7 +364,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int32_t &levels, int32_t &gia
 			bv::launch_build_lists(gd, v, ~0ull, g->parse_windows ? 6 : 2, nullptr, g->pkey16.as<uint16_t>(), ph, pKeyBase, pKeyBase + (bv::NKEYS + 1), g->plist.as<int32_t>(),
 			                       g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->pad, g->stream);
 		}
-		if (coop && !ovl) bv::launch_classify(v.cnt, v.outd, g->coop_min, g->giant_min, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, g->stream);
+		if (coop && !ovl) bv::launch_classify(v.cnt, v.outd, coopMin, giantMin, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, g->stream);
 		mark(g, 3);
 		if (coop && !ovl) bv::launch_parse_giants(gd, s.def, v, g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->giant_groups, derr, g->stream);
 		mark(g, 4);
@@ -456,7 +470,13 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 	v.succ = succ_dev; v.halo = g->halo.as<int32_t>(); v.succ_cap = succ_cap;
 	int32_t levels = 0;
 	int32_t giantCap = 0;
-	if (succ_dev) { int rc = enqueue_decode(g, v, levels, giantCap); if (rc) return rc; }
+	if (succ_dev) {
+		// arcs of the job, estimated from its share of the bit stream (the true count is still on the device)
+		const int64_t bits = s.h_offsets[to] - s.h_offsets[from - nh], allBits = std::max<int64_t>(s.h_offsets.back(), 1);
+		const int64_t estArcs = (int64_t)((double)s.info.arcs * (double)bits / (double)allBits);
+		int rc = enqueue_decode(g, v, estArcs, levels, giantCap);
+		if (rc) return rc;
+	}
 	if (!succ_dev) { mark(g, 3); mark(g, 4); mark(g, 5); mark(g, 6); }
 	mark(g, 7);
 	bv::launch_rebase(v.nh, v.cnt, v.rowstart, rowptr_dev, g->stream);
@@ -768,7 +788,7 @@ extern "C" int bvg_successors_batch(bvg_t *g, const int32_t *nodes, size_t q, in
 		if (!g->halo.need(sizeof(int32_t) * (size_t)std::max<int64_t>(g->h_small->halo_total, 1))) return fail(g, BVG_ENOMEM, "arena allocation failed");
 		v.succ = nullptr; v.halo = g->halo.as<int32_t>(); v.succ_cap = 0;
 		int32_t levels = 0, giantCap = 0;
-		rc = enqueue_decode(g, v, levels, giantCap);
+		rc = enqueue_decode(g, v, g->h_small->halo_total, levels, giantCap);
 		if (rc) return rc;
 		HIPCHK(g, hipGetLastError());
 		g->pend.active = true; g->pend.view = v; g->pend.levels_done = levels; g->pend.want_succ = true; g->pend.giantCap = giantCap;
@@ -824,18 +844,20 @@ extern "C" int bvg_successors_batch(bvg_t *g, const int32_t *nodes, size_t q, in
 	bv::BatchView v{};
 	v.cnt = S; v.node = g->b_node.as<int32_t>(); v.outd = g->outd.as<int32_t>(); v.depth = g->depth.as<int32_t>(); v.qidx = g->b_qidx.as<int32_t>();
 	v.arow = g->rowstart.as<int64_t>(); v.rowptr = d_rowptr; v.succ = d_succ; v.arena = g->halo.as<int32_t>(); v.succ_cap = succ_cap;
-	const bool coop = g->coop_min < 0x7fffffff && S <= 0x7fffffff;
-	v.coop_min = coop ? g->coop_min : 0x7fffffff;
+	int32_t coopMin, giantMin;
+	pick_thresholds(g, (int64_t)arcs + g->h_small->halo_total, coopMin, giantMin);
+	const bool coop = coopMin < 0x7fffffff && S <= 0x7fffffff;
+	v.coop_min = coop ? coopMin : 0x7fffffff;
 	const bool ovl = coop && g->overlap && !g->profile;
 	if (coop) { // long records: the cooperative kernels of the scan path, over the batch's slots
 		const int64_t arcsTot = (int64_t)arcs + g->h_small->halo_total;
-		const int32_t giantCap = (int32_t)std::min<int64_t>(arcsTot / g->giant_min + 2, 0x7fffffff);
+		const int32_t giantCap = (int32_t)std::min<int64_t>(arcsTot / giantMin + 2, 0x7fffffff);
 		const int64_t arenaCap = s.info.min_interval_length > 0 ? arcsTot / s.info.min_interval_length + 2 : 1;
 		if (!g->biglist.need(4 * Sz) || !g->giantlist.need(sizeof(int32_t) * (size_t)giantCap) || !g->arena.need((size_t)bv::ARENA_ENTRY_BYTES * (size_t)arenaCap))
 			return fail(g, BVG_ENOMEM, "device scratch allocation failed");
 		int32_t *ctl = g->coopctl.as<int32_t>();
 		HIPCHK(g, hipMemsetAsync(ctl, 0, 8 * sizeof(int32_t), g->stream));
-		bv::launch_bparse_big(gd, s.def, v, g->coop_min, g->giant_min, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, g->arena.p, arenaCap,
+		bv::launch_bparse_big(gd, s.def, v, coopMin, giantMin, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, g->arena.p, arenaCap,
 		                      g->coop_waves, g->giant_groups, &dsm->err, g->stream, ovl ? g->sideB : g->stream, ovl ? g->sideA : g->stream, g->evFork, g->evB, g->evA);
 	}
 	bv::launch_bparse(gd, s.def, v, &dsm->err, g->stream);
