@@ -345,11 +345,12 @@ __global__ void __launch_bounds__(TPB) k_parse(GraphDev g, RangeView v, int *__r
 // ------------------------------------------------------------------------------------------------ work lists
 // Records are decoded one reference-chain level at a time, and inside a level in order of their length in bits
 // (known from the offsets, no decoding needed), so that the 64 lanes of a wave get similar amounts of work.
-//   key(s) = level * NBIN + bin,  bin = clamp(floor(log2(bits)) - 5, 0, NBIN-1);  giants go to their own list.
+//   key(s) = level * NBIN + bin,  bin = half-octaves of the length above 16 bits (record_bin);  giants go to their own list.
 // Chain levels >= MAXLVL-1 share the last level's buckets and are swept once per level (rare: deep chains).
-__device__ __forceinline__ int32_t record_bin(uint64_t bitsLen) {
+__device__ __forceinline__ int32_t record_bin(uint64_t bitsLen) { // half-octave steps from 16 bits up: the lanes of a wave differ by < 1.5x
 	const int lg = 63 - __clzll((long long)(bitsLen | 1));
-	return lg < 6 ? 0 : lg - 5 >= NBIN ? NBIN - 1 : lg - 5;
+	const int h = 2 * lg + (lg > 0 ? (int)((bitsLen >> (lg - 1)) & 1) : 0);
+	return h < 8 ? 0 : h - 8 >= NBIN ? NBIN - 1 : h - 8;
 }
 
 // A row that copies from a very long referent can have a block list of thousands of codes, whatever its own length:
@@ -360,7 +361,7 @@ __device__ __forceinline__ int copy_class_of(int32_t d, int32_t dref, int32_t mi
 	if (d >= bigMin || (dref >= COPY_REF_BIG && bigMin != 0x7fffffff)) return 3;
 	return d >= midMin ? 2 : 1;
 }
-constexpr int WINDOWED_BINS = 6; // work < 2^(5 + WINDOWED_BINS) bits: binned per window of nodes (noBin & 4)
+constexpr int WINDOWED_BINS = 14; // work < 2048 bits (bin 14): binned per window of nodes (noBin & 4)
 constexpr int LIST_ITEMS = 16, LIST_TILE = TPB * LIST_ITEMS; // slots per block: few blocks -> few same-address atomics (~88 M/s each)
 
 __global__ void __launch_bounds__(TPB) k_depth_keys(GraphDev g, int32_t lo, int32_t cnt, const int32_t *__restrict__ outd, const uint16_t *__restrict__ ref,

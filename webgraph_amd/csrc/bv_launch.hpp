@@ -5,7 +5,7 @@
 namespace bv {
 
 // work-list keys (bv_kernels.hip, "work lists")
-constexpr int NBIN = 11, MAXLVL = 64, NKEYS = NBIN * MAXLVL;
+constexpr int NBIN = 24, MAXLVL = 64, NKEYS = NBIN * MAXLVL;
 constexpr uint16_t KEY_NONE = 0xffff, KEY_GIANT = 0xfffe;
 
 // A decode job over consecutive nodes: slot s <-> node lo+s; slots [0,nh) are halo nodes whose rows live
