@@ -22,3 +22,13 @@ for rep in range(5):
     g.decode_range_device(lo, lo + cnt, d_rowptr.data_ptr(), d_succ.data_ptr(), m)
     print("call %d: %.3f ms" % (rep, (time.perf_counter() - t0) * 1e3))
 g.close()
+g = BVGraph.load(base)
+for rep in range(4):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    g.decode_range_device(lo, lo + cnt, d_rowptr.data_ptr(), d_succ.data_ptr(), m, asynchronous=True)
+    t1 = time.perf_counter()
+    g.sync()
+    t2 = time.perf_counter()
+    print("async call %d: host returns after %.3f ms, done after %.3f ms" % (rep, (t1 - t0) * 1e3, (t2 - t0) * 1e3))
+g.close()
