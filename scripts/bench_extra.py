@@ -50,6 +50,7 @@ def main():
     n = g.numNodes()
     rng = np.random.Generator(np.random.PCG64(0x5EEDB5E70004))
     q = rng.integers(0, n, size=10_000_000, dtype=np.int64).astype(np.int32)
+    g.successors_batch(q)  # first call: staging buffers and arenas are allocated
     t0 = time.perf_counter()
     rp, sc = g.successors_batch(q)
     dt = time.perf_counter() - t0
@@ -65,7 +66,7 @@ def main():
                  "cpu_oracle_queries_per_s": k / cdt, "cpu_cores": 1}
     g.close()
     import c4_time
-    out["C4_device_resident"] = c4_time.run(10_000_000)  # ids and outputs in HBM, one call
+    out["C4_device_resident"] = c4_time.run(10_000_000, out=sys.stderr)  # ids and outputs in HBM, one call
     print(json.dumps(out))
 
 

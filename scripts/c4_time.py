@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def run(nq=None):
+def run(nq=None, out=sys.stdout):
     import numpy as np
     import torch
     import bench
@@ -47,7 +47,7 @@ def run(nq=None):
     sc = d_succ[:int(orp[-1])].cpu().numpy()
     ok = np.array_equal(rp, orp) and np.array_equal(sc, osc)
     print("C4 device-resident: %d queries, %d arcs: %.2f ms = %.1f M queries/s, %.2f G edges/s (all runs ms: %s), first %d bit-exact: %s"
-          % (nq, arcs.value, dt * 1e3, nq / dt / 1e6, arcs.value / dt / 1e9, " ".join("%.1f" % (t * 1e3) for t in times), k, ok))
+          % (nq, arcs.value, dt * 1e3, nq / dt / 1e6, arcs.value / dt / 1e9, " ".join("%.1f" % (t * 1e3) for t in times), k, ok), file=out)
     g.close()
     return {"queries": nq, "arcs_out": int(arcs.value), "gpu_ms_device_resident": dt * 1e3, "gpu_queries_per_s": nq / dt, "gpu_edges_per_s": arcs.value / dt,
             "parity": "first %d queries bit-exact vs oracle: %s" % (k, ok)}
