@@ -127,6 +127,12 @@ __global__ __launch_bounds__(GATHER_ROWS) void k_gather_rows(const int32_t *__re
 #pragma unroll
 		for (int step = GATHER_ROWS / 2; step > 0; step >>= 1) if (dst[j + step] <= first) j += step;
 		int32_t val[4];
+		if (pos >= d0 && dst[j + 1] >= pos + 4) { // all four from row j: one 16-byte load (dword-aligned is enough for global loads)
+			typedef int32_t int4u __attribute__((ext_vector_type(4), aligned(4)));
+			const int4u q4 = *(const int4u *)(arena + src[j] + (pos - dst[j]));
+			*(int4 *)(succ + pos) = int4{ q4.x, q4.y, q4.z, q4.w };
+			continue;
+		}
 #pragma unroll
 		for (int k = 0; k < 4; k++) {
 			const int64_t p = pos + k;
