@@ -16,6 +16,7 @@ int main(int argc, char **argv) {
 		REQUIRE(g.numArcs() == atoll(argv[3]));
 		REQUIRE(g.randomAccess() && g.hasCopiableIterators());
 		REQUIRE(g.hashCode() == atoi(argv[2]));
+		{ BVGraph c = g.copy(); REQUIRE(g.equals(c) && c.equals(g)); } // ImmutableGraph.equals over a flyweight copy
 		// sequential vs random access on a sample, including the -1 terminator
 		NodeIterator it = g.nodeIterator();
 		int64_t arcs = 0;

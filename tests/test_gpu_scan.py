@@ -47,6 +47,29 @@ def test_cnr2000_hashcode(cnr_gpu):
     assert cnr_gpu.hashCode() == 1711395807  # ImmutableGraph.hashCode(), SURVEY.md App. C
 
 
+def test_equals_like_the_reference(cnr_gpu, tmp_path):
+    """ImmutableGraph.equals (ImmutableGraph.java:731-749): a re-encoding of the same graph with other parameters is
+    equal, a graph with one successor changed or one node more is not."""
+    from webgraph_amd import tools as T
+    from webgraph_amd.bvgraph import BVGraph
+    rowptr, succ = cnr_gpu.decode_range()
+    T.store(str(tmp_path / "same"), rowptr, succ, window=3, max_ref_count=5, min_interval=2, zeta_k=4)
+    g2 = BVGraph.load(str(tmp_path / "same"))
+    assert cnr_gpu.equals(g2) and g2.equals(cnr_gpu) and cnr_gpu.equals(cnr_gpu.copy())
+    succ2 = succ.copy()
+    assert succ2[-1] < cnr_gpu.numNodes() - 1
+    succ2[-1] += 1  # the last id of the last non-empty row: the row stays sorted
+    T.store(str(tmp_path / "diff"), rowptr, succ2, window=7, max_ref_count=3, min_interval=3)
+    g3 = BVGraph.load(str(tmp_path / "diff"))
+    assert not cnr_gpu.equals(g3) and not g3.equals(cnr_gpu)
+    rp4 = np.concatenate([rowptr, rowptr[-1:]])  # one more (empty) node
+    T.store(str(tmp_path / "longer"), rp4, succ, window=7, max_ref_count=3, min_interval=3)
+    g4 = BVGraph.load(str(tmp_path / "longer"))
+    assert not cnr_gpu.equals(g4) and not cnr_gpu.equals("not a graph")
+    for g in (g2, g3, g4):
+        g.close()
+
+
 def test_cnr2000_outdegrees(cnr_gpu, cnr_oracle):
     _, rowptr, _ = cnr_oracle
     d = cnr_gpu.outdegrees()

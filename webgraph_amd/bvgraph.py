@@ -416,6 +416,23 @@ class BVGraph:
             h = self.csr_hashcode(lo, hi, rowptr.data_ptr(), succ.data_ptr(), h)
         return h
 
+    def equals(self, other):
+        """ImmutableGraph.equals() (ImmutableGraph.java:731-749): same number of nodes and the same successor list for
+        every node; both graphs are scanned in lock step, a batch of nodes at a time."""
+        if not hasattr(other, "numNodes") or not hasattr(other, "decode_range"):
+            return False
+        n = self.numNodes()
+        if n != other.numNodes():
+            return False
+        step = 1 << 22
+        for lo in range(0, n, step):
+            hi = min(lo + step, n)
+            rp1, sc1 = self.decode_range(lo, hi)
+            rp2, sc2 = other.decode_range(lo, hi)
+            if not (np.array_equal(rp1, rp2) and np.array_equal(sc1, sc2)):
+                return False
+        return True
+
 
 class ArcLabelledBVGraph:
     """BitStreamArcLabelledImmutableGraph over a BVGraph (labelling/BitStreamArcLabelledImmutableGraph.java:383-470), int

@@ -152,6 +152,21 @@ public:
 		}
 		return (int32_t)h;
 	}
+	// ImmutableGraph.equals() (ImmutableGraph.java:731-749): same size, same successor list for every node
+	bool equals(const BVGraph &o) const {
+		int32_t n = numNodes();
+		if (n != o.numNodes()) return false;
+		NodeIterator i = nodeIterator(), j = o.nodeIterator();
+		while (n-- != 0) {
+			i.nextInt();
+			j.nextInt();
+			int32_t d = i.outdegree();
+			if (d != j.outdegree()) return false;
+			const int32_t *s = i.successorArray(), *t = j.successorArray();
+			while (d-- != 0) if (s[d] != t[d]) return false;
+		}
+		return true;
+	}
 };
 
 inline NodeIterator::NodeIterator(const BVGraph *g, int32_t from, int32_t upperBound, int32_t batchNodes) : g_(g), from_(from), batch_(batchNodes) {
