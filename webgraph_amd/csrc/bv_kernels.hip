@@ -851,22 +851,34 @@ __global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, con
 
 // ------------------------------------------------------------------------------------------------ long records
 // ctl[0] = #big, ctl[1] = #giant, ctl[2] / ctl[3] = heads of the two work queues
+constexpr int CLASSIFY_ITEMS = 16; // nodes per thread: long records are rare, most blocks only stream outdegrees
 __global__ void __launch_bounds__(TPB) k_classify(int32_t cnt, const int32_t *__restrict__ outd, int32_t coopMin, int32_t giantMin,
                                                   int32_t *__restrict__ biglist, int32_t *__restrict__ giantlist, int32_t giantCap, int32_t *__restrict__ ctl) {
 	// block-aggregated append: one atomic per block and list instead of one per long record
 	__shared__ int32_t s_cnt[2], s_base[2];
-	const int32_t s = blockIdx.x * TPB + threadIdx.x;
+	const int32_t base = blockIdx.x * (TPB * CLASSIFY_ITEMS) + threadIdx.x;
+	int32_t d[CLASSIFY_ITEMS];
+	bool any = false;
+#pragma unroll
+	for (int it = 0; it < CLASSIFY_ITEMS; it++) {
+		const int32_t s = base + it * TPB;
+		d[it] = s < cnt ? outd[s] : 0;
+		any |= d[it] >= coopMin;
+	}
 	if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
-	__syncthreads();
-	const int32_t d = s < cnt ? outd[s] : 0;
-	const int kind = d >= giantMin ? 1 : d >= coopMin ? 0 : -1;
-	int32_t local = 0;
-	if (kind >= 0) local = atomicAdd(&s_cnt[kind], 1);
+	if (!__syncthreads_or(any)) return; // (also orders the zeroing above before the atomics below)
+	int32_t local[CLASSIFY_ITEMS];
+#pragma unroll
+	for (int it = 0; it < CLASSIFY_ITEMS; it++) if (d[it] >= coopMin) local[it] = atomicAdd(&s_cnt[d[it] >= giantMin ? 1 : 0], 1);
 	__syncthreads();
 	if (threadIdx.x < 2 && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&ctl[threadIdx.x], s_cnt[threadIdx.x]);
 	__syncthreads();
-	if (kind == 1) { const int32_t k = s_base[1] + local; if (k < giantCap) giantlist[k] = s; } // giantCap >= arcs / giantMin: always fits
-	else if (kind == 0) biglist[s_base[0] + local] = s;
+#pragma unroll
+	for (int it = 0; it < CLASSIFY_ITEMS; it++) {
+		const int32_t s = base + it * TPB;
+		if (d[it] >= giantMin) { const int32_t k = s_base[1] + local[it]; if (k < giantCap) giantlist[k] = s; } // giantCap >= arcs / giantMin: always fits
+		else if (d[it] >= coopMin) biglist[s_base[0] + local[it]] = s;
+	}
 }
 
 // Longest first: the work queues of the long records are ordered by outdegree, descending, so that the records that
@@ -875,9 +887,11 @@ __global__ void __launch_bounds__(TPB) k_classify(int32_t cnt, const int32_t *__
 // the outdegree (exponent + 3 mantissa bits: order inside a bin does not matter); a list longer than the LDS
 // table keeps its (node) order.
 constexpr int SORT_CAP = 16384, SORT_BINS = 256;
-__global__ void __launch_bounds__(1024) k_sort_desc(int32_t *__restrict__ list, const int32_t *__restrict__ count, int32_t cap, const int32_t *__restrict__ outd) {
+__global__ void __launch_bounds__(1024) k_sort_desc(int32_t *__restrict__ listA, const int32_t *__restrict__ countA, int32_t capA,
+                                                    int32_t *__restrict__ listB, const int32_t *__restrict__ countB, int32_t capB, const int32_t *__restrict__ outd) {
 	__shared__ int32_t s_out[SORT_CAP], s_cur[SORT_BINS];
-	const int32_t n = min(*count, cap);
+	int32_t *__restrict__ list = blockIdx.x ? listB : listA; // one block per queue, side by side
+	const int32_t n = blockIdx.x ? min(*countB, capB) : min(*countA, capA);
 	if (n <= 1 || n > SORT_CAP) return;
 	auto key = [](int32_t d) { // larger outdegree -> smaller key
 		const uint32_t u = (uint32_t)max(d, 1);
@@ -1234,9 +1248,8 @@ void launch_bcopy(const GraphDev &g, int def, const BatchView &v, int32_t level,
 
 void launch_classify(int32_t cnt, const int32_t *outd, int32_t coopMin, int32_t giantMin, int32_t *biglist, int32_t *giantlist, int32_t giantCap, int32_t *ctl, hipStream_t st) {
 	if (cnt <= 0) return;
-	hipLaunchKernelGGL(k_classify, dim3(nblk(cnt, TPB)), dim3(TPB), 0, st, cnt, outd, coopMin, giantMin, biglist, giantlist, giantCap, ctl);
-	hipLaunchKernelGGL(k_sort_desc, dim3(1), dim3(1024), 0, st, giantlist, ctl + 1, giantCap, outd);
-	hipLaunchKernelGGL(k_sort_desc, dim3(1), dim3(1024), 0, st, biglist, ctl + 0, cnt, outd);
+	hipLaunchKernelGGL(k_classify, dim3(nblk(cnt, TPB * CLASSIFY_ITEMS)), dim3(TPB), 0, st, cnt, outd, coopMin, giantMin, biglist, giantlist, giantCap, ctl);
+	hipLaunchKernelGGL(k_sort_desc, dim3(2), dim3(1024), 0, st, giantlist, ctl + 1, giantCap, biglist, ctl + 0, cnt, outd);
 }
 
 void launch_parse_big(const GraphDev &g, int def, const RangeView &v, const int32_t *biglist, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap,
