@@ -1111,19 +1111,46 @@ __global__ void __launch_bounds__(TPB) k_bcopy(GraphDev g, BatchView v, int32_t 
 struct Affine { uint32_t a, b; }; // h -> a*h + b
 __device__ __forceinline__ Affine compose(Affine f, Affine g2) { return Affine{ f.a * g2.a, g2.a * f.b + g2.b }; } // g2 after f
 
+__device__ __forceinline__ uint32_t pow31(uint64_t e) { // 31^e mod 2^32
+	uint32_t r = 1u, m = 31u;
+	while (e) { if (e & 1) r *= m; m *= m; e >>= 1; }
+	return r;
+}
+constexpr int HASH_LONG = 512; // rows from here on are folded by the whole block (one lane would be the tail of the kernel)
 __global__ void __launch_bounds__(TPB) k_hash_nodes(int32_t from, int32_t cnt, const int64_t *__restrict__ rowptr,
                                                     const int32_t *__restrict__ succ, uint32_t *__restrict__ outA, uint32_t *__restrict__ outB) {
 	__shared__ Affine sh[TPB];
+	__shared__ int32_t s_long[TPB], s_nlong;
+	__shared__ uint32_t s_part[TPB];
+	if (threadIdx.x == 0) s_nlong = 0;
+	__syncthreads();
 	const int32_t s = blockIdx.x * TPB + threadIdx.x;
 	Affine f{ 1u, 0u };
 	if (s < cnt) {
-		uint32_t a = 31u, b = (uint32_t)(from + s);
+		// node x with successors s_0 < ... < s_{d-1}: h -> 31^(d+1) h + x 31^d + sum_j s_j 31^j  (ImmutableGraph.java:757-770)
 		const int64_t lo = rowptr[s], hi = rowptr[s + 1];
-		for (int64_t j = hi; j-- > lo;) { b = b * 31u + (uint32_t)succ[j]; a *= 31u; }
-		f = Affine{ a, b };
+		if (hi - lo >= HASH_LONG) s_long[atomicAdd(&s_nlong, 1)] = threadIdx.x;
+		else {
+			uint32_t a = 31u, b = (uint32_t)(from + s);
+			for (int64_t j = hi; j-- > lo;) { b = b * 31u + (uint32_t)succ[j]; a *= 31u; }
+			f = Affine{ a, b };
+		}
 	}
 	sh[threadIdx.x] = f;
 	__syncthreads();
+	for (int32_t q = 0; q < s_nlong; q++) { // (uniform)
+		const int32_t t = s_long[q], sx = blockIdx.x * TPB + t;
+		const int64_t lo = rowptr[sx], hi = rowptr[sx + 1], d = hi - lo;
+		// thread k folds the contiguous piece [c0, c1) of the row: sum_j s_j 31^(j - lo) = sum_k 31^(c0 - lo) * (piece k by Horner)
+		const int64_t per = (d + TPB - 1) / TPB, c0 = min(lo + per * threadIdx.x, hi), c1 = min(c0 + per, hi);
+		uint32_t pz = 0;
+		for (int64_t j = c1; j-- > c0;) pz = pz * 31u + (uint32_t)succ[j];
+		s_part[threadIdx.x] = pz * pow31((uint64_t)(c0 - lo));
+		__syncthreads();
+		for (int o = TPB / 2; o > 0; o >>= 1) { if (threadIdx.x < o) s_part[threadIdx.x] += s_part[threadIdx.x + o]; __syncthreads(); }
+		if (threadIdx.x == 0) sh[t] = Affine{ pow31((uint64_t)d + 1), (uint32_t)(from + sx) * pow31((uint64_t)d) + s_part[0] };
+		__syncthreads();
+	}
 	for (int o = 1; o < TPB; o <<= 1) { // ordered tree: element t absorbs t+o
 		if ((threadIdx.x % (2 * o)) == 0 && threadIdx.x + o < TPB) sh[threadIdx.x] = compose(sh[threadIdx.x], sh[threadIdx.x + o]);
 		__syncthreads();
