@@ -121,7 +121,11 @@ __global__ __launch_bounds__(GATHER_ROWS) void k_gather_rows(const int32_t *__re
 	// four consecutive ids per lane and step, on 16-byte boundaries of the output: one search per four ids
 	const int64_t d0 = dst[0], d1 = dst[GATHER_ROWS];
 	const int64_t mis = (int64_t)(((uintptr_t)succ >> 2) & 3); // the caller's buffer need not be 16-byte aligned
-	for (int64_t pos = ((d0 + mis) & ~(int64_t)3) - mis + 4 * (int64_t)t; pos < d1; pos += 4 * GATHER_ROWS) {
+	// (a few queries for very long rows: gridDim.y blocks share the ids of these rows, each a contiguous run of quads)
+	const int64_t A = ((d0 + mis) & ~(int64_t)3) - mis, quads = (d1 - A + 3) >> 2, qper = (quads + gridDim.y - 1) / gridDim.y;
+	const int64_t qend = min(quads, (int64_t)(blockIdx.y + 1) * qper);
+	for (int64_t qd = (int64_t)blockIdx.y * qper + t; qd < qend; qd += GATHER_ROWS) {
+		const int64_t pos = A + 4 * qd;
 		const int64_t first = max(pos, d0);
 		int j = 0; // last row of the block that starts at or before `first`
 #pragma unroll
@@ -1216,8 +1220,11 @@ void launch_query_mark(const int32_t *nodes, int64_t q, int32_t n, int32_t *outd
 	hipLaunchKernelGGL(k_query_mark, dim3(nblk(q, TPB)), dim3(TPB), 0, st, nodes, q, n, outd, ref, need, qoutd, err);
 	if (need) hipLaunchKernelGGL(k_apply_need, dim3(nblk(n, TPB)), dim3(TPB), 0, st, n, need, outd, ref);
 }
-void launch_gather_rows(const int32_t *nodes, int64_t q, const int64_t *rowstart, const int32_t *arena, const int64_t *rowptr, int32_t *succ, hipStream_t st) {
-	if (q > 0) hipLaunchKernelGGL(k_gather_rows, dim3(nblk(q, GATHER_ROWS)), dim3(GATHER_ROWS), 0, st, nodes, q, rowstart, arena, rowptr, succ);
+void launch_gather_rows(const int32_t *nodes, int64_t q, int64_t arcs, const int64_t *rowstart, const int32_t *arena, const int64_t *rowptr, int32_t *succ, hipStream_t st) {
+	if (q <= 0) return;
+	const unsigned bx = nblk(q, GATHER_ROWS);
+	const unsigned by = (unsigned)std::min<int64_t>(std::max<int64_t>(arcs / bx / 16384, 1), 32768); // ~16 K ids per block
+	hipLaunchKernelGGL(k_gather_rows, dim3(bx, by), dim3(GATHER_ROWS), 0, st, nodes, q, rowstart, arena, rowptr, succ);
 }
 void launch_rebase(int32_t nh, int32_t cnt, const int64_t *rowstart, int64_t *out, hipStream_t st) {
 	hipLaunchKernelGGL(k_rebase, dim3(nblk((int64_t)cnt - nh + 1, TPB)), dim3(TPB), 0, st, nh, cnt, rowstart, out);

@@ -749,7 +749,7 @@ extern "C" int bvg_successors_batch(bvg_t *g, const int32_t *nodes, size_t q, in
 		if (arcs_out) *arcs_out = 0;
 		return BVG_OK;
 	}
-	if (g->batch_dense > 0 && (uint64_t)q * (uint64_t)g->batch_dense >= (uint64_t)s.info.nodes) {
+	auto run_dense = [&]() -> int {
 		// Dense batch: a masked scan of the whole graph (every needed record is decoded once, however many queries or
 		// reference chains want it), then a gather of the rows into the caller's order.
 		const int32_t n = s.info.nodes;
@@ -794,12 +794,14 @@ extern "C" int bvg_successors_batch(bvg_t *g, const int32_t *nodes, size_t q, in
 		g->pend.active = true; g->pend.view = v; g->pend.levels_done = levels; g->pend.want_succ = true; g->pend.giantCap = giantCap;
 		rc = finish_pending(g, nullptr); // the levels of the copy pass still missing, errors
 		if (rc) return rc;
-		bv::launch_gather_rows(d_nodes, (int64_t)q, v.rowstart, v.halo, d_rowptr, d_succ, g->stream);
+		bv::launch_gather_rows(d_nodes, (int64_t)q, (int64_t)arcs, v.rowstart, v.halo, d_rowptr, d_succ, g->stream);
 		if (!dev && arcs) HIPCHK(g, hipMemcpyAsync(succ, d_succ, sizeof(int32_t) * (size_t)arcs, hipMemcpyDeviceToHost, g->stream));
 		HIPCHK(g, hipStreamSynchronize(g->stream));
 		HIPCHK(g, hipGetLastError());
 		return BVG_OK;
-	}
+	};
+	// many queries, or (below) few queries for a good part of the arcs: the masked scan
+	if (g->batch_dense > 0 && (uint64_t)q * (uint64_t)g->batch_dense >= (uint64_t)s.info.nodes) return run_dense();
 	// 1. chain lengths -> slot bases
 	if (!g->b_chainlen.need(sizeof(int32_t) * q) || !g->b_slotbase.need(sizeof(int64_t) * (q + 1)) || !g->sums.need(sizeof(int64_t) * (size_t)bv::scan_num_sums((int64_t)q)))
 		return fail(g, BVG_ENOMEM, "device scratch allocation failed");
@@ -834,6 +836,12 @@ extern "C" int bvg_successors_batch(bvg_t *g, const int32_t *nodes, size_t q, in
 	if (!dev) HIPCHK(g, hipMemcpyAsync(rowptr, d_rowptr, sizeof(int64_t) * (q + 1), hipMemcpyDeviceToHost, g->stream));
 	if (!succ) { HIPCHK(g, hipStreamSynchronize(g->stream)); return BVG_OK; }
 	if (arcs > succ_cap) { HIPCHK(g, hipStreamSynchronize(g->stream)); return fail(g, BVG_ECAP, "successor buffer too small"); }
+	// the rows wanted (with their ancestors) hold a good part of the graph's arcs: long rows, decoded once each by the masked scan
+	if (g->batch_dense > 0 && ((uint64_t)arcs + (uint64_t)g->h_small->halo_total) * 8 >= (uint64_t)std::max<int64_t>(s.info.arcs, 1)) {
+		HIPCHK(g, hipStreamSynchronize(g->stream));
+		HIPCHK(g, hipMemsetAsync(g->small.p, 0, sizeof(Small), g->stream));
+		return run_dense();
+	}
 	int32_t *d_succ = succ;
 	if (!dev) {
 		if (!g->stage_succ.need(sizeof(int32_t) * (size_t)std::max<uint64_t>(arcs, 1))) return fail(g, BVG_ENOMEM, "staging allocation failed");
