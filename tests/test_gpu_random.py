@@ -107,3 +107,15 @@ def test_device_buffers_need_not_be_16_byte_aligned(cnr_gpu, cnr_oracle, shift):
     out = d_sc.cpu().numpy()
     assert np.array_equal(d_rp.cpu().numpy(), orp) and np.array_equal(out[shift:shift + osc.size], osc)
     assert (out[:shift] == -7).all() and (out[shift + osc.size:] == -7).all()  # nothing written outside the rows
+
+
+def test_few_queries_for_the_longest_rows(cnr_gpu, cnr_oracle):
+    """A batch of few ids whose rows hold a good part of the arcs (the masked-scan strategy is chosen by arcs then,
+    and the gather shares the long rows among several blocks), with repeats and in descending order."""
+    og, rowptr, succ = cnr_oracle
+    d = np.diff(rowptr)
+    q = np.argsort(d)[::-1][:3000].astype(np.int32)
+    q = np.concatenate([q, q[:17], q[::-1][:5]]).astype(np.int32)
+    rp, sc = cnr_gpu.successors_batch(q)
+    orp, osc = og.successors_batch(q)
+    assert np.array_equal(rp, orp) and np.array_equal(sc, osc)
