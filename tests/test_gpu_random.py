@@ -119,3 +119,35 @@ def test_few_queries_for_the_longest_rows(cnr_gpu, cnr_oracle):
     rp, sc = cnr_gpu.successors_batch(q)
     orp, osc = og.successors_batch(q)
     assert np.array_equal(rp, orp) and np.array_equal(sc, osc)
+
+
+def test_successor_buffer_too_small_is_reported_not_overrun(cnr_gpu, cnr_oracle):
+    """BVG_ECAP (include/bvgpu.h): a caller buffer smaller than the result is an error, arcs_out still reports the
+    need, and nothing is written past the capacity given -- for the scan and for both batch strategies."""
+    import ctypes as C
+    import torch
+    from webgraph_amd import bvgraph as B
+    og, rowptr, succ = cnr_oracle
+    dev = torch.device("cuda", 0)
+    lib = B.lib()
+    lo, hi = 1000, 200000
+    need = int(rowptr[hi] - rowptr[lo])
+    cap = need - 5
+    d_rp = torch.empty(hi - lo + 1, dtype=torch.int64, device=dev)
+    d_sc = torch.full((need + 64,), -7, dtype=torch.int32, device=dev)
+    arcs = C.c_uint64(0)
+    rc = lib.bvg_decode_range(cnr_gpu._h, lo, hi, d_rp.data_ptr(), d_sc.data_ptr(), cap, C.byref(arcs), B.BVG_OUT_DEVICE)
+    assert rc == B.BVG_ECAP and arcs.value == need
+    assert (d_sc[cap:].cpu().numpy() == -7).all()
+    rc = lib.bvg_decode_range(cnr_gpu._h, lo, hi, d_rp.data_ptr(), d_sc.data_ptr(), need, C.byref(arcs), B.BVG_OUT_DEVICE)
+    assert rc == 0 and np.array_equal(d_sc[:need].cpu().numpy(), succ[rowptr[lo]:rowptr[hi]])  # the handle is usable afterwards
+    q = np.random.default_rng(11).integers(0, cnr_gpu.numNodes(), 30000).astype(np.int32)
+    orp, osc = og.successors_batch(q)
+    d_q = torch.from_numpy(q).to(dev)
+    d_rp = torch.empty(q.size + 1, dtype=torch.int64, device=dev)
+    d_sc = torch.full((osc.size + 64,), -7, dtype=torch.int32, device=dev)
+    rc = lib.bvg_successors_batch(cnr_gpu._h, d_q.data_ptr(), q.size, d_rp.data_ptr(), d_sc.data_ptr(), osc.size - 1, C.byref(arcs), B.BVG_OUT_DEVICE)
+    assert rc == B.BVG_ECAP and arcs.value == osc.size
+    assert (d_sc.cpu().numpy() == -7).all()  # the batch call checks before it decodes
+    rc = lib.bvg_successors_batch(cnr_gpu._h, d_q.data_ptr(), q.size, d_rp.data_ptr(), d_sc.data_ptr(), osc.size, C.byref(arcs), B.BVG_OUT_DEVICE)
+    assert rc == 0 and np.array_equal(d_sc[:osc.size].cpu().numpy(), osc)
