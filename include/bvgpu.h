@@ -117,15 +117,19 @@ int bvg_outdegrees(bvg_t *g, int32_t from, int32_t to, int32_t *out, int flags);
  * (BVGraphNodeIterator BVG:1136-1281 over successors(x, ibs, window, outd) BVG:1032-1133), in CSR form:
  *   rowptr[to-from+1]  exclusive prefix sums of the outdegrees, rowptr[0] = 0
  *   succ[rowptr[to-from]]  the successor lists, each strictly increasing
- * succ == NULL: count-only (rowptr and *arcs_out).  succ_cap is the capacity of succ in int32 elements.
- * rowptr may be NULL when only succ is wanted?  No: rowptr is required (it is how rows are found).
+ * succ == NULL: count-only (rowptr and *arcs_out).  succ_cap is the capacity of succ in int32 elements; a smaller
+ * result is BVG_ECAP (nothing is written past succ_cap, *arcs_out reports the need).  rowptr is required.
+ * from > 0: referents before `from` are decoded into library scratch (a halo), never into the caller's buffers.
  */
 int bvg_decode_range(bvg_t *g, int32_t from, int32_t to, int64_t *rowptr, int32_t *succ, size_t succ_cap,
                      uint64_t *arcs_out, int flags);
 
 /*
  * Random access: concatenation of successorArray(nodes[i]) (BVG:897-904, ImmutableGraph.java:329-333),
- * reference chains resolved on the device.  rowptr has q+1 entries.
+ * reference chains resolved on the device.  rowptr has q+1 entries; ids may repeat and come in any order; an id
+ * outside [0, n) is BVG_EARG (BVG:900).  succ == NULL: count-only; BVG_ECAP as above, checked before any decode.
+ * A batch that touches a good part of the graph is decoded as one masked scan (every needed record once) plus a
+ * gather, a sparse one query by query: batch the ids, one call per id is the slow way to use this entry point.
  */
 int bvg_successors_batch(bvg_t *g, const int32_t *nodes, size_t q, int64_t *rowptr, int32_t *succ, size_t succ_cap,
                          uint64_t *arcs_out, int flags);
