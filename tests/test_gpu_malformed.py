@@ -46,6 +46,13 @@ def test_bit_flips_never_crash(tmp_path, seed):
         g.successors_batch(np.array([0, 1, 325556], dtype=np.int32))
     except _errors():
         pass
+    # a dense batch goes through the masked scan + gather: same promise
+    q = rng.integers(0, g.numNodes(), 40000).astype(np.int32)
+    try:
+        rp, sc = g.successors_batch(q)
+        assert rp[0] == 0 and np.all(np.diff(rp) >= 0) and rp[-1] == sc.size
+    except _errors():
+        pass
     g.close()
 
 
