@@ -196,15 +196,14 @@ __global__ void __launch_bounds__(TPB) k_scan_sums(const int32_t *__restrict__ i
 
 // single block: exclusive scan of nb block sums in place (loops in tiles of TPB with a carry)
 __global__ void __launch_bounds__(TPB) k_scan_top(int64_t *__restrict__ sums, int64_t nb) {
-	int64_t carry = 0;
-	for (int64_t b = 0; b < nb; b += TPB) {
-		const int64_t j = b + threadIdx.x;
-		const int64_t v = j < nb ? sums[j] : 0;
-		int64_t tot;
-		const int64_t ex = block_excl_scan(v, &tot);
-		if (j < nb) sums[j] = carry + ex;
-		carry += tot;
-	}
+	// one block, one barrier round: every thread owns a contiguous run of the tile sums (the kernel sits between two
+	// grid-wide kernels of every scan: a loop of block scans, two barriers per 256 sums, made it last 30 us)
+	const int64_t per = (nb + TPB - 1) / TPB, lo = min(per * threadIdx.x, nb), hi = min(lo + per, nb);
+	int64_t mine = 0;
+	for (int64_t j = lo; j < hi; j++) mine += sums[j];
+	int64_t tot;
+	int64_t run = block_excl_scan(mine, &tot);
+	for (int64_t j = lo; j < hi; j++) { const int64_t v = sums[j]; sums[j] = run; run += v; }
 }
 
 __global__ void __launch_bounds__(TPB) k_scan_apply(const int32_t *__restrict__ in, int64_t n, const int64_t *__restrict__ sums, int64_t *__restrict__ out) {
