@@ -434,17 +434,20 @@ __global__ void __launch_bounds__(TPB) k_key_offsets(const int32_t *__restrict__
 	__shared__ int32_t s_top;
 	if (threadIdx.x == 0) s_top = 0;
 	__syncthreads();
-	int64_t carry = 0;
-	for (int base = 0; base < NKEYS; base += TPB) {
-		const int k = base + threadIdx.x;
-		const int64_t v = k < NKEYS ? hist[k] : 0;
-		int64_t tot;
-		const int64_t ex = block_excl_scan(v, &tot);
-		if (k < NKEYS) { keyBase[k] = (int32_t)(carry + ex); cursor[k] = (int32_t)(carry + ex); if (v) atomicMax(&s_top, k / NBIN); }
-		carry += tot;
+	constexpr int PER = (NKEYS + TPB - 1) / TPB; // every thread owns a run of keys: one barrier round
+	const int lo = min(PER * (int)threadIdx.x, NKEYS), hi = min(lo + PER, NKEYS);
+	int64_t mine = 0;
+	for (int k = lo; k < hi; k++) mine += hist[k];
+	int64_t tot;
+	int64_t run = block_excl_scan(mine, &tot);
+	for (int k = lo; k < hi; k++) {
+		const int32_t v = hist[k];
+		keyBase[k] = (int32_t)run; cursor[k] = (int32_t)run;
+		if (v) atomicMax(&s_top, k / NBIN);
+		run += v;
 	}
 	__syncthreads();
-	if (threadIdx.x == 0) { keyBase[NKEYS] = (int32_t)carry; atomicMax(maxdepth, s_top); }
+	if (threadIdx.x == 0) { keyBase[NKEYS] = (int32_t)tot; atomicMax(maxdepth, s_top); }
 }
 
 __global__ void __launch_bounds__(TPB) k_scatter_keys(int32_t cnt, const uint16_t *__restrict__ key16, int32_t *__restrict__ cursor, int32_t *__restrict__ list,
