@@ -101,7 +101,7 @@ struct bvg_graph {
 	DevBuf stats; // BVGPU_STATS=1: tuning counters
 	// the three parse kernels (giant / big / short records) are independent: they run on forked streams
 	hipStream_t sideA = nullptr, sideB = nullptr; // (more streams than this share hardware queues with each other: they would serialise)
-	hipEvent_t evFork = nullptr, evA = nullptr, evB = nullptr, evC = nullptr;
+	hipEvent_t evFork = nullptr, evA = nullptr, evB = nullptr, evC = nullptr, evHdr = nullptr, evP = nullptr;
 	bool overlap = true;
 	int batch_dense = 32;   // a random-access batch of q nodes with q * batch_dense >= n is decoded as a masked scan of the graph (0: never;
 	                        // measured crossover on the 10 M-node C2 graph: q = 300 000)
@@ -182,6 +182,8 @@ int init_handle(bvg_graph *g) {
 	HIPCHK(g, hipEventCreateWithFlags(&g->evA, hipEventDisableTiming));
 	HIPCHK(g, hipEventCreateWithFlags(&g->evB, hipEventDisableTiming));
 	HIPCHK(g, hipEventCreateWithFlags(&g->evC, hipEventDisableTiming));
+	HIPCHK(g, hipEventCreateWithFlags(&g->evHdr, hipEventDisableTiming));
+	HIPCHK(g, hipEventCreateWithFlags(&g->evP, hipEventDisableTiming));
 	if (const char *e = getenv("BVGPU_STATS")) if (atoi(e)) { if (!g->stats.need(32 * sizeof(unsigned long long))) return fail(g, BVG_ENOMEM, "device allocation failed"); HIPCHK(g, hipMemset(g->stats.p, 0, 256)); }
 	return BVG_OK;
 }
@@ -205,6 +207,7 @@ int enqueue_structure(bvg_graph *g, int32_t from, int32_t to, int32_t nh, bv::Ra
 	mark(g, 0);
 	bv::launch_headers(gd, s.def, lo, cnt, v.outd, v.ref, derr, g->stream);
 	if (nh) bv::launch_mark_halo(nh, cnt, s.info.window_size, v.outd, v.ref, g->need.as<uint8_t>(), derr, g->stream);
+	HIPCHK(g, hipEventRecord(g->evHdr, g->stream)); // outdegrees and references are final: the parse list can be built while the scan runs
 	mark(g, 1);
 	bv::launch_scan(v.outd, cnt, v.rowstart, g->sums.as<int64_t>(), g->stream);
 	mark(g, 2);
@@ -293,7 +296,7 @@ void pick_thresholds(const bvg_graph *g, int64_t estArcs, int32_t &coopMin, int3
 	if (estArcs < 150000000) giantMin = 8192;
 }
 
-int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &levels, int32_t &giantCap) {
+int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &levels, int32_t &giantCap, bool hdrEvent = false) {
 	const Staged &s = *g->st;
 	int32_t coopMin, giantMin;
 	pick_thresholds(g, estArcs, coopMin, giantMin);
@@ -333,6 +336,20 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		//   side A: chain depths + per-level lists + copy queues (only the copy pass needs them), then the big records (a wave each);
 		//   here:   the parse list and the one-lane parse of everything else.
 		hipStream_t stLists = g->stream;
+		// parse list (every non-empty record, sorted by work bin inside windows of nodes): needs the outdegrees only, so
+		// with the headers' event at hand it is built on side A while the scan of the outdegrees still runs
+		int32_t *pKeyBase = nullptr;
+		const bool earlyList = g->parse_lists && ovl && hdrEvent;
+		if (g->parse_lists) {
+			if (!g->plist.need(sizeof(int32_t) * (size_t)v.cnt) || !g->pkeys.need(3 * (bv::NKEYS + 1) * sizeof(int32_t)) || !g->pkey16.need(sizeof(uint16_t) * (size_t)v.cnt)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
+			pKeyBase = g->pkeys.as<int32_t>() + (bv::NKEYS + 1);
+		}
+		if (earlyList) {
+			HIPCHK(g, hipStreamWaitEvent(g->sideA, g->evHdr, 0));
+			bv::launch_build_lists(gd, v, ~0ull, g->parse_windows ? 6 : 2, nullptr, g->pkey16.as<uint16_t>(), g->pkeys.as<int32_t>(), pKeyBase, pKeyBase + (bv::NKEYS + 1), g->plist.as<int32_t>(),
+			                       g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->pad, g->sideA);
+			HIPCHK(g, hipEventRecord(g->evP, g->sideA));
+		}
 		if (ovl) {
 			HIPCHK(g, hipEventRecord(g->evFork, g->stream));
 			HIPCHK(g, hipStreamWaitEvent(g->sideA, g->evFork, 0));
@@ -355,15 +372,10 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			}
 			HIPCHK(g, hipEventRecord(g->evA, g->sideA));
 		}
-		// parse list: every non-empty record, sorted by work bin only
-		int32_t *pKeyBase = nullptr;
-		if (g->parse_lists) {
-			if (!g->plist.need(sizeof(int32_t) * (size_t)v.cnt) || !g->pkeys.need(3 * (bv::NKEYS + 1) * sizeof(int32_t)) || !g->pkey16.need(sizeof(uint16_t) * (size_t)v.cnt)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
-			int32_t *ph = g->pkeys.as<int32_t>();
-			pKeyBase = ph + (bv::NKEYS + 1);
-			bv::launch_build_lists(gd, v, ~0ull, g->parse_windows ? 6 : 2, nullptr, g->pkey16.as<uint16_t>(), ph, pKeyBase, pKeyBase + (bv::NKEYS + 1), g->plist.as<int32_t>(),
+		if (g->parse_lists && !earlyList)
+			bv::launch_build_lists(gd, v, ~0ull, g->parse_windows ? 6 : 2, nullptr, g->pkey16.as<uint16_t>(), g->pkeys.as<int32_t>(), pKeyBase, pKeyBase + (bv::NKEYS + 1), g->plist.as<int32_t>(),
 			                       g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->pad, g->stream);
-		}
+		if (earlyList) HIPCHK(g, hipStreamWaitEvent(g->stream, g->evP, 0));
 		if (coop && !ovl) bv::launch_classify(v.cnt, v.outd, coopMin, giantMin, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, g->stream);
 		mark(g, 3);
 		if (coop && !ovl) bv::launch_parse_giants(gd, s.def, v, g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->giant_groups, derr, g->stream);
@@ -474,7 +486,7 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 		// arcs of the job, estimated from its share of the bit stream (the true count is still on the device)
 		const int64_t bits = s.h_offsets[to] - s.h_offsets[from - nh], allBits = std::max<int64_t>(s.h_offsets.back(), 1);
 		const int64_t estArcs = (int64_t)((double)s.info.arcs * (double)bits / (double)allBits);
-		int rc = enqueue_decode(g, v, estArcs, levels, giantCap);
+		int rc = enqueue_decode(g, v, estArcs, levels, giantCap, true);
 		if (rc) return rc;
 	}
 	if (!succ_dev) { mark(g, 3); mark(g, 4); mark(g, 5); mark(g, 6); }
@@ -620,7 +632,7 @@ extern "C" int bvg_close(bvg_t *g) {
 		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist, &g->plist, &g->pkeys, &g->pkey16, &g->copyq, &g->bigtmp }) b->release();
 		if (g->h_small) (void)hipHostFree(g->h_small);
 		for (auto &e : g->ev) if (e) (void)hipEventDestroy(e);
-		for (hipEvent_t e : { g->evFork, g->evA, g->evB, g->evC, g->evIn, g->evOut }) if (e) (void)hipEventDestroy(e);
+		for (hipEvent_t e : { g->evFork, g->evA, g->evB, g->evC, g->evHdr, g->evP, g->evIn, g->evOut }) if (e) (void)hipEventDestroy(e);
 		for (hipStream_t st : { g->sideA, g->sideB }) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
 	}
 	delete g;
