@@ -316,7 +316,9 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			return fail(g, BVG_ENOMEM, "device scratch allocation failed");
 		int32_t *hist = g->keys.as<int32_t>(), *keyBase = hist + (bv::NKEYS + 1), *cursor = keyBase + (bv::NKEYS + 1);
 		int32_t *ctl = g->coopctl.as<int32_t>();
-		HIPCHK(g, hipMemsetAsync(ctl, 0, 8 * sizeof(int32_t), g->stream));
+		// (ctl[0..3], the queues of the long records, are zeroed on side B when the classification starts early)
+		const bool early = hdrEvent && coopMin < 0x7fffffff && g->overlap && !g->profile;
+		HIPCHK(g, hipMemsetAsync(ctl + (early ? 4 : 0), 0, (early ? 4 : 8) * sizeof(int32_t), g->stream));
 		// rows with a reference and >= 1024 (resp. >= copy_mid_min) successors: at most arcs / 1024 (resp. / copy_mid_min) of them
 		const int32_t bigCap = (int32_t)std::min<int64_t>(arcsBound / 1024 + 2, 0x3fffffff);
 		const int32_t midCap = g->copy_mid_min > 0 ? (int32_t)std::min<int64_t>(arcsBound / g->copy_mid_min + 2, 0x3fffffff) : 0;
@@ -351,27 +353,34 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			HIPCHK(g, hipEventRecord(g->evP, g->sideA));
 		}
 		if (ovl) {
+			if (early) { // side B: classification and sort of the long records next to the scan (they need the outdegrees only)
+				HIPCHK(g, hipStreamWaitEvent(g->sideB, g->evHdr, 0));
+				HIPCHK(g, hipMemsetAsync(ctl, 0, 4 * sizeof(int32_t), g->sideB));
+				bv::launch_classify(v.cnt, v.outd, coopMin, giantMin, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, g->sideB);
+				HIPCHK(g, hipEventRecord(g->evC, g->sideB));
+			}
 			HIPCHK(g, hipEventRecord(g->evFork, g->stream));
 			HIPCHK(g, hipStreamWaitEvent(g->sideA, g->evFork, 0));
 			HIPCHK(g, hipStreamWaitEvent(g->sideB, g->evFork, 0));
 			stLists = g->sideA;
-			if (coop) {
+			if (coop && !early) {
 				bv::launch_classify(v.cnt, v.outd, coopMin, giantMin, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, g->sideB);
 				HIPCHK(g, hipEventRecord(g->evC, g->sideB));
 			}
 		}
-		// chain depth of every record (+ per-level lists, node order inside a level)
+		// the long records first on both side streams: giants on B, the wave class on A ...
+		if (ovl && coop) {
+			HIPCHK(g, hipStreamWaitEvent(g->sideA, g->evC, 0));
+			bv::launch_parse_big(gd, s.def, v, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, g->giant_groups, derr, g->sideB, g->sideA); // (giants, big)
+			HIPCHK(g, hipEventRecord(g->evB, g->sideB));
+		}
+		// ... then, behind the wave class, the chain depth of every record + per-level lists (node order inside a level) +
+		// copy queues: only the copy pass needs them, and launched first they would sit in front of the wave class while
+		// the one-lane kernel holds every CU
 		if (W > 0) bv::launch_build_lists(gd, v, ~0ull, 1, g->depth.as<int32_t>(), g->key16.as<uint16_t>(), hist, keyBase, cursor, g->lvlist.as<int32_t>(),
 		                                  g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->maxdepth, stLists,
 		                                  g->copy_lists ? g->copyq.as<int32_t>() : nullptr, bigCap, g->copyq.as<int32_t>() + bigCap, midCap, g->copy_mid_min, g->copy_big != 0);
-		if (ovl) {
-			if (coop) {
-				HIPCHK(g, hipStreamWaitEvent(g->sideA, g->evC, 0));
-				bv::launch_parse_big(gd, s.def, v, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, g->giant_groups, derr, g->sideB, g->sideA); // (giants, big)
-				HIPCHK(g, hipEventRecord(g->evB, g->sideB));
-			}
-			HIPCHK(g, hipEventRecord(g->evA, g->sideA));
-		}
+		if (ovl) HIPCHK(g, hipEventRecord(g->evA, g->sideA));
 		if (g->parse_lists && !earlyList)
 			bv::launch_build_lists(gd, v, ~0ull, g->parse_windows ? 6 : 2, nullptr, g->pkey16.as<uint16_t>(), g->pkeys.as<int32_t>(), pKeyBase, pKeyBase + (bv::NKEYS + 1), g->plist.as<int32_t>(),
 			                       g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->pad, g->stream);
