@@ -21,7 +21,9 @@ def main():
     bad = 0
     for t in range(24):
         size = int(10 ** rng.uniform(1, 6.8))
-        lo = int(rng.integers(0, n - size))
+        lo = 0 if t % 4 == 0 else int(rng.integers(0, n - size))  # prefixes of the graph take the path without a halo
+        if t % 8 == 0:
+            size = int(rng.integers(1 << 20, n))  # ... and large ones the fused key path of k_headers
         rp, sc = g.decode_range(lo, lo + size)
         ok = np.array_equal(rp, rowptr[lo:lo + size + 1] - rowptr[lo]) and np.array_equal(sc, succ[rowptr[lo]:rowptr[lo + size]])
         bad += not ok
