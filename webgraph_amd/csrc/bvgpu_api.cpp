@@ -103,6 +103,7 @@ struct bvg_graph {
 	hipStream_t sideA = nullptr, sideB = nullptr; // (more streams than this share hardware queues with each other: they would serialise)
 	hipEvent_t evFork = nullptr, evA = nullptr, evB = nullptr, evC = nullptr, evHdr = nullptr, evP = nullptr;
 	bool overlap = true;
+	int64_t *early_rowptr = nullptr; // decode_range_device: caller's rowptr, written on a side stream as soon as the scan is done (set per call)
 	int batch_dense = 32;   // a random-access batch of q nodes with q * batch_dense >= n is decoded as a masked scan of the graph (0: never;
 	                        // measured crossover on the 10 M-node C2 graph: q = 300 000)
 	Small *h_small = nullptr; // pinned
@@ -363,6 +364,10 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			HIPCHK(g, hipStreamWaitEvent(g->sideA, g->evFork, 0));
 			HIPCHK(g, hipStreamWaitEvent(g->sideB, g->evFork, 0));
 			stLists = g->sideA;
+			if (g->early_rowptr) { // the caller's rowptr needs the scan only: written now, not at the end of the call
+				bv::launch_rebase(v.nh, v.cnt, v.rowstart, g->early_rowptr, g->sideA);
+				hipLaunchKernelGGL(k_totals, dim3(1), dim3(1), 0, g->sideA, v.rowstart, v.nh, v.cnt, g->small.as<Small>());
+			}
 			if (coop && !early) {
 				bv::launch_classify(v.cnt, v.outd, coopMin, giantMin, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, g->sideB);
 				HIPCHK(g, hipEventRecord(g->evC, g->sideB));
@@ -491,6 +496,7 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 	v.succ = succ_dev; v.halo = g->halo.as<int32_t>(); v.succ_cap = succ_cap;
 	int32_t levels = 0;
 	int32_t giantCap = 0;
+	g->early_rowptr = succ_dev && g->overlap && !g->profile && !g->fused ? rowptr_dev : nullptr;
 	if (succ_dev) {
 		// arcs of the job, estimated from its share of the bit stream (the true count is still on the device)
 		const int64_t bits = s.h_offsets[to] - s.h_offsets[from - nh], allBits = std::max<int64_t>(s.h_offsets.back(), 1);
@@ -500,8 +506,11 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 	}
 	if (!succ_dev) { mark(g, 3); mark(g, 4); mark(g, 5); mark(g, 6); }
 	mark(g, 7);
-	bv::launch_rebase(v.nh, v.cnt, v.rowstart, rowptr_dev, g->stream);
-	hipLaunchKernelGGL(k_totals, dim3(1), dim3(1), 0, g->stream, v.rowstart, v.nh, v.cnt, g->small.as<Small>());
+	if (!g->early_rowptr) {
+		bv::launch_rebase(v.nh, v.cnt, v.rowstart, rowptr_dev, g->stream);
+		hipLaunchKernelGGL(k_totals, dim3(1), dim3(1), 0, g->stream, v.rowstart, v.nh, v.cnt, g->small.as<Small>());
+	}
+	g->early_rowptr = nullptr;
 	mark(g, 8);
 	g->ev_valid = g->profile;
 	{ int rc = join_to_user(g); if (rc) return rc; }
