@@ -378,3 +378,33 @@ def test_empty_and_degenerate_graphs(tmp_path):
             orp, osc = og.successors_batch(q)
             assert np.array_equal(rp, orp) and np.array_equal(sc, osc), name
         g.close()
+
+
+def test_subranges_when_the_halo_guess_is_wrong(tmp_path_factory, monkeypatch, cnr_oracle):
+    """A sub-range is decoded before the host knows how deep and how large its halo is (chains are assumed to be no
+    longer than maxrefcount says, rows to fit the scratch of earlier calls); when the guess is wrong the call is repeated
+    with a sized halo.  Both ways to be wrong: a .properties file that understates maxrefcount (chains escape the
+    window), and a scratch buffer of a few bytes (BVGPU_HALO_MIN)."""
+    from webgraph_amd.bvgraph import BVGraph
+    from oracle import oracle as O
+    base, rowptr, succ = make_graph(tmp_path_factory, "lyingprops", 30000, 500000, 23, 0.95, window=7, max_ref_count=60, min_interval=2)
+    props = open(base + ".properties").read()
+    assert "maxrefcount=60" in props
+    open(base + ".properties", "w").write(props.replace("maxrefcount=60", "maxrefcount=1"))
+    og = O.OracleGraph.load(base)
+    for halo_min in (None, "4"):
+        if halo_min:
+            monkeypatch.setenv("BVGPU_HALO_MIN", halo_min)
+        g = BVGraph.load(base)
+        for lo, hi in [(15000, 15400), (29000, 30000), (7, 9), (20000, 20001), (12345, 23456)]:
+            rp, sc = g.decode_range(lo, hi)
+            assert np.array_equal(rp, rowptr[lo:hi + 1] - rowptr[lo]) and np.array_equal(sc, succ[rowptr[lo]:rowptr[hi]]), (lo, hi, halo_min)
+        g.close()
+    from webgraph_amd.bvgraph import BVGraph as B2
+    from conftest import CNR
+    g = B2.load(CNR)  # (BVGPU_HALO_MIN=4 still set: every sub-range of the fixture takes the repeat)
+    _, crp, csc = cnr_oracle
+    for lo, hi in [(1000, 200000), (46900, 46930), (325000, 325557)]:
+        rp, sc = g.decode_range(lo, hi)
+        assert np.array_equal(rp, crp[lo:hi + 1] - crp[lo]) and np.array_equal(sc, csc[crp[lo]:crp[hi]])
+    g.close()

@@ -17,7 +17,7 @@ namespace bv {
 enum : int { C_DELTA = 1, C_GAMMA = 2, C_GOLOMB = 3, C_SKEWED_GOLOMB = 4, C_UNARY = 5, C_ZETA = 6, C_NIBBLE = 7 };
 
 // sticky device error bits
-enum : int { E_REF = 1, E_FORMAT = 2, E_CAP = 4, E_UNSUP = 8, E_ESCAPED = 16, E_ARG = 32 };
+enum : int { E_REF = 1, E_FORMAT = 2, E_CAP = 4, E_UNSUP = 8, E_ESCAPED = 16, E_ARG = 32, E_HALO = 64 }; // E_HALO: a halo row past the scratch capacity (the host retries)
 
 struct GraphDev {
 	const uint32_t *bits;   // .graph bytes viewed as big-endian 32-bit words

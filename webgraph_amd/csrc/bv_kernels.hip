@@ -82,7 +82,9 @@ __global__ void k_mark_halo(int32_t nh, int32_t cnt, int32_t W, const int32_t *_
 
 __global__ void k_apply_need(int32_t nh, const uint8_t *__restrict__ need, int32_t *__restrict__ outd, uint16_t *__restrict__ ref) {
 	const int32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-	if (s < nh && !need[s]) { outd[s] = 0; ref[s] = 0; }
+	if (s >= nh) return;
+	if (!need[s]) { outd[s] = 0; ref[s] = 0; }
+	else if ((int32_t)ref[s] > s) ref[s] = 0; // a needed chain leaves the window (k_mark_halo raised E_ESCAPED): nothing before it may be touched
 }
 
 // ------------------------------------------------------------------------------------------------ dense batches
@@ -347,7 +349,7 @@ __global__ void __launch_bounds__(TPB) k_parse(GraphDev g, RangeView v, int *__r
 	const int32_t d = v.outd[s];
 	if (d == 0 || d >= v.coop_min) return; // long records are decoded by whole waves (k_parse_big)
 	const int32_t r = v.ref[s];
-	if (s >= v.nh && (uint64_t)(v.rowstart[s + 1] - v.rowstart[v.nh]) > v.succ_cap) { atomicOr(err, E_CAP); return; }
+	if (!v.fits(s)) { atomicOr(err, s >= v.nh ? E_CAP : E_HALO); return; }
 	parse_node<DEF>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), err);
 }
 
@@ -487,7 +489,7 @@ __global__ void __launch_bounds__(TPB) k_decode_level(GraphDev g, RangeView v, c
 		if (level >= MAXLVL - 1 && depth[s] != level) continue; // shared overflow bucket
 		const int32_t d = v.outd[s];
 		const int32_t r = v.ref[s];
-		if (s >= v.nh && (uint64_t)(v.rowstart[s + 1] - v.rowstart[v.nh]) > v.succ_cap) { atomicOr(err, E_CAP); continue; }
+		if (!v.fits(s) || (r > 0 && !v.fits(s - r))) { atomicOr(err, s >= v.nh && v.fits(s - r) ? E_CAP : E_HALO); continue; }
 		decode_node_full<DEF, HAS_REF>(g, v.lo + s, d, r, r > 0 ? (int64_t)v.outd[s - r] : 0, r > 0 ? v.row(s - r) : nullptr, v.row(s), lds, err);
 	}
 }
@@ -501,7 +503,7 @@ __global__ void __launch_bounds__(64) k_copy_giants(GraphDev g, RangeView v, con
 	const int32_t s = giantlist[idx];
 	if (depth[s] != level || v.ref[s] == 0) return;
 	const int32_t r = v.ref[s];
-	if (s >= v.nh && (uint64_t)(v.rowstart[s + 1] - v.rowstart[v.nh]) > v.succ_cap) return;
+	if (!v.fits(s) || !v.fits(s - r)) return;
 	copy_node<DEF>(g, v.lo + s, v.outd[s], (int64_t)v.outd[s - r], v.row(s), v.row(s - r), err);
 }
 
@@ -514,7 +516,7 @@ constexpr int COPY_BIG_MIN = 1024;
 __device__ __forceinline__ int copy_class(const RangeView &v, const int32_t *__restrict__ depth, int32_t level, int32_t s, int32_t midMin, int32_t bigMin) {
 	if (level >= MAXLVL - 1 && depth[s] != level) return 0; // shared overflow bucket
 	if (v.ref[s] == 0) return 0;
-	if (s >= v.nh && (uint64_t)(v.rowstart[s + 1] - v.rowstart[v.nh]) > v.succ_cap) return 0; // E_CAP already raised
+	if (!v.fits(s) || !v.fits(s - v.ref[s])) return 0; // E_CAP / E_HALO already raised by the parse kernel
 	return copy_class_of(v.outd[s], v.outd[s - v.ref[s]], midMin, bigMin);
 }
 template <int DEF>
@@ -849,7 +851,7 @@ __global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, con
 		const int32_t d = v.outd[s];
 		if (d >= v.coop_min || d == 0) continue; // decoded by whole waves (k_parse_big) / nothing to decode
 		const int32_t r = v.ref[s];
-		if (s >= v.nh && (uint64_t)(v.rowstart[s + 1] - v.rowstart[v.nh]) > v.succ_cap) { atomicOr(err, E_CAP); continue; }
+		if (!v.fits(s)) { atomicOr(err, s >= v.nh ? E_CAP : E_HALO); continue; }
 		if (DEF) parse_node_lw<DEF == 1 ? 3 : 0>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), lw, err);
 		else parse_node<DEF>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), err);
 	}
@@ -921,17 +923,17 @@ __global__ void __launch_bounds__(1024) k_sort_desc(int32_t *__restrict__ listA,
 // What the cooperative decoder needs to know about one long record, for a scan (slot of a node range) and for a
 // random-access batch (slot of a query's reference chain).  `prefix` = successors of all the slots before this one in
 // one common numbering: it places the record's slice of the interval arena.
-struct LongRec { int32_t x, d; bool hasRef; int64_t dref; int32_t *row; int64_t prefix; bool capOk; };
+struct LongRec { int32_t x, d; bool hasRef; int64_t dref; int32_t *row; int64_t prefix; int capErr; }; // capErr: 0, or the flag of the buffer the row does not fit
 __device__ __forceinline__ LongRec long_rec(const RangeView &v, int32_t s) {
 	const int32_t r = v.ref[s];
 	return LongRec{ v.lo + s, v.outd[s], r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), v.rowstart[s],
-	                !(s >= v.nh && (uint64_t)(v.rowstart[s + 1] - v.rowstart[v.nh]) > v.succ_cap) };
+	                v.fits(s) ? 0 : (s >= v.nh ? E_CAP : E_HALO) };
 }
 __device__ __forceinline__ LongRec long_rec(const BatchView &v, int32_t s) {
 	const int32_t qi = v.qidx[s];
 	const bool hasRef = v.depth[s] > 0;
 	return LongRec{ v.node[s], v.outd[s], hasRef, hasRef ? (int64_t)v.outd[s + 1] : 0, v.row(s), qi >= 0 ? v.arow[v.cnt] + v.rowptr[qi] : v.arow[s],
-	                !(qi >= 0 && (uint64_t)v.rowptr[qi + 1] > v.succ_cap) };
+	                (qi >= 0 && (uint64_t)v.rowptr[qi + 1] > v.succ_cap) ? E_CAP : 0 };
 }
 
 template <int DEF, int NW, class View>
@@ -953,7 +955,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? COOP1_MINWAVES : COOPG_MINW
 		__syncthreads();
 		if (idx >= count) break;
 		const LongRec rec = long_rec(v, list[idx]);
-		if (!rec.capOk) { if (threadIdx.x == 0) atomicOr(err, E_CAP); continue; }
+		if (rec.capErr) { if (threadIdx.x == 0) atomicOr(err, rec.capErr); continue; }
 		// arena slice of this record: interval counts are bounded by d / minIntervalLength, and
 		// floor(a/k) + floor(b/k) <= floor((a+b)/k) keeps the slices of different records disjoint
 		const int64_t abase = g.minInt > 0 ? rec.prefix / g.minInt : 0;
@@ -1016,7 +1018,7 @@ __global__ void __launch_bounds__(TPB) k_copy(GraphDev g, RangeView v, const int
 	if (s >= v.cnt) return;
 	if (depth[s] != level) return;
 	const int32_t r = v.ref[s];
-	if (s >= v.nh && (uint64_t)(v.rowstart[s + 1] - v.rowstart[v.nh]) > v.succ_cap) return; // E_CAP already raised by k_parse
+	if (!v.fits(s) || !v.fits(s - r)) return; // E_CAP / E_HALO already raised by k_parse
 	copy_node<DEF>(g, v.lo + s, v.outd[s], (int64_t)v.outd[s - r], v.row(s), v.row(s - r), err);
 }
 

@@ -19,6 +19,11 @@ struct RangeView {
 	int32_t *halo;          // halo rows
 	uint64_t succ_cap;      // capacity of succ in elements
 	int32_t coop_min;       // records with outdegree >= coop_min are decoded by whole waves (k_parse_big)
+	uint64_t halo_cap;      // capacity of halo in elements (a sub-range is decoded before the size of its halo is known on the host)
+	// does row s lie inside the buffer it belongs to?  (rows are laid out in node order: if s fits, so does every row before it in the same buffer)
+	__device__ __forceinline__ bool fits(int32_t s) const {
+		return s >= nh ? (uint64_t)(rowstart[s + 1] - rowstart[nh]) <= succ_cap : (uint64_t)rowstart[s + 1] <= halo_cap;
+	}
 	__device__ __forceinline__ int32_t *row(int32_t s) const {
 		const int64_t o = rowstart[s];
 		return s < nh ? halo + o : succ + (o - rowstart[nh]);

@@ -68,6 +68,12 @@ struct Pending { // an enqueued range decode whose status has not been collected
 	bool want_succ = false;
 	int32_t giantCap = 0, bigCap = 0, midCap = 0;
 	uint32_t tmpCap = 0;
+	// a sub-range decoded before its halo was sized (optimistic): what to repeat if the guess was wrong
+	bool optimistic = false;
+	int32_t from = 0, to = 0;
+	int64_t *rowptr = nullptr;
+	int32_t *succ = nullptr;
+	size_t succ_cap = 0;
 };
 
 } // namespace
@@ -103,6 +109,8 @@ struct bvg_graph {
 	hipStream_t sideA = nullptr, sideB = nullptr; // (more streams than this share hardware queues with each other: they would serialise)
 	hipEvent_t evFork = nullptr, evA = nullptr, evB = nullptr, evC = nullptr, evHdr = nullptr, evP = nullptr;
 	bool overlap = true;
+	size_t halo_min = (size_t)16 << 20; // bytes of halo scratch an optimistic sub-range decode starts with (BVGPU_HALO_MIN)
+	bool force_halo_sync = false;   // (retry of an optimistic sub-range decode: size the halo with a host round trip)
 	int64_t *early_rowptr = nullptr; // decode_range_device: caller's rowptr, written on a side stream as soon as the scan is done (set per call)
 	int batch_dense = 32;   // a random-access batch of q nodes with q * batch_dense >= n is decoded as a masked scan of the graph (0: never;
 	                        // measured crossover on the 10 M-node C2 graph: q = 300 000)
@@ -174,6 +182,7 @@ int init_handle(bvg_graph *g) {
 	if (const char *e = getenv("BVGPU_PARSE_WINDOWS")) g->parse_windows = atoi(e);
 	if (const char *e = getenv("BVGPU_COPY_MID_MIN")) g->copy_mid_min = std::min(std::max(0, atoi(e)), 1024); // 0: no wave-per-row copy
 	if (const char *e = getenv("BVGPU_OVERLAP")) g->overlap = atoi(e) != 0;
+	if (const char *e = getenv("BVGPU_HALO_MIN")) g->halo_min = (size_t)std::max(4, atoi(e));
 	if (const char *e = getenv("BVGPU_BATCH_DENSE")) g->batch_dense = std::max(0, atoi(e));
 	HIPCHK(g, hipStreamCreateWithFlags(&g->sideA, hipStreamNonBlocking));
 	HIPCHK(g, hipStreamCreateWithFlags(&g->sideB, hipStreamNonBlocking));
@@ -201,6 +210,7 @@ int enqueue_structure(bvg_graph *g, int32_t from, int32_t to, int32_t nh, bv::Ra
 	    (nh && !g->need.need((size_t)nh)))
 		return fail(g, BVG_ENOMEM, "device scratch allocation failed");
 	v = bv::RangeView{};
+	v.halo_cap = ~0ull;
 	v.lo = lo; v.cnt = cnt; v.nh = nh;
 	v.outd = g->outd.as<int32_t>(); v.ref = g->ref.as<uint16_t>(); v.rowstart = g->rowstart.as<int64_t>();
 	int *derr = &g->small.as<Small>()->err;
@@ -241,6 +251,8 @@ __global__ void k_totals(const int64_t *rowstart, int32_t nh, int32_t cnt, Small
 	sm->halo_total = rowstart[nh];
 }
 
+int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_dev, int32_t *succ_dev, size_t succ_cap, bool async, uint64_t *arcs_out);
+
 // Collects the status of the pending job: runs the reference-chain levels that the optimistic launch did
 // not cover, then reports errors / arc count.
 int finish_pending(bvg_graph *g, uint64_t *arcs_out) {
@@ -248,6 +260,16 @@ int finish_pending(bvg_graph *g, uint64_t *arcs_out) {
 	const Staged &s = *g->st;
 	int rc = fetch_small(g);
 	if (rc) { g->pend.active = false; return rc; }
+	if (g->pend.optimistic && (g->h_small->err & (bv::E_ESCAPED | bv::E_HALO))) {
+		if (getenv("BVGPU_TRACE_RETRY")) fprintf(stderr, "[bvgpu] optimistic halo missed (err %d): repeating [%d, %d)\n", g->h_small->err, g->pend.from, g->pend.to);
+		// the halo of this sub-range was deeper or larger than guessed: once more, sized with a host round trip
+		const Pending p = g->pend;
+		g->pend.active = false; g->pend.optimistic = false;
+		g->force_halo_sync = true;
+		rc = decode_range_device(g, p.from, p.to, p.rowptr, p.succ, p.succ_cap, false, arcs_out);
+		g->force_halo_sync = false;
+		return rc;
+	}
 	if (g->pend.want_succ && !g->h_small->err) {
 		const bv::GraphDev gd = graph_dev(s);
 		int *derr = &g->small.as<Small>()->err;
@@ -476,7 +498,18 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 		nh = (int32_t)std::min<int64_t>(from, (int64_t)W * mr);
 	}
 	bv::RangeView v;
-	for (;;) {
+	// A sub-range needs a halo whose depth and size are only known on the device.  The common case (chains no deeper
+	// than maxrefcount says, rows that fit the scratch buffer of the previous calls) is decoded without asking: the
+	// kernels check every halo row against the capacity, and finish_pending repeats the call the slow way if a chain
+	// escaped or a row did not fit.
+	const bool optimistic = nh > 0 && succ_dev && !g->force_halo_sync && g->overlap && !g->profile;
+	if (optimistic) {
+		if (!g->halo.need(std::max<size_t>(g->halo.cap, g->halo_min))) return fail(g, BVG_ENOMEM, "halo allocation failed");
+		int rc = enqueue_structure(g, from, to, nh, v);
+		if (rc) return rc;
+		v.halo_cap = g->halo.cap / sizeof(int32_t);
+	}
+	else for (;;) {
 		int rc = enqueue_structure(g, from, to, nh, v);
 		if (rc) return rc;
 		if (nh == 0) break;
@@ -516,6 +549,7 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 	{ int rc = join_to_user(g); if (rc) return rc; }
 	HIPCHK(g, hipGetLastError());
 	g->pend.active = true; g->pend.view = v; g->pend.levels_done = levels; g->pend.want_succ = succ_dev != nullptr; g->pend.giantCap = giantCap;
+	g->pend.optimistic = optimistic; g->pend.from = from; g->pend.to = to; g->pend.rowptr = rowptr_dev; g->pend.succ = succ_dev; g->pend.succ_cap = succ_cap;
 	if (async) return BVG_OK;
 	return finish_pending(g, arcs_out);
 }
@@ -787,6 +821,7 @@ extern "C" int bvg_successors_batch(bvg_t *g, const int32_t *nodes, size_t q, in
 		    !g->sums.need(sizeof(int64_t) * (size_t)bv::scan_num_sums((int64_t)std::max<size_t>((size_t)n, q))) || !g->b_qoutd.need(sizeof(int32_t) * q) || (succ && !g->need.need((size_t)n)))
 			return fail(g, BVG_ENOMEM, "device scratch allocation failed");
 		bv::RangeView v{};
+		v.halo_cap = ~0ull;
 		v.lo = 0; v.cnt = n; v.nh = n; // every row lives in the arena ("halo" rows of the scan)
 		v.outd = g->outd.as<int32_t>(); v.ref = g->ref.as<uint16_t>(); v.rowstart = g->rowstart.as<int64_t>();
 		bv::launch_headers(gd, s.def, 0, n, v.outd, v.ref, &dsm->err, g->stream);
