@@ -62,7 +62,9 @@ enum {
 	BVG_OUT_HOST = 0,     /* rowptr / succ / nodes are host pointers (copied through a staging buffer) */
 	BVG_OUT_DEVICE = 1,   /* ... are device pointers on the handle's device */
 	BVG_ASYNC = 2         /* with BVG_OUT_DEVICE: enqueue on the handle's stream and return without synchronising;
-	                         errors and *arcs_out are then delivered by bvg_sync() */
+	                         errors and *arcs_out are then delivered by bvg_sync(), which also launches what the
+	                         optimistic launch left out (deeper chain levels; a sub-range whose halo was deeper or
+	                         larger than guessed is decoded again there): the buffers must stay valid until then */
 };
 
 /* ---- lifecycle ------------------------------------------------------------------------------------- */
