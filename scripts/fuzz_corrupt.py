@@ -36,25 +36,45 @@ def main():
             pos = int(rng.integers(0, len(raw) // int(rng.choice([1, 1, 4, 64]))))
             raw[pos] ^= 1 << int(rng.integers(0, 8))
         open(base + ".graph", "wb").write(bytes(raw))
+        only = os.environ.get("FUZZ_ONLY")
+        skip = only is not None and c != int(only)
         os.environ["BVGPU_BATCH_DENSE"] = str(rng.choice(["0", "32", "1000000000"]))
         if rng.random() < 0.4:
             os.environ["BVGPU_COOP_MIN"] = "64"; os.environ["BVGPU_GIANT_MIN"] = "2000"
-        g = BVGraph.load(base)
+        if os.environ.get("FUZZ_VERBOSE") and c >= int(os.environ["FUZZ_VERBOSE"]):
+            print("case %d env dense=%s coop=%s" % (c, os.environ.get("BVGPU_BATCH_DENSE"), os.environ.get("BVGPU_COOP_MIN")), flush=True)
+        g = None if skip else BVGraph.load(base)
+        if only is not None and not skip and os.environ.get("FUZZ_KEEP"):
+            import shutil
+            for ext in (".graph", ".offsets", ".properties"):
+                shutil.copy(base + ext, os.path.join(os.environ["FUZZ_KEEP"], "case" + ext))
         for k in ("BVGPU_BATCH_DENSE", "BVGPU_COOP_MIN", "BVGPU_GIANT_MIN"):
             os.environ.pop(k, None)
+        import time as _t
         for what in range(3):
+            _t0 = _t.perf_counter()
+            if os.environ.get("FUZZ_VERBOSE") and c >= int(os.environ["FUZZ_VERBOSE"]):
+                print("case %d op %d start (%s)" % (c, what, base), flush=True)
             try:
                 if what == 0:
+                    if skip: continue
                     rp, sc = g.decode_range()
                 elif what == 1:
-                    lo = int(rng.integers(0, n - 1000)); rp, sc = g.decode_range(lo, lo + int(rng.integers(1, 50000)) if lo + 50000 < n else n)
+                    lo = int(rng.integers(0, n - 1000)); hi = lo + int(rng.integers(1, 50000)) if lo + 50000 < n else n
+                    if skip: continue
+                    rp, sc = g.decode_range(lo, hi)
                 else:
-                    rp, sc = g.successors_batch(rng.integers(0, n, size=int(10 ** rng.uniform(0, 4.7))).astype(np.int32))
+                    qq = rng.integers(0, n, size=int(10 ** rng.uniform(0, 4.7))).astype(np.int32)
+                    if skip: continue
+                    rp, sc = g.successors_batch(qq)
                 assert rp[0] == 0 and np.all(np.diff(rp) >= 0) and rp[-1] == sc.size, "malformed CSR"
                 outcomes["csr"] += 1
             except errs:
                 outcomes["error"] += 1
-        g.close()
+            if _t.perf_counter() - _t0 > 1.0:
+                print("slow request: case %d op %d took %.1f s (BATCH_DENSE/COOP env of this case: see seed)" % (c, what, _t.perf_counter() - _t0), flush=True)
+        if g is not None:
+            g.close()
         if c % 10 == 0:
             print("case %d ok %s" % (c, outcomes), flush=True)
     print("corrupt fuzz: %d cases, outcomes %s" % (cases, outcomes))

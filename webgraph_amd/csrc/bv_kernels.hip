@@ -93,20 +93,32 @@ __global__ void k_apply_need(int32_t nh, const uint8_t *__restrict__ need, int32
 // the scan; each needed record is then decoded ONCE, however many queries (or chains) want it, and the rows are
 // gathered into the caller's order at the end (k_gather_rows).
 __global__ void k_query_mark(const int32_t *__restrict__ nodes, int64_t q, int32_t n, const int32_t *__restrict__ outd, const uint16_t *__restrict__ ref,
-                             uint8_t *need, int32_t *__restrict__ qoutd, int *__restrict__ err) {
+                             uint8_t *need, int32_t *__restrict__ qoutd, int walk, int *__restrict__ err) {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= q) return;
 	const int32_t x = nodes[i];
 	if ((uint32_t)x >= (uint32_t)n) { atomicOr(err, E_ARG); qoutd[i] = 0; return; } // BVG:900
 	qoutd[i] = outd[x];
 	if (!need) return; // count only
-	// walk the chain; whoever marks a node first goes on from there, so a marked node ends the walk
+	if (!walk) { need[x] = 1; return; } // (the closure follows in streaming passes, k_need_prop)
+	// few queries: walk the chain; whoever marks a node first goes on from there, so a marked node ends the walk
 	int32_t y = x;
 	while (!need[y]) {
 		need[y] = 1;
 		if (outd[y] <= 0 || ref[y] == 0) break;
 		y -= (int32_t)ref[y]; // >= 0: k_headers drops references before node 0
 	}
+}
+// One step of the closure of the marks under "is copied from": every marked node marks its referent.  The passes
+// stream the three arrays (a chain walk per query is three random accesses per step: 0.6 ms for 10 M queries,
+// against 25 us per pass here); `changed` tells the host whether the closure had not been reached before this pass.
+__global__ void k_need_prop(int32_t n, const int32_t *__restrict__ outd, const uint16_t *__restrict__ ref, uint8_t *need, int32_t *__restrict__ changed) {
+	const int32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= n || !need[s] || outd[s] <= 0) return;
+	const int32_t r = ref[s];
+	if (r == 0) return;
+	const int32_t t = s - r; // >= 0: k_headers drops references before node 0
+	if (!need[t]) { need[t] = 1; if (changed) *changed = 1; }
 }
 
 constexpr int GATHER_ROWS = 256;
@@ -955,13 +967,15 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? COOP1_MINWAVES : COOPG_MINW
 		__syncthreads();
 		if (idx >= count) break;
 		const LongRec rec = long_rec(v, list[idx]);
-		if (rec.capErr) { if (threadIdx.x == 0) atomicOr(err, rec.capErr); continue; }
 		// arena slice of this record: interval counts are bounded by d / minIntervalLength, and
 		// floor(a/k) + floor(b/k) <= floor((a+b)/k) keeps the slices of different records disjoint
 		const int64_t abase = g.minInt > 0 ? rec.prefix / g.minInt : 0;
-		if (g.minInt > 0 && abase + rec.d / g.minInt + 1 > arenaCap) { if (threadIdx.x == 0) atomicOr(err, E_FORMAT); continue; }
+		// (one path to the end of the loop body: a `continue` behind `if (threadIdx.x == 0) ...` left the lanes of a
+		// one-wave block apart at the barrier at the top -- lane 0 late with the next index, the others reading the old one for ever)
+		const int bad = rec.capErr ? rec.capErr : (g.minInt > 0 && (abase < 0 || abase + rec.d / g.minInt + 1 > arenaCap)) ? E_FORMAT : 0;
 		const unsigned long long t0 = g.stats ? __builtin_readcyclecounter() : 0;
-		coop_parse_node<DEF, NW>(g, rec.x, rec.d, rec.hasRef, rec.dref, rec.row, arena + abase, lds, err);
+		if (bad) { if (threadIdx.x == 0) atomicOr(err, bad); }
+		else coop_parse_node<DEF, NW>(g, rec.x, rec.d, rec.hasRef, rec.dref, rec.row, arena + abase, lds, err);
 		if (g.stats) { const unsigned long long dt = __builtin_readcyclecounter() - t0; stat_add(g, 5, 1); stat_add(g, 6, dt); stat_max(g, 7, dt); }
 	}
 }
@@ -1219,10 +1233,26 @@ void launch_depth(int32_t cnt, const uint16_t *ref, int32_t *depth, int32_t *max
 	hipLaunchKernelGGL(k_depth, dim3(nblk(cnt, TPB)), dim3(TPB), 0, st, cnt, ref, depth, maxdepth);
 }
 
-void launch_query_mark(const int32_t *nodes, int64_t q, int32_t n, int32_t *outd, uint16_t *ref, uint8_t *need, int32_t *qoutd, int *err, hipStream_t st) {
+bool launch_query_mark(const int32_t *nodes, int64_t q, int32_t n, int32_t *outd, uint16_t *ref, uint8_t *need, int32_t *qoutd, int passes, int32_t *changed, int *err, hipStream_t st) {
 	if (need) (void)hipMemsetAsync(need, 0, (size_t)n, st);
-	hipLaunchKernelGGL(k_query_mark, dim3(nblk(q, TPB)), dim3(TPB), 0, st, nodes, q, n, outd, ref, need, qoutd, err);
-	if (need) hipLaunchKernelGGL(k_apply_need, dim3(nblk(n, TPB)), dim3(TPB), 0, st, n, need, outd, ref);
+	// many queries: marks closed by streaming passes over the nodes (25 us each on 10 M nodes); few: a chain walk per query
+	const bool walk = q * 4 < (int64_t)n;
+	hipLaunchKernelGGL(k_query_mark, dim3(nblk(q, TPB)), dim3(TPB), 0, st, nodes, q, n, outd, ref, need, qoutd, walk ? 1 : 0, err);
+	if (need && !walk) launch_need_prop(n, outd, ref, need, passes, changed, st);
+	return need && !walk; // true: *changed must be looked at (and more passes run) before the marks are used
+}
+// the marks again from scratch, a chain walk per query (for chains too deep for streaming passes)
+void launch_query_walk(const int32_t *nodes, int64_t q, int32_t n, int32_t *outd, uint16_t *ref, uint8_t *need, int32_t *qoutd, int *err, hipStream_t st) {
+	(void)hipMemsetAsync(need, 0, (size_t)n, st);
+	hipLaunchKernelGGL(k_query_mark, dim3(nblk(q, TPB)), dim3(TPB), 0, st, nodes, q, n, outd, ref, need, qoutd, 1, err);
+}
+// `passes` steps of the closure, then one more that reports into *changed whether it still found something to mark
+void launch_need_prop(int32_t n, const int32_t *outd, const uint16_t *ref, uint8_t *need, int passes, int32_t *changed, hipStream_t st) {
+	for (int p = 0; p < passes; p++) hipLaunchKernelGGL(k_need_prop, dim3(nblk(n, TPB)), dim3(TPB), 0, st, n, outd, ref, need, (int32_t *)nullptr);
+	hipLaunchKernelGGL(k_need_prop, dim3(nblk(n, TPB)), dim3(TPB), 0, st, n, outd, ref, need, changed);
+}
+void launch_apply_need(int32_t n, const uint8_t *need, int32_t *outd, uint16_t *ref, hipStream_t st) {
+	hipLaunchKernelGGL(k_apply_need, dim3(nblk(n, TPB)), dim3(TPB), 0, st, n, need, outd, ref);
 }
 void launch_gather_rows(const int32_t *nodes, int64_t q, int64_t arcs, const int64_t *rowstart, const int32_t *arena, const int64_t *rowptr, int32_t *succ, hipStream_t st) {
 	if (q <= 0) return;

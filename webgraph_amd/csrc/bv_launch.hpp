@@ -49,7 +49,10 @@ void launch_scan(const int32_t *in, int64_t n, int64_t *out, int64_t *sums, hipS
 int64_t scan_num_sums(int64_t n);
 void launch_depth(int32_t cnt, const uint16_t *ref, int32_t *depth, int32_t *maxdepth, hipStream_t st);
 void launch_rebase(int32_t nh, int32_t cnt, const int64_t *rowstart, int64_t *out, hipStream_t st);
-void launch_query_mark(const int32_t *nodes, int64_t q, int32_t n, int32_t *outd, uint16_t *ref, uint8_t *need, int32_t *qoutd, int *err, hipStream_t st);
+bool launch_query_mark(const int32_t *nodes, int64_t q, int32_t n, int32_t *outd, uint16_t *ref, uint8_t *need, int32_t *qoutd, int passes, int32_t *changed, int *err, hipStream_t st);
+void launch_query_walk(const int32_t *nodes, int64_t q, int32_t n, int32_t *outd, uint16_t *ref, uint8_t *need, int32_t *qoutd, int *err, hipStream_t st);
+void launch_need_prop(int32_t n, const int32_t *outd, const uint16_t *ref, uint8_t *need, int passes, int32_t *changed, hipStream_t st);
+void launch_apply_need(int32_t n, const uint8_t *need, int32_t *outd, uint16_t *ref, hipStream_t st);
 void launch_gather_rows(const int32_t *nodes, int64_t q, int64_t arcs, const int64_t *rowstart, const int32_t *arena, const int64_t *rowptr, int32_t *succ, hipStream_t st);
 void launch_parse(const GraphDev &g, int def, const RangeView &v, int *err, hipStream_t st);
 void launch_copy(const GraphDev &g, int def, const RangeView &v, const int32_t *depth, int32_t level, int *err, hipStream_t st);

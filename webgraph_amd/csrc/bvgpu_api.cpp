@@ -825,7 +825,23 @@ extern "C" int bvg_successors_batch(bvg_t *g, const int32_t *nodes, size_t q, in
 		v.lo = 0; v.cnt = n; v.nh = n; // every row lives in the arena ("halo" rows of the scan)
 		v.outd = g->outd.as<int32_t>(); v.ref = g->ref.as<uint16_t>(); v.rowstart = g->rowstart.as<int64_t>();
 		bv::launch_headers(gd, s.def, 0, n, v.outd, v.ref, &dsm->err, g->stream);
-		bv::launch_query_mark(d_nodes, (int64_t)q, n, v.outd, v.ref, succ ? g->need.as<uint8_t>() : nullptr, g->b_qoutd.as<int32_t>(), &dsm->err, g->stream);
+		// queries mark their nodes; the marks are closed under "is copied from" in streaming passes (as many as chains
+		// were deep last time, plus one that reports whether it still found something)
+		const bool streamed = bv::launch_query_mark(d_nodes, (int64_t)q, n, v.outd, v.ref, succ ? g->need.as<uint8_t>() : nullptr, g->b_qoutd.as<int32_t>(), g->levels_hint, &dsm->pad, &dsm->err, g->stream);
+		if (succ) {
+			for (int round = 0; streamed; round++) { // (the reporting pass found nothing in the common case: one round trip)
+				int rc0 = fetch_small(g);
+				if (rc0) return rc0;
+				if (!g->h_small->pad) break;
+				HIPCHK(g, hipMemsetAsync(&dsm->pad, 0, sizeof(int32_t), g->stream));
+				if (round == 6) { // chains of dozens of levels (no maxrefcount, or a corrupt file): a pass per level would never end -- walk them
+					bv::launch_query_walk(d_nodes, (int64_t)q, n, v.outd, v.ref, g->need.as<uint8_t>(), g->b_qoutd.as<int32_t>(), &dsm->err, g->stream);
+					break;
+				}
+				bv::launch_need_prop(n, v.outd, v.ref, g->need.as<uint8_t>(), 4, &dsm->pad, g->stream);
+			}
+			bv::launch_apply_need(n, g->need.as<uint8_t>(), v.outd, v.ref, g->stream);
+		}
 		bv::launch_scan(g->b_qoutd.as<int32_t>(), (int64_t)q, d_rowptr, g->sums.as<int64_t>(), g->stream);
 		HIPCHK(g, hipMemcpyAsync(&dsm->total, d_rowptr + q, sizeof(int64_t), hipMemcpyDeviceToDevice, g->stream));
 		if (succ) {
