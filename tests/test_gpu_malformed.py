@@ -81,3 +81,30 @@ def test_garbage_offsets_are_rejected(tmp_path):
     except _errors():
         pass
     g.close()
+
+
+@pytest.mark.timeout(120)
+def test_understated_arcs_is_an_error_not_a_livelock(tmp_path, monkeypatch):
+    """The interval arena of the cooperative parse kernels is sized from the `arcs` property.  A file that understates
+    it makes the slices of most long records fall outside: those records must be skipped with BVG_EFORMAT.  (The skip
+    used to be a `continue` behind `if (threadIdx.x == 0) ...` in a loop that hands out work through shared memory:
+    in a one-wave block the lanes never met again at the barrier and the kernel spun for ever.)"""
+    from webgraph_amd import tools as T
+    from webgraph_amd.bvgraph import BVGraph
+    rowptr, succ = T.generate(60000, 1500000, seed=77, p_copy=0.6)
+    base = str(tmp_path / "fewarcs")
+    T.store(base, rowptr, succ, window=7, max_ref_count=3, min_interval=3, zeta_k=5)
+    props = open(base + ".properties").read()
+    assert "arcs=%d" % succ.size in props
+    open(base + ".properties", "w").write(props.replace("arcs=%d" % succ.size, "arcs=3000"))
+    for env in ({"BVGPU_COOP_MIN": "64", "BVGPU_GIANT_MIN": "2000"}, {}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        g = BVGraph.load(base)
+        with pytest.raises(_errors()):
+            g.decode_range()
+        with pytest.raises(_errors()):
+            g.successors_batch(np.arange(0, 60000, 3, dtype=np.int32))
+        g.close()
+        for k in env:
+            monkeypatch.delenv(k)
