@@ -43,6 +43,7 @@ struct Staged {
 	uint64_t nwords = 0;
 	int64_t *d_offsets = nullptr;
 	std::vector<int64_t> h_offsets; // host copy: shard bounds and halo sizing
+	int64_t arcs_sizing = 0;        // max(arcs property, sum of the outdegrees in the stream): what scratch is sized by
 	int def = 0;                    // kernel variant: 1 default codings with zeta_3, 2 default codings with another zeta_k, 0 generic
 	std::string basename;
 	~Staged() {
@@ -331,7 +332,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 	if (!g->fused) {
 		// default path: depth + per-level lists; cooperative decode of long records (two classes) next to the
 		// one-lane decode of the short ones; then the copy pass level by level over compact lists
-		const int64_t arcsBound = std::max<int64_t>(s.info.arcs, 1);
+		const int64_t arcsBound = std::max<int64_t>(s.arcs_sizing, 1);
 		giantCap = (int32_t)std::min<int64_t>(arcsBound / giantMin + 2, 0x7fffffff);
 		const int64_t arenaCap = s.info.min_interval_length > 0 ? arcsBound / s.info.min_interval_length + 2 : 1;
 		if (!g->depth.need(sizeof(int32_t) * (size_t)v.cnt) || !g->key16.need(sizeof(uint16_t) * (size_t)v.cnt) || !g->lvlist.need(sizeof(int32_t) * (size_t)v.cnt) ||
@@ -438,7 +439,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		}
 	}
 	if (g->fused) {
-		const int64_t arcsBound = std::max<int64_t>(s.info.arcs, 1);
+		const int64_t arcsBound = std::max<int64_t>(s.arcs_sizing, 1);
 		// a giant record has >= giant_bits bits; the whole stream has graph_bytes * 8
 		// a giant record has >= giant_bits bits or >= giant_bits / 8 successors
 		giantCap = (int32_t)std::min<uint64_t>((s.info.graph_bytes * 8 + (uint64_t)arcsBound * 8) / std::max<uint64_t>(g->giant_bits, 1) + 2, 0x7fffffff);
@@ -664,6 +665,26 @@ extern "C" int bvg_open(const char *basename, int device, bvg_t **out) {
 	st->info.offsets_on_device = onDevice ? 1 : 0;
 	if ((uint64_t)st->h_offsets.back() > (uint64_t)graph.size() * 8) return fail(g, BVG_EIO, "offsets run past the end of the .graph file");
 	for (size_t i = 1; i < st->h_offsets.size(); i++) if (st->h_offsets[i] < st->h_offsets[i - 1]) return fail(g, BVG_EIO, "offsets are not monotone");
+	// Scratch (interval arena, copy queues, giant list) is sized by the number of arcs: by what the stream holds, not by
+	// what .properties claims -- one pass over the record headers at load time
+	st->arcs_sizing = std::max<int64_t>(in.arcs, 1);
+	if (in.nodes > 0) {
+		const int32_t n = in.nodes;
+		void *p_outd = nullptr, *p_ref = nullptr, *p_rs = nullptr, *p_sums = nullptr, *p_err = nullptr;
+		const bool ok = hipMalloc(&p_outd, sizeof(int32_t) * (size_t)n) == hipSuccess && hipMalloc(&p_ref, sizeof(uint16_t) * (size_t)n) == hipSuccess &&
+		                hipMalloc(&p_rs, sizeof(int64_t) * ((size_t)n + 1)) == hipSuccess && hipMalloc(&p_sums, sizeof(int64_t) * (size_t)bv::scan_num_sums(n)) == hipSuccess &&
+		                hipMalloc(&p_err, sizeof(int)) == hipSuccess;
+		int64_t total = 0;
+		hipError_t e = ok ? hipMemset(p_err, 0, sizeof(int)) : hipErrorOutOfMemory;
+		if (e == hipSuccess) {
+			bv::launch_headers(graph_dev0(*st), st->def, 0, n, (int32_t *)p_outd, (uint16_t *)p_ref, (int *)p_err, nullptr);
+			bv::launch_scan((const int32_t *)p_outd, n, (int64_t *)p_rs, (int64_t *)p_sums, nullptr);
+			e = hipMemcpy(&total, (int64_t *)p_rs + n, sizeof(int64_t), hipMemcpyDeviceToHost);
+		}
+		for (void *q : { p_outd, p_ref, p_rs, p_sums, p_err }) if (q) (void)hipFree(q);
+		if (e != hipSuccess) return fail(g, e == hipErrorOutOfMemory ? BVG_ENOMEM : BVG_EHIP, "cannot scan the record headers");
+		st->arcs_sizing = std::max<int64_t>(st->arcs_sizing, total);
+	}
 	g->st = st;
 	return init_handle(g);
 }
