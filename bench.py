@@ -30,15 +30,17 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def prepare_graph(n, m, seed, p_copy, cache_dir, threads):
+def prepare_graph(n, m, seed, p_copy, cache_dir, threads, p_same=0.0, p_keep=0.7):
     """Generates + compresses the synthetic workload unless it is already in the cache directory."""
     from webgraph_amd import tools as T
     os.makedirs(cache_dir, exist_ok=True)
     base = os.path.join(cache_dir, "syn_n%d_m%d_s%x_p%02d" % (n, m, seed, int(round(p_copy * 100))))
+    if p_same:
+        base += "_r%02d_k%02d" % (int(round(p_same * 100)), int(round(p_keep * 100)))
     done = base + ".done"
     if not os.path.exists(done):
         t0 = time.time()
-        rowptr, succ = T.generate(n, m, seed=seed, p_copy=p_copy, threads=threads)
+        rowptr, succ = T.generate(n, m, seed=seed, p_copy=p_copy, threads=threads, p_same=p_same, p_keep=p_keep)
         t1 = time.time()
         st = T.store(base, rowptr, succ, window=7, max_ref_count=3, min_interval=4, zeta_k=3, flags=0, threads=threads)
         t2 = time.time()

@@ -127,6 +127,29 @@ int bvg_decode_range(bvg_t *g, int32_t from, int32_t to, int64_t *rowptr, int32_
                      uint64_t *arcs_out, int flags);
 
 /*
+ * The same scan with the results in pinned host memory OWNED BY THE HANDLE: one call, no counting call before it, the
+ * successors cross PCIe chunk by chunk while the next chunk is being decoded.  *rowptr_out (to-from+1 entries) and
+ * *succ_out (*arcs_out entries) stay valid until the next call on this handle.  What a JNI caller wants: one native call,
+ * then NewIntArray + SetIntArrayRegion (or a direct ByteBuffer over the pinned memory).
+ * bvg_decode_range with BVG_OUT_HOST runs the same pipeline into the caller's buffers (at PCIe speed when they are
+ * pinned -- bvg_host_alloc --, through a pinned ring and host threads when they are pageable).
+ */
+int bvg_decode_range_view(bvg_t *g, int32_t from, int32_t to, const int64_t **rowptr_out, const int32_t **succ_out, uint64_t *arcs_out);
+
+/* Pinned host memory for output buffers (hipHostMalloc); release with bvg_host_free. */
+int bvg_host_alloc(size_t bytes, void **out);
+void bvg_host_free(void *p);
+
+/*
+ * A scan that hands nothing back but its fingerprint -- the consumer every test of the reference is
+ * (ImmutableGraph.equals / hashCode, ImmutableGraph.java:731-770) and the first of the no-materialise modes (SURVEY.md
+ * section 8 row f4): continues ImmutableGraph.hashCode() from *hash_io over nodes [from, to) and counts their arcs.  The rows
+ * are decoded piece by piece into library scratch that stays on the die; no 4 B/edge array reaches the caller.
+ * Shards compose: h(whole) = fold of the shards' maps in node order (webgraph_amd/parallel.py).
+ */
+int bvg_scan_checksum(bvg_t *g, int32_t from, int32_t to, int32_t *hash_io, uint64_t *arcs_out);
+
+/*
  * Random access: concatenation of successorArray(nodes[i]) (BVG:897-904, ImmutableGraph.java:329-333),
  * reference chains resolved on the device.  rowptr has q+1 entries; ids may repeat and come in any order; an id
  * outside [0, n) is BVG_EARG (BVG:900).  succ == NULL: count-only; BVG_ECAP as above, checked before any decode.

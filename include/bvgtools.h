@@ -48,7 +48,20 @@ int bvt_store(const char *basename, int32_t n, const int64_t *rowptr, const int3
 int bvt_generate(int32_t n, int64_t m, uint64_t seed, double p_copy, int threads,
                  int64_t **rowptr_out, int32_t **succ_out);
 
+/* The same generator with two more knobs (config C5): p_same = probability that a node repeats its predecessor's raw
+ * outdegree and, when it copies, takes that predecessor as its prototype; p_keep = probability that a prototype's successor
+ * is kept (0.7 in C2).  bvt_generate(...) == bvt_generate_ex(..., p_same 0, p_keep 0.7, ...). */
+int bvt_generate_ex(int32_t n, int64_t m, uint64_t seed, double p_copy, double p_same, double p_keep, int threads,
+                    int64_t **rowptr_out, int32_t **succ_out);
+
 void bvt_free(void *p);
+
+/*
+ * The node ids of the random-access leg of the reference's SpeedTest (src/it/unimi/dsi/webgraph/test/SpeedTest.java:79,
+ * :98-111): XoRoShiRo128PlusRandom.setSeed(seed), then nextInt(n) `count` times (dsiutils' generator restated; see the
+ * source for what is pinned).  Config C4 of BASELINE.json uses seed 0x5EEDB5E70004.
+ */
+int bvt_random_nodes(uint64_t seed, int32_t n, int64_t count, int32_t *out);
 
 /*
  * Arc labels: writes <basename>.labels / .labeloffsets / .properties as

@@ -42,8 +42,11 @@ public class GpuBVGraph extends ImmutableGraph {
 	private static native long[] info(long handle);                                             // bvg_info: {nodes, arcs, window, maxref}
 	private static native int outdegree(long handle, int x);                                    // bvg_outdegrees(x, x+1)
 	private static native int[] successorArray(long handle, int x);                             // bvg_successors_batch, q = 1
-	/** Fills rowptr[to-from+1]; returns the successors of nodes [from,to) concatenated. */
-	private static native int[] decodeRange(long handle, int from, int to, long[] rowptr);      // bvg_decode_range
+	/** Fills rowptr[to-from+1]; returns the successors of nodes [from,to) concatenated.  ONE native call: the results arrive in
+	 *  the handle's pinned buffers (chunks cross PCIe while the next chunk is decoded) and are copied into a fresh int[]. */
+	private static native int[] decodeRange(long handle, int from, int to, long[] rowptr);      // bvg_decode_range_view
+	/** hashCode() continued from h over [from,to) on the device; nothing is materialised. */
+	private static native int scanChecksum(long handle, int from, int to, int h);               // bvg_scan_checksum
 
 	private GpuBVGraph(final long handle, final CharSequence basename) {
 		this.handle = handle;
@@ -83,7 +86,10 @@ public class GpuBVGraph extends ImmutableGraph {
 	/** Flyweight copy sharing the staged graph (BVGraph.copy()). */
 	@Override public GpuBVGraph copy() { return new GpuBVGraph(cloneHandle(handle), basename); }
 
-	@Override public NodeIterator nodeIterator(final int from) { return new BatchIterator(from, Integer.MAX_VALUE); }
+	@Override public NodeIterator nodeIterator(final int from) { return new BatchIterator(handle, false, from, Integer.MAX_VALUE); }
+
+	/** ImmutableGraph.hashCode() (ImmutableGraph.java:757-770) as one checksum scan on the device. */
+	@Override public int hashCode() { return scanChecksum(handle, 0, n, -1); }
 
 	/** Sequential scan served from GPU-decoded batches; same contract as BVGraph's node iterator. */
 	private final class BatchIterator extends NodeIterator {
@@ -91,19 +97,29 @@ public class GpuBVGraph extends ImmutableGraph {
 		private int curr, lo, hi;
 		private long[] rowptr;
 		private int[] succ;
+		/** The bvg_t this iterator decodes through.  A copy (and so every split iterator) owns a flyweight handle of its
+		 *  own (bvg_clone): the reference hands copies to other threads (BVGraph.java:2471-2477, ImmutableGraph.java:379-409)
+		 *  and a bvg_t is not thread-safe.  Closed when the iterator is exhausted, or by the finalizer. */
+		private long h;
+		private final boolean ownsHandle;
 
-		BatchIterator(final int from, final int upperBound) {
+		BatchIterator(final long h, final boolean ownsHandle, final int from, final int upperBound) {
 			if (from < 0 || from > n) throw new IllegalArgumentException("Node index out of range: " + from);
+			this.h = h; this.ownsHandle = ownsHandle;
 			this.from = from; curr = from - 1; lo = hi = from;
 			limit = Math.min(upperBound, n) - 1;
 		}
+		private void release() { if (ownsHandle && h != 0) { close(h); h = 0; } }
+		@SuppressWarnings("deprecation")
+		@Override protected void finalize() throws Throwable { try { release(); } finally { super.finalize(); } }
 		@Override public boolean hasNext() { return curr < limit; }
 		@Override public int nextInt() {
 			if (!hasNext()) throw new NoSuchElementException();
 			if (++curr >= hi) {
 				lo = curr; hi = (int)Math.min((long)lo + BATCH_NODES, (long)limit + 1);
 				rowptr = new long[hi - lo + 1];
-				succ = decodeRange(handle, lo, hi, rowptr);
+				succ = decodeRange(h, lo, hi, rowptr);
+				if (hi > limit) release(); // the last batch is in: the handle is not needed any more
 			}
 			return curr;
 		}
@@ -118,7 +134,7 @@ public class GpuBVGraph extends ImmutableGraph {
 			return a;
 		}
 		@Override public LazyIntIterator successors() { final int[] a = successorArray(); return LazyIntIterators.wrap(a, a.length); }
-		@Override public NodeIterator copy(final int upperBound) { return new BatchIterator(curr + 1, upperBound); }
+		@Override public NodeIterator copy(final int upperBound) { return new BatchIterator(cloneHandle(handle), true, curr + 1, upperBound); }
 	}
 
 	@SuppressWarnings("deprecation")

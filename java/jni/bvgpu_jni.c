@@ -4,6 +4,7 @@
  *   gcc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -I../../include bvgpu_jni.c -L../../webgraph_amd -lbvgpu -o libbvgpu_jni.so
  */
 #include <jni.h>
+#include <limits.h>
 #include <stdlib.h>
 #include "bvgpu.h"
 
@@ -52,26 +53,35 @@ JNIEXPORT jintArray JNICALL Java_it_unimi_dsi_webgraph_gpu_GpuBVGraph_successorA
 	int64_t rp[2]; uint64_t arcs = 0; int32_t node = x;
 	int rc = bvg_successors_batch(h, &node, 1, rp, NULL, 0, &arcs, BVG_OUT_HOST);
 	if (rc) { throw_status(env, rc, h); return NULL; }
+	if (arcs > (uint64_t)INT_MAX) { throw_status(env, BVG_ENOMEM, NULL); return NULL; }
 	jintArray a = (*env)->NewIntArray(env, (jsize)arcs);   /* a fresh exact-length array per call, ImmutableGraph.java:329-333 */
+	if (!a) return NULL;                                    /* OutOfMemoryError is pending */
 	jint *p = (*env)->GetPrimitiveArrayCritical(env, a, NULL);
+	if (!p) return NULL;
 	rc = bvg_successors_batch(h, &node, 1, rp, (int32_t *)p, arcs, &arcs, BVG_OUT_HOST);
 	(*env)->ReleasePrimitiveArrayCritical(env, a, p, 0);
 	if (rc) { throw_status(env, rc, h); return NULL; }
 	return a;
 }
+/* ONE library call per batch: the scan runs once, its chunks cross PCIe into the handle's pinned buffers while the next
+ * chunk is decoded (bvg_decode_range_view); the JVM then copies them into the arrays it owns. */
 JNIEXPORT jintArray JNICALL Java_it_unimi_dsi_webgraph_gpu_GpuBVGraph_decodeRange(JNIEnv *env, jclass c, jlong handle, jint from, jint to, jlongArray rowptr) {
 	bvg_t *h = (bvg_t *)(intptr_t)handle;
+	const int64_t *rp = NULL; const int32_t *sc = NULL;
 	uint64_t arcs = 0;
-	jlong *rp = (*env)->GetLongArrayElements(env, rowptr, NULL);
-	int rc = bvg_decode_range(h, from, to, (int64_t *)rp, NULL, 0, &arcs, BVG_OUT_HOST);           /* count */
-	jintArray a = NULL;
-	if (!rc) {
-		a = (*env)->NewIntArray(env, (jsize)arcs);
-		jint *p = (*env)->GetPrimitiveArrayCritical(env, a, NULL);
-		rc = bvg_decode_range(h, from, to, (int64_t *)rp, (int32_t *)p, arcs, &arcs, BVG_OUT_HOST);  /* decode */
-		(*env)->ReleasePrimitiveArrayCritical(env, a, p, 0);
-	}
-	(*env)->ReleaseLongArrayElements(env, rowptr, rp, 0);
+	const int rc = bvg_decode_range_view(h, from, to, &rp, &sc, &arcs);
 	if (rc) { throw_status(env, rc, h); return NULL; }
+	if (arcs > (uint64_t)INT_MAX) { throw_status(env, BVG_ENOMEM, NULL); return NULL; } /* a Java array holds < 2^31 ints: use smaller batches */
+	jintArray a = (*env)->NewIntArray(env, (jsize)arcs);
+	if (!a) return NULL;                                    /* OutOfMemoryError is pending */
+	(*env)->SetLongArrayRegion(env, rowptr, 0, (jsize)(to - from + 1), (const jlong *)rp);
+	(*env)->SetIntArrayRegion(env, a, 0, (jsize)arcs, (const jint *)sc);
 	return a;
+}
+JNIEXPORT jint JNICALL Java_it_unimi_dsi_webgraph_gpu_GpuBVGraph_scanChecksum(JNIEnv *env, jclass c, jlong handle, jint from, jint to, jint hash) {
+	bvg_t *h = (bvg_t *)(intptr_t)handle;
+	int32_t v = hash;
+	const int rc = bvg_scan_checksum(h, from, to, &v, NULL);
+	if (rc) throw_status(env, rc, h);
+	return v;
 }

@@ -452,6 +452,26 @@ int bvo_outdegrees(const bvo_graph *h, int32_t from, int32_t to, int32_t *out) {
 	return BVO_OK;
 }
 
+/* reference field of every node of [from,to), 0 where there is none (empty node, window 0): BVG:1048-1056.
+ * Chain depths -- what maxrefcount bounds in a file written by the reference, BVG:2315-2326 -- follow from it. */
+int bvo_references(const bvo_graph *h, int32_t from, int32_t to, int32_t *out) {
+	if (from < 0 || to > h->p.n || from > to) return BVO_EARG;
+	if (!h->offsets) return BVO_ESTATE;
+	for (int32_t x = from; x < to; x++) {
+		ibs_t s = { h->g, (uint64_t)h->offsets[x], (uint64_t)h->len * 8, 0 };
+		int unsup = 0;
+		const uint64_t d = read_coded(&s, h->p.outdegree_coding, 0, &unsup);
+		uint64_t r = 0;
+		if (d != 0 && h->p.window > 0) {
+			r = read_coded(&s, h->p.reference_coding, 0, &unsup);
+			if (r > (uint64_t)h->p.window) return BVO_ESTATE; /* BVG:705 */
+		}
+		if (s.err || unsup) return unsup ? BVO_EUNSUP : BVO_EARG;
+		out[x - from] = (int32_t)r;
+	}
+	return BVO_OK;
+}
+
 /* batch of random-access successor lists: concatenation of successorArray(nodes[i]) */
 int bvo_successors_batch(const bvo_graph *h, const int32_t *nodes, size_t q, int64_t *rowptr, int32_t *succ, size_t cap) {
 	uint64_t arcs = 0;

@@ -53,6 +53,7 @@ def lib():
         L.bvo_scan.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t,
                                C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
         L.bvo_successors_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.bvo_references.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         _lib = L
     return _lib
 
@@ -213,6 +214,53 @@ class OracleGraph:
         if want_hash:
             return rowptr, succ, arcs.value, h.value
         return rowptr, succ, arcs.value
+
+    def references(self, lo=0, hi=None):
+        """Reference field of every node of [lo, hi) (0 = none)."""
+        hi = self.n if hi is None else hi
+        out = np.empty(hi - lo, dtype=np.int32)
+        rc = lib().bvo_references(self._h, lo, hi, out.ctypes.data)
+        if rc:
+            raise OracleError(rc)
+        return out
+
+    def chain_depths(self):
+        """Length of every node's reference chain (0 = no reference): what maxrefcount bounds (BVGraph.java:2315-2326)."""
+        ref = self.references().astype(np.int64)
+        idx = np.arange(self.n, dtype=np.int64)
+        depth = np.zeros(self.n, dtype=np.int32)
+        has = ref > 0
+        for _ in range(1 << 16):  # one pass per level
+            nd = np.where(has, depth[idx - ref] + 1, 0).astype(np.int32)
+            if np.array_equal(nd, depth):
+                break
+            depth = nd
+        return depth
+
+    def scan_mt(self, lo=0, hi=None, threads=None, want_succ=True):
+        """scan(lo, hi) on `threads` host threads: contiguous node ranges holding the same share of the bit stream, the
+        window of each refilled through the random-access path (as ImmutableGraph.splitNodeIterators does,
+        ImmutableGraph.java:379-409; ctypes releases the GIL).  Returns (rowptr, succ or None, arcs)."""
+        import concurrent.futures as cf
+        hi = self.n if hi is None else hi
+        T = max(1, min(threads or (os.cpu_count() or 1), 256, max(hi - lo, 1)))
+        off = self.offsets
+        cuts = [lo]
+        for k in range(1, T):
+            t = int(off[lo]) + (int(off[hi]) - int(off[lo])) * k // T
+            cuts.append(max(cuts[-1], min(hi, int(np.searchsorted(off[lo:hi], t, side="left")) + lo)))
+        cuts.append(hi)
+        rngs = [(cuts[k], cuts[k + 1]) for k in range(T) if cuts[k + 1] > cuts[k]] or [(lo, hi)]
+        with cf.ThreadPoolExecutor(max_workers=len(rngs)) as ex:
+            parts = list(ex.map(lambda ab: self.scan(ab[0], ab[1], want_succ=want_succ), rngs))
+        rowptr = np.empty(hi - lo + 1, dtype=np.int64)
+        rowptr[0] = 0
+        base = 0
+        for (a, b), (rp, sc, arcs) in zip(rngs, parts):
+            rowptr[a - lo + 1:b - lo + 1] = rp[1:] + base
+            base += arcs
+        succ = np.concatenate([p[1] for p in parts]) if want_succ else None
+        return rowptr, succ, base
 
     def hashcode(self):
         """ImmutableGraph.hashCode() (ImmutableGraph.java:757-770)."""

@@ -2,8 +2,10 @@
 // (WebGraphTestCase.assertGraph / BVGraphTest.testLarge).  Usage: host_mirror_test <basename> <expected hashCode> <expected arcs>
 #include "../../webgraph_amd/host/bvgraph.hpp"
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
+#include <thread>
 
 #define REQUIRE(c) do { if (!(c)) { fprintf(stderr, "FAILED: %s (line %d)\n", #c, __LINE__); return 1; } } while (0)
 
@@ -36,6 +38,37 @@ int main(int argc, char **argv) {
 		int32_t seen = 0;
 		for (NodeIterator &s : g.splitNodeIterators(5)) while (s.hasNext()) REQUIRE(s.nextInt() == seen++);
 		REQUIRE(seen == n);
+		// ... and are drained by concurrent threads, as the reference's parallel consumers do (BVGraph.java:2471-2477,
+		// ImmutableGraph.java:379-409): every split iterator decodes through a flyweight handle of its own
+		{
+			std::vector<NodeIterator> parts = g.splitNodeIterators(4);
+			std::vector<uint32_t> fa(parts.size(), 1), fb(parts.size(), 0); // the affine map h -> a*h + b of each part
+			std::vector<int64_t> parcs(parts.size(), 0);
+			std::atomic<int> bad{ 0 };
+			std::vector<std::thread> th;
+			for (size_t k = 0; k < parts.size(); k++) th.emplace_back([&, k] {
+				try {
+					NodeIterator &s = parts[k];
+					uint32_t a = 1, b = 0;
+					while (s.hasNext()) {
+						const int32_t x = s.nextInt();
+						a *= 31u; b = b * 31u + (uint32_t)x;
+						const int32_t *sc = s.successorArray();
+						for (int32_t d = s.outdegree(); d-- != 0;) { a *= 31u; b = b * 31u + (uint32_t)sc[d]; }
+						parcs[k] += s.outdegree();
+					}
+					fa[k] = a; fb[k] = b;
+				} catch (...) { bad++; }
+			});
+			for (auto &t : th) t.join();
+			REQUIRE(bad == 0);
+			uint32_t h = (uint32_t)-1;
+			int64_t tot = 0;
+			for (size_t k = 0; k < parts.size(); k++) { h = fa[k] * h + fb[k]; tot += parcs[k]; }
+			REQUIRE((int32_t)h == atoi(argv[2]) && tot == g.numArcs());
+		}
+		// the checksum scan (nothing materialised) agrees with the host-side fold
+		{ uint64_t a = 0; REQUIRE(g.scanChecksum(0, n, -1, &a) == atoi(argv[2]) && (int64_t)a == g.numArcs()); }
 		// flyweight copy
 		BVGraph c = g.copy();
 		REQUIRE(c.successorArray(n - 1) == g.successorArray(n - 1));

@@ -1,0 +1,161 @@
+"""Every BASELINE.json configuration at its real size (or, for the 8-GPU ones, one GPU's share of it) through the C ABI
+against the CPU oracle: C2 (10 M nodes / 200 M arcs, the configuration the metric is quoted on, with the library's default
+thresholds), C4 (10 M random ids on the C2 graph, SpeedTest's generator and seed), a C5 shard (12.5 M nodes / 250 M arcs with
+deep reference chains) decoded whole and in the eight bits-balanced slices of SURVEY.md section 8(e), and a web-graph-shaped
+input (the reference's cnr-2000 fixture tiled 30 times).  The oracle runs on all host cores (ranges split as
+ImmutableGraph.splitNodeIterators does); each test takes some tens of seconds."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import CNR
+
+pytestmark = pytest.mark.gpu
+
+CACHE = os.environ.get("BVGPU_CACHE", "/tmp/bvgpu_cache")
+C2 = dict(n=10_000_000, m=200_000_000, seed=0x5EEDB5E70001, p_copy=0.5, p_same=0.0, p_keep=0.7)
+C5_SHARD = dict(n=12_500_000, m=250_000_000, seed=0x5EEDB5E70005, p_copy=0.85, p_same=0.95, p_keep=0.95)
+
+
+def _prepare(cfg):
+    import bench
+    return bench.prepare_graph(cfg["n"], cfg["m"], cfg["seed"], cfg["p_copy"], CACHE, os.cpu_count() or 1, p_same=cfg["p_same"], p_keep=cfg["p_keep"])[0]
+
+
+def _device_scan(g, lo=0, hi=None):
+    import torch
+    hi = g.numNodes() if hi is None else hi
+    dev = torch.device("cuda", 0)
+    rowptr = torch.empty(hi - lo + 1, dtype=torch.int64, device=dev)
+    arcs = g.decode_range_device(lo, hi, rowptr.data_ptr(), None, 0)
+    succ = torch.empty(max(arcs, 1), dtype=torch.int32, device=dev)
+    got = g.decode_range_device(lo, hi, rowptr.data_ptr(), succ.data_ptr(), succ.numel())
+    assert got == arcs
+    return rowptr, succ, arcs
+
+
+@pytest.fixture(scope="module")
+def c2():
+    from oracle import oracle as O
+    from webgraph_amd.bvgraph import BVGraph
+    base = _prepare(C2)
+    g = BVGraph.load(base)
+    og = O.OracleGraph.load(base)
+    yield g, og
+    g.close()
+
+
+@pytest.mark.timeout(900)
+def test_c2_full_size_default_thresholds(c2):
+    """The headline configuration, whole: 200 M arcs, so the job-size dependent thresholds are the full-scan ones (a wave
+    per record from 2 048 successors, a group of waves from 32 768)."""
+    g, og = c2
+    assert g.numNodes() == C2["n"] and g.numArcs() == C2["m"]
+    rowptr, succ, arcs = _device_scan(g)
+    assert arcs == C2["m"]
+    orp, osc, oarcs = og.scan_mt()
+    assert oarcs == arcs
+    assert np.array_equal(rowptr.cpu().numpy(), orp), "rowptr differs from the CPU oracle"
+    assert np.array_equal(succ.cpu().numpy(), osc), "successors differ from the CPU oracle"
+    oh = og.hashcode()
+    assert g.csr_hashcode(0, g.numNodes(), rowptr.data_ptr(), succ.data_ptr(), -1) == oh
+    h, a = g.scan_checksum()
+    assert (h, a) == (oh, arcs)
+
+
+@pytest.mark.timeout(900)
+def test_c4_random_batch_on_c2(c2):
+    """C4: successors(x) for 10 M ids drawn like SpeedTest's random leg (xoroshiro128+, seed 0x5EEDB5E70004,
+    SpeedTest.java:95-111), ids and results resident in HBM."""
+    import ctypes as C
+    import torch
+    from webgraph_amd import bvgraph as B
+    from webgraph_amd import tools as T
+    g, og = c2
+    n = g.numNodes()
+    q = T.random_nodes(n, 10_000_000, seed=0x5EEDB5E70004)
+    dev = torch.device("cuda", 0)
+    d_q = torch.from_numpy(q).to(dev)
+    d_rowptr = torch.empty(q.size + 1, dtype=torch.int64, device=dev)
+    arcs = C.c_uint64(0)
+    lib = B.lib()
+    assert lib.bvg_successors_batch(g._h, d_q.data_ptr(), q.size, d_rowptr.data_ptr(), None, 0, C.byref(arcs), B.BVG_OUT_DEVICE) == 0
+    d_succ = torch.empty(max(arcs.value, 1), dtype=torch.int32, device=dev)
+    assert lib.bvg_successors_batch(g._h, d_q.data_ptr(), q.size, d_rowptr.data_ptr(), d_succ.data_ptr(), d_succ.numel(), C.byref(arcs), B.BVG_OUT_DEVICE) == 0
+    rp = d_rowptr.cpu().numpy()
+    deg = og.outdegrees().astype(np.int64)
+    assert np.array_equal(np.diff(rp), deg[q]) and rp[-1] == arcs.value      # every query: the right number of successors
+    k = 200_000
+    orp, osc = og.successors_batch(q[:k])                                     # a sample of them: the right successors
+    assert np.array_equal(rp[:k + 1], orp) and np.array_equal(d_succ[:int(orp[-1])].cpu().numpy(), osc)
+    orp, osc = og.successors_batch(q[-k:])
+    tail = d_succ[int(rp[-k - 1]):int(rp[-1])].cpu().numpy()
+    assert np.array_equal(rp[-k - 1:] - rp[-k - 1], orp) and np.array_equal(tail, osc)
+    # the whole output is a concatenation of strictly increasing lists
+    bad = (d_succ[1:arcs.value] <= d_succ[:arcs.value - 1]).nonzero().flatten() + 1
+    starts = torch.zeros(arcs.value + 1, dtype=torch.bool, device=dev)
+    starts[d_rowptr] = True
+    assert bool(starts[bad].all())
+
+
+@pytest.mark.timeout(1200)
+def test_c5_shard_deep_chains():
+    """One GPU's share of C5 (100 M nodes / 2 B arcs over 8 GPUs): 12.5 M nodes / 250 M arcs, maxRefCount 3, at least 40 % of
+    the non-empty nodes at chain depth 3 (cnr-2000: 47.5 %).  Decoded whole and as the eight bits-balanced slices a node of
+    8 GPUs would take; the slices' (arcs, affine hash) fold to the whole graph's hashCode."""
+    from oracle import oracle as O
+    from webgraph_amd import parallel as P
+    from webgraph_amd.bvgraph import BVGraph
+    base = _prepare(C5_SHARD)
+    og = O.OracleGraph.load(base)
+    depth = og.chain_depths()
+    od = og.outdegrees()
+    share = np.bincount(depth[od > 0], minlength=4) / max(int((od > 0).sum()), 1)
+    assert depth.max() == 3 and share[3] >= 0.40, share
+    g = BVGraph.load(base)
+    rowptr, succ, arcs = _device_scan(g)
+    orp, osc, oarcs = og.scan_mt()
+    assert arcs == oarcs == C5_SHARD["m"]
+    assert np.array_equal(rowptr.cpu().numpy(), orp) and np.array_equal(succ.cpu().numpy(), osc)
+    whole = g.csr_hashcode(0, g.numNodes(), rowptr.data_ptr(), succ.data_ptr(), -1)
+    del rowptr, succ
+    b = g.shard_bounds(8)
+    assert np.array_equal(b, P.shard_bounds_from_offsets(og.offsets, 8))
+    pairs, tot = [], 0
+    for k in range(8):
+        lo, hi = int(b[k]), int(b[k + 1])
+        rp, sc, a = _device_scan(g, lo, hi)
+        assert np.array_equal(sc[:a].cpu().numpy(), osc[orp[lo]:orp[hi]]), "shard %d differs from the oracle" % k
+        h0 = g.csr_hashcode(lo, hi, rp.data_ptr(), sc.data_ptr(), 0)
+        h1 = g.csr_hashcode(lo, hi, rp.data_ptr(), sc.data_ptr(), 1)
+        pairs.append(P.affine_from_two_hashes(h0, h1))
+        c0, ca = g.scan_checksum(lo, hi, 0)                                  # the same map without materialising the rows
+        c1, _ = g.scan_checksum(lo, hi, 1)
+        assert (c0, c1, ca) == (h0, h1, a)
+        tot += a
+    assert tot == arcs and P.fold_affine(pairs) == whole
+    g.close()
+
+
+@pytest.mark.timeout(900)
+def test_tiled_cnr_web_shape(tmp_path_factory, cnr_oracle):
+    """A web-graph-shaped input at scale: the reference's cnr-2000 fixture tiled 30 times (ids shifted per copy) and stored
+    with the fixture's parameters -- two thirds of the arcs copied, half the rows at chain depth 3."""
+    from webgraph_amd import tools as T
+    from webgraph_amd.bvgraph import BVGraph
+    og, rp, sc = cnr_oracle
+    K = 30
+    n0, m0 = og.n, sc.size
+    rowptr = np.concatenate([[0], (rp[1:][None, :] + (np.arange(K, dtype=np.int64) * m0)[:, None]).ravel()])
+    succ = (sc[None, :].astype(np.int64) + (np.arange(K, dtype=np.int64) * n0)[:, None]).astype(np.int32).ravel()
+    base = str(tmp_path_factory.mktemp("cnrx") / "cnr_x30")
+    st = T.store(base, rowptr, succ, window=7, max_ref_count=3, min_interval=3, threads=os.cpu_count())
+    assert st["copied_arcs"] > 0.6 * succ.size
+    g = BVGraph.load(base)
+    d_rowptr, d_succ, arcs = _device_scan(g)
+    assert arcs == succ.size
+    assert np.array_equal(d_rowptr.cpu().numpy(), rowptr) and np.array_equal(d_succ.cpu().numpy(), succ)
+    h, a = g.scan_checksum()
+    assert a == arcs and h == g.csr_hashcode(0, g.numNodes(), d_rowptr.data_ptr(), d_succ.data_ptr(), -1)
+    g.close()

@@ -112,3 +112,61 @@ def test_understated_arcs_property(tmp_path, monkeypatch):
         g.close()
         for k in env:
             monkeypatch.delenv(k)
+
+
+def _plain_row(first, d, x):
+    """record of node x: d successors first, first+2, ... as residuals, no reference, no intervals"""
+    from bitio import int2nat
+
+    def rec(w):
+        w.gamma(d)
+        w.unary(0)
+        if d:
+            w.zeta(int2nat(first - x))
+            for _ in range(d - 1):
+                w.zeta(1)  # gap 2
+    return rec
+
+
+@pytest.mark.parametrize("d", [3, 200, 700, 3000])
+@pytest.mark.parametrize("dense", ["0", "1"])
+def test_block_lengths_that_wrap_are_rejected(tmp_path, monkeypatch, d, dense):
+    """Copy-block lengths are gamma codes of up to 2^64 - 2: with len0 = 2^62, len1 = 1, len2 = 2^64 - 2^62 the 64-bit sums
+    of a careless decoder wrap to total = 1 <= dref and copied = 0, every later check passes, and the copy pass walks 2^62
+    ids past the referent's row.  Each length is checked against what is left of the referent (MaskedIntIterator would
+    simply run off the referent's list in the reference)."""
+    from bitio import write_graph, int2nat
+    from webgraph_amd.bvgraph import BVGraph
+    monkeypatch.setenv("BVGPU_BATCH_DENSE", dense)
+
+    def evil(x, blocks):
+        def rec(w):
+            w.gamma(d)
+            w.unary(1)
+            w.gamma(len(blocks))
+            for i, b in enumerate(blocks):
+                w.gamma(b if i == 0 else b - 1)
+            w.zeta(int2nat(5 - x))
+            for _ in range(d - 1):
+                w.zeta(0)
+        return rec
+
+    cases = [[1 << 62, 1, (1 << 64) - (1 << 62)],      # total wraps to 1, copied to 0
+             [(1 << 64) - 2],                            # a single huge block
+             [1, (1 << 64) - 1 - 1, 1],                  # the skipped block wraps the index
+             [0, 1, (1 << 63), 1, (1 << 63)]]            # two halves that cancel
+    recs = [_plain_row(10, d, 0)]
+    for i, blocks in enumerate(cases):
+        recs.append(evil(2 * i + 1, blocks))
+        recs.append(_plain_row(10, d, 2 * i + 2))
+    base = str(tmp_path / "wrap")
+    write_graph(base, recs, arcs=d * len(recs))
+    g = BVGraph.load(base)
+    with pytest.raises(_errors()):
+        g.decode_range()
+    with pytest.raises(_errors()):
+        g.successors_batch(np.arange(len(recs), dtype=np.int32))
+    # the well-formed rows are still served
+    rp, sc = g.successors_batch(np.array([0, 2], dtype=np.int32))
+    assert list(np.diff(rp)) == [d, d] and sc[0] == 10 and sc[d - 1] == 10 + 2 * (d - 1)
+    g.close()

@@ -80,7 +80,7 @@ def test_cpp_host_mirror_runs(tmp_path):
     from conftest import ROOT
     exe = str(tmp_path / "host_mirror_test")
     pkg = os.path.join(ROOT, "webgraph_amd")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(ROOT, "tests", "cpp", "host_mirror_test.cpp"),
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-o", exe, os.path.join(ROOT, "tests", "cpp", "host_mirror_test.cpp"),
                            "-L" + pkg, "-lbvgpu", "-Wl,-rpath," + pkg, "-L/opt/rocm/lib", "-lamdhip64"])
     p = subprocess.run([exe, CNR, "1711395807", "3216152"], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr

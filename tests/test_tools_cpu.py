@@ -133,7 +133,7 @@ def test_cpp_host_mirror_compiles(tmp_path):
     from conftest import ROOT
     exe = str(tmp_path / "host_mirror_test")
     pkg = os.path.join(ROOT, "webgraph_amd")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(ROOT, "tests", "cpp", "host_mirror_test.cpp"),
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-o", exe, os.path.join(ROOT, "tests", "cpp", "host_mirror_test.cpp"),
                            "-L" + pkg, "-lbvgpu", "-Wl,-rpath," + pkg, "-L/opt/rocm/lib", "-lamdhip64"])
     if not torch.cuda.is_available():
         p = subprocess.run([exe, CNR, "1711395807", "3216152"], capture_output=True, text=True)

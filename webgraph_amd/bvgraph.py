@@ -32,7 +32,7 @@ class BvgLabelsInfo(C.Structure):
 
 
 EXPORTS = ["bvg_open", "bvg_clone", "bvg_close", "bvg_info", "bvg_last_error", "bvg_set_stream", "bvg_sync",
-           "bvg_outdegrees", "bvg_decode_range", "bvg_successors_batch", "bvg_csr_hashcode", "bvg_shard_bounds",
+           "bvg_outdegrees", "bvg_decode_range", "bvg_decode_range_view", "bvg_host_alloc", "bvg_host_free", "bvg_scan_checksum", "bvg_successors_batch", "bvg_csr_hashcode", "bvg_shard_bounds",
            "bvg_parse_properties", "bvg_flags_from_string", "bvg_decode_offsets_host", "bvg_decode_offsets_device", "bvg_labels_open", "bvg_labels_close", "bvg_labels_info",
            "bvg_labels_last_error", "bvg_labels_parse_properties", "bvg_labels_decode_range", "bvg_set_profile", "bvg_get_profile", "bvg_debug_stats"]
 
@@ -63,6 +63,11 @@ def lib():
         L.bvg_sync.argtypes = [vp, C.POINTER(u64)]
         L.bvg_outdegrees.argtypes = [vp, i32, i32, vp, C.c_int]
         L.bvg_decode_range.argtypes = [vp, i32, i32, vp, vp, sz, C.POINTER(u64), C.c_int]
+        L.bvg_decode_range_view.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
+        L.bvg_host_alloc.argtypes = [sz, C.POINTER(vp)]
+        L.bvg_host_free.argtypes = [vp]
+        L.bvg_host_free.restype = None
+        L.bvg_scan_checksum.argtypes = [vp, i32, i32, C.POINTER(i32), C.POINTER(u64)]
         L.bvg_successors_batch.argtypes = [vp, vp, sz, vp, vp, sz, C.POINTER(u64), C.c_int]
         L.bvg_csr_hashcode.argtypes = [vp, i32, i32, vp, vp, C.POINTER(i32)]
         L.bvg_shard_bounds.argtypes = [vp, C.c_int, vp]
@@ -168,11 +173,12 @@ class LazyIntIterator:
 class NodeIterator:
     """BVGraphNodeIterator (BVGraph.java:1136-1281): sequential scan served from GPU-decoded batches."""
 
-    def __init__(self, graph, from_, upper_bound=2**31 - 1, batch_nodes=1 << 20):
+    def __init__(self, graph, from_, upper_bound=2**31 - 1, batch_nodes=1 << 20, owns_graph=False):
         n = graph.numNodes()
         if from_ < 0 or from_ > n:
             raise ValueError("Node index out of range: %d" % from_)   # BVGraph.java:1165
         self._g = graph
+        self._owns = owns_graph  # a copy()/split iterator decodes through a flyweight handle of its own (bvg_clone)
         self._from = from_
         self._curr = from_ - 1
         self._limit = min(upper_bound, n) - 1                         # hasNextLimit, BVGraph.java:1185
@@ -183,6 +189,17 @@ class NodeIterator:
 
     def hasNext(self):
         return self._curr < self._limit                               # BVGraph.java:1216
+
+    def close(self):
+        if self._owns and self._g is not None:
+            self._g.close()
+            self._owns = False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def nextInt(self):
         if not self.hasNext():
@@ -210,9 +227,10 @@ class NodeIterator:
         return LazyIntIterator(self._row())
 
     def copy(self, upper_bound=2**31 - 1):
-        """NodeIterator.copy(upperBound) (BVGraph.java:1253-1260): same position, never returns nodes >= upperBound."""
-        it = NodeIterator(self._g, self._curr + 1, upper_bound, self._batch)
-        return it
+        """NodeIterator.copy(upperBound) (BVGraph.java:1253-1260): same position, never returns nodes >= upperBound.
+        The reference's copy owns a bit stream of its own and may be drained by another thread (BVGraph.java:2471-2477,
+        ImmutableGraph.java:379-409); here it owns a flyweight handle (bvg_clone): a bvg_t is not thread-safe."""
+        return NodeIterator(self._g.copy(), self._curr + 1, upper_bound, self._batch, owns_graph=True)
 
 
 class _EmptyNodeIterator:
@@ -314,12 +332,32 @@ class BVGraph:
     def decode_range(self, lo=0, hi=None):
         """CSR of nodes [lo,hi): (rowptr int64[hi-lo+1], succ int32[arcs]) in host memory."""
         hi = self.numNodes() if hi is None else hi
-        rowptr = np.empty(max(hi - lo, 0) + 1, dtype=np.int64)
+        rp, sc = self.decode_range_view(lo, hi)
+        return rp.copy(), sc.copy()
+
+    def decode_range_view(self, lo=0, hi=None):
+        """One call, no counting call first: (rowptr, succ) as views of the handle's pinned result buffers, valid until
+        the next call on this graph (bvg_decode_range_view)."""
+        hi = self.numNodes() if hi is None else hi
+        rp, sp, arcs = C.c_void_p(), C.c_void_p(), C.c_uint64(0)
+        self._check(lib().bvg_decode_range_view(self._h, lo, hi, C.byref(rp), C.byref(sp), C.byref(arcs)))
+        rowptr = np.ctypeslib.as_array(C.cast(rp, C.POINTER(C.c_int64)), shape=(max(hi - lo, 0) + 1,))
+        succ = np.ctypeslib.as_array(C.cast(sp, C.POINTER(C.c_int32)), shape=(max(arcs.value, 1),))[:arcs.value]
+        return rowptr, succ
+
+    def decode_range_into(self, lo, hi, rowptr, succ):
+        """bvg_decode_range with BVG_OUT_HOST into caller-owned numpy arrays (pageable or pinned); returns the arc count."""
         arcs = C.c_uint64(0)
-        self._check(lib().bvg_decode_range(self._h, lo, hi, rowptr.ctypes.data, None, 0, C.byref(arcs), BVG_OUT_HOST))
-        succ = np.empty(max(arcs.value, 1), dtype=np.int32)
-        self._check(lib().bvg_decode_range(self._h, lo, hi, rowptr.ctypes.data, succ.ctypes.data, succ.size, C.byref(arcs), BVG_OUT_HOST))
-        return rowptr, succ[:arcs.value]
+        self._check(lib().bvg_decode_range(self._h, lo, hi, rowptr.ctypes.data, succ.ctypes.data if succ is not None else None,
+                                           succ.size if succ is not None else 0, C.byref(arcs), BVG_OUT_HOST))
+        return arcs.value
+
+    def scan_checksum(self, lo=0, hi=None, h=-1):
+        """(hash, arcs) of nodes [lo, hi): ImmutableGraph.hashCode() continued from h, nothing materialised for the caller."""
+        hi = self.numNodes() if hi is None else hi
+        hh, arcs = C.c_int32(h), C.c_uint64(0)
+        self._check(lib().bvg_scan_checksum(self._h, lo, hi, C.byref(hh), C.byref(arcs)))
+        return hh.value, arcs.value
 
     def decode_range_device(self, lo, hi, rowptr_ptr, succ_ptr, succ_cap, asynchronous=False):
         """Device-pointer form: rowptr_ptr / succ_ptr are raw device addresses (e.g. torch.Tensor.data_ptr())."""
@@ -401,20 +439,8 @@ class BVGraph:
         return hh.value
 
     def hashCode(self):
-        """ImmutableGraph.hashCode() (ImmutableGraph.java:757-770), folded on the device per batch."""
-        import torch
-        n = self.numNodes()
-        dev = torch.device("cuda", self.info.device)
-        h = -1
-        step = 1 << 22
-        for lo in range(0, n, step):
-            hi = min(lo + step, n)
-            rowptr = torch.empty(hi - lo + 1, dtype=torch.int64, device=dev)
-            arcs = self.decode_range_device(lo, hi, rowptr.data_ptr(), None, 0)
-            succ = torch.empty(max(arcs, 1), dtype=torch.int32, device=dev)
-            self.decode_range_device(lo, hi, rowptr.data_ptr(), succ.data_ptr(), succ.numel())
-            h = self.csr_hashcode(lo, hi, rowptr.data_ptr(), succ.data_ptr(), h)
-        return h
+        """ImmutableGraph.hashCode() (ImmutableGraph.java:757-770): a checksum scan on the device (bvg_scan_checksum)."""
+        return self.scan_checksum(0, self.numNodes(), -1)[0]
 
     def equals(self, other):
         """ImmutableGraph.equals() (ImmutableGraph.java:731-749): same number of nodes and the same successor list for

@@ -488,7 +488,7 @@ __device__ __forceinline__ void spec_tile(const Grp<NW> &G, const GraphDev &g, c
 // Decodes the 2*ic gamma codes of the interval section starting at `pos` into arena entries (BVG:1077-1095);
 // returns the bit position after them (start of the residual section) and the number of intervalised arcs.
 template <int DEF, int NW>
-__device__ __forceinline__ void coop_intervals(const Grp<NW> &G, const GraphDev &g, int32_t x, uint64_t pos, uint64_t recEnd, int64_t ic, uint32_t B,
+__device__ __forceinline__ void coop_intervals(const Grp<NW> &G, const GraphDev &g, int32_t x, uint64_t pos, uint64_t recEnd, int64_t ic, int64_t extra, uint32_t B,
                                                IvEntry *__restrict__ list, uint32_t *lds, uint64_t &posAfter, int64_t &intervalArcs, int &err) {
 	uint32_t *win = lds + CoopLds<NW>::OFF_WIN;
 	int64_t codesDone = 0;              // uniform
@@ -516,7 +516,10 @@ __device__ __forceinline__ void coop_intervals(const Grp<NW> &G, const GraphDev 
 			for (uint32_t k = 0; k < c; k++) {
 				const int64_t q = codesDone + cb + k;
 				const uint64_t v = win_code_rel<DEF, 1>(g, src, p, err);
-				if (q & 1) { const int64_t len = (int64_t)v + g.minInt; dcur += len; dp += len; }
+				if (q & 1) {
+					if (v > (uint64_t)extra) err |= E_FORMAT; // (any 64-bit value in a malformed stream: the sums below must not wrap)
+					const int64_t len = (int64_t)(v & 0x7fffffffu) + g.minInt; dcur += len; dp += len;
+				}
 				else dcur += q == 0 ? nat2int(v) : (int64_t)v + 1;
 			}
 			myEnd = p;
@@ -532,7 +535,7 @@ __device__ __forceinline__ void coop_intervals(const Grp<NW> &G, const GraphDev 
 			for (uint32_t k = 0; k < c; k++) {
 				const int64_t q = codesDone + cb + k;
 				const uint64_t v = win_code_rel<DEF, 1>(g, src, p, e2);
-				if (q & 1) { const int64_t len = (int64_t)v + g.minInt; list[q >> 1].pstart = (int32_t)pc; list[q >> 1].len = (int32_t)len; cur += len; pc += len; }
+				if (q & 1) { const int64_t len = (int64_t)(v & 0x7fffffffu) + g.minInt; list[q >> 1].pstart = (int32_t)pc; list[q >> 1].len = (int32_t)len; cur += len; pc += len; }
 				else { cur += q == 0 ? nat2int(v) : (int64_t)v + 1; list[q >> 1].left = (int32_t)cur; }
 			}
 		}
@@ -695,11 +698,11 @@ __device__ __forceinline__ void coop_parse_node(const GraphDev &g, int32_t x, in
 		if (bc > (uint64_t)dref + 1) err |= E_FORMAT;
 		else {
 			for (uint64_t b = 0; b < bc; b++) {
-				const int64_t len = (int64_t)Fields<DEF>::block(br, g) + (b ? 1 : 0);
+				int64_t len;
+				if (!block_len_ok(Fields<DEF>::block(br, g), b == 0, total, dref, len)) { err |= E_FORMAT; break; }
 				total += len;
 				if (!(b & 1)) copied += len;
 			}
-			if (total > dref) err |= E_FORMAT;
 			if (!(bc & 1)) copied += dref - total;
 		}
 	}
@@ -721,7 +724,7 @@ __device__ __forceinline__ void coop_parse_node(const GraphDev &g, int32_t x, in
 			const uint64_t restBits = recEnd > pos ? recEnd - pos : 0, restCodes = (uint64_t)(2 * ic + (extra - ic * g.minInt));
 			const uint64_t secEst = min(restBits, (restBits * (uint64_t)(2 * ic) + restCodes - 1) / restCodes * 2); // x2: interval gaps are longer than residual gaps
 			const uint32_t B = coop_pick_B(secEst, (uint64_t)(2 * ic), Grp<NW>::N, CoopCfg<NW>::B_MAX);
-			coop_intervals<DEF, NW>(G, g, x, pos, recEnd, ic, B, list, lds, pos, intervalArcs, err);
+			coop_intervals<DEF, NW>(G, g, x, pos, recEnd, ic, extra, B, list, lds, pos, intervalArcs, err);
 			if (G.any(err != 0)) { if (err) atomicOr(errOut, err); return; } // group-uniform exit
 		}
 	}

@@ -234,6 +234,15 @@ template <class Src> struct BitReaderT {
 // Fast.nat2int
 __device__ __forceinline__ int64_t nat2int(uint64_t v) { return (int64_t)(v >> 1) ^ -(int64_t)(v & 1); }
 
+// One copy block (BVG:1063-1069) checked against what is left of the referent's row.  `total` = blocks so far, with the
+// invariant 0 <= total <= dref.  A code of a malformed stream can be any 64-bit value: it is rejected here, before it
+// reaches a sum (a wrapped sum would pass every later "total <= dref" test and send the copy pass out of bounds).
+__device__ __forceinline__ bool block_len_ok(uint64_t code, bool first, int64_t total, int64_t dref, int64_t &len) {
+	if (code > (uint64_t)(dref - total)) return false;
+	len = (int64_t)code + (first ? 0 : 1);
+	return total + len <= dref;
+}
+
 using BitReader = BitReaderT<GlobalSrc>;
 using WinReader = BitReaderT<WindowSrc>;
 using PReader = BitReaderT<PrefetchSrc>;

@@ -284,11 +284,11 @@ __device__ __forceinline__ void parse_node(const GraphDev &g, int32_t x, int32_t
 		if (bc > (uint64_t)dref + 1) e |= E_FORMAT;
 		else {
 			for (uint64_t b = 0; b < bc; b++) {
-				const int64_t len = (int64_t)Fields<DEF>::block(br, g) + (b ? 1 : 0);
+				int64_t len;
+				if (!block_len_ok(Fields<DEF>::block(br, g), b == 0, total, dref, len)) { e |= E_FORMAT; break; }
 				total += len;
 				if (!(b & 1)) copied += len;
 			}
-			if (total > dref) e |= E_FORMAT;
 			if (!(bc & 1)) copied += dref - total;
 		}
 	}
@@ -308,7 +308,9 @@ __device__ __forceinline__ void parse_node(const GraphDev &g, int32_t x, int32_t
 			bi.seek(br.pos());
 			for (int64_t i = 0; i < nIntervals; i++) {
 				(void)br.gamma();
-				intervalArcs += (int64_t)br.gamma() + g.minInt;
+				const uint64_t len = br.gamma();
+				if (len > (uint64_t)extra) { br.err |= E_FORMAT; break; } // (any 64-bit value in a malformed stream: kept out of the sum)
+				intervalArcs += (int64_t)len + g.minInt;
 			}
 		}
 	}
@@ -645,7 +647,9 @@ __device__ __forceinline__ void coop_block_walk(const GraphDev &g, uint64_t pos,
 			uint32_t p = s;
 			for (uint32_t k = 0; k < c; k++) {
 				const int64_t q = done + cb + k;
-				const int64_t len = (int64_t)win_code_rel<1, 1>(g, src, p, err) + (q ? 1 : 0);
+				const uint64_t v = win_code_rel<1, 1>(g, src, p, err);
+				if (v > (uint64_t)dref) err |= 1; // (any 64-bit value in a malformed stream: the sums below must not wrap)
+				const int64_t len = (int64_t)(v & 0x7fffffffu) + (q ? 1 : 0);
 				dAll += len;
 				if (!(q & 1)) dEven += len;
 			}
@@ -660,7 +664,7 @@ __device__ __forceinline__ void coop_block_walk(const GraphDev &g, uint64_t pos,
 			int e2 = 0;
 			for (uint32_t k = 0; k < c; k++) {
 				const int64_t q = done + cb + k;
-				const int64_t len = (int64_t)win_code_rel<1, 1>(g, src, p, e2) + (q ? 1 : 0);
+				const int64_t len = (int64_t)(win_code_rel<1, 1>(g, src, p, e2) & 0x7fffffffu) + (q ? 1 : 0);
 				if (!(q & 1)) {
 					const int64_t j = q >> 1;
 					if (j < tabCap) { kend[j] = (int32_t)min<int64_t>(cp + len, 0x7fffffff); delta[j] = (int32_t)(t - cp); }
@@ -996,11 +1000,11 @@ __device__ __forceinline__ void copy_node(const GraphDev &g, int32_t x, int32_t 
 	const uint64_t blocksPos = br.pos();
 	int64_t total = 0, copied = 0;
 	for (uint64_t b = 0; b < bc; b++) {
-		const int64_t len = (int64_t)Fields<DEF>::block(br, g) + (b ? 1 : 0);
+		int64_t len;
+		if (!block_len_ok(Fields<DEF>::block(br, g), b == 0, total, dref, len)) return; // flagged by the parse kernel
 		total += len;
 		if (!(b & 1)) copied += len;
 	}
-	if (total > dref) return; // flagged in k_parse
 	if (!(bc & 1)) copied += dref - total;
 	if (copied > d) return;
 	br.seek(blocksPos);
@@ -1014,7 +1018,7 @@ __device__ __forceinline__ void copy_node(const GraphDev &g, int32_t x, int32_t 
 		if (b < bc) len = (int64_t)Fields<DEF>::block(br, g) + (b ? 1 : 0);
 		else len = dref - i; // implicit last block: the rest of the referent
 		if (b & 1) { i += len; continue; } // skip block
-		for (int64_t t = 0; t < len; t++) {
+		for (int64_t t = 0; t < len && i < dref && k < d; t++) { // (the bounds hold by the checks above: belt and braces)
 			const int32_t cv = src[i++];
 			while (j < d && ev < cv) { row[k++] = ev; j++; if (j < d) ev = row[j]; }
 			if (j < d && ev == cv) { j++; if (j < d) ev = row[j]; } // equal heads emitted once (never in a valid file)

@@ -123,11 +123,11 @@ __device__ __forceinline__ void parse_node_lw(const GraphDev &g, int32_t x, int3
 		if (bc > (uint64_t)dref + 1) e |= E_FORMAT;
 		else {
 			for (uint64_t b = 0; b < bc; b++) {
-				const int64_t len = (int64_t)br.code<1>(g, e) + (b ? 1 : 0);
+				int64_t len;
+				if (!block_len_ok(br.code<1>(g, e), b == 0, total, dref, len)) { e |= E_FORMAT; break; }
 				total += len;
 				if (!(b & 1)) copied += len;
 			}
-			if (total > dref) e |= E_FORMAT;
 			if (!(bc & 1)) copied += dref - total;
 		}
 	}
@@ -144,7 +144,9 @@ __device__ __forceinline__ void parse_node_lw(const GraphDev &g, int32_t x, int3
 			bi.seek(g, br.pos());
 			for (int64_t i = 0; i < nIntervals; i++) {
 				(void)br.code<1>(g, e);
-				intervalArcs += (int64_t)br.code<1>(g, e) + g.minInt;
+				const uint64_t len = br.code<1>(g, e);
+				if (len > (uint64_t)extra) { e |= E_FORMAT; break; } // (any 64-bit value in a malformed stream: kept out of the sum)
+				intervalArcs += (int64_t)len + g.minInt;
 			}
 		}
 	}

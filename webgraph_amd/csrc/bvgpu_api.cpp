@@ -14,6 +14,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -32,6 +33,22 @@ struct DevBuf {
 		return true;
 	}
 	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+	template <class T> T *as() const { return (T *)p; }
+};
+
+struct PinBuf { // pinned host memory (grows, never shrinks; contents are NOT preserved)
+	void *p = nullptr;
+	size_t cap = 0;
+	bool need(size_t bytes) {
+		if (bytes <= cap) return true;
+		if (p) (void)hipHostFree(p);
+		p = nullptr; cap = 0;
+		const size_t want = bytes + bytes / 8 + 4096;
+		if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; (void)hipGetLastError(); return false; }
+		cap = want;
+		return true;
+	}
+	void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
 	template <class T> T *as() const { return (T *)p; }
 };
 
@@ -115,6 +132,13 @@ struct bvg_graph {
 	int64_t *early_rowptr = nullptr; // decode_range_device: caller's rowptr, written on a side stream as soon as the scan is done (set per call)
 	int batch_dense = 32;   // a random-access batch of q nodes with q * batch_dense >= n is decoded as a masked scan of the graph (0: never;
 	                        // measured crossover on the 10 M-node C2 graph: q = 300 000)
+	// host-output scans (BVG_OUT_HOST, bvg_decode_range_view): chunks are decoded into two device buffers in turn and
+	// leave over PCIe on a copy stream of their own while the next chunk is being decoded
+	DevBuf hchunk[2];
+	PinBuf hring[2];               // pageable destinations: the chunk lands here first and is copied out by host threads
+	PinBuf view_rowptr, view_succ; // bvg_decode_range_view: library-owned pinned results
+	hipStream_t copyStream = nullptr;
+	hipEvent_t evChunk[2] = {}, evCopied[2] = {};
 	Small *h_small = nullptr; // pinned
 	int32_t levels_hint = 1;
 	Pending pend;
@@ -187,6 +211,8 @@ int init_handle(bvg_graph *g) {
 	if (const char *e = getenv("BVGPU_BATCH_DENSE")) g->batch_dense = std::max(0, atoi(e));
 	HIPCHK(g, hipStreamCreateWithFlags(&g->sideA, hipStreamNonBlocking));
 	HIPCHK(g, hipStreamCreateWithFlags(&g->sideB, hipStreamNonBlocking));
+	HIPCHK(g, hipStreamCreateWithFlags(&g->copyStream, hipStreamNonBlocking));
+	for (int i = 0; i < 2; i++) { HIPCHK(g, hipEventCreateWithFlags(&g->evChunk[i], hipEventDisableTiming)); HIPCHK(g, hipEventCreateWithFlags(&g->evCopied[i], hipEventDisableTiming)); }
 	HIPCHK(g, hipEventCreateWithFlags(&g->evFork, hipEventDisableTiming));
 	HIPCHK(g, hipEventCreateWithFlags(&g->evIn, hipEventDisableTiming));
 	HIPCHK(g, hipEventCreateWithFlags(&g->evOut, hipEventDisableTiming));
@@ -260,12 +286,12 @@ int finish_pending(bvg_graph *g, uint64_t *arcs_out) {
 	if (!g->pend.active) { if (arcs_out) *arcs_out = g->last_arcs; return BVG_OK; }
 	const Staged &s = *g->st;
 	int rc = fetch_small(g);
-	if (rc) { g->pend.active = false; return rc; }
+	if (rc) { g->pend = Pending{}; return rc; }
 	if (g->pend.optimistic && (g->h_small->err & (bv::E_ESCAPED | bv::E_HALO))) {
 		if (getenv("BVGPU_TRACE_RETRY")) fprintf(stderr, "[bvgpu] optimistic halo missed (err %d): repeating [%d, %d)\n", g->h_small->err, g->pend.from, g->pend.to);
 		// the halo of this sub-range was deeper or larger than guessed: once more, sized with a host round trip
 		const Pending p = g->pend;
-		g->pend.active = false; g->pend.optimistic = false;
+		g->pend = Pending{};
 		g->force_halo_sync = true;
 		rc = decode_range_device(g, p.from, p.to, p.rowptr, p.succ, p.succ_cap, false, arcs_out);
 		g->force_halo_sync = false;
@@ -293,11 +319,11 @@ int finish_pending(bvg_graph *g, uint64_t *arcs_out) {
 			}
 			g->pend.levels_done = upto;
 			rc = fetch_small(g);
-			if (rc) { g->pend.active = false; return rc; }
+			if (rc) { g->pend = Pending{}; return rc; }
 		}
 		g->levels_hint = std::max(1, std::min<int32_t>(g->h_small->maxdepth, 64));
 	}
-	g->pend.active = false;
+	g->pend = Pending{}; // (a later job never sees this one's buffers or its "optimistic" flag)
 	g->last_arcs = (uint64_t)g->h_small->total;
 	if (arcs_out) *arcs_out = g->last_arcs;
 	if (g->h_small->err) {
@@ -703,6 +729,10 @@ extern "C" int bvg_close(bvg_t *g) {
 		(void)hipSetDevice(g->st->device);
 		if (g->own) { (void)hipStreamSynchronize(g->own); (void)hipStreamDestroy(g->own); }
 		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist, &g->plist, &g->pkeys, &g->pkey16, &g->copyq, &g->bigtmp }) b->release();
+		for (DevBuf *b : { &g->hchunk[0], &g->hchunk[1] }) b->release();
+		for (PinBuf *b : { &g->hring[0], &g->hring[1], &g->view_rowptr, &g->view_succ }) b->release();
+		if (g->copyStream) { (void)hipStreamSynchronize(g->copyStream); (void)hipStreamDestroy(g->copyStream); }
+		for (hipEvent_t e : { g->evChunk[0], g->evChunk[1], g->evCopied[0], g->evCopied[1] }) if (e) (void)hipEventDestroy(e);
 		if (g->h_small) (void)hipHostFree(g->h_small);
 		for (auto &e : g->ev) if (e) (void)hipEventDestroy(e);
 		for (hipEvent_t e : { g->evFork, g->evA, g->evB, g->evC, g->evHdr, g->evP, g->evIn, g->evOut }) if (e) (void)hipEventDestroy(e);
@@ -783,12 +813,52 @@ extern "C" int bvg_outdegrees(bvg_t *g, int32_t from, int32_t to, int32_t *out, 
 	return BVG_OK;
 }
 
-extern "C" int bvg_decode_range(bvg_t *g, int32_t from, int32_t to, int64_t *rowptr, int32_t *succ, size_t succ_cap, uint64_t *arcs_out, int flags) {
-	if (!g || !g->st) return BVG_EARG;
+namespace {
+
+// Is p pinned (or otherwise known to the HIP runtime as host memory)?  Then a device-to-host copy goes straight there at
+// PCIe speed; pageable memory is filled by host threads from a pinned ring instead.
+bool is_pinned_host(const void *p) {
+	hipPointerAttribute_t a{};
+	if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+	return a.type == hipMemoryTypeHost;
+}
+
+void parallel_memcpy(void *dst, const void *src, size_t bytes) {
+	constexpr size_t PIECE = (size_t)8 << 20;
+	const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+	const size_t want = std::min<size_t>({ (bytes + PIECE - 1) / PIECE, (size_t)hw, (size_t)16 });
+	if (want <= 1) { memcpy(dst, src, bytes); return; }
+	std::vector<std::thread> th;
+	const size_t per = ((bytes + want - 1) / want + 63) & ~(size_t)63;
+	for (size_t k = 0; k < want; k++) {
+		const size_t o = std::min(bytes, k * per), e = std::min(bytes, o + per);
+		if (e > o) th.emplace_back([=] { memcpy((char *)dst + o, (const char *)src + o, e - o); });
+	}
+	for (auto &t : th) t.join();
+}
+
+// Cuts [from, to) into pieces of roughly `target` arcs each, by the share of the bit stream they hold (host offsets).
+std::vector<int32_t> plan_chunks_by_bits(const Staged &s, int32_t from, int32_t to, int64_t target) {
+	const int64_t allBits = std::max<int64_t>(s.h_offsets.back(), 1);
+	const int64_t bits = s.h_offsets[to] - s.h_offsets[from];
+	const double estArcs = (double)std::max<int64_t>(s.arcs_sizing, 1) * (double)bits / (double)allBits;
+	const int64_t parts = std::max<int64_t>(1, (int64_t)(estArcs / (double)std::max<int64_t>(target, 1) + 0.999));
+	std::vector<int32_t> b{ from };
+	for (int64_t k = 1; k < parts; k++) {
+		const int64_t t = s.h_offsets[from] + (int64_t)((__int128)bits * k / parts);
+		int32_t x = (int32_t)(std::lower_bound(s.h_offsets.begin() + from, s.h_offsets.begin() + to, t) - s.h_offsets.begin());
+		x = std::min(std::max(x, b.back()), to);
+		if (x > b.back()) b.push_back(x);
+	}
+	if (to > b.back() || b.size() == 1) b.push_back(to);
+	return b;
+}
+
+// Host-output scan in ONE pass: the structure (outdegrees, CSR row starts) of the whole range first -- that is the
+// rowptr the caller gets and the exact chunk plan --, then the successors chunk by chunk: chunk k leaves over PCIe on the
+// copy stream while chunk k+1 is being decoded.  rowptr_h: to-from+1 entries (host); succ_h may be NULL (count only).
+int host_scan(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_h, int32_t *succ_h, size_t succ_cap, uint64_t *arcs_out) {
 	const Staged &s = *g->st;
-	if (from < 0 || from > s.info.nodes || to < from || to > s.info.nodes || !rowptr) return fail(g, BVG_EARG, "node range out of bounds"); // BVG:1165
-	if (flags & BVG_OUT_DEVICE) return decode_range_device(g, from, to, rowptr, succ, succ_cap, (flags & BVG_ASYNC) != 0, arcs_out);
-	// host outputs: count first, then decode into staging buffers and copy back
 	HIPCHK(g, hipSetDevice(s.device));
 	const size_t nrow = (size_t)(to - from) + 1;
 	if (!g->stage_rowptr.need(sizeof(int64_t) * nrow)) return fail(g, BVG_ENOMEM, "staging allocation failed");
@@ -796,14 +866,137 @@ extern "C" int bvg_decode_range(bvg_t *g, int32_t from, int32_t to, int64_t *row
 	int rc = decode_range_device(g, from, to, g->stage_rowptr.as<int64_t>(), nullptr, 0, false, &arcs);
 	if (rc) return rc;
 	if (arcs_out) *arcs_out = arcs;
-	if (succ) {
-		if (arcs > succ_cap) return fail(g, BVG_ECAP, "successor buffer too small");
-		if (!g->stage_succ.need(sizeof(int32_t) * (size_t)std::max<uint64_t>(arcs, 1))) return fail(g, BVG_ENOMEM, "staging allocation failed");
-		rc = decode_range_device(g, from, to, g->stage_rowptr.as<int64_t>(), g->stage_succ.as<int32_t>(), (size_t)arcs, false, &arcs);
-		if (rc) return rc;
-		if (arcs) HIPCHK(g, hipMemcpy(succ, g->stage_succ.p, sizeof(int32_t) * (size_t)arcs, hipMemcpyDeviceToHost));
+	HIPCHK(g, hipMemcpy(rowptr_h, g->stage_rowptr.p, sizeof(int64_t) * nrow, hipMemcpyDeviceToHost));
+	if (!succ_h || arcs == 0) return BVG_OK;
+	if (arcs > succ_cap) return fail(g, BVG_ECAP, "successor buffer too small");
+	// chunks of ~1/8 of the range, between 4 M and 32 M arcs: cut where the (exact) row starts say
+	const uint64_t target = std::min<uint64_t>(std::max<uint64_t>(arcs / 8, (uint64_t)4 << 20), (uint64_t)32 << 20);
+	std::vector<int32_t> cut{ from };
+	while (cut.back() < to) {
+		const int64_t base = rowptr_h[cut.back() - from];
+		const int64_t *lo = rowptr_h + (cut.back() - from) + 1, *hi = rowptr_h + nrow;
+		int32_t nx = from + (int32_t)(std::upper_bound(lo, hi, base + (int64_t)target) - rowptr_h) - 1; // last node whose row still ends inside the target
+		nx = std::max(nx, cut.back() + 1);                                                             // (a single row longer than the target is a chunk of its own)
+		cut.push_back(std::min(nx, to));
 	}
-	HIPCHK(g, hipMemcpy(rowptr, g->stage_rowptr.p, sizeof(int64_t) * nrow, hipMemcpyDeviceToHost));
+	uint64_t maxChunk = 0;
+	for (size_t k = 0; k + 1 < cut.size(); k++) maxChunk = std::max<uint64_t>(maxChunk, (uint64_t)(rowptr_h[cut[k + 1] - from] - rowptr_h[cut[k] - from]));
+	const bool pinned = is_pinned_host(succ_h);
+	for (int b = 0; b < 2; b++) {
+		if (!g->hchunk[b].need(sizeof(int32_t) * (size_t)std::max<uint64_t>(maxChunk, 1))) return fail(g, BVG_ENOMEM, "staging allocation failed");
+		if (!pinned && !g->hring[b].need(sizeof(int32_t) * (size_t)std::max<uint64_t>(maxChunk, 1))) return fail(g, BVG_ENOMEM, "pinned staging allocation failed");
+	}
+	int32_t maxNodes = 0;
+	for (size_t k = 0; k + 1 < cut.size(); k++) maxNodes = std::max(maxNodes, cut[k + 1] - cut[k]);
+	if (!g->stage_rowptr.need(sizeof(int64_t) * ((size_t)maxNodes + 1))) return fail(g, BVG_ENOMEM, "staging allocation failed");
+	struct Out { int32_t *dst; const int32_t *src; size_t bytes; bool live = false; } out[2];
+	for (size_t k = 0; k + 1 < cut.size(); k++) {
+		const int b = (int)(k & 1);
+		const int32_t a = cut[k], e = cut[k + 1];
+		const uint64_t want = (uint64_t)(rowptr_h[e - from] - rowptr_h[a - from]);
+		if (out[b].live) HIPCHK(g, hipEventSynchronize(g->evCopied[b])); // chunk k-2 has left device buffer b
+		rc = decode_range_device(g, a, e, g->stage_rowptr.as<int64_t>(), g->hchunk[b].as<int32_t>(), (size_t)std::max<uint64_t>(want, 1), true, nullptr);
+		if (rc) return rc;
+		// while the GPU decodes: chunk k-2 goes from the ring to a pageable destination (host threads)
+		if (out[b].live && !pinned) parallel_memcpy(out[b].dst, out[b].src, out[b].bytes);
+		out[b].live = false;
+		uint64_t got = 0;
+		rc = finish_pending(g, &got);
+		if (rc) return rc;
+		if (got != want) return fail(g, BVG_EFORMAT, "a chunk decoded to another number of arcs than the scan counted");
+		if (want == 0) continue;
+		HIPCHK(g, hipEventRecord(g->evChunk[b], g->stream));
+		HIPCHK(g, hipStreamWaitEvent(g->copyStream, g->evChunk[b], 0));
+		int32_t *dst = succ_h + (rowptr_h[a - from] - rowptr_h[0]);
+		void *land = pinned ? (void *)dst : g->hring[b].p;
+		HIPCHK(g, hipMemcpyAsync(land, g->hchunk[b].p, sizeof(int32_t) * (size_t)want, hipMemcpyDeviceToHost, g->copyStream)); // overlaps the next chunk's decode
+		HIPCHK(g, hipEventRecord(g->evCopied[b], g->copyStream));
+		out[b] = Out{ dst, (const int32_t *)g->hring[b].p, sizeof(int32_t) * (size_t)want, true };
+	}
+	for (size_t k = cut.size() - 1, i = 0; i < 2; i++, k++) { // the last two chunks, in order
+		const int b = (int)(k & 1);
+		if (!out[b].live) continue;
+		HIPCHK(g, hipEventSynchronize(g->evCopied[b]));
+		if (!pinned) parallel_memcpy(out[b].dst, out[b].src, out[b].bytes);
+		out[b].live = false;
+	}
+	g->last_arcs = arcs;
+	return BVG_OK;
+}
+
+} // namespace
+
+extern "C" int bvg_decode_range(bvg_t *g, int32_t from, int32_t to, int64_t *rowptr, int32_t *succ, size_t succ_cap, uint64_t *arcs_out, int flags) {
+	if (!g || !g->st) return BVG_EARG;
+	const Staged &s = *g->st;
+	if (from < 0 || from > s.info.nodes || to < from || to > s.info.nodes || !rowptr) return fail(g, BVG_EARG, "node range out of bounds"); // BVG:1165
+	if (flags & BVG_OUT_DEVICE) return decode_range_device(g, from, to, rowptr, succ, succ_cap, (flags & BVG_ASYNC) != 0, arcs_out);
+	return host_scan(g, from, to, rowptr, succ, succ_cap, arcs_out);
+}
+
+extern "C" int bvg_decode_range_view(bvg_t *g, int32_t from, int32_t to, const int64_t **rowptr_out, const int32_t **succ_out, uint64_t *arcs_out) {
+	if (!g || !g->st) return BVG_EARG;
+	const Staged &s = *g->st;
+	if (from < 0 || from > s.info.nodes || to < from || to > s.info.nodes || !rowptr_out || !succ_out) return fail(g, BVG_EARG, "node range out of bounds"); // BVG:1165
+	HIPCHK(g, hipSetDevice(s.device));
+	const size_t nrow = (size_t)(to - from) + 1;
+	if (!g->view_rowptr.need(sizeof(int64_t) * nrow)) return fail(g, BVG_ENOMEM, "pinned result allocation failed");
+	// the successor buffer is sized by the range's share of the bit stream first (no counting pass of its own)
+	const int64_t allBits = std::max<int64_t>(s.h_offsets.back(), 1), bits = s.h_offsets[to] - s.h_offsets[from];
+	const uint64_t guess = (uint64_t)((double)std::max<int64_t>(s.arcs_sizing, 1) * (double)bits / (double)allBits * 1.05) + 1024;
+	if (!g->view_succ.need(sizeof(int32_t) * (size_t)guess)) return fail(g, BVG_ENOMEM, "pinned result allocation failed");
+	uint64_t arcs = 0;
+	int rc = host_scan(g, from, to, g->view_rowptr.as<int64_t>(), g->view_succ.as<int32_t>(), g->view_succ.cap / sizeof(int32_t), &arcs);
+	if (rc == BVG_ECAP) { // more arcs than the share of the stream suggested: now the count is known
+		if (!g->view_succ.need(sizeof(int32_t) * (size_t)std::max<uint64_t>(arcs, 1))) return fail(g, BVG_ENOMEM, "pinned result allocation failed");
+		rc = host_scan(g, from, to, g->view_rowptr.as<int64_t>(), g->view_succ.as<int32_t>(), g->view_succ.cap / sizeof(int32_t), &arcs);
+	}
+	if (rc) return rc;
+	*rowptr_out = g->view_rowptr.as<int64_t>();
+	*succ_out = g->view_succ.as<int32_t>();
+	if (arcs_out) *arcs_out = arcs;
+	return BVG_OK;
+}
+
+extern "C" int bvg_host_alloc(size_t bytes, void **out) {
+	if (!out) return BVG_EARG;
+	*out = nullptr;
+	if (hipHostMalloc(out, std::max<size_t>(bytes, 1), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return BVG_ENOMEM; }
+	return BVG_OK;
+}
+extern "C" void bvg_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+extern "C" int bvg_scan_checksum(bvg_t *g, int32_t from, int32_t to, int32_t *hash_io, uint64_t *arcs_out) {
+	if (!g || !g->st || !hash_io) return BVG_EARG;
+	const Staged &s = *g->st;
+	if (from < 0 || from > s.info.nodes || to < from || to > s.info.nodes) return fail(g, BVG_EARG, "node range out of bounds"); // BVG:1165
+	HIPCHK(g, hipSetDevice(s.device));
+	// The rows never reach the caller: they are decoded piece by piece into one scratch buffer that stays on the die
+	// (<= 32 M arcs = 128 MB, half the Infinity Cache) and folded into the running hash there.
+	const std::vector<int32_t> cut = plan_chunks_by_bits(s, from, to, (int64_t)32 << 20);
+	uint64_t total = 0;
+	int32_t h = *hash_io;
+	for (size_t k = 0; k + 1 < cut.size(); k++) {
+		const int32_t a = cut[k], e = cut[k + 1];
+		if (e == a) continue;
+		if (!g->stage_rowptr.need(sizeof(int64_t) * ((size_t)(e - a) + 1))) return fail(g, BVG_ENOMEM, "staging allocation failed");
+		const int64_t allBits = std::max<int64_t>(s.h_offsets.back(), 1), bits = s.h_offsets[e] - s.h_offsets[a];
+		const uint64_t guess = (uint64_t)((double)std::max<int64_t>(s.arcs_sizing, 1) * (double)bits / (double)allBits * 1.1) + 4096;
+		if (!g->stage_succ.need(sizeof(int32_t) * (size_t)guess)) return fail(g, BVG_ENOMEM, "staging allocation failed");
+		uint64_t arcs = 0;
+		int rc = decode_range_device(g, a, e, g->stage_rowptr.as<int64_t>(), g->stage_succ.as<int32_t>(), g->stage_succ.cap / sizeof(int32_t), false, &arcs);
+		if (rc == BVG_ECAP) {
+			if (!g->stage_succ.need(sizeof(int32_t) * (size_t)std::max<uint64_t>(arcs, 1))) return fail(g, BVG_ENOMEM, "staging allocation failed");
+			rc = decode_range_device(g, a, e, g->stage_rowptr.as<int64_t>(), g->stage_succ.as<int32_t>(), g->stage_succ.cap / sizeof(int32_t), false, &arcs);
+		}
+		if (rc) return rc;
+		rc = bvg_csr_hashcode(g, a, e, g->stage_rowptr.as<int64_t>(), g->stage_succ.as<int32_t>(), &h);
+		if (rc) return rc;
+		total += arcs;
+	}
+	*hash_io = h;
+	if (arcs_out) *arcs_out = total;
+	g->last_arcs = total;
 	return BVG_OK;
 }
 
@@ -894,6 +1087,7 @@ extern "C" int bvg_successors_batch(bvg_t *g, const int32_t *nodes, size_t q, in
 		if (rc) return rc;
 		HIPCHK(g, hipGetLastError());
 		g->pend.active = true; g->pend.view = v; g->pend.levels_done = levels; g->pend.want_succ = true; g->pend.giantCap = giantCap;
+		g->pend.optimistic = false; // (nothing to repeat: the arena was sized by a round trip)
 		rc = finish_pending(g, nullptr); // the levels of the copy pass still missing, errors
 		if (rc) return rc;
 		bv::launch_gather_rows(d_nodes, (int64_t)q, (int64_t)arcs, v.rowstart, v.halo, d_rowptr, d_succ, g->stream);

@@ -298,6 +298,8 @@ const int GEN_BLOCK = 1 << 16; // nodes per independent generation block
 
 } // namespace
 
+extern "C" int bvt_generate_ex(int32_t n, int64_t m, uint64_t seed, double p_copy, double p_same, double p_keep, int threads, int64_t **rowptr_out, int32_t **succ_out);
+
 extern "C" int bvt_store(const char *basename, int32_t n, const int64_t *rowptr, const int32_t *succ,
                          int window, int max_ref_count, int min_interval, int zeta_k, uint32_t flags, int threads,
                          bvt_store_stats *stats) {
@@ -363,6 +365,14 @@ extern "C" int bvt_store(const char *basename, int32_t n, const int64_t *rowptr,
 }
 
 extern "C" int bvt_generate(int32_t n, int64_t m, uint64_t seed, double p_copy, int threads, int64_t **rowptr_out, int32_t **succ_out) {
+	return bvt_generate_ex(n, m, seed, p_copy, 0.0, 0.7, threads, rowptr_out, succ_out);
+}
+
+// p_same > 0: outdegrees come in runs (a node repeats its predecessor's raw outdegree with probability p_same), and a
+// copying node prefers its immediate predecessor as prototype -- pages of one site with near-identical link lists, the
+// shape that gives real web graphs their deep reference chains (cnr-2000: 47.5 % of the non-empty nodes at depth 3).
+// p_same = 0, p_keep = 0.7 is the C2 recipe, bit for bit (no extra random draws).
+extern "C" int bvt_generate_ex(int32_t n, int64_t m, uint64_t seed, double p_copy, double p_same, double p_keep, int threads, int64_t **rowptr_out, int32_t **succ_out) {
 	if (n <= 0 || m < 0 || !rowptr_out || !succ_out) return -EINVAL;
 	if (threads < 1) threads = 1;
 	const int64_t dcap = std::max<int64_t>(1, n / 4);
@@ -380,7 +390,10 @@ extern "C" int bvt_generate(int32_t n, int64_t m, uint64_t seed, double p_copy, 
 	par([&](int b) {
 		Rng r(seed ^ (0xD1B54A32D192ED03ULL * (uint64_t)(b + 1)));
 		int32_t lo = b * GEN_BLOCK, hi = std::min<int64_t>((int64_t)lo + GEN_BLOCK, n);
-		for (int32_t x = lo; x < hi; x++) raw[(size_t)x] = r.unit() < 0.2 ? 0 : (int32_t)pareto_floor(r, 1.1, 1e5);
+		for (int32_t x = lo; x < hi; x++) {
+			if (p_same > 0 && x > lo && raw[(size_t)x - 1] && r.unit() < p_same) { raw[(size_t)x] = raw[(size_t)x - 1]; continue; }
+			raw[(size_t)x] = r.unit() < 0.2 ? 0 : (int32_t)pareto_floor(r, 1.1, 1e5);
+		}
 	});
 	// 2. rescale to hit exactly m arcs: d = clamp(round(raw*s), 1, dcap) for raw>0, s by bisection
 	auto total = [&](double s) { int64_t t = 0; for (int32_t x = 0; x < n; x++) if (raw[(size_t)x]) t += std::min<int64_t>(dcap, std::max<int64_t>(1, (int64_t)std::llround(raw[(size_t)x] * s))); return t; };
@@ -415,9 +428,10 @@ extern "C" int bvt_generate(int32_t n, int64_t m, uint64_t seed, double p_copy, 
 			cur.clear();
 			if (x > lo && r.unit() < p_copy) {
 				int32_t back = 1 + (int32_t)(r.next() % (uint64_t)std::min(7, x - lo));
+				if (p_same > 0 && r.unit() < p_same) back = 1;
 				int32_t y = x - back;
 				const int32_t *pl = succ + rowptr[y]; int64_t pd = rowptr[y + 1] - rowptr[y];
-				for (int64_t i = 0; i < pd && (int64_t)cur.size() < d; i++) if (r.unit() < 0.7) cur.push_back(pl[i]);
+				for (int64_t i = 0; i < pd && (int64_t)cur.size() < d; i++) if (r.unit() < p_keep) cur.push_back(pl[i]);
 			}
 			for (int round = 0; (int64_t)cur.size() < d; round++) {
 				int64_t need = d - (int64_t)cur.size();
@@ -444,6 +458,25 @@ extern "C" int bvt_generate(int32_t n, int64_t m, uint64_t seed, double p_copy, 
 }
 
 extern "C" void bvt_free(void *p) { free(p); }
+
+// The node ids of SpeedTest's random-access leg (src/it/unimi/dsi/webgraph/test/SpeedTest.java:79, :98-111):
+// `r.setSeed(seed)` before every repetition, then `r.nextInt(n)` per sample, r an XoRoShiRo128PlusRandom.  That class
+// lives in dsiutils (not in the reference repository, version unpinned): restated here as xoroshiro128+ with the 2018
+// constants (24, 16, 37), state = two SplitMix64 outputs of the seed, nextInt(n) = nextLong(n) by the high bits for a power
+// of two and by rejection on the top 63 bits otherwise.  The exact id stream is therefore "parity unpinned"; the protocol
+// (the same ids in every repetition, uniform over [0, n)) is what the reference pins.
+extern "C" int bvt_random_nodes(uint64_t seed, int32_t n, int64_t count, int32_t *out) {
+	if (n <= 0 || count < 0 || !out) return -EINVAL;
+	Rng r(seed);
+	const uint64_t nn = (uint64_t)n, nm1 = nn - 1;
+	for (int64_t i = 0; i < count; i++) {
+		uint64_t t = r.next();
+		if ((nn & nm1) == 0) { out[i] = (int32_t)(nm1 ? (t >> __builtin_clzll(nm1)) & nm1 : 0); continue; }
+		for (uint64_t u = t >> 1; (int64_t)(u + nm1 - (t = u % nn)) < 0; u = r.next() >> 1) {}
+		out[i] = (int32_t)t;
+	}
+	return 0;
+}
 
 // BitStreamArcLabelledImmutableGraph.store (labelling/BitStreamArcLabelledImmutableGraph.java:650-693): the labels of
 // all arcs in enumeration order as one bit stream, gamma(0) + gamma(bits of every node's list) as offsets, and the

@@ -53,12 +53,15 @@ class BVGraph;
 // Sequential scan served from GPU-decoded batches (BVGraphNodeIterator, BVGraph.java:1136-1281).
 class NodeIterator {
 	const BVGraph *g_;
+	std::shared_ptr<const BVGraph> own_; // copy() / split iterators decode through a flyweight handle of their own (bvg_clone):
+	                                     // the reference hands them to other threads (BVGraph.java:2471-2477) and a bvg_t is not thread-safe
 	int32_t from_, curr_, limit_, lo_ = 0, hi_ = 0, batch_;
 	std::vector<int64_t> rowptr_;
 	std::vector<int32_t> succ_;
 	void fill();
 public:
 	NodeIterator(const BVGraph *g, int32_t from, int32_t upperBound, int32_t batchNodes = 1 << 20);
+	NodeIterator(std::shared_ptr<const BVGraph> own, int32_t from, int32_t upperBound, int32_t batchNodes);
 	bool hasNext() const { return curr_ < limit_; }                                  // BVGraph.java:1216
 	int32_t nextInt() {
 		if (!hasNext()) throw std::out_of_range("NoSuchElementException");
@@ -122,13 +125,19 @@ public:
 		detail::check(bvg_successors_batch(h_.get(), &x, 1, rp, out.data(), out.size(), &arcs, BVG_OUT_HOST), h_.get());
 		return out;
 	}
-	// CSR of nodes [from, to): what draining nodeIterator(from).copy(to) yields
+	// CSR of nodes [from, to): what draining nodeIterator(from).copy(to) yields.  One call: the results arrive in the
+	// handle's pinned buffers (bvg_decode_range_view) and are copied out once.
 	void decodeRange(int32_t from, int32_t to, std::vector<int64_t> &rowptr, std::vector<int32_t> &succ) const {
-		rowptr.assign((size_t)std::max(to - from, 0) + 1, 0);
+		const int64_t *rp = nullptr; const int32_t *sc = nullptr;
 		uint64_t arcs = 0;
-		detail::check(bvg_decode_range(h_.get(), from, to, rowptr.data(), nullptr, 0, &arcs, BVG_OUT_HOST), h_.get());
-		succ.resize((size_t)arcs);
-		detail::check(bvg_decode_range(h_.get(), from, to, rowptr.data(), succ.data(), succ.size(), &arcs, BVG_OUT_HOST), h_.get());
+		detail::check(bvg_decode_range_view(h_.get(), from, to, &rp, &sc, &arcs), h_.get());
+		rowptr.assign(rp, rp + (size_t)std::max(to - from, 0) + 1);
+		succ.assign(sc, sc + arcs);
+	}
+	// hashCode() continued from h over nodes [from, to) on the device, nothing materialised (bvg_scan_checksum)
+	int32_t scanChecksum(int32_t from, int32_t to, int32_t h, uint64_t *arcs = nullptr) const {
+		detail::check(bvg_scan_checksum(h_.get(), from, to, &h, arcs), h_.get());
+		return h;
 	}
 	NodeIterator nodeIterator(int32_t from = 0) const { return NodeIterator(this, from, INT32_MAX); } // BVGraph.java:1293
 	// ImmutableGraph.splitNodeIterators (ImmutableGraph.java:379-409), random-access branch; unused slots are empty iterators
@@ -180,6 +189,7 @@ inline void NodeIterator::fill() {
 	hi_ = (int32_t)std::min<int64_t>((int64_t)lo_ + batch_, (int64_t)limit_ + 1);
 	g_->decodeRange(lo_, hi_, rowptr_, succ_);
 }
-inline NodeIterator NodeIterator::copy(int32_t upperBound) const { return NodeIterator(g_, curr_ + 1, upperBound, batch_); }
+inline NodeIterator::NodeIterator(std::shared_ptr<const BVGraph> own, int32_t from, int32_t upperBound, int32_t batchNodes) : NodeIterator(own.get(), from, upperBound, batchNodes) { own_ = std::move(own); }
+inline NodeIterator NodeIterator::copy(int32_t upperBound) const { return NodeIterator(std::make_shared<const BVGraph>(g_->copy()), curr_ + 1, upperBound, batch_); }
 
 } // namespace webgraph

@@ -50,6 +50,8 @@ def lib():
                                 C.c_uint32, C.c_int, C.POINTER(StoreStats)]
         L.bvt_generate.argtypes = [C.c_int32, C.c_int64, C.c_uint64, C.c_double, C.c_int,
                                    C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+        L.bvt_generate_ex.argtypes = [C.c_int32, C.c_int64, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_int,
+                                      C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
         L.bvt_free.argtypes = [C.c_void_p]
         _lib = L
     return _lib
@@ -68,11 +70,12 @@ def store(basename, rowptr, succ, window=7, max_ref_count=3, min_interval=4, zet
     return st.as_dict()
 
 
-def generate(n, m, seed=0x5EEDB5E70001, p_copy=0.5, threads=None):
-    """Seeded power-law / copy-model graph; returns (rowptr int64[n+1], succ int32[m])."""
+def generate(n, m, seed=0x5EEDB5E70001, p_copy=0.5, threads=None, p_same=0.0, p_keep=0.7):
+    """Seeded power-law / copy-model graph; returns (rowptr int64[n+1], succ int32[m]).
+    p_same / p_keep: the C5 knobs (runs of equal outdegrees copying from their predecessor; include/bvgtools.h)."""
     threads = threads or os.cpu_count() or 1
     rp, sp = C.c_void_p(), C.c_void_p()
-    rc = lib().bvt_generate(n, m, seed, p_copy, threads, C.byref(rp), C.byref(sp))
+    rc = lib().bvt_generate_ex(n, m, seed, p_copy, p_same, p_keep, threads, C.byref(rp), C.byref(sp))
     if rc:
         raise OSError(-rc, "bvt_generate failed: %s" % os.strerror(-rc))
     try:
@@ -82,6 +85,17 @@ def generate(n, m, seed=0x5EEDB5E70001, p_copy=0.5, threads=None):
         lib().bvt_free(rp)
         lib().bvt_free(sp)
     return rowptr, succ
+
+
+def random_nodes(n, count, seed=0x5EEDB5E70004):
+    """SpeedTest's random-access ids (xoroshiro128+ re-seeded per repetition, SpeedTest.java:98-111): int32[count]."""
+    out = np.empty(max(count, 1), dtype=np.int32)
+    L = lib()
+    L.bvt_random_nodes.argtypes = [C.c_uint64, C.c_int32, C.c_int64, C.c_void_p]
+    rc = L.bvt_random_nodes(seed, n, count, out.ctypes.data)
+    if rc:
+        raise OSError(-rc, "bvt_random_nodes failed")
+    return out[:count]
 
 
 def store_labels(basename, underlying, rowptr, labels, kind="gamma", width=0, key="FOO"):
