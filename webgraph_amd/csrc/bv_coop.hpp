@@ -674,6 +674,86 @@ __device__ __forceinline__ void coop_residuals(const Grp<NW> &G, const GraphDev 
 #undef RT
 }
 
+// A long copy-block list (gamma codes, default coding) walked by ONE wave cooperatively instead of code by code: the
+// same speculative tile decode as an interval section (coop_intervals in bv_coop.hpp), block b playing the part of
+// a (copied, skipped) alternation.  Fills kend[j] / delta[j] for the j-th copied block exactly as the serial walk
+// does, including the implicit last block, and returns the totals.  Called by the 64 lanes of wave 0 only.
+constexpr int COPY_COOP_WALK_MIN = 192; // below this many blocks the serial walk is as fast
+__device__ __forceinline__ void coop_block_walk(const GraphDev &g, uint64_t pos, uint64_t recEnd, int64_t bc, int64_t dref, int32_t d, int32_t *kend, int32_t *delta, int32_t tabCap,
+                                                uint32_t *lds, int64_t &totalOut, int64_t &copiedOut, int32_t &nKeptOut, int &bad, uint64_t *posAfter = nullptr) {
+	Grp<1> G{ (int64_t *)(lds + CoopLds<1>::OFF_XCH) };
+	const uint32_t B = coop_pick_B(min<uint64_t>(recEnd > pos ? recEnd - pos : 0, (uint64_t)bc * 8), (uint64_t)bc, 64, CoopCfg<1>::B_MAX);
+	int64_t done = 0, total = 0, copied = 0; // uniform
+	int err = 0;
+	while (done < bc) {
+		const WindowSrc src = stage_tile<1>(G, g, lds + CoopLds<1>::OFF_WIN, pos, B);
+		const uint64_t base = src.w0 << 5;
+		uint64_t E; uint32_t s, c; int64_t unused;
+		spec_tile<1, 1, 1>(G, g, src, pos, recEnd, B, false, bc - done, s, c, unused, E);
+		int64_t tileTotal;
+		const int64_t cincl = G.incl_scan((int64_t)c, tileTotal);
+		const int64_t cb = cincl - c, rem = bc - done;
+		if (cb >= rem) c = 0; else if (cb + c > rem) c = (uint32_t)(rem - cb);
+		const int64_t n = min(rem, tileTotal);
+		if (n <= 0) { err = 1; break; }
+		// pass 1: what my codes add to the referent index and to the number of copied ids
+		int64_t dAll = 0, dEven = 0;
+		uint32_t myEnd = s;
+		{
+			uint32_t p = s;
+			for (uint32_t k = 0; k < c; k++) {
+				const int64_t q = done + cb + k;
+				const uint64_t v = win_code_rel<1, 1>(g, src, p, err);
+				if (v > (uint64_t)dref) err |= 1; // (any 64-bit value in a malformed stream: the sums below must not wrap)
+				const int64_t len = (int64_t)(v & 0x7fffffffu) + (q ? 1 : 0);
+				dAll += len;
+				if (!(q & 1)) dEven += len;
+			}
+			myEnd = p;
+		}
+		int64_t allTot, evenTot;
+		const int64_t iAll = G.incl_scan(dAll, allTot), iEven = G.incl_scan(dEven, evenTot);
+		int64_t t = total + iAll - dAll, cp = copied + iEven - dEven;
+		// pass 2: the table entries of my copied blocks
+		{
+			uint32_t p = s;
+			int e2 = 0;
+			for (uint32_t k = 0; k < c; k++) {
+				const int64_t q = done + cb + k;
+				const int64_t len = (int64_t)(win_code_rel<1, 1>(g, src, p, e2) & 0x7fffffffu) + (q ? 1 : 0);
+				if (!(q & 1)) {
+					const int64_t j = q >> 1;
+					if (j < tabCap) { kend[j] = (int32_t)min<int64_t>(cp + len, 0x7fffffff); delta[j] = (int32_t)(t - cp); }
+					cp += len;
+				}
+				t += len;
+			}
+		}
+		const int lastTid = G.last_set(c > 0);
+		const uint64_t endPos = base + (uint64_t)G.bcast((int64_t)myEnd, lastTid);
+		total += allTot;
+		copied += evenTot;
+		done += n;
+		pos = done >= bc ? endPos : E;
+		if (total > dref || copied > d) { err = 1; break; } // (uniform)
+	}
+	if (G.any(err != 0)) { bad = 1; return; }
+	// implicit last block: the rest of the referent's row, copied when the block count is even
+	const int64_t rest = dref - total;
+	if (rest < 0) { bad = 1; return; }
+	if (!(bc & 1)) {
+		const int64_t j = bc >> 1;
+		if (j < tabCap && threadIdx.x == 0) { kend[j] = (int32_t)min<int64_t>(copied + rest, 0x7fffffff); delta[j] = (int32_t)(total - copied); }
+		copied += rest;
+	}
+	total += rest;
+	totalOut = total;
+	copiedOut = copied;
+	if (posAfter) *posAfter = pos;
+	nKeptOut = (int32_t)min<int64_t>((bc >> 1) + 1, 0x7fffffff);
+}
+
+
 // The whole record of node x by one group.  Same contract as parse_node: extras merged into row[copied..d).
 template <int DEF, int NW>
 __device__ __forceinline__ void coop_parse_node(const GraphDev &g, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row,
@@ -696,6 +776,24 @@ __device__ __forceinline__ void coop_parse_node(const GraphDev &g, int32_t x, in
 		const uint64_t bc = Fields<DEF>::block_count(br, g);
 		int64_t total = 0;
 		if (bc > (uint64_t)dref + 1) err |= E_FORMAT;
+		else if (DEF && bc >= COPY_COOP_WALK_MIN && !br.err) {
+			// A long block list (a long row copying a long row: thousands of codes) walked code by code would be the serial
+			// part of the whole record: the first wave decodes it cooperatively, totals only (no tables), and tells the others.
+			int64_t cp = 0;
+			int32_t nKept = 0;
+			int bad = 0;
+			uint64_t after = br.pos();
+			if (NW == 1 || G.wave() == 0) coop_block_walk(g, br.pos(), recEnd, (int64_t)bc, dref, d, (int32_t *)nullptr, (int32_t *)nullptr, 0, lds, total, cp, nKept, bad, &after);
+			if (NW > 1) {
+				if (tid == 0) { G.xch[NW + 1] = cp; G.xch[NW + 2] = (int64_t)after; G.xch[NW + 3] = bad; }
+				__syncthreads();
+				cp = G.xch[NW + 1]; after = (uint64_t)G.xch[NW + 2]; bad = (int)G.xch[NW + 3];
+				__syncthreads();
+			}
+			if (bad) err |= E_FORMAT;
+			copied = cp;
+			br.seek(after);
+		}
 		else {
 			for (uint64_t b = 0; b < bc; b++) {
 				int64_t len;

@@ -26,6 +26,7 @@
 #include "bv_coop.hpp"
 #include "bv_lanewin.hpp"
 #include "bv_lane.hpp"
+#include "bv_tile.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -617,85 +618,7 @@ __global__ void __launch_bounds__(64 * COPY_MID_WAVES) k_copy_mid(GraphDev g, Ra
 	}
 }
 
-// A long copy-block list (gamma codes, default coding) walked by ONE wave cooperatively instead of code by code: the
-// same speculative tile decode as an interval section (coop_intervals in bv_coop.hpp), block b playing the part of
-// a (copied, skipped) alternation.  Fills kend[j] / delta[j] for the j-th copied block exactly as the serial walk
-// does, including the implicit last block, and returns the totals.  Called by the 64 lanes of wave 0 only.
 constexpr int COPY_BIG_THREADS = 1024, COPY_BIG_CAP = 6144, COPY_BIG_ITEMS = 8;
-constexpr int COPY_COOP_WALK_MIN = 192; // below this many blocks the serial walk is as fast
-__device__ __forceinline__ void coop_block_walk(const GraphDev &g, uint64_t pos, uint64_t recEnd, int64_t bc, int64_t dref, int32_t d, int32_t *kend, int32_t *delta, int32_t tabCap,
-                                                uint32_t *lds, int64_t &totalOut, int64_t &copiedOut, int32_t &nKeptOut, int &bad) {
-	Grp<1> G{ (int64_t *)(lds + CoopLds<1>::OFF_XCH) };
-	const uint32_t B = coop_pick_B(min<uint64_t>(recEnd > pos ? recEnd - pos : 0, (uint64_t)bc * 8), (uint64_t)bc, 64, CoopCfg<1>::B_MAX);
-	int64_t done = 0, total = 0, copied = 0; // uniform
-	int err = 0;
-	while (done < bc) {
-		const WindowSrc src = stage_tile<1>(G, g, lds + CoopLds<1>::OFF_WIN, pos, B);
-		const uint64_t base = src.w0 << 5;
-		uint64_t E; uint32_t s, c; int64_t unused;
-		spec_tile<1, 1, 1>(G, g, src, pos, recEnd, B, false, bc - done, s, c, unused, E);
-		int64_t tileTotal;
-		const int64_t cincl = G.incl_scan((int64_t)c, tileTotal);
-		const int64_t cb = cincl - c, rem = bc - done;
-		if (cb >= rem) c = 0; else if (cb + c > rem) c = (uint32_t)(rem - cb);
-		const int64_t n = min(rem, tileTotal);
-		if (n <= 0) { err = 1; break; }
-		// pass 1: what my codes add to the referent index and to the number of copied ids
-		int64_t dAll = 0, dEven = 0;
-		uint32_t myEnd = s;
-		{
-			uint32_t p = s;
-			for (uint32_t k = 0; k < c; k++) {
-				const int64_t q = done + cb + k;
-				const uint64_t v = win_code_rel<1, 1>(g, src, p, err);
-				if (v > (uint64_t)dref) err |= 1; // (any 64-bit value in a malformed stream: the sums below must not wrap)
-				const int64_t len = (int64_t)(v & 0x7fffffffu) + (q ? 1 : 0);
-				dAll += len;
-				if (!(q & 1)) dEven += len;
-			}
-			myEnd = p;
-		}
-		int64_t allTot, evenTot;
-		const int64_t iAll = G.incl_scan(dAll, allTot), iEven = G.incl_scan(dEven, evenTot);
-		int64_t t = total + iAll - dAll, cp = copied + iEven - dEven;
-		// pass 2: the table entries of my copied blocks
-		{
-			uint32_t p = s;
-			int e2 = 0;
-			for (uint32_t k = 0; k < c; k++) {
-				const int64_t q = done + cb + k;
-				const int64_t len = (int64_t)(win_code_rel<1, 1>(g, src, p, e2) & 0x7fffffffu) + (q ? 1 : 0);
-				if (!(q & 1)) {
-					const int64_t j = q >> 1;
-					if (j < tabCap) { kend[j] = (int32_t)min<int64_t>(cp + len, 0x7fffffff); delta[j] = (int32_t)(t - cp); }
-					cp += len;
-				}
-				t += len;
-			}
-		}
-		const int lastTid = G.last_set(c > 0);
-		const uint64_t endPos = base + (uint64_t)G.bcast((int64_t)myEnd, lastTid);
-		total += allTot;
-		copied += evenTot;
-		done += n;
-		pos = done >= bc ? endPos : E;
-		if (total > dref || copied > d) { err = 1; break; } // (uniform)
-	}
-	if (G.any(err != 0)) { bad = 1; return; }
-	// implicit last block: the rest of the referent's row, copied when the block count is even
-	const int64_t rest = dref - total;
-	if (rest < 0) { bad = 1; return; }
-	if (!(bc & 1)) {
-		const int64_t j = bc >> 1;
-		if (j < tabCap && threadIdx.x == 0) { kend[j] = (int32_t)min<int64_t>(copied + rest, 0x7fffffff); delta[j] = (int32_t)(total - copied); }
-		copied += rest;
-	}
-	total += rest;
-	totalOut = total;
-	copiedOut = copied;
-	nKeptOut = (int32_t)min<int64_t>((bc >> 1) + 1, 0x7fffffff);
-}
-
 // One 1024-thread group per long row with a reference.  The block list is walked once, without memory traffic
 // (it is the serial part of a row with thousands of blocks), into the same two LDS tables as in k_copy_mid; the
 // copied ids (<= COPY_BIG_CAP of them) are then gathered into LDS and ranked among the row's extras
@@ -1422,6 +1345,7 @@ void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int
 		if (stBig != st) (void)hipStreamWaitEvent(stBig, evFork, 0);
 	}
 	if (bigGroups) {
+		(void)hipMemsetAsync(ctl + 7, 0, sizeof(int32_t), stBig); // the scratch tables of the previous level's rows are free again
 		if (def == 1) hipLaunchKernelGGL(k_copy_big<1>, dim3(512), dim3(COPY_BIG_THREADS), 0, stBig, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 7), err);
 		else if (def == 2) hipLaunchKernelGGL(k_copy_big<2>, dim3(512), dim3(COPY_BIG_THREADS), 0, stBig, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 7), err);
 		else hipLaunchKernelGGL(k_copy_big<0>, dim3(512), dim3(COPY_BIG_THREADS), 0, stBig, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 7), err);
@@ -1438,6 +1362,16 @@ void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int
 	else hipLaunchKernelGGL(k_copy_list<0>, dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, midMin, bigMin, err);
 	if (stMid != st) (void)hipStreamWaitEvent(st, evMid, 0);
 	if (bigGroups && stBig != st) (void)hipStreamWaitEvent(st, evBig, 0);
+}
+
+int32_t tile_count(int64_t bitSpan, int32_t cnt) { return (int32_t)std::min<int64_t>((bitSpan + (int64_t)TILE_NODE_BITS * cnt) / TILE_SPAN + 1, 0x7ffffff0); }
+void launch_tile_bounds(const GraphDev &g, int32_t lo, int32_t cnt, int32_t ntiles, int32_t *tb, hipStream_t st) {
+	hipLaunchKernelGGL(k_tile_bounds, dim3(nblk((int64_t)ntiles + 1, 256)), dim3(256), 0, st, g.offsets, lo, cnt, ntiles, tb);
+}
+void launch_parse_tile(const GraphDev &g, int def, const RangeView &v, const int32_t *tb, int32_t ntiles, int *err, hipStream_t st) {
+	if (v.cnt <= 0 || ntiles <= 0) return;
+	if (def == 1) hipLaunchKernelGGL(k_parse_tile<1>, dim3(ntiles), dim3(TILE_T), 0, st, g, v, tb, err);
+	else hipLaunchKernelGGL(k_parse_tile<2>, dim3(ntiles), dim3(TILE_T), 0, st, g, v, tb, err);
 }
 
 void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st) {

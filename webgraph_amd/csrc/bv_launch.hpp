@@ -78,6 +78,10 @@ void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int
 void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st);
 void launch_parse_waves(const GraphDev &g, int def, const RangeView &v, const int32_t *biglist, int32_t *ctl, void *arena, int64_t arenaCap, int waves, int *err, hipStream_t st);
 void launch_parse_giants(const GraphDev &g, int def, const RangeView &v, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap, int giantGroups, int *err, hipStream_t st);
+// bv_tile.hpp: short records decoded tile by tile from one LDS image of a contiguous slice of the stream
+int32_t tile_count(int64_t bitSpan, int32_t cnt);
+void launch_tile_bounds(const GraphDev &g, int32_t lo, int32_t cnt, int32_t ntiles, int32_t *tb, hipStream_t st);
+void launch_parse_tile(const GraphDev &g, int def, const RangeView &v, const int32_t *tb, int32_t ntiles, int *err, hipStream_t st);
 void launch_hash(int32_t from, int32_t cnt, const int64_t *rowptr, const int32_t *succ, uint32_t *A, uint32_t *B, int32_t *hash, hipStream_t st);
 
 void launch_bparse_big(const GraphDev &g, int def, const BatchView &v, int32_t coopMin, int32_t giantMin, int32_t *biglist, int32_t *giantlist, int32_t giantCap, int32_t *ctl,

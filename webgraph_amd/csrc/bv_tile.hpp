@@ -1,0 +1,244 @@
+// bv_tile.hpp -- the records of a CONTIGUOUS tile of nodes decoded by one work-group from one LDS image of their bits (gfx950).
+//
+// Consecutive nodes are consecutive in the bit stream and in the CSR.  A work-group owns the nodes whose records START in
+// one slice of the stream (TILE_SPAN bits, counting 32 bits per node so that a run of empty nodes cannot make a tile of a
+// million rows): it loads the slice ONCE, with coalesced 16-byte loads, byte-swaps it into LDS, and every lane then decodes
+// whole records from that shared image with the stateless short-code decoders of bv_coop.hpp -- no per-lane stream
+// windows, no refills, no global load inside the decode loop (gfx950 counts loads and stores in one counter: a lane that
+// loads while it has stores in flight waits for all of them).  The rows of a tile are neighbours in the CSR, so the 16-byte
+// stores of its lanes fill whole cache lines in the L2 before they leave for HBM.
+//
+// Balance inside the tile: its records are sorted by work (max(bits, 8 * outdegree), half-octave bins, counting sort in
+// LDS) and handed to the lanes longest first, so that the 64 lanes of a wave hold records of similar length.
+//
+// Record grammar and semantics: BVG:1032-1133; same contract as parse_node / parse_node_lw: the
+// record's extras (intervals merged with residuals, IntIntervalSequenceIterator + ResidualIntIterator under a
+// MergedIntIterator, BVG:1103-1110) go to the TAIL of its CSR row, row[copied..d).  Default codings only (DEF 1 / 2).
+#pragma once
+#include "bv_coop.hpp"
+#include "bv_lanewin.hpp"
+#include "bv_launch.hpp"
+
+namespace bv {
+
+constexpr int TILE_T = 256;                    // threads per tile
+constexpr int TILE_SPAN = 1 << 16;             // tile weight: bits of the records that start in it + TILE_NODE_BITS per node
+constexpr int TILE_NODE_BITS = 32;             // => at most TILE_SPAN / 32 = 2048 nodes per tile
+constexpr int TILE_NODES = TILE_SPAN / TILE_NODE_BITS;
+constexpr int TILE_WIN_WORDS = TILE_SPAN / 32 + 256; // staged words: the slice, 1 KB of overhang for the last record, look-ahead
+constexpr int TILE_NBIN = 32;
+
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+
+struct TWin {
+	const lds_u32 *win; // staged words, byte-swapped (first stream bit = bit 31)
+	uint32_t nw;        // staged words
+	uint64_t w0;        // absolute index of win[0] (multiple of 4)
+	const uint32_t *gbits;
+	uint64_t gnw;
+};
+// a word the tile did not stage (the tail of a record that overhangs the slice by more than the slack): straight from HBM
+__device__ __attribute__((noinline)) uint32_t tw_word_slow(const uint32_t *gbits, uint64_t gnw, uint64_t j) { return j < gnw ? __builtin_bswap32(gbits[j]) : 0u; }
+__device__ __forceinline__ uint32_t tw_word(const TWin &t, uint32_t k) { // k: word index relative to w0
+	if (__builtin_expect(k < t.nw, 1)) return t.win[k];
+	return tw_word_slow(t.gbits, t.gnw, t.w0 + k);
+}
+
+// One record's cursor: k0 = its first word (relative to the window), q = bit offset from that word.
+struct TCur {
+	uint32_t k0, q;
+	__device__ __forceinline__ uint64_t abs_pos(const TWin &t) const { return ((t.w0 + k0) << 5) + q; }
+	__device__ __forceinline__ void set_abs(const TWin &t, uint64_t p) { q = (uint32_t)(p - ((t.w0 + k0) << 5)); }
+	// KIND 0: zeta_k (ZK = 3 folded in, 0: zk at run time), 1: gamma, 2: unary
+	template <int KIND, int ZK> __device__ __forceinline__ uint64_t code(const TWin &t, uint32_t zk, int &err) {
+		const uint32_t j = k0 + (q >> 5), sh = q & 31u;
+		const uint32_t a = tw_word(t, j), b = tw_word(t, j + 1);
+		const uint64_t ab = ((uint64_t)a << 32) | b;
+		const uint32_t W = (uint32_t)((ab << sh) >> 32);
+		uint32_t v, len;
+		if (KIND == 2) {
+			if (__builtin_expect(W != 0, 1)) { const uint32_t z = (uint32_t)__clz((int)W); q += z + 1; return z; }
+		} else if (__builtin_expect(KIND == 1 ? fast_gamma32(W, v, len) : fast_zeta_32<ZK>(W, zk, v, len), 1)) { q += len; return v; }
+		const uint32_t c = tw_word(t, j + 2);
+		const uint64_t W64 = sh ? (ab << sh) | ((uint64_t)c >> (32u - sh)) : ab;
+		uint64_t v64;
+		if (KIND == 2) {
+			if (W64) { const uint32_t z = (uint32_t)__clzll((long long)W64); q += z + 1; return z; }
+		} else if (KIND == 1 ? fast_gamma(W64, v64, len) : fast_zeta<ZK>(W64, zk, v64, len)) { q += len; return v64; }
+		const SlowAbs sa = (KIND == 0 && ZK != 3) ? lane_zeta_slow(t.gbits, t.gnw, abs_pos(t), (int)zk) : lane_code_slow<KIND>(t.gbits, t.gnw, abs_pos(t));
+		err |= sa.err;
+		set_abs(t, sa.pos);
+		return sa.v;
+	}
+};
+
+// Same contract as parse_node_lw, reading the record from the tile's window.
+template <int ZK>
+__device__ __forceinline__ void parse_node_tile(const GraphDev &g, const TWin &tw, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row, int *__restrict__ err) {
+	const uint64_t p0 = (uint64_t)g.offsets[x];
+	TCur br, bi;
+	br.k0 = (uint32_t)((p0 >> 5) - tw.w0);
+	br.q = (uint32_t)p0 & 31u;
+	const uint32_t zk = ZK == 3 ? 3u : (uint32_t)g.zetaK;
+	int e = 0;
+	(void)br.code<1, ZK>(tw, zk, e);              // outdegree (known from k_headers)
+	if (g.W > 0) (void)br.code<2, ZK>(tw, zk, e); // reference
+	int64_t copied = 0;
+	if (hasRef) { // BVG:1058-1071
+		const uint64_t bc = br.code<1, ZK>(tw, zk, e);
+		int64_t total = 0;
+		if (bc > (uint64_t)dref + 1) e |= E_FORMAT;
+		else {
+			for (uint64_t b = 0; b < bc; b++) {
+				int64_t len;
+				if (!block_len_ok(br.code<1, ZK>(tw, zk, e), b == 0, total, dref, len)) { e |= E_FORMAT; break; }
+				total += len;
+				if (!(b & 1)) copied += len;
+			}
+			if (!(bc & 1)) copied += dref - total;
+		}
+	}
+	const int64_t extra = (int64_t)d - copied;
+	if (extra < 0 || copied < 0) e |= E_FORMAT;
+	if (e) { atomicOr(err, e); return; }
+	if (extra == 0) return;
+
+	int64_t nIntervals = 0, intervalArcs = 0;
+	bi = br;
+	if (g.minInt != 0) { // BVG:1073-1096: skip-parse to find the residual section and the number of residuals
+		nIntervals = (int64_t)br.code<1, ZK>(tw, zk, e);
+		if (nIntervals > extra) { atomicOr(err, E_FORMAT); return; }
+		bi = br;
+		for (int64_t i = 0; i < nIntervals; i++) {
+			(void)br.code<1, ZK>(tw, zk, e);
+			const uint64_t len = br.code<1, ZK>(tw, zk, e);
+			if (len > (uint64_t)extra) { e |= E_FORMAT; break; }
+			intervalArcs += (int64_t)len + g.minInt;
+		}
+	}
+	const int64_t nRes = extra - intervalArcs;
+	if (nRes < 0 || e) { atomicOr(err, E_FORMAT | e); return; }
+
+	// merge(intervals, residuals) -> row[copied ..), in 16-byte stores where the row allows it.  Ids are Java ints:
+	// 32-bit wrapping arithmetic throughout (BVG:954, :966, :1084-1093 compute in int).
+	int32_t *out = row + copied;
+	const int32_t nExtra = (int32_t)extra;
+	int32_t k = 0;
+	const int32_t head = min(nExtra, (int32_t)(((16u - ((uint32_t)(uintptr_t)out & 15u)) & 15u) >> 2));
+	int32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0, on = 0;
+	int32_t ivLeft = 0, ivRem = 0, ivPrev = 0;
+	int32_t ivTodo = (int32_t)nIntervals;
+	bool firstIv = true;
+	int32_t resTodo = (int32_t)nRes;
+	int32_t resVal = 0;
+	if (resTodo) resVal = (int32_t)((int64_t)x + nat2int(br.code<0, ZK>(tw, zk, e))); // BVG:954
+	while (k < nExtra) {
+		if (ivRem == 0 && ivTodo) { // BVG:1084-1093
+			if (firstIv) { ivLeft = (int32_t)((int64_t)x + nat2int(bi.code<1, ZK>(tw, zk, e))); firstIv = false; }
+			else ivLeft = ivPrev + (int32_t)bi.code<1, ZK>(tw, zk, e) + 1;
+			ivRem = (int32_t)bi.code<1, ZK>(tw, zk, e) + g.minInt;
+			ivPrev = ivLeft + ivRem;
+			ivTodo--;
+		}
+		int32_t val;
+		if (ivRem && (!resTodo || ivLeft < resVal)) { val = ivLeft; ivLeft++; ivRem--; }
+		else if (resTodo) {
+			val = resVal;
+			if (ivRem && ivLeft == resVal) { ivLeft++; ivRem--; } // equal heads are emitted once (MergedIntIterator.java:69-72)
+			if (--resTodo) resVal += (int32_t)br.code<0, ZK>(tw, zk, e) + 1; // BVG:966
+		} else val = -1; // malformed: fewer values than the outdegree promises (BVG:1210 would store -1)
+		if (k < head) { out[k++] = val; continue; }
+		o0 = o1; o1 = o2; o2 = o3; o3 = val; k++;
+		if (++on == 4) { *(int4 *)(out + k - 4) = int4{ o0, o1, o2, o3 }; on = 0; }
+	}
+	if (on == 3) { out[k - 3] = o1; out[k - 2] = o2; out[k - 1] = o3; }
+	else if (on == 2) { out[k - 2] = o2; out[k - 1] = o3; }
+	else if (on == 1) out[k - 1] = o3;
+	if (e) atomicOr(err, e);
+}
+
+// tile t = the slots s of the view with  t * TILE_SPAN <= (offsets[lo+s] - offsets[lo]) + TILE_NODE_BITS * s < (t+1) * TILE_SPAN
+__global__ void __launch_bounds__(256) k_tile_bounds(const int64_t *__restrict__ offsets, int32_t lo, int32_t cnt, int32_t ntiles, int32_t *__restrict__ tb) {
+	const int32_t t = blockIdx.x * 256 + threadIdx.x;
+	if (t > ntiles) return;
+	const int64_t target = (int64_t)t * TILE_SPAN, base = offsets[lo];
+	int32_t a = 0, b = cnt; // first s in [0, cnt) with weight(s) >= target, cnt if none
+	while (a < b) {
+		const int32_t mid = (int32_t)(((int64_t)a + b) >> 1);
+		if ((offsets[lo + mid] - base) + (int64_t)TILE_NODE_BITS * mid < target) a = mid + 1; else b = mid;
+	}
+	tb[t] = a;
+}
+
+template <int DEF>
+__global__ void __launch_bounds__(TILE_T) k_parse_tile(GraphDev g, RangeView v, const int32_t *__restrict__ tb, int *__restrict__ err) {
+	__shared__ __attribute__((aligned(16))) uint32_t s_win[TILE_WIN_WORDS];
+	__shared__ uint16_t s_list[TILE_NODES];
+	__shared__ int32_t s_hist[TILE_NBIN], s_n;
+	const int tid = threadIdx.x;
+	const int32_t a = tb[blockIdx.x], b = tb[blockIdx.x + 1];
+	if (a >= b) return;
+	// ---- the tile's slice of the stream -> LDS (all loads of a lane in flight together, then the byte-swapped stores)
+	const uint64_t p0 = (uint64_t)g.offsets[v.lo + a], p1 = (uint64_t)g.offsets[v.lo + b];
+	const uint64_t w0 = (p0 >> 5) & ~(uint64_t)3;
+	const uint32_t nw = (uint32_t)min<uint64_t>(TILE_WIN_WORDS, (((p1 + 31) >> 5) - w0 + 3 + 3) & ~(uint64_t)3); // + look-ahead of the short-code decoders
+	{
+		constexpr int NV = (TILE_WIN_WORDS / 4 + TILE_T - 1) / TILE_T;
+		const uint4 *src4 = (const uint4 *)(g.bits + w0);
+		const uint64_t lim4 = (g.nwords + 8 - w0) / 4; // the image is followed by >= 8 zero words
+		uint4 q4[NV];
+#pragma unroll
+		for (int k = 0; k < NV; k++) {
+			const uint32_t i = (uint32_t)tid + (uint32_t)k * TILE_T;
+			q4[k] = (i < nw / 4 && i < lim4) ? src4[i] : uint4{ 0u, 0u, 0u, 0u };
+		}
+#pragma unroll
+		for (int k = 0; k < NV; k++) {
+			const uint32_t i = (uint32_t)tid + (uint32_t)k * TILE_T;
+			if (i < nw / 4) ((uint4 *)s_win)[i] = uint4{ __builtin_bswap32(q4[k].x), __builtin_bswap32(q4[k].y), __builtin_bswap32(q4[k].z), __builtin_bswap32(q4[k].w) };
+		}
+	}
+	// ---- the records this tile decodes, sorted by work, longest first (counting sort on half-octave bins)
+	if (tid < TILE_NBIN) s_hist[tid] = 0;
+	__syncthreads();
+	constexpr int RPT = TILE_NODES / TILE_T; // rows per thread
+	int32_t bin[RPT], pos[RPT];
+#pragma unroll
+	for (int k = 0; k < RPT; k++) {
+		const int32_t s = a + tid + k * TILE_T;
+		bin[k] = -1;
+		if (s < b) {
+			const int32_t d = v.outd[s];
+			if (d > 0 && d < v.coop_min) {
+				const uint64_t bitsLen = (uint64_t)(g.offsets[v.lo + s + 1] - g.offsets[v.lo + s]);
+				const uint64_t work = max(bitsLen, (uint64_t)d * 8);
+				const int lg = 63 - __clzll((long long)(work | 1));
+				const int h = 2 * lg + (lg > 0 ? (int)((work >> (lg - 1)) & 1) : 0);
+				bin[k] = TILE_NBIN - 1 - min(max(h - 8, 0), TILE_NBIN - 1); // bin 0 = the longest
+				pos[k] = atomicAdd(&s_hist[bin[k]], 1);
+			}
+		}
+	}
+	__syncthreads();
+	if (tid < 64) { // exclusive scan of the 32 bins by one wave
+		int32_t c = tid < TILE_NBIN ? s_hist[tid] : 0, inc = c;
+#pragma unroll
+		for (int o = 1; o < TILE_NBIN; o <<= 1) { const int32_t t2 = __shfl_up(inc, o, 64); if (tid >= o) inc += t2; }
+		if (tid < TILE_NBIN) s_hist[tid] = inc - c;
+		if (tid == TILE_NBIN - 1) s_n = inc;
+	}
+	__syncthreads();
+#pragma unroll
+	for (int k = 0; k < RPT; k++) if (bin[k] >= 0) s_list[s_hist[bin[k]] + pos[k]] = (uint16_t)(tid + k * TILE_T);
+	__syncthreads();
+	const TWin tw{ (const lds_u32 *)s_win, nw, w0, g.bits, g.nwords };
+	const int32_t nList = s_n;
+	for (int32_t idx = tid; idx < nList; idx += TILE_T) {
+		const int32_t s = a + (int32_t)s_list[idx];
+		const int32_t d = v.outd[s], r = v.ref[s];
+		if (!v.fits(s)) { atomicOr(err, s >= v.nh ? E_CAP : E_HALO); continue; }
+		parse_node_tile<DEF == 1 ? 3 : 0>(g, tw, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), err);
+	}
+}
+
+} // namespace bv

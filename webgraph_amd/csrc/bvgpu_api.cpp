@@ -113,6 +113,8 @@ struct bvg_graph {
 	DevBuf lvlist;
 	int parse_lists = 1; // BVGPU_PARSE_LISTS=0: short records parsed in node order instead of by work bin
 	DevBuf plist, pkeys, pkey16;
+	int tile = 1;        // BVGPU_TILE=0: short records through the bin-sorted parse list (k_parse_list) instead of contiguous tiles (k_parse_tile)
+	DevBuf tilebounds;
 	int copy_big = 1;    // BVGPU_COPY_BIG=0: every row is copied by one lane
 	int parse_windows = 1; // BVGPU_PARSE_WINDOWS=0: the parse list is sorted by work bin over the whole range
 	int copy_mid_min = 128; // rows with at least this many successors (and fewer than 1024) are copied by one wave each
@@ -205,6 +207,7 @@ int init_handle(bvg_graph *g) {
 	if (const char *e = getenv("BVGPU_PARSE_LISTS")) g->parse_lists = atoi(e);
 	if (const char *e = getenv("BVGPU_COPY_BIG")) g->copy_big = atoi(e);
 	if (const char *e = getenv("BVGPU_PARSE_WINDOWS")) g->parse_windows = atoi(e);
+	if (const char *e = getenv("BVGPU_TILE")) g->tile = atoi(e);
 	if (const char *e = getenv("BVGPU_COPY_MID_MIN")) g->copy_mid_min = std::min(std::max(0, atoi(e)), 1024); // 0: no wave-per-row copy
 	if (const char *e = getenv("BVGPU_OVERLAP")) g->overlap = atoi(e) != 0;
 	if (const char *e = getenv("BVGPU_HALO_MIN")) g->halo_min = (size_t)std::max(4, atoi(e));
@@ -374,9 +377,9 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		const int32_t midCap = g->copy_mid_min > 0 ? (int32_t)std::min<int64_t>(arcsBound / g->copy_mid_min + 2, 0x3fffffff) : 0;
 		if (g->copy_lists && !g->copyq.need(sizeof(int32_t) * ((size_t)bigCap + (size_t)midCap))) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
 		g->pend.bigCap = bigCap; g->pend.midCap = midCap;
-		// scratch tables of the rows that copy more ids than k_copy_big's LDS tables hold (bump-allocated, ctl[7]): a
-		// quarter of the arcs covers every realistic mix; a row that does not fit falls back to one lane
-		const uint32_t tmpCap = (uint32_t)std::min<int64_t>(std::max<int64_t>(arcsBound / 4, 1 << 22), 0x7fffffff);
+		// scratch tables of the rows that copy more ids than k_copy_big's LDS tables hold (bump-allocated per level, ctl[7]):
+		// <= 4 ints per copied id, and a level's long rows copy a fraction of the arcs; a row that does not fit falls back to one lane
+		const uint32_t tmpCap = (uint32_t)std::min<int64_t>(std::max<int64_t>(arcsBound, 1 << 22), 0x7fffffff);
 		if (g->copy_lists && g->copy_big && !g->bigtmp.need(sizeof(int32_t) * (size_t)tmpCap)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
 		g->pend.tmpCap = g->copy_lists && g->copy_big ? tmpCap : 0;
 		const bool coop = coopMin < 0x7fffffff;
@@ -391,8 +394,18 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		// parse list (every non-empty record, sorted by work bin inside windows of nodes): needs the outdegrees only, so
 		// with the headers' event at hand it is built on side A while the scan of the outdegrees still runs
 		int32_t *pKeyBase = nullptr;
-		const bool earlyList = g->parse_lists && ovl && hdrEvent;
-		if (g->parse_lists) {
+		// short records of the default codings: contiguous tiles of the stream, one LDS image each (bv_tile.hpp); the tile
+		// bounds follow from the offsets alone
+		const bool tiles = g->tile && s.def != 0;
+		int32_t ntiles = 0;
+		if (tiles) {
+			ntiles = bv::tile_count(s.h_offsets[(size_t)v.lo + v.cnt] - s.h_offsets[(size_t)v.lo], v.cnt);
+			if (!g->tilebounds.need(sizeof(int32_t) * ((size_t)ntiles + 2))) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
+			bv::launch_tile_bounds(gd, v.lo, v.cnt, ntiles, g->tilebounds.as<int32_t>(), ovl && hdrEvent ? g->sideA : g->stream);
+			if (ovl && hdrEvent) HIPCHK(g, hipEventRecord(g->evP, g->sideA));
+		}
+		const bool earlyList = !tiles && g->parse_lists && ovl && hdrEvent;
+		if (!tiles && g->parse_lists) {
 			if (!g->plist.need(sizeof(int32_t) * (size_t)v.cnt) || !g->pkeys.need(3 * (bv::NKEYS + 1) * sizeof(int32_t)) || !g->pkey16.need(sizeof(uint16_t) * (size_t)v.cnt)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
 			pKeyBase = g->pkeys.as<int32_t>() + (bv::NKEYS + 1);
 		}
@@ -435,17 +448,18 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		                                  g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->maxdepth, stLists,
 		                                  g->copy_lists ? g->copyq.as<int32_t>() : nullptr, bigCap, g->copyq.as<int32_t>() + bigCap, midCap, g->copy_mid_min, g->copy_big != 0);
 		if (ovl) HIPCHK(g, hipEventRecord(g->evA, g->sideA));
-		if (g->parse_lists && !earlyList)
+		if (!tiles && g->parse_lists && !earlyList)
 			bv::launch_build_lists(gd, v, ~0ull, g->parse_windows ? 6 : 2, nullptr, g->pkey16.as<uint16_t>(), g->pkeys.as<int32_t>(), pKeyBase, pKeyBase + (bv::NKEYS + 1), g->plist.as<int32_t>(),
 			                       g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->pad, g->stream);
-		if (earlyList) HIPCHK(g, hipStreamWaitEvent(g->stream, g->evP, 0));
+		if (earlyList || (tiles && ovl && hdrEvent)) HIPCHK(g, hipStreamWaitEvent(g->stream, g->evP, 0));
 		if (coop && !ovl) bv::launch_classify(v.cnt, v.outd, coopMin, giantMin, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, g->stream);
 		mark(g, 3);
 		if (coop && !ovl) bv::launch_parse_giants(gd, s.def, v, g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->giant_groups, derr, g->stream);
 		mark(g, 4);
 		if (coop && !ovl) bv::launch_parse_waves(gd, s.def, v, g->biglist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, derr, g->stream);
 		mark(g, 5);
-		if (pKeyBase) {
+		if (tiles) bv::launch_parse_tile(gd, s.def, v, g->tilebounds.as<int32_t>(), ntiles, derr, g->stream);
+		else if (pKeyBase) {
 			bv::launch_parse_list(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, g->level_blocks, derr, g->stream);
 		}
 		else bv::launch_parse(gd, s.def, v, derr, g->stream);
@@ -728,7 +742,7 @@ extern "C" int bvg_close(bvg_t *g) {
 	if (g->st && g->st->device >= 0) {
 		(void)hipSetDevice(g->st->device);
 		if (g->own) { (void)hipStreamSynchronize(g->own); (void)hipStreamDestroy(g->own); }
-		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist, &g->plist, &g->pkeys, &g->pkey16, &g->copyq, &g->bigtmp }) b->release();
+		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist, &g->plist, &g->pkeys, &g->pkey16, &g->copyq, &g->bigtmp, &g->tilebounds }) b->release();
 		for (DevBuf *b : { &g->hchunk[0], &g->hchunk[1] }) b->release();
 		for (PinBuf *b : { &g->hring[0], &g->hring[1], &g->view_rowptr, &g->view_succ }) b->release();
 		if (g->copyStream) { (void)hipStreamSynchronize(g->copyStream); (void)hipStreamDestroy(g->copyStream); }
