@@ -82,6 +82,10 @@ void launch_parse_giants(const GraphDev &g, int def, const RangeView &v, const i
 int32_t tile_count(int64_t bitSpan, int32_t cnt);
 void launch_tile_bounds(const GraphDev &g, int32_t lo, int32_t cnt, int32_t ntiles, int32_t *tb, hipStream_t st);
 void launch_parse_tile(const GraphDev &g, int def, const RangeView &v, const int32_t *tb, int32_t ntiles, int *err, hipStream_t st);
+// bv_ctile.hpp: the copy pass of the short rows, tile by tile in LDS (even tiles, then odd tiles); ref2 = what is left
+int32_t ctile_count(int64_t arcsBound, int32_t cnt);
+bool ctile_applicable(int def, int32_t window);
+void launch_copy_tiles(const GraphDev &g, int def, const RangeView &v, int32_t ntiles, int32_t *tb, uint16_t *ref2, int *err, hipStream_t st);
 void launch_hash(int32_t from, int32_t cnt, const int64_t *rowptr, const int32_t *succ, uint32_t *A, uint32_t *B, int32_t *hash, hipStream_t st);
 
 void launch_bparse_big(const GraphDev &g, int def, const BatchView &v, int32_t coopMin, int32_t giantMin, int32_t *biglist, int32_t *giantlist, int32_t giantCap, int32_t *ctl,

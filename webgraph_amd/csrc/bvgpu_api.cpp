@@ -113,8 +113,10 @@ struct bvg_graph {
 	DevBuf lvlist;
 	int parse_lists = 1; // BVGPU_PARSE_LISTS=0: short records parsed in node order instead of by work bin
 	DevBuf plist, pkeys, pkey16;
-	int tile = 1;        // BVGPU_TILE=0: short records through the bin-sorted parse list (k_parse_list) instead of contiguous tiles (k_parse_tile)
+	int tile = 0;        // BVGPU_TILE=1: short records decoded from contiguous tiles of the stream (k_parse_tile) instead of the bin-sorted parse list (k_parse_list)
 	DevBuf tilebounds;
+	int ctile = 1;       // BVGPU_CTILE=0: the whole copy pass by the level-wise kernels (no LDS tiles)
+	DevBuf ctilebounds, ref2;
 	int copy_big = 1;    // BVGPU_COPY_BIG=0: every row is copied by one lane
 	int parse_windows = 1; // BVGPU_PARSE_WINDOWS=0: the parse list is sorted by work bin over the whole range
 	int copy_mid_min = 128; // rows with at least this many successors (and fewer than 1024) are copied by one wave each
@@ -208,6 +210,7 @@ int init_handle(bvg_graph *g) {
 	if (const char *e = getenv("BVGPU_COPY_BIG")) g->copy_big = atoi(e);
 	if (const char *e = getenv("BVGPU_PARSE_WINDOWS")) g->parse_windows = atoi(e);
 	if (const char *e = getenv("BVGPU_TILE")) g->tile = atoi(e);
+	if (const char *e = getenv("BVGPU_CTILE")) g->ctile = atoi(e);
 	if (const char *e = getenv("BVGPU_COPY_MID_MIN")) g->copy_mid_min = std::min(std::max(0, atoi(e)), 1024); // 0: no wave-per-row copy
 	if (const char *e = getenv("BVGPU_OVERLAP")) g->overlap = atoi(e) != 0;
 	if (const char *e = getenv("BVGPU_HALO_MIN")) g->halo_min = (size_t)std::max(4, atoi(e));
@@ -444,7 +447,10 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		// ... then, behind the wave class, the chain depth of every record + per-level lists (node order inside a level) +
 		// copy queues: only the copy pass needs them, and launched first they would sit in front of the wave class while
 		// the one-lane kernel holds every CU
-		if (W > 0) bv::launch_build_lists(gd, v, ~0ull, 1, g->depth.as<int32_t>(), g->key16.as<uint16_t>(), hist, keyBase, cursor, g->lvlist.as<int32_t>(),
+		// The copy pass of the short rows runs tile by tile in LDS once every record is parsed (bv_ctile.hpp); the chain depths
+		// and level lists are then built from what it leaves (ref2), behind it
+		const bool ctiles = g->ctile && g->copy_lists && bv::ctile_applicable(s.def, W);
+		if (W > 0 && !ctiles) bv::launch_build_lists(gd, v, ~0ull, 1, g->depth.as<int32_t>(), g->key16.as<uint16_t>(), hist, keyBase, cursor, g->lvlist.as<int32_t>(),
 		                                  g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->maxdepth, stLists,
 		                                  g->copy_lists ? g->copyq.as<int32_t>() : nullptr, bigCap, g->copyq.as<int32_t>() + bigCap, midCap, g->copy_mid_min, g->copy_big != 0);
 		if (ovl) HIPCHK(g, hipEventRecord(g->evA, g->sideA));
@@ -468,6 +474,17 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			if (coop) HIPCHK(g, hipStreamWaitEvent(g->stream, g->evB, 0));
 		}
 		mark(g, 6);
+		if (ctiles) {
+			const int64_t arcsEst = std::min<int64_t>(arcsBound, estArcs * 2 + 65536);
+			const int32_t nct = bv::ctile_count(arcsEst, v.cnt);
+			if (!g->ctilebounds.need(sizeof(int32_t) * ((size_t)nct + 2)) || !g->ref2.need(sizeof(uint16_t) * (size_t)v.cnt)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
+			HIPCHK(g, hipMemcpyAsync(g->ref2.p, v.ref, sizeof(uint16_t) * (size_t)v.cnt, hipMemcpyDeviceToDevice, g->stream));
+			bv::launch_copy_tiles(gd, s.def, v, nct, g->ctilebounds.as<int32_t>(), g->ref2.as<uint16_t>(), derr, g->stream);
+			v.ref = g->ref2.as<uint16_t>(); // from here on: what is left of the chains
+			bv::launch_build_lists(gd, v, ~0ull, 1, g->depth.as<int32_t>(), g->key16.as<uint16_t>(), hist, keyBase, cursor, g->lvlist.as<int32_t>(),
+			                       g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->maxdepth, g->stream,
+			                       g->copyq.as<int32_t>(), bigCap, g->copyq.as<int32_t>() + bigCap, midCap, g->copy_mid_min, g->copy_big != 0);
+		}
 		if (W > 0) {
 			levels = g->levels_hint;
 			for (int32_t l = 1; l <= levels; l++) {
@@ -742,7 +759,7 @@ extern "C" int bvg_close(bvg_t *g) {
 	if (g->st && g->st->device >= 0) {
 		(void)hipSetDevice(g->st->device);
 		if (g->own) { (void)hipStreamSynchronize(g->own); (void)hipStreamDestroy(g->own); }
-		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist, &g->plist, &g->pkeys, &g->pkey16, &g->copyq, &g->bigtmp, &g->tilebounds }) b->release();
+		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist, &g->plist, &g->pkeys, &g->pkey16, &g->copyq, &g->bigtmp, &g->tilebounds, &g->ctilebounds, &g->ref2 }) b->release();
 		for (DevBuf *b : { &g->hchunk[0], &g->hchunk[1] }) b->release();
 		for (PinBuf *b : { &g->hring[0], &g->hring[1], &g->view_rowptr, &g->view_succ }) b->release();
 		if (g->copyStream) { (void)hipStreamSynchronize(g->copyStream); (void)hipStreamDestroy(g->copyStream); }
