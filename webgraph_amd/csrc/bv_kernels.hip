@@ -1380,7 +1380,7 @@ bool ctile_applicable(int def, int32_t window) { return def != 0 && window > 0 &
 void launch_copy_tiles(const GraphDev &g, int def, const RangeView &v, int32_t ntiles, int32_t *tb, uint16_t *ref2, int *err, hipStream_t st) {
 	if (v.cnt <= 0 || ntiles <= 0) return;
 	hipLaunchKernelGGL(k_ctile_bounds, dim3(nblk((int64_t)ntiles + 1, 256)), dim3(256), 0, st, v.rowstart, v.cnt, ntiles, tb);
-	for (int parity = 0; parity < 2 && !(g.dbg & 1); parity++) {
+	for (int parity = 0; parity < 2; parity++) {
 		const unsigned blocks = (unsigned)((ntiles - parity + 1) / 2);
 		if (!blocks) continue;
 		if (def == 1) hipLaunchKernelGGL(k_copy_tile<1>, dim3(blocks), dim3(CT_T), 0, st, g, v, tb, parity, ref2, err);

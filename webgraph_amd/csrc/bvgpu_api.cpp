@@ -115,7 +115,8 @@ struct bvg_graph {
 	DevBuf plist, pkeys, pkey16;
 	int tile = 0;        // BVGPU_TILE=1: short records decoded from contiguous tiles of the stream (k_parse_tile) instead of the bin-sorted parse list (k_parse_list)
 	DevBuf tilebounds;
-	int ctile = 1;       // BVGPU_CTILE=0: the whole copy pass by the level-wise kernels (no LDS tiles)
+	int ctile = 0;       // BVGPU_CTILE=1: the copy pass of the short rows tile by tile in LDS (bv_ctile.hpp) before the level-wise kernels
+	                     // (bit-exact; measured slower than the level-wise kernels alone on C2, cnr-2000 x30 and the C5 shard: DESIGN.md section 6)
 	DevBuf ctilebounds, ref2;
 	int copy_big = 1;    // BVGPU_COPY_BIG=0: every row is copied by one lane
 	int parse_windows = 1; // BVGPU_PARSE_WINDOWS=0: the parse list is sorted by work bin over the whole range
