@@ -55,6 +55,8 @@ typedef struct bvg_info {
 	uint64_t graph_bytes;      /* size of <basename>.graph */
 	int32_t  device;           /* HIP device ordinal the handle lives on, -1 for a host-only parse */
 	int32_t  offsets_on_device; /* 1: the .offsets stream was decoded by the GPU kernels, 0: by the host decoder */
+	int32_t  shard_from, shard_to; /* nodes this handle decodes: [0, nodes) for bvg_open, one slice for bvg_open_shard */
+	int32_t  staged_from;          /* first node whose record is staged (shard_from minus the room kept for referents before it) */
 } bvg_info_t;
 
 /* flags for the *_range / *_batch calls */
@@ -72,6 +74,14 @@ enum {
 /* ImmutableGraph.load(basename) -> BVGraph.load -> loadInternal (BVG:1380, :1516-1609): parse .properties,
  * read .graph and .offsets, stage the bit stream and the decoded int64 offset table in HBM on `device`. */
 int bvg_open(const char *basename, int device, bvg_t **out);
+
+/* One GPU's share of a graph that is scanned by `parts` GPUs: same files, same bounds as
+ * bvg_shard_bounds(parts) -- bounds[k] = min{x : off[x] >= k*off[n]/parts} -- but only the slice of the bit stream and of
+ * the offset table that nodes [bounds[part], bounds[part+1]) need is staged in HBM (plus a few thousand nodes before it
+ * for the referents of its first rows).  The handle decodes ranges inside its slice (bvg_decode_range, bvg_decode_range_view,
+ * bvg_scan_checksum, bvg_outdegrees; node ids stay global); random access needs the whole graph (BVG_EUNSUPPORTED here).
+ * There is no exchange step between the parts: a host-side reduction of (arcs, hash) pairs is all a scan needs. */
+int bvg_open_shard(const char *basename, int device, int part, int parts, bvg_t **out);
 
 /* BVGraph.copy() (BVG:552-577): flyweight sharing the staged graph; own stream and scratch. */
 int bvg_clone(const bvg_t *g, bvg_t **out);

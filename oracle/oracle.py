@@ -186,12 +186,12 @@ class OracleGraph:
             raise OracleError(int(d))
         return out[:d].copy()
 
-    def scan(self, lo=0, hi=None, want_succ=True, want_hash=False, cap=None):
-        """nodeIterator(lo).copy(hi) drained: returns (rowptr[hi-lo+1], succ, arcs[, hash])."""
+    def scan(self, lo=0, hi=None, want_succ=True, want_hash=False, cap=None, h0=-1):
+        """nodeIterator(lo).copy(hi) drained: returns (rowptr[hi-lo+1], succ, arcs[, hash]); the hash continues from h0."""
         hi = self.n if hi is None else hi
         rowptr = np.empty(max(hi - lo, 0) + 1, dtype=np.int64)
         arcs = C.c_uint64(0)
-        h = C.c_int32(-1)
+        h = C.c_int32(h0)
         if want_succ:
             if cap is None:
                 # first a counting pass
@@ -261,6 +261,30 @@ class OracleGraph:
             base += arcs
         succ = np.concatenate([p[1] for p in parts]) if want_succ else None
         return rowptr, succ, base
+
+    def hashcode_mt(self, threads=None):
+        """ImmutableGraph.hashCode() on all host cores: every thread scans a contiguous node range twice, from h = 0 and from
+        h = 1 -- the range acts on the running hash as h -> A*h + B over Z/2^32 (a chain of h = 31*h + v,
+        ImmutableGraph.java:757-770), so B = f(0), A = f(1) - f(0) -- and the maps are folded in node order from -1."""
+        import concurrent.futures as cf
+        T = max(1, min(threads or (os.cpu_count() or 1), 256, max(self.n, 1)))
+        off = self.offsets
+        cuts = [0]
+        for k in range(1, T):
+            cuts.append(max(cuts[-1], min(self.n, int(np.searchsorted(off[:self.n], int(off[self.n]) * k // T, side="left")))))
+        cuts.append(self.n)
+        rngs = [(cuts[k], cuts[k + 1]) for k in range(T) if cuts[k + 1] > cuts[k]]
+
+        def one(ab):
+            f0 = self.scan(ab[0], ab[1], want_succ=False, want_hash=True, h0=0)[3]
+            f1 = self.scan(ab[0], ab[1], want_succ=False, want_hash=True, h0=1)[3]
+            return (f1 - f0) & 0xFFFFFFFF, f0 & 0xFFFFFFFF
+        with cf.ThreadPoolExecutor(max_workers=max(len(rngs), 1)) as ex:
+            maps = list(ex.map(one, rngs))
+        h = 0xFFFFFFFF
+        for a, b in maps:
+            h = (a * h + b) & 0xFFFFFFFF
+        return h - (1 << 32) if h & 0x80000000 else h
 
     def hashcode(self):
         """ImmutableGraph.hashCode() (ImmutableGraph.java:757-770)."""

@@ -1,6 +1,4 @@
 mkdir -p gpurun_out
-for w in c2 cnr30; do
-  timeout 200 python scripts/ab_time.py $w
-done 2>&1 | grep -v amdgpu.ids | tee gpurun_out/ab4.log
-LINES_SHOWN=8 timeout 200 bash scripts/prof2.sh cnr_ct cnr30
-LINES_SHOWN=8 timeout 200 bash scripts/prof2.sh c2_ct c2
+timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 > gpurun_out/t5.log 2>&1; tail -3 gpurun_out/t5.log
+timeout 600 python bench.py > gpurun_out/bench5.json 2> gpurun_out/bench5.err; tail -c 600 gpurun_out/bench5.err; head -c 3000 gpurun_out/bench5.json
+timeout 300 python bench.py --mode random --steps 5 2>/dev/null | head -c 1200

@@ -136,6 +136,25 @@ def test_c5_shard_deep_chains():
         tot += a
     assert tot == arcs and P.fold_affine(pairs) == whole
     g.close()
+    # the same slices through handles that stage nothing but their slice (bvg_open_shard: what bench.py --gpus N runs)
+    pairs2, tot2 = [], 0
+    for k in range(8):
+        gs = BVGraph.load_shard(base, k, 8)
+        lo, hi = int(gs.info.shard_from), int(gs.info.shard_to)
+        assert (lo, hi) == (int(b[k]), int(b[k + 1])) and gs.info.staged_from <= lo
+        rp, sc, a = _device_scan(gs, lo, hi)
+        assert np.array_equal(rp.cpu().numpy(), orp[lo:hi + 1] - orp[lo]) and np.array_equal(sc[:a].cpu().numpy(), osc[orp[lo]:orp[hi]])
+        c0, ca = gs.scan_checksum(lo, hi, 0)
+        c1, _ = gs.scan_checksum(lo, hi, 1)
+        pairs2.append(P.affine_from_two_hashes(c0, c1))
+        tot2 += ca
+        if k > 0:
+            with pytest.raises(ValueError):
+                gs.decode_range(lo - 1, hi)          # outside the slice
+        with pytest.raises(NotImplementedError):
+            gs.successors_batch(np.array([lo], dtype=np.int32))
+        gs.close()
+    assert tot2 == arcs and P.fold_affine(pairs2) == whole
 
 
 @pytest.mark.timeout(900)

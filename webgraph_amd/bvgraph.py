@@ -23,7 +23,8 @@ class BvgInfo(C.Structure):
                 ("min_interval_length", C.c_int32), ("zeta_k", C.c_int32), ("flags", C.c_uint32),
                 ("outdegree_coding", C.c_int32), ("block_coding", C.c_int32), ("residual_coding", C.c_int32),
                 ("reference_coding", C.c_int32), ("block_count_coding", C.c_int32), ("offset_coding", C.c_int32),
-                ("graph_bytes", C.c_uint64), ("device", C.c_int32), ("offsets_on_device", C.c_int32)]
+                ("graph_bytes", C.c_uint64), ("device", C.c_int32), ("offsets_on_device", C.c_int32),
+                ("shard_from", C.c_int32), ("shard_to", C.c_int32), ("staged_from", C.c_int32)]
 
 
 class BvgLabelsInfo(C.Structure):
@@ -31,7 +32,7 @@ class BvgLabelsInfo(C.Structure):
                 ("labels_bits", C.c_uint64), ("underlying", C.c_char * 1024), ("key", C.c_char * 128)]
 
 
-EXPORTS = ["bvg_open", "bvg_clone", "bvg_close", "bvg_info", "bvg_last_error", "bvg_set_stream", "bvg_sync",
+EXPORTS = ["bvg_open", "bvg_open_shard", "bvg_clone", "bvg_close", "bvg_info", "bvg_last_error", "bvg_set_stream", "bvg_sync",
            "bvg_outdegrees", "bvg_decode_range", "bvg_decode_range_view", "bvg_host_alloc", "bvg_host_free", "bvg_scan_checksum", "bvg_successors_batch", "bvg_csr_hashcode", "bvg_shard_bounds",
            "bvg_parse_properties", "bvg_flags_from_string", "bvg_decode_offsets_host", "bvg_decode_offsets_device", "bvg_labels_open", "bvg_labels_close", "bvg_labels_info",
            "bvg_labels_last_error", "bvg_labels_parse_properties", "bvg_labels_decode_range", "bvg_set_profile", "bvg_get_profile", "bvg_debug_stats"]
@@ -54,6 +55,7 @@ def lib():
         L = C.CDLL(_LIBPATH)
         vp, i32, i64, u64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_size_t
         L.bvg_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+        L.bvg_open_shard.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
         L.bvg_clone.argtypes = [vp, C.POINTER(vp)]
         L.bvg_close.argtypes = [vp]
         L.bvg_info.argtypes = [vp, C.POINTER(BvgInfo)]
@@ -269,6 +271,19 @@ class BVGraph:
 
     loadMapped = load
     loadOffline = load
+
+    @classmethod
+    def load_shard(cls, basename, part, parts, device=0):
+        """One GPU's share of a graph scanned by `parts` GPUs (bvg_open_shard): only the slice of the bit stream and of the
+        offset table that nodes [shard_bounds(parts)[part], ...[part+1]) need is staged; info.shard_from / shard_to say which."""
+        h = C.c_void_p()
+        rc = lib().bvg_open_shard(os.fsencode(basename), device, part, parts, C.byref(h))
+        if rc:
+            msg = lib().bvg_last_error(h).decode("latin-1") if h else ""
+            if h:
+                lib().bvg_close(h)
+            _raise(rc, msg)
+        return cls(h, basename)
 
     def close(self):
         if self._h:

@@ -56,17 +56,20 @@ struct PinBuf { // pinned host memory (grows, never shrinks; contents are NOT pr
 struct Staged {
 	int device = -1;
 	bvg_info_t info{};
-	uint32_t *d_bits = nullptr;
+	uint32_t *d_bits = nullptr;     // word i of the .graph image is d_bits[i]; a shard stages words [word_lo, nwords) only: d_bits = allocation - word_lo
+	uint32_t *d_bits_alloc = nullptr;
 	uint64_t nwords = 0;
-	int64_t *d_offsets = nullptr;
+	int64_t *d_offsets = nullptr;   // likewise: d_offsets[x] for x in [stage_lo, node_hi]
+	int64_t *d_offsets_alloc = nullptr;
+	int32_t node_lo = 0, node_hi = 0, stage_lo = 0; // the nodes this handle decodes / the first node staged
 	std::vector<int64_t> h_offsets; // host copy: shard bounds and halo sizing
 	int64_t arcs_sizing = 0;        // max(arcs property, sum of the outdegrees in the stream): what scratch is sized by
 	int def = 0;                    // kernel variant: 1 default codings with zeta_3, 2 default codings with another zeta_k, 0 generic
 	std::string basename;
 	~Staged() {
 		if (device >= 0) (void)hipSetDevice(device);
-		if (d_bits) (void)hipFree(d_bits);
-		if (d_offsets) (void)hipFree(d_offsets);
+		if (d_bits_alloc) (void)hipFree(d_bits_alloc);
+		if (d_offsets_alloc) (void)hipFree(d_offsets_alloc);
 	}
 };
 
@@ -540,6 +543,7 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 	HIPCHK(g, hipSetDevice(s.device));
 	if (g->pend.active) { int rc = finish_pending(g, nullptr); if (rc) return rc; }
 	const int32_t W = s.info.window_size;
+	if (from < s.node_lo || to > s.node_hi) return fail(g, BVG_EARG, "node range outside the slice this handle stages (bvg_open_shard)");
 	{ int rc = fork_from_user(g); if (rc) return rc; }
 	HIPCHK(g, hipMemsetAsync(g->small.p, 0, sizeof(Small), g->stream));
 	if (to == from) {
@@ -554,7 +558,7 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 	int32_t nh = 0;
 	if (succ_dev && from > 0 && W > 0) {
 		const int64_t mr = s.info.max_ref_count < 1 ? 1 : std::min(s.info.max_ref_count, 64);
-		nh = (int32_t)std::min<int64_t>(from, (int64_t)W * mr);
+		nh = (int32_t)std::min<int64_t>(from - s.stage_lo, (int64_t)W * mr);
 	}
 	bv::RangeView v;
 	// A sub-range needs a halo whose depth and size are only known on the device.  The common case (chains no deeper
@@ -577,8 +581,8 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 		rc = fetch_small(g);
 		if (rc) return rc;
 		if (g->h_small->err & bv::E_ESCAPED) {
-			if (nh == from) return fail(g, BVG_EFORMAT, "reference chain runs before node 0");
-			nh = (int32_t)std::min<int64_t>(from, (int64_t)nh * 8);
+			if (nh == from - s.stage_lo) return fail(g, BVG_EFORMAT, s.stage_lo ? "reference chain runs before the nodes staged for this slice" : "reference chain runs before node 0");
+			nh = (int32_t)std::min<int64_t>(from - s.stage_lo, (int64_t)nh * 8);
 			HIPCHK(g, hipMemsetAsync(g->small.p, 0, sizeof(Small), g->stream));
 			continue;
 		}
@@ -656,7 +660,13 @@ extern "C" int bvg_decode_offsets_device(int device, const uint8_t *offsets_file
 	return rc;
 }
 
-extern "C" int bvg_open(const char *basename, int device, bvg_t **out) {
+static int open_impl(const char *basename, int device, int part, int parts, bvg_t **out);
+extern "C" int bvg_open(const char *basename, int device, bvg_t **out) { return open_impl(basename, device, 0, 1, out); }
+extern "C" int bvg_open_shard(const char *basename, int device, int part, int parts, bvg_t **out) {
+	if (parts < 1 || part < 0 || part >= parts) { if (out) *out = nullptr; return BVG_EARG; }
+	return open_impl(basename, device, part, parts, out);
+}
+static int open_impl(const char *basename, int device, int part, int parts, bvg_t **out) {
 	if (!basename || !out) return BVG_EARG;
 	*out = nullptr;
 	auto *g = new bvg_graph();
@@ -691,12 +701,8 @@ extern "C" int bvg_open(const char *basename, int device, bvg_t **out) {
 	st->device = device;
 	st->info.device = device;
 	HIPCHK(g, hipSetDevice(device));
-	st->nwords = (graph.size() + 3) / 4;
-	const size_t padded = (size_t)(st->nwords + 8) * 4;
-	HIPCHK(g, hipMalloc((void **)&st->d_bits, padded));
-	HIPCHK(g, hipMemset(st->d_bits, 0, padded));
-	if (!graph.empty()) HIPCHK(g, hipMemcpy(st->d_bits, graph.data(), graph.size(), hipMemcpyHostToDevice));
-	HIPCHK(g, hipMalloc((void **)&st->d_offsets, sizeof(int64_t) * st->h_offsets.size()));
+	HIPCHK(g, hipMalloc((void **)&st->d_offsets_alloc, sizeof(int64_t) * st->h_offsets.size()));
+	st->d_offsets = st->d_offsets_alloc;
 
 	// offsets: gamma-coded gaps (the default) are decoded on the device (bv_offsets.hip) and copied back for shard
 	// planning; delta-coded ones, BVGPU_OFFSETS=host, or a stream the device decoder rejects take the host decoder
@@ -723,11 +729,41 @@ extern "C" int bvg_open(const char *basename, int device, bvg_t **out) {
 	st->info.offsets_on_device = onDevice ? 1 : 0;
 	if ((uint64_t)st->h_offsets.back() > (uint64_t)graph.size() * 8) return fail(g, BVG_EIO, "offsets run past the end of the .graph file");
 	for (size_t i = 1; i < st->h_offsets.size(); i++) if (st->h_offsets[i] < st->h_offsets[i - 1]) return fail(g, BVG_EIO, "offsets are not monotone");
+	// ---- what this handle stages: the whole graph, or one bits-balanced slice of it
+	st->node_lo = 0; st->node_hi = in.nodes; st->stage_lo = 0;
+	if (parts > 1) {
+		const std::vector<int64_t> &off = st->h_offsets;
+		auto bound = [&](int k) { return k >= parts ? in.nodes : (int32_t)(std::lower_bound(off.begin(), off.begin() + in.nodes, (int64_t)((__int128)off.back() * k / parts)) - off.begin()); };
+		st->node_lo = part == 0 ? 0 : bound(part);
+		st->node_hi = std::max(st->node_lo, bound(part + 1));
+		// room for the referents of the slice's first rows: chains of any realistic depth (window x 64 levels, at least 4096 nodes)
+		st->stage_lo = (int32_t)std::max<int64_t>(0, (int64_t)st->node_lo - std::max<int64_t>(4096, (int64_t)in.window_size * 64));
+		// the offsets of [stage_lo, node_hi] only
+		int64_t *slice = nullptr;
+		const size_t cntOff = (size_t)(st->node_hi - st->stage_lo) + 1;
+		HIPCHK(g, hipMalloc((void **)&slice, sizeof(int64_t) * cntOff));
+		HIPCHK(g, hipMemcpy(slice, st->d_offsets_alloc + st->stage_lo, sizeof(int64_t) * cntOff, hipMemcpyDeviceToDevice));
+		(void)hipFree(st->d_offsets_alloc);
+		st->d_offsets_alloc = slice;
+		st->d_offsets = (int64_t *)((uintptr_t)slice - sizeof(int64_t) * (size_t)st->stage_lo);
+	}
+	{ // the bit stream: words [word_lo, nwords) plus >= 8 zero words
+		const uint64_t allWords = (graph.size() + 3) / 4;
+		const uint64_t wordLo = parts > 1 ? ((uint64_t)st->h_offsets[st->stage_lo] >> 5) & ~(uint64_t)3 : 0;
+		st->nwords = parts > 1 ? std::min<uint64_t>(allWords, (((uint64_t)st->h_offsets[st->node_hi] + 31) >> 5)) : allWords;
+		const size_t words = (size_t)(st->nwords - wordLo);
+		HIPCHK(g, hipMalloc((void **)&st->d_bits_alloc, (words + 8) * 4));
+		HIPCHK(g, hipMemset(st->d_bits_alloc, 0, (words + 8) * 4));
+		const size_t byteLo = (size_t)wordLo * 4, byteHi = std::min<size_t>(graph.size(), (size_t)st->nwords * 4);
+		if (byteHi > byteLo) HIPCHK(g, hipMemcpy(st->d_bits_alloc, graph.data() + byteLo, byteHi - byteLo, hipMemcpyHostToDevice));
+		st->d_bits = (uint32_t *)((uintptr_t)st->d_bits_alloc - (size_t)wordLo * 4);
+	}
+	st->info.shard_from = st->node_lo; st->info.shard_to = st->node_hi; st->info.staged_from = st->stage_lo;
 	// Scratch (interval arena, copy queues, giant list) is sized by the number of arcs: by what the stream holds, not by
 	// what .properties claims -- one pass over the record headers at load time
-	st->arcs_sizing = std::max<int64_t>(in.arcs, 1);
-	if (in.nodes > 0) {
-		const int32_t n = in.nodes;
+	st->arcs_sizing = parts > 1 ? 1 : std::max<int64_t>(in.arcs, 1);
+	if (st->node_hi > st->stage_lo) {
+		const int32_t n = st->node_hi - st->stage_lo;
 		void *p_outd = nullptr, *p_ref = nullptr, *p_rs = nullptr, *p_sums = nullptr, *p_err = nullptr;
 		const bool ok = hipMalloc(&p_outd, sizeof(int32_t) * (size_t)n) == hipSuccess && hipMalloc(&p_ref, sizeof(uint16_t) * (size_t)n) == hipSuccess &&
 		                hipMalloc(&p_rs, sizeof(int64_t) * ((size_t)n + 1)) == hipSuccess && hipMalloc(&p_sums, sizeof(int64_t) * (size_t)bv::scan_num_sums(n)) == hipSuccess &&
@@ -735,7 +771,7 @@ extern "C" int bvg_open(const char *basename, int device, bvg_t **out) {
 		int64_t total = 0;
 		hipError_t e = ok ? hipMemset(p_err, 0, sizeof(int)) : hipErrorOutOfMemory;
 		if (e == hipSuccess) {
-			bv::launch_headers(graph_dev0(*st), st->def, 0, n, (int32_t *)p_outd, (uint16_t *)p_ref, (int *)p_err, nullptr);
+			bv::launch_headers(graph_dev0(*st), st->def, st->stage_lo, n, (int32_t *)p_outd, (uint16_t *)p_ref, (int *)p_err, nullptr);
 			bv::launch_scan((const int32_t *)p_outd, n, (int64_t *)p_rs, (int64_t *)p_sums, nullptr);
 			e = hipMemcpy(&total, (int64_t *)p_rs + n, sizeof(int64_t), hipMemcpyDeviceToHost);
 		}
@@ -829,7 +865,7 @@ extern "C" int bvg_sync(bvg_t *g, uint64_t *arcs_out) {
 extern "C" int bvg_outdegrees(bvg_t *g, int32_t from, int32_t to, int32_t *out, int flags) {
 	if (!g || !g->st) return BVG_EARG;
 	const Staged &s = *g->st;
-	if (from < 0 || to > s.info.nodes || from > to || (!out && to > from)) return fail(g, BVG_EARG, "node range out of bounds"); // BVG:860
+	if (from < s.stage_lo || to > s.node_hi || from > to || (!out && to > from)) return fail(g, BVG_EARG, "node range out of bounds"); // BVG:860
 	if (to == from) return BVG_OK;
 	HIPCHK(g, hipSetDevice(s.device));
 	if (g->pend.active) { int rc = finish_pending(g, nullptr); if (rc) return rc; }
@@ -1036,6 +1072,7 @@ extern "C" int bvg_successors_batch(bvg_t *g, const int32_t *nodes, size_t q, in
 	if (!g || !g->st) return BVG_EARG;
 	if (!rowptr || (!nodes && q)) return fail(g, BVG_EARG, "null argument");
 	const Staged &s = *g->st;
+	if (s.node_lo != 0 || s.node_hi != s.info.nodes) return fail(g, BVG_EUNSUPPORTED, "random access needs the whole graph: open it with bvg_open");
 	HIPCHK(g, hipSetDevice(s.device));
 	if (g->pend.active) { int rc = finish_pending(g, nullptr); if (rc) return rc; }
 	{ int rc = fork_from_user(g); if (rc) return rc; }
