@@ -27,6 +27,7 @@
 #include "bv_lanewin.hpp"
 #include "bv_lane.hpp"
 #include "bv_tile.hpp"
+#include "bv_tile2.hpp"
 #include "bv_ctile.hpp"
 
 #include <algorithm>
@@ -1369,10 +1370,16 @@ int32_t tile_count(int64_t bitSpan, int32_t cnt) { return (int32_t)std::min<int6
 void launch_tile_bounds(const GraphDev &g, int32_t lo, int32_t cnt, int32_t ntiles, int32_t *tb, hipStream_t st) {
 	hipLaunchKernelGGL(k_tile_bounds, dim3(nblk((int64_t)ntiles + 1, 256)), dim3(256), 0, st, g.offsets, lo, cnt, ntiles, tb);
 }
-void launch_parse_tile(const GraphDev &g, int def, const RangeView &v, const int32_t *tb, int32_t ntiles, int *err, hipStream_t st) {
+void launch_parse_tile(const GraphDev &g, int def, const RangeView &v, const int32_t *tb, int32_t ntiles, int variant, int *err, hipStream_t st) {
 	if (v.cnt <= 0 || ntiles <= 0) return;
-	if (def == 1) hipLaunchKernelGGL(k_parse_tile<1>, dim3(ntiles), dim3(TILE_T), 0, st, g, v, tb, err);
-	else hipLaunchKernelGGL(k_parse_tile<2>, dim3(ntiles), dim3(TILE_T), 0, st, g, v, tb, err);
+	if (variant == 1) { // one lane per record (bv_tile.hpp)
+		if (def == 1) hipLaunchKernelGGL(k_parse_tile<1>, dim3(ntiles), dim3(TILE_T), 0, st, g, v, tb, err);
+		else hipLaunchKernelGGL(k_parse_tile<2>, dim3(ntiles), dim3(TILE_T), 0, st, g, v, tb, err);
+		return;
+	}
+	// long residual sections segment by segment (bv_tile2.hpp)
+	if (def == 1) hipLaunchKernelGGL(k_parse_tile2<1>, dim3(ntiles), dim3(T2_T), 0, st, g, v, tb, err);
+	else hipLaunchKernelGGL(k_parse_tile2<2>, dim3(ntiles), dim3(T2_T), 0, st, g, v, tb, err);
 }
 
 int32_t ctile_count(int64_t arcsBound, int32_t cnt) { return (int32_t)std::min<int64_t>((arcsBound + (int64_t)CT_NODE_W * cnt) / CT_SPAN + 1, 0x3ffffff0); }

@@ -81,7 +81,7 @@ void launch_parse_giants(const GraphDev &g, int def, const RangeView &v, const i
 // bv_tile.hpp: short records decoded tile by tile from one LDS image of a contiguous slice of the stream
 int32_t tile_count(int64_t bitSpan, int32_t cnt);
 void launch_tile_bounds(const GraphDev &g, int32_t lo, int32_t cnt, int32_t ntiles, int32_t *tb, hipStream_t st);
-void launch_parse_tile(const GraphDev &g, int def, const RangeView &v, const int32_t *tb, int32_t ntiles, int *err, hipStream_t st);
+void launch_parse_tile(const GraphDev &g, int def, const RangeView &v, const int32_t *tb, int32_t ntiles, int variant, int *err, hipStream_t st);
 // bv_ctile.hpp: the copy pass of the short rows, tile by tile in LDS (even tiles, then odd tiles); ref2 = what is left
 int32_t ctile_count(int64_t arcsBound, int32_t cnt);
 bool ctile_applicable(int def, int32_t window);

@@ -72,6 +72,48 @@ struct TCur {
 	}
 };
 
+// ---- the straight-line reader ------------------------------------------------------------------------------------------
+// TCur::code above checks every word against the window and falls through three decoder tiers: ~40 branches per merged
+// successor, and on gfx950 a wave pays for every one of them (measured: ~2 000 cycles per code).  TFast::code is for code
+// that KNOWS its words are staged (the caller checks the record once): two LDS words, one branch-free 32-bit decode of
+// the short codes that make up almost all of a record (gamma < 2^16, zeta_3 < 2^21, unary < 32), ONE branch to an
+// out-of-line function for everything else.  q = bit offset from the first staged word.
+struct SlowRel { uint64_t v; uint32_t q; int err; };
+template <int KIND, int ZK>
+__device__ __attribute__((noinline)) SlowRel tfast_slow(const uint32_t *gbits, uint64_t gnw, uint64_t w0, uint32_t q, uint32_t zk) {
+	const uint64_t base = w0 << 5;
+	const SlowAbs sa = (KIND == 0 && ZK != 3) ? lane_zeta_slow(gbits, gnw, base + q, (int)zk) : lane_code_slow<KIND>(gbits, gnw, base + q);
+	return SlowRel{ sa.v, (uint32_t)min<uint64_t>(sa.pos - base, 0x7fffff00ull), sa.err };
+}
+struct TFast {
+	uint32_t q;
+	// KIND 0: zeta_k (ZK = 3 folded in, 0: zk at run time), 1: gamma, 2: unary
+	template <int KIND, int ZK> __device__ __forceinline__ uint64_t code(const TWin &t, uint32_t zk, int &err) {
+		const uint32_t j = q >> 5, sh = q & 31u;
+		const uint32_t a = t.win[j], b = t.win[j + 1];
+		const uint32_t W = (uint32_t)(((((uint64_t)a << 32) | b) << sh) >> 32);
+		const uint32_t h = (uint32_t)__clz((int)W); // 32 for W == 0
+		uint32_t v, len;
+		bool ok;
+		if (KIND == 2) { ok = W != 0; v = h; len = h + 1; }
+		else if (KIND == 1) { ok = h < 16; len = 2 * h + 1; v = (W >> ((31u - 2 * h) & 31u)) - 1; }
+		else {
+			const uint32_t k = ZK == 3 ? 3u : zk;
+			const uint32_t nb = k * h + k - 1;                    // payload bits of the short codeword
+			ok = ZK == 3 ? h < 7 : (h + 2 + nb <= 32u && nb != 0); // (zeta_1 with h = 0 has no payload: left to the slow path)
+			const uint32_t mm = (W << ((h + 1) & 31u)) >> ((31u - nb) & 31u); // the nb payload bits plus the extra bit of the long codeword
+			const uint32_t m = mm >> 1, left = 1u << ((k * h) & 31u);
+			const bool lng = m >= left;
+			v = lng ? mm - 1 : m + left - 1;
+			len = h + 1 + nb + (lng ? 1u : 0u);
+		}
+		if (__builtin_expect(ok, 1)) { q += len; return v; }
+		const SlowRel sr = tfast_slow<KIND, ZK>(t.gbits, t.gnw, t.w0, q, zk);
+		q = sr.q; err |= sr.err;
+		return sr.v;
+	}
+};
+
 // Same contract as parse_node_lw, reading the record from the tile's window.
 template <int ZK>
 __device__ __forceinline__ void parse_node_tile(const GraphDev &g, const TWin &tw, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row, int *__restrict__ err) {
