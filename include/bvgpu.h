@@ -160,6 +160,33 @@ void bvg_host_free(void *p);
 int bvg_scan_checksum(bvg_t *g, int32_t from, int32_t to, int32_t *hash_io, uint64_t *arcs_out);
 
 /*
+ * Two more consumers that never hand the caller a successor array; both work a chunk of the
+ * graph at a time on rows decoded into library scratch.
+ *
+ * bvg_scan_stats: the scan of Stats.run (src/it/unimi/dsi/webgraph/Stats.java:111-160) over nodes [from, to).  tot_gap and
+ * tot_loc are BigIntegers in the reference; 64 bits hold them for every graph whose ids fit an int.  indegree_dev: NULL, or a
+ * DEVICE array of `nodes` int32 that is incremented once per arc (Stats.java:130; zero it first).
+ */
+typedef struct bvg_scan_stats {
+	uint64_t nodes, arcs, loops, dangling, terminal, num_gaps;
+	uint64_t tot_gap;   /* sum over nodes with d > 1 of (last - first) + int2nat(first - node)   Stats.java:119-122 */
+	uint64_t tot_loc;   /* sum over arcs of |successor - node|                                   :125 */
+	int32_t  min_outdegree, max_outdegree, min_outdegree_node, max_outdegree_node; /* :140-148 (first node in node order) */
+	uint64_t successor_delta_stats[32]; /* arcs with successor != node, by mostSignificantBit(|node - successor|)   :127 */
+} bvg_scan_stats_t;
+int bvg_scan_stats(bvg_t *g, int32_t from, int32_t to, bvg_scan_stats_t *out, int32_t *indegree_dev);
+
+/*
+ * One round of ParallelBreadthFirstVisit (src/it/unimi/dsi/webgraph/algo/ParallelBreadthFirstVisit.java:146-170): for
+ * every node x of the frontier and every successor s of x, marker.compareAndSet(s, -1, parent ? x : round); the successors
+ * that were still unmarked form the next frontier (in no particular order, as in the reference, where it depends on the
+ * threads).  All pointers are DEVICE pointers: frontier[q], marker[nodes] (-1 = not enqueued yet), out[out_cap]; *out_count
+ * (host) receives the size of the next frontier -- if it exceeds out_cap only out_cap entries were written (BVG_ECAP).
+ */
+int bvg_bfs_expand(bvg_t *g, const int32_t *frontier_dev, size_t q, int32_t *marker_dev, int32_t round, int parent,
+                   int32_t *out_dev, size_t out_cap, uint64_t *out_count);
+
+/*
  * Random access: concatenation of successorArray(nodes[i]) (BVG:897-904, ImmutableGraph.java:329-333),
  * reference chains resolved on the device.  rowptr has q+1 entries; ids may repeat and come in any order; an id
  * outside [0, n) is BVG_EARG (BVG:900).  succ == NULL: count-only; BVG_ECAP as above, checked before any decode.

@@ -1,0 +1,23 @@
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["BVGPU_STATS"] = "1"
+os.environ["BVGPU_DBG"] = "16"
+import torch
+from scripts.ab_time import workload
+from webgraph_amd.bvgraph import BVGraph
+base = workload(sys.argv[1] if len(sys.argv) > 1 else "c5")
+g = BVGraph.load(base)
+n, m = g.numNodes(), g.numArcs()
+dev = torch.device("cuda", 0)
+rowptr = torch.empty(n + 1, dtype=torch.int64, device=dev)
+succ = torch.empty(max(m, 1), dtype=torch.int32, device=dev)
+g.decode_range_device(0, n, rowptr.data_ptr(), succ.data_ptr(), succ.numel())
+g.debug_stats(reset=True)
+g.decode_range_device(0, n, rowptr.data_ptr(), succ.data_ptr(), succ.numel())
+st = g.debug_stats()
+print("k_copy_big rows %d, kept blocks %d (max %d), ids %d" % (st[8], st[9], st[15], st[4]))
+names = ["walk", "gather", "rank", "move", "scatter"]
+tot = sum(int(st[24 + i]) for i in range(5))
+for i, nm in enumerate(names):
+    print("  %-8s %14d ticks %5.1f%%" % (nm, st[24 + i], 100.0 * st[24 + i] / max(tot, 1)))

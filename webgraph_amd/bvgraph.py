@@ -27,13 +27,19 @@ class BvgInfo(C.Structure):
                 ("shard_from", C.c_int32), ("shard_to", C.c_int32), ("staged_from", C.c_int32)]
 
 
+class BvgScanStats(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("nodes", "arcs", "loops", "dangling", "terminal", "num_gaps", "tot_gap", "tot_loc")] + [
+        ("min_outdegree", C.c_int32), ("max_outdegree", C.c_int32), ("min_outdegree_node", C.c_int32), ("max_outdegree_node", C.c_int32),
+        ("successor_delta_stats", C.c_uint64 * 32)]
+
+
 class BvgLabelsInfo(C.Structure):
     _fields_ = [("kind", C.c_int32), ("width", C.c_int32), ("nodes", C.c_int32), ("device", C.c_int32), ("labels_bytes", C.c_uint64),
                 ("labels_bits", C.c_uint64), ("underlying", C.c_char * 1024), ("key", C.c_char * 128)]
 
 
 EXPORTS = ["bvg_open", "bvg_open_shard", "bvg_clone", "bvg_close", "bvg_info", "bvg_last_error", "bvg_set_stream", "bvg_sync",
-           "bvg_outdegrees", "bvg_decode_range", "bvg_decode_range_view", "bvg_host_alloc", "bvg_host_free", "bvg_scan_checksum", "bvg_successors_batch", "bvg_csr_hashcode", "bvg_shard_bounds",
+           "bvg_outdegrees", "bvg_decode_range", "bvg_decode_range_view", "bvg_host_alloc", "bvg_host_free", "bvg_scan_checksum", "bvg_scan_stats", "bvg_bfs_expand", "bvg_successors_batch", "bvg_csr_hashcode", "bvg_shard_bounds",
            "bvg_parse_properties", "bvg_flags_from_string", "bvg_decode_offsets_host", "bvg_decode_offsets_device", "bvg_labels_open", "bvg_labels_close", "bvg_labels_info",
            "bvg_labels_last_error", "bvg_labels_parse_properties", "bvg_labels_decode_range", "bvg_set_profile", "bvg_get_profile", "bvg_debug_stats"]
 
@@ -70,6 +76,8 @@ def lib():
         L.bvg_host_free.argtypes = [vp]
         L.bvg_host_free.restype = None
         L.bvg_scan_checksum.argtypes = [vp, i32, i32, C.POINTER(i32), C.POINTER(u64)]
+        L.bvg_scan_stats.argtypes = [vp, i32, i32, C.POINTER(BvgScanStats), vp]
+        L.bvg_bfs_expand.argtypes = [vp, vp, sz, vp, i32, C.c_int, vp, sz, C.POINTER(u64)]
         L.bvg_successors_batch.argtypes = [vp, vp, sz, vp, vp, sz, C.POINTER(u64), C.c_int]
         L.bvg_csr_hashcode.argtypes = [vp, i32, i32, vp, vp, C.POINTER(i32)]
         L.bvg_shard_bounds.argtypes = [vp, C.c_int, vp]
@@ -404,6 +412,41 @@ class BVGraph:
         out = np.zeros(32, dtype=np.uint64)
         self._check(lib().bvg_debug_stats(self._h, out.ctypes.data, 1 if reset else 0))
         return out
+
+    def scan_stats(self, lo=0, hi=None, indegree_ptr=None):
+        """The scan of Stats.run (Stats.java:111-160) over nodes [lo, hi) on the device; indegree_ptr: device int32[n] or None."""
+        hi = self.numNodes() if hi is None else hi
+        st = BvgScanStats()
+        self._check(lib().bvg_scan_stats(self._h, lo, hi, C.byref(st), indegree_ptr))
+        d = {k: getattr(st, k) for k, _ in BvgScanStats._fields_ if k != "successor_delta_stats"}
+        d["successor_delta_stats"] = list(st.successor_delta_stats)
+        return d
+
+    def bfs_expand(self, frontier_ptr, q, marker_ptr, round_, parent, out_ptr, out_cap):
+        """One round of ParallelBreadthFirstVisit (device pointers); returns the size of the next frontier."""
+        cnt = C.c_uint64(0)
+        self._check(lib().bvg_bfs_expand(self._h, frontier_ptr, q, marker_ptr, round_, 1 if parent else 0, out_ptr, out_cap, C.byref(cnt)))
+        return cnt.value
+
+    def bfs(self, start, parent=False, round_=0, marker=None):
+        """ParallelBreadthFirstVisit.visit(start) (ParallelBreadthFirstVisit.java:205-247) with the frontier expansion on the
+        device: returns (queue, cutPoints, marker) -- the nodes of queue[cutPoints[d]:cutPoints[d+1]] are at distance d."""
+        import torch
+        n = self.numNodes()
+        dev = torch.device("cuda", self.info.device)
+        if marker is None:
+            marker = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        if int(marker[start]) != -1:
+            return torch.empty(0, dtype=torch.int32, device=dev), [0], marker
+        marker[start] = start if parent else round_
+        queue = torch.empty(n, dtype=torch.int32, device=dev)
+        queue[0] = start
+        cut = [0, 1]
+        while cut[-1] > cut[-2]:
+            lo, hi = cut[-2], cut[-1]
+            got = self.bfs_expand(queue.data_ptr() + 4 * lo, hi - lo, marker.data_ptr(), round_, parent, queue.data_ptr() + 4 * hi, n - hi)
+            cut.append(hi + got)
+        return queue[:cut[-1]], cut[:-1], marker
 
     def successors_batch(self, nodes):
         """Concatenated successorArray(nodes[i]) (random access, BVGraph.java:897-904)."""

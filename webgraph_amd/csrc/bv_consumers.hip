@@ -1,0 +1,146 @@
+// bv_consumers.hip -- consumers of decoded rows that never hand a successor array to the caller.
+//
+// Every user of the decode path in the reference reduces a successor list as soon as it has it.  Two of them, restated over
+// rows that the decode kernels have just written to scratch that stays on the die (a chunk of the graph at a time):
+//   k_stats_*     Stats.run's scan (src/it/unimi/dsi/webgraph/Stats.java:111-160): arcs, loops, dangling / terminal nodes,
+//                 min / max outdegree and the first node that has it, gap and locality sums, the exponentially binned
+//                 histogram of |successor - node|, optionally the indegrees
+//   k_bfs_expand  one round of ParallelBreadthFirstVisit (src/it/unimi/dsi/webgraph/algo/ParallelBreadthFirstVisit.java:
+//                 146-170): for every node of the frontier and every successor s, marker.compareAndSet(s, -1, mark)
+//                 and, where that wins, s joins the next frontier
+#include "bv_launch.hpp"
+
+#include <hip/hip_runtime.h>
+
+namespace bv {
+
+constexpr int CS_T = 256, CS_ARCS = 2048; // arcs per block of the per-arc kernels
+
+// the row of arc `a` among rows [rlo, rhi] whose starts are staged in LDS (s_rp[k] = rowptr[rlo + k])
+__device__ __forceinline__ int32_t row_of(const int64_t *s_rp, int32_t nrows, int64_t a) {
+	int32_t lo = 0, hi = nrows; // last k with s_rp[k] <= a
+	while (hi - lo > 1) { const int32_t mid = (lo + hi) >> 1; if (s_rp[mid] <= a) lo = mid; else hi = mid; }
+	return lo;
+}
+// rows whose arcs [a0, a1) belong to: first row holding a0 .. row holding a1 - 1; their starts go to LDS (at most CS_ARCS + 1
+// rows hold arcs of the slice; empty rows in between make it longer: then the search runs on the global array)
+struct RowSlice { int32_t rlo, n; const int64_t *rp; };
+__device__ __forceinline__ RowSlice stage_rows(const int64_t *__restrict__ rowptr, int32_t cnt, int64_t a0, int64_t a1, int64_t *s_rp, int32_t *s_b) {
+	if (threadIdx.x < 2) {
+		const int64_t a = threadIdx.x ? a1 - 1 : a0;
+		int32_t lo = 0, hi = cnt; // last row with rowptr[row] <= a  (rowptr[cnt] = arcs > a)
+		while (hi - lo > 1) { const int32_t mid = (int32_t)(((int64_t)lo + hi) >> 1); if (rowptr[mid] <= a) lo = mid; else hi = mid; }
+		s_b[threadIdx.x] = lo;
+	}
+	__syncthreads();
+	const int32_t rlo = s_b[0], n = s_b[1] - s_b[0] + 1;
+	if (n <= CS_ARCS + 1) {
+		for (int32_t k = threadIdx.x; k < n; k += CS_T) s_rp[k] = rowptr[rlo + k];
+		__syncthreads();
+		return RowSlice{ rlo, n, s_rp };
+	}
+	return RowSlice{ rlo, n, rowptr + rlo };
+}
+
+struct StatsDev { // accumulated with atomics
+	unsigned long long arcs, loops, dangling, terminal, num_gaps, tot_loc, tot_gap, min_key, max_key, delta[32];
+};
+
+__global__ void __launch_bounds__(CS_T) k_stats_nodes(int32_t from, int32_t cnt, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ, StatsDev *st) {
+	const int32_t s = blockIdx.x * CS_T + threadIdx.x;
+	unsigned long long dang = 0, term = 0, gaps = 0, totgap = 0, mn = ~0ull, mx = 0;
+	if (s < cnt) {
+		const int64_t lo = rowptr[s], hi = rowptr[s + 1];
+		const int64_t d = hi - lo;
+		const int32_t curr = from + s;
+		if (d == 0) { dang = 1; term = 1; }                                   // Stats.java:133-136
+		if (d == 1 && succ[lo] == curr) term = 1;                             // :138
+		if (d > 1) {                                                          // :119-123
+			const int32_t a = succ[lo], z = succ[hi - 1];
+			const int32_t diff = a - curr;
+			totgap = (unsigned long long)(int64_t)(z - a) + (unsigned long long)(diff >= 0 ? 2ll * diff : -2ll * diff - 1); // Fast.int2nat
+			gaps = (unsigned long long)d;
+		}
+		mn = ((unsigned long long)d << 32) | (uint32_t)curr;                  // smallest outdegree, then the first node that has it (:140-143)
+		mx = ((unsigned long long)d << 32) | (0xffffffffu - (uint32_t)curr);  // largest outdegree, then the first node that has it (:145-148)
+	}
+	// wave reductions, then one atomic per wave and field
+	for (int o = 32; o > 0; o >>= 1) {
+		dang += __shfl_xor(dang, o, 64); term += __shfl_xor(term, o, 64); gaps += __shfl_xor(gaps, o, 64); totgap += __shfl_xor(totgap, o, 64);
+		mn = min(mn, (unsigned long long)__shfl_xor(mn, o, 64)); mx = max(mx, (unsigned long long)__shfl_xor(mx, o, 64));
+	}
+	if ((threadIdx.x & 63) == 0) {
+		if (dang) atomicAdd(&st->dangling, dang);
+		if (term) atomicAdd(&st->terminal, term);
+		if (gaps) { atomicAdd(&st->num_gaps, gaps); atomicAdd(&st->tot_gap, totgap); }
+		if (mn != ~0ull) { atomicMin(&st->min_key, mn); atomicMax(&st->max_key, mx); }
+	}
+}
+
+__global__ void __launch_bounds__(CS_T) k_stats_arcs(int32_t from, int32_t cnt, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ, StatsDev *st, int32_t *__restrict__ indegree) {
+	__shared__ int64_t s_rp[CS_ARCS + 2];
+	__shared__ int32_t s_b[2];
+	__shared__ unsigned long long s_delta[32];
+	const int64_t arcs = rowptr[cnt], a0 = (int64_t)blockIdx.x * CS_ARCS, a1 = min(a0 + CS_ARCS, arcs);
+	if (a0 >= a1) return;
+	if (threadIdx.x < 32) s_delta[threadIdx.x] = 0;
+	const RowSlice rs = stage_rows(rowptr, cnt, a0, a1, s_rp, s_b);
+	__syncthreads();
+	unsigned long long loops = 0, loc = 0;
+	for (int64_t a = a0 + threadIdx.x; a < a1; a += CS_T) {
+		const int32_t curr = from + rs.rlo + row_of(rs.rp, rs.n, a), sx = succ[a];
+		const int64_t dist = (int64_t)sx - curr;
+		const unsigned long long ad = (unsigned long long)(dist < 0 ? -dist : dist);
+		loc += ad;                                                            // Stats.java:125
+		if (sx != curr) atomicAdd(&s_delta[63 - __clzll((long long)ad)], 1ull); // :127  Fast.mostSignificantBit
+		else loops++;                                                         // :128
+		if (indegree) atomicAdd(&indegree[sx], 1);                            // :130
+	}
+	for (int o = 32; o > 0; o >>= 1) { loops += __shfl_xor(loops, o, 64); loc += __shfl_xor(loc, o, 64); }
+	if ((threadIdx.x & 63) == 0) { if (loops) atomicAdd(&st->loops, loops); atomicAdd(&st->tot_loc, loc); }
+	__syncthreads();
+	if (threadIdx.x < 32 && s_delta[threadIdx.x]) atomicAdd(&st->delta[threadIdx.x], s_delta[threadIdx.x]);
+	if (threadIdx.x == 0) atomicAdd(&st->arcs, (unsigned long long)(a1 - a0));
+}
+
+// One round of the visit over the rows of the frontier's nodes (rowptr / succ = bvg_successors_batch of the frontier).
+__global__ void __launch_bounds__(CS_T) k_bfs_expand(const int32_t *__restrict__ frontier, int32_t q, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ,
+                                                     int32_t *marker, int32_t n, int32_t round, int parent, int32_t *__restrict__ out, unsigned long long outCap, unsigned long long *outCount) {
+	__shared__ int64_t s_rp[CS_ARCS + 2];
+	__shared__ int32_t s_b[2];
+	const int64_t arcs = rowptr[q], a0 = (int64_t)blockIdx.x * CS_ARCS, a1 = min(a0 + CS_ARCS, arcs);
+	if (a0 >= a1) return;
+	const RowSlice rs = stage_rows(rowptr, q, a0, a1, s_rp, s_b);
+	for (int64_t base = a0; base < a1; base += CS_T) { // (uniform trip count: the ballot below needs whole waves)
+		const int64_t a = base + threadIdx.x;
+		bool won = false;
+		int32_t sx = 0;
+		if (a < a1) {
+			sx = succ[a];
+			const int32_t mark = parent ? frontier[rs.rlo + row_of(rs.rp, rs.n, a)] : round; // ParallelBreadthFirstVisit.java:162
+			won = (uint32_t)sx < (uint32_t)n && atomicCAS(&marker[sx], -1, mark) == -1;     // :165 marker.compareAndSet(s, -1, mark)
+		}
+		const unsigned long long m = __ballot(won); // one append per wave
+		if (m) {
+			const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+			unsigned long long at = 0;
+			if (lane == leader) at = atomicAdd(outCount, (unsigned long long)__popcll(m));
+			at = __shfl(at, leader, 64);
+			if (won) { const unsigned long long p = at + (unsigned long long)__popcll(m & ((1ull << lane) - 1)); if (p < outCap) out[p] = sx; }
+		}
+	}
+}
+
+void launch_stats(int32_t from, int32_t cnt, const int64_t *rowptr, const int32_t *succ, int64_t arcsUpper, void *statsDev, int32_t *indegree, hipStream_t st) {
+	if (cnt <= 0) return;
+	hipLaunchKernelGGL(k_stats_nodes, dim3((unsigned)((cnt + CS_T - 1) / CS_T)), dim3(CS_T), 0, st, from, cnt, rowptr, succ, (StatsDev *)statsDev);
+	if (arcsUpper > 0) hipLaunchKernelGGL(k_stats_arcs, dim3((unsigned)((arcsUpper + CS_ARCS - 1) / CS_ARCS)), dim3(CS_T), 0, st, from, cnt, rowptr, succ, (StatsDev *)statsDev, indegree);
+}
+size_t stats_dev_bytes() { return sizeof(StatsDev); }
+void launch_bfs_expand(const int32_t *frontier, int32_t q, const int64_t *rowptr, const int32_t *succ, int64_t arcs, int32_t *marker, int32_t n, int32_t round, int parent,
+                       int32_t *out, uint64_t outCap, unsigned long long *outCount, hipStream_t st) {
+	if (q <= 0 || arcs <= 0) return;
+	hipLaunchKernelGGL(k_bfs_expand, dim3((unsigned)((arcs + CS_ARCS - 1) / CS_ARCS)), dim3(CS_T), 0, st, frontier, q, rowptr, succ, marker, n, round, parent, out, (unsigned long long)outCap, outCount);
+}
+
+} // namespace bv

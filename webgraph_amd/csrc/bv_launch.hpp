@@ -91,6 +91,12 @@ void launch_hash(int32_t from, int32_t cnt, const int64_t *rowptr, const int32_t
 void launch_bparse_big(const GraphDev &g, int def, const BatchView &v, int32_t coopMin, int32_t giantMin, int32_t *biglist, int32_t *giantlist, int32_t giantCap, int32_t *ctl,
                        void *arena, int64_t arenaCap, int waves, int giantGroups, int *err, hipStream_t st, hipStream_t stGiant, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evGiant, hipEvent_t evBig);
 
+// bv_consumers.hip: consumers of rows decoded into on-die scratch
+void launch_stats(int32_t from, int32_t cnt, const int64_t *rowptr, const int32_t *succ, int64_t arcsUpper, void *statsDev, int32_t *indegree, hipStream_t st);
+size_t stats_dev_bytes();
+void launch_bfs_expand(const int32_t *frontier, int32_t q, const int64_t *rowptr, const int32_t *succ, int64_t arcs, int32_t *marker, int32_t n, int32_t round, int parent,
+                       int32_t *out, uint64_t outCap, unsigned long long *outCount, hipStream_t st);
+
 // bv_offsets.hip: gamma-coded .offsets stream (words + >= 8 zero words in HBM) -> int64 offsets[nodes + 1] in HBM
 int offsets_decode_device(const uint32_t *d_words, uint64_t nwords, uint64_t totalBits, int32_t nodes, int64_t *d_out, hipStream_t st);
 // arc labels (.labels stream in HBM, same padding): `count` consecutive labels starting at bit `startBit`

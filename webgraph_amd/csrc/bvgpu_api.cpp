@@ -142,6 +142,7 @@ struct bvg_graph {
 	                        // measured crossover on the 10 M-node C2 graph: q = 300 000)
 	// host-output scans (BVG_OUT_HOST, bvg_decode_range_view): chunks are decoded into two device buffers in turn and
 	// leave over PCIe on a copy stream of their own while the next chunk is being decoded
+	DevBuf statsbuf, bfs_rowptr, bfs_succ, bfs_ctr; // consumers (bv_consumers.hip)
 	DevBuf hchunk[2];
 	PinBuf hring[2];               // pageable destinations: the chunk lands here first and is copied out by host threads
 	PinBuf view_rowptr, view_succ; // bvg_decode_range_view: library-owned pinned results
@@ -797,7 +798,7 @@ extern "C" int bvg_close(bvg_t *g) {
 		(void)hipSetDevice(g->st->device);
 		if (g->own) { (void)hipStreamSynchronize(g->own); (void)hipStreamDestroy(g->own); }
 		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist, &g->plist, &g->pkeys, &g->pkey16, &g->copyq, &g->bigtmp, &g->tilebounds, &g->ctilebounds, &g->ref2 }) b->release();
-		for (DevBuf *b : { &g->hchunk[0], &g->hchunk[1] }) b->release();
+		for (DevBuf *b : { &g->hchunk[0], &g->hchunk[1], &g->statsbuf, &g->bfs_rowptr, &g->bfs_succ, &g->bfs_ctr }) b->release();
 		for (PinBuf *b : { &g->hring[0], &g->hring[1], &g->view_rowptr, &g->view_succ }) b->release();
 		if (g->copyStream) { (void)hipStreamSynchronize(g->copyStream); (void)hipStreamDestroy(g->copyStream); }
 		for (hipEvent_t e : { g->evChunk[0], g->evChunk[1], g->evCopied[0], g->evCopied[1] }) if (e) (void)hipEventDestroy(e);
@@ -1263,6 +1264,78 @@ extern "C" int bvg_csr_hashcode(bvg_t *g, int32_t from, int32_t to, const int64_
 	int rc = fetch_small(g);
 	if (rc) return rc;
 	*hash_io = g->h_small->hash;
+	return BVG_OK;
+}
+
+namespace {
+struct StatsHost { unsigned long long arcs, loops, dangling, terminal, num_gaps, tot_loc, tot_gap, min_key, max_key, delta[32]; }; // = bv::StatsDev
+}
+
+extern "C" int bvg_scan_stats(bvg_t *g, int32_t from, int32_t to, bvg_scan_stats_t *out, int32_t *indegree_dev) {
+	if (!g || !g->st || !out) return BVG_EARG;
+	const Staged &s = *g->st;
+	if (from < 0 || from > s.info.nodes || to < from || to > s.info.nodes) return fail(g, BVG_EARG, "node range out of bounds"); // BVG:1165
+	HIPCHK(g, hipSetDevice(s.device));
+	if (bv::stats_dev_bytes() != sizeof(StatsHost) || !g->statsbuf.need(sizeof(StatsHost))) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
+	StatsHost h{};
+	h.min_key = ~0ull;
+	HIPCHK(g, hipMemcpy(g->statsbuf.p, &h, sizeof(h), hipMemcpyHostToDevice));
+	const std::vector<int32_t> cut = plan_chunks_by_bits(s, from, to, (int64_t)32 << 20);
+	for (size_t k = 0; k + 1 < cut.size(); k++) {
+		const int32_t a = cut[k], e = cut[k + 1];
+		if (e == a) continue;
+		if (!g->stage_rowptr.need(sizeof(int64_t) * ((size_t)(e - a) + 1))) return fail(g, BVG_ENOMEM, "staging allocation failed");
+		const int64_t allBits = std::max<int64_t>(s.h_offsets.back(), 1), bits = s.h_offsets[e] - s.h_offsets[a];
+		const uint64_t guess = (uint64_t)((double)std::max<int64_t>(s.arcs_sizing, 1) * (double)bits / (double)allBits * 1.1) + 4096;
+		if (!g->stage_succ.need(sizeof(int32_t) * (size_t)guess)) return fail(g, BVG_ENOMEM, "staging allocation failed");
+		uint64_t arcs = 0;
+		int rc = decode_range_device(g, a, e, g->stage_rowptr.as<int64_t>(), g->stage_succ.as<int32_t>(), g->stage_succ.cap / sizeof(int32_t), false, &arcs);
+		if (rc == BVG_ECAP) {
+			if (!g->stage_succ.need(sizeof(int32_t) * (size_t)std::max<uint64_t>(arcs, 1))) return fail(g, BVG_ENOMEM, "staging allocation failed");
+			rc = decode_range_device(g, a, e, g->stage_rowptr.as<int64_t>(), g->stage_succ.as<int32_t>(), g->stage_succ.cap / sizeof(int32_t), false, &arcs);
+		}
+		if (rc) return rc;
+		bv::launch_stats(a, e - a, g->stage_rowptr.as<int64_t>(), g->stage_succ.as<int32_t>(), (int64_t)arcs, g->statsbuf.p, indegree_dev, g->stream);
+		HIPCHK(g, hipStreamSynchronize(g->stream)); // the scratch rows are reused by the next chunk
+	}
+	HIPCHK(g, hipMemcpy(&h, g->statsbuf.p, sizeof(h), hipMemcpyDeviceToHost));
+	memset(out, 0, sizeof(*out));
+	out->nodes = (uint64_t)(to - from); out->arcs = h.arcs; out->loops = h.loops; out->dangling = h.dangling; out->terminal = h.terminal;
+	out->num_gaps = h.num_gaps; out->tot_gap = h.tot_gap; out->tot_loc = h.tot_loc;
+	for (int i = 0; i < 32; i++) out->successor_delta_stats[i] = h.delta[i];
+	// the reference starts from mind = Integer.MAX_VALUE, maxd = 0, both nodes 0, and moves on strict comparisons (Stats.java:98, :140-148)
+	out->min_outdegree = 0x7fffffff; out->min_outdegree_node = 0; out->max_outdegree = 0; out->max_outdegree_node = 0;
+	if (to > from) {
+		out->min_outdegree = (int32_t)(h.min_key >> 32); out->min_outdegree_node = (int32_t)(uint32_t)h.min_key;
+		out->max_outdegree = (int32_t)(h.max_key >> 32);
+		out->max_outdegree_node = out->max_outdegree > 0 ? (int32_t)(0xffffffffu - (uint32_t)h.max_key) : 0;
+	}
+	return BVG_OK;
+}
+
+extern "C" int bvg_bfs_expand(bvg_t *g, const int32_t *frontier_dev, size_t q, int32_t *marker_dev, int32_t round, int parent, int32_t *out_dev, size_t out_cap, uint64_t *out_count) {
+	if (!g || !g->st || !marker_dev || (!frontier_dev && q) || (!out_dev && out_cap) || !out_count) return BVG_EARG;
+	const Staged &s = *g->st;
+	*out_count = 0;
+	if (q == 0) return BVG_OK;
+	if (q > 0x7fffffffull) return fail(g, BVG_EARG, "frontier too long");
+	HIPCHK(g, hipSetDevice(s.device));
+	if (!g->bfs_rowptr.need(sizeof(int64_t) * (q + 1)) || !g->bfs_ctr.need(sizeof(unsigned long long))) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
+	uint64_t arcs = 0;
+	int rc = bvg_successors_batch(g, frontier_dev, q, g->bfs_rowptr.as<int64_t>(), nullptr, 0, &arcs, BVG_OUT_DEVICE);
+	if (rc) return rc;
+	if (arcs == 0) return BVG_OK;
+	if (!g->bfs_succ.need(sizeof(int32_t) * (size_t)arcs)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
+	rc = bvg_successors_batch(g, frontier_dev, q, g->bfs_rowptr.as<int64_t>(), g->bfs_succ.as<int32_t>(), (size_t)arcs, &arcs, BVG_OUT_DEVICE);
+	if (rc) return rc;
+	HIPCHK(g, hipMemsetAsync(g->bfs_ctr.p, 0, sizeof(unsigned long long), g->stream));
+	bv::launch_bfs_expand(frontier_dev, (int32_t)q, g->bfs_rowptr.as<int64_t>(), g->bfs_succ.as<int32_t>(), (int64_t)arcs, marker_dev, s.info.nodes, round, parent,
+	                      out_dev, (uint64_t)out_cap, g->bfs_ctr.as<unsigned long long>(), g->stream);
+	unsigned long long cnt = 0;
+	HIPCHK(g, hipMemcpyAsync(&cnt, g->bfs_ctr.p, sizeof(cnt), hipMemcpyDeviceToHost, g->stream));
+	HIPCHK(g, hipStreamSynchronize(g->stream));
+	*out_count = cnt;
+	if (cnt > out_cap) return fail(g, BVG_ECAP, "next frontier larger than the output buffer");
 	return BVG_OK;
 }
 
