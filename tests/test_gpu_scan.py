@@ -235,22 +235,9 @@ def test_sharded_scan_equals_whole(cnr_gpu, cnr_oracle):
         assert arcs == 3216152 and fold_affine(pairs) == 1711395807
 
 
-def test_fused_path_matches(tmp_path_factory, cnr_oracle, monkeypatch):
-    """The experimental level-by-level single-pass decoder (BVGPU_PATH=fused) gives the same bits."""
-    from webgraph_amd.bvgraph import BVGraph
-    monkeypatch.setenv("BVGPU_PATH", "fused")
-    _, rowptr, succ = cnr_oracle
-    g = BVGraph.load(CNR)
-    rp, sc = g.decode_range()
-    assert np.array_equal(rp, rowptr) and np.array_equal(sc, succ)
-    rp, sc = g.decode_range(100000, 140000)
-    assert np.array_equal(sc, succ[rowptr[100000]:rowptr[140000]])
-    g.close()
-
-
 KNOBS = [
     {"BVGPU_OVERLAP": "0"}, {"BVGPU_COOP_MIN": "16", "BVGPU_GIANT_MIN": "64"}, {"BVGPU_COOP_MIN": "2147483647"},
-    {"BVGPU_PARSE_LISTS": "0", "BVGPU_COPY_LISTS": "0"}, {"BVGPU_COPY_BIG": "0"}, {"BVGPU_PATH": "fused", "BVGPU_GIANT_BITS": "2048"},
+    {"BVGPU_PARSE_LISTS": "0", "BVGPU_COPY_LISTS": "0"}, {"BVGPU_COPY_BIG": "0"},
     # the contiguous-tile kernels (bv_tile.hpp, bv_tile2.hpp, bv_ctile.hpp): parse from one LDS image per tile, copy pass in LDS
     {"BVGPU_TILE": "1"}, {"BVGPU_TILE": "2"}, {"BVGPU_CTILE": "1"}, {"BVGPU_TILE": "2", "BVGPU_CTILE": "1", "BVGPU_COOP_MIN": "300", "BVGPU_GIANT_MIN": "4000"},
 ]

@@ -19,13 +19,12 @@
 //   k_copy_big       per row                                                 (MaskedIntIterator / MergedIntIterator)
 //   k_chain_*, k_bparse, k_bcopy   the same for batches of random-access queries (slots of reference chains)
 //   k_hash_*         ImmutableGraph.hashCode of a decoded CSR
-// Older single-purpose variants kept for the tuning knobs and as fallbacks: k_parse, k_copy, k_depth, and the fused
-// single-pass path (k_decode_level, bv_lane.hpp).  All arithmetic is integer; nothing here is MFMA-shaped.
+// Older single-purpose variants kept as fallbacks behind knobs: k_parse, k_copy (node-order sweeps).  Tile kernels behind
+// knobs: bv_tile.hpp, bv_tile2.hpp, bv_ctile.hpp.  All arithmetic is integer; nothing here is MFMA-shaped.
 #include "bv_device.hpp"
 #include "bv_launch.hpp"
 #include "bv_coop.hpp"
 #include "bv_lanewin.hpp"
-#include "bv_lane.hpp"
 #include "bv_tile.hpp"
 #include "bv_tile2.hpp"
 #include "bv_ctile.hpp"
@@ -493,37 +492,6 @@ __global__ void __launch_bounds__(TPB) k_scatter_keys(int32_t cnt, const uint16_
 	}
 }
 
-// One lane per record of chain level `level`; waves walk the level's slice of the list (sorted by length bin).
-template <int DEF, bool HAS_REF>
-__global__ void __launch_bounds__(TPB) k_decode_level(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ list,
-                                                      const int32_t *__restrict__ keyBase, int32_t level, int *__restrict__ err) {
-	__shared__ int32_t lds[LANE_LDS_INTS_PER_THREAD * TPB];
-	const int32_t bucket = min(level, MAXLVL - 1);
-	const int32_t lo = keyBase[bucket * NBIN], hi = keyBase[(bucket + 1) * NBIN];
-	// longest records first: the waves that take longest start first
-	for (int32_t idx = hi - 1 - (blockIdx.x * TPB + threadIdx.x); idx >= lo; idx -= gridDim.x * TPB) {
-		const int32_t s = list[idx];
-		if (level >= MAXLVL - 1 && depth[s] != level) continue; // shared overflow bucket
-		const int32_t d = v.outd[s];
-		const int32_t r = v.ref[s];
-		if (!v.fits(s) || (r > 0 && !v.fits(s - r))) { atomicOr(err, s >= v.nh && v.fits(s - r) ? E_CAP : E_HALO); continue; }
-		decode_node_full<DEF, HAS_REF>(g, v.lo + s, d, r, r > 0 ? (int64_t)v.outd[s - r] : 0, r > 0 ? v.row(s - r) : nullptr, v.row(s), lds, err);
-	}
-}
-
-// copy pass restricted to the giant list (their extras were written by k_parse_big)
-template <int DEF>
-__global__ void __launch_bounds__(64) k_copy_giants(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ giantlist,
-                                                    const int32_t *__restrict__ ctl, int32_t level, int *__restrict__ err) {
-	const int32_t idx = blockIdx.x * 64 + threadIdx.x;
-	if (idx >= ctl[1]) return;
-	const int32_t s = giantlist[idx];
-	if (depth[s] != level || v.ref[s] == 0) return;
-	const int32_t r = v.ref[s];
-	if (!v.fits(s) || !v.fits(s - r)) return;
-	copy_node<DEF>(g, v.lo + s, v.outd[s], (int64_t)v.outd[s - r], v.row(s), v.row(s - r), err);
-}
-
 // The copy pass of one chain level runs as three kernels side by side over the level's compact list, each picking
 // the rows of its class: rows with fewer than midMin successors are merged by one lane each (k_copy_list), rows
 // with fewer than COPY_BIG_MIN by one wave each (k_copy_mid), longer ones by a 1024-thread group each (k_copy_big).
@@ -637,7 +605,7 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 	__shared__ int32_t cval[COPY_BIG_CAP], cpos[COPY_BIG_CAP + 1], delta[COPY_BIG_CAP + 1];
 	__shared__ uint32_t lwin[DEF ? LW_MAIN * LW_STRIDE : 1]; // stream window of the wave that walks the block list
 	__shared__ __attribute__((aligned(16))) uint32_t cwin[DEF ? CoopLds<1>::WORDS : 4]; // tile of the cooperative walk of a long block list
-	__shared__ int64_t s_copied, s_tmp;
+	__shared__ int64_t s_copied, s_tmp, s_kmax;
 	__shared__ int32_t s_kept, s_bad;
 	// the queue holds the long rows of ALL levels (a few hundred): a group takes the entries of this level among its share
 	const int32_t nq = min(*count, cap);
@@ -748,29 +716,46 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 			for (int32_t t = threadIdx.x; t < nc; t += COPY_BIG_THREADS) row[cp_[t]] = cv_[t];
 			CT(4);
 		};
-		walk_row(cpos, delta, COPY_BIG_CAP + 1);
+		// Where the tables live is decided BEFORE the walk (a long block list is the serial part of the row: it is walked once):
+		// at most bc / 2 + 1 blocks are copied and at most min(dref, d) ids, so a referent of up to COPY_BIG_CAP ids with a
+		// block list of up to 2 * COPY_BIG_CAP codes fits the LDS tables for sure; everything else gets tables in global
+		// scratch (bump allocator), sized by those bounds.
+		if (threadIdx.x == 0) {
+			BitReader hb;
+			hb.init(g.bits, g.nwords);
+			hb.seek((uint64_t)g.offsets[v.lo + s]);
+			(void)Fields<DEF>::outdegree(hb, g);
+			(void)Fields<DEF>::reference(hb, g);
+			const uint64_t bc = Fields<DEF>::block_count(hb, g);
+			s_tmp = -2; // LDS tables
+			if (bc > (uint64_t)dref + 1) s_tmp = -3; // flagged by the parse kernel
+			else if (dref > COPY_BIG_CAP || (bc >> 1) + 1 > (uint64_t)COPY_BIG_CAP + 1) {
+				const uint64_t kMax = (bc >> 1) + 1, cMax = (uint64_t)(dref < (int64_t)d ? dref : (int64_t)d), need = 2 * kMax + 2 * cMax;
+				s_tmp = -1; // one lane does the row
+				if (tmp && need <= tmpCap) { const uint32_t o = atomicAdd(tmpCursor, (uint32_t)need); if ((uint64_t)o + need <= tmpCap) s_tmp = o; }
+				s_kmax = (int64_t)kMax;
+			}
+		}
+		__syncthreads();
+		const int64_t where = s_tmp, kMax = s_kmax;
+		__syncthreads();
+		if (where == -3) continue;
+		if (where == -1) {
+			if (threadIdx.x == 0) copy_node<DEF>(g, v.lo + s, d, dref, row, src, err);
+			continue;
+		}
+		int32_t *tabK = where == -2 ? cpos : tmp + where, *tabD = where == -2 ? delta : tabK + kMax;
+		walk_row(tabK, tabD, where == -2 ? COPY_BIG_CAP + 1 : (int32_t)min<int64_t>(kMax, 0x7fffffff));
 		const int64_t copied = s_copied;
 		const int32_t nKept = s_kept;
 		if (s_bad || copied > d || copied == 0) continue; // malformed (flagged by the parse kernel) / nothing to merge: the extras already fill the row
 		if (g.stats && threadIdx.x == 0) { stat_add(g, 8, 1); stat_add(g, 9, (unsigned long long)nKept); stat_max(g, 15, (unsigned long long)nKept); stat_add(g, 4, (unsigned long long)d); }
 		CT(0);
-		if (copied <= COPY_BIG_CAP && nKept <= COPY_BIG_CAP + 1) { merge_row(cpos, delta, cval, cpos, (int32_t)copied, nKept); continue; }
-		// More copied ids than the LDS tables hold (a long row copying most of a long referent): the same merge on
-		// tables in global scratch, taken from a bump allocator; if that is exhausted, one lane does the row.
-		const uint64_t need = 2ull * (uint64_t)nKept + 2ull * (uint64_t)copied;
-		if (threadIdx.x == 0) {
-			s_tmp = -1;
-			if (tmp && need <= tmpCap) { const uint32_t o = atomicAdd(tmpCursor, (uint32_t)need); if ((uint64_t)o + need <= tmpCap) s_tmp = o; }
-		}
-		__syncthreads();
-		if (s_tmp < 0) {
-			if (threadIdx.x == 0) copy_node<DEF>(g, v.lo + s, d, dref, row, src, err);
-			continue;
-		}
-		int32_t *gk = tmp + s_tmp, *gd = gk + nKept, *gv = gd + nKept, *gp = gv + copied;
-		walk_row(gk, gd, nKept);
-		if (s_bad || s_copied != copied || s_kept != nKept) continue; // (cannot differ: same stream)
-		merge_row(gk, gd, gv, gp, (int32_t)copied, nKept);
+		if (where == -2) { merge_row(cpos, delta, cval, cpos, (int32_t)copied, nKept); continue; } // (copied <= dref <= COPY_BIG_CAP, nKept <= COPY_BIG_CAP + 1)
+		const int64_t cMaxRow = dref < (int64_t)d ? dref : (int64_t)d;
+		if (nKept > kMax || copied > cMaxRow) continue; // (cannot happen: the bounds above)
+		int32_t *gv = tabD + kMax, *gp = gv + cMaxRow;
+		merge_row(tabK, tabD, gv, gp, (int32_t)copied, nKept);
 #undef CT
 	}
 }
@@ -1287,30 +1272,6 @@ void launch_build_lists(const GraphDev &g, const RangeView &v, uint64_t giantBit
 	                   bigQ, bigCap, midQ, midCap, midMin, bigMin);
 	hipLaunchKernelGGL(k_key_offsets, dim3(1), dim3(TPB), 0, st, hist, keyBase, cursor, maxdepth);
 	hipLaunchKernelGGL(k_scatter_keys, dim3(nblk(v.cnt, LIST_TILE)), dim3(TPB), 0, st, v.cnt, key16, cursor, list, giantlist, giantCap, ctl);
-}
-
-void launch_decode_level(const GraphDev &g, int def, const RangeView &v, const int32_t *depth, const int32_t *list, const int32_t *keyBase, int32_t level, int blocks,
-                         int *err, hipStream_t st) {
-	if (v.cnt <= 0) return;
-	// level 0 records have no reference: the copy stream is compiled out
-	if (level == 0) {
-		if (def == 1) hipLaunchKernelGGL((k_decode_level<1, false>), dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, err);
-		else if (def == 2) hipLaunchKernelGGL((k_decode_level<2, false>), dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, err);
-		else hipLaunchKernelGGL((k_decode_level<0, false>), dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, err);
-	} else {
-		if (def == 1) hipLaunchKernelGGL((k_decode_level<1, true>), dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, err);
-		else if (def == 2) hipLaunchKernelGGL((k_decode_level<2, true>), dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, err);
-		else hipLaunchKernelGGL((k_decode_level<0, true>), dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, err);
-	}
-}
-
-void launch_copy_giants(const GraphDev &g, int def, const RangeView &v, const int32_t *depth, const int32_t *giantlist, const int32_t *ctl, int32_t giantCap, int32_t level,
-                        int *err, hipStream_t st) {
-	if (v.cnt <= 0 || giantCap <= 0) return;
-	const int blocks = (int)std::min<int64_t>(((int64_t)giantCap + 63) / 64, 65535);
-	if (def == 1) hipLaunchKernelGGL(k_copy_giants<1>, dim3(blocks), dim3(64), 0, st, g, v, depth, giantlist, ctl, level, err);
-	else if (def == 2) hipLaunchKernelGGL(k_copy_giants<2>, dim3(blocks), dim3(64), 0, st, g, v, depth, giantlist, ctl, level, err);
-	else hipLaunchKernelGGL(k_copy_giants<0>, dim3(blocks), dim3(64), 0, st, g, v, depth, giantlist, ctl, level, err);
 }
 
 void launch_parse_giants(const GraphDev &g, int def, const RangeView &v, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap, int giantGroups, int *err, hipStream_t st) {

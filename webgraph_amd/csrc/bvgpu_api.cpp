@@ -109,10 +109,7 @@ struct bvg_graph {
 	DevBuf b_chainlen, b_slotbase, b_node, b_qidx, b_aoutd, b_qoutd; // random-access batches
 	DevBuf biglist, giantlist, arena, coopctl;                        // work lists; cooperative decode of giant records
 	DevBuf key16, keys;                                               // per-slot list key; hist / keyBase / cursor
-	uint64_t giant_bits = 65536;                                      // records at least this long (bits) are decoded cooperatively (BVGPU_GIANT_BITS)
 	int level_blocks = 2048;
-	int no_bin = 0;
-	int fused = 0; // BVGPU_PATH=fused: level-by-level single-pass decode (bv_lane.hpp); default: parse all, then copy level by level
 	DevBuf lvlist;
 	int parse_lists = 1; // BVGPU_PARSE_LISTS=0: short records parsed in node order instead of by work bin
 	DevBuf plist, pkeys, pkey16;
@@ -206,10 +203,7 @@ int init_handle(bvg_graph *g) {
 	if (const char *e = getenv("BVGPU_COOP_WAVES")) g->coop_waves = std::max(1, atoi(e));
 	if (const char *e = getenv("BVGPU_GIANT_GROUPS")) g->giant_groups = std::max(1, atoi(e));
 	if (!g->coopctl.need(8 * sizeof(int32_t)) || !g->keys.need(3 * (bv::NKEYS + 1) * sizeof(int32_t))) return fail(g, BVG_ENOMEM, "device allocation failed");
-	if (const char *e = getenv("BVGPU_GIANT_BITS")) g->giant_bits = strtoull(e, nullptr, 10);
 	if (const char *e = getenv("BVGPU_LEVEL_BLOCKS")) g->level_blocks = std::max(1, atoi(e));
-	if (const char *e = getenv("BVGPU_NOBIN")) g->no_bin = atoi(e);
-	if (const char *e = getenv("BVGPU_PATH")) g->fused = strcmp(e, "fused") == 0;
 	if (const char *e = getenv("BVGPU_COPY_LISTS")) g->copy_lists = atoi(e);
 	if (const char *e = getenv("BVGPU_PARSE_LISTS")) g->parse_lists = atoi(e);
 	if (const char *e = getenv("BVGPU_COPY_BIG")) g->copy_big = atoi(e);
@@ -315,18 +309,13 @@ int finish_pending(bvg_graph *g, uint64_t *arcs_out) {
 			const int32_t upto = g->h_small->maxdepth;
 			int32_t *keyBase = g->keys.as<int32_t>() + (bv::NKEYS + 1);
 			for (int32_t l = g->pend.levels_done + 1; l <= upto; l++) {
-				if (!g->fused) {
-					if (g->copy_lists) {
-						const bool ov2 = g->overlap && !g->profile;
-						bv::launch_copy_level(gd, s.def, g->pend.view, g->depth.as<int32_t>(), g->lvlist.as<int32_t>(), keyBase, l, g->level_blocks, g->copy_mid_min, g->copy_big != 0,
-						                      g->copyq.as<int32_t>(), g->pend.bigCap, g->copyq.as<int32_t>() + g->pend.bigCap, g->pend.midCap, g->coopctl.as<int32_t>(), g->bigtmp.as<int32_t>(), g->pend.tmpCap, derr,
-						                      g->stream, ov2 ? g->sideB : g->stream, ov2 ? g->sideA : g->stream, g->evFork, g->evB, g->evA);
-					}
-					else bv::launch_copy(gd, s.def, g->pend.view, g->depth.as<int32_t>(), l, derr, g->stream);
-					continue;
+				if (g->copy_lists) {
+					const bool ov2 = g->overlap && !g->profile;
+					bv::launch_copy_level(gd, s.def, g->pend.view, g->depth.as<int32_t>(), g->lvlist.as<int32_t>(), keyBase, l, g->level_blocks, g->copy_mid_min, g->copy_big != 0,
+					                      g->copyq.as<int32_t>(), g->pend.bigCap, g->copyq.as<int32_t>() + g->pend.bigCap, g->pend.midCap, g->coopctl.as<int32_t>(), g->bigtmp.as<int32_t>(), g->pend.tmpCap, derr,
+					                      g->stream, ov2 ? g->sideB : g->stream, ov2 ? g->sideA : g->stream, g->evFork, g->evB, g->evA);
 				}
-				bv::launch_copy_giants(gd, s.def, g->pend.view, g->depth.as<int32_t>(), g->giantlist.as<int32_t>(), g->coopctl.as<int32_t>(), g->pend.giantCap, l, derr, g->stream);
-				bv::launch_decode_level(gd, s.def, g->pend.view, g->depth.as<int32_t>(), g->biglist.as<int32_t>(), keyBase, l, g->level_blocks, derr, g->stream);
+				else bv::launch_copy(gd, s.def, g->pend.view, g->depth.as<int32_t>(), l, derr, g->stream);
 			}
 			g->pend.levels_done = upto;
 			rc = fetch_small(g);
@@ -366,7 +355,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 	const bv::GraphDev gd = graph_dev(s);
 	levels = 0;
 	giantCap = 0;
-	if (!g->fused) {
+	{
 		// default path: depth + per-level lists; cooperative decode of long records (two classes) next to the
 		// one-lane decode of the short ones; then the copy pass level by level over compact lists
 		const int64_t arcsBound = std::max<int64_t>(s.arcs_sizing, 1);
@@ -500,41 +489,6 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			}
 		}
 	}
-	if (g->fused) {
-		const int64_t arcsBound = std::max<int64_t>(s.arcs_sizing, 1);
-		// a giant record has >= giant_bits bits; the whole stream has graph_bytes * 8
-		// a giant record has >= giant_bits bits or >= giant_bits / 8 successors
-		giantCap = (int32_t)std::min<uint64_t>((s.info.graph_bytes * 8 + (uint64_t)arcsBound * 8) / std::max<uint64_t>(g->giant_bits, 1) + 2, 0x7fffffff);
-		const int64_t arenaCap = s.info.min_interval_length > 0 ? arcsBound / s.info.min_interval_length + 2 : 1;
-		if (!g->depth.need(sizeof(int32_t) * (size_t)v.cnt) || !g->key16.need(sizeof(uint16_t) * (size_t)v.cnt) || !g->biglist.need(sizeof(int32_t) * (size_t)v.cnt) ||
-		    !g->giantlist.need(sizeof(int32_t) * (size_t)giantCap) || !g->arena.need((size_t)bv::ARENA_ENTRY_BYTES * (size_t)arenaCap))
-			return fail(g, BVG_ENOMEM, "device scratch allocation failed");
-		int32_t *hist = g->keys.as<int32_t>(), *keyBase = hist + (bv::NKEYS + 1), *cursor = keyBase + (bv::NKEYS + 1);
-		int32_t *ctl = g->coopctl.as<int32_t>();
-		v.coop_min = 0x7fffffff;
-		HIPCHK(g, hipMemsetAsync(ctl, 0, 8 * sizeof(int32_t), g->stream));
-		// chain depth of every record + work lists keyed by (level, length bin); giants apart
-		bv::launch_build_lists(gd, v, g->giant_bits, g->no_bin, g->depth.as<int32_t>(), g->key16.as<uint16_t>(), hist, keyBase, cursor, g->biglist.as<int32_t>(),
-		                       g->giantlist.as<int32_t>(), giantCap, ctl, &g->small.as<Small>()->maxdepth, g->stream);
-		mark(g, 3);
-		// giants: cooperative decode of their intervals + residuals on a side stream, overlapping level 0
-		HIPCHK(g, hipEventRecord(g->evFork, g->stream));
-		HIPCHK(g, hipStreamWaitEvent(g->sideA, g->evFork, 0));
-		bv::launch_parse_giants(gd, s.def, v, g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->giant_groups, derr, g->overlap ? g->sideA : g->stream);
-		if (g->overlap) HIPCHK(g, hipEventRecord(g->evA, g->sideA));
-		bv::launch_decode_level(gd, s.def, v, g->depth.as<int32_t>(), g->biglist.as<int32_t>(), keyBase, 0, g->level_blocks, derr, g->stream);
-		if (g->overlap) HIPCHK(g, hipStreamWaitEvent(g->stream, g->evA, 0));
-		mark(g, 4);
-		mark(g, 5);
-		mark(g, 6);
-		if (W > 0) {
-			levels = g->levels_hint;
-			for (int32_t l = 1; l <= levels; l++) {
-				bv::launch_copy_giants(gd, s.def, v, g->depth.as<int32_t>(), g->giantlist.as<int32_t>(), ctl, giantCap, l, derr, g->stream);
-				bv::launch_decode_level(gd, s.def, v, g->depth.as<int32_t>(), g->biglist.as<int32_t>(), keyBase, l, g->level_blocks, derr, g->stream);
-			}
-		}
-	}
 	return BVG_OK;
 }
 
@@ -593,7 +547,7 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 	v.succ = succ_dev; v.halo = g->halo.as<int32_t>(); v.succ_cap = succ_cap;
 	int32_t levels = 0;
 	int32_t giantCap = 0;
-	g->early_rowptr = succ_dev && g->overlap && !g->profile && !g->fused ? rowptr_dev : nullptr;
+	g->early_rowptr = succ_dev && g->overlap && !g->profile ? rowptr_dev : nullptr;
 	if (succ_dev) {
 		// arcs of the job, estimated from its share of the bit stream (the true count is still on the device)
 		const int64_t bits = s.h_offsets[to] - s.h_offsets[from - nh], allBits = std::max<int64_t>(s.h_offsets.back(), 1);
