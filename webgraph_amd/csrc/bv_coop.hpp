@@ -51,13 +51,18 @@ constexpr int COOP_B_MIN = 96, COOP_CODES_PER_SEG = 12;
 #ifndef COOP_GIANT_NW
 #define COOP_GIANT_NW 8
 #endif
+#ifndef COOP1_CK
+#define COOP1_CK 20 // gaps a lane of the one-wave decoder keeps from its first parse (a segment holds ~12 codes)
+#endif
 template <int NW> struct CoopCfg { static constexpr int N = 64 * NW, B_MAX = NW == 1 ? COOP1_BMAX : COOPG_BMAX, IVCAP = NW == 1 ? COOP1_IVCAP : COOPG_IVCAP; };
 
 template <int NW> struct CoopLds { // LDS layout of one group, in 32-bit words
 	static constexpr int WIN_WORDS = CoopCfg<NW>::N * CoopCfg<NW>::B_MAX / 32 + 12; // staged tile bits (+ alignment and look-ahead slack), multiple of 4
 	static constexpr int XCH_WORDS = 2 * (3 * NW + 8);                               // int64 exchange slots
 	static constexpr int OFF_WIN = 0, OFF_IVL = WIN_WORDS, OFF_XCH = ((OFF_IVL + 2 * (CoopCfg<NW>::IVCAP + 1) + 1) & ~1); // staged intervals: left[], pstart[]
-	static constexpr int WORDS = OFF_XCH + XCH_WORDS;
+	static constexpr int OFF_CACHE = OFF_XCH + XCH_WORDS;                            // one wave per record: the gaps of the lane's segment, [slot][lane]
+	static constexpr int CACHE_WORDS = NW == 1 ? COOP1_CK * 64 : 0;
+	static constexpr int WORDS = OFF_CACHE + CACHE_WORDS;
 };
 
 struct IvEntry { int32_t left; int32_t pstart; int32_t rank; int32_t len; }; // one interval in the scratch arena
@@ -484,6 +489,86 @@ __device__ __forceinline__ void spec_tile(const Grp<NW> &G, const GraphDev &g, c
 	E = base + (uint64_t)G.bcast((int64_t)e, Grp<NW>::N - 1);
 }
 
+// ---------------------------------------------------------------------------------------------- one wave, lean: gamma lists
+// A tile of a list of gamma codes (copy blocks, interval pairs) by ONE wave with every codeword decoded once: straight-line
+// decoder (two LDS words, branch-free for values < 2^16, one branch to the generic reader otherwise; values saturate at
+// 2^32 - 1, which every caller rejects), the raw values of the lane's first COOP1_CK codes kept in LDS ([slot][lane]) for the
+// passes that interpret them.  Same fixed point as spec_tile: run-in, then every lane adopts its left neighbour's end until
+// the clean prefix of lanes holds the codes the section still needs.
+template <int DEF>
+__device__ __forceinline__ uint32_t w1_gamma(const GraphDev &g, const lds_u32 *lw, const WindowSrc &src, uint32_t &q, int &err) {
+	const uint32_t j = q >> 5, sh = q & 31u;
+	const uint32_t a = lw[j], b = lw[j + 1];
+	const uint32_t W = (uint32_t)(((((uint64_t)a << 32) | b) << sh) >> 32);
+	const uint32_t h = (uint32_t)__clz((int)W); // 32 for W == 0
+	if (__builtin_expect(h < 16, 1)) { q += 2 * h + 1; return (W >> ((31u - 2 * h) & 31u)) - 1; }
+	const SlowCode sc = win_code_slow<DEF, 1>(&g, src.win, src.w0, src.nw, q);
+	q = sc.q; err |= sc.err;
+	return (uint32_t)min<uint64_t>(sc.v, 0xffffffffull);
+}
+struct W1Tile { WindowSrc src; uint32_t s, c, pCK; uint64_t E; }; // start, codes, position behind the cached ones; end of the tile's last code (uniform)
+template <int DEF>
+__device__ __forceinline__ W1Tile w1_gamma_tile(const Grp<1> &G, const GraphDev &g, uint32_t *lds, uint64_t pos, uint64_t secEnd, uint32_t B, int64_t needCodes) {
+	constexpr int CK = COOP1_CK;
+	const int lane = threadIdx.x & 63;
+	uint32_t *win = lds + CoopLds<1>::OFF_WIN;
+	const lds_u32 *lw = (const lds_u32 *)win;
+	lds_u32 *cache = (lds_u32 *)(lds + CoopLds<1>::OFF_CACHE);
+	W1Tile t;
+	t.src = stage_tile<1>(G, g, win, pos, B);
+	const uint64_t base = t.src.w0 << 5;
+	const uint32_t p0 = (uint32_t)(pos - base), secEndR = (uint32_t)min(secEnd - base, (uint64_t)0x7fffff00u);
+	const uint32_t segEnd = min(p0 + (uint32_t)(lane + 1) * B, secEndR);
+	uint32_t s = lane == 0 ? min(p0, secEndR) : min(p0 + (uint32_t)lane * B, secEndR);
+	const uint32_t R = min((uint32_t)COOP_RUNIN_MAX, B >> COOP_RUNIN_SHIFT);
+	if (lane > 0 && s < secEndR && R) { // run-in: lock onto the code boundaries before the segment starts
+		uint32_t p = s - min(R, s - p0);
+		int e2 = 0;
+		while (p < s && !e2) (void)w1_gamma<DEF>(g, lw, t.src, p, e2);
+		s = e2 ? s : min(p, secEndR);
+	}
+	uint32_t e, c, pCK;
+	auto parse = [&]() {
+		c = 0;
+		uint32_t p = s;
+		pCK = s;
+		int e2 = 0; // a speculative parse may run through garbage: errors only stop it
+		while (p < segEnd && !e2) {
+			const uint32_t v = w1_gamma<DEF>(g, lw, t.src, p, e2);
+			if (c < (uint32_t)CK) { cache[c * 64 + lane] = v; pCK = p; }
+			c++;
+		}
+		e = e2 ? secEndR : min(p, secEndR);
+	};
+	parse();
+	for (int round = 0; round < 66; round++) {
+		const uint32_t ns = (uint32_t)__shfl_up((int)e, 1, 64);
+		const bool dirty = lane > 0 && ns != s;
+		const unsigned long long dm = __ballot(dirty);
+		if (!dm) break;
+		{ // the section ends after needCodes codes, somewhere inside the tile: the lanes behind that point parse the NEXT section's
+		  // bits and need not converge; enough that the clean prefix of lanes already holds needCodes codes
+			int32_t ci = (int32_t)c;
+#pragma unroll
+			for (int o = 1; o < 64; o <<= 1) { const int32_t t2 = __shfl_up(ci, o, 64); if (lane >= o) ci += t2; }
+			const int firstDirty = __ffsll((long long)dm) - 1; // >= 1: lane 0 is never dirty
+			if ((int64_t)__shfl(ci, firstDirty - 1, 64) >= needCodes) break;
+		}
+		if (dirty) { s = ns; if (s < segEnd) parse(); else { c = 0; e = s; pCK = s; } }
+	}
+	t.s = s; t.c = c; t.pCK = pCK;
+	t.E = base + (uint64_t)(uint32_t)__shfl((int)e, 63, 64);
+	return t;
+}
+// position behind the lane's first n codes (one lane asks, for the last code of a section)
+template <int DEF>
+__device__ __forceinline__ uint32_t w1_gamma_skip(const GraphDev &g, const lds_u32 *lw, const WindowSrc &src, uint32_t s, uint32_t n) {
+	uint32_t p = s;
+	int e2 = 0;
+	for (uint32_t k = 0; k < n && !e2; k++) (void)w1_gamma<DEF>(g, lw, src, p, e2);
+	return p;
+}
+
 // ---------------------------------------------------------------------------------------------- phase I
 // Decodes the 2*ic gamma codes of the interval section starting at `pos` into arena entries (BVG:1077-1095);
 // returns the bit position after them (start of the residual section) and the number of intervalised arcs.
@@ -547,6 +632,70 @@ __device__ __forceinline__ void coop_intervals(const Grp<NW> &G, const GraphDev 
 		pcount += pTot;
 		codesDone += total;
 		pos = codesDone >= codesAll ? endPos : E;
+	}
+	posAfter = pos;
+	intervalArcs = pcount;
+}
+
+// Phase I by one wave, lean (default codings): the 2 * ic gamma codes of the interval section -> arena entries, every
+// codeword decoded once (w1_gamma_tile keeps the values); same results as coop_intervals.
+template <int DEF>
+__device__ __forceinline__ void coop_intervals_w1(const Grp<1> &G, const GraphDev &g, int32_t x, uint64_t pos, uint64_t recEnd, int64_t ic, int64_t extra, uint32_t B,
+                                                  IvEntry *__restrict__ list, uint32_t *lds, uint64_t &posAfter, int64_t &intervalArcs, int &err) {
+	constexpr int CK = COOP1_CK;
+	const int lane = threadIdx.x & 63;
+	const lds_u32 *lw = (const lds_u32 *)(lds + CoopLds<1>::OFF_WIN);
+	const lds_u32 *cache = (const lds_u32 *)(lds + CoopLds<1>::OFF_CACHE);
+	int64_t codesDone = 0;
+	const int64_t codesAll = 2 * ic;
+	int64_t cursor = x, pcount = 0; // end of the previous interval (the first left is x + nat2int(v)); intervalised arcs so far
+	while (codesDone < codesAll) {
+		const W1Tile t = w1_gamma_tile<DEF>(G, g, lds, pos, recEnd, B, codesAll - codesDone);
+		const uint64_t base = t.src.w0 << 5;
+		uint32_t c = t.c;
+		int64_t tileTotal;
+		const int64_t cincl = G.incl_scan((int64_t)c, tileTotal);
+		const int64_t cb = cincl - c, rem = codesAll - codesDone;
+		if (cb >= rem) c = 0; else if (cb + c > rem) c = (uint32_t)(rem - cb);
+		const int64_t total = min(rem, tileTotal);
+		if (total <= 0) { err |= E_FORMAT; break; }
+		// pass 1 (kept values): what my codes add to the cursor and to the arc count; code q is a left gap (q even) or a length (q odd)
+		int64_t dcur = 0, dp = 0;
+		{
+			uint32_t p = t.pCK;
+			for (uint32_t k = 0; k < c; k++) {
+				const int64_t q = codesDone + cb + k;
+				const uint32_t v = k < (uint32_t)CK ? cache[k * 64 + lane] : w1_gamma<DEF>(g, lw, t.src, p, err);
+				if (q & 1) {
+					if ((uint64_t)v > (uint64_t)extra) err |= E_FORMAT; // (any value in a malformed stream: the sums below must not wrap)
+					const int64_t len = (int64_t)(v & 0x7fffffffu) + g.minInt; dcur += len; dp += len;
+				}
+				else dcur += q == 0 ? nat2int((uint64_t)v) : (int64_t)v + 1;
+			}
+		}
+		int64_t curTot, pTot, icur, ip;
+		G.incl_scan2(dcur, dp, icur, ip, curTot, pTot);
+		int64_t cur = cursor + icur - dcur, pc = pcount + ip - dp;
+		{ // pass 2: the entries
+			uint32_t p = t.pCK;
+			int e2 = 0;
+			for (uint32_t k = 0; k < c; k++) {
+				const int64_t q = codesDone + cb + k;
+				const uint32_t v = k < (uint32_t)CK ? cache[k * 64 + lane] : w1_gamma<DEF>(g, lw, t.src, p, e2);
+				if (q & 1) { const int64_t len = (int64_t)(v & 0x7fffffffu) + g.minInt; list[q >> 1].pstart = (int32_t)pc; list[q >> 1].len = (int32_t)len; cur += len; pc += len; }
+				else { cur += q == 0 ? nat2int((uint64_t)v) : (int64_t)v + 1; list[q >> 1].left = (int32_t)cur; }
+			}
+		}
+		cursor += curTot;
+		pcount += pTot;
+		codesDone += total;
+		if (codesDone >= codesAll) { // the lane that owns the last code knows where the residual section starts
+			const int lastTid = G.last_set(c > 0);
+			uint32_t myEnd = 0;
+			if (lane == lastTid) myEnd = w1_gamma_skip<DEF>(g, lw, t.src, t.s, c);
+			pos = base + (uint64_t)G.bcast((int64_t)myEnd, lastTid);
+		} else pos = t.E;
+		G.sync(); // the window and the value slots are reused by the next tile
 	}
 	posAfter = pos;
 	intervalArcs = pcount;
@@ -682,59 +831,65 @@ constexpr int COPY_COOP_WALK_MIN = 192; // below this many blocks the serial wal
 __device__ __forceinline__ void coop_block_walk(const GraphDev &g, uint64_t pos, uint64_t recEnd, int64_t bc, int64_t dref, int32_t d, int32_t *kend, int32_t *delta, int32_t tabCap,
                                                 uint32_t *lds, int64_t &totalOut, int64_t &copiedOut, int32_t &nKeptOut, int &bad, uint64_t *posAfter = nullptr) {
 	Grp<1> G{ (int64_t *)(lds + CoopLds<1>::OFF_XCH) };
+	constexpr int CK = COOP1_CK;
+	const int lane = threadIdx.x & 63;
+	const lds_u32 *lw = (const lds_u32 *)(lds + CoopLds<1>::OFF_WIN);
+	const lds_u32 *cache = (const lds_u32 *)(lds + CoopLds<1>::OFF_CACHE);
 	const uint32_t B = coop_pick_B(min<uint64_t>(recEnd > pos ? recEnd - pos : 0, (uint64_t)bc * 8), (uint64_t)bc, 64, CoopCfg<1>::B_MAX);
 	int64_t done = 0, total = 0, copied = 0; // uniform
 	int err = 0;
 	while (done < bc) {
-		const WindowSrc src = stage_tile<1>(G, g, lds + CoopLds<1>::OFF_WIN, pos, B);
-		const uint64_t base = src.w0 << 5;
-		uint64_t E; uint32_t s, c; int64_t unused;
-		spec_tile<1, 1, 1>(G, g, src, pos, recEnd, B, false, bc - done, s, c, unused, E);
+		const W1Tile t = w1_gamma_tile<1>(G, g, lds, pos, recEnd, B, bc - done);
+		const uint64_t base = t.src.w0 << 5;
+		uint32_t c = t.c;
 		int64_t tileTotal;
 		const int64_t cincl = G.incl_scan((int64_t)c, tileTotal);
 		const int64_t cb = cincl - c, rem = bc - done;
 		if (cb >= rem) c = 0; else if (cb + c > rem) c = (uint32_t)(rem - cb);
 		const int64_t n = min(rem, tileTotal);
 		if (n <= 0) { err = 1; break; }
-		// pass 1: what my codes add to the referent index and to the number of copied ids
+		// pass 1 (from the kept values): what my codes add to the referent index and to the number of copied ids
 		int64_t dAll = 0, dEven = 0;
-		uint32_t myEnd = s;
 		{
-			uint32_t p = s;
+			uint32_t p = t.pCK;
 			for (uint32_t k = 0; k < c; k++) {
 				const int64_t q = done + cb + k;
-				const uint64_t v = win_code_rel<1, 1>(g, src, p, err);
-				if (v > (uint64_t)dref) err |= 1; // (any 64-bit value in a malformed stream: the sums below must not wrap)
+				const uint32_t v = k < (uint32_t)CK ? cache[k * 64 + lane] : w1_gamma<1>(g, lw, t.src, p, err);
+				if ((uint64_t)v > (uint64_t)dref) err |= 1; // (any value in a malformed stream: the sums below must not wrap)
 				const int64_t len = (int64_t)(v & 0x7fffffffu) + (q ? 1 : 0);
 				dAll += len;
 				if (!(q & 1)) dEven += len;
 			}
-			myEnd = p;
 		}
 		int64_t allTot, evenTot;
 		const int64_t iAll = G.incl_scan(dAll, allTot), iEven = G.incl_scan(dEven, evenTot);
-		int64_t t = total + iAll - dAll, cp = copied + iEven - dEven;
+		int64_t tt = total + iAll - dAll, cp = copied + iEven - dEven;
 		// pass 2: the table entries of my copied blocks
-		{
-			uint32_t p = s;
+		if (tabCap > 0) {
+			uint32_t p = t.pCK;
 			int e2 = 0;
 			for (uint32_t k = 0; k < c; k++) {
 				const int64_t q = done + cb + k;
-				const int64_t len = (int64_t)(win_code_rel<1, 1>(g, src, p, e2) & 0x7fffffffu) + (q ? 1 : 0);
+				const uint32_t v = k < (uint32_t)CK ? cache[k * 64 + lane] : w1_gamma<1>(g, lw, t.src, p, e2);
+				const int64_t len = (int64_t)(v & 0x7fffffffu) + (q ? 1 : 0);
 				if (!(q & 1)) {
 					const int64_t j = q >> 1;
-					if (j < tabCap) { kend[j] = (int32_t)min<int64_t>(cp + len, 0x7fffffff); delta[j] = (int32_t)(t - cp); }
+					if (j < tabCap) { kend[j] = (int32_t)min<int64_t>(cp + len, 0x7fffffff); delta[j] = (int32_t)(tt - cp); }
 					cp += len;
 				}
-				t += len;
+				tt += len;
 			}
 		}
-		const int lastTid = G.last_set(c > 0);
-		const uint64_t endPos = base + (uint64_t)G.bcast((int64_t)myEnd, lastTid);
 		total += allTot;
 		copied += evenTot;
 		done += n;
-		pos = done >= bc ? endPos : E;
+		if (done >= bc) { // the lane that owns the last code of the list knows where the next section starts
+			const int lastTid = G.last_set(c > 0);
+			uint32_t myEnd = 0;
+			if (lane == lastTid) myEnd = w1_gamma_skip<1>(g, lw, t.src, t.s, c);
+			pos = base + (uint64_t)G.bcast((int64_t)myEnd, lastTid);
+		} else pos = t.E;
+		G.sync(); // the window and the value slots are reused by the next tile
 		if (total > dref || copied > d) { err = 1; break; } // (uniform)
 	}
 	if (G.any(err != 0)) { bad = 1; return; }
@@ -753,6 +908,139 @@ __device__ __forceinline__ void coop_block_walk(const GraphDev &g, uint64_t pos,
 	nKeptOut = (int32_t)min<int64_t>((bc >> 1) + 1, 0x7fffffff);
 }
 
+
+// ---------------------------------------------------------------------------------------------- phases R, one wave, lean
+// The residual section of a record decoded by ONE wave with every codeword decoded once where the general version above
+// decodes it up to three times (run-in, counting parse, value pass): the lane keeps the gaps of its first parse in LDS
+// ([slot][lane], COOP1_CK of them) and the value pass only adds them up.  The decoder is straight-line: two LDS words, a
+// branch-free decode of the short codewords (zeta_3 < 2^21, or zeta_k that fits 32 bits), ONE branch to the generic reader
+// for the rest; counts and sums are 32-bit (ids are Java ints: BVG:954, :966 compute in int).  Default codings only.
+template <int DEF>
+__device__ __forceinline__ uint32_t w1_residual(const GraphDev &g, const lds_u32 *lw, const WindowSrc &src, uint32_t &q, int &err) {
+	const uint32_t j = q >> 5, sh = q & 31u;
+	const uint32_t a = lw[j], b = lw[j + 1];
+	const uint32_t W = (uint32_t)(((((uint64_t)a << 32) | b) << sh) >> 32);
+	const uint32_t h = (uint32_t)__clz((int)W); // 32 for W == 0
+	const uint32_t k = DEF == 1 ? 3u : (uint32_t)g.zetaK;
+	const uint32_t nb = k * h + k - 1;
+	const bool ok = DEF == 1 ? h < 7 : (h + 2 + nb <= 32u && nb != 0);
+	const uint32_t mm = (W << ((h + 1) & 31u)) >> ((31u - nb) & 31u); // the nb payload bits plus the extra bit of the long codeword
+	const uint32_t m = mm >> 1, left = 1u << ((k * h) & 31u);
+	const bool lng = m >= left;
+	if (__builtin_expect(ok, 1)) { q += h + 1 + nb + (lng ? 1u : 0u); return lng ? mm - 1 : m + left - 1; }
+	const SlowCode sc = win_code_slow<DEF, 0>(&g, src.win, src.w0, src.nw, q);
+	q = sc.q; err |= sc.err;
+	return (uint32_t)sc.v;
+}
+
+template <int DEF>
+__device__ __forceinline__ void coop_residuals_w1(const GraphDev &g, int32_t x, uint64_t pos, uint64_t recEnd, int64_t nRes64, int64_t ic64, int64_t intervalArcs,
+                                                  IvEntry *__restrict__ list, int32_t *__restrict__ out, uint32_t *lds, int &err) {
+	constexpr int IVCAP = CoopCfg<1>::IVCAP, CK = COOP1_CK;
+	const Grp<1> G{ (int64_t *)(lds + CoopLds<1>::OFF_XCH) };
+	const int lane = threadIdx.x & 63;
+	uint32_t *win = lds + CoopLds<1>::OFF_WIN;
+	const lds_u32 *lw = (const lds_u32 *)win;
+	lds_u32 *ivLeft = (lds_u32 *)(lds + CoopLds<1>::OFF_IVL), *ivP = ivLeft + (IVCAP + 1), *cache = (lds_u32 *)(lds + CoopLds<1>::OFF_CACHE);
+	const int32_t nRes = (int32_t)nRes64, ic = (int32_t)ic64;
+	int32_t ia = 0; // first interval that no residual has passed yet (uniform)
+	const uint32_t B = coop_pick_B(recEnd > pos ? recEnd - pos : 0, (uint64_t)nRes, 64, CoopCfg<1>::B_MAX);
+	const uint32_t R = min((uint32_t)COOP_RUNIN_MAX, B >> COOP_RUNIN_SHIFT);
+	int32_t resDone = 0, baseVal = x;
+	bool firstTile = true;
+	auto wscan = [&](int32_t vv) { // inclusive scan over the wave
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) { const int32_t t = __shfl_up(vv, o, 64); if (lane >= o) vv += t; }
+		return vv;
+	};
+	while (resDone < nRes) {
+		const WindowSrc src = stage_tile<1>(G, g, win, pos, B); // (ends with a wave sync: the interval table above is in place too)
+		const uint64_t base = src.w0 << 5;
+		const uint32_t p0 = (uint32_t)(pos - base), secEndR = (uint32_t)min(recEnd - base, (uint64_t)0x7fffff00u);
+		const uint32_t segEnd = min(p0 + (uint32_t)(lane + 1) * B, secEndR);
+		uint32_t s = lane == 0 ? min(p0, secEndR) : min(p0 + (uint32_t)lane * B, secEndR);
+		if (lane > 0 && s < secEndR && R) { // run-in: lock onto the code boundaries before the segment starts
+			uint32_t p = s - min(R, s - p0);
+			int e2 = 0;
+			while (p < s && !e2) (void)w1_residual<DEF>(g, lw, src, p, e2);
+			s = e2 ? s : min(p, secEndR);
+		}
+		uint32_t e, c, pCK; int32_t sum;
+		auto parse = [&]() { // the codes that start in [s, segEnd): count, what they add to the running id, end; the first CK gaps kept
+			c = 0; sum = 0;
+			uint32_t p = s;
+			pCK = s;
+			int e2 = 0; // a speculative parse may run through garbage: errors only stop it
+			while (p < segEnd && !e2) {
+				const uint32_t cv = w1_residual<DEF>(g, lw, src, p, e2);
+				const int32_t add = (firstTile && lane == 0 && c == 0) ? (int32_t)nat2int(cv) : (int32_t)cv + 1; // BVG:954 / :966
+				if (c < (uint32_t)CK) { cache[c * 64 + lane] = (uint32_t)add; pCK = p; }
+				sum += add; c++;
+			}
+			e = e2 ? secEndR : min(p, secEndR);
+		};
+		parse();
+		for (int round = 0; round < 66; round++) { // a segment starts where its left neighbour ended
+			uint32_t ns = (uint32_t)__shfl_up((int)e, 1, 64);
+			const bool dirty = lane > 0 && ns != s;
+			if (!__any(dirty)) break;
+			if (dirty) { s = ns; if (s < segEnd) parse(); else { c = 0; sum = 0; e = s; } }
+		}
+		const int32_t cincl = wscan((int32_t)c), sincl = wscan(sum);
+		const int32_t tileTotal = __shfl(cincl, 63, 64);
+		const int32_t cb = cincl - (int32_t)c, lim = nRes - resDone;
+		int32_t cn = (int32_t)c;
+		if (cb >= lim) cn = 0; else if (cb + cn > lim) cn = lim - cb; // no more codes than the section still has
+		const int32_t T = min(lim, tileTotal);
+		if (T <= 0) { err |= E_FORMAT; break; }
+		int32_t val = baseVal + sincl - sum; // the residual before my first one
+		// ---- the intervals that can fall among this tile's residuals -> LDS: [ia, first left >= the tile's last value), IVCAP at most
+		int32_t staged = 0;
+		if (ic > ia) {
+			const bool lastTile = tileTotal >= lim;
+			const int32_t hiVal = lastTile ? 0x7fffffff : baseVal + __shfl(sincl, 63, 64);
+			for (int32_t b0 = 0; b0 < IVCAP; b0 += 64) {
+				const int32_t i = ia + b0 + lane;
+				int32_t l = 0x7fffffff, pp = (int32_t)intervalArcs;
+				if (i < ic) { l = list[i].left; pp = list[i].pstart; }
+				ivLeft[b0 + lane] = (uint32_t)l; ivP[b0 + lane] = (uint32_t)pp;
+				staged = b0 + 64;
+				if (__popcll(__ballot(i < ic && l < hiVal)) < 64) break;
+			}
+			staged = min(staged, ic - ia);
+			G.sync();
+		}
+		auto iv_left = [&](int32_t i) -> int32_t { if (i >= ic) return 0x7fffffff; const int32_t o = i - ia; if (__builtin_expect(o < staged, 1)) return (int32_t)ivLeft[o]; return iv_field_slow(list, i, 0); };
+		auto iv_p = [&](int32_t i) -> int32_t { if (i >= ic) return (int32_t)intervalArcs; const int32_t o = i - ia; if (__builtin_expect(o < staged, 1)) return (int32_t)ivP[o]; return iv_field_slow(list, i, 1); };
+		// ---- my run of residuals at their final places, between the intervals
+		int32_t jj = resDone + cb, ii = ia;
+		if (cn && ic > ia && !(firstTile && lane == 0)) { // first interval that the residuals before mine have not passed
+			int32_t lo2 = ia, hi2 = ic;
+			while (lo2 < hi2) { const int32_t mid = (lo2 + hi2) >> 1; if (iv_left(mid) < val) lo2 = mid + 1; else hi2 = mid; }
+			ii = lo2;
+		}
+		int32_t before = ic ? iv_p(ii) : 0, nextLeft = (cn && ic) ? iv_left(ii) : 0x7fffffff;
+		uint32_t p = pCK;
+		for (int32_t k2 = 0; k2 < cn; k2++) {
+			const int32_t add = k2 < CK ? (int32_t)cache[k2 * 64 + lane] : (int32_t)w1_residual<DEF>(g, lw, src, p, err) + 1;
+			val += add;
+			if (nextLeft < val) {
+				do { list[ii].rank = jj; ii++; nextLeft = iv_left(ii); } while (nextLeft < val); // interval ii sits after jj residuals
+				before = iv_p(ii);
+			}
+			out[jj + before] = val;
+			jj++;
+		}
+		const unsigned long long has = __ballot(cn > 0);
+		const int lastL = has ? 63 - __clzll((long long)has) : 0;
+		baseVal = __shfl(val, lastL, 64);
+		ia = has ? __shfl(ii, lastL, 64) : ia; // everything before it has been ranked
+		resDone += T;
+		pos = base + (uint64_t)(uint32_t)__shfl((int)e, 63, 64);
+		firstTile = false;
+		G.sync(); // the window and the gap slots are reused by the next tile
+	}
+}
 
 // The whole record of node x by one group.  Same contract as parse_node: extras merged into row[copied..d).
 template <int DEF, int NW>
@@ -822,7 +1110,8 @@ __device__ __forceinline__ void coop_parse_node(const GraphDev &g, int32_t x, in
 			const uint64_t restBits = recEnd > pos ? recEnd - pos : 0, restCodes = (uint64_t)(2 * ic + (extra - ic * g.minInt));
 			const uint64_t secEst = min(restBits, (restBits * (uint64_t)(2 * ic) + restCodes - 1) / restCodes * 2); // x2: interval gaps are longer than residual gaps
 			const uint32_t B = coop_pick_B(secEst, (uint64_t)(2 * ic), Grp<NW>::N, CoopCfg<NW>::B_MAX);
-			coop_intervals<DEF, NW>(G, g, x, pos, recEnd, ic, extra, B, list, lds, pos, intervalArcs, err);
+			if constexpr (NW == 1 && DEF != 0) coop_intervals_w1<DEF>(G, g, x, pos, recEnd, ic, extra, B, list, lds, pos, intervalArcs, err);
+			else coop_intervals<DEF, NW>(G, g, x, pos, recEnd, ic, extra, B, list, lds, pos, intervalArcs, err);
 			if (G.any(err != 0)) { if (err) atomicOr(errOut, err); return; } // group-uniform exit
 		}
 	}
@@ -832,7 +1121,29 @@ __device__ __forceinline__ void coop_parse_node(const GraphDev &g, int32_t x, in
 	// default rank: the interval follows every residual (phase R fixes up the others)
 	for (int64_t i = tid; i < ic; i += Grp<NW>::N) list[i].rank = (int32_t)nRes;
 	G.sync_global();
-	coop_residuals<DEF, NW>(G, g, x, pos, recEnd, nRes, ic, intervalArcs, list, row + copied, lds, err);
+	if (NW == 1 && DEF != 0 && ic < 0x7fffffff && nRes < 0x7fffffff) { // one wave, default codings: every codeword decoded once
+		if (nRes > 0) coop_residuals_w1<DEF>(g, x, pos, recEnd, nRes, ic, intervalArcs, list, row + copied, lds, err);
+		if (ic > 0) { // phase X: interval i occupies out[pstart + rank .. + len)  (IntIntervalSequenceIterator.java:64-78)
+			G.sync_global();
+			int32_t *out = row + copied;
+			for (int64_t i0 = 0; i0 < ic; i0 += 64) {
+				const int64_t i = i0 + tid;
+				int32_t left = 0, len = 0; int64_t p = 0;
+				if (i < ic) { const IvEntry en = list[i]; left = en.left; len = en.len; p = (int64_t)en.pstart + en.rank; }
+				const bool isLong = len > 16;
+				if (!isLong) for (int32_t t = 0; t < len; t++) out[p + t] = left + t;
+				unsigned long long lm = __ballot(isLong);
+				while (lm) {
+					const int srcl = __ffsll((long long)lm) - 1;
+					lm &= lm - 1;
+					const int32_t L = __shfl(left, srcl, 64), Nn = __shfl(len, srcl, 64);
+					const int64_t P = shfl_i64(p, srcl);
+					for (int32_t t = G.lane(); t < Nn; t += 64) out[P + t] = L + t;
+				}
+			}
+		}
+	}
+	else coop_residuals<DEF, NW>(G, g, x, pos, recEnd, nRes, ic, intervalArcs, list, row + copied, lds, err);
 	COOP_TICK(2);
 #undef COOP_TICK
 	if (err) atomicOr(errOut, err);

@@ -13,6 +13,8 @@
 
 namespace bv {
 
+typedef __attribute__((address_space(3))) uint32_t lds_u32; // a word in LDS: accesses through it are ds_* instructions, never flat ones
+
 // CompressionFlags.java:26-44
 enum : int { C_DELTA = 1, C_GAMMA = 2, C_GOLOMB = 3, C_SKEWED_GOLOMB = 4, C_UNARY = 5, C_ZETA = 6, C_NIBBLE = 7 };
 

@@ -28,8 +28,6 @@ constexpr int TILE_NODES = TILE_SPAN / TILE_NODE_BITS;
 constexpr int TILE_WIN_WORDS = TILE_SPAN / 32 + 256; // staged words: the slice, 1 KB of overhang for the last record, look-ahead
 constexpr int TILE_NBIN = 32;
 
-typedef __attribute__((address_space(3))) uint32_t lds_u32;
-
 struct TWin {
 	const lds_u32 *win; // staged words, byte-swapped (first stream bit = bit 31)
 	uint32_t nw;        // staged words
