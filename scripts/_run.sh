@@ -1,7 +1,5 @@
-mkdir -p gpurun_out
-BVGPU_TILE=2 timeout 100 python scripts/dbg_ctile.py 20000 400000 2>&1 | grep -v amdgpu.ids | tail -3
-BVGPU_TILE=2 timeout 100 python scripts/dbg_ctile.py 1500000 30000000 2>&1 | grep -v amdgpu.ids | tail -3
-for w in c2 cnr30; do
-  BVGPU_TILE=2 timeout 200 python scripts/ab_time.py $w
-done 2>&1 | grep -v amdgpu.ids | tee gpurun_out/ab6.log
-BVGPU_TILE=2 timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 > gpurun_out/t6.log 2>&1; tail -3 gpurun_out/t6.log
+cd /root/repo
+timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+timeout 200 python scripts/host_path_time.py 2>&1 | tail -5
+for v in "" "BVGPU_DBG=32"; do env $v timeout 300 python scripts/ab_time.py c5 5 2>&1 | grep -v amdgpu.ids | tail -1; done
+timeout 300 python scripts/ab_time.py c2 10 2>&1 | tail -1

@@ -77,6 +77,16 @@ def test_scan_checksum(cnr_gpu, cnr_oracle):
         cnr_gpu.scan_checksum(5, n + 1)
 
 
+def test_scans_in_pieces(cnr_gpu, cnr_oracle, monkeypatch):
+    """The device-side scans cut a range into pieces of bounded scratch (256 M arcs by default): same answers in 20 pieces."""
+    monkeypatch.setenv("BVGPU_SCAN_PIECE", "170000")
+    n = cnr_gpu.numNodes()
+    assert cnr_gpu.scan_checksum() == (1711395807, 3216152)
+    whole = cnr_gpu.scan_stats(0, n)
+    monkeypatch.delenv("BVGPU_SCAN_PIECE")
+    assert cnr_gpu.scan_stats(0, n) == whole
+
+
 def test_split_iterators_drained_by_concurrent_threads(cnr_gpu, cnr_oracle):
     """The reference hands the iterators of splitNodeIterators to one thread each (BVGraph.java:2471-2477).  Each copy
     decodes through its own bvg_clone; small batches so that every thread makes many calls while the others do."""

@@ -602,7 +602,9 @@ template <int DEF>
 __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ queue,
                                                                const int32_t *__restrict__ count, int32_t cap, int32_t level, int32_t *__restrict__ tmp, uint32_t tmpCap,
                                                                uint32_t *__restrict__ tmpCursor, int *__restrict__ err) {
-	__shared__ int32_t cval[COPY_BIG_CAP], cpos[COPY_BIG_CAP + 1], delta[COPY_BIG_CAP + 1];
+	__shared__ int32_t tabs[3 * COPY_BIG_CAP + 2];
+	int32_t *const cval = tabs, *const cpos = tabs + COPY_BIG_CAP, *const delta = tabs + 2 * COPY_BIG_CAP + 1;
+	__shared__ int32_t s_b[2];
 	__shared__ uint32_t lwin[DEF ? LW_MAIN * LW_STRIDE : 1]; // stream window of the wave that walks the block list
 	__shared__ __attribute__((aligned(16))) uint32_t cwin[DEF ? CoopLds<1>::WORDS : 4]; // tile of the cooperative walk of a long block list
 	__shared__ int64_t s_copied, s_tmp, s_kmax;
@@ -716,6 +718,85 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 			for (int32_t t = threadIdx.x; t < nc; t += COPY_BIG_THREADS) row[cp_[t]] = cv_[t];
 			CT(4);
 		};
+		// The same merge for a row whose tables (kend, dlt) and copied ids (cv_) live in global scratch.  Nothing here searches
+		// global memory element by element (a row of 300 000 ids spent 4 ms in such searches): the copied ids are gathered
+		// tile by tile with the tile's slice of the block tables in LDS; then the OUTPUT is cut into tiles of STREAM_TS ids --
+		// one diagonal search per tile boundary, all boundaries at once, says how many copied ids precede it (merge path) --
+		// and each tile's copied ids and extras are ranked against each other in LDS.  In place: tile k overwrites
+		// row[p0..p1), which held extras with index < p1 - nc <= j1, all read by then; tile k + 1 is on its way meanwhile.
+		auto merge_row_stream = [&](const int32_t *kend, const int32_t *dlt, int32_t *cv_, int32_t nc, int32_t nKept) {
+			constexpr int32_t GT = 4096, TS = 8192, ITEMS = TS / COPY_BIG_THREADS;
+			const int32_t nExtra = d - nc;
+			int32_t *bufK = tabs, *bufD = tabs + GT + 1;
+			for (int32_t t0 = 0; t0 < nc; t0 += GT) {
+				const int32_t t1 = min(nc, t0 + GT);
+				__syncthreads(); // the buffers are free
+				if (threadIdx.x < 2) {
+					const int32_t target = threadIdx.x ? t1 - 1 : t0;
+					int32_t lo = 0, hi = nKept;
+					while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (kend[mid] <= target) lo = mid + 1; else hi = mid; }
+					s_b[threadIdx.x] = lo;
+				}
+				__syncthreads();
+				const int32_t b0 = s_b[0], nb = min(s_b[1] - b0 + 1, GT + 1); // (blocks after the first are non-empty: at most one per id of the tile)
+				for (int32_t k = threadIdx.x; k < nb; k += COPY_BIG_THREADS) { bufK[k] = kend[b0 + k]; bufD[k] = dlt[b0 + k]; }
+				__syncthreads();
+				for (int32_t t = t0 + (int32_t)threadIdx.x; t < t1; t += COPY_BIG_THREADS) {
+					int32_t lo = 0, hi = nb - 1;
+					while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (bufK[mid] <= t) lo = mid + 1; else hi = mid; }
+					cv_[t] = src[t + bufD[lo]];
+				}
+			}
+			CT(1);
+			int32_t *buf = tabs, *splits = tabs + TS;
+			int32_t iBase = 0;
+			for (int32_t base = 0; base < d; base += COPY_BIG_THREADS * TS) {
+				const int32_t ntl = (int32_t)min<int64_t>(COPY_BIG_THREADS, ((int64_t)d - base + TS - 1) / TS);
+				__syncthreads(); // cv_ is complete (first round) / the last tile of the previous round is out
+				for (int32_t k = threadIdx.x; k <= ntl; k += COPY_BIG_THREADS) {
+					const int32_t p = (int32_t)min<int64_t>(d, (int64_t)base + (int64_t)k * TS);
+					// copied ids among the first p of the merge; extras below index base - iBase are gone: i(p) <= iBase + (p - base)
+					int32_t lo = max(max(0, p - nExtra), iBase), hi = min(min(p, nc), iBase + (p - base));
+					while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (cv_[mid] < row[nc + (p - 1 - mid)]) lo = mid + 1; else hi = mid; }
+					splits[k] = lo;
+				}
+				__syncthreads();
+				CT(2);
+				int32_t x[ITEMS];
+				auto fetch = [&](int32_t k) {
+					const int32_t p0 = base + k * TS, p1 = (int32_t)min<int64_t>(d, (int64_t)p0 + TS);
+					const int32_t i0 = splits[k], ni = splits[k + 1] - i0, j0 = p0 - i0, tot = p1 - p0;
+#pragma unroll
+					for (int u = 0; u < ITEMS; u++) { const int32_t t = u * COPY_BIG_THREADS + (int32_t)threadIdx.x; x[u] = t < ni ? cv_[i0 + t] : t < tot ? row[nc + j0 + (t - ni)] : 0; }
+				};
+				if (splits[0] < nc) fetch(0);
+				for (int32_t k = 0; k < ntl; k++) {
+					const int32_t p0 = base + k * TS, p1 = (int32_t)min<int64_t>(d, (int64_t)p0 + TS);
+					const int32_t i0 = splits[k], ni = splits[k + 1] - i0, tot = p1 - p0;
+					if (i0 >= nc) break; // every copied id is placed: the remaining extras are where they belong
+					__syncthreads(); // the previous tile's searches are done
+#pragma unroll
+					for (int u = 0; u < ITEMS; u++) buf[u * COPY_BIG_THREADS + threadIdx.x] = x[u];
+					__syncthreads();
+					int32_t y[ITEMS];
+#pragma unroll
+					for (int u = 0; u < ITEMS; u++) y[u] = x[u];
+					if (k + 1 < ntl && splits[k + 1] < nc) fetch(k + 1); // reads only what no tile before it overwrites
+#pragma unroll
+					for (int u = 0; u < ITEMS; u++) {
+						const int32_t t = u * COPY_BIG_THREADS + (int32_t)threadIdx.x;
+						if (t >= tot) continue;
+						int32_t lo, hi, self;
+						if (t < ni) { lo = ni; hi = tot; self = t - ni; }
+						else { lo = 0; hi = ni; self = t - ni; }
+						while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (buf[mid] < y[u]) lo = mid + 1; else hi = mid; }
+						row[p0 + self + lo] = y[u];
+					}
+				}
+				iBase = splits[ntl];
+				CT(3);
+			}
+		};
 		// Where the tables live is decided BEFORE the walk (a long block list is the serial part of the row: it is walked once):
 		// at most bc / 2 + 1 blocks are copied and at most min(dref, d) ids, so a referent of up to COPY_BIG_CAP ids with a
 		// block list of up to 2 * COPY_BIG_CAP codes fits the LDS tables for sure; everything else gets tables in global
@@ -754,8 +835,8 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 		if (where == -2) { merge_row(cpos, delta, cval, cpos, (int32_t)copied, nKept); continue; } // (copied <= dref <= COPY_BIG_CAP, nKept <= COPY_BIG_CAP + 1)
 		const int64_t cMaxRow = dref < (int64_t)d ? dref : (int64_t)d;
 		if (nKept > kMax || copied > cMaxRow) continue; // (cannot happen: the bounds above)
-		int32_t *gv = tabD + kMax, *gp = gv + cMaxRow;
-		merge_row(tabK, tabD, gv, gp, (int32_t)copied, nKept);
+		if (g.dbg & 32) { int32_t *gv = tabD + kMax, *gp = gv + cMaxRow; merge_row(tabK, tabD, gv, gp, (int32_t)copied, nKept); continue; } // (the element-wise merge on global tables, kept for A/B timing: BVGPU_DBG=32)
+		merge_row_stream(tabK, tabD, tabD + kMax, (int32_t)copied, nKept);
 #undef CT
 	}
 }

@@ -15,6 +15,7 @@
 #include <memory>
 #include <string>
 #include <thread>
+#include <chrono>
 #include <vector>
 
 namespace {
@@ -130,6 +131,7 @@ struct bvg_graph {
 	DevBuf stats; // BVGPU_STATS=1: tuning counters
 	// the three parse kernels (giant / big / short records) are independent: they run on forked streams
 	hipStream_t sideA = nullptr, sideB = nullptr; // (more streams than this share hardware queues with each other: they would serialise)
+	bool host_mode = false;                       // host_scan: sideB carries the PCIe copies, its kernels go to sideA
 	hipEvent_t evFork = nullptr, evA = nullptr, evB = nullptr, evC = nullptr, evHdr = nullptr, evP = nullptr;
 	bool overlap = true;
 	size_t halo_min = (size_t)16 << 20; // bytes of halo scratch an optimistic sub-range decode starts with (BVGPU_HALO_MIN)
@@ -216,7 +218,8 @@ int init_handle(bvg_graph *g) {
 	if (const char *e = getenv("BVGPU_BATCH_DENSE")) g->batch_dense = std::max(0, atoi(e));
 	HIPCHK(g, hipStreamCreateWithFlags(&g->sideA, hipStreamNonBlocking));
 	HIPCHK(g, hipStreamCreateWithFlags(&g->sideB, hipStreamNonBlocking));
-	HIPCHK(g, hipStreamCreateWithFlags(&g->copyStream, hipStreamNonBlocking));
+	g->copyStream = g->sideB; // a fourth stream would share a hardware queue with one of the other three (GPU_MAX_HW_QUEUES = 4, one is the null stream's):
+	                          // its copies then hold back the kernels queued behind them -- measured: every chunk of a host scan took decode + copy, 25 ms instead of 17
 	for (int i = 0; i < 2; i++) { HIPCHK(g, hipEventCreateWithFlags(&g->evChunk[i], hipEventDisableTiming)); HIPCHK(g, hipEventCreateWithFlags(&g->evCopied[i], hipEventDisableTiming)); }
 	HIPCHK(g, hipEventCreateWithFlags(&g->evFork, hipEventDisableTiming));
 	HIPCHK(g, hipEventCreateWithFlags(&g->evIn, hipEventDisableTiming));
@@ -272,6 +275,8 @@ int join_to_user(bvg_graph *g) {
 	return BVG_OK;
 }
 
+inline hipStream_t side_b(const bvg_graph *g) { return g->host_mode ? g->sideA : g->sideB; }
+
 int fetch_small(bvg_graph *g) {
 	HIPCHK(g, hipMemcpyAsync(g->h_small, g->small.p, sizeof(Small), hipMemcpyDeviceToHost, g->stream));
 	HIPCHK(g, hipStreamSynchronize(g->stream));
@@ -313,7 +318,7 @@ int finish_pending(bvg_graph *g, uint64_t *arcs_out) {
 					const bool ov2 = g->overlap && !g->profile;
 					bv::launch_copy_level(gd, s.def, g->pend.view, g->depth.as<int32_t>(), g->lvlist.as<int32_t>(), keyBase, l, g->level_blocks, g->copy_mid_min, g->copy_big != 0,
 					                      g->copyq.as<int32_t>(), g->pend.bigCap, g->copyq.as<int32_t>() + g->pend.bigCap, g->pend.midCap, g->coopctl.as<int32_t>(), g->bigtmp.as<int32_t>(), g->pend.tmpCap, derr,
-					                      g->stream, ov2 ? g->sideB : g->stream, ov2 ? g->sideA : g->stream, g->evFork, g->evB, g->evA);
+					                      g->stream, ov2 ? side_b(g) : g->stream, ov2 ? g->sideA : g->stream, g->evFork, g->evB, g->evA);
 				}
 				else bv::launch_copy(gd, s.def, g->pend.view, g->depth.as<int32_t>(), l, derr, g->stream);
 			}
@@ -414,29 +419,29 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		}
 		if (ovl) {
 			if (early) { // side B: classification and sort of the long records next to the scan (they need the outdegrees only)
-				HIPCHK(g, hipStreamWaitEvent(g->sideB, g->evHdr, 0));
-				HIPCHK(g, hipMemsetAsync(ctl, 0, 4 * sizeof(int32_t), g->sideB));
-				bv::launch_classify(v.cnt, v.outd, coopMin, giantMin, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, g->sideB);
-				HIPCHK(g, hipEventRecord(g->evC, g->sideB));
+				HIPCHK(g, hipStreamWaitEvent(side_b(g), g->evHdr, 0));
+				HIPCHK(g, hipMemsetAsync(ctl, 0, 4 * sizeof(int32_t), side_b(g)));
+				bv::launch_classify(v.cnt, v.outd, coopMin, giantMin, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, side_b(g));
+				HIPCHK(g, hipEventRecord(g->evC, side_b(g)));
 			}
 			HIPCHK(g, hipEventRecord(g->evFork, g->stream));
 			HIPCHK(g, hipStreamWaitEvent(g->sideA, g->evFork, 0));
-			HIPCHK(g, hipStreamWaitEvent(g->sideB, g->evFork, 0));
+			HIPCHK(g, hipStreamWaitEvent(side_b(g), g->evFork, 0));
 			stLists = g->sideA;
 			if (g->early_rowptr) { // the caller's rowptr needs the scan only: written now, not at the end of the call
 				bv::launch_rebase(v.nh, v.cnt, v.rowstart, g->early_rowptr, g->sideA);
 				hipLaunchKernelGGL(k_totals, dim3(1), dim3(1), 0, g->sideA, v.rowstart, v.nh, v.cnt, g->small.as<Small>());
 			}
 			if (coop && !early) {
-				bv::launch_classify(v.cnt, v.outd, coopMin, giantMin, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, g->sideB);
-				HIPCHK(g, hipEventRecord(g->evC, g->sideB));
+				bv::launch_classify(v.cnt, v.outd, coopMin, giantMin, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, side_b(g));
+				HIPCHK(g, hipEventRecord(g->evC, side_b(g)));
 			}
 		}
 		// the long records first on both side streams: giants on B, the wave class on A ...
 		if (ovl && coop) {
 			HIPCHK(g, hipStreamWaitEvent(g->sideA, g->evC, 0));
-			bv::launch_parse_big(gd, s.def, v, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, g->giant_groups, derr, g->sideB, g->sideA); // (giants, big)
-			HIPCHK(g, hipEventRecord(g->evB, g->sideB));
+			bv::launch_parse_big(gd, s.def, v, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, g->giant_groups, derr, side_b(g), g->sideA); // (giants, big)
+			HIPCHK(g, hipEventRecord(g->evB, side_b(g)));
 		}
 		// ... then, behind the wave class, the chain depth of every record + per-level lists (node order inside a level) +
 		// copy queues: only the copy pass needs them, and launched first they would sit in front of the wave class while
@@ -484,7 +489,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			for (int32_t l = 1; l <= levels; l++) {
 				if (g->copy_lists) bv::launch_copy_level(gd, s.def, v, g->depth.as<int32_t>(), g->lvlist.as<int32_t>(), keyBase, l, g->level_blocks, g->copy_mid_min, g->copy_big != 0,
 				                                          g->copyq.as<int32_t>(), bigCap, g->copyq.as<int32_t>() + bigCap, midCap, ctl, g->bigtmp.as<int32_t>(), g->pend.tmpCap, derr,
-				                                          g->stream, ovl ? g->sideB : g->stream, ovl ? g->sideA : g->stream, g->evFork, g->evB, g->evA);
+				                                          g->stream, ovl ? side_b(g) : g->stream, ovl ? g->sideA : g->stream, g->evFork, g->evB, g->evA);
 				else bv::launch_copy(gd, s.def, v, g->depth.as<int32_t>(), l, derr, g->stream); // sweep in node order: rows of neighbouring nodes are neighbours in memory
 			}
 		}
@@ -754,7 +759,6 @@ extern "C" int bvg_close(bvg_t *g) {
 		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist, &g->plist, &g->pkeys, &g->pkey16, &g->copyq, &g->bigtmp, &g->tilebounds, &g->ctilebounds, &g->ref2 }) b->release();
 		for (DevBuf *b : { &g->hchunk[0], &g->hchunk[1], &g->statsbuf, &g->bfs_rowptr, &g->bfs_succ, &g->bfs_ctr }) b->release();
 		for (PinBuf *b : { &g->hring[0], &g->hring[1], &g->view_rowptr, &g->view_succ }) b->release();
-		if (g->copyStream) { (void)hipStreamSynchronize(g->copyStream); (void)hipStreamDestroy(g->copyStream); }
 		for (hipEvent_t e : { g->evChunk[0], g->evChunk[1], g->evCopied[0], g->evCopied[1] }) if (e) (void)hipEventDestroy(e);
 		if (g->h_small) (void)hipHostFree(g->h_small);
 		for (auto &e : g->ev) if (e) (void)hipEventDestroy(e);
@@ -877,6 +881,12 @@ std::vector<int32_t> plan_chunks_by_bits(const Staged &s, int32_t from, int32_t 
 	return b;
 }
 
+// Arcs per piece of the scans that keep their rows on the device (checksum, statistics).  BVGPU_SCAN_PIECE: tests only.
+int64_t scan_piece_arcs() {
+	if (const char *e = getenv("BVGPU_SCAN_PIECE")) { const long long v = atoll(e); if (v > 0) return (int64_t)v; }
+	return (int64_t)256 << 20;
+}
+
 // Host-output scan in ONE pass: the structure (outdegrees, CSR row starts) of the whole range first -- that is the
 // rowptr the caller gets and the exact chunk plan --, then the successors chunk by chunk: chunk k leaves over PCIe on the
 // copy stream while chunk k+1 is being decoded.  rowptr_h: to-from+1 entries (host); succ_h may be NULL (count only).
@@ -884,12 +894,17 @@ int host_scan(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_h, int32_t
 	const Staged &s = *g->st;
 	HIPCHK(g, hipSetDevice(s.device));
 	const size_t nrow = (size_t)(to - from) + 1;
+	static const bool trace = getenv("BVGPU_TRACE_HOST") != nullptr;
+	const auto t0 = std::chrono::steady_clock::now();
+	auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
 	if (!g->stage_rowptr.need(sizeof(int64_t) * nrow)) return fail(g, BVG_ENOMEM, "staging allocation failed");
 	uint64_t arcs = 0;
 	int rc = decode_range_device(g, from, to, g->stage_rowptr.as<int64_t>(), nullptr, 0, false, &arcs);
 	if (rc) return rc;
 	if (arcs_out) *arcs_out = arcs;
+	if (trace) fprintf(stderr, "[host_scan] %.2f ms structure pass done\n", ms());
 	HIPCHK(g, hipMemcpy(rowptr_h, g->stage_rowptr.p, sizeof(int64_t) * nrow, hipMemcpyDeviceToHost));
+	if (trace) fprintf(stderr, "[host_scan] %.2f ms rowptr on the host\n", ms());
 	if (!succ_h || arcs == 0) return BVG_OK;
 	if (arcs > succ_cap) return fail(g, BVG_ECAP, "successor buffer too small");
 	// chunks of ~1/8 of the range, between 4 M and 32 M arcs: cut where the (exact) row starts say
@@ -913,11 +928,17 @@ int host_scan(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_h, int32_t
 	for (size_t k = 0; k + 1 < cut.size(); k++) maxNodes = std::max(maxNodes, cut[k + 1] - cut[k]);
 	if (!g->stage_rowptr.need(sizeof(int64_t) * ((size_t)maxNodes + 1))) return fail(g, BVG_ENOMEM, "staging allocation failed");
 	struct Out { int32_t *dst; const int32_t *src; size_t bytes; bool live = false; } out[2];
+	struct HostMode { // the copies own sideB until the last one has landed (also on the error paths)
+		bvg_graph *g;
+		explicit HostMode(bvg_graph *g_) : g(g_) { g->host_mode = true; }
+		~HostMode() { (void)hipStreamSynchronize(g->sideB); g->host_mode = false; }
+	} hostMode(g);
 	for (size_t k = 0; k + 1 < cut.size(); k++) {
 		const int b = (int)(k & 1);
 		const int32_t a = cut[k], e = cut[k + 1];
 		const uint64_t want = (uint64_t)(rowptr_h[e - from] - rowptr_h[a - from]);
 		if (out[b].live) HIPCHK(g, hipEventSynchronize(g->evCopied[b])); // chunk k-2 has left device buffer b
+		if (trace) fprintf(stderr, "[host_scan] %.2f ms chunk %zu: buffer free, decode starts (%llu arcs)\n", ms(), k, (unsigned long long)want);
 		rc = decode_range_device(g, a, e, g->stage_rowptr.as<int64_t>(), g->hchunk[b].as<int32_t>(), (size_t)std::max<uint64_t>(want, 1), true, nullptr);
 		if (rc) return rc;
 		// while the GPU decodes: chunk k-2 goes from the ring to a pageable destination (host threads)
@@ -927,6 +948,7 @@ int host_scan(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_h, int32_t
 		rc = finish_pending(g, &got);
 		if (rc) return rc;
 		if (got != want) return fail(g, BVG_EFORMAT, "a chunk decoded to another number of arcs than the scan counted");
+		if (trace) fprintf(stderr, "[host_scan] %.2f ms chunk %zu decoded\n", ms(), k);
 		if (want == 0) continue;
 		HIPCHK(g, hipEventRecord(g->evChunk[b], g->stream));
 		HIPCHK(g, hipStreamWaitEvent(g->copyStream, g->evChunk[b], 0));
@@ -942,6 +964,7 @@ int host_scan(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_h, int32_t
 		HIPCHK(g, hipEventSynchronize(g->evCopied[b]));
 		if (!pinned) parallel_memcpy(out[b].dst, out[b].src, out[b].bytes);
 		out[b].live = false;
+		if (trace) fprintf(stderr, "[host_scan] %.2f ms chunk %zu on the host\n", ms(), k);
 	}
 	g->last_arcs = arcs;
 	return BVG_OK;
@@ -994,9 +1017,10 @@ extern "C" int bvg_scan_checksum(bvg_t *g, int32_t from, int32_t to, int32_t *ha
 	const Staged &s = *g->st;
 	if (from < 0 || from > s.info.nodes || to < from || to > s.info.nodes) return fail(g, BVG_EARG, "node range out of bounds"); // BVG:1165
 	HIPCHK(g, hipSetDevice(s.device));
-	// The rows never reach the caller: they are decoded piece by piece into one scratch buffer that stays on the die
-	// (<= 32 M arcs = 128 MB, half the Infinity Cache) and folded into the running hash there.
-	const std::vector<int32_t> cut = plan_chunks_by_bits(s, from, to, (int64_t)32 << 20);
+	// The rows never reach the caller: they are decoded piece by piece into one scratch buffer and folded into the running
+	// hash there.  Pieces of <= 256 M arcs (1 GB of scratch): smaller ones that would stay in the Infinity Cache (32 M arcs)
+	// cost more in per-call set-up than they save (C2: 12.2 ms in 7 pieces, 4 ms in one).
+	const std::vector<int32_t> cut = plan_chunks_by_bits(s, from, to, scan_piece_arcs());
 	uint64_t total = 0;
 	int32_t h = *hash_io;
 	for (size_t k = 0; k + 1 < cut.size(); k++) {
@@ -1186,7 +1210,7 @@ extern "C" int bvg_successors_batch(bvg_t *g, const int32_t *nodes, size_t q, in
 		int32_t *ctl = g->coopctl.as<int32_t>();
 		HIPCHK(g, hipMemsetAsync(ctl, 0, 8 * sizeof(int32_t), g->stream));
 		bv::launch_bparse_big(gd, s.def, v, coopMin, giantMin, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, g->arena.p, arenaCap,
-		                      g->coop_waves, g->giant_groups, &dsm->err, g->stream, ovl ? g->sideB : g->stream, ovl ? g->sideA : g->stream, g->evFork, g->evB, g->evA);
+		                      g->coop_waves, g->giant_groups, &dsm->err, g->stream, ovl ? side_b(g) : g->stream, ovl ? g->sideA : g->stream, g->evFork, g->evB, g->evA);
 	}
 	bv::launch_bparse(gd, s.def, v, &dsm->err, g->stream);
 	if (ovl) {
@@ -1234,7 +1258,7 @@ extern "C" int bvg_scan_stats(bvg_t *g, int32_t from, int32_t to, bvg_scan_stats
 	StatsHost h{};
 	h.min_key = ~0ull;
 	HIPCHK(g, hipMemcpy(g->statsbuf.p, &h, sizeof(h), hipMemcpyHostToDevice));
-	const std::vector<int32_t> cut = plan_chunks_by_bits(s, from, to, (int64_t)32 << 20);
+	const std::vector<int32_t> cut = plan_chunks_by_bits(s, from, to, scan_piece_arcs());
 	for (size_t k = 0; k + 1 < cut.size(); k++) {
 		const int32_t a = cut[k], e = cut[k + 1];
 		if (e == a) continue;
