@@ -588,7 +588,13 @@ __global__ void __launch_bounds__(64 * COPY_MID_WAVES) k_copy_mid(GraphDev g, Ra
 	}
 }
 
-constexpr int COPY_BIG_THREADS = 1024, COPY_BIG_CAP = 6144, COPY_BIG_ITEMS = 8;
+#ifndef COPY_BIG_THREADS_
+#define COPY_BIG_THREADS_ 1024
+#define COPY_BIG_CAP_ 6144
+#endif
+// (512 threads and LDS tables for 2048 copied ids -- 38 KB of LDS, four groups per CU instead of one -- changed nothing on C2 and
+// cnr-2000 x30 and cost 4 % on C5: a level of k_copy_big lasts as long as its longest row, not as long as its rows in sum.)
+constexpr int COPY_BIG_THREADS = COPY_BIG_THREADS_, COPY_BIG_CAP = COPY_BIG_CAP_, COPY_BIG_ITEMS = 8, COPY_BIG_FIRST = 16384, COPY_BIG_GRID = 256 * (2048 / COPY_BIG_THREADS);
 // One 1024-thread group per long row with a reference.  The block list is walked once, without memory traffic
 // (it is the serial part of a row with thousands of blocks), into the same two LDS tables as in k_copy_mid; the
 // copied ids (<= COPY_BIG_CAP of them) are then gathered into LDS and ranked among the row's extras
@@ -601,7 +607,7 @@ constexpr int COPY_BIG_THREADS = 1024, COPY_BIG_CAP = 6144, COPY_BIG_ITEMS = 8;
 template <int DEF>
 __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ queue,
                                                                const int32_t *__restrict__ count, int32_t cap, int32_t level, int32_t *__restrict__ tmp, uint32_t tmpCap,
-                                                               uint32_t *__restrict__ tmpCursor, int *__restrict__ err) {
+                                                               uint32_t *__restrict__ tmpCursor, int32_t *__restrict__ qhead, int *__restrict__ err) {
 	__shared__ int32_t tabs[3 * COPY_BIG_CAP + 2];
 	int32_t *const cval = tabs, *const cpos = tabs + COPY_BIG_CAP, *const delta = tabs + 2 * COPY_BIG_CAP + 1;
 	__shared__ int32_t s_b[2];
@@ -609,11 +615,20 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 	__shared__ __attribute__((aligned(16))) uint32_t cwin[DEF ? CoopLds<1>::WORDS : 4]; // tile of the cooperative walk of a long block list
 	__shared__ int64_t s_copied, s_tmp, s_kmax;
 	__shared__ int32_t s_kept, s_bad;
-	// the queue holds the long rows of ALL levels (a few hundred): a group takes the entries of this level among its share
+	// The queue holds the long rows of ALL levels; a group takes the next entry that is of this level and of this pass from a
+	// shared head (rows differ by 200x in length: fixed shares left most groups idle while a few worked through several
+	// giant rows).  Two passes, the rows of >= COPY_BIG_FIRST ids first, so that the longest merges start at once.
+	__shared__ int32_t s_qi;
 	const int32_t nq = min(*count, cap);
-	for (int32_t qi = blockIdx.x; qi < nq; qi += gridDim.x) {
+	for (;;) {
+		__syncthreads(); // everybody has read s_qi, the tables are free
+		if (threadIdx.x == 0) s_qi = atomicAdd(&qhead[0], 1);
+		__syncthreads();
+		const int32_t qraw = s_qi;
+		if (qraw >= 2 * nq) break;
+		const int32_t qi = qraw >= nq ? qraw - nq : qraw;
 		const int32_t s = queue[qi];
-		if (depth[s] != level || copy_class(v, depth, level, s, 0, 0x7fffffff) == 0) continue;
+		if (depth[s] != level || (v.outd[s] >= COPY_BIG_FIRST) != (qraw < nq) || copy_class(v, depth, level, s, 0, 0x7fffffff) == 0) continue;
 		const int32_t d = v.outd[s], r = v.ref[s];
 		const int64_t dref = v.outd[s - r];
 		int32_t *row = v.row(s);
@@ -725,29 +740,28 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 		// and each tile's copied ids and extras are ranked against each other in LDS.  In place: tile k overwrites
 		// row[p0..p1), which held extras with index < p1 - nc <= j1, all read by then; tile k + 1 is on its way meanwhile.
 		auto merge_row_stream = [&](const int32_t *kend, const int32_t *dlt, int32_t *cv_, int32_t nc, int32_t nKept) {
-			constexpr int32_t GT = 4096, TS = 8192, ITEMS = TS / COPY_BIG_THREADS;
+			constexpr int32_t TS = COPY_BIG_THREADS * 8, GT = TS / 2, ITEMS = TS / COPY_BIG_THREADS;
+			static_assert(2 * (GT + 1) <= 3 * COPY_BIG_CAP + 2 && TS + COPY_BIG_THREADS + 1 <= 3 * COPY_BIG_CAP + 2, "the tiles of the streaming merge live in the LDS tables");
 			const int32_t nExtra = d - nc;
 			int32_t *bufK = tabs, *bufD = tabs + GT + 1;
+			// b0 = the block that holds id t0.  Blocks after the first are non-empty, so the blocks of the GT ids of a tile are among
+			// the GT + 1 table entries from b0 on: they are loaded as they lie, and the next tile's b0 is found in LDS.
+			int32_t b0 = (nKept > 1 && kend[0] == 0) ? 1 : 0;
 			for (int32_t t0 = 0; t0 < nc; t0 += GT) {
-				const int32_t t1 = min(nc, t0 + GT);
+				const int32_t t1 = min(nc, t0 + GT), nb = min(nKept - b0, GT + 1);
 				__syncthreads(); // the buffers are free
-				if (threadIdx.x < 2) {
-					const int32_t target = threadIdx.x ? t1 - 1 : t0;
-					int32_t lo = 0, hi = nKept;
-					while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (kend[mid] <= target) lo = mid + 1; else hi = mid; }
-					s_b[threadIdx.x] = lo;
-				}
-				__syncthreads();
-				const int32_t b0 = s_b[0], nb = min(s_b[1] - b0 + 1, GT + 1); // (blocks after the first are non-empty: at most one per id of the tile)
 				for (int32_t k = threadIdx.x; k < nb; k += COPY_BIG_THREADS) { bufK[k] = kend[b0 + k]; bufD[k] = dlt[b0 + k]; }
 				__syncthreads();
 				for (int32_t t = t0 + (int32_t)threadIdx.x; t < t1; t += COPY_BIG_THREADS) {
 					int32_t lo = 0, hi = nb - 1;
 					while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (bufK[mid] <= t) lo = mid + 1; else hi = mid; }
 					cv_[t] = src[t + bufD[lo]];
+					if (t == t1 - 1) s_b[0] = b0 + lo + (bufK[lo] <= t1 ? 1 : 0); // the block of id t1 (bufK[lo] > t1 - 1: it ends at t1 or later)
 				}
+				__syncthreads();
+				b0 = min(s_b[0], nKept - 1);
 			}
-			CT(1);
+			CT(5);
 			int32_t *buf = tabs, *splits = tabs + TS;
 			int32_t iBase = 0;
 			for (int32_t base = 0; base < d; base += COPY_BIG_THREADS * TS) {
@@ -761,7 +775,7 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 					splits[k] = lo;
 				}
 				__syncthreads();
-				CT(2);
+				CT(6);
 				int32_t x[ITEMS];
 				auto fetch = [&](int32_t k) {
 					const int32_t p0 = base + k * TS, p1 = (int32_t)min<int64_t>(d, (int64_t)p0 + TS);
@@ -794,7 +808,7 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 					}
 				}
 				iBase = splits[ntl];
-				CT(3);
+				CT(7);
 			}
 		};
 		// Where the tables live is decided BEFORE the walk (a long block list is the serial part of the row: it is walked once):
@@ -831,12 +845,18 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 		const int32_t nKept = s_kept;
 		if (s_bad || copied > d || copied == 0) continue; // malformed (flagged by the parse kernel) / nothing to merge: the extras already fill the row
 		if (g.stats && threadIdx.x == 0) { stat_add(g, 8, 1); stat_add(g, 9, (unsigned long long)nKept); stat_max(g, 15, (unsigned long long)nKept); stat_add(g, 4, (unsigned long long)d); }
+		const unsigned long long tRow0 = tk;
 		CT(0);
-		if (where == -2) { merge_row(cpos, delta, cval, cpos, (int32_t)copied, nKept); continue; } // (copied <= dref <= COPY_BIG_CAP, nKept <= COPY_BIG_CAP + 1)
+		const unsigned long long tWalk = tk - tRow0;
+#define ROWDBG() do { if (g.stats && (g.dbg & 128) && threadIdx.x == 0) { const unsigned long long tot_ = __builtin_readcyclecounter() - tRow0; atomicMax(&g.stats[min(level, 3) - 1], tot_); atomicMax(&g.stats[3], tWalk); } \
+		if ((g.dbg & 64) && threadIdx.x == 0) { const unsigned long long tot_ = __builtin_readcyclecounter() - tRow0; if (tot_ > 200000) printf("row s=%d lvl=%d d=%d dref=%ld copied=%ld nKept=%d where=%ld walk=%llu total=%llu\n", s, level, d, (long)dref, (long)copied, nKept, (long)where, tWalk, tot_); } } while (0)
+		if (where == -2) { merge_row(cpos, delta, cval, cpos, (int32_t)copied, nKept); ROWDBG(); continue; } // (copied <= dref <= COPY_BIG_CAP, nKept <= COPY_BIG_CAP + 1)
 		const int64_t cMaxRow = dref < (int64_t)d ? dref : (int64_t)d;
 		if (nKept > kMax || copied > cMaxRow) continue; // (cannot happen: the bounds above)
 		if (g.dbg & 32) { int32_t *gv = tabD + kMax, *gp = gv + cMaxRow; merge_row(tabK, tabD, gv, gp, (int32_t)copied, nKept); continue; } // (the element-wise merge on global tables, kept for A/B timing: BVGPU_DBG=32)
+		if (g.stats && threadIdx.x == 0) { stat_add(g, 16, 1); stat_add(g, 17, (unsigned long long)d); stat_add(g, 18, (unsigned long long)copied); stat_max(g, 19, (unsigned long long)d); }
 		merge_row_stream(tabK, tabD, tabD + kMax, (int32_t)copied, nKept);
+		ROWDBG();
 #undef CT
 	}
 }
@@ -1158,11 +1178,19 @@ __global__ void __launch_bounds__(TPB) k_hash_nodes(int32_t from, int32_t cnt, c
 	for (int32_t q = 0; q < s_nlong; q++) { // (uniform)
 		const int32_t t = s_long[q], sx = blockIdx.x * TPB + t;
 		const int64_t lo = rowptr[sx], hi = rowptr[sx + 1], d = hi - lo;
-		// thread k folds the contiguous piece [c0, c1) of the row: sum_j s_j 31^(j - lo) = sum_k 31^(c0 - lo) * (piece k by Horner)
-		const int64_t per = (d + TPB - 1) / TPB, c0 = min(lo + per * threadIdx.x, hi), c1 = min(c0 + per, hi);
+		// thread k folds the ids k, k + TPB, k + 2 TPB, ... of the row (coalesced loads; contiguous pieces per thread made a block
+		// of 30 neighbouring rows of 190 000 ids last 15 ms): sum_j s_j 31^j = sum_k 31^k * (Horner in 31^TPB over thread k's ids)
+		const uint32_t step = pow31(TPB);
+		const int64_t cntK = (d - (int64_t)threadIdx.x + TPB - 1) / TPB; // ids of this thread
 		uint32_t pz = 0;
-		for (int64_t j = c1; j-- > c0;) pz = pz * 31u + (uint32_t)succ[j];
-		s_part[threadIdx.x] = pz * pow31((uint64_t)(c0 - lo));
+		int64_t i = cntK;
+		for (; i >= 4; i -= 4) {
+			const int64_t j = lo + threadIdx.x + (i - 1) * TPB;
+			const uint32_t x3 = (uint32_t)succ[j], x2 = (uint32_t)succ[j - TPB], x1 = (uint32_t)succ[j - 2 * TPB], x0 = (uint32_t)succ[j - 3 * TPB];
+			pz = (((pz * step + x3) * step + x2) * step + x1) * step + x0;
+		}
+		for (; i > 0; i--) pz = pz * step + (uint32_t)succ[lo + threadIdx.x + (i - 1) * TPB];
+		s_part[threadIdx.x] = pz * pow31((uint64_t)threadIdx.x);
 		__syncthreads();
 		for (int o = TPB / 2; o > 0; o >>= 1) { if (threadIdx.x < o) s_part[threadIdx.x] += s_part[threadIdx.x + o]; __syncthreads(); }
 		if (threadIdx.x == 0) sh[t] = Affine{ pow31((uint64_t)d + 1), (uint32_t)(from + sx) * pow31((uint64_t)d) + s_part[0] };
@@ -1389,10 +1417,10 @@ void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int
 		if (stBig != st) (void)hipStreamWaitEvent(stBig, evFork, 0);
 	}
 	if (bigGroups) {
-		(void)hipMemsetAsync(ctl + 7, 0, sizeof(int32_t), stBig); // the scratch tables of the previous level's rows are free again
-		if (def == 1) hipLaunchKernelGGL(k_copy_big<1>, dim3(512), dim3(COPY_BIG_THREADS), 0, stBig, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 7), err);
-		else if (def == 2) hipLaunchKernelGGL(k_copy_big<2>, dim3(512), dim3(COPY_BIG_THREADS), 0, stBig, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 7), err);
-		else hipLaunchKernelGGL(k_copy_big<0>, dim3(512), dim3(COPY_BIG_THREADS), 0, stBig, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 7), err);
+		(void)hipMemsetAsync(ctl + 7, 0, 2 * sizeof(int32_t), stBig); // the scratch tables of the previous level's rows are free again; the head of the level's work queue
+		if (def == 1) hipLaunchKernelGGL(k_copy_big<1>, dim3(COPY_BIG_GRID), dim3(COPY_BIG_THREADS), 0, stBig, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 7), ctl + 8, err);
+		else if (def == 2) hipLaunchKernelGGL(k_copy_big<2>, dim3(COPY_BIG_GRID), dim3(COPY_BIG_THREADS), 0, stBig, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 7), ctl + 8, err);
+		else hipLaunchKernelGGL(k_copy_big<0>, dim3(COPY_BIG_GRID), dim3(COPY_BIG_THREADS), 0, stBig, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 7), ctl + 8, err);
 		if (stBig != st) (void)hipEventRecord(evBig, stBig);
 	}
 	if (midMin < bigMin) {

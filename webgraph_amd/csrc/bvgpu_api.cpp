@@ -204,7 +204,7 @@ int init_handle(bvg_graph *g) {
 	if (const char *e = getenv("BVGPU_GIANT_MIN")) { g->giant_min = std::max(g->coop_min, atoi(e)); g->adaptive = false; }
 	if (const char *e = getenv("BVGPU_COOP_WAVES")) g->coop_waves = std::max(1, atoi(e));
 	if (const char *e = getenv("BVGPU_GIANT_GROUPS")) g->giant_groups = std::max(1, atoi(e));
-	if (!g->coopctl.need(8 * sizeof(int32_t)) || !g->keys.need(3 * (bv::NKEYS + 1) * sizeof(int32_t))) return fail(g, BVG_ENOMEM, "device allocation failed");
+	if (!g->coopctl.need(16 * sizeof(int32_t)) || !g->keys.need(3 * (bv::NKEYS + 1) * sizeof(int32_t))) return fail(g, BVG_ENOMEM, "device allocation failed");
 	if (const char *e = getenv("BVGPU_LEVEL_BLOCKS")) g->level_blocks = std::max(1, atoi(e));
 	if (const char *e = getenv("BVGPU_COPY_LISTS")) g->copy_lists = atoi(e);
 	if (const char *e = getenv("BVGPU_PARSE_LISTS")) g->parse_lists = atoi(e);
