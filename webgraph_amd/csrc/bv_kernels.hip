@@ -1417,10 +1417,10 @@ void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int
 		if (stBig != st) (void)hipStreamWaitEvent(stBig, evFork, 0);
 	}
 	if (bigGroups) {
-		(void)hipMemsetAsync(ctl + 7, 0, 2 * sizeof(int32_t), stBig); // the scratch tables of the previous level's rows are free again; the head of the level's work queue
-		if (def == 1) hipLaunchKernelGGL(k_copy_big<1>, dim3(COPY_BIG_GRID), dim3(COPY_BIG_THREADS), 0, stBig, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 7), ctl + 8, err);
-		else if (def == 2) hipLaunchKernelGGL(k_copy_big<2>, dim3(COPY_BIG_GRID), dim3(COPY_BIG_THREADS), 0, stBig, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 7), ctl + 8, err);
-		else hipLaunchKernelGGL(k_copy_big<0>, dim3(COPY_BIG_GRID), dim3(COPY_BIG_THREADS), 0, stBig, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 7), ctl + 8, err);
+		(void)hipMemsetAsync(ctl + 8, 0, 2 * sizeof(int32_t), stBig); // the scratch tables of the previous level's rows are free again; the head of the level's work queue
+		if (def == 1) hipLaunchKernelGGL(k_copy_big<1>, dim3(COPY_BIG_GRID), dim3(COPY_BIG_THREADS), 0, stBig, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 8), ctl + 9, err);
+		else if (def == 2) hipLaunchKernelGGL(k_copy_big<2>, dim3(COPY_BIG_GRID), dim3(COPY_BIG_THREADS), 0, stBig, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 8), ctl + 9, err);
+		else hipLaunchKernelGGL(k_copy_big<0>, dim3(COPY_BIG_GRID), dim3(COPY_BIG_THREADS), 0, stBig, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 8), ctl + 9, err);
 		if (stBig != st) (void)hipEventRecord(evBig, stBig);
 	}
 	if (midMin < bigMin) {
