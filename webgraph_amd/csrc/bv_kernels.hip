@@ -607,7 +607,8 @@ constexpr int COPY_BIG_THREADS = COPY_BIG_THREADS_, COPY_BIG_CAP = COPY_BIG_CAP_
 template <int DEF>
 __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ queue,
                                                                const int32_t *__restrict__ count, int32_t cap, int32_t level, int32_t *__restrict__ tmp, uint32_t tmpCap,
-                                                               uint32_t *__restrict__ tmpCursor, int32_t *__restrict__ qhead, int *__restrict__ err) {
+                                                               uint32_t *__restrict__ tmpCursor, int32_t *__restrict__ qhead, int32_t *__restrict__ nextPair, int *__restrict__ err) {
+	if (blockIdx.x == 0 && threadIdx.x < 2) nextPair[threadIdx.x] = 0;
 	__shared__ int32_t tabs[3 * COPY_BIG_CAP + 2];
 	int32_t *const cval = tabs, *const cpos = tabs + COPY_BIG_CAP, *const delta = tabs + 2 * COPY_BIG_CAP + 1;
 	__shared__ int32_t s_b[2];
@@ -1417,10 +1418,12 @@ void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int
 		if (stBig != st) (void)hipStreamWaitEvent(stBig, evFork, 0);
 	}
 	if (bigGroups) {
-		(void)hipMemsetAsync(ctl + 8, 0, 2 * sizeof(int32_t), stBig); // the scratch tables of the previous level's rows are free again; the head of the level's work queue
-		if (def == 1) hipLaunchKernelGGL(k_copy_big<1>, dim3(COPY_BIG_GRID), dim3(COPY_BIG_THREADS), 0, stBig, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 8), ctl + 9, err);
-		else if (def == 2) hipLaunchKernelGGL(k_copy_big<2>, dim3(COPY_BIG_GRID), dim3(COPY_BIG_THREADS), 0, stBig, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 8), ctl + 9, err);
-		else hipLaunchKernelGGL(k_copy_big<0>, dim3(COPY_BIG_GRID), dim3(COPY_BIG_THREADS), 0, stBig, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 8), ctl + 9, err);
+		// ctl[8 + 2 (level & 3)], ctl[9 + 2 (level & 3)]: this level's bump pointer into the scratch tables (the previous level's are free
+		// again) and the head of its work queue.  Level l zeroes the pair of level l + 1 (no memset launches between the levels);
+		// the job's set-up zeroes all four pairs.
+		if (def == 1) hipLaunchKernelGGL(k_copy_big<1>, dim3(COPY_BIG_GRID), dim3(COPY_BIG_THREADS), 0, stBig, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 8 + 2 * (level & 3)), ctl + 9 + 2 * (level & 3), ctl + 8 + 2 * ((level + 1) & 3), err);
+		else if (def == 2) hipLaunchKernelGGL(k_copy_big<2>, dim3(COPY_BIG_GRID), dim3(COPY_BIG_THREADS), 0, stBig, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 8 + 2 * (level & 3)), ctl + 9 + 2 * (level & 3), ctl + 8 + 2 * ((level + 1) & 3), err);
+		else hipLaunchKernelGGL(k_copy_big<0>, dim3(COPY_BIG_GRID), dim3(COPY_BIG_THREADS), 0, stBig, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 8 + 2 * (level & 3)), ctl + 9 + 2 * (level & 3), ctl + 8 + 2 * ((level + 1) & 3), err);
 		if (stBig != st) (void)hipEventRecord(evBig, stBig);
 	}
 	if (midMin < bigMin) {

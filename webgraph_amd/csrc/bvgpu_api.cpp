@@ -374,7 +374,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		int32_t *ctl = g->coopctl.as<int32_t>();
 		// (ctl[0..3], the queues of the long records, are zeroed on side B when the classification starts early)
 		const bool early = hdrEvent && coopMin < 0x7fffffff && g->overlap && !g->profile;
-		HIPCHK(g, hipMemsetAsync(ctl + (early ? 4 : 0), 0, (early ? 4 : 8) * sizeof(int32_t), g->stream));
+		HIPCHK(g, hipMemsetAsync(ctl + (early ? 4 : 0), 0, (early ? 12 : 16) * sizeof(int32_t), g->stream));
 		// rows with a reference and >= 1024 (resp. >= copy_mid_min) successors: at most arcs / 1024 (resp. / copy_mid_min) of them
 		const int32_t bigCap = (int32_t)std::min<int64_t>(arcsBound / 1024 + 2, 0x3fffffff);
 		const int32_t midCap = g->copy_mid_min > 0 ? (int32_t)std::min<int64_t>(arcsBound / g->copy_mid_min + 2, 0x3fffffff) : 0;
@@ -1209,7 +1209,7 @@ extern "C" int bvg_successors_batch(bvg_t *g, const int32_t *nodes, size_t q, in
 		if (!g->biglist.need(4 * Sz) || !g->giantlist.need(sizeof(int32_t) * (size_t)giantCap) || !g->arena.need((size_t)bv::ARENA_ENTRY_BYTES * (size_t)arenaCap))
 			return fail(g, BVG_ENOMEM, "device scratch allocation failed");
 		int32_t *ctl = g->coopctl.as<int32_t>();
-		HIPCHK(g, hipMemsetAsync(ctl, 0, 8 * sizeof(int32_t), g->stream));
+		HIPCHK(g, hipMemsetAsync(ctl, 0, 16 * sizeof(int32_t), g->stream));
 		bv::launch_bparse_big(gd, s.def, v, coopMin, giantMin, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, g->arena.p, arenaCap,
 		                      g->coop_waves, g->giant_groups, &dsm->err, g->stream, ovl ? side_b(g) : g->stream, ovl ? g->sideA : g->stream, g->evFork, g->evB, g->evA);
 	}
