@@ -116,6 +116,11 @@ int bvg_set_profile(bvg_t *g, int enable);
 /* Milliseconds of each phase of the last range decode issued with profiling on; ms has BVG_NUM_PHASES floats. */
 int bvg_get_profile(bvg_t *g, float *ms);
 
+/* The outdegree thresholds the last bvg_decode_range ran with: records with at least coop_min successors were decoded by one
+ * wavefront each, with at least giant_min by a group of wavefronts, the others by one lane each.  The first is
+ * picked on the device from the job's outdegrees, the second from the job's size; bench.py prices each kernel on its own records. */
+int bvg_last_thresholds(bvg_t *g, int32_t *coop_min, int32_t *giant_min);
+
 /* Tuning counters of the cooperative decoder (only when BVGPU_STATS=1 was set at bvg_open): 32 uint64, see bv_device.hpp. */
 int bvg_debug_stats(bvg_t *g, uint64_t *out16, int reset);
 

@@ -63,8 +63,8 @@ def main():
             ph[k] = ph.get(k, 0.0) + v / 3
     g.set_profile(False)
     knobs = " ".join("%s=%s" % (k, v) for k, v in sorted(os.environ.items()) if k.startswith("BVGPU_") and k != "BVGPU_CACHE")
-    print("%-6s %-40s arcs %d hash %d | scan %.3f ms = %.1f G edges/s | serial %s sum %.3f" % (
-        name, knobs or "(defaults)", arcs, h, dt * 1e3, arcs / dt / 1e9, " ".join("%s %.3f" % (k, v) for k, v in ph.items()), sum(ph.values())))
+    print("%-6s %-40s thr %s arcs %d hash %d | scan %.3f ms = %.1f G edges/s | serial %s sum %.3f" % (
+        name, knobs or "(defaults)", "%d/%d" % g.last_thresholds(), arcs, h, dt * 1e3, arcs / dt / 1e9, " ".join("%s %.3f" % (k, v) for k, v in ph.items()), sum(ph.values())))
     g.close()
 
 

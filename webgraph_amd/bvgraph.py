@@ -41,7 +41,7 @@ class BvgLabelsInfo(C.Structure):
 EXPORTS = ["bvg_open", "bvg_open_shard", "bvg_clone", "bvg_close", "bvg_info", "bvg_last_error", "bvg_set_stream", "bvg_sync",
            "bvg_outdegrees", "bvg_decode_range", "bvg_decode_range_view", "bvg_host_alloc", "bvg_host_free", "bvg_scan_checksum", "bvg_scan_stats", "bvg_bfs_expand", "bvg_successors_batch", "bvg_csr_hashcode", "bvg_shard_bounds",
            "bvg_parse_properties", "bvg_flags_from_string", "bvg_decode_offsets_host", "bvg_decode_offsets_device", "bvg_labels_open", "bvg_labels_close", "bvg_labels_info",
-           "bvg_labels_last_error", "bvg_labels_parse_properties", "bvg_labels_decode_range", "bvg_set_profile", "bvg_get_profile", "bvg_debug_stats"]
+           "bvg_labels_last_error", "bvg_labels_parse_properties", "bvg_labels_decode_range", "bvg_set_profile", "bvg_get_profile", "bvg_debug_stats", "bvg_last_thresholds"]
 
 _lib = None
 
@@ -96,6 +96,7 @@ def lib():
         L.bvg_labels_decode_range.argtypes = [vp, i32, i32, u64, vp, C.c_int]
         L.bvg_set_profile.argtypes = [vp, C.c_int]
         L.bvg_get_profile.argtypes = [vp, C.POINTER(C.c_float)]
+        L.bvg_last_thresholds.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.bvg_debug_stats.argtypes = [vp, vp, C.c_int]
         _lib = L
     return _lib
@@ -407,6 +408,12 @@ class BVGraph:
         ms = (C.c_float * len(self.PHASES))()
         self._check(lib().bvg_get_profile(self._h, ms))
         return dict(zip(self.PHASES, [float(x) for x in ms]))
+
+    def last_thresholds(self):
+        """(coop_min, giant_min) of the last range decode: outdegrees from which a record is decoded by a wave / a group of waves."""
+        a, b = C.c_int32(0), C.c_int32(0)
+        self._check(lib().bvg_last_thresholds(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     def debug_stats(self, reset=True):
         out = np.zeros(32, dtype=np.uint64)

@@ -46,26 +46,43 @@ __device__ __forceinline__ void parse_node(const GraphDev &g, int32_t x, int32_t
 // ------------------------------------------------------------------------------------------------ headers
 template <int DEF>
 __global__ void __launch_bounds__(TPB) k_headers(GraphDev g, int32_t lo, int32_t cnt, int32_t *__restrict__ outd,
-                                                 uint16_t *__restrict__ ref, int *__restrict__ err) {
+                                                 uint16_t *__restrict__ ref, int *__restrict__ err, int32_t *__restrict__ part) {
 	const int32_t s = blockIdx.x * TPB + threadIdx.x;
-	if (s >= cnt) return;
-	const int32_t x = lo + s;
-	BitReader br;
-	br.init(g.bits, g.nwords);
-	br.seek((uint64_t)g.offsets[x]);
-	uint64_t d = Fields<DEF>::outdegree(br, g);
-	uint64_t r = 0;
-	int e = 0;
-	if (d > 0x7fffffffull) { e |= E_FORMAT; d = 0; }
-	if (d > 0 && g.W > 0) {
-		r = Fields<DEF>::reference(br, g);
-		if (r > (uint64_t)g.W) { e |= E_REF; r = 0; }       // BVG:705
-		else if (r > (uint64_t)x) { e |= E_FORMAT; r = 0; } // referent before node 0
+	uint64_t d = 0;
+	if (s < cnt) {
+		const int32_t x = lo + s;
+		BitReader br;
+		br.init(g.bits, g.nwords);
+		br.seek((uint64_t)g.offsets[x]);
+		d = Fields<DEF>::outdegree(br, g);
+		uint64_t r = 0;
+		int e = 0;
+		if (d > 0x7fffffffull) { e |= E_FORMAT; d = 0; }
+		if (d > 0 && g.W > 0) {
+			r = Fields<DEF>::reference(br, g);
+			if (r > (uint64_t)g.W) { e |= E_REF; r = 0; }       // BVG:705
+			else if (r > (uint64_t)x) { e |= E_FORMAT; r = 0; } // referent before node 0
+		}
+		e |= br.err;
+		outd[s] = (int32_t)d;
+		ref[s] = (uint16_t)r;
+		if (e) atomicOr(err, e);
 	}
-	e |= br.err;
-	outd[s] = (int32_t)d;
-	ref[s] = (uint16_t)r;
-	if (e) atomicOr(err, e);
+	// How many of the block's records have >= 128, 256, ..., 2048 successors: k_pick_coop adds the blocks up and picks the
+	// job's wave-class threshold.  (Per-block slots, no atomics on shared counters and no fences: a streaming kernel of its
+	// own with a last-block-done ticket took 85 us on C2 -- its __threadfence() writes back an L2 full of fresh outdegrees.)
+	if (part) {
+		__shared__ int32_t s_c[5];
+		if (threadIdx.x < 5) s_c[threadIdx.x] = 0;
+		__syncthreads();
+		const int32_t dd = (int32_t)d;
+		if (__ballot(dd >= 128)) {
+#pragma unroll
+			for (int k = 0; k < 5; k++) { const int n = __popcll(__ballot(dd >= (128 << k))); if ((threadIdx.x & 63) == 0 && n) atomicAdd(&s_c[k], n); }
+		}
+		__syncthreads();
+		if (threadIdx.x < 5) part[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = s_c[threadIdx.x];
+	}
 }
 
 // ------------------------------------------------------------------------------------------------ halo closure
@@ -363,7 +380,7 @@ __global__ void __launch_bounds__(TPB) k_parse(GraphDev g, RangeView v, int *__r
 	const int32_t s = blockIdx.x * TPB + threadIdx.x;
 	if (s >= v.cnt) return;
 	const int32_t d = v.outd[s];
-	if (d == 0 || d >= v.coop_min) return; // long records are decoded by whole waves (k_parse_big)
+	if (d == 0 || d >= v.coopmin()) return; // long records are decoded by whole waves (k_parse_big)
 	const int32_t r = v.ref[s];
 	if (!v.fits(s)) { atomicOr(err, s >= v.nh ? E_CAP : E_HALO); return; }
 	parse_node<DEF>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), err);
@@ -867,7 +884,7 @@ template <int DEF>
 __global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, const int32_t *__restrict__ list, const int32_t *__restrict__ keyBase, int32_t binLo, int32_t binHi,
                                                     int *__restrict__ err) {
 	__shared__ uint32_t lw[DEF ? LW_LDS_WORDS : 1]; // lane-private stream windows (default codings)
-	const int32_t lo = keyBase[binLo], hi = keyBase[binHi];
+	const int32_t lo = keyBase[binLo], hi = keyBase[binHi], coopMin = v.coopmin();
 	// The list is sorted longest first.  Thread T takes entries T, 2G-1-T, 2G+T, 4G-1-T, ... (G = threads in the
 	// grid): a snake, so that the threads that got the longest records of one sweep get the shortest of the next.
 	const int64_t G = (int64_t)gridDim.x * TPB, T = (int64_t)blockIdx.x * TPB + threadIdx.x;
@@ -877,7 +894,7 @@ __global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, con
 		const int32_t idx = (int32_t)(hi - 1 - off);
 		const int32_t s = list[idx];
 		const int32_t d = v.outd[s];
-		if (d >= v.coop_min || d == 0) continue; // decoded by whole waves (k_parse_big) / nothing to decode
+		if (d >= coopMin || d == 0) continue; // decoded by whole waves (k_parse_big) / nothing to decode
 		const int32_t r = v.ref[s];
 		if (!v.fits(s)) { atomicOr(err, s >= v.nh ? E_CAP : E_HALO); continue; }
 		if (DEF) parse_node_lw<DEF == 1 ? 3 : 0>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), lw, err);
@@ -888,8 +905,9 @@ __global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, con
 // ------------------------------------------------------------------------------------------------ long records
 // ctl[0] = #big, ctl[1] = #giant, ctl[2] / ctl[3] = heads of the two work queues
 constexpr int CLASSIFY_ITEMS = 16; // nodes per thread: long records are rare, most blocks only stream outdegrees
-__global__ void __launch_bounds__(TPB) k_classify(int32_t cnt, const int32_t *__restrict__ outd, int32_t coopMin, int32_t giantMin,
+__global__ void __launch_bounds__(TPB) k_classify(int32_t cnt, const int32_t *__restrict__ outd, const int32_t *__restrict__ coopPtr, int32_t coopMin, int32_t giantMin,
                                                   int32_t *__restrict__ biglist, int32_t *__restrict__ giantlist, int32_t giantCap, int32_t *__restrict__ ctl) {
+	if (coopPtr) coopMin = min(*coopPtr, giantMin);
 	// block-aggregated append: one atomic per block and list instead of one per long record
 	__shared__ int32_t s_cnt[2], s_base[2];
 	const int32_t base = blockIdx.x * (TPB * CLASSIFY_ITEMS) + threadIdx.x;
@@ -1230,12 +1248,13 @@ namespace bv {
 
 static inline unsigned nblk(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
-void launch_headers(const GraphDev &g, int def, int32_t lo, int32_t cnt, int32_t *outd, uint16_t *ref, int *err, hipStream_t st) {
+void launch_headers(const GraphDev &g, int def, int32_t lo, int32_t cnt, int32_t *outd, uint16_t *ref, int *err, hipStream_t st, int32_t *part) {
 	if (cnt <= 0) return;
-	if (def == 1) hipLaunchKernelGGL(k_headers<1>, dim3(nblk(cnt, TPB)), dim3(TPB), 0, st, g, lo, cnt, outd, ref, err);
-	else if (def == 2) hipLaunchKernelGGL(k_headers<2>, dim3(nblk(cnt, TPB)), dim3(TPB), 0, st, g, lo, cnt, outd, ref, err);
-	else hipLaunchKernelGGL(k_headers<0>, dim3(nblk(cnt, TPB)), dim3(TPB), 0, st, g, lo, cnt, outd, ref, err);
+	if (def == 1) hipLaunchKernelGGL(k_headers<1>, dim3(nblk(cnt, TPB)), dim3(TPB), 0, st, g, lo, cnt, outd, ref, err, part);
+	else if (def == 2) hipLaunchKernelGGL(k_headers<2>, dim3(nblk(cnt, TPB)), dim3(TPB), 0, st, g, lo, cnt, outd, ref, err, part);
+	else hipLaunchKernelGGL(k_headers<0>, dim3(nblk(cnt, TPB)), dim3(TPB), 0, st, g, lo, cnt, outd, ref, err, part);
 }
+int64_t headers_blocks(int32_t cnt) { return cnt > 0 ? (int64_t)nblk(cnt, TPB) : 0; }
 
 void launch_mark_halo(int32_t nh, int32_t cnt, int32_t W, int32_t *outd, uint16_t *ref, uint8_t *need, int *err, hipStream_t st) {
 	if (nh <= 0 || W <= 0) return;
@@ -1338,9 +1357,43 @@ void launch_bcopy(const GraphDev &g, int def, const BatchView &v, int32_t level,
 	else hipLaunchKernelGGL(k_bcopy<0>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, level, err);
 }
 
-void launch_classify(int32_t cnt, const int32_t *outd, int32_t coopMin, int32_t giantMin, int32_t *biglist, int32_t *giantlist, int32_t giantCap, int32_t *ctl, hipStream_t st) {
+// Which records leave the one-lane decoder for a wave: counted, not guessed.  A lane decodes ~0.6 us per successor whatever its
+// neighbours do, so the lane class lasts as long as its longest record unless it holds enough records of that length to fill
+// whole waves with them (the parse list is sorted by length); a wave costs ~30 us per record but 3 072 of them run side by side.
+// The threshold is the smallest of 128 .. 2048 that sends at most `budget` records to the waves (C2: 7 121 records >= 2 048,
+// 15 410 >= 1 024 -> 2 048; cnr-2000 x 30: 11 250 >= 128 -> 128, 3.06 -> 2.67 ms; measured optimum in both cases).
+constexpr int PICK_THREADS = 1024;
+__global__ void __launch_bounds__(PICK_THREADS) k_pick_coop(const int32_t *__restrict__ part, int32_t nblocks, int32_t budget, int32_t *__restrict__ ctl) {
+	__shared__ int32_t s_cnt[5];
+	if (threadIdx.x < 5) s_cnt[threadIdx.x] = 0;
+	__syncthreads();
+#pragma unroll
+	for (int k = 0; k < 5; k++) {
+		int32_t t = 0;
+		const int32_t *pk = part + (size_t)k * nblocks;
+		int32_t b = threadIdx.x;
+		for (; b + 7 * PICK_THREADS < nblocks; b += 8 * PICK_THREADS) { // eight loads in flight
+			const int32_t x0 = pk[b], x1 = pk[b + PICK_THREADS], x2 = pk[b + 2 * PICK_THREADS], x3 = pk[b + 3 * PICK_THREADS], x4 = pk[b + 4 * PICK_THREADS],
+			              x5 = pk[b + 5 * PICK_THREADS], x6 = pk[b + 6 * PICK_THREADS], x7 = pk[b + 7 * PICK_THREADS];
+			t += ((x0 + x1) + (x2 + x3)) + ((x4 + x5) + (x6 + x7));
+		}
+		for (; b < nblocks; b += PICK_THREADS) t += pk[b];
+		for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o);
+		if ((threadIdx.x & 63) == 0 && t) atomicAdd(&s_cnt[k], t);
+	}
+	__syncthreads();
+	if (threadIdx.x != 0) return;
+	int32_t pick = 2048;
+	for (int k = 4; k >= 0; k--) { if (s_cnt[k] <= budget) pick = 128 << k; else break; }
+	ctl[CTL_COOP] = pick;
+}
+void launch_pick_coop(const int32_t *part, int32_t nblocks, int32_t budget, int32_t *ctl, hipStream_t st) {
+	hipLaunchKernelGGL(k_pick_coop, dim3(1), dim3(PICK_THREADS), 0, st, part, nblocks, budget, ctl);
+}
+
+void launch_classify(int32_t cnt, const int32_t *outd, const int32_t *coopPtr, int32_t coopMin, int32_t giantMin, int32_t *biglist, int32_t *giantlist, int32_t giantCap, int32_t *ctl, hipStream_t st) {
 	if (cnt <= 0) return;
-	hipLaunchKernelGGL(k_classify, dim3(nblk(cnt, TPB * CLASSIFY_ITEMS)), dim3(TPB), 0, st, cnt, outd, coopMin, giantMin, biglist, giantlist, giantCap, ctl);
+	hipLaunchKernelGGL(k_classify, dim3(nblk(cnt, TPB * CLASSIFY_ITEMS)), dim3(TPB), 0, st, cnt, outd, coopPtr, coopMin, giantMin, biglist, giantlist, giantCap, ctl);
 	hipLaunchKernelGGL(k_sort_desc, dim3(2), dim3(1024), 0, st, giantlist, ctl + 1, giantCap, biglist, ctl + 0, cnt, outd);
 }
 
@@ -1360,7 +1413,7 @@ void copy_thresholds(int32_t midMinKnob, bool bigGroups, int32_t &midMin, int32_
 void launch_bparse_big(const GraphDev &g, int def, const BatchView &v, int32_t coopMin, int32_t giantMin, int32_t *biglist, int32_t *giantlist, int32_t giantCap, int32_t *ctl,
                        void *arena, int64_t arenaCap, int waves, int giantGroups, int *err, hipStream_t st, hipStream_t stGiant, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evGiant, hipEvent_t evBig) {
 	if (v.cnt <= 0) return;
-	launch_classify((int32_t)v.cnt, v.outd, coopMin, giantMin, biglist, giantlist, giantCap, ctl, st);
+	launch_classify((int32_t)v.cnt, v.outd, nullptr, coopMin, giantMin, biglist, giantlist, giantCap, ctl, st);
 	if (stGiant != st) { (void)hipEventRecord(evFork, st); (void)hipStreamWaitEvent(stGiant, evFork, 0); (void)hipStreamWaitEvent(stBig, evFork, 0); }
 	if (def == 1) hipLaunchKernelGGL((k_parse_big<1, GIANT_NW, BatchView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
 	else if (def == 2) hipLaunchKernelGGL((k_parse_big<2, GIANT_NW, BatchView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);

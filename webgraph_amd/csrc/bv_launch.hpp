@@ -18,7 +18,8 @@ struct RangeView {
 	int32_t *succ;          // caller rows
 	int32_t *halo;          // halo rows
 	uint64_t succ_cap;      // capacity of succ in elements
-	int32_t coop_min;       // records with outdegree >= coop_min are decoded by whole waves (k_parse_big)
+	int32_t coop_min;       // records with outdegree >= coop_min are decoded by whole waves (k_parse_big) ...
+	const int32_t *coop_ptr; // ... unless the job picks the threshold on the device (k_pick_coop): then it is read from here
 	uint64_t halo_cap;      // capacity of halo in elements (a sub-range is decoded before the size of its halo is known on the host)
 	// does row s lie inside the buffer it belongs to?  (rows are laid out in node order: if s fits, so does every row before it in the same buffer)
 	__device__ __forceinline__ bool fits(int32_t s) const {
@@ -28,6 +29,7 @@ struct RangeView {
 		const int64_t o = rowstart[s];
 		return s < nh ? halo + o : succ + (o - rowstart[nh]);
 	}
+	__device__ __forceinline__ int32_t coopmin() const { return coop_ptr ? *coop_ptr : coop_min; }
 };
 
 
@@ -43,7 +45,8 @@ struct BatchView {
 	__device__ __forceinline__ int32_t *row(int64_t s) const { const int32_t qi = qidx[s]; return qi >= 0 ? succ + rowptr[qi] : arena + arow[s]; }
 };
 
-void launch_headers(const GraphDev &g, int def, int32_t lo, int32_t cnt, int32_t *outd, uint16_t *ref, int *err, hipStream_t st);
+void launch_headers(const GraphDev &g, int def, int32_t lo, int32_t cnt, int32_t *outd, uint16_t *ref, int *err, hipStream_t st, int32_t *part = nullptr);
+int64_t headers_blocks(int32_t cnt); // part: 5 counts per block of k_headers, [5][headers_blocks(cnt)] (input of k_pick_coop)
 void launch_mark_halo(int32_t nh, int32_t cnt, int32_t W, int32_t *outd, uint16_t *ref, uint8_t *need, int *err, hipStream_t st);
 void launch_scan(const int32_t *in, int64_t n, int64_t *out, int64_t *sums, hipStream_t st);
 int64_t scan_num_sums(int64_t n);
@@ -61,7 +64,9 @@ void launch_chain_fill(const GraphDev &g, int def, const int32_t *nodes, int64_t
                        int32_t *sdepth, int32_t *sq, int32_t *aoutd, int32_t *qoutd, hipStream_t st);
 void launch_bparse(const GraphDev &g, int def, const BatchView &v, int *err, hipStream_t st);
 void launch_bcopy(const GraphDev &g, int def, const BatchView &v, int32_t level, int *err, hipStream_t st);
-void launch_classify(int32_t cnt, const int32_t *outd, int32_t coopMin, int32_t giantMin, int32_t *biglist, int32_t *giantlist, int32_t giantCap, int32_t *ctl, hipStream_t st);
+void launch_pick_coop(const int32_t *part, int32_t nblocks, int32_t budget, int32_t *ctl, hipStream_t st);
+constexpr int CTL_INTS = 32, CTL_COOP = 22, CTL_TOTAL_INTS = CTL_INTS; // control block (bv_kernels.hip)
+void launch_classify(int32_t cnt, const int32_t *outd, const int32_t *coopPtr, int32_t coopMin, int32_t giantMin, int32_t *biglist, int32_t *giantlist, int32_t giantCap, int32_t *ctl, hipStream_t st);
 void launch_parse_big(const GraphDev &g, int def, const RangeView &v, const int32_t *biglist, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap,
                       int waves, int giantGroups, int *err, hipStream_t stGiant, hipStream_t stBig);
 constexpr int ARENA_ENTRY_BYTES = 16;

@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(TILE_T) k_parse_tile(GraphDev g, RangeView v, 
 		bin[k] = -1;
 		if (s < b) {
 			const int32_t d = v.outd[s];
-			if (d > 0 && d < v.coop_min) {
+			if (d > 0 && d < v.coopmin()) {
 				const uint64_t bitsLen = (uint64_t)(g.offsets[v.lo + s + 1] - g.offsets[v.lo + s]);
 				const uint64_t work = max(bitsLen, (uint64_t)d * 8);
 				const int lg = 63 - __clzll((long long)(work | 1));

@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(T2_T) k_parse_tile2(GraphDev g, RangeView v, c
 		const int32_t s = a + tid + k * T2_T;
 		if (s >= b) break;
 		const int32_t d = v.outd[s];
-		if (d == 0 || d >= v.coop_min) continue; // nothing to decode / decoded by whole waves (k_parse_big)
+		if (d == 0 || d >= v.coopmin()) continue; // nothing to decode / decoded by whole waves (k_parse_big)
 		if (!v.fits(s)) { atomicOr(err, s >= v.nh ? E_CAP : E_HALO); continue; }
 		const int32_t r = v.ref[s], x = v.lo + s;
 		const int64_t dref = r > 0 ? (int64_t)v.outd[s - r] : 0;

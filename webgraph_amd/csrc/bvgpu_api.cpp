@@ -74,6 +74,8 @@ struct Staged {
 	}
 };
 
+constexpr int32_t COOP_BUDGET = 12288; // records a job sends to the wave class at most (4 x the waves in flight): see k_pick_coop
+
 struct Small { // device <-> host mailbox
 	int err;
 	int32_t maxdepth;
@@ -81,6 +83,8 @@ struct Small { // device <-> host mailbox
 	int32_t pad;
 	int64_t total;     // rowstart[cnt] - rowstart[nh]
 	int64_t halo_total;
+	int32_t coop_used; // the wave-class threshold the job ran with
+	int32_t pad2;
 };
 
 struct Pending { // an enqueued range decode whose status has not been collected yet
@@ -108,6 +112,7 @@ struct bvg_graph {
 	mutable std::string err;
 	DevBuf outd, ref, rowstart, depth, sums, need, halo, hashA, hashB, stage_rowptr, stage_succ, stage_nodes, small;
 	DevBuf b_chainlen, b_slotbase, b_node, b_qidx, b_aoutd, b_qoutd; // random-access batches
+	DevBuf pickpart;                                                  // per-block outdegree class counts of k_headers
 	DevBuf biglist, giantlist, arena, coopctl;                        // work lists; cooperative decode of giant records
 	DevBuf key16, keys;                                               // per-slot list key; hist / keyBase / cursor
 	int level_blocks = 2048;
@@ -151,6 +156,7 @@ struct bvg_graph {
 	int32_t levels_hint = 1;
 	Pending pend;
 	uint64_t last_arcs = 0;
+	int32_t last_coop_min = 0, last_giant_min = 0; // thresholds of the last range decode (bvg_last_thresholds)
 	// optional per-phase timing (bvg_set_profile): events recorded between the phases of a range decode
 	bool profile = false;
 	hipEvent_t ev[BVG_NUM_PHASES + 1] = {};
@@ -204,7 +210,8 @@ int init_handle(bvg_graph *g) {
 	if (const char *e = getenv("BVGPU_GIANT_MIN")) { g->giant_min = std::max(g->coop_min, atoi(e)); g->adaptive = false; }
 	if (const char *e = getenv("BVGPU_COOP_WAVES")) g->coop_waves = std::max(1, atoi(e));
 	if (const char *e = getenv("BVGPU_GIANT_GROUPS")) g->giant_groups = std::max(1, atoi(e));
-	if (!g->coopctl.need(16 * sizeof(int32_t)) || !g->keys.need(3 * (bv::NKEYS + 1) * sizeof(int32_t))) return fail(g, BVG_ENOMEM, "device allocation failed");
+	if (!g->coopctl.need(bv::CTL_TOTAL_INTS * sizeof(int32_t)) || !g->keys.need(3 * (bv::NKEYS + 1) * sizeof(int32_t))) return fail(g, BVG_ENOMEM, "device allocation failed");
+	HIPCHK(g, hipMemset(g->coopctl.p, 0, bv::CTL_TOTAL_INTS * sizeof(int32_t))); // (k_pick_coop leaves its counters zeroed for the next job)
 	if (const char *e = getenv("BVGPU_LEVEL_BLOCKS")) g->level_blocks = std::max(1, atoi(e));
 	if (const char *e = getenv("BVGPU_COPY_LISTS")) g->copy_lists = atoi(e);
 	if (const char *e = getenv("BVGPU_PARSE_LISTS")) g->parse_lists = atoi(e);
@@ -237,7 +244,7 @@ void mark(bvg_graph *g, int i) { if (g->profile) (void)hipEventRecord(g->ev[i], 
 
 // Enqueues headers (+halo closure) + scan for nodes [from,to) with a halo of nh nodes before `from`.
 // On return the view describes the job; rowstart lives in scratch.
-int enqueue_structure(bvg_graph *g, int32_t from, int32_t to, int32_t nh, bv::RangeView &v) {
+int enqueue_structure(bvg_graph *g, int32_t from, int32_t to, int32_t nh, bv::RangeView &v, bool pickCoop = false) {
 	const Staged &s = *g->st;
 	const int32_t lo = from - nh, cnt = to - lo;
 	if (!g->outd.need(sizeof(int32_t) * (size_t)cnt) || !g->ref.need(sizeof(uint16_t) * (size_t)cnt) ||
@@ -251,8 +258,15 @@ int enqueue_structure(bvg_graph *g, int32_t from, int32_t to, int32_t nh, bv::Ra
 	int *derr = &g->small.as<Small>()->err;
 	const bv::GraphDev gd = graph_dev(s);
 	mark(g, 0);
-	bv::launch_headers(gd, s.def, lo, cnt, v.outd, v.ref, derr, g->stream);
+	const bool pick = pickCoop && g->adaptive; // the wave-class threshold of this job comes from its outdegrees (k_pick_coop)
+	const int64_t hb = bv::headers_blocks(cnt);
+	if (pick && !g->pickpart.need(sizeof(int32_t) * 5 * (size_t)hb)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
+	bv::launch_headers(gd, s.def, lo, cnt, v.outd, v.ref, derr, g->stream, pick ? g->pickpart.as<int32_t>() : nullptr);
 	if (nh) bv::launch_mark_halo(nh, cnt, s.info.window_size, v.outd, v.ref, g->need.as<uint8_t>(), derr, g->stream);
+	if (pick) {
+		bv::launch_pick_coop(g->pickpart.as<int32_t>(), (int32_t)hb, COOP_BUDGET, g->coopctl.as<int32_t>(), g->stream);
+		v.coop_ptr = g->coopctl.as<int32_t>() + bv::CTL_COOP;
+	}
 	HIPCHK(g, hipEventRecord(g->evHdr, g->stream)); // outdegrees and references are final: the parse list can be built while the scan runs
 	mark(g, 1);
 	bv::launch_scan(v.outd, cnt, v.rowstart, g->sums.as<int64_t>(), g->stream);
@@ -283,9 +297,10 @@ int fetch_small(bvg_graph *g) {
 	return BVG_OK;
 }
 
-__global__ void k_totals(const int64_t *rowstart, int32_t nh, int32_t cnt, Small *sm) {
+__global__ void k_totals(const int64_t *rowstart, int32_t nh, int32_t cnt, Small *sm, const int32_t *coopPtr = nullptr, int32_t coopMin = 0) {
 	sm->total = rowstart[cnt] - rowstart[nh];
 	sm->halo_total = rowstart[nh];
+	sm->coop_used = coopPtr ? *coopPtr : coopMin;
 }
 
 int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_dev, int32_t *succ_dev, size_t succ_cap, bool async, uint64_t *arcs_out);
@@ -330,6 +345,7 @@ int finish_pending(bvg_graph *g, uint64_t *arcs_out) {
 	}
 	g->pend = Pending{}; // (a later job never sees this one's buffers or its "optimistic" flag)
 	g->last_arcs = (uint64_t)g->h_small->total;
+	g->last_coop_min = g->h_small->coop_used;
 	if (arcs_out) *arcs_out = g->last_arcs;
 	if (g->h_small->err) {
 		const int st = dev_err_to_status(g->h_small->err);
@@ -388,6 +404,8 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		const bool coop = coopMin < 0x7fffffff;
 		const bool ovl = g->overlap && !g->profile; // per-kernel timing needs the kernels one after the other
 		v.coop_min = coop ? coopMin : 0x7fffffff;
+		if (!coop) v.coop_ptr = nullptr;
+		g->last_giant_min = giantMin;
 		// Three things run next to each other from here on (unless profiling serialises them):
 		//   side B: classification of the long records, then the giant ones (a group of waves each) -- the longest
 		//           dependency chains of the scan, which need nothing but the outdegrees and the row starts;
@@ -422,7 +440,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			if (early) { // side B: classification and sort of the long records next to the scan (they need the outdegrees only)
 				HIPCHK(g, hipStreamWaitEvent(side_b(g), g->evHdr, 0));
 				HIPCHK(g, hipMemsetAsync(ctl, 0, 4 * sizeof(int32_t), side_b(g)));
-				bv::launch_classify(v.cnt, v.outd, coopMin, giantMin, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, side_b(g));
+				bv::launch_classify(v.cnt, v.outd, v.coop_ptr, coopMin, giantMin, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, side_b(g));
 				HIPCHK(g, hipEventRecord(g->evC, side_b(g)));
 			}
 			HIPCHK(g, hipEventRecord(g->evFork, g->stream));
@@ -431,10 +449,10 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			stLists = g->sideA;
 			if (g->early_rowptr) { // the caller's rowptr needs the scan only: written now, not at the end of the call
 				bv::launch_rebase(v.nh, v.cnt, v.rowstart, g->early_rowptr, g->sideA);
-				hipLaunchKernelGGL(k_totals, dim3(1), dim3(1), 0, g->sideA, v.rowstart, v.nh, v.cnt, g->small.as<Small>());
+				hipLaunchKernelGGL(k_totals, dim3(1), dim3(1), 0, g->sideA, v.rowstart, v.nh, v.cnt, g->small.as<Small>(), v.coop_ptr, v.coop_min);
 			}
 			if (coop && !early) {
-				bv::launch_classify(v.cnt, v.outd, coopMin, giantMin, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, side_b(g));
+				bv::launch_classify(v.cnt, v.outd, v.coop_ptr, coopMin, giantMin, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, side_b(g));
 				HIPCHK(g, hipEventRecord(g->evC, side_b(g)));
 			}
 		}
@@ -458,7 +476,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			bv::launch_build_lists(gd, v, ~0ull, g->parse_windows ? 6 : 2, nullptr, g->pkey16.as<uint16_t>(), g->pkeys.as<int32_t>(), pKeyBase, pKeyBase + (bv::NKEYS + 1), g->plist.as<int32_t>(),
 			                       g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->pad, g->stream);
 		if (earlyList || (tiles && ovl && hdrEvent)) HIPCHK(g, hipStreamWaitEvent(g->stream, g->evP, 0));
-		if (coop && !ovl) bv::launch_classify(v.cnt, v.outd, coopMin, giantMin, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, g->stream);
+		if (coop && !ovl) bv::launch_classify(v.cnt, v.outd, v.coop_ptr, coopMin, giantMin, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, g->stream);
 		mark(g, 3);
 		if (coop && !ovl) bv::launch_parse_giants(gd, s.def, v, g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->giant_groups, derr, g->stream);
 		mark(g, 4);
@@ -529,16 +547,16 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 	const bool optimistic = nh > 0 && succ_dev && !g->force_halo_sync && g->overlap && !g->profile;
 	if (optimistic) {
 		if (!g->halo.need(std::max<size_t>(g->halo.cap, g->halo_min))) return fail(g, BVG_ENOMEM, "halo allocation failed");
-		int rc = enqueue_structure(g, from, to, nh, v);
+		int rc = enqueue_structure(g, from, to, nh, v, succ_dev != nullptr);
 		if (rc) return rc;
 		v.halo_cap = g->halo.cap / sizeof(int32_t);
 	}
 	else for (;;) {
-		int rc = enqueue_structure(g, from, to, nh, v);
+		int rc = enqueue_structure(g, from, to, nh, v, succ_dev != nullptr);
 		if (rc) return rc;
 		if (nh == 0) break;
 		// the halo buffer size and the "chain escaped the window" flag need a round trip
-		hipLaunchKernelGGL(k_totals, dim3(1), dim3(1), 0, g->stream, v.rowstart, v.nh, v.cnt, g->small.as<Small>());
+		hipLaunchKernelGGL(k_totals, dim3(1), dim3(1), 0, g->stream, v.rowstart, v.nh, v.cnt, g->small.as<Small>(), (const int32_t *)nullptr, 0);
 		rc = fetch_small(g);
 		if (rc) return rc;
 		if (g->h_small->err & bv::E_ESCAPED) {
@@ -565,7 +583,7 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 	mark(g, 7);
 	if (!g->early_rowptr) {
 		bv::launch_rebase(v.nh, v.cnt, v.rowstart, rowptr_dev, g->stream);
-		hipLaunchKernelGGL(k_totals, dim3(1), dim3(1), 0, g->stream, v.rowstart, v.nh, v.cnt, g->small.as<Small>());
+		hipLaunchKernelGGL(k_totals, dim3(1), dim3(1), 0, g->stream, v.rowstart, v.nh, v.cnt, g->small.as<Small>(), v.coop_ptr, v.coop_min);
 	}
 	g->early_rowptr = nullptr;
 	mark(g, 8);
@@ -791,6 +809,14 @@ extern "C" int bvg_set_profile(bvg_t *g, int enable) {
 	if (enable && !g->ev[0]) for (auto &e : g->ev) HIPCHK(g, hipEventCreate(&e));
 	g->profile = enable != 0;
 	g->ev_valid = false;
+	return BVG_OK;
+}
+
+extern "C" int bvg_last_thresholds(bvg_t *g, int32_t *coop_min, int32_t *giant_min) {
+	if (!g || !g->st) return BVG_EARG;
+	if (g->pend.active) { int rc = finish_pending(g, nullptr); if (rc) return rc; }
+	if (coop_min) *coop_min = g->last_coop_min;
+	if (giant_min) *giant_min = g->last_giant_min;
 	return BVG_OK;
 }
 
