@@ -2,7 +2,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ["BVGPU_STATS"] = "1"
-os.environ["BVGPU_DBG"] = os.environ.get("BVGPU_DBG", "16")
+os.environ["BVGPU_DBG"] = os.environ.get("BVGPU_DBG", "144")  # 16: phase ticks of k_copy_big, 128: longest row per level
 import torch
 from scripts.ab_time import workload
 from webgraph_amd.bvgraph import BVGraph
@@ -17,7 +17,6 @@ g.debug_stats(reset=True)
 g.decode_range_device(0, n, rowptr.data_ptr(), succ.data_ptr(), succ.numel())
 st = g.debug_stats()
 print("k_copy_big rows %d, kept blocks %d (max %d), ids %d" % (st[8], st[9], st[15], st[4]))
-print("  of which on global tables: rows %d, ids %d (copied %d), longest %d" % (st[16], st[17], st[18], st[19]))
 names = ["walk", "gather", "rank", "move", "scatter", "g:gather", "g:splits", "g:tiles"]
 tot = sum(int(st[24 + i]) for i in range(8))
 for i, nm in enumerate(names):

@@ -96,7 +96,6 @@ __global__ void __launch_bounds__(CT_T) k_copy_tile(GraphDev g, RangeView v, con
 		}
 	}
 	if (!__syncthreads_or(work)) return;   // no short row with a reference starts here
-	if (g.dbg == 101) return;
 	if (__syncthreads_or(unfit)) return;   // rows past the caller's capacity: the level-wise kernels report it
 	// ---- 2. chain levels; the rows before the tile that the chains run through
 	auto walk = [&](int32_t i) -> uint32_t {
@@ -140,7 +139,6 @@ __global__ void __launch_bounds__(CT_T) k_copy_tile(GraphDev g, RangeView v, con
 		}
 		s_hn = hn; s_hp = hp;
 	}
-	if (g.dbg == 102) return;
 	// the rows to merge, sorted by chain level: a level is then ONE sweep with a row per lane (in node order a wave would
 	// meet the few rows of a level one by one, slot by slot)
 	int32_t lpos[RPT];
@@ -156,7 +154,6 @@ __global__ void __launch_bounds__(CT_T) k_copy_tile(GraphDev g, RangeView v, con
 	__syncthreads();
 	if (tid == 0) { int32_t acc = 0; for (int l = 0; l < 16; l++) { const int32_t c = s_lcnt[l]; s_lcnt[l] = acc; acc += c; } }
 	__syncthreads();
-	if (g.dbg == 103) return;
 	// ---- 3. rows and bits -> LDS: every load of a lane is in flight before its first LDS store (one memory round trip)
 	const int32_t last = nloc - 1;
 	const int32_t span = (int32_t)(v.rowstart[hs + last] - E0) + ((s_fl[last] & CF_INLDS) ? (int32_t)s_d[last] : 0);
@@ -205,7 +202,6 @@ __global__ void __launch_bounds__(CT_T) k_copy_tile(GraphDev g, RangeView v, con
 		}
 	}
 	__syncthreads();
-	if (g.dbg == 104) return;
 	const TWin tw{ (const lds_u32 *)s_win, nw, w0, g.bits, g.nwords };
 	constexpr int ZK = DEF == 1 ? 3 : 0;
 	const uint32_t zk = ZK == 3 ? 3u : (uint32_t)g.zetaK;
@@ -279,7 +275,6 @@ __global__ void __launch_bounds__(CT_T) k_copy_tile(GraphDev g, RangeView v, con
 		}
 		__syncthreads();
 	}
-	if (g.dbg == 105) return;
 	// ---- 5. what changed goes back (rows in between are rewritten with what was loaded)
 	const int32_t mlo = s_modlo, mhi = s_modhi;
 	if (mlo < mhi) for (int32_t e = mlo + tid; e < mhi; e += CT_T) *gaddr(E0 + e) = s_out[CT_HOUT + e];

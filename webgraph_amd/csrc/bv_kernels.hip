@@ -866,13 +866,11 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 		const unsigned long long tRow0 = tk;
 		CT(0);
 		const unsigned long long tWalk = tk - tRow0;
-#define ROWDBG() do { if (g.stats && (g.dbg & 128) && threadIdx.x == 0) { const unsigned long long tot_ = __builtin_readcyclecounter() - tRow0; atomicMax(&g.stats[min(level, 3) - 1], tot_); atomicMax(&g.stats[3], tWalk); } \
-		if ((g.dbg & 64) && threadIdx.x == 0) { const unsigned long long tot_ = __builtin_readcyclecounter() - tRow0; if (tot_ > 200000) printf("row s=%d lvl=%d d=%d dref=%ld copied=%ld nKept=%d where=%ld walk=%llu total=%llu\n", s, level, d, (long)dref, (long)copied, nKept, (long)where, tWalk, tot_); } } while (0)
+#define ROWDBG() do { if (g.stats && (g.dbg & 128) && threadIdx.x == 0) { const unsigned long long tot_ = __builtin_readcyclecounter() - tRow0; atomicMax(&g.stats[min(level, 3) - 1], tot_); atomicMax(&g.stats[3], tWalk); } } while (0)
 		if (where == -2) { merge_row(cpos, delta, cval, cpos, (int32_t)copied, nKept); ROWDBG(); continue; } // (copied <= dref <= COPY_BIG_CAP, nKept <= COPY_BIG_CAP + 1)
 		const int64_t cMaxRow = dref < (int64_t)d ? dref : (int64_t)d;
 		if (nKept > kMax || copied > cMaxRow) continue; // (cannot happen: the bounds above)
 		if (g.dbg & 32) { int32_t *gv = tabD + kMax, *gp = gv + cMaxRow; merge_row(tabK, tabD, gv, gp, (int32_t)copied, nKept); continue; } // (the element-wise merge on global tables, kept for A/B timing: BVGPU_DBG=32)
-		if (g.stats && threadIdx.x == 0) { stat_add(g, 16, 1); stat_add(g, 17, (unsigned long long)d); stat_add(g, 18, (unsigned long long)copied); stat_max(g, 19, (unsigned long long)d); }
 		merge_row_stream(tabK, tabD, tabD + kMax, (int32_t)copied, nKept);
 		ROWDBG();
 #undef CT

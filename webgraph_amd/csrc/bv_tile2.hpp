@@ -246,7 +246,6 @@ __global__ void __launch_bounds__(T2_T) k_parse_tile2(GraphDev g, RangeView v, c
 	}
 	__syncthreads();
 	T2_TICK(1);
-	if (g.dbg == 101) return;
 	const int32_t njobs = min(s_njobs, T2_JOBS), nivs = min(s_nivs, T2_IVS);
 	if (g.stats && tid == 0) { atomicAdd(&g.stats[8], 1ull); atomicAdd(&g.stats[10], (unsigned long long)njobs); }
 	if (njobs == 0) return;
@@ -309,7 +308,6 @@ __global__ void __launch_bounds__(T2_T) k_parse_tile2(GraphDev g, RangeView v, c
 		return lo2;
 	};
 	T2_TICK(2);
-	if (g.dbg == 102) return;
 	if (g.stats && tid == 0) atomicAdd(&g.stats[11], (unsigned long long)S);
 	// ---- R1: every segment parsed from a guessed boundary
 	int32_t myJob[T2_SPL];
@@ -336,7 +334,6 @@ __global__ void __launch_bounds__(T2_T) k_parse_tile2(GraphDev g, RangeView v, c
 	}
 	__syncthreads();
 	T2_TICK(3);
-	if (g.dbg == 103) return;
 	// ---- R2: a segment starts where its left neighbour ended
 	for (int round = 0; round < T2_SEGS + 2; round++) {
 		uint32_t want[T2_SPL];
@@ -364,7 +361,6 @@ __global__ void __launch_bounds__(T2_T) k_parse_tile2(GraphDev g, RangeView v, c
 		if (!__syncthreads_or(changed)) break;
 	}
 	T2_TICK(4);
-	if (g.dbg == 104) return;
 	// ---- R3: codes and sums before every segment (exclusive prefix in segment order: chunk i = segments [i * T2_T, (i + 1) * T2_T))
 	{
 		int32_t carryC = 0, carryS = 0;
@@ -384,7 +380,6 @@ __global__ void __launch_bounds__(T2_T) k_parse_tile2(GraphDev g, RangeView v, c
 	}
 	__syncthreads();
 	T2_TICK(5);
-	if (g.dbg == 105) return;
 	// ---- R4: the residuals at their final places; every interval learns how many residuals precede it
 #pragma unroll
 	for (int i = 0; i < T2_SPL; i++) {
@@ -396,7 +391,7 @@ __global__ void __launch_bounds__(T2_T) k_parse_tile2(GraphDev g, RangeView v, c
 		int32_t jj = (int32_t)(sg_c[gs] - sg_c[g0]);
 		if (gs == g1 - 1 && jj + (int32_t)cnt != nRes) atomicOr(err, E_FORMAT); // the section does not hold the residuals the header promises
 		int32_t val = j_x[j] + (sg_sum[gs] - sg_sum[g0]);
-		const int32_t ic = (g.dbg & 2) ? 0 : j_ic[j], ivb = j_iv[j];
+		const int32_t ic = j_ic[j], ivb = j_iv[j];
 		const int64_t rowEl = E0 + (int64_t)j_row[j];
 		const int32_t ivArcs = ic ? (int32_t)iv_p[ivb + ic - 1] + (int32_t)iv_len[ivb + ic - 1] : 0;
 		int32_t ii = 0;
@@ -410,7 +405,7 @@ __global__ void __launch_bounds__(T2_T) k_parse_tile2(GraphDev g, RangeView v, c
 		TFast p{ sg_s[gs] };
 		const uint32_t secStart = j_q[j];
 		int e2 = 0;
-		for (uint32_t t2 = 0; t2 < cnt && jj < nRes && !(g.dbg & 4); t2++, jj++) {
+		for (uint32_t t2 = 0; t2 < cnt && jj < nRes; t2++, jj++) {
 			const bool first = p.q == secStart;
 			const uint64_t cv = p.code<0, ZK>(tw, zk, e2);
 			val += first ? (int32_t)nat2int(cv) : (int32_t)cv + 1; // BVG:954, :966
@@ -419,13 +414,12 @@ __global__ void __launch_bounds__(T2_T) k_parse_tile2(GraphDev g, RangeView v, c
 				nextLeft = ii < ic ? iv_left[ivb + ii] : 0x7fffffff;
 				before = ii < ic ? (int32_t)iv_p[ivb + ii] : ivArcs;
 			}
-			if (!(g.dbg & 1)) *gaddr(rowEl + jj + before) = val;
+			*gaddr(rowEl + jj + before) = val;
 		}
 		if (e2) atomicOr(err, e2);
 	}
 	__syncthreads();
 	T2_TICK(6);
-	if (g.dbg == 106) return;
 	// ---- X: interval ids at their final places: interval i occupies [arcs before it + residuals before it, + len)
 	for (int32_t base = 0; base < nivs; base += T2_T) {
 		const int32_t idx = base + tid;
