@@ -48,12 +48,14 @@ def c2():
 
 @pytest.mark.timeout(900)
 def test_c2_full_size_default_thresholds(c2):
-    """The headline configuration, whole: 200 M arcs, so the job-size dependent thresholds are the full-scan ones (a wave
-    per record from 2 048 successors, a group of waves from 32 768)."""
+    """The headline configuration, whole: 200 M arcs.  The thresholds are the full-scan ones: a wave per record from 2 048
+    successors (counted on the device: 7 121 records have that many, 15 410 have 1 024), a group of waves from 32 768."""
     g, og = c2
     assert g.numNodes() == C2["n"] and g.numArcs() == C2["m"]
     rowptr, succ, arcs = _device_scan(g)
     assert arcs == C2["m"]
+    if not any(k in os.environ for k in ("BVGPU_COOP_MIN", "BVGPU_GIANT_MIN")):
+        assert g.last_thresholds() == (2048, 32768)
     orp, osc, oarcs = og.scan_mt()
     assert oarcs == arcs
     assert np.array_equal(rowptr.cpu().numpy(), orp), "rowptr differs from the CPU oracle"
@@ -174,6 +176,9 @@ def test_tiled_cnr_web_shape(tmp_path_factory, cnr_oracle):
     g = BVGraph.load(base)
     d_rowptr, d_succ, arcs = _device_scan(g)
     assert arcs == succ.size
+    if not any(k in os.environ for k in ("BVGPU_COOP_MIN", "BVGPU_GIANT_MIN")):
+        deg = np.diff(rowptr)
+        assert int((deg >= 128).sum()) <= 12288 and g.last_thresholds() == (128, 8192)  # few long rows: all of them go to whole waves
     assert np.array_equal(d_rowptr.cpu().numpy(), rowptr) and np.array_equal(d_succ.cpu().numpy(), succ)
     h, a = g.scan_checksum()
     assert a == arcs and h == g.csr_hashcode(0, g.numNodes(), d_rowptr.data_ptr(), d_succ.data_ptr(), -1)

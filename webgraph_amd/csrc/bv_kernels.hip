@@ -611,7 +611,7 @@ __global__ void __launch_bounds__(64 * COPY_MID_WAVES) k_copy_mid(GraphDev g, Ra
 #endif
 // (512 threads and LDS tables for 2048 copied ids -- 38 KB of LDS, four groups per CU instead of one -- changed nothing on C2 and
 // cnr-2000 x30 and cost 4 % on C5: a level of k_copy_big lasts as long as its longest row, not as long as its rows in sum.)
-constexpr int COPY_BIG_THREADS = COPY_BIG_THREADS_, COPY_BIG_CAP = COPY_BIG_CAP_, COPY_BIG_ITEMS = 8, COPY_BIG_FIRST = 16384, COPY_BIG_GRID = 256 * (2048 / COPY_BIG_THREADS);
+constexpr int COPY_BIG_THREADS = COPY_BIG_THREADS_, COPY_BIG_CAP = COPY_BIG_CAP_, COPY_BIG_ITEMS = 8, COPY_BIG_FIRST = 16384, COPY_BIG_TAKE = 8, COPY_BIG_GRID = 256 * (2048 / COPY_BIG_THREADS);
 // One 1024-thread group per long row with a reference.  The block list is walked once, without memory traffic
 // (it is the serial part of a row with thousands of blocks), into the same two LDS tables as in k_copy_mid; the
 // copied ids (<= COPY_BIG_CAP of them) are then gathered into LDS and ranked among the row's extras
@@ -636,14 +636,24 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 	// The queue holds the long rows of ALL levels; a group takes the next entry that is of this level and of this pass from a
 	// shared head (rows differ by 200x in length: fixed shares left most groups idle while a few worked through several
 	// giant rows).  Two passes, the rows of >= COPY_BIG_FIRST ids first, so that the longest merges start at once.
+	// (entries are taken COPY_BIG_TAKE at a time: one atomic and two barriers per entry made the kernel 0.56 ms on C2, whose queue
+	// holds 20 000 rows of all levels, most of them skipped)
 	__shared__ int32_t s_qi;
 	const int32_t nq = min(*count, cap);
+	// A take is COPY_BIG_TAKE entries a stride apart, not neighbours: long rows come in runs of similar neighbours (C5), which must not
+	// land in one group.
+	const int32_t stride = (2 * nq + COPY_BIG_TAKE - 1) / COPY_BIG_TAKE;
+	int32_t qbase = 0, qoff = COPY_BIG_TAKE;
 	for (;;) {
-		__syncthreads(); // everybody has read s_qi, the tables are free
-		if (threadIdx.x == 0) s_qi = atomicAdd(&qhead[0], 1);
-		__syncthreads();
-		const int32_t qraw = s_qi;
-		if (qraw >= 2 * nq) break;
+		if (qoff >= COPY_BIG_TAKE) {
+			__syncthreads(); // everybody has read s_qi
+			if (threadIdx.x == 0) s_qi = atomicAdd(&qhead[0], 1);
+			__syncthreads();
+			qbase = s_qi; qoff = 0;
+			if (qbase >= stride) break;
+		}
+		const int32_t qraw = qbase + stride * qoff++;
+		if (qraw >= 2 * nq) continue;
 		const int32_t qi = qraw >= nq ? qraw - nq : qraw;
 		const int32_t s = queue[qi];
 		if (depth[s] != level || (v.outd[s] >= COPY_BIG_FIRST) != (qraw < nq) || copy_class(v, depth, level, s, 0, 0x7fffffff) == 0) continue;
@@ -1364,6 +1374,7 @@ constexpr int PICK_THREADS = 1024;
 __global__ void __launch_bounds__(PICK_THREADS) k_pick_coop(const int32_t *__restrict__ part, int32_t nblocks, int32_t budget, int32_t *__restrict__ ctl) {
 	__shared__ int32_t s_cnt[5];
 	if (threadIdx.x < 5) s_cnt[threadIdx.x] = 0;
+	if (threadIdx.x >= 64 && threadIdx.x < 64 + 12) ctl[4 + (threadIdx.x - 64)] = 0; // counters of the level lists, copy queues and copy levels of this job
 	__syncthreads();
 #pragma unroll
 	for (int k = 0; k < 5; k++) {
@@ -1463,6 +1474,10 @@ void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int
 	int32_t midMin, bigMin;
 	copy_thresholds(midMinKnob, bigGroups, midMin, bigMin);
 	const bool split = stMid != st || stBig != st;
+	// The groups of k_copy_big need a whole CU's LDS and 1 024 thread slots each: launched behind the list kernel they wait for its
+	// blocks to drain and end 0.13 ms after it (C2, level 1).  So they go first, on the level's own stream, and the list kernel takes
+	// the side stream.
+	const hipStream_t stList = bigGroups ? stBig : st;
 	if (split) {
 		(void)hipEventRecord(evFork, st);
 		if (stMid != st) (void)hipStreamWaitEvent(stMid, evFork, 0);
@@ -1472,10 +1487,9 @@ void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int
 		// ctl[8 + 2 (level & 3)], ctl[9 + 2 (level & 3)]: this level's bump pointer into the scratch tables (the previous level's are free
 		// again) and the head of its work queue.  Level l zeroes the pair of level l + 1 (no memset launches between the levels);
 		// the job's set-up zeroes all four pairs.
-		if (def == 1) hipLaunchKernelGGL(k_copy_big<1>, dim3(COPY_BIG_GRID), dim3(COPY_BIG_THREADS), 0, stBig, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 8 + 2 * (level & 3)), ctl + 9 + 2 * (level & 3), ctl + 8 + 2 * ((level + 1) & 3), err);
-		else if (def == 2) hipLaunchKernelGGL(k_copy_big<2>, dim3(COPY_BIG_GRID), dim3(COPY_BIG_THREADS), 0, stBig, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 8 + 2 * (level & 3)), ctl + 9 + 2 * (level & 3), ctl + 8 + 2 * ((level + 1) & 3), err);
-		else hipLaunchKernelGGL(k_copy_big<0>, dim3(COPY_BIG_GRID), dim3(COPY_BIG_THREADS), 0, stBig, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 8 + 2 * (level & 3)), ctl + 9 + 2 * (level & 3), ctl + 8 + 2 * ((level + 1) & 3), err);
-		if (stBig != st) (void)hipEventRecord(evBig, stBig);
+		if (def == 1) hipLaunchKernelGGL(k_copy_big<1>, dim3(COPY_BIG_GRID), dim3(COPY_BIG_THREADS), 0, st, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 8 + 2 * (level & 3)), ctl + 9 + 2 * (level & 3), ctl + 8 + 2 * ((level + 1) & 3), err);
+		else if (def == 2) hipLaunchKernelGGL(k_copy_big<2>, dim3(COPY_BIG_GRID), dim3(COPY_BIG_THREADS), 0, st, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 8 + 2 * (level & 3)), ctl + 9 + 2 * (level & 3), ctl + 8 + 2 * ((level + 1) & 3), err);
+		else hipLaunchKernelGGL(k_copy_big<0>, dim3(COPY_BIG_GRID), dim3(COPY_BIG_THREADS), 0, st, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 8 + 2 * (level & 3)), ctl + 9 + 2 * (level & 3), ctl + 8 + 2 * ((level + 1) & 3), err);
 	}
 	if (midMin < bigMin) {
 		if (def == 1) hipLaunchKernelGGL(k_copy_mid<1>, dim3(1024), dim3(64 * COPY_MID_WAVES), 0, stMid, g, v, depth, midQ, ctl + 6, midCap, level, err);
@@ -1483,11 +1497,12 @@ void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int
 		else hipLaunchKernelGGL(k_copy_mid<0>, dim3(1024), dim3(64 * COPY_MID_WAVES), 0, stMid, g, v, depth, midQ, ctl + 6, midCap, level, err);
 	}
 	if (stMid != st) (void)hipEventRecord(evMid, stMid);
-	if (def == 1) hipLaunchKernelGGL(k_copy_list<1>, dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, midMin, bigMin, err);
-	else if (def == 2) hipLaunchKernelGGL(k_copy_list<2>, dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, midMin, bigMin, err);
-	else hipLaunchKernelGGL(k_copy_list<0>, dim3(blocks), dim3(TPB), 0, st, g, v, depth, list, keyBase, level, midMin, bigMin, err);
+	if (def == 1) hipLaunchKernelGGL(k_copy_list<1>, dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
+	else if (def == 2) hipLaunchKernelGGL(k_copy_list<2>, dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
+	else hipLaunchKernelGGL(k_copy_list<0>, dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
+	if (stList != st) (void)hipEventRecord(evBig, stList);
 	if (stMid != st) (void)hipStreamWaitEvent(st, evMid, 0);
-	if (bigGroups && stBig != st) (void)hipStreamWaitEvent(st, evBig, 0);
+	if (stList != st) (void)hipStreamWaitEvent(st, evBig, 0);
 }
 
 int32_t tile_count(int64_t bitSpan, int32_t cnt) { return (int32_t)std::min<int64_t>((bitSpan + (int64_t)TILE_NODE_BITS * cnt) / TILE_SPAN + 1, 0x7ffffff0); }
