@@ -226,9 +226,9 @@ int64_t bvg_flags_from_string(const char *s);
 /* OffsetsLongIterator (BVG:907-935): decodes n+1 gamma/delta coded gaps of a .offsets image into running sums. */
 int bvg_decode_offsets_host(const uint8_t *offsets_file, size_t len, int32_t nodes, int offset_coding, int64_t *out);
 
-/* [device] The same decode on the GPU (bv_offsets.hip; what bvg_open uses for gamma-coded offsets): OffsetsLongIterator
- * (BVG:907-935) as a grid-wide cooperative decode of the gap stream.  `out` is a HOST array of nodes + 1 values.
- * BVG_EUNSUPPORTED for delta-coded offsets, BVG_EFORMAT when the stream does not hold exactly nodes + 1 codes. */
+/* [device] The same decode on the GPU (bv_offsets.hip; what bvg_open uses): OffsetsLongIterator (BVG:907-935) as a grid-wide
+ * cooperative decode of the gap stream, gamma- or delta-coded.  `out` is a HOST array of nodes + 1 values.
+ * BVG_EFORMAT when the stream does not hold exactly nodes + 1 codes. */
 int bvg_decode_offsets_device(int device, const uint8_t *offsets_file, size_t len, int32_t nodes, int offset_coding, int64_t *out);
 
 /* ---- arc labels ----------------------------------------------------------------

@@ -41,6 +41,21 @@ def test_synthetic_offsets_on_device(tmp_path_factory, n, m, seed):
     g.close()
 
 
+@pytest.mark.parametrize("n,m,seed", [(64, 300, 13), (5000, 60000, 14), (300000, 9000000, 15)])
+def test_delta_coded_offsets_on_device(tmp_path_factory, n, m, seed):
+    """OFFSETS_DELTA (CompressionFlags.java, the offset_coding field of BVG:1317-1325): the same kernels with the delta decoder."""
+    from webgraph_amd.bvgraph import BVGraph, decode_offsets_device, decode_offsets_host, flags_from_string
+    base, rowptr, succ = make_graph(tmp_path_factory, "offd%d" % n, n, m, seed, 0.5, window=7, max_ref_count=3, min_interval=4, flags=flags_from_string("OFFSETS_DELTA"))
+    raw = open(base + ".offsets", "rb").read()
+    host = decode_offsets_host(raw, n, 1)
+    assert np.array_equal(decode_offsets_device(raw, n, coding=1), host)
+    g = BVGraph.load(base)
+    assert g.info.offset_coding == 1 and g.info.offsets_on_device == 1
+    rp, sc = g.decode_range()
+    assert np.array_equal(rp, rowptr) and np.array_equal(sc, succ)
+    g.close()
+
+
 def test_offsets_rejects_wrong_count_and_delta():
     from webgraph_amd.bvgraph import decode_offsets_device
     raw = open(CNR + ".offsets", "rb").read()
@@ -49,7 +64,7 @@ def test_offsets_rejects_wrong_count_and_delta():
     with pytest.raises(Exception):
         decode_offsets_device(raw, 1000)        # fewer: the count must match exactly
     with pytest.raises(Exception):
-        decode_offsets_device(raw, 325557, coding=1)  # delta-coded offsets are decoded on the host
+        decode_offsets_device(raw, 325557, coding=1)  # a gamma stream read as delta codes does not hold n + 1 of them
 
 
 def test_host_offsets_knob(monkeypatch):

@@ -272,14 +272,14 @@ __device__ __forceinline__ bool fast_zeta(uint64_t W, uint32_t krt, uint64_t &v,
 	else { v = ((m << 1) | ((W2 >> (63u - nb)) & 1)) - 1; len = h + 2 + nb; }
 	return true;
 }
-// one code at bit position p of the staged window; advances p.  KIND 0: residual code, KIND 1 / 2: gamma code
+// one code at bit position p of the staged window; advances p.  KIND 0: residual code, KIND 1 / 2: gamma code, KIND 3: delta code
 template <int DEF, int KIND>
 __device__ __forceinline__ uint64_t win_code(const GraphDev &g, const WindowSrc &src, uint64_t &p, int &err) {
 	uint64_t W, v; uint32_t len;
-	if ((KIND != 0 || DEF) && win_peek64(src, p, W) && (KIND != 0 ? fast_gamma(W, v, len) : fast_zeta<DEF == 1 ? 3 : 0>(W, DEF == 1 ? 3u : (uint32_t)g.zetaK, v, len))) { p += len; return v; }
+	if (KIND != 3 && (KIND != 0 || DEF) && win_peek64(src, p, W) && (KIND != 0 ? fast_gamma(W, v, len) : fast_zeta<DEF == 1 ? 3 : 0>(W, DEF == 1 ? 3u : (uint32_t)g.zetaK, v, len))) { p += len; return v; }
 	WinReader br; br.init_src(src, g.nwords);
 	br.seek(p);
-	v = KIND != 0 ? br.gamma() : Fields<DEF>::residual(br, g);
+	v = KIND == 3 ? br.delta() : KIND != 0 ? br.gamma() : Fields<DEF>::residual(br, g);
 	p = br.pos();
 	err |= br.err;
 	return v;
@@ -294,6 +294,16 @@ __device__ __forceinline__ bool fast_gamma32(uint32_t W, uint32_t &v, uint32_t &
 	const uint32_t m = (uint32_t)__clz((int)W);
 	len = 2 * m + 1;
 	v = (W >> (31u - 2 * m)) - 1;
+	return true;
+}
+// delta: gamma(L) then the L low bits of value + 1 (its top bit is implied); codes of up to 32 bits (values < 2^12 .. 2^13)
+__device__ __forceinline__ bool fast_delta32(uint32_t W, uint32_t &v, uint32_t &len) {
+	if (W < (1u << 27)) return false; // gamma part longer than 9 bits: L > 30
+	const uint32_t m = (uint32_t)__clz((int)W), lg = 2 * m + 1;
+	const uint32_t L = (W >> (31u - 2 * m)) - 1;
+	if (lg + L > 32u) return false;
+	v = L ? ((1u << L) | ((W << lg) >> (32u - L))) - 1 : 0;
+	len = lg + L;
 	return true;
 }
 template <int K>
@@ -342,7 +352,7 @@ __device__ __forceinline__ uint64_t win_code_rel(const GraphDev &g, const Window
 		const uint64_t ab = ((uint64_t)src.win[j] << 32) | src.win[j + 1];
 		const uint32_t W = (uint32_t)((ab << (q & 31u)) >> 32);
 		uint32_t v, len;
-		if (__builtin_expect(KIND != 0 ? fast_gamma32(W, v, len) : fast_zeta_32<DEF == 1 ? 3 : 0>(W, DEF == 1 ? 3u : (uint32_t)g.zetaK, v, len), 1)) { q += len; return v; }
+		if (__builtin_expect(KIND == 3 ? fast_delta32(W, v, len) : KIND != 0 ? fast_gamma32(W, v, len) : fast_zeta_32<DEF == 1 ? 3 : 0>(W, DEF == 1 ? 3u : (uint32_t)g.zetaK, v, len), 1)) { q += len; return v; }
 	}
 	const SlowCode sc = win_code_slow<DEF, KIND>(&g, src.win, src.w0, src.nw, q);
 	q = sc.q;
@@ -352,7 +362,7 @@ __device__ __forceinline__ uint64_t win_code_rel(const GraphDev &g, const Window
 
 // One speculative parse of the codes starting in [s, segEnd): end position, count and the sum of the decoded
 // contributions.  KIND 0: residual codes (gap+1 each; the first code of the section is the zig-zag value);
-// KIND 1: gamma codes, positions only; KIND 2: gamma codes, the sum of their values (offset gaps, bv_offsets.hip).
+// KIND 1: gamma codes, positions only; KIND 2 / 3: gamma / delta codes, the sum of their values (offset gaps, bv_offsets.hip).
 template <int DEF, int KIND>
 __device__ __forceinline__ void spec_parse(const GraphDev &g, const WindowSrc &src, uint64_t base, uint32_t s, uint32_t segEnd, bool firstOfSection, uint32_t &e, uint32_t &c, int64_t &sum) {
 	c = 0; sum = 0;
@@ -362,8 +372,8 @@ __device__ __forceinline__ void spec_parse(const GraphDev &g, const WindowSrc &s
 	while (p < segEnd && !err) {
 		const uint64_t v = win_code_rel<DEF, KIND>(g, src, p, err);
 		if (KIND == 0) sum += (int64_t)v + 1;
-		if (KIND == 2 && !err) sum += (int64_t)v;
-		if (KIND == 2 && err) break; // (a gap stream ends in zero padding: not a code)
+		if (KIND >= 2 && !err) sum += (int64_t)v;
+		if (KIND >= 2 && err) break; // (a gap stream ends in zero padding: not a code)
 		c++;
 	}
 	e = err ? 0x7fffff00u : p;
@@ -384,8 +394,8 @@ __device__ __forceinline__ void spec_resync(const GraphDev &g, const WindowSrc &
 		int err = 0;
 		const uint64_t v = win_code_rel<DEF, KIND>(g, src, q, err);
 		if (err) q = 0x7fffff00u; // garbage: this chain ends here (as in spec_parse)
-		const int64_t w = KIND == 0 ? (int64_t)v + 1 : KIND == 2 ? (int64_t)v : 0;
-		if (KIND == 2 && err) { if (adv) pn = q; else po = q; continue; } // padding: ends the chain, counts nothing
+		const int64_t w = KIND == 0 ? (int64_t)v + 1 : KIND >= 2 ? (int64_t)v : 0;
+		if (KIND >= 2 && err) { if (adv) pn = q; else po = q; continue; } // padding: ends the chain, counts nothing
 		if (adv) { pn = q; dc++; ds += w; }
 		else { po = q; dc--; ds -= w; }
 	}

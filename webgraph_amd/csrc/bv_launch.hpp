@@ -99,7 +99,7 @@ void launch_bfs_expand(const int32_t *frontier, int32_t q, const int64_t *rowptr
                        int32_t *out, uint64_t outCap, unsigned long long *outCount, hipStream_t st);
 
 // bv_offsets.hip: gamma-coded .offsets stream (words + >= 8 zero words in HBM) -> int64 offsets[nodes + 1] in HBM
-int offsets_decode_device(const uint32_t *d_words, uint64_t nwords, uint64_t totalBits, int32_t nodes, int64_t *d_out, hipStream_t st);
+int offsets_decode_device(const uint32_t *d_words, uint64_t nwords, uint64_t totalBits, int32_t nodes, int64_t *d_out, hipStream_t st, bool deltaCoded = false);
 // arc labels (.labels stream in HBM, same padding): `count` consecutive labels starting at bit `startBit`
 int gamma_labels_decode_device(const uint32_t *d_words, uint64_t nwords, uint64_t startBit, uint64_t endBit, int64_t count, int32_t *d_out, hipStream_t st);
 int fixed_labels_decode_device(const uint32_t *d_words, uint64_t nwords, uint64_t startBit, int32_t width, int64_t count, int32_t *d_out, hipStream_t st);

@@ -9,7 +9,8 @@
 // predecessor's end from the previous round and parsing again only if that moved its start -- universal codes
 // re-synchronise within a few codewords, so round 1 repairs a handful of chunks and round 2 finds nothing to do.
 // Two scans over the chunks (codes, gap sums) and a value pass then write off[i] = sum of the first i+1 gaps.
-// Only gamma-coded offsets (the default, A.4 of SURVEY.md); delta-coded files take the host decoder.
+// gamma-coded offsets (the default, A.4 of SURVEY.md) and delta-coded ones (OFFSETS_DELTA): the codeword decoder is a template
+// argument (KIND 2 / 3 of bv_coop.hpp), the speculation is the same -- both codes are self-delimiting and re-synchronise.
 #include "bv_coop.hpp"
 #include "bv_launch.hpp"
 
@@ -26,6 +27,7 @@ __device__ __forceinline__ GraphDev offsets_stream(const uint32_t *words, uint64
 }
 
 // round 0: every chunk guesses its start by run-in; round r > 0: start = end of the previous chunk in round r-1
+template <int KIND>
 __global__ void __launch_bounds__(64) k_off_parse(const uint32_t *__restrict__ words, uint64_t nwords, uint64_t startBit, uint64_t totalBits, int64_t nchunks, int round,
                                                   const uint64_t *__restrict__ endPrev, uint64_t *__restrict__ endNew, uint64_t *__restrict__ startUsed,
                                                   uint32_t *__restrict__ cnt, int64_t *__restrict__ gapsum, OffLane *__restrict__ lanes, int *__restrict__ changed) {
@@ -47,14 +49,14 @@ __global__ void __launch_bounds__(64) k_off_parse(const uint32_t *__restrict__ w
 		uint32_t p = (uint32_t)(posW - base);
 		const uint32_t a0 = (uint32_t)(anchor - base);
 		int err = 0;
-		while (p < a0 && !err) (void)win_code_rel<1, 2>(g, src, p, err);
+		while (p < a0 && !err) (void)win_code_rel<1, KIND>(g, src, p, err);
 		start = err ? anchor : base + p;
 	}
 	// a start that is not in [anchor, anchor + 64 + OFF_SEG) cannot come from a valid stream: keep the lanes in range
 	if (start < anchor) start = anchor;
 	if (start > anchor + OFF_SEG) start = anchor + OFF_SEG;
 	uint32_t s, n; int64_t sum; uint64_t E;
-	spec_tile<1, 2, 1>(G, g, src, start, totalBits, OFF_SEG, false, INT64_MAX, s, n, sum, E, anchor);
+	spec_tile<1, KIND, 1>(G, g, src, start, totalBits, OFF_SEG, false, INT64_MAX, s, n, sum, E, anchor);
 	int64_t ntot, stot;
 	(void)G.incl_scan((int64_t)n, ntot);
 	(void)G.incl_scan(sum, stot);
@@ -90,7 +92,7 @@ __global__ void __launch_bounds__(1024) k_off_scan(const uint32_t *__restrict__ 
 }
 
 // value pass: every lane decodes the codes it owns again and writes the running sums
-template <bool PREFIX, class T>
+template <bool PREFIX, class T, int KIND>
 __global__ void __launch_bounds__(64) k_off_values(const uint32_t *__restrict__ words, uint64_t nwords, uint64_t startBit, int64_t nchunks, const OffLane *__restrict__ lanes,
                                                    const int64_t *__restrict__ cntBase, const int64_t *__restrict__ sumBase, int64_t nOut, T *__restrict__ out) {
 	__shared__ __attribute__((aligned(16))) uint32_t lds[CoopLds<1>::WORDS];
@@ -108,7 +110,7 @@ __global__ void __launch_bounds__(64) k_off_values(const uint32_t *__restrict__ 
 	uint32_t p = (uint32_t)(anchor + me.s - (src.w0 << 5));
 	int err = 0;
 	for (uint32_t k = 0; k < me.c; k++) {
-		const int64_t v = (int64_t)win_code_rel<1, 2>(g, src, p, err);
+		const int64_t v = (int64_t)win_code_rel<1, KIND>(g, src, p, err);
 		acc += v;
 		if (idx < nOut) out[idx] = (T)(PREFIX ? acc : v); // offsets: running sum of the gaps; labels: the values themselves
 		idx++;
@@ -132,8 +134,8 @@ __global__ void __launch_bounds__(256) k_fixed_width(const uint32_t *__restrict_
 // back to the host decoder, which produces the precise error).
 // One contiguous stream of gamma codes in [startBit, endBit) holding exactly nOut codes: running sums -> int64 (offsets)
 // or the values themselves -> int32 (gamma-coded labels).  startBit must be a codeword boundary.
-template <bool PREFIX, class T>
-static int gamma_stream_decode(const uint32_t *d_words, uint64_t nwords, uint64_t startBit, uint64_t totalBits, int64_t nOut, T *d_out, hipStream_t st) {
+template <bool PREFIX, class T, int KIND>
+static int code_stream_decode(const uint32_t *d_words, uint64_t nwords, uint64_t startBit, uint64_t totalBits, int64_t nOut, T *d_out, hipStream_t st) {
 	if (nOut == 0) return totalBits == startBit ? 0 : -1;
 	const int64_t nchunks = totalBits > startBit ? (int64_t)((totalBits - startBit + OFF_CHUNK - 1) / OFF_CHUNK) : 0;
 	if (nchunks <= 0 || nchunks > 0x7fffffff) return -1;
@@ -152,7 +154,7 @@ static int gamma_stream_decode(const uint32_t *d_words, uint64_t nwords, uint64_
 		bool fine = true;
 		for (int round = 0; round < 64 && fine; round++) { // (a round only repeats while some chunk's end still moves: 2-3 rounds)
 			fine = ok(hipMemsetAsync(changed, 0, sizeof(int), st));
-			hipLaunchKernelGGL(k_off_parse, dim3((unsigned)nchunks), dim3(64), 0, st, d_words, nwords, startBit, totalBits, nchunks, round, ends + (size_t)cur * nchunks,
+			hipLaunchKernelGGL(k_off_parse<KIND>, dim3((unsigned)nchunks), dim3(64), 0, st, d_words, nwords, startBit, totalBits, nchunks, round, ends + (size_t)cur * nchunks,
 			                   ends + (size_t)(cur ^ 1) * nchunks, startUsed, cnt, gapsum, lanes, changed);
 			cur ^= 1;
 			int h = 0;
@@ -164,7 +166,7 @@ static int gamma_stream_decode(const uint32_t *d_words, uint64_t nwords, uint64_
 			hipLaunchKernelGGL(k_off_scan, dim3(1), dim3(1024), 0, st, cnt, gapsum, nchunks, cntBase, sumBase, total);
 			int64_t h = -1;
 			if (ok(hipMemcpyAsync(&h, total, sizeof(int64_t), hipMemcpyDeviceToHost, st)) && ok(hipStreamSynchronize(st)) && h == nOut) {
-				hipLaunchKernelGGL((k_off_values<PREFIX, T>), dim3((unsigned)nchunks), dim3(64), 0, st, d_words, nwords, startBit, nchunks, lanes, cntBase, sumBase, nOut, d_out);
+				hipLaunchKernelGGL((k_off_values<PREFIX, T, KIND>), dim3((unsigned)nchunks), dim3(64), 0, st, d_words, nwords, startBit, nchunks, lanes, cntBase, sumBase, nOut, d_out);
 				if (ok(hipStreamSynchronize(st))) rc = 0;
 			}
 		}
@@ -173,13 +175,14 @@ static int gamma_stream_decode(const uint32_t *d_words, uint64_t nwords, uint64_
 	return rc;
 }
 
-int offsets_decode_device(const uint32_t *d_words, uint64_t nwords, uint64_t totalBits, int32_t nodes, int64_t *d_out, hipStream_t st) {
-	return gamma_stream_decode<true, int64_t>(d_words, nwords, 0, totalBits, (int64_t)nodes + 1, d_out, st);
+int offsets_decode_device(const uint32_t *d_words, uint64_t nwords, uint64_t totalBits, int32_t nodes, int64_t *d_out, hipStream_t st, bool deltaCoded) {
+	return deltaCoded ? code_stream_decode<true, int64_t, 3>(d_words, nwords, 0, totalBits, (int64_t)nodes + 1, d_out, st)
+	                  : code_stream_decode<true, int64_t, 2>(d_words, nwords, 0, totalBits, (int64_t)nodes + 1, d_out, st);
 }
 
 // labels of `count` consecutive arcs, stored in [startBit, endBit) of the .labels stream (GammaCodedIntLabel.java:60-64)
 int gamma_labels_decode_device(const uint32_t *d_words, uint64_t nwords, uint64_t startBit, uint64_t endBit, int64_t count, int32_t *d_out, hipStream_t st) {
-	return gamma_stream_decode<false, int32_t>(d_words, nwords, startBit, endBit, count, d_out, st);
+	return code_stream_decode<false, int32_t, 2>(d_words, nwords, startBit, endBit, count, d_out, st);
 }
 
 int fixed_labels_decode_device(const uint32_t *d_words, uint64_t nwords, uint64_t startBit, int32_t width, int64_t count, int32_t *d_out, hipStream_t st) {

@@ -621,7 +621,7 @@ extern "C" int bvg_decode_offsets_host(const uint8_t *offsets_file, size_t len, 
 
 extern "C" int bvg_decode_offsets_device(int device, const uint8_t *offsets_file, size_t len, int32_t nodes, int offset_coding, int64_t *out) {
 	if (!offsets_file || !out || nodes < 0) return BVG_EARG;
-	if (offset_coding != BVG_GAMMA) return BVG_EUNSUPPORTED;
+	if (offset_coding != BVG_GAMMA && offset_coding != BVG_DELTA) return BVG_EUNSUPPORTED;
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return BVG_EHIP;
 	if (device < 0 || device >= ndev) return BVG_EARG;
@@ -633,7 +633,7 @@ extern "C" int bvg_decode_offsets_device(int device, const uint8_t *offsets_file
 	if (hipMalloc((void **)&d_ow, (size_t)(ow + 8) * 4) == hipSuccess && hipMalloc((void **)&d_out, sizeof(int64_t) * ((size_t)nodes + 1)) == hipSuccess) {
 		rc = BVG_EHIP;
 		if (hipMemset(d_ow, 0, (size_t)(ow + 8) * 4) == hipSuccess && (len == 0 || hipMemcpy(d_ow, offsets_file, len, hipMemcpyHostToDevice) == hipSuccess)) {
-			if (len > 0 && bv::offsets_decode_device(d_ow, ow, (uint64_t)len * 8, nodes, d_out, nullptr) == 0)
+			if (len > 0 && bv::offsets_decode_device(d_ow, ow, (uint64_t)len * 8, nodes, d_out, nullptr, offset_coding == BVG_DELTA) == 0)
 				rc = hipMemcpy(out, d_out, sizeof(int64_t) * ((size_t)nodes + 1), hipMemcpyDeviceToHost) == hipSuccess ? BVG_OK : BVG_EHIP;
 			else rc = BVG_EFORMAT;
 		}
@@ -692,12 +692,12 @@ static int open_impl(const char *basename, int device, int part, int parts, bvg_
 	// (OffsetsLongIterator, BVG:907-935), which also produces the precise error
 	bool onDevice = false;
 	const char *offEnv = getenv("BVGPU_OFFSETS");
-	if (in.offset_coding == BVG_GAMMA && !offs.empty() && !(offEnv && strcmp(offEnv, "host") == 0)) {
+	if ((in.offset_coding == BVG_GAMMA || in.offset_coding == BVG_DELTA) && !offs.empty() && !(offEnv && strcmp(offEnv, "host") == 0)) {
 		const uint64_t ow = (offs.size() + 3) / 4;
 		uint32_t *d_ow = nullptr;
 		if (hipMalloc((void **)&d_ow, (size_t)(ow + 8) * 4) == hipSuccess) {
 			if (hipMemset(d_ow, 0, (size_t)(ow + 8) * 4) == hipSuccess && hipMemcpy(d_ow, offs.data(), offs.size(), hipMemcpyHostToDevice) == hipSuccess &&
-			    bv::offsets_decode_device(d_ow, ow, (uint64_t)offs.size() * 8, in.nodes, st->d_offsets, nullptr) == 0 &&
+			    bv::offsets_decode_device(d_ow, ow, (uint64_t)offs.size() * 8, in.nodes, st->d_offsets, nullptr, in.offset_coding == BVG_DELTA) == 0 &&
 			    hipMemcpy(st->h_offsets.data(), st->d_offsets, sizeof(int64_t) * st->h_offsets.size(), hipMemcpyDeviceToHost) == hipSuccess)
 				onDevice = true;
 			(void)hipFree(d_ow);
