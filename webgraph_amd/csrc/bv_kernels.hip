@@ -1180,54 +1180,69 @@ __device__ __forceinline__ uint32_t pow31(uint64_t e) { // 31^e mod 2^32
 	while (e) { if (e & 1) r *= m; m *= m; e >>= 1; }
 	return r;
 }
-constexpr int HASH_LONG = 512; // rows from here on are folded by the whole block (one lane would be the tail of the kernel)
-__global__ void __launch_bounds__(TPB) k_hash_nodes(int32_t from, int32_t cnt, const int64_t *__restrict__ rowptr,
-                                                    const int32_t *__restrict__ succ, uint32_t *__restrict__ outA, uint32_t *__restrict__ outB) {
-	__shared__ Affine sh[TPB];
-	__shared__ int32_t s_long[TPB], s_nlong;
+// The scan order of hashCode() is ONE sequence of n + m values -- node x, then its successors from the last to the first -- and the
+// position of node x's header in it is P(x) = (rowptr[x] - rowptr[0]) + x.  The sequence is cut into chunks of HASH_CHUNK positions,
+// whatever the rows are (one lane per node made the kernel 1.6 ms on C2, one block per 1 024 nodes 70 ms on C5, where thirty
+// neighbouring rows hold 5.6 M ids): k_hash_bounds finds the node that holds every chunk's first position; a block loads the rowptr
+// slice of its chunk into LDS and its threads walk the chunk's positions backwards with stride TPB -- so the weight 31^(values
+// that follow in the chunk) of a thread's next value is its last one times 31^TPB -- looking each position's node up in LDS.
+// Successors are read in descending order of index: coalesced.
+constexpr int HASH_CHUNK = 4096;
+__global__ void __launch_bounds__(TPB) k_hash_bounds(int32_t cnt, const int64_t *__restrict__ rowptr, int64_t nchunks, int32_t *__restrict__ bounds) {
+	const int64_t c = (int64_t)blockIdx.x * TPB + threadIdx.x;
+	if (c > nchunks) return;
+	if (c == nchunks) { bounds[c] = cnt - 1; return; }
+	const int64_t target = c * HASH_CHUNK, r0 = rowptr[0];
+	int32_t lo = 0, hi = cnt; // last x with P(x) <= target (P(0) = 0)
+	while (hi - lo > 1) { const int32_t mid = lo + ((hi - lo) >> 1); if ((rowptr[mid] - r0) + mid <= target) lo = mid; else hi = mid; }
+	bounds[c] = lo;
+}
+__global__ void __launch_bounds__(TPB) k_hash_nodes(int32_t from, int32_t cnt, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ,
+                                                    const int32_t *__restrict__ bounds, int64_t L, uint32_t *__restrict__ outA, uint32_t *__restrict__ outB) {
+	__shared__ int64_t R[HASH_CHUNK + 4];
+	__shared__ int32_t coarse[HASH_CHUNK / 64 + 1];
 	__shared__ uint32_t s_part[TPB];
-	if (threadIdx.x == 0) s_nlong = 0;
+	const int64_t c = blockIdx.x, start = c * HASH_CHUNK, end = min(L, start + HASH_CHUNK), r0 = rowptr[0];
+	const int32_t xa = bounds[c], xb = bounds[c + 1], nx = xb - xa + 1; // (nodes xa .. xb: at most HASH_CHUNK + 1 of them start in [start, end])
+	for (int32_t k = threadIdx.x; k <= nx; k += TPB) R[k] = rowptr[xa + k];
 	__syncthreads();
-	const int32_t s = blockIdx.x * TPB + threadIdx.x;
-	Affine f{ 1u, 0u };
-	if (s < cnt) {
-		// node x with successors s_0 < ... < s_{d-1}: h -> 31^(d+1) h + x 31^d + sum_j s_j 31^j  (ImmutableGraph.java:757-770)
-		const int64_t lo = rowptr[s], hi = rowptr[s + 1];
-		if (hi - lo >= HASH_LONG) s_long[atomicAdd(&s_nlong, 1)] = threadIdx.x;
-		else {
-			uint32_t a = 31u, b = (uint32_t)(from + s);
-			for (int64_t j = hi; j-- > lo;) { b = b * 31u + (uint32_t)succ[j]; a *= 31u; }
-			f = Affine{ a, b };
-		}
-	}
-	sh[threadIdx.x] = f;
+	auto P = [&](int32_t k) { return (R[k] - r0) + (xa + k); }; // position of node xa + k's header
+	auto node_of = [&](int64_t p, int32_t lo, int32_t hi) { // last k in [lo, hi) with P(k) <= p
+		while (hi - lo > 1) { const int32_t mid = (lo + hi) >> 1; if (P(mid) <= p) lo = mid; else hi = mid; }
+		return lo;
+	};
+	// the node of every 64th position, by binary search, once; a value then finds its node a few headers further on (a search of
+	// thirteen dependent LDS reads per value made the kernel 0.96 ms on C2)
+	constexpr int HASH_STRIDE = 64, HASH_SCAN = 12;
+	const int32_t ncoarse = (int32_t)((end - start + HASH_STRIDE - 1) / HASH_STRIDE);
+	for (int32_t t = threadIdx.x; t < ncoarse; t += TPB) coarse[t] = node_of(start + (int64_t)t * HASH_STRIDE, 0, nx);
 	__syncthreads();
-	for (int32_t q = 0; q < s_nlong; q++) { // (uniform)
-		const int32_t t = s_long[q], sx = blockIdx.x * TPB + t;
-		const int64_t lo = rowptr[sx], hi = rowptr[sx + 1], d = hi - lo;
-		// thread k folds the ids k, k + TPB, k + 2 TPB, ... of the row (coalesced loads; contiguous pieces per thread made a block
-		// of 30 neighbouring rows of 190 000 ids last 15 ms): sum_j s_j 31^j = sum_k 31^k * (Horner in 31^TPB over thread k's ids)
-		const uint32_t step = pow31(TPB);
-		const int64_t cntK = (d - (int64_t)threadIdx.x + TPB - 1) / TPB; // ids of this thread
-		uint32_t pz = 0;
-		int64_t i = cntK;
-		for (; i >= 4; i -= 4) {
-			const int64_t j = lo + threadIdx.x + (i - 1) * TPB;
-			const uint32_t x3 = (uint32_t)succ[j], x2 = (uint32_t)succ[j - TPB], x1 = (uint32_t)succ[j - 2 * TPB], x0 = (uint32_t)succ[j - 3 * TPB];
-			pz = (((pz * step + x3) * step + x2) * step + x1) * step + x0;
-		}
-		for (; i > 0; i--) pz = pz * step + (uint32_t)succ[lo + threadIdx.x + (i - 1) * TPB];
-		s_part[threadIdx.x] = pz * pow31((uint64_t)threadIdx.x);
-		__syncthreads();
-		for (int o = TPB / 2; o > 0; o >>= 1) { if (threadIdx.x < o) s_part[threadIdx.x] += s_part[threadIdx.x + o]; __syncthreads(); }
-		if (threadIdx.x == 0) sh[t] = Affine{ pow31((uint64_t)d + 1), (uint32_t)(from + sx) * pow31((uint64_t)d) + s_part[0] };
-		__syncthreads();
+	// where value p lives: a node's own number (from + x, flagged by a negative index) or an index into succ
+	auto locate = [&](int64_t p) -> int64_t {
+		const int32_t t = (int32_t)((p - start) / HASH_STRIDE);
+		int32_t lo = coarse[t], n = 0;
+		while (lo + 1 < nx && P(lo + 1) <= p) { lo++; if (++n == HASH_SCAN) { lo = node_of(p, lo, t + 1 < ncoarse ? coarse[t + 1] + 1 : nx); break; } } // (a run of empty nodes)
+		// position 0 of a node is its header; position q + 1 its successor d - 1 - q (ImmutableGraph.java:757-770 runs over them backwards)
+		const int64_t pos = p - P(lo);
+		return pos == 0 ? -1 - (int64_t)(xa + lo) : R[lo + 1] - pos;
+	};
+	uint32_t acc = 0, w = pow31((uint64_t)threadIdx.x);
+	const uint32_t step = pow31(TPB), step2 = step * step, step3 = step2 * step, step4 = step2 * step2;
+	int64_t p = end - 1 - threadIdx.x;
+	for (; p - 3 * TPB >= start; p -= 4 * TPB, w *= step4) { // four loads in flight per lane (one at a time: 0.87 ms on C2, the lanes waiting)
+		const int64_t a0 = locate(p), a1 = locate(p - TPB), a2 = locate(p - 2 * TPB), a3 = locate(p - 3 * TPB);
+		const uint32_t v0 = a0 < 0 ? (uint32_t)(from - 1 - a0) : (uint32_t)succ[a0], v1 = a1 < 0 ? (uint32_t)(from - 1 - a1) : (uint32_t)succ[a1];
+		const uint32_t v2 = a2 < 0 ? (uint32_t)(from - 1 - a2) : (uint32_t)succ[a2], v3 = a3 < 0 ? (uint32_t)(from - 1 - a3) : (uint32_t)succ[a3];
+		acc += v0 * w + v1 * (w * step) + v2 * (w * step2) + v3 * (w * step3);
 	}
-	for (int o = 1; o < TPB; o <<= 1) { // ordered tree: element t absorbs t+o
-		if ((threadIdx.x % (2 * o)) == 0 && threadIdx.x + o < TPB) sh[threadIdx.x] = compose(sh[threadIdx.x], sh[threadIdx.x + o]);
-		__syncthreads();
+	for (; p >= start; p -= TPB, w *= step) {
+		const int64_t a = locate(p);
+		acc += (a < 0 ? (uint32_t)(from - 1 - a) : (uint32_t)succ[a]) * w;
 	}
-	if (threadIdx.x == 0) { outA[blockIdx.x] = sh[0].a; outB[blockIdx.x] = sh[0].b; }
+	s_part[threadIdx.x] = acc;
+	__syncthreads();
+	for (int o = TPB / 2; o > 0; o >>= 1) { if (threadIdx.x < o) s_part[threadIdx.x] += s_part[threadIdx.x + o]; __syncthreads(); }
+	if (threadIdx.x == 0) { outA[c] = pow31((uint64_t)(end - start)); outB[c] = s_part[0]; }
 }
 
 // single block: fold nb block maps in order and apply to *hash
@@ -1329,11 +1344,14 @@ void launch_copy(const GraphDev &g, int def, const RangeView &v, const int32_t *
 	else hipLaunchKernelGGL(k_copy<0>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, depth, level, err);
 }
 
-void launch_hash(int32_t from, int32_t cnt, const int64_t *rowptr, const int32_t *succ, uint32_t *A, uint32_t *B, int32_t *hash, hipStream_t st) {
+int64_t hash_chunks(int32_t cnt, int64_t arcs) { return ((int64_t)cnt + arcs + HASH_CHUNK - 1) / HASH_CHUNK; }
+// A, B: hash_chunks(cnt, arcs) entries each; bounds: one more.  arcs = rowptr[cnt] - rowptr[0].
+void launch_hash(int32_t from, int32_t cnt, int64_t arcs, const int64_t *rowptr, const int32_t *succ, uint32_t *A, uint32_t *B, int32_t *bounds, int32_t *hash, hipStream_t st) {
 	if (cnt <= 0) return;
-	const int64_t nb = nblk(cnt, TPB);
-	hipLaunchKernelGGL(k_hash_nodes, dim3((unsigned)nb), dim3(TPB), 0, st, from, cnt, rowptr, succ, A, B);
-	hipLaunchKernelGGL(k_hash_fold, dim3(1), dim3(TPB), 0, st, A, B, nb, hash);
+	const int64_t nc = hash_chunks(cnt, arcs);
+	hipLaunchKernelGGL(k_hash_bounds, dim3(nblk(nc + 1, TPB)), dim3(TPB), 0, st, cnt, rowptr, nc, bounds);
+	hipLaunchKernelGGL(k_hash_nodes, dim3((unsigned)nc), dim3(TPB), 0, st, from, cnt, rowptr, succ, bounds, (int64_t)cnt + arcs, A, B);
+	hipLaunchKernelGGL(k_hash_fold, dim3(1), dim3(TPB), 0, st, A, B, nc, hash);
 }
 
 void launch_chain_len(const GraphDev &g, int def, const int32_t *nodes, int64_t q, int32_t *chainlen, int32_t *maxlen, int *err, hipStream_t st) {

@@ -87,7 +87,8 @@ void launch_parse_tile(const GraphDev &g, int def, const RangeView &v, const int
 int32_t ctile_count(int64_t arcsBound, int32_t cnt);
 bool ctile_applicable(int def, int32_t window);
 void launch_copy_tiles(const GraphDev &g, int def, const RangeView &v, int32_t ntiles, int32_t *tb, uint16_t *ref2, int *err, hipStream_t st);
-void launch_hash(int32_t from, int32_t cnt, const int64_t *rowptr, const int32_t *succ, uint32_t *A, uint32_t *B, int32_t *hash, hipStream_t st);
+int64_t hash_chunks(int32_t cnt, int64_t arcs);
+void launch_hash(int32_t from, int32_t cnt, int64_t arcs, const int64_t *rowptr, const int32_t *succ, uint32_t *A, uint32_t *B, int32_t *bounds, int32_t *hash, hipStream_t st);
 
 void launch_bparse_big(const GraphDev &g, int def, const BatchView &v, int32_t coopMin, int32_t giantMin, int32_t *biglist, int32_t *giantlist, int32_t giantCap, int32_t *ctl,
                        void *arena, int64_t arenaCap, int waves, int giantGroups, int *err, hipStream_t st, hipStream_t stGiant, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evGiant, hipEvent_t evBig);

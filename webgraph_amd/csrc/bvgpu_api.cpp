@@ -110,7 +110,7 @@ struct bvg_graph {
 	hipStream_t user = nullptr;                  // caller's stream (bvg_set_stream): work is ordered after it and it waits for our results
 	hipEvent_t evIn = nullptr, evOut = nullptr;
 	mutable std::string err;
-	DevBuf outd, ref, rowstart, depth, sums, need, halo, hashA, hashB, stage_rowptr, stage_succ, stage_nodes, small;
+	DevBuf outd, ref, rowstart, depth, sums, need, halo, hashA, hashB, hashBounds, stage_rowptr, stage_succ, stage_nodes, small;
 	DevBuf b_chainlen, b_slotbase, b_node, b_qidx, b_aoutd, b_qoutd; // random-access batches
 	DevBuf pickpart;                                                  // per-block outdegree class counts of k_headers
 	DevBuf biglist, giantlist, arena, coopctl;                        // work lists; cooperative decode of giant records
@@ -779,7 +779,7 @@ extern "C" int bvg_close(bvg_t *g) {
 	if (g->st && g->st->device >= 0) {
 		(void)hipSetDevice(g->st->device);
 		if (g->own) { (void)hipStreamSynchronize(g->own); (void)hipStreamDestroy(g->own); }
-		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist, &g->plist, &g->pkeys, &g->pkey16, &g->copyq, &g->bigtmp, &g->tilebounds, &g->ctilebounds, &g->ref2 }) b->release();
+		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->hashBounds, &g->pickpart, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist, &g->plist, &g->pkeys, &g->pkey16, &g->copyq, &g->bigtmp, &g->tilebounds, &g->ctilebounds, &g->ref2 }) b->release();
 		for (DevBuf *b : { &g->hchunk[0], &g->hchunk[1], &g->statsbuf, &g->bfs_rowptr, &g->bfs_succ, &g->bfs_ctr }) b->release();
 		for (PinBuf *b : { &g->hring[0], &g->hring[1], &g->view_rowptr, &g->view_succ }) b->release();
 		for (hipEvent_t e : { g->evChunk[0], g->evChunk[1], g->evCopied[0], g->evCopied[1] }) if (e) (void)hipEventDestroy(e);
@@ -1264,12 +1264,19 @@ extern "C" int bvg_csr_hashcode(bvg_t *g, int32_t from, int32_t to, const int64_
 	{ int rc = fork_from_user(g); if (rc) return rc; }
 	const int32_t cnt = to - from;
 	if (cnt == 0) return BVG_OK;
-	const size_t nb = ((size_t)cnt + 255) / 256;
-	if (!g->hashA.need(sizeof(uint32_t) * nb) || !g->hashB.need(sizeof(uint32_t) * nb)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
+	// the fold runs over chunks of the n + m values of the scan order: their number depends on the arcs, which only the device knows
+	int64_t ends[2] = { 0, 0 };
+	HIPCHK(g, hipMemcpyAsync(&ends[0], rowptr_dev, sizeof(int64_t), hipMemcpyDeviceToHost, g->stream));
+	HIPCHK(g, hipMemcpyAsync(&ends[1], rowptr_dev + cnt, sizeof(int64_t), hipMemcpyDeviceToHost, g->stream));
+	HIPCHK(g, hipStreamSynchronize(g->stream));
+	const int64_t arcs = ends[1] - ends[0];
+	if (arcs < 0) return fail(g, BVG_EARG, "rowptr is not a CSR row pointer array");
+	const size_t nb = (size_t)bv::hash_chunks(cnt, arcs);
+	if (!g->hashA.need(sizeof(uint32_t) * nb) || !g->hashB.need(sizeof(uint32_t) * nb) || !g->hashBounds.need(sizeof(int32_t) * (nb + 1))) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
 	g->h_small->hash = *hash_io;
 	int32_t *dh = &g->small.as<Small>()->hash;
 	HIPCHK(g, hipMemcpyAsync(dh, &g->h_small->hash, sizeof(int32_t), hipMemcpyHostToDevice, g->stream));
-	bv::launch_hash(from, cnt, rowptr_dev, succ_dev, g->hashA.as<uint32_t>(), g->hashB.as<uint32_t>(), dh, g->stream);
+	bv::launch_hash(from, cnt, arcs, rowptr_dev, succ_dev, g->hashA.as<uint32_t>(), g->hashB.as<uint32_t>(), g->hashBounds.as<int32_t>(), dh, g->stream);
 	int rc = fetch_small(g);
 	if (rc) return rc;
 	*hash_io = g->h_small->hash;
