@@ -1389,10 +1389,10 @@ void launch_bcopy(const GraphDev &g, int def, const BatchView &v, int32_t level,
 // The threshold is the smallest of 128 .. 2048 that sends at most `budget` records to the waves (C2: 7 121 records >= 2 048,
 // 15 410 >= 1 024 -> 2 048; cnr-2000 x 30: 11 250 >= 128 -> 128, 3.06 -> 2.67 ms; measured optimum in both cases).
 constexpr int PICK_THREADS = 1024;
-__global__ void __launch_bounds__(PICK_THREADS) k_pick_coop(const int32_t *__restrict__ part, int32_t nblocks, int32_t budget, int32_t *__restrict__ ctl) {
+__global__ void __launch_bounds__(PICK_THREADS) k_pick_coop(const int32_t *__restrict__ part, int32_t nblocks, int32_t budget, int32_t *__restrict__ ctl, int32_t *__restrict__ counts) {
 	__shared__ int32_t s_cnt[5];
 	if (threadIdx.x < 5) s_cnt[threadIdx.x] = 0;
-	if (threadIdx.x >= 64 && threadIdx.x < 64 + 12) ctl[4 + (threadIdx.x - 64)] = 0; // counters of the level lists, copy queues and copy levels of this job
+	if (!counts && threadIdx.x >= 64 && threadIdx.x < 64 + 12) ctl[4 + (threadIdx.x - 64)] = 0; // counters of the level lists, copy queues and copy levels of this job
 	__syncthreads();
 #pragma unroll
 	for (int k = 0; k < 5; k++) {
@@ -1409,13 +1409,14 @@ __global__ void __launch_bounds__(PICK_THREADS) k_pick_coop(const int32_t *__res
 		if ((threadIdx.x & 63) == 0 && t) atomicAdd(&s_cnt[k], t);
 	}
 	__syncthreads();
+	if (counts) { if (threadIdx.x < 5) counts[threadIdx.x] = s_cnt[threadIdx.x]; return; } // (load time: the whole graph's counts, for the host)
 	if (threadIdx.x != 0) return;
 	int32_t pick = 2048;
 	for (int k = 4; k >= 0; k--) { if (s_cnt[k] <= budget) pick = 128 << k; else break; }
 	ctl[CTL_COOP] = pick;
 }
-void launch_pick_coop(const int32_t *part, int32_t nblocks, int32_t budget, int32_t *ctl, hipStream_t st) {
-	hipLaunchKernelGGL(k_pick_coop, dim3(1), dim3(PICK_THREADS), 0, st, part, nblocks, budget, ctl);
+void launch_pick_coop(const int32_t *part, int32_t nblocks, int32_t budget, int32_t *ctl, hipStream_t st, int32_t *counts) {
+	hipLaunchKernelGGL(k_pick_coop, dim3(1), dim3(PICK_THREADS), 0, st, part, nblocks, budget, ctl, counts);
 }
 
 void launch_classify(int32_t cnt, const int32_t *outd, const int32_t *coopPtr, int32_t coopMin, int32_t giantMin, int32_t *biglist, int32_t *giantlist, int32_t giantCap, int32_t *ctl, hipStream_t st) {

@@ -64,7 +64,7 @@ void launch_chain_fill(const GraphDev &g, int def, const int32_t *nodes, int64_t
                        int32_t *sdepth, int32_t *sq, int32_t *aoutd, int32_t *qoutd, hipStream_t st);
 void launch_bparse(const GraphDev &g, int def, const BatchView &v, int *err, hipStream_t st);
 void launch_bcopy(const GraphDev &g, int def, const BatchView &v, int32_t level, int *err, hipStream_t st);
-void launch_pick_coop(const int32_t *part, int32_t nblocks, int32_t budget, int32_t *ctl, hipStream_t st);
+void launch_pick_coop(const int32_t *part, int32_t nblocks, int32_t budget, int32_t *ctl, hipStream_t st, int32_t *counts = nullptr);
 constexpr int CTL_INTS = 32, CTL_COOP = 22, CTL_TOTAL_INTS = CTL_INTS; // control block (bv_kernels.hip)
 void launch_classify(int32_t cnt, const int32_t *outd, const int32_t *coopPtr, int32_t coopMin, int32_t giantMin, int32_t *biglist, int32_t *giantlist, int32_t giantCap, int32_t *ctl, hipStream_t st);
 void launch_parse_big(const GraphDev &g, int def, const RangeView &v, const int32_t *biglist, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap,

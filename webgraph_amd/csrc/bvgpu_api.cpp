@@ -65,6 +65,7 @@ struct Staged {
 	int32_t node_lo = 0, node_hi = 0, stage_lo = 0; // the nodes this handle decodes / the first node staged
 	std::vector<int64_t> h_offsets; // host copy: shard bounds and halo sizing
 	int64_t arcs_sizing = 0;        // max(arcs property, sum of the outdegrees in the stream): what scratch is sized by
+	int32_t deg_counts[5] = { -1, -1, -1, -1, -1 }; // staged records with >= 128, 256, 512, 1024, 2048 successors (counted with arcs_sizing; -1: unknown)
 	int def = 0;                    // kernel variant: 1 default codings with zeta_3, 2 default codings with another zeta_k, 0 generic
 	std::string basename;
 	~Staged() {
@@ -119,7 +120,7 @@ struct bvg_graph {
 	DevBuf lvlist;
 	int parse_lists = 1; // BVGPU_PARSE_LISTS=0: short records parsed in node order instead of by work bin
 	DevBuf plist, pkeys, pkey16;
-	int tile = 0;        // BVGPU_TILE=1: short records decoded from contiguous tiles of the stream (k_parse_tile) instead of the bin-sorted parse list (k_parse_list)
+	int tile = -1;       // -1: automatic (see enqueue_decode); BVGPU_TILE=0: never; BVGPU_TILE=1: short records decoded from contiguous tiles of the stream (k_parse_tile) instead of the bin-sorted parse list (k_parse_list)
 	DevBuf tilebounds;
 	int ctile = 0;       // BVGPU_CTILE=1: the copy pass of the short rows tile by tile in LDS (bv_ctile.hpp) before the level-wise kernels
 	                     // (bit-exact; measured slower than the level-wise kernels alone on C2, cnr-2000 x30 and the C5 shard: DESIGN.md section 6)
@@ -421,7 +422,16 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		int32_t *pKeyBase = nullptr;
 		// short records of the default codings: contiguous tiles of the stream, one LDS image each (bv_tile.hpp); the tile
 		// bounds follow from the offsets alone
-		const bool tiles = g->tile && s.def != 0;
+		// BVGPU_TILE=1|2 forces them, 0 forbids them; by default (-1) they are taken when the job is expected to keep only short records
+		// in the lane class -- its share (by bits) of the staged records with >= 128 successors fits the wave class, so that
+		// k_pick_coop will pick 128 --: neighbouring short records are alike, a tile's lanes stay even, and the coalesced tile
+		// kernel is 20 % faster than the bins (cnr-2000 x 30: 0.42 against 0.53 ms); with a heavy-tailed lane class it is 2.6x slower (C2).
+		int tileVariant = g->tile > 0 ? g->tile : 0;
+		if (g->tile < 0 && g->adaptive && v.coop_ptr && s.deg_counts[0] >= 0 && g->parse_lists) {
+			const double share = (double)(s.h_offsets[(size_t)v.lo + v.cnt] - s.h_offsets[(size_t)v.lo]) / (double)std::max<int64_t>(s.h_offsets[(size_t)s.node_hi] - s.h_offsets[(size_t)s.stage_lo], 1);
+			if ((double)s.deg_counts[0] * share <= (double)COOP_BUDGET * (share > 0.999 ? 1.0 : 0.8)) tileVariant = 1; // (a sub-range: an estimate, with a margin)
+		}
+		const bool tiles = tileVariant != 0 && s.def != 0;
 		int32_t ntiles = 0;
 		if (tiles) {
 			ntiles = bv::tile_count(s.h_offsets[(size_t)v.lo + v.cnt] - s.h_offsets[(size_t)v.lo], v.cnt);
@@ -486,7 +496,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		mark(g, 4);
 		if (coop && !ovl) bv::launch_parse_waves(gd, s.def, v, g->biglist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, derr, g->stream);
 		mark(g, 5);
-		if (tiles) bv::launch_parse_tile(gd, s.def, v, g->tilebounds.as<int32_t>(), ntiles, g->tile, derr, g->stream);
+		if (tiles) bv::launch_parse_tile(gd, s.def, v, g->tilebounds.as<int32_t>(), ntiles, tileVariant, derr, g->stream);
 		else if (pKeyBase) {
 			bv::launch_parse_list(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, g->level_blocks, derr, g->stream);
 		}
@@ -747,18 +757,21 @@ static int open_impl(const char *basename, int device, int part, int parts, bvg_
 	st->arcs_sizing = parts > 1 ? 1 : std::max<int64_t>(in.arcs, 1);
 	if (st->node_hi > st->stage_lo) {
 		const int32_t n = st->node_hi - st->stage_lo;
-		void *p_outd = nullptr, *p_ref = nullptr, *p_rs = nullptr, *p_sums = nullptr, *p_err = nullptr;
+		void *p_outd = nullptr, *p_ref = nullptr, *p_rs = nullptr, *p_sums = nullptr, *p_err = nullptr, *p_part = nullptr;
 		const bool ok = hipMalloc(&p_outd, sizeof(int32_t) * (size_t)n) == hipSuccess && hipMalloc(&p_ref, sizeof(uint16_t) * (size_t)n) == hipSuccess &&
 		                hipMalloc(&p_rs, sizeof(int64_t) * ((size_t)n + 1)) == hipSuccess && hipMalloc(&p_sums, sizeof(int64_t) * (size_t)bv::scan_num_sums(n)) == hipSuccess &&
-		                hipMalloc(&p_err, sizeof(int)) == hipSuccess;
+		                hipMalloc(&p_err, sizeof(int)) == hipSuccess && hipMalloc(&p_part, sizeof(int32_t) * (5 * (size_t)bv::headers_blocks(n) + 8)) == hipSuccess;
 		int64_t total = 0;
 		hipError_t e = ok ? hipMemset(p_err, 0, sizeof(int)) : hipErrorOutOfMemory;
 		if (e == hipSuccess) {
-			bv::launch_headers(graph_dev0(*st), st->def, st->stage_lo, n, (int32_t *)p_outd, (uint16_t *)p_ref, (int *)p_err, nullptr);
+			const int64_t hb = bv::headers_blocks(n);
+			bv::launch_headers(graph_dev0(*st), st->def, st->stage_lo, n, (int32_t *)p_outd, (uint16_t *)p_ref, (int *)p_err, nullptr, (int32_t *)p_part);
 			bv::launch_scan((const int32_t *)p_outd, n, (int64_t *)p_rs, (int64_t *)p_sums, nullptr);
+			bv::launch_pick_coop((const int32_t *)p_part, (int32_t)hb, 0, nullptr, nullptr, (int32_t *)p_part + 5 * hb); // how long the records are: the lane class is decoded from tiles when few are long (enqueue_decode)
 			e = hipMemcpy(&total, (int64_t *)p_rs + n, sizeof(int64_t), hipMemcpyDeviceToHost);
+			if (e == hipSuccess) e = hipMemcpy(st->deg_counts, (int32_t *)p_part + 5 * hb, sizeof(st->deg_counts), hipMemcpyDeviceToHost);
 		}
-		for (void *q : { p_outd, p_ref, p_rs, p_sums, p_err }) if (q) (void)hipFree(q);
+		for (void *q : { p_outd, p_ref, p_rs, p_sums, p_err, p_part }) if (q) (void)hipFree(q);
 		if (e != hipSuccess) return fail(g, e == hipErrorOutOfMemory ? BVG_ENOMEM : BVG_EHIP, "cannot scan the record headers");
 		st->arcs_sizing = std::max<int64_t>(st->arcs_sizing, total);
 	}
