@@ -918,6 +918,85 @@ __device__ __forceinline__ void coop_block_walk(const GraphDev &g, uint64_t pos,
 	nKeptOut = (int32_t)min<int64_t>((bc >> 1) + 1, 0x7fffffff);
 }
 
+// The same walk by ALL the waves of a group of NW (its tile is NW times as wide; every codeword is decoded three times -- speculation,
+// sums, table entries -- instead of once, and every scan costs two barriers): for block lists of tens of thousands of codes, where
+// one wave's walk is the longest thing the record or the row does (77 000 codes: 0.9 ms).  `win` holds N * bmax / 32 + 12 words.
+constexpr int COPY_GROUP_WALK_MIN = 4096;
+template <int NW>
+__device__ __forceinline__ void coop_block_walk_nw(const GraphDev &g, uint64_t pos, uint64_t recEnd, int64_t bc, int64_t dref, int32_t d, int32_t *kend, int32_t *delta, int32_t tabCap,
+                                                   uint32_t *win, int64_t *xch, uint32_t bmax, int64_t &totalOut, int64_t &copiedOut, int32_t &nKeptOut, int &bad, uint64_t *posAfter = nullptr) {
+	Grp<NW> G{ xch };
+	const uint32_t B = coop_pick_B(min<uint64_t>(recEnd > pos ? recEnd - pos : 0, (uint64_t)bc * 8), (uint64_t)bc, Grp<NW>::N, bmax);
+	int64_t done = 0, total = 0, copied = 0; // uniform
+	int err = 0;
+	while (done < bc) {
+		const WindowSrc src = stage_tile<NW>(G, g, win, pos, B);
+		const uint64_t base = src.w0 << 5;
+		uint64_t E; uint32_t s, c; int64_t unused;
+		spec_tile<1, 1, NW>(G, g, src, pos, recEnd, B, false, bc - done, s, c, unused, E);
+		int64_t tileTotal;
+		const int64_t cincl = G.incl_scan((int64_t)c, tileTotal);
+		const int64_t cb = cincl - c, rem = bc - done;
+		if (cb >= rem) c = 0; else if (cb + c > rem) c = (uint32_t)(rem - cb);
+		const int64_t n = min(rem, tileTotal);
+		if (n <= 0) { err = 1; break; } // (uniform)
+		// pass 1: what my codes add to the referent index and to the number of copied ids
+		int64_t dAll = 0, dEven = 0;
+		uint32_t myEnd = s;
+		{
+			uint32_t p = s;
+			for (uint32_t k = 0; k < c; k++) {
+				const int64_t q = done + cb + k;
+				const uint64_t v = win_code_rel<1, 1>(g, src, p, err);
+				if (v > (uint64_t)dref) err |= 1; // (any 64-bit value in a malformed stream: the sums below must not wrap)
+				const int64_t len = (int64_t)(v & 0x7fffffffu) + (q ? 1 : 0);
+				dAll += len;
+				if (!(q & 1)) dEven += len;
+			}
+			myEnd = p;
+		}
+		int64_t iAll, iEven, allTot, evenTot;
+		G.incl_scan2(dAll, dEven, iAll, iEven, allTot, evenTot);
+		// pass 2: the table entries of my copied blocks
+		if (tabCap > 0) {
+			int64_t t = total + iAll - dAll, cp = copied + iEven - dEven;
+			uint32_t p = s;
+			int e2 = 0;
+			for (uint32_t k = 0; k < c; k++) {
+				const int64_t q = done + cb + k;
+				const int64_t len = (int64_t)(win_code_rel<1, 1>(g, src, p, e2) & 0x7fffffffu) + (q ? 1 : 0);
+				if (!(q & 1)) {
+					const int64_t j = q >> 1;
+					if (j < tabCap) { kend[j] = (int32_t)min<int64_t>(cp + len, 0x7fffffff); delta[j] = (int32_t)(t - cp); }
+					cp += len;
+				}
+				t += len;
+			}
+		}
+		const int lastTid = G.last_set(c > 0);
+		const uint64_t endPos = base + (uint64_t)G.bcast((int64_t)myEnd, lastTid);
+		total += allTot;
+		copied += evenTot;
+		done += n;
+		pos = done >= bc ? endPos : E;
+		if (total > dref || copied > d) { err = 1; break; } // (uniform)
+	}
+	if (G.any(err != 0)) { bad = 1; return; }
+	// implicit last block: the rest of the referent's row, copied when the block count is even
+	const int64_t rest = dref - total;
+	if (rest < 0) { bad = 1; return; }
+	if (!(bc & 1)) {
+		const int64_t j = bc >> 1;
+		if (j < tabCap && threadIdx.x == 0) { kend[j] = (int32_t)min<int64_t>(copied + rest, 0x7fffffff); delta[j] = (int32_t)(total - copied); }
+		copied += rest;
+	}
+	total += rest;
+	totalOut = total;
+	copiedOut = copied;
+	if (posAfter) *posAfter = pos;
+	nKeptOut = (int32_t)min<int64_t>((bc >> 1) + 1, 0x7fffffff);
+}
+
 
 // ---------------------------------------------------------------------------------------------- phases R, one wave, lean
 // The residual section of a record decoded by ONE wave with every codeword decoded once where the general version above
@@ -1081,8 +1160,11 @@ __device__ __forceinline__ void coop_parse_node(const GraphDev &g, int32_t x, in
 			int32_t nKept = 0;
 			int bad = 0;
 			uint64_t after = br.pos();
-			if (NW == 1 || G.wave() == 0) coop_block_walk(g, br.pos(), recEnd, (int64_t)bc, dref, d, (int32_t *)nullptr, (int32_t *)nullptr, 0, lds, total, cp, nKept, bad, &after);
-			if (NW > 1) {
+			const bool allWaves = NW > 1 && bc >= COPY_GROUP_WALK_MIN; // (uniform)
+			if (allWaves) coop_block_walk_nw<NW>(g, br.pos(), recEnd, (int64_t)bc, dref, d, (int32_t *)nullptr, (int32_t *)nullptr, 0, lds + CoopLds<NW>::OFF_WIN,
+			                                     (int64_t *)(lds + CoopLds<NW>::OFF_XCH), CoopCfg<NW>::B_MAX, total, cp, nKept, bad, &after);
+			else if (NW == 1 || G.wave() == 0) coop_block_walk(g, br.pos(), recEnd, (int64_t)bc, dref, d, (int32_t *)nullptr, (int32_t *)nullptr, 0, lds, total, cp, nKept, bad, &after);
+			if (NW > 1 && !allWaves) {
 				if (tid == 0) { G.xch[NW + 1] = cp; G.xch[NW + 2] = (int64_t)after; G.xch[NW + 3] = bad; }
 				__syncthreads();
 				cp = G.xch[NW + 1]; after = (uint64_t)G.xch[NW + 2]; bad = (int)G.xch[NW + 3];
