@@ -1149,6 +1149,8 @@ __device__ __forceinline__ void coop_parse_node(const GraphDev &g, int32_t x, in
 	(void)Fields<DEF>::outdegree(br, g);
 	if (g.W > 0) (void)Fields<DEF>::reference(br, g);
 	int64_t copied = 0;
+	int64_t woff = -1; // where this record's block tables went (NW > 1, long lists), if anywhere
+	int32_t wKept = 0;
 	if (hasRef) {
 		const uint64_t bc = Fields<DEF>::block_count(br, g);
 		int64_t total = 0;
@@ -1161,7 +1163,20 @@ __device__ __forceinline__ void coop_parse_node(const GraphDev &g, int32_t x, in
 			int bad = 0;
 			uint64_t after = br.pos();
 			const bool allWaves = NW > 1 && bc >= COPY_GROUP_WALK_MIN; // (uniform)
-			if (allWaves) coop_block_walk_nw<NW>(g, br.pos(), recEnd, (int64_t)bc, dref, d, (int32_t *)nullptr, (int32_t *)nullptr, 0, lds + CoopLds<NW>::OFF_WIN,
+			const int64_t kMaxW = (int64_t)(bc >> 1) + 1;
+			if (allWaves && g.walktab && d >= g.walkMin) { // the copy pass will want this list's tables: they fall out of the walk (GraphDev::walktab)
+				if (tid == 0) {
+					const uint64_t need = 2 * (uint64_t)kMaxW;
+					int64_t o = -1;
+					if (need <= g.walkCap) { const uint32_t a = atomicAdd(g.walkCursor, (uint32_t)need); if ((uint64_t)a + need <= g.walkCap) o = a; }
+					G.xch[NW + 4] = o;
+				}
+				__syncthreads();
+				woff = G.xch[NW + 4];
+				__syncthreads();
+			}
+			if (allWaves) coop_block_walk_nw<NW>(g, br.pos(), recEnd, (int64_t)bc, dref, d, woff >= 0 ? g.walktab + woff : (int32_t *)nullptr, woff >= 0 ? g.walktab + woff + kMaxW : (int32_t *)nullptr,
+			                                     woff >= 0 ? (int32_t)min<int64_t>(kMaxW, 0x7fffffff) : 0, lds + CoopLds<NW>::OFF_WIN,
 			                                     (int64_t *)(lds + CoopLds<NW>::OFF_XCH), CoopCfg<NW>::B_MAX, total, cp, nKept, bad, &after);
 			else if (NW == 1 || G.wave() == 0) coop_block_walk(g, br.pos(), recEnd, (int64_t)bc, dref, d, (int32_t *)nullptr, (int32_t *)nullptr, 0, lds, total, cp, nKept, bad, &after);
 			if (NW > 1 && !allWaves) {
@@ -1172,6 +1187,7 @@ __device__ __forceinline__ void coop_parse_node(const GraphDev &g, int32_t x, in
 			}
 			if (bad) err |= E_FORMAT;
 			copied = cp;
+			wKept = nKept;
 			br.seek(after);
 		}
 		else {
@@ -1188,6 +1204,10 @@ __device__ __forceinline__ void coop_parse_node(const GraphDev &g, int32_t x, in
 	if (extra < 0 || copied < 0) err |= E_FORMAT;
 	err |= br.err;
 	if (err) { if (tid == 0) atomicOr(errOut, err); return; }
+	if (NW > 1 && hasRef && copied >= 1 && tid == 0 && g.walktab && d >= g.walkMin) { // (row[0 .. copied) is free until the copy pass)
+		if (woff >= 0 && copied >= 4) { row[0] = -2; row[1] = (int32_t)woff; row[2] = wKept; row[3] = (int32_t)copied; }
+		else row[0] = -1;
+	}
 	COOP_TICK(0);
 	if (extra == 0) return;
 	int64_t ic = 0, intervalArcs = 0;

@@ -30,6 +30,14 @@ struct GraphDev {
 	int32_t c_outd, c_ref, c_bc, c_blk, c_res;
 	unsigned long long *stats; // optional tuning counters (BVGPU_STATS=1), NULL otherwise
 	int32_t dbg;               // BVGPU_DBG: selects which tick counters BVGPU_STATS collects (bit 4: copy kernels); never changes results
+	// The block tables of the giant records (outdegree >= walkMin), written by the parse kernel that walks their lists anyway and read
+	// by k_copy_big instead of walking them again: walktab[walkCap] ints, bump-allocated through *walkCursor (NULL: not kept).
+	// A record's tables are announced in the free head of its row: row[0] = -2, row[1] = offset, row[2] = copied blocks, row[3] = copied
+	// ids; row[0] = -1: none (every giant record with a reference that copies something gets one or the other).
+	int32_t *walktab;
+	uint32_t walkCap;
+	uint32_t *walkCursor;
+	int32_t walkMin;
 };
 
 // tuning counters: 0 tiles(residual) 1 rounds(residual) 2 tiles(interval) 3 rounds(interval) 4 lane-parses 5 big nodes 6 clock ticks in coop nodes 7 max ticks of one node

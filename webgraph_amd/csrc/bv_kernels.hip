@@ -631,7 +631,7 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 	__shared__ int32_t s_b[2];
 	__shared__ uint32_t lwin[DEF ? LW_MAIN * LW_STRIDE : 1]; // stream window of the wave that walks the block list
 	__shared__ __attribute__((aligned(16))) uint32_t cwin[DEF ? CoopLds<1>::WORDS : 4]; // tile of the cooperative walk of a long block list
-	__shared__ int64_t s_copied, s_tmp, s_kmax;
+	__shared__ int64_t s_copied, s_tmp, s_kmax, s_desc;
 	__shared__ int32_t s_kept, s_bad;
 	// The queue holds the long rows of ALL levels; a group takes the next entry that is of this level and of this pass from a
 	// shared head (rows differ by 200x in length: fixed shares left most groups idle while a few worked through several
@@ -851,7 +851,17 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 			(void)Fields<DEF>::reference(hb, g);
 			const uint64_t bc = Fields<DEF>::block_count(hb, g);
 			s_tmp = -2; // LDS tables
-			if (bc > (uint64_t)dref + 1) s_tmp = -3; // flagged by the parse kernel
+			s_desc = -1;
+			if (bc <= (uint64_t)dref + 1 && g.walktab && d >= g.walkMin && row[0] == -2) {
+				// the parse kernel walked this list with eight waves and kept the tables (GraphDev::walktab): nothing to walk here
+				const int64_t off = row[1], nk = row[2], cp = row[3], kM = (int64_t)(bc >> 1) + 1, cMax = dref < (int64_t)d ? dref : (int64_t)d;
+				if (off >= 0 && (uint64_t)off + 2 * (uint64_t)kM <= g.walkCap && nk >= 1 && nk <= kM && cp >= 4 && cp <= cMax && tmp && (uint64_t)cMax <= tmpCap) {
+					const uint32_t o = atomicAdd(tmpCursor, (uint32_t)cMax); // room for the copied ids
+					if ((uint64_t)o + (uint64_t)cMax <= tmpCap) { s_desc = off; s_tmp = o; s_kmax = kM; s_copied = cp; s_kept = (int32_t)nk; s_bad = 0; }
+				}
+			}
+			if (s_desc >= 0) {}
+			else if (bc > (uint64_t)dref + 1) s_tmp = -3; // flagged by the parse kernel
 			else if (dref > COPY_BIG_CAP || (bc >> 1) + 1 > (uint64_t)COPY_BIG_CAP + 1) {
 				const uint64_t kMax = (bc >> 1) + 1, cMax = (uint64_t)(dref < (int64_t)d ? dref : (int64_t)d), need = 2 * kMax + 2 * cMax;
 				s_tmp = -1; // one lane does the row
@@ -860,8 +870,13 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 			}
 		}
 		__syncthreads();
-		const int64_t where = s_tmp, kMax = s_kmax;
+		const int64_t where = s_tmp, kMax = s_kmax, desc = s_desc;
 		__syncthreads();
+		if (desc >= 0) { // (copied >= 4, so there is something to merge; bounds checked above)
+			CT(0);
+			merge_row_stream(g.walktab + desc, g.walktab + desc + kMax, tmp + where, (int32_t)s_copied, s_kept);
+			continue;
+		}
 		if (where == -3) continue;
 		if (where == -1) {
 			if (threadIdx.x == 0) copy_node<DEF>(g, v.lo + s, d, dref, row, src, err);

@@ -93,7 +93,7 @@ struct Pending { // an enqueued range decode whose status has not been collected
 	bv::RangeView view{};
 	int32_t levels_done = 0;
 	bool want_succ = false;
-	int32_t giantCap = 0, bigCap = 0, midCap = 0;
+	int32_t giantCap = 0, bigCap = 0, midCap = 0, walkMin = 0x7fffffff;
 	uint32_t tmpCap = 0;
 	// a sub-range decoded before its halo was sized (optimistic): what to repeat if the guess was wrong
 	bool optimistic = false;
@@ -113,6 +113,8 @@ struct bvg_graph {
 	mutable std::string err;
 	DevBuf outd, ref, rowstart, depth, sums, need, halo, hashA, hashB, hashBounds, stage_rowptr, stage_succ, stage_nodes, small;
 	DevBuf b_chainlen, b_slotbase, b_node, b_qidx, b_aoutd, b_qoutd; // random-access batches
+	DevBuf walktab;                                                   // block tables of the giant records (GraphDev::walktab)
+	int walk_tables = 1;                                              // BVGPU_WALK_TABLES=0: the copy pass walks every block list itself
 	DevBuf pickpart;                                                  // per-block outdegree class counts of k_headers
 	DevBuf biglist, giantlist, arena, coopctl;                        // work lists; cooperative decode of giant records
 	DevBuf key16, keys;                                               // per-slot list key; hist / keyBase / cursor
@@ -220,6 +222,7 @@ int init_handle(bvg_graph *g) {
 	if (const char *e = getenv("BVGPU_COPY_BIG")) g->copy_big = atoi(e);
 	if (const char *e = getenv("BVGPU_PARSE_WINDOWS")) g->parse_windows = atoi(e);
 	if (const char *e = getenv("BVGPU_TILE")) g->tile = atoi(e);
+	if (const char *e = getenv("BVGPU_WALK_TABLES")) g->walk_tables = atoi(e);
 	if (const char *e = getenv("BVGPU_CTILE")) g->ctile = atoi(e);
 	if (const char *e = getenv("BVGPU_COPY_MID_MIN")) g->copy_mid_min = std::min(std::max(0, atoi(e)), 1024); // 0: no wave-per-row copy
 	if (const char *e = getenv("BVGPU_OVERLAP")) g->overlap = atoi(e) != 0;
@@ -294,6 +297,14 @@ int join_to_user(bvg_graph *g) {
 
 inline hipStream_t side_b(const bvg_graph *g) { return g->host_mode ? g->sideA : g->sideB; }
 
+// GraphDev::walktab for this handle's job (walkMin = 0x7fffffff: none); the bump pointer is ctl[7], zeroed with the job's other counters
+void set_walk(bv::GraphDev &gd, bvg_graph *g, int32_t walkMin) {
+	gd.walkMin = walkMin;
+	gd.walktab = walkMin < 0x7fffffff ? g->walktab.as<int32_t>() : nullptr;
+	gd.walkCap = walkMin < 0x7fffffff ? (uint32_t)std::min<size_t>(g->walktab.cap / sizeof(int32_t), 0x7fffffff) : 0;
+	gd.walkCursor = (uint32_t *)(g->coopctl.as<int32_t>() + 7);
+}
+
 int fetch_small(bvg_graph *g) {
 	HIPCHK(g, hipMemcpyAsync(g->h_small, g->small.p, sizeof(Small), hipMemcpyDeviceToHost, g->stream));
 	HIPCHK(g, hipStreamSynchronize(g->stream));
@@ -326,7 +337,8 @@ int finish_pending(bvg_graph *g, uint64_t *arcs_out) {
 		return rc;
 	}
 	if (g->pend.want_succ && !g->h_small->err) {
-		const bv::GraphDev gd = graph_dev(s);
+		bv::GraphDev gd = graph_dev(s);
+		set_walk(gd, g, g->pend.walkMin);
 		int *derr = &g->small.as<Small>()->err;
 		while (g->pend.levels_done < g->h_small->maxdepth) {
 			const int32_t upto = g->h_small->maxdepth;
@@ -377,10 +389,17 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 	pick_thresholds(g, estArcs, coopMin, giantMin);
 	const int32_t W = s.info.window_size;
 	int *derr = &g->small.as<Small>()->err;
-	const bv::GraphDev gd = graph_dev(s);
+	bv::GraphDev gd = graph_dev(s);
 	levels = 0;
 	giantCap = 0;
 	{
+		// the block tables of the giant records, kept by the parse kernel for the copy pass (GraphDev::walktab): on when the job has a giant class
+		g->pend.walkMin = 0x7fffffff;
+		if (g->walk_tables && coopMin < 0x7fffffff && s.def != 0 && W > 0 && g->copy_lists && g->copy_big) {
+			const size_t cap = (size_t)std::min<int64_t>(std::max<int64_t>(s.arcs_sizing / 8, 1 << 20), 0x7fffffff);
+			if (g->walktab.need(sizeof(int32_t) * cap)) g->pend.walkMin = giantMin; // (no room: the copy pass walks the lists itself)
+		}
+		set_walk(gd, g, g->pend.walkMin);
 		// default path: depth + per-level lists; cooperative decode of long records (two classes) next to the
 		// one-lane decode of the short ones; then the copy pass level by level over compact lists
 		const int64_t arcsBound = std::max<int64_t>(s.arcs_sizing, 1);
@@ -792,7 +811,7 @@ extern "C" int bvg_close(bvg_t *g) {
 	if (g->st && g->st->device >= 0) {
 		(void)hipSetDevice(g->st->device);
 		if (g->own) { (void)hipStreamSynchronize(g->own); (void)hipStreamDestroy(g->own); }
-		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->hashBounds, &g->pickpart, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist, &g->plist, &g->pkeys, &g->pkey16, &g->copyq, &g->bigtmp, &g->tilebounds, &g->ctilebounds, &g->ref2 }) b->release();
+		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->hashBounds, &g->pickpart, &g->walktab, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist, &g->plist, &g->pkeys, &g->pkey16, &g->copyq, &g->bigtmp, &g->tilebounds, &g->ctilebounds, &g->ref2 }) b->release();
 		for (DevBuf *b : { &g->hchunk[0], &g->hchunk[1], &g->statsbuf, &g->bfs_rowptr, &g->bfs_succ, &g->bfs_ctr }) b->release();
 		for (PinBuf *b : { &g->hring[0], &g->hring[1], &g->view_rowptr, &g->view_succ }) b->release();
 		for (hipEvent_t e : { g->evChunk[0], g->evChunk[1], g->evCopied[0], g->evCopied[1] }) if (e) (void)hipEventDestroy(e);
