@@ -783,7 +783,8 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 				for (int32_t t = t0 + (int32_t)threadIdx.x; t < t1; t += COPY_BIG_THREADS) {
 					int32_t lo = 0, hi = nb - 1;
 					while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (bufK[mid] <= t) lo = mid + 1; else hi = mid; }
-					cv_[t] = src[t + bufD[lo]];
+					const int64_t si = (int64_t)t + bufD[lo]; // (inside the referent's row for tables of a valid walk; tables taken over from the parse
+					cv_[t] = si >= 0 && si < dref ? src[si] : 0; //  kernel of a record it flagged could hold anything: never read outside the row)
 					if (t == t1 - 1) s_b[0] = b0 + lo + (bufK[lo] <= t1 ? 1 : 0); // the block of id t1 (bufK[lo] > t1 - 1: it ends at t1 or later)
 				}
 				__syncthreads();
