@@ -105,12 +105,21 @@ template <int NWORDS> struct LaneWin {
 };
 
 // Same contract as parse_node<true>: the extras (intervals merged with residuals) of node x go to row[copied..d).
-template <int ZK>
-__device__ __forceinline__ void parse_node_lw(const GraphDev &g, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row, uint32_t *lds, int *__restrict__ err) {
+// !ARENA: the interval section is read twice, once to find the residual section and the number of residuals, once more, lazily, by a
+// second cursor (with a window of its own) during the merge.  ARENA (iv = the record's slice of the interval arena, >= d / minInt + 1
+// entries of 8 bytes): the first reading keeps what it decodes -- (left, length) per interval -- in a ring of LW_RING entries in the
+// lane's LDS column (where the second window would be) and, when there are more, in the arena; the merge takes an interval from the
+// ring with two LDS reads instead of two gamma decodes -- which SOME lane of the wave needed in almost every iteration -- and the
+// rings are topped up from the arena by all lanes together, like the stream windows.  (Loading the intervals back from the arena
+// one ahead, without a ring, was 30 % slower: a load in the merge loop waits for the loop's stores.)
+constexpr int LW_RING = LW_SIDE / 2;
+template <int ZK, bool ARENA>
+__device__ __forceinline__ void parse_node_lw(const GraphDev &g, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row, uint32_t *lds, int2 *__restrict__ iv, int *__restrict__ err) {
 	LaneWin<LW_MAIN> br;
-	LaneWin<LW_SIDE> bi; // second cursor, re-reads the interval section lazily during the merge
+	LaneWin<ARENA ? 4 : LW_SIDE> bi; // second cursor, re-reads the interval section lazily during the merge (!ARENA)
 	br.col = lds + threadIdx.x;
 	bi.col = lds + LW_MAIN * LW_STRIDE + threadIdx.x;
+	uint32_t *const ring = lds + LW_MAIN * LW_STRIDE + threadIdx.x; // (ARENA) entry j of the ring: ring[2 j * LW_STRIDE], ring[(2 j + 1) * LW_STRIDE]
 	br.vlast = bi.vlast = min((((uint64_t)g.offsets[x + 1] >> 5) + 2) & ~(uint64_t)3, (g.nwords + 4) & ~(uint64_t)3);
 	br.seek(g, (uint64_t)g.offsets[x]);
 	int e = 0;
@@ -141,12 +150,19 @@ __device__ __forceinline__ void parse_node_lw(const GraphDev &g, int32_t x, int3
 		nIntervals = (int64_t)br.code<1>(g, e);
 		if (nIntervals > extra) { atomicOr(err, E_FORMAT); return; }
 		if (nIntervals) {
-			bi.seek(g, br.pos());
+			if (!ARENA) bi.seek(g, br.pos());
+			int32_t prevEnd = 0;
 			for (int64_t i = 0; i < nIntervals; i++) {
-				(void)br.code<1>(g, e);
+				const uint64_t a = br.code<1>(g, e);
 				const uint64_t len = br.code<1>(g, e);
 				if (len > (uint64_t)extra) { e |= E_FORMAT; break; } // (any 64-bit value in a malformed stream: kept out of the sum)
 				intervalArcs += (int64_t)len + g.minInt;
+				if (ARENA) { // BVG:1084-1093, in Java ints
+					const int32_t left = i == 0 ? (int32_t)((int64_t)x + nat2int(a)) : prevEnd + (int32_t)a + 1, n = (int32_t)len + g.minInt;
+					prevEnd = left + n;
+					if (i < LW_RING) { ring[(2 * i) * LW_STRIDE] = (uint32_t)left; ring[(2 * i + 1) * LW_STRIDE] = (uint32_t)n; }
+					if (nIntervals > LW_RING) iv[i] = int2{ left, n };
+				}
 			}
 		}
 	}
@@ -163,18 +179,41 @@ __device__ __forceinline__ void parse_node_lw(const GraphDev &g, int32_t x, int3
 	int32_t ivLeft = 0, ivRem = 0, ivPrev = 0; // current interval: next value, values left; end of the previous interval
 	int32_t ivTodo = (int32_t)nIntervals;
 	bool firstIv = true;
+	int32_t ivIdx = 0, ivBase = 0, ivLoaded = min(ivTodo, LW_RING); // (ARENA) next interval; oldest one in the ring; intervals [ivBase, ivLoaded) are in the ring
 	int32_t resTodo = (int32_t)nRes;
 	int32_t resVal = 0;
 	if (resTodo) resVal = (int32_t)((int64_t)x + nat2int(br.template code<0, ZK>(g, e))); // BVG:954
 	while (k < nExtra) {
 		br.wave_refill<3>(g);
-		if (ivTodo) bi.wave_refill<6>(g); // an interval is two gamma codes
-		if (ivRem == 0 && ivTodo) { // BVG:1084-1093
-			if (firstIv) { ivLeft = (int32_t)((int64_t)x + nat2int(bi.code<1>(g, e))); firstIv = false; }
-			else ivLeft = ivPrev + (int32_t)bi.code<1>(g, e) + 1;
-			ivRem = (int32_t)bi.code<1>(g, e) + g.minInt;
-			ivPrev = ivLeft + ivRem;
-			ivTodo--;
+		if (ARENA) {
+			if (__any(ivLoaded < (int32_t)nIntervals && ivIdx - ivBase >= LW_RING - 2)) { // some lane's ring runs low: every lane tops its own up (rare: the wave waits once)
+				const int32_t cnt = min((ivIdx - ivBase) & ~1, (int32_t)nIntervals - ivLoaded); // (ivLoaded stays even until the last top-up)
+#pragma unroll
+				for (int p = 0; p < LW_RING / 2; p++) {
+					if (2 * p < cnt) {
+						const int4 t = *(const int4 *)(iv + ivLoaded + 2 * p); // (the slice has room for twice the entries: reading one past the last is harmless)
+						const int j0 = (ivLoaded + 2 * p) & (LW_RING - 1);
+						ring[(2 * j0) * LW_STRIDE] = (uint32_t)t.x; ring[(2 * j0 + 1) * LW_STRIDE] = (uint32_t)t.y;
+						ring[(2 * j0 + 2) * LW_STRIDE] = (uint32_t)t.z; ring[(2 * j0 + 3) * LW_STRIDE] = (uint32_t)t.w;
+					}
+				}
+				if (cnt > 0) { ivBase += cnt; ivLoaded += cnt; }
+			}
+			if (ivRem == 0 && ivTodo) {
+				const int j = ivIdx & (LW_RING - 1);
+				ivLeft = (int32_t)ring[(2 * j) * LW_STRIDE]; ivRem = (int32_t)ring[(2 * j + 1) * LW_STRIDE];
+				ivIdx++;
+				ivTodo--;
+			}
+		} else {
+			if (ivTodo) bi.template wave_refill<6>(g); // an interval is two gamma codes
+			if (ivRem == 0 && ivTodo) { // BVG:1084-1093
+				if (firstIv) { ivLeft = (int32_t)((int64_t)x + nat2int(bi.template code<1>(g, e))); firstIv = false; }
+				else ivLeft = ivPrev + (int32_t)bi.template code<1>(g, e) + 1;
+				ivRem = (int32_t)bi.template code<1>(g, e) + g.minInt;
+				ivPrev = ivLeft + ivRem;
+				ivTodo--;
+			}
 		}
 		int32_t val;
 		if (ivRem && (!resTodo || ivLeft < resVal)) { val = ivLeft; ivLeft++; ivRem--; }

@@ -114,6 +114,7 @@ struct bvg_graph {
 	DevBuf outd, ref, rowstart, depth, sums, need, halo, hashA, hashB, hashBounds, stage_rowptr, stage_succ, stage_nodes, small;
 	DevBuf b_chainlen, b_slotbase, b_node, b_qidx, b_aoutd, b_qoutd; // random-access batches
 	DevBuf walktab;                                                   // block tables of the giant records (GraphDev::walktab)
+	int iv_arena = 1;                                                 // BVGPU_IV_ARENA=0: the one-lane decoder reads every interval section twice instead of keeping it in the arena
 	int walk_tables = 1;                                              // BVGPU_WALK_TABLES=0: the copy pass walks every block list itself
 	DevBuf pickpart;                                                  // per-block outdegree class counts of k_headers
 	DevBuf biglist, giantlist, arena, coopctl;                        // work lists; cooperative decode of giant records
@@ -223,6 +224,7 @@ int init_handle(bvg_graph *g) {
 	if (const char *e = getenv("BVGPU_PARSE_WINDOWS")) g->parse_windows = atoi(e);
 	if (const char *e = getenv("BVGPU_TILE")) g->tile = atoi(e);
 	if (const char *e = getenv("BVGPU_WALK_TABLES")) g->walk_tables = atoi(e);
+	if (const char *e = getenv("BVGPU_IV_ARENA")) g->iv_arena = atoi(e);
 	if (const char *e = getenv("BVGPU_CTILE")) g->ctile = atoi(e);
 	if (const char *e = getenv("BVGPU_COPY_MID_MIN")) g->copy_mid_min = std::min(std::max(0, atoi(e)), 1024); // 0: no wave-per-row copy
 	if (const char *e = getenv("BVGPU_OVERLAP")) g->overlap = atoi(e) != 0;
@@ -517,7 +519,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		mark(g, 5);
 		if (tiles) bv::launch_parse_tile(gd, s.def, v, g->tilebounds.as<int32_t>(), ntiles, tileVariant, derr, g->stream);
 		else if (pKeyBase) {
-			bv::launch_parse_list(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, g->level_blocks, derr, g->stream);
+			bv::launch_parse_list(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, g->level_blocks, derr, g->stream, g->iv_arena ? g->arena.p : nullptr, arenaCap);
 		}
 		else bv::launch_parse(gd, s.def, v, derr, g->stream);
 		if (ovl) {
