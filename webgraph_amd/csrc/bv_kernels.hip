@@ -907,7 +907,7 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 template <int DEF, bool ARENA>
 __global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, const int32_t *__restrict__ list, const int32_t *__restrict__ keyBase, int32_t binLo, int32_t binHi,
                                                     IvEntry *__restrict__ arena, int64_t arenaCap, int *__restrict__ err) {
-	__shared__ uint32_t lw[DEF ? LW_LDS_WORDS : 1]; // lane-private stream windows, or one window and a ring of intervals (default codings)
+	__shared__ uint32_t lw[DEF ? (ARENA ? (LW_MAIN + 2 * LW_RING) * LW_STRIDE : LW_LDS_WORDS) : 1]; // lane-private stream windows, or one window and a ring of intervals (default codings)
 	const int32_t lo = keyBase[binLo], hi = keyBase[binHi], coopMin = v.coopmin();
 	// The list is sorted longest first.  Thread T takes entries T, 2G-1-T, 2G+T, 4G-1-T, ... (G = threads in the
 	// grid): a snake, so that the threads that got the longest records of one sweep get the shortest of the next.

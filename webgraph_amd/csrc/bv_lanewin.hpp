@@ -112,7 +112,10 @@ template <int NWORDS> struct LaneWin {
 // ring with two LDS reads instead of two gamma decodes -- which SOME lane of the wave needed in almost every iteration -- and the
 // rings are topped up from the arena by all lanes together, like the stream windows.  (Loading the intervals back from the arena
 // one ahead, without a ring, was 30 % slower: a load in the merge loop waits for the loop's stores.)
-constexpr int LW_RING = LW_SIDE / 2;
+#ifndef LW_RING_
+#define LW_RING_ 8
+#endif
+constexpr int LW_RING = LW_RING_; // (a power of two; 2 * LW_RING <= LW_SIDE words of the lane's column)
 template <int ZK, bool ARENA>
 __device__ __forceinline__ void parse_node_lw(const GraphDev &g, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row, uint32_t *lds, int2 *__restrict__ iv, int *__restrict__ err) {
 	LaneWin<LW_MAIN> br;
