@@ -1,0 +1,50 @@
+"""The N > 1 path of bench.py (bvg_open_shard per rank + reduce_scan of (arcs, hash map) + the hashCode gate against the CPU
+oracle) under test on ONE GPU: two ranks launched exactly as the driver launches them (python -m torch.distributed.run,
+one process per rank, rendezvous on 127.0.0.1), both on cuda:0 with the gloo backend for the host-side reduction.  What
+a real multi-GPU run adds is one device per rank and RCCL for the same three-integer all_gather; the sharding
+(ImmutableGraph.splitNodeIterators, ImmutableGraph.java:379-409), the slice staging and the parity
+gate are what runs here."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(workload, ranks, nodes, arcs, tmp_path):
+    env = dict(os.environ)
+    env["BVGPU_CACHE"] = str(tmp_path / "cache")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--backend", "gloo", "--one-device",
+           "--workload", workload, "--nodes", str(nodes), "--arcs", str(arcs), "--steps", "3", "--warmup", "1", "--no-pmc", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, "bench.py failed:\n" + p.stdout[-2000:] + "\n" + p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 must print exactly one JSON line, got %d" % len(lines)
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("workload,nodes,arcs", [("C2", 1_000_000, 20_000_000), ("C5", 600_000, 12_000_000)])
+def test_two_rank_bench_line(tmp_path, workload, nodes, arcs):
+    out = _run(workload, 2, nodes, arcs, tmp_path)
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1
+    assert out["scaling"] == "weak" and out["higher_is_better"] is True and out["unit"] == "edges/s"
+    cfg = out["config"]
+    assert cfg["arcs_total"] == 2 * arcs and cfg["nodes_total"] == 2 * nodes
+    assert cfg["parity"].endswith("== CPU oracle's")
+    assert out["value"] > 0 and abs(out["value"] - cfg["arcs_total"] / (out["ms_per_step"] * 1e-3)) <= 1e-3 * out["value"]
+    assert out.get("cpu_baseline") is None or isinstance(out["cpu_baseline"], dict)

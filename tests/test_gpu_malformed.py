@@ -170,3 +170,31 @@ def test_block_lengths_that_wrap_are_rejected(tmp_path, monkeypatch, d, dense):
     rp, sc = g.successors_batch(np.array([0, 2], dtype=np.int32))
     assert list(np.diff(rp)) == [d, d] and sc[0] == 10 and sc[d - 1] == 10 + 2 * (d - 1)
     g.close()
+
+
+def test_stats_scan_rejects_successors_outside_the_graph(tmp_path):
+    """A stream can name any id (ids wrap in Java ints, BVG:954): the statistics scan counts indegrees by successor, so an id
+    outside [0, n) must end the scan with an error instead of an increment at an address the file chose (the
+    reference throws ArrayIndexOutOfBoundsException at Stats.java:130)."""
+    import torch
+    from bitio import write_graph
+    from webgraph_amd.bvgraph import BVGraph
+    n = 50
+    recs = [_plain_row(3, 4, x) for x in range(n)]
+    recs[17] = _plain_row(1 << 20, 4, 17)      # far past the last node
+    recs[31] = _plain_row(-5000, 3, 31)        # negative ids
+    base = str(tmp_path / "oob")
+    write_graph(base, recs, arcs=4 * n - 1)
+    g = BVGraph.load(base)
+    rp, sc = g.decode_range()                  # the plain scan hands the ids out as they are, like the reference
+    assert sc[rp[17]] == 1 << 20 and sc[rp[31]] == -5000
+    guard = torch.zeros(n + 4096, dtype=torch.int32, device="cuda")
+    with pytest.raises(_errors()):
+        g.scan_stats(0, n, indegree_ptr=guard.data_ptr())
+    torch.cuda.synchronize()
+    assert int(guard[n:].sum()) == 0 and int(guard[:n].sum()) == 4 * n - 1 - 7
+    with pytest.raises(_errors()):
+        g.scan_stats(0, n)
+    st = g.scan_stats(0, 17)                   # well-formed ranges are still served
+    assert st["arcs"] == 4 * 17
+    g.close()

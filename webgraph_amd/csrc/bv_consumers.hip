@@ -44,6 +44,7 @@ __device__ __forceinline__ RowSlice stage_rows(const int64_t *__restrict__ rowpt
 
 struct StatsDev { // accumulated with atomics
 	unsigned long long arcs, loops, dangling, terminal, num_gaps, tot_loc, tot_gap, min_key, max_key, delta[32];
+	unsigned long long bad; // arcs whose successor is outside [0, n): a malformed stream (the reference would throw ArrayIndexOutOfBounds at Stats.java:130)
 };
 
 __global__ void __launch_bounds__(CS_T) k_stats_nodes(int32_t from, int32_t cnt, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ, StatsDev *st) {
@@ -77,7 +78,7 @@ __global__ void __launch_bounds__(CS_T) k_stats_nodes(int32_t from, int32_t cnt,
 	}
 }
 
-__global__ void __launch_bounds__(CS_T) k_stats_arcs(int32_t from, int32_t cnt, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ, StatsDev *st, int32_t *__restrict__ indegree) {
+__global__ void __launch_bounds__(CS_T) k_stats_arcs(int32_t from, int32_t cnt, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ, StatsDev *st, int32_t *__restrict__ indegree, int32_t n) {
 	__shared__ int64_t s_rp[CS_ARCS + 2];
 	__shared__ int32_t s_b[2];
 	__shared__ unsigned long long s_delta[32];
@@ -86,7 +87,7 @@ __global__ void __launch_bounds__(CS_T) k_stats_arcs(int32_t from, int32_t cnt, 
 	if (threadIdx.x < 32) s_delta[threadIdx.x] = 0;
 	const RowSlice rs = stage_rows(rowptr, cnt, a0, a1, s_rp, s_b);
 	__syncthreads();
-	unsigned long long loops = 0, loc = 0;
+	unsigned long long loops = 0, loc = 0, bad = 0;
 	for (int64_t a = a0 + threadIdx.x; a < a1; a += CS_T) {
 		const int32_t curr = from + rs.rlo + row_of(rs.rp, rs.n, a), sx = succ[a];
 		const int64_t dist = (int64_t)sx - curr;
@@ -94,10 +95,11 @@ __global__ void __launch_bounds__(CS_T) k_stats_arcs(int32_t from, int32_t cnt, 
 		loc += ad;                                                            // Stats.java:125
 		if (sx != curr) atomicAdd(&s_delta[63 - __clzll((long long)ad)], 1ull); // :127  Fast.mostSignificantBit
 		else loops++;                                                         // :128
-		if (indegree) atomicAdd(&indegree[sx], 1);                            // :130
+		if ((uint32_t)sx >= (uint32_t)n) bad++;                               // never index with an id the stream made up
+		else if (indegree) atomicAdd(&indegree[sx], 1);                       // :130
 	}
-	for (int o = 32; o > 0; o >>= 1) { loops += __shfl_xor(loops, o, 64); loc += __shfl_xor(loc, o, 64); }
-	if ((threadIdx.x & 63) == 0) { if (loops) atomicAdd(&st->loops, loops); atomicAdd(&st->tot_loc, loc); }
+	for (int o = 32; o > 0; o >>= 1) { loops += __shfl_xor(loops, o, 64); loc += __shfl_xor(loc, o, 64); bad += __shfl_xor(bad, o, 64); }
+	if ((threadIdx.x & 63) == 0) { if (loops) atomicAdd(&st->loops, loops); atomicAdd(&st->tot_loc, loc); if (bad) atomicAdd(&st->bad, bad); }
 	__syncthreads();
 	if (threadIdx.x < 32 && s_delta[threadIdx.x]) atomicAdd(&st->delta[threadIdx.x], s_delta[threadIdx.x]);
 	if (threadIdx.x == 0) atomicAdd(&st->arcs, (unsigned long long)(a1 - a0));
@@ -131,10 +133,10 @@ __global__ void __launch_bounds__(CS_T) k_bfs_expand(const int32_t *__restrict__
 	}
 }
 
-void launch_stats(int32_t from, int32_t cnt, const int64_t *rowptr, const int32_t *succ, int64_t arcsUpper, void *statsDev, int32_t *indegree, hipStream_t st) {
+void launch_stats(int32_t from, int32_t cnt, const int64_t *rowptr, const int32_t *succ, int64_t arcsUpper, void *statsDev, int32_t *indegree, int32_t n, hipStream_t st) {
 	if (cnt <= 0) return;
 	hipLaunchKernelGGL(k_stats_nodes, dim3((unsigned)((cnt + CS_T - 1) / CS_T)), dim3(CS_T), 0, st, from, cnt, rowptr, succ, (StatsDev *)statsDev);
-	if (arcsUpper > 0) hipLaunchKernelGGL(k_stats_arcs, dim3((unsigned)((arcsUpper + CS_ARCS - 1) / CS_ARCS)), dim3(CS_T), 0, st, from, cnt, rowptr, succ, (StatsDev *)statsDev, indegree);
+	if (arcsUpper > 0) hipLaunchKernelGGL(k_stats_arcs, dim3((unsigned)((arcsUpper + CS_ARCS - 1) / CS_ARCS)), dim3(CS_T), 0, st, from, cnt, rowptr, succ, (StatsDev *)statsDev, indegree, n);
 }
 size_t stats_dev_bytes() { return sizeof(StatsDev); }
 void launch_bfs_expand(const int32_t *frontier, int32_t q, const int64_t *rowptr, const int32_t *succ, int64_t arcs, int32_t *marker, int32_t n, int32_t round, int parent,

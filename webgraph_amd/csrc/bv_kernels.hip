@@ -26,8 +26,6 @@
 #include "bv_coop.hpp"
 #include "bv_lanewin.hpp"
 #include "bv_tile.hpp"
-#include "bv_tile2.hpp"
-#include "bv_ctile.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -1552,27 +1550,9 @@ void launch_tile_bounds(const GraphDev &g, int32_t lo, int32_t cnt, int32_t ntil
 }
 void launch_parse_tile(const GraphDev &g, int def, const RangeView &v, const int32_t *tb, int32_t ntiles, int variant, int *err, hipStream_t st) {
 	if (v.cnt <= 0 || ntiles <= 0) return;
-	if (variant == 1) { // one lane per record (bv_tile.hpp)
-		if (def == 1) hipLaunchKernelGGL(k_parse_tile<1>, dim3(ntiles), dim3(TILE_T), 0, st, g, v, tb, err);
-		else hipLaunchKernelGGL(k_parse_tile<2>, dim3(ntiles), dim3(TILE_T), 0, st, g, v, tb, err);
-		return;
-	}
-	// long residual sections segment by segment (bv_tile2.hpp)
-	if (def == 1) hipLaunchKernelGGL(k_parse_tile2<1>, dim3(ntiles), dim3(T2_T), 0, st, g, v, tb, err);
-	else hipLaunchKernelGGL(k_parse_tile2<2>, dim3(ntiles), dim3(T2_T), 0, st, g, v, tb, err);
-}
-
-int32_t ctile_count(int64_t arcsBound, int32_t cnt) { return (int32_t)std::min<int64_t>((arcsBound + (int64_t)CT_NODE_W * cnt) / CT_SPAN + 1, 0x3ffffff0); }
-bool ctile_applicable(int def, int32_t window) { return def != 0 && window > 0 && window <= CT_HALO_ROWS; }
-void launch_copy_tiles(const GraphDev &g, int def, const RangeView &v, int32_t ntiles, int32_t *tb, uint16_t *ref2, int *err, hipStream_t st) {
-	if (v.cnt <= 0 || ntiles <= 0) return;
-	hipLaunchKernelGGL(k_ctile_bounds, dim3(nblk((int64_t)ntiles + 1, 256)), dim3(256), 0, st, v.rowstart, v.cnt, ntiles, tb);
-	for (int parity = 0; parity < 2; parity++) {
-		const unsigned blocks = (unsigned)((ntiles - parity + 1) / 2);
-		if (!blocks) continue;
-		if (def == 1) hipLaunchKernelGGL(k_copy_tile<1>, dim3(blocks), dim3(CT_T), 0, st, g, v, tb, parity, ref2, err);
-		else hipLaunchKernelGGL(k_copy_tile<2>, dim3(blocks), dim3(CT_T), 0, st, g, v, tb, parity, ref2, err);
-	}
+	(void)variant; // one lane per record (bv_tile.hpp)
+	if (def == 1) hipLaunchKernelGGL(k_parse_tile<1>, dim3(ntiles), dim3(TILE_T), 0, st, g, v, tb, err);
+	else hipLaunchKernelGGL(k_parse_tile<2>, dim3(ntiles), dim3(TILE_T), 0, st, g, v, tb, err);
 }
 
 void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, void *arena, int64_t arenaCap) {

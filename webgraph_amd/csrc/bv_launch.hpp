@@ -83,10 +83,6 @@ void launch_parse_giants(const GraphDev &g, int def, const RangeView &v, const i
 int32_t tile_count(int64_t bitSpan, int32_t cnt);
 void launch_tile_bounds(const GraphDev &g, int32_t lo, int32_t cnt, int32_t ntiles, int32_t *tb, hipStream_t st);
 void launch_parse_tile(const GraphDev &g, int def, const RangeView &v, const int32_t *tb, int32_t ntiles, int variant, int *err, hipStream_t st);
-// bv_ctile.hpp: the copy pass of the short rows, tile by tile in LDS (even tiles, then odd tiles); ref2 = what is left
-int32_t ctile_count(int64_t arcsBound, int32_t cnt);
-bool ctile_applicable(int def, int32_t window);
-void launch_copy_tiles(const GraphDev &g, int def, const RangeView &v, int32_t ntiles, int32_t *tb, uint16_t *ref2, int *err, hipStream_t st);
 int64_t hash_chunks(int32_t cnt, int64_t arcs);
 void launch_hash(int32_t from, int32_t cnt, int64_t arcs, const int64_t *rowptr, const int32_t *succ, uint32_t *A, uint32_t *B, int32_t *bounds, int32_t *hash, hipStream_t st);
 
@@ -94,7 +90,7 @@ void launch_bparse_big(const GraphDev &g, int def, const BatchView &v, int32_t c
                        void *arena, int64_t arenaCap, int waves, int giantGroups, int *err, hipStream_t st, hipStream_t stGiant, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evGiant, hipEvent_t evBig);
 
 // bv_consumers.hip: consumers of rows decoded into on-die scratch
-void launch_stats(int32_t from, int32_t cnt, const int64_t *rowptr, const int32_t *succ, int64_t arcsUpper, void *statsDev, int32_t *indegree, hipStream_t st);
+void launch_stats(int32_t from, int32_t cnt, const int64_t *rowptr, const int32_t *succ, int64_t arcsUpper, void *statsDev, int32_t *indegree, int32_t n, hipStream_t st);
 size_t stats_dev_bytes();
 void launch_bfs_expand(const int32_t *frontier, int32_t q, const int64_t *rowptr, const int32_t *succ, int64_t arcs, int32_t *marker, int32_t n, int32_t round, int parent,
                        int32_t *out, uint64_t outCap, unsigned long long *outCount, hipStream_t st);

@@ -125,9 +125,6 @@ struct bvg_graph {
 	DevBuf plist, pkeys, pkey16;
 	int tile = -1;       // -1: automatic (see enqueue_decode); BVGPU_TILE=0: never; BVGPU_TILE=1: short records decoded from contiguous tiles of the stream (k_parse_tile) instead of the bin-sorted parse list (k_parse_list)
 	DevBuf tilebounds;
-	int ctile = 0;       // BVGPU_CTILE=1: the copy pass of the short rows tile by tile in LDS (bv_ctile.hpp) before the level-wise kernels
-	                     // (bit-exact; measured slower than the level-wise kernels alone on C2, cnr-2000 x30 and the C5 shard: DESIGN.md section 6)
-	DevBuf ctilebounds, ref2;
 	int copy_big = 1;    // BVGPU_COPY_BIG=0: every row is copied by one lane
 	int parse_windows = 1; // BVGPU_PARSE_WINDOWS=0: the parse list is sorted by work bin over the whole range
 	int copy_mid_min = 128; // rows with at least this many successors (and fewer than 1024) are copied by one wave each
@@ -225,7 +222,6 @@ int init_handle(bvg_graph *g) {
 	if (const char *e = getenv("BVGPU_TILE")) g->tile = atoi(e);
 	if (const char *e = getenv("BVGPU_WALK_TABLES")) g->walk_tables = atoi(e);
 	if (const char *e = getenv("BVGPU_IV_ARENA")) g->iv_arena = atoi(e);
-	if (const char *e = getenv("BVGPU_CTILE")) g->ctile = atoi(e);
 	if (const char *e = getenv("BVGPU_COPY_MID_MIN")) g->copy_mid_min = std::min(std::max(0, atoi(e)), 1024); // 0: no wave-per-row copy
 	if (const char *e = getenv("BVGPU_OVERLAP")) g->overlap = atoi(e) != 0;
 	if (const char *e = getenv("BVGPU_HALO_MIN")) g->halo_min = (size_t)std::max(4, atoi(e));
@@ -500,10 +496,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		// ... then, behind the wave class, the chain depth of every record + per-level lists (node order inside a level) +
 		// copy queues: only the copy pass needs them, and launched first they would sit in front of the wave class while
 		// the one-lane kernel holds every CU
-		// The copy pass of the short rows runs tile by tile in LDS once every record is parsed (bv_ctile.hpp); the chain depths
-		// and level lists are then built from what it leaves (ref2), behind it
-		const bool ctiles = g->ctile && g->copy_lists && bv::ctile_applicable(s.def, W);
-		if (W > 0 && !ctiles) bv::launch_build_lists(gd, v, ~0ull, 1, g->depth.as<int32_t>(), g->key16.as<uint16_t>(), hist, keyBase, cursor, g->lvlist.as<int32_t>(),
+		if (W > 0) bv::launch_build_lists(gd, v, ~0ull, 1, g->depth.as<int32_t>(), g->key16.as<uint16_t>(), hist, keyBase, cursor, g->lvlist.as<int32_t>(),
 		                                  g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->maxdepth, stLists,
 		                                  g->copy_lists ? g->copyq.as<int32_t>() : nullptr, bigCap, g->copyq.as<int32_t>() + bigCap, midCap, g->copy_mid_min, g->copy_big != 0);
 		if (ovl) HIPCHK(g, hipEventRecord(g->evA, g->sideA));
@@ -527,17 +520,6 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			if (coop) HIPCHK(g, hipStreamWaitEvent(g->stream, g->evB, 0));
 		}
 		mark(g, 6);
-		if (ctiles) {
-			const int64_t arcsEst = std::min<int64_t>(arcsBound, estArcs * 2 + 65536);
-			const int32_t nct = bv::ctile_count(arcsEst, v.cnt);
-			if (!g->ctilebounds.need(sizeof(int32_t) * ((size_t)nct + 2)) || !g->ref2.need(sizeof(uint16_t) * (size_t)v.cnt)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
-			HIPCHK(g, hipMemcpyAsync(g->ref2.p, v.ref, sizeof(uint16_t) * (size_t)v.cnt, hipMemcpyDeviceToDevice, g->stream));
-			bv::launch_copy_tiles(gd, s.def, v, nct, g->ctilebounds.as<int32_t>(), g->ref2.as<uint16_t>(), derr, g->stream);
-			v.ref = g->ref2.as<uint16_t>(); // from here on: what is left of the chains
-			bv::launch_build_lists(gd, v, ~0ull, 1, g->depth.as<int32_t>(), g->key16.as<uint16_t>(), hist, keyBase, cursor, g->lvlist.as<int32_t>(),
-			                       g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->maxdepth, g->stream,
-			                       g->copyq.as<int32_t>(), bigCap, g->copyq.as<int32_t>() + bigCap, midCap, g->copy_mid_min, g->copy_big != 0);
-		}
 		if (W > 0) {
 			levels = g->levels_hint;
 			for (int32_t l = 1; l <= levels; l++) {
@@ -813,7 +795,7 @@ extern "C" int bvg_close(bvg_t *g) {
 	if (g->st && g->st->device >= 0) {
 		(void)hipSetDevice(g->st->device);
 		if (g->own) { (void)hipStreamSynchronize(g->own); (void)hipStreamDestroy(g->own); }
-		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->hashBounds, &g->pickpart, &g->walktab, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist, &g->plist, &g->pkeys, &g->pkey16, &g->copyq, &g->bigtmp, &g->tilebounds, &g->ctilebounds, &g->ref2 }) b->release();
+		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->hashBounds, &g->pickpart, &g->walktab, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist, &g->plist, &g->pkeys, &g->pkey16, &g->copyq, &g->bigtmp, &g->tilebounds }) b->release();
 		for (DevBuf *b : { &g->hchunk[0], &g->hchunk[1], &g->statsbuf, &g->bfs_rowptr, &g->bfs_succ, &g->bfs_ctr }) b->release();
 		for (PinBuf *b : { &g->hring[0], &g->hring[1], &g->view_rowptr, &g->view_succ }) b->release();
 		for (hipEvent_t e : { g->evChunk[0], g->evChunk[1], g->evCopied[0], g->evCopied[1] }) if (e) (void)hipEventDestroy(e);
@@ -1318,7 +1300,7 @@ extern "C" int bvg_csr_hashcode(bvg_t *g, int32_t from, int32_t to, const int64_
 }
 
 namespace {
-struct StatsHost { unsigned long long arcs, loops, dangling, terminal, num_gaps, tot_loc, tot_gap, min_key, max_key, delta[32]; }; // = bv::StatsDev
+struct StatsHost { unsigned long long arcs, loops, dangling, terminal, num_gaps, tot_loc, tot_gap, min_key, max_key, delta[32], bad; }; // = bv::StatsDev
 }
 
 extern "C" int bvg_scan_stats(bvg_t *g, int32_t from, int32_t to, bvg_scan_stats_t *out, int32_t *indegree_dev) {
@@ -1345,11 +1327,12 @@ extern "C" int bvg_scan_stats(bvg_t *g, int32_t from, int32_t to, bvg_scan_stats
 			rc = decode_range_device(g, a, e, g->stage_rowptr.as<int64_t>(), g->stage_succ.as<int32_t>(), g->stage_succ.cap / sizeof(int32_t), false, &arcs);
 		}
 		if (rc) return rc;
-		bv::launch_stats(a, e - a, g->stage_rowptr.as<int64_t>(), g->stage_succ.as<int32_t>(), (int64_t)arcs, g->statsbuf.p, indegree_dev, g->stream);
+		bv::launch_stats(a, e - a, g->stage_rowptr.as<int64_t>(), g->stage_succ.as<int32_t>(), (int64_t)arcs, g->statsbuf.p, indegree_dev, s.info.nodes, g->stream);
 		HIPCHK(g, hipStreamSynchronize(g->stream)); // the scratch rows are reused by the next chunk
 	}
 	HIPCHK(g, hipMemcpy(&h, g->statsbuf.p, sizeof(h), hipMemcpyDeviceToHost));
 	memset(out, 0, sizeof(*out));
+	if (h.bad) return fail(g, BVG_EFORMAT, "malformed bit stream: successor outside [0, nodes)");
 	out->nodes = (uint64_t)(to - from); out->arcs = h.arcs; out->loops = h.loops; out->dangling = h.dangling; out->terminal = h.terminal;
 	out->num_gaps = h.num_gaps; out->tot_gap = h.tot_gap; out->tot_loc = h.tot_loc;
 	for (int i = 0; i < 32; i++) out->successor_delta_stats[i] = h.delta[i];
