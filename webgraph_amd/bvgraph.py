@@ -416,7 +416,7 @@ class BVGraph:
         return int(a.value), int(b.value)
 
     def debug_stats(self, reset=True):
-        out = np.zeros(32, dtype=np.uint64)
+        out = np.zeros(64, dtype=np.uint64)
         self._check(lib().bvg_debug_stats(self._h, out.ctypes.data, 1 if reset else 0))
         return out
 

@@ -1022,6 +1022,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? COOP1_MINWAVES : COOPG_MINW
 	__shared__ __attribute__((aligned(16))) uint32_t lds[CoopLds<NW>::WORDS];
 	__shared__ int32_t s_idx;
 	const int32_t count = ctl[which]; // (the giant list is sized for arcs / giantMin entries, which bounds their number)
+	if (count <= 0) return; // (an empty list -- the usual state of the strip kernel's escape list -- costs no atomics)
 	for (;;) {
 		if (threadIdx.x == 0) s_idx = atomicAdd(&ctl[2 + which], 1);
 		__syncthreads();

@@ -125,6 +125,9 @@ struct bvg_graph {
 	DevBuf plist, pkeys, pkey16;
 	int tile = -1;       // -1: automatic (see enqueue_decode); BVGPU_TILE=0: never; BVGPU_TILE=1: short records decoded from contiguous tiles of the stream (k_parse_tile) instead of the bin-sorted parse list (k_parse_list)
 	DevBuf tilebounds;
+	int strip = 1;       // BVGPU_STRIP=0: the strip kernel (bv_strip.hip) is not used for the records below the wave class
+	int32_t strip_max = 0; // records with fewer successors are strip work (BVGPU_STRIP_MAX; 0: the kernel's default)
+	DevBuf stripbounds, esclist;
 	int copy_big = 1;    // BVGPU_COPY_BIG=0: every row is copied by one lane
 	int parse_windows = 1; // BVGPU_PARSE_WINDOWS=0: the parse list is sorted by work bin over the whole range
 	int copy_mid_min = 128; // rows with at least this many successors (and fewer than 1024) are copied by one wave each
@@ -220,6 +223,9 @@ int init_handle(bvg_graph *g) {
 	if (const char *e = getenv("BVGPU_COPY_BIG")) g->copy_big = atoi(e);
 	if (const char *e = getenv("BVGPU_PARSE_WINDOWS")) g->parse_windows = atoi(e);
 	if (const char *e = getenv("BVGPU_TILE")) g->tile = atoi(e);
+	if (const char *e = getenv("BVGPU_STRIP")) g->strip = atoi(e);
+	g->strip_max = bv::strip_max_default();
+	if (const char *e = getenv("BVGPU_STRIP_MAX")) g->strip_max = std::min(std::max(2, atoi(e)), 2048);
 	if (const char *e = getenv("BVGPU_WALK_TABLES")) g->walk_tables = atoi(e);
 	if (const char *e = getenv("BVGPU_IV_ARENA")) g->iv_arena = atoi(e);
 	if (const char *e = getenv("BVGPU_COPY_MID_MIN")) g->copy_mid_min = std::min(std::max(0, atoi(e)), 1024); // 0: no wave-per-row copy
@@ -239,7 +245,7 @@ int init_handle(bvg_graph *g) {
 	HIPCHK(g, hipEventCreateWithFlags(&g->evC, hipEventDisableTiming));
 	HIPCHK(g, hipEventCreateWithFlags(&g->evHdr, hipEventDisableTiming));
 	HIPCHK(g, hipEventCreateWithFlags(&g->evP, hipEventDisableTiming));
-	if (const char *e = getenv("BVGPU_STATS")) if (atoi(e)) { if (!g->stats.need(32 * sizeof(unsigned long long))) return fail(g, BVG_ENOMEM, "device allocation failed"); HIPCHK(g, hipMemset(g->stats.p, 0, 256)); }
+	if (const char *e = getenv("BVGPU_STATS")) if (atoi(e)) { if (!g->stats.need(64 * sizeof(unsigned long long))) return fail(g, BVG_ENOMEM, "device allocation failed"); HIPCHK(g, hipMemset(g->stats.p, 0, 512)); }
 	return BVG_OK;
 }
 
@@ -385,6 +391,14 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 	const Staged &s = *g->st;
 	int32_t coopMin, giantMin;
 	pick_thresholds(g, estArcs, coopMin, giantMin);
+	// The strip kernel (default codings) takes every record below its threshold, whatever the job: its unit of work is a segment
+	// of a residual section, so a lane never decodes a long record alone and the wave class has nothing to protect the tail from.
+	const bool strips = g->strip != 0 && s.def != 0;
+	if (strips) {
+		coopMin = g->adaptive ? g->strip_max : std::min(g->strip_max, g->coop_min);
+		giantMin = std::max(giantMin, coopMin);
+		v.coop_ptr = nullptr; // (k_pick_coop still ran: it zeroes the job's counters)
+	}
 	const int32_t W = s.info.window_size;
 	int *derr = &g->small.as<Small>()->err;
 	bv::GraphDev gd = graph_dev(s);
@@ -443,8 +457,8 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		// in the lane class -- its share (by bits) of the staged records with >= 128 successors fits the wave class, so that
 		// k_pick_coop will pick 128 --: neighbouring short records are alike, a tile's lanes stay even, and the coalesced tile
 		// kernel is 20 % faster than the bins (cnr-2000 x 30: 0.42 against 0.53 ms); with a heavy-tailed lane class it is 2.6x slower (C2).
-		int tileVariant = g->tile > 0 ? g->tile : 0;
-		if (g->tile < 0 && g->adaptive && v.coop_ptr && s.deg_counts[0] >= 0 && g->parse_lists) {
+		int tileVariant = g->tile > 0 && !strips ? g->tile : 0;
+		if (!strips && g->tile < 0 && g->adaptive && v.coop_ptr && s.deg_counts[0] >= 0 && g->parse_lists) {
 			const double share = (double)(s.h_offsets[(size_t)v.lo + v.cnt] - s.h_offsets[(size_t)v.lo]) / (double)std::max<int64_t>(s.h_offsets[(size_t)s.node_hi] - s.h_offsets[(size_t)s.stage_lo], 1);
 			if ((double)s.deg_counts[0] * share <= (double)COOP_BUDGET * (share > 0.999 ? 1.0 : 0.8)) tileVariant = 1; // (a sub-range: an estimate, with a margin)
 		}
@@ -456,8 +470,8 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			bv::launch_tile_bounds(gd, v.lo, v.cnt, ntiles, g->tilebounds.as<int32_t>(), ovl && hdrEvent ? g->sideA : g->stream);
 			if (ovl && hdrEvent) HIPCHK(g, hipEventRecord(g->evP, g->sideA));
 		}
-		const bool earlyList = !tiles && g->parse_lists && ovl && hdrEvent;
-		if (!tiles && g->parse_lists) {
+		const bool earlyList = !tiles && !strips && g->parse_lists && ovl && hdrEvent;
+		if (!tiles && !strips && g->parse_lists) {
 			if (!g->plist.need(sizeof(int32_t) * (size_t)v.cnt) || !g->pkeys.need(3 * (bv::NKEYS + 1) * sizeof(int32_t)) || !g->pkey16.need(sizeof(uint16_t) * (size_t)v.cnt)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
 			pKeyBase = g->pkeys.as<int32_t>() + (bv::NKEYS + 1);
 		}
@@ -500,7 +514,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		                                  g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->maxdepth, stLists,
 		                                  g->copy_lists ? g->copyq.as<int32_t>() : nullptr, bigCap, g->copyq.as<int32_t>() + bigCap, midCap, g->copy_mid_min, g->copy_big != 0);
 		if (ovl) HIPCHK(g, hipEventRecord(g->evA, g->sideA));
-		if (!tiles && g->parse_lists && !earlyList)
+		if (!tiles && !strips && g->parse_lists && !earlyList)
 			bv::launch_build_lists(gd, v, ~0ull, g->parse_windows ? 6 : 2, nullptr, g->pkey16.as<uint16_t>(), g->pkeys.as<int32_t>(), pKeyBase, pKeyBase + (bv::NKEYS + 1), g->plist.as<int32_t>(),
 			                       g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->pad, g->stream);
 		if (earlyList || (tiles && ovl && hdrEvent)) HIPCHK(g, hipStreamWaitEvent(g->stream, g->evP, 0));
@@ -510,7 +524,18 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		mark(g, 4);
 		if (coop && !ovl) bv::launch_parse_waves(gd, s.def, v, g->biglist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, derr, g->stream);
 		mark(g, 5);
-		if (tiles) bv::launch_parse_tile(gd, s.def, v, g->tilebounds.as<int32_t>(), ntiles, tileVariant, derr, g->stream);
+		if (strips) {
+			// strips of the stream, each decoded by one work-group entirely in LDS (bv_strip.hip); the bounds need the row starts
+			const uint64_t haloRoom = std::min<uint64_t>(v.halo_cap, (uint64_t)arcsBound);
+			const int64_t arcsJob = (int64_t)std::min<uint64_t>((uint64_t)arcsBound, v.succ_cap + (v.nh ? haloRoom : 0));
+			const int32_t nstrips = bv::strip_count(s.h_offsets[(size_t)v.lo + v.cnt] - s.h_offsets[(size_t)v.lo], v.cnt, arcsJob);
+			if (!g->stripbounds.need(sizeof(int32_t) * ((size_t)nstrips + 2)) || !g->esclist.need(sizeof(int32_t) * (size_t)v.cnt)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
+			bv::launch_strip_bounds(gd, v, nstrips, g->stripbounds.as<int32_t>(), ctl + bv::CTL_ESC, derr, g->stream);
+			bv::launch_strips(gd, s.def, v, g->stripbounds.as<int32_t>(), nstrips, coopMin, g->esclist.as<int32_t>(), ctl + bv::CTL_ESC, v.cnt, derr, g->stream);
+			// what a strip could not take (no room in its LDS budget, a codeword of more than 64 bits, a malformed record): one wave each
+			bv::launch_parse_waves(gd, s.def, v, g->esclist.as<int32_t>(), ctl + bv::CTL_ESC, g->arena.p, arenaCap, std::min(g->coop_waves, 1024), derr, g->stream);
+		}
+		else if (tiles) bv::launch_parse_tile(gd, s.def, v, g->tilebounds.as<int32_t>(), ntiles, tileVariant, derr, g->stream);
 		else if (pKeyBase) {
 			bv::launch_parse_list(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, g->level_blocks, derr, g->stream, g->iv_arena ? g->arena.p : nullptr, arenaCap);
 		}
@@ -795,7 +820,7 @@ extern "C" int bvg_close(bvg_t *g) {
 	if (g->st && g->st->device >= 0) {
 		(void)hipSetDevice(g->st->device);
 		if (g->own) { (void)hipStreamSynchronize(g->own); (void)hipStreamDestroy(g->own); }
-		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->hashBounds, &g->pickpart, &g->walktab, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist, &g->plist, &g->pkeys, &g->pkey16, &g->copyq, &g->bigtmp, &g->tilebounds }) b->release();
+		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->hashBounds, &g->pickpart, &g->walktab, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist, &g->plist, &g->pkeys, &g->pkey16, &g->copyq, &g->bigtmp, &g->tilebounds, &g->stripbounds, &g->esclist }) b->release();
 		for (DevBuf *b : { &g->hchunk[0], &g->hchunk[1], &g->statsbuf, &g->bfs_rowptr, &g->bfs_succ, &g->bfs_ctr }) b->release();
 		for (PinBuf *b : { &g->hring[0], &g->hring[1], &g->view_rowptr, &g->view_succ }) b->release();
 		for (hipEvent_t e : { g->evChunk[0], g->evChunk[1], g->evCopied[0], g->evCopied[1] }) if (e) (void)hipEventDestroy(e);
@@ -854,8 +879,8 @@ extern "C" int bvg_debug_stats(bvg_t *g, uint64_t *out8, int reset) {
 	if (!g->stats.p) return fail(g, BVG_ESTATE, "set BVGPU_STATS=1 before opening the graph");
 	HIPCHK(g, hipSetDevice(g->st->device));
 	HIPCHK(g, hipDeviceSynchronize());
-	HIPCHK(g, hipMemcpy(out8, g->stats.p, 256, hipMemcpyDeviceToHost));
-	if (reset) HIPCHK(g, hipMemset(g->stats.p, 0, 256));
+	HIPCHK(g, hipMemcpy(out8, g->stats.p, 512, hipMemcpyDeviceToHost));
+	if (reset) HIPCHK(g, hipMemset(g->stats.p, 0, 512));
 	return BVG_OK;
 }
 
