@@ -27,14 +27,14 @@ for _ in range(R):
     g.decode_range_device(0, n, rowptr.data_ptr(), succ.data_ptr(), succ.numel())
 st = g.debug_stats(True).astype(np.float64)
 strips = st[32 + 15] / R
-names = ["load+scan", "stage+fields+sort", "S structure", "seg alloc", "A anchors", "B chain", "seg sort", "R residuals", "X intervals", "W write-out"]
-print("strips %d  nodes/strip %.0f  arcs/strip %.0f  segs/strip %.0f  longsegs/strip %.0f" % (strips, st[32 + 14] / R / strips, st[32 + 11] / R / strips, st[32 + 13] / R / strips, st[32 + 12] / R / strips))
+names = ["loads+staging", "S structure", "segments + A anchors", "B chain", "R residuals", "X intervals"]
+print("strips %d  nodes/strip %.1f  intervals/strip %.1f  segs/strip %.1f  longsegs/strip %.1f" % (strips, st[32 + 14] / R / strips, st[32 + 11] / R / strips, st[32 + 13] / R / strips, st[32 + 12] / R / strips))
 tot = 0
 for k, nm in enumerate(names):
     us = st[32 + k] / R / strips / 100.0  # 100 MHz clock
     tot += us
     print("  %-20s %7.2f us" % (nm, us))
-print("  %-20s %7.2f us per strip; x strips / 512 resident = %.3f ms" % ("total", tot, tot * strips / 512 / 1e3))
+print("  %-20s %7.2f us per strip; x strips / (256 CUs x 20 waves) = %.3f ms" % ("total", tot, tot * strips / 5120 / 1e3))
 g.set_profile(True)
 g.decode_range_device(0, n, rowptr.data_ptr(), succ.data_ptr(), succ.numel())
 print("phases", {k: round(v, 3) for k, v in g.get_profile().items()})

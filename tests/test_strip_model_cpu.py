@@ -89,7 +89,7 @@ def test_cnr2000_whole(model):
     n = check(r, 512)
     assert n > 200000
     st = r["stats"]
-    assert st[0] > 10 and st[1] <= 19 * 1024 and st[3] > 0  # strips, pool use, long sections exist
+    assert st[0] > 1000 and st[1] <= 2048 and st[3] > 0  # strips, pool use (words of a wave's 8 KB), long sections exist
 
 
 @pytest.mark.parametrize("lo,hi", [(1000, 21000), (300000, 325557), (77, 78)])
@@ -112,6 +112,6 @@ def test_synthetic_parameters(model, tmp_path_factory, kw):
     base, rowptr, succ = make_graph(tmp_path_factory, "sm", 60000, 1500000, 4242, 0.6, **kw)
     r = run_model(model, base, strip_max=1024)
     assert np.array_equal(r["succ"], succ)
-    # (a strip can run out of room for a record's intervals or segments: those records escape to the cooperative kernel)
-    n = check(r, 1024, max_escapes=200)
+    # (a wave can run out of room for a record's intervals or segments: those records escape to the cooperative kernel)
+    n = check(r, 1024, max_escapes=600)
     assert n > 30000

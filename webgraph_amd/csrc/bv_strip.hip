@@ -1,8 +1,7 @@
-// bv_strip.hip -- the strip kernel: device side of bv_strip.hpp (gfx950).  One work-group of STRIP_T threads owns the
-// records that start in one slice of the stream; see bv_strip.hpp for the phases and for why the unit of work is a
-// segment and never a record.  What lives here: the strip bounds, the carve-up of the LDS pool, staging, the block-wide
-// scan and the counting sorts, the hand-out of work items to wavefronts (64 at a time from an LDS counter, longest first),
-// the barriers between the phases, and the write-out.
+// bv_strip.hip -- the strip kernel: device side of bv_strip.hpp (gfx950).  One WAVEFRONT owns the records that start in one
+// small slice of the stream (at most 64: a lane per record in the structure phase); see bv_strip.hpp for the phases and for
+// why a wave never waits for another one.  What lives here: the strip bounds, staging of the slice, the wave-wide scans that
+// hand out arena and segment slots, the loops over work items, and the escape list.
 #include "bv_strip.hpp"
 #include "bv_launch.hpp"
 
@@ -12,19 +11,16 @@ using namespace bvs;
 typedef __attribute__((address_space(3))) uint32_t l_u32; // LDS-qualified: accesses through these are ds_* instructions, never flat ones
 typedef __attribute__((address_space(3))) uint16_t l_u16;
 typedef __attribute__((address_space(3))) int32_t l_i32;
-typedef __attribute__((address_space(3))) Seg l_seg;
-using StripL = StripT<l_u32 *, l_u16 *, l_i32 *, l_seg *>;
+using StripL = StripT<l_u32 *, l_u16 *, l_i32 *>;
 
-// counters of a strip (LDS)
-enum : int { C_NARCS = 0, C_NIV, C_NBLK, C_NSEG, C_IVLIM, C_SEGLIM, C_NLSEG, C_NLREC, C_NLIV, C_FETCH, C_FETCH2, C_HIST = 16, C_WSUM = 48, C_TOTAL = 64 };
-
-__device__ __forceinline__ int lds_add(l_i32 *p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ int lds_min(l_i32 *p, int v) { return __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-// a wave takes the next 64 items of a list; returns the first one's index (uniform)
-__device__ __forceinline__ int fetch64(l_i32 *ctr) {
-	int b = 0;
-	if ((threadIdx.x & 63) == 0) b = lds_add(ctr, 64);
-	return __builtin_amdgcn_readfirstlane(b);
+// LDS hand-off inside the wave: the LDS executes a wave's DS instructions in issue order, so keeping the program order is enough
+__device__ __forceinline__ void wsync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); }
+__device__ __forceinline__ int32_t wave_excl_scan(int32_t v, int lane, int32_t &total) {
+	int32_t inc = v;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) { const int32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+	total = __shfl(inc, 63, 64);
+	return inc - v;
 }
 
 // strip t = the slots s of the view with  t * SPAN_W <= weight(s) < (t+1) * SPAN_W,
@@ -45,232 +41,150 @@ __global__ void __launch_bounds__(256) k_strip_bounds(const int64_t *__restrict_
 	if (t == ntiles && a < cnt) atomicOr(err, E_CAP);
 }
 
-constexpr int RPT = (MAX_NODES + STRIP_T - 1) / STRIP_T; // records per thread (consecutive)
-
 template <int ZK>
-__global__ void __launch_bounds__(STRIP_T, 4) k_strip(GraphDev g, RangeView v, const int32_t *__restrict__ tb, int32_t stripMax, int32_t *__restrict__ esc,
-                                                        int32_t *__restrict__ escCtl, int32_t escCap, int *__restrict__ err) {
-	__shared__ __attribute__((aligned(16))) uint32_t pool_[POOL_WORDS];
-	__shared__ int32_t ctr_[C_TOTAL];
+__global__ void __launch_bounds__(64) k_strip(GraphDev g, RangeView v, const int32_t *__restrict__ tb, int32_t stripMax, int32_t *__restrict__ esc,
+                                              int32_t *__restrict__ escCtl, int32_t escCap, int *__restrict__ err) {
+	__shared__ __attribute__((aligned(16))) uint32_t pool_[WPOOL_WORDS];
 	l_u32 *pool = (l_u32 *)pool_;
-	l_i32 *ctr = (l_i32 *)ctr_;
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int lane = threadIdx.x;
 	const int32_t a = tb[blockIdx.x], b = tb[blockIdx.x + 1];
 	if (a >= b) return;
+	const int32_t n = min(b - a, (int32_t)STRIP_NODES); // (b - a <= STRIP_NODES by construction of the bounds;
+	if (b - a > (int32_t)STRIP_NODES && lane == 0) atomicOr(err, E_FORMAT); // if that were ever wrong, records would be skipped: make it loud)
 	// BVGPU_STATS=1: clock ticks (100 MHz) per phase, summed over the strips: stats[32 + phase]; stats[32 + 15] = strips
 	unsigned long long tPrev = g.stats ? wall_clock64() : 0;
 	int tPhase = 0;
-#define STRIP_TICK() do { if (g.stats) { if (tid == 0) { const unsigned long long tn_ = wall_clock64(); atomicAdd(&g.stats[32 + tPhase], tn_ - tPrev); tPrev = tn_; } tPhase++; } } while (0)
-	const int32_t n = min(b - a, (int32_t)MAX_NODES); // (b - a <= MAX_NODES by construction of the bounds)
-	if (tid < C_TOTAL) ctr[tid] = tid == C_IVLIM || tid == C_SEGLIM ? 0x7fffffff : 0;
-	__syncthreads();
+#define STRIP_TICK() do { if (g.stats) { if (lane == 0) { const unsigned long long tn_ = wall_clock64(); atomicAdd(&g.stats[32 + tPhase], tn_ - tPrev); tPrev = tn_; } tPhase++; } } while (0)
 
-	// ---- the strip's records: outdegree, reference, position (registers until the layout is known)
-	int32_t rd[RPT], rr[RPT];
-	int64_t ro[RPT], rn[RPT];
-	int32_t mine = 0;
-#pragma unroll
-	for (int k = 0; k < RPT; k++) {
-		const int32_t i = tid * RPT + k;
-		rd[k] = 0; rr[k] = 0; ro[k] = 0; rn[k] = 0;
-		if (i < n) {
-			const int32_t s = a + i;
-			const int32_t d = v.outd[s];
-			ro[k] = g.offsets[v.lo + s]; rn[k] = g.offsets[v.lo + s + 1];
-			if (d > 0 && d < stripMax) { rd[k] = d; rr[k] = v.ref[s]; mine += d; }
-		}
+	// ---- the strip's records, one per lane
+	const int32_t s = a + lane;
+	const bool have = lane < n;
+	int32_t d = have ? v.outd[s] : 0;
+	const int64_t o0 = have ? g.offsets[v.lo + s] : 0, o1 = have ? g.offsets[v.lo + s + 1] : 0;
+	const int64_t rs = have ? v.rowstart[s] : 0, rsn = have ? v.rowstart[s + 1] : 0;
+	bool own = d > 0 && d < stripMax;
+	const int32_t r = own ? (int32_t)v.ref[s] : 0;
+	const int64_t dref = r > 0 ? (s - r >= 0 ? (int64_t)v.outd[s - r] : -1) : 0; // (referents before the view: k_apply_need clears such references)
+	// rows: in the caller's buffer from slot nh on, in the halo scratch before; a strip that straddles nh leaves its halo records to the escape path
+	const int64_t rowNh = v.rowstart[v.nh];
+	const bool inHalo = b <= v.nh;
+	const int64_t rowBase = (int64_t)__shfl((long long)rs, 0, 64); // row start of slot a
+	const int64_t rowFirst = inHalo ? rowBase : (a >= v.nh ? rowBase : rowNh);
+	int32_t *const rows = inHalo ? v.halo + rowBase : v.succ + (rowFirst - rowNh);
+	bool escNow = false; // this lane's record goes to the escape list
+	if (own) {
+		if (!inHalo && s < v.nh) { escNow = true; own = false; }
+		else if (!(inHalo ? (uint64_t)rsn <= v.halo_cap : (uint64_t)(rsn - rowNh) <= v.succ_cap)) { atomicOr(err, inHalo ? E_HALO : E_CAP); own = false; }
+		else if (rs - rowFirst + d > 0x7fffffffll) { escNow = true; own = false; }
 	}
-	// exclusive scan of the outdegrees over the strip (threads hold consecutive records)
-	int32_t inc = mine;
-#pragma unroll
-	for (int o = 1; o < 64; o <<= 1) { const int32_t t2 = __shfl_up(inc, o, 64); if (lane >= o) inc += t2; }
-	if (lane == 63) ctr[C_WSUM + wave] = inc;
-	__syncthreads();
-	int32_t wbase = 0, narcs = 0;
-#pragma unroll
-	for (int w = 0; w < STRIP_T / 64; w++) { const int32_t t2 = ctr[C_WSUM + w]; if (w < wave) wbase += t2; narcs += t2; }
-	int32_t rowOff = wbase + inc - mine;
+	const uint32_t rowOff = (uint32_t)(rs - rowFirst);
 
-	STRIP_TICK(); // 0: record loads + scan
 	// ---- layout of the pool, staging of the stream slice
-	const int64_t p0 = g.offsets[v.lo + a], p1 = g.offsets[v.lo + b];
+	const int64_t p0 = (int64_t)__shfl((long long)o0, 0, 64), p1 = (int64_t)__shfl((long long)o1, n - 1, 64);
 	const uint64_t w0 = ((uint64_t)p0 >> 5) & ~(uint64_t)3;
 	const int64_t base = (int64_t)(w0 << 5);
-	const StripLayout L = strip_layout(n, narcs, ((p1 - base + 31) >> 5) + 8, g.minInt);
+	const StripLayout L = strip_layout(((p1 - base + 31) >> 5) + 8);
 	StripL st;
 	strip_bind(st, pool, L);
-	l_u16 *const listB = st.listB;
 	const uint32_t nw = (uint32_t)L.nw;
 	const uint32_t qmax = (nw - 3) * 32;
 	{
 		const uint4 *src4 = (const uint4 *)(g.bits + w0);
 		const uint64_t lim4 = (g.nwords + 8 - w0) / 4; // the image is followed by >= 8 zero words
-		for (uint32_t i4 = (uint32_t)tid; i4 < nw / 4; i4 += STRIP_T) {
+		for (uint32_t i4 = (uint32_t)lane; i4 < nw / 4; i4 += 64) {
 			const uint4 q4 = i4 < lim4 ? src4[i4] : uint4{ 0u, 0u, 0u, 0u };
 			st.win[4 * i4 + 0] = __builtin_bswap32(q4.x); st.win[4 * i4 + 1] = __builtin_bswap32(q4.y);
 			st.win[4 * i4 + 2] = __builtin_bswap32(q4.z); st.win[4 * i4 + 3] = __builtin_bswap32(q4.w);
 		}
 	}
-	auto escape = [&](int32_t i) { // the record is decoded by the cooperative kernel after this one
-		st.m_d[i] = 0;
-		const int32_t k = atomicAdd(&escCtl[0], 1);
-		if (k < escCap) esc[k] = a + i; else atomicOr(err, E_FORMAT);
-	};
-	// ---- record fields; records sorted by outdegree, longest first (counting sort on the bit length)
-	int32_t bin[RPT], pos[RPT];
-#pragma unroll
-	for (int k = 0; k < RPT; k++) {
-		const int32_t i = tid * RPT + k;
-		bin[k] = -1;
-		if (i < n) {
-			int32_t d = rd[k];
-			const int64_t q0 = ro[k] - base, q1 = rn[k] - base;
-			st.m_ref[i] = (uint16_t)rr[k];
-			st.m_off[i] = (uint16_t)rowOff;
-			rowOff += d;
-			if (d > 0 && (!L.ok || q1 > (int64_t)qmax || q1 - q0 > 0xffff || q1 <= q0)) { st.m_d[i] = (uint16_t)d; escape(i); d = 0; } // does not fit the staged slice
-			st.m_d[i] = (uint16_t)d;
-			st.m_bit[i] = d ? (uint32_t)q0 : 0u;
-			st.m_sbits[i] = d ? (uint16_t)(q1 - q0) : 0; // until phase S: length of the record
-			st.m_nres[i] = 0; st.m_niv[i] = 0; st.m_cop[i] = 0; st.m_seg0[i] = 0xffff;
-			if (d) { bin[k] = (int)clz32((uint32_t)d) - 16; pos[k] = lds_add(&ctr[C_HIST + bin[k]], 1); } // d < 2^16: bins 0 (longest) .. 15
-		}
-	}
-	// (records beyond MAX_NODES cannot exist; if the bounds were ever wrong they would be silently skipped: make it loud)
-	if (tid == 0 && b - a > (int32_t)MAX_NODES) atomicOr(err, E_FORMAT);
-	__syncthreads();
-	if (tid < 64) { // exclusive scan of the 16 bins by one wave
-		const int32_t c = tid < 16 ? ctr[C_HIST + tid] : 0;
-		int32_t in2 = c;
-#pragma unroll
-		for (int o = 1; o < 16; o <<= 1) { const int32_t t2 = __shfl_up(in2, o, 64); if (tid >= o) in2 += t2; }
-		if (tid < 16) ctr[C_HIST + tid] = in2 - c;
-		if (tid == 15) ctr[C_HIST + 16] = in2; // records with work
-	}
-	__syncthreads();
-#pragma unroll
-	for (int k = 0; k < RPT; k++) if (bin[k] >= 0) st.list[ctr[C_HIST + bin[k]] + pos[k]] = (uint16_t)(tid * RPT + k);
-	__syncthreads();
-	STRIP_TICK(); // 1: staging, fields, sort
-	const int32_t nRec = ctr[C_HIST + 16];
+	const int64_t q0 = o0 - base, q1 = o1 - base;
+	if (own && (q1 > (int64_t)qmax || q1 <= q0)) { escNow = true; own = false; } // the record overhangs the staged slice
+	wsync();
+	STRIP_TICK(); // 0: loads, staging
 	Job job;
-	job.W = g.W; job.minInt = g.minInt; job.zk = (uint32_t)g.zetaK; job.stripMax = stripMax; job.x0 = v.lo + a;
+	job.W = g.W; job.minInt = g.minInt; job.zk = (uint32_t)g.zetaK;
+	const int32_t x = v.lo + s;
 
 	// ---- phase S: structure, one lane per record
+	Rec R; R.q = 0; R.sbits = 0; R.copied = 0; R.extra = 0; R.nIv = 0; R.ivb = 0; R.nRes = 0; R.ok = false;
+	if (own) { R = structure_head(st, job, qmax, (uint32_t)q0, d, r, dref); if (!R.ok) { escNow = true; own = false; R.nIv = 0; } }
+	int32_t ivTotal;
+	R.ivb = wave_excl_scan(own ? R.nIv : 0, lane, ivTotal);
+	if (own && R.ivb + R.nIv > st.ivCap) { escNow = true; own = false; R.nIv = 0; } // no room for its intervals (nothing of it is in the arena)
+	const int32_t nIvAll = min(ivTotal, st.ivCap);
+	const uint32_t rowOut = rowOff + (uint32_t)R.copied;
+	// (an arena slot that no lane fills -- the slice of a record that escapes -- may hold what an earlier strip left there: phase X skips length 0)
+	for (int32_t j = lane; j < nIvAll; j += 64) st.iv_len[j] = 0;
+	wsync();
+	if (own) {
+		structure_intervals(st, job, qmax, R, x, rowOut, (uint32_t)q1);
+		if (!R.ok) { escNow = true; own = false; }
+	}
+	if (!own) for (int32_t j = 0; j < R.nIv; j++) st.iv_len[R.ivb + j] = 0; // (a record that escaped half-way through its intervals)
+	STRIP_TICK(); // 1: phase S
+	// ---- segments of the residual sections: the short sections first (one each), then the nominal segments of the long ones
+	const int32_t m = own ? segments_of(R.nRes, R.sbits) : 0;
+	const unsigned long long shortMask = __ballot(m == 1);
+	const int32_t nShort = __popcll(shortMask);
+	const int32_t eS = __popcll(shortMask & ((1ull << lane) - 1));
+	int32_t longTotal;
+	const int32_t eL = nShort + wave_excl_scan(m > 1 ? m : 0, lane, longTotal);
+	bool isLong = m > 1;
+	if (isLong && eL + m > st.segCap) { escNow = true; own = false; isLong = false; for (int32_t j = 0; j < R.nIv; j++) st.iv_len[R.ivb + j] = 0; } // no room for its segments
+	if (m == 1) segment_short(st, eS, R, x, rowOut);
+	int32_t nSeg = nShort;
 	{
-		auto drefOf = [&](int32_t i, int32_t r) -> int64_t { return a + i - r >= 0 ? (int64_t)v.outd[a + i - r] : -1; }; // (referents before the view: k_apply_need clears such references)
-		auto ivAlloc = [&](int32_t cnt) -> int32_t { const int32_t o = lds_add(&ctr[C_NIV], cnt); if (o + cnt > st.ivCap) { lds_min(&ctr[C_IVLIM], o); return -1; } return o; };
-		auto blkAlloc = [&](int32_t cnt) -> int32_t { const int32_t o = lds_add(&ctr[C_NBLK], cnt); return o + cnt > st.blkCap ? -1 : o; };
-		for (;;) {
-			const int32_t b0 = fetch64(&ctr[C_FETCH]);
-			if (b0 >= nRec) break;
-			const int32_t idx = b0 + lane;
-			if (idx < nRec) {
-				const int32_t i = (int32_t)st.list[idx];
-				const uint32_t recEnd = st.m_bit[i] + (uint32_t)st.m_sbits[i];
-				if (!phase_structure<ZK>(st, job, qmax, i, recEnd, drefOf, ivAlloc, blkAlloc, false)) escape(i);
-			}
+		unsigned long long lm = __ballot(isLong);
+		while (lm) {
+			const int Ls = __ffsll((long long)lm) - 1;
+			lm &= lm - 1;
+			const int32_t e0 = __shfl(eL, Ls, 64), mL = __shfl(m, Ls, 64);
+			const uint32_t r0 = (uint32_t)__shfl((int)R.q, Ls, 64), sb = (uint32_t)__shfl((int)R.sbits, Ls, 64);
+			for (int32_t k = lane; k < mL; k += 64) segment_nominal(st, e0 + k, r0, r0 + sb, k);
+			nSeg = e0 + mL; // (the lanes that fit are a prefix of the long ones: their entries are contiguous)
 		}
 	}
-	__syncthreads();
-	STRIP_TICK(); // 2: phase S
-	// ---- segments of the residual sections (static: one lane per record)
-	for (int32_t i = tid; i < n; i += STRIP_T) {
-		const uint32_t nRes = st.m_nres[i];
-		if (st.m_d[i] == 0 || nRes == 0) continue;
-		const int32_t m = segments_of(nRes, st.m_sbits[i]);
-		const int32_t e0 = lds_add(&ctr[C_NSEG], m);
-		if (e0 + m > st.segCap) { lds_min(&ctr[C_SEGLIM], e0); escape(i); continue; }
-		st.m_seg0[i] = (uint16_t)e0;
-		if (m == 1) { st.seg[e0].start = st.m_bit[i]; st.seg[e0].end = 0; st.seg[e0].base = job.x0 + i; st.seg[e0].cnt = (uint16_t)nRes; st.seg[e0].rec = (uint16_t)i; }
-		else {
-			const int32_t la = lds_add(&ctr[C_NLSEG], m);
-			for (int32_t k = 0; k < m; k++) { st.seg[e0 + k].end = (uint32_t)k; st.seg[e0 + k].rec = (uint16_t)i; st.seg[e0 + k].cnt = 0; listB[la + k] = (uint16_t)(e0 + k); }
-			st.list[st.listLen - 1 - lds_add(&ctr[C_NLREC], 1)] = (uint16_t)i; // long sections: from the back of the (now free) record list
-		}
-	}
-	__syncthreads();
-	STRIP_TICK(); // 3: segment allocation
-	const int32_t nSeg = min(ctr[C_NSEG], ctr[C_SEGLIM]);
-	const int32_t nLongSeg = ctr[C_NLSEG], nLongRec = ctr[C_NLREC];
-	const int32_t listEnd = st.listLen;
+	wsync();
 	// ---- phase A: anchors of the long sections, one lane per nominal segment
-	for (int32_t t = tid; t < nLongSeg; t += STRIP_T) phase_anchor<ZK>(st, job, qmax, (int32_t)listB[t]);
-	__syncthreads();
-	STRIP_TICK(); // 4: phase A
-	// ---- phase B: chain the segments of each long section
-	for (int32_t t = tid; t < nLongRec; t += STRIP_T) {
-		const int32_t i = (int32_t)st.list[listEnd - 1 - t];
-		if (st.m_d[i] != 0 && !phase_chain<ZK>(st, job, qmax, i)) escape(i);
+	for (int32_t e = nShort + lane; e < nSeg; e += 64) phase_anchor<ZK>(st, job, qmax, e);
+	wsync();
+	STRIP_TICK(); // 2: segments + phase A
+	// ---- phase B: the record's lane chains its segments
+	if (isLong && !phase_chain<ZK>(st, job, qmax, eL, m, R, x, rowOut)) {
+		escNow = true; own = false;
+		for (int32_t k = 0; k < m; k++) st.seg_cnt[eL + k] = 0;
+		for (int32_t j = 0; j < R.nIv; j++) st.iv_len[R.ivb + j] = 0;
 	}
-	if (tid < 33) ctr[C_HIST + tid] = 0;
-	__syncthreads();
-	STRIP_TICK(); // 5: phase B
-	// ---- segments sorted by length, longest first
-	constexpr int SPT = 8; // a thread sorts up to SPT segments (segCap <= POOL: a few thousand)
-	int32_t sbin[SPT], spos[SPT];
-#pragma unroll
-	for (int k = 0; k < SPT; k++) {
-		const int32_t e = tid + k * STRIP_T;
-		sbin[k] = -1;
-		if (e < nSeg) {
-			const int32_t i = (int32_t)st.seg[e].rec;
-			const int32_t c = st.m_d[i] ? (int32_t)st.seg[e].cnt : 0;
-			if (c > 0) { sbin[k] = 31 - min(c >> 2, 31); spos[k] = lds_add(&ctr[C_HIST + sbin[k]], 1); }
+	wsync();
+	STRIP_TICK(); // 3: phase B
+	// ---- phase R: residuals, one lane per segment, stored straight into the rows
+	bool badR = false;
+	for (int32_t e = lane; e < nSeg; e += 64) if (st.seg_cnt[e] != 0 && !phase_residuals<ZK>(st, job, qmax, rows, e)) badR = true;
+	wsync();
+	STRIP_TICK(); // 4: phase R
+	if (__any(badR)) { if (own) { escNow = true; own = false; } } // (a codeword the decoders reject: malformed -- every record of the strip is decoded again by the escape path, which reports it)
+	else {
+		// ---- phase X: intervals, one lane each; the long ones by the whole wave
+		for (int32_t j0 = 0; j0 < nIvAll; j0 += 64) {
+			const int32_t j = j0 + lane;
+			const int32_t len = j < nIvAll ? (int32_t)st.iv_len[j] : 0;
+			if (len > 0 && len < LONG_INTERVAL) phase_interval(st, rows, j, 0, 1);
+			unsigned long long lm = __ballot(len >= LONG_INTERVAL);
+			while (lm) { const int Ls = __ffsll((long long)lm) - 1; lm &= lm - 1; phase_interval(st, rows, j0 + Ls, lane, 64); }
 		}
 	}
-	__syncthreads();
-	if (tid < 64) {
-		const int32_t c = tid < 32 ? ctr[C_HIST + tid] : 0;
-		int32_t in2 = c;
-#pragma unroll
-		for (int o = 1; o < 32; o <<= 1) { const int32_t t2 = __shfl_up(in2, o, 64); if (tid >= o) in2 += t2; }
-		if (tid < 32) ctr[C_HIST + tid] = in2 - c;
-		if (tid == 31) ctr[C_HIST + 32] = in2;
-	}
-	__syncthreads();
-#pragma unroll
-	for (int k = 0; k < SPT; k++) if (sbin[k] >= 0) listB[ctr[C_HIST + sbin[k]] + spos[k]] = (uint16_t)(tid + k * STRIP_T);
-	// (segments beyond SPT * STRIP_T cannot exist: segCap < 4096)
-	__syncthreads();
-	STRIP_TICK(); // 6: segment sort
-	const int32_t nWork = ctr[C_HIST + 32];
-	// ---- phase R: residuals, one lane per segment
-	for (;;) {
-		const int32_t b0 = fetch64(&ctr[C_FETCH2]);
-		if (b0 >= nWork) break;
-		const int32_t idx = b0 + lane;
-		if (idx < nWork) {
-			const int32_t e = (int32_t)listB[idx];
-			if (!phase_residuals<ZK>(st, job, qmax, e)) { const int32_t i = (int32_t)st.seg[e].rec; if (st.m_d[i]) escape(i); }
-		}
-	}
-	__syncthreads();
-	STRIP_TICK(); // 7: phase R
-	// ---- phase X: intervals, one lane each; the long ones by a wave each
-	const int32_t nIv = min(ctr[C_NIV], ctr[C_IVLIM]);
-	for (int32_t j = tid; j < nIv; j += STRIP_T) {
-		if ((int32_t)st.iv_len[j] >= LONG_INTERVAL) { const int32_t k = lds_add(&ctr[C_NLIV], 1); st.list[k] = (uint16_t)j; }
-		else phase_interval(st, j, 0, 1);
-	}
-	__syncthreads();
+	STRIP_TICK(); // 5: phase X
+	// ---- the records this strip leaves to the cooperative kernel
 	{
-		const int32_t nLongIv = ctr[C_NLIV];
-		for (int32_t t = wave; t < nLongIv; t += STRIP_T / 64) phase_interval(st, (int32_t)st.list[t], lane, 64);
+		const unsigned long long em = __ballot(escNow);
+		if (em) {
+			int32_t k0 = 0;
+			if (lane == 0) k0 = atomicAdd(&escCtl[0], __popcll(em));
+			k0 = __shfl(k0, 0, 64);
+			if (escNow) { const int32_t k = k0 + __popcll(em & ((1ull << lane) - 1)); if (k < escCap) esc[k] = s; else atomicOr(err, E_FORMAT); }
+		}
 	}
-	__syncthreads();
-	STRIP_TICK(); // 8: phase X
-	// ---- phase W: the rows leave for the CSR, 16 lanes per row
-	for (int32_t i = tid >> 4; i < n; i += STRIP_T / 16) {
-		const int32_t d = (int32_t)st.m_d[i];
-		if (d == 0) continue;
-		const int32_t s = a + i;
-		if (!v.fits(s)) { if ((tid & 15) == 0) atomicOr(err, s >= v.nh ? E_CAP : E_HALO); continue; }
-		int32_t *__restrict__ dst = v.row(s);
-		const int32_t off = (int32_t)st.m_off[i];
-		for (int32_t t = tid & 15; t < d; t += 16) dst[t] = st.rows[off + t];
-	}
-	if (g.stats) { __syncthreads(); STRIP_TICK(); if (tid == 0) { atomicAdd(&g.stats[32 + 15], 1ull); atomicAdd(&g.stats[32 + 14], (unsigned long long)n); atomicAdd(&g.stats[32 + 13], (unsigned long long)nSeg); atomicAdd(&g.stats[32 + 12], (unsigned long long)nLongSeg); atomicAdd(&g.stats[32 + 11], (unsigned long long)narcs); } } // 9: phase W
+	if (g.stats && lane == 0) { atomicAdd(&g.stats[32 + 15], 1ull); atomicAdd(&g.stats[32 + 14], (unsigned long long)n); atomicAdd(&g.stats[32 + 13], (unsigned long long)nSeg); atomicAdd(&g.stats[32 + 12], (unsigned long long)(nSeg - nShort)); atomicAdd(&g.stats[32 + 11], (unsigned long long)nIvAll); }
 #undef STRIP_TICK
 }
 
@@ -284,8 +198,8 @@ void launch_strip_bounds(const GraphDev &g, const RangeView &v, int32_t ntiles, 
 }
 void launch_strips(const GraphDev &g, int def, const RangeView &v, const int32_t *tb, int32_t ntiles, int32_t stripMax, int32_t *esc, int32_t *escCtl, int32_t escCap, int *err, hipStream_t st) {
 	if (v.cnt <= 0 || ntiles <= 0) return;
-	if (def == 1) hipLaunchKernelGGL(k_strip<3>, dim3(ntiles), dim3(STRIP_T), 0, st, g, v, tb, stripMax, esc, escCtl, escCap, err);
-	else hipLaunchKernelGGL(k_strip<0>, dim3(ntiles), dim3(STRIP_T), 0, st, g, v, tb, stripMax, esc, escCtl, escCap, err);
+	if (def == 1) hipLaunchKernelGGL(k_strip<3>, dim3(ntiles), dim3(64), 0, st, g, v, tb, stripMax, esc, escCtl, escCap, err);
+	else hipLaunchKernelGGL(k_strip<0>, dim3(ntiles), dim3(64), 0, st, g, v, tb, stripMax, esc, escCtl, escCap, err);
 }
 int32_t strip_max_default() { return STRIP_MAX_DEFAULT; }
 
