@@ -4,6 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ["BVGPU_STATS"] = "1"
 os.environ.setdefault("BVGPU_OVERLAP", "0")
+os.environ.setdefault("BVGPU_STRIP", "1")
 import numpy as np, torch, bench
 import __graft_entry__ as ge
 ge.build()
@@ -34,7 +35,7 @@ for k, nm in enumerate(names):
     us = st[32 + k] / R / strips / 100.0  # 100 MHz clock
     tot += us
     print("  %-20s %7.2f us" % (nm, us))
-print("  %-20s %7.2f us per strip; x strips / (256 CUs x 20 waves) = %.3f ms" % ("total", tot, tot * strips / 5120 / 1e3))
+print("  %-20s %7.2f us per strip (1 in 64 sampled); x strips / (256 CUs x 20 waves) = %.3f ms" % ("total", tot, tot * strips * 64 / 5120 / 1e3))
 g.set_profile(True)
 g.decode_range_device(0, n, rowptr.data_ptr(), succ.data_ptr(), succ.numel())
 print("phases", {k: round(v, 3) for k, v in g.get_profile().items()})

@@ -55,7 +55,7 @@ def test_c2_full_size_default_thresholds(c2):
     rowptr, succ, arcs = _device_scan(g)
     assert arcs == C2["m"]
     if not any(k in os.environ for k in ("BVGPU_COOP_MIN", "BVGPU_GIANT_MIN")):
-        assert g.last_thresholds() == (512, 32768)
+        assert g.last_thresholds() == (2048, 32768)
     orp, osc, oarcs = og.scan_mt()
     assert oarcs == arcs
     assert np.array_equal(rowptr.cpu().numpy(), orp), "rowptr differs from the CPU oracle"

@@ -512,6 +512,7 @@ __global__ void __launch_bounds__(TPB) k_scatter_keys(int32_t cnt, const uint16_
 // with fewer than COPY_BIG_MIN by one wave each (k_copy_mid), longer ones by a 1024-thread group each (k_copy_big).
 // A lane-serial merge of a long row would be the tail of the whole scan.
 constexpr int COPY_BIG_MIN = 1024;
+constexpr int COPY2_BLOCKS_ = 16; // (= COPY2_BLOCKS, defined with copy_node2)
 // class of row s at this level: 0 nothing to do, 1 one lane, 2 one wave, 3 one group
 __device__ __forceinline__ int copy_class(const RangeView &v, const int32_t *__restrict__ depth, int32_t level, int32_t s, int32_t midMin, int32_t bigMin) {
 	if (level >= MAXLVL - 1 && depth[s] != level) return 0; // shared overflow bucket
@@ -519,16 +520,19 @@ __device__ __forceinline__ int copy_class(const RangeView &v, const int32_t *__r
 	if (!v.fits(s) || !v.fits(s - v.ref[s])) return 0; // E_CAP / E_HALO already raised by the parse kernel
 	return copy_class_of(v.outd[s], v.outd[s - v.ref[s]], midMin, bigMin);
 }
-template <int DEF>
+template <int DEF> __device__ __forceinline__ void copy_node2(const GraphDev &g, int32_t x, int32_t d, int64_t dref, int32_t *__restrict__ row, const int32_t *__restrict__ src, uint32_t *ldsCol, int *__restrict__ err);
+template <int DEF, bool CHUNKED>
 __global__ void __launch_bounds__(TPB) k_copy_list(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ list,
                                                    const int32_t *__restrict__ keyBase, int32_t level, int32_t midMin, int32_t bigMin, int *__restrict__ err) {
+	__shared__ uint32_t s_blk[CHUNKED ? COPY2_BLOCKS_ * TPB : 1]; // the block lengths of the row a lane is merging, [code][thread]
 	const int32_t bucket = min(level, MAXLVL - 1);
 	const int32_t lo = keyBase[bucket * NBIN], hi = keyBase[(bucket + 1) * NBIN];
 	for (int32_t idx = hi - 1 - (blockIdx.x * TPB + threadIdx.x); idx >= lo; idx -= gridDim.x * TPB) {
 		const int32_t s = list[idx];
 		if (copy_class(v, depth, level, s, midMin, bigMin) != 1) continue;
 		const int32_t r = v.ref[s];
-		copy_node<DEF>(g, v.lo + s, v.outd[s], (int64_t)v.outd[s - r], v.row(s), v.row(s - r), err);
+		if (CHUNKED) copy_node2<DEF>(g, v.lo + s, v.outd[s], (int64_t)v.outd[s - r], v.row(s), v.row(s - r), s_blk + threadIdx.x, err);
+		else copy_node<DEF>(g, v.lo + s, v.outd[s], (int64_t)v.outd[s - r], v.row(s), v.row(s - r), err);
 	}
 }
 
@@ -902,7 +906,7 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 }
 
 // parse pass over a list sorted by work bin only (all chain levels together): 64 records of similar length per wave
-template <int DEF, bool ARENA>
+template <int DEF, int ARENA> // ARENA: 0 the interval section is read twice, 1 kept in a ring + the arena, 2 the same with the lean merge (parse_node_lw2)
 __global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, const int32_t *__restrict__ list, const int32_t *__restrict__ keyBase, int32_t binLo, int32_t binHi,
                                                     IvEntry *__restrict__ arena, int64_t arenaCap, int *__restrict__ err) {
 	__shared__ uint32_t lw[DEF ? (ARENA ? (LW_MAIN + 2 * LW_RING) * LW_STRIDE : LW_LDS_WORDS) : 1]; // lane-private stream windows, or one window and a ring of intervals (default codings)
@@ -923,7 +927,8 @@ __global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, con
 			// the record's slice of the interval arena (the same slices as the cooperative kernels': floor(rowstart / minInt), d / minInt + 1 entries)
 			const int64_t abase = g.minInt > 0 ? v.rowstart[s] / g.minInt : 0;
 			if (g.minInt > 0 && (abase < 0 || abase + d / g.minInt + 1 > arenaCap)) { atomicOr(err, E_FORMAT); continue; }
-			parse_node_lw<DEF == 1 ? 3 : 0, true>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), lw, (int2 *)(arena + abase), err);
+			if (ARENA == 2) parse_node_lw2<DEF == 1 ? 3 : 0>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), lw, (int2 *)(arena + abase), err);
+			else parse_node_lw<DEF == 1 ? 3 : 0, true>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), lw, (int2 *)(arena + abase), err);
 		}
 		else if (DEF) parse_node_lw<DEF == 1 ? 3 : 0, false>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), lw, nullptr, err);
 		else parse_node<DEF>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), err);
@@ -1086,6 +1091,84 @@ __device__ __forceinline__ void copy_node(const GraphDev &g, int32_t x, int32_t 
 	}
 	// remaining extras row[j..d) are already in place when k == j; a malformed duplicate leaves a gap: pad with -1
 	if (k != j) { while (j < d) { row[k++] = row[j++]; } while (k < d) row[k++] = -1; }
+	if (br.err) atomicOr(err, br.err);
+}
+
+// The same merge with far fewer dependent loads (round 3).  copy_node reads the referent's ids and the row's extras one
+// 4-byte load at a time, each depending on the previous compare, and walks the block list twice through the generic reader
+// (a dependent load per 32 bits): a lane merged ~1 id per microsecond, all of it latency.  Here both id streams are read in
+// 16-byte chunks (one dependent load per four ids), the merged ids leave in 16-byte stores, the block lengths of the first
+// walk are kept in the lane's LDS column for the second (lists of up to COPY2_BLOCKS codes; longer ones are decoded again),
+// and the stream is read through the 16-byte prefetching source.  Same in-place argument as copy_node: ids are read earlier
+// and written later than there, never the other way round.
+constexpr int COPY2_BLOCKS = 16;
+struct __attribute__((packed, aligned(4))) Int4u { int32_t x, y, z, w; }; // a 16-byte access that only promises 4-byte alignment
+struct IdChunks { // sequential reader of ids p[0 .. n) in chunks of four
+	const int32_t *__restrict__ p;
+	int64_t n, base;
+	int32_t v0, v1, v2, v3;
+	__device__ __forceinline__ void init(const int32_t *p_, int64_t n_) { p = p_; n = n_; base = -4; v0 = v1 = v2 = v3 = 0; }
+	__device__ __forceinline__ int32_t get(int64_t i) {
+		const int64_t b = i & ~(int64_t)3;
+		if (b != base) {
+			base = b;
+			if (b + 4 <= n) { const Int4u t = *(const Int4u *)(p + b); v0 = t.x; v1 = t.y; v2 = t.z; v3 = t.w; }
+			else { v0 = b < n ? p[b] : 0; v1 = b + 1 < n ? p[b + 1] : 0; v2 = b + 2 < n ? p[b + 2] : 0; v3 = 0; }
+		}
+		const int k = (int)(i & 3);
+		return k == 0 ? v0 : k == 1 ? v1 : k == 2 ? v2 : v3;
+	}
+};
+template <int DEF>
+__device__ __forceinline__ void copy_node2(const GraphDev &g, int32_t x, int32_t d, int64_t dref, int32_t *__restrict__ row, const int32_t *__restrict__ src, uint32_t *ldsCol, int *__restrict__ err) {
+	PReader br;
+	br.init(g.bits, g.nwords);
+	br.seek((uint64_t)g.offsets[x]);
+	(void)Fields<DEF>::outdegree(br, g);
+	(void)Fields<DEF>::reference(br, g);
+	const uint64_t bc = Fields<DEF>::block_count(br, g);
+	if (bc > (uint64_t)dref + 1) return; // flagged in k_parse
+	const uint64_t blocksPos = br.pos();
+	int64_t total = 0, copied = 0;
+	const bool kept = bc <= (uint64_t)COPY2_BLOCKS && dref <= 0x7fffffff;
+	for (uint64_t b = 0; b < bc; b++) {
+		int64_t len;
+		if (!block_len_ok(Fields<DEF>::block(br, g), b == 0, total, dref, len)) return; // flagged by the parse kernel
+		if (kept) ldsCol[b * TPB] = (uint32_t)len;
+		total += len;
+		if (!(b & 1)) copied += len;
+	}
+	if (!(bc & 1)) copied += dref - total;
+	if (copied > d) return;
+	if (!kept) br.seek(blocksPos);
+
+	IdChunks rs, ex;
+	rs.init(src, dref);
+	ex.init(row, d);
+	int64_t i = 0;      // index in the referent row
+	int64_t k = 0;      // write index
+	int64_t j = copied; // extras read index
+	int32_t ev = j < d ? ex.get(j) : 0;
+	int32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0; // the last ids merged: stored four at a time
+	auto put = [&](int32_t val) {
+		o0 = o1; o1 = o2; o2 = o3; o3 = val; k++;
+		if ((k & 3) == 0) { Int4u t; t.x = o0; t.y = o1; t.z = o2; t.w = o3; *(Int4u *)(row + k - 4) = t; }
+	};
+	for (uint64_t b = 0; b <= bc; b++) {
+		int64_t len;
+		if (b < bc) len = kept ? (int64_t)ldsCol[b * TPB] : (int64_t)Fields<DEF>::block(br, g) + (b ? 1 : 0);
+		else len = dref - i; // implicit last block: the rest of the referent
+		if (b & 1) { i += len; continue; } // skip block
+		for (int64_t t = 0; t < len && i < dref && k < d; t++) { // (the bounds hold by the checks above: belt and braces)
+			const int32_t cv = rs.get(i++);
+			while (j < d && ev < cv && k < d) { put(ev); j++; if (j < d) ev = ex.get(j); }
+			if (j < d && ev == cv) { j++; if (j < d) ev = ex.get(j); } // equal heads emitted once (never in a valid file)
+			if (k < d) put(cv);
+		}
+	}
+	// the ids still in the store buffer; the remaining extras row[j..d) are already in place when k == j; a malformed duplicate leaves a gap: pad with -1
+	{ const int rem = (int)(k & 3); if (rem == 3) { row[k - 3] = o1; row[k - 2] = o2; row[k - 1] = o3; } else if (rem == 2) { row[k - 2] = o2; row[k - 1] = o3; } else if (rem == 1) row[k - 1] = o3; }
+	if (k != j) { while (j < d) { row[k++] = ex.get(j); j++; } while (k < d) row[k++] = -1; }
 	if (br.err) atomicOr(err, br.err);
 }
 
@@ -1537,9 +1620,13 @@ void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int
 		else hipLaunchKernelGGL(k_copy_mid<0>, dim3(1024), dim3(64 * COPY_MID_WAVES), 0, stMid, g, v, depth, midQ, ctl + 6, midCap, level, err);
 	}
 	if (stMid != st) (void)hipEventRecord(evMid, stMid);
-	if (def == 1) hipLaunchKernelGGL(k_copy_list<1>, dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
-	else if (def == 2) hipLaunchKernelGGL(k_copy_list<2>, dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
-	else hipLaunchKernelGGL(k_copy_list<0>, dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
+	const bool chunked = !(g.dbg & 256); // BVGPU_DBG=256: the first formulation of the one-lane merge (copy_node), for A/B timing
+	if (def == 1 && chunked) hipLaunchKernelGGL((k_copy_list<1, true>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
+	else if (def == 2 && chunked) hipLaunchKernelGGL((k_copy_list<2, true>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
+	else if (chunked) hipLaunchKernelGGL((k_copy_list<0, true>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
+	else if (def == 1) hipLaunchKernelGGL((k_copy_list<1, false>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
+	else if (def == 2) hipLaunchKernelGGL((k_copy_list<2, false>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
+	else hipLaunchKernelGGL((k_copy_list<0, false>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
 	if (stList != st) (void)hipEventRecord(evBig, stList);
 	if (stMid != st) (void)hipStreamWaitEvent(st, evMid, 0);
 	if (stList != st) (void)hipStreamWaitEvent(st, evBig, 0);
@@ -1556,14 +1643,16 @@ void launch_parse_tile(const GraphDev &g, int def, const RangeView &v, const int
 	else hipLaunchKernelGGL(k_parse_tile<2>, dim3(ntiles), dim3(TILE_T), 0, st, g, v, tb, err);
 }
 
-void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, void *arena, int64_t arenaCap) {
+void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, void *arena, int64_t arenaCap, bool lean) {
 	if (v.cnt <= 0) return;
 	IvEntry *a = (IvEntry *)arena;
-	if (def == 1 && a) hipLaunchKernelGGL((k_parse_list<1, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
-	else if (def == 2 && a) hipLaunchKernelGGL((k_parse_list<2, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
-	else if (def == 1) hipLaunchKernelGGL((k_parse_list<1, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
-	else if (def == 2) hipLaunchKernelGGL((k_parse_list<2, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
-	else hipLaunchKernelGGL((k_parse_list<0, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
+	if (def == 1 && a && lean) hipLaunchKernelGGL((k_parse_list<1, 2>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
+	else if (def == 2 && a && lean) hipLaunchKernelGGL((k_parse_list<2, 2>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
+	else if (def == 1 && a) hipLaunchKernelGGL((k_parse_list<1, 1>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
+	else if (def == 2 && a) hipLaunchKernelGGL((k_parse_list<2, 1>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
+	else if (def == 1) hipLaunchKernelGGL((k_parse_list<1, 0>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
+	else if (def == 2) hipLaunchKernelGGL((k_parse_list<2, 0>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
+	else hipLaunchKernelGGL((k_parse_list<0, 0>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
 }
 
 } // namespace bv

@@ -41,6 +41,8 @@ __global__ void __launch_bounds__(256) k_strip_bounds(const int64_t *__restrict_
 	if (t == ntiles && a < cnt) atomicOr(err, E_CAP);
 }
 
+struct RowsMasked { int32_t *p; uint32_t mask; __device__ __forceinline__ int32_t &operator[](uint32_t i) const { return p[i & mask]; } }; // mask = ~0; BVGPU_DBG=512 (timing experiment, wrong results): every store lands in the strip's first 64 ids
+
 template <int ZK>
 __global__ void __launch_bounds__(64) k_strip(GraphDev g, RangeView v, const int32_t *__restrict__ tb, int32_t stripMax, int32_t *__restrict__ esc,
                                               int32_t *__restrict__ escCtl, int32_t escCap, int *__restrict__ err) {
@@ -52,9 +54,10 @@ __global__ void __launch_bounds__(64) k_strip(GraphDev g, RangeView v, const int
 	const int32_t n = min(b - a, (int32_t)STRIP_NODES); // (b - a <= STRIP_NODES by construction of the bounds;
 	if (b - a > (int32_t)STRIP_NODES && lane == 0) atomicOr(err, E_FORMAT); // if that were ever wrong, records would be skipped: make it loud)
 	// BVGPU_STATS=1: clock ticks (100 MHz) per phase, summed over the strips: stats[32 + phase]; stats[32 + 15] = strips
-	unsigned long long tPrev = g.stats ? wall_clock64() : 0;
+	const bool tSample = g.stats && (blockIdx.x & 63) == 0; // (one strip in 64: the atomics of every strip would be what is measured)
+	unsigned long long tPrev = tSample ? wall_clock64() : 0;
 	int tPhase = 0;
-#define STRIP_TICK() do { if (g.stats) { if (lane == 0) { const unsigned long long tn_ = wall_clock64(); atomicAdd(&g.stats[32 + tPhase], tn_ - tPrev); tPrev = tn_; } tPhase++; } } while (0)
+#define STRIP_TICK() do { if (tSample) { if (lane == 0) { const unsigned long long tn_ = wall_clock64(); atomicAdd(&g.stats[32 + tPhase], tn_ - tPrev); tPrev = tn_; } tPhase++; } } while (0)
 
 	// ---- the strip's records, one per lane
 	const int32_t s = a + lane;
@@ -70,7 +73,7 @@ __global__ void __launch_bounds__(64) k_strip(GraphDev g, RangeView v, const int
 	const bool inHalo = b <= v.nh;
 	const int64_t rowBase = (int64_t)__shfl((long long)rs, 0, 64); // row start of slot a
 	const int64_t rowFirst = inHalo ? rowBase : (a >= v.nh ? rowBase : rowNh);
-	int32_t *const rows = inHalo ? v.halo + rowBase : v.succ + (rowFirst - rowNh);
+	const RowsMasked rows{ inHalo ? v.halo + rowBase : v.succ + (rowFirst - rowNh), (g.dbg & 512) ? 63u : 0xffffffffu };
 	bool escNow = false; // this lane's record goes to the escape list
 	if (own) {
 		if (!inHalo && s < v.nh) { escNow = true; own = false; }
@@ -184,7 +187,7 @@ __global__ void __launch_bounds__(64) k_strip(GraphDev g, RangeView v, const int
 			if (escNow) { const int32_t k = k0 + __popcll(em & ((1ull << lane) - 1)); if (k < escCap) esc[k] = s; else atomicOr(err, E_FORMAT); }
 		}
 	}
-	if (g.stats && lane == 0) { atomicAdd(&g.stats[32 + 15], 1ull); atomicAdd(&g.stats[32 + 14], (unsigned long long)n); atomicAdd(&g.stats[32 + 13], (unsigned long long)nSeg); atomicAdd(&g.stats[32 + 12], (unsigned long long)(nSeg - nShort)); atomicAdd(&g.stats[32 + 11], (unsigned long long)nIvAll); }
+	if (tSample && lane == 0) { atomicAdd(&g.stats[32 + 15], 1ull); atomicAdd(&g.stats[32 + 14], (unsigned long long)n); atomicAdd(&g.stats[32 + 13], (unsigned long long)nSeg); atomicAdd(&g.stats[32 + 12], (unsigned long long)(nSeg - nShort)); atomicAdd(&g.stats[32 + 11], (unsigned long long)nIvAll); }
 #undef STRIP_TICK
 }
 

@@ -125,7 +125,8 @@ struct bvg_graph {
 	DevBuf plist, pkeys, pkey16;
 	int tile = -1;       // -1: automatic (see enqueue_decode); BVGPU_TILE=0: never; BVGPU_TILE=1: short records decoded from contiguous tiles of the stream (k_parse_tile) instead of the bin-sorted parse list (k_parse_list)
 	DevBuf tilebounds;
-	int strip = 1;       // BVGPU_STRIP=0: the strip kernel (bv_strip.hip) is not used for the records below the wave class
+	int lean = 1;        // BVGPU_LEAN=0: the one-lane decoder merges with its first formulation (one successor per iteration: parse_node_lw)
+	int strip = 0;       // BVGPU_STRIP=1: the strip kernel (bv_strip.hip) instead of the bin-sorted one-lane decoder for the records below the wave class
 	int32_t strip_max = 0; // records with fewer successors are strip work (BVGPU_STRIP_MAX; 0: the kernel's default)
 	DevBuf stripbounds, esclist;
 	int copy_big = 1;    // BVGPU_COPY_BIG=0: every row is copied by one lane
@@ -224,6 +225,7 @@ int init_handle(bvg_graph *g) {
 	if (const char *e = getenv("BVGPU_PARSE_WINDOWS")) g->parse_windows = atoi(e);
 	if (const char *e = getenv("BVGPU_TILE")) g->tile = atoi(e);
 	if (const char *e = getenv("BVGPU_STRIP")) g->strip = atoi(e);
+	if (const char *e = getenv("BVGPU_LEAN")) g->lean = atoi(e);
 	g->strip_max = bv::strip_max_default();
 	if (const char *e = getenv("BVGPU_STRIP_MAX")) g->strip_max = std::min(std::max(2, atoi(e)), 2048);
 	if (const char *e = getenv("BVGPU_WALK_TABLES")) g->walk_tables = atoi(e);
@@ -537,7 +539,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		}
 		else if (tiles) bv::launch_parse_tile(gd, s.def, v, g->tilebounds.as<int32_t>(), ntiles, tileVariant, derr, g->stream);
 		else if (pKeyBase) {
-			bv::launch_parse_list(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, g->level_blocks, derr, g->stream, g->iv_arena ? g->arena.p : nullptr, arenaCap);
+			bv::launch_parse_list(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, g->level_blocks, derr, g->stream, g->iv_arena ? g->arena.p : nullptr, arenaCap, g->lean != 0);
 		}
 		else bv::launch_parse(gd, s.def, v, derr, g->stream);
 		if (ovl) {
