@@ -9,6 +9,10 @@ if os.environ.get("SWEEP_CHILD"):
     if which in bench.WORKLOADS:
         wl = bench.WORKLOADS[which]
         base = bench.prepare_graph(wl["n"], wl["m"], wl["seed"], wl["p_copy"], "/tmp/bvgpu_cache", os.cpu_count() or 1, p_same=wl["p_same"], p_keep=wl["p_keep"])[0]
+    elif which.startswith("cnr"):
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        import ab_time
+        base = ab_time.workload(which)
     else:
         base = which
     g = BVGraph.load(base)

@@ -45,7 +45,7 @@ int strip_model_run(const uint8_t *graph, uint64_t nbytes, const int64_t *offset
 		const uint64_t w0 = ((uint64_t)p0 >> 5) & ~(uint64_t)3;
 		const int64_t base = (int64_t)(w0 << 5);
 		const StripLayout L = strip_layout(((p1 - base + 31) >> 5) + 8);
-		if (L.oIv + 4 * L.ivCap > WPOOL_WORDS || L.oSeg + 5 * L.segCap > L.oIv || L.oWin + L.nw > L.oSeg) { fprintf(stderr, "strip_model: layout overflow\n"); return -2; }
+		if (L.oIv + 4 * L.ivCap > WPOOL_WORDS || L.oSeg + 5 * L.segCap > L.oOrd || L.oOrd + (L.segCap + 1) / 2 > L.oIv || L.oWin + L.nw > L.oSeg) { fprintf(stderr, "strip_model: layout overflow\n"); return -2; }
 		stats[1] = std::max<int64_t>(stats[1], L.oIv + 4 * L.ivCap);
 		StripH st;
 		strip_bind(st, pool.data(), L);
@@ -57,11 +57,11 @@ int strip_model_run(const uint8_t *graph, uint64_t nbytes, const int64_t *offset
 			st.win[k] = word;
 		}
 		int32_t *rows = succ + (rowstart[a] - rowstart[0]);
-		// per-lane state
-		struct Lane { bool own = false, esc = false, isLong = false; int32_t d = 0, r = 0, x = 0, m = 0, eS = 0, eL = 0; int64_t dref = 0, q0 = 0, q1 = 0; uint32_t rowOff = 0, rowOut = 0; Rec R{}; };
-		std::vector<Lane> ln(64);
+		// per-record state: record i = k * 64 + lane lives in lane (i & 63), pass (i >> 6)
+		struct Lane { bool own = false, esc = false, isLong = false; int32_t d = 0, r = 0, x = 0, m = 0, eFirst = 0; int64_t dref = 0, q0 = 0, q1 = 0; uint32_t rowOut = 0; Rec R{}; };
+		std::vector<Lane> ln(64 * KREC);
 		const char *stage = "fields";
-		auto escape = [&](int l) { if (trace) fprintf(stderr, "escape(why %d): strip %lld slot %d (lane %d of %d) at %s: d %d ref %d nres %d niv %d ivCap %d segCap %d nw %d\n", g_why, (long long)t, a + l, l, n, stage, ln[l].d, ln[l].r, ln[l].R.nRes, ln[l].R.nIv, st.ivCap, st.segCap, L.nw); ln[l].own = false; ln[l].esc = true; };
+		auto escape = [&](int l) { if (trace) fprintf(stderr, "escape(why %d): strip %lld slot %d (record %d of %d) at %s: d %d ref %d nres %d niv %d ivCap %d segCap %d nw %d\n", g_why, (long long)t, a + l, l, n, stage, ln[l].d, ln[l].r, ln[l].R.nRes, ln[l].R.nIv, st.ivCap, st.segCap, L.nw); ln[l].own = false; ln[l].esc = true; };
 		for (int l = 0; l < n; l++) {
 			Lane &z = ln[l];
 			const int32_t s = a + l;
@@ -69,50 +69,75 @@ int strip_model_run(const uint8_t *graph, uint64_t nbytes, const int64_t *offset
 			z.own = z.d > 0 && z.d < stripMax;
 			z.r = z.own ? ref[s] : 0;
 			z.dref = z.r > 0 ? (s - z.r >= 0 ? (int64_t)outd[s - z.r] : -1) : 0;
-			z.rowOff = (uint32_t)(rowstart[s] - rowstart[a]);
+			z.rowOut = (uint32_t)(rowstart[s] - rowstart[a]);
 			z.q0 = offsets[lo + s] - base; z.q1 = offsets[lo + s + 1] - base;
 			if (z.own) stats[7]++;
 			if (z.own && (z.q1 > (int64_t)qmax || z.q1 <= z.q0)) { g_why = 100; escape(l); }
 		}
-		stage = "head";
-		for (int l = 0; l < n; l++) { Lane &z = ln[l]; if (z.own) { z.R = structure_head(st, job, qmax, (uint32_t)z.q0, z.d, z.r, z.dref); if (!z.R.ok) { escape(l); z.R.nIv = 0; } } }
-		int32_t ivTotal = 0;
-		for (int l = 0; l < 64; l++) { Lane &z = ln[l]; z.R.ivb = ivTotal; ivTotal += z.own ? z.R.nIv : 0; }
-		for (int l = 0; l < n; l++) { Lane &z = ln[l]; if (z.own && z.R.ivb + z.R.nIv > st.ivCap) { g_why = 101; escape(l); z.R.nIv = 0; } }
-		const int32_t nIvAll = std::min(ivTotal, st.ivCap);
-		for (int32_t j = 0; j < nIvAll; j++) st.iv_len[j] = 0;
-		stage = "intervals";
-		for (int l = 0; l < n; l++) {
-			Lane &z = ln[l];
-			z.rowOut = z.rowOff + (uint32_t)z.R.copied;
-			if (z.own) { structure_intervals(st, job, qmax, z.R, z.x, z.rowOut, (uint32_t)z.q1); if (!z.R.ok) escape(l); }
-			if (!z.own) for (int32_t j = 0; j < z.R.nIv; j++) st.iv_len[z.R.ivb + j] = 0;
+		int32_t ivBase = 0;
+		for (int k = 0; k < KREC && k * 64 < n; k++) {
+			stage = "head";
+			for (int l = k * 64; l < k * 64 + 64; l++) { Lane &z = ln[l]; if (z.own) { z.R = structure_head(st, job, qmax, (uint32_t)z.q0, z.d, z.r, z.dref); if (!z.R.ok) { escape(l); z.R.nIv = 0; } } }
+			int32_t ivTotal = 0;
+			for (int l = k * 64; l < k * 64 + 64; l++) { Lane &z = ln[l]; z.R.ivb = ivBase + ivTotal; ivTotal += z.own ? z.R.nIv : 0; }
+			for (int l = k * 64; l < k * 64 + 64; l++) { Lane &z = ln[l]; if (z.own && z.R.ivb + z.R.nIv > st.ivCap) { g_why = 101; escape(l); z.R.nIv = 0; } }
+			const int32_t ivEnd = std::min(ivBase + ivTotal, st.ivCap);
+			for (int32_t j = ivBase; j < ivEnd; j++) st.iv_len[j] = 0;
+			ivBase = ivEnd;
+			stage = "intervals";
+			for (int l = k * 64; l < k * 64 + 64; l++) {
+				Lane &z = ln[l];
+				z.rowOut += (uint32_t)z.R.copied;
+				if (z.own) { structure_intervals(st, job, qmax, z.R, z.x, z.rowOut, (uint32_t)z.q1); if (!z.R.ok) escape(l); }
+				if (!z.own) for (int32_t j = 0; j < z.R.nIv; j++) st.iv_len[z.R.ivb + j] = 0;
+			}
 		}
+		const int32_t nIvAll = ivBase;
 		stage = "segments";
-		int32_t nShort = 0, longTotal = 0;
-		for (int l = 0; l < 64; l++) { Lane &z = ln[l]; z.m = z.own ? segments_of(z.R.nRes, z.R.sbits) : 0; z.eS = nShort; if (z.m == 1) nShort++; }
-		for (int l = 0; l < 64; l++) { Lane &z = ln[l]; z.eL = nShort + longTotal; if (z.m > 1) longTotal += z.m; }
-		int32_t nSeg = nShort;
-		for (int l = 0; l < n; l++) {
+		int32_t nShort = 0;
+		for (int l = 0; l < 64 * KREC; l++) {
 			Lane &z = ln[l];
-			z.isLong = z.m > 1;
-			if (z.isLong && z.eL + z.m > st.segCap) { g_why = 102; escape(l); z.isLong = false; for (int32_t j = 0; j < z.R.nIv; j++) st.iv_len[z.R.ivb + j] = 0; }
-			if (z.m == 1) segment_short(st, z.eS, z.R, z.x, z.rowOut);
+			z.m = z.own ? segments_of(z.R.nRes, z.R.sbits) : 0;
+			if (z.m == 1) {
+				z.eFirst = nShort++;
+				if (z.eFirst < st.segCap) segment_short(st, z.eFirst, z.R, z.x, z.rowOut);
+				else { g_why = 105; escape(l); z.m = 0; for (int32_t j = 0; j < z.R.nIv; j++) st.iv_len[z.R.ivb + j] = 0; }
+			}
 		}
-		for (int l = 0; l < n; l++) { Lane &z = ln[l]; if (z.isLong) { for (int32_t k = 0; k < z.m; k++) segment_nominal(st, z.eL + k, z.R.q, z.R.q + z.R.sbits, k); nSeg = z.eL + z.m; } }
+		nShort = std::min(nShort, st.segCap);
+		int32_t nSeg = nShort;
+		bool full = false;
+		for (int k = 0; k < KREC && !full; k++) {
+			int32_t run = nSeg;
+			for (int l = k * 64; l < k * 64 + 64; l++) { Lane &z = ln[l]; if (z.m > 1) { z.eFirst = run; run += z.m; } }
+			for (int l = k * 64; l < k * 64 + 64; l++) {
+				Lane &z = ln[l];
+				z.isLong = z.m > 1;
+				if (z.isLong && z.eFirst + z.m > st.segCap) { g_why = 102; escape(l); z.isLong = false; full = true; for (int32_t j = 0; j < z.R.nIv; j++) st.iv_len[z.R.ivb + j] = 0; }
+				if (z.isLong) { for (int32_t kk = 0; kk < z.m; kk++) segment_nominal(st, z.eFirst + kk, z.R.q, z.R.q + z.R.sbits, kk); nSeg = z.eFirst + z.m; }
+			}
+		}
+		for (int l = 0; l < 64 * KREC; l++) { Lane &z = ln[l]; if (z.m > 1 && !z.isLong && z.own) { g_why = 106; escape(l); for (int32_t j = 0; j < z.R.nIv; j++) st.iv_len[z.R.ivb + j] = 0; } }
 		stats[2] += nSeg; stats[3] += nSeg - nShort;
 		for (int32_t e = nShort; e < nSeg; e++) { if (zk == 3) phase_anchor<3>(st, job, qmax, e); else phase_anchor<0>(st, job, qmax, e); }
 		stage = "chain";
-		for (int l = 0; l < n; l++) {
+		for (int l = 0; l < 64 * KREC; l++) {
 			Lane &z = ln[l];
 			if (!z.isLong) continue;
-			for (int32_t k = 1; k < z.m; k++) if (st.seg_start[z.eL + k] != st.seg_out[z.eL + k - 1]) stats[4]++;
-			const bool ok = zk == 3 ? phase_chain<3>(st, job, qmax, z.eL, z.m, z.R, z.x, z.rowOut) : phase_chain<0>(st, job, qmax, z.eL, z.m, z.R, z.x, z.rowOut);
-			if (!ok) { g_why = 103; escape(l); for (int32_t k = 0; k < z.m; k++) st.seg_cnt[z.eL + k] = 0; for (int32_t j = 0; j < z.R.nIv; j++) st.iv_len[z.R.ivb + j] = 0; }
+			for (int32_t kk = 1; kk < z.m; kk++) if (st.seg_start[z.eFirst + kk] != st.seg_out[z.eFirst + kk - 1]) stats[4]++;
+			const bool ok = zk == 3 ? phase_chain<3>(st, job, qmax, z.eFirst, z.m, z.R, z.x, z.rowOut) : phase_chain<0>(st, job, qmax, z.eFirst, z.m, z.R, z.x, z.rowOut);
+			if (!ok) { g_why = 103; escape(l); for (int32_t kk = 0; kk < z.m; kk++) st.seg_cnt[z.eFirst + kk] = 0; for (int32_t j = 0; j < z.R.nIv; j++) st.iv_len[z.R.ivb + j] = 0; }
 		}
 		stage = "residuals";
+		// the segments in the order of phase R: counting sort on bins of 4 codewords, longest first, the empty ones last
+		int32_t histo[SORT_BINS + 1] = { 0 };
+		auto binOf = [&](int32_t c) { return c ? SORT_BINS - 1 - std::min(c >> 2, SORT_BINS - 1) : SORT_BINS; };
+		for (int32_t e = 0; e < nSeg; e++) histo[binOf(st.seg_cnt[e])]++;
+		{ int32_t acc = 0; for (int bI = 0; bI <= SORT_BINS; bI++) { const int32_t c = histo[bI]; histo[bI] = acc; acc += c; } }
+		const int32_t nWork = histo[SORT_BINS];
+		for (int32_t e = 0; e < nSeg; e++) st.order[histo[binOf(st.seg_cnt[e])]++] = (uint16_t)e;
 		bool badR = false;
-		for (int32_t e = 0; e < nSeg; e++) if (st.seg_cnt[e] != 0) { const bool ok = zk == 3 ? phase_residuals<3>(st, job, qmax, rows, e) : phase_residuals<0>(st, job, qmax, rows, e); if (!ok) badR = true; }
+		for (int32_t tt = 0; tt < nWork; tt++) { const int32_t e = st.order[tt]; const bool ok = zk == 3 ? phase_residuals<3>(st, job, qmax, rows, e) : phase_residuals<0>(st, job, qmax, rows, e); if (!ok) badR = true; }
 		if (badR) { g_why = 104; for (int l = 0; l < n; l++) if (ln[l].own) escape(l); }
 		else {
 			stats[5] += nIvAll;

@@ -47,43 +47,27 @@ template <int ZK>
 __global__ void __launch_bounds__(64) k_strip(GraphDev g, RangeView v, const int32_t *__restrict__ tb, int32_t stripMax, int32_t *__restrict__ esc,
                                               int32_t *__restrict__ escCtl, int32_t escCap, int *__restrict__ err) {
 	__shared__ __attribute__((aligned(16))) uint32_t pool_[WPOOL_WORDS];
+	__shared__ int32_t hist_[SORT_BINS + 1];
 	l_u32 *pool = (l_u32 *)pool_;
+	l_i32 *hist = (l_i32 *)hist_;
 	const int lane = threadIdx.x;
 	const int32_t a = tb[blockIdx.x], b = tb[blockIdx.x + 1];
 	if (a >= b) return;
 	const int32_t n = min(b - a, (int32_t)STRIP_NODES); // (b - a <= STRIP_NODES by construction of the bounds;
 	if (b - a > (int32_t)STRIP_NODES && lane == 0) atomicOr(err, E_FORMAT); // if that were ever wrong, records would be skipped: make it loud)
-	// BVGPU_STATS=1: clock ticks (100 MHz) per phase, summed over the strips: stats[32 + phase]; stats[32 + 15] = strips
-	const bool tSample = g.stats && (blockIdx.x & 63) == 0; // (one strip in 64: the atomics of every strip would be what is measured)
+	// BVGPU_STATS=1: clock ticks (100 MHz) per phase of one strip in 64, summed: stats[32 + phase]; stats[32 + 15] = strips sampled
+	const bool tSample = g.stats && (blockIdx.x & 63) == 0; // (the atomics of every strip would be what is measured)
 	unsigned long long tPrev = tSample ? wall_clock64() : 0;
 	int tPhase = 0;
 #define STRIP_TICK() do { if (tSample) { if (lane == 0) { const unsigned long long tn_ = wall_clock64(); atomicAdd(&g.stats[32 + tPhase], tn_ - tPrev); tPrev = tn_; } tPhase++; } } while (0)
 
-	// ---- the strip's records, one per lane
-	const int32_t s = a + lane;
-	const bool have = lane < n;
-	int32_t d = have ? v.outd[s] : 0;
-	const int64_t o0 = have ? g.offsets[v.lo + s] : 0, o1 = have ? g.offsets[v.lo + s + 1] : 0;
-	const int64_t rs = have ? v.rowstart[s] : 0, rsn = have ? v.rowstart[s + 1] : 0;
-	bool own = d > 0 && d < stripMax;
-	const int32_t r = own ? (int32_t)v.ref[s] : 0;
-	const int64_t dref = r > 0 ? (s - r >= 0 ? (int64_t)v.outd[s - r] : -1) : 0; // (referents before the view: k_apply_need clears such references)
+	// ---- the strip: rows, stream slice, layout of the pool
 	// rows: in the caller's buffer from slot nh on, in the halo scratch before; a strip that straddles nh leaves its halo records to the escape path
-	const int64_t rowNh = v.rowstart[v.nh];
+	const int64_t rowNh = v.rowstart[v.nh], rowA = v.rowstart[a];
 	const bool inHalo = b <= v.nh;
-	const int64_t rowBase = (int64_t)__shfl((long long)rs, 0, 64); // row start of slot a
-	const int64_t rowFirst = inHalo ? rowBase : (a >= v.nh ? rowBase : rowNh);
-	const RowsMasked rows{ inHalo ? v.halo + rowBase : v.succ + (rowFirst - rowNh), (g.dbg & 512) ? 63u : 0xffffffffu };
-	bool escNow = false; // this lane's record goes to the escape list
-	if (own) {
-		if (!inHalo && s < v.nh) { escNow = true; own = false; }
-		else if (!(inHalo ? (uint64_t)rsn <= v.halo_cap : (uint64_t)(rsn - rowNh) <= v.succ_cap)) { atomicOr(err, inHalo ? E_HALO : E_CAP); own = false; }
-		else if (rs - rowFirst + d > 0x7fffffffll) { escNow = true; own = false; }
-	}
-	const uint32_t rowOff = (uint32_t)(rs - rowFirst);
-
-	// ---- layout of the pool, staging of the stream slice
-	const int64_t p0 = (int64_t)__shfl((long long)o0, 0, 64), p1 = (int64_t)__shfl((long long)o1, n - 1, 64);
+	const int64_t rowFirst = inHalo ? rowA : (a >= v.nh ? rowA : rowNh);
+	const RowsMasked rows{ inHalo ? v.halo + rowA : v.succ + (rowFirst - rowNh), (g.dbg & 512) ? 63u : 0xffffffffu };
+	const int64_t p0 = g.offsets[v.lo + a], p1 = g.offsets[v.lo + a + n];
 	const uint64_t w0 = ((uint64_t)p0 >> 5) & ~(uint64_t)3;
 	const int64_t base = (int64_t)(w0 << 5);
 	const StripLayout L = strip_layout(((p1 - base + 31) >> 5) + 8);
@@ -100,72 +84,143 @@ __global__ void __launch_bounds__(64) k_strip(GraphDev g, RangeView v, const int
 			st.win[4 * i4 + 2] = __builtin_bswap32(q4.z); st.win[4 * i4 + 3] = __builtin_bswap32(q4.w);
 		}
 	}
-	const int64_t q0 = o0 - base, q1 = o1 - base;
-	if (own && (q1 > (int64_t)qmax || q1 <= q0)) { escNow = true; own = false; } // the record overhangs the staged slice
-	wsync();
-	STRIP_TICK(); // 0: loads, staging
 	Job job;
 	job.W = g.W; job.minInt = g.minInt; job.zk = (uint32_t)g.zetaK;
-	const int32_t x = v.lo + s;
 
-	// ---- phase S: structure, one lane per record
-	Rec R; R.q = 0; R.sbits = 0; R.copied = 0; R.extra = 0; R.nIv = 0; R.ivb = 0; R.nRes = 0; R.ok = false;
-	if (own) { R = structure_head(st, job, qmax, (uint32_t)q0, d, r, dref); if (!R.ok) { escNow = true; own = false; R.nIv = 0; } }
-	int32_t ivTotal;
-	R.ivb = wave_excl_scan(own ? R.nIv : 0, lane, ivTotal);
-	if (own && R.ivb + R.nIv > st.ivCap) { escNow = true; own = false; R.nIv = 0; } // no room for its intervals (nothing of it is in the arena)
-	const int32_t nIvAll = min(ivTotal, st.ivCap);
-	const uint32_t rowOut = rowOff + (uint32_t)R.copied;
-	// (an arena slot that no lane fills -- the slice of a record that escapes -- may hold what an earlier strip left there: phase X skips length 0)
-	for (int32_t j = lane; j < nIvAll; j += 64) st.iv_len[j] = 0;
-	wsync();
-	if (own) {
-		structure_intervals(st, job, qmax, R, x, rowOut, (uint32_t)q1);
-		if (!R.ok) { escNow = true; own = false; }
+	// ---- the strip's records: KREC per lane (record k * 64 + lane in pass k)
+	Rec R[KREC];
+	int32_t x[KREC], m[KREC], eFirst[KREC];
+	uint32_t rowOut[KREC], recEnd[KREC];
+	bool own[KREC], escNow[KREC], isLong[KREC];
+	int32_t dk[KREC], rk[KREC];
+	int64_t drefk[KREC];
+	uint32_t q0k[KREC];
+#pragma unroll
+	for (int k = 0; k < KREC; k++) {
+		const int32_t i = k * 64 + lane, s = a + i;
+		const bool have = i < n;
+		const int32_t d = have ? v.outd[s] : 0;
+		const int64_t o0 = have ? g.offsets[v.lo + s] : 0, o1 = have ? g.offsets[v.lo + s + 1] : 0;
+		const int64_t rs = have ? v.rowstart[s] : 0, rsn = have ? v.rowstart[s + 1] : 0;
+		own[k] = d > 0 && d < stripMax; escNow[k] = false; isLong[k] = false; m[k] = 0; eFirst[k] = 0;
+		const int32_t r = own[k] ? (int32_t)v.ref[s] : 0;
+		drefk[k] = r > 0 ? (s - r >= 0 ? (int64_t)v.outd[s - r] : -1) : 0; // (referents before the view: k_apply_need clears such references)
+		dk[k] = d; rk[k] = r; x[k] = v.lo + s;
+		if (own[k]) {
+			if (!inHalo && s < v.nh) { escNow[k] = true; own[k] = false; }
+			else if (!(inHalo ? (uint64_t)rsn <= v.halo_cap : (uint64_t)(rsn - rowNh) <= v.succ_cap)) { atomicOr(err, inHalo ? E_HALO : E_CAP); own[k] = false; }
+			else if (rs - rowFirst + d > 0x7fffffffll) { escNow[k] = true; own[k] = false; }
+		}
+		rowOut[k] = (uint32_t)(rs - rowFirst);
+		const int64_t q0 = o0 - base, q1 = o1 - base;
+		if (own[k] && (q1 > (int64_t)qmax || q1 <= q0)) { escNow[k] = true; own[k] = false; } // the record overhangs the staged slice
+		q0k[k] = (uint32_t)q0; recEnd[k] = (uint32_t)q1;
+		R[k].q = 0; R[k].sbits = 0; R[k].copied = 0; R[k].extra = 0; R[k].nIv = 0; R[k].ivb = 0; R[k].nRes = 0; R[k].ok = false;
 	}
-	if (!own) for (int32_t j = 0; j < R.nIv; j++) st.iv_len[R.ivb + j] = 0; // (a record that escaped half-way through its intervals)
+	wsync();
+	STRIP_TICK(); // 0: loads, staging
+
+	// ---- phase S: structure, KREC passes of one lane per record
+	int32_t ivBase = 0; // arena slots handed out so far
+#pragma unroll
+	for (int k = 0; k < KREC; k++) {
+		if (k * 64 >= n) break;
+		if (own[k]) { R[k] = structure_head(st, job, qmax, q0k[k], dk[k], rk[k], drefk[k]); if (!R[k].ok) { escNow[k] = true; own[k] = false; R[k].nIv = 0; } }
+		int32_t ivTotal;
+		R[k].ivb = ivBase + wave_excl_scan(own[k] ? R[k].nIv : 0, lane, ivTotal);
+		if (own[k] && R[k].ivb + R[k].nIv > st.ivCap) { escNow[k] = true; own[k] = false; R[k].nIv = 0; } // no room for its intervals (nothing of it is in the arena)
+		const int32_t ivEnd = min(ivBase + ivTotal, st.ivCap);
+		// (an arena slot that no lane fills -- the slice of a record that escapes -- may hold what an earlier strip left there: phase X skips length 0)
+		for (int32_t j = ivBase + lane; j < ivEnd; j += 64) st.iv_len[j] = 0;
+		wsync();
+		ivBase = ivEnd;
+		rowOut[k] += (uint32_t)R[k].copied;
+		if (own[k]) {
+			structure_intervals(st, job, qmax, R[k], x[k], rowOut[k], recEnd[k]);
+			if (!R[k].ok) { escNow[k] = true; own[k] = false; }
+		}
+		if (!own[k]) for (int32_t j = 0; j < R[k].nIv; j++) st.iv_len[R[k].ivb + j] = 0; // (a record that escaped half-way through its intervals)
+	}
+	const int32_t nIvAll = ivBase;
 	STRIP_TICK(); // 1: phase S
 	// ---- segments of the residual sections: the short sections first (one each), then the nominal segments of the long ones
-	const int32_t m = own ? segments_of(R.nRes, R.sbits) : 0;
-	const unsigned long long shortMask = __ballot(m == 1);
-	const int32_t nShort = __popcll(shortMask);
-	const int32_t eS = __popcll(shortMask & ((1ull << lane) - 1));
-	int32_t longTotal;
-	const int32_t eL = nShort + wave_excl_scan(m > 1 ? m : 0, lane, longTotal);
-	bool isLong = m > 1;
-	if (isLong && eL + m > st.segCap) { escNow = true; own = false; isLong = false; for (int32_t j = 0; j < R.nIv; j++) st.iv_len[R.ivb + j] = 0; } // no room for its segments
-	if (m == 1) segment_short(st, eS, R, x, rowOut);
+	int32_t nShort = 0;
+#pragma unroll
+	for (int k = 0; k < KREC; k++) {
+		m[k] = own[k] ? segments_of(R[k].nRes, R[k].sbits) : 0;
+		const unsigned long long sm = __ballot(m[k] == 1);
+		if (m[k] == 1) { eFirst[k] = nShort + __popcll(sm & ((1ull << lane) - 1)); if (eFirst[k] < st.segCap) segment_short(st, eFirst[k], R[k], x[k], rowOut[k]); else { escNow[k] = true; own[k] = false; m[k] = 0; for (int32_t j = 0; j < R[k].nIv; j++) st.iv_len[R[k].ivb + j] = 0; } }
+		nShort += __popcll(sm);
+	}
+	nShort = min(nShort, st.segCap);
 	int32_t nSeg = nShort;
-	{
-		unsigned long long lm = __ballot(isLong);
+#pragma unroll
+	for (int k = 0; k < KREC; k++) {
+		int32_t longTotal;
+		const int32_t exL = wave_excl_scan(m[k] > 1 ? m[k] : 0, lane, longTotal);
+		if (m[k] > 1) eFirst[k] = nSeg + exL;
+		isLong[k] = m[k] > 1;
+		if (isLong[k] && eFirst[k] + m[k] > st.segCap) { escNow[k] = true; own[k] = false; isLong[k] = false; for (int32_t j = 0; j < R[k].nIv; j++) st.iv_len[R[k].ivb + j] = 0; } // no room for its segments
+		unsigned long long lm = __ballot(isLong[k]);
 		while (lm) {
 			const int Ls = __ffsll((long long)lm) - 1;
 			lm &= lm - 1;
-			const int32_t e0 = __shfl(eL, Ls, 64), mL = __shfl(m, Ls, 64);
-			const uint32_t r0 = (uint32_t)__shfl((int)R.q, Ls, 64), sb = (uint32_t)__shfl((int)R.sbits, Ls, 64);
-			for (int32_t k = lane; k < mL; k += 64) segment_nominal(st, e0 + k, r0, r0 + sb, k);
+			const int32_t e0 = __shfl(eFirst[k], Ls, 64), mL = __shfl(m[k], Ls, 64);
+			const uint32_t r0 = (uint32_t)__shfl((int)R[k].q, Ls, 64), sb = (uint32_t)__shfl((int)R[k].sbits, Ls, 64);
+			for (int32_t kk = lane; kk < mL; kk += 64) segment_nominal(st, e0 + kk, r0, r0 + sb, kk);
 			nSeg = e0 + mL; // (the lanes that fit are a prefix of the long ones: their entries are contiguous)
 		}
+		if (__ballot(m[k] > 1 && !isLong[k])) break; // the table is full: the later passes' long sections do not fit either (their records escape below)
 	}
+#pragma unroll
+	for (int k = 0; k < KREC; k++) if (m[k] > 1 && !isLong[k] && own[k]) { escNow[k] = true; own[k] = false; for (int32_t j = 0; j < R[k].nIv; j++) st.iv_len[R[k].ivb + j] = 0; }
 	wsync();
 	// ---- phase A: anchors of the long sections, one lane per nominal segment
 	for (int32_t e = nShort + lane; e < nSeg; e += 64) phase_anchor<ZK>(st, job, qmax, e);
 	wsync();
 	STRIP_TICK(); // 2: segments + phase A
 	// ---- phase B: the record's lane chains its segments
-	if (isLong && !phase_chain<ZK>(st, job, qmax, eL, m, R, x, rowOut)) {
-		escNow = true; own = false;
-		for (int32_t k = 0; k < m; k++) st.seg_cnt[eL + k] = 0;
-		for (int32_t j = 0; j < R.nIv; j++) st.iv_len[R.ivb + j] = 0;
+#pragma unroll
+	for (int k = 0; k < KREC; k++) {
+		if (isLong[k] && !phase_chain<ZK>(st, job, qmax, eFirst[k], m[k], R[k], x[k], rowOut[k])) {
+			escNow[k] = true; own[k] = false;
+			for (int32_t kk = 0; kk < m[k]; kk++) st.seg_cnt[eFirst[k] + kk] = 0;
+			for (int32_t j = 0; j < R[k].nIv; j++) st.iv_len[R[k].ivb + j] = 0;
+		}
 	}
 	wsync();
 	STRIP_TICK(); // 3: phase B
+	// ---- the segments sorted by length, longest first (counting sort, bins of 4 codewords): the lanes of a round of phase R get segments of about the same length
+	if (lane <= SORT_BINS) hist[lane] = 0;
+	wsync();
+	for (int32_t e0 = 0; e0 < nSeg; e0 += 64) {
+		const int32_t e = e0 + lane;
+		if (e < nSeg) { const int32_t c = (int32_t)st.seg_cnt[e]; __hip_atomic_fetch_add(&hist[c ? SORT_BINS - 1 - min(c >> 2, SORT_BINS - 1) : SORT_BINS], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+	}
+	wsync();
+	{
+		const int32_t c = lane <= SORT_BINS ? hist[lane] : 0;
+		int32_t tot;
+		const int32_t ex = wave_excl_scan(c, lane, tot);
+		wsync();
+		if (lane <= SORT_BINS) hist[lane] = ex;
+	}
+	wsync();
+	const int32_t nWork = hist[SORT_BINS]; // segments with codewords (the empty ones -- escaped records -- sort last)
+	for (int32_t e0 = 0; e0 < nSeg; e0 += 64) {
+		const int32_t e = e0 + lane;
+		if (e < nSeg) { const int32_t c = (int32_t)st.seg_cnt[e]; const int32_t at = __hip_atomic_fetch_add(&hist[c ? SORT_BINS - 1 - min(c >> 2, SORT_BINS - 1) : SORT_BINS], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); st.order[at] = (uint16_t)e; }
+	}
+	wsync();
 	// ---- phase R: residuals, one lane per segment, stored straight into the rows
 	bool badR = false;
-	for (int32_t e = lane; e < nSeg; e += 64) if (st.seg_cnt[e] != 0 && !phase_residuals<ZK>(st, job, qmax, rows, e)) badR = true;
+	for (int32_t t = lane; t < nWork; t += 64) { if (!phase_residuals<ZK>(st, job, qmax, rows, (int32_t)st.order[t])) badR = true; }
 	wsync();
-	STRIP_TICK(); // 4: phase R
-	if (__any(badR)) { if (own) { escNow = true; own = false; } } // (a codeword the decoders reject: malformed -- every record of the strip is decoded again by the escape path, which reports it)
+	STRIP_TICK(); // 4: sort + phase R
+	if (__any(badR)) { // (a codeword the decoders reject: malformed -- every record of the strip is decoded again by the escape path, which reports it)
+#pragma unroll
+		for (int k = 0; k < KREC; k++) if (own[k]) { escNow[k] = true; own[k] = false; }
+	}
 	else {
 		// ---- phase X: intervals, one lane each; the long ones by the whole wave
 		for (int32_t j0 = 0; j0 < nIvAll; j0 += 64) {
@@ -178,13 +233,14 @@ __global__ void __launch_bounds__(64) k_strip(GraphDev g, RangeView v, const int
 	}
 	STRIP_TICK(); // 5: phase X
 	// ---- the records this strip leaves to the cooperative kernel
-	{
-		const unsigned long long em = __ballot(escNow);
+#pragma unroll
+	for (int k = 0; k < KREC; k++) {
+		const unsigned long long em = __ballot(escNow[k]);
 		if (em) {
 			int32_t k0 = 0;
 			if (lane == 0) k0 = atomicAdd(&escCtl[0], __popcll(em));
 			k0 = __shfl(k0, 0, 64);
-			if (escNow) { const int32_t k = k0 + __popcll(em & ((1ull << lane) - 1)); if (k < escCap) esc[k] = s; else atomicOr(err, E_FORMAT); }
+			if (escNow[k]) { const int32_t at = k0 + __popcll(em & ((1ull << lane) - 1)); if (at < escCap) esc[at] = a + k * 64 + lane; else atomicOr(err, E_FORMAT); }
 		}
 	}
 	if (tSample && lane == 0) { atomicAdd(&g.stats[32 + 15], 1ull); atomicAdd(&g.stats[32 + 14], (unsigned long long)n); atomicAdd(&g.stats[32 + 13], (unsigned long long)nSeg); atomicAdd(&g.stats[32 + 12], (unsigned long long)(nSeg - nShort)); atomicAdd(&g.stats[32 + 11], (unsigned long long)nIvAll); }

@@ -46,17 +46,25 @@
 namespace bvs {
 
 // ---- geometry ----------------------------------------------------------------------------------------------------------
-constexpr int WPOOL_WORDS = 2048;   // LDS pool of a wave: 8 KB (20 waves per CU)
-constexpr int WIN_MAX_WORDS = 1152; // at most this much stream is staged (36 Kbit); a record that overhangs it escapes
+// A wave is issue-bound, not latency-bound, once a CU holds a dozen of them (measured: 20 waves per CU retire one instruction
+// every 2.4 cycles per SIMD): what a strip costs is the number of wave-instructions it executes, and that is set by how many
+// lanes have work in each loop.  A strip therefore holds up to KREC records per lane -- phase S runs KREC passes of 64
+// records --, so that the fixed work of a strip, its anchor / chain phases and the rounds of phase R (segments sorted by length)
+// are shared by ~200 records instead of ~40.
+constexpr int KREC = 4;             // records per lane
+constexpr int WPOOL_WORDS = 3584;   // LDS pool of a wave: 14 KB (11 waves per CU)
+constexpr int WIN_MAX_WORDS = 2048; // at most this much stream is staged (64 Kbit); a record that overhangs it escapes
 // A strip is the set of slots s whose weight(s) = bits(s) + NODE_W * s + ARC_W * rowstart(s) falls into one window of SPAN_W:
 // at most STRIP_NODES records, at most SPAN_W bits of record starts, at most SPAN_W / ARC_W arcs (plus the last row).
-constexpr int64_t SPAN_W = 16384;
-constexpr int NODE_W = 260, ARC_W = 4;
-constexpr int STRIP_NODES = (int)(SPAN_W / NODE_W) + 1; // 64: one lane per record
+constexpr int64_t SPAN_W = 131072;
+constexpr int NODE_W = 514, ARC_W = 2;
+constexpr int STRIP_NODES = (int)(SPAN_W / NODE_W) + 1; // 256: KREC records per lane
+static_assert(STRIP_NODES <= 64 * KREC, "a lane holds KREC records");
 constexpr int STRIP_MAX_DEFAULT = 512; // records with more successors are not strip work (cooperative kernels)
 constexpr int SEG_BITS = 256, SEG_SHORT_BITS = 384, RUNIN_BITS = 192;
 constexpr int MAX_BLOCKS = 1023, MAX_INTERVALS = 1023; // per record; more: escape
 constexpr int LONG_INTERVAL = 48;   // intervals at least this long are expanded by the whole wave
+constexpr int SORT_BINS = 16;       // phase R takes the segments longest first: bins of 4 codewords
 
 BVS_HD uint32_t clz32(uint32_t x) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -156,6 +164,7 @@ template <class U32P, class U16P, class I32P> struct StripT {
 	U32P seg_out;             // row position of the record's extras + index of the segment's first residual; phase A: end of its last codeword
 	U16P seg_cnt, seg_i0;     // codewords in the segment; index of its first residual in the section (bit 15: last segment of the section)
 	U16P seg_ivb, seg_ive;    // the record's slice of the interval arena
+	U16P order;               // the segments in the order phase R takes them (longest first)
 	// interval arena
 	I32P iv_left;             // left end
 	U32P iv_out;              // row position of the record's extras
@@ -163,18 +172,20 @@ template <class U32P, class U16P, class I32P> struct StripT {
 	int32_t segCap, ivCap;
 };
 constexpr uint16_t SEG_LAST = 0x8000;
-struct StripLayout { int nw, oWin, oSeg, oIv, segCap, ivCap; };
-// words [0, nw) the stream; then the segment table (5 words per entry) and the interval arena (4 words per entry, the last half word unused)
+struct StripLayout { int nw, oWin, oSeg, oIv, oOrd, segCap, ivCap; };
+// words [0, nw) the stream; then the segment table (5 words per entry + half a word in the order list) and the interval arena
+// (4 words per entry, the last half word unused)
 BVS_HD StripLayout strip_layout(int64_t nwWant) {
 	StripLayout L;
 	L.nw = (int)(nwWant < (int64_t)WIN_MAX_WORDS ? nwWant : (int64_t)WIN_MAX_WORDS) & ~3;
 	if (L.nw < 8) L.nw = 8;
 	L.oWin = 0;
 	const int rest = WPOOL_WORDS - L.nw;
-	const int cap = (rest / 9) & ~1; // as many segments as intervals
+	const int cap = ((rest * 2) / 19) & ~1; // as many segments (5.5 words) as intervals (4 words)
 	L.segCap = cap; L.ivCap = cap;
 	L.oSeg = L.nw;
-	L.oIv = L.oSeg + 5 * cap;
+	L.oOrd = L.oSeg + 5 * cap;
+	L.oIv = L.oOrd + cap / 2;
 	return L;
 }
 template <class S, class PoolP> BVS_HD void strip_bind(S &st, PoolP pool, const StripLayout &L) {
@@ -184,6 +195,7 @@ template <class S, class PoolP> BVS_HD void strip_bind(S &st, PoolP pool, const 
 	st.seg_out = (decltype(st.seg_out))(pool + L.oSeg + 2 * L.segCap);
 	st.seg_cnt = (decltype(st.seg_cnt))(pool + L.oSeg + 3 * L.segCap);
 	st.seg_i0 = st.seg_cnt + L.segCap; st.seg_ivb = st.seg_i0 + L.segCap; st.seg_ive = st.seg_ivb + L.segCap;
+	st.order = (decltype(st.order))(pool + L.oOrd);
 	st.iv_left = (decltype(st.iv_left))(pool + L.oIv);
 	st.iv_out = (decltype(st.iv_out))(pool + L.oIv + L.ivCap);
 	st.iv_len = (decltype(st.iv_len))(pool + L.oIv + 2 * L.ivCap);

@@ -125,7 +125,7 @@ struct bvg_graph {
 	DevBuf plist, pkeys, pkey16;
 	int tile = -1;       // -1: automatic (see enqueue_decode); BVGPU_TILE=0: never; BVGPU_TILE=1: short records decoded from contiguous tiles of the stream (k_parse_tile) instead of the bin-sorted parse list (k_parse_list)
 	DevBuf tilebounds;
-	int lean = 1;        // BVGPU_LEAN=0: the one-lane decoder merges with its first formulation (one successor per iteration: parse_node_lw)
+	int lean = 0;        // BVGPU_LEAN=1: the one-lane decoder with an inner loop per interval and 4-byte stores (parse_node_lw2; measured 1.3x slower: divergent inner loops)
 	int strip = 0;       // BVGPU_STRIP=1: the strip kernel (bv_strip.hip) instead of the bin-sorted one-lane decoder for the records below the wave class
 	int32_t strip_max = 0; // records with fewer successors are strip work (BVGPU_STRIP_MAX; 0: the kernel's default)
 	DevBuf stripbounds, esclist;
