@@ -4,7 +4,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ["BVGPU_STATS"] = "1"
 os.environ.setdefault("BVGPU_OVERLAP", "0")
-os.environ.setdefault("BVGPU_STRIP", "1")
 import numpy as np, torch, bench
 import __graft_entry__ as ge
 ge.build()

@@ -512,7 +512,7 @@ __global__ void __launch_bounds__(TPB) k_scatter_keys(int32_t cnt, const uint16_
 // with fewer than COPY_BIG_MIN by one wave each (k_copy_mid), longer ones by a 1024-thread group each (k_copy_big).
 // A lane-serial merge of a long row would be the tail of the whole scan.
 constexpr int COPY_BIG_MIN = 1024;
-constexpr int COPY2_BLOCKS_ = 16; // (= COPY2_BLOCKS, defined with copy_node2)
+constexpr int COPY2_BLOCKS_ = 16; // (= 2 * COPY2_RUNS words per lane, defined with copy_node2)
 // class of row s at this level: 0 nothing to do, 1 one lane, 2 one wave, 3 one group
 __device__ __forceinline__ int copy_class(const RangeView &v, const int32_t *__restrict__ depth, int32_t level, int32_t s, int32_t midMin, int32_t bigMin) {
 	if (level >= MAXLVL - 1 && depth[s] != level) return 0; // shared overflow bucket
@@ -1054,6 +1054,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? COOP1_MINWAVES : COOPG_MINW
 // extras read index: k = (#copied so far) + (j - copied) <= j.
 template <int DEF>
 __device__ __forceinline__ void copy_node(const GraphDev &g, int32_t x, int32_t d, int64_t dref, int32_t *__restrict__ row, const int32_t *__restrict__ src, int *__restrict__ err) {
+	if (g.dbg & 1024) return; // (timing experiment)
 	BitReader br;
 	br.init(g.bits, g.nwords);
 	br.seek((uint64_t)g.offsets[x]);
@@ -1071,6 +1072,7 @@ __device__ __forceinline__ void copy_node(const GraphDev &g, int32_t x, int32_t 
 	}
 	if (!(bc & 1)) copied += dref - total;
 	if (copied > d) return;
+	if (g.dbg & 2048) return; // (timing experiment)
 	br.seek(blocksPos);
 
 	int64_t i = 0;      // index in the referent row
@@ -1094,34 +1096,13 @@ __device__ __forceinline__ void copy_node(const GraphDev &g, int32_t x, int32_t 
 	if (br.err) atomicOr(err, br.err);
 }
 
-// The same merge with fewer dependent loads (round 3).  copy_node reads the referent's ids and the row's extras one 4-byte
-// load at a time, each depending on the previous compare, and walks the block list twice through the word-by-word reader: a
-// lane merges ~1 id per microsecond, all of it latency, and the kernel already runs at full occupancy (40 VGPRs).  Here both
-// id streams are read in 16-byte chunks (one dependent load per four ids), the merged ids leave in 16-byte stores, and the
-// block lengths of the first walk are kept in the lane's LDS column for the merge (lists of up to COPY2_BLOCKS codes; a row
-// with a longer list takes copy_node).  Everything is sized to stay at 64 VGPRs: a first version with 64-bit indices and the
-// prefetching reader needed 111 and was slower than copy_node -- in a latency-bound kernel occupancy is what hides the loads.
-// Same in-place argument as copy_node: ids are read earlier and written later than there, never the other way round.
-constexpr int COPY2_BLOCKS = 16;
-struct __attribute__((packed, aligned(4))) Int4u { int32_t x, y, z, w; }; // a 16-byte access that only promises 4-byte alignment
-struct IdChunks { // sequential reader of ids p[0 .. n) in chunks of four
-	const int32_t *__restrict__ p;
-	int32_t n, base;
-	int32_t v0, v1, v2, v3;
-	__device__ __forceinline__ void init(const int32_t *p_, int32_t n_) { p = p_; n = n_; base = -4; v0 = v1 = v2 = v3 = 0; }
-	__device__ __forceinline__ int32_t get(int32_t i) {
-		const int32_t b = i & ~3;
-		if (b != base) {
-			base = b;
-			// (the last chunk of a row is read from four ids before its end instead of past it: rows shorter than four take single loads)
-			if (b + 4 <= n) { const Int4u t = *(const Int4u *)(p + b); v0 = t.x; v1 = t.y; v2 = t.z; v3 = t.w; }
-			else if (n >= 4) { const Int4u t = *(const Int4u *)(p + n - 4); const int sh = b + 4 - n; v0 = sh == 1 ? t.y : sh == 2 ? t.z : t.w; v1 = sh == 1 ? t.z : t.w; v2 = t.w; v3 = 0; }
-			else { v0 = b < n ? p[b] : 0; v1 = b + 1 < n ? p[b + 1] : 0; v2 = b + 2 < n ? p[b + 2] : 0; v3 = 0; }
-		}
-		const int k = i & 3;
-		return k == 0 ? v0 : k == 1 ? v1 : k == 2 ? v2 : v3;
-	}
-};
+// The same merge as ONE flat loop (round 3).  copy_node nests three loops whose trip counts differ from lane to lane (blocks, ids of
+// a block, extras below an id): a wave executes the union of its lanes' paths, and the merge proper was 75-87 % of k_copy_list's
+// time although the kernel runs at full occupancy (measured by returning early: list + class 27 us, block walk +39 us, merge +203 us
+// per level on C2).  Here the block list is walked once into a short table of copied runs (first index in the referent, length) in
+// the lane's LDS column, and the merge is a single loop that emits exactly one id per iteration for every lane: the smaller of the
+// next copied id and the next extra.  Rows with more than COPY2_RUNS runs take copy_node.  Same in-place argument as there.
+constexpr int COPY2_RUNS = 8;
 template <int DEF>
 __device__ __forceinline__ void copy_node2(const GraphDev &g, int32_t x, int32_t d, int64_t dref64, int32_t *__restrict__ row, const int32_t *__restrict__ src, uint32_t *ldsCol, int *__restrict__ err) {
 	BitReader br;
@@ -1130,46 +1111,37 @@ __device__ __forceinline__ void copy_node2(const GraphDev &g, int32_t x, int32_t
 	(void)Fields<DEF>::outdegree(br, g);
 	(void)Fields<DEF>::reference(br, g);
 	const uint64_t bc64 = Fields<DEF>::block_count(br, g);
-	if (bc64 > (uint64_t)COPY2_BLOCKS || dref64 > 0x7fffffff) { copy_node<DEF>(g, x, d, dref64, row, src, err); return; }
+	if (bc64 > (uint64_t)(2 * COPY2_RUNS - 2) || dref64 > 0x7fffffff) { copy_node<DEF>(g, x, d, dref64, row, src, err); return; } // (at most COPY2_RUNS - 1 listed copy blocks and the implicit one)
 	const int32_t dref = (int32_t)dref64, bc = (int32_t)bc64;
 	if (bc > dref + 1) return; // flagged in k_parse
-	int32_t total = 0, copied = 0;
+	int32_t total = 0, copied = 0, nr = 0;
 	for (int32_t b = 0; b < bc; b++) {
 		int64_t len;
 		if (!block_len_ok(Fields<DEF>::block(br, g), b == 0, total, dref, len)) return; // flagged by the parse kernel
-		ldsCol[b * TPB] = (uint32_t)len;
+		if (!(b & 1) && len > 0) { ldsCol[(2 * nr) * TPB] = (uint32_t)total; ldsCol[(2 * nr + 1) * TPB] = (uint32_t)len; nr++; copied += (int32_t)len; }
 		total += (int32_t)len;
-		if (!(b & 1)) copied += (int32_t)len;
 	}
-	if (!(bc & 1)) copied += dref - total;
-	if (copied > d) return;
+	if (!(bc & 1) && dref > total) { ldsCol[(2 * nr) * TPB] = (uint32_t)total; ldsCol[(2 * nr + 1) * TPB] = (uint32_t)(dref - total); nr++; copied += dref - total; } // implicit last block: the rest of the referent
 	if (br.err) atomicOr(err, br.err);
-
-	IdChunks rs, ex;
-	rs.init(src, dref);
-	ex.init(row, d);
-	int32_t i = 0;      // index in the referent row
-	int32_t k = 0;      // write index
-	int32_t j = copied; // extras read index
-	int32_t ev = j < d ? ex.get(j) : 0;
-	int32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0; // the last ids merged: stored four at a time
-	auto put = [&](int32_t val) {
-		o0 = o1; o1 = o2; o2 = o3; o3 = val; k++;
-		if ((k & 3) == 0) { Int4u t; t.x = o0; t.y = o1; t.z = o2; t.w = o3; *(Int4u *)(row + k - 4) = t; }
-	};
-	for (int32_t b = 0; b <= bc; b++) {
-		const int32_t len = b < bc ? (int32_t)ldsCol[b * TPB] : dref - i; // implicit last block: the rest of the referent
-		if (b & 1) { i += len; continue; } // skip block
-		for (int32_t t = 0; t < len && i < dref && k < d; t++) { // (the bounds hold by the checks above: belt and braces)
-			const int32_t cv = rs.get(i++);
-			while (j < d && ev < cv && k < d) { put(ev); j++; if (j < d) ev = ex.get(j); }
-			if (j < d && ev == cv) { j++; if (j < d) ev = ex.get(j); } // equal heads emitted once (never in a valid file)
-			if (k < d) put(cv);
+	if (copied > d || copied == 0) return; // (copied == 0: the extras are the row)
+	int32_t r = 0, ri = (int32_t)ldsCol[0], rl = (int32_t)ldsCol[TPB]; // current run: next index in the referent, ids left
+	int32_t j = copied, k = 0;
+	int32_t cv = src[ri], ev = j < d ? row[j] : 0x7fffffff;
+	bool haveC = true;
+	while (haveC && k < d) { // one id per iteration: the write index never overtakes the extras read index (k <= j)
+		const bool takeE = j < d && ev < cv;
+		const int32_t out = takeE ? ev : cv;
+		if (takeE) { j++; ev = j < d ? row[j] : 0x7fffffff; }
+		else {
+			if (j < d && ev == cv) { j++; ev = j < d ? row[j] : 0x7fffffff; } // equal heads emitted once (never in a valid file)
+			ri++;
+			if (--rl == 0) { r++; haveC = r < nr; if (haveC) { ri = (int32_t)ldsCol[(2 * r) * TPB]; rl = (int32_t)ldsCol[(2 * r + 1) * TPB]; } }
+			if (haveC) cv = src[ri];
 		}
+		row[k++] = out;
 	}
-	// the ids still in the store buffer; the remaining extras row[j..d) are already in place when k == j; a malformed duplicate leaves a gap: pad with -1
-	{ const int rem = k & 3; if (rem == 3) { row[k - 3] = o1; row[k - 2] = o2; row[k - 1] = o3; } else if (rem == 2) { row[k - 2] = o2; row[k - 1] = o3; } else if (rem == 1) row[k - 1] = o3; }
-	if (k != j) { while (j < d) { row[k++] = ex.get(j); j++; } while (k < d) row[k++] = -1; }
+	// the remaining extras row[j..d) are already in place when k == j; a malformed duplicate leaves a gap: pad with -1
+	if (k != j) { while (j < d && k < d) { row[k++] = row[j++]; } while (k < d) row[k++] = -1; }
 }
 
 template <int DEF>
@@ -1620,7 +1592,7 @@ void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int
 		else hipLaunchKernelGGL(k_copy_mid<0>, dim3(1024), dim3(64 * COPY_MID_WAVES), 0, stMid, g, v, depth, midQ, ctl + 6, midCap, level, err);
 	}
 	if (stMid != st) (void)hipEventRecord(evMid, stMid);
-	const bool chunked = (g.dbg & 256) != 0; // BVGPU_DBG=256: the one-lane merge with 16-byte chunks (copy_node2; measured 15 % slower: the rows are short, the fixed cost per row is what counts)
+	const bool chunked = !(g.dbg & 256); // BVGPU_DBG=256: the nested-loop merge (copy_node) for every row, for A/B timing
 	if (def == 1 && chunked) hipLaunchKernelGGL((k_copy_list<1, true>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
 	else if (def == 2 && chunked) hipLaunchKernelGGL((k_copy_list<2, true>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
 	else if (chunked) hipLaunchKernelGGL((k_copy_list<0, true>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);

@@ -89,7 +89,7 @@ int32_t strip_count(int64_t bitSpan, int32_t cnt, int64_t arcsBound);
 int32_t strip_max_default();
 void launch_strip_bounds(const GraphDev &g, const RangeView &v, int32_t ntiles, int32_t *tb, int32_t *escCtl, int *err, hipStream_t st);
 constexpr int CTL_ESC = 24; // ctl[CTL_ESC] = records the strip kernel left to the cooperative kernel, ctl[CTL_ESC + 2] = head of that queue
-void launch_strips(const GraphDev &g, int def, const RangeView &v, const int32_t *tb, int32_t ntiles, int32_t stripMax, int32_t *esc, int32_t *escCtl, int32_t escCap, int *err, hipStream_t st);
+void launch_strips(const GraphDev &g, int def, const RangeView &v, const int32_t *tb, int32_t ntiles, int32_t stripMin, int32_t stripMax, int32_t *esc, int32_t *escCtl, int32_t escCap, int *err, hipStream_t st);
 int64_t hash_chunks(int32_t cnt, int64_t arcs);
 void launch_hash(int32_t from, int32_t cnt, int64_t arcs, const int64_t *rowptr, const int32_t *succ, uint32_t *A, uint32_t *B, int32_t *bounds, int32_t *hash, hipStream_t st);
 

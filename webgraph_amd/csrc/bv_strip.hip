@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(256) k_strip_bounds(const int64_t *__restrict_
 struct RowsMasked { int32_t *p; uint32_t mask; __device__ __forceinline__ int32_t &operator[](uint32_t i) const { return p[i & mask]; } }; // mask = ~0; BVGPU_DBG=512 (timing experiment, wrong results): every store lands in the strip's first 64 ids
 
 template <int ZK>
-__global__ void __launch_bounds__(64) k_strip(GraphDev g, RangeView v, const int32_t *__restrict__ tb, int32_t stripMax, int32_t *__restrict__ esc,
+__global__ void __launch_bounds__(64) k_strip(GraphDev g, RangeView v, const int32_t *__restrict__ tb, int32_t stripMin, int32_t stripMax, int32_t *__restrict__ esc,
                                               int32_t *__restrict__ escCtl, int32_t escCap, int *__restrict__ err) {
 	__shared__ __attribute__((aligned(16))) uint32_t pool_[WPOOL_WORDS];
 	__shared__ int32_t hist_[SORT_BINS + 1];
@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(64) k_strip(GraphDev g, RangeView v, const int
 		const int32_t d = have ? v.outd[s] : 0;
 		const int64_t o0 = have ? g.offsets[v.lo + s] : 0, o1 = have ? g.offsets[v.lo + s + 1] : 0;
 		const int64_t rs = have ? v.rowstart[s] : 0, rsn = have ? v.rowstart[s + 1] : 0;
-		own[k] = d > 0 && d < stripMax; escNow[k] = false; isLong[k] = false; m[k] = 0; eFirst[k] = 0;
+		own[k] = d >= stripMin && d > 0 && d < stripMax; escNow[k] = false; isLong[k] = false; m[k] = 0; eFirst[k] = 0;
 		const int32_t r = own[k] ? (int32_t)v.ref[s] : 0;
 		drefk[k] = r > 0 ? (s - r >= 0 ? (int64_t)v.outd[s - r] : -1) : 0; // (referents before the view: k_apply_need clears such references)
 		dk[k] = d; rk[k] = r; x[k] = v.lo + s;
@@ -255,10 +255,10 @@ int32_t strip_count(int64_t bitSpan, int32_t cnt, int64_t arcsBound) {
 void launch_strip_bounds(const GraphDev &g, const RangeView &v, int32_t ntiles, int32_t *tb, int32_t *escCtl, int *err, hipStream_t st) {
 	hipLaunchKernelGGL(k_strip_bounds, dim3((unsigned)(((int64_t)ntiles + 1 + 255) / 256)), dim3(256), 0, st, g.offsets, v.rowstart, v.lo, v.cnt, ntiles, tb, escCtl, err);
 }
-void launch_strips(const GraphDev &g, int def, const RangeView &v, const int32_t *tb, int32_t ntiles, int32_t stripMax, int32_t *esc, int32_t *escCtl, int32_t escCap, int *err, hipStream_t st) {
+void launch_strips(const GraphDev &g, int def, const RangeView &v, const int32_t *tb, int32_t ntiles, int32_t stripMin, int32_t stripMax, int32_t *esc, int32_t *escCtl, int32_t escCap, int *err, hipStream_t st) {
 	if (v.cnt <= 0 || ntiles <= 0) return;
-	if (def == 1) hipLaunchKernelGGL(k_strip<3>, dim3(ntiles), dim3(64), 0, st, g, v, tb, stripMax, esc, escCtl, escCap, err);
-	else hipLaunchKernelGGL(k_strip<0>, dim3(ntiles), dim3(64), 0, st, g, v, tb, stripMax, esc, escCtl, escCap, err);
+	if (def == 1) hipLaunchKernelGGL(k_strip<3>, dim3(ntiles), dim3(64), 0, st, g, v, tb, stripMin, stripMax, esc, escCtl, escCap, err);
+	else hipLaunchKernelGGL(k_strip<0>, dim3(ntiles), dim3(64), 0, st, g, v, tb, stripMin, stripMax, esc, escCtl, escCap, err);
 }
 int32_t strip_max_default() { return STRIP_MAX_DEFAULT; }
 

@@ -126,8 +126,8 @@ struct bvg_graph {
 	int tile = -1;       // -1: automatic (see enqueue_decode); BVGPU_TILE=0: never; BVGPU_TILE=1: short records decoded from contiguous tiles of the stream (k_parse_tile) instead of the bin-sorted parse list (k_parse_list)
 	DevBuf tilebounds;
 	int lean = 0;        // BVGPU_LEAN=1: the one-lane decoder with an inner loop per interval and 4-byte stores (parse_node_lw2; measured 1.3x slower: divergent inner loops)
-	int strip = 0;       // BVGPU_STRIP=1: the strip kernel (bv_strip.hip) instead of the bin-sorted one-lane decoder for the records below the wave class
-	int32_t strip_max = 0; // records with fewer successors are strip work (BVGPU_STRIP_MAX; 0: the kernel's default)
+	int strip = 0;       // BVGPU_STRIP=1: the strip kernel (bv_strip.hip) instead of the one-wave cooperative decoder (k_parse_big<1>) for the records above strip_min successors
+	int32_t strip_min = 256, strip_max = 0; // records with strip_min <= successors < strip_max are strip work (BVGPU_STRIP_MIN / BVGPU_STRIP_MAX; 0: up to the giant threshold)
 	DevBuf stripbounds, esclist;
 	int copy_big = 1;    // BVGPU_COPY_BIG=0: every row is copied by one lane
 	int parse_windows = 1; // BVGPU_PARSE_WINDOWS=0: the parse list is sorted by work bin over the whole range
@@ -226,8 +226,8 @@ int init_handle(bvg_graph *g) {
 	if (const char *e = getenv("BVGPU_TILE")) g->tile = atoi(e);
 	if (const char *e = getenv("BVGPU_STRIP")) g->strip = atoi(e);
 	if (const char *e = getenv("BVGPU_LEAN")) g->lean = atoi(e);
-	g->strip_max = bv::strip_max_default();
-	if (const char *e = getenv("BVGPU_STRIP_MAX")) g->strip_max = std::min(std::max(2, atoi(e)), 2048);
+	if (const char *e = getenv("BVGPU_STRIP_MIN")) g->strip_min = std::min(std::max(1, atoi(e)), 16384);
+	if (const char *e = getenv("BVGPU_STRIP_MAX")) g->strip_max = std::min(std::max(2, atoi(e)), 32768);
 	if (const char *e = getenv("BVGPU_WALK_TABLES")) g->walk_tables = atoi(e);
 	if (const char *e = getenv("BVGPU_IV_ARENA")) g->iv_arena = atoi(e);
 	if (const char *e = getenv("BVGPU_COPY_MID_MIN")) g->copy_mid_min = std::min(std::max(0, atoi(e)), 1024); // 0: no wave-per-row copy
@@ -393,12 +393,17 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 	const Staged &s = *g->st;
 	int32_t coopMin, giantMin;
 	pick_thresholds(g, estArcs, coopMin, giantMin);
-	// The strip kernel (default codings) takes every record below its threshold, whatever the job: its unit of work is a segment
-	// of a residual section, so a lane never decodes a long record alone and the wave class has nothing to protect the tail from.
-	const bool strips = g->strip != 0 && s.def != 0;
+	// Three classes of records (default codings): below strip_min successors one lane each, sorted into work bins (k_parse_list / k_parse_tile);
+	// from there up to the giant threshold the strip kernel (bv_strip.hip: a wave per strip of the stream, residual sections cut into
+	// segments -- 9x cheaper per record than the one-wave cooperative decoder, which it replaces; what does not fit a strip's LDS budget
+	// escapes to that decoder); the giant records a group of waves each.
+	const bool strips = g->strip != 0 && s.def != 0 && g->parse_lists && g->copy_lists;
+	int32_t stripLo = 0, stripHi = 0;
 	if (strips) {
-		coopMin = g->adaptive ? g->strip_max : std::min(g->strip_max, g->coop_min);
-		giantMin = std::max(giantMin, coopMin);
+		stripLo = g->adaptive ? g->strip_min : std::min(g->strip_min, g->coop_min);
+		stripHi = g->strip_max > 0 ? std::min(std::max(g->strip_max, stripLo), giantMin) : giantMin;
+		giantMin = std::max(giantMin, stripLo);
+		coopMin = stripLo;
 		v.coop_ptr = nullptr; // (k_pick_coop still ran: it zeroes the job's counters)
 	}
 	const int32_t W = s.info.window_size;
@@ -442,6 +447,19 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		const bool coop = coopMin < 0x7fffffff;
 		const bool ovl = g->overlap && !g->profile; // per-kernel timing needs the kernels one after the other
 		v.coop_min = coop ? coopMin : 0x7fffffff;
+		const int32_t waveMin = strips ? stripHi : coopMin; // (with strips reaching the giant threshold the one-wave class is empty: it only serves the strips' escape list)
+		int32_t nstrips = 0;
+		if (strips) {
+			const uint64_t haloRoom = std::min<uint64_t>(v.halo_cap, (uint64_t)arcsBound);
+			const int64_t arcsJob = (int64_t)std::min<uint64_t>((uint64_t)arcsBound, v.succ_cap + (v.nh ? haloRoom : 0));
+			nstrips = bv::strip_count(s.h_offsets[(size_t)v.lo + v.cnt] - s.h_offsets[(size_t)v.lo], v.cnt, arcsJob);
+			if (!g->stripbounds.need(sizeof(int32_t) * ((size_t)nstrips + 2)) || !g->esclist.need(sizeof(int32_t) * (size_t)v.cnt)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
+		}
+		auto launchStrips = [&](hipStream_t st) { // needs the row starts (the scan): strip bounds, the strips, then what a strip could not take -- no room in its LDS budget, a codeword of more than 64 bits, a malformed record -- by one wave each
+			bv::launch_strip_bounds(gd, v, nstrips, g->stripbounds.as<int32_t>(), ctl + bv::CTL_ESC, derr, st);
+			bv::launch_strips(gd, s.def, v, g->stripbounds.as<int32_t>(), nstrips, stripLo, stripHi, g->esclist.as<int32_t>(), ctl + bv::CTL_ESC, v.cnt, derr, st);
+			bv::launch_parse_waves(gd, s.def, v, g->esclist.as<int32_t>(), ctl + bv::CTL_ESC, g->arena.p, arenaCap, std::min(g->coop_waves, 2048), derr, st);
+		};
 		if (!coop) v.coop_ptr = nullptr;
 		g->last_giant_min = giantMin;
 		// Three things run next to each other from here on (unless profiling serialises them):
@@ -459,8 +477,8 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		// in the lane class -- its share (by bits) of the staged records with >= 128 successors fits the wave class, so that
 		// k_pick_coop will pick 128 --: neighbouring short records are alike, a tile's lanes stay even, and the coalesced tile
 		// kernel is 20 % faster than the bins (cnr-2000 x 30: 0.42 against 0.53 ms); with a heavy-tailed lane class it is 2.6x slower (C2).
-		int tileVariant = g->tile > 0 && !strips ? g->tile : 0;
-		if (!strips && g->tile < 0 && g->adaptive && v.coop_ptr && s.deg_counts[0] >= 0 && g->parse_lists) {
+		int tileVariant = g->tile > 0 ? g->tile : 0;
+		if (g->tile < 0 && g->adaptive && (v.coop_ptr || strips) && s.deg_counts[0] >= 0 && g->parse_lists) {
 			const double share = (double)(s.h_offsets[(size_t)v.lo + v.cnt] - s.h_offsets[(size_t)v.lo]) / (double)std::max<int64_t>(s.h_offsets[(size_t)s.node_hi] - s.h_offsets[(size_t)s.stage_lo], 1);
 			if ((double)s.deg_counts[0] * share <= (double)COOP_BUDGET * (share > 0.999 ? 1.0 : 0.8)) tileVariant = 1; // (a sub-range: an estimate, with a margin)
 		}
@@ -472,8 +490,8 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			bv::launch_tile_bounds(gd, v.lo, v.cnt, ntiles, g->tilebounds.as<int32_t>(), ovl && hdrEvent ? g->sideA : g->stream);
 			if (ovl && hdrEvent) HIPCHK(g, hipEventRecord(g->evP, g->sideA));
 		}
-		const bool earlyList = !tiles && !strips && g->parse_lists && ovl && hdrEvent;
-		if (!tiles && !strips && g->parse_lists) {
+		const bool earlyList = !tiles && g->parse_lists && ovl && hdrEvent;
+		if (!tiles && g->parse_lists) {
 			if (!g->plist.need(sizeof(int32_t) * (size_t)v.cnt) || !g->pkeys.need(3 * (bv::NKEYS + 1) * sizeof(int32_t)) || !g->pkey16.need(sizeof(uint16_t) * (size_t)v.cnt)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
 			pKeyBase = g->pkeys.as<int32_t>() + (bv::NKEYS + 1);
 		}
@@ -487,7 +505,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			if (early) { // side B: classification and sort of the long records next to the scan (they need the outdegrees only)
 				HIPCHK(g, hipStreamWaitEvent(side_b(g), g->evHdr, 0));
 				HIPCHK(g, hipMemsetAsync(ctl, 0, 4 * sizeof(int32_t), side_b(g)));
-				bv::launch_classify(v.cnt, v.outd, v.coop_ptr, coopMin, giantMin, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, side_b(g));
+				bv::launch_classify(v.cnt, v.outd, v.coop_ptr, waveMin, giantMin, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, side_b(g));
 				HIPCHK(g, hipEventRecord(g->evC, side_b(g)));
 			}
 			HIPCHK(g, hipEventRecord(g->evFork, g->stream));
@@ -499,11 +517,12 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 				hipLaunchKernelGGL(k_totals, dim3(1), dim3(1), 0, g->sideA, v.rowstart, v.nh, v.cnt, g->small.as<Small>(), v.coop_ptr, v.coop_min);
 			}
 			if (coop && !early) {
-				bv::launch_classify(v.cnt, v.outd, v.coop_ptr, coopMin, giantMin, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, side_b(g));
+				bv::launch_classify(v.cnt, v.outd, v.coop_ptr, waveMin, giantMin, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, side_b(g));
 				HIPCHK(g, hipEventRecord(g->evC, side_b(g)));
 			}
 		}
 		// the long records first on both side streams: giants on B, the wave class on A ...
+		if (ovl && strips) launchStrips(g->sideA);
 		if (ovl && coop) {
 			HIPCHK(g, hipStreamWaitEvent(g->sideA, g->evC, 0));
 			bv::launch_parse_big(gd, s.def, v, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, g->giant_groups, derr, side_b(g), g->sideA); // (giants, big)
@@ -512,32 +531,22 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		// ... then, behind the wave class, the chain depth of every record + per-level lists (node order inside a level) +
 		// copy queues: only the copy pass needs them, and launched first they would sit in front of the wave class while
 		// the one-lane kernel holds every CU
-		if (W > 0) bv::launch_build_lists(gd, v, ~0ull, 1, g->depth.as<int32_t>(), g->key16.as<uint16_t>(), hist, keyBase, cursor, g->lvlist.as<int32_t>(),
+		if (W > 0) bv::launch_build_lists(gd, v, ~0ull, getenv("BVGPU_COPY_BINS") ? 0 : 1, g->depth.as<int32_t>(), g->key16.as<uint16_t>(), hist, keyBase, cursor, g->lvlist.as<int32_t>(),
 		                                  g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->maxdepth, stLists,
 		                                  g->copy_lists ? g->copyq.as<int32_t>() : nullptr, bigCap, g->copyq.as<int32_t>() + bigCap, midCap, g->copy_mid_min, g->copy_big != 0);
 		if (ovl) HIPCHK(g, hipEventRecord(g->evA, g->sideA));
-		if (!tiles && !strips && g->parse_lists && !earlyList)
+		if (!tiles && g->parse_lists && !earlyList)
 			bv::launch_build_lists(gd, v, ~0ull, g->parse_windows ? 6 : 2, nullptr, g->pkey16.as<uint16_t>(), g->pkeys.as<int32_t>(), pKeyBase, pKeyBase + (bv::NKEYS + 1), g->plist.as<int32_t>(),
 			                       g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->pad, g->stream);
 		if (earlyList || (tiles && ovl && hdrEvent)) HIPCHK(g, hipStreamWaitEvent(g->stream, g->evP, 0));
-		if (coop && !ovl) bv::launch_classify(v.cnt, v.outd, v.coop_ptr, coopMin, giantMin, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, g->stream);
+		if (coop && !ovl) bv::launch_classify(v.cnt, v.outd, v.coop_ptr, waveMin, giantMin, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, g->stream);
 		mark(g, 3);
 		if (coop && !ovl) bv::launch_parse_giants(gd, s.def, v, g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->giant_groups, derr, g->stream);
 		mark(g, 4);
 		if (coop && !ovl) bv::launch_parse_waves(gd, s.def, v, g->biglist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, derr, g->stream);
+		if (strips && !ovl) launchStrips(g->stream);
 		mark(g, 5);
-		if (strips) {
-			// strips of the stream, each decoded by one work-group entirely in LDS (bv_strip.hip); the bounds need the row starts
-			const uint64_t haloRoom = std::min<uint64_t>(v.halo_cap, (uint64_t)arcsBound);
-			const int64_t arcsJob = (int64_t)std::min<uint64_t>((uint64_t)arcsBound, v.succ_cap + (v.nh ? haloRoom : 0));
-			const int32_t nstrips = bv::strip_count(s.h_offsets[(size_t)v.lo + v.cnt] - s.h_offsets[(size_t)v.lo], v.cnt, arcsJob);
-			if (!g->stripbounds.need(sizeof(int32_t) * ((size_t)nstrips + 2)) || !g->esclist.need(sizeof(int32_t) * (size_t)v.cnt)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
-			bv::launch_strip_bounds(gd, v, nstrips, g->stripbounds.as<int32_t>(), ctl + bv::CTL_ESC, derr, g->stream);
-			bv::launch_strips(gd, s.def, v, g->stripbounds.as<int32_t>(), nstrips, coopMin, g->esclist.as<int32_t>(), ctl + bv::CTL_ESC, v.cnt, derr, g->stream);
-			// what a strip could not take (no room in its LDS budget, a codeword of more than 64 bits, a malformed record): one wave each
-			bv::launch_parse_waves(gd, s.def, v, g->esclist.as<int32_t>(), ctl + bv::CTL_ESC, g->arena.p, arenaCap, std::min(g->coop_waves, 1024), derr, g->stream);
-		}
-		else if (tiles) bv::launch_parse_tile(gd, s.def, v, g->tilebounds.as<int32_t>(), ntiles, tileVariant, derr, g->stream);
+		if (tiles) bv::launch_parse_tile(gd, s.def, v, g->tilebounds.as<int32_t>(), ntiles, tileVariant, derr, g->stream);
 		else if (pKeyBase) {
 			bv::launch_parse_list(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, g->level_blocks, derr, g->stream, g->iv_arena ? g->arena.p : nullptr, arenaCap, g->lean != 0);
 		}
