@@ -237,7 +237,7 @@ def test_sharded_scan_equals_whole(cnr_gpu, cnr_oracle):
 
 KNOBS = [
     {"BVGPU_OVERLAP": "0"}, {"BVGPU_COOP_MIN": "16", "BVGPU_GIANT_MIN": "64"}, {"BVGPU_COOP_MIN": "2147483647"},
-    {"BVGPU_PARSE_LISTS": "0", "BVGPU_COPY_LISTS": "0"}, {"BVGPU_COPY_BIG": "0"}, {"BVGPU_WALK_TABLES": "0"}, {"BVGPU_IV_ARENA": "0", "BVGPU_TILE": "0"}, {"BVGPU_IV_ARENA": "1", "BVGPU_TILE": "0"},
+    {"BVGPU_COPY_BIG": "0"}, {"BVGPU_WALK_TABLES": "0"}, {"BVGPU_IV_ARENA": "0", "BVGPU_TILE": "0"}, {"BVGPU_IV_ARENA": "1", "BVGPU_TILE": "0"},
     # the contiguous-tile kernel (bv_tile.hpp): parse from one LDS image per tile
     {"BVGPU_TILE": "0"}, {"BVGPU_TILE": "1"}, {"BVGPU_TILE": "1", "BVGPU_COOP_MIN": "300", "BVGPU_GIANT_MIN": "4000"},
 ]

@@ -256,23 +256,6 @@ __global__ void __launch_bounds__(TPB) k_scan_apply(const int32_t *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------ chain depth
-__global__ void __launch_bounds__(TPB) k_depth(int32_t cnt, const uint16_t *__restrict__ ref, int32_t *__restrict__ depth,
-                                               int32_t *__restrict__ maxdepth) {
-	const int32_t s = blockIdx.x * TPB + threadIdx.x;
-	int32_t dd = 0;
-	if (s < cnt) {
-		int32_t y = s;
-		while (ref[y] > 0) { y -= ref[y]; dd++; } // ref[] is 0 for empty / unneeded nodes; y >= 0 was checked in k_headers / k_mark_halo
-		depth[s] = dd;
-	}
-	// one atomic per wave
-	int32_t m = dd;
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
-	// one atomic per wave at most, and none once the maximum is known (a stale read only costs an atomic)
-	if ((threadIdx.x & 63) == 0 && m > 0 && m > __builtin_nontemporal_load(maxdepth)) atomicMax(maxdepth, m);
-}
-
 __global__ void k_rebase(int32_t nh, int32_t cnt, const int64_t *__restrict__ rowstart, int64_t *__restrict__ out) {
 	const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (j <= (int64_t)(cnt - nh)) out[j] = rowstart[nh + j] - rowstart[nh];
@@ -373,22 +356,6 @@ __device__ __forceinline__ void parse_node(const GraphDev &g, int32_t x, int32_t
 	if (br.err | bi.err) atomicOr(err, br.err | bi.err);
 }
 
-template <int DEF>
-__global__ void __launch_bounds__(TPB) k_parse(GraphDev g, RangeView v, int *__restrict__ err) {
-	const int32_t s = blockIdx.x * TPB + threadIdx.x;
-	if (s >= v.cnt) return;
-	const int32_t d = v.outd[s];
-	if (d == 0 || d >= v.coopmin()) return; // long records are decoded by whole waves (k_parse_big)
-	const int32_t r = v.ref[s];
-	if (!v.fits(s)) { atomicOr(err, s >= v.nh ? E_CAP : E_HALO); return; }
-	parse_node<DEF>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), err);
-}
-
-// ------------------------------------------------------------------------------------------------ work lists
-// Records are decoded one reference-chain level at a time, and inside a level in order of their length in bits
-// (known from the offsets, no decoding needed), so that the 64 lanes of a wave get similar amounts of work.
-//   key(s) = level * NBIN + bin,  bin = half-octaves of the length above 16 bits (record_bin);  giants go to their own list.
-// Chain levels >= MAXLVL-1 share the last level's buckets and are swept once per level (rare: deep chains).
 __device__ __forceinline__ int32_t record_bin(uint64_t bitsLen) { // half-octave steps from 16 bits up: the lanes of a wave differ by < 1.5x
 	const int lg = 63 - __clzll((long long)(bitsLen | 1));
 	const int h = 2 * lg + (lg > 0 ? (int)((bitsLen >> (lg - 1)) & 1) : 0);
@@ -512,7 +479,6 @@ __global__ void __launch_bounds__(TPB) k_scatter_keys(int32_t cnt, const uint16_
 // with fewer than COPY_BIG_MIN by one wave each (k_copy_mid), longer ones by a 1024-thread group each (k_copy_big).
 // A lane-serial merge of a long row would be the tail of the whole scan.
 constexpr int COPY_BIG_MIN = 1024;
-constexpr int COPY2_BLOCKS_ = 16; // (= 2 * COPY2_RUNS words per lane, defined with copy_node2)
 // class of row s at this level: 0 nothing to do, 1 one lane, 2 one wave, 3 one group
 __device__ __forceinline__ int copy_class(const RangeView &v, const int32_t *__restrict__ depth, int32_t level, int32_t s, int32_t midMin, int32_t bigMin) {
 	if (level >= MAXLVL - 1 && depth[s] != level) return 0; // shared overflow bucket
@@ -520,19 +486,16 @@ __device__ __forceinline__ int copy_class(const RangeView &v, const int32_t *__r
 	if (!v.fits(s) || !v.fits(s - v.ref[s])) return 0; // E_CAP / E_HALO already raised by the parse kernel
 	return copy_class_of(v.outd[s], v.outd[s - v.ref[s]], midMin, bigMin);
 }
-template <int DEF> __device__ __forceinline__ void copy_node2(const GraphDev &g, int32_t x, int32_t d, int64_t dref, int32_t *__restrict__ row, const int32_t *__restrict__ src, uint32_t *ldsCol, int *__restrict__ err);
-template <int DEF, bool CHUNKED>
-__global__ void __launch_bounds__(TPB, CHUNKED ? 8 : 1) k_copy_list(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ list,
+template <int DEF>
+__global__ void __launch_bounds__(TPB) k_copy_list(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ list,
                                                    const int32_t *__restrict__ keyBase, int32_t level, int32_t midMin, int32_t bigMin, int *__restrict__ err) {
-	__shared__ uint32_t s_blk[CHUNKED ? COPY2_BLOCKS_ * TPB : 1]; // the block lengths of the row a lane is merging, [code][thread]
 	const int32_t bucket = min(level, MAXLVL - 1);
 	const int32_t lo = keyBase[bucket * NBIN], hi = keyBase[(bucket + 1) * NBIN];
 	for (int32_t idx = hi - 1 - (blockIdx.x * TPB + threadIdx.x); idx >= lo; idx -= gridDim.x * TPB) {
 		const int32_t s = list[idx];
 		if (copy_class(v, depth, level, s, midMin, bigMin) != 1) continue;
 		const int32_t r = v.ref[s];
-		if (CHUNKED) copy_node2<DEF>(g, v.lo + s, v.outd[s], (int64_t)v.outd[s - r], v.row(s), v.row(s - r), s_blk + threadIdx.x, err);
-		else copy_node<DEF>(g, v.lo + s, v.outd[s], (int64_t)v.outd[s - r], v.row(s), v.row(s - r), err);
+		copy_node<DEF>(g, v.lo + s, v.outd[s], (int64_t)v.outd[s - r], v.row(s), v.row(s - r), err);
 	}
 }
 
@@ -894,19 +857,16 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 		const unsigned long long tRow0 = tk;
 		CT(0);
 		const unsigned long long tWalk = tk - tRow0;
-#define ROWDBG() do { if (g.stats && (g.dbg & 128) && threadIdx.x == 0) { const unsigned long long tot_ = __builtin_readcyclecounter() - tRow0; atomicMax(&g.stats[min(level, 3) - 1], tot_); atomicMax(&g.stats[3], tWalk); } } while (0)
-		if (where == -2) { merge_row(cpos, delta, cval, cpos, (int32_t)copied, nKept); ROWDBG(); continue; } // (copied <= dref <= COPY_BIG_CAP, nKept <= COPY_BIG_CAP + 1)
+		if (where == -2) { merge_row(cpos, delta, cval, cpos, (int32_t)copied, nKept); continue; } // (copied <= dref <= COPY_BIG_CAP, nKept <= COPY_BIG_CAP + 1)
 		const int64_t cMaxRow = dref < (int64_t)d ? dref : (int64_t)d;
 		if (nKept > kMax || copied > cMaxRow) continue; // (cannot happen: the bounds above)
-		if (g.dbg & 32) { int32_t *gv = tabD + kMax, *gp = gv + cMaxRow; merge_row(tabK, tabD, gv, gp, (int32_t)copied, nKept); continue; } // (the element-wise merge on global tables, kept for A/B timing: BVGPU_DBG=32)
 		merge_row_stream(tabK, tabD, tabD + kMax, (int32_t)copied, nKept);
-		ROWDBG();
 #undef CT
 	}
 }
 
 // parse pass over a list sorted by work bin only (all chain levels together): 64 records of similar length per wave
-template <int DEF, int ARENA> // ARENA: 0 the interval section is read twice, 1 kept in a ring + the arena, 2 the same with the lean merge (parse_node_lw2)
+template <int DEF, bool ARENA>
 __global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, const int32_t *__restrict__ list, const int32_t *__restrict__ keyBase, int32_t binLo, int32_t binHi,
                                                     IvEntry *__restrict__ arena, int64_t arenaCap, int *__restrict__ err) {
 	__shared__ uint32_t lw[DEF ? (ARENA ? (LW_MAIN + 2 * LW_RING) * LW_STRIDE : LW_LDS_WORDS) : 1]; // lane-private stream windows, or one window and a ring of intervals (default codings)
@@ -927,8 +887,7 @@ __global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, con
 			// the record's slice of the interval arena (the same slices as the cooperative kernels': floor(rowstart / minInt), d / minInt + 1 entries)
 			const int64_t abase = g.minInt > 0 ? v.rowstart[s] / g.minInt : 0;
 			if (g.minInt > 0 && (abase < 0 || abase + d / g.minInt + 1 > arenaCap)) { atomicOr(err, E_FORMAT); continue; }
-			if (ARENA == 2) parse_node_lw2<DEF == 1 ? 3 : 0>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), lw, (int2 *)(arena + abase), err);
-			else parse_node_lw<DEF == 1 ? 3 : 0, true>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), lw, (int2 *)(arena + abase), err);
+			parse_node_lw<DEF == 1 ? 3 : 0, true>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), lw, (int2 *)(arena + abase), err);
 		}
 		else if (DEF) parse_node_lw<DEF == 1 ? 3 : 0, false>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), lw, nullptr, err);
 		else parse_node<DEF>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), err);
@@ -1054,7 +1013,6 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? COOP1_MINWAVES : COOPG_MINW
 // extras read index: k = (#copied so far) + (j - copied) <= j.
 template <int DEF>
 __device__ __forceinline__ void copy_node(const GraphDev &g, int32_t x, int32_t d, int64_t dref, int32_t *__restrict__ row, const int32_t *__restrict__ src, int *__restrict__ err) {
-	if (g.dbg & 1024) return; // (timing experiment)
 	BitReader br;
 	br.init(g.bits, g.nwords);
 	br.seek((uint64_t)g.offsets[x]);
@@ -1072,7 +1030,6 @@ __device__ __forceinline__ void copy_node(const GraphDev &g, int32_t x, int32_t 
 	}
 	if (!(bc & 1)) copied += dref - total;
 	if (copied > d) return;
-	if (g.dbg & 2048) return; // (timing experiment)
 	br.seek(blocksPos);
 
 	int64_t i = 0;      // index in the referent row
@@ -1096,68 +1053,6 @@ __device__ __forceinline__ void copy_node(const GraphDev &g, int32_t x, int32_t 
 	if (br.err) atomicOr(err, br.err);
 }
 
-// The same merge as ONE flat loop (round 3).  copy_node nests three loops whose trip counts differ from lane to lane (blocks, ids of
-// a block, extras below an id): a wave executes the union of its lanes' paths, and the merge proper was 75-87 % of k_copy_list's
-// time although the kernel runs at full occupancy (measured by returning early: list + class 27 us, block walk +39 us, merge +203 us
-// per level on C2).  Here the block list is walked once into a short table of copied runs (first index in the referent, length) in
-// the lane's LDS column, and the merge is a single loop that emits exactly one id per iteration for every lane: the smaller of the
-// next copied id and the next extra.  Rows with more than COPY2_RUNS runs take copy_node.  Same in-place argument as there.
-constexpr int COPY2_RUNS = 8;
-template <int DEF>
-__device__ __forceinline__ void copy_node2(const GraphDev &g, int32_t x, int32_t d, int64_t dref64, int32_t *__restrict__ row, const int32_t *__restrict__ src, uint32_t *ldsCol, int *__restrict__ err) {
-	BitReader br;
-	br.init(g.bits, g.nwords);
-	br.seek((uint64_t)g.offsets[x]);
-	(void)Fields<DEF>::outdegree(br, g);
-	(void)Fields<DEF>::reference(br, g);
-	const uint64_t bc64 = Fields<DEF>::block_count(br, g);
-	if (bc64 > (uint64_t)(2 * COPY2_RUNS - 2) || dref64 > 0x7fffffff) { copy_node<DEF>(g, x, d, dref64, row, src, err); return; } // (at most COPY2_RUNS - 1 listed copy blocks and the implicit one)
-	const int32_t dref = (int32_t)dref64, bc = (int32_t)bc64;
-	if (bc > dref + 1) return; // flagged in k_parse
-	int32_t total = 0, copied = 0, nr = 0;
-	for (int32_t b = 0; b < bc; b++) {
-		int64_t len;
-		if (!block_len_ok(Fields<DEF>::block(br, g), b == 0, total, dref, len)) return; // flagged by the parse kernel
-		if (!(b & 1) && len > 0) { ldsCol[(2 * nr) * TPB] = (uint32_t)total; ldsCol[(2 * nr + 1) * TPB] = (uint32_t)len; nr++; copied += (int32_t)len; }
-		total += (int32_t)len;
-	}
-	if (!(bc & 1) && dref > total) { ldsCol[(2 * nr) * TPB] = (uint32_t)total; ldsCol[(2 * nr + 1) * TPB] = (uint32_t)(dref - total); nr++; copied += dref - total; } // implicit last block: the rest of the referent
-	if (br.err) atomicOr(err, br.err);
-	if (copied > d || copied == 0) return; // (copied == 0: the extras are the row)
-	int32_t r = 0, ri = (int32_t)ldsCol[0], rl = (int32_t)ldsCol[TPB]; // current run: next index in the referent, ids left
-	int32_t j = copied, k = 0;
-	int32_t cv = src[ri], ev = j < d ? row[j] : 0x7fffffff;
-	bool haveC = true;
-	while (haveC && k < d) { // one id per iteration: the write index never overtakes the extras read index (k <= j)
-		const bool takeE = j < d && ev < cv;
-		const int32_t out = takeE ? ev : cv;
-		if (takeE) { j++; ev = j < d ? row[j] : 0x7fffffff; }
-		else {
-			if (j < d && ev == cv) { j++; ev = j < d ? row[j] : 0x7fffffff; } // equal heads emitted once (never in a valid file)
-			ri++;
-			if (--rl == 0) { r++; haveC = r < nr; if (haveC) { ri = (int32_t)ldsCol[(2 * r) * TPB]; rl = (int32_t)ldsCol[(2 * r + 1) * TPB]; } }
-			if (haveC) cv = src[ri];
-		}
-		row[k++] = out;
-	}
-	// the remaining extras row[j..d) are already in place when k == j; a malformed duplicate leaves a gap: pad with -1
-	if (k != j) { while (j < d && k < d) { row[k++] = row[j++]; } while (k < d) row[k++] = -1; }
-}
-
-template <int DEF>
-__global__ void __launch_bounds__(TPB) k_copy(GraphDev g, RangeView v, const int32_t *__restrict__ depth, int32_t level, int *__restrict__ err) {
-	const int32_t s = blockIdx.x * TPB + threadIdx.x;
-	if (s >= v.cnt) return;
-	if (depth[s] != level) return;
-	const int32_t r = v.ref[s];
-	if (!v.fits(s) || !v.fits(s - r)) return; // E_CAP / E_HALO already raised by k_parse
-	copy_node<DEF>(g, v.lo + s, v.outd[s], (int64_t)v.outd[s - r], v.row(s), v.row(s - r), err);
-}
-
-// ------------------------------------------------------------------------------------------------ random access
-// bvg_successors_batch: every query node x owns a private chain of slots x, x-r1, x-r1-r2, ... (what the
-// recursion of BVG:1120 would visit); slot t of a chain has depth L-1-t and its referent is slot t+1.
-// Query rows go to the caller's succ at rowptr[query]; ancestor rows go to a scratch arena.
 template <int DEF>
 __device__ __forceinline__ void read_header(const GraphDev &g, int32_t x, int32_t &d, int32_t &r, int &e) {
 	BitReader br;
@@ -1370,10 +1265,6 @@ void launch_scan(const int32_t *in, int64_t n, int64_t *out, int64_t *sums, hipS
 }
 int64_t scan_num_sums(int64_t n) { return n > 0 ? (n + SCAN_TILE - 1) / SCAN_TILE : 1; }
 
-void launch_depth(int32_t cnt, const uint16_t *ref, int32_t *depth, int32_t *maxdepth, hipStream_t st) {
-	if (cnt <= 0) return;
-	hipLaunchKernelGGL(k_depth, dim3(nblk(cnt, TPB)), dim3(TPB), 0, st, cnt, ref, depth, maxdepth);
-}
 
 bool launch_query_mark(const int32_t *nodes, int64_t q, int32_t n, int32_t *outd, uint16_t *ref, uint8_t *need, int32_t *qoutd, int passes, int32_t *changed, int *err, hipStream_t st) {
 	if (need) (void)hipMemsetAsync(need, 0, (size_t)n, st);
@@ -1406,19 +1297,7 @@ void launch_rebase(int32_t nh, int32_t cnt, const int64_t *rowstart, int64_t *ou
 	hipLaunchKernelGGL(k_rebase, dim3(nblk((int64_t)cnt - nh + 1, TPB)), dim3(TPB), 0, st, nh, cnt, rowstart, out);
 }
 
-void launch_parse(const GraphDev &g, int def, const RangeView &v, int *err, hipStream_t st) {
-	if (v.cnt <= 0) return;
-	if (def == 1) hipLaunchKernelGGL(k_parse<1>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, err);
-	else if (def == 2) hipLaunchKernelGGL(k_parse<2>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, err);
-	else hipLaunchKernelGGL(k_parse<0>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, err);
-}
 
-void launch_copy(const GraphDev &g, int def, const RangeView &v, const int32_t *depth, int32_t level, int *err, hipStream_t st) {
-	if (v.cnt <= 0) return;
-	if (def == 1) hipLaunchKernelGGL(k_copy<1>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, depth, level, err);
-	else if (def == 2) hipLaunchKernelGGL(k_copy<2>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, depth, level, err);
-	else hipLaunchKernelGGL(k_copy<0>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, depth, level, err);
-}
 
 int64_t hash_chunks(int32_t cnt, int64_t arcs) { return ((int64_t)cnt + arcs + HASH_CHUNK - 1) / HASH_CHUNK; }
 // A, B: hash_chunks(cnt, arcs) entries each; bounds: one more.  arcs = rowptr[cnt] - rowptr[0].
@@ -1592,13 +1471,9 @@ void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int
 		else hipLaunchKernelGGL(k_copy_mid<0>, dim3(1024), dim3(64 * COPY_MID_WAVES), 0, stMid, g, v, depth, midQ, ctl + 6, midCap, level, err);
 	}
 	if (stMid != st) (void)hipEventRecord(evMid, stMid);
-	const bool chunked = !(g.dbg & 256); // BVGPU_DBG=256: the nested-loop merge (copy_node) for every row, for A/B timing
-	if (def == 1 && chunked) hipLaunchKernelGGL((k_copy_list<1, true>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
-	else if (def == 2 && chunked) hipLaunchKernelGGL((k_copy_list<2, true>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
-	else if (chunked) hipLaunchKernelGGL((k_copy_list<0, true>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
-	else if (def == 1) hipLaunchKernelGGL((k_copy_list<1, false>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
-	else if (def == 2) hipLaunchKernelGGL((k_copy_list<2, false>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
-	else hipLaunchKernelGGL((k_copy_list<0, false>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
+	if (def == 1) hipLaunchKernelGGL(k_copy_list<1>, dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
+	else if (def == 2) hipLaunchKernelGGL(k_copy_list<2>, dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
+	else hipLaunchKernelGGL(k_copy_list<0>, dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
 	if (stList != st) (void)hipEventRecord(evBig, stList);
 	if (stMid != st) (void)hipStreamWaitEvent(st, evMid, 0);
 	if (stList != st) (void)hipStreamWaitEvent(st, evBig, 0);
@@ -1615,16 +1490,14 @@ void launch_parse_tile(const GraphDev &g, int def, const RangeView &v, const int
 	else hipLaunchKernelGGL(k_parse_tile<2>, dim3(ntiles), dim3(TILE_T), 0, st, g, v, tb, err);
 }
 
-void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, void *arena, int64_t arenaCap, bool lean) {
+void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, void *arena, int64_t arenaCap) {
 	if (v.cnt <= 0) return;
 	IvEntry *a = (IvEntry *)arena;
-	if (def == 1 && a && lean) hipLaunchKernelGGL((k_parse_list<1, 2>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
-	else if (def == 2 && a && lean) hipLaunchKernelGGL((k_parse_list<2, 2>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
-	else if (def == 1 && a) hipLaunchKernelGGL((k_parse_list<1, 1>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
-	else if (def == 2 && a) hipLaunchKernelGGL((k_parse_list<2, 1>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
-	else if (def == 1) hipLaunchKernelGGL((k_parse_list<1, 0>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
-	else if (def == 2) hipLaunchKernelGGL((k_parse_list<2, 0>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
-	else hipLaunchKernelGGL((k_parse_list<0, 0>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
+	if (def == 1 && a) hipLaunchKernelGGL((k_parse_list<1, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
+	else if (def == 2 && a) hipLaunchKernelGGL((k_parse_list<2, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
+	else if (def == 1) hipLaunchKernelGGL((k_parse_list<1, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
+	else if (def == 2) hipLaunchKernelGGL((k_parse_list<2, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
+	else hipLaunchKernelGGL((k_parse_list<0, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
 }
 
 } // namespace bv

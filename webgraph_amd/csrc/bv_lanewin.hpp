@@ -235,105 +235,4 @@ __device__ __forceinline__ void parse_node_lw(const GraphDev &g, int32_t x, int3
 	if (e) atomicOr(err, e);
 }
 
-// The same record decoder with a lean merge (round 3).  parse_node_lw emits ONE successor per iteration of one big loop --
-// interval ids included -- and every iteration pays for the 16-byte store buffer, the ring top-up test and the three-way
-// choice between interval id, residual and "both": ~250 instructions per successor.  Here the outer loop runs once per
-// RESIDUAL (decode, prefix-add, one 4-byte store), and the intervals that precede the residual are expanded by a tight inner
-// loop (add, store) the moment the residual passes their left end; the ring hands over the next interval only then.
-// Same contract, same ring / arena handling as parse_node_lw<ZK, true>; ids are Java ints (BVG:954, :966, :1084-1093).
-template <int ZK>
-__device__ __forceinline__ void parse_node_lw2(const GraphDev &g, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row, uint32_t *lds, int2 *__restrict__ iv, int *__restrict__ err) {
-	LaneWin<LW_MAIN> br;
-	br.col = lds + threadIdx.x;
-	uint32_t *const ring = lds + LW_MAIN * LW_STRIDE + threadIdx.x; // entry j of the ring: ring[2 j * LW_STRIDE], ring[(2 j + 1) * LW_STRIDE]
-	br.vlast = min((((uint64_t)g.offsets[x + 1] >> 5) + 2) & ~(uint64_t)3, (g.nwords + 4) & ~(uint64_t)3);
-	br.seek(g, (uint64_t)g.offsets[x]);
-	int e = 0;
-	(void)br.code<1>(g, e);              // outdegree (known from k_headers)
-	if (g.W > 0) (void)br.code<2>(g, e); // reference
-	int64_t copied = 0;
-	if (hasRef) { // BVG:1058-1071
-		const uint64_t bc = br.code<1>(g, e);
-		int64_t total = 0;
-		if (bc > (uint64_t)dref + 1) e |= E_FORMAT;
-		else {
-			for (uint64_t b = 0; b < bc; b++) {
-				int64_t len;
-				if (!block_len_ok(br.code<1>(g, e), b == 0, total, dref, len)) { e |= E_FORMAT; break; }
-				total += len;
-				if (!(b & 1)) copied += len;
-			}
-			if (!(bc & 1)) copied += dref - total;
-		}
-	}
-	const int64_t extra = (int64_t)d - copied;
-	if (extra < 0 || copied < 0) e |= E_FORMAT;
-	if (e) { atomicOr(err, e); return; }
-	if (extra == 0) return;
-	int64_t nIntervals = 0, intervalArcs = 0;
-	if (g.minInt != 0) { // BVG:1073-1096: the interval section is decoded once; (left, length) go to the ring and, when there are more than it holds, to the arena
-		nIntervals = (int64_t)br.code<1>(g, e);
-		if (nIntervals > extra) { atomicOr(err, E_FORMAT); return; }
-		int32_t prevEnd = 0;
-		for (int64_t i = 0; i < nIntervals; i++) {
-			const uint64_t a = br.code<1>(g, e);
-			const uint64_t len = br.code<1>(g, e);
-			if (len > (uint64_t)extra) { e |= E_FORMAT; break; }
-			intervalArcs += (int64_t)len + g.minInt;
-			const int32_t left = i == 0 ? (int32_t)((int64_t)x + nat2int(a)) : prevEnd + (int32_t)a + 1, n = (int32_t)len + g.minInt;
-			prevEnd = left + n;
-			if (i < LW_RING) { ring[(2 * i) * LW_STRIDE] = (uint32_t)left; ring[(2 * i + 1) * LW_STRIDE] = (uint32_t)n; }
-			if (nIntervals > LW_RING) iv[i] = int2{ left, n };
-		}
-	}
-	const int64_t nRes = extra - intervalArcs;
-	if (nRes < 0 || e) { atomicOr(err, E_FORMAT | e); return; }
-
-	int32_t *__restrict__ out = row + copied;
-	int32_t pos = 0;                                   // extras written so far (<= extra: the lengths were summed above)
-	const int32_t nIv = (int32_t)nIntervals;
-	int32_t ivIdx = 0, ivBase = 0, ivLoaded = min(nIv, LW_RING); // next interval; oldest one in the ring; intervals [ivBase, ivLoaded) are in the ring
-	int32_t ivLeft = 0, ivLen = 0;                     // the interval waiting to be expanded (ivHave)
-	bool ivHave = false;
-	auto take = [&]() { // the next interval leaves the ring -- if the ring holds one (a long list is topped up from the arena below)
-		ivHave = ivIdx < ivLoaded;
-		if (ivHave) { const int j = ivIdx & (LW_RING - 1); ivLeft = (int32_t)ring[(2 * j) * LW_STRIDE]; ivLen = (int32_t)ring[(2 * j + 1) * LW_STRIDE]; ivIdx++; }
-	};
-	take();
-	int32_t val = x, i = 0;
-	const int32_t nR = (int32_t)nRes;
-	bool pend = false; // a residual is decoded and waits for the intervals below it
-	while (pend || i < nR || ivHave || ivIdx < nIv) {
-		br.wave_refill<3>(g);
-		if (nIv > LW_RING) {
-			if (__any(ivLoaded < nIv && ivIdx - ivBase >= LW_RING - 2)) { // some lane's ring runs low: every lane tops its own up from the arena (rare: the wave waits once)
-				const int32_t cnt = min((ivIdx - ivBase) & ~1, nIv - ivLoaded); // (ivLoaded stays even until the last top-up)
-#pragma unroll
-				for (int p = 0; p < LW_RING / 2; p++) {
-					if (2 * p < cnt) {
-						const int4 t = *(const int4 *)(iv + ivLoaded + 2 * p); // (the slice has room for twice the entries: reading one past the last is harmless)
-						const int j0 = (ivLoaded + 2 * p) & (LW_RING - 1);
-						ring[(2 * j0) * LW_STRIDE] = (uint32_t)t.x; ring[(2 * j0 + 1) * LW_STRIDE] = (uint32_t)t.y;
-						ring[(2 * j0 + 2) * LW_STRIDE] = (uint32_t)t.z; ring[(2 * j0 + 3) * LW_STRIDE] = (uint32_t)t.w;
-					}
-				}
-				if (cnt > 0) { ivBase += cnt; ivLoaded += cnt; }
-			}
-			if (!ivHave) take();
-		}
-		if (!pend && i < nR) {
-			const uint32_t c = (uint32_t)br.template code<0, ZK>(g, e);
-			val = i == 0 ? (int32_t)((int64_t)x + nat2int(c)) : val + (int32_t)c + 1; // BVG:954, :966
-			pend = true; i++;
-		}
-		while (ivHave && (!pend || ivLeft < val)) { // the intervals below the waiting residual (all of them once the residuals are out): expanded now
-			for (int32_t t = 0; t < ivLen; t++) out[pos + t] = ivLeft + t;
-			pos += ivLen;
-			take();
-		}
-		if (pend && (ivHave || ivIdx >= nIv)) { out[pos++] = val; pend = false; } // (ring dry with intervals still in the arena: wait for the top-up)
-	}
-	if (e) atomicOr(err, e);
-}
-
 } // namespace bv

@@ -50,15 +50,12 @@ int64_t headers_blocks(int32_t cnt); // part: 5 counts per block of k_headers, [
 void launch_mark_halo(int32_t nh, int32_t cnt, int32_t W, int32_t *outd, uint16_t *ref, uint8_t *need, int *err, hipStream_t st);
 void launch_scan(const int32_t *in, int64_t n, int64_t *out, int64_t *sums, hipStream_t st);
 int64_t scan_num_sums(int64_t n);
-void launch_depth(int32_t cnt, const uint16_t *ref, int32_t *depth, int32_t *maxdepth, hipStream_t st);
 void launch_rebase(int32_t nh, int32_t cnt, const int64_t *rowstart, int64_t *out, hipStream_t st);
 bool launch_query_mark(const int32_t *nodes, int64_t q, int32_t n, int32_t *outd, uint16_t *ref, uint8_t *need, int32_t *qoutd, int passes, int32_t *changed, int *err, hipStream_t st);
 void launch_query_walk(const int32_t *nodes, int64_t q, int32_t n, int32_t *outd, uint16_t *ref, uint8_t *need, int32_t *qoutd, int *err, hipStream_t st);
 void launch_need_prop(int32_t n, const int32_t *outd, const uint16_t *ref, uint8_t *need, int passes, int32_t *changed, hipStream_t st);
 void launch_apply_need(int32_t n, const uint8_t *need, int32_t *outd, uint16_t *ref, hipStream_t st);
 void launch_gather_rows(const int32_t *nodes, int64_t q, int64_t arcs, const int64_t *rowstart, const int32_t *arena, const int64_t *rowptr, int32_t *succ, hipStream_t st);
-void launch_parse(const GraphDev &g, int def, const RangeView &v, int *err, hipStream_t st);
-void launch_copy(const GraphDev &g, int def, const RangeView &v, const int32_t *depth, int32_t level, int *err, hipStream_t st);
 void launch_chain_len(const GraphDev &g, int def, const int32_t *nodes, int64_t q, int32_t *chainlen, int32_t *maxlen, int *err, hipStream_t st);
 void launch_chain_fill(const GraphDev &g, int def, const int32_t *nodes, int64_t q, const int64_t *slotbase, int32_t *snode, int32_t *soutd,
                        int32_t *sdepth, int32_t *sq, int32_t *aoutd, int32_t *qoutd, hipStream_t st);
@@ -76,20 +73,13 @@ void launch_build_lists(const GraphDev &g, const RangeView &v, uint64_t giantBit
 void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int32_t *depth, const int32_t *list, const int32_t *keyBase, int32_t level, int blocks,
                        int32_t midMinKnob, bool bigGroups, const int32_t *bigQ, int32_t bigCap, const int32_t *midQ, int32_t midCap, int32_t *ctl, int32_t *tmp, uint32_t tmpCap, int *err,
                        hipStream_t st, hipStream_t stMid, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evMid, hipEvent_t evBig);
-void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, void *arena = nullptr, int64_t arenaCap = 0, bool lean = true);
+void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, void *arena = nullptr, int64_t arenaCap = 0);
 void launch_parse_waves(const GraphDev &g, int def, const RangeView &v, const int32_t *biglist, int32_t *ctl, void *arena, int64_t arenaCap, int waves, int *err, hipStream_t st);
 void launch_parse_giants(const GraphDev &g, int def, const RangeView &v, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap, int giantGroups, int *err, hipStream_t st);
 // bv_tile.hpp: short records decoded tile by tile from one LDS image of a contiguous slice of the stream
 int32_t tile_count(int64_t bitSpan, int32_t cnt);
 void launch_tile_bounds(const GraphDev &g, int32_t lo, int32_t cnt, int32_t ntiles, int32_t *tb, hipStream_t st);
 void launch_parse_tile(const GraphDev &g, int def, const RangeView &v, const int32_t *tb, int32_t ntiles, int variant, int *err, hipStream_t st);
-// bv_strip.hip: the records below stripMax successors, strip by strip entirely in LDS (bv_strip.hpp); what a strip cannot
-// handle is appended to esc[] (escCtl[0] = count) for the one-wave cooperative kernel
-int32_t strip_count(int64_t bitSpan, int32_t cnt, int64_t arcsBound);
-int32_t strip_max_default();
-void launch_strip_bounds(const GraphDev &g, const RangeView &v, int32_t ntiles, int32_t *tb, int32_t *escCtl, int *err, hipStream_t st);
-constexpr int CTL_ESC = 24; // ctl[CTL_ESC] = records the strip kernel left to the cooperative kernel, ctl[CTL_ESC + 2] = head of that queue
-void launch_strips(const GraphDev &g, int def, const RangeView &v, const int32_t *tb, int32_t ntiles, int32_t stripMin, int32_t stripMax, int32_t *esc, int32_t *escCtl, int32_t escCap, int *err, hipStream_t st);
 int64_t hash_chunks(int32_t cnt, int64_t arcs);
 void launch_hash(int32_t from, int32_t cnt, int64_t arcs, const int64_t *rowptr, const int32_t *succ, uint32_t *A, uint32_t *B, int32_t *bounds, int32_t *hash, hipStream_t st);
 

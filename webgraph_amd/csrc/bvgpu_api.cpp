@@ -121,18 +121,12 @@ struct bvg_graph {
 	DevBuf key16, keys;                                               // per-slot list key; hist / keyBase / cursor
 	int level_blocks = 4096; // blocks of the list kernels (k_parse_list, k_copy_list): 2048..4096 are within 1 % on C2, 4096 is 3 % faster on cnr-2000 x30
 	DevBuf lvlist;
-	int parse_lists = 1; // BVGPU_PARSE_LISTS=0: short records parsed in node order instead of by work bin
 	DevBuf plist, pkeys, pkey16;
 	int tile = -1;       // -1: automatic (see enqueue_decode); BVGPU_TILE=0: never; BVGPU_TILE=1: short records decoded from contiguous tiles of the stream (k_parse_tile) instead of the bin-sorted parse list (k_parse_list)
 	DevBuf tilebounds;
-	int lean = 0;        // BVGPU_LEAN=1: the one-lane decoder with an inner loop per interval and 4-byte stores (parse_node_lw2; measured 1.3x slower: divergent inner loops)
-	int strip = 0;       // BVGPU_STRIP=1: the strip kernel (bv_strip.hip) instead of the one-wave cooperative decoder (k_parse_big<1>) for the records above strip_min successors
-	int32_t strip_min = 256, strip_max = 0; // records with strip_min <= successors < strip_max are strip work (BVGPU_STRIP_MIN / BVGPU_STRIP_MAX; 0: up to the giant threshold)
-	DevBuf stripbounds, esclist;
 	int copy_big = 1;    // BVGPU_COPY_BIG=0: every row is copied by one lane
 	int parse_windows = 1; // BVGPU_PARSE_WINDOWS=0: the parse list is sorted by work bin over the whole range
 	int copy_mid_min = 128; // rows with at least this many successors (and fewer than 1024) are copied by one wave each
-	int copy_lists = 1; // BVGPU_COPY_LISTS=0: node-order sweeps over all slots instead of per-level compact lists
 	int32_t coop_min = 2048, giant_min = 32768;                         // thresholds on the outdegree (BVGPU_COOP_MIN / BVGPU_GIANT_MIN)
 	bool adaptive = true;                                               // smaller jobs lower them (pick_thresholds) unless a knob pins them
 	int coop_waves = 4096, giant_groups = 256;
@@ -219,15 +213,9 @@ int init_handle(bvg_graph *g) {
 	if (!g->coopctl.need(bv::CTL_TOTAL_INTS * sizeof(int32_t)) || !g->keys.need(3 * (bv::NKEYS + 1) * sizeof(int32_t))) return fail(g, BVG_ENOMEM, "device allocation failed");
 	HIPCHK(g, hipMemset(g->coopctl.p, 0, bv::CTL_TOTAL_INTS * sizeof(int32_t))); // (k_pick_coop leaves its counters zeroed for the next job)
 	if (const char *e = getenv("BVGPU_LEVEL_BLOCKS")) g->level_blocks = std::max(1, atoi(e));
-	if (const char *e = getenv("BVGPU_COPY_LISTS")) g->copy_lists = atoi(e);
-	if (const char *e = getenv("BVGPU_PARSE_LISTS")) g->parse_lists = atoi(e);
 	if (const char *e = getenv("BVGPU_COPY_BIG")) g->copy_big = atoi(e);
 	if (const char *e = getenv("BVGPU_PARSE_WINDOWS")) g->parse_windows = atoi(e);
 	if (const char *e = getenv("BVGPU_TILE")) g->tile = atoi(e);
-	if (const char *e = getenv("BVGPU_STRIP")) g->strip = atoi(e);
-	if (const char *e = getenv("BVGPU_LEAN")) g->lean = atoi(e);
-	if (const char *e = getenv("BVGPU_STRIP_MIN")) g->strip_min = std::min(std::max(1, atoi(e)), 16384);
-	if (const char *e = getenv("BVGPU_STRIP_MAX")) g->strip_max = std::min(std::max(2, atoi(e)), 32768);
 	if (const char *e = getenv("BVGPU_WALK_TABLES")) g->walk_tables = atoi(e);
 	if (const char *e = getenv("BVGPU_IV_ARENA")) g->iv_arena = atoi(e);
 	if (const char *e = getenv("BVGPU_COPY_MID_MIN")) g->copy_mid_min = std::min(std::max(0, atoi(e)), 1024); // 0: no wave-per-row copy
@@ -350,13 +338,12 @@ int finish_pending(bvg_graph *g, uint64_t *arcs_out) {
 			const int32_t upto = g->h_small->maxdepth;
 			int32_t *keyBase = g->keys.as<int32_t>() + (bv::NKEYS + 1);
 			for (int32_t l = g->pend.levels_done + 1; l <= upto; l++) {
-				if (g->copy_lists) {
+				{
 					const bool ov2 = g->overlap && !g->profile;
 					bv::launch_copy_level(gd, s.def, g->pend.view, g->depth.as<int32_t>(), g->lvlist.as<int32_t>(), keyBase, l, g->level_blocks, g->copy_mid_min, g->copy_big != 0,
 					                      g->copyq.as<int32_t>(), g->pend.bigCap, g->copyq.as<int32_t>() + g->pend.bigCap, g->pend.midCap, g->coopctl.as<int32_t>(), g->bigtmp.as<int32_t>(), g->pend.tmpCap, derr,
 					                      g->stream, ov2 ? side_b(g) : g->stream, ov2 ? g->sideA : g->stream, g->evFork, g->evB, g->evA);
 				}
-				else bv::launch_copy(gd, s.def, g->pend.view, g->depth.as<int32_t>(), l, derr, g->stream);
 			}
 			g->pend.levels_done = upto;
 			rc = fetch_small(g);
@@ -393,19 +380,6 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 	const Staged &s = *g->st;
 	int32_t coopMin, giantMin;
 	pick_thresholds(g, estArcs, coopMin, giantMin);
-	// Three classes of records (default codings): below strip_min successors one lane each, sorted into work bins (k_parse_list / k_parse_tile);
-	// from there up to the giant threshold the strip kernel (bv_strip.hip: a wave per strip of the stream, residual sections cut into
-	// segments -- 9x cheaper per record than the one-wave cooperative decoder, which it replaces; what does not fit a strip's LDS budget
-	// escapes to that decoder); the giant records a group of waves each.
-	const bool strips = g->strip != 0 && s.def != 0 && g->parse_lists && g->copy_lists;
-	int32_t stripLo = 0, stripHi = 0;
-	if (strips) {
-		stripLo = g->adaptive ? g->strip_min : std::min(g->strip_min, g->coop_min);
-		stripHi = g->strip_max > 0 ? std::min(std::max(g->strip_max, stripLo), giantMin) : giantMin;
-		giantMin = std::max(giantMin, stripLo);
-		coopMin = stripLo;
-		v.coop_ptr = nullptr; // (k_pick_coop still ran: it zeroes the job's counters)
-	}
 	const int32_t W = s.info.window_size;
 	int *derr = &g->small.as<Small>()->err;
 	bv::GraphDev gd = graph_dev(s);
@@ -414,7 +388,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 	{
 		// the block tables of the giant records, kept by the parse kernel for the copy pass (GraphDev::walktab): on when the job has a giant class
 		g->pend.walkMin = 0x7fffffff;
-		if (g->walk_tables && coopMin < 0x7fffffff && s.def != 0 && W > 0 && g->copy_lists && g->copy_big) {
+		if (g->walk_tables && coopMin < 0x7fffffff && s.def != 0 && W > 0 && g->copy_big) {
 			const size_t cap = (size_t)std::min<int64_t>(std::max<int64_t>(s.arcs_sizing / 8, 1 << 20), 0x7fffffff);
 			if (g->walktab.need(sizeof(int32_t) * cap)) g->pend.walkMin = giantMin; // (no room: the copy pass walks the lists itself)
 		}
@@ -437,30 +411,16 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		// rows with a reference and >= 1024 (resp. >= copy_mid_min) successors: at most arcs / 1024 (resp. / copy_mid_min) of them
 		const int32_t bigCap = (int32_t)std::min<int64_t>(arcsBound / 1024 + 2, 0x3fffffff);
 		const int32_t midCap = g->copy_mid_min > 0 ? (int32_t)std::min<int64_t>(arcsBound / g->copy_mid_min + 2, 0x3fffffff) : 0;
-		if (g->copy_lists && !g->copyq.need(sizeof(int32_t) * ((size_t)bigCap + (size_t)midCap))) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
+		if (!g->copyq.need(sizeof(int32_t) * ((size_t)bigCap + (size_t)midCap))) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
 		g->pend.bigCap = bigCap; g->pend.midCap = midCap;
 		// scratch tables of the rows that copy more ids than k_copy_big's LDS tables hold (bump-allocated per level, ctl[8]; ctl[9] = head of the level's queue of long rows):
 		// <= 4 ints per copied id, and a level's long rows copy a fraction of the arcs; a row that does not fit falls back to one lane
 		const uint32_t tmpCap = (uint32_t)std::min<int64_t>(std::max<int64_t>(arcsBound, 1 << 22), 0x7fffffff);
-		if (g->copy_lists && g->copy_big && !g->bigtmp.need(sizeof(int32_t) * (size_t)tmpCap)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
-		g->pend.tmpCap = g->copy_lists && g->copy_big ? tmpCap : 0;
+		if (g->copy_big && !g->bigtmp.need(sizeof(int32_t) * (size_t)tmpCap)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
+		g->pend.tmpCap = g->copy_big ? tmpCap : 0;
 		const bool coop = coopMin < 0x7fffffff;
 		const bool ovl = g->overlap && !g->profile; // per-kernel timing needs the kernels one after the other
 		v.coop_min = coop ? coopMin : 0x7fffffff;
-		const int32_t waveMin = strips ? stripHi : coopMin; // (with strips reaching the giant threshold the one-wave class is empty: it only serves the strips' escape list)
-		int32_t nstrips = 0;
-		if (strips) {
-			const uint64_t haloRoom = std::min<uint64_t>(v.halo_cap, (uint64_t)arcsBound);
-			const int64_t arcsJob = (int64_t)std::min<uint64_t>((uint64_t)arcsBound, v.succ_cap + (v.nh ? haloRoom : 0));
-			nstrips = bv::strip_count(s.h_offsets[(size_t)v.lo + v.cnt] - s.h_offsets[(size_t)v.lo], v.cnt, arcsJob);
-			if (!g->stripbounds.need(sizeof(int32_t) * ((size_t)nstrips + 2)) || !g->esclist.need(sizeof(int32_t) * (size_t)v.cnt)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
-		}
-		auto launchStrips = [&](hipStream_t st) { // needs the row starts (the scan): strip bounds, the strips, then what a strip could not take -- no room in its LDS budget, a codeword of more than 64 bits, a malformed record -- by one wave each
-			bv::launch_strip_bounds(gd, v, nstrips, g->stripbounds.as<int32_t>(), ctl + bv::CTL_ESC, derr, st);
-			bv::launch_strips(gd, s.def, v, g->stripbounds.as<int32_t>(), nstrips, stripLo, stripHi, g->esclist.as<int32_t>(), ctl + bv::CTL_ESC, v.cnt, derr, st);
-			bv::launch_parse_waves(gd, s.def, v, g->esclist.as<int32_t>(), ctl + bv::CTL_ESC, g->arena.p, arenaCap, std::min(g->coop_waves, 2048), derr, st);
-		};
-		if (!coop) v.coop_ptr = nullptr;
 		g->last_giant_min = giantMin;
 		// Three things run next to each other from here on (unless profiling serialises them):
 		//   side B: classification of the long records, then the giant ones (a group of waves each) -- the longest
@@ -478,7 +438,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		// k_pick_coop will pick 128 --: neighbouring short records are alike, a tile's lanes stay even, and the coalesced tile
 		// kernel is 20 % faster than the bins (cnr-2000 x 30: 0.42 against 0.53 ms); with a heavy-tailed lane class it is 2.6x slower (C2).
 		int tileVariant = g->tile > 0 ? g->tile : 0;
-		if (g->tile < 0 && g->adaptive && (v.coop_ptr || strips) && s.deg_counts[0] >= 0 && g->parse_lists) {
+		if (g->tile < 0 && g->adaptive && v.coop_ptr && s.deg_counts[0] >= 0) {
 			const double share = (double)(s.h_offsets[(size_t)v.lo + v.cnt] - s.h_offsets[(size_t)v.lo]) / (double)std::max<int64_t>(s.h_offsets[(size_t)s.node_hi] - s.h_offsets[(size_t)s.stage_lo], 1);
 			if ((double)s.deg_counts[0] * share <= (double)COOP_BUDGET * (share > 0.999 ? 1.0 : 0.8)) tileVariant = 1; // (a sub-range: an estimate, with a margin)
 		}
@@ -490,8 +450,8 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			bv::launch_tile_bounds(gd, v.lo, v.cnt, ntiles, g->tilebounds.as<int32_t>(), ovl && hdrEvent ? g->sideA : g->stream);
 			if (ovl && hdrEvent) HIPCHK(g, hipEventRecord(g->evP, g->sideA));
 		}
-		const bool earlyList = !tiles && g->parse_lists && ovl && hdrEvent;
-		if (!tiles && g->parse_lists) {
+		const bool earlyList = !tiles && ovl && hdrEvent;
+		if (!tiles) {
 			if (!g->plist.need(sizeof(int32_t) * (size_t)v.cnt) || !g->pkeys.need(3 * (bv::NKEYS + 1) * sizeof(int32_t)) || !g->pkey16.need(sizeof(uint16_t) * (size_t)v.cnt)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
 			pKeyBase = g->pkeys.as<int32_t>() + (bv::NKEYS + 1);
 		}
@@ -505,7 +465,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			if (early) { // side B: classification and sort of the long records next to the scan (they need the outdegrees only)
 				HIPCHK(g, hipStreamWaitEvent(side_b(g), g->evHdr, 0));
 				HIPCHK(g, hipMemsetAsync(ctl, 0, 4 * sizeof(int32_t), side_b(g)));
-				bv::launch_classify(v.cnt, v.outd, v.coop_ptr, waveMin, giantMin, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, side_b(g));
+				bv::launch_classify(v.cnt, v.outd, v.coop_ptr, coopMin, giantMin, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, side_b(g));
 				HIPCHK(g, hipEventRecord(g->evC, side_b(g)));
 			}
 			HIPCHK(g, hipEventRecord(g->evFork, g->stream));
@@ -517,12 +477,11 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 				hipLaunchKernelGGL(k_totals, dim3(1), dim3(1), 0, g->sideA, v.rowstart, v.nh, v.cnt, g->small.as<Small>(), v.coop_ptr, v.coop_min);
 			}
 			if (coop && !early) {
-				bv::launch_classify(v.cnt, v.outd, v.coop_ptr, waveMin, giantMin, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, side_b(g));
+				bv::launch_classify(v.cnt, v.outd, v.coop_ptr, coopMin, giantMin, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, side_b(g));
 				HIPCHK(g, hipEventRecord(g->evC, side_b(g)));
 			}
 		}
 		// the long records first on both side streams: giants on B, the wave class on A ...
-		if (ovl && strips) launchStrips(g->sideA);
 		if (ovl && coop) {
 			HIPCHK(g, hipStreamWaitEvent(g->sideA, g->evC, 0));
 			bv::launch_parse_big(gd, s.def, v, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, g->giant_groups, derr, side_b(g), g->sideA); // (giants, big)
@@ -531,26 +490,22 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		// ... then, behind the wave class, the chain depth of every record + per-level lists (node order inside a level) +
 		// copy queues: only the copy pass needs them, and launched first they would sit in front of the wave class while
 		// the one-lane kernel holds every CU
-		if (W > 0) bv::launch_build_lists(gd, v, ~0ull, getenv("BVGPU_COPY_BINS") ? 0 : 1, g->depth.as<int32_t>(), g->key16.as<uint16_t>(), hist, keyBase, cursor, g->lvlist.as<int32_t>(),
+		if (W > 0) bv::launch_build_lists(gd, v, ~0ull, 1, g->depth.as<int32_t>(), g->key16.as<uint16_t>(), hist, keyBase, cursor, g->lvlist.as<int32_t>(),
 		                                  g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->maxdepth, stLists,
-		                                  g->copy_lists ? g->copyq.as<int32_t>() : nullptr, bigCap, g->copyq.as<int32_t>() + bigCap, midCap, g->copy_mid_min, g->copy_big != 0);
+		                                  g->copyq.as<int32_t>(), bigCap, g->copyq.as<int32_t>() + bigCap, midCap, g->copy_mid_min, g->copy_big != 0);
 		if (ovl) HIPCHK(g, hipEventRecord(g->evA, g->sideA));
-		if (!tiles && g->parse_lists && !earlyList)
+		if (!tiles && !earlyList)
 			bv::launch_build_lists(gd, v, ~0ull, g->parse_windows ? 6 : 2, nullptr, g->pkey16.as<uint16_t>(), g->pkeys.as<int32_t>(), pKeyBase, pKeyBase + (bv::NKEYS + 1), g->plist.as<int32_t>(),
 			                       g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->pad, g->stream);
 		if (earlyList || (tiles && ovl && hdrEvent)) HIPCHK(g, hipStreamWaitEvent(g->stream, g->evP, 0));
-		if (coop && !ovl) bv::launch_classify(v.cnt, v.outd, v.coop_ptr, waveMin, giantMin, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, g->stream);
+		if (coop && !ovl) bv::launch_classify(v.cnt, v.outd, v.coop_ptr, coopMin, giantMin, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, g->stream);
 		mark(g, 3);
 		if (coop && !ovl) bv::launch_parse_giants(gd, s.def, v, g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->giant_groups, derr, g->stream);
 		mark(g, 4);
 		if (coop && !ovl) bv::launch_parse_waves(gd, s.def, v, g->biglist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, derr, g->stream);
-		if (strips && !ovl) launchStrips(g->stream);
 		mark(g, 5);
 		if (tiles) bv::launch_parse_tile(gd, s.def, v, g->tilebounds.as<int32_t>(), ntiles, tileVariant, derr, g->stream);
-		else if (pKeyBase) {
-			bv::launch_parse_list(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, g->level_blocks, derr, g->stream, g->iv_arena ? g->arena.p : nullptr, arenaCap, g->lean != 0);
-		}
-		else bv::launch_parse(gd, s.def, v, derr, g->stream);
+		else bv::launch_parse_list(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, g->level_blocks, derr, g->stream, g->iv_arena ? g->arena.p : nullptr, arenaCap);
 		if (ovl) {
 			HIPCHK(g, hipStreamWaitEvent(g->stream, g->evA, 0));
 			if (coop) HIPCHK(g, hipStreamWaitEvent(g->stream, g->evB, 0));
@@ -559,10 +514,9 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		if (W > 0) {
 			levels = g->levels_hint;
 			for (int32_t l = 1; l <= levels; l++) {
-				if (g->copy_lists) bv::launch_copy_level(gd, s.def, v, g->depth.as<int32_t>(), g->lvlist.as<int32_t>(), keyBase, l, g->level_blocks, g->copy_mid_min, g->copy_big != 0,
+				bv::launch_copy_level(gd, s.def, v, g->depth.as<int32_t>(), g->lvlist.as<int32_t>(), keyBase, l, g->level_blocks, g->copy_mid_min, g->copy_big != 0,
 				                                          g->copyq.as<int32_t>(), bigCap, g->copyq.as<int32_t>() + bigCap, midCap, ctl, g->bigtmp.as<int32_t>(), g->pend.tmpCap, derr,
 				                                          g->stream, ovl ? side_b(g) : g->stream, ovl ? g->sideA : g->stream, g->evFork, g->evB, g->evA);
-				else bv::launch_copy(gd, s.def, v, g->depth.as<int32_t>(), l, derr, g->stream); // sweep in node order: rows of neighbouring nodes are neighbours in memory
 			}
 		}
 	}
@@ -831,7 +785,7 @@ extern "C" int bvg_close(bvg_t *g) {
 	if (g->st && g->st->device >= 0) {
 		(void)hipSetDevice(g->st->device);
 		if (g->own) { (void)hipStreamSynchronize(g->own); (void)hipStreamDestroy(g->own); }
-		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->hashBounds, &g->pickpart, &g->walktab, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist, &g->plist, &g->pkeys, &g->pkey16, &g->copyq, &g->bigtmp, &g->tilebounds, &g->stripbounds, &g->esclist }) b->release();
+		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->hashBounds, &g->pickpart, &g->walktab, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist, &g->plist, &g->pkeys, &g->pkey16, &g->copyq, &g->bigtmp, &g->tilebounds }) b->release();
 		for (DevBuf *b : { &g->hchunk[0], &g->hchunk[1], &g->statsbuf, &g->bfs_rowptr, &g->bfs_succ, &g->bfs_ctr }) b->release();
 		for (PinBuf *b : { &g->hring[0], &g->hring[1], &g->view_rowptr, &g->view_succ }) b->release();
 		for (hipEvent_t e : { g->evChunk[0], g->evChunk[1], g->evCopied[0], g->evCopied[1] }) if (e) (void)hipEventDestroy(e);
