@@ -80,7 +80,9 @@ int bvg_open(const char *basename, int device, bvg_t **out);
  * the offset table that nodes [bounds[part], bounds[part+1]) need is staged in HBM (plus a few thousand nodes before it
  * for the referents of its first rows).  The handle decodes ranges inside its slice (bvg_decode_range, bvg_decode_range_view,
  * bvg_scan_checksum, bvg_outdegrees; node ids stay global); random access needs the whole graph (BVG_EUNSUPPORTED here).
- * There is no exchange step between the parts: a host-side reduction of (arcs, hash) pairs is all a scan needs. */
+ * There is no exchange step between the parts: a host-side reduction of (arcs, hash) pairs is all a scan needs.
+ * The room before the slice is max(4096, 64 x windowsize) nodes: a file whose reference chains run deeper than that (written with a
+ * huge or unlimited maxrefcount) decodes through bvg_open only -- a range decode of such a slice returns BVG_EUNSUPPORTED. */
 int bvg_open_shard(const char *basename, int device, int part, int parts, bvg_t **out);
 
 /* BVGraph.copy() (BVG:552-577): flyweight sharing the staged graph; own stream and scratch. */

@@ -75,6 +75,7 @@ JNIEXPORT jintArray JNICALL Java_it_unimi_dsi_webgraph_gpu_GpuBVGraph_decodeRang
 	jintArray a = (*env)->NewIntArray(env, (jsize)arcs);
 	if (!a) return NULL;                                    /* OutOfMemoryError is pending */
 	(*env)->SetLongArrayRegion(env, rowptr, 0, (jsize)(to - from + 1), (const jlong *)rp);
+	if ((*env)->ExceptionCheck(env)) return NULL;           /* rowptr shorter than to - from + 1: ArrayIndexOutOfBoundsException is pending, no JNI call may follow */
 	(*env)->SetIntArrayRegion(env, a, 0, (jsize)arcs, (const jint *)sc);
 	return a;
 }

@@ -243,7 +243,7 @@ void mark(bvg_graph *g, int i) { if (g->profile) (void)hipEventRecord(g->ev[i], 
 
 // Enqueues headers (+halo closure) + scan for nodes [from,to) with a halo of nh nodes before `from`.
 // On return the view describes the job; rowstart lives in scratch.
-int enqueue_structure(bvg_graph *g, int32_t from, int32_t to, int32_t nh, bv::RangeView &v, bool pickCoop = false) {
+int enqueue_structure(bvg_graph *g, int32_t from, int32_t to, int32_t nh, bv::RangeView &v, bool pickCoop = false, int64_t *rowstart_out = nullptr) {
 	const Staged &s = *g->st;
 	const int32_t lo = from - nh, cnt = to - lo;
 	if (!g->outd.need(sizeof(int32_t) * (size_t)cnt) || !g->ref.need(sizeof(uint16_t) * (size_t)cnt) ||
@@ -254,6 +254,7 @@ int enqueue_structure(bvg_graph *g, int32_t from, int32_t to, int32_t nh, bv::Ra
 	v.halo_cap = ~0ull;
 	v.lo = lo; v.cnt = cnt; v.nh = nh;
 	v.outd = g->outd.as<int32_t>(); v.ref = g->ref.as<uint16_t>(); v.rowstart = g->rowstart.as<int64_t>();
+	if (rowstart_out && nh == 0) v.rowstart = rowstart_out; // without a halo the row starts ARE the caller's rowptr: scanned in place (no k_rebase pass: 160 MB less per C2 scan)
 	int *derr = &g->small.as<Small>()->err;
 	const bv::GraphDev gd = graph_dev(s);
 	mark(g, 0);
@@ -473,7 +474,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			HIPCHK(g, hipStreamWaitEvent(side_b(g), g->evFork, 0));
 			stLists = g->sideA;
 			if (g->early_rowptr) { // the caller's rowptr needs the scan only: written now, not at the end of the call
-				bv::launch_rebase(v.nh, v.cnt, v.rowstart, g->early_rowptr, g->sideA);
+				if (v.rowstart != g->early_rowptr) bv::launch_rebase(v.nh, v.cnt, v.rowstart, g->early_rowptr, g->sideA);
 				hipLaunchKernelGGL(k_totals, dim3(1), dim3(1), 0, g->sideA, v.rowstart, v.nh, v.cnt, g->small.as<Small>(), v.coop_ptr, v.coop_min);
 			}
 			if (coop && !early) {
@@ -528,6 +529,7 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 	const Staged &s = *g->st;
 	HIPCHK(g, hipSetDevice(s.device));
 	if (g->pend.active) { int rc = finish_pending(g, nullptr); if (rc) return rc; }
+	g->ctl_clean = false; // (only this job's own k_pick_coop vouches for the counters: a job that failed half-way leaves them dirty -- ADVICE r2)
 	const int32_t W = s.info.window_size;
 	if (from < s.node_lo || to > s.node_hi) return fail(g, BVG_EARG, "node range outside the slice this handle stages (bvg_open_shard)");
 	{ int rc = fork_from_user(g); if (rc) return rc; }
@@ -559,7 +561,7 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 		v.halo_cap = g->halo.cap / sizeof(int32_t);
 	}
 	else for (;;) {
-		int rc = enqueue_structure(g, from, to, nh, v, succ_dev != nullptr);
+		int rc = enqueue_structure(g, from, to, nh, v, succ_dev != nullptr, rowptr_dev);
 		if (rc) return rc;
 		if (nh == 0) break;
 		// the halo buffer size and the "chain escaped the window" flag need a round trip
@@ -567,7 +569,11 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 		rc = fetch_small(g);
 		if (rc) return rc;
 		if (g->h_small->err & bv::E_ESCAPED) {
-			if (nh == from - s.stage_lo) return fail(g, BVG_EFORMAT, s.stage_lo ? "reference chain runs before the nodes staged for this slice" : "reference chain runs before node 0");
+			if (nh == from - s.stage_lo) {
+				// a valid file with reference chains deeper than the room a shard stages before its slice (files written with a huge or unlimited maxRefCount)
+				if (s.stage_lo) return fail(g, BVG_EUNSUPPORTED, "a reference chain of the slice's first rows reaches before the nodes staged for it (max(4096, 64 x window) nodes): open the graph with bvg_open");
+				return fail(g, BVG_EFORMAT, "reference chain runs before node 0");
+			}
 			nh = (int32_t)std::min<int64_t>(from - s.stage_lo, (int64_t)nh * 8);
 			HIPCHK(g, hipMemsetAsync(g->small.p, 0, sizeof(Small), g->stream));
 			continue;
@@ -589,7 +595,7 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 	if (!succ_dev) { mark(g, 3); mark(g, 4); mark(g, 5); mark(g, 6); }
 	mark(g, 7);
 	if (!g->early_rowptr) {
-		bv::launch_rebase(v.nh, v.cnt, v.rowstart, rowptr_dev, g->stream);
+		if (v.rowstart != rowptr_dev) bv::launch_rebase(v.nh, v.cnt, v.rowstart, rowptr_dev, g->stream);
 		hipLaunchKernelGGL(k_totals, dim3(1), dim3(1), 0, g->stream, v.rowstart, v.nh, v.cnt, g->small.as<Small>(), v.coop_ptr, v.coop_min);
 	}
 	g->early_rowptr = nullptr;
@@ -901,11 +907,18 @@ void parallel_memcpy(void *dst, const void *src, size_t bytes) {
 	for (auto &t : th) t.join();
 }
 
+// Arcs of nodes [a, e), estimated from their share of the bits this handle stages: arcs_sizing counts the staged records only (a
+// bvg_open_shard handle stages one slice), so the share is taken of the staged span, not of the whole file (buffers of a
+// shard's scans were under-sized by the number of shards and every first scan was decoded twice).
+double est_arcs(const Staged &s, int32_t a, int32_t e) {
+	const int64_t staged = std::max<int64_t>(s.h_offsets[(size_t)s.node_hi] - s.h_offsets[(size_t)s.stage_lo], 1);
+	return (double)std::max<int64_t>(s.arcs_sizing, 1) * (double)(s.h_offsets[(size_t)e] - s.h_offsets[(size_t)a]) / (double)staged;
+}
+
 // Cuts [from, to) into pieces of roughly `target` arcs each, by the share of the bit stream they hold (host offsets).
 std::vector<int32_t> plan_chunks_by_bits(const Staged &s, int32_t from, int32_t to, int64_t target) {
-	const int64_t allBits = std::max<int64_t>(s.h_offsets.back(), 1);
 	const int64_t bits = s.h_offsets[to] - s.h_offsets[from];
-	const double estArcs = (double)std::max<int64_t>(s.arcs_sizing, 1) * (double)bits / (double)allBits;
+	const double estArcs = est_arcs(s, from, to);
 	const int64_t parts = std::max<int64_t>(1, (int64_t)(estArcs / (double)std::max<int64_t>(target, 1) + 0.999));
 	std::vector<int32_t> b{ from };
 	for (int64_t k = 1; k < parts; k++) {
@@ -1025,8 +1038,7 @@ extern "C" int bvg_decode_range_view(bvg_t *g, int32_t from, int32_t to, const i
 	const size_t nrow = (size_t)(to - from) + 1;
 	if (!g->view_rowptr.need(sizeof(int64_t) * nrow)) return fail(g, BVG_ENOMEM, "pinned result allocation failed");
 	// the successor buffer is sized by the range's share of the bit stream first (no counting pass of its own)
-	const int64_t allBits = std::max<int64_t>(s.h_offsets.back(), 1), bits = s.h_offsets[to] - s.h_offsets[from];
-	const uint64_t guess = (uint64_t)((double)std::max<int64_t>(s.arcs_sizing, 1) * (double)bits / (double)allBits * 1.05) + 1024;
+	const uint64_t guess = (uint64_t)(est_arcs(s, from, to) * 1.05) + 1024;
 	if (!g->view_succ.need(sizeof(int32_t) * (size_t)guess)) return fail(g, BVG_ENOMEM, "pinned result allocation failed");
 	uint64_t arcs = 0;
 	int rc = host_scan(g, from, to, g->view_rowptr.as<int64_t>(), g->view_succ.as<int32_t>(), g->view_succ.cap / sizeof(int32_t), &arcs);
@@ -1064,8 +1076,7 @@ extern "C" int bvg_scan_checksum(bvg_t *g, int32_t from, int32_t to, int32_t *ha
 		const int32_t a = cut[k], e = cut[k + 1];
 		if (e == a) continue;
 		if (!g->stage_rowptr.need(sizeof(int64_t) * ((size_t)(e - a) + 1))) return fail(g, BVG_ENOMEM, "staging allocation failed");
-		const int64_t allBits = std::max<int64_t>(s.h_offsets.back(), 1), bits = s.h_offsets[e] - s.h_offsets[a];
-		const uint64_t guess = (uint64_t)((double)std::max<int64_t>(s.arcs_sizing, 1) * (double)bits / (double)allBits * 1.1) + 4096;
+		const uint64_t guess = (uint64_t)(est_arcs(s, a, e) * 1.1) + 4096;
 		if (!g->stage_succ.need(sizeof(int32_t) * (size_t)guess)) return fail(g, BVG_ENOMEM, "staging allocation failed");
 		uint64_t arcs = 0;
 		int rc = decode_range_device(g, a, e, g->stage_rowptr.as<int64_t>(), g->stage_succ.as<int32_t>(), g->stage_succ.cap / sizeof(int32_t), false, &arcs);
@@ -1091,6 +1102,7 @@ extern "C" int bvg_successors_batch(bvg_t *g, const int32_t *nodes, size_t q, in
 	if (s.node_lo != 0 || s.node_hi != s.info.nodes) return fail(g, BVG_EUNSUPPORTED, "random access needs the whole graph: open it with bvg_open");
 	HIPCHK(g, hipSetDevice(s.device));
 	if (g->pend.active) { int rc = finish_pending(g, nullptr); if (rc) return rc; }
+	g->ctl_clean = false; // (see decode_range_device)
 	{ int rc = fork_from_user(g); if (rc) return rc; }
 	const bool dev = (flags & BVG_OUT_DEVICE) != 0;
 	const bv::GraphDev gd = graph_dev(s);
@@ -1307,8 +1319,7 @@ extern "C" int bvg_scan_stats(bvg_t *g, int32_t from, int32_t to, bvg_scan_stats
 		const int32_t a = cut[k], e = cut[k + 1];
 		if (e == a) continue;
 		if (!g->stage_rowptr.need(sizeof(int64_t) * ((size_t)(e - a) + 1))) return fail(g, BVG_ENOMEM, "staging allocation failed");
-		const int64_t allBits = std::max<int64_t>(s.h_offsets.back(), 1), bits = s.h_offsets[e] - s.h_offsets[a];
-		const uint64_t guess = (uint64_t)((double)std::max<int64_t>(s.arcs_sizing, 1) * (double)bits / (double)allBits * 1.1) + 4096;
+		const uint64_t guess = (uint64_t)(est_arcs(s, a, e) * 1.1) + 4096;
 		if (!g->stage_succ.need(sizeof(int32_t) * (size_t)guess)) return fail(g, BVG_ENOMEM, "staging allocation failed");
 		uint64_t arcs = 0;
 		int rc = decode_range_device(g, a, e, g->stage_rowptr.as<int64_t>(), g->stage_succ.as<int32_t>(), g->stage_succ.cap / sizeof(int32_t), false, &arcs);
