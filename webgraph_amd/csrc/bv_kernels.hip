@@ -982,7 +982,7 @@ template <int DEF, int NW, class View>
 #define COOPG_MINWAVES 1
 #endif
 __global__ void __launch_bounds__(64 * NW, NW == 1 ? COOP1_MINWAVES : COOPG_MINWAVES) k_parse_big(GraphDev g, View v, const int32_t *__restrict__ list, int32_t *__restrict__ ctl, int which,
-                                                       IvEntry *__restrict__ arena, int64_t arenaCap, int *__restrict__ err, int32_t dmin) { // dmin: shorter records of the list are k_mid's (bv_seg.hip)
+                                                       IvEntry *__restrict__ arena, int64_t arenaCap, int *__restrict__ err) {
 	__shared__ __attribute__((aligned(16))) uint32_t lds[CoopLds<NW>::WORDS];
 	__shared__ int32_t s_idx;
 	const int32_t count = ctl[which]; // (the giant list is sized for arcs / giantMin entries, which bounds their number)
@@ -1001,8 +1001,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? COOP1_MINWAVES : COOPG_MINW
 		// one-wave block apart at the barrier at the top -- lane 0 late with the next index, the others reading the old one for ever)
 		const int bad = rec.capErr ? rec.capErr : (g.minInt > 0 && (abase < 0 || abase + rec.d / g.minInt + 1 > arenaCap)) ? E_FORMAT : 0;
 		const unsigned long long t0 = g.stats ? __builtin_readcyclecounter() : 0;
-		if (rec.d < dmin) {}
-		else if (bad) { if (threadIdx.x == 0) atomicOr(err, bad); }
+		if (bad) { if (threadIdx.x == 0) atomicOr(err, bad); }
 		else coop_parse_node<DEF, NW>(g, rec.x, rec.d, rec.hasRef, rec.dref, rec.row, arena + abase, lds, err);
 		if (g.stats) { const unsigned long long dt = __builtin_readcyclecounter() - t0; stat_add(g, 5, 1); stat_add(g, 6, dt); stat_max(g, 7, dt); }
 	}
@@ -1345,7 +1344,7 @@ void launch_bcopy(const GraphDev &g, int def, const BatchView &v, int32_t level,
 // The threshold is the smallest of 128 .. 2048 that sends at most `budget` records to the waves (C2: 7 121 records >= 2 048,
 // 15 410 >= 1 024 -> 2 048; cnr-2000 x 30: 11 250 >= 128 -> 128, 3.06 -> 2.67 ms; measured optimum in both cases).
 constexpr int PICK_THREADS = 1024;
-__global__ void __launch_bounds__(PICK_THREADS) k_pick_coop(const int32_t *__restrict__ part, int32_t nblocks, int32_t budget, int32_t *__restrict__ ctl, int32_t *__restrict__ counts, int32_t maxPick) {
+__global__ void __launch_bounds__(PICK_THREADS) k_pick_coop(const int32_t *__restrict__ part, int32_t nblocks, int32_t budget, int32_t *__restrict__ ctl, int32_t *__restrict__ counts) {
 	__shared__ int32_t s_cnt[5];
 	if (threadIdx.x < 5) s_cnt[threadIdx.x] = 0;
 	if (!counts && threadIdx.x >= 64 && threadIdx.x < 64 + 12) ctl[4 + (threadIdx.x - 64)] = 0; // counters of the level lists, copy queues and copy levels of this job
@@ -1369,10 +1368,10 @@ __global__ void __launch_bounds__(PICK_THREADS) k_pick_coop(const int32_t *__res
 	if (threadIdx.x != 0) return;
 	int32_t pick = 2048;
 	for (int k = 4; k >= 0; k--) { if (s_cnt[k] <= budget) pick = 128 << k; else break; }
-	ctl[CTL_COOP] = min(pick, maxPick); // (maxPick: the records from there on are cheap enough for any job -- k_mid)
+	ctl[CTL_COOP] = pick;
 }
-void launch_pick_coop(const int32_t *part, int32_t nblocks, int32_t budget, int32_t *ctl, hipStream_t st, int32_t *counts, int32_t maxPick) {
-	hipLaunchKernelGGL(k_pick_coop, dim3(1), dim3(PICK_THREADS), 0, st, part, nblocks, budget, ctl, counts, maxPick);
+void launch_pick_coop(const int32_t *part, int32_t nblocks, int32_t budget, int32_t *ctl, hipStream_t st, int32_t *counts) {
+	hipLaunchKernelGGL(k_pick_coop, dim3(1), dim3(PICK_THREADS), 0, st, part, nblocks, budget, ctl, counts);
 }
 
 void launch_classify(int32_t cnt, const int32_t *outd, const int32_t *coopPtr, int32_t coopMin, int32_t giantMin, int32_t *biglist, int32_t *giantlist, int32_t giantCap, int32_t *ctl, hipStream_t st) {
@@ -1384,12 +1383,12 @@ void launch_classify(int32_t cnt, const int32_t *outd, const int32_t *coopPtr, i
 void launch_parse_big(const GraphDev &g, int def, const RangeView &v, const int32_t *biglist, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap,
                       int waves, int giantGroups, int *err, hipStream_t stGiant, hipStream_t stBig) {
 	if (v.cnt <= 0) return;
-	if (def == 1) hipLaunchKernelGGL((k_parse_big<1, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err, 0);
-	else if (def == 2) hipLaunchKernelGGL((k_parse_big<2, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err, 0);
-	else hipLaunchKernelGGL((k_parse_big<0, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err, 0);
-	if (def == 1) hipLaunchKernelGGL((k_parse_big<1, 1, RangeView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err, 0);
-	else if (def == 2) hipLaunchKernelGGL((k_parse_big<2, 1, RangeView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err, 0);
-	else hipLaunchKernelGGL((k_parse_big<0, 1, RangeView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err, 0);
+	if (def == 1) hipLaunchKernelGGL((k_parse_big<1, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+	else if (def == 2) hipLaunchKernelGGL((k_parse_big<2, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+	else hipLaunchKernelGGL((k_parse_big<0, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+	if (def == 1) hipLaunchKernelGGL((k_parse_big<1, 1, RangeView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
+	else if (def == 2) hipLaunchKernelGGL((k_parse_big<2, 1, RangeView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
+	else hipLaunchKernelGGL((k_parse_big<0, 1, RangeView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
 }
 
 void copy_thresholds(int32_t midMinKnob, bool bigGroups, int32_t &midMin, int32_t &bigMin);
@@ -1399,12 +1398,12 @@ void launch_bparse_big(const GraphDev &g, int def, const BatchView &v, int32_t c
 	if (v.cnt <= 0) return;
 	launch_classify((int32_t)v.cnt, v.outd, nullptr, coopMin, giantMin, biglist, giantlist, giantCap, ctl, st);
 	if (stGiant != st) { (void)hipEventRecord(evFork, st); (void)hipStreamWaitEvent(stGiant, evFork, 0); (void)hipStreamWaitEvent(stBig, evFork, 0); }
-	if (def == 1) hipLaunchKernelGGL((k_parse_big<1, GIANT_NW, BatchView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err, 0);
-	else if (def == 2) hipLaunchKernelGGL((k_parse_big<2, GIANT_NW, BatchView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err, 0);
-	else hipLaunchKernelGGL((k_parse_big<0, GIANT_NW, BatchView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err, 0);
-	if (def == 1) hipLaunchKernelGGL((k_parse_big<1, 1, BatchView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err, 0);
-	else if (def == 2) hipLaunchKernelGGL((k_parse_big<2, 1, BatchView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err, 0);
-	else hipLaunchKernelGGL((k_parse_big<0, 1, BatchView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err, 0);
+	if (def == 1) hipLaunchKernelGGL((k_parse_big<1, GIANT_NW, BatchView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+	else if (def == 2) hipLaunchKernelGGL((k_parse_big<2, GIANT_NW, BatchView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+	else hipLaunchKernelGGL((k_parse_big<0, GIANT_NW, BatchView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+	if (def == 1) hipLaunchKernelGGL((k_parse_big<1, 1, BatchView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
+	else if (def == 2) hipLaunchKernelGGL((k_parse_big<2, 1, BatchView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
+	else hipLaunchKernelGGL((k_parse_big<0, 1, BatchView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
 	if (stGiant != st) { (void)hipEventRecord(evGiant, stGiant); (void)hipEventRecord(evBig, stBig); }
 }
 
@@ -1423,16 +1422,16 @@ void launch_build_lists(const GraphDev &g, const RangeView &v, uint64_t giantBit
 
 void launch_parse_giants(const GraphDev &g, int def, const RangeView &v, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap, int giantGroups, int *err, hipStream_t st) {
 	if (v.cnt <= 0) return;
-	if (def == 1) hipLaunchKernelGGL((k_parse_big<1, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, st, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err, 0);
-	else if (def == 2) hipLaunchKernelGGL((k_parse_big<2, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, st, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err, 0);
-	else hipLaunchKernelGGL((k_parse_big<0, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, st, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err, 0);
+	if (def == 1) hipLaunchKernelGGL((k_parse_big<1, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, st, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+	else if (def == 2) hipLaunchKernelGGL((k_parse_big<2, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, st, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+	else hipLaunchKernelGGL((k_parse_big<0, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, st, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
 }
 
-void launch_parse_waves(const GraphDev &g, int def, const RangeView &v, const int32_t *biglist, int32_t *ctl, void *arena, int64_t arenaCap, int waves, int *err, hipStream_t st, int32_t dmin) {
+void launch_parse_waves(const GraphDev &g, int def, const RangeView &v, const int32_t *biglist, int32_t *ctl, void *arena, int64_t arenaCap, int waves, int *err, hipStream_t st) {
 	if (v.cnt <= 0) return;
-	if (def == 1) hipLaunchKernelGGL((k_parse_big<1, 1, RangeView>), dim3(waves), dim3(64), 0, st, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err, dmin);
-	else if (def == 2) hipLaunchKernelGGL((k_parse_big<2, 1, RangeView>), dim3(waves), dim3(64), 0, st, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err, dmin);
-	else hipLaunchKernelGGL((k_parse_big<0, 1, RangeView>), dim3(waves), dim3(64), 0, st, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err, dmin);
+	if (def == 1) hipLaunchKernelGGL((k_parse_big<1, 1, RangeView>), dim3(waves), dim3(64), 0, st, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
+	else if (def == 2) hipLaunchKernelGGL((k_parse_big<2, 1, RangeView>), dim3(waves), dim3(64), 0, st, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
+	else hipLaunchKernelGGL((k_parse_big<0, 1, RangeView>), dim3(waves), dim3(64), 0, st, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
 }
 
 // One chain level of the copy pass: three kernels, one per row class.  With side streams they run next to each

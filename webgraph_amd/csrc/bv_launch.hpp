@@ -61,7 +61,7 @@ void launch_chain_fill(const GraphDev &g, int def, const int32_t *nodes, int64_t
                        int32_t *sdepth, int32_t *sq, int32_t *aoutd, int32_t *qoutd, hipStream_t st);
 void launch_bparse(const GraphDev &g, int def, const BatchView &v, int *err, hipStream_t st);
 void launch_bcopy(const GraphDev &g, int def, const BatchView &v, int32_t level, int *err, hipStream_t st);
-void launch_pick_coop(const int32_t *part, int32_t nblocks, int32_t budget, int32_t *ctl, hipStream_t st, int32_t *counts = nullptr, int32_t maxPick = 0x7fffffff);
+void launch_pick_coop(const int32_t *part, int32_t nblocks, int32_t budget, int32_t *ctl, hipStream_t st, int32_t *counts = nullptr);
 constexpr int CTL_INTS = 32, CTL_COOP = 22, CTL_TOTAL_INTS = CTL_INTS; // control block (bv_kernels.hip)
 void launch_classify(int32_t cnt, const int32_t *outd, const int32_t *coopPtr, int32_t coopMin, int32_t giantMin, int32_t *biglist, int32_t *giantlist, int32_t giantCap, int32_t *ctl, hipStream_t st);
 void launch_parse_big(const GraphDev &g, int def, const RangeView &v, const int32_t *biglist, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap,
@@ -74,12 +74,7 @@ void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int
                        int32_t midMinKnob, bool bigGroups, const int32_t *bigQ, int32_t bigCap, const int32_t *midQ, int32_t midCap, int32_t *ctl, int32_t *tmp, uint32_t tmpCap, int *err,
                        hipStream_t st, hipStream_t stMid, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evMid, hipEvent_t evBig);
 void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, void *arena = nullptr, int64_t arenaCap = 0);
-void launch_parse_waves(const GraphDev &g, int def, const RangeView &v, const int32_t *biglist, int32_t *ctl, void *arena, int64_t arenaCap, int waves, int *err, hipStream_t st, int32_t dmin = 0);
-// bv_seg.hip: the records of the cooperative list with fewer than midMax successors, one wave each (what does not fit escapes to esc[], escCtl[0] = count)
-void launch_mid(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *count, int32_t listCap, int32_t midMax, int32_t *esc, int32_t *escCtl, int32_t escCap, int *err, hipStream_t st);
-int32_t mid_min_default();
-int32_t mid_max_default();
-constexpr int CTL_ESC = 24; // ctl[CTL_ESC] = records k_mid left to the cooperative kernel, ctl[CTL_ESC + 2] = head of that queue
+void launch_parse_waves(const GraphDev &g, int def, const RangeView &v, const int32_t *biglist, int32_t *ctl, void *arena, int64_t arenaCap, int waves, int *err, hipStream_t st);
 void launch_parse_giants(const GraphDev &g, int def, const RangeView &v, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap, int giantGroups, int *err, hipStream_t st);
 // bv_tile.hpp: short records decoded tile by tile from one LDS image of a contiguous slice of the stream
 int32_t tile_count(int64_t bitSpan, int32_t cnt);

@@ -124,10 +124,6 @@ struct bvg_graph {
 	DevBuf plist, pkeys, pkey16;
 	int tile = -1;       // -1: automatic (see enqueue_decode); BVGPU_TILE=0: never; BVGPU_TILE=1: short records decoded from contiguous tiles of the stream (k_parse_tile) instead of the bin-sorted parse list (k_parse_list)
 	DevBuf tilebounds;
-	int mid = 1;         // BVGPU_MID=0: every record between the lane class and the giants goes to the one-wave cooperative decoder (k_parse_big<1>); default: those below
-	                     // mid_max successors to the segment decoder (bv_seg.hip), and the lane class ends at mid_min at the latest
-	int32_t mid_min = 0, mid_max = 0; // BVGPU_MID_MIN / BVGPU_MID_MAX (0: the kernel's defaults)
-	DevBuf esclist;      // records the segment decoder left to the cooperative kernel
 	int copy_big = 1;    // BVGPU_COPY_BIG=0: every row is copied by one lane
 	int parse_windows = 1; // BVGPU_PARSE_WINDOWS=0: the parse list is sorted by work bin over the whole range
 	int copy_mid_min = 128; // rows with at least this many successors (and fewer than 1024) are copied by one wave each
@@ -220,10 +216,6 @@ int init_handle(bvg_graph *g) {
 	if (const char *e = getenv("BVGPU_COPY_BIG")) g->copy_big = atoi(e);
 	if (const char *e = getenv("BVGPU_PARSE_WINDOWS")) g->parse_windows = atoi(e);
 	if (const char *e = getenv("BVGPU_TILE")) g->tile = atoi(e);
-	if (const char *e = getenv("BVGPU_MID")) g->mid = atoi(e);
-	g->mid_min = bv::mid_min_default(); g->mid_max = bv::mid_max_default();
-	if (const char *e = getenv("BVGPU_MID_MIN")) g->mid_min = std::min(std::max(16, atoi(e)), 8192);
-	if (const char *e = getenv("BVGPU_MID_MAX")) g->mid_max = std::min(std::max(16, atoi(e)), 8192);
 	if (const char *e = getenv("BVGPU_WALK_TABLES")) g->walk_tables = atoi(e);
 	if (const char *e = getenv("BVGPU_IV_ARENA")) g->iv_arena = atoi(e);
 	if (const char *e = getenv("BVGPU_COPY_MID_MIN")) g->copy_mid_min = std::min(std::max(0, atoi(e)), 1024); // 0: no wave-per-row copy
@@ -272,7 +264,7 @@ int enqueue_structure(bvg_graph *g, int32_t from, int32_t to, int32_t nh, bv::Ra
 	bv::launch_headers(gd, s.def, lo, cnt, v.outd, v.ref, derr, g->stream, pick ? g->pickpart.as<int32_t>() : nullptr);
 	if (nh) bv::launch_mark_halo(nh, cnt, s.info.window_size, v.outd, v.ref, g->need.as<uint8_t>(), derr, g->stream);
 	if (pick) { // (also zeroes ctl[4..16), the counters of the lists and of the copy levels: a memset behind the scan kernels sat 22 us on the critical path)
-		bv::launch_pick_coop(g->pickpart.as<int32_t>(), (int32_t)hb, COOP_BUDGET, g->coopctl.as<int32_t>(), g->stream, nullptr, g->mid && s.def != 0 ? g->mid_min : 0x7fffffff);
+		bv::launch_pick_coop(g->pickpart.as<int32_t>(), (int32_t)hb, COOP_BUDGET, g->coopctl.as<int32_t>(), g->stream);
 		v.coop_ptr = g->coopctl.as<int32_t>() + bv::CTL_COOP;
 		g->ctl_clean = true;
 	}
@@ -389,10 +381,6 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 	const Staged &s = *g->st;
 	int32_t coopMin, giantMin;
 	pick_thresholds(g, estArcs, coopMin, giantMin);
-	// the records from mid_min successors up are cheap for any job (a wave each, their residual sections cut into segments: bv_seg.hip)
-	const bool mid = g->mid != 0 && s.def != 0 && coopMin < 0x7fffffff;
-	if (mid && g->adaptive) coopMin = std::min(coopMin, g->mid_min);
-	const int32_t midMax = mid ? std::max(g->mid_max, coopMin) : 0;
 	const int32_t W = s.info.window_size;
 	int *derr = &g->small.as<Small>()->err;
 	bv::GraphDev gd = graph_dev(s);
@@ -495,31 +483,9 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			}
 		}
 		// the long records first on both side streams: giants on B, the wave class on A ...
-		// the records of the cooperative list below mid_max successors: one wave each through the segment decoder; the rest of the list, and what that
-		// decoder could not take, through the one-wave cooperative decoder
-		int32_t segListCap = 0;
-		if (mid) {
-			int64_t c = arcsBound / std::max(coopMin, 1) + 2;
-			if (s.deg_counts[0] >= 0) { // (counted at load time: records of the staged graph with >= 128 << k successors)
-				int k = -1;
-				for (int t = 0; t < 5; t++) if ((128 << t) <= (v.coop_ptr ? 128 : coopMin)) k = t;
-				if (k >= 0) c = std::min<int64_t>(c, (int64_t)s.deg_counts[k] + 1);
-			}
-			segListCap = (int32_t)std::min<int64_t>(c, v.cnt);
-			if (!g->esclist.need(sizeof(int32_t) * (size_t)std::max(segListCap, 1))) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
-		}
-		auto launchWaveClass = [&](hipStream_t st) {
-			if (mid) {
-				bv::launch_mid(gd, s.def, v, g->biglist.as<int32_t>(), ctl, segListCap, midMax, g->esclist.as<int32_t>(), ctl + bv::CTL_ESC, segListCap, derr, st);
-				bv::launch_parse_waves(gd, s.def, v, g->biglist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, derr, st, midMax);
-				bv::launch_parse_waves(gd, s.def, v, g->esclist.as<int32_t>(), ctl + bv::CTL_ESC, g->arena.p, arenaCap, std::min(g->coop_waves, 1024), derr, st, 0);
-			}
-			else bv::launch_parse_waves(gd, s.def, v, g->biglist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, derr, st, 0);
-		};
 		if (ovl && coop) {
 			HIPCHK(g, hipStreamWaitEvent(g->sideA, g->evC, 0));
-			bv::launch_parse_giants(gd, s.def, v, g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->giant_groups, derr, side_b(g));
-			launchWaveClass(g->sideA);
+			bv::launch_parse_big(gd, s.def, v, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, g->giant_groups, derr, side_b(g), g->sideA); // (giants, big)
 			HIPCHK(g, hipEventRecord(g->evB, side_b(g)));
 		}
 		// ... then, behind the wave class, the chain depth of every record + per-level lists (node order inside a level) +
@@ -537,7 +503,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		mark(g, 3);
 		if (coop && !ovl) bv::launch_parse_giants(gd, s.def, v, g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->giant_groups, derr, g->stream);
 		mark(g, 4);
-		if (coop && !ovl) launchWaveClass(g->stream);
+		if (coop && !ovl) bv::launch_parse_waves(gd, s.def, v, g->biglist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, derr, g->stream);
 		mark(g, 5);
 		if (tiles) bv::launch_parse_tile(gd, s.def, v, g->tilebounds.as<int32_t>(), ntiles, tileVariant, derr, g->stream);
 		else bv::launch_parse_list(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, g->level_blocks, derr, g->stream, g->iv_arena ? g->arena.p : nullptr, arenaCap);
@@ -825,7 +791,7 @@ extern "C" int bvg_close(bvg_t *g) {
 	if (g->st && g->st->device >= 0) {
 		(void)hipSetDevice(g->st->device);
 		if (g->own) { (void)hipStreamSynchronize(g->own); (void)hipStreamDestroy(g->own); }
-		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->hashBounds, &g->pickpart, &g->walktab, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist, &g->plist, &g->pkeys, &g->pkey16, &g->copyq, &g->bigtmp, &g->tilebounds, &g->esclist }) b->release();
+		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->hashBounds, &g->pickpart, &g->walktab, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist, &g->plist, &g->pkeys, &g->pkey16, &g->copyq, &g->bigtmp, &g->tilebounds }) b->release();
 		for (DevBuf *b : { &g->hchunk[0], &g->hchunk[1], &g->statsbuf, &g->bfs_rowptr, &g->bfs_succ, &g->bfs_ctr }) b->release();
 		for (PinBuf *b : { &g->hring[0], &g->hring[1], &g->view_rowptr, &g->view_succ }) b->release();
 		for (hipEvent_t e : { g->evChunk[0], g->evChunk[1], g->evCopied[0], g->evCopied[1] }) if (e) (void)hipEventDestroy(e);
