@@ -123,8 +123,7 @@ int bvg_get_profile(bvg_t *g, float *ms);
  * picked on the device from the job's outdegrees, the second from the job's size; bench.py prices each kernel on its own records. */
 int bvg_last_thresholds(bvg_t *g, int32_t *coop_min, int32_t *giant_min);
 
-/* Tuning counters (only when BVGPU_STATS=1 was set at bvg_open): 64 uint64 -- [0, 32) the cooperative decoder's (bv_device.hpp),
- * [32, 64) the strip kernel's per-phase clock ticks (bv_strip.hip). */
+/* Tuning counters (only when BVGPU_STATS=1 was set at bvg_open): 64 uint64 -- [0, 32) the cooperative decoder's (bv_device.hpp), the rest spare. */
 int bvg_debug_stats(bvg_t *g, uint64_t *out16, int reset);
 
 /* ---- the hot path ---------------------------------------------------------------------------------- */

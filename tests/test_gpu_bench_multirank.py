@@ -48,3 +48,35 @@ def test_two_rank_bench_line(tmp_path, workload, nodes, arcs):
     assert cfg["parity"].endswith("== CPU oracle's")
     assert out["value"] > 0 and abs(out["value"] - cfg["arcs_total"] / (out["ms_per_step"] * 1e-3)) <= 1e-3 * out["value"]
     assert out.get("cpu_baseline") is None or isinstance(out["cpu_baseline"], dict)
+
+
+def _bench(args, tmp_path, timeout=900):
+    env = dict(os.environ)
+    env["BVGPU_CACHE"] = str(tmp_path / "cache")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, "bench.py failed:\n" + p.stdout[-2000:] + "\n" + p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(1200)
+def test_single_gpu_bench_line_prices_every_phase(tmp_path):
+    """The N = 1 line at a small size: whole CSR against the oracle before anything is timed, `roofline` with the copy pass priced
+    (4 B x ids of the rows with a reference and of their referents: SURVEY.md section 8(d)), `cpu_baseline` present."""
+    out = _bench(["--nodes", "400000", "--arcs", "8000000", "--steps", "3", "--warmup", "1", "--no-pmc", "--cpu-budget", "2"], tmp_path)
+    assert out["n_gpus"] == 1 and out["unit"] == "edges/s" and out["config"]["parity"].startswith("whole CSR bit-exact vs CPU oracle")
+    r = out["roofline"]
+    assert r["bound"] == "hbm" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    copy = [v for k, v in r["kernels"].items() if k.startswith("k_copy_list")][0]
+    assert copy["alg_bytes"] and copy["alg_bytes"] > 0 and copy["GBps"] > 0
+    assert any(v["alg_bytes"] == r["kernel_algorithmic_bytes"] for v in r["kernels"].values())
+    assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["cores"] == 1 and out["cpu_baseline"]["value"] > 0
+
+
+@pytest.mark.timeout(1200)
+def test_random_access_bench_with_first(tmp_path):
+    """SpeedTest's random leg with --first (SpeedTest.java:107-108): the first successor of every list, checked against the oracle inside bench.py."""
+    out = _bench(["--mode", "random", "--first", "--nodes", "300000", "--arcs", "6000000", "--queries", "200000", "--steps", "2", "--warmup", "1"], tmp_path)
+    assert out["unit"] == "lists/s" and out["config"]["first"] is True and "first successor of" in out["config"]["parity"]
+    assert 0 < out["roofline"]["frac"] < 1 and out["roofline"]["algorithmic_bytes_per_step"] > 4 * 200000
