@@ -194,6 +194,18 @@ int bvg_bfs_expand(bvg_t *g, const int32_t *frontier_dev, size_t q, int32_t *mar
                    int32_t *out_dev, size_t out_cap, uint64_t *out_count);
 
 /*
+ * One standard iteration of HyperBall over nodes [from, to) (src/it/unimi/dsi/webgraph/algo/HyperBall.java:875-915, :972-978): for every node x,
+ * regs_out[x] = register-wise maximum of regs_in[x] and regs_in[s] over the successors s != x whose counter changed in the previous iteration
+ * (modified_in[s] != 0; modified_in == NULL: every counter counts, as in the first iteration), and modified_out[x] = (regs_out[x] != regs_in[x]).
+ * A counter is 2^log2m registers of one byte each (HyperLogLog registers are at most 7 bits wide; the reference packs them into longwords).
+ * All pointers are DEVICE pointers: regs_in / regs_out [nodes << log2m] bytes, modified_in / modified_out [nodes] bytes; only the entries of
+ * [from, to) are written.  *changed (host) receives the number of counters of [from, to) that changed.  The rows are decoded piece by piece
+ * into library scratch; no successor array reaches the caller.
+ */
+int bvg_hyperball_step(bvg_t *g, int32_t from, int32_t to, int log2m, const uint8_t *regs_in_dev, uint8_t *regs_out_dev, const uint8_t *modified_in_dev,
+                       uint8_t *modified_out_dev, uint64_t *changed);
+
+/*
  * Random access: concatenation of successorArray(nodes[i]) (BVG:897-904, ImmutableGraph.java:329-333),
  * reference chains resolved on the device.  rowptr has q+1 entries; ids may repeat and come in any order; an id
  * outside [0, n) is BVG_EARG (BVG:900).  succ == NULL: count-only; BVG_ECAP as above, checked before any decode.

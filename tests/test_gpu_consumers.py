@@ -112,3 +112,50 @@ def test_breadth_first_visit(cnr_gpu, cnr_oracle, parent):
     # a second visit from a marked node visits nothing (visit() returns 0 when marker[start] != -1)
     q2, cut2, _ = cnr_gpu.bfs(int(q[-1]), parent=parent, round_=4, marker=marker)
     assert q2.numel() == 0
+
+
+def hyperball_restated(rp, sc, regs, modified, lo, hi):
+    """HyperBall.java:875-915 for a standard iteration: register-wise max with the successors whose counter changed, self-loops skipped."""
+    out = regs.copy()
+    for x in range(lo, hi):
+        s = sc[rp[x]:rp[x + 1]].astype(np.int64)
+        s = s[s != x]
+        if modified is not None:
+            s = s[modified[s] != 0]
+        if s.size:
+            out[x] = np.maximum(regs[x], regs[s].max(axis=0))
+    mod = np.zeros(regs.shape[0], dtype=np.uint8)
+    mod[lo:hi] = (out[lo:hi] != regs[lo:hi]).any(axis=1)
+    return out, mod
+
+
+@pytest.mark.parametrize("log2m", [4, 7])
+def test_hyperball_iterations(cnr_gpu, cnr_oracle, log2m):
+    """Three iterations of the register-max step on the fixture (random 6-bit registers), every register and every `modified` flag against a
+    numpy restatement; the second and third iterations only look at counters that changed, as HyperBall.java:909 does."""
+    import torch
+    og, rp, sc = cnr_oracle
+    n, m = og.n, 1 << log2m
+    rng = np.random.Generator(np.random.PCG64(99 + log2m))
+    regs = (rng.integers(0, 64, size=(n, m)) * (rng.random((n, m)) < 0.2)).astype(np.uint8)
+    d_in = torch.from_numpy(regs).cuda()
+    d_out = d_in.clone()
+    d_mod_in, d_mod_out = None, torch.zeros(n, dtype=torch.uint8, device="cuda")
+    mod = None
+    for it in range(3):
+        changed = cnr_gpu.hyperball_step(log2m, d_in.data_ptr(), d_out.data_ptr(), d_mod_in.data_ptr() if d_mod_in is not None else None, d_mod_out.data_ptr())
+        want, wmod = hyperball_restated(rp, sc, regs, mod, 0, n)
+        assert np.array_equal(d_out.cpu().numpy(), want), "iteration %d" % it
+        assert np.array_equal(d_mod_out.cpu().numpy(), wmod) and changed == int(wmod.sum())
+        regs, mod = want, wmod
+        d_in, d_out = d_out, d_in.clone()
+        d_in = torch.from_numpy(regs).cuda()
+        d_out = d_in.clone()
+        d_mod_in, d_mod_out = torch.from_numpy(mod).cuda(), torch.zeros(n, dtype=torch.uint8, device="cuda")
+    # a sub-range only writes its own counters
+    d_in = torch.from_numpy(regs).cuda()
+    d_out = torch.full_like(d_in, 255)
+    cnr_gpu.hyperball_step(log2m, d_in.data_ptr(), d_out.data_ptr(), None, d_mod_out.data_ptr(), 1000, 3000)
+    o = d_out.cpu().numpy()
+    assert np.all(o[:1000] == 255) and np.all(o[3000:] == 255)
+    assert np.array_equal(o[1000:3000], hyperball_restated(rp, sc, regs, None, 1000, 3000)[0][1000:3000])

@@ -39,7 +39,7 @@ class BvgLabelsInfo(C.Structure):
 
 
 EXPORTS = ["bvg_open", "bvg_open_shard", "bvg_clone", "bvg_close", "bvg_info", "bvg_last_error", "bvg_set_stream", "bvg_sync",
-           "bvg_outdegrees", "bvg_decode_range", "bvg_decode_range_view", "bvg_host_alloc", "bvg_host_free", "bvg_scan_checksum", "bvg_scan_stats", "bvg_bfs_expand", "bvg_successors_batch", "bvg_csr_hashcode", "bvg_shard_bounds",
+           "bvg_outdegrees", "bvg_decode_range", "bvg_decode_range_view", "bvg_host_alloc", "bvg_host_free", "bvg_scan_checksum", "bvg_scan_stats", "bvg_bfs_expand", "bvg_hyperball_step", "bvg_successors_batch", "bvg_csr_hashcode", "bvg_shard_bounds",
            "bvg_parse_properties", "bvg_flags_from_string", "bvg_decode_offsets_host", "bvg_decode_offsets_device", "bvg_labels_open", "bvg_labels_close", "bvg_labels_info",
            "bvg_labels_last_error", "bvg_labels_parse_properties", "bvg_labels_decode_range", "bvg_set_profile", "bvg_get_profile", "bvg_debug_stats", "bvg_last_thresholds"]
 
@@ -78,6 +78,7 @@ def lib():
         L.bvg_scan_checksum.argtypes = [vp, i32, i32, C.POINTER(i32), C.POINTER(u64)]
         L.bvg_scan_stats.argtypes = [vp, i32, i32, C.POINTER(BvgScanStats), vp]
         L.bvg_bfs_expand.argtypes = [vp, vp, sz, vp, i32, C.c_int, vp, sz, C.POINTER(u64)]
+        L.bvg_hyperball_step.argtypes = [vp, i32, i32, C.c_int, vp, vp, vp, vp, C.POINTER(u64)]
         L.bvg_successors_batch.argtypes = [vp, vp, sz, vp, vp, sz, C.POINTER(u64), C.c_int]
         L.bvg_csr_hashcode.argtypes = [vp, i32, i32, vp, vp, C.POINTER(i32)]
         L.bvg_shard_bounds.argtypes = [vp, C.c_int, vp]
@@ -428,6 +429,14 @@ class BVGraph:
         d = {k: getattr(st, k) for k, _ in BvgScanStats._fields_ if k != "successor_delta_stats"}
         d["successor_delta_stats"] = list(st.successor_delta_stats)
         return d
+
+    def hyperball_step(self, log2m, regs_in_ptr, regs_out_ptr, modified_in_ptr, modified_out_ptr, lo=0, hi=None):
+        """One standard iteration of HyperBall over nodes [lo, hi) (HyperBall.java:875-915) on the device: register-wise maximum of every
+        node's counter with its successors' (device pointers; modified_in_ptr None: every counter counts); returns the number of counters that changed."""
+        hi = self.numNodes() if hi is None else hi
+        cnt = C.c_uint64(0)
+        self._check(lib().bvg_hyperball_step(self._h, lo, hi, log2m, regs_in_ptr, regs_out_ptr, modified_in_ptr, modified_out_ptr, C.byref(cnt)))
+        return cnt.value
 
     def bfs_expand(self, frontier_ptr, q, marker_ptr, round_, parent, out_ptr, out_cap):
         """One round of ParallelBreadthFirstVisit (device pointers); returns the size of the next frontier."""

@@ -145,4 +145,39 @@ void launch_bfs_expand(const int32_t *frontier, int32_t q, const int64_t *rowptr
 	hipLaunchKernelGGL(k_bfs_expand, dim3((unsigned)((arcs + CS_ARCS - 1) / CS_ARCS)), dim3(CS_T), 0, st, frontier, q, rowptr, succ, marker, n, round, parent, out, (unsigned long long)outCap, outCount);
 }
 
+// One standard (non-systolic) iteration of HyperBall over rows decoded into scratch (src/it/unimi/dsi/webgraph/algo/HyperBall.java:875-915):
+// t = counter[node]; for every successor s != node whose counter changed in the previous iteration, t = max(t, counter[s]) register by
+// register (:907-913, max() is a register-wise maximum); a counter that changed is stored in the result array and flagged (:972-978).  A counter
+// is m = 2^log2m registers, one byte each here (the reference packs registerSize bits into longwords and maximises them broadword: same values).
+// One wave per node, lane r takes registers r, r + 64, ...: the successors' counters are read 64 bytes at a time.
+__global__ void __launch_bounds__(CS_T) k_hyperball(int32_t from, int32_t cnt, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ, int32_t n, int32_t m,
+                                                    const uint8_t *__restrict__ regsIn, uint8_t *__restrict__ regsOut, const uint8_t *__restrict__ modIn, uint8_t *__restrict__ modOut,
+                                                    unsigned long long *__restrict__ changed) {
+	const int lane = threadIdx.x & 63;
+	const int32_t row = blockIdx.x * (CS_T / 64) + (threadIdx.x >> 6);
+	if (row >= cnt) return;
+	const int32_t node = from + row;
+	const int64_t lo = rowptr[row], hi = rowptr[row + 1];
+	bool any = false;
+	for (int32_t r0 = 0; r0 < m; r0 += 64) {
+		const int32_t r = r0 + lane;
+		const uint8_t t0 = r < m ? regsIn[(size_t)node * m + r] : 0;
+		uint8_t t = t0;
+		for (int64_t a = lo; a < hi; a++) {
+			const int32_t sx = succ[a]; // (the same address for every lane: one broadcast load)
+			if (sx == node || (uint32_t)sx >= (uint32_t)n || (modIn && !modIn[sx])) continue; // neither self-loops nor unmodified counters influence the computation (:909)
+			if (r < m) { const uint8_t u = regsIn[(size_t)sx * m + r]; t = u > t ? u : t; }
+		}
+		if (r < m) regsOut[(size_t)node * m + r] = t;
+		any |= t != t0;
+	}
+	const bool rowChanged = __any(any);
+	if (lane == 0) { modOut[node] = rowChanged ? 1 : 0; if (rowChanged) atomicAdd(changed, 1ull); }
+}
+void launch_hyperball(int32_t from, int32_t cnt, const int64_t *rowptr, const int32_t *succ, int32_t n, int32_t m, const uint8_t *regsIn, uint8_t *regsOut, const uint8_t *modIn, uint8_t *modOut,
+                      unsigned long long *changed, hipStream_t st) {
+	if (cnt <= 0) return;
+	hipLaunchKernelGGL(k_hyperball, dim3((unsigned)((cnt + CS_T / 64 - 1) / (CS_T / 64))), dim3(CS_T), 0, st, from, cnt, rowptr, succ, n, m, regsIn, regsOut, modIn, modOut, changed);
+}
+
 } // namespace bv

@@ -1347,6 +1347,40 @@ extern "C" int bvg_scan_stats(bvg_t *g, int32_t from, int32_t to, bvg_scan_stats
 	return BVG_OK;
 }
 
+extern "C" int bvg_hyperball_step(bvg_t *g, int32_t from, int32_t to, int log2m, const uint8_t *regs_in_dev, uint8_t *regs_out_dev, const uint8_t *modified_in_dev,
+                                  uint8_t *modified_out_dev, uint64_t *changed) {
+	if (!g || !g->st || !regs_in_dev || !regs_out_dev || !modified_out_dev || !changed) return BVG_EARG;
+	const Staged &s = *g->st;
+	if (log2m < 0 || log2m > 16) return fail(g, BVG_EARG, "log2m out of range");
+	if (from < 0 || from > s.info.nodes || to < from || to > s.info.nodes) return fail(g, BVG_EARG, "node range out of bounds"); // BVG:1165
+	HIPCHK(g, hipSetDevice(s.device));
+	*changed = 0;
+	if (!g->bfs_ctr.need(sizeof(unsigned long long))) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
+	HIPCHK(g, hipMemset(g->bfs_ctr.p, 0, sizeof(unsigned long long)));
+	const std::vector<int32_t> cut = plan_chunks_by_bits(s, from, to, scan_piece_arcs());
+	for (size_t k = 0; k + 1 < cut.size(); k++) {
+		const int32_t a = cut[k], e = cut[k + 1];
+		if (e == a) continue;
+		if (!g->stage_rowptr.need(sizeof(int64_t) * ((size_t)(e - a) + 1))) return fail(g, BVG_ENOMEM, "staging allocation failed");
+		const uint64_t guess = (uint64_t)(est_arcs(s, a, e) * 1.1) + 4096;
+		if (!g->stage_succ.need(sizeof(int32_t) * (size_t)guess)) return fail(g, BVG_ENOMEM, "staging allocation failed");
+		uint64_t arcs = 0;
+		int rc = decode_range_device(g, a, e, g->stage_rowptr.as<int64_t>(), g->stage_succ.as<int32_t>(), g->stage_succ.cap / sizeof(int32_t), false, &arcs);
+		if (rc == BVG_ECAP) {
+			if (!g->stage_succ.need(sizeof(int32_t) * (size_t)std::max<uint64_t>(arcs, 1))) return fail(g, BVG_ENOMEM, "staging allocation failed");
+			rc = decode_range_device(g, a, e, g->stage_rowptr.as<int64_t>(), g->stage_succ.as<int32_t>(), g->stage_succ.cap / sizeof(int32_t), false, &arcs);
+		}
+		if (rc) return rc;
+		bv::launch_hyperball(a, e - a, g->stage_rowptr.as<int64_t>(), g->stage_succ.as<int32_t>(), s.info.nodes, 1 << log2m, regs_in_dev, regs_out_dev, modified_in_dev, modified_out_dev,
+		                     g->bfs_ctr.as<unsigned long long>(), g->stream);
+		HIPCHK(g, hipStreamSynchronize(g->stream)); // the scratch rows are reused by the next piece
+	}
+	unsigned long long c = 0;
+	HIPCHK(g, hipMemcpy(&c, g->bfs_ctr.p, sizeof(c), hipMemcpyDeviceToHost));
+	*changed = (uint64_t)c;
+	return BVG_OK;
+}
+
 extern "C" int bvg_bfs_expand(bvg_t *g, const int32_t *frontier_dev, size_t q, int32_t *marker_dev, int32_t round, int parent, int32_t *out_dev, size_t out_cap, uint64_t *out_count) {
 	if (!g || !g->st || !marker_dev || (!frontier_dev && q) || (!out_dev && out_cap) || !out_count) return BVG_EARG;
 	const Staged &s = *g->st;
