@@ -249,13 +249,14 @@ int bvg_decode_offsets_device(int device, const uint8_t *offsets_file, size_t le
  * labelling/BitStreamArcLabelledImmutableGraph.java:60-135: <basename>.properties names the underlying graph and the
  * label class (`underlyinggraph`, `labelspec`), <basename>.labels holds the labels of all arcs in enumeration order as
  * one bit stream, <basename>.labeloffsets the gamma-coded lengths of the per-node label lists (:652-671).  Supported
- * label classes: GammaCodedIntLabel (GammaCodedIntLabel.java:60-64) and FixedWidthIntLabel (FixedWidthIntLabel.java:70-73).
+ * label classes: GammaCodedIntLabel (GammaCodedIntLabel.java:60-64), FixedWidthIntLabel (FixedWidthIntLabel.java:70-73) and
+ * FixedWidthIntListLabel (FixedWidthIntListLabel.java:107-112, a list of ints per arc: bvg_labels_decode_lists).
  * The labels of the arcs of nodes [from, to) come out in the CSR order of bvg_decode_range on the underlying graph. */
 typedef struct bvg_labels bvg_labels_t;
-enum { BVG_LABEL_GAMMA = 1, BVG_LABEL_FIXED = 2 };
+enum { BVG_LABEL_GAMMA = 1, BVG_LABEL_FIXED = 2, BVG_LABEL_FIXED_LIST = 3 };
 typedef struct bvg_labels_info {
-	int32_t  kind;             /* BVG_LABEL_GAMMA / BVG_LABEL_FIXED */
-	int32_t  width;            /* bits per label (BVG_LABEL_FIXED) */
+	int32_t  kind;             /* BVG_LABEL_GAMMA / BVG_LABEL_FIXED / BVG_LABEL_FIXED_LIST */
+	int32_t  width;            /* bits per label (BVG_LABEL_FIXED) or per list element (BVG_LABEL_FIXED_LIST) */
 	int32_t  nodes;            /* nodes of the underlying graph */
 	int32_t  device;
 	uint64_t labels_bytes;     /* size of <basename>.labels */
@@ -275,6 +276,15 @@ int bvg_labels_parse_properties(const char *basename, bvg_labels_info_t *out, ch
 /* Labels of the `arcs` arcs of nodes [from, to) (arcs = rowptr[to] - rowptr[from] of the underlying graph; checked against
  * the stream: BVG_EFORMAT if the stream holds another number of labels).  flags: BVG_OUT_HOST or BVG_OUT_DEVICE. */
 int bvg_labels_decode_range(bvg_labels_t *h, int32_t from, int32_t to, uint64_t arcs, int32_t *labels, int flags);
+/* FixedWidthIntListLabel.fromBitStream (FixedWidthIntListLabel.java:107-112: value = new int[readGamma()], then readInt(width)
+ * each): the lists of the `arcs` arcs of nodes [from, to) as a CSR over the arcs -- the list of arc k (CSR order of
+ * bvg_decode_range) is values[list_ptr[k] .. list_ptr[k+1]).  list_ptr: int64[arcs + 1]; values: int32[values_cap].
+ * *nvalues reports the number of values of the range; BVG_ECAP if it exceeds values_cap (nothing is written to `values`
+ * then: call with values_cap = 0 to size the buffer).  BVG_EFORMAT if the stream does not hold exactly `arcs` lists ending on
+ * the node boundaries of .labeloffsets; BVG_EUNSUPPORTED for the one-int-per-arc label classes (and bvg_labels_decode_range
+ * answers BVG_EUNSUPPORTED for this one).  flags: BVG_OUT_HOST or BVG_OUT_DEVICE (both arrays). */
+int bvg_labels_decode_lists(bvg_labels_t *h, int32_t from, int32_t to, uint64_t arcs, int64_t *list_ptr, int32_t *values, uint64_t values_cap,
+                            uint64_t *nvalues, int flags);
 
 #ifdef __cplusplus
 }

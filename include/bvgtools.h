@@ -71,6 +71,10 @@ int bvt_random_nodes(uint64_t seed, int32_t n, int64_t count, int32_t *out);
  */
 int bvt_store_labels(const char *basename, const char *underlying, int32_t n, const int64_t *rowptr, const int32_t *labels,
                      int kind, int width, const char *key);
+/* The same for FixedWidthIntListLabel(key, width) (FixedWidthIntListLabel.java:114-119): arc a (CSR order) carries the list
+ * values[listptr[a] .. listptr[a+1]); every value must fit in `width` bits.  listptr: int64[rowptr[n] + 1]. */
+int bvt_store_label_lists(const char *basename, const char *underlying, int32_t n, const int64_t *rowptr, const int64_t *listptr,
+                          const int32_t *values, int width, const char *key);
 
 #ifdef __cplusplus
 }

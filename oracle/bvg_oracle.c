@@ -523,3 +523,42 @@ int bvo_labels_decode(const uint8_t *labels, size_t len, const uint8_t *loffs, s
 	free(b); free(off);
 	return rc;
 }
+
+/* FixedWidthIntListLabel.java:107-112 (fromBitStream): value = new int[ibs.readGamma()]; value[i] = ibs.readInt(width).
+ * One list per arc; the lists of node x start at labeloffsets[x] as for the int labels above.  Out: listptr[k] = index in
+ * `values` of the first element of arc k's list, listptr[arcs] = number of values.  Parity unpinned (the reference holds
+ * no fixture for labelled graphs; see tests/test_labels_cpu.py). */
+int bvo_labels_decode_lists(const uint8_t *labels, size_t len, const uint8_t *loffs, size_t olen, int32_t n, int width, int32_t from, int32_t to,
+                            const int32_t *outd, int64_t *listptr, size_t lcap, int32_t *values, size_t vcap, uint64_t *nlists, uint64_t *nvalues) {
+	if ((!labels && len) || !loffs || from < 0 || to < from || to > n || width < 0 || width > 32) return BVO_EARG;
+	int64_t *off = (int64_t *)malloc(sizeof(int64_t) * ((size_t)n + 1));
+	if (!off) return BVO_ENOMEM;
+	int rc = bvo_decode_offsets(loffs, olen, n, 2 /* gamma */, off);
+	if (rc) { free(off); return rc; }
+	uint8_t *b = (uint8_t *)calloc(len + 16, 1);
+	if (!b) { free(off); return BVO_ENOMEM; }
+	if (len) memcpy(b, labels, len);
+	ibs_t s = { b, 0, (uint64_t)len * 8, 0 };
+	uint64_t k = 0, v = 0;
+	for (int32_t x = from; x < to && !rc; x++) {
+		s.pos = (uint64_t)off[x];
+		for (int32_t j = 0; j < outd[x - from] && !rc; j++) {
+			const uint64_t cnt = read_gamma(&s);
+			if (s.err) { rc = BVO_EFORMAT; break; }
+			if (listptr) { if (k >= lcap) { rc = BVO_EARG; break; } listptr[k] = (int64_t)v; }
+			k++;
+			for (uint64_t i = 0; i < cnt; i++) {
+				const uint64_t e = width ? read_bits(&s, (unsigned)width) : 0;
+				if (s.err) { rc = BVO_EFORMAT; break; }
+				if (values) { if (v >= vcap) { rc = BVO_EARG; break; } values[v] = (int32_t)(uint32_t)e; }
+				v++;
+			}
+		}
+		if (!rc && s.pos != (uint64_t)off[x + 1]) rc = BVO_EFORMAT;
+	}
+	if (!rc && listptr) { if (k >= lcap) rc = BVO_EARG; else listptr[k] = (int64_t)v; }
+	if (nlists) *nlists = k;
+	if (nvalues) *nvalues = v;
+	free(b); free(off);
+	return rc;
+}

@@ -331,7 +331,7 @@ def read_ascii_graph_gz(path):
 
 
 def parse_labelspec(spec):
-    """'<class>(KEY[,WIDTH])' -> (kind, width, key): kind 1 = GammaCodedIntLabel, 2 = FixedWidthIntLabel (Label.toSpec())."""
+    """'<class>(KEY[,WIDTH])' -> (kind, width, key): kind 1 = GammaCodedIntLabel, 2 = FixedWidthIntLabel, 3 = FixedWidthIntListLabel (Label.toSpec())."""
     cls, args = spec.split("(", 1)
     args = [a.strip() for a in args.rsplit(")", 1)[0].split(",")]
     name = cls.strip().rsplit(".", 1)[-1]
@@ -339,6 +339,8 @@ def parse_labelspec(spec):
         return 1, -1, args[0]
     if name == "FixedWidthIntLabel" and len(args) == 2:
         return 2, int(args[1]), args[0]
+    if name == "FixedWidthIntListLabel" and len(args) == 2:
+        return 3, int(args[1]), args[0]
     raise ValueError("unsupported label class: " + spec)
 
 
@@ -357,3 +359,29 @@ def labels_decode(basename, n, outd, lo=0, hi=None):
     if rc:
         raise OracleError(rc)
     return out[:cnt.value]
+
+
+def label_lists_decode(basename, n, outd, lo=0, hi=None):
+    """(listptr, values) of the arcs of nodes [lo, hi) of a graph labelled with FixedWidthIntListLabel (test oracle)."""
+    props = parse_properties(basename + ".properties")
+    kind, width, _ = parse_labelspec(props["labelspec"])
+    assert kind == 3
+    hi = n if hi is None else hi
+    lab = np.frombuffer(open(basename + ".labels", "rb").read(), dtype=np.uint8)
+    lof = np.frombuffer(open(basename + ".labeloffsets", "rb").read(), dtype=np.uint8)
+    outd = np.ascontiguousarray(outd, dtype=np.int32)
+    arcs = int(outd.sum())
+    f = lib().bvo_labels_decode_lists
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int32, C.c_int, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t,
+                  C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    nl, nv = C.c_uint64(0), C.c_uint64(0)
+    args = (lab.ctypes.data if lab.size else None, lab.size, lof.ctypes.data, lof.size, n, width, lo, hi, outd.ctypes.data)
+    rc = f(*args, None, 0, None, 0, C.byref(nl), C.byref(nv))  # sizing pass
+    if rc:
+        raise OracleError(rc)
+    listptr = np.empty(arcs + 1, dtype=np.int64)
+    values = np.empty(max(nv.value, 1), dtype=np.int32)
+    rc = f(*args, listptr.ctypes.data, listptr.size, values.ctypes.data, values.size, C.byref(nl), C.byref(nv))
+    if rc:
+        raise OracleError(rc)
+    return listptr, values[:nv.value]

@@ -47,3 +47,36 @@ def test_labels_wrong_arc_count_is_an_error(tmp_path):
     assert lib().bvg_labels_decode_range(g._h, 0, 2001, succ.size, out.ctypes.data, 0) != 0      # node range out of bounds
     assert lib().bvg_labels_decode_range(g._h, 0, 2000, succ.size, out.ctypes.data, 0) == 0
     g.close()
+
+
+@pytest.mark.parametrize("width,n,m", [(9, 20000, 400000), (32, 500, 4000), (0, 500, 4000), (1, 100000, 2000000)])
+def test_label_lists_match_oracle(tmp_path, width, n, m):
+    """FixedWidthIntListLabel: a list of ints per arc, decoded as a CSR over the arcs (bvg_labels_decode_lists)."""
+    import ctypes as C
+    from webgraph_amd import tools as T
+    from webgraph_amd.bvgraph import ArcLabelledBVGraph, lib
+    from oracle import oracle as O
+    from test_labels_cpu import _lists
+    rowptr, succ = T.generate(n, m, seed=77 + width, p_copy=0.5)
+    T.store(str(tmp_path / "g"), rowptr, succ, window=7, max_ref_count=3, min_interval=4)
+    listptr, values = _lists(np.random.Generator(np.random.PCG64(width)), m, width)
+    lbase = str(tmp_path / "lab")
+    T.store_label_lists(lbase, "g", rowptr, listptr, values, width)
+    g = ArcLabelledBVGraph.load(lbase)
+    assert (g.info.kind, g.info.width, g.info.nodes) == (3, width, n)
+    rp, sc, lp, vals = g.decode_label_lists()
+    assert np.array_equal(rp, rowptr) and np.array_equal(sc, succ) and np.array_equal(lp, listptr) and np.array_equal(vals, values)
+    d = np.diff(rowptr).astype(np.int32)
+    for lo, hi in [(0, 1), (n // 3, min(n, n // 3 + 777)), (n - 5, n), (7, 7)]:
+        rp, sc, lp, vals = g.decode_label_lists(lo, hi)
+        olp, ovals = O.label_lists_decode(lbase, n, d[lo:hi], lo, hi)
+        assert np.array_equal(lp, olp) and np.array_equal(vals, ovals)
+    # errors: the one-int-per-arc entry point refuses this class; a wrong arc count is a format error; a short buffer reports the need
+    out = np.empty(m + 8, dtype=np.int32)
+    assert lib().bvg_labels_decode_range(g._h, 0, n, m, out.ctypes.data, 0) == -3
+    lpb = np.empty(m + 8, dtype=np.int64)
+    nv = C.c_uint64(0)
+    assert lib().bvg_labels_decode_lists(g._h, 0, n, m + 1, lpb.ctypes.data, None, 0, C.byref(nv), 0) == -7
+    assert lib().bvg_labels_decode_lists(g._h, 0, n, m, lpb.ctypes.data, None, 0, C.byref(nv), 0) == (-8 if values.size else 0)
+    assert nv.value == values.size
+    g.close()

@@ -56,4 +56,43 @@ def test_labels_properties_host_parser(tmp_path):
     open(str(tmp_path / "lab") + ".properties", "w").write(
         "graphclass = it.unimi.dsi.webgraph.labelling.BitStreamArcLabelledImmutableGraph\nunderlyinggraph = g\n"
         "labelspec = it.unimi.dsi.webgraph.labelling.FixedWidthIntListLabel(K,3)\n")
+    assert lib().bvg_labels_parse_properties(str(tmp_path / "lab").encode(), C.byref(info), err, 256) == 0
+    assert (info.kind, info.width, info.key) == (3, 3, b"K")
+    open(str(tmp_path / "lab") + ".properties", "w").write(
+        "graphclass = it.unimi.dsi.webgraph.labelling.BitStreamArcLabelledImmutableGraph\nunderlyinggraph = g\n"
+        "labelspec = org.example.SomeOtherLabel(K,3)\n")
     assert lib().bvg_labels_parse_properties(str(tmp_path / "lab").encode(), C.byref(info), err, 256) == -3
+
+
+def _lists(rng, m, width, mean=1.5):
+    lens = rng.poisson(mean, size=m).astype(np.int64)
+    lens[rng.integers(0, m, size=max(m // 500, 1))] += rng.integers(50, 400)  # a few long lists
+    listptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    nv = int(listptr[-1])
+    values = (rng.integers(0, 2**width, size=nv, dtype=np.int64) if width else np.zeros(nv, dtype=np.int64)).astype(np.uint32).view(np.int32)
+    return listptr, values
+
+
+@pytest.mark.parametrize("width", [0, 1, 9, 32])
+def test_label_lists_round_trip_through_the_oracle(tmp_path, width):
+    """FixedWidthIntListLabel (FixedWidthIntListLabel.java:107-119): writer and oracle decoder agree; lists may be empty."""
+    from webgraph_amd import tools as T
+    from oracle import oracle as O
+    base, rowptr, succ = _graph(tmp_path)
+    n, m = rowptr.size - 1, succ.size
+    listptr, values = _lists(np.random.Generator(np.random.PCG64(11 + width)), m, width)
+    lbase = str(tmp_path / "lab")
+    T.store_label_lists(lbase, "g", rowptr, listptr, values, width, key="L")
+    props = O.parse_properties(lbase + ".properties")
+    assert O.parse_labelspec(props["labelspec"]) == (3, width, "L")
+    d = np.diff(rowptr).astype(np.int32)
+    lp, vals = O.label_lists_decode(lbase, n, d)
+    assert np.array_equal(lp, listptr) and np.array_equal(vals, values)
+    lo, hi = 1000, 1777
+    lp, vals = O.label_lists_decode(lbase, n, d[lo:hi], lo, hi)
+    a0, a1 = rowptr[lo], rowptr[hi]
+    assert np.array_equal(lp, listptr[a0:a1 + 1] - listptr[a0]) and np.array_equal(vals, values[listptr[a0]:listptr[a1]])
+    # a wrong outdegree vector does not end on the node boundaries
+    d2 = d.copy(); d2[5] += 1
+    with pytest.raises(O.OracleError):
+        O.label_lists_decode(lbase, n, d2)

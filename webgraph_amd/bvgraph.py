@@ -41,7 +41,7 @@ class BvgLabelsInfo(C.Structure):
 EXPORTS = ["bvg_open", "bvg_open_shard", "bvg_clone", "bvg_close", "bvg_info", "bvg_last_error", "bvg_set_stream", "bvg_sync",
            "bvg_outdegrees", "bvg_decode_range", "bvg_decode_range_view", "bvg_host_alloc", "bvg_host_free", "bvg_scan_checksum", "bvg_scan_stats", "bvg_bfs_expand", "bvg_hyperball_step", "bvg_successors_batch", "bvg_csr_hashcode", "bvg_shard_bounds",
            "bvg_parse_properties", "bvg_flags_from_string", "bvg_decode_offsets_host", "bvg_decode_offsets_device", "bvg_labels_open", "bvg_labels_close", "bvg_labels_info",
-           "bvg_labels_last_error", "bvg_labels_parse_properties", "bvg_labels_decode_range", "bvg_set_profile", "bvg_get_profile", "bvg_debug_stats", "bvg_last_thresholds"]
+           "bvg_labels_last_error", "bvg_labels_parse_properties", "bvg_labels_decode_range", "bvg_labels_decode_lists", "bvg_set_profile", "bvg_get_profile", "bvg_debug_stats", "bvg_last_thresholds"]
 
 _lib = None
 
@@ -95,6 +95,7 @@ def lib():
         L.bvg_labels_last_error.restype = C.c_char_p
         L.bvg_labels_parse_properties.argtypes = [C.c_char_p, C.POINTER(BvgLabelsInfo), C.c_char_p, sz]
         L.bvg_labels_decode_range.argtypes = [vp, i32, i32, u64, vp, C.c_int]
+        L.bvg_labels_decode_lists.argtypes = [vp, i32, i32, u64, vp, vp, u64, C.POINTER(u64), C.c_int]
         L.bvg_set_profile.argtypes = [vp, C.c_int]
         L.bvg_get_profile.argtypes = [vp, C.POINTER(C.c_float)]
         L.bvg_last_thresholds.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
@@ -536,7 +537,8 @@ class BVGraph:
 
 class ArcLabelledBVGraph:
     """BitStreamArcLabelledImmutableGraph over a BVGraph (labelling/BitStreamArcLabelledImmutableGraph.java:383-470), int
-    labels only (GammaCodedIntLabel / FixedWidthIntLabel): the underlying graph and the label stream both live in HBM."""
+    labels (GammaCodedIntLabel / FixedWidthIntLabel) and int-list labels (FixedWidthIntListLabel): the underlying graph and the
+    label stream both live in HBM."""
 
     def __init__(self, graph, handle, basename):
         self.graph = graph
@@ -591,6 +593,23 @@ class ArcLabelledBVGraph:
         if rc:
             _raise(rc, lib().bvg_labels_last_error(self._h).decode("utf-8", "replace"))
         return rowptr, succ, labels[:succ.size]
+
+    def decode_label_lists(self, lo=0, hi=None):
+        """(rowptr, successors, listptr, values) of nodes [lo, hi) for FixedWidthIntListLabel: arc k carries values[listptr[k]:listptr[k+1]]."""
+        hi = self.numNodes() if hi is None else hi
+        rowptr, succ = self.graph.decode_range(lo, hi)
+        arcs = int(rowptr[-1])
+        listptr = np.empty(arcs + 1, dtype=np.int64)
+        nv = C.c_uint64(0)
+        rc = lib().bvg_labels_decode_lists(self._h, lo, hi, arcs, listptr.ctypes.data, None, 0, C.byref(nv), BVG_OUT_HOST)  # sizing call
+        if rc not in (0, -8):
+            _raise(rc, lib().bvg_labels_last_error(self._h).decode("utf-8", "replace"))
+        values = np.empty(max(nv.value, 1), dtype=np.int32)
+        if nv.value:
+            rc = lib().bvg_labels_decode_lists(self._h, lo, hi, arcs, listptr.ctypes.data, values.ctypes.data, values.size, C.byref(nv), BVG_OUT_HOST)
+            if rc:
+                _raise(rc, lib().bvg_labels_last_error(self._h).decode("utf-8", "replace"))
+        return rowptr, succ, listptr, values[:nv.value]
 
     def decode_labels_device(self, lo, hi, arcs, labels_ptr):
         rc = lib().bvg_labels_decode_range(self._h, lo, hi, int(arcs), labels_ptr, BVG_OUT_DEVICE)

@@ -99,5 +99,8 @@ int offsets_decode_device(const uint32_t *d_words, uint64_t nwords, uint64_t tot
 // arc labels (.labels stream in HBM, same padding): `count` consecutive labels starting at bit `startBit`
 int gamma_labels_decode_device(const uint32_t *d_words, uint64_t nwords, uint64_t startBit, uint64_t endBit, int64_t count, int32_t *d_out, hipStream_t st);
 int fixed_labels_decode_device(const uint32_t *d_words, uint64_t nwords, uint64_t startBit, int32_t width, int64_t count, int32_t *d_out, hipStream_t st);
+// lists of fixed-width ints per arc (FixedWidthIntListLabel): nodes [from, from + cnt) through their label offsets -> listptr[arcs + 1], values
+int label_lists_decode_device(const uint32_t *d_words, uint64_t nwords, const int64_t *d_off, int32_t from, int32_t cnt, int32_t width, uint64_t arcs,
+                              int64_t *d_listptr, int32_t *d_values, uint64_t valuesCap, uint64_t *nvalues, hipStream_t st);
 
 } // namespace bv

@@ -192,4 +192,74 @@ int fixed_labels_decode_device(const uint32_t *d_words, uint64_t nwords, uint64_
 	return hipStreamSynchronize(st) == hipSuccess ? 0 : -1;
 }
 
+// ---- FixedWidthIntListLabel (FixedWidthIntListLabel.java:107-112, fromBitStream): every arc carries a LIST, stored as
+// gamma(length) followed by length x readInt(width).  The lengths make this a mixed stream, not a stream of universal
+// codes, so the grid-wide speculation above does not apply; the label offsets give a true boundary per NODE, and a lane
+// walks its node's lists from there: pass 1 counts lists and values per node, two scans place them, pass 2 writes.
+template <bool FILL>
+__global__ void __launch_bounds__(256) k_label_lists(const uint32_t *__restrict__ words, uint64_t nwords, const int64_t *__restrict__ off, int32_t from, int32_t cnt,
+                                                     int32_t width, int32_t *__restrict__ nlists, int32_t *__restrict__ nvals, const int64_t *__restrict__ listBase,
+                                                     const int64_t *__restrict__ valBase, int64_t *__restrict__ listptr, int32_t *__restrict__ values, int *__restrict__ err) {
+	const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= cnt) return;
+	const uint64_t end = (uint64_t)off[from + i + 1];
+	uint64_t pos = (uint64_t)off[from + i];
+	BitReader br;
+	br.init(words, nwords);
+	int64_t lists = 0, vals = 0;
+	int64_t lb = 0, vb = 0;
+	if (FILL) { lb = listBase[i]; vb = valBase[i]; }
+	bool bad = false;
+	while (pos < end) {
+		br.seek(pos);
+		const uint64_t len = br.gamma();
+		const uint64_t p1 = br.pos();
+		// the list must fit in what is left of the node's bits (also bounds `len` for width > 0)
+		if (br.err || p1 > end || len > 0x7fffffffull || (width > 0 && len > (end - p1) / (uint64_t)width)) { bad = true; break; }
+		if (FILL) {
+			listptr[lb + lists] = vb + vals;
+			for (uint64_t j = 0; j < len; j++) values[vb + vals + (int64_t)j] = (int32_t)br.bits((uint32_t)width);
+		}
+		lists++;
+		vals += (int64_t)len;
+		if (vals > 0x7fffffffll) { bad = true; break; }
+		pos = p1 + len * (uint64_t)width;
+	}
+	if (bad || pos != end) { atomicOr(err, 1); lists = 0; vals = 0; }
+	if (!FILL) { nlists[i] = (int32_t)lists; nvals[i] = (int32_t)vals; }
+	else if (i == cnt - 1) listptr[listBase[cnt]] = valBase[cnt];
+}
+
+// 0 ok; -1 malformed / not `arcs` lists; -2 more than valuesCap values (*nvalues tells how many); -3 HIP / memory
+int label_lists_decode_device(const uint32_t *d_words, uint64_t nwords, const int64_t *d_off, int32_t from, int32_t cnt, int32_t width, uint64_t arcs,
+                              int64_t *d_listptr, int32_t *d_values, uint64_t valuesCap, uint64_t *nvalues, hipStream_t st) {
+	if (nvalues) *nvalues = 0;
+	if (cnt <= 0) return arcs == 0 ? 0 : -1;
+	if (width < 0 || width > 32) return -1;
+	const int64_t ns = scan_num_sums(cnt);
+	int32_t *cnts = nullptr;
+	int64_t *bases = nullptr, *sums = nullptr;
+	int *err = nullptr;
+	auto done = [&](int rc) { for (void *p : { (void *)cnts, (void *)bases, (void *)sums, (void *)err }) if (p) (void)hipFree(p); return rc; };
+	if (hipMalloc((void **)&cnts, sizeof(int32_t) * 2 * (size_t)cnt) != hipSuccess || hipMalloc((void **)&bases, sizeof(int64_t) * 2 * ((size_t)cnt + 1)) != hipSuccess ||
+	    hipMalloc((void **)&sums, sizeof(int64_t) * (size_t)(ns + 1)) != hipSuccess || hipMalloc((void **)&err, sizeof(int)) != hipSuccess) return done(-3);
+	int32_t *nl = cnts, *nv = cnts + cnt;
+	int64_t *lb = bases, *vb = bases + cnt + 1;
+	(void)hipMemsetAsync(err, 0, sizeof(int), st);
+	const dim3 grid((unsigned)(((int64_t)cnt + 255) / 256));
+	hipLaunchKernelGGL(k_label_lists<false>, grid, dim3(256), 0, st, d_words, nwords, d_off, from, cnt, width, nl, nv, nullptr, nullptr, nullptr, nullptr, err);
+	launch_scan(nl, cnt, lb, sums, st);
+	launch_scan(nv, cnt, vb, sums, st);
+	int herr = 0;
+	int64_t tot[2] = { 0, 0 };
+	if (hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipMemcpyAsync(&tot[0], lb + cnt, sizeof(int64_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+	    hipMemcpyAsync(&tot[1], vb + cnt, sizeof(int64_t), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return done(-3);
+	if (herr || (uint64_t)tot[0] != arcs) return done(-1);
+	if (nvalues) *nvalues = (uint64_t)tot[1];
+	if ((uint64_t)tot[1] > valuesCap) return done(-2);
+	hipLaunchKernelGGL(k_label_lists<true>, grid, dim3(256), 0, st, d_words, nwords, d_off, from, cnt, width, nullptr, nullptr, lb, vb, d_listptr, d_values, err);
+	if (hipStreamSynchronize(st) != hipSuccess) return done(-3);
+	return done(0);
+}
+
 } // namespace bv

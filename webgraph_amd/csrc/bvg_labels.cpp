@@ -6,6 +6,8 @@
 // .offsets file.  Both are therefore decoded by the grid-wide gamma stream decoder of bv_offsets.hip: the offsets as
 // running sums, gamma-coded labels (GammaCodedIntLabel.java:60-64) as plain values; fixed-width labels
 // (FixedWidthIntLabel.java:70-73) need no decoding at all, label a of a range sits at startBit + a * width.
+// FixedWidthIntListLabel (FixedWidthIntListLabel.java:107-112) stores a LIST per arc, gamma(length) + length x width bits:
+// a lane per node walks its lists from the node's label offset (k_label_lists), the result is a CSR over the arcs.
 #include "bv_host.hpp"
 #include "bv_launch.hpp"
 
@@ -49,6 +51,12 @@ int parse_labelspec(const std::string &spec, bvg_labels_info_t &info, std::strin
 		char *end = nullptr;
 		const long w = strtol(a[1].c_str(), &end, 10);
 		if (!end || *end || w < 0 || w > 32) { err = "Width out of range: " + a[1]; return BVG_EARG; } // FixedWidthIntLabel.java:45
+		info.width = (int32_t)w;
+	} else if (simple == "FixedWidthIntListLabel" && a.size() == 2) {
+		info.kind = BVG_LABEL_FIXED_LIST;
+		char *end = nullptr;
+		const long w = strtol(a[1].c_str(), &end, 10);
+		if (!end || *end || w < 0 || w > 32) { err = "Width out of range: " + a[1]; return BVG_EARG; } // FixedWidthIntListLabel.java:48
 		info.width = (int32_t)w;
 	} else { err = "unsupported label class: " + cls; return BVG_EUNSUPPORTED; }
 	strncpy(info.key, a[0].c_str(), sizeof info.key - 1);
@@ -145,6 +153,7 @@ extern "C" int bvg_labels_open(const char *basename, int32_t nodes, int device, 
 
 extern "C" int bvg_labels_decode_range(bvg_labels_t *h, int32_t from, int32_t to, uint64_t arcs, int32_t *labels, int flags) {
 	if (!h || !h->d_words || from < 0 || to < from || to > h->info.nodes || (arcs && !labels)) return lfail(h, BVG_EARG, "Node index out of range"); // as BVG:1165
+	if (h->info.kind == BVG_LABEL_FIXED_LIST) return lfail(h, BVG_EUNSUPPORTED, "FixedWidthIntListLabel carries a list per arc: use bvg_labels_decode_lists");
 	if (hipSetDevice(h->info.device) != hipSuccess) return lfail(h, BVG_EHIP, "hipSetDevice failed");
 	if (arcs == 0) return h->h_off[to] == h->h_off[from] ? BVG_OK : lfail(h, BVG_EFORMAT, "the label stream holds labels for a range without arcs");
 	if (arcs > 0x7fffffffffffull) return lfail(h, BVG_EARG, "too many arcs");
@@ -168,4 +177,49 @@ extern "C" int bvg_labels_decode_range(bvg_labels_t *h, int32_t from, int32_t to
 	if (rc) { (void)hipGetLastError(); return lfail(h, BVG_EFORMAT, "the label stream does not hold one label per arc of the range"); }
 	if (!dev && hipMemcpy(labels, d_out, sizeof(int32_t) * (size_t)arcs, hipMemcpyDeviceToHost) != hipSuccess) return lfail(h, BVG_EHIP, "copying the labels back failed");
 	return BVG_OK;
+}
+
+extern "C" int bvg_labels_decode_lists(bvg_labels_t *h, int32_t from, int32_t to, uint64_t arcs, int64_t *list_ptr, int32_t *values, uint64_t values_cap,
+                                       uint64_t *nvalues, int flags) {
+	if (nvalues) *nvalues = 0;
+	if (!h || !h->d_words || from < 0 || to < from || to > h->info.nodes || !list_ptr || (values_cap && !values)) return lfail(h, BVG_EARG, "Node index out of range");
+	if (h->info.kind != BVG_LABEL_FIXED_LIST) return lfail(h, BVG_EUNSUPPORTED, "the label class carries one int per arc: use bvg_labels_decode_range");
+	if (arcs > 0x7fffffffffffull) return lfail(h, BVG_EARG, "too many arcs");
+	if (hipSetDevice(h->info.device) != hipSuccess) return lfail(h, BVG_EHIP, "hipSetDevice failed");
+	const bool dev = (flags & BVG_OUT_DEVICE) != 0;
+	if (to == from || arcs == 0) {
+		if (h->h_off[to] != h->h_off[from]) return lfail(h, BVG_EFORMAT, "the label stream holds labels for a range without arcs");
+		if (arcs) return lfail(h, BVG_EFORMAT, "the label stream does not hold one list per arc of the range");
+		const int64_t zero = 0;
+		if (dev) { if (hipMemcpy(list_ptr, &zero, sizeof zero, hipMemcpyHostToDevice) != hipSuccess) return lfail(h, BVG_EHIP, "writing the list pointer failed"); }
+		else list_ptr[0] = 0;
+		return BVG_OK;
+	}
+	int64_t *d_lp = list_ptr;
+	int32_t *d_val = values;
+	auto release = [&]() { if (!dev) { if (d_lp) (void)hipFree(d_lp); if (d_val) (void)hipFree(d_val); } };
+	if (!dev) {
+		d_lp = nullptr; d_val = nullptr;
+		if (hipMalloc((void **)&d_lp, sizeof(int64_t) * ((size_t)arcs + 1)) != hipSuccess || (values_cap && hipMalloc((void **)&d_val, sizeof(int32_t) * (size_t)values_cap) != hipSuccess)) {
+			release();
+			(void)hipGetLastError();
+			return lfail(h, BVG_ENOMEM, "staging allocation failed");
+		}
+	}
+	uint64_t nv = 0;
+	const int rc = bv::label_lists_decode_device(h->d_words, h->nwords, h->d_off, from, to - from, h->info.width, arcs, d_lp, d_val, values_cap, &nv, nullptr);
+	if (nvalues) *nvalues = nv;
+	if (rc) {
+		release();
+		(void)hipGetLastError();
+		if (rc == -2) return lfail(h, BVG_ECAP, "the value buffer is too small for the lists of the range");
+		if (rc == -3) return lfail(h, BVG_EHIP, "decoding the label lists failed");
+		return lfail(h, BVG_EFORMAT, "the label stream does not hold one list per arc of the range");
+	}
+	int out = BVG_OK;
+	if (!dev && (hipMemcpy(list_ptr, d_lp, sizeof(int64_t) * ((size_t)arcs + 1), hipMemcpyDeviceToHost) != hipSuccess ||
+	             (nv && hipMemcpy(values, d_val, sizeof(int32_t) * (size_t)nv, hipMemcpyDeviceToHost) != hipSuccess)))
+		out = lfail(h, BVG_EHIP, "copying the label lists back failed");
+	release();
+	return out;
 }

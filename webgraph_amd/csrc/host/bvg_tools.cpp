@@ -506,3 +506,33 @@ extern "C" int bvt_store_labels(const char *basename, const char *underlying, in
 	fclose(f);
 	return 0;
 }
+
+// FixedWidthIntListLabel.toBitStream (FixedWidthIntListLabel.java:114-119): gamma(length), then every element on `width` bits
+extern "C" int bvt_store_label_lists(const char *basename, const char *underlying, int32_t n, const int64_t *rowptr, const int64_t *listptr,
+                                     const int32_t *values, int width, const char *key) {
+	if (!basename || !underlying || n < 0 || !rowptr || !listptr || width < 0 || width > 32) return -EINVAL;
+	BitSink lab, offs;
+	offs.gamma(0);
+	for (int32_t x = 0; x < n; x++) {
+		const uint64_t before = lab.bits;
+		for (int64_t a = rowptr[x]; a < rowptr[x + 1]; a++) {
+			if (listptr[a + 1] < listptr[a]) return -EINVAL;
+			lab.gamma((uint64_t)(listptr[a + 1] - listptr[a]));
+			for (int64_t i = listptr[a]; i < listptr[a + 1]; i++) {
+				const uint32_t v = (uint32_t)values[i];
+				if (width < 32 && (v >> width)) return -EINVAL; // "Value too large" (:64)
+				lab.put(v, width);
+			}
+		}
+		offs.gamma(lab.bits - before);
+	}
+	std::string base(basename);
+	if (!lab.write_file(base + ".labels") || !offs.write_file(base + ".labeloffsets")) return -EIO;
+	FILE *f = fopen((base + ".properties").c_str(), "w");
+	if (!f) return -EIO;
+	fprintf(f, "graphclass = it.unimi.dsi.webgraph.labelling.BitStreamArcLabelledImmutableGraph\n");
+	fprintf(f, "underlyinggraph = %s\n", underlying);
+	fprintf(f, "labelspec = it.unimi.dsi.webgraph.labelling.FixedWidthIntListLabel(%s,%d)\n", key ? key : "FOO", width);
+	fclose(f);
+	return 0;
+}

@@ -108,3 +108,16 @@ def store_labels(basename, underlying, rowptr, labels, kind="gamma", width=0, ke
                             1 if kind == "gamma" else 2, width, key.encode("ascii"))
     if rc:
         raise OSError(-rc, "bvt_store_labels failed: %s" % os.strerror(-rc))
+
+
+def store_label_lists(basename, underlying, rowptr, listptr, values, width, key="FOO"):
+    """BitStreamArcLabelledImmutableGraph.store for FixedWidthIntListLabel: arc a carries values[listptr[a]:listptr[a+1]]."""
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+    listptr = np.ascontiguousarray(listptr, dtype=np.int64)
+    values = np.ascontiguousarray(values, dtype=np.int32)
+    L = lib()
+    L.bvt_store_label_lists.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_char_p]
+    rc = L.bvt_store_label_lists(os.fsencode(basename), os.fsencode(underlying), rowptr.size - 1, rowptr.ctypes.data, listptr.ctypes.data,
+                                 values.ctypes.data, int(width), key.encode())
+    if rc:
+        raise OSError(-rc, "bvt_store_label_lists failed: %s" % os.strerror(-rc))
