@@ -245,6 +245,46 @@ int bvg_decode_offsets_host(const uint8_t *offsets_file, size_t len, int32_t nod
  * BVG_EFORMAT when the stream does not hold exactly nodes + 1 codes. */
 int bvg_decode_offsets_device(int device, const uint8_t *offsets_file, size_t len, int32_t nodes, int offset_coding, int64_t *out);
 
+/* ---- the compressor --------------------------------------------------------------
+ * BVGraph.store(graph, basename, windowSize, maxRefCount, minIntervalLength, zetaK, flags, numberOfThreads)
+ * (BVGraph.java:1679-1730 -> storeInternal :2436-2650; per node CompressionThread.call :2222-2386, diffComp :2049-2219,
+ * intervalize :1631-1654) on the GPU.  The graph comes as a CSR: rowptr int64[n + 1] (rowptr[0] = 0), succ
+ * int32[rowptr[n]], every row strictly increasing (BVG_EARG otherwise); in_flags: BVG_OUT_HOST (0) = host pointers,
+ * BVG_OUT_DEVICE = device pointers on `device` (e.g. what bvg_decode_range just wrote: recompression without a trip to
+ * the host).  The streams are the reference's byte for byte: the choice of the reference (first cheapest candidate whose
+ * chain is shorter than maxRefCount, :2313-2327), copy blocks, intervals, residuals, codings by `flags` (layout
+ * :1317-1325, 0 = defaults); `threads` > 1 reproduces the reference's multi-threaded store (contiguous ranges of
+ * ceil(n / threads) nodes, each starting with an empty window, streams concatenated, :2471-2550) -- it does not change how
+ * the GPU works.  Limits: windowSize <= 63, records shorter than 2^31 bits (BVG_EUNSUPPORTED). */
+typedef struct bvg_store_stats {   /* the counters BVGraph.java:2558-2600 persists in .properties */
+	uint64_t written_bits, offsets_bits;
+	uint64_t bits_outdegrees, bits_references, bits_blocks, bits_intervals, bits_residuals;
+	uint64_t copied_arcs, intervalised_arcs, residual_arcs;
+	uint64_t tot_ref, tot_dist;    /* avgref = tot_ref / n, avgdist = tot_dist / n */
+	int32_t  max_ref_chain;        /* longest reference chain produced */
+	int32_t  threads;
+	int32_t  selection_rounds;     /* measurement only: rounds the reference-selection recurrence took to settle */
+	int32_t  reserved;
+} bvg_store_stats_t;
+typedef struct bvg_compressed {    /* result of bvg_compress, in HBM of `device`; release with bvg_compressed_free */
+	int32_t  device, reserved;
+	uint8_t *graph_dev;            /* the bytes of <basename>.graph: (graph_bits + 7) / 8 of them, zero padded to 32 more */
+	uint64_t graph_bits;
+	uint8_t *offsets_stream_dev;   /* the bytes of <basename>.offsets */
+	uint64_t offsets_bits;
+	int64_t *bit_offsets_dev;      /* int64[n + 1]: bit offset of every record = the decoded .offsets */
+	bvg_store_stats_t stats;
+} bvg_compressed_t;
+int bvg_compress(int device, int32_t n, const int64_t *rowptr, const int32_t *succ, int in_flags, int window, int max_ref_count, int min_interval, int zeta_k,
+                 uint32_t flags, int threads, bvg_compressed_t *out, char *errbuf, size_t errlen);
+void bvg_compressed_free(bvg_compressed_t *c);
+/* Copies the result to host memory: graph_host (graph_bits + 7) / 8 bytes, offsets_host (offsets_bits + 7) / 8 bytes,
+ * bit_offsets_host int64[n + 1]; any of the three may be NULL. */
+int bvg_compressed_copy(const bvg_compressed_t *c, int32_t n, uint8_t *graph_host, uint8_t *offsets_host, int64_t *bit_offsets_host);
+/* bvg_compress + the three files <basename>.graph / .offsets / .properties (the properties as :2558-2600 writes them). */
+int bvg_store(const char *basename, int device, int32_t n, const int64_t *rowptr, const int32_t *succ, int in_flags, int window, int max_ref_count,
+              int min_interval, int zeta_k, uint32_t flags, int threads, bvg_store_stats_t *stats, char *errbuf, size_t errlen);
+
 /* ---- arc labels ----------------------------------------------------------------
  * labelling/BitStreamArcLabelledImmutableGraph.java:60-135: <basename>.properties names the underlying graph and the
  * label class (`underlyinggraph`, `labelspec`), <basename>.labels holds the labels of all arcs in enumeration order as

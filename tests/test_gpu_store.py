@@ -1,0 +1,99 @@
+"""BVGraph.store on the GPU (include/bvgpu.h bvg_compress / bvg_store) against the reference's own
+cnr-2000 files and against the CPU writer, byte for byte; then the decoder reads back what the compressor wrote."""
+import filecmp
+import os
+
+import numpy as np
+import pytest
+
+from conftest import CNR
+from test_encode_model_cpu import DELTA, FLAG, GAMMA, GOLOMB, NIBBLE, UNARY
+
+pytestmark = pytest.mark.gpu
+
+
+def test_store_reproduces_reference_bytes(tmp_path, cnr_oracle):
+    """The pin: cnr-2000 recompressed with its own parameters gives the reference-produced .graph / .offsets back."""
+    from webgraph_amd import bvgraph as B
+    _, rowptr, succ = cnr_oracle
+    base = str(tmp_path / "cnr")
+    st = B.store(rowptr, succ, base, windowSize=7, maxRefCount=3, minIntervalLength=3, zetaK=3)
+    assert filecmp.cmp(base + ".graph", CNR + ".graph", shallow=False)
+    assert filecmp.cmp(base + ".offsets", CNR + ".offsets", shallow=False)
+    bits = st["bits_outdegrees"] + st["bits_references"] + st["bits_blocks"] + st["bits_intervals"] + st["bits_residuals"]
+    assert bits == st["written_bits"] and os.path.getsize(base + ".graph") == (bits + 7) // 8
+    assert (st["copied_arcs"], st["intervalised_arcs"], st["residual_arcs"], st["max_ref_chain"]) == (2130833, 361894, 723425, 3)
+    # the properties load, and the graph decodes to what went in
+    g = B.BVGraph.load(base)
+    rp, sc = g.decode_range()
+    assert np.array_equal(rp, rowptr) and np.array_equal(sc, succ)
+    g.close()
+
+
+def test_recompress_on_the_device(tmp_path, cnr_oracle):
+    """decode -> compress without leaving HBM: the CSR bvg_decode_range wrote is the compressor's input."""
+    import torch
+    from webgraph_amd import bvgraph as B
+    g = B.BVGraph.load(CNR)
+    n, m = g.numNodes(), g.numArcs()
+    rp = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    sc = torch.empty(m, dtype=torch.int32, device="cuda")
+    g.decode_range_device(0, n, rp.data_ptr(), sc.data_ptr(), m)
+    torch.cuda.synchronize()
+    graph, offs, bitoff, st = B.compress(rp, sc, windowSize=7, maxRefCount=3, minIntervalLength=3, zetaK=3)
+    assert graph == open(CNR + ".graph", "rb").read() and offs == open(CNR + ".offsets", "rb").read()
+    from oracle import oracle as O
+    assert np.array_equal(bitoff, O.decode_offsets(open(CNR + ".offsets", "rb").read(), n))
+    g.close()
+
+
+@pytest.mark.parametrize("W,R,I,K,flags,threads", [
+    (7, 3, 4, 3, 0, 1), (7, 3, 4, 3, 0, 3), (0, 0, 0, 3, 0, 1), (1, 1, 2, 3, 0, 1), (3, 100, 1, 2, 0, 2), (7, 3, 0, 3, 0, 1), (16, 2, 3, 5, 0, 1),
+    (7, 3, 4, 3, (DELTA << FLAG["outd"]) | (DELTA << FLAG["blk"]) | (DELTA << FLAG["res"]) | (GAMMA << FLAG["ref"]) | (DELTA << FLAG["bc"]) | (DELTA << FLAG["off"]), 1),
+    (7, 3, 4, 3, (UNARY << FLAG["blk"]) | (NIBBLE << FLAG["res"]) | (DELTA << FLAG["ref"]) | (UNARY << FLAG["bc"]), 1),
+    (7, 3, 4, 5, (GOLOMB << FLAG["res"]), 1)])
+def test_store_matches_cpu_writer(tmp_path, W, R, I, K, flags, threads):
+    from webgraph_amd import bvgraph as B
+    from webgraph_amd import tools as T
+    rowptr, succ = T.generate(60000, 1200000, seed=23 + W, p_copy=0.7)
+    cpu, gpu = str(tmp_path / "cpu"), str(tmp_path / "gpu")
+    st_cpu = T.store(cpu, rowptr, succ, window=W, max_ref_count=R, min_interval=I, zeta_k=K, flags=flags, threads=threads)
+    st_gpu = B.store(rowptr, succ, gpu, windowSize=W, maxRefCount=R, minIntervalLength=I, zetaK=K, flags=flags, numberOfThreads=threads)
+    for ext in (".graph", ".offsets", ".properties"):
+        assert filecmp.cmp(cpu + ext, gpu + ext, shallow=False), ext
+    for k in st_cpu:
+        assert st_cpu[k] == st_gpu[k], k
+
+
+def test_store_c2_shape_round_trip(tmp_path):
+    """A 1 M-node slice of the C2 recipe (giant rows included): compress on the GPU, decode on the GPU, compare with the input;
+    and the CPU writer produces the same bytes."""
+    from webgraph_amd import bvgraph as B
+    from webgraph_amd import tools as T
+    rowptr, succ = T.generate(1000000, 20000000, seed=0x5EEDB5E70001, p_copy=0.5)
+    gpu, cpu = str(tmp_path / "gpu"), str(tmp_path / "cpu")
+    B.store(rowptr, succ, gpu)
+    T.store(cpu, rowptr, succ, threads=1)
+    assert filecmp.cmp(cpu + ".graph", gpu + ".graph", shallow=False) and filecmp.cmp(cpu + ".offsets", gpu + ".offsets", shallow=False)
+    g = B.BVGraph.load(gpu)
+    rp, sc = g.decode_range()
+    assert np.array_equal(rp, rowptr) and np.array_equal(sc, succ)
+    g.close()
+
+
+def test_store_errors(tmp_path):
+    from webgraph_amd import bvgraph as B
+    rowptr = np.array([0, 3, 5], dtype=np.int64)
+    with pytest.raises(ValueError):  # a row that is not strictly increasing
+        B.store(rowptr, np.array([1, 1, 2, 0, 4], dtype=np.int32), str(tmp_path / "x"))
+    with pytest.raises(ValueError):
+        B.store(rowptr, np.array([0, 1, 2, 3, 4], dtype=np.int32), str(tmp_path / "x"), windowSize=-1)
+    with pytest.raises(NotImplementedError):  # windows above the device compressor's limit
+        B.store(rowptr, np.array([0, 1, 2, 3, 4], dtype=np.int32), str(tmp_path / "x"), windowSize=64)
+    with pytest.raises(NotImplementedError):  # a coding the reference's writer rejects too (BVGraph.java:1846)
+        B.store(rowptr, np.array([0, 1, 2, 3, 4], dtype=np.int32), str(tmp_path / "x"), flags=NIBBLE << FLAG["outd"])
+    st = B.store(np.zeros(1, dtype=np.int64), np.zeros(0, dtype=np.int32), str(tmp_path / "empty"))
+    assert st["written_bits"] == 0 and open(str(tmp_path / "empty") + ".offsets", "rb").read() == b"\x80"
+    # rows may start lower than the previous row ended: only the order inside a row matters
+    st = B.store(rowptr, np.array([5, 6, 7, 0, 1], dtype=np.int32), str(tmp_path / "ok"))
+    assert st["copied_arcs"] + st["intervalised_arcs"] + st["residual_arcs"] == 5

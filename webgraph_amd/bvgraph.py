@@ -33,6 +33,20 @@ class BvgScanStats(C.Structure):
         ("successor_delta_stats", C.c_uint64 * 32)]
 
 
+class BvgStoreStats(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("written_bits", "offsets_bits", "bits_outdegrees", "bits_references", "bits_blocks", "bits_intervals", "bits_residuals",
+                                           "copied_arcs", "intervalised_arcs", "residual_arcs", "tot_ref", "tot_dist")] + [
+        ("max_ref_chain", C.c_int32), ("threads", C.c_int32), ("selection_rounds", C.c_int32), ("reserved", C.c_int32)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"}
+
+
+class BvgCompressed(C.Structure):
+    _fields_ = [("device", C.c_int32), ("reserved", C.c_int32), ("graph_dev", C.c_void_p), ("graph_bits", C.c_uint64), ("offsets_stream_dev", C.c_void_p),
+                ("offsets_bits", C.c_uint64), ("bit_offsets_dev", C.c_void_p), ("stats", BvgStoreStats)]
+
+
 class BvgLabelsInfo(C.Structure):
     _fields_ = [("kind", C.c_int32), ("width", C.c_int32), ("nodes", C.c_int32), ("device", C.c_int32), ("labels_bytes", C.c_uint64),
                 ("labels_bits", C.c_uint64), ("underlying", C.c_char * 1024), ("key", C.c_char * 128)]
@@ -41,7 +55,7 @@ class BvgLabelsInfo(C.Structure):
 EXPORTS = ["bvg_open", "bvg_open_shard", "bvg_clone", "bvg_close", "bvg_info", "bvg_last_error", "bvg_set_stream", "bvg_sync",
            "bvg_outdegrees", "bvg_decode_range", "bvg_decode_range_view", "bvg_host_alloc", "bvg_host_free", "bvg_scan_checksum", "bvg_scan_stats", "bvg_bfs_expand", "bvg_hyperball_step", "bvg_successors_batch", "bvg_csr_hashcode", "bvg_shard_bounds",
            "bvg_parse_properties", "bvg_flags_from_string", "bvg_decode_offsets_host", "bvg_decode_offsets_device", "bvg_labels_open", "bvg_labels_close", "bvg_labels_info",
-           "bvg_labels_last_error", "bvg_labels_parse_properties", "bvg_labels_decode_range", "bvg_labels_decode_lists", "bvg_set_profile", "bvg_get_profile", "bvg_debug_stats", "bvg_last_thresholds"]
+           "bvg_labels_last_error", "bvg_labels_parse_properties", "bvg_labels_decode_range", "bvg_labels_decode_lists", "bvg_compress", "bvg_compressed_free", "bvg_compressed_copy", "bvg_store", "bvg_set_profile", "bvg_get_profile", "bvg_debug_stats", "bvg_last_thresholds"]
 
 _lib = None
 
@@ -96,6 +110,11 @@ def lib():
         L.bvg_labels_parse_properties.argtypes = [C.c_char_p, C.POINTER(BvgLabelsInfo), C.c_char_p, sz]
         L.bvg_labels_decode_range.argtypes = [vp, i32, i32, u64, vp, C.c_int]
         L.bvg_labels_decode_lists.argtypes = [vp, i32, i32, u64, vp, vp, u64, C.POINTER(u64), C.c_int]
+        L.bvg_compress.argtypes = [C.c_int, i32, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.POINTER(BvgCompressed), C.c_char_p, sz]
+        L.bvg_compressed_free.argtypes = [C.POINTER(BvgCompressed)]
+        L.bvg_compressed_free.restype = None
+        L.bvg_compressed_copy.argtypes = [C.POINTER(BvgCompressed), i32, vp, vp, vp]
+        L.bvg_store.argtypes = [C.c_char_p, C.c_int, i32, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.POINTER(BvgStoreStats), C.c_char_p, sz]
         L.bvg_set_profile.argtypes = [vp, C.c_int]
         L.bvg_get_profile.argtypes = [vp, C.POINTER(C.c_float)]
         L.bvg_last_thresholds.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
@@ -123,6 +142,50 @@ def _raise(code, msg):
     if code == BVG_ENOMEM:
         raise MemoryError(msg)
     raise BvgError(code, msg)
+
+
+def _csr_ptrs(rowptr, succ):
+    """(n, rowptr pointer, succ pointer, in_flags, keepalive): numpy arrays are host pointers, anything with data_ptr() (torch) a device pointer."""
+    if hasattr(rowptr, "data_ptr"):
+        return int(rowptr.numel()) - 1, rowptr.data_ptr(), succ.data_ptr(), BVG_OUT_DEVICE, (rowptr, succ)
+    rp = np.ascontiguousarray(rowptr, dtype=np.int64)
+    sc = np.ascontiguousarray(succ, dtype=np.int32)
+    return rp.size - 1, rp.ctypes.data, sc.ctypes.data if sc.size else None, BVG_OUT_HOST, (rp, sc)
+
+
+def store(rowptr, succ, basename, windowSize=7, maxRefCount=3, minIntervalLength=4, zetaK=3, flags=0, numberOfThreads=1, device=0):
+    """BVGraph.store(graph, basename, windowSize, maxRefCount, minIntervalLength, zetaK, flags, numberOfThreads)
+    (BVGraph.java:1679-1730) for a CSR graph, compressed on the GPU: numpy arrays (host) or torch tensors on `device`
+    (int64 rowptr, int32 successors).  Returns the counters of the .properties file."""
+    n, rp, sp, fl, keep = _csr_ptrs(rowptr, succ)
+    st = BvgStoreStats()
+    err = C.create_string_buffer(512)
+    rc = lib().bvg_store(os.fsencode(basename), device, n, rp, sp, fl, windowSize, maxRefCount, minIntervalLength, zetaK, flags, numberOfThreads, C.byref(st), err, 512)
+    del keep
+    if rc:
+        _raise(rc, err.value.decode("utf-8", "replace"))
+    return st.as_dict()
+
+
+def compress(rowptr, succ, windowSize=7, maxRefCount=3, minIntervalLength=4, zetaK=3, flags=0, numberOfThreads=1, device=0):
+    """The compression of store() alone: returns (graph bytes, offsets-file bytes, bit offsets int64[n+1], counters), copied to the host."""
+    n, rp, sp, fl, keep = _csr_ptrs(rowptr, succ)
+    c = BvgCompressed()
+    err = C.create_string_buffer(512)
+    rc = lib().bvg_compress(device, n, rp, sp, fl, windowSize, maxRefCount, minIntervalLength, zetaK, flags, numberOfThreads, C.byref(c), err, 512)
+    del keep
+    if rc:
+        _raise(rc, err.value.decode("utf-8", "replace"))
+    try:
+        graph = np.empty((c.graph_bits + 7) // 8, dtype=np.uint8)
+        offs = np.empty((c.offsets_bits + 7) // 8, dtype=np.uint8)
+        bitoff = np.empty(n + 1, dtype=np.int64)
+        rc = lib().bvg_compressed_copy(C.byref(c), n, graph.ctypes.data, offs.ctypes.data, bitoff.ctypes.data)
+        if rc:
+            _raise(rc, "copying the compressed streams back failed")
+        return graph.tobytes(), offs.tobytes(), bitoff, c.stats.as_dict()
+    finally:
+        lib().bvg_compressed_free(C.byref(c))
 
 
 def parse_properties(basename):

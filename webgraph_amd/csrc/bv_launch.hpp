@@ -1,6 +1,9 @@
 // bv_launch.hpp -- host-visible launch interface of bv_kernels.hip (internal to libbvgpu.so).
 #pragma once
 #include "bv_device.hpp"
+#include "bv_encode.hpp"
+
+#include <string>
 
 namespace bv {
 
@@ -102,5 +105,19 @@ int fixed_labels_decode_device(const uint32_t *d_words, uint64_t nwords, uint64_
 // lists of fixed-width ints per arc (FixedWidthIntListLabel): nodes [from, from + cnt) through their label offsets -> listptr[arcs + 1], values
 int label_lists_decode_device(const uint32_t *d_words, uint64_t nwords, const int64_t *d_off, int32_t from, int32_t cnt, int32_t width, uint64_t arcs,
                               int64_t *d_listptr, int32_t *d_values, uint64_t valuesCap, uint64_t *nvalues, hipStream_t st);
+
+// BVGraph.store on the device (bv_encode.hip): device CSR -> .graph stream, bit offsets, .offsets stream, counters of the .properties file
+struct EncodeOut {
+	uint32_t *graph_words = nullptr; // big-endian words = the bytes of <basename>.graph, zero padded (+ >= 8 zero words)
+	uint64_t graph_bits = 0;
+	uint32_t *off_words = nullptr;   // <basename>.offsets
+	uint64_t off_bits = 0;
+	int64_t *offsets = nullptr;      // [n + 1] bit offset of every record
+	uint64_t bits_outdegrees = 0, bits_references = 0, bits_blocks = 0, bits_intervals = 0, bits_residuals = 0;
+	uint64_t copied_arcs = 0, intervalised_arcs = 0, residual_arcs = 0, tot_ref = 0, tot_dist = 0;
+	int32_t max_ref_chain = 0, rounds = 0;
+};
+int encode_device(const bve::Params &p, int32_t n, const int64_t *d_rowptr, const int32_t *d_succ, uint64_t m, EncodeOut &out, std::string &err, hipStream_t st);
+void encode_free(EncodeOut &o);
 
 } // namespace bv

@@ -7,6 +7,7 @@
 // differently: candidate costs are computed arithmetically from code lengths instead of writing to a
 // bit-counting stream, per-thread streams live in memory and are spliced bit-exactly at the end.
 #include "../../../include/bvgtools.h"
+#include "bv_props.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -255,25 +256,6 @@ void compress_range(int32_t lo, int32_t hi, const int64_t *rowptr, const int32_t
 	}
 }
 
-std::string flags_to_string(uint32_t flags) { // flags2String, BVGraph.java:1333-1345
-	static const char *names[] = { "DEFAULT", "DELTA", "GAMMA", "GOLOMB", "SKEWED_GOLOMB", "UNARY", "ZETA", "NIBBLE" };
-	static const char *fields[] = { "OUTDEGREES_", "BLOCKS_", "RESIDUALS_", "REFERENCES_", "BLOCK_COUNT_", "OFFSETS_" };
-	std::string s;
-	for (int f = 0; f < 6; f++) {
-		unsigned c = (flags >> (4 * f)) & 0xF;
-		if (c && c < 8) { if (!s.empty()) s += " | "; s += fields[f]; s += names[c]; }
-	}
-	return s;
-}
-
-std::string fmt3(double v) { // DecimalFormat("0.###")
-	char b[64]; snprintf(b, sizeof b, "%.3f", v);
-	std::string s(b);
-	while (!s.empty() && s.back() == '0') s.pop_back();
-	if (!s.empty() && s.back() == '.') s.pop_back();
-	return s;
-}
-
 // ---------------------------------------------------------------- RNG: splitmix64-seeded xoroshiro128+
 struct Rng {
 	uint64_t s0, s1;
@@ -346,20 +328,9 @@ extern "C" int bvt_store(const char *basename, int32_t n, const int64_t *rowptr,
 	if (!graph.write_file(base + ".graph") || !offs.write_file(base + ".offsets")) return -EIO;
 
 	const uint64_t m = n ? (uint64_t)rowptr[n] : 0;
-	FILE *f = fopen((base + ".properties").c_str(), "w");
-	if (!f) return -EIO;
-	fprintf(f, "#BVGraph properties\n");
-	fprintf(f, "nodes=%d\narcs=%llu\nwindowsize=%d\nmaxrefcount=%d\nminintervallength=%d\n", n, (unsigned long long)m, window, max_ref_count, min_interval);
-	if (g.c.residual == ZETA) fprintf(f, "zetak=%d\n", zeta_k);
-	fprintf(f, "compressionflags=%s\n", flags_to_string(flags).c_str());
-	fprintf(f, "avgref=%s\navgdist=%s\n", fmt3(n ? (double)st.tot_ref / n : 0).c_str(), fmt3(n ? (double)st.tot_dist / n : 0).c_str());
-	fprintf(f, "copiedarcs=%llu\nintervalisedarcs=%llu\nresidualarcs=%llu\n", (unsigned long long)st.copied_arcs, (unsigned long long)st.intervalised_arcs, (unsigned long long)st.residual_arcs);
-	fprintf(f, "bitsperlink=%s\nbitspernode=%s\n", fmt3(m ? (double)st.written_bits / m : 0).c_str(), fmt3(n ? (double)st.written_bits / n : 0).c_str());
-	fprintf(f, "bitsforoutdegrees=%llu\nbitsforreferences=%llu\nbitsforblocks=%llu\nbitsforresiduals=%llu\nbitsforintervals=%llu\n",
-	        (unsigned long long)st.bits_outdegrees, (unsigned long long)st.bits_references, (unsigned long long)st.bits_blocks,
-	        (unsigned long long)st.bits_residuals, (unsigned long long)st.bits_intervals);
-	fprintf(f, "graphclass=it.unimi.dsi.webgraph.BVGraph\nversion=0\n");
-	fclose(f);
+	const bvprops::Counters cnt{ st.written_bits, st.bits_outdegrees, st.bits_references, st.bits_blocks, st.bits_intervals, st.bits_residuals,
+	                             st.copied_arcs, st.intervalised_arcs, st.residual_arcs, st.tot_ref, st.tot_dist };
+	if (!bvprops::write(base + ".properties", n, m, window, max_ref_count, min_interval, zeta_k, g.c.residual == ZETA, flags, cnt)) return -EIO;
 	if (stats) *stats = st;
 	return 0;
 }
