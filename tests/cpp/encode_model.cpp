@@ -13,10 +13,11 @@ extern "C" int bve_model_compress(int32_t n, const int64_t *rowptr, const int32_
                                   uint64_t off_cap_words, uint64_t *off_bits_out, uint64_t *stats /* 11 */, int32_t *rounds_out) {
 	Params p{ W, R, I, K, codings[0], codings[1], codings[2], codings[3], codings[4], codings[5], per };
 	const int cyc = W + 1;
+	const bool def = default_codings(p); // the compile-time variant of the default codings is what the device runs for them
 	int err = 0;
 	// A
 	std::vector<uint32_t> cost((size_t)n * cyc);
-	for (int64_t q = 0; q < (int64_t)n * cyc; q++) cost[(size_t)q] = pair_cost(p, rowptr, succ, (int32_t)(q / cyc), (int)(q % cyc), &err);
+	for (int64_t q = 0; q < (int64_t)n * cyc; q++) cost[(size_t)q] = def ? pair_cost<true>(p, rowptr, succ, (int32_t)(q / cyc), (int)(q % cyc), &err) : pair_cost<false>(p, rowptr, succ, (int32_t)(q / cyc), (int)(q % cyc), &err);
 	if (err) return -3;
 	// B: rounds of select_span until nothing moves, as encode_device does (round 0: one chunk per lane; then `span` chunks per lane)
 	const int64_t nchunks = ((int64_t)n + chunk - 1) / chunk;
@@ -55,7 +56,7 @@ extern "C" int bve_model_compress(int32_t n, const int64_t *rowptr, const int32_
 	memset(stats, 0, 11 * sizeof(uint64_t));
 	for (int32_t x = 0; x < n; x++) {
 		NodeStats st;
-		const uint64_t len = emit_node(p, rowptr, succ, x, best[(size_t)x], words, (uint64_t)off[x], &st);
+		const uint64_t len = def ? emit_node<true>(p, rowptr, succ, x, best[(size_t)x], words, (uint64_t)off[x], &st) : emit_node<false>(p, rowptr, succ, x, best[(size_t)x], words, (uint64_t)off[x], &st);
 		if (len != reclen[(size_t)x]) return -100;
 		stats[0] += st.bitsOutd; stats[1] += st.bitsRef; stats[2] += st.bitsBlocks; stats[3] += st.bitsIntervals; stats[4] += st.bitsResiduals;
 		stats[5] += st.copied; stats[6] += st.intervalised; stats[7] += st.residuals;

@@ -4,8 +4,8 @@
 // The reference compresses node after node: per node, up to W + 1 runs of diffComp against a bit-counting stream, the
 // cheapest admissible one again for real (CompressionThread.call, BVGraph.java:2222-2386).  Only the admissibility --
 // the length of the reference chain, :2313-2327 -- links a node to its predecessors; the W + 1 costs do not.  So:
-//   A  k_enc_cost    one lane per (node, candidate) pair: the pair's cost in bits.  The 8 candidates of a node sit in
-//                    neighbouring lanes (same successor list, similar trip counts).                [the bulk of the work]
+//   A  k_enc_cost    one lane per (node, candidate) pair: the pair's cost in bits.  The pairs are taken from a list
+//                    grouped by size (k_enc_hist / k_enc_scatter), biggest first.                    [the bulk of the work]
 //   B  k_enc_select  the chain-length recurrence, cut into chunks of SEL_CHUNK nodes: every chunk runs from a guessed
 //                    state of the W nodes before it, then again only if its predecessor's final state turned out
 //                    different.  On a copy-model graph the choice forgets its past within a few nodes (a node that
@@ -18,6 +18,7 @@
 //   E  the .offsets stream (gamma / delta coded gaps) the same way: lengths, scan, emit.
 // The per-node logic is bv_encode.hpp, shared with the host model that the CPU tests compare with the CPU writer.
 #include "bv_encode.hpp"
+#include "bv_encode_wave.hpp"
 #include "bv_launch.hpp"
 
 #include <cstdio>
@@ -33,33 +34,128 @@ constexpr int SEL_CHUNK = 64; // nodes per chunk of the selection recurrence
 constexpr int SEL_SPAN = 16, SEL_BATCH = 8;
 constexpr int ENC_MAX_W = 63; // state of a chunk boundary: W chain lengths
 
-__global__ void __launch_bounds__(256) k_enc_check(const int32_t *__restrict__ succ, int64_t m, unsigned long long *__restrict__ viol) {
-	const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
-	const bool bad = a >= 1 && a < m && succ[a] <= succ[a - 1];
-	const unsigned long long cnt = __popcll(__ballot(bad));
-	if (cnt && (threadIdx.x & 63) == 0) atomicAdd(viol, cnt);
-}
-// descents at the first successor of a row are not violations: count them too (row starts are distinct positions)
-__global__ void __launch_bounds__(256) k_enc_check_rows(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ, int32_t n, unsigned long long *__restrict__ viol) {
-	const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
-	bool hit = false;
-	if (x < n) {
-		const int64_t a = rowptr[x];
-		hit = rowptr[x + 1] > a && a >= 1 && succ[a] <= succ[a - 1];
+// ---- work lists: the items of a phase (pairs, nodes) grouped by the log2 of their size, biggest first.  A lane walks its
+// item alone, so a wave lasts as long as its longest item: waves of like-sized items waste no lane-time, and the long ones
+// start first.  Within a bin the items stay in (nearly) node order: the pairs of a node share its successor list.
+constexpr int ENC_NBIN = 32, SORT_ITEMS = 8, SORT_TILE = 256 * SORT_ITEMS;
+constexpr int BIG_BIN = 8;         // items of 2^(BIG_BIN - 1) = 128 elements or more are walked by a wave
+constexpr int WAVE_BLOCKS = 2048; // 4 waves each, striding over the head of the list
+__device__ __forceinline__ int size_bin(uint64_t s) { return s == 0 ? 0 : (s >> 30 ? 31 : 32 - __clz((uint32_t)s)); }
+
+struct PairItems { // item q <-> (node q / (W + 1), candidate q % (W + 1)); size = successors of the node + successors of the candidate
+	Params p;
+	const int64_t *rowptr;
+	int64_t count;
+	__device__ __forceinline__ int bin(int64_t q) const {
+		const int cyc = p.W + 1;
+		const int32_t x = (int32_t)(q / cyc);
+		const int r = (int)(q - (int64_t)x * cyc);
+		const int64_t a = rowptr[x], d = rowptr[x + 1] - a;
+		const int32_t y = x - r;
+		if (d == 0 || y < bve::part_lo(p, x)) return -1;
+		const int64_t dr = r == 0 ? 0 : rowptr[y + 1] - rowptr[y];
+		if (r != 0 && dr == 0) return -1;
+		return size_bin((uint64_t)(d + dr));
 	}
-	const unsigned long long cnt = __popcll(__ballot(hit));
-	if (cnt && (threadIdx.x & 63) == 0) atomicAdd(viol + 1, cnt);
+};
+struct NodeItems { // item x <-> node x; size = its successors + those of the chosen reference
+	Params p;
+	const int64_t *rowptr;
+	const uint8_t *best;
+	int64_t count;
+	__device__ __forceinline__ int bin(int64_t x) const {
+		const int64_t d = rowptr[x + 1] - rowptr[x];
+		const int r = d ? best[x] : 0;
+		return size_bin((uint64_t)(d + (r ? rowptr[x - r + 1] - rowptr[x - r] : 0)));
+	}
+};
+
+template <class Items>
+__global__ void __launch_bounds__(256) k_enc_hist(const Items it, uint32_t *__restrict__ hist) {
+	__shared__ uint32_t s_cnt[ENC_NBIN];
+	if (threadIdx.x < ENC_NBIN) s_cnt[threadIdx.x] = 0;
+	__syncthreads();
+#pragma unroll
+	for (int i = 0; i < SORT_ITEMS; i++) {
+		const int64_t q = (int64_t)blockIdx.x * SORT_TILE + i * 256 + threadIdx.x;
+		if (q < it.count) { const int b = it.bin(q); if (b >= 0) atomicAdd(&s_cnt[b], 1u); }
+	}
+	__syncthreads();
+	if (threadIdx.x < ENC_NBIN && s_cnt[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_cnt[threadIdx.x]);
+}
+// cursor[b] = first list slot of bin b, bins in descending order; cursor[ENC_NBIN] = number of listed items
+// cursor[ENC_NBIN + 1] = items of the bins >= bigBin (the head of the list): those go to whole waves
+__global__ void k_enc_bases(const uint32_t *__restrict__ hist, uint32_t *__restrict__ cursor, int bigBin) {
+	if (threadIdx.x != 0 || blockIdx.x != 0) return;
+	uint32_t run = 0;
+	for (int b = ENC_NBIN - 1; b >= 0; b--) { if (b == bigBin - 1) cursor[ENC_NBIN + 1] = run; cursor[b] = run; run += hist[b]; }
+	cursor[ENC_NBIN] = run;
+	if (bigBin <= 0) cursor[ENC_NBIN + 1] = run;
+}
+template <class Items>
+__global__ void __launch_bounds__(256) k_enc_scatter(const Items it, uint32_t *__restrict__ cursor, uint32_t *__restrict__ list, uint32_t *__restrict__ none) {
+	__shared__ uint32_t s_cnt[ENC_NBIN], s_base[ENC_NBIN];
+	if (threadIdx.x < ENC_NBIN) s_cnt[threadIdx.x] = 0;
+	__syncthreads();
+	int bin[SORT_ITEMS];
+	uint32_t rank[SORT_ITEMS];
+#pragma unroll
+	for (int i = 0; i < SORT_ITEMS; i++) {
+		const int64_t q = (int64_t)blockIdx.x * SORT_TILE + i * 256 + threadIdx.x;
+		bin[i] = q < it.count ? it.bin(q) : -2;
+		rank[i] = bin[i] >= 0 ? atomicAdd(&s_cnt[bin[i]], 1u) : 0;
+		if (bin[i] == -1 && none) none[q] = bve::COST_NONE; // not a candidate: its cost is known without a walk
+	}
+	__syncthreads();
+	if (threadIdx.x < ENC_NBIN && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], s_cnt[threadIdx.x]);
+	__syncthreads();
+#pragma unroll
+	for (int i = 0; i < SORT_ITEMS; i++)
+		if (bin[i] >= 0) list[s_base[bin[i]] + rank[i]] = (uint32_t)((int64_t)blockIdx.x * SORT_TILE + i * 256 + threadIdx.x);
 }
 
-__global__ void __launch_bounds__(256) k_enc_cost(const Params p, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ, int64_t npairs, uint32_t *__restrict__ cost, int *__restrict__ err) {
-	const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
-	if (q >= npairs) return;
+template <bool DEF>
+__global__ void __launch_bounds__(256) k_enc_cost(const Params p, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ, const uint32_t *__restrict__ list,
+                                                  const uint32_t *__restrict__ total, uint32_t *__restrict__ cost, int *__restrict__ err, int64_t skip) {
+	const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x + skip + total[1]; // the lanes take what the waves leave
+	if (t >= *total) return;
+	const int64_t q = list[t];
 	const int cyc = p.W + 1;
 	const int32_t x = (int32_t)(q / cyc);
 	const int r = (int)(q - (int64_t)x * cyc);
 	int e = 0;
-	cost[q] = bve::pair_cost(p, rowptr, succ, x, r, &e);
+	cost[q] = bve::pair_cost<DEF>(p, rowptr, succ, x, r, &e);
 	if (e) atomicOr(err, e);
+}
+
+// the pairs at the head of the list, one wave each (bv_encode_wave.hpp)
+template <bool DEF>
+__global__ void __launch_bounds__(256) k_enc_cost_wave(const Params p, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ, const uint32_t *__restrict__ list,
+                                                       const uint32_t *__restrict__ total, uint32_t *__restrict__ cost, int *__restrict__ err, int64_t skip, int64_t dbgq) {
+	const int64_t nbig = total[1], stride = (int64_t)gridDim.x * 4;
+	for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6) + skip; t < nbig; t += stride) {
+		const int64_t q = list[t];
+		const int cyc = p.W + 1;
+		const int32_t x = (int32_t)(q / cyc);
+		const int r = (int)(q - (int64_t)x * cyc);
+		int e = 0;
+		const uint32_t c = bvw::wave_pair_cost<DEF>(p, rowptr, succ, x, r, &e, q == dbgq);
+		if ((threadIdx.x & 63) == 0) { cost[q] = c; if (e) atomicOr(err, e); }
+	}
+}
+
+// experiment (BVGPU_ENC_VERIFY): the lane walk over the pairs the waves took; mismatches -> dbg[0] = count, then (q, wave, lane) triples
+template <bool DEF>
+__global__ void __launch_bounds__(256) k_enc_verify(const Params p, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ, const uint32_t *__restrict__ list,
+                                                    const uint32_t *__restrict__ total, const uint32_t *__restrict__ cost, unsigned long long *__restrict__ dbg) {
+	const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (t >= total[1]) return;
+	const int64_t q = list[t];
+	const int cyc = p.W + 1;
+	const int32_t x = (int32_t)(q / cyc);
+	int e = 0;
+	const uint32_t c = bve::pair_cost<DEF>(p, rowptr, succ, x, (int)(q - (int64_t)x * cyc), &e);
+	if (c != cost[q]) { const unsigned long long k = atomicAdd(dbg, 1ull); if (k < 16) { dbg[1 + 3 * k] = (unsigned long long)q; dbg[2 + 3 * k] = cost[q]; dbg[3 + 3 * k] = c; } }
 }
 
 // one round of bve::select_span: lane l walks the chunks [l * span, (l + 1) * span)
@@ -92,14 +188,16 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 	return v;
 }
 
+template <bool DEF>
 __global__ void __launch_bounds__(256) k_enc_emit(const Params p, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ, const uint8_t *__restrict__ best, const int32_t *__restrict__ refc,
-                                                  const int64_t *__restrict__ off, int32_t n, uint32_t *__restrict__ words, EncStatsDev *__restrict__ stats) {
-	const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
+                                                  const int64_t *__restrict__ off, const uint32_t *__restrict__ list, const uint32_t *__restrict__ total, int32_t n, uint32_t *__restrict__ words, EncStatsDev *__restrict__ stats) {
+	const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x + total[1];
 	bve::NodeStats st;
 	unsigned long long totRef = 0, totDist = 0, chain = 0;
-	if (x < n) {
+	if (t < n) {
+		const int64_t x = list[t];
 		const int r = best[x];
-		(void)bve::emit_node(p, rowptr, succ, (int32_t)x, r, words, (uint64_t)off[x], &st);
+		(void)bve::emit_node<DEF>(p, rowptr, succ, (int32_t)x, r, words, (uint64_t)off[x], &st);
 		if (rowptr[x + 1] > rowptr[x]) { totRef = (unsigned long long)refc[x]; totDist = (unsigned long long)r; chain = totRef; }
 	}
 	const unsigned long long vals[10] = { st.bitsOutd, st.bitsRef, st.bitsBlocks, st.bitsIntervals, st.bitsResiduals, st.copied, st.intervalised, st.residuals, totRef, totDist };
@@ -110,6 +208,27 @@ __global__ void __launch_bounds__(256) k_enc_emit(const Params p, const int64_t 
 	}
 	for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(chain, o); chain = t > chain ? t : chain; }
 	if ((threadIdx.x & 63) == 0 && chain) atomicMax(&stats->v[10], chain);
+}
+
+template <bool DEF>
+__global__ void __launch_bounds__(256) k_enc_emit_wave(const Params p, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ, const uint8_t *__restrict__ best, const int32_t *__restrict__ refc,
+                                                       const int64_t *__restrict__ off, const uint32_t *__restrict__ list, const uint32_t *__restrict__ total, uint32_t *__restrict__ words,
+                                                       EncStatsDev *__restrict__ stats) {
+	const int64_t nbig = total[1], stride = (int64_t)gridDim.x * 4;
+	unsigned long long acc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, chain = 0; // lane 0 of the wave
+	for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < nbig; t += stride) {
+		const int32_t x = (int32_t)list[t];
+		const int r = best[x];
+		bve::NodeStats st;
+		bvw::wave_emit_node<DEF>(p, rowptr, succ, x, r, words, (uint64_t)off[x], st);
+		acc[0] += st.bitsOutd; acc[1] += st.bitsRef; acc[2] += st.bitsBlocks; acc[3] += st.bitsIntervals; acc[4] += st.bitsResiduals;
+		acc[5] += st.copied; acc[6] += st.intervalised; acc[7] += st.residuals; acc[8] += (unsigned long long)refc[x]; acc[9] += (unsigned long long)r;
+		if ((unsigned long long)refc[x] > chain) chain = (unsigned long long)refc[x];
+	}
+	if ((threadIdx.x & 63) == 0) {
+		for (int i = 0; i < 10; i++) if (acc[i]) atomicAdd(&stats->v[i], acc[i]);
+		if (chain) atomicMax(&stats->v[10], chain);
+	}
 }
 
 // the .offsets stream: code 0 is the offset of node 0, code i the length of record i - 1 (BVGraph.java:2285, :2369)
@@ -146,13 +265,13 @@ int encode_device(const Params &p, int32_t n, const int64_t *d_rowptr, const int
 	uint8_t *best = nullptr;
 	int32_t *refc = nullptr, *reclen = nullptr, *offlen = nullptr, *state = nullptr, *used = nullptr;
 	int64_t *sums = nullptr, *offat = nullptr;
+	uint32_t *list = nullptr, *bins = nullptr; // bins: [0, 32) histogram, [32, 65) cursors + total
 	int *flags = nullptr, *moved = nullptr; // flags[0]: error bits; moved[i]: did round i of the batch change a chunk's final state
-	unsigned long long *viol = nullptr;
 	EncStatsDev *dstats = nullptr;
 	std::vector<hipEvent_t> ev;
 	auto mark = [&]() { if (trace) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st); ev.push_back(e); } };
 	auto cleanup = [&](int rc) {
-		for (void *q : { (void *)cost, (void *)best, (void *)refc, (void *)reclen, (void *)offlen, (void *)state, (void *)used, (void *)sums, (void *)offat, (void *)flags, (void *)moved, (void *)viol, (void *)dstats })
+		for (void *q : { (void *)cost, (void *)best, (void *)refc, (void *)reclen, (void *)offlen, (void *)state, (void *)used, (void *)sums, (void *)offat, (void *)list, (void *)bins, (void *)flags, (void *)moved, (void *)dstats })
 			if (q) (void)hipFree(q);
 		for (auto e : ev) (void)hipEventDestroy(e);
 		if (rc) { encode_free(out); (void)hipGetLastError(); }
@@ -160,21 +279,63 @@ int encode_device(const Params &p, int32_t n, const int64_t *d_rowptr, const int
 	};
 	auto alloc = [&](void **q, size_t bytes) { return hipMalloc(q, bytes ? bytes : 16) == hipSuccess; };
 	const size_t nn = (size_t)n + 1;
+	if (npairs >= 0xffffffffll) { err = "too many (node, candidate) pairs for one call"; return cleanup(-3); }
+	const bool def = bve::default_codings(p);
+	const int bigBin = getenv("BVGPU_ENC_BIGBIN") ? atoi(getenv("BVGPU_ENC_BIGBIN")) : BIG_BIN; // experiment: 32 = everything lane by lane
+	const int64_t dbgQ = getenv("BVGPU_ENC_DEBUGQ") ? atoll(getenv("BVGPU_ENC_DEBUGQ")) : -1; // experiment: trace the wave walk of one pair
+	const int64_t dbgSkip = getenv("BVGPU_ENC_SKIP") ? atoll(getenv("BVGPU_ENC_SKIP")) : 0; // experiment: leave out the first pairs of the list (the biggest)
 	if (!alloc((void **)&cost, sizeof(uint32_t) * (size_t)npairs) || !alloc((void **)&best, nn) || !alloc((void **)&refc, sizeof(int32_t) * nn) ||
 	    !alloc((void **)&reclen, sizeof(int32_t) * nn) || !alloc((void **)&offlen, sizeof(int32_t) * nn) || !alloc((void **)&state, sizeof(int32_t) * 2 * (size_t)nchunks * (size_t)(p.W ? p.W : 1)) ||
 	    !alloc((void **)&used, sizeof(int32_t) * (size_t)nchunks * (size_t)(p.W ? p.W : 1)) || !alloc((void **)&sums, sizeof(int64_t) * (size_t)(ns + 1)) ||
-	    !alloc((void **)&offat, sizeof(int64_t) * (nn + 1)) || !alloc((void **)&flags, 2 * sizeof(int)) || !alloc((void **)&moved, SEL_BATCH * sizeof(int)) || !alloc((void **)&viol, 2 * sizeof(unsigned long long)) ||
+	    !alloc((void **)&offat, sizeof(int64_t) * (nn + 1)) || !alloc((void **)&list, sizeof(uint32_t) * (size_t)(npairs > (int64_t)nn ? npairs : (int64_t)nn)) || !alloc((void **)&bins, sizeof(uint32_t) * (2 * ENC_NBIN + 2)) || !alloc((void **)&flags, 2 * sizeof(int)) || !alloc((void **)&moved, SEL_BATCH * sizeof(int)) ||
 	    !alloc((void **)&dstats, sizeof(EncStatsDev)) || !alloc((void **)&out.offsets, sizeof(int64_t) * nn)) { err = "device allocation failed"; return cleanup(-5); }
 	(void)hipMemsetAsync(flags, 0, 2 * sizeof(int), st);
-	(void)hipMemsetAsync(viol, 0, 2 * sizeof(unsigned long long), st);
 	(void)hipMemsetAsync(dstats, 0, sizeof(EncStatsDev), st);
 	mark();
 	auto blocks = [](int64_t items, int per) { return dim3((unsigned)((items + per - 1) / per > 0 ? (items + per - 1) / per : 1)); };
-	// rows must be strictly increasing (the reference's iterators guarantee it; a CSR from elsewhere may not)
-	hipLaunchKernelGGL(k_enc_check, blocks((int64_t)m, 256), dim3(256), 0, st, d_succ, (int64_t)m, viol);
-	hipLaunchKernelGGL(k_enc_check_rows, blocks(n, 256), dim3(256), 0, st, d_rowptr, d_succ, n, viol);
 	// A
-	if (npairs) hipLaunchKernelGGL(k_enc_cost, blocks(npairs, 256), dim3(256), 0, st, p, d_rowptr, d_succ, npairs, cost, flags);
+	if (npairs) {
+		const PairItems items{ p, d_rowptr, npairs };
+		(void)hipMemsetAsync(bins, 0, sizeof(uint32_t) * (2 * ENC_NBIN + 2), st);
+		hipLaunchKernelGGL(k_enc_hist<PairItems>, blocks(npairs, SORT_TILE), dim3(256), 0, st, items, bins);
+		hipLaunchKernelGGL(k_enc_bases, dim3(1), dim3(64), 0, st, bins, bins + ENC_NBIN, bigBin);
+		hipLaunchKernelGGL(k_enc_scatter<PairItems>, blocks(npairs, SORT_TILE), dim3(256), 0, st, items, bins + ENC_NBIN, list, cost);
+		if (def) {
+			hipLaunchKernelGGL(k_enc_cost_wave<true>, dim3(WAVE_BLOCKS), dim3(256), 0, st, p, d_rowptr, d_succ, list, bins + 2 * ENC_NBIN, cost, flags, dbgSkip, dbgQ);
+			hipLaunchKernelGGL(k_enc_cost<true>, blocks(npairs, 256), dim3(256), 0, st, p, d_rowptr, d_succ, list, bins + 2 * ENC_NBIN, cost, flags, (int64_t)0);
+		} else {
+			hipLaunchKernelGGL(k_enc_cost_wave<false>, dim3(WAVE_BLOCKS), dim3(256), 0, st, p, d_rowptr, d_succ, list, bins + 2 * ENC_NBIN, cost, flags, dbgSkip, dbgQ);
+			hipLaunchKernelGGL(k_enc_cost<false>, blocks(npairs, 256), dim3(256), 0, st, p, d_rowptr, d_succ, list, bins + 2 * ENC_NBIN, cost, flags, (int64_t)0);
+		}
+	}
+	if (npairs && getenv("BVGPU_ENC_VERIFY")) {
+		unsigned long long *dbg = nullptr, h[49] = { 0 };
+		if (hipMalloc((void **)&dbg, sizeof h) == hipSuccess) {
+			(void)hipMemsetAsync(dbg, 0, sizeof h, st);
+			if (def) hipLaunchKernelGGL(k_enc_verify<true>, blocks(npairs, 256), dim3(256), 0, st, p, d_rowptr, d_succ, list, bins + 2 * ENC_NBIN, cost, dbg);
+			else hipLaunchKernelGGL(k_enc_verify<false>, blocks(npairs, 256), dim3(256), 0, st, p, d_rowptr, d_succ, list, bins + 2 * ENC_NBIN, cost, dbg);
+			(void)hipMemcpyAsync(h, dbg, sizeof h, hipMemcpyDeviceToHost, st);
+			(void)hipStreamSynchronize(st);
+			(void)hipFree(dbg);
+			fprintf(stderr, "[bvgpu enc] verify: %llu pairs priced differently by the waves\n", h[0]);
+			std::vector<int64_t> rp((size_t)n + 1);
+			(void)hipMemcpy(rp.data(), d_rowptr, sizeof(int64_t) * rp.size(), hipMemcpyDeviceToHost);
+			for (unsigned long long k = 0; k < h[0] && k < 16; k++) {
+				const int64_t q = (int64_t)h[1 + 3 * k];
+				const int32_t x = (int32_t)(q / cyc); const int r = (int)(q % cyc);
+				fprintf(stderr, "[bvgpu enc]   node %d ref %d: d %lld dr %lld wave %llu lane %llu\n", x, r, (long long)(rp[(size_t)x + 1] - rp[(size_t)x]),
+				        (long long)(rp[(size_t)(x - r) + 1] - rp[(size_t)(x - r)]), h[2 + 3 * k], h[3 + 3 * k]);
+			}
+		}
+	}
+	if (trace && npairs) {
+		uint32_t h[ENC_NBIN];
+		if (hipMemcpyAsync(h, bins, sizeof h, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess) {
+			fprintf(stderr, "[bvgpu enc] pairs by size bin (bin b: < 2^b elements):");
+			for (int b = 0; b < ENC_NBIN; b++) if (h[b]) fprintf(stderr, " %d:%u", b, h[b]);
+			fprintf(stderr, "\n");
+		}
+	}
 	mark();
 	// B: round 0 one chunk per lane, then SEL_SPAN chunks per lane; SEL_BATCH rounds are enqueued between two looks at the flags
 	int rounds = 0;
@@ -197,14 +358,12 @@ int encode_device(const Params &p, int32_t n, const int64_t *d_rowptr, const int
 	}
 	mark();
 	// C
-	unsigned long long hviol[2] = { 0, 0 };
 	int herr = 0;
 	if (n) hipLaunchKernelGGL(k_enc_reclen, blocks(n, 256), dim3(256), 0, st, p, d_rowptr, cost, best, n, reclen, flags);
 	launch_scan(reclen, n, out.offsets, sums, st);
 	int64_t totalBits = 0;
-	if (hipMemcpyAsync(&totalBits, out.offsets + n, sizeof(int64_t), hipMemcpyDeviceToHost, st) != hipSuccess || hipMemcpyAsync(&herr, flags, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
-	    hipMemcpyAsync(hviol, viol, sizeof hviol, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { err = "the compressor kernels failed"; return cleanup(-6); }
-	if (hviol[0] != hviol[1]) { err = "successor lists must be strictly increasing"; return cleanup(-1); }
+	if (hipMemcpyAsync(&totalBits, out.offsets + n, sizeof(int64_t), hipMemcpyDeviceToHost, st) != hipSuccess || hipMemcpyAsync(&herr, flags, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { err = "the compressor kernels failed"; return cleanup(-6); }
+	if (herr & 1) { err = "successor lists must be strictly increasing"; return cleanup(-1); }
 	if (herr) { err = "a record of 2^31 bits or more"; return cleanup(-3); }
 	mark();
 	// D
@@ -212,7 +371,20 @@ int encode_device(const Params &p, int32_t n, const int64_t *d_rowptr, const int
 	const size_t gw = (size_t)((totalBits + 31) / 32) + 8;
 	if (!alloc((void **)&out.graph_words, gw * 4)) { err = "device allocation failed"; return cleanup(-5); }
 	(void)hipMemsetAsync(out.graph_words, 0, gw * 4, st);
-	if (n) hipLaunchKernelGGL(k_enc_emit, blocks(n, 256), dim3(256), 0, st, p, d_rowptr, d_succ, best, refc, out.offsets, n, out.graph_words, dstats);
+	if (n) {
+		const NodeItems items{ p, d_rowptr, best, n };
+		(void)hipMemsetAsync(bins, 0, sizeof(uint32_t) * (2 * ENC_NBIN + 2), st);
+		hipLaunchKernelGGL(k_enc_hist<NodeItems>, blocks(n, SORT_TILE), dim3(256), 0, st, items, bins);
+		hipLaunchKernelGGL(k_enc_bases, dim3(1), dim3(64), 0, st, bins, bins + ENC_NBIN, bigBin);
+		hipLaunchKernelGGL(k_enc_scatter<NodeItems>, blocks(n, SORT_TILE), dim3(256), 0, st, items, bins + ENC_NBIN, list, (uint32_t *)nullptr);
+		if (def) {
+			hipLaunchKernelGGL(k_enc_emit_wave<true>, dim3(WAVE_BLOCKS), dim3(256), 0, st, p, d_rowptr, d_succ, best, refc, out.offsets, list, bins + 2 * ENC_NBIN, out.graph_words, dstats);
+			hipLaunchKernelGGL(k_enc_emit<true>, blocks(n, 256), dim3(256), 0, st, p, d_rowptr, d_succ, best, refc, out.offsets, list, bins + 2 * ENC_NBIN, n, out.graph_words, dstats);
+		} else {
+			hipLaunchKernelGGL(k_enc_emit_wave<false>, dim3(WAVE_BLOCKS), dim3(256), 0, st, p, d_rowptr, d_succ, best, refc, out.offsets, list, bins + 2 * ENC_NBIN, out.graph_words, dstats);
+			hipLaunchKernelGGL(k_enc_emit<false>, blocks(n, 256), dim3(256), 0, st, p, d_rowptr, d_succ, best, refc, out.offsets, list, bins + 2 * ENC_NBIN, n, out.graph_words, dstats);
+		}
+	}
 	mark();
 	// E
 	hipLaunchKernelGGL(k_enc_offlen, blocks((int64_t)n + 1, 256), dim3(256), 0, st, p, reclen, n, offlen);

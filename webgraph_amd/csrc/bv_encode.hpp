@@ -117,6 +117,14 @@ template <class S> BVE_HD void w_code(S &s, int coding, uint64_t x, int k) {
 	}
 }
 
+// the five fields of a record whose coding the flags choose; DEF = the default codings with zetak = 3, resolved at compile time
+BVE_HD bool default_codings(const Params &p) { return p.c_outd == C_GAMMA && p.c_blk == C_GAMMA && p.c_res == C_ZETA && p.K == 3 && p.c_ref == C_UNARY && p.c_bc == C_GAMMA; }
+template <bool DEF, class S> BVE_HD void f_outd(S &s, const Params &p, uint64_t x) { if (DEF) w_gamma(s, x); else w_code(s, p.c_outd, x, 0); }
+template <bool DEF, class S> BVE_HD void f_ref(S &s, const Params &p, uint64_t x) { if (DEF) w_unary(s, x); else w_code(s, p.c_ref, x, 0); }
+template <bool DEF, class S> BVE_HD void f_bc(S &s, const Params &p, uint64_t x) { if (DEF) w_gamma(s, x); else w_code(s, p.c_bc, x, 0); }
+template <bool DEF, class S> BVE_HD void f_blk(S &s, const Params &p, uint64_t x) { if (DEF) w_gamma(s, x); else w_code(s, p.c_blk, x, 0); }
+template <bool DEF, class S> BVE_HD void f_res(S &s, const Params &p, uint64_t x) { if (DEF) w_zeta(s, x, 3); else w_code(s, p.c_res, x, p.K); }
+
 // ---- the walk.  V sees, in stream order within each section: block(run) for every copy block, interval(left, len) and
 // residual(v) for the extras.  (Blocks, intervals and residuals are three sections of the record; a visitor that writes
 // keeps a cursor per section.)
@@ -166,6 +174,7 @@ BVE_HD int32_t diff_walk(const int32_t *__restrict__ cur, int32_t d, const int32
 
 // ---- visitors
 // section sizes of one (node, candidate) description: what the forReal = false run of diffComp measures
+template <bool DEF>
 struct CountVisitor {
 	const Params &p;
 	int32_t node;
@@ -174,7 +183,7 @@ struct CountVisitor {
 	int64_t prevEnd = 0, prevRes = 0;
 	uint64_t ivArcs = 0;
 	BVE_HD CountVisitor(const Params &p_, int32_t node_) : p(p_), node(node_) {}
-	BVE_HD void block(int32_t run) { LenSink s; w_code(s, p.c_blk, (uint64_t)(nb == 0 ? run : run - 1), 0); bitsB += s.bits; nb++; }
+	BVE_HD void block(int32_t run) { LenSink s; f_blk<DEF>(s, p, (uint64_t)(nb == 0 ? run : run - 1)); bitsB += s.bits; nb++; }
 	BVE_HD void interval(int32_t left, int32_t len) {
 		LenSink s;
 		w_gamma(s, ni == 0 ? int2nat((int64_t)left - node) : (uint64_t)((int64_t)left - prevEnd - 1));
@@ -183,17 +192,18 @@ struct CountVisitor {
 	}
 	BVE_HD void residual(int32_t x) {
 		LenSink s;
-		w_code(s, p.c_res, nr == 0 ? int2nat((int64_t)x - node) : (uint64_t)((int64_t)x - prevRes - 1), p.K);
+		f_res<DEF>(s, p, nr == 0 ? int2nat((int64_t)x - node) : (uint64_t)((int64_t)x - prevRes - 1));
 		bitsR += s.bits; nr++; prevRes = x;
 	}
 	// bits of the description after the outdegree (reference field, block section, interval section, residual section)
-	BVE_HD uint64_t bits_ref(int r) const { LenSink s; if (p.W > 0) w_code(s, p.c_ref, (uint64_t)r, 0); return s.bits; }
-	BVE_HD uint64_t bits_blocks(int r) const { LenSink s; if (r != 0) w_code(s, p.c_bc, nb, 0); return s.bits + (r != 0 ? bitsB : 0); }
+	BVE_HD uint64_t bits_ref(int r) const { LenSink s; if (p.W > 0) f_ref<DEF>(s, p, (uint64_t)r); return s.bits; }
+	BVE_HD uint64_t bits_blocks(int r) const { LenSink s; if (r != 0) f_bc<DEF>(s, p, nb); return s.bits + (r != 0 ? bitsB : 0); }
 	BVE_HD uint64_t bits_intervals(int32_t nextra) const { LenSink s; if (nextra > 0 && p.I != 0) w_gamma(s, ni); return s.bits + bitsI; }
 	BVE_HD uint64_t total(int r, int32_t nextra) const { return bits_ref(r) + bits_blocks(r) + bits_intervals(nextra) + bitsR; }
 };
 
 // writes the three sections through three cursors
+template <bool DEF>
 struct EmitVisitor {
 	const Params &p;
 	int32_t node;
@@ -202,14 +212,14 @@ struct EmitVisitor {
 	int64_t prevEnd = 0, prevRes = 0;
 	BVE_HD EmitVisitor(const Params &p_, int32_t node_, uint32_t *words, uint64_t posB, uint64_t posI, uint64_t posR)
 	    : p(p_), node(node_), sB(words, posB), sI(words, posI), sR(words, posR) {}
-	BVE_HD void block(int32_t run) { w_code(sB, p.c_blk, (uint64_t)(nb == 0 ? run : run - 1), 0); nb++; }
+	BVE_HD void block(int32_t run) { f_blk<DEF>(sB, p, (uint64_t)(nb == 0 ? run : run - 1)); nb++; }
 	BVE_HD void interval(int32_t left, int32_t len) {
 		w_gamma(sI, ni == 0 ? int2nat((int64_t)left - node) : (uint64_t)((int64_t)left - prevEnd - 1));
 		w_gamma(sI, (uint64_t)(len - p.I));
 		ni++; prevEnd = (int64_t)left + len;
 	}
 	BVE_HD void residual(int32_t x) {
-		w_code(sR, p.c_res, nr == 0 ? int2nat((int64_t)x - node) : (uint64_t)((int64_t)x - prevRes - 1), p.K);
+		f_res<DEF>(sR, p, nr == 0 ? int2nat((int64_t)x - node) : (uint64_t)((int64_t)x - prevRes - 1));
 		nr++; prevRes = x;
 	}
 	BVE_HD void finish() { sB.finish(); sI.finish(); sR.finish(); }
@@ -223,6 +233,7 @@ BVE_HD int32_t part_lo(const Params &p, int32_t x) { return p.per > 0 ? (x / p.p
 
 // Phase A for one pair: cost in bits of describing x through x - r (r = 0: no reference), COST_NONE if the pair is not a
 // candidate whatever the chain lengths are (BVGraph.java:2313-2327 also asks refCount < maxRefCount: phase B).
+template <bool DEF>
 BVE_HD uint32_t pair_cost(const Params &p, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ, int32_t x, int r, int *err) {
 	const int64_t a = rowptr[x];
 	const int32_t d = (int32_t)(rowptr[x + 1] - a);
@@ -232,7 +243,8 @@ BVE_HD uint32_t pair_cost(const Params &p, const int64_t *__restrict__ rowptr, c
 	const int64_t b = rowptr[y];
 	const int32_t dr = r == 0 ? 0 : (int32_t)(rowptr[y + 1] - b);
 	if (r != 0 && dr == 0) return COST_NONE;
-	CountVisitor v(p, x);
+	if (r == 0) for (int32_t j = 1; j < d; j++) if (succ[a + j] <= succ[a + j - 1]) *err |= 1; // the lists must increase strictly (every non-empty list has this pair)
+	CountVisitor<DEF> v(p, x);
 	const int32_t nextra = diff_walk(succ + a, d, succ + b, dr, p.I, v);
 	const uint64_t t = v.total(r, nextra);
 	if (t > COST_MAX) { *err |= 2; return COST_NONE; }
@@ -303,12 +315,13 @@ struct NodeStats {
 };
 
 // Phase D for one node: write the record at bit `pos` of `words` (zeroed beforehand).  Returns its length in bits.
+template <bool DEF>
 BVE_HD uint64_t emit_node(const Params &p, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ, int32_t x, int r, uint32_t *words,
                           uint64_t pos, NodeStats *st) {
 	const int64_t a = rowptr[x];
 	const int32_t d = (int32_t)(rowptr[x + 1] - a);
 	WordSink head(words, pos);
-	w_code(head, p.c_outd, (uint64_t)d, 0);
+	f_outd<DEF>(head, p, (uint64_t)d);
 	const uint64_t afterOutd = head.pos;
 	if (st) st->bitsOutd = afterOutd - pos;
 	if (d == 0) { head.finish(); return afterOutd - pos; }
@@ -316,11 +329,11 @@ BVE_HD uint64_t emit_node(const Params &p, const int64_t *__restrict__ rowptr, c
 	const int64_t b = rowptr[y];
 	const int32_t dr = r == 0 ? 0 : (int32_t)(rowptr[y + 1] - b);
 	// sizes of the sections first: the counts precede the items in the stream
-	CountVisitor cv(p, x);
+	CountVisitor<DEF> cv(p, x);
 	const int32_t nextra = diff_walk(succ + a, d, succ + b, dr, p.I, cv);
-	if (p.W > 0) w_code(head, p.c_ref, (uint64_t)r, 0);
+	if (p.W > 0) f_ref<DEF>(head, p, (uint64_t)r);
 	const uint64_t afterRef = head.pos;
-	if (r != 0) w_code(head, p.c_bc, cv.nb, 0);
+	if (r != 0) f_bc<DEF>(head, p, cv.nb);
 	const uint64_t posB = head.pos;
 	head.finish();
 	const uint64_t startI = posB + (r != 0 ? cv.bitsB : 0);
@@ -329,7 +342,7 @@ BVE_HD uint64_t emit_node(const Params &p, const int64_t *__restrict__ rowptr, c
 	const uint64_t posI = ic.pos;
 	ic.finish();
 	const uint64_t posR = posI + cv.bitsI;
-	EmitVisitor ev(p, x, words, posB, posI, posR);
+	EmitVisitor<DEF> ev(p, x, words, posB, posI, posR);
 	(void)diff_walk(succ + a, d, succ + b, dr, p.I, ev);
 	ev.finish();
 	const uint64_t end = posR + cv.bitsR;
