@@ -97,3 +97,53 @@ def test_store_errors(tmp_path):
     # rows may start lower than the previous row ended: only the order inside a row matters
     st = B.store(rowptr, np.array([5, 6, 7, 0, 1], dtype=np.int32), str(tmp_path / "ok"))
     assert st["copied_arcs"] + st["intervalised_arcs"] + st["residual_arcs"] == 5
+
+
+def _shaped_graph(rng, n=3000):
+    """Rows built to stress the wave walk: long runs of consecutive ids (intervals longer than a tile of 64), rows that copy a
+    long predecessor keeping 2 of every 3 / dropping stretches / adding a few, empty rows in between, one giant row."""
+    rows = []
+    for x in range(n):
+        k = rng.integers(0, 12)
+        prev = rows[x - int(rng.integers(1, 4))] if x >= 3 else []
+        if k == 0 or x < 3:
+            base = int(rng.integers(0, 200000))
+            row = set(range(base, base + int(rng.integers(1, 700))))                      # one long interval
+            row |= set(int(v) for v in rng.integers(0, 300000, size=int(rng.integers(0, 90))))
+        elif k == 1:
+            row = set()
+        elif k <= 5 and len(prev):
+            keep = rng.random(len(prev)) < rng.choice([0.3, 0.66, 0.95])
+            row = set(np.asarray(prev)[keep].tolist())
+            row |= set(int(v) for v in rng.integers(0, 300000, size=int(rng.integers(0, 40))))
+        elif k <= 8 and len(prev):
+            a, b = sorted(rng.integers(0, len(prev) + 1, size=2))
+            row = set(prev[:a]) | set(prev[b:])                                         # a stretch dropped
+            row |= set(range(int(prev[0]) + 5, int(prev[0]) + 5 + int(rng.integers(0, 150))))
+        else:
+            row = set(int(v) for v in rng.integers(0, 300000, size=int(rng.integers(1, 400))))
+            start = int(rng.integers(0, 250000))
+            for i in range(int(rng.integers(0, 5))):                                    # runs of 2..70 consecutive ids
+                row |= set(range(start + 200 * i, start + 200 * i + int(rng.integers(2, 71))))
+        rows.append(sorted(row))
+    rows[n // 2] = sorted(set(int(v) for v in rng.integers(0, 300000, size=60000)) | set(range(100000, 109000)))
+    rows[n // 2 + 1] = sorted(set(rows[n // 2][::2]) | set(range(150000, 150400)))
+    rowptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+    succ = np.array([v for r in rows for v in r], dtype=np.int32)
+    return rowptr, succ
+
+
+@pytest.mark.parametrize("W,R,I", [(7, 3, 4), (7, 3, 2), (3, 2, 100), (7, 3, 0), (7, 8, 65), (1, 1, 3)])
+def test_store_shapes_that_stress_the_wave_walk(tmp_path, monkeypatch, W, R, I):
+    """Pairs of 128 elements or more are priced and written by whole waves (bv_encode_wave.hpp): runs and blocks that span tiles,
+    minIntervalLength below / at / above the tile size.  BVGPU_ENC_VERIFY makes the library price those pairs lane by lane too."""
+    from webgraph_amd import bvgraph as B
+    from webgraph_amd import tools as T
+    monkeypatch.setenv("BVGPU_ENC_VERIFY", "1")
+    rowptr, succ = _shaped_graph(np.random.Generator(np.random.PCG64(100 + W + I)))
+    cpu, gpu = str(tmp_path / "cpu"), str(tmp_path / "gpu")
+    st_cpu = T.store(cpu, rowptr, succ, window=W, max_ref_count=R, min_interval=I, threads=1)
+    st_gpu = B.store(rowptr, succ, gpu, windowSize=W, maxRefCount=R, minIntervalLength=I)
+    for ext in (".graph", ".offsets", ".properties"):
+        assert filecmp.cmp(cpu + ext, gpu + ext, shallow=False), ext
+    assert all(st_cpu[k] == st_gpu[k] for k in st_cpu)

@@ -63,10 +63,12 @@ struct NodeItems { // item x <-> node x; size = its successors + those of the ch
 	const int64_t *rowptr;
 	const uint8_t *best;
 	int64_t count;
+	int bigBin; // nodes whose chosen pair is that big are written by the waves, straight from the list of pairs
 	__device__ __forceinline__ int bin(int64_t x) const {
 		const int64_t d = rowptr[x + 1] - rowptr[x];
 		const int r = d ? best[x] : 0;
-		return size_bin((uint64_t)(d + (r ? rowptr[x - r + 1] - rowptr[x - r] : 0)));
+		const int b = size_bin((uint64_t)(d + (r ? rowptr[x - r + 1] - rowptr[x - r] : 0)));
+		return b >= bigBin ? -1 : b;
 	}
 };
 
@@ -116,8 +118,8 @@ __global__ void __launch_bounds__(256) k_enc_scatter(const Items it, uint32_t *_
 
 template <bool DEF>
 __global__ void __launch_bounds__(256) k_enc_cost(const Params p, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ, const uint32_t *__restrict__ list,
-                                                  const uint32_t *__restrict__ total, uint32_t *__restrict__ cost, int *__restrict__ err, int64_t skip) {
-	const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x + skip + total[1]; // the lanes take what the waves leave
+                                                  const uint32_t *__restrict__ total, uint32_t *__restrict__ cost, int *__restrict__ err) {
+	const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x + total[1]; // the lanes take what the waves leave
 	if (t >= *total) return;
 	const int64_t q = list[t];
 	const int cyc = p.W + 1;
@@ -131,20 +133,25 @@ __global__ void __launch_bounds__(256) k_enc_cost(const Params p, const int64_t 
 // the pairs at the head of the list, one wave each (bv_encode_wave.hpp)
 template <bool DEF>
 __global__ void __launch_bounds__(256) k_enc_cost_wave(const Params p, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ, const uint32_t *__restrict__ list,
-                                                       const uint32_t *__restrict__ total, uint32_t *__restrict__ cost, int *__restrict__ err, int64_t skip, int64_t dbgq) {
+                                                       const uint32_t *__restrict__ total, uint32_t *__restrict__ cost, bvw::PairInfo *__restrict__ info, int *__restrict__ err) {
 	const int64_t nbig = total[1], stride = (int64_t)gridDim.x * 4;
-	for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6) + skip; t < nbig; t += stride) {
+	for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < nbig; t += stride) {
 		const int64_t q = list[t];
 		const int cyc = p.W + 1;
 		const int32_t x = (int32_t)(q / cyc);
 		const int r = (int)(q - (int64_t)x * cyc);
 		int e = 0;
-		const uint32_t c = bvw::wave_pair_cost<DEF>(p, rowptr, succ, x, r, &e, q == dbgq);
-		if ((threadIdx.x & 63) == 0) { cost[q] = c; if (e) atomicOr(err, e); }
+		bvw::WaveTotals wt;
+		const uint32_t c = bvw::wave_pair_cost<DEF>(p, rowptr, succ, x, r, &e, wt);
+		if ((threadIdx.x & 63) == 0) {
+			cost[q] = c;
+			info[t] = bvw::PairInfo{ wt.nb, (uint32_t)wt.bitsB, wt.ni | (wt.nextra > 0 ? 0x80000000u : 0u), (uint32_t)wt.bitsI }; // (sections of 2^31 bits: c = COST_NONE, error raised)
+			if (e) atomicOr(err, e);
+		}
 	}
 }
 
-// experiment (BVGPU_ENC_VERIFY): the lane walk over the pairs the waves took; mismatches -> dbg[0] = count, then (q, wave, lane) triples
+// self-check (BVGPU_ENC_VERIFY, used by the tests): the lane walk over the pairs the waves took; mismatches -> dbg[0] = count, then (q, wave, lane) triples
 template <bool DEF>
 __global__ void __launch_bounds__(256) k_enc_verify(const Params p, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ, const uint32_t *__restrict__ list,
                                                     const uint32_t *__restrict__ total, const uint32_t *__restrict__ cost, unsigned long long *__restrict__ dbg) {
@@ -191,10 +198,10 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 template <bool DEF>
 __global__ void __launch_bounds__(256) k_enc_emit(const Params p, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ, const uint8_t *__restrict__ best, const int32_t *__restrict__ refc,
                                                   const int64_t *__restrict__ off, const uint32_t *__restrict__ list, const uint32_t *__restrict__ total, int32_t n, uint32_t *__restrict__ words, EncStatsDev *__restrict__ stats) {
-	const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x + total[1];
+	const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
 	bve::NodeStats st;
 	unsigned long long totRef = 0, totDist = 0, chain = 0;
-	if (t < n) {
+	if (t < total[0]) {
 		const int64_t x = list[t];
 		const int r = best[x];
 		(void)bve::emit_node<DEF>(p, rowptr, succ, (int32_t)x, r, words, (uint64_t)off[x], &st);
@@ -210,17 +217,21 @@ __global__ void __launch_bounds__(256) k_enc_emit(const Params p, const int64_t 
 	if ((threadIdx.x & 63) == 0 && chain) atomicMax(&stats->v[10], chain);
 }
 
+// the nodes whose chosen pair is at the head of the list of pairs: one wave each, with the sizes the pricing left
 template <bool DEF>
 __global__ void __launch_bounds__(256) k_enc_emit_wave(const Params p, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ, const uint8_t *__restrict__ best, const int32_t *__restrict__ refc,
-                                                       const int64_t *__restrict__ off, const uint32_t *__restrict__ list, const uint32_t *__restrict__ total, uint32_t *__restrict__ words,
-                                                       EncStatsDev *__restrict__ stats) {
-	const int64_t nbig = total[1], stride = (int64_t)gridDim.x * 4;
+                                                       const int64_t *__restrict__ off, const uint32_t *__restrict__ pairList, const uint32_t *__restrict__ pairTotal,
+                                                       const bvw::PairInfo *__restrict__ info, uint32_t *__restrict__ words, EncStatsDev *__restrict__ stats) {
+	const int64_t nbig = pairTotal[1], stride = (int64_t)gridDim.x * 4;
+	const int cyc = p.W + 1;
 	unsigned long long acc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, chain = 0; // lane 0 of the wave
 	for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < nbig; t += stride) {
-		const int32_t x = (int32_t)list[t];
-		const int r = best[x];
+		const int64_t q = pairList[t];
+		const int32_t x = (int32_t)(q / cyc);
+		const int r = (int)(q - (int64_t)x * cyc);
+		if (best[x] != r) continue;
 		bve::NodeStats st;
-		bvw::wave_emit_node<DEF>(p, rowptr, succ, x, r, words, (uint64_t)off[x], st);
+		bvw::wave_emit_node<DEF>(p, rowptr, succ, x, r, info[t], words, (uint64_t)off[x], st);
 		acc[0] += st.bitsOutd; acc[1] += st.bitsRef; acc[2] += st.bitsBlocks; acc[3] += st.bitsIntervals; acc[4] += st.bitsResiduals;
 		acc[5] += st.copied; acc[6] += st.intervalised; acc[7] += st.residuals; acc[8] += (unsigned long long)refc[x]; acc[9] += (unsigned long long)r;
 		if ((unsigned long long)refc[x] > chain) chain = (unsigned long long)refc[x];
@@ -265,13 +276,14 @@ int encode_device(const Params &p, int32_t n, const int64_t *d_rowptr, const int
 	uint8_t *best = nullptr;
 	int32_t *refc = nullptr, *reclen = nullptr, *offlen = nullptr, *state = nullptr, *used = nullptr;
 	int64_t *sums = nullptr, *offat = nullptr;
-	uint32_t *list = nullptr, *bins = nullptr; // bins: [0, 32) histogram, [32, 65) cursors + total
+	uint32_t *list = nullptr, *nlist = nullptr, *bins = nullptr, *nbins = nullptr; // lists of pairs / of nodes; bins: [0, 32) histogram, [32, 64) cursors, [64] listed items, [65] of them for the waves
+	bvw::PairInfo *info = nullptr;
 	int *flags = nullptr, *moved = nullptr; // flags[0]: error bits; moved[i]: did round i of the batch change a chunk's final state
 	EncStatsDev *dstats = nullptr;
 	std::vector<hipEvent_t> ev;
 	auto mark = [&]() { if (trace) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st); ev.push_back(e); } };
 	auto cleanup = [&](int rc) {
-		for (void *q : { (void *)cost, (void *)best, (void *)refc, (void *)reclen, (void *)offlen, (void *)state, (void *)used, (void *)sums, (void *)offat, (void *)list, (void *)bins, (void *)flags, (void *)moved, (void *)dstats })
+		for (void *q : { (void *)cost, (void *)best, (void *)refc, (void *)reclen, (void *)offlen, (void *)state, (void *)used, (void *)sums, (void *)offat, (void *)list, (void *)nlist, (void *)bins, (void *)nbins, (void *)info, (void *)flags, (void *)moved, (void *)dstats })
 			if (q) (void)hipFree(q);
 		for (auto e : ev) (void)hipEventDestroy(e);
 		if (rc) { encode_free(out); (void)hipGetLastError(); }
@@ -282,12 +294,10 @@ int encode_device(const Params &p, int32_t n, const int64_t *d_rowptr, const int
 	if (npairs >= 0xffffffffll) { err = "too many (node, candidate) pairs for one call"; return cleanup(-3); }
 	const bool def = bve::default_codings(p);
 	const int bigBin = getenv("BVGPU_ENC_BIGBIN") ? atoi(getenv("BVGPU_ENC_BIGBIN")) : BIG_BIN; // experiment: 32 = everything lane by lane
-	const int64_t dbgQ = getenv("BVGPU_ENC_DEBUGQ") ? atoll(getenv("BVGPU_ENC_DEBUGQ")) : -1; // experiment: trace the wave walk of one pair
-	const int64_t dbgSkip = getenv("BVGPU_ENC_SKIP") ? atoll(getenv("BVGPU_ENC_SKIP")) : 0; // experiment: leave out the first pairs of the list (the biggest)
 	if (!alloc((void **)&cost, sizeof(uint32_t) * (size_t)npairs) || !alloc((void **)&best, nn) || !alloc((void **)&refc, sizeof(int32_t) * nn) ||
 	    !alloc((void **)&reclen, sizeof(int32_t) * nn) || !alloc((void **)&offlen, sizeof(int32_t) * nn) || !alloc((void **)&state, sizeof(int32_t) * 2 * (size_t)nchunks * (size_t)(p.W ? p.W : 1)) ||
 	    !alloc((void **)&used, sizeof(int32_t) * (size_t)nchunks * (size_t)(p.W ? p.W : 1)) || !alloc((void **)&sums, sizeof(int64_t) * (size_t)(ns + 1)) ||
-	    !alloc((void **)&offat, sizeof(int64_t) * (nn + 1)) || !alloc((void **)&list, sizeof(uint32_t) * (size_t)(npairs > (int64_t)nn ? npairs : (int64_t)nn)) || !alloc((void **)&bins, sizeof(uint32_t) * (2 * ENC_NBIN + 2)) || !alloc((void **)&flags, 2 * sizeof(int)) || !alloc((void **)&moved, SEL_BATCH * sizeof(int)) ||
+	    !alloc((void **)&offat, sizeof(int64_t) * (nn + 1)) || !alloc((void **)&list, sizeof(uint32_t) * (size_t)npairs) || !alloc((void **)&nlist, sizeof(uint32_t) * nn) || !alloc((void **)&bins, sizeof(uint32_t) * (2 * ENC_NBIN + 2)) || !alloc((void **)&nbins, sizeof(uint32_t) * (2 * ENC_NBIN + 2)) || !alloc((void **)&flags, 2 * sizeof(int)) || !alloc((void **)&moved, SEL_BATCH * sizeof(int)) ||
 	    !alloc((void **)&dstats, sizeof(EncStatsDev)) || !alloc((void **)&out.offsets, sizeof(int64_t) * nn)) { err = "device allocation failed"; return cleanup(-5); }
 	(void)hipMemsetAsync(flags, 0, 2 * sizeof(int), st);
 	(void)hipMemsetAsync(dstats, 0, sizeof(EncStatsDev), st);
@@ -299,15 +309,19 @@ int encode_device(const Params &p, int32_t n, const int64_t *d_rowptr, const int
 		(void)hipMemsetAsync(bins, 0, sizeof(uint32_t) * (2 * ENC_NBIN + 2), st);
 		hipLaunchKernelGGL(k_enc_hist<PairItems>, blocks(npairs, SORT_TILE), dim3(256), 0, st, items, bins);
 		hipLaunchKernelGGL(k_enc_bases, dim3(1), dim3(64), 0, st, bins, bins + ENC_NBIN, bigBin);
+		uint32_t nbig = 0; // the pricing of the long pairs leaves their section sizes for the emission: one entry per such pair
+		if (hipMemcpyAsync(&nbig, bins + 2 * ENC_NBIN + 1, sizeof nbig, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { err = "the list kernels failed"; return cleanup(-6); }
+		if (!alloc((void **)&info, sizeof(bvw::PairInfo) * (size_t)nbig)) { err = "device allocation failed"; return cleanup(-5); }
 		hipLaunchKernelGGL(k_enc_scatter<PairItems>, blocks(npairs, SORT_TILE), dim3(256), 0, st, items, bins + ENC_NBIN, list, cost);
 		if (def) {
-			hipLaunchKernelGGL(k_enc_cost_wave<true>, dim3(WAVE_BLOCKS), dim3(256), 0, st, p, d_rowptr, d_succ, list, bins + 2 * ENC_NBIN, cost, flags, dbgSkip, dbgQ);
-			hipLaunchKernelGGL(k_enc_cost<true>, blocks(npairs, 256), dim3(256), 0, st, p, d_rowptr, d_succ, list, bins + 2 * ENC_NBIN, cost, flags, (int64_t)0);
+			hipLaunchKernelGGL(k_enc_cost_wave<true>, dim3(WAVE_BLOCKS), dim3(256), 0, st, p, d_rowptr, d_succ, list, bins + 2 * ENC_NBIN, cost, info, flags);
+			hipLaunchKernelGGL(k_enc_cost<true>, blocks(npairs, 256), dim3(256), 0, st, p, d_rowptr, d_succ, list, bins + 2 * ENC_NBIN, cost, flags);
 		} else {
-			hipLaunchKernelGGL(k_enc_cost_wave<false>, dim3(WAVE_BLOCKS), dim3(256), 0, st, p, d_rowptr, d_succ, list, bins + 2 * ENC_NBIN, cost, flags, dbgSkip, dbgQ);
-			hipLaunchKernelGGL(k_enc_cost<false>, blocks(npairs, 256), dim3(256), 0, st, p, d_rowptr, d_succ, list, bins + 2 * ENC_NBIN, cost, flags, (int64_t)0);
+			hipLaunchKernelGGL(k_enc_cost_wave<false>, dim3(WAVE_BLOCKS), dim3(256), 0, st, p, d_rowptr, d_succ, list, bins + 2 * ENC_NBIN, cost, info, flags);
+			hipLaunchKernelGGL(k_enc_cost<false>, blocks(npairs, 256), dim3(256), 0, st, p, d_rowptr, d_succ, list, bins + 2 * ENC_NBIN, cost, flags);
 		}
 	}
+	bool verifyBad = false; // BVGPU_ENC_VERIFY (tests): the pairs the waves priced, priced again lane by lane
 	if (npairs && getenv("BVGPU_ENC_VERIFY")) {
 		unsigned long long *dbg = nullptr, h[49] = { 0 };
 		if (hipMalloc((void **)&dbg, sizeof h) == hipSuccess) {
@@ -317,7 +331,8 @@ int encode_device(const Params &p, int32_t n, const int64_t *d_rowptr, const int
 			(void)hipMemcpyAsync(h, dbg, sizeof h, hipMemcpyDeviceToHost, st);
 			(void)hipStreamSynchronize(st);
 			(void)hipFree(dbg);
-			fprintf(stderr, "[bvgpu enc] verify: %llu pairs priced differently by the waves\n", h[0]);
+			if (h[0]) fprintf(stderr, "[bvgpu enc] verify: %llu pairs priced differently by the waves\n", h[0]);
+			verifyBad = h[0] != 0;
 			std::vector<int64_t> rp((size_t)n + 1);
 			(void)hipMemcpy(rp.data(), d_rowptr, sizeof(int64_t) * rp.size(), hipMemcpyDeviceToHost);
 			for (unsigned long long k = 0; k < h[0] && k < 16; k++) {
@@ -328,6 +343,7 @@ int encode_device(const Params &p, int32_t n, const int64_t *d_rowptr, const int
 			}
 		}
 	}
+	if (verifyBad) { err = "the wave walk and the lane walk price some pair differently"; return cleanup(-6); }
 	if (trace && npairs) {
 		uint32_t h[ENC_NBIN];
 		if (hipMemcpyAsync(h, bins, sizeof h, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess) {
@@ -372,17 +388,17 @@ int encode_device(const Params &p, int32_t n, const int64_t *d_rowptr, const int
 	if (!alloc((void **)&out.graph_words, gw * 4)) { err = "device allocation failed"; return cleanup(-5); }
 	(void)hipMemsetAsync(out.graph_words, 0, gw * 4, st);
 	if (n) {
-		const NodeItems items{ p, d_rowptr, best, n };
-		(void)hipMemsetAsync(bins, 0, sizeof(uint32_t) * (2 * ENC_NBIN + 2), st);
-		hipLaunchKernelGGL(k_enc_hist<NodeItems>, blocks(n, SORT_TILE), dim3(256), 0, st, items, bins);
-		hipLaunchKernelGGL(k_enc_bases, dim3(1), dim3(64), 0, st, bins, bins + ENC_NBIN, bigBin);
-		hipLaunchKernelGGL(k_enc_scatter<NodeItems>, blocks(n, SORT_TILE), dim3(256), 0, st, items, bins + ENC_NBIN, list, (uint32_t *)nullptr);
+		const NodeItems items{ p, d_rowptr, best, n, bigBin };
+		(void)hipMemsetAsync(nbins, 0, sizeof(uint32_t) * (2 * ENC_NBIN + 2), st);
+		hipLaunchKernelGGL(k_enc_hist<NodeItems>, blocks(n, SORT_TILE), dim3(256), 0, st, items, nbins);
+		hipLaunchKernelGGL(k_enc_bases, dim3(1), dim3(64), 0, st, nbins, nbins + ENC_NBIN, ENC_NBIN);
+		hipLaunchKernelGGL(k_enc_scatter<NodeItems>, blocks(n, SORT_TILE), dim3(256), 0, st, items, nbins + ENC_NBIN, nlist, (uint32_t *)nullptr);
 		if (def) {
-			hipLaunchKernelGGL(k_enc_emit_wave<true>, dim3(WAVE_BLOCKS), dim3(256), 0, st, p, d_rowptr, d_succ, best, refc, out.offsets, list, bins + 2 * ENC_NBIN, out.graph_words, dstats);
-			hipLaunchKernelGGL(k_enc_emit<true>, blocks(n, 256), dim3(256), 0, st, p, d_rowptr, d_succ, best, refc, out.offsets, list, bins + 2 * ENC_NBIN, n, out.graph_words, dstats);
+			if (npairs) hipLaunchKernelGGL(k_enc_emit_wave<true>, dim3(WAVE_BLOCKS), dim3(256), 0, st, p, d_rowptr, d_succ, best, refc, out.offsets, list, bins + 2 * ENC_NBIN, info, out.graph_words, dstats);
+			hipLaunchKernelGGL(k_enc_emit<true>, blocks(n, 256), dim3(256), 0, st, p, d_rowptr, d_succ, best, refc, out.offsets, nlist, nbins + 2 * ENC_NBIN, n, out.graph_words, dstats);
 		} else {
-			hipLaunchKernelGGL(k_enc_emit_wave<false>, dim3(WAVE_BLOCKS), dim3(256), 0, st, p, d_rowptr, d_succ, best, refc, out.offsets, list, bins + 2 * ENC_NBIN, out.graph_words, dstats);
-			hipLaunchKernelGGL(k_enc_emit<false>, blocks(n, 256), dim3(256), 0, st, p, d_rowptr, d_succ, best, refc, out.offsets, list, bins + 2 * ENC_NBIN, n, out.graph_words, dstats);
+			if (npairs) hipLaunchKernelGGL(k_enc_emit_wave<false>, dim3(WAVE_BLOCKS), dim3(256), 0, st, p, d_rowptr, d_succ, best, refc, out.offsets, list, bins + 2 * ENC_NBIN, info, out.graph_words, dstats);
+			hipLaunchKernelGGL(k_enc_emit<false>, blocks(n, 256), dim3(256), 0, st, p, d_rowptr, d_succ, best, refc, out.offsets, nlist, nbins + 2 * ENC_NBIN, n, out.graph_words, dstats);
 		}
 	}
 	mark();

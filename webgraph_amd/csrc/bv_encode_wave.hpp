@@ -30,6 +30,11 @@ __device__ __forceinline__ uint64_t wave_incl_scan(uint64_t v, int lane) {
 	for (int o = 1; o < 64; o <<= 1) { const uint64_t t = __shfl_up(v, o); if (lane >= o) v += t; }
 	return v;
 }
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) { // the default codings: 64 codes are far below 2^32 bits (a unary code may not be)
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(v, o); if (lane >= o) v += t; }
+	return v;
+}
 __device__ __forceinline__ uint64_t wave_total(uint64_t v) {
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -63,20 +68,20 @@ struct WaveWalk {
 	const int lane;
 	uint32_t *words;
 	uint64_t posB, posI, posR;                 // EMIT: cursors of the three sections
+	const uint64_t posB0, posI0, posR0;
 	uint64_t accB = 0, accI = 0, accR = 0, accArcs = 0; // COUNT: per-lane partial sums
 	uint32_t nb = 0, ni = 0, nr = 0;
 	int64_t prevEnd = 0, prevRes = 0;
-	bool dbg = false;
 
 	__device__ __forceinline__ WaveWalk(const Params &p_, int32_t node_, uint32_t *w, uint64_t pb, uint64_t pi, uint64_t pr)
-	    : p(p_), node(node_), lane((int)(threadIdx.x & 63)), words(w), posB(pb), posI(pi), posR(pr) {}
+	    : p(p_), node(node_), lane((int)(threadIdx.x & 63)), words(w), posB(pb), posI(pi), posR(pr), posB0(pb), posI0(pi), posR0(pr) {}
 
 	// the lanes with `on` hold one block each (`val`, already the value to code), in lane order
 	__device__ __forceinline__ void blocks(bool on, uint64_t val) {
 		bve::LenSink s;
 		if (on) bve::f_blk<DEF>(s, p, val);
 		if (!EMIT) { accB += s.bits; return; }
-		const uint64_t inc = wave_incl_scan(s.bits, lane);
+		const uint64_t inc = DEF ? (uint64_t)wave_incl_scan((uint32_t)s.bits, lane) : wave_incl_scan(s.bits, lane);
 		if (on) { bve::WordSink w(words, posB + inc - s.bits); bve::f_blk<DEF>(w, p, val); w.finish(); }
 		posB += __shfl(inc, 63);
 	}
@@ -85,7 +90,7 @@ struct WaveWalk {
 		bve::LenSink s;
 		if (on) { bve::w_gamma(s, v1); bve::w_gamma(s, v2); }
 		if (!EMIT) { accI += s.bits; return; }
-		const uint64_t inc = wave_incl_scan(s.bits, lane);
+		const uint64_t inc = DEF ? (uint64_t)wave_incl_scan((uint32_t)s.bits, lane) : wave_incl_scan(s.bits, lane);
 		if (on) { bve::WordSink w(words, posI + inc - s.bits); bve::w_gamma(w, v1); bve::w_gamma(w, v2); w.finish(); }
 		posI += __shfl(inc, 63);
 	}
@@ -94,7 +99,7 @@ struct WaveWalk {
 		bve::LenSink s;
 		if (on) bve::f_res<DEF>(s, p, val);
 		if (!EMIT) { accR += s.bits; return; }
-		const uint64_t inc = wave_incl_scan(s.bits, lane);
+		const uint64_t inc = DEF ? (uint64_t)wave_incl_scan((uint32_t)s.bits, lane) : wave_incl_scan(s.bits, lane);
 		if (on) { bve::WordSink w(words, posR + inc - s.bits); bve::f_res<DEF>(w, p, val); w.finish(); }
 		posR += __shfl(inc, 63);
 	}
@@ -122,19 +127,20 @@ struct WaveWalk {
 		int64_t nextra = 0;
 		int64_t lastA = INT64_MIN; // last consumed element of cur: the list must increase strictly
 		int bad = 0;
+		int32_t a = lane < d ? cur[lane] : INT32_MAX, b = lane < dr ? ref[lane] : INT32_MAX;
 		while (j0 < d || k0 < dr) {
 			const int na = d - j0 < 64 ? (int)(d - j0) : 64, nv = dr - k0 < 64 ? (int)(dr - k0) : 64;
-			const int32_t a = lane < na ? cur[j0 + lane] : INT32_MAX;
-			const int32_t b = lane < nv ? ref[k0 + lane] : INT32_MAX;
 			const int32_t boundA = j0 + 64 < d ? __shfl(a, 63) : INT32_MAX;
 			const int32_t boundB = k0 + 64 < dr ? __shfl(b, 63) : INT32_MAX;
 			const int32_t limit = boundA < boundB ? boundA : boundB;
 			const uint64_t VA = __ballot(lane < na && a <= limit), VB = __ballot(lane < nv && b <= limit);
 			const int ca = __popcll(VA), cb = __popcll(VB);
-			const bool inRef = lane_search(a, b), inCur = lane_search(b, a);
+			// the next tiles are known now: their loads fly while this stretch is worked on
+			const int32_t an = j0 + ca + lane < d ? cur[j0 + ca + lane] : INT32_MAX, bn = k0 + cb + lane < dr ? ref[k0 + cb + lane] : INT32_MAX;
+			const bool both = na > 0 && nv > 0; // (wave-uniform) nothing to look up in an empty tile
+			const bool inRef = both && lane_search(a, b), inCur = both && lane_search(b, a);
 			const uint64_t E = __ballot(!inRef) & VA, M = __ballot(inCur) & VB;
 			const int32_t ap = __shfl_up(a, 1);
-			if (dbg && lane == 0) printf("[wave] j0 %lld k0 %lld na %d nv %d limit %d ca %d cb %d E %016llx M %016llx nb %u ni %u nr %u open %lld+%lld\n", (long long)j0, (long long)k0, na, nv, limit, ca, cb, (unsigned long long)E, (unsigned long long)M, nb, ni, nr, (long long)openStart, (long long)openLen);
 			if (__ballot(lane < na && (lane == 0 ? (int64_t)a <= lastA : a <= ap))) bad = 1;
 			if (ca) lastA = __shfl(a, ca - 1);
 
@@ -185,7 +191,6 @@ struct WaveWalk {
 						const int len = ej - sj + 1;
 						const bool iv = I != 0 && len >= 2 && len >= I;
 						const uint64_t IS = __ballot(inR && lane == sj && iv), RS = __ballot(inR && !iv);
-						if (dbg && lane == 0) printf("[wave]   link %016llx c %d R %016llx S %016llx IS %016llx RS %016llx\n", (unsigned long long)link, c, (unsigned long long)R, (unsigned long long)S, (unsigned long long)IS, (unsigned long long)RS);
 						if (IS) {
 							const uint64_t below = IS & lt_mask(lane);
 							const int pl = below ? hibit(below) : 0;
@@ -213,22 +218,22 @@ struct WaveWalk {
 				}
 			}
 			j0 += ca; k0 += cb;
+			a = an; b = bn;
 		}
-		tot.bitsB = wave_total(accB); tot.bitsI = wave_total(accI); tot.bitsR = wave_total(accR); tot.ivArcs = wave_total(accArcs);
+		if (EMIT) { tot.bitsB = posB - posB0; tot.bitsI = posI - posI0; tot.bitsR = posR - posR0; }
+		else { tot.bitsB = wave_total(accB); tot.bitsI = wave_total(accI); tot.bitsR = wave_total(accR); }
+		tot.ivArcs = wave_total(accArcs);
 		tot.nb = nb; tot.ni = ni; tot.nr = nr; tot.nextra = (int32_t)nextra; tot.bad = bad;
 	}
 };
 
 // the cost of one pair, as bve::pair_cost computes it, by a wave (the pair is known to be a candidate)
 template <bool DEF>
-__device__ __forceinline__ uint32_t wave_pair_cost(const Params &p, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ, int32_t x, int r, int *err, bool dbg = false) {
+__device__ __forceinline__ uint32_t wave_pair_cost(const Params &p, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ, int32_t x, int r, int *err, WaveTotals &t) {
 	const int64_t a = rowptr[x], b = rowptr[x - r];
 	const int32_t d = (int32_t)(rowptr[x + 1] - a), dr = r == 0 ? 0 : (int32_t)(rowptr[x - r + 1] - b);
 	WaveWalk<DEF, false> w(p, x, nullptr, 0, 0, 0);
-	w.dbg = dbg;
-	WaveTotals t;
 	w.run(succ + a, d, succ + b, dr, t);
-	if (dbg && (threadIdx.x & 63) == 0) printf("[wave] totals nb %u bB %llu ni %u bI %llu nr %u bR %llu nextra %d\n", t.nb, (unsigned long long)t.bitsB, t.ni, (unsigned long long)t.bitsI, t.nr, (unsigned long long)t.bitsR, t.nextra);
 	bve::LenSink s;
 	if (p.W > 0) bve::f_ref<DEF>(s, p, (uint64_t)r);
 	if (r != 0) bve::f_bc<DEF>(s, p, t.nb);
@@ -239,43 +244,45 @@ __device__ __forceinline__ uint32_t wave_pair_cost(const Params &p, const int64_
 	return (uint32_t)total;
 }
 
-// the record of node x written by a wave, as bve::emit_node does; `st` is filled in lane 0 only
+// what the pricing of a pair leaves for its emission: the sizes that precede the items in the stream
+struct PairInfo { uint32_t nb, bitsB, ni, bitsI; }; // ni: bit 31 = the list has extras (an interval count is written)
+
+// the record of node x written by a wave, as bve::emit_node does, given what the pricing of the pair (x, r) found;
+// `st` is filled in lane 0 only
 template <bool DEF>
-__device__ __forceinline__ void wave_emit_node(const Params &p, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ, int32_t x, int r, uint32_t *words, uint64_t pos,
-                                               bve::NodeStats &st) {
+__device__ __forceinline__ void wave_emit_node(const Params &p, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ, int32_t x, int r, const PairInfo info,
+                                               uint32_t *words, uint64_t pos, bve::NodeStats &st) {
 	const int lane = (int)(threadIdx.x & 63);
 	const int64_t a = rowptr[x], b = rowptr[x - r];
 	const int32_t d = (int32_t)(rowptr[x + 1] - a), dr = r == 0 ? 0 : (int32_t)(rowptr[x - r + 1] - b);
-	WaveTotals t;
-	{
-		WaveWalk<DEF, false> w(p, x, nullptr, 0, 0, 0);
-		w.run(succ + a, d, succ + b, dr, t);
-	}
-	// the fixed fields, by lane 0 (every lane computes the positions)
+	const uint32_t ni = info.ni & 0x7fffffffu;
+	const bool extras = (info.ni >> 31) != 0;
 	bve::LenSink h;
 	bve::f_outd<DEF>(h, p, (uint64_t)d);
 	const uint64_t afterOutd = pos + h.bits;
 	if (p.W > 0) bve::f_ref<DEF>(h, p, (uint64_t)r);
 	const uint64_t afterRef = pos + h.bits;
-	if (r != 0) bve::f_bc<DEF>(h, p, t.nb);
+	if (r != 0) bve::f_bc<DEF>(h, p, info.nb);
 	const uint64_t posB = pos + h.bits;
-	const uint64_t startI = posB + (r != 0 ? t.bitsB : 0);
+	const uint64_t startI = posB + (r != 0 ? info.bitsB : 0);
 	bve::LenSink ic;
-	if (t.nextra > 0 && p.I != 0) bve::w_gamma(ic, t.ni);
-	const uint64_t posI = startI + ic.bits, posR = posI + t.bitsI;
+	if (extras && p.I != 0) bve::w_gamma(ic, ni);
+	const uint64_t posI = startI + ic.bits, posR = posI + info.bitsI;
 	if (lane == 0) {
-		bve::WordSink w(words, pos);
-		bve::f_outd<DEF>(w, p, (uint64_t)d);
-		if (p.W > 0) bve::f_ref<DEF>(w, p, (uint64_t)r);
-		if (r != 0) bve::f_bc<DEF>(w, p, t.nb);
-		w.finish();
-		if (t.nextra > 0 && p.I != 0) { bve::WordSink wi(words, startI); bve::w_gamma(wi, t.ni); wi.finish(); }
+		bve::WordSink hw(words, pos);
+		bve::f_outd<DEF>(hw, p, (uint64_t)d);
+		if (p.W > 0) bve::f_ref<DEF>(hw, p, (uint64_t)r);
+		if (r != 0) bve::f_bc<DEF>(hw, p, info.nb);
+		hw.finish();
+		if (extras && p.I != 0) { bve::WordSink wi(words, startI); bve::w_gamma(wi, ni); wi.finish(); }
+	}
+	WaveWalk<DEF, true> w(p, x, words, posB, posI, posR);
+	WaveTotals t;
+	w.run(succ + a, d, succ + b, dr, t);
+	if (lane == 0) {
 		st.bitsOutd = afterOutd - pos; st.bitsRef = afterRef - afterOutd; st.bitsBlocks = startI - afterRef; st.bitsIntervals = posR - startI;
 		st.bitsResiduals = t.bitsR; st.copied = (uint64_t)(d - t.nextra); st.intervalised = t.ivArcs; st.residuals = t.nr;
 	}
-	WaveWalk<DEF, true> w(p, x, words, posB, posI, posR);
-	WaveTotals t2;
-	w.run(succ + a, d, succ + b, dr, t2);
 }
 
 } // namespace bvw
