@@ -285,6 +285,12 @@ int bvg_compressed_copy(const bvg_compressed_t *c, int32_t n, uint8_t *graph_hos
 int bvg_store(const char *basename, int device, int32_t n, const int64_t *rowptr, const int32_t *succ, int in_flags, int window, int max_ref_count,
               int min_interval, int zeta_k, uint32_t flags, int threads, bvg_store_stats_t *stats, char *errbuf, size_t errlen);
 
+/* BVGraph.store(graph, ...) when `graph` is a handle of this library: the whole graph is decoded into HBM (bvg_decode_range,
+ * BVG_OUT_DEVICE) and compressed from there with the new parameters; nothing but the three result files leaves the device.
+ * BVG_EUNSUPPORTED for a shard handle. */
+int bvg_recompress(bvg_t *g, const char *basename, int window, int max_ref_count, int min_interval, int zeta_k, uint32_t flags, int threads,
+                   bvg_store_stats_t *stats, char *errbuf, size_t errlen);
+
 /* ---- arc labels ----------------------------------------------------------------
  * labelling/BitStreamArcLabelledImmutableGraph.java:60-135: <basename>.properties names the underlying graph and the
  * label class (`underlyinggraph`, `labelspec`), <basename>.labels holds the labels of all arcs in enumeration order as

@@ -47,6 +47,12 @@ public class GpuBVGraph extends ImmutableGraph {
 	private static native int[] decodeRange(long handle, int from, int to, long[] rowptr);      // bvg_decode_range_view
 	/** hashCode() continued from h over [from,to) on the device; nothing is materialised. */
 	private static native int scanChecksum(long handle, int from, int to, int h);               // bvg_scan_checksum
+	/** bvg_store: compresses the CSR (rowptr[n+1], succ) on the device and writes basename.graph / .offsets / .properties. */
+	private static native void storeCsr(String basename, int device, int n, long[] rowptr, int[] succ, int windowSize, int maxRefCount, int minIntervalLength,
+		int zetaK, int flags, int numberOfThreads) throws IOException;
+	/** bvg_recompress: decode -> compress without leaving the device. */
+	private static native void recompress(long handle, String basename, int windowSize, int maxRefCount, int minIntervalLength, int zetaK, int flags,
+		int numberOfThreads) throws IOException;
 
 	private GpuBVGraph(final long handle, final CharSequence basename) {
 		this.handle = handle;
@@ -62,6 +68,33 @@ public class GpuBVGraph extends ImmutableGraph {
 	public static GpuBVGraph loadMapped(final CharSequence basename, final ProgressLogger pl) throws IOException { return load(basename); }
 	public static GpuBVGraph loadOffline(final CharSequence basename) throws IOException { return load(basename); }
 	public static GpuBVGraph loadOffline(final CharSequence basename, final ProgressLogger pl) throws IOException { return load(basename); }
+
+	// ---- BVGraph.store (BVGraph.java:1679-1730): same arguments, same files, compressed on the GPU
+	public static void store(final ImmutableGraph graph, final CharSequence basename, final int windowSize, final int maxRefCount, final int minIntervalLength,
+			final int zetaK, final int flags, final int numberOfThreads, final ProgressLogger pl) throws IOException {
+		if (graph instanceof GpuBVGraph) { recompress(((GpuBVGraph)graph).handle, basename.toString(), windowSize, maxRefCount, minIntervalLength, zetaK, flags, numberOfThreads); return; }
+		// any other ImmutableGraph: drain it into a CSR (what storeInternal's node iterator does, BVGraph.java:2471-2550) and hand that over
+		final int n = graph.numNodes();
+		final long[] rowptr = new long[n + 1];
+		int[] succ = new int[(int)Math.min(Integer.MAX_VALUE - 8, Math.max(16, graph.numArcs() >= 0 ? graph.numArcs() : 16))];
+		long m = 0;
+		final NodeIterator it = graph.nodeIterator();
+		for (int x = 0; x < n; x++) {
+			it.nextInt();
+			final int d = it.outdegree();
+			final int[] s = it.successorArray();
+			if (m + d > Integer.MAX_VALUE - 8) throw new UnsupportedOperationException("more than 2^31 arcs: store the graph in parts");
+			if (m + d > succ.length) succ = java.util.Arrays.copyOf(succ, (int)Math.min(Integer.MAX_VALUE - 8, Math.max(m + d, succ.length * 2L)));
+			System.arraycopy(s, 0, succ, (int)m, d);
+			m += d;
+			rowptr[x + 1] = m;
+		}
+		storeCsr(basename.toString(), 0, n, rowptr, succ, windowSize, maxRefCount, minIntervalLength, zetaK, flags, numberOfThreads);
+	}
+	public static void store(final ImmutableGraph graph, final CharSequence basename, final int windowSize, final int maxRefCount, final int minIntervalLength,
+			final int zetaK, final int flags) throws IOException { store(graph, basename, windowSize, maxRefCount, minIntervalLength, zetaK, flags, 1, null); }
+	/** BVGraph.store(graph, basename) with the reference's defaults (BVGraph.java:455-470: window 7, maxRefCount 3, minIntervalLength 4, zeta_3). */
+	public static void store(final ImmutableGraph graph, final CharSequence basename) throws IOException { store(graph, basename, 7, 3, 4, 3, 0); }
 
 	@Override public int numNodes() { return n; }
 	@Override public long numArcs() { return m; }

@@ -86,3 +86,38 @@ JNIEXPORT jint JNICALL Java_it_unimi_dsi_webgraph_gpu_GpuBVGraph_scanChecksum(JN
 	if (rc) throw_status(env, rc, h);
 	return v;
 }
+
+static void throw_msg(JNIEnv *env, int rc, const char *msg) {
+	const char *cls = rc == BVG_EARG ? "java/lang/IllegalArgumentException"
+	                : rc == BVG_EUNSUPPORTED ? "java/lang/UnsupportedOperationException"
+	                : rc == BVG_EIO ? "java/io/IOException"
+	                : rc == BVG_ENOMEM ? "java/lang/OutOfMemoryError" : "java/lang/RuntimeException";
+	(*env)->ThrowNew(env, (*env)->FindClass(env, cls), msg);
+}
+
+/* BVGraph.store for a CSR drained on the Java side (GpuBVGraph.store): bvg_store, host pointers */
+JNIEXPORT void JNICALL Java_it_unimi_dsi_webgraph_gpu_GpuBVGraph_storeCsr(JNIEnv *env, jclass c, jstring basename, jint device, jint n, jlongArray rowptr, jintArray succ,
+                                                                          jint window, jint maxRef, jint minInterval, jint zetaK, jint flags, jint threads) {
+	const char *base = (*env)->GetStringUTFChars(env, basename, NULL);
+	if (!base) return;
+	jlong *rp = (*env)->GetLongArrayElements(env, rowptr, NULL);
+	jint *sc = rp ? (*env)->GetIntArrayElements(env, succ, NULL) : NULL;
+	char err[512] = "";
+	int rc = BVG_ENOMEM;
+	if (rp && sc) rc = bvg_store(base, device, n, (const int64_t *)rp, (const int32_t *)sc, BVG_OUT_HOST, window, maxRef, minInterval, zetaK, (uint32_t)flags, threads, NULL, err, sizeof err);
+	if (sc) (*env)->ReleaseIntArrayElements(env, succ, sc, JNI_ABORT);
+	if (rp) (*env)->ReleaseLongArrayElements(env, rowptr, rp, JNI_ABORT);
+	(*env)->ReleaseStringUTFChars(env, basename, base);
+	if (rc && !(*env)->ExceptionCheck(env)) throw_msg(env, rc, err);
+}
+
+/* BVGraph.store when the graph is a GpuBVGraph: bvg_recompress */
+JNIEXPORT void JNICALL Java_it_unimi_dsi_webgraph_gpu_GpuBVGraph_recompress(JNIEnv *env, jclass c, jlong handle, jstring basename, jint window, jint maxRef, jint minInterval,
+                                                                            jint zetaK, jint flags, jint threads) {
+	const char *base = (*env)->GetStringUTFChars(env, basename, NULL);
+	if (!base) return;
+	char err[512] = "";
+	const int rc = bvg_recompress((bvg_t *)(intptr_t)handle, base, window, maxRef, minInterval, zetaK, (uint32_t)flags, threads, NULL, err, sizeof err);
+	(*env)->ReleaseStringUTFChars(env, basename, base);
+	if (rc) throw_msg(env, rc, err);
+}

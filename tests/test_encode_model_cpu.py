@@ -93,3 +93,17 @@ def test_model_edge_rows(model, tmp_path):
         assert graph == open(base + ".graph", "rb").read() and offs == open(base + ".offsets", "rb").read()
     graph, offs, _, _, _ = run_model(model, np.zeros(1, dtype=np.int64), np.zeros(0, dtype=np.int32), 7, 3, 4, 3)
     assert graph == b"" and offs == b"\x80"  # gamma(0)
+
+
+def test_model_chains_that_never_forget(model, tmp_path):
+    """Identical rows: every chunk-boundary guess is wrong; the rounds must still end at the sequential result."""
+    from webgraph_amd import tools as T
+    n = 5000
+    rowptr = np.arange(n + 1, dtype=np.int64) * 10
+    succ = np.tile(np.arange(5, 105, 10, dtype=np.int32), n)
+    base = str(tmp_path / "same")
+    T.store(base, rowptr, succ, window=7, max_ref_count=3, min_interval=4, threads=1)
+    for chunk, span in [(64, 16), (4, 2), (7, 1)]:
+        graph, offs, _, _, rounds = run_model(model, rowptr, succ, 7, 3, 4, 3, chunk=chunk, span=span)
+        assert graph == open(base + ".graph", "rb").read() and offs == open(base + ".offsets", "rb").read()
+        assert rounds > 2

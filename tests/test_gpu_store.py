@@ -147,3 +147,44 @@ def test_store_shapes_that_stress_the_wave_walk(tmp_path, monkeypatch, W, R, I):
     for ext in (".graph", ".offsets", ".properties"):
         assert filecmp.cmp(cpu + ext, gpu + ext, shallow=False), ext
     assert all(st_cpu[k] == st_gpu[k] for k in st_cpu)
+
+
+def test_store_chains_that_never_forget(tmp_path):
+    """Identical rows: the chain lengths repeat with a period that does not divide the chunk size, so every guess at a chunk
+    boundary is wrong and the selection has to carry the truth across the whole graph (spans doubling batch after batch)."""
+    from webgraph_amd import bvgraph as B
+    from webgraph_amd import tools as T
+    n = 300000
+    rowptr = np.arange(n + 1, dtype=np.int64) * 10
+    succ = np.tile(np.arange(5, 105, 10, dtype=np.int32), n)
+    cpu, gpu = str(tmp_path / "cpu"), str(tmp_path / "gpu")
+    T.store(cpu, rowptr, succ, window=7, max_ref_count=3, min_interval=4, threads=1)
+    st = B.store(rowptr, succ, gpu, windowSize=7, maxRefCount=3, minIntervalLength=4)
+    assert filecmp.cmp(cpu + ".graph", gpu + ".graph", shallow=False) and filecmp.cmp(cpu + ".offsets", gpu + ".offsets", shallow=False)
+    assert st["selection_rounds"] > 8  # more than one batch was needed
+
+
+def test_recompress_from_a_handle(tmp_path, cnr_oracle):
+    """BVGraph.store(graph, ...) with the graph itself on the GPU: same parameters -> the reference's bytes back; other
+    parameters -> what the CPU writer makes of the same lists; a shard handle is refused."""
+    from webgraph_amd import bvgraph as B
+    from webgraph_amd import tools as T
+    _, rowptr, succ = cnr_oracle
+    g = B.BVGraph.load(CNR)
+    same = str(tmp_path / "same")
+    g.store(same, windowSize=7, maxRefCount=3, minIntervalLength=3, zetaK=3)
+    assert filecmp.cmp(same + ".graph", CNR + ".graph", shallow=False) and filecmp.cmp(same + ".offsets", CNR + ".offsets", shallow=False)
+    other, cpu = str(tmp_path / "other"), str(tmp_path / "cpu")
+    g.store(other, windowSize=3, maxRefCount=10, minIntervalLength=2, zetaK=4)
+    T.store(cpu, rowptr, succ, window=3, max_ref_count=10, min_interval=2, zeta_k=4, threads=1)
+    for ext in (".graph", ".offsets", ".properties"):
+        assert filecmp.cmp(cpu + ext, other + ext, shallow=False), ext
+    g.close()
+    h = B.BVGraph.load(other)
+    rp, sc = h.decode_range()
+    assert np.array_equal(rp, rowptr) and np.array_equal(sc, succ)
+    h.close()
+    s = B.BVGraph.load_shard(CNR, 1, 4)
+    with pytest.raises(NotImplementedError):
+        s.store(str(tmp_path / "shard"))
+    s.close()

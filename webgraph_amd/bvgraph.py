@@ -55,7 +55,7 @@ class BvgLabelsInfo(C.Structure):
 EXPORTS = ["bvg_open", "bvg_open_shard", "bvg_clone", "bvg_close", "bvg_info", "bvg_last_error", "bvg_set_stream", "bvg_sync",
            "bvg_outdegrees", "bvg_decode_range", "bvg_decode_range_view", "bvg_host_alloc", "bvg_host_free", "bvg_scan_checksum", "bvg_scan_stats", "bvg_bfs_expand", "bvg_hyperball_step", "bvg_successors_batch", "bvg_csr_hashcode", "bvg_shard_bounds",
            "bvg_parse_properties", "bvg_flags_from_string", "bvg_decode_offsets_host", "bvg_decode_offsets_device", "bvg_labels_open", "bvg_labels_close", "bvg_labels_info",
-           "bvg_labels_last_error", "bvg_labels_parse_properties", "bvg_labels_decode_range", "bvg_labels_decode_lists", "bvg_compress", "bvg_compressed_free", "bvg_compressed_copy", "bvg_store", "bvg_set_profile", "bvg_get_profile", "bvg_debug_stats", "bvg_last_thresholds"]
+           "bvg_labels_last_error", "bvg_labels_parse_properties", "bvg_labels_decode_range", "bvg_labels_decode_lists", "bvg_compress", "bvg_compressed_free", "bvg_compressed_copy", "bvg_store", "bvg_recompress", "bvg_set_profile", "bvg_get_profile", "bvg_debug_stats", "bvg_last_thresholds"]
 
 _lib = None
 
@@ -115,6 +115,7 @@ def lib():
         L.bvg_compressed_free.restype = None
         L.bvg_compressed_copy.argtypes = [C.POINTER(BvgCompressed), i32, vp, vp, vp]
         L.bvg_store.argtypes = [C.c_char_p, C.c_int, i32, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.POINTER(BvgStoreStats), C.c_char_p, sz]
+        L.bvg_recompress.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.POINTER(BvgStoreStats), C.c_char_p, sz]
         L.bvg_set_profile.argtypes = [vp, C.c_int]
         L.bvg_get_profile.argtypes = [vp, C.POINTER(C.c_float)]
         L.bvg_last_thresholds.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
@@ -447,6 +448,15 @@ class BVGraph:
         hh, arcs = C.c_int32(h), C.c_uint64(0)
         self._check(lib().bvg_scan_checksum(self._h, lo, hi, C.byref(hh), C.byref(arcs)))
         return hh.value, arcs.value
+
+    def store(self, basename, windowSize=7, maxRefCount=3, minIntervalLength=4, zetaK=3, flags=0, numberOfThreads=1):
+        """BVGraph.store(this, basename, ...) (BVGraph.java:1679-1730): decode and recompress without leaving the device."""
+        st = BvgStoreStats()
+        err = C.create_string_buffer(512)
+        rc = lib().bvg_recompress(self._h, os.fsencode(basename), windowSize, maxRefCount, minIntervalLength, zetaK, flags, numberOfThreads, C.byref(st), err, 512)
+        if rc:
+            _raise(rc, err.value.decode("utf-8", "replace"))
+        return st.as_dict()
 
     def decode_range_device(self, lo, hi, rowptr_ptr, succ_ptr, succ_cap, asynchronous=False):
         """Device-pointer form: rowptr_ptr / succ_ptr are raw device addresses (e.g. torch.Tensor.data_ptr())."""

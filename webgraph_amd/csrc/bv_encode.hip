@@ -11,7 +11,8 @@
 //                    different.  On a copy-model graph the choice forgets its past within a few nodes (a node that
 //                    takes no reference, or whose cheapest candidate is admissible either way); on a web graph runs of
 //                    similar pages carry the phase of their chains for thousands of nodes (cnr-2000: 7 000), so after
-//                    round 0 a lane walks SEL_SPAN chunks in order, skipping those whose in-state did not move.  Exact:
+//                    round 0 a lane walks SEL_SPAN chunks in order (twice as many after every batch of rounds that
+//                    did not settle), skipping those whose in-state did not move.  Exact:
 //                    the loop runs until a round moves nothing (bve::select_span).
 //   C  k_enc_reclen + scan: record lengths -> bit offsets (what the reference's .offsets file holds).
 //   D  k_enc_emit    one lane per node writes its record at its offset; words shared by two records are ORed.
@@ -356,11 +357,12 @@ int encode_device(const Params &p, int32_t n, const int64_t *d_rowptr, const int
 	// B: round 0 one chunk per lane, then SEL_SPAN chunks per lane; SEL_BATCH rounds are enqueued between two looks at the flags
 	int rounds = 0;
 	const size_t stateHalf = (size_t)nchunks * (size_t)(p.W ? p.W : 1);
+	int spanNow = SEL_SPAN; // doubled after every batch that did not settle: a stretch of any length is crossed in O(log) batches
 	for (bool settled = nchunks == 0; !settled;) {
 		(void)hipMemsetAsync(moved, 0, SEL_BATCH * sizeof(int), st);
 		const int first = rounds;
 		for (int i = 0; i < SEL_BATCH; i++, rounds++) {
-			const int span = rounds == 0 ? 1 : SEL_SPAN;
+			const int span = rounds == 0 ? 1 : spanNow;
 			const int64_t lanes = (nchunks + span - 1) / span;
 			int32_t *sPrev = state + (size_t)((rounds + 1) & 1) * stateHalf, *sNew = state + (size_t)(rounds & 1) * stateHalf;
 			hipLaunchKernelGGL(k_enc_select, blocks(lanes, 64), dim3(64), 0, st, p, d_rowptr, cost, n, nchunks, span, rounds, sPrev, sNew, used, best, refc, moved + i);
@@ -371,6 +373,7 @@ int encode_device(const Params &p, int32_t n, const int64_t *d_rowptr, const int
 		if (p.W == 0 || p.R == 0) break;
 		for (int i = 0; i < rounds - first; i++) if (first + i > 0 && !h[i]) { settled = true; rounds = first + i + 1; break; }
 		if (!settled && (int64_t)rounds > nchunks + 2 * SEL_BATCH) { err = "the selection did not settle"; return cleanup(-6); }
+		if (!settled && (int64_t)spanNow < nchunks) spanNow *= 2;
 	}
 	mark();
 	// C

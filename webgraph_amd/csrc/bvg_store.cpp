@@ -167,3 +167,28 @@ extern "C" int bvg_store(const char *basename, int device, int32_t n, const int6
 	if (stats) *stats = st;
 	return BVG_OK;
 }
+
+// decode -> compress without leaving HBM: BVGraph.store(graph, ...) for a graph that is itself a handle of this library
+extern "C" int bvg_recompress(bvg_t *g, const char *basename, int window, int max_ref_count, int min_interval, int zeta_k, uint32_t flags, int threads,
+                              bvg_store_stats_t *stats, char *errbuf, size_t errlen) {
+	if (!g || !basename) return sfail(errbuf, errlen, BVG_EARG, "null argument");
+	bvg_info_t info;
+	int rc = bvg_info(g, &info);
+	if (rc) return sfail(errbuf, errlen, rc, bvg_last_error(g));
+	if (info.shard_from != 0 || info.shard_to != info.nodes) return sfail(errbuf, errlen, BVG_EUNSUPPORTED, "a shard handle holds a slice of the graph: recompress from a whole-graph handle");
+	if (hipSetDevice(info.device) != hipSuccess) return sfail(errbuf, errlen, BVG_EHIP, "hipSetDevice failed");
+	int64_t *d_rowptr = nullptr;
+	int32_t *d_succ = nullptr;
+	const size_t m = (size_t)info.arcs;
+	if (hipMalloc((void **)&d_rowptr, sizeof(int64_t) * ((size_t)info.nodes + 1)) != hipSuccess || hipMalloc((void **)&d_succ, sizeof(int32_t) * (m ? m : 1)) != hipSuccess) {
+		if (d_rowptr) (void)hipFree(d_rowptr);
+		(void)hipGetLastError();
+		return sfail(errbuf, errlen, BVG_ENOMEM, "device allocation failed");
+	}
+	uint64_t arcs = 0;
+	rc = bvg_decode_range(g, 0, info.nodes, d_rowptr, d_succ, m, &arcs, BVG_OUT_DEVICE);
+	if (rc) sfail(errbuf, errlen, rc, bvg_last_error(g));
+	else rc = bvg_store(basename, info.device, info.nodes, d_rowptr, d_succ, BVG_OUT_DEVICE, window, max_ref_count, min_interval, zeta_k, flags, threads, stats, errbuf, errlen);
+	(void)hipFree(d_rowptr); (void)hipFree(d_succ);
+	return rc;
+}
