@@ -57,7 +57,13 @@ typedef struct bvg_info {
 	int32_t  offsets_on_device; /* 1: the .offsets stream was decoded by the GPU kernels, 0: by the host decoder */
 	int32_t  shard_from, shard_to; /* nodes this handle decodes: [0, nodes) for bvg_open, one slice for bvg_open_shard */
 	int32_t  staged_from;          /* first node whose record is staged (shard_from minus the room kept for referents before it) */
+	int32_t  format;               /* BVG_FORMAT_BV: graphclass BVGraph; BVG_FORMAT_EF: graphclass EFGraph (the fields from window_size to offset_coding
+	                                  do not apply, except offset_coding = delta) */
+	int32_t  ef_upper_bound;       /* EFGraph: the `upperbound` property (default: nodes), EFGraph.java:742 */
+	int32_t  ef_log2_quantum;      /* EFGraph: log2 of the `quantum` property, :743-745 */
+	int32_t  ef_big_endian;        /* EFGraph: `byteorder` = BIG_ENDIAN (the words are swapped once, at load time), :747-750 */
 } bvg_info_t;
+enum { BVG_FORMAT_BV = 0, BVG_FORMAT_EF = 1 };
 
 /* flags for the *_range / *_batch calls */
 enum {
@@ -70,6 +76,14 @@ enum {
 };
 
 /* ---- lifecycle ------------------------------------------------------------------------------------- */
+
+/* A second on-disk format behind the same handle: when <basename>.properties says
+ * graphclass = it.unimi.dsi.webgraph.EFGraph, bvg_open loads the quasi-succinct (Elias-Fano) files EFGraph.store writes
+ * (src/it/unimi/dsi/webgraph/EFGraph.java:709-789: 64-bit words in `byteorder`, delta-coded .offsets) and every call of this
+ * header that decodes -- bvg_outdegrees, bvg_decode_range[_view], bvg_successors_batch, bvg_scan_checksum, bvg_scan_stats,
+ * bvg_bfs_expand, bvg_hyperball_step, bvg_recompress -- works on them: no record of an EFGraph refers to another one, so a
+ * range is outdegrees -> scan -> one pass that writes every list (bv_ef.hip).  BVG_ASYNC is accepted and ignored (the call
+ * synchronises). */
 
 /* ImmutableGraph.load(basename) -> BVGraph.load -> loadInternal (BVG:1380, :1516-1609): parse .properties,
  * read .graph and .offsets, stage the bit stream and the decoded int64 offset table in HBM on `device`. */

@@ -76,6 +76,14 @@ int bvt_store_labels(const char *basename, const char *underlying, int32_t n, co
 int bvt_store_label_lists(const char *basename, const char *underlying, int32_t n, const int64_t *rowptr, const int64_t *listptr,
                           const int32_t *values, int width, const char *key);
 
+/*
+ * EFGraph.store (src/it/unimi/dsi/webgraph/EFGraph.java:812-889): the same CSR as <basename>.graph (64-bit words, bits from
+ * the low end, `big_endian` chooses the byte order of the words: the `byteorder` property), <basename>.offsets (delta-coded
+ * record lengths) and <basename>.properties with graphclass = it.unimi.dsi.webgraph.EFGraph.  upper_bound >= n (the
+ * reference's default is n), log2_quantum: the reference's default is 8.
+ */
+int bvt_store_ef(const char *basename, int32_t n, const int64_t *rowptr, const int32_t *succ, int32_t upper_bound, int log2_quantum, int big_endian);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,7 +28,7 @@ class Params(C.Structure):
 
 
 def build(force=False):
-    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_HERE, "bvg_oracle.c")):
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("bvg_oracle.c", "efg_oracle.c")):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _LIB
 
@@ -385,3 +385,44 @@ def label_lists_decode(basename, n, outd, lo=0, hi=None):
     if rc:
         raise OracleError(rc)
     return listptr, values[:nv.value]
+
+
+class OracleEFGraph:
+    """EFGraph (the reference's quasi-succinct second format) read by the CPU oracle (oracle/efg_oracle.c; parity unpinned)."""
+
+    def __init__(self, words, offsets, n, arcs, upper_bound, log2_quantum):
+        self.words, self.offsets, self.n, self.arcs, self.upper_bound, self.log2_quantum = words, offsets, n, arcs, upper_bound, log2_quantum
+
+    @classmethod
+    def load(cls, basename):
+        props = parse_properties(basename + ".properties")
+        if props.get("graphclass", "").replace("it.unimi.dsi.big.webgraph", "it.unimi.dsi.webgraph") != "it.unimi.dsi.webgraph.EFGraph":
+            raise ValueError("not an EFGraph: " + props.get("graphclass", ""))
+        n, m = int(props["nodes"]), int(props["arcs"])
+        ub = int(props.get("upperbound", n))
+        q = int(props["quantum"])
+        lq = q.bit_length() - 1
+        assert 1 << lq == q
+        raw = open(basename + ".graph", "rb").read()
+        raw += b"\0" * (-len(raw) % 8)
+        words = np.frombuffer(raw, dtype=">u8" if props["byteorder"] == "BIG_ENDIAN" else "<u8").astype(np.uint64)
+        offsets = decode_offsets(open(basename + ".offsets", "rb").read(), n, coding=DELTA)
+        return cls(np.ascontiguousarray(words), offsets, n, m, ub, lq)
+
+    def scan(self, lo=0, hi=None, want_succ=True):
+        hi = self.n if hi is None else hi
+        f = lib().efo_scan
+        f.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int32, C.c_int32, C.c_int, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
+        rowptr = np.empty(hi - lo + 1, dtype=np.int64)
+        arcs = C.c_uint64(0)
+        rc = f(self.words.ctypes.data, self.words.size, self.offsets.ctypes.data, self.n, self.upper_bound, self.log2_quantum, lo, hi, rowptr.ctypes.data, None, 0, C.byref(arcs))
+        if rc:
+            raise OracleError(rc)
+        if not want_succ:
+            return rowptr, None, arcs.value
+        succ = np.empty(max(arcs.value, 1), dtype=np.int32)
+        rc = f(self.words.ctypes.data, self.words.size, self.offsets.ctypes.data, self.n, self.upper_bound, self.log2_quantum, lo, hi, rowptr.ctypes.data, succ.ctypes.data, succ.size,
+               C.byref(arcs))
+        if rc:
+            raise OracleError(rc)
+        return rowptr, succ[:arcs.value], arcs.value

@@ -1,0 +1,133 @@
+"""EFGraph decoded on the GPU (bv_ef.hip behind the same C ABI) against the CPU oracle's reader and
+against what was stored: scans, sub-ranges, random access, the consumers, both byte orders, an upper bound above n, shards."""
+import numpy as np
+import pytest
+
+from test_efgraph_cpu import KAT_ROWS, _csr
+
+pytestmark = pytest.mark.gpu
+
+
+def _store(tmp_path, n, m, seed, **kw):
+    from webgraph_amd import tools as T
+    rowptr, succ = T.generate(n, m, seed=seed, p_copy=0.5)
+    base = str(tmp_path / "ef")
+    T.store_ef(base, rowptr, succ, **kw)
+    return base, rowptr, succ
+
+
+def test_hand_made_record(tmp_path):
+    from webgraph_amd import bvgraph as B
+    from webgraph_amd import tools as T
+    rowptr, succ = _csr(KAT_ROWS)
+    T.store_ef(str(tmp_path / "kat"), rowptr, succ)
+    g = B.EFGraph.load(str(tmp_path / "kat"))
+    assert (g.numNodes(), g.numArcs(), g.info.format, g.upperBound()) == (4, 7, B.BVG_FORMAT_EF, 4)
+    rp, sc = g.decode_range()
+    assert np.array_equal(rp, rowptr) and np.array_equal(sc, succ)
+    assert [g.successorArray(x).tolist() for x in range(4)] == KAT_ROWS and [g.outdegree(x) for x in range(4)] == [2, 0, 4, 1]
+    g.close()
+
+
+@pytest.mark.parametrize("n,m,lq,big,ub", [(200000, 4000000, 8, False, None), (50000, 1000000, 2, True, None), (3000, 100000, 0, False, 5000)])
+def test_scan_and_random_access_match_the_oracle(tmp_path, n, m, lq, big, ub):
+    from webgraph_amd import bvgraph as B
+    from oracle import oracle as O
+    base, rowptr, succ = _store(tmp_path, n, m, 7 + lq, upper_bound=ub, log2_quantum=lq, big_endian=big)
+    og = O.OracleEFGraph.load(base)
+    g = B.BVGraph.load(base)  # the graphclass property decides
+    assert g.info.format == B.BVG_FORMAT_EF and g.numArcs() == m
+    rp, sc = g.decode_range()
+    orp, osc, _ = og.scan()
+    assert np.array_equal(rp, orp) and np.array_equal(sc, osc) and np.array_equal(sc, succ)
+    for lo, hi in [(0, 1), (n // 3, n // 3 + 999), (n - 7, n), (5, 5)]:
+        rp, sc = g.decode_range(lo, hi)
+        orp, osc, _ = og.scan(lo, hi)
+        assert np.array_equal(rp, orp) and np.array_equal(sc, osc)
+    assert np.array_equal(g.outdegrees(0, n), np.diff(rowptr))
+    q = np.random.Generator(np.random.PCG64(3)).integers(0, n, size=20000).astype(np.int32)
+    brp, bsc = g.successors_batch(q)
+    want = np.concatenate([succ[rowptr[x]:rowptr[x + 1]] for x in q]) if q.size else np.empty(0, np.int32)
+    assert np.array_equal(np.diff(brp), np.diff(rowptr)[q]) and np.array_equal(bsc, want)
+    with pytest.raises(ValueError):
+        g.successors_batch(np.array([0, n], dtype=np.int32))
+    # the consumers run on the decoded rows whatever the format: same hashCode() as the BVGraph of the same lists (itself checked
+    # against the oracle's in test_gpu_scan), and equals() between the two
+    from webgraph_amd import tools as T
+    T.store(str(tmp_path / "bv"), rowptr, succ)
+    h = B.BVGraph.load(str(tmp_path / "bv"))
+    assert g.hashCode() == h.hashCode() and g.equals(h) and h.equals(g)
+    h.close()
+    g.close()
+
+
+def test_long_lists_go_to_the_waves(tmp_path):
+    """Lists of 256 successors or more are decoded by a wave each: dense (l = 0) and sparse ones, one of 200 000."""
+    from webgraph_amd import bvgraph as B
+    from webgraph_amd import tools as T
+    rng = np.random.Generator(np.random.PCG64(9))
+    n = 300000
+    rows = [[] for _ in range(40)]
+    rows[3] = sorted(set(rng.integers(0, n, size=200000).tolist()))
+    rows[4] = list(range(1000, 260000))                    # denser than one value per slot: l = 0
+    rows[7] = sorted(set(rng.integers(0, n, size=256).tolist()))
+    rows[8] = sorted(set(rng.integers(0, n, size=255).tolist()))
+    rows[20] = list(range(0, n, 2))
+    rows[39] = [n - 1]
+    rows += [[] for _ in range(n - len(rows))]
+    rowptr, succ = _csr(rows)
+    T.store_ef(str(tmp_path / "long"), rowptr, succ, log2_quantum=4)
+    g = B.EFGraph.load(str(tmp_path / "long"))
+    rp, sc = g.decode_range()
+    assert np.array_equal(rp, rowptr) and np.array_equal(sc, succ)
+    brp, bsc = g.successors_batch(np.array([20, 3, 39, 4, 0], dtype=np.int32))
+    assert np.array_equal(bsc, np.array(rows[20] + rows[3] + rows[39] + rows[4], dtype=np.int32))
+    g.close()
+
+
+def test_recompress_an_efgraph_as_bvgraph(tmp_path):
+    """EFGraph -> BVGraph without leaving the device (bvg_recompress), equal to the CPU writer's files for the same lists."""
+    import filecmp
+    from webgraph_amd import bvgraph as B
+    from webgraph_amd import tools as T
+    base, rowptr, succ = _store(tmp_path, 60000, 1200000, 11)
+    g = B.EFGraph.load(base)
+    g.store(str(tmp_path / "bv"))
+    g.close()
+    T.store(str(tmp_path / "cpu"), rowptr, succ, threads=1)
+    assert filecmp.cmp(str(tmp_path / "bv.graph"), str(tmp_path / "cpu.graph"), shallow=False)
+    h = B.BVGraph.load(str(tmp_path / "bv"))
+    assert h.info.format == B.BVG_FORMAT_BV
+    rp, sc = h.decode_range()
+    assert np.array_equal(rp, rowptr) and np.array_equal(sc, succ)
+    h.close()
+
+
+def test_shards_and_errors(tmp_path):
+    from webgraph_amd import bvgraph as B
+    base, rowptr, succ = _store(tmp_path, 100000, 2000000, 13)
+    parts, chunks = 4, []
+    for k in range(parts):
+        s = B.BVGraph.load_shard(base, k, parts)
+        lo, hi = s.info.shard_from, s.info.shard_to
+        rp, sc = s.decode_range(lo, hi)
+        assert np.array_equal(rp, rowptr[lo:hi + 1] - rowptr[lo])
+        chunks.append(sc)
+        s.close()
+    assert np.array_equal(np.concatenate(chunks), succ)
+    with pytest.raises(IOError):
+        B.EFGraph.load(str(tmp_path / "missing"))
+    # a BVGraph is not an EFGraph
+    from conftest import CNR
+    with pytest.raises(IOError):
+        B.EFGraph.load(CNR)
+    # truncated stream: an error, not a crash
+    raw = open(base + ".graph", "rb").read()
+    open(base + ".graph", "wb").write(raw[:len(raw) // 2])
+    try:
+        g = B.BVGraph.load(base)
+    except (IOError, B.BvgError):
+        return
+    with pytest.raises((B.BvgError, ValueError, IOError)):
+        g.decode_range()
+    g.close()

@@ -105,7 +105,17 @@ def test_parse_properties_like_the_reference(tmp_path):
     with pytest.raises(NotImplementedError):  # missing version (BVG:1533)
         B.parse_properties(write("d", ok.replace("version=0\n", "")))
     with pytest.raises(NotImplementedError):  # another graph class (BVG:1528)
-        B.parse_properties(write("e", ok.replace("BVGraph", "EFGraph")))
+        B.parse_properties(write("e", ok.replace("BVGraph", "ASCIIGraph")))
+    # EFGraph is the second format this library reads (EFGraph.loadInternal, EFGraph.java:709-750)
+    ef = "graphclass=it.unimi.dsi.webgraph.EFGraph\nversion=0\nnodes=5\narcs=7\nquantum=256\nbyteorder=LITTLE_ENDIAN\n"
+    i4 = B.parse_properties(write("f", ef))
+    assert (i4.format, i4.nodes, i4.arcs, i4.ef_upper_bound, i4.ef_log2_quantum, i4.ef_big_endian, i4.offset_coding) == (B.BVG_FORMAT_EF, 5, 7, 5, 8, 0, 1)
+    i5 = B.parse_properties(write("g", ef.replace("LITTLE", "BIG") + "upperbound=9\n"))
+    assert (i5.ef_upper_bound, i5.ef_big_endian) == (9, 1)
+    with pytest.raises(ValueError):  # "Illegal quantum (must be a power of 2)", :745
+        B.parse_properties(write("h", ef.replace("quantum=256", "quantum=255")))
+    with pytest.raises(ValueError):  # "Unknown byte order", :750
+        B.parse_properties(write("i", ef.replace("LITTLE_ENDIAN", "PDP")))
     with pytest.raises(ValueError):  # nodes >= 2^31 (BVG:1537)
         B.parse_properties(write("f", ok.replace("nodes=5", "nodes=2147483648")))
     with pytest.raises(NotImplementedError):  # unknown flag name (BVG:1361)

@@ -16,6 +16,7 @@ _LIBPATH = os.environ.get("BVGPU_LIB") or os.path.join(_HERE, "libbvgpu.so")  # 
 
 BVG_OK, BVG_EARG, BVG_ESTATE, BVG_EUNSUPPORTED, BVG_EIO, BVG_ENOMEM, BVG_EHIP, BVG_EFORMAT, BVG_ECAP = 0, -1, -2, -3, -4, -5, -6, -7, -8
 BVG_OUT_HOST, BVG_OUT_DEVICE, BVG_ASYNC = 0, 1, 2
+BVG_FORMAT_BV, BVG_FORMAT_EF = 0, 1
 
 
 class BvgInfo(C.Structure):
@@ -24,7 +25,8 @@ class BvgInfo(C.Structure):
                 ("outdegree_coding", C.c_int32), ("block_coding", C.c_int32), ("residual_coding", C.c_int32),
                 ("reference_coding", C.c_int32), ("block_count_coding", C.c_int32), ("offset_coding", C.c_int32),
                 ("graph_bytes", C.c_uint64), ("device", C.c_int32), ("offsets_on_device", C.c_int32),
-                ("shard_from", C.c_int32), ("shard_to", C.c_int32), ("staged_from", C.c_int32)]
+                ("shard_from", C.c_int32), ("shard_to", C.c_int32), ("staged_from", C.c_int32),
+                ("format", C.c_int32), ("ef_upper_bound", C.c_int32), ("ef_log2_quantum", C.c_int32), ("ef_big_endian", C.c_int32)]
 
 
 class BvgScanStats(C.Structure):
@@ -606,6 +608,25 @@ class BVGraph:
             if not (np.array_equal(rp1, rp2) and np.array_equal(sc1, sc2)):
                 return False
         return True
+
+
+class EFGraph(BVGraph):
+    """EFGraph (src/it/unimi/dsi/webgraph/EFGraph.java), the quasi-succinct second format, behind the same handle: every
+    method of BVGraph applies.  load() insists that the files are an EFGraph, as EFGraph.loadInternal does (:716-718)."""
+
+    @classmethod
+    def load(cls, basename, device=0):
+        g = super().load(basename, device)
+        if g.info.format != BVG_FORMAT_EF:
+            g.close()
+            raise IOError("This class (EFGraph) cannot load a graph stored using another class")
+        return g
+
+    loadMapped = load
+    loadOffline = load
+
+    def upperBound(self):
+        return self.info.ef_upper_bound
 
 
 class ArcLabelledBVGraph:

@@ -130,6 +130,28 @@ int parse_properties(const std::string &basename, bvg_info_t &info, std::string 
 		const std::string big = "it.unimi.dsi.big.webgraph";
 		size_t at = c.find(big);
 		if (at != std::string::npos) c.replace(at, big.size(), "it.unimi.dsi.webgraph");
+		if (c == "it.unimi.dsi.webgraph.EFGraph") { // EFGraph.loadInternal, EFGraph.java:709-750
+			long long t;
+			std::string w;
+			info.format = BVG_FORMAT_EF;
+			if (!get("version", w)) { err = "Missing format version information"; return BVG_EUNSUPPORTED; }
+			if (!parse_ll(w, t) || t > 0) { err = "This graph uses format " + w + ", but this library understands only graphs up to format 0"; return BVG_EUNSUPPORTED; }
+			if (!get("nodes", w) || !parse_ll(w, t) || t < 0) { err = "bad or missing nodes"; return BVG_EUNSUPPORTED; }
+			if (t > 0x7fffffffLL) { err = "cannot handle graphs with " + w + " (>=2^31) nodes"; return BVG_EARG; }
+			info.nodes = (int32_t)t;
+			if (!get("arcs", w) || !parse_ll(w, t) || t < 0) { err = "bad or missing arcs"; return BVG_EUNSUPPORTED; }
+			info.arcs = t;
+			info.ef_upper_bound = info.nodes;
+			if (get("upperbound", w)) { if (!parse_ll(w, t) || t < info.nodes || t > 0x7fffffffLL) { err = "bad upperbound"; return BVG_EUNSUPPORTED; } info.ef_upper_bound = (int32_t)t; }
+			if (!get("quantum", w)) { err = "missing quantum"; return BVG_EUNSUPPORTED; }
+			if (!parse_ll(w, t) || t < 1 || (t & (t - 1))) { err = "Illegal quantum (must be a power of 2): " + w; return BVG_EARG; }
+			info.ef_log2_quantum = 63 - __builtin_clzll((unsigned long long)t);
+			if (!get("byteorder", w)) { err = "missing byteorder"; return BVG_EUNSUPPORTED; }
+			if (w != "BIG_ENDIAN" && w != "LITTLE_ENDIAN") { err = "Unknown byte order " + w; return BVG_EARG; }
+			info.ef_big_endian = w == "BIG_ENDIAN";
+			info.offset_coding = BVG_DELTA; // offsets.writeLongDelta, :830, :855
+			return BVG_OK;
+		}
 		if (c != "it.unimi.dsi.webgraph.BVGraph") { err = "this class cannot load a graph stored using class \"" + v + "\""; return BVG_EUNSUPPORTED; }
 	}
 	std::string fs;

@@ -106,6 +106,14 @@ int fixed_labels_decode_device(const uint32_t *d_words, uint64_t nwords, uint64_
 int label_lists_decode_device(const uint32_t *d_words, uint64_t nwords, const int64_t *d_off, int32_t from, int32_t cnt, int32_t width, uint64_t arcs,
                               int64_t *d_listptr, int32_t *d_values, uint64_t valuesCap, uint64_t *nvalues, hipStream_t st);
 
+// EFGraph (bv_ef.hip): the .graph image as 64-bit words in host order (low bit first), decoded offsets, upper bound, log2 quantum
+struct EfDev { const uint64_t *words; uint64_t nwords; const int64_t *offsets; int32_t n; uint64_t ub; int lq; };
+// slot s <-> node nodes[s] (nodes != nullptr) or lo + s.  outd[cnt]; slots with >= bigMin successors are appended to biglist (*nbig of them)
+void launch_ef_outdeg(const EfDev &g, const int32_t *nodes, int32_t lo, int64_t cnt, int32_t bigMin, int32_t *outd, int32_t *biglist, int32_t *nbig, int *err, hipStream_t st);
+// rowstart[cnt + 1] = exclusive scan of outd; writes succ[rowstart[s] .. rowstart[s + 1]) for every slot whose list fits in `cap` (E_CAP otherwise)
+void launch_ef_decode(const EfDev &g, const int32_t *nodes, int32_t lo, int64_t cnt, int32_t bigMin, const int32_t *biglist, const int32_t *nbig, const int64_t *rowstart, int32_t *succ,
+                      uint64_t cap, int *err, hipStream_t st);
+
 // BVGraph.store on the device (bv_encode.hip): device CSR -> .graph stream, bit offsets, .offsets stream, counters of the .properties file
 struct EncodeOut {
 	uint32_t *graph_words = nullptr; // big-endian words = the bytes of <basename>.graph, zero padded (+ >= 8 zero words)

@@ -525,8 +525,85 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 }
 
 // Device-pointer core of bvg_decode_range.  rowptr_dev: to-from+1 int64; succ_dev may be NULL (count only).
+// ---- EFGraph (bv_ef.hip): no references between records, so a job is outdegrees -> scan -> one decode pass
+constexpr int32_t EF_BIG_MIN = 256; // lists of that many successors are decoded by a wave each
+
+bv::EfDev ef_dev(const Staged &s) {
+	return bv::EfDev{ (const uint64_t *)s.d_bits, (s.nwords + 1) / 2, s.d_offsets, s.info.nodes, (uint64_t)s.info.ef_upper_bound, s.info.ef_log2_quantum };
+}
+
+// slots <-> nodes[0..cnt) (device pointer) or from + s; rowptr_dev[cnt + 1] and succ_dev (may be null: outdegrees only) on the device
+int ef_job(bvg_graph *g, const int32_t *d_nodes, int32_t from, int64_t cnt, int64_t *rowptr_dev, int32_t *succ_dev, size_t succ_cap, uint64_t *arcs_out) {
+	const Staged &s = *g->st;
+	Small *dsm = g->small.as<Small>();
+	HIPCHK(g, hipMemsetAsync(g->small.p, 0, sizeof(Small), g->stream));
+	if (cnt == 0) {
+		HIPCHK(g, hipMemsetAsync(rowptr_dev, 0, sizeof(int64_t), g->stream));
+		HIPCHK(g, hipStreamSynchronize(g->stream));
+		g->last_arcs = 0;
+		if (arcs_out) *arcs_out = 0;
+		return BVG_OK;
+	}
+	if (!g->outd.need(sizeof(int32_t) * (size_t)cnt) || !g->biglist.need(sizeof(int32_t) * (size_t)cnt) || !g->sums.need(sizeof(int64_t) * (size_t)(bv::scan_num_sums(cnt) + 1)))
+		return fail(g, BVG_ENOMEM, "device scratch allocation failed");
+	int32_t *nbig = g->coopctl.as<int32_t>();
+	HIPCHK(g, hipMemsetAsync(nbig, 0, sizeof(int32_t), g->stream));
+	const bv::EfDev gd = ef_dev(s);
+	bv::launch_ef_outdeg(gd, d_nodes, from, cnt, EF_BIG_MIN, g->outd.as<int32_t>(), g->biglist.as<int32_t>(), nbig, &dsm->err, g->stream);
+	bv::launch_scan(g->outd.as<int32_t>(), cnt, rowptr_dev, g->sums.as<int64_t>(), g->stream);
+	HIPCHK(g, hipMemcpyAsync(&dsm->total, rowptr_dev + cnt, sizeof(int64_t), hipMemcpyDeviceToDevice, g->stream));
+	if (succ_dev) bv::launch_ef_decode(gd, d_nodes, from, cnt, EF_BIG_MIN, g->biglist.as<int32_t>(), nbig, rowptr_dev, succ_dev, (uint64_t)succ_cap, &dsm->err, g->stream);
+	HIPCHK(g, hipMemsetAsync(nbig, 0, sizeof(int32_t), g->stream)); // (the BV jobs expect their control block zeroed)
+	int rc = fetch_small(g);
+	if (rc) return rc;
+	g->last_arcs = (uint64_t)g->h_small->total;
+	if (arcs_out) *arcs_out = g->last_arcs;
+	if (g->h_small->err & bv::E_REF) return fail(g, BVG_EARG, "Node index out of range");
+	if (g->h_small->err & bv::E_FORMAT) return fail(g, BVG_EFORMAT, "malformed bit stream");
+	if (g->h_small->err & bv::E_CAP) return fail(g, BVG_ECAP, "successor buffer too small");
+	return BVG_OK;
+}
+
+int ef_decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_dev, int32_t *succ_dev, size_t succ_cap, uint64_t *arcs_out) {
+	const Staged &s = *g->st;
+	HIPCHK(g, hipSetDevice(s.device));
+	if (from < s.node_lo || to > s.node_hi) return fail(g, BVG_EARG, "node range outside the slice this handle stages (bvg_open_shard)");
+	{ int rc = fork_from_user(g); if (rc) return rc; }
+	int rc = ef_job(g, nullptr, from, (int64_t)to - from, rowptr_dev, succ_dev, succ_cap, arcs_out);
+	if (rc) return rc;
+	return join_to_user(g);
+}
+
+// host outputs: the job runs into staging buffers on the device, the results cross PCIe afterwards
+int ef_to_host(bvg_graph *g, const int32_t *nodes_h, int32_t from, int64_t cnt, int64_t *rowptr_h, int32_t *succ_h, size_t succ_cap, uint64_t *arcs_out) {
+	const Staged &s = *g->st;
+	HIPCHK(g, hipSetDevice(s.device));
+	{ int rc = fork_from_user(g); if (rc) return rc; }
+	if (!g->stage_rowptr.need(sizeof(int64_t) * ((size_t)cnt + 1))) return fail(g, BVG_ENOMEM, "staging allocation failed");
+	const int32_t *d_nodes = nullptr;
+	if (nodes_h) {
+		if (!g->stage_nodes.need(sizeof(int32_t) * std::max<size_t>((size_t)cnt, 1))) return fail(g, BVG_ENOMEM, "staging allocation failed");
+		if (cnt) HIPCHK(g, hipMemcpyAsync(g->stage_nodes.p, nodes_h, sizeof(int32_t) * (size_t)cnt, hipMemcpyHostToDevice, g->stream));
+		d_nodes = g->stage_nodes.as<int32_t>();
+	}
+	// outdegrees first: the staging buffer is sized by what the range holds
+	uint64_t arcs = 0;
+	int rc = ef_job(g, d_nodes, from, cnt, g->stage_rowptr.as<int64_t>(), nullptr, 0, &arcs);
+	if (rc) return rc;
+	if (arcs_out) *arcs_out = arcs;
+	HIPCHK(g, hipMemcpy(rowptr_h, g->stage_rowptr.p, sizeof(int64_t) * ((size_t)cnt + 1), hipMemcpyDeviceToHost));
+	if (!succ_h) return BVG_OK;
+	if (arcs > succ_cap) return fail(g, BVG_ECAP, "successor buffer too small");
+	if (!g->stage_succ.need(sizeof(int32_t) * std::max<size_t>((size_t)arcs, 1))) return fail(g, BVG_ENOMEM, "staging allocation failed");
+	rc = ef_job(g, d_nodes, from, cnt, g->stage_rowptr.as<int64_t>(), g->stage_succ.as<int32_t>(), (size_t)arcs, nullptr);
+	if (rc) return rc;
+	if (arcs) HIPCHK(g, hipMemcpy(succ_h, g->stage_succ.p, sizeof(int32_t) * (size_t)arcs, hipMemcpyDeviceToHost));
+	return BVG_OK;
+}
+
 int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_dev, int32_t *succ_dev, size_t succ_cap, bool async, uint64_t *arcs_out) {
 	const Staged &s = *g->st;
+	if (s.info.format == BVG_FORMAT_EF) return ef_decode_range_device(g, from, to, rowptr_dev, succ_dev, succ_cap, arcs_out);
 	HIPCHK(g, hipSetDevice(s.device));
 	if (g->pend.active) { int rc = finish_pending(g, nullptr); if (rc) return rc; }
 	g->ctl_clean = false; // (only this job's own k_pick_coop vouches for the counters: a job that failed half-way leaves them dirty -- ADVICE r2)
@@ -668,11 +745,12 @@ static int open_impl(const char *basename, int device, int part, int parts, bvg_
 	int rc = bvh::parse_properties(basename, st->info, err);
 	if (rc) return fail(g, rc, err);
 	const bvg_info_t &in = st->info;
+	const bool ef = in.format == BVG_FORMAT_EF;
 	auto okc = [](int c, std::initializer_list<int> l) { for (int v : l) if (c == v) return true; return false; };
 	// the switch statements of BVG:631-816 accept exactly these
-	if (!okc(in.outdegree_coding, { BVG_GAMMA, BVG_DELTA }) || !okc(in.block_coding, { BVG_UNARY, BVG_GAMMA, BVG_DELTA }) ||
+	if (!ef && (!okc(in.outdegree_coding, { BVG_GAMMA, BVG_DELTA }) || !okc(in.block_coding, { BVG_UNARY, BVG_GAMMA, BVG_DELTA }) ||
 	    !okc(in.block_count_coding, { BVG_UNARY, BVG_GAMMA, BVG_DELTA }) || !okc(in.reference_coding, { BVG_UNARY, BVG_GAMMA, BVG_DELTA }) ||
-	    !okc(in.residual_coding, { BVG_GAMMA, BVG_ZETA, BVG_DELTA, BVG_GOLOMB, BVG_NIBBLE }) || !okc(in.offset_coding, { BVG_GAMMA, BVG_DELTA }))
+	    !okc(in.residual_coding, { BVG_GAMMA, BVG_ZETA, BVG_DELTA, BVG_GOLOMB, BVG_NIBBLE }) || !okc(in.offset_coding, { BVG_GAMMA, BVG_DELTA })))
 		return fail(g, BVG_EUNSUPPORTED, "The required coding is not supported");
 	st->basename = basename;
 	// kernel variant: 1 = every coding is the default one and zeta_3 (constants folded in), 2 = the default codings
@@ -686,6 +764,10 @@ static int open_impl(const char *basename, int device, int part, int parts, bvg_
 	if (!bvh::read_file(st->basename + ".offsets", offs, err)) return fail(g, BVG_EIO, err);
 	st->info.graph_bytes = graph.size();
 	st->h_offsets.resize((size_t)in.nodes + 1);
+	if (ef) { // 64-bit words (EFGraph.loadLongBigList, EFGraph.java:677-707): padded to a whole word, brought to host order once
+		graph.resize((graph.size() + 7) & ~(size_t)7, 0);
+		if (in.ef_big_endian) for (size_t i = 0; i + 8 <= graph.size(); i += 8) { std::swap(graph[i], graph[i + 7]); std::swap(graph[i + 1], graph[i + 6]); std::swap(graph[i + 2], graph[i + 5]); std::swap(graph[i + 3], graph[i + 4]); }
+	}
 
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(g, BVG_EHIP, "no HIP device available (libbvgpu has no CPU fallback)");
@@ -729,7 +811,7 @@ static int open_impl(const char *basename, int device, int part, int parts, bvg_
 		st->node_lo = part == 0 ? 0 : bound(part);
 		st->node_hi = std::max(st->node_lo, bound(part + 1));
 		// room for the referents of the slice's first rows: chains of any realistic depth (window x 64 levels, at least 4096 nodes)
-		st->stage_lo = (int32_t)std::max<int64_t>(0, (int64_t)st->node_lo - std::max<int64_t>(4096, (int64_t)in.window_size * 64));
+		st->stage_lo = ef ? st->node_lo : (int32_t)std::max<int64_t>(0, (int64_t)st->node_lo - std::max<int64_t>(4096, (int64_t)in.window_size * 64)); // (no record of an EFGraph refers to another)
 		// the offsets of [stage_lo, node_hi] only
 		int64_t *slice = nullptr;
 		const size_t cntOff = (size_t)(st->node_hi - st->stage_lo) + 1;
@@ -754,7 +836,7 @@ static int open_impl(const char *basename, int device, int part, int parts, bvg_
 	// Scratch (interval arena, copy queues, giant list) is sized by the number of arcs: by what the stream holds, not by
 	// what .properties claims -- one pass over the record headers at load time
 	st->arcs_sizing = parts > 1 ? 1 : std::max<int64_t>(in.arcs, 1);
-	if (st->node_hi > st->stage_lo) {
+	if (!ef && st->node_hi > st->stage_lo) {
 		const int32_t n = st->node_hi - st->stage_lo;
 		void *p_outd = nullptr, *p_ref = nullptr, *p_rs = nullptr, *p_sums = nullptr, *p_err = nullptr, *p_part = nullptr;
 		const bool ok = hipMalloc(&p_outd, sizeof(int32_t) * (size_t)n) == hipSuccess && hipMalloc(&p_ref, sizeof(uint16_t) * (size_t)n) == hipSuccess &&
@@ -873,6 +955,16 @@ extern "C" int bvg_outdegrees(bvg_t *g, int32_t from, int32_t to, int32_t *out, 
 	if (g->pend.active) { int rc = finish_pending(g, nullptr); if (rc) return rc; }
 	{ int rc = fork_from_user(g); if (rc) return rc; }
 	const int32_t cnt = to - from;
+	if (s.info.format == BVG_FORMAT_EF) {
+		if (!g->outd.need(sizeof(int32_t) * (size_t)cnt)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
+		HIPCHK(g, hipMemsetAsync(g->small.p, 0, sizeof(Small), g->stream));
+		bv::launch_ef_outdeg(ef_dev(s), nullptr, from, cnt, 0x7fffffff, g->outd.as<int32_t>(), nullptr, nullptr, &g->small.as<Small>()->err, g->stream);
+		HIPCHK(g, hipMemcpyAsync(out, g->outd.p, sizeof(int32_t) * (size_t)cnt, (flags & BVG_OUT_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, g->stream));
+		int rc = fetch_small(g);
+		if (rc) return rc;
+		if (g->h_small->err) return fail(g, BVG_EFORMAT, "malformed bit stream");
+		return BVG_OK;
+	}
 	if (!g->outd.need(sizeof(int32_t) * (size_t)cnt) || !g->ref.need(sizeof(uint16_t) * (size_t)cnt)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
 	HIPCHK(g, hipMemsetAsync(g->small.p, 0, sizeof(Small), g->stream));
 	bv::launch_headers(graph_dev(s), s.def, from, cnt, g->outd.as<int32_t>(), g->ref.as<uint16_t>(), &g->small.as<Small>()->err, g->stream);
@@ -1027,6 +1119,10 @@ extern "C" int bvg_decode_range(bvg_t *g, int32_t from, int32_t to, int64_t *row
 	const Staged &s = *g->st;
 	if (from < 0 || from > s.info.nodes || to < from || to > s.info.nodes || !rowptr) return fail(g, BVG_EARG, "node range out of bounds"); // BVG:1165
 	if (flags & BVG_OUT_DEVICE) return decode_range_device(g, from, to, rowptr, succ, succ_cap, (flags & BVG_ASYNC) != 0, arcs_out);
+	if (s.info.format == BVG_FORMAT_EF) {
+		if (from < s.node_lo || to > s.node_hi) return fail(g, BVG_EARG, "node range outside the slice this handle stages (bvg_open_shard)");
+		return ef_to_host(g, nullptr, from, (int64_t)to - from, rowptr, succ, succ_cap, arcs_out);
+	}
 	return host_scan(g, from, to, rowptr, succ, succ_cap, arcs_out);
 }
 
@@ -1041,10 +1137,12 @@ extern "C" int bvg_decode_range_view(bvg_t *g, int32_t from, int32_t to, const i
 	const uint64_t guess = (uint64_t)(est_arcs(s, from, to) * 1.05) + 1024;
 	if (!g->view_succ.need(sizeof(int32_t) * (size_t)guess)) return fail(g, BVG_ENOMEM, "pinned result allocation failed");
 	uint64_t arcs = 0;
-	int rc = host_scan(g, from, to, g->view_rowptr.as<int64_t>(), g->view_succ.as<int32_t>(), g->view_succ.cap / sizeof(int32_t), &arcs);
+	auto scan = [&]() { return s.info.format == BVG_FORMAT_EF ? ef_to_host(g, nullptr, from, (int64_t)to - from, g->view_rowptr.as<int64_t>(), g->view_succ.as<int32_t>(), g->view_succ.cap / sizeof(int32_t), &arcs)
+	                                                        : host_scan(g, from, to, g->view_rowptr.as<int64_t>(), g->view_succ.as<int32_t>(), g->view_succ.cap / sizeof(int32_t), &arcs); };
+	int rc = scan();
 	if (rc == BVG_ECAP) { // more arcs than the share of the stream suggested: now the count is known
 		if (!g->view_succ.need(sizeof(int32_t) * (size_t)std::max<uint64_t>(arcs, 1))) return fail(g, BVG_ENOMEM, "pinned result allocation failed");
-		rc = host_scan(g, from, to, g->view_rowptr.as<int64_t>(), g->view_succ.as<int32_t>(), g->view_succ.cap / sizeof(int32_t), &arcs);
+		rc = scan();
 	}
 	if (rc) return rc;
 	*rowptr_out = g->view_rowptr.as<int64_t>();
@@ -1105,6 +1203,13 @@ extern "C" int bvg_successors_batch(bvg_t *g, const int32_t *nodes, size_t q, in
 	g->ctl_clean = false; // (see decode_range_device)
 	{ int rc = fork_from_user(g); if (rc) return rc; }
 	const bool dev = (flags & BVG_OUT_DEVICE) != 0;
+	if (s.info.format == BVG_FORMAT_EF) { // every list is decoded from its own record: a batch is a range with an indirection
+		if (q > 0x7fffffffu) return fail(g, BVG_EARG, "too many queries");
+		if (!dev) return ef_to_host(g, nodes, 0, (int64_t)q, rowptr, succ, succ_cap, arcs_out);
+		int rc = ef_job(g, nodes, 0, (int64_t)q, rowptr, succ, succ_cap, arcs_out);
+		if (rc) return rc;
+		return join_to_user(g);
+	}
 	const bv::GraphDev gd = graph_dev(s);
 	Small *dsm = g->small.as<Small>();
 	HIPCHK(g, hipMemsetAsync(g->small.p, 0, sizeof(Small), g->stream));

@@ -507,3 +507,107 @@ extern "C" int bvt_store_label_lists(const char *basename, const char *underlyin
 	fclose(f);
 	return 0;
 }
+
+// ---------------------------------------------------------------- EFGraph writer (second format)
+// EFGraph.store (EFGraph.java:812-889) with its Accumulator (:420-552) and LongWordOutputBitStream (:298-418): per node
+// gamma(outdegree), then the quasi-succinct (Elias-Fano) encoding of the successors followed by the terminator `upperBound`:
+// forward pointers, lower bits, upper bits.  Bits are taken from the LOW end of 64-bit words, the words are written in `byteorder`.
+namespace {
+struct LongWordSink { // LongWordOutputBitStream: value bits go in from bit `64 - free` upwards
+	std::vector<uint64_t> w;
+	uint64_t buffer = 0; int free = 64; uint64_t bits = 0;
+	int append(uint64_t value, int width) { // EFGraph.java:316-340
+		if (width == 0) return 0;
+		bits += (uint64_t)width;
+		buffer |= free == 64 ? value : value << (64 - free);
+		if (width < free) free -= width;
+		else {
+			w.push_back(buffer);
+			if (width == free) { buffer = 0; free = 64; }
+			else { buffer = value >> free; free = 64 - width + free; }
+		}
+		return width;
+	}
+	int gamma(uint64_t value) { // writeGamma -> writeNonZeroGamma(value + 1), :398-410
+		const uint64_t v = value + 1; const int msb = msb64(v); const uint64_t unary = (uint64_t)1 << msb;
+		append(unary, msb + 1); append(v ^ unary, msb);
+		return 2 * msb + 1;
+	}
+	void unary(uint64_t zeros) { while (zeros >= 64) { append(0, 64); zeros -= 64; } append((uint64_t)1 << zeros, (int)zeros + 1 > 64 ? 64 : (int)zeros + 1); }
+	void append_all(const LongWordSink &o) { // append(LongWordCache), :368-378
+		for (uint64_t v : o.w) append(v, 64);
+		if (o.free != 64) append(o.buffer, 64 - o.free);
+	}
+	void clear() { w.clear(); buffer = 0; free = 64; bits = 0; }
+};
+inline int ef_lower_bits(uint64_t length, uint64_t ub) { if (length == 0) return 0; const uint64_t q = ub / length; return q == 0 ? 0 : msb64(q); }          // EFGraph.java:145-147
+inline int ef_ceil_log2(uint64_t x) { return x <= 2 ? (int)x - 1 : 64 - __builtin_clzll(x - 1); }                                                     // dsiutils Fast.ceilLog2
+inline int ef_pointer_size(uint64_t length, uint64_t ub) { return std::max(0, ef_ceil_log2(length + (ub >> ef_lower_bits(length, ub)))); }             // :156-158
+inline uint64_t ef_num_pointers(uint64_t length, uint64_t ub, int lq) { return length == 0 ? 0 : (ub >> ef_lower_bits(length, ub)) >> lq; }          // :168-171
+} // namespace
+
+extern "C" int bvt_store_ef(const char *basename, int32_t n, const int64_t *rowptr, const int32_t *succ, int32_t upper_bound, int log2_quantum, int big_endian) {
+	if (!basename || n < 0 || !rowptr || log2_quantum < 0 || log2_quantum > 62 || upper_bound < n) return -EINVAL;
+	LongWordSink graph, pointers, lower, upper;
+	BitSink offs;
+	offs.delta(0); // offsets.writeLongDelta(0), :830
+	uint64_t bitsOutd = 0, bitsSucc = 0;
+	const uint64_t ub = (uint64_t)upper_bound, quantum = (uint64_t)1 << log2_quantum;
+	for (int32_t x = 0; x < n; x++) {
+		const int64_t a = rowptr[x], d = rowptr[x + 1] - a;
+		const int ob = graph.gamma((uint64_t)d);
+		bitsOutd += (uint64_t)ob;
+		// Accumulator.init(outdegree, upperBound, strict = false, indexZeroes = true, log2Quantum), :483-507
+		const uint64_t len = (uint64_t)d + 1;
+		const int l = ef_lower_bits(len, ub), ps = ef_pointer_size(len, ub);
+		pointers.clear(); lower.clear(); upper.clear();
+		int64_t lastOne = -1; uint64_t cur = 0;
+		int64_t prev = -1;
+		for (int64_t i = 0; i <= d; i++) { // add(), :509-525; the last turn is dump()'s terminator, :529-531
+			const uint64_t v = i < d ? (uint64_t)(uint32_t)succ[a + i] : ub;
+			if (i < d && (succ[a + i] < 0 || (int64_t)v <= prev || v >= ub)) return -EINVAL; // strictly increasing, below the bound (:510, :513)
+			prev = (int64_t)v;
+			if (l) lower.append(v & (((uint64_t)1 << l) - 1), l);
+			const int64_t one = (int64_t)(v >> l) + (int64_t)cur;
+			upper.unary((uint64_t)(one - lastOne - 1));
+			int64_t zeroesBefore = lastOne - (int64_t)cur + 1;
+			for (int64_t pos = lastOne + (zeroesBefore & -(int64_t)quantum) + (int64_t)quantum - zeroesBefore; pos < one; pos += (int64_t)quantum, zeroesBefore += (int64_t)quantum)
+				pointers.append((uint64_t)(pos + 1), ps);
+			lastOne = one; cur++;
+		}
+		graph.append_all(pointers); graph.append_all(lower); graph.append_all(upper);
+		const uint64_t sb = pointers.bits + lower.bits + upper.bits;
+		bitsSucc += sb;
+		offs.delta((uint64_t)ob + sb); // :855
+	}
+	graph.w.push_back(graph.buffer); // close() writes the buffer whatever it holds, :412-417
+	std::string base(basename);
+	{
+		FILE *f = fopen((base + ".graph").c_str(), "wb");
+		if (!f) return -EIO;
+		std::vector<uint8_t> buf; buf.reserve(1 << 20);
+		for (uint64_t v : graph.w) {
+			for (int b = 0; b < 8; b++) buf.push_back((uint8_t)(big_endian ? v >> (56 - 8 * b) : v >> (8 * b)));
+			if (buf.size() >= (1 << 20)) { fwrite(buf.data(), 1, buf.size(), f); buf.clear(); }
+		}
+		if (!buf.empty()) fwrite(buf.data(), 1, buf.size(), f);
+		const bool ok = !ferror(f);
+		if (fclose(f) != 0 || !ok) return -EIO;
+	}
+	if (!offs.write_file(base + ".offsets")) return -EIO;
+	const uint64_t m = n ? (uint64_t)rowptr[n] : 0, written = (uint64_t)graph.w.size() * 64;
+	FILE *f = fopen((base + ".properties").c_str(), "w");
+	if (!f) return -EIO;
+	auto stirling = [](double v) { return v * std::log(v) - v + 0.5 * std::log(2 * M_PI * v); }; // :804-806
+	fprintf(f, "#EFGraph properties\n");
+	fprintf(f, "nodes=%d\narcs=%llu\n", n, (unsigned long long)m);
+	if (upper_bound != n) fprintf(f, "upperbound=%d\n", upper_bound);
+	fprintf(f, "quantum=%llu\nbyteorder=%s\n", (unsigned long long)quantum, big_endian ? "BIG_ENDIAN" : "LITTLE_ENDIAN");
+	fprintf(f, "bitsperlink=%s\n", bvprops::fmt3(m ? (double)written / m : 0).c_str());
+	if (n > 0 && m > 0 && (double)n * n > (double)m) fprintf(f, "compratio=%s\n", bvprops::fmt3(written * std::log(2.0) / (stirling((double)n * n) - stirling((double)m) - stirling((double)n * n - (double)m))).c_str());
+	fprintf(f, "bitspernode=%s\navgbitsforoutdegrees=%s\n", bvprops::fmt3(n ? (double)written / n : 0).c_str(), bvprops::fmt3(n ? (double)bitsOutd / n : 0).c_str());
+	fprintf(f, "bitsforoutdegrees=%llu\nbitsforsuccessors=%llu\n", (unsigned long long)bitsOutd, (unsigned long long)bitsSucc);
+	fprintf(f, "graphclass=it.unimi.dsi.webgraph.EFGraph\nversion=0\n");
+	fclose(f);
+	return 0;
+}

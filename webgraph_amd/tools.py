@@ -121,3 +121,15 @@ def store_label_lists(basename, underlying, rowptr, listptr, values, width, key=
                                  values.ctypes.data, int(width), key.encode())
     if rc:
         raise OSError(-rc, "bvt_store_label_lists failed: %s" % os.strerror(-rc))
+
+
+def store_ef(basename, rowptr, succ, upper_bound=None, log2_quantum=8, big_endian=False):
+    """EFGraph.store(graph, basename) for a CSR graph (include/bvgtools.h): the quasi-succinct second format."""
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+    succ = np.ascontiguousarray(succ, dtype=np.int32)
+    n = rowptr.size - 1
+    L = lib()
+    L.bvt_store_ef.argtypes = [C.c_char_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int, C.c_int]
+    rc = L.bvt_store_ef(os.fsencode(basename), n, rowptr.ctypes.data, succ.ctypes.data, n if upper_bound is None else upper_bound, log2_quantum, 1 if big_endian else 0)
+    if rc:
+        raise OSError(-rc, "bvt_store_ef failed: %s" % os.strerror(-rc))
