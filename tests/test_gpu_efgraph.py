@@ -82,6 +82,11 @@ def test_long_lists_go_to_the_waves(tmp_path):
     assert np.array_equal(rp, rowptr) and np.array_equal(sc, succ)
     brp, bsc = g.successors_batch(np.array([20, 3, 39, 4, 0], dtype=np.int32))
     assert np.array_equal(bsc, np.array(rows[20] + rows[3] + rows[39] + rows[4], dtype=np.int32))
+    # the same giant lists asked for many times: more rounds than the scratch for them holds
+    q = np.array([3, 4, 20] * 400, dtype=np.int32)
+    brp, bsc = g.successors_batch(q)
+    one = np.array(rows[3] + rows[4] + rows[20], dtype=np.int32)
+    assert bsc.size == 400 * one.size and np.array_equal(bsc.reshape(400, -1), np.tile(one, (400, 1)))
     g.close()
 
 

@@ -6,8 +6,8 @@
 // number and width follow from the outdegree, :156-171), l lower bits per value, and the upper bits in negated unary, where
 // value i sets bit (value >> l) + i (EliasFanoSuccessorReader, :1103-1145).  No record refers to another one: the scan is
 // outdegrees (k_ef_outdeg) -> scan -> one pass that writes every list (k_ef_decode, k_ef_decode_wave), with nothing to wait
-// for between nodes.  Successor i is  ((position of the i-th one) - i) << l | lower_i : a select in the upper bits, which a
-// lane does by walking the ones of its words and a wave by a prefix sum over the popcounts of 64 words.
+// for between nodes.  Successor i is  ((position of the i-th one) - i) << l | lower_i : a select in the upper bits, done per
+// successor by popcounts for the short lists and by a prefix sum over the popcounts of 64 words for the long ones.
 #include "bv_launch.hpp"
 
 namespace bv {
@@ -23,8 +23,8 @@ __device__ __forceinline__ uint64_t ef_get(const EfDev &g, uint64_t pos, int wid
 	return width == 64 ? v : v & ((1ull << width) - 1);
 }
 struct EfRecord { uint32_t d; int l; uint64_t lowerStart, upperStart; };
-// header of the record at bit `pos`: gamma(outdegree), then the sizes that follow from it (EFGraph.java:145-171, :1110-1115)
-__device__ __forceinline__ bool ef_header(const EfDev &g, uint64_t pos, EfRecord &r) {
+// gamma(outdegree) at bit `pos` (readGamma, EFGraph.java:1024-1032); `after`: the bit that follows it
+__device__ __forceinline__ bool ef_outdegree(const EfDev &g, uint64_t pos, uint32_t &d, uint64_t &after) {
 	// readUnary: zeros up to the next one (a gamma code of a valid outdegree has at most 31 of them)
 	uint64_t i = pos >> 6;
 	uint64_t w = ef_ld(g, i) & (~0ull << (pos & 63));
@@ -34,10 +34,17 @@ __device__ __forceinline__ bool ef_header(const EfDev &g, uint64_t pos, EfRecord
 	if (msb > 31) return false;
 	const uint64_t v = (ef_get(g, one + 1, (int)msb) | (1ull << msb)) - 1;
 	if (v > g.ub) return false; // more successors than values below the bound
-	const uint64_t after = one + 1 + msb;
-	r.d = (uint32_t)v;
-	const uint64_t len = v + 1, q = g.ub / len;
-	r.l = q == 0 ? 0 : 63 - __builtin_clzll(q);
+	after = one + 1 + msb;
+	d = (uint32_t)v;
+	return true;
+}
+// header of the record at bit `pos`: the outdegree, then the sizes that follow from it (EFGraph.java:145-171, :1110-1115)
+__device__ __forceinline__ bool ef_header(const EfDev &g, uint64_t pos, EfRecord &r) {
+	uint64_t after;
+	if (!ef_outdegree(g, pos, r.d, after)) return false;
+	const uint64_t len = (uint64_t)r.d + 1;
+	const uint32_t q = (uint32_t)g.ub / (uint32_t)len; // (both below 2^31 + 1: a 32-bit division)
+	r.l = q == 0 ? 0 : 31 - __builtin_clz(q);
 	const uint64_t hi = g.ub >> r.l, x = len + hi;
 	const int ps = x <= 2 ? (int)x - 1 : 64 - __builtin_clzll(x - 1); // Fast.ceilLog2
 	r.lowerStart = after + (uint64_t)(ps < 0 ? 0 : ps) * (hi >> g.lq);
@@ -46,84 +53,244 @@ __device__ __forceinline__ bool ef_header(const EfDev &g, uint64_t pos, EfRecord
 }
 
 // slot s <-> node nodes[s] (a batch) or lo + s (a range)
-__global__ void __launch_bounds__(256) k_ef_outdeg(const EfDev g, const int32_t *__restrict__ nodes, int32_t lo, int64_t cnt, int32_t bigMin, int32_t *__restrict__ outd,
-                                                   int32_t *__restrict__ biglist, int32_t *__restrict__ nbig, int *__restrict__ err) {
+__global__ void __launch_bounds__(256) k_ef_outdeg(const EfDev g, const int32_t *__restrict__ nodes, int32_t lo, int64_t cnt, int32_t *__restrict__ outd, int *__restrict__ err) {
 	const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
-	if (s >= cnt) return;
-	const int32_t x = nodes ? nodes[s] : (int32_t)(lo + s);
-	EfRecord r;
-	if (x < 0 || x >= g.n || !ef_header(g, (uint64_t)g.offsets[x], r)) { outd[s] = 0; atomicOr(err, x < 0 || x >= g.n ? E_REF : E_FORMAT); return; }
-	outd[s] = (int32_t)r.d;
-	if (biglist && (int32_t)r.d >= bigMin) biglist[atomicAdd(nbig, 1)] = (int32_t)s;
-}
-
-// one lane per list of fewer than bigMin successors
-__global__ void __launch_bounds__(256) k_ef_decode(const EfDev g, const int32_t *__restrict__ nodes, int32_t lo, int64_t cnt, int32_t bigMin, const int64_t *__restrict__ rowstart,
-                                                   int32_t *__restrict__ succ, uint64_t cap, int *__restrict__ err) {
-	const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
-	if (s >= cnt) return;
-	const int64_t base = rowstart[s];
-	const uint32_t d = (uint32_t)(rowstart[s + 1] - base);
-	if (d == 0 || (int32_t)d >= bigMin) return;
-	if ((uint64_t)(base + d) > cap) { atomicOr(err, E_CAP); return; }
-	const int32_t x = nodes ? nodes[s] : (int32_t)(lo + s);
-	EfRecord r;
-	if (!ef_header(g, (uint64_t)g.offsets[x], r) || r.d != d) { atomicOr(err, E_FORMAT); return; }
-	uint64_t wi = r.upperStart >> 6;
-	uint64_t w = ef_ld(g, wi) & (~0ull << (r.upperStart & 63));
-	uint64_t lp = r.lowerStart;
-	for (uint32_t i = 0; i < d; i++) {
-		while (w == 0) { if (++wi >= g.nwords) { atomicOr(err, E_FORMAT); return; } w = g.words[wi]; }
-		const uint64_t high = wi * 64 + (uint64_t)__builtin_ctzll(w) - r.upperStart - i;
-		w &= w - 1;
-		succ[base + i] = (int32_t)((high << r.l) | ef_get(g, lp, r.l));
-		lp += (uint64_t)r.l;
+	uint32_t d = 0;
+	if (s < cnt) {
+		const int32_t x = nodes ? nodes[s] : (int32_t)(lo + s);
+		uint64_t after;
+		if (x < 0 || x >= g.n || !ef_outdegree(g, (uint64_t)g.offsets[x], d, after)) { d = 0; atomicOr(err, x < 0 || x >= g.n ? E_REF : E_FORMAT); }
+		outd[s] = (int32_t)d;
 	}
 }
 
-// one wave per long list: 64 words of upper bits per round, a prefix sum over their popcounts gives every one its index
-__global__ void __launch_bounds__(256) k_ef_decode_wave(const EfDev g, const int32_t *__restrict__ nodes, int32_t lo, const int32_t *__restrict__ biglist, const int32_t *__restrict__ nbig,
+// Lists of fewer than bigMin successors, 256 slots per block.  Phase 1: one lane per slot reads the header of its record (l,
+// where the lower and the upper bits start) into LDS, a block scan numbers the successors of the tile.  Phase 2: one lane per
+// SUCCESSOR -- its slot by a search in the tile's prefix sums, the position of its one in the upper bits by popcounts (a select
+// within a few words: a short list has about two upper bits per successor), its lower bits by one extraction -- so that
+// neighbouring lanes read neighbouring bits and write neighbouring ids, whatever the lengths of the lists are.
+constexpr int EF_TILE = 256;
+__global__ void __launch_bounds__(EF_TILE) k_ef_decode(const EfDev g, const int32_t *__restrict__ nodes, int32_t lo, int64_t cnt, int32_t bigMin, const int64_t *__restrict__ rowstart,
+                                                       int32_t *__restrict__ succ, uint64_t cap, int *__restrict__ err) {
+	__shared__ uint64_t s_lower[EF_TILE], s_upper[EF_TILE];
+	__shared__ int64_t s_row[EF_TILE];
+	__shared__ int32_t s_first[EF_TILE + 1]; // successors of the tile's short lists before slot t
+	__shared__ int32_t s_l[EF_TILE], s_wsum[EF_TILE / 64];
+	const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+	const int64_t s = (int64_t)blockIdx.x * EF_TILE + t;
+	int32_t d = 0;
+	if (s < cnt) {
+		const int64_t base = rowstart[s];
+		d = (int32_t)(rowstart[s + 1] - base);
+		if (d >= bigMin) d = 0; // a wave's
+		else if (d > 0) {
+			if ((uint64_t)(base + d) > cap) { atomicOr(err, E_CAP); d = 0; }
+			else {
+				EfRecord r;
+				const int32_t x = nodes ? nodes[s] : (int32_t)(lo + s);
+				if (!ef_header(g, (uint64_t)g.offsets[x], r) || (int32_t)r.d != d) { atomicOr(err, E_FORMAT); d = 0; }
+				else { s_lower[t] = r.lowerStart; s_upper[t] = r.upperStart; s_l[t] = r.l; s_row[t] = base; }
+			}
+		}
+	}
+	// exclusive scan of d over the block
+	int32_t inc = d;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) { const int32_t v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+	if (lane == 63) s_wsum[wv] = inc;
+	__syncthreads();
+	int32_t before = 0;
+	for (int w = 0; w < wv; w++) before += s_wsum[w];
+	s_first[t] = before + inc - d;
+	if (t == EF_TILE - 1) s_first[EF_TILE] = before + inc;
+	__syncthreads();
+	const int32_t total = s_first[EF_TILE];
+	for (int32_t k = t; k < total; k += EF_TILE) {
+		int a = 0, b = EF_TILE; // last slot with s_first <= k (slots without short lists repeat their successor's value: the last of them is the one)
+#pragma unroll
+		for (int step = 0; step < 8; step++) { const int mid = (a + b) >> 1; if (s_first[mid] <= k) a = mid; else b = mid; }
+		const uint32_t i = (uint32_t)(k - s_first[a]);
+		const uint64_t up = s_upper[a];
+		const int l = s_l[a];
+		// select: the i-th one at or after bit `up`
+		uint64_t wi = up >> 6;
+		uint64_t w = ef_ld(g, wi) & (~0ull << (up & 63));
+		uint32_t r = i;
+		bool bad = false;
+		for (uint32_t c = (uint32_t)__popcll(w); r >= c; c = (uint32_t)__popcll(w)) { r -= c; if (++wi >= g.nwords) { bad = true; break; } w = ef_ld(g, wi); }
+		if (bad) { atomicOr(err, E_FORMAT); continue; }
+		uint32_t bit = 0;
+#pragma unroll
+		for (int sh = 32; sh > 0; sh >>= 1) { const uint32_t c = (uint32_t)__popcll(w & ((1ull << sh) - 1)); if (r >= c) { r -= c; w >>= sh; bit += sh; } }
+		const uint64_t high = wi * 64 + bit - up - i;
+		succ[s_row[a] + i] = (int32_t)((high << l) | ef_get(g, s_lower[a] + (uint64_t)i * (uint64_t)l, l));
+	}
+}
+
+// ---- long lists.  A round takes 64 words of upper bits: a prefix sum over their popcounts gives every one its index; the lower
+// bits of the round's successors are one contiguous stretch of the stream, staged in LDS so that the walk over a word's ones
+// waits for nothing.  Lists below giantMin are decoded by one wave, round after round (k_ef_decode_wave).  A giant list (C2 has
+// one of 3.5 * 10^5 successors: 240 rounds one after the other, 2.3 ms) is first measured -- k_ef_rank: popcounts only, the
+// number of ones before every round -- which makes its rounds independent work items for as many waves (k_ef_decode_chunks).
+constexpr int EF_LDS_WORDS = 512; // per wave: 32 768 lower bits
+struct EfChunk { int32_t slot; uint32_t round; uint64_t rank; }; // round `round` of the list in slot `slot` starts with successor `rank`
+
+__device__ __forceinline__ void ef_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); }
+
+// words [w0, w0 + 64) of the upper bits of record r, `done` successors before them; returns the ones in these words
+__device__ __forceinline__ uint32_t ef_round(const EfDev &g, const EfRecord &r, int64_t base, uint32_t d, uint64_t w0, uint64_t done, uint64_t *low, int lane,
+                                             int32_t *__restrict__ succ) {
+	uint64_t w = ef_ld(g, w0 + lane);
+	if (w0 + lane == (r.upperStart >> 6)) w &= ~0ull << (r.upperStart & 63);
+	uint32_t inc = (uint32_t)__popcll(w);
+	const uint32_t mine = inc;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+	const uint32_t total = __shfl(inc, 63);
+	if (done >= d) return total;
+	const uint64_t todo = d - done < total ? d - done : total; // successors of this round
+	// their lower bits: [lb, lb + todo * l)
+	const uint64_t lb = r.lowerStart + done * (uint64_t)r.l, lw0 = lb >> 6;
+	const uint64_t nlw = r.l ? ((lb + todo * (uint64_t)r.l + 63) >> 6) - lw0 : 0;
+	const bool staged = nlw <= EF_LDS_WORDS;
+	if (staged) {
+		ef_wave_sync(); // (the previous round's reads are over)
+		for (uint64_t j = lane; j < nlw + 1; j += 64) low[j] = ef_ld(g, lw0 + j);
+		ef_wave_sync();
+	}
+	uint64_t i = done + inc - mine; // index of this lane's first one
+	const uint64_t bit0 = (w0 + lane) * 64 - r.upperStart;
+	while (w && i < d) {
+		const uint64_t high = bit0 + (uint64_t)__builtin_ctzll(w) - i;
+		w &= w - 1;
+		uint64_t lowv = 0;
+		if (r.l) {
+			const uint64_t p = r.lowerStart + i * (uint64_t)r.l;
+			if (staged) {
+				const uint64_t q = p - lw0 * 64, k = q >> 6;
+				const int b = (int)(q & 63);
+				lowv = low[k] >> b;
+				if (b + r.l > 64) lowv |= low[k + 1] << (64 - b);
+				lowv &= (1ull << r.l) - 1;
+			} else lowv = ef_get(g, p, r.l);
+		}
+		succ[base + i] = (int32_t)((high << r.l) | lowv);
+		i++;
+	}
+	return total;
+}
+
+// The long lists are found where they are: a wave looks at 64 slots at a time (their lengths are neighbouring words of
+// rowstart) and takes the ones in its range -- no list of them is built (an atomic append per long list cost more than their
+// decoding: 35 000 atomics on one counter, 0.5 ms).
+__global__ void __launch_bounds__(256) k_ef_decode_wave(const EfDev g, const int32_t *__restrict__ nodes, int32_t lo, int64_t cnt, int32_t bigMin, int32_t giantMin,
                                                         const int64_t *__restrict__ rowstart, int32_t *__restrict__ succ, uint64_t cap, int *__restrict__ err) {
+	__shared__ uint64_t s_low[4][EF_LDS_WORDS + 2];
 	const int lane = threadIdx.x & 63;
-	const int64_t n = *nbig, stride = (int64_t)gridDim.x * 4;
-	for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < n; t += stride) {
-		const int64_t s = biglist[t];
+	uint64_t *low = s_low[threadIdx.x >> 6];
+	const int64_t groups = (cnt + 63) / 64, stride = (int64_t)gridDim.x * 4;
+	for (int64_t gi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); gi < groups; gi += stride) {
+		const int64_t sl = gi * 64 + lane;
+		const int64_t dl = sl < cnt ? rowstart[sl + 1] - rowstart[sl] : 0;
+		for (uint64_t m = __ballot(dl >= bigMin && dl < giantMin); m; m &= m - 1) {
+			const int64_t s = gi * 64 + __builtin_ctzll(m);
+			const int64_t base = rowstart[s];
+			const uint32_t d = (uint32_t)(rowstart[s + 1] - base);
+			if ((uint64_t)(base + d) > cap) { if (lane == 0) atomicOr(err, E_CAP); continue; }
+			const int32_t x = nodes ? nodes[s] : (int32_t)(lo + s);
+			EfRecord r;
+			if (!ef_header(g, (uint64_t)g.offsets[x], r) || r.d != d) { if (lane == 0) atomicOr(err, E_FORMAT); continue; }
+			uint64_t done = 0;
+			for (uint64_t w0 = r.upperStart >> 6; done < d; w0 += 64) {
+				if (w0 >= g.nwords) { if (lane == 0) atomicOr(err, E_FORMAT); break; }
+				done += ef_round(g, r, base, d, w0, done, low, lane, succ);
+			}
+		}
+	}
+}
+
+// the giant lists: ones before every round -> work items.  chunks[] is a bump allocation: *nchunks slots are in use.
+__global__ void __launch_bounds__(256) k_ef_rank(const EfDev g, const int32_t *__restrict__ nodes, int32_t lo, int64_t cnt, int32_t giantMin, const int64_t *__restrict__ rowstart,
+                                                 int32_t *__restrict__ succ, uint64_t cap, EfChunk *__restrict__ chunks, uint32_t chunkCap, uint32_t *__restrict__ nchunks,
+                                                 int *__restrict__ err) {
+	__shared__ uint64_t s_low[4][EF_LDS_WORDS + 2];
+	uint64_t *low = s_low[threadIdx.x >> 6];
+	const int lane = threadIdx.x & 63;
+	const int64_t groups = (cnt + 63) / 64, stride = (int64_t)gridDim.x * 4;
+	for (int64_t gi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); gi < groups; gi += stride) {
+	const int64_t sl = gi * 64 + lane;
+	const int64_t dl = sl < cnt ? rowstart[sl + 1] - rowstart[sl] : 0;
+	for (uint64_t m = __ballot(dl >= giantMin); m; m &= m - 1) {
+		const int64_t s = gi * 64 + __builtin_ctzll(m);
 		const int64_t base = rowstart[s];
 		const uint32_t d = (uint32_t)(rowstart[s + 1] - base);
 		if ((uint64_t)(base + d) > cap) { if (lane == 0) atomicOr(err, E_CAP); continue; }
 		const int32_t x = nodes ? nodes[s] : (int32_t)(lo + s);
 		EfRecord r;
 		if (!ef_header(g, (uint64_t)g.offsets[x], r) || r.d != d) { if (lane == 0) atomicOr(err, E_FORMAT); continue; }
-		uint64_t done = 0;
-		for (uint64_t w0 = r.upperStart >> 6; done < d; w0 += 64) {
-			if (w0 >= g.nwords) { if (lane == 0) atomicOr(err, E_FORMAT); break; }
-			uint64_t w = ef_ld(g, w0 + lane);
-			if (w0 + lane == (r.upperStart >> 6)) w &= ~0ull << (r.upperStart & 63);
-			uint32_t inc = (uint32_t)__popcll(w);
-			const uint32_t mine = inc;
+		// the record ends with the terminator's one: its upper bits are the words up to offsets[x + 1]
+		const uint64_t wFirst = r.upperStart >> 6, wEnd = ((uint64_t)g.offsets[x + 1] + 63) >> 6;
+		if (wEnd <= wFirst || wEnd > g.nwords + 1) { if (lane == 0) atomicOr(err, E_FORMAT); continue; }
+		const uint32_t rounds = (uint32_t)((wEnd - wFirst + 63) / 64);
+		uint32_t at = 0;
+		if (lane == 0) at = atomicAdd(nchunks, rounds);
+		at = __shfl(at, 0);
+		if ((uint64_t)at + rounds > chunkCap) { // no room (a batch that asks for the same giant list many times): this wave decodes it, round after round
+			for (uint64_t j = (uint64_t)at + lane; j < chunkCap; j += 64) chunks[j].slot = -1;
+			uint64_t done = 0;
+			for (uint64_t w0 = wFirst; done < d && w0 < g.nwords; w0 += 64) done += ef_round(g, r, base, d, w0, done, low, lane, succ);
+			continue;
+		}
+		uint64_t rank = 0;
+		for (uint32_t rd = 0; rd < rounds; rd += 4) { // four rounds of loads in flight
+			uint32_t c[4];
 #pragma unroll
-			for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if (lane >= o) inc += v; }
-			uint64_t i = done + inc - mine; // index of this lane's first one
-			const uint64_t bit0 = (w0 + lane) * 64 - r.upperStart;
-			while (w && i < d) {
-				const uint64_t high = bit0 + (uint64_t)__builtin_ctzll(w) - i;
-				w &= w - 1;
-				succ[base + i] = (int32_t)((high << r.l) | ef_get(g, r.lowerStart + i * (uint64_t)r.l, r.l));
-				i++;
+			for (int u = 0; u < 4; u++) {
+				const uint64_t wi = wFirst + (uint64_t)(rd + u) * 64 + lane;
+				uint64_t w = rd + u < rounds && wi < wEnd ? ef_ld(g, wi) : 0;
+				if (wi == wFirst) w &= ~0ull << (r.upperStart & 63);
+				c[u] = (uint32_t)__popcll(w);
 			}
-			done += __shfl(inc, 63);
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+#pragma unroll
+				for (int o = 32; o > 0; o >>= 1) c[u] += __shfl_xor(c[u], o);
+				if (rd + u < rounds) { if (lane == 0) chunks[at + rd + u] = EfChunk{ (int32_t)s, rd + u, rank }; rank += c[u]; }
+			}
 		}
 	}
 }
+}
+__global__ void __launch_bounds__(256) k_ef_decode_chunks(const EfDev g, const int32_t *__restrict__ nodes, int32_t lo, const EfChunk *__restrict__ chunks, const uint32_t *__restrict__ nchunks,
+                                                          uint32_t chunkCap, const int64_t *__restrict__ rowstart, int32_t *__restrict__ succ, int *__restrict__ err) {
+	__shared__ uint64_t s_low[4][EF_LDS_WORDS + 2];
+	const int lane = threadIdx.x & 63;
+	uint64_t *low = s_low[threadIdx.x >> 6];
+	const int64_t n = *nchunks < chunkCap ? *nchunks : chunkCap, stride = (int64_t)gridDim.x * 4;
+	for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < n; t += stride) {
+		const EfChunk c = chunks[t];
+		if (c.slot < 0) continue; // slots given up by a list that did not fit
+		const int64_t base = rowstart[c.slot];
+		const uint32_t d = (uint32_t)(rowstart[c.slot + 1] - base);
+		if (c.rank >= d) continue; // nothing but the terminator (or padding) in this round
+		const int32_t x = nodes ? nodes[c.slot] : (int32_t)(lo + c.slot);
+		EfRecord r;
+		if (!ef_header(g, (uint64_t)g.offsets[x], r) || r.d != d) { if (lane == 0) atomicOr(err, E_FORMAT); continue; }
+		(void)ef_round(g, r, base, d, (r.upperStart >> 6) + (uint64_t)c.round * 64, c.rank, low, lane, succ);
+	}
+}
 
-void launch_ef_outdeg(const EfDev &g, const int32_t *nodes, int32_t lo, int64_t cnt, int32_t bigMin, int32_t *outd, int32_t *biglist, int32_t *nbig, int *err, hipStream_t st) {
-	if (cnt > 0) hipLaunchKernelGGL(k_ef_outdeg, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, g, nodes, lo, cnt, bigMin, outd, biglist, nbig, err);
+void launch_ef_outdeg(const EfDev &g, const int32_t *nodes, int32_t lo, int64_t cnt, int32_t *outd, int *err, hipStream_t st) {
+	if (cnt > 0) hipLaunchKernelGGL(k_ef_outdeg, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, g, nodes, lo, cnt, outd, err);
 }
-void launch_ef_decode(const EfDev &g, const int32_t *nodes, int32_t lo, int64_t cnt, int32_t bigMin, const int32_t *biglist, const int32_t *nbig, const int64_t *rowstart, int32_t *succ,
-                      uint64_t cap, int *err, hipStream_t st) {
+void launch_ef_decode(const EfDev &g, const int32_t *nodes, int32_t lo, int64_t cnt, int32_t bigMin, const int64_t *rowstart, int32_t *succ, uint64_t cap, int *err, int32_t giantMin,
+                      void *chunks, uint32_t chunkCap, uint32_t *nchunks, hipStream_t st, hipStream_t stLong, hipStream_t stGiant) {
 	if (cnt <= 0) return;
-	hipLaunchKernelGGL(k_ef_decode_wave, dim3(1024), dim3(256), 0, st, g, nodes, lo, biglist, nbig, rowstart, succ, cap, err);
-	hipLaunchKernelGGL(k_ef_decode, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, g, nodes, lo, cnt, bigMin, rowstart, succ, cap, err);
+	hipLaunchKernelGGL(k_ef_rank, dim3(256), dim3(256), 0, stGiant, g, nodes, lo, cnt, giantMin, rowstart, succ, cap, (EfChunk *)chunks, chunkCap, nchunks, err);
+	hipLaunchKernelGGL(k_ef_decode_chunks, dim3(1024), dim3(256), 0, stGiant, g, nodes, lo, (const EfChunk *)chunks, nchunks, chunkCap, rowstart, succ, err);
+	hipLaunchKernelGGL(k_ef_decode_wave, dim3(1024), dim3(256), 0, stLong, g, nodes, lo, cnt, bigMin, giantMin, rowstart, succ, cap, err);
+	hipLaunchKernelGGL(k_ef_decode, dim3((unsigned)((cnt + EF_TILE - 1) / EF_TILE)), dim3(EF_TILE), 0, st, g, nodes, lo, cnt, bigMin, rowstart, succ, cap, err);
 }
+size_t ef_chunk_bytes() { return sizeof(EfChunk); }
 
 } // namespace bv

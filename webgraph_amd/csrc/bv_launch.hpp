@@ -108,11 +108,14 @@ int label_lists_decode_device(const uint32_t *d_words, uint64_t nwords, const in
 
 // EFGraph (bv_ef.hip): the .graph image as 64-bit words in host order (low bit first), decoded offsets, upper bound, log2 quantum
 struct EfDev { const uint64_t *words; uint64_t nwords; const int64_t *offsets; int32_t n; uint64_t ub; int lq; };
-// slot s <-> node nodes[s] (nodes != nullptr) or lo + s.  outd[cnt]; slots with >= bigMin successors are appended to biglist (*nbig of them)
-void launch_ef_outdeg(const EfDev &g, const int32_t *nodes, int32_t lo, int64_t cnt, int32_t bigMin, int32_t *outd, int32_t *biglist, int32_t *nbig, int *err, hipStream_t st);
-// rowstart[cnt + 1] = exclusive scan of outd; writes succ[rowstart[s] .. rowstart[s + 1]) for every slot whose list fits in `cap` (E_CAP otherwise)
-void launch_ef_decode(const EfDev &g, const int32_t *nodes, int32_t lo, int64_t cnt, int32_t bigMin, const int32_t *biglist, const int32_t *nbig, const int64_t *rowstart, int32_t *succ,
-                      uint64_t cap, int *err, hipStream_t st);
+// slot s <-> node nodes[s] (nodes != nullptr) or lo + s.  outd[cnt]
+void launch_ef_outdeg(const EfDev &g, const int32_t *nodes, int32_t lo, int64_t cnt, int32_t *outd, int *err, hipStream_t st);
+// rowstart[cnt + 1] = exclusive scan of outd; writes succ[rowstart[s] .. rowstart[s + 1]) for every slot whose list fits in `cap` (E_CAP otherwise).
+// Lists shorter than bigMin: st; longer ones: stLong; giant ones: stGiant (the kernels touch different lists).  Lists of giantMin successors or more are cut
+// into rounds of 64 words of upper bits, one work item each: chunks = chunkCap * ef_chunk_bytes() bytes of scratch, *nchunks zeroed
+void launch_ef_decode(const EfDev &g, const int32_t *nodes, int32_t lo, int64_t cnt, int32_t bigMin, const int64_t *rowstart, int32_t *succ, uint64_t cap, int *err, int32_t giantMin,
+                      void *chunks, uint32_t chunkCap, uint32_t *nchunks, hipStream_t st, hipStream_t stLong, hipStream_t stGiant);
+size_t ef_chunk_bytes();
 
 // BVGraph.store on the device (bv_encode.hip): device CSR -> .graph stream, bit offsets, .offsets stream, counters of the .properties file
 struct EncodeOut {

@@ -526,7 +526,8 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 
 // Device-pointer core of bvg_decode_range.  rowptr_dev: to-from+1 int64; succ_dev may be NULL (count only).
 // ---- EFGraph (bv_ef.hip): no references between records, so a job is outdegrees -> scan -> one decode pass
-constexpr int32_t EF_BIG_MIN = 256; // lists of that many successors are decoded by a wave each
+constexpr int32_t EF_BIG_MIN = 256;     // lists of that many successors are decoded by a wave each ...
+constexpr int32_t EF_GIANT_MIN = 2048; // ... and from here on by a wave per round of 64 words of upper bits
 
 bv::EfDev ef_dev(const Staged &s) {
 	return bv::EfDev{ (const uint64_t *)s.d_bits, (s.nwords + 1) / 2, s.d_offsets, s.info.nodes, (uint64_t)s.info.ef_upper_bound, s.info.ef_log2_quantum };
@@ -544,16 +545,31 @@ int ef_job(bvg_graph *g, const int32_t *d_nodes, int32_t from, int64_t cnt, int6
 		if (arcs_out) *arcs_out = 0;
 		return BVG_OK;
 	}
-	if (!g->outd.need(sizeof(int32_t) * (size_t)cnt) || !g->biglist.need(sizeof(int32_t) * (size_t)cnt) || !g->sums.need(sizeof(int64_t) * (size_t)(bv::scan_num_sums(cnt) + 1)))
+	if (!g->outd.need(sizeof(int32_t) * (size_t)cnt) || !g->sums.need(sizeof(int64_t) * (size_t)(bv::scan_num_sums(cnt) + 1)))
 		return fail(g, BVG_ENOMEM, "device scratch allocation failed");
 	int32_t *nbig = g->coopctl.as<int32_t>();
-	HIPCHK(g, hipMemsetAsync(nbig, 0, sizeof(int32_t), g->stream));
+	HIPCHK(g, hipMemsetAsync(nbig, 0, 2 * sizeof(int32_t), g->stream)); // [0] rounds of the giant lists (k_ef_rank)
 	const bv::EfDev gd = ef_dev(s);
-	bv::launch_ef_outdeg(gd, d_nodes, from, cnt, EF_BIG_MIN, g->outd.as<int32_t>(), g->biglist.as<int32_t>(), nbig, &dsm->err, g->stream);
+	bv::launch_ef_outdeg(gd, d_nodes, from, cnt, g->outd.as<int32_t>(), &dsm->err, g->stream);
 	bv::launch_scan(g->outd.as<int32_t>(), cnt, rowptr_dev, g->sums.as<int64_t>(), g->stream);
 	HIPCHK(g, hipMemcpyAsync(&dsm->total, rowptr_dev + cnt, sizeof(int64_t), hipMemcpyDeviceToDevice, g->stream));
-	if (succ_dev) bv::launch_ef_decode(gd, d_nodes, from, cnt, EF_BIG_MIN, g->biglist.as<int32_t>(), nbig, rowptr_dev, succ_dev, (uint64_t)succ_cap, &dsm->err, g->stream);
-	HIPCHK(g, hipMemsetAsync(nbig, 0, sizeof(int32_t), g->stream)); // (the BV jobs expect their control block zeroed)
+	if (succ_dev) { // the long lists on a side stream, next to the short ones
+		HIPCHK(g, hipEventRecord(g->evFork, g->stream));
+		HIPCHK(g, hipStreamWaitEvent(g->sideA, g->evFork, 0));
+		HIPCHK(g, hipStreamWaitEvent(g->sideB, g->evFork, 0));
+		// rounds of the giant lists: one per 64 words of the stream plus one per list when every list is asked for once (more queries
+		// for giant lists than that fits are decoded the slow way, k_ef_rank)
+		const uint64_t chunkCap64 = gd.nwords / 64 + (uint64_t)cnt / 16 + 64;
+		const uint32_t chunkCap = (uint32_t)std::min<uint64_t>(chunkCap64, 0x7fffffffu);
+		if (!g->arena.need((size_t)chunkCap * bv::ef_chunk_bytes())) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
+		bv::launch_ef_decode(gd, d_nodes, from, cnt, EF_BIG_MIN, rowptr_dev, succ_dev, (uint64_t)succ_cap, &dsm->err, EF_GIANT_MIN, g->arena.p, chunkCap, (uint32_t *)nbig, g->stream,
+		                     g->sideA, g->sideB);
+		HIPCHK(g, hipEventRecord(g->evA, g->sideA));
+		HIPCHK(g, hipStreamWaitEvent(g->stream, g->evA, 0));
+		HIPCHK(g, hipEventRecord(g->evB, g->sideB));
+		HIPCHK(g, hipStreamWaitEvent(g->stream, g->evB, 0));
+	}
+	HIPCHK(g, hipMemsetAsync(nbig, 0, 2 * sizeof(int32_t), g->stream)); // (the BV jobs expect their control block zeroed)
 	int rc = fetch_small(g);
 	if (rc) return rc;
 	g->last_arcs = (uint64_t)g->h_small->total;
@@ -958,7 +974,7 @@ extern "C" int bvg_outdegrees(bvg_t *g, int32_t from, int32_t to, int32_t *out, 
 	if (s.info.format == BVG_FORMAT_EF) {
 		if (!g->outd.need(sizeof(int32_t) * (size_t)cnt)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
 		HIPCHK(g, hipMemsetAsync(g->small.p, 0, sizeof(Small), g->stream));
-		bv::launch_ef_outdeg(ef_dev(s), nullptr, from, cnt, 0x7fffffff, g->outd.as<int32_t>(), nullptr, nullptr, &g->small.as<Small>()->err, g->stream);
+		bv::launch_ef_outdeg(ef_dev(s), nullptr, from, cnt, g->outd.as<int32_t>(), &g->small.as<Small>()->err, g->stream);
 		HIPCHK(g, hipMemcpyAsync(out, g->outd.p, sizeof(int32_t) * (size_t)cnt, (flags & BVG_OUT_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, g->stream));
 		int rc = fetch_small(g);
 		if (rc) return rc;
