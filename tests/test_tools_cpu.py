@@ -112,6 +112,10 @@ def test_parse_properties_like_the_reference(tmp_path):
     assert (i4.format, i4.nodes, i4.arcs, i4.ef_upper_bound, i4.ef_log2_quantum, i4.ef_big_endian, i4.offset_coding) == (B.BVG_FORMAT_EF, 5, 7, 5, 8, 0, 1)
     i5 = B.parse_properties(write("g", ef.replace("LITTLE", "BIG") + "upperbound=9\n"))
     assert (i5.ef_upper_bound, i5.ef_big_endian) == (9, 1)
+    # the binding's class name in graphclass (what INTEGRATION.md tells a user to put there): the other properties say which format
+    i6 = B.parse_properties(write("j", ok.replace("it.unimi.dsi.webgraph.BVGraph", "it.unimi.dsi.webgraph.gpu.GpuBVGraph")))
+    i7 = B.parse_properties(write("k", ef.replace("it.unimi.dsi.webgraph.EFGraph", "it.unimi.dsi.webgraph.gpu.GpuBVGraph")))
+    assert (i6.format, i6.window_size, i7.format, i7.ef_log2_quantum) == (B.BVG_FORMAT_BV, 7, B.BVG_FORMAT_EF, 8)
     with pytest.raises(ValueError):  # "Illegal quantum (must be a power of 2)", :745
         B.parse_properties(write("h", ef.replace("quantum=256", "quantum=255")))
     with pytest.raises(ValueError):  # "Unknown byte order", :750

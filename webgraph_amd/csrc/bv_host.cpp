@@ -130,6 +130,9 @@ int parse_properties(const std::string &basename, bvg_info_t &info, std::string 
 		const std::string big = "it.unimi.dsi.big.webgraph";
 		size_t at = c.find(big);
 		if (at != std::string::npos) c.replace(at, big.size(), "it.unimi.dsi.webgraph");
+		// the binding's own class (graphclass=it.unimi.dsi.webgraph.gpu.GpuBVGraph makes ImmutableGraph.load reflect on
+		// it): the files are a BVGraph's or an EFGraph's -- an EFGraph has a byteorder, a BVGraph a windowsize
+		if (c == "it.unimi.dsi.webgraph.gpu.GpuBVGraph") { std::string w; c = get("byteorder", w) ? "it.unimi.dsi.webgraph.EFGraph" : "it.unimi.dsi.webgraph.BVGraph"; }
 		if (c == "it.unimi.dsi.webgraph.EFGraph") { // EFGraph.loadInternal, EFGraph.java:709-750
 			long long t;
 			std::string w;
