@@ -72,6 +72,11 @@ def test_single_gpu_bench_line_prices_every_phase(tmp_path):
     assert copy["alg_bytes"] and copy["alg_bytes"] > 0 and copy["GBps"] > 0
     assert any(v["alg_bytes"] == r["kernel_algorithmic_bytes"] for v in r["kernels"].values())
     assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["cores"] == 1 and out["cpu_baseline"]["value"] > 0
+    # the side measurements on the same lists: the compressor on the device, the EFGraph scan -- each checked before it is timed
+    ex = out["extras"]
+    assert "error" not in ex["compress"] and "error" not in ex["efgraph_scan"]
+    assert ex["compress"]["parity"].startswith("streams byte-equal") and ex["compress"]["ms"] > 0
+    assert ex["efgraph_scan"]["parity"].startswith("rowptr and successors equal") and 0 < ex["efgraph_scan"]["frac_of_hbm_peak"] < 1
 
 
 @pytest.mark.timeout(1200)
