@@ -305,6 +305,16 @@ int bvg_store(const char *basename, int device, int32_t n, const int64_t *rowptr
 int bvg_recompress(bvg_t *g, const char *basename, int window, int max_ref_count, int min_interval, int zeta_k, uint32_t flags, int threads,
                    bvg_store_stats_t *stats, char *errbuf, size_t errlen);
 
+/* EFGraph.store(graph, upperBound, basename, log2Quantum, cacheSize, byteOrder, pl) (EFGraph.java:812-889; Accumulator :420-552) on the
+ * GPU: the CSR (as for bvg_store) becomes <basename>.graph (64-bit words, bits from the low end, in the byte order asked for),
+ * <basename>.offsets (delta-coded record lengths) and <basename>.properties with graphclass = it.unimi.dsi.webgraph.EFGraph.
+ * upper_bound: 0 = the number of nodes (the reference's default), otherwise >= n; log2_quantum: the reference's default is 8.
+ * Every piece of a record has a position that follows from the outdegree and the value: one lane per arc, one per forward pointer.
+ * bvg_recompress_ef: the same for a graph that is a handle of this library, in either format (BVGraph -> EFGraph on the device). */
+int bvg_store_ef(const char *basename, int device, int32_t n, const int64_t *rowptr, const int32_t *succ, int in_flags, int32_t upper_bound, int log2_quantum, int big_endian,
+                 char *errbuf, size_t errlen);
+int bvg_recompress_ef(bvg_t *g, const char *basename, int32_t upper_bound, int log2_quantum, int big_endian, char *errbuf, size_t errlen);
+
 /* ---- arc labels ----------------------------------------------------------------
  * labelling/BitStreamArcLabelledImmutableGraph.java:60-135: <basename>.properties names the underlying graph and the
  * label class (`underlyinggraph`, `labelspec`), <basename>.labels holds the labels of all arcs in enumeration order as

@@ -62,6 +62,12 @@ def main():
             best = min(best, time.perf_counter() - t0)
             assert rc == 0, rc
         print("%s: 10 M random lists (%d arcs) in %.2f ms = %.1f G edges/s" % (name, arcs.value, best * 1e3, arcs.value / best / 1e9))
+    # EFGraph.store on the device from the decoded CSR (BVGPU_ENC_TRACE=1 prints the device time; the call also writes the three files)
+    t0 = time.perf_counter()
+    B.store_ef(want_rp, want_sc, "/tmp/bvgpu_cache/ef_dev")
+    print("bvg_store_ef from HBM incl. copying back and writing 443 MB of files: %.2f s" % (time.perf_counter() - t0))
+    import filecmp
+    print("device writer's .graph equal to the CPU writer's:", filecmp.cmp("/tmp/bvgpu_cache/ef_dev.graph", ef + ".graph", shallow=False))
     g.close(); h.close()
 
 

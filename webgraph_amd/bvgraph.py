@@ -57,7 +57,7 @@ class BvgLabelsInfo(C.Structure):
 EXPORTS = ["bvg_open", "bvg_open_shard", "bvg_clone", "bvg_close", "bvg_info", "bvg_last_error", "bvg_set_stream", "bvg_sync",
            "bvg_outdegrees", "bvg_decode_range", "bvg_decode_range_view", "bvg_host_alloc", "bvg_host_free", "bvg_scan_checksum", "bvg_scan_stats", "bvg_bfs_expand", "bvg_hyperball_step", "bvg_successors_batch", "bvg_csr_hashcode", "bvg_shard_bounds",
            "bvg_parse_properties", "bvg_flags_from_string", "bvg_decode_offsets_host", "bvg_decode_offsets_device", "bvg_labels_open", "bvg_labels_close", "bvg_labels_info",
-           "bvg_labels_last_error", "bvg_labels_parse_properties", "bvg_labels_decode_range", "bvg_labels_decode_lists", "bvg_compress", "bvg_compressed_free", "bvg_compressed_copy", "bvg_store", "bvg_recompress", "bvg_set_profile", "bvg_get_profile", "bvg_debug_stats", "bvg_last_thresholds"]
+           "bvg_labels_last_error", "bvg_labels_parse_properties", "bvg_labels_decode_range", "bvg_labels_decode_lists", "bvg_compress", "bvg_compressed_free", "bvg_compressed_copy", "bvg_store", "bvg_recompress", "bvg_store_ef", "bvg_recompress_ef", "bvg_set_profile", "bvg_get_profile", "bvg_debug_stats", "bvg_last_thresholds"]
 
 _lib = None
 
@@ -118,6 +118,8 @@ def lib():
         L.bvg_compressed_copy.argtypes = [C.POINTER(BvgCompressed), i32, vp, vp, vp]
         L.bvg_store.argtypes = [C.c_char_p, C.c_int, i32, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.POINTER(BvgStoreStats), C.c_char_p, sz]
         L.bvg_recompress.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.POINTER(BvgStoreStats), C.c_char_p, sz]
+        L.bvg_store_ef.argtypes = [C.c_char_p, C.c_int, i32, vp, vp, C.c_int, i32, C.c_int, C.c_int, C.c_char_p, sz]
+        L.bvg_recompress_ef.argtypes = [vp, C.c_char_p, i32, C.c_int, C.c_int, C.c_char_p, sz]
         L.bvg_set_profile.argtypes = [vp, C.c_int]
         L.bvg_get_profile.argtypes = [vp, C.POINTER(C.c_float)]
         L.bvg_last_thresholds.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
@@ -168,6 +170,16 @@ def store(rowptr, succ, basename, windowSize=7, maxRefCount=3, minIntervalLength
     if rc:
         _raise(rc, err.value.decode("utf-8", "replace"))
     return st.as_dict()
+
+
+def store_ef(rowptr, succ, basename, upperBound=None, log2Quantum=8, bigEndian=False, device=0):
+    """EFGraph.store(graph, upperBound, basename, log2Quantum, cacheSize, byteOrder, pl) (EFGraph.java:812-889) for a CSR graph, on the GPU."""
+    n, rp, sp, fl, keep = _csr_ptrs(rowptr, succ)
+    err = C.create_string_buffer(512)
+    rc = lib().bvg_store_ef(os.fsencode(basename), device, n, rp, sp, fl, 0 if upperBound is None else upperBound, log2Quantum, 1 if bigEndian else 0, err, 512)
+    del keep
+    if rc:
+        _raise(rc, err.value.decode("utf-8", "replace"))
 
 
 def compress(rowptr, succ, windowSize=7, maxRefCount=3, minIntervalLength=4, zetaK=3, flags=0, numberOfThreads=1, device=0):
@@ -459,6 +471,13 @@ class BVGraph:
         if rc:
             _raise(rc, err.value.decode("utf-8", "replace"))
         return st.as_dict()
+
+    def store_ef(self, basename, upperBound=None, log2Quantum=8, bigEndian=False):
+        """EFGraph.store(this, basename, ...): decode and re-encode as an EFGraph without leaving the device."""
+        err = C.create_string_buffer(512)
+        rc = lib().bvg_recompress_ef(self._h, os.fsencode(basename), 0 if upperBound is None else upperBound, log2Quantum, 1 if bigEndian else 0, err, 512)
+        if rc:
+            _raise(rc, err.value.decode("utf-8", "replace"))
 
     def decode_range_device(self, lo, hi, rowptr_ptr, succ_ptr, succ_cap, asynchronous=False):
         """Device-pointer form: rowptr_ptr / succ_ptr are raw device addresses (e.g. torch.Tensor.data_ptr())."""

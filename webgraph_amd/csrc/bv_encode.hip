@@ -260,6 +260,31 @@ __global__ void __launch_bounds__(256) k_enc_offemit(const Params p, const int32
 }
 
 // ---------------------------------------------------------------------------------------------------------------- host
+// the .offsets stream of n record lengths (code 0: the offset of node 0), gamma or delta coded; *d_words_out is hipMalloc'ed
+int offsets_stream_device(int coding, const int32_t *d_reclen, int32_t n, uint32_t **d_words_out, uint64_t *bits_out, hipStream_t st) {
+	*d_words_out = nullptr; *bits_out = 0;
+	Params p{};
+	p.c_off = coding;
+	int32_t *offlen = nullptr;
+	int64_t *offat = nullptr, *sums = nullptr;
+	const size_t nn = (size_t)n + 1;
+	auto done = [&](int rc) { for (void *q : { (void *)offlen, (void *)offat, (void *)sums }) if (q) (void)hipFree(q); if (rc && *d_words_out) { (void)hipFree(*d_words_out); *d_words_out = nullptr; } return rc; };
+	if (hipMalloc((void **)&offlen, sizeof(int32_t) * nn) != hipSuccess || hipMalloc((void **)&offat, sizeof(int64_t) * (nn + 1)) != hipSuccess ||
+	    hipMalloc((void **)&sums, sizeof(int64_t) * (size_t)(scan_num_sums((int64_t)nn) + 1)) != hipSuccess) return done(-5);
+	const dim3 grid((unsigned)((nn + 255) / 256));
+	hipLaunchKernelGGL(k_enc_offlen, grid, dim3(256), 0, st, p, d_reclen, n, offlen);
+	launch_scan(offlen, (int64_t)nn, offat, sums, st);
+	int64_t offBits = 0;
+	if (hipMemcpyAsync(&offBits, offat + nn, sizeof(int64_t), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return done(-6);
+	const size_t ow = (size_t)((offBits + 31) / 32) + 8;
+	if (hipMalloc((void **)d_words_out, ow * 4) != hipSuccess) return done(-5);
+	(void)hipMemsetAsync(*d_words_out, 0, ow * 4, st);
+	hipLaunchKernelGGL(k_enc_offemit, grid, dim3(256), 0, st, p, d_reclen, offat, n, *d_words_out);
+	if (hipStreamSynchronize(st) != hipSuccess) return done(-6);
+	*bits_out = (uint64_t)offBits;
+	return done(0);
+}
+
 void encode_free(EncodeOut &o) {
 	for (void *q : { (void *)o.graph_words, (void *)o.off_words, (void *)o.offsets }) if (q) (void)hipFree(q);
 	o.graph_words = nullptr; o.off_words = nullptr; o.offsets = nullptr;

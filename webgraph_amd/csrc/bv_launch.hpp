@@ -117,6 +117,12 @@ void launch_ef_decode(const EfDev &g, const int32_t *nodes, int32_t lo, int64_t 
                       void *chunks, uint32_t chunkCap, uint32_t *nchunks, hipStream_t st, hipStream_t stLong, hipStream_t stGiant);
 size_t ef_chunk_bytes();
 
+// EFGraph.store on the device (bv_efw.hip): device CSR -> stream words (host order), record lengths, bit offsets; all hipMalloc'ed on success
+int ef_encode_device(int32_t n, const int64_t *d_rowptr, const int32_t *d_succ, uint64_t ub, int lq, uint64_t **d_words_out, uint64_t *nwords_out, uint64_t *bits_out,
+                     int32_t **d_reclen_out, int64_t **d_off_out, hipStream_t st);
+// the .offsets stream of n record lengths (bv_encode.hip), coding = BVG_GAMMA / BVG_DELTA numbering; *d_words_out hipMalloc'ed
+int offsets_stream_device(int coding, const int32_t *d_reclen, int32_t n, uint32_t **d_words_out, uint64_t *bits_out, hipStream_t st);
+
 // BVGraph.store on the device (bv_encode.hip): device CSR -> .graph stream, bit offsets, .offsets stream, counters of the .properties file
 struct EncodeOut {
 	uint32_t *graph_words = nullptr; // big-endian words = the bytes of <basename>.graph, zero padded (+ >= 8 zero words)

@@ -10,7 +10,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -189,6 +191,98 @@ extern "C" int bvg_recompress(bvg_t *g, const char *basename, int window, int ma
 	rc = bvg_decode_range(g, 0, info.nodes, d_rowptr, d_succ, m, &arcs, BVG_OUT_DEVICE);
 	if (rc) sfail(errbuf, errlen, rc, bvg_last_error(g));
 	else rc = bvg_store(basename, info.device, info.nodes, d_rowptr, d_succ, BVG_OUT_DEVICE, window, max_ref_count, min_interval, zeta_k, flags, threads, stats, errbuf, errlen);
+	(void)hipFree(d_rowptr); (void)hipFree(d_succ);
+	return rc;
+}
+
+// ---- EFGraph.store on the device (bv_efw.hip)
+namespace {
+int store_ef_impl(const char *basename, int device, int32_t n, const int64_t *d_rowptr, const int32_t *d_succ, uint64_t m, int32_t upper_bound, int log2_quantum, int big_endian,
+                  std::string &err) {
+	uint64_t *d_words = nullptr, nwords = 0, bits = 0, obits = 0;
+	int32_t *d_reclen = nullptr;
+	int64_t *d_off = nullptr;
+	uint32_t *d_ow = nullptr;
+	auto release = [&]() { for (void *q : { (void *)d_words, (void *)d_reclen, (void *)d_off, (void *)d_ow }) if (q) (void)hipFree(q); };
+	const auto t0 = std::chrono::steady_clock::now();
+	int rc = bv::ef_encode_device(n, d_rowptr, d_succ, (uint64_t)upper_bound, log2_quantum, &d_words, &nwords, &bits, &d_reclen, &d_off, nullptr);
+	if (getenv("BVGPU_ENC_TRACE")) fprintf(stderr, "[bvgpu enc] EFGraph: CSR in HBM -> stream in HBM %.3f ms (%llu bits, rc %d)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), (unsigned long long)bits, rc);
+	if (rc) {
+		err = rc == -1 ? "successor lists must be strictly increasing, non-negative and below the upper bound" : rc == -3 ? "a record of 2^31 bits or more" : rc == -5 ? "device allocation failed" : "the EFGraph kernels failed";
+		return rc == -1 ? BVG_EARG : rc == -3 ? BVG_EUNSUPPORTED : rc == -5 ? BVG_ENOMEM : BVG_EHIP;
+	}
+	rc = bv::offsets_stream_device(BVG_DELTA, d_reclen, n, &d_ow, &obits, nullptr); // offsets.writeLongDelta, EFGraph.java:830, :855
+	if (rc) { release(); err = "the offsets kernels failed"; return rc == -5 ? BVG_ENOMEM : BVG_EHIP; }
+	std::vector<uint8_t> graph((size_t)nwords * 8), offs((size_t)((obits + 7) / 8));
+	// bits of the outdegrees: gamma(d) = 2 * msb(d + 1) + 1; the rest of every record is successors (:866-888 persists both)
+	std::vector<int64_t> rp((size_t)n + 1);
+	if (hipMemcpy(graph.data(), d_words, graph.size(), hipMemcpyDeviceToHost) != hipSuccess || (!offs.empty() && hipMemcpy(offs.data(), d_ow, offs.size(), hipMemcpyDeviceToHost) != hipSuccess) ||
+	    hipMemcpy(rp.data(), d_rowptr, sizeof(int64_t) * rp.size(), hipMemcpyDeviceToHost) != hipSuccess) { release(); err = "copying the streams back failed"; return BVG_EHIP; }
+	release();
+	if (big_endian) for (size_t i = 0; i + 8 <= graph.size(); i += 8) { std::swap(graph[i], graph[i + 7]); std::swap(graph[i + 1], graph[i + 6]); std::swap(graph[i + 2], graph[i + 5]); std::swap(graph[i + 3], graph[i + 4]); }
+	uint64_t bitsOutd = 0;
+	for (int32_t x = 0; x < n; x++) bitsOutd += 2 * (uint64_t)(63 - __builtin_clzll((unsigned long long)(rp[(size_t)x + 1] - rp[(size_t)x] + 1))) + 1;
+	const std::string base(basename);
+	if (!write_bytes(base + ".graph", graph) || !write_bytes(base + ".offsets", offs)) { err = "cannot write " + base + ".graph / .offsets"; return BVG_EIO; }
+	if (!bvprops::write_ef(base + ".properties", n, m, upper_bound, log2_quantum, big_endian != 0, nwords * 64, bitsOutd, bits - bitsOutd)) { err = "cannot write " + base + ".properties"; return BVG_EIO; }
+	return BVG_OK;
+}
+} // namespace
+
+extern "C" int bvg_store_ef(const char *basename, int device, int32_t n, const int64_t *rowptr, const int32_t *succ, int in_flags, int32_t upper_bound, int log2_quantum, int big_endian,
+                            char *errbuf, size_t errlen) {
+	if (!basename || n < 0 || !rowptr) return sfail(errbuf, errlen, BVG_EARG, "null argument or negative node count");
+	if (upper_bound == 0) upper_bound = n; // EFGraph.store(graph, basename): the number of nodes (:808-810)
+	if (upper_bound < n || log2_quantum < 0 || log2_quantum > 62) return sfail(errbuf, errlen, BVG_EARG, "upper bound below the number of nodes, or a negative quantum"); // :814
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return sfail(errbuf, errlen, BVG_EHIP, "no HIP device available (libbvgpu has no CPU fallback)");
+	if (device < 0 || device >= ndev) return sfail(errbuf, errlen, BVG_EARG, "no such HIP device");
+	if (hipSetDevice(device) != hipSuccess) return sfail(errbuf, errlen, BVG_EHIP, "hipSetDevice failed");
+	const bool dev = (in_flags & BVG_OUT_DEVICE) != 0;
+	int64_t *d_rowptr = const_cast<int64_t *>(rowptr);
+	int32_t *d_succ = const_cast<int32_t *>(succ);
+	int64_t m = 0;
+	auto release = [&]() { if (!dev) { if (d_rowptr) (void)hipFree(d_rowptr); if (d_succ) (void)hipFree(d_succ); } };
+	if (dev) {
+		int64_t ends[2] = { 0, 0 };
+		if (hipMemcpy(&ends[0], rowptr, sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(&ends[1], rowptr + n, sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess) return sfail(errbuf, errlen, BVG_EHIP, "reading rowptr failed");
+		if (ends[0] != 0 || ends[1] < 0) return sfail(errbuf, errlen, BVG_EARG, "rowptr must start at 0 and be monotone");
+		m = ends[1];
+	} else {
+		if (rowptr[0] != 0) return sfail(errbuf, errlen, BVG_EARG, "rowptr must start at 0 and be monotone");
+		for (int32_t x = 0; x < n; x++) if (rowptr[x + 1] < rowptr[x]) return sfail(errbuf, errlen, BVG_EARG, "rowptr must start at 0 and be monotone");
+		m = rowptr[n];
+		d_rowptr = nullptr; d_succ = nullptr;
+		if (hipMalloc((void **)&d_rowptr, sizeof(int64_t) * ((size_t)n + 1)) != hipSuccess || hipMalloc((void **)&d_succ, sizeof(int32_t) * (size_t)(m ? m : 1)) != hipSuccess) { release(); (void)hipGetLastError(); return sfail(errbuf, errlen, BVG_ENOMEM, "device allocation failed"); }
+		if (hipMemcpy(d_rowptr, rowptr, sizeof(int64_t) * ((size_t)n + 1), hipMemcpyHostToDevice) != hipSuccess || (m && hipMemcpy(d_succ, succ, sizeof(int32_t) * (size_t)m, hipMemcpyHostToDevice) != hipSuccess)) { release(); return sfail(errbuf, errlen, BVG_EHIP, "staging the graph failed"); }
+	}
+	if (m && !succ) { release(); return sfail(errbuf, errlen, BVG_EARG, "null successor array"); }
+	std::string err;
+	const int rc = store_ef_impl(basename, device, n, d_rowptr, d_succ, (uint64_t)m, upper_bound, log2_quantum, big_endian, err);
+	release();
+	return rc ? sfail(errbuf, errlen, rc, err) : BVG_OK;
+}
+
+// EFGraph.store(graph, basename) for a graph that is a handle of this library (either format): decode into HBM, encode from there
+extern "C" int bvg_recompress_ef(bvg_t *g, const char *basename, int32_t upper_bound, int log2_quantum, int big_endian, char *errbuf, size_t errlen) {
+	if (!g || !basename) return sfail(errbuf, errlen, BVG_EARG, "null argument");
+	bvg_info_t info;
+	int rc = bvg_info(g, &info);
+	if (rc) return sfail(errbuf, errlen, rc, bvg_last_error(g));
+	if (info.shard_from != 0 || info.shard_to != info.nodes) return sfail(errbuf, errlen, BVG_EUNSUPPORTED, "a shard handle holds a slice of the graph: recompress from a whole-graph handle");
+	if (hipSetDevice(info.device) != hipSuccess) return sfail(errbuf, errlen, BVG_EHIP, "hipSetDevice failed");
+	int64_t *d_rowptr = nullptr;
+	int32_t *d_succ = nullptr;
+	const size_t m = (size_t)info.arcs;
+	if (hipMalloc((void **)&d_rowptr, sizeof(int64_t) * ((size_t)info.nodes + 1)) != hipSuccess || hipMalloc((void **)&d_succ, sizeof(int32_t) * (m ? m : 1)) != hipSuccess) {
+		if (d_rowptr) (void)hipFree(d_rowptr);
+		(void)hipGetLastError();
+		return sfail(errbuf, errlen, BVG_ENOMEM, "device allocation failed");
+	}
+	uint64_t arcs = 0;
+	rc = bvg_decode_range(g, 0, info.nodes, d_rowptr, d_succ, m, &arcs, BVG_OUT_DEVICE);
+	if (rc) sfail(errbuf, errlen, rc, bvg_last_error(g));
+	else rc = bvg_store_ef(basename, info.device, info.nodes, d_rowptr, d_succ, BVG_OUT_DEVICE, upper_bound, log2_quantum, big_endian, errbuf, errlen);
 	(void)hipFree(d_rowptr); (void)hipFree(d_succ);
 	return rc;
 }

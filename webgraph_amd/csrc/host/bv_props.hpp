@@ -3,6 +3,7 @@
 #pragma once
 #include <stdint.h>
 
+#include <cmath>
 #include <cstdio>
 #include <string>
 
@@ -46,6 +47,26 @@ inline bool write(const std::string &path, int32_t n, uint64_t m, int window, in
 	        (unsigned long long)st.bits_outdegrees, (unsigned long long)st.bits_references, (unsigned long long)st.bits_blocks,
 	        (unsigned long long)st.bits_residuals, (unsigned long long)st.bits_intervals);
 	fprintf(f, "graphclass=it.unimi.dsi.webgraph.BVGraph\nversion=0\n");
+	const bool ok = !ferror(f);
+	return fclose(f) == 0 && ok;
+}
+
+// the .properties file EFGraph.store writes (EFGraph.java:866-888)
+inline bool write_ef(const std::string &path, int32_t n, uint64_t m, int32_t upper_bound, int log2_quantum, bool big_endian, uint64_t written_bits, uint64_t bits_outdegrees,
+                     uint64_t bits_successors) {
+	FILE *f = fopen(path.c_str(), "w");
+	if (!f) return false;
+	auto stirling = [](double v) { return v * std::log(v) - v + 0.5 * std::log(2 * 3.14159265358979323846 * v); }; // :804-806
+	fprintf(f, "#EFGraph properties\n");
+	fprintf(f, "nodes=%d\narcs=%llu\n", n, (unsigned long long)m);
+	if (upper_bound != n) fprintf(f, "upperbound=%d\n", upper_bound);
+	fprintf(f, "quantum=%llu\nbyteorder=%s\n", 1ull << log2_quantum, big_endian ? "BIG_ENDIAN" : "LITTLE_ENDIAN");
+	fprintf(f, "bitsperlink=%s\n", fmt3(m ? (double)written_bits / m : 0).c_str());
+	if (n > 0 && m > 0 && (double)n * n > (double)m)
+		fprintf(f, "compratio=%s\n", fmt3(written_bits * std::log(2.0) / (stirling((double)n * n) - stirling((double)m) - stirling((double)n * n - (double)m))).c_str());
+	fprintf(f, "bitspernode=%s\navgbitsforoutdegrees=%s\n", fmt3(n ? (double)written_bits / n : 0).c_str(), fmt3(n ? (double)bits_outdegrees / n : 0).c_str());
+	fprintf(f, "bitsforoutdegrees=%llu\nbitsforsuccessors=%llu\n", (unsigned long long)bits_outdegrees, (unsigned long long)bits_successors);
+	fprintf(f, "graphclass=it.unimi.dsi.webgraph.EFGraph\nversion=0\n");
 	const bool ok = !ferror(f);
 	return fclose(f) == 0 && ok;
 }

@@ -596,18 +596,6 @@ extern "C" int bvt_store_ef(const char *basename, int32_t n, const int64_t *rowp
 	}
 	if (!offs.write_file(base + ".offsets")) return -EIO;
 	const uint64_t m = n ? (uint64_t)rowptr[n] : 0, written = (uint64_t)graph.w.size() * 64;
-	FILE *f = fopen((base + ".properties").c_str(), "w");
-	if (!f) return -EIO;
-	auto stirling = [](double v) { return v * std::log(v) - v + 0.5 * std::log(2 * M_PI * v); }; // :804-806
-	fprintf(f, "#EFGraph properties\n");
-	fprintf(f, "nodes=%d\narcs=%llu\n", n, (unsigned long long)m);
-	if (upper_bound != n) fprintf(f, "upperbound=%d\n", upper_bound);
-	fprintf(f, "quantum=%llu\nbyteorder=%s\n", (unsigned long long)quantum, big_endian ? "BIG_ENDIAN" : "LITTLE_ENDIAN");
-	fprintf(f, "bitsperlink=%s\n", bvprops::fmt3(m ? (double)written / m : 0).c_str());
-	if (n > 0 && m > 0 && (double)n * n > (double)m) fprintf(f, "compratio=%s\n", bvprops::fmt3(written * std::log(2.0) / (stirling((double)n * n) - stirling((double)m) - stirling((double)n * n - (double)m))).c_str());
-	fprintf(f, "bitspernode=%s\navgbitsforoutdegrees=%s\n", bvprops::fmt3(n ? (double)written / n : 0).c_str(), bvprops::fmt3(n ? (double)bitsOutd / n : 0).c_str());
-	fprintf(f, "bitsforoutdegrees=%llu\nbitsforsuccessors=%llu\n", (unsigned long long)bitsOutd, (unsigned long long)bitsSucc);
-	fprintf(f, "graphclass=it.unimi.dsi.webgraph.EFGraph\nversion=0\n");
-	fclose(f);
+	if (!bvprops::write_ef(base + ".properties", n, m, upper_bound, log2_quantum, big_endian != 0, written, bitsOutd, bitsSucc)) return -EIO;
 	return 0;
 }
