@@ -254,8 +254,50 @@ BVE_HD uint32_t pair_cost(const Params &p, const int64_t *__restrict__ rowptr, c
 // Phase B for the nodes [lo, hi) of one chunk: the reference's choice (first candidate of minimal cost among those whose
 // chain is shorter than maxRefCount, :2313-2327) given the chain lengths of the W nodes before lo in `inState`
 // (inState[W - t] = chain length of node lo - t).  Writes best[x] (0 = none) and refc[x] for every node with successors.
+struct alignas(16) Cost4 { uint32_t v[4]; };
+BVE_HD Cost4 load_cost4(const uint32_t *q) { // q is 16-byte aligned on the device (hipMalloc + rows of 32 bytes); the host model may get any pointer
+#if defined(__HIP_DEVICE_COMPILE__)
+	return *(const Cost4 *)q;
+#else
+	Cost4 c;
+	for (int i = 0; i < 4; i++) c.v[i] = q[i];
+	return c;
+#endif
+}
+// windowsize 7 (the reference's default: 8 candidates, a row of prices is two 16-byte loads): the chain lengths of the last 7 nodes
+// live in registers and the next node's prices are on their way while this node chooses -- the walk is a chain of dependent steps,
+// and with a global load per candidate it took about a microsecond per node.  A node without successors is one whose r = 0 price
+// is COST_NONE.  Same choices as the general loop below.
+BVE_HD void select_chunk_w7(const Params &p, const uint32_t *__restrict__ cost, int32_t lo, int32_t hi, const int32_t *__restrict__ inState, uint8_t *__restrict__ best,
+                            int32_t *__restrict__ refc) {
+	int32_t w0 = inState[6], w1 = inState[5], w2 = inState[4], w3 = inState[3], w4 = inState[2], w5 = inState[1], w6 = inState[0]; // w_t: chain length of node x - 1 - t
+	const int32_t R = p.R;
+	if (lo >= hi) return;
+	Cost4 a = load_cost4(cost + (int64_t)lo * 8), b = load_cost4(cost + (int64_t)lo * 8 + 4);
+	for (int32_t x = lo; x < hi; x++) {
+		const Cost4 ca = a, cb = b;
+		if (x + 1 < hi) { a = load_cost4(cost + (int64_t)(x + 1) * 8); b = load_cost4(cost + (int64_t)(x + 1) * 8 + 4); }
+		int bestR = 0;
+		int32_t rc = 0;
+		if (ca.v[0] != COST_NONE) {
+			uint32_t bc = ca.v[0];
+			if (ca.v[1] < bc && w0 < R) { bc = ca.v[1]; bestR = 1; rc = w0 + 1; }
+			if (ca.v[2] < bc && w1 < R) { bc = ca.v[2]; bestR = 2; rc = w1 + 1; }
+			if (ca.v[3] < bc && w2 < R) { bc = ca.v[3]; bestR = 3; rc = w2 + 1; }
+			if (cb.v[0] < bc && w3 < R) { bc = cb.v[0]; bestR = 4; rc = w3 + 1; }
+			if (cb.v[1] < bc && w4 < R) { bc = cb.v[1]; bestR = 5; rc = w4 + 1; }
+			if (cb.v[2] < bc && w5 < R) { bc = cb.v[2]; bestR = 6; rc = w5 + 1; }
+			if (cb.v[3] < bc && w6 < R) { bc = cb.v[3]; bestR = 7; rc = w6 + 1; }
+		}
+		best[x] = (uint8_t)bestR;
+		refc[x] = rc;
+		w6 = w5; w5 = w4; w4 = w3; w3 = w2; w2 = w1; w1 = w0; w0 = rc;
+	}
+}
+
 BVE_HD void select_chunk(const Params &p, const int64_t *__restrict__ rowptr, const uint32_t *__restrict__ cost, int32_t lo, int32_t hi,
                          const int32_t *__restrict__ inState, uint8_t *__restrict__ best, int32_t *__restrict__ refc) {
+	if (p.W == 7) { select_chunk_w7(p, cost, lo, hi, inState, best, refc); return; }
 	const int cyc = p.W + 1;
 	for (int32_t x = lo; x < hi; x++) {
 		if (rowptr[x + 1] == rowptr[x]) { best[x] = 0; refc[x] = 0; continue; }
