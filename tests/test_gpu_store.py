@@ -133,13 +133,18 @@ def _shaped_graph(rng, n=3000):
     return rowptr, succ
 
 
+@pytest.mark.parametrize("seg", [None, (8, 100), (8, 37)])
 @pytest.mark.parametrize("W,R,I", [(7, 3, 4), (7, 3, 2), (3, 2, 100), (7, 3, 0), (7, 8, 65), (1, 1, 3)])
-def test_store_shapes_that_stress_the_wave_walk(tmp_path, monkeypatch, W, R, I):
+def test_store_shapes_that_stress_the_wave_walk(tmp_path, monkeypatch, W, R, I, seg):
     """Pairs of 128 elements or more are priced and written by whole waves (bv_encode_wave.hpp): runs and blocks that span tiles,
-    minIntervalLength below / at / above the tile size.  BVGPU_ENC_VERIFY makes the library price those pairs lane by lane too."""
+    minIntervalLength below / at / above the tile size; and with every such pair cut into short segments that are priced independently and
+    stitched (what the library does to pairs of 2^15 elements or more).  BVGPU_ENC_VERIFY makes the library price those pairs lane by lane too."""
     from webgraph_amd import bvgraph as B
     from webgraph_amd import tools as T
     monkeypatch.setenv("BVGPU_ENC_VERIFY", "1")
+    if seg:  # every pair the waves take is cut into segments of ~100 / ~37 elements (the default cuts pairs of 2^15 elements into 8192s)
+        monkeypatch.setenv("BVGPU_ENC_SEGBIN", str(seg[0]))
+        monkeypatch.setenv("BVGPU_ENC_SEGELEMS", str(seg[1]))
     rowptr, succ = _shaped_graph(np.random.Generator(np.random.PCG64(100 + W + I)))
     cpu, gpu = str(tmp_path / "cpu"), str(tmp_path / "gpu")
     st_cpu = T.store(cpu, rowptr, succ, window=W, max_ref_count=R, min_interval=I, threads=1)

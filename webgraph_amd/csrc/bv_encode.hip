@@ -22,6 +22,7 @@
 #include "bv_encode_wave.hpp"
 #include "bv_launch.hpp"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -34,6 +35,8 @@ using bve::Params;
 constexpr int SEL_CHUNK = 64; // nodes per chunk of the selection recurrence
 constexpr int SEL_SPAN = 16, SEL_BATCH = 8;
 constexpr int ENC_MAX_W = 63; // state of a chunk boundary: W chain lengths
+
+struct EncStatsDev { unsigned long long v[12]; }; // bitsOutd, bitsRef, bitsBlocks, bitsIntervals, bitsResiduals, copied, intervalised, residuals, totRef, totDist, maxRef, -
 
 // ---- work lists: the items of a phase (pairs, nodes) grouped by the log2 of their size, biggest first.  A lane walks its
 // item alone, so a wave lasts as long as its longest item: waves of like-sized items waste no lane-time, and the long ones
@@ -88,12 +91,15 @@ __global__ void __launch_bounds__(256) k_enc_hist(const Items it, uint32_t *__re
 }
 // cursor[b] = first list slot of bin b, bins in descending order; cursor[ENC_NBIN] = number of listed items
 // cursor[ENC_NBIN + 1] = items of the bins >= bigBin (the head of the list): those go to whole waves
-__global__ void k_enc_bases(const uint32_t *__restrict__ hist, uint32_t *__restrict__ cursor, int bigBin) {
+// cursor[ENC_NBIN + 2] = of those, the items of the bins >= segBin (the very head): pairs that are cut into segments
+__global__ void k_enc_bases(const uint32_t *__restrict__ hist, uint32_t *__restrict__ cursor, int bigBin, int segBin) {
 	if (threadIdx.x != 0 || blockIdx.x != 0) return;
 	uint32_t run = 0;
-	for (int b = ENC_NBIN - 1; b >= 0; b--) { if (b == bigBin - 1) cursor[ENC_NBIN + 1] = run; cursor[b] = run; run += hist[b]; }
+	cursor[ENC_NBIN + 2] = 0;
+	for (int b = ENC_NBIN - 1; b >= 0; b--) { if (b == bigBin - 1) cursor[ENC_NBIN + 1] = run; if (b == segBin - 1) cursor[ENC_NBIN + 2] = run; cursor[b] = run; run += hist[b]; }
 	cursor[ENC_NBIN] = run;
 	if (bigBin <= 0) cursor[ENC_NBIN + 1] = run;
+	if (segBin <= 0 || segBin < bigBin) cursor[ENC_NBIN + 2] = 0; // (only pairs the waves take can be cut)
 }
 template <class Items>
 __global__ void __launch_bounds__(256) k_enc_scatter(const Items it, uint32_t *__restrict__ cursor, uint32_t *__restrict__ list, uint32_t *__restrict__ none) {
@@ -136,7 +142,7 @@ template <bool DEF>
 __global__ void __launch_bounds__(256) k_enc_cost_wave(const Params p, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ, const uint32_t *__restrict__ list,
                                                        const uint32_t *__restrict__ total, uint32_t *__restrict__ cost, bvw::PairInfo *__restrict__ info, int *__restrict__ err) {
 	const int64_t nbig = total[1], stride = (int64_t)gridDim.x * 4;
-	for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < nbig; t += stride) {
+	for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6) + total[2]; t < nbig; t += stride) { // (the first total[2] pairs are cut into segments: k_seg_*)
 		const int64_t q = list[t];
 		const int cyc = p.W + 1;
 		const int32_t x = (int32_t)(q / cyc);
@@ -149,6 +155,183 @@ __global__ void __launch_bounds__(256) k_enc_cost_wave(const Params p, const int
 			info[t] = bvw::PairInfo{ wt.nb, (uint32_t)wt.bitsB, wt.ni | (wt.nextra > 0 ? 0x80000000u : 0u), (uint32_t)wt.bitsI }; // (sections of 2^31 bits: c = COST_NONE, error raised)
 			if (e) atomicOr(err, e);
 		}
+	}
+}
+
+// ---- the longest pairs, cut into segments.  A pair of 2^15 elements or more is some thousands of rounds of one wave (C2 has
+// pairs of 4 * 10^5: 13 ms of pricing, 18 ms of emission, each the tail of its kernel).  Its lists are cut at values where no
+// run of consecutive successors crosses (k_seg_plan): then a segment is an independent walk except for what it inherits -- the
+// copy run in progress, the previous residual, the previous interval's end, and how much of each section precedes it.  Every
+// segment is first walked in SEG mode (k_seg_count: everything priced but the three items that depend on the predecessors), a
+// lane stitches the segments of a pair in order (k_seg_compose: the pair's price and section sizes, and every segment's
+// inherited state and section offsets), and the emission walks the segments again with that state (k_seg_emit).
+constexpr int SEG_ELEMS = 8192, SEG_BIN = 16, SEG_MAX = 64;
+struct Seg { uint32_t pair; int32_t ja, jb, ka, kb; }; // segment = cur[ja, jb) x ref[ka, kb) of pair list[pair]
+struct SegSum {
+	int32_t firstFlag, lastFlag, nextra, bad;
+	uint32_t nb, nr, ni, pad;
+	int64_t firstChange, lastChange, firstRes, lastRes, firstLeft, lastEnd; // (changes: indices relative to ka)
+	uint64_t bitsB, bitsI, bitsR, ivArcs;
+};
+struct SegIn { uint32_t prevFlag, nb, nr, ni; int64_t runStart, prevRes, prevEnd; uint64_t offB, offI, offR; }; // runStart relative to ka
+struct SegPair { uint32_t segBase, nseg, nr; int32_t nextra; uint64_t bitsR, ivArcs; };
+
+__global__ void __launch_bounds__(256) k_seg_plan(const Params p, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ, const uint32_t *__restrict__ list,
+                                                  const uint32_t *__restrict__ total, int segElems, Seg *__restrict__ segs, uint32_t segCap, uint32_t *__restrict__ nsegs, SegPair *__restrict__ pairs, int *__restrict__ err) {
+	const int lane = threadIdx.x & 63;
+	const int64_t ng = total[2], stride = (int64_t)gridDim.x * 4;
+	const int cyc = p.W + 1;
+	for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < ng; t += stride) {
+		const int64_t q = list[t];
+		const int32_t x = (int32_t)(q / cyc);
+		const int r = (int)(q - (int64_t)x * cyc);
+		const int64_t a = rowptr[x], b = rowptr[x - r];
+		const int32_t d = (int32_t)(rowptr[x + 1] - a), dr = r == 0 ? 0 : (int32_t)(rowptr[x - r + 1] - b);
+		const int32_t *cur = succ + a, *ref = succ + b;
+		const int64_t size = (int64_t)d + dr;
+		const int nseg = (int)((size + segElems - 1) / segElems < SEG_MAX ? (size + segElems - 1) / segElems : SEG_MAX);
+		// cut s (lane s, 0 < s < nseg): the first index at or after the nominal one where cur does not continue a run of consecutive ids
+		int32_t j = lane == 0 ? 0 : d, k = lane == 0 ? 0 : dr;
+		if (lane > 0 && lane < nseg) {
+			j = (int32_t)((int64_t)d * lane / nseg);
+			while (j > 0 && j < d && (int64_t)cur[j] == (int64_t)cur[j - 1] + 1) j++;
+			if (j < d) { int32_t lo = 0, hi = dr; const int32_t v = cur[j]; while (lo < hi) { const int32_t mid = (int32_t)(((int64_t)lo + hi) >> 1); if (ref[mid] < v) lo = mid + 1; else hi = mid; } k = lo; }
+		}
+		const int32_t jn = __shfl_down(j, 1), kn = __shfl_down(k, 1); // lanes >= nseg hold (d, dr): lane nseg - 1 ends there
+		uint32_t base = 0;
+		if (lane == 0) base = atomicAdd(nsegs, (uint32_t)nseg);
+		base = __shfl(base, 0);
+		if ((uint64_t)base + nseg > segCap) { if (lane == 0) { atomicOr(err, 4); pairs[t] = SegPair{ 0, 0, 0, 0, 0, 0 }; } continue; }
+		if (lane < nseg) segs[base + lane] = Seg{ (uint32_t)t, j, lane == nseg - 1 ? d : jn, k, lane == nseg - 1 ? dr : kn };
+		if (lane == 0) pairs[t] = SegPair{ base, (uint32_t)nseg, 0, 0, 0, 0 };
+	}
+}
+
+template <bool DEF>
+__global__ void __launch_bounds__(256) k_seg_count(const Params p, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ, const uint32_t *__restrict__ list,
+                                                   const Seg *__restrict__ segs, const uint32_t *__restrict__ nsegs, uint32_t segCap, SegSum *__restrict__ sums) {
+	const int64_t n = *nsegs < segCap ? *nsegs : segCap, stride = (int64_t)gridDim.x * 4;
+	const int cyc = p.W + 1;
+	for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += stride) {
+		const Seg sg = segs[i];
+		const int64_t q = list[sg.pair];
+		const int32_t x = (int32_t)(q / cyc);
+		const int r = (int)(q - (int64_t)x * cyc);
+		const int32_t *cur = succ + rowptr[x] + sg.ja, *ref = succ + rowptr[x - r] + sg.ka;
+		bvw::WaveWalk<DEF, false, true> w(p, x, nullptr, 0, 0, 0);
+		bvw::WaveTotals t;
+		w.run(cur, sg.jb - sg.ja, ref, r == 0 ? 0 : sg.kb - sg.ka, t);
+		if ((threadIdx.x & 63) == 0)
+			sums[i] = SegSum{ w.firstFlag, (int32_t)w.prevFlag, t.nextra, t.bad, t.nb, t.nr, t.ni, 0, w.firstChange, w.runStart, w.firstRes, w.prevRes, w.firstLeft, w.prevEnd,
+			                  t.bitsB, t.bitsI, t.bitsR, t.ivArcs };
+	}
+}
+
+// one lane per cut pair: its segments in order
+template <bool DEF>
+__global__ void __launch_bounds__(64) k_seg_compose(const Params p, const uint32_t *__restrict__ list, const uint32_t *__restrict__ total, const Seg *__restrict__ segs,
+                                                    const SegSum *__restrict__ sums, SegIn *__restrict__ ins, SegPair *__restrict__ pairs, uint32_t *__restrict__ cost,
+                                                    bvw::PairInfo *__restrict__ info, int *__restrict__ err) {
+	const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
+	if (t >= total[2]) return;
+	const int cyc = p.W + 1;
+	const int64_t q = list[t];
+	const int32_t x = (int32_t)(q / cyc);
+	const int r = (int)(q - (int64_t)x * cyc);
+	SegPair sp = pairs[t];
+	uint32_t prevFlag = 1, nb = 0, nr = 0, ni = 0;
+	int64_t runStart = 0, prevRes = 0, prevEnd = 0, nextra = 0;
+	uint64_t bitsB = 0, bitsI = 0, bitsR = 0, ivArcs = 0;
+	int bad = sp.nseg == 0 ? 4 : 0;
+	auto lenBlk = [&](int64_t len) { bve::LenSink s; bve::f_blk<DEF>(s, p, (uint64_t)(nb == 0 ? len : len - 1)); return s.bits; };
+	for (uint32_t i = 0; i < sp.nseg; i++) {
+		const Seg sg = segs[sp.segBase + i];
+		const SegSum sm = sums[sp.segBase + i];
+		ins[sp.segBase + i] = SegIn{ prevFlag, nb, nr, ni, runStart - sg.ka, prevRes, prevEnd, bitsB, bitsI, bitsR };
+		if (r != 0 && sg.kb > sg.ka) {
+			if ((uint32_t)sm.firstFlag != prevFlag) { bitsB += lenBlk((int64_t)sg.ka - runStart); nb++; runStart = sg.ka; } // the flag changes where the segment begins
+			if (sm.nb > 0) {
+				bitsB += lenBlk((int64_t)sg.ka + sm.firstChange - runStart); nb++;
+				nb += sm.nb - 1; bitsB += sm.bitsB;
+				runStart = (int64_t)sg.ka + sm.lastChange;
+			}
+			prevFlag = (uint32_t)sm.lastFlag;
+		}
+		if (sm.ni > 0) {
+			bve::LenSink s;
+			bve::w_gamma(s, ni == 0 ? bve::int2nat(sm.firstLeft - x) : (uint64_t)(sm.firstLeft - prevEnd - 1));
+			bitsI += s.bits + sm.bitsI; ni += sm.ni; prevEnd = sm.lastEnd;
+		}
+		if (sm.nr > 0) {
+			bve::LenSink s;
+			bve::f_res<DEF>(s, p, nr == 0 ? bve::int2nat(sm.firstRes - x) : (uint64_t)(sm.firstRes - prevRes - 1));
+			bitsR += s.bits + sm.bitsR; nr += sm.nr; prevRes = sm.lastRes;
+		}
+		nextra += sm.nextra; ivArcs += sm.ivArcs; bad |= sm.bad;
+	}
+	bve::LenSink s;
+	if (p.W > 0) bve::f_ref<DEF>(s, p, (uint64_t)r);
+	if (r != 0) bve::f_bc<DEF>(s, p, nb);
+	if (nextra > 0 && p.I != 0) bve::w_gamma(s, ni);
+	const uint64_t tot = s.bits + (r != 0 ? bitsB : 0) + bitsI + bitsR;
+	if (bad & 1) atomicOr(err, 1);
+	if (bad & 4) atomicOr(err, 4);
+	if (tot > bve::COST_MAX) { atomicOr(err, 2); cost[q] = bve::COST_NONE; }
+	else cost[q] = (uint32_t)tot;
+	info[t] = bvw::PairInfo{ nb, (uint32_t)bitsB, ni | (nextra > 0 ? 0x80000000u : 0u), (uint32_t)bitsI };
+	sp.nr = nr; sp.nextra = (int32_t)nextra; sp.bitsR = bitsR; sp.ivArcs = ivArcs;
+	pairs[t] = sp;
+}
+
+// emission of the cut pairs that were chosen: one wave per segment, with the state the stitching handed it
+template <bool DEF>
+__global__ void __launch_bounds__(256) k_seg_emit(const Params p, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ, const uint8_t *__restrict__ best,
+                                                  const int32_t *__restrict__ refc, const int64_t *__restrict__ off, const uint32_t *__restrict__ list, const Seg *__restrict__ segs,
+                                                  const uint32_t *__restrict__ nsegs, uint32_t segCap, const SegIn *__restrict__ ins, const SegPair *__restrict__ pairs,
+                                                  const bvw::PairInfo *__restrict__ info, uint32_t *__restrict__ words, EncStatsDev *__restrict__ stats) {
+	const int lane = threadIdx.x & 63;
+	const int64_t n = *nsegs < segCap ? *nsegs : segCap, stride = (int64_t)gridDim.x * 4;
+	const int cyc = p.W + 1;
+	for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += stride) {
+		const Seg sg = segs[i];
+		const int64_t q = list[sg.pair];
+		const int32_t x = (int32_t)(q / cyc);
+		const int r = (int)(q - (int64_t)x * cyc);
+		if (best[x] != r) continue;
+		const SegPair sp = pairs[sg.pair];
+		const bvw::PairInfo pi = info[sg.pair];
+		const SegIn in = ins[i];
+		const int64_t a = rowptr[x], b = rowptr[x - r];
+		const int32_t d = (int32_t)(rowptr[x + 1] - a);
+		const uint32_t ni = pi.ni & 0x7fffffffu;
+		const bool extras = (pi.ni >> 31) != 0;
+		const uint64_t pos = (uint64_t)off[x];
+		bve::LenSink h;
+		bve::f_outd<DEF>(h, p, (uint64_t)d);
+		const uint64_t afterOutd = pos + h.bits;
+		if (p.W > 0) bve::f_ref<DEF>(h, p, (uint64_t)r);
+		const uint64_t afterRef = pos + h.bits;
+		if (r != 0) bve::f_bc<DEF>(h, p, pi.nb);
+		const uint64_t posB = pos + h.bits, startI = posB + (r != 0 ? pi.bitsB : 0);
+		bve::LenSink ic;
+		if (extras && p.I != 0) bve::w_gamma(ic, ni);
+		const uint64_t posI = startI + ic.bits, posR = posI + pi.bitsI;
+		if ((uint32_t)i == sp.segBase && lane == 0) { // the record's fixed fields and its contribution to the counters, once
+			bve::WordSink hw(words, pos);
+			bve::f_outd<DEF>(hw, p, (uint64_t)d);
+			if (p.W > 0) bve::f_ref<DEF>(hw, p, (uint64_t)r);
+			if (r != 0) bve::f_bc<DEF>(hw, p, pi.nb);
+			hw.finish();
+			if (extras && p.I != 0) { bve::WordSink wi(words, startI); bve::w_gamma(wi, ni); wi.finish(); }
+			const unsigned long long v[10] = { afterOutd - pos, afterRef - afterOutd, startI - afterRef, posR - startI, sp.bitsR, (unsigned long long)(d - sp.nextra), sp.ivArcs, sp.nr,
+			                                   (unsigned long long)refc[x], (unsigned long long)r };
+			for (int k = 0; k < 10; k++) if (v[k]) atomicAdd(&stats->v[k], v[k]);
+			atomicMax(&stats->v[10], (unsigned long long)refc[x]);
+		}
+		bvw::WaveWalk<DEF, true> w(p, x, words, posB + in.offB, posI + in.offI, posR + in.offR);
+		w.prevFlag = in.prevFlag; w.runStart = in.runStart; w.nb = in.nb; w.nr = in.nr; w.ni = in.ni; w.prevRes = in.prevRes; w.prevEnd = in.prevEnd;
+		bvw::WaveTotals t;
+		w.run(succ + a + sg.ja, sg.jb - sg.ja, succ + b + sg.ka, r == 0 ? 0 : sg.kb - sg.ka, t);
 	}
 }
 
@@ -189,7 +372,6 @@ __global__ void __launch_bounds__(256) k_enc_reclen(const Params p, const int64_
 	reclen[x] = (int32_t)t;
 }
 
-struct EncStatsDev { unsigned long long v[12]; }; // bitsOutd, bitsRef, bitsBlocks, bitsIntervals, bitsResiduals, copied, intervalised, residuals, totRef, totDist, maxRef, -
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -226,7 +408,7 @@ __global__ void __launch_bounds__(256) k_enc_emit_wave(const Params p, const int
 	const int64_t nbig = pairTotal[1], stride = (int64_t)gridDim.x * 4;
 	const int cyc = p.W + 1;
 	unsigned long long acc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, chain = 0; // lane 0 of the wave
-	for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < nbig; t += stride) {
+	for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6) + pairTotal[2]; t < nbig; t += stride) { // (the cut pairs: k_seg_emit)
 		const int64_t q = pairList[t];
 		const int32_t x = (int32_t)(q / cyc);
 		const int r = (int)(q - (int64_t)x * cyc);
@@ -304,12 +486,14 @@ int encode_device(const Params &p, int32_t n, const int64_t *d_rowptr, const int
 	int64_t *sums = nullptr, *offat = nullptr;
 	uint32_t *list = nullptr, *nlist = nullptr, *bins = nullptr, *nbins = nullptr; // lists of pairs / of nodes; bins: [0, 32) histogram, [32, 64) cursors, [64] listed items, [65] of them for the waves
 	bvw::PairInfo *info = nullptr;
+	Seg *segs = nullptr; SegSum *ssums = nullptr; SegIn *sins = nullptr; SegPair *spairs = nullptr; uint32_t *nsegs = nullptr; // the cut pairs
+	uint32_t segCap = 0, ngiant = 0;
 	int *flags = nullptr, *moved = nullptr; // flags[0]: error bits; moved[i]: did round i of the batch change a chunk's final state
 	EncStatsDev *dstats = nullptr;
 	std::vector<hipEvent_t> ev;
 	auto mark = [&]() { if (trace) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st); ev.push_back(e); } };
 	auto cleanup = [&](int rc) {
-		for (void *q : { (void *)cost, (void *)best, (void *)refc, (void *)reclen, (void *)offlen, (void *)state, (void *)used, (void *)sums, (void *)offat, (void *)list, (void *)nlist, (void *)bins, (void *)nbins, (void *)info, (void *)flags, (void *)moved, (void *)dstats })
+		for (void *q : { (void *)cost, (void *)best, (void *)refc, (void *)reclen, (void *)offlen, (void *)state, (void *)used, (void *)sums, (void *)offat, (void *)list, (void *)nlist, (void *)bins, (void *)nbins, (void *)info, (void *)segs, (void *)ssums, (void *)sins, (void *)spairs, (void *)nsegs, (void *)flags, (void *)moved, (void *)dstats })
 			if (q) (void)hipFree(q);
 		for (auto e : ev) (void)hipEventDestroy(e);
 		if (rc) { encode_free(out); (void)hipGetLastError(); }
@@ -320,10 +504,12 @@ int encode_device(const Params &p, int32_t n, const int64_t *d_rowptr, const int
 	if (npairs >= 0xffffffffll) { err = "too many (node, candidate) pairs for one call"; return cleanup(-3); }
 	const bool def = bve::default_codings(p);
 	const int bigBin = getenv("BVGPU_ENC_BIGBIN") ? atoi(getenv("BVGPU_ENC_BIGBIN")) : BIG_BIN; // experiment: 32 = everything lane by lane
+	const int segElems = getenv("BVGPU_ENC_SEGELEMS") ? std::max(1, atoi(getenv("BVGPU_ENC_SEGELEMS"))) : SEG_ELEMS; // tests: short segments
+	const int segBin = getenv("BVGPU_ENC_SEGBIN") ? atoi(getenv("BVGPU_ENC_SEGBIN")) : SEG_BIN; // experiment / tests: 32 = no pair is cut, 8 = every pair the waves take
 	if (!alloc((void **)&cost, sizeof(uint32_t) * (size_t)npairs) || !alloc((void **)&best, nn) || !alloc((void **)&refc, sizeof(int32_t) * nn) ||
 	    !alloc((void **)&reclen, sizeof(int32_t) * nn) || !alloc((void **)&offlen, sizeof(int32_t) * nn) || !alloc((void **)&state, sizeof(int32_t) * 2 * (size_t)nchunks * (size_t)(p.W ? p.W : 1)) ||
 	    !alloc((void **)&used, sizeof(int32_t) * (size_t)nchunks * (size_t)(p.W ? p.W : 1)) || !alloc((void **)&sums, sizeof(int64_t) * (size_t)(ns + 1)) ||
-	    !alloc((void **)&offat, sizeof(int64_t) * (nn + 1)) || !alloc((void **)&list, sizeof(uint32_t) * (size_t)npairs) || !alloc((void **)&nlist, sizeof(uint32_t) * nn) || !alloc((void **)&bins, sizeof(uint32_t) * (2 * ENC_NBIN + 2)) || !alloc((void **)&nbins, sizeof(uint32_t) * (2 * ENC_NBIN + 2)) || !alloc((void **)&flags, 2 * sizeof(int)) || !alloc((void **)&moved, SEL_BATCH * sizeof(int)) ||
+	    !alloc((void **)&offat, sizeof(int64_t) * (nn + 1)) || !alloc((void **)&list, sizeof(uint32_t) * (size_t)npairs) || !alloc((void **)&nlist, sizeof(uint32_t) * nn) || !alloc((void **)&bins, sizeof(uint32_t) * (2 * ENC_NBIN + 3)) || !alloc((void **)&nbins, sizeof(uint32_t) * (2 * ENC_NBIN + 3)) || !alloc((void **)&flags, 2 * sizeof(int)) || !alloc((void **)&moved, SEL_BATCH * sizeof(int)) ||
 	    !alloc((void **)&dstats, sizeof(EncStatsDev)) || !alloc((void **)&out.offsets, sizeof(int64_t) * nn)) { err = "device allocation failed"; return cleanup(-5); }
 	(void)hipMemsetAsync(flags, 0, 2 * sizeof(int), st);
 	(void)hipMemsetAsync(dstats, 0, sizeof(EncStatsDev), st);
@@ -332,13 +518,31 @@ int encode_device(const Params &p, int32_t n, const int64_t *d_rowptr, const int
 	// A
 	if (npairs) {
 		const PairItems items{ p, d_rowptr, npairs };
-		(void)hipMemsetAsync(bins, 0, sizeof(uint32_t) * (2 * ENC_NBIN + 2), st);
+		(void)hipMemsetAsync(bins, 0, sizeof(uint32_t) * (2 * ENC_NBIN + 3), st);
 		hipLaunchKernelGGL(k_enc_hist<PairItems>, blocks(npairs, SORT_TILE), dim3(256), 0, st, items, bins);
-		hipLaunchKernelGGL(k_enc_bases, dim3(1), dim3(64), 0, st, bins, bins + ENC_NBIN, bigBin);
-		uint32_t nbig = 0; // the pricing of the long pairs leaves their section sizes for the emission: one entry per such pair
-		if (hipMemcpyAsync(&nbig, bins + 2 * ENC_NBIN + 1, sizeof nbig, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { err = "the list kernels failed"; return cleanup(-6); }
+		hipLaunchKernelGGL(k_enc_bases, dim3(1), dim3(64), 0, st, bins, bins + ENC_NBIN, bigBin, segBin);
+		uint32_t hb[2 * ENC_NBIN + 3]; // the pricing of the long pairs leaves their section sizes for the emission: one entry per such pair
+		if (hipMemcpyAsync(hb, bins, sizeof hb, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { err = "the list kernels failed"; return cleanup(-6); }
+		const uint32_t nbig = hb[2 * ENC_NBIN + 1];
+		ngiant = hb[2 * ENC_NBIN + 2];
 		if (!alloc((void **)&info, sizeof(bvw::PairInfo) * (size_t)nbig)) { err = "device allocation failed"; return cleanup(-5); }
 		hipLaunchKernelGGL(k_enc_scatter<PairItems>, blocks(npairs, SORT_TILE), dim3(256), 0, st, items, bins + ENC_NBIN, list, cost);
+		if (ngiant) { // segments of the cut pairs: at most SEG_MAX each, and a pair of bin b has fewer than 2^b elements
+			uint64_t cap = 0;
+			for (int b = segBin; b < ENC_NBIN; b++) cap += (uint64_t)hb[b] * std::min<uint64_t>(SEG_MAX, ((1ull << b) + segElems - 1) / segElems);
+			segCap = (uint32_t)std::min<uint64_t>(cap, 0x7fffffffu);
+			if (!alloc((void **)&segs, sizeof(Seg) * (size_t)segCap) || !alloc((void **)&ssums, sizeof(SegSum) * (size_t)segCap) || !alloc((void **)&sins, sizeof(SegIn) * (size_t)segCap) ||
+			    !alloc((void **)&spairs, sizeof(SegPair) * (size_t)ngiant) || !alloc((void **)&nsegs, sizeof(uint32_t))) { err = "device allocation failed"; return cleanup(-5); }
+			(void)hipMemsetAsync(nsegs, 0, sizeof(uint32_t), st);
+			hipLaunchKernelGGL(k_seg_plan, dim3(256), dim3(256), 0, st, p, d_rowptr, d_succ, list, bins + 2 * ENC_NBIN, segElems, segs, segCap, nsegs, spairs, flags);
+			if (def) {
+				hipLaunchKernelGGL(k_seg_count<true>, dim3(WAVE_BLOCKS), dim3(256), 0, st, p, d_rowptr, d_succ, list, segs, nsegs, segCap, ssums);
+				hipLaunchKernelGGL(k_seg_compose<true>, blocks(ngiant, 64), dim3(64), 0, st, p, list, bins + 2 * ENC_NBIN, segs, ssums, sins, spairs, cost, info, flags);
+			} else {
+				hipLaunchKernelGGL(k_seg_count<false>, dim3(WAVE_BLOCKS), dim3(256), 0, st, p, d_rowptr, d_succ, list, segs, nsegs, segCap, ssums);
+				hipLaunchKernelGGL(k_seg_compose<false>, blocks(ngiant, 64), dim3(64), 0, st, p, list, bins + 2 * ENC_NBIN, segs, ssums, sins, spairs, cost, info, flags);
+			}
+		}
 		if (def) {
 			hipLaunchKernelGGL(k_enc_cost_wave<true>, dim3(WAVE_BLOCKS), dim3(256), 0, st, p, d_rowptr, d_succ, list, bins + 2 * ENC_NBIN, cost, info, flags);
 			hipLaunchKernelGGL(k_enc_cost<true>, blocks(npairs, 256), dim3(256), 0, st, p, d_rowptr, d_succ, list, bins + 2 * ENC_NBIN, cost, flags);
@@ -408,6 +612,7 @@ int encode_device(const Params &p, int32_t n, const int64_t *d_rowptr, const int
 	int64_t totalBits = 0;
 	if (hipMemcpyAsync(&totalBits, out.offsets + n, sizeof(int64_t), hipMemcpyDeviceToHost, st) != hipSuccess || hipMemcpyAsync(&herr, flags, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { err = "the compressor kernels failed"; return cleanup(-6); }
 	if (herr & 1) { err = "successor lists must be strictly increasing"; return cleanup(-1); }
+	if (herr & 4) { err = "the segment table of the cut pairs overflowed"; return cleanup(-6); }
 	if (herr) { err = "a record of 2^31 bits or more"; return cleanup(-3); }
 	mark();
 	// D
@@ -417,10 +622,14 @@ int encode_device(const Params &p, int32_t n, const int64_t *d_rowptr, const int
 	(void)hipMemsetAsync(out.graph_words, 0, gw * 4, st);
 	if (n) {
 		const NodeItems items{ p, d_rowptr, best, n, bigBin };
-		(void)hipMemsetAsync(nbins, 0, sizeof(uint32_t) * (2 * ENC_NBIN + 2), st);
+		(void)hipMemsetAsync(nbins, 0, sizeof(uint32_t) * (2 * ENC_NBIN + 3), st);
 		hipLaunchKernelGGL(k_enc_hist<NodeItems>, blocks(n, SORT_TILE), dim3(256), 0, st, items, nbins);
-		hipLaunchKernelGGL(k_enc_bases, dim3(1), dim3(64), 0, st, nbins, nbins + ENC_NBIN, ENC_NBIN);
+		hipLaunchKernelGGL(k_enc_bases, dim3(1), dim3(64), 0, st, nbins, nbins + ENC_NBIN, ENC_NBIN, 0);
 		hipLaunchKernelGGL(k_enc_scatter<NodeItems>, blocks(n, SORT_TILE), dim3(256), 0, st, items, nbins + ENC_NBIN, nlist, (uint32_t *)nullptr);
+		if (ngiant) {
+			if (def) hipLaunchKernelGGL(k_seg_emit<true>, dim3(WAVE_BLOCKS), dim3(256), 0, st, p, d_rowptr, d_succ, best, refc, out.offsets, list, segs, nsegs, segCap, sins, spairs, info, out.graph_words, dstats);
+			else hipLaunchKernelGGL(k_seg_emit<false>, dim3(WAVE_BLOCKS), dim3(256), 0, st, p, d_rowptr, d_succ, best, refc, out.offsets, list, segs, nsegs, segCap, sins, spairs, info, out.graph_words, dstats);
+		}
 		if (def) {
 			if (npairs) hipLaunchKernelGGL(k_enc_emit_wave<true>, dim3(WAVE_BLOCKS), dim3(256), 0, st, p, d_rowptr, d_succ, best, refc, out.offsets, list, bins + 2 * ENC_NBIN, info, out.graph_words, dstats);
 			hipLaunchKernelGGL(k_enc_emit<true>, blocks(n, 256), dim3(256), 0, st, p, d_rowptr, d_succ, best, refc, out.offsets, nlist, nbins + 2 * ENC_NBIN, n, out.graph_words, dstats);

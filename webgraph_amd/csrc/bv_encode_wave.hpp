@@ -61,7 +61,10 @@ struct WaveTotals { // what CountVisitor holds after a walk (the same in every l
 	int bad; // a list that is not strictly increasing
 };
 
-template <bool DEF, bool EMIT>
+// SEG (with EMIT = false): the walk is over a SEGMENT of a pair whose predecessors' state is not known yet: it starts in the state of
+// its own first element and prices every item but the three that depend on what came before -- the block that ends at the first
+// change of the membership flag, the first residual, the left extreme of the first interval -- and reports those instead.
+template <bool DEF, bool EMIT, bool SEG = false>
 struct WaveWalk {
 	const Params &p;
 	const int32_t node;
@@ -72,6 +75,10 @@ struct WaveWalk {
 	uint64_t accB = 0, accI = 0, accR = 0, accArcs = 0; // COUNT: per-lane partial sums
 	uint32_t nb = 0, ni = 0, nr = 0;
 	int64_t prevEnd = 0, prevRes = 0;
+	uint32_t prevFlag = 1;   // the walk starts in a copy run ...
+	int64_t runStart = 0;    // ... that began at index 0 of ref (a later segment of a cut pair: where the run in progress began, relative to the segment)
+	int32_t firstFlag = -1;  // SEG: membership flag of the segment's first element of ref (-1: none), index of the first change, first residual, first interval
+	int64_t firstChange = -1, firstRes = 0, firstLeft = 0;
 
 	__device__ __forceinline__ WaveWalk(const Params &p_, int32_t node_, uint32_t *w, uint64_t pb, uint64_t pi, uint64_t pr)
 	    : p(p_), node(node_), lane((int)(threadIdx.x & 63)), words(w), posB(pb), posI(pi), posR(pr), posB0(pb), posI0(pi), posR0(pr) {}
@@ -86,9 +93,9 @@ struct WaveWalk {
 		posB += __shfl(inc, 63);
 	}
 	// ... one interval each: (v1, v2) = (coded left extreme, length - minIntervalLength)
-	__device__ __forceinline__ void intervals(bool on, uint64_t v1, uint64_t v2) {
+	__device__ __forceinline__ void intervals(bool on, uint64_t v1, uint64_t v2, bool noV1 = false) { // noV1 (SEG): the left extreme is priced by whoever knows the previous interval
 		bve::LenSink s;
-		if (on) { bve::w_gamma(s, v1); bve::w_gamma(s, v2); }
+		if (on) { if (!noV1) bve::w_gamma(s, v1); bve::w_gamma(s, v2); }
 		if (!EMIT) { accI += s.bits; return; }
 		const uint64_t inc = DEF ? (uint64_t)wave_incl_scan((uint32_t)s.bits, lane) : wave_incl_scan(s.bits, lane);
 		if (on) { bve::WordSink w(words, posI + inc - s.bits); bve::w_gamma(w, v1); bve::w_gamma(w, v2); w.finish(); }
@@ -108,12 +115,15 @@ struct WaveWalk {
 	__device__ __forceinline__ void close_run(int64_t start, int64_t T) {
 		if (T >= 2 && T >= p.I) { // p.I != 0: runs are only carried when intervals exist
 			const uint64_t v1 = ni == 0 ? bve::int2nat(start - node) : (uint64_t)(start - prevEnd - 1);
-			intervals(lane == 0, v1, (uint64_t)(T - p.I));
+			intervals(lane == 0, v1, (uint64_t)(T - p.I), SEG && ni == 0);
+			if (SEG && ni == 0) firstLeft = start;
 			if (lane == 0) accArcs += (uint64_t)T;
 			prevEnd = start + T; ni++;
 		} else { // T residuals: the first one's gap, then gaps of 0
 			const uint64_t v0 = nr == 0 ? bve::int2nat(start - node) : (uint64_t)(start - prevRes - 1);
-			for (int64_t t0 = 0; t0 < T; t0 += 64) residuals(t0 + lane < T, t0 + lane == 0 ? v0 : 0);
+			const bool skipFirst = SEG && nr == 0;
+			if (skipFirst) firstRes = start;
+			for (int64_t t0 = 0; t0 < T; t0 += 64) residuals(t0 + lane < T && !(skipFirst && t0 + lane == 0), t0 + lane == 0 ? v0 : 0);
 			prevRes = start + T - 1; nr += (uint32_t)T;
 		}
 	}
@@ -121,8 +131,6 @@ struct WaveWalk {
 	__device__ __forceinline__ void run(const int32_t *__restrict__ cur, int32_t d, const int32_t *__restrict__ ref, int32_t dr, WaveTotals &tot) {
 		const int32_t I = p.I;
 		int64_t j0 = 0, k0 = 0;
-		uint32_t prevFlag = 1;   // the walk starts in a copy run
-		int64_t runStart = 0;    // index in ref where the run in progress began
 		int64_t openStart = 0, openLen = 0; // run of consecutive extras in progress at the end of the consumed part of cur
 		int64_t nextra = 0;
 		int64_t lastA = INT64_MIN; // last consumed element of cur: the list must increase strictly
@@ -147,11 +155,14 @@ struct WaveWalk {
 			// ---- copy blocks: one per change of the membership flag along ref
 			if (cb > 0) {
 				const uint64_t maskB = lt_mask(cb);
+				if (SEG && firstFlag < 0) { firstFlag = (int32_t)(M & 1); prevFlag = (uint32_t)firstFlag; } // no change at the segment's own start
 				const uint64_t Bd = (M ^ ((M << 1) | prevFlag)) & maskB;
 				if (Bd) {
 					const uint64_t below = Bd & lt_mask(lane);
 					const int64_t len = k0 + lane - (below ? k0 + hibit(below) : runStart);
-					blocks((Bd >> lane) & 1, (uint64_t)(nb == 0 && !below ? len : len - 1));
+					const bool firstInternal = SEG && nb == 0 && !below; // its length depends on where the run began: priced by the stitching
+					if (SEG && nb == 0) firstChange = k0 + lobit(Bd);
+					blocks(((Bd >> lane) & 1) && !firstInternal, (uint64_t)(nb == 0 && !below ? len : len - 1));
 					nb += (uint32_t)__popcll(Bd);
 					runStart = k0 + hibit(Bd);
 				}
@@ -198,7 +209,8 @@ struct WaveWalk {
 							const int64_t pend = below ? pe : prevEnd;
 							const bool on = (IS >> lane) & 1;
 							const uint64_t v1 = ni == 0 && !below ? bve::int2nat((int64_t)a - node) : (uint64_t)((int64_t)a - pend - 1);
-							intervals(on, v1, (uint64_t)(len - I));
+							if (SEG && ni == 0) firstLeft = __shfl(a, lobit(IS));
+							intervals(on, v1, (uint64_t)(len - I), SEG && ni == 0 && !below);
 							if (on) accArcs += (uint64_t)len;
 							const int last = hibit(IS);
 							prevEnd = (int64_t)__shfl(a, last) + __shfl(len, last);
@@ -210,7 +222,8 @@ struct WaveWalk {
 							const int64_t pa = __shfl(a, pl);
 							const int64_t prv = below ? pa : prevRes;
 							const uint64_t v = nr == 0 && !below ? bve::int2nat((int64_t)a - node) : (uint64_t)((int64_t)a - prv - 1);
-							residuals((RS >> lane) & 1, v);
+							if (SEG && nr == 0) firstRes = __shfl(a, lobit(RS));
+							residuals(((RS >> lane) & 1) && !(SEG && nr == 0 && !below), v);
 							prevRes = __shfl(a, hibit(RS));
 							nr += (uint32_t)__popcll(RS);
 						}
