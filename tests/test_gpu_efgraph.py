@@ -178,3 +178,29 @@ def test_bvgraph_to_efgraph_on_the_device(tmp_path, cnr_oracle):
     rp, sc = h.decode_range()
     assert np.array_equal(rp, rowptr) and np.array_equal(sc, succ)
     h.close()
+
+
+def test_checksum_without_writing_the_lists(tmp_path, monkeypatch):
+    """bvg_scan_checksum on an EFGraph folds hashCode() inside the decode kernels (no successor is written); it must equal the
+    decode-then-fold path and the BVGraph's hashCode of the same lists; ranges compose; long and giant lists included."""
+    from webgraph_amd import bvgraph as B
+    from webgraph_amd import tools as T
+    rng = np.random.Generator(np.random.PCG64(21))
+    rowptr, succ = T.generate(120000, 2400000, seed=31, p_copy=0.5)
+    n = rowptr.size - 1
+    rows = [succ[rowptr[x]:rowptr[x + 1]].tolist() for x in range(n)]
+    rows[5] = sorted(set(rng.integers(0, n, size=40000).tolist()))      # a giant list, a long one, and neighbours without successors
+    rows[6] = []
+    rows[7] = list(range(100, 1100))
+    rowptr, succ = _csr(rows)
+    T.store_ef(str(tmp_path / "ef"), rowptr, succ)
+    T.store(str(tmp_path / "bv"), rowptr, succ)
+    g, h = B.EFGraph.load(str(tmp_path / "ef")), B.BVGraph.load(str(tmp_path / "bv"))
+    want = h.hashCode()
+    assert g.hashCode() == want
+    a, arcs_a = g.scan_checksum(0, 777, -1)
+    b, arcs_b = g.scan_checksum(777, n, a)
+    assert b == want and arcs_a + arcs_b == succ.size
+    monkeypatch.setenv("BVGPU_EF_HASH_MATERIALISE", "1")
+    assert g.hashCode() == want
+    g.close(); h.close()

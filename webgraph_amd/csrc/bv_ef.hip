@@ -64,19 +64,39 @@ __global__ void __launch_bounds__(256) k_ef_outdeg(const EfDev g, const int32_t 
 	}
 }
 
+// ImmutableGraph.hashCode() (ImmutableGraph.java:757-770) without the lists ever being written: h -> 31 h + x, then 31 h + s for the
+// successors from the last to the first, i.e. node x maps h to 31^(d+1) h + x 31^d + sum_i s_i 31^i (s_0 the smallest).  In HASH
+// mode a decoded successor goes, times its power of 31, into its node's accumulator instead of into the CSR; the nodes' maps are
+// composed in order per block (k_ef_decode) and the blocks' maps by k_ef_hash_fold.
+__device__ __forceinline__ uint32_t pow31(uint32_t e) { uint32_t r = 1, b = 31; while (e) { if (e & 1) r *= b; b *= b; e >>= 1; } return r; }
+struct Affine { uint32_t m, b; }; // h -> m h + b
+__device__ __forceinline__ Affine then(Affine first, Affine second) { return Affine{ second.m * first.m, second.m * first.b + second.b }; }
+__device__ __forceinline__ Affine wave_compose(Affine v, int lane) { // inclusive scan: lane l holds the composition of lanes 0 .. l, in order
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const uint32_t pm = __shfl_up(v.m, o), pb = __shfl_up(v.b, o);
+		if (lane >= o) v = then(Affine{ pm, pb }, v);
+	}
+	return v;
+}
+
 // Lists of fewer than bigMin successors, 256 slots per block.  Phase 1: one lane per slot reads the header of its record (l,
 // where the lower and the upper bits start) into LDS, a block scan numbers the successors of the tile.  Phase 2: one lane per
 // SUCCESSOR -- its slot by a search in the tile's prefix sums, the position of its one in the upper bits by popcounts (a select
 // within a few words: a short list has about two upper bits per successor), its lower bits by one extraction -- so that
 // neighbouring lanes read neighbouring bits and write neighbouring ids, whatever the lengths of the lists are.
 constexpr int EF_TILE = 256;
+// HASH: `succ` is the array of per-slot sums (the short lists' are written here, the long-list kernels add theirs)
+template <bool HASH>
 __global__ void __launch_bounds__(EF_TILE) k_ef_decode(const EfDev g, const int32_t *__restrict__ nodes, int32_t lo, int64_t cnt, int32_t bigMin, const int64_t *__restrict__ rowstart,
                                                        int32_t *__restrict__ succ, uint64_t cap, int *__restrict__ err) {
 	__shared__ uint64_t s_lower[EF_TILE], s_upper[EF_TILE];
 	__shared__ int64_t s_row[EF_TILE];
 	__shared__ int32_t s_first[EF_TILE + 1]; // successors of the tile's short lists before slot t
 	__shared__ int32_t s_l[EF_TILE], s_wsum[EF_TILE / 64];
+	__shared__ uint32_t s_acc[HASH ? EF_TILE : 1], s_pow[HASH ? EF_TILE : 1]; // HASH: the slots' sums; 31^i for i < 256 (a short list has fewer successors)
 	const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+	if (HASH) { s_acc[t] = 0; s_pow[t] = pow31((uint32_t)t); }
 	const int64_t s = (int64_t)blockIdx.x * EF_TILE + t;
 	int32_t d = 0;
 	if (s < cnt) {
@@ -105,7 +125,11 @@ __global__ void __launch_bounds__(EF_TILE) k_ef_decode(const EfDev g, const int3
 	if (t == EF_TILE - 1) s_first[EF_TILE] = before + inc;
 	__syncthreads();
 	const int32_t total = s_first[EF_TILE];
-	for (int32_t k = t; k < total; k += EF_TILE) {
+	for (int32_t k0 = 0; k0 < total; k0 += EF_TILE) { // (uniform trip count: the HASH reduction shuffles)
+		const int32_t k = k0 + t;
+		uint32_t hv = 0;
+		int ha = -1;
+		if (k < total) {
 		int a = 0, b = EF_TILE; // last slot with s_first <= k (slots without short lists repeat their successor's value: the last of them is the one)
 #pragma unroll
 		for (int step = 0; step < 8; step++) { const int mid = (a + b) >> 1; if (s_first[mid] <= k) a = mid; else b = mid; }
@@ -118,13 +142,55 @@ __global__ void __launch_bounds__(EF_TILE) k_ef_decode(const EfDev g, const int3
 		uint32_t r = i;
 		bool bad = false;
 		for (uint32_t c = (uint32_t)__popcll(w); r >= c; c = (uint32_t)__popcll(w)) { r -= c; if (++wi >= g.nwords) { bad = true; break; } w = ef_ld(g, wi); }
-		if (bad) { atomicOr(err, E_FORMAT); continue; }
+		if (bad) atomicOr(err, E_FORMAT);
+		else {
 		uint32_t bit = 0;
 #pragma unroll
 		for (int sh = 32; sh > 0; sh >>= 1) { const uint32_t c = (uint32_t)__popcll(w & ((1ull << sh) - 1)); if (r >= c) { r -= c; w >>= sh; bit += sh; } }
 		const uint64_t high = wi * 64 + bit - up - i;
-		succ[s_row[a] + i] = (int32_t)((high << l) | ef_get(g, s_lower[a] + (uint64_t)i * (uint64_t)l, l));
+		const uint32_t val = (uint32_t)((high << l) | ef_get(g, s_lower[a] + (uint64_t)i * (uint64_t)l, l));
+		if (!HASH) succ[s_row[a] + i] = (int32_t)val;
+		else hv = val * s_pow[i & (EF_TILE - 1)], ha = a;
+		}
+		}
+		if (HASH) { // neighbouring lanes hold neighbouring successors: the lanes of one list add up among themselves, its first lane adds to the slot
+#pragma unroll
+			for (int o = 1; o < 64; o <<= 1) { const uint32_t v2 = __shfl_down(hv, o); const int a2 = __shfl_down(ha, o); if (lane + o < 64 && a2 == ha) hv += v2; }
+			const int ap = __shfl_up(ha, 1);
+			if (ha >= 0 && (lane == 0 || ap != ha)) atomicAdd(&s_acc[ha], hv);
+		}
 	}
+	if (HASH) { // the sums of the short lists: the long-list kernels add theirs to the same array
+		__syncthreads();
+		if (s < cnt && (int32_t)(rowstart[s + 1] - rowstart[s]) < bigMin) ((uint32_t *)succ)[s] = s_acc[t];
+	}
+}
+// HASH: the nodes of a block of 256 slots, in order, as one map (after every sum is in)
+__global__ void __launch_bounds__(EF_TILE) k_ef_hash_nodes(int32_t lo, int64_t cnt, const int64_t *__restrict__ rowstart, const uint32_t *__restrict__ acc, Affine *__restrict__ maps) {
+	__shared__ Affine s_wmap[EF_TILE / 64];
+	const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+	const int64_t s = (int64_t)blockIdx.x * EF_TILE + t;
+	Affine mine{ 1, 0 };
+	if (s < cnt) {
+		const uint32_t pd = pow31((uint32_t)(rowstart[s + 1] - rowstart[s]));
+		mine = Affine{ pd * 31u, (uint32_t)(lo + s) * pd + acc[s] };
+	}
+	const Affine inc = wave_compose(mine, lane);
+	if (lane == 63) s_wmap[wv] = inc;
+	__syncthreads();
+	if (t == 0) { Affine all = s_wmap[0]; for (int w = 1; w < EF_TILE / 64; w++) all = then(all, s_wmap[w]); maps[blockIdx.x] = all; }
+}
+// the blocks' maps in order, applied to *h
+__global__ void __launch_bounds__(256) k_ef_hash_fold(const Affine *__restrict__ maps, int64_t n, int32_t *__restrict__ h) {
+	__shared__ Affine s_w[4];
+	const int t = threadIdx.x, lane = t & 63;
+	const int64_t per = (n + 255) / 256, a = (int64_t)t * per, e = a + per < n ? a + per : n;
+	Affine mine{ 1, 0 };
+	for (int64_t i = a; i < e; i++) mine = then(mine, maps[i]);
+	const Affine inc = wave_compose(mine, lane);
+	if (lane == 63) s_w[t >> 6] = inc;
+	__syncthreads();
+	if (t == 0) { Affine all = s_w[0]; for (int w = 1; w < 4; w++) all = then(all, s_w[w]); *h = (int32_t)(all.m * (uint32_t)*h + all.b); }
 }
 
 // ---- long lists.  A round takes 64 words of upper bits: a prefix sum over their popcounts gives every one its index; the lower
@@ -138,6 +204,8 @@ struct EfChunk { int32_t slot; uint32_t round; uint64_t rank; }; // round `round
 __device__ __forceinline__ void ef_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); }
 
 // words [w0, w0 + 64) of the upper bits of record r, `done` successors before them; returns the ones in these words
+// HASH: `succ` is the array of per-slot accumulators and `base` the slot
+template <bool HASH>
 __device__ __forceinline__ uint32_t ef_round(const EfDev &g, const EfRecord &r, int64_t base, uint32_t d, uint64_t w0, uint64_t done, uint64_t *low, int lane,
                                              int32_t *__restrict__ succ) {
 	uint64_t w = ef_ld(g, w0 + lane);
@@ -160,6 +228,7 @@ __device__ __forceinline__ uint32_t ef_round(const EfDev &g, const EfRecord &r, 
 	}
 	uint64_t i = done + inc - mine; // index of this lane's first one
 	const uint64_t bit0 = (w0 + lane) * 64 - r.upperStart;
+	uint32_t hsum = 0, pw = HASH ? pow31((uint32_t)i) : 0; // a lane's successors are consecutive: 31^i runs along
 	while (w && i < d) {
 		const uint64_t high = bit0 + (uint64_t)__builtin_ctzll(w) - i;
 		w &= w - 1;
@@ -174,15 +243,19 @@ __device__ __forceinline__ uint32_t ef_round(const EfDev &g, const EfRecord &r, 
 				lowv &= (1ull << r.l) - 1;
 			} else lowv = ef_get(g, p, r.l);
 		}
-		succ[base + i] = (int32_t)((high << r.l) | lowv);
+		const uint32_t val = (uint32_t)((high << r.l) | lowv);
+		if (HASH) { hsum += val * pw; pw *= 31u; }
+		else succ[base + i] = (int32_t)val;
 		i++;
 	}
+	if (HASH && hsum) atomicAdd((uint32_t *)succ + base, hsum);
 	return total;
 }
 
 // The long lists are found where they are: a wave looks at 64 slots at a time (their lengths are neighbouring words of
 // rowstart) and takes the ones in its range -- no list of them is built (an atomic append per long list cost more than their
 // decoding: 35 000 atomics on one counter, 0.5 ms).
+template <bool HASH>
 __global__ void __launch_bounds__(256) k_ef_decode_wave(const EfDev g, const int32_t *__restrict__ nodes, int32_t lo, int64_t cnt, int32_t bigMin, int32_t giantMin,
                                                         const int64_t *__restrict__ rowstart, int32_t *__restrict__ succ, uint64_t cap, int *__restrict__ err) {
 	__shared__ uint64_t s_low[4][EF_LDS_WORDS + 2];
@@ -203,13 +276,14 @@ __global__ void __launch_bounds__(256) k_ef_decode_wave(const EfDev g, const int
 			uint64_t done = 0;
 			for (uint64_t w0 = r.upperStart >> 6; done < d; w0 += 64) {
 				if (w0 >= g.nwords) { if (lane == 0) atomicOr(err, E_FORMAT); break; }
-				done += ef_round(g, r, base, d, w0, done, low, lane, succ);
+				done += ef_round<HASH>(g, r, HASH ? s : base, d, w0, done, low, lane, succ);
 			}
 		}
 	}
 }
 
 // the giant lists: ones before every round -> work items.  chunks[] is a bump allocation: *nchunks slots are in use.
+template <bool HASH>
 __global__ void __launch_bounds__(256) k_ef_rank(const EfDev g, const int32_t *__restrict__ nodes, int32_t lo, int64_t cnt, int32_t giantMin, const int64_t *__restrict__ rowstart,
                                                  int32_t *__restrict__ succ, uint64_t cap, EfChunk *__restrict__ chunks, uint32_t chunkCap, uint32_t *__restrict__ nchunks,
                                                  int *__restrict__ err) {
@@ -238,7 +312,7 @@ __global__ void __launch_bounds__(256) k_ef_rank(const EfDev g, const int32_t *_
 		if ((uint64_t)at + rounds > chunkCap) { // no room (a batch that asks for the same giant list many times): this wave decodes it, round after round
 			for (uint64_t j = (uint64_t)at + lane; j < chunkCap; j += 64) chunks[j].slot = -1;
 			uint64_t done = 0;
-			for (uint64_t w0 = wFirst; done < d && w0 < g.nwords; w0 += 64) done += ef_round(g, r, base, d, w0, done, low, lane, succ);
+			for (uint64_t w0 = wFirst; done < d && w0 < g.nwords; w0 += 64) done += ef_round<HASH>(g, r, HASH ? s : base, d, w0, done, low, lane, succ);
 			continue;
 		}
 		uint64_t rank = 0;
@@ -261,6 +335,7 @@ __global__ void __launch_bounds__(256) k_ef_rank(const EfDev g, const int32_t *_
 	}
 }
 }
+template <bool HASH>
 __global__ void __launch_bounds__(256) k_ef_decode_chunks(const EfDev g, const int32_t *__restrict__ nodes, int32_t lo, const EfChunk *__restrict__ chunks, const uint32_t *__restrict__ nchunks,
                                                           uint32_t chunkCap, const int64_t *__restrict__ rowstart, int32_t *__restrict__ succ, int *__restrict__ err) {
 	__shared__ uint64_t s_low[4][EF_LDS_WORDS + 2];
@@ -276,7 +351,7 @@ __global__ void __launch_bounds__(256) k_ef_decode_chunks(const EfDev g, const i
 		const int32_t x = nodes ? nodes[c.slot] : (int32_t)(lo + c.slot);
 		EfRecord r;
 		if (!ef_header(g, (uint64_t)g.offsets[x], r) || r.d != d) { if (lane == 0) atomicOr(err, E_FORMAT); continue; }
-		(void)ef_round(g, r, base, d, (r.upperStart >> 6) + (uint64_t)c.round * 64, c.rank, low, lane, succ);
+		(void)ef_round<HASH>(g, r, HASH ? (int64_t)c.slot : base, d, (r.upperStart >> 6) + (uint64_t)c.round * 64, c.rank, low, lane, succ);
 	}
 }
 
@@ -286,11 +361,29 @@ void launch_ef_outdeg(const EfDev &g, const int32_t *nodes, int32_t lo, int64_t 
 void launch_ef_decode(const EfDev &g, const int32_t *nodes, int32_t lo, int64_t cnt, int32_t bigMin, const int64_t *rowstart, int32_t *succ, uint64_t cap, int *err, int32_t giantMin,
                       void *chunks, uint32_t chunkCap, uint32_t *nchunks, hipStream_t st, hipStream_t stLong, hipStream_t stGiant) {
 	if (cnt <= 0) return;
-	hipLaunchKernelGGL(k_ef_rank, dim3(256), dim3(256), 0, stGiant, g, nodes, lo, cnt, giantMin, rowstart, succ, cap, (EfChunk *)chunks, chunkCap, nchunks, err);
-	hipLaunchKernelGGL(k_ef_decode_chunks, dim3(1024), dim3(256), 0, stGiant, g, nodes, lo, (const EfChunk *)chunks, nchunks, chunkCap, rowstart, succ, err);
-	hipLaunchKernelGGL(k_ef_decode_wave, dim3(1024), dim3(256), 0, stLong, g, nodes, lo, cnt, bigMin, giantMin, rowstart, succ, cap, err);
-	hipLaunchKernelGGL(k_ef_decode, dim3((unsigned)((cnt + EF_TILE - 1) / EF_TILE)), dim3(EF_TILE), 0, st, g, nodes, lo, cnt, bigMin, rowstart, succ, cap, err);
+	hipLaunchKernelGGL(k_ef_rank<false>, dim3(256), dim3(256), 0, stGiant, g, nodes, lo, cnt, giantMin, rowstart, succ, cap, (EfChunk *)chunks, chunkCap, nchunks, err);
+	hipLaunchKernelGGL(k_ef_decode_chunks<false>, dim3(1024), dim3(256), 0, stGiant, g, nodes, lo, (const EfChunk *)chunks, nchunks, chunkCap, rowstart, succ, err);
+	hipLaunchKernelGGL(k_ef_decode_wave<false>, dim3(1024), dim3(256), 0, stLong, g, nodes, lo, cnt, bigMin, giantMin, rowstart, succ, cap, err);
+	hipLaunchKernelGGL(k_ef_decode<false>, dim3((unsigned)((cnt + EF_TILE - 1) / EF_TILE)), dim3(EF_TILE), 0, st, g, nodes, lo, cnt, bigMin, rowstart, succ, cap, err);
 }
+// hashCode() of the nodes lo .. lo + cnt - 1 folded into *h (device): acc = uint32[cnt] zeroed, maps = ef_hash_blocks(cnt) * 8 bytes.  The three
+// decode kernels run side by side (st, stLong, stGiant); the caller joins the streams before launch_ef_hash_fold
+void launch_ef_hash(const EfDev &g, int32_t lo, int64_t cnt, int32_t bigMin, const int64_t *rowstart, uint32_t *acc, int *err, int32_t giantMin, void *chunks, uint32_t chunkCap,
+                    uint32_t *nchunks, hipStream_t st, hipStream_t stLong, hipStream_t stGiant) {
+	if (cnt <= 0) return;
+	const uint64_t cap = ~0ull;
+	hipLaunchKernelGGL(k_ef_rank<true>, dim3(256), dim3(256), 0, stGiant, g, (const int32_t *)nullptr, lo, cnt, giantMin, rowstart, (int32_t *)acc, cap, (EfChunk *)chunks, chunkCap, nchunks, err);
+	hipLaunchKernelGGL(k_ef_decode_chunks<true>, dim3(1024), dim3(256), 0, stGiant, g, (const int32_t *)nullptr, lo, (const EfChunk *)chunks, nchunks, chunkCap, rowstart, (int32_t *)acc, err);
+	hipLaunchKernelGGL(k_ef_decode_wave<true>, dim3(1024), dim3(256), 0, stLong, g, (const int32_t *)nullptr, lo, cnt, bigMin, giantMin, rowstart, (int32_t *)acc, cap, err);
+	hipLaunchKernelGGL(k_ef_decode<true>, dim3((unsigned)((cnt + EF_TILE - 1) / EF_TILE)), dim3(EF_TILE), 0, st, g, (const int32_t *)nullptr, lo, cnt, bigMin, rowstart, (int32_t *)acc, cap, err);
+}
+void launch_ef_hash_fold(int32_t lo, int64_t cnt, const int64_t *rowstart, const uint32_t *acc, void *maps, int32_t *h, hipStream_t st) {
+	if (cnt <= 0) return;
+	const int64_t nb = (cnt + EF_TILE - 1) / EF_TILE;
+	hipLaunchKernelGGL(k_ef_hash_nodes, dim3((unsigned)nb), dim3(EF_TILE), 0, st, lo, cnt, rowstart, acc, (Affine *)maps);
+	hipLaunchKernelGGL(k_ef_hash_fold, dim3(1), dim3(256), 0, st, (const Affine *)maps, nb, h);
+}
+int64_t ef_hash_blocks(int64_t cnt) { return (cnt + EF_TILE - 1) / EF_TILE; }
 size_t ef_chunk_bytes() { return sizeof(EfChunk); }
 
 } // namespace bv

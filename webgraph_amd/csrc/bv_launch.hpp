@@ -116,6 +116,13 @@ void launch_ef_outdeg(const EfDev &g, const int32_t *nodes, int32_t lo, int64_t 
 void launch_ef_decode(const EfDev &g, const int32_t *nodes, int32_t lo, int64_t cnt, int32_t bigMin, const int64_t *rowstart, int32_t *succ, uint64_t cap, int *err, int32_t giantMin,
                       void *chunks, uint32_t chunkCap, uint32_t *nchunks, hipStream_t st, hipStream_t stLong, hipStream_t stGiant);
 size_t ef_chunk_bytes();
+// ImmutableGraph.hashCode() of nodes lo .. lo + cnt - 1 without writing a successor: launch_ef_hash adds every successor, times its power of 31,
+// to its slot's sum (acc = uint32[cnt] zeroed; three kernels on three streams), launch_ef_hash_fold -- after the streams are joined -- composes the
+// nodes' maps in order and applies them to *h (device memory); maps = ef_hash_blocks(cnt) * 8 bytes of scratch
+void launch_ef_hash(const EfDev &g, int32_t lo, int64_t cnt, int32_t bigMin, const int64_t *rowstart, uint32_t *acc, int *err, int32_t giantMin, void *chunks, uint32_t chunkCap,
+                    uint32_t *nchunks, hipStream_t st, hipStream_t stLong, hipStream_t stGiant);
+void launch_ef_hash_fold(int32_t lo, int64_t cnt, const int64_t *rowstart, const uint32_t *acc, void *maps, int32_t *h, hipStream_t st);
+int64_t ef_hash_blocks(int64_t cnt);
 
 // EFGraph.store on the device (bv_efw.hip): device CSR -> stream words (host order), record lengths, bit offsets; all hipMalloc'ed on success
 int ef_encode_device(int32_t n, const int64_t *d_rowptr, const int32_t *d_succ, uint64_t ub, int lq, uint64_t **d_words_out, uint64_t *nwords_out, uint64_t *bits_out,

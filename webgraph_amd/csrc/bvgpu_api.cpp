@@ -617,6 +617,49 @@ int ef_to_host(bvg_graph *g, const int32_t *nodes_h, int32_t from, int64_t cnt, 
 	return BVG_OK;
 }
 
+// ImmutableGraph.hashCode() over [from, to) of an EFGraph folded into *h without a successor ever being written (bv_ef.hip, HASH mode):
+// the write side of the scan is 8 bytes per 256 nodes
+int ef_scan_checksum(bvg_graph *g, int32_t from, int32_t to, int32_t *h, uint64_t *arcs_out) {
+	const Staged &s = *g->st;
+	if (from < s.node_lo || to > s.node_hi) return fail(g, BVG_EARG, "node range outside the slice this handle stages (bvg_open_shard)");
+	const int64_t cnt = (int64_t)to - from;
+	if (cnt == 0) { if (arcs_out) *arcs_out = 0; return BVG_OK; }
+	{ int rc = fork_from_user(g); if (rc) return rc; }
+	Small *dsm = g->small.as<Small>();
+	HIPCHK(g, hipMemsetAsync(g->small.p, 0, sizeof(Small), g->stream));
+	const bv::EfDev gd = ef_dev(s);
+	const uint64_t chunkCap64 = gd.nwords / 64 + (uint64_t)cnt / 16 + 64;
+	const uint32_t chunkCap = (uint32_t)std::min<uint64_t>(chunkCap64, 0x7fffffffu);
+	if (!g->outd.need(sizeof(int32_t) * (size_t)cnt) || !g->sums.need(sizeof(int64_t) * (size_t)(bv::scan_num_sums(cnt) + 1)) || !g->stage_rowptr.need(sizeof(int64_t) * ((size_t)cnt + 1)) ||
+	    !g->stage_nodes.need(sizeof(uint32_t) * (size_t)cnt) || !g->hashA.need((size_t)bv::ef_hash_blocks(cnt) * 8) || !g->arena.need((size_t)chunkCap * bv::ef_chunk_bytes()))
+		return fail(g, BVG_ENOMEM, "device scratch allocation failed");
+	int32_t *nbig = g->coopctl.as<int32_t>();
+	HIPCHK(g, hipMemsetAsync(nbig, 0, 2 * sizeof(int32_t), g->stream));
+	HIPCHK(g, hipMemsetAsync(g->stage_nodes.p, 0, sizeof(uint32_t) * (size_t)cnt, g->stream)); // the long lists' accumulators
+	HIPCHK(g, hipMemcpyAsync(&dsm->hash, h, sizeof(int32_t), hipMemcpyHostToDevice, g->stream));
+	int64_t *rowstart = g->stage_rowptr.as<int64_t>();
+	bv::launch_ef_outdeg(gd, nullptr, from, cnt, g->outd.as<int32_t>(), &dsm->err, g->stream);
+	bv::launch_scan(g->outd.as<int32_t>(), cnt, rowstart, g->sums.as<int64_t>(), g->stream);
+	HIPCHK(g, hipMemcpyAsync(&dsm->total, rowstart + cnt, sizeof(int64_t), hipMemcpyDeviceToDevice, g->stream));
+	HIPCHK(g, hipEventRecord(g->evFork, g->stream));
+	HIPCHK(g, hipStreamWaitEvent(g->sideA, g->evFork, 0));
+	HIPCHK(g, hipStreamWaitEvent(g->sideB, g->evFork, 0));
+	bv::launch_ef_hash(gd, from, cnt, EF_BIG_MIN, rowstart, g->stage_nodes.as<uint32_t>(), &dsm->err, EF_GIANT_MIN, g->arena.p, chunkCap, (uint32_t *)nbig, g->stream, g->sideA, g->sideB);
+	HIPCHK(g, hipEventRecord(g->evA, g->sideA));
+	HIPCHK(g, hipStreamWaitEvent(g->stream, g->evA, 0));
+	HIPCHK(g, hipEventRecord(g->evB, g->sideB));
+	HIPCHK(g, hipStreamWaitEvent(g->stream, g->evB, 0));
+	bv::launch_ef_hash_fold(from, cnt, rowstart, g->stage_nodes.as<uint32_t>(), g->hashA.p, &dsm->hash, g->stream);
+	HIPCHK(g, hipMemsetAsync(nbig, 0, 2 * sizeof(int32_t), g->stream));
+	int rc = fetch_small(g);
+	if (rc) return rc;
+	if (g->h_small->err) return fail(g, BVG_EFORMAT, "malformed bit stream");
+	*h = g->h_small->hash;
+	g->last_arcs = (uint64_t)g->h_small->total;
+	if (arcs_out) *arcs_out = g->last_arcs;
+	return join_to_user(g);
+}
+
 int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_dev, int32_t *succ_dev, size_t succ_cap, bool async, uint64_t *arcs_out) {
 	const Staged &s = *g->st;
 	if (s.info.format == BVG_FORMAT_EF) return ef_decode_range_device(g, from, to, rowptr_dev, succ_dev, succ_cap, arcs_out);
@@ -1180,6 +1223,7 @@ extern "C" int bvg_scan_checksum(bvg_t *g, int32_t from, int32_t to, int32_t *ha
 	const Staged &s = *g->st;
 	if (from < 0 || from > s.info.nodes || to < from || to > s.info.nodes) return fail(g, BVG_EARG, "node range out of bounds"); // BVG:1165
 	HIPCHK(g, hipSetDevice(s.device));
+	if (s.info.format == BVG_FORMAT_EF && !getenv("BVGPU_EF_HASH_MATERIALISE")) return ef_scan_checksum(g, from, to, hash_io, arcs_out); // (the knob: the decode-then-fold path below, for comparison)
 	// The rows never reach the caller: they are decoded piece by piece into one scratch buffer and folded into the running
 	// hash there.  Pieces of <= 256 M arcs (1 GB of scratch): smaller ones that would stay in the Infinity Cache (32 M arcs)
 	// cost more in per-call set-up than they save (C2: 12.2 ms in 7 pieces, 4 ms in one).
