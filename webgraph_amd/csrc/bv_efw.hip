@@ -31,10 +31,11 @@ __device__ __forceinline__ EfwRec efw_layout(uint64_t d, uint64_t ub, int lq) {
 	r.bits = r.upperStart + hi + d + 1;                       // the terminator's one is the last bit: position (ub >> l) + d
 	return r;
 }
-// ORs the low `width` bits of v in at bit `pos`
-__device__ __forceinline__ void efw_put(unsigned long long *words, uint64_t pos, uint64_t v, int width) {
+// ORs the low `width` bits of v in at bit `pos`.  `words` is the stream in HBM, or -- with w0 -- the image in LDS of its words from w0 on:
+// a block whose records fit assembles them there and writes whole words afterwards
+__device__ __forceinline__ void efw_put(unsigned long long *words, uint64_t pos, uint64_t v, int width, uint64_t w0 = 0) {
 	if (width == 0) return;
-	const uint64_t i = pos >> 6;
+	const uint64_t i = (pos >> 6) - w0;
 	const int b = (int)(pos & 63);
 	atomicOr(words + i, (unsigned long long)(v << b));
 	if (b + width > 64) atomicOr(words + i + 1, (unsigned long long)(v >> (64 - b)));
@@ -51,14 +52,22 @@ __global__ void __launch_bounds__(256) k_efw_sizes(const int64_t *__restrict__ r
 }
 
 // 256 nodes per block: headers (gamma, terminator, pointers of the nodes that have few), then one lane per arc of the tile
-constexpr int EFW_TILE = 256, EFW_LANE_PTRS = 32;
+constexpr int EFW_TILE = 256, EFW_LANE_PTRS = 32, EFW_IMG_WORDS = 4096; // 32 KB of LDS for the tile's image
 __global__ void __launch_bounds__(EFW_TILE) k_efw_emit(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ, int32_t n, uint64_t ub, int lq, const int64_t *__restrict__ off,
                                                        unsigned long long *__restrict__ words, int *__restrict__ err) {
 	__shared__ uint64_t s_lower[EFW_TILE], s_upper[EFW_TILE];
 	__shared__ int64_t s_row[EFW_TILE + 1];
 	__shared__ int32_t s_l[EFW_TILE];
+	__shared__ unsigned long long s_img[EFW_IMG_WORDS + 1];
 	const int t = threadIdx.x;
 	const int64_t x0 = (int64_t)blockIdx.x * EFW_TILE, x = x0 + t;
+	// the tile's records are one stretch of the stream: words [iw0, iw0 + inw)
+	const int64_t xEnd = x0 + EFW_TILE < n ? x0 + EFW_TILE : n;
+	const uint64_t iw0 = (uint64_t)off[x0] >> 6, inw = (((uint64_t)off[xEnd] + 63) >> 6) - iw0;
+	const bool img = inw <= EFW_IMG_WORDS; // (wave-uniform)
+	unsigned long long *const out = img ? s_img : words;
+	const uint64_t ow0 = img ? iw0 : 0;
+	if (img) { for (uint64_t j = t; j <= inw; j += EFW_TILE) s_img[j] = 0; __syncthreads(); }
 	if (x <= n) s_row[t] = rowptr[x];
 	if (t == 0) s_row[EFW_TILE] = rowptr[x0 + EFW_TILE < n ? x0 + EFW_TILE : n];
 	if (x < n) {
@@ -69,18 +78,18 @@ __global__ void __launch_bounds__(EFW_TILE) k_efw_emit(const int64_t *__restrict
 		// gamma(d): the unary part 1 << msb on msb + 1 bits, then the msb low bits of d + 1
 		const uint64_t v = d + 1;
 		const int msb = 63 - __builtin_clzll(v);
-		efw_put(words, p, 1ull << msb, msb + 1);
-		efw_put(words, p + msb + 1, v ^ (1ull << msb), msb);
+		efw_put(out, p, 1ull << msb, msb + 1, ow0);
+		efw_put(out, p + msb + 1, v ^ (1ull << msb), msb, ow0);
 		// the terminator: value ub at index d
-		efw_put(words, p + r.lowerStart + d * (uint64_t)r.l, r.l ? ub & ((1ull << r.l) - 1) : 0, r.l);
-		efw_put(words, p + r.upperStart + (ub >> r.l) + d, 1, 1);
+		efw_put(out, p + r.lowerStart + d * (uint64_t)r.l, r.l ? ub & ((1ull << r.l) - 1) : 0, r.l, ow0);
+		efw_put(out, p + r.upperStart + (ub >> r.l) + d, 1, 1, ow0);
 		s_lower[t] = p + r.lowerStart; s_upper[t] = p + r.upperStart; s_l[t] = r.l;
 		if (r.np <= EFW_LANE_PTRS) { // pointer k: k * quantum + the values whose upper part is below k * quantum
 			for (uint64_t k = 1; k <= r.np; k++) {
 				const uint64_t z = k << lq;
 				uint64_t lo = 0, hi = d; // first index with (succ >> l) >= z
 				while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (((uint64_t)(uint32_t)succ[a + mid] >> r.l) < z) lo = mid + 1; else hi = mid; }
-				efw_put(words, p + r.ptrStart + (k - 1) * (uint64_t)r.ps, z + lo, r.ps);
+				efw_put(out, p + r.ptrStart + (k - 1) * (uint64_t)r.ps, z + lo, r.ps, ow0);
 			}
 		}
 	}
@@ -95,8 +104,16 @@ __global__ void __launch_bounds__(EFW_TILE) k_efw_emit(const int64_t *__restrict
 		const int32_t sv = succ[a];
 		if (sv < 0 || (uint64_t)sv >= ub || (i > 0 && sv <= succ[a - 1])) { atomicOr(err, 1); continue; } // strictly increasing, below the bound (:510-513)
 		const int l = s_l[lo];
-		efw_put(words, s_lower[lo] + i * (uint64_t)l, l ? (uint64_t)sv & ((1ull << l) - 1) : 0, l);
-		efw_put(words, s_upper[lo] + ((uint64_t)sv >> l) + i, 1, 1);
+		efw_put(out, s_lower[lo] + i * (uint64_t)l, l ? (uint64_t)sv & ((1ull << l) - 1) : 0, l, ow0);
+		efw_put(out, s_upper[lo] + ((uint64_t)sv >> l) + i, 1, 1, ow0);
+	}
+	if (img) { // whole words go out as they are; the first and the last are shared with the neighbouring tiles
+		__syncthreads();
+		for (uint64_t j2 = t; j2 < inw; j2 += EFW_TILE) {
+			const unsigned long long v = s_img[j2];
+			if (j2 == 0 || j2 + 1 == inw) { if (v) atomicOr(words + iw0 + j2, v); }
+			else words[iw0 + j2] = v;
+		}
 	}
 }
 
