@@ -175,7 +175,8 @@ void bvg_host_free(void *p);
  * A scan that hands nothing back but its fingerprint -- the consumer every test of the reference is
  * (ImmutableGraph.equals / hashCode, ImmutableGraph.java:731-770) and the first of the no-materialise modes (SURVEY.md
  * section 8 row f4): continues ImmutableGraph.hashCode() from *hash_io over nodes [from, to) and counts their arcs.  The rows
- * are decoded piece by piece into library scratch that stays on the die; no 4 B/edge array reaches the caller.
+ * are decoded piece by piece into library scratch that stays on the die; no 4 B/edge array reaches the caller.  On an EFGraph
+ * handle the fold happens inside the decode kernels: no successor is written at all (4 B per node of sums instead of 4 B per arc).
  * Shards compose: h(whole) = fold of the shards' maps in node order (webgraph_amd/parallel.py).
  */
 int bvg_scan_checksum(bvg_t *g, int32_t from, int32_t to, int32_t *hash_io, uint64_t *arcs_out);
