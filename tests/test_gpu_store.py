@@ -92,6 +92,10 @@ def test_store_errors(tmp_path):
         B.store(rowptr, np.array([0, 1, 2, 3, 4], dtype=np.int32), str(tmp_path / "x"), windowSize=64)
     with pytest.raises(NotImplementedError):  # a coding the reference's writer rejects too (BVGraph.java:1846)
         B.store(rowptr, np.array([0, 1, 2, 3, 4], dtype=np.int32), str(tmp_path / "x"), flags=NIBBLE << FLAG["outd"])
+    import torch
+    bad_rp = torch.tensor([0, 4, 2, 5], dtype=torch.int64, device="cuda")  # a CSR in device memory is checked too
+    with pytest.raises(ValueError):
+        B.store(bad_rp, torch.arange(5, dtype=torch.int32, device="cuda"), str(tmp_path / "x"))
     st = B.store(np.zeros(1, dtype=np.int64), np.zeros(0, dtype=np.int32), str(tmp_path / "empty"))
     assert st["written_bits"] == 0 and open(str(tmp_path / "empty") + ".offsets", "rb").read() == b"\x80"
     # rows may start lower than the previous row ended: only the order inside a row matters

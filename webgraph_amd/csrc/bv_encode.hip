@@ -38,6 +38,12 @@ constexpr int ENC_MAX_W = 63; // state of a chunk boundary: W chain lengths
 
 struct EncStatsDev { unsigned long long v[12]; }; // bitsOutd, bitsRef, bitsBlocks, bitsIntervals, bitsResiduals, copied, intervalised, residuals, totRef, totDist, maxRef, -
 
+// a CSR handed over in device memory is checked like one from the host: rowptr must not decrease (every list then lies inside succ[0, rowptr[n]))
+__global__ void __launch_bounds__(256) k_enc_check_rowptr(const int64_t *__restrict__ rowptr, int32_t n, int *__restrict__ err) {
+	const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (x < n && (rowptr[x + 1] < rowptr[x] || rowptr[x + 1] - rowptr[x] > 0x7fffffffll)) atomicOr(err, 8);
+}
+
 // ---- work lists: the items of a phase (pairs, nodes) grouped by the log2 of their size, biggest first.  A lane walks its
 // item alone, so a wave lasts as long as its longest item: waves of like-sized items waste no lane-time, and the long ones
 // start first.  Within a bin the items stay in (nearly) node order: the pairs of a node share its successor list.
@@ -515,6 +521,12 @@ int encode_device(const Params &p, int32_t n, const int64_t *d_rowptr, const int
 	(void)hipMemsetAsync(dstats, 0, sizeof(EncStatsDev), st);
 	mark();
 	auto blocks = [](int64_t items, int per) { return dim3((unsigned)((items + per - 1) / per > 0 ? (items + per - 1) / per : 1)); };
+	if (n) hipLaunchKernelGGL(k_enc_check_rowptr, blocks(n, 256), dim3(256), 0, st, d_rowptr, n, flags);
+	{
+		int h0 = 0;
+		if (hipMemcpyAsync(&h0, flags, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { err = "the compressor kernels failed"; return cleanup(-6); }
+		if (h0 & 8) { err = "rowptr must start at 0 and be monotone"; return cleanup(-1); }
+	}
 	// A
 	if (npairs) {
 		const PairItems items{ p, d_rowptr, npairs };
