@@ -204,3 +204,42 @@ def test_checksum_without_writing_the_lists(tmp_path, monkeypatch):
     monkeypatch.setenv("BVGPU_EF_HASH_MATERIALISE", "1")
     assert g.hashCode() == want
     g.close(); h.close()
+
+
+def test_corrupt_streams_fail_cleanly(tmp_path):
+    """Bit flips anywhere in an EFGraph's stream: every call comes back (an error, or lists that differ), nothing is written past the
+    caller's buffers (a guard band behind them stays intact)."""
+    import ctypes as C
+    from webgraph_amd import bvgraph as B
+    base, rowptr, succ = _store(tmp_path, 20000, 400000, 17, log2_quantum=3)
+    raw = bytearray(open(base + ".graph", "rb").read())
+    rng = np.random.Generator(np.random.PCG64(5))
+    n, m = rowptr.size - 1, succ.size
+    guard = 4096
+    outcomes = set()
+    for trial in range(40):
+        bad = bytearray(raw)
+        for _ in range(int(rng.integers(1, 40))):
+            bad[int(rng.integers(0, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+        open(base + ".graph", "wb").write(bytes(bad))
+        g = B.BVGraph.load(base)
+        rp = np.full(n + 1 + guard, -7, dtype=np.int64)
+        sc = np.full(2 * m + guard, -7, dtype=np.int32)
+        arcs = C.c_uint64(0)
+        rc = B.lib().bvg_decode_range(g._h, 0, n, rp.ctypes.data, sc.ctypes.data, 2 * m, C.byref(arcs), B.BVG_OUT_HOST)
+        outcomes.add(rc)
+        assert rc in (0, B.BVG_EFORMAT, B.BVG_ECAP, B.BVG_ENOMEM), rc
+        assert np.all(rp[n + 1:] == -7) and np.all(sc[2 * m:] == -7)
+        if rc == 0:
+            assert arcs.value <= 2 * m
+        q = rng.integers(0, n, size=500).astype(np.int32)
+        brp = np.empty(501, dtype=np.int64)
+        rc = B.lib().bvg_successors_batch(g._h, q.ctypes.data, 500, brp.ctypes.data, sc.ctypes.data, 2 * m, C.byref(arcs), B.BVG_OUT_HOST)
+        assert rc in (0, B.BVG_EFORMAT, B.BVG_ECAP, B.BVG_ENOMEM), rc
+        assert np.all(sc[2 * m:] == -7)
+        hh = C.c_int32(-1)
+        rc = B.lib().bvg_scan_checksum(g._h, 0, n, C.byref(hh), C.byref(arcs))
+        assert rc in (0, B.BVG_EFORMAT, B.BVG_ENOMEM), rc
+        g.close()
+    open(base + ".graph", "wb").write(bytes(raw))
+    assert len(outcomes) >= 1
