@@ -243,3 +243,26 @@ def test_corrupt_streams_fail_cleanly(tmp_path):
         g.close()
     open(base + ".graph", "wb").write(bytes(raw))
     assert len(outcomes) >= 1
+
+
+def test_cache_as_efgraph(cnr_oracle):
+    """bvg_cache_as_efgraph: the handle re-encodes its lists in HBM and answers from there -- the same lists, the same hashCode; a clone
+    made before keeps the BVGraph image."""
+    from conftest import CNR
+    from webgraph_amd import bvgraph as B
+    _, rowptr, succ = cnr_oracle
+    g = B.BVGraph.load(CNR)
+    c = g.copy()
+    h0 = g.hashCode()
+    g.cache_as_efgraph()
+    assert g.info.format == B.BVG_FORMAT_EF and c.info.format == B.BVG_FORMAT_BV and g.numArcs() == succ.size
+    rp, sc = g.decode_range()
+    assert np.array_equal(rp, rowptr) and np.array_equal(sc, succ) and g.hashCode() == h0 == 1711395807
+    q = np.array([7, 100000, 46918, 325556, 7], dtype=np.int32)
+    brp, bsc = g.successors_batch(q)
+    crp, csc = c.successors_batch(q)
+    assert np.array_equal(brp, crp) and np.array_equal(bsc, csc)
+    g.cache_as_efgraph()  # a second call is a no-op
+    rp, sc = c.decode_range(1000, 2000)
+    assert np.array_equal(sc, succ[rowptr[1000]:rowptr[2000]])
+    g.close(); c.close()

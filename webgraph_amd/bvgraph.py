@@ -57,7 +57,7 @@ class BvgLabelsInfo(C.Structure):
 EXPORTS = ["bvg_open", "bvg_open_shard", "bvg_clone", "bvg_close", "bvg_info", "bvg_last_error", "bvg_set_stream", "bvg_sync",
            "bvg_outdegrees", "bvg_decode_range", "bvg_decode_range_view", "bvg_host_alloc", "bvg_host_free", "bvg_scan_checksum", "bvg_scan_stats", "bvg_bfs_expand", "bvg_hyperball_step", "bvg_successors_batch", "bvg_csr_hashcode", "bvg_shard_bounds",
            "bvg_parse_properties", "bvg_flags_from_string", "bvg_decode_offsets_host", "bvg_decode_offsets_device", "bvg_labels_open", "bvg_labels_close", "bvg_labels_info",
-           "bvg_labels_last_error", "bvg_labels_parse_properties", "bvg_labels_decode_range", "bvg_labels_decode_lists", "bvg_compress", "bvg_compressed_free", "bvg_compressed_copy", "bvg_store", "bvg_recompress", "bvg_store_ef", "bvg_recompress_ef", "bvg_set_profile", "bvg_get_profile", "bvg_debug_stats", "bvg_last_thresholds"]
+           "bvg_labels_last_error", "bvg_labels_parse_properties", "bvg_labels_decode_range", "bvg_labels_decode_lists", "bvg_compress", "bvg_compressed_free", "bvg_compressed_copy", "bvg_store", "bvg_recompress", "bvg_store_ef", "bvg_recompress_ef", "bvg_cache_as_efgraph", "bvg_set_profile", "bvg_get_profile", "bvg_debug_stats", "bvg_last_thresholds"]
 
 _lib = None
 
@@ -120,6 +120,7 @@ def lib():
         L.bvg_recompress.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.POINTER(BvgStoreStats), C.c_char_p, sz]
         L.bvg_store_ef.argtypes = [C.c_char_p, C.c_int, i32, vp, vp, C.c_int, i32, C.c_int, C.c_int, C.c_char_p, sz]
         L.bvg_recompress_ef.argtypes = [vp, C.c_char_p, i32, C.c_int, C.c_int, C.c_char_p, sz]
+        L.bvg_cache_as_efgraph.argtypes = [vp]
         L.bvg_set_profile.argtypes = [vp, C.c_int]
         L.bvg_get_profile.argtypes = [vp, C.POINTER(C.c_float)]
         L.bvg_last_thresholds.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
@@ -471,6 +472,13 @@ class BVGraph:
         if rc:
             _raise(rc, err.value.decode("utf-8", "replace"))
         return st.as_dict()
+
+    def cache_as_efgraph(self):
+        """Re-encodes the handle's lists as an EFGraph image in HBM and decodes from it from now on (bvg_cache_as_efgraph): same lists, faster."""
+        self._check(lib().bvg_cache_as_efgraph(self._h))
+        rc = lib().bvg_info(self._h, C.byref(self.info))
+        if rc:
+            _raise(rc, "bvg_info")
 
     def store_ef(self, basename, upperBound=None, log2Quantum=8, bigEndian=False):
         """EFGraph.store(this, basename, ...): decode and re-encode as an EFGraph without leaving the device."""
