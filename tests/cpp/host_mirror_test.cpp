@@ -10,7 +10,7 @@
 #define REQUIRE(c) do { if (!(c)) { fprintf(stderr, "FAILED: %s (line %d)\n", #c, __LINE__); return 1; } } while (0)
 
 int main(int argc, char **argv) {
-	if (argc < 4) { fprintf(stderr, "usage: %s basename hashcode arcs\n", argv[0]); return 2; }
+	if (argc < 4) { fprintf(stderr, "usage: %s basename hashcode arcs [out-basename minintervallength]\n", argv[0]); return 2; }
 	using namespace webgraph;
 	try {
 		BVGraph g = BVGraph::load(argv[1]);
@@ -69,6 +69,19 @@ int main(int argc, char **argv) {
 		}
 		// the checksum scan (nothing materialised) agrees with the host-side fold
 		{ uint64_t a = 0; REQUIRE(g.scanChecksum(0, n, -1, &a) == atoi(argv[2]) && (int64_t)a == g.numArcs()); }
+		// BVGraph.store / EFGraph.store of the loaded graph, on the device: with the fixture's own parameters the reference's bytes come back;
+		// the EFGraph loads through the same class and equals the graph it was made from
+		if (argc > 4) {
+			const std::string out = argv[4];
+			BVGraph::store(g, out + "_bv", g.windowSize(), g.maxRefCount(), atoi(argv[5]), 3);
+			auto slurp = [](const std::string &path) { std::vector<char> b; FILE *f = fopen(path.c_str(), "rb"); if (f) { char buf[65536]; size_t k; while ((k = fread(buf, 1, sizeof buf, f)) > 0) b.insert(b.end(), buf, buf + k); fclose(f); } return b; };
+			REQUIRE(slurp(out + "_bv.graph") == slurp(std::string(argv[1]) + ".graph") && !slurp(out + "_bv.graph").empty());
+			REQUIRE(slurp(out + "_bv.offsets") == slurp(std::string(argv[1]) + ".offsets"));
+			BVGraph::storeEF(g, out + "_ef");
+			BVGraph e = BVGraph::load(out + "_ef");
+			REQUIRE(e.isEFGraph() && !g.isEFGraph() && e.numArcs() == g.numArcs());
+			REQUIRE(e.equals(g) && e.scanChecksum(0, n, -1) == atoi(argv[2]));
+		}
 		// flyweight copy
 		BVGraph c = g.copy();
 		REQUIRE(c.successorArray(n - 1) == g.successorArray(n - 1));

@@ -82,7 +82,7 @@ def test_cpp_host_mirror_runs(tmp_path):
     pkg = os.path.join(ROOT, "webgraph_amd")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-o", exe, os.path.join(ROOT, "tests", "cpp", "host_mirror_test.cpp"),
                            "-L" + pkg, "-lbvgpu", "-Wl,-rpath," + pkg, "-L/opt/rocm/lib", "-lamdhip64"])
-    p = subprocess.run([exe, CNR, "1711395807", "3216152"], capture_output=True, text=True)
+    p = subprocess.run([exe, CNR, "1711395807", "3216152", str(tmp_path / "out"), "3"], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
     assert "host mirror ok" in p.stdout
 

@@ -37,6 +37,17 @@ inline void check(int rc, const bvg_t *h) {
 	default: throw std::runtime_error(msg + " (bvg_status " + std::to_string(rc) + ")");
 	}
 }
+inline void check_msg(int rc, const char *msg) { // entry points that report through a caller's buffer
+	if (rc == BVG_OK) return;
+	switch (rc) {
+	case BVG_EARG: throw std::invalid_argument(msg);
+	case BVG_ESTATE: throw std::logic_error(msg);
+	case BVG_EUNSUPPORTED: throw unsupported_operation(msg);
+	case BVG_EIO: throw io_error(msg);
+	case BVG_ENOMEM: throw std::bad_alloc();
+	default: throw std::runtime_error(std::string(msg) + " (bvg_status " + std::to_string(rc) + ")");
+	}
+}
 } // namespace detail
 
 // Increasing successor ids, then -1 forever (LazyIntIterator.java:28-43).
@@ -93,6 +104,20 @@ public:
 	}
 	static BVGraph loadMapped(const std::string &b, int device = 0) { return load(b, device); }
 	static BVGraph loadOffline(const std::string &b, int device = 0) { return load(b, device); }
+
+	// BVGraph.store(graph, basename, windowSize, maxRefCount, minIntervalLength, zetaK, flags, numberOfThreads) (BVGraph.java:1679-1730) for a graph
+	// that is a handle of this library: decoded and recompressed on the device (bvg_recompress); the reference's defaults (BVGraph.java:455-470)
+	static void store(const BVGraph &graph, const std::string &basename, int windowSize = 7, int maxRefCount = 3, int minIntervalLength = 4, int zetaK = 3, uint32_t flags = 0,
+	                  int numberOfThreads = 1) {
+		char err[512] = "";
+		detail::check_msg(bvg_recompress(graph.handle(), basename.c_str(), windowSize, maxRefCount, minIntervalLength, zetaK, flags, numberOfThreads, nullptr, err, sizeof err), err);
+	}
+	// EFGraph.store(graph, basename) (EFGraph.java:800-810): the quasi-succinct format, written on the device (bvg_recompress_ef)
+	static void storeEF(const BVGraph &graph, const std::string &basename, int log2Quantum = 8, bool bigEndian = false) {
+		char err[512] = "";
+		detail::check_msg(bvg_recompress_ef(graph.handle(), basename.c_str(), 0, log2Quantum, bigEndian ? 1 : 0, err, sizeof err), err);
+	}
+	bool isEFGraph() const { return info_.format == BVG_FORMAT_EF; }
 
 	int32_t numNodes() const { return info_.nodes; }               // ImmutableGraph.java:254
 	int64_t numArcs() const { return info_.arcs; }                 // :260
