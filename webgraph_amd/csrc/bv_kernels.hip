@@ -1216,6 +1216,22 @@ __global__ void __launch_bounds__(TPB) k_hash_nodes(int32_t from, int32_t cnt, c
 	if (threadIdx.x == 0) { outA[c] = pow31((uint64_t)(end - start)); outB[c] = s_part[0]; }
 }
 
+// 256 consecutive maps -> one (the single block below needed 0.24 ms for the 51 000 chunk maps of a C2 scan: 200 rounds of a tree with eight barriers)
+__global__ void __launch_bounds__(TPB) k_hash_reduce(const uint32_t *__restrict__ A, const uint32_t *__restrict__ B, int64_t nb, uint32_t *__restrict__ A2, uint32_t *__restrict__ B2) {
+	__shared__ Affine sw[TPB / 64];
+	const int64_t j = (int64_t)blockIdx.x * TPB + threadIdx.x;
+	const int lane = threadIdx.x & 63;
+	Affine v = j < nb ? Affine{ A[j], B[j] } : Affine{ 1u, 0u };
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) { // inclusive scan in order: lane l = maps of lanes 0 .. l composed
+		const uint32_t pa = __shfl_up(v.a, o), pb = __shfl_up(v.b, o);
+		if (lane >= o) v = compose(Affine{ pa, pb }, v);
+	}
+	if (lane == 63) sw[threadIdx.x >> 6] = v;
+	__syncthreads();
+	if (threadIdx.x == 0) { Affine all = sw[0]; for (int w = 1; w < TPB / 64; w++) all = compose(all, sw[w]); A2[blockIdx.x] = all.a; B2[blockIdx.x] = all.b; }
+}
+
 // single block: fold nb block maps in order and apply to *hash
 __global__ void __launch_bounds__(TPB) k_hash_fold(const uint32_t *__restrict__ A, const uint32_t *__restrict__ B, int64_t nb, int32_t *__restrict__ hash) {
 	__shared__ Affine sh[TPB];
@@ -1306,7 +1322,12 @@ void launch_hash(int32_t from, int32_t cnt, int64_t arcs, const int64_t *rowptr,
 	const int64_t nc = hash_chunks(cnt, arcs);
 	hipLaunchKernelGGL(k_hash_bounds, dim3(nblk(nc + 1, TPB)), dim3(TPB), 0, st, cnt, rowptr, nc, bounds);
 	hipLaunchKernelGGL(k_hash_nodes, dim3((unsigned)nc), dim3(TPB), 0, st, from, cnt, rowptr, succ, bounds, (int64_t)cnt + arcs, A, B);
-	hipLaunchKernelGGL(k_hash_fold, dim3(1), dim3(TPB), 0, st, A, B, nc, hash);
+	if (nc >= 4 * TPB) { // the chunk maps are reduced 256 to one first; `bounds` (nc + 1 words, done with) holds the reduced maps
+		const int64_t n2 = (nc + TPB - 1) / TPB;
+		uint32_t *A2 = (uint32_t *)bounds, *B2 = A2 + n2;
+		hipLaunchKernelGGL(k_hash_reduce, dim3((unsigned)n2), dim3(TPB), 0, st, A, B, nc, A2, B2);
+		hipLaunchKernelGGL(k_hash_fold, dim3(1), dim3(TPB), 0, st, A2, B2, n2, hash);
+	} else hipLaunchKernelGGL(k_hash_fold, dim3(1), dim3(TPB), 0, st, A, B, nc, hash);
 }
 
 void launch_chain_len(const GraphDev &g, int def, const int32_t *nodes, int64_t q, int32_t *chainlen, int32_t *maxlen, int *err, hipStream_t st) {
