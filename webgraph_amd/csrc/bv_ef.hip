@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(EF_TILE) k_ef_decode(const EfDev g, const int3
 		const uint64_t high = wi * 64 + bit - up - i;
 		const uint32_t val = (uint32_t)((high << l) | ef_get(g, s_lower[a] + (uint64_t)i * (uint64_t)l, l));
 		if (!HASH) succ[s_row[a] + i] = (int32_t)val;
-		else hv = val * s_pow[i & (EF_TILE - 1)], ha = a;
+		else hv = val * (i < (uint32_t)EF_TILE ? s_pow[i] : pow31(i)), ha = a;
 		}
 		}
 		if (HASH) { // neighbouring lanes hold neighbouring successors: the lanes of one list add up among themselves, its first lane adds to the slot
