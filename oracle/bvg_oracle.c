@@ -427,7 +427,7 @@ int bvo_scan(const bvo_graph *h, int32_t from, int32_t to, int64_t *rowptr, int3
 		if (d < 0) { rc = (int)d; goto out; }
 		if (succ) {
 			if (arcs + (uint64_t)d > cap) { rc = BVO_ECAP; goto out; }
-			memcpy(succ + arcs, win[idx].v, sizeof(int32_t) * (size_t)d);
+			if (d) memcpy(succ + arcs, win[idx].v, sizeof(int32_t) * (size_t)d); /* (an empty list may have no buffer at all) */
 		}
 		if (hash_io) { /* ImmutableGraph.java:762-766 */
 			hh = hh * 31u + (uint32_t)x;
@@ -484,7 +484,7 @@ int bvo_successors_batch(const bvo_graph *h, const int32_t *nodes, size_t q, int
 		if (d < 0) { free(dst.v); return (int)d; }
 		if (succ) {
 			if (arcs + (uint64_t)d > cap) { free(dst.v); return BVO_ECAP; }
-			memcpy(succ + arcs, dst.v, sizeof(int32_t) * (size_t)d);
+			if (d) memcpy(succ + arcs, dst.v, sizeof(int32_t) * (size_t)d);
 		}
 		arcs += (uint64_t)d;
 		rowptr[i + 1] = (int64_t)arcs;

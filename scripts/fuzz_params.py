@@ -36,6 +36,8 @@ def main():
         dense = str(rng.choice(["0", "32", "1000000000"]))
         env["BVGPU_BATCH_DENSE"] = dense
         desc = "n=%d m=%d p=%.2f W=%d mr=%d mi=%d k=%d flags=[%s] env=%s" % (n, m, p_copy, W, mr, mi, k, fl, env)
+        if os.environ.get("FUZZ_VERBOSE"):
+            print("case", c, desc, file=sys.stderr, flush=True)
         try:
             rowptr, succ = T.generate(n, m, seed=int(rng.integers(1, 1 << 30)), p_copy=p_copy)
             base = os.path.join(tmp, "g%d" % c)
