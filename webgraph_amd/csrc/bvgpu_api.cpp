@@ -28,7 +28,9 @@ struct DevBuf {
 		if (bytes <= cap) return true;
 		if (p) (void)hipFree(p);
 		p = nullptr; cap = 0;
-		size_t want = bytes + bytes / 8 + 256;
+		// BVGPU_EXACT_ALLOC=1 (tests): no slack, so that scripts/guard_alloc.cpp's unmapped page sits right behind what was asked for
+		static const bool exact = [] { const char *e = getenv("BVGPU_EXACT_ALLOC"); return e && atoi(e) != 0; }();
+		size_t want = exact ? bytes : bytes + bytes / 8 + 256;
 		if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return false; }
 		cap = want;
 		return true;
@@ -358,6 +360,7 @@ int finish_pending(bvg_graph *g, uint64_t *arcs_out) {
 	if (arcs_out) *arcs_out = g->last_arcs;
 	if (g->h_small->err) {
 		const int st = dev_err_to_status(g->h_small->err);
+		if (getenv("BVGPU_TRACE_ERR")) fprintf(stderr, "[bvgpu] range job: device error bits 0x%x\n", g->h_small->err);
 		return fail(g, st, st == BVG_ECAP ? "successor buffer too small" : st == BVG_ESTATE ? "reference incompatible with the window size" : "malformed or unsupported bit stream");
 	}
 	return BVG_OK;
