@@ -10,8 +10,6 @@
 // successor by popcounts for the short lists and by a prefix sum over the popcounts of 64 words for the long ones.
 #include "bv_launch.hpp"
 
-#include <cstdlib>
-
 namespace bv {
 
 __device__ __forceinline__ uint64_t ef_ld(const EfDev &g, uint64_t i) { return i < g.nwords ? g.words[i] : 0ull; } // (the image is followed by zero words; a malformed offset may point anywhere)
@@ -195,118 +193,6 @@ __global__ void __launch_bounds__(256) k_ef_hash_fold(const Affine *__restrict__
 	if (t == 0) { Affine all = s_w[0]; for (int w = 1; w < 4; w++) all = then(all, s_w[w]); *h = (int32_t)(all.m * (uint32_t)*h + all.b); }
 }
 
-// ---- lists below giantMin, one lane per WORD of upper bits.  Phase 1 as in k_ef_decode (a lane per slot reads its record's
-// header), but what the block scan numbers are the words that hold the lists' ones: the i-th one of a list sits at bit
-// (s_i >> l) + i <= ((ub - 1) >> l) + d - 1 of its upper bits, which bounds the words of a list without looking at them.  Phase 2:
-// a lane takes one word; a segmented prefix sum over the popcounts (segments = lists; carried across the waves and across the
-// rounds of 256 words) tells it the index of its first one, and it walks its ones as ef_round does.  A list of 300 successors
-// keeps ten lanes busy here instead of a whole wave, and a short list costs one search per word instead of one search and one
-// select per successor.
-constexpr int EFI_T = 256;
-template <bool HASH>
-__global__ void __launch_bounds__(EFI_T) k_ef_items(const EfDev g, const int32_t *__restrict__ nodes, int32_t lo, int64_t cnt, int32_t giantMin, const int64_t *__restrict__ rowstart,
-                                                    int32_t *__restrict__ succ, uint64_t cap, int *__restrict__ err, int mode) {
-	__shared__ uint64_t s_lower[EFI_T], s_upper[EFI_T];
-	__shared__ int64_t s_row[EFI_T];
-	__shared__ int32_t s_first[EFI_T + 1]; // words of the tile's lists before slot t
-	__shared__ int32_t s_d[EFI_T], s_l[EFI_T], s_wsum[EFI_T / 64];
-	__shared__ uint32_t s_wv[EFI_T / 64], s_wf[EFI_T / 64], s_carry;
-	__shared__ uint32_t s_acc[HASH ? EFI_T : 1];
-	const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-	if (HASH) s_acc[t] = 0;
-	if (t == 0) s_carry = 0;
-	const int64_t s = (int64_t)blockIdx.x * EFI_T + t;
-	int32_t nw = 0;
-	bool mine = false; // HASH: this slot's sum is written by this kernel
-	if (s < cnt) {
-		const int64_t base = rowstart[s];
-		const int64_t d = rowstart[s + 1] - base;
-		mine = d < giantMin;
-		if (d > 0 && d < giantMin) {
-			if ((uint64_t)(base + d) > cap) atomicOr(err, E_CAP);
-			else {
-				EfRecord r;
-				const int32_t x = nodes ? nodes[s] : (int32_t)(lo + s);
-				if (!ef_header(g, (uint64_t)g.offsets[x], r) || (int64_t)r.d != d) atomicOr(err, E_FORMAT);
-				else {
-					s_lower[t] = r.lowerStart; s_upper[t] = r.upperStart; s_l[t] = r.l; s_row[t] = base; s_d[t] = (int32_t)d;
-					const uint64_t lastBit = r.upperStart + ((g.ub ? g.ub - 1 : 0) >> r.l) + (uint64_t)d - 1;
-					nw = (int32_t)((lastBit >> 6) - (r.upperStart >> 6) + 1);
-				}
-			}
-		}
-	}
-	int32_t inc = nw;
-#pragma unroll
-	for (int o = 1; o < 64; o <<= 1) { const int32_t v = __shfl_up(inc, o); if (lane >= o) inc += v; }
-	if (lane == 63) s_wsum[wv] = inc;
-	__syncthreads();
-	int32_t before = 0;
-	for (int w = 0; w < wv; w++) before += s_wsum[w];
-	s_first[t] = before + inc - nw;
-	if (t == EFI_T - 1) s_first[EFI_T] = before + inc;
-	__syncthreads();
-	const int32_t total = s_first[EFI_T];
-	for (int32_t k0 = 0; k0 < total; k0 += EFI_T) { // (uniform trip count: shuffles and barriers inside)
-		const int32_t k = k0 + t;
-		const bool valid = k < total;
-		int a = 0;
-		uint32_t j = 0, pc = 0;
-		uint64_t w = 0;
-		if (valid) {
-			int b = EFI_T; // last slot with s_first <= k (slots without words repeat their successor's value: the last of them is the one)
-#pragma unroll
-			for (int step = 0; step < 8; step++) { const int mid = (a + b) >> 1; if (s_first[mid] <= k) a = mid; else b = mid; }
-			j = (uint32_t)(k - s_first[a]);
-			const uint64_t up = s_upper[a];
-			w = ef_ld(g, (up >> 6) + j);
-			if (j == 0) w &= ~0ull << (up & 63);
-			pc = (uint32_t)__popcll(w);
-		}
-		// ones of the same list before this word: segmented inclusive scan (a list's first word opens a segment; so does a lane without a word)
-		uint32_t v = pc;
-		int f = !valid || j == 0;
-#pragma unroll
-		for (int o = 1; o < 64; o <<= 1) {
-			const uint32_t pv = __shfl_up(v, o);
-			const int pf = __shfl_up(f, o);
-			if (lane >= o && !f) { v += pv; f = pf; }
-		}
-		if (lane == 63) { s_wv[wv] = v; s_wf[wv] = (uint32_t)f; }
-		__syncthreads();
-		uint32_t carry = s_carry; // ones of the list that runs into this round
-		for (int u = 0; u < wv; u++) carry = s_wf[u] ? s_wv[u] : carry + s_wv[u];
-		if (!f) v += carry;
-		__syncthreads(); // (everybody has read s_carry and the waves' sums)
-		if (t == EFI_T - 1) s_carry = v;
-		if (valid) {
-			const uint32_t d = (uint32_t)s_d[a];
-			if (k + 1 == s_first[a + 1] && v < d) atomicOr(err, E_FORMAT); // the list's last word, and not all of its ones seen
-			uint32_t i = v - pc; // index of this word's first one
-			if (pc && i < d && mode != 2) {
-				const int l = s_l[a];
-				const uint64_t lowS = s_lower[a];
-				const int32_t bit0 = (int32_t)(j * 64u) - (int32_t)(s_upper[a] & 63); // bit 0 of this word, counted from the start of the upper bits
-				int32_t *__restrict__ out = HASH ? nullptr : succ + s_row[a];
-				uint32_t hsum = 0, pw = HASH ? pow31(i) : 0;
-				while (w && i < d) {
-					const uint32_t high = (uint32_t)(bit0 + __builtin_ctzll(w)) - i;
-					w &= w - 1;
-					const uint32_t val = (high << l) | (mode == 3 ? 0u : (uint32_t)ef_get(g, lowS + (uint64_t)(i * (uint32_t)l), l));
-					if (HASH) { hsum += val * pw; pw *= 31u; }
-					else out[i] = (int32_t)val;
-					i++;
-				}
-				if (HASH && hsum) atomicAdd(&s_acc[a], hsum);
-			}
-		}
-	}
-	if (HASH) {
-		__syncthreads();
-		if (s < cnt && mine) ((uint32_t *)succ)[s] = s_acc[t];
-	}
-}
-
 // ---- long lists.  A round takes 64 words of upper bits: a prefix sum over their popcounts gives every one its index; the lower
 // bits of the round's successors are one contiguous stretch of the stream, staged in LDS so that the walk over a word's ones
 // waits for nothing.  Lists below giantMin are decoded by one wave, round after round (k_ef_decode_wave).  A giant list (C2 has
@@ -469,8 +355,6 @@ __global__ void __launch_bounds__(256) k_ef_decode_chunks(const EfDev g, const i
 	}
 }
 
-static int ef_items() { static const int on = [] { const char *e = getenv("BVGPU_EF_ITEMS"); return e ? atoi(e) : 0; }(); return on; } // experiment: one lane per word of upper bits
-
 void launch_ef_outdeg(const EfDev &g, const int32_t *nodes, int32_t lo, int64_t cnt, int32_t *outd, int *err, hipStream_t st) {
 	if (cnt > 0) hipLaunchKernelGGL(k_ef_outdeg, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, g, nodes, lo, cnt, outd, err);
 }
@@ -479,7 +363,6 @@ void launch_ef_decode(const EfDev &g, const int32_t *nodes, int32_t lo, int64_t 
 	if (cnt <= 0) return;
 	hipLaunchKernelGGL(k_ef_rank<false>, dim3(256), dim3(256), 0, stGiant, g, nodes, lo, cnt, giantMin, rowstart, succ, cap, (EfChunk *)chunks, chunkCap, nchunks, err);
 	hipLaunchKernelGGL(k_ef_decode_chunks<false>, dim3(1024), dim3(256), 0, stGiant, g, nodes, lo, (const EfChunk *)chunks, nchunks, chunkCap, rowstart, succ, err);
-	if (ef_items()) { hipLaunchKernelGGL(k_ef_items<false>, dim3((unsigned)((cnt + EFI_T - 1) / EFI_T)), dim3(EFI_T), 0, st, g, nodes, lo, cnt, giantMin, rowstart, succ, cap, err, ef_items()); return; }
 	hipLaunchKernelGGL(k_ef_decode_wave<false>, dim3(1024), dim3(256), 0, stLong, g, nodes, lo, cnt, bigMin, giantMin, rowstart, succ, cap, err);
 	hipLaunchKernelGGL(k_ef_decode<false>, dim3((unsigned)((cnt + EF_TILE - 1) / EF_TILE)), dim3(EF_TILE), 0, st, g, nodes, lo, cnt, bigMin, rowstart, succ, cap, err);
 }
@@ -491,7 +374,6 @@ void launch_ef_hash(const EfDev &g, int32_t lo, int64_t cnt, int32_t bigMin, con
 	const uint64_t cap = ~0ull;
 	hipLaunchKernelGGL(k_ef_rank<true>, dim3(256), dim3(256), 0, stGiant, g, (const int32_t *)nullptr, lo, cnt, giantMin, rowstart, (int32_t *)acc, cap, (EfChunk *)chunks, chunkCap, nchunks, err);
 	hipLaunchKernelGGL(k_ef_decode_chunks<true>, dim3(1024), dim3(256), 0, stGiant, g, (const int32_t *)nullptr, lo, (const EfChunk *)chunks, nchunks, chunkCap, rowstart, (int32_t *)acc, err);
-	if (ef_items()) { hipLaunchKernelGGL(k_ef_items<true>, dim3((unsigned)((cnt + EFI_T - 1) / EFI_T)), dim3(EFI_T), 0, st, g, (const int32_t *)nullptr, lo, cnt, giantMin, rowstart, (int32_t *)acc, cap, err, ef_items()); return; }
 	hipLaunchKernelGGL(k_ef_decode_wave<true>, dim3(1024), dim3(256), 0, stLong, g, (const int32_t *)nullptr, lo, cnt, bigMin, giantMin, rowstart, (int32_t *)acc, cap, err);
 	hipLaunchKernelGGL(k_ef_decode<true>, dim3((unsigned)((cnt + EF_TILE - 1) / EF_TILE)), dim3(EF_TILE), 0, st, g, (const int32_t *)nullptr, lo, cnt, bigMin, rowstart, (int32_t *)acc, cap, err);
 }
