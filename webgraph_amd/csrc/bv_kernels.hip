@@ -499,179 +499,6 @@ __global__ void __launch_bounds__(TPB) k_copy_list(GraphDev g, RangeView v, cons
 	}
 }
 
-// The block list of every row of the lane class, walked ONCE for all levels while the parse kernels still run (nothing here
-// needs a referent's ids): a row that copies nc > 0 ids keeps its kept blocks in row[0 .. nk), nk <= nc -- words the parse
-// kernel leaves alone, its extras start at row[nc] -- as  1 << 31 | last << 30 | end among the copied ids << 16 | index offset
-// (end <= d < 2^14, offset < dref < COPY_REF_BIG <= 2^16).  A successor is never negative, so a row without a table (nc = 0: its
-// extras start at row[0]) cannot be taken for one; a list that does not parse leaves a table that fails k_copy_tile's checks.
-constexpr uint32_t BT_ENTRY = 0x80000000u, BT_LAST = 0x40000000u;
-template <int DEF>
-__global__ void __launch_bounds__(TPB) k_block_tables(GraphDev g, RangeView v, const int32_t *__restrict__ list, const int32_t *__restrict__ keyBase, int32_t midMin, int32_t bigMin, int *__restrict__ err) {
-	// the level lists from level 1 on: the records with a reference, packed (one lane in four of a sweep over the nodes would have one)
-	const int32_t lo = keyBase[NBIN], hi = keyBase[NKEYS];
-	for (int32_t idx = lo + blockIdx.x * TPB + threadIdx.x; idx < hi; idx += gridDim.x * TPB) {
-	const int32_t s = list[idx];
-	const int32_t r = v.ref[s], d = v.outd[s];
-	if (r == 0 || d <= 0 || !v.fits(s) || !v.fits(s - r)) continue;
-	const int64_t dref = v.outd[s - r];
-	if (copy_class_of(d, (int32_t)dref, midMin, bigMin) != 1) continue;
-	int32_t *row = v.row(s);
-	BitReader br;
-	br.init(g.bits, g.nwords);
-	br.seek((uint64_t)g.offsets[v.lo + s]);
-	(void)Fields<DEF>::outdegree(br, g);
-	(void)Fields<DEF>::reference(br, g);
-	const uint64_t bc = Fields<DEF>::block_count(br, g);
-	bool ok = bc <= (uint64_t)dref + 1; // (otherwise flagged by the parse kernel)
-	int64_t tot = 0, copied = 0;
-	int32_t nk = 0;
-	uint32_t pending = 0;
-	for (uint64_t b = 0; ok && b <= bc; b++) {
-		int64_t len;
-		if (b < bc) { if (!block_len_ok(Fields<DEF>::block(br, g), b == 0, tot, dref, len)) { ok = false; break; } }
-		else len = dref - tot; // implicit last block: the rest of the referent (copied when the block count is even)
-		if (!(b & 1) && len > 0) {
-			if (copied + len > d) { ok = false; break; }
-			copied += len;
-			if (nk) row[nk - 1] = (int32_t)pending;
-			pending = BT_ENTRY | (uint32_t)copied << 16 | (uint32_t)(tot + len - copied);
-			nk++;
-		}
-		tot += len;
-	}
-	if (br.err) ok = false;
-	if (!ok) row[0] = (int32_t)(BT_ENTRY | BT_LAST); // (ends at 0: not a table)
-	else if (nk) row[nk - 1] = (int32_t)(pending | BT_LAST);
-	}
-}
-
-// The lane class of a level, 64 rows per wave (experiment, BVGPU_COPY_TILE=1).  A lane fetches its row's kept blocks (k_block_tables)
-// into LDS; then the wave works per ID, whatever row it belongs to: a copied id finds its block and with it its index in the
-// referent's row, the copied ids are loaded through those indices and the extras from the row's tail (neighbouring lanes read
-// neighbouring words), every id finds its place by one binary search in the other set of its row (in LDS), and goes there.  A row
-// with an id in both sets (never in a valid file), or without a table that checks, is left to copy_node.
-constexpr int CT_WAVES = 4;
-#ifndef CT_CAP
-#define CT_CAP 1024
-#endif
-template <int DEF>
-__global__ void __launch_bounds__(64 * CT_WAVES) k_copy_tile(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ list,
-                                                             const int32_t *__restrict__ keyBase, int32_t level, int32_t midMin, int32_t bigMin, int *__restrict__ err, int stage) {
-	__shared__ int32_t s_ids[CT_WAVES][CT_CAP];   // a row's slice: its kept blocks (end among the copied ids << 16 | index offset), then its ids -- copied ones first
-	__shared__ uint16_t s_pos[CT_WAVES][CT_CAP];  // index in the referent's row, then the id's final place in its row
-	__shared__ uint8_t s_rowi[CT_WAVES][CT_CAP];  // the row (lane) an id belongs to
-	__shared__ uint16_t s_base[CT_WAVES][65], s_nc[CT_WAVES][64], s_nk[CT_WAVES][64], s_dref[CT_WAVES][64];
-	__shared__ int32_t *s_rowp[CT_WAVES][64];
-	__shared__ const int32_t *s_srcp[CT_WAVES][64];
-	__shared__ uint8_t s_bad[CT_WAVES][64];
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	int32_t *ids = s_ids[wave];
-	uint16_t *posv = s_pos[wave], *base = s_base[wave], *ncs = s_nc[wave], *nks = s_nk[wave];
-	uint8_t *rowi = s_rowi[wave], *bad = s_bad[wave];
-	auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); };
-	const int32_t bucket = min(level, MAXLVL - 1);
-	const int32_t lo = keyBase[bucket * NBIN], hi = keyBase[(bucket + 1) * NBIN];
-	const int32_t ngroups = (hi - lo + 63) / 64;
-	for (int32_t gi = blockIdx.x * CT_WAVES + wave; gi < ngroups; gi += gridDim.x * CT_WAVES) {
-		const int32_t idx = lo + gi * 64 + lane;
-		int32_t s = -1, d = 0;
-		if (idx < hi) { s = list[idx]; if (copy_class(v, depth, level, s, midMin, bigMin) == 1) d = v.outd[s]; else s = -1; }
-		int32_t incl = d;
-#pragma unroll
-		for (int o = 1; o < 64; o <<= 1) { const int32_t t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-		if (__shfl(incl, 63) == 0) continue;
-		int start = 0;
-		int32_t before = 0; // ids of the rows before `start`
-		while (start < 64) { // (wave-uniform) rows [start, end): as many as fit the LDS tables
-			const uint64_t fit = __ballot(lane >= start && incl - before <= CT_CAP) >> start;
-			const int nfit = ~fit ? __builtin_ctzll(~fit) : 64; // (at least one: a row of this class has fewer than midMin <= CT_CAP ids)
-			const int end = start + nfit;
-			const bool in = lane >= start && lane < end;
-			const int32_t total = __shfl(incl, end - 1) - before;
-			if (total == 0) { start = end; continue; }
-			const int32_t mybase = incl - d - before;
-			if (in) { base[lane] = (uint16_t)mybase; bad[lane] = 0; ncs[lane] = 0; nks[lane] = 0; }
-			if (lane == end - 1) base[end] = (uint16_t)total;
-			if (stage == 1) { start = end; before += total; continue; }
-			if (in && s >= 0) {
-				const int32_t r = v.ref[s];
-				s_dref[wave][lane] = (uint16_t)v.outd[s - r]; // (below COPY_REF_BIG in this class)
-				s_rowp[wave][lane] = v.row(s);
-				s_srcp[wave][lane] = v.row(s - r);
-				const int32_t *row = s_rowp[wave][lane];
-				int32_t *mine = ids + mybase;
-				int32_t nk = 0, copied = 0;
-				const int32_t e0 = row[0];
-				bool ok = true;
-				if (e0 < 0) { // the kept blocks of this row (k_block_tables)
-					ok = false;
-					for (int32_t k = 0; k < d; k++) {
-						const int32_t e = k ? row[k] : e0;
-						const int32_t kend = (e >> 16) & 0x3fff;
-						if (e >= 0 || kend <= copied || kend > d) break;
-						mine[k] = kend << 16 | (e & 0xffff);
-						copied = kend;
-						nk = k + 1;
-						if ((uint32_t)e & BT_LAST) { ok = true; break; }
-					}
-					if (!ok) { bad[lane] = 1; copied = 0; } // not a table: a list that does not parse (flagged by the parse kernel), or a negative "successor" of a malformed record
-				}
-				ncs[lane] = ok ? (uint16_t)copied : 0;
-				nks[lane] = (uint16_t)nk;
-			}
-			wave_sync();
-			if (stage == 2) { start = end; before += total; continue; }
-			// the row of every id, and for a copied id its index in the referent's row
-			for (int32_t slot = lane; slot < total; slot += 64) {
-				int a = start, b = end; // last row whose ids start at or before `slot` (rows without ids repeat their successor's start)
-				while (b - a > 1) { const int mid = (a + b) >> 1; if ((int32_t)base[mid] <= slot) a = mid; else b = mid; }
-				rowi[slot] = (uint8_t)a;
-				const int32_t b0 = base[a], local = slot - b0;
-				if (local < (int32_t)ncs[a]) {
-					int32_t l = 0, h = nks[a] - 1; // first kept block that ends behind `local`
-					while (l < h) { const int32_t mid = (l + h) >> 1; if ((int32_t)((uint32_t)ids[b0 + mid] >> 16) <= local) l = mid + 1; else h = mid; }
-					const int32_t si = local + (int32_t)((uint32_t)ids[b0 + l] & 0xffffu);
-					const bool inside = si < (int32_t)s_dref[wave][a];
-					if (!inside) bad[a] = 1; // (something that only looks like a table: never read outside the referent's row)
-					posv[slot] = (uint16_t)(inside ? si : 0);
-				}
-			}
-			wave_sync();
-			for (int32_t slot = lane; slot < total; slot += 64) {
-				const int a = rowi[slot];
-				const int32_t local = slot - base[a], nc = ncs[a];
-				if (nc == 0) continue; // nothing copied: the extras are the row
-				ids[slot] = local < nc ? s_srcp[wave][a][posv[slot]] : s_rowp[wave][a][local];
-			}
-			wave_sync();
-			if (stage == 3) { start = end; before += total; continue; }
-			for (int32_t slot = lane; slot < total; slot += 64) {
-				const int a = rowi[slot];
-				const int32_t b0 = base[a], local = slot - b0, nc = ncs[a], dd = base[a + 1] - b0;
-				if (nc == 0) continue;
-				const int32_t val = ids[slot];
-				int32_t l, h;
-				if (local < nc) { l = b0 + nc; h = b0 + dd; } else { l = b0; h = b0 + nc; }
-				const int32_t l0 = l;
-				while (l < h) { const int32_t mid = (l + h) >> 1; if (ids[mid] < val) l = mid + 1; else h = mid; }
-				if (local >= nc && l < b0 + nc && ids[l] == val) bad[a] = 1;
-				posv[slot] = (uint16_t)((local < nc ? local : local - nc) + (l - l0));
-			}
-			wave_sync();
-			for (int32_t slot = lane; slot < total; slot += 64) {
-				const int a = rowi[slot];
-				if (ncs[a] == 0 || bad[a]) continue;
-				s_rowp[wave][a][posv[slot]] = ids[slot];
-			}
-			wave_sync();
-			if (in && s >= 0 && bad[lane]) { const int32_t r = v.ref[s]; copy_node<DEF>(g, v.lo + s, d, (int64_t)v.outd[s - r], v.row(s), v.row(s - r), err); }
-			wave_sync(); // (the tables are free for the next rows)
-			before += total;
-			start = end;
-		}
-	}
-}
-
 // One wave per row of fewer than COPY_BIG_MIN successors with a reference.  The block list is walked once (by
 // every lane: it is short) into two LDS tables -- for the j-th copied block, the number of ids copied up to its
 // end and the offset between an id's index in the referent's row and its index among the copied ids.  Then the
@@ -1635,21 +1462,6 @@ void copy_thresholds(int32_t midMinKnob, bool bigGroups, int32_t &midMin, int32_
 	bigMin = bigGroups ? COPY_BIG_MIN : 0x7fffffff; // !bigGroups: every row is merged by one lane
 	midMin = (midMinKnob <= 0 || midMinKnob > bigMin || !bigGroups) ? bigMin : midMinKnob; // = bigMin: no wave-per-row class
 }
-static bool copy_tile_on() { static const bool on = [] { const char *e = getenv("BVGPU_COPY_TILE"); return e && atoi(e) != 0; }(); return on; }
-// whether the copy pass of a job with these knobs takes the lane class through k_copy_tile: then launch_block_tables must run before its first level
-bool copy_tables_wanted(int32_t midMinKnob, bool bigGroups) {
-	int32_t midMin, bigMin;
-	copy_thresholds(midMinKnob, bigGroups, midMin, bigMin);
-	return copy_tile_on() && midMin <= CT_CAP;
-}
-void launch_block_tables(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int32_t midMinKnob, bool bigGroups, int *err, hipStream_t st) {
-	if (v.cnt <= 0) return;
-	int32_t midMin, bigMin;
-	copy_thresholds(midMinKnob, bigGroups, midMin, bigMin);
-	if (def == 1) hipLaunchKernelGGL(k_block_tables<1>, dim3(4096), dim3(TPB), 0, st, g, v, list, keyBase, midMin, bigMin, err);
-	else if (def == 2) hipLaunchKernelGGL(k_block_tables<2>, dim3(4096), dim3(TPB), 0, st, g, v, list, keyBase, midMin, bigMin, err);
-	else hipLaunchKernelGGL(k_block_tables<0>, dim3(4096), dim3(TPB), 0, st, g, v, list, keyBase, midMin, bigMin, err);
-}
 void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int32_t *depth, const int32_t *list, const int32_t *keyBase, int32_t level, int blocks,
                        int32_t midMinKnob, bool bigGroups, const int32_t *bigQ, int32_t bigCap, const int32_t *midQ, int32_t midCap, int32_t *ctl, int32_t *tmp, uint32_t tmpCap, int *err,
                        hipStream_t st, hipStream_t stMid, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evMid, hipEvent_t evBig) {
@@ -1680,14 +1492,6 @@ void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int
 		else hipLaunchKernelGGL(k_copy_mid<0>, dim3(1024), dim3(64 * COPY_MID_WAVES), 0, stMid, g, v, depth, midQ, ctl + 6, midCap, level, err);
 	}
 	if (stMid != st) (void)hipEventRecord(evMid, stMid);
-	const bool copyTile = copy_tile_on();
-	static const int ctStage = [] { const char *e = getenv("BVGPU_CT_STAGE"); return e ? atoi(e) : 0; }();
-	static const int ctBlocks = [] { const char *e = getenv("BVGPU_CT_BLOCKS"); return e ? atoi(e) : 2048; }();
-	if (copyTile && midMin <= CT_CAP) {
-		if (def == 1) hipLaunchKernelGGL(k_copy_tile<1>, dim3(ctBlocks), dim3(64 * CT_WAVES), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err, ctStage);
-		else if (def == 2) hipLaunchKernelGGL(k_copy_tile<2>, dim3(ctBlocks), dim3(64 * CT_WAVES), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err, ctStage);
-		else hipLaunchKernelGGL(k_copy_tile<0>, dim3(ctBlocks), dim3(64 * CT_WAVES), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err, ctStage);
-	} else
 	if (def == 1) hipLaunchKernelGGL(k_copy_list<1>, dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
 	else if (def == 2) hipLaunchKernelGGL(k_copy_list<2>, dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
 	else hipLaunchKernelGGL(k_copy_list<0>, dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);

@@ -73,8 +73,6 @@ constexpr int ARENA_ENTRY_BYTES = 16;
 void launch_build_lists(const GraphDev &g, const RangeView &v, uint64_t giantBits, int32_t noBin, int32_t *depth, uint16_t *key16, int32_t *hist, int32_t *keyBase, int32_t *cursor,
                         int32_t *list, int32_t *giantlist, int32_t giantCap, int32_t *ctl, int32_t *maxdepth, hipStream_t st,
                         int32_t *bigQ = nullptr, int32_t bigCap = 0, int32_t *midQ = nullptr, int32_t midCap = 0, int32_t midMinKnob = 0, bool bigGroups = false);
-bool copy_tables_wanted(int32_t midMinKnob, bool bigGroups);
-void launch_block_tables(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int32_t midMinKnob, bool bigGroups, int *err, hipStream_t st);
 void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int32_t *depth, const int32_t *list, const int32_t *keyBase, int32_t level, int blocks,
                        int32_t midMinKnob, bool bigGroups, const int32_t *bigQ, int32_t bigCap, const int32_t *midQ, int32_t midCap, int32_t *ctl, int32_t *tmp, uint32_t tmpCap, int *err,
                        hipStream_t st, hipStream_t stMid, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evMid, hipEvent_t evBig);

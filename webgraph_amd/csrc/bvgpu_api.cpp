@@ -497,8 +497,6 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		if (W > 0) bv::launch_build_lists(gd, v, ~0ull, 1, g->depth.as<int32_t>(), g->key16.as<uint16_t>(), hist, keyBase, cursor, g->lvlist.as<int32_t>(),
 		                                  g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->maxdepth, stLists,
 		                                  g->copyq.as<int32_t>(), bigCap, g->copyq.as<int32_t>() + bigCap, midCap, g->copy_mid_min, g->copy_big != 0);
-		// the block lists of the lane class of the copy pass, walked once for all levels behind the lists, while the one-lane parse kernel still runs
-		if (W > 0 && bv::copy_tables_wanted(g->copy_mid_min, g->copy_big != 0)) bv::launch_block_tables(gd, s.def, v, g->lvlist.as<int32_t>(), keyBase, g->copy_mid_min, g->copy_big != 0, derr, stLists);
 		if (ovl) HIPCHK(g, hipEventRecord(g->evA, g->sideA));
 		if (!tiles && !earlyList)
 			bv::launch_build_lists(gd, v, ~0ull, g->parse_windows ? 6 : 2, nullptr, g->pkey16.as<uint16_t>(), g->pkeys.as<int32_t>(), pKeyBase, pKeyBase + (bv::NKEYS + 1), g->plist.as<int32_t>(),
