@@ -16,7 +16,7 @@ extern "C" {
 // graph: the .graph bytes followed by >= 64 zero bytes (nbytes = file size).  View = nodes [lo, lo + cnt), no halo.
 // outd / ref / rowstart as the kernels' RangeView holds them.  succ[rowstart[cnt]]: rows (only the records of the class are written).
 // esc[cnt]: flagged slots (the cooperative kernel's work), *nEsc their number.  cop[cnt]: ids copied from the referent (-1: not this class).
-// stats[8]: records, segments, segments whose chains did not meet, flagged records, codes walked by A2, intervals, max segments of a record, -
+// stats[8]: records, segments, segments whose chains did not meet, flagged records, pieces the fix pass walked again, intervals, max segments of a record, -
 int seg_model_run(const uint8_t *graph, uint64_t nbytes, const int64_t *offsets, int32_t lo, int32_t cnt, const int32_t *outd, const uint16_t *ref,
                   const int64_t *rowstart, int W, int minInt, int zk, int dmin, int dmax, int32_t *succ, int32_t *esc, int32_t *nEsc, int32_t *cop, int64_t *stats) {
 	SegGraph g{ (const uint32_t *)graph, (nbytes + 3) / 4, offsets, W, minInt, zk };
@@ -24,7 +24,7 @@ int seg_model_run(const uint8_t *graph, uint64_t nbytes, const int64_t *offsets,
 	for (int s = 0; s < cnt; s++) cop[s] = -1;
 	for (int k = 0; k < 8; k++) stats[k] = 0;
 	std::vector<uint32_t> lds(WIN_WORDS + 2 * RING);
-	Col<1> col{ lds.data() }, ring{ lds.data() + WIN_WORDS };
+	uint32_t *col = lds.data(), *ring = lds.data() + WIN_WORDS;
 	const int64_t arcs = rowstart[cnt] - rowstart[0];
 	std::vector<SegIv> arena((size_t)(minInt > 0 ? arcs / minInt + cnt + 2 : 1));
 	// the class
@@ -48,58 +48,82 @@ int seg_model_run(const uint8_t *graph, uint64_t nbytes, const int64_t *offsets,
 	}
 	const int32_t S = segbase[R];
 	stats[1] = S;
-	std::vector<uint64_t> segOut((size_t)S + 1), segBad((size_t)S + 1);
-	std::vector<uint32_t> segCnt((size_t)S + 1), segSum((size_t)S + 1), pc((size_t)S + 1), ps((size_t)S + 1);
-	std::vector<int32_t> seg2rec((size_t)S + 1);
-	std::vector<uint8_t> flag(R, 0);
+	std::vector<SegA1> a1((size_t)S + 1);
+	std::vector<SegFin> fin((size_t)S + 1);
+	std::vector<uint32_t> pc((size_t)S + 1), ps((size_t)S + 1);
+	std::vector<int32_t> seg2rec((size_t)S + 1), fixlist;
+	std::vector<uint8_t> flag(R, 0), miss((size_t)S + 1, 0);
+	auto span = [&](int32_t sg, uint64_t &cell, uint32_t &a, uint32_t &b) {
+		const int32_t r = seg2rec[sg];
+		seg_span(desc[r], (uint64_t)offsets[lo + desc[r].slot + 1], sg - segbase[r], cell, a, b);
+	};
+	auto a2 = [&](int32_t sg, uint32_t inRel, uint32_t &cnt, uint32_t &sum, uint32_t &tRel) {
+		uint64_t cell; uint32_t a, b;
+		span(sg, cell, a, b);
+		return zk == 3 ? seg_a2<3, 1>(g, col, cell, inRel, b, a1[sg], cnt, sum, tRel) : seg_a2<0, 1>(g, col, cell, inRel, b, a1[sg], cnt, sum, tRel);
+	};
 	// A1
 	for (size_t r = 0; r < R; r++) {
 		const int32_t x = lo + desc[r].slot;
 		for (int32_t i = 0; i < segbase[r + 1] - segbase[r]; i++) {
 			const int32_t sg = segbase[r] + i;
-			uint64_t a, b;
-			seg_span(desc[r], (uint64_t)offsets[x + 1], i, a, b);
-			if (zk == 3) seg_a1<3, 1>(g, col, x, a, b, i == 0, segOut[sg], segCnt[sg], segSum[sg], segBad[sg]);
-			else seg_a1<0, 1>(g, col, x, a, b, i == 0, segOut[sg], segCnt[sg], segSum[sg], segBad[sg]);
-			if (i == 0 && segBad[sg] != ~(uint64_t)0) flag[r] = 1;
 			seg2rec[sg] = (int32_t)r;
+			uint64_t cell; uint32_t a, b;
+			span(sg, cell, a, b);
+			if (zk == 3) seg_a1<3, 1>(g, col, x, cell, a, b, i == 0, a1[sg]);
+			else seg_a1<0, 1>(g, col, x, cell, a, b, i == 0, a1[sg]);
+			if (i == 0 && a1[sg].badIdx != ~0u) { flag[r] = 1; if (getenv("SEG_MODEL_TRACE")) fprintf(stderr, "A1 bad: slot %d\n", desc[r].slot); }
 		}
 	}
-	// A2 (reads the ends A1 wrote, writes counts and sums of its own segment only)
-	for (size_t r = 0; r < R; r++) {
-		const int32_t x = lo + desc[r].slot, ns = segbase[r + 1] - segbase[r];
-		for (int32_t i = 1; i < ns; i++) {
-			const int32_t sg = segbase[r] + i;
-			uint64_t a, b;
-			seg_span(desc[r], (uint64_t)offsets[x + 1], i, a, b);
-			bool bad = false;
-			const uint32_t c0 = segCnt[sg];
-			const bool ok = zk == 3 ? seg_a2<3, 1>(g, col, a, segOut[sg - 1], b, i == ns - 1, segBad[sg], segCnt[sg], segSum[sg]) : seg_a2<0, 1>(g, col, a, segOut[sg - 1], b, i == ns - 1, segBad[sg], segCnt[sg], segSum[sg]);
-			(void)c0;
-			if (!ok || bad) { flag[r] = 1; stats[2]++; if (getenv("SEG_MODEL_TRACE")) fprintf(stderr, "a2 fail: slot %d seg %d/%d gstart %llu in %llu end %llu bad %d cnt0 %u\n", desc[r].slot, i, ns, (unsigned long long)a, (unsigned long long)segOut[sg - 1], (unsigned long long)b, (int)bad, c0); }
+	// A2 (reads what A1 wrote of this piece and the one before; writes fin / miss of its own piece only)
+	for (int32_t sg = 0; sg < S; sg++) {
+		const int32_t r = seg2rec[sg], i = sg - segbase[r];
+		uint32_t cnt = a1[sg].cnt, sum = a1[sg].sum, tRel = 0, inRel;
+		int st = 0;
+		if (i > 0) { inRel = a1[sg - 1].outRel - SEG_BITS; st = a2(sg, inRel, cnt, sum, tRel); }
+		else { uint64_t cell; uint32_t a, b; span(sg, cell, a, b); inRel = a; }
+		const bool last = sg + 1 == segbase[r + 1];
+		if (st == 1) stats[2]++;
+		const bool m = st == 1 && !last && tRel != a1[sg].outRel;
+		miss[sg] = m;
+		if (m) fixlist.push_back(sg);
+		fin[sg] = SegFin{ inRel, cnt, sum, st == 2 ? ~0u : st == 1 ? tRel : 0u };
+	}
+	// fix
+	for (int32_t k0 : fixlist) {
+		const int32_t r = seg2rec[k0], kEnd = segbase[r + 1];
+		if (k0 > segbase[r] && miss[k0 - 1]) continue;
+		uint32_t inRel = fin[k0].tRel - SEG_BITS;
+		for (int32_t k = k0 + 1, steps = 0; k < kEnd; k++, steps++) {
+			if (steps >= FIX_MAX) { flag[r] = 1; break; }
+			uint32_t cnt, sum, tRel;
+			const int st = a2(k, inRel, cnt, sum, tRel);
+			stats[4]++;
+			fin[k] = SegFin{ inRel, cnt, sum, st == 2 ? ~0u : st == 1 ? tRel : 0u };
+			if (st == 2) break;
+			if (st == 1 && tRel != a1[k].outRel) { inRel = tRel - SEG_BITS; continue; }
+			if (k + 1 < kEnd && miss[k] && miss[k + 1]) { inRel = a1[k].outRel - SEG_BITS; continue; }
+			break;
 		}
 	}
 	// scan
 	pc[0] = ps[0] = 0;
-	for (int32_t sg = 0; sg < S; sg++) { pc[sg + 1] = pc[sg] + segCnt[sg]; ps[sg + 1] = ps[sg] + segSum[sg]; }
-	for (size_t r = 0; r < R; r++) if (segbase[r + 1] > segbase[r] && pc[segbase[r + 1]] - pc[segbase[r]] != (uint32_t)desc[r].nres) flag[r] = 1;
+	for (int32_t sg = 0; sg < S; sg++) { pc[sg + 1] = pc[sg] + fin[sg].cnt; ps[sg + 1] = ps[sg] + fin[sg].sum; }
 	// B
-	for (size_t r = 0; r < R; r++) {
-		if (flag[r] || (desc[r].flags & RF_FALLBACK)) continue;
-		const int32_t s = desc[r].slot, x = lo + s, ns = segbase[r + 1] - segbase[r];
+	for (int32_t sg = 0; sg < S; sg++) {
+		const int32_t r = seg2rec[sg];
+		if (flag[r]) continue; // (on the GPU a record may be flagged while its other pieces are already being written: harmless, the cooperative kernel rewrites the row)
+		const int32_t k0 = segbase[r], i = sg - k0, s = desc[r].slot, x = lo + s;
+		const bool last = sg + 1 == segbase[r + 1];
+		if (last && pc[sg] + fin[sg].cnt - pc[k0] != (uint32_t)desc[r].nres) { flag[r] = 1; if (getenv("SEG_MODEL_TRACE")) fprintf(stderr, "count: slot %d has %u wants %d\n", s, pc[sg] + fin[sg].cnt - pc[k0], desc[r].nres); continue; }
+		uint64_t cell; uint32_t a, b;
+		span(sg, cell, a, b);
 		int32_t *out = succ + (rowstart[s] - rowstart[0]) + desc[r].copied;
 		const int32_t extra = outd[s] - desc[r].copied;
-		for (int32_t i = 0; i < ns; i++) {
-			const int32_t sg = segbase[r] + i;
-			uint64_t a, b;
-			seg_span(desc[r], (uint64_t)offsets[x + 1], i, a, b);
-			const uint64_t in = i == 0 ? a : segOut[sg - 1];
-			const uint32_t j0 = pc[sg] - pc[segbase[r]];
-			const int32_t v0 = (int32_t)(ps[sg] - ps[segbase[r]]);
-			const bool ok = zk == 3 ? seg_b<3, 1>(g, col, ring, x, in, b, segCnt[sg], j0, v0, i == 0, out, extra, iv_of(s), desc[r].nIv)
-			                        : seg_b<0, 1>(g, col, ring, x, in, b, segCnt[sg], j0, v0, i == 0, out, extra, iv_of(s), desc[r].nIv);
-			if (!ok) flag[r] = 1;
-		}
+		uint32_t endRel;
+		const bool ok = zk == 3 ? seg_b<3, 1>(g, col, ring, x, cell, fin[sg].inRel, fin[sg].cnt, pc[sg] - pc[k0], (int32_t)(ps[sg] - ps[k0]), i == 0, out, extra, iv_of(s), desc[r].nIv, endRel)
+		                        : seg_b<0, 1>(g, col, ring, x, cell, fin[sg].inRel, fin[sg].cnt, pc[sg] - pc[k0], (int32_t)(ps[sg] - ps[k0]), i == 0, out, extra, iv_of(s), desc[r].nIv, endRel);
+		if (!ok || fin[sg].tRel == ~0u || (!last && endRel != fin[sg + 1].inRel + SEG_BITS)) { flag[r] = 1; if (getenv("SEG_MODEL_TRACE")) fprintf(stderr, "B: slot %d piece %d/%d ok %d endRel %u next in %u\n", s, i, segbase[r + 1] - k0, (int)ok, endRel, last ? 0u : fin[sg + 1].inRel + SEG_BITS); }
 	}
 	// expand
 	for (size_t r = 0; r < R; r++) {

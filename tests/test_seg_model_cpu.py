@@ -13,11 +13,13 @@ import pytest
 from conftest import CNR, ROOT, make_graph
 
 
-def build_model(dirname, seg_bits_log2=None):
-    so = os.path.join(str(dirname), "libsegmodel%s.so" % (seg_bits_log2 or ""))
+def build_model(dirname, seg_bits_log2=None, any_always=False):
+    so = os.path.join(str(dirname), "libsegmodel%s%s.so" % (seg_bits_log2 or "", "a" if any_always else ""))
     cmd = ["g++", "-std=c++17", "-O2", "-g", "-shared", "-fPIC", "-D_GLIBCXX_ASSERTIONS", "-o", so, os.path.join(ROOT, "tests", "cpp", "seg_model.cpp")]
     if seg_bits_log2:
         cmd.insert(1, "-DSEG_BITS_LOG2_=%d" % seg_bits_log2)
+    if any_always:
+        cmd.insert(1, "-DSG_ANY_ALWAYS")
     subprocess.check_call(cmd)
     L = C.CDLL(so)
     L.seg_model_run.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -28,6 +30,12 @@ def build_model(dirname, seg_bits_log2=None):
 @pytest.fixture(scope="module")
 def model(tmp_path_factory):
     return build_model(tmp_path_factory.mktemp("seg_model"))
+
+
+@pytest.fixture(scope="module")
+def model_always(tmp_path_factory):
+    """on the GPU a lane refills its window and tops up its ring whenever ANY lane of its wave needs to: here, always"""
+    return build_model(tmp_path_factory.mktemp("seg_modela"), 9, True)
 
 
 @pytest.fixture(scope="module")
@@ -114,6 +122,12 @@ def test_cnr2000_small_pieces(model_small):
     assert st[1] > st[0] and st[2] > 0 and n > 50000  # some chains do not meet within 128 bits
 
 
+def test_cnr2000_wave_synchronised_steps_are_harmless(model_always):
+    r = run_model(model_always, CNR)
+    n = check(r, 1, 1 << 30, max_escapes=int(r["stats"][0]) // 50)
+    assert n > 240000
+
+
 @pytest.mark.parametrize("lo,hi", [(1000, 21000), (300000, 325557)])
 def test_cnr2000_subranges(model, lo, hi):
     r = run_model(model, CNR, lo, hi)
@@ -124,12 +138,14 @@ def test_cnr2000_subranges(model, lo, hi):
                                 dict(window=0, max_ref_count=0, min_interval=0, zeta_k=1), dict(window=3, max_ref_count=8, min_interval=0, zeta_k=2),
                                 dict(window=16, max_ref_count=30, min_interval=3, zeta_k=7)],
                          ids=lambda kw: "w%d_m%d_i%d_z%d" % (kw["window"], kw["max_ref_count"], kw["min_interval"], kw["zeta_k"]))
-def test_synthetic_parameters(model, model_small, tmp_path_factory, kw):
+def test_synthetic_parameters(model, model_small, model_always, tmp_path_factory, kw):
     base, rowptr, succ = make_graph(tmp_path_factory, "sm", 60000, 1500000, 4242, 0.6, **kw)
     r = run_model(model, base)
     assert np.array_equal(r["succ"], succ)
     n = check(r, 1, 1 << 30, max_escapes=8)  # (chains that do not meet inside a piece: rarer than one in 10^5 pieces of 2 048 bits)
     assert n > 30000 and r["stats"][6] > 10  # a record of more than ten pieces
+    r = run_model(model_always, base)
+    check(r, 1, 1 << 30, max_escapes=int(r["stats"][0]) // 20)
     r = run_model(model_small, base, dmin=64)
     n = check(r, 64, 1 << 30, max_escapes=int(r["stats"][0]))  # (most chains do not meet within 128 bits of these codes: those records are the cooperative kernel's)
     assert n > 100

@@ -19,6 +19,7 @@
 // (IntIntervalSequenceIterator + ResidualIntIterator under a MergedIntIterator, BVG:1103-1110).
 #pragma once
 #include "bv_device.hpp"
+#include "bv_seg.hpp"
 
 namespace bv {
 
@@ -1134,7 +1135,7 @@ __device__ __forceinline__ void coop_residuals_w1(const GraphDev &g, int32_t x, 
 // The whole record of node x by one group.  Same contract as parse_node: extras merged into row[copied..d).
 template <int DEF, int NW>
 __device__ __forceinline__ void coop_parse_node(const GraphDev &g, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row,
-                                                IvEntry *__restrict__ list, uint32_t *lds, int *__restrict__ errOut) {
+                                                IvEntry *__restrict__ list, uint32_t *lds, int *__restrict__ errOut, bvsg::RecDesc *segOut = nullptr) {
 	Grp<NW> G{ (int64_t *)(lds + CoopLds<NW>::OFF_XCH) };
 	const int tid = G.tid();
 	const uint64_t recEnd = (uint64_t)g.offsets[x + 1];
@@ -1232,6 +1233,10 @@ __device__ __forceinline__ void coop_parse_node(const GraphDev &g, int32_t x, in
 	COOP_TICK(1);
 	// default rank: the interval follows every residual (phase R fixes up the others)
 	for (int64_t i = tid; i < ic; i += Grp<NW>::N) list[i].rank = (int32_t)nRes;
+	if (segOut && nRes > 0 && nRes < 0x7fffffff && ic < 0x7fffffff) { // the residual section goes to the segment pipeline, cut into pieces (bv_seg.hip); it also expands the intervals
+		if (tid == 0) { segOut->rpos = (int64_t)pos; segOut->nres = (int32_t)nRes; segOut->copied = (int32_t)copied; segOut->nIv = (int32_t)ic; segOut->ivArcs = (int32_t)intervalArcs; segOut->flags = 0; }
+		return;
+	}
 	G.sync_global();
 	if (NW == 1 && DEF != 0 && ic < 0x7fffffff && nRes < 0x7fffffff) { // one wave, default codings: every codeword decoded once
 		if (nRes > 0) coop_residuals_w1<DEF>(g, x, pos, recEnd, nRes, ic, intervalArcs, list, row + copied, lds, err);

@@ -38,6 +38,12 @@ struct GraphDev {
 	uint32_t walkCap;
 	uint32_t *walkCursor;
 	int32_t walkMin;
+	// Hand-over of the long records' residual sections to the segment pipeline (bv_seg.hip): a cooperative kernel that serves queue
+	// `which` (0: the wave class, 1: the giants) parses the structure of its idx-th record only and leaves a descriptor in
+	// segDesc[segOff[which] + idx] (segNseg: how many pieces its residual section has).  NULL: it decodes the residuals itself.
+	void *segDesc;
+	int32_t *segNseg, *segFlag;
+	int32_t segOff[2], segCap[2];
 };
 
 // tuning counters: 0 tiles(residual) 1 rounds(residual) 2 tiles(interval) 3 rounds(interval) 4 lane-parses 5 big nodes 6 clock ticks in coop nodes 7 max ticks of one node

@@ -370,7 +370,7 @@ __device__ __forceinline__ int copy_class_of(int32_t d, int32_t dref, int32_t mi
 	if (d >= bigMin || (dref >= COPY_REF_BIG && bigMin != 0x7fffffff)) return 3;
 	return d >= midMin ? 2 : 1;
 }
-constexpr int WINDOWED_BINS = 14; // work < 2048 bits (bin 14): binned per window of nodes (noBin & 4)
+constexpr int WINDOWED_BINS = PARSE_LONG_BIN; // work < 2048 bits (bin 14): binned per window of nodes (noBin & 4)
 constexpr int LIST_ITEMS = 16, LIST_TILE = TPB * LIST_ITEMS; // slots per block: few blocks -> few same-address atomics (~88 M/s each)
 
 __global__ void __launch_bounds__(TPB) k_depth_keys(GraphDev g, int32_t lo, int32_t cnt, const int32_t *__restrict__ outd, const uint16_t *__restrict__ ref,
@@ -1001,8 +1001,15 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? COOP1_MINWAVES : COOPG_MINW
 		// one-wave block apart at the barrier at the top -- lane 0 late with the next index, the others reading the old one for ever)
 		const int bad = rec.capErr ? rec.capErr : (g.minInt > 0 && (abase < 0 || abase + rec.d / g.minInt + 1 > arenaCap)) ? E_FORMAT : 0;
 		const unsigned long long t0 = g.stats ? __builtin_readcyclecounter() : 0;
+		// (scans only) the residual section of the record is handed to the segment pipeline: descriptor idx of this queue's part
+		bvsg::RecDesc *segOut = nullptr;
+		if (std::is_same<View, RangeView>::value && DEF != 0 && which < 2 && g.segDesc && idx < g.segCap[which]) {
+			segOut = (bvsg::RecDesc *)g.segDesc + g.segOff[which] + idx;
+			if (threadIdx.x == 0) { *segOut = bvsg::RecDesc{ 0, list[idx], 0, 0, 0, bvsg::RF_SKIP, 0 }; g.segFlag[g.segOff[which] + idx] = 0; }
+		}
 		if (bad) { if (threadIdx.x == 0) atomicOr(err, bad); }
-		else coop_parse_node<DEF, NW>(g, rec.x, rec.d, rec.hasRef, rec.dref, rec.row, arena + abase, lds, err);
+		else coop_parse_node<DEF, NW>(g, rec.x, rec.d, rec.hasRef, rec.dref, rec.row, arena + abase, lds, err, segOut);
+		if (segOut && threadIdx.x == 0) g.segNseg[g.segOff[which] + idx] = bvsg::seg_count(*segOut, (uint64_t)g.offsets[rec.x + 1]); // (0 when the record was decoded here after all)
 		if (g.stats) { const unsigned long long dt = __builtin_readcyclecounter() - t0; stat_add(g, 5, 1); stat_add(g, 6, dt); stat_max(g, 7, dt); }
 	}
 }
@@ -1511,14 +1518,21 @@ void launch_parse_tile(const GraphDev &g, int def, const RangeView &v, const int
 	else hipLaunchKernelGGL(k_parse_tile<2>, dim3(ntiles), dim3(TILE_T), 0, st, g, v, tb, err);
 }
 
-void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, void *arena, int64_t arenaCap) {
+void launch_parse_listed(const GraphDev &g, int def, const RangeView &v, const int32_t *list, int32_t *ctl, int which, void *arena, int64_t arenaCap, int waves, int *err, hipStream_t st) {
+	if (v.cnt <= 0) return;
+	if (def == 1) hipLaunchKernelGGL((k_parse_big<1, 1, RangeView>), dim3(waves), dim3(64), 0, st, g, v, list, ctl, which, (IvEntry *)arena, arenaCap, err);
+	else if (def == 2) hipLaunchKernelGGL((k_parse_big<2, 1, RangeView>), dim3(waves), dim3(64), 0, st, g, v, list, ctl, which, (IvEntry *)arena, arenaCap, err);
+	else hipLaunchKernelGGL((k_parse_big<0, 1, RangeView>), dim3(waves), dim3(64), 0, st, g, v, list, ctl, which, (IvEntry *)arena, arenaCap, err);
+}
+
+void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, void *arena, int64_t arenaCap, int32_t keyHi) {
 	if (v.cnt <= 0) return;
 	IvEntry *a = (IvEntry *)arena;
-	if (def == 1 && a) hipLaunchKernelGGL((k_parse_list<1, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
-	else if (def == 2 && a) hipLaunchKernelGGL((k_parse_list<2, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
-	else if (def == 1) hipLaunchKernelGGL((k_parse_list<1, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
-	else if (def == 2) hipLaunchKernelGGL((k_parse_list<2, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
-	else hipLaunchKernelGGL((k_parse_list<0, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
+	if (def == 1 && a) hipLaunchKernelGGL((k_parse_list<1, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, keyHi, a, arenaCap, err);
+	else if (def == 2 && a) hipLaunchKernelGGL((k_parse_list<2, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, keyHi, a, arenaCap, err);
+	else if (def == 1) hipLaunchKernelGGL((k_parse_list<1, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, keyHi, a, arenaCap, err);
+	else if (def == 2) hipLaunchKernelGGL((k_parse_list<2, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, keyHi, a, arenaCap, err);
+	else hipLaunchKernelGGL((k_parse_list<0, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, keyHi, a, arenaCap, err);
 }
 
 } // namespace bv

@@ -65,7 +65,7 @@ void launch_chain_fill(const GraphDev &g, int def, const int32_t *nodes, int64_t
 void launch_bparse(const GraphDev &g, int def, const BatchView &v, int *err, hipStream_t st);
 void launch_bcopy(const GraphDev &g, int def, const BatchView &v, int32_t level, int *err, hipStream_t st);
 void launch_pick_coop(const int32_t *part, int32_t nblocks, int32_t budget, int32_t *ctl, hipStream_t st, int32_t *counts = nullptr);
-constexpr int CTL_INTS = 32, CTL_COOP = 22, CTL_TOTAL_INTS = CTL_INTS; // control block (bv_kernels.hip)
+constexpr int CTL_INTS = 32, CTL_COOP = 22, CTL_SEG = 24, CTL_TOTAL_INTS = CTL_INTS; // control block (bv_kernels.hip); ctl[CTL_SEG], ctl[CTL_SEG + 2]: records the segment pipeline hands to the cooperative kernel, head of that queue
 void launch_classify(int32_t cnt, const int32_t *outd, const int32_t *coopPtr, int32_t coopMin, int32_t giantMin, int32_t *biglist, int32_t *giantlist, int32_t giantCap, int32_t *ctl, hipStream_t st);
 void launch_parse_big(const GraphDev &g, int def, const RangeView &v, const int32_t *biglist, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap,
                       int waves, int giantGroups, int *err, hipStream_t stGiant, hipStream_t stBig);
@@ -76,7 +76,19 @@ void launch_build_lists(const GraphDev &g, const RangeView &v, uint64_t giantBit
 void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int32_t *depth, const int32_t *list, const int32_t *keyBase, int32_t level, int blocks,
                        int32_t midMinKnob, bool bigGroups, const int32_t *bigQ, int32_t bigCap, const int32_t *midQ, int32_t midCap, int32_t *ctl, int32_t *tmp, uint32_t tmpCap, int *err,
                        hipStream_t st, hipStream_t stMid, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evMid, hipEvent_t evBig);
-void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, void *arena = nullptr, int64_t arenaCap = 0);
+void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, void *arena = nullptr, int64_t arenaCap = 0, int32_t keyHi = NKEYS);
+// one wave per record of `list` (ctl[which] entries, queue head ctl[which + 2]): k_parse_big<1>
+void launch_parse_listed(const GraphDev &g, int def, const RangeView &v, const int32_t *list, int32_t *ctl, int which, void *arena, int64_t arenaCap, int waves, int *err, hipStream_t st);
+// bv_seg.hip: the segment pipeline for the records of the parse list's keys [kLo, kHi) that have fewer than coop_min successors
+constexpr int PARSE_LONG_BIN = 14; // work bins from here up (>= 2048 bits of work) are not windowed (k_depth_keys) -- and are the segment pipeline's
+size_t seg_scratch_bytes(int32_t Rtot, int32_t Scap);
+int32_t seg_bits_log2();
+// records of the pipeline: [0, RcapM) the parse list's long bins, then capBig / capGiant hand-over slots of the cooperative kernels' queues (Rtot = the sum)
+void seg_handover(GraphDev &g, void *scratch, int32_t RcapM, int32_t capBig, int32_t capGiant, int32_t Scap, hipStream_t st);
+void launch_seg_struct(const GraphDev &g, int def, const RangeView &v, const int32_t *plist, const int32_t *keyBase, int32_t kLo, int32_t kHi, int32_t RcapM, int32_t Rtot, int32_t Scap,
+                       void *scratch, void *arena, int64_t arenaCap, int32_t *ctl, int blocks, int *err, hipStream_t st);
+void launch_seg_chain(const GraphDev &g, int def, const RangeView &v, const int32_t *plist, const int32_t *keyBase, int32_t kLo, int32_t kHi, int32_t RcapM, int32_t Rtot, int32_t Scap,
+                      void *scratch, void *arena, int64_t arenaCap, int32_t *ctl, int blocks, int *err, hipStream_t st);
 void launch_parse_waves(const GraphDev &g, int def, const RangeView &v, const int32_t *biglist, int32_t *ctl, void *arena, int64_t arenaCap, int waves, int *err, hipStream_t st);
 void launch_parse_giants(const GraphDev &g, int def, const RangeView &v, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap, int giantGroups, int *err, hipStream_t st);
 // bv_tile.hpp: short records decoded tile by tile from one LDS image of a contiguous slice of the stream

@@ -1,0 +1,407 @@
+// bv_seg.hip -- kernels of the segment pipeline (bodies: bv_seg.hpp): the residual sections of the records too
+// long for one lane, decoded in pieces of SEG_BITS bits of stream by one lane per piece.  Every kernel is a grid-stride loop over a
+// count that lives on the device (records of the class, segments): nothing here waits for the host.
+#include "bv_device.hpp"
+#include "bv_launch.hpp"
+#include "bv_coop.hpp"
+#include "bv_seg.hpp"
+
+namespace bv {
+
+using namespace bvsg;
+static_assert(sizeof(SegIv) == sizeof(IvEntry) && offsetof(SegIv, rank) == offsetof(IvEntry, rank) && offsetof(SegIv, len) == offsetof(IvEntry, len) &&
+              offsetof(SegIv, pstart) == offsetof(IvEntry, pstart), "arena entries of the cooperative kernels and of the segment pipeline are the same thing");
+static_assert(sizeof(RecDesc) == 32, "RecDesc");
+
+constexpr int STPB = 256;
+
+__device__ __forceinline__ SegGraph seg_graph(const GraphDev &g) { return SegGraph{ g.bits, g.nwords, g.offsets, g.W, g.minInt, g.zetaK }; }
+
+// record r of the class <-> entry keyBase[kHi] - 1 - r of the parse list (sorted by work bin, ascending: r = 0 is the longest)
+struct SegRecs {
+	const int32_t *plist, *keyBase;
+	int32_t kLo, kHi;
+	__device__ __forceinline__ int32_t count() const { return keyBase[kHi] - keyBase[kLo]; }
+	__device__ __forceinline__ int32_t slot(int32_t r) const { return plist[keyBase[kHi] - 1 - r]; }
+};
+
+// ------------------------------------------------------------------------------------------------ struct
+__global__ void __launch_bounds__(STPB) k_seg_struct(GraphDev g, RangeView v, SegRecs recs, int32_t Rcap, RecDesc *__restrict__ desc, int32_t *__restrict__ nseg,
+                                                     int32_t *__restrict__ flag, IvEntry *__restrict__ arena, int64_t arenaCap, int32_t *__restrict__ ctl, int *__restrict__ err) {
+	__shared__ uint32_t lds[WIN_WORDS * STPB];
+	if (blockIdx.x == 0 && threadIdx.x < 4) ctl[CTL_SEG + threadIdx.x] = 0; // count and queue head of the flagged records (k_seg_collect, k_parse_big)
+	const SegGraph sg = seg_graph(g);
+	const int32_t nrec = min(recs.count(), Rcap), coopMin = v.coopmin();
+		for (int32_t r = blockIdx.x * STPB + threadIdx.x; r < Rcap; r += gridDim.x * STPB) {
+		int32_t ns = 0, fl = 0;
+		if (r < nrec) {
+			const int32_t s = recs.slot(r), d = v.outd[s];
+			RecDesc o{};
+			o.slot = s;
+			o.flags = RF_SKIP;
+			if (d > 0 && d < coopMin) { // (longer records: the cooperative kernels)
+				const int32_t rf = v.ref[s];
+				const int64_t abase = g.minInt > 0 ? v.rowstart[s] / g.minInt : 0;
+				if (!v.fits(s)) atomicOr(err, s >= v.nh ? E_CAP : E_HALO);
+				else if (g.minInt > 0 && (abase < 0 || abase + d / g.minInt + 1 > arenaCap)) atomicOr(err, E_FORMAT);
+				else {
+					SegIv *iv = (SegIv *)(arena + abase);
+					struct_lane<STPB>(sg, lds + threadIdx.x, v.lo + s, d, rf > 0, rf > 0 ? (int64_t)v.outd[s - rf] : 0, iv, o);
+					o.slot = s;
+					if (o.flags & RF_FALLBACK) fl = 1;
+					else {
+						ns = seg_count(o, (uint64_t)g.offsets[v.lo + s + 1]);
+						if (o.nres > 0 && ns == 0) { fl = 1; o.flags |= RF_FALLBACK; }
+						if (o.nres == 0 && o.nIv > 0) { // no residuals, no segments: the intervals are final where they are
+							int32_t *out = v.row(s) + o.copied;
+							for (int32_t i = 0; i < o.nIv; i++) expand_interval(iv[i], 0, out, d - o.copied);
+						}
+					}
+				}
+			}
+			desc[r] = o;
+			flag[r] = fl;
+		}
+		nseg[r] = ns;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------ scans
+// exclusive scans in three phases (tile sums, scan of the sums by one block, tile scan + carry); out[n] = total
+struct U2 { uint32_t x, y; };
+__device__ __forceinline__ U2 operator+(U2 a, U2 b) { return U2{ a.x + b.x, a.y + b.y }; }
+__device__ __forceinline__ int32_t sg_shfl_up(int32_t v, int o) { return __shfl_up(v, o, 64); }
+__device__ __forceinline__ U2 sg_shfl_up(U2 v, int o) { return U2{ (uint32_t)__shfl_up((int)v.x, o, 64), (uint32_t)__shfl_up((int)v.y, o, 64) }; }
+template <class T> __device__ __forceinline__ T sg_zero();
+template <> __device__ __forceinline__ int32_t sg_zero<int32_t>() { return 0; }
+template <> __device__ __forceinline__ U2 sg_zero<U2>() { return U2{ 0, 0 }; }
+
+constexpr int SS_ITEMS = 4, SS_TILE = STPB * SS_ITEMS;
+template <class T> __device__ __forceinline__ T sg_block_excl(T v, T *total, T *wsum /* STPB / 64 */) {
+	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+	T inc = v;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) { const T t = sg_shfl_up(inc, o); if (lane >= o) inc = inc + t; }
+	if (lane == 63) wsum[wid] = inc;
+	__syncthreads();
+	T base = sg_zero<T>(), tot = sg_zero<T>();
+#pragma unroll
+	for (int i = 0; i < STPB / 64; i++) { if (i < wid) base = base + wsum[i]; tot = tot + wsum[i]; }
+	__syncthreads();
+	*total = tot;
+	// exclusive = inclusive of the lane before
+	T prev = sg_shfl_up(inc, 1);
+	if (lane == 0) prev = sg_zero<T>();
+	return base + prev;
+}
+template <class T> __global__ void __launch_bounds__(STPB) k_sg_scan_sums(const T *__restrict__ in, int64_t n, T *__restrict__ sums) {
+	__shared__ T wsum[STPB / 64];
+	const int64_t base = (int64_t)blockIdx.x * SS_TILE;
+	T v = sg_zero<T>();
+#pragma unroll
+	for (int i = 0; i < SS_ITEMS; i++) { const int64_t j = base + (int64_t)threadIdx.x * SS_ITEMS + i; if (j < n) v = v + in[j]; }
+	T tot;
+	(void)sg_block_excl(v, &tot, wsum);
+	if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+template <class T> __global__ void __launch_bounds__(STPB) k_sg_scan_top(T *__restrict__ sums, int64_t nb) {
+	__shared__ T wsum[STPB / 64];
+	const int64_t per = (nb + STPB - 1) / STPB, lo = min(per * (int64_t)threadIdx.x, nb), hi = min(lo + per, nb);
+	T mine = sg_zero<T>();
+	for (int64_t j = lo; j < hi; j++) mine = mine + sums[j];
+	T tot;
+	T run = sg_block_excl(mine, &tot, wsum);
+	for (int64_t j = lo; j < hi; j++) { const T x = sums[j]; sums[j] = run; run = run + x; }
+}
+template <class T> __global__ void __launch_bounds__(STPB) k_sg_scan_apply(const T *__restrict__ in, int64_t n, const T *__restrict__ sums, T *__restrict__ out) {
+	__shared__ T wsum[STPB / 64];
+	const int64_t base = (int64_t)blockIdx.x * SS_TILE;
+	T vals[SS_ITEMS];
+	T v = sg_zero<T>();
+#pragma unroll
+	for (int i = 0; i < SS_ITEMS; i++) { const int64_t j = base + (int64_t)threadIdx.x * SS_ITEMS + i; vals[i] = j < n ? in[j] : sg_zero<T>(); v = v + vals[i]; }
+	T tot;
+	T ex = sg_block_excl(v, &tot, wsum) + sums[blockIdx.x];
+#pragma unroll
+	for (int i = 0; i < SS_ITEMS; i++) {
+		const int64_t j = base + (int64_t)threadIdx.x * SS_ITEMS + i;
+		if (j < n) out[j] = ex;
+		ex = ex + vals[i];
+		if (j == n - 1) out[n] = ex;
+	}
+}
+template <class T> static void sg_scan(const T *in, int64_t n, T *out, T *sums, hipStream_t st) {
+	const int64_t nb = (n + SS_TILE - 1) / SS_TILE;
+	hipLaunchKernelGGL(k_sg_scan_sums<T>, dim3((unsigned)nb), dim3(STPB), 0, st, in, n, sums);
+	hipLaunchKernelGGL(k_sg_scan_top<T>, dim3(1), dim3(STPB), 0, st, sums, nb);
+	hipLaunchKernelGGL(k_sg_scan_apply<T>, dim3((unsigned)nb), dim3(STPB), 0, st, in, n, sums, out);
+}
+
+// which record every segment belongs to: a record's lane writes its own stretch (a record of a thousand segments: a thousand stores
+// that nobody waits for)
+__global__ void __launch_bounds__(STPB) k_seg_fill(int32_t Rcap, const int32_t *__restrict__ segbase, int32_t Scap, int32_t *__restrict__ seg2rec) {
+	for (int32_t r = blockIdx.x * STPB + threadIdx.x; r < Rcap; r += gridDim.x * STPB) {
+		const int32_t a = segbase[r], b = min(segbase[r + 1], Scap);
+		for (int32_t sg = a; sg < b; sg++) seg2rec[sg] = r;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------ A1
+template <int ZK>
+__global__ void __launch_bounds__(STPB) k_seg_a1(GraphDev g, RangeView v, const RecDesc *__restrict__ desc, const int32_t *__restrict__ segbase, int32_t Rcap, int32_t Scap,
+                                                 const int32_t *__restrict__ seg2rec, SegA1 *__restrict__ a1, int32_t *__restrict__ flag) {
+	__shared__ uint32_t lds[WIN_WORDS * STPB];
+	const SegGraph sg = seg_graph(g);
+	const int32_t S = min(segbase[Rcap], Scap);
+	for (int32_t k = blockIdx.x * STPB + threadIdx.x; k < S; k += gridDim.x * STPB) {
+		const int32_t r = seg2rec[k], i = k - segbase[r];
+		const RecDesc d = desc[r];
+		const int32_t x = v.lo + d.slot;
+		uint64_t cell;
+		uint32_t a, b;
+		seg_span(d, (uint64_t)g.offsets[x + 1], i, cell, a, b);
+		SegA1 o;
+		seg_a1<ZK, STPB>(sg, lds + threadIdx.x, x, cell, a, b, i == 0, o);
+		a1[k] = o;
+		if (i == 0 && o.badIdx != ~0u) flag[r] = 1;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------ A2
+// pair[k] = (count, sum) of piece k for the scan; fin[k] = its true start and, when the chains did not meet, the true end;
+// miss[k] = 1 and an entry in the fix list when the piece after it must be told its true start
+template <int ZK>
+__global__ void __launch_bounds__(STPB) k_seg_a2(GraphDev g, RangeView v, const RecDesc *__restrict__ desc, const int32_t *__restrict__ segbase, int32_t Rcap, int32_t Scap,
+                                                 const int32_t *__restrict__ seg2rec, const SegA1 *__restrict__ a1, SegFin *__restrict__ fin, U2 *__restrict__ pair, uint8_t *__restrict__ miss,
+                                                 int32_t *__restrict__ fixlist, int32_t *__restrict__ ctl, int32_t *__restrict__ flag) {
+	__shared__ uint32_t lds[WIN_WORDS * STPB];
+	const SegGraph sg = seg_graph(g);
+	const int32_t S = min(segbase[Rcap], Scap);
+	for (int32_t k = blockIdx.x * STPB + threadIdx.x; k < Scap; k += gridDim.x * STPB) {
+		if (k >= S) { pair[k] = U2{ 0, 0 }; continue; } // (the scan runs over the capacity)
+		const int32_t r = seg2rec[k], i = k - segbase[r];
+		const SegA1 me = a1[k];
+		uint32_t cnt = me.cnt, sum = me.sum, tRel = 0, inRel;
+		const RecDesc d = desc[r];
+		const int32_t x = v.lo + d.slot;
+		uint64_t cell;
+		uint32_t a, b;
+		seg_span(d, (uint64_t)g.offsets[x + 1], i, cell, a, b);
+		int st = 0;
+		if (i > 0) {
+			inRel = a1[k - 1].outRel - SEG_BITS; // (>= 0: the chain of the piece before left its piece)
+			st = seg_a2<ZK, STPB>(sg, lds + threadIdx.x, cell, inRel, b, me, cnt, sum, tRel);
+		} else inRel = a;
+		const bool last = k + 1 == segbase[r + 1];
+		// (st == 2 is no verdict yet: this piece's start may itself be wrong -- then the fix pass comes by, or B's check fails)
+		const bool m = st == 1 && !last && tRel != me.outRel; // the next piece took A1's end for its start: wrong
+		miss[k] = m ? 1 : 0;
+		if (m) fixlist[atomicAdd(&ctl[CTL_SEG + 1], 1)] = k;
+		fin[k] = SegFin{ inRel, cnt, sum, st == 2 ? ~0u : st == 1 ? tRel : 0u };
+		pair[k] = U2{ cnt, sum };
+	}
+}
+
+// ------------------------------------------------------------------------------------------------ fix
+// One lane per piece whose chains did not meet: the next piece again with its true start, and on along the record while chains keep
+// missing each other (or the next piece had missed on its own).  A piece whose predecessor missed too is not a start: the lane that
+// began further up comes by.  Best effort (FIX_MAX pieces; two runs may collide): B checks every start.
+template <int ZK>
+__global__ void __launch_bounds__(64) k_seg_fix(GraphDev g, RangeView v, const RecDesc *__restrict__ desc, const int32_t *__restrict__ segbase, const int32_t *__restrict__ seg2rec,
+                                                const SegA1 *__restrict__ a1, SegFin *__restrict__ fin, U2 *__restrict__ pair, const uint8_t *__restrict__ miss,
+                                                const int32_t *__restrict__ fixlist, const int32_t *__restrict__ ctl, int32_t *__restrict__ flag) {
+	__shared__ uint32_t lds[WIN_WORDS * 64];
+	const SegGraph sg = seg_graph(g);
+	const int32_t n = ctl[CTL_SEG + 1];
+	for (int32_t e = blockIdx.x * 64 + threadIdx.x; e < n; e += gridDim.x * 64) {
+		const int32_t k0 = fixlist[e], r = seg2rec[k0];
+		if (k0 > segbase[r] && miss[k0 - 1]) continue;
+		const RecDesc d = desc[r];
+		const int32_t x = v.lo + d.slot, kEnd = segbase[r + 1];
+		const uint64_t recEnd = (uint64_t)g.offsets[x + 1];
+		uint32_t inRel = fin[k0].tRel - SEG_BITS;
+		for (int32_t k = k0 + 1, steps = 0; k < kEnd; k++, steps++) {
+			if (steps >= FIX_MAX) { flag[r] = 1; break; }
+			uint64_t cell;
+			uint32_t a, b, cnt, sum, tRel;
+			seg_span(d, recEnd, k - segbase[r], cell, a, b);
+			const SegA1 me = a1[k];
+			const int st = seg_a2<ZK, 64>(sg, lds + threadIdx.x, cell, inRel, b, me, cnt, sum, tRel);
+			fin[k] = SegFin{ inRel, cnt, sum, st == 2 ? ~0u : st == 1 ? tRel : 0u };
+			pair[k] = U2{ cnt, sum };
+			if (st == 2) break; // (B flags the record)
+			if (st == 1 && tRel != me.outRel) { inRel = tRel - SEG_BITS; continue; } // missed again: on to the next piece with the true end
+			// A1's end of this piece is a true boundary, and that is what the next piece started from: its own walk was right.  If it missed, its
+			// entry in the list stood down when this piece had missed (with the wrong start) before: take it along
+			if (k + 1 < kEnd && miss[k] && miss[k + 1]) { inRel = me.outRel - SEG_BITS; continue; }
+			break;
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------ B
+template <int ZK>
+__global__ void __launch_bounds__(STPB) k_seg_b(GraphDev g, RangeView v, const RecDesc *__restrict__ desc, const int32_t *__restrict__ segbase, int32_t Rcap, int32_t Scap,
+                                                const int32_t *__restrict__ seg2rec, const SegFin *__restrict__ fin, const U2 *__restrict__ pre,
+                                                IvEntry *__restrict__ arena, int32_t *__restrict__ flag) {
+	__shared__ uint32_t lds[(WIN_WORDS + 2 * RING) * STPB];
+	const SegGraph sg = seg_graph(g);
+	const int32_t S = min(segbase[Rcap], Scap);
+	for (int32_t k = blockIdx.x * STPB + threadIdx.x; k < S; k += gridDim.x * STPB) {
+		const int32_t r = seg2rec[k];
+		if (flag[r]) continue;
+		const int32_t k0 = segbase[r], i = k - k0;
+		const RecDesc d = desc[r];
+		const int32_t s = d.slot, x = v.lo + s;
+		const U2 p0 = pre[k0], p = pre[k];
+		const SegFin me = fin[k];
+		const bool last = k + 1 == segbase[r + 1];
+		if (last && p.x + me.cnt - p0.x != (uint32_t)d.nres) { flag[r] = 1; continue; } // the codes of the section do not add up to the residuals the header promises
+		const uint64_t cell = (((uint64_t)d.rpos >> SEG_BITS_LOG2) + (uint64_t)i) << SEG_BITS_LOG2;
+		const int64_t abase = g.minInt > 0 ? v.rowstart[s] / g.minInt : 0;
+		uint32_t endRel;
+		const bool ok = seg_b<ZK, STPB>(sg, lds + threadIdx.x, lds + WIN_WORDS * STPB + threadIdx.x, x, cell, me.inRel, me.cnt, p.x - p0.x, (int32_t)(p.y - p0.y), i == 0,
+		                                v.row(s) + d.copied, v.outd[s] - d.copied, (SegIv *)(arena + abase), d.nIv, endRel);
+		// the proof that every piece started on a codeword boundary: its codes end where the next piece starts (by induction from the record's first piece)
+		if (!ok || me.tRel == ~0u || (!last && endRel != fin[k + 1].inRel + SEG_BITS)) flag[r] = 1;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------ expand
+// The intervals of a record are shared out evenly among the lanes of its segments.  Every lane of a wave takes its k-th interval in
+// the same iteration: short ones it writes itself, long ones are written by the whole wave, one after the other.
+__global__ void __launch_bounds__(STPB) k_seg_expand(RangeView v, int32_t minInt, const RecDesc *__restrict__ desc, const int32_t *__restrict__ segbase, int32_t Rcap, int32_t Scap,
+                                                     const int32_t *__restrict__ seg2rec, const IvEntry *__restrict__ arena, const int32_t *__restrict__ flag) {
+	const int32_t S = min(segbase[Rcap], Scap);
+	const int32_t G = gridDim.x * STPB;
+	for (int32_t k0 = blockIdx.x * STPB + (threadIdx.x & ~63); k0 < S; k0 += G) { // (wave-uniform)
+		const int32_t k = k0 + (threadIdx.x & 63);
+		int32_t lo = 0, hi = 0, nres = 0, extra = 0;
+		int32_t *out = nullptr;
+		const IvEntry *iv = nullptr;
+		if (k < S) {
+			const int32_t r = seg2rec[k];
+			if (!flag[r]) {
+				const RecDesc d = desc[r];
+				const int32_t ns = segbase[r + 1] - segbase[r], i = k - segbase[r];
+				lo = (int32_t)((int64_t)d.nIv * i / ns); hi = (int32_t)((int64_t)d.nIv * (i + 1) / ns);
+				nres = d.nres; extra = v.outd[d.slot] - d.copied;
+				out = v.row(d.slot) + d.copied;
+				iv = arena + (minInt > 0 ? v.rowstart[d.slot] / minInt : 0);
+			}
+		}
+		int32_t most = hi - lo;
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) most = max(most, __shfl_xor(most, o, 64));
+		for (int32_t t = 0; t < most; t++) {
+			IvEntry e{ 0, 0, 0, 0 };
+			if (lo + t < hi) e = iv[lo + t];
+			const bool isLong = e.len > 32;
+			if (!isLong && e.len > 0) expand_interval(SegIv{ e.left, e.pstart, e.rank, e.len }, nres, out, extra);
+			unsigned long long lm = __ballot(isLong);
+			while (lm) {
+				const int src = __ffsll((long long)lm) - 1;
+				lm &= lm - 1;
+				const int32_t L = __shfl(e.left, src, 64), N = __shfl(e.len, src, 64), X = __shfl(extra, src, 64);
+				const int64_t P = shfl_i64((int64_t)e.pstart + (e.rank < 0 ? nres : e.rank), src);
+				int32_t *O = (int32_t *)shfl_i64((int64_t)(uintptr_t)out, src);
+				for (int32_t u = threadIdx.x & 63; u < N; u += 64) if (P + u < (int64_t)X) O[P + u] = (int32_t)((uint32_t)L + (uint32_t)u);
+			}
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------ flagged records
+// -> the list of the cooperative one-wave kernel (k_parse_big<1> with which = CTL_SEG): it decodes them from scratch, whatever the
+// pipeline left in their rows and arena slices
+__global__ void __launch_bounds__(STPB) k_seg_collect(SegRecs recs, int32_t RcapM, int32_t Rtot, const RecDesc *__restrict__ desc, const int32_t *__restrict__ nseg, const int32_t *__restrict__ flag,
+                                                      int32_t *__restrict__ fblist, int32_t *__restrict__ ctl) {
+	const int32_t nrec = min(recs.count(), RcapM);
+	for (int32_t r = blockIdx.x * STPB + threadIdx.x; r < Rtot; r += gridDim.x * STPB) {
+		// the class's own records: every one the struct kernel looked at has a flag; the long records: those whose residuals were handed over
+		const bool mine = r < RcapM ? (r < nrec && !(desc[r].flags & RF_SKIP)) : nseg[r] > 0;
+		if (mine && flag[r]) fblist[atomicAdd(&ctl[CTL_SEG], 1)] = desc[r].slot;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------ launch
+int32_t seg_bits_log2() { return SEG_BITS_LOG2; }
+
+// Records of the pipeline, in this order: [0, RcapM) the parse list's long bins (records below the wave class; the others are skipped),
+// [RcapM, RcapM + capBig) the wave class's queue, then capGiant entries for the giants' queue (their descriptors come from k_parse_big).
+namespace {
+struct SegPtrs {
+	RecDesc *desc; int32_t *nseg, *segbase, *flag, *sumsR, *fblist, *seg2rec, *fixlist;
+	SegA1 *a1; SegFin *fin; uint8_t *miss; U2 *pair, *pre, *sumsS;
+	size_t bytes;
+};
+SegPtrs seg_ptrs(void *scratch, int32_t Rtot, int32_t Scap) {
+	auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+	char *p = (char *)scratch;
+	auto take = [&](size_t bytes) { char *q = p; p += up(bytes); return (void *)q; };
+	const size_t nbR = ((size_t)Rtot + SS_TILE - 1) / SS_TILE + 1, nbS = ((size_t)Scap + SS_TILE - 1) / SS_TILE + 1;
+	SegPtrs o;
+	o.desc = (RecDesc *)take(sizeof(RecDesc) * (size_t)Rtot);
+	o.nseg = (int32_t *)take(sizeof(int32_t) * ((size_t)Rtot + 1));
+	o.segbase = (int32_t *)take(sizeof(int32_t) * ((size_t)Rtot + 1));
+	o.flag = (int32_t *)take(sizeof(int32_t) * ((size_t)Rtot + 1));
+	o.sumsR = (int32_t *)take(sizeof(int32_t) * nbR);
+	o.fblist = (int32_t *)take(sizeof(int32_t) * (size_t)Rtot);
+	o.seg2rec = (int32_t *)take(sizeof(int32_t) * ((size_t)Scap + 1));
+	o.fixlist = (int32_t *)take(sizeof(int32_t) * ((size_t)Scap + 1));
+	o.a1 = (SegA1 *)take(sizeof(SegA1) * ((size_t)Scap + 1));
+	o.fin = (SegFin *)take(sizeof(SegFin) * ((size_t)Scap + 1));
+	o.miss = (uint8_t *)take((size_t)Scap + 1);
+	o.pair = (U2 *)take(sizeof(U2) * ((size_t)Scap + 1));
+	o.pre = (U2 *)take(sizeof(U2) * ((size_t)Scap + 1));
+	o.sumsS = (U2 *)take(sizeof(U2) * nbS);
+	o.bytes = (size_t)(p - (char *)scratch);
+	return o;
+}
+}
+size_t seg_scratch_bytes(int32_t Rtot, int32_t Scap) { return seg_ptrs(nullptr, Rtot, Scap).bytes; }
+
+// the hand-over slots of the cooperative kernels (GraphDev::segDesc ...); the counts of their parts are zeroed on `st`
+void seg_handover(GraphDev &g, void *scratch, int32_t RcapM, int32_t capBig, int32_t capGiant, int32_t Scap, hipStream_t st) {
+	const int32_t Rtot = RcapM + capBig + capGiant;
+	const SegPtrs P = seg_ptrs(scratch, Rtot, Scap);
+	g.segDesc = P.desc; g.segNseg = P.nseg; g.segFlag = P.flag;
+	g.segOff[0] = RcapM; g.segCap[0] = capBig;
+	g.segOff[1] = RcapM + capBig; g.segCap[1] = capGiant;
+	if (capBig + capGiant > 0) (void)hipMemsetAsync(P.nseg + RcapM, 0, sizeof(int32_t) * ((size_t)capBig + capGiant), st);
+}
+
+// the structure of the class's own records (needs the parse list and the row starts)
+void launch_seg_struct(const GraphDev &g, int def, const RangeView &v, const int32_t *plist, const int32_t *keyBase, int32_t kLo, int32_t kHi, int32_t RcapM, int32_t Rtot, int32_t Scap,
+                       void *scratch, void *arena, int64_t arenaCap, int32_t *ctl, int blocks, int *err, hipStream_t st) {
+	if (v.cnt <= 0 || Rtot <= 0 || def == 0) return;
+	const SegPtrs P = seg_ptrs(scratch, Rtot, Scap);
+	hipLaunchKernelGGL(k_seg_struct, dim3((unsigned)blocks), dim3(STPB), 0, st, g, v, SegRecs{ plist, keyBase, kLo, kHi }, RcapM, P.desc, P.nseg, P.flag, (IvEntry *)arena, arenaCap, ctl, err);
+}
+
+// everything behind the descriptors (the class's own and the cooperative kernels')
+void launch_seg_chain(const GraphDev &g, int def, const RangeView &v, const int32_t *plist, const int32_t *keyBase, int32_t kLo, int32_t kHi, int32_t RcapM, int32_t Rtot, int32_t Scap,
+                      void *scratch, void *arena, int64_t arenaCap, int32_t *ctl, int blocks, int *err, hipStream_t st) {
+	if (v.cnt <= 0 || Rtot <= 0 || def == 0) return;
+	const SegPtrs P = seg_ptrs(scratch, Rtot, Scap);
+	const SegRecs recs{ plist, keyBase, kLo, kHi };
+	const dim3 grid((unsigned)blocks), blk(STPB);
+	IvEntry *a = (IvEntry *)arena;
+	GraphDev g0 = g; g0.segDesc = nullptr; // (the kernel of the flagged records decodes whole records)
+	sg_scan<int32_t>(P.nseg, Rtot, P.segbase, P.sumsR, st);
+	hipLaunchKernelGGL(k_seg_fill, grid, blk, 0, st, Rtot, P.segbase, Scap, P.seg2rec);
+	if (def == 1) hipLaunchKernelGGL(k_seg_a1<3>, grid, blk, 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.a1, P.flag);
+	else hipLaunchKernelGGL(k_seg_a1<0>, grid, blk, 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.a1, P.flag);
+	if (def == 1) hipLaunchKernelGGL(k_seg_a2<3>, grid, blk, 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.a1, P.fin, P.pair, P.miss, P.fixlist, ctl, P.flag);
+	else hipLaunchKernelGGL(k_seg_a2<0>, grid, blk, 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.a1, P.fin, P.pair, P.miss, P.fixlist, ctl, P.flag);
+	if (def == 1) hipLaunchKernelGGL(k_seg_fix<3>, dim3(64), dim3(64), 0, st, g0, v, P.desc, P.segbase, P.seg2rec, P.a1, P.fin, P.pair, P.miss, P.fixlist, ctl, P.flag);
+	else hipLaunchKernelGGL(k_seg_fix<0>, dim3(64), dim3(64), 0, st, g0, v, P.desc, P.segbase, P.seg2rec, P.a1, P.fin, P.pair, P.miss, P.fixlist, ctl, P.flag);
+	sg_scan<U2>(P.pair, Scap, P.pre, P.sumsS, st);
+	if (def == 1) hipLaunchKernelGGL(k_seg_b<3>, grid, blk, 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.fin, P.pre, a, P.flag);
+	else hipLaunchKernelGGL(k_seg_b<0>, grid, blk, 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.fin, P.pre, a, P.flag);
+	hipLaunchKernelGGL(k_seg_expand, grid, blk, 0, st, v, g.minInt, P.desc, P.segbase, Rtot, Scap, P.seg2rec, a, P.flag);
+	hipLaunchKernelGGL(k_seg_collect, grid, blk, 0, st, recs, RcapM, Rtot, P.desc, P.nseg, P.flag, P.fblist, ctl);
+	launch_parse_listed(g0, def, v, P.fblist, ctl, CTL_SEG, arena, arenaCap, 256, err, st);
+}
+
+} // namespace bv

@@ -15,7 +15,11 @@
 //   A2       one lane per segment: takes its predecessor's end as its true start and walks the true chain and its own false chain in
 //            lock step (always the one that is behind) until they meet; only the difference of the two prefixes is applied to (count,
 //            sum).  If they meet inside the piece, the end found by A1 was a true boundary -- by induction from segment 0 every start
-//            is then exact; if not, the record is flagged
+//            is then exact.  If not (about one piece in 2 000 of 1 024 bits), the lane has followed the true chain to the end of
+//            its piece and knows where the NEXT piece really starts: it says so in a list
+//   fix      one lane per entry of that list: the same walk for the next piece with its true start, and on along the record for
+//            as long as chains keep missing each other.  Best effort: what proves the starts right is B, which checks that the
+//            codes it decodes end exactly where the next piece is said to start
 //   scan     counts and sums -> index of the segment's first residual in its record, value of the residual before it
 //   B        one lane per segment: decodes its codes again, adds up the gaps (BVG:954, :966) and stores every residual at its final
 //            place among the record's extras, walking the record's interval list alongside (a small ring in LDS) to count the interval
@@ -38,18 +42,23 @@
 #define SG_ANY(p) __any(p)
 #else
 #define SG_D inline
+#if defined(SG_ANY_ALWAYS) // model: as if some other lane of the wave always needed it -- whatever SG_ANY guards must be harmless at any time
+#define SG_ANY(p) ((void)(p), true)
+#else
 #define SG_ANY(p) (p)
+#endif
 #endif
 
 namespace bvsg {
 
 #ifndef SEG_BITS_LOG2_
-#define SEG_BITS_LOG2_ 11
+#define SEG_BITS_LOG2_ 10
 #endif
 constexpr int SEG_BITS_LOG2 = SEG_BITS_LOG2_;
-constexpr uint64_t SEG_BITS = (uint64_t)1 << SEG_BITS_LOG2; // a piece of stream; its start is a multiple of 128 bits (16-byte loads)
-constexpr int WIN_WORDS = 16;                               // a lane's window of the stream in LDS
-constexpr int RING = 8;                                     // intervals a lane of B keeps at hand (2 words each)
+constexpr uint32_t SEG_BITS = 1u << SEG_BITS_LOG2; // a piece of stream: [c * SEG_BITS, (c + 1) * SEG_BITS), "cell" c of the grid; a multiple of 128 bits (16-byte loads)
+constexpr int WIN_WORDS = 16;                      // a lane's window of the stream in LDS
+constexpr int RING = 8;                            // intervals a lane of B keeps at hand (2 words each)
+constexpr int FIX_MAX = 64;                        // pieces one lane of the fix kernel follows a run of missed meetings for
 
 struct SegGraph { // what the bodies need of bv::GraphDev
 	const uint32_t *bits;   // .graph bytes as big-endian words (byte-swapped on load), padded with >= 8 zero words
@@ -59,7 +68,21 @@ struct SegGraph { // what the bodies need of bv::GraphDev
 };
 struct SegIv { int32_t left, pstart, rank, len; };                                  // = bv::IvEntry (bv_coop.hpp)
 struct RecDesc { int64_t rpos; int32_t slot, nres, copied, nIv, flags, ivArcs; };   // one record of the class (32 bytes)
-enum { RF_FALLBACK = 1 };
+enum { RF_FALLBACK = 1, RF_SKIP = 2 }; // flagged: the cooperative kernel decodes it; not this pipeline's record at all
+// positions inside a piece are relative to the start of its cell (c << SEG_BITS_LOG2): they fit 32 bits
+struct SegA1 { uint32_t outRel, cnt, sum, badIdx; };  // A1: where the chain that started at the piece's nominal start leaves it; its codes; their sum; index of its first "codeword" of more than 64 bits (~0: none)
+struct SegFin { uint32_t inRel, cnt, sum, tRel; };    // A2 / fix: the piece's true start; true count and sum; tRel: 0, or where the true chain ends when the chains did not meet, or ~0: a codeword this decoder does not take
+
+#if defined(__HIPCC__)
+#define SG_ASSERT(c) ((void)0)
+#define SG_LIKELY(c) __builtin_expect(!!(c), 1)
+#define SG_UNLIKELY(c) __builtin_expect(!!(c), 0)
+#else
+#include <assert.h>
+#define SG_ASSERT(c) assert(c)
+#define SG_LIKELY(c) (c)
+#define SG_UNLIKELY(c) (c)
+#endif
 
 SG_D uint32_t clz32(uint32_t x) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -77,19 +100,20 @@ SG_D uint32_t clz64(uint64_t x) {
 }
 SG_D int32_t zigzag32(uint32_t v) { return (int32_t)(v >> 1) ^ -(int32_t)(v & 1); } // Fast.nat2int, truncated to a Java int
 SG_D uint64_t umin64(uint64_t a, uint64_t b) { return a < b ? a : b; }
+SG_D uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
 
-template <int STRIDE> struct Col { // word k of a lane's column: one LDS bank per lane on the device (STRIDE = threads of the block), plain array in the model
-	uint32_t *p;
-	SG_D uint32_t get(uint32_t k) const { return p[k * STRIDE]; }
-	SG_D void set(uint32_t k, uint32_t v) const { p[k * STRIDE] = v; }
-};
-
-// A lane's window of WIN_WORDS words of the stream, refilled with four 16-byte loads that are all in flight together.
+// A lane's window of WIN_WORDS words of the stream: word k lives at p[k * STRIDE] (one LDS bank per lane on the device, STRIDE =
+// threads of the block; a plain array in the model).  Refilled with four 16-byte loads that are all in flight together.  Cursors
+// are bit offsets from window word 0.  A codeword may be decoded at cursor q when q <= Q_OK (it reads words q / 32 .. q / 32 + 2);
+// a decoder advances its cursor by at most 65, and every decode below is preceded by a refill check: the reads stay inside the
+// window whatever the stream holds.
+constexpr uint32_t Q_OK = (WIN_WORDS - 3) * 32 + 31;
 template <int STRIDE> struct Win {
-	Col<STRIDE> c;
+	uint32_t *p;
 	const uint32_t *bits;
 	uint64_t w0;    // absolute index of window word 0 (a multiple of 4)
 	uint64_t vlast; // first word of the last 16-byte vector worth fetching: past it the last vector is simply read again (branch-free)
+	SG_D uint32_t word(uint32_t j) const { SG_ASSERT(j < (uint32_t)WIN_WORDS); return p[j * STRIDE]; }
 	SG_D void fill() {
 #if defined(__HIP_DEVICE_COMPILE__)
 		uint4 v[WIN_WORDS / 4];
@@ -97,103 +121,108 @@ template <int STRIDE> struct Win {
 		for (int k = 0; k < WIN_WORDS / 4; k++) v[k] = *(const uint4 *)(bits + umin64(w0 + 4 * k, vlast));
 #pragma unroll
 		for (int k = 0; k < WIN_WORDS / 4; k++) {
-			c.set(4 * k + 0, __builtin_bswap32(v[k].x)); c.set(4 * k + 1, __builtin_bswap32(v[k].y));
-			c.set(4 * k + 2, __builtin_bswap32(v[k].z)); c.set(4 * k + 3, __builtin_bswap32(v[k].w));
+			p[(4 * k + 0) * STRIDE] = __builtin_bswap32(v[k].x); p[(4 * k + 1) * STRIDE] = __builtin_bswap32(v[k].y);
+			p[(4 * k + 2) * STRIDE] = __builtin_bswap32(v[k].z); p[(4 * k + 3) * STRIDE] = __builtin_bswap32(v[k].w);
 		}
 #else
 		for (int k = 0; k < WIN_WORDS / 4; k++) {
 			uint32_t t[4];
 			memcpy(t, bits + umin64(w0 + 4 * k, vlast), 16);
-			for (int e = 0; e < 4; e++) c.set(4 * k + e, __builtin_bswap32(t[e]));
+			for (int e = 0; e < 4; e++) p[(4 * k + e) * STRIDE] = __builtin_bswap32(t[e]);
 		}
 #endif
 	}
-	SG_D void init(const SegGraph &g, Col<STRIDE> col, uint64_t lastBit) { // lastBit: no codeword that matters starts after it
-		c = col; bits = g.bits;
+	SG_D void init(const SegGraph &g, uint32_t *col, uint64_t lastBit) { // lastBit: no codeword that matters starts after it
+		p = col; bits = g.bits;
 		vlast = umin64((((lastBit + 64) >> 5) + 2) & ~(uint64_t)3, (g.nwords + 4) & ~(uint64_t)3);
 	}
 	SG_D uint32_t seek(uint64_t pos) { w0 = (pos >> 5) & ~(uint64_t)3; fill(); return (uint32_t)(pos - (w0 << 5)); }
 	SG_D uint64_t pos(uint32_t q) const { return (w0 << 5) + q; }
-	// a cursor at q may decode one codeword of up to 64 bits when q's word index is <= WIN_WORDS - 3
-	SG_D static bool low(uint32_t q) { return (q >> 5) + 3 > (uint32_t)WIN_WORDS; }
 	SG_D uint32_t slide(uint32_t qmin) { const uint32_t adv = (qmin >> 5) & ~3u; w0 += adv; fill(); return adv << 5; } // returns the bits every cursor moves down by
 	SG_D uint32_t peek32(uint32_t q) const {
-		const uint32_t j = (q >> 5) & (WIN_WORDS - 1), sh = q & 31u; // (masked: memory-safe on garbage)
-		const uint64_t ab = ((uint64_t)c.get(j) << 32) | c.get((j + 1) & (WIN_WORDS - 1));
-		return (uint32_t)((ab << sh) >> 32);
+		const uint32_t j = q >> 5;
+		const uint64_t ab = ((uint64_t)word(j) << 32) | word(j + 1);
+		return (uint32_t)((ab << (q & 31u)) >> 32);
 	}
 	SG_D uint64_t peek64(uint32_t q) const {
-		const uint32_t j = (q >> 5) & (WIN_WORDS - 1), sh = q & 31u;
-		const uint64_t ab = ((uint64_t)c.get(j) << 32) | c.get((j + 1) & (WIN_WORDS - 1));
-		return sh ? (ab << sh) | ((uint64_t)c.get((j + 2) & (WIN_WORDS - 1)) >> (32u - sh)) : ab;
+		const uint32_t j = q >> 5, sh = q & 31u;
+		const uint64_t ab = ((uint64_t)word(j) << 32) | word(j + 1);
+		return sh ? (ab << sh) | ((uint64_t)word(j + 2) >> (32u - sh)) : ab;
 	}
-	// The decoders: the common codewords (gamma < 2^16, zeta_3 < 2^21, unary < 32) from one 32-bit peek, longer ones from a 64-bit peek
-	// behind one rarely taken branch; `bad` when a codeword does not fit 64 bits or its value 32.  q advances by at most 64.
+	// The decoders: the common codewords (gamma < 2^16, zeta_3 < 2^21, unary < 32) from one 32-bit peek, a dozen instructions; longer
+	// ones out of line from a 64-bit peek; `bad` when a codeword does not fit 64 bits or its value 32 (then q advances by one bit).
+	SG_D uint32_t gamma_slow(uint32_t &q, bool &bad) const {
+		const uint64_t W64 = peek64(q);
+		const uint32_t m = clz64(W64);
+		if (m > 31) { bad = true; q += 1; return 0; }
+		q += 2 * m + 1;
+		return (uint32_t)(((W64 << m) >> (63u - m)) - 1);
+	}
 	SG_D uint32_t gamma(uint32_t &q, bool &bad) const { // the value (x, not x + 1)
 		const uint32_t W = peek32(q);
-		const uint32_t h = clz32(W);
-		uint32_t len = 2 * h + 1, v = (W >> ((31u - 2 * h) & 31u)) - 1;
-		if (__builtin_expect(h >= 16, 0)) {
-			const uint64_t W64 = peek64(q);
-			const uint32_t m = clz64(W64);
-			if (m > 31) { bad = true; len = 1; v = 0; }
-			else { len = 2 * m + 1; const uint64_t vv = ((W64 << m) >> (63u - m)) - 1; v = (uint32_t)vv; }
-		}
-		q += len;
-		return v;
+		if (SG_LIKELY(W >= (1u << 16))) { const uint32_t h = clz32(W); q += 2 * h + 1; return (W >> (31u - 2 * h)) - 1; }
+		return gamma_slow(q, bad);
 	}
 	SG_D uint32_t unary(uint32_t &q, bool &bad) const {
 		uint32_t z = clz32(peek32(q));
-		if (__builtin_expect(z >= 32, 0)) { z = clz64(peek64(q)); if (z >= 64) { bad = true; z = 0; } }
+		if (SG_UNLIKELY(z >= 32)) { z = clz64(peek64(q)); if (z >= 64) { bad = true; z = 0; } }
 		q += z + 1;
 		return z;
 	}
+	SG_D uint32_t zeta_slow(uint32_t &q, uint32_t k, bool &bad) const {
+		const uint64_t W64 = peek64(q);
+		const uint32_t h = clz64(W64);
+		const uint32_t nb = k * h + k - 1;
+		if (h + 2 + nb > 64u || k * h > 32u) { bad = true; q += 1; return 0; }
+		if (nb == 0) { q += 1; return 0; } // zeta_1, h = 0: the codeword "1" has no payload and means 0
+		const uint64_t mm = (W64 << (h + 1)) >> (63u - nb); // nb payload bits plus the extra bit of a long codeword
+		const uint64_t m = mm >> 1, left = (uint64_t)1 << (k * h);
+		const bool lng = m >= left;
+		const uint64_t vv = lng ? mm - 1 : m + left - 1;
+		if (vv > 0xffffffffull) bad = true;
+		q += h + 1 + nb + (lng ? 1u : 0u);
+		return (uint32_t)vv;
+	}
 	template <int K> SG_D uint32_t zeta(uint32_t &q, uint32_t krt, bool &bad) const { // K = 3 folded in; K = 0: k at run time (1 <= k <= 16)
-		const uint32_t k = K ? (uint32_t)K : krt;
 		const uint32_t W = peek32(q);
-		const uint32_t h = clz32(W);
-		const uint32_t nb = k * h + k - 1;                 // payload bits of the short codeword
-		const bool fits = h + 2 + nb <= 32u;
-		const uint32_t mm = nb ? (W << ((h + 1) & 31u)) >> ((31u - nb) & 31u) : 0u; // nb payload bits plus the extra bit of a long codeword (shifts masked: only used when it fits)
-		const uint32_t m = mm >> 1, left = 1u << ((k * h) & 31u);
-		const bool lng = nb != 0 && m >= left;             // (zeta_1, h = 0: the codeword "1" has no payload and means 0)
-		uint32_t v = lng ? mm - 1 : m + left - 1;
-		uint32_t len = h + 1 + nb + (lng ? 1u : 0u);
-		if (__builtin_expect(!fits, 0)) {
-			const uint64_t W64 = peek64(q);
-			const uint32_t h2 = clz64(W64);
-			const uint32_t nb2 = k * h2 + k - 1;
-			if (h2 + 2 + nb2 > 64u || k * h2 > 32u) { bad = true; v = 0; len = 1; }
-			else {
-				const uint64_t mm2 = (W64 << (h2 + 1)) >> (63u - nb2);
-				const uint64_t m2 = mm2 >> 1, left2 = (uint64_t)1 << (k * h2);
-				const bool lng2 = m2 >= left2;
-				const uint64_t vv = lng2 ? mm2 - 1 : m2 + left2 - 1;
-				if (vv > 0xffffffffull) bad = true;
-				v = (uint32_t)vv;
-				len = h2 + 1 + nb2 + (lng2 ? 1u : 0u);
+		if (K == 3) {
+			if (SG_LIKELY(W >= (1u << 25))) { // h <= 6: at most 28 bits
+				const uint32_t h = clz32(W), h3 = 3 * h;
+				const uint32_t mm = (W << (h + 1)) >> (29u - h3); // 3h + 2 payload bits plus the extra bit of a long codeword
+				const uint32_t m = mm >> 1, left = 1u << h3;
+				const bool lng = m >= left;
+				q += 4 * h + 3 + (lng ? 1u : 0u);
+				return lng ? mm - 1 : m + left - 1;
 			}
+			return zeta_slow(q, 3, bad);
 		}
-		q += len;
-		return v;
+		const uint32_t k = krt, h = clz32(W), nb = k * h + k - 1;
+		if (SG_LIKELY(h + 2 + nb <= 32u && nb != 0)) {
+			const uint32_t mm = (W << (h + 1)) >> (31u - nb);
+			const uint32_t m = mm >> 1, left = 1u << (k * h);
+			const bool lng = m >= left;
+			q += h + 1 + nb + (lng ? 1u : 0u);
+			return lng ? mm - 1 : m + left - 1;
+		}
+		return zeta_slow(q, k, bad);
 	}
 };
 
 // wave-synchronised refill: if ANY lane of the wave is about to run out of window, ALL (active) lanes move theirs up to their cursor
 // (left to themselves the lanes would each stall the whole wave for a memory round trip at a different iteration)
-#define SG_REFILL(w, q) do { if (SG_ANY(w.low(q))) q -= w.slide(q); } while (0)
+#define SG_REFILL(w, q) do { if (SG_ANY((q) > Q_OK)) q -= w.slide(q); } while (0)
 
 // ------------------------------------------------------------------------------------------------ struct
 // The gamma-coded front of record x (outdegree d; referent's outdegree dref if it has a reference): BVG:1048-1096.
 template <int STRIDE>
-SG_D void struct_lane(const SegGraph &g, Col<STRIDE> col, int32_t x, int32_t d, bool hasRef, int64_t dref, SegIv *iv, RecDesc &o) {
+SG_D void struct_lane(const SegGraph &g, uint32_t *col, int32_t x, int32_t d, bool hasRef, int64_t dref, SegIv *iv, RecDesc &o) {
 	Win<STRIDE> w;
 	const uint64_t recEnd = (uint64_t)g.offsets[x + 1];
 	w.init(g, col, recEnd);
 	uint32_t q = w.seek((uint64_t)g.offsets[x]);
 	bool bad = false;
 	(void)w.gamma(q, bad);               // outdegree (known from k_headers)
-	if (g.W > 0) (void)w.unary(q, bad);  // reference
+	if (g.W > 0) { SG_REFILL(w, q); (void)w.unary(q, bad); } // reference
 	int64_t copied = 0;
 	if (hasRef) { // BVG:1058-1071
 		SG_REFILL(w, q);
@@ -213,23 +242,25 @@ SG_D void struct_lane(const SegGraph &g, Col<STRIDE> col, int32_t x, int32_t d, 
 	}
 	const int64_t extra = (int64_t)d - copied;
 	if (extra < 0 || copied < 0) bad = true;
-	int64_t nIv = 0, ivArcs = 0;
+	int32_t nIv = 0, ivArcs = 0;
 	if (!bad && extra > 0 && g.minInt != 0) { // BVG:1073-1096
 		SG_REFILL(w, q);
-		nIv = (int64_t)w.gamma(q, bad);
-		if (nIv > extra / g.minInt) { bad = true; nIv = 0; }
+		const uint32_t ic = w.gamma(q, bad);
+		const int32_t xtr = (int32_t)extra, minInt = g.minInt;
+		if ((int64_t)ic > extra / minInt) bad = true; else nIv = (int32_t)ic;
 		int32_t prevEnd = 0;
-		for (int64_t i = 0; i < nIv && !bad; i++) {
+		for (int32_t i = 0; i < nIv && !bad; i++) {
 			SG_REFILL(w, q);
 			const uint32_t a = w.gamma(q, bad);
 			SG_REFILL(w, q);
 			const uint32_t l = w.gamma(q, bad);
-			if ((int64_t)l > extra) { bad = true; break; }
-			const int32_t left = i == 0 ? (int32_t)((uint32_t)x + (uint32_t)zigzag32(a)) : (int32_t)((uint32_t)prevEnd + a + 1u), n = (int32_t)l + g.minInt; // in Java ints (BVG:1084-1093)
+			if (l > (uint32_t)xtr) { bad = true; break; }
+			const int32_t left = i == 0 ? (int32_t)((uint32_t)x + (uint32_t)zigzag32(a)) : (int32_t)((uint32_t)prevEnd + a + 1u), n = (int32_t)l + minInt; // in Java ints (BVG:1084-1093)
+			if (i > 0 && left < prevEnd) { bad = true; break; } // intervals that wrap around: not here
 			prevEnd = (int32_t)((uint32_t)left + (uint32_t)n);
-			iv[i] = SegIv{ left, (int32_t)ivArcs, -1, n }; // rank -1: behind every residual, unless B says otherwise
-			ivArcs += n;
-			if (ivArcs > extra) { bad = true; break; }
+			iv[i] = SegIv{ left, ivArcs, -1, n }; // rank -1: behind every residual, unless B says otherwise
+			ivArcs += n;                          // (<= extra + minInt: no overflow)
+			if (ivArcs > xtr) { bad = true; break; }
 		}
 	}
 	// (the zig-zag value of the first interval is a long in the file: one that does not fit 33 bits made gamma() say bad)
@@ -238,152 +269,169 @@ SG_D void struct_lane(const SegGraph &g, Col<STRIDE> col, int32_t x, int32_t d, 
 	o.rpos = (int64_t)w.pos(q);
 	o.nres = bad ? 0 : (int32_t)nres;
 	o.copied = bad ? 0 : (int32_t)copied;
-	o.nIv = bad ? 0 : (int32_t)nIv;
-	o.ivArcs = bad ? 0 : (int32_t)ivArcs;
+	o.nIv = bad ? 0 : nIv;
+	o.ivArcs = bad ? 0 : ivArcs;
 	o.flags = bad ? RF_FALLBACK : 0;
 	if (!bad && nres > 0 && (uint64_t)o.rpos >= recEnd) o.flags = RF_FALLBACK; // residuals past the record's end (offsets that disagree with the stream)
 }
 
-// segments of a record: the pieces of the SEG_BITS grid that its residual section [rpos, recEnd) touches
+// segments of a record: the cells of the grid that its residual section [rpos, recEnd) touches
 SG_D int32_t seg_count(const RecDesc &r, uint64_t recEnd) {
-	if ((r.flags & RF_FALLBACK) || r.nres <= 0) return 0;
+	if ((r.flags & (RF_FALLBACK | RF_SKIP)) || r.nres <= 0) return 0;
 	const uint64_t c0 = (uint64_t)r.rpos >> SEG_BITS_LOG2, c1 = (recEnd - 1) >> SEG_BITS_LOG2;
 	const uint64_t n = c1 - c0 + 1;
 	return n > 0x3fffffffull ? 0 : (int32_t)n;
 }
-SG_D void seg_span(const RecDesc &r, uint64_t recEnd, int32_t i, uint64_t &start, uint64_t &end) { // codes of segment i start in [start, end)
+// segment i of the record: its cell's first bit, and where the codes that are its own start: [cell + startRel, cell + endRel)
+SG_D void seg_span(const RecDesc &r, uint64_t recEnd, int32_t i, uint64_t &cell, uint32_t &startRel, uint32_t &endRel) {
 	const uint64_t c = ((uint64_t)r.rpos >> SEG_BITS_LOG2) + (uint64_t)i;
-	start = i == 0 ? (uint64_t)r.rpos : c << SEG_BITS_LOG2;
-	end = umin64((c + 1) << SEG_BITS_LOG2, recEnd);
+	cell = c << SEG_BITS_LOG2;
+	startRel = i == 0 ? (uint32_t)((uint64_t)r.rpos - cell) : 0u;
+	endRel = (uint32_t)(umin64(cell + SEG_BITS, recEnd) - cell);
 }
 
 // ------------------------------------------------------------------------------------------------ A1
-// The codes that start in [start, end), from `start`: where the chain leaves the piece, how many codes, the sum of their contributions
-// (gap + 1 each; the first code of a record is the zig-zag value relative to x, BVG:954).  Sums are Java ints: they wrap.
-// A chain that starts off a codeword boundary reads garbage until it locks on, and garbage can look like a codeword of more than 64
-// bits: such a "codeword" is stepped over as one bit and its position reported in badAt (~0: none) -- A2 knows whether it lay before
-// the point where the true chain joins this one (harmless) or behind it (the record is flagged).
+// The codes that start in [startRel, endRel) of the cell, from startRel: where the chain leaves the piece, how many codes, the sum of
+// their contributions (gap + 1 each; the first code of a record is the zig-zag value relative to x, BVG:954).  Sums are Java ints:
+// they wrap.  A chain that starts off a codeword boundary reads garbage until it locks on, and garbage can look like a codeword of
+// more than 64 bits: such a "codeword" is stepped over as one bit and its index reported -- A2 knows whether it lay before the point
+// where the true chain joins this one (harmless) or behind it (the record is flagged).
 template <int ZK, int STRIDE>
-SG_D void seg_a1(const SegGraph &g, Col<STRIDE> col, int32_t x, uint64_t start, uint64_t end, bool firstOfRecord, uint64_t &out, uint32_t &cnt, uint32_t &sum, uint64_t &badAt) {
+SG_D void seg_a1(const SegGraph &g, uint32_t *col, int32_t x, uint64_t cell, uint32_t startRel, uint32_t endRel, bool firstOfRecord, SegA1 &o) {
 	Win<STRIDE> w;
-	w.init(g, col, end);
-	uint32_t q = w.seek(start);
-	cnt = 0; sum = 0; badAt = ~(uint64_t)0;
-	while (w.pos(q) < end) {
-		SG_REFILL(w, q);
+	w.init(g, col, cell + endRel);
+	uint32_t q = w.seek(cell + startRel);
+	uint32_t qend = q + (endRel - startRel);
+	uint32_t cnt = 0, sum = 0, badIdx = ~0u;
+	if (firstOfRecord && q < qend) {
 		bool bad = false;
-		const uint64_t p0 = w.pos(q);
 		const uint32_t v = w.template zeta<ZK>(q, (uint32_t)g.zetaK, bad);
-		if (bad && badAt == ~(uint64_t)0) badAt = p0;
-		sum = (firstOfRecord && cnt == 0) ? (uint32_t)x + (uint32_t)zigzag32(v) : sum + v + 1u;
+		if (bad) badIdx = 0;
+		sum = (uint32_t)x + (uint32_t)zigzag32(v);
+		cnt = 1;
+	}
+	while (q < qend) {
+		if (SG_ANY(q > Q_OK)) { const uint32_t dn = w.slide(q); q -= dn; qend -= dn; }
+		bool bad = false;
+		const uint32_t v = w.template zeta<ZK>(q, (uint32_t)g.zetaK, bad);
+		if (SG_UNLIKELY(bad)) badIdx = umin32(badIdx, cnt);
+		sum += v + 1u;
 		cnt++;
 	}
-	out = w.pos(q);
+	o.outRel = (uint32_t)(w.pos(q) - cell);
+	o.cnt = cnt; o.sum = sum; o.badIdx = badIdx;
 }
 
 // ------------------------------------------------------------------------------------------------ A2
-// Segment i >= 1: A1 started at the grid point `gstart`; the true chain enters the piece at `in` (>= gstart: the end of the segment
-// before).  Walks both chains in lock step until they meet, correcting (cnt, sum).  false: they did not meet inside the piece, so the
-// end A1 found is not known to be a true boundary -- or the true chain holds a codeword this decoder does not take.  The last segment
-// of a record has no successor that would take its end on trust: there the true chain is simply followed to the end of the record.
+// A piece that does not start its record: A1 started at the cell's first bit; the true chain enters the piece at inRel (the end of the
+// piece before, minus SEG_BITS).  Walks both chains in lock step until they meet, correcting A1's (cnt, sum).
+// 0: they met inside the piece -- the end A1 found is a true boundary; 1: they did not: the true chain was followed to the end of the
+// piece, (cnt, sum) are its own and tRel is where it ends (the true start of the next piece, plus SEG_BITS); 2: the true chain holds a
+// codeword this decoder does not take (the record is flagged).
 template <int ZK, int STRIDE>
-SG_D bool seg_a2(const SegGraph &g, Col<STRIDE> col, uint64_t gstart, uint64_t in, uint64_t end, bool last, uint64_t badAt, uint32_t &cnt, uint32_t &sum) {
-	if (in == gstart) return badAt == ~(uint64_t)0;
-	if (in < gstart || in - gstart > 128) return false; // (a codeword of the segment before cannot reach that far)
+SG_D int seg_a2(const SegGraph &g, uint32_t *col, uint64_t cell, uint32_t inRel, uint32_t endRel, const SegA1 &a1, uint32_t &cnt, uint32_t &sum, uint32_t &tRel) {
+	cnt = a1.cnt; sum = a1.sum; tRel = 0;
+	if (inRel == 0) return a1.badIdx == ~0u ? 0 : 2;
+	if (inRel > 128) return 2; // (a codeword of the piece before cannot reach that far)
 	Win<STRIDE> w;
-	w.init(g, col, end);
-	uint32_t qa = w.seek(gstart);               // the false chain
-	uint32_t qb = qa + (uint32_t)(in - gstart); // the true chain
+	w.init(g, col, cell + endRel);
+	uint32_t qa = w.seek(cell);   // the false chain (cell is a multiple of 128 bits: qa = 0)
+	uint32_t qb = qa + inRel;     // the true chain
+	uint32_t qend = qa + endRel;
 	uint32_t ca = 0, cb = 0, sa = 0, sb = 0;
 	bool met = true, badB = false;
 	while (qa != qb) {
 		const bool aBehind = qa < qb;
 		uint32_t &q = aBehind ? qa : qb;
-		if (w.pos(q) >= end) { met = false; break; } // the chain that is behind has left the piece (and so has the other): no meeting point
-		if (SG_ANY(w.low(qa > qb ? qa : qb))) { const uint32_t dn = w.slide(qa < qb ? qa : qb); qa -= dn; qb -= dn; }
+		if (q >= qend) { met = false; break; } // the chain that is behind has left the piece (and so has the other): no meeting point
+		if (SG_ANY((aBehind ? qb : qa) > Q_OK)) { const uint32_t dn = w.slide(q); qa -= dn; qb -= dn; qend -= dn; }
 		bool bad = false;
 		const uint32_t v = w.template zeta<ZK>(q, (uint32_t)g.zetaK, bad);
 		if (aBehind) { ca++; sa += v + 1u; } else { cb++; sb += v + 1u; badB |= bad; }
 	}
-	if (badB) return false;
-	if (!met) {
-		if (!last) return false;
-		cnt = cb; sum = sb; // both chains are past the end: the true one has been followed all the way
-		return true;
-	}
-	if (badAt != ~(uint64_t)0 && badAt >= w.pos(qa)) return false; // the codeword A1 could not take lies on the true chain
-	cnt = cnt - ca + cb;
-	sum = sum - sa + sb;
-	return true;
+	if (badB) return 2;
+	if (!met) { cnt = cb; sum = sb; tRel = (uint32_t)(w.pos(qb) - cell); return 1; } // both chains are past the end: the true one has been followed all the way
+	if (a1.badIdx != ~0u && a1.badIdx >= ca) return 2; // the codeword A1 could not take lies on the true chain
+	cnt = a1.cnt - ca + cb;
+	sum = a1.sum - sa + sb;
+	return 0;
 }
 
 // ------------------------------------------------------------------------------------------------ B
-// Decodes the cnt codes of a segment from its true start `in` and stores every residual at its place among the record's extras:
-// residual j (value r) goes to out[j + #(interval ids below r)].  v0 = the residual before the segment's first one, j0 = its index + 1.
-// Intervals that the segment's residuals pass learn their rank (= residuals before them).  false: the record must be flagged.
+// Decodes the cnt codes of a piece from its true start and stores every residual at its place among the record's extras: residual j
+// (value r) goes to out[j + #(interval ids below r)].  v0 = the residual before the piece's first one, j0 = its index + 1.
+// Intervals that the piece's residuals pass learn their rank (= residuals before them).  endRel: where the last code ended (the
+// caller checks it against the start of the next piece).  false: the record must be flagged.
 template <int ZK, int STRIDE>
-SG_D bool seg_b(const SegGraph &g, Col<STRIDE> col, Col<STRIDE> ring, int32_t x, uint64_t in, uint64_t end, uint32_t cnt, uint32_t j0, int32_t v0, bool firstOfRecord,
-                int32_t *out, int32_t extra, SegIv *iv, int32_t nIv) {
+SG_D bool seg_b(const SegGraph &g, uint32_t *col, uint32_t *ring, int32_t x, uint64_t cell, uint32_t inRel, uint32_t cnt, uint32_t j0, int32_t v0, bool firstOfRecord,
+                int32_t *out, int32_t extra, SegIv *iv, int32_t nIv, uint32_t &endRel) {
+#if defined(SG_DBG_NOIV)
+	nIv = 0;
+#endif
 	Win<STRIDE> w;
-	w.init(g, col, end);
-	uint32_t q = w.seek(in);
+	w.init(g, col, cell + SEG_BITS);
+	uint32_t q = w.seek(cell + inRel);
 	bool bad = false;
-	// intervals [0, idx) lie below v0 (passed by the segments before): a binary search in the record's arena slice
+	// intervals [0, idx) lie below v0 (passed by the pieces before): a binary search in the record's arena slice
 	int32_t idx = 0;
 	if (!firstOfRecord && nIv > 0) {
 		int32_t lo = 0, hi = nIv;
 		while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (iv[mid].left <= v0) lo = mid + 1; else hi = mid; }
 		idx = lo;
 	}
-	int32_t before = 0, prevEnd = 0; // interval ids below the cursor; end of the last interval passed
-	bool havePrev = false;
-	if (idx > 0) { const SegIv e = iv[idx - 1]; before = e.pstart + e.len; prevEnd = (int32_t)((uint32_t)e.left + (uint32_t)e.len); havePrev = true; }
+	// between the end of the last interval passed and the start of the next one a residual simply goes to out[j + before]
+	int32_t before = 0, prevEnd = (int32_t)0x80000000, nl = 0x7fffffff, ncum = 0; // ids of the intervals passed; [prevEnd, nl): the free stretch; ids up to the end of the next interval
+	if (idx > 0) { const SegIv e = iv[idx - 1]; before = e.pstart + e.len; prevEnd = (int32_t)((uint32_t)e.left + (uint32_t)e.len); }
 	// ring entry k & (RING - 1) holds interval k: (left, pstart + len); intervals [idx, loaded) are in the ring
 	int32_t loaded = idx;
-	{
-		const int32_t n = nIv - idx < RING ? nIv - idx : RING;
-		for (int32_t k = 0; k < n; k++) { const SegIv e = iv[idx + k]; const uint32_t s = (uint32_t)(idx + k) & (RING - 1); ring.set(2 * s, (uint32_t)e.left); ring.set(2 * s + 1, (uint32_t)(e.pstart + e.len)); }
-		loaded = idx + n;
-	}
-	int32_t nl = 0, ncum = 0; // the next interval: left, ids up to its end
-	if (idx < nIv) { const uint32_t s = (uint32_t)idx & (RING - 1); nl = (int32_t)ring.get(2 * s); ncum = (int32_t)ring.get(2 * s + 1); }
 	uint32_t j = j0;
 	int32_t val = v0;
 	for (uint32_t t = 0; t < cnt; t++) {
-		SG_REFILL(w, q);
+		if (SG_ANY(q > Q_OK)) q -= w.slide(q);
 		if (SG_ANY(loaded < nIv && loaded - idx <= 2)) { // some lane's ring runs low: every lane tops its own up (the wave waits once)
-			const int32_t room = RING / 2, n = nIv - loaded < room ? nIv - loaded : room; // (at most half a ring at a time: registers)
+			const int32_t free_ = RING - (loaded - idx), room = free_ < RING / 2 ? free_ : RING / 2, n = nIv - loaded < room ? nIv - loaded : room; // (this lane may not need it: only what fits; at most half a ring at a time: registers)
 #if defined(__HIP_DEVICE_COMPILE__)
 			int4 e[RING / 2];
 #pragma unroll
 			for (int k = 0; k < RING / 2; k++) if (k < n) e[k] = *(const int4 *)(iv + loaded + k);
 #pragma unroll
-			for (int k = 0; k < RING / 2; k++) if (k < n) { const uint32_t s = (uint32_t)(loaded + k) & (RING - 1); ring.set(2 * s, (uint32_t)e[k].x); ring.set(2 * s + 1, (uint32_t)(e[k].y + e[k].w)); }
+			for (int k = 0; k < RING / 2; k++) if (k < n) { const uint32_t s = (uint32_t)(loaded + k) & (RING - 1); ring[(2 * s) * STRIDE] = (uint32_t)e[k].x; ring[(2 * s + 1) * STRIDE] = (uint32_t)(e[k].y + e[k].w); }
 #else
-			for (int k = 0; k < n; k++) { const SegIv e = iv[loaded + k]; const uint32_t s = (uint32_t)(loaded + k) & (RING - 1); ring.set(2 * s, (uint32_t)e.left); ring.set(2 * s + 1, (uint32_t)(e.pstart + e.len)); }
+			for (int k = 0; k < n; k++) { const SegIv e = iv[loaded + k]; const uint32_t s = (uint32_t)(loaded + k) & (RING - 1); ring[(2 * s) * STRIDE] = (uint32_t)e.left; ring[(2 * s + 1) * STRIDE] = (uint32_t)(e.pstart + e.len); }
 #endif
 			if (n > 0) {
-				if (loaded == idx) { const uint32_t s = (uint32_t)idx & (RING - 1); nl = (int32_t)ring.get(2 * s); ncum = (int32_t)ring.get(2 * s + 1); }
+				if (loaded == idx) { const uint32_t s = (uint32_t)idx & (RING - 1); nl = (int32_t)ring[(2 * s) * STRIDE]; ncum = (int32_t)ring[(2 * s + 1) * STRIDE]; }
 				loaded += n;
 			}
 		}
 		const uint32_t v = w.template zeta<ZK>(q, (uint32_t)g.zetaK, bad);
 		val = (firstOfRecord && t == 0) ? (int32_t)((uint32_t)x + (uint32_t)zigzag32(v)) : (int32_t)((uint32_t)val + v + 1u); // BVG:954, :966
-		while (idx < nIv && nl < val) { // the residual passes interval idx: j residuals precede it
-			iv[idx].rank = (int32_t)j;
-			prevEnd = (int32_t)((uint32_t)nl + (uint32_t)(ncum - before)); havePrev = true;
-			before = ncum;
-			idx++;
-			if (idx < nIv) {
-				if (idx < loaded) { const uint32_t s = (uint32_t)idx & (RING - 1); nl = (int32_t)ring.get(2 * s); ncum = (int32_t)ring.get(2 * s + 1); }
-				else { const SegIv e = iv[idx]; nl = e.left; ncum = e.pstart + e.len; loaded = idx; } // (more than RING intervals between two residuals: straight from the arena)
+		if (SG_UNLIKELY((uint32_t)(val - prevEnd) >= (uint32_t)(nl - prevEnd))) { // not in the free stretch: the residual passes intervals -- or sits inside one
+			if (val < prevEnd) bad = true; // inside an interval: equal heads are emitted once (MergedIntIterator.java:69-72) -- not here
+			while (idx < nIv && nl < val) { // the residual passes interval idx: j residuals precede it
+#if !defined(SG_DBG_NORANK)
+				iv[idx].rank = (int32_t)j;
+#endif
+				prevEnd = (int32_t)((uint32_t)nl + (uint32_t)(ncum - before));
+				before = ncum;
+				idx++;
+				if (idx < nIv) {
+					if (idx < loaded) { const uint32_t s = (uint32_t)idx & (RING - 1); nl = (int32_t)ring[(2 * s) * STRIDE]; ncum = (int32_t)ring[(2 * s + 1) * STRIDE]; }
+					else { const SegIv e = iv[idx]; nl = e.left; ncum = e.pstart + e.len; loaded = idx; } // (more than RING intervals between two residuals: straight from the arena)
+					if (nl < prevEnd) bad = true;
+				} else nl = 0x7fffffff;
 			}
+			if ((idx < nIv && nl == val) || val < prevEnd) bad = true;
 		}
-		if ((idx < nIv && nl == val) || (havePrev && val < prevEnd)) bad = true; // a residual inside an interval: equal heads are emitted once (MergedIntIterator.java:69-72) -- not here
 		const int64_t p = (int64_t)j + before;
+#if defined(SG_DBG_NOSTORE)
+		if (p >= (int64_t)extra) bad = true;
+#else
 		if (p < (int64_t)extra) out[p] = val; else bad = true;
+#endif
 		j++;
 	}
+	endRel = (uint32_t)(w.pos(q) - cell);
 	return !bad;
 }
 

@@ -124,6 +124,10 @@ struct bvg_graph {
 	int level_blocks = 4096; // blocks of the list kernels (k_parse_list, k_copy_list): 2048..4096 are within 1 % on C2, 4096 is 3 % faster on cnr-2000 x30
 	DevBuf lvlist;
 	DevBuf plist, pkeys, pkey16;
+	DevBuf segbuf;       // scratch of the segment pipeline (bv_seg.hip)
+	int seg = 1;         // BVGPU_SEG=0: never; 1: jobs of >= 4 M arcs; 2: always -- records of the long work bins below the wave class go through the segment pipeline instead of k_parse_list
+	int seg_blocks = 2048;
+	int seg_handover = 1; // BVGPU_SEG_HANDOVER=0: the cooperative kernels decode the residuals of their records themselves
 	int tile = -1;       // -1: automatic (see enqueue_decode); BVGPU_TILE=0: never; BVGPU_TILE=1: short records decoded from contiguous tiles of the stream (k_parse_tile) instead of the bin-sorted parse list (k_parse_list)
 	DevBuf tilebounds;
 	int copy_big = 1;    // BVGPU_COPY_BIG=0: every row is copied by one lane
@@ -139,7 +143,7 @@ struct bvg_graph {
 	hipStream_t sideA = nullptr, sideB = nullptr; // (more streams than this share hardware queues with each other: they would serialise)
 	bool ctl_clean = false;                       // ctl[4..16) were zeroed by this job's k_pick_coop
 	bool host_mode = false;                       // host_scan: sideB carries the PCIe copies, its kernels go to sideA
-	hipEvent_t evFork = nullptr, evA = nullptr, evB = nullptr, evC = nullptr, evHdr = nullptr, evP = nullptr;
+	hipEvent_t evFork = nullptr, evA = nullptr, evB = nullptr, evC = nullptr, evHdr = nullptr, evP = nullptr, evW = nullptr, evM = nullptr;
 	bool overlap = true;
 	size_t halo_min = (size_t)16 << 20; // bytes of halo scratch an optimistic sub-range decode starts with (BVGPU_HALO_MIN)
 	bool force_halo_sync = false;   // (retry of an optimistic sub-range decode: size the halo with a host round trip)
@@ -218,6 +222,9 @@ int init_handle(bvg_graph *g) {
 	if (const char *e = getenv("BVGPU_COPY_BIG")) g->copy_big = atoi(e);
 	if (const char *e = getenv("BVGPU_PARSE_WINDOWS")) g->parse_windows = atoi(e);
 	if (const char *e = getenv("BVGPU_TILE")) g->tile = atoi(e);
+	if (const char *e = getenv("BVGPU_SEG")) g->seg = atoi(e);
+	if (const char *e = getenv("BVGPU_SEG_BLOCKS")) g->seg_blocks = std::max(1, atoi(e));
+	if (const char *e = getenv("BVGPU_SEG_HANDOVER")) g->seg_handover = atoi(e);
 	if (const char *e = getenv("BVGPU_WALK_TABLES")) g->walk_tables = atoi(e);
 	if (const char *e = getenv("BVGPU_IV_ARENA")) g->iv_arena = atoi(e);
 	if (const char *e = getenv("BVGPU_COPY_MID_MIN")) g->copy_mid_min = std::min(std::max(0, atoi(e)), 1024); // 0: no wave-per-row copy
@@ -237,6 +244,8 @@ int init_handle(bvg_graph *g) {
 	HIPCHK(g, hipEventCreateWithFlags(&g->evC, hipEventDisableTiming));
 	HIPCHK(g, hipEventCreateWithFlags(&g->evHdr, hipEventDisableTiming));
 	HIPCHK(g, hipEventCreateWithFlags(&g->evP, hipEventDisableTiming));
+	HIPCHK(g, hipEventCreateWithFlags(&g->evW, hipEventDisableTiming));
+	HIPCHK(g, hipEventCreateWithFlags(&g->evM, hipEventDisableTiming));
 	if (const char *e = getenv("BVGPU_STATS")) if (atoi(e)) { if (!g->stats.need(64 * sizeof(unsigned long long))) return fail(g, BVG_ENOMEM, "device allocation failed"); HIPCHK(g, hipMemset(g->stats.p, 0, 512)); }
 	return BVG_OK;
 }
@@ -455,6 +464,24 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			if (ovl && hdrEvent) HIPCHK(g, hipEventRecord(g->evP, g->sideA));
 		}
 		const bool earlyList = !tiles && ovl && hdrEvent;
+		// The segment pipeline (bv_seg.hip): the residual sections of the records of the long work bins (>= 2 048 bits of work), cut into pieces of stream, one lane
+		// per piece.  The class's own records (below the wave class) have their structure parsed by one lane each (k_seg_struct); the cooperative kernels parse the
+		// structure of theirs and hand the residuals over (GraphDev::segDesc); k_parse_list keeps the short bins.
+		const bool segOn = g->seg && !tiles && s.def != 0 && g->iv_arena && coop && (g->seg > 1 || estArcs >= 4000000);
+		const int32_t segKLo = g->parse_windows ? (bv::MAXLVL - 1) * bv::NBIN + bv::PARSE_LONG_BIN : bv::PARSE_LONG_BIN, segKHi = g->parse_windows ? bv::NKEYS : bv::NBIN;
+		int32_t segRcapM = 0, segRtot = 0, segScap = 0;
+		bool segReady = false;
+		if (segOn) {
+			const int64_t bits = s.h_offsets[(size_t)v.lo + v.cnt] - s.h_offsets[(size_t)v.lo];
+			segRcapM = (int32_t)std::min<int64_t>(v.cnt, (bits + 8 * arcsBound) / 2048 + 16); // records with >= 2 048 bits of work (max(bits, 8 successors)): every record with pieces is one
+			const int32_t capBig = g->seg_handover ? (int32_t)std::min<int64_t>(v.cnt, arcsBound / 128 + 2) : 0, capGiant = g->seg_handover ? giantCap : 0;
+			segRtot = segRcapM + capBig + capGiant;
+			segScap = (int32_t)std::min<int64_t>((bits >> bv::seg_bits_log2()) + 2 * (int64_t)segRcapM + 2, 0x7ffffff0);
+			if (g->segbuf.need(bv::seg_scratch_bytes(segRtot, segScap))) {
+				segReady = true;
+				if (g->seg_handover) bv::seg_handover(gd, g->segbuf.p, segRcapM, capBig, capGiant, segScap, g->stream); // (before the fork: the cooperative kernels start behind it)
+			}
+		}
 		if (!tiles) {
 			if (!g->plist.need(sizeof(int32_t) * (size_t)v.cnt) || !g->pkeys.need(3 * (bv::NKEYS + 1) * sizeof(int32_t)) || !g->pkey16.need(sizeof(uint16_t) * (size_t)v.cnt)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
 			pKeyBase = g->pkeys.as<int32_t>() + (bv::NKEYS + 1);
@@ -489,7 +516,8 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		if (ovl && coop) {
 			HIPCHK(g, hipStreamWaitEvent(g->sideA, g->evC, 0));
 			bv::launch_parse_big(gd, s.def, v, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, g->giant_groups, derr, side_b(g), g->sideA); // (giants, big)
-			HIPCHK(g, hipEventRecord(g->evB, side_b(g)));
+			if (segReady) HIPCHK(g, hipEventRecord(g->evW, g->sideA)); // (evB: behind the segment pipeline's chain, below)
+			else HIPCHK(g, hipEventRecord(g->evB, side_b(g)));
 		}
 		// ... then, behind the wave class, the chain depth of every record + per-level lists (node order inside a level) +
 		// copy queues: only the copy pass needs them, and launched first they would sit in front of the wave class while
@@ -509,7 +537,24 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		if (coop && !ovl) bv::launch_parse_waves(gd, s.def, v, g->biglist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, derr, g->stream);
 		mark(g, 5);
 		if (tiles) bv::launch_parse_tile(gd, s.def, v, g->tilebounds.as<int32_t>(), ntiles, tileVariant, derr, g->stream);
-		else bv::launch_parse_list(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, g->level_blocks, derr, g->stream, g->iv_arena ? g->arena.p : nullptr, arenaCap);
+		else {
+			int32_t keyHi = bv::NKEYS;
+			if (segReady) {
+				// here: the structure of the class's own records; on side B, behind the giants and once the wave class has handed its residual sections over: everything else
+				bv::launch_seg_struct(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, segKLo, segKHi, segRcapM, segRtot, segScap, g->segbuf.p, g->arena.p, arenaCap, ctl, g->seg_blocks, derr, g->stream);
+				hipStream_t stChain = g->stream;
+				if (ovl) {
+					stChain = side_b(g);
+					HIPCHK(g, hipEventRecord(g->evM, g->stream));
+					HIPCHK(g, hipStreamWaitEvent(stChain, g->evM, 0));
+					HIPCHK(g, hipStreamWaitEvent(stChain, g->evW, 0));
+				}
+				bv::launch_seg_chain(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, segKLo, segKHi, segRcapM, segRtot, segScap, g->segbuf.p, g->arena.p, arenaCap, ctl, g->seg_blocks, derr, stChain);
+				if (ovl) HIPCHK(g, hipEventRecord(g->evB, stChain));
+				keyHi = segKLo;
+			}
+			bv::launch_parse_list(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, g->level_blocks, derr, g->stream, g->iv_arena ? g->arena.p : nullptr, arenaCap, keyHi);
+		}
 		if (ovl) {
 			HIPCHK(g, hipStreamWaitEvent(g->stream, g->evA, 0));
 			if (coop) HIPCHK(g, hipStreamWaitEvent(g->stream, g->evB, 0));
@@ -984,7 +1029,7 @@ extern "C" int bvg_close(bvg_t *g) {
 		for (hipEvent_t e : { g->evChunk[0], g->evChunk[1], g->evCopied[0], g->evCopied[1] }) if (e) (void)hipEventDestroy(e);
 		if (g->h_small) (void)hipHostFree(g->h_small);
 		for (auto &e : g->ev) if (e) (void)hipEventDestroy(e);
-		for (hipEvent_t e : { g->evFork, g->evA, g->evB, g->evC, g->evHdr, g->evP, g->evIn, g->evOut }) if (e) (void)hipEventDestroy(e);
+		for (hipEvent_t e : { g->evFork, g->evA, g->evB, g->evC, g->evHdr, g->evP, g->evW, g->evM, g->evIn, g->evOut }) if (e) (void)hipEventDestroy(e);
 		for (hipStream_t st : { g->sideA, g->sideB }) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
 	}
 	delete g;
