@@ -23,8 +23,8 @@ int seg_model_run(const uint8_t *graph, uint64_t nbytes, const int64_t *offsets,
 	*nEsc = 0;
 	for (int s = 0; s < cnt; s++) cop[s] = -1;
 	for (int k = 0; k < 8; k++) stats[k] = 0;
-	std::vector<uint32_t> lds(WIN_WORDS + 2 * RING);
-	uint32_t *col = lds.data(), *ring = lds.data() + WIN_WORDS;
+	std::vector<uint32_t> lds(WIN_WORDS);
+	uint32_t *col = lds.data();
 	const int64_t arcs = rowstart[cnt] - rowstart[0];
 	std::vector<SegIv> arena((size_t)(minInt > 0 ? arcs / minInt + cnt + 2 : 1));
 	// the class
@@ -48,6 +48,7 @@ int seg_model_run(const uint8_t *graph, uint64_t nbytes, const int64_t *offsets,
 	}
 	const int32_t S = segbase[R];
 	stats[1] = S;
+	const uint32_t cap = (uint32_t)((SEG_BITS / (uint32_t)(zk < 1 ? 1 : zk) + 2 + 3) & ~3u); // = bv::seg_cell_cap
 	std::vector<SegA1> a1((size_t)S + 1);
 	std::vector<SegFin> fin((size_t)S + 1);
 	std::vector<uint32_t> pc((size_t)S + 1), ps((size_t)S + 1);
@@ -57,10 +58,11 @@ int seg_model_run(const uint8_t *graph, uint64_t nbytes, const int64_t *offsets,
 		const int32_t r = seg2rec[sg];
 		seg_span(desc[r], (uint64_t)offsets[lo + desc[r].slot + 1], sg - segbase[r], cell, a, b);
 	};
-	auto a2 = [&](int32_t sg, uint32_t inRel, uint32_t &cnt, uint32_t &sum, uint32_t &tRel) {
+	auto a2 = [&](int32_t sg, uint32_t inRel, bool rewritten, SegFin &o) {
 		uint64_t cell; uint32_t a, b;
 		span(sg, cell, a, b);
-		return zk == 3 ? seg_a2<3, 1>(g, col, cell, inRel, b, a1[sg], cnt, sum, tRel) : seg_a2<0, 1>(g, col, cell, inRel, b, a1[sg], cnt, sum, tRel);
+		if (zk == 3) seg_a2<3, 1>(g, col, cell, inRel, b, a1[sg], (int32_t *)nullptr, cap, (uint32_t *)nullptr, false, o);
+		else seg_a2<0, 1>(g, col, cell, inRel, b, a1[sg], (int32_t *)nullptr, cap, (uint32_t *)nullptr, false, o);
 	};
 	// A1
 	for (size_t r = 0; r < R; r++) {
@@ -70,24 +72,23 @@ int seg_model_run(const uint8_t *graph, uint64_t nbytes, const int64_t *offsets,
 			seg2rec[sg] = (int32_t)r;
 			uint64_t cell; uint32_t a, b;
 			span(sg, cell, a, b);
-			if (zk == 3) seg_a1<3, 1>(g, col, x, cell, a, b, i == 0, a1[sg]);
-			else seg_a1<0, 1>(g, col, x, cell, a, b, i == 0, a1[sg]);
-			if (i == 0 && a1[sg].badIdx != ~0u) { flag[r] = 1; if (getenv("SEG_MODEL_TRACE")) fprintf(stderr, "A1 bad: slot %d\n", desc[r].slot); }
+			if (zk == 3) seg_a1<3, 1>(g, col, x, cell, a, b, i == 0, (int32_t *)nullptr, cap, a1[sg]);
+			else seg_a1<0, 1>(g, col, x, cell, a, b, i == 0, (int32_t *)nullptr, cap, a1[sg]);
+			if (i == 0 && a1[sg].badIdx != ~0u) flag[r] = 1;
 		}
 	}
 	// A2 (reads what A1 wrote of this piece and the one before; writes fin / miss of its own piece only)
 	for (int32_t sg = 0; sg < S; sg++) {
 		const int32_t r = seg2rec[sg], i = sg - segbase[r];
-		uint32_t cnt = a1[sg].cnt, sum = a1[sg].sum, tRel = 0, inRel;
-		int st = 0;
-		if (i > 0) { inRel = a1[sg - 1].outRel - SEG_BITS; st = a2(sg, inRel, cnt, sum, tRel); }
-		else { uint64_t cell; uint32_t a, b; span(sg, cell, a, b); inRel = a; }
-		const bool last = sg + 1 == segbase[r + 1];
-		if (st == 1) stats[2]++;
-		const bool m = st == 1 && !last && tRel != a1[sg].outRel;
+		uint64_t cell; uint32_t a, b;
+		span(sg, cell, a, b);
+		SegFin o{ a, a1[sg].cnt, a1[sg].sum, 0, 0, 0, 0, a1[sg].badIdx != ~0u ? 2u : 0u };
+		if (i > 0) a2(sg, a1[sg - 1].outRel - SEG_BITS, false, o);
+		if ((o.mode & 3) == 1) stats[2]++;
+		const bool m = (o.mode & 3) == 1 && sg + 1 != segbase[r + 1] && o.tRel != a1[sg].outRel;
 		miss[sg] = m;
 		if (m) fixlist.push_back(sg);
-		fin[sg] = SegFin{ inRel, cnt, sum, st == 2 ? ~0u : st == 1 ? tRel : 0u };
+		fin[sg] = o;
 	}
 	// fix
 	for (int32_t k0 : fixlist) {
@@ -96,12 +97,12 @@ int seg_model_run(const uint8_t *graph, uint64_t nbytes, const int64_t *offsets,
 		uint32_t inRel = fin[k0].tRel - SEG_BITS;
 		for (int32_t k = k0 + 1, steps = 0; k < kEnd; k++, steps++) {
 			if (steps >= FIX_MAX) { flag[r] = 1; break; }
-			uint32_t cnt, sum, tRel;
-			const int st = a2(k, inRel, cnt, sum, tRel);
+			SegFin o;
+			a2(k, inRel, (fin[k].mode & SEG_REWRITTEN) != 0, o);
 			stats[4]++;
-			fin[k] = SegFin{ inRel, cnt, sum, st == 2 ? ~0u : st == 1 ? tRel : 0u };
-			if (st == 2) break;
-			if (st == 1 && tRel != a1[k].outRel) { inRel = tRel - SEG_BITS; continue; }
+			fin[k] = o;
+			if ((o.mode & 3) == 2) break;
+			if ((o.mode & 3) == 1 && o.tRel != a1[k].outRel) { inRel = o.tRel - SEG_BITS; continue; }
 			if (k + 1 < kEnd && miss[k] && miss[k + 1]) { inRel = a1[k].outRel - SEG_BITS; continue; }
 			break;
 		}
@@ -109,31 +110,60 @@ int seg_model_run(const uint8_t *graph, uint64_t nbytes, const int64_t *offsets,
 	// scan
 	pc[0] = ps[0] = 0;
 	for (int32_t sg = 0; sg < S; sg++) { pc[sg + 1] = pc[sg] + fin[sg].cnt; ps[sg + 1] = ps[sg] + fin[sg].sum; }
-	// B
+	// B: every piece's residuals, decoded from its true start, into the record's stretch of R; the chain of starts and ends is checked here
+	std::vector<int32_t> Rv((size_t)arcs + 8, -9);
 	for (int32_t sg = 0; sg < S; sg++) {
 		const int32_t r = seg2rec[sg];
 		if (flag[r]) continue; // (on the GPU a record may be flagged while its other pieces are already being written: harmless, the cooperative kernel rewrites the row)
-		const int32_t k0 = segbase[r], i = sg - k0, s = desc[r].slot, x = lo + s;
+		const int32_t k0 = segbase[r], i = sg - k0, s = desc[r].slot;
 		const bool last = sg + 1 == segbase[r + 1];
-		if (last && pc[sg] + fin[sg].cnt - pc[k0] != (uint32_t)desc[r].nres) { flag[r] = 1; if (getenv("SEG_MODEL_TRACE")) fprintf(stderr, "count: slot %d has %u wants %d\n", s, pc[sg] + fin[sg].cnt - pc[k0], desc[r].nres); continue; }
-		uint64_t cell; uint32_t a, b;
-		span(sg, cell, a, b);
+		const SegFin me = fin[sg];
+		const uint32_t j0 = pc[sg] - pc[k0];
+		const int64_t base = (rowstart[s] - rowstart[0]) + desc[r].copied + desc[r].ivArcs + (int64_t)j0;
+		bool ok = (me.mode & 3) != 2 && j0 + me.cnt <= (uint32_t)desc[r].nres;
+		if (last) ok = ok && j0 + me.cnt == (uint32_t)desc[r].nres;
+		uint32_t endRel = 0;
+		if (ok) {
+			uint64_t cell; uint32_t a, b;
+			span(sg, cell, a, b);
+			ok = zk == 3 ? seg_b_dense<3, 1>(g, col, lo + s, cell, me.inRel, me.cnt, (int32_t)(ps[sg] - ps[k0]), i == 0, Rv.data() + base, endRel)
+			             : seg_b_dense<0, 1>(g, col, lo + s, cell, me.inRel, me.cnt, (int32_t)(ps[sg] - ps[k0]), i == 0, Rv.data() + base, endRel);
+			if (!last) ok = ok && endRel == fin[sg + 1].inRel + SEG_BITS;
+		}
+		if (!ok) { flag[r] = 1; if (getenv("SEG_MODEL_TRACE")) fprintf(stderr, "B: slot %d piece %d/%d mode %u cnt %u\n", s, i, segbase[r + 1] - k0, me.mode, me.cnt); }
+	}
+	// merge (a scalar restatement of k_seg_merge, which ranks residuals and intervals against each other by binary searches, a wave per run of pieces)
+	for (size_t r = 0; r < R; r++) {
+		if (flag[r] || (desc[r].flags & RF_FALLBACK) || desc[r].nres <= 0) continue;
+		const int32_t s = desc[r].slot, nIv = desc[r].nIv, nres = desc[r].nres;
 		int32_t *out = succ + (rowstart[s] - rowstart[0]) + desc[r].copied;
 		const int32_t extra = outd[s] - desc[r].copied;
-		uint32_t endRel;
-		const bool ok = zk == 3 ? seg_b<3, 1>(g, col, ring, x, cell, fin[sg].inRel, fin[sg].cnt, pc[sg] - pc[k0], (int32_t)(ps[sg] - ps[k0]), i == 0, out, extra, iv_of(s), desc[r].nIv, endRel)
-		                        : seg_b<0, 1>(g, col, ring, x, cell, fin[sg].inRel, fin[sg].cnt, pc[sg] - pc[k0], (int32_t)(ps[sg] - ps[k0]), i == 0, out, extra, iv_of(s), desc[r].nIv, endRel);
-		if (!ok || fin[sg].tRel == ~0u || (!last && endRel != fin[sg + 1].inRel + SEG_BITS)) { flag[r] = 1; if (getenv("SEG_MODEL_TRACE")) fprintf(stderr, "B: slot %d piece %d/%d ok %d endRel %u next in %u\n", s, i, segbase[r + 1] - k0, (int)ok, endRel, last ? 0u : fin[sg + 1].inRel + SEG_BITS); }
+		const int32_t *res = Rv.data() + (rowstart[s] - rowstart[0]) + desc[r].copied + desc[r].ivArcs;
+		const SegIv *iv = iv_of(s);
+		int32_t c = 0, before = 0, prevEnd = (int32_t)0x80000000;
+		for (int32_t j = 0; j < nres; j++) {
+			while (c < nIv && iv[c].left < res[j]) { // interval c: j residuals below it
+				const int64_t P = (int64_t)iv[c].pstart + j;
+				for (int32_t u = 0; u < iv[c].len; u++) if (P + u < (int64_t)extra) out[P + u] = (int32_t)((uint32_t)iv[c].left + (uint32_t)u);
+				before = iv[c].pstart + iv[c].len; prevEnd = (int32_t)((uint32_t)iv[c].left + (uint32_t)iv[c].len);
+				c++;
+			}
+			if ((c < nIv && iv[c].left == res[j]) || res[j] < prevEnd) flag[r] = 1;
+			const int64_t P = (int64_t)j + before;
+			if (P < (int64_t)extra) out[P] = res[j]; else flag[r] = 1;
+		}
+		for (; c < nIv; c++) { const int64_t P = (int64_t)iv[c].pstart + nres; for (int32_t u = 0; u < iv[c].len; u++) if (P + u < (int64_t)extra) out[P + u] = (int32_t)((uint32_t)iv[c].left + (uint32_t)u); }
 	}
-	// expand
+	// what is left: flagged records -> the cooperative kernel; records without residuals have their intervals expanded by the struct lane
 	for (size_t r = 0; r < R; r++) {
 		const int32_t s = desc[r].slot;
 		if (flag[r] || (desc[r].flags & RF_FALLBACK)) { esc[(*nEsc)++] = s; stats[3]++; continue; }
 		cop[s] = desc[r].copied;
-		int32_t *out = succ + (rowstart[s] - rowstart[0]) + desc[r].copied;
-		const int32_t extra = outd[s] - desc[r].copied;
 		stats[5] += desc[r].nIv;
-		for (int32_t i = 0; i < desc[r].nIv; i++) expand_interval(iv_of(s)[i], desc[r].nres, out, extra);
+		if (desc[r].nres == 0) {
+			int32_t *out = succ + (rowstart[s] - rowstart[0]) + desc[r].copied;
+			for (int32_t i = 0; i < desc[r].nIv; i++) expand_interval(iv_of(s)[i], 0, out, outd[s] - desc[r].copied);
+		}
 	}
 	return 0;
 }

@@ -1003,7 +1003,9 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? COOP1_MINWAVES : COOPG_MINW
 		const unsigned long long t0 = g.stats ? __builtin_readcyclecounter() : 0;
 		// (scans only) the residual section of the record is handed to the segment pipeline: descriptor idx of this queue's part
 		bvsg::RecDesc *segOut = nullptr;
-		if (std::is_same<View, RangeView>::value && DEF != 0 && which < 2 && g.segDesc && idx < g.segCap[which]) {
+		// (only records of the long work bins, >= 2 048 bits of work: the pipeline's scratch is sized for those)
+		if (std::is_same<View, RangeView>::value && DEF != 0 && which < 2 && g.segDesc && idx < g.segCap[which] &&
+		    ((uint64_t)rec.d * 8 >= 2048 || (uint64_t)(g.offsets[rec.x + 1] - g.offsets[rec.x]) >= 2048)) {
 			segOut = (bvsg::RecDesc *)g.segDesc + g.segOff[which] + idx;
 			if (threadIdx.x == 0) { *segOut = bvsg::RecDesc{ 0, list[idx], 0, 0, 0, bvsg::RF_SKIP, 0 }; g.segFlag[g.segOff[which] + idx] = 0; }
 		}

@@ -81,14 +81,15 @@ void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int
 void launch_parse_listed(const GraphDev &g, int def, const RangeView &v, const int32_t *list, int32_t *ctl, int which, void *arena, int64_t arenaCap, int waves, int *err, hipStream_t st);
 // bv_seg.hip: the segment pipeline for the records of the parse list's keys [kLo, kHi) that have fewer than coop_min successors
 constexpr int PARSE_LONG_BIN = 14; // work bins from here up (>= 2048 bits of work) are not windowed (k_depth_keys) -- and are the segment pipeline's
-size_t seg_scratch_bytes(int32_t Rtot, int32_t Scap);
+size_t seg_scratch_bytes(int32_t Rtot, int32_t Scap, int zetaK);
+void launch_seg_sizing(const int64_t *offsets, int32_t lo, int32_t n, const int32_t *outd, unsigned long long *out2, hipStream_t st); // load time: records of the long work bins, their bits
 int32_t seg_bits_log2();
 // records of the pipeline: [0, RcapM) the parse list's long bins, then capBig / capGiant hand-over slots of the cooperative kernels' queues (Rtot = the sum)
 void seg_handover(GraphDev &g, void *scratch, int32_t RcapM, int32_t capBig, int32_t capGiant, int32_t Scap, hipStream_t st);
 void launch_seg_struct(const GraphDev &g, int def, const RangeView &v, const int32_t *plist, const int32_t *keyBase, int32_t kLo, int32_t kHi, int32_t RcapM, int32_t Rtot, int32_t Scap,
                        void *scratch, void *arena, int64_t arenaCap, int32_t *ctl, int blocks, int *err, hipStream_t st);
 void launch_seg_chain(const GraphDev &g, int def, const RangeView &v, const int32_t *plist, const int32_t *keyBase, int32_t kLo, int32_t kHi, int32_t RcapM, int32_t Rtot, int32_t Scap,
-                      void *scratch, void *arena, int64_t arenaCap, int32_t *ctl, int blocks, int *err, hipStream_t st);
+                      void *scratch, void *arena, int64_t arenaCap, int32_t *R, int64_t Rcap, int32_t *ctl, int blocks, int *err, hipStream_t st); // R: Rcap ints of scratch, >= the arcs of the view
 void launch_parse_waves(const GraphDev &g, int def, const RangeView &v, const int32_t *biglist, int32_t *ctl, void *arena, int64_t arenaCap, int waves, int *err, hipStream_t st);
 void launch_parse_giants(const GraphDev &g, int def, const RangeView &v, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap, int giantGroups, int *err, hipStream_t st);
 // bv_tile.hpp: short records decoded tile by tile from one LDS image of a contiguous slice of the stream

@@ -6,6 +6,8 @@
 #include "bv_coop.hpp"
 #include "bv_seg.hpp"
 
+#include <algorithm>
+
 namespace bv {
 
 using namespace bvsg;
@@ -94,8 +96,9 @@ template <class T> __device__ __forceinline__ T sg_block_excl(T v, T *total, T *
 	if (lane == 0) prev = sg_zero<T>();
 	return base + prev;
 }
-template <class T> __global__ void __launch_bounds__(STPB) k_sg_scan_sums(const T *__restrict__ in, int64_t n, T *__restrict__ sums) {
+template <class T> __global__ void __launch_bounds__(STPB) k_sg_scan_sums(const T *__restrict__ in, int64_t n, T *__restrict__ sums, const int32_t *__restrict__ nDev) {
 	__shared__ T wsum[STPB / 64];
+	if (nDev) n = min(n, (int64_t)*nDev); // (the grid covers the capacity; tiles past the end add nothing)
 	const int64_t base = (int64_t)blockIdx.x * SS_TILE;
 	T v = sg_zero<T>();
 #pragma unroll
@@ -113,8 +116,10 @@ template <class T> __global__ void __launch_bounds__(STPB) k_sg_scan_top(T *__re
 	T run = sg_block_excl(mine, &tot, wsum);
 	for (int64_t j = lo; j < hi; j++) { const T x = sums[j]; sums[j] = run; run = run + x; }
 }
-template <class T> __global__ void __launch_bounds__(STPB) k_sg_scan_apply(const T *__restrict__ in, int64_t n, const T *__restrict__ sums, T *__restrict__ out) {
+template <class T> __global__ void __launch_bounds__(STPB) k_sg_scan_apply(const T *__restrict__ in, int64_t n, const T *__restrict__ sums, T *__restrict__ out, const int32_t *__restrict__ nDev) {
 	__shared__ T wsum[STPB / 64];
+	if (nDev) n = min(n, (int64_t)*nDev);
+	if ((int64_t)blockIdx.x * SS_TILE >= n + 1) return;
 	const int64_t base = (int64_t)blockIdx.x * SS_TILE;
 	T vals[SS_ITEMS];
 	T v = sg_zero<T>();
@@ -129,12 +134,13 @@ template <class T> __global__ void __launch_bounds__(STPB) k_sg_scan_apply(const
 		ex = ex + vals[i];
 		if (j == n - 1) out[n] = ex;
 	}
+	if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) out[0] = sg_zero<T>();
 }
-template <class T> static void sg_scan(const T *in, int64_t n, T *out, T *sums, hipStream_t st) {
+template <class T> static void sg_scan(const T *in, int64_t n, T *out, T *sums, hipStream_t st, const int32_t *nDev = nullptr) {
 	const int64_t nb = (n + SS_TILE - 1) / SS_TILE;
-	hipLaunchKernelGGL(k_sg_scan_sums<T>, dim3((unsigned)nb), dim3(STPB), 0, st, in, n, sums);
+	hipLaunchKernelGGL(k_sg_scan_sums<T>, dim3((unsigned)nb), dim3(STPB), 0, st, in, n, sums, nDev);
 	hipLaunchKernelGGL(k_sg_scan_top<T>, dim3(1), dim3(STPB), 0, st, sums, nb);
-	hipLaunchKernelGGL(k_sg_scan_apply<T>, dim3((unsigned)nb), dim3(STPB), 0, st, in, n, sums, out);
+	hipLaunchKernelGGL(k_sg_scan_apply<T>, dim3((unsigned)nb), dim3(STPB), 0, st, in, n, sums, out, nDev);
 }
 
 // which record every segment belongs to: a record's lane writes its own stretch (a record of a thousand segments: a thousand stores
@@ -147,69 +153,64 @@ __global__ void __launch_bounds__(STPB) k_seg_fill(int32_t Rcap, const int32_t *
 }
 
 // ------------------------------------------------------------------------------------------------ A1
+// cells: cap ints per piece (cap = the most codes a piece can hold, a multiple of 4: 16-byte stores)
 template <int ZK>
-__global__ void __launch_bounds__(STPB) k_seg_a1(GraphDev g, RangeView v, const RecDesc *__restrict__ desc, const int32_t *__restrict__ segbase, int32_t Rcap, int32_t Scap,
-                                                 const int32_t *__restrict__ seg2rec, SegA1 *__restrict__ a1, int32_t *__restrict__ flag) {
+__global__ void __launch_bounds__(STPB) k_seg_a1(GraphDev g, RangeView v, const RecDesc *__restrict__ desc, const int32_t *__restrict__ segbase, int32_t Rtot, int32_t Scap,
+                                                 const int32_t *__restrict__ seg2rec, SegA1 *__restrict__ a1, int32_t *__restrict__ cells, uint32_t cap, int32_t *__restrict__ flag) {
 	__shared__ uint32_t lds[WIN_WORDS * STPB];
 	const SegGraph sg = seg_graph(g);
-	const int32_t S = min(segbase[Rcap], Scap);
+	const int32_t S = min(segbase[Rtot], Scap);
 	for (int32_t k = blockIdx.x * STPB + threadIdx.x; k < S; k += gridDim.x * STPB) {
 		const int32_t r = seg2rec[k], i = k - segbase[r];
 		const RecDesc d = desc[r];
 		const int32_t x = v.lo + d.slot;
-		uint64_t cell;
+		uint64_t cellBit;
 		uint32_t a, b;
-		seg_span(d, (uint64_t)g.offsets[x + 1], i, cell, a, b);
+		seg_span(d, (uint64_t)g.offsets[x + 1], i, cellBit, a, b);
 		SegA1 o;
-		seg_a1<ZK, STPB>(sg, lds + threadIdx.x, x, cell, a, b, i == 0, o);
+		seg_a1<ZK, STPB>(sg, lds + threadIdx.x, x, cellBit, a, b, i == 0, cells ? cells + (size_t)k * cap : nullptr, cap, o);
 		a1[k] = o;
 		if (i == 0 && o.badIdx != ~0u) flag[r] = 1;
 	}
 }
 
 // ------------------------------------------------------------------------------------------------ A2
-// pair[k] = (count, sum) of piece k for the scan; fin[k] = its true start and, when the chains did not meet, the true end;
+// fin[k]: the piece's true start, count, sum and how to read its residuals (SegFin); pair[k] = (count, sum) for the scan;
 // miss[k] = 1 and an entry in the fix list when the piece after it must be told its true start
 template <int ZK>
-__global__ void __launch_bounds__(STPB) k_seg_a2(GraphDev g, RangeView v, const RecDesc *__restrict__ desc, const int32_t *__restrict__ segbase, int32_t Rcap, int32_t Scap,
-                                                 const int32_t *__restrict__ seg2rec, const SegA1 *__restrict__ a1, SegFin *__restrict__ fin, U2 *__restrict__ pair, uint8_t *__restrict__ miss,
-                                                 int32_t *__restrict__ fixlist, int32_t *__restrict__ ctl, int32_t *__restrict__ flag) {
+__global__ void __launch_bounds__(STPB) k_seg_a2(GraphDev g, RangeView v, const RecDesc *__restrict__ desc, const int32_t *__restrict__ segbase, int32_t Rtot, int32_t Scap,
+                                                 const int32_t *__restrict__ seg2rec, const SegA1 *__restrict__ a1, int32_t *__restrict__ cells, uint32_t cap, uint32_t *__restrict__ fixbuf,
+                                                 SegFin *__restrict__ fin, U2 *__restrict__ pair, uint8_t *__restrict__ miss, int32_t *__restrict__ fixlist, int32_t *__restrict__ ctl) {
 	__shared__ uint32_t lds[WIN_WORDS * STPB];
 	const SegGraph sg = seg_graph(g);
-	const int32_t S = min(segbase[Rcap], Scap);
-	for (int32_t k = blockIdx.x * STPB + threadIdx.x; k < Scap; k += gridDim.x * STPB) {
-		if (k >= S) { pair[k] = U2{ 0, 0 }; continue; } // (the scan runs over the capacity)
+	const int32_t S = min(segbase[Rtot], Scap);
+	for (int32_t k = blockIdx.x * STPB + threadIdx.x; k < S; k += gridDim.x * STPB) {
 		const int32_t r = seg2rec[k], i = k - segbase[r];
 		const SegA1 me = a1[k];
-		uint32_t cnt = me.cnt, sum = me.sum, tRel = 0, inRel;
 		const RecDesc d = desc[r];
 		const int32_t x = v.lo + d.slot;
-		uint64_t cell;
+		uint64_t cellBit;
 		uint32_t a, b;
-		seg_span(d, (uint64_t)g.offsets[x + 1], i, cell, a, b);
-		int st = 0;
-		if (i > 0) {
-			inRel = a1[k - 1].outRel - SEG_BITS; // (>= 0: the chain of the piece before left its piece)
-			st = seg_a2<ZK, STPB>(sg, lds + threadIdx.x, cell, inRel, b, me, cnt, sum, tRel);
-		} else inRel = a;
-		const bool last = k + 1 == segbase[r + 1];
-		// (st == 2 is no verdict yet: this piece's start may itself be wrong -- then the fix pass comes by, or B's check fails)
-		const bool m = st == 1 && !last && tRel != me.outRel; // the next piece took A1's end for its start: wrong
+		seg_span(d, (uint64_t)g.offsets[x + 1], i, cellBit, a, b);
+		SegFin o{ a, me.cnt, me.sum, 0, 0, 0, 0, me.badIdx != ~0u ? 2u : 0u };
+		if (i > 0) seg_a2<ZK, STPB>(sg, lds + threadIdx.x, cellBit, a1[k - 1].outRel - SEG_BITS, b, me, cells ? cells + (size_t)k * cap : nullptr, cap, fixbuf ? fixbuf + (size_t)k * FIX_CODES : nullptr, false, o);
+		// (mode 2 is no verdict yet: this piece's start may itself be wrong -- then the fix pass comes by, or B's check of the chain fails)
+		const bool m = (o.mode & 3) == 1 && k + 1 != segbase[r + 1] && o.tRel != me.outRel; // the next piece took A1's end for its start: wrong
 		miss[k] = m ? 1 : 0;
 		if (m) fixlist[atomicAdd(&ctl[CTL_SEG + 1], 1)] = k;
-		fin[k] = SegFin{ inRel, cnt, sum, st == 2 ? ~0u : st == 1 ? tRel : 0u };
-		pair[k] = U2{ cnt, sum };
+		fin[k] = o;
+		pair[k] = U2{ o.cnt, o.sum };
 	}
 }
 
 // ------------------------------------------------------------------------------------------------ fix
 // One lane per piece whose chains did not meet: the next piece again with its true start, and on along the record while chains keep
 // missing each other (or the next piece had missed on its own).  A piece whose predecessor missed too is not a start: the lane that
-// began further up comes by.  Best effort (FIX_MAX pieces; two runs may collide): B checks every start.
+// began further up comes by.  Best effort (FIX_MAX pieces; two runs may collide): B checks the chain of starts and ends.
 template <int ZK>
 __global__ void __launch_bounds__(64) k_seg_fix(GraphDev g, RangeView v, const RecDesc *__restrict__ desc, const int32_t *__restrict__ segbase, const int32_t *__restrict__ seg2rec,
-                                                const SegA1 *__restrict__ a1, SegFin *__restrict__ fin, U2 *__restrict__ pair, const uint8_t *__restrict__ miss,
-                                                const int32_t *__restrict__ fixlist, const int32_t *__restrict__ ctl, int32_t *__restrict__ flag) {
+                                                const SegA1 *__restrict__ a1, int32_t *__restrict__ cells, uint32_t cap, uint32_t *__restrict__ fixbuf, SegFin *__restrict__ fin, U2 *__restrict__ pair,
+                                                const uint8_t *__restrict__ miss, const int32_t *__restrict__ fixlist, const int32_t *__restrict__ ctl, int32_t *__restrict__ flag) {
 	__shared__ uint32_t lds[WIN_WORDS * 64];
 	const SegGraph sg = seg_graph(g);
 	const int32_t n = ctl[CTL_SEG + 1];
@@ -222,15 +223,16 @@ __global__ void __launch_bounds__(64) k_seg_fix(GraphDev g, RangeView v, const R
 		uint32_t inRel = fin[k0].tRel - SEG_BITS;
 		for (int32_t k = k0 + 1, steps = 0; k < kEnd; k++, steps++) {
 			if (steps >= FIX_MAX) { flag[r] = 1; break; }
-			uint64_t cell;
-			uint32_t a, b, cnt, sum, tRel;
-			seg_span(d, recEnd, k - segbase[r], cell, a, b);
+			uint64_t cellBit;
+			uint32_t a, b;
+			seg_span(d, recEnd, k - segbase[r], cellBit, a, b);
 			const SegA1 me = a1[k];
-			const int st = seg_a2<ZK, 64>(sg, lds + threadIdx.x, cell, inRel, b, me, cnt, sum, tRel);
-			fin[k] = SegFin{ inRel, cnt, sum, st == 2 ? ~0u : st == 1 ? tRel : 0u };
-			pair[k] = U2{ cnt, sum };
-			if (st == 2) break; // (B flags the record)
-			if (st == 1 && tRel != me.outRel) { inRel = tRel - SEG_BITS; continue; } // missed again: on to the next piece with the true end
+			SegFin o;
+			seg_a2<ZK, 64>(sg, lds + threadIdx.x, cellBit, inRel, b, me, cells ? cells + (size_t)k * cap : nullptr, cap, fixbuf ? fixbuf + (size_t)k * FIX_CODES : nullptr, cells && (fin[k].mode & SEG_REWRITTEN) != 0, o);
+			fin[k] = o;
+			pair[k] = U2{ o.cnt, o.sum };
+			if ((o.mode & 3) == 2) break; // (B flags the record)
+			if ((o.mode & 3) == 1 && o.tRel != me.outRel) { inRel = o.tRel - SEG_BITS; continue; } // missed again: on to the next piece with the true end
 			// A1's end of this piece is a true boundary, and that is what the next piece started from: its own walk was right.  If it missed, its
 			// entry in the list stood down when this piece had missed (with the wrong start) before: take it along
 			if (k + 1 < kEnd && miss[k] && miss[k + 1]) { inRel = me.outRel - SEG_BITS; continue; }
@@ -240,73 +242,139 @@ __global__ void __launch_bounds__(64) k_seg_fix(GraphDev g, RangeView v, const R
 }
 
 // ------------------------------------------------------------------------------------------------ B
+// One lane per piece: its residuals, decoded from its true start, to the record's stretch of the scratch array R (the residuals of a
+// record are contiguous there, in order).  The proof that every piece starts on a codeword boundary: the record's first piece does,
+// and every piece's codes end where the next piece says it starts.
 template <int ZK>
-__global__ void __launch_bounds__(STPB) k_seg_b(GraphDev g, RangeView v, const RecDesc *__restrict__ desc, const int32_t *__restrict__ segbase, int32_t Rcap, int32_t Scap,
-                                                const int32_t *__restrict__ seg2rec, const SegFin *__restrict__ fin, const U2 *__restrict__ pre,
-                                                IvEntry *__restrict__ arena, int32_t *__restrict__ flag) {
-	__shared__ uint32_t lds[(WIN_WORDS + 2 * RING) * STPB];
+__global__ void __launch_bounds__(STPB) k_seg_bd(GraphDev g, RangeView v, const RecDesc *__restrict__ desc, const int32_t *__restrict__ segbase, int32_t Rtot, int32_t Scap,
+                                                 const int32_t *__restrict__ seg2rec, const SegFin *__restrict__ fin, const U2 *__restrict__ pre, int32_t *__restrict__ R, int64_t Rcap,
+                                                 int32_t *__restrict__ flag) {
+	__shared__ uint32_t lds[WIN_WORDS * STPB];
 	const SegGraph sg = seg_graph(g);
-	const int32_t S = min(segbase[Rcap], Scap);
+	const int32_t S = min(segbase[Rtot], Scap);
 	for (int32_t k = blockIdx.x * STPB + threadIdx.x; k < S; k += gridDim.x * STPB) {
 		const int32_t r = seg2rec[k];
 		if (flag[r]) continue;
-		const int32_t k0 = segbase[r], i = k - k0;
 		const RecDesc d = desc[r];
-		const int32_t s = d.slot, x = v.lo + s;
-		const U2 p0 = pre[k0], p = pre[k];
-		const SegFin me = fin[k];
+		const int32_t s = d.slot, k0 = segbase[r], i = k - k0;
 		const bool last = k + 1 == segbase[r + 1];
-		if (last && p.x + me.cnt - p0.x != (uint32_t)d.nres) { flag[r] = 1; continue; } // the codes of the section do not add up to the residuals the header promises
-		const uint64_t cell = (((uint64_t)d.rpos >> SEG_BITS_LOG2) + (uint64_t)i) << SEG_BITS_LOG2;
-		const int64_t abase = g.minInt > 0 ? v.rowstart[s] / g.minInt : 0;
-		uint32_t endRel;
-		const bool ok = seg_b<ZK, STPB>(sg, lds + threadIdx.x, lds + WIN_WORDS * STPB + threadIdx.x, x, cell, me.inRel, me.cnt, p.x - p0.x, (int32_t)(p.y - p0.y), i == 0,
-		                                v.row(s) + d.copied, v.outd[s] - d.copied, (SegIv *)(arena + abase), d.nIv, endRel);
-		// the proof that every piece started on a codeword boundary: its codes end where the next piece starts (by induction from the record's first piece)
-		if (!ok || me.tRel == ~0u || (!last && endRel != fin[k + 1].inRel + SEG_BITS)) flag[r] = 1;
+		const SegFin me = fin[k];
+		const U2 p0 = pre[k0], p = pre[k];
+		const uint32_t j0 = p.x - p0.x;
+		const int64_t base = v.rowstart[s] + d.copied + d.ivArcs + (int64_t)j0;
+		bool ok = (me.mode & 3) != 2 && base >= 0 && base + (int64_t)me.cnt <= Rcap && j0 + me.cnt <= (uint32_t)d.nres;
+		if (last) ok = ok && j0 + me.cnt == (uint32_t)d.nres; // the codes of the section add up to the residuals the header promises
+		uint32_t endRel = 0;
+		if (ok) {
+			const uint64_t cellBit = (((uint64_t)d.rpos >> SEG_BITS_LOG2) + (uint64_t)i) << SEG_BITS_LOG2;
+			ok = seg_b_dense<ZK, STPB>(sg, lds + threadIdx.x, v.lo + s, cellBit, me.inRel, me.cnt, (int32_t)(p.y - p0.y), i == 0, R + base, endRel);
+			if (!last) ok = ok && endRel == fin[k + 1].inRel + SEG_BITS;
+		}
+		if (!ok) flag[r] = 1;
 	}
 }
 
-// ------------------------------------------------------------------------------------------------ expand
-// The intervals of a record are shared out evenly among the lanes of its segments.  Every lane of a wave takes its k-th interval in
-// the same iteration: short ones it writes itself, long ones are written by the whole wave, one after the other.
-__global__ void __launch_bounds__(STPB) k_seg_expand(RangeView v, int32_t minInt, const RecDesc *__restrict__ desc, const int32_t *__restrict__ segbase, int32_t Rcap, int32_t Scap,
-                                                     const int32_t *__restrict__ seg2rec, const IvEntry *__restrict__ arena, const int32_t *__restrict__ flag) {
-	const int32_t S = min(segbase[Rcap], Scap);
-	const int32_t G = gridDim.x * STPB;
-	for (int32_t k0 = blockIdx.x * STPB + (threadIdx.x & ~63); k0 < S; k0 += G) { // (wave-uniform)
-		const int32_t k = k0 + (threadIdx.x & 63);
-		int32_t lo = 0, hi = 0, nres = 0, extra = 0;
-		int32_t *out = nullptr;
-		const IvEntry *iv = nullptr;
-		if (k < S) {
-			const int32_t r = seg2rec[k];
-			if (!flag[r]) {
-				const RecDesc d = desc[r];
-				const int32_t ns = segbase[r + 1] - segbase[r], i = k - segbase[r];
-				lo = (int32_t)((int64_t)d.nIv * i / ns); hi = (int32_t)((int64_t)d.nIv * (i + 1) / ns);
-				nres = d.nres; extra = v.outd[d.slot] - d.copied;
-				out = v.row(d.slot) + d.copied;
-				iv = arena + (minInt > 0 ? v.rowstart[d.slot] / minInt : 0);
+// ------------------------------------------------------------------------------------------------ merge
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); }
+// how many of the n intervals have left <= v (the lefts increase): a 64-ary search by the whole wave, two round trips for 4 096 intervals
+__device__ __forceinline__ int32_t wave_count_le(const IvEntry *__restrict__ iv, int32_t n, int32_t v) {
+	const int lane = threadIdx.x & 63;
+	int32_t lo = 0, hi = n;
+	while (hi > lo) {
+		const int32_t span = hi - lo, step = (span + 63) >> 6, idx = lo + lane * step;
+		const bool p = idx < hi && iv[idx].left <= v;
+		const int32_t c = __popcll(__ballot(p)); // (a prefix of the lanes)
+		if (step == 1) return lo + c;
+		if (c == 0) return lo;
+		hi = min(lo + c * step, hi);
+		lo = lo + (c - 1) * step + 1;
+	}
+	return lo;
+}
+constexpr int MG_WAVES = 4, MG_IVCAP = 256, MG_VALCAP = 1408;
+// One wave per run of up to G consecutive pieces of a record: its residuals (from R) and the intervals they pass are ranked against each
+// other by binary searches in LDS -- residual j goes to out[j + ids of the intervals below it], interval e to out[pstart + residuals
+// below it ..) (MergedIntIterator.java:50-74, IntIntervalSequenceIterator.java:64-78).  Behind the record's last residual every
+// interval has rank nres.  Neighbouring lanes read and write neighbouring ids.
+__global__ void __launch_bounds__(64 * MG_WAVES) k_seg_merge(GraphDev g, RangeView v, const RecDesc *__restrict__ desc, const int32_t *__restrict__ segbase, int32_t Rtot, int32_t Scap,
+                                                             const int32_t *__restrict__ seg2rec, const U2 *__restrict__ pre, const int32_t *__restrict__ R, int32_t G,
+                                                             const IvEntry *__restrict__ arena, int32_t *__restrict__ flag) {
+	__shared__ int32_t s_valAll[MG_WAVES][MG_VALCAP];
+	__shared__ int32_t s_ivAll[MG_WAVES][3][MG_IVCAP]; // left, ids up to the interval's end, its end
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	int32_t *s_val = s_valAll[wv], *s_left = s_ivAll[wv][0], *s_cum = s_ivAll[wv][1], *s_end = s_ivAll[wv][2];
+	const int32_t S = min(segbase[Rtot], Scap);
+	const int64_t nGroups = ((int64_t)S + G - 1) / G;
+	for (int64_t w = (int64_t)blockIdx.x * MG_WAVES + wv; w < nGroups; w += (int64_t)gridDim.x * MG_WAVES) { // (wave-uniform)
+		const int32_t kLim = (int32_t)min((w + 1) * G, (int64_t)S);
+		for (int32_t ka = (int32_t)(w * G); ka < kLim;) { // the group's pieces, record by record
+			const int32_t r = seg2rec[ka], k0 = segbase[r], kE = segbase[r + 1], kb = min(kE, kLim);
+			const int32_t kaRun = ka;
+			ka = kb;
+			if (flag[r]) continue;
+			const RecDesc d = desc[r];
+			const int32_t s = d.slot;
+			const bool firstRun = kaRun == k0, lastRun = kb == kE;
+			const U2 p0 = pre[k0], pa = pre[kaRun], pb = pre[kb];
+			const uint32_t j0 = pa.x - p0.x, cnt = pb.x - pa.x;
+			const int32_t v0 = (int32_t)(pa.y - p0.y), vEnd = (int32_t)(pb.y - p0.y);
+			if (cnt > (uint32_t)MG_VALCAP || j0 + cnt > (uint32_t)d.nres) { if (lane == 0) flag[r] = 1; continue; }
+			int32_t *out = v.row(s) + d.copied;
+			const int32_t extra = v.outd[s] - d.copied, nIv = d.nIv;
+			const IvEntry *iv = arena + (g.minInt > 0 ? v.rowstart[s] / g.minInt : 0);
+			const int32_t *src = R + (v.rowstart[s] + d.copied + d.ivArcs + (int64_t)j0);
+			wave_sync(); // (the wave is done with what the LDS held before)
+			for (uint32_t t = lane; t < cnt; t += 64) s_val[t] = src[t];
+			int32_t iLo = 0, iHi = 0;
+			if (nIv > 0) {
+				iLo = firstRun ? 0 : wave_count_le(iv, nIv, v0);
+				iHi = lastRun ? nIv : (cnt > 0 ? wave_count_le(iv, nIv, vEnd) : iLo);
 			}
-		}
-		int32_t most = hi - lo;
-#pragma unroll
-		for (int o = 32; o > 0; o >>= 1) most = max(most, __shfl_xor(most, o, 64));
-		for (int32_t t = 0; t < most; t++) {
-			IvEntry e{ 0, 0, 0, 0 };
-			if (lo + t < hi) e = iv[lo + t];
-			const bool isLong = e.len > 32;
-			if (!isLong && e.len > 0) expand_interval(SegIv{ e.left, e.pstart, e.rank, e.len }, nres, out, extra);
-			unsigned long long lm = __ballot(isLong);
-			while (lm) {
-				const int src = __ffsll((long long)lm) - 1;
-				lm &= lm - 1;
-				const int32_t L = __shfl(e.left, src, 64), N = __shfl(e.len, src, 64), X = __shfl(extra, src, 64);
-				const int64_t P = shfl_i64((int64_t)e.pstart + (e.rank < 0 ? nres : e.rank), src);
-				int32_t *O = (int32_t *)shfl_i64((int64_t)(uintptr_t)out, src);
-				for (int32_t u = threadIdx.x & 63; u < N; u += 64) if (P + u < (int64_t)X) O[P + u] = (int32_t)((uint32_t)L + (uint32_t)u);
+			int32_t before0 = 0, prevEnd0 = (int32_t)0x80000000;
+			if (iLo > 0) { const IvEntry e = iv[iLo - 1]; before0 = e.pstart + e.len; prevEnd0 = (int32_t)((uint32_t)e.left + (uint32_t)e.len); }
+			wave_sync();
+			bool lbad = false;
+			// intervals: rank among the run's residuals, expansion
+			for (int32_t e0 = iLo; e0 < iHi; e0 += 64) {
+				const int32_t e = e0 + lane;
+				IvEntry en{ 0, 0, 0, 0 };
+				if (e < iHi) {
+					en = iv[e];
+					if (e - iLo < MG_IVCAP) { s_left[e - iLo] = en.left; s_cum[e - iLo] = en.pstart + en.len; s_end[e - iLo] = (int32_t)((uint32_t)en.left + (uint32_t)en.len); }
+					uint32_t lo = 0, hi = cnt; // residuals below en.left
+					while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (s_val[mid] < en.left) lo = mid + 1; else hi = mid; }
+					if (lo < cnt && s_val[lo] == en.left) lbad = true; // a residual on an interval's first id: equal heads are emitted once (MergedIntIterator.java:69-72) -- not here
+					en.rank = (int32_t)(j0 + lo);
+				}
+				const bool isLong = en.len > 32;
+				if (!isLong) { const int64_t P = (int64_t)en.pstart + en.rank; for (int32_t u = 0; u < en.len; u++) if (P + u < (int64_t)extra) out[P + u] = (int32_t)((uint32_t)en.left + (uint32_t)u); }
+				unsigned long long lm = __ballot(isLong);
+				while (lm) { // long intervals: the whole wave, one after the other
+					const int src2 = __ffsll((long long)lm) - 1;
+					lm &= lm - 1;
+					const int32_t L = __shfl(en.left, src2, 64), N = __shfl(en.len, src2, 64);
+					const int64_t P = (int64_t)__shfl(en.pstart, src2, 64) + __shfl(en.rank, src2, 64);
+					for (int32_t u = lane; u < N; u += 64) if (P + u < (int64_t)extra) out[P + u] = (int32_t)((uint32_t)L + (uint32_t)u);
+				}
 			}
+			wave_sync();
+			// residuals: ids of the intervals below each
+			const int32_t nI = iHi - iLo, nStaged = min(nI, MG_IVCAP);
+			for (uint32_t t = lane; t < cnt; t += 64) {
+				const int32_t val = s_val[t];
+				int32_t c; // intervals of [iLo, iHi) with left < val
+				if (nI <= MG_IVCAP) { int32_t lo = 0, hi = nStaged; while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (s_left[mid] < val) lo = mid + 1; else hi = mid; } c = lo; }
+				else { int32_t lo = iLo, hi = iHi; while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (iv[mid].left < val) lo = mid + 1; else hi = mid; } c = lo - iLo; } // (a run that passes hundreds of intervals: straight from the arena)
+				int32_t before = before0, prevEnd = prevEnd0;
+				if (c > 0) {
+					if (c <= MG_IVCAP) { before = s_cum[c - 1]; prevEnd = s_end[c - 1]; }
+					else { const IvEntry e = iv[iLo + c - 1]; before = e.pstart + e.len; prevEnd = (int32_t)((uint32_t)e.left + (uint32_t)e.len); }
+				}
+				if (val < prevEnd) lbad = true; // inside an interval
+				const int64_t P = (int64_t)j0 + t + before;
+				if (P < (int64_t)extra) out[P] = val; else lbad = true;
+			}
+			if (__any(lbad)) { if (lane == 0) flag[r] = 1; }
 		}
 	}
 }
@@ -314,13 +382,13 @@ __global__ void __launch_bounds__(STPB) k_seg_expand(RangeView v, int32_t minInt
 // ------------------------------------------------------------------------------------------------ flagged records
 // -> the list of the cooperative one-wave kernel (k_parse_big<1> with which = CTL_SEG): it decodes them from scratch, whatever the
 // pipeline left in their rows and arena slices
-__global__ void __launch_bounds__(STPB) k_seg_collect(SegRecs recs, int32_t RcapM, int32_t Rtot, const RecDesc *__restrict__ desc, const int32_t *__restrict__ nseg, const int32_t *__restrict__ flag,
-                                                      int32_t *__restrict__ fblist, int32_t *__restrict__ ctl) {
+__global__ void __launch_bounds__(STPB) k_seg_collect(SegRecs recs, int32_t RcapM, int32_t Rtot, int32_t Scap, const RecDesc *__restrict__ desc, const int32_t *__restrict__ nseg, const int32_t *__restrict__ segbase,
+                                                      const int32_t *__restrict__ flag, int32_t *__restrict__ fblist, int32_t *__restrict__ ctl) {
 	const int32_t nrec = min(recs.count(), RcapM);
 	for (int32_t r = blockIdx.x * STPB + threadIdx.x; r < Rtot; r += gridDim.x * STPB) {
 		// the class's own records: every one the struct kernel looked at has a flag; the long records: those whose residuals were handed over
 		const bool mine = r < RcapM ? (r < nrec && !(desc[r].flags & RF_SKIP)) : nseg[r] > 0;
-		if (mine && flag[r]) fblist[atomicAdd(&ctl[CTL_SEG], 1)] = desc[r].slot;
+		if (mine && (flag[r] || segbase[r + 1] > Scap)) fblist[atomicAdd(&ctl[CTL_SEG], 1)] = desc[r].slot; // (pieces beyond the scratch: cannot happen while the sizing holds)
 	}
 }
 
@@ -333,9 +401,10 @@ namespace {
 struct SegPtrs {
 	RecDesc *desc; int32_t *nseg, *segbase, *flag, *sumsR, *fblist, *seg2rec, *fixlist;
 	SegA1 *a1; SegFin *fin; uint8_t *miss; U2 *pair, *pre, *sumsS;
+	int32_t *cells; uint32_t *fixbuf;
 	size_t bytes;
 };
-SegPtrs seg_ptrs(void *scratch, int32_t Rtot, int32_t Scap) {
+SegPtrs seg_ptrs(void *scratch, int32_t Rtot, int32_t Scap, uint32_t cap) {
 	auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
 	char *p = (char *)scratch;
 	auto take = [&](size_t bytes) { char *q = p; p += up(bytes); return (void *)q; };
@@ -355,16 +424,39 @@ SegPtrs seg_ptrs(void *scratch, int32_t Rtot, int32_t Scap) {
 	o.pair = (U2 *)take(sizeof(U2) * ((size_t)Scap + 1));
 	o.pre = (U2 *)take(sizeof(U2) * ((size_t)Scap + 1));
 	o.sumsS = (U2 *)take(sizeof(U2) * nbS);
+	o.cells = nullptr; o.fixbuf = nullptr; (void)cap;
 	o.bytes = (size_t)(p - (char *)scratch);
 	return o;
 }
 }
-size_t seg_scratch_bytes(int32_t Rtot, int32_t Scap) { return seg_ptrs(nullptr, Rtot, Scap).bytes; }
+// the most codes a piece can hold (a zeta_k codeword has at least k bits), rounded up to whole 16-byte stores
+uint32_t seg_cell_cap(int zetaK) { return (uint32_t)((SEG_BITS / (uint32_t)(zetaK < 1 ? 1 : zetaK) + 2 + 3) & ~3u); }
+size_t seg_scratch_bytes(int32_t Rtot, int32_t Scap, int zetaK) { return seg_ptrs(nullptr, Rtot, Scap, seg_cell_cap(zetaK)).bytes; }
+
+// Sizing at load time: how many records have >= 2 048 bits of work (max(bits, 8 successors): the long bins of the parse list) and how many
+// bits they hold -- every piece belongs to one of them.  out[0] += records, out[1] += bits (device memory, zeroed by the caller)
+__global__ void __launch_bounds__(STPB) k_seg_sizing(const int64_t *__restrict__ offsets, int32_t lo, int32_t n, const int32_t *__restrict__ outd, unsigned long long *__restrict__ out) {
+	__shared__ unsigned long long s_acc[2];
+	if (threadIdx.x < 2) s_acc[threadIdx.x] = 0;
+	__syncthreads();
+	unsigned long long recs = 0, bits = 0;
+	for (int32_t s = blockIdx.x * STPB + threadIdx.x; s < n; s += gridDim.x * STPB) {
+		const uint64_t b = (uint64_t)(offsets[lo + s + 1] - offsets[lo + s]);
+		if (outd[s] > 0 && (b >= 2048 || (uint64_t)outd[s] * 8 >= 2048)) { recs++; bits += b; }
+	}
+	for (int o = 32; o > 0; o >>= 1) { recs += __shfl_down(recs, o, 64); bits += __shfl_down(bits, o, 64); }
+	if ((threadIdx.x & 63) == 0) { atomicAdd(&s_acc[0], recs); atomicAdd(&s_acc[1], bits); }
+	__syncthreads();
+	if (threadIdx.x < 2 && s_acc[threadIdx.x]) atomicAdd(&out[threadIdx.x], s_acc[threadIdx.x]);
+}
+void launch_seg_sizing(const int64_t *offsets, int32_t lo, int32_t n, const int32_t *outd, unsigned long long *out2, hipStream_t st) {
+	if (n > 0) hipLaunchKernelGGL(k_seg_sizing, dim3(1024), dim3(STPB), 0, st, offsets, lo, n, outd, out2);
+}
 
 // the hand-over slots of the cooperative kernels (GraphDev::segDesc ...); the counts of their parts are zeroed on `st`
 void seg_handover(GraphDev &g, void *scratch, int32_t RcapM, int32_t capBig, int32_t capGiant, int32_t Scap, hipStream_t st) {
 	const int32_t Rtot = RcapM + capBig + capGiant;
-	const SegPtrs P = seg_ptrs(scratch, Rtot, Scap);
+	const SegPtrs P = seg_ptrs(scratch, Rtot, Scap, seg_cell_cap(g.zetaK));
 	g.segDesc = P.desc; g.segNseg = P.nseg; g.segFlag = P.flag;
 	g.segOff[0] = RcapM; g.segCap[0] = capBig;
 	g.segOff[1] = RcapM + capBig; g.segCap[1] = capGiant;
@@ -375,32 +467,35 @@ void seg_handover(GraphDev &g, void *scratch, int32_t RcapM, int32_t capBig, int
 void launch_seg_struct(const GraphDev &g, int def, const RangeView &v, const int32_t *plist, const int32_t *keyBase, int32_t kLo, int32_t kHi, int32_t RcapM, int32_t Rtot, int32_t Scap,
                        void *scratch, void *arena, int64_t arenaCap, int32_t *ctl, int blocks, int *err, hipStream_t st) {
 	if (v.cnt <= 0 || Rtot <= 0 || def == 0) return;
-	const SegPtrs P = seg_ptrs(scratch, Rtot, Scap);
+	const SegPtrs P = seg_ptrs(scratch, Rtot, Scap, seg_cell_cap(g.zetaK));
 	hipLaunchKernelGGL(k_seg_struct, dim3((unsigned)blocks), dim3(STPB), 0, st, g, v, SegRecs{ plist, keyBase, kLo, kHi }, RcapM, P.desc, P.nseg, P.flag, (IvEntry *)arena, arenaCap, ctl, err);
 }
 
 // everything behind the descriptors (the class's own and the cooperative kernels')
 void launch_seg_chain(const GraphDev &g, int def, const RangeView &v, const int32_t *plist, const int32_t *keyBase, int32_t kLo, int32_t kHi, int32_t RcapM, int32_t Rtot, int32_t Scap,
-                      void *scratch, void *arena, int64_t arenaCap, int32_t *ctl, int blocks, int *err, hipStream_t st) {
+                      void *scratch, void *arena, int64_t arenaCap, int32_t *R, int64_t Rcap, int32_t *ctl, int blocks, int *err, hipStream_t st) {
 	if (v.cnt <= 0 || Rtot <= 0 || def == 0) return;
-	const SegPtrs P = seg_ptrs(scratch, Rtot, Scap);
+	const uint32_t cap = seg_cell_cap(g.zetaK);
+	const SegPtrs P = seg_ptrs(scratch, Rtot, Scap, cap);
 	const SegRecs recs{ plist, keyBase, kLo, kHi };
 	const dim3 grid((unsigned)blocks), blk(STPB);
 	IvEntry *a = (IvEntry *)arena;
 	GraphDev g0 = g; g0.segDesc = nullptr; // (the kernel of the flagged records decodes whole records)
 	sg_scan<int32_t>(P.nseg, Rtot, P.segbase, P.sumsR, st);
 	hipLaunchKernelGGL(k_seg_fill, grid, blk, 0, st, Rtot, P.segbase, Scap, P.seg2rec);
-	if (def == 1) hipLaunchKernelGGL(k_seg_a1<3>, grid, blk, 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.a1, P.flag);
-	else hipLaunchKernelGGL(k_seg_a1<0>, grid, blk, 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.a1, P.flag);
-	if (def == 1) hipLaunchKernelGGL(k_seg_a2<3>, grid, blk, 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.a1, P.fin, P.pair, P.miss, P.fixlist, ctl, P.flag);
-	else hipLaunchKernelGGL(k_seg_a2<0>, grid, blk, 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.a1, P.fin, P.pair, P.miss, P.fixlist, ctl, P.flag);
-	if (def == 1) hipLaunchKernelGGL(k_seg_fix<3>, dim3(64), dim3(64), 0, st, g0, v, P.desc, P.segbase, P.seg2rec, P.a1, P.fin, P.pair, P.miss, P.fixlist, ctl, P.flag);
-	else hipLaunchKernelGGL(k_seg_fix<0>, dim3(64), dim3(64), 0, st, g0, v, P.desc, P.segbase, P.seg2rec, P.a1, P.fin, P.pair, P.miss, P.fixlist, ctl, P.flag);
-	sg_scan<U2>(P.pair, Scap, P.pre, P.sumsS, st);
-	if (def == 1) hipLaunchKernelGGL(k_seg_b<3>, grid, blk, 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.fin, P.pre, a, P.flag);
-	else hipLaunchKernelGGL(k_seg_b<0>, grid, blk, 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.fin, P.pre, a, P.flag);
-	hipLaunchKernelGGL(k_seg_expand, grid, blk, 0, st, v, g.minInt, P.desc, P.segbase, Rtot, Scap, P.seg2rec, a, P.flag);
-	hipLaunchKernelGGL(k_seg_collect, grid, blk, 0, st, recs, RcapM, Rtot, P.desc, P.nseg, P.flag, P.fblist, ctl);
+	int32_t *noCells = nullptr; uint32_t *noFix = nullptr; // (the residuals are decoded a second time, by k_seg_bd: nothing is kept of the chains)
+	if (def == 1) hipLaunchKernelGGL(k_seg_a1<3>, grid, blk, 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.a1, noCells, cap, P.flag);
+	else hipLaunchKernelGGL(k_seg_a1<0>, grid, blk, 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.a1, noCells, cap, P.flag);
+	if (def == 1) hipLaunchKernelGGL(k_seg_a2<3>, grid, blk, 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.a1, noCells, cap, noFix, P.fin, P.pair, P.miss, P.fixlist, ctl);
+	else hipLaunchKernelGGL(k_seg_a2<0>, grid, blk, 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.a1, noCells, cap, noFix, P.fin, P.pair, P.miss, P.fixlist, ctl);
+	if (def == 1) hipLaunchKernelGGL(k_seg_fix<3>, dim3(64), dim3(64), 0, st, g0, v, P.desc, P.segbase, P.seg2rec, P.a1, noCells, cap, noFix, P.fin, P.pair, P.miss, P.fixlist, ctl, P.flag);
+	else hipLaunchKernelGGL(k_seg_fix<0>, dim3(64), dim3(64), 0, st, g0, v, P.desc, P.segbase, P.seg2rec, P.a1, noCells, cap, noFix, P.fin, P.pair, P.miss, P.fixlist, ctl, P.flag);
+	sg_scan<U2>(P.pair, Scap, P.pre, P.sumsS, st, P.segbase + Rtot);
+	if (def == 1) hipLaunchKernelGGL(k_seg_bd<3>, grid, blk, 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.fin, P.pre, R, Rcap, P.flag);
+	else hipLaunchKernelGGL(k_seg_bd<0>, grid, blk, 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.fin, P.pre, R, Rcap, P.flag);
+	const int32_t G = (int32_t)std::max<uint32_t>(1u, std::min<uint32_t>(8u, (uint32_t)MG_VALCAP / cap)); // pieces per wave of the merge: what fits its LDS
+	hipLaunchKernelGGL(k_seg_merge, dim3((unsigned)(2 * blocks)), dim3(64 * MG_WAVES), 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.pre, R, G, a, P.flag);
+	hipLaunchKernelGGL(k_seg_collect, grid, blk, 0, st, recs, RcapM, Rtot, Scap, P.desc, P.nseg, P.segbase, P.flag, P.fblist, ctl);
 	launch_parse_listed(g0, def, v, P.fblist, ctl, CTL_SEG, arena, arenaCap, 256, err, st);
 }
 

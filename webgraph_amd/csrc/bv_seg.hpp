@@ -21,10 +21,11 @@
 //            as long as chains keep missing each other.  Best effort: what proves the starts right is B, which checks that the
 //            codes it decodes end exactly where the next piece is said to start
 //   scan     counts and sums -> index of the segment's first residual in its record, value of the residual before it
-//   B        one lane per segment: decodes its codes again, adds up the gaps (BVG:954, :966) and stores every residual at its final
-//            place among the record's extras, walking the record's interval list alongside (a small ring in LDS) to count the interval
-//            ids that precede it -- which also tells every interval its rank                      (MergedIntIterator.java:50-74)
-//   expand   one lane per interval: left .. left + len - 1 at pstart + rank                (IntIntervalSequenceIterator.java:64-78)
+//   B        one WAVE per segment, one lane per residual and per interval: no codeword is decoded a second time -- A1 left the running
+//            sums of its chain in a scratch cell per piece, A2 the few sums of the true chain before the meeting point; a residual is
+//            base + running sum (BVG:954, :966).  Residuals and the intervals they pass are ranked against each other by binary
+//            searches in LDS: residual j goes to out[j + #(interval ids below it)], interval i to out[pstart + #(residuals below it)]
+//            (MergedIntIterator.java:50-74, IntIntervalSequenceIterator.java:64-78); neighbouring lanes write neighbouring ids
 //
 // Same contract as the other parse kernels: the extras (intervals merged with residuals) of node x end up in row[copied..d); the
 // copy pass fills in the rest.  Default codings only (gamma / unary / zeta_k).  Anything unusual -- a codeword longer than 64 bits, a
@@ -57,7 +58,6 @@ namespace bvsg {
 constexpr int SEG_BITS_LOG2 = SEG_BITS_LOG2_;
 constexpr uint32_t SEG_BITS = 1u << SEG_BITS_LOG2; // a piece of stream: [c * SEG_BITS, (c + 1) * SEG_BITS), "cell" c of the grid; a multiple of 128 bits (16-byte loads)
 constexpr int WIN_WORDS = 16;                      // a lane's window of the stream in LDS
-constexpr int RING = 8;                            // intervals a lane of B keeps at hand (2 words each)
 constexpr int FIX_MAX = 64;                        // pieces one lane of the fix kernel follows a run of missed meetings for
 
 struct SegGraph { // what the bodies need of bv::GraphDev
@@ -71,7 +71,12 @@ struct RecDesc { int64_t rpos; int32_t slot, nres, copied, nIv, flags, ivArcs; }
 enum { RF_FALLBACK = 1, RF_SKIP = 2 }; // flagged: the cooperative kernel decodes it; not this pipeline's record at all
 // positions inside a piece are relative to the start of its cell (c << SEG_BITS_LOG2): they fit 32 bits
 struct SegA1 { uint32_t outRel, cnt, sum, badIdx; };  // A1: where the chain that started at the piece's nominal start leaves it; its codes; their sum; index of its first "codeword" of more than 64 bits (~0: none)
-struct SegFin { uint32_t inRel, cnt, sum, tRel; };    // A2 / fix: the piece's true start; true count and sum; tRel: 0, or where the true chain ends when the chains did not meet, or ~0: a codeword this decoder does not take
+// A2 / fix: the piece's true start; true count and sum; where the true chain ends (mode 1 only).  Residual t of the piece is
+// base + (t < cb ? fix[t] : cell[t - cb + ca] + delta): cb sums of the true chain before it joins A1's chain at that chain's code ca.
+// mode 0: as said; 1: the chains did not meet within FIX_CODES codes -- the lane decoded the whole piece again and the cell holds the
+// true chain (ca = cb = delta = 0); 2: a codeword this decoder does not take.  Bit 2 (SEG_REWRITTEN): the cell no longer holds A1's chain
+struct SegFin { uint32_t inRel, cnt, sum, tRel, ca, cb, delta, mode; };
+constexpr uint32_t FIX_CODES = 32, SEG_REWRITTEN = 4;
 
 #if defined(__HIPCC__)
 #define SG_ASSERT(c) ((void)0)
@@ -291,23 +296,22 @@ SG_D void seg_span(const RecDesc &r, uint64_t recEnd, int32_t i, uint64_t &cell,
 }
 
 // ------------------------------------------------------------------------------------------------ A1
-// The codes that start in [startRel, endRel) of the cell, from startRel: where the chain leaves the piece, how many codes, the sum of
-// their contributions (gap + 1 each; the first code of a record is the zig-zag value relative to x, BVG:954).  Sums are Java ints:
-// they wrap.  A chain that starts off a codeword boundary reads garbage until it locks on, and garbage can look like a codeword of
-// more than 64 bits: such a "codeword" is stepped over as one bit and its index reported -- A2 knows whether it lay before the point
-// where the true chain joins this one (harmless) or behind it (the record is flagged).
+// A run of residual codes from cursor q up to qend (cursors relative to the window), the running sum of their contributions (gap + 1
+// each; the first code of a record is the zig-zag value relative to x, BVG:954) written to cell[0 ..) after every code, 16 bytes at a
+// time.  Sums are Java ints: they wrap.  A chain that starts off a codeword boundary reads garbage until it locks on, and garbage can
+// look like a codeword of more than 64 bits: such a "codeword" is stepped over as one bit and its index reported -- A2 knows whether
+// it lay before the point where the true chain joins this one (harmless) or behind it (the record is flagged).
 template <int ZK, int STRIDE>
-SG_D void seg_a1(const SegGraph &g, uint32_t *col, int32_t x, uint64_t cell, uint32_t startRel, uint32_t endRel, bool firstOfRecord, SegA1 &o) {
-	Win<STRIDE> w;
-	w.init(g, col, cell + endRel);
-	uint32_t q = w.seek(cell + startRel);
-	uint32_t qend = q + (endRel - startRel);
-	uint32_t cnt = 0, sum = 0, badIdx = ~0u;
+SG_D void decode_run(const SegGraph &g, Win<STRIDE> &w, uint32_t &q, uint32_t qend, bool firstOfRecord, int32_t x, int32_t *cell, uint32_t cap, uint32_t &cntOut, uint32_t &sumOut, uint32_t &badIdx) {
+	uint32_t cnt = 0, sum = 0;
+	uint32_t o1 = 0, o2 = 0, o3 = 0;
+	badIdx = ~0u;
 	if (firstOfRecord && q < qend) {
 		bool bad = false;
 		const uint32_t v = w.template zeta<ZK>(q, (uint32_t)g.zetaK, bad);
 		if (bad) badIdx = 0;
 		sum = (uint32_t)x + (uint32_t)zigzag32(v);
+		o3 = sum;
 		cnt = 1;
 	}
 	while (q < qend) {
@@ -316,122 +320,111 @@ SG_D void seg_a1(const SegGraph &g, uint32_t *col, int32_t x, uint64_t cell, uin
 		const uint32_t v = w.template zeta<ZK>(q, (uint32_t)g.zetaK, bad);
 		if (SG_UNLIKELY(bad)) badIdx = umin32(badIdx, cnt);
 		sum += v + 1u;
+		const uint32_t o0 = o1; o1 = o2; o2 = o3; o3 = sum;
 		cnt++;
+		if (cell && (cnt & 3u) == 0 && cnt <= cap) { // (cell is 16-byte aligned)
+#if defined(__HIP_DEVICE_COMPILE__)
+			*(int4 *)(cell + cnt - 4) = int4{ (int32_t)o0, (int32_t)o1, (int32_t)o2, (int32_t)o3 };
+#else
+			cell[cnt - 4] = (int32_t)o0; cell[cnt - 3] = (int32_t)o1; cell[cnt - 2] = (int32_t)o2; cell[cnt - 1] = (int32_t)o3;
+#endif
+		}
 	}
-	o.outRel = (uint32_t)(w.pos(q) - cell);
-	o.cnt = cnt; o.sum = sum; o.badIdx = badIdx;
+	if (!cell) { if (cnt > cap) badIdx = 0; }
+	else if (cnt <= cap) {
+		const uint32_t m = cnt & 3u;
+		if (m >= 3) cell[cnt - 3] = (int32_t)o1;
+		if (m >= 2) cell[cnt - 2] = (int32_t)o2;
+		if (m >= 1) cell[cnt - 1] = (int32_t)o3;
+	} else badIdx = 0; // (more codes than the shortest codeword allows: cannot happen)
+	cntOut = cnt; sumOut = sum;
+}
+
+// The codes that start in [startRel, endRel) of the cell, from startRel.
+template <int ZK, int STRIDE>
+SG_D void seg_a1(const SegGraph &g, uint32_t *col, int32_t x, uint64_t cellBit, uint32_t startRel, uint32_t endRel, bool firstOfRecord, int32_t *cell, uint32_t cap, SegA1 &o) {
+	Win<STRIDE> w;
+	w.init(g, col, cellBit + endRel);
+	uint32_t q = w.seek(cellBit + startRel);
+	const uint32_t qend = q + (endRel - startRel);
+	decode_run<ZK, STRIDE>(g, w, q, qend, firstOfRecord, x, cell, cap, o.cnt, o.sum, o.badIdx);
+	o.outRel = (uint32_t)(w.pos(q) - cellBit);
 }
 
 // ------------------------------------------------------------------------------------------------ A2
 // A piece that does not start its record: A1 started at the cell's first bit; the true chain enters the piece at inRel (the end of the
-// piece before, minus SEG_BITS).  Walks both chains in lock step until they meet, correcting A1's (cnt, sum).
-// 0: they met inside the piece -- the end A1 found is a true boundary; 1: they did not: the true chain was followed to the end of the
-// piece, (cnt, sum) are its own and tRel is where it ends (the true start of the next piece, plus SEG_BITS); 2: the true chain holds a
-// codeword this decoder does not take (the record is flagged).
+// piece before, minus SEG_BITS).  Walks both chains in lock step (always the one that is behind) until they meet, keeping the running
+// sums of the true chain's codes in fix[]; see SegFin for what it leaves.
 template <int ZK, int STRIDE>
-SG_D int seg_a2(const SegGraph &g, uint32_t *col, uint64_t cell, uint32_t inRel, uint32_t endRel, const SegA1 &a1, uint32_t &cnt, uint32_t &sum, uint32_t &tRel) {
-	cnt = a1.cnt; sum = a1.sum; tRel = 0;
-	if (inRel == 0) return a1.badIdx == ~0u ? 0 : 2;
-	if (inRel > 128) return 2; // (a codeword of the piece before cannot reach that far)
+SG_D void seg_a2(const SegGraph &g, uint32_t *col, uint64_t cellBit, uint32_t inRel, uint32_t endRel, const SegA1 &a1, int32_t *cell, uint32_t cap, uint32_t *fix, bool cellRewritten, SegFin &o) {
+	// cellRewritten (the fix pass, a piece it or A2 visited before): the cell no longer holds A1's chain -- the whole piece again, whatever the chains do
+	o = SegFin{ inRel, a1.cnt, a1.sum, 0, 0, 0, 0, cellRewritten ? SEG_REWRITTEN : 0u };
+	if (inRel == 0 && !cellRewritten) { if (a1.badIdx != ~0u) o.mode = 2; return; }
+	if (inRel > 128) { o.mode |= 2; return; } // (a codeword of the piece before cannot reach that far)
 	Win<STRIDE> w;
-	w.init(g, col, cell + endRel);
-	uint32_t qa = w.seek(cell);   // the false chain (cell is a multiple of 128 bits: qa = 0)
-	uint32_t qb = qa + inRel;     // the true chain
+	w.init(g, col, cellBit + endRel);
+	uint32_t qa = w.seek(cellBit);  // the false chain (a cell starts on a multiple of 128 bits: qa = 0)
+	uint32_t qb = qa + inRel;       // the true chain
 	uint32_t qend = qa + endRel;
 	uint32_t ca = 0, cb = 0, sa = 0, sb = 0;
-	bool met = true, badB = false;
-	while (qa != qb) {
+	bool met = !cellRewritten, badB = false;
+	while (qa != qb && !cellRewritten) {
 		const bool aBehind = qa < qb;
-		uint32_t &q = aBehind ? qa : qb;
-		if (q >= qend) { met = false; break; } // the chain that is behind has left the piece (and so has the other): no meeting point
-		if (SG_ANY((aBehind ? qb : qa) > Q_OK)) { const uint32_t dn = w.slide(q); qa -= dn; qb -= dn; qend -= dn; }
+		uint32_t q = aBehind ? qa : qb;
+		if (q >= qend || (!aBehind && cb == FIX_CODES)) { met = false; break; } // the chain that is behind has left the piece (and so has the other) -- or this takes too long
+		if (SG_ANY((aBehind ? qb : qa) > Q_OK)) { const uint32_t dn = w.slide(q); q -= dn; qa -= dn; qb -= dn; qend -= dn; }
 		bool bad = false;
-		const uint32_t v = w.template zeta<ZK>(q, (uint32_t)g.zetaK, bad);
-		if (aBehind) { ca++; sa += v + 1u; } else { cb++; sb += v + 1u; badB |= bad; }
+		const uint32_t inc = w.template zeta<ZK>(q, (uint32_t)g.zetaK, bad) + 1u;
+		if (aBehind) { qa = q; ca++; sa += inc; }
+		else { qb = q; sb += inc; if (fix) fix[cb] = sb; cb++; badB |= bad; }
 	}
-	if (badB) return 2;
-	if (!met) { cnt = cb; sum = sb; tRel = (uint32_t)(w.pos(qb) - cell); return 1; } // both chains are past the end: the true one has been followed all the way
-	if (a1.badIdx != ~0u && a1.badIdx >= ca) return 2; // the codeword A1 could not take lies on the true chain
-	cnt = a1.cnt - ca + cb;
-	sum = a1.sum - sa + sb;
-	return 0;
+	if (badB) { o.mode |= 2; return; }
+	if (met) {
+		if (a1.badIdx != ~0u && a1.badIdx >= ca) { o.mode = 2; return; } // the codeword A1 could not take lies on the true chain
+		o.cnt = a1.cnt - ca + cb; o.sum = a1.sum - sa + sb;
+		o.ca = ca; o.cb = cb; o.delta = sb - sa;
+		return;
+	}
+	// no meeting point in sight: the whole piece again, from its true start, into the cell
+	uint32_t q = w.seek(cellBit + inRel), badIdx;
+	qend = q + (endRel > inRel ? endRel - inRel : 0u);
+	decode_run<ZK, STRIDE>(g, w, q, qend, false, 0, cell, cap, o.cnt, o.sum, badIdx);
+	o.tRel = (uint32_t)(w.pos(q) - cellBit);
+	o.mode = (badIdx != ~0u ? 2u : 1u) | SEG_REWRITTEN;
 }
 
-// ------------------------------------------------------------------------------------------------ B
-// Decodes the cnt codes of a piece from its true start and stores every residual at its place among the record's extras: residual j
-// (value r) goes to out[j + #(interval ids below r)].  v0 = the residual before the piece's first one, j0 = its index + 1.
-// Intervals that the piece's residuals pass learn their rank (= residuals before them).  endRel: where the last code ended (the
-// caller checks it against the start of the next piece).  false: the record must be flagged.
+// ------------------------------------------------------------------------------------------------ B (dense)
+// Decodes the cnt codes of a piece from its true start and writes the residuals themselves -- v0 + the running sum (BVG:954, :966) --
+// to dst[0 .. cnt), the piece's stretch of the record's residuals in scratch, 16 bytes at a time where the alignment allows.
+// endRel: where the last code ended (the caller checks it against the start of the next piece).  false: a codeword this decoder does
+// not take.
 template <int ZK, int STRIDE>
-SG_D bool seg_b(const SegGraph &g, uint32_t *col, uint32_t *ring, int32_t x, uint64_t cell, uint32_t inRel, uint32_t cnt, uint32_t j0, int32_t v0, bool firstOfRecord,
-                int32_t *out, int32_t extra, SegIv *iv, int32_t nIv, uint32_t &endRel) {
-#if defined(SG_DBG_NOIV)
-	nIv = 0;
-#endif
+SG_D bool seg_b_dense(const SegGraph &g, uint32_t *col, int32_t x, uint64_t cellBit, uint32_t inRel, uint32_t cnt, int32_t v0, bool firstOfRecord, int32_t *dst, uint32_t &endRel) {
 	Win<STRIDE> w;
-	w.init(g, col, cell + SEG_BITS);
-	uint32_t q = w.seek(cell + inRel);
+	w.init(g, col, cellBit + SEG_BITS);
+	uint32_t q = w.seek(cellBit + inRel);
 	bool bad = false;
-	// intervals [0, idx) lie below v0 (passed by the pieces before): a binary search in the record's arena slice
-	int32_t idx = 0;
-	if (!firstOfRecord && nIv > 0) {
-		int32_t lo = 0, hi = nIv;
-		while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (iv[mid].left <= v0) lo = mid + 1; else hi = mid; }
-		idx = lo;
-	}
-	// between the end of the last interval passed and the start of the next one a residual simply goes to out[j + before]
-	int32_t before = 0, prevEnd = (int32_t)0x80000000, nl = 0x7fffffff, ncum = 0; // ids of the intervals passed; [prevEnd, nl): the free stretch; ids up to the end of the next interval
-	if (idx > 0) { const SegIv e = iv[idx - 1]; before = e.pstart + e.len; prevEnd = (int32_t)((uint32_t)e.left + (uint32_t)e.len); }
-	// ring entry k & (RING - 1) holds interval k: (left, pstart + len); intervals [idx, loaded) are in the ring
-	int32_t loaded = idx;
-	uint32_t j = j0;
-	int32_t val = v0;
+	const uint32_t head = umin32(cnt, ((16u - ((uint32_t)(uintptr_t)dst & 15u)) & 15u) >> 2); // scalar stores up to the first 16-byte boundary
+	uint32_t val = (uint32_t)v0, o1 = 0, o2 = 0, o3 = 0, on = 0;
 	for (uint32_t t = 0; t < cnt; t++) {
 		if (SG_ANY(q > Q_OK)) q -= w.slide(q);
-		if (SG_ANY(loaded < nIv && loaded - idx <= 2)) { // some lane's ring runs low: every lane tops its own up (the wave waits once)
-			const int32_t free_ = RING - (loaded - idx), room = free_ < RING / 2 ? free_ : RING / 2, n = nIv - loaded < room ? nIv - loaded : room; // (this lane may not need it: only what fits; at most half a ring at a time: registers)
-#if defined(__HIP_DEVICE_COMPILE__)
-			int4 e[RING / 2];
-#pragma unroll
-			for (int k = 0; k < RING / 2; k++) if (k < n) e[k] = *(const int4 *)(iv + loaded + k);
-#pragma unroll
-			for (int k = 0; k < RING / 2; k++) if (k < n) { const uint32_t s = (uint32_t)(loaded + k) & (RING - 1); ring[(2 * s) * STRIDE] = (uint32_t)e[k].x; ring[(2 * s + 1) * STRIDE] = (uint32_t)(e[k].y + e[k].w); }
-#else
-			for (int k = 0; k < n; k++) { const SegIv e = iv[loaded + k]; const uint32_t s = (uint32_t)(loaded + k) & (RING - 1); ring[(2 * s) * STRIDE] = (uint32_t)e.left; ring[(2 * s + 1) * STRIDE] = (uint32_t)(e.pstart + e.len); }
-#endif
-			if (n > 0) {
-				if (loaded == idx) { const uint32_t s = (uint32_t)idx & (RING - 1); nl = (int32_t)ring[(2 * s) * STRIDE]; ncum = (int32_t)ring[(2 * s + 1) * STRIDE]; }
-				loaded += n;
-			}
-		}
 		const uint32_t v = w.template zeta<ZK>(q, (uint32_t)g.zetaK, bad);
-		val = (firstOfRecord && t == 0) ? (int32_t)((uint32_t)x + (uint32_t)zigzag32(v)) : (int32_t)((uint32_t)val + v + 1u); // BVG:954, :966
-		if (SG_UNLIKELY((uint32_t)(val - prevEnd) >= (uint32_t)(nl - prevEnd))) { // not in the free stretch: the residual passes intervals -- or sits inside one
-			if (val < prevEnd) bad = true; // inside an interval: equal heads are emitted once (MergedIntIterator.java:69-72) -- not here
-			while (idx < nIv && nl < val) { // the residual passes interval idx: j residuals precede it
-#if !defined(SG_DBG_NORANK)
-				iv[idx].rank = (int32_t)j;
-#endif
-				prevEnd = (int32_t)((uint32_t)nl + (uint32_t)(ncum - before));
-				before = ncum;
-				idx++;
-				if (idx < nIv) {
-					if (idx < loaded) { const uint32_t s = (uint32_t)idx & (RING - 1); nl = (int32_t)ring[(2 * s) * STRIDE]; ncum = (int32_t)ring[(2 * s + 1) * STRIDE]; }
-					else { const SegIv e = iv[idx]; nl = e.left; ncum = e.pstart + e.len; loaded = idx; } // (more than RING intervals between two residuals: straight from the arena)
-					if (nl < prevEnd) bad = true;
-				} else nl = 0x7fffffff;
-			}
-			if ((idx < nIv && nl == val) || val < prevEnd) bad = true;
-		}
-		const int64_t p = (int64_t)j + before;
-#if defined(SG_DBG_NOSTORE)
-		if (p >= (int64_t)extra) bad = true;
+		val = (firstOfRecord && t == 0) ? (uint32_t)x + (uint32_t)zigzag32(v) : val + v + 1u;
+		if (t < head) { dst[t] = (int32_t)val; continue; }
+		const uint32_t o0 = o1; o1 = o2; o2 = o3; o3 = val;
+		if (++on == 4) {
+#if defined(__HIP_DEVICE_COMPILE__)
+			*(int4 *)(dst + t - 3) = int4{ (int32_t)o0, (int32_t)o1, (int32_t)o2, (int32_t)o3 };
 #else
-		if (p < (int64_t)extra) out[p] = val; else bad = true;
+			dst[t - 3] = (int32_t)o0; dst[t - 2] = (int32_t)o1; dst[t - 1] = (int32_t)o2; dst[t] = (int32_t)o3;
 #endif
-		j++;
+			on = 0;
+		}
 	}
-	endRel = (uint32_t)(w.pos(q) - cell);
+	if (on >= 3) dst[cnt - 3] = (int32_t)o1;
+	if (on >= 2) dst[cnt - 2] = (int32_t)o2;
+	if (on >= 1) dst[cnt - 1] = (int32_t)o3;
+	endRel = (uint32_t)(w.pos(q) - cellBit);
 	return !bad;
 }
 

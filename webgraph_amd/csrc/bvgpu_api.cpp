@@ -67,6 +67,7 @@ struct Staged {
 	int32_t node_lo = 0, node_hi = 0, stage_lo = 0; // the nodes this handle decodes / the first node staged
 	std::vector<int64_t> h_offsets; // host copy: shard bounds and halo sizing
 	int64_t arcs_sizing = 0;        // max(arcs property, sum of the outdegrees in the stream): what scratch is sized by
+	int64_t seg_long_records = -1, seg_long_bits = -1; // staged records with >= 2 048 bits of work (the parse list's long bins) and their bits (counted with arcs_sizing; -1: unknown): they size the segment pipeline
 	int32_t deg_counts[5] = { -1, -1, -1, -1, -1 }; // staged records with >= 128, 256, 512, 1024, 2048 successors (counted with arcs_sizing; -1: unknown)
 	int def = 0;                    // kernel variant: 1 default codings with zeta_3, 2 default codings with another zeta_k, 0 generic
 	std::string basename;
@@ -124,7 +125,7 @@ struct bvg_graph {
 	int level_blocks = 4096; // blocks of the list kernels (k_parse_list, k_copy_list): 2048..4096 are within 1 % on C2, 4096 is 3 % faster on cnr-2000 x30
 	DevBuf lvlist;
 	DevBuf plist, pkeys, pkey16;
-	DevBuf segbuf;       // scratch of the segment pipeline (bv_seg.hip)
+	DevBuf segbuf, segR; // scratch of the segment pipeline (bv_seg.hip); the residuals of its records, contiguous per record, before they are merged with the intervals
 	int seg = 1;         // BVGPU_SEG=0: never; 1: jobs of >= 4 M arcs; 2: always -- records of the long work bins below the wave class go through the segment pipeline instead of k_parse_list
 	int seg_blocks = 2048;
 	int seg_handover = 1; // BVGPU_SEG_HANDOVER=0: the cooperative kernels decode the residuals of their records themselves
@@ -467,7 +468,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		// The segment pipeline (bv_seg.hip): the residual sections of the records of the long work bins (>= 2 048 bits of work), cut into pieces of stream, one lane
 		// per piece.  The class's own records (below the wave class) have their structure parsed by one lane each (k_seg_struct); the cooperative kernels parse the
 		// structure of theirs and hand the residuals over (GraphDev::segDesc); k_parse_list keeps the short bins.
-		const bool segOn = g->seg && !tiles && s.def != 0 && g->iv_arena && coop && (g->seg > 1 || estArcs >= 4000000);
+		const bool segOn = g->seg && !tiles && s.def != 0 && g->iv_arena && coop && s.seg_long_records >= 0 && (g->seg > 1 || estArcs >= 4000000);
 		const int32_t segKLo = g->parse_windows ? (bv::MAXLVL - 1) * bv::NBIN + bv::PARSE_LONG_BIN : bv::PARSE_LONG_BIN, segKHi = g->parse_windows ? bv::NKEYS : bv::NBIN;
 		int32_t segRcapM = 0, segRtot = 0, segScap = 0;
 		bool segReady = false;
@@ -476,8 +477,9 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			segRcapM = (int32_t)std::min<int64_t>(v.cnt, (bits + 8 * arcsBound) / 2048 + 16); // records with >= 2 048 bits of work (max(bits, 8 successors)): every record with pieces is one
 			const int32_t capBig = g->seg_handover ? (int32_t)std::min<int64_t>(v.cnt, arcsBound / 128 + 2) : 0, capGiant = g->seg_handover ? giantCap : 0;
 			segRtot = segRcapM + capBig + capGiant;
-			segScap = (int32_t)std::min<int64_t>((bits >> bv::seg_bits_log2()) + 2 * (int64_t)segRcapM + 2, 0x7ffffff0);
-			if (g->segbuf.need(bv::seg_scratch_bytes(segRtot, segScap))) {
+			// every record with pieces is one of the staged records of the long bins, and has at most bits / piece + 2 of them
+			segScap = (int32_t)std::min<int64_t>(std::min<int64_t>(bits, s.seg_long_bits) / ((int64_t)1 << bv::seg_bits_log2()) + 2 * std::min<int64_t>(segRcapM, s.seg_long_records) + 2, 0x7ffffff0);
+			if (g->segbuf.need(bv::seg_scratch_bytes(segRtot, segScap, s.info.zeta_k)) && g->segR.need(sizeof(int32_t) * (size_t)std::max<int64_t>(arcsBound, 1 << 22))) {
 				segReady = true;
 				if (g->seg_handover) bv::seg_handover(gd, g->segbuf.p, segRcapM, capBig, capGiant, segScap, g->stream); // (before the fork: the cooperative kernels start behind it)
 			}
@@ -549,7 +551,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 					HIPCHK(g, hipStreamWaitEvent(stChain, g->evM, 0));
 					HIPCHK(g, hipStreamWaitEvent(stChain, g->evW, 0));
 				}
-				bv::launch_seg_chain(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, segKLo, segKHi, segRcapM, segRtot, segScap, g->segbuf.p, g->arena.p, arenaCap, ctl, g->seg_blocks, derr, stChain);
+				bv::launch_seg_chain(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, segKLo, segKHi, segRcapM, segRtot, segScap, g->segbuf.p, g->arena.p, arenaCap, g->segR.as<int32_t>(), std::max<int64_t>(arcsBound, 1 << 22), ctl, g->seg_blocks, derr, stChain);
 				if (ovl) HIPCHK(g, hipEventRecord(g->evB, stChain));
 				keyHi = segKLo;
 			}
@@ -958,6 +960,12 @@ static int open_impl(const char *basename, int device, int part, int parts, bvg_
 			bv::launch_pick_coop((const int32_t *)p_part, (int32_t)hb, 0, nullptr, nullptr, (int32_t *)p_part + 5 * hb); // how long the records are: the lane class is decoded from tiles when few are long (enqueue_decode)
 			e = hipMemcpy(&total, (int64_t *)p_rs + n, sizeof(int64_t), hipMemcpyDeviceToHost);
 			if (e == hipSuccess) e = hipMemcpy(st->deg_counts, (int32_t *)p_part + 5 * hb, sizeof(st->deg_counts), hipMemcpyDeviceToHost);
+			if (e == hipSuccess && st->def != 0) { // (p_rs is done with: two counters)
+				unsigned long long two[2] = { 0, 0 };
+				e = hipMemset(p_rs, 0, sizeof(two));
+				if (e == hipSuccess) { bv::launch_seg_sizing(st->d_offsets, st->stage_lo, n, (const int32_t *)p_outd, (unsigned long long *)p_rs, nullptr); e = hipMemcpy(two, p_rs, sizeof(two), hipMemcpyDeviceToHost); }
+				if (e == hipSuccess) { st->seg_long_records = (int64_t)two[0]; st->seg_long_bits = (int64_t)two[1]; }
+			}
 		}
 		for (void *q : { p_outd, p_ref, p_rs, p_sums, p_err, p_part }) if (q) (void)hipFree(q);
 		if (e != hipSuccess) return fail(g, e == hipErrorOutOfMemory ? BVG_ENOMEM : BVG_EHIP, "cannot scan the record headers");
