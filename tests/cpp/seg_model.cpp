@@ -52,17 +52,17 @@ int seg_model_run(const uint8_t *graph, uint64_t nbytes, const int64_t *offsets,
 	std::vector<SegA1> a1((size_t)S + 1);
 	std::vector<SegFin> fin((size_t)S + 1);
 	std::vector<uint32_t> pc((size_t)S + 1), ps((size_t)S + 1);
-	std::vector<int32_t> seg2rec((size_t)S + 1), fixlist;
+	std::vector<int32_t> seg2rec((size_t)S + 1), fixlist, pendlist;
 	std::vector<uint8_t> flag(R, 0), miss((size_t)S + 1, 0);
 	auto span = [&](int32_t sg, uint64_t &cell, uint32_t &a, uint32_t &b) {
 		const int32_t r = seg2rec[sg];
 		seg_span(desc[r], (uint64_t)offsets[lo + desc[r].slot + 1], sg - segbase[r], cell, a, b);
 	};
-	auto a2 = [&](int32_t sg, uint32_t inRel, bool rewritten, SegFin &o) {
+	auto a2 = [&](int32_t sg, uint32_t inRel, bool follow, SegFin &o) {
 		uint64_t cell; uint32_t a, b;
 		span(sg, cell, a, b);
-		if (zk == 3) seg_a2<3, 1>(g, col, cell, inRel, b, a1[sg], (int32_t *)nullptr, cap, (uint32_t *)nullptr, false, o);
-		else seg_a2<0, 1>(g, col, cell, inRel, b, a1[sg], (int32_t *)nullptr, cap, (uint32_t *)nullptr, false, o);
+		if (zk == 3) seg_a2<3, 1>(g, col, cell, inRel, b, a1[sg], (int32_t *)nullptr, cap, (uint32_t *)nullptr, false, follow, o);
+		else seg_a2<0, 1>(g, col, cell, inRel, b, a1[sg], (int32_t *)nullptr, cap, (uint32_t *)nullptr, false, follow, o);
 	};
 	// A1
 	for (size_t r = 0; r < R; r++) {
@@ -84,11 +84,26 @@ int seg_model_run(const uint8_t *graph, uint64_t nbytes, const int64_t *offsets,
 		span(sg, cell, a, b);
 		SegFin o{ a, a1[sg].cnt, a1[sg].sum, 0, 0, 0, 0, a1[sg].badIdx != ~0u ? 2u : 0u };
 		if (i > 0) a2(sg, a1[sg - 1].outRel - SEG_BITS, false, o);
-		if ((o.mode & 3) == 1) stats[2]++;
-		const bool m = (o.mode & 3) == 1 && sg + 1 != segbase[r + 1] && o.tRel != a1[sg].outRel;
-		miss[sg] = m;
-		if (m) fixlist.push_back(sg);
+		if ((o.mode & 3) == 3) pendlist.push_back(sg);
 		fin[sg] = o;
+	}
+	// fix, phase 1: the true chain of the pieces A2 left open, followed to the end of the piece
+	for (int32_t k : pendlist) {
+		const int32_t r = seg2rec[k];
+		uint64_t cell; uint32_t a, b;
+		span(k, cell, a, b);
+		SegFin o = fin[k];
+		Win<1> w;
+		w.init(g, col, cell + b);
+		uint32_t q = w.seek(cell + o.inRel), badIdx;
+		const uint32_t qend = q + (b > o.inRel ? b - o.inRel : 0u);
+		if (zk == 3) decode_run<3, 1>(g, w, q, qend, false, 0, nullptr, ~0u, o.cnt, o.sum, badIdx);
+		else decode_run<0, 1>(g, w, q, qend, false, 0, nullptr, ~0u, o.cnt, o.sum, badIdx);
+		o.tRel = (uint32_t)(w.pos(q) - cell);
+		o.mode = badIdx != ~0u ? 2u : 1u;
+		fin[k] = o;
+		stats[2]++;
+		if (o.mode == 1 && k + 1 != segbase[r + 1] && o.tRel != a1[k].outRel) { miss[k] = 1; fixlist.push_back(k); }
 	}
 	// fix
 	for (int32_t k0 : fixlist) {
@@ -98,7 +113,7 @@ int seg_model_run(const uint8_t *graph, uint64_t nbytes, const int64_t *offsets,
 		for (int32_t k = k0 + 1, steps = 0; k < kEnd; k++, steps++) {
 			if (steps >= FIX_MAX) { flag[r] = 1; break; }
 			SegFin o;
-			a2(k, inRel, (fin[k].mode & SEG_REWRITTEN) != 0, o);
+			a2(k, inRel, true, o);
 			stats[4]++;
 			fin[k] = o;
 			if ((o.mode & 3) == 2) break;
@@ -110,49 +125,33 @@ int seg_model_run(const uint8_t *graph, uint64_t nbytes, const int64_t *offsets,
 	// scan
 	pc[0] = ps[0] = 0;
 	for (int32_t sg = 0; sg < S; sg++) { pc[sg + 1] = pc[sg] + fin[sg].cnt; ps[sg + 1] = ps[sg] + fin[sg].sum; }
-	// B: every piece's residuals, decoded from its true start, into the record's stretch of R; the chain of starts and ends is checked here
-	std::vector<int32_t> Rv((size_t)arcs + 8, -9);
+	// B
+	std::vector<uint32_t> ringv(2 * RING);
 	for (int32_t sg = 0; sg < S; sg++) {
 		const int32_t r = seg2rec[sg];
 		if (flag[r]) continue; // (on the GPU a record may be flagged while its other pieces are already being written: harmless, the cooperative kernel rewrites the row)
 		const int32_t k0 = segbase[r], i = sg - k0, s = desc[r].slot;
 		const bool last = sg + 1 == segbase[r + 1];
 		const SegFin me = fin[sg];
-		const uint32_t j0 = pc[sg] - pc[k0];
-		const int64_t base = (rowstart[s] - rowstart[0]) + desc[r].copied + desc[r].ivArcs + (int64_t)j0;
-		bool ok = (me.mode & 3) != 2 && j0 + me.cnt <= (uint32_t)desc[r].nres;
-		if (last) ok = ok && j0 + me.cnt == (uint32_t)desc[r].nres;
-		uint32_t endRel = 0;
+		bool ok = (me.mode & 3) < 2;
+		if (last) ok = ok && pc[sg] + me.cnt - pc[k0] == (uint32_t)desc[r].nres;
 		if (ok) {
 			uint64_t cell; uint32_t a, b;
 			span(sg, cell, a, b);
-			ok = zk == 3 ? seg_b_dense<3, 1>(g, col, lo + s, cell, me.inRel, me.cnt, (int32_t)(ps[sg] - ps[k0]), i == 0, Rv.data() + base, endRel)
-			             : seg_b_dense<0, 1>(g, col, lo + s, cell, me.inRel, me.cnt, (int32_t)(ps[sg] - ps[k0]), i == 0, Rv.data() + base, endRel);
+			int32_t *out = succ + (rowstart[s] - rowstart[0]) + desc[r].copied;
+			uint32_t endRel;
+			ok = zk == 3 ? seg_b<3, 1>(g, col, ringv.data(), lo + s, cell, me.inRel, me.cnt, pc[sg] - pc[k0], (int32_t)(ps[sg] - ps[k0]), i == 0, out, outd[s] - desc[r].copied, iv_of(s), desc[r].nIv, endRel)
+			             : seg_b<0, 1>(g, col, ringv.data(), lo + s, cell, me.inRel, me.cnt, pc[sg] - pc[k0], (int32_t)(ps[sg] - ps[k0]), i == 0, out, outd[s] - desc[r].copied, iv_of(s), desc[r].nIv, endRel);
 			if (!last) ok = ok && endRel == fin[sg + 1].inRel + SEG_BITS;
 		}
 		if (!ok) { flag[r] = 1; if (getenv("SEG_MODEL_TRACE")) fprintf(stderr, "B: slot %d piece %d/%d mode %u cnt %u\n", s, i, segbase[r + 1] - k0, me.mode, me.cnt); }
 	}
-	// merge (a scalar restatement of k_seg_merge, which ranks residuals and intervals against each other by binary searches, a wave per run of pieces)
+	// expand
 	for (size_t r = 0; r < R; r++) {
 		if (flag[r] || (desc[r].flags & RF_FALLBACK) || desc[r].nres <= 0) continue;
-		const int32_t s = desc[r].slot, nIv = desc[r].nIv, nres = desc[r].nres;
+		const int32_t s = desc[r].slot;
 		int32_t *out = succ + (rowstart[s] - rowstart[0]) + desc[r].copied;
-		const int32_t extra = outd[s] - desc[r].copied;
-		const int32_t *res = Rv.data() + (rowstart[s] - rowstart[0]) + desc[r].copied + desc[r].ivArcs;
-		const SegIv *iv = iv_of(s);
-		int32_t c = 0, before = 0, prevEnd = (int32_t)0x80000000;
-		for (int32_t j = 0; j < nres; j++) {
-			while (c < nIv && iv[c].left < res[j]) { // interval c: j residuals below it
-				const int64_t P = (int64_t)iv[c].pstart + j;
-				for (int32_t u = 0; u < iv[c].len; u++) if (P + u < (int64_t)extra) out[P + u] = (int32_t)((uint32_t)iv[c].left + (uint32_t)u);
-				before = iv[c].pstart + iv[c].len; prevEnd = (int32_t)((uint32_t)iv[c].left + (uint32_t)iv[c].len);
-				c++;
-			}
-			if ((c < nIv && iv[c].left == res[j]) || res[j] < prevEnd) flag[r] = 1;
-			const int64_t P = (int64_t)j + before;
-			if (P < (int64_t)extra) out[P] = res[j]; else flag[r] = 1;
-		}
-		for (; c < nIv; c++) { const int64_t P = (int64_t)iv[c].pstart + nres; for (int32_t u = 0; u < iv[c].len; u++) if (P + u < (int64_t)extra) out[P + u] = (int32_t)((uint32_t)iv[c].left + (uint32_t)u); }
+		for (int32_t i = 0; i < desc[r].nIv; i++) expand_interval(iv_of(s)[i], desc[r].nres, out, outd[s] - desc[r].copied);
 	}
 	// what is left: flagged records -> the cooperative kernel; records without residuals have their intervals expanded by the struct lane
 	for (size_t r = 0; r < R; r++) {

@@ -152,65 +152,166 @@ __global__ void __launch_bounds__(STPB) k_seg_fill(int32_t Rcap, const int32_t *
 	}
 }
 
+// ------------------------------------------------------------------------------------------------ order inside a tile
+// A lane kernel lasts, wave by wave, as long as the longest of its 64 pieces -- and pieces differ: a record's first and last piece are
+// partial, and a piece holds 30 or 300 codes depending on the gaps of its record (A1 as first written: 37 % of the lanes' iterations did
+// work).  So every block takes a tile of TILE_P consecutive pieces and orders them by (expected) number of codes, most first, in LDS
+// (a counting sort); thread t then processes entries t, t + 256, ...: the 64 lanes of a wave get pieces of like length.
+#ifndef TILE_P_
+#define TILE_P_ 256
+#endif
+constexpr int TILE_P = TILE_P_, TILE_ITEMS = TILE_P / STPB, ORD_KEYS = 512; // (a tile of more than one piece per thread is processed in rounds, one after the other: measured slower)
+struct TileOrder { uint16_t ord[TILE_P]; int32_t cur[ORD_KEYS]; };
+// key[i] of entry i * STPB + threadIdx.x (< 0: no such piece).  On return o.ord[0 .. n) lists the tile's entries by key, descending.
+__device__ __forceinline__ int32_t tile_order(TileOrder &o, const int32_t (&key)[TILE_ITEMS]) {
+	for (int b = threadIdx.x; b < ORD_KEYS; b += STPB) o.cur[b] = 0;
+	__syncthreads();
+#pragma unroll
+	for (int i = 0; i < TILE_ITEMS; i++) if (key[i] >= 0) atomicAdd(&o.cur[min(key[i], ORD_KEYS - 1)], 1);
+	__syncthreads();
+	if (threadIdx.x < 64) { // one wave: exclusive scan over the keys from the highest down (8 keys per lane)
+		constexpr int PER = ORD_KEYS / 64;
+		const int hi = ORD_KEYS - 1 - threadIdx.x * PER; // this lane owns keys hi, hi - 1, ..., hi - PER + 1
+		int32_t mine = 0;
+#pragma unroll
+		for (int j = 0; j < PER; j++) mine += o.cur[hi - j];
+		int32_t inc = mine;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) { const int32_t t = __shfl_up(inc, d, 64); if ((int)threadIdx.x >= d) inc += t; }
+		int32_t run = inc - mine;
+#pragma unroll
+		for (int j = 0; j < PER; j++) { const int32_t c = o.cur[hi - j]; o.cur[hi - j] = run; run += c; }
+	}
+	__syncthreads();
+	int32_t n = 0;
+#pragma unroll
+	for (int i = 0; i < TILE_ITEMS; i++) if (key[i] >= 0) { o.ord[atomicAdd(&o.cur[min(key[i], ORD_KEYS - 1)], 1)] = (uint16_t)(i * STPB + threadIdx.x); n = 1; }
+	__syncthreads();
+	// how many entries the tile has: the cursor of key 0 ends at the total
+	return o.cur[0] | (n & 0);
+}
+
 // ------------------------------------------------------------------------------------------------ A1
-// cells: cap ints per piece (cap = the most codes a piece can hold, a multiple of 4: 16-byte stores)
 template <int ZK>
 __global__ void __launch_bounds__(STPB) k_seg_a1(GraphDev g, RangeView v, const RecDesc *__restrict__ desc, const int32_t *__restrict__ segbase, int32_t Rtot, int32_t Scap,
-                                                 const int32_t *__restrict__ seg2rec, SegA1 *__restrict__ a1, int32_t *__restrict__ cells, uint32_t cap, int32_t *__restrict__ flag) {
+                                                 const int32_t *__restrict__ seg2rec, SegA1 *__restrict__ a1, int32_t *__restrict__ flag) {
 	__shared__ uint32_t lds[WIN_WORDS * STPB];
+	__shared__ TileOrder ord;
 	const SegGraph sg = seg_graph(g);
 	const int32_t S = min(segbase[Rtot], Scap);
-	for (int32_t k = blockIdx.x * STPB + threadIdx.x; k < S; k += gridDim.x * STPB) {
-		const int32_t r = seg2rec[k], i = k - segbase[r];
-		const RecDesc d = desc[r];
-		const int32_t x = v.lo + d.slot;
-		uint64_t cellBit;
-		uint32_t a, b;
-		seg_span(d, (uint64_t)g.offsets[x + 1], i, cellBit, a, b);
-		SegA1 o;
-		seg_a1<ZK, STPB>(sg, lds + threadIdx.x, x, cellBit, a, b, i == 0, cells ? cells + (size_t)k * cap : nullptr, cap, o);
-		a1[k] = o;
-		if (i == 0 && o.badIdx != ~0u) flag[r] = 1;
+	for (int32_t kb = blockIdx.x * TILE_P; kb < S; kb += gridDim.x * TILE_P) {
+		int32_t key[TILE_ITEMS];
+#pragma unroll
+		for (int it = 0; it < TILE_ITEMS; it++) { // codes a piece is expected to hold: its bits times the codes per bit of its record's section
+			const int32_t k = kb + it * STPB + threadIdx.x;
+			key[it] = -1;
+			if (k < S) {
+				const int32_t r = seg2rec[k];
+				const RecDesc d = desc[r];
+				uint64_t cellBit; uint32_t a, b;
+				const uint64_t recEnd = (uint64_t)g.offsets[v.lo + d.slot + 1];
+				seg_span(d, recEnd, k - segbase[r], cellBit, a, b);
+				const uint64_t sec = recEnd - (uint64_t)d.rpos;
+				key[it] = (int32_t)(((uint64_t)(b - a) * (uint64_t)d.nres) / (sec ? sec : 1));
+			}
+		}
+		const int32_t n = tile_order(ord, key);
+		for (int32_t e = threadIdx.x; e < n; e += STPB) {
+			const int32_t k = kb + ord.ord[e];
+			const int32_t r = seg2rec[k], i = k - segbase[r];
+			const RecDesc d = desc[r];
+			const int32_t x = v.lo + d.slot;
+			uint64_t cellBit;
+			uint32_t a, b;
+			seg_span(d, (uint64_t)g.offsets[x + 1], i, cellBit, a, b);
+			SegA1 o;
+			seg_a1<ZK, STPB>(sg, lds + threadIdx.x, x, cellBit, a, b, i == 0, nullptr, ~0u, o);
+			a1[k] = o;
+			if (i == 0 && o.badIdx != ~0u) flag[r] = 1;
+		}
+		__syncthreads(); // (the next tile's order overwrites this one's)
 	}
 }
 
 // ------------------------------------------------------------------------------------------------ A2
-// fin[k]: the piece's true start, count, sum and how to read its residuals (SegFin); pair[k] = (count, sum) for the scan;
-// miss[k] = 1 and an entry in the fix list when the piece after it must be told its true start
+// fin[k]: the piece's true start, count and sum (SegFin); pair[k] = (count, sum) for the scan.  A piece whose chains have not met after
+// FIX_CODES codes of the true chain is left to the fix pass (pendlist: block-aggregated, one atomic per block and tile)
 template <int ZK>
 __global__ void __launch_bounds__(STPB) k_seg_a2(GraphDev g, RangeView v, const RecDesc *__restrict__ desc, const int32_t *__restrict__ segbase, int32_t Rtot, int32_t Scap,
-                                                 const int32_t *__restrict__ seg2rec, const SegA1 *__restrict__ a1, int32_t *__restrict__ cells, uint32_t cap, uint32_t *__restrict__ fixbuf,
-                                                 SegFin *__restrict__ fin, U2 *__restrict__ pair, uint8_t *__restrict__ miss, int32_t *__restrict__ fixlist, int32_t *__restrict__ ctl) {
+                                                 const int32_t *__restrict__ seg2rec, const SegA1 *__restrict__ a1, SegFin *__restrict__ fin, U2 *__restrict__ pair, uint8_t *__restrict__ miss,
+                                                 int32_t *__restrict__ pendlist, int32_t *__restrict__ ctl) {
 	__shared__ uint32_t lds[WIN_WORDS * STPB];
+	__shared__ int32_t s_n, s_base;
 	const SegGraph sg = seg_graph(g);
 	const int32_t S = min(segbase[Rtot], Scap);
-	for (int32_t k = blockIdx.x * STPB + threadIdx.x; k < S; k += gridDim.x * STPB) {
-		const int32_t r = seg2rec[k], i = k - segbase[r];
-		const SegA1 me = a1[k];
-		const RecDesc d = desc[r];
-		const int32_t x = v.lo + d.slot;
-		uint64_t cellBit;
-		uint32_t a, b;
-		seg_span(d, (uint64_t)g.offsets[x + 1], i, cellBit, a, b);
-		SegFin o{ a, me.cnt, me.sum, 0, 0, 0, 0, me.badIdx != ~0u ? 2u : 0u };
-		if (i > 0) seg_a2<ZK, STPB>(sg, lds + threadIdx.x, cellBit, a1[k - 1].outRel - SEG_BITS, b, me, cells ? cells + (size_t)k * cap : nullptr, cap, fixbuf ? fixbuf + (size_t)k * FIX_CODES : nullptr, false, o);
-		// (mode 2 is no verdict yet: this piece's start may itself be wrong -- then the fix pass comes by, or B's check of the chain fails)
-		const bool m = (o.mode & 3) == 1 && k + 1 != segbase[r + 1] && o.tRel != me.outRel; // the next piece took A1's end for its start: wrong
-		miss[k] = m ? 1 : 0;
-		if (m) fixlist[atomicAdd(&ctl[CTL_SEG + 1], 1)] = k;
-		fin[k] = o;
-		pair[k] = U2{ o.cnt, o.sum };
+	for (int32_t kb = blockIdx.x * STPB; kb < S; kb += gridDim.x * STPB) {
+		const int32_t k = kb + threadIdx.x;
+		if (threadIdx.x == 0) s_n = 0;
+		__syncthreads();
+		bool pending = false;
+		if (k < S) {
+			const int32_t r = seg2rec[k], i = k - segbase[r];
+			const SegA1 me = a1[k];
+			const RecDesc d = desc[r];
+			const int32_t x = v.lo + d.slot;
+			uint64_t cellBit;
+			uint32_t a, b;
+			seg_span(d, (uint64_t)g.offsets[x + 1], i, cellBit, a, b);
+			SegFin o{ a, me.cnt, me.sum, 0, 0, 0, 0, me.badIdx != ~0u ? 2u : 0u };
+			if (i > 0) seg_a2<ZK, STPB>(sg, lds + threadIdx.x, cellBit, a1[k - 1].outRel - SEG_BITS, b, me, nullptr, ~0u, nullptr, false, false, o);
+			// (mode 2 is no verdict yet: this piece's start may itself be wrong -- then the fix pass comes by, or B's check of the chain fails)
+			pending = (o.mode & 3) == 3;
+			miss[k] = 0;
+			fin[k] = o;
+			pair[k] = U2{ o.cnt, o.sum };
+		}
+		int32_t mySlot = -1;
+		if (pending) mySlot = atomicAdd(&s_n, 1);
+		__syncthreads();
+		if (threadIdx.x == 0 && s_n) s_base = atomicAdd(&ctl[CTL_SEG + 3], s_n);
+		__syncthreads();
+		if (pending) pendlist[s_base + mySlot] = k;
+		__syncthreads();
 	}
 }
 
 // ------------------------------------------------------------------------------------------------ fix
-// One lane per piece whose chains did not meet: the next piece again with its true start, and on along the record while chains keep
-// missing each other (or the next piece had missed on its own).  A piece whose predecessor missed too is not a start: the lane that
-// began further up comes by.  Best effort (FIX_MAX pieces; two runs may collide): B checks the chain of starts and ends.
+// Phase 1, one lane per piece that A2 left open: the true chain followed to the end of the piece.  If it ends where A1's chain did
+// (they met after all) nothing else changes; if not, the piece after it took a wrong start: miss[k] = 1 and an entry in the fix list.
+template <int ZK>
+__global__ void __launch_bounds__(64) k_seg_follow(GraphDev g, RangeView v, const RecDesc *__restrict__ desc, const int32_t *__restrict__ segbase, const int32_t *__restrict__ seg2rec,
+                                                   const SegA1 *__restrict__ a1, SegFin *__restrict__ fin, U2 *__restrict__ pair, uint8_t *__restrict__ miss,
+                                                   const int32_t *__restrict__ pendlist, int32_t *__restrict__ fixlist, int32_t *__restrict__ ctl) {
+	__shared__ uint32_t lds[WIN_WORDS * 64];
+	const SegGraph sg = seg_graph(g);
+	const int32_t n = ctl[CTL_SEG + 3];
+	for (int32_t e = blockIdx.x * 64 + threadIdx.x; e < n; e += gridDim.x * 64) {
+		const int32_t k = pendlist[e], r = seg2rec[k];
+		const RecDesc d = desc[r];
+		const int32_t x = v.lo + d.slot;
+		uint64_t cellBit;
+		uint32_t a, b;
+		seg_span(d, (uint64_t)g.offsets[x + 1], k - segbase[r], cellBit, a, b);
+		SegFin o = fin[k];
+		Win<64> w;
+		w.init(sg, lds + threadIdx.x, cellBit + b);
+		uint32_t q = w.seek(cellBit + o.inRel), badIdx;
+		const uint32_t qend = q + (b > o.inRel ? b - o.inRel : 0u);
+		decode_run<ZK, 64>(sg, w, q, qend, false, 0, nullptr, ~0u, o.cnt, o.sum, badIdx);
+		o.tRel = (uint32_t)(w.pos(q) - cellBit);
+		o.mode = badIdx != ~0u ? 2u : 1u;
+		fin[k] = o;
+		pair[k] = U2{ o.cnt, o.sum };
+		if (o.mode == 1 && k + 1 != segbase[r + 1] && o.tRel != a1[k].outRel) { miss[k] = 1; fixlist[atomicAdd(&ctl[CTL_SEG + 1], 1)] = k; }
+	}
+}
+// Phase 2, one lane per piece whose true chain ended elsewhere than A1's: the next piece again with its true start, and on along the
+// record while chains keep missing each other (or the next piece had missed on its own).  A piece whose predecessor missed too is
+// not a start: the lane that began further up comes by.  Best effort (FIX_MAX pieces; two runs may collide): B checks every start.
 template <int ZK>
 __global__ void __launch_bounds__(64) k_seg_fix(GraphDev g, RangeView v, const RecDesc *__restrict__ desc, const int32_t *__restrict__ segbase, const int32_t *__restrict__ seg2rec,
-                                                const SegA1 *__restrict__ a1, int32_t *__restrict__ cells, uint32_t cap, uint32_t *__restrict__ fixbuf, SegFin *__restrict__ fin, U2 *__restrict__ pair,
-                                                const uint8_t *__restrict__ miss, const int32_t *__restrict__ fixlist, const int32_t *__restrict__ ctl, int32_t *__restrict__ flag) {
+                                                const SegA1 *__restrict__ a1, SegFin *__restrict__ fin, U2 *__restrict__ pair, const uint8_t *__restrict__ miss,
+                                                const int32_t *__restrict__ fixlist, const int32_t *__restrict__ ctl, int32_t *__restrict__ flag) {
 	__shared__ uint32_t lds[WIN_WORDS * 64];
 	const SegGraph sg = seg_graph(g);
 	const int32_t n = ctl[CTL_SEG + 1];
@@ -228,7 +329,7 @@ __global__ void __launch_bounds__(64) k_seg_fix(GraphDev g, RangeView v, const R
 			seg_span(d, recEnd, k - segbase[r], cellBit, a, b);
 			const SegA1 me = a1[k];
 			SegFin o;
-			seg_a2<ZK, 64>(sg, lds + threadIdx.x, cellBit, inRel, b, me, cells ? cells + (size_t)k * cap : nullptr, cap, fixbuf ? fixbuf + (size_t)k * FIX_CODES : nullptr, cells && (fin[k].mode & SEG_REWRITTEN) != 0, o);
+			seg_a2<ZK, 64>(sg, lds + threadIdx.x, cellBit, inRel, b, me, nullptr, ~0u, nullptr, false, true, o);
 			fin[k] = o;
 			pair[k] = U2{ o.cnt, o.sum };
 			if ((o.mode & 3) == 2) break; // (B flags the record)
@@ -242,139 +343,87 @@ __global__ void __launch_bounds__(64) k_seg_fix(GraphDev g, RangeView v, const R
 }
 
 // ------------------------------------------------------------------------------------------------ B
-// One lane per piece: its residuals, decoded from its true start, to the record's stretch of the scratch array R (the residuals of a
-// record are contiguous there, in order).  The proof that every piece starts on a codeword boundary: the record's first piece does,
-// and every piece's codes end where the next piece says it starts.
+// One lane per piece, the pieces of a tile ordered by their number of codes.  The proof that every piece starts on a codeword boundary:
+// the record's first piece does, and every piece's codes end where the next piece says it starts.
 template <int ZK>
-__global__ void __launch_bounds__(STPB) k_seg_bd(GraphDev g, RangeView v, const RecDesc *__restrict__ desc, const int32_t *__restrict__ segbase, int32_t Rtot, int32_t Scap,
-                                                 const int32_t *__restrict__ seg2rec, const SegFin *__restrict__ fin, const U2 *__restrict__ pre, int32_t *__restrict__ R, int64_t Rcap,
-                                                 int32_t *__restrict__ flag) {
-	__shared__ uint32_t lds[WIN_WORDS * STPB];
+__global__ void __launch_bounds__(STPB) k_seg_b(GraphDev g, RangeView v, const RecDesc *__restrict__ desc, const int32_t *__restrict__ segbase, int32_t Rtot, int32_t Scap,
+                                                const int32_t *__restrict__ seg2rec, const SegFin *__restrict__ fin, const U2 *__restrict__ pre,
+                                                IvEntry *__restrict__ arena, int32_t *__restrict__ flag) {
+	__shared__ uint32_t lds[(WIN_WORDS + 2 * RING) * STPB];
+	__shared__ TileOrder ord;
 	const SegGraph sg = seg_graph(g);
 	const int32_t S = min(segbase[Rtot], Scap);
-	for (int32_t k = blockIdx.x * STPB + threadIdx.x; k < S; k += gridDim.x * STPB) {
-		const int32_t r = seg2rec[k];
-		if (flag[r]) continue;
-		const RecDesc d = desc[r];
-		const int32_t s = d.slot, k0 = segbase[r], i = k - k0;
-		const bool last = k + 1 == segbase[r + 1];
-		const SegFin me = fin[k];
-		const U2 p0 = pre[k0], p = pre[k];
-		const uint32_t j0 = p.x - p0.x;
-		const int64_t base = v.rowstart[s] + d.copied + d.ivArcs + (int64_t)j0;
-		bool ok = (me.mode & 3) != 2 && base >= 0 && base + (int64_t)me.cnt <= Rcap && j0 + me.cnt <= (uint32_t)d.nres;
-		if (last) ok = ok && j0 + me.cnt == (uint32_t)d.nres; // the codes of the section add up to the residuals the header promises
-		uint32_t endRel = 0;
-		if (ok) {
-			const uint64_t cellBit = (((uint64_t)d.rpos >> SEG_BITS_LOG2) + (uint64_t)i) << SEG_BITS_LOG2;
-			ok = seg_b_dense<ZK, STPB>(sg, lds + threadIdx.x, v.lo + s, cellBit, me.inRel, me.cnt, (int32_t)(p.y - p0.y), i == 0, R + base, endRel);
-			if (!last) ok = ok && endRel == fin[k + 1].inRel + SEG_BITS;
+	for (int32_t kb = blockIdx.x * TILE_P; kb < S; kb += gridDim.x * TILE_P) {
+		int32_t key[TILE_ITEMS];
+#pragma unroll
+		for (int it = 0; it < TILE_ITEMS; it++) { const int32_t k = kb + it * STPB + threadIdx.x; key[it] = k < S ? (int32_t)min(fin[k].cnt, 0x7fffu) : -1; }
+		const int32_t n = tile_order(ord, key);
+		for (int32_t e = threadIdx.x; e < n; e += STPB) {
+			const int32_t k = kb + ord.ord[e];
+			const int32_t r = seg2rec[k];
+			if (flag[r]) continue;
+			const int32_t k0 = segbase[r], i = k - k0;
+			const RecDesc d = desc[r];
+			const int32_t s = d.slot, x = v.lo + s;
+			const U2 p0 = pre[k0], p = pre[k];
+			const SegFin me = fin[k];
+			const bool last = k + 1 == segbase[r + 1];
+			bool ok = (me.mode & 3) < 2;
+			if (last) ok = ok && p.x + me.cnt - p0.x == (uint32_t)d.nres; // the codes of the section add up to the residuals the header promises
+			if (ok) {
+				const uint64_t cellBit = (((uint64_t)d.rpos >> SEG_BITS_LOG2) + (uint64_t)i) << SEG_BITS_LOG2;
+				const int64_t abase = g.minInt > 0 ? v.rowstart[s] / g.minInt : 0;
+				uint32_t endRel;
+				ok = seg_b<ZK, STPB>(sg, lds + threadIdx.x, lds + WIN_WORDS * STPB + threadIdx.x, x, cellBit, me.inRel, me.cnt, p.x - p0.x, (int32_t)(p.y - p0.y), i == 0,
+				                     v.row(s) + d.copied, v.outd[s] - d.copied, (SegIv *)(arena + abase), d.nIv, endRel);
+				if (!last) ok = ok && endRel == fin[k + 1].inRel + SEG_BITS;
+			}
+			if (!ok) flag[r] = 1;
 		}
-		if (!ok) flag[r] = 1;
+		__syncthreads();
 	}
 }
 
-// ------------------------------------------------------------------------------------------------ merge
-__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); }
-// how many of the n intervals have left <= v (the lefts increase): a 64-ary search by the whole wave, two round trips for 4 096 intervals
-__device__ __forceinline__ int32_t wave_count_le(const IvEntry *__restrict__ iv, int32_t n, int32_t v) {
-	const int lane = threadIdx.x & 63;
-	int32_t lo = 0, hi = n;
-	while (hi > lo) {
-		const int32_t span = hi - lo, step = (span + 63) >> 6, idx = lo + lane * step;
-		const bool p = idx < hi && iv[idx].left <= v;
-		const int32_t c = __popcll(__ballot(p)); // (a prefix of the lanes)
-		if (step == 1) return lo + c;
-		if (c == 0) return lo;
-		hi = min(lo + c * step, hi);
-		lo = lo + (c - 1) * step + 1;
-	}
-	return lo;
-}
-constexpr int MG_WAVES = 4, MG_IVCAP = 256, MG_VALCAP = 1408;
-// One wave per run of up to G consecutive pieces of a record: its residuals (from R) and the intervals they pass are ranked against each
-// other by binary searches in LDS -- residual j goes to out[j + ids of the intervals below it], interval e to out[pstart + residuals
-// below it ..) (MergedIntIterator.java:50-74, IntIntervalSequenceIterator.java:64-78).  Behind the record's last residual every
-// interval has rank nres.  Neighbouring lanes read and write neighbouring ids.
-__global__ void __launch_bounds__(64 * MG_WAVES) k_seg_merge(GraphDev g, RangeView v, const RecDesc *__restrict__ desc, const int32_t *__restrict__ segbase, int32_t Rtot, int32_t Scap,
-                                                             const int32_t *__restrict__ seg2rec, const U2 *__restrict__ pre, const int32_t *__restrict__ R, int32_t G,
-                                                             const IvEntry *__restrict__ arena, int32_t *__restrict__ flag) {
-	__shared__ int32_t s_valAll[MG_WAVES][MG_VALCAP];
-	__shared__ int32_t s_ivAll[MG_WAVES][3][MG_IVCAP]; // left, ids up to the interval's end, its end
-	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	int32_t *s_val = s_valAll[wv], *s_left = s_ivAll[wv][0], *s_cum = s_ivAll[wv][1], *s_end = s_ivAll[wv][2];
-	const int32_t S = min(segbase[Rtot], Scap);
-	const int64_t nGroups = ((int64_t)S + G - 1) / G;
-	for (int64_t w = (int64_t)blockIdx.x * MG_WAVES + wv; w < nGroups; w += (int64_t)gridDim.x * MG_WAVES) { // (wave-uniform)
-		const int32_t kLim = (int32_t)min((w + 1) * G, (int64_t)S);
-		for (int32_t ka = (int32_t)(w * G); ka < kLim;) { // the group's pieces, record by record
-			const int32_t r = seg2rec[ka], k0 = segbase[r], kE = segbase[r + 1], kb = min(kE, kLim);
-			const int32_t kaRun = ka;
-			ka = kb;
-			if (flag[r]) continue;
-			const RecDesc d = desc[r];
-			const int32_t s = d.slot;
-			const bool firstRun = kaRun == k0, lastRun = kb == kE;
-			const U2 p0 = pre[k0], pa = pre[kaRun], pb = pre[kb];
-			const uint32_t j0 = pa.x - p0.x, cnt = pb.x - pa.x;
-			const int32_t v0 = (int32_t)(pa.y - p0.y), vEnd = (int32_t)(pb.y - p0.y);
-			if (cnt > (uint32_t)MG_VALCAP || j0 + cnt > (uint32_t)d.nres) { if (lane == 0) flag[r] = 1; continue; }
-			int32_t *out = v.row(s) + d.copied;
-			const int32_t extra = v.outd[s] - d.copied, nIv = d.nIv;
-			const IvEntry *iv = arena + (g.minInt > 0 ? v.rowstart[s] / g.minInt : 0);
-			const int32_t *src = R + (v.rowstart[s] + d.copied + d.ivArcs + (int64_t)j0);
-			wave_sync(); // (the wave is done with what the LDS held before)
-			for (uint32_t t = lane; t < cnt; t += 64) s_val[t] = src[t];
-			int32_t iLo = 0, iHi = 0;
-			if (nIv > 0) {
-				iLo = firstRun ? 0 : wave_count_le(iv, nIv, v0);
-				iHi = lastRun ? nIv : (cnt > 0 ? wave_count_le(iv, nIv, vEnd) : iLo);
+// ------------------------------------------------------------------------------------------------ expand
+// The intervals of a record are shared out evenly among the lanes of its segments.  Every lane of a wave takes its k-th interval in
+// the same iteration: short ones it writes itself, long ones are written by the whole wave, one after the other.
+__global__ void __launch_bounds__(STPB) k_seg_expand(RangeView v, int32_t minInt, const RecDesc *__restrict__ desc, const int32_t *__restrict__ segbase, int32_t Rcap, int32_t Scap,
+                                                     const int32_t *__restrict__ seg2rec, const IvEntry *__restrict__ arena, const int32_t *__restrict__ flag) {
+	const int32_t S = min(segbase[Rcap], Scap);
+	const int32_t G = gridDim.x * STPB;
+	for (int32_t k0 = blockIdx.x * STPB + (threadIdx.x & ~63); k0 < S; k0 += G) { // (wave-uniform)
+		const int32_t k = k0 + (threadIdx.x & 63);
+		int32_t lo = 0, hi = 0, nres = 0, extra = 0;
+		int32_t *out = nullptr;
+		const IvEntry *iv = nullptr;
+		if (k < S) {
+			const int32_t r = seg2rec[k];
+			if (!flag[r]) {
+				const RecDesc d = desc[r];
+				const int32_t ns = segbase[r + 1] - segbase[r], i = k - segbase[r];
+				lo = (int32_t)((int64_t)d.nIv * i / ns); hi = (int32_t)((int64_t)d.nIv * (i + 1) / ns);
+				nres = d.nres; extra = v.outd[d.slot] - d.copied;
+				out = v.row(d.slot) + d.copied;
+				iv = arena + (minInt > 0 ? v.rowstart[d.slot] / minInt : 0);
 			}
-			int32_t before0 = 0, prevEnd0 = (int32_t)0x80000000;
-			if (iLo > 0) { const IvEntry e = iv[iLo - 1]; before0 = e.pstart + e.len; prevEnd0 = (int32_t)((uint32_t)e.left + (uint32_t)e.len); }
-			wave_sync();
-			bool lbad = false;
-			// intervals: rank among the run's residuals, expansion
-			for (int32_t e0 = iLo; e0 < iHi; e0 += 64) {
-				const int32_t e = e0 + lane;
-				IvEntry en{ 0, 0, 0, 0 };
-				if (e < iHi) {
-					en = iv[e];
-					if (e - iLo < MG_IVCAP) { s_left[e - iLo] = en.left; s_cum[e - iLo] = en.pstart + en.len; s_end[e - iLo] = (int32_t)((uint32_t)en.left + (uint32_t)en.len); }
-					uint32_t lo = 0, hi = cnt; // residuals below en.left
-					while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (s_val[mid] < en.left) lo = mid + 1; else hi = mid; }
-					if (lo < cnt && s_val[lo] == en.left) lbad = true; // a residual on an interval's first id: equal heads are emitted once (MergedIntIterator.java:69-72) -- not here
-					en.rank = (int32_t)(j0 + lo);
-				}
-				const bool isLong = en.len > 32;
-				if (!isLong) { const int64_t P = (int64_t)en.pstart + en.rank; for (int32_t u = 0; u < en.len; u++) if (P + u < (int64_t)extra) out[P + u] = (int32_t)((uint32_t)en.left + (uint32_t)u); }
-				unsigned long long lm = __ballot(isLong);
-				while (lm) { // long intervals: the whole wave, one after the other
-					const int src2 = __ffsll((long long)lm) - 1;
-					lm &= lm - 1;
-					const int32_t L = __shfl(en.left, src2, 64), N = __shfl(en.len, src2, 64);
-					const int64_t P = (int64_t)__shfl(en.pstart, src2, 64) + __shfl(en.rank, src2, 64);
-					for (int32_t u = lane; u < N; u += 64) if (P + u < (int64_t)extra) out[P + u] = (int32_t)((uint32_t)L + (uint32_t)u);
-				}
+		}
+		int32_t most = hi - lo;
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) most = max(most, __shfl_xor(most, o, 64));
+		for (int32_t t = 0; t < most; t++) {
+			IvEntry e{ 0, 0, 0, 0 };
+			if (lo + t < hi) e = iv[lo + t];
+			const bool isLong = e.len > 32;
+			if (!isLong && e.len > 0) expand_interval(SegIv{ e.left, e.pstart, e.rank, e.len }, nres, out, extra);
+			unsigned long long lm = __ballot(isLong);
+			while (lm) {
+				const int src = __ffsll((long long)lm) - 1;
+				lm &= lm - 1;
+				const int32_t L = __shfl(e.left, src, 64), N = __shfl(e.len, src, 64), X = __shfl(extra, src, 64);
+				const int64_t P = shfl_i64((int64_t)e.pstart + (e.rank < 0 ? nres : e.rank), src);
+				int32_t *O = (int32_t *)shfl_i64((int64_t)(uintptr_t)out, src);
+				for (int32_t u = threadIdx.x & 63; u < N; u += 64) if (P + u < (int64_t)X) O[P + u] = (int32_t)((uint32_t)L + (uint32_t)u);
 			}
-			wave_sync();
-			// residuals: ids of the intervals below each
-			const int32_t nI = iHi - iLo, nStaged = min(nI, MG_IVCAP);
-			for (uint32_t t = lane; t < cnt; t += 64) {
-				const int32_t val = s_val[t];
-				int32_t c; // intervals of [iLo, iHi) with left < val
-				if (nI <= MG_IVCAP) { int32_t lo = 0, hi = nStaged; while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (s_left[mid] < val) lo = mid + 1; else hi = mid; } c = lo; }
-				else { int32_t lo = iLo, hi = iHi; while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (iv[mid].left < val) lo = mid + 1; else hi = mid; } c = lo - iLo; } // (a run that passes hundreds of intervals: straight from the arena)
-				int32_t before = before0, prevEnd = prevEnd0;
-				if (c > 0) {
-					if (c <= MG_IVCAP) { before = s_cum[c - 1]; prevEnd = s_end[c - 1]; }
-					else { const IvEntry e = iv[iLo + c - 1]; before = e.pstart + e.len; prevEnd = (int32_t)((uint32_t)e.left + (uint32_t)e.len); }
-				}
-				if (val < prevEnd) lbad = true; // inside an interval
-				const int64_t P = (int64_t)j0 + t + before;
-				if (P < (int64_t)extra) out[P] = val; else lbad = true;
-			}
-			if (__any(lbad)) { if (lane == 0) flag[r] = 1; }
 		}
 	}
 }
@@ -399,7 +448,7 @@ int32_t seg_bits_log2() { return SEG_BITS_LOG2; }
 // [RcapM, RcapM + capBig) the wave class's queue, then capGiant entries for the giants' queue (their descriptors come from k_parse_big).
 namespace {
 struct SegPtrs {
-	RecDesc *desc; int32_t *nseg, *segbase, *flag, *sumsR, *fblist, *seg2rec, *fixlist;
+	RecDesc *desc; int32_t *nseg, *segbase, *flag, *sumsR, *fblist, *seg2rec, *fixlist, *pendlist;
 	SegA1 *a1; SegFin *fin; uint8_t *miss; U2 *pair, *pre, *sumsS;
 	int32_t *cells; uint32_t *fixbuf;
 	size_t bytes;
@@ -418,6 +467,7 @@ SegPtrs seg_ptrs(void *scratch, int32_t Rtot, int32_t Scap, uint32_t cap) {
 	o.fblist = (int32_t *)take(sizeof(int32_t) * (size_t)Rtot);
 	o.seg2rec = (int32_t *)take(sizeof(int32_t) * ((size_t)Scap + 1));
 	o.fixlist = (int32_t *)take(sizeof(int32_t) * ((size_t)Scap + 1));
+	o.pendlist = (int32_t *)take(sizeof(int32_t) * ((size_t)Scap + 1));
 	o.a1 = (SegA1 *)take(sizeof(SegA1) * ((size_t)Scap + 1));
 	o.fin = (SegFin *)take(sizeof(SegFin) * ((size_t)Scap + 1));
 	o.miss = (uint8_t *)take((size_t)Scap + 1);
@@ -483,18 +533,19 @@ void launch_seg_chain(const GraphDev &g, int def, const RangeView &v, const int3
 	GraphDev g0 = g; g0.segDesc = nullptr; // (the kernel of the flagged records decodes whole records)
 	sg_scan<int32_t>(P.nseg, Rtot, P.segbase, P.sumsR, st);
 	hipLaunchKernelGGL(k_seg_fill, grid, blk, 0, st, Rtot, P.segbase, Scap, P.seg2rec);
-	int32_t *noCells = nullptr; uint32_t *noFix = nullptr; // (the residuals are decoded a second time, by k_seg_bd: nothing is kept of the chains)
-	if (def == 1) hipLaunchKernelGGL(k_seg_a1<3>, grid, blk, 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.a1, noCells, cap, P.flag);
-	else hipLaunchKernelGGL(k_seg_a1<0>, grid, blk, 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.a1, noCells, cap, P.flag);
-	if (def == 1) hipLaunchKernelGGL(k_seg_a2<3>, grid, blk, 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.a1, noCells, cap, noFix, P.fin, P.pair, P.miss, P.fixlist, ctl);
-	else hipLaunchKernelGGL(k_seg_a2<0>, grid, blk, 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.a1, noCells, cap, noFix, P.fin, P.pair, P.miss, P.fixlist, ctl);
-	if (def == 1) hipLaunchKernelGGL(k_seg_fix<3>, dim3(64), dim3(64), 0, st, g0, v, P.desc, P.segbase, P.seg2rec, P.a1, noCells, cap, noFix, P.fin, P.pair, P.miss, P.fixlist, ctl, P.flag);
-	else hipLaunchKernelGGL(k_seg_fix<0>, dim3(64), dim3(64), 0, st, g0, v, P.desc, P.segbase, P.seg2rec, P.a1, noCells, cap, noFix, P.fin, P.pair, P.miss, P.fixlist, ctl, P.flag);
+	(void)cap; (void)R; (void)Rcap;
+	if (def == 1) hipLaunchKernelGGL(k_seg_a1<3>, grid, blk, 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.a1, P.flag);
+	else hipLaunchKernelGGL(k_seg_a1<0>, grid, blk, 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.a1, P.flag);
+	if (def == 1) hipLaunchKernelGGL(k_seg_a2<3>, grid, blk, 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.a1, P.fin, P.pair, P.miss, P.pendlist, ctl);
+	else hipLaunchKernelGGL(k_seg_a2<0>, grid, blk, 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.a1, P.fin, P.pair, P.miss, P.pendlist, ctl);
+	if (def == 1) hipLaunchKernelGGL(k_seg_follow<3>, dim3(1024), dim3(64), 0, st, g0, v, P.desc, P.segbase, P.seg2rec, P.a1, P.fin, P.pair, P.miss, P.pendlist, P.fixlist, ctl);
+	else hipLaunchKernelGGL(k_seg_follow<0>, dim3(1024), dim3(64), 0, st, g0, v, P.desc, P.segbase, P.seg2rec, P.a1, P.fin, P.pair, P.miss, P.pendlist, P.fixlist, ctl);
+	if (def == 1) hipLaunchKernelGGL(k_seg_fix<3>, dim3(64), dim3(64), 0, st, g0, v, P.desc, P.segbase, P.seg2rec, P.a1, P.fin, P.pair, P.miss, P.fixlist, ctl, P.flag);
+	else hipLaunchKernelGGL(k_seg_fix<0>, dim3(64), dim3(64), 0, st, g0, v, P.desc, P.segbase, P.seg2rec, P.a1, P.fin, P.pair, P.miss, P.fixlist, ctl, P.flag);
 	sg_scan<U2>(P.pair, Scap, P.pre, P.sumsS, st, P.segbase + Rtot);
-	if (def == 1) hipLaunchKernelGGL(k_seg_bd<3>, grid, blk, 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.fin, P.pre, R, Rcap, P.flag);
-	else hipLaunchKernelGGL(k_seg_bd<0>, grid, blk, 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.fin, P.pre, R, Rcap, P.flag);
-	const int32_t G = (int32_t)std::max<uint32_t>(1u, std::min<uint32_t>(8u, (uint32_t)MG_VALCAP / cap)); // pieces per wave of the merge: what fits its LDS
-	hipLaunchKernelGGL(k_seg_merge, dim3((unsigned)(2 * blocks)), dim3(64 * MG_WAVES), 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.pre, R, G, a, P.flag);
+	if (def == 1) hipLaunchKernelGGL(k_seg_b<3>, grid, blk, 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.fin, P.pre, a, P.flag);
+	else hipLaunchKernelGGL(k_seg_b<0>, grid, blk, 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.fin, P.pre, a, P.flag);
+	hipLaunchKernelGGL(k_seg_expand, grid, blk, 0, st, v, g.minInt, P.desc, P.segbase, Rtot, Scap, P.seg2rec, a, P.flag);
 	hipLaunchKernelGGL(k_seg_collect, grid, blk, 0, st, recs, RcapM, Rtot, Scap, P.desc, P.nseg, P.segbase, P.flag, P.fblist, ctl);
 	launch_parse_listed(g0, def, v, P.fblist, ctl, CTL_SEG, arena, arenaCap, 256, err, st);
 }

@@ -58,6 +58,7 @@ namespace bvsg {
 constexpr int SEG_BITS_LOG2 = SEG_BITS_LOG2_;
 constexpr uint32_t SEG_BITS = 1u << SEG_BITS_LOG2; // a piece of stream: [c * SEG_BITS, (c + 1) * SEG_BITS), "cell" c of the grid; a multiple of 128 bits (16-byte loads)
 constexpr int WIN_WORDS = 16;                      // a lane's window of the stream in LDS
+constexpr int RING = 8;                            // intervals a lane of B keeps at hand (2 words each)
 constexpr int FIX_MAX = 64;                        // pieces one lane of the fix kernel follows a run of missed meetings for
 
 struct SegGraph { // what the bodies need of bv::GraphDev
@@ -74,7 +75,8 @@ struct SegA1 { uint32_t outRel, cnt, sum, badIdx; };  // A1: where the chain tha
 // A2 / fix: the piece's true start; true count and sum; where the true chain ends (mode 1 only).  Residual t of the piece is
 // base + (t < cb ? fix[t] : cell[t - cb + ca] + delta): cb sums of the true chain before it joins A1's chain at that chain's code ca.
 // mode 0: as said; 1: the chains did not meet within FIX_CODES codes -- the lane decoded the whole piece again and the cell holds the
-// true chain (ca = cb = delta = 0); 2: a codeword this decoder does not take.  Bit 2 (SEG_REWRITTEN): the cell no longer holds A1's chain
+// true chain (ca = cb = delta = 0); 2: a codeword this decoder does not take; 3: not known yet (the fix pass follows the true chain).
+// Bit 2 (SEG_REWRITTEN): the cell no longer holds A1's chain
 struct SegFin { uint32_t inRel, cnt, sum, tRel, ca, cb, delta, mode; };
 constexpr uint32_t FIX_CODES = 32, SEG_REWRITTEN = 4;
 
@@ -356,7 +358,7 @@ SG_D void seg_a1(const SegGraph &g, uint32_t *col, int32_t x, uint64_t cellBit, 
 // piece before, minus SEG_BITS).  Walks both chains in lock step (always the one that is behind) until they meet, keeping the running
 // sums of the true chain's codes in fix[]; see SegFin for what it leaves.
 template <int ZK, int STRIDE>
-SG_D void seg_a2(const SegGraph &g, uint32_t *col, uint64_t cellBit, uint32_t inRel, uint32_t endRel, const SegA1 &a1, int32_t *cell, uint32_t cap, uint32_t *fix, bool cellRewritten, SegFin &o) {
+SG_D void seg_a2(const SegGraph &g, uint32_t *col, uint64_t cellBit, uint32_t inRel, uint32_t endRel, const SegA1 &a1, int32_t *cell, uint32_t cap, uint32_t *fix, bool cellRewritten, bool follow, SegFin &o) {
 	// cellRewritten (the fix pass, a piece it or A2 visited before): the cell no longer holds A1's chain -- the whole piece again, whatever the chains do
 	o = SegFin{ inRel, a1.cnt, a1.sum, 0, 0, 0, 0, cellRewritten ? SEG_REWRITTEN : 0u };
 	if (inRel == 0 && !cellRewritten) { if (a1.badIdx != ~0u) o.mode = 2; return; }
@@ -385,7 +387,9 @@ SG_D void seg_a2(const SegGraph &g, uint32_t *col, uint64_t cellBit, uint32_t in
 		o.ca = ca; o.cb = cb; o.delta = sb - sa;
 		return;
 	}
-	// no meeting point in sight: the whole piece again, from its true start, into the cell
+	// no meeting point in sight.  !follow (A2, where a lane that went on would hold up its whole wave): left to the fix pass (mode 3)
+	if (!follow) { o.mode = 3; return; }
+	// the whole piece again, from its true start (into the cell, if one is kept)
 	uint32_t q = w.seek(cellBit + inRel), badIdx;
 	qend = q + (endRel > inRel ? endRel - inRel : 0u);
 	decode_run<ZK, STRIDE>(g, w, q, qend, false, 0, cell, cap, o.cnt, o.sum, badIdx);
@@ -393,38 +397,94 @@ SG_D void seg_a2(const SegGraph &g, uint32_t *col, uint64_t cellBit, uint32_t in
 	o.mode = (badIdx != ~0u ? 2u : 1u) | SEG_REWRITTEN;
 }
 
-// ------------------------------------------------------------------------------------------------ B (dense)
-// Decodes the cnt codes of a piece from its true start and writes the residuals themselves -- v0 + the running sum (BVG:954, :966) --
-// to dst[0 .. cnt), the piece's stretch of the record's residuals in scratch, 16 bytes at a time where the alignment allows.
-// endRel: where the last code ended (the caller checks it against the start of the next piece).  false: a codeword this decoder does
-// not take.
-template <int ZK, int STRIDE>
-SG_D bool seg_b_dense(const SegGraph &g, uint32_t *col, int32_t x, uint64_t cellBit, uint32_t inRel, uint32_t cnt, int32_t v0, bool firstOfRecord, int32_t *dst, uint32_t &endRel) {
-	Win<STRIDE> w;
-	w.init(g, col, cellBit + SEG_BITS);
-	uint32_t q = w.seek(cellBit + inRel);
-	bool bad = false;
-	const uint32_t head = umin32(cnt, ((16u - ((uint32_t)(uintptr_t)dst & 15u)) & 15u) >> 2); // scalar stores up to the first 16-byte boundary
-	uint32_t val = (uint32_t)v0, o1 = 0, o2 = 0, o3 = 0, on = 0;
-	for (uint32_t t = 0; t < cnt; t++) {
-		if (SG_ANY(q > Q_OK)) q -= w.slide(q);
-		const uint32_t v = w.template zeta<ZK>(q, (uint32_t)g.zetaK, bad);
-		val = (firstOfRecord && t == 0) ? (uint32_t)x + (uint32_t)zigzag32(v) : val + v + 1u;
-		if (t < head) { dst[t] = (int32_t)val; continue; }
-		const uint32_t o0 = o1; o1 = o2; o2 = o3; o3 = val;
-		if (++on == 4) {
+// ------------------------------------------------------------------------------------------------ B
+// Decodes the cnt codes of a piece from its true start and stores every residual at its place among the record's extras: residual j
+// (value r) goes to out[j + #(interval ids below r)].  v0 = the residual before the piece's first one, j0 = its index + 1.
+// Intervals that the piece's residuals pass learn their rank (= residuals before them).  endRel: where the last code ended (the
+// caller checks it against the start of the next piece).  false: the record must be flagged.
+//
+// What a wave executes per iteration is what counts (all of these kernels are bound by instruction issue): the loop proper is the
+// decode, one range test and one store.  The lane's next intervals wait in a ring in LDS -- (left, ids up to its end) -- that is
+// topped up, four entries at a time and without a branch per entry, whenever the wave refills its stream windows anyway: no loads of
+// their own in the loop (a load waits for every store before it: the GPU counts both in one counter).  A lane that runs out of ring
+// all the same takes its next interval straight from the arena.
+template <int STRIDE> struct IvRing {
+	uint32_t *ring; const SegIv *iv; int32_t nIv, idx, loaded; // intervals [idx, loaded) are in the ring, entry k at slot k & (RING - 1)
+	SG_D void top_up() { // four more, if this lane has the room and the record has them
+		if (RING - (loaded - idx) >= 4 && loaded < nIv) {
+			const int32_t last = nIv - 1;
 #if defined(__HIP_DEVICE_COMPILE__)
-			*(int4 *)(dst + t - 3) = int4{ (int32_t)o0, (int32_t)o1, (int32_t)o2, (int32_t)o3 };
+			int4 e[4];
+#pragma unroll
+			for (int k = 0; k < 4; k++) e[k] = *(const int4 *)(iv + (loaded + k < last ? loaded + k : last)); // (past the record's last interval: read again, never used)
+#pragma unroll
+			for (int k = 0; k < 4; k++) { const uint32_t s = (uint32_t)(loaded + k) & (RING - 1); ring[(2 * s) * STRIDE] = (uint32_t)e[k].x; ring[(2 * s + 1) * STRIDE] = (uint32_t)(e[k].y + e[k].w); }
 #else
-			dst[t - 3] = (int32_t)o0; dst[t - 2] = (int32_t)o1; dst[t - 1] = (int32_t)o2; dst[t] = (int32_t)o3;
+			for (int k = 0; k < 4; k++) { const SegIv e = iv[loaded + k < last ? loaded + k : last]; const uint32_t s = (uint32_t)(loaded + k) & (RING - 1); ring[(2 * s) * STRIDE] = (uint32_t)e.left; ring[(2 * s + 1) * STRIDE] = (uint32_t)(e.pstart + e.len); }
 #endif
-			on = 0;
+			loaded = loaded + 4 < nIv ? loaded + 4 : nIv;
 		}
 	}
-	if (on >= 3) dst[cnt - 3] = (int32_t)o1;
-	if (on >= 2) dst[cnt - 2] = (int32_t)o2;
-	if (on >= 1) dst[cnt - 1] = (int32_t)o3;
-	endRel = (uint32_t)(w.pos(q) - cellBit);
+	SG_D void get(int32_t &left, int32_t &cum) { // interval idx (idx < nIv)
+		if (idx < loaded) { const uint32_t s = (uint32_t)idx & (RING - 1); left = (int32_t)ring[(2 * s) * STRIDE]; cum = (int32_t)ring[(2 * s + 1) * STRIDE]; }
+		else { const SegIv e = iv[idx]; left = e.left; cum = e.pstart + e.len; loaded = idx; } // (the ring is empty: straight from the arena)
+	}
+};
+template <int ZK, int STRIDE>
+SG_D bool seg_b(const SegGraph &g, uint32_t *col, uint32_t *ring, int32_t x, uint64_t cell, uint32_t inRel, uint32_t cnt, uint32_t j0, int32_t v0, bool firstOfRecord,
+                int32_t *out, int32_t extra, SegIv *iv, int32_t nIv, uint32_t &endRel) {
+#if defined(SG_DBG_NOIV)
+	nIv = 0;
+#endif
+	Win<STRIDE> w;
+	w.init(g, col, cell + SEG_BITS);
+	uint32_t q = w.seek(cell + inRel);
+	bool bad = false;
+	// intervals [0, idx) lie below v0 (passed by the pieces before): a binary search in the record's arena slice
+	IvRing<STRIDE> R{ ring, iv, nIv, 0, 0 };
+	if (!firstOfRecord && nIv > 0) {
+		int32_t lo = 0, hi = nIv;
+		while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (iv[mid].left <= v0) lo = mid + 1; else hi = mid; }
+		R.idx = lo;
+	}
+	R.loaded = R.idx;
+	// between the end of the last interval passed and the start of the next one a residual simply goes to out[j + before]
+	int32_t before = 0, prevEnd = (int32_t)0x80000000, nl = 0x7fffffff, ncum = 0; // ids of the intervals passed; [prevEnd, nl): the free stretch; ids up to the end of the next interval
+	if (R.idx > 0) { const SegIv e = iv[R.idx - 1]; before = e.pstart + e.len; prevEnd = (int32_t)((uint32_t)e.left + (uint32_t)e.len); }
+	R.top_up(); R.top_up();
+	if (R.idx < nIv) R.get(nl, ncum);
+	uint32_t span = (uint32_t)nl - (uint32_t)prevEnd;
+	uint32_t j = j0, val = (uint32_t)v0;
+	const uint32_t xtr = (uint32_t)extra;
+	for (uint32_t t = 0; t < cnt; t++) {
+		if (SG_ANY(q > Q_OK)) { q -= w.slide(q); R.top_up(); }
+		const uint32_t v = w.template zeta<ZK>(q, (uint32_t)g.zetaK, bad);
+		val = (firstOfRecord && t == 0) ? (uint32_t)x + (uint32_t)zigzag32(v) : val + v + 1u; // BVG:954, :966
+		if (SG_UNLIKELY(val - (uint32_t)prevEnd >= span)) { // not in the free stretch: the residual passes intervals -- or sits inside one
+			const int32_t sv = (int32_t)val;
+			if (sv < prevEnd) bad = true; // inside an interval: equal heads are emitted once (MergedIntIterator.java:69-72) -- not here
+			while (R.idx < nIv && nl < sv) { // the residual passes interval idx: j residuals precede it
+#if !defined(SG_DBG_NORANK)
+				iv[R.idx].rank = (int32_t)j;
+#endif
+				prevEnd = (int32_t)((uint32_t)nl + (uint32_t)(ncum - before));
+				before = ncum;
+				R.idx++;
+				if (R.idx < nIv) { R.get(nl, ncum); if (nl < prevEnd) bad = true; }
+				else nl = 0x7fffffff;
+			}
+			if ((R.idx < nIv && nl == sv) || sv < prevEnd) bad = true;
+			span = (uint32_t)nl - (uint32_t)prevEnd;
+		}
+		const uint32_t p = j + (uint32_t)before;
+#if defined(SG_DBG_NOSTORE)
+		if (p >= xtr) bad = true;
+#else
+		if (p < xtr) out[p] = (int32_t)val; else bad = true;
+#endif
+		j++;
+	}
+	endRel = (uint32_t)(w.pos(q) - cell);
 	return !bad;
 }
 
