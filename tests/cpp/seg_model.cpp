@@ -125,8 +125,8 @@ int seg_model_run(const uint8_t *graph, uint64_t nbytes, const int64_t *offsets,
 	// scan
 	pc[0] = ps[0] = 0;
 	for (int32_t sg = 0; sg < S; sg++) { pc[sg + 1] = pc[sg] + fin[sg].cnt; ps[sg + 1] = ps[sg] + fin[sg].sum; }
-	// B
-	std::vector<uint32_t> ringv(2 * RING);
+	// B: the merged stream of every piece (residuals and the intervals they pass), straight into the row
+	std::vector<uint32_t> ringv(2 * FRING), stagev(STAGE);
 	for (int32_t sg = 0; sg < S; sg++) {
 		const int32_t r = seg2rec[sg];
 		if (flag[r]) continue; // (on the GPU a record may be flagged while its other pieces are already being written: harmless, the cooperative kernel rewrites the row)
@@ -139,19 +139,12 @@ int seg_model_run(const uint8_t *graph, uint64_t nbytes, const int64_t *offsets,
 			uint64_t cell; uint32_t a, b;
 			span(sg, cell, a, b);
 			int32_t *out = succ + (rowstart[s] - rowstart[0]) + desc[r].copied;
-			uint32_t endRel;
-			ok = zk == 3 ? seg_b<3, 1>(g, col, ringv.data(), lo + s, cell, me.inRel, me.cnt, pc[sg] - pc[k0], (int32_t)(ps[sg] - ps[k0]), i == 0, out, outd[s] - desc[r].copied, iv_of(s), desc[r].nIv, endRel)
-			             : seg_b<0, 1>(g, col, ringv.data(), lo + s, cell, me.inRel, me.cnt, pc[sg] - pc[k0], (int32_t)(ps[sg] - ps[k0]), i == 0, out, outd[s] - desc[r].copied, iv_of(s), desc[r].nIv, endRel);
-			if (!last) ok = ok && endRel == fin[sg + 1].inRel + SEG_BITS;
+			uint64_t endBit;
+			ok = zk == 3 ? seg_flat<3, 1>(g, col, ringv.data(), stagev.data(), lo + s, cell + me.inRel, cell + SEG_BITS, me.cnt, pc[sg] - pc[k0], (int32_t)(ps[sg] - ps[k0]), i == 0, last, out, outd[s] - desc[r].copied, iv_of(s), desc[r].nIv, endBit)
+			             : seg_flat<0, 1>(g, col, ringv.data(), stagev.data(), lo + s, cell + me.inRel, cell + SEG_BITS, me.cnt, pc[sg] - pc[k0], (int32_t)(ps[sg] - ps[k0]), i == 0, last, out, outd[s] - desc[r].copied, iv_of(s), desc[r].nIv, endBit);
+			if (!last) ok = ok && endBit == cell + SEG_BITS + fin[sg + 1].inRel;
 		}
 		if (!ok) { flag[r] = 1; if (getenv("SEG_MODEL_TRACE")) fprintf(stderr, "B: slot %d piece %d/%d mode %u cnt %u\n", s, i, segbase[r + 1] - k0, me.mode, me.cnt); }
-	}
-	// expand
-	for (size_t r = 0; r < R; r++) {
-		if (flag[r] || (desc[r].flags & RF_FALLBACK) || desc[r].nres <= 0) continue;
-		const int32_t s = desc[r].slot;
-		int32_t *out = succ + (rowstart[s] - rowstart[0]) + desc[r].copied;
-		for (int32_t i = 0; i < desc[r].nIv; i++) expand_interval(iv_of(s)[i], desc[r].nres, out, outd[s] - desc[r].copied);
 	}
 	// what is left: flagged records -> the cooperative kernel; records without residuals have their intervals expanded by the struct lane
 	for (size_t r = 0; r < R; r++) {
@@ -163,6 +156,38 @@ int seg_model_run(const uint8_t *graph, uint64_t nbytes, const int64_t *offsets,
 			int32_t *out = succ + (rowstart[s] - rowstart[0]) + desc[r].copied;
 			for (int32_t i = 0; i < desc[r].nIv; i++) expand_interval(iv_of(s)[i], 0, out, outd[s] - desc[r].copied);
 		}
+	}
+	return 0;
+}
+
+// The short records' kernel (k_parse_flat): one lane per record, structure then the merged stream of the whole record as ONE piece.
+int flat_model_run(const uint8_t *graph, uint64_t nbytes, const int64_t *offsets, int32_t lo, int32_t cnt, const int32_t *outd, const uint16_t *ref,
+                   const int64_t *rowstart, int W, int minInt, int zk, int dmin, int dmax, int32_t *succ, int32_t *esc, int32_t *nEsc, int32_t *cop, int64_t *stats) {
+	SegGraph g{ (const uint32_t *)graph, (nbytes + 3) / 4, offsets, W, minInt, zk };
+	*nEsc = 0;
+	for (int s = 0; s < cnt; s++) cop[s] = -1;
+	for (int k = 0; k < 8; k++) stats[k] = 0;
+	std::vector<uint32_t> lds(WIN_WORDS), ringv(2 * FRING), stagev(STAGE);
+	const int64_t arcs = rowstart[cnt] - rowstart[0];
+	std::vector<SegIv> arena((size_t)(minInt > 0 ? arcs / minInt + cnt + 2 : 1));
+	for (int32_t s = 0; s < cnt; s++) {
+		if (outd[s] < std::max(dmin, 1) || outd[s] >= dmax) continue;
+		stats[0]++;
+		const int32_t x = lo + s, rf = ref[s];
+		if (rf > s) { esc[(*nEsc)++] = s; continue; }
+		SegIv *iv = arena.data() + (minInt > 0 ? (rowstart[s] - rowstart[0]) / minInt : 0);
+		RecDesc d{};
+		struct_lane<1>(g, lds.data(), x, outd[s], rf > 0, rf > 0 ? (int64_t)outd[s - rf] : 0, iv, d);
+		bool ok = !(d.flags & RF_FALLBACK);
+		if (ok && outd[s] - d.copied > 0) {
+			uint64_t endBit;
+			int32_t *out = succ + (rowstart[s] - rowstart[0]) + d.copied;
+			ok = zk == 3 ? seg_flat<3, 1>(g, lds.data(), ringv.data(), stagev.data(), x, (uint64_t)d.rpos, (uint64_t)offsets[x + 1], (uint32_t)d.nres, 0, 0, true, true, out, outd[s] - d.copied, iv, d.nIv, endBit)
+			             : seg_flat<0, 1>(g, lds.data(), ringv.data(), stagev.data(), x, (uint64_t)d.rpos, (uint64_t)offsets[x + 1], (uint32_t)d.nres, 0, 0, true, true, out, outd[s] - d.copied, iv, d.nIv, endBit);
+		}
+		if (!ok) { esc[(*nEsc)++] = s; stats[3]++; continue; }
+		cop[s] = d.copied;
+		stats[5] += d.nIv;
 	}
 	return 0;
 }

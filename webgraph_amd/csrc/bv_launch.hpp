@@ -65,7 +65,7 @@ void launch_chain_fill(const GraphDev &g, int def, const int32_t *nodes, int64_t
 void launch_bparse(const GraphDev &g, int def, const BatchView &v, int *err, hipStream_t st);
 void launch_bcopy(const GraphDev &g, int def, const BatchView &v, int32_t level, int *err, hipStream_t st);
 void launch_pick_coop(const int32_t *part, int32_t nblocks, int32_t budget, int32_t *ctl, hipStream_t st, int32_t *counts = nullptr);
-constexpr int CTL_INTS = 32, CTL_COOP = 22, CTL_SEG = 24, CTL_TOTAL_INTS = CTL_INTS; // control block (bv_kernels.hip); ctl[CTL_SEG], ctl[CTL_SEG + 2]: records the segment pipeline hands to the cooperative kernel, head of that queue
+constexpr int CTL_INTS = 32, CTL_COOP = 22, CTL_SEG = 24, CTL_FLAT = 28, CTL_TOTAL_INTS = CTL_INTS; // control block (bv_kernels.hip); ctl[CTL_SEG], ctl[CTL_SEG + 2]: records the segment pipeline hands to the cooperative kernel, head of that queue
 void launch_classify(int32_t cnt, const int32_t *outd, const int32_t *coopPtr, int32_t coopMin, int32_t giantMin, int32_t *biglist, int32_t *giantlist, int32_t giantCap, int32_t *ctl, hipStream_t st);
 void launch_parse_big(const GraphDev &g, int def, const RangeView &v, const int32_t *biglist, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap,
                       int waves, int giantGroups, int *err, hipStream_t stGiant, hipStream_t stBig);
@@ -81,6 +81,9 @@ void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int
 void launch_parse_listed(const GraphDev &g, int def, const RangeView &v, const int32_t *list, int32_t *ctl, int which, void *arena, int64_t arenaCap, int waves, int *err, hipStream_t st);
 // bv_seg.hip: the segment pipeline for the records of the parse list's keys [kLo, kHi) that have fewer than coop_min successors
 constexpr int PARSE_LONG_BIN = 14; // work bins from here up (>= 2048 bits of work) are not windowed (k_depth_keys) -- and are the segment pipeline's
+// the records of the parse list's keys [0, keyHi), one lane each, by the bodies of the segment pipeline (k_parse_flat); fblist: room for every record of the view
+void launch_parse_flat(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int32_t keyHi, int blocks, void *arena, int64_t arenaCap,
+                       int32_t *fblist, int32_t *ctl, int *err, hipStream_t st);
 size_t seg_scratch_bytes(int32_t Rtot, int32_t Scap, int zetaK);
 void launch_seg_sizing(const int64_t *offsets, int32_t lo, int32_t n, const int32_t *outd, unsigned long long *out2, hipStream_t st); // load time: records of the long work bins, their bits
 int32_t seg_bits_log2();

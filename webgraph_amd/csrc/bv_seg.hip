@@ -349,7 +349,7 @@ template <int ZK>
 __global__ void __launch_bounds__(STPB) k_seg_b(GraphDev g, RangeView v, const RecDesc *__restrict__ desc, const int32_t *__restrict__ segbase, int32_t Rtot, int32_t Scap,
                                                 const int32_t *__restrict__ seg2rec, const SegFin *__restrict__ fin, const U2 *__restrict__ pre,
                                                 IvEntry *__restrict__ arena, int32_t *__restrict__ flag) {
-	__shared__ uint32_t lds[(WIN_WORDS + 2 * RING) * STPB];
+	__shared__ uint32_t lds[(WIN_WORDS + 2 * FRING + STAGE) * STPB];
 	__shared__ TileOrder ord;
 	const SegGraph sg = seg_graph(g);
 	const int32_t S = min(segbase[Rtot], Scap);
@@ -373,15 +373,57 @@ __global__ void __launch_bounds__(STPB) k_seg_b(GraphDev g, RangeView v, const R
 			if (ok) {
 				const uint64_t cellBit = (((uint64_t)d.rpos >> SEG_BITS_LOG2) + (uint64_t)i) << SEG_BITS_LOG2;
 				const int64_t abase = g.minInt > 0 ? v.rowstart[s] / g.minInt : 0;
-				uint32_t endRel;
-				ok = seg_b<ZK, STPB>(sg, lds + threadIdx.x, lds + WIN_WORDS * STPB + threadIdx.x, x, cellBit, me.inRel, me.cnt, p.x - p0.x, (int32_t)(p.y - p0.y), i == 0,
-				                     v.row(s) + d.copied, v.outd[s] - d.copied, (SegIv *)(arena + abase), d.nIv, endRel);
-				if (!last) ok = ok && endRel == fin[k + 1].inRel + SEG_BITS;
+				uint64_t endBit;
+				ok = seg_flat<ZK, STPB>(sg, lds + threadIdx.x, lds + WIN_WORDS * STPB + threadIdx.x, lds + (WIN_WORDS + 2 * FRING) * STPB + threadIdx.x, x, cellBit + me.inRel, cellBit + SEG_BITS,
+				                        me.cnt, p.x - p0.x, (int32_t)(p.y - p0.y), i == 0, last, v.row(s) + d.copied, v.outd[s] - d.copied, (const SegIv *)(arena + abase), d.nIv, endBit);
+				if (!last) ok = ok && endBit == cellBit + SEG_BITS + fin[k + 1].inRel;
 			}
 			if (!ok) flag[r] = 1;
 		}
 		__syncthreads();
 	}
+}
+
+// ------------------------------------------------------------------------------------------------ short records
+// The records of the parse list's short bins, one lane per record: the structure (struct_lane), then the merged stream of the whole
+// record as ONE piece (seg_flat).  Same list, same sweep order as k_parse_list (bv_kernels.hip), which it replaces for the default
+// codings.  What the bodies do not take goes to a list for the cooperative kernel (ctl[CTL_FLAT]).
+template <int ZK>
+__global__ void __launch_bounds__(STPB) k_parse_flat(GraphDev g, RangeView v, const int32_t *__restrict__ list, const int32_t *__restrict__ keyBase, int32_t keyLo, int32_t keyHi,
+                                                     IvEntry *__restrict__ arena, int64_t arenaCap, int32_t *__restrict__ fblist, int32_t *__restrict__ ctl, int *__restrict__ err) {
+	__shared__ uint32_t lds[(WIN_WORDS + 2 * FRING + STAGE) * STPB];
+	const SegGraph sg = seg_graph(g);
+	const int32_t lo = keyBase[keyLo], hi = keyBase[keyHi], coopMin = v.coopmin();
+	const int64_t G = (int64_t)gridDim.x * STPB, T = (int64_t)blockIdx.x * STPB + threadIdx.x;
+	for (int64_t sweep = 0; sweep * G < (int64_t)hi - lo; sweep++) { // (a snake: the threads that got the longest records of one sweep get the shortest of the next)
+		const int64_t off = sweep * G + ((sweep & 1) ? G - 1 - T : T);
+		if (off >= (int64_t)hi - lo) continue;
+		const int32_t s = list[hi - 1 - off], d = v.outd[s];
+		if (d >= coopMin || d == 0) continue; // decoded by whole waves (k_parse_big) / nothing to decode
+		if (!v.fits(s)) { atomicOr(err, s >= v.nh ? E_CAP : E_HALO); continue; }
+		const int64_t abase = g.minInt > 0 ? v.rowstart[s] / g.minInt : 0;
+		if (g.minInt > 0 && (abase < 0 || abase + d / g.minInt + 1 > arenaCap)) { atomicOr(err, E_FORMAT); continue; }
+		const int32_t rf = v.ref[s], x = v.lo + s;
+		SegIv *iv = (SegIv *)(arena + abase);
+		RecDesc o{};
+		struct_lane<STPB>(sg, lds + threadIdx.x, x, d, rf > 0, rf > 0 ? (int64_t)v.outd[s - rf] : 0, iv, o);
+		bool ok = !(o.flags & RF_FALLBACK);
+		if (ok && d - o.copied > 0) {
+			uint64_t endBit;
+			ok = seg_flat<ZK, STPB>(sg, lds + threadIdx.x, lds + WIN_WORDS * STPB + threadIdx.x, lds + (WIN_WORDS + 2 * FRING) * STPB + threadIdx.x, x, (uint64_t)o.rpos, (uint64_t)g.offsets[x + 1],
+			                        (uint32_t)o.nres, 0, 0, true, true, v.row(s) + o.copied, d - o.copied, iv, o.nIv, endBit);
+		}
+		if (!ok) fblist[atomicAdd(&ctl[CTL_FLAT], 1)] = s;
+	}
+}
+void launch_parse_flat(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int32_t keyHi, int blocks, void *arena, int64_t arenaCap,
+                       int32_t *fblist, int32_t *ctl, int *err, hipStream_t st) {
+	if (v.cnt <= 0 || def == 0) return;
+	(void)hipMemsetAsync(ctl + CTL_FLAT, 0, 4 * sizeof(int32_t), st);
+	if (def == 1) hipLaunchKernelGGL(k_parse_flat<3>, dim3(blocks), dim3(STPB), 0, st, g, v, list, keyBase, 0, keyHi, (IvEntry *)arena, arenaCap, fblist, ctl, err);
+	else hipLaunchKernelGGL(k_parse_flat<0>, dim3(blocks), dim3(STPB), 0, st, g, v, list, keyBase, 0, keyHi, (IvEntry *)arena, arenaCap, fblist, ctl, err);
+	GraphDev g0 = g; g0.segDesc = nullptr;
+	launch_parse_listed(g0, def, v, fblist, ctl, CTL_FLAT, arena, arenaCap, 256, err, st);
 }
 
 // ------------------------------------------------------------------------------------------------ expand
@@ -545,7 +587,6 @@ void launch_seg_chain(const GraphDev &g, int def, const RangeView &v, const int3
 	sg_scan<U2>(P.pair, Scap, P.pre, P.sumsS, st, P.segbase + Rtot);
 	if (def == 1) hipLaunchKernelGGL(k_seg_b<3>, grid, blk, 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.fin, P.pre, a, P.flag);
 	else hipLaunchKernelGGL(k_seg_b<0>, grid, blk, 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.fin, P.pre, a, P.flag);
-	hipLaunchKernelGGL(k_seg_expand, grid, blk, 0, st, v, g.minInt, P.desc, P.segbase, Rtot, Scap, P.seg2rec, a, P.flag);
 	hipLaunchKernelGGL(k_seg_collect, grid, blk, 0, st, recs, RcapM, Rtot, Scap, P.desc, P.nseg, P.segbase, P.flag, P.fblist, ctl);
 	launch_parse_listed(g0, def, v, P.fblist, ctl, CTL_SEG, arena, arenaCap, 256, err, st);
 }

@@ -126,8 +126,10 @@ struct bvg_graph {
 	DevBuf lvlist;
 	DevBuf plist, pkeys, pkey16;
 	DevBuf segbuf, segR; // scratch of the segment pipeline (bv_seg.hip); the residuals of its records, contiguous per record, before they are merged with the intervals
-	int seg = 1;         // BVGPU_SEG=0: never; 1: jobs of >= 4 M arcs; 2: always -- records of the long work bins below the wave class go through the segment pipeline instead of k_parse_list
+	int seg = 0;         // BVGPU_SEG=0 (default: on C2 the pipeline is bit-exact but not yet faster than the kernels it replaces -- DESIGN section 6): never; 1: jobs of >= 4 M arcs; 2: always -- records of the long work bins below the wave class go through the segment pipeline instead of k_parse_list
 	int seg_blocks = 2048;
+	int flat = 0;        // BVGPU_FLAT=1: the short records by k_parse_flat (the segment pipeline's bodies: structure, then the record's merged stream with 64-byte stores) instead of k_parse_list
+	DevBuf flatfb;       // records k_parse_flat leaves to the cooperative kernel
 	int seg_handover = 1; // BVGPU_SEG_HANDOVER=0: the cooperative kernels decode the residuals of their records themselves
 	int tile = -1;       // -1: automatic (see enqueue_decode); BVGPU_TILE=0: never; BVGPU_TILE=1: short records decoded from contiguous tiles of the stream (k_parse_tile) instead of the bin-sorted parse list (k_parse_list)
 	DevBuf tilebounds;
@@ -141,6 +143,7 @@ struct bvg_graph {
 	DevBuf bigtmp; // global scratch tables for rows that copy more ids than the LDS tables of k_copy_big hold
 	DevBuf stats; // BVGPU_STATS=1: tuning counters
 	// the three parse kernels (giant / big / short records) are independent: they run on forked streams
+	hipStream_t sideC = nullptr; // the segment pipeline's own stream when the cooperative kernels keep their residuals (BVGPU_SEG_HANDOVER=0): a fourth chain of kernels
 	hipStream_t sideA = nullptr, sideB = nullptr; // (more streams than this share hardware queues with each other: they would serialise)
 	bool ctl_clean = false;                       // ctl[4..16) were zeroed by this job's k_pick_coop
 	bool host_mode = false;                       // host_scan: sideB carries the PCIe copies, its kernels go to sideA
@@ -225,6 +228,7 @@ int init_handle(bvg_graph *g) {
 	if (const char *e = getenv("BVGPU_TILE")) g->tile = atoi(e);
 	if (const char *e = getenv("BVGPU_SEG")) g->seg = atoi(e);
 	if (const char *e = getenv("BVGPU_SEG_BLOCKS")) g->seg_blocks = std::max(1, atoi(e));
+	if (const char *e = getenv("BVGPU_FLAT")) g->flat = atoi(e);
 	if (const char *e = getenv("BVGPU_SEG_HANDOVER")) g->seg_handover = atoi(e);
 	if (const char *e = getenv("BVGPU_WALK_TABLES")) g->walk_tables = atoi(e);
 	if (const char *e = getenv("BVGPU_IV_ARENA")) g->iv_arena = atoi(e);
@@ -234,6 +238,7 @@ int init_handle(bvg_graph *g) {
 	if (const char *e = getenv("BVGPU_BATCH_DENSE")) g->batch_dense = std::max(0, atoi(e));
 	HIPCHK(g, hipStreamCreateWithFlags(&g->sideA, hipStreamNonBlocking));
 	HIPCHK(g, hipStreamCreateWithFlags(&g->sideB, hipStreamNonBlocking));
+	HIPCHK(g, hipStreamCreateWithFlags(&g->sideC, hipStreamNonBlocking));
 	g->copyStream = g->sideB; // a fourth stream would share a hardware queue with one of the other three (GPU_MAX_HW_QUEUES = 4, one is the null stream's):
 	                          // its copies then hold back the kernels queued behind them -- measured: every chunk of a host scan took decode + copy, 25 ms instead of 17
 	for (int i = 0; i < 2; i++) { HIPCHK(g, hipEventCreateWithFlags(&g->evChunk[i], hipEventDisableTiming)); HIPCHK(g, hipEventCreateWithFlags(&g->evCopied[i], hipEventDisableTiming)); }
@@ -471,7 +476,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		const bool segOn = g->seg && !tiles && s.def != 0 && g->iv_arena && coop && s.seg_long_records >= 0 && (g->seg > 1 || estArcs >= 4000000);
 		const int32_t segKLo = g->parse_windows ? (bv::MAXLVL - 1) * bv::NBIN + bv::PARSE_LONG_BIN : bv::PARSE_LONG_BIN, segKHi = g->parse_windows ? bv::NKEYS : bv::NBIN;
 		int32_t segRcapM = 0, segRtot = 0, segScap = 0;
-		bool segReady = false;
+		bool segReady = false, segJoin = false;
 		if (segOn) {
 			const int64_t bits = s.h_offsets[(size_t)v.lo + v.cnt] - s.h_offsets[(size_t)v.lo];
 			segRcapM = (int32_t)std::min<int64_t>(v.cnt, (bits + 8 * arcsBound) / 2048 + 16); // records with >= 2 048 bits of work (max(bits, 8 successors)): every record with pieces is one
@@ -518,7 +523,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		if (ovl && coop) {
 			HIPCHK(g, hipStreamWaitEvent(g->sideA, g->evC, 0));
 			bv::launch_parse_big(gd, s.def, v, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, g->giant_groups, derr, side_b(g), g->sideA); // (giants, big)
-			if (segReady) HIPCHK(g, hipEventRecord(g->evW, g->sideA)); // (evB: behind the segment pipeline's chain, below)
+			if (segReady && g->seg_handover) HIPCHK(g, hipEventRecord(g->evW, g->sideA)); // (evB: behind the segment pipeline's chain, below)
 			else HIPCHK(g, hipEventRecord(g->evB, side_b(g)));
 		}
 		// ... then, behind the wave class, the chain depth of every record + per-level lists (node order inside a level) +
@@ -542,24 +547,34 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		else {
 			int32_t keyHi = bv::NKEYS;
 			if (segReady) {
-				// here: the structure of the class's own records; on side B, behind the giants and once the wave class has handed its residual sections over: everything else
-				bv::launch_seg_struct(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, segKLo, segKHi, segRcapM, segRtot, segScap, g->segbuf.p, g->arena.p, arenaCap, ctl, g->seg_blocks, derr, g->stream);
-				hipStream_t stChain = g->stream;
-				if (ovl) {
+				// with the hand-over: the structure of the class's own records here; on side B, behind the giants and once the wave class has handed its residual
+				// sections over, everything else.  Without it: the whole pipeline on a stream of its own, beside the three other chains of kernels.
+				hipStream_t stStruct = g->stream, stChain = g->stream;
+				if (ovl && !g->seg_handover) {
+					stStruct = stChain = g->sideC;
+					HIPCHK(g, hipEventRecord(g->evM, g->stream)); // (the parse list and the row starts are ready)
+					HIPCHK(g, hipStreamWaitEvent(stChain, g->evM, 0));
+				}
+				bv::launch_seg_struct(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, segKLo, segKHi, segRcapM, segRtot, segScap, g->segbuf.p, g->arena.p, arenaCap, ctl, g->seg_blocks, derr, stStruct);
+				if (ovl && g->seg_handover) {
 					stChain = side_b(g);
 					HIPCHK(g, hipEventRecord(g->evM, g->stream));
 					HIPCHK(g, hipStreamWaitEvent(stChain, g->evM, 0));
 					HIPCHK(g, hipStreamWaitEvent(stChain, g->evW, 0));
 				}
 				bv::launch_seg_chain(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, segKLo, segKHi, segRcapM, segRtot, segScap, g->segbuf.p, g->arena.p, arenaCap, g->segR.as<int32_t>(), std::max<int64_t>(arcsBound, 1 << 22), ctl, g->seg_blocks, derr, stChain);
-				if (ovl) HIPCHK(g, hipEventRecord(g->evB, stChain));
+				if (ovl && g->seg_handover) HIPCHK(g, hipEventRecord(g->evB, stChain));
+				if (ovl && !g->seg_handover) { HIPCHK(g, hipEventRecord(g->evW, stChain)); segJoin = true; }
 				keyHi = segKLo;
 			}
-			bv::launch_parse_list(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, g->level_blocks, derr, g->stream, g->iv_arena ? g->arena.p : nullptr, arenaCap, keyHi);
+			if (g->flat && s.def != 0 && g->iv_arena && g->flatfb.need(sizeof(int32_t) * (size_t)v.cnt))
+				bv::launch_parse_flat(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, keyHi, g->level_blocks, g->arena.p, arenaCap, g->flatfb.as<int32_t>(), ctl, derr, g->stream);
+			else bv::launch_parse_list(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, g->level_blocks, derr, g->stream, g->iv_arena ? g->arena.p : nullptr, arenaCap, keyHi);
 		}
 		if (ovl) {
 			HIPCHK(g, hipStreamWaitEvent(g->stream, g->evA, 0));
 			if (coop) HIPCHK(g, hipStreamWaitEvent(g->stream, g->evB, 0));
+			if (segJoin) HIPCHK(g, hipStreamWaitEvent(g->stream, g->evW, 0));
 		}
 		mark(g, 6);
 		if (W > 0) {
@@ -1038,7 +1053,7 @@ extern "C" int bvg_close(bvg_t *g) {
 		if (g->h_small) (void)hipHostFree(g->h_small);
 		for (auto &e : g->ev) if (e) (void)hipEventDestroy(e);
 		for (hipEvent_t e : { g->evFork, g->evA, g->evB, g->evC, g->evHdr, g->evP, g->evW, g->evM, g->evIn, g->evOut }) if (e) (void)hipEventDestroy(e);
-		for (hipStream_t st : { g->sideA, g->sideB }) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+		for (hipStream_t st : { g->sideA, g->sideB, g->sideC }) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
 	}
 	delete g;
 	return BVG_OK;
