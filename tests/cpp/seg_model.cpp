@@ -125,8 +125,8 @@ int seg_model_run(const uint8_t *graph, uint64_t nbytes, const int64_t *offsets,
 	// scan
 	pc[0] = ps[0] = 0;
 	for (int32_t sg = 0; sg < S; sg++) { pc[sg + 1] = pc[sg] + fin[sg].cnt; ps[sg + 1] = ps[sg] + fin[sg].sum; }
-	// B: the merged stream of every piece (residuals and the intervals they pass), straight into the row
-	std::vector<uint32_t> ringv(2 * FRING), stagev(STAGE);
+	// B
+	std::vector<uint32_t> ringv(2 * RING);
 	for (int32_t sg = 0; sg < S; sg++) {
 		const int32_t r = seg2rec[sg];
 		if (flag[r]) continue; // (on the GPU a record may be flagged while its other pieces are already being written: harmless, the cooperative kernel rewrites the row)
@@ -139,12 +139,19 @@ int seg_model_run(const uint8_t *graph, uint64_t nbytes, const int64_t *offsets,
 			uint64_t cell; uint32_t a, b;
 			span(sg, cell, a, b);
 			int32_t *out = succ + (rowstart[s] - rowstart[0]) + desc[r].copied;
-			uint64_t endBit;
-			ok = zk == 3 ? seg_flat<3, 1>(g, col, ringv.data(), stagev.data(), lo + s, cell + me.inRel, cell + SEG_BITS, me.cnt, pc[sg] - pc[k0], (int32_t)(ps[sg] - ps[k0]), i == 0, last, out, outd[s] - desc[r].copied, iv_of(s), desc[r].nIv, endBit)
-			             : seg_flat<0, 1>(g, col, ringv.data(), stagev.data(), lo + s, cell + me.inRel, cell + SEG_BITS, me.cnt, pc[sg] - pc[k0], (int32_t)(ps[sg] - ps[k0]), i == 0, last, out, outd[s] - desc[r].copied, iv_of(s), desc[r].nIv, endBit);
-			if (!last) ok = ok && endBit == cell + SEG_BITS + fin[sg + 1].inRel;
+			uint32_t endRel;
+			ok = zk == 3 ? seg_b<3, 1>(g, col, ringv.data(), lo + s, cell, me.inRel, me.cnt, pc[sg] - pc[k0], (int32_t)(ps[sg] - ps[k0]), i == 0, out, outd[s] - desc[r].copied, iv_of(s), desc[r].nIv, endRel)
+			             : seg_b<0, 1>(g, col, ringv.data(), lo + s, cell, me.inRel, me.cnt, pc[sg] - pc[k0], (int32_t)(ps[sg] - ps[k0]), i == 0, out, outd[s] - desc[r].copied, iv_of(s), desc[r].nIv, endRel);
+			if (!last) ok = ok && endRel == fin[sg + 1].inRel + SEG_BITS;
 		}
 		if (!ok) { flag[r] = 1; if (getenv("SEG_MODEL_TRACE")) fprintf(stderr, "B: slot %d piece %d/%d mode %u cnt %u\n", s, i, segbase[r + 1] - k0, me.mode, me.cnt); }
+	}
+	// expand
+	for (size_t r = 0; r < R; r++) {
+		if (flag[r] || (desc[r].flags & RF_FALLBACK) || desc[r].nres <= 0) continue;
+		const int32_t s = desc[r].slot;
+		int32_t *out = succ + (rowstart[s] - rowstart[0]) + desc[r].copied;
+		for (int32_t i = 0; i < desc[r].nIv; i++) expand_interval(iv_of(s)[i], desc[r].nres, out, outd[s] - desc[r].copied);
 	}
 	// what is left: flagged records -> the cooperative kernel; records without residuals have their intervals expanded by the struct lane
 	for (size_t r = 0; r < R; r++) {

@@ -46,6 +46,39 @@ def c2():
     g.close()
 
 
+@pytest.mark.timeout(1500)
+def test_more_than_two_gib_of_successors():
+    """North star size class: a scan whose successor array does not fit 2^31 bytes (27.5 M nodes / 550 M arcs = 2.2 GB of
+    int32; the 1 B-edge run itself is profiles/r4_bench_1B*.json) -- exactly where a stray 32-bit index would show
+    (BVGraph.java:1562-1568 is the reference's own path for graphs beyond 2 GiB).  hashCode() and sampled rows against the
+    CPU oracle, strict sortedness of every row on the device."""
+    import torch
+    from oracle import oracle as O
+    from webgraph_amd.bvgraph import BVGraph
+    cfg = dict(n=27_500_000, m=550_000_000, seed=0x5EEDB5E70001, p_copy=0.5, p_same=0.0, p_keep=0.7)
+    base = _prepare(cfg)
+    g = BVGraph.load(base)
+    og = O.OracleGraph.load(base)
+    rowptr, succ, arcs = _device_scan(g)
+    assert arcs == cfg["m"] and succ.numel() * 4 > 2 ** 31
+    assert int(rowptr[-1]) == arcs
+    bad = (succ[1:arcs] <= succ[:arcs - 1]).nonzero().flatten() + 1  # the only non-increasing neighbours sit on row boundaries
+    starts = torch.zeros(arcs + 1, dtype=torch.bool, device=succ.device)
+    starts[rowptr.clamp(max=arcs)] = True
+    assert bool(starts[bad].all())
+    del bad, starts
+    assert g.csr_hashcode(0, cfg["n"], rowptr.data_ptr(), succ.data_ptr(), -1) == og.hashcode_mt()
+    rng = np.random.Generator(np.random.PCG64(11))
+    q = np.sort(np.concatenate([rng.integers(0, cfg["n"], size=4000), np.arange(cfg["n"] - 64, cfg["n"])])).astype(np.int32)
+    orp, osc = og.successors_batch(q)
+    rp = rowptr.cpu().numpy()
+    for i, x in enumerate(q):  # (rows at the far end of the array: offsets beyond 2^31 bytes)
+        a, b = int(rp[x]), int(rp[x + 1])
+        assert b - a == orp[i + 1] - orp[i] and np.array_equal(succ[a:b].cpu().numpy(), osc[orp[i]:orp[i + 1]])
+    og.close()
+    g.close()
+
+
 @pytest.mark.timeout(900)
 def test_c2_full_size_default_thresholds(c2):
     """The headline configuration, whole: 200 M arcs.  The thresholds are the full-scan ones: a wave per record from 2 048

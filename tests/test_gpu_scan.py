@@ -305,6 +305,15 @@ LONG_ROW_CASES = [
     ("zeta7", 0, 7, {}),  # codewords outgrow the 32-bit window early: the 64-bit and generic fallbacks run
     ("zeta16", 0, 16, {}),
     ("zeta5_small_thresholds", 0, 5, {"BVGPU_COOP_MIN": "64", "BVGPU_GIANT_MIN": "2000"}),
+    # the segment pipeline (bv_seg.hip; off by default): residual sections in pieces of stream, with and without the hand-over from the cooperative kernels
+    ("seg", 0, 3, {"BVGPU_SEG": "2"}),
+    ("seg_own_records_only", 0, 3, {"BVGPU_SEG": "2", "BVGPU_SEG_HANDOVER": "0"}),
+    ("seg_serial", 0, 3, {"BVGPU_SEG": "2", "BVGPU_OVERLAP": "0"}),
+    ("seg_small_thresholds", 0, 3, {"BVGPU_SEG": "2", "BVGPU_COOP_MIN": "64", "BVGPU_GIANT_MIN": "2000"}),
+    ("seg_zeta5", 0, 5, {"BVGPU_SEG": "2"}),
+    ("seg_zeta1", 0, 1, {"BVGPU_SEG": "2"}),
+    ("seg_zeta7_flat", 0, 7, {"BVGPU_SEG": "2", "BVGPU_FLAT": "1"}),
+    ("flat", 0, 3, {"BVGPU_FLAT": "1"}),  # the short records by k_parse_flat
     ("batch_dense", 0, 3, {"BVGPU_BATCH_DENSE": "1000000000"}),  # random access as a masked scan + gather
     ("batch_dense_small_thresholds", 0, 3, {"BVGPU_BATCH_DENSE": "1000000000", "BVGPU_COOP_MIN": "64", "BVGPU_GIANT_MIN": "2000"}),
 ]
@@ -335,6 +344,74 @@ def test_long_rows_with_references(tmp_path_factory, monkeypatch, case):
     orp, osc = og.successors_batch(q)
     assert np.array_equal(rp, orp) and np.array_equal(sc, osc)
     assert g.hashCode() == og.hashcode()
+    g.close()
+
+
+@pytest.mark.parametrize("env", [{"BVGPU_SEG": "2"}, {"BVGPU_SEG": "2", "BVGPU_SEG_HANDOVER": "0"}, {"BVGPU_SEG": "2", "BVGPU_FLAT": "1"}], ids=["seg", "own", "flat"])
+def test_segment_pipeline_on_streams_that_never_resynchronise(tmp_path, monkeypatch, env):
+    """A piece of a residual section is decoded from a guessed start and trusted only once its chain of codewords has met
+    the true one.  Rows whose gaps are all alike repeat one codeword for ever (gap 7 is zeta_3 '1111'): a chain that starts
+    off a boundary never meets the true one.  The fix pass walks such rows piece by piece, or the record goes to the
+    cooperative kernel -- either way the rows come out right."""
+    from webgraph_amd import tools as T
+    from webgraph_amd.bvgraph import BVGraph
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    n = 400000
+    rows = [np.empty(0, dtype=np.int64) for _ in range(n)]
+    rows[10] = np.arange(3, 3 + 7 * 50000, 7)                       # 50 000 codewords '1111'
+    rows[11] = np.arange(5, 5 + 3 * 100000, 3)                      # 100 000 codewords of 4 bits, another phase
+    rows[12] = np.concatenate([np.arange(0, 9 * 3000, 9), np.arange(30000, 30000 + 2 * 40000, 2)])  # two periods in one row
+    rows[500] = np.arange(1, 1 + 1000 * 300, 1000)                   # 300 long codewords
+    rng = np.random.Generator(np.random.PCG64(3))
+    rows[501] = np.unique(rng.integers(0, n, size=20000))            # an ordinary long row next to them
+    for y in rng.integers(0, n, size=3000):
+        if rows[y].size == 0:
+            rows[y] = np.unique(rng.integers(0, n, size=rng.integers(1, 40)))
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    rowptr[1:] = np.cumsum([r.size for r in rows])
+    succ = np.concatenate(rows).astype(np.int32)
+    base = str(tmp_path / "periodic")
+    T.store(base, rowptr, succ, window=7, max_ref_count=3, min_interval=4, zeta_k=3)
+    g = BVGraph.load(base)
+    rp, sc = g.decode_range()
+    assert np.array_equal(rp, rowptr) and np.array_equal(sc, succ)
+    g.close()
+
+
+@pytest.mark.parametrize("env", [{}, {"BVGPU_SEG": "0"}, {"BVGPU_SEG": "3", "BVGPU_SEG_HUB_MIN": "50000"}], ids=["auto", "off", "forced"])
+def test_hub_rows_hand_their_residuals_to_the_segment_pipeline(tmp_path, monkeypatch, env):
+    """A social-graph shape: a few rows with more than a million successors.  By default such records (>= BVGPU_SEG_HUB_MIN
+    successors) have only their structure parsed by their group of waves; the residual section is cut into pieces of stream
+    and decoded by one lane per piece (bv_seg.hip), so that the scan does not last as long as its longest record."""
+    from webgraph_amd import tools as T
+    from webgraph_amd.bvgraph import BVGraph
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    n = 3_000_000
+    rowptr, succ = T.generate(n, 6_000_000, seed=31, p_copy=0.5)
+    rng = np.random.Generator(np.random.PCG64(5))
+    hubs = {12345: np.unique(rng.integers(0, n, size=1_600_000)), 12347: None, 2_000_000: np.unique(rng.integers(0, n, size=90_000))}
+    hubs[12347] = np.unique(np.concatenate([hubs[12345][::3], rng.integers(0, n, size=200_000)]))  # copies from the hub two nodes before it
+    deg = np.diff(rowptr)
+    for x, r in hubs.items():
+        deg[x] = r.size
+    rp = np.zeros(n + 1, dtype=np.int64)
+    rp[1:] = np.cumsum(deg)
+    out = np.empty(rp[-1], dtype=np.int32)
+    prev = 0
+    for x in sorted(hubs):
+        out[rp[prev]:rp[x]] = succ[rowptr[prev]:rowptr[x]]
+        out[rp[x]:rp[x + 1]] = hubs[x]
+        prev = x + 1
+    out[rp[prev]:] = succ[rowptr[prev]:]
+    base = str(tmp_path / "hubs")
+    T.store(base, rp, out, window=7, max_ref_count=3, min_interval=4, zeta_k=3, threads=4)
+    g = BVGraph.load(base)
+    got_rp, got = g.decode_range()
+    assert np.array_equal(got_rp, rp) and np.array_equal(got, out)
+    got_rp, got = g.decode_range(12346, 2_500_000)  # the second hub's referent comes in through the halo
+    assert np.array_equal(got, out[rp[12346]:rp[2_500_000]])
     g.close()
 
 

@@ -44,6 +44,7 @@ struct GraphDev {
 	void *segDesc;
 	int32_t *segNseg, *segFlag;
 	int32_t segOff[2], segCap[2];
+	int32_t segMinD; // only records with at least this many successors are handed over
 };
 
 // tuning counters: 0 tiles(residual) 1 rounds(residual) 2 tiles(interval) 3 rounds(interval) 4 lane-parses 5 big nodes 6 clock ticks in coop nodes 7 max ticks of one node

@@ -868,7 +868,7 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 // parse pass over a list sorted by work bin only (all chain levels together): 64 records of similar length per wave
 template <int DEF, bool ARENA>
 __global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, const int32_t *__restrict__ list, const int32_t *__restrict__ keyBase, int32_t binLo, int32_t binHi,
-                                                    IvEntry *__restrict__ arena, int64_t arenaCap, int *__restrict__ err) {
+                                                    IvEntry *__restrict__ arena, int64_t arenaCap, int *__restrict__ err, int32_t dMax) {
 	__shared__ uint32_t lw[DEF ? (ARENA ? (LW_MAIN + 2 * LW_RING) * LW_STRIDE : LW_LDS_WORDS) : 1]; // lane-private stream windows, or one window and a ring of intervals (default codings)
 	const int32_t lo = keyBase[binLo], hi = keyBase[binHi], coopMin = v.coopmin();
 	// The list is sorted longest first.  Thread T takes entries T, 2G-1-T, 2G+T, 4G-1-T, ... (G = threads in the
@@ -880,7 +880,7 @@ __global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, con
 		const int32_t idx = (int32_t)(hi - 1 - off);
 		const int32_t s = list[idx];
 		const int32_t d = v.outd[s];
-		if (d >= coopMin || d == 0) continue; // decoded by whole waves (k_parse_big) / nothing to decode
+		if (d >= coopMin || d >= dMax || d == 0) continue; // decoded by whole waves (k_parse_big) / by the segment pipeline (bv_seg.hip) / nothing to decode
 		const int32_t r = v.ref[s];
 		if (!v.fits(s)) { atomicOr(err, s >= v.nh ? E_CAP : E_HALO); continue; }
 		if (DEF && ARENA) {
@@ -1004,7 +1004,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? COOP1_MINWAVES : COOPG_MINW
 		// (scans only) the residual section of the record is handed to the segment pipeline: descriptor idx of this queue's part
 		bvsg::RecDesc *segOut = nullptr;
 		// (only records of the long work bins, >= 2 048 bits of work: the pipeline's scratch is sized for those)
-		if (std::is_same<View, RangeView>::value && DEF != 0 && which < 2 && g.segDesc && idx < g.segCap[which] &&
+		if (std::is_same<View, RangeView>::value && DEF != 0 && which < 2 && g.segDesc && idx < g.segCap[which] && rec.d >= g.segMinD &&
 		    ((uint64_t)rec.d * 8 >= 2048 || (uint64_t)(g.offsets[rec.x + 1] - g.offsets[rec.x]) >= 2048)) {
 			segOut = (bvsg::RecDesc *)g.segDesc + g.segOff[which] + idx;
 			if (threadIdx.x == 0) { *segOut = bvsg::RecDesc{ 0, list[idx], 0, 0, 0, bvsg::RF_SKIP, 0 }; g.segFlag[g.segOff[which] + idx] = 0; }
@@ -1527,14 +1527,14 @@ void launch_parse_listed(const GraphDev &g, int def, const RangeView &v, const i
 	else hipLaunchKernelGGL((k_parse_big<0, 1, RangeView>), dim3(waves), dim3(64), 0, st, g, v, list, ctl, which, (IvEntry *)arena, arenaCap, err);
 }
 
-void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, void *arena, int64_t arenaCap, int32_t keyHi) {
+void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, void *arena, int64_t arenaCap, int32_t keyHi, int32_t dMax) {
 	if (v.cnt <= 0) return;
 	IvEntry *a = (IvEntry *)arena;
-	if (def == 1 && a) hipLaunchKernelGGL((k_parse_list<1, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, keyHi, a, arenaCap, err);
-	else if (def == 2 && a) hipLaunchKernelGGL((k_parse_list<2, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, keyHi, a, arenaCap, err);
-	else if (def == 1) hipLaunchKernelGGL((k_parse_list<1, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, keyHi, a, arenaCap, err);
-	else if (def == 2) hipLaunchKernelGGL((k_parse_list<2, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, keyHi, a, arenaCap, err);
-	else hipLaunchKernelGGL((k_parse_list<0, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, keyHi, a, arenaCap, err);
+	if (def == 1 && a) hipLaunchKernelGGL((k_parse_list<1, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, keyHi, a, arenaCap, err, dMax);
+	else if (def == 2 && a) hipLaunchKernelGGL((k_parse_list<2, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, keyHi, a, arenaCap, err, dMax);
+	else if (def == 1) hipLaunchKernelGGL((k_parse_list<1, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, keyHi, a, arenaCap, err, dMax);
+	else if (def == 2) hipLaunchKernelGGL((k_parse_list<2, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, keyHi, a, arenaCap, err, dMax);
+	else hipLaunchKernelGGL((k_parse_list<0, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, keyHi, a, arenaCap, err, dMax);
 }
 
 } // namespace bv

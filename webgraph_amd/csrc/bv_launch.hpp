@@ -76,7 +76,7 @@ void launch_build_lists(const GraphDev &g, const RangeView &v, uint64_t giantBit
 void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int32_t *depth, const int32_t *list, const int32_t *keyBase, int32_t level, int blocks,
                        int32_t midMinKnob, bool bigGroups, const int32_t *bigQ, int32_t bigCap, const int32_t *midQ, int32_t midCap, int32_t *ctl, int32_t *tmp, uint32_t tmpCap, int *err,
                        hipStream_t st, hipStream_t stMid, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evMid, hipEvent_t evBig);
-void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, void *arena = nullptr, int64_t arenaCap = 0, int32_t keyHi = NKEYS);
+void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, void *arena = nullptr, int64_t arenaCap = 0, int32_t keyHi = NKEYS, int32_t dMax = 0x7fffffff); // records with >= dMax successors are somebody else's
 // one wave per record of `list` (ctl[which] entries, queue head ctl[which + 2]): k_parse_big<1>
 void launch_parse_listed(const GraphDev &g, int def, const RangeView &v, const int32_t *list, int32_t *ctl, int which, void *arena, int64_t arenaCap, int waves, int *err, hipStream_t st);
 // bv_seg.hip: the segment pipeline for the records of the parse list's keys [kLo, kHi) that have fewer than coop_min successors
@@ -85,12 +85,12 @@ constexpr int PARSE_LONG_BIN = 14; // work bins from here up (>= 2048 bits of wo
 void launch_parse_flat(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int32_t keyHi, int blocks, void *arena, int64_t arenaCap,
                        int32_t *fblist, int32_t *ctl, int *err, hipStream_t st);
 size_t seg_scratch_bytes(int32_t Rtot, int32_t Scap, int zetaK);
-void launch_seg_sizing(const int64_t *offsets, int32_t lo, int32_t n, const int32_t *outd, unsigned long long *out2, hipStream_t st); // load time: records of the long work bins, their bits
+void launch_seg_sizing(const int64_t *offsets, int32_t lo, int32_t n, const int32_t *outd, unsigned long long *out3, hipStream_t st); // load time: records of the long work bins, their bits, the largest outdegree
 int32_t seg_bits_log2();
 // records of the pipeline: [0, RcapM) the parse list's long bins, then capBig / capGiant hand-over slots of the cooperative kernels' queues (Rtot = the sum)
-void seg_handover(GraphDev &g, void *scratch, int32_t RcapM, int32_t capBig, int32_t capGiant, int32_t Scap, hipStream_t st);
+void seg_handover(GraphDev &g, void *scratch, int32_t RcapM, int32_t capBig, int32_t capGiant, int32_t Scap, int32_t minD, hipStream_t st); // minD: records with fewer successors are not handed over
 void launch_seg_struct(const GraphDev &g, int def, const RangeView &v, const int32_t *plist, const int32_t *keyBase, int32_t kLo, int32_t kHi, int32_t RcapM, int32_t Rtot, int32_t Scap,
-                       void *scratch, void *arena, int64_t arenaCap, int32_t *ctl, int blocks, int *err, hipStream_t st);
+                       void *scratch, void *arena, int64_t arenaCap, int32_t *ctl, int blocks, int *err, hipStream_t st, int32_t dMin = 0); // dMin: the class's own records have at least that many successors
 void launch_seg_chain(const GraphDev &g, int def, const RangeView &v, const int32_t *plist, const int32_t *keyBase, int32_t kLo, int32_t kHi, int32_t RcapM, int32_t Rtot, int32_t Scap,
                       void *scratch, void *arena, int64_t arenaCap, int32_t *R, int64_t Rcap, int32_t *ctl, int blocks, int *err, hipStream_t st); // R: Rcap ints of scratch, >= the arcs of the view
 void launch_parse_waves(const GraphDev &g, int def, const RangeView &v, const int32_t *biglist, int32_t *ctl, void *arena, int64_t arenaCap, int waves, int *err, hipStream_t st);

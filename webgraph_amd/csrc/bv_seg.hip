@@ -29,7 +29,7 @@ struct SegRecs {
 
 // ------------------------------------------------------------------------------------------------ struct
 __global__ void __launch_bounds__(STPB) k_seg_struct(GraphDev g, RangeView v, SegRecs recs, int32_t Rcap, RecDesc *__restrict__ desc, int32_t *__restrict__ nseg,
-                                                     int32_t *__restrict__ flag, IvEntry *__restrict__ arena, int64_t arenaCap, int32_t *__restrict__ ctl, int *__restrict__ err) {
+                                                     int32_t *__restrict__ flag, IvEntry *__restrict__ arena, int64_t arenaCap, int32_t *__restrict__ ctl, int *__restrict__ err, int32_t dMin) {
 	__shared__ uint32_t lds[WIN_WORDS * STPB];
 	if (blockIdx.x == 0 && threadIdx.x < 4) ctl[CTL_SEG + threadIdx.x] = 0; // count and queue head of the flagged records (k_seg_collect, k_parse_big)
 	const SegGraph sg = seg_graph(g);
@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(STPB) k_seg_struct(GraphDev g, RangeView v, Se
 			RecDesc o{};
 			o.slot = s;
 			o.flags = RF_SKIP;
-			if (d > 0 && d < coopMin) { // (longer records: the cooperative kernels)
+			if (d > 0 && d < coopMin && d >= dMin) { // (longer records: the cooperative kernels; shorter ones: k_parse_list)
 				const int32_t rf = v.ref[s];
 				const int64_t abase = g.minInt > 0 ? v.rowstart[s] / g.minInt : 0;
 				if (!v.fits(s)) atomicOr(err, s >= v.nh ? E_CAP : E_HALO);
@@ -349,7 +349,7 @@ template <int ZK>
 __global__ void __launch_bounds__(STPB) k_seg_b(GraphDev g, RangeView v, const RecDesc *__restrict__ desc, const int32_t *__restrict__ segbase, int32_t Rtot, int32_t Scap,
                                                 const int32_t *__restrict__ seg2rec, const SegFin *__restrict__ fin, const U2 *__restrict__ pre,
                                                 IvEntry *__restrict__ arena, int32_t *__restrict__ flag) {
-	__shared__ uint32_t lds[(WIN_WORDS + 2 * FRING + STAGE) * STPB];
+	__shared__ uint32_t lds[(WIN_WORDS + 2 * RING) * STPB];
 	__shared__ TileOrder ord;
 	const SegGraph sg = seg_graph(g);
 	const int32_t S = min(segbase[Rtot], Scap);
@@ -373,10 +373,10 @@ __global__ void __launch_bounds__(STPB) k_seg_b(GraphDev g, RangeView v, const R
 			if (ok) {
 				const uint64_t cellBit = (((uint64_t)d.rpos >> SEG_BITS_LOG2) + (uint64_t)i) << SEG_BITS_LOG2;
 				const int64_t abase = g.minInt > 0 ? v.rowstart[s] / g.minInt : 0;
-				uint64_t endBit;
-				ok = seg_flat<ZK, STPB>(sg, lds + threadIdx.x, lds + WIN_WORDS * STPB + threadIdx.x, lds + (WIN_WORDS + 2 * FRING) * STPB + threadIdx.x, x, cellBit + me.inRel, cellBit + SEG_BITS,
-				                        me.cnt, p.x - p0.x, (int32_t)(p.y - p0.y), i == 0, last, v.row(s) + d.copied, v.outd[s] - d.copied, (const SegIv *)(arena + abase), d.nIv, endBit);
-				if (!last) ok = ok && endBit == cellBit + SEG_BITS + fin[k + 1].inRel;
+				uint32_t endRel;
+				ok = seg_b<ZK, STPB>(sg, lds + threadIdx.x, lds + WIN_WORDS * STPB + threadIdx.x, x, cellBit, me.inRel, me.cnt, p.x - p0.x, (int32_t)(p.y - p0.y), i == 0,
+				                     v.row(s) + d.copied, v.outd[s] - d.copied, (SegIv *)(arena + abase), d.nIv, endRel);
+				if (!last) ok = ok && endRel == fin[k + 1].inRel + SEG_BITS;
 			}
 			if (!ok) flag[r] = 1;
 		}
@@ -532,21 +532,26 @@ __global__ void __launch_bounds__(STPB) k_seg_sizing(const int64_t *__restrict__
 	if (threadIdx.x < 2) s_acc[threadIdx.x] = 0;
 	__syncthreads();
 	unsigned long long recs = 0, bits = 0;
+	int32_t mx = 0;
 	for (int32_t s = blockIdx.x * STPB + threadIdx.x; s < n; s += gridDim.x * STPB) {
+		mx = max(mx, outd[s]);
 		const uint64_t b = (uint64_t)(offsets[lo + s + 1] - offsets[lo + s]);
 		if (outd[s] > 0 && (b >= 2048 || (uint64_t)outd[s] * 8 >= 2048)) { recs++; bits += b; }
 	}
-	for (int o = 32; o > 0; o >>= 1) { recs += __shfl_down(recs, o, 64); bits += __shfl_down(bits, o, 64); }
+	for (int o = 32; o > 0; o >>= 1) { recs += __shfl_down(recs, o, 64); bits += __shfl_down(bits, o, 64); mx = max(mx, __shfl_down(mx, o, 64)); }
+	mx = (threadIdx.x & 63) == 0 ? mx : 0;
 	if ((threadIdx.x & 63) == 0) { atomicAdd(&s_acc[0], recs); atomicAdd(&s_acc[1], bits); }
 	__syncthreads();
 	if (threadIdx.x < 2 && s_acc[threadIdx.x]) atomicAdd(&out[threadIdx.x], s_acc[threadIdx.x]);
+	if (mx) atomicMax(&out[2], (unsigned long long)mx); // (the longest record: out[2])
 }
 void launch_seg_sizing(const int64_t *offsets, int32_t lo, int32_t n, const int32_t *outd, unsigned long long *out2, hipStream_t st) {
 	if (n > 0) hipLaunchKernelGGL(k_seg_sizing, dim3(1024), dim3(STPB), 0, st, offsets, lo, n, outd, out2);
 }
 
 // the hand-over slots of the cooperative kernels (GraphDev::segDesc ...); the counts of their parts are zeroed on `st`
-void seg_handover(GraphDev &g, void *scratch, int32_t RcapM, int32_t capBig, int32_t capGiant, int32_t Scap, hipStream_t st) {
+void seg_handover(GraphDev &g, void *scratch, int32_t RcapM, int32_t capBig, int32_t capGiant, int32_t Scap, int32_t minD, hipStream_t st) {
+	g.segMinD = minD;
 	const int32_t Rtot = RcapM + capBig + capGiant;
 	const SegPtrs P = seg_ptrs(scratch, Rtot, Scap, seg_cell_cap(g.zetaK));
 	g.segDesc = P.desc; g.segNseg = P.nseg; g.segFlag = P.flag;
@@ -557,10 +562,10 @@ void seg_handover(GraphDev &g, void *scratch, int32_t RcapM, int32_t capBig, int
 
 // the structure of the class's own records (needs the parse list and the row starts)
 void launch_seg_struct(const GraphDev &g, int def, const RangeView &v, const int32_t *plist, const int32_t *keyBase, int32_t kLo, int32_t kHi, int32_t RcapM, int32_t Rtot, int32_t Scap,
-                       void *scratch, void *arena, int64_t arenaCap, int32_t *ctl, int blocks, int *err, hipStream_t st) {
+                       void *scratch, void *arena, int64_t arenaCap, int32_t *ctl, int blocks, int *err, hipStream_t st, int32_t dMin) {
 	if (v.cnt <= 0 || Rtot <= 0 || def == 0) return;
 	const SegPtrs P = seg_ptrs(scratch, Rtot, Scap, seg_cell_cap(g.zetaK));
-	hipLaunchKernelGGL(k_seg_struct, dim3((unsigned)blocks), dim3(STPB), 0, st, g, v, SegRecs{ plist, keyBase, kLo, kHi }, RcapM, P.desc, P.nseg, P.flag, (IvEntry *)arena, arenaCap, ctl, err);
+	hipLaunchKernelGGL(k_seg_struct, dim3((unsigned)blocks), dim3(STPB), 0, st, g, v, SegRecs{ plist, keyBase, kLo, kHi }, RcapM, P.desc, P.nseg, P.flag, (IvEntry *)arena, arenaCap, ctl, err, dMin);
 }
 
 // everything behind the descriptors (the class's own and the cooperative kernels')
@@ -587,6 +592,7 @@ void launch_seg_chain(const GraphDev &g, int def, const RangeView &v, const int3
 	sg_scan<U2>(P.pair, Scap, P.pre, P.sumsS, st, P.segbase + Rtot);
 	if (def == 1) hipLaunchKernelGGL(k_seg_b<3>, grid, blk, 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.fin, P.pre, a, P.flag);
 	else hipLaunchKernelGGL(k_seg_b<0>, grid, blk, 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.fin, P.pre, a, P.flag);
+	hipLaunchKernelGGL(k_seg_expand, grid, blk, 0, st, v, g.minInt, P.desc, P.segbase, Rtot, Scap, P.seg2rec, a, P.flag);
 	hipLaunchKernelGGL(k_seg_collect, grid, blk, 0, st, recs, RcapM, Rtot, Scap, P.desc, P.nseg, P.segbase, P.flag, P.fblist, ctl);
 	launch_parse_listed(g0, def, v, P.fblist, ctl, CTL_SEG, arena, arenaCap, 256, err, st);
 }

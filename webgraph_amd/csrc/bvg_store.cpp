@@ -28,7 +28,8 @@ bool one_of(int c, std::initializer_list<int> ok) { for (int v : ok) if (c == v)
 
 // setFlags (BVGraph.java:1317-1325) + the codings the writer accepts (writeOutdegree/writeReference/... :1839-2030)
 int make_params(int window, int max_ref_count, int min_interval, int zeta_k, uint32_t flags, int threads, int32_t n, bve::Params &p, std::string &err) {
-	if (window < 0 || max_ref_count < 0 || min_interval < 0 || zeta_k < 1 || threads < 1) { err = "negative window / maxrefcount / minintervallength, zetak < 1 or threads < 1"; return BVG_EARG; }
+	if (window < 0 || max_ref_count < 0 || min_interval < 0 || zeta_k < 1) { err = "negative window / maxrefcount / minintervallength or zetak < 1"; return BVG_EARG; }
+	if (threads <= 0) threads = 1; // numberOfThreads <= 0 means "choose" in the reference (BVGraph.java:2446-2450: the available processors); here the parts only bound the candidates: one
 	p.W = window; p.R = max_ref_count; p.I = min_interval; p.K = zeta_k;
 	p.c_outd = bve::C_GAMMA; p.c_blk = bve::C_GAMMA; p.c_res = bve::C_ZETA; p.c_ref = bve::C_UNARY; p.c_bc = bve::C_GAMMA; p.c_off = bve::C_GAMMA;
 	if (flags & 0xF) p.c_outd = flags & 0xF;
@@ -77,6 +78,7 @@ int compress(int device, int32_t n, const int64_t *rowptr, const int32_t *succ, 
 		if (rowptr[0] != 0) { err = "rowptr must start at 0 and be monotone"; return BVG_EARG; }
 		for (int32_t x = 0; x < n; x++) if (rowptr[x + 1] < rowptr[x]) { err = "rowptr must start at 0 and be monotone"; return BVG_EARG; }
 		m = rowptr[n];
+		if (m && !succ) { err = "null successor array"; return BVG_EARG; } // (before anything is staged)
 		if (hipMalloc((void **)&d_rowptr, sizeof(int64_t) * ((size_t)n + 1)) != hipSuccess || hipMalloc((void **)&d_succ, sizeof(int32_t) * (size_t)(m ? m : 1)) != hipSuccess) {
 			release(); (void)hipGetLastError(); err = "device allocation failed"; return BVG_ENOMEM;
 		}
@@ -252,6 +254,7 @@ extern "C" int bvg_store_ef(const char *basename, int device, int32_t n, const i
 		if (rowptr[0] != 0) return sfail(errbuf, errlen, BVG_EARG, "rowptr must start at 0 and be monotone");
 		for (int32_t x = 0; x < n; x++) if (rowptr[x + 1] < rowptr[x]) return sfail(errbuf, errlen, BVG_EARG, "rowptr must start at 0 and be monotone");
 		m = rowptr[n];
+		if (m && !succ) return sfail(errbuf, errlen, BVG_EARG, "null successor array"); // (before anything is staged)
 		d_rowptr = nullptr; d_succ = nullptr;
 		if (hipMalloc((void **)&d_rowptr, sizeof(int64_t) * ((size_t)n + 1)) != hipSuccess || hipMalloc((void **)&d_succ, sizeof(int32_t) * (size_t)(m ? m : 1)) != hipSuccess) { release(); (void)hipGetLastError(); return sfail(errbuf, errlen, BVG_ENOMEM, "device allocation failed"); }
 		if (hipMemcpy(d_rowptr, rowptr, sizeof(int64_t) * ((size_t)n + 1), hipMemcpyHostToDevice) != hipSuccess || (m && hipMemcpy(d_succ, succ, sizeof(int32_t) * (size_t)m, hipMemcpyHostToDevice) != hipSuccess)) { release(); return sfail(errbuf, errlen, BVG_EHIP, "staging the graph failed"); }

@@ -67,6 +67,7 @@ struct Staged {
 	int32_t node_lo = 0, node_hi = 0, stage_lo = 0; // the nodes this handle decodes / the first node staged
 	std::vector<int64_t> h_offsets; // host copy: shard bounds and halo sizing
 	int64_t arcs_sizing = 0;        // max(arcs property, sum of the outdegrees in the stream): what scratch is sized by
+	int64_t max_outdegree = -1; // the longest staged record (counted with arcs_sizing; -1: unknown)
 	int64_t seg_long_records = -1, seg_long_bits = -1; // staged records with >= 2 048 bits of work (the parse list's long bins) and their bits (counted with arcs_sizing; -1: unknown): they size the segment pipeline
 	int32_t deg_counts[5] = { -1, -1, -1, -1, -1 }; // staged records with >= 128, 256, 512, 1024, 2048 successors (counted with arcs_sizing; -1: unknown)
 	int def = 0;                    // kernel variant: 1 default codings with zeta_3, 2 default codings with another zeta_k, 0 generic
@@ -126,8 +127,13 @@ struct bvg_graph {
 	DevBuf lvlist;
 	DevBuf plist, pkeys, pkey16;
 	DevBuf segbuf, segR; // scratch of the segment pipeline (bv_seg.hip); the residuals of its records, contiguous per record, before they are merged with the intervals
-	int seg = 0;         // BVGPU_SEG=0 (default: on C2 the pipeline is bit-exact but not yet faster than the kernels it replaces -- DESIGN section 6): never; 1: jobs of >= 4 M arcs; 2: always -- records of the long work bins below the wave class go through the segment pipeline instead of k_parse_list
+	int seg = 1;         // BVGPU_SEG: the segment pipeline (bv_seg.hip).  0: never; 1 (default): for the hubs of a job -- the giant records with >= seg_hub_min successors hand their
+	                     // residual sections over, everything else as before; 3: that, whatever the graph holds; 2: everything it can take (the records of the long work bins and every cooperative
+	                     // record: bit-exact, slower than the kernels it replaces on C2 -- DESIGN section 6)
+	int seg_hub_min = 1000000; // BVGPU_SEG_HUB_MIN -- records of the long work bins below the wave class go through the segment pipeline instead of k_parse_list
 	int seg_blocks = 2048;
+	int lists_on_b = 0;  // BVGPU_LISTS_ON_B=1: the chain depths / level lists behind the giants (side B) instead of behind the wave class (side A)
+	int seg_min_d = 0;   // BVGPU_SEG_MIN_D: the pipeline's own records have at least that many successors (the others of the long bins stay with k_parse_list)
 	int flat = 0;        // BVGPU_FLAT=1: the short records by k_parse_flat (the segment pipeline's bodies: structure, then the record's merged stream with 64-byte stores) instead of k_parse_list
 	DevBuf flatfb;       // records k_parse_flat leaves to the cooperative kernel
 	int seg_handover = 1; // BVGPU_SEG_HANDOVER=0: the cooperative kernels decode the residuals of their records themselves
@@ -227,8 +233,11 @@ int init_handle(bvg_graph *g) {
 	if (const char *e = getenv("BVGPU_PARSE_WINDOWS")) g->parse_windows = atoi(e);
 	if (const char *e = getenv("BVGPU_TILE")) g->tile = atoi(e);
 	if (const char *e = getenv("BVGPU_SEG")) g->seg = atoi(e);
+	if (const char *e = getenv("BVGPU_SEG_HUB_MIN")) g->seg_hub_min = std::max(1, atoi(e));
 	if (const char *e = getenv("BVGPU_SEG_BLOCKS")) g->seg_blocks = std::max(1, atoi(e));
 	if (const char *e = getenv("BVGPU_FLAT")) g->flat = atoi(e);
+	if (const char *e = getenv("BVGPU_SEG_MIN_D")) g->seg_min_d = std::max(0, atoi(e));
+	if (const char *e = getenv("BVGPU_LISTS_ON_B")) g->lists_on_b = atoi(e);
 	if (const char *e = getenv("BVGPU_SEG_HANDOVER")) g->seg_handover = atoi(e);
 	if (const char *e = getenv("BVGPU_WALK_TABLES")) g->walk_tables = atoi(e);
 	if (const char *e = getenv("BVGPU_IV_ARENA")) g->iv_arena = atoi(e);
@@ -447,6 +456,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		//   side A: chain depths + per-level lists + copy queues (only the copy pass needs them), then the big records (a wave each);
 		//   here:   the parse list and the one-lane parse of everything else.
 		hipStream_t stLists = g->stream;
+		const bool listsOnB = g->lists_on_b && !(g->seg && g->seg_handover); // (with the hand-over side B carries the segment pipeline's chain)
 		// parse list (every non-empty record, sorted by work bin inside windows of nodes): needs the outdegrees only, so
 		// with the headers' event at hand it is built on side A while the scan of the outdegrees still runs
 		int32_t *pKeyBase = nullptr;
@@ -473,20 +483,25 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		// The segment pipeline (bv_seg.hip): the residual sections of the records of the long work bins (>= 2 048 bits of work), cut into pieces of stream, one lane
 		// per piece.  The class's own records (below the wave class) have their structure parsed by one lane each (k_seg_struct); the cooperative kernels parse the
 		// structure of theirs and hand the residuals over (GraphDev::segDesc); k_parse_list keeps the short bins.
-		const bool segOn = g->seg && !tiles && s.def != 0 && g->iv_arena && coop && s.seg_long_records >= 0 && (g->seg > 1 || estArcs >= 4000000);
+		const bool segAble = g->seg && !tiles && s.def != 0 && g->iv_arena && coop && s.seg_long_records >= 0;
+		const bool segFull = segAble && g->seg == 2;
+		const bool segHubs = segAble && !segFull && (g->seg == 3 || (s.max_outdegree >= g->seg_hub_min && estArcs >= 4000000)) && g->seg_handover;
+		const bool segOn = segFull || segHubs;
 		const int32_t segKLo = g->parse_windows ? (bv::MAXLVL - 1) * bv::NBIN + bv::PARSE_LONG_BIN : bv::PARSE_LONG_BIN, segKHi = g->parse_windows ? bv::NKEYS : bv::NBIN;
 		int32_t segRcapM = 0, segRtot = 0, segScap = 0;
-		bool segReady = false, segJoin = false;
+		bool segReady = false, segJoin = false, segWaves = false;
 		if (segOn) {
 			const int64_t bits = s.h_offsets[(size_t)v.lo + v.cnt] - s.h_offsets[(size_t)v.lo];
-			segRcapM = (int32_t)std::min<int64_t>(v.cnt, (bits + 8 * arcsBound) / 2048 + 16); // records with >= 2 048 bits of work (max(bits, 8 successors)): every record with pieces is one
-			const int32_t capBig = g->seg_handover ? (int32_t)std::min<int64_t>(v.cnt, arcsBound / 128 + 2) : 0, capGiant = g->seg_handover ? giantCap : 0;
+			segRcapM = segFull ? (int32_t)std::min<int64_t>(v.cnt, (bits + 8 * arcsBound) / 2048 + 16) : 0; // records with >= 2 048 bits of work (max(bits, 8 successors)): every record with pieces is one
+			segWaves = segFull && g->seg_handover;
+			const int32_t capBig = segWaves ? (int32_t)std::min<int64_t>(v.cnt, arcsBound / 128 + 2) : 0, capGiant = g->seg_handover ? giantCap : 0;
 			segRtot = segRcapM + capBig + capGiant;
 			// every record with pieces is one of the staged records of the long bins, and has at most bits / piece + 2 of them
-			segScap = (int32_t)std::min<int64_t>(std::min<int64_t>(bits, s.seg_long_bits) / ((int64_t)1 << bv::seg_bits_log2()) + 2 * std::min<int64_t>(segRcapM, s.seg_long_records) + 2, 0x7ffffff0);
-			if (g->segbuf.need(bv::seg_scratch_bytes(segRtot, segScap, s.info.zeta_k)) && g->segR.need(sizeof(int32_t) * (size_t)std::max<int64_t>(arcsBound, 1 << 22))) {
+			const int64_t recsBound = std::min<int64_t>(segFull ? (int64_t)v.cnt : (int64_t)giantCap, s.seg_long_records);
+			segScap = (int32_t)std::min<int64_t>(std::min<int64_t>(bits, s.seg_long_bits) / ((int64_t)1 << bv::seg_bits_log2()) + 2 * recsBound + 2, 0x7ffffff0);
+			if (segRtot > 0 && g->segbuf.need(bv::seg_scratch_bytes(segRtot, segScap, s.info.zeta_k)) && g->segR.need(sizeof(int32_t) * (size_t)std::max<int64_t>(arcsBound, 1 << 22))) {
 				segReady = true;
-				if (g->seg_handover) bv::seg_handover(gd, g->segbuf.p, segRcapM, capBig, capGiant, segScap, g->stream); // (before the fork: the cooperative kernels start behind it)
+				if (g->seg_handover) bv::seg_handover(gd, g->segbuf.p, segRcapM, capBig, capGiant, segScap, segHubs ? g->seg_hub_min : 0, g->stream); // (before the fork: the cooperative kernels start behind it)
 			}
 		}
 		if (!tiles) {
@@ -509,7 +524,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			HIPCHK(g, hipEventRecord(g->evFork, g->stream));
 			HIPCHK(g, hipStreamWaitEvent(g->sideA, g->evFork, 0));
 			HIPCHK(g, hipStreamWaitEvent(side_b(g), g->evFork, 0));
-			stLists = g->sideA;
+			stLists = listsOnB ? side_b(g) : g->sideA;
 			if (g->early_rowptr) { // the caller's rowptr needs the scan only: written now, not at the end of the call
 				if (v.rowstart != g->early_rowptr) bv::launch_rebase(v.nh, v.cnt, v.rowstart, g->early_rowptr, g->sideA);
 				hipLaunchKernelGGL(k_totals, dim3(1), dim3(1), 0, g->sideA, v.rowstart, v.nh, v.cnt, g->small.as<Small>(), v.coop_ptr, v.coop_min);
@@ -523,8 +538,8 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		if (ovl && coop) {
 			HIPCHK(g, hipStreamWaitEvent(g->sideA, g->evC, 0));
 			bv::launch_parse_big(gd, s.def, v, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, g->giant_groups, derr, side_b(g), g->sideA); // (giants, big)
-			if (segReady && g->seg_handover) HIPCHK(g, hipEventRecord(g->evW, g->sideA)); // (evB: behind the segment pipeline's chain, below)
-			else HIPCHK(g, hipEventRecord(g->evB, side_b(g)));
+			if (segReady && segWaves) HIPCHK(g, hipEventRecord(g->evW, g->sideA)); // (the wave class has handed its residual sections over)
+			if (!(segReady && g->seg_handover)) HIPCHK(g, hipEventRecord(g->evB, side_b(g))); // (else: behind the segment pipeline's chain, below)
 		}
 		// ... then, behind the wave class, the chain depth of every record + per-level lists (node order inside a level) +
 		// copy queues: only the copy pass needs them, and launched first they would sit in front of the wave class while
@@ -533,6 +548,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		                                  g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->maxdepth, stLists,
 		                                  g->copyq.as<int32_t>(), bigCap, g->copyq.as<int32_t>() + bigCap, midCap, g->copy_mid_min, g->copy_big != 0);
 		if (ovl) HIPCHK(g, hipEventRecord(g->evA, g->sideA));
+		if (ovl && coop && listsOnB) HIPCHK(g, hipEventRecord(g->evB, side_b(g))); // (the lists sit behind the giants: side B is done when they are)
 		if (!tiles && !earlyList)
 			bv::launch_build_lists(gd, v, ~0ull, g->parse_windows ? 6 : 2, nullptr, g->pkey16.as<uint16_t>(), g->pkeys.as<int32_t>(), pKeyBase, pKeyBase + (bv::NKEYS + 1), g->plist.as<int32_t>(),
 			                       g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->pad, g->stream);
@@ -545,7 +561,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		mark(g, 5);
 		if (tiles) bv::launch_parse_tile(gd, s.def, v, g->tilebounds.as<int32_t>(), ntiles, tileVariant, derr, g->stream);
 		else {
-			int32_t keyHi = bv::NKEYS;
+			int32_t keyHi = bv::NKEYS, dMaxList = 0x7fffffff;
 			if (segReady) {
 				// with the hand-over: the structure of the class's own records here; on side B, behind the giants and once the wave class has handed its residual
 				// sections over, everything else.  Without it: the whole pipeline on a stream of its own, beside the three other chains of kernels.
@@ -555,21 +571,21 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 					HIPCHK(g, hipEventRecord(g->evM, g->stream)); // (the parse list and the row starts are ready)
 					HIPCHK(g, hipStreamWaitEvent(stChain, g->evM, 0));
 				}
-				bv::launch_seg_struct(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, segKLo, segKHi, segRcapM, segRtot, segScap, g->segbuf.p, g->arena.p, arenaCap, ctl, g->seg_blocks, derr, stStruct);
+				bv::launch_seg_struct(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, segKLo, segKHi, segRcapM, segRtot, segScap, g->segbuf.p, g->arena.p, arenaCap, ctl, g->seg_blocks, derr, stStruct, g->seg_min_d);
 				if (ovl && g->seg_handover) {
 					stChain = side_b(g);
 					HIPCHK(g, hipEventRecord(g->evM, g->stream));
 					HIPCHK(g, hipStreamWaitEvent(stChain, g->evM, 0));
-					HIPCHK(g, hipStreamWaitEvent(stChain, g->evW, 0));
+					if (segWaves) HIPCHK(g, hipStreamWaitEvent(stChain, g->evW, 0));
 				}
 				bv::launch_seg_chain(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, segKLo, segKHi, segRcapM, segRtot, segScap, g->segbuf.p, g->arena.p, arenaCap, g->segR.as<int32_t>(), std::max<int64_t>(arcsBound, 1 << 22), ctl, g->seg_blocks, derr, stChain);
 				if (ovl && g->seg_handover) HIPCHK(g, hipEventRecord(g->evB, stChain));
 				if (ovl && !g->seg_handover) { HIPCHK(g, hipEventRecord(g->evW, stChain)); segJoin = true; }
-				keyHi = segKLo;
+				if (!segFull) {} else if (g->seg_min_d > 0) dMaxList = g->seg_min_d; else keyHi = segKLo; // (with a lower bound on the pipeline's records k_parse_list keeps the long bins, minus those)
 			}
 			if (g->flat && s.def != 0 && g->iv_arena && g->flatfb.need(sizeof(int32_t) * (size_t)v.cnt))
 				bv::launch_parse_flat(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, keyHi, g->level_blocks, g->arena.p, arenaCap, g->flatfb.as<int32_t>(), ctl, derr, g->stream);
-			else bv::launch_parse_list(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, g->level_blocks, derr, g->stream, g->iv_arena ? g->arena.p : nullptr, arenaCap, keyHi);
+			else bv::launch_parse_list(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, g->level_blocks, derr, g->stream, g->iv_arena ? g->arena.p : nullptr, arenaCap, keyHi, dMaxList);
 		}
 		if (ovl) {
 			HIPCHK(g, hipStreamWaitEvent(g->stream, g->evA, 0));
@@ -964,7 +980,7 @@ static int open_impl(const char *basename, int device, int part, int parts, bvg_
 		const int32_t n = st->node_hi - st->stage_lo;
 		void *p_outd = nullptr, *p_ref = nullptr, *p_rs = nullptr, *p_sums = nullptr, *p_err = nullptr, *p_part = nullptr;
 		const bool ok = hipMalloc(&p_outd, sizeof(int32_t) * (size_t)n) == hipSuccess && hipMalloc(&p_ref, sizeof(uint16_t) * (size_t)n) == hipSuccess &&
-		                hipMalloc(&p_rs, sizeof(int64_t) * ((size_t)n + 1)) == hipSuccess && hipMalloc(&p_sums, sizeof(int64_t) * (size_t)bv::scan_num_sums(n)) == hipSuccess &&
+		                hipMalloc(&p_rs, sizeof(int64_t) * ((size_t)n + 4)) == hipSuccess /* (also the three counters of the sizing pass) */ && hipMalloc(&p_sums, sizeof(int64_t) * (size_t)bv::scan_num_sums(n)) == hipSuccess &&
 		                hipMalloc(&p_err, sizeof(int)) == hipSuccess && hipMalloc(&p_part, sizeof(int32_t) * (5 * (size_t)bv::headers_blocks(n) + 8)) == hipSuccess;
 		int64_t total = 0;
 		hipError_t e = ok ? hipMemset(p_err, 0, sizeof(int)) : hipErrorOutOfMemory;
@@ -976,10 +992,10 @@ static int open_impl(const char *basename, int device, int part, int parts, bvg_
 			e = hipMemcpy(&total, (int64_t *)p_rs + n, sizeof(int64_t), hipMemcpyDeviceToHost);
 			if (e == hipSuccess) e = hipMemcpy(st->deg_counts, (int32_t *)p_part + 5 * hb, sizeof(st->deg_counts), hipMemcpyDeviceToHost);
 			if (e == hipSuccess && st->def != 0) { // (p_rs is done with: two counters)
-				unsigned long long two[2] = { 0, 0 };
-				e = hipMemset(p_rs, 0, sizeof(two));
-				if (e == hipSuccess) { bv::launch_seg_sizing(st->d_offsets, st->stage_lo, n, (const int32_t *)p_outd, (unsigned long long *)p_rs, nullptr); e = hipMemcpy(two, p_rs, sizeof(two), hipMemcpyDeviceToHost); }
-				if (e == hipSuccess) { st->seg_long_records = (int64_t)two[0]; st->seg_long_bits = (int64_t)two[1]; }
+				unsigned long long three[3] = { 0, 0, 0 };
+				e = hipMemset(p_rs, 0, sizeof(three));
+				if (e == hipSuccess) { bv::launch_seg_sizing(st->d_offsets, st->stage_lo, n, (const int32_t *)p_outd, (unsigned long long *)p_rs, nullptr); e = hipMemcpy(three, p_rs, sizeof(three), hipMemcpyDeviceToHost); }
+				if (e == hipSuccess) { st->seg_long_records = (int64_t)three[0]; st->seg_long_bits = (int64_t)three[1]; st->max_outdegree = (int64_t)three[2]; }
 			}
 		}
 		for (void *q : { p_outd, p_ref, p_rs, p_sums, p_err, p_part }) if (q) (void)hipFree(q);
