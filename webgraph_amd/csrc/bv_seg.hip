@@ -143,12 +143,23 @@ template <class T> static void sg_scan(const T *in, int64_t n, T *out, T *sums, 
 	hipLaunchKernelGGL(k_sg_scan_apply<T>, dim3((unsigned)nb), dim3(STPB), 0, st, in, n, sums, out, nDev);
 }
 
-// which record every segment belongs to: a record's lane writes its own stretch (a record of a thousand segments: a thousand stores
-// that nobody waits for)
+// which record every piece belongs to: a record's lane writes its own stretch; a record of more than 64 pieces (a hub has tens of
+// thousands: one lane took 0.23 ms) is written by its wave together
 __global__ void __launch_bounds__(STPB) k_seg_fill(int32_t Rcap, const int32_t *__restrict__ segbase, int32_t Scap, int32_t *__restrict__ seg2rec) {
-	for (int32_t r = blockIdx.x * STPB + threadIdx.x; r < Rcap; r += gridDim.x * STPB) {
-		const int32_t a = segbase[r], b = min(segbase[r + 1], Scap);
-		for (int32_t sg = a; sg < b; sg++) seg2rec[sg] = r;
+	const int lane = threadIdx.x & 63;
+	for (int32_t r0 = blockIdx.x * STPB + (threadIdx.x & ~63); r0 < Rcap; r0 += gridDim.x * STPB) { // (wave-uniform)
+		const int32_t r = r0 + lane;
+		int32_t a = 0, b = 0;
+		if (r < Rcap) { a = segbase[r]; b = min(segbase[r + 1], Scap); }
+		const bool isLong = b - a > 64;
+		if (!isLong) for (int32_t sg = a; sg < b; sg++) seg2rec[sg] = r;
+		unsigned long long lm = __ballot(isLong);
+		while (lm) {
+			const int src = __ffsll((long long)lm) - 1;
+			lm &= lm - 1;
+			const int32_t A = __shfl(a, src, 64), B = __shfl(b, src, 64);
+			for (int32_t sg = A + lane; sg < B; sg += 64) seg2rec[sg] = r0 + src;
+		}
 	}
 }
 
@@ -572,6 +583,7 @@ void launch_seg_struct(const GraphDev &g, int def, const RangeView &v, const int
 void launch_seg_chain(const GraphDev &g, int def, const RangeView &v, const int32_t *plist, const int32_t *keyBase, int32_t kLo, int32_t kHi, int32_t RcapM, int32_t Rtot, int32_t Scap,
                       void *scratch, void *arena, int64_t arenaCap, int32_t *R, int64_t Rcap, int32_t *ctl, int blocks, int *err, hipStream_t st) {
 	if (v.cnt <= 0 || Rtot <= 0 || def == 0) return;
+	if (RcapM == 0) (void)hipMemsetAsync(ctl + CTL_SEG, 0, 4 * sizeof(int32_t), st); // (no k_seg_struct ran: the counters of this job's lists)
 	const uint32_t cap = seg_cell_cap(g.zetaK);
 	const SegPtrs P = seg_ptrs(scratch, Rtot, Scap, cap);
 	const SegRecs recs{ plist, keyBase, kLo, kHi };

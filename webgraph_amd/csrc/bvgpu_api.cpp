@@ -571,7 +571,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 					HIPCHK(g, hipEventRecord(g->evM, g->stream)); // (the parse list and the row starts are ready)
 					HIPCHK(g, hipStreamWaitEvent(stChain, g->evM, 0));
 				}
-				bv::launch_seg_struct(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, segKLo, segKHi, segRcapM, segRtot, segScap, g->segbuf.p, g->arena.p, arenaCap, ctl, g->seg_blocks, derr, stStruct, g->seg_min_d);
+				if (segRcapM > 0) bv::launch_seg_struct(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, segKLo, segKHi, segRcapM, segRtot, segScap, g->segbuf.p, g->arena.p, arenaCap, ctl, g->seg_blocks, derr, stStruct, g->seg_min_d); // (hubs only: the pipeline has no records of its own -- an empty kernel here waited 0.8 ms for CUs in front of k_parse_list)
 				if (ovl && g->seg_handover) {
 					stChain = side_b(g);
 					HIPCHK(g, hipEventRecord(g->evM, g->stream));
