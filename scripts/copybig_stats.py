@@ -21,4 +21,5 @@ names = ["walk", "gather", "rank", "move", "scatter", "g:gather", "g:splits", "g
 tot = sum(int(st[24 + i]) for i in range(8))
 for i, nm in enumerate(names):
     print("  %-8s %14d ticks %5.1f%%" % (nm, st[24 + i], 100.0 * st[24 + i] / max(tot, 1)))
+print("head %d; seek+3codes %d; serial walks %d rows %d codes %d ticks; coop walks %d rows %d codes %d ticks" % (st[47], st[40], st[43], st[45], st[41], st[44], st[46], st[42]))
 print("longest row, ticks: level 1 %d, level 2 %d, level 3 %d; longest walk %d" % (st[0], st[1], st[2], st[3]))

@@ -85,9 +85,10 @@ __device__ __forceinline__ int64_t wave_incl_scan_i64(int64_t v) {
 template <int NW> struct Grp {
 	static constexpr int N = 64 * NW;
 	int64_t *xch; // LDS, NW + 8 slots
-	__device__ __forceinline__ int tid() const { return threadIdx.x; }
+	// (a one-wave group may be any wave of its block: its thread index is the lane)
+	__device__ __forceinline__ int tid() const { return NW == 1 ? (int)(threadIdx.x & 63) : (int)threadIdx.x; }
 	__device__ __forceinline__ int lane() const { return threadIdx.x & 63; }
-	__device__ __forceinline__ int wave() const { return threadIdx.x >> 6; }
+	__device__ __forceinline__ int wave() const { return NW == 1 ? 0 : (int)(threadIdx.x >> 6); }
 	// LDS hand-off inside the group.  One wave: the LDS executes a wave's DS instructions in issue order, so
 	// keeping the program order is enough.  Several waves: a workgroup barrier.
 	__device__ __forceinline__ void sync() const {
@@ -909,7 +910,7 @@ __device__ __forceinline__ void coop_block_walk(const GraphDev &g, uint64_t pos,
 	if (rest < 0) { bad = 1; return; }
 	if (!(bc & 1)) {
 		const int64_t j = bc >> 1;
-		if (j < tabCap && threadIdx.x == 0) { kend[j] = (int32_t)min<int64_t>(copied + rest, 0x7fffffff); delta[j] = (int32_t)(total - copied); }
+		if (j < tabCap && lane == 0) { kend[j] = (int32_t)min<int64_t>(copied + rest, 0x7fffffff); delta[j] = (int32_t)(total - copied); }
 		copied += rest;
 	}
 	total += rest;

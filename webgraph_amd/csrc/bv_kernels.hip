@@ -570,6 +570,71 @@ __global__ void __launch_bounds__(64 * COPY_MID_WAVES) k_copy_mid(GraphDev g, Ra
 	}
 }
 
+// The block lists of the rows of the group class (and, since they cost nothing more, their headers), walked BEFORE the copy pass, all
+// levels at once, one wave per row, beside the parse kernels: a block list is a serial chain of codes that depends on nothing but the
+// stream, and walked inside k_copy_big -- by one wave of a 1024-thread group while the fifteen others wait, two groups per CU -- it was
+// 71 % of that kernel's time on the C5 shard (14 000 rows of 590 codes: 600 ticks per code walked by one lane, 105 per code by the
+// wave; profiles/r4_experiments.txt).  Here sixteen waves per CU walk, each its own row.  The tables (kend, delta, as in k_copy_mid)
+// go to the bump arena GraphDev::walktab, (bc >> 1) + 1 entries each; desc[qi] = (offset of the tables | -1 not walked: k_copy_big
+// walks the list itself | -2 nothing to merge or malformed, number of copied blocks, copied ids, block count).
+constexpr int PREWALK_WAVES = 4;
+template <int DEF>
+__global__ void __launch_bounds__(64 * PREWALK_WAVES) k_copy_prewalk(GraphDev g, RangeView v, const int32_t *__restrict__ queue, const int32_t *__restrict__ count, int32_t cap, int4 *__restrict__ desc) {
+	static_assert(DEF != 0 && 64 * PREWALK_WAVES == LW_STRIDE, "default codings; the lane windows are LW_STRIDE columns wide");
+	__shared__ uint32_t lwin[LW_MAIN * LW_STRIDE];
+	__shared__ __attribute__((aligned(16))) uint32_t cwin[PREWALK_WAVES][CoopLds<1>::WORDS];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int32_t nq = min(*count, cap);
+	for (int32_t qi = blockIdx.x * PREWALK_WAVES + wave; qi < nq; qi += gridDim.x * PREWALK_WAVES) {
+		const int32_t s = queue[qi];
+		int4 out = int4{ -1, 0, 0, 0 };
+		const int32_t r = v.ref[s], d = v.outd[s];
+		if (r != 0 && v.fits(s) && v.fits(s - r) && !(d >= g.walkMin)) { // (the giant records' tables fall out of their parse: bv_coop.hpp)
+			const int64_t dref = v.outd[s - r];
+			LaneWin<LW_MAIN> lw;
+			lw.col = lwin + threadIdx.x;
+			lw.vlast = min((((uint64_t)g.offsets[v.lo + s + 1] >> 5) + 2) & ~(uint64_t)3, (g.nwords + 4) & ~(uint64_t)3);
+			lw.seek(g, (uint64_t)g.offsets[v.lo + s]);
+			int e = 0;
+			(void)lw.template code<1>(g, e);
+			(void)lw.template code<2>(g, e);
+			const uint64_t bc = lw.template code<1>(g, e);
+			if (e || bc > (uint64_t)dref + 1) out.x = -2; // flagged by the parse kernel
+			else {
+				const uint64_t kMax = (bc >> 1) + 1, need = 2 * kMax;
+				int64_t off = -1;
+				if (lane == 0 && need <= g.walkCap) { const uint32_t a = atomicAdd(g.walkCursor, (uint32_t)need); if ((uint64_t)a + need <= g.walkCap) off = a; }
+				off = shfl_i64(off, 0);
+				if (off >= 0) {
+					int32_t *kend = g.walktab + off, *dlt = kend + kMax;
+					int64_t total = 0, copied = 0;
+					int32_t nKept = 0;
+					int bad = 0;
+					if (bc >= COPY_COOP_WALK_MIN) coop_block_walk(g, lw.pos(), (uint64_t)g.offsets[v.lo + s + 1], (int64_t)bc, dref, d, kend, dlt, (int32_t)kMax, cwin[wave], total, copied, nKept, bad);
+					else {
+						for (uint64_t b = 0; b <= bc; b++) { // (every lane walks: the list is short)
+							int64_t len;
+							if (b < bc) len = (int64_t)lw.template code<1>(g, e) + (b ? 1 : 0);
+							else len = dref - total; // implicit last block (copied when the block count is even)
+							if (len < 0 || total + len > dref) { bad = 1; break; }
+							if (!(b & 1)) {
+								if (lane == (nKept & 63)) { kend[nKept] = (int32_t)min<int64_t>(copied + len, 0x7fffffff); dlt[nKept] = (int32_t)(total - copied); }
+								nKept++;
+								copied += len;
+							}
+							total += len;
+						}
+						bad |= e;
+					}
+					if (bad || copied > d || copied == 0) out.x = -2;
+					else out = int4{ (int32_t)off, nKept, (int32_t)copied, (int32_t)min<uint64_t>(bc, 0x7fffffff) };
+				}
+			}
+		}
+		if (lane == 0) desc[qi] = out;
+	}
+}
+
 #ifndef COPY_BIG_THREADS_
 #define COPY_BIG_THREADS_ 1024
 #define COPY_BIG_CAP_ 6144
@@ -589,7 +654,7 @@ constexpr int COPY_BIG_THREADS = COPY_BIG_THREADS_, COPY_BIG_CAP = COPY_BIG_CAP_
 template <int DEF>
 __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ queue,
                                                                const int32_t *__restrict__ count, int32_t cap, int32_t level, int32_t *__restrict__ tmp, uint32_t tmpCap,
-                                                               uint32_t *__restrict__ tmpCursor, int32_t *__restrict__ qhead, int32_t *__restrict__ nextPair, int *__restrict__ err) {
+                                                               uint32_t *__restrict__ tmpCursor, int32_t *__restrict__ qhead, int32_t *__restrict__ nextPair, int *__restrict__ err, const int4 *__restrict__ pre) {
 	if (blockIdx.x == 0 && threadIdx.x < 2) nextPair[threadIdx.x] = 0;
 	__shared__ int32_t tabs[3 * COPY_BIG_CAP + 2];
 	int32_t *const cval = tabs, *const cpos = tabs + COPY_BIG_CAP, *const delta = tabs + 2 * COPY_BIG_CAP + 1;
@@ -627,6 +692,7 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 		int32_t *row = v.row(s);
 		const int32_t *src = v.row(s - r);
 		unsigned long long tk = (g.stats && (g.dbg & 16)) ? __builtin_readcyclecounter() : 0;
+		const unsigned long long tkRow = tk;
 #define CT(slot) do { if (g.stats && (g.dbg & 16)) { const unsigned long long now_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g.stats[24 + slot], now_ - tk); tk = now_; } } while (0)
 		// header + blocks, by the first wave only (sixteen waves walking the list side by side would only slow each
 		// other down); default codings read through a lane window in LDS with the short-code decoders.  Fills the
@@ -637,6 +703,7 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 				int64_t total = 0, copied = 0;
 				int32_t nKept = 0;
 				int bad = 0;
+				unsigned long long wt0 = (g.stats && (g.dbg & 16)) ? __builtin_readcyclecounter() : 0;
 				auto walk = [&](auto &&next_gamma, uint64_t bc) {
 					if (bc > (uint64_t)dref + 1) { bad = 1; return; } // flagged by the parse kernel
 					for (uint64_t b = 0; b <= bc; b++) {
@@ -661,9 +728,12 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 					(void)lw.template code<1>(g, e);
 					(void)lw.template code<2>(g, e);
 					const uint64_t bc = lw.template code<1>(g, e);
+					unsigned long long wt1 = (g.stats && (g.dbg & 16)) ? __builtin_readcyclecounter() : 0;
 					if (bc >= COPY_COOP_WALK_MIN && bc <= (uint64_t)dref + 1 && !e)
 						coop_block_walk(g, lw.pos(), (uint64_t)g.offsets[v.lo + s + 1], (int64_t)bc, dref, d, kend, dlt, tabCap, cwin, total, copied, nKept, bad);
 					else walk([&] { return lw.template code<1>(g, e); }, bc);
+					if (g.stats && (g.dbg & 16) && threadIdx.x == 0) { const unsigned long long wt2 = __builtin_readcyclecounter(); const int c = bc >= COPY_COOP_WALK_MIN ? 1 : 0;
+						atomicAdd(&g.stats[40], wt1 - wt0); atomicAdd(&g.stats[41 + c], wt2 - wt1); atomicAdd(&g.stats[43 + c], 1ull); atomicAdd(&g.stats[45 + c], (unsigned long long)bc); }
 					bad |= e;
 				} else {
 					BitReader br;
@@ -809,6 +879,31 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 		// at most bc / 2 + 1 blocks are copied and at most min(dref, d) ids, so a referent of up to COPY_BIG_CAP ids with a
 		// block list of up to 2 * COPY_BIG_CAP codes fits the LDS tables for sure; everything else gets tables in global
 		// scratch (bump allocator), sized by those bounds.
+		const int4 pw = pre ? pre[qi] : int4{ -1, 0, 0, 0 }; // (uniform)
+		if (pw.x == -2) continue; // k_copy_prewalk: nothing to merge, or flagged by the parse kernel
+		if (pw.x >= 0) {
+			// the list was walked by k_copy_prewalk: tables in GraphDev::walktab (bounds as below; values of our own kernel)
+			const int64_t kM = ((int64_t)pw.w >> 1) + 1, cMax = dref < (int64_t)d ? dref : (int64_t)d;
+			const bool inLds = !(dref > COPY_BIG_CAP || kM > COPY_BIG_CAP + 1);
+			__syncthreads(); // the tables and s_tmp are free
+			if (inLds) {
+				for (int32_t k = threadIdx.x; k < pw.y; k += COPY_BIG_THREADS) { cpos[k] = g.walktab[pw.x + k]; delta[k] = g.walktab[pw.x + kM + k]; }
+			} else if (threadIdx.x == 0) {
+				s_tmp = -1;
+				if (tmp && (uint64_t)cMax <= tmpCap) { const uint32_t o = atomicAdd(tmpCursor, (uint32_t)cMax); if ((uint64_t)o + (uint64_t)cMax <= tmpCap) s_tmp = o; } // room for the copied ids
+			}
+			__syncthreads();
+			if (g.stats && threadIdx.x == 0) { stat_add(g, 8, 1); stat_add(g, 9, (unsigned long long)pw.y); stat_max(g, 15, (unsigned long long)pw.y); stat_add(g, 4, (unsigned long long)d); }
+			CT(0);
+			if (inLds) merge_row(cpos, delta, cval, cpos, pw.z, pw.y);
+			else {
+				const int64_t where = s_tmp;
+				__syncthreads(); // everybody has read s_tmp
+				if (where < 0) { if (threadIdx.x == 0) copy_node<DEF>(g, v.lo + s, d, dref, row, src, err); }
+				else merge_row_stream(g.walktab + pw.x, g.walktab + pw.x + kM, tmp + where, pw.z, pw.y);
+			}
+			continue;
+		}
 		if (threadIdx.x == 0) {
 			BitReader hb;
 			hb.init(g.bits, g.nwords);
@@ -838,6 +933,7 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 		__syncthreads();
 		const int64_t where = s_tmp, kMax = s_kmax, desc = s_desc;
 		__syncthreads();
+		if (g.stats && (g.dbg & 16) && threadIdx.x == 0) atomicAdd(&g.stats[47], __builtin_readcyclecounter() - tkRow);
 		if (desc >= 0) { // (copied >= 4, so there is something to merge; bounds checked above)
 			CT(0);
 			merge_row_stream(g.walktab + desc, g.walktab + desc + kMax, tmp + where, (int32_t)s_copied, s_kept);
@@ -1471,10 +1567,17 @@ void copy_thresholds(int32_t midMinKnob, bool bigGroups, int32_t &midMin, int32_
 	bigMin = bigGroups ? COPY_BIG_MIN : 0x7fffffff; // !bigGroups: every row is merged by one lane
 	midMin = (midMinKnob <= 0 || midMinKnob > bigMin || !bigGroups) ? bigMin : midMinKnob; // = bigMin: no wave-per-row class
 }
+// walks the block lists of the rows in the group class's queue (all levels); desc: 16 bytes per queue entry
+void launch_copy_prewalk(const GraphDev &g, int def, const RangeView &v, const int32_t *bigQ, int32_t bigCap, const int32_t *ctl, void *desc, int blocks, hipStream_t st) {
+	if (v.cnt <= 0 || !g.walktab) return;
+	if (def == 1) hipLaunchKernelGGL(k_copy_prewalk<1>, dim3(blocks), dim3(64 * PREWALK_WAVES), 0, st, g, v, bigQ, ctl + 5, bigCap, (int4 *)desc);
+	else if (def == 2) hipLaunchKernelGGL(k_copy_prewalk<2>, dim3(blocks), dim3(64 * PREWALK_WAVES), 0, st, g, v, bigQ, ctl + 5, bigCap, (int4 *)desc);
+}
 void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int32_t *depth, const int32_t *list, const int32_t *keyBase, int32_t level, int blocks,
                        int32_t midMinKnob, bool bigGroups, const int32_t *bigQ, int32_t bigCap, const int32_t *midQ, int32_t midCap, int32_t *ctl, int32_t *tmp, uint32_t tmpCap, int *err,
-                       hipStream_t st, hipStream_t stMid, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evMid, hipEvent_t evBig) {
+                       hipStream_t st, hipStream_t stMid, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evMid, hipEvent_t evBig, const void *preDesc) {
 	if (v.cnt <= 0) return;
+	const int4 *pre = (const int4 *)preDesc;
 	int32_t midMin, bigMin;
 	copy_thresholds(midMinKnob, bigGroups, midMin, bigMin);
 	const bool split = stMid != st || stBig != st;
@@ -1491,9 +1594,9 @@ void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int
 		// ctl[8 + 2 (level & 3)], ctl[9 + 2 (level & 3)]: this level's bump pointer into the scratch tables (the previous level's are free
 		// again) and the head of its work queue.  Level l zeroes the pair of level l + 1 (no memset launches between the levels);
 		// the job's set-up zeroes all four pairs.
-		if (def == 1) hipLaunchKernelGGL(k_copy_big<1>, dim3(COPY_BIG_GRID), dim3(COPY_BIG_THREADS), 0, st, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 8 + 2 * (level & 3)), ctl + 9 + 2 * (level & 3), ctl + 8 + 2 * ((level + 1) & 3), err);
-		else if (def == 2) hipLaunchKernelGGL(k_copy_big<2>, dim3(COPY_BIG_GRID), dim3(COPY_BIG_THREADS), 0, st, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 8 + 2 * (level & 3)), ctl + 9 + 2 * (level & 3), ctl + 8 + 2 * ((level + 1) & 3), err);
-		else hipLaunchKernelGGL(k_copy_big<0>, dim3(COPY_BIG_GRID), dim3(COPY_BIG_THREADS), 0, st, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 8 + 2 * (level & 3)), ctl + 9 + 2 * (level & 3), ctl + 8 + 2 * ((level + 1) & 3), err);
+		if (def == 1) hipLaunchKernelGGL(k_copy_big<1>, dim3(COPY_BIG_GRID), dim3(COPY_BIG_THREADS), 0, st, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 8 + 2 * (level & 3)), ctl + 9 + 2 * (level & 3), ctl + 8 + 2 * ((level + 1) & 3), err, pre);
+		else if (def == 2) hipLaunchKernelGGL(k_copy_big<2>, dim3(COPY_BIG_GRID), dim3(COPY_BIG_THREADS), 0, st, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 8 + 2 * (level & 3)), ctl + 9 + 2 * (level & 3), ctl + 8 + 2 * ((level + 1) & 3), err, pre);
+		else hipLaunchKernelGGL(k_copy_big<0>, dim3(COPY_BIG_GRID), dim3(COPY_BIG_THREADS), 0, st, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 8 + 2 * (level & 3)), ctl + 9 + 2 * (level & 3), ctl + 8 + 2 * ((level + 1) & 3), err, pre);
 	}
 	if (midMin < bigMin) {
 		if (def == 1) hipLaunchKernelGGL(k_copy_mid<1>, dim3(1024), dim3(64 * COPY_MID_WAVES), 0, stMid, g, v, depth, midQ, ctl + 6, midCap, level, err);
