@@ -499,6 +499,143 @@ __global__ void __launch_bounds__(TPB) k_copy_list(GraphDev g, RangeView v, cons
 	}
 }
 
+// ------------------------------------------------------------------------------------------------ copy pass, tiles of neighbours
+// A referent is at most W nodes before its row, and rows of neighbouring nodes are neighbours in the CSR: a work-group that loads
+// the rows of a run of consecutive nodes into LDS (coalesced) holds most reference chains of those nodes whole.  It merges the
+// short rows (the lane class of the copy pass) whose chain lies inside its tile there, level after level with a barrier in between
+// -- no launch per level, no scattered 4-byte loads and stores from 64 different rows per wave instruction (k_copy_list: 2.3 ms
+// of the C5 shard, 0.8 ms of C2) --, writes the tile back (coalesced) and takes the rows it has finished off the level kernels'
+// hands by zeroing their reference (copy_class: 0).  Everything else -- rows of the wave and group classes, rows whose chain
+// leaves the tile or passes through such a row, chains deeper than CT_LV -- is left to the level kernels, which run afterwards.
+// A tile is the nodes whose weighted start rowstart[s] + CT_NODE_W * s falls into one slice of CT_C (so that a run of empty
+// nodes cannot make a tile of a million nodes); inside a level the rows are handed to the lanes by length (counting sort, eight
+// bins), longest first.  The merge is copy_node's (MaskedIntIterator / MergedIntIterator, BVG:1095-1133), on LDS pointers.
+constexpr int CT_T = 512, CT_C = 12288, CT_NODE_W = 6, CT_NODES = CT_C / CT_NODE_W, CT_SLACK = 256, CT_IDS = CT_C + CT_SLACK, CT_LV = 16, CT_NB = 8, CT_KEYS = CT_LV * CT_NB;
+typedef __attribute__((address_space(3))) int32_t lds_i32;
+
+// tb[k] = first slot s in [nh, cnt] with (rowstart[s] - rowstart[nh]) + CT_NODE_W * (s - nh) >= k * CT_C
+__global__ void __launch_bounds__(256) k_ctile_bounds(const int64_t *__restrict__ rowstart, int32_t nh, int32_t cnt, int32_t ntiles, int32_t *__restrict__ tb) {
+	const int32_t k = blockIdx.x * 256 + threadIdx.x;
+	if (k > ntiles) return;
+	const int64_t want = (int64_t)k * CT_C, r0 = rowstart[nh];
+	int32_t lo = nh, hi = cnt;
+	while (lo < hi) { const int32_t mid = lo + ((hi - lo) >> 1); if (rowstart[mid] - r0 + (int64_t)CT_NODE_W * (mid - nh) < want) lo = mid + 1; else hi = mid; }
+	tb[k] = lo;
+}
+
+// copy_node on a row and a referent that live in LDS; false: nothing done (the level kernels will do, or flag, the row)
+template <int DEF>
+__device__ __forceinline__ bool copy_node_lds(const GraphDev &g, int32_t x, int32_t d, int64_t dref, lds_i32 *row, const lds_i32 *src, int *__restrict__ err) {
+	BitReader br;
+	br.init(g.bits, g.nwords);
+	br.seek((uint64_t)g.offsets[x]);
+	(void)Fields<DEF>::outdegree(br, g);
+	(void)Fields<DEF>::reference(br, g);
+	const uint64_t bc = Fields<DEF>::block_count(br, g);
+	if (bc > (uint64_t)dref + 1) return false;
+	const uint64_t blocksPos = br.pos();
+	int64_t total = 0, copied = 0;
+	for (uint64_t b = 0; b < bc; b++) {
+		int64_t len;
+		if (!block_len_ok(Fields<DEF>::block(br, g), b == 0, total, dref, len)) return false;
+		total += len;
+		if (!(b & 1)) copied += len;
+	}
+	if (!(bc & 1)) copied += dref - total;
+	if (copied > d || br.err) return false;
+	br.seek(blocksPos);
+	int32_t i = 0, k = 0, j = (int32_t)copied; // index in the referent's row, write index, extras read index (k <= j throughout)
+	int32_t ev = j < d ? row[j] : 0;
+	for (uint64_t b = 0; b <= bc; b++) {
+		int32_t len;
+		if (b < bc) len = (int32_t)Fields<DEF>::block(br, g) + (b ? 1 : 0);
+		else len = (int32_t)dref - i; // implicit last block: the rest of the referent
+		if (b & 1) { i += len; continue; }
+		for (int32_t t = 0; t < len && i < (int32_t)dref && k < d; t++) {
+			const int32_t cv = src[i++];
+			while (j < d && ev < cv) { row[k++] = ev; j++; if (j < d) ev = row[j]; }
+			if (j < d && ev == cv) { j++; if (j < d) ev = row[j]; } // equal heads emitted once (never in a valid file)
+			row[k++] = cv;
+		}
+	}
+	if (k != j) { while (j < d) { row[k++] = row[j++]; } while (k < d) row[k++] = -1; }
+	if (br.err) atomicOr(err, br.err);
+	return true;
+}
+
+template <int DEF>
+__global__ void __launch_bounds__(CT_T) k_copy_tile(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ tb, int32_t midMin, int32_t bigMin, int *__restrict__ err) {
+	__shared__ int32_t s_ids[CT_IDS];
+	__shared__ uint16_t s_list[CT_NODES];
+	__shared__ uint8_t s_ok[CT_NODES];
+	__shared__ int32_t s_cnt[CT_KEYS + 1], s_base[CT_KEYS + 1], s_wb[2];
+	const int32_t a = tb[blockIdx.x], b = tb[blockIdx.x + 1];
+	if (a >= b) return;
+	const int32_t nn = min(b - a, CT_NODES), tid = threadIdx.x;
+	const int64_t R0 = v.rowstart[a];
+	const int32_t span = (int32_t)min<int64_t>(v.rowstart[a + nn] - R0, CT_IDS);
+	if ((uint64_t)(R0 + span - v.rowstart[v.nh]) > v.succ_cap) return; // (E_CAP: raised by the parse kernels)
+	int32_t *const gbase = v.succ + (R0 - v.rowstart[v.nh]);
+	lds_i32 *const ids = (lds_i32 *)s_ids;
+	for (int k = tid; k <= CT_KEYS; k += CT_T) s_cnt[k] = 0;
+	if (tid == 0) { s_wb[0] = 0x7fffffff; s_wb[1] = 0; }
+	__syncthreads();
+	// keys: (level, length bin, longest first) of the rows this tile may finish
+	constexpr int PER = CT_NODES / CT_T;
+	int32_t key[PER], rank[PER];
+#pragma unroll
+	for (int it = 0; it < PER; it++) {
+		const int32_t i = it * CT_T + tid;
+		key[it] = -1;
+		if (i < nn) {
+			s_ok[i] = 0;
+			const int32_t s2 = a + i, r = v.ref[s2], d = v.outd[s2];
+			if (r != 0 && d > 0 && s2 - r >= a) {
+				const int32_t lvl = depth[s2];
+				if (copy_class_of(d, v.outd[s2 - r], midMin, bigMin) == 1 && v.rowstart[s2 + 1] - R0 <= span && lvl >= 1 && lvl < CT_LV) {
+					const int bin = min(CT_NB - 1, 31 - __clz(d));
+					key[it] = lvl * CT_NB + (CT_NB - 1 - bin);
+					rank[it] = atomicAdd(&s_cnt[key[it]], 1);
+				}
+			}
+		}
+	}
+	__syncthreads();
+	if (tid < 64) { // exclusive scan of the CT_KEYS counters: two per lane
+		static_assert(CT_KEYS == 128, "two counters per lane");
+		const int32_t c0 = s_cnt[2 * tid], c1 = s_cnt[2 * tid + 1];
+		const int64_t inc = wave_incl_scan_i64((int64_t)c0 + c1);
+		s_base[2 * tid] = (int32_t)inc - c0 - c1; s_base[2 * tid + 1] = (int32_t)inc - c1;
+		if (tid == 63) s_base[CT_KEYS] = (int32_t)inc;
+	}
+	__syncthreads();
+	const int32_t nrows = s_base[CT_KEYS];
+	if (nrows == 0) return;
+#pragma unroll
+	for (int it = 0; it < PER; it++) if (key[it] >= 0) s_list[s_base[key[it]] + rank[it]] = (uint16_t)(it * CT_T + tid);
+	for (int32_t k = tid; k < span; k += CT_T) ids[k] = gbase[k];
+	__syncthreads();
+	for (int lvl = 1; lvl < CT_LV; lvl++) {
+		const int32_t lo = s_base[lvl * CT_NB], hi = s_base[(lvl + 1) * CT_NB];
+		if (lo == nrows) break; // (uniform) no deeper rows
+		for (int32_t e = lo + tid; e < hi; e += CT_T) {
+			const int32_t i = s_list[e], s2 = a + i, t = s2 - v.ref[s2];
+			if (v.ref[t] != 0 && !s_ok[t - a]) continue; // the referent is not final yet: this row is the level kernels'
+			const int32_t d = v.outd[s2], o = (int32_t)(v.rowstart[s2] - R0);
+			if (copy_node_lds<DEF>(g, v.lo + s2, d, (int64_t)v.outd[t], ids + o, ids + (int32_t)(v.rowstart[t] - R0), err)) {
+				s_ok[i] = 1;
+				atomicMin(&s_wb[0], o); atomicMax(&s_wb[1], o + d);
+			}
+		}
+		__syncthreads();
+	}
+	const int32_t w0 = s_wb[0], w1 = s_wb[1];
+	if (w0 >= w1) return; // (uniform) nothing merged
+	for (int32_t k = w0 + tid; k < w1; k += CT_T) gbase[k] = ids[k];
+#pragma unroll
+	for (int it = 0; it < PER; it++) { const int32_t i = it * CT_T + tid; if (key[it] >= 0 && s_ok[i]) v.ref[a + i] = 0; }
+}
+
 // One wave per row of fewer than COPY_BIG_MIN successors with a reference.  The block list is walked once (by
 // every lane: it is short) into two LDS tables -- for the j-th copied block, the number of ids copied up to its
 // end and the offset between an id's index in the referent's row and its index among the copied ids.  Then the
@@ -508,7 +645,7 @@ __global__ void __launch_bounds__(TPB) k_copy_list(GraphDev g, RangeView v, cons
 constexpr int COPY_MID_WAVES = 4;
 template <int DEF>
 __global__ void __launch_bounds__(64 * COPY_MID_WAVES) k_copy_mid(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ queue,
-                                                                  const int32_t *__restrict__ count, int32_t cap, int32_t level, int *__restrict__ err) {
+                                                                  const int32_t *__restrict__ count, int32_t cap, int32_t level, int *__restrict__ err, const int4 *__restrict__ pre) {
 	__shared__ int32_t s_vals[COPY_MID_WAVES][COPY_BIG_MIN], s_kend[COPY_MID_WAVES][COPY_BIG_MIN + 1], s_delta[COPY_MID_WAVES][COPY_BIG_MIN + 1];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	int32_t *vals = s_vals[wave], *kend = s_kend[wave], *delta = s_delta[wave];
@@ -522,18 +659,27 @@ __global__ void __launch_bounds__(64 * COPY_MID_WAVES) k_copy_mid(GraphDev g, Ra
 		const int64_t dref = v.outd[s - r];
 		int32_t *row = v.row(s);
 		const int32_t *src = v.row(s - r);
-		// header + blocks (uniform)
-		BitReader br;
-		br.init(g.bits, g.nwords);
-		br.seek((uint64_t)g.offsets[v.lo + s]);
-		(void)Fields<DEF>::outdegree(br, g);
-		(void)Fields<DEF>::reference(br, g);
-		const uint64_t bc = Fields<DEF>::block_count(br, g);
-		if (bc > (uint64_t)dref + 1) continue; // flagged by the parse kernel
 		int64_t total = 0, copied = 0;
 		int32_t nKept = 0;
 		bool bad = false;
-		for (uint64_t b = 0; b <= bc; b++) {
+		const int4 pw = pre ? pre[qi] : int4{ -1, 0, 0, 0 }; // (uniform)
+		if (pw.x == -2) continue; // k_copy_prewalk_lanes: nothing to merge, or flagged by the parse kernel
+		// header + blocks (uniform)
+		BitReader br;
+		br.init(g.bits, g.nwords);
+		uint64_t bc = 0;
+		if (pw.x >= 0) { // walked already: the tables are in GraphDev::walktab
+			const int32_t kM = (pw.w >> 1) + 1;
+			nKept = pw.y; copied = pw.z;
+			for (int32_t k = lane; k < nKept; k += 64) { kend[k] = g.walktab[pw.x + k]; delta[k] = g.walktab[pw.x + kM + k]; }
+		} else {
+			br.seek((uint64_t)g.offsets[v.lo + s]);
+			(void)Fields<DEF>::outdegree(br, g);
+			(void)Fields<DEF>::reference(br, g);
+			bc = Fields<DEF>::block_count(br, g);
+			if (bc > (uint64_t)dref + 1) continue; // flagged by the parse kernel
+		}
+		for (uint64_t b = 0; pw.x < 0 && b <= bc; b++) {
 			int64_t len;
 			if (b < bc) len = (int64_t)Fields<DEF>::block(br, g) + (b ? 1 : 0);
 			else len = dref - total; // implicit last block (copied when the block count is even)
@@ -632,6 +778,70 @@ __global__ void __launch_bounds__(64 * PREWALK_WAVES) k_copy_prewalk(GraphDev g,
 			}
 		}
 		if (lane == 0) desc[qi] = out;
+	}
+}
+
+// The same for the rows of the wave class (k_copy_mid), one LANE per row: their lists are short (a row of 320 ids that keeps 95 % of
+// its referent's has 32 codes), and k_copy_mid walked each with all 64 lanes side by side -- the serial part of the row, 600 ticks
+// per code.  Lists of COPY_COOP_WALK_MIN codes and more are left to k_copy_mid (desc = -1).
+template <int DEF>
+__global__ void __launch_bounds__(LW_STRIDE) k_copy_prewalk_lanes(GraphDev g, RangeView v, const int32_t *__restrict__ queue, const int32_t *__restrict__ count, int32_t cap, int4 *__restrict__ desc) {
+	static_assert(DEF != 0, "default codings");
+	__shared__ uint32_t lwin[LW_MAIN * LW_STRIDE];
+	const int lane = threadIdx.x & 63;
+	const int32_t nq = min(*count, cap);
+	for (int32_t q0 = blockIdx.x * LW_STRIDE; q0 < nq; q0 += gridDim.x * LW_STRIDE) {
+		const int32_t qi = q0 + (int32_t)threadIdx.x;
+		int4 out = int4{ -1, 0, 0, 0 };
+		uint64_t bc = 0, need = 0;
+		int64_t dref = 0;
+		int32_t d = 0;
+		int e = 0;
+		bool mine = false;
+		LaneWin<LW_MAIN> lw;
+		lw.col = lwin + threadIdx.x;
+		if (qi < nq) {
+			const int32_t s = queue[qi];
+			const int32_t r = v.ref[s];
+			d = v.outd[s];
+			if (r != 0 && v.fits(s) && v.fits(s - r)) {
+				dref = v.outd[s - r];
+				lw.vlast = min((((uint64_t)g.offsets[v.lo + s + 1] >> 5) + 2) & ~(uint64_t)3, (g.nwords + 4) & ~(uint64_t)3);
+				lw.seek(g, (uint64_t)g.offsets[v.lo + s]);
+				(void)lw.template code<1>(g, e);
+				(void)lw.template code<2>(g, e);
+				bc = lw.template code<1>(g, e);
+				if (e || bc > (uint64_t)dref + 1) out.x = -2; // flagged by the parse kernel
+				else if (bc < COPY_COOP_WALK_MIN) { mine = true; need = 2 * ((bc >> 1) + 1); }
+			}
+		}
+		// one bump of the arena per wave
+		const int64_t incl = wave_incl_scan_i64((int64_t)need), tot = shfl_i64(incl, 63);
+		int64_t base = -1;
+		if (lane == 0 && tot > 0 && (uint64_t)tot <= g.walkCap) { const uint32_t a = atomicAdd(g.walkCursor, (uint32_t)tot); if ((uint64_t)a + (uint64_t)tot <= g.walkCap) base = a; }
+		base = shfl_i64(base, 0);
+		if (mine && base >= 0) {
+			const int64_t off = base + incl - (int64_t)need, kMax = (int64_t)(bc >> 1) + 1;
+			int32_t *kend = g.walktab + off, *dlt = kend + kMax;
+			int64_t total = 0, copied = 0;
+			int32_t nKept = 0;
+			int bad = 0;
+			for (uint64_t b = 0; b <= bc; b++) {
+				int64_t len;
+				if (b < bc) len = (int64_t)lw.template code<1>(g, e) + (b ? 1 : 0);
+				else len = dref - total; // implicit last block (copied when the block count is even)
+				if (len < 0 || total + len > dref) { bad = 1; break; }
+				if (!(b & 1)) {
+					kend[nKept] = (int32_t)min<int64_t>(copied + len, 0x7fffffff); dlt[nKept] = (int32_t)(total - copied);
+					nKept++;
+					copied += len;
+				}
+				total += len;
+			}
+			if (bad || e || copied > d || copied == 0 || nKept > COPY_BIG_MIN) out.x = -2;
+			else out = int4{ (int32_t)off, nKept, (int32_t)copied, (int32_t)bc };
+		}
+		if (qi < nq) desc[qi] = out;
 	}
 }
 
@@ -1567,15 +1777,31 @@ void copy_thresholds(int32_t midMinKnob, bool bigGroups, int32_t &midMin, int32_
 	bigMin = bigGroups ? COPY_BIG_MIN : 0x7fffffff; // !bigGroups: every row is merged by one lane
 	midMin = (midMinKnob <= 0 || midMinKnob > bigMin || !bigGroups) ? bigMin : midMinKnob; // = bigMin: no wave-per-row class
 }
+int32_t copy_tile_count(int64_t arcsBound, int32_t nodes) { return (int32_t)std::min<int64_t>((arcsBound + (int64_t)CT_NODE_W * nodes) / CT_C + 1, 0x7ffffff0); }
+void launch_copy_tile_bounds(const RangeView &v, int32_t ntiles, int32_t *tb, hipStream_t st) {
+	hipLaunchKernelGGL(k_ctile_bounds, dim3(nblk((int64_t)ntiles + 1, 256)), dim3(256), 0, st, v.rowstart, v.nh, v.cnt, ntiles, tb);
+}
+// tiles of neighbouring rows merged in LDS, every level at once (k_copy_tile): before the level kernels
+void launch_copy_tile(const GraphDev &g, int def, const RangeView &v, const int32_t *depth, const int32_t *tb, int32_t ntiles, int32_t midMinKnob, bool bigGroups, int *err, hipStream_t st) {
+	if (v.cnt <= v.nh || ntiles <= 0) return;
+	int32_t midMin, bigMin;
+	copy_thresholds(midMinKnob, bigGroups, midMin, bigMin);
+	if (def == 1) hipLaunchKernelGGL(k_copy_tile<1>, dim3(ntiles), dim3(CT_T), 0, st, g, v, depth, tb, midMin, bigMin, err);
+	else if (def == 2) hipLaunchKernelGGL(k_copy_tile<2>, dim3(ntiles), dim3(CT_T), 0, st, g, v, depth, tb, midMin, bigMin, err);
+	else hipLaunchKernelGGL(k_copy_tile<0>, dim3(ntiles), dim3(CT_T), 0, st, g, v, depth, tb, midMin, bigMin, err);
+}
 // walks the block lists of the rows in the group class's queue (all levels); desc: 16 bytes per queue entry
-void launch_copy_prewalk(const GraphDev &g, int def, const RangeView &v, const int32_t *bigQ, int32_t bigCap, const int32_t *ctl, void *desc, int blocks, hipStream_t st) {
+void launch_copy_prewalk(const GraphDev &g, int def, const RangeView &v, const int32_t *bigQ, int32_t bigCap, const int32_t *ctl, void *desc, int blocks, hipStream_t st, int32_t midCap) {
 	if (v.cnt <= 0 || !g.walktab) return;
+	// (the wave class's queue follows the group class's, and so do its descriptors)
+	if (midCap > 0 && def == 1) hipLaunchKernelGGL(k_copy_prewalk_lanes<1>, dim3(blocks), dim3(LW_STRIDE), 0, st, g, v, bigQ + bigCap, ctl + 6, midCap, (int4 *)desc + bigCap);
+	else if (midCap > 0 && def == 2) hipLaunchKernelGGL(k_copy_prewalk_lanes<2>, dim3(blocks), dim3(LW_STRIDE), 0, st, g, v, bigQ + bigCap, ctl + 6, midCap, (int4 *)desc + bigCap);
 	if (def == 1) hipLaunchKernelGGL(k_copy_prewalk<1>, dim3(blocks), dim3(64 * PREWALK_WAVES), 0, st, g, v, bigQ, ctl + 5, bigCap, (int4 *)desc);
 	else if (def == 2) hipLaunchKernelGGL(k_copy_prewalk<2>, dim3(blocks), dim3(64 * PREWALK_WAVES), 0, st, g, v, bigQ, ctl + 5, bigCap, (int4 *)desc);
 }
 void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int32_t *depth, const int32_t *list, const int32_t *keyBase, int32_t level, int blocks,
                        int32_t midMinKnob, bool bigGroups, const int32_t *bigQ, int32_t bigCap, const int32_t *midQ, int32_t midCap, int32_t *ctl, int32_t *tmp, uint32_t tmpCap, int *err,
-                       hipStream_t st, hipStream_t stMid, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evMid, hipEvent_t evBig, const void *preDesc) {
+                       hipStream_t st, hipStream_t stMid, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evMid, hipEvent_t evBig, const void *preDesc, bool preMid) {
 	if (v.cnt <= 0) return;
 	const int4 *pre = (const int4 *)preDesc;
 	int32_t midMin, bigMin;
@@ -1599,9 +1825,9 @@ void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int
 		else hipLaunchKernelGGL(k_copy_big<0>, dim3(COPY_BIG_GRID), dim3(COPY_BIG_THREADS), 0, st, g, v, depth, bigQ, ctl + 5, bigCap, level, tmp, tmpCap, (uint32_t *)(ctl + 8 + 2 * (level & 3)), ctl + 9 + 2 * (level & 3), ctl + 8 + 2 * ((level + 1) & 3), err, pre);
 	}
 	if (midMin < bigMin) {
-		if (def == 1) hipLaunchKernelGGL(k_copy_mid<1>, dim3(1024), dim3(64 * COPY_MID_WAVES), 0, stMid, g, v, depth, midQ, ctl + 6, midCap, level, err);
-		else if (def == 2) hipLaunchKernelGGL(k_copy_mid<2>, dim3(1024), dim3(64 * COPY_MID_WAVES), 0, stMid, g, v, depth, midQ, ctl + 6, midCap, level, err);
-		else hipLaunchKernelGGL(k_copy_mid<0>, dim3(1024), dim3(64 * COPY_MID_WAVES), 0, stMid, g, v, depth, midQ, ctl + 6, midCap, level, err);
+		if (def == 1) hipLaunchKernelGGL(k_copy_mid<1>, dim3(1024), dim3(64 * COPY_MID_WAVES), 0, stMid, g, v, depth, midQ, ctl + 6, midCap, level, err, pre && preMid && midQ == bigQ + bigCap ? pre + bigCap : nullptr);
+		else if (def == 2) hipLaunchKernelGGL(k_copy_mid<2>, dim3(1024), dim3(64 * COPY_MID_WAVES), 0, stMid, g, v, depth, midQ, ctl + 6, midCap, level, err, pre && preMid && midQ == bigQ + bigCap ? pre + bigCap : nullptr);
+		else hipLaunchKernelGGL(k_copy_mid<0>, dim3(1024), dim3(64 * COPY_MID_WAVES), 0, stMid, g, v, depth, midQ, ctl + 6, midCap, level, err, pre && preMid && midQ == bigQ + bigCap ? pre + bigCap : nullptr);
 	}
 	if (stMid != st) (void)hipEventRecord(evMid, stMid);
 	if (def == 1) hipLaunchKernelGGL(k_copy_list<1>, dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);

@@ -75,8 +75,11 @@ void launch_build_lists(const GraphDev &g, const RangeView &v, uint64_t giantBit
                         int32_t *bigQ = nullptr, int32_t bigCap = 0, int32_t *midQ = nullptr, int32_t midCap = 0, int32_t midMinKnob = 0, bool bigGroups = false);
 void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int32_t *depth, const int32_t *list, const int32_t *keyBase, int32_t level, int blocks,
                        int32_t midMinKnob, bool bigGroups, const int32_t *bigQ, int32_t bigCap, const int32_t *midQ, int32_t midCap, int32_t *ctl, int32_t *tmp, uint32_t tmpCap, int *err,
-                       hipStream_t st, hipStream_t stMid, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evMid, hipEvent_t evBig, const void *preDesc = nullptr); // preDesc: launch_copy_prewalk's descriptors
-void launch_copy_prewalk(const GraphDev &g, int def, const RangeView &v, const int32_t *bigQ, int32_t bigCap, const int32_t *ctl, void *desc, int blocks, hipStream_t st);
+                       hipStream_t st, hipStream_t stMid, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evMid, hipEvent_t evBig, const void *preDesc = nullptr, bool preMid = false); // preDesc: launch_copy_prewalk's descriptors
+int32_t copy_tile_count(int64_t arcsBound, int32_t nodes);
+void launch_copy_tile_bounds(const RangeView &v, int32_t ntiles, int32_t *tb, hipStream_t st);
+void launch_copy_tile(const GraphDev &g, int def, const RangeView &v, const int32_t *depth, const int32_t *tb, int32_t ntiles, int32_t midMinKnob, bool bigGroups, int *err, hipStream_t st);
+void launch_copy_prewalk(const GraphDev &g, int def, const RangeView &v, const int32_t *bigQ, int32_t bigCap, const int32_t *ctl, void *desc, int blocks, hipStream_t st, int32_t midCap = 0); // midCap > 0: also the wave class's rows (queue at bigQ + bigCap, descriptors at desc + bigCap)
 void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, void *arena = nullptr, int64_t arenaCap = 0, int32_t keyHi = NKEYS, int32_t dMax = 0x7fffffff); // records with >= dMax successors are somebody else's
 // one wave per record of `list` (ctl[which] entries, queue head ctl[which + 2]): k_parse_big<1>
 void launch_parse_listed(const GraphDev &g, int def, const RangeView &v, const int32_t *list, int32_t *ctl, int which, void *arena, int64_t arenaCap, int waves, int *err, hipStream_t st);

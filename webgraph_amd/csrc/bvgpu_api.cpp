@@ -147,6 +147,8 @@ struct bvg_graph {
 	bool adaptive = true;                                               // smaller jobs lower them (pick_thresholds) unless a knob pins them
 	int coop_waves = 4096, giant_groups = 256;
 	DevBuf copyq; // rows the copy pass merges with a group / a wave each (all levels), filled while the level lists are built
+	DevBuf ctilebounds; // k_copy_tile: first node of every tile
+	int copy_tile = 0; // BVGPU_COPY_TILE=1: tiles of neighbouring short rows merged in LDS before the level kernels (k_copy_tile: bit-exact, slower -- 4.4 ms of its own on the C5 shard)
 	DevBuf walkdesc; // k_copy_prewalk: 16 bytes per entry of the group class's queue
 	int prewalk_blocks = 1024;
 	int prewalk = 1; // BVGPU_PREWALK=0: k_copy_big walks its rows' block lists itself
@@ -157,7 +159,7 @@ struct bvg_graph {
 	hipStream_t sideA = nullptr, sideB = nullptr; // (more streams than this share hardware queues with each other: they would serialise)
 	bool ctl_clean = false;                       // ctl[4..16) were zeroed by this job's k_pick_coop
 	bool host_mode = false;                       // host_scan: sideB carries the PCIe copies, its kernels go to sideA
-	hipEvent_t evFork = nullptr, evA = nullptr, evB = nullptr, evC = nullptr, evHdr = nullptr, evP = nullptr, evW = nullptr, evM = nullptr;
+	hipEvent_t evFork = nullptr, evA = nullptr, evB = nullptr, evC = nullptr, evHdr = nullptr, evP = nullptr, evW = nullptr, evM = nullptr, evL = nullptr;
 	bool overlap = true;
 	size_t halo_min = (size_t)16 << 20; // bytes of halo scratch an optimistic sub-range decode starts with (BVGPU_HALO_MIN)
 	bool force_halo_sync = false;   // (retry of an optimistic sub-range decode: size the halo with a host round trip)
@@ -245,6 +247,7 @@ int init_handle(bvg_graph *g) {
 	if (const char *e = getenv("BVGPU_SEG_HANDOVER")) g->seg_handover = atoi(e);
 	if (const char *e = getenv("BVGPU_WALK_TABLES")) g->walk_tables = atoi(e);
 	if (const char *e = getenv("BVGPU_PREWALK")) g->prewalk = atoi(e);
+	if (const char *e = getenv("BVGPU_COPY_TILE")) g->copy_tile = atoi(e);
 	if (const char *e = getenv("BVGPU_PREWALK_BLOCKS")) g->prewalk_blocks = std::max(1, atoi(e));
 	if (const char *e = getenv("BVGPU_IV_ARENA")) g->iv_arena = atoi(e);
 	if (const char *e = getenv("BVGPU_COPY_MID_MIN")) g->copy_mid_min = std::min(std::max(0, atoi(e)), 1024); // 0: no wave-per-row copy
@@ -267,6 +270,7 @@ int init_handle(bvg_graph *g) {
 	HIPCHK(g, hipEventCreateWithFlags(&g->evP, hipEventDisableTiming));
 	HIPCHK(g, hipEventCreateWithFlags(&g->evW, hipEventDisableTiming));
 	HIPCHK(g, hipEventCreateWithFlags(&g->evM, hipEventDisableTiming));
+	HIPCHK(g, hipEventCreateWithFlags(&g->evL, hipEventDisableTiming));
 	if (const char *e = getenv("BVGPU_STATS")) if (atoi(e)) { if (!g->stats.need(64 * sizeof(unsigned long long))) return fail(g, BVG_ENOMEM, "device allocation failed"); HIPCHK(g, hipMemset(g->stats.p, 0, 512)); }
 	return BVG_OK;
 }
@@ -375,7 +379,7 @@ int finish_pending(bvg_graph *g, uint64_t *arcs_out) {
 					const bool ov2 = g->overlap && !g->profile;
 					bv::launch_copy_level(gd, s.def, g->pend.view, g->depth.as<int32_t>(), g->lvlist.as<int32_t>(), keyBase, l, g->level_blocks, g->copy_mid_min, g->copy_big != 0,
 					                      g->copyq.as<int32_t>(), g->pend.bigCap, g->copyq.as<int32_t>() + g->pend.bigCap, g->pend.midCap, g->coopctl.as<int32_t>(), g->bigtmp.as<int32_t>(), g->pend.tmpCap, derr,
-					                      g->stream, ov2 ? side_b(g) : g->stream, ov2 ? g->sideA : g->stream, g->evFork, g->evB, g->evA, g->pend.preDesc);
+					                      g->stream, ov2 ? side_b(g) : g->stream, ov2 ? g->sideA : g->stream, g->evFork, g->evB, g->evA, g->pend.preDesc, g->prewalk < 2 && g->pend.midCap > 0);
 				}
 			}
 			g->pend.levels_done = upto;
@@ -462,7 +466,6 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		//   side A: chain depths + per-level lists + copy queues (only the copy pass needs them), then the big records (a wave each);
 		//   here:   the parse list and the one-lane parse of everything else.
 		hipStream_t stLists = g->stream;
-		const bool listsOnB = g->lists_on_b && !(g->seg && g->seg_handover); // (with the hand-over side B carries the segment pipeline's chain)
 		// parse list (every non-empty record, sorted by work bin inside windows of nodes): needs the outdegrees only, so
 		// with the headers' event at hand it is built on side A while the scan of the outdegrees still runs
 		int32_t *pKeyBase = nullptr;
@@ -510,6 +513,8 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 				if (g->seg_handover) bv::seg_handover(gd, g->segbuf.p, segRcapM, capBig, capGiant, segScap, segHubs ? g->seg_hub_min : 0, g->stream); // (before the fork: the cooperative kernels start behind it)
 			}
 		}
+		const bool listsOnB = g->lists_on_b == 1 && !(segReady && g->seg_handover); // (with the hand-over side B carries the segment pipeline's chain)
+		const bool listsOnC = g->lists_on_b == 2 && ovl;
 		if (!tiles) {
 			if (!g->plist.need(sizeof(int32_t) * (size_t)v.cnt) || !g->pkeys.need(3 * (bv::NKEYS + 1) * sizeof(int32_t)) || !g->pkey16.need(sizeof(uint16_t) * (size_t)v.cnt)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
 			pKeyBase = g->pkeys.as<int32_t>() + (bv::NKEYS + 1);
@@ -530,7 +535,8 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			HIPCHK(g, hipEventRecord(g->evFork, g->stream));
 			HIPCHK(g, hipStreamWaitEvent(g->sideA, g->evFork, 0));
 			HIPCHK(g, hipStreamWaitEvent(side_b(g), g->evFork, 0));
-			stLists = listsOnB ? side_b(g) : g->sideA;
+			stLists = listsOnB ? side_b(g) : listsOnC ? g->sideC : g->sideA;
+			if (listsOnC) HIPCHK(g, hipStreamWaitEvent(g->sideC, g->evFork, 0));
 			if (g->early_rowptr) { // the caller's rowptr needs the scan only: written now, not at the end of the call
 				if (v.rowstart != g->early_rowptr) bv::launch_rebase(v.nh, v.cnt, v.rowstart, g->early_rowptr, g->sideA);
 				hipLaunchKernelGGL(k_totals, dim3(1), dim3(1), 0, g->sideA, v.rowstart, v.nh, v.cnt, g->small.as<Small>(), v.coop_ptr, v.coop_min);
@@ -555,10 +561,17 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		                                  g->copyq.as<int32_t>(), bigCap, g->copyq.as<int32_t>() + bigCap, midCap, g->copy_mid_min, g->copy_big != 0);
 		// the block lists of the group class's rows, walked beside the parse kernels (k_copy_prewalk)
 		g->pend.preDesc = nullptr;
-		if (W > 0 && g->prewalk && g->copy_big && gd.walktab && s.def != 0 && g->walkdesc.need(16 * (size_t)bigCap)) {
-			bv::launch_copy_prewalk(gd, s.def, v, g->copyq.as<int32_t>(), bigCap, ctl, g->walkdesc.p, g->prewalk_blocks, stLists);
+		if (W > 0 && g->prewalk && g->copy_big && gd.walktab && s.def != 0 && g->walkdesc.need(16 * ((size_t)bigCap + (size_t)midCap))) {
+			bv::launch_copy_prewalk(gd, s.def, v, g->copyq.as<int32_t>(), bigCap, ctl, g->walkdesc.p, g->prewalk_blocks, stLists, g->prewalk >= 2 ? 0 : midCap); // (BVGPU_PREWALK=2: the group class only)
 			g->pend.preDesc = g->walkdesc.p;
 		}
+		int32_t ctiles = 0;
+		if (W > 0 && g->copy_tile && v.cnt > v.nh) {
+			ctiles = bv::copy_tile_count(arcsBound, v.cnt - v.nh);
+			if (g->ctilebounds.need(sizeof(int32_t) * ((size_t)ctiles + 2))) bv::launch_copy_tile_bounds(v, ctiles, g->ctilebounds.as<int32_t>(), stLists);
+			else ctiles = 0;
+		}
+		if (listsOnC) HIPCHK(g, hipEventRecord(g->evL, g->sideC));
 		if (ovl) HIPCHK(g, hipEventRecord(g->evA, g->sideA));
 		if (ovl && coop && listsOnB) HIPCHK(g, hipEventRecord(g->evB, side_b(g))); // (the lists sit behind the giants: side B is done when they are)
 		if (!tiles && !earlyList)
@@ -603,14 +616,16 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			HIPCHK(g, hipStreamWaitEvent(g->stream, g->evA, 0));
 			if (coop) HIPCHK(g, hipStreamWaitEvent(g->stream, g->evB, 0));
 			if (segJoin) HIPCHK(g, hipStreamWaitEvent(g->stream, g->evW, 0));
+			if (listsOnC) HIPCHK(g, hipStreamWaitEvent(g->stream, g->evL, 0));
 		}
 		mark(g, 6);
+		if (ctiles > 0) bv::launch_copy_tile(gd, s.def, v, g->depth.as<int32_t>(), g->ctilebounds.as<int32_t>(), ctiles, g->copy_mid_min, g->copy_big != 0, derr, g->stream);
 		if (W > 0) {
 			levels = g->levels_hint;
 			for (int32_t l = 1; l <= levels; l++) {
 				bv::launch_copy_level(gd, s.def, v, g->depth.as<int32_t>(), g->lvlist.as<int32_t>(), keyBase, l, g->level_blocks, g->copy_mid_min, g->copy_big != 0,
 				                                          g->copyq.as<int32_t>(), bigCap, g->copyq.as<int32_t>() + bigCap, midCap, ctl, g->bigtmp.as<int32_t>(), g->pend.tmpCap, derr,
-				                                          g->stream, ovl ? side_b(g) : g->stream, ovl ? g->sideA : g->stream, g->evFork, g->evB, g->evA, g->pend.preDesc);
+				                                          g->stream, ovl ? side_b(g) : g->stream, ovl ? g->sideA : g->stream, g->evFork, g->evB, g->evA, g->pend.preDesc, g->prewalk < 2 && g->pend.midCap > 0);
 			}
 		}
 	}
@@ -1074,13 +1089,13 @@ extern "C" int bvg_close(bvg_t *g) {
 	if (g->st && g->st->device >= 0) {
 		(void)hipSetDevice(g->st->device);
 		if (g->own) { (void)hipStreamSynchronize(g->own); (void)hipStreamDestroy(g->own); }
-		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->hashBounds, &g->pickpart, &g->walktab, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist, &g->plist, &g->pkeys, &g->pkey16, &g->copyq, &g->walkdesc, &g->bigtmp, &g->tilebounds }) b->release();
+		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->hashBounds, &g->pickpart, &g->walktab, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist, &g->plist, &g->pkeys, &g->pkey16, &g->copyq, &g->walkdesc, &g->ctilebounds, &g->bigtmp, &g->tilebounds }) b->release();
 		for (DevBuf *b : { &g->hchunk[0], &g->hchunk[1], &g->statsbuf, &g->bfs_rowptr, &g->bfs_succ, &g->bfs_ctr }) b->release();
 		for (PinBuf *b : { &g->hring[0], &g->hring[1], &g->view_rowptr, &g->view_succ }) b->release();
 		for (hipEvent_t e : { g->evChunk[0], g->evChunk[1], g->evCopied[0], g->evCopied[1] }) if (e) (void)hipEventDestroy(e);
 		if (g->h_small) (void)hipHostFree(g->h_small);
 		for (auto &e : g->ev) if (e) (void)hipEventDestroy(e);
-		for (hipEvent_t e : { g->evFork, g->evA, g->evB, g->evC, g->evHdr, g->evP, g->evW, g->evM, g->evIn, g->evOut }) if (e) (void)hipEventDestroy(e);
+		for (hipEvent_t e : { g->evFork, g->evA, g->evB, g->evC, g->evHdr, g->evP, g->evW, g->evM, g->evL, g->evIn, g->evOut }) if (e) (void)hipEventDestroy(e);
 		for (hipStream_t st : { g->sideA, g->sideB, g->sideC }) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
 	}
 	delete g;
