@@ -34,3 +34,14 @@ python scripts/pmc_summary.py $O/r4_pmc > $O/r4_seg_pmc_c2.txt 2>&1
 rm -rf $O/r4_pmc
 for wl in c5 cnr30; do timeout 300 python scripts/ab_time.py $wl 10 2>&1 | grep "| scan" | tail -1 >> $O/r4_seg_scan_times.txt; done
 cat $O/r4_seg_scan_times.txt | cut -c1-200
+# the C5 shard: per-kernel times (serial), timeline of an overlapped scan, the group class's phases with and without the pre-walk
+LINES_SHOWN=0 bash scripts/kstats.sh r4c5 c5 > /dev/null 2>&1; cp $O/kstats_r4c5.txt $O/r4_kernel_stats_serial_c5.txt
+cd /tmp; rm -rf /tmp/tl
+AB_NO_PROFILE=1 timeout 300 rocprofv3 --kernel-trace -d /tmp/tl -o res -- python $R/scripts/ab_time.py c5 3 > /tmp/tl.log 2>&1
+cd $R
+python scripts/timeline.py $(find /tmp/tl -name "*.db" | head -1) > $O/r4_timeline_c5.txt 2>&1
+for pw in 0 1; do echo "BVGPU_PREWALK=$pw" >> $O/r4_copybig_stats_c5.txt; BVGPU_PREWALK=$pw timeout 300 python scripts/copybig_stats.py c5 2>&1 | tail -12 >> $O/r4_copybig_stats_c5.txt; done
+for pw in 0 2 1; do for wl in c5 c2 cnr30; do BVGPU_PREWALK=$pw timeout 300 python scripts/ab_time.py $wl 10 2>&1 | grep "| scan" | tail -1 >> $O/r4_prewalk_scan_times.txt; done; done
+# hubs: rows of millions of successors, with and without the hand-over of their residuals (checked against the oracle)
+for sizes in "8000000 4000000 2000000" "3000000" "1000000 1000000 500000 500000"; do for sg in 0 1; do HUB_CHECK=1 BVGPU_SEG=$sg timeout 600 python scripts/hub_time.py $sizes 2>&1 | tail -1 >> $O/r4_hubs.txt; done; done
+cat $O/r4_hubs.txt $O/r4_prewalk_scan_times.txt | cut -c1-220

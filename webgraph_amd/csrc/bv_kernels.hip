@@ -720,7 +720,7 @@ __global__ void __launch_bounds__(64 * COPY_MID_WAVES) k_copy_mid(GraphDev g, Ra
 // levels at once, one wave per row, beside the parse kernels: a block list is a serial chain of codes that depends on nothing but the
 // stream, and walked inside k_copy_big -- by one wave of a 1024-thread group while the fifteen others wait, two groups per CU -- it was
 // 71 % of that kernel's time on the C5 shard (14 000 rows of 590 codes: 600 ticks per code walked by one lane, 105 per code by the
-// wave; profiles/r4_experiments.txt).  Here sixteen waves per CU walk, each its own row.  The tables (kend, delta, as in k_copy_mid)
+// wave; profiles/r4_experiments.txt).  Here eight waves per CU walk (the LDS of the cooperative walk), each its own row.  The tables (kend, delta, as in k_copy_mid)
 // go to the bump arena GraphDev::walktab, (bc >> 1) + 1 entries each; desc[qi] = (offset of the tables | -1 not walked: k_copy_big
 // walks the list itself | -2 nothing to merge or malformed, number of copied blocks, copied ids, block count).
 constexpr int PREWALK_WAVES = 4;
