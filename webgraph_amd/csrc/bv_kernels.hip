@@ -40,6 +40,8 @@ template <int DEF>
 __device__ __forceinline__ void copy_node(const GraphDev &g, int32_t x, int32_t d, int64_t dref, int32_t *__restrict__ row, const int32_t *__restrict__ src, int *__restrict__ err);
 template <int DEF>
 __device__ __forceinline__ void parse_node(const GraphDev &g, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row, int *__restrict__ err);
+template <int DEF>
+__device__ __forceinline__ void copy_node_v(const GraphDev &g, int32_t x, int32_t d, int32_t dref, int32_t *__restrict__ row, const int32_t *__restrict__ src, int *__restrict__ err);
 
 // ------------------------------------------------------------------------------------------------ headers
 template <int DEF>
@@ -486,7 +488,7 @@ __device__ __forceinline__ int copy_class(const RangeView &v, const int32_t *__r
 	if (!v.fits(s) || !v.fits(s - v.ref[s])) return 0; // E_CAP / E_HALO already raised by the parse kernel
 	return copy_class_of(v.outd[s], v.outd[s - v.ref[s]], midMin, bigMin);
 }
-template <int DEF>
+template <int DEF, bool VEC>
 __global__ void __launch_bounds__(TPB) k_copy_list(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ list,
                                                    const int32_t *__restrict__ keyBase, int32_t level, int32_t midMin, int32_t bigMin, int *__restrict__ err) {
 	const int32_t bucket = min(level, MAXLVL - 1);
@@ -495,7 +497,8 @@ __global__ void __launch_bounds__(TPB) k_copy_list(GraphDev g, RangeView v, cons
 		const int32_t s = list[idx];
 		if (copy_class(v, depth, level, s, midMin, bigMin) != 1) continue;
 		const int32_t r = v.ref[s];
-		copy_node<DEF>(g, v.lo + s, v.outd[s], (int64_t)v.outd[s - r], v.row(s), v.row(s - r), err);
+		if (VEC) copy_node_v<DEF>(g, v.lo + s, v.outd[s], v.outd[s - r], v.row(s), v.row(s - r), err);
+		else copy_node<DEF>(g, v.lo + s, v.outd[s], (int64_t)v.outd[s - r], v.row(s), v.row(s - r), err);
 	}
 }
 
@@ -1368,6 +1371,93 @@ __device__ __forceinline__ void copy_node(const GraphDev &g, int32_t x, int32_t 
 	if (br.err) atomicOr(err, br.err);
 }
 
+// copy_node for the lane class of the copy pass (k_copy_list), with a quarter of its memory instructions.  A wave of k_copy_list
+// touches 64 different rows with every load and store, and its counters put it at the rate at which the texture path takes scattered
+// cache lines (11.4 M memory instructions per launch on the C5 shard, ~1.6 lines per cycle and CU, full occupancy): what it issues
+// per id is what it costs.  Here the referent's ids and the row's extras are read 16 bytes at a time into registers (unaligned
+// dwordx4 loads: gfx950 takes them), the merged ids leave 16 bytes at a time once the write index is 16-byte aligned, and the first
+// four block lengths stay in registers from the first walk of the list (a second walk only for longer lists, from the fifth code).
+// In place, as copy_node: a store goes to k - 4 .. k - 1 with k <= j, and every extra below j has been read (the buffered ones at
+// j .. j + 3 too) by then.  Results identical to copy_node's.
+typedef int32_t i32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+template <int DEF>
+__device__ __forceinline__ void copy_node_v(const GraphDev &g, int32_t x, int32_t d, int32_t dref, int32_t *__restrict__ row, const int32_t *__restrict__ src, int *__restrict__ err) {
+	BitReader br;
+	br.init(g.bits, g.nwords);
+	br.seek((uint64_t)g.offsets[x]);
+	(void)Fields<DEF>::outdegree(br, g);
+	(void)Fields<DEF>::reference(br, g);
+	const uint64_t bc64 = Fields<DEF>::block_count(br, g);
+	if (bc64 > (uint64_t)dref + 1) return; // flagged in k_parse
+	const int32_t bc = (int32_t)bc64;
+	int32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0;
+	uint64_t pos4 = 0;
+	int64_t total = 0, copied64 = 0;
+	for (int32_t b = 0; b < bc; b++) {
+		if (b == 4) pos4 = br.pos();
+		int64_t len;
+		if (!block_len_ok(Fields<DEF>::block(br, g), b == 0, total, (int64_t)dref, len)) return; // flagged by the parse kernel
+		if (b == 0) l0 = (int32_t)len; else if (b == 1) l1 = (int32_t)len; else if (b == 2) l2 = (int32_t)len; else if (b == 3) l3 = (int32_t)len;
+		total += len;
+		if (!(b & 1)) copied64 += len;
+	}
+	if (!(bc & 1)) copied64 += dref - total;
+	if (copied64 > d) return;
+	if (copied64 == 0) { if (br.err) atomicOr(err, br.err); return; } // the extras are the row
+	if (bc > 4) br.seek(pos4);
+	const int32_t copied = (int32_t)copied64;
+
+	// the extras row[copied .. d), four at a time
+	int32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0, en = 0, ej = copied; // buffered extras (e0 is the head), how many, index of the next one to load
+	auto ext_fill = [&] {
+		if (ej + 4 <= d) { const i32x4_u q = *(const i32x4_u *)(row + ej); e0 = q.x; e1 = q.y; e2 = q.z; e3 = q.w; en = 4; ej += 4; }
+		else if (ej < d) { e0 = row[ej++]; en = 1; }
+	};
+	auto ext_pop = [&] { e0 = e1; e1 = e2; e2 = e3; if (--en == 0) ext_fill(); };
+	ext_fill();
+	// the referent's ids, four at a time inside a copied block
+	int32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, sn = 0;
+	// output: scalar stores up to the first 16-byte boundary, then 16 bytes at a time
+	int32_t k = 0, o0 = 0, o1 = 0, o2 = 0, o3 = 0, on = 0;
+	const int32_t head = min(d, (int32_t)(((16u - ((uint32_t)(uintptr_t)row & 15u)) & 15u) >> 2));
+	auto emit = [&](int32_t val) {
+		if (k < head) { row[k++] = val; return; }
+		o0 = o1; o1 = o2; o2 = o3; o3 = val; k++;
+		if (++on == 4) { *(int4 *)(row + k - 4) = int4{ o0, o1, o2, o3 }; on = 0; }
+	};
+	int32_t i = 0; // index in the referent's row
+	for (int32_t b = 0; b <= bc; b++) {
+		int32_t len;
+		if (b >= bc) len = dref - i; // implicit last block: the rest of the referent
+		else if (b == 0) len = l0; else if (b == 1) len = l1; else if (b == 2) len = l2; else if (b == 3) len = l3;
+		else len = (int32_t)Fields<DEF>::block(br, g) + 1;
+		if (b & 1) { i += len; continue; } // skip block
+		const int32_t end = min(i + len, dref);
+		sn = 0;
+		while (i < end && k < d) { // (the bounds hold by the checks above: belt and braces)
+			if (sn == 0) {
+				if (i + 4 <= end) { const i32x4_u q = *(const i32x4_u *)(src + i); s0 = q.x; s1 = q.y; s2 = q.z; s3 = q.w; sn = 4; }
+				else { s0 = src[i]; sn = 1; }
+			}
+			const int32_t cv = s0;
+			s0 = s1; s1 = s2; s2 = s3; sn--; i++;
+			while (en && e0 < cv && k < d) { emit(e0); ext_pop(); }
+			if (en && e0 == cv) ext_pop(); // equal heads emitted once (never in a valid file)
+			emit(cv);
+		}
+	}
+	// the pending ids; the remaining extras are in place already when no duplicate was dropped (k + remaining == d)
+	const int32_t left = en + (d - ej); // extras not emitted yet
+	if (k + left != d) { // a malformed duplicate left a gap: move the rest down, pad with -1 (as copy_node)
+		while (en && k < d) { emit(e0); ext_pop(); }
+		while (k < d) emit(-1);
+	}
+	if (on == 3) { row[k - 3] = o1; row[k - 2] = o2; row[k - 1] = o3; }
+	else if (on == 2) { row[k - 2] = o2; row[k - 1] = o3; }
+	else if (on == 1) row[k - 1] = o3;
+	if (br.err) atomicOr(err, br.err);
+}
+
 template <int DEF>
 __device__ __forceinline__ void read_header(const GraphDev &g, int32_t x, int32_t &d, int32_t &r, int &e) {
 	BitReader br;
@@ -1801,7 +1891,7 @@ void launch_copy_prewalk(const GraphDev &g, int def, const RangeView &v, const i
 }
 void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int32_t *depth, const int32_t *list, const int32_t *keyBase, int32_t level, int blocks,
                        int32_t midMinKnob, bool bigGroups, const int32_t *bigQ, int32_t bigCap, const int32_t *midQ, int32_t midCap, int32_t *ctl, int32_t *tmp, uint32_t tmpCap, int *err,
-                       hipStream_t st, hipStream_t stMid, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evMid, hipEvent_t evBig, const void *preDesc, bool preMid) {
+                       hipStream_t st, hipStream_t stMid, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evMid, hipEvent_t evBig, const void *preDesc, bool preMid, bool vecList) {
 	if (v.cnt <= 0) return;
 	const int4 *pre = (const int4 *)preDesc;
 	int32_t midMin, bigMin;
@@ -1830,9 +1920,11 @@ void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int
 		else hipLaunchKernelGGL(k_copy_mid<0>, dim3(1024), dim3(64 * COPY_MID_WAVES), 0, stMid, g, v, depth, midQ, ctl + 6, midCap, level, err, pre && preMid && midQ == bigQ + bigCap ? pre + bigCap : nullptr);
 	}
 	if (stMid != st) (void)hipEventRecord(evMid, stMid);
-	if (def == 1) hipLaunchKernelGGL(k_copy_list<1>, dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
-	else if (def == 2) hipLaunchKernelGGL(k_copy_list<2>, dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
-	else hipLaunchKernelGGL(k_copy_list<0>, dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
+#define COPY_LIST(D, V) hipLaunchKernelGGL((k_copy_list<D, V>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err)
+	if (def == 1) { if (vecList) COPY_LIST(1, true); else COPY_LIST(1, false); }
+	else if (def == 2) { if (vecList) COPY_LIST(2, true); else COPY_LIST(2, false); }
+	else { if (vecList) COPY_LIST(0, true); else COPY_LIST(0, false); }
+#undef COPY_LIST
 	if (stList != st) (void)hipEventRecord(evBig, stList);
 	if (stMid != st) (void)hipStreamWaitEvent(st, evMid, 0);
 	if (stList != st) (void)hipStreamWaitEvent(st, evBig, 0);

@@ -75,7 +75,7 @@ void launch_build_lists(const GraphDev &g, const RangeView &v, uint64_t giantBit
                         int32_t *bigQ = nullptr, int32_t bigCap = 0, int32_t *midQ = nullptr, int32_t midCap = 0, int32_t midMinKnob = 0, bool bigGroups = false);
 void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int32_t *depth, const int32_t *list, const int32_t *keyBase, int32_t level, int blocks,
                        int32_t midMinKnob, bool bigGroups, const int32_t *bigQ, int32_t bigCap, const int32_t *midQ, int32_t midCap, int32_t *ctl, int32_t *tmp, uint32_t tmpCap, int *err,
-                       hipStream_t st, hipStream_t stMid, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evMid, hipEvent_t evBig, const void *preDesc = nullptr, bool preMid = false); // preDesc: launch_copy_prewalk's descriptors
+                       hipStream_t st, hipStream_t stMid, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evMid, hipEvent_t evBig, const void *preDesc = nullptr, bool preMid = false, bool vecList = false); // vecList: the lane class merges with 16-byte loads and stores (copy_node_v) // preDesc: launch_copy_prewalk's descriptors
 int32_t copy_tile_count(int64_t arcsBound, int32_t nodes);
 void launch_copy_tile_bounds(const RangeView &v, int32_t ntiles, int32_t *tb, hipStream_t st);
 void launch_copy_tile(const GraphDev &g, int def, const RangeView &v, const int32_t *depth, const int32_t *tb, int32_t ntiles, int32_t midMinKnob, bool bigGroups, int *err, hipStream_t st);
@@ -89,7 +89,7 @@ constexpr int PARSE_LONG_BIN = 14; // work bins from here up (>= 2048 bits of wo
 void launch_parse_flat(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int32_t keyHi, int blocks, void *arena, int64_t arenaCap,
                        int32_t *fblist, int32_t *ctl, int *err, hipStream_t st);
 size_t seg_scratch_bytes(int32_t Rtot, int32_t Scap, int zetaK);
-void launch_seg_sizing(const int64_t *offsets, int32_t lo, int32_t n, const int32_t *outd, unsigned long long *out3, hipStream_t st); // load time: records of the long work bins, their bits, the largest outdegree
+void launch_seg_sizing(const int64_t *offsets, int32_t lo, int32_t n, const int32_t *outd, const uint16_t *ref, unsigned long long *out5, hipStream_t st); // out5 (zeroed by the caller): records and bits of the long bins, longest record, rows and ids of the copy pass's lane class // load time: records of the long work bins, their bits, the largest outdegree
 int32_t seg_bits_log2();
 // records of the pipeline: [0, RcapM) the parse list's long bins, then capBig / capGiant hand-over slots of the cooperative kernels' queues (Rtot = the sum)
 void seg_handover(GraphDev &g, void *scratch, int32_t RcapM, int32_t capBig, int32_t capGiant, int32_t Scap, int32_t minD, hipStream_t st); // minD: records with fewer successors are not handed over

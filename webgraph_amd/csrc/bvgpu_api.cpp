@@ -68,6 +68,7 @@ struct Staged {
 	std::vector<int64_t> h_offsets; // host copy: shard bounds and halo sizing
 	int64_t arcs_sizing = 0;        // max(arcs property, sum of the outdegrees in the stream): what scratch is sized by
 	int64_t max_outdegree = -1; // the longest staged record (counted with arcs_sizing; -1: unknown)
+	int64_t lane_rows = 0, lane_ids = 0; // staged rows with a reference and fewer than 128 successors, and their ids (the lane class of the copy pass)
 	int64_t seg_long_records = -1, seg_long_bits = -1; // staged records with >= 2 048 bits of work (the parse list's long bins) and their bits (counted with arcs_sizing; -1: unknown): they size the segment pipeline
 	int32_t deg_counts[5] = { -1, -1, -1, -1, -1 }; // staged records with >= 128, 256, 512, 1024, 2048 successors (counted with arcs_sizing; -1: unknown)
 	int def = 0;                    // kernel variant: 1 default codings with zeta_3, 2 default codings with another zeta_k, 0 generic
@@ -150,6 +151,7 @@ struct bvg_graph {
 	DevBuf ctilebounds; // k_copy_tile: first node of every tile
 	int copy_tile = 0; // BVGPU_COPY_TILE=1: tiles of neighbouring short rows merged in LDS before the level kernels (k_copy_tile: bit-exact, slower -- 4.4 ms of its own on the C5 shard)
 	DevBuf walkdesc; // k_copy_prewalk: 16 bytes per entry of the group class's queue
+	int copy_vec = -1; // BVGPU_COPY_VEC=1|0: the lane class of the copy pass merges with 16-byte loads and stores (copy_node_v) or id by id; -1: by the mean length of its rows (counted at load time)
 	int prewalk_blocks = 1024;
 	int prewalk = 1; // BVGPU_PREWALK=0: k_copy_big walks its rows' block lists itself
 	DevBuf bigtmp; // global scratch tables for rows that copy more ids than the LDS tables of k_copy_big hold
@@ -188,6 +190,7 @@ struct bvg_graph {
 namespace {
 
 bv::GraphDev graph_dev0(const Staged &s);
+bool copy_vec(const bvg_graph *g);
 bv::GraphDev graph_dev_h(const bvg_graph *g, const Staged &s) { bv::GraphDev d = graph_dev0(s); d.stats = (unsigned long long *)g->stats.p; d.dbg = getenv("BVGPU_DBG") ? atoi(getenv("BVGPU_DBG")) : 0; return d; }
 
 int fail(const bvg_graph *g, int code, const std::string &msg) { if (g) g->err = msg; return code; }
@@ -246,6 +249,7 @@ int init_handle(bvg_graph *g) {
 	if (const char *e = getenv("BVGPU_LISTS_ON_B")) g->lists_on_b = atoi(e);
 	if (const char *e = getenv("BVGPU_SEG_HANDOVER")) g->seg_handover = atoi(e);
 	if (const char *e = getenv("BVGPU_WALK_TABLES")) g->walk_tables = atoi(e);
+	if (const char *e = getenv("BVGPU_COPY_VEC")) g->copy_vec = atoi(e);
 	if (const char *e = getenv("BVGPU_PREWALK")) g->prewalk = atoi(e);
 	if (const char *e = getenv("BVGPU_COPY_TILE")) g->copy_tile = atoi(e);
 	if (const char *e = getenv("BVGPU_PREWALK_BLOCKS")) g->prewalk_blocks = std::max(1, atoi(e));
@@ -379,7 +383,7 @@ int finish_pending(bvg_graph *g, uint64_t *arcs_out) {
 					const bool ov2 = g->overlap && !g->profile;
 					bv::launch_copy_level(gd, s.def, g->pend.view, g->depth.as<int32_t>(), g->lvlist.as<int32_t>(), keyBase, l, g->level_blocks, g->copy_mid_min, g->copy_big != 0,
 					                      g->copyq.as<int32_t>(), g->pend.bigCap, g->copyq.as<int32_t>() + g->pend.bigCap, g->pend.midCap, g->coopctl.as<int32_t>(), g->bigtmp.as<int32_t>(), g->pend.tmpCap, derr,
-					                      g->stream, ov2 ? side_b(g) : g->stream, ov2 ? g->sideA : g->stream, g->evFork, g->evB, g->evA, g->pend.preDesc, g->prewalk < 2 && g->pend.midCap > 0);
+					                      g->stream, ov2 ? side_b(g) : g->stream, ov2 ? g->sideA : g->stream, g->evFork, g->evB, g->evA, g->pend.preDesc, g->prewalk < 2 && g->pend.midCap > 0, copy_vec(g));
 				}
 			}
 			g->pend.levels_done = upto;
@@ -412,6 +416,15 @@ void pick_thresholds(const bvg_graph *g, int64_t estArcs, int32_t &coopMin, int3
 	// (a lane takes ~0.6 us per successor, a wave ~30 us per record: cnr-2000, 3.2 M arcs, 0.80 ms at 512, 0.62 ms at 128)
 	if (estArcs < 8000000) coopMin = 128; else if (estArcs < 32000000) coopMin = 512; else if (estArcs < 80000000) coopMin = 1024;
 	if (estArcs < 150000000) giantMin = 8192;
+}
+
+// The lane class of the copy pass reads and writes 16 bytes at a time where its rows are long enough to pay for the bookkeeping:
+// cnr-2000 (14.4 ids per row of the class, copied in runs of 6.6) gains 13 % on k_copy_list, the synthetic workloads (6.9 and 8.8 ids,
+// runs of 4.5 and 2.4) lose 5-8 %.
+bool copy_vec(const bvg_graph *g) {
+	if (g->copy_vec >= 0) return g->copy_vec != 0;
+	const Staged &s = *g->st;
+	return s.lane_rows > 0 && s.lane_ids >= 11 * s.lane_rows;
 }
 
 int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &levels, int32_t &giantCap, bool hdrEvent = false) {
@@ -625,7 +638,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			for (int32_t l = 1; l <= levels; l++) {
 				bv::launch_copy_level(gd, s.def, v, g->depth.as<int32_t>(), g->lvlist.as<int32_t>(), keyBase, l, g->level_blocks, g->copy_mid_min, g->copy_big != 0,
 				                                          g->copyq.as<int32_t>(), bigCap, g->copyq.as<int32_t>() + bigCap, midCap, ctl, g->bigtmp.as<int32_t>(), g->pend.tmpCap, derr,
-				                                          g->stream, ovl ? side_b(g) : g->stream, ovl ? g->sideA : g->stream, g->evFork, g->evB, g->evA, g->pend.preDesc, g->prewalk < 2 && g->pend.midCap > 0);
+				                                          g->stream, ovl ? side_b(g) : g->stream, ovl ? g->sideA : g->stream, g->evFork, g->evB, g->evA, g->pend.preDesc, g->prewalk < 2 && g->pend.midCap > 0, copy_vec(g));
 			}
 		}
 	}
@@ -1007,7 +1020,7 @@ static int open_impl(const char *basename, int device, int part, int parts, bvg_
 		const int32_t n = st->node_hi - st->stage_lo;
 		void *p_outd = nullptr, *p_ref = nullptr, *p_rs = nullptr, *p_sums = nullptr, *p_err = nullptr, *p_part = nullptr;
 		const bool ok = hipMalloc(&p_outd, sizeof(int32_t) * (size_t)n) == hipSuccess && hipMalloc(&p_ref, sizeof(uint16_t) * (size_t)n) == hipSuccess &&
-		                hipMalloc(&p_rs, sizeof(int64_t) * ((size_t)n + 4)) == hipSuccess /* (also the three counters of the sizing pass) */ && hipMalloc(&p_sums, sizeof(int64_t) * (size_t)bv::scan_num_sums(n)) == hipSuccess &&
+		                hipMalloc(&p_rs, sizeof(int64_t) * ((size_t)n + 8)) == hipSuccess /* (also the five counters of the sizing pass) */ && hipMalloc(&p_sums, sizeof(int64_t) * (size_t)bv::scan_num_sums(n)) == hipSuccess &&
 		                hipMalloc(&p_err, sizeof(int)) == hipSuccess && hipMalloc(&p_part, sizeof(int32_t) * (5 * (size_t)bv::headers_blocks(n) + 8)) == hipSuccess;
 		int64_t total = 0;
 		hipError_t e = ok ? hipMemset(p_err, 0, sizeof(int)) : hipErrorOutOfMemory;
@@ -1019,10 +1032,10 @@ static int open_impl(const char *basename, int device, int part, int parts, bvg_
 			e = hipMemcpy(&total, (int64_t *)p_rs + n, sizeof(int64_t), hipMemcpyDeviceToHost);
 			if (e == hipSuccess) e = hipMemcpy(st->deg_counts, (int32_t *)p_part + 5 * hb, sizeof(st->deg_counts), hipMemcpyDeviceToHost);
 			if (e == hipSuccess && st->def != 0) { // (p_rs is done with: two counters)
-				unsigned long long three[3] = { 0, 0, 0 };
-				e = hipMemset(p_rs, 0, sizeof(three));
-				if (e == hipSuccess) { bv::launch_seg_sizing(st->d_offsets, st->stage_lo, n, (const int32_t *)p_outd, (unsigned long long *)p_rs, nullptr); e = hipMemcpy(three, p_rs, sizeof(three), hipMemcpyDeviceToHost); }
-				if (e == hipSuccess) { st->seg_long_records = (int64_t)three[0]; st->seg_long_bits = (int64_t)three[1]; st->max_outdegree = (int64_t)three[2]; }
+				unsigned long long five[5] = { 0, 0, 0, 0, 0 };
+				e = hipMemset(p_rs, 0, sizeof(five));
+				if (e == hipSuccess) { bv::launch_seg_sizing(st->d_offsets, st->stage_lo, n, (const int32_t *)p_outd, (const uint16_t *)p_ref, (unsigned long long *)p_rs, nullptr); e = hipMemcpy(five, p_rs, sizeof(five), hipMemcpyDeviceToHost); }
+				if (e == hipSuccess) { st->seg_long_records = (int64_t)five[0]; st->seg_long_bits = (int64_t)five[1]; st->max_outdegree = (int64_t)five[2]; st->lane_rows = (int64_t)five[3]; st->lane_ids = (int64_t)five[4]; }
 			}
 		}
 		for (void *q : { p_outd, p_ref, p_rs, p_sums, p_err, p_part }) if (q) (void)hipFree(q);
