@@ -86,6 +86,10 @@ def test_store_errors(tmp_path):
     rowptr = np.array([0, 3, 5], dtype=np.int64)
     with pytest.raises(ValueError):  # a row that is not strictly increasing
         B.store(rowptr, np.array([1, 1, 2, 0, 4], dtype=np.int32), str(tmp_path / "x"))
+    with pytest.raises(ValueError):  # a negative id; the id that the wave path pads its tiles with
+        B.store(rowptr, np.array([-1, 1, 2, 0, 4], dtype=np.int32), str(tmp_path / "x"))
+    with pytest.raises(ValueError):
+        B.store(rowptr, np.array([0, 1, 2, 3, 2**31 - 1], dtype=np.int32), str(tmp_path / "x"))
     with pytest.raises(ValueError):
         B.store(rowptr, np.array([0, 1, 2, 3, 4], dtype=np.int32), str(tmp_path / "x"), windowSize=-1)
     with pytest.raises(NotImplementedError):  # windows above the device compressor's limit

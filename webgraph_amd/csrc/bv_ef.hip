@@ -312,7 +312,8 @@ __global__ void __launch_bounds__(256) k_ef_rank(const EfDev g, const int32_t *_
 		if ((uint64_t)at + rounds > chunkCap) { // no room (a batch that asks for the same giant list many times): this wave decodes it, round after round
 			for (uint64_t j = (uint64_t)at + lane; j < chunkCap; j += 64) chunks[j].slot = -1;
 			uint64_t done = 0;
-			for (uint64_t w0 = wFirst; done < d && w0 < g.nwords; w0 += 64) done += ef_round<HASH>(g, r, HASH ? s : base, d, w0, done, low, lane, succ);
+			for (uint64_t w0 = wFirst; done < d && w0 < wEnd; w0 += 64) done += ef_round<HASH>(g, r, HASH ? s : base, d, w0, done, low, lane, succ);
+			if (done < d && lane == 0) atomicOr(err, E_FORMAT);
 			continue;
 		}
 		uint64_t rank = 0;
@@ -332,6 +333,7 @@ __global__ void __launch_bounds__(256) k_ef_rank(const EfDev g, const int32_t *_
 				if (rd + u < rounds) { if (lane == 0) chunks[at + rd + u] = EfChunk{ (int32_t)s, rd + u, rank }; rank += c[u]; }
 			}
 		}
+		if (rank < d && lane == 0) atomicOr(err, E_FORMAT); // fewer ones than successors before the record ends: part of the row would stay unwritten
 	}
 }
 }

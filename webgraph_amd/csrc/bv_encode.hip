@@ -623,7 +623,7 @@ int encode_device(const Params &p, int32_t n, const int64_t *d_rowptr, const int
 	launch_scan(reclen, n, out.offsets, sums, st);
 	int64_t totalBits = 0;
 	if (hipMemcpyAsync(&totalBits, out.offsets + n, sizeof(int64_t), hipMemcpyDeviceToHost, st) != hipSuccess || hipMemcpyAsync(&herr, flags, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { err = "the compressor kernels failed"; return cleanup(-6); }
-	if (herr & 1) { err = "successor lists must be strictly increasing"; return cleanup(-1); }
+	if (herr & 1) { err = "successor lists must be strictly increasing, with ids in [0, 2^31 - 1)"; return cleanup(-1); }
 	if (herr & 4) { err = "the segment table of the cut pairs overflowed"; return cleanup(-6); }
 	if (herr) { err = "a record of 2^31 bits or more"; return cleanup(-3); }
 	mark();

@@ -244,6 +244,7 @@ BVE_HD uint32_t pair_cost(const Params &p, const int64_t *__restrict__ rowptr, c
 	const int32_t dr = r == 0 ? 0 : (int32_t)(rowptr[y + 1] - b);
 	if (r != 0 && dr == 0) return COST_NONE;
 	if (r == 0) for (int32_t j = 1; j < d; j++) if (succ[a + j] <= succ[a + j - 1]) *err |= 1; // the lists must increase strictly (every non-empty list has this pair)
+	if (r == 0 && (succ[a] < 0 || succ[a + d - 1] == INT32_MAX)) *err |= 1; // node ids: never negative, and 2^31 - 1 is the padding of the wave path's tiles
 	CountVisitor<DEF> v(p, x);
 	const int32_t nextra = diff_walk(succ + a, d, succ + b, dr, p.I, v);
 	const uint64_t t = v.total(r, nextra);

@@ -252,7 +252,7 @@ __device__ __forceinline__ uint32_t wave_pair_cost(const Params &p, const int64_
 	if (r != 0) bve::f_bc<DEF>(s, p, t.nb);
 	if (t.nextra > 0 && p.I != 0) bve::w_gamma(s, t.ni);
 	const uint64_t total = s.bits + (r != 0 ? t.bitsB : 0) + t.bitsI + t.bitsR;
-	if (t.bad) *err |= 1;
+	if (t.bad || (r == 0 && d > 0 && (succ[a] < 0 || succ[a + d - 1] == INT32_MAX))) *err |= 1; // (as pair_cost: ids in [0, 2^31 - 1))
 	if (total > bve::COST_MAX) { *err |= 2; return bve::COST_NONE; }
 	return (uint32_t)total;
 }
