@@ -493,12 +493,22 @@ __global__ void __launch_bounds__(TPB) k_copy_list(GraphDev g, RangeView v, cons
                                                    const int32_t *__restrict__ keyBase, int32_t level, int32_t midMin, int32_t bigMin, int *__restrict__ err) {
 	const int32_t bucket = min(level, MAXLVL - 1);
 	const int32_t lo = keyBase[bucket * NBIN], hi = keyBase[(bucket + 1) * NBIN];
+	const int64_t rsNh = v.rowstart[v.nh];
 	for (int32_t idx = hi - 1 - (blockIdx.x * TPB + threadIdx.x); idx >= lo; idx -= gridDim.x * TPB) {
+		// (copy_class and RangeView::row / ::fits spelled out: every load of this kernel goes to a line of its own, so each is issued once --
+		// the outdegrees are differences of the row starts, which are needed anyway)
 		const int32_t s = list[idx];
-		if (copy_class(v, depth, level, s, midMin, bigMin) != 1) continue;
 		const int32_t r = v.ref[s];
-		if (VEC) copy_node_v<DEF>(g, v.lo + s, v.outd[s], v.outd[s - r], v.row(s), v.row(s - r), err);
-		else copy_node<DEF>(g, v.lo + s, v.outd[s], (int64_t)v.outd[s - r], v.row(s), v.row(s - r), err);
+		if (r == 0 || (level >= MAXLVL - 1 && depth[s] != level)) continue;
+		const int32_t t = s - r;
+		const int64_t rs0 = v.rowstart[s], rs1 = v.rowstart[s + 1], rt0 = v.rowstart[t], rt1 = v.rowstart[t + 1];
+		if (!(s >= v.nh ? (uint64_t)(rs1 - rsNh) <= v.succ_cap : (uint64_t)rs1 <= v.halo_cap) || !(t >= v.nh ? (uint64_t)(rt1 - rsNh) <= v.succ_cap : (uint64_t)rt1 <= v.halo_cap)) continue; // E_CAP / E_HALO already raised by the parse kernel
+		const int32_t d = (int32_t)(rs1 - rs0), dref = (int32_t)(rt1 - rt0);
+		if (copy_class_of(d, dref, midMin, bigMin) != 1) continue;
+		int32_t *row = s < v.nh ? v.halo + rs0 : v.succ + (rs0 - rsNh);
+		const int32_t *src = t < v.nh ? v.halo + rt0 : v.succ + (rt0 - rsNh);
+		if (VEC) copy_node_v<DEF>(g, v.lo + s, d, dref, row, src, err);
+		else copy_node<DEF>(g, v.lo + s, d, (int64_t)dref, row, src, err);
 	}
 }
 
