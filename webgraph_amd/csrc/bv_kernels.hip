@@ -748,7 +748,7 @@ __global__ void __launch_bounds__(64 * PREWALK_WAVES) k_copy_prewalk(GraphDev g,
 		const int32_t s = queue[qi];
 		int4 out = int4{ -1, 0, 0, 0 };
 		const int32_t r = v.ref[s], d = v.outd[s];
-		if (r != 0 && v.fits(s) && v.fits(s - r) && !(d >= g.walkMin)) { // (the giant records' tables fall out of their parse: bv_coop.hpp)
+		if (r != 0 && v.fits(s) && v.fits(s - r)) {
 			const int64_t dref = v.outd[s - r];
 			LaneWin<LW_MAIN> lw;
 			lw.col = lwin + threadIdx.x;
@@ -759,6 +759,7 @@ __global__ void __launch_bounds__(64 * PREWALK_WAVES) k_copy_prewalk(GraphDev g,
 			(void)lw.template code<2>(g, e);
 			const uint64_t bc = lw.template code<1>(g, e);
 			if (e || bc > (uint64_t)dref + 1) out.x = -2; // flagged by the parse kernel
+			else if (d >= g.walkMin && bc >= (uint64_t)COPY_GROUP_WALK_MIN) {} // a giant record's long list: its tables fall out of its parse (coop_parse_node, bv_coop.hpp)
 			else {
 				const uint64_t kMax = (bc >> 1) + 1, need = 2 * kMax;
 				int64_t off = -1;
@@ -862,6 +863,9 @@ __global__ void __launch_bounds__(LW_STRIDE) k_copy_prewalk_lanes(GraphDev g, Ra
 #define COPY_BIG_THREADS_ 1024
 #define COPY_BIG_CAP_ 6144
 #endif
+#ifndef COPY_BIG_LEAN_
+#define COPY_BIG_LEAN_ 1
+#endif
 // (512 threads and LDS tables for 2048 copied ids -- 38 KB of LDS, four groups per CU instead of one -- changed nothing on C2 and
 // cnr-2000 x30 and cost 4 % on C5: a level of k_copy_big lasts as long as its longest row, not as long as its rows in sum.)
 constexpr int COPY_BIG_THREADS = COPY_BIG_THREADS_, COPY_BIG_CAP = COPY_BIG_CAP_, COPY_BIG_ITEMS = 8, COPY_BIG_FIRST = 16384, COPY_BIG_TAKE = 8, COPY_BIG_GRID = 256 * (2048 / COPY_BIG_THREADS);
@@ -882,8 +886,11 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 	__shared__ int32_t tabs[3 * COPY_BIG_CAP + 2];
 	int32_t *const cval = tabs, *const cpos = tabs + COPY_BIG_CAP, *const delta = tabs + 2 * COPY_BIG_CAP + 1;
 	__shared__ int32_t s_b[2];
-	__shared__ uint32_t lwin[DEF ? LW_MAIN * LW_STRIDE : 1]; // stream window of the wave that walks the block list
-	__shared__ __attribute__((aligned(16))) uint32_t cwin[DEF ? CoopLds<1>::WORDS : 4]; // tile of the cooperative walk of a long block list
+	// (since k_copy_prewalk the group walks a list itself only when the pre-walk could not -- its arena was full, it is off, a giant row whose parse kernel kept no
+	// tables --: one lane through the generic reader then, and no 29 KB of LDS for the lane window and the cooperative walk's tile held by every group)
+	constexpr bool OWN_WALK = DEF != 0 && !COPY_BIG_LEAN_;
+	__shared__ uint32_t lwin[OWN_WALK ? LW_MAIN * LW_STRIDE : 1]; // stream window of the wave that walks the block list
+	__shared__ __attribute__((aligned(16))) uint32_t cwin[OWN_WALK ? CoopLds<1>::WORDS : 4]; // tile of the cooperative walk of a long block list
 	__shared__ int64_t s_copied, s_tmp, s_kmax, s_desc;
 	__shared__ int32_t s_kept, s_bad;
 	// The queue holds the long rows of ALL levels; a group takes the next entry that is of this level and of this pass from a
@@ -942,7 +949,7 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 						total += len;
 					}
 				};
-				if (DEF) {
+				if (OWN_WALK) {
 					LaneWin<LW_MAIN> lw;
 					lw.col = lwin + threadIdx.x;
 					lw.vlast = min((((uint64_t)g.offsets[v.lo + s + 1] >> 5) + 2) & ~(uint64_t)3, (g.nwords + 4) & ~(uint64_t)3);
