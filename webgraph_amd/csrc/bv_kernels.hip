@@ -736,9 +736,9 @@ __global__ void __launch_bounds__(64 * COPY_MID_WAVES) k_copy_mid(GraphDev g, Ra
 // wave; profiles/r4_experiments.txt).  Here eight waves per CU walk (the LDS of the cooperative walk), each its own row.  The tables (kend, delta, as in k_copy_mid)
 // go to the bump arena GraphDev::walktab, (bc >> 1) + 1 entries each; desc[qi] = (offset of the tables | -1 not walked: k_copy_big
 // walks the list itself | -2 nothing to merge or malformed, number of copied blocks, copied ids, block count).
-constexpr int PREWALK_WAVES = 4;
+constexpr int PREWALK_WAVES = 4, PREWALK_LONG_MIN = 2048, PWL_NW = 4; // (lists of PREWALK_LONG_MIN codes and more: k_copy_prewalk_long, below)
 template <int DEF>
-__global__ void __launch_bounds__(64 * PREWALK_WAVES) k_copy_prewalk(GraphDev g, RangeView v, const int32_t *__restrict__ queue, const int32_t *__restrict__ count, int32_t cap, int4 *__restrict__ desc) {
+__global__ void __launch_bounds__(64 * PREWALK_WAVES) k_copy_prewalk(GraphDev g, RangeView v, const int32_t *__restrict__ queue, const int32_t *__restrict__ count, int32_t cap, int4 *__restrict__ desc, uint32_t longMin) {
 	static_assert(DEF != 0 && 64 * PREWALK_WAVES == LW_STRIDE, "default codings; the lane windows are LW_STRIDE columns wide");
 	__shared__ uint32_t lwin[LW_MAIN * LW_STRIDE];
 	__shared__ __attribute__((aligned(16))) uint32_t cwin[PREWALK_WAVES][CoopLds<1>::WORDS];
@@ -747,6 +747,7 @@ __global__ void __launch_bounds__(64 * PREWALK_WAVES) k_copy_prewalk(GraphDev g,
 	for (int32_t qi = blockIdx.x * PREWALK_WAVES + wave; qi < nq; qi += gridDim.x * PREWALK_WAVES) {
 		const int32_t s = queue[qi];
 		int4 out = int4{ -1, 0, 0, 0 };
+		bool leave = false;
 		const int32_t r = v.ref[s], d = v.outd[s];
 		if (r != 0 && v.fits(s) && v.fits(s - r)) {
 			const int64_t dref = v.outd[s - r];
@@ -760,6 +761,7 @@ __global__ void __launch_bounds__(64 * PREWALK_WAVES) k_copy_prewalk(GraphDev g,
 			const uint64_t bc = lw.template code<1>(g, e);
 			if (e || bc > (uint64_t)dref + 1) out.x = -2; // flagged by the parse kernel
 			else if (d >= g.walkMin && bc >= (uint64_t)COPY_GROUP_WALK_MIN) {} // a giant record's long list: its tables fall out of its parse (coop_parse_node, bv_coop.hpp)
+			else if (bc >= (uint64_t)longMin) leave = true; // k_copy_prewalk_long's
 			else {
 				const uint64_t kMax = (bc >> 1) + 1, need = 2 * kMax;
 				int64_t off = -1;
@@ -791,7 +793,54 @@ __global__ void __launch_bounds__(64 * PREWALK_WAVES) k_copy_prewalk(GraphDev g,
 				}
 			}
 		}
-		if (lane == 0) desc[qi] = out;
+		if (lane == 0 && !leave) desc[qi] = out;
+	}
+}
+
+// The lists of PREWALK_LONG_MIN codes and more are walked by a GROUP of four waves each (coop_block_walk_nw), in a kernel of their own that is
+// launched first: one wave needs ~105 ticks per code, the longest list of the C5 shard has 12 500 -- 0.6 ms, which was how long k_copy_prewalk
+// lasted, and what the copy pass waited for behind the parse kernels.  Every block reads the headers of its share of the queue (generic
+// reader, all threads alike: the walk is a collective) and walks the long lists among them; k_copy_prewalk leaves those entries alone.
+template <int DEF>
+__global__ void __launch_bounds__(64 * PWL_NW) k_copy_prewalk_long(GraphDev g, RangeView v, const int32_t *__restrict__ queue, const int32_t *__restrict__ count, int32_t cap, int4 *__restrict__ desc) {
+	static_assert(DEF != 0, "default codings");
+	__shared__ __attribute__((aligned(16))) uint32_t win[CoopLds<PWL_NW>::WIN_WORDS];
+	__shared__ int64_t xch[3 * PWL_NW + 8 + 1];
+	const int32_t nq = min(*count, cap);
+	for (int32_t qi = blockIdx.x; qi < nq; qi += gridDim.x) { // (uniform)
+		const int32_t s = queue[qi];
+		const int32_t r = v.ref[s], d = v.outd[s];
+		if (r == 0 || !v.fits(s) || !v.fits(s - r)) continue;
+		const int64_t dref = v.outd[s - r];
+		if (dref + 1 < PREWALK_LONG_MIN) continue; // (bc <= dref + 1)
+		BitReader br;
+		br.init(g.bits, g.nwords);
+		br.seek((uint64_t)g.offsets[v.lo + s]);
+		(void)Fields<DEF>::outdegree(br, g);
+		(void)Fields<DEF>::reference(br, g);
+		const uint64_t bc = Fields<DEF>::block_count(br, g);
+		if (br.err || bc > (uint64_t)dref + 1 || bc < (uint64_t)PREWALK_LONG_MIN) continue; // (short, or flagged: k_copy_prewalk's)
+		if (d >= g.walkMin && bc >= (uint64_t)COPY_GROUP_WALK_MIN) continue;               // (a giant record's long list: its parse keeps the tables)
+		const uint64_t kMax = (bc >> 1) + 1, need = 2 * kMax;
+		__syncthreads(); // xch is free
+		if (threadIdx.x == 0) {
+			int64_t off = -1;
+			if (need <= g.walkCap) { const uint32_t a = atomicAdd(g.walkCursor, (uint32_t)need); if ((uint64_t)a + need <= g.walkCap) off = a; }
+			xch[3 * PWL_NW + 8] = off;
+		}
+		__syncthreads();
+		const int64_t off = xch[3 * PWL_NW + 8];
+		int4 out = int4{ -1, 0, 0, 0 };
+		if (off >= 0) {
+			int64_t total = 0, copied = 0;
+			int32_t nKept = 0;
+			int bad = 0;
+			coop_block_walk_nw<PWL_NW>(g, br.pos(), (uint64_t)g.offsets[v.lo + s + 1], (int64_t)bc, dref, d, g.walktab + off, g.walktab + off + kMax, (int32_t)kMax, win, xch,
+			                           CoopCfg<PWL_NW>::B_MAX, total, copied, nKept, bad);
+			if (bad || copied > d || copied == 0) out.x = -2;
+			else out = int4{ (int32_t)off, nKept, (int32_t)copied, (int32_t)min<uint64_t>(bc, 0x7fffffff) };
+		}
+		if (threadIdx.x == 0) desc[qi] = out;
 	}
 }
 
@@ -1898,13 +1947,18 @@ void launch_copy_tile(const GraphDev &g, int def, const RangeView &v, const int3
 	else hipLaunchKernelGGL(k_copy_tile<0>, dim3(ntiles), dim3(CT_T), 0, st, g, v, depth, tb, midMin, bigMin, err);
 }
 // walks the block lists of the rows in the group class's queue (all levels); desc: 16 bytes per queue entry
-void launch_copy_prewalk(const GraphDev &g, int def, const RangeView &v, const int32_t *bigQ, int32_t bigCap, const int32_t *ctl, void *desc, int blocks, hipStream_t st, int32_t midCap) {
+void launch_copy_prewalk(const GraphDev &g, int def, const RangeView &v, const int32_t *bigQ, int32_t bigCap, const int32_t *ctl, void *desc, int blocks, hipStream_t st, int32_t midCap, hipStream_t stLong, bool longKernel, hipStream_t stWalk) {
 	if (v.cnt <= 0 || !g.walktab) return;
+	const uint32_t longMin = longKernel ? (uint32_t)PREWALK_LONG_MIN : 0xffffffffu;
+	// the long lists first, on a stream of their own if the caller has one (ordered behind the queues by the caller)
 	// (the wave class's queue follows the group class's, and so do its descriptors)
+	if (!longKernel) {}
+	else if (def == 1) hipLaunchKernelGGL(k_copy_prewalk_long<1>, dim3(blocks), dim3(64 * PWL_NW), 0, stLong, g, v, bigQ, ctl + 5, bigCap, (int4 *)desc);
+	else if (def == 2) hipLaunchKernelGGL(k_copy_prewalk_long<2>, dim3(blocks), dim3(64 * PWL_NW), 0, stLong, g, v, bigQ, ctl + 5, bigCap, (int4 *)desc);
 	if (midCap > 0 && def == 1) hipLaunchKernelGGL(k_copy_prewalk_lanes<1>, dim3(blocks), dim3(LW_STRIDE), 0, st, g, v, bigQ + bigCap, ctl + 6, midCap, (int4 *)desc + bigCap);
 	else if (midCap > 0 && def == 2) hipLaunchKernelGGL(k_copy_prewalk_lanes<2>, dim3(blocks), dim3(LW_STRIDE), 0, st, g, v, bigQ + bigCap, ctl + 6, midCap, (int4 *)desc + bigCap);
-	if (def == 1) hipLaunchKernelGGL(k_copy_prewalk<1>, dim3(blocks), dim3(64 * PREWALK_WAVES), 0, st, g, v, bigQ, ctl + 5, bigCap, (int4 *)desc);
-	else if (def == 2) hipLaunchKernelGGL(k_copy_prewalk<2>, dim3(blocks), dim3(64 * PREWALK_WAVES), 0, st, g, v, bigQ, ctl + 5, bigCap, (int4 *)desc);
+	if (def == 1) hipLaunchKernelGGL(k_copy_prewalk<1>, dim3(blocks), dim3(64 * PREWALK_WAVES), 0, stWalk, g, v, bigQ, ctl + 5, bigCap, (int4 *)desc, longMin);
+	else if (def == 2) hipLaunchKernelGGL(k_copy_prewalk<2>, dim3(blocks), dim3(64 * PREWALK_WAVES), 0, stWalk, g, v, bigQ, ctl + 5, bigCap, (int4 *)desc, longMin);
 }
 void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int32_t *depth, const int32_t *list, const int32_t *keyBase, int32_t level, int blocks,
                        int32_t midMinKnob, bool bigGroups, const int32_t *bigQ, int32_t bigCap, const int32_t *midQ, int32_t midCap, int32_t *ctl, int32_t *tmp, uint32_t tmpCap, int *err,

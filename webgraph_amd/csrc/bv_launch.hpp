@@ -79,7 +79,7 @@ void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int
 int32_t copy_tile_count(int64_t arcsBound, int32_t nodes);
 void launch_copy_tile_bounds(const RangeView &v, int32_t ntiles, int32_t *tb, hipStream_t st);
 void launch_copy_tile(const GraphDev &g, int def, const RangeView &v, const int32_t *depth, const int32_t *tb, int32_t ntiles, int32_t midMinKnob, bool bigGroups, int *err, hipStream_t st);
-void launch_copy_prewalk(const GraphDev &g, int def, const RangeView &v, const int32_t *bigQ, int32_t bigCap, const int32_t *ctl, void *desc, int blocks, hipStream_t st, int32_t midCap = 0); // midCap > 0: also the wave class's rows (queue at bigQ + bigCap, descriptors at desc + bigCap)
+void launch_copy_prewalk(const GraphDev &g, int def, const RangeView &v, const int32_t *bigQ, int32_t bigCap, const int32_t *ctl, void *desc, int blocks, hipStream_t st, int32_t midCap, hipStream_t stLong, bool longKernel, hipStream_t stWalk); // stWalk: the stream of k_copy_prewalk (as stLong) // stLong: the stream of the long lists' kernel (ordered behind the queues by the caller; may be st); // midCap > 0: also the wave class's rows (queue at bigQ + bigCap, descriptors at desc + bigCap)
 void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, void *arena = nullptr, int64_t arenaCap = 0, int32_t keyHi = NKEYS, int32_t dMax = 0x7fffffff); // records with >= dMax successors are somebody else's
 // one wave per record of `list` (ctl[which] entries, queue head ctl[which + 2]): k_parse_big<1>
 void launch_parse_listed(const GraphDev &g, int def, const RangeView &v, const int32_t *list, int32_t *ctl, int which, void *arena, int64_t arenaCap, int waves, int *err, hipStream_t st);

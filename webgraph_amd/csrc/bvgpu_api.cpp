@@ -152,6 +152,7 @@ struct bvg_graph {
 	int copy_tile = 0; // BVGPU_COPY_TILE=1: tiles of neighbouring short rows merged in LDS before the level kernels (k_copy_tile: bit-exact, slower -- 4.4 ms of its own on the C5 shard)
 	DevBuf walkdesc; // k_copy_prewalk: 16 bytes per entry of the group class's queue
 	int copy_vec = -1; // BVGPU_COPY_VEC=1|0: the lane class of the copy pass merges with 16-byte loads and stores (copy_node_v) or id by id; -1: by the mean length of its rows (counted at load time)
+	int prewalk_long = 1; // BVGPU_PREWALK_LONG=0: no kernel of their own for the lists of >= 2048 codes; 2: on the lists' stream instead of side B
 	int prewalk_blocks = 1024;
 	int prewalk = 1; // BVGPU_PREWALK=0: k_copy_big walks its rows' block lists itself
 	DevBuf bigtmp; // global scratch tables for rows that copy more ids than the LDS tables of k_copy_big hold
@@ -251,6 +252,7 @@ int init_handle(bvg_graph *g) {
 	if (const char *e = getenv("BVGPU_WALK_TABLES")) g->walk_tables = atoi(e);
 	if (const char *e = getenv("BVGPU_COPY_VEC")) g->copy_vec = atoi(e);
 	if (const char *e = getenv("BVGPU_PREWALK")) g->prewalk = atoi(e);
+	if (const char *e = getenv("BVGPU_PREWALK_LONG")) g->prewalk_long = atoi(e);
 	if (const char *e = getenv("BVGPU_COPY_TILE")) g->copy_tile = atoi(e);
 	if (const char *e = getenv("BVGPU_PREWALK_BLOCKS")) g->prewalk_blocks = std::max(1, atoi(e));
 	if (const char *e = getenv("BVGPU_IV_ARENA")) g->iv_arena = atoi(e);
@@ -575,7 +577,19 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		// the block lists of the group class's rows, walked beside the parse kernels (k_copy_prewalk)
 		g->pend.preDesc = nullptr;
 		if (W > 0 && g->prewalk && g->copy_big && gd.walktab && s.def != 0 && g->walkdesc.need(16 * ((size_t)bigCap + (size_t)midCap))) {
-			bv::launch_copy_prewalk(gd, s.def, v, g->copyq.as<int32_t>(), bigCap, ctl, g->walkdesc.p, g->prewalk_blocks, stLists, g->prewalk >= 2 ? 0 : midCap); // (BVGPU_PREWALK=2: the group class only)
+			// (the long lists' kernel on side B, which has been idle since the giants -- unless it carries the lists themselves, or the segment pipeline's chain)
+			hipStream_t stLong = stLists, stWalk = stLists;
+			const bool longKernel = g->prewalk_long != 0;
+			const bool cross = g->prewalk_long != 2 && ovl && coop && !(segReady && g->seg_handover);
+			const bool longOnB = cross && longKernel && stLists == g->sideA;   // lists behind the wave class: the long lists on side B
+			const bool walkOnA = cross && stLists == side_b(g);                // lists behind the giants: the waves' kernel behind the wave class
+			if (longOnB || walkOnA) {
+				HIPCHK(g, hipEventRecord(g->evL, stLists));
+				if (longOnB) { stLong = side_b(g); HIPCHK(g, hipStreamWaitEvent(stLong, g->evL, 0)); }
+				else { stWalk = g->sideA; HIPCHK(g, hipStreamWaitEvent(stWalk, g->evL, 0)); }
+			}
+			bv::launch_copy_prewalk(gd, s.def, v, g->copyq.as<int32_t>(), bigCap, ctl, g->walkdesc.p, g->prewalk_blocks, stLists, g->prewalk >= 2 ? 0 : midCap, stLong, longKernel, stWalk); // (BVGPU_PREWALK=2: the group class only)
+			if (longOnB) HIPCHK(g, hipEventRecord(g->evB, stLong)); // (side B is done when this kernel is)
 			g->pend.preDesc = g->walkdesc.p;
 		}
 		int32_t ctiles = 0;
