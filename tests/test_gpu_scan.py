@@ -240,6 +240,7 @@ KNOBS = [
     {"BVGPU_COPY_BIG": "0"}, {"BVGPU_WALK_TABLES": "0"}, {"BVGPU_IV_ARENA": "0", "BVGPU_TILE": "0"}, {"BVGPU_IV_ARENA": "1", "BVGPU_TILE": "0"},
     # the contiguous-tile kernel (bv_tile.hpp): parse from one LDS image per tile
     {"BVGPU_TILE": "0"}, {"BVGPU_TILE": "1"}, {"BVGPU_TILE": "1", "BVGPU_COOP_MIN": "300", "BVGPU_GIANT_MIN": "4000"},
+    {"BVGPU_PREWALK": "0"}, {"BVGPU_COPY_VEC": "1"}, {"BVGPU_COPY_VEC": "1", "BVGPU_COPY_MID_MIN": "16", "BVGPU_COOP_MIN": "16", "BVGPU_GIANT_MIN": "64"}, {"BVGPU_COPY_TILE": "1"},
 ]
 
 
@@ -314,6 +315,18 @@ LONG_ROW_CASES = [
     ("seg_zeta1", 0, 1, {"BVGPU_SEG": "2"}),
     ("seg_zeta7_flat", 0, 7, {"BVGPU_SEG": "2", "BVGPU_FLAT": "1"}),
     ("flat", 0, 3, {"BVGPU_FLAT": "1"}),  # the short records by k_parse_flat
+    # the copy pass's block lists walked before the levels (k_copy_prewalk*, default on), its variants and what it replaces
+    ("prewalk_off", 0, 3, {"BVGPU_PREWALK": "0"}),
+    ("prewalk_group_class_only", 0, 3, {"BVGPU_PREWALK": "2"}),
+    ("prewalk_no_long_kernel", 0, 3, {"BVGPU_PREWALK_LONG": "0"}),
+    ("prewalk_long_on_lists_stream", 0, 5, {"BVGPU_PREWALK_LONG": "2"}),
+    ("prewalk_small_thresholds_midmin4", 0, 3, {"BVGPU_COOP_MIN": "64", "BVGPU_GIANT_MIN": "2000", "BVGPU_COPY_MID_MIN": "4"}),
+    ("prewalk_lists_on_b", 0, 3, {"BVGPU_LISTS_ON_B": "1"}),
+    ("prewalk_lists_on_c", 0, 3, {"BVGPU_LISTS_ON_B": "2"}),
+    ("prewalk_serial", 0, 2, {"BVGPU_OVERLAP": "0", "BVGPU_COPY_VEC": "1"}),
+    ("copy_vec_on", 0, 3, {"BVGPU_COPY_VEC": "1"}),
+    ("copy_vec_off", 0, 3, {"BVGPU_COPY_VEC": "0"}),
+    ("copy_tile", 0, 3, {"BVGPU_COPY_TILE": "1"}),
     ("batch_dense", 0, 3, {"BVGPU_BATCH_DENSE": "1000000000"}),  # random access as a masked scan + gather
     ("batch_dense_small_thresholds", 0, 3, {"BVGPU_BATCH_DENSE": "1000000000", "BVGPU_COOP_MIN": "64", "BVGPU_GIANT_MIN": "2000"}),
 ]
