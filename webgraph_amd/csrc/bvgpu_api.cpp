@@ -442,7 +442,9 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		// the block tables of the giant records, kept by the parse kernel for the copy pass (GraphDev::walktab): on when the job has a giant class
 		g->pend.walkMin = 0x7fffffff;
 		if (g->walk_tables && coopMin < 0x7fffffff && s.def != 0 && W > 0 && g->copy_big) {
-			const size_t cap = (size_t)std::min<int64_t>(std::max<int64_t>(s.arcs_sizing / 8, 1 << 20), 0x7fffffff);
+			// (arcs / 4 ints: two per copied block of the rows of the wave and group classes -- lists denser than one block per eight ids of ALL rows do not fit,
+			// and the rows that find no room are walked by one lane inside k_copy_big, correct and slow)
+			const size_t cap = (size_t)std::min<int64_t>(std::max<int64_t>(s.arcs_sizing / 4, 1 << 20), 0x7fffffff);
 			if (g->walktab.need(sizeof(int32_t) * cap)) g->pend.walkMin = giantMin; // (no room: the copy pass walks the lists itself)
 		}
 		set_walk(gd, g, g->pend.walkMin);
