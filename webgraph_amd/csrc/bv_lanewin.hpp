@@ -12,7 +12,10 @@
 namespace bv {
 
 constexpr int LW_STRIDE = 256;               // threads per block: word k of lane t lives at lds[k * LW_STRIDE + t] (one bank per lane)
-constexpr int LW_MAIN = 16, LW_SIDE = 16;    // words per lane: main cursor / interval cursor
+#ifndef LW_MAIN_
+#define LW_MAIN_ 16
+#endif
+constexpr int LW_MAIN = LW_MAIN_, LW_SIDE = 16;    // words per lane: main cursor / interval cursor
 constexpr int LW_LDS_WORDS = (LW_MAIN + LW_SIDE) * LW_STRIDE;
 
 struct SlowAbs { uint64_t v, pos; int err; };
