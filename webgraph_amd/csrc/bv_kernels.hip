@@ -933,6 +933,7 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
                                                                uint32_t *__restrict__ tmpCursor, int32_t *__restrict__ qhead, int32_t *__restrict__ nextPair, int *__restrict__ err, const int4 *__restrict__ pre) {
 	if (blockIdx.x == 0 && threadIdx.x < 2) nextPair[threadIdx.x] = 0;
 	__shared__ int32_t tabs[3 * COPY_BIG_CAP + 2];
+	__shared__ int32_t s_ext[COPY_BIG_CAP]; // the row's extras, when they fit (registers hold the kernel to one group per CU: its LDS is free)
 	int32_t *const cval = tabs, *const cpos = tabs + COPY_BIG_CAP, *const delta = tabs + 2 * COPY_BIG_CAP + 1;
 	__shared__ int32_t s_b[2];
 	// (since k_copy_prewalk the group walks a list itself only when the pre-walk could not -- its arena was full, it is off, a giant row whose parse kernel kept no
@@ -1037,6 +1038,28 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 				int32_t lo = 0, hi = nKept; // first copied block with kend > t (a block of length 0 is possible only in first position)
 				while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (kend[mid] <= t) lo = mid + 1; else hi = mid; }
 				cv_[t] = src[t + dlt[lo]];
+			}
+			if (nExtra <= COPY_BIG_CAP) {
+				// both sets in LDS: every id finds its place by one search in the other set and goes straight to the row -- no search in global memory (the ranks
+				// of the copied ids among the extras: a quarter of this kernel), no chunk-wise move of the extras around their own unread tail
+				for (int32_t e = threadIdx.x; e < nExtra; e += COPY_BIG_THREADS) s_ext[e] = row[nc + e];
+				__syncthreads();
+				CT(1);
+				for (int32_t t = threadIdx.x; t < nc; t += COPY_BIG_THREADS) {
+					const int32_t cv = cv_[t];
+					int32_t lo = 0, hi = nExtra;
+					while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (s_ext[mid] < cv) lo = mid + 1; else hi = mid; }
+					row[t + lo] = cv;
+				}
+				CT(2);
+				for (int32_t e = threadIdx.x; e < nExtra; e += COPY_BIG_THREADS) {
+					const int32_t ev = s_ext[e];
+					int32_t lo = 0, hi = nc; // copied ids smaller than this extra
+					while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (cv_[mid] < ev) lo = mid + 1; else hi = mid; }
+					if (lo < nc) row[e + lo] = ev; // (the extras behind the last copied id stay where they are)
+				}
+				CT(3);
+				return;
 			}
 			__syncthreads();
 			CT(1);
