@@ -1105,7 +1105,7 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 		// and each tile's copied ids and extras are ranked against each other in LDS.  In place: tile k overwrites
 		// row[p0..p1), which held extras with index < p1 - nc <= j1, all read by then; tile k + 1 is on its way meanwhile.
 		auto merge_row_stream = [&](const int32_t *kend, const int32_t *dlt, int32_t *cv_, int32_t nc, int32_t nKept) {
-			constexpr int32_t TS = COPY_BIG_THREADS * 8, GT = TS / 2, ITEMS = TS / COPY_BIG_THREADS;
+			constexpr int32_t TS = COPY_BIG_THREADS * 8, GT = TS, ITEMS = TS / COPY_BIG_THREADS; // (a round of the gather is a chain of latencies -- table, search, id, store, barriers --: as many ids per round as the LDS tables allow)
 			static_assert(2 * (GT + 1) <= 3 * COPY_BIG_CAP + 2 && TS + COPY_BIG_THREADS + 1 <= 3 * COPY_BIG_CAP + 2, "the tiles of the streaming merge live in the LDS tables");
 			const int32_t nExtra = d - nc;
 			int32_t *bufK = tabs, *bufD = tabs + GT + 1;
@@ -1113,16 +1113,40 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 			// the GT + 1 table entries from b0 on: they are loaded as they lie, and the next tile's b0 is found in LDS.
 			int32_t b0 = (nKept > 1 && kend[0] == 0) ? 1 : 0;
 			for (int32_t t0 = 0; t0 < nc; t0 += GT) {
-				const int32_t t1 = min(nc, t0 + GT), nb = min(nKept - b0, GT + 1);
+				const int32_t t1 = min(nc, t0 + GT), nbMax = min(nKept - b0, GT + 1);
 				__syncthreads(); // the buffers are free
-				for (int32_t k = threadIdx.x; k < nb; k += COPY_BIG_THREADS) { bufK[k] = kend[b0 + k]; bufD[k] = dlt[b0 + k]; }
-				__syncthreads();
-				for (int32_t t = t0 + (int32_t)threadIdx.x; t < t1; t += COPY_BIG_THREADS) {
-					int32_t lo = 0, hi = nb - 1;
-					while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (bufK[mid] <= t) lo = mid + 1; else hi = mid; }
-					const int64_t si = (int64_t)t + bufD[lo]; // (inside the referent's row for tables of a valid walk; tables taken over from the parse
-					cv_[t] = si >= 0 && si < dref ? src[si] : 0; //  kernel of a record it flagged could hold anything: never read outside the row)
-					if (t == t1 - 1) s_b[0] = b0 + lo + (bufK[lo] <= t1 ? 1 : 0); // the block of id t1 (bufK[lo] > t1 - 1: it ends at t1 or later)
+				// (the tile's blocks, a thousand table entries at a time until one ends at t1 or later: a tile of 4 096 ids of the C5 shard has ~340 blocks,
+				// and loading all GT + 1 entries it COULD have was twice the loads of the ids themselves)
+				int32_t nb = 0;
+				for (;;) {
+					const int32_t upto = min(nbMax, nb + COPY_BIG_THREADS);
+					for (int32_t k = nb + (int32_t)threadIdx.x; k < upto; k += COPY_BIG_THREADS) { bufK[k] = kend[b0 + k]; bufD[k] = dlt[b0 + k]; }
+					__syncthreads();
+					nb = upto;
+					if (nb >= nbMax || bufK[nb - 1] >= t1) break; // (uniform)
+				}
+				{
+					// the thread's ids of the tile searched side by side, branch-free (one search after the other is a chain of a dozen dependent LDS reads each)
+					constexpr int GI = GT / COPY_BIG_THREADS;
+					int32_t lo[GI];
+#pragma unroll
+					for (int u = 0; u < GI; u++) lo[u] = 0;
+					const int32_t m = nb - 1; // the answer lies in [0, m]: the number of entries among the first m with kend <= t
+					for (int32_t step = m > 0 ? 1 << (31 - __clz(m)) : 0; step > 0; step >>= 1) {
+#pragma unroll
+						for (int u = 0; u < GI; u++) {
+							const int32_t t = t0 + u * COPY_BIG_THREADS + (int32_t)threadIdx.x, nx = lo[u] + step;
+							if (nx <= m && bufK[nx - 1] <= t) lo[u] = nx;
+						}
+					}
+#pragma unroll
+					for (int u = 0; u < GI; u++) {
+						const int32_t t = t0 + u * COPY_BIG_THREADS + (int32_t)threadIdx.x;
+						if (t >= t1) continue;
+						const int64_t si = (int64_t)t + bufD[lo[u]]; // (inside the referent's row for tables of a valid walk; tables taken over from the parse
+						cv_[t] = si >= 0 && si < dref ? src[si] : 0; //  kernel of a record it flagged could hold anything: never read outside the row)
+						if (t == t1 - 1) s_b[0] = b0 + lo[u] + (bufK[lo[u]] <= t1 ? 1 : 0); // the block of id t1 (bufK[lo] > t1 - 1: it ends at t1 or later)
+					}
 				}
 				__syncthreads();
 				b0 = min(s_b[0], nKept - 1);
