@@ -66,6 +66,12 @@ template <int NW> struct CoopLds { // LDS layout of one group, in 32-bit words
 	static constexpr int WORDS = OFF_CACHE + CACHE_WORDS;
 };
 
+// the part of CoopLds<1> that a block-list walk needs (coop_block_walk: window, exchange slots, the lanes' cached codes -- no staged intervals): 9.4 KB per wave
+struct WalkLds {
+	static constexpr int WIN_WORDS = CoopLds<1>::WIN_WORDS, XCH_WORDS = CoopLds<1>::XCH_WORDS;
+	static constexpr int OFF_WIN = 0, OFF_XCH = (WIN_WORDS + 1) & ~1, OFF_CACHE = OFF_XCH + XCH_WORDS, WORDS = (OFF_CACHE + COOP1_CK * 64 + 3) & ~3;
+};
+
 struct IvEntry { int32_t left; int32_t pstart; int32_t rank; int32_t len; }; // one interval in the scratch arena
 
 __device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d) { return (uint64_t)__shfl_up((long long)v, d, 64); }
@@ -519,13 +525,13 @@ __device__ __forceinline__ uint32_t w1_gamma(const GraphDev &g, const lds_u32 *l
 	return (uint32_t)min<uint64_t>(sc.v, 0xffffffffull);
 }
 struct W1Tile { WindowSrc src; uint32_t s, c, pCK; uint64_t E; }; // start, codes, position behind the cached ones; end of the tile's last code (uniform)
-template <int DEF>
+template <int DEF, class L = CoopLds<1>>
 __device__ __forceinline__ W1Tile w1_gamma_tile(const Grp<1> &G, const GraphDev &g, uint32_t *lds, uint64_t pos, uint64_t secEnd, uint32_t B, int64_t needCodes) {
 	constexpr int CK = COOP1_CK;
 	const int lane = threadIdx.x & 63;
-	uint32_t *win = lds + CoopLds<1>::OFF_WIN;
+	uint32_t *win = lds + L::OFF_WIN;
 	const lds_u32 *lw = (const lds_u32 *)win;
-	lds_u32 *cache = (lds_u32 *)(lds + CoopLds<1>::OFF_CACHE);
+	lds_u32 *cache = (lds_u32 *)(lds + L::OFF_CACHE);
 	W1Tile t;
 	t.src = stage_tile<1>(G, g, win, pos, B);
 	const uint64_t base = t.src.w0 << 5;
@@ -840,18 +846,19 @@ __device__ __forceinline__ void coop_residuals(const Grp<NW> &G, const GraphDev 
 // a (copied, skipped) alternation.  Fills kend[j] / delta[j] for the j-th copied block exactly as the serial walk
 // does, including the implicit last block, and returns the totals.  Called by the 64 lanes of wave 0 only.
 constexpr int COPY_COOP_WALK_MIN = 192; // below this many blocks the serial walk is as fast
+template <class L = CoopLds<1>>
 __device__ __forceinline__ void coop_block_walk(const GraphDev &g, uint64_t pos, uint64_t recEnd, int64_t bc, int64_t dref, int32_t d, int32_t *kend, int32_t *delta, int32_t tabCap,
                                                 uint32_t *lds, int64_t &totalOut, int64_t &copiedOut, int32_t &nKeptOut, int &bad, uint64_t *posAfter = nullptr) {
-	Grp<1> G{ (int64_t *)(lds + CoopLds<1>::OFF_XCH) };
+	Grp<1> G{ (int64_t *)(lds + L::OFF_XCH) };
 	constexpr int CK = COOP1_CK;
 	const int lane = threadIdx.x & 63;
-	const lds_u32 *lw = (const lds_u32 *)(lds + CoopLds<1>::OFF_WIN);
-	const lds_u32 *cache = (const lds_u32 *)(lds + CoopLds<1>::OFF_CACHE);
+	const lds_u32 *lw = (const lds_u32 *)(lds + L::OFF_WIN);
+	const lds_u32 *cache = (const lds_u32 *)(lds + L::OFF_CACHE);
 	const uint32_t B = coop_pick_B(min<uint64_t>(recEnd > pos ? recEnd - pos : 0, (uint64_t)bc * 8), (uint64_t)bc, 64, CoopCfg<1>::B_MAX);
 	int64_t done = 0, total = 0, copied = 0; // uniform
 	int err = 0;
 	while (done < bc) {
-		const W1Tile t = w1_gamma_tile<1>(G, g, lds, pos, recEnd, B, bc - done);
+		const W1Tile t = w1_gamma_tile<1, L>(G, g, lds, pos, recEnd, B, bc - done);
 		const uint64_t base = t.src.w0 << 5;
 		uint32_t c = t.c;
 		int64_t tileTotal;

@@ -733,15 +733,19 @@ __global__ void __launch_bounds__(64 * COPY_MID_WAVES) k_copy_mid(GraphDev g, Ra
 // levels at once, one wave per row, beside the parse kernels: a block list is a serial chain of codes that depends on nothing but the
 // stream, and walked inside k_copy_big -- by one wave of a 1024-thread group while the fifteen others wait, two groups per CU -- it was
 // 71 % of that kernel's time on the C5 shard (14 000 rows of 590 codes: 600 ticks per code walked by one lane, 105 per code by the
-// wave; profiles/r4_experiments.txt).  Here eight waves per CU walk (the LDS of the cooperative walk), each its own row.  The tables (kend, delta, as in k_copy_mid)
+// wave; profiles/r4_experiments.txt).  Here sixteen waves per CU walk (9.4 KB of LDS each: WalkLds), each its own row.  The tables (kend, delta, as in k_copy_mid)
 // go to the bump arena GraphDev::walktab, (bc >> 1) + 1 entries each; desc[qi] = (offset of the tables | -1 not walked: k_copy_big
 // walks the list itself | -2 nothing to merge or malformed, number of copied blocks, copied ids, block count).
-constexpr int PREWALK_WAVES = 4, PREWALK_LONG_MIN = 2048, PWL_NW = 4; // (lists of PREWALK_LONG_MIN codes and more: k_copy_prewalk_long, below)
+#ifndef PREWALK_COOP_MIN_
+#define PREWALK_COOP_MIN_ 64
+#endif
+constexpr int PREWALK_WAVES = 4, PREWALK_LONG_MIN = 2048, PWL_NW = 4, PREWALK_COOP_MIN = PREWALK_COOP_MIN_; // (lists of PREWALK_LONG_MIN codes and more: k_copy_prewalk_long, below)
 template <int DEF>
 __global__ void __launch_bounds__(64 * PREWALK_WAVES) k_copy_prewalk(GraphDev g, RangeView v, const int32_t *__restrict__ queue, const int32_t *__restrict__ count, int32_t cap, int4 *__restrict__ desc, uint32_t longMin) {
-	static_assert(DEF != 0 && 64 * PREWALK_WAVES == LW_STRIDE, "default codings; the lane windows are LW_STRIDE columns wide");
-	__shared__ uint32_t lwin[LW_MAIN * LW_STRIDE];
-	__shared__ __attribute__((aligned(16))) uint32_t cwin[PREWALK_WAVES][CoopLds<1>::WORDS];
+	static_assert(DEF != 0, "default codings");
+	// 9.4 KB of LDS per wave (WalkLds: the cooperative walk's window, exchange slots and cached codes; the header and the short lists go through the generic
+	// reader, all lanes alike): sixteen walking waves per CU
+	__shared__ __attribute__((aligned(16))) uint32_t cwin[PREWALK_WAVES][WalkLds::WORDS];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const int32_t nq = min(*count, cap);
 	for (int32_t qi = blockIdx.x * PREWALK_WAVES + wave; qi < nq; qi += gridDim.x * PREWALK_WAVES) {
@@ -751,15 +755,13 @@ __global__ void __launch_bounds__(64 * PREWALK_WAVES) k_copy_prewalk(GraphDev g,
 		const int32_t r = v.ref[s], d = v.outd[s];
 		if (r != 0 && v.fits(s) && v.fits(s - r)) {
 			const int64_t dref = v.outd[s - r];
-			LaneWin<LW_MAIN> lw;
-			lw.col = lwin + threadIdx.x;
-			lw.vlast = min((((uint64_t)g.offsets[v.lo + s + 1] >> 5) + 2) & ~(uint64_t)3, (g.nwords + 4) & ~(uint64_t)3);
-			lw.seek(g, (uint64_t)g.offsets[v.lo + s]);
-			int e = 0;
-			(void)lw.template code<1>(g, e);
-			(void)lw.template code<2>(g, e);
-			const uint64_t bc = lw.template code<1>(g, e);
-			if (e || bc > (uint64_t)dref + 1) out.x = -2; // flagged by the parse kernel
+			BitReader br;
+			br.init(g.bits, g.nwords);
+			br.seek((uint64_t)g.offsets[v.lo + s]);
+			(void)Fields<DEF>::outdegree(br, g);
+			(void)Fields<DEF>::reference(br, g);
+			const uint64_t bc = Fields<DEF>::block_count(br, g);
+			if (br.err || bc > (uint64_t)dref + 1) out.x = -2; // flagged by the parse kernel
 			else if (d >= g.walkMin && bc >= (uint64_t)COPY_GROUP_WALK_MIN) {} // a giant record's long list: its tables fall out of its parse (coop_parse_node, bv_coop.hpp)
 			else if (bc >= (uint64_t)longMin) leave = true; // k_copy_prewalk_long's
 			else {
@@ -772,11 +774,11 @@ __global__ void __launch_bounds__(64 * PREWALK_WAVES) k_copy_prewalk(GraphDev g,
 					int64_t total = 0, copied = 0;
 					int32_t nKept = 0;
 					int bad = 0;
-					if (bc >= COPY_COOP_WALK_MIN) coop_block_walk(g, lw.pos(), (uint64_t)g.offsets[v.lo + s + 1], (int64_t)bc, dref, d, kend, dlt, (int32_t)kMax, cwin[wave], total, copied, nKept, bad);
+					if (bc >= PREWALK_COOP_MIN) coop_block_walk<WalkLds>(g, br.pos(), (uint64_t)g.offsets[v.lo + s + 1], (int64_t)bc, dref, d, kend, dlt, (int32_t)kMax, cwin[wave], total, copied, nKept, bad);
 					else {
 						for (uint64_t b = 0; b <= bc; b++) { // (every lane walks: the list is short)
 							int64_t len;
-							if (b < bc) len = (int64_t)lw.template code<1>(g, e) + (b ? 1 : 0);
+							if (b < bc) len = (int64_t)Fields<DEF>::block(br, g) + (b ? 1 : 0);
 							else len = dref - total; // implicit last block (copied when the block count is even)
 							if (len < 0 || total + len > dref) { bad = 1; break; }
 							if (!(b & 1)) {
@@ -786,7 +788,7 @@ __global__ void __launch_bounds__(64 * PREWALK_WAVES) k_copy_prewalk(GraphDev g,
 							}
 							total += len;
 						}
-						bad |= e;
+						bad |= br.err;
 					}
 					if (bad || copied > d || copied == 0) out.x = -2;
 					else out = int4{ (int32_t)off, nKept, (int32_t)copied, (int32_t)min<uint64_t>(bc, 0x7fffffff) };
