@@ -665,18 +665,35 @@ __global__ void __launch_bounds__(64 * COPY_MID_WAVES) k_copy_mid(GraphDev g, Ra
 	auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); };
 	// the queue holds the rows of this class of ALL levels: a wave takes the entries of this level among its share
 	const int32_t nq = min(*count, cap);
-	for (int32_t qi = blockIdx.x * COPY_MID_WAVES + wave; qi < nq; qi += gridDim.x * COPY_MID_WAVES) {
-		const int32_t s = queue[qi];
-		if (depth[s] != level || copy_class(v, depth, level, s, 0, 0x7fffffff) == 0) continue;
-		const int32_t d = v.outd[s], r = v.ref[s];
-		const int64_t dref = v.outd[s - r];
-		int32_t *row = v.row(s);
-		const int32_t *src = v.row(s - r);
+	const int64_t rsNh = v.rowstart[v.nh];
+	// The queue holds the rows of ALL levels, and a row's data sit behind three dependent loads (queue -> row -> referent).  A wave's entries are W apart (its
+	// share is as even as with one entry per iteration); it looks at up to 64 of them at once, one per lane -- levels, descriptors, row starts and referents'
+	// row starts in three round trips for all of them -- and then works through the ones of this level with everything at hand.
+	const int32_t W = (int32_t)(gridDim.x * COPY_MID_WAVES), w = (int32_t)(blockIdx.x * COPY_MID_WAVES + wave);
+	for (int64_t k0 = 0; w + k0 * W < nq; k0 += 64) { // (uniform)
+		const int64_t qiL64 = w + (k0 + lane) * (int64_t)W;
+		const bool inL = qiL64 < nq;
+		const int32_t qiL = inL ? (int32_t)qiL64 : 0;
+		const int32_t sL = inL ? queue[qiL] : 0;
+		const int4 pwL = inL && pre ? pre[qiL] : int4{ -1, 0, 0, 0 };
+		const int32_t depL = inL ? depth[sL] : -1, rL = inL ? (int32_t)v.ref[sL] : 0;
+		const int64_t rs0L = inL ? v.rowstart[sL] : 0, rs1L = inL ? v.rowstart[sL + 1] : 0;
+		const int32_t tL = sL - rL;
+		const bool wantL = inL && depL == level && pwL.x != -2 && rL != 0;
+		const int64_t rt0L = wantL ? v.rowstart[tL] : 0, rt1L = wantL ? v.rowstart[tL + 1] : 0;
+		const bool fitL = wantL && (sL >= v.nh ? (uint64_t)(rs1L - rsNh) <= v.succ_cap : (uint64_t)rs1L <= v.halo_cap) && (tL >= v.nh ? (uint64_t)(rt1L - rsNh) <= v.succ_cap : (uint64_t)rt1L <= v.halo_cap); // (else: E_CAP / E_HALO already raised by the parse kernel)
+	for (unsigned long long todo = __ballot(fitL); todo; todo &= todo - 1) {
+		const int bsel = __builtin_ctzll(todo);
+		const int32_t s = __shfl(sL, bsel, 64), t0 = __shfl(tL, bsel, 64);
+		const int4 pw = int4{ __shfl(pwL.x, bsel, 64), __shfl(pwL.y, bsel, 64), __shfl(pwL.z, bsel, 64), __shfl(pwL.w, bsel, 64) };
+		const int64_t rs0 = shfl_i64(rs0L, bsel), rs1 = shfl_i64(rs1L, bsel), rt0 = shfl_i64(rt0L, bsel), rt1 = shfl_i64(rt1L, bsel);
+		const int32_t d = (int32_t)(rs1 - rs0);
+		const int64_t dref = rt1 - rt0;
+		int32_t *row = s < v.nh ? v.halo + rs0 : v.succ + (rs0 - rsNh);
+		const int32_t *src = t0 < v.nh ? v.halo + rt0 : v.succ + (rt0 - rsNh);
 		int64_t total = 0, copied = 0;
 		int32_t nKept = 0;
 		bool bad = false;
-		const int4 pw = pre ? pre[qi] : int4{ -1, 0, 0, 0 }; // (uniform)
-		if (pw.x == -2) continue; // k_copy_prewalk_lanes: nothing to merge, or flagged by the parse kernel
 		// header + blocks (uniform)
 		BitReader br;
 		br.init(g.bits, g.nwords);
@@ -726,6 +743,7 @@ __global__ void __launch_bounds__(64 * COPY_MID_WAVES) k_copy_mid(GraphDev g, Ra
 			row[t - nc + lo] = val;
 		}
 		wave_sync(); // the tables are reused by the next row
+	}
 	}
 }
 
