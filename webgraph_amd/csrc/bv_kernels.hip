@@ -766,16 +766,28 @@ __global__ void __launch_bounds__(64 * PREWALK_WAVES) k_copy_prewalk(GraphDev g,
 	__shared__ __attribute__((aligned(16))) uint32_t cwin[PREWALK_WAVES][WalkLds::WORDS];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const int32_t nq = min(*count, cap);
-	for (int32_t qi = blockIdx.x * PREWALK_WAVES + wave; qi < nq; qi += gridDim.x * PREWALK_WAVES) {
-		const int32_t s = queue[qi];
+	// (as k_copy_mid: a wave looks at 64 of its strided queue entries at once, one per lane -- row, reference, outdegrees, record bounds in three round
+	// trips for all of them -- and then walks them one by one)
+	const int32_t W = (int32_t)(gridDim.x * PREWALK_WAVES), w = (int32_t)(blockIdx.x * PREWALK_WAVES + wave);
+	for (int64_t k0 = 0; w + k0 * W < nq; k0 += 64) { // (uniform)
+		const int64_t qiL64 = w + (k0 + lane) * (int64_t)W;
+		const bool inL = qiL64 < nq;
+		const int32_t sL = inL ? queue[inL ? (int32_t)qiL64 : 0] : 0;
+		const int32_t rL = inL ? (int32_t)v.ref[sL] : 0, dL = inL ? v.outd[sL] : 0;
+		const bool okL = inL && rL != 0 && v.fits(sL) && v.fits(sL - rL);
+		const int32_t drefL = okL ? v.outd[sL - rL] : 0;
+		const int64_t off0L = okL ? g.offsets[v.lo + sL] : 0, off1L = okL ? g.offsets[v.lo + sL + 1] : 0;
+	for (unsigned long long todo = __ballot(inL); todo; todo &= todo - 1) {
+		const int bsel = __builtin_ctzll(todo);
+		const int32_t qi = (int32_t)(w + (k0 + bsel) * (int64_t)W);
 		int4 out = int4{ -1, 0, 0, 0 };
 		bool leave = false;
-		const int32_t r = v.ref[s], d = v.outd[s];
-		if (r != 0 && v.fits(s) && v.fits(s - r)) {
-			const int64_t dref = v.outd[s - r];
+		const int32_t d = __shfl(dL, bsel, 64);
+		if (__shfl((int)okL, bsel, 64)) {
+			const int64_t dref = __shfl(drefL, bsel, 64), off0 = shfl_i64(off0L, bsel), off1 = shfl_i64(off1L, bsel);
 			BitReader br;
 			br.init(g.bits, g.nwords);
-			br.seek((uint64_t)g.offsets[v.lo + s]);
+			br.seek((uint64_t)off0);
 			(void)Fields<DEF>::outdegree(br, g);
 			(void)Fields<DEF>::reference(br, g);
 			const uint64_t bc = Fields<DEF>::block_count(br, g);
@@ -792,7 +804,7 @@ __global__ void __launch_bounds__(64 * PREWALK_WAVES) k_copy_prewalk(GraphDev g,
 					int64_t total = 0, copied = 0;
 					int32_t nKept = 0;
 					int bad = 0;
-					if (bc >= PREWALK_COOP_MIN) coop_block_walk<WalkLds>(g, br.pos(), (uint64_t)g.offsets[v.lo + s + 1], (int64_t)bc, dref, d, kend, dlt, (int32_t)kMax, cwin[wave], total, copied, nKept, bad);
+					if (bc >= PREWALK_COOP_MIN) coop_block_walk<WalkLds>(g, br.pos(), (uint64_t)off1, (int64_t)bc, dref, d, kend, dlt, (int32_t)kMax, cwin[wave], total, copied, nKept, bad);
 					else {
 						for (uint64_t b = 0; b <= bc; b++) { // (every lane walks: the list is short)
 							int64_t len;
@@ -814,6 +826,7 @@ __global__ void __launch_bounds__(64 * PREWALK_WAVES) k_copy_prewalk(GraphDev g,
 			}
 		}
 		if (lane == 0 && !leave) desc[qi] = out;
+	}
 	}
 }
 
