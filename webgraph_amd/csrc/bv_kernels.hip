@@ -1321,7 +1321,7 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 }
 
 // parse pass over a list sorted by work bin only (all chain levels together): 64 records of similar length per wave
-template <int DEF, bool ARENA>
+template <int DEF, bool ARENA, bool RES = false>
 __global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, const int32_t *__restrict__ list, const int32_t *__restrict__ keyBase, int32_t binLo, int32_t binHi,
                                                     IvEntry *__restrict__ arena, int64_t arenaCap, int *__restrict__ err, int32_t dMax) {
 	__shared__ uint32_t lw[DEF ? (ARENA ? (LW_MAIN + 2 * LW_RING) * LW_STRIDE : LW_LDS_WORDS) : 1]; // lane-private stream windows, or one window and a ring of intervals (default codings)
@@ -1342,7 +1342,8 @@ __global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, con
 			// the record's slice of the interval arena (the same slices as the cooperative kernels': floor(rowstart / minInt), d / minInt + 1 entries)
 			const int64_t abase = g.minInt > 0 ? v.rowstart[s] / g.minInt : 0;
 			if (g.minInt > 0 && (abase < 0 || abase + d / g.minInt + 1 > arenaCap)) { atomicOr(err, E_FORMAT); continue; }
-			parse_node_lw<DEF == 1 ? 3 : 0, true>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), lw, (int2 *)(arena + abase), err);
+			if (RES && DEF == 1) parse_node_lwb(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), lw, (int2 *)(arena + abase), err);
+			else parse_node_lw<DEF == 1 ? 3 : 0, true>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), lw, (int2 *)(arena + abase), err);
 		}
 		else if (DEF) parse_node_lw<DEF == 1 ? 3 : 0, false>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), lw, nullptr, err);
 		else parse_node<DEF>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), err);
@@ -2102,7 +2103,10 @@ void launch_parse_listed(const GraphDev &g, int def, const RangeView &v, const i
 void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, void *arena, int64_t arenaCap, int32_t keyHi, int32_t dMax) {
 	if (v.cnt <= 0) return;
 	IvEntry *a = (IvEntry *)arena;
-	if (def == 1 && a) hipLaunchKernelGGL((k_parse_list<1, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, keyHi, a, arenaCap, err, dMax);
+	if (const char *e = getenv("BVGPU_LW_DMAX")) dMax = atoi(e); // (timing experiments only: longer records are left undecoded)
+	static const bool res = [] { const char *e = getenv("BVGPU_LW_RES"); return !e || atoi(e) != 0; }(); // 0: the loop that makes a trip per successor (parse_node_lw)
+	if (def == 1 && a && res) hipLaunchKernelGGL((k_parse_list<1, true, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, keyHi, a, arenaCap, err, dMax);
+	else if (def == 1 && a) hipLaunchKernelGGL((k_parse_list<1, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, keyHi, a, arenaCap, err, dMax);
 	else if (def == 2 && a) hipLaunchKernelGGL((k_parse_list<2, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, keyHi, a, arenaCap, err, dMax);
 	else if (def == 1) hipLaunchKernelGGL((k_parse_list<1, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, keyHi, a, arenaCap, err, dMax);
 	else if (def == 2) hipLaunchKernelGGL((k_parse_list<2, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, keyHi, a, arenaCap, err, dMax);

@@ -238,4 +238,155 @@ __device__ __forceinline__ void parse_node_lw(const GraphDev &g, int32_t x, int3
 	if (e) atomicOr(err, e);
 }
 
+// The same record by a loop that the 64 lanes of a wave walk in step (round 4; zeta_3 residuals, interval arena).  parse_node_lw's
+// merge loop executes ~250 wave-instructions per trip, a third of them scalar: every `if` of a lane is an exec-mask region
+// (s_and_saveexec / s_cbranch / s_or) that the wave runs through as soon as ONE lane takes it, and every code() carries a refill
+// check and three fallbacks of its own.  Here a trip is straight-line: the next gap and the next ring entry are decoded speculatively
+// by every lane and kept or dropped by selects; what is rare (window refill, ring top-up, a codeword of more than 28 bits, the
+// unaligned head of the row) sits behind ONE wave-uniform vote each.  The sections in front of the residuals are read by loops the
+// wave walks together too (code_w).  Semantics as parse_node_lw (BVG:1040-1126; equal heads once, MergedIntIterator.java:69-72).
+template <int KIND> __device__ __forceinline__ bool lane_fast_code(uint32_t W, uint32_t &v, uint32_t &len) { // branch-free; v / len are junk when the result is false
+	if (KIND == 2) { const uint32_t z = (uint32_t)__clz((int)(W | 1u)); v = z; len = z + 1; return W != 0; }
+	if (KIND == 1) { const uint32_t m = (uint32_t)__clz((int)(W | (1u << 16))); len = 2 * m + 1; v = (W >> (31u - 2 * m)) - 1; return W >= (1u << 16); }
+	const uint32_t h = (uint32_t)__clz((int)(W | (1u << 25))); // zeta_3, h <= 6
+	const uint32_t nb = 3 * h + 2;
+	const uint32_t mm = (W << (h + 1)) >> (31u - nb);
+	const uint32_t m = mm >> 1, left = 1u << (3 * h);
+	const bool lng = m >= left;
+	v = lng ? mm - 1 : m + left - 1;
+	len = 4 * h + 3 + (lng ? 1u : 0u);
+	return W >= (1u << 25);
+}
+// Called where the wave is converged: the lanes with `want` consume one code, the others keep their cursor.
+template <int KIND> __device__ __forceinline__ uint64_t code_w(LaneWin<LW_MAIN> &br, const GraphDev &g, bool want, int &err) {
+	br.template wave_refill<3>(g);
+	const uint32_t j = br.q >> 5, sh = br.q & 31u;
+	const uint64_t ab = ((uint64_t)br.col[j * LW_STRIDE] << 32) | br.col[(j + 1) * LW_STRIDE];
+	uint32_t v, len;
+	const bool ok = lane_fast_code<KIND>((uint32_t)((ab << sh) >> 32), v, len);
+	uint64_t r = v;
+	if (__any(want && !ok)) {
+		if (want && !ok) r = br.template code<KIND, 3>(g, err);
+		else if (want) br.q += len;
+	} else br.q += want ? len : 0u;
+	return r;
+}
+__device__ __forceinline__ void parse_node_lwb(const GraphDev &g, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row, uint32_t *lds, int2 *__restrict__ iv, int *__restrict__ err) {
+	LaneWin<LW_MAIN> br;
+	br.col = lds + threadIdx.x;
+	uint32_t *const ring = lds + LW_MAIN * LW_STRIDE + threadIdx.x; // entry j of the ring: ring[2 j * LW_STRIDE] = left, ring[(2 j + 1) * LW_STRIDE] = length
+	br.vlast = min((((uint64_t)g.offsets[x + 1] >> 5) + 2) & ~(uint64_t)3, (g.nwords + 4) & ~(uint64_t)3);
+	br.seek(g, (uint64_t)g.offsets[x]);
+	int e = 0;
+	(void)code_w<1>(br, g, true, e);              // outdegree (known from k_headers)
+	if (g.W > 0) (void)code_w<2>(br, g, true, e); // reference
+	int64_t copied = 0;
+	{ // BVG:1058-1071
+		uint64_t bc = code_w<1>(br, g, hasRef, e);
+		if (!hasRef) bc = 0;
+		if (bc > (uint64_t)dref + 1) { e |= E_FORMAT; bc = 0; }
+		int64_t total = 0;
+		const uint32_t nb = (uint32_t)bc; // (<= dref + 1 <= 2^31)
+		for (uint32_t b = 0; __any(b < nb && !e); b++) {
+			const bool w = b < nb && !e;
+			const uint64_t c = code_w<1>(br, g, w, e);
+			int64_t len = 0;
+			const bool good = block_len_ok(c, b == 0, total, dref, len);
+			if (w && !good) e |= E_FORMAT;
+			if (w && good) { total += len; if (!(b & 1)) copied += len; }
+		}
+		if (hasRef && !e && !(bc & 1)) copied += dref - total;
+	}
+	const int64_t extra = (int64_t)d - copied;
+	if (extra < 0 || copied < 0) e |= E_FORMAT;
+	if (e) { atomicOr(err, e); return; }
+	if (extra == 0) return;
+
+	int32_t nIntervals = 0;
+	int64_t intervalArcs = 0;
+	if (g.minInt != 0) { // BVG:1073-1096: the interval section, kept as (left, length) in the ring / the arena
+		const uint64_t ni = code_w<1>(br, g, true, e);
+		if (ni > (uint64_t)extra) { atomicOr(err, E_FORMAT); return; }
+		nIntervals = (int32_t)ni;
+		int32_t prevEnd = 0;
+		for (int32_t i = 0; __any(i < nIntervals && !e); i++) {
+			const bool w = i < nIntervals && !e;
+			const uint64_t a = code_w<1>(br, g, w, e);
+			const uint64_t len = code_w<1>(br, g, w, e);
+			if (w) {
+				if (len > (uint64_t)extra) e |= E_FORMAT; // (any 64-bit value in a malformed stream: kept out of the sum)
+				else {
+					intervalArcs += (int64_t)len + g.minInt;
+					const int32_t left = i == 0 ? (int32_t)((int64_t)x + nat2int(a)) : prevEnd + (int32_t)a + 1, n = (int32_t)len + g.minInt; // BVG:1084-1093, in Java ints
+					prevEnd = left + n;
+					if (i < LW_RING) { ring[(2 * i) * LW_STRIDE] = (uint32_t)left; ring[(2 * i + 1) * LW_STRIDE] = (uint32_t)n; }
+					if (nIntervals > LW_RING) iv[i] = int2{ left, n };
+				}
+			}
+		}
+	}
+	const int64_t nRes = extra - intervalArcs;
+	if (nRes < 0 || e) { atomicOr(err, E_FORMAT | e); return; }
+
+	// merge(intervals, residuals) -> row[copied ..), 16 bytes at a time behind an unaligned head.  Ids are Java ints (BVG:954, :966, :1084-1093).
+	int32_t *const out = row + copied;
+	const int32_t nExtra = (int32_t)extra;
+	const int32_t head = min(nExtra, (int32_t)(((16u - ((uint32_t)(uintptr_t)out & 15u)) & 15u) >> 2));
+	int32_t k = 0, o0 = 0, o1 = 0, o2 = 0, o3 = 0, on = 0;
+	int32_t ivLeft = 0, ivRem = 0, ivTodo = nIntervals;
+	int32_t ivIdx = 0, ivBase = 0, ivLoaded = min(ivTodo, LW_RING); // next interval; oldest one in the ring; intervals [ivBase, ivLoaded) are in the ring
+	int32_t resTodo = (int32_t)nRes;
+	int32_t resVal = (int32_t)((int64_t)x + nat2int(code_w<0>(br, g, resTodo != 0, e))); // BVG:954
+	while (k < nExtra) {
+		const bool lowRing = ivLoaded < nIntervals && ivIdx - ivBase >= LW_RING - 2;
+		if (__any(lowRing | ((br.q >> 5) + 3 >= (uint32_t)LW_MAIN))) {
+			br.template wave_refill<3>(g);
+			if (__any(lowRing)) { // some lane's ring runs low: every lane tops its own up from the arena
+				const int32_t cnt = min((ivIdx - ivBase) & ~1, nIntervals - ivLoaded); // (ivLoaded stays even until the last top-up)
+#pragma unroll
+				for (int p = 0; p < LW_RING / 2; p++) {
+					if (2 * p < cnt) {
+						const int4 t = *(const int4 *)(iv + ivLoaded + 2 * p); // (the slice has room for twice the entries: reading one past the last is harmless)
+						const int j0 = (ivLoaded + 2 * p) & (LW_RING - 1);
+						ring[(2 * j0) * LW_STRIDE] = (uint32_t)t.x; ring[(2 * j0 + 1) * LW_STRIDE] = (uint32_t)t.y;
+						ring[(2 * j0 + 2) * LW_STRIDE] = (uint32_t)t.z; ring[(2 * j0 + 3) * LW_STRIDE] = (uint32_t)t.w;
+					}
+				}
+				if (cnt > 0) { ivBase += cnt; ivLoaded += cnt; }
+			}
+		}
+		// the ring's next entry and the stream's next gap, read by every lane whether it will use them or not
+		const int jr = ivIdx & (LW_RING - 1);
+		const int32_t rl = (int32_t)ring[(2 * jr) * LW_STRIDE], rn = (int32_t)ring[(2 * jr + 1) * LW_STRIDE];
+		const uint32_t jw = br.q >> 5, sh = br.q & 31u;
+		const uint64_t ab = ((uint64_t)br.col[jw * LW_STRIDE] << 32) | br.col[(jw + 1) * LW_STRIDE];
+		uint32_t gap, len;
+		const bool ok = lane_fast_code<0>((uint32_t)((ab << sh) >> 32), gap, len);
+		const bool fetch = ivRem == 0 && ivTodo != 0;
+		ivLeft = fetch ? rl : ivLeft; ivRem = fetch ? rn : ivRem; ivIdx += fetch; ivTodo -= fetch;
+		const bool haveRes = resTodo != 0;
+		const bool takeIv = ivRem != 0 && (!haveRes || ivLeft < resVal);
+		const int32_t val = takeIv ? ivLeft : haveRes ? resVal : -1; // (-1: malformed, fewer values than the outdegree promises; BVG:1210 would store -1)
+		const bool ivAdv = takeIv || (haveRes && ivRem != 0 && ivLeft == resVal); // equal heads are emitted once (MergedIntIterator.java:69-72)
+		ivLeft += ivAdv; ivRem -= ivAdv;
+		const bool useRes = !takeIv && haveRes;
+		resTodo -= useRes;
+		const bool adv = useRes && resTodo != 0;
+		if (__any(adv && !ok)) {
+			if (adv && !ok) resVal += (int32_t)br.template code<0, 3>(g, e) + 1;
+			else if (adv) { resVal += (int32_t)gap + 1; br.q += len; }
+		} else { resVal += adv ? (int32_t)gap + 1 : 0; br.q += adv ? len : 0u; } // BVG:966
+		const bool inHead = k < head;
+		if (__any(inHead)) { if (inHead) out[k] = val; }
+		k++;
+		o0 = o1; o1 = o2; o2 = o3; o3 = val;
+		on += !inHead;
+		if (on == 4) { *(int4 *)(out + k - 4) = int4{ o0, o1, o2, o3 }; on = 0; }
+	}
+	if (on == 3) { out[k - 3] = o1; out[k - 2] = o2; out[k - 1] = o3; }
+	else if (on == 2) { out[k - 2] = o2; out[k - 1] = o3; }
+	else if (on == 1) out[k - 1] = o3;
+	if (e) atomicOr(err, e);
+}
+
 } // namespace bv
