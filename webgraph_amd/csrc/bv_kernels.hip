@@ -1326,6 +1326,35 @@ __global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, con
                                                     IvEntry *__restrict__ arena, int64_t arenaCap, int *__restrict__ err, int32_t dMax) {
 	__shared__ uint32_t lw[DEF ? (ARENA ? (LW_MAIN + 2 * LW_RING) * LW_STRIDE : LW_LDS_WORDS) : 1]; // lane-private stream windows, or one window and a ring of intervals (default codings)
 	const int32_t lo = keyBase[binLo], hi = keyBase[binHi], coopMin = v.coopmin();
+	if (RES && DEF == 1) {
+		// The same snake as below with the loads that lead to a record issued ahead of it: a sweep of short records is three dependent round
+		// trips (list entry -> outdegree / reference / row start / offsets -> the referent's outdegree and the stream words) in front of ~5 us
+		// of decoding; the entry is fetched two sweeps ahead and what hangs on it one sweep ahead, so a sweep waits for the last trip only.
+		const int64_t G = (int64_t)gridDim.x * TPB, T = (int64_t)blockIdx.x * TPB + threadIdx.x, N = (int64_t)hi - lo;
+		const int64_t rs0 = v.rowstart[v.nh];
+		auto entry = [&](int64_t sweep) -> int32_t {
+			const int64_t off = sweep * G + ((sweep & 1) ? G - 1 - T : T);
+			return sweep * G < N && off < N ? list[hi - 1 - off] : -1;
+		};
+		int32_t sCur = entry(0), sNext = entry(1);
+		int32_t d = 0, r = 0; int64_t ra = 0, rb = 0; uint64_t oa = 0, ob = 0;
+		if (sCur >= 0) { d = v.outd[sCur]; r = v.ref[sCur]; ra = v.rowstart[sCur]; rb = v.rowstart[sCur + 1]; oa = (uint64_t)g.offsets[v.lo + sCur]; ob = (uint64_t)g.offsets[v.lo + sCur + 1]; }
+		for (int64_t sweep = 0; sweep * G < N; sweep++) {
+			const int32_t s = sCur, dC = d, rC = r; const int64_t raC = ra, rbC = rb; const uint64_t oaC = oa, obC = ob;
+			const int32_t drefC = s >= 0 && rC > 0 ? v.outd[s - rC] : 0;
+			sCur = sNext; sNext = entry(sweep + 2);
+			d = 0;
+			if (sCur >= 0) { d = v.outd[sCur]; r = v.ref[sCur]; ra = v.rowstart[sCur]; rb = v.rowstart[sCur + 1]; oa = (uint64_t)g.offsets[v.lo + sCur]; ob = (uint64_t)g.offsets[v.lo + sCur + 1]; }
+			if (s < 0 || dC >= coopMin || dC >= dMax || dC == 0) continue; // decoded by whole waves (k_parse_big) / by the segment pipeline (bv_seg.hip) / nothing to decode
+			const bool fits = s >= v.nh ? (uint64_t)(rbC - rs0) <= v.succ_cap : (uint64_t)rbC <= v.halo_cap; // (RangeView::fits)
+			if (!fits) { atomicOr(err, s >= v.nh ? E_CAP : E_HALO); continue; }
+			const int64_t abase = g.minInt > 0 ? raC / g.minInt : 0;
+			if (g.minInt > 0 && (abase < 0 || abase + dC / g.minInt + 1 > arenaCap)) { atomicOr(err, E_FORMAT); continue; }
+			int32_t *const row = s < v.nh ? v.halo + raC : v.succ + (raC - rs0); // (RangeView::row)
+			parse_node_lwb(g, v.lo + s, dC, rC > 0, (int64_t)drefC, row, lw, (int2 *)(arena + abase), err, oaC, obC);
+		}
+		return;
+	}
 	// The list is sorted longest first.  Thread T takes entries T, 2G-1-T, 2G+T, 4G-1-T, ... (G = threads in the
 	// grid): a snake, so that the threads that got the longest records of one sweep get the shortest of the next.
 	const int64_t G = (int64_t)gridDim.x * TPB, T = (int64_t)blockIdx.x * TPB + threadIdx.x;
@@ -1342,8 +1371,7 @@ __global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, con
 			// the record's slice of the interval arena (the same slices as the cooperative kernels': floor(rowstart / minInt), d / minInt + 1 entries)
 			const int64_t abase = g.minInt > 0 ? v.rowstart[s] / g.minInt : 0;
 			if (g.minInt > 0 && (abase < 0 || abase + d / g.minInt + 1 > arenaCap)) { atomicOr(err, E_FORMAT); continue; }
-			if (RES && DEF == 1) parse_node_lwb(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), lw, (int2 *)(arena + abase), err);
-			else parse_node_lw<DEF == 1 ? 3 : 0, true>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), lw, (int2 *)(arena + abase), err);
+			parse_node_lw<DEF == 1 ? 3 : 0, true>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), lw, (int2 *)(arena + abase), err);
 		}
 		else if (DEF) parse_node_lw<DEF == 1 ? 3 : 0, false>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), lw, nullptr, err);
 		else parse_node<DEF>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), err);
@@ -2103,7 +2131,6 @@ void launch_parse_listed(const GraphDev &g, int def, const RangeView &v, const i
 void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, void *arena, int64_t arenaCap, int32_t keyHi, int32_t dMax) {
 	if (v.cnt <= 0) return;
 	IvEntry *a = (IvEntry *)arena;
-	if (const char *e = getenv("BVGPU_LW_DMAX")) dMax = atoi(e); // (timing experiments only: longer records are left undecoded)
 	static const bool res = [] { const char *e = getenv("BVGPU_LW_RES"); return !e || atoi(e) != 0; }(); // 0: the loop that makes a trip per successor (parse_node_lw)
 	if (def == 1 && a && res) hipLaunchKernelGGL((k_parse_list<1, true, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, keyHi, a, arenaCap, err, dMax);
 	else if (def == 1 && a) hipLaunchKernelGGL((k_parse_list<1, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, keyHi, a, arenaCap, err, dMax);

@@ -245,6 +245,7 @@ __device__ __forceinline__ void parse_node_lw(const GraphDev &g, int32_t x, int3
 // by every lane and kept or dropped by selects; what is rare (window refill, ring top-up, a codeword of more than 28 bits, the
 // unaligned head of the row) sits behind ONE wave-uniform vote each.  The sections in front of the residuals are read by loops the
 // wave walks together too (code_w).  Semantics as parse_node_lw (BVG:1040-1126; equal heads once, MergedIntIterator.java:69-72).
+__device__ __forceinline__ bool wave_any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0; } // (one s_cmp on the mask; __any goes through a 0 / 1 value per lane)
 template <int KIND> __device__ __forceinline__ bool lane_fast_code(uint32_t W, uint32_t &v, uint32_t &len) { // branch-free; v / len are junk when the result is false
 	if (KIND == 2) { const uint32_t z = (uint32_t)__clz((int)(W | 1u)); v = z; len = z + 1; return W != 0; }
 	if (KIND == 1) { const uint32_t m = (uint32_t)__clz((int)(W | (1u << 16))); len = 2 * m + 1; v = (W >> (31u - 2 * m)) - 1; return W >= (1u << 16); }
@@ -265,18 +266,19 @@ template <int KIND> __device__ __forceinline__ uint64_t code_w(LaneWin<LW_MAIN> 
 	uint32_t v, len;
 	const bool ok = lane_fast_code<KIND>((uint32_t)((ab << sh) >> 32), v, len);
 	uint64_t r = v;
-	if (__any(want && !ok)) {
+	if (wave_any(want && !ok)) {
 		if (want && !ok) r = br.template code<KIND, 3>(g, err);
 		else if (want) br.q += len;
 	} else br.q += want ? len : 0u;
 	return r;
 }
-__device__ __forceinline__ void parse_node_lwb(const GraphDev &g, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row, uint32_t *lds, int2 *__restrict__ iv, int *__restrict__ err) {
+// off0 / off1: the record's first bit and the next record's (g.offsets[x], g.offsets[x + 1]; the caller fetched them a sweep ahead)
+__device__ __forceinline__ void parse_node_lwb(const GraphDev &g, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row, uint32_t *lds, int2 *__restrict__ iv, int *__restrict__ err, uint64_t off0, uint64_t off1) {
 	LaneWin<LW_MAIN> br;
 	br.col = lds + threadIdx.x;
 	uint32_t *const ring = lds + LW_MAIN * LW_STRIDE + threadIdx.x; // entry j of the ring: ring[2 j * LW_STRIDE] = left, ring[(2 j + 1) * LW_STRIDE] = length
-	br.vlast = min((((uint64_t)g.offsets[x + 1] >> 5) + 2) & ~(uint64_t)3, (g.nwords + 4) & ~(uint64_t)3);
-	br.seek(g, (uint64_t)g.offsets[x]);
+	br.vlast = min(((off1 >> 5) + 2) & ~(uint64_t)3, (g.nwords + 4) & ~(uint64_t)3);
+	br.seek(g, off0);
 	int e = 0;
 	(void)code_w<1>(br, g, true, e);              // outdegree (known from k_headers)
 	if (g.W > 0) (void)code_w<2>(br, g, true, e); // reference
@@ -287,7 +289,7 @@ __device__ __forceinline__ void parse_node_lwb(const GraphDev &g, int32_t x, int
 		if (bc > (uint64_t)dref + 1) { e |= E_FORMAT; bc = 0; }
 		int64_t total = 0;
 		const uint32_t nb = (uint32_t)bc; // (<= dref + 1 <= 2^31)
-		for (uint32_t b = 0; __any(b < nb && !e); b++) {
+		for (uint32_t b = 0; wave_any(b < nb && !e); b++) {
 			const bool w = b < nb && !e;
 			const uint64_t c = code_w<1>(br, g, w, e);
 			int64_t len = 0;
@@ -309,7 +311,7 @@ __device__ __forceinline__ void parse_node_lwb(const GraphDev &g, int32_t x, int
 		if (ni > (uint64_t)extra) { atomicOr(err, E_FORMAT); return; }
 		nIntervals = (int32_t)ni;
 		int32_t prevEnd = 0;
-		for (int32_t i = 0; __any(i < nIntervals && !e); i++) {
+		for (int32_t i = 0; wave_any(i < nIntervals && !e); i++) {
 			const bool w = i < nIntervals && !e;
 			const uint64_t a = code_w<1>(br, g, w, e);
 			const uint64_t len = code_w<1>(br, g, w, e);
@@ -339,9 +341,9 @@ __device__ __forceinline__ void parse_node_lwb(const GraphDev &g, int32_t x, int
 	int32_t resVal = (int32_t)((int64_t)x + nat2int(code_w<0>(br, g, resTodo != 0, e))); // BVG:954
 	while (k < nExtra) {
 		const bool lowRing = ivLoaded < nIntervals && ivIdx - ivBase >= LW_RING - 2;
-		if (__any(lowRing | ((br.q >> 5) + 3 >= (uint32_t)LW_MAIN))) {
+		if (wave_any(lowRing | ((br.q >> 5) + 3 >= (uint32_t)LW_MAIN))) {
 			br.template wave_refill<3>(g);
-			if (__any(lowRing)) { // some lane's ring runs low: every lane tops its own up from the arena
+			if (wave_any(lowRing)) { // some lane's ring runs low: every lane tops its own up from the arena
 				const int32_t cnt = min((ivIdx - ivBase) & ~1, nIntervals - ivLoaded); // (ivLoaded stays even until the last top-up)
 #pragma unroll
 				for (int p = 0; p < LW_RING / 2; p++) {
@@ -372,12 +374,12 @@ __device__ __forceinline__ void parse_node_lwb(const GraphDev &g, int32_t x, int
 		const bool useRes = !takeIv && haveRes;
 		resTodo -= useRes;
 		const bool adv = useRes && resTodo != 0;
-		if (__any(adv && !ok)) {
+		if (wave_any(adv && !ok)) {
 			if (adv && !ok) resVal += (int32_t)br.template code<0, 3>(g, e) + 1;
 			else if (adv) { resVal += (int32_t)gap + 1; br.q += len; }
 		} else { resVal += adv ? (int32_t)gap + 1 : 0; br.q += adv ? len : 0u; } // BVG:966
 		const bool inHead = k < head;
-		if (__any(inHead)) { if (inHead) out[k] = val; }
+		if (wave_any(inHead)) { if (inHead) out[k] = val; }
 		k++;
 		o0 = o1; o1 = o2; o2 = o3; o3 = val;
 		on += !inHead;
