@@ -2073,6 +2073,7 @@ void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int
                        int32_t midMinKnob, bool bigGroups, const int32_t *bigQ, int32_t bigCap, const int32_t *midQ, int32_t midCap, int32_t *ctl, int32_t *tmp, uint32_t tmpCap, int *err,
                        hipStream_t st, hipStream_t stMid, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evMid, hipEvent_t evBig, const void *preDesc, bool preMid, bool vecList) {
 	if (v.cnt <= 0) return;
+	blocks = (int)std::min<int64_t>(blocks, nblk(v.cnt, TPB)); // (a thread per row at most: a small range does not launch thousands of idle blocks)
 	const int4 *pre = (const int4 *)preDesc;
 	int32_t midMin, bigMin;
 	copy_thresholds(midMinKnob, bigGroups, midMin, bigMin);
@@ -2130,6 +2131,7 @@ void launch_parse_listed(const GraphDev &g, int def, const RangeView &v, const i
 
 void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, void *arena, int64_t arenaCap, int32_t keyHi, int32_t dMax) {
 	if (v.cnt <= 0) return;
+	blocks = (int)std::min<int64_t>(blocks, nblk(v.cnt, TPB)); // (a thread per record at most)
 	IvEntry *a = (IvEntry *)arena;
 	static const bool res = [] { const char *e = getenv("BVGPU_LW_RES"); return !e || atoi(e) != 0; }(); // 0: the loop that makes a trip per successor (parse_node_lw)
 	if (def == 1 && a && res) hipLaunchKernelGGL((k_parse_list<1, true, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, keyHi, a, arenaCap, err, dMax);

@@ -125,7 +125,7 @@ struct bvg_graph {
 	DevBuf pickpart;                                                  // per-block outdegree class counts of k_headers
 	DevBuf biglist, giantlist, arena, coopctl;                        // work lists; cooperative decode of giant records
 	DevBuf key16, keys;                                               // per-slot list key; hist / keyBase / cursor
-	int level_blocks = 4096; // blocks of the list kernels (k_parse_list, k_copy_list): 2048..4096 are within 1 % on C2, 4096 is 3 % faster on cnr-2000 x30
+	int level_blocks = 16384; // blocks of the list kernels (k_parse_list, k_copy_list), at most one thread per node of the range: 8192 .. 32768 are within 1 % on C2, 2 % faster than 4096 on the C5 shard and cnr-2000 x 30 (profiles/r4_experiments.txt section 9)
 	DevBuf lvlist;
 	DevBuf plist, pkeys, pkey16;
 	DevBuf segbuf, segR; // scratch of the segment pipeline (bv_seg.hip); the residuals of its records, contiguous per record, before they are merged with the intervals
