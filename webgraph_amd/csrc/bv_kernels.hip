@@ -1326,7 +1326,7 @@ __global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, con
                                                     IvEntry *__restrict__ arena, int64_t arenaCap, int *__restrict__ err, int32_t dMax) {
 	__shared__ uint32_t lw[DEF ? (ARENA ? (LW_MAIN + 2 * LW_RING) * LW_STRIDE : LW_LDS_WORDS) : 1]; // lane-private stream windows, or one window and a ring of intervals (default codings)
 	const int32_t lo = keyBase[binLo], hi = keyBase[binHi], coopMin = v.coopmin();
-	if (RES && DEF == 1) {
+	if (RES && DEF != 0) {
 		// The same snake as below with the loads that lead to a record issued ahead of it: a sweep of short records is three dependent round
 		// trips (list entry -> outdegree / reference / row start / offsets -> the referent's outdegree and the stream words) in front of ~5 us
 		// of decoding; the entry is fetched two sweeps ahead and what hangs on it one sweep ahead, so a sweep waits for the last trip only.
@@ -1351,7 +1351,7 @@ __global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, con
 			const int64_t abase = g.minInt > 0 ? raC / g.minInt : 0;
 			if (g.minInt > 0 && (abase < 0 || abase + dC / g.minInt + 1 > arenaCap)) { atomicOr(err, E_FORMAT); continue; }
 			int32_t *const row = s < v.nh ? v.halo + raC : v.succ + (raC - rs0); // (RangeView::row)
-			parse_node_lwb(g, v.lo + s, dC, rC > 0, (int64_t)drefC, row, lw, (int2 *)(arena + abase), err, oaC, obC);
+			parse_node_lwb<DEF == 1 ? 3 : 0>(g, v.lo + s, dC, rC > 0, (int64_t)drefC, row, lw, (int2 *)(arena + abase), err, oaC, obC);
 		}
 		return;
 	}
@@ -2135,6 +2135,7 @@ void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int
 	IvEntry *a = (IvEntry *)arena;
 	static const bool res = [] { const char *e = getenv("BVGPU_LW_RES"); return !e || atoi(e) != 0; }(); // 0: the loop that makes a trip per successor (parse_node_lw)
 	if (def == 1 && a && res) hipLaunchKernelGGL((k_parse_list<1, true, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, keyHi, a, arenaCap, err, dMax);
+	else if (def == 2 && a && res) hipLaunchKernelGGL((k_parse_list<2, true, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, keyHi, a, arenaCap, err, dMax);
 	else if (def == 1 && a) hipLaunchKernelGGL((k_parse_list<1, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, keyHi, a, arenaCap, err, dMax);
 	else if (def == 2 && a) hipLaunchKernelGGL((k_parse_list<2, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, keyHi, a, arenaCap, err, dMax);
 	else if (def == 1) hipLaunchKernelGGL((k_parse_list<1, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, keyHi, a, arenaCap, err, dMax);

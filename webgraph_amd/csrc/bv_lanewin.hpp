@@ -238,7 +238,7 @@ __device__ __forceinline__ void parse_node_lw(const GraphDev &g, int32_t x, int3
 	if (e) atomicOr(err, e);
 }
 
-// The same record by a loop that the 64 lanes of a wave walk in step (round 4; zeta_3 residuals, interval arena).  parse_node_lw's
+// The same record by a loop that the 64 lanes of a wave walk in step (round 4; default codings -- zeta_3, or ZK = 0: the graph's zeta_k --, interval arena).  parse_node_lw's
 // merge loop executes ~250 wave-instructions per trip, a third of them scalar: every `if` of a lane is an exec-mask region
 // (s_and_saveexec / s_cbranch / s_or) that the wave runs through as soon as ONE lane takes it, and every code() carries a refill
 // check and three fallbacks of its own.  Here a trip is straight-line: the next gap and the next ring entry are decoded speculatively
@@ -246,33 +246,45 @@ __device__ __forceinline__ void parse_node_lw(const GraphDev &g, int32_t x, int3
 // unaligned head of the row) sits behind ONE wave-uniform vote each.  The sections in front of the residuals are read by loops the
 // wave walks together too (code_w).  Semantics as parse_node_lw (BVG:1040-1126; equal heads once, MergedIntIterator.java:69-72).
 __device__ __forceinline__ bool wave_any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0; } // (one s_cmp on the mask; __any goes through a 0 / 1 value per lane)
-template <int KIND> __device__ __forceinline__ bool lane_fast_code(uint32_t W, uint32_t &v, uint32_t &len) { // branch-free; v / len are junk when the result is false
+template <int KIND, int ZK = 3> __device__ __forceinline__ bool lane_fast_code(uint32_t W, uint32_t &v, uint32_t &len, uint32_t zk = 3u) { // branch-free; v / len are junk when the result is false
 	if (KIND == 2) { const uint32_t z = (uint32_t)__clz((int)(W | 1u)); v = z; len = z + 1; return W != 0; }
 	if (KIND == 1) { const uint32_t m = (uint32_t)__clz((int)(W | (1u << 16))); len = 2 * m + 1; v = (W >> (31u - 2 * m)) - 1; return W >= (1u << 16); }
-	const uint32_t h = (uint32_t)__clz((int)(W | (1u << 25))); // zeta_3, h <= 6
-	const uint32_t nb = 3 * h + 2;
-	const uint32_t mm = (W << (h + 1)) >> (31u - nb);
-	const uint32_t m = mm >> 1, left = 1u << (3 * h);
+	if (ZK == 3) {
+		const uint32_t h = (uint32_t)__clz((int)(W | (1u << 25))); // zeta_3, h <= 6
+		const uint32_t nb = 3 * h + 2;
+		const uint32_t mm = (W << (h + 1)) >> (31u - nb);
+		const uint32_t m = mm >> 1, left = 1u << (3 * h);
+		const bool lng = m >= left;
+		v = lng ? mm - 1 : m + left - 1;
+		len = 4 * h + 3 + (lng ? 1u : 0u);
+		return W >= (1u << 25);
+	}
+	// zeta_k with the graph's k (1 .. 16): unary h, then k h + k - 1 bits, one more if that is not a short codeword; codewords of up to 32 bits
+	const uint32_t h = (uint32_t)__clz((int)(W | 1u)), nb = zk * h + zk - 1;
+	const bool ok = W != 0 && h + 2 + nb <= 32u; // (then h <= 30 and nb <= 30: the shifts below are in range; otherwise they are masked and the result dropped)
+	const uint32_t mm = (W << ((h + 1) & 31u)) >> ((31u - nb) & 31u);
+	const uint32_t m = mm >> 1, left = 1u << ((zk * h) & 31u);
 	const bool lng = m >= left;
-	v = lng ? mm - 1 : m + left - 1;
-	len = 4 * h + 3 + (lng ? 1u : 0u);
-	return W >= (1u << 25);
+	v = lng ? mm - 1 : m + left - 1; // (zeta_1, h = 0: nb = 0, mm = the extra bit, m = 0 < left = 1: v = 0, len = 1)
+	len = h + 1 + nb + (lng ? 1u : 0u);
+	return ok;
 }
 // Called where the wave is converged: the lanes with `want` consume one code, the others keep their cursor.
-template <int KIND> __device__ __forceinline__ uint64_t code_w(LaneWin<LW_MAIN> &br, const GraphDev &g, bool want, int &err) {
+template <int KIND, int ZK = 3> __device__ __forceinline__ uint64_t code_w(LaneWin<LW_MAIN> &br, const GraphDev &g, bool want, int &err) {
 	br.template wave_refill<3>(g);
 	const uint32_t j = br.q >> 5, sh = br.q & 31u;
 	const uint64_t ab = ((uint64_t)br.col[j * LW_STRIDE] << 32) | br.col[(j + 1) * LW_STRIDE];
 	uint32_t v, len;
-	const bool ok = lane_fast_code<KIND>((uint32_t)((ab << sh) >> 32), v, len);
+	const bool ok = lane_fast_code<KIND, ZK>((uint32_t)((ab << sh) >> 32), v, len, (uint32_t)g.zetaK);
 	uint64_t r = v;
 	if (wave_any(want && !ok)) {
-		if (want && !ok) r = br.template code<KIND, 3>(g, err);
+		if (want && !ok) r = br.template code<KIND, ZK>(g, err);
 		else if (want) br.q += len;
 	} else br.q += want ? len : 0u;
 	return r;
 }
 // off0 / off1: the record's first bit and the next record's (g.offsets[x], g.offsets[x + 1]; the caller fetched them a sweep ahead)
+template <int ZK>
 __device__ __forceinline__ void parse_node_lwb(const GraphDev &g, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row, uint32_t *lds, int2 *__restrict__ iv, int *__restrict__ err, uint64_t off0, uint64_t off1) {
 	LaneWin<LW_MAIN> br;
 	br.col = lds + threadIdx.x;
@@ -338,7 +350,7 @@ __device__ __forceinline__ void parse_node_lwb(const GraphDev &g, int32_t x, int
 	int32_t ivLeft = 0, ivRem = 0, ivTodo = nIntervals;
 	int32_t ivIdx = 0, ivBase = 0, ivLoaded = min(ivTodo, LW_RING); // next interval; oldest one in the ring; intervals [ivBase, ivLoaded) are in the ring
 	int32_t resTodo = (int32_t)nRes;
-	int32_t resVal = (int32_t)((int64_t)x + nat2int(code_w<0>(br, g, resTodo != 0, e))); // BVG:954
+	int32_t resVal = (int32_t)((int64_t)x + nat2int(code_w<0, ZK>(br, g, resTodo != 0, e))); // BVG:954
 	while (k < nExtra) {
 		const bool lowRing = ivLoaded < nIntervals && ivIdx - ivBase >= LW_RING - 2;
 		if (wave_any(lowRing | ((br.q >> 5) + 3 >= (uint32_t)LW_MAIN))) {
@@ -363,7 +375,7 @@ __device__ __forceinline__ void parse_node_lwb(const GraphDev &g, int32_t x, int
 		const uint32_t jw = br.q >> 5, sh = br.q & 31u;
 		const uint64_t ab = ((uint64_t)br.col[jw * LW_STRIDE] << 32) | br.col[(jw + 1) * LW_STRIDE];
 		uint32_t gap, len;
-		const bool ok = lane_fast_code<0>((uint32_t)((ab << sh) >> 32), gap, len);
+		const bool ok = lane_fast_code<0, ZK>((uint32_t)((ab << sh) >> 32), gap, len, (uint32_t)g.zetaK);
 		const bool fetch = ivRem == 0 && ivTodo != 0;
 		ivLeft = fetch ? rl : ivLeft; ivRem = fetch ? rn : ivRem; ivIdx += fetch; ivTodo -= fetch;
 		const bool haveRes = resTodo != 0;
@@ -375,7 +387,7 @@ __device__ __forceinline__ void parse_node_lwb(const GraphDev &g, int32_t x, int
 		resTodo -= useRes;
 		const bool adv = useRes && resTodo != 0;
 		if (wave_any(adv && !ok)) {
-			if (adv && !ok) resVal += (int32_t)br.template code<0, 3>(g, e) + 1;
+			if (adv && !ok) resVal += (int32_t)br.template code<0, ZK>(g, e) + 1;
 			else if (adv) { resVal += (int32_t)gap + 1; br.q += len; }
 		} else { resVal += adv ? (int32_t)gap + 1 : 0; br.q += adv ? len : 0u; } // BVG:966
 		const bool inHead = k < head;
