@@ -198,3 +198,63 @@ def test_stats_scan_rejects_successors_outside_the_graph(tmp_path):
     st = g.scan_stats(0, 17)                   # well-formed ranges are still served
     assert st["arcs"] == 4 * 17
     g.close()
+
+
+@pytest.mark.parametrize("knobs", [{}, {"BVGPU_LW_RES": "0"}, {"BVGPU_TILE": "1"}, {"BVGPU_COOP_MIN": "2147483647"}])
+def test_residuals_inside_intervals_are_emitted_once(tmp_path, monkeypatch, knobs):
+    """A residual that equals an id of an interval: MergedIntIterator.java:69-72 emits the two equal heads once, so the list is
+    shorter than its outdegree and BVGraph.java:1210 would pad the array with -1.  No writer produces such a record; the
+    one-lane decoders (straight-line and general loop, lane windows and tiles) must still agree with the oracle on it."""
+    from bitio import write_graph, int2nat
+    from webgraph_amd.bvgraph import BVGraph
+    from oracle import oracle as O
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    MI = 3
+
+    def rec_of(x, ivs, res):
+        d = sum(n for _, n in ivs) + len(res)
+
+        def rec(w):
+            w.gamma(d)
+            w.unary(0)
+            w.gamma(len(ivs))
+            prev = None
+            for (l, n) in ivs:
+                w.gamma(int2nat(l - x) if prev is None else l - prev - 1)
+                w.gamma(n - MI)
+                prev = l + n
+            pv = None
+            for r in res:
+                w.zeta(int2nat(r - x) if pv is None else r - pv - 1)
+                pv = r
+        return rec, d
+
+    rng = np.random.default_rng(5)
+    specs = [([(10, 4)], [12, 20]), ([(10, 4), (30, 5)], [5, 10, 31, 40]), ([(5, 3)], [7]), ([(5, 3)], [1, 9]), ([], [3, 4]), ([(2, 3)], [])]
+    for _ in range(40):  # longer rows: a dozen intervals, residuals drawn over the same range (a third of them collide)
+        ivs, pos = [], 0
+        for _ in range(int(rng.integers(1, 14))):
+            pos += int(rng.integers(1, 9))
+            n = int(rng.integers(MI, 9))
+            ivs.append((pos, n))
+            pos += n
+        res = sorted(set(int(v) for v in rng.integers(0, pos + 10, size=int(rng.integers(1, 30)))))
+        specs.append((ivs, res))
+    recs, arcs = [], 0
+    for x, (ivs, res) in enumerate(specs):
+        r, d = rec_of(x, ivs, res)
+        recs.append(r)
+        arcs += d
+    base = str(tmp_path / "equalheads")
+    write_graph(base, recs, min_interval=MI, arcs=arcs)
+    rp0, sc0, _ = O.OracleGraph.load(base).scan()
+    assert (sc0 == -1).any()
+    g = BVGraph.load(base)
+    rp, sc = g.decode_range()
+    assert np.array_equal(rp, rp0) and np.array_equal(sc, sc0)
+    q = np.arange(len(recs) - 1, -1, -1, dtype=np.int32)
+    rpb, scb = g.successors_batch(q)
+    for i, x in enumerate(q):
+        assert np.array_equal(scb[rpb[i]:rpb[i + 1]], sc0[rp0[x]:rp0[x + 1]])
+    g.close()
