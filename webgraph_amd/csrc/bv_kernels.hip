@@ -68,20 +68,20 @@ __global__ void __launch_bounds__(TPB) k_headers(GraphDev g, int32_t lo, int32_t
 		ref[s] = (uint16_t)r;
 		if (e) atomicOr(err, e);
 	}
-	// How many of the block's records have >= 128, 256, ..., 2048 successors: k_pick_coop adds the blocks up and picks the
+	// How many of the block's records have >= 128, 256, ..., 8192 successors: k_pick_coop adds the blocks up and picks the
 	// job's wave-class threshold.  (Per-block slots, no atomics on shared counters and no fences: a streaming kernel of its
 	// own with a last-block-done ticket took 85 us on C2 -- its __threadfence() writes back an L2 full of fresh outdegrees.)
 	if (part) {
-		__shared__ int32_t s_c[5];
-		if (threadIdx.x < 5) s_c[threadIdx.x] = 0;
+		__shared__ int32_t s_c[PICK_LEVELS];
+		if (threadIdx.x < PICK_LEVELS) s_c[threadIdx.x] = 0;
 		__syncthreads();
 		const int32_t dd = (int32_t)d;
 		if (__ballot(dd >= 128)) {
 #pragma unroll
-			for (int k = 0; k < 5; k++) { const int n = __popcll(__ballot(dd >= (128 << k))); if ((threadIdx.x & 63) == 0 && n) atomicAdd(&s_c[k], n); }
+			for (int k = 0; k < PICK_LEVELS; k++) { const int n = __popcll(__ballot(dd >= (128 << k))); if ((threadIdx.x & 63) == 0 && n) atomicAdd(&s_c[k], n); }
 		}
 		__syncthreads();
-		if (threadIdx.x < 5) part[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = s_c[threadIdx.x];
+		if (threadIdx.x < PICK_LEVELS) part[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = s_c[threadIdx.x];
 	}
 }
 
@@ -1942,16 +1942,17 @@ void launch_bcopy(const GraphDev &g, int def, const BatchView &v, int32_t level,
 // Which records leave the one-lane decoder for a wave: counted, not guessed.  A lane decodes ~0.6 us per successor whatever its
 // neighbours do, so the lane class lasts as long as its longest record unless it holds enough records of that length to fill
 // whole waves with them (the parse list is sorted by length); a wave costs ~30 us per record but 3 072 of them run side by side.
-// The threshold is the smallest of 128 .. 2048 that sends at most `budget` records to the waves (C2: 7 121 records >= 2 048,
-// 15 410 >= 1 024 -> 2 048; cnr-2000 x 30: 11 250 >= 128 -> 128, 3.06 -> 2.67 ms; measured optimum in both cases).
+// The threshold is the smallest of 128 .. 8192 that sends at most `budget` records to the waves (C2: 7 121 records >= 2 048,
+// 15 410 >= 1 024 -> 2 048; cnr-2000 x 30: 11 250 >= 128 -> 128, 3.06 -> 2.67 ms; the same generator at 50 M nodes / 1 B arcs:
+// 8 192, 14.7 -> 13.3 ms -- a scan five times as long hides a lane four times as long; measured optimum in all three cases).
 constexpr int PICK_THREADS = 1024;
 __global__ void __launch_bounds__(PICK_THREADS) k_pick_coop(const int32_t *__restrict__ part, int32_t nblocks, int32_t budget, int32_t *__restrict__ ctl, int32_t *__restrict__ counts) {
-	__shared__ int32_t s_cnt[5];
-	if (threadIdx.x < 5) s_cnt[threadIdx.x] = 0;
+	__shared__ int32_t s_cnt[PICK_LEVELS];
+	if (threadIdx.x < PICK_LEVELS) s_cnt[threadIdx.x] = 0;
 	if (!counts && threadIdx.x >= 64 && threadIdx.x < 64 + 12) ctl[4 + (threadIdx.x - 64)] = 0; // counters of the level lists, copy queues and copy levels of this job
 	__syncthreads();
 #pragma unroll
-	for (int k = 0; k < 5; k++) {
+	for (int k = 0; k < PICK_LEVELS; k++) {
 		int32_t t = 0;
 		const int32_t *pk = part + (size_t)k * nblocks;
 		int32_t b = threadIdx.x;
@@ -1965,10 +1966,10 @@ __global__ void __launch_bounds__(PICK_THREADS) k_pick_coop(const int32_t *__res
 		if ((threadIdx.x & 63) == 0 && t) atomicAdd(&s_cnt[k], t);
 	}
 	__syncthreads();
-	if (counts) { if (threadIdx.x < 5) counts[threadIdx.x] = s_cnt[threadIdx.x]; return; } // (load time: the whole graph's counts, for the host)
+	if (counts) { if (threadIdx.x < PICK_LEVELS) counts[threadIdx.x] = s_cnt[threadIdx.x]; return; } // (load time: the whole graph's counts, for the host)
 	if (threadIdx.x != 0) return;
-	int32_t pick = 2048;
-	for (int k = 4; k >= 0; k--) { if (s_cnt[k] <= budget) pick = 128 << k; else break; }
+	int32_t pick = 128 << (PICK_LEVELS - 1);
+	for (int k = PICK_LEVELS - 1; k >= 0; k--) { if (s_cnt[k] <= budget) pick = 128 << k; else break; }
 	ctl[CTL_COOP] = pick;
 }
 void launch_pick_coop(const int32_t *part, int32_t nblocks, int32_t budget, int32_t *ctl, hipStream_t st, int32_t *counts) {

@@ -65,6 +65,7 @@ void launch_chain_fill(const GraphDev &g, int def, const int32_t *nodes, int64_t
 void launch_bparse(const GraphDev &g, int def, const BatchView &v, int *err, hipStream_t st);
 void launch_bcopy(const GraphDev &g, int def, const BatchView &v, int32_t level, int *err, hipStream_t st);
 void launch_pick_coop(const int32_t *part, int32_t nblocks, int32_t budget, int32_t *ctl, hipStream_t st, int32_t *counts = nullptr);
+constexpr int PICK_LEVELS = 7; // outdegree classes counted by k_headers / k_pick_coop: >= 128, 256, ..., 8192 successors
 constexpr int CTL_INTS = 32, CTL_COOP = 22, CTL_SEG = 24, CTL_FLAT = 28, CTL_TOTAL_INTS = CTL_INTS; // control block (bv_kernels.hip); ctl[CTL_SEG], ctl[CTL_SEG + 2]: records the segment pipeline hands to the cooperative kernel, head of that queue
 void launch_classify(int32_t cnt, const int32_t *outd, const int32_t *coopPtr, int32_t coopMin, int32_t giantMin, int32_t *biglist, int32_t *giantlist, int32_t giantCap, int32_t *ctl, hipStream_t st);
 void launch_parse_big(const GraphDev &g, int def, const RangeView &v, const int32_t *biglist, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap,

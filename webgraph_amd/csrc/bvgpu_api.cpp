@@ -70,7 +70,7 @@ struct Staged {
 	int64_t max_outdegree = -1; // the longest staged record (counted with arcs_sizing; -1: unknown)
 	int64_t lane_rows = 0, lane_ids = 0; // staged rows with a reference and fewer than 128 successors, and their ids (the lane class of the copy pass)
 	int64_t seg_long_records = -1, seg_long_bits = -1; // staged records with >= 2 048 bits of work (the parse list's long bins) and their bits (counted with arcs_sizing; -1: unknown): they size the segment pipeline
-	int32_t deg_counts[5] = { -1, -1, -1, -1, -1 }; // staged records with >= 128, 256, 512, 1024, 2048 successors (counted with arcs_sizing; -1: unknown)
+	int32_t deg_counts[bv::PICK_LEVELS] = { -1, -1, -1, -1, -1, -1, -1 }; // staged records with >= 128, 256, ..., 8192 successors (counted with arcs_sizing; -1: unknown)
 	int def = 0;                    // kernel variant: 1 default codings with zeta_3, 2 default codings with another zeta_k, 0 generic
 	std::string basename;
 	~Staged() {
@@ -302,7 +302,7 @@ int enqueue_structure(bvg_graph *g, int32_t from, int32_t to, int32_t nh, bv::Ra
 	mark(g, 0);
 	const bool pick = pickCoop && g->adaptive; // the wave-class threshold of this job comes from its outdegrees (k_pick_coop)
 	const int64_t hb = bv::headers_blocks(cnt);
-	if (pick && !g->pickpart.need(sizeof(int32_t) * 5 * (size_t)hb)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
+	if (pick && !g->pickpart.need(sizeof(int32_t) * bv::PICK_LEVELS * (size_t)hb)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
 	bv::launch_headers(gd, s.def, lo, cnt, v.outd, v.ref, derr, g->stream, pick ? g->pickpart.as<int32_t>() : nullptr);
 	if (nh) bv::launch_mark_halo(nh, cnt, s.info.window_size, v.outd, v.ref, g->need.as<uint8_t>(), derr, g->stream);
 	if (pick) { // (also zeroes ctl[4..16), the counters of the lists and of the copy levels: a memset behind the scan kernels sat 22 us on the critical path)
@@ -418,6 +418,9 @@ void pick_thresholds(const bvg_graph *g, int64_t estArcs, int32_t &coopMin, int3
 	// (a lane takes ~0.6 us per successor, a wave ~30 us per record: cnr-2000, 3.2 M arcs, 0.80 ms at 512, 0.62 ms at 128)
 	if (estArcs < 8000000) coopMin = 128; else if (estArcs < 32000000) coopMin = 512; else if (estArcs < 80000000) coopMin = 1024;
 	if (estArcs < 150000000) giantMin = 8192;
+	// (the longer the scan, the longer the chains it hides: at 1 B arcs the wave class starts at 8 192 (k_pick_coop) and a group of waves pays from 131 072 -- 14.7 -> 12.7 ms)
+	else if (estArcs >= 700000000) giantMin = std::max(giantMin, 131072);
+	else if (estArcs >= 350000000) giantMin = std::max(giantMin, 65536);
 }
 
 // The lane class of the copy pass reads and writes 16 bytes at a time where its rows are long enough to pay for the bookkeeping:
@@ -1037,16 +1040,16 @@ static int open_impl(const char *basename, int device, int part, int parts, bvg_
 		void *p_outd = nullptr, *p_ref = nullptr, *p_rs = nullptr, *p_sums = nullptr, *p_err = nullptr, *p_part = nullptr;
 		const bool ok = hipMalloc(&p_outd, sizeof(int32_t) * (size_t)n) == hipSuccess && hipMalloc(&p_ref, sizeof(uint16_t) * (size_t)n) == hipSuccess &&
 		                hipMalloc(&p_rs, sizeof(int64_t) * ((size_t)n + 8)) == hipSuccess /* (also the five counters of the sizing pass) */ && hipMalloc(&p_sums, sizeof(int64_t) * (size_t)bv::scan_num_sums(n)) == hipSuccess &&
-		                hipMalloc(&p_err, sizeof(int)) == hipSuccess && hipMalloc(&p_part, sizeof(int32_t) * (5 * (size_t)bv::headers_blocks(n) + 8)) == hipSuccess;
+		                hipMalloc(&p_err, sizeof(int)) == hipSuccess && hipMalloc(&p_part, sizeof(int32_t) * (bv::PICK_LEVELS * (size_t)bv::headers_blocks(n) + 8)) == hipSuccess;
 		int64_t total = 0;
 		hipError_t e = ok ? hipMemset(p_err, 0, sizeof(int)) : hipErrorOutOfMemory;
 		if (e == hipSuccess) {
 			const int64_t hb = bv::headers_blocks(n);
 			bv::launch_headers(graph_dev0(*st), st->def, st->stage_lo, n, (int32_t *)p_outd, (uint16_t *)p_ref, (int *)p_err, nullptr, (int32_t *)p_part);
 			bv::launch_scan((const int32_t *)p_outd, n, (int64_t *)p_rs, (int64_t *)p_sums, nullptr);
-			bv::launch_pick_coop((const int32_t *)p_part, (int32_t)hb, 0, nullptr, nullptr, (int32_t *)p_part + 5 * hb); // how long the records are: the lane class is decoded from tiles when few are long (enqueue_decode)
+			bv::launch_pick_coop((const int32_t *)p_part, (int32_t)hb, 0, nullptr, nullptr, (int32_t *)p_part + bv::PICK_LEVELS * hb); // how long the records are: the lane class is decoded from tiles when few are long (enqueue_decode)
 			e = hipMemcpy(&total, (int64_t *)p_rs + n, sizeof(int64_t), hipMemcpyDeviceToHost);
-			if (e == hipSuccess) e = hipMemcpy(st->deg_counts, (int32_t *)p_part + 5 * hb, sizeof(st->deg_counts), hipMemcpyDeviceToHost);
+			if (e == hipSuccess) e = hipMemcpy(st->deg_counts, (int32_t *)p_part + bv::PICK_LEVELS * hb, sizeof(st->deg_counts), hipMemcpyDeviceToHost);
 			if (e == hipSuccess && st->def != 0) { // (p_rs is done with: two counters)
 				unsigned long long five[5] = { 0, 0, 0, 0, 0 };
 				e = hipMemset(p_rs, 0, sizeof(five));
