@@ -239,6 +239,39 @@ __global__ void __launch_bounds__(TPB) k_scan_top(int64_t *__restrict__ sums, in
 	for (int64_t j = lo; j < hi; j++) { const int64_t v = sums[j]; sums[j] = run; run += v; }
 }
 
+// The same for many sums (ranges of tens of millions of nodes: the kernel above grows with nb -- 342 us for the 48 829 sums of a 50 M-node scan, on the
+// chain in front of every parse kernel): tiles of 1 024 sums with a carry, coalesced loads, the next tile's in flight while this one is scanned.
+// (Not for small ranges: there the scan of the outdegrees must not end before the parse list is built -- the giants start behind it and their
+// groups, a CU each, starve k_scatter_keys; profiles/r4_experiments.txt section 9.)
+constexpr int SCAN_TOP_T = 1024, SCAN_TOP_I = 4, SCAN_TOP_TILED_MIN = 16384;
+__global__ void __launch_bounds__(SCAN_TOP_T) k_scan_top_tiled(int64_t *__restrict__ sums, int64_t nb) {
+	__shared__ int64_t wsum[SCAN_TOP_T / 64];
+	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+	constexpr int TILE = SCAN_TOP_T * SCAN_TOP_I; // (a thread owns SCAN_TOP_I consecutive sums of a tile: 32 bytes)
+	int64_t carry = 0;
+	int64_t vn[SCAN_TOP_I];
+#pragma unroll
+	for (int i = 0; i < SCAN_TOP_I; i++) { const int64_t j = (int64_t)threadIdx.x * SCAN_TOP_I + i; vn[i] = j < nb ? sums[j] : 0; }
+	for (int64_t base = 0; base < nb; base += TILE) {
+		int64_t v[SCAN_TOP_I], mine = 0;
+#pragma unroll
+		for (int i = 0; i < SCAN_TOP_I; i++) { v[i] = vn[i]; mine += v[i]; }
+#pragma unroll
+		for (int i = 0; i < SCAN_TOP_I; i++) { const int64_t j = base + TILE + (int64_t)threadIdx.x * SCAN_TOP_I + i; vn[i] = j < nb ? sums[j] : 0; }
+		const int64_t inc = wave_incl_scan(mine);
+		if (lane == 63) wsum[wid] = inc;
+		__syncthreads();
+		int64_t wbase = 0, tot = 0;
+#pragma unroll
+		for (int i = 0; i < SCAN_TOP_T / 64; i++) { const int64_t w = wsum[i]; if (i < wid) wbase += w; tot += w; }
+		__syncthreads();
+		int64_t run = carry + wbase + inc - mine;
+#pragma unroll
+		for (int i = 0; i < SCAN_TOP_I; i++) { const int64_t j = base + (int64_t)threadIdx.x * SCAN_TOP_I + i; if (j < nb) sums[j] = run; run += v[i]; }
+		carry += tot;
+	}
+}
+
 __global__ void __launch_bounds__(TPB) k_scan_apply(const int32_t *__restrict__ in, int64_t n, const int64_t *__restrict__ sums, int64_t *__restrict__ out) {
 	const int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
 	int64_t vals[SCAN_ITEMS];
@@ -1856,7 +1889,9 @@ void launch_mark_halo(int32_t nh, int32_t cnt, int32_t W, int32_t *outd, uint16_
 void launch_scan(const int32_t *in, int64_t n, int64_t *out, int64_t *sums, hipStream_t st) {
 	const int64_t nb = n > 0 ? (n + SCAN_TILE - 1) / SCAN_TILE : 1;
 	hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nb), dim3(TPB), 0, st, in, n, sums);
-	hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(TPB), 0, st, sums, nb);
+	static const int64_t tiledMin = [] { const char *e = getenv("BVGPU_SCAN_TOP_TILED_MIN"); return e ? (int64_t)atoll(e) : (int64_t)SCAN_TOP_TILED_MIN; }();
+	if (nb >= tiledMin) hipLaunchKernelGGL(k_scan_top_tiled, dim3(1), dim3(SCAN_TOP_T), 0, st, sums, nb);
+	else hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(TPB), 0, st, sums, nb);
 	hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(TPB), 0, st, in, n, sums, out);
 }
 int64_t scan_num_sums(int64_t n) { return n > 0 ? (n + SCAN_TILE - 1) / SCAN_TILE : 1; }
