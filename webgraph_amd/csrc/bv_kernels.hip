@@ -1451,10 +1451,12 @@ __global__ void __launch_bounds__(TPB) k_classify(int32_t cnt, const int32_t *__
 // table keeps its (node) order.
 constexpr int SORT_CAP = 16384, SORT_BINS = 256;
 __global__ void __launch_bounds__(1024) k_sort_desc(int32_t *__restrict__ listA, const int32_t *__restrict__ countA, int32_t capA,
-                                                    int32_t *__restrict__ listB, const int32_t *__restrict__ countB, int32_t capB, const int32_t *__restrict__ outd) {
+                                                    int32_t *__restrict__ listB, const int32_t *__restrict__ countB, int32_t capB, const int32_t *__restrict__ outd,
+                                                    int32_t *__restrict__ started) {
 	__shared__ int32_t s_out[SORT_CAP], s_cur[SORT_BINS];
 	int32_t *__restrict__ list = blockIdx.x ? listB : listA; // one block per queue, side by side
 	const int32_t n = blockIdx.x ? min(*countB, capB) : min(*countA, capA);
+	if (blockIdx.x == 0 && threadIdx.x == 0 && started) *started = 0; // (k_wait_giants: groups of the giants' kernel that have started, this job)
 	if (n <= 1 || n > SORT_CAP) return;
 	auto key = [](int32_t d) { // larger outdegree -> smaller key
 		const uint32_t u = (uint32_t)max(d, 1);
@@ -1504,6 +1506,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? COOP1_MINWAVES : COOPG_MINW
 	__shared__ int32_t s_idx;
 	const int32_t count = ctl[which]; // (the giant list is sized for arcs / giantMin entries, which bounds their number)
 	if (count <= 0) return; // (an empty list -- the usual state of the strip kernel's escape list -- costs no atomics)
+	if (NW != 1 && which == 1 && threadIdx.x == 0) atomicAdd(&ctl[CTL_GIANT_STARTED], 1); // (k_wait_giants)
 	for (;;) {
 		if (threadIdx.x == 0) s_idx = atomicAdd(&ctl[2 + which], 1);
 		__syncthreads();
@@ -2014,7 +2017,25 @@ void launch_pick_coop(const int32_t *part, int32_t nblocks, int32_t budget, int3
 void launch_classify(int32_t cnt, const int32_t *outd, const int32_t *coopPtr, int32_t coopMin, int32_t giantMin, int32_t *biglist, int32_t *giantlist, int32_t giantCap, int32_t *ctl, hipStream_t st) {
 	if (cnt <= 0) return;
 	hipLaunchKernelGGL(k_classify, dim3(nblk(cnt, TPB * CLASSIFY_ITEMS)), dim3(TPB), 0, st, cnt, outd, coopPtr, coopMin, giantMin, biglist, giantlist, giantCap, ctl);
-	hipLaunchKernelGGL(k_sort_desc, dim3(2), dim3(1024), 0, st, giantlist, ctl + 1, giantCap, biglist, ctl + 0, cnt, outd);
+	hipLaunchKernelGGL(k_sort_desc, dim3(2), dim3(1024), 0, st, giantlist, ctl + 1, giantCap, biglist, ctl + 0, cnt, outd, ctl + CTL_GIANT_STARTED);
+}
+
+// The giants' groups need a CU each (eight waves at 241 VGPRs, 99 KB of LDS) and find one only while the other parse kernels are not there yet: launched
+// in the same microsecond as k_parse_list and the wave class (a range of tens of millions of nodes: the scan of the outdegrees and the parse list end
+// together) they waited for those to drain -- 8.2 ms for 0.95 ms of work at 1 B arcs, the last kernel of the parse phase.  One wave in front of each of
+// the two other kernels holds its stream until the giants' groups have counted themselves in (or 30 us have passed: then they are not coming soon).
+__global__ void __launch_bounds__(64) k_wait_giants(const int32_t *__restrict__ ctl, int32_t groups) {
+	if (threadIdx.x) return;
+	const int32_t want = min(groups, ctl[1]);
+	const uint64_t t0 = __builtin_amdgcn_s_memrealtime(); // 100 MHz
+	while (__hip_atomic_load(ctl + CTL_GIANT_STARTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+		if (__builtin_amdgcn_s_memrealtime() - t0 > 3000) break;
+		__builtin_amdgcn_s_sleep(16);
+	}
+}
+void launch_wait_giants(const int32_t *ctl, int giantGroups, hipStream_t st) {
+	static const bool on = [] { const char *e = getenv("BVGPU_WAIT_GIANTS"); return !e || atoi(e) != 0; }();
+	if (on) hipLaunchKernelGGL(k_wait_giants, dim3(1), dim3(64), 0, st, ctl, (int32_t)giantGroups);
 }
 
 void launch_parse_big(const GraphDev &g, int def, const RangeView &v, const int32_t *biglist, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap,
@@ -2023,6 +2044,7 @@ void launch_parse_big(const GraphDev &g, int def, const RangeView &v, const int3
 	if (def == 1) hipLaunchKernelGGL((k_parse_big<1, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
 	else if (def == 2) hipLaunchKernelGGL((k_parse_big<2, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
 	else hipLaunchKernelGGL((k_parse_big<0, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+	if (stBig != stGiant) launch_wait_giants(ctl, giantGroups, stBig);
 	if (def == 1) hipLaunchKernelGGL((k_parse_big<1, 1, RangeView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
 	else if (def == 2) hipLaunchKernelGGL((k_parse_big<2, 1, RangeView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
 	else hipLaunchKernelGGL((k_parse_big<0, 1, RangeView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);

@@ -66,7 +66,7 @@ void launch_bparse(const GraphDev &g, int def, const BatchView &v, int *err, hip
 void launch_bcopy(const GraphDev &g, int def, const BatchView &v, int32_t level, int *err, hipStream_t st);
 void launch_pick_coop(const int32_t *part, int32_t nblocks, int32_t budget, int32_t *ctl, hipStream_t st, int32_t *counts = nullptr);
 constexpr int PICK_LEVELS = 7; // outdegree classes counted by k_headers / k_pick_coop: >= 128, 256, ..., 8192 successors
-constexpr int CTL_INTS = 32, CTL_COOP = 22, CTL_SEG = 24, CTL_FLAT = 28, CTL_TOTAL_INTS = CTL_INTS; // control block (bv_kernels.hip); ctl[CTL_SEG], ctl[CTL_SEG + 2]: records the segment pipeline hands to the cooperative kernel, head of that queue
+constexpr int CTL_INTS = 32, CTL_COOP = 22, CTL_SEG = 24, CTL_FLAT = 28, CTL_GIANT_STARTED = 31, CTL_TOTAL_INTS = CTL_INTS; // control block (bv_kernels.hip); ctl[CTL_SEG], ctl[CTL_SEG + 2]: records the segment pipeline hands to the cooperative kernel, head of that queue
 void launch_classify(int32_t cnt, const int32_t *outd, const int32_t *coopPtr, int32_t coopMin, int32_t giantMin, int32_t *biglist, int32_t *giantlist, int32_t giantCap, int32_t *ctl, hipStream_t st);
 void launch_parse_big(const GraphDev &g, int def, const RangeView &v, const int32_t *biglist, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap,
                       int waves, int giantGroups, int *err, hipStream_t stGiant, hipStream_t stBig);
@@ -83,6 +83,7 @@ void launch_copy_tile(const GraphDev &g, int def, const RangeView &v, const int3
 void launch_copy_prewalk(const GraphDev &g, int def, const RangeView &v, const int32_t *bigQ, int32_t bigCap, const int32_t *ctl, void *desc, int blocks, hipStream_t st, int32_t midCap, hipStream_t stLong, bool longKernel, hipStream_t stWalk); // stWalk: the stream of k_copy_prewalk (as stLong) // stLong: the stream of the long lists' kernel (ordered behind the queues by the caller; may be st); // midCap > 0: also the wave class's rows (queue at bigQ + bigCap, descriptors at desc + bigCap)
 void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, void *arena = nullptr, int64_t arenaCap = 0, int32_t keyHi = NKEYS, int32_t dMax = 0x7fffffff); // records with >= dMax successors are somebody else's
 // one wave per record of `list` (ctl[which] entries, queue head ctl[which + 2]): k_parse_big<1>
+void launch_wait_giants(const int32_t *ctl, int giantGroups, hipStream_t st); // holds st until the giants' groups are on their CUs (or 30 us have passed)
 void launch_parse_listed(const GraphDev &g, int def, const RangeView &v, const int32_t *list, int32_t *ctl, int which, void *arena, int64_t arenaCap, int waves, int *err, hipStream_t st);
 // bv_seg.hip: the segment pipeline for the records of the parse list's keys [kLo, kHi) that have fewer than coop_min successors
 constexpr int PARSE_LONG_BIN = 14; // work bins from here up (>= 2048 bits of work) are not windowed (k_depth_keys) -- and are the segment pipeline's

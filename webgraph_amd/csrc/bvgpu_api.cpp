@@ -642,7 +642,10 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			}
 			if (g->flat && s.def != 0 && g->iv_arena && g->flatfb.need(sizeof(int32_t) * (size_t)v.cnt))
 				bv::launch_parse_flat(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, keyHi, g->level_blocks, g->arena.p, arenaCap, g->flatfb.as<int32_t>(), ctl, derr, g->stream);
-			else bv::launch_parse_list(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, g->level_blocks, derr, g->stream, g->iv_arena ? g->arena.p : nullptr, arenaCap, keyHi, dMaxList);
+			else {
+				if (ovl && coop) { HIPCHK(g, hipStreamWaitEvent(g->stream, g->evC, 0)); bv::launch_wait_giants(ctl, g->giant_groups, g->stream); } // (the giants first: k_wait_giants)
+				bv::launch_parse_list(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, g->level_blocks, derr, g->stream, g->iv_arena ? g->arena.p : nullptr, arenaCap, keyHi, dMaxList);
+			}
 		}
 		if (ovl) {
 			HIPCHK(g, hipStreamWaitEvent(g->stream, g->evA, 0));
