@@ -240,6 +240,9 @@ KNOBS = [
     {"BVGPU_COPY_BIG": "0"}, {"BVGPU_WALK_TABLES": "0"}, {"BVGPU_IV_ARENA": "0", "BVGPU_TILE": "0"}, {"BVGPU_IV_ARENA": "1", "BVGPU_TILE": "0"},
     # the contiguous-tile kernel (bv_tile.hpp): parse from one LDS image per tile
     {"BVGPU_TILE": "0"}, {"BVGPU_TILE": "1"}, {"BVGPU_TILE": "1", "BVGPU_COOP_MIN": "300", "BVGPU_GIANT_MIN": "4000"},
+    # round 4: the general one-lane loop instead of the straight-line one (with the lane windows, not the tiles), the tiled top scan on small ranges, no gate for the giants
+    {"BVGPU_LW_RES": "0", "BVGPU_TILE": "0"}, {"BVGPU_LW_RES": "1", "BVGPU_TILE": "0", "BVGPU_COOP_MIN": "2147483647"}, {"BVGPU_SCAN_TOP_TILED_MIN": "1"},
+    {"BVGPU_WAIT_GIANTS": "0", "BVGPU_COOP_MIN": "16", "BVGPU_GIANT_MIN": "64"},
     {"BVGPU_PREWALK": "0"}, {"BVGPU_COPY_VEC": "1"}, {"BVGPU_COPY_VEC": "1", "BVGPU_COPY_MID_MIN": "16", "BVGPU_COOP_MIN": "16", "BVGPU_GIANT_MIN": "64"}, {"BVGPU_COPY_TILE": "1"},
 ]
 

@@ -1892,7 +1892,8 @@ void launch_mark_halo(int32_t nh, int32_t cnt, int32_t W, int32_t *outd, uint16_
 void launch_scan(const int32_t *in, int64_t n, int64_t *out, int64_t *sums, hipStream_t st) {
 	const int64_t nb = n > 0 ? (n + SCAN_TILE - 1) / SCAN_TILE : 1;
 	hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nb), dim3(TPB), 0, st, in, n, sums);
-	static const int64_t tiledMin = [] { const char *e = getenv("BVGPU_SCAN_TOP_TILED_MIN"); return e ? (int64_t)atoll(e) : (int64_t)SCAN_TOP_TILED_MIN; }();
+	const char *eTiled = getenv("BVGPU_SCAN_TOP_TILED_MIN"); // (read per launch: the tests switch it inside one process)
+	const int64_t tiledMin = eTiled ? (int64_t)atoll(eTiled) : (int64_t)SCAN_TOP_TILED_MIN;
 	if (nb >= tiledMin) hipLaunchKernelGGL(k_scan_top_tiled, dim3(1), dim3(SCAN_TOP_T), 0, st, sums, nb);
 	else hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(TPB), 0, st, sums, nb);
 	hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(TPB), 0, st, in, n, sums, out);
@@ -2034,7 +2035,8 @@ __global__ void __launch_bounds__(64) k_wait_giants(const int32_t *__restrict__ 
 	}
 }
 void launch_wait_giants(const int32_t *ctl, int giantGroups, hipStream_t st) {
-	static const bool on = [] { const char *e = getenv("BVGPU_WAIT_GIANTS"); return !e || atoi(e) != 0; }();
+	const char *eWait = getenv("BVGPU_WAIT_GIANTS"); // (read per launch)
+	const bool on = !eWait || atoi(eWait) != 0;
 	if (on) hipLaunchKernelGGL(k_wait_giants, dim3(1), dim3(64), 0, st, ctl, (int32_t)giantGroups);
 }
 
@@ -2191,7 +2193,8 @@ void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int
 	if (v.cnt <= 0) return;
 	blocks = (int)std::min<int64_t>(blocks, nblk(v.cnt, TPB)); // (a thread per record at most)
 	IvEntry *a = (IvEntry *)arena;
-	static const bool res = [] { const char *e = getenv("BVGPU_LW_RES"); return !e || atoi(e) != 0; }(); // 0: the loop that makes a trip per successor (parse_node_lw)
+	const char *eRes = getenv("BVGPU_LW_RES"); // (read per launch) 0: the loop that makes a trip per successor (parse_node_lw)
+	const bool res = !eRes || atoi(eRes) != 0;
 	if (def == 1 && a && res) hipLaunchKernelGGL((k_parse_list<1, true, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, keyHi, a, arenaCap, err, dMax);
 	else if (def == 2 && a && res) hipLaunchKernelGGL((k_parse_list<2, true, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, keyHi, a, arenaCap, err, dMax);
 	else if (def == 1 && a) hipLaunchKernelGGL((k_parse_list<1, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, keyHi, a, arenaCap, err, dMax);
