@@ -1,5 +1,5 @@
 // seg_model.cpp -- host-side model of the segment pipeline (webgraph_amd/csrc/bv_seg.hip): the SAME bodies (bv_seg.hpp, compiled here
-// for the CPU) driven lane after lane in the order the kernels run them -- struct, A1, A2, scan, B, expand.  Test infrastructure:
+// for the CPU) driven lane after lane in the order the kernels run them -- struct (here: see below), A1, A2, scan, B, expand.  Test infrastructure:
 // tests/test_seg_model_cpu.py builds it with g++ and compares what it decodes with the CPU oracle, so that the logic of the kernels is
 // checked in the `-m "not gpu"` suite before it ever runs on a GPU.  Not part of the product.
 #include "../../webgraph_amd/csrc/bv_seg.hpp"
@@ -10,6 +10,73 @@
 #include <vector>
 
 using namespace bvsg;
+
+// The structure of a record as one lane reads it (round 4's k_seg_struct, which gave the pipeline records of its own, is tag r4-experiments;
+// in the product the descriptors of the pipeline's records come from the cooperative kernel, bv_coop.hpp).  Kept here: the model's source of descriptors.
+namespace bvsg {
+// The gamma-coded front of record x (outdegree d; referent's outdegree dref if it has a reference): BVG:1048-1096.
+template <int STRIDE>
+SG_D void struct_lane(const SegGraph &g, uint32_t *col, int32_t x, int32_t d, bool hasRef, int64_t dref, SegIv *iv, RecDesc &o) {
+	Win<STRIDE> w;
+	const uint64_t recEnd = (uint64_t)g.offsets[x + 1];
+	w.init(g, col, recEnd);
+	uint32_t q = w.seek((uint64_t)g.offsets[x]);
+	bool bad = false;
+	(void)w.gamma(q, bad);               // outdegree (known from k_headers)
+	if (g.W > 0) { SG_REFILL(w, q); (void)w.unary(q, bad); } // reference
+	int64_t copied = 0;
+	if (hasRef) { // BVG:1058-1071
+		SG_REFILL(w, q);
+		const uint32_t bc = w.gamma(q, bad);
+		int64_t total = 0;
+		if ((int64_t)bc > dref + 1) bad = true;
+		for (uint32_t b = 0; b < bc && !bad; b++) {
+			SG_REFILL(w, q);
+			const int64_t code = (int64_t)w.gamma(q, bad);
+			if (code > dref - total) { bad = true; break; } // (a code of a malformed stream is rejected before it reaches a sum)
+			const int64_t len = code + (b ? 1 : 0);
+			if (total + len > dref) { bad = true; break; }
+			total += len;
+			if (!(b & 1)) copied += len;
+		}
+		if (!(bc & 1)) copied += dref - total;
+	}
+	const int64_t extra = (int64_t)d - copied;
+	if (extra < 0 || copied < 0) bad = true;
+	int32_t nIv = 0, ivArcs = 0;
+	if (!bad && extra > 0 && g.minInt != 0) { // BVG:1073-1096
+		SG_REFILL(w, q);
+		const uint32_t ic = w.gamma(q, bad);
+		const int32_t xtr = (int32_t)extra, minInt = g.minInt;
+		if ((int64_t)ic > extra / minInt) bad = true; else nIv = (int32_t)ic;
+		int32_t prevEnd = 0;
+		for (int32_t i = 0; i < nIv && !bad; i++) {
+			SG_REFILL(w, q);
+			const uint32_t a = w.gamma(q, bad);
+			SG_REFILL(w, q);
+			const uint32_t l = w.gamma(q, bad);
+			if (l > (uint32_t)xtr) { bad = true; break; }
+			const int32_t left = i == 0 ? (int32_t)((uint32_t)x + (uint32_t)zigzag32(a)) : (int32_t)((uint32_t)prevEnd + a + 1u), n = (int32_t)l + minInt; // in Java ints (BVG:1084-1093)
+			if (i > 0 && left < prevEnd) { bad = true; break; } // intervals that wrap around: not here
+			prevEnd = (int32_t)((uint32_t)left + (uint32_t)n);
+			iv[i] = SegIv{ left, ivArcs, -1, n }; // rank -1: behind every residual, unless B says otherwise
+			ivArcs += n;                          // (<= extra + minInt: no overflow)
+			if (ivArcs > xtr) { bad = true; break; }
+		}
+	}
+	// (the zig-zag value of the first interval is a long in the file: one that does not fit 33 bits made gamma() say bad)
+	const int64_t nres = extra - ivArcs;
+	if (nres < 0) bad = true;
+	o.rpos = (int64_t)w.pos(q);
+	o.nres = bad ? 0 : (int32_t)nres;
+	o.copied = bad ? 0 : (int32_t)copied;
+	o.nIv = bad ? 0 : nIv;
+	o.ivArcs = bad ? 0 : ivArcs;
+	o.flags = bad ? RF_FALLBACK : 0;
+	if (!bad && nres > 0 && (uint64_t)o.rpos >= recEnd) o.flags = RF_FALLBACK; // residuals past the record's end (offsets that disagree with the stream)
+}
+
+}
 
 extern "C" {
 
@@ -163,38 +230,6 @@ int seg_model_run(const uint8_t *graph, uint64_t nbytes, const int64_t *offsets,
 			int32_t *out = succ + (rowstart[s] - rowstart[0]) + desc[r].copied;
 			for (int32_t i = 0; i < desc[r].nIv; i++) expand_interval(iv_of(s)[i], 0, out, outd[s] - desc[r].copied);
 		}
-	}
-	return 0;
-}
-
-// The short records' kernel (k_parse_flat): one lane per record, structure then the merged stream of the whole record as ONE piece.
-int flat_model_run(const uint8_t *graph, uint64_t nbytes, const int64_t *offsets, int32_t lo, int32_t cnt, const int32_t *outd, const uint16_t *ref,
-                   const int64_t *rowstart, int W, int minInt, int zk, int dmin, int dmax, int32_t *succ, int32_t *esc, int32_t *nEsc, int32_t *cop, int64_t *stats) {
-	SegGraph g{ (const uint32_t *)graph, (nbytes + 3) / 4, offsets, W, minInt, zk };
-	*nEsc = 0;
-	for (int s = 0; s < cnt; s++) cop[s] = -1;
-	for (int k = 0; k < 8; k++) stats[k] = 0;
-	std::vector<uint32_t> lds(WIN_WORDS), ringv(2 * FRING), stagev(STAGE);
-	const int64_t arcs = rowstart[cnt] - rowstart[0];
-	std::vector<SegIv> arena((size_t)(minInt > 0 ? arcs / minInt + cnt + 2 : 1));
-	for (int32_t s = 0; s < cnt; s++) {
-		if (outd[s] < std::max(dmin, 1) || outd[s] >= dmax) continue;
-		stats[0]++;
-		const int32_t x = lo + s, rf = ref[s];
-		if (rf > s) { esc[(*nEsc)++] = s; continue; }
-		SegIv *iv = arena.data() + (minInt > 0 ? (rowstart[s] - rowstart[0]) / minInt : 0);
-		RecDesc d{};
-		struct_lane<1>(g, lds.data(), x, outd[s], rf > 0, rf > 0 ? (int64_t)outd[s - rf] : 0, iv, d);
-		bool ok = !(d.flags & RF_FALLBACK);
-		if (ok && outd[s] - d.copied > 0) {
-			uint64_t endBit;
-			int32_t *out = succ + (rowstart[s] - rowstart[0]) + d.copied;
-			ok = zk == 3 ? seg_flat<3, 1>(g, lds.data(), ringv.data(), stagev.data(), x, (uint64_t)d.rpos, (uint64_t)offsets[x + 1], (uint32_t)d.nres, 0, 0, true, true, out, outd[s] - d.copied, iv, d.nIv, endBit)
-			             : seg_flat<0, 1>(g, lds.data(), ringv.data(), stagev.data(), x, (uint64_t)d.rpos, (uint64_t)offsets[x + 1], (uint32_t)d.nres, 0, 0, true, true, out, outd[s] - d.copied, iv, d.nIv, endBit);
-		}
-		if (!ok) { esc[(*nEsc)++] = s; stats[3]++; continue; }
-		cop[s] = d.copied;
-		stats[5] += d.nIv;
 	}
 	return 0;
 }

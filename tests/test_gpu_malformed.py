@@ -200,7 +200,7 @@ def test_stats_scan_rejects_successors_outside_the_graph(tmp_path):
     g.close()
 
 
-@pytest.mark.parametrize("knobs", [{}, {"BVGPU_LW_RES": "0"}, {"BVGPU_TILE": "1"}, {"BVGPU_COOP_MIN": "2147483647"}])
+@pytest.mark.parametrize("knobs", [{}, {"BVGPU_TILE": "1"}, {"BVGPU_COOP_MIN": "2147483647"}])
 def test_residuals_inside_intervals_are_emitted_once(tmp_path, monkeypatch, knobs):
     """A residual that equals an id of an interval: MergedIntIterator.java:69-72 emits the two equal heads once, so the list is
     shorter than its outdegree and BVGraph.java:1210 would pad the array with -1.  No writer produces such a record; the

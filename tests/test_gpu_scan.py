@@ -237,13 +237,13 @@ def test_sharded_scan_equals_whole(cnr_gpu, cnr_oracle):
 
 KNOBS = [
     {"BVGPU_OVERLAP": "0"}, {"BVGPU_COOP_MIN": "16", "BVGPU_GIANT_MIN": "64"}, {"BVGPU_COOP_MIN": "2147483647"},
-    {"BVGPU_COPY_BIG": "0"}, {"BVGPU_WALK_TABLES": "0"}, {"BVGPU_IV_ARENA": "0", "BVGPU_TILE": "0"}, {"BVGPU_IV_ARENA": "1", "BVGPU_TILE": "0"},
+    {"BVGPU_COPY_BIG": "0"}, {"BVGPU_WALK_TABLES": "0"},
     # the contiguous-tile kernel (bv_tile.hpp): parse from one LDS image per tile
     {"BVGPU_TILE": "0"}, {"BVGPU_TILE": "1"}, {"BVGPU_TILE": "1", "BVGPU_COOP_MIN": "300", "BVGPU_GIANT_MIN": "4000"},
-    # round 4: the general one-lane loop instead of the straight-line one (with the lane windows, not the tiles), the tiled top scan on small ranges, no gate for the giants
-    {"BVGPU_LW_RES": "0", "BVGPU_TILE": "0"}, {"BVGPU_LW_RES": "1", "BVGPU_TILE": "0", "BVGPU_COOP_MIN": "2147483647"}, {"BVGPU_SCAN_TOP_TILED_MIN": "1"},
+    # round 4: the one-lane loop with the lane windows (not the tiles) for every record, the tiled top scan on small ranges, no gate for the giants
+    {"BVGPU_TILE": "0", "BVGPU_COOP_MIN": "2147483647"}, {"BVGPU_SCAN_TOP_TILED_MIN": "1"},
     {"BVGPU_WAIT_GIANTS": "0", "BVGPU_COOP_MIN": "16", "BVGPU_GIANT_MIN": "64"},
-    {"BVGPU_PREWALK": "0"}, {"BVGPU_COPY_VEC": "1"}, {"BVGPU_COPY_VEC": "1", "BVGPU_COPY_MID_MIN": "16", "BVGPU_COOP_MIN": "16", "BVGPU_GIANT_MIN": "64"}, {"BVGPU_COPY_TILE": "1"},
+    {"BVGPU_PREWALK": "0"}, {"BVGPU_COPY_VEC": "1"}, {"BVGPU_COPY_VEC": "1", "BVGPU_COPY_MID_MIN": "16", "BVGPU_COOP_MIN": "16", "BVGPU_GIANT_MIN": "64"},
 ]
 
 
@@ -309,15 +309,13 @@ LONG_ROW_CASES = [
     ("zeta7", 0, 7, {}),  # codewords outgrow the 32-bit window early: the 64-bit and generic fallbacks run
     ("zeta16", 0, 16, {}),
     ("zeta5_small_thresholds", 0, 5, {"BVGPU_COOP_MIN": "64", "BVGPU_GIANT_MIN": "2000"}),
-    # the segment pipeline (bv_seg.hip; off by default): residual sections in pieces of stream, with and without the hand-over from the cooperative kernels
-    ("seg", 0, 3, {"BVGPU_SEG": "2"}),
-    ("seg_own_records_only", 0, 3, {"BVGPU_SEG": "2", "BVGPU_SEG_HANDOVER": "0"}),
-    ("seg_serial", 0, 3, {"BVGPU_SEG": "2", "BVGPU_OVERLAP": "0"}),
-    ("seg_small_thresholds", 0, 3, {"BVGPU_SEG": "2", "BVGPU_COOP_MIN": "64", "BVGPU_GIANT_MIN": "2000"}),
-    ("seg_zeta5", 0, 5, {"BVGPU_SEG": "2"}),
-    ("seg_zeta1", 0, 1, {"BVGPU_SEG": "2"}),
-    ("seg_zeta7_flat", 0, 7, {"BVGPU_SEG": "2", "BVGPU_FLAT": "1"}),
-    ("flat", 0, 3, {"BVGPU_FLAT": "1"}),  # the short records by k_parse_flat
+    # the segment pipeline (bv_seg.hip; by default only for hubs of >= 1 M successors): the giants hand their residual sections over, decoded in pieces of stream
+    ("seg", 0, 3, {"BVGPU_SEG": "3", "BVGPU_SEG_HUB_MIN": "2000", "BVGPU_COOP_MIN": "64", "BVGPU_GIANT_MIN": "2000"}),
+    ("seg_serial", 0, 3, {"BVGPU_SEG": "3", "BVGPU_SEG_HUB_MIN": "2000", "BVGPU_COOP_MIN": "64", "BVGPU_GIANT_MIN": "2000", "BVGPU_OVERLAP": "0"}),
+    ("seg_some", 0, 3, {"BVGPU_SEG": "3", "BVGPU_SEG_HUB_MIN": "20000", "BVGPU_COOP_MIN": "64", "BVGPU_GIANT_MIN": "2000"}),
+    ("seg_zeta5", 0, 5, {"BVGPU_SEG": "3", "BVGPU_SEG_HUB_MIN": "2000", "BVGPU_COOP_MIN": "64", "BVGPU_GIANT_MIN": "2000"}),
+    ("seg_zeta1", 0, 1, {"BVGPU_SEG": "3", "BVGPU_SEG_HUB_MIN": "2000", "BVGPU_COOP_MIN": "64", "BVGPU_GIANT_MIN": "2000"}),
+    ("seg_zeta7", 0, 7, {"BVGPU_SEG": "3", "BVGPU_SEG_HUB_MIN": "2000", "BVGPU_COOP_MIN": "64", "BVGPU_GIANT_MIN": "2000"}),
     # the copy pass's block lists walked before the levels (k_copy_prewalk*, default on), its variants and what it replaces
     ("prewalk_off", 0, 3, {"BVGPU_PREWALK": "0"}),
     ("prewalk_group_class_only", 0, 3, {"BVGPU_PREWALK": "2"}),
@@ -329,7 +327,6 @@ LONG_ROW_CASES = [
     ("prewalk_serial", 0, 2, {"BVGPU_OVERLAP": "0", "BVGPU_COPY_VEC": "1"}),
     ("copy_vec_on", 0, 3, {"BVGPU_COPY_VEC": "1"}),
     ("copy_vec_off", 0, 3, {"BVGPU_COPY_VEC": "0"}),
-    ("copy_tile", 0, 3, {"BVGPU_COPY_TILE": "1"}),
     ("batch_dense", 0, 3, {"BVGPU_BATCH_DENSE": "1000000000"}),  # random access as a masked scan + gather
     ("batch_dense_small_thresholds", 0, 3, {"BVGPU_BATCH_DENSE": "1000000000", "BVGPU_COOP_MIN": "64", "BVGPU_GIANT_MIN": "2000"}),
 ]
@@ -363,7 +360,7 @@ def test_long_rows_with_references(tmp_path_factory, monkeypatch, case):
     g.close()
 
 
-@pytest.mark.parametrize("env", [{"BVGPU_SEG": "2"}, {"BVGPU_SEG": "2", "BVGPU_SEG_HANDOVER": "0"}, {"BVGPU_SEG": "2", "BVGPU_FLAT": "1"}], ids=["seg", "own", "flat"])
+@pytest.mark.parametrize("env", [{"BVGPU_SEG": "3", "BVGPU_SEG_HUB_MIN": "2000", "BVGPU_COOP_MIN": "64", "BVGPU_GIANT_MIN": "2000"}, {"BVGPU_SEG": "3", "BVGPU_SEG_HUB_MIN": "60000"}, {}], ids=["seg", "seg_longest_only", "default"])
 def test_segment_pipeline_on_streams_that_never_resynchronise(tmp_path, monkeypatch, env):
     """A piece of a residual section is decoded from a guessed start and trusted only once its chain of codewords has met
     the true one.  Rows whose gaps are all alike repeat one codeword for ever (gap 7 is zeta_3 '1111'): a chain that starts

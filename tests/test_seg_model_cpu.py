@@ -22,7 +22,7 @@ def build_model(dirname, seg_bits_log2=None, any_always=False):
         cmd.insert(1, "-DSG_ANY_ALWAYS")
     subprocess.check_call(cmd)
     L = C.CDLL(so)
-    for f in (L.seg_model_run, L.flat_model_run):
+    for f in (L.seg_model_run,):
         f.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                       C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p]
     return L
@@ -45,7 +45,7 @@ def model_small(tmp_path_factory):
     return build_model(tmp_path_factory.mktemp("seg_model7"), 7)
 
 
-def run_model(L, base, lo=0, hi=None, dmin=1, dmax=1 << 30, flat=False):
+def run_model(L, base, lo=0, hi=None, dmin=1, dmax=1 << 30):
     from oracle import oracle as O
     og = O.OracleGraph.load(base)
     n = og.n
@@ -63,7 +63,7 @@ def run_model(L, base, lo=0, hi=None, dmin=1, dmax=1 << 30, flat=False):
     cop = np.zeros(max(cnt, 1), dtype=np.int32)
     stats = np.zeros(8, dtype=np.int64)
     p = og.params
-    rc = (L.flat_model_run if flat else L.seg_model_run)(graph.ctypes.data, len(raw), offsets.ctypes.data, lo, cnt, outd.ctypes.data, ref.ctypes.data, rowptr.ctypes.data,
+    rc = L.seg_model_run(graph.ctypes.data, len(raw), offsets.ctypes.data, lo, cnt, outd.ctypes.data, ref.ctypes.data, rowptr.ctypes.data,
                          p.window, p.min_interval, p.zeta_k, dmin, dmax, got.ctypes.data, esc.ctypes.data, C.byref(nesc), cop.ctypes.data, stats.ctypes.data)
     assert rc == 0
     return dict(rowptr=rowptr, succ=succ, outd=outd, ref=ref.astype(np.int64), got=got, esc=esc[:nesc.value], cop=cop, stats=stats, cnt=cnt)
@@ -150,14 +150,3 @@ def test_synthetic_parameters(model, model_small, model_always, tmp_path_factory
     r = run_model(model_small, base, dmin=64)
     n = check(r, 64, 1 << 30, max_escapes=int(r["stats"][0]))  # (most chains do not meet within 128 bits of these codes: those records are the cooperative kernel's)
     assert n > 100
-
-
-def test_whole_records_as_one_piece(model, model_always, tmp_path_factory):
-    """k_parse_flat: a short record is one piece that starts and ends its record -- structure, then the merged stream"""
-    r = run_model(model, CNR, flat=True)
-    assert check(r, 1, 1 << 30, max_escapes=0) > 240000
-    r = run_model(model_always, CNR, flat=True)
-    check(r, 1, 1 << 30, max_escapes=0)
-    base, rowptr, succ = make_graph(tmp_path_factory, "fl", 60000, 1500000, 99, 0.6, window=5, max_ref_count=4, min_interval=2, zeta_k=4)
-    r = run_model(model, base, flat=True)
-    assert check(r, 1, 1 << 30, max_escapes=0) > 30000

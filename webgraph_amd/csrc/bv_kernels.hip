@@ -36,8 +36,11 @@ namespace bv {
 constexpr int TPB = 256;
 constexpr int GIANT_NW = COOP_GIANT_NW; // waves per giant record
 
-template <int DEF>
+template <int DEF, int AG = 0>
 __device__ __forceinline__ void copy_node(const GraphDev &g, int32_t x, int32_t d, int64_t dref, int32_t *__restrict__ row, const int32_t *__restrict__ src, int *__restrict__ err);
+// agent-scope (write-through / L1-bypassing) accesses: what a row needs when another workgroup of the SAME launch reads it (MI355X_MICROARCH.md, inter-workgroup visibility)
+__device__ __forceinline__ void st_agent(int32_t *p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int32_t ld_agent(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <int DEF>
 __device__ __forceinline__ void parse_node(const GraphDev &g, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row, int *__restrict__ err);
 template <int DEF>
@@ -521,7 +524,7 @@ __device__ __forceinline__ int copy_class(const RangeView &v, const int32_t *__r
 	if (!v.fits(s) || !v.fits(s - v.ref[s])) return 0; // E_CAP / E_HALO already raised by the parse kernel
 	return copy_class_of(v.outd[s], v.outd[s - v.ref[s]], midMin, bigMin);
 }
-template <int DEF, bool VEC>
+template <int DEF, bool VEC, int AG = 0>
 __global__ void __launch_bounds__(TPB) k_copy_list(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ list,
                                                    const int32_t *__restrict__ keyBase, int32_t level, int32_t midMin, int32_t bigMin, int *__restrict__ err) {
 	const int32_t bucket = min(level, MAXLVL - 1);
@@ -541,145 +544,8 @@ __global__ void __launch_bounds__(TPB) k_copy_list(GraphDev g, RangeView v, cons
 		int32_t *row = s < v.nh ? v.halo + rs0 : v.succ + (rs0 - rsNh);
 		const int32_t *src = t < v.nh ? v.halo + rt0 : v.succ + (rt0 - rsNh);
 		if (VEC) copy_node_v<DEF>(g, v.lo + s, d, dref, row, src, err);
-		else copy_node<DEF>(g, v.lo + s, d, (int64_t)dref, row, src, err);
+		else copy_node<DEF, AG>(g, v.lo + s, d, (int64_t)dref, row, src, err);
 	}
-}
-
-// ------------------------------------------------------------------------------------------------ copy pass, tiles of neighbours
-// A referent is at most W nodes before its row, and rows of neighbouring nodes are neighbours in the CSR: a work-group that loads
-// the rows of a run of consecutive nodes into LDS (coalesced) holds most reference chains of those nodes whole.  It merges the
-// short rows (the lane class of the copy pass) whose chain lies inside its tile there, level after level with a barrier in between
-// -- no launch per level, no scattered 4-byte loads and stores from 64 different rows per wave instruction (k_copy_list: 2.3 ms
-// of the C5 shard, 0.8 ms of C2) --, writes the tile back (coalesced) and takes the rows it has finished off the level kernels'
-// hands by zeroing their reference (copy_class: 0).  Everything else -- rows of the wave and group classes, rows whose chain
-// leaves the tile or passes through such a row, chains deeper than CT_LV -- is left to the level kernels, which run afterwards.
-// A tile is the nodes whose weighted start rowstart[s] + CT_NODE_W * s falls into one slice of CT_C (so that a run of empty
-// nodes cannot make a tile of a million nodes); inside a level the rows are handed to the lanes by length (counting sort, eight
-// bins), longest first.  The merge is copy_node's (MaskedIntIterator / MergedIntIterator, BVG:1095-1133), on LDS pointers.
-constexpr int CT_T = 512, CT_C = 12288, CT_NODE_W = 6, CT_NODES = CT_C / CT_NODE_W, CT_SLACK = 256, CT_IDS = CT_C + CT_SLACK, CT_LV = 16, CT_NB = 8, CT_KEYS = CT_LV * CT_NB;
-typedef __attribute__((address_space(3))) int32_t lds_i32;
-
-// tb[k] = first slot s in [nh, cnt] with (rowstart[s] - rowstart[nh]) + CT_NODE_W * (s - nh) >= k * CT_C
-__global__ void __launch_bounds__(256) k_ctile_bounds(const int64_t *__restrict__ rowstart, int32_t nh, int32_t cnt, int32_t ntiles, int32_t *__restrict__ tb) {
-	const int32_t k = blockIdx.x * 256 + threadIdx.x;
-	if (k > ntiles) return;
-	const int64_t want = (int64_t)k * CT_C, r0 = rowstart[nh];
-	int32_t lo = nh, hi = cnt;
-	while (lo < hi) { const int32_t mid = lo + ((hi - lo) >> 1); if (rowstart[mid] - r0 + (int64_t)CT_NODE_W * (mid - nh) < want) lo = mid + 1; else hi = mid; }
-	tb[k] = lo;
-}
-
-// copy_node on a row and a referent that live in LDS; false: nothing done (the level kernels will do, or flag, the row)
-template <int DEF>
-__device__ __forceinline__ bool copy_node_lds(const GraphDev &g, int32_t x, int32_t d, int64_t dref, lds_i32 *row, const lds_i32 *src, int *__restrict__ err) {
-	BitReader br;
-	br.init(g.bits, g.nwords);
-	br.seek((uint64_t)g.offsets[x]);
-	(void)Fields<DEF>::outdegree(br, g);
-	(void)Fields<DEF>::reference(br, g);
-	const uint64_t bc = Fields<DEF>::block_count(br, g);
-	if (bc > (uint64_t)dref + 1) return false;
-	const uint64_t blocksPos = br.pos();
-	int64_t total = 0, copied = 0;
-	for (uint64_t b = 0; b < bc; b++) {
-		int64_t len;
-		if (!block_len_ok(Fields<DEF>::block(br, g), b == 0, total, dref, len)) return false;
-		total += len;
-		if (!(b & 1)) copied += len;
-	}
-	if (!(bc & 1)) copied += dref - total;
-	if (copied > d || br.err) return false;
-	br.seek(blocksPos);
-	int32_t i = 0, k = 0, j = (int32_t)copied; // index in the referent's row, write index, extras read index (k <= j throughout)
-	int32_t ev = j < d ? row[j] : 0;
-	for (uint64_t b = 0; b <= bc; b++) {
-		int32_t len;
-		if (b < bc) len = (int32_t)Fields<DEF>::block(br, g) + (b ? 1 : 0);
-		else len = (int32_t)dref - i; // implicit last block: the rest of the referent
-		if (b & 1) { i += len; continue; }
-		for (int32_t t = 0; t < len && i < (int32_t)dref && k < d; t++) {
-			const int32_t cv = src[i++];
-			while (j < d && ev < cv) { row[k++] = ev; j++; if (j < d) ev = row[j]; }
-			if (j < d && ev == cv) { j++; if (j < d) ev = row[j]; } // equal heads emitted once (never in a valid file)
-			row[k++] = cv;
-		}
-	}
-	if (k != j) { while (j < d) { row[k++] = row[j++]; } while (k < d) row[k++] = -1; }
-	if (br.err) atomicOr(err, br.err);
-	return true;
-}
-
-template <int DEF>
-__global__ void __launch_bounds__(CT_T) k_copy_tile(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ tb, int32_t midMin, int32_t bigMin, int *__restrict__ err) {
-	__shared__ int32_t s_ids[CT_IDS];
-	__shared__ uint16_t s_list[CT_NODES];
-	__shared__ uint8_t s_ok[CT_NODES];
-	__shared__ int32_t s_cnt[CT_KEYS + 1], s_base[CT_KEYS + 1], s_wb[2];
-	const int32_t a = tb[blockIdx.x], b = tb[blockIdx.x + 1];
-	if (a >= b) return;
-	const int32_t nn = min(b - a, CT_NODES), tid = threadIdx.x;
-	const int64_t R0 = v.rowstart[a];
-	const int32_t span = (int32_t)min<int64_t>(v.rowstart[a + nn] - R0, CT_IDS);
-	if ((uint64_t)(R0 + span - v.rowstart[v.nh]) > v.succ_cap) return; // (E_CAP: raised by the parse kernels)
-	int32_t *const gbase = v.succ + (R0 - v.rowstart[v.nh]);
-	lds_i32 *const ids = (lds_i32 *)s_ids;
-	for (int k = tid; k <= CT_KEYS; k += CT_T) s_cnt[k] = 0;
-	if (tid == 0) { s_wb[0] = 0x7fffffff; s_wb[1] = 0; }
-	__syncthreads();
-	// keys: (level, length bin, longest first) of the rows this tile may finish
-	constexpr int PER = CT_NODES / CT_T;
-	int32_t key[PER], rank[PER];
-#pragma unroll
-	for (int it = 0; it < PER; it++) {
-		const int32_t i = it * CT_T + tid;
-		key[it] = -1;
-		if (i < nn) {
-			s_ok[i] = 0;
-			const int32_t s2 = a + i, r = v.ref[s2], d = v.outd[s2];
-			if (r != 0 && d > 0 && s2 - r >= a) {
-				const int32_t lvl = depth[s2];
-				if (copy_class_of(d, v.outd[s2 - r], midMin, bigMin) == 1 && v.rowstart[s2 + 1] - R0 <= span && lvl >= 1 && lvl < CT_LV) {
-					const int bin = min(CT_NB - 1, 31 - __clz(d));
-					key[it] = lvl * CT_NB + (CT_NB - 1 - bin);
-					rank[it] = atomicAdd(&s_cnt[key[it]], 1);
-				}
-			}
-		}
-	}
-	__syncthreads();
-	if (tid < 64) { // exclusive scan of the CT_KEYS counters: two per lane
-		static_assert(CT_KEYS == 128, "two counters per lane");
-		const int32_t c0 = s_cnt[2 * tid], c1 = s_cnt[2 * tid + 1];
-		const int64_t inc = wave_incl_scan_i64((int64_t)c0 + c1);
-		s_base[2 * tid] = (int32_t)inc - c0 - c1; s_base[2 * tid + 1] = (int32_t)inc - c1;
-		if (tid == 63) s_base[CT_KEYS] = (int32_t)inc;
-	}
-	__syncthreads();
-	const int32_t nrows = s_base[CT_KEYS];
-	if (nrows == 0) return;
-#pragma unroll
-	for (int it = 0; it < PER; it++) if (key[it] >= 0) s_list[s_base[key[it]] + rank[it]] = (uint16_t)(it * CT_T + tid);
-	for (int32_t k = tid; k < span; k += CT_T) ids[k] = gbase[k];
-	__syncthreads();
-	for (int lvl = 1; lvl < CT_LV; lvl++) {
-		const int32_t lo = s_base[lvl * CT_NB], hi = s_base[(lvl + 1) * CT_NB];
-		if (lo == nrows) break; // (uniform) no deeper rows
-		for (int32_t e = lo + tid; e < hi; e += CT_T) {
-			const int32_t i = s_list[e], s2 = a + i, t = s2 - v.ref[s2];
-			if (v.ref[t] != 0 && !s_ok[t - a]) continue; // the referent is not final yet: this row is the level kernels'
-			const int32_t d = v.outd[s2], o = (int32_t)(v.rowstart[s2] - R0);
-			if (copy_node_lds<DEF>(g, v.lo + s2, d, (int64_t)v.outd[t], ids + o, ids + (int32_t)(v.rowstart[t] - R0), err)) {
-				s_ok[i] = 1;
-				atomicMin(&s_wb[0], o); atomicMax(&s_wb[1], o + d);
-			}
-		}
-		__syncthreads();
-	}
-	const int32_t w0 = s_wb[0], w1 = s_wb[1];
-	if (w0 >= w1) return; // (uniform) nothing merged
-	for (int32_t k = w0 + tid; k < w1; k += CT_T) gbase[k] = ids[k];
-#pragma unroll
-	for (int it = 0; it < PER; it++) { const int32_t i = it * CT_T + tid; if (key[it] >= 0 && s_ok[i]) v.ref[a + i] = 0; }
 }
 
 // One wave per row of fewer than COPY_BIG_MIN successors with a reference.  The block list is walked once (by
@@ -1353,61 +1219,43 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 	}
 }
 
-// parse pass over a list sorted by work bin only (all chain levels together): 64 records of similar length per wave
-template <int DEF, bool ARENA, bool RES = false>
+// parse pass over a list sorted by work bin only (all chain levels together): 64 records of similar length per wave.
+// The list is sorted longest first.  Thread T takes entries T, 2G-1-T, 2G+T, 4G-1-T, ... (G = threads in the grid): a snake, so that the
+// threads that got the longest records of one sweep get the shortest of the next.  The loads that lead to a record are issued ahead of it:
+// a sweep of short records is three dependent round trips (list entry -> outdegree / reference / row start / offsets -> the referent's
+// outdegree and the stream words) in front of ~5 us of decoding; the entry is fetched two sweeps ahead and what hangs on it one sweep
+// ahead, so a sweep waits for the last trip only.  Default codings: parse_node_lwb (bv_lanewin.hpp); others: the generic reader.
+template <int DEF>
 __global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, const int32_t *__restrict__ list, const int32_t *__restrict__ keyBase, int32_t binLo, int32_t binHi,
-                                                    IvEntry *__restrict__ arena, int64_t arenaCap, int *__restrict__ err, int32_t dMax) {
-	__shared__ uint32_t lw[DEF ? (ARENA ? (LW_MAIN + 2 * LW_RING) * LW_STRIDE : LW_LDS_WORDS) : 1]; // lane-private stream windows, or one window and a ring of intervals (default codings)
+                                                    IvEntry *__restrict__ arena, int64_t arenaCap, int *__restrict__ err) {
+	__shared__ uint32_t lw[DEF ? (LW_MAIN + 2 * LW_RING) * LW_STRIDE : 1]; // per lane: a window of the stream and a ring of intervals (default codings)
 	const int32_t lo = keyBase[binLo], hi = keyBase[binHi], coopMin = v.coopmin();
-	if (RES && DEF != 0) {
-		// The same snake as below with the loads that lead to a record issued ahead of it: a sweep of short records is three dependent round
-		// trips (list entry -> outdegree / reference / row start / offsets -> the referent's outdegree and the stream words) in front of ~5 us
-		// of decoding; the entry is fetched two sweeps ahead and what hangs on it one sweep ahead, so a sweep waits for the last trip only.
-		const int64_t G = (int64_t)gridDim.x * TPB, T = (int64_t)blockIdx.x * TPB + threadIdx.x, N = (int64_t)hi - lo;
-		const int64_t rs0 = v.rowstart[v.nh];
-		auto entry = [&](int64_t sweep) -> int32_t {
-			const int64_t off = sweep * G + ((sweep & 1) ? G - 1 - T : T);
-			return sweep * G < N && off < N ? list[hi - 1 - off] : -1;
-		};
-		int32_t sCur = entry(0), sNext = entry(1);
-		int32_t d = 0, r = 0; int64_t ra = 0, rb = 0; uint64_t oa = 0, ob = 0;
+	const int64_t G = (int64_t)gridDim.x * TPB, T = (int64_t)blockIdx.x * TPB + threadIdx.x, N = (int64_t)hi - lo;
+	const int64_t rs0 = v.rowstart[v.nh];
+	auto entry = [&](int64_t sweep) -> int32_t {
+		const int64_t off = sweep * G + ((sweep & 1) ? G - 1 - T : T);
+		return sweep * G < N && off < N ? list[hi - 1 - off] : -1;
+	};
+	int32_t sCur = entry(0), sNext = entry(1);
+	int32_t d = 0, r = 0; int64_t ra = 0, rb = 0; uint64_t oa = 0, ob = 0;
+	if (sCur >= 0) { d = v.outd[sCur]; r = v.ref[sCur]; ra = v.rowstart[sCur]; rb = v.rowstart[sCur + 1]; oa = (uint64_t)g.offsets[v.lo + sCur]; ob = (uint64_t)g.offsets[v.lo + sCur + 1]; }
+	for (int64_t sweep = 0; sweep * G < N; sweep++) {
+		const int32_t s = sCur, dC = d, rC = r; const int64_t raC = ra, rbC = rb; const uint64_t oaC = oa, obC = ob;
+		const int32_t drefC = s >= 0 && rC > 0 ? v.outd[s - rC] : 0;
+		sCur = sNext; sNext = entry(sweep + 2);
+		d = 0;
 		if (sCur >= 0) { d = v.outd[sCur]; r = v.ref[sCur]; ra = v.rowstart[sCur]; rb = v.rowstart[sCur + 1]; oa = (uint64_t)g.offsets[v.lo + sCur]; ob = (uint64_t)g.offsets[v.lo + sCur + 1]; }
-		for (int64_t sweep = 0; sweep * G < N; sweep++) {
-			const int32_t s = sCur, dC = d, rC = r; const int64_t raC = ra, rbC = rb; const uint64_t oaC = oa, obC = ob;
-			const int32_t drefC = s >= 0 && rC > 0 ? v.outd[s - rC] : 0;
-			sCur = sNext; sNext = entry(sweep + 2);
-			d = 0;
-			if (sCur >= 0) { d = v.outd[sCur]; r = v.ref[sCur]; ra = v.rowstart[sCur]; rb = v.rowstart[sCur + 1]; oa = (uint64_t)g.offsets[v.lo + sCur]; ob = (uint64_t)g.offsets[v.lo + sCur + 1]; }
-			if (s < 0 || dC >= coopMin || dC >= dMax || dC == 0) continue; // decoded by whole waves (k_parse_big) / by the segment pipeline (bv_seg.hip) / nothing to decode
-			const bool fits = s >= v.nh ? (uint64_t)(rbC - rs0) <= v.succ_cap : (uint64_t)rbC <= v.halo_cap; // (RangeView::fits)
-			if (!fits) { atomicOr(err, s >= v.nh ? E_CAP : E_HALO); continue; }
+		if (s < 0 || dC >= coopMin || dC == 0) continue; // decoded by whole waves (k_parse_big) / nothing to decode
+		const bool fits = s >= v.nh ? (uint64_t)(rbC - rs0) <= v.succ_cap : (uint64_t)rbC <= v.halo_cap; // (RangeView::fits)
+		if (!fits) { atomicOr(err, s >= v.nh ? E_CAP : E_HALO); continue; }
+		int32_t *const row = s < v.nh ? v.halo + raC : v.succ + (raC - rs0); // (RangeView::row)
+		if (DEF) {
+			// the record's slice of the interval arena (the same slices as the cooperative kernels': floor(rowstart / minInt), d / minInt + 1 entries)
 			const int64_t abase = g.minInt > 0 ? raC / g.minInt : 0;
 			if (g.minInt > 0 && (abase < 0 || abase + dC / g.minInt + 1 > arenaCap)) { atomicOr(err, E_FORMAT); continue; }
-			int32_t *const row = s < v.nh ? v.halo + raC : v.succ + (raC - rs0); // (RangeView::row)
 			parse_node_lwb<DEF == 1 ? 3 : 0>(g, v.lo + s, dC, rC > 0, (int64_t)drefC, row, lw, (int2 *)(arena + abase), err, oaC, obC);
 		}
-		return;
-	}
-	// The list is sorted longest first.  Thread T takes entries T, 2G-1-T, 2G+T, 4G-1-T, ... (G = threads in the
-	// grid): a snake, so that the threads that got the longest records of one sweep get the shortest of the next.
-	const int64_t G = (int64_t)gridDim.x * TPB, T = (int64_t)blockIdx.x * TPB + threadIdx.x;
-	for (int64_t sweep = 0; sweep * G < (int64_t)hi - lo; sweep++) {
-		const int64_t off = sweep * G + ((sweep & 1) ? G - 1 - T : T);
-		if (off >= (int64_t)hi - lo) continue;
-		const int32_t idx = (int32_t)(hi - 1 - off);
-		const int32_t s = list[idx];
-		const int32_t d = v.outd[s];
-		if (d >= coopMin || d >= dMax || d == 0) continue; // decoded by whole waves (k_parse_big) / by the segment pipeline (bv_seg.hip) / nothing to decode
-		const int32_t r = v.ref[s];
-		if (!v.fits(s)) { atomicOr(err, s >= v.nh ? E_CAP : E_HALO); continue; }
-		if (DEF && ARENA) {
-			// the record's slice of the interval arena (the same slices as the cooperative kernels': floor(rowstart / minInt), d / minInt + 1 entries)
-			const int64_t abase = g.minInt > 0 ? v.rowstart[s] / g.minInt : 0;
-			if (g.minInt > 0 && (abase < 0 || abase + d / g.minInt + 1 > arenaCap)) { atomicOr(err, E_FORMAT); continue; }
-			parse_node_lw<DEF == 1 ? 3 : 0, true>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), lw, (int2 *)(arena + abase), err);
-		}
-		else if (DEF) parse_node_lw<DEF == 1 ? 3 : 0, false>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), lw, nullptr, err);
-		else parse_node<DEF>(g, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), err);
+		else parse_node<DEF>(g, v.lo + s, dC, rC > 0, (int64_t)drefC, row, err);
 	}
 }
 
@@ -1506,7 +1354,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? COOP1_MINWAVES : COOPG_MINW
 	__shared__ int32_t s_idx;
 	const int32_t count = ctl[which]; // (the giant list is sized for arcs / giantMin entries, which bounds their number)
 	if (count <= 0) return; // (an empty list -- the usual state of the strip kernel's escape list -- costs no atomics)
-	if (NW != 1 && which == 1 && threadIdx.x == 0) atomicAdd(&ctl[CTL_GIANT_STARTED], 1); // (k_wait_giants)
+	if (std::is_same<View, RangeView>::value && NW != 1 && which == 1 && threadIdx.x == 0) atomicAdd(&ctl[CTL_GIANT_STARTED], 1); // (k_wait_giants; scans only)
 	for (;;) {
 		if (threadIdx.x == 0) s_idx = atomicAdd(&ctl[2 + which], 1);
 		__syncthreads();
@@ -1531,7 +1379,12 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? COOP1_MINWAVES : COOPG_MINW
 		}
 		if (bad) { if (threadIdx.x == 0) atomicOr(err, bad); }
 		else coop_parse_node<DEF, NW>(g, rec.x, rec.d, rec.hasRef, rec.dref, rec.row, arena + abase, lds, err, segOut);
-		if (segOut && threadIdx.x == 0) g.segNseg[g.segOff[which] + idx] = bvsg::seg_count(*segOut, (uint64_t)g.offsets[rec.x + 1]); // (0 when the record was decoded here after all)
+		if (segOut && threadIdx.x == 0) {
+			const int32_t ns = bvsg::seg_count(*segOut, (uint64_t)g.offsets[rec.x + 1]); // (0 when the record was decoded here after all)
+			// residuals handed over but no piece to decode them from: offsets that put the section at or behind the record's end -- nobody would decode them
+			if (ns == 0 && segOut->flags == 0 && segOut->nres > 0) atomicOr(err, E_FORMAT);
+			g.segNseg[g.segOff[which] + idx] = ns;
+		}
 		if (g.stats) { const unsigned long long dt = __builtin_readcyclecounter() - t0; stat_add(g, 5, 1); stat_add(g, 6, dt); stat_max(g, 7, dt); }
 	}
 }
@@ -1540,7 +1393,9 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? COOP1_MINWAVES : COOPG_MINW
 // One lane per node of chain depth `level`: merge the masked copy of the referent's final row with the
 // node's extras (sitting at row[copied..d)), forward and in place.  The write index never overtakes the
 // extras read index: k = (#copied so far) + (j - copied) <= j.
-template <int DEF>
+// AG bit 0: the row leaves in agent-scope (write-through) stores; bit 1: the referent's ids come in by agent-scope loads (it was written by another
+// workgroup of this launch: k_copy_dep)
+template <int DEF, int AG>
 __device__ __forceinline__ void copy_node(const GraphDev &g, int32_t x, int32_t d, int64_t dref, int32_t *__restrict__ row, const int32_t *__restrict__ src, int *__restrict__ err) {
 	BitReader br;
 	br.init(g.bits, g.nwords);
@@ -1571,14 +1426,15 @@ __device__ __forceinline__ void copy_node(const GraphDev &g, int32_t x, int32_t 
 		else len = dref - i; // implicit last block: the rest of the referent
 		if (b & 1) { i += len; continue; } // skip block
 		for (int64_t t = 0; t < len && i < dref && k < d; t++) { // (the bounds hold by the checks above: belt and braces)
-			const int32_t cv = src[i++];
-			while (j < d && ev < cv) { row[k++] = ev; j++; if (j < d) ev = row[j]; }
+			const int32_t cv = (AG & 2) ? ld_agent(src + i) : src[i]; i++;
+			while (j < d && ev < cv) { if (AG & 1) st_agent(row + k, ev); else row[k] = ev; k++; j++; if (j < d) ev = row[j]; }
 			if (j < d && ev == cv) { j++; if (j < d) ev = row[j]; } // equal heads emitted once (never in a valid file)
-			row[k++] = cv;
+			if (AG & 1) st_agent(row + k, cv); else row[k] = cv;
+			k++;
 		}
 	}
 	// remaining extras row[j..d) are already in place when k == j; a malformed duplicate leaves a gap: pad with -1
-	if (k != j) { while (j < d) { row[k++] = row[j++]; } while (k < d) row[k++] = -1; }
+	if (k != j) { while (j < d) { const int32_t t = row[j++]; if (AG & 1) st_agent(row + k, t); else row[k] = t; k++; } while (k < d) { if (AG & 1) st_agent(row + k, -1); else row[k] = -1; k++; } }
 	if (br.err) atomicOr(err, br.err);
 }
 
@@ -2102,19 +1958,6 @@ void copy_thresholds(int32_t midMinKnob, bool bigGroups, int32_t &midMin, int32_
 	bigMin = bigGroups ? COPY_BIG_MIN : 0x7fffffff; // !bigGroups: every row is merged by one lane
 	midMin = (midMinKnob <= 0 || midMinKnob > bigMin || !bigGroups) ? bigMin : midMinKnob; // = bigMin: no wave-per-row class
 }
-int32_t copy_tile_count(int64_t arcsBound, int32_t nodes) { return (int32_t)std::min<int64_t>((arcsBound + (int64_t)CT_NODE_W * nodes) / CT_C + 1, 0x7ffffff0); }
-void launch_copy_tile_bounds(const RangeView &v, int32_t ntiles, int32_t *tb, hipStream_t st) {
-	hipLaunchKernelGGL(k_ctile_bounds, dim3(nblk((int64_t)ntiles + 1, 256)), dim3(256), 0, st, v.rowstart, v.nh, v.cnt, ntiles, tb);
-}
-// tiles of neighbouring rows merged in LDS, every level at once (k_copy_tile): before the level kernels
-void launch_copy_tile(const GraphDev &g, int def, const RangeView &v, const int32_t *depth, const int32_t *tb, int32_t ntiles, int32_t midMinKnob, bool bigGroups, int *err, hipStream_t st) {
-	if (v.cnt <= v.nh || ntiles <= 0) return;
-	int32_t midMin, bigMin;
-	copy_thresholds(midMinKnob, bigGroups, midMin, bigMin);
-	if (def == 1) hipLaunchKernelGGL(k_copy_tile<1>, dim3(ntiles), dim3(CT_T), 0, st, g, v, depth, tb, midMin, bigMin, err);
-	else if (def == 2) hipLaunchKernelGGL(k_copy_tile<2>, dim3(ntiles), dim3(CT_T), 0, st, g, v, depth, tb, midMin, bigMin, err);
-	else hipLaunchKernelGGL(k_copy_tile<0>, dim3(ntiles), dim3(CT_T), 0, st, g, v, depth, tb, midMin, bigMin, err);
-}
 // walks the block lists of the rows in the group class's queue (all levels); desc: 16 bytes per queue entry
 void launch_copy_prewalk(const GraphDev &g, int def, const RangeView &v, const int32_t *bigQ, int32_t bigCap, const int32_t *ctl, void *desc, int blocks, hipStream_t st, int32_t midCap, hipStream_t stLong, bool longKernel, hipStream_t stWalk) {
 	if (v.cnt <= 0 || !g.walktab) return;
@@ -2162,6 +2005,11 @@ void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int
 	}
 	if (stMid != st) (void)hipEventRecord(evMid, stMid);
 #define COPY_LIST(D, V) hipLaunchKernelGGL((k_copy_list<D, V>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err)
+	const char *eAg = getenv("BVGPU_EXP_AG"); const int ag = eAg ? atoi(eAg) : 0; // EXPERIMENT
+	if (def == 1 && ag == 1) hipLaunchKernelGGL((k_copy_list<1, false, 1>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
+	else if (def == 1 && ag == 2) hipLaunchKernelGGL((k_copy_list<1, false, 2>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
+	else if (def == 1 && ag == 3) hipLaunchKernelGGL((k_copy_list<1, false, 3>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
+	else
 	if (def == 1) { if (vecList) COPY_LIST(1, true); else COPY_LIST(1, false); }
 	else if (def == 2) { if (vecList) COPY_LIST(2, true); else COPY_LIST(2, false); }
 	else { if (vecList) COPY_LIST(0, true); else COPY_LIST(0, false); }
@@ -2189,19 +2037,13 @@ void launch_parse_listed(const GraphDev &g, int def, const RangeView &v, const i
 	else hipLaunchKernelGGL((k_parse_big<0, 1, RangeView>), dim3(waves), dim3(64), 0, st, g, v, list, ctl, which, (IvEntry *)arena, arenaCap, err);
 }
 
-void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, void *arena, int64_t arenaCap, int32_t keyHi, int32_t dMax) {
+void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, void *arena, int64_t arenaCap) {
 	if (v.cnt <= 0) return;
 	blocks = (int)std::min<int64_t>(blocks, nblk(v.cnt, TPB)); // (a thread per record at most)
 	IvEntry *a = (IvEntry *)arena;
-	const char *eRes = getenv("BVGPU_LW_RES"); // (read per launch) 0: the loop that makes a trip per successor (parse_node_lw)
-	const bool res = !eRes || atoi(eRes) != 0;
-	if (def == 1 && a && res) hipLaunchKernelGGL((k_parse_list<1, true, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, keyHi, a, arenaCap, err, dMax);
-	else if (def == 2 && a && res) hipLaunchKernelGGL((k_parse_list<2, true, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, keyHi, a, arenaCap, err, dMax);
-	else if (def == 1 && a) hipLaunchKernelGGL((k_parse_list<1, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, keyHi, a, arenaCap, err, dMax);
-	else if (def == 2 && a) hipLaunchKernelGGL((k_parse_list<2, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, keyHi, a, arenaCap, err, dMax);
-	else if (def == 1) hipLaunchKernelGGL((k_parse_list<1, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, keyHi, a, arenaCap, err, dMax);
-	else if (def == 2) hipLaunchKernelGGL((k_parse_list<2, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, keyHi, a, arenaCap, err, dMax);
-	else hipLaunchKernelGGL((k_parse_list<0, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, keyHi, a, arenaCap, err, dMax);
+	if (def == 1) hipLaunchKernelGGL(k_parse_list<1>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
+	else if (def == 2) hipLaunchKernelGGL(k_parse_list<2>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
+	else hipLaunchKernelGGL(k_parse_list<0>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
 }
 
 } // namespace bv

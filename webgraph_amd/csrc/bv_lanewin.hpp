@@ -108,143 +108,23 @@ template <int NWORDS> struct LaneWin {
 };
 
 // Same contract as parse_node<true>: the extras (intervals merged with residuals) of node x go to row[copied..d).
-// !ARENA: the interval section is read twice, once to find the residual section and the number of residuals, once more, lazily, by a
-// second cursor (with a window of its own) during the merge.  ARENA (iv = the record's slice of the interval arena, >= d / minInt + 1
-// entries of 8 bytes): the first reading keeps what it decodes -- (left, length) per interval -- in a ring of LW_RING entries in the
-// lane's LDS column (where the second window would be) and, when there are more, in the arena; the merge takes an interval from the
-// ring with two LDS reads instead of two gamma decodes -- which SOME lane of the wave needed in almost every iteration -- and the
-// rings are topped up from the arena by all lanes together, like the stream windows.  (Loading the intervals back from the arena
-// one ahead, without a ring, was 30 % slower: a load in the merge loop waits for the loop's stores.)
+// iv = the record's slice of the interval arena (>= d / minInt + 1 entries of 8 bytes): the reading of the interval section keeps what it
+// decodes -- (left, length) per interval -- in a ring of LW_RING entries in the lane's LDS column and, when there are more, in the arena;
+// the merge takes an interval from the ring with two LDS reads instead of two gamma decodes, and the rings are topped up from the arena
+// by all lanes together, like the stream windows.  (Loading the intervals back from the arena one ahead, without a ring, was 30 % slower:
+// a load in the merge loop waits for the loop's stores.  Round 3's loop -- a trip per successor with a branch per case, ~250
+// wave-instructions per trip -- and the variant that read the interval section twice are tag r4-experiments.)
 #ifndef LW_RING_
 #define LW_RING_ 8
 #endif
 constexpr int LW_RING = LW_RING_; // (a power of two; 2 * LW_RING <= LW_SIDE words of the lane's column)
-template <int ZK, bool ARENA>
-__device__ __forceinline__ void parse_node_lw(const GraphDev &g, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row, uint32_t *lds, int2 *__restrict__ iv, int *__restrict__ err) {
-	LaneWin<LW_MAIN> br;
-	LaneWin<ARENA ? 4 : LW_SIDE> bi; // second cursor, re-reads the interval section lazily during the merge (!ARENA)
-	br.col = lds + threadIdx.x;
-	bi.col = lds + LW_MAIN * LW_STRIDE + threadIdx.x;
-	uint32_t *const ring = lds + LW_MAIN * LW_STRIDE + threadIdx.x; // (ARENA) entry j of the ring: ring[2 j * LW_STRIDE], ring[(2 j + 1) * LW_STRIDE]
-	br.vlast = bi.vlast = min((((uint64_t)g.offsets[x + 1] >> 5) + 2) & ~(uint64_t)3, (g.nwords + 4) & ~(uint64_t)3);
-	br.seek(g, (uint64_t)g.offsets[x]);
-	int e = 0;
-	(void)br.code<1>(g, e);              // outdegree (known from k_headers)
-	if (g.W > 0) (void)br.code<2>(g, e); // reference
-	int64_t copied = 0;
-	if (hasRef) { // BVG:1058-1071
-		const uint64_t bc = br.code<1>(g, e);
-		int64_t total = 0;
-		if (bc > (uint64_t)dref + 1) e |= E_FORMAT;
-		else {
-			for (uint64_t b = 0; b < bc; b++) {
-				int64_t len;
-				if (!block_len_ok(br.code<1>(g, e), b == 0, total, dref, len)) { e |= E_FORMAT; break; }
-				total += len;
-				if (!(b & 1)) copied += len;
-			}
-			if (!(bc & 1)) copied += dref - total;
-		}
-	}
-	const int64_t extra = (int64_t)d - copied;
-	if (extra < 0 || copied < 0) e |= E_FORMAT;
-	if (e) { atomicOr(err, e); return; }
-	if (extra == 0) return;
-
-	int64_t nIntervals = 0, intervalArcs = 0;
-	if (g.minInt != 0) { // BVG:1073-1096: skip-parse to find the residual section and the number of residuals
-		nIntervals = (int64_t)br.code<1>(g, e);
-		if (nIntervals > extra) { atomicOr(err, E_FORMAT); return; }
-		if (nIntervals) {
-			if (!ARENA) bi.seek(g, br.pos());
-			int32_t prevEnd = 0;
-			for (int64_t i = 0; i < nIntervals; i++) {
-				const uint64_t a = br.code<1>(g, e);
-				const uint64_t len = br.code<1>(g, e);
-				if (len > (uint64_t)extra) { e |= E_FORMAT; break; } // (any 64-bit value in a malformed stream: kept out of the sum)
-				intervalArcs += (int64_t)len + g.minInt;
-				if (ARENA) { // BVG:1084-1093, in Java ints
-					const int32_t left = i == 0 ? (int32_t)((int64_t)x + nat2int(a)) : prevEnd + (int32_t)a + 1, n = (int32_t)len + g.minInt;
-					prevEnd = left + n;
-					if (i < LW_RING) { ring[(2 * i) * LW_STRIDE] = (uint32_t)left; ring[(2 * i + 1) * LW_STRIDE] = (uint32_t)n; }
-					if (nIntervals > LW_RING) iv[i] = int2{ left, n };
-				}
-			}
-		}
-	}
-	const int64_t nRes = extra - intervalArcs;
-	if (nRes < 0 || e) { atomicOr(err, E_FORMAT | e); return; }
-
-	// merge(intervals, residuals) -> row[copied ..), in 16-byte stores where the row allows it.  Ids are Java ints:
-	// 32-bit wrapping arithmetic throughout (BVG:954, :966, :1084-1093 compute in int).
-	int32_t *out = row + copied;
-	const int32_t nExtra = (int32_t)extra;
-	int32_t k = 0;
-	const int32_t head = min(nExtra, (int32_t)(((16u - ((uint32_t)(uintptr_t)out & 15u)) & 15u) >> 2));
-	int32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0, on = 0;
-	int32_t ivLeft = 0, ivRem = 0, ivPrev = 0; // current interval: next value, values left; end of the previous interval
-	int32_t ivTodo = (int32_t)nIntervals;
-	bool firstIv = true;
-	int32_t ivIdx = 0, ivBase = 0, ivLoaded = min(ivTodo, LW_RING); // (ARENA) next interval; oldest one in the ring; intervals [ivBase, ivLoaded) are in the ring
-	int32_t resTodo = (int32_t)nRes;
-	int32_t resVal = 0;
-	if (resTodo) resVal = (int32_t)((int64_t)x + nat2int(br.template code<0, ZK>(g, e))); // BVG:954
-	while (k < nExtra) {
-		br.wave_refill<3>(g);
-		if (ARENA) {
-			if (__any(ivLoaded < (int32_t)nIntervals && ivIdx - ivBase >= LW_RING - 2)) { // some lane's ring runs low: every lane tops its own up (rare: the wave waits once)
-				const int32_t cnt = min((ivIdx - ivBase) & ~1, (int32_t)nIntervals - ivLoaded); // (ivLoaded stays even until the last top-up)
-#pragma unroll
-				for (int p = 0; p < LW_RING / 2; p++) {
-					if (2 * p < cnt) {
-						const int4 t = *(const int4 *)(iv + ivLoaded + 2 * p); // (the slice has room for twice the entries: reading one past the last is harmless)
-						const int j0 = (ivLoaded + 2 * p) & (LW_RING - 1);
-						ring[(2 * j0) * LW_STRIDE] = (uint32_t)t.x; ring[(2 * j0 + 1) * LW_STRIDE] = (uint32_t)t.y;
-						ring[(2 * j0 + 2) * LW_STRIDE] = (uint32_t)t.z; ring[(2 * j0 + 3) * LW_STRIDE] = (uint32_t)t.w;
-					}
-				}
-				if (cnt > 0) { ivBase += cnt; ivLoaded += cnt; }
-			}
-			if (ivRem == 0 && ivTodo) {
-				const int j = ivIdx & (LW_RING - 1);
-				ivLeft = (int32_t)ring[(2 * j) * LW_STRIDE]; ivRem = (int32_t)ring[(2 * j + 1) * LW_STRIDE];
-				ivIdx++;
-				ivTodo--;
-			}
-		} else {
-			if (ivTodo) bi.template wave_refill<6>(g); // an interval is two gamma codes
-			if (ivRem == 0 && ivTodo) { // BVG:1084-1093
-				if (firstIv) { ivLeft = (int32_t)((int64_t)x + nat2int(bi.template code<1>(g, e))); firstIv = false; }
-				else ivLeft = ivPrev + (int32_t)bi.template code<1>(g, e) + 1;
-				ivRem = (int32_t)bi.template code<1>(g, e) + g.minInt;
-				ivPrev = ivLeft + ivRem;
-				ivTodo--;
-			}
-		}
-		int32_t val;
-		if (ivRem && (!resTodo || ivLeft < resVal)) { val = ivLeft; ivLeft++; ivRem--; }
-		else if (resTodo) {
-			val = resVal;
-			if (ivRem && ivLeft == resVal) { ivLeft++; ivRem--; } // equal heads are emitted once (MergedIntIterator.java:69-72)
-			if (--resTodo) resVal += (int32_t)br.template code<0, ZK>(g, e) + 1; // BVG:966
-		} else val = -1; // malformed: fewer values than the outdegree promises (BVG:1210 would store -1)
-		if (k < head) { out[k++] = val; continue; }
-		o0 = o1; o1 = o2; o2 = o3; o3 = val; k++;
-		if (++on == 4) { *(int4 *)(out + k - 4) = int4{ o0, o1, o2, o3 }; on = 0; }
-	}
-	if (on == 3) { out[k - 3] = o1; out[k - 2] = o2; out[k - 1] = o3; }
-	else if (on == 2) { out[k - 2] = o2; out[k - 1] = o3; }
-	else if (on == 1) out[k - 1] = o3;
-	if (e) atomicOr(err, e);
-}
-
-// The same record by a loop that the 64 lanes of a wave walk in step (round 4; default codings -- zeta_3, or ZK = 0: the graph's zeta_k --, interval arena).  parse_node_lw's
-// merge loop executes ~250 wave-instructions per trip, a third of them scalar: every `if` of a lane is an exec-mask region
+// The record by a loop that the 64 lanes of a wave walk in step (round 4; default codings -- zeta_3, or ZK = 0: the graph's zeta_k --, interval arena).  A merge loop with a
+// branch per case executes ~250 wave-instructions per trip, a third of them scalar: every `if` of a lane is an exec-mask region
 // (s_and_saveexec / s_cbranch / s_or) that the wave runs through as soon as ONE lane takes it, and every code() carries a refill
 // check and three fallbacks of its own.  Here a trip is straight-line: the next gap and the next ring entry are decoded speculatively
 // by every lane and kept or dropped by selects; what is rare (window refill, ring top-up, a codeword of more than 28 bits, the
 // unaligned head of the row) sits behind ONE wave-uniform vote each.  The sections in front of the residuals are read by loops the
-// wave walks together too (code_w).  Semantics as parse_node_lw (BVG:1040-1126; equal heads once, MergedIntIterator.java:69-72).
+// wave walks together too (code_w).  Semantics: BVG:1040-1126 (equal heads once, MergedIntIterator.java:69-72).
 __device__ __forceinline__ bool wave_any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0; } // (one s_cmp on the mask; __any goes through a 0 / 1 value per lane)
 template <int KIND, int ZK = 3> __device__ __forceinline__ bool lane_fast_code(uint32_t W, uint32_t &v, uint32_t &len, uint32_t zk = 3u) { // branch-free; v / len are junk when the result is false
 	if (KIND == 2) { const uint32_t z = (uint32_t)__clz((int)(W | 1u)); v = z; len = z + 1; return W != 0; }
@@ -320,7 +200,7 @@ __device__ __forceinline__ void parse_node_lwb(const GraphDev &g, int32_t x, int
 	int64_t intervalArcs = 0;
 	if (g.minInt != 0) { // BVG:1073-1096: the interval section, kept as (left, length) in the ring / the arena
 		const uint64_t ni = code_w<1>(br, g, true, e);
-		if (ni > (uint64_t)extra) { atomicOr(err, E_FORMAT); return; }
+		if (ni > (uint64_t)extra / (uint64_t)g.minInt) { atomicOr(err, E_FORMAT); return; } // (an interval holds >= minInt ids; the arena slice has d / minInt + 1 entries -- ADVICE r4)
 		nIntervals = (int32_t)ni;
 		int32_t prevEnd = 0;
 		for (int32_t i = 0; wave_any(i < nIntervals && !e); i++) {

@@ -66,7 +66,7 @@ void launch_bparse(const GraphDev &g, int def, const BatchView &v, int *err, hip
 void launch_bcopy(const GraphDev &g, int def, const BatchView &v, int32_t level, int *err, hipStream_t st);
 void launch_pick_coop(const int32_t *part, int32_t nblocks, int32_t budget, int32_t *ctl, hipStream_t st, int32_t *counts = nullptr);
 constexpr int PICK_LEVELS = 7; // outdegree classes counted by k_headers / k_pick_coop: >= 128, 256, ..., 8192 successors
-constexpr int CTL_INTS = 32, CTL_COOP = 22, CTL_SEG = 24, CTL_FLAT = 28, CTL_GIANT_STARTED = 31, CTL_TOTAL_INTS = CTL_INTS; // control block (bv_kernels.hip); ctl[CTL_SEG], ctl[CTL_SEG + 2]: records the segment pipeline hands to the cooperative kernel, head of that queue
+constexpr int CTL_INTS = 32, CTL_COOP = 22, CTL_SEG = 24, CTL_GIANT_STARTED = 31, CTL_TOTAL_INTS = CTL_INTS; // control block (bv_kernels.hip); ctl[CTL_SEG], ctl[CTL_SEG + 2]: records the segment pipeline hands to the cooperative kernel, head of that queue
 void launch_classify(int32_t cnt, const int32_t *outd, const int32_t *coopPtr, int32_t coopMin, int32_t giantMin, int32_t *biglist, int32_t *giantlist, int32_t giantCap, int32_t *ctl, hipStream_t st);
 void launch_parse_big(const GraphDev &g, int def, const RangeView &v, const int32_t *biglist, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap,
                       int waves, int giantGroups, int *err, hipStream_t stGiant, hipStream_t stBig);
@@ -77,28 +77,18 @@ void launch_build_lists(const GraphDev &g, const RangeView &v, uint64_t giantBit
 void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int32_t *depth, const int32_t *list, const int32_t *keyBase, int32_t level, int blocks,
                        int32_t midMinKnob, bool bigGroups, const int32_t *bigQ, int32_t bigCap, const int32_t *midQ, int32_t midCap, int32_t *ctl, int32_t *tmp, uint32_t tmpCap, int *err,
                        hipStream_t st, hipStream_t stMid, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evMid, hipEvent_t evBig, const void *preDesc = nullptr, bool preMid = false, bool vecList = false); // vecList: the lane class merges with 16-byte loads and stores (copy_node_v) // preDesc: launch_copy_prewalk's descriptors
-int32_t copy_tile_count(int64_t arcsBound, int32_t nodes);
-void launch_copy_tile_bounds(const RangeView &v, int32_t ntiles, int32_t *tb, hipStream_t st);
-void launch_copy_tile(const GraphDev &g, int def, const RangeView &v, const int32_t *depth, const int32_t *tb, int32_t ntiles, int32_t midMinKnob, bool bigGroups, int *err, hipStream_t st);
 void launch_copy_prewalk(const GraphDev &g, int def, const RangeView &v, const int32_t *bigQ, int32_t bigCap, const int32_t *ctl, void *desc, int blocks, hipStream_t st, int32_t midCap, hipStream_t stLong, bool longKernel, hipStream_t stWalk); // stWalk: the stream of k_copy_prewalk (as stLong) // stLong: the stream of the long lists' kernel (ordered behind the queues by the caller; may be st); // midCap > 0: also the wave class's rows (queue at bigQ + bigCap, descriptors at desc + bigCap)
-void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, void *arena = nullptr, int64_t arenaCap = 0, int32_t keyHi = NKEYS, int32_t dMax = 0x7fffffff); // records with >= dMax successors are somebody else's
+void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, void *arena, int64_t arenaCap);
 // one wave per record of `list` (ctl[which] entries, queue head ctl[which + 2]): k_parse_big<1>
 void launch_wait_giants(const int32_t *ctl, int giantGroups, hipStream_t st); // holds st until the giants' groups are on their CUs (or 30 us have passed)
 void launch_parse_listed(const GraphDev &g, int def, const RangeView &v, const int32_t *list, int32_t *ctl, int which, void *arena, int64_t arenaCap, int waves, int *err, hipStream_t st);
-// bv_seg.hip: the segment pipeline for the records of the parse list's keys [kLo, kHi) that have fewer than coop_min successors
-constexpr int PARSE_LONG_BIN = 14; // work bins from here up (>= 2048 bits of work) are not windowed (k_depth_keys) -- and are the segment pipeline's
-// the records of the parse list's keys [0, keyHi), one lane each, by the bodies of the segment pipeline (k_parse_flat); fblist: room for every record of the view
-void launch_parse_flat(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int32_t keyHi, int blocks, void *arena, int64_t arenaCap,
-                       int32_t *fblist, int32_t *ctl, int *err, hipStream_t st);
+constexpr int PARSE_LONG_BIN = 14; // work bins from here up (>= 2048 bits of work) are not windowed (k_depth_keys)
+// bv_seg.hip: the segment pipeline -- the residual sections of the hubs (giant records with >= minD successors), handed over by k_parse_big
 size_t seg_scratch_bytes(int32_t Rtot, int32_t Scap, int zetaK);
-void launch_seg_sizing(const int64_t *offsets, int32_t lo, int32_t n, const int32_t *outd, const uint16_t *ref, unsigned long long *out5, hipStream_t st); // out5 (zeroed by the caller): records and bits of the long bins, longest record, rows and ids of the copy pass's lane class // load time: records of the long work bins, their bits, the largest outdegree
+void launch_seg_sizing(const int64_t *offsets, int32_t lo, int32_t n, const int32_t *outd, const uint16_t *ref, unsigned long long *out5, hipStream_t st); // out5 (zeroed by the caller): records and bits of the long bins, longest record, rows and ids of the copy pass's lane class
 int32_t seg_bits_log2();
-// records of the pipeline: [0, RcapM) the parse list's long bins, then capBig / capGiant hand-over slots of the cooperative kernels' queues (Rtot = the sum)
-void seg_handover(GraphDev &g, void *scratch, int32_t RcapM, int32_t capBig, int32_t capGiant, int32_t Scap, int32_t minD, hipStream_t st); // minD: records with fewer successors are not handed over
-void launch_seg_struct(const GraphDev &g, int def, const RangeView &v, const int32_t *plist, const int32_t *keyBase, int32_t kLo, int32_t kHi, int32_t RcapM, int32_t Rtot, int32_t Scap,
-                       void *scratch, void *arena, int64_t arenaCap, int32_t *ctl, int blocks, int *err, hipStream_t st, int32_t dMin = 0); // dMin: the class's own records have at least that many successors
-void launch_seg_chain(const GraphDev &g, int def, const RangeView &v, const int32_t *plist, const int32_t *keyBase, int32_t kLo, int32_t kHi, int32_t RcapM, int32_t Rtot, int32_t Scap,
-                      void *scratch, void *arena, int64_t arenaCap, int32_t *R, int64_t Rcap, int32_t *ctl, int blocks, int *err, hipStream_t st); // R: Rcap ints of scratch, >= the arcs of the view
+void seg_handover(GraphDev &g, void *scratch, int32_t capGiant, int32_t Scap, int32_t minD, hipStream_t st); // capGiant hand-over slots, one per entry of the giants' queue; minD: records with fewer successors are not handed over
+void launch_seg_chain(const GraphDev &g, int def, const RangeView &v, int32_t Rtot, int32_t Scap, void *scratch, void *arena, int64_t arenaCap, int32_t *ctl, int blocks, int *err, hipStream_t st);
 void launch_parse_waves(const GraphDev &g, int def, const RangeView &v, const int32_t *biglist, int32_t *ctl, void *arena, int64_t arenaCap, int waves, int *err, hipStream_t st);
 void launch_parse_giants(const GraphDev &g, int def, const RangeView &v, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap, int giantGroups, int *err, hipStream_t st);
 // bv_tile.hpp: short records decoded tile by tile from one LDS image of a contiguous slice of the stream

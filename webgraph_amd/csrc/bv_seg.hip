@@ -19,55 +19,6 @@ constexpr int STPB = 256;
 
 __device__ __forceinline__ SegGraph seg_graph(const GraphDev &g) { return SegGraph{ g.bits, g.nwords, g.offsets, g.W, g.minInt, g.zetaK }; }
 
-// record r of the class <-> entry keyBase[kHi] - 1 - r of the parse list (sorted by work bin, ascending: r = 0 is the longest)
-struct SegRecs {
-	const int32_t *plist, *keyBase;
-	int32_t kLo, kHi;
-	__device__ __forceinline__ int32_t count() const { return keyBase[kHi] - keyBase[kLo]; }
-	__device__ __forceinline__ int32_t slot(int32_t r) const { return plist[keyBase[kHi] - 1 - r]; }
-};
-
-// ------------------------------------------------------------------------------------------------ struct
-__global__ void __launch_bounds__(STPB) k_seg_struct(GraphDev g, RangeView v, SegRecs recs, int32_t Rcap, RecDesc *__restrict__ desc, int32_t *__restrict__ nseg,
-                                                     int32_t *__restrict__ flag, IvEntry *__restrict__ arena, int64_t arenaCap, int32_t *__restrict__ ctl, int *__restrict__ err, int32_t dMin) {
-	__shared__ uint32_t lds[WIN_WORDS * STPB];
-	if (blockIdx.x == 0 && threadIdx.x < 4) ctl[CTL_SEG + threadIdx.x] = 0; // count and queue head of the flagged records (k_seg_collect, k_parse_big)
-	const SegGraph sg = seg_graph(g);
-	const int32_t nrec = min(recs.count(), Rcap), coopMin = v.coopmin();
-		for (int32_t r = blockIdx.x * STPB + threadIdx.x; r < Rcap; r += gridDim.x * STPB) {
-		int32_t ns = 0, fl = 0;
-		if (r < nrec) {
-			const int32_t s = recs.slot(r), d = v.outd[s];
-			RecDesc o{};
-			o.slot = s;
-			o.flags = RF_SKIP;
-			if (d > 0 && d < coopMin && d >= dMin) { // (longer records: the cooperative kernels; shorter ones: k_parse_list)
-				const int32_t rf = v.ref[s];
-				const int64_t abase = g.minInt > 0 ? v.rowstart[s] / g.minInt : 0;
-				if (!v.fits(s)) atomicOr(err, s >= v.nh ? E_CAP : E_HALO);
-				else if (g.minInt > 0 && (abase < 0 || abase + d / g.minInt + 1 > arenaCap)) atomicOr(err, E_FORMAT);
-				else {
-					SegIv *iv = (SegIv *)(arena + abase);
-					struct_lane<STPB>(sg, lds + threadIdx.x, v.lo + s, d, rf > 0, rf > 0 ? (int64_t)v.outd[s - rf] : 0, iv, o);
-					o.slot = s;
-					if (o.flags & RF_FALLBACK) fl = 1;
-					else {
-						ns = seg_count(o, (uint64_t)g.offsets[v.lo + s + 1]);
-						if (o.nres > 0 && ns == 0) { fl = 1; o.flags |= RF_FALLBACK; }
-						if (o.nres == 0 && o.nIv > 0) { // no residuals, no segments: the intervals are final where they are
-							int32_t *out = v.row(s) + o.copied;
-							for (int32_t i = 0; i < o.nIv; i++) expand_interval(iv[i], 0, out, d - o.copied);
-						}
-					}
-				}
-			}
-			desc[r] = o;
-			flag[r] = fl;
-		}
-		nseg[r] = ns;
-	}
-}
-
 // ------------------------------------------------------------------------------------------------ scans
 // exclusive scans in three phases (tile sums, scan of the sums by one block, tile scan + carry); out[n] = total
 struct U2 { uint32_t x, y; };
@@ -395,48 +346,6 @@ __global__ void __launch_bounds__(STPB) k_seg_b(GraphDev g, RangeView v, const R
 	}
 }
 
-// ------------------------------------------------------------------------------------------------ short records
-// The records of the parse list's short bins, one lane per record: the structure (struct_lane), then the merged stream of the whole
-// record as ONE piece (seg_flat).  Same list, same sweep order as k_parse_list (bv_kernels.hip), which it replaces for the default
-// codings.  What the bodies do not take goes to a list for the cooperative kernel (ctl[CTL_FLAT]).
-template <int ZK>
-__global__ void __launch_bounds__(STPB) k_parse_flat(GraphDev g, RangeView v, const int32_t *__restrict__ list, const int32_t *__restrict__ keyBase, int32_t keyLo, int32_t keyHi,
-                                                     IvEntry *__restrict__ arena, int64_t arenaCap, int32_t *__restrict__ fblist, int32_t *__restrict__ ctl, int *__restrict__ err) {
-	__shared__ uint32_t lds[(WIN_WORDS + 2 * FRING + STAGE) * STPB];
-	const SegGraph sg = seg_graph(g);
-	const int32_t lo = keyBase[keyLo], hi = keyBase[keyHi], coopMin = v.coopmin();
-	const int64_t G = (int64_t)gridDim.x * STPB, T = (int64_t)blockIdx.x * STPB + threadIdx.x;
-	for (int64_t sweep = 0; sweep * G < (int64_t)hi - lo; sweep++) { // (a snake: the threads that got the longest records of one sweep get the shortest of the next)
-		const int64_t off = sweep * G + ((sweep & 1) ? G - 1 - T : T);
-		if (off >= (int64_t)hi - lo) continue;
-		const int32_t s = list[hi - 1 - off], d = v.outd[s];
-		if (d >= coopMin || d == 0) continue; // decoded by whole waves (k_parse_big) / nothing to decode
-		if (!v.fits(s)) { atomicOr(err, s >= v.nh ? E_CAP : E_HALO); continue; }
-		const int64_t abase = g.minInt > 0 ? v.rowstart[s] / g.minInt : 0;
-		if (g.minInt > 0 && (abase < 0 || abase + d / g.minInt + 1 > arenaCap)) { atomicOr(err, E_FORMAT); continue; }
-		const int32_t rf = v.ref[s], x = v.lo + s;
-		SegIv *iv = (SegIv *)(arena + abase);
-		RecDesc o{};
-		struct_lane<STPB>(sg, lds + threadIdx.x, x, d, rf > 0, rf > 0 ? (int64_t)v.outd[s - rf] : 0, iv, o);
-		bool ok = !(o.flags & RF_FALLBACK);
-		if (ok && d - o.copied > 0) {
-			uint64_t endBit;
-			ok = seg_flat<ZK, STPB>(sg, lds + threadIdx.x, lds + WIN_WORDS * STPB + threadIdx.x, lds + (WIN_WORDS + 2 * FRING) * STPB + threadIdx.x, x, (uint64_t)o.rpos, (uint64_t)g.offsets[x + 1],
-			                        (uint32_t)o.nres, 0, 0, true, true, v.row(s) + o.copied, d - o.copied, iv, o.nIv, endBit);
-		}
-		if (!ok) fblist[atomicAdd(&ctl[CTL_FLAT], 1)] = s;
-	}
-}
-void launch_parse_flat(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int32_t keyHi, int blocks, void *arena, int64_t arenaCap,
-                       int32_t *fblist, int32_t *ctl, int *err, hipStream_t st) {
-	if (v.cnt <= 0 || def == 0) return;
-	(void)hipMemsetAsync(ctl + CTL_FLAT, 0, 4 * sizeof(int32_t), st);
-	if (def == 1) hipLaunchKernelGGL(k_parse_flat<3>, dim3(blocks), dim3(STPB), 0, st, g, v, list, keyBase, 0, keyHi, (IvEntry *)arena, arenaCap, fblist, ctl, err);
-	else hipLaunchKernelGGL(k_parse_flat<0>, dim3(blocks), dim3(STPB), 0, st, g, v, list, keyBase, 0, keyHi, (IvEntry *)arena, arenaCap, fblist, ctl, err);
-	GraphDev g0 = g; g0.segDesc = nullptr;
-	launch_parse_listed(g0, def, v, fblist, ctl, CTL_FLAT, arena, arenaCap, 256, err, st);
-}
-
 // ------------------------------------------------------------------------------------------------ expand
 // The intervals of a record are shared out evenly among the lanes of its segments.  Every lane of a wave takes its k-th interval in
 // the same iteration: short ones it writes itself, long ones are written by the whole wave, one after the other.
@@ -484,21 +393,18 @@ __global__ void __launch_bounds__(STPB) k_seg_expand(RangeView v, int32_t minInt
 // ------------------------------------------------------------------------------------------------ flagged records
 // -> the list of the cooperative one-wave kernel (k_parse_big<1> with which = CTL_SEG): it decodes them from scratch, whatever the
 // pipeline left in their rows and arena slices
-__global__ void __launch_bounds__(STPB) k_seg_collect(SegRecs recs, int32_t RcapM, int32_t Rtot, int32_t Scap, const RecDesc *__restrict__ desc, const int32_t *__restrict__ nseg, const int32_t *__restrict__ segbase,
+__global__ void __launch_bounds__(STPB) k_seg_collect(int32_t Rtot, int32_t Scap, const RecDesc *__restrict__ desc, const int32_t *__restrict__ nseg, const int32_t *__restrict__ segbase,
                                                       const int32_t *__restrict__ flag, int32_t *__restrict__ fblist, int32_t *__restrict__ ctl) {
-	const int32_t nrec = min(recs.count(), RcapM);
 	for (int32_t r = blockIdx.x * STPB + threadIdx.x; r < Rtot; r += gridDim.x * STPB) {
-		// the class's own records: every one the struct kernel looked at has a flag; the long records: those whose residuals were handed over
-		const bool mine = r < RcapM ? (r < nrec && !(desc[r].flags & RF_SKIP)) : nseg[r] > 0;
-		if (mine && (flag[r] || segbase[r + 1] > Scap)) fblist[atomicAdd(&ctl[CTL_SEG], 1)] = desc[r].slot; // (pieces beyond the scratch: cannot happen while the sizing holds)
+		// the records whose residuals were handed over
+		if (nseg[r] > 0 && (flag[r] || segbase[r + 1] > Scap)) fblist[atomicAdd(&ctl[CTL_SEG], 1)] = desc[r].slot; // (pieces beyond the scratch: cannot happen while the sizing holds)
 	}
 }
 
 // ------------------------------------------------------------------------------------------------ launch
 int32_t seg_bits_log2() { return SEG_BITS_LOG2; }
 
-// Records of the pipeline, in this order: [0, RcapM) the parse list's long bins (records below the wave class; the others are skipped),
-// [RcapM, RcapM + capBig) the wave class's queue, then capGiant entries for the giants' queue (their descriptors come from k_parse_big).
+// Records of the pipeline: the entries of the giants' queue that hand their residual sections over (their descriptors come from k_parse_big).
 namespace {
 struct SegPtrs {
 	RecDesc *desc; int32_t *nseg, *segbase, *flag, *sumsR, *fblist, *seg2rec, *fixlist, *pendlist;
@@ -563,38 +469,26 @@ void launch_seg_sizing(const int64_t *offsets, int32_t lo, int32_t n, const int3
 }
 
 // the hand-over slots of the cooperative kernels (GraphDev::segDesc ...); the counts of their parts are zeroed on `st`
-void seg_handover(GraphDev &g, void *scratch, int32_t RcapM, int32_t capBig, int32_t capGiant, int32_t Scap, int32_t minD, hipStream_t st) {
+void seg_handover(GraphDev &g, void *scratch, int32_t capGiant, int32_t Scap, int32_t minD, hipStream_t st) {
 	g.segMinD = minD;
-	const int32_t Rtot = RcapM + capBig + capGiant;
-	const SegPtrs P = seg_ptrs(scratch, Rtot, Scap, seg_cell_cap(g.zetaK));
+	const SegPtrs P = seg_ptrs(scratch, capGiant, Scap, seg_cell_cap(g.zetaK));
 	g.segDesc = P.desc; g.segNseg = P.nseg; g.segFlag = P.flag;
-	g.segOff[0] = RcapM; g.segCap[0] = capBig;
-	g.segOff[1] = RcapM + capBig; g.segCap[1] = capGiant;
-	if (capBig + capGiant > 0) (void)hipMemsetAsync(P.nseg + RcapM, 0, sizeof(int32_t) * ((size_t)capBig + capGiant), st);
+	g.segOff[0] = 0; g.segCap[0] = 0; // (the wave class keeps its residuals)
+	g.segOff[1] = 0; g.segCap[1] = capGiant;
+	if (capGiant > 0) (void)hipMemsetAsync(P.nseg, 0, sizeof(int32_t) * (size_t)capGiant, st);
 }
 
-// the structure of the class's own records (needs the parse list and the row starts)
-void launch_seg_struct(const GraphDev &g, int def, const RangeView &v, const int32_t *plist, const int32_t *keyBase, int32_t kLo, int32_t kHi, int32_t RcapM, int32_t Rtot, int32_t Scap,
-                       void *scratch, void *arena, int64_t arenaCap, int32_t *ctl, int blocks, int *err, hipStream_t st, int32_t dMin) {
+// everything behind the descriptors of the cooperative kernel
+void launch_seg_chain(const GraphDev &g, int def, const RangeView &v, int32_t Rtot, int32_t Scap, void *scratch, void *arena, int64_t arenaCap, int32_t *ctl, int blocks, int *err, hipStream_t st) {
 	if (v.cnt <= 0 || Rtot <= 0 || def == 0) return;
-	const SegPtrs P = seg_ptrs(scratch, Rtot, Scap, seg_cell_cap(g.zetaK));
-	hipLaunchKernelGGL(k_seg_struct, dim3((unsigned)blocks), dim3(STPB), 0, st, g, v, SegRecs{ plist, keyBase, kLo, kHi }, RcapM, P.desc, P.nseg, P.flag, (IvEntry *)arena, arenaCap, ctl, err, dMin);
-}
-
-// everything behind the descriptors (the class's own and the cooperative kernels')
-void launch_seg_chain(const GraphDev &g, int def, const RangeView &v, const int32_t *plist, const int32_t *keyBase, int32_t kLo, int32_t kHi, int32_t RcapM, int32_t Rtot, int32_t Scap,
-                      void *scratch, void *arena, int64_t arenaCap, int32_t *R, int64_t Rcap, int32_t *ctl, int blocks, int *err, hipStream_t st) {
-	if (v.cnt <= 0 || Rtot <= 0 || def == 0) return;
-	if (RcapM == 0) (void)hipMemsetAsync(ctl + CTL_SEG, 0, 4 * sizeof(int32_t), st); // (no k_seg_struct ran: the counters of this job's lists)
+	(void)hipMemsetAsync(ctl + CTL_SEG, 0, 4 * sizeof(int32_t), st); // the counters of this job's list of flagged records
 	const uint32_t cap = seg_cell_cap(g.zetaK);
 	const SegPtrs P = seg_ptrs(scratch, Rtot, Scap, cap);
-	const SegRecs recs{ plist, keyBase, kLo, kHi };
 	const dim3 grid((unsigned)blocks), blk(STPB);
 	IvEntry *a = (IvEntry *)arena;
 	GraphDev g0 = g; g0.segDesc = nullptr; // (the kernel of the flagged records decodes whole records)
 	sg_scan<int32_t>(P.nseg, Rtot, P.segbase, P.sumsR, st);
 	hipLaunchKernelGGL(k_seg_fill, grid, blk, 0, st, Rtot, P.segbase, Scap, P.seg2rec);
-	(void)cap; (void)R; (void)Rcap;
 	if (def == 1) hipLaunchKernelGGL(k_seg_a1<3>, grid, blk, 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.a1, P.flag);
 	else hipLaunchKernelGGL(k_seg_a1<0>, grid, blk, 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.a1, P.flag);
 	if (def == 1) hipLaunchKernelGGL(k_seg_a2<3>, grid, blk, 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.a1, P.fin, P.pair, P.miss, P.pendlist, ctl);
@@ -607,7 +501,7 @@ void launch_seg_chain(const GraphDev &g, int def, const RangeView &v, const int3
 	if (def == 1) hipLaunchKernelGGL(k_seg_b<3>, grid, blk, 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.fin, P.pre, a, P.flag);
 	else hipLaunchKernelGGL(k_seg_b<0>, grid, blk, 0, st, g0, v, P.desc, P.segbase, Rtot, Scap, P.seg2rec, P.fin, P.pre, a, P.flag);
 	hipLaunchKernelGGL(k_seg_expand, grid, blk, 0, st, v, g.minInt, P.desc, P.segbase, Rtot, Scap, P.seg2rec, a, P.flag);
-	hipLaunchKernelGGL(k_seg_collect, grid, blk, 0, st, recs, RcapM, Rtot, Scap, P.desc, P.nseg, P.segbase, P.flag, P.fblist, ctl);
+	hipLaunchKernelGGL(k_seg_collect, grid, blk, 0, st, Rtot, Scap, P.desc, P.nseg, P.segbase, P.flag, P.fblist, ctl);
 	launch_parse_listed(g0, def, v, P.fblist, ctl, CTL_SEG, arena, arenaCap, 256, err, st);
 }
 

@@ -219,69 +219,6 @@ template <int STRIDE> struct Win {
 // (left to themselves the lanes would each stall the whole wave for a memory round trip at a different iteration)
 #define SG_REFILL(w, q) do { if (SG_ANY((q) > Q_OK)) q -= w.slide(q); } while (0)
 
-// ------------------------------------------------------------------------------------------------ struct
-// The gamma-coded front of record x (outdegree d; referent's outdegree dref if it has a reference): BVG:1048-1096.
-template <int STRIDE>
-SG_D void struct_lane(const SegGraph &g, uint32_t *col, int32_t x, int32_t d, bool hasRef, int64_t dref, SegIv *iv, RecDesc &o) {
-	Win<STRIDE> w;
-	const uint64_t recEnd = (uint64_t)g.offsets[x + 1];
-	w.init(g, col, recEnd);
-	uint32_t q = w.seek((uint64_t)g.offsets[x]);
-	bool bad = false;
-	(void)w.gamma(q, bad);               // outdegree (known from k_headers)
-	if (g.W > 0) { SG_REFILL(w, q); (void)w.unary(q, bad); } // reference
-	int64_t copied = 0;
-	if (hasRef) { // BVG:1058-1071
-		SG_REFILL(w, q);
-		const uint32_t bc = w.gamma(q, bad);
-		int64_t total = 0;
-		if ((int64_t)bc > dref + 1) bad = true;
-		for (uint32_t b = 0; b < bc && !bad; b++) {
-			SG_REFILL(w, q);
-			const int64_t code = (int64_t)w.gamma(q, bad);
-			if (code > dref - total) { bad = true; break; } // (a code of a malformed stream is rejected before it reaches a sum)
-			const int64_t len = code + (b ? 1 : 0);
-			if (total + len > dref) { bad = true; break; }
-			total += len;
-			if (!(b & 1)) copied += len;
-		}
-		if (!(bc & 1)) copied += dref - total;
-	}
-	const int64_t extra = (int64_t)d - copied;
-	if (extra < 0 || copied < 0) bad = true;
-	int32_t nIv = 0, ivArcs = 0;
-	if (!bad && extra > 0 && g.minInt != 0) { // BVG:1073-1096
-		SG_REFILL(w, q);
-		const uint32_t ic = w.gamma(q, bad);
-		const int32_t xtr = (int32_t)extra, minInt = g.minInt;
-		if ((int64_t)ic > extra / minInt) bad = true; else nIv = (int32_t)ic;
-		int32_t prevEnd = 0;
-		for (int32_t i = 0; i < nIv && !bad; i++) {
-			SG_REFILL(w, q);
-			const uint32_t a = w.gamma(q, bad);
-			SG_REFILL(w, q);
-			const uint32_t l = w.gamma(q, bad);
-			if (l > (uint32_t)xtr) { bad = true; break; }
-			const int32_t left = i == 0 ? (int32_t)((uint32_t)x + (uint32_t)zigzag32(a)) : (int32_t)((uint32_t)prevEnd + a + 1u), n = (int32_t)l + minInt; // in Java ints (BVG:1084-1093)
-			if (i > 0 && left < prevEnd) { bad = true; break; } // intervals that wrap around: not here
-			prevEnd = (int32_t)((uint32_t)left + (uint32_t)n);
-			iv[i] = SegIv{ left, ivArcs, -1, n }; // rank -1: behind every residual, unless B says otherwise
-			ivArcs += n;                          // (<= extra + minInt: no overflow)
-			if (ivArcs > xtr) { bad = true; break; }
-		}
-	}
-	// (the zig-zag value of the first interval is a long in the file: one that does not fit 33 bits made gamma() say bad)
-	const int64_t nres = extra - ivArcs;
-	if (nres < 0) bad = true;
-	o.rpos = (int64_t)w.pos(q);
-	o.nres = bad ? 0 : (int32_t)nres;
-	o.copied = bad ? 0 : (int32_t)copied;
-	o.nIv = bad ? 0 : nIv;
-	o.ivArcs = bad ? 0 : ivArcs;
-	o.flags = bad ? RF_FALLBACK : 0;
-	if (!bad && nres > 0 && (uint64_t)o.rpos >= recEnd) o.flags = RF_FALLBACK; // residuals past the record's end (offsets that disagree with the stream)
-}
-
 // segments of a record: the cells of the grid that its residual section [rpos, recEnd) touches
 SG_D int32_t seg_count(const RecDesc &r, uint64_t recEnd) {
 	if ((r.flags & (RF_FALLBACK | RF_SKIP)) || r.nres <= 0) return 0;
@@ -485,109 +422,6 @@ SG_D bool seg_b(const SegGraph &g, uint32_t *col, uint32_t *ring, int32_t x, uin
 		j++;
 	}
 	endRel = (uint32_t)(w.pos(q) - cell);
-	return !bad;
-}
-
-// ------------------------------------------------------------------------------------------------ flat
-// The merged stream of a piece -- or of a whole record, which is one piece that starts and ends it --, one id per iteration
-// whichever lane and whichever kind: the residuals decoded from `in` (cnt of them, BVG:954, :966) and, expanded where they fall, the
-// intervals that precede each of them (IntIntervalSequenceIterator.java:64-78, MergedIntIterator.java:50-74); a record's last piece
-// also emits the intervals behind its last residual.  The ids are consecutive in the row -- out[p0 ..), p0 = j0 + the ids of the
-// intervals below v0 --, so a lane parks them in 16 words of LDS and writes 64 bytes at a time: a lane's ids leave in whole half
-// lines (4-byte stores from 64 lanes to 64 places made the memory side write six times the bytes, PMC WRITE_SIZE).  Every active
-// lane emits exactly one id per iteration, so all lanes flush in the same iteration.  No ranks, no second kernel for the intervals.
-constexpr int FRING = 4;   // intervals a lane keeps at hand: (left, length) each
-constexpr int STAGE = 16;  // ids parked before they are written
-template <int STRIDE> struct IvRing2 {
-	uint32_t *ring; const SegIv *iv; int32_t nIv, idx, loaded; // intervals [idx, loaded) are in the ring, entry k at slot k & (FRING - 1)
-	SG_D void top_up() { // two more, if this lane has the room and the record has them
-		if (FRING - (loaded - idx) >= 2 && loaded < nIv) {
-			const int32_t last = nIv - 1;
-#if defined(__HIP_DEVICE_COMPILE__)
-			int4 e[2];
-#pragma unroll
-			for (int k = 0; k < 2; k++) e[k] = *(const int4 *)(iv + (loaded + k < last ? loaded + k : last)); // (past the record's last interval: read again, never used)
-#pragma unroll
-			for (int k = 0; k < 2; k++) { const uint32_t s = (uint32_t)(loaded + k) & (FRING - 1); ring[(2 * s) * STRIDE] = (uint32_t)e[k].x; ring[(2 * s + 1) * STRIDE] = (uint32_t)e[k].w; }
-#else
-			for (int k = 0; k < 2; k++) { const SegIv e = iv[loaded + k < last ? loaded + k : last]; const uint32_t s = (uint32_t)(loaded + k) & (FRING - 1); ring[(2 * s) * STRIDE] = (uint32_t)e.left; ring[(2 * s + 1) * STRIDE] = (uint32_t)e.len; }
-#endif
-			loaded = loaded + 2 < nIv ? loaded + 2 : nIv;
-		}
-	}
-	SG_D void get(int32_t &left, int32_t &len) { // interval idx (idx < nIv)
-		if (idx < loaded) { const uint32_t s = (uint32_t)idx & (FRING - 1); left = (int32_t)ring[(2 * s) * STRIDE]; len = (int32_t)ring[(2 * s + 1) * STRIDE]; }
-		else { const SegIv e = iv[idx]; left = e.left; len = e.len; loaded = idx; } // (the ring is empty: straight from the arena)
-	}
-};
-template <int ZK, int STRIDE>
-SG_D bool seg_flat(const SegGraph &g, uint32_t *col, uint32_t *ring, uint32_t *stage, int32_t x, uint64_t inBit, uint64_t lastBit, uint32_t cnt, uint32_t j0, int32_t v0,
-                   bool firstOfRecord, bool lastOfRecord, int32_t *out, int32_t extra, const SegIv *iv, int32_t nIv, uint64_t &endBit) {
-	Win<STRIDE> w;
-	w.init(g, col, lastBit);
-	uint32_t q = w.seek(inBit);
-	bool bad = false;
-	IvRing2<STRIDE> R{ ring, iv, nIv, 0, 0 };
-	uint32_t p0 = j0; // where the piece's stream starts among the record's extras
-	int32_t prevEnd = (int32_t)0x80000000;
-	if (!firstOfRecord && nIv > 0) { // intervals [0, idx) lie below v0 (emitted by the pieces before): a binary search in the record's arena slice
-		int32_t lo = 0, hi = nIv;
-		while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (iv[mid].left <= v0) lo = mid + 1; else hi = mid; }
-		R.idx = lo;
-		if (lo > 0) { const SegIv e = iv[lo - 1]; p0 += (uint32_t)(e.pstart + e.len); prevEnd = (int32_t)((uint32_t)e.left + (uint32_t)e.len); }
-	}
-	R.loaded = R.idx;
-	R.top_up(); R.top_up();
-	uint32_t resTodo = cnt, resVal = (uint32_t)v0;
-	if (resTodo) { // the first residual of the piece
-		const uint32_t v = w.template zeta<ZK>(q, (uint32_t)g.zetaK, bad);
-		resVal = firstOfRecord ? (uint32_t)x + (uint32_t)zigzag32(v) : resVal + v + 1u;
-		if ((int32_t)resVal < prevEnd) bad = true; // inside the interval before it
-	}
-	int32_t ivLeft = 0, ivRem = 0;
-	int32_t nl = 0x7fffffff, nlen = 0; // the record's next interval (idx), if any
-	if (R.idx < nIv) R.get(nl, nlen);
-	uint32_t n = 0; // ids emitted
-	const uint32_t room = p0 <= (uint32_t)extra ? (uint32_t)extra - p0 : 0u;
-	int32_t *dst = out + p0;
-	for (;;) {
-		if (ivRem == 0) { // between intervals: does the next one come before the next residual?  (Behind a record's last residual: all that are left)
-			if (R.idx < nIv && (resTodo ? nl <= (int32_t)resVal : lastOfRecord)) {
-				if (nl < prevEnd || nlen <= 0 || (resTodo && nl == (int32_t)resVal)) bad = true; // (a residual on an interval's first id: equal heads are emitted once, MergedIntIterator.java:69-72 -- not here)
-				ivLeft = nl; ivRem = nlen > 0 ? nlen : 0; R.idx++;
-				prevEnd = (int32_t)((uint32_t)nl + (uint32_t)nlen);
-				if (resTodo && (int32_t)resVal < prevEnd) bad = true; // the next residual lies inside this interval
-				if (R.idx < nIv) R.get(nl, nlen); else nl = 0x7fffffff;
-			}
-			if (ivRem == 0 && !resTodo) break;
-		}
-		if (SG_ANY(q > Q_OK)) { q -= w.slide(q); R.top_up(); }
-		uint32_t val;
-		if (ivRem) { val = (uint32_t)ivLeft; ivLeft++; ivRem--; }
-		else {
-			val = resVal;
-			if (--resTodo) resVal += w.template zeta<ZK>(q, (uint32_t)g.zetaK, bad) + 1u;
-		}
-		stage[(n & (STAGE - 1)) * STRIDE] = val;
-		n++;
-		if ((n & (STAGE - 1)) == 0) { // (every active lane of the wave at once)
-			if (n <= room) {
-#if defined(SG_DBG_NOSTORE)
-#elif defined(__HIP_DEVICE_COMPILE__) && !defined(SG_DBG_SCALAR)
-#pragma unroll
-				for (int k = 0; k < STAGE; k += 4) *(int4 *)(dst + n - STAGE + k) = int4{ (int32_t)stage[(k + 0) * STRIDE], (int32_t)stage[(k + 1) * STRIDE], (int32_t)stage[(k + 2) * STRIDE], (int32_t)stage[(k + 3) * STRIDE] };
-#else
-				for (int k = 0; k < STAGE; k++) dst[n - STAGE + k] = (int32_t)stage[k * STRIDE];
-#endif
-			} else bad = true;
-		}
-	}
-	{ // what is left in the stage
-		const uint32_t m = n & (STAGE - 1), base = n - m;
-		if (n <= room) { for (uint32_t k = 0; k < m; k++) dst[base + k] = (int32_t)stage[k * STRIDE]; }
-		else bad = true;
-	}
-	endBit = w.pos(q);
 	return !bad;
 }
 

@@ -37,6 +37,10 @@ struct DevBuf {
 	}
 	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 	template <class T> T *as() const { return (T *)p; }
+	DevBuf() = default;
+	DevBuf(const DevBuf &) = delete;
+	DevBuf &operator=(const DevBuf &) = delete;
+	~DevBuf() { release(); } // (a buffer that bvg_close's list forgets is still freed with the handle -- ADVICE r4)
 };
 
 struct PinBuf { // pinned host memory (grows, never shrinks; contents are NOT preserved)
@@ -120,7 +124,6 @@ struct bvg_graph {
 	DevBuf outd, ref, rowstart, depth, sums, need, halo, hashA, hashB, hashBounds, stage_rowptr, stage_succ, stage_nodes, small;
 	DevBuf b_chainlen, b_slotbase, b_node, b_qidx, b_aoutd, b_qoutd; // random-access batches
 	DevBuf walktab;                                                   // block tables of the giant records (GraphDev::walktab)
-	int iv_arena = 1;                                                 // BVGPU_IV_ARENA=0: the one-lane decoder reads every interval section twice instead of keeping it in the arena
 	int walk_tables = 1;                                              // BVGPU_WALK_TABLES=0: the copy pass walks every block list itself
 	DevBuf pickpart;                                                  // per-block outdegree class counts of k_headers
 	DevBuf biglist, giantlist, arena, coopctl;                        // work lists; cooperative decode of giant records
@@ -128,17 +131,12 @@ struct bvg_graph {
 	int level_blocks = 16384; // blocks of the list kernels (k_parse_list, k_copy_list), at most one thread per node of the range: 8192 .. 32768 are within 1 % on C2, 2 % faster than 4096 on the C5 shard and cnr-2000 x 30 (profiles/r4_experiments.txt section 9)
 	DevBuf lvlist;
 	DevBuf plist, pkeys, pkey16;
-	DevBuf segbuf, segR; // scratch of the segment pipeline (bv_seg.hip); the residuals of its records, contiguous per record, before they are merged with the intervals
+	DevBuf segbuf;       // scratch of the segment pipeline (bv_seg.hip)
 	int seg = 1;         // BVGPU_SEG: the segment pipeline (bv_seg.hip).  0: never; 1 (default): for the hubs of a job -- the giant records with >= seg_hub_min successors hand their
-	                     // residual sections over, everything else as before; 3: that, whatever the graph holds; 2: everything it can take (the records of the long work bins and every cooperative
-	                     // record: bit-exact, slower than the kernels it replaces on C2 -- DESIGN section 6)
-	int seg_hub_min = 1000000; // BVGPU_SEG_HUB_MIN -- records of the long work bins below the wave class go through the segment pipeline instead of k_parse_list
+	                     // residual sections over, everything else as before; 3: that, whatever the graph holds.  (Mode 2 of round 4 -- everything it can take -- is tag r4-experiments.)
+	int seg_hub_min = 1000000; // BVGPU_SEG_HUB_MIN
 	int seg_blocks = 2048;
 	int lists_on_b = 0;  // BVGPU_LISTS_ON_B=1: the chain depths / level lists behind the giants (side B) instead of behind the wave class (side A)
-	int seg_min_d = 0;   // BVGPU_SEG_MIN_D: the pipeline's own records have at least that many successors (the others of the long bins stay with k_parse_list)
-	int flat = 0;        // BVGPU_FLAT=1: the short records by k_parse_flat (the segment pipeline's bodies: structure, then the record's merged stream with 64-byte stores) instead of k_parse_list
-	DevBuf flatfb;       // records k_parse_flat leaves to the cooperative kernel
-	int seg_handover = 1; // BVGPU_SEG_HANDOVER=0: the cooperative kernels decode the residuals of their records themselves
 	int tile = -1;       // -1: automatic (see enqueue_decode); BVGPU_TILE=0: never; BVGPU_TILE=1: short records decoded from contiguous tiles of the stream (k_parse_tile) instead of the bin-sorted parse list (k_parse_list)
 	DevBuf tilebounds;
 	int copy_big = 1;    // BVGPU_COPY_BIG=0: every row is copied by one lane
@@ -148,8 +146,6 @@ struct bvg_graph {
 	bool adaptive = true;                                               // smaller jobs lower them (pick_thresholds) unless a knob pins them
 	int coop_waves = 4096, giant_groups = 256;
 	DevBuf copyq; // rows the copy pass merges with a group / a wave each (all levels), filled while the level lists are built
-	DevBuf ctilebounds; // k_copy_tile: first node of every tile
-	int copy_tile = 0; // BVGPU_COPY_TILE=1: tiles of neighbouring short rows merged in LDS before the level kernels (k_copy_tile: bit-exact, slower -- 4.4 ms of its own on the C5 shard)
 	DevBuf walkdesc; // k_copy_prewalk: 16 bytes per entry of the group class's queue
 	int copy_vec = -1; // BVGPU_COPY_VEC=1|0: the lane class of the copy pass merges with 16-byte loads and stores (copy_node_v) or id by id; -1: by the mean length of its rows (counted at load time)
 	int prewalk_long = 1; // BVGPU_PREWALK_LONG=0: no kernel of their own for the lists of >= 2048 codes; 2: on the lists' stream instead of side B
@@ -158,11 +154,11 @@ struct bvg_graph {
 	DevBuf bigtmp; // global scratch tables for rows that copy more ids than the LDS tables of k_copy_big hold
 	DevBuf stats; // BVGPU_STATS=1: tuning counters
 	// the three parse kernels (giant / big / short records) are independent: they run on forked streams
-	hipStream_t sideC = nullptr; // the segment pipeline's own stream when the cooperative kernels keep their residuals (BVGPU_SEG_HANDOVER=0): a fourth chain of kernels
+	hipStream_t sideC = nullptr; // BVGPU_LISTS_ON_B=2: the level lists on a stream of their own
 	hipStream_t sideA = nullptr, sideB = nullptr; // (more streams than this share hardware queues with each other: they would serialise)
 	bool ctl_clean = false;                       // ctl[4..16) were zeroed by this job's k_pick_coop
 	bool host_mode = false;                       // host_scan: sideB carries the PCIe copies, its kernels go to sideA
-	hipEvent_t evFork = nullptr, evA = nullptr, evB = nullptr, evC = nullptr, evHdr = nullptr, evP = nullptr, evW = nullptr, evM = nullptr, evL = nullptr;
+	hipEvent_t evFork = nullptr, evA = nullptr, evB = nullptr, evC = nullptr, evHdr = nullptr, evP = nullptr, evM = nullptr, evL = nullptr;
 	bool overlap = true;
 	size_t halo_min = (size_t)16 << 20; // bytes of halo scratch an optimistic sub-range decode starts with (BVGPU_HALO_MIN)
 	bool force_halo_sync = false;   // (retry of an optimistic sub-range decode: size the halo with a host round trip)
@@ -245,17 +241,12 @@ int init_handle(bvg_graph *g) {
 	if (const char *e = getenv("BVGPU_SEG")) g->seg = atoi(e);
 	if (const char *e = getenv("BVGPU_SEG_HUB_MIN")) g->seg_hub_min = std::max(1, atoi(e));
 	if (const char *e = getenv("BVGPU_SEG_BLOCKS")) g->seg_blocks = std::max(1, atoi(e));
-	if (const char *e = getenv("BVGPU_FLAT")) g->flat = atoi(e);
-	if (const char *e = getenv("BVGPU_SEG_MIN_D")) g->seg_min_d = std::max(0, atoi(e));
 	if (const char *e = getenv("BVGPU_LISTS_ON_B")) g->lists_on_b = atoi(e);
-	if (const char *e = getenv("BVGPU_SEG_HANDOVER")) g->seg_handover = atoi(e);
 	if (const char *e = getenv("BVGPU_WALK_TABLES")) g->walk_tables = atoi(e);
 	if (const char *e = getenv("BVGPU_COPY_VEC")) g->copy_vec = atoi(e);
 	if (const char *e = getenv("BVGPU_PREWALK")) g->prewalk = atoi(e);
 	if (const char *e = getenv("BVGPU_PREWALK_LONG")) g->prewalk_long = atoi(e);
-	if (const char *e = getenv("BVGPU_COPY_TILE")) g->copy_tile = atoi(e);
 	if (const char *e = getenv("BVGPU_PREWALK_BLOCKS")) g->prewalk_blocks = std::max(1, atoi(e));
-	if (const char *e = getenv("BVGPU_IV_ARENA")) g->iv_arena = atoi(e);
 	if (const char *e = getenv("BVGPU_COPY_MID_MIN")) g->copy_mid_min = std::min(std::max(0, atoi(e)), 1024); // 0: no wave-per-row copy
 	if (const char *e = getenv("BVGPU_OVERLAP")) g->overlap = atoi(e) != 0;
 	if (const char *e = getenv("BVGPU_HALO_MIN")) g->halo_min = (size_t)std::max(4, atoi(e));
@@ -274,7 +265,6 @@ int init_handle(bvg_graph *g) {
 	HIPCHK(g, hipEventCreateWithFlags(&g->evC, hipEventDisableTiming));
 	HIPCHK(g, hipEventCreateWithFlags(&g->evHdr, hipEventDisableTiming));
 	HIPCHK(g, hipEventCreateWithFlags(&g->evP, hipEventDisableTiming));
-	HIPCHK(g, hipEventCreateWithFlags(&g->evW, hipEventDisableTiming));
 	HIPCHK(g, hipEventCreateWithFlags(&g->evM, hipEventDisableTiming));
 	HIPCHK(g, hipEventCreateWithFlags(&g->evL, hipEventDisableTiming));
 	if (const char *e = getenv("BVGPU_STATS")) if (atoi(e)) { if (!g->stats.need(64 * sizeof(unsigned long long))) return fail(g, BVG_ENOMEM, "device allocation failed"); HIPCHK(g, hipMemset(g->stats.p, 0, 512)); }
@@ -509,31 +499,23 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			if (ovl && hdrEvent) HIPCHK(g, hipEventRecord(g->evP, g->sideA));
 		}
 		const bool earlyList = !tiles && ovl && hdrEvent;
-		// The segment pipeline (bv_seg.hip): the residual sections of the records of the long work bins (>= 2 048 bits of work), cut into pieces of stream, one lane
-		// per piece.  The class's own records (below the wave class) have their structure parsed by one lane each (k_seg_struct); the cooperative kernels parse the
-		// structure of theirs and hand the residuals over (GraphDev::segDesc); k_parse_list keeps the short bins.
-		const bool segAble = g->seg && !tiles && s.def != 0 && g->iv_arena && coop && s.seg_long_records >= 0;
-		const bool segFull = segAble && g->seg == 2;
-		const bool segHubs = segAble && !segFull && (g->seg == 3 || (s.max_outdegree >= g->seg_hub_min && estArcs >= 4000000)) && g->seg_handover;
-		const bool segOn = segFull || segHubs;
-		const int32_t segKLo = g->parse_windows ? (bv::MAXLVL - 1) * bv::NBIN + bv::PARSE_LONG_BIN : bv::PARSE_LONG_BIN, segKHi = g->parse_windows ? bv::NKEYS : bv::NBIN;
-		int32_t segRcapM = 0, segRtot = 0, segScap = 0;
-		bool segReady = false, segJoin = false, segWaves = false;
+		// The segment pipeline (bv_seg.hip): the residual sections of the hubs -- giant records with >= seg_hub_min successors --, cut into pieces of stream, one lane
+		// per piece.  The giants' kernel parses the structure of such a record and hands the residuals over (GraphDev::segDesc).
+		const bool segAble = g->seg && g->seg != 2 && !tiles && s.def != 0 && coop && s.seg_long_records >= 0;
+		const bool segOn = segAble && (g->seg == 3 || (s.max_outdegree >= g->seg_hub_min && estArcs >= 4000000));
+		int32_t segScap = 0;
+		bool segReady = false;
 		if (segOn) {
 			const int64_t bits = s.h_offsets[(size_t)v.lo + v.cnt] - s.h_offsets[(size_t)v.lo];
-			segRcapM = segFull ? (int32_t)std::min<int64_t>(v.cnt, (bits + 8 * arcsBound) / 2048 + 16) : 0; // records with >= 2 048 bits of work (max(bits, 8 successors)): every record with pieces is one
-			segWaves = segFull && g->seg_handover;
-			const int32_t capBig = segWaves ? (int32_t)std::min<int64_t>(v.cnt, arcsBound / 128 + 2) : 0, capGiant = g->seg_handover ? giantCap : 0;
-			segRtot = segRcapM + capBig + capGiant;
 			// every record with pieces is one of the staged records of the long bins, and has at most bits / piece + 2 of them
-			const int64_t recsBound = std::min<int64_t>(segFull ? (int64_t)v.cnt : (int64_t)giantCap, s.seg_long_records);
+			const int64_t recsBound = std::min<int64_t>((int64_t)giantCap, s.seg_long_records);
 			segScap = (int32_t)std::min<int64_t>(std::min<int64_t>(bits, s.seg_long_bits) / ((int64_t)1 << bv::seg_bits_log2()) + 2 * recsBound + 2, 0x7ffffff0);
-			if (segRtot > 0 && g->segbuf.need(bv::seg_scratch_bytes(segRtot, segScap, s.info.zeta_k)) && g->segR.need(sizeof(int32_t) * (size_t)std::max<int64_t>(arcsBound, 1 << 22))) {
+			if (giantCap > 0 && g->segbuf.need(bv::seg_scratch_bytes(giantCap, segScap, s.info.zeta_k))) {
 				segReady = true;
-				if (g->seg_handover) bv::seg_handover(gd, g->segbuf.p, segRcapM, capBig, capGiant, segScap, segHubs ? g->seg_hub_min : 0, g->stream); // (before the fork: the cooperative kernels start behind it)
+				bv::seg_handover(gd, g->segbuf.p, giantCap, segScap, g->seg_hub_min, g->stream); // (before the fork: the cooperative kernels start behind it)
 			}
 		}
-		const bool listsOnB = g->lists_on_b == 1 && !(segReady && g->seg_handover); // (with the hand-over side B carries the segment pipeline's chain)
+		const bool listsOnB = g->lists_on_b == 1 && !segReady; // (with the hand-over side B carries the segment pipeline's chain)
 		const bool listsOnC = g->lists_on_b == 2 && ovl;
 		if (!tiles) {
 			if (!g->plist.need(sizeof(int32_t) * (size_t)v.cnt) || !g->pkeys.need(3 * (bv::NKEYS + 1) * sizeof(int32_t)) || !g->pkey16.need(sizeof(uint16_t) * (size_t)v.cnt)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
@@ -570,8 +552,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		if (ovl && coop) {
 			HIPCHK(g, hipStreamWaitEvent(g->sideA, g->evC, 0));
 			bv::launch_parse_big(gd, s.def, v, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, g->giant_groups, derr, side_b(g), g->sideA); // (giants, big)
-			if (segReady && segWaves) HIPCHK(g, hipEventRecord(g->evW, g->sideA)); // (the wave class has handed its residual sections over)
-			if (!(segReady && g->seg_handover)) HIPCHK(g, hipEventRecord(g->evB, side_b(g))); // (else: behind the segment pipeline's chain, below)
+			if (!segReady) HIPCHK(g, hipEventRecord(g->evB, side_b(g))); // (else: behind the segment pipeline's chain, below)
 		}
 		// ... then, behind the wave class, the chain depth of every record + per-level lists (node order inside a level) +
 		// copy queues: only the copy pass needs them, and launched first they would sit in front of the wave class while
@@ -585,7 +566,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			// (the long lists' kernel on side B, which has been idle since the giants -- unless it carries the lists themselves, or the segment pipeline's chain)
 			hipStream_t stLong = stLists, stWalk = stLists;
 			const bool longKernel = g->prewalk_long != 0;
-			const bool cross = g->prewalk_long != 2 && ovl && coop && !(segReady && g->seg_handover);
+			const bool cross = g->prewalk_long != 2 && ovl && coop && !segReady;
 			const bool longOnB = cross && longKernel && stLists == g->sideA;   // lists behind the wave class: the long lists on side B
 			const bool walkOnA = cross && stLists == side_b(g);                // lists behind the giants: the waves' kernel behind the wave class
 			if (longOnB || walkOnA) {
@@ -596,12 +577,6 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			bv::launch_copy_prewalk(gd, s.def, v, g->copyq.as<int32_t>(), bigCap, ctl, g->walkdesc.p, g->prewalk_blocks, stLists, g->prewalk >= 2 ? 0 : midCap, stLong, longKernel, stWalk); // (BVGPU_PREWALK=2: the group class only)
 			if (longOnB) HIPCHK(g, hipEventRecord(g->evB, stLong)); // (side B is done when this kernel is)
 			g->pend.preDesc = g->walkdesc.p;
-		}
-		int32_t ctiles = 0;
-		if (W > 0 && g->copy_tile && v.cnt > v.nh) {
-			ctiles = bv::copy_tile_count(arcsBound, v.cnt - v.nh);
-			if (g->ctilebounds.need(sizeof(int32_t) * ((size_t)ctiles + 2))) bv::launch_copy_tile_bounds(v, ctiles, g->ctilebounds.as<int32_t>(), stLists);
-			else ctiles = 0;
 		}
 		if (listsOnC) HIPCHK(g, hipEventRecord(g->evL, g->sideC));
 		if (ovl) HIPCHK(g, hipEventRecord(g->evA, g->sideA));
@@ -618,43 +593,25 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		mark(g, 5);
 		if (tiles) bv::launch_parse_tile(gd, s.def, v, g->tilebounds.as<int32_t>(), ntiles, tileVariant, derr, g->stream);
 		else {
-			int32_t keyHi = bv::NKEYS, dMaxList = 0x7fffffff;
-			if (segReady) {
-				// with the hand-over: the structure of the class's own records here; on side B, behind the giants and once the wave class has handed its residual
-				// sections over, everything else.  Without it: the whole pipeline on a stream of its own, beside the three other chains of kernels.
-				hipStream_t stStruct = g->stream, stChain = g->stream;
-				if (ovl && !g->seg_handover) {
-					stStruct = stChain = g->sideC;
-					HIPCHK(g, hipEventRecord(g->evM, g->stream)); // (the parse list and the row starts are ready)
-					HIPCHK(g, hipStreamWaitEvent(stChain, g->evM, 0));
-				}
-				if (segRcapM > 0) bv::launch_seg_struct(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, segKLo, segKHi, segRcapM, segRtot, segScap, g->segbuf.p, g->arena.p, arenaCap, ctl, g->seg_blocks, derr, stStruct, g->seg_min_d); // (hubs only: the pipeline has no records of its own -- an empty kernel here waited 0.8 ms for CUs in front of k_parse_list)
-				if (ovl && g->seg_handover) {
+			if (segReady) { // on side B, behind the giants: the pieces of the records that handed their residual sections over
+				hipStream_t stChain = g->stream;
+				if (ovl) {
 					stChain = side_b(g);
-					HIPCHK(g, hipEventRecord(g->evM, g->stream));
+					HIPCHK(g, hipEventRecord(g->evM, g->stream)); // (the row starts are ready)
 					HIPCHK(g, hipStreamWaitEvent(stChain, g->evM, 0));
-					if (segWaves) HIPCHK(g, hipStreamWaitEvent(stChain, g->evW, 0));
 				}
-				bv::launch_seg_chain(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, segKLo, segKHi, segRcapM, segRtot, segScap, g->segbuf.p, g->arena.p, arenaCap, g->segR.as<int32_t>(), std::max<int64_t>(arcsBound, 1 << 22), ctl, g->seg_blocks, derr, stChain);
-				if (ovl && g->seg_handover) HIPCHK(g, hipEventRecord(g->evB, stChain));
-				if (ovl && !g->seg_handover) { HIPCHK(g, hipEventRecord(g->evW, stChain)); segJoin = true; }
-				if (!segFull) {} else if (g->seg_min_d > 0) dMaxList = g->seg_min_d; else keyHi = segKLo; // (with a lower bound on the pipeline's records k_parse_list keeps the long bins, minus those)
+				bv::launch_seg_chain(gd, s.def, v, giantCap, segScap, g->segbuf.p, g->arena.p, arenaCap, ctl, g->seg_blocks, derr, stChain);
+				if (ovl) HIPCHK(g, hipEventRecord(g->evB, stChain));
 			}
-			if (g->flat && s.def != 0 && g->iv_arena && g->flatfb.need(sizeof(int32_t) * (size_t)v.cnt))
-				bv::launch_parse_flat(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, keyHi, g->level_blocks, g->arena.p, arenaCap, g->flatfb.as<int32_t>(), ctl, derr, g->stream);
-			else {
-				if (ovl && coop) { HIPCHK(g, hipStreamWaitEvent(g->stream, g->evC, 0)); bv::launch_wait_giants(ctl, g->giant_groups, g->stream); } // (the giants first: k_wait_giants)
-				bv::launch_parse_list(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, g->level_blocks, derr, g->stream, g->iv_arena ? g->arena.p : nullptr, arenaCap, keyHi, dMaxList);
-			}
+			if (ovl && coop) { HIPCHK(g, hipStreamWaitEvent(g->stream, g->evC, 0)); bv::launch_wait_giants(ctl, g->giant_groups, g->stream); } // (the giants first: k_wait_giants)
+			bv::launch_parse_list(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, g->level_blocks, derr, g->stream, g->arena.p, arenaCap);
 		}
 		if (ovl) {
 			HIPCHK(g, hipStreamWaitEvent(g->stream, g->evA, 0));
 			if (coop) HIPCHK(g, hipStreamWaitEvent(g->stream, g->evB, 0));
-			if (segJoin) HIPCHK(g, hipStreamWaitEvent(g->stream, g->evW, 0));
 			if (listsOnC) HIPCHK(g, hipStreamWaitEvent(g->stream, g->evL, 0));
 		}
 		mark(g, 6);
-		if (ctiles > 0) bv::launch_copy_tile(gd, s.def, v, g->depth.as<int32_t>(), g->ctilebounds.as<int32_t>(), ctiles, g->copy_mid_min, g->copy_big != 0, derr, g->stream);
 		if (W > 0) {
 			levels = g->levels_hint;
 			for (int32_t l = 1; l <= levels; l++) {
@@ -1124,13 +1081,13 @@ extern "C" int bvg_close(bvg_t *g) {
 	if (g->st && g->st->device >= 0) {
 		(void)hipSetDevice(g->st->device);
 		if (g->own) { (void)hipStreamSynchronize(g->own); (void)hipStreamDestroy(g->own); }
-		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->hashBounds, &g->pickpart, &g->walktab, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist, &g->plist, &g->pkeys, &g->pkey16, &g->copyq, &g->walkdesc, &g->ctilebounds, &g->bigtmp, &g->tilebounds }) b->release();
+		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->hashBounds, &g->pickpart, &g->walktab, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist, &g->plist, &g->pkeys, &g->pkey16, &g->copyq, &g->walkdesc, &g->bigtmp, &g->tilebounds, &g->segbuf }) b->release();
 		for (DevBuf *b : { &g->hchunk[0], &g->hchunk[1], &g->statsbuf, &g->bfs_rowptr, &g->bfs_succ, &g->bfs_ctr }) b->release();
 		for (PinBuf *b : { &g->hring[0], &g->hring[1], &g->view_rowptr, &g->view_succ }) b->release();
 		for (hipEvent_t e : { g->evChunk[0], g->evChunk[1], g->evCopied[0], g->evCopied[1] }) if (e) (void)hipEventDestroy(e);
 		if (g->h_small) (void)hipHostFree(g->h_small);
 		for (auto &e : g->ev) if (e) (void)hipEventDestroy(e);
-		for (hipEvent_t e : { g->evFork, g->evA, g->evB, g->evC, g->evHdr, g->evP, g->evW, g->evM, g->evL, g->evIn, g->evOut }) if (e) (void)hipEventDestroy(e);
+		for (hipEvent_t e : { g->evFork, g->evA, g->evB, g->evC, g->evHdr, g->evP, g->evM, g->evL, g->evIn, g->evOut }) if (e) (void)hipEventDestroy(e);
 		for (hipStream_t st : { g->sideA, g->sideB, g->sideC }) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
 	}
 	delete g;
