@@ -36,11 +36,8 @@ namespace bv {
 constexpr int TPB = 256;
 constexpr int GIANT_NW = COOP_GIANT_NW; // waves per giant record
 
-template <int DEF, int AG = 0>
-__device__ __forceinline__ void copy_node(const GraphDev &g, int32_t x, int32_t d, int64_t dref, int32_t *__restrict__ row, const int32_t *__restrict__ src, int *__restrict__ err);
-// agent-scope (write-through / L1-bypassing) accesses: what a row needs when another workgroup of the SAME launch reads it (MI355X_MICROARCH.md, inter-workgroup visibility)
-__device__ __forceinline__ void st_agent(int32_t *p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ int32_t ld_agent(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <int DEF, bool HASH = false>
+__device__ __forceinline__ void copy_node(const GraphDev &g, int32_t x, int32_t d, int64_t dref, int32_t *__restrict__ row, const int32_t *__restrict__ src, int *__restrict__ err, uint32_t *hacc = nullptr, uint32_t hw = 0);
 template <int DEF>
 __device__ __forceinline__ void parse_node(const GraphDev &g, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row, int *__restrict__ err);
 template <int DEF>
@@ -49,7 +46,7 @@ __device__ __forceinline__ void copy_node_v(const GraphDev &g, int32_t x, int32_
 // ------------------------------------------------------------------------------------------------ headers
 template <int DEF>
 __global__ void __launch_bounds__(TPB) k_headers(GraphDev g, int32_t lo, int32_t cnt, int32_t *__restrict__ outd,
-                                                 uint16_t *__restrict__ ref, int *__restrict__ err, int32_t *__restrict__ part) {
+                                                 uint16_t *__restrict__ ref, int *__restrict__ err, int32_t *__restrict__ part, uint8_t *__restrict__ mark) {
 	const int32_t s = blockIdx.x * TPB + threadIdx.x;
 	uint64_t d = 0;
 	if (s < cnt) {
@@ -69,6 +66,7 @@ __global__ void __launch_bounds__(TPB) k_headers(GraphDev g, int32_t lo, int32_t
 		e |= br.err;
 		outd[s] = (int32_t)d;
 		ref[s] = (uint16_t)r;
+		if (mark && r > 0 && (uint64_t)s >= r) mark[s - (int32_t)r] = 1; // (bvg_scan_checksum: the rows somebody copies from are the ones that must exist in memory)
 		if (e) atomicOr(err, e);
 	}
 	// How many of the block's records have >= 128, 256, ..., 8192 successors: k_pick_coop adds the blocks up and picks the
@@ -275,8 +273,10 @@ __global__ void __launch_bounds__(SCAN_TOP_T) k_scan_top_tiled(int64_t *__restri
 	}
 }
 
-__global__ void __launch_bounds__(TPB) k_scan_apply(const int32_t *__restrict__ in, int64_t n, const int64_t *__restrict__ sums, int64_t *__restrict__ out) {
+template <bool HASH>
+__global__ void __launch_bounds__(TPB) k_scan_apply(const int32_t *__restrict__ in, int64_t n, const int64_t *__restrict__ sums, int64_t *__restrict__ out, const HashCtx *__restrict__ hxp, int32_t lo, int32_t nh) {
 	const int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
+	uint32_t hacc = 0;
 	int64_t vals[SCAN_ITEMS];
 	int64_t v = 0;
 #pragma unroll
@@ -287,10 +287,16 @@ __global__ void __launch_bounds__(TPB) k_scan_apply(const int32_t *__restrict__ 
 	for (int i = 0; i < SCAN_ITEMS; i++) {
 		const int64_t j = base + (int64_t)threadIdx.x * SCAN_ITEMS + i;
 		if (j < n) out[j] = ex;
+		if (HASH && j < n && j >= nh) hacc += (uint32_t)(lo + (int32_t)j) * hash_upow(hxp->ptab, (uint64_t)(1 + ex + j)); // (bvg_scan_checksum: the node's own number, HashCtx)
 		ex += vals[i];
 		if (j == n - 1) out[n] = ex;
 	}
 	if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) out[0] = 0;
+	if (HASH) {
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) hacc += (uint32_t)__shfl_xor((int)hacc, o, 64);
+		if ((threadIdx.x & 63) == 0) hash_add(*hxp, hacc);
+	}
 }
 
 // ------------------------------------------------------------------------------------------------ chain depth
@@ -524,12 +530,15 @@ __device__ __forceinline__ int copy_class(const RangeView &v, const int32_t *__r
 	if (!v.fits(s) || !v.fits(s - v.ref[s])) return 0; // E_CAP / E_HALO already raised by the parse kernel
 	return copy_class_of(v.outd[s], v.outd[s - v.ref[s]], midMin, bigMin);
 }
-template <int DEF, bool VEC, int AG = 0>
+template <int DEF, bool VEC, bool HASH = false>
 __global__ void __launch_bounds__(TPB) k_copy_list(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ list,
                                                    const int32_t *__restrict__ keyBase, int32_t level, int32_t midMin, int32_t bigMin, int *__restrict__ err) {
 	const int32_t bucket = min(level, MAXLVL - 1);
 	const int32_t lo = keyBase[bucket * NBIN], hi = keyBase[(bucket + 1) * NBIN];
 	const int64_t rsNh = v.rowstart[v.nh];
+	// HASH (bvg_scan_checksum): the rows merged here are added to the job's hash as they are written (copy_node<., true>)
+	const HashCtx hx = HASH ? *v.hx : HashCtx{};
+	uint32_t hacc = 0;
 	for (int32_t idx = hi - 1 - (blockIdx.x * TPB + threadIdx.x); idx >= lo; idx -= gridDim.x * TPB) {
 		// (copy_class and RangeView::row / ::fits spelled out: every load of this kernel goes to a line of its own, so each is issued once --
 		// the outdegrees are differences of the row starts, which are needed anyway)
@@ -543,8 +552,14 @@ __global__ void __launch_bounds__(TPB) k_copy_list(GraphDev g, RangeView v, cons
 		if (copy_class_of(d, dref, midMin, bigMin) != 1) continue;
 		int32_t *row = s < v.nh ? v.halo + rs0 : v.succ + (rs0 - rsNh);
 		const int32_t *src = t < v.nh ? v.halo + rt0 : v.succ + (rt0 - rsNh);
-		if (VEC) copy_node_v<DEF>(g, v.lo + s, d, dref, row, src, err);
-		else copy_node<DEF, AG>(g, v.lo + s, d, (int64_t)dref, row, src, err);
+		if (HASH) copy_node<DEF, true>(g, v.lo + s, d, (int64_t)dref, row, src, err, &hacc, s >= v.nh ? hash_upow(hx.ptab, (uint64_t)(1 + rs1 + (int64_t)s)) : 0u);
+		else if (VEC) copy_node_v<DEF>(g, v.lo + s, d, dref, row, src, err);
+		else copy_node<DEF>(g, v.lo + s, d, (int64_t)dref, row, src, err);
+	}
+	if (HASH) {
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) hacc += (uint32_t)__shfl_xor((int)hacc, o, 64);
+		if ((threadIdx.x & 63) == 0) hash_add(hx, hacc);
 	}
 }
 
@@ -1225,11 +1240,15 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 // a sweep of short records is three dependent round trips (list entry -> outdegree / reference / row start / offsets -> the referent's
 // outdegree and the stream words) in front of ~5 us of decoding; the entry is fetched two sweeps ahead and what hangs on it one sweep
 // ahead, so a sweep waits for the last trip only.  Default codings: parse_node_lwb (bv_lanewin.hpp); others: the generic reader.
-template <int DEF>
+template <int DEF, bool HASH = false>
 __global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, const int32_t *__restrict__ list, const int32_t *__restrict__ keyBase, int32_t binLo, int32_t binHi,
                                                     IvEntry *__restrict__ arena, int64_t arenaCap, int *__restrict__ err) {
+	static_assert(!HASH || DEF != 0, "the hash fold rides on the default codings' loop");
 	__shared__ uint32_t lw[DEF ? (LW_MAIN + 2 * LW_RING) * LW_STRIDE : 1]; // per lane: a window of the stream and a ring of intervals (default codings)
 	const int32_t lo = keyBase[binLo], hi = keyBase[binHi], coopMin = v.coopmin();
+	// HASH: the rows without a reference are added to the job's hash as they are decoded and written only where a row of the view copies from them
+	const HashCtx hx = HASH ? *v.hx : HashCtx{};
+	uint32_t hacc = 0;
 	const int64_t G = (int64_t)gridDim.x * TPB, T = (int64_t)blockIdx.x * TPB + threadIdx.x, N = (int64_t)hi - lo;
 	const int64_t rs0 = v.rowstart[v.nh];
 	auto entry = [&](int64_t sweep) -> int32_t {
@@ -1253,10 +1272,110 @@ __global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, con
 			// the record's slice of the interval arena (the same slices as the cooperative kernels': floor(rowstart / minInt), d / minInt + 1 entries)
 			const int64_t abase = g.minInt > 0 ? raC / g.minInt : 0;
 			if (g.minInt > 0 && (abase < 0 || abase + dC / g.minInt + 1 > arenaCap)) { atomicOr(err, E_FORMAT); continue; }
-			parse_node_lwb<DEF == 1 ? 3 : 0>(g, v.lo + s, dC, rC > 0, (int64_t)drefC, row, lw, (int2 *)(arena + abase), err, oaC, obC);
+			if (HASH) {
+				const bool mine = s >= v.nh && rC == 0; // hashed here; the others (rows with a reference, halo rows) are written as ever
+				const uint32_t hw = mine ? hash_upow(hx.ptab, (uint64_t)(1 + rbC + (int64_t)s)) : 0u; // successor j of slot s weighs u^(1 + rowstart[s + 1] + s) * 31^j
+				const bool keep = !mine || hx.mark[s] != 0;
+				parse_node_lwb<DEF == 1 ? 3 : 0, true>(g, v.lo + s, dC, rC > 0, (int64_t)drefC, row, lw, (int2 *)(arena + abase), err, oaC, obC, &hacc, hw, keep);
+			}
+			else parse_node_lwb<DEF == 1 ? 3 : 0>(g, v.lo + s, dC, rC > 0, (int64_t)drefC, row, lw, (int2 *)(arena + abase), err, oaC, obC);
 		}
 		else parse_node<DEF>(g, v.lo + s, dC, rC > 0, (int64_t)drefC, row, err);
 	}
+	if (HASH) {
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) hacc += (uint32_t)__shfl_xor((int)hacc, o, 64);
+		if ((threadIdx.x & 63) == 0) hash_add(hx, hacc);
+	}
+}
+
+// bvg_scan_checksum, what the kernels that decode do not add themselves.  The one-lane parse adds the rows without a reference that it decodes (HASH above), the
+// lane class of the copy pass the rows it merges (copy_node<., true>); here, from memory: the node numbers, the rows without a reference that the wave / group
+// classes decoded (or every such row when the parse did not hash: codings other than the default set) -- `what` bit 0, launched beside the copy pass --, and the rows
+// with a reference that the wave / group classes of the copy pass merged (or all of them when the lane class did not hash) -- bit 1, behind the copy pass.
+// A block takes 256 consecutive nodes: a lane adds its node's number and, if its row is short, the row; longer rows are cut into pieces of 4 096 ids that go to a
+// queue; k_hash_pieces gives every piece to a block: coalesced loads, the weights stepping by 31^256 per lane.
+constexpr int HASH_ROW_LANE = 96, HASH_PIECE = 4096;
+__global__ void __launch_bounds__(TPB) k_hash_rest(RangeView v, int what, bool inParse, bool inCopy, int32_t midMin, int32_t bigMin, int2 *__restrict__ pieceq, int32_t *__restrict__ npieces, int32_t cap) {
+	__shared__ uint32_t s_part[TPB / 64];
+	const HashCtx hx = *v.hx;
+	const int64_t r0 = v.rowstart[v.nh];
+	const int32_t coopMin = v.coopmin();
+	const int32_t s = v.nh + blockIdx.x * TPB + threadIdx.x;
+	uint32_t acc = 0;
+	if (s < v.cnt) {
+		const int64_t a = v.rowstart[s] - r0, b = v.rowstart[s + 1] - r0;
+		const int32_t d = (int32_t)(b - a), r = v.ref[s];
+		const uint64_t ebase = (uint64_t)(1 + v.rowstart[s + 1] + (int64_t)s);
+		if (what & 4) acc = (uint32_t)(v.lo + s) * hash_upow(hx.ptab, ebase - (uint64_t)d); // the node's own number (when k_scan_apply did not add it)
+		bool mine = d > 0 && (uint64_t)b <= v.succ_cap;
+		if (r == 0) mine = mine && (what & 1) && (!inParse || d >= coopMin);
+		else mine = mine && (what & 2) && (!inCopy || copy_class_of(d, v.outd[s - r], midMin, bigMin) != 1);
+		if (mine) {
+			if (d < HASH_ROW_LANE) {
+				const int32_t *row = v.succ + a;
+				uint32_t w = hash_upow(hx.ptab, ebase);
+				for (int32_t j = 0; j < d; j++) { acc += (uint32_t)row[j] * w; w *= 31u; }
+			} else {
+				const int32_t np = (d + HASH_PIECE - 1) / HASH_PIECE, q0 = atomicAdd(npieces, np);
+				for (int32_t q = 0; q < np; q++) if (q0 + q < cap) pieceq[q0 + q] = int2{ s, q };
+			}
+		}
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) acc += (uint32_t)__shfl_xor((int)acc, o, 64);
+	if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+	__syncthreads();
+	if (threadIdx.x == 0) { uint32_t t = 0; for (int k = 0; k < TPB / 64; k++) t += s_part[k]; hash_add(hx, t); }
+}
+// the same for the rows of a work list (the wave / group classes' parse lists: rows without a reference only, wantRef false; the copy pass's queues of the wave and
+// group classes: wantRef true): the lists exist anyway, so nobody has to look at every node to find these rows
+__global__ void __launch_bounds__(TPB) k_hash_queue(RangeView v, const int32_t *__restrict__ queue, const int32_t *__restrict__ count, int32_t qcap, bool wantRef,
+                                                    int2 *__restrict__ pieceq, int32_t *__restrict__ npieces, int32_t cap) {
+	const HashCtx hx = *v.hx;
+	const int64_t r0 = v.rowstart[v.nh];
+	const int32_t n = min(*count, qcap);
+	uint32_t acc = 0;
+	for (int32_t i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) {
+		const int32_t s = queue[i];
+		if (s < v.nh || (v.ref[s] != 0) != wantRef) continue;
+		const int64_t a = v.rowstart[s] - r0, b = v.rowstart[s + 1] - r0;
+		const int32_t d = (int32_t)(b - a);
+		if (d <= 0 || (uint64_t)b > v.succ_cap) continue;
+		if (d < HASH_ROW_LANE) {
+			const int32_t *row = v.succ + a;
+			uint32_t w = hash_upow(hx.ptab, (uint64_t)(1 + v.rowstart[s + 1] + (int64_t)s));
+			for (int32_t j = 0; j < d; j++) { acc += (uint32_t)row[j] * w; w *= 31u; }
+		} else {
+			const int32_t np = (d + HASH_PIECE - 1) / HASH_PIECE, q0 = atomicAdd(npieces, np);
+			for (int32_t q = 0; q < np; q++) if (q0 + q < cap) pieceq[q0 + q] = int2{ s, q };
+		}
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) acc += (uint32_t)__shfl_xor((int)acc, o, 64);
+	if ((threadIdx.x & 63) == 0) hash_add(hx, acc);
+}
+__global__ void __launch_bounds__(TPB) k_hash_pieces(RangeView v, const int2 *__restrict__ pieceq, const int32_t *__restrict__ npieces, int32_t cap) {
+	__shared__ uint32_t s_part[TPB / 64];
+	const HashCtx hx = *v.hx;
+	const int64_t r0 = v.rowstart[v.nh];
+	const int32_t n = min(*npieces, cap);
+	uint32_t step = 1; // 31^256
+	for (int k = 0; k < TPB; k++) step *= 31u;
+	uint32_t acc = 0;
+	for (int32_t k = blockIdx.x; k < n; k += gridDim.x) {
+		const int2 e = pieceq[k];
+		const int64_t a = v.rowstart[e.x] - r0, b = v.rowstart[e.x + 1] - r0;
+		const int32_t d = (int32_t)(b - a), j0 = e.y * HASH_PIECE, j1 = min(d, j0 + HASH_PIECE);
+		const int32_t *row = v.succ + a;
+		uint32_t w = hash_upow(hx.ptab, (uint64_t)(1 + v.rowstart[e.x + 1] + (int64_t)e.x - (int64_t)(j0 + (int32_t)threadIdx.x))); // u^E * 31^j = u^(E - j), E > j
+		for (int32_t j = j0 + threadIdx.x; j < j1; j += TPB) { acc += (uint32_t)row[j] * w; w *= step; }
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) acc += (uint32_t)__shfl_xor((int)acc, o, 64);
+	if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+	__syncthreads();
+	if (threadIdx.x == 0) { uint32_t t = 0; for (int k = 0; k < TPB / 64; k++) t += s_part[k]; hash_add(hx, t); }
 }
 
 // ------------------------------------------------------------------------------------------------ long records
@@ -1393,10 +1512,10 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? COOP1_MINWAVES : COOPG_MINW
 // One lane per node of chain depth `level`: merge the masked copy of the referent's final row with the
 // node's extras (sitting at row[copied..d)), forward and in place.  The write index never overtakes the
 // extras read index: k = (#copied so far) + (j - copied) <= j.
-// AG bit 0: the row leaves in agent-scope (write-through) stores; bit 1: the referent's ids come in by agent-scope loads (it was written by another
-// workgroup of this launch: k_copy_dep)
-template <int DEF, int AG>
-__device__ __forceinline__ void copy_node(const GraphDev &g, int32_t x, int32_t d, int64_t dref, int32_t *__restrict__ row, const int32_t *__restrict__ src, int *__restrict__ err) {
+// HASH (bvg_scan_checksum): every id of the final row is also added to *hacc with weight hw, hw * 31, ... (HashCtx, bv_launch.hpp) -- the merged ones as they are
+// written, the extras that are already in place by one more pass over them; a row that is left alone (malformed: an error is raised elsewhere) adds nothing.
+template <int DEF, bool HASH>
+__device__ __forceinline__ void copy_node(const GraphDev &g, int32_t x, int32_t d, int64_t dref, int32_t *__restrict__ row, const int32_t *__restrict__ src, int *__restrict__ err, uint32_t *hacc, uint32_t hw) {
 	BitReader br;
 	br.init(g.bits, g.nwords);
 	br.seek((uint64_t)g.offsets[x]);
@@ -1426,15 +1545,16 @@ __device__ __forceinline__ void copy_node(const GraphDev &g, int32_t x, int32_t 
 		else len = dref - i; // implicit last block: the rest of the referent
 		if (b & 1) { i += len; continue; } // skip block
 		for (int64_t t = 0; t < len && i < dref && k < d; t++) { // (the bounds hold by the checks above: belt and braces)
-			const int32_t cv = (AG & 2) ? ld_agent(src + i) : src[i]; i++;
-			while (j < d && ev < cv) { if (AG & 1) st_agent(row + k, ev); else row[k] = ev; k++; j++; if (j < d) ev = row[j]; }
+			const int32_t cv = src[i++];
+			while (j < d && ev < cv) { if (HASH) { *hacc += (uint32_t)ev * hw; hw *= 31u; } row[k++] = ev; j++; if (j < d) ev = row[j]; }
 			if (j < d && ev == cv) { j++; if (j < d) ev = row[j]; } // equal heads emitted once (never in a valid file)
-			if (AG & 1) st_agent(row + k, cv); else row[k] = cv;
-			k++;
+			if (HASH) { *hacc += (uint32_t)cv * hw; hw *= 31u; }
+			row[k++] = cv;
 		}
 	}
 	// remaining extras row[j..d) are already in place when k == j; a malformed duplicate leaves a gap: pad with -1
-	if (k != j) { while (j < d) { const int32_t t = row[j++]; if (AG & 1) st_agent(row + k, t); else row[k] = t; k++; } while (k < d) { if (AG & 1) st_agent(row + k, -1); else row[k] = -1; k++; } }
+	if (k != j) { while (j < d) { const int32_t t = row[j++]; if (HASH) { *hacc += (uint32_t)t * hw; hw *= 31u; } row[k++] = t; } while (k < d) { if (HASH) { *hacc -= hw; hw *= 31u; } row[k++] = -1; } }
+	else if (HASH) { if (j < d) { *hacc += (uint32_t)ev * hw; hw *= 31u; j++; } for (; j < d; j++) { *hacc += (uint32_t)row[j] * hw; hw *= 31u; } } // (ev = row[j] is at hand)
 	if (br.err) atomicOr(err, br.err);
 }
 
@@ -1730,11 +1850,34 @@ namespace bv {
 
 static inline unsigned nblk(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
-void launch_headers(const GraphDev &g, int def, int32_t lo, int32_t cnt, int32_t *outd, uint16_t *ref, int *err, hipStream_t st, int32_t *part) {
+void launch_headers(const GraphDev &g, int def, int32_t lo, int32_t cnt, int32_t *outd, uint16_t *ref, int *err, hipStream_t st, int32_t *part, uint8_t *mark) {
 	if (cnt <= 0) return;
-	if (def == 1) hipLaunchKernelGGL(k_headers<1>, dim3(nblk(cnt, TPB)), dim3(TPB), 0, st, g, lo, cnt, outd, ref, err, part);
-	else if (def == 2) hipLaunchKernelGGL(k_headers<2>, dim3(nblk(cnt, TPB)), dim3(TPB), 0, st, g, lo, cnt, outd, ref, err, part);
-	else hipLaunchKernelGGL(k_headers<0>, dim3(nblk(cnt, TPB)), dim3(TPB), 0, st, g, lo, cnt, outd, ref, err, part);
+	if (mark) (void)hipMemsetAsync(mark, 0, (size_t)cnt, st);
+	if (def == 1) hipLaunchKernelGGL(k_headers<1>, dim3(nblk(cnt, TPB)), dim3(TPB), 0, st, g, lo, cnt, outd, ref, err, part, mark);
+	else if (def == 2) hipLaunchKernelGGL(k_headers<2>, dim3(nblk(cnt, TPB)), dim3(TPB), 0, st, g, lo, cnt, outd, ref, err, part, mark);
+	else hipLaunchKernelGGL(k_headers<0>, dim3(nblk(cnt, TPB)), dim3(TPB), 0, st, g, lo, cnt, outd, ref, err, part, mark);
+}
+__global__ void __launch_bounds__(HASH_ACC_SLOTS) k_hash_sum(const HashCtx *__restrict__ hx, int32_t *__restrict__ out) {
+	__shared__ uint32_t s_part[HASH_ACC_SLOTS / 64];
+	uint32_t acc = hx->acc[threadIdx.x];
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) acc += (uint32_t)__shfl_xor((int)acc, o, 64);
+	if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+	__syncthreads();
+	if (threadIdx.x == 0) { uint32_t t = 0; for (int k = 0; k < HASH_ACC_SLOTS / 64; k++) t += s_part[k]; *out = (int32_t)t; }
+}
+void launch_hash_sum(const HashCtx *hx, int32_t *out, hipStream_t st) { hipLaunchKernelGGL(k_hash_sum, dim3(1), dim3(HASH_ACC_SLOTS), 0, st, hx, out); }
+void copy_thresholds(int32_t midMinKnob, bool bigGroups, int32_t &midMin, int32_t &bigMin);
+void launch_hash_rest(const RangeView &v, int what, bool inParse, bool inCopy, int32_t midMinKnob, bool bigGroups, void *pieceq, int32_t *npieces, int32_t cap, hipStream_t st,
+                      const int32_t *qA, const int32_t *nA, int32_t capA, const int32_t *qB, const int32_t *nB, int32_t capB, bool wantRef) {
+	if (v.cnt <= v.nh) return;
+	int32_t midMin, bigMin;
+	copy_thresholds(midMinKnob, bigGroups, midMin, bigMin);
+	(void)hipMemsetAsync(npieces, 0, sizeof(int32_t), st);
+	if (what) hipLaunchKernelGGL(k_hash_rest, dim3(nblk((int64_t)v.cnt - v.nh, TPB)), dim3(TPB), 0, st, v, what, inParse, inCopy, midMin, bigMin, (int2 *)pieceq, npieces, cap);
+	if (qA && capA > 0) hipLaunchKernelGGL(k_hash_queue, dim3(256), dim3(TPB), 0, st, v, qA, nA, capA, wantRef, (int2 *)pieceq, npieces, cap);
+	if (qB && capB > 0) hipLaunchKernelGGL(k_hash_queue, dim3(256), dim3(TPB), 0, st, v, qB, nB, capB, wantRef, (int2 *)pieceq, npieces, cap);
+	hipLaunchKernelGGL(k_hash_pieces, dim3(2048), dim3(TPB), 0, st, v, (const int2 *)pieceq, npieces, cap);
 }
 int64_t headers_blocks(int32_t cnt) { return cnt > 0 ? (int64_t)nblk(cnt, TPB) : 0; }
 
@@ -1745,14 +1888,15 @@ void launch_mark_halo(int32_t nh, int32_t cnt, int32_t W, int32_t *outd, uint16_
 	hipLaunchKernelGGL(k_apply_need, dim3(nblk(nh, TPB)), dim3(TPB), 0, st, nh, need, outd, ref);
 }
 
-void launch_scan(const int32_t *in, int64_t n, int64_t *out, int64_t *sums, hipStream_t st) {
+void launch_scan(const int32_t *in, int64_t n, int64_t *out, int64_t *sums, hipStream_t st, const HashCtx *hx, int32_t lo, int32_t nh) {
 	const int64_t nb = n > 0 ? (n + SCAN_TILE - 1) / SCAN_TILE : 1;
 	hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nb), dim3(TPB), 0, st, in, n, sums);
 	const char *eTiled = getenv("BVGPU_SCAN_TOP_TILED_MIN"); // (read per launch: the tests switch it inside one process)
 	const int64_t tiledMin = eTiled ? (int64_t)atoll(eTiled) : (int64_t)SCAN_TOP_TILED_MIN;
 	if (nb >= tiledMin) hipLaunchKernelGGL(k_scan_top_tiled, dim3(1), dim3(SCAN_TOP_T), 0, st, sums, nb);
 	else hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(TPB), 0, st, sums, nb);
-	hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(TPB), 0, st, in, n, sums, out);
+	if (hx) hipLaunchKernelGGL(k_scan_apply<true>, dim3((unsigned)nb), dim3(TPB), 0, st, in, n, sums, out, hx, lo, nh);
+	else hipLaunchKernelGGL(k_scan_apply<false>, dim3((unsigned)nb), dim3(TPB), 0, st, in, n, sums, out, hx, lo, nh);
 }
 int64_t scan_num_sums(int64_t n) { return n > 0 ? (n + SCAN_TILE - 1) / SCAN_TILE : 1; }
 
@@ -2005,10 +2149,9 @@ void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int
 	}
 	if (stMid != st) (void)hipEventRecord(evMid, stMid);
 #define COPY_LIST(D, V) hipLaunchKernelGGL((k_copy_list<D, V>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err)
-	const char *eAg = getenv("BVGPU_EXP_AG"); const int ag = eAg ? atoi(eAg) : 0; // EXPERIMENT
-	if (def == 1 && ag == 1) hipLaunchKernelGGL((k_copy_list<1, false, 1>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
-	else if (def == 1 && ag == 2) hipLaunchKernelGGL((k_copy_list<1, false, 2>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
-	else if (def == 1 && ag == 3) hipLaunchKernelGGL((k_copy_list<1, false, 3>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
+	if (v.hx && def == 1) hipLaunchKernelGGL((k_copy_list<1, false, true>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err); // (the hash fold: ids added as they are merged)
+	else if (v.hx && def == 2) hipLaunchKernelGGL((k_copy_list<2, false, true>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
+	else if (v.hx) hipLaunchKernelGGL((k_copy_list<0, false, true>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
 	else
 	if (def == 1) { if (vecList) COPY_LIST(1, true); else COPY_LIST(1, false); }
 	else if (def == 2) { if (vecList) COPY_LIST(2, true); else COPY_LIST(2, false); }
@@ -2041,7 +2184,9 @@ void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int
 	if (v.cnt <= 0) return;
 	blocks = (int)std::min<int64_t>(blocks, nblk(v.cnt, TPB)); // (a thread per record at most)
 	IvEntry *a = (IvEntry *)arena;
-	if (def == 1) hipLaunchKernelGGL(k_parse_list<1>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
+	if (def == 1 && v.hx) hipLaunchKernelGGL((k_parse_list<1, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
+	else if (def == 2 && v.hx) hipLaunchKernelGGL((k_parse_list<2, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
+	else if (def == 1) hipLaunchKernelGGL(k_parse_list<1>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
 	else if (def == 2) hipLaunchKernelGGL(k_parse_list<2>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
 	else hipLaunchKernelGGL(k_parse_list<0>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
 }

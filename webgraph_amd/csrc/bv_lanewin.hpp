@@ -164,8 +164,11 @@ template <int KIND, int ZK = 3> __device__ __forceinline__ uint64_t code_w(LaneW
 	return r;
 }
 // off0 / off1: the record's first bit and the next record's (g.offsets[x], g.offsets[x + 1]; the caller fetched them a sweep ahead)
-template <int ZK>
-__device__ __forceinline__ void parse_node_lwb(const GraphDev &g, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row, uint32_t *lds, int2 *__restrict__ iv, int *__restrict__ err, uint64_t off0, uint64_t off1) {
+// HASH (bvg_scan_checksum, HashCtx in bv_launch.hpp): every id the loop emits is also added to hacc with weight hw (then hw *= 31: the ids of a row are consecutive in the
+// hashed sequence; hw = 0 for a row that is hashed elsewhere), and the row is written only if hstore (somebody copies from it, or it is not hashed here).
+template <int ZK, bool HASH = false>
+__device__ __forceinline__ void parse_node_lwb(const GraphDev &g, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row, uint32_t *lds, int2 *__restrict__ iv, int *__restrict__ err, uint64_t off0, uint64_t off1,
+                                               uint32_t *hacc = nullptr, uint32_t hw = 0, bool hstore = true) {
 	LaneWin<LW_MAIN> br;
 	br.col = lds + threadIdx.x;
 	uint32_t *const ring = lds + LW_MAIN * LW_STRIDE + threadIdx.x; // entry j of the ring: ring[2 j * LW_STRIDE] = left, ring[(2 j + 1) * LW_STRIDE] = length
@@ -270,16 +273,19 @@ __device__ __forceinline__ void parse_node_lwb(const GraphDev &g, int32_t x, int
 			if (adv && !ok) resVal += (int32_t)br.template code<0, ZK>(g, e) + 1;
 			else if (adv) { resVal += (int32_t)gap + 1; br.q += len; }
 		} else { resVal += adv ? (int32_t)gap + 1 : 0; br.q += adv ? len : 0u; } // BVG:966
+		if (HASH) { *hacc += (uint32_t)val * hw; hw *= 31u; }
 		const bool inHead = k < head;
-		if (wave_any(inHead)) { if (inHead) out[k] = val; }
+		if (wave_any(inHead)) { if (inHead && (!HASH || hstore)) out[k] = val; }
 		k++;
 		o0 = o1; o1 = o2; o2 = o3; o3 = val;
 		on += !inHead;
-		if (on == 4) { *(int4 *)(out + k - 4) = int4{ o0, o1, o2, o3 }; on = 0; }
+		if (on == 4) { if (!HASH || hstore) *(int4 *)(out + k - 4) = int4{ o0, o1, o2, o3 }; on = 0; }
 	}
-	if (on == 3) { out[k - 3] = o1; out[k - 2] = o2; out[k - 1] = o3; }
-	else if (on == 2) { out[k - 2] = o2; out[k - 1] = o3; }
-	else if (on == 1) out[k - 1] = o3;
+	if (!HASH || hstore) {
+		if (on == 3) { out[k - 3] = o1; out[k - 2] = o2; out[k - 1] = o3; }
+		else if (on == 2) { out[k - 2] = o2; out[k - 1] = o3; }
+		else if (on == 1) out[k - 1] = o3;
+	}
 	if (e) atomicOr(err, e);
 }
 

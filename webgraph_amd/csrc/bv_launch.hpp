@@ -11,6 +11,24 @@ namespace bv {
 constexpr int NBIN = 24, MAXLVL = 64, NKEYS = NBIN * MAXLVL;
 constexpr uint16_t KEY_NONE = 0xffff, KEY_GIANT = 0xfffe;
 
+// A scan that folds ImmutableGraph.hashCode() (ImmutableGraph.java:757-770) instead of handing the rows to anybody (bvg_scan_checksum).  The hash of the
+// sequence "node, its successors backwards, next node ..." (L values) is 31^L h0 + sum(value_i * 31^(L - 1 - i)) mod 2^32.  With u = 31^-1 mod 2^32 that is
+// 31^L h0 + 31^(L + c) * sum(value_i * u^(i + c + 1)) for any c: taking c = rowstart[nh] + nh, a value's weight depends on nothing but the row starts as the kernels see
+// them -- successor j (ascending) of slot s weighs u^(1 + rowstart[s + 1] + s) * 31^j, the node's own number u^(1 + rowstart[s] + s) -- and any kernel can add to the
+// sum in any order: k_scan_apply adds the node numbers while it writes the row starts, the one-lane parse the rows without a reference as it decodes them (writing
+// only those that some row of the view copies from: mark), the lane class of the copy pass the rows it merges; the rows of the wave / group classes are added from
+// memory, found through their work lists (k_hash_queue).  The host multiplies by 31^(L + c) when the job's status comes home.
+struct HashCtx {
+	const uint8_t *mark;  // [cnt] 1: some row of the view copies from this row (k_headers)
+	uint32_t *acc;        // the sum, in HASH_ACC_SLOTS parts (zeroed per job; a wave adds to part (block + wave) mod HASH_ACC_SLOTS: same-address atomics run at ~88 M/s, and 40 000 waves adding to ONE word made k_scan_apply last 0.45 ms instead of 0.05)
+	const uint32_t *ptab; // u^e for e mod 2^30 (the order of any odd number divides 2^30): ptab[e & 1023] * ptab[1024 + ((e >> 10) & 1023)] * ptab[2048 + ((e >> 20) & 1023)]
+};
+constexpr int HASH_ACC_SLOTS = 256;
+__device__ __forceinline__ void hash_add(const HashCtx &hx, uint32_t v) { if (v) atomicAdd(hx.acc + ((blockIdx.x * 4u + (threadIdx.x >> 6)) & (HASH_ACC_SLOTS - 1)), v); }
+__device__ __forceinline__ uint32_t hash_upow(const uint32_t *__restrict__ ptab, uint64_t e) {
+	return ptab[e & 1023u] * ptab[1024u + ((e >> 10) & 1023u)] * ptab[2048u + ((e >> 20) & 1023u)];
+}
+
 // A decode job over consecutive nodes: slot s <-> node lo+s; slots [0,nh) are halo nodes whose rows live
 // in `halo`, slots [nh,cnt) are the caller's nodes whose rows live in `succ`.
 struct RangeView {
@@ -24,6 +42,7 @@ struct RangeView {
 	int32_t coop_min;       // records with outdegree >= coop_min are decoded by whole waves (k_parse_big) ...
 	const int32_t *coop_ptr; // ... unless the job picks the threshold on the device (k_pick_coop): then it is read from here
 	uint64_t halo_cap;      // capacity of halo in elements (a sub-range is decoded before the size of its halo is known on the host)
+	const HashCtx *hx;      // null, or (device memory) the hash fold of bvg_scan_checksum: see HashCtx
 	// does row s lie inside the buffer it belongs to?  (rows are laid out in node order: if s fits, so does every row before it in the same buffer)
 	__device__ __forceinline__ bool fits(int32_t s) const {
 		return s >= nh ? (uint64_t)(rowstart[s + 1] - rowstart[nh]) <= succ_cap : (uint64_t)rowstart[s + 1] <= halo_cap;
@@ -48,10 +67,10 @@ struct BatchView {
 	__device__ __forceinline__ int32_t *row(int64_t s) const { const int32_t qi = qidx[s]; return qi >= 0 ? succ + rowptr[qi] : arena + arow[s]; }
 };
 
-void launch_headers(const GraphDev &g, int def, int32_t lo, int32_t cnt, int32_t *outd, uint16_t *ref, int *err, hipStream_t st, int32_t *part = nullptr);
+void launch_headers(const GraphDev &g, int def, int32_t lo, int32_t cnt, int32_t *outd, uint16_t *ref, int *err, hipStream_t st, int32_t *part = nullptr, uint8_t *mark = nullptr); // mark[cnt] (zeroed): set for every referent
 int64_t headers_blocks(int32_t cnt); // part: 5 counts per block of k_headers, [5][headers_blocks(cnt)] (input of k_pick_coop)
 void launch_mark_halo(int32_t nh, int32_t cnt, int32_t W, int32_t *outd, uint16_t *ref, uint8_t *need, int *err, hipStream_t st);
-void launch_scan(const int32_t *in, int64_t n, int64_t *out, int64_t *sums, hipStream_t st);
+void launch_scan(const int32_t *in, int64_t n, int64_t *out, int64_t *sums, hipStream_t st, const HashCtx *hx = nullptr, int32_t lo = 0, int32_t nh = 0); // hx: the node numbers of slots >= nh are added to the hash (HashCtx)
 int64_t scan_num_sums(int64_t n);
 void launch_rebase(int32_t nh, int32_t cnt, const int64_t *rowstart, int64_t *out, hipStream_t st);
 bool launch_query_mark(const int32_t *nodes, int64_t q, int32_t n, int32_t *outd, uint16_t *ref, uint8_t *need, int32_t *qoutd, int passes, int32_t *changed, int *err, hipStream_t st);
@@ -78,7 +97,14 @@ void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int
                        int32_t midMinKnob, bool bigGroups, const int32_t *bigQ, int32_t bigCap, const int32_t *midQ, int32_t midCap, int32_t *ctl, int32_t *tmp, uint32_t tmpCap, int *err,
                        hipStream_t st, hipStream_t stMid, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evMid, hipEvent_t evBig, const void *preDesc = nullptr, bool preMid = false, bool vecList = false); // vecList: the lane class merges with 16-byte loads and stores (copy_node_v) // preDesc: launch_copy_prewalk's descriptors
 void launch_copy_prewalk(const GraphDev &g, int def, const RangeView &v, const int32_t *bigQ, int32_t bigCap, const int32_t *ctl, void *desc, int blocks, hipStream_t st, int32_t midCap, hipStream_t stLong, bool longKernel, hipStream_t stWalk); // stWalk: the stream of k_copy_prewalk (as stLong) // stLong: the stream of the long lists' kernel (ordered behind the queues by the caller; may be st); // midCap > 0: also the wave class's rows (queue at bigQ + bigCap, descriptors at desc + bigCap)
-void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, void *arena, int64_t arenaCap);
+void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, void *arena, int64_t arenaCap); // v.hx (default codings only): hash fold
+// what the decoding kernels did not add to v.hx->acc, from memory: what bit 2 = the node numbers, bit 0 = every row without a reference that the one-lane parse did not
+// hash (a pass over all nodes: only when the rows are not in a list), bit 1 = the same for the rows with a reference and the lane class of the copy pass; qA / qB: work
+// lists whose rows are hashed (those with a reference if wantRef, those without otherwise); inParse / inCopy: the one-lane parse / the lane class of the copy pass
+// hashed their rows themselves; pieceq: cap entries of 8 bytes, *npieces is zeroed here
+void launch_hash_sum(const HashCtx *hx, int32_t *out, hipStream_t st); // *out = the sum of the parts
+void launch_hash_rest(const RangeView &v, int what, bool inParse, bool inCopy, int32_t midMinKnob, bool bigGroups, void *pieceq, int32_t *npieces, int32_t cap, hipStream_t st,
+                      const int32_t *qA = nullptr, const int32_t *nA = nullptr, int32_t capA = 0, const int32_t *qB = nullptr, const int32_t *nB = nullptr, int32_t capB = 0, bool wantRef = false);
 // one wave per record of `list` (ctl[which] entries, queue head ctl[which + 2]): k_parse_big<1>
 void launch_wait_giants(const int32_t *ctl, int giantGroups, hipStream_t st); // holds st until the giants' groups are on their CUs (or 30 us have passed)
 void launch_parse_listed(const GraphDev &g, int def, const RangeView &v, const int32_t *list, int32_t *ctl, int which, void *arena, int64_t arenaCap, int waves, int *err, hipStream_t st);

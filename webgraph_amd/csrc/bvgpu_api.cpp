@@ -158,7 +158,7 @@ struct bvg_graph {
 	hipStream_t sideA = nullptr, sideB = nullptr; // (more streams than this share hardware queues with each other: they would serialise)
 	bool ctl_clean = false;                       // ctl[4..16) were zeroed by this job's k_pick_coop
 	bool host_mode = false;                       // host_scan: sideB carries the PCIe copies, its kernels go to sideA
-	hipEvent_t evFork = nullptr, evA = nullptr, evB = nullptr, evC = nullptr, evHdr = nullptr, evP = nullptr, evM = nullptr, evL = nullptr;
+	hipEvent_t evFork = nullptr, evA = nullptr, evB = nullptr, evC = nullptr, evHdr = nullptr, evP = nullptr, evM = nullptr, evH = nullptr, evL = nullptr;
 	bool overlap = true;
 	size_t halo_min = (size_t)16 << 20; // bytes of halo scratch an optimistic sub-range decode starts with (BVGPU_HALO_MIN)
 	bool force_halo_sync = false;   // (retry of an optimistic sub-range decode: size the halo with a host round trip)
@@ -168,6 +168,10 @@ struct bvg_graph {
 	// host-output scans (BVG_OUT_HOST, bvg_decode_range_view): chunks are decoded into two device buffers in turn and
 	// leave over PCIe on a copy stream of their own while the next chunk is being decoded
 	DevBuf statsbuf, bfs_rowptr, bfs_succ, bfs_ctr; // consumers (bv_consumers.hip)
+	// bvg_scan_checksum without the 4 B / edge round trip (bv::HashCtx): hash_job is set around its range decodes; hashctx = { HashCtx, acc, two counters }
+	DevBuf hashmark, hashctx, hashtab, hashq;
+	bool hash_job = false, hash_in_parse = false, hash_stale = false; // hash_stale: the copy pass needed more levels than were launched before the rows were folded
+	bv::RangeView hash_view{};
 	DevBuf hchunk[2];
 	PinBuf hring[2];               // pageable destinations: the chunk lands here first and is copied out by host threads
 	PinBuf view_rowptr, view_succ; // bvg_decode_range_view: library-owned pinned results
@@ -266,12 +270,43 @@ int init_handle(bvg_graph *g) {
 	HIPCHK(g, hipEventCreateWithFlags(&g->evHdr, hipEventDisableTiming));
 	HIPCHK(g, hipEventCreateWithFlags(&g->evP, hipEventDisableTiming));
 	HIPCHK(g, hipEventCreateWithFlags(&g->evM, hipEventDisableTiming));
+	HIPCHK(g, hipEventCreateWithFlags(&g->evH, hipEventDisableTiming));
 	HIPCHK(g, hipEventCreateWithFlags(&g->evL, hipEventDisableTiming));
 	if (const char *e = getenv("BVGPU_STATS")) if (atoi(e)) { if (!g->stats.need(64 * sizeof(unsigned long long))) return fail(g, BVG_ENOMEM, "device allocation failed"); HIPCHK(g, hipMemset(g->stats.p, 0, 512)); }
 	return BVG_OK;
 }
 
 void mark(bvg_graph *g, int i) { if (g->profile) (void)hipEventRecord(g->ev[i], g->stream); }
+
+// ---- bvg_scan_checksum's fold (bv::HashCtx): the device-side context of a hash job; the sum and the two counters of k_hash_rest sit behind it
+constexpr size_t HASH_ACC_OFF = 64, HASH_SLOTS_OFF = 128; // bytes: (unused word at +64,) counters of the piece queues at +68, +72; the parts of the sum from +128
+uint32_t host_pow31(uint64_t e) { uint32_t r = 1, b = 31; while (e) { if (e & 1) r *= b; b *= b; e >>= 1; } return r; }
+int hash_prepare(bvg_graph *g) {
+	if (!g->hashtab.p) {
+		if (!g->hashtab.need(3 * 1024 * sizeof(uint32_t))) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
+		std::vector<uint32_t> t(3 * 1024);
+		uint32_t u = 31; // u = 31^-1 mod 2^32 (Newton: every step doubles the correct low bits)
+		for (int k = 0; k < 6; k++) u *= 2u - 31u * u;
+		for (int k = 0; k < 3; k++) {
+			uint32_t step = u; // u^(2^(10 k))
+			for (int i = 0; i < 10 * k; i++) step *= step;
+			uint32_t w = 1;
+			for (int i = 0; i < 1024; i++) { t[(size_t)k * 1024 + i] = w; w *= step; }
+		}
+		HIPCHK(g, hipMemcpy(g->hashtab.p, t.data(), t.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	}
+	static_assert(sizeof(bv::HashCtx) <= HASH_ACC_OFF, "HashCtx");
+	if (!g->hashctx.need(HASH_SLOTS_OFF + sizeof(uint32_t) * bv::HASH_ACC_SLOTS)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
+	return BVG_OK; // (the context itself is written by hash_publish, from enqueue_structure, which sizes the mark buffer)
+}
+int hash_publish(bvg_graph *g) { // after enqueue_structure: every pointer of the context is final
+	struct Init { bv::HashCtx c; char pad[HASH_SLOTS_OFF - sizeof(bv::HashCtx)]; uint32_t acc[bv::HASH_ACC_SLOTS]; } init{};
+	init.c.mark = g->hashmark.as<uint8_t>();
+	init.c.acc = (uint32_t *)((char *)g->hashctx.p + HASH_SLOTS_OFF);
+	init.c.ptab = g->hashtab.as<uint32_t>();
+	HIPCHK(g, hipMemcpyAsync(g->hashctx.p, &init, sizeof(init), hipMemcpyHostToDevice, g->stream)); // (pageable source: the copy is staged before the call returns)
+	return BVG_OK;
+}
 
 // Enqueues headers (+halo closure) + scan for nodes [from,to) with a halo of nh nodes before `from`.
 // On return the view describes the job; rowstart lives in scratch.
@@ -293,7 +328,12 @@ int enqueue_structure(bvg_graph *g, int32_t from, int32_t to, int32_t nh, bv::Ra
 	const bool pick = pickCoop && g->adaptive; // the wave-class threshold of this job comes from its outdegrees (k_pick_coop)
 	const int64_t hb = bv::headers_blocks(cnt);
 	if (pick && !g->pickpart.need(sizeof(int32_t) * bv::PICK_LEVELS * (size_t)hb)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
-	bv::launch_headers(gd, s.def, lo, cnt, v.outd, v.ref, derr, g->stream, pick ? g->pickpart.as<int32_t>() : nullptr);
+	if (g->hash_job) { // bvg_scan_checksum: the context of the fold, written in front of the first kernel that adds to it (the scan: node numbers)
+		if (!g->hashmark.need((size_t)cnt)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
+		const int rc = hash_publish(g);
+		if (rc) return rc;
+	}
+	bv::launch_headers(gd, s.def, lo, cnt, v.outd, v.ref, derr, g->stream, pick ? g->pickpart.as<int32_t>() : nullptr, g->hash_job ? g->hashmark.as<uint8_t>() : nullptr);
 	if (nh) bv::launch_mark_halo(nh, cnt, s.info.window_size, v.outd, v.ref, g->need.as<uint8_t>(), derr, g->stream);
 	if (pick) { // (also zeroes ctl[4..16), the counters of the lists and of the copy levels: a memset behind the scan kernels sat 22 us on the critical path)
 		bv::launch_pick_coop(g->pickpart.as<int32_t>(), (int32_t)hb, COOP_BUDGET, g->coopctl.as<int32_t>(), g->stream);
@@ -302,7 +342,7 @@ int enqueue_structure(bvg_graph *g, int32_t from, int32_t to, int32_t nh, bv::Ra
 	}
 	HIPCHK(g, hipEventRecord(g->evHdr, g->stream)); // outdegrees and references are final: the parse list can be built while the scan runs
 	mark(g, 1);
-	bv::launch_scan(v.outd, cnt, v.rowstart, g->sums.as<int64_t>(), g->stream);
+	bv::launch_scan(v.outd, cnt, v.rowstart, g->sums.as<int64_t>(), g->stream, g->hash_job ? g->hashctx.as<bv::HashCtx>() : nullptr, lo, nh);
 	mark(g, 2);
 	return BVG_OK;
 }
@@ -368,6 +408,7 @@ int finish_pending(bvg_graph *g, uint64_t *arcs_out) {
 		set_walk(gd, g, g->pend.walkMin);
 		int *derr = &g->small.as<Small>()->err;
 		while (g->pend.levels_done < g->h_small->maxdepth) {
+			g->hash_stale = g->hash_job; // (rows were folded before these levels ran: bvg_scan_checksum repeats the piece the plain way)
 			const int32_t upto = g->h_small->maxdepth;
 			int32_t *keyBase = g->keys.as<int32_t>() + (bv::NKEYS + 1);
 			for (int32_t l = g->pend.levels_done + 1; l <= upto; l++) {
@@ -468,6 +509,9 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		g->pend.tmpCap = g->copy_big ? tmpCap : 0;
 		const bool coop = coopMin < 0x7fffffff;
 		const bool ovl = g->overlap && !g->profile; // per-kernel timing needs the kernels one after the other
+		// bvg_scan_checksum: k_parse_list (default codings) and the lane class of the copy pass add the rows they produce to the job's hash (v.hx; the other kernels ignore it)
+		g->hash_in_parse = g->hash_job && s.def != 0;
+		if (g->hash_job) v.hx = g->hashctx.as<bv::HashCtx>();
 		v.coop_min = coop ? coopMin : 0x7fffffff;
 		g->last_giant_min = giantMin;
 		// Three things run next to each other from here on (unless profiling serialises them):
@@ -486,7 +530,8 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		// k_pick_coop will pick 128 --: neighbouring short records are alike, a tile's lanes stay even, and the coalesced tile
 		// kernel is 20 % faster than the bins (cnr-2000 x 30: 0.42 against 0.53 ms); with a heavy-tailed lane class it is 2.6x slower (C2).
 		int tileVariant = g->tile > 0 ? g->tile : 0;
-		if (g->tile < 0 && g->adaptive && v.coop_ptr && s.deg_counts[0] >= 0) {
+		if (g->hash_job) tileVariant = 0; // (the hash fold rides on k_parse_list)
+		else if (g->tile < 0 && g->adaptive && v.coop_ptr && s.deg_counts[0] >= 0) {
 			const double share = (double)(s.h_offsets[(size_t)v.lo + v.cnt] - s.h_offsets[(size_t)v.lo]) / (double)std::max<int64_t>(s.h_offsets[(size_t)s.node_hi] - s.h_offsets[(size_t)s.stage_lo], 1);
 			if ((double)s.deg_counts[0] * share <= (double)COOP_BUDGET * (share > 0.999 ? 1.0 : 0.8)) tileVariant = 1; // (a sub-range: an estimate, with a margin)
 		}
@@ -501,7 +546,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		const bool earlyList = !tiles && ovl && hdrEvent;
 		// The segment pipeline (bv_seg.hip): the residual sections of the hubs -- giant records with >= seg_hub_min successors --, cut into pieces of stream, one lane
 		// per piece.  The giants' kernel parses the structure of such a record and hands the residuals over (GraphDev::segDesc).
-		const bool segAble = g->seg && g->seg != 2 && !tiles && s.def != 0 && coop && s.seg_long_records >= 0;
+		const bool segAble = g->seg && g->seg != 2 && !tiles && s.def != 0 && coop && s.seg_long_records >= 0 && !g->hash_job;
 		const bool segOn = segAble && (g->seg == 3 || (s.max_outdegree >= g->seg_hub_min && estArcs >= 4000000));
 		int32_t segScap = 0;
 		bool segReady = false;
@@ -579,6 +624,19 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			g->pend.preDesc = g->walkdesc.p;
 		}
 		if (listsOnC) HIPCHK(g, hipEventRecord(g->evL, g->sideC));
+		auto hash_phase_a = [&](hipStream_t stH) { // the node numbers and the rows without a reference that the wave / group classes decoded (their lists), or every such row (codings the one-lane parse does not hash)
+			const int32_t pcap = (int32_t)std::min<int64_t>((int64_t)v.cnt + arcsBound / 4096 + 2, 0x7ffffff0);
+			if (!g->hashq.need(sizeof(int64_t) * (size_t)pcap)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
+			const bool lists = g->hash_in_parse && coop;
+			bv::launch_hash_rest(v, g->hash_in_parse ? 0 : 1, g->hash_in_parse, true, g->copy_mid_min, g->copy_big != 0, g->hashq.p, (int32_t *)((char *)g->hashctx.p + HASH_ACC_OFF + 4), pcap, stH,
+			                     lists ? g->biglist.as<int32_t>() : nullptr, ctl + 0, v.cnt, lists ? g->giantlist.as<int32_t>() : nullptr, ctl + 1, giantCap, false);
+			return (int)BVG_OK;
+		};
+		if (g->hash_job && ovl) { // behind side A's chain, once the giants are done too: beside the tail of the one-lane parse
+			if (coop) HIPCHK(g, hipStreamWaitEvent(g->sideA, g->evB, 0));
+			const int rc = hash_phase_a(g->sideA);
+			if (rc) return rc;
+		}
 		if (ovl) HIPCHK(g, hipEventRecord(g->evA, g->sideA));
 		if (ovl && coop && listsOnB) HIPCHK(g, hipEventRecord(g->evB, side_b(g))); // (the lists sit behind the giants: side B is done when they are)
 		if (!tiles && !earlyList)
@@ -612,6 +670,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			if (listsOnC) HIPCHK(g, hipStreamWaitEvent(g->stream, g->evL, 0));
 		}
 		mark(g, 6);
+		if (g->hash_job && !ovl) { const int rc = hash_phase_a(g->stream); if (rc) return rc; }
 		if (W > 0) {
 			levels = g->levels_hint;
 			for (int32_t l = 1; l <= levels; l++) {
@@ -619,6 +678,12 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 				                                          g->copyq.as<int32_t>(), bigCap, g->copyq.as<int32_t>() + bigCap, midCap, ctl, g->bigtmp.as<int32_t>(), g->pend.tmpCap, derr,
 				                                          g->stream, ovl ? side_b(g) : g->stream, ovl ? g->sideA : g->stream, g->evFork, g->evB, g->evA, g->pend.preDesc, g->prewalk < 2 && g->pend.midCap > 0, copy_vec(g));
 			}
+		}
+		if (g->hash_job) { // the rows that the wave / group classes of the copy pass merged (its queues), then the sum rides home in the job's mailbox
+			if (W > 0 && g->copy_big)
+				bv::launch_hash_rest(v, 0, g->hash_in_parse, true, g->copy_mid_min, true, g->hashq.p, (int32_t *)((char *)g->hashctx.p + HASH_ACC_OFF + 8), (int32_t)(g->hashq.cap / sizeof(int64_t)), g->stream,
+				                     g->copyq.as<int32_t>(), ctl + 5, bigCap, midCap > 0 ? g->copyq.as<int32_t>() + bigCap : nullptr, ctl + 6, midCap, true);
+			bv::launch_hash_sum(g->hashctx.as<bv::HashCtx>(), &g->small.as<Small>()->hash, g->stream);
 		}
 	}
 	return BVG_OK;
@@ -770,6 +835,7 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 	if (from < s.node_lo || to > s.node_hi) return fail(g, BVG_EARG, "node range outside the slice this handle stages (bvg_open_shard)");
 	{ int rc = fork_from_user(g); if (rc) return rc; }
 	HIPCHK(g, hipMemsetAsync(g->small.p, 0, sizeof(Small), g->stream));
+	if (g->hash_job) { int rc = hash_prepare(g); if (rc) return rc; }
 	if (to == from) {
 		HIPCHK(g, hipMemsetAsync(rowptr_dev, 0, sizeof(int64_t), g->stream));
 		{ int rc = join_to_user(g); if (rc) return rc; }
@@ -839,6 +905,7 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 	g->ev_valid = g->profile;
 	{ int rc = join_to_user(g); if (rc) return rc; }
 	HIPCHK(g, hipGetLastError());
+	if (g->hash_job) g->hash_view = v;
 	g->pend.active = true; g->pend.view = v; g->pend.levels_done = levels; g->pend.want_succ = succ_dev != nullptr; g->pend.giantCap = giantCap;
 	g->pend.optimistic = optimistic; g->pend.from = from; g->pend.to = to; g->pend.rowptr = rowptr_dev; g->pend.succ = succ_dev; g->pend.succ_cap = succ_cap;
 	if (async) return BVG_OK;
@@ -1081,13 +1148,13 @@ extern "C" int bvg_close(bvg_t *g) {
 	if (g->st && g->st->device >= 0) {
 		(void)hipSetDevice(g->st->device);
 		if (g->own) { (void)hipStreamSynchronize(g->own); (void)hipStreamDestroy(g->own); }
-		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->hashBounds, &g->pickpart, &g->walktab, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist, &g->plist, &g->pkeys, &g->pkey16, &g->copyq, &g->walkdesc, &g->bigtmp, &g->tilebounds, &g->segbuf }) b->release();
+		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->hashBounds, &g->pickpart, &g->walktab, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist, &g->plist, &g->pkeys, &g->pkey16, &g->copyq, &g->walkdesc, &g->bigtmp, &g->tilebounds, &g->segbuf, &g->hashmark, &g->hashctx, &g->hashtab, &g->hashq }) b->release();
 		for (DevBuf *b : { &g->hchunk[0], &g->hchunk[1], &g->statsbuf, &g->bfs_rowptr, &g->bfs_succ, &g->bfs_ctr }) b->release();
 		for (PinBuf *b : { &g->hring[0], &g->hring[1], &g->view_rowptr, &g->view_succ }) b->release();
 		for (hipEvent_t e : { g->evChunk[0], g->evChunk[1], g->evCopied[0], g->evCopied[1] }) if (e) (void)hipEventDestroy(e);
 		if (g->h_small) (void)hipHostFree(g->h_small);
 		for (auto &e : g->ev) if (e) (void)hipEventDestroy(e);
-		for (hipEvent_t e : { g->evFork, g->evA, g->evB, g->evC, g->evHdr, g->evP, g->evM, g->evL, g->evIn, g->evOut }) if (e) (void)hipEventDestroy(e);
+		for (hipEvent_t e : { g->evFork, g->evA, g->evB, g->evC, g->evHdr, g->evP, g->evM, g->evH, g->evL, g->evIn, g->evOut }) if (e) (void)hipEventDestroy(e);
 		for (hipStream_t st : { g->sideA, g->sideB, g->sideC }) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
 	}
 	delete g;
@@ -1379,6 +1446,11 @@ extern "C" int bvg_scan_checksum(bvg_t *g, int32_t from, int32_t to, int32_t *ha
 	const std::vector<int32_t> cut = plan_chunks_by_bits(s, from, to, scan_piece_arcs());
 	uint64_t total = 0;
 	int32_t h = *hash_io;
+	// Since round 5 the fold is part of the scan (bv::HashCtx): the one-lane parse adds the rows without a reference to the sum as it decodes them and writes only
+	// those that a row of the piece copies from; k_hash_rest adds the node numbers and the rows that are in memory anyway.  BVGPU_HASH_MATERIALISE=1: decode every
+	// row, then fold from memory (round 2's path, kept for comparison and for the tests).
+	const char *eMat = getenv("BVGPU_HASH_MATERIALISE"); // (read per call: the tests switch it)
+	const bool materialise = eMat && atoi(eMat) != 0;
 	for (size_t k = 0; k + 1 < cut.size(); k++) {
 		const int32_t a = cut[k], e = cut[k + 1];
 		if (e == a) continue;
@@ -1386,13 +1458,26 @@ extern "C" int bvg_scan_checksum(bvg_t *g, int32_t from, int32_t to, int32_t *ha
 		const uint64_t guess = (uint64_t)(est_arcs(s, a, e) * 1.1) + 4096;
 		if (!g->stage_succ.need(sizeof(int32_t) * (size_t)guess)) return fail(g, BVG_ENOMEM, "staging allocation failed");
 		uint64_t arcs = 0;
+		g->hash_job = !materialise;
+		g->hash_stale = false;
 		int rc = decode_range_device(g, a, e, g->stage_rowptr.as<int64_t>(), g->stage_succ.as<int32_t>(), g->stage_succ.cap / sizeof(int32_t), false, &arcs);
 		if (rc == BVG_ECAP) {
-			if (!g->stage_succ.need(sizeof(int32_t) * (size_t)std::max<uint64_t>(arcs, 1))) return fail(g, BVG_ENOMEM, "staging allocation failed");
+			if (!g->stage_succ.need(sizeof(int32_t) * (size_t)std::max<uint64_t>(arcs, 1))) { g->hash_job = false; return fail(g, BVG_ENOMEM, "staging allocation failed"); }
+			g->hash_stale = false;
 			rc = decode_range_device(g, a, e, g->stage_rowptr.as<int64_t>(), g->stage_succ.as<int32_t>(), g->stage_succ.cap / sizeof(int32_t), false, &arcs);
 		}
+		const bool folded = g->hash_job && !g->hash_stale;
+		if (!rc && g->hash_job && g->hash_stale) { // reference chains deeper than the levels launched ahead (a file that understates maxrefcount): every row is final now -- fold from memory
+			g->hash_job = false;
+			rc = decode_range_device(g, a, e, g->stage_rowptr.as<int64_t>(), g->stage_succ.as<int32_t>(), g->stage_succ.cap / sizeof(int32_t), false, &arcs);
+		}
+		g->hash_job = false;
 		if (rc) return rc;
-		rc = bvg_csr_hashcode(g, a, e, g->stage_rowptr.as<int64_t>(), g->stage_succ.as<int32_t>(), &h);
+		if (folded) { // the piece's map h -> 31^L h + 31^(L + c) sum, c = rowstart[nh] + nh (HashCtx); the sum and rowstart[nh] came home with the job's status
+			const uint64_t L = (uint64_t)(e - a) + arcs, c = (uint64_t)g->h_small->halo_total + (uint64_t)g->hash_view.nh;
+			h = (int32_t)(host_pow31(L) * (uint32_t)h + host_pow31(L + c) * (uint32_t)g->h_small->hash);
+		}
+		else rc = bvg_csr_hashcode(g, a, e, g->stage_rowptr.as<int64_t>(), g->stage_succ.as<int32_t>(), &h);
 		if (rc) return rc;
 		total += arcs;
 	}
