@@ -1450,7 +1450,7 @@ extern "C" int bvg_scan_checksum(bvg_t *g, int32_t from, int32_t to, int32_t *ha
 	// those that a row of the piece copies from; k_hash_rest adds the node numbers and the rows that are in memory anyway.  BVGPU_HASH_MATERIALISE=1: decode every
 	// row, then fold from memory (round 2's path, kept for comparison and for the tests).
 	const char *eMat = getenv("BVGPU_HASH_MATERIALISE"); // (read per call: the tests switch it)
-	const bool materialise = eMat && atoi(eMat) != 0;
+	const bool materialise = (eMat && atoi(eMat) != 0) || s.info.format == BVG_FORMAT_EF; // (an EFGraph gets here only through BVGPU_EF_HASH_MATERIALISE: the fold of bv_ef.hip is the other path)
 	for (size_t k = 0; k + 1 < cut.size(); k++) {
 		const int32_t a = cut[k], e = cut[k + 1];
 		if (e == a) continue;
