@@ -112,6 +112,7 @@ constexpr int PARSE_LONG_BIN = 14; // work bins from here up (>= 2048 bits of wo
 // bv_seg.hip: the segment pipeline -- the residual sections of the hubs (giant records with >= minD successors), handed over by k_parse_big
 size_t seg_scratch_bytes(int32_t Rtot, int32_t Scap, int zetaK);
 void launch_seg_sizing(const int64_t *offsets, int32_t lo, int32_t n, const int32_t *outd, const uint16_t *ref, unsigned long long *out5, hipStream_t st); // out5 (zeroed by the caller): records and bits of the long bins, longest record, rows and ids of the copy pass's lane class
+constexpr int SIZING_OCTAVES = 24, SIZING_WORDS = 8 + 2 * SIZING_OCTAVES; // launch_seg_sizing: out5[8 + 2 k], out5[9 + 2 k] = records and arcs with 2^(7 + k) <= outdegree < 2^(8 + k)
 int32_t seg_bits_log2();
 void seg_handover(GraphDev &g, void *scratch, int32_t capGiant, int32_t Scap, int32_t minD, hipStream_t st); // capGiant hand-over slots, one per entry of the giants' queue; minD: records with fewer successors are not handed over
 void launch_seg_chain(const GraphDev &g, int def, const RangeView &v, int32_t Rtot, int32_t Scap, void *scratch, void *arena, int64_t arenaCap, int32_t *ctl, int blocks, int *err, hipStream_t st);

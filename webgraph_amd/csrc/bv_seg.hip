@@ -445,8 +445,9 @@ size_t seg_scratch_bytes(int32_t Rtot, int32_t Scap, int zetaK) { return seg_ptr
 // Sizing at load time: how many records have >= 2 048 bits of work (max(bits, 8 successors): the long bins of the parse list) and how many
 // bits they hold -- every piece belongs to one of them.  out[0] += records, out[1] += bits (device memory, zeroed by the caller)
 __global__ void __launch_bounds__(STPB) k_seg_sizing(const int64_t *__restrict__ offsets, int32_t lo, int32_t n, const int32_t *__restrict__ outd, const uint16_t *__restrict__ ref, unsigned long long *__restrict__ out) {
-	__shared__ unsigned long long s_acc[4];
+	__shared__ unsigned long long s_acc[4], s_oct[2 * SIZING_OCTAVES];
 	if (threadIdx.x < 4) s_acc[threadIdx.x] = 0;
+	if (threadIdx.x < 2 * SIZING_OCTAVES) s_oct[threadIdx.x] = 0;
 	__syncthreads();
 	unsigned long long recs = 0, bits = 0, lrows = 0, lids = 0; // (lrows, lids: the rows of the copy pass's lane class -- a reference, fewer than 128 successors -- and their ids)
 	int32_t mx = 0;
@@ -455,6 +456,10 @@ __global__ void __launch_bounds__(STPB) k_seg_sizing(const int64_t *__restrict__
 		const uint64_t b = (uint64_t)(offsets[lo + s + 1] - offsets[lo + s]);
 		if (outd[s] > 0 && (b >= 2048 || (uint64_t)outd[s] * 8 >= 2048)) { recs++; bits += b; }
 		if (ref && ref[s] != 0 && outd[s] > 0 && outd[s] < 128) { lrows++; lids += (unsigned long long)outd[s]; }
+		if (outd[s] >= 128) { // records and arcs per octave of the outdegree, from 2^7 up: what the class thresholds are chosen from (pick_thresholds)
+			const int k = min(31 - __clz(outd[s]) - 7, SIZING_OCTAVES - 1);
+			atomicAdd(&s_oct[2 * k], 1ull); atomicAdd(&s_oct[2 * k + 1], (unsigned long long)outd[s]);
+		}
 	}
 	for (int o = 32; o > 0; o >>= 1) { recs += __shfl_down(recs, o, 64); bits += __shfl_down(bits, o, 64); lrows += __shfl_down(lrows, o, 64); lids += __shfl_down(lids, o, 64); mx = max(mx, __shfl_down(mx, o, 64)); }
 	mx = (threadIdx.x & 63) == 0 ? mx : 0;
@@ -463,6 +468,7 @@ __global__ void __launch_bounds__(STPB) k_seg_sizing(const int64_t *__restrict__
 	if (threadIdx.x < 2 && s_acc[threadIdx.x]) atomicAdd(&out[threadIdx.x], s_acc[threadIdx.x]);
 	if (threadIdx.x >= 2 && threadIdx.x < 4 && s_acc[threadIdx.x]) atomicAdd(&out[threadIdx.x + 1], s_acc[threadIdx.x]); // out[3], out[4]
 	if (mx) atomicMax(&out[2], (unsigned long long)mx); // (the longest record: out[2])
+	if (threadIdx.x < 2 * SIZING_OCTAVES && s_oct[threadIdx.x]) atomicAdd(&out[8 + threadIdx.x], s_oct[threadIdx.x]);
 }
 void launch_seg_sizing(const int64_t *offsets, int32_t lo, int32_t n, const int32_t *outd, const uint16_t *ref, unsigned long long *out5, hipStream_t st) {
 	if (n > 0) hipLaunchKernelGGL(k_seg_sizing, dim3(1024), dim3(STPB), 0, st, offsets, lo, n, outd, ref, out5);

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
@@ -74,6 +75,7 @@ struct Staged {
 	int64_t max_outdegree = -1; // the longest staged record (counted with arcs_sizing; -1: unknown)
 	int64_t lane_rows = 0, lane_ids = 0; // staged rows with a reference and fewer than 128 successors, and their ids (the lane class of the copy pass)
 	int64_t seg_long_records = -1, seg_long_bits = -1; // staged records with >= 2 048 bits of work (the parse list's long bins) and their bits (counted with arcs_sizing; -1: unknown): they size the segment pipeline
+	int64_t oct_recs[bv::SIZING_OCTAVES] = {}, oct_arcs[bv::SIZING_OCTAVES] = {}; // staged records / their arcs with 2^(7 + k) <= outdegree < 2^(8 + k) (valid when max_outdegree >= 0)
 	int32_t deg_counts[bv::PICK_LEVELS] = { -1, -1, -1, -1, -1, -1, -1 }; // staged records with >= 128, 256, ..., 8192 successors (counted with arcs_sizing; -1: unknown)
 	int def = 0;                    // kernel variant: 1 default codings with zeta_3, 2 default codings with another zeta_k, 0 generic
 	std::string basename;
@@ -143,7 +145,7 @@ struct bvg_graph {
 	int parse_windows = 1; // BVGPU_PARSE_WINDOWS=0: the parse list is sorted by work bin over the whole range
 	int copy_mid_min = 128; // rows with at least this many successors (and fewer than 1024) are copied by one wave each
 	int32_t coop_min = 2048, giant_min = 32768;                         // thresholds on the outdegree (BVGPU_COOP_MIN / BVGPU_GIANT_MIN)
-	bool adaptive = true;                                               // smaller jobs lower them (pick_thresholds) unless a knob pins them
+	bool adaptive = true, adaptive_giant = true;                        // smaller jobs lower them (pick_thresholds) unless a knob pins them (each knob pins its own threshold)
 	int coop_waves = 4096, giant_groups = 256;
 	DevBuf copyq; // rows the copy pass merges with a group / a wave each (all levels), filled while the level lists are built
 	DevBuf walkdesc; // k_copy_prewalk: 16 bytes per entry of the group class's queue
@@ -233,7 +235,7 @@ int init_handle(bvg_graph *g) {
 	const int mr = g->st->info.max_ref_count;
 	g->levels_hint = mr < 1 ? 1 : (mr > 8 ? 8 : mr);
 	if (const char *e = getenv("BVGPU_COOP_MIN")) { g->coop_min = std::max(1, atoi(e)); g->adaptive = false; }   // 0x7fffffff disables the cooperative path
-	if (const char *e = getenv("BVGPU_GIANT_MIN")) { g->giant_min = std::max(g->coop_min, atoi(e)); g->adaptive = false; }
+	if (const char *e = getenv("BVGPU_GIANT_MIN")) { g->giant_min = std::max(1, atoi(e)); g->adaptive_giant = false; }
 	if (const char *e = getenv("BVGPU_COOP_WAVES")) g->coop_waves = std::max(1, atoi(e));
 	if (const char *e = getenv("BVGPU_GIANT_GROUPS")) g->giant_groups = std::max(1, atoi(e));
 	if (!g->coopctl.need(bv::CTL_TOTAL_INTS * sizeof(int32_t)) || !g->keys.need(3 * (bv::NKEYS + 1) * sizeof(int32_t))) return fail(g, BVG_ENOMEM, "device allocation failed");
@@ -445,13 +447,21 @@ int finish_pending(bvg_graph *g, uint64_t *arcs_out) {
 // arcs ends when its longest chain does.  Steps measured on C2 sub-ranges (scripts/small_range.py).
 void pick_thresholds(const bvg_graph *g, int64_t estArcs, int32_t &coopMin, int32_t &giantMin) {
 	coopMin = g->coop_min; giantMin = g->giant_min;
-	if (!g->adaptive) return;
-	// (a lane takes ~0.6 us per successor, a wave ~30 us per record: cnr-2000, 3.2 M arcs, 0.80 ms at 512, 0.62 ms at 128)
-	if (estArcs < 8000000) coopMin = 128; else if (estArcs < 32000000) coopMin = 512; else if (estArcs < 80000000) coopMin = 1024;
-	if (estArcs < 150000000) giantMin = 8192;
-	// (the longer the scan, the longer the chains it hides: at 1 B arcs the wave class starts at 8 192 (k_pick_coop) and a group of waves pays from 131 072 -- 14.7 -> 12.7 ms)
-	else if (estArcs >= 700000000) giantMin = std::max(giantMin, 131072);
-	else if (estArcs >= 350000000) giantMin = std::max(giantMin, 65536);
+	if (g->adaptive) { // (a lane takes ~0.6 us per successor, a wave ~30 us per record: cnr-2000, 3.2 M arcs, 0.80 ms at 512, 0.62 ms at 128)
+		if (estArcs < 8000000) coopMin = 128; else if (estArcs < 32000000) coopMin = 512; else if (estArcs < 80000000) coopMin = 1024;
+	}
+	if (g->adaptive_giant) {
+		// The group class is for the records a WAVE could not finish inside the scan: a wave decodes ~25 ns per successor whatever else runs, so the chain it can hide
+		// grows with the job -- but a group of eight waves needs a CU to itself, and many records of middling length lose as groups to 3 000 waves side by side (675
+		// records of 32 768 .. 65 535 successors: 0.6 ms more as groups).  Fitted on the best fixed threshold of seven workloads (100 M .. 1 B arcs, three outdegree
+		// exponents, deep chains, a web shape; profiles/r5_thresholds.txt): 32 768 x (arcs / 10^8)^0.6, rounded to a power of two, from 8 192 to 2^20 --
+		// 100 M arcs 32 768, 200 - 400 M 65 536, 1 B 131 072; within 3 % of the best on all seven (round 4's steps by job size: 9 % off at 100 M arcs, 20 % off on a
+		// heavier-tailed outdegree distribution).
+		const double target = 32768.0 * std::pow((double)std::max<int64_t>(estArcs, 1) / 1e8, 0.6);
+		const int lg = (int)std::lround(std::log2(std::max(target, 1.0)));
+		giantMin = 1 << std::min(20, std::max(13, lg));
+	}
+	giantMin = std::max(giantMin, coopMin);
 }
 
 // The lane class of the copy pass reads and writes 16 bytes at a time where its rows are long enough to pay for the bookkeeping:
@@ -1066,7 +1076,7 @@ static int open_impl(const char *basename, int device, int part, int parts, bvg_
 		const int32_t n = st->node_hi - st->stage_lo;
 		void *p_outd = nullptr, *p_ref = nullptr, *p_rs = nullptr, *p_sums = nullptr, *p_err = nullptr, *p_part = nullptr;
 		const bool ok = hipMalloc(&p_outd, sizeof(int32_t) * (size_t)n) == hipSuccess && hipMalloc(&p_ref, sizeof(uint16_t) * (size_t)n) == hipSuccess &&
-		                hipMalloc(&p_rs, sizeof(int64_t) * ((size_t)n + 8)) == hipSuccess /* (also the five counters of the sizing pass) */ && hipMalloc(&p_sums, sizeof(int64_t) * (size_t)bv::scan_num_sums(n)) == hipSuccess &&
+		                hipMalloc(&p_rs, sizeof(int64_t) * ((size_t)n + bv::SIZING_WORDS)) == hipSuccess /* (also the five counters of the sizing pass) */ && hipMalloc(&p_sums, sizeof(int64_t) * (size_t)bv::scan_num_sums(n)) == hipSuccess &&
 		                hipMalloc(&p_err, sizeof(int)) == hipSuccess && hipMalloc(&p_part, sizeof(int32_t) * (bv::PICK_LEVELS * (size_t)bv::headers_blocks(n) + 8)) == hipSuccess;
 		int64_t total = 0;
 		hipError_t e = ok ? hipMemset(p_err, 0, sizeof(int)) : hipErrorOutOfMemory;
@@ -1078,10 +1088,12 @@ static int open_impl(const char *basename, int device, int part, int parts, bvg_
 			e = hipMemcpy(&total, (int64_t *)p_rs + n, sizeof(int64_t), hipMemcpyDeviceToHost);
 			if (e == hipSuccess) e = hipMemcpy(st->deg_counts, (int32_t *)p_part + bv::PICK_LEVELS * hb, sizeof(st->deg_counts), hipMemcpyDeviceToHost);
 			if (e == hipSuccess && st->def != 0) { // (p_rs is done with: two counters)
-				unsigned long long five[5] = { 0, 0, 0, 0, 0 };
+				unsigned long long five[bv::SIZING_WORDS] = {};
 				e = hipMemset(p_rs, 0, sizeof(five));
 				if (e == hipSuccess) { bv::launch_seg_sizing(st->d_offsets, st->stage_lo, n, (const int32_t *)p_outd, (const uint16_t *)p_ref, (unsigned long long *)p_rs, nullptr); e = hipMemcpy(five, p_rs, sizeof(five), hipMemcpyDeviceToHost); }
-				if (e == hipSuccess) { st->seg_long_records = (int64_t)five[0]; st->seg_long_bits = (int64_t)five[1]; st->max_outdegree = (int64_t)five[2]; st->lane_rows = (int64_t)five[3]; st->lane_ids = (int64_t)five[4]; }
+				if (e == hipSuccess) { st->seg_long_records = (int64_t)five[0]; st->seg_long_bits = (int64_t)five[1]; st->max_outdegree = (int64_t)five[2]; st->lane_rows = (int64_t)five[3]; st->lane_ids = (int64_t)five[4];
+					for (int k = 0; k < bv::SIZING_OCTAVES; k++) { st->oct_recs[k] = (int64_t)five[8 + 2 * k]; st->oct_arcs[k] = (int64_t)five[9 + 2 * k]; }
+					if (getenv("BVGPU_TRACE_HIST")) for (int k = 0; k < bv::SIZING_OCTAVES; k++) if (st->oct_recs[k]) fprintf(stderr, "[bvgpu] outdegree >= %d: %lld records, %lld arcs\n", 128 << k, (long long)st->oct_recs[k], (long long)st->oct_arcs[k]); }
 			}
 		}
 		for (void *q : { p_outd, p_ref, p_rs, p_sums, p_err, p_part }) if (q) (void)hipFree(q);

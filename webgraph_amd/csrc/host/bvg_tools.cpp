@@ -350,7 +350,10 @@ extern "C" int bvt_generate_ex(int32_t n, int64_t m, uint64_t seed, double p_cop
 	if (m > (int64_t)n * dcap / 2) return -EINVAL;
 	const int nblocks = (n + GEN_BLOCK - 1) / GEN_BLOCK;
 
-	// 1. raw power-law outdegrees: P(d) ~ d^-2.1 on [1, 1e5]; 20% of the nodes forced empty
+	// 1. raw power-law outdegrees: P(d) ~ d^-2.1 on [1, 1e5]; 20% of the nodes forced empty.  BVT_DEGREE_ALPHA (default 1.1: the recipe of C2 / C5) moves the
+	// exponent for the threshold experiments of round 5 (density ~ d^-(alpha + 1): 0.8 = heavier tail, 1.6 = lighter); the cache names of bench.py carry it.
+	const char *eAlpha = getenv("BVT_DEGREE_ALPHA");
+	const double degAlpha = eAlpha && atof(eAlpha) > 0 ? atof(eAlpha) : 1.1;
 	std::vector<int32_t> raw((size_t)n);
 	auto par = [&](auto fn) {
 		std::atomic<int> next{0};
@@ -363,7 +366,7 @@ extern "C" int bvt_generate_ex(int32_t n, int64_t m, uint64_t seed, double p_cop
 		int32_t lo = b * GEN_BLOCK, hi = std::min<int64_t>((int64_t)lo + GEN_BLOCK, n);
 		for (int32_t x = lo; x < hi; x++) {
 			if (p_same > 0 && x > lo && raw[(size_t)x - 1] && r.unit() < p_same) { raw[(size_t)x] = raw[(size_t)x - 1]; continue; }
-			raw[(size_t)x] = r.unit() < 0.2 ? 0 : (int32_t)pareto_floor(r, 1.1, 1e5);
+			raw[(size_t)x] = r.unit() < 0.2 ? 0 : (int32_t)pareto_floor(r, degAlpha, 1e5);
 		}
 	});
 	// 2. rescale to hit exactly m arcs: d = clamp(round(raw*s), 1, dcap) for raw>0, s by bisection
