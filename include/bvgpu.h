@@ -134,6 +134,11 @@ int bvg_sync(bvg_t *g, uint64_t *arcs_out);
  * rowptr rebase + totals */
 #define BVG_NUM_PHASES 8
 /* Enables / disables per-phase HIP-event timing on this handle (off by default; costs a few event records). */
+/* Tuning and debug knobs of a handle, by name ("coop_min", "giant_min", "overlap", "copy_mid_min", "hash_materialise", ... -- the names of the BVGPU_<NAME>
+ * environment variables, which are read ONCE when a handle is created and never per launch; -DBVGPU_NO_ENV builds ignore the environment altogether and keep only
+ * this entry point).  Every knob is a choice of speed, never of results.  Waits for the handle's pending job.  BVG_EARG: unknown name.  No counterpart in the
+ * reference (its only run-time knobs are the JVM's). */
+int bvg_set_option(bvg_t *g, const char *name, const char *value);
 int bvg_set_profile(bvg_t *g, int enable);
 /* Milliseconds of each phase of the last range decode issued with profiling on; ms has BVG_NUM_PHASES floats. */
 int bvg_get_profile(bvg_t *g, float *ms);

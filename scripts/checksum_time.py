@@ -35,10 +35,10 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / reps * 1e3, r
     scan_ms, _ = t(lambda: g.decode_range_device(0, n, rowptr.data_ptr(), succ.data_ptr(), succ.numel()))
-    os.environ.pop("BVGPU_HASH_MATERIALISE", None)
+    g.set_option("hash_materialise", 0)
     fold_ms, r = t(lambda: g.scan_checksum())
     assert r == (want, m), (r, want, m)
-    os.environ["BVGPU_HASH_MATERIALISE"] = "1"
+    g.set_option("hash_materialise", 1)
     mat_ms, r = t(lambda: g.scan_checksum())
     assert r == (want, m), (r, want, m)
     print("%-6s arcs %d hash %d | scan (rows to the caller) %.3f ms | checksum folded in the scan %.3f ms | checksum decode-then-fold %.3f ms" % (name, m, want, scan_ms, fold_ms, mat_ms))

@@ -5,6 +5,8 @@ ImmutableGraph.splitNodeIterators, ImmutableGraph.java:379-409, and by BVGraph.j
 import ctypes as C
 import threading
 
+import os
+
 import numpy as np
 import pytest
 
@@ -80,28 +82,36 @@ def test_scan_checksum(cnr_gpu, cnr_oracle):
 @pytest.mark.parametrize("env", [{}, {"BVGPU_HASH_MATERIALISE": "1"}, {"BVGPU_COOP_MIN": "16", "BVGPU_GIANT_MIN": "64"}, {"BVGPU_COOP_MIN": "2147483647"}, {"BVGPU_SCAN_PIECE": "90000"},
                                  {"BVGPU_OVERLAP": "0"}, {"BVGPU_COPY_MID_MIN": "8", "BVGPU_COOP_MIN": "300", "BVGPU_GIANT_MIN": "3000"}],
                          ids=["fold_in_scan", "materialise_then_fold", "small_thresholds", "lanes_only", "pieces", "serial", "mid_thresholds"])
-def test_scan_checksum_folds_inside_the_scan(cnr_gpu, cnr_oracle, monkeypatch, env):
-    """Round 5: the hash is folded by the scan itself -- the one-lane parse adds the rows without a reference as it decodes them and writes only the rows
-    some other row copies from; the node numbers, the rows with a reference and the rows of the wave / group classes are added from memory (k_hash_rest).  Every split of
-    the rows between the two (thresholds), every piece size and the old decode-then-fold path give the reference's hashCode (ImmutableGraph.java:757-770) on every range."""
+def test_scan_checksum_folds_inside_the_scan(cnr_oracle, monkeypatch, env):
+    """Round 5: the hash is folded by the scan itself -- the node numbers while the row starts are written, the rows without a reference by the one-lane
+    parse as it decodes them (writing only the rows some other row copies from), the lane class of the copy pass as it merges, the rows of the wave / group classes from
+    memory through their work lists.  Every split of the rows between these (thresholds), every piece size and the old decode-then-fold path give the reference's
+    hashCode (ImmutableGraph.java:757-770) on every range.  (The knobs are read when a handle is created: a handle of its own per case.)"""
+    from webgraph_amd.bvgraph import BVGraph
     og, rp, sc = cnr_oracle
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    n = cnr_gpu.numNodes()
-    assert cnr_gpu.scan_checksum() == (1711395807, 3216152)
+    g = BVGraph.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cnr-2000"))
+    n = g.numNodes()
+    assert g.scan_checksum() == (1711395807, 3216152)
     for lo, hi, h0 in [(0, 1, 7), (3, 4, -1), (0, 2000, 0), (1999, 64001, 12345), (200000, n, -1), (n - 1, n, 5)]:
-        h, a = cnr_gpu.scan_checksum(lo, hi, h0)
+        h, a = g.scan_checksum(lo, hi, h0)
         assert a == rp[hi] - rp[lo]
         assert h == og.scan(lo, hi, want_succ=False, want_hash=True, h0=h0)[3], (lo, hi)
+    g.set_option("hash_materialise", 1)  # the same handle the other way (bvg_set_option on a live handle)
+    assert g.scan_checksum() == (1711395807, 3216152)
+    with pytest.raises(ValueError):
+        g.set_option("no_such_knob", 1)
+    g.close()
 
 
 def test_scans_in_pieces(cnr_gpu, cnr_oracle, monkeypatch):
     """The device-side scans cut a range into pieces of bounded scratch (256 M arcs by default): same answers in 20 pieces."""
-    monkeypatch.setenv("BVGPU_SCAN_PIECE", "170000")
+    cnr_gpu.set_option("scan_piece", 170000)
     n = cnr_gpu.numNodes()
     assert cnr_gpu.scan_checksum() == (1711395807, 3216152)
     whole = cnr_gpu.scan_stats(0, n)
-    monkeypatch.delenv("BVGPU_SCAN_PIECE")
+    cnr_gpu.set_option("scan_piece", 0)
     assert cnr_gpu.scan_stats(0, n) == whole
 
 

@@ -88,7 +88,7 @@ def test_c2_full_size_default_thresholds(c2):
     rowptr, succ, arcs = _device_scan(g)
     assert arcs == C2["m"]
     if not any(k in os.environ for k in ("BVGPU_COOP_MIN", "BVGPU_GIANT_MIN")):
-        assert g.last_thresholds() == (2048, 32768)
+        assert g.last_thresholds() == (2048, 65536)
     orp, osc, oarcs = og.scan_mt()
     assert oarcs == arcs
     assert np.array_equal(rowptr.cpu().numpy(), orp), "rowptr differs from the CPU oracle"
@@ -211,7 +211,7 @@ def test_tiled_cnr_web_shape(tmp_path_factory, cnr_oracle):
     assert arcs == succ.size
     if not any(k in os.environ for k in ("BVGPU_COOP_MIN", "BVGPU_GIANT_MIN")):
         deg = np.diff(rowptr)
-        assert int((deg >= 128).sum()) <= 12288 and g.last_thresholds() == (128, 8192)  # few long rows: all of them go to whole waves
+        assert int((deg >= 128).sum()) <= 12288 and g.last_thresholds() == (128, 32768)  # (cnr-2000 x 30 = 96 M arcs: the group class from 32 768) few long rows: all of them go to whole waves
     assert np.array_equal(d_rowptr.cpu().numpy(), rowptr) and np.array_equal(d_succ.cpu().numpy(), succ)
     h, a = g.scan_checksum()
     assert a == arcs and h == g.csr_hashcode(0, g.numNodes(), d_rowptr.data_ptr(), d_succ.data_ptr(), -1)

@@ -201,7 +201,7 @@ def test_checksum_without_writing_the_lists(tmp_path, monkeypatch):
     a, arcs_a = g.scan_checksum(0, 777, -1)
     b, arcs_b = g.scan_checksum(777, n, a)
     assert b == want and arcs_a + arcs_b == succ.size
-    monkeypatch.setenv("BVGPU_EF_HASH_MATERIALISE", "1")
+    g.set_option("ef_hash_materialise", 1)
     assert g.hashCode() == want
     g.close(); h.close()
 

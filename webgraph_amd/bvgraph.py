@@ -57,7 +57,7 @@ class BvgLabelsInfo(C.Structure):
 EXPORTS = ["bvg_open", "bvg_open_shard", "bvg_clone", "bvg_close", "bvg_info", "bvg_last_error", "bvg_set_stream", "bvg_sync",
            "bvg_outdegrees", "bvg_decode_range", "bvg_decode_range_view", "bvg_host_alloc", "bvg_host_free", "bvg_scan_checksum", "bvg_scan_stats", "bvg_bfs_expand", "bvg_hyperball_step", "bvg_successors_batch", "bvg_csr_hashcode", "bvg_shard_bounds",
            "bvg_parse_properties", "bvg_flags_from_string", "bvg_decode_offsets_host", "bvg_decode_offsets_device", "bvg_labels_open", "bvg_labels_close", "bvg_labels_info",
-           "bvg_labels_last_error", "bvg_labels_parse_properties", "bvg_labels_decode_range", "bvg_labels_decode_lists", "bvg_compress", "bvg_compressed_free", "bvg_compressed_copy", "bvg_store", "bvg_recompress", "bvg_store_ef", "bvg_recompress_ef", "bvg_cache_as_efgraph", "bvg_set_profile", "bvg_get_profile", "bvg_debug_stats", "bvg_last_thresholds"]
+           "bvg_labels_last_error", "bvg_labels_parse_properties", "bvg_labels_decode_range", "bvg_labels_decode_lists", "bvg_compress", "bvg_compressed_free", "bvg_compressed_copy", "bvg_store", "bvg_recompress", "bvg_store_ef", "bvg_recompress_ef", "bvg_cache_as_efgraph", "bvg_set_option", "bvg_set_profile", "bvg_get_profile", "bvg_debug_stats", "bvg_last_thresholds"]
 
 _lib = None
 
@@ -121,6 +121,7 @@ def lib():
         L.bvg_store_ef.argtypes = [C.c_char_p, C.c_int, i32, vp, vp, C.c_int, i32, C.c_int, C.c_int, C.c_char_p, sz]
         L.bvg_recompress_ef.argtypes = [vp, C.c_char_p, i32, C.c_int, C.c_int, C.c_char_p, sz]
         L.bvg_cache_as_efgraph.argtypes = [vp]
+        L.bvg_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
         L.bvg_set_profile.argtypes = [vp, C.c_int]
         L.bvg_get_profile.argtypes = [vp, C.POINTER(C.c_float)]
         L.bvg_last_thresholds.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
@@ -503,6 +504,10 @@ class BVGraph:
         self._check(lib().bvg_set_stream(self._h, hip_stream))
 
     PHASES = ("headers", "scan", "lists", "parse_giant", "parse_big", "parse_short", "copy", "tail")
+
+    def set_option(self, name, value):
+        """A tuning / debug knob of this handle (bvg_set_option): the BVGPU_<NAME> environment variables are only read when a handle is created."""
+        self._check(lib().bvg_set_option(self._h, str(name).encode(), str(value).encode()))
 
     def set_profile(self, on):
         self._check(lib().bvg_set_profile(self._h, 1 if on else 0))

@@ -481,7 +481,7 @@ void encode_free(EncodeOut &o) {
 int encode_device(const Params &p, int32_t n, const int64_t *d_rowptr, const int32_t *d_succ, uint64_t m, EncodeOut &out, std::string &err, hipStream_t st) {
 	out = EncodeOut{};
 	if (p.W < 0 || p.W > ENC_MAX_W) { err = "windowsize above 63 is not supported by the device compressor"; return -3; }
-	const bool trace = getenv("BVGPU_ENC_TRACE") != nullptr;
+	const bool trace = bv_env("BVGPU_ENC_TRACE") != nullptr;
 	const int cyc = p.W + 1;
 	const int64_t npairs = (int64_t)n * cyc;
 	const int64_t nchunks = ((int64_t)n + SEL_CHUNK - 1) / SEL_CHUNK;
@@ -509,9 +509,9 @@ int encode_device(const Params &p, int32_t n, const int64_t *d_rowptr, const int
 	const size_t nn = (size_t)n + 1;
 	if (npairs >= 0xffffffffll) { err = "too many (node, candidate) pairs for one call"; return cleanup(-3); }
 	const bool def = bve::default_codings(p);
-	const int bigBin = getenv("BVGPU_ENC_BIGBIN") ? atoi(getenv("BVGPU_ENC_BIGBIN")) : BIG_BIN; // experiment: 32 = everything lane by lane
-	const int segElems = getenv("BVGPU_ENC_SEGELEMS") ? std::max(1, atoi(getenv("BVGPU_ENC_SEGELEMS"))) : SEG_ELEMS; // tests: short segments
-	const int segBin = getenv("BVGPU_ENC_SEGBIN") ? atoi(getenv("BVGPU_ENC_SEGBIN")) : SEG_BIN; // experiment / tests: 32 = no pair is cut, 8 = every pair the waves take
+	const int bigBin = bv_env("BVGPU_ENC_BIGBIN") ? atoi(bv_env("BVGPU_ENC_BIGBIN")) : BIG_BIN; // experiment: 32 = everything lane by lane
+	const int segElems = bv_env("BVGPU_ENC_SEGELEMS") ? std::max(1, atoi(bv_env("BVGPU_ENC_SEGELEMS"))) : SEG_ELEMS; // tests: short segments
+	const int segBin = bv_env("BVGPU_ENC_SEGBIN") ? atoi(bv_env("BVGPU_ENC_SEGBIN")) : SEG_BIN; // experiment / tests: 32 = no pair is cut, 8 = every pair the waves take
 	if (!alloc((void **)&cost, sizeof(uint32_t) * (size_t)npairs) || !alloc((void **)&best, nn) || !alloc((void **)&refc, sizeof(int32_t) * nn) ||
 	    !alloc((void **)&reclen, sizeof(int32_t) * nn) || !alloc((void **)&offlen, sizeof(int32_t) * nn) || !alloc((void **)&state, sizeof(int32_t) * 2 * (size_t)nchunks * (size_t)(p.W ? p.W : 1)) ||
 	    !alloc((void **)&used, sizeof(int32_t) * (size_t)nchunks * (size_t)(p.W ? p.W : 1)) || !alloc((void **)&sums, sizeof(int64_t) * (size_t)(ns + 1)) ||
@@ -564,7 +564,7 @@ int encode_device(const Params &p, int32_t n, const int64_t *d_rowptr, const int
 		}
 	}
 	bool verifyBad = false; // BVGPU_ENC_VERIFY (tests): the pairs the waves priced, priced again lane by lane
-	if (npairs && getenv("BVGPU_ENC_VERIFY")) {
+	if (npairs && bv_env("BVGPU_ENC_VERIFY")) {
 		unsigned long long *dbg = nullptr, h[49] = { 0 };
 		if (hipMalloc((void **)&dbg, sizeof h) == hipSuccess) {
 			(void)hipMemsetAsync(dbg, 0, sizeof h, st);

@@ -1888,11 +1888,10 @@ void launch_mark_halo(int32_t nh, int32_t cnt, int32_t W, int32_t *outd, uint16_
 	hipLaunchKernelGGL(k_apply_need, dim3(nblk(nh, TPB)), dim3(TPB), 0, st, nh, need, outd, ref);
 }
 
-void launch_scan(const int32_t *in, int64_t n, int64_t *out, int64_t *sums, hipStream_t st, const HashCtx *hx, int32_t lo, int32_t nh) {
+void launch_scan(const int32_t *in, int64_t n, int64_t *out, int64_t *sums, hipStream_t st, const HashCtx *hx, int32_t lo, int32_t nh, long long topTiledMin) {
 	const int64_t nb = n > 0 ? (n + SCAN_TILE - 1) / SCAN_TILE : 1;
 	hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nb), dim3(TPB), 0, st, in, n, sums);
-	const char *eTiled = getenv("BVGPU_SCAN_TOP_TILED_MIN"); // (read per launch: the tests switch it inside one process)
-	const int64_t tiledMin = eTiled ? (int64_t)atoll(eTiled) : (int64_t)SCAN_TOP_TILED_MIN;
+	const int64_t tiledMin = topTiledMin > 0 ? (int64_t)topTiledMin : (int64_t)SCAN_TOP_TILED_MIN;
 	if (nb >= tiledMin) hipLaunchKernelGGL(k_scan_top_tiled, dim3(1), dim3(SCAN_TOP_T), 0, st, sums, nb);
 	else hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(TPB), 0, st, sums, nb);
 	if (hx) hipLaunchKernelGGL(k_scan_apply<true>, dim3((unsigned)nb), dim3(TPB), 0, st, in, n, sums, out, hx, lo, nh);
@@ -2035,18 +2034,16 @@ __global__ void __launch_bounds__(64) k_wait_giants(const int32_t *__restrict__ 
 	}
 }
 void launch_wait_giants(const int32_t *ctl, int giantGroups, hipStream_t st) {
-	const char *eWait = getenv("BVGPU_WAIT_GIANTS"); // (read per launch)
-	const bool on = !eWait || atoi(eWait) != 0;
-	if (on) hipLaunchKernelGGL(k_wait_giants, dim3(1), dim3(64), 0, st, ctl, (int32_t)giantGroups);
+	hipLaunchKernelGGL(k_wait_giants, dim3(1), dim3(64), 0, st, ctl, (int32_t)giantGroups);
 }
 
 void launch_parse_big(const GraphDev &g, int def, const RangeView &v, const int32_t *biglist, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap,
-                      int waves, int giantGroups, int *err, hipStream_t stGiant, hipStream_t stBig) {
+                      int waves, int giantGroups, int *err, hipStream_t stGiant, hipStream_t stBig, bool waitGiants) {
 	if (v.cnt <= 0) return;
 	if (def == 1) hipLaunchKernelGGL((k_parse_big<1, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
 	else if (def == 2) hipLaunchKernelGGL((k_parse_big<2, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
 	else hipLaunchKernelGGL((k_parse_big<0, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
-	if (stBig != stGiant) launch_wait_giants(ctl, giantGroups, stBig);
+	if (stBig != stGiant && waitGiants) launch_wait_giants(ctl, giantGroups, stBig);
 	if (def == 1) hipLaunchKernelGGL((k_parse_big<1, 1, RangeView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
 	else if (def == 2) hipLaunchKernelGGL((k_parse_big<2, 1, RangeView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
 	else hipLaunchKernelGGL((k_parse_big<0, 1, RangeView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);

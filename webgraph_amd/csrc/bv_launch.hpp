@@ -5,6 +5,16 @@
 
 #include <string>
 
+#include <cstdlib>
+// the only door to the environment (debug / tuning knobs; see apply_option in bvgpu_api.cpp): -DBVGPU_NO_ENV closes it
+inline const char *bv_env(const char *name) {
+#if defined(BVGPU_NO_ENV)
+	(void)name; return nullptr;
+#else
+	return getenv(name);
+#endif
+}
+
 namespace bv {
 
 // work-list keys (bv_kernels.hip, "work lists")
@@ -70,7 +80,7 @@ struct BatchView {
 void launch_headers(const GraphDev &g, int def, int32_t lo, int32_t cnt, int32_t *outd, uint16_t *ref, int *err, hipStream_t st, int32_t *part = nullptr, uint8_t *mark = nullptr); // mark[cnt] (zeroed): set for every referent
 int64_t headers_blocks(int32_t cnt); // part: 5 counts per block of k_headers, [5][headers_blocks(cnt)] (input of k_pick_coop)
 void launch_mark_halo(int32_t nh, int32_t cnt, int32_t W, int32_t *outd, uint16_t *ref, uint8_t *need, int *err, hipStream_t st);
-void launch_scan(const int32_t *in, int64_t n, int64_t *out, int64_t *sums, hipStream_t st, const HashCtx *hx = nullptr, int32_t lo = 0, int32_t nh = 0); // hx: the node numbers of slots >= nh are added to the hash (HashCtx)
+void launch_scan(const int32_t *in, int64_t n, int64_t *out, int64_t *sums, hipStream_t st, const HashCtx *hx = nullptr, int32_t lo = 0, int32_t nh = 0, long long topTiledMin = -1); // topTiledMin: block sums from which the top level runs tiled (-1: default) // hx: the node numbers of slots >= nh are added to the hash (HashCtx)
 int64_t scan_num_sums(int64_t n);
 void launch_rebase(int32_t nh, int32_t cnt, const int64_t *rowstart, int64_t *out, hipStream_t st);
 bool launch_query_mark(const int32_t *nodes, int64_t q, int32_t n, int32_t *outd, uint16_t *ref, uint8_t *need, int32_t *qoutd, int passes, int32_t *changed, int *err, hipStream_t st);
@@ -88,7 +98,7 @@ constexpr int PICK_LEVELS = 7; // outdegree classes counted by k_headers / k_pic
 constexpr int CTL_INTS = 32, CTL_COOP = 22, CTL_SEG = 24, CTL_GIANT_STARTED = 31, CTL_TOTAL_INTS = CTL_INTS; // control block (bv_kernels.hip); ctl[CTL_SEG], ctl[CTL_SEG + 2]: records the segment pipeline hands to the cooperative kernel, head of that queue
 void launch_classify(int32_t cnt, const int32_t *outd, const int32_t *coopPtr, int32_t coopMin, int32_t giantMin, int32_t *biglist, int32_t *giantlist, int32_t giantCap, int32_t *ctl, hipStream_t st);
 void launch_parse_big(const GraphDev &g, int def, const RangeView &v, const int32_t *biglist, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap,
-                      int waves, int giantGroups, int *err, hipStream_t stGiant, hipStream_t stBig);
+                      int waves, int giantGroups, int *err, hipStream_t stGiant, hipStream_t stBig, bool waitGiants = true);
 constexpr int ARENA_ENTRY_BYTES = 16;
 void launch_build_lists(const GraphDev &g, const RangeView &v, uint64_t giantBits, int32_t noBin, int32_t *depth, uint16_t *key16, int32_t *hist, int32_t *keyBase, int32_t *cursor,
                         int32_t *list, int32_t *giantlist, int32_t giantCap, int32_t *ctl, int32_t *maxdepth, hipStream_t st,

@@ -208,7 +208,7 @@ int store_ef_impl(const char *basename, int device, int32_t n, const int64_t *d_
 	auto release = [&]() { for (void *q : { (void *)d_words, (void *)d_reclen, (void *)d_off, (void *)d_ow }) if (q) (void)hipFree(q); };
 	const auto t0 = std::chrono::steady_clock::now();
 	int rc = bv::ef_encode_device(n, d_rowptr, d_succ, (uint64_t)upper_bound, log2_quantum, &d_words, &nwords, &bits, &d_reclen, &d_off, nullptr);
-	if (getenv("BVGPU_ENC_TRACE")) fprintf(stderr, "[bvgpu enc] EFGraph: CSR in HBM -> stream in HBM %.3f ms (%llu bits, rc %d)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), (unsigned long long)bits, rc);
+	if (bv_env("BVGPU_ENC_TRACE")) fprintf(stderr, "[bvgpu enc] EFGraph: CSR in HBM -> stream in HBM %.3f ms (%llu bits, rc %d)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), (unsigned long long)bits, rc);
 	if (rc) {
 		err = rc == -1 ? "successor lists must be strictly increasing, non-negative and below the upper bound" : rc == -3 ? "a record of 2^31 bits or more" : rc == -5 ? "device allocation failed" : "the EFGraph kernels failed";
 		return rc == -1 ? BVG_EARG : rc == -3 ? BVG_EUNSUPPORTED : rc == -5 ? BVG_ENOMEM : BVG_EHIP;

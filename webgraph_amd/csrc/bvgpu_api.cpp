@@ -30,7 +30,7 @@ struct DevBuf {
 		if (p) (void)hipFree(p);
 		p = nullptr; cap = 0;
 		// BVGPU_EXACT_ALLOC=1 (tests): no slack, so that scripts/guard_alloc.cpp's unmapped page sits right behind what was asked for
-		static const bool exact = [] { const char *e = getenv("BVGPU_EXACT_ALLOC"); return e && atoi(e) != 0; }();
+		static const bool exact = [] { const char *e = bv_env("BVGPU_EXACT_ALLOC"); return e && atoi(e) != 0; }();
 		size_t want = exact ? bytes : bytes + bytes / 8 + 256;
 		if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return false; }
 		cap = want;
@@ -145,6 +145,9 @@ struct bvg_graph {
 	int parse_windows = 1; // BVGPU_PARSE_WINDOWS=0: the parse list is sorted by work bin over the whole range
 	int copy_mid_min = 128; // rows with at least this many successors (and fewer than 1024) are copied by one wave each
 	int32_t coop_min = 2048, giant_min = 32768;                         // thresholds on the outdegree (BVGPU_COOP_MIN / BVGPU_GIANT_MIN)
+	long long scan_top_tiled_min = -1, scan_piece = 0; // (-1 / 0: the defaults of bv_kernels.hip / scan_piece_arcs)
+	bool wait_giants = true, hash_materialise = false, ef_hash_materialise = false, want_stats = false, trace_retry = false, trace_err = false, trace_host = false;
+	int dbg = 0;
 	bool adaptive = true, adaptive_giant = true;                        // smaller jobs lower them (pick_thresholds) unless a knob pins them (each knob pins its own threshold)
 	int coop_waves = 4096, giant_groups = 256;
 	DevBuf copyq; // rows the copy pass merges with a group / a wave each (all levels), filled while the level lists are built
@@ -194,7 +197,7 @@ namespace {
 
 bv::GraphDev graph_dev0(const Staged &s);
 bool copy_vec(const bvg_graph *g);
-bv::GraphDev graph_dev_h(const bvg_graph *g, const Staged &s) { bv::GraphDev d = graph_dev0(s); d.stats = (unsigned long long *)g->stats.p; d.dbg = getenv("BVGPU_DBG") ? atoi(getenv("BVGPU_DBG")) : 0; return d; }
+bv::GraphDev graph_dev_h(const bvg_graph *g, const Staged &s) { bv::GraphDev d = graph_dev0(s); d.stats = (unsigned long long *)g->stats.p; d.dbg = g->dbg; return d; }
 
 int fail(const bvg_graph *g, int code, const std::string &msg) { if (g) g->err = msg; return code; }
 
@@ -226,6 +229,58 @@ int dev_err_to_status(int e) {
 	return BVG_OK;
 }
 
+// ---- tuning and debug knobs of a handle.  One table: bvg_set_option(name, value) sets a knob of a live handle, and init_handle applies the environment's
+// BVGPU_<NAME> through the same function, once per handle -- nothing reads the environment per launch.  -DBVGPU_NO_ENV compiles the environment out (bv_env):
+// a release build has the defaults and bvg_set_option only.  Every knob is a choice of speed, never of results (tests/test_gpu_scan.py::test_tuning_knobs_keep_parity).
+int apply_option(bvg_graph *g, const std::string &name, const char *value) {
+	const long long v = value ? atoll(value) : 0;
+	const int iv = (int)std::max<long long>(std::min<long long>(v, 0x7fffffff), -0x7fffffff);
+	if (name == "coop_min") { g->coop_min = std::max(1, iv); g->adaptive = false; }   // 0x7fffffff disables the cooperative path
+	else if (name == "giant_min") { g->giant_min = std::max(1, iv); g->adaptive_giant = false; }
+	else if (name == "adaptive") { g->adaptive = g->adaptive_giant = iv != 0; }        // 1: both thresholds chosen per job again
+	else if (name == "coop_waves") g->coop_waves = std::max(1, iv);
+	else if (name == "giant_groups") g->giant_groups = std::max(1, iv);
+	else if (name == "level_blocks") g->level_blocks = std::max(1, iv);
+	else if (name == "copy_big") g->copy_big = iv;
+	else if (name == "parse_windows") g->parse_windows = iv;
+	else if (name == "tile") g->tile = iv;
+	else if (name == "seg") g->seg = iv;
+	else if (name == "seg_hub_min") g->seg_hub_min = std::max(1, iv);
+	else if (name == "seg_blocks") g->seg_blocks = std::max(1, iv);
+	else if (name == "lists_on_b") g->lists_on_b = iv;
+	else if (name == "walk_tables") g->walk_tables = iv;
+	else if (name == "copy_vec") g->copy_vec = iv;
+	else if (name == "prewalk") g->prewalk = iv;
+	else if (name == "prewalk_long") g->prewalk_long = iv;
+	else if (name == "prewalk_blocks") g->prewalk_blocks = std::max(1, iv);
+	else if (name == "copy_mid_min") g->copy_mid_min = std::min(std::max(0, iv), 1024); // 0: no wave-per-row copy
+	else if (name == "overlap") g->overlap = iv != 0;
+	else if (name == "halo_min") g->halo_min = (size_t)std::max(4, iv);
+	else if (name == "batch_dense") g->batch_dense = std::max(0, iv);
+	else if (name == "scan_top_tiled_min") g->scan_top_tiled_min = v > 0 ? v : -1;
+	else if (name == "wait_giants") g->wait_giants = iv != 0;
+	else if (name == "hash_materialise") g->hash_materialise = iv != 0;
+	else if (name == "ef_hash_materialise") g->ef_hash_materialise = iv != 0;
+	else if (name == "scan_piece") g->scan_piece = v > 0 ? v : 0;
+	else if (name == "dbg") g->dbg = iv;
+	else if (name == "stats") g->want_stats = iv != 0; // (the counters are allocated by init_handle: environment only)
+	else if (name == "trace_retry") g->trace_retry = iv != 0;
+	else if (name == "trace_err") g->trace_err = iv != 0;
+	else if (name == "trace_host") g->trace_host = iv != 0;
+	else return BVG_EARG;
+	return BVG_OK;
+}
+const char *const OPTION_NAMES[] = { "coop_min", "giant_min", "coop_waves", "giant_groups", "level_blocks", "copy_big", "parse_windows", "tile", "seg", "seg_hub_min", "seg_blocks", "lists_on_b",
+	"walk_tables", "copy_vec", "prewalk", "prewalk_long", "prewalk_blocks", "copy_mid_min", "overlap", "halo_min", "batch_dense", "scan_top_tiled_min", "wait_giants", "hash_materialise",
+	"ef_hash_materialise", "scan_piece", "dbg", "stats", "trace_retry", "trace_err", "trace_host" };
+void options_from_env(bvg_graph *g) {
+	for (const char *n : OPTION_NAMES) {
+		std::string e = "BVGPU_";
+		for (const char *c = n; *c; c++) e += (char)toupper((unsigned char)*c);
+		if (const char *val = bv_env(e.c_str())) (void)apply_option(g, n, val);
+	}
+}
+
 int init_handle(bvg_graph *g) {
 	HIPCHK(g, hipSetDevice(g->st->device));
 	HIPCHK(g, hipStreamCreateWithFlags(&g->own, hipStreamNonBlocking));
@@ -234,29 +289,9 @@ int init_handle(bvg_graph *g) {
 	if (!g->small.need(sizeof(Small))) return fail(g, BVG_ENOMEM, "device allocation failed");
 	const int mr = g->st->info.max_ref_count;
 	g->levels_hint = mr < 1 ? 1 : (mr > 8 ? 8 : mr);
-	if (const char *e = getenv("BVGPU_COOP_MIN")) { g->coop_min = std::max(1, atoi(e)); g->adaptive = false; }   // 0x7fffffff disables the cooperative path
-	if (const char *e = getenv("BVGPU_GIANT_MIN")) { g->giant_min = std::max(1, atoi(e)); g->adaptive_giant = false; }
-	if (const char *e = getenv("BVGPU_COOP_WAVES")) g->coop_waves = std::max(1, atoi(e));
-	if (const char *e = getenv("BVGPU_GIANT_GROUPS")) g->giant_groups = std::max(1, atoi(e));
 	if (!g->coopctl.need(bv::CTL_TOTAL_INTS * sizeof(int32_t)) || !g->keys.need(3 * (bv::NKEYS + 1) * sizeof(int32_t))) return fail(g, BVG_ENOMEM, "device allocation failed");
 	HIPCHK(g, hipMemset(g->coopctl.p, 0, bv::CTL_TOTAL_INTS * sizeof(int32_t))); // (k_pick_coop leaves its counters zeroed for the next job)
-	if (const char *e = getenv("BVGPU_LEVEL_BLOCKS")) g->level_blocks = std::max(1, atoi(e));
-	if (const char *e = getenv("BVGPU_COPY_BIG")) g->copy_big = atoi(e);
-	if (const char *e = getenv("BVGPU_PARSE_WINDOWS")) g->parse_windows = atoi(e);
-	if (const char *e = getenv("BVGPU_TILE")) g->tile = atoi(e);
-	if (const char *e = getenv("BVGPU_SEG")) g->seg = atoi(e);
-	if (const char *e = getenv("BVGPU_SEG_HUB_MIN")) g->seg_hub_min = std::max(1, atoi(e));
-	if (const char *e = getenv("BVGPU_SEG_BLOCKS")) g->seg_blocks = std::max(1, atoi(e));
-	if (const char *e = getenv("BVGPU_LISTS_ON_B")) g->lists_on_b = atoi(e);
-	if (const char *e = getenv("BVGPU_WALK_TABLES")) g->walk_tables = atoi(e);
-	if (const char *e = getenv("BVGPU_COPY_VEC")) g->copy_vec = atoi(e);
-	if (const char *e = getenv("BVGPU_PREWALK")) g->prewalk = atoi(e);
-	if (const char *e = getenv("BVGPU_PREWALK_LONG")) g->prewalk_long = atoi(e);
-	if (const char *e = getenv("BVGPU_PREWALK_BLOCKS")) g->prewalk_blocks = std::max(1, atoi(e));
-	if (const char *e = getenv("BVGPU_COPY_MID_MIN")) g->copy_mid_min = std::min(std::max(0, atoi(e)), 1024); // 0: no wave-per-row copy
-	if (const char *e = getenv("BVGPU_OVERLAP")) g->overlap = atoi(e) != 0;
-	if (const char *e = getenv("BVGPU_HALO_MIN")) g->halo_min = (size_t)std::max(4, atoi(e));
-	if (const char *e = getenv("BVGPU_BATCH_DENSE")) g->batch_dense = std::max(0, atoi(e));
+	options_from_env(g); // every tuning / debug knob of a handle: read here ONCE (and never per launch), or set later through bvg_set_option
 	HIPCHK(g, hipStreamCreateWithFlags(&g->sideA, hipStreamNonBlocking));
 	HIPCHK(g, hipStreamCreateWithFlags(&g->sideB, hipStreamNonBlocking));
 	HIPCHK(g, hipStreamCreateWithFlags(&g->sideC, hipStreamNonBlocking));
@@ -274,7 +309,7 @@ int init_handle(bvg_graph *g) {
 	HIPCHK(g, hipEventCreateWithFlags(&g->evM, hipEventDisableTiming));
 	HIPCHK(g, hipEventCreateWithFlags(&g->evH, hipEventDisableTiming));
 	HIPCHK(g, hipEventCreateWithFlags(&g->evL, hipEventDisableTiming));
-	if (const char *e = getenv("BVGPU_STATS")) if (atoi(e)) { if (!g->stats.need(64 * sizeof(unsigned long long))) return fail(g, BVG_ENOMEM, "device allocation failed"); HIPCHK(g, hipMemset(g->stats.p, 0, 512)); }
+	if (g->want_stats) { if (!g->stats.need(64 * sizeof(unsigned long long))) return fail(g, BVG_ENOMEM, "device allocation failed"); HIPCHK(g, hipMemset(g->stats.p, 0, 512)); }
 	return BVG_OK;
 }
 
@@ -344,7 +379,7 @@ int enqueue_structure(bvg_graph *g, int32_t from, int32_t to, int32_t nh, bv::Ra
 	}
 	HIPCHK(g, hipEventRecord(g->evHdr, g->stream)); // outdegrees and references are final: the parse list can be built while the scan runs
 	mark(g, 1);
-	bv::launch_scan(v.outd, cnt, v.rowstart, g->sums.as<int64_t>(), g->stream, g->hash_job ? g->hashctx.as<bv::HashCtx>() : nullptr, lo, nh);
+	bv::launch_scan(v.outd, cnt, v.rowstart, g->sums.as<int64_t>(), g->stream, g->hash_job ? g->hashctx.as<bv::HashCtx>() : nullptr, lo, nh, g->scan_top_tiled_min);
 	mark(g, 2);
 	return BVG_OK;
 }
@@ -396,7 +431,7 @@ int finish_pending(bvg_graph *g, uint64_t *arcs_out) {
 	int rc = fetch_small(g);
 	if (rc) { g->pend = Pending{}; return rc; }
 	if (g->pend.optimistic && (g->h_small->err & (bv::E_ESCAPED | bv::E_HALO))) {
-		if (getenv("BVGPU_TRACE_RETRY")) fprintf(stderr, "[bvgpu] optimistic halo missed (err %d): repeating [%d, %d)\n", g->h_small->err, g->pend.from, g->pend.to);
+		if (g->trace_retry) fprintf(stderr, "[bvgpu] optimistic halo missed (err %d): repeating [%d, %d)\n", g->h_small->err, g->pend.from, g->pend.to);
 		// the halo of this sub-range was deeper or larger than guessed: once more, sized with a host round trip
 		const Pending p = g->pend;
 		g->pend = Pending{};
@@ -433,7 +468,7 @@ int finish_pending(bvg_graph *g, uint64_t *arcs_out) {
 	if (arcs_out) *arcs_out = g->last_arcs;
 	if (g->h_small->err) {
 		const int st = dev_err_to_status(g->h_small->err);
-		if (getenv("BVGPU_TRACE_ERR")) fprintf(stderr, "[bvgpu] range job: device error bits 0x%x\n", g->h_small->err);
+		if (g->trace_err) fprintf(stderr, "[bvgpu] range job: device error bits 0x%x\n", g->h_small->err);
 		return fail(g, st, st == BVG_ECAP ? "successor buffer too small" : st == BVG_ESTATE ? "reference incompatible with the window size" : "malformed or unsupported bit stream");
 	}
 	return BVG_OK;
@@ -606,7 +641,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		// the long records first on both side streams: giants on B, the wave class on A ...
 		if (ovl && coop) {
 			HIPCHK(g, hipStreamWaitEvent(g->sideA, g->evC, 0));
-			bv::launch_parse_big(gd, s.def, v, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, g->giant_groups, derr, side_b(g), g->sideA); // (giants, big)
+			bv::launch_parse_big(gd, s.def, v, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, g->giant_groups, derr, side_b(g), g->sideA, g->wait_giants); // (giants, big)
 			if (!segReady) HIPCHK(g, hipEventRecord(g->evB, side_b(g))); // (else: behind the segment pipeline's chain, below)
 		}
 		// ... then, behind the wave class, the chain depth of every record + per-level lists (node order inside a level) +
@@ -671,7 +706,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 				bv::launch_seg_chain(gd, s.def, v, giantCap, segScap, g->segbuf.p, g->arena.p, arenaCap, ctl, g->seg_blocks, derr, stChain);
 				if (ovl) HIPCHK(g, hipEventRecord(g->evB, stChain));
 			}
-			if (ovl && coop) { HIPCHK(g, hipStreamWaitEvent(g->stream, g->evC, 0)); bv::launch_wait_giants(ctl, g->giant_groups, g->stream); } // (the giants first: k_wait_giants)
+			if (ovl && coop) { HIPCHK(g, hipStreamWaitEvent(g->stream, g->evC, 0)); if (g->wait_giants) bv::launch_wait_giants(ctl, g->giant_groups, g->stream); } // (the giants first: k_wait_giants)
 			bv::launch_parse_list(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, g->level_blocks, derr, g->stream, g->arena.p, arenaCap);
 		}
 		if (ovl) {
@@ -1018,7 +1053,7 @@ static int open_impl(const char *basename, int device, int part, int parts, bvg_
 	// planning; delta-coded ones, BVGPU_OFFSETS=host, or a stream the device decoder rejects take the host decoder
 	// (OffsetsLongIterator, BVG:907-935), which also produces the precise error
 	bool onDevice = false;
-	const char *offEnv = getenv("BVGPU_OFFSETS");
+	const char *offEnv = bv_env("BVGPU_OFFSETS");
 	if ((in.offset_coding == BVG_GAMMA || in.offset_coding == BVG_DELTA) && !offs.empty() && !(offEnv && strcmp(offEnv, "host") == 0)) {
 		const uint64_t ow = (offs.size() + 3) / 4;
 		uint32_t *d_ow = nullptr;
@@ -1093,7 +1128,7 @@ static int open_impl(const char *basename, int device, int part, int parts, bvg_
 				if (e == hipSuccess) { bv::launch_seg_sizing(st->d_offsets, st->stage_lo, n, (const int32_t *)p_outd, (const uint16_t *)p_ref, (unsigned long long *)p_rs, nullptr); e = hipMemcpy(five, p_rs, sizeof(five), hipMemcpyDeviceToHost); }
 				if (e == hipSuccess) { st->seg_long_records = (int64_t)five[0]; st->seg_long_bits = (int64_t)five[1]; st->max_outdegree = (int64_t)five[2]; st->lane_rows = (int64_t)five[3]; st->lane_ids = (int64_t)five[4];
 					for (int k = 0; k < bv::SIZING_OCTAVES; k++) { st->oct_recs[k] = (int64_t)five[8 + 2 * k]; st->oct_arcs[k] = (int64_t)five[9 + 2 * k]; }
-					if (getenv("BVGPU_TRACE_HIST")) for (int k = 0; k < bv::SIZING_OCTAVES; k++) if (st->oct_recs[k]) fprintf(stderr, "[bvgpu] outdegree >= %d: %lld records, %lld arcs\n", 128 << k, (long long)st->oct_recs[k], (long long)st->oct_arcs[k]); }
+					if (bv_env("BVGPU_TRACE_HIST")) for (int k = 0; k < bv::SIZING_OCTAVES; k++) if (st->oct_recs[k]) fprintf(stderr, "[bvgpu] outdegree >= %d: %lld records, %lld arcs\n", 128 << k, (long long)st->oct_recs[k], (long long)st->oct_arcs[k]); }
 			}
 		}
 		for (void *q : { p_outd, p_ref, p_rs, p_sums, p_err, p_part }) if (q) (void)hipFree(q);
@@ -1186,6 +1221,16 @@ extern "C" int bvg_set_stream(bvg_t *g, void *hip_stream) {
 	if (g->pend.active) { int rc = finish_pending(g, nullptr); if (rc) return rc; }
 	g->user = (hipStream_t)hip_stream;
 	return BVG_OK;
+}
+
+extern "C" int bvg_set_option(bvg_t *g, const char *name, const char *value) {
+	if (!g || !name) return BVG_EARG;
+	if (g->pend.active) { int rc = finish_pending(g, nullptr); if (rc) return rc; }
+	std::string n(name);
+	for (char &c : n) c = (char)tolower((unsigned char)c);
+	if (n.rfind("bvgpu_", 0) == 0) n = n.substr(6);
+	const int rc = apply_option(g, n, value);
+	return rc ? fail(g, rc, "unknown option: " + n) : BVG_OK;
 }
 
 extern "C" int bvg_set_profile(bvg_t *g, int enable) {
@@ -1311,10 +1356,7 @@ std::vector<int32_t> plan_chunks_by_bits(const Staged &s, int32_t from, int32_t 
 }
 
 // Arcs per piece of the scans that keep their rows on the device (checksum, statistics).  BVGPU_SCAN_PIECE: tests only.
-int64_t scan_piece_arcs() {
-	if (const char *e = getenv("BVGPU_SCAN_PIECE")) { const long long v = atoll(e); if (v > 0) return (int64_t)v; }
-	return (int64_t)256 << 20;
-}
+int64_t scan_piece_arcs(const bvg_graph *g) { return g->scan_piece > 0 ? (int64_t)g->scan_piece : (int64_t)256 << 20; }
 
 // Host-output scan in ONE pass: the structure (outdegrees, CSR row starts) of the whole range first -- that is the
 // rowptr the caller gets and the exact chunk plan --, then the successors chunk by chunk: chunk k leaves over PCIe on the
@@ -1323,7 +1365,7 @@ int host_scan(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_h, int32_t
 	const Staged &s = *g->st;
 	HIPCHK(g, hipSetDevice(s.device));
 	const size_t nrow = (size_t)(to - from) + 1;
-	static const bool trace = getenv("BVGPU_TRACE_HOST") != nullptr;
+	const bool trace = g->trace_host;
 	const auto t0 = std::chrono::steady_clock::now();
 	auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
 	if (!g->stage_rowptr.need(sizeof(int64_t) * nrow)) return fail(g, BVG_ENOMEM, "staging allocation failed");
@@ -1451,18 +1493,17 @@ extern "C" int bvg_scan_checksum(bvg_t *g, int32_t from, int32_t to, int32_t *ha
 	const Staged &s = *g->st;
 	if (from < 0 || from > s.info.nodes || to < from || to > s.info.nodes) return fail(g, BVG_EARG, "node range out of bounds"); // BVG:1165
 	HIPCHK(g, hipSetDevice(s.device));
-	if (s.info.format == BVG_FORMAT_EF && !getenv("BVGPU_EF_HASH_MATERIALISE")) return ef_scan_checksum(g, from, to, hash_io, arcs_out); // (the knob: the decode-then-fold path below, for comparison)
+	if (s.info.format == BVG_FORMAT_EF && !g->ef_hash_materialise) return ef_scan_checksum(g, from, to, hash_io, arcs_out); // (the knob: the decode-then-fold path below, for comparison)
 	// The rows never reach the caller: they are decoded piece by piece into one scratch buffer and folded into the running
 	// hash there.  Pieces of <= 256 M arcs (1 GB of scratch): smaller ones that would stay in the Infinity Cache (32 M arcs)
 	// cost more in per-call set-up than they save (C2: 12.2 ms in 7 pieces, 4 ms in one).
-	const std::vector<int32_t> cut = plan_chunks_by_bits(s, from, to, scan_piece_arcs());
+	const std::vector<int32_t> cut = plan_chunks_by_bits(s, from, to, scan_piece_arcs(g));
 	uint64_t total = 0;
 	int32_t h = *hash_io;
 	// Since round 5 the fold is part of the scan (bv::HashCtx): the one-lane parse adds the rows without a reference to the sum as it decodes them and writes only
 	// those that a row of the piece copies from; k_hash_rest adds the node numbers and the rows that are in memory anyway.  BVGPU_HASH_MATERIALISE=1: decode every
 	// row, then fold from memory (round 2's path, kept for comparison and for the tests).
-	const char *eMat = getenv("BVGPU_HASH_MATERIALISE"); // (read per call: the tests switch it)
-	const bool materialise = (eMat && atoi(eMat) != 0) || s.info.format == BVG_FORMAT_EF; // (an EFGraph gets here only through BVGPU_EF_HASH_MATERIALISE: the fold of bv_ef.hip is the other path)
+	const bool materialise = g->hash_materialise || s.info.format == BVG_FORMAT_EF; // (an EFGraph gets here only through BVGPU_EF_HASH_MATERIALISE: the fold of bv_ef.hip is the other path)
 	for (size_t k = 0; k + 1 < cut.size(); k++) {
 		const int32_t a = cut[k], e = cut[k + 1];
 		if (e == a) continue;
@@ -1725,7 +1766,7 @@ extern "C" int bvg_scan_stats(bvg_t *g, int32_t from, int32_t to, bvg_scan_stats
 	StatsHost h{};
 	h.min_key = ~0ull;
 	HIPCHK(g, hipMemcpy(g->statsbuf.p, &h, sizeof(h), hipMemcpyHostToDevice));
-	const std::vector<int32_t> cut = plan_chunks_by_bits(s, from, to, scan_piece_arcs());
+	const std::vector<int32_t> cut = plan_chunks_by_bits(s, from, to, scan_piece_arcs(g));
 	for (size_t k = 0; k + 1 < cut.size(); k++) {
 		const int32_t a = cut[k], e = cut[k + 1];
 		if (e == a) continue;
@@ -1768,7 +1809,7 @@ extern "C" int bvg_hyperball_step(bvg_t *g, int32_t from, int32_t to, int log2m,
 	*changed = 0;
 	if (!g->bfs_ctr.need(sizeof(unsigned long long))) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
 	HIPCHK(g, hipMemset(g->bfs_ctr.p, 0, sizeof(unsigned long long)));
-	const std::vector<int32_t> cut = plan_chunks_by_bits(s, from, to, scan_piece_arcs());
+	const std::vector<int32_t> cut = plan_chunks_by_bits(s, from, to, scan_piece_arcs(g));
 	for (size_t k = 0; k + 1 < cut.size(); k++) {
 		const int32_t a = cut[k], e = cut[k + 1];
 		if (e == a) continue;
