@@ -2177,15 +2177,15 @@ void launch_parse_listed(const GraphDev &g, int def, const RangeView &v, const i
 	else hipLaunchKernelGGL((k_parse_big<0, 1, RangeView>), dim3(waves), dim3(64), 0, st, g, v, list, ctl, which, (IvEntry *)arena, arenaCap, err);
 }
 
-void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, void *arena, int64_t arenaCap) {
+void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, void *arena, int64_t arenaCap, int32_t keyLo, int32_t keyHi) {
 	if (v.cnt <= 0) return;
 	blocks = (int)std::min<int64_t>(blocks, nblk(v.cnt, TPB)); // (a thread per record at most)
 	IvEntry *a = (IvEntry *)arena;
-	if (def == 1 && v.hx) hipLaunchKernelGGL((k_parse_list<1, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
-	else if (def == 2 && v.hx) hipLaunchKernelGGL((k_parse_list<2, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
-	else if (def == 1) hipLaunchKernelGGL(k_parse_list<1>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
-	else if (def == 2) hipLaunchKernelGGL(k_parse_list<2>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
-	else hipLaunchKernelGGL(k_parse_list<0>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, 0, NKEYS, a, arenaCap, err);
+	if (def == 1 && v.hx) hipLaunchKernelGGL((k_parse_list<1, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, keyLo, keyHi, a, arenaCap, err);
+	else if (def == 2 && v.hx) hipLaunchKernelGGL((k_parse_list<2, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, keyLo, keyHi, a, arenaCap, err);
+	else if (def == 1) hipLaunchKernelGGL(k_parse_list<1>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, keyLo, keyHi, a, arenaCap, err);
+	else if (def == 2) hipLaunchKernelGGL(k_parse_list<2>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, keyLo, keyHi, a, arenaCap, err);
+	else hipLaunchKernelGGL(k_parse_list<0>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, keyLo, keyHi, a, arenaCap, err);
 }
 
 } // namespace bv

@@ -16,6 +16,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <unistd.h>
 
 namespace {
 
@@ -105,6 +106,19 @@ bool write_bytes(const std::string &path, const std::vector<uint8_t> &b) {
 	return fclose(f) == 0 && ok;
 }
 
+// The three files of a graph appear together or not at all: each is written next to its place (<file>.tmp.<pid>) and renamed into it once all three are complete,
+// .properties last -- a loader starts from it (BVG:1516-1530), so a store that dies half-way leaves the old graph, or none, never a new .graph with old .offsets.
+struct AtomicTriple {
+	std::string base, tag;
+	explicit AtomicTriple(const std::string &b) : base(b), tag(".tmp." + std::to_string((long long)getpid())) {}
+	std::string tmp(const char *ext) const { return base + ext + tag; }
+	bool commit() const {
+		for (const char *ext : { ".graph", ".offsets", ".properties" }) if (rename(tmp(ext).c_str(), (base + ext).c_str()) != 0) { discard(); return false; }
+		return true;
+	}
+	void discard() const { for (const char *ext : { ".graph", ".offsets", ".properties" }) (void)remove(tmp(ext).c_str()); }
+};
+
 } // namespace
 
 extern "C" int bvg_compress(int device, int32_t n, const int64_t *rowptr, const int32_t *succ, int in_flags, int window, int max_ref_count, int min_interval, int zeta_k,
@@ -162,12 +176,13 @@ extern "C" int bvg_store(const char *basename, int device, int32_t n, const int6
 	const bvg_store_stats_t st = c.stats;
 	bvg_compressed_free(&c);
 	const std::string base(basename);
-	if (!write_bytes(base + ".graph", graph) || !write_bytes(base + ".offsets", offs)) return sfail(errbuf, errlen, BVG_EIO, "cannot write " + base + ".graph / .offsets");
+	const AtomicTriple files(base);
+	if (!write_bytes(files.tmp(".graph"), graph) || !write_bytes(files.tmp(".offsets"), offs)) { files.discard(); return sfail(errbuf, errlen, BVG_EIO, "cannot write " + base + ".graph / .offsets"); }
 	const bvprops::Counters cnt{ st.written_bits, st.bits_outdegrees, st.bits_references, st.bits_blocks, st.bits_intervals, st.bits_residuals,
 	                             st.copied_arcs, st.intervalised_arcs, st.residual_arcs, st.tot_ref, st.tot_dist };
 	const int resCoding = (flags >> 8) & 0xF;
-	if (!bvprops::write(base + ".properties", n, m, window, max_ref_count, min_interval, zeta_k, resCoding == 0 || resCoding == bve::C_ZETA, flags, cnt))
-		return sfail(errbuf, errlen, BVG_EIO, "cannot write " + base + ".properties");
+	if (!bvprops::write(files.tmp(".properties"), n, m, window, max_ref_count, min_interval, zeta_k, resCoding == 0 || resCoding == bve::C_ZETA, flags, cnt) || !files.commit())
+		{ files.discard(); return sfail(errbuf, errlen, BVG_EIO, "cannot write " + base + ".properties"); }
 	if (stats) *stats = st;
 	return BVG_OK;
 }
@@ -225,8 +240,9 @@ int store_ef_impl(const char *basename, int device, int32_t n, const int64_t *d_
 	uint64_t bitsOutd = 0;
 	for (int32_t x = 0; x < n; x++) bitsOutd += 2 * (uint64_t)(63 - __builtin_clzll((unsigned long long)(rp[(size_t)x + 1] - rp[(size_t)x] + 1))) + 1;
 	const std::string base(basename);
-	if (!write_bytes(base + ".graph", graph) || !write_bytes(base + ".offsets", offs)) { err = "cannot write " + base + ".graph / .offsets"; return BVG_EIO; }
-	if (!bvprops::write_ef(base + ".properties", n, m, upper_bound, log2_quantum, big_endian != 0, nwords * 64, bitsOutd, bits - bitsOutd)) { err = "cannot write " + base + ".properties"; return BVG_EIO; }
+	const AtomicTriple files(base);
+	if (!write_bytes(files.tmp(".graph"), graph) || !write_bytes(files.tmp(".offsets"), offs)) { files.discard(); err = "cannot write " + base + ".graph / .offsets"; return BVG_EIO; }
+	if (!bvprops::write_ef(files.tmp(".properties"), n, m, upper_bound, log2_quantum, big_endian != 0, nwords * 64, bitsOutd, bits - bitsOutd) || !files.commit()) { files.discard(); err = "cannot write " + base + ".properties"; return BVG_EIO; }
 	return BVG_OK;
 }
 } // namespace

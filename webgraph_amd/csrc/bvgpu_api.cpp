@@ -1107,6 +1107,11 @@ static int open_impl(const char *basename, int device, int part, int parts, bvg_
 	// Scratch (interval arena, copy queues, giant list) is sized by the number of arcs: by what the stream holds, not by
 	// what .properties claims -- one pass over the record headers at load time
 	st->arcs_sizing = parts > 1 ? 1 : std::max<int64_t>(in.arcs, 1);
+	if (ef && parts > 1) { // an EFGraph has no header pass to count with: the slice's share of the file's bits, with a margin (est_arcs takes shares of THIS; ADVICE r3: it was 1)
+		const double all = (double)std::max<int64_t>(st->h_offsets.back() - st->h_offsets.front(), 1);
+		const double mine = (double)(st->h_offsets[(size_t)st->node_hi] - st->h_offsets[(size_t)st->stage_lo]);
+		st->arcs_sizing = std::max<int64_t>((int64_t)((double)std::max<int64_t>(in.arcs, 1) * mine / all * 1.1) + 4096, 1);
+	}
 	if (!ef && st->node_hi > st->stage_lo) {
 		const int32_t n = st->node_hi - st->stage_lo;
 		void *p_outd = nullptr, *p_ref = nullptr, *p_rs = nullptr, *p_sums = nullptr, *p_err = nullptr, *p_part = nullptr;
