@@ -34,6 +34,14 @@ def main():
             r = f()
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / reps * 1e3, r
+    only = os.environ.get("CK_ONLY")  # counter passes: one of the two paths alone (fold | materialise), marked by a k_totals-free region: every kernel of the run counts
+    if only:
+        g.set_option("hash_materialise", 1 if only == "materialise" else 0)
+        for _ in range(reps):
+            assert g.scan_checksum() == (want, m)
+        print("CK_ONLY=%s: %d checksum scans (+ 1 plain scan and 1 fold from memory at start-up)" % (only, reps))
+        g.close()
+        return
     scan_ms, _ = t(lambda: g.decode_range_device(0, n, rowptr.data_ptr(), succ.data_ptr(), succ.numel()))
     g.set_option("hash_materialise", 0)
     fold_ms, r = t(lambda: g.scan_checksum())

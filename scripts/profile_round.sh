@@ -15,7 +15,7 @@ cd /tmp
 for mode in overlapped serial; do
   rm -rf /tmp/prof_$mode
   if [ $mode = serial ]; then export BVGPU_OVERLAP=0; else unset BVGPU_OVERLAP; fi
-  rocprofv3 --kernel-trace --stats -d /tmp/prof_$mode -o res -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /tmp/prof_$mode.log 2>&1
+  rocprofv3 --kernel-trace --stats -d /tmp/prof_$mode -o res -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --no-pmc > /tmp/prof_$mode.log 2>&1
   db=$(find /tmp/prof_$mode -name "*.db" | head -1)
   python $R/scripts/rocprof_summary.py $db $R/gpurun_out/${tag}_kernel_stats_$mode.txt
 done
@@ -29,3 +29,14 @@ head -12 $R/gpurun_out/${tag}_kernel_stats_serial.txt | cut -c1-140
 cd $R
 BVGPU_OVERLAP=0 scripts/pmc.sh gpurun_out/${tag}_pmc scripts/tune.py --reps 2 > /dev/null 2>&1
 tail -5 gpurun_out/${tag}_pmc/summary.txt
+# the checksum scan (hash folded inside the scan) against decode-then-fold: time, and bytes written (WRITE_SIZE, a pass of its own)
+cd /tmp
+python $R/scripts/checksum_time.py c2 > $R/gpurun_out/${tag}_checksum_time.txt 2>&1
+python $R/scripts/checksum_time.py c5 >> $R/gpurun_out/${tag}_checksum_time.txt 2>&1
+python $R/scripts/checksum_time.py cnr30 >> $R/gpurun_out/${tag}_checksum_time.txt 2>&1
+for m in fold materialise; do
+  rm -rf /tmp/prof_ck_$m
+  CK_ONLY=$m BVGPU_OVERLAP=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_ck_$m -o ck --output-format csv -- python $R/scripts/checksum_time.py c2 3 > /tmp/prof_ck_$m.log 2>&1
+  python $R/scripts/pmc_total.py /tmp/prof_ck_$m WRITE_SIZE >> $R/gpurun_out/${tag}_checksum_time.txt 2>&1
+done
+cat $R/gpurun_out/${tag}_checksum_time.txt
