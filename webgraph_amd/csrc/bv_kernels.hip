@@ -442,18 +442,14 @@ __global__ void __launch_bounds__(TPB) k_depth_keys(GraphDev g, int32_t lo, int3
 			const uint64_t bitsLen = (uint64_t)(g.offsets[lo + s + 1] - g.offsets[lo + s]);
 			const uint64_t work = max(bitsLen, (uint64_t)outd[s] * 8);
 			if (work >= giantBits) key = KEY_GIANT;
-#ifdef BV_EXP_DROP_LO // (ablation builds: the records of an outdegree range are not decoded at all -- what the range costs inside the overlapped scan)
+#ifdef BV_EXP_DROP_LO // (ablation builds, scripts/ablate.sh: the records of an outdegree range are not decoded at all -- what the range costs inside the overlapped scan)
 			else if ((noBin & 4) && outd[s] >= BV_EXP_DROP_LO && outd[s] < BV_EXP_DROP_HI) key = KEY_NONE;
 #endif
 			else if (noBin & 4) {
 				// parse list: short records keep their neighbourhood -- sorted by work bin inside MAXLVL windows of
 				// consecutive nodes (a sweep of the parse kernel then touches a few windows of stream and rows, not
 				// the whole graph); the long ones (bin >= WINDOWED_BINS) stay together at the end: they are swept first
-#ifdef LW_BIN_BITS
-				const int32_t bin = record_bin(bitsLen + (uint64_t)outd[s] * LW_BIN_BITS);
-#else
 				const int32_t bin = record_bin(work);
-#endif
 				const int32_t win = bin >= WINDOWED_BINS ? MAXLVL - 1 : (int32_t)(((int64_t)s * MAXLVL) / cnt);
 				key = (uint16_t)(win * NBIN + bin);
 			} else key = (uint16_t)(((noBin & 2) ? 0 : min(dd, MAXLVL - 1)) * NBIN + ((noBin & 1) ? 0 : record_bin(work))); // noBin: bit 0 = ignore the length, bit 1 = ignore the level
@@ -537,45 +533,19 @@ __device__ __forceinline__ int copy_class(const RangeView &v, const int32_t *__r
 	if (!v.fits(s) || !v.fits(s - v.ref[s])) return 0; // E_CAP / E_HALO already raised by the parse kernel
 	return copy_class_of(v.outd[s], v.outd[s - v.ref[s]], midMin, bigMin);
 }
-constexpr int CL_BINS = 16; // half-octave bins of a row's length for the deal inside a block (rows of the lane class have < 2^8 ids)
 template <int DEF, bool VEC, bool HASH = false>
 __global__ void __launch_bounds__(TPB) k_copy_list(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ list,
-                                                   const int32_t *__restrict__ keyBase, int32_t level, int32_t midMin, int32_t bigMin, int *__restrict__ err, bool sortRows) {
+                                                   const int32_t *__restrict__ keyBase, int32_t level, int32_t midMin, int32_t bigMin, int *__restrict__ err) {
 	const int32_t bucket = min(level, MAXLVL - 1);
 	const int32_t lo = keyBase[bucket * NBIN], hi = keyBase[(bucket + 1) * NBIN];
 	const int64_t rsNh = v.rowstart[v.nh];
 	// HASH (bvg_scan_checksum): the rows merged here are added to the job's hash as they are written (copy_node<., true>)
 	const HashCtx hx = HASH ? *v.hx : HashCtx{};
 	uint32_t hacc = 0;
-	// sortRows (round 5): a wave lasts as long as the longest of its 64 rows, and the rows of a level come in node order -- 9 ids on average, the longest of 64
-	// has ~80.  The block's 256 entries of a sweep are dealt to its lanes by length (half-octave bins, counting sort in LDS): the four waves then hold rows of
-	// ~127..25, 25..12, 12..6 and 6..1 ids instead of four times 80..1, and the rows are still the block's own 256 neighbours (a sort of the whole level by
-	// length loses the neighbourhood: +70 % on C2, r5_experiments section 8).
-	__shared__ int32_t s_rows[TPB], s_bin[CL_BINS + 1];
-	for (int64_t top = (int64_t)hi - 1 - (int64_t)blockIdx.x * TPB; top >= lo; top -= (int64_t)gridDim.x * TPB) { // (uniform in the block)
+	for (int32_t idx = hi - 1 - (blockIdx.x * TPB + threadIdx.x); idx >= lo; idx -= gridDim.x * TPB) {
 		// (copy_class and RangeView::row / ::fits spelled out: every load of this kernel goes to a line of its own, so each is issued once --
 		// the outdegrees are differences of the row starts, which are needed anyway)
-		const int64_t idx = top - threadIdx.x;
-		int32_t s = idx >= lo ? list[idx] : -1;
-		if (sortRows) {
-			int key = CL_BINS; // longest first; the lanes without an entry last
-			if (s >= 0) {
-				const uint32_t dd = (uint32_t)(v.rowstart[s + 1] - v.rowstart[s]) | 1u;
-				const int lg = 31 - __clz((int)dd);
-				key = max(0, CL_BINS - 1 - (2 * lg + (lg > 0 ? (int)((dd >> (lg - 1)) & 1u) : 0)));
-			}
-			if (threadIdx.x <= CL_BINS) s_bin[threadIdx.x] = 0;
-			__syncthreads();
-			const int32_t pos = atomicAdd(&s_bin[key], 1);
-			__syncthreads();
-			int32_t before = 0;
-			for (int k = 0; k < key; k++) before += s_bin[k];
-			s_rows[before + pos] = s;
-			__syncthreads();
-			s = s_rows[threadIdx.x];
-			__syncthreads(); // (the tables are reused by the next sweep)
-		}
-		if (s < 0) continue;
+		const int32_t s = list[idx];
 		const int32_t r = v.ref[s];
 		if (r == 0 || (level >= MAXLVL - 1 && depth[s] != level)) continue;
 		const int32_t t = s - r;
@@ -593,216 +563,6 @@ __global__ void __launch_bounds__(TPB) k_copy_list(GraphDev g, RangeView v, cons
 #pragma unroll
 		for (int o = 32; o > 0; o >>= 1) hacc += (uint32_t)__shfl_xor((int)hacc, o, 64);
 		if ((threadIdx.x & 63) == 0) hash_add(hx, hacc);
-	}
-}
-
-// The lane class of the copy pass, 64 rows of a level at a time by one wave (round 5; default codings).  k_copy_list gives a row to a lane: the merge is a chain of
-// dependent loads -- a lane merges ~1 id per microsecond, gfx950 counts loads and stores in one counter -- and the wave lasts as long as the longest of its 64 rows
-// (rows of 9 ids on average, the longest of 64 has ~80): 466 us for C2's first level, and without the kernel the scans of C2 / the C5 shard / cnr-2000 x 30 take
-// 2.48 / 4.70 / 1.20 ms instead of 3.04 / 5.45 / 2.09 (profiles/r5_experiments.txt, section 7).  Here the wave's lanes are rows only while they have to be: a lane
-// reads its row's header and walks its block list through a window of the stream in LDS, in step with the others (code_w), into a table (end among the copied ids,
-// offset into the referent's row) per copy block; from then on a lane is an ID of the wave's rows taken together (their lengths summed over the lanes: the row and
-// the index come from a search in the 64 sums): the id is fetched -- from the referent's row through the block table, or from the row's own tail --, parked in LDS,
-// ranked in the other set of its row by one binary search there, and stored at its place.  Five round trips per 64 rows instead of one per id, every lane busy
-// whatever the lengths are.  A pass takes the rows that fit CS_CAP ids, in list (node) order: neighbouring lanes touch neighbouring lines.
-// A row whose two sets share an id (never in a valid file; MergedIntIterator.java:69-72 emits equal heads once and BVG:1210 pads the row with -1) or whose referent
-// is too long for the table's 16-bit fields is left to copy_node, one lane, after the pass.  Rows whose lists are malformed are left alone (the parse kernel raised the error).
-#ifndef CS_CAP_
-#define CS_CAP_ 512
-#endif
-constexpr int CS_CAP = CS_CAP_, CS_WIN = 8 /* (the window's first fill is spelled out in the kernel) */, COPY_SMALL_GRID = 2048, CS_ROW_MAX = 255; // (a row's lane number and an id's place are bytes)
-static_assert(CS_CAP % 64 == 0 && CS_CAP >= 256, "a pass holds at least one row");
-struct CsWave {
-	int32_t vals[CS_CAP];    // the ids of the pass: per row the copied ones, then the extras
-	uint32_t tab[CS_CAP];    // per row (at its base): copy block k = end among the copied ids | offset into the referent's row << 16
-	uint32_t desc[CS_CAP];   // what an id is: row's lane | index in the row << 8 | copied ids of the row << 16 | ids of the row << 24
-	int32_t nk[64];          // copy blocks of row r
-	int64_t rowp[64], srcp[64];
-	int32_t odd[64];
-};
-template <int DEF>
-__global__ void __launch_bounds__(TPB, 4) k_copy_small(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ list,
-                                                    const int32_t *__restrict__ keyBase, int32_t level, int32_t midMin, int32_t bigMin, int *__restrict__ err) {
-	static_assert(DEF != 0, "default codings");
-	__shared__ uint32_t lw[CS_WIN * LW_STRIDE];
-	__shared__ CsWave cws[TPB / 64];
-	const int lane = threadIdx.x & 63;
-	CsWave &cw = cws[threadIdx.x >> 6];
-	auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); };
-	const int32_t bucket = min(level, MAXLVL - 1);
-	const int64_t lo = keyBase[bucket * NBIN], hi = keyBase[(bucket + 1) * NBIN];
-	const int64_t rsNh = v.rowstart[v.nh];
-	const int64_t nWaves = (int64_t)gridDim.x * (TPB / 64), w0 = (int64_t)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
-	// The loads that lead to a row are issued ahead of it: the list entry two chunks ahead, what hangs on it (reference, row starts, record offset) one chunk ahead;
-	// the referent's row starts and the record's first 256 bits of stream are fetched together when the chunk begins.
-	auto entry = [&](int64_t c) -> int32_t { const int64_t idx = lo + c * 64 + lane; return lo + c * 64 < hi && idx < hi ? list[idx] : -1; };
-	int32_t sCur = entry(w0), sNext = entry(w0 + nWaves);
-	int32_t rN = 0; int64_t rs0N = 0, rs1N = 0; uint64_t offN = (uint64_t)g.offsets[v.lo];
-	if (sCur >= 0) { rN = (int32_t)v.ref[sCur]; rs0N = v.rowstart[sCur]; rs1N = v.rowstart[sCur + 1]; offN = (uint64_t)g.offsets[v.lo + sCur]; }
-	for (int64_t c = w0; lo + c * 64 < hi; c += nWaves) { // (uniform)
-		const int32_t s = max(sCur, 0), r = rN;
-		const int64_t rs0 = rs0N, rs1 = rs1N;
-		bool want = sCur >= 0 && r != 0;
-		const int32_t t = s - r;
-		const int64_t rt0 = want ? v.rowstart[t] : 0, rt1 = want ? v.rowstart[t + 1] : 0;
-		const uint64_t off = want ? offN : (uint64_t)g.offsets[v.lo]; // (a lane without a row reads along at the first record of the view: a shard handle stages nothing in front of it)
-		const uint64_t vlast = (g.nwords + 4) & ~(uint64_t)3, wv0 = (off >> 5) & ~(uint64_t)3;
-		const uint4 win0 = *(const uint4 *)(g.bits + min(wv0, vlast)), win1 = *(const uint4 *)(g.bits + min(wv0 + 4, vlast));
-		if (want && level >= MAXLVL - 1 && depth[s] != level) want = false;
-		sCur = sNext; sNext = entry(c + 2 * nWaves);
-		rN = 0;
-		if (sCur >= 0) { rN = (int32_t)v.ref[sCur]; rs0N = v.rowstart[sCur]; rs1N = v.rowstart[sCur + 1]; offN = (uint64_t)g.offsets[v.lo + sCur]; }
-		want = want && (s >= v.nh ? (uint64_t)(rs1 - rsNh) <= v.succ_cap : (uint64_t)rs1 <= v.halo_cap) && (t >= v.nh ? (uint64_t)(rt1 - rsNh) <= v.succ_cap : (uint64_t)rt1 <= v.halo_cap); // (else: E_CAP / E_HALO already raised by the parse kernel)
-		const int32_t d = (int32_t)(rs1 - rs0), dref = (int32_t)(rt1 - rt0);
-		want = want && copy_class_of(d, dref, midMin, bigMin) == 1 && d > 0;
-		int32_t *const row = s < v.nh ? v.halo + rs0 : v.succ + (rs0 - rsNh);
-		const int32_t *const src = t < v.nh ? v.halo + rt0 : v.succ + (rt0 - rsNh);
-		bool pending = want;
-		while (wave_any(pending)) {
-			// ---- the rows of this pass: the longest run of pending rows whose ids fit (a row has < midMin <= CS_CAP ids: at least one)
-			const bool far = pending && (d > CS_ROW_MAX || dref >= 65536); // (only with the wave / group classes switched off: one lane, below)
-			const int32_t dd = pending && !far ? d : 0;
-			int32_t inc = dd;
-#pragma unroll
-			for (int o = 1; o < 64; o <<= 1) { const int32_t u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
-			const bool take = pending && !far && inc <= CS_CAP;
-			const unsigned long long tk = __builtin_amdgcn_ballot_w64(take);
-			const int32_t E = tk ? __shfl(inc, 63 - __builtin_clzll(tk), 64) : 0;
-			const int32_t base = inc - dd;
-			// ---- header and block list, a lane per row, in step (BVG:1058-1071)
-			LaneWin<CS_WIN> br;
-			br.col = lw + threadIdx.x;
-			br.vlast = vlast;
-			br.w0 = wv0; br.q = (uint32_t)(off - (wv0 << 5));
-			br.col[0 * LW_STRIDE] = __builtin_bswap32(win0.x); br.col[1 * LW_STRIDE] = __builtin_bswap32(win0.y); br.col[2 * LW_STRIDE] = __builtin_bswap32(win0.z); br.col[3 * LW_STRIDE] = __builtin_bswap32(win0.w);
-			br.col[4 * LW_STRIDE] = __builtin_bswap32(win1.x); br.col[5 * LW_STRIDE] = __builtin_bswap32(win1.y); br.col[6 * LW_STRIDE] = __builtin_bswap32(win1.z); br.col[7 * LW_STRIDE] = __builtin_bswap32(win1.w);
-			int e = 0;
-			(void)code_w<1, 3, CS_WIN>(br, g, take, e);
-			if (g.W > 0) (void)code_w<2, 3, CS_WIN>(br, g, take, e);
-			uint64_t bc = code_w<1, 3, CS_WIN>(br, g, take, e);
-			bool bad = take && bc > (uint64_t)dref + 1;
-			if (!take || bad) bc = 0;
-#ifdef CS_EXP_NO_WALK
-			bc = 0;
-#endif
-			const uint32_t nb = (uint32_t)bc;
-			int64_t total = 0;
-			int32_t copied = 0, nK = 0;
-			for (uint32_t b = 0; wave_any(b < nb && !bad); b++) {
-				const bool wv = b < nb && !bad;
-				const uint64_t cd = code_w<1, 3, CS_WIN>(br, g, wv, e);
-				int64_t len = 0;
-				const bool good = block_len_ok(cd, b == 0, total, (int64_t)dref, len);
-				if (wv && !good) bad = true;
-				if (wv && good) {
-					if (!(b & 1) && len > 0) {
-						if ((int64_t)copied + len > d) bad = true;
-						else { cw.tab[base + nK] = (uint32_t)(copied + (int32_t)len) | ((uint32_t)(total - copied) << 16); nK++; copied += (int32_t)len; }
-					}
-					total += len;
-				}
-			}
-			if (take && !bad && !(bc & 1)) { // the implicit last block
-				const int64_t len = (int64_t)dref - total;
-				if (len > 0) {
-					if ((int64_t)copied + len > d) bad = true;
-					else { cw.tab[base + nK] = (uint32_t)(copied + (int32_t)len) | ((uint32_t)(total - copied) << 16); nK++; copied += (int32_t)len; }
-				}
-			}
-			if (e) { atomicOr(err, e); bad = true; }
-			const bool live = take && !bad && copied > 0; // (else: malformed -- flagged by the parse kernel -- or nothing to merge: the extras already fill the row)
-			cw.nk[lane] = nK;
-			cw.rowp[lane] = (int64_t)(uintptr_t)row;
-			cw.srcp[lane] = (int64_t)(uintptr_t)src;
-			cw.odd[lane] = 0;
-			wave_sync();
-#ifdef CS_EXP_ROWS_ONLY
-			pending = pending && !take && !far;
-			continue;
-#endif
-			// ---- every id learns what it is (a lane writes over its row's ids: stores that wait for nothing): row's lane | index in the row << 8 | copied ids << 16 | ids << 24
-			if (take) { const uint32_t hd = (uint32_t)lane | ((uint32_t)(live ? copied : 0) << 16) | ((uint32_t)d << 24); for (int32_t q = 0; q < d; q++) cw.desc[base + q] = hd | ((uint32_t)q << 8); }
-			wave_sync();
-			constexpr int U = CS_CAP / 64; // ids per lane and pass; the loops below are unrolled and walk the U searches of a lane step by step together: U LDS reads (loads) in flight
-			uint32_t ds[U];
-			int32_t gv[U], sl[U], sn[U];
-			// ---- gather: a lane per id; a copied id finds its block (the first one that ends behind it) and with it its place in the referent's row
-#pragma unroll
-			for (int u = 0; u < U; u++) {
-				const int32_t i = lane + 64 * u;
-				ds[u] = i < E ? cw.desc[i] : 0u; // (0: no copied ids -- nothing to do)
-				const int32_t j = (ds[u] >> 8) & 255, nc = (ds[u] >> 16) & 255;
-				sl[u] = 0; sn[u] = j < nc ? cw.nk[ds[u] & 63u] : 0;
-			}
-#pragma unroll 1
-			for (int step = 0; step < 8; step++) {
-				bool more = false;
-#pragma unroll
-				for (int u = 0; u < U; u++) {
-					const int32_t i = lane + 64 * u, j = (ds[u] >> 8) & 255;
-					const int32_t half = sn[u] >> 1, mid = sl[u] + half;
-					const int32_t x = sn[u] > 0 ? (int32_t)(cw.tab[i - j + mid] & 0xffffu) : 0x7fffffff;
-					const bool right = x <= j;
-					sl[u] = right ? mid + 1 : sl[u];
-					sn[u] = right ? sn[u] - half - 1 : half;
-					more |= sn[u] > 0;
-				}
-				if (!wave_any(more)) break;
-			}
-#pragma unroll
-			for (int u = 0; u < U; u++) {
-				const int32_t i = lane + 64 * u, rr = ds[u] & 63u, j = (ds[u] >> 8) & 255, nc = (ds[u] >> 16) & 255;
-				gv[u] = 0;
-				if (nc != 0) {
-					if (j < nc) gv[u] = ((const int32_t *)(uintptr_t)cw.srcp[rr])[j + (int32_t)(cw.tab[i - j + sl[u]] >> 16)];
-					else gv[u] = ((const int32_t *)(uintptr_t)cw.rowp[rr])[j];
-				}
-			}
-#pragma unroll
-			for (int u = 0; u < U; u++) { const int32_t i = lane + 64 * u; if (i < E) cw.vals[i] = gv[u]; }
-			wave_sync();
-			// ---- places: an id's rank in its own set plus the ids of the other set below it (a lower bound there)
-#pragma unroll
-			for (int u = 0; u < U; u++) {
-				const int32_t j = (ds[u] >> 8) & 255, nc = (ds[u] >> 16) & 255, rowLen = ds[u] >> 24;
-				if (nc == 0) { sl[u] = 0; sn[u] = 0; } else if (j < nc) { sl[u] = nc; sn[u] = rowLen - nc; } else { sl[u] = 0; sn[u] = nc; }
-			}
-#pragma unroll 1
-			for (int step = 0; step < 8; step++) { // (a row of the pass has <= 255 ids)
-				bool more = false;
-#pragma unroll
-				for (int u = 0; u < U; u++) {
-					const int32_t i = lane + 64 * u, j = (ds[u] >> 8) & 255;
-					const int32_t half = sn[u] >> 1, mid = sl[u] + half;
-					const int32_t x = sn[u] > 0 ? cw.vals[i - j + mid] : 0x7fffffff;
-					const bool right = sn[u] > 0 && x < gv[u];
-					sl[u] = right ? mid + 1 : sl[u];
-					sn[u] = right ? sn[u] - half - 1 : half;
-					more |= sn[u] > 0;
-				}
-				if (!wave_any(more)) break;
-			}
-#pragma unroll
-			for (int u = 0; u < U; u++) {
-				const int32_t i = lane + 64 * u, rr = ds[u] & 63u, j = (ds[u] >> 8) & 255, nc = (ds[u] >> 16) & 255, rowLen = ds[u] >> 24;
-				if (nc != 0) {
-					const int32_t l2 = sl[u];
-					const bool inOther = j < nc ? l2 < rowLen : l2 < nc;
-					if (inOther && cw.vals[i - j + l2] == gv[u]) cw.odd[rr] = 1;
-					sl[u] = j < nc ? j + l2 - nc : j - nc + l2; // the id's place in its row
-				}
-			}
-			wave_sync();
-#pragma unroll
-			for (int u = 0; u < U; u++) {
-				const int32_t rr = ds[u] & 63u, nc = (ds[u] >> 16) & 255;
-				if (nc != 0 && !cw.odd[rr]) ((int32_t *)(uintptr_t)cw.rowp[rr])[sl[u]] = gv[u];
-			}
-			const bool alone = far || (take && cw.odd[lane] != 0);
-			if (wave_any(alone)) { if (alone) copy_node<DEF>(g, v.lo + s, d, (int64_t)dref, row, src, err); }
-			wave_sync(); // (the tables are reused by the next pass)
-			pending = pending && !take && !far;
-		}
 	}
 }
 
@@ -1521,21 +1281,7 @@ __global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, con
 				const bool keep = !mine || hx.mark[s] != 0;
 				parse_node_lwb<DEF == 1 ? 3 : 0, true>(g, v.lo + s, dC, rC > 0, (int64_t)drefC, row, lw, (int2 *)(arena + abase), err, oaC, obC, &hacc, hw, keep);
 			}
-#if LW_POS_
-			else {
-				const bool odd = parse_node_lwp<DEF == 1 ? 3 : 0>(g, v.lo + s, dC, rC > 0, (int64_t)drefC, row, lw, (int2 *)(arena + abase), err, oaC, obC);
-				if (wave_any(odd)) { // (rare: everything the loop by places needs is read again from the slot number, so that nothing stays live across it)
-					if (odd) {
-						const int32_t d2 = v.outd[s], r2 = v.ref[s];
-						const int64_t ra2 = v.rowstart[s];
-						parse_node_lwb<DEF == 1 ? 3 : 0>(g, v.lo + s, d2, r2 > 0, r2 > 0 ? (int64_t)v.outd[s - r2] : 0, s < v.nh ? v.halo + ra2 : v.succ + (ra2 - rs0), lw,
-						                                 (int2 *)(arena + (g.minInt > 0 ? ra2 / g.minInt : 0)), err, (uint64_t)g.offsets[v.lo + s], (uint64_t)g.offsets[v.lo + s + 1]);
-					}
-				}
-			}
-#else
 			else parse_node_lwb<DEF == 1 ? 3 : 0>(g, v.lo + s, dC, rC > 0, (int64_t)drefC, row, lw, (int2 *)(arena + abase), err, oaC, obC);
-#endif
 		}
 		else parse_node<DEF>(g, v.lo + s, dC, rC > 0, (int64_t)drefC, row, err);
 	}
@@ -2375,9 +2121,9 @@ void launch_copy_prewalk(const GraphDev &g, int def, const RangeView &v, const i
 }
 void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int32_t *depth, const int32_t *list, const int32_t *keyBase, int32_t level, int blocks,
                        int32_t midMinKnob, bool bigGroups, const int32_t *bigQ, int32_t bigCap, const int32_t *midQ, int32_t midCap, int32_t *ctl, int32_t *tmp, uint32_t tmpCap, int *err,
-                       hipStream_t st, hipStream_t stMid, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evMid, hipEvent_t evBig, const void *preDesc, bool preMid, bool vecList, bool copySmall, bool sortRows) {
+                       hipStream_t st, hipStream_t stMid, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evMid, hipEvent_t evBig, const void *preDesc, bool preMid, bool vecList) {
 	if (v.cnt <= 0) return;
-#ifdef BV_EXP_NOCOPY
+#ifdef BV_EXP_NOCOPY // (ablation builds: the scan without its copy pass, or without one of its three row classes)
 	return;
 #endif
 	blocks = (int)std::min<int64_t>(blocks, nblk(v.cnt, TPB)); // (a thread per row at most: a small range does not launch thousands of idle blocks)
@@ -2416,18 +2162,15 @@ void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int
 		else hipLaunchKernelGGL(k_copy_mid<0>, dim3(1024), dim3(64 * COPY_MID_WAVES), 0, stMid, g, v, depth, midQ, ctl + 6, midCap, level, err, pre && preMid && midQ == bigQ + bigCap ? pre + bigCap : nullptr);
 	}
 	if (stMid != st) (void)hipEventRecord(evMid, stMid);
-#define COPY_LIST(D, V) hipLaunchKernelGGL((k_copy_list<D, V>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err, sortRows)
-	if (v.hx && def == 1) hipLaunchKernelGGL((k_copy_list<1, false, true>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err, sortRows); // (the hash fold: ids added as they are merged)
-	else if (v.hx && def == 2) hipLaunchKernelGGL((k_copy_list<2, false, true>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err, sortRows);
-	else if (v.hx) hipLaunchKernelGGL((k_copy_list<0, false, true>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err, sortRows);
+#define COPY_LIST(D, V) hipLaunchKernelGGL((k_copy_list<D, V>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err)
+	if (v.hx && def == 1) hipLaunchKernelGGL((k_copy_list<1, false, true>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err); // (the hash fold: ids added as they are merged)
+	else if (v.hx && def == 2) hipLaunchKernelGGL((k_copy_list<2, false, true>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
+	else if (v.hx) hipLaunchKernelGGL((k_copy_list<0, false, true>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
 	else
 #ifdef BV_EXP_NOCOPY_LIST
 	if (true) {}
 	else
 #endif
-	if (copySmall && def == 1) hipLaunchKernelGGL(k_copy_small<1>, dim3(std::min(blocks, COPY_SMALL_GRID)), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
-	else if (copySmall && def == 2) hipLaunchKernelGGL(k_copy_small<2>, dim3(std::min(blocks, COPY_SMALL_GRID)), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
-	else
 	if (def == 1) { if (vecList) COPY_LIST(1, true); else COPY_LIST(1, false); }
 	else if (def == 2) { if (vecList) COPY_LIST(2, true); else COPY_LIST(2, false); }
 	else { if (vecList) COPY_LIST(0, true); else COPY_LIST(0, false); }

@@ -117,9 +117,6 @@ template <int NWORDS> struct LaneWin {
 #ifndef LW_RING_
 #define LW_RING_ 8
 #endif
-#ifndef LW_POS_
-#define LW_POS_ 0 // 1: the one-lane loop by places (parse_node_lwp, a tuning build: slower, profiles/r5_experiments.txt section 6); 0: a trip per successor (parse_node_lwb)
-#endif
 constexpr int LW_RING = LW_RING_; // (a power of two; 2 * LW_RING <= LW_SIDE words of the lane's column)
 // The record by a loop that the 64 lanes of a wave walk in step (round 4; default codings -- zeta_3, or ZK = 0: the graph's zeta_k --, interval arena).  A merge loop with a
 // branch per case executes ~250 wave-instructions per trip, a third of them scalar: every `if` of a lane is an exec-mask region
@@ -153,7 +150,7 @@ template <int KIND, int ZK = 3> __device__ __forceinline__ bool lane_fast_code(u
 	return ok;
 }
 // Called where the wave is converged: the lanes with `want` consume one code, the others keep their cursor.
-template <int KIND, int ZK = 3, int NWORDS = LW_MAIN> __device__ __forceinline__ uint64_t code_w(LaneWin<NWORDS> &br, const GraphDev &g, bool want, int &err) {
+template <int KIND, int ZK = 3> __device__ __forceinline__ uint64_t code_w(LaneWin<LW_MAIN> &br, const GraphDev &g, bool want, int &err) {
 	br.template wave_refill<3>(g);
 	const uint32_t j = br.q >> 5, sh = br.q & 31u;
 	const uint64_t ab = ((uint64_t)br.col[j * LW_STRIDE] << 32) | br.col[(j + 1) * LW_STRIDE];
@@ -290,173 +287,6 @@ __device__ __forceinline__ void parse_node_lwb(const GraphDev &g, int32_t x, int
 		else if (on == 1) out[k - 1] = o3;
 	}
 	if (e) atomicOr(err, e);
-}
-
-// The absorbed intervals [ivFilled, ivIdx) of the lane's ring, written to their places: entry j holds (left, n | pos << 16), pos = the interval's first place in out[].
-typedef int32_t int4u __attribute__((ext_vector_type(4), aligned(4))); // a 16-byte store at any 4-byte boundary (one global_store_dwordx4: gfx950 needs dword alignment only)
-__device__ __forceinline__ void lw_fill_intervals(int32_t *__restrict__ out, const uint32_t *ring, int32_t &ivFilled, int32_t ivIdx) {
-	int32_t rem = 0, val = 0;
-	bool wide = false;
-	int32_t *p = out;
-	while (ivFilled < ivIdx || rem > 0) {
-		if (rem <= 0) {
-			const int j = ivFilled & (LW_RING - 1);
-			const uint32_t pk = ring[(2 * j + 1) * LW_STRIDE];
-			val = (int32_t)ring[(2 * j) * LW_STRIDE];
-			rem = (int32_t)(pk & 0xffffu);
-			wide = rem >= 4;
-			p = out + (pk >> 16);
-			ivFilled++;
-		}
-		if (wide) { // four ids per store; the last store of an interval steps back over ids already written
-			const int32_t back = rem < 4 ? 4 - rem : 0;
-			const int32_t v0 = val - back;
-			*(int4u *)(p - back) = int4u{ v0, v0 + 1, v0 + 2, v0 + 3 };
-			p += 4; val += 4; rem -= 4;
-		} else { *p++ = val++; rem--; }
-	}
-}
-
-// Round 5: the same record with a trip per RESIDUAL and per INTERVAL instead of a trip per successor (C2: 31 % of the arcs are ids of intervals, an interval holds 5 - 6).
-// A residual's place in the row is its rank among the residuals plus the ids of the intervals that begin before it, so the loop only walks the two HEADS: an interval that begins
-// at or before the next residual is absorbed (its length joins the offset, its place goes into its ring entry), otherwise the residual is stored at its place and the next gap is
-// decoded; the ids of the absorbed intervals are written afterwards (and before a ring top-up overwrites them) by a loop of four instructions per id.  Everything the places rest
-// on -- ids ascending, no residual inside an interval, no 32-bit wrap, places below 2^16 -- is checked on the way; a record that breaks any of it (the reference decodes such streams
-// too: equal heads once, BVG:1210's -1 fill) makes the function return true: the caller decodes it again with parse_node_lwb, which takes no such short cut.
-template <int ZK>
-__device__ __forceinline__ bool parse_node_lwp(const GraphDev &g, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row, uint32_t *lds, int2 *__restrict__ iv, int *__restrict__ err, uint64_t off0, uint64_t off1) {
-	LaneWin<LW_MAIN> br;
-	br.col = lds + threadIdx.x;
-	uint32_t *const ring = lds + LW_MAIN * LW_STRIDE + threadIdx.x;
-	br.vlast = min(((off1 >> 5) + 2) & ~(uint64_t)3, (g.nwords + 4) & ~(uint64_t)3);
-	br.seek(g, off0);
-	int e = 0;
-	bool odd = d >= 65536; // the record is left to parse_node_lwb
-	bool live = true;      // false: nothing (more) to decode here
-	(void)code_w<1>(br, g, true, e);
-	if (g.W > 0) (void)code_w<2>(br, g, true, e);
-	int64_t copied = 0;
-	{ // BVG:1058-1071
-		uint64_t bc = code_w<1>(br, g, hasRef, e);
-		if (!hasRef) bc = 0;
-		if (bc > (uint64_t)dref + 1) { e |= E_FORMAT; bc = 0; }
-		int64_t total = 0;
-		const uint32_t nb = (uint32_t)bc;
-		for (uint32_t b = 0; wave_any(b < nb && !e); b++) {
-			const bool w = b < nb && !e;
-			const uint64_t c = code_w<1>(br, g, w, e);
-			int64_t len = 0;
-			const bool good = block_len_ok(c, b == 0, total, dref, len);
-			if (w && !good) e |= E_FORMAT;
-			if (w && good) { total += len; if (!(b & 1)) copied += len; }
-		}
-		if (hasRef && !e && !(bc & 1)) copied += dref - total;
-	}
-	const int64_t extra = (int64_t)d - copied;
-	if (extra < 0 || copied < 0) e |= E_FORMAT;
-	if (e) { atomicOr(err, e); live = false; }
-	if (extra == 0) live = false;
-
-	int32_t nIntervals = 0;
-	int64_t intervalArcs = 0;
-	if (g.minInt != 0) { // BVG:1073-1096
-		const uint64_t ni = code_w<1>(br, g, live, e);
-		if (live && ni > (uint64_t)extra / (uint64_t)g.minInt) { atomicOr(err, E_FORMAT); live = false; }
-		nIntervals = live ? (int32_t)ni : 0;
-		int64_t prevEnd = 0;
-		for (int32_t i = 0; wave_any(i < nIntervals && !e); i++) {
-			const bool w = i < nIntervals && !e;
-			const uint64_t a = code_w<1>(br, g, w, e);
-			const uint64_t len = code_w<1>(br, g, w, e);
-			if (w) {
-				if (len > (uint64_t)extra) e |= E_FORMAT;
-				else {
-					intervalArcs += (int64_t)len + g.minInt;
-					const int64_t left = i == 0 ? (int64_t)x + nat2int(a) : prevEnd + (int64_t)a + 1, n = (int64_t)len + g.minInt; // BVG:1084-1093
-					if (a > 0x7fffffffull || left + n > 0x7fffffffll || left < -0x80000000ll) odd = true; // (Java ints would wrap)
-					prevEnd = left + n;
-					if (i < LW_RING) { ring[(2 * i) * LW_STRIDE] = (uint32_t)(int32_t)left; ring[(2 * i + 1) * LW_STRIDE] = (uint32_t)n; }
-					if (nIntervals > LW_RING) iv[i] = int2{ (int32_t)left, (int32_t)n };
-				}
-			}
-		}
-	}
-	const int64_t nRes = extra - intervalArcs;
-	if (live && (nRes < 0 || e)) { atomicOr(err, E_FORMAT | e); live = false; }
-	if (odd || !live) nIntervals = 0;
-
-	int32_t *const out = row + copied;
-	int32_t k = 0, ivBefore = 0, kRun = 0, o0 = 0, o1 = 0, o2 = 0, o3 = 0, on = 0;
-	int32_t ivIdx = 0, ivBase = 0, ivLoaded = min(nIntervals, LW_RING), ivFilled = 0;
-	int32_t resTodo = live && !odd ? (int32_t)nRes : 0;
-	int32_t resVal;
-	{
-		const uint64_t first = code_w<0, ZK>(br, g, resTodo != 0, e);
-		const int64_t r0 = (int64_t)x + nat2int(first); // BVG:954
-		if (resTodo != 0 && (first > 0xffffffffull || r0 > 0x7fffffffll || r0 < -0x80000000ll)) { odd = true; resTodo = 0; nIntervals = 0; ivLoaded = 0; }
-		resVal = (int32_t)r0;
-	}
-	while (resTodo != 0 || ivIdx < nIntervals) {
-		const bool lowRing = ivLoaded < nIntervals && ivIdx - ivBase >= LW_RING - 2;
-		if (wave_any(lowRing | ((br.q >> 5) + 3 >= (uint32_t)LW_MAIN))) {
-			br.template wave_refill<3>(g);
-			if (wave_any(lowRing)) { // some lane's ring runs low: every lane writes out what it has absorbed and tops its ring up from the arena
-				lw_fill_intervals(out, ring, ivFilled, ivIdx);
-				const int32_t cnt = min((ivIdx - ivBase) & ~1, nIntervals - ivLoaded);
-#pragma unroll
-				for (int p = 0; p < LW_RING / 2; p++) {
-					if (2 * p < cnt) {
-						const int4 t = *(const int4 *)(iv + ivLoaded + 2 * p);
-						const int j0 = (ivLoaded + 2 * p) & (LW_RING - 1);
-						ring[(2 * j0) * LW_STRIDE] = (uint32_t)t.x; ring[(2 * j0 + 1) * LW_STRIDE] = (uint32_t)t.y;
-						ring[(2 * j0 + 2) * LW_STRIDE] = (uint32_t)t.z; ring[(2 * j0 + 3) * LW_STRIDE] = (uint32_t)t.w;
-					}
-				}
-				if (cnt > 0) { ivBase += cnt; ivLoaded += cnt; }
-			}
-		}
-		const int jr = ivIdx & (LW_RING - 1);
-		const int32_t rl = (int32_t)ring[(2 * jr) * LW_STRIDE], rn = (int32_t)ring[(2 * jr + 1) * LW_STRIDE];
-		const uint32_t jw = br.q >> 5, sh = br.q & 31u;
-		const uint64_t ab = ((uint64_t)br.col[jw * LW_STRIDE] << 32) | br.col[(jw + 1) * LW_STRIDE];
-		uint32_t gap, len;
-		const bool ok = lane_fast_code<0, ZK>((uint32_t)((ab << sh) >> 32), gap, len, (uint32_t)g.zetaK);
-		const bool haveRes = resTodo != 0;
-		const bool absorb = ivIdx < nIntervals && (!haveRes || rl <= resVal);
-		const int32_t place = k + ivBefore;
-		if (absorb) {
-			if (haveRes && resVal - rl < rn) odd = true; // the residual lies inside the interval
-			ring[(2 * jr + 1) * LW_STRIDE] = (uint32_t)rn | ((uint32_t)place << 16);
-			ivBefore += rn;
-			ivIdx++;
-			if (on != 0) { // the parked residuals end a run: as the last four of the run (some of them written before), or one by one
-				if (k - kRun >= 4) *(int4u *)(out + place - 4) = int4u{ o0, o1, o2, o3 };
-				else { out[place - 1] = o3; if (on > 1) out[place - 2] = o2; if (on > 2) out[place - 3] = o1; }
-				on = 0;
-			}
-			kRun = k;
-		}
-		const bool useRes = !absorb;
-		if (useRes) { o0 = o1; o1 = o2; o2 = o3; o3 = resVal; on++; }
-		k += useRes; resTodo -= useRes;
-		if (on == 4) { *(int4u *)(out + place - 3) = int4u{ o0, o1, o2, o3 }; on = 0; }
-		const bool adv = useRes && resTodo != 0;
-		const int32_t prev = resVal;
-		if (wave_any(adv && !ok)) {
-			if (adv && !ok) { const uint64_t gl = br.template code<0, ZK>(g, e); if (gl > 0x7ffffffeull) odd = true; resVal += (int32_t)gl + 1; }
-			else if (adv) { resVal += (int32_t)gap + 1; br.q += len; }
-		} else { resVal += adv ? (int32_t)gap + 1 : 0; br.q += adv ? len : 0u; } // BVG:966
-		if (adv && resVal <= prev) odd = true; // (wrapped)
-		if (odd) { resTodo = 0; nIntervals = ivIdx; }
-	}
-	lw_fill_intervals(out, ring, ivFilled, ivIdx);
-	if (on != 0) {
-		const int32_t place = k + ivBefore;
-		if (k - kRun >= 4) *(int4u *)(out + place - 4) = int4u{ o0, o1, o2, o3 };
-		else { out[place - 1] = o3; if (on > 1) out[place - 2] = o2; if (on > 2) out[place - 3] = o1; }
-	}
-	if (e) atomicOr(err, e);
-	return odd;
 }
 
 } // namespace bv

@@ -143,9 +143,6 @@ struct bvg_graph {
 	DevBuf tilebounds;
 	int copy_big = 1;    // BVGPU_COPY_BIG=0: every row is copied by one lane
 	int parse_windows = 1; // BVGPU_PARSE_WINDOWS=0: the parse list is sorted by work bin over the whole range
-	int level_bins = 0;    // BVGPU_LEVEL_BINS=1: the level lists of the copy pass sorted by work bin inside a level (0: node order)
-	int copy_sort = 1;     // BVGPU_COPY_SORT=0: the lane class of the copy pass takes the rows of a level in list order (1: a block deals its 256 rows to its lanes by length)
-	int copy_small = 1;    // BVGPU_COPY_SMALL=0: the lane class of the copy pass by a lane per row (k_copy_list) instead of 64 rows per wave, a lane per id (k_copy_small)
 	int copy_mid_min = 128; // rows with at least this many successors (and fewer than 1024) are copied by one wave each
 	int32_t coop_min = 2048, giant_min = 32768;                         // thresholds on the outdegree (BVGPU_COOP_MIN / BVGPU_GIANT_MIN)
 	long long scan_top_tiled_min = -1, scan_piece = 0; // (-1 / 0: the defaults of bv_kernels.hip / scan_piece_arcs)
@@ -246,9 +243,6 @@ int apply_option(bvg_graph *g, const std::string &name, const char *value) {
 	else if (name == "level_blocks") g->level_blocks = std::max(1, iv);
 	else if (name == "copy_big") g->copy_big = iv;
 	else if (name == "parse_windows") g->parse_windows = iv;
-	else if (name == "level_bins") g->level_bins = iv;
-	else if (name == "copy_small") g->copy_small = iv;
-	else if (name == "copy_sort") g->copy_sort = iv;
 	else if (name == "tile") g->tile = iv;
 	else if (name == "seg") g->seg = iv;
 	else if (name == "seg_hub_min") g->seg_hub_min = std::max(1, iv);
@@ -276,7 +270,7 @@ int apply_option(bvg_graph *g, const std::string &name, const char *value) {
 	else return BVG_EARG;
 	return BVG_OK;
 }
-const char *const OPTION_NAMES[] = { "coop_min", "giant_min", "coop_waves", "giant_groups", "level_blocks", "copy_big", "parse_windows", "level_bins", "copy_small", "copy_sort", "tile", "seg", "seg_hub_min", "seg_blocks", "lists_on_b",
+const char *const OPTION_NAMES[] = { "coop_min", "giant_min", "coop_waves", "giant_groups", "level_blocks", "copy_big", "parse_windows", "tile", "seg", "seg_hub_min", "seg_blocks", "lists_on_b",
 	"walk_tables", "copy_vec", "prewalk", "prewalk_long", "prewalk_blocks", "copy_mid_min", "overlap", "halo_min", "batch_dense", "scan_top_tiled_min", "wait_giants", "hash_materialise",
 	"ef_hash_materialise", "scan_piece", "dbg", "stats", "trace_retry", "trace_err", "trace_host" };
 void options_from_env(bvg_graph *g) {
@@ -459,7 +453,7 @@ int finish_pending(bvg_graph *g, uint64_t *arcs_out) {
 					const bool ov2 = g->overlap && !g->profile;
 					bv::launch_copy_level(gd, s.def, g->pend.view, g->depth.as<int32_t>(), g->lvlist.as<int32_t>(), keyBase, l, g->level_blocks, g->copy_mid_min, g->copy_big != 0,
 					                      g->copyq.as<int32_t>(), g->pend.bigCap, g->copyq.as<int32_t>() + g->pend.bigCap, g->pend.midCap, g->coopctl.as<int32_t>(), g->bigtmp.as<int32_t>(), g->pend.tmpCap, derr,
-					                      g->stream, ov2 ? side_b(g) : g->stream, ov2 ? g->sideA : g->stream, g->evFork, g->evB, g->evA, g->pend.preDesc, g->prewalk < 2 && g->pend.midCap > 0, copy_vec(g), g->copy_small != 0 && s.def != 0, g->copy_sort != 0);
+					                      g->stream, ov2 ? side_b(g) : g->stream, ov2 ? g->sideA : g->stream, g->evFork, g->evB, g->evA, g->pend.preDesc, g->prewalk < 2 && g->pend.midCap > 0, copy_vec(g));
 				}
 			}
 			g->pend.levels_done = upto;
@@ -653,7 +647,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		// ... then, behind the wave class, the chain depth of every record + per-level lists (node order inside a level) +
 		// copy queues: only the copy pass needs them, and launched first they would sit in front of the wave class while
 		// the one-lane kernel holds every CU
-		if (W > 0) bv::launch_build_lists(gd, v, ~0ull, g->level_bins ? 0 : 1, g->depth.as<int32_t>(), g->key16.as<uint16_t>(), hist, keyBase, cursor, g->lvlist.as<int32_t>(),
+		if (W > 0) bv::launch_build_lists(gd, v, ~0ull, 1, g->depth.as<int32_t>(), g->key16.as<uint16_t>(), hist, keyBase, cursor, g->lvlist.as<int32_t>(),
 		                                  g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->maxdepth, stLists,
 		                                  g->copyq.as<int32_t>(), bigCap, g->copyq.as<int32_t>() + bigCap, midCap, g->copy_mid_min, g->copy_big != 0);
 		// the block lists of the group class's rows, walked beside the parse kernels (k_copy_prewalk)
@@ -727,7 +721,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			for (int32_t l = 1; l <= levels; l++) {
 				bv::launch_copy_level(gd, s.def, v, g->depth.as<int32_t>(), g->lvlist.as<int32_t>(), keyBase, l, g->level_blocks, g->copy_mid_min, g->copy_big != 0,
 				                                          g->copyq.as<int32_t>(), bigCap, g->copyq.as<int32_t>() + bigCap, midCap, ctl, g->bigtmp.as<int32_t>(), g->pend.tmpCap, derr,
-				                                          g->stream, ovl ? side_b(g) : g->stream, ovl ? g->sideA : g->stream, g->evFork, g->evB, g->evA, g->pend.preDesc, g->prewalk < 2 && g->pend.midCap > 0, copy_vec(g), g->copy_small != 0 && s.def != 0, g->copy_sort != 0);
+				                                          g->stream, ovl ? side_b(g) : g->stream, ovl ? g->sideA : g->stream, g->evFork, g->evB, g->evA, g->pend.preDesc, g->prewalk < 2 && g->pend.midCap > 0, copy_vec(g));
 			}
 		}
 		if (g->hash_job) { // the rows that the wave / group classes of the copy pass merged (its queues), then the sum rides home in the job's mailbox
