@@ -546,7 +546,6 @@ __global__ void __launch_bounds__(TPB) k_copy_list(GraphDev g, RangeView v, cons
 		// (copy_class and RangeView::row / ::fits spelled out: every load of this kernel goes to a line of its own, so each is issued once --
 		// the outdegrees are differences of the row starts, which are needed anyway)
 		const int32_t s = list[idx];
-		if (v.done && v.done[s]) continue; // (merged inside its tile: k_tile_full)
 		const int32_t r = v.ref[s];
 		if (r == 0 || (level >= MAXLVL - 1 && depth[s] != level)) continue;
 		const int32_t t = s - r;
@@ -1521,18 +1520,11 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? COOP1_MINWAVES : COOPG_MINW
 // extras read index: k = (#copied so far) + (j - copied) <= j.
 // HASH (bvg_scan_checksum): every id of the final row is also added to *hacc with weight hw, hw * 31, ... (HashCtx, bv_launch.hpp) -- the merged ones as they are
 // written, the extras that are already in place by one more pass over them; a row that is left alone (malformed: an error is raised elsewhere) adds nothing.
-// (copy_node_from: the same with the caller's reader, already at the record's first bit -- k_tile_full reads the stream from its LDS image)
-template <int DEF, bool HASH, class R>
-__device__ __forceinline__ void copy_node_from(R &br, const GraphDev &g, int32_t d, int64_t dref, int32_t *__restrict__ row, const int32_t *__restrict__ src, int *__restrict__ err, uint32_t *hacc, uint32_t hw);
 template <int DEF, bool HASH>
 __device__ __forceinline__ void copy_node(const GraphDev &g, int32_t x, int32_t d, int64_t dref, int32_t *__restrict__ row, const int32_t *__restrict__ src, int *__restrict__ err, uint32_t *hacc, uint32_t hw) {
 	BitReader br;
 	br.init(g.bits, g.nwords);
 	br.seek((uint64_t)g.offsets[x]);
-	copy_node_from<DEF, HASH>(br, g, d, dref, row, src, err, hacc, hw);
-}
-template <int DEF, bool HASH, class R>
-__device__ __forceinline__ void copy_node_from(R &br, const GraphDev &g, int32_t d, int64_t dref, int32_t *__restrict__ row, const int32_t *__restrict__ src, int *__restrict__ err, uint32_t *hacc, uint32_t hw) {
 	(void)Fields<DEF>::outdegree(br, g);
 	(void)Fields<DEF>::reference(br, g);
 	const uint64_t bc = Fields<DEF>::block_count(br, g);
@@ -2188,224 +2180,9 @@ void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int
 	if (stList != st) (void)hipStreamWaitEvent(st, evBig, 0);
 }
 
-// ------------------------------------------------------------------------------------------------ whole tiles: parse AND copy in LDS (round 5)
-// On a web-shaped graph the copy pass IS the scan: cnr-2000 x 30 takes 2.11 ms, 1.22 of them the three levels of the copy pass and 0.96 its lane class alone
-// (profiles/r5_ablation.txt) -- a lane per row merging through global memory, every load and store of a wave 64 different lines.  But a row copies from one of the
-// W nodes in front of it, and a tile of consecutive nodes holds almost every referent of its rows.  Here a work-group keeps the ROWS of its tile in LDS: the
-// records are parsed into them (parse_node_tile, as k_parse_tile), the rows whose whole chain lies inside the tile are merged there, level by level of the chain
-// behind work-group barriers (copy_node through LDS: a step of the merge is an LDS round trip, not a global one), and the tile's rows leave in ONE coalesced sweep --
-// they are neighbours in the CSR.  A row whose chain leaves the tile (the first nodes of a tile; a referent of the wave class) stays as the parse kernels leave
-// it, extras at its tail, for the level kernels; done[s] = 1 tells k_copy_list which rows not to touch.  Only rows of the copy pass's lane class are merged here
-// (the queues of its wave and group classes know nothing of tiles).
-// Tile t = the slots with t * TF_SPAN <= bits(s) + TF_NODE_BITS * s + TF_ARC_BITS * arcs(s) < (t + 1) * TF_SPAN, all three counted from the view's first slot:
-// at most TF_SPAN bits of stream, TF_NODES nodes and TF_CAP ids start in a tile.
-struct LdsSrc { // the bit reader's words from a tile's LDS image (byte-swapped already); outside it, from HBM
-	const lds_u32 *win;
-	uint64_t w0;
-	uint32_t nw;
-	GlobalSrc g;
-	__device__ __forceinline__ void start(uint64_t) {}
-	__device__ __forceinline__ uint32_t ld(uint64_t i) const { const uint64_t j = i - w0; return j < (uint64_t)nw ? win[j] : g.ld(i); }
-};
-using LdsReader = BitReaderT<LdsSrc>;
-#ifndef TF_SPAN_
-#define TF_SPAN_ 49152
-#endif
-#ifndef TF_SLACK_
-#define TF_SLACK_ 1024
-#endif
-constexpr int TF_T = 256, TF_SPAN = TF_SPAN_, TF_NODE_BITS = 64, TF_ARC_BITS = 8, TF_NODES = TF_SPAN / TF_NODE_BITS, TF_IDS = TF_SPAN / TF_ARC_BITS;
-constexpr int TF_CAP = TF_IDS + TF_SLACK_;              // ids of LDS rows (the last record of a tile may reach past the tile's share); more: the tile decodes straight into the CSR
-constexpr int TF_WIN_WORDS = TF_SPAN / 32 + 256;   // staged words: the slice, 1 KB of overhang for the last record, look-ahead
-constexpr int TF_RPT = (TF_NODES + TF_T - 1) / TF_T, TF_BRK = 32;
-constexpr uint8_t TF_OUT = 255, TF_WAIT = 254;     // a row's level: its chain leaves the tile / not known yet
-__global__ void __launch_bounds__(256) k_tilefull_bounds(const int64_t *__restrict__ offsets, const int64_t *__restrict__ rowstart, int32_t lo, int32_t cnt, int32_t ntiles, int32_t *__restrict__ tb) {
-	const int32_t t = blockIdx.x * 256 + threadIdx.x;
-	if (t > ntiles) return;
-	const int64_t target = (int64_t)t * TF_SPAN, base = offsets[lo], rbase = rowstart[0];
-	int32_t a = 0, b = cnt; // first s in [0, cnt) with weight(s) >= target, cnt if none
-	while (a < b) {
-		const int32_t mid = (int32_t)(((int64_t)a + b) >> 1);
-		if ((offsets[lo + mid] - base) + (int64_t)TF_NODE_BITS * mid + (int64_t)TF_ARC_BITS * (rowstart[mid] - rbase) < target) a = mid + 1; else b = mid;
-	}
-	tb[t] = a;
-}
-template <int DEF>
-__global__ void __launch_bounds__(TF_T) k_tile_full(GraphDev g, RangeView v, const int32_t *__restrict__ tb, int32_t midMin, int32_t bigMin, uint8_t *__restrict__ done, int *__restrict__ err) {
-	static_assert(DEF != 0, "default codings");
-	__shared__ __attribute__((aligned(16))) uint32_t s_win[TF_WIN_WORDS];
-	__shared__ __attribute__((aligned(16))) int32_t s_rows[TF_CAP];
-	__shared__ uint16_t s_off[TF_NODES + 1], s_list[TF_NODES];
-	__shared__ uint8_t s_lvl[TF_NODES];
-	__shared__ int32_t s_hist[TILE_NBIN], s_n, s_nbrk, s_brkOff[TF_BRK], s_brkLen[TF_BRK], s_maxl;
-	const int tid = threadIdx.x;
-	const int32_t a = tb[blockIdx.x], b = tb[blockIdx.x + 1];
-	if (a >= b) return;
-	const int32_t nn = b - a, coopMin = v.coopmin();
-	// ---- the tile's slice of the stream -> LDS
-	const uint64_t p0 = (uint64_t)g.offsets[v.lo + a], p1 = (uint64_t)g.offsets[v.lo + b];
-	const uint64_t w0 = (p0 >> 5) & ~(uint64_t)3;
-	const uint32_t nw = (uint32_t)min<uint64_t>(TF_WIN_WORDS, (((p1 + 31) >> 5) - w0 + 3 + 3) & ~(uint64_t)3);
-	{
-		constexpr int NV = (TF_WIN_WORDS / 4 + TF_T - 1) / TF_T;
-		const uint4 *src4 = (const uint4 *)(g.bits + w0);
-		const uint64_t lim4 = (g.nwords + 8 - w0) / 4;
-		uint4 q4[NV];
-#pragma unroll
-		for (int k = 0; k < NV; k++) { const uint32_t i = (uint32_t)tid + (uint32_t)k * TF_T; q4[k] = (i < nw / 4 && i < lim4) ? src4[i] : uint4{ 0u, 0u, 0u, 0u }; }
-#pragma unroll
-		for (int k = 0; k < NV; k++) {
-			const uint32_t i = (uint32_t)tid + (uint32_t)k * TF_T;
-			if (i < nw / 4) ((uint4 *)s_win)[i] = uint4{ __builtin_bswap32(q4[k].x), __builtin_bswap32(q4[k].y), __builtin_bswap32(q4[k].z), __builtin_bswap32(q4[k].w) };
-		}
-	}
-	if (tid < TILE_NBIN) s_hist[tid] = 0;
-	if (tid == 0) { s_nbrk = 0; s_maxl = 0; }
-	// ---- the nodes: which rows live in LDS (the records this kernel decodes), where; the others' rows are gaps of the sweep at the end
-	const int64_t rsNh = v.rowstart[v.nh];
-	int32_t dN[TF_RPT], rN[TF_RPT];
-	uint64_t pN[TF_RPT]; // (the record's first bit: the merges below then load nothing from global memory)
-	bool inl[TF_RPT];
-	int64_t carry = 0;
-	__syncthreads();
-#pragma unroll
-	for (int k = 0; k < TF_RPT; k++) {
-		const int32_t n = tid + k * TF_T, s = a + n;
-		dN[k] = 0; rN[k] = 0; inl[k] = false; pN[k] = 0;
-		int32_t dl = 0;
-		if (n < nn) {
-			dN[k] = v.outd[s]; rN[k] = v.ref[s]; pN[k] = (uint64_t)g.offsets[v.lo + s];
-			const bool mine = dN[k] > 0 && dN[k] < coopMin;
-			if (mine && !v.fits(s)) atomicOr(err, s >= v.nh ? E_CAP : E_HALO);
-			inl[k] = mine && s >= v.nh && v.fits(s);
-			dl = inl[k] ? dN[k] : 0;
-		}
-		int64_t tot;
-		const int64_t ex = block_excl_scan((int64_t)dl, &tot) + carry;
-		if (n < nn) s_off[n] = (uint16_t)min<int64_t>(ex, 0xffff);
-		if (n < nn && dN[k] > 0 && !inl[k] && s >= v.nh) { // a row of somebody else's (the wave class, the giants): a gap in the tile's stretch of the CSR
-			const int32_t j = atomicAdd(&s_nbrk, 1);
-			if (j < TF_BRK) { s_brkOff[j] = (int32_t)min<int64_t>(ex, 0x7fffffff); s_brkLen[j] = dN[k]; }
-		}
-		carry += tot;
-	}
-	const int32_t T = (int32_t)min<int64_t>(carry, 0x7fffffff);
-	if (tid == 0) s_off[nn] = (uint16_t)min(T, 0xffff); // (a row's length in LDS: the difference of two offsets)
-	__syncthreads();
-	// (halo slots have rows elsewhere and no place in the sweep: a tile that holds one decodes as k_parse_tile does)
-	const bool direct = T > TF_CAP || s_nbrk > TF_BRK || a < v.nh;
-	// ---- the records, sorted by work, longest first (as k_parse_tile)
-	int32_t bin[TF_RPT], pos[TF_RPT];
-#pragma unroll
-	for (int k = 0; k < TF_RPT; k++) {
-		const int32_t n = tid + k * TF_T, s = a + n;
-		bin[k] = -1;
-		const bool dec = direct ? (n < nn && dN[k] > 0 && dN[k] < coopMin && v.fits(s)) : inl[k];
-		if (dec) {
-			const uint64_t bitsLen = (uint64_t)(g.offsets[v.lo + s + 1] - g.offsets[v.lo + s]);
-			const uint64_t work = max(bitsLen, (uint64_t)dN[k] * 8);
-			const int lg = 63 - __clzll((long long)(work | 1));
-			const int h = 2 * lg + (lg > 0 ? (int)((work >> (lg - 1)) & 1) : 0);
-			bin[k] = TILE_NBIN - 1 - min(max(h - 8, 0), TILE_NBIN - 1);
-			pos[k] = atomicAdd(&s_hist[bin[k]], 1);
-		}
-	}
-	__syncthreads();
-	if (tid < 64) {
-		int32_t c = tid < TILE_NBIN ? s_hist[tid] : 0, inc = c;
-#pragma unroll
-		for (int o = 1; o < TILE_NBIN; o <<= 1) { const int32_t t2 = __shfl_up(inc, o, 64); if (tid >= o) inc += t2; }
-		if (tid < TILE_NBIN) s_hist[tid] = inc - c;
-		if (tid == TILE_NBIN - 1) s_n = inc;
-	}
-	__syncthreads();
-#pragma unroll
-	for (int k = 0; k < TF_RPT; k++) if (bin[k] >= 0) s_list[s_hist[bin[k]] + pos[k]] = (uint16_t)(tid + k * TF_T);
-	__syncthreads();
-	const TWin tw{ (const lds_u32 *)s_win, nw, w0, g.bits, g.nwords };
-	const int32_t nList = s_n;
-	for (int32_t idx = tid; idx < nList; idx += TF_T) {
-		const int32_t n = (int32_t)s_list[idx], s = a + n;
-		const int32_t d = v.outd[s], r = v.ref[s];
-		// (two calls: the compiler then knows which of them writes LDS)
-		if (direct) parse_node_tile<DEF == 1 ? 3 : 0>(g, tw, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), err);
-		else parse_node_tile<DEF == 1 ? 3 : 0>(g, tw, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, s_rows + s_off[n], err);
-	}
-	if (direct) return;
-#ifdef TF_EXP_PARSEONLY
-	return;
-#endif
-	__syncthreads();
-	// ---- the level of every row inside the tile: 0 without a reference, the referent's + 1 -- or TF_OUT: the chain leaves the tile, the row is not of the lane class, ...
-#pragma unroll
-	for (int k = 0; k < TF_RPT; k++) {
-		const int32_t n = tid + k * TF_T;
-		if (n < nn) s_lvl[n] = dN[k] == 0 ? 0 : !inl[k] ? TF_OUT : rN[k] == 0 ? 0 : (rN[k] > n || copy_class_of(dN[k], v.outd[a + n - rN[k]], midMin, bigMin) != 1) ? TF_OUT : TF_WAIT;
-	}
-	__syncthreads();
-	for (int it = 0; it < 256; it++) {
-		bool moved = false;
-		uint8_t nl[TF_RPT];
-#pragma unroll
-		for (int k = 0; k < TF_RPT; k++) {
-			const int32_t n = tid + k * TF_T;
-			nl[k] = TF_WAIT;
-			if (n < nn && s_lvl[n] == TF_WAIT) {
-				const uint8_t lt = s_lvl[n - rN[k]];
-				if (lt == TF_OUT || lt == TF_WAIT - 1) nl[k] = TF_OUT; else if (lt != TF_WAIT) nl[k] = (uint8_t)(lt + 1);
-			}
-		}
-		__syncthreads();
-#pragma unroll
-		for (int k = 0; k < TF_RPT; k++) { const int32_t n = tid + k * TF_T; if (nl[k] != TF_WAIT) { s_lvl[n] = nl[k]; moved = true; if (nl[k] != TF_OUT) atomicMax(&s_maxl, (int32_t)nl[k]); } }
-		if (!__syncthreads_or(moved)) break;
-	}
-	// ---- the merges, level by level (a row that is still waiting after 256 rounds is left to the level kernels)
-	const int32_t maxl = s_maxl;
-	for (int32_t L = 1; L <= maxl; L++) {
-#pragma unroll
-		for (int k = 0; k < TF_RPT; k++) {
-			const int32_t n = tid + k * TF_T;
-			if (n < nn && s_lvl[n] == (uint8_t)L) {
-				const int32_t t = n - rN[k];
-#ifndef TF_EXP_NOMERGE
-				LdsReader br;
-				br.init_src(LdsSrc{ (const lds_u32 *)s_win, w0, nw, GlobalSrc{ g.bits, g.nwords } }, g.nwords);
-				br.seek(pN[k]);
-				copy_node_from<DEF, false>(br, g, dN[k], (int64_t)(s_off[t + 1] - s_off[t]), s_rows + s_off[n], s_rows + s_off[t], err, nullptr, 0u);
-#endif
-				done[a + n] = 1;
-			}
-		}
-		__syncthreads();
-	}
-	// ---- the tile's rows -> the CSR, in one sweep (behind every foreign row in front of an id lies that row's length)
-	const int32_t nbrk = s_nbrk;
-	int32_t *const out0 = v.succ + (v.rowstart[a] - rsNh);
-#ifdef TF_EXP_NOWRITE
-	if (nbrk >= 0) return;
-#endif
-	for (int32_t e = tid; e < T; e += TF_T) {
-		int64_t skip = 0;
-		for (int32_t j = 0; j < nbrk; j++) skip += s_brkOff[j] <= e ? s_brkLen[j] : 0;
-		out0[e + skip] = s_rows[e];
-	}
-}
-
 int32_t tile_count(int64_t bitSpan, int32_t cnt) { return (int32_t)std::min<int64_t>((bitSpan + (int64_t)TILE_NODE_BITS * cnt) / TILE_SPAN + 1, 0x7ffffff0); }
 void launch_tile_bounds(const GraphDev &g, int32_t lo, int32_t cnt, int32_t ntiles, int32_t *tb, hipStream_t st) {
 	hipLaunchKernelGGL(k_tile_bounds, dim3(nblk((int64_t)ntiles + 1, 256)), dim3(256), 0, st, g.offsets, lo, cnt, ntiles, tb);
-}
-int32_t tilefull_count(int64_t bitSpan, int32_t cnt, int64_t arcs) { return (int32_t)std::min<int64_t>((bitSpan + (int64_t)TF_NODE_BITS * cnt + (int64_t)TF_ARC_BITS * arcs) / TF_SPAN + 1, 0x7ffffff0); }
-void launch_tilefull_bounds(const GraphDev &g, const RangeView &v, int32_t ntiles, int32_t *tb, hipStream_t st) {
-	hipLaunchKernelGGL(k_tilefull_bounds, dim3(nblk((int64_t)ntiles + 1, 256)), dim3(256), 0, st, g.offsets, v.rowstart, v.lo, v.cnt, ntiles, tb);
-}
-void launch_tile_full(const GraphDev &g, int def, const RangeView &v, const int32_t *tb, int32_t ntiles, int32_t midMinKnob, bool bigGroups, uint8_t *done, int *err, hipStream_t st) {
-	if (v.cnt <= 0 || ntiles <= 0) return;
-	int32_t midMin, bigMin;
-	copy_thresholds(midMinKnob, bigGroups, midMin, bigMin);
-	if (def == 1) hipLaunchKernelGGL(k_tile_full<1>, dim3(ntiles), dim3(TF_T), 0, st, g, v, tb, midMin, bigMin, done, err);
-	else hipLaunchKernelGGL(k_tile_full<2>, dim3(ntiles), dim3(TF_T), 0, st, g, v, tb, midMin, bigMin, done, err);
 }
 void launch_parse_tile(const GraphDev &g, int def, const RangeView &v, const int32_t *tb, int32_t ntiles, int variant, int *err, hipStream_t st) {
 	if (v.cnt <= 0 || ntiles <= 0) return;

@@ -53,7 +53,6 @@ struct RangeView {
 	const int32_t *coop_ptr; // ... unless the job picks the threshold on the device (k_pick_coop): then it is read from here
 	uint64_t halo_cap;      // capacity of halo in elements (a sub-range is decoded before the size of its halo is known on the host)
 	const HashCtx *hx;      // null, or (device memory) the hash fold of bvg_scan_checksum: see HashCtx
-	const uint8_t *done;    // null, or [cnt]: rows with a reference that are final before the copy pass (k_tile_full merged them inside their tile)
 	// does row s lie inside the buffer it belongs to?  (rows are laid out in node order: if s fits, so does every row before it in the same buffer)
 	__device__ __forceinline__ bool fits(int32_t s) const {
 		return s >= nh ? (uint64_t)(rowstart[s + 1] - rowstart[nh]) <= succ_cap : (uint64_t)rowstart[s + 1] <= halo_cap;
@@ -133,10 +132,6 @@ void launch_parse_giants(const GraphDev &g, int def, const RangeView &v, const i
 int32_t tile_count(int64_t bitSpan, int32_t cnt);
 void launch_tile_bounds(const GraphDev &g, int32_t lo, int32_t cnt, int32_t ntiles, int32_t *tb, hipStream_t st);
 void launch_parse_tile(const GraphDev &g, int def, const RangeView &v, const int32_t *tb, int32_t ntiles, int variant, int *err, hipStream_t st);
-// whole tiles (k_tile_full): the bounds need the row starts; done[cnt], zeroed by the caller
-int32_t tilefull_count(int64_t bitSpan, int32_t cnt, int64_t arcs);
-void launch_tilefull_bounds(const GraphDev &g, const RangeView &v, int32_t ntiles, int32_t *tb, hipStream_t st);
-void launch_tile_full(const GraphDev &g, int def, const RangeView &v, const int32_t *tb, int32_t ntiles, int32_t midMinKnob, bool bigGroups, uint8_t *done, int *err, hipStream_t st);
 int64_t hash_chunks(int32_t cnt, int64_t arcs);
 void launch_hash(int32_t from, int32_t cnt, int64_t arcs, const int64_t *rowptr, const int32_t *succ, uint32_t *A, uint32_t *B, int32_t *bounds, int32_t *hash, hipStream_t st);
 

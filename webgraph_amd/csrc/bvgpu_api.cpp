@@ -140,10 +140,9 @@ struct bvg_graph {
 	int seg_blocks = 2048;
 	int lists_on_b = 0;  // BVGPU_LISTS_ON_B=1: the chain depths / level lists behind the giants (side B) instead of behind the wave class (side A)
 	int tile = -1;       // -1: automatic (see enqueue_decode); BVGPU_TILE=0: never; BVGPU_TILE=1: short records decoded from contiguous tiles of the stream (k_parse_tile) instead of the bin-sorted parse list (k_parse_list)
-	DevBuf tilebounds, tiledone;
+	DevBuf tilebounds;
 	int copy_big = 1;    // BVGPU_COPY_BIG=0: every row is copied by one lane
 	int parse_windows = 1; // BVGPU_PARSE_WINDOWS=0: the parse list is sorted by work bin over the whole range
-	int tile_full = 1;     // BVGPU_TILE_FULL=0: a job that decodes its lane class from tiles takes k_parse_tile (rows straight into the CSR, every copy in the level kernels), not k_tile_full
 	int copy_mid_min = 128; // rows with at least this many successors (and fewer than 1024) are copied by one wave each
 	int32_t coop_min = 2048, giant_min = 32768;                         // thresholds on the outdegree (BVGPU_COOP_MIN / BVGPU_GIANT_MIN)
 	long long scan_top_tiled_min = -1, scan_piece = 0; // (-1 / 0: the defaults of bv_kernels.hip / scan_piece_arcs)
@@ -244,7 +243,6 @@ int apply_option(bvg_graph *g, const std::string &name, const char *value) {
 	else if (name == "level_blocks") g->level_blocks = std::max(1, iv);
 	else if (name == "copy_big") g->copy_big = iv;
 	else if (name == "parse_windows") g->parse_windows = iv;
-	else if (name == "tile_full") g->tile_full = iv;
 	else if (name == "tile") g->tile = iv;
 	else if (name == "seg") g->seg = iv;
 	else if (name == "seg_hub_min") g->seg_hub_min = std::max(1, iv);
@@ -272,7 +270,7 @@ int apply_option(bvg_graph *g, const std::string &name, const char *value) {
 	else return BVG_EARG;
 	return BVG_OK;
 }
-const char *const OPTION_NAMES[] = { "coop_min", "giant_min", "coop_waves", "giant_groups", "level_blocks", "copy_big", "parse_windows", "tile_full", "tile", "seg", "seg_hub_min", "seg_blocks", "lists_on_b",
+const char *const OPTION_NAMES[] = { "coop_min", "giant_min", "coop_waves", "giant_groups", "level_blocks", "copy_big", "parse_windows", "tile", "seg", "seg_hub_min", "seg_blocks", "lists_on_b",
 	"walk_tables", "copy_vec", "prewalk", "prewalk_long", "prewalk_blocks", "copy_mid_min", "overlap", "halo_min", "batch_dense", "scan_top_tiled_min", "wait_giants", "hash_materialise",
 	"ef_hash_materialise", "scan_piece", "dbg", "stats", "trace_retry", "trace_err", "trace_host" };
 void options_from_env(bvg_graph *g) {
@@ -580,17 +578,11 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		if (g->hash_job) tileVariant = 0; // (the hash fold rides on k_parse_list)
 		else if (g->tile < 0 && g->adaptive && v.coop_ptr && s.deg_counts[0] >= 0) {
 			const double share = (double)(s.h_offsets[(size_t)v.lo + v.cnt] - s.h_offsets[(size_t)v.lo]) / (double)std::max<int64_t>(s.h_offsets[(size_t)s.node_hi] - s.h_offsets[(size_t)s.stage_lo], 1);
-			if ((double)s.deg_counts[0] * share <= (double)COOP_BUDGET * (share > 0.999 ? 1.0 : 0.8)) tileVariant = g->tile_full ? 2 : 1; // (a sub-range: an estimate, with a margin)
+			if ((double)s.deg_counts[0] * share <= (double)COOP_BUDGET * (share > 0.999 ? 1.0 : 0.8)) tileVariant = 1; // (a sub-range: an estimate, with a margin)
 		}
 		const bool tiles = tileVariant != 0 && s.def != 0;
-		// whole tiles (k_tile_full, tile = 2 or chosen with tile_full on): the rows of a tile stay in LDS until the copies inside the tile are done; its bounds need the row starts
-		const bool tileFull = tiles && tileVariant == 2 && W > 0 && g->tiledone.need((size_t)v.cnt);
 		int32_t ntiles = 0;
-		if (tileFull) {
-			ntiles = bv::tilefull_count(s.h_offsets[(size_t)v.lo + v.cnt] - s.h_offsets[(size_t)v.lo], v.cnt, arcsBound);
-			if (!g->tilebounds.need(sizeof(int32_t) * ((size_t)ntiles + 2))) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
-			v.done = g->tiledone.as<uint8_t>();
-		} else if (tiles) {
+		if (tiles) {
 			ntiles = bv::tile_count(s.h_offsets[(size_t)v.lo + v.cnt] - s.h_offsets[(size_t)v.lo], v.cnt);
 			if (!g->tilebounds.need(sizeof(int32_t) * ((size_t)ntiles + 2))) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
 			bv::launch_tile_bounds(gd, v.lo, v.cnt, ntiles, g->tilebounds.as<int32_t>(), ovl && hdrEvent ? g->sideA : g->stream);
@@ -695,19 +687,14 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		if (!tiles && !earlyList)
 			bv::launch_build_lists(gd, v, ~0ull, g->parse_windows ? 6 : 2, nullptr, g->pkey16.as<uint16_t>(), g->pkeys.as<int32_t>(), pKeyBase, pKeyBase + (bv::NKEYS + 1), g->plist.as<int32_t>(),
 			                       g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->pad, g->stream);
-		if (earlyList || (tiles && !tileFull && ovl && hdrEvent)) HIPCHK(g, hipStreamWaitEvent(g->stream, g->evP, 0));
+		if (earlyList || (tiles && ovl && hdrEvent)) HIPCHK(g, hipStreamWaitEvent(g->stream, g->evP, 0));
 		if (coop && !ovl) bv::launch_classify(v.cnt, v.outd, v.coop_ptr, coopMin, giantMin, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, g->stream);
 		mark(g, 3);
 		if (coop && !ovl) bv::launch_parse_giants(gd, s.def, v, g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->giant_groups, derr, g->stream);
 		mark(g, 4);
 		if (coop && !ovl) bv::launch_parse_waves(gd, s.def, v, g->biglist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, derr, g->stream);
 		mark(g, 5);
-		if (tileFull) {
-			HIPCHK(g, hipMemsetAsync(g->tiledone.p, 0, (size_t)v.cnt, g->stream));
-			bv::launch_tilefull_bounds(gd, v, ntiles, g->tilebounds.as<int32_t>(), g->stream);
-			bv::launch_tile_full(gd, s.def, v, g->tilebounds.as<int32_t>(), ntiles, g->copy_mid_min, g->copy_big != 0, g->tiledone.as<uint8_t>(), derr, g->stream);
-		}
-		else if (tiles) bv::launch_parse_tile(gd, s.def, v, g->tilebounds.as<int32_t>(), ntiles, tileVariant, derr, g->stream);
+		if (tiles) bv::launch_parse_tile(gd, s.def, v, g->tilebounds.as<int32_t>(), ntiles, tileVariant, derr, g->stream);
 		else {
 			if (segReady) { // on side B, behind the giants: the pieces of the records that handed their residual sections over
 				hipStream_t stChain = g->stream;
@@ -1213,7 +1200,7 @@ extern "C" int bvg_close(bvg_t *g) {
 	if (g->st && g->st->device >= 0) {
 		(void)hipSetDevice(g->st->device);
 		if (g->own) { (void)hipStreamSynchronize(g->own); (void)hipStreamDestroy(g->own); }
-		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->hashBounds, &g->pickpart, &g->walktab, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist, &g->plist, &g->pkeys, &g->pkey16, &g->copyq, &g->walkdesc, &g->bigtmp, &g->tilebounds, &g->tiledone, &g->segbuf, &g->hashmark, &g->hashctx, &g->hashtab, &g->hashq }) b->release();
+		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->hashBounds, &g->pickpart, &g->walktab, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist, &g->plist, &g->pkeys, &g->pkey16, &g->copyq, &g->walkdesc, &g->bigtmp, &g->tilebounds, &g->segbuf, &g->hashmark, &g->hashctx, &g->hashtab, &g->hashq }) b->release();
 		for (DevBuf *b : { &g->hchunk[0], &g->hchunk[1], &g->statsbuf, &g->bfs_rowptr, &g->bfs_succ, &g->bfs_ctr }) b->release();
 		for (PinBuf *b : { &g->hring[0], &g->hring[1], &g->view_rowptr, &g->view_succ }) b->release();
 		for (hipEvent_t e : { g->evChunk[0], g->evChunk[1], g->evCopied[0], g->evCopied[1] }) if (e) (void)hipEventDestroy(e);
