@@ -11,6 +11,8 @@ cd /tmp
 pass() { local name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" -d "$R/$OUT/$name" -o "$name" --output-format csv -- python "$R/scripts/ab_time.py" $WL 3 > "$R/$OUT/$name.log" 2>&1; }
 pass sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD
 pass sq2 SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS
+
+
 python - "$R/$OUT" "$PAT" <<'PY'
 import csv, glob, os, sys, re
 from collections import defaultdict
