@@ -11,6 +11,7 @@
 #include "bv_launch.hpp"
 
 #include <hip/hip_runtime.h>
+#include <algorithm>
 
 namespace bv {
 
@@ -47,62 +48,78 @@ struct StatsDev { // accumulated with atomics
 	unsigned long long bad; // arcs whose successor is outside [0, n): a malformed stream (the reference would throw ArrayIndexOutOfBounds at Stats.java:130)
 };
 
+// Both kernels run as a few thousand blocks that walk the range and keep their sums to themselves until the end: ONE atomic per block and field.  (Round 5: with a
+// block per 256 nodes / 2 048 arcs and an atomic per wave and field, C2's 200 M arcs were 490 000 additions to the same eight words -- same-address atomics run at
+// ~88 M/s -- and bvg_scan_stats took 22.3 ms for a graph that scans in 3.0; scripts/stats_time.py.)
+constexpr int CS_GRID = 2048;
+__device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, unsigned long long *s_w) { // (all threads; the result is valid in thread 0)
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+	__syncthreads();
+	if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+	__syncthreads();
+	unsigned long long t = 0;
+	if (threadIdx.x == 0) for (int k = 0; k < CS_T / 64; k++) t += s_w[k];
+	return t;
+}
 __global__ void __launch_bounds__(CS_T) k_stats_nodes(int32_t from, int32_t cnt, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ, StatsDev *st) {
-	const int32_t s = blockIdx.x * CS_T + threadIdx.x;
+	__shared__ unsigned long long s_w[CS_T / 64], s_mn, s_mx;
 	unsigned long long dang = 0, term = 0, gaps = 0, totgap = 0, mn = ~0ull, mx = 0;
-	if (s < cnt) {
+	if (threadIdx.x == 0) { s_mn = ~0ull; s_mx = 0; }
+	for (int64_t s = (int64_t)blockIdx.x * CS_T + threadIdx.x; s < cnt; s += (int64_t)gridDim.x * CS_T) {
 		const int64_t lo = rowptr[s], hi = rowptr[s + 1];
 		const int64_t d = hi - lo;
-		const int32_t curr = from + s;
-		if (d == 0) { dang = 1; term = 1; }                                   // Stats.java:133-136
-		if (d == 1 && succ[lo] == curr) term = 1;                             // :138
+		const int32_t curr = from + (int32_t)s;
+		if (d == 0) { dang++; term++; }                                       // Stats.java:133-136
+		if (d == 1 && succ[lo] == curr) term++;                               // :138
 		if (d > 1) {                                                          // :119-123
 			const int32_t a = succ[lo], z = succ[hi - 1];
 			const int32_t diff = a - curr;
-			totgap = (unsigned long long)(int64_t)(z - a) + (unsigned long long)(diff >= 0 ? 2ll * diff : -2ll * diff - 1); // Fast.int2nat
-			gaps = (unsigned long long)d;
+			totgap += (unsigned long long)(int64_t)(z - a) + (unsigned long long)(diff >= 0 ? 2ll * diff : -2ll * diff - 1); // Fast.int2nat
+			gaps += (unsigned long long)d;
 		}
-		mn = ((unsigned long long)d << 32) | (uint32_t)curr;                  // smallest outdegree, then the first node that has it (:140-143)
-		mx = ((unsigned long long)d << 32) | (0xffffffffu - (uint32_t)curr);  // largest outdegree, then the first node that has it (:145-148)
+		mn = min(mn, ((unsigned long long)d << 32) | (uint32_t)curr);                  // smallest outdegree, then the first node that has it (:140-143)
+		mx = max(mx, ((unsigned long long)d << 32) | (0xffffffffu - (uint32_t)curr));  // largest outdegree, then the first node that has it (:145-148)
 	}
-	// wave reductions, then one atomic per wave and field
-	for (int o = 32; o > 0; o >>= 1) {
-		dang += __shfl_xor(dang, o, 64); term += __shfl_xor(term, o, 64); gaps += __shfl_xor(gaps, o, 64); totgap += __shfl_xor(totgap, o, 64);
-		mn = min(mn, (unsigned long long)__shfl_xor(mn, o, 64)); mx = max(mx, (unsigned long long)__shfl_xor(mx, o, 64));
-	}
-	if ((threadIdx.x & 63) == 0) {
+	for (int o = 32; o > 0; o >>= 1) { mn = min(mn, (unsigned long long)__shfl_xor(mn, o, 64)); mx = max(mx, (unsigned long long)__shfl_xor(mx, o, 64)); }
+	__syncthreads();
+	if ((threadIdx.x & 63) == 0) { atomicMin(&s_mn, mn); atomicMax(&s_mx, mx); }
+	dang = block_sum_u64(dang, s_w); term = block_sum_u64(term, s_w); gaps = block_sum_u64(gaps, s_w); totgap = block_sum_u64(totgap, s_w);
+	if (threadIdx.x == 0) {
 		if (dang) atomicAdd(&st->dangling, dang);
 		if (term) atomicAdd(&st->terminal, term);
 		if (gaps) { atomicAdd(&st->num_gaps, gaps); atomicAdd(&st->tot_gap, totgap); }
-		if (mn != ~0ull) { atomicMin(&st->min_key, mn); atomicMax(&st->max_key, mx); }
+		if (s_mn != ~0ull) { atomicMin(&st->min_key, s_mn); atomicMax(&st->max_key, s_mx); }
 	}
 }
 
 __global__ void __launch_bounds__(CS_T) k_stats_arcs(int32_t from, int32_t cnt, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ, StatsDev *st, int32_t *__restrict__ indegree, int32_t n) {
 	__shared__ int64_t s_rp[CS_ARCS + 2];
 	__shared__ int32_t s_b[2];
-	__shared__ unsigned long long s_delta[32];
-	const int64_t arcs = rowptr[cnt], a0 = (int64_t)blockIdx.x * CS_ARCS, a1 = min(a0 + CS_ARCS, arcs);
-	if (a0 >= a1) return;
+	__shared__ unsigned long long s_delta[32], s_w[CS_T / 64];
+	const int64_t arcs = rowptr[cnt];
 	if (threadIdx.x < 32) s_delta[threadIdx.x] = 0;
-	const RowSlice rs = stage_rows(rowptr, cnt, a0, a1, s_rp, s_b);
-	__syncthreads();
-	unsigned long long loops = 0, loc = 0, bad = 0;
-	for (int64_t a = a0 + threadIdx.x; a < a1; a += CS_T) {
-		const int32_t curr = from + rs.rlo + row_of(rs.rp, rs.n, a), sx = succ[a];
-		const int64_t dist = (int64_t)sx - curr;
-		const unsigned long long ad = (unsigned long long)(dist < 0 ? -dist : dist);
-		loc += ad;                                                            // Stats.java:125
-		if (sx != curr) atomicAdd(&s_delta[63 - __clzll((long long)ad)], 1ull); // :127  Fast.mostSignificantBit
-		else loops++;                                                         // :128
-		if ((uint32_t)sx >= (uint32_t)n) bad++;                               // never index with an id the stream made up
-		else if (indegree) atomicAdd(&indegree[sx], 1);                       // :130
+	unsigned long long loops = 0, loc = 0, bad = 0, seen = 0;
+	for (int64_t a0 = (int64_t)blockIdx.x * CS_ARCS; a0 < arcs; a0 += (int64_t)gridDim.x * CS_ARCS) { // (uniform in the block)
+		const int64_t a1 = min(a0 + CS_ARCS, arcs);
+		__syncthreads(); // (the staged rows of the slice before)
+		const RowSlice rs = stage_rows(rowptr, cnt, a0, a1, s_rp, s_b);
+		__syncthreads();
+		for (int64_t a = a0 + threadIdx.x; a < a1; a += CS_T) {
+			const int32_t curr = from + rs.rlo + row_of(rs.rp, rs.n, a), sx = succ[a];
+			const int64_t dist = (int64_t)sx - curr;
+			const unsigned long long ad = (unsigned long long)(dist < 0 ? -dist : dist);
+			loc += ad;                                                            // Stats.java:125
+			if (sx != curr) atomicAdd(&s_delta[63 - __clzll((long long)ad)], 1ull); // :127  Fast.mostSignificantBit
+			else loops++;                                                         // :128
+			if ((uint32_t)sx >= (uint32_t)n) bad++;                               // never index with an id the stream made up
+			else if (indegree) atomicAdd(&indegree[sx], 1);                       // :130
+			seen++;
+		}
 	}
-	for (int o = 32; o > 0; o >>= 1) { loops += __shfl_xor(loops, o, 64); loc += __shfl_xor(loc, o, 64); bad += __shfl_xor(bad, o, 64); }
-	if ((threadIdx.x & 63) == 0) { if (loops) atomicAdd(&st->loops, loops); atomicAdd(&st->tot_loc, loc); if (bad) atomicAdd(&st->bad, bad); }
+	loops = block_sum_u64(loops, s_w); loc = block_sum_u64(loc, s_w); bad = block_sum_u64(bad, s_w); seen = block_sum_u64(seen, s_w);
+	if (threadIdx.x == 0) { if (loops) atomicAdd(&st->loops, loops); if (loc) atomicAdd(&st->tot_loc, loc); if (bad) atomicAdd(&st->bad, bad); if (seen) atomicAdd(&st->arcs, seen); }
 	__syncthreads();
 	if (threadIdx.x < 32 && s_delta[threadIdx.x]) atomicAdd(&st->delta[threadIdx.x], s_delta[threadIdx.x]);
-	if (threadIdx.x == 0) atomicAdd(&st->arcs, (unsigned long long)(a1 - a0));
 }
 
 // One round of the visit over the rows of the frontier's nodes (rowptr / succ = bvg_successors_batch of the frontier).
@@ -135,8 +152,8 @@ __global__ void __launch_bounds__(CS_T) k_bfs_expand(const int32_t *__restrict__
 
 void launch_stats(int32_t from, int32_t cnt, const int64_t *rowptr, const int32_t *succ, int64_t arcsUpper, void *statsDev, int32_t *indegree, int32_t n, hipStream_t st) {
 	if (cnt <= 0) return;
-	hipLaunchKernelGGL(k_stats_nodes, dim3((unsigned)((cnt + CS_T - 1) / CS_T)), dim3(CS_T), 0, st, from, cnt, rowptr, succ, (StatsDev *)statsDev);
-	if (arcsUpper > 0) hipLaunchKernelGGL(k_stats_arcs, dim3((unsigned)((arcsUpper + CS_ARCS - 1) / CS_ARCS)), dim3(CS_T), 0, st, from, cnt, rowptr, succ, (StatsDev *)statsDev, indegree, n);
+	hipLaunchKernelGGL(k_stats_nodes, dim3((unsigned)std::min<int64_t>(((int64_t)cnt + CS_T - 1) / CS_T, CS_GRID)), dim3(CS_T), 0, st, from, cnt, rowptr, succ, (StatsDev *)statsDev);
+	if (arcsUpper > 0) hipLaunchKernelGGL(k_stats_arcs, dim3((unsigned)std::min<int64_t>((arcsUpper + CS_ARCS - 1) / CS_ARCS, CS_GRID)), dim3(CS_T), 0, st, from, cnt, rowptr, succ, (StatsDev *)statsDev, indegree, n);
 }
 size_t stats_dev_bytes() { return sizeof(StatsDev); }
 void launch_bfs_expand(const int32_t *frontier, int32_t q, const int64_t *rowptr, const int32_t *succ, int64_t arcs, int32_t *marker, int32_t n, int32_t round, int parent,
