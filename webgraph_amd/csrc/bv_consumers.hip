@@ -122,32 +122,30 @@ __global__ void __launch_bounds__(CS_T) k_stats_arcs(int32_t from, int32_t cnt, 
 	if (threadIdx.x < 32 && s_delta[threadIdx.x]) atomicAdd(&st->delta[threadIdx.x], s_delta[threadIdx.x]);
 }
 
-// One round of the visit over the rows of the frontier's nodes (rowptr / succ = bvg_successors_batch of the frontier).
+// One round of the visit over the rows of the frontier's nodes (rowptr / succ = bvg_successors_batch of the frontier).  A block keeps the winners of its 2 048 arcs in
+// LDS and appends them with ONE addition to the frontier's counter (round 5: an addition per wave was 195 000 same-address atomics for a frontier of 12 M arcs, half the round).
 __global__ void __launch_bounds__(CS_T) k_bfs_expand(const int32_t *__restrict__ frontier, int32_t q, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ,
                                                      int32_t *marker, int32_t n, int32_t round, int parent, int32_t *__restrict__ out, unsigned long long outCap, unsigned long long *outCount) {
 	__shared__ int64_t s_rp[CS_ARCS + 2];
-	__shared__ int32_t s_b[2];
+	__shared__ int32_t s_b[2], s_won[CS_ARCS], s_n;
+	__shared__ unsigned long long s_at;
 	const int64_t arcs = rowptr[q], a0 = (int64_t)blockIdx.x * CS_ARCS, a1 = min(a0 + CS_ARCS, arcs);
 	if (a0 >= a1) return;
+	if (threadIdx.x == 0) s_n = 0;
 	const RowSlice rs = stage_rows(rowptr, q, a0, a1, s_rp, s_b);
-	for (int64_t base = a0; base < a1; base += CS_T) { // (uniform trip count: the ballot below needs whole waves)
-		const int64_t a = base + threadIdx.x;
-		bool won = false;
-		int32_t sx = 0;
-		if (a < a1) {
-			sx = succ[a];
-			const int32_t mark = parent ? frontier[rs.rlo + row_of(rs.rp, rs.n, a)] : round; // ParallelBreadthFirstVisit.java:162
-			won = (uint32_t)sx < (uint32_t)n && atomicCAS(&marker[sx], -1, mark) == -1;     // :165 marker.compareAndSet(s, -1, mark)
-		}
-		const unsigned long long m = __ballot(won); // one append per wave
-		if (m) {
-			const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
-			unsigned long long at = 0;
-			if (lane == leader) at = atomicAdd(outCount, (unsigned long long)__popcll(m));
-			at = __shfl(at, leader, 64);
-			if (won) { const unsigned long long p = at + (unsigned long long)__popcll(m & ((1ull << lane) - 1)); if (p < outCap) out[p] = sx; }
-		}
+	__syncthreads();
+	for (int64_t a = a0 + threadIdx.x; a < a1; a += CS_T) {
+		const int32_t sx = succ[a];
+		const int32_t mark = parent ? frontier[rs.rlo + row_of(rs.rp, rs.n, a)] : round;    // ParallelBreadthFirstVisit.java:162
+		if ((uint32_t)sx < (uint32_t)n && atomicCAS(&marker[sx], -1, mark) == -1) s_won[atomicAdd(&s_n, 1)] = sx; // :165 marker.compareAndSet(s, -1, mark)
 	}
+	__syncthreads();
+	const int32_t nw = s_n;
+	if (nw == 0) return;
+	if (threadIdx.x == 0) s_at = atomicAdd(outCount, (unsigned long long)nw);
+	__syncthreads();
+	const unsigned long long at = s_at;
+	for (int32_t k = threadIdx.x; k < nw; k += CS_T) if (at + k < outCap) out[at + k] = s_won[k];
 }
 
 void launch_stats(int32_t from, int32_t cnt, const int64_t *rowptr, const int32_t *succ, int64_t arcsUpper, void *statsDev, int32_t *indegree, int32_t n, hipStream_t st) {
@@ -167,34 +165,105 @@ void launch_bfs_expand(const int32_t *frontier, int32_t q, const int64_t *rowptr
 // register (:907-913, max() is a register-wise maximum); a counter that changed is stored in the result array and flagged (:972-978).  A counter
 // is m = 2^log2m registers, one byte each here (the reference packs registerSize bits into longwords and maximises them broadword: same values).
 // One wave per node, lane r takes registers r, r + 64, ...: the successors' counters are read 64 bytes at a time.
+// Round 5: rows of fewer than HB_BIG successors by a wave each -- the waves walk the range (one addition to `changed` per block), a row's successors 64 at a time (ids and
+// modified flags fetched by the 64 lanes), the counters of the ones that count four at a time in flight; longer rows by a group of sixteen waves each (k_hyperball_big).  Before: a
+// wave per node walking its successors one dependent load after the other, an atomic per changed counter -- C2 (m = 64): 219 ms for a graph that scans in 3, its row of 347 500
+// successors alone a third of a second of one wave.
+constexpr int HB_BIG = 2048, HB_GRID = 4096, HB_BIG_T = 1024;
+__device__ __forceinline__ uint8_t hb_max4(uint8_t t, uint8_t a, uint8_t b, uint8_t c, uint8_t d) { const uint8_t x = a > b ? a : b, y = c > d ? c : d, z = x > y ? x : y; return z > t ? z : t; }
+// the counters of the successors in [a0, a0 + 64) of a row, register r of each, folded into t (wave-uniform control flow)
+__device__ __forceinline__ uint8_t hb_chunk(uint8_t t, int64_t a0, int64_t hi, int32_t node, int32_t n, int32_t m, int32_t r, const int32_t *__restrict__ succ, const uint8_t *__restrict__ regsIn, const uint8_t *__restrict__ modIn) {
+	const int lane = threadIdx.x & 63;
+	const int64_t a = a0 + lane;
+	const int32_t sx = a < hi ? succ[a] : -1;
+	const bool use = a < hi && sx != node && (uint32_t)sx < (uint32_t)n && (!modIn || modIn[sx]); // neither self-loops nor unmodified counters influence the computation (:909)
+	unsigned long long mask = __ballot(use);
+	while (mask) {
+		const int k0 = __ffsll((long long)mask) - 1; mask &= mask - 1;
+		const int k1 = mask ? __ffsll((long long)mask) - 1 : k0; mask &= mask - 1;
+		const int k2 = mask ? __ffsll((long long)mask) - 1 : k1; mask &= mask - 1;
+		const int k3 = mask ? __ffsll((long long)mask) - 1 : k2; mask &= mask - 1;
+		const int32_t s0 = __shfl(sx, k0, 64), s1 = __shfl(sx, k1, 64), s2 = __shfl(sx, k2, 64), s3 = __shfl(sx, k3, 64);
+		if (r < m) {
+			const uint8_t u0 = regsIn[(size_t)s0 * m + r], u1 = regsIn[(size_t)s1 * m + r], u2 = regsIn[(size_t)s2 * m + r], u3 = regsIn[(size_t)s3 * m + r];
+			t = hb_max4(t, u0, u1, u2, u3);
+		}
+	}
+	return t;
+}
 __global__ void __launch_bounds__(CS_T) k_hyperball(int32_t from, int32_t cnt, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ, int32_t n, int32_t m,
                                                     const uint8_t *__restrict__ regsIn, uint8_t *__restrict__ regsOut, const uint8_t *__restrict__ modIn, uint8_t *__restrict__ modOut,
                                                     unsigned long long *__restrict__ changed) {
+	__shared__ unsigned long long s_w[CS_T / 64];
 	const int lane = threadIdx.x & 63;
-	const int32_t row = blockIdx.x * (CS_T / 64) + (threadIdx.x >> 6);
-	if (row >= cnt) return;
-	const int32_t node = from + row;
-	const int64_t lo = rowptr[row], hi = rowptr[row + 1];
-	bool any = false;
-	for (int32_t r0 = 0; r0 < m; r0 += 64) {
-		const int32_t r = r0 + lane;
-		const uint8_t t0 = r < m ? regsIn[(size_t)node * m + r] : 0;
-		uint8_t t = t0;
-		for (int64_t a = lo; a < hi; a++) {
-			const int32_t sx = succ[a]; // (the same address for every lane: one broadcast load)
-			if (sx == node || (uint32_t)sx >= (uint32_t)n || (modIn && !modIn[sx])) continue; // neither self-loops nor unmodified counters influence the computation (:909)
-			if (r < m) { const uint8_t u = regsIn[(size_t)sx * m + r]; t = u > t ? u : t; }
+	const int64_t nWaves = (int64_t)gridDim.x * (CS_T / 64);
+	unsigned long long nch = 0;
+	for (int64_t row = (int64_t)blockIdx.x * (CS_T / 64) + (threadIdx.x >> 6); row < cnt; row += nWaves) {
+		const int64_t lo = rowptr[row], hi = rowptr[row + 1];
+		if (hi - lo >= HB_BIG) continue;
+		const int32_t node = from + (int32_t)row;
+		bool any = false;
+		for (int32_t r0 = 0; r0 < m; r0 += 64) {
+			const int32_t r = r0 + lane;
+			const uint8_t t0 = r < m ? regsIn[(size_t)node * m + r] : 0;
+			uint8_t t = t0;
+			for (int64_t a0 = lo; a0 < hi; a0 += 64) t = hb_chunk(t, a0, hi, node, n, m, r, succ, regsIn, modIn);
+			if (r < m) regsOut[(size_t)node * m + r] = t;
+			any |= t != t0;
 		}
-		if (r < m) regsOut[(size_t)node * m + r] = t;
-		any |= t != t0;
+		const bool rowChanged = __any(any);
+		if (lane == 0) { modOut[node] = rowChanged ? 1 : 0; nch += rowChanged ? 1 : 0; }
 	}
-	const bool rowChanged = __any(any);
-	if (lane == 0) { modOut[node] = rowChanged ? 1 : 0; if (rowChanged) atomicAdd(changed, 1ull); }
+	nch = block_sum_u64(nch, s_w);
+	if (threadIdx.x == 0 && nch) atomicAdd(changed, nch);
+}
+// the rows of HB_BIG successors and more: a group of sixteen waves per row, every wave a share of the row's chunks of 64 successors, the waves' maxima joined in LDS
+__global__ void __launch_bounds__(HB_BIG_T) k_hyperball_big(int32_t from, int32_t cnt, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ, int32_t n, int32_t m,
+                                                            const uint8_t *__restrict__ regsIn, uint8_t *__restrict__ regsOut, const uint8_t *__restrict__ modIn, uint8_t *__restrict__ modOut,
+                                                            unsigned long long *__restrict__ changed) {
+	constexpr int NWV = HB_BIG_T / 64;
+	__shared__ int32_t s_rows[HB_BIG_T], s_n;
+	__shared__ uint8_t s_t[NWV][64];
+	__shared__ int32_t s_any;
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	unsigned long long nch = 0;
+	for (int64_t base = (int64_t)blockIdx.x * HB_BIG_T; base < cnt; base += (int64_t)gridDim.x * HB_BIG_T) { // (uniform in the block)
+		if (threadIdx.x == 0) s_n = 0;
+		__syncthreads();
+		const int64_t row = base + threadIdx.x;
+		if (row < cnt && rowptr[row + 1] - rowptr[row] >= HB_BIG) s_rows[atomicAdd(&s_n, 1)] = (int32_t)row;
+		__syncthreads();
+		const int32_t nb = s_n;
+		for (int32_t q = 0; q < nb; q++) {
+			const int32_t rw = s_rows[q], node = from + rw;
+			const int64_t lo = rowptr[rw], hi = rowptr[rw + 1];
+			if (threadIdx.x == 0) s_any = 0;
+			for (int32_t r0 = 0; r0 < m; r0 += 64) {
+				const int32_t r = r0 + lane;
+				const uint8_t t0 = r < m ? regsIn[(size_t)node * m + r] : 0;
+				uint8_t t = t0;
+				for (int64_t a0 = lo + 64 * wv; a0 < hi; a0 += 64 * NWV) t = hb_chunk(t, a0, hi, node, n, m, r, succ, regsIn, modIn);
+				s_t[wv][lane] = t;
+				__syncthreads();
+				if (wv == 0) {
+					uint8_t x = t;
+					for (int k = 1; k < NWV; k++) { const uint8_t y = s_t[k][lane]; x = y > x ? y : x; }
+					if (r < m) regsOut[(size_t)node * m + r] = x;
+					if (__any(x != t0) && lane == 0) s_any = 1;
+				}
+				__syncthreads();
+			}
+			if (threadIdx.x == 0) { modOut[node] = s_any ? 1 : 0; nch += s_any ? 1 : 0; }
+			__syncthreads();
+		}
+	}
+	if (threadIdx.x == 0 && nch) atomicAdd(changed, nch);
 }
 void launch_hyperball(int32_t from, int32_t cnt, const int64_t *rowptr, const int32_t *succ, int32_t n, int32_t m, const uint8_t *regsIn, uint8_t *regsOut, const uint8_t *modIn, uint8_t *modOut,
                       unsigned long long *changed, hipStream_t st) {
 	if (cnt <= 0) return;
-	hipLaunchKernelGGL(k_hyperball, dim3((unsigned)((cnt + CS_T / 64 - 1) / (CS_T / 64))), dim3(CS_T), 0, st, from, cnt, rowptr, succ, n, m, regsIn, regsOut, modIn, modOut, changed);
+	hipLaunchKernelGGL(k_hyperball, dim3((unsigned)std::min<int64_t>(((int64_t)cnt + CS_T / 64 - 1) / (CS_T / 64), HB_GRID)), dim3(CS_T), 0, st, from, cnt, rowptr, succ, n, m, regsIn, regsOut, modIn, modOut, changed);
+	hipLaunchKernelGGL(k_hyperball_big, dim3((unsigned)std::min<int64_t>(((int64_t)cnt + HB_BIG_T - 1) / HB_BIG_T, 512)), dim3(HB_BIG_T), 0, st, from, cnt, rowptr, succ, n, m, regsIn, regsOut, modIn, modOut, changed);
 }
 
 } // namespace bv
