@@ -193,6 +193,14 @@ void bvg_host_free(void *p);
 int bvg_scan_checksum(bvg_t *g, int32_t from, int32_t to, int32_t *hash_io, uint64_t *arcs_out);
 
 /*
+ * ImmutableGraph.equals() (ImmutableGraph.java:731-749) restricted to nodes [from, to): *equal = 1 iff both handles give every node of the range the same
+ * outdegree and the same successors.  Both graphs are decoded piece by piece into the scratch of their handles and compared on the device: no row reaches
+ * the host (the mirrors' equals() ran two host-bound scans and a host comparison: 329 ms for C2 against 8 here).  The handles must live on the same device
+ * and hold at least `to` nodes each (BVG_EARG otherwise); they may be the same handle or clones.
+ */
+int bvg_equal_range(bvg_t *a, bvg_t *b, int32_t from, int32_t to, int *equal);
+
+/*
  * Two more consumers that never hand the caller a successor array; both work a chunk of the
  * graph at a time on rows decoded into library scratch.
  *

@@ -47,6 +47,7 @@ public class GpuBVGraph extends ImmutableGraph {
 	private static native int[] decodeRange(long handle, int from, int to, long[] rowptr);      // bvg_decode_range_view
 	/** hashCode() continued from h over [from,to) on the device; nothing is materialised. */
 	private static native int scanChecksum(long handle, int from, int to, int h);               // bvg_scan_checksum
+	private static native boolean equalRange(long handleA, long handleB, int from, int to);      // bvg_equal_range
 	/** bvg_store: compresses the CSR (rowptr[n+1], succ) on the device and writes basename.graph / .offsets / .properties. */
 	private static native void storeCsr(String basename, int device, int n, long[] rowptr, int[] succ, int windowSize, int maxRefCount, int minIntervalLength,
 		int zetaK, int flags, int numberOfThreads) throws IOException;
@@ -123,6 +124,11 @@ public class GpuBVGraph extends ImmutableGraph {
 
 	/** ImmutableGraph.hashCode() (ImmutableGraph.java:757-770) as one checksum scan on the device. */
 	@Override public int hashCode() { return scanChecksum(handle, 0, n, -1); }
+	/** ImmutableGraph.equals (ImmutableGraph.java:731-749); two graphs of this class are compared on the device, row by row, without a list reaching the JVM. */
+	@Override public boolean equals(final Object o) {
+		if (o instanceof GpuBVGraph) { final GpuBVGraph g = (GpuBVGraph)o; return n == g.n && equalRange(handle, g.handle, 0, n); }
+		return super.equals(o);
+	}
 
 	/** Sequential scan served from GPU-decoded batches; same contract as BVGraph's node iterator. */
 	private final class BatchIterator extends NodeIterator {

@@ -87,6 +87,14 @@ JNIEXPORT jint JNICALL Java_it_unimi_dsi_webgraph_gpu_GpuBVGraph_scanChecksum(JN
 	return v;
 }
 
+JNIEXPORT jboolean JNICALL Java_it_unimi_dsi_webgraph_gpu_GpuBVGraph_equalRange(JNIEnv *env, jclass c, jlong handleA, jlong handleB, jint from, jint to) {
+	bvg_t *a = (bvg_t *)(intptr_t)handleA, *b = (bvg_t *)(intptr_t)handleB;
+	int eq = 0;
+	const int rc = bvg_equal_range(a, b, from, to, &eq);
+	if (rc) throw_status(env, rc, a);
+	return eq ? JNI_TRUE : JNI_FALSE;
+}
+
 static void throw_msg(JNIEnv *env, int rc, const char *msg) {
 	const char *cls = rc == BVG_EARG ? "java/lang/IllegalArgumentException"
 	                : rc == BVG_EUNSUPPORTED ? "java/lang/UnsupportedOperationException"

@@ -66,6 +66,17 @@ def test_equals_like_the_reference(cnr_gpu, tmp_path):
     T.store(str(tmp_path / "longer"), rp4, succ, window=7, max_ref_count=3, min_interval=3)
     g4 = BVGraph.load(str(tmp_path / "longer"))
     assert not cnr_gpu.equals(g4) and not cnr_gpu.equals("not a graph")
+    # the same through the entry point the mirrors call (bvg_equal_range): the differing id sits in the last non-empty row, every range in front of it is equal
+    n = cnr_gpu.numNodes()
+    last = int(np.nonzero(np.diff(rowptr))[0][-1])
+    assert cnr_gpu.equal_range(g3, 0, last) and cnr_gpu.equal_range(g3, 1000, 20000) and not cnr_gpu.equal_range(g3, last, last + 1) and not cnr_gpu.equal_range(g3, 0, n)
+    assert cnr_gpu.equal_range(g4, 0, n) and cnr_gpu.equal_range(cnr_gpu, 0, n) and cnr_gpu.equal_range(g2, 12345, 12345)
+    with pytest.raises(ValueError):
+        cnr_gpu.equal_range(g2, 0, n + 1)
+    for knob in ("1000", "200000"):  # in pieces
+        cnr_gpu.set_option("scan_piece", knob)
+        assert cnr_gpu.equal_range(g2, 0, n) and not cnr_gpu.equal_range(g3, 0, n)
+    cnr_gpu.set_option("scan_piece", "0")
     for g in (g2, g3, g4):
         g.close()
 

@@ -55,7 +55,7 @@ class BvgLabelsInfo(C.Structure):
 
 
 EXPORTS = ["bvg_open", "bvg_open_shard", "bvg_clone", "bvg_close", "bvg_info", "bvg_last_error", "bvg_set_stream", "bvg_sync",
-           "bvg_outdegrees", "bvg_decode_range", "bvg_decode_range_view", "bvg_host_alloc", "bvg_host_free", "bvg_scan_checksum", "bvg_scan_stats", "bvg_bfs_expand", "bvg_hyperball_step", "bvg_successors_batch", "bvg_csr_hashcode", "bvg_shard_bounds",
+           "bvg_outdegrees", "bvg_decode_range", "bvg_decode_range_view", "bvg_host_alloc", "bvg_host_free", "bvg_scan_checksum", "bvg_equal_range", "bvg_scan_stats", "bvg_bfs_expand", "bvg_hyperball_step", "bvg_successors_batch", "bvg_csr_hashcode", "bvg_shard_bounds",
            "bvg_parse_properties", "bvg_flags_from_string", "bvg_decode_offsets_host", "bvg_decode_offsets_device", "bvg_labels_open", "bvg_labels_close", "bvg_labels_info",
            "bvg_labels_last_error", "bvg_labels_parse_properties", "bvg_labels_decode_range", "bvg_labels_decode_lists", "bvg_compress", "bvg_compressed_free", "bvg_compressed_copy", "bvg_store", "bvg_recompress", "bvg_store_ef", "bvg_recompress_ef", "bvg_cache_as_efgraph", "bvg_set_option", "bvg_set_profile", "bvg_get_profile", "bvg_debug_stats", "bvg_last_thresholds"]
 
@@ -92,6 +92,7 @@ def lib():
         L.bvg_host_free.argtypes = [vp]
         L.bvg_host_free.restype = None
         L.bvg_scan_checksum.argtypes = [vp, i32, i32, C.POINTER(i32), C.POINTER(u64)]
+        L.bvg_equal_range.argtypes = [vp, vp, C.c_int32, C.c_int32, C.POINTER(C.c_int)]
         L.bvg_scan_stats.argtypes = [vp, i32, i32, C.POINTER(BvgScanStats), vp]
         L.bvg_bfs_expand.argtypes = [vp, vp, sz, vp, i32, C.c_int, vp, sz, C.POINTER(u64)]
         L.bvg_hyperball_step.argtypes = [vp, i32, i32, C.c_int, vp, vp, vp, vp, C.POINTER(u64)]
@@ -624,6 +625,13 @@ class BVGraph:
         """ImmutableGraph.hashCode() (ImmutableGraph.java:757-770): a checksum scan on the device (bvg_scan_checksum)."""
         return self.scan_checksum(0, self.numNodes(), -1)[0]
 
+    def equal_range(self, other, lo=0, hi=None):
+        """bvg_equal_range: do both handles give every node of [lo, hi) the same successors?  Compared on the device."""
+        hi = self.numNodes() if hi is None else hi
+        eq = C.c_int(0)
+        self._check(lib().bvg_equal_range(self._h, other._h, lo, hi, C.byref(eq)))
+        return bool(eq.value)
+
     def equals(self, other):
         """ImmutableGraph.equals() (ImmutableGraph.java:731-749): same number of nodes and the same successor list for
         every node; both graphs are scanned in lock step, a batch of nodes at a time."""
@@ -632,6 +640,13 @@ class BVGraph:
         n = self.numNodes()
         if n != other.numNodes():
             return False
+        if isinstance(other, BVGraph) and getattr(other, "_h", None) and self._h:  # two handles of this library: compared on the device (bvg_equal_range)
+            eq = C.c_int(0)
+            rc = lib().bvg_equal_range(self._h, other._h, 0, n, C.byref(eq))
+            if rc == 0:
+                return bool(eq.value)
+            if rc != BVG_EARG:  # (BVG_EARG: e.g. handles on different devices -- the host comparison below serves them)
+                self._check(rc)
         step = 1 << 22
         for lo in range(0, n, step):
             hi = min(lo + step, n)

@@ -154,6 +154,19 @@ void launch_stats(int32_t from, int32_t cnt, const int64_t *rowptr, const int32_
 	if (arcsUpper > 0) hipLaunchKernelGGL(k_stats_arcs, dim3((unsigned)std::min<int64_t>((arcsUpper + CS_ARCS - 1) / CS_ARCS, CS_GRID)), dim3(CS_T), 0, st, from, cnt, rowptr, succ, (StatsDev *)statsDev, indegree, n);
 }
 size_t stats_dev_bytes() { return sizeof(StatsDev); }
+// bvg_equal_range: rows of the same nodes decoded from two handles; *differ |= 1 where the row starts or the successors differ (the successors are only looked at
+// where both row-start arrays agree up to there: a lane compares position i of both arrays and stays inside both)
+__global__ void __launch_bounds__(CS_T) k_rows_differ(int32_t cnt, const int64_t *__restrict__ rpA, const int64_t *__restrict__ rpB, const int32_t *__restrict__ scA, const int32_t *__restrict__ scB, int *__restrict__ differ) {
+	const int64_t arcsA = rpA[cnt] - rpA[0], arcsB = rpB[cnt] - rpB[0], arcs = arcsA < arcsB ? arcsA : arcsB, stride = (int64_t)gridDim.x * CS_T;
+	bool bad = arcsA != arcsB;
+	for (int64_t i = (int64_t)blockIdx.x * CS_T + threadIdx.x; i <= cnt; i += stride) bad |= rpA[i] - rpA[0] != rpB[i] - rpB[0];
+	for (int64_t i = (int64_t)blockIdx.x * CS_T + threadIdx.x; i < arcs; i += stride) bad |= scA[i] != scB[i];
+	if (__any(bad) && (threadIdx.x & 63) == 0) *differ = 1; // (a plain store: every writer writes the same value)
+}
+void launch_rows_differ(int32_t cnt, const int64_t *rpA, const int64_t *rpB, const int32_t *scA, const int32_t *scB, int *differ, hipStream_t st) {
+	if (cnt < 0) return;
+	hipLaunchKernelGGL(k_rows_differ, dim3(CS_GRID), dim3(CS_T), 0, st, cnt, rpA, rpB, scA, scB, differ);
+}
 void launch_bfs_expand(const int32_t *frontier, int32_t q, const int64_t *rowptr, const int32_t *succ, int64_t arcs, int32_t *marker, int32_t n, int32_t round, int parent,
                        int32_t *out, uint64_t outCap, unsigned long long *outCount, hipStream_t st) {
 	if (q <= 0 || arcs <= 0) return;

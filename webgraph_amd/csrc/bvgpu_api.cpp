@@ -1804,6 +1804,46 @@ extern "C" int bvg_scan_stats(bvg_t *g, int32_t from, int32_t to, bvg_scan_stats
 	return BVG_OK;
 }
 
+extern "C" int bvg_equal_range(bvg_t *a, bvg_t *b, int32_t from, int32_t to, int *equal) {
+	if (!a || !b || !a->st || !b->st || !equal) return BVG_EARG;
+	*equal = 0;
+	const Staged &sa = *a->st, &sb = *b->st;
+	if (sa.device != sb.device) return fail(a, BVG_EARG, "the two handles live on different devices");
+	if (from < 0 || to < from || to > sa.info.nodes || to > sb.info.nodes) return fail(a, BVG_EARG, "node range out of bounds"); // BVG:1165
+	HIPCHK(a, hipSetDevice(sa.device));
+	if (!a->bfs_ctr.need(sizeof(unsigned long long))) return fail(a, BVG_ENOMEM, "device scratch allocation failed");
+	HIPCHK(a, hipMemset(a->bfs_ctr.p, 0, sizeof(unsigned long long)));
+	int differ = 0;
+	const std::vector<int32_t> cut = plan_chunks_by_bits(sa, from, to, scan_piece_arcs(a));
+	for (size_t k = 0; k + 1 < cut.size() && !differ; k++) {
+		const int32_t lo = cut[k], hi = cut[k + 1];
+		if (hi == lo) continue;
+		uint64_t arcs[2] = { 0, 0 };
+		bvg_t *h[2] = { a, b };
+		for (int w = 0; w < 2; w++) { // (the same handle twice: its scratch holds one piece at a time -- compared with itself it is equal)
+			bvg_t *g = h[w];
+			if (w == 1 && b == a) break;
+			const Staged &s = *g->st;
+			if (!g->stage_rowptr.need(sizeof(int64_t) * ((size_t)(hi - lo) + 1))) return fail(a, BVG_ENOMEM, "staging allocation failed");
+			const uint64_t guess = (uint64_t)(est_arcs(s, lo, hi) * 1.1) + 4096;
+			if (!g->stage_succ.need(sizeof(int32_t) * (size_t)guess)) return fail(a, BVG_ENOMEM, "staging allocation failed");
+			int rc = decode_range_device(g, lo, hi, g->stage_rowptr.as<int64_t>(), g->stage_succ.as<int32_t>(), g->stage_succ.cap / sizeof(int32_t), false, &arcs[w]);
+			if (rc == BVG_ECAP) {
+				if (!g->stage_succ.need(sizeof(int32_t) * (size_t)std::max<uint64_t>(arcs[w], 1))) return fail(a, BVG_ENOMEM, "staging allocation failed");
+				rc = decode_range_device(g, lo, hi, g->stage_rowptr.as<int64_t>(), g->stage_succ.as<int32_t>(), g->stage_succ.cap / sizeof(int32_t), false, &arcs[w]);
+			}
+			if (rc) { if (g != a) fail(a, rc, b->err); return rc; }
+		}
+		if (b == a) continue;
+		HIPCHK(a, hipStreamSynchronize(b->stream)); // b's rows are in place; the comparison runs on a's stream, behind a's decode
+		bv::launch_rows_differ(hi - lo, a->stage_rowptr.as<int64_t>(), b->stage_rowptr.as<int64_t>(), a->stage_succ.as<int32_t>(), b->stage_succ.as<int32_t>(), (int *)a->bfs_ctr.p, a->stream);
+		HIPCHK(a, hipMemcpyAsync(&differ, a->bfs_ctr.p, sizeof(int), hipMemcpyDeviceToHost, a->stream));
+		HIPCHK(a, hipStreamSynchronize(a->stream)); // (the scratch rows are reused by the next piece)
+	}
+	*equal = differ ? 0 : 1;
+	return BVG_OK;
+}
+
 extern "C" int bvg_hyperball_step(bvg_t *g, int32_t from, int32_t to, int log2m, const uint8_t *regs_in_dev, uint8_t *regs_out_dev, const uint8_t *modified_in_dev,
                                   uint8_t *modified_out_dev, uint64_t *changed) {
 	if (!g || !g->st || !regs_in_dev || !regs_out_dev || !modified_out_dev || !changed) return BVG_EARG;

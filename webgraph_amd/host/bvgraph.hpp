@@ -190,6 +190,12 @@ public:
 	bool equals(const BVGraph &o) const {
 		int32_t n = numNodes();
 		if (n != o.numNodes()) return false;
+		{ // two handles of the library: compared on the device, no row reaches the host (bvg_equal_range)
+			int eq = 0;
+			const int rc = bvg_equal_range(h_.get(), o.h_.get(), 0, n, &eq);
+			if (rc == BVG_OK) return eq != 0;
+			if (rc != BVG_EARG) detail::check(rc, h_.get()); // (BVG_EARG: handles on different devices -- the host comparison below serves them)
+		}
 		NodeIterator i = nodeIterator(), j = o.nodeIterator();
 		while (n-- != 0) {
 			i.nextInt();
