@@ -159,3 +159,47 @@ def test_hyperball_iterations(cnr_gpu, cnr_oracle, log2m):
     o = d_out.cpu().numpy()
     assert np.all(o[:1000] == 255) and np.all(o[3000:] == 255)
     assert np.array_equal(o[1000:3000], hyperball_restated(rp, sc, regs, None, 1000, 3000)[0][1000:3000])
+
+
+@pytest.mark.parametrize("piece", ["0", "500000"])
+def test_hyperball_and_bfs_with_runs_of_long_rows(tmp_path_factory, piece):
+    """Rows of thousands of successors in runs of neighbours (what the deep-chain recipe is made of): the long rows of a piece are listed and dealt to the groups of sixteen
+    waves (k_hyperball_big), the others go to a wave each; one iteration with every counter counting, one with flags, whole and in pieces, against the numpy restatement;
+    a round of the visit from every 7th node appends the same set of nodes as the restatement (a block's winners leave in one append)."""
+    import torch
+    from webgraph_amd.bvgraph import BVGraph
+    from webgraph_amd import tools as T
+    base = str(tmp_path_factory.mktemp("hbruns") / "hbruns")
+    rowptr, succ = T.generate(60_000, 3_000_000, seed=11, p_copy=0.85, p_same=0.95, p_keep=0.95)
+    T.store(base, rowptr, succ)
+    od = np.diff(rowptr)
+    assert (od >= 2048).sum() >= 8 and ((od[1:] >= 2048) & (od[:-1] >= 2048)).any()
+    g = BVGraph.load(base)
+    g.set_option("scan_piece", piece)
+    n, log2m = g.numNodes(), 6
+    m = 1 << log2m
+    rng = np.random.Generator(np.random.PCG64(7))
+    regs = (rng.integers(0, 64, size=(n, m)) * (rng.random((n, m)) < 0.1)).astype(np.uint8)
+    mod = None
+    for it in range(2):
+        d_in = torch.from_numpy(regs).cuda()
+        d_out = d_in.clone()
+        d_mod_out = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        d_mod_in = torch.from_numpy(mod).cuda() if mod is not None else None
+        changed = g.hyperball_step(log2m, d_in.data_ptr(), d_out.data_ptr(), d_mod_in.data_ptr() if d_mod_in is not None else None, d_mod_out.data_ptr())
+        want, wmod = hyperball_restated(rowptr, succ, regs, mod, 0, n)
+        assert np.array_equal(d_out.cpu().numpy(), want) and np.array_equal(d_mod_out.cpu().numpy(), wmod) and changed == int(wmod.sum()), "iteration %d" % it
+        regs, mod = want, wmod
+    frontier = np.arange(0, n, 7, dtype=np.int32)
+    marker = np.full(n, -1, dtype=np.int32)
+    marker[frontier] = 0
+    d_marker = torch.from_numpy(marker).cuda()
+    d_front = torch.from_numpy(frontier).cuda()
+    d_out = torch.empty(n, dtype=torch.int32, device="cuda")
+    cnt = g.bfs_expand(d_front.data_ptr(), frontier.size, d_marker.data_ptr(), 1, False, d_out.data_ptr(), n)
+    reach = np.unique(np.concatenate([succ[rowptr[x]:rowptr[x + 1]] for x in frontier]))
+    reach = reach[marker[reach] == -1]
+    got = np.sort(d_out[:cnt].cpu().numpy())
+    assert cnt == reach.size and np.array_equal(got, reach)
+    assert np.array_equal(np.nonzero(d_marker.cpu().numpy() == 1)[0], reach)
+    g.close()

@@ -206,14 +206,17 @@ __device__ __forceinline__ uint8_t hb_chunk(uint8_t t, int64_t a0, int64_t hi, i
 }
 __global__ void __launch_bounds__(CS_T) k_hyperball(int32_t from, int32_t cnt, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ, int32_t n, int32_t m,
                                                     const uint8_t *__restrict__ regsIn, uint8_t *__restrict__ regsOut, const uint8_t *__restrict__ modIn, uint8_t *__restrict__ modOut,
-                                                    unsigned long long *__restrict__ changed) {
+                                                    unsigned long long *__restrict__ changed, int32_t *__restrict__ bigRows, int32_t bigCap, int32_t *__restrict__ bigCount) {
 	__shared__ unsigned long long s_w[CS_T / 64];
 	const int lane = threadIdx.x & 63;
 	const int64_t nWaves = (int64_t)gridDim.x * (CS_T / 64);
 	unsigned long long nch = 0;
 	for (int64_t row = (int64_t)blockIdx.x * (CS_T / 64) + (threadIdx.x >> 6); row < cnt; row += nWaves) {
 		const int64_t lo = rowptr[row], hi = rowptr[row + 1];
-		if (hi - lo >= HB_BIG) continue;
+		if (hi - lo >= HB_BIG) { // a long row: listed for k_hyperball_big (long rows come in runs of neighbours: a list deals them to all groups)
+			if (lane == 0) { const int32_t k = atomicAdd(bigCount, 1); if (k < bigCap) bigRows[k] = (int32_t)row; }
+			continue;
+		}
 		const int32_t node = from + (int32_t)row;
 		bool any = false;
 		for (int32_t r0 = 0; r0 < m; r0 += 64) {
@@ -233,22 +236,16 @@ __global__ void __launch_bounds__(CS_T) k_hyperball(int32_t from, int32_t cnt, c
 // the rows of HB_BIG successors and more: a group of sixteen waves per row, every wave a share of the row's chunks of 64 successors, the waves' maxima joined in LDS
 __global__ void __launch_bounds__(HB_BIG_T) k_hyperball_big(int32_t from, int32_t cnt, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ, int32_t n, int32_t m,
                                                             const uint8_t *__restrict__ regsIn, uint8_t *__restrict__ regsOut, const uint8_t *__restrict__ modIn, uint8_t *__restrict__ modOut,
-                                                            unsigned long long *__restrict__ changed) {
+                                                            unsigned long long *__restrict__ changed, const int32_t *__restrict__ bigRows, int32_t bigCap, const int32_t *__restrict__ bigCount) {
 	constexpr int NWV = HB_BIG_T / 64;
-	__shared__ int32_t s_rows[HB_BIG_T], s_n;
 	__shared__ uint8_t s_t[NWV][64];
 	__shared__ int32_t s_any;
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	unsigned long long nch = 0;
-	for (int64_t base = (int64_t)blockIdx.x * HB_BIG_T; base < cnt; base += (int64_t)gridDim.x * HB_BIG_T) { // (uniform in the block)
-		if (threadIdx.x == 0) s_n = 0;
-		__syncthreads();
-		const int64_t row = base + threadIdx.x;
-		if (row < cnt && rowptr[row + 1] - rowptr[row] >= HB_BIG) s_rows[atomicAdd(&s_n, 1)] = (int32_t)row;
-		__syncthreads();
-		const int32_t nb = s_n;
-		for (int32_t q = 0; q < nb; q++) {
-			const int32_t rw = s_rows[q], node = from + rw;
+	{
+		const int32_t nb = min(*bigCount, bigCap); // (bigCap >= arcs / HB_BIG: every long row is listed)
+		for (int32_t q = blockIdx.x; q < nb; q += gridDim.x) { // (uniform in the block)
+			const int32_t rw = bigRows[q], node = from + rw;
 			const int64_t lo = rowptr[rw], hi = rowptr[rw + 1];
 			if (threadIdx.x == 0) s_any = 0;
 			for (int32_t r0 = 0; r0 < m; r0 += 64) {
@@ -272,11 +269,14 @@ __global__ void __launch_bounds__(HB_BIG_T) k_hyperball_big(int32_t from, int32_
 	}
 	if (threadIdx.x == 0 && nch) atomicAdd(changed, nch);
 }
+int64_t hyperball_big_cap(int64_t arcs) { return arcs / HB_BIG + 1; }
+// bigRows: hyperball_big_cap(arcs of the piece) ints, bigCount: one int (zeroed here)
 void launch_hyperball(int32_t from, int32_t cnt, const int64_t *rowptr, const int32_t *succ, int32_t n, int32_t m, const uint8_t *regsIn, uint8_t *regsOut, const uint8_t *modIn, uint8_t *modOut,
-                      unsigned long long *changed, hipStream_t st) {
+                      unsigned long long *changed, int32_t *bigRows, int32_t bigCap, int32_t *bigCount, hipStream_t st) {
 	if (cnt <= 0) return;
-	hipLaunchKernelGGL(k_hyperball, dim3((unsigned)std::min<int64_t>(((int64_t)cnt + CS_T / 64 - 1) / (CS_T / 64), HB_GRID)), dim3(CS_T), 0, st, from, cnt, rowptr, succ, n, m, regsIn, regsOut, modIn, modOut, changed);
-	hipLaunchKernelGGL(k_hyperball_big, dim3((unsigned)std::min<int64_t>(((int64_t)cnt + HB_BIG_T - 1) / HB_BIG_T, 512)), dim3(HB_BIG_T), 0, st, from, cnt, rowptr, succ, n, m, regsIn, regsOut, modIn, modOut, changed);
+	(void)hipMemsetAsync(bigCount, 0, sizeof(int32_t), st);
+	hipLaunchKernelGGL(k_hyperball, dim3((unsigned)std::min<int64_t>(((int64_t)cnt + CS_T / 64 - 1) / (CS_T / 64), HB_GRID)), dim3(CS_T), 0, st, from, cnt, rowptr, succ, n, m, regsIn, regsOut, modIn, modOut, changed, bigRows, bigCap, bigCount);
+	hipLaunchKernelGGL(k_hyperball_big, dim3(512), dim3(HB_BIG_T), 0, st, from, cnt, rowptr, succ, n, m, regsIn, regsOut, modIn, modOut, changed, bigRows, bigCap, bigCount);
 }
 
 } // namespace bv

@@ -142,8 +142,9 @@ void launch_bparse_big(const GraphDev &g, int def, const BatchView &v, int32_t c
 void launch_stats(int32_t from, int32_t cnt, const int64_t *rowptr, const int32_t *succ, int64_t arcsUpper, void *statsDev, int32_t *indegree, int32_t n, hipStream_t st);
 void launch_rows_differ(int32_t cnt, const int64_t *rpA, const int64_t *rpB, const int32_t *scA, const int32_t *scB, int *differ, hipStream_t st);
 size_t stats_dev_bytes();
+int64_t hyperball_big_cap(int64_t arcs);
 void launch_hyperball(int32_t from, int32_t cnt, const int64_t *rowptr, const int32_t *succ, int32_t n, int32_t m, const uint8_t *regsIn, uint8_t *regsOut, const uint8_t *modIn, uint8_t *modOut,
-                      unsigned long long *changed, hipStream_t st);
+                      unsigned long long *changed, int32_t *bigRows, int32_t bigCap, int32_t *bigCount, hipStream_t st);
 void launch_bfs_expand(const int32_t *frontier, int32_t q, const int64_t *rowptr, const int32_t *succ, int64_t arcs, int32_t *marker, int32_t n, int32_t round, int parent,
                        int32_t *out, uint64_t outCap, unsigned long long *outCount, hipStream_t st);
 

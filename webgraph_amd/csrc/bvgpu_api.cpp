@@ -1868,8 +1868,10 @@ extern "C" int bvg_hyperball_step(bvg_t *g, int32_t from, int32_t to, int log2m,
 			rc = decode_range_device(g, a, e, g->stage_rowptr.as<int64_t>(), g->stage_succ.as<int32_t>(), g->stage_succ.cap / sizeof(int32_t), false, &arcs);
 		}
 		if (rc) return rc;
+		const int64_t bigCap = std::min<int64_t>(bv::hyperball_big_cap((int64_t)arcs), 0x7ffffff0);
+		if (!g->bfs_rowptr.need(sizeof(int32_t) * ((size_t)bigCap + 1))) return fail(g, BVG_ENOMEM, "device scratch allocation failed"); // (the list of the piece's long rows, its count behind it)
 		bv::launch_hyperball(a, e - a, g->stage_rowptr.as<int64_t>(), g->stage_succ.as<int32_t>(), s.info.nodes, 1 << log2m, regs_in_dev, regs_out_dev, modified_in_dev, modified_out_dev,
-		                     g->bfs_ctr.as<unsigned long long>(), g->stream);
+		                     g->bfs_ctr.as<unsigned long long>(), g->bfs_rowptr.as<int32_t>(), (int32_t)bigCap, g->bfs_rowptr.as<int32_t>() + bigCap, g->stream);
 		HIPCHK(g, hipStreamSynchronize(g->stream)); // the scratch rows are reused by the next piece
 	}
 	unsigned long long c = 0;
