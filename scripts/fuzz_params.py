@@ -49,17 +49,21 @@ def main():
                 del os.environ[kk]
             og = O.OracleGraph.load(base)
             orp, osc, _ = og.scan()
+            which = []
             ok = np.array_equal(orp, rowptr) and np.array_equal(osc, succ)
+            if not ok: which.append("oracle")
             rp, sc = g.decode_range()
-            ok &= np.array_equal(rp, rowptr) and np.array_equal(sc, succ)
+            if not (np.array_equal(rp, rowptr) and np.array_equal(sc, succ)): which.append("scan")
             lo = int(rng.integers(0, n)); hi = int(rng.integers(lo, n + 1))
             rp, sc = g.decode_range(lo, hi)
-            ok &= np.array_equal(rp, rowptr[lo:hi + 1] - rowptr[lo]) and np.array_equal(sc, succ[rowptr[lo]:rowptr[hi]])
+            if not (np.array_equal(rp, rowptr[lo:hi + 1] - rowptr[lo]) and np.array_equal(sc, succ[rowptr[lo]:rowptr[hi]])): which.append("range[%d,%d)" % (lo, hi))
             q = rng.integers(0, n, size=int(10 ** rng.uniform(0, 4))).astype(np.int32)
             rp, sc = g.successors_batch(q)
             brp, bsc = og.successors_batch(q)
-            ok &= np.array_equal(rp, brp) and np.array_equal(sc, bsc)
-            ok &= g.hashCode() == og.hashcode()
+            if not (np.array_equal(rp, brp) and np.array_equal(sc, bsc)): which.append("batch(%d)" % q.size)
+            if g.hashCode() != og.hashcode(): which.append("hashCode")
+            ok = not which
+            if which: desc += " FAILED: " + ", ".join(which)
             g.close()
             for ext in (".graph", ".offsets", ".properties"):
                 os.remove(base + ext)

@@ -186,6 +186,16 @@ def test_nondefault_codings(tmp_path_factory, flagstr, k):
     orp, osc, _ = og.scan(1500, 2500)
     rp, sc = g.decode_range(1500, 2500)
     assert np.array_equal(rp, orp) and np.array_equal(sc, osc)
+    # hashCode() through the checksum scan: with these codings the one-lane parse does not fold, its rows are hashed from memory -- behind it, not beside it
+    # (round 5: the fold read rows that were not written yet; scripts/fuzz_params.py found it, the suite had no checksum over non-default codings)
+    want = og.hashcode()
+    for _ in range(3):
+        assert g.hashCode() == want
+    h, a = g.scan_checksum(1500, 2500, -1)
+    rp0, sc0 = g.decode_range(1500, 2500)
+    import torch
+    d_rp, d_sc = torch.from_numpy(rp0).cuda(), torch.from_numpy(sc0).cuda()
+    assert a == sc0.size and h == g.csr_hashcode(1500, 2500, d_rp.data_ptr(), d_sc.data_ptr(), -1)
     g.close()
 
 

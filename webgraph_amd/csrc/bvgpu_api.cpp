@@ -677,7 +677,9 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			                     lists ? g->biglist.as<int32_t>() : nullptr, ctl + 0, v.cnt, lists ? g->giantlist.as<int32_t>() : nullptr, ctl + 1, giantCap, false);
 			return (int)BVG_OK;
 		};
-		if (g->hash_job && ovl) { // behind side A's chain, once the giants are done too: beside the tail of the one-lane parse
+		// (codings other than the default set: the one-lane parse does not hash, k_hash_rest reads the rows of ITS class from memory too -- behind it, below;
+		// beside it the fold read rows that were not written yet: fuzz_params.py, hashCode of graphs with non-default flags)
+		if (g->hash_job && ovl && g->hash_in_parse) { // behind side A's chain, once the giants are done too: beside the tail of the one-lane parse
 			if (coop) HIPCHK(g, hipStreamWaitEvent(g->sideA, g->evB, 0));
 			const int rc = hash_phase_a(g->sideA);
 			if (rc) return rc;
@@ -715,7 +717,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			if (listsOnC) HIPCHK(g, hipStreamWaitEvent(g->stream, g->evL, 0));
 		}
 		mark(g, 6);
-		if (g->hash_job && !ovl) { const int rc = hash_phase_a(g->stream); if (rc) return rc; }
+		if (g->hash_job && (!ovl || !g->hash_in_parse)) { const int rc = hash_phase_a(g->stream); if (rc) return rc; }
 		if (W > 0) {
 			levels = g->levels_hint;
 			for (int32_t l = 1; l <= levels; l++) {
