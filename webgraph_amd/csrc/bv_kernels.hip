@@ -2046,10 +2046,11 @@ void launch_wait_giants(const int32_t *ctl, int giantGroups, hipStream_t st) {
 void launch_parse_big(const GraphDev &g, int def, const RangeView &v, const int32_t *biglist, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap,
                       int waves, int giantGroups, int *err, hipStream_t stGiant, hipStream_t stBig, bool waitGiants) {
 	if (v.cnt <= 0) return;
-	if (def == 1) hipLaunchKernelGGL((k_parse_big<1, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+	if (giantGroups <= 0) {} // (the caller knows that the job has no giant record)
+	else if (def == 1) hipLaunchKernelGGL((k_parse_big<1, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
 	else if (def == 2) hipLaunchKernelGGL((k_parse_big<2, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
 	else hipLaunchKernelGGL((k_parse_big<0, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
-	if (stBig != stGiant && waitGiants) launch_wait_giants(ctl, giantGroups, stBig);
+	if (stBig != stGiant && waitGiants && giantGroups > 0) launch_wait_giants(ctl, giantGroups, stBig);
 	if (def == 1) hipLaunchKernelGGL((k_parse_big<1, 1, RangeView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
 	else if (def == 2) hipLaunchKernelGGL((k_parse_big<2, 1, RangeView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
 	else hipLaunchKernelGGL((k_parse_big<0, 1, RangeView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);

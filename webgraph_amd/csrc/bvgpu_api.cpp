@@ -138,7 +138,8 @@ struct bvg_graph {
 	                     // residual sections over, everything else as before; 3: that, whatever the graph holds.  (Mode 2 of round 4 -- everything it can take -- is tag r4-experiments.)
 	int seg_hub_min = 1000000; // BVGPU_SEG_HUB_MIN
 	int seg_blocks = 2048;
-	int lists_on_b = 0;  // BVGPU_LISTS_ON_B=1: the chain depths / level lists behind the giants (side B) instead of behind the wave class (side A)
+	int lists_on_b = 0;  // BVGPU_LISTS_ON_B=1: the chain depths / level lists behind the giants (side B) instead of behind the wave class (side A); 0: side B when the graph has no giants; 3: side A
+	int skip_empty_giants = 1; // BVGPU_SKIP_EMPTY_GIANTS=0: the giants' kernel is launched even when the graph holds no record that long
 	int tile = -1;       // -1: automatic (see enqueue_decode); BVGPU_TILE=0: never; BVGPU_TILE=1: short records decoded from contiguous tiles of the stream (k_parse_tile) instead of the bin-sorted parse list (k_parse_list)
 	DevBuf tilebounds;
 	int copy_big = 1;    // BVGPU_COPY_BIG=0: every row is copied by one lane
@@ -248,6 +249,7 @@ int apply_option(bvg_graph *g, const std::string &name, const char *value) {
 	else if (name == "seg_hub_min") g->seg_hub_min = std::max(1, iv);
 	else if (name == "seg_blocks") g->seg_blocks = std::max(1, iv);
 	else if (name == "lists_on_b") g->lists_on_b = iv;
+	else if (name == "skip_empty_giants") g->skip_empty_giants = iv;
 	else if (name == "walk_tables") g->walk_tables = iv;
 	else if (name == "copy_vec") g->copy_vec = iv;
 	else if (name == "prewalk") g->prewalk = iv;
@@ -270,7 +272,7 @@ int apply_option(bvg_graph *g, const std::string &name, const char *value) {
 	else return BVG_EARG;
 	return BVG_OK;
 }
-const char *const OPTION_NAMES[] = { "coop_min", "giant_min", "coop_waves", "giant_groups", "level_blocks", "copy_big", "parse_windows", "tile", "seg", "seg_hub_min", "seg_blocks", "lists_on_b",
+const char *const OPTION_NAMES[] = { "coop_min", "giant_min", "coop_waves", "giant_groups", "level_blocks", "copy_big", "parse_windows", "tile", "seg", "seg_hub_min", "seg_blocks", "lists_on_b", "skip_empty_giants",
 	"walk_tables", "copy_vec", "prewalk", "prewalk_long", "prewalk_blocks", "copy_mid_min", "overlap", "halo_min", "batch_dense", "scan_top_tiled_min", "wait_giants", "hash_materialise",
 	"ef_hash_materialise", "scan_piece", "dbg", "stats", "trace_retry", "trace_err", "trace_host" };
 void options_from_env(bvg_graph *g) {
@@ -605,7 +607,11 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 				bv::seg_handover(gd, g->segbuf.p, giantCap, segScap, g->seg_hub_min, g->stream); // (before the fork: the cooperative kernels start behind it)
 			}
 		}
-		const bool listsOnB = g->lists_on_b == 1 && !segReady; // (with the hand-over side B carries the segment pipeline's chain)
+		// A graph without a record of giantMin successors (known since load time: every web-shaped graph at this size) has no giants' kernel to launch -- queued behind the
+		// tile / list kernel's blocks its groups, a CU each, would only be scheduled when those drain (cnr-2000 x 30: 600 us on side B for nothing) -- and side B is free for
+		// the chain depths and level lists, which otherwise wait behind the wave class on side A (lists_on_b = 3: on side A all the same).
+		const bool noGiants = g->skip_empty_giants && s.max_outdegree >= 0 && s.max_outdegree < (int64_t)giantMin;
+		const bool listsOnB = (g->lists_on_b == 1 || (g->lists_on_b == 0 && noGiants && ovl && coop)) && !segReady; // (with the hand-over side B carries the segment pipeline's chain)
 		const bool listsOnC = g->lists_on_b == 2 && ovl;
 		if (!tiles) {
 			if (!g->plist.need(sizeof(int32_t) * (size_t)v.cnt) || !g->pkeys.need(3 * (bv::NKEYS + 1) * sizeof(int32_t)) || !g->pkey16.need(sizeof(uint16_t) * (size_t)v.cnt)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
@@ -641,7 +647,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		// the long records first on both side streams: giants on B, the wave class on A ...
 		if (ovl && coop) {
 			HIPCHK(g, hipStreamWaitEvent(g->sideA, g->evC, 0));
-			bv::launch_parse_big(gd, s.def, v, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, g->giant_groups, derr, side_b(g), g->sideA, g->wait_giants); // (giants, big)
+			bv::launch_parse_big(gd, s.def, v, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, noGiants ? 0 : g->giant_groups, derr, side_b(g), g->sideA, g->wait_giants); // (giants, big)
 			if (!segReady) HIPCHK(g, hipEventRecord(g->evB, side_b(g))); // (else: behind the segment pipeline's chain, below)
 		}
 		// ... then, behind the wave class, the chain depth of every record + per-level lists (node order inside a level) +
@@ -708,7 +714,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 				bv::launch_seg_chain(gd, s.def, v, giantCap, segScap, g->segbuf.p, g->arena.p, arenaCap, ctl, g->seg_blocks, derr, stChain);
 				if (ovl) HIPCHK(g, hipEventRecord(g->evB, stChain));
 			}
-			if (ovl && coop) { HIPCHK(g, hipStreamWaitEvent(g->stream, g->evC, 0)); if (g->wait_giants) bv::launch_wait_giants(ctl, g->giant_groups, g->stream); } // (the giants first: k_wait_giants)
+			if (ovl && coop) { HIPCHK(g, hipStreamWaitEvent(g->stream, g->evC, 0)); if (g->wait_giants && !noGiants) bv::launch_wait_giants(ctl, g->giant_groups, g->stream); } // (the giants first: k_wait_giants)
 			bv::launch_parse_list(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, g->level_blocks, derr, g->stream, g->arena.p, arenaCap);
 		}
 		if (ovl) {
