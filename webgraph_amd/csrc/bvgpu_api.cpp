@@ -139,6 +139,7 @@ struct bvg_graph {
 	int seg_hub_min = 1000000; // BVGPU_SEG_HUB_MIN
 	int seg_blocks = 2048;
 	int lists_on_b = 0;  // BVGPU_LISTS_ON_B=1: the chain depths / level lists behind the giants (side B) instead of behind the wave class (side A); 0: side B when the graph has no giants; 3: side A
+	int level_lists_early = 1; // BVGPU_LEVEL_LISTS_EARLY=0: a job that decodes its lane class from tiles builds its level lists behind the wave class, like the others
 	int skip_empty_giants = 1; // BVGPU_SKIP_EMPTY_GIANTS=0: the giants' kernel is launched even when the graph holds no record that long
 	int tile = -1;       // -1: automatic (see enqueue_decode); BVGPU_TILE=0: never; BVGPU_TILE=1: short records decoded from contiguous tiles of the stream (k_parse_tile) instead of the bin-sorted parse list (k_parse_list)
 	DevBuf tilebounds;
@@ -250,6 +251,7 @@ int apply_option(bvg_graph *g, const std::string &name, const char *value) {
 	else if (name == "seg_blocks") g->seg_blocks = std::max(1, iv);
 	else if (name == "lists_on_b") g->lists_on_b = iv;
 	else if (name == "skip_empty_giants") g->skip_empty_giants = iv;
+	else if (name == "level_lists_early") g->level_lists_early = iv;
 	else if (name == "walk_tables") g->walk_tables = iv;
 	else if (name == "copy_vec") g->copy_vec = iv;
 	else if (name == "prewalk") g->prewalk = iv;
@@ -272,7 +274,7 @@ int apply_option(bvg_graph *g, const std::string &name, const char *value) {
 	else return BVG_EARG;
 	return BVG_OK;
 }
-const char *const OPTION_NAMES[] = { "coop_min", "giant_min", "coop_waves", "giant_groups", "level_blocks", "copy_big", "parse_windows", "tile", "seg", "seg_hub_min", "seg_blocks", "lists_on_b", "skip_empty_giants",
+const char *const OPTION_NAMES[] = { "coop_min", "giant_min", "coop_waves", "giant_groups", "level_blocks", "copy_big", "parse_windows", "tile", "seg", "seg_hub_min", "seg_blocks", "lists_on_b", "skip_empty_giants", "level_lists_early",
 	"walk_tables", "copy_vec", "prewalk", "prewalk_long", "prewalk_blocks", "copy_mid_min", "overlap", "halo_min", "batch_dense", "scan_top_tiled_min", "wait_giants", "hash_materialise",
 	"ef_hash_materialise", "scan_piece", "dbg", "stats", "trace_retry", "trace_err", "trace_host" };
 void options_from_env(bvg_graph *g) {
@@ -542,6 +544,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		// (ctl[0..3], the queues of the long records, are zeroed on side B when the classification starts early)
 		const bool early = hdrEvent && coopMin < 0x7fffffff && g->overlap && !g->profile;
 		if (!early) HIPCHK(g, hipMemsetAsync(ctl, 0, 4 * sizeof(int32_t), g->stream));
+		const bool ctlWasClean = g->ctl_clean; // (zeroed in front of the headers' event: a side stream may use ctl[4..16) as soon as it has seen that event)
 		if (!g->ctl_clean) HIPCHK(g, hipMemsetAsync(ctl + 4, 0, 12 * sizeof(int32_t), g->stream));
 		g->ctl_clean = false;
 		// rows with a reference and >= 1024 (resp. >= copy_mid_min) successors: at most arcs / 1024 (resp. / copy_mid_min) of them
@@ -617,6 +620,39 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			if (!g->plist.need(sizeof(int32_t) * (size_t)v.cnt) || !g->pkeys.need(3 * (bv::NKEYS + 1) * sizeof(int32_t)) || !g->pkey16.need(sizeof(uint16_t) * (size_t)v.cnt)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
 			pKeyBase = g->pkeys.as<int32_t>() + (bv::NKEYS + 1);
 		}
+		// chain depths + per-level lists + copy queues, then the pre-walks of the wave and group classes' block lists: on stL; alone: everything on that one stream
+		auto build_levels = [&](hipStream_t stLists, bool alone) -> int {
+			if (W > 0) bv::launch_build_lists(gd, v, ~0ull, 1, g->depth.as<int32_t>(), g->key16.as<uint16_t>(), hist, keyBase, cursor, g->lvlist.as<int32_t>(),
+			                                  g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->maxdepth, stLists,
+			                                  g->copyq.as<int32_t>(), bigCap, g->copyq.as<int32_t>() + bigCap, midCap, g->copy_mid_min, g->copy_big != 0);
+			// the block lists of the group class's rows, walked beside the parse kernels (k_copy_prewalk)
+			g->pend.preDesc = nullptr;
+			if (W > 0 && g->prewalk && g->copy_big && gd.walktab && s.def != 0 && g->walkdesc.need(16 * ((size_t)bigCap + (size_t)midCap))) {
+				// (the long lists' kernel on side B, which has been idle since the giants -- unless it carries the lists themselves, or the segment pipeline's chain)
+				hipStream_t stLong = stLists, stWalk = stLists;
+				const bool longKernel = g->prewalk_long != 0;
+				const bool cross = !alone && g->prewalk_long != 2 && ovl && coop && !segReady;
+				const bool longOnB = cross && longKernel && stLists == g->sideA;   // lists behind the wave class: the long lists on side B
+				const bool walkOnA = cross && stLists == side_b(g);                // lists behind the giants: the waves' kernel behind the wave class
+				if (longOnB || walkOnA) {
+					HIPCHK(g, hipEventRecord(g->evL, stLists));
+					if (longOnB) { stLong = side_b(g); HIPCHK(g, hipStreamWaitEvent(stLong, g->evL, 0)); }
+					else { stWalk = g->sideA; HIPCHK(g, hipStreamWaitEvent(stWalk, g->evL, 0)); }
+				}
+				bv::launch_copy_prewalk(gd, s.def, v, g->copyq.as<int32_t>(), bigCap, ctl, g->walkdesc.p, g->prewalk_blocks, stLists, g->prewalk >= 2 ? 0 : midCap, stLong, longKernel, stWalk); // (BVGPU_PREWALK=2: the group class only)
+				if (longOnB) HIPCHK(g, hipEventRecord(g->evB, stLong)); // (side B is done when this kernel is)
+				g->pend.preDesc = g->walkdesc.p;
+			}
+			return BVG_OK;
+		};
+		// A job that decodes its lane class from tiles builds no parse list: side A is idle until the classification is done, and the chain depths, level lists, copy queues and
+		// pre-walks -- which need the headers and the stream only -- run there during the set-up instead of behind the wave class, beside the tile kernel (level_lists_early = 0: behind).
+		const bool earlyLevels = g->level_lists_early && tiles && ovl && hdrEvent && ctlWasClean && W > 0 && !segReady;
+		if (earlyLevels) {
+			HIPCHK(g, hipStreamWaitEvent(g->sideA, g->evHdr, 0));
+			const int rc = build_levels(g->sideA, true);
+			if (rc) return rc;
+		}
 		if (earlyList) {
 			HIPCHK(g, hipStreamWaitEvent(g->sideA, g->evHdr, 0));
 			bv::launch_build_lists(gd, v, ~0ull, g->parse_windows ? 6 : 2, nullptr, g->pkey16.as<uint16_t>(), g->pkeys.as<int32_t>(), pKeyBase, pKeyBase + (bv::NKEYS + 1), g->plist.as<int32_t>(),
@@ -653,27 +689,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		// ... then, behind the wave class, the chain depth of every record + per-level lists (node order inside a level) +
 		// copy queues: only the copy pass needs them, and launched first they would sit in front of the wave class while
 		// the one-lane kernel holds every CU
-		if (W > 0) bv::launch_build_lists(gd, v, ~0ull, 1, g->depth.as<int32_t>(), g->key16.as<uint16_t>(), hist, keyBase, cursor, g->lvlist.as<int32_t>(),
-		                                  g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->maxdepth, stLists,
-		                                  g->copyq.as<int32_t>(), bigCap, g->copyq.as<int32_t>() + bigCap, midCap, g->copy_mid_min, g->copy_big != 0);
-		// the block lists of the group class's rows, walked beside the parse kernels (k_copy_prewalk)
-		g->pend.preDesc = nullptr;
-		if (W > 0 && g->prewalk && g->copy_big && gd.walktab && s.def != 0 && g->walkdesc.need(16 * ((size_t)bigCap + (size_t)midCap))) {
-			// (the long lists' kernel on side B, which has been idle since the giants -- unless it carries the lists themselves, or the segment pipeline's chain)
-			hipStream_t stLong = stLists, stWalk = stLists;
-			const bool longKernel = g->prewalk_long != 0;
-			const bool cross = g->prewalk_long != 2 && ovl && coop && !segReady;
-			const bool longOnB = cross && longKernel && stLists == g->sideA;   // lists behind the wave class: the long lists on side B
-			const bool walkOnA = cross && stLists == side_b(g);                // lists behind the giants: the waves' kernel behind the wave class
-			if (longOnB || walkOnA) {
-				HIPCHK(g, hipEventRecord(g->evL, stLists));
-				if (longOnB) { stLong = side_b(g); HIPCHK(g, hipStreamWaitEvent(stLong, g->evL, 0)); }
-				else { stWalk = g->sideA; HIPCHK(g, hipStreamWaitEvent(stWalk, g->evL, 0)); }
-			}
-			bv::launch_copy_prewalk(gd, s.def, v, g->copyq.as<int32_t>(), bigCap, ctl, g->walkdesc.p, g->prewalk_blocks, stLists, g->prewalk >= 2 ? 0 : midCap, stLong, longKernel, stWalk); // (BVGPU_PREWALK=2: the group class only)
-			if (longOnB) HIPCHK(g, hipEventRecord(g->evB, stLong)); // (side B is done when this kernel is)
-			g->pend.preDesc = g->walkdesc.p;
-		}
+		if (!earlyLevels) { const int rc = build_levels(stLists, false); if (rc) return rc; }
 		if (listsOnC) HIPCHK(g, hipEventRecord(g->evL, g->sideC));
 		auto hash_phase_a = [&](hipStream_t stH) { // the node numbers and the rows without a reference that the wave / group classes decoded (their lists), or every such row (codings the one-lane parse does not hash)
 			const int32_t pcap = (int32_t)std::min<int64_t>((int64_t)v.cnt + arcsBound / 4096 + 2, 0x7ffffff0);
