@@ -614,7 +614,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		// tile / list kernel's blocks its groups, a CU each, would only be scheduled when those drain (cnr-2000 x 30: 600 us on side B for nothing) -- and side B is free for
 		// the chain depths and level lists, which otherwise wait behind the wave class on side A (lists_on_b = 3: on side A all the same).
 		const bool noGiants = g->skip_empty_giants && s.max_outdegree >= 0 && s.max_outdegree < (int64_t)giantMin;
-		const bool listsOnB = (g->lists_on_b == 1 || (g->lists_on_b == 0 && noGiants && ovl && coop)) && !segReady; // (with the hand-over side B carries the segment pipeline's chain)
+		const bool listsOnB = (g->lists_on_b == 1 || (g->lists_on_b == 0 && noGiants && ovl && coop && !(tiles && g->level_lists_early))) && !segReady; // (with the hand-over side B carries the segment pipeline's chain)
 		const bool listsOnC = g->lists_on_b == 2 && ovl;
 		if (!tiles) {
 			if (!g->plist.need(sizeof(int32_t) * (size_t)v.cnt) || !g->pkeys.need(3 * (bv::NKEYS + 1) * sizeof(int32_t)) || !g->pkey16.need(sizeof(uint16_t) * (size_t)v.cnt)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
