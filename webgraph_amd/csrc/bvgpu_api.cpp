@@ -1661,7 +1661,10 @@ extern "C" int bvg_successors_batch(bvg_t *g, const int32_t *nodes, size_t q, in
 		if (!g->halo.need(sizeof(int32_t) * (size_t)std::max<int64_t>(g->h_small->halo_total, 1))) return fail(g, BVG_ENOMEM, "arena allocation failed");
 		v.succ = nullptr; v.halo = g->halo.as<int32_t>(); v.succ_cap = 0;
 		int32_t levels = 0, giantCap = 0;
-		rc = enqueue_decode(g, v, g->h_small->halo_total, levels, giantCap);
+		// (the headers' event: outdegrees and references have been final since the round trip above -- with it the parse list is built and the long records are classified
+		// side by side BEFORE the cooperative kernels start, as in a range job; without it the list's three kernels ran beside the giants and the wave class, starved: 0.8 of C4's 4.3 ms)
+		HIPCHK(g, hipEventRecord(g->evHdr, g->stream));
+		rc = enqueue_decode(g, v, g->h_small->halo_total, levels, giantCap, true);
 		if (rc) return rc;
 		HIPCHK(g, hipGetLastError());
 		g->pend.active = true; g->pend.view = v; g->pend.levels_done = levels; g->pend.want_succ = true; g->pend.giantCap = giantCap;
