@@ -1727,6 +1727,12 @@ __global__ void __launch_bounds__(TPB) k_bparse(GraphDev g, BatchView v, int *__
 	parse_node<DEF>(g, v.node[s], d, hasRef, hasRef ? (int64_t)v.outd[s + 1] : 0, v.row(s), err);
 }
 
+// Slots of BCOPY_WAVE_MIN .. COPY_BIG_MIN - 1 successors are merged by a wave each, slots of up to BCOPY_GROUP_CAP - 1 by a group of four waves (k_bcopy_coop, the method of
+// k_copy_mid: block list -> two LDS tables, copied ids and extras gathered into LDS, every id placed by one binary search in the other set); a lane merges ~1 id per
+// microsecond, and a batch of 100 000 random ids of C2 ended 0.9 ms after its other slots, behind ONE row of a few thousand ids (round 5).  Longer slots stay with their
+// lane (a batch that holds many of them takes the masked scan).
+constexpr int BCOPY_WAVE_MIN = 96, BCOPY_GROUP_CAP = 8192;
+__device__ __forceinline__ int bcopy_class(int32_t d, int32_t dref) { return (d < BCOPY_WAVE_MIN || dref >= 65536) ? 0 : d < COPY_BIG_MIN ? 1 : d < BCOPY_GROUP_CAP ? 2 : 0; } // 0: a lane, 1: a wave, 2: a group
 template <int DEF>
 __global__ void __launch_bounds__(TPB) k_bcopy(GraphDev g, BatchView v, int32_t level, int *__restrict__ err) {
 	const int64_t s = (int64_t)blockIdx.x * TPB + threadIdx.x;
@@ -1734,7 +1740,98 @@ __global__ void __launch_bounds__(TPB) k_bcopy(GraphDev g, BatchView v, int32_t 
 	if (v.depth[s] != level) return;
 	const int32_t qi = v.qidx[s];
 	if (qi >= 0 && (uint64_t)v.rowptr[qi + 1] > v.succ_cap) return;
+	if (bcopy_class(v.outd[s], v.outd[s + 1]) != 0) return; // k_bcopy_coop
 	copy_node<DEF>(g, v.node[s], v.outd[s], (int64_t)v.outd[s + 1], v.row(s), v.row(s + 1), err);
+}
+// CLS 1: NT = 64, CAP = COPY_BIG_MIN, four groups per block; CLS 2: NT = 256, CAP = BCOPY_GROUP_CAP, one group per block
+template <int DEF, int CLS>
+__global__ void __launch_bounds__(256) k_bcopy_coop(GraphDev g, BatchView v, int32_t level, int *__restrict__ err) {
+	constexpr int NT = CLS == 1 ? 64 : 256, NG = 256 / NT, CAP = CLS == 1 ? COPY_BIG_MIN : BCOPY_GROUP_CAP;
+	__shared__ int32_t s_vals[NG][CAP], s_kend[NG][CAP + 1], s_delta[NG][CAP + 1];
+	__shared__ int32_t s_list[NG][NT], s_n[NG];
+	const int tid = threadIdx.x % NT, grp = threadIdx.x / NT;
+	int32_t *vals = s_vals[grp], *kend = s_kend[grp], *delta = s_delta[grp];
+	auto group_sync = [] {
+		if (NT == 64) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); }
+		else __syncthreads();
+	};
+	const int64_t nGroups = (int64_t)gridDim.x * NG, w = (int64_t)blockIdx.x * NG + grp;
+	for (int64_t s0 = w * NT; s0 < v.cnt; s0 += nGroups * NT) { // (uniform in the group: NT slots at a time, a thread looks at one)
+		if (tid == 0) s_n[grp] = 0;
+		group_sync();
+		const int64_t sL = s0 + tid;
+		bool mine = sL < v.cnt && v.depth[sL] == level;
+		if (mine) { const int32_t qi = v.qidx[sL]; mine = !(qi >= 0 && (uint64_t)v.rowptr[qi + 1] > v.succ_cap) && bcopy_class(v.outd[sL], v.outd[sL + 1]) == CLS; }
+		if (mine) s_list[grp][atomicAdd(&s_n[grp], 1)] = tid;
+		group_sync();
+		const int32_t nl = s_n[grp];
+		for (int32_t q = 0; q < nl; q++) {
+			const int64_t s = s0 + s_list[grp][q];
+			const int32_t d = v.outd[s];
+			const int64_t dref = v.outd[s + 1];
+			int32_t *row = v.row(s);
+			const int32_t *src = v.row(s + 1);
+			// header + blocks, every thread alike (BVG:1058-1071)
+			BitReader br;
+			br.init(g.bits, g.nwords);
+			br.seek((uint64_t)g.offsets[v.node[s]]);
+			(void)Fields<DEF>::outdegree(br, g);
+			(void)Fields<DEF>::reference(br, g);
+			const uint64_t bc = Fields<DEF>::block_count(br, g);
+			int64_t total = 0, copied = 0;
+			int32_t nKept = 0;
+			bool bad = bc > (uint64_t)dref + 1; // (flagged by the parse kernel)
+			for (uint64_t b = 0; !bad && b <= bc; b++) {
+				int64_t len;
+				if (b < bc) len = (int64_t)Fields<DEF>::block(br, g) + (b ? 1 : 0);
+				else len = dref - total; // implicit last block (copied when the block count is even)
+				if (len < 0 || total + len > dref) { bad = true; break; }
+				if (!(b & 1)) {
+					if (copied + len > d || nKept >= CAP) { bad = true; break; }
+					if (tid == (nKept % NT)) { kend[nKept] = (int32_t)(copied + len); delta[nKept] = (int32_t)(total - copied); }
+					nKept++;
+					copied += len;
+				}
+				total += len;
+			}
+			if (br.err && tid == 0) atomicOr(err, br.err);
+			const bool skip = bad || br.err || copied == 0; // malformed (flagged by the parse kernel) or nothing to merge (uniform)
+			const int32_t nExtra = d - (int32_t)copied, nc = (int32_t)copied;
+			group_sync();
+			if (!skip) {
+				for (int32_t t = tid; t < nc; t += NT) { // copied ids -> vals[0 .. nc)
+					int32_t lo = 0, hi = nKept; // first kept block with kend > t
+					while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (kend[mid] <= t) lo = mid + 1; else hi = mid; }
+					vals[t] = src[t + delta[lo]];
+				}
+				for (int32_t e = tid; e < nExtra; e += NT) vals[nc + e] = row[nc + e]; // extras -> vals[nc .. d)
+			}
+			group_sync();
+			bool dup = false; // an id in both sets (never in a valid file): the lane-serial merge emits equal heads once and pads the row (copy_node)
+			int32_t place[CAP / NT];
+#pragma unroll
+			for (int k = 0; k < CAP / NT; k++) {
+				const int32_t t = tid + NT * k;
+				place[k] = -1;
+				if (!skip && t < d) {
+					const int32_t val = vals[t];
+					int32_t lo, hi;
+					if (t < nc) { lo = nc; hi = d; } else { lo = 0; hi = nc; }
+					const int32_t end = hi;
+					while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (vals[mid] < val) lo = mid + 1; else hi = mid; }
+					dup |= lo < end && vals[lo] == val;
+					place[k] = t < nc ? t + lo - nc : t - nc + lo;
+				}
+			}
+			const bool anyDup = NT == 64 ? (bool)__any(dup) : (bool)__syncthreads_or(dup);
+			if (anyDup) { if (tid == 0) copy_node<DEF>(g, v.node[s], d, dref, row, src, err); }
+			else {
+#pragma unroll
+				for (int k = 0; k < CAP / NT; k++) if (place[k] >= 0) row[place[k]] = vals[tid + NT * k];
+			}
+			group_sync(); // (the tables are reused by the next row)
+		}
+	}
 }
 
 // ------------------------------------------------------------------------------------------------ hashCode
@@ -1981,6 +2078,11 @@ void launch_bcopy(const GraphDev &g, int def, const BatchView &v, int32_t level,
 	if (def == 1) hipLaunchKernelGGL(k_bcopy<1>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, level, err);
 	else if (def == 2) hipLaunchKernelGGL(k_bcopy<2>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, level, err);
 	else hipLaunchKernelGGL(k_bcopy<0>, dim3(nblk(v.cnt, TPB)), dim3(TPB), 0, st, g, v, level, err);
+	// (the slots that a wave or a group merges: the same level, other rows)
+	const unsigned wb = (unsigned)std::min<int64_t>(nblk(v.cnt, 256), 1024), gb = (unsigned)std::min<int64_t>(nblk(v.cnt, 256), 256);
+	if (def == 1) { hipLaunchKernelGGL((k_bcopy_coop<1, 1>), dim3(wb), dim3(256), 0, st, g, v, level, err); hipLaunchKernelGGL((k_bcopy_coop<1, 2>), dim3(gb), dim3(256), 0, st, g, v, level, err); }
+	else if (def == 2) { hipLaunchKernelGGL((k_bcopy_coop<2, 1>), dim3(wb), dim3(256), 0, st, g, v, level, err); hipLaunchKernelGGL((k_bcopy_coop<2, 2>), dim3(gb), dim3(256), 0, st, g, v, level, err); }
+	else { hipLaunchKernelGGL((k_bcopy_coop<0, 1>), dim3(wb), dim3(256), 0, st, g, v, level, err); hipLaunchKernelGGL((k_bcopy_coop<0, 2>), dim3(gb), dim3(256), 0, st, g, v, level, err); }
 }
 
 // Which records leave the one-lane decoder for a wave: counted, not guessed.  A lane decodes ~0.6 us per successor whatever its
