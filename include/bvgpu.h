@@ -290,7 +290,7 @@ int bvg_decode_offsets_device(int device, const uint8_t *offsets_file, size_t le
  * :1317-1325, 0 = defaults); `threads` > 1 reproduces the reference's multi-threaded store (contiguous ranges of
  * ceil(n / threads) nodes, each starting with an empty window, streams concatenated, :2471-2550) -- it does not change how
  * the GPU works.  Limits: windowSize <= 63, records shorter than 2^31 bits (BVG_EUNSUPPORTED). */
-typedef struct bvg_store_stats {   /* the counters BVGraph.java:2558-2600 persists in .properties */
+typedef struct bvg_store_stats {   /* the counters BVGraph.java:2558-2632 persists in .properties */
 	uint64_t written_bits, offsets_bits;
 	uint64_t bits_outdegrees, bits_references, bits_blocks, bits_intervals, bits_residuals;
 	uint64_t copied_arcs, intervalised_arcs, residual_arcs;
@@ -299,6 +299,10 @@ typedef struct bvg_store_stats {   /* the counters BVGraph.java:2558-2600 persis
 	int32_t  threads;
 	int32_t  selection_rounds;     /* measurement only: rounds the reference-selection recurrence took to settle */
 	int32_t  reserved;
+	/* successorGapStats / residualGapStats (updateBins, BVGraph.java:1940-1944; :2303, :2196): the gaps of every successor list, and of
+	 * every list of residuals, counted by their most significant bit -- the first element of a list by int2nat(first - node), skipped
+	 * when that is 0.  .properties carries them as successorexpstats / residualexpstats and the averages derived from them (:2592-2632). */
+	uint64_t successor_gap_bins[32], residual_gap_bins[32];
 } bvg_store_stats_t;
 typedef struct bvg_compressed {    /* result of bvg_compress, in HBM of `device`; release with bvg_compressed_free */
 	int32_t  device, reserved;
@@ -315,7 +319,7 @@ void bvg_compressed_free(bvg_compressed_t *c);
 /* Copies the result to host memory: graph_host (graph_bits + 7) / 8 bytes, offsets_host (offsets_bits + 7) / 8 bytes,
  * bit_offsets_host int64[n + 1]; any of the three may be NULL. */
 int bvg_compressed_copy(const bvg_compressed_t *c, int32_t n, uint8_t *graph_host, uint8_t *offsets_host, int64_t *bit_offsets_host);
-/* bvg_compress + the three files <basename>.graph / .offsets / .properties (the properties as :2558-2600 writes them). */
+/* bvg_compress + the three files <basename>.graph / .offsets / .properties (the properties as :2558-2632 writes them). */
 int bvg_store(const char *basename, int device, int32_t n, const int64_t *rowptr, const int32_t *succ, int in_flags, int window, int max_ref_count,
               int min_interval, int zeta_k, uint32_t flags, int threads, bvg_store_stats_t *stats, char *errbuf, size_t errlen);
 

@@ -63,6 +63,19 @@ def test_store_matches_cpu_writer(tmp_path, W, R, I, K, flags, threads):
         assert filecmp.cmp(cpu + ext, gpu + ext, shallow=False), ext
     for k in st_cpu:
         assert st_cpu[k] == st_gpu[k], k
+    # the gap histograms the call hands back are the ones .properties carries (BVGraph.java:2592-2632; the CPU writer's file is the same, byte for byte)
+    props = dict(l.strip().split("=", 1) for l in open(gpu + ".properties") if "=" in l and not l.startswith("#"))
+    for name in ("successor", "residual"):
+        bins = st_gpu[name + "_gap_bins"]
+        while bins and bins[-1] == 0:
+            bins = bins[:-1]
+        assert props[name + "expstats"] == ",".join(str(b) for b in bins), name
+    lists_first = succ[rowptr[:-1][np.diff(rowptr) > 0]].astype(np.int64) - np.nonzero(np.diff(rowptr) > 0)[0]
+    inner = np.diff(succ.astype(np.int64))
+    inner = np.delete(inner, rowptr[1:-1][(rowptr[1:-1] > 0) & (rowptr[1:-1] < len(succ))] - 1)
+    nat = np.where(lists_first >= 0, 2 * lists_first, -2 * lists_first - 1)
+    want = np.bincount(np.floor(np.log2(np.concatenate([inner[inner > 0], nat[nat > 0]]).astype(np.float64))).astype(np.int64), minlength=32)
+    assert [int(v) for v in want] == st_gpu["successor_gap_bins"]
 
 
 def test_store_c2_shape_round_trip(tmp_path):

@@ -152,3 +152,76 @@ def test_cpp_host_mirror_compiles(tmp_path):
     if not torch.cuda.is_available():
         p = subprocess.run([exe, CNR, "1711395807", "3216152"], capture_output=True, text=True)
         assert p.returncode != 0 and "no HIP device" in p.stderr
+
+
+def _props(path):
+    return dict(l.strip().split("=", 1) for l in open(path) if "=" in l and not l.startswith("#"))
+
+
+def _gap_keys(bins):
+    """The three keys BVGraph.java:2592-2632 derives from one histogram, restated with Python's exact arithmetic."""
+    import math
+    from decimal import ROUND_HALF_EVEN, Decimal
+    used = [i for i, b in enumerate(bins) if b]
+    l = used[-1] if used else -1
+    gaps = sum(bins[:l + 1])
+    tot = sum((3 * (1 << i) - 1) * bins[i] for i in range(l + 1))
+    tot_log = 0.0
+    for i in range(l + 1):
+        tot_log += (math.log(float(3 * (1 << i) + 1)) / 0.6931471805599453 - 1) * bins[i]
+    exp = ",".join(str(b) for b in bins[:l + 1])
+    if gaps == 0:
+        return exp, "0", "0"
+    return exp, str((Decimal(tot) / Decimal(2 * gaps)).quantize(Decimal("0.001"), rounding=ROUND_HALF_EVEN)), repr(tot_log / gaps)
+
+
+def _bins_of_lists(nodes, lists):
+    """updateBins (BVGraph.java:1940-1944): gaps by most significant bit; the first element by int2nat(first - node), skipped when 0."""
+    bins = [0] * 32
+    for x, v in zip(nodes, lists):
+        if len(v) == 0:
+            continue
+        d = int(v[0]) - int(x)
+        g = 2 * d if d >= 0 else -2 * d - 1
+        if g:
+            bins[g.bit_length() - 1] += 1
+        for a, b in zip(v[:-1], v[1:]):
+            bins[(int(b) - int(a)).bit_length() - 1] += 1
+    return bins
+
+
+@pytest.mark.parametrize("I", [0, 3])
+def test_properties_carry_the_gap_statistics(tmp_path, I):
+    """successorexpstats / residualexpstats and their averages (BVGraph.java:2592-2632), against a restatement of updateBins; without references
+    the residuals are what intervalize (:1631-1654) leaves of the successor list."""
+    from webgraph_amd import tools as T
+    rowptr, succ = T.generate(3000, 40000, seed=99, p_copy=0.3)
+    base = str(tmp_path / "g")
+    st = T.store(base, rowptr, succ, window=0, max_ref_count=0, min_interval=I)
+    p = _props(base + ".properties")
+    lists = [succ[rowptr[x]:rowptr[x + 1]] for x in range(3000)]
+    sb = _bins_of_lists(range(3000), lists)
+    exp, avg, avglog = _gap_keys(sb)
+    assert (p["successorexpstats"], p["successoravggap"], p["successoravgloggap"]) == (exp, avg, avglog)
+    res = []
+    for v in lists:
+        v = [int(t) for t in v]
+        out, i = [], 0
+        while i < len(v):
+            j = i
+            while j + 1 < len(v) and v[j + 1] == v[j] + 1:
+                j += 1
+            if I == 0 or j - i + 1 < I:
+                out += v[i:j + 1]
+            i = j + 1
+        res.append(out)
+    assert sum(len(r) for r in res) == st["residual_arcs"]
+    rb = _bins_of_lists(range(3000), res)
+    exp, avg, avglog = _gap_keys(rb)
+    assert (p["residualexpstats"], p["residualavggap"], p["residualavgloggap"]) == (exp, avg, avglog)
+    n, m = 3000, int(rowptr[-1])
+    for k, bits in (("outdegrees", st["bits_outdegrees"]), ("references", st["bits_references"]), ("blocks", st["bits_blocks"]),
+                    ("residuals", st["bits_residuals"]), ("intervals", st["bits_intervals"])):
+        want = ("%.3f" % (bits / n)).rstrip("0").rstrip(".")
+        assert p["avgbitsfor" + k] == want, k
+    assert "compratio" in p

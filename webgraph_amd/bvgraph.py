@@ -38,10 +38,14 @@ class BvgScanStats(C.Structure):
 class BvgStoreStats(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ("written_bits", "offsets_bits", "bits_outdegrees", "bits_references", "bits_blocks", "bits_intervals", "bits_residuals",
                                            "copied_arcs", "intervalised_arcs", "residual_arcs", "tot_ref", "tot_dist")] + [
-        ("max_ref_chain", C.c_int32), ("threads", C.c_int32), ("selection_rounds", C.c_int32), ("reserved", C.c_int32)]
+        ("max_ref_chain", C.c_int32), ("threads", C.c_int32), ("selection_rounds", C.c_int32), ("reserved", C.c_int32),
+        ("successor_gap_bins", C.c_uint64 * 32), ("residual_gap_bins", C.c_uint64 * 32)]
 
     def as_dict(self):
-        return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"}
+        d = {k: int(getattr(self, k)) for k, t in self._fields_ if k != "reserved" and not k.endswith("_bins")}
+        d["successor_gap_bins"] = [int(v) for v in self.successor_gap_bins]  # updateBins, BVGraph.java:1940-1944
+        d["residual_gap_bins"] = [int(v) for v in self.residual_gap_bins]
+        return d
 
 
 class BvgCompressed(C.Structure):

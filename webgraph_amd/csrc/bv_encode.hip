@@ -36,7 +36,46 @@ constexpr int SEL_CHUNK = 64; // nodes per chunk of the selection recurrence
 constexpr int SEL_SPAN = 16, SEL_BATCH = 8;
 constexpr int ENC_MAX_W = 63; // state of a chunk boundary: W chain lengths
 
-struct EncStatsDev { unsigned long long v[12]; }; // bitsOutd, bitsRef, bitsBlocks, bitsIntervals, bitsResiduals, copied, intervalised, residuals, totRef, totDist, maxRef, -
+struct EncStatsDev { // bitsOutd, bitsRef, bitsBlocks, bitsIntervals, bitsResiduals, copied, intervalised, residuals, totRef, totDist, maxRef, -
+	unsigned long long v[12];
+	unsigned long long resBins[32];                  // gaps between residuals by their most significant bit (bve::res_bin; residualGapStats, BVGraph.java:2196)
+	unsigned long long succBins[32], succBinsOff[32]; // the same over whole successor lists (successorGapStats, :2303): counted over the array, less what k_enc_succ_bins_rows takes back
+};
+
+// the histogram of a block, folded into the global one
+__device__ __forceinline__ void flush_bins(const unsigned long long *s_bins, unsigned long long *bins) {
+	__syncthreads();
+	if (threadIdx.x < 32 && s_bins[threadIdx.x]) atomicAdd(&bins[threadIdx.x], s_bins[threadIdx.x]);
+}
+
+// successorGapStats (updateBins, BVGraph.java:1940-1944) in two sweeps.  Over the ARRAY of successors: every positive difference between neighbours is binned, row starts included ...
+constexpr int SB_GRID = 2048;
+__global__ void __launch_bounds__(256) k_enc_succ_bins(const int32_t *__restrict__ succ, int64_t m, EncStatsDev *__restrict__ stats) {
+	__shared__ unsigned long long s_b[32];
+	if (threadIdx.x < 32) s_b[threadIdx.x] = 0;
+	__syncthreads();
+	for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x + 1; i < m; i += (int64_t)SB_GRID * 256) {
+		const int64_t d = (int64_t)succ[i] - succ[i - 1];
+		if (d > 0) atomicAdd(&s_b[bve::msb64((uint64_t)d)], 1ull);
+	}
+	flush_bins(s_b, stats->succBins);
+}
+// ... over the ROWS: what the first sweep counted across a row's start is taken back (succBinsOff), and the row's first successor is binned by int2nat(first - node)
+__global__ void __launch_bounds__(256) k_enc_succ_bins_rows(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ, int32_t n, EncStatsDev *__restrict__ stats) {
+	__shared__ unsigned long long s_b[64];
+	if (threadIdx.x < 64) s_b[threadIdx.x] = 0;
+	__syncthreads();
+	for (int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x; x < n; x += (int64_t)SB_GRID * 256) {
+		const int64_t a = rowptr[x];
+		if (rowptr[x + 1] == a) continue;
+		const int32_t f = succ[a];
+		if (a > 0) { const int64_t d = (int64_t)f - succ[a - 1]; if (d > 0) atomicAdd(&s_b[32 + bve::msb64((uint64_t)d)], 1ull); }
+		const uint64_t g = bve::int2nat((int64_t)f - x);
+		if (g) atomicAdd(&s_b[bve::msb64(g) < 31 ? bve::msb64(g) : 31], 1ull);
+	}
+	flush_bins(s_b, stats->succBins);
+	if (threadIdx.x < 32 && s_b[32 + threadIdx.x]) atomicAdd(&stats->succBinsOff[threadIdx.x], s_b[32 + threadIdx.x]);
+}
 
 // a CSR handed over in device memory is checked like one from the host: rowptr must not decrease (every list then lies inside succ[0, rowptr[n]))
 __global__ void __launch_bounds__(256) k_enc_check_rowptr(const int64_t *__restrict__ rowptr, int32_t n, int *__restrict__ err) {
@@ -298,6 +337,9 @@ __global__ void __launch_bounds__(256) k_seg_emit(const Params p, const int64_t 
 	const int lane = threadIdx.x & 63;
 	const int64_t n = *nsegs < segCap ? *nsegs : segCap, stride = (int64_t)gridDim.x * 4;
 	const int cyc = p.W + 1;
+	__shared__ unsigned long long s_rb[32];
+	if (threadIdx.x < 32) s_rb[threadIdx.x] = 0;
+	__syncthreads();
 	for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += stride) {
 		const Seg sg = segs[i];
 		const int64_t q = list[sg.pair];
@@ -336,9 +378,11 @@ __global__ void __launch_bounds__(256) k_seg_emit(const Params p, const int64_t 
 		}
 		bvw::WaveWalk<DEF, true> w(p, x, words, posB + in.offB, posI + in.offI, posR + in.offR);
 		w.prevFlag = in.prevFlag; w.runStart = in.runStart; w.nb = in.nb; w.nr = in.nr; w.ni = in.ni; w.prevRes = in.prevRes; w.prevEnd = in.prevEnd;
+		w.rbins = s_rb;
 		bvw::WaveTotals t;
 		w.run(succ + a + sg.ja, sg.jb - sg.ja, succ + b + sg.ka, r == 0 ? 0 : sg.kb - sg.ka, t);
 	}
+	flush_bins(s_rb, stats->resBins);
 }
 
 // self-check (BVGPU_ENC_VERIFY, used by the tests): the lane walk over the pairs the waves took; mismatches -> dbg[0] = count, then (q, wave, lane) triples
@@ -390,10 +434,13 @@ __global__ void __launch_bounds__(256) k_enc_emit(const Params p, const int64_t 
 	const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
 	bve::NodeStats st;
 	unsigned long long totRef = 0, totDist = 0, chain = 0;
+	__shared__ unsigned long long s_rb[32];
+	if (threadIdx.x < 32) s_rb[threadIdx.x] = 0;
+	__syncthreads();
 	if (t < total[0]) {
 		const int64_t x = list[t];
 		const int r = best[x];
-		(void)bve::emit_node<DEF>(p, rowptr, succ, (int32_t)x, r, words, (uint64_t)off[x], &st);
+		(void)bve::emit_node<DEF>(p, rowptr, succ, (int32_t)x, r, words, (uint64_t)off[x], &st, s_rb);
 		if (rowptr[x + 1] > rowptr[x]) { totRef = (unsigned long long)refc[x]; totDist = (unsigned long long)r; chain = totRef; }
 	}
 	// (the counters of a block joined in LDS first: 156 000 waves x 10 additions to the same ten words were ~2 ms of C2's emission, same-address atomics run at ~88 M/s)
@@ -411,6 +458,7 @@ __global__ void __launch_bounds__(256) k_enc_emit(const Params p, const int64_t 
 	__syncthreads();
 	if (threadIdx.x < 10 && s_acc[threadIdx.x]) atomicAdd(&stats->v[threadIdx.x], s_acc[threadIdx.x]);
 	if (threadIdx.x == 10 && s_acc[10]) atomicMax(&stats->v[10], s_acc[10]);
+	flush_bins(s_rb, stats->resBins);
 }
 
 // the nodes whose chosen pair is at the head of the list of pairs: one wave each, with the sizes the pricing left
@@ -421,13 +469,16 @@ __global__ void __launch_bounds__(256) k_enc_emit_wave(const Params p, const int
 	const int64_t nbig = pairTotal[1], stride = (int64_t)gridDim.x * 4;
 	const int cyc = p.W + 1;
 	unsigned long long acc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, chain = 0; // lane 0 of the wave
+	__shared__ unsigned long long s_rb[32];
+	if (threadIdx.x < 32) s_rb[threadIdx.x] = 0;
+	__syncthreads();
 	for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6) + pairTotal[2]; t < nbig; t += stride) { // (the cut pairs: k_seg_emit)
 		const int64_t q = pairList[t];
 		const int32_t x = (int32_t)(q / cyc);
 		const int r = (int)(q - (int64_t)x * cyc);
 		if (best[x] != r) continue;
 		bve::NodeStats st;
-		bvw::wave_emit_node<DEF>(p, rowptr, succ, x, r, info[t], words, (uint64_t)off[x], st);
+		bvw::wave_emit_node<DEF>(p, rowptr, succ, x, r, info[t], words, (uint64_t)off[x], st, s_rb);
 		acc[0] += st.bitsOutd; acc[1] += st.bitsRef; acc[2] += st.bitsBlocks; acc[3] += st.bitsIntervals; acc[4] += st.bitsResiduals;
 		acc[5] += st.copied; acc[6] += st.intervalised; acc[7] += st.residuals; acc[8] += (unsigned long long)refc[x]; acc[9] += (unsigned long long)r;
 		if ((unsigned long long)refc[x] > chain) chain = (unsigned long long)refc[x];
@@ -436,6 +487,7 @@ __global__ void __launch_bounds__(256) k_enc_emit_wave(const Params p, const int
 		for (int i = 0; i < 10; i++) if (acc[i]) atomicAdd(&stats->v[i], acc[i]);
 		if (chain) atomicMax(&stats->v[10], chain);
 	}
+	flush_bins(s_rb, stats->resBins);
 }
 
 // the .offsets stream: code 0 is the offset of node 0, code i the length of record i - 1 (BVGraph.java:2285, :2369)
@@ -668,12 +720,15 @@ int encode_device(const Params &p, int32_t n, const int64_t *d_rowptr, const int
 	if (!alloc((void **)&out.off_words, ow * 4)) { err = "device allocation failed"; return cleanup(-5); }
 	(void)hipMemsetAsync(out.off_words, 0, ow * 4, st);
 	hipLaunchKernelGGL(k_enc_offemit, blocks((int64_t)n + 1, 256), dim3(256), 0, st, p, reclen, offat, n, out.off_words);
+	if (m > 1) hipLaunchKernelGGL(k_enc_succ_bins, dim3(SB_GRID), dim3(256), 0, st, d_succ, (int64_t)m, dstats);
+	if (n > 0 && m > 0) hipLaunchKernelGGL(k_enc_succ_bins_rows, dim3(SB_GRID), dim3(256), 0, st, d_rowptr, d_succ, n, dstats);
 	EncStatsDev hs{};
 	if (hipMemcpyAsync(&hs, dstats, sizeof hs, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { err = "the emission kernels failed"; return cleanup(-6); }
 	mark();
 	out.bits_outdegrees = hs.v[0]; out.bits_references = hs.v[1]; out.bits_blocks = hs.v[2]; out.bits_intervals = hs.v[3]; out.bits_residuals = hs.v[4];
 	out.copied_arcs = hs.v[5]; out.intervalised_arcs = hs.v[6]; out.residual_arcs = hs.v[7]; out.tot_ref = hs.v[8]; out.tot_dist = hs.v[9];
 	out.max_ref_chain = (int32_t)hs.v[10];
+	for (int i = 0; i < 32; i++) { out.residual_gap_bins[i] = hs.resBins[i]; out.successor_gap_bins[i] = hs.succBins[i] - hs.succBinsOff[i]; }
 	out.rounds = rounds;
 	if (trace && ev.size() == 6) {
 		static const char *names[] = { "A cost", "B select", "C lengths+scan", "D emit", "E offsets" };

@@ -202,6 +202,20 @@ struct CountVisitor {
 	BVE_HD uint64_t total(int r, int32_t nextra) const { return bits_ref(r) + bits_blocks(r) + bits_intervals(nextra) + bitsR; }
 };
 
+// updateBins (BVGraph.java:1940-1944) for one residual, from the value its code carries: the first of a node by the most significant bit of int2nat(first - node)
+// (nothing when that is 0), a later one by that of its distance from the one before (= coded value + 1).  `bins`: 32 counters of the block or wave, in LDS on the device.
+BVE_HD void res_bin(unsigned long long *bins, bool first, uint64_t coded) {
+	if (!bins) return;
+	const uint64_t g = first ? coded : coded + 1;
+	if (g == 0) return;
+	const int b = msb64(g);
+#if defined(__HIP_DEVICE_COMPILE__)
+	atomicAdd(&bins[b < 31 ? b : 31], 1ull);
+#else
+	bins[b < 31 ? b : 31]++;
+#endif
+}
+
 // writes the three sections through three cursors
 template <bool DEF>
 struct EmitVisitor {
@@ -210,8 +224,9 @@ struct EmitVisitor {
 	WordSink sB, sI, sR;
 	uint32_t nb = 0, ni = 0, nr = 0;
 	int64_t prevEnd = 0, prevRes = 0;
-	BVE_HD EmitVisitor(const Params &p_, int32_t node_, uint32_t *words, uint64_t posB, uint64_t posI, uint64_t posR)
-	    : p(p_), node(node_), sB(words, posB), sI(words, posI), sR(words, posR) {}
+	unsigned long long *rbins; // the block's histogram of the residuals' gaps (res_bin), or null
+	BVE_HD EmitVisitor(const Params &p_, int32_t node_, uint32_t *words, uint64_t posB, uint64_t posI, uint64_t posR, unsigned long long *rbins_)
+	    : p(p_), node(node_), sB(words, posB), sI(words, posI), sR(words, posR), rbins(rbins_) {}
 	BVE_HD void block(int32_t run) { f_blk<DEF>(sB, p, (uint64_t)(nb == 0 ? run : run - 1)); nb++; }
 	BVE_HD void interval(int32_t left, int32_t len) {
 		w_gamma(sI, ni == 0 ? int2nat((int64_t)left - node) : (uint64_t)((int64_t)left - prevEnd - 1));
@@ -219,7 +234,9 @@ struct EmitVisitor {
 		ni++; prevEnd = (int64_t)left + len;
 	}
 	BVE_HD void residual(int32_t x) {
-		f_res<DEF>(sR, p, nr == 0 ? int2nat((int64_t)x - node) : (uint64_t)((int64_t)x - prevRes - 1));
+		const uint64_t v = nr == 0 ? int2nat((int64_t)x - node) : (uint64_t)((int64_t)x - prevRes - 1);
+		f_res<DEF>(sR, p, v);
+		res_bin(rbins, nr == 0, v);
 		nr++; prevRes = x;
 	}
 	BVE_HD void finish() { sB.finish(); sI.finish(); sR.finish(); }
@@ -360,7 +377,7 @@ struct NodeStats {
 // Phase D for one node: write the record at bit `pos` of `words` (zeroed beforehand).  Returns its length in bits.
 template <bool DEF>
 BVE_HD uint64_t emit_node(const Params &p, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ, int32_t x, int r, uint32_t *words,
-                          uint64_t pos, NodeStats *st) {
+                          uint64_t pos, NodeStats *st, unsigned long long *rbins = nullptr) {
 	const int64_t a = rowptr[x];
 	const int32_t d = (int32_t)(rowptr[x + 1] - a);
 	WordSink head(words, pos);
@@ -385,7 +402,7 @@ BVE_HD uint64_t emit_node(const Params &p, const int64_t *__restrict__ rowptr, c
 	const uint64_t posI = ic.pos;
 	ic.finish();
 	const uint64_t posR = posI + cv.bitsI;
-	EmitVisitor<DEF> ev(p, x, words, posB, posI, posR);
+	EmitVisitor<DEF> ev(p, x, words, posB, posI, posR, rbins);
 	(void)diff_walk(succ + a, d, succ + b, dr, p.I, ev);
 	ev.finish();
 	const uint64_t end = posR + cv.bitsR;

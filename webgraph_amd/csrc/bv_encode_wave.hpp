@@ -77,6 +77,7 @@ struct WaveWalk {
 	int64_t prevEnd = 0, prevRes = 0;
 	uint32_t prevFlag = 1;   // the walk starts in a copy run ...
 	int64_t runStart = 0;    // ... that began at index 0 of ref (a later segment of a cut pair: where the run in progress began, relative to the segment)
+	unsigned long long *rbins = nullptr; // EMIT: the block's histogram of the residuals' gaps (bve::res_bin), set by the caller
 	int32_t firstFlag = -1;  // SEG: membership flag of the segment's first element of ref (-1: none), index of the first change, first residual, first interval
 	int64_t firstChange = -1, firstRes = 0, firstLeft = 0;
 
@@ -101,13 +102,13 @@ struct WaveWalk {
 		if (on) { bve::WordSink w(words, posI + inc - s.bits); bve::w_gamma(w, v1); bve::w_gamma(w, v2); w.finish(); }
 		posI += __shfl(inc, 63);
 	}
-	// ... one residual each
-	__device__ __forceinline__ void residuals(bool on, uint64_t val) {
+	// ... one residual each (`first`: the lane's is the node's first residual -- for the histogram of the gaps only)
+	__device__ __forceinline__ void residuals(bool on, uint64_t val, bool first) {
 		bve::LenSink s;
 		if (on) bve::f_res<DEF>(s, p, val);
 		if (!EMIT) { accR += s.bits; return; }
 		const uint64_t inc = DEF ? (uint64_t)wave_incl_scan((uint32_t)s.bits, lane) : wave_incl_scan(s.bits, lane);
-		if (on) { bve::WordSink w(words, posR + inc - s.bits); bve::f_res<DEF>(w, p, val); w.finish(); }
+		if (on) { bve::WordSink w(words, posR + inc - s.bits); bve::f_res<DEF>(w, p, val); w.finish(); bve::res_bin(rbins, first, val); }
 		posR += __shfl(inc, 63);
 	}
 
@@ -123,7 +124,7 @@ struct WaveWalk {
 			const uint64_t v0 = nr == 0 ? bve::int2nat(start - node) : (uint64_t)(start - prevRes - 1);
 			const bool skipFirst = SEG && nr == 0;
 			if (skipFirst) firstRes = start;
-			for (int64_t t0 = 0; t0 < T; t0 += 64) residuals(t0 + lane < T && !(skipFirst && t0 + lane == 0), t0 + lane == 0 ? v0 : 0);
+			for (int64_t t0 = 0; t0 < T; t0 += 64) residuals(t0 + lane < T && !(skipFirst && t0 + lane == 0), t0 + lane == 0 ? v0 : 0, nr == 0 && t0 + lane == 0);
 			prevRes = start + T - 1; nr += (uint32_t)T;
 		}
 	}
@@ -223,7 +224,7 @@ struct WaveWalk {
 							const int64_t prv = below ? pa : prevRes;
 							const uint64_t v = nr == 0 && !below ? bve::int2nat((int64_t)a - node) : (uint64_t)((int64_t)a - prv - 1);
 							if (SEG && nr == 0) firstRes = __shfl(a, lobit(RS));
-							residuals(((RS >> lane) & 1) && !(SEG && nr == 0 && !below), v);
+							residuals(((RS >> lane) & 1) && !(SEG && nr == 0 && !below), v, nr == 0 && !below);
 							prevRes = __shfl(a, hibit(RS));
 							nr += (uint32_t)__popcll(RS);
 						}
@@ -264,7 +265,7 @@ struct PairInfo { uint32_t nb, bitsB, ni, bitsI; }; // ni: bit 31 = the list has
 // `st` is filled in lane 0 only
 template <bool DEF>
 __device__ __forceinline__ void wave_emit_node(const Params &p, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ succ, int32_t x, int r, const PairInfo info,
-                                               uint32_t *words, uint64_t pos, bve::NodeStats &st) {
+                                               uint32_t *words, uint64_t pos, bve::NodeStats &st, unsigned long long *rbins) {
 	const int lane = (int)(threadIdx.x & 63);
 	const int64_t a = rowptr[x], b = rowptr[x - r];
 	const int32_t d = (int32_t)(rowptr[x + 1] - a), dr = r == 0 ? 0 : (int32_t)(rowptr[x - r + 1] - b);
@@ -290,6 +291,7 @@ __device__ __forceinline__ void wave_emit_node(const Params &p, const int64_t *_
 		if (extras && p.I != 0) { bve::WordSink wi(words, startI); bve::w_gamma(wi, ni); wi.finish(); }
 	}
 	WaveWalk<DEF, true> w(p, x, words, posB, posI, posR);
+	w.rbins = rbins;
 	WaveTotals t;
 	w.run(succ + a, d, succ + b, dr, t);
 	if (lane == 0) {

@@ -191,6 +191,7 @@ struct EncodeOut {
 	uint64_t bits_outdegrees = 0, bits_references = 0, bits_blocks = 0, bits_intervals = 0, bits_residuals = 0;
 	uint64_t copied_arcs = 0, intervalised_arcs = 0, residual_arcs = 0, tot_ref = 0, tot_dist = 0;
 	int32_t max_ref_chain = 0, rounds = 0;
+	uint64_t successor_gap_bins[32] = {}, residual_gap_bins[32] = {}; // successorGapStats / residualGapStats (BVGraph.java:1940-1944, :2196, :2303)
 };
 int encode_device(const bve::Params &p, int32_t n, const int64_t *d_rowptr, const int32_t *d_succ, uint64_t m, EncodeOut &out, std::string &err, hipStream_t st);
 void encode_free(EncodeOut &o);

@@ -57,6 +57,7 @@ void fill_stats(const bv::EncodeOut &o, uint64_t off_bits, int threads, bvg_stor
 	st->bits_intervals = o.bits_intervals; st->bits_residuals = o.bits_residuals;
 	st->copied_arcs = o.copied_arcs; st->intervalised_arcs = o.intervalised_arcs; st->residual_arcs = o.residual_arcs;
 	st->tot_ref = o.tot_ref; st->tot_dist = o.tot_dist; st->max_ref_chain = o.max_ref_chain; st->threads = threads; st->selection_rounds = o.rounds;
+	for (int i = 0; i < 32; i++) { st->successor_gap_bins[i] = o.successor_gap_bins[i]; st->residual_gap_bins[i] = o.residual_gap_bins[i]; }
 }
 
 int compress(int device, int32_t n, const int64_t *rowptr, const int32_t *succ, int in_flags, const bve::Params &p, bv::EncodeOut &out, std::string &err) {
@@ -178,8 +179,9 @@ extern "C" int bvg_store(const char *basename, int device, int32_t n, const int6
 	const std::string base(basename);
 	const AtomicTriple files(base);
 	if (!write_bytes(files.tmp(".graph"), graph) || !write_bytes(files.tmp(".offsets"), offs)) { files.discard(); return sfail(errbuf, errlen, BVG_EIO, "cannot write " + base + ".graph / .offsets"); }
-	const bvprops::Counters cnt{ st.written_bits, st.bits_outdegrees, st.bits_references, st.bits_blocks, st.bits_intervals, st.bits_residuals,
-	                             st.copied_arcs, st.intervalised_arcs, st.residual_arcs, st.tot_ref, st.tot_dist };
+	bvprops::Counters cnt{ st.written_bits, st.bits_outdegrees, st.bits_references, st.bits_blocks, st.bits_intervals, st.bits_residuals,
+	                       st.copied_arcs, st.intervalised_arcs, st.residual_arcs, st.tot_ref, st.tot_dist, {}, {} };
+	for (int i = 0; i < 32; i++) { cnt.successor_gap_bins[i] = st.successor_gap_bins[i]; cnt.residual_gap_bins[i] = st.residual_gap_bins[i]; }
 	const int resCoding = (flags >> 8) & 0xF;
 	if (!bvprops::write(files.tmp(".properties"), n, m, window, max_ref_count, min_interval, zeta_k, resCoding == 0 || resCoding == bve::C_ZETA, flags, cnt) || !files.commit())
 		{ files.discard(); return sfail(errbuf, errlen, BVG_EIO, "cannot write " + base + ".properties"); }

@@ -182,7 +182,7 @@ struct Diff {
 		}
 		return t;
 	}
-	void emit(BitSink &o, int32_t node, int ref, const Cfg &g, bvt_store_stats &st) const {
+	void emit(BitSink &o, int32_t node, int ref, const Cfg &g, bvt_store_stats &st, uint64_t *resBins) const {
 		uint64_t b0 = o.bits;
 		if (g.W > 0) { o.code(g.c.reference, (uint64_t)ref, 0); st.bits_references += o.bits - b0; }
 		if (ref != 0) {
@@ -207,6 +207,10 @@ struct Diff {
 			if (!residuals.empty()) {
 				b0 = o.bits;
 				st.residual_arcs += residuals.size();
+				for (size_t i = 0; i < residuals.size(); i++) { // updateBins(currNode, residual, residualCount, residualGapStats), BVGraph.java:2196
+					const int b = bvprops::gap_bin(i == 0, i == 0 ? node : residuals[i - 1], residuals[i]);
+					if (b >= 0) resBins[b]++;
+				}
 				o.code(g.c.residual, int2nat((int64_t)residuals[0] - node), g.K);
 				for (size_t i = 1; i < residuals.size(); i++) o.code(g.c.residual, (uint64_t)(residuals[i] - residuals[i - 1] - 1), g.K);
 				st.bits_residuals += o.bits - b0;
@@ -215,7 +219,7 @@ struct Diff {
 	}
 };
 
-struct ThreadOut { BitSink graph; std::vector<uint64_t> reclen; bvt_store_stats st{}; int err = 0; };
+struct ThreadOut { BitSink graph; std::vector<uint64_t> reclen; bvt_store_stats st{}; uint64_t succBins[32] = {}, resBins[32] = {}; int err = 0; };
 
 // CompressionThread.call for nodes [lo, hi): empty window at lo (BVGraph.java:2222-2386).
 void compress_range(int32_t lo, int32_t hi, const int64_t *rowptr, const int32_t *succ, const Cfg &g, ThreadOut &out) {
@@ -232,6 +236,10 @@ void compress_range(int32_t lo, int32_t hi, const int64_t *rowptr, const int32_t
 		listNode[ci] = x;
 		if (d > 0) {
 			for (int i = 1; i < d; i++) if (cur[i] <= cur[i - 1]) { out.err = -EINVAL; return; } // strictly increasing rows only
+			for (int i = 0; i < d; i++) { // updateBins(currNode, list[currIndex], outd, successorGapStats), BVGraph.java:2303
+				const int b = bvprops::gap_bin(i == 0, i == 0 ? x : cur[i - 1], cur[i]);
+				if (b >= 0) out.succBins[b]++;
+			}
 			uint64_t bestCost = UINT64_MAX; int bestRef = -1, bestCand = -1;
 			refCount[ci] = -1;
 			for (int r = 0; r < cyc; r++) {
@@ -245,7 +253,7 @@ void compress_range(int32_t lo, int32_t hi, const int64_t *rowptr, const int32_t
 				}
 			}
 			refCount[ci] = refCount[bestCand] + 1;
-			best.emit(out.graph, x, bestRef, g, out.st);
+			best.emit(out.graph, x, bestRef, g, out.st, out.resBins);
 			uint64_t copied = (uint64_t)d - best.extras.size();
 			out.st.copied_arcs += copied;
 			out.st.tot_ref += (uint64_t)refCount[ci];
@@ -313,8 +321,10 @@ extern "C" int bvt_store(const char *basename, int32_t n, const int64_t *rowptr,
 	BitSink graph, offs;
 	bvt_store_stats st{};
 	st.threads = threads;
+	uint64_t succBins[32] = {}, resBins[32] = {};
 	offs.code(g.c.offset, 0, 0); // offset of node 0
 	for (auto &o : outs) {
+		for (int i = 0; i < 32; i++) { succBins[i] += o.succBins[i]; resBins[i] += o.resBins[i]; }
 		if (threads == 1) graph = std::move(o.graph); else graph.append(o.graph);
 		for (uint64_t l : o.reclen) offs.code(g.c.offset, l, 0);
 		st.bits_outdegrees += o.st.bits_outdegrees; st.bits_references += o.st.bits_references; st.bits_blocks += o.st.bits_blocks;
@@ -328,8 +338,9 @@ extern "C" int bvt_store(const char *basename, int32_t n, const int64_t *rowptr,
 	if (!graph.write_file(base + ".graph") || !offs.write_file(base + ".offsets")) return -EIO;
 
 	const uint64_t m = n ? (uint64_t)rowptr[n] : 0;
-	const bvprops::Counters cnt{ st.written_bits, st.bits_outdegrees, st.bits_references, st.bits_blocks, st.bits_intervals, st.bits_residuals,
-	                             st.copied_arcs, st.intervalised_arcs, st.residual_arcs, st.tot_ref, st.tot_dist };
+	bvprops::Counters cnt{ st.written_bits, st.bits_outdegrees, st.bits_references, st.bits_blocks, st.bits_intervals, st.bits_residuals,
+	                       st.copied_arcs, st.intervalised_arcs, st.residual_arcs, st.tot_ref, st.tot_dist, {}, {} };
+	for (int i = 0; i < 32; i++) { cnt.successor_gap_bins[i] = succBins[i]; cnt.residual_gap_bins[i] = resBins[i]; }
 	if (!bvprops::write(base + ".properties", n, m, window, max_ref_count, min_interval, zeta_k, g.c.residual == ZETA, flags, cnt)) return -EIO;
 	if (stats) *stats = st;
 	return 0;
