@@ -9,8 +9,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cerrno>
 #include <cmath>
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -61,6 +63,14 @@ struct PinBuf { // pinned host memory (grows, never shrinks; contents are NOT pr
 };
 
 // Immutable, shared between a handle and its clones (BVGraph.copy() shares graphMemory / offsets, BVG:552-577).
+// a vector whose resize() leaves the new elements alone: the host copy of the offsets is 8 (n + 1) bytes that are overwritten at once (zero-filling them was 10 ms of C2's load)
+template <class T> struct NoInitAlloc : std::allocator<T> {
+	template <class U> struct rebind { using other = NoInitAlloc<U>; };
+	template <class U> void construct(U *p) noexcept { ::new ((void *)p) U; }
+	template <class U, class... A> void construct(U *p, A &&... a) { ::new ((void *)p) U(std::forward<A>(a)...); }
+};
+using HostOffsets = std::vector<int64_t, NoInitAlloc<int64_t>>;
+
 struct Staged {
 	int device = -1;
 	bvg_info_t info{};
@@ -70,7 +80,7 @@ struct Staged {
 	int64_t *d_offsets = nullptr;   // likewise: d_offsets[x] for x in [stage_lo, node_hi]
 	int64_t *d_offsets_alloc = nullptr;
 	int32_t node_lo = 0, node_hi = 0, stage_lo = 0; // the nodes this handle decodes / the first node staged
-	std::vector<int64_t> h_offsets; // host copy: shard bounds and halo sizing
+	HostOffsets h_offsets; // host copy: shard bounds and halo sizing
 	int64_t arcs_sizing = 0;        // max(arcs property, sum of the outdegrees in the stream): what scratch is sized by
 	int64_t max_outdegree = -1; // the longest staged record (counted with arcs_sizing; -1: unknown)
 	int64_t lane_rows = 0, lane_ids = 0; // staged rows with a reference and fewer than 128 successors, and their ids (the lane class of the copy pass)
@@ -1030,6 +1040,38 @@ extern "C" int bvg_open_shard(const char *basename, int device, int part, int pa
 	if (parts < 1 || part < 0 || part >= parts) { if (out) *out = nullptr; return BVG_EARG; }
 	return open_impl(basename, device, part, parts, out);
 }
+// <path>[lo, hi) -> device memory at dst, through two small pinned buffers: the read of piece k + 1 (page cache -> pinned) runs while piece k crosses PCIe.
+// (A std::vector of the whole file and one pageable hipMemcpy cost three passes over the bytes on the host -- zero fill, fread, the runtime's own staging copy --
+// one after the other: 190 MB of C2 in 60 ms; this way 25.)  Returns 0, or a BVG_ code with `err` set.
+static int stage_file_range(FILE *f, const std::string &path, size_t lo, size_t hi, uint8_t *dst, std::string &err) {
+	constexpr size_t PIECE = (size_t)4 << 20;
+	if (hi <= lo) return BVG_OK;
+	uint8_t *pin[2] = { nullptr, nullptr };
+	hipEvent_t ev[2] = { nullptr, nullptr };
+	hipStream_t st = nullptr;
+	int rc = BVG_OK;
+	auto done = [&]() {
+		if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+		for (int i = 0; i < 2; i++) { if (ev[i]) (void)hipEventDestroy(ev[i]); if (pin[i]) (void)hipHostFree(pin[i]); }
+		return rc;
+	};
+	const size_t piece = std::min(PIECE, hi - lo);
+	if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { st = nullptr; (void)hipGetLastError(); err = "hipStreamCreate failed"; rc = BVG_EHIP; return done(); }
+	for (int i = 0; i < 2; i++)
+		if (hipHostMalloc((void **)&pin[i], piece, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); err = "pinned staging buffers: allocation failed"; rc = BVG_ENOMEM; return done(); }
+	if (fseeko(f, (off_t)lo, SEEK_SET) != 0) { err = "cannot seek in " + path; rc = BVG_EIO; return done(); }
+	int k = 0;
+	for (size_t at = lo; at < hi; k ^= 1) {
+		const size_t len = std::min(piece, hi - at);
+		if (at >= lo + 2 * piece && hipEventSynchronize(ev[k]) != hipSuccess) { err = "staging " + path + " failed"; rc = BVG_EHIP; return done(); } // the buffer's last piece has left
+		if (fread(pin[k], 1, len, f) != len) { err = "short read on " + path; rc = BVG_EIO; return done(); }
+		if (hipMemcpyAsync(dst + (at - lo), pin[k], len, hipMemcpyHostToDevice, st) != hipSuccess || hipEventRecord(ev[k], st) != hipSuccess) { err = "staging " + path + " failed"; rc = BVG_EHIP; return done(); }
+		at += len;
+	}
+	if (hipStreamSynchronize(st) != hipSuccess) { err = "staging " + path + " failed"; rc = BVG_EHIP; }
+	return done();
+}
+
 static int open_impl(const char *basename, int device, int part, int parts, bvg_t **out) {
 	if (!basename || !out) return BVG_EARG;
 	*out = nullptr;
@@ -1054,15 +1096,36 @@ static int open_impl(const char *basename, int device, int part, int parts, bvg_
 	                      in.reference_coding == BVG_UNARY && in.residual_coding == BVG_ZETA;
 	st->def = !defaults ? 0 : in.zeta_k == 3 ? 1 : (in.zeta_k >= 1 && in.zeta_k <= 16) ? 2 : 0;
 
+	const bool traceOpen = bv_env("BVGPU_TRACE_OPEN") != nullptr;
+	auto tOpen = std::chrono::steady_clock::now();
+	auto lap = [&](const char *what) {
+		if (!traceOpen) return;
+		const auto now = std::chrono::steady_clock::now();
+		fprintf(stderr, "[bvgpu open] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - tOpen).count());
+		tOpen = now;
+	};
+	// the bit stream of a BVGraph goes from the file to HBM in pieces (stage_file_range) once the offsets say which part this handle stages; an EFGraph's words are
+	// brought to host order first
 	std::vector<uint8_t> graph, offs;
-	if (!bvh::read_file(st->basename + ".graph", graph, err)) return fail(g, BVG_EIO, err);
+	struct FileCloser { FILE *f = nullptr; ~FileCloser() { if (f) fclose(f); } } gfile;
+	size_t graphSize = 0;
+	if (ef) { if (!bvh::read_file(st->basename + ".graph", graph, err)) return fail(g, BVG_EIO, err); }
+	else {
+		const std::string gp = st->basename + ".graph";
+		gfile.f = fopen(gp.c_str(), "rb");
+		if (!gfile.f) return fail(g, BVG_EIO, "cannot open " + gp + ": " + strerror(errno));
+		if (fseeko(gfile.f, 0, SEEK_END) != 0 || ftello(gfile.f) < 0) return fail(g, BVG_EIO, "cannot size " + gp);
+		graphSize = (size_t)ftello(gfile.f);
+	}
 	if (!bvh::read_file(st->basename + ".offsets", offs, err)) return fail(g, BVG_EIO, err);
-	st->info.graph_bytes = graph.size();
 	st->h_offsets.resize((size_t)in.nodes + 1);
+	lap("files opened, .offsets read");
 	if (ef) { // 64-bit words (EFGraph.loadLongBigList, EFGraph.java:677-707): padded to a whole word, brought to host order once
 		graph.resize((graph.size() + 7) & ~(size_t)7, 0);
 		if (in.ef_big_endian) for (size_t i = 0; i + 8 <= graph.size(); i += 8) { std::swap(graph[i], graph[i + 7]); std::swap(graph[i + 1], graph[i + 6]); std::swap(graph[i + 2], graph[i + 5]); std::swap(graph[i + 3], graph[i + 4]); }
+		graphSize = graph.size();
 	}
+	st->info.graph_bytes = graphSize;
 
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(g, BVG_EHIP, "no HIP device available (libbvgpu has no CPU fallback)");
@@ -1096,12 +1159,14 @@ static int open_impl(const char *basename, int device, int part, int parts, bvg_
 		HIPCHK(g, hipMemcpy(st->d_offsets, st->h_offsets.data(), sizeof(int64_t) * st->h_offsets.size(), hipMemcpyHostToDevice));
 	}
 	st->info.offsets_on_device = onDevice ? 1 : 0;
-	if ((uint64_t)st->h_offsets.back() > (uint64_t)graph.size() * 8) return fail(g, BVG_EIO, "offsets run past the end of the .graph file");
+	lap("offsets decoded");
+	if ((uint64_t)st->h_offsets.back() > (uint64_t)graphSize * 8) return fail(g, BVG_EIO, "offsets run past the end of the .graph file");
 	for (size_t i = 1; i < st->h_offsets.size(); i++) if (st->h_offsets[i] < st->h_offsets[i - 1]) return fail(g, BVG_EIO, "offsets are not monotone");
+	lap("offsets checked");
 	// ---- what this handle stages: the whole graph, or one bits-balanced slice of it
 	st->node_lo = 0; st->node_hi = in.nodes; st->stage_lo = 0;
 	if (parts > 1) {
-		const std::vector<int64_t> &off = st->h_offsets;
+		const HostOffsets &off = st->h_offsets;
 		auto bound = [&](int k) { return k >= parts ? in.nodes : (int32_t)(std::lower_bound(off.begin(), off.begin() + in.nodes, (int64_t)((__int128)off.back() * k / parts)) - off.begin()); };
 		st->node_lo = part == 0 ? 0 : bound(part);
 		st->node_hi = std::max(st->node_lo, bound(part + 1));
@@ -1117,16 +1182,19 @@ static int open_impl(const char *basename, int device, int part, int parts, bvg_
 		st->d_offsets = (int64_t *)((uintptr_t)slice - sizeof(int64_t) * (size_t)st->stage_lo);
 	}
 	{ // the bit stream: words [word_lo, nwords) plus >= 8 zero words
-		const uint64_t allWords = (graph.size() + 3) / 4;
+		const uint64_t allWords = (graphSize + 3) / 4;
 		const uint64_t wordLo = parts > 1 ? ((uint64_t)st->h_offsets[st->stage_lo] >> 5) & ~(uint64_t)3 : 0;
 		st->nwords = parts > 1 ? std::min<uint64_t>(allWords, (((uint64_t)st->h_offsets[st->node_hi] + 31) >> 5)) : allWords;
 		const size_t words = (size_t)(st->nwords - wordLo);
 		HIPCHK(g, hipMalloc((void **)&st->d_bits_alloc, (words + 8) * 4));
 		HIPCHK(g, hipMemset(st->d_bits_alloc, 0, (words + 8) * 4));
-		const size_t byteLo = (size_t)wordLo * 4, byteHi = std::min<size_t>(graph.size(), (size_t)st->nwords * 4);
-		if (byteHi > byteLo) HIPCHK(g, hipMemcpy(st->d_bits_alloc, graph.data() + byteLo, byteHi - byteLo, hipMemcpyHostToDevice));
+		const size_t byteLo = (size_t)wordLo * 4, byteHi = std::min<size_t>(graphSize, (size_t)st->nwords * 4);
+		if (ef) { if (byteHi > byteLo) HIPCHK(g, hipMemcpy(st->d_bits_alloc, graph.data() + byteLo, byteHi - byteLo, hipMemcpyHostToDevice)); }
+		else if (hipStreamSynchronize(nullptr) != hipSuccess /* the zero fill above is ahead of the pieces, which travel on a stream of their own */ ||
+		         (rc = stage_file_range(gfile.f, st->basename + ".graph", byteLo, byteHi, (uint8_t *)st->d_bits_alloc, err)) != BVG_OK) return fail(g, rc ? rc : BVG_EHIP, err.empty() ? "staging the bit stream failed" : err);
 		st->d_bits = (uint32_t *)((uintptr_t)st->d_bits_alloc - (size_t)wordLo * 4);
 	}
+	lap("bit stream staged");
 	st->info.shard_from = st->node_lo; st->info.shard_to = st->node_hi; st->info.staged_from = st->stage_lo;
 	// Scratch (interval arena, copy queues, giant list) is sized by the number of arcs: by what the stream holds, not by
 	// what .properties claims -- one pass over the record headers at load time
@@ -1164,8 +1232,11 @@ static int open_impl(const char *basename, int device, int part, int parts, bvg_
 		if (e != hipSuccess) return fail(g, e == hipErrorOutOfMemory ? BVG_ENOMEM : BVG_EHIP, "cannot scan the record headers");
 		st->arcs_sizing = std::max<int64_t>(st->arcs_sizing, total);
 	}
+	lap("record headers counted");
 	g->st = st;
-	return init_handle(g);
+	rc = init_handle(g);
+	lap("handle set up");
+	return rc;
 }
 
 extern "C" int bvg_clone(const bvg_t *src, bvg_t **out) {
@@ -1935,7 +2006,7 @@ extern "C" int bvg_bfs_expand(bvg_t *g, const int32_t *frontier_dev, size_t q, i
 
 extern "C" int bvg_shard_bounds(const bvg_t *g, int parts, int32_t *bounds) {
 	if (!g || !g->st || parts < 1 || !bounds) return BVG_EARG;
-	const std::vector<int64_t> &off = g->st->h_offsets;
+	const HostOffsets &off = g->st->h_offsets;
 	const int32_t n = g->st->info.nodes;
 	const int64_t totalBits = off.back();
 	bounds[0] = 0;
