@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU box, under rocprofv3 --kernel-trace: one call of an entry point on a cached workload, three times; scripts/op_dump.py prints the kernels of the last call.
-usage: op_timeline.py <c2|c5|cnr30> <range|checksum|sparse|stats|efscan>"""
+usage: op_timeline.py <c2|c5|cnr30|hubs> <scan|range|checksum|sparse|stats>"""
 import os
 import sys
 
@@ -14,7 +14,11 @@ def main():
     import torch
     from webgraph_amd.bvgraph import BVGraph
     name, op = sys.argv[1], sys.argv[2]
-    g = BVGraph.load(workload(name))
+    if name == "hubs":  # scripts/hub_time.py's graph: three rows of 8 M / 4 M / 2 M successors
+        from scripts.hub_time import build
+        g = BVGraph.load(build([8_000_000, 4_000_000, 2_000_000]))
+    else:
+        g = BVGraph.load(workload(name))
     n, m = g.numNodes(), g.numArcs()
     dev = torch.device("cuda", 0)
     rowptr = torch.empty(n + 1, dtype=torch.int64, device=dev)
@@ -26,6 +30,8 @@ def main():
         torch.cuda.synchronize()
         if op == "range":
             g.decode_range_device(n // 3, n // 3 + n // 4, rowptr.data_ptr(), succ.data_ptr(), succ.numel())
+        elif op == "scan":
+            g.decode_range_device(0, n, rowptr.data_ptr(), succ.data_ptr(), succ.numel())
         elif op == "checksum":
             g.scan_checksum(0, n, -1)
         elif op == "sparse":
