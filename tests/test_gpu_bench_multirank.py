@@ -71,12 +71,14 @@ def test_single_gpu_bench_line_prices_every_phase(tmp_path):
     copy = [v for k, v in r["kernels"].items() if k.startswith("k_copy_list")][0]
     assert copy["alg_bytes"] and copy["alg_bytes"] > 0 and copy["GBps"] > 0
     assert any(v["alg_bytes"] == r["kernel_algorithmic_bytes"] for v in r["kernels"].values())
+    assert r["kernel"].startswith("k_parse") and 0 < r["copy_pass_frac"] < 1  # the dominant kernel is ONE kernel, one launch per scan; the copy pass is reported beside it
     assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["cores"] == 1 and out["cpu_baseline"]["value"] > 0
     # the side measurements on the same lists: the compressor on the device, the EFGraph scan -- each checked before it is timed
     ex = out["extras"]
     assert "error" not in ex["compress"] and "error" not in ex["efgraph_scan"]
     assert ex["compress"]["parity"].startswith("streams byte-equal") and ex["compress"]["ms"] > 0
     assert ex["efgraph_scan"]["parity"].startswith("rowptr and successors equal") and 0 < ex["efgraph_scan"]["frac_of_hbm_peak"] < 1
+    assert ex["load"]["ok"] and ex["load"]["ms"] > 0
 
 
 @pytest.mark.timeout(1200)
