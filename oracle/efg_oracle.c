@@ -8,7 +8,8 @@
  *
  * PARITY UNPINNED: the reference holds no EFGraph fixture (test/it/unimi/dsi/webgraph/EFGraphTest.java round-trips only) and
  * cannot be built here (Java).  This file, the writer (bvt_store_ef) and the GPU kernels are checked against each other, and
- * the writer against a record worked out by hand from the format description (tests/test_efgraph_cpu.py).
+ * the writer against a record worked out by hand from the format description (tests/test_efgraph_cpu.py).  The forward
+ * pointers, which no scan reads, are read by efo_skip_to below the way the reference's skipTo reads them (:1147-1215).
  */
 #include <stdint.h>
 #include <stdlib.h>
@@ -83,5 +84,52 @@ int efo_scan(const uint64_t *words, uint64_t nwords, const int64_t *offsets, int
 	}
 	if (rowptr) rowptr[to - from] = (int64_t)k;
 	if (arcs_out) *arcs_out = k;
+	return s.err ? EFO_EFORMAT : EFO_OK;
+}
+
+/* EliasFanoSuccessorReader.skipTo(lowerBound) on a fresh reader of node x (EFGraph.java:1147-1215), for q (node, bound) pairs: the first successor >= bound, or -1
+ * at the end of the list.  The forward pointers are used exactly where the reference uses them -- more than `quantum` zeros to skip: block = zeros >> log2Quantum,
+ * skip = pointer[block - 1], the reader lands on bit upperBitsStart + skip of the upper bits with skip - (block << log2Quantum) ones behind it (:1164-1173) --, the
+ * rest of the way is the plain walk (the reference's broadword select finds the same bit).  used[i] = 1 when query i went through a pointer.  A pointer that does
+ * not say what the writer's Accumulator.add (:502-516) must put there sends the reader to the wrong element: the answers are compared with a search in the scanned lists. */
+int efo_skip_to(const uint64_t *words, uint64_t nwords, const int64_t *offsets, int32_t n, int32_t upper_bound, int log2_quantum, const int32_t *nodes, const int32_t *bounds,
+                size_t q, int32_t *out, uint8_t *used) {
+	if (!words || !offsets || !nodes || !bounds || !out || upper_bound < n || log2_quantum < 0) return EFO_EARG;
+	lw_t s = { words, nwords, 0 };
+	const uint64_t ub = (uint64_t)upper_bound, quantum = (uint64_t)1 << log2_quantum;
+	for (size_t i = 0; i < q; i++) {
+		const int32_t x = nodes[i];
+		if (x < 0 || x >= n || bounds[i] < 0) return EFO_EARG;
+		uint64_t pos = (uint64_t)offsets[x];
+		const uint64_t d = lw_gamma(&s, &pos);
+		if (s.err || d > ub) return EFO_EFORMAT;
+		const uint64_t len = d + 1;
+		const int l = ef_lower_bits(len, ub);
+		const uint64_t np = (ub >> l) >> log2_quantum;
+		const int ps = ef_ceil_log2(len + (ub >> l)) < 0 ? 0 : ef_ceil_log2(len + (ub >> l));
+		const uint64_t ptrStart = pos, lowerStart = pos + (uint64_t)ps * np, upperStart = lowerStart + (uint64_t)l * len;
+		const uint64_t lb = (uint64_t)bounds[i], zeroesToSkip = lb >> l;
+		uint64_t up = upperStart, index = 0; /* bit of the upper stream the reader stands on; ones behind it (currentIndex) */
+		if (used) used[i] = 0;
+		if (zeroesToSkip > quantum && np > 0) { /* delta > quantum with last = Integer.MIN_VALUE, :1164 */
+			const uint64_t block = zeroesToSkip >> log2_quantum;
+			if (block == 0 || block > np) return EFO_EFORMAT;
+			const uint64_t skip = lw_get(&s, ptrStart + (block - 1) * (uint64_t)ps, ps);
+			if (skip == 0 || skip < (block << log2_quantum)) return EFO_EFORMAT;
+			up = upperStart + skip;
+			index = skip - (block << log2_quantum);
+			if (used) used[i] = 1;
+		}
+		int32_t ans = -1;
+		while (index < d) { /* nextInt until last >= lowerBound (:1211-1214); the terminator is never returned */
+			(void)lw_unary(&s, &up);
+			if (s.err) return EFO_EFORMAT;
+			const uint64_t high = (up - 1 - upperStart) - index;
+			const uint64_t v = (high << l) | lw_get(&s, lowerStart + (uint64_t)l * index, l);
+			index++;
+			if (v >= lb) { ans = (int32_t)v; break; }
+		}
+		out[i] = ans;
+	}
 	return s.err ? EFO_EFORMAT : EFO_OK;
 }

@@ -426,3 +426,19 @@ class OracleEFGraph:
         if rc:
             raise OracleError(rc)
         return rowptr, succ[:arcs.value], arcs.value
+
+    def skip_to(self, nodes, bounds):
+        """EliasFanoSuccessorReader.skipTo on a fresh reader per (node, bound) pair, THROUGH the forward pointers where the reference uses them (efo_skip_to):
+        (answers, -1 at the end of a list; which queries went through a pointer)."""
+        f = lib().efo_skip_to
+        f.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int32, C.c_int32, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        nodes = np.ascontiguousarray(nodes, dtype=np.int32)
+        bounds = np.ascontiguousarray(bounds, dtype=np.int32)
+        out = np.empty(nodes.size, dtype=np.int32)
+        used = np.zeros(nodes.size, dtype=np.uint8)
+        rc = f(self.words.ctypes.data, self.words.size, self.offsets.ctypes.data, self.n, self.upper_bound, self.log2_quantum, nodes.ctypes.data, bounds.ctypes.data, nodes.size,
+               out.ctypes.data, used.ctypes.data)
+        if rc:
+            raise OracleError(rc)
+        return out, used.astype(bool)
+

@@ -67,3 +67,29 @@ def test_rows_must_increase_below_the_bound(tmp_path):
         T.store_ef(str(tmp_path / "x"), *_csr([[1, 1], []]))
     with pytest.raises(OSError):
         T.store_ef(str(tmp_path / "x"), *_csr([[0, 5], []]))
+
+
+@pytest.mark.parametrize("n,m,lq,big,ub", [(3000, 60000, 2, False, None), (3000, 60000, 0, True, None), (800, 40000, 3, False, 1500), (20000, 100000, 8, False, None)])
+def test_forward_pointers_take_skip_to_where_a_search_goes(tmp_path, n, m, lq, big, ub):
+    """The forward pointers of a record (Accumulator.add, EFGraph.java:502-516) are read by nothing in a scan; here skipTo (:1147-1215) goes THROUGH them --
+    more than a quantum of zeros to skip -- and must land on the first successor >= the bound, which a search in the scanned list gives."""
+    from webgraph_amd import tools as T
+    from oracle import oracle as O
+    rowptr, succ = T.generate(n, m, seed=77 + lq, p_copy=0.4, threads=2)
+    base = str(tmp_path / "ef")
+    T.store_ef(base, rowptr, succ, upper_bound=ub, log2_quantum=lq, big_endian=big)
+    g = O.OracleEFGraph.load(base)
+    rng = np.random.default_rng(5)
+    deg = np.diff(rowptr)
+    long_rows = np.nonzero(deg >= 8)[0]
+    nodes = np.concatenate([rng.integers(0, n, 3000), rng.choice(long_rows, 3000)]).astype(np.int32)
+    bounds = rng.integers(0, ub or n, nodes.size).astype(np.int32)
+    got, used = g.skip_to(nodes, bounds)
+    want = np.empty_like(got)
+    for i, (x, b) in enumerate(zip(nodes, bounds)):
+        row = succ[rowptr[x]:rowptr[x + 1]]
+        k = np.searchsorted(row, b)
+        want[i] = row[k] if k < row.size else -1
+    assert np.array_equal(got, want)
+    if lq <= 3:
+        assert used.sum() > 1000  # the pointers were on the path

@@ -154,6 +154,18 @@ def test_device_writer_reproduces_the_cpu_writer(tmp_path, n, m, lq, big, ub):
     B.store_ef(rowptr, succ, gpu, upperBound=ub, log2Quantum=lq, bigEndian=big)
     for ext in (".graph", ".offsets", ".properties"):
         assert filecmp.cmp(cpu + ext, gpu + ext, shallow=False), ext
+    if m and lq <= 2:  # the forward pointers the device wrote, read the way the reference's skipTo reads them (EFGraph.java:1147-1215; oracle efo_skip_to)
+        from oracle import oracle as O
+        og = O.OracleEFGraph.load(gpu)
+        rng = np.random.default_rng(11)
+        nodes = rng.choice(np.nonzero(np.diff(rowptr) >= 8)[0], 4000).astype(np.int32)
+        bounds = rng.integers(0, ub or n, nodes.size).astype(np.int32)
+        got, used = og.skip_to(nodes, bounds)
+        for x, b, v in zip(nodes, bounds, got):
+            row = succ[rowptr[x]:rowptr[x + 1]]
+            k = np.searchsorted(row, b)
+            assert v == (row[k] if k < row.size else -1)
+        assert used.sum() > 500
     with pytest.raises(ValueError):
         B.store_ef(np.array([0, 2], dtype=np.int64), np.array([1, 1], dtype=np.int32), gpu)       # not strictly increasing
     with pytest.raises(ValueError):
