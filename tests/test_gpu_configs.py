@@ -5,6 +5,7 @@ deep reference chains) decoded whole and in the eight bits-balanced slices of SU
 input (the reference's cnr-2000 fixture tiled 30 times).  The oracle runs on all host cores (ranges split as
 ImmutableGraph.splitNodeIterators does); each test takes some tens of seconds."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -77,6 +78,24 @@ def test_more_than_two_gib_of_successors():
         assert b - a == orp[i + 1] - orp[i] and np.array_equal(succ[a:b].cpu().numpy(), osc[orp[i]:orp[i + 1]])
     og.close()
     g.close()
+
+
+@pytest.mark.timeout(1500)
+def test_graph_file_of_more_than_two_gib():
+    """The other 2 GiB limit (BVGraph.java:1562-1568 loads such a file into several byte arrays): a `.graph` FILE of 2.27 GiB -- 42 M nodes, 16 successors
+    each with gaps of ~10^6, 28 bits per arc -- staged in pieces at load, scanned, folded; hashCode() and the rows at the far end of the file (from the scan and as a batch)
+    against the CPU oracle (scripts/big_file.py)."""
+    import torch
+    from scripts import big_file
+    free_b, _ = torch.cuda.mem_get_info()
+    if free_b < (16 << 30):
+        pytest.skip("needs 16 GB of free HBM")
+    argv = sys.argv
+    try:
+        sys.argv = ["big_file.py"]
+        assert big_file.main() == 0
+    finally:
+        sys.argv = argv
 
 
 @pytest.mark.timeout(900)
