@@ -211,6 +211,25 @@ def test_c5_shard_deep_chains():
     assert tot2 == arcs and P.fold_affine(pairs2) == whole
 
 
+@pytest.mark.timeout(2400)
+def test_c5_at_full_size_in_the_eight_slices_of_eight_ranks():
+    """BASELINE.json's C5 as it is quoted: 100 M nodes / 2 G arcs with deep reference chains.  One GPU plays the eight ranks of `bench.py --gpus 8 --workload C5` one after
+    the other -- bvg_open_shard(k, 8) on the same files, each slice scanned, the whole graph's hashCode folded from the slices' maps (ImmutableGraph.java:757-770) -- and then
+    scans the whole graph at once; both against the CPU oracle's hashCode (scripts/c5_full.py; profiles/r5_c5_full.txt: 5.7 - 5.9 ms per slice, 36 ms whole)."""
+    import psutil
+    import torch
+    from scripts import c5_full
+    free_b, _ = torch.cuda.mem_get_info()
+    if free_b < (48 << 30) or psutil.virtual_memory().available < (96 << 30):
+        pytest.skip("needs 48 GB of free HBM and 96 GB of host memory")
+    argv = sys.argv
+    try:
+        sys.argv = ["c5_full.py"]
+        assert c5_full.main() == 0
+    finally:
+        sys.argv = argv
+
+
 @pytest.mark.timeout(900)
 def test_tiled_cnr_web_shape(tmp_path_factory, cnr_oracle):
     """A web-graph-shaped input at scale: the reference's cnr-2000 fixture tiled 30 times (ids shifted per copy) and stored
