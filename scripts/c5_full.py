@@ -2,7 +2,7 @@
 """GPU box: C5 at its FULL size (100 M nodes / 2 G arcs, deep reference chains; BASELINE.json configs[4], quoted for 8 GPUs) on ONE GPU: the eight bits-balanced slices that
 `bench.py --gpus 8 --workload C5` gives its eight ranks (bvg_open_shard), opened and scanned one after the other on this GPU -- the ranks' own code path, no
 collective on the data path -- with the whole graph's hashCode folded from the slices' maps against the CPU oracle's; then the whole graph as one scan.  What eight GPUs would take is
-the longest slice (the ranks share nothing but the files).  usage: c5_full.py [nodes arcs [slices]]"""
+the longest slice (the ranks share nothing but the files).  usage: c5_full.py [nodes arcs [slices [C5|C2]]]   (105900000 3740000000 8 C2: a synthetic graph of the size of C3, uk-2007-05 -- more than 2^31 arcs in one scan)"""
 import os
 import sys
 import time
@@ -20,7 +20,7 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 2 else 100_000_000
     m = int(sys.argv[2]) if len(sys.argv) > 2 else 2_000_000_000
     parts = int(sys.argv[3]) if len(sys.argv) > 3 else 8
-    wl = bench.WORKLOADS["C5"]
+    wl = bench.WORKLOADS[sys.argv[4] if len(sys.argv) > 4 else "C5"]  # (the recipe: C5's deep chains, or C2's)
     t0 = time.time()
     base, meta = bench.prepare_graph(n, m, wl["seed"], wl["p_copy"], "/tmp/bvgpu_cache", os.cpu_count(), p_same=wl["p_same"], p_keep=wl["p_keep"])
     print("graph ready in %.0f s: .graph %.2f GB, %.3f bits/link" % (time.time() - t0, os.path.getsize(base + ".graph") / 1e9, os.path.getsize(base + ".graph") * 8 / m), flush=True)
