@@ -66,6 +66,8 @@ def main():
     succ = torch.empty(m, dtype=torch.int32, device=dev)
     arcs = g.decode_range_device(0, n, rowptr.data_ptr(), succ.data_ptr(), m)
     h = g.csr_hashcode(0, n, rowptr.data_ptr(), succ.data_ptr(), -1)
+    hs = g.hashCode()  # (bvg_scan_checksum: the fold inside the scan, piece by piece)
+    st = g.scan_stats(0, n)
     for _ in range(2):
         g.decode_range_device(0, n, rowptr.data_ptr(), succ.data_ptr(), m, asynchronous=True)
     g.sync()
@@ -74,9 +76,11 @@ def main():
         g.decode_range_device(0, n, rowptr.data_ptr(), succ.data_ptr(), m, asynchronous=True)
     g.sync()
     dt = (time.perf_counter() - t0) / 5
-    print("whole graph, one scan on one GPU: %d arcs, hashCode %s | %.2f ms = %.1f G edges/s" % (arcs, "ok" if h == want else "MISMATCH", dt * 1e3, m / dt / 1e9), flush=True)
+    stats_ok = int(st["arcs"]) == m
+    print("whole graph, one scan on one GPU: %d arcs, hashCode %s (folded inside the scan: %s; bvg_scan_stats counts %d arcs) | %.2f ms = %.1f G edges/s" % (
+        arcs, "ok" if h == want else "MISMATCH", "ok" if hs == want else "MISMATCH", int(st["arcs"]), dt * 1e3, m / dt / 1e9), flush=True)
     g.close()
-    return 0 if ok and h == want and arcs == m else 1
+    return 0 if ok and h == want and hs == want and stats_ok and arcs == m else 1
 
 
 if __name__ == "__main__":
