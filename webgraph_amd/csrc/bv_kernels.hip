@@ -33,6 +33,10 @@
 
 namespace bv {
 
+// A thread's item among up to 2^31 - 1 (a graph may have that many nodes, BVGraph.java:1537): the sum of block, tile and thread index is formed without sign and
+// capped at INT32_MAX, which no count exceeds -- `s < cnt` then holds for real items only (as a plain int32 the last block's idle threads went negative and passed it).
+__device__ __forceinline__ int32_t item_of(uint32_t i) { return (int32_t)(i < 0x7fffffffu ? i : 0x7fffffffu); }
+
 constexpr int TPB = 256;
 constexpr int GIANT_NW = COOP_GIANT_NW; // waves per giant record
 
@@ -47,7 +51,7 @@ __device__ __forceinline__ void copy_node_v(const GraphDev &g, int32_t x, int32_
 template <int DEF>
 __global__ void __launch_bounds__(TPB) k_headers(GraphDev g, int32_t lo, int32_t cnt, int32_t *__restrict__ outd,
                                                  uint16_t *__restrict__ ref, int *__restrict__ err, int32_t *__restrict__ part, uint8_t *__restrict__ mark) {
-	const int32_t s = blockIdx.x * TPB + threadIdx.x;
+	const int32_t s = item_of(blockIdx.x * TPB + threadIdx.x);
 	uint64_t d = 0;
 	if (s < cnt) {
 		const int32_t x = lo + s;
@@ -101,7 +105,7 @@ __global__ void k_mark_halo(int32_t nh, int32_t cnt, int32_t W, const int32_t *_
 }
 
 __global__ void k_apply_need(int32_t nh, const uint8_t *__restrict__ need, int32_t *__restrict__ outd, uint16_t *__restrict__ ref) {
-	const int32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+	const int32_t s = item_of(blockIdx.x * blockDim.x + threadIdx.x);
 	if (s >= nh) return;
 	if (!need[s]) { outd[s] = 0; ref[s] = 0; }
 	else if ((int32_t)ref[s] > s) ref[s] = 0; // a needed chain leaves the window (k_mark_halo raised E_ESCAPED): nothing before it may be touched
@@ -133,7 +137,7 @@ __global__ void k_query_mark(const int32_t *__restrict__ nodes, int64_t q, int32
 // stream the three arrays (a chain walk per query is three random accesses per step: 0.6 ms for 10 M queries,
 // against 25 us per pass here); `changed` tells the host whether the closure had not been reached before this pass.
 __global__ void k_need_prop(int32_t n, const int32_t *__restrict__ outd, const uint16_t *__restrict__ ref, uint8_t *need, int32_t *__restrict__ changed) {
-	const int32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+	const int32_t s = item_of(blockIdx.x * blockDim.x + threadIdx.x);
 	if (s >= n || !need[s] || outd[s] <= 0) return;
 	const int32_t r = ref[s];
 	if (r == 0) return;
@@ -427,7 +431,7 @@ __global__ void __launch_bounds__(TPB) k_depth_keys(GraphDev g, int32_t lo, int3
 	if (threadIdx.x < 2) s_qn[threadIdx.x] = 0;
 	__syncthreads();
 	for (int it = 0; it < LIST_ITEMS; it++) {
-		const int32_t s = blockIdx.x * LIST_TILE + it * TPB + threadIdx.x;
+		const int32_t s = item_of(blockIdx.x * LIST_TILE + it * TPB + threadIdx.x);
 		if (s >= cnt) break;
 		int32_t dd = 0;
 		if (!(noBin & 2)) { // (a list that ignores the level needs no depth: `depth` may be NULL)
@@ -506,7 +510,7 @@ __global__ void __launch_bounds__(TPB) k_scatter_keys(int32_t cnt, const uint16_
 	int32_t local[LIST_ITEMS];
 #pragma unroll
 	for (int it = 0; it < LIST_ITEMS; it++) {
-		const int32_t s = blockIdx.x * LIST_TILE + it * TPB + threadIdx.x;
+		const int32_t s = item_of(blockIdx.x * LIST_TILE + it * TPB + threadIdx.x);
 		keys[it] = s < cnt ? key16[s] : KEY_NONE;
 		local[it] = keys[it] != KEY_NONE ? atomicAdd(&s_cnt[keys[it] == KEY_GIANT ? NKEYS : keys[it]], 1) : 0;
 	}
@@ -515,7 +519,7 @@ __global__ void __launch_bounds__(TPB) k_scatter_keys(int32_t cnt, const uint16_
 	__syncthreads();
 #pragma unroll
 	for (int it = 0; it < LIST_ITEMS; it++) {
-		const int32_t s = blockIdx.x * LIST_TILE + it * TPB + threadIdx.x;
+		const int32_t s = item_of(blockIdx.x * LIST_TILE + it * TPB + threadIdx.x);
 		if (keys[it] == KEY_GIANT) { const int32_t k = s_base[NKEYS] + local[it]; if (k < giantCap) giantlist[k] = s; }
 		else if (keys[it] != KEY_NONE) list[s_base[keys[it]] + local[it]] = s;
 	}
@@ -803,8 +807,8 @@ __global__ void __launch_bounds__(LW_STRIDE) k_copy_prewalk_lanes(GraphDev g, Ra
 	__shared__ uint32_t lwin[LW_MAIN * LW_STRIDE];
 	const int lane = threadIdx.x & 63;
 	const int32_t nq = min(*count, cap);
-	for (int32_t q0 = blockIdx.x * LW_STRIDE; q0 < nq; q0 += gridDim.x * LW_STRIDE) {
-		const int32_t qi = q0 + (int32_t)threadIdx.x;
+	for (int64_t q0 = (int64_t)blockIdx.x * LW_STRIDE; q0 < nq; q0 += (int64_t)gridDim.x * LW_STRIDE) {
+		const int32_t qi = item_of((uint32_t)q0 + threadIdx.x);
 		int4 out = int4{ -1, 0, 0, 0 };
 		uint64_t bc = 0, need = 0;
 		int64_t dref = 0;
@@ -1304,7 +1308,7 @@ __global__ void __launch_bounds__(TPB) k_hash_rest(RangeView v, int what, bool i
 	const HashCtx hx = *v.hx;
 	const int64_t r0 = v.rowstart[v.nh];
 	const int32_t coopMin = v.coopmin();
-	const int32_t s = v.nh + blockIdx.x * TPB + threadIdx.x;
+	const int32_t s = item_of((uint32_t)v.nh + blockIdx.x * TPB + threadIdx.x);
 	uint32_t acc = 0;
 	if (s < v.cnt) {
 		const int64_t a = v.rowstart[s] - r0, b = v.rowstart[s + 1] - r0;
@@ -1389,12 +1393,12 @@ __global__ void __launch_bounds__(TPB) k_classify(int32_t cnt, const int32_t *__
 	if (coopPtr) coopMin = min(*coopPtr, giantMin);
 	// block-aggregated append: one atomic per block and list instead of one per long record
 	__shared__ int32_t s_cnt[2], s_base[2];
-	const int32_t base = blockIdx.x * (TPB * CLASSIFY_ITEMS) + threadIdx.x;
+	const uint32_t base = blockIdx.x * (TPB * CLASSIFY_ITEMS) + threadIdx.x;
 	int32_t d[CLASSIFY_ITEMS];
 	bool any = false;
 #pragma unroll
 	for (int it = 0; it < CLASSIFY_ITEMS; it++) {
-		const int32_t s = base + it * TPB;
+		const int32_t s = item_of(base + it * TPB);
 		d[it] = s < cnt ? outd[s] : 0;
 #ifdef BV_EXP_DROP_LO
 		if (d[it] >= BV_EXP_DROP_LO && d[it] < BV_EXP_DROP_HI) d[it] = 0;

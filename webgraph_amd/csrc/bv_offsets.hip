@@ -152,7 +152,11 @@ static int code_stream_decode(const uint32_t *d_words, uint64_t nwords, uint64_t
 	    ok(hipMalloc((void **)&total, sizeof(int64_t))) && ok(hipMalloc((void **)&lanes, sizeof(OffLane) * 64 * nchunks)) && ok(hipMalloc((void **)&changed, sizeof(int)))) {
 		int cur = 0;
 		bool fine = true;
-		for (int round = 0; round < 64 && fine; round++) { // (a round only repeats while some chunk's end still moves: 2-3 rounds)
+		// (a round only repeats while some chunk's end still moves: 2-3 rounds.  A stretch of equal codes never re-synchronises -- thousands of empty nodes in a row are
+		// 010 010 010 ..., and a chain that starts one bit late reads 1, 00100, 1, 00100, ... for ever --, so the true boundaries advance one chunk per round there:
+		// after MAX_ROUNDS the host decoder takes over; 64 rounds were 15 s of a 2^31-node load that the host decodes in 6)
+		constexpr int MAX_ROUNDS = 12;
+		for (int round = 0; round < MAX_ROUNDS && fine; round++) {
 			fine = ok(hipMemsetAsync(changed, 0, sizeof(int), st));
 			hipLaunchKernelGGL(k_off_parse<KIND>, dim3((unsigned)nchunks), dim3(64), 0, st, d_words, nwords, startBit, totalBits, nchunks, round, ends + (size_t)cur * nchunks,
 			                   ends + (size_t)(cur ^ 1) * nchunks, startUsed, cnt, gapsum, lanes, changed);
@@ -160,7 +164,7 @@ static int code_stream_decode(const uint32_t *d_words, uint64_t nwords, uint64_t
 			int h = 0;
 			fine = fine && ok(hipMemcpyAsync(&h, changed, sizeof(int), hipMemcpyDeviceToHost, st)) && ok(hipStreamSynchronize(st));
 			if (round > 0 && h == 0) break;
-			if (round == 63) fine = false;
+			if (round == MAX_ROUNDS - 1) fine = false;
 		}
 		if (fine) {
 			hipLaunchKernelGGL(k_off_scan, dim3(1), dim3(1024), 0, st, cnt, gapsum, nchunks, cntBase, sumBase, total);

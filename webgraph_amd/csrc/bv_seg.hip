@@ -451,7 +451,8 @@ __global__ void __launch_bounds__(STPB) k_seg_sizing(const int64_t *__restrict__
 	__syncthreads();
 	unsigned long long recs = 0, bits = 0, lrows = 0, lids = 0; // (lrows, lids: the rows of the copy pass's lane class -- a reference, fewer than 128 successors -- and their ids)
 	int32_t mx = 0;
-	for (int32_t s = blockIdx.x * STPB + threadIdx.x; s < n; s += gridDim.x * STPB) {
+	for (int64_t s64 = (int64_t)blockIdx.x * STPB + threadIdx.x; s64 < n; s64 += (int64_t)gridDim.x * STPB) { // (n may be 2^31 - 1: an int32 index would step past it and come back negative)
+		const int32_t s = (int32_t)s64;
 		mx = max(mx, outd[s]);
 		const uint64_t b = (uint64_t)(offsets[lo + s + 1] - offsets[lo + s]);
 		if (outd[s] > 0 && (b >= 2048 || (uint64_t)outd[s] * 8 >= 2048)) { recs++; bits += b; }

@@ -1145,10 +1145,13 @@ static int open_impl(const char *basename, int device, int part, int parts, bvg_
 		const uint64_t ow = (offs.size() + 3) / 4;
 		uint32_t *d_ow = nullptr;
 		if (hipMalloc((void **)&d_ow, (size_t)(ow + 8) * 4) == hipSuccess) {
-			if (hipMemset(d_ow, 0, (size_t)(ow + 8) * 4) == hipSuccess && hipMemcpy(d_ow, offs.data(), offs.size(), hipMemcpyHostToDevice) == hipSuccess &&
-			    bv::offsets_decode_device(d_ow, ow, (uint64_t)offs.size() * 8, in.nodes, st->d_offsets, nullptr, in.offset_coding == BVG_DELTA) == 0 &&
-			    hipMemcpy(st->h_offsets.data(), st->d_offsets, sizeof(int64_t) * st->h_offsets.size(), hipMemcpyDeviceToHost) == hipSuccess)
+			const bool up = hipMemset(d_ow, 0, (size_t)(ow + 8) * 4) == hipSuccess && hipMemcpy(d_ow, offs.data(), offs.size(), hipMemcpyHostToDevice) == hipSuccess;
+			lap("  .offsets to the device");
+			const bool dec = up && bv::offsets_decode_device(d_ow, ow, (uint64_t)offs.size() * 8, in.nodes, st->d_offsets, nullptr, in.offset_coding == BVG_DELTA) == 0;
+			lap(dec ? "  decoded on the device" : "  device decoder gave up");
+			if (dec && hipMemcpy(st->h_offsets.data(), st->d_offsets, sizeof(int64_t) * st->h_offsets.size(), hipMemcpyDeviceToHost) == hipSuccess)
 				onDevice = true;
+			lap("  table to the host");
 			(void)hipFree(d_ow);
 		}
 		(void)hipGetLastError();
