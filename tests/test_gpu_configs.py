@@ -117,6 +117,25 @@ def test_as_many_nodes_as_the_format_allows():
         sys.argv = argv
 
 
+@pytest.mark.timeout(3000)
+@pytest.mark.skipif(os.environ.get("BVGPU_SLOW") != "1", reason="the reference keeps this one under slow/ too: BVGPU_SLOW=1 runs it (2.5 minutes; profiles/r5_slow_test_shape.txt)")
+def test_the_shape_of_the_references_slow_test():
+    """BVGraphSlowTest.testStore (slow/it/unimi/dsi/webgraph/BVGraphSlowTest.java:30-101): Integer.MAX_VALUE nodes, two rows of 2^30 successors, 6.4 G arcs -- more than 2^32 --
+    in one scan; hashCode() by scan and by fold, the long rows and rows at both ends against the CPU oracle (scripts/slow_test_shape.py)."""
+    import psutil
+    import torch
+    from scripts import slow_test_shape
+    free_b, _ = torch.cuda.mem_get_info()
+    if free_b < (220 << 30) or psutil.virtual_memory().available < (256 << 30):
+        pytest.skip("needs 220 GB of free HBM and 256 GB of host memory")
+    argv = sys.argv
+    try:
+        sys.argv = ["slow_test_shape.py"]
+        assert slow_test_shape.main() == 0
+    finally:
+        sys.argv = argv
+
+
 @pytest.mark.timeout(900)
 def test_c2_full_size_default_thresholds(c2):
     """The headline configuration, whole: 200 M arcs.  The thresholds are the full-scan ones: a wave per record from 2 048
