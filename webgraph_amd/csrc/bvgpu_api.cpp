@@ -1459,7 +1459,14 @@ std::vector<int32_t> plan_chunks_by_bits(const Staged &s, int32_t from, int32_t 
 }
 
 // Arcs per piece of the scans that keep their rows on the device (checksum, statistics).  BVGPU_SCAN_PIECE: tests only.
-int64_t scan_piece_arcs(const bvg_graph *g) { return g->scan_piece > 0 ? (int64_t)g->scan_piece : (int64_t)256 << 20; }
+// arcs per piece of the scans whose rows stay in the library (checksum, statistics, equality, HyperBall): a piece is one job, and a job four times as long hides more of its set-up and
+// tails than four jobs do -- 1 G arcs (4.4 GB of scratch rows) where the device has the memory: the checksum of a 1 G-arc graph 16.3 -> 12.5 ms, below the 12.8 ms of the scan that hands the
+// rows to the caller; 256 M arcs (1 GB) on a device of less than 96 GB
+int64_t scan_piece_arcs(const bvg_graph *g) {
+	if (g->scan_piece > 0) return (int64_t)g->scan_piece;
+	static const bool roomy = [] { size_t fr = 0, tot = 0; return hipMemGetInfo(&fr, &tot) == hipSuccess && tot >= ((size_t)96 << 30); }();
+	return roomy ? (int64_t)1 << 30 : (int64_t)256 << 20;
+}
 
 // Host-output scan in ONE pass: the structure (outdegrees, CSR row starts) of the whole range first -- that is the
 // rowptr the caller gets and the exact chunk plan --, then the successors chunk by chunk: chunk k leaves over PCIe on the
@@ -1598,7 +1605,7 @@ extern "C" int bvg_scan_checksum(bvg_t *g, int32_t from, int32_t to, int32_t *ha
 	HIPCHK(g, hipSetDevice(s.device));
 	if (s.info.format == BVG_FORMAT_EF && !g->ef_hash_materialise) return ef_scan_checksum(g, from, to, hash_io, arcs_out); // (the knob: the decode-then-fold path below, for comparison)
 	// The rows never reach the caller: they are decoded piece by piece into one scratch buffer and folded into the running
-	// hash there.  Pieces of <= 256 M arcs (1 GB of scratch): smaller ones that would stay in the Infinity Cache (32 M arcs)
+	// hash there.  Pieces of <= 1 G arcs (scan_piece_arcs): smaller ones that would stay in the Infinity Cache (32 M arcs)
 	// cost more in per-call set-up than they save (C2: 12.2 ms in 7 pieces, 4 ms in one).
 	const std::vector<int32_t> cut = plan_chunks_by_bits(s, from, to, scan_piece_arcs(g));
 	uint64_t total = 0;
