@@ -67,9 +67,21 @@ def main():
     ok = ok and np.array_equal(tail[0], orp) and np.array_equal(tail[1], osc)
     od = g.outdegrees(n - 130, n)
     ok = ok and np.array_equal(od, np.diff(orp)[-130:])
+    st = g.scan_stats(0, n)  # (Stats.java:111-160 on the device: every node and arc counted once)
+    ok = ok and int(st["nodes"]) == n and int(st["arcs"]) == m and int(st["max_outdegree"]) == 2 and int(st["dangling"]) == n - (n + 63) // 64 - (1 if (n - 1) % 64 else 0)
     print("max nodes: n %d m %d | scan %.2f ms = %.1f G nodes/s | hashCode scan/fold %s, rows at both ends, a batch, a sub-range at the end vs oracle: %s" % (
         n, m, dt * 1e3, n / dt / 1e9, "ok" if h == want and hs == want else "MISMATCH (%d %d want %d)" % (h, hs, want), "ok" if ok else "MISMATCH"))
     og.close()
+    if os.environ.get("MAXN_EF"):  # the same lists as an EFGraph image in HBM (bvg_cache_as_efgraph: decode, re-encode, switch): the second format's kernels at the same limit
+        t0 = time.perf_counter()
+        g.cache_as_efgraph()
+        t1 = time.perf_counter()
+        arcs2 = g.decode_range_device(0, n, rowptr.data_ptr(), succ.data_ptr(), m)
+        h2 = g.csr_hashcode(0, n, rowptr.data_ptr(), succ.data_ptr(), -1)
+        hs2 = g.hashCode()
+        ok2 = arcs2 == m and h2 == want and hs2 == want
+        print("as an EFGraph image (%.1f s to re-encode): hashCode scan/fold %s" % (t1 - t0, "ok" if ok2 else "MISMATCH (%d %d want %d)" % (h2, hs2, want)))
+        ok = ok and ok2
     g.close()
     return 0 if ok else 1
 
