@@ -20,6 +20,7 @@ def main():
     flagsets = ["", "", "", "", "RESIDUALS_DELTA", "RESIDUALS_GAMMA", "BLOCKS_DELTA | BLOCK_COUNT_DELTA", "OUTDEGREES_DELTA", "REFERENCES_GAMMA", "RESIDUALS_NIBBLE",
                 "OUTDEGREES_DELTA | BLOCKS_DELTA | RESIDUALS_DELTA | REFERENCES_DELTA | BLOCK_COUNT_DELTA"]
     bad = 0
+    wide = os.environ.get("FUZZ_WIDE") == "1"
     tmp = tempfile.mkdtemp(prefix="bvfuzz")
     for c in range(cases):
         n = int(10 ** rng.uniform(1.5, 4.7))
@@ -30,6 +31,14 @@ def main():
         mi = int(rng.choice([0, 2, 3, 4, 4, 8]))
         k = int(rng.choice([1, 2, 3, 3, 3, 4, 5, 7]))
         fl = str(rng.choice(flagsets))
+        if wide:  # FUZZ_WIDE=1: windows, chains, interval lengths and zeta_k far from the defaults, the rarer codings
+            W = int(rng.choice([0, 1, 5, 40, 100, 300]))
+            mr = int(rng.choice([1, 4, 100, 1000000])) if W else 0
+            mi = int(rng.choice([0, 1, 2, 16, 100]))
+            k = int(rng.choice([1, 6, 8, 11, 16, 17, 30]))
+            fl = str(rng.choice(flagsets + ["BLOCKS_DELTA | BLOCK_COUNT_UNARY", "REFERENCES_DELTA | OFFSETS_DELTA", "RESIDUALS_GOLOMB", "OUTDEGREES_DELTA | RESIDUALS_NIBBLE | BLOCKS_DELTA"]))
+            if "GOLOMB" in fl:
+                k = 3  # (the only modulus a Golomb graph can be read back with: .properties carries zetak for zeta residuals only, BVGraph.java:2566)
         env = {}
         if rng.random() < 0.3:
             env = {"BVGPU_COOP_MIN": str(int(rng.choice([8, 64, 300]))), "BVGPU_GIANT_MIN": str(int(rng.choice([300, 1000, 4000])))}
