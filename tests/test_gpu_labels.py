@@ -80,3 +80,22 @@ def test_label_lists_match_oracle(tmp_path, width, n, m):
     assert lib().bvg_labels_decode_lists(g._h, 0, n, m, lpb.ctypes.data, None, 0, C.byref(nv), 0) == (-8 if values.size else 0)
     assert nv.value == values.size
     g.close()
+
+
+@pytest.mark.parametrize("value", [0, 5, 1000])
+def test_equal_labels_do_not_resynchronise(tmp_path, value):
+    """Every arc with the SAME gamma-coded label: 00110 00110 ... is a stream on which a chain of codes that starts one bit late never meets the true one, so the device decoder's
+    rounds advance one chunk each and it hands the stretch to the host walk (bvh::decode_gammas) -- which must give the labels, not an error."""
+    from webgraph_amd import tools as T
+    from webgraph_amd.bvgraph import ArcLabelledBVGraph
+    rowptr, succ = T.generate(60000, 2000000, seed=9, p_copy=0.5)
+    T.store(str(tmp_path / "g"), rowptr, succ, window=7, max_ref_count=3, min_interval=4)
+    lab = np.full(succ.size, value, dtype=np.int32)
+    T.store_labels(str(tmp_path / "lab"), "g", rowptr, lab, kind="gamma")
+    g = ArcLabelledBVGraph.load(str(tmp_path / "lab"))
+    rp, sc, got = g.decode_range()
+    assert np.array_equal(rp, rowptr) and np.array_equal(sc, succ) and np.array_equal(got[:succ.size], lab)
+    lo, hi = 20000, 41000
+    rp, sc, got = g.decode_range(lo, hi)
+    assert np.array_equal(got[:rowptr[hi] - rowptr[lo]], lab[rowptr[lo]:rowptr[hi]])
+    g.close()

@@ -225,4 +225,17 @@ int decode_offsets(const uint8_t *p, size_t len, int32_t nodes, int coding, int6
 	return BVG_OK;
 }
 
+// `count` gamma codes in bits [lo, hi) of p, one after the other (GammaCodedIntLabel.fromBitStream, labelling/GammaCodedIntLabel.java:60-64): BVG_OK when exactly the count
+// fits the stretch, BVG_EFORMAT otherwise
+int decode_gammas(const uint8_t *p, uint64_t lo, uint64_t hi, int64_t count, int32_t *out) {
+	HostBits hb{ p, hi };
+	hb.pos = lo;
+	for (int64_t i = 0; i < count; i++) {
+		const uint64_t v = hb.gamma();
+		if (hb.bad || v > 0x7fffffffull) return BVG_EFORMAT;
+		out[i] = (int32_t)v;
+	}
+	return hb.pos == hi ? BVG_OK : BVG_EFORMAT;
+}
+
 } // namespace bvh

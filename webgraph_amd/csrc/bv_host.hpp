@@ -22,5 +22,6 @@ int parse_properties(const std::string &basename, bvg_info_t &info, std::string 
 int decode_offsets(const uint8_t *p, size_t len, int32_t nodes, int coding, int64_t *out);
 
 bool read_file(const std::string &path, std::vector<uint8_t> &out, std::string &err);
+int decode_gammas(const uint8_t *p, uint64_t lo, uint64_t hi, int64_t count, int32_t *out); // `count` gamma codes in bits [lo, hi), one after the other
 
 } // namespace bvh

@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(256) k_fixed_width(const uint32_t *__restrict_
 // One contiguous stream of gamma codes in [startBit, endBit) holding exactly nOut codes: running sums -> int64 (offsets)
 // or the values themselves -> int32 (gamma-coded labels).  startBit must be a codeword boundary.
 template <bool PREFIX, class T, int KIND>
-static int code_stream_decode(const uint32_t *d_words, uint64_t nwords, uint64_t startBit, uint64_t totalBits, int64_t nOut, T *d_out, hipStream_t st) {
+static int code_stream_decode(const uint32_t *d_words, uint64_t nwords, uint64_t startBit, uint64_t totalBits, int64_t nOut, T *d_out, hipStream_t st, int maxRounds) {
 	if (nOut == 0) return totalBits == startBit ? 0 : -1;
 	const int64_t nchunks = totalBits > startBit ? (int64_t)((totalBits - startBit + OFF_CHUNK - 1) / OFF_CHUNK) : 0;
 	if (nchunks <= 0 || nchunks > 0x7fffffff) return -1;
@@ -154,9 +154,9 @@ static int code_stream_decode(const uint32_t *d_words, uint64_t nwords, uint64_t
 		bool fine = true;
 		// (a round only repeats while some chunk's end still moves: 2-3 rounds.  A stretch of equal codes never re-synchronises -- thousands of empty nodes in a row are
 		// 010 010 010 ..., and a chain that starts one bit late reads 1, 00100, 1, 00100, ... for ever --, so the true boundaries advance one chunk per round there:
-		// after MAX_ROUNDS the host decoder takes over; 64 rounds were 15 s of a 2^31-node load that the host decodes in 6)
-		constexpr int MAX_ROUNDS = 12;
-		for (int round = 0; round < MAX_ROUNDS && fine; round++) {
+		// after maxRounds the caller's host decoder takes over -- 12 for .offsets: 64 rounds were 15 s of a 2^31-node load that the host decodes in 6; the label streams have no host
+		// decoder behind them and keep 64)
+		for (int round = 0; round < maxRounds && fine; round++) {
 			fine = ok(hipMemsetAsync(changed, 0, sizeof(int), st));
 			hipLaunchKernelGGL(k_off_parse<KIND>, dim3((unsigned)nchunks), dim3(64), 0, st, d_words, nwords, startBit, totalBits, nchunks, round, ends + (size_t)cur * nchunks,
 			                   ends + (size_t)(cur ^ 1) * nchunks, startUsed, cnt, gapsum, lanes, changed);
@@ -164,7 +164,7 @@ static int code_stream_decode(const uint32_t *d_words, uint64_t nwords, uint64_t
 			int h = 0;
 			fine = fine && ok(hipMemcpyAsync(&h, changed, sizeof(int), hipMemcpyDeviceToHost, st)) && ok(hipStreamSynchronize(st));
 			if (round > 0 && h == 0) break;
-			if (round == MAX_ROUNDS - 1) fine = false;
+			if (round == maxRounds - 1) fine = false;
 		}
 		if (fine) {
 			hipLaunchKernelGGL(k_off_scan, dim3(1), dim3(1024), 0, st, cnt, gapsum, nchunks, cntBase, sumBase, total);
@@ -180,13 +180,13 @@ static int code_stream_decode(const uint32_t *d_words, uint64_t nwords, uint64_t
 }
 
 int offsets_decode_device(const uint32_t *d_words, uint64_t nwords, uint64_t totalBits, int32_t nodes, int64_t *d_out, hipStream_t st, bool deltaCoded) {
-	return deltaCoded ? code_stream_decode<true, int64_t, 3>(d_words, nwords, 0, totalBits, (int64_t)nodes + 1, d_out, st)
-	                  : code_stream_decode<true, int64_t, 2>(d_words, nwords, 0, totalBits, (int64_t)nodes + 1, d_out, st);
+	return deltaCoded ? code_stream_decode<true, int64_t, 3>(d_words, nwords, 0, totalBits, (int64_t)nodes + 1, d_out, st, 12)
+	                  : code_stream_decode<true, int64_t, 2>(d_words, nwords, 0, totalBits, (int64_t)nodes + 1, d_out, st, 12);
 }
 
 // labels of `count` consecutive arcs, stored in [startBit, endBit) of the .labels stream (GammaCodedIntLabel.java:60-64)
 int gamma_labels_decode_device(const uint32_t *d_words, uint64_t nwords, uint64_t startBit, uint64_t endBit, int64_t count, int32_t *d_out, hipStream_t st) {
-	return code_stream_decode<false, int32_t, 2>(d_words, nwords, startBit, endBit, count, d_out, st);
+	return code_stream_decode<false, int32_t, 2>(d_words, nwords, startBit, endBit, count, d_out, st, 64);
 }
 
 int fixed_labels_decode_device(const uint32_t *d_words, uint64_t nwords, uint64_t startBit, int32_t width, int64_t count, int32_t *d_out, hipStream_t st) {

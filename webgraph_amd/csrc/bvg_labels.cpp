@@ -173,7 +173,19 @@ extern "C" int bvg_labels_decode_range(bvg_labels_t *h, int32_t from, int32_t to
 	if (h->info.kind == BVG_LABEL_FIXED) {
 		if ((uint64_t)h->info.width * arcs != b1 - b0) return lfail(h, BVG_EFORMAT, "the label stream does not hold one fixed-width label per arc");
 		rc = bv::fixed_labels_decode_device(h->d_words, h->nwords, b0, h->info.width, (int64_t)arcs, d_out, nullptr);
-	} else rc = bv::gamma_labels_decode_device(h->d_words, h->nwords, b0, b1, (int64_t)arcs, d_out, nullptr);
+	} else {
+		rc = bv::gamma_labels_decode_device(h->d_words, h->nwords, b0, b1, (int64_t)arcs, d_out, nullptr);
+		if (rc) { // the device decoder gives up on streams that do not re-synchronise -- a long stretch of EQUAL labels is one (every label 5: 00110 00110 ...; a chain that starts one
+			// bit late never meets the true one) -- and on streams that do not hold `arcs` codes: the stretch is walked on the host, which tells the two apart
+			(void)hipGetLastError();
+			const uint64_t byteLo = b0 >> 3, byteHi = (b1 + 7) >> 3;
+			std::vector<uint8_t> bytes((size_t)(byteHi - byteLo) + 1);
+			std::vector<int32_t> vals((size_t)arcs);
+			if (byteHi > byteLo && hipMemcpy(bytes.data(), (const uint8_t *)h->d_words + byteLo, (size_t)(byteHi - byteLo), hipMemcpyDeviceToHost) != hipSuccess) return lfail(h, BVG_EHIP, "copying the label stream back failed");
+			rc = bvh::decode_gammas(bytes.data(), b0 - byteLo * 8, b1 - byteLo * 8, (int64_t)arcs, vals.data());
+			if (!rc && arcs && hipMemcpy(d_out, vals.data(), sizeof(int32_t) * (size_t)arcs, hipMemcpyHostToDevice) != hipSuccess) return lfail(h, BVG_EHIP, "staging the labels failed");
+		}
+	}
 	if (rc) { (void)hipGetLastError(); return lfail(h, BVG_EFORMAT, "the label stream does not hold one label per arc of the range"); }
 	if (!dev && hipMemcpy(labels, d_out, sizeof(int32_t) * (size_t)arcs, hipMemcpyDeviceToHost) != hipSuccess) return lfail(h, BVG_EHIP, "copying the labels back failed");
 	return BVG_OK;
