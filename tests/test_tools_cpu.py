@@ -225,3 +225,14 @@ def test_properties_carry_the_gap_statistics(tmp_path, I):
         want = ("%.3f" % (bits / n)).rstrip("0").rstrip(".")
         assert p["avgbitsfor" + k] == want, k
     assert "compratio" in p
+
+
+def test_host_walk_of_gamma_labels(tmp_path):
+    """bvh::decode_gammas (bv_host.cpp): the host walk that stands behind the device decoder of gamma-coded labels (streams that never re-synchronise; streams that do not
+    hold one label per arc) -- tests/cpp/host_bits_test.cpp writes streams bit by bit and reads them back from any offset."""
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "host_bits_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(ROOT, "tests", "cpp", "host_bits_test.cpp"), os.path.join(ROOT, "webgraph_amd", "csrc", "bv_host.cpp")])
+    p = subprocess.run([exe], capture_output=True, text=True)
+    assert p.returncode == 0 and "ok" in p.stdout, p.stderr
