@@ -126,7 +126,13 @@ public class GpuBVGraph extends ImmutableGraph {
 	@Override public int hashCode() { return scanChecksum(handle, 0, n, -1); }
 	/** ImmutableGraph.equals (ImmutableGraph.java:731-749); two graphs of this class are compared on the device, row by row, without a list reaching the JVM. */
 	@Override public boolean equals(final Object o) {
-		if (o instanceof GpuBVGraph) { final GpuBVGraph g = (GpuBVGraph)o; return n == g.n && equalRange(handle, g.handle, 0, n); }
+		if (o instanceof GpuBVGraph) {
+			final GpuBVGraph g = (GpuBVGraph)o;
+			if (n != g.n) return false;
+			// (handles on different devices, or shard handles that stage different ranges: bvg_equal_range answers BVG_EARG, which the binding throws as
+			// IllegalArgumentException -- then the comparison of ImmutableGraph.equals through the iterators, as the C++ and Python mirrors do)
+			try { return equalRange(handle, g.handle, 0, n); } catch (final IllegalArgumentException e) { return super.equals(o); }
+		}
 		return super.equals(o);
 	}
 

@@ -33,6 +33,7 @@ free_fn real_free() { static free_fn f = (free_fn)dlsym(RTLD_NEXT, "hipFree"); r
 size_t guard_align() { static size_t a = [] { const char *e = getenv("GUARD_ALIGN"); const long v = e ? atol(e) : 16; return (size_t)(v >= 1 ? v : 16); }(); return a; }
 size_t guard_max() { static size_t a = [] { const char *e = getenv("GUARD_MAX_BYTES"); return e ? (size_t)atoll(e) : (size_t)1 << 30; }(); return a; } // larger buffers go to the real hipMalloc
 int guard_fill() { static int a = [] { const char *e = getenv("GUARD_FILL"); return e ? (int)strtol(e, nullptr, 0) : -1; }(); return a; } // >= 0: every new buffer is filled with this byte
+bool guard_front() { static bool a = [] { const char *e = getenv("GUARD_FRONT"); return e && atoi(e) != 0; }(); return a; } // 1: the unmapped granule sits IN FRONT of the buffer (negative indices fault; overruns do not)
 bool guard_vmm() { static bool a = [] { const char *e = getenv("GUARD_VMM"); return !e || atoi(e) != 0; }(); return a; } // 0: plain hipMalloc (only the fill remains)
 long guard_only() { static long a = [] { const char *e = getenv("GUARD_ONLY"); return e ? atol(e) : -1L; }(); return a; } // >= 0: only the allocation with this ordinal is guarded (bisection)
 size_t n_seen = 0;
@@ -64,8 +65,10 @@ extern "C" hipError_t hipMalloc(void **out, size_t size) {
 	if (hipMemGetAllocationGranularity(&g, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || g == 0) { (void)hipGetLastError(); n_fallback++; return real_malloc()(out, size); }
 	const size_t a = guard_align(), user = (size + a - 1) / a * a, mapped = (user + g - 1) / g * g, reserved = mapped + g;
 	Rec r = { nullptr, reserved, mapped, {} };
-	if (hipMemAddressReserve(&r.va, reserved, g, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); n_fallback++; return real_malloc()(out, size); }
-	if (hipMemCreate(&r.h, mapped, &prop, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipMemAddressFree(r.va, reserved); return hipErrorOutOfMemory; }
+	void *resv = nullptr;
+	if (hipMemAddressReserve(&resv, reserved, g, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); n_fallback++; return real_malloc()(out, size); }
+	r.va = guard_front() ? (void *)((char *)resv + g) : resv; // (front mode: the first granule of the reservation stays unmapped)
+	if (hipMemCreate(&r.h, mapped, &prop, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipMemAddressFree(resv, reserved); return hipErrorOutOfMemory; }
 	hipMemAccessDesc ad = {};
 	ad.location = prop.location;
 	ad.flags = hipMemAccessFlagsProtReadWrite;
@@ -73,12 +76,13 @@ extern "C" hipError_t hipMalloc(void **out, size_t size) {
 		(void)hipGetLastError();
 		(void)hipMemUnmap(r.va, mapped);
 		(void)hipMemRelease(r.h);
-		(void)hipMemAddressFree(r.va, reserved);
+		(void)hipMemAddressFree(resv, reserved);
 		n_fallback++;
 		return real_malloc()(out, size);
 	}
 	if (guard_fill() >= 0) { (void)hipMemset(r.va, guard_fill(), mapped); (void)hipDeviceSynchronize(); }
-	void *p = (char *)r.va + (mapped - user);
+	void *p = guard_front() ? r.va : (void *)((char *)r.va + (mapped - user));
+	if (getenv("GUARD_TRACE")) fprintf(stderr, "[guard_alloc] #%zu: [%p, %p) mapped [%p, %p)\n", ordinal, p, (void *)((char *)p + size), r.va, (void *)((char *)r.va + mapped));
 	{
 		std::lock_guard<std::mutex> lk(mu);
 		live[p] = r;
@@ -106,6 +110,6 @@ extern "C" hipError_t hipFree(void *p) {
 	// (measured: a 36-byte buffer freed and allocated again read back the words of its previous life).  It also
 	// turns a use after free into a fault.
 	static const bool reuse = [] { const char *e = getenv("GUARD_REUSE_VA"); return e && atoi(e) != 0; }();
-	if (reuse) (void)hipMemAddressFree(r.va, r.reserved);
+	if (reuse) (void)hipMemAddressFree(guard_front() ? (void *)((char *)r.va - (r.reserved - r.mapped)) : r.va, r.reserved);
 	return hipSuccess;
 }

@@ -117,6 +117,31 @@ def test_as_many_nodes_as_the_format_allows():
         sys.argv = argv
 
 
+@pytest.mark.timeout(900)
+def test_last_tile_of_a_graph_with_int32_max_nodes_under_the_guard_allocator(tmp_path):
+    """The root cause of the illegal access that BVGraphSlowTest's shape met inside pytest in round 5: k_parse_tile formed a slot as
+    `a + tid + k * TILE_T` in 32 bits, and the LAST tile of a job over 2^31 - 1 slots read the outdegrees -- then offsets and row starts -- of slots behind the end of the view;
+    harmless while the memory behind the buffers was zero, a wild store when it held a previous job's bytes.  scripts/last_tile.py (hand-made files: 2^31 - 1 nodes, the last 3 000
+    non-empty) in a process of its own under scripts/guard_alloc.cpp -- EVERY device buffer, the 17 GB ones too, ends at an unmapped page, the library allocates without
+    slack --: the old kernel faults every time (profiles/r6_fault_hunt.txt), the fixed one decodes the graph with and without the tile kernel, bit-exact."""
+    import shutil
+    import subprocess
+    import psutil
+    import torch
+    free_b, _ = torch.cuda.mem_get_info()
+    if free_b < (100 << 30) or psutil.virtual_memory().available < (64 << 30):
+        pytest.skip("needs 100 GB of free HBM and 64 GB of host memory")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    guard = str(tmp_path / "libguard.so")
+    if os.path.exists(hipcc) and subprocess.call([hipcc, "-O1", "-shared", "-fPIC", "-o", guard, os.path.join(root, "scripts", "guard_alloc.cpp"), "-ldl"]) == 0:
+        env.update(LD_PRELOAD=guard, BVGPU_EXACT_ALLOC="1", GUARD_MAX_BYTES=str(1 << 44))
+    r = subprocess.run([sys.executable, "-u", os.path.join(root, "scripts", "last_tile.py")], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=800)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0 and "last tile: ok" in out, out[-3000:]
+
+
 @pytest.mark.timeout(3000)
 @pytest.mark.skipif(os.environ.get("BVGPU_SLOW") != "1", reason="the reference keeps this one under slow/ too: BVGPU_SLOW=1 runs it (2.5 minutes; profiles/r5_slow_test_shape.txt)")
 def test_the_shape_of_the_references_slow_test():

@@ -695,7 +695,7 @@ __global__ void __launch_bounds__(64 * PREWALK_WAVES) k_copy_prewalk(GraphDev g,
 		const bool inL = qiL64 < nq;
 		const int32_t sL = inL ? queue[inL ? (int32_t)qiL64 : 0] : 0;
 		const int32_t rL = inL ? (int32_t)v.ref[sL] : 0, dL = inL ? v.outd[sL] : 0;
-		const bool okL = inL && rL != 0 && v.fits(sL) && v.fits(sL - rL);
+		const bool okL = inL && rL != 0; // (no RangeView::fits here: the walk touches no row -- k_copy_big / k_copy_mid check the rows themselves --, and a tile job runs this kernel beside the scan that writes rowstart: ADVICE r5)
 		const int32_t drefL = okL ? v.outd[sL - rL] : 0;
 		const int64_t off0L = okL ? g.offsets[v.lo + sL] : 0, off1L = okL ? g.offsets[v.lo + sL + 1] : 0;
 	for (unsigned long long todo = __ballot(inL); todo; todo &= todo - 1) {
@@ -764,7 +764,7 @@ __global__ void __launch_bounds__(64 * PWL_NW) k_copy_prewalk_long(GraphDev g, R
 	for (int32_t qi = blockIdx.x; qi < nq; qi += gridDim.x) { // (uniform)
 		const int32_t s = queue[qi];
 		const int32_t r = v.ref[s], d = v.outd[s];
-		if (r == 0 || !v.fits(s) || !v.fits(s - r)) continue;
+		if (r == 0) continue; // (no RangeView::fits: see k_copy_prewalk)
 		const int64_t dref = v.outd[s - r];
 		if (dref + 1 < PREWALK_LONG_MIN) continue; // (bc <= dref + 1)
 		BitReader br;
@@ -821,7 +821,7 @@ __global__ void __launch_bounds__(LW_STRIDE) k_copy_prewalk_lanes(GraphDev g, Ra
 			const int32_t s = queue[qi];
 			const int32_t r = v.ref[s];
 			d = v.outd[s];
-			if (r != 0 && v.fits(s) && v.fits(s - r)) {
+			if (r != 0) { // (no RangeView::fits: see k_copy_prewalk)
 				dref = v.outd[s - r];
 				lw.vlast = min((((uint64_t)g.offsets[v.lo + s + 1] >> 5) + 2) & ~(uint64_t)3, (g.nwords + 4) & ~(uint64_t)3);
 				lw.seek(g, (uint64_t)g.offsets[v.lo + s]);
@@ -1784,14 +1784,15 @@ __global__ void __launch_bounds__(256) k_bcopy_coop(GraphDev g, BatchView v, int
 			const uint64_t bc = Fields<DEF>::block_count(br, g);
 			int64_t total = 0, copied = 0;
 			int32_t nKept = 0;
-			bool bad = bc > (uint64_t)dref + 1; // (flagged by the parse kernel)
+			bool bad = bc > (uint64_t)dref + 1, full = false; // (bad: flagged by the parse kernel)
 			for (uint64_t b = 0; !bad && b <= bc; b++) {
 				int64_t len;
 				if (b < bc) len = (int64_t)Fields<DEF>::block(br, g) + (b ? 1 : 0);
 				else len = dref - total; // implicit last block (copied when the block count is even)
 				if (len < 0 || total + len > dref) { bad = true; break; }
 				if (!(b & 1)) {
-					if (copied + len > d || nKept >= CAP) { bad = true; break; }
+					if (copied + len > d) { bad = true; break; }
+					if (nKept > CAP) { full = true; break; } // (the tables hold CAP + 1 kept blocks: a valid record of CAP - 1 ids copied one by one behind an empty first block and in front of an empty last one has that many -- ADVICE r5; more: not malformed, the lane-serial merge takes the row)
 					if (tid == (nKept % NT)) { kend[nKept] = (int32_t)(copied + len); delta[nKept] = (int32_t)(total - copied); }
 					nKept++;
 					copied += len;
@@ -1799,7 +1800,7 @@ __global__ void __launch_bounds__(256) k_bcopy_coop(GraphDev g, BatchView v, int
 				total += len;
 			}
 			if (br.err && tid == 0) atomicOr(err, br.err);
-			const bool skip = bad || br.err || copied == 0; // malformed (flagged by the parse kernel) or nothing to merge (uniform)
+			const bool skip = bad || br.err || full || copied == 0; // malformed (flagged by the parse kernel), nothing to merge, or more kept blocks than the tables hold (uniform)
 			const int32_t nExtra = d - (int32_t)copied, nc = (int32_t)copied;
 			group_sync();
 			if (!skip) {
@@ -1811,7 +1812,7 @@ __global__ void __launch_bounds__(256) k_bcopy_coop(GraphDev g, BatchView v, int
 				for (int32_t e = tid; e < nExtra; e += NT) vals[nc + e] = row[nc + e]; // extras -> vals[nc .. d)
 			}
 			group_sync();
-			bool dup = false; // an id in both sets (never in a valid file): the lane-serial merge emits equal heads once and pads the row (copy_node)
+			bool dup = full && !bad && !br.err; // an id in both sets (never in a valid file): the lane-serial merge emits equal heads once and pads the row (copy_node); it also takes the rows whose tables overflowed
 			int32_t place[CAP / NT];
 #pragma unroll
 			for (int k = 0; k < CAP / NT; k++) {

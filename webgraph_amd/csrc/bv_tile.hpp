@@ -245,9 +245,13 @@ __global__ void __launch_bounds__(TILE_T) k_parse_tile(GraphDev g, RangeView v, 
 	int32_t bin[RPT], pos[RPT];
 #pragma unroll
 	for (int k = 0; k < RPT; k++) {
-		const int32_t s = a + tid + k * TILE_T;
+		// (a tile holds <= TILE_NODES slots: the offset is compared, not the sum -- for a graph of 2^31 - 1 nodes `a + tid + k * TILE_T` of the LAST tile passes
+		// INT32_MAX, the compiler forms the address from the unwrapped sum, and the block read outdegrees -- and then offsets and row starts -- of slots that do not
+		// exist: the illegal access of the slow-test shape)
+		const int32_t o = tid + k * TILE_T;
+		const int32_t s = a + min(o, b - a);
 		bin[k] = -1;
-		if (s < b) {
+		if (o < b - a) {
 			const int32_t d = v.outd[s];
 			if (d > 0 && d < v.coopmin()) {
 				const uint64_t bitsLen = (uint64_t)(g.offsets[v.lo + s + 1] - g.offsets[v.lo + s]);

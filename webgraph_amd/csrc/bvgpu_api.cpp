@@ -1464,8 +1464,16 @@ std::vector<int32_t> plan_chunks_by_bits(const Staged &s, int32_t from, int32_t 
 // rows to the caller; 256 M arcs (1 GB) on a device of less than 96 GB
 int64_t scan_piece_arcs(const bvg_graph *g) {
 	if (g->scan_piece > 0) return (int64_t)g->scan_piece;
-	static const bool roomy = [] { size_t fr = 0, tot = 0; return hipMemGetInfo(&fr, &tot) == hipSuccess && tot >= ((size_t)96 << 30); }();
-	return roomy ? (int64_t)1 << 30 : (int64_t)256 << 20;
+	// (by the memory of the handle's OWN device, asked once per device: a process may hold handles on devices of different sizes -- ADVICE r5)
+	static std::atomic<int> roomy[64]; // 0 unknown, 1 small, 2 roomy
+	const int dev = g->st ? g->st->device : 0, slot = dev >= 0 && dev < 64 ? dev : 0;
+	int r = roomy[slot].load(std::memory_order_relaxed);
+	if (r == 0) {
+		hipDeviceProp_t prop;
+		r = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.totalGlobalMem >= ((size_t)96 << 30) ? 2 : 1;
+		roomy[slot].store(r, std::memory_order_relaxed);
+	}
+	return r == 2 ? (int64_t)1 << 30 : (int64_t)256 << 20;
 }
 
 // Host-output scan in ONE pass: the structure (outdegrees, CSR row starts) of the whole range first -- that is the
