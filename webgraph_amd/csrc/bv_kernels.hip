@@ -46,6 +46,8 @@ template <int DEF>
 __device__ __forceinline__ void parse_node(const GraphDev &g, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row, int *__restrict__ err);
 template <int DEF>
 __device__ __forceinline__ void copy_node_v(const GraphDev &g, int32_t x, int32_t d, int32_t dref, int32_t *__restrict__ row, const int32_t *__restrict__ src, int *__restrict__ err);
+template <bool VEC>
+__device__ __forceinline__ void copy_node_tab(int32_t d, int32_t dref, int32_t *__restrict__ row, const int32_t *__restrict__ src, const int32_t *__restrict__ tabEnd, int4 hd);
 
 // ------------------------------------------------------------------------------------------------ headers
 template <int DEF>
@@ -537,12 +539,16 @@ __device__ __forceinline__ int copy_class(const RangeView &v, const int32_t *__r
 	if (!v.fits(s) || !v.fits(s - v.ref[s])) return 0; // E_CAP / E_HALO already raised by the parse kernel
 	return copy_class_of(v.outd[s], v.outd[s - v.ref[s]], midMin, bigMin);
 }
-template <int DEF, bool VEC, bool HASH = false>
+// TAB: the rows that the one-lane parse decoded (fewer than coopMin successors) carry their copy blocks as a table at the end of their slice of the interval arena
+// (parse_node_lwc / parse_node_tile, bv_lanewin.hpp): the merge reads neither the stream nor the offsets and runs no bit reader (copy_node_tab).
+template <int DEF, bool VEC, bool HASH = false, bool TAB = false>
 __global__ void __launch_bounds__(TPB) k_copy_list(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ list,
-                                                   const int32_t *__restrict__ keyBase, int32_t level, int32_t midMin, int32_t bigMin, int *__restrict__ err) {
+                                                   const int32_t *__restrict__ keyBase, int32_t level, int32_t midMin, int32_t bigMin, int *__restrict__ err,
+                                                   const IvEntry *__restrict__ arena = nullptr, int64_t arenaCap = 0, const CopyTab *__restrict__ ctab = nullptr) {
 	const int32_t bucket = min(level, MAXLVL - 1);
 	const int32_t lo = keyBase[bucket * NBIN], hi = keyBase[(bucket + 1) * NBIN];
 	const int64_t rsNh = v.rowstart[v.nh];
+	const int32_t coopMin = TAB ? v.coopmin() : 0;
 	// HASH (bvg_scan_checksum): the rows merged here are added to the job's hash as they are written (copy_node<., true>)
 	const HashCtx hx = HASH ? *v.hx : HashCtx{};
 	uint32_t hacc = 0;
@@ -559,6 +565,21 @@ __global__ void __launch_bounds__(TPB) k_copy_list(GraphDev g, RangeView v, cons
 		if (copy_class_of(d, dref, midMin, bigMin) != 1) continue;
 		int32_t *row = s < v.nh ? v.halo + rs0 : v.succ + (rs0 - rsNh);
 		const int32_t *src = t < v.nh ? v.halo + rt0 : v.succ + (rt0 - rsNh);
+		if (TAB && d < coopMin) {
+			const int4 hd = *(const int4 *)(ctab + s);
+			const uint32_t kept = (uint32_t)hd.w & 0xffffu;
+			if (kept != CT_NONE) {
+				const int32_t *ovfEnd = nullptr;
+				bool ok = true;
+				if (kept > 3) { // the kept blocks from the fourth on: the end of the record's own part of the interval arena
+					int64_t abase = 0; int32_t an = 0;
+					if (g.minInt > 0) arena_slice(g.minInt, rs0, d, abase, an);
+					ok = g.minInt > 0 && abase >= 0 && abase + an <= arenaCap && (int32_t)kept - 3 <= 4 * (an - 1);
+					ovfEnd = (const int32_t *)(arena + abase + (an - 1));
+				}
+				if (ok) { copy_node_tab<VEC>(d, dref, row, src, ovfEnd, hd); continue; }
+			}
+		}
 		if (HASH) copy_node<DEF, true>(g, v.lo + s, d, (int64_t)dref, row, src, err, &hacc, s >= v.nh ? hash_upow(hx.ptab, (uint64_t)(1 + rs1 + (int64_t)s)) : 0u);
 		else if (VEC) copy_node_v<DEF>(g, v.lo + s, d, dref, row, src, err);
 		else copy_node<DEF>(g, v.lo + s, d, (int64_t)dref, row, src, err);
@@ -1247,9 +1268,9 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 // a sweep of short records is three dependent round trips (list entry -> outdegree / reference / row start / offsets -> the referent's
 // outdegree and the stream words) in front of ~5 us of decoding; the entry is fetched two sweeps ahead and what hangs on it one sweep
 // ahead, so a sweep waits for the last trip only.  Default codings: parse_node_lwb (bv_lanewin.hpp); others: the generic reader.
-template <int DEF, bool HASH = false>
+template <int DEF, bool HASH = false, bool LWC = true> // LWC: the round-6 loop (parse_node_lwc: leaves the copy blocks as tables); false: round 4's (parse_node_lwb; knob lane_loop = 0)
 __global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, const int32_t *__restrict__ list, const int32_t *__restrict__ keyBase, int32_t binLo, int32_t binHi,
-                                                    IvEntry *__restrict__ arena, int64_t arenaCap, int *__restrict__ err) {
+                                                    IvEntry *__restrict__ arena, int64_t arenaCap, int *__restrict__ err, CopyTab *__restrict__ ctab = nullptr) {
 	static_assert(!HASH || DEF != 0, "the hash fold rides on the default codings' loop");
 	__shared__ uint32_t lw[DEF ? (LW_MAIN + 2 * LW_RING) * LW_STRIDE : 1]; // per lane: a window of the stream and a ring of intervals (default codings)
 	const int32_t lo = keyBase[binLo], hi = keyBase[binHi], coopMin = v.coopmin();
@@ -1277,9 +1298,22 @@ __global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, con
 		int32_t *const row = s < v.nh ? v.halo + raC : v.succ + (raC - rs0); // (RangeView::row)
 		if (DEF) {
 			// the record's slice of the interval arena (the same slices as the cooperative kernels': floor(rowstart / minInt), d / minInt + 1 entries)
-			const int64_t abase = g.minInt > 0 ? raC / g.minInt : 0;
-			if (g.minInt > 0 && (abase < 0 || abase + dC / g.minInt + 1 > arenaCap)) { atomicOr(err, E_FORMAT); continue; }
-			if (HASH) {
+			int64_t abase = 0;
+			int32_t aslice = 0;
+			if (g.minInt > 0) arena_slice(g.minInt, raC, dC, abase, aslice);
+			if (g.minInt > 0 && (abase < 0 || abase + aslice > arenaCap)) { atomicOr(err, E_FORMAT); continue; }
+			if (LWC) {
+				CopyTab *const ct = ctab ? ctab + s : nullptr; // the slot's table of copy blocks, for the copy pass
+				const int32_t own = g.minInt > 0 ? aslice - 1 : 0;
+				if (HASH) {
+					const bool mine = s >= v.nh && rC == 0;
+					const uint32_t hw = mine ? hash_upow(hx.ptab, (uint64_t)(1 + rbC + (int64_t)s)) : 0u;
+					const bool keep = !mine || hx.mark[s] != 0;
+					parse_node_lwc<DEF == 1 ? 3 : 0, true>(g, v.lo + s, dC, rC, drefC, row, lw, (int2 *)(arena + abase), own, ct, err, oaC, obC, &hacc, hw, keep);
+				}
+				else parse_node_lwc<DEF == 1 ? 3 : 0>(g, v.lo + s, dC, rC, drefC, row, lw, (int2 *)(arena + abase), own, ct, err, oaC, obC);
+			}
+			else if (HASH) {
 				const bool mine = s >= v.nh && rC == 0; // hashed here; the others (rows with a reference, halo rows) are written as ever
 				const uint32_t hw = mine ? hash_upow(hx.ptab, (uint64_t)(1 + rbC + (int64_t)s)) : 0u; // successor j of slot s weighs u^(1 + rowstart[s + 1] + s) * 31^j
 				const bool keep = !mine || hx.mark[s] != 0;
@@ -1653,6 +1687,75 @@ __device__ __forceinline__ void copy_node_v(const GraphDev &g, int32_t x, int32_
 	else if (on == 2) { row[k - 2] = o2; row[k - 1] = o3; }
 	else if (on == 1) row[k - 1] = o3;
 	if (br.err) atomicOr(err, br.err);
+}
+
+// The same merges from a row's TABLE of copied blocks (k_copy_list<., ., ., true>): hd = the slot's CopyTab -- header (copied << 16 | kept blocks) and the first three
+// entries; entry j = first index in the referent's row << 16 | length, entries from the fourth on at tabEnd[2 - j] (the end of the record's own part of the interval arena).
+// The table is the parse kernel's own (its blocks passed block_len_ok), but it is read as data: no index leaves the two rows whatever it holds.
+template <bool VEC>
+__device__ __forceinline__ void copy_node_tab(int32_t d, int32_t dref, int32_t *__restrict__ row, const int32_t *__restrict__ src, const int32_t *__restrict__ tabEnd, int4 hd) {
+	const int32_t kept = (int32_t)((uint32_t)hd.w & 0xffffu), copied = (int32_t)((uint32_t)hd.w >> 16);
+	if (copied == 0 || copied > d) return; // the extras are the row
+	auto entry = [&](int32_t b) -> uint32_t { return (uint32_t)(b == 0 ? hd.z : b == 1 ? hd.y : b == 2 ? hd.x : tabEnd[2 - b]); };
+	if (!VEC) {
+		int32_t k = 0, j = copied;
+		int32_t ev = j < d ? row[j] : 0;
+		for (int32_t b = 0; b < kept; b++) {
+			const uint32_t en = entry(b);
+			int32_t i = (int32_t)(en >> 16);
+			const int32_t end = min(i + (int32_t)(en & 0xffffu), dref);
+			for (; i < end && k < d; i++) {
+				const int32_t cv = src[i];
+				while (j < d && ev < cv) { row[k++] = ev; j++; if (j < d) ev = row[j]; }
+				if (j < d && ev == cv) { j++; if (j < d) ev = row[j]; } // equal heads emitted once (never in a valid file)
+				row[k++] = cv;
+			}
+		}
+		// remaining extras row[j..d) are already in place when k == j; a malformed duplicate leaves a gap: pad with -1
+		if (k != j) { while (j < d) row[k++] = row[j++]; while (k < d) row[k++] = -1; }
+		return;
+	}
+	// 16 bytes at a time (copy_node_v)
+	int32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0, en = 0, ej = copied;
+	auto ext_fill = [&] {
+		if (ej + 4 <= d) { const i32x4_u q = *(const i32x4_u *)(row + ej); e0 = q.x; e1 = q.y; e2 = q.z; e3 = q.w; en = 4; ej += 4; }
+		else if (ej < d) { e0 = row[ej++]; en = 1; }
+	};
+	auto ext_pop = [&] { e0 = e1; e1 = e2; e2 = e3; if (--en == 0) ext_fill(); };
+	ext_fill();
+	int32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, sn = 0;
+	int32_t k = 0, o0 = 0, o1 = 0, o2 = 0, o3 = 0, on = 0;
+	const int32_t head = min(d, (int32_t)(((16u - ((uint32_t)(uintptr_t)row & 15u)) & 15u) >> 2));
+	auto emit = [&](int32_t val) {
+		if (k < head) { row[k++] = val; return; }
+		o0 = o1; o1 = o2; o2 = o3; o3 = val; k++;
+		if (++on == 4) { *(int4 *)(row + k - 4) = int4{ o0, o1, o2, o3 }; on = 0; }
+	};
+	for (int32_t b = 0; b < kept; b++) {
+		const uint32_t ent = entry(b);
+		int32_t i = (int32_t)(ent >> 16);
+		const int32_t end = min(i + (int32_t)(ent & 0xffffu), dref);
+		sn = 0;
+		while (i < end && k < d) {
+			if (sn == 0) {
+				if (i + 4 <= end) { const i32x4_u q = *(const i32x4_u *)(src + i); s0 = q.x; s1 = q.y; s2 = q.z; s3 = q.w; sn = 4; }
+				else { s0 = src[i]; sn = 1; }
+			}
+			const int32_t cv = s0;
+			s0 = s1; s1 = s2; s2 = s3; sn--; i++;
+			while (en && e0 < cv && k < d) { emit(e0); ext_pop(); }
+			if (en && e0 == cv) ext_pop(); // equal heads emitted once (never in a valid file)
+			emit(cv);
+		}
+	}
+	const int32_t left = en + (d - ej);
+	if (k + left != d) { // a malformed duplicate left a gap: move the rest down, pad with -1 (as copy_node)
+		while (en && k < d) { emit(e0); ext_pop(); }
+		while (k < d) emit(-1);
+	}
+	if (on == 3) { row[k - 3] = o1; row[k - 2] = o2; row[k - 1] = o3; }
+	else if (on == 2) { row[k - 2] = o2; row[k - 1] = o3; }
+	else if (on == 1) row[k - 1] = o3;
 }
 
 template <int DEF>
@@ -2229,7 +2332,8 @@ void launch_copy_prewalk(const GraphDev &g, int def, const RangeView &v, const i
 }
 void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int32_t *depth, const int32_t *list, const int32_t *keyBase, int32_t level, int blocks,
                        int32_t midMinKnob, bool bigGroups, const int32_t *bigQ, int32_t bigCap, const int32_t *midQ, int32_t midCap, int32_t *ctl, int32_t *tmp, uint32_t tmpCap, int *err,
-                       hipStream_t st, hipStream_t stMid, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evMid, hipEvent_t evBig, const void *preDesc, bool preMid, bool vecList) {
+                       hipStream_t st, hipStream_t stMid, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evMid, hipEvent_t evBig, const void *preDesc, bool preMid, bool vecList,
+                       const void *tabArena, int64_t tabArenaCap, const void *copyTab) {
 	if (v.cnt <= 0) return;
 #ifdef BV_EXP_NOCOPY // (ablation builds: the scan without its copy pass, or without one of its three row classes)
 	return;
@@ -2270,10 +2374,11 @@ void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int
 		else hipLaunchKernelGGL(k_copy_mid<0>, dim3(1024), dim3(64 * COPY_MID_WAVES), 0, stMid, g, v, depth, midQ, ctl + 6, midCap, level, err, pre && preMid && midQ == bigQ + bigCap ? pre + bigCap : nullptr);
 	}
 	if (stMid != st) (void)hipEventRecord(evMid, stMid);
-#define COPY_LIST(D, V) hipLaunchKernelGGL((k_copy_list<D, V>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err)
-	if (v.hx && def == 1) hipLaunchKernelGGL((k_copy_list<1, false, true>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err); // (the hash fold: ids added as they are merged)
-	else if (v.hx && def == 2) hipLaunchKernelGGL((k_copy_list<2, false, true>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
-	else if (v.hx) hipLaunchKernelGGL((k_copy_list<0, false, true>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err);
+#define COPY_LIST(D, V) do { if (copyTab && D != 0) hipLaunchKernelGGL((k_copy_list<D, V, false, (D != 0)>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err, (const IvEntry *)tabArena, tabArenaCap, (const CopyTab *)copyTab); \
+	else hipLaunchKernelGGL((k_copy_list<D, V>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err, (const IvEntry *)nullptr, (int64_t)0, (const CopyTab *)nullptr); } while (0)
+	if (v.hx && def == 1) hipLaunchKernelGGL((k_copy_list<1, false, true>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err, (const IvEntry *)nullptr, (int64_t)0, (const CopyTab *)nullptr); // (the hash fold: ids added as they are merged)
+	else if (v.hx && def == 2) hipLaunchKernelGGL((k_copy_list<2, false, true>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err, (const IvEntry *)nullptr, (int64_t)0, (const CopyTab *)nullptr);
+	else if (v.hx) hipLaunchKernelGGL((k_copy_list<0, false, true>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err, (const IvEntry *)nullptr, (int64_t)0, (const CopyTab *)nullptr);
 	else
 #ifdef BV_EXP_NOCOPY_LIST
 	if (true) {}
@@ -2292,11 +2397,12 @@ int32_t tile_count(int64_t bitSpan, int32_t cnt) { return (int32_t)std::min<int6
 void launch_tile_bounds(const GraphDev &g, int32_t lo, int32_t cnt, int32_t ntiles, int32_t *tb, hipStream_t st) {
 	hipLaunchKernelGGL(k_tile_bounds, dim3(nblk((int64_t)ntiles + 1, 256)), dim3(256), 0, st, g.offsets, lo, cnt, ntiles, tb);
 }
-void launch_parse_tile(const GraphDev &g, int def, const RangeView &v, const int32_t *tb, int32_t ntiles, int variant, int *err, hipStream_t st) {
+void launch_parse_tile(const GraphDev &g, int def, const RangeView &v, const int32_t *tb, int32_t ntiles, int variant, int *err, hipStream_t st, void *tabArena, int64_t tabArenaCap, void *copyTab) {
 	if (v.cnt <= 0 || ntiles <= 0) return;
 	(void)variant; // one lane per record (bv_tile.hpp)
-	if (def == 1) hipLaunchKernelGGL(k_parse_tile<1>, dim3(ntiles), dim3(TILE_T), 0, st, g, v, tb, err);
-	else hipLaunchKernelGGL(k_parse_tile<2>, dim3(ntiles), dim3(TILE_T), 0, st, g, v, tb, err);
+	IvEntry *a = g.minInt > 0 ? (IvEntry *)tabArena : nullptr;
+	if (def == 1) hipLaunchKernelGGL(k_parse_tile<1>, dim3(ntiles), dim3(TILE_T), 0, st, g, v, tb, err, a, tabArenaCap, (CopyTab *)copyTab);
+	else hipLaunchKernelGGL(k_parse_tile<2>, dim3(ntiles), dim3(TILE_T), 0, st, g, v, tb, err, a, tabArenaCap, (CopyTab *)copyTab);
 }
 
 void launch_parse_listed(const GraphDev &g, int def, const RangeView &v, const int32_t *list, int32_t *ctl, int which, void *arena, int64_t arenaCap, int waves, int *err, hipStream_t st) {
@@ -2306,15 +2412,23 @@ void launch_parse_listed(const GraphDev &g, int def, const RangeView &v, const i
 	else hipLaunchKernelGGL((k_parse_big<0, 1, RangeView>), dim3(waves), dim3(64), 0, st, g, v, list, ctl, which, (IvEntry *)arena, arenaCap, err);
 }
 
-void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, void *arena, int64_t arenaCap, int32_t keyLo, int32_t keyHi) {
+void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, void *arena, int64_t arenaCap, int32_t keyLo, int32_t keyHi, bool lwc, void *copyTab) {
+	CopyTab *ct = (CopyTab *)copyTab;
 	if (v.cnt <= 0) return;
 	blocks = (int)std::min<int64_t>(blocks, nblk(v.cnt, TPB)); // (a thread per record at most)
 	IvEntry *a = (IvEntry *)arena;
-	if (def == 1 && v.hx) hipLaunchKernelGGL((k_parse_list<1, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, keyLo, keyHi, a, arenaCap, err);
-	else if (def == 2 && v.hx) hipLaunchKernelGGL((k_parse_list<2, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, keyLo, keyHi, a, arenaCap, err);
-	else if (def == 1) hipLaunchKernelGGL(k_parse_list<1>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, keyLo, keyHi, a, arenaCap, err);
-	else if (def == 2) hipLaunchKernelGGL(k_parse_list<2>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, keyLo, keyHi, a, arenaCap, err);
-	else hipLaunchKernelGGL(k_parse_list<0>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, keyLo, keyHi, a, arenaCap, err);
+	if (!lwc && def != 0) { // round 4's loop (knob lane_loop = 0): no tables for the copy pass
+		if (def == 1 && v.hx) hipLaunchKernelGGL((k_parse_list<1, true, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, keyLo, keyHi, a, arenaCap, err, (CopyTab *)nullptr);
+		else if (def == 2 && v.hx) hipLaunchKernelGGL((k_parse_list<2, true, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, keyLo, keyHi, a, arenaCap, err, (CopyTab *)nullptr);
+		else if (def == 1) hipLaunchKernelGGL((k_parse_list<1, false, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, keyLo, keyHi, a, arenaCap, err, (CopyTab *)nullptr);
+		else hipLaunchKernelGGL((k_parse_list<2, false, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, keyLo, keyHi, a, arenaCap, err, (CopyTab *)nullptr);
+		return;
+	}
+	if (def == 1 && v.hx) hipLaunchKernelGGL((k_parse_list<1, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, keyLo, keyHi, a, arenaCap, err, ct);
+	else if (def == 2 && v.hx) hipLaunchKernelGGL((k_parse_list<2, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, keyLo, keyHi, a, arenaCap, err, ct);
+	else if (def == 1) hipLaunchKernelGGL(k_parse_list<1>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, keyLo, keyHi, a, arenaCap, err, ct);
+	else if (def == 2) hipLaunchKernelGGL(k_parse_list<2>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, keyLo, keyHi, a, arenaCap, err, ct);
+	else hipLaunchKernelGGL(k_parse_list<0>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, keyLo, keyHi, a, arenaCap, err, ct);
 }
 
 } // namespace bv

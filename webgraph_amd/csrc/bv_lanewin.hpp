@@ -289,4 +289,211 @@ __device__ __forceinline__ void parse_node_lwb(const GraphDev &g, int32_t x, int
 	if (e) atomicOr(err, e);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// Round 6: the same record by a loop with less in it (parse_node_lwc).  What changed against parse_node_lwb, and why:
+//  * the outdegree and the reference are not decoded again: k_headers did, and a gamma code of d takes 2 floor(log2(d + 1)) + 1 bits, a unary
+//    reference r + 1 -- the window is opened behind them;
+//  * the sums of the block section are 32-bit (block_len_ok keeps 0 <= total <= dref <= 2^31 - 1), the interval arcs are checked as they
+//    accumulate (no sum can pass `extra`);
+//  * the merge state carries SENTINELS instead of flags: an exhausted residual section is resVal = 0xffffffff, the entry behind the last interval
+//    is (0xffffffff, 1) -- in the ring and, for lists that do not fit it, in the arena --, so a trip is val = min(ivLeft, resVal) (unsigned: ids
+//    are Java ints >= 0 in every valid file), `both equal` advances both (MergedIntIterator.java:69-72), and a row that runs out of values pads
+//    itself with -1 (BVG:1210) with no case of its own.  ~17 vector and one scalar instruction of merge logic per id instead of ~20 + 12;
+//  * the trip counter is the WAVE's: lane l's k-th id is decoded in trip k by every lane, finished lanes idle on their sentinels (no exec masks
+//    inside the trip), four trips per pass; the four ids leave in ONE 16-byte store at out + k, whatever its alignment (gfx950 takes
+//    dwordx4 stores on 4-byte boundaries; scripts/ubench_store.hip: +15 % on the store itself) -- no unaligned head, no per-lane phase of the
+//    store, no register shuffle; the refill vote is once per pass;
+//  * the copy blocks leave as a TABLE for the copy pass's lane class: 16 bytes per slot in a scratch array of its own (CopyTab: header =
+//    copied << 16 | kept blocks -- CT_NONE in the low half: no table, walk the stream -- and the first three kept blocks, each first index in the referent's
+//    row << 16 | length); kept blocks from the fourth on go to the END of the part of the interval arena that is the record's alone (16 floor(d / minInt)
+//    bytes from floor(rowstart / minInt): its front holds the record's own intervals while it is parsed), entry j at ovfEnd[2 - j].
+//    k_copy_list then touches neither the stream nor the offsets and runs no bit reader.
+constexpr uint32_t CT_NONE = 0xffffu;
+constexpr int32_t LW_TAB_D = 1024; // rows with fewer successors get a table (the lane class of the copy pass ends at copy_mid_min <= COPY_BIG_MIN = 1024)
+typedef int32_t i32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+// the record's slice of the interval arena: entries [abase, abase + n) of 16 bytes, abase = floor(rowstart / minInt), n = d / minInt + 1 (minInt > 0).  The LAST entry is
+// shared with the next record (floor(a / k) + floor(b / k) <= floor((a + b) / k): only the first n - 1 are the record's alone).
+__device__ __forceinline__ void arena_slice(int32_t minInt, int64_t rowstart, int32_t d, int64_t &abase, int32_t &n) {
+	if ((minInt & (minInt - 1)) == 0) { const int sh = 31 - __clz(minInt); abase = rowstart >> sh; n = (d >> sh) + 1; } // (uniform: the usual 4 costs two shifts, not a 64-bit division)
+	else { abase = rowstart / minInt; n = d / minInt + 1; }
+}
+struct CopyTab { int32_t t2, t1, t0, hdr; }; // one per slot (16 bytes, read and written as an int4)
+
+// zeta_3 from a 32-bit window, branch-free: what the code ADDS to the running id (gap + 1 = value + 1) and its length; false: longer than 28 bits
+__device__ __forceinline__ bool lane_zeta3_add(uint32_t W, uint32_t &add, uint32_t &len) {
+	const uint32_t h = (uint32_t)__clz((int)(W | (1u << 25))); // h <= 6
+	const uint32_t h3 = 3u * h;
+	const uint32_t mm = (W << (h + 1u)) >> (29u - h3); // 3 h + 3 bits: the short codeword's 3 h + 2 and the extra bit of the long one
+	const uint32_t m = mm >> 1, left = 1u << h3;
+	const bool lng = m >= left;
+	add = lng ? mm : m + left; // value + 1
+	len = 4u * h + 3u + (lng ? 1u : 0u);
+	return W >= (1u << 25);
+}
+// As code_w, 32 bits wide: values past 2^32 - 1 (a malformed stream) saturate, which every caller rejects.
+template <int KIND, int ZK = 3> __device__ __forceinline__ uint32_t code_w32(LaneWin<LW_MAIN> &br, const GraphDev &g, bool want, int &err) {
+	br.template wave_refill<3>(g);
+	const uint32_t j = br.q >> 5, sh = br.q & 31u;
+	const uint64_t ab = ((uint64_t)br.col[j * LW_STRIDE] << 32) | br.col[(j + 1) * LW_STRIDE];
+	uint32_t v, len;
+	const bool ok = lane_fast_code<KIND, ZK>((uint32_t)((ab << sh) >> 32), v, len, (uint32_t)g.zetaK);
+	if (wave_any(want && !ok)) {
+		if (want && !ok) { const uint64_t t = br.template code<KIND, ZK>(g, err); v = KIND == 0 ? (uint32_t)t : (uint32_t)min<uint64_t>(t, 0xffffffffull); } // (residuals are Java ints: truncated, BVG:954)
+		else if (want) br.q += len;
+	} else br.q += want ? len : 0u;
+	return v;
+}
+
+// off0 / off1: the record's first bit and the next record's; r: its reference (0: none), dref: the referent's outdegree; iv: the record's slice of the interval arena
+// (ivOwn 16-byte entries of it are the record's alone); ctab: the slot's table (null: none).  HASH: as parse_node_lwb.
+template <int ZK, bool HASH = false>
+__device__ __forceinline__ void parse_node_lwc(const GraphDev &g, int32_t x, int32_t d, int32_t r, int32_t dref, int32_t *__restrict__ row, uint32_t *lds, int2 *__restrict__ iv, int32_t ivOwn,
+                                               CopyTab *__restrict__ ctab, int *__restrict__ err, uint64_t off0, uint64_t off1, uint32_t *hacc = nullptr, uint32_t hw = 0, bool hstore = true) {
+	LaneWin<LW_MAIN> br;
+	br.col = lds + threadIdx.x;
+	uint32_t *const ring = lds + LW_MAIN * LW_STRIDE + threadIdx.x; // entry j of the ring: ring[2 j * LW_STRIDE] = left, ring[(2 j + 1) * LW_STRIDE] = length
+	br.vlast = min(((off1 >> 5) + 2) & ~(uint64_t)3, (g.nwords + 4) & ~(uint64_t)3);
+	const bool hasRef = r > 0;
+	br.seek(g, off0 + (2u * (31u - (uint32_t)__clz((int)((uint32_t)d + 1u))) + 1u) + (g.W > 0 ? (uint32_t)r + 1u : 0u)); // behind the outdegree and the reference (BVG:1048-1054; k_headers read them)
+	int e = 0;
+	int32_t copied = 0;
+	const bool tab = hasRef && ctab != nullptr;
+	bool tabOk = tab && d < LW_TAB_D && dref < 65536;
+	uint32_t t0 = 0, t1 = 0, t2 = 0, kept = 0;
+	int32_t *const ovfEnd = (int32_t *)(iv + 2 * (int64_t)ivOwn); // kept blocks from the fourth on: down from the end of the record's own part of the arena
+	auto push = [&](uint32_t en) { // kept block `kept` of the table
+		t0 = kept == 0 ? en : t0; t1 = kept == 1 ? en : t1; t2 = kept == 2 ? en : t2;
+		if (kept >= 3) { if ((int32_t)kept - 2 <= 4 * ivOwn) ovfEnd[2 - (int32_t)kept] = (int32_t)en; else tabOk = false; }
+		kept++;
+	};
+	{ // BVG:1058-1071
+		uint32_t bc = code_w32<1>(br, g, hasRef, e);
+		if (!hasRef) bc = 0;
+		if (bc > (uint32_t)dref + 1u) { e |= E_FORMAT; bc = 0; }
+		int32_t total = 0;
+		for (uint32_t b = 0; wave_any(b < bc && !e); b++) {
+			const bool w = b < bc && !e;
+			const uint32_t c = code_w32<1>(br, g, w, e);
+			const uint32_t room = (uint32_t)(dref - total), len = c + (b ? 1u : 0u);
+			const bool good = c <= room && len <= room; // (block_len_ok)
+			if (w && !good) e |= E_FORMAT;
+			if (w && good) {
+				if (!(b & 1)) { if (tabOk && len) push(((uint32_t)total << 16) | len); copied += (int32_t)len; }
+				total += (int32_t)len;
+			}
+		}
+		if (hasRef && !e && !(bc & 1)) { const int32_t rest = dref - total; if (tabOk && rest) push(((uint32_t)total << 16) | (uint32_t)rest); copied += rest; }
+	}
+	const int32_t extra = d - copied;
+	if (extra < 0) e |= E_FORMAT;
+	auto leave_table = [&](bool ok) { if (tab) *(int4 *)ctab = int4{ (int32_t)t2, (int32_t)t1, (int32_t)t0, ok ? (int32_t)(((uint32_t)copied << 16) | kept) : (int32_t)CT_NONE }; };
+	if (e) { leave_table(false); atomicOr(err, e); return; }
+	if (extra == 0) { leave_table(tabOk); return; }
+
+	int32_t nIv = 0, ivArcs = 0;
+	const uint32_t SENT = 0xffffffffu;
+	if (g.minInt != 0) { // BVG:1073-1096: the interval section, kept as (left, length) in the ring / the arena
+		const uint32_t ni = code_w32<1>(br, g, true, e);
+		if ((uint64_t)ni * (uint32_t)g.minInt > (uint64_t)(uint32_t)extra) { leave_table(false); atomicOr(err, E_FORMAT); return; } // (an interval holds >= minInt ids; the arena slice has d / minInt + 1 entries)
+		nIv = (int32_t)ni;
+		const bool spill = nIv >= LW_RING; // with the sentinel the list does not fit the ring: all of it goes to the arena too
+		int32_t prevEnd = 0;
+		for (int32_t i = 0; wave_any(i < nIv && !e); i++) {
+			const bool w = i < nIv && !e;
+			const uint32_t a = code_w32<1>(br, g, w, e);
+			const uint32_t len = code_w32<1>(br, g, w, e);
+			if (w) {
+				if (len > (uint32_t)(extra - ivArcs) || len + (uint32_t)g.minInt > (uint32_t)(extra - ivArcs)) e |= E_FORMAT; // (the intervals' ids are among the `extra`: no sum passes it)
+				else {
+					const int32_t n = (int32_t)len + g.minInt;
+					ivArcs += n;
+					const int32_t left = i == 0 ? (int32_t)((int64_t)x + nat2int(a)) : prevEnd + (int32_t)a + 1; // BVG:1084-1093, in Java ints
+					prevEnd = left + n;
+					if (i < LW_RING) { ring[(2 * i) * LW_STRIDE] = (uint32_t)left; ring[(2 * i + 1) * LW_STRIDE] = (uint32_t)n; }
+					if (spill) iv[i] = int2{ left, n };
+				}
+			}
+		}
+		if (nIv < LW_RING) { ring[(2 * nIv) * LW_STRIDE] = SENT; ring[(2 * nIv + 1) * LW_STRIDE] = 1u; }
+		else iv[nIv] = int2{ -1, 1 };
+		if (spill && tabOk && kept > 3 && 8 * ((int64_t)nIv + 2) + 4 * ((int64_t)kept - 3) > 16 * (int64_t)ivOwn) tabOk = false; // (the list reached into the table's end of the record's part)
+	} else { ring[0] = SENT; ring[LW_STRIDE] = 1u; }
+	leave_table(tabOk && !e);
+	if (e) { atomicOr(err, E_FORMAT | e); return; }
+	const int32_t nRes = extra - ivArcs; // >= 0
+
+	// merge(intervals, residuals) -> row[copied ..).  Ids are Java ints (BVG:954, :966, :1084-1093).
+	int32_t *const out = row + copied;
+	uint32_t ivLeft = ring[0], ivRem = ring[LW_STRIDE]; // the first interval (or the sentinel)
+	int32_t ivIdx = min(1, nIv);                          // the next entry to take: never past the sentinel's
+	int32_t ivLoaded = LW_RING;                           // (lists in the arena) entries [ivLoaded - LW_RING, ivLoaded) are in the ring; even
+	const bool spillLane = nIv >= LW_RING;
+	const bool anySpill = wave_any(spillLane);
+	uint32_t resVal = SENT;
+	int32_t resLeft = 0; // codes of the residual section not read yet
+	{
+		const uint32_t first = code_w32<0, ZK>(br, g, nRes != 0, e);
+		if (nRes != 0) { resVal = (uint32_t)((int64_t)x + nat2int(first)); resLeft = nRes - 1; } // BVG:954
+	}
+	auto trip = [&](int32_t k) -> int32_t {
+		// the ring's next entry and the stream's next gap, read by every lane whether it will use them or not
+		const int jr = ivIdx & (LW_RING - 1);
+		const uint32_t rl = ring[(2 * jr) * LW_STRIDE], rn = ring[(2 * jr + 1) * LW_STRIDE];
+		const uint32_t jw = br.q >> 5, sh = br.q & 31u;
+		const uint64_t ab = ((uint64_t)br.col[jw * LW_STRIDE] << 32) | br.col[(jw + 1) * LW_STRIDE];
+		const uint32_t W = (uint32_t)((ab << sh) >> 32);
+		uint32_t add, len;
+		bool ok;
+		if (ZK == 3) ok = lane_zeta3_add(W, add, len);
+		else { ok = lane_fast_code<0, ZK>(W, add, len, (uint32_t)g.zetaK); add += 1u; }
+		const uint32_t val = min(ivLeft, resVal);
+		const bool aI = ivLeft == val, aR = resVal == val; // equal heads are emitted once (MergedIntIterator.java:69-72)
+		ivLeft += aI ? 1u : 0u; ivRem -= aI ? 1u : 0u;
+		const bool need = ivRem == 0;
+		ivLeft = need ? rl : ivLeft; ivRem = need ? rn : ivRem;
+		ivIdx = min(ivIdx + (need ? 1 : 0), nIv);
+		const bool more = resLeft != 0, adv = aR && more;
+		uint32_t nv = resVal + add; // BVG:966
+		if (wave_any(adv && !ok)) {
+			if (adv && !ok) nv = resVal + (uint32_t)br.template code<0, ZK>(g, e) + 1u;
+			else if (adv) br.q += len;
+		} else br.q += adv ? len : 0u;
+		resVal = aR ? (more ? nv : SENT) : resVal;
+		resLeft -= adv ? 1 : 0;
+		if (HASH) { *hacc += k < extra ? val * hw : 0u; hw *= 31u; }
+		return (int32_t)val;
+	};
+	for (int32_t k0 = 0; wave_any(k0 < extra); k0 += 4) {
+		// four codes of <= 32 bits behind the cursor, four entries of the ring: or ALL lanes move their windows / top their rings up
+		const bool low = spillLane && ivLoaded <= nIv && ivLoaded - ivIdx < 4;
+		if (wave_any(low | ((br.q >> 5) + 5 >= (uint32_t)LW_MAIN))) {
+			br.template wave_refill<5>(g);
+			if (anySpill && wave_any(low)) {
+				// entries [ivLoaded, upto) replace consumed ones (index - LW_RING < ivIdx), two per 16-byte load (ivLoaded is even; one entry past the sentinel may be read: the slice has the room)
+				const int32_t upto = spillLane ? min((ivIdx + LW_RING) & ~1, (nIv + 2) & ~1) : 0;
+#pragma unroll
+				for (int p = 0; p < LW_RING / 2; p++) {
+					const int32_t i0 = ivLoaded + 2 * p;
+					if (i0 < upto) {
+						const int4 t = *(const int4 *)(iv + i0);
+						const int j0 = i0 & (LW_RING - 1);
+						ring[(2 * j0) * LW_STRIDE] = (uint32_t)t.x; ring[(2 * j0 + 1) * LW_STRIDE] = (uint32_t)t.y;
+						ring[(2 * j0 + 2) * LW_STRIDE] = (uint32_t)t.z; ring[(2 * j0 + 3) * LW_STRIDE] = (uint32_t)t.w;
+					}
+				}
+				ivLoaded = max(ivLoaded, upto);
+			}
+		}
+		const int32_t v0 = trip(k0), v1 = trip(k0 + 1), v2 = trip(k0 + 2), v3 = trip(k0 + 3);
+		if (!HASH || hstore) {
+			const int32_t left = extra - k0;
+			if (left >= 4) *(i32x4_a4 *)(out + k0) = i32x4_a4{ v0, v1, v2, v3 };
+			else if (left > 0) { out[k0] = v0; if (left > 1) out[k0 + 1] = v1; if (left > 2) out[k0 + 2] = v2; }
+		}
+	}
+	if (e) atomicOr(err, e);
+}
+
 } // namespace bv

@@ -105,9 +105,10 @@ void launch_build_lists(const GraphDev &g, const RangeView &v, uint64_t giantBit
                         int32_t *bigQ = nullptr, int32_t bigCap = 0, int32_t *midQ = nullptr, int32_t midCap = 0, int32_t midMinKnob = 0, bool bigGroups = false);
 void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int32_t *depth, const int32_t *list, const int32_t *keyBase, int32_t level, int blocks,
                        int32_t midMinKnob, bool bigGroups, const int32_t *bigQ, int32_t bigCap, const int32_t *midQ, int32_t midCap, int32_t *ctl, int32_t *tmp, uint32_t tmpCap, int *err,
-                       hipStream_t st, hipStream_t stMid, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evMid, hipEvent_t evBig, const void *preDesc = nullptr, bool preMid = false, bool vecList = false); // vecList: the lane class merges with 16-byte loads and stores (copy_node_v) // preDesc: launch_copy_prewalk's descriptors
+                       hipStream_t st, hipStream_t stMid, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evMid, hipEvent_t evBig, const void *preDesc = nullptr, bool preMid = false, bool vecList = false,
+                       const void *tabArena = nullptr, int64_t tabArenaCap = 0, const void *copyTab = nullptr); // copyTab: 16 bytes per slot, the copy blocks of the rows that the one-lane parse decoded (parse_node_lwc / parse_node_tile; bv_lanewin.hpp), blocks from the fourth on in tabArena = the interval arena; null: the lane class walks the stream // vecList: the lane class merges with 16-byte loads and stores (copy_node_v) // preDesc: launch_copy_prewalk's descriptors
 void launch_copy_prewalk(const GraphDev &g, int def, const RangeView &v, const int32_t *bigQ, int32_t bigCap, const int32_t *ctl, void *desc, int blocks, hipStream_t st, int32_t midCap, hipStream_t stLong, bool longKernel, hipStream_t stWalk); // stWalk: the stream of k_copy_prewalk (as stLong) // stLong: the stream of the long lists' kernel (ordered behind the queues by the caller; may be st); // midCap > 0: also the wave class's rows (queue at bigQ + bigCap, descriptors at desc + bigCap)
-void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, void *arena, int64_t arenaCap, int32_t keyLo = 0, int32_t keyHi = NKEYS); // the list's keys [keyLo, keyHi); v.hx (default codings only): hash fold
+void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, void *arena, int64_t arenaCap, int32_t keyLo = 0, int32_t keyHi = NKEYS, bool lwc = true, void *copyTab = nullptr); // lwc: round 6's loop (parse_node_lwc), which leaves the tables in copyTab; false: round 4's // the list's keys [keyLo, keyHi); v.hx (default codings only): hash fold
 // what the decoding kernels did not add to v.hx->acc, from memory: what bit 2 = the node numbers, bit 0 = every row without a reference that the one-lane parse did not
 // hash (a pass over all nodes: only when the rows are not in a list), bit 1 = the same for the rows with a reference and the lane class of the copy pass; qA / qB: work
 // lists whose rows are hashed (those with a reference if wantRef, those without otherwise); inParse / inCopy: the one-lane parse / the lane class of the copy pass
@@ -131,7 +132,7 @@ void launch_parse_giants(const GraphDev &g, int def, const RangeView &v, const i
 // bv_tile.hpp: short records decoded tile by tile from one LDS image of a contiguous slice of the stream
 int32_t tile_count(int64_t bitSpan, int32_t cnt);
 void launch_tile_bounds(const GraphDev &g, int32_t lo, int32_t cnt, int32_t ntiles, int32_t *tb, hipStream_t st);
-void launch_parse_tile(const GraphDev &g, int def, const RangeView &v, const int32_t *tb, int32_t ntiles, int variant, int *err, hipStream_t st);
+void launch_parse_tile(const GraphDev &g, int def, const RangeView &v, const int32_t *tb, int32_t ntiles, int variant, int *err, hipStream_t st, void *tabArena = nullptr, int64_t tabArenaCap = 0, void *copyTab = nullptr); // copyTab / tabArena: the copy blocks' tables (launch_copy_level), null: none
 int64_t hash_chunks(int32_t cnt, int64_t arcs);
 void launch_hash(int32_t from, int32_t cnt, int64_t arcs, const int64_t *rowptr, const int32_t *succ, uint32_t *A, uint32_t *B, int32_t *bounds, int32_t *hash, hipStream_t st);
 

@@ -113,8 +113,11 @@ struct TFast {
 };
 
 // Same contract as parse_node_lw, reading the record from the tile's window.
+// ctab: the slot's table (null: none) -- a record with a reference leaves its copy blocks there for the lane class of the copy pass, as parse_node_lwc does
+// (bv_lanewin.hpp: the format); this reader never touches the arena otherwise.
 template <int ZK>
-__device__ __forceinline__ void parse_node_tile(const GraphDev &g, const TWin &tw, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row, int *__restrict__ err) {
+__device__ __forceinline__ void parse_node_tile(const GraphDev &g, const TWin &tw, int32_t x, int32_t d, bool hasRef, int64_t dref, int32_t *__restrict__ row, int *__restrict__ err,
+                                                CopyTab *__restrict__ ctab = nullptr, int32_t *__restrict__ ovfEnd = nullptr, int32_t ovfCap = 0) { // ovfEnd / ovfCap: the end of the record's own part of the interval arena, in ints
 	const uint64_t p0 = (uint64_t)g.offsets[x];
 	TCur br, bi;
 	br.k0 = (uint32_t)((p0 >> 5) - tw.w0);
@@ -124,6 +127,14 @@ __device__ __forceinline__ void parse_node_tile(const GraphDev &g, const TWin &t
 	(void)br.code<1, ZK>(tw, zk, e);              // outdegree (known from k_headers)
 	if (g.W > 0) (void)br.code<2, ZK>(tw, zk, e); // reference
 	int64_t copied = 0;
+	const bool tab = hasRef && ctab != nullptr;
+	bool tabOk = tab && d < LW_TAB_D && dref < 65536;
+	uint32_t t0 = 0, t1 = 0, t2 = 0, kept = 0;
+	auto push = [&](uint32_t en) {
+		if (kept == 0) t0 = en; else if (kept == 1) t1 = en; else if (kept == 2) t2 = en;
+		else if ((int32_t)kept - 2 <= ovfCap) ovfEnd[2 - (int32_t)kept] = (int32_t)en; else tabOk = false;
+		kept++;
+	};
 	if (hasRef) { // BVG:1058-1071
 		const uint64_t bc = br.code<1, ZK>(tw, zk, e);
 		int64_t total = 0;
@@ -132,14 +143,16 @@ __device__ __forceinline__ void parse_node_tile(const GraphDev &g, const TWin &t
 			for (uint64_t b = 0; b < bc; b++) {
 				int64_t len;
 				if (!block_len_ok(br.code<1, ZK>(tw, zk, e), b == 0, total, dref, len)) { e |= E_FORMAT; break; }
+				if (!(b & 1)) { if (tabOk && len) push(((uint32_t)total << 16) | (uint32_t)len); copied += len; }
 				total += len;
-				if (!(b & 1)) copied += len;
 			}
-			if (!(bc & 1)) copied += dref - total;
+			if (!(bc & 1) && !e) { if (tabOk && dref > total) push(((uint32_t)total << 16) | (uint32_t)(dref - total)); copied += dref - total; }
 		}
 	}
 	const int64_t extra = (int64_t)d - copied;
 	if (extra < 0 || copied < 0) e |= E_FORMAT;
+	// (the table's header is written on every path: the copy pass must never read a previous job's)
+	if (tab) *(int4 *)ctab = int4{ (int32_t)t2, (int32_t)t1, (int32_t)t0, tabOk && !e ? (int32_t)(((uint32_t)copied << 16) | kept) : (int32_t)CT_NONE };
 	if (e) { atomicOr(err, e); return; }
 	if (extra == 0) return;
 
@@ -211,7 +224,7 @@ __global__ void __launch_bounds__(256) k_tile_bounds(const int64_t *__restrict__
 }
 
 template <int DEF>
-__global__ void __launch_bounds__(TILE_T) k_parse_tile(GraphDev g, RangeView v, const int32_t *__restrict__ tb, int *__restrict__ err) {
+__global__ void __launch_bounds__(TILE_T) k_parse_tile(GraphDev g, RangeView v, const int32_t *__restrict__ tb, int *__restrict__ err, IvEntry *__restrict__ arena, int64_t arenaCap, CopyTab *__restrict__ ctab) { // ctab (null: none), arena: the copy blocks' tables for the copy pass
 	__shared__ __attribute__((aligned(16))) uint32_t s_win[TILE_WIN_WORDS];
 	__shared__ uint16_t s_list[TILE_NODES];
 	__shared__ int32_t s_hist[TILE_NBIN], s_n;
@@ -281,7 +294,14 @@ __global__ void __launch_bounds__(TILE_T) k_parse_tile(GraphDev g, RangeView v, 
 		const int32_t s = a + (int32_t)s_list[idx];
 		const int32_t d = v.outd[s], r = v.ref[s];
 		if (!v.fits(s)) { atomicOr(err, s >= v.nh ? E_CAP : E_HALO); continue; }
-		parse_node_tile<DEF == 1 ? 3 : 0>(g, tw, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), err);
+		int32_t *ovfEnd = nullptr;
+		int32_t ovfCap = 0;
+		if (ctab && arena && r > 0 && d >= 4) { // (only a row of four copied blocks or more needs the room)
+			int64_t abase; int32_t an;
+			arena_slice(g.minInt, v.rowstart[s], d, abase, an);
+			if (abase >= 0 && abase + an <= arenaCap) { ovfEnd = (int32_t *)(arena + abase + (an - 1)); ovfCap = 4 * (an - 1); }
+		}
+		parse_node_tile<DEF == 1 ? 3 : 0>(g, tw, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), err, ctab ? ctab + s : nullptr, ovfEnd, ovfCap);
 	}
 }
 

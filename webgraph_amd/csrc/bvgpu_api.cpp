@@ -117,6 +117,9 @@ struct Pending { // an enqueued range decode whose status has not been collected
 	int32_t giantCap = 0, bigCap = 0, midCap = 0, walkMin = 0x7fffffff;
 	uint32_t tmpCap = 0;
 	const void *preDesc = nullptr; // k_copy_prewalk's descriptors (null: not run)
+	const void *copyTab = nullptr; // 16 bytes per slot: the copy blocks of the rows that the one-lane parse decoded, as tables (null: the copy pass walks the stream)
+	const void *tabArena = nullptr; // the interval arena (their blocks from the fourth on)
+	int64_t tabArenaCap = 0;
 	// a sub-range decoded before its halo was sized (optimistic): what to repeat if the guess was wrong
 	bool optimistic = false;
 	int32_t from = 0, to = 0;
@@ -164,7 +167,10 @@ struct bvg_graph {
 	int coop_waves = 4096, giant_groups = 256;
 	DevBuf copyq; // rows the copy pass merges with a group / a wave each (all levels), filled while the level lists are built
 	DevBuf walkdesc; // k_copy_prewalk: 16 bytes per entry of the group class's queue
+	DevBuf copytab;  // 16 bytes per slot: the copy blocks of the rows that the one-lane parse decoded, for the lane class of the copy pass (CopyTab, bv_lanewin.hpp)
 	int copy_vec = -1; // BVGPU_COPY_VEC=1|0: the lane class of the copy pass merges with 16-byte loads and stores (copy_node_v) or id by id; -1: by the mean length of its rows (counted at load time)
+	int lane_loop = 1;   // BVGPU_LANE_LOOP=0: round 4's one-lane loop (parse_node_lwb) instead of round 6's (parse_node_lwc)
+	int copy_tables = 1; // BVGPU_COPY_TABLES=0: the lane class of the copy pass walks the block lists in the stream although the parse left them as tables
 	int prewalk_long = 1; // BVGPU_PREWALK_LONG=0: no kernel of their own for the lists of >= 2048 codes; 2: on the lists' stream instead of side B
 	int prewalk_blocks = 1024;
 	int prewalk = 1; // BVGPU_PREWALK=0: k_copy_big walks its rows' block lists itself
@@ -264,6 +270,8 @@ int apply_option(bvg_graph *g, const std::string &name, const char *value) {
 	else if (name == "level_lists_early") g->level_lists_early = iv;
 	else if (name == "walk_tables") g->walk_tables = iv;
 	else if (name == "copy_vec") g->copy_vec = iv;
+	else if (name == "lane_loop") g->lane_loop = iv;
+	else if (name == "copy_tables") g->copy_tables = iv;
 	else if (name == "prewalk") g->prewalk = iv;
 	else if (name == "prewalk_long") g->prewalk_long = iv;
 	else if (name == "prewalk_blocks") g->prewalk_blocks = std::max(1, iv);
@@ -285,7 +293,7 @@ int apply_option(bvg_graph *g, const std::string &name, const char *value) {
 	return BVG_OK;
 }
 const char *const OPTION_NAMES[] = { "coop_min", "giant_min", "coop_waves", "giant_groups", "level_blocks", "copy_big", "parse_windows", "tile", "seg", "seg_hub_min", "seg_blocks", "lists_on_b", "skip_empty_giants", "level_lists_early",
-	"walk_tables", "copy_vec", "prewalk", "prewalk_long", "prewalk_blocks", "copy_mid_min", "overlap", "halo_min", "batch_dense", "scan_top_tiled_min", "wait_giants", "hash_materialise",
+	"walk_tables", "copy_vec", "lane_loop", "copy_tables", "prewalk", "prewalk_long", "prewalk_blocks", "copy_mid_min", "overlap", "halo_min", "batch_dense", "scan_top_tiled_min", "wait_giants", "hash_materialise",
 	"ef_hash_materialise", "scan_piece", "dbg", "stats", "trace_retry", "trace_err", "trace_host" };
 void options_from_env(bvg_graph *g) {
 	for (const char *n : OPTION_NAMES) {
@@ -467,7 +475,8 @@ int finish_pending(bvg_graph *g, uint64_t *arcs_out) {
 					const bool ov2 = g->overlap && !g->profile;
 					bv::launch_copy_level(gd, s.def, g->pend.view, g->depth.as<int32_t>(), g->lvlist.as<int32_t>(), keyBase, l, g->level_blocks, g->copy_mid_min, g->copy_big != 0,
 					                      g->copyq.as<int32_t>(), g->pend.bigCap, g->copyq.as<int32_t>() + g->pend.bigCap, g->pend.midCap, g->coopctl.as<int32_t>(), g->bigtmp.as<int32_t>(), g->pend.tmpCap, derr,
-					                      g->stream, ov2 ? side_b(g) : g->stream, ov2 ? g->sideA : g->stream, g->evFork, g->evB, g->evA, g->pend.preDesc, g->prewalk < 2 && g->pend.midCap > 0, copy_vec(g));
+					                      g->stream, ov2 ? side_b(g) : g->stream, ov2 ? g->sideA : g->stream, g->evFork, g->evB, g->evA, g->pend.preDesc, g->prewalk < 2 && g->pend.midCap > 0, copy_vec(g),
+					                      g->pend.tabArena, g->pend.tabArenaCap, g->pend.copyTab);
 				}
 			}
 			g->pend.levels_done = upto;
@@ -551,6 +560,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			return fail(g, BVG_ENOMEM, "device scratch allocation failed");
 		int32_t *hist = g->keys.as<int32_t>(), *keyBase = hist + (bv::NKEYS + 1), *cursor = keyBase + (bv::NKEYS + 1);
 		int32_t *ctl = g->coopctl.as<int32_t>();
+
 		// (ctl[0..3], the queues of the long records, are zeroed on side B when the classification starts early)
 		const bool early = hdrEvent && coopMin < 0x7fffffff && g->overlap && !g->profile;
 		if (!early) HIPCHK(g, hipMemsetAsync(ctl, 0, 4 * sizeof(int32_t), g->stream));
@@ -596,6 +606,10 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			if ((double)s.deg_counts[0] * share <= (double)COOP_BUDGET * (share > 0.999 ? 1.0 : 0.8)) tileVariant = 1; // (a sub-range: an estimate, with a margin)
 		}
 		const bool tiles = tileVariant != 0 && s.def != 0;
+		// the tables of copy blocks that the one-lane parse leaves for the lane class of the copy pass: 16 bytes per slot (a range of more than 2^28 slots walks the stream as before:
+		// 4 GB of tables and more; so does a job that finds no room for them, and one that decodes its lane class with round 4's loop, which writes none)
+		void *copyTab = nullptr;
+		if (g->copy_tables && s.def != 0 && W > 0 && (tiles || g->lane_loop != 0) && v.cnt <= (1 << 28) && g->copytab.need(16 * (size_t)v.cnt)) copyTab = g->copytab.p;
 		int32_t ntiles = 0;
 		if (tiles) {
 			ntiles = bv::tile_count(s.h_offsets[(size_t)v.lo + v.cnt] - s.h_offsets[(size_t)v.lo], v.cnt);
@@ -728,7 +742,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		mark(g, 4);
 		if (coop && !ovl) bv::launch_parse_waves(gd, s.def, v, g->biglist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, derr, g->stream);
 		mark(g, 5);
-		if (tiles) bv::launch_parse_tile(gd, s.def, v, g->tilebounds.as<int32_t>(), ntiles, tileVariant, derr, g->stream);
+		if (tiles) bv::launch_parse_tile(gd, s.def, v, g->tilebounds.as<int32_t>(), ntiles, tileVariant, derr, g->stream, g->arena.p, arenaCap, copyTab);
 		else {
 			if (segReady) { // on side B, behind the giants: the pieces of the records that handed their residual sections over
 				hipStream_t stChain = g->stream;
@@ -741,7 +755,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 				if (ovl) HIPCHK(g, hipEventRecord(g->evB, stChain));
 			}
 			if (ovl && coop) { HIPCHK(g, hipStreamWaitEvent(g->stream, g->evC, 0)); if (g->wait_giants && !noGiants) bv::launch_wait_giants(ctl, g->giant_groups, g->stream); } // (the giants first: k_wait_giants)
-			bv::launch_parse_list(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, g->level_blocks, derr, g->stream, g->arena.p, arenaCap);
+			bv::launch_parse_list(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, g->level_blocks, derr, g->stream, g->arena.p, arenaCap, 0, bv::NKEYS, g->lane_loop != 0, copyTab);
 		}
 		if (ovl) {
 			HIPCHK(g, hipStreamWaitEvent(g->stream, g->evA, 0));
@@ -750,12 +764,16 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		}
 		mark(g, 6);
 		if (g->hash_job && (!ovl || !g->hash_in_parse)) { const int rc = hash_phase_a(g->stream); if (rc) return rc; }
+		g->pend.copyTab = g->hash_job ? nullptr : copyTab; // (the hash fold rides on the lane class's stream-walking merge)
+		g->pend.tabArena = g->arena.p;
+		g->pend.tabArenaCap = arenaCap;
 		if (W > 0) {
 			levels = g->levels_hint;
 			for (int32_t l = 1; l <= levels; l++) {
 				bv::launch_copy_level(gd, s.def, v, g->depth.as<int32_t>(), g->lvlist.as<int32_t>(), keyBase, l, g->level_blocks, g->copy_mid_min, g->copy_big != 0,
 				                                          g->copyq.as<int32_t>(), bigCap, g->copyq.as<int32_t>() + bigCap, midCap, ctl, g->bigtmp.as<int32_t>(), g->pend.tmpCap, derr,
-				                                          g->stream, ovl ? side_b(g) : g->stream, ovl ? g->sideA : g->stream, g->evFork, g->evB, g->evA, g->pend.preDesc, g->prewalk < 2 && g->pend.midCap > 0, copy_vec(g));
+				                                          g->stream, ovl ? side_b(g) : g->stream, ovl ? g->sideA : g->stream, g->evFork, g->evB, g->evA, g->pend.preDesc, g->prewalk < 2 && g->pend.midCap > 0, copy_vec(g),
+				                                          g->pend.tabArena, g->pend.tabArenaCap, g->pend.copyTab);
 			}
 		}
 		if (g->hash_job) { // the rows that the wave / group classes of the copy pass merged (its queues), then the sum rides home in the job's mailbox
@@ -1298,7 +1316,7 @@ extern "C" int bvg_close(bvg_t *g) {
 	if (g->st && g->st->device >= 0) {
 		(void)hipSetDevice(g->st->device);
 		if (g->own) { (void)hipStreamSynchronize(g->own); (void)hipStreamDestroy(g->own); }
-		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->hashBounds, &g->pickpart, &g->walktab, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist, &g->plist, &g->pkeys, &g->pkey16, &g->copyq, &g->walkdesc, &g->bigtmp, &g->tilebounds, &g->segbuf, &g->hashmark, &g->hashctx, &g->hashtab, &g->hashq }) b->release();
+		for (DevBuf *b : { &g->outd, &g->ref, &g->rowstart, &g->depth, &g->sums, &g->need, &g->halo, &g->hashA, &g->hashB, &g->hashBounds, &g->pickpart, &g->walktab, &g->stage_rowptr, &g->stage_succ, &g->stage_nodes, &g->small, &g->b_chainlen, &g->b_slotbase, &g->b_node, &g->b_qidx, &g->b_aoutd, &g->b_qoutd, &g->biglist, &g->giantlist, &g->arena, &g->coopctl, &g->stats, &g->key16, &g->keys, &g->lvlist, &g->plist, &g->pkeys, &g->pkey16, &g->copyq, &g->walkdesc, &g->copytab, &g->bigtmp, &g->tilebounds, &g->segbuf, &g->hashmark, &g->hashctx, &g->hashtab, &g->hashq }) b->release();
 		for (DevBuf *b : { &g->hchunk[0], &g->hchunk[1], &g->statsbuf, &g->bfs_rowptr, &g->bfs_succ, &g->bfs_ctr }) b->release();
 		for (PinBuf *b : { &g->hring[0], &g->hring[1], &g->view_rowptr, &g->view_succ }) b->release();
 		for (hipEvent_t e : { g->evChunk[0], g->evChunk[1], g->evCopied[0], g->evCopied[1] }) if (e) (void)hipEventDestroy(e);
