@@ -472,6 +472,39 @@ int bvo_references(const bvo_graph *h, int32_t from, int32_t to, int32_t *out) {
 	return BVO_OK;
 }
 
+/* how many successors every record of [from,to) takes from its referent (the copy blocks, BVG:1058-1071), 0 without a reference: bench.py prices the parse
+ * kernels by the ids they write themselves -- the extras -- and the copy pass by the ids it merges. */
+int bvo_copied(const bvo_graph *h, int32_t from, int32_t to, int32_t *out) {
+	if (from < 0 || to > h->p.n || from > to) return BVO_EARG;
+	if (!h->offsets) return BVO_ESTATE;
+	for (int32_t x = from; x < to; x++) {
+		ibs_t s = { h->g, (uint64_t)h->offsets[x], (uint64_t)h->len * 8, 0 };
+		int unsup = 0;
+		const uint64_t d = read_coded(&s, h->p.outdegree_coding, 0, &unsup);
+		int64_t copied = 0;
+		if (d != 0 && h->p.window > 0) {
+			const uint64_t r = read_coded(&s, h->p.reference_coding, 0, &unsup);
+			if (r > (uint64_t)h->p.window) return BVO_ESTATE; /* BVG:705 */
+			if (r > 0) {
+				if ((int64_t)x - (int64_t)r < 0) return BVO_EARG;
+				const int64_t blockCount = (int64_t)read_coded(&s, h->p.block_count_coding, 0, &unsup);
+				int64_t total = 0;
+				for (int64_t i = 0; i < blockCount && !s.err; i++) {
+					const int64_t b = (int64_t)read_coded(&s, h->p.block_coding, 0, &unsup) + (i == 0 ? 0 : 1);
+					total += b;
+					if ((i & 1) == 0) copied += b;
+				}
+				int32_t refd;
+				int rc = outdegree_at(h, x - (int32_t)r, &refd, NULL); if (rc) return rc;
+				if ((blockCount & 1) == 0) copied += refd - total; /* BVG:1069 */
+			}
+		}
+		if (s.err || unsup) return unsup ? BVO_EUNSUP : BVO_EARG;
+		out[x - from] = (int32_t)copied;
+	}
+	return BVO_OK;
+}
+
 /* batch of random-access successor lists: concatenation of successorArray(nodes[i]) */
 int bvo_successors_batch(const bvo_graph *h, const int32_t *nodes, size_t q, int64_t *rowptr, int32_t *succ, size_t cap) {
 	uint64_t arcs = 0;

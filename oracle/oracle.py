@@ -54,6 +54,7 @@ def lib():
                                C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
         L.bvo_successors_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
         L.bvo_references.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        L.bvo_copied.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         _lib = L
     return _lib
 
@@ -222,6 +223,23 @@ class OracleGraph:
         rc = lib().bvo_references(self._h, lo, hi, out.ctypes.data)
         if rc:
             raise OracleError(rc)
+        return out
+
+    def copied(self, lo=0, hi=None, threads=None):
+        """How many successors every record of [lo, hi) copies from its referent (BVGraph.java:1058-1071), 0 without a reference."""
+        hi = self.n if hi is None else hi
+        out = np.empty(hi - lo, dtype=np.int32)
+        threads = threads or min(os.cpu_count() or 1, 64)
+        cuts = [lo + (hi - lo) * k // threads for k in range(threads + 1)]
+
+        def one(k):
+            a, b = cuts[k], cuts[k + 1]
+            rc = lib().bvo_copied(self._h, a, b, out[a - lo:].ctypes.data) if b > a else 0
+            if rc:
+                raise OracleError(rc)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=threads) as ex:
+            list(ex.map(one, range(threads)))
         return out
 
     def chain_depths(self):

@@ -64,6 +64,8 @@ def main():
         print("residual tile rounds histogram (<=2,<=4,<=8,<=16,<=32,<=64):", [int(v) for v in st[8:14]])
         print("ticks (M) NW=1: A %.1f I %.1f R+X %.1f | NW=16: A %.1f I %.1f R+X %.1f" % tuple(float(v) / 1e6 for v in (st[16], st[17], st[18], st[20], st[21], st[22])))
         print("giants residual ticks (M): stage %.0f rounds %.0f values %.0f rank %.0f flush %.0f fence %.0f expand %.0f loop %.0f" % tuple(float(v) / 1e6 for v in st[24:32]))
+        print("wave class (NW=1) ticks (M): A %.0f I %.0f R %.0f X %.0f | residual steps: stage %.0f run-in %.0f first parse %.0f rounds %.0f scans+iv staging %.0f search+values %.0f tail %.0f | records %d tiles %d extra rounds %d avg B %.0f codes %d" % (
+            tuple(float(v) / 1e6 for v in (st[16], st[17], st[18], st[19])) + tuple(float(v) / 1e6 for v in st[48:55]) + (int(st[57]), int(st[55]), int(st[56]), float(st[58]) / max(int(st[57]), 1), int(st[59]))))
         ns = max(int(st[13]), 1)
         print("slow tiles: avg B %.0f avg remaining codes %.0f avg codes in tile %.0f" % (st[15] / ns, st[4] / ns, st[14] / ns))
     if args.check:

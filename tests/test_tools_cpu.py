@@ -23,6 +23,9 @@ def test_writer_reproduces_reference_bytes(tmp_path, cnr_oracle):
     assert st["copied_arcs"] + st["intervalised_arcs"] + st["residual_arcs"] == rowptr[-1]
     assert (st["copied_arcs"], st["intervalised_arcs"], st["residual_arcs"]) == (2130833, 361894, 723425)
     assert st["max_ref_chain"] == 3
+    og = cnr_oracle[0]
+    c = og.copied()  # (the oracle's own count of the ids every record takes from its referent: what bench.py prices the copy pass by)
+    assert int(c.sum()) == 2130833 and np.all(c <= np.diff(rowptr)) and not np.any((c > 0) & (og.references() == 0))
 
 
 @pytest.mark.parametrize("w,r,i", [(0, 0, 0), (1, 1, 2), (2, 2, 3), (7, 3, 4), (3, 100, 1)])

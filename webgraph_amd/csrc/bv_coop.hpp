@@ -35,7 +35,7 @@ constexpr int COOP_B_MIN = 96, COOP_CODES_PER_SEG = 12;
 #define COOP1_BMAX 512
 #endif
 #ifndef COOP1_IVCAP
-#define COOP1_IVCAP 512
+#define COOP1_IVCAP 256
 #endif
 #ifndef COOPG_BMAX
 #define COOPG_BMAX 1024
@@ -63,7 +63,11 @@ template <int NW> struct CoopLds { // LDS layout of one group, in 32-bit words
 	static constexpr int OFF_WIN = 0, OFF_IVL = WIN_WORDS, OFF_XCH = ((OFF_IVL + 2 * (CoopCfg<NW>::IVCAP + 1) + 1) & ~1); // staged intervals: left[], pstart[]
 	static constexpr int OFF_CACHE = OFF_XCH + XCH_WORDS;                            // one wave per record: the gaps of the lane's segment, [slot][lane]
 	static constexpr int CACHE_WORDS = NW == 1 ? COOP1_CK * 64 : 0;
-	static constexpr int WORDS = OFF_CACHE + CACHE_WORDS;
+	// one wave per record: the value pass hands its ids to the stores through LDS, COOP1_ST rows of (value, position) per lane -- a lane's run of ids is contiguous in the row, so
+	// a store instruction of eight lanes' eight ids each touches ~10 cache lines where 64 lanes' one id each touch 64 (scripts/ubench_lines.hip: a store costs a CU ~2.6 cycles
+	// per line it touches, 24 cycles for 256 contiguous bytes against 170 for 64 lines; the value pass was half of the wave class's residual phase, all of it in that queue)
+	static constexpr int OFF_STG = OFF_CACHE + CACHE_WORDS, STG_WORDS = NW == 1 ? 2 * 8 * 64 : 0;
+	static constexpr int WORDS = OFF_STG + STG_WORDS;
 };
 
 // the part of CoopLds<1> that a block-list walk needs (coop_block_walk: window, exchange slots, the lanes' cached codes -- no staged intervals): 9.4 KB per wave
@@ -1046,13 +1050,20 @@ __device__ __forceinline__ void coop_residuals_w1(const GraphDev &g, int32_t x, 
 	const uint32_t R = min((uint32_t)COOP_RUNIN_MAX, B >> COOP_RUNIN_SHIFT);
 	int32_t resDone = 0, baseVal = x;
 	bool firstTile = true;
+	// (BVGPU_STATS=1: the wave class's ticks by step, slots 48 ..: stage, run-in, first parse, rounds, scans + interval staging, search + values, tail; 55 tiles, 58 sum of B, 59 codes)
+	unsigned long long wk = g.stats ? __builtin_readcyclecounter() : 0;
+#define WT(slot) do { if (g.stats) { const unsigned long long now_ = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(&g.stats[48 + slot], now_ - wk); wk = now_; } } while (0)
+	if (g.stats && lane == 0) { atomicAdd(&g.stats[58], (unsigned long long)B); atomicAdd(&g.stats[59], (unsigned long long)nRes); atomicAdd(&g.stats[57], 1ull); }
 	auto wscan = [&](int32_t vv) { // inclusive scan over the wave
 #pragma unroll
 		for (int o = 1; o < 64; o <<= 1) { const int32_t t = __shfl_up(vv, o, 64); if (lane >= o) vv += t; }
 		return vv;
 	};
 	while (resDone < nRes) {
+		WT(6);
 		const WindowSrc src = stage_tile<1>(G, g, win, pos, B); // (ends with a wave sync: the interval table above is in place too)
+		WT(0);
+		if (g.stats && lane == 0) atomicAdd(&g.stats[55], 1ull);
 		const uint64_t base = src.w0 << 5;
 		const uint32_t p0 = (uint32_t)(pos - base), secEndR = (uint32_t)min(recEnd - base, (uint64_t)0x7fffff00u);
 		const uint32_t segEnd = min(p0 + (uint32_t)(lane + 1) * B, secEndR);
@@ -1063,6 +1074,7 @@ __device__ __forceinline__ void coop_residuals_w1(const GraphDev &g, int32_t x, 
 			while (p < s && !e2) (void)w1_residual<DEF>(g, lw, src, p, e2);
 			s = e2 ? s : min(p, secEndR);
 		}
+		WT(1);
 		uint32_t e, c, pCK; int32_t sum;
 		auto parse = [&]() { // the codes that start in [s, segEnd): count, what they add to the running id, end; the first CK gaps kept
 			c = 0; sum = 0;
@@ -1078,12 +1090,15 @@ __device__ __forceinline__ void coop_residuals_w1(const GraphDev &g, int32_t x, 
 			e = e2 ? secEndR : min(p, secEndR);
 		};
 		parse();
+		WT(2);
 		for (int round = 0; round < 66; round++) { // a segment starts where its left neighbour ended
 			uint32_t ns = (uint32_t)__shfl_up((int)e, 1, 64);
 			const bool dirty = lane > 0 && ns != s;
 			if (!__any(dirty)) break;
+			if (g.stats && lane == 0) atomicAdd(&g.stats[56], 1ull);
 			if (dirty) { s = ns; if (s < segEnd) parse(); else { c = 0; sum = 0; e = s; } }
 		}
+		WT(3);
 		const int32_t cincl = wscan((int32_t)c), sincl = wscan(sum);
 		const int32_t tileTotal = __shfl(cincl, 63, 64);
 		const int32_t cb = cincl - (int32_t)c, lim = nRes - resDone;
@@ -1119,15 +1134,46 @@ __device__ __forceinline__ void coop_residuals_w1(const GraphDev &g, int32_t x, 
 		}
 		int32_t before = ic ? iv_p(ii) : 0, nextLeft = (cn && ic) ? iv_left(ii) : 0x7fffffff;
 		uint32_t p = pCK;
-		for (int32_t k2 = 0; k2 < cn; k2++) {
-			const int32_t add = k2 < CK ? (int32_t)cache[k2 * 64 + lane] : (int32_t)w1_residual<DEF>(g, lw, src, p, err) + 1;
-			val += add;
-			if (nextLeft < val) {
-				do { list[ii].rank = jj; ii++; nextLeft = iv_left(ii); } while (nextLeft < val); // interval ii sits after jj residuals
-				before = iv_p(ii);
+		WT(4);
+		// eight ids per lane at a time into LDS (row u: [u][lane], no bank conflict), then eight store instructions, each for eight lanes' runs of eight
+		lds_u32 *sv = (lds_u32 *)(lds + CoopLds<1>::OFF_STG), *sp = sv + 8 * 64;
+		if (!(g.dbg & 512)) { // (experiment switch: the direct stores of round 5)
+			if (!(g.dbg & 128)) for (int32_t k2 = 0; k2 < cn; k2++) {
+				const int32_t add = k2 < CK ? (int32_t)cache[k2 * 64 + lane] : (int32_t)w1_residual<DEF>(g, lw, src, p, err) + 1;
+				val += add;
+				if (nextLeft < val) {
+					do { list[ii].rank = jj; ii++; nextLeft = iv_left(ii); } while (nextLeft < val); // interval ii sits after jj residuals
+					before = iv_p(ii);
+				}
+				if (!(g.dbg & 32)) out[jj + before] = val;
+				jj++;
 			}
-			out[jj + before] = val;
-			jj++;
+		} else
+		for (int32_t k0 = 0; __any(k0 < cn); k0 += 8) {
+#pragma unroll
+			for (int u = 0; u < 8; u++) {
+				const int32_t k2 = k0 + u;
+				int32_t at = -1;
+				if (k2 < cn) {
+					const int32_t add = k2 < CK ? (int32_t)cache[k2 * 64 + lane] : (int32_t)w1_residual<DEF>(g, lw, src, p, err) + 1;
+					val += add;
+					if (nextLeft < val) {
+						do { list[ii].rank = jj; ii++; nextLeft = iv_left(ii); } while (nextLeft < val); // interval ii sits after jj residuals
+						before = iv_p(ii);
+					}
+					at = jj + before;
+					jj++;
+				}
+				sv[u * 64 + lane] = (uint32_t)val; sp[u * 64 + lane] = (uint32_t)at;
+			}
+			G.sync();
+#pragma unroll
+			for (int r = 0; r < 8; r++) {
+				const int idx = (lane & 7) * 64 + 8 * r + (lane >> 3);
+				const int32_t at = (int32_t)sp[idx], vv = (int32_t)sv[idx];
+				if (at >= 0) out[at] = vv;
+			}
+			G.sync();
 		}
 		const unsigned long long has = __ballot(cn > 0);
 		const int lastL = has ? 63 - __clzll((long long)has) : 0;
@@ -1136,8 +1182,10 @@ __device__ __forceinline__ void coop_residuals_w1(const GraphDev &g, int32_t x, 
 		resDone += T;
 		pos = base + (uint64_t)(uint32_t)__shfl((int)e, 63, 64);
 		firstTile = false;
+		WT(5);
 		G.sync(); // the window and the gap slots are reused by the next tile
 	}
+#undef WT
 }
 
 // The whole record of node x by one group.  Same contract as parse_node: extras merged into row[copied..d).
@@ -1248,15 +1296,36 @@ __device__ __forceinline__ void coop_parse_node(const GraphDev &g, int32_t x, in
 	G.sync_global();
 	if (NW == 1 && DEF != 0 && ic < 0x7fffffff && nRes < 0x7fffffff) { // one wave, default codings: every codeword decoded once
 		if (nRes > 0) coop_residuals_w1<DEF>(g, x, pos, recEnd, nRes, ic, intervalArcs, list, row + copied, lds, err);
+		COOP_TICK(2);
 		if (ic > 0) { // phase X: interval i occupies out[pstart + rank .. + len)  (IntIntervalSequenceIterator.java:64-78)
 			G.sync_global();
 			int32_t *out = row + copied;
+			lds_u32 *xs = (lds_u32 *)(lds + CoopLds<1>::OFF_STG), *xl = xs + 64, *xp = xs + 128; // (the value pass's staging rows are free)
 			for (int64_t i0 = 0; i0 < ic; i0 += 64) {
 				const int64_t i = i0 + tid;
 				int32_t left = 0, len = 0; int64_t p = 0;
 				if (i < ic) { const IvEntry en = list[i]; left = en.left; len = en.len; p = (int64_t)en.pstart + en.rank; }
-				const bool isLong = len > 16;
-				if (!isLong) for (int32_t t = 0; t < len; t++) out[p + t] = left + t;
+				const bool flat = (g.dbg & 1024) != 0; // (experiment switch)
+				const bool isLong = len > (flat ? 64 : 16);
+				if (!flat) { if (!isLong && !(g.dbg & 64)) for (int32_t t = 0; t < len; t++) out[p + t] = left + t; }
+				else { // the short intervals of these 64, flat: id f of their concatenation by thread f mod 64 -- consecutive threads write consecutive ids of the same few intervals
+				  // (a lane per interval wrote 64 different lines with every store)
+					const int32_t ls = isLong ? 0 : len;
+					int32_t incl = ls;
+#pragma unroll
+					for (int o = 1; o < 64; o <<= 1) { const int32_t t2 = __shfl_up(incl, o, 64); if (tid >= o) incl += t2; }
+					const int32_t tot = __shfl(incl, 63, 64);
+					xs[tid] = (uint32_t)(incl - ls); xl[tid] = (uint32_t)left; xp[tid] = (uint32_t)p; // (p < 2^31: a position inside the row)
+					G.sync();
+					for (int32_t f = tid; f < tot; f += 64) {
+						int o = 0; // the last interval that starts at or before f (the empty ones among them start where the next one does)
+#pragma unroll
+						for (int st = 32; st > 0; st >>= 1) if ((int32_t)xs[o + st] <= f) o += st;
+						const int32_t k = f - (int32_t)xs[o];
+						out[(int32_t)xp[o] + k] = (int32_t)xl[o] + k;
+					}
+					G.sync();
+				}
 				unsigned long long lm = __ballot(isLong);
 				while (lm) {
 					const int srcl = __ffsll((long long)lm) - 1;
@@ -1269,7 +1338,7 @@ __device__ __forceinline__ void coop_parse_node(const GraphDev &g, int32_t x, in
 		}
 	}
 	else coop_residuals<DEF, NW>(G, g, x, pos, recEnd, nRes, ic, intervalArcs, list, row + copied, lds, err);
-	COOP_TICK(2);
+	COOP_TICK(NW == 1 ? 3 : 2); // (one wave: slot 2 = the residuals, slot 3 = the expansion of the intervals)
 #undef COOP_TICK
 	if (err) atomicOr(errOut, err);
 }

@@ -50,16 +50,20 @@ template <bool VEC>
 __device__ __forceinline__ void copy_node_tab(int32_t d, int32_t dref, int32_t *__restrict__ row, const int32_t *__restrict__ src, const int32_t *__restrict__ tabEnd, int4 hd);
 
 // ------------------------------------------------------------------------------------------------ headers
+__device__ __forceinline__ int32_t record_bin(uint64_t bitsLen);
 template <int DEF>
 __global__ void __launch_bounds__(TPB) k_headers(GraphDev g, int32_t lo, int32_t cnt, int32_t *__restrict__ outd,
-                                                 uint16_t *__restrict__ ref, int *__restrict__ err, int32_t *__restrict__ part, uint8_t *__restrict__ mark) {
+                                                 uint16_t *__restrict__ ref, int *__restrict__ err, int32_t *__restrict__ part, uint8_t *__restrict__ mark,
+                                                 uint16_t *__restrict__ pkey16, int32_t *__restrict__ phist, int32_t pwindows) {
 	const int32_t s = item_of(blockIdx.x * TPB + threadIdx.x);
 	uint64_t d = 0;
+	uint64_t off0 = 0;
 	if (s < cnt) {
 		const int32_t x = lo + s;
 		BitReader br;
 		br.init(g.bits, g.nwords);
-		br.seek((uint64_t)g.offsets[x]);
+		off0 = (uint64_t)g.offsets[x];
+		br.seek(off0);
 		d = Fields<DEF>::outdegree(br, g);
 		uint64_t r = 0;
 		int e = 0;
@@ -89,6 +93,19 @@ __global__ void __launch_bounds__(TPB) k_headers(GraphDev g, int32_t lo, int32_t
 		}
 		__syncthreads();
 		if (threadIdx.x < PICK_LEVELS) part[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = s_c[threadIdx.x];
+	}
+	// The parse list's keys (work bin inside a window of nodes: k_depth_keys with noBin = 6 / 2) while the header and the record's bounds are at hand: k_depth_keys re-read
+	// 24 bytes per node for them, 70-80 us on C2 on the path to every parse kernel; the histogram of the keys is k_key_hist's, 2 bytes per node.  (Counted here -- per
+	// block in LDS, one global addition per non-empty bin -- the blocks of a window, which run together, queued on the same two dozen words: k_headers 68 -> 540 us.)
+	if (pkey16 && s < cnt) {
+		uint16_t key = KEY_NONE;
+		if (d > 0) {
+			const uint64_t bitsLen = (uint64_t)g.offsets[lo + s + 1] - off0;
+			const int32_t bin = record_bin(max(bitsLen, d * 8));
+			const int32_t win = !pwindows ? 0 : bin >= PARSE_LONG_BIN ? MAXLVL - 1 : (int32_t)(((int64_t)s * MAXLVL) / cnt);
+			key = (uint16_t)(win * NBIN + bin);
+		}
+		pkey16[s] = key;
 	}
 }
 
@@ -250,7 +267,7 @@ __global__ void __launch_bounds__(TPB) k_scan_top(int64_t *__restrict__ sums, in
 // chain in front of every parse kernel): tiles of 1 024 sums with a carry, coalesced loads, the next tile's in flight while this one is scanned.
 // (Not for small ranges: there the scan of the outdegrees must not end before the parse list is built -- the giants start behind it and their
 // groups, a CU each, starve k_scatter_keys; profiles/r4_experiments.txt section 9.)
-constexpr int SCAN_TOP_T = 1024, SCAN_TOP_I = 4, SCAN_TOP_TILED_MIN = 16384;
+constexpr int SCAN_TOP_T = 1024, SCAN_TOP_I = 4, SCAN_TOP_TILED_MIN = 1024; // (round 6: from 1 M nodes on -- the giants now WAIT for the parse list, giants_after_list, so a faster scan no longer lets them starve its scatter)
 __global__ void __launch_bounds__(SCAN_TOP_T) k_scan_top_tiled(int64_t *__restrict__ sums, int64_t nb) {
 	__shared__ int64_t wsum[SCAN_TOP_T / 64];
 	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -501,6 +518,21 @@ __global__ void __launch_bounds__(TPB) k_key_offsets(const int32_t *__restrict__
 	}
 	__syncthreads();
 	if (threadIdx.x == 0) { keyBase[NKEYS] = (int32_t)tot; atomicMax(maxdepth, s_top); }
+}
+
+// histogram of the keys that k_headers wrote (the parse list of a scan without a halo)
+__global__ void __launch_bounds__(TPB) k_key_hist(int32_t cnt, const uint16_t *__restrict__ key16, int32_t *__restrict__ hist) {
+	__shared__ int32_t s_hist[NKEYS];
+	for (int k = threadIdx.x; k < NKEYS; k += TPB) s_hist[k] = 0;
+	__syncthreads();
+#pragma unroll
+	for (int it = 0; it < LIST_ITEMS; it++) {
+		const int32_t s = item_of(blockIdx.x * LIST_TILE + it * TPB + threadIdx.x);
+		const uint16_t key = s < cnt ? key16[s] : KEY_NONE;
+		if (key < NKEYS) atomicAdd(&s_hist[key], 1);
+	}
+	__syncthreads();
+	for (int k = threadIdx.x; k < NKEYS; k += TPB) { const int32_t c = s_hist[k]; if (c) atomicAdd(&hist[k], c); }
 }
 
 __global__ void __launch_bounds__(TPB) k_scatter_keys(int32_t cnt, const uint16_t *__restrict__ key16, int32_t *__restrict__ cursor, int32_t *__restrict__ list,
@@ -2061,12 +2093,21 @@ namespace bv {
 
 static inline unsigned nblk(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
-void launch_headers(const GraphDev &g, int def, int32_t lo, int32_t cnt, int32_t *outd, uint16_t *ref, int *err, hipStream_t st, int32_t *part, uint8_t *mark) {
+void launch_headers(const GraphDev &g, int def, int32_t lo, int32_t cnt, int32_t *outd, uint16_t *ref, int *err, hipStream_t st, int32_t *part, uint8_t *mark,
+                    uint16_t *pkey16, int32_t *phist, bool pwindows) {
 	if (cnt <= 0) return;
 	if (mark) (void)hipMemsetAsync(mark, 0, (size_t)cnt, st);
-	if (def == 1) hipLaunchKernelGGL(k_headers<1>, dim3(nblk(cnt, TPB)), dim3(TPB), 0, st, g, lo, cnt, outd, ref, err, part, mark);
-	else if (def == 2) hipLaunchKernelGGL(k_headers<2>, dim3(nblk(cnt, TPB)), dim3(TPB), 0, st, g, lo, cnt, outd, ref, err, part, mark);
-	else hipLaunchKernelGGL(k_headers<0>, dim3(nblk(cnt, TPB)), dim3(TPB), 0, st, g, lo, cnt, outd, ref, err, part, mark);
+	if (pkey16) (void)hipMemsetAsync(phist, 0, sizeof(int32_t) * NKEYS, st);
+	if (def == 1) hipLaunchKernelGGL(k_headers<1>, dim3(nblk(cnt, TPB)), dim3(TPB), 0, st, g, lo, cnt, outd, ref, err, part, mark, pkey16, phist, pwindows ? 1 : 0);
+	else if (def == 2) hipLaunchKernelGGL(k_headers<2>, dim3(nblk(cnt, TPB)), dim3(TPB), 0, st, g, lo, cnt, outd, ref, err, part, mark, pkey16, phist, pwindows ? 1 : 0);
+	else hipLaunchKernelGGL(k_headers<0>, dim3(nblk(cnt, TPB)), dim3(TPB), 0, st, g, lo, cnt, outd, ref, err, part, mark, pkey16, phist, pwindows ? 1 : 0);
+}
+// the parse list from keys and a histogram that k_headers left (launch_headers with pkey16): the two kernels that remain of launch_build_lists
+void launch_scatter_lists(int32_t cnt, const uint16_t *key16, const int32_t *hist, int32_t *keyBase, int32_t *cursor, int32_t *list, int32_t *giantlist, int32_t *ctl, int32_t *maxdepth, hipStream_t st) {
+	if (cnt <= 0) return;
+	hipLaunchKernelGGL(k_key_hist, dim3(nblk(cnt, LIST_TILE)), dim3(TPB), 0, st, cnt, key16, (int32_t *)hist);
+	hipLaunchKernelGGL(k_key_offsets, dim3(1), dim3(TPB), 0, st, hist, keyBase, cursor, maxdepth);
+	hipLaunchKernelGGL(k_scatter_keys, dim3(nblk(cnt, LIST_TILE)), dim3(TPB), 0, st, cnt, key16, cursor, list, giantlist, 0, ctl);
 }
 __global__ void __launch_bounds__(HASH_ACC_SLOTS) k_hash_sum(const HashCtx *__restrict__ hx, int32_t *__restrict__ out) {
 	__shared__ uint32_t s_part[HASH_ACC_SLOTS / 64];

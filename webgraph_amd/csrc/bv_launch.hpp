@@ -77,7 +77,9 @@ struct BatchView {
 	__device__ __forceinline__ int32_t *row(int64_t s) const { const int32_t qi = qidx[s]; return qi >= 0 ? succ + rowptr[qi] : arena + arow[s]; }
 };
 
-void launch_headers(const GraphDev &g, int def, int32_t lo, int32_t cnt, int32_t *outd, uint16_t *ref, int *err, hipStream_t st, int32_t *part = nullptr, uint8_t *mark = nullptr); // mark[cnt] (zeroed): set for every referent
+void launch_headers(const GraphDev &g, int def, int32_t lo, int32_t cnt, int32_t *outd, uint16_t *ref, int *err, hipStream_t st, int32_t *part = nullptr, uint8_t *mark = nullptr, // mark[cnt] (zeroed): set for every referent
+                    uint16_t *pkey16 = nullptr, int32_t *phist = nullptr, bool pwindows = true); // pkey16 / phist: the parse list's keys and their histogram (zeroed here), as k_depth_keys with noBin = 6 (pwindows) / 2 writes them
+void launch_scatter_lists(int32_t cnt, const uint16_t *key16, const int32_t *hist, int32_t *keyBase, int32_t *cursor, int32_t *list, int32_t *giantlist, int32_t *ctl, int32_t *maxdepth, hipStream_t st);
 int64_t headers_blocks(int32_t cnt); // part: 5 counts per block of k_headers, [5][headers_blocks(cnt)] (input of k_pick_coop)
 void launch_mark_halo(int32_t nh, int32_t cnt, int32_t W, int32_t *outd, uint16_t *ref, uint8_t *need, int *err, hipStream_t st);
 void launch_scan(const int32_t *in, int64_t n, int64_t *out, int64_t *sums, hipStream_t st, const HashCtx *hx = nullptr, int32_t lo = 0, int32_t nh = 0, long long topTiledMin = -1); // topTiledMin: block sums from which the top level runs tiled (-1: default) // hx: the node numbers of slots >= nh are added to the hash (HashCtx)

@@ -169,6 +169,9 @@ struct bvg_graph {
 	DevBuf walkdesc; // k_copy_prewalk: 16 bytes per entry of the group class's queue
 	DevBuf copytab;  // 16 bytes per slot: the copy blocks of the rows that the one-lane parse decoded, for the lane class of the copy pass (CopyTab, bv_lanewin.hpp)
 	int copy_vec = -1; // BVGPU_COPY_VEC=1|0: the lane class of the copy pass merges with 16-byte loads and stores (copy_node_v) or id by id; -1: by the mean length of its rows (counted at load time)
+	int giants_after_list = 1; // BVGPU_GIANTS_AFTER_LIST=0: the giants' kernel does not wait for the parse list
+	int keys_in_headers = 1; // BVGPU_KEYS_IN_HEADERS=0: the parse list's keys by k_depth_keys, not by k_headers
+	bool keys_ready = false; // (per job) k_headers wrote them
 	int lane_loop = 1;   // BVGPU_LANE_LOOP=0: round 4's one-lane loop (parse_node_lwb) instead of round 6's (parse_node_lwc)
 	int copy_tables = 1; // BVGPU_COPY_TABLES=0: the lane class of the copy pass walks the block lists in the stream although the parse left them as tables
 	int prewalk_long = 1; // BVGPU_PREWALK_LONG=0: no kernel of their own for the lists of >= 2048 codes; 2: on the lists' stream instead of side B
@@ -271,6 +274,8 @@ int apply_option(bvg_graph *g, const std::string &name, const char *value) {
 	else if (name == "walk_tables") g->walk_tables = iv;
 	else if (name == "copy_vec") g->copy_vec = iv;
 	else if (name == "lane_loop") g->lane_loop = iv;
+	else if (name == "keys_in_headers") g->keys_in_headers = iv;
+	else if (name == "giants_after_list") g->giants_after_list = iv;
 	else if (name == "copy_tables") g->copy_tables = iv;
 	else if (name == "prewalk") g->prewalk = iv;
 	else if (name == "prewalk_long") g->prewalk_long = iv;
@@ -293,7 +298,7 @@ int apply_option(bvg_graph *g, const std::string &name, const char *value) {
 	return BVG_OK;
 }
 const char *const OPTION_NAMES[] = { "coop_min", "giant_min", "coop_waves", "giant_groups", "level_blocks", "copy_big", "parse_windows", "tile", "seg", "seg_hub_min", "seg_blocks", "lists_on_b", "skip_empty_giants", "level_lists_early",
-	"walk_tables", "copy_vec", "lane_loop", "copy_tables", "prewalk", "prewalk_long", "prewalk_blocks", "copy_mid_min", "overlap", "halo_min", "batch_dense", "scan_top_tiled_min", "wait_giants", "hash_materialise",
+	"walk_tables", "copy_vec", "lane_loop", "copy_tables", "giants_after_list", "keys_in_headers", "prewalk", "prewalk_long", "prewalk_blocks", "copy_mid_min", "overlap", "halo_min", "batch_dense", "scan_top_tiled_min", "wait_giants", "hash_materialise",
 	"ef_hash_materialise", "scan_piece", "dbg", "stats", "trace_retry", "trace_err", "trace_host" };
 void options_from_env(bvg_graph *g) {
 	for (const char *n : OPTION_NAMES) {
@@ -367,6 +372,19 @@ int hash_publish(bvg_graph *g) { // after enqueue_structure: every pointer of th
 	return BVG_OK;
 }
 
+// Does a job over slots [lo, lo + cnt) decode its lane class from tiles (bv_tile.hpp) rather than from the parse list?  (Decided from what the host knows when the job is
+// enqueued: enqueue_structure asks -- a tile job needs no parse-list keys from k_headers -- and enqueue_decode acts on it.)
+int job_tile_variant(const bvg_graph *g, int32_t lo, int32_t cnt, bool pick) {
+	const Staged &s = *g->st;
+	int tileVariant = g->tile > 0 ? g->tile : 0;
+	if (g->hash_job) tileVariant = 0; // (the hash fold rides on k_parse_list)
+	else if (g->tile < 0 && g->adaptive && pick && s.deg_counts[0] >= 0) {
+		const double share = (double)(s.h_offsets[(size_t)lo + cnt] - s.h_offsets[(size_t)lo]) / (double)std::max<int64_t>(s.h_offsets[(size_t)s.node_hi] - s.h_offsets[(size_t)s.stage_lo], 1);
+		if ((double)s.deg_counts[0] * share <= (double)COOP_BUDGET * (share > 0.999 ? 1.0 : 0.8)) tileVariant = 1; // (a sub-range: an estimate, with a margin)
+	}
+	return s.def != 0 ? tileVariant : 0;
+}
+
 // Enqueues headers (+halo closure) + scan for nodes [from,to) with a halo of nh nodes before `from`.
 // On return the view describes the job; rowstart lives in scratch.
 int enqueue_structure(bvg_graph *g, int32_t from, int32_t to, int32_t nh, bv::RangeView &v, bool pickCoop = false, int64_t *rowstart_out = nullptr) {
@@ -392,7 +410,13 @@ int enqueue_structure(bvg_graph *g, int32_t from, int32_t to, int32_t nh, bv::Ra
 		const int rc = hash_publish(g);
 		if (rc) return rc;
 	}
-	bv::launch_headers(gd, s.def, lo, cnt, v.outd, v.ref, derr, g->stream, pick ? g->pickpart.as<int32_t>() : nullptr, g->hash_job ? g->hashmark.as<uint8_t>() : nullptr);
+	// the parse list's keys fall out of the headers (a scan job without a halo that will build a parse list: not a tile job; keys_in_headers = 0: k_depth_keys computes them as before)
+	g->keys_ready = false;
+	uint16_t *pk16 = nullptr;
+	if (g->keys_in_headers && pickCoop && nh == 0 && s.def != 0 && g->overlap && !g->profile && job_tile_variant(g, lo, cnt, pick) == 0 &&
+	    g->pkey16.need(sizeof(uint16_t) * (size_t)cnt) && g->pkeys.need(3 * (bv::NKEYS + 1) * sizeof(int32_t))) { pk16 = g->pkey16.as<uint16_t>(); g->keys_ready = true; }
+	bv::launch_headers(gd, s.def, lo, cnt, v.outd, v.ref, derr, g->stream, pick ? g->pickpart.as<int32_t>() : nullptr, g->hash_job ? g->hashmark.as<uint8_t>() : nullptr,
+	                   pk16, pk16 ? g->pkeys.as<int32_t>() : nullptr, g->parse_windows != 0);
 	if (nh) bv::launch_mark_halo(nh, cnt, s.info.window_size, v.outd, v.ref, g->need.as<uint8_t>(), derr, g->stream);
 	if (pick) { // (also zeroes ctl[4..16), the counters of the lists and of the copy levels: a memset behind the scan kernels sat 22 us on the critical path)
 		bv::launch_pick_coop(g->pickpart.as<int32_t>(), (int32_t)hb, COOP_BUDGET, g->coopctl.as<int32_t>(), g->stream);
@@ -599,12 +623,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		// in the lane class -- its share (by bits) of the staged records with >= 128 successors fits the wave class, so that
 		// k_pick_coop will pick 128 --: neighbouring short records are alike, a tile's lanes stay even, and the coalesced tile
 		// kernel is 20 % faster than the bins (cnr-2000 x 30: 0.42 against 0.53 ms); with a heavy-tailed lane class it is 2.6x slower (C2).
-		int tileVariant = g->tile > 0 ? g->tile : 0;
-		if (g->hash_job) tileVariant = 0; // (the hash fold rides on k_parse_list)
-		else if (g->tile < 0 && g->adaptive && v.coop_ptr && s.deg_counts[0] >= 0) {
-			const double share = (double)(s.h_offsets[(size_t)v.lo + v.cnt] - s.h_offsets[(size_t)v.lo]) / (double)std::max<int64_t>(s.h_offsets[(size_t)s.node_hi] - s.h_offsets[(size_t)s.stage_lo], 1);
-			if ((double)s.deg_counts[0] * share <= (double)COOP_BUDGET * (share > 0.999 ? 1.0 : 0.8)) tileVariant = 1; // (a sub-range: an estimate, with a margin)
-		}
+		const int tileVariant = job_tile_variant(g, v.lo, v.cnt, v.coop_ptr != nullptr);
 		const bool tiles = tileVariant != 0 && s.def != 0;
 		// the tables of copy blocks that the one-lane parse leaves for the lane class of the copy pass: 16 bytes per slot (a range of more than 2^28 slots walks the stream as before:
 		// 4 GB of tables and more; so does a job that finds no room for them, and one that decodes its lane class with round 4's loop, which writes none)
@@ -677,7 +696,13 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			const int rc = build_levels(g->sideA, true);
 			if (rc) return rc;
 		}
-		if (earlyList) {
+		if (earlyList && g->keys_ready) { // k_headers left the keys and their histogram: two kernels to the list
+			HIPCHK(g, hipStreamWaitEvent(g->sideA, g->evHdr, 0));
+			bv::launch_scatter_lists(v.cnt, g->pkey16.as<uint16_t>(), g->pkeys.as<int32_t>(), pKeyBase, pKeyBase + (bv::NKEYS + 1), g->plist.as<int32_t>(), g->giantlist.as<int32_t>(), ctl,
+			                         &g->small.as<Small>()->pad, g->sideA);
+			HIPCHK(g, hipEventRecord(g->evP, g->sideA));
+		}
+		else if (earlyList) {
 			HIPCHK(g, hipStreamWaitEvent(g->sideA, g->evHdr, 0));
 			bv::launch_build_lists(gd, v, ~0ull, g->parse_windows ? 6 : 2, nullptr, g->pkey16.as<uint16_t>(), g->pkeys.as<int32_t>(), pKeyBase, pKeyBase + (bv::NKEYS + 1), g->plist.as<int32_t>(),
 			                       g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->pad, g->sideA);
@@ -707,6 +732,9 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		// the long records first on both side streams: giants on B, the wave class on A ...
 		if (ovl && coop) {
 			HIPCHK(g, hipStreamWaitEvent(g->sideA, g->evC, 0));
+			// the giants' groups take a CU each: started while the parse list is still being scattered they starve k_scatter_keys of its blocks (profiles/r4_experiments.txt section 9:
+			// 48 -> 402 us) -- until round 5 the order rested on the scan of the outdegrees being the slower of the two chains; now the giants WAIT for the list (giants_after_list = 0: as before)
+			if (earlyList && g->giants_after_list && !noGiants) HIPCHK(g, hipStreamWaitEvent(side_b(g), g->evP, 0));
 			bv::launch_parse_big(gd, s.def, v, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, noGiants ? 0 : g->giant_groups, derr, side_b(g), g->sideA, g->wait_giants); // (giants, big)
 			if (!segReady) HIPCHK(g, hipEventRecord(g->evB, side_b(g))); // (else: behind the segment pipeline's chain, below)
 		}
