@@ -35,7 +35,7 @@ constexpr int COOP_B_MIN = 96, COOP_CODES_PER_SEG = 12;
 #define COOP1_BMAX 512
 #endif
 #ifndef COOP1_IVCAP
-#define COOP1_IVCAP 256
+#define COOP1_IVCAP 512
 #endif
 #ifndef COOPG_BMAX
 #define COOPG_BMAX 1024
@@ -63,11 +63,7 @@ template <int NW> struct CoopLds { // LDS layout of one group, in 32-bit words
 	static constexpr int OFF_WIN = 0, OFF_IVL = WIN_WORDS, OFF_XCH = ((OFF_IVL + 2 * (CoopCfg<NW>::IVCAP + 1) + 1) & ~1); // staged intervals: left[], pstart[]
 	static constexpr int OFF_CACHE = OFF_XCH + XCH_WORDS;                            // one wave per record: the gaps of the lane's segment, [slot][lane]
 	static constexpr int CACHE_WORDS = NW == 1 ? COOP1_CK * 64 : 0;
-	// one wave per record: the value pass hands its ids to the stores through LDS, COOP1_ST rows of (value, position) per lane -- a lane's run of ids is contiguous in the row, so
-	// a store instruction of eight lanes' eight ids each touches ~10 cache lines where 64 lanes' one id each touch 64 (scripts/ubench_lines.hip: a store costs a CU ~2.6 cycles
-	// per line it touches, 24 cycles for 256 contiguous bytes against 170 for 64 lines; the value pass was half of the wave class's residual phase, all of it in that queue)
-	static constexpr int OFF_STG = OFF_CACHE + CACHE_WORDS, STG_WORDS = NW == 1 ? 2 * 8 * 64 : 0;
-	static constexpr int WORDS = OFF_STG + STG_WORDS;
+	static constexpr int WORDS = OFF_CACHE + CACHE_WORDS;
 };
 
 // the part of CoopLds<1> that a block-list walk needs (coop_block_walk: window, exchange slots, the lanes' cached codes -- no staged intervals): 9.4 KB per wave
@@ -1068,7 +1064,8 @@ __device__ __forceinline__ void coop_residuals_w1(const GraphDev &g, int32_t x, 
 		const uint32_t p0 = (uint32_t)(pos - base), secEndR = (uint32_t)min(recEnd - base, (uint64_t)0x7fffff00u);
 		const uint32_t segEnd = min(p0 + (uint32_t)(lane + 1) * B, secEndR);
 		uint32_t s = lane == 0 ? min(p0, secEndR) : min(p0 + (uint32_t)lane * B, secEndR);
-		if (lane > 0 && s < secEndR && R) { // run-in: lock onto the code boundaries before the segment starts
+		if (g.dbg & 0x800) { resDone = nRes; break; } // (timing experiments only, scripts/r6g.sh: the tile's stage and nothing else)
+		if (lane > 0 && s < secEndR && R && !(g.dbg & 0x1000)) { // run-in: lock onto the code boundaries before the segment starts
 			uint32_t p = s - min(R, s - p0);
 			int e2 = 0;
 			while (p < s && !e2) (void)w1_residual<DEF>(g, lw, src, p, e2);
@@ -1094,7 +1091,7 @@ __device__ __forceinline__ void coop_residuals_w1(const GraphDev &g, int32_t x, 
 		for (int round = 0; round < 66; round++) { // a segment starts where its left neighbour ended
 			uint32_t ns = (uint32_t)__shfl_up((int)e, 1, 64);
 			const bool dirty = lane > 0 && ns != s;
-			if (!__any(dirty)) break;
+			if (!__any(dirty) || (g.dbg & 0x2000)) break;
 			if (g.stats && lane == 0) atomicAdd(&g.stats[56], 1ull);
 			if (dirty) { s = ns; if (s < segEnd) parse(); else { c = 0; sum = 0; e = s; } }
 		}
@@ -1135,45 +1132,19 @@ __device__ __forceinline__ void coop_residuals_w1(const GraphDev &g, int32_t x, 
 		int32_t before = ic ? iv_p(ii) : 0, nextLeft = (cn && ic) ? iv_left(ii) : 0x7fffffff;
 		uint32_t p = pCK;
 		WT(4);
-		// eight ids per lane at a time into LDS (row u: [u][lane], no bank conflict), then eight store instructions, each for eight lanes' runs of eight
-		lds_u32 *sv = (lds_u32 *)(lds + CoopLds<1>::OFF_STG), *sp = sv + 8 * 64;
-		if (!(g.dbg & 512)) { // (experiment switch: the direct stores of round 5)
-			if (!(g.dbg & 128)) for (int32_t k2 = 0; k2 < cn; k2++) {
-				const int32_t add = k2 < CK ? (int32_t)cache[k2 * 64 + lane] : (int32_t)w1_residual<DEF>(g, lw, src, p, err) + 1;
-				val += add;
-				if (nextLeft < val) {
-					do { list[ii].rank = jj; ii++; nextLeft = iv_left(ii); } while (nextLeft < val); // interval ii sits after jj residuals
-					before = iv_p(ii);
-				}
-				if (!(g.dbg & 32)) out[jj + before] = val;
-				jj++;
+		// (the ids go straight to the row, a run per lane: handing them to the stores through LDS -- eight lanes' runs of eight per instruction, ~10 lines touched instead of 64 --
+		// made the kernel 6 % SLOWER, and without its stores the loop is 3 % faster: the value pass is a third of the kernel for what it issues, not for what it stores;
+		// profiles/r6_experiments.txt section 3)
+		if (!(g.dbg & 128)) // (timing experiments only)
+		for (int32_t k2 = 0; k2 < cn; k2++) {
+			const int32_t add = k2 < CK ? (int32_t)cache[k2 * 64 + lane] : (int32_t)w1_residual<DEF>(g, lw, src, p, err) + 1;
+			val += add;
+			if (nextLeft < val) {
+				do { list[ii].rank = jj; ii++; nextLeft = iv_left(ii); } while (nextLeft < val); // interval ii sits after jj residuals
+				before = iv_p(ii);
 			}
-		} else
-		for (int32_t k0 = 0; __any(k0 < cn); k0 += 8) {
-#pragma unroll
-			for (int u = 0; u < 8; u++) {
-				const int32_t k2 = k0 + u;
-				int32_t at = -1;
-				if (k2 < cn) {
-					const int32_t add = k2 < CK ? (int32_t)cache[k2 * 64 + lane] : (int32_t)w1_residual<DEF>(g, lw, src, p, err) + 1;
-					val += add;
-					if (nextLeft < val) {
-						do { list[ii].rank = jj; ii++; nextLeft = iv_left(ii); } while (nextLeft < val); // interval ii sits after jj residuals
-						before = iv_p(ii);
-					}
-					at = jj + before;
-					jj++;
-				}
-				sv[u * 64 + lane] = (uint32_t)val; sp[u * 64 + lane] = (uint32_t)at;
-			}
-			G.sync();
-#pragma unroll
-			for (int r = 0; r < 8; r++) {
-				const int idx = (lane & 7) * 64 + 8 * r + (lane >> 3);
-				const int32_t at = (int32_t)sp[idx], vv = (int32_t)sv[idx];
-				if (at >= 0) out[at] = vv;
-			}
-			G.sync();
+			out[jj + before] = val;
+			jj++;
 		}
 		const unsigned long long has = __ballot(cn > 0);
 		const int lastL = has ? 63 - __clzll((long long)has) : 0;
@@ -1295,37 +1266,17 @@ __device__ __forceinline__ void coop_parse_node(const GraphDev &g, int32_t x, in
 	}
 	G.sync_global();
 	if (NW == 1 && DEF != 0 && ic < 0x7fffffff && nRes < 0x7fffffff) { // one wave, default codings: every codeword decoded once
-		if (nRes > 0) coop_residuals_w1<DEF>(g, x, pos, recEnd, nRes, ic, intervalArcs, list, row + copied, lds, err);
+		if (nRes > 0 && !(g.dbg & 0x4000)) coop_residuals_w1<DEF>(g, x, pos, recEnd, nRes, ic, intervalArcs, list, row + copied, lds, err);
 		COOP_TICK(2);
-		if (ic > 0) { // phase X: interval i occupies out[pstart + rank .. + len)  (IntIntervalSequenceIterator.java:64-78)
+		if (ic > 0 && !(g.dbg & 0x8000)) { // phase X: interval i occupies out[pstart + rank .. + len)  (IntIntervalSequenceIterator.java:64-78)
 			G.sync_global();
 			int32_t *out = row + copied;
-			lds_u32 *xs = (lds_u32 *)(lds + CoopLds<1>::OFF_STG), *xl = xs + 64, *xp = xs + 128; // (the value pass's staging rows are free)
 			for (int64_t i0 = 0; i0 < ic; i0 += 64) {
 				const int64_t i = i0 + tid;
 				int32_t left = 0, len = 0; int64_t p = 0;
 				if (i < ic) { const IvEntry en = list[i]; left = en.left; len = en.len; p = (int64_t)en.pstart + en.rank; }
-				const bool flat = (g.dbg & 1024) != 0; // (experiment switch)
-				const bool isLong = len > (flat ? 64 : 16);
-				if (!flat) { if (!isLong && !(g.dbg & 64)) for (int32_t t = 0; t < len; t++) out[p + t] = left + t; }
-				else { // the short intervals of these 64, flat: id f of their concatenation by thread f mod 64 -- consecutive threads write consecutive ids of the same few intervals
-				  // (a lane per interval wrote 64 different lines with every store)
-					const int32_t ls = isLong ? 0 : len;
-					int32_t incl = ls;
-#pragma unroll
-					for (int o = 1; o < 64; o <<= 1) { const int32_t t2 = __shfl_up(incl, o, 64); if (tid >= o) incl += t2; }
-					const int32_t tot = __shfl(incl, 63, 64);
-					xs[tid] = (uint32_t)(incl - ls); xl[tid] = (uint32_t)left; xp[tid] = (uint32_t)p; // (p < 2^31: a position inside the row)
-					G.sync();
-					for (int32_t f = tid; f < tot; f += 64) {
-						int o = 0; // the last interval that starts at or before f (the empty ones among them start where the next one does)
-#pragma unroll
-						for (int st = 32; st > 0; st >>= 1) if ((int32_t)xs[o + st] <= f) o += st;
-						const int32_t k = f - (int32_t)xs[o];
-						out[(int32_t)xp[o] + k] = (int32_t)xl[o] + k;
-					}
-					G.sync();
-				}
+				const bool isLong = len > 16;
+				if (!isLong) for (int32_t t = 0; t < len; t++) out[p + t] = left + t; // (the short ones flat over the wave -- id f of their concatenation by lane f mod 64 -- cost 3 % more: r6_experiments.txt)
 				unsigned long long lm = __ballot(isLong);
 				while (lm) {
 					const int srcl = __ffsll((long long)lm) - 1;

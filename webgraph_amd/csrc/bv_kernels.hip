@@ -1543,7 +1543,7 @@ template <int DEF, int NW, class View>
 #ifndef COOPG_MINWAVES
 #define COOPG_MINWAVES 1
 #endif
-__global__ void __launch_bounds__(64 * NW, NW == 1 ? COOP1_MINWAVES : COOPG_MINWAVES) k_parse_big(GraphDev g, View v, const int32_t *__restrict__ list, int32_t *__restrict__ ctl, int which,
+__device__ __forceinline__ void parse_big_body(const GraphDev &g, const View &v, const int32_t *__restrict__ list, int32_t *__restrict__ ctl, int which,
                                                        IvEntry *__restrict__ arena, int64_t arenaCap, int *__restrict__ err) {
 	__shared__ __attribute__((aligned(16))) uint32_t lds[CoopLds<NW>::WORDS];
 	__shared__ int32_t s_idx;
@@ -1582,6 +1582,11 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? COOP1_MINWAVES : COOPG_MINW
 		}
 		if (g.stats) { const unsigned long long dt = __builtin_readcyclecounter() - t0; stat_add(g, 5, 1); stat_add(g, 6, dt); stat_max(g, 7, dt); }
 	}
+}
+template <int DEF, int NW, class View>
+__global__ void __launch_bounds__(64 * NW, NW == 1 ? COOP1_MINWAVES : COOPG_MINWAVES) k_parse_big(GraphDev g, View v, const int32_t *__restrict__ list, int32_t *__restrict__ ctl, int which,
+                                                       IvEntry *__restrict__ arena, int64_t arenaCap, int *__restrict__ err) {
+	parse_big_body<DEF, NW, View>(g, v, list, ctl, which, arena, arenaCap, err);
 }
 
 // ------------------------------------------------------------------------------------------------ copy
@@ -1729,62 +1734,48 @@ __device__ __forceinline__ void copy_node_tab(int32_t d, int32_t dref, int32_t *
 	const int32_t kept = (int32_t)((uint32_t)hd.w & 0xffffu), copied = (int32_t)((uint32_t)hd.w >> 16);
 	if (copied == 0 || copied > d) return; // the extras are the row
 	auto entry = [&](int32_t b) -> uint32_t { return (uint32_t)(b == 0 ? hd.z : b == 1 ? hd.y : b == 2 ? hd.x : tabEnd[2 - b]); };
-	if (!VEC) {
-		int32_t k = 0, j = copied;
-		int32_t ev = j < d ? row[j] : 0;
-		for (int32_t b = 0; b < kept; b++) {
-			const uint32_t en = entry(b);
-			int32_t i = (int32_t)(en >> 16);
-			const int32_t end = min(i + (int32_t)(en & 0xffffu), dref);
-			for (; i < end && k < d; i++) {
-				const int32_t cv = src[i];
-				while (j < d && ev < cv) { row[k++] = ev; j++; if (j < d) ev = row[j]; }
-				if (j < d && ev == cv) { j++; if (j < d) ev = row[j]; } // equal heads emitted once (never in a valid file)
-				row[k++] = cv;
-			}
-		}
-		// remaining extras row[j..d) are already in place when k == j; a malformed duplicate leaves a gap: pad with -1
-		if (k != j) { while (j < d) row[k++] = row[j++]; while (k < d) row[k++] = -1; }
-		return;
-	}
-	// 16 bytes at a time (copy_node_v)
-	int32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0, en = 0, ej = copied;
+	// The merged ids leave four at a time, in ONE 16-byte store at row + k - 4 whatever its alignment (gfx950 takes dwordx4 on 4-byte boundaries: scripts/ubench_store.hip) -- a
+	// memory instruction of this kernel touches 64 lines whatever it carries, so what it issues per id is what it costs.  In place: the store covers k - 4 .. k - 1 with k <= j,
+	// the index of the first extra not yet consumed, and every extra below j (the buffered ones too) has been read by then.
+	int32_t k = 0, o0 = 0, o1 = 0, o2 = 0, o3 = 0;
+	auto emit = [&](int32_t val) {
+		o0 = o1; o1 = o2; o2 = o3; o3 = val; k++;
+		if ((k & 3) == 0) *(i32x4_u *)(row + k - 4) = i32x4_u{ o0, o1, o2, o3 };
+	};
+	// the extras row[copied .. d): VEC four at a time (the lane class of a web-shaped graph: long enough rows), else one by one
+	int32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0, en = 0, ej = copied; // buffered extras (e0 is the head), how many, index of the next one to load
 	auto ext_fill = [&] {
-		if (ej + 4 <= d) { const i32x4_u q = *(const i32x4_u *)(row + ej); e0 = q.x; e1 = q.y; e2 = q.z; e3 = q.w; en = 4; ej += 4; }
+		if (VEC && ej + 4 <= d) { const i32x4_u q = *(const i32x4_u *)(row + ej); e0 = q.x; e1 = q.y; e2 = q.z; e3 = q.w; en = 4; ej += 4; }
 		else if (ej < d) { e0 = row[ej++]; en = 1; }
 	};
-	auto ext_pop = [&] { e0 = e1; e1 = e2; e2 = e3; if (--en == 0) ext_fill(); };
+	auto ext_pop = [&] { if (VEC) { e0 = e1; e1 = e2; e2 = e3; } if (--en == 0) ext_fill(); };
 	ext_fill();
-	int32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, sn = 0;
-	int32_t k = 0, o0 = 0, o1 = 0, o2 = 0, o3 = 0, on = 0;
-	const int32_t head = min(d, (int32_t)(((16u - ((uint32_t)(uintptr_t)row & 15u)) & 15u) >> 2));
-	auto emit = [&](int32_t val) {
-		if (k < head) { row[k++] = val; return; }
-		o0 = o1; o1 = o2; o2 = o3; o3 = val; k++;
-		if (++on == 4) { *(int4 *)(row + k - 4) = int4{ o0, o1, o2, o3 }; on = 0; }
-	};
+	int32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, sn = 0; // the referent's ids, VEC: four at a time inside a copied block
 	for (int32_t b = 0; b < kept; b++) {
 		const uint32_t ent = entry(b);
 		int32_t i = (int32_t)(ent >> 16);
 		const int32_t end = min(i + (int32_t)(ent & 0xffffu), dref);
 		sn = 0;
-		while (i < end && k < d) {
+		while (i < end && k < d) { // (the bounds hold for a table of the parse kernel's: belt and braces)
 			if (sn == 0) {
-				if (i + 4 <= end) { const i32x4_u q = *(const i32x4_u *)(src + i); s0 = q.x; s1 = q.y; s2 = q.z; s3 = q.w; sn = 4; }
+				if (VEC && i + 4 <= end) { const i32x4_u q = *(const i32x4_u *)(src + i); s0 = q.x; s1 = q.y; s2 = q.z; s3 = q.w; sn = 4; }
 				else { s0 = src[i]; sn = 1; }
 			}
 			const int32_t cv = s0;
-			s0 = s1; s1 = s2; s2 = s3; sn--; i++;
+			if (VEC) { s0 = s1; s1 = s2; s2 = s3; }
+			sn--; i++;
 			while (en && e0 < cv && k < d) { emit(e0); ext_pop(); }
 			if (en && e0 == cv) ext_pop(); // equal heads emitted once (never in a valid file)
 			emit(cv);
 		}
 	}
-	const int32_t left = en + (d - ej);
+	// the remaining extras are in place already when no duplicate was dropped (k + remaining == d)
+	const int32_t left = en + (d - ej); // extras not emitted yet
 	if (k + left != d) { // a malformed duplicate left a gap: move the rest down, pad with -1 (as copy_node)
 		while (en && k < d) { emit(e0); ext_pop(); }
 		while (k < d) emit(-1);
 	}
+	const int32_t on = k & 3; // the ids still in the buffer
 	if (on == 3) { row[k - 3] = o1; row[k - 2] = o2; row[k - 1] = o3; }
 	else if (on == 2) { row[k - 2] = o2; row[k - 1] = o3; }
 	else if (on == 1) row[k - 1] = o3;

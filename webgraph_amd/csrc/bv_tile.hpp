@@ -177,8 +177,7 @@ __device__ __forceinline__ void parse_node_tile(const GraphDev &g, const TWin &t
 	int32_t *out = row + copied;
 	const int32_t nExtra = (int32_t)extra;
 	int32_t k = 0;
-	const int32_t head = min(nExtra, (int32_t)(((16u - ((uint32_t)(uintptr_t)out & 15u)) & 15u) >> 2));
-	int32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0, on = 0;
+	int32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0; // (four ids per store, at out + k - 4 whatever its alignment: gfx950 takes dwordx4 on 4-byte boundaries -- no scalar head, round 6)
 	int32_t ivLeft = 0, ivRem = 0, ivPrev = 0;
 	int32_t ivTodo = (int32_t)nIntervals;
 	bool firstIv = true;
@@ -200,10 +199,10 @@ __device__ __forceinline__ void parse_node_tile(const GraphDev &g, const TWin &t
 			if (ivRem && ivLeft == resVal) { ivLeft++; ivRem--; } // equal heads are emitted once (MergedIntIterator.java:69-72)
 			if (--resTodo) resVal += (int32_t)br.code<0, ZK>(tw, zk, e) + 1; // BVG:966
 		} else val = -1; // malformed: fewer values than the outdegree promises (BVG:1210 would store -1)
-		if (k < head) { out[k++] = val; continue; }
 		o0 = o1; o1 = o2; o2 = o3; o3 = val; k++;
-		if (++on == 4) { *(int4 *)(out + k - 4) = int4{ o0, o1, o2, o3 }; on = 0; }
+		if ((k & 3) == 0) *(i32x4_a4 *)(out + k - 4) = i32x4_a4{ o0, o1, o2, o3 };
 	}
+	const int32_t on = k & 3;
 	if (on == 3) { out[k - 3] = o1; out[k - 2] = o2; out[k - 1] = o3; }
 	else if (on == 2) { out[k - 2] = o2; out[k - 1] = o3; }
 	else if (on == 1) out[k - 1] = o3;
