@@ -37,6 +37,7 @@ namespace bv {
 // capped at INT32_MAX, which no count exceeds -- `s < cnt` then holds for real items only (as a plain int32 the last block's idle threads went negative and passed it).
 __device__ __forceinline__ int32_t item_of(uint32_t i) { return (int32_t)(i < 0x7fffffffu ? i : 0x7fffffffu); }
 
+typedef long long i64x2_a8 __attribute__((ext_vector_type(2), aligned(8))); // two neighbouring int64 (row starts, offsets) in one load
 constexpr int TPB = 256;
 constexpr int GIANT_NW = COOP_GIANT_NW; // waves per giant record
 
@@ -591,7 +592,8 @@ __global__ void __launch_bounds__(TPB) k_copy_list(GraphDev g, RangeView v, cons
 		const int32_t r = v.ref[s];
 		if (r == 0 || (level >= MAXLVL - 1 && depth[s] != level)) continue;
 		const int32_t t = s - r;
-		const int64_t rs0 = v.rowstart[s], rs1 = v.rowstart[s + 1], rt0 = v.rowstart[t], rt1 = v.rowstart[t + 1];
+		const i64x2_a8 rsp = *(const i64x2_a8 *)(v.rowstart + s), rtp = *(const i64x2_a8 *)(v.rowstart + t); // (a 16-byte load per pair of row starts)
+		const int64_t rs0 = rsp.x, rs1 = rsp.y, rt0 = rtp.x, rt1 = rtp.y;
 		if (!(s >= v.nh ? (uint64_t)(rs1 - rsNh) <= v.succ_cap : (uint64_t)rs1 <= v.halo_cap) || !(t >= v.nh ? (uint64_t)(rt1 - rsNh) <= v.succ_cap : (uint64_t)rt1 <= v.halo_cap)) continue; // E_CAP / E_HALO already raised by the parse kernel
 		const int32_t d = (int32_t)(rs1 - rs0), dref = (int32_t)(rt1 - rt0);
 		if (copy_class_of(d, dref, midMin, bigMin) != 1) continue;
@@ -1317,13 +1319,20 @@ __global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, con
 	};
 	int32_t sCur = entry(0), sNext = entry(1);
 	int32_t d = 0, r = 0; int64_t ra = 0, rb = 0; uint64_t oa = 0, ob = 0;
-	if (sCur >= 0) { d = v.outd[sCur]; r = v.ref[sCur]; ra = v.rowstart[sCur]; rb = v.rowstart[sCur + 1]; oa = (uint64_t)g.offsets[v.lo + sCur]; ob = (uint64_t)g.offsets[v.lo + sCur + 1]; }
+	// (rowstart[s], rowstart[s + 1] and offsets[x], offsets[x + 1] by ONE 16-byte load each: every load of this kernel goes to a line of its own and costs its CU as much
+	// whatever it carries -- scripts/ubench_lines.hip)
+	auto fetch_meta = [&](int32_t sc) {
+		d = v.outd[sc]; r = v.ref[sc];
+		const i64x2_a8 rr = *(const i64x2_a8 *)(v.rowstart + sc), oo = *(const i64x2_a8 *)(g.offsets + (v.lo + sc));
+		ra = rr.x; rb = rr.y; oa = (uint64_t)oo.x; ob = (uint64_t)oo.y;
+	};
+	if (sCur >= 0) fetch_meta(sCur);
 	for (int64_t sweep = 0; sweep * G < N; sweep++) {
 		const int32_t s = sCur, dC = d, rC = r; const int64_t raC = ra, rbC = rb; const uint64_t oaC = oa, obC = ob;
 		const int32_t drefC = s >= 0 && rC > 0 ? v.outd[s - rC] : 0;
 		sCur = sNext; sNext = entry(sweep + 2);
 		d = 0;
-		if (sCur >= 0) { d = v.outd[sCur]; r = v.ref[sCur]; ra = v.rowstart[sCur]; rb = v.rowstart[sCur + 1]; oa = (uint64_t)g.offsets[v.lo + sCur]; ob = (uint64_t)g.offsets[v.lo + sCur + 1]; }
+		if (sCur >= 0) fetch_meta(sCur);
 		if (s < 0 || dC >= coopMin || dC == 0) continue; // decoded by whole waves (k_parse_big) / nothing to decode
 		const bool fits = s >= v.nh ? (uint64_t)(rbC - rs0) <= v.succ_cap : (uint64_t)rbC <= v.halo_cap; // (RangeView::fits)
 		if (!fits) { atomicOr(err, s >= v.nh ? E_CAP : E_HALO); continue; }

@@ -66,6 +66,25 @@ template <int NWORDS> struct LaneWin {
 		q = (uint32_t)(pos - (w0 << 5));
 		fill(g);
 	}
+	// Called where the wave is converged, for records of `bits` bits from pos on: when EVERY lane's record (and the two words its decoders look ahead) ends inside the first half
+	// of the window, only that half is fetched -- two 16-byte loads per lane instead of four (each goes to a line of its own: scripts/ubench_lines.hip); the other half keeps
+	// what it held, which nothing reads (no cursor gets there: a record that ends in the first half never triggers a refill).
+	__device__ __forceinline__ void seek_short(const GraphDev &g, uint64_t pos, uint64_t bits) {
+		w0 = (pos >> 5) & ~(uint64_t)3;
+		q = (uint32_t)(pos - (w0 << 5));
+		if (__builtin_amdgcn_ballot_w64((uint64_t)q + bits + 64 > (uint64_t)NWORDS * 16) != 0) { fill(g); return; }
+		constexpr int NV = NWORDS / 8;
+		uint4 v[NV];
+#pragma unroll
+		for (int k = 0; k < NV; k++) v[k] = *(const uint4 *)(g.bits + min(w0 + 4 * k, vlast));
+#pragma unroll
+		for (int k = 0; k < NV; k++) {
+			col[(4 * k + 0) * LW_STRIDE] = __builtin_bswap32(v[k].x);
+			col[(4 * k + 1) * LW_STRIDE] = __builtin_bswap32(v[k].y);
+			col[(4 * k + 2) * LW_STRIDE] = __builtin_bswap32(v[k].z);
+			col[(4 * k + 3) * LW_STRIDE] = __builtin_bswap32(v[k].w);
+		}
+	}
 	__device__ __forceinline__ uint64_t pos() const { return (w0 << 5) + q; }
 	// Called where the wave is converged: if ANY lane is about to run out of window, ALL lanes move theirs up to
 	// their cursor.  Left to themselves the lanes would each stall the whole wave for a memory round trip at a
@@ -356,7 +375,10 @@ __device__ __forceinline__ void parse_node_lwc(const GraphDev &g, int32_t x, int
 	uint32_t *const ring = lds + LW_MAIN * LW_STRIDE + threadIdx.x; // entry j of the ring: ring[2 j * LW_STRIDE] = left, ring[(2 j + 1) * LW_STRIDE] = length
 	br.vlast = min(((off1 >> 5) + 2) & ~(uint64_t)3, (g.nwords + 4) & ~(uint64_t)3);
 	const bool hasRef = r > 0;
-	br.seek(g, off0 + (2u * (31u - (uint32_t)__clz((int)((uint32_t)d + 1u))) + 1u) + (g.W > 0 ? (uint32_t)r + 1u : 0u)); // behind the outdegree and the reference (BVG:1048-1054; k_headers read them)
+	{
+		const uint64_t at = off0 + (2u * (31u - (uint32_t)__clz((int)((uint32_t)d + 1u))) + 1u) + (g.W > 0 ? (uint32_t)r + 1u : 0u); // behind the outdegree and the reference (BVG:1048-1054; k_headers read them)
+		br.seek_short(g, at, off1 > at ? off1 - at : 0);
+	}
 	int e = 0;
 	int32_t copied = 0;
 	const bool tab = hasRef && ctab != nullptr;
@@ -487,7 +509,7 @@ __device__ __forceinline__ void parse_node_lwc(const GraphDev &g, int32_t x, int
 			}
 		}
 		const int32_t v0 = trip(k0), v1 = trip(k0 + 1), v2 = trip(k0 + 2), v3 = trip(k0 + 3);
-		if (!HASH || hstore) {
+		if ((!HASH || hstore) && !(g.dbg & 0x10000)) { // (0x10000: timing experiments only)
 			const int32_t left = extra - k0;
 			if (left >= 4) *(i32x4_a4 *)(out + k0) = i32x4_a4{ v0, v1, v2, v3 };
 			else if (left > 0) { out[k0] = v0; if (left > 1) out[k0 + 1] = v1; if (left > 2) out[k0 + 2] = v2; }
