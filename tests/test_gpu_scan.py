@@ -265,6 +265,11 @@ KNOBS = [
     {"BVGPU_TILE": "0", "BVGPU_COOP_MIN": "2147483647"}, {"BVGPU_SCAN_TOP_TILED_MIN": "1"},
     {"BVGPU_WAIT_GIANTS": "0", "BVGPU_COOP_MIN": "16", "BVGPU_GIANT_MIN": "64"},
     {"BVGPU_PREWALK": "0"}, {"BVGPU_COPY_VEC": "1"}, {"BVGPU_COPY_VEC": "1", "BVGPU_COPY_MID_MIN": "16", "BVGPU_COOP_MIN": "16", "BVGPU_GIANT_MIN": "64"},
+    # round 6: round 4's one-lane loop instead of the sentinel loop (no copy tables then), the lane class of the copy pass walking the stream although the tables exist,
+    # tables with the tile kernel and with the vector merge, the parse list's keys by k_depth_keys, the giants not waiting for the parse list
+    {"BVGPU_LANE_LOOP": "0", "BVGPU_TILE": "0"}, {"BVGPU_COPY_TABLES": "0", "BVGPU_TILE": "0"}, {"BVGPU_TILE": "0", "BVGPU_COPY_VEC": "1"}, {"BVGPU_TILE": "1", "BVGPU_COPY_VEC": "0"},
+    {"BVGPU_TILE": "0", "BVGPU_COPY_MID_MIN": "1024", "BVGPU_COOP_MIN": "2147483647"}, {"BVGPU_TILE": "0", "BVGPU_COPY_MID_MIN": "1000", "BVGPU_COOP_MIN": "64", "BVGPU_GIANT_MIN": "4000"},
+    {"BVGPU_KEYS_IN_HEADERS": "0", "BVGPU_TILE": "0"}, {"BVGPU_GIANTS_AFTER_LIST": "0", "BVGPU_TILE": "0", "BVGPU_COOP_MIN": "16", "BVGPU_GIANT_MIN": "64"},
 ]
 
 
@@ -282,6 +287,52 @@ def test_tuning_knobs_keep_parity(tmp_path_factory, monkeypatch, env):
     rp, sc = g.decode_range(12345, 23456)
     assert np.array_equal(sc, succ[rowptr[12345]:rowptr[23456]])
     g.close()
+
+
+@pytest.mark.parametrize("mi", [0, 1, 2, 3, 4, 5, 7, 16])
+@pytest.mark.parametrize("tile", ["0", "1"])
+def test_copy_tables_of_the_lane_class(tmp_path, monkeypatch, mi, tile):
+    """The copy blocks that the one-lane parse leaves as tables for the lane class of the copy pass (round 6; CopyTab, bv_lanewin.hpp): rows that keep MANY blocks of their
+    referent (single ids, every second one: up to 60 kept blocks -- the table's first three entries sit in the slot, the others at the end of the record's own part of the
+    interval arena, which is 16 floor(d / minIntervalLength) bytes: too small for some of these rows, which then walk the stream), beside rows with many intervals (nine and
+    more: their list goes through the arena too), for minIntervalLength 0 (no arena at all), powers of two and others; both one-lane parse kernels, the plain and the vector merge."""
+    from webgraph_amd import tools as T
+    from webgraph_amd.bvgraph import BVGraph
+    monkeypatch.setenv("BVGPU_TILE", tile)
+    rng = np.random.Generator(np.random.PCG64(100 + mi))
+    n = 6000
+    rows = []
+    for x in range(n):
+        k = x % 12
+        if x == 0 or k == 0:  # a prototype: 40 .. 120 ids, some of them in runs
+            base = np.unique(np.concatenate([rng.integers(0, n, size=int(rng.integers(30, 100)))] + [np.arange(r, r + int(rng.integers(2, 12))) for r in rng.integers(0, n - 20, size=4)]))
+            rows.append(base)
+        elif k in (1, 2, 3):  # every second id of its predecessor (single-id blocks), a few of its own
+            prev = rows[-1]
+            rows.append(np.unique(np.concatenate([prev[::2], rng.integers(0, n, size=int(rng.integers(0, 4)))])))
+        elif k in (4, 5):  # the predecessor with stretches dropped, plus twelve short runs of its own (many intervals)
+            prev = rows[-1]
+            keep = prev[(np.arange(prev.size) // 3) % 2 == 0]
+            rows.append(np.unique(np.concatenate([keep] + [np.arange(r, r + int(rng.integers(2, 9))) for r in rng.integers(0, n - 10, size=12)])))
+        elif k == 6:
+            rows.append(np.empty(0, dtype=np.int64))
+        else:  # short rows copying one or two ids
+            prev = rows[-1] if rows[-1].size else rows[-2]
+            rows.append(np.unique(np.concatenate([prev[:int(rng.integers(0, 3))], rng.integers(0, n, size=int(rng.integers(0, 3)))])))
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    rowptr[1:] = np.cumsum([r.size for r in rows])
+    succ = np.concatenate(rows).astype(np.int32)
+    base = str(tmp_path / ("tabs%d" % mi))
+    st = T.store(base, rowptr, succ, window=7, max_ref_count=3, min_interval=mi, zeta_k=3)
+    assert st["copied_arcs"] > succ.size // 4
+    for vec in ("0", "1"):
+        monkeypatch.setenv("BVGPU_COPY_VEC", vec)
+        g = BVGraph.load(base)
+        rp, sc = g.decode_range()
+        assert np.array_equal(rp, rowptr) and np.array_equal(sc, succ), (mi, tile, vec)
+        rp, sc = g.decode_range(1234, 4321)
+        assert np.array_equal(sc, succ[rowptr[1234]:rowptr[4321]])
+        g.close()
 
 
 def _long_rows_graph(n=120000, seed=5):

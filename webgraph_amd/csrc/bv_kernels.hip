@@ -2097,7 +2097,6 @@ void launch_headers(const GraphDev &g, int def, int32_t lo, int32_t cnt, int32_t
                     uint16_t *pkey16, int32_t *phist, bool pwindows) {
 	if (cnt <= 0) return;
 	if (mark) (void)hipMemsetAsync(mark, 0, (size_t)cnt, st);
-	if (pkey16) (void)hipMemsetAsync(phist, 0, sizeof(int32_t) * NKEYS, st);
 	if (def == 1) hipLaunchKernelGGL(k_headers<1>, dim3(nblk(cnt, TPB)), dim3(TPB), 0, st, g, lo, cnt, outd, ref, err, part, mark, pkey16, phist, pwindows ? 1 : 0);
 	else if (def == 2) hipLaunchKernelGGL(k_headers<2>, dim3(nblk(cnt, TPB)), dim3(TPB), 0, st, g, lo, cnt, outd, ref, err, part, mark, pkey16, phist, pwindows ? 1 : 0);
 	else hipLaunchKernelGGL(k_headers<0>, dim3(nblk(cnt, TPB)), dim3(TPB), 0, st, g, lo, cnt, outd, ref, err, part, mark, pkey16, phist, pwindows ? 1 : 0);
@@ -2105,6 +2104,7 @@ void launch_headers(const GraphDev &g, int def, int32_t lo, int32_t cnt, int32_t
 // the parse list from keys and a histogram that k_headers left (launch_headers with pkey16): the two kernels that remain of launch_build_lists
 void launch_scatter_lists(int32_t cnt, const uint16_t *key16, const int32_t *hist, int32_t *keyBase, int32_t *cursor, int32_t *list, int32_t *giantlist, int32_t *ctl, int32_t *maxdepth, hipStream_t st) {
 	if (cnt <= 0) return;
+	(void)hipMemsetAsync((void *)hist, 0, sizeof(int32_t) * NKEYS, st);
 	hipLaunchKernelGGL(k_key_hist, dim3(nblk(cnt, LIST_TILE)), dim3(TPB), 0, st, cnt, key16, (int32_t *)hist);
 	hipLaunchKernelGGL(k_key_offsets, dim3(1), dim3(TPB), 0, st, hist, keyBase, cursor, maxdepth);
 	hipLaunchKernelGGL(k_scatter_keys, dim3(nblk(cnt, LIST_TILE)), dim3(TPB), 0, st, cnt, key16, cursor, list, giantlist, 0, ctl);

@@ -696,7 +696,9 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			const int rc = build_levels(g->sideA, true);
 			if (rc) return rc;
 		}
-		if (earlyList && g->keys_ready) { // k_headers left the keys and their histogram: two kernels to the list
+		const bool keysReady = g->keys_ready; // (this job's: a job that did not go through enqueue_structure -- the masked scan of a dense batch -- must not see the last one's)
+		g->keys_ready = false;
+		if (earlyList && keysReady) { // k_headers left the keys: three small kernels to the list
 			HIPCHK(g, hipStreamWaitEvent(g->sideA, g->evHdr, 0));
 			bv::launch_scatter_lists(v.cnt, g->pkey16.as<uint16_t>(), g->pkeys.as<int32_t>(), pKeyBase, pKeyBase + (bv::NKEYS + 1), g->plist.as<int32_t>(), g->giantlist.as<int32_t>(), ctl,
 			                         &g->small.as<Small>()->pad, g->sideA);
@@ -1751,6 +1753,7 @@ extern "C" int bvg_successors_batch(bvg_t *g, const int32_t *nodes, size_t q, in
 		v.halo_cap = ~0ull;
 		v.lo = 0; v.cnt = n; v.nh = n; // every row lives in the arena ("halo" rows of the scan)
 		v.outd = g->outd.as<int32_t>(); v.ref = g->ref.as<uint16_t>(); v.rowstart = g->rowstart.as<int64_t>();
+		g->keys_ready = false; // (no parse-list keys from these headers: the marks change the outdegrees behind them)
 		bv::launch_headers(gd, s.def, 0, n, v.outd, v.ref, &dsm->err, g->stream);
 		// queries mark their nodes; the marks are closed under "is copied from" in streaming passes (as many as chains
 		// were deep last time, plus one that reports whether it still found something)
