@@ -40,6 +40,14 @@ __device__ __forceinline__ int32_t item_of(uint32_t i) { return (int32_t)(i < 0x
 typedef long long i64x2_a8 __attribute__((ext_vector_type(2), aligned(8))); // two neighbouring int64 (row starts, offsets) in one load
 constexpr int TPB = 256;
 constexpr int GIANT_NW = COOP_GIANT_NW; // waves per giant record
+#ifndef COOPG_STATIC_LDS
+#define COOPG_DYNLDS 1
+#endif
+#ifdef COOPG_DYNLDS
+constexpr unsigned GIANT_DYN_LDS = CoopLds<COOP_GIANT_NW>::WORDS * 4;
+#else
+constexpr unsigned GIANT_DYN_LDS = 0;
+#endif
 
 template <int DEF, bool HASH = false>
 __device__ __forceinline__ void copy_node(const GraphDev &g, int32_t x, int32_t d, int64_t dref, int32_t *__restrict__ row, const int32_t *__restrict__ src, int *__restrict__ err, uint32_t *hacc = nullptr, uint32_t hw = 0);
@@ -1550,11 +1558,21 @@ template <int DEF, int NW, class View>
 #define COOP1_MINWAVES 4
 #endif
 #ifndef COOPG_MINWAVES
-#define COOPG_MINWAVES 1
+#define COOPG_MINWAVES 3 // (round 6, with the groups' tile in dynamic LDS: 168 registers and 128 bytes of scratch per lane instead of 241 -- a group no longer takes every register of its CU)
 #endif
 __device__ __forceinline__ void parse_big_body(const GraphDev &g, const View &v, const int32_t *__restrict__ list, int32_t *__restrict__ ctl, int which,
                                                        IvEntry *__restrict__ arena, int64_t arenaCap, int *__restrict__ err) {
+#ifdef COOPG_DYNLDS
+	// The groups' tile in DYNAMIC LDS (round 6; -DCOOPG_STATIC_LDS: as before): with 99 KB of static LDS the compiler sees one group per CU and takes every register that leaves
+	// (241), whatever __launch_bounds__ asks for -- and a group of eight waves at 241 registers leaves its CU nothing to run beside it.  With the
+	// size out of its sight it honours COOPG_MINWAVES = 3: 168 registers, the kernel alone 0.77 -> 0.82 ms, the scan of C2 2.94 -> 2.83, of the C5 shard 5.35 -> 5.23
+	// (profiles/r6_experiments.txt section 6)
+	extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
+	__shared__ __attribute__((aligned(16))) uint32_t lds_st[NW == 1 ? CoopLds<NW>::WORDS : 4];
+	uint32_t *const lds = NW == 1 ? lds_st : lds_dyn;
+#else
 	__shared__ __attribute__((aligned(16))) uint32_t lds[CoopLds<NW>::WORDS];
+#endif
 	__shared__ int32_t s_idx;
 	const int32_t count = ctl[which]; // (the giant list is sized for arcs / giantMin entries, which bounds their number)
 	if (count <= 0) return; // (an empty list -- the usual state of the strip kernel's escape list -- costs no atomics)
@@ -2294,13 +2312,30 @@ void launch_wait_giants(const int32_t *ctl, int giantGroups, hipStream_t st) {
 	hipLaunchKernelGGL(k_wait_giants, dim3(1), dim3(64), 0, st, ctl, (int32_t)giantGroups);
 }
 
+// (COOPG_DYNLDS builds) the giants' tile is dynamic LDS of more than 64 KB: every instantiation is told so once
+static void giant_lds_attr() {
+#ifdef COOPG_DYNLDS
+	static const bool done = [] {
+		const int bytes = (int)GIANT_DYN_LDS;
+		(void)hipFuncSetAttribute((const void *)k_parse_big<1, GIANT_NW, RangeView>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+		(void)hipFuncSetAttribute((const void *)k_parse_big<2, GIANT_NW, RangeView>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+		(void)hipFuncSetAttribute((const void *)k_parse_big<0, GIANT_NW, RangeView>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+		(void)hipFuncSetAttribute((const void *)k_parse_big<1, GIANT_NW, BatchView>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+		(void)hipFuncSetAttribute((const void *)k_parse_big<2, GIANT_NW, BatchView>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+		(void)hipFuncSetAttribute((const void *)k_parse_big<0, GIANT_NW, BatchView>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+		return true;
+	}();
+	(void)done;
+#endif
+}
 void launch_parse_big(const GraphDev &g, int def, const RangeView &v, const int32_t *biglist, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap,
                       int waves, int giantGroups, int *err, hipStream_t stGiant, hipStream_t stBig, bool waitGiants) {
+	giant_lds_attr();
 	if (v.cnt <= 0) return;
 	if (giantGroups <= 0) {} // (the caller knows that the job has no giant record)
-	else if (def == 1) hipLaunchKernelGGL((k_parse_big<1, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
-	else if (def == 2) hipLaunchKernelGGL((k_parse_big<2, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
-	else hipLaunchKernelGGL((k_parse_big<0, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+	else if (def == 1) hipLaunchKernelGGL((k_parse_big<1, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), GIANT_DYN_LDS, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+	else if (def == 2) hipLaunchKernelGGL((k_parse_big<2, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), GIANT_DYN_LDS, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+	else hipLaunchKernelGGL((k_parse_big<0, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), GIANT_DYN_LDS, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
 	if (stBig != stGiant && waitGiants && giantGroups > 0) launch_wait_giants(ctl, giantGroups, stBig);
 	if (def == 1) hipLaunchKernelGGL((k_parse_big<1, 1, RangeView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
 	else if (def == 2) hipLaunchKernelGGL((k_parse_big<2, 1, RangeView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
@@ -2311,12 +2346,13 @@ void copy_thresholds(int32_t midMinKnob, bool bigGroups, int32_t &midMin, int32_
 // long records of a random-access batch: same classification, queues and cooperative kernels as a scan, over slots
 void launch_bparse_big(const GraphDev &g, int def, const BatchView &v, int32_t coopMin, int32_t giantMin, int32_t *biglist, int32_t *giantlist, int32_t giantCap, int32_t *ctl,
                        void *arena, int64_t arenaCap, int waves, int giantGroups, int *err, hipStream_t st, hipStream_t stGiant, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evGiant, hipEvent_t evBig) {
+	giant_lds_attr();
 	if (v.cnt <= 0) return;
 	launch_classify((int32_t)v.cnt, v.outd, nullptr, coopMin, giantMin, biglist, giantlist, giantCap, ctl, st);
 	if (stGiant != st) { (void)hipEventRecord(evFork, st); (void)hipStreamWaitEvent(stGiant, evFork, 0); (void)hipStreamWaitEvent(stBig, evFork, 0); }
-	if (def == 1) hipLaunchKernelGGL((k_parse_big<1, GIANT_NW, BatchView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
-	else if (def == 2) hipLaunchKernelGGL((k_parse_big<2, GIANT_NW, BatchView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
-	else hipLaunchKernelGGL((k_parse_big<0, GIANT_NW, BatchView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+	if (def == 1) hipLaunchKernelGGL((k_parse_big<1, GIANT_NW, BatchView>), dim3(giantGroups), dim3(64 * GIANT_NW), GIANT_DYN_LDS, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+	else if (def == 2) hipLaunchKernelGGL((k_parse_big<2, GIANT_NW, BatchView>), dim3(giantGroups), dim3(64 * GIANT_NW), GIANT_DYN_LDS, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+	else hipLaunchKernelGGL((k_parse_big<0, GIANT_NW, BatchView>), dim3(giantGroups), dim3(64 * GIANT_NW), GIANT_DYN_LDS, stGiant, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
 	if (def == 1) hipLaunchKernelGGL((k_parse_big<1, 1, BatchView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
 	else if (def == 2) hipLaunchKernelGGL((k_parse_big<2, 1, BatchView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
 	else hipLaunchKernelGGL((k_parse_big<0, 1, BatchView>), dim3(waves), dim3(64), 0, stBig, g, v, biglist, ctl, 0, (IvEntry *)arena, arenaCap, err);
@@ -2337,10 +2373,11 @@ void launch_build_lists(const GraphDev &g, const RangeView &v, uint64_t giantBit
 }
 
 void launch_parse_giants(const GraphDev &g, int def, const RangeView &v, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap, int giantGroups, int *err, hipStream_t st) {
+	giant_lds_attr();
 	if (v.cnt <= 0) return;
-	if (def == 1) hipLaunchKernelGGL((k_parse_big<1, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, st, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
-	else if (def == 2) hipLaunchKernelGGL((k_parse_big<2, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, st, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
-	else hipLaunchKernelGGL((k_parse_big<0, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), 0, st, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+	if (def == 1) hipLaunchKernelGGL((k_parse_big<1, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), GIANT_DYN_LDS, st, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+	else if (def == 2) hipLaunchKernelGGL((k_parse_big<2, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), GIANT_DYN_LDS, st, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
+	else hipLaunchKernelGGL((k_parse_big<0, GIANT_NW, RangeView>), dim3(giantGroups), dim3(64 * GIANT_NW), GIANT_DYN_LDS, st, g, v, giantlist, ctl, 1, (IvEntry *)arena, arenaCap, err);
 }
 
 void launch_parse_waves(const GraphDev &g, int def, const RangeView &v, const int32_t *biglist, int32_t *ctl, void *arena, int64_t arenaCap, int waves, int *err, hipStream_t st) {
