@@ -62,7 +62,7 @@ template <int NW> struct CoopLds { // LDS layout of one group, in 32-bit words
 	static constexpr int XCH_WORDS = 2 * (3 * NW + 8);                               // int64 exchange slots
 	static constexpr int OFF_WIN = 0, OFF_IVL = WIN_WORDS, OFF_XCH = ((OFF_IVL + 2 * (CoopCfg<NW>::IVCAP + 1) + 1) & ~1); // staged intervals: left[], pstart[]
 	static constexpr int OFF_CACHE = OFF_XCH + XCH_WORDS;                            // one wave per record: the gaps of the lane's segment, [slot][lane]
-	static constexpr int CACHE_WORDS = NW == 1 ? (COOP1_CK + 1) * 64 : 0; // (+ a row that takes the stores of lanes with nothing to keep: the straight-line parse has no branch for them)
+	static constexpr int CACHE_WORDS = NW == 1 ? COOP1_CK * 64 : 0;
 	static constexpr int WORDS = OFF_CACHE + CACHE_WORDS;
 };
 
@@ -1031,25 +1031,6 @@ __device__ __forceinline__ uint32_t w1_residual(const GraphDev &g, const lds_u32
 	return (uint32_t)sc.v;
 }
 
-#ifndef COOP1_STRAIGHT
-#define COOP1_STRAIGHT 1 // the one-wave residual phase as straight-line loops (round 6); 0: round 5's per-lane loops
-#endif
-// The same decoder without its branch: value and length of the residual code at q when it is a short one (false: w1_residual's slow path must read it)
-template <int DEF>
-__device__ __forceinline__ bool w2_peek(const GraphDev &g, const lds_u32 *lw, uint32_t q, uint32_t &v, uint32_t &len) {
-	const uint32_t j = q >> 5, sh = q & 31u;
-	const uint32_t a = lw[j], b = lw[j + 1];
-	const uint32_t W = (uint32_t)(((((uint64_t)a << 32) | b) << sh) >> 32);
-	const uint32_t h = (uint32_t)__clz((int)W); // 32 for W == 0
-	const uint32_t k = DEF == 1 ? 3u : (uint32_t)g.zetaK;
-	const uint32_t nb = k * h + k - 1;
-	const uint32_t mm = (W << ((h + 1) & 31u)) >> ((31u - nb) & 31u);
-	const uint32_t m = mm >> 1, left = 1u << ((k * h) & 31u);
-	const bool lng = m >= left;
-	v = lng ? mm - 1 : m + left - 1;
-	len = h + 1 + nb + (lng ? 1u : 0u);
-	return DEF == 1 ? h < 7 : (h + 2 + nb <= 32u && nb != 0);
-}
 template <int DEF>
 __device__ __forceinline__ void coop_residuals_w1(const GraphDev &g, int32_t x, uint64_t pos, uint64_t recEnd, int64_t nRes64, int64_t ic64, int64_t intervalArcs,
                                                   IvEntry *__restrict__ list, int32_t *__restrict__ out, uint32_t *lds, int &err) {
@@ -1084,67 +1065,14 @@ __device__ __forceinline__ void coop_residuals_w1(const GraphDev &g, int32_t x, 
 		const uint32_t segEnd = min(p0 + (uint32_t)(lane + 1) * B, secEndR);
 		uint32_t s = lane == 0 ? min(p0, secEndR) : min(p0 + (uint32_t)lane * B, secEndR);
 		if (g.dbg & 0x800) { resDone = nRes; break; } // (timing experiments only, scripts/r6g.sh: the tile's stage and nothing else)
-#if COOP1_STRAIGHT
-		// Straight-line loops (round 6): the wave walks every loop of this phase together -- the next code is read by every lane, kept or dropped by selects, the rare
-		// long codeword sits behind one vote -- instead of per-lane `while` loops, whose exec-mask code was as many scalar instructions as the kernel had vector ones
-		// (196 M + 151 M per C2 scan: profiles/r5_pmc_summary_c2.txt).
-		{ // run-in: lock onto the code boundaries before the segment starts
-			const bool ri = lane > 0 && s < secEndR && R != 0 && !(g.dbg & 0x1000);
-			uint32_t p = ri ? s - min(R, s - p0) : s;
-			bool bad = false;
-			while (__builtin_amdgcn_ballot_w64(ri && p < s && !bad) != 0) {
-				uint32_t v, len;
-				const bool ok = w2_peek<DEF>(g, lw, p, v, len);
-				const bool act = ri && p < s && !bad;
-				if (__builtin_amdgcn_ballot_w64(act && !ok) != 0) {
-					if (act && !ok) { const SlowCode sc = win_code_slow<DEF, 0>(&g, src.win, src.w0, src.nw, p); p = sc.q; bad = sc.err != 0; }
-					else if (act) p += len;
-				} else p += act ? len : 0u;
-			}
-			if (ri) s = bad ? s : min(p, secEndR);
-		}
-#else
 		if (lane > 0 && s < secEndR && R && !(g.dbg & 0x1000)) { // run-in: lock onto the code boundaries before the segment starts
 			uint32_t p = s - min(R, s - p0);
 			int e2 = 0;
 			while (p < s && !e2) (void)w1_residual<DEF>(g, lw, src, p, e2);
 			s = e2 ? s : min(p, secEndR);
 		}
-#endif
 		WT(1);
-		uint32_t e = 0, c = 0, pCK = 0; int32_t sum = 0;
-#if COOP1_STRAIGHT
-		auto parse = [&](bool who) { // the lanes of `who`: the codes that start in [s, segEnd) -- count, what they add to the running id, end; the first CK gaps kept
-			uint32_t p = s, cc = 0, pck = s;
-			int32_t ss = 0;
-			bool stop = false; // a speculative parse may run through garbage: errors only stop it
-			while (__builtin_amdgcn_ballot_w64(who && p < segEnd && !stop) != 0) {
-				uint32_t v, len;
-				const bool ok = w2_peek<DEF>(g, lw, p, v, len);
-				const bool act = who && p < segEnd && !stop;
-				uint32_t pn = p + len;
-				if (__builtin_amdgcn_ballot_w64(act && !ok) != 0) {
-					if (act && !ok) { const SlowCode sc = win_code_slow<DEF, 0>(&g, src.win, src.w0, src.nw, p); v = (uint32_t)sc.v; pn = sc.q; stop = sc.err != 0; }
-				}
-				const int32_t add = (firstTile && lane == 0 && cc == 0) ? (int32_t)nat2int(v) : (int32_t)v + 1; // BVG:954 / :966
-				const bool keep = act && cc < (uint32_t)CK;
-				cache[(keep ? cc : (uint32_t)CK) * 64 + lane] = (uint32_t)add; // (row CK: nobody reads it)
-				pck = keep ? pn : pck;
-				ss += act ? add : 0; cc += act ? 1u : 0u; p = act ? pn : p;
-			}
-			if (who) { c = cc; sum = ss; pCK = pck; e = stop ? secEndR : min(p, secEndR); }
-		};
-		parse(true);
-		WT(2);
-		for (int round = 0; round < 66; round++) { // a segment starts where its left neighbour ended
-			uint32_t ns = (uint32_t)__shfl_up((int)e, 1, 64);
-			const bool dirty = lane > 0 && ns != s;
-			if (!__any(dirty) || (g.dbg & 0x2000)) break;
-			if (g.stats && lane == 0) atomicAdd(&g.stats[56], 1ull);
-			if (dirty) s = ns;
-			parse(dirty); // (a lane whose new start lies behind its segment: no trip, c = 0, e = s)
-		}
-#else
+		uint32_t e, c, pCK; int32_t sum;
 		auto parse = [&]() { // the codes that start in [s, segEnd): count, what they add to the running id, end; the first CK gaps kept
 			c = 0; sum = 0;
 			uint32_t p = s;
@@ -1167,7 +1095,6 @@ __device__ __forceinline__ void coop_residuals_w1(const GraphDev &g, int32_t x, 
 			if (g.stats && lane == 0) atomicAdd(&g.stats[56], 1ull);
 			if (dirty) { s = ns; if (s < segEnd) parse(); else { c = 0; sum = 0; e = s; } }
 		}
-#endif
 		WT(3);
 		const int32_t cincl = wscan((int32_t)c), sincl = wscan(sum);
 		const int32_t tileTotal = __shfl(cincl, 63, 64);
@@ -1208,33 +1135,6 @@ __device__ __forceinline__ void coop_residuals_w1(const GraphDev &g, int32_t x, 
 		// (the ids go straight to the row, a run per lane: handing them to the stores through LDS -- eight lanes' runs of eight per instruction, ~10 lines touched instead of 64 --
 		// made the kernel 6 % SLOWER, and without its stores the loop is 3 % faster: the value pass is a third of the kernel for what it issues, not for what it stores;
 		// profiles/r6_experiments.txt section 3)
-#if COOP1_STRAIGHT
-		if (!(g.dbg & 128)) // (timing experiments only)
-		for (int32_t k2 = 0; __builtin_amdgcn_ballot_w64(k2 < cn) != 0; k2++) {
-			const bool act = k2 < cn;
-			int32_t add;
-			if (k2 < CK) add = (int32_t)cache[k2 * 64 + lane]; // (k2 is the wave's: a uniform branch)
-			else {
-				uint32_t v, len;
-				const bool ok = w2_peek<DEF>(g, lw, p, v, len);
-				uint32_t pn = p + len;
-				if (__builtin_amdgcn_ballot_w64(act && !ok) != 0) {
-					if (act && !ok) { const SlowCode sc = win_code_slow<DEF, 0>(&g, src.win, src.w0, src.nw, p); v = (uint32_t)sc.v; pn = sc.q; err |= sc.err; }
-				}
-				add = (int32_t)v + 1;
-				p = act ? pn : p;
-			}
-			val += act ? add : 0;
-			if (__builtin_amdgcn_ballot_w64(act && nextLeft < val) != 0) { // some lane's residual passes its next interval (one in fourteen does: most trips of a wave)
-				if (act && nextLeft < val) {
-					do { list[ii].rank = jj; ii++; nextLeft = iv_left(ii); } while (nextLeft < val); // interval ii sits after jj residuals
-					before = iv_p(ii);
-				}
-			}
-			if (act) out[jj + before] = val;
-			jj += act ? 1 : 0;
-		}
-#else
 		if (!(g.dbg & 128)) // (timing experiments only)
 		for (int32_t k2 = 0; k2 < cn; k2++) {
 			const int32_t add = k2 < CK ? (int32_t)cache[k2 * 64 + lane] : (int32_t)w1_residual<DEF>(g, lw, src, p, err) + 1;
@@ -1246,7 +1146,6 @@ __device__ __forceinline__ void coop_residuals_w1(const GraphDev &g, int32_t x, 
 			out[jj + before] = val;
 			jj++;
 		}
-#endif
 		const unsigned long long has = __ballot(cn > 0);
 		const int lastL = has ? 63 - __clzll((long long)has) : 0;
 		baseVal = __shfl(val, lastL, 64);
