@@ -1,5 +1,5 @@
 #!/bin/bash
-# timing experiments (results are garbage with any switch set): what each step of the wave class's residual phase costs -- BVGPU_DBG bits: 0x800 stage only, 0x1000 no run-in,
+# timing experiments (a -DBV_EXP_TIMING tuning build: scripts/variants.sh -s bv_kernels.hip timing "-DBV_EXP_TIMING", BVGPU_LIB=...; results are garbage with any switch set): what each step of the wave class's residual phase costs -- BVGPU_DBG bits: 0x800 stage only, 0x1000 no run-in,
 # 0x2000 no rounds, 128 no value pass, 0x4000 no residual phase, 0x8000 no interval expansion
 cd "$(dirname "$0")/.."
 O=gpurun_out/r6g; mkdir -p $O

@@ -1064,8 +1064,8 @@ __device__ __forceinline__ void coop_residuals_w1(const GraphDev &g, int32_t x, 
 		const uint32_t p0 = (uint32_t)(pos - base), secEndR = (uint32_t)min(recEnd - base, (uint64_t)0x7fffff00u);
 		const uint32_t segEnd = min(p0 + (uint32_t)(lane + 1) * B, secEndR);
 		uint32_t s = lane == 0 ? min(p0, secEndR) : min(p0 + (uint32_t)lane * B, secEndR);
-		if (g.dbg & 0x800) { resDone = nRes; break; } // (timing experiments only, scripts/r6g.sh: the tile's stage and nothing else)
-		if (lane > 0 && s < secEndR && R && !(g.dbg & 0x1000)) { // run-in: lock onto the code boundaries before the segment starts
+		if BV_TIMING(g, 0x800) { resDone = nRes; break; } // (timing experiments only, scripts/r6g.sh: the tile's stage and nothing else)
+		if (lane > 0 && s < secEndR && R && !BV_TIMING(g, 0x1000)) { // run-in: lock onto the code boundaries before the segment starts
 			uint32_t p = s - min(R, s - p0);
 			int e2 = 0;
 			while (p < s && !e2) (void)w1_residual<DEF>(g, lw, src, p, e2);
@@ -1091,7 +1091,7 @@ __device__ __forceinline__ void coop_residuals_w1(const GraphDev &g, int32_t x, 
 		for (int round = 0; round < 66; round++) { // a segment starts where its left neighbour ended
 			uint32_t ns = (uint32_t)__shfl_up((int)e, 1, 64);
 			const bool dirty = lane > 0 && ns != s;
-			if (!__any(dirty) || (g.dbg & 0x2000)) break;
+			if (!__any(dirty) || BV_TIMING(g, 0x2000)) break;
 			if (g.stats && lane == 0) atomicAdd(&g.stats[56], 1ull);
 			if (dirty) { s = ns; if (s < segEnd) parse(); else { c = 0; sum = 0; e = s; } }
 		}
@@ -1135,7 +1135,7 @@ __device__ __forceinline__ void coop_residuals_w1(const GraphDev &g, int32_t x, 
 		// (the ids go straight to the row, a run per lane: handing them to the stores through LDS -- eight lanes' runs of eight per instruction, ~10 lines touched instead of 64 --
 		// made the kernel 6 % SLOWER, and without its stores the loop is 3 % faster: the value pass is a third of the kernel for what it issues, not for what it stores;
 		// profiles/r6_experiments.txt section 3)
-		if (!(g.dbg & 128)) // (timing experiments only)
+		if (!BV_TIMING(g, 128)) // (timing experiments only)
 		for (int32_t k2 = 0; k2 < cn; k2++) {
 			const int32_t add = k2 < CK ? (int32_t)cache[k2 * 64 + lane] : (int32_t)w1_residual<DEF>(g, lw, src, p, err) + 1;
 			val += add;
@@ -1266,9 +1266,9 @@ __device__ __forceinline__ void coop_parse_node(const GraphDev &g, int32_t x, in
 	}
 	G.sync_global();
 	if (NW == 1 && DEF != 0 && ic < 0x7fffffff && nRes < 0x7fffffff) { // one wave, default codings: every codeword decoded once
-		if (nRes > 0 && !(g.dbg & 0x4000)) coop_residuals_w1<DEF>(g, x, pos, recEnd, nRes, ic, intervalArcs, list, row + copied, lds, err);
+		if (nRes > 0 && !BV_TIMING(g, 0x4000)) coop_residuals_w1<DEF>(g, x, pos, recEnd, nRes, ic, intervalArcs, list, row + copied, lds, err);
 		COOP_TICK(2);
-		if (ic > 0 && !(g.dbg & 0x8000)) { // phase X: interval i occupies out[pstart + rank .. + len)  (IntIntervalSequenceIterator.java:64-78)
+		if (ic > 0 && !BV_TIMING(g, 0x8000)) { // phase X: interval i occupies out[pstart + rank .. + len)  (IntIntervalSequenceIterator.java:64-78)
 			G.sync_global();
 			int32_t *out = row + copied;
 			for (int64_t i0 = 0; i0 < ic; i0 += 64) {

@@ -47,6 +47,13 @@ struct GraphDev {
 	int32_t segMinD; // only records with at least this many successors are handed over
 };
 
+// Timing switches (scripts/r6g.sh, profiles/r6_wave_class_ablation.txt): BVGPU_DBG bits that leave a step of a kernel OUT to see what it costs -- the results are garbage, so
+// they exist only in -DBV_EXP_TIMING tuning builds; in the library every knob is a choice of speed, never of results.
+#ifdef BV_EXP_TIMING
+#define BV_TIMING(g, bit) (((g).dbg & (bit)) != 0)
+#else
+#define BV_TIMING(g, bit) false
+#endif
 // tuning counters: 0 tiles(residual) 1 rounds(residual) 2 tiles(interval) 3 rounds(interval) 4 lane-parses 5 big nodes 6 clock ticks in coop nodes 7 max ticks of one node
 __device__ __forceinline__ void stat_add(const GraphDev &g, int i, unsigned long long v) { if (g.stats && (threadIdx.x & 63) == 0) atomicAdd(&g.stats[i], v); }
 __device__ __forceinline__ void stat_max(const GraphDev &g, int i, unsigned long long v) { if (g.stats && (threadIdx.x & 63) == 0) atomicMax(&g.stats[i], v); }

@@ -509,7 +509,7 @@ __device__ __forceinline__ void parse_node_lwc(const GraphDev &g, int32_t x, int
 			}
 		}
 		const int32_t v0 = trip(k0), v1 = trip(k0 + 1), v2 = trip(k0 + 2), v3 = trip(k0 + 3);
-		if ((!HASH || hstore) && !(g.dbg & 0x10000)) { // (0x10000: timing experiments only)
+		if ((!HASH || hstore) && !BV_TIMING(g, 0x10000)) { // (0x10000: timing experiments only)
 			const int32_t left = extra - k0;
 			if (left >= 4) *(i32x4_a4 *)(out + k0) = i32x4_a4{ v0, v1, v2, v3 };
 			else if (left > 0) { out[k0] = v0; if (left > 1) out[k0 + 1] = v1; if (left > 2) out[k0 + 2] = v2; }
