@@ -1064,7 +1064,7 @@ __device__ __forceinline__ void coop_residuals_w1(const GraphDev &g, int32_t x, 
 		const uint32_t p0 = (uint32_t)(pos - base), secEndR = (uint32_t)min(recEnd - base, (uint64_t)0x7fffff00u);
 		const uint32_t segEnd = min(p0 + (uint32_t)(lane + 1) * B, secEndR);
 		uint32_t s = lane == 0 ? min(p0, secEndR) : min(p0 + (uint32_t)lane * B, secEndR);
-		if BV_TIMING(g, 0x800) { resDone = nRes; break; } // (timing experiments only, scripts/r6g.sh: the tile's stage and nothing else)
+		if (BV_TIMING(g, 0x800)) { resDone = nRes; break; } // (timing experiments only, scripts/r6g.sh: the tile's stage and nothing else)
 		if (lane > 0 && s < secEndR && R && !BV_TIMING(g, 0x1000)) { // run-in: lock onto the code boundaries before the segment starts
 			uint32_t p = s - min(R, s - p0);
 			int e2 = 0;
