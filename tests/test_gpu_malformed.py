@@ -258,3 +258,68 @@ def test_residuals_inside_intervals_are_emitted_once(tmp_path, monkeypatch, knob
     for i, x in enumerate(q):
         assert np.array_equal(scb[rpb[i]:rpb[i + 1]], sc0[rp0[x]:rp0[x + 1]])
     g.close()
+
+
+@pytest.mark.parametrize("knobs", [{}, {"BVGPU_COPY_LOOP": "0"}, {"BVGPU_TILE": "1"}, {"BVGPU_TILE": "0", "BVGPU_COPY_VEC": "1"}, {"BVGPU_COPY_TABLES": "0"}, {"BVGPU_COPY_MID_MIN": "4", "BVGPU_COOP_MIN": "2147483647"}, {"BVGPU_COPY_MID_MIN": "4", "BVGPU_PREWALK": "0"}])
+def test_extras_that_equal_copied_ids_are_emitted_once(tmp_path, monkeypatch, knobs):
+    """The same one level up: a residual (or an id of an interval) that equals an id COPIED from the referent.  MergedIntIterator.java:69-72 emits the equal heads once, the
+    list is shorter than its outdegree and the array ends in -1 (BVGraph.java:1210).  The copy pass's merges -- the wave's loop (k_copy_list_w), the lane-by-lane merges, the
+    wave class's ranks (k_copy_mid: rows of 128 .. 1023 ids by default, here from 4 on) -- must agree with the oracle; the rows that copy from such a row (its -1 included) too.
+    (The group class -- rows of 1024 ids and more -- ranks its two sets against each other and would leave a hole behind such a pair: DESIGN.md, open list.)"""
+    from bitio import write_graph, int2nat
+    from webgraph_amd.bvgraph import BVGraph
+    from oracle import oracle as O
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(11)
+
+    def row(x, ref, blocks, res, d):
+        def rec(w):
+            w.gamma(d)
+            if d == 0:
+                return
+            w.unary(ref)
+            if ref:
+                w.gamma(len(blocks))
+                for i, b in enumerate(blocks):
+                    w.gamma(b if i == 0 else b - 1)
+            if res:
+                w.gamma(0)  # no intervals (the count is there only when the row has extras: BVG:1073)
+            pv = None
+            for r in res:
+                w.zeta(int2nat(r - x) if pv is None else r - pv - 1)
+                pv = r
+        return rec
+
+    recs, arcs = [], 0
+    protos = {}
+    for x in range(0, 400, 4):
+        base_ids = sorted(set(int(v) for v in rng.integers(0, 3000, size=int(rng.integers(6, 60)))))
+        protos[x] = base_ids
+        recs.append(row(x, 0, [], base_ids, len(base_ids))); arcs += len(base_ids)
+        # x + 1 copies everything and adds residuals of which some collide
+        coll = [base_ids[i] for i in sorted(set(int(v) for v in rng.integers(0, len(base_ids), size=3)))]
+        fresh = [int(v) for v in rng.integers(0, 3000, size=4) if int(v) not in base_ids]
+        res = sorted(set(coll + fresh))
+        d1 = len(base_ids) + len(res)
+        recs.append(row(x + 1, 1, [], res, d1)); arcs += d1
+        # x + 2 copies the first three of x, skips two, copies the rest; a colliding residual in each part
+        if len(base_ids) >= 8:
+            kept = base_ids[:3] + base_ids[5:]
+            res2 = sorted(set([base_ids[1], base_ids[6], 2999 + x]))
+            d2 = len(kept) + len(res2)
+            recs.append(row(x + 2, 2, [3, 2], res2, d2)); arcs += d2
+        else:
+            recs.append(row(x + 2, 0, [], [], 0))
+        # x + 3 copies x + 1 whole (a row that ends in -1): no extras
+        recs.append(row(x + 3, 2, [], [], d1)); arcs += d1
+    base = str(tmp_path / "equalcopied")
+    write_graph(base, recs, min_interval=2, arcs=arcs)
+    rp0, sc0, _ = O.OracleGraph.load(base).scan()
+    assert (sc0 == -1).any()
+    g = BVGraph.load(base)
+    rp, sc = g.decode_range()
+    assert np.array_equal(rp, rp0) and np.array_equal(sc, sc0)
+    rp, sc = g.decode_range(101, 303)
+    assert np.array_equal(sc, sc0[rp0[101]:rp0[303]])
+    g.close()

@@ -267,6 +267,7 @@ KNOBS = [
     {"BVGPU_PREWALK": "0"}, {"BVGPU_COPY_VEC": "1"}, {"BVGPU_COPY_VEC": "1", "BVGPU_COPY_MID_MIN": "16", "BVGPU_COOP_MIN": "16", "BVGPU_GIANT_MIN": "64"},
     # round 6: round 4's one-lane loop instead of the sentinel loop (no copy tables then), the lane class of the copy pass walking the stream although the tables exist,
     # tables with the tile kernel and with the vector merge, the parse list's keys by k_depth_keys, the giants not waiting for the parse list
+    {"BVGPU_COPY_LOOP": "0"}, {"BVGPU_LEVEL_BINS": "0"}, {"BVGPU_COPY_LOOP": "0", "BVGPU_LEVEL_BINS": "0", "BVGPU_TILE": "0"}, {"BVGPU_COPY_LOOP": "1", "BVGPU_TILE": "1", "BVGPU_COPY_MID_MIN": "1024"},
     {"BVGPU_LANE_LOOP": "0", "BVGPU_TILE": "0"}, {"BVGPU_COPY_TABLES": "0", "BVGPU_TILE": "0"}, {"BVGPU_TILE": "0", "BVGPU_COPY_VEC": "1"}, {"BVGPU_TILE": "1", "BVGPU_COPY_VEC": "0"},
     {"BVGPU_TILE": "0", "BVGPU_COPY_MID_MIN": "1024", "BVGPU_COOP_MIN": "2147483647"}, {"BVGPU_TILE": "0", "BVGPU_COPY_MID_MIN": "1000", "BVGPU_COOP_MIN": "64", "BVGPU_GIANT_MIN": "4000"},
     {"BVGPU_KEYS_IN_HEADERS": "0", "BVGPU_TILE": "0"}, {"BVGPU_GIANTS_AFTER_LIST": "0", "BVGPU_TILE": "0", "BVGPU_COOP_MIN": "16", "BVGPU_GIANT_MIN": "64"},
@@ -325,13 +326,18 @@ def test_copy_tables_of_the_lane_class(tmp_path, monkeypatch, mi, tile):
     base = str(tmp_path / ("tabs%d" % mi))
     st = T.store(base, rowptr, succ, window=7, max_ref_count=3, min_interval=mi, zeta_k=3)
     assert st["copied_arcs"] > succ.size // 4
-    for vec in ("0", "1"):
+    for vec, loop in (("0", "1"), ("1", "1"), ("0", "0"), ("1", "0")):  # loop: the merges as a loop of the whole wave (k_copy_list_w) / lane by lane (copy_node_tab)
         monkeypatch.setenv("BVGPU_COPY_VEC", vec)
+        monkeypatch.setenv("BVGPU_COPY_LOOP", loop)
         g = BVGraph.load(base)
         rp, sc = g.decode_range()
-        assert np.array_equal(rp, rowptr) and np.array_equal(sc, succ), (mi, tile, vec)
+        assert np.array_equal(rp, rowptr) and np.array_equal(sc, succ), (mi, tile, vec, loop)
         rp, sc = g.decode_range(1234, 4321)
         assert np.array_equal(sc, succ[rowptr[1234]:rowptr[4321]])
+        # rows at the very end of the caller's buffer: the wave loop's 16-byte windows fall back to single ids there (the range's last rows, exact capacity)
+        for lo, hi in ((n - 3, n), (n - 40, n - 1), (5990, 5991)):
+            rp, sc = g.decode_range(lo, hi)
+            assert np.array_equal(sc, succ[rowptr[lo]:rowptr[hi]]), (lo, hi)
         g.close()
 
 

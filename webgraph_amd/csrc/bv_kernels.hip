@@ -57,6 +57,7 @@ template <int DEF>
 __device__ __forceinline__ void copy_node_v(const GraphDev &g, int32_t x, int32_t d, int32_t dref, int32_t *__restrict__ row, const int32_t *__restrict__ src, int *__restrict__ err);
 template <bool VEC>
 __device__ __forceinline__ void copy_node_tab(int32_t d, int32_t dref, int32_t *__restrict__ row, const int32_t *__restrict__ src, const int32_t *__restrict__ tabEnd, int4 hd);
+__device__ __forceinline__ void copy_rows_tab(bool have, int32_t d, int32_t dref, int32_t *__restrict__ row, const int32_t *__restrict__ src, int32_t limE, int32_t limS, const int32_t *__restrict__ tabEnd, int4 hd);
 
 // ------------------------------------------------------------------------------------------------ headers
 __device__ __forceinline__ int32_t record_bin(uint64_t bitsLen);
@@ -633,6 +634,61 @@ __global__ void __launch_bounds__(TPB) k_copy_list(GraphDev g, RangeView v, cons
 	}
 }
 
+// k_copy_list<., ., false, true> with the merge as a loop the 64 lanes of a wave walk TOGETHER (copy_rows_tab): in copy_node_tab every lane loads when ITS buffer runs dry, so a
+// wave waits for memory at nearly every id of its longest row -- a level of cnr-2000 x 30 lasted 215 us for rows of 12 ids, whatever the class bound.  Here a pass is: every lane
+// loads its next four copied ids, the first four of its next kept block and its next four extras (three loads in flight at once, ONE wait), then four trips that emit min(copied
+// head, extra head) each.  Rows without a table (CT_NONE, or an overflow that does not fit) take the old merges, lane by lane, before the wave's loop.
+template <int DEF, bool VEC>
+__global__ void __launch_bounds__(TPB) k_copy_list_w(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ list,
+                                                     const int32_t *__restrict__ keyBase, int32_t level, int32_t midMin, int32_t bigMin, int *__restrict__ err,
+                                                     const IvEntry *__restrict__ arena, int64_t arenaCap, const CopyTab *__restrict__ ctab) {
+	const int32_t bucket = min(level, MAXLVL - 1);
+	const int32_t lo = keyBase[bucket * NBIN], hi = keyBase[(bucket + 1) * NBIN];
+	const int64_t rsNh = v.rowstart[v.nh];
+	const int32_t coopMin = v.coopmin();
+	for (int32_t idx = hi - 1 - (blockIdx.x * TPB + threadIdx.x); wave_any(idx >= lo); idx -= gridDim.x * TPB) {
+		bool have = false;
+		int32_t d = 0, dref = 0, limE = 0, limS = 0;
+		int32_t *row = nullptr;
+		const int32_t *src = nullptr, *ovfEnd = nullptr;
+		int4 hd = int4{ 0, 0, 0, 0 };
+		if (idx >= lo) do {
+			const int32_t s = list[idx];
+			const int32_t r = v.ref[s];
+			if (r == 0 || (level >= MAXLVL - 1 && depth[s] != level)) break;
+			const int32_t t = s - r;
+			const i64x2_a8 rsp = *(const i64x2_a8 *)(v.rowstart + s), rtp = *(const i64x2_a8 *)(v.rowstart + t);
+			const int64_t rs0 = rsp.x, rs1 = rsp.y, rt0 = rtp.x, rt1 = rtp.y;
+			if (!(s >= v.nh ? (uint64_t)(rs1 - rsNh) <= v.succ_cap : (uint64_t)rs1 <= v.halo_cap) || !(t >= v.nh ? (uint64_t)(rt1 - rsNh) <= v.succ_cap : (uint64_t)rt1 <= v.halo_cap)) break; // E_CAP / E_HALO already raised by the parse kernel
+			d = (int32_t)(rs1 - rs0); dref = (int32_t)(rt1 - rt0);
+			if (copy_class_of(d, dref, midMin, bigMin) != 1) break;
+			row = s < v.nh ? v.halo + rs0 : v.succ + (rs0 - rsNh);
+			src = t < v.nh ? v.halo + rt0 : v.succ + (rt0 - rsNh);
+			// ints that may be READ from the row's start on (a 16-byte load at the end of a row reads into its neighbours, never past the buffer)
+			limE = (int32_t)min<int64_t>(s < v.nh ? (int64_t)v.halo_cap - rs0 : (int64_t)v.succ_cap - (rs0 - rsNh), 0x7fffffff);
+			limS = (int32_t)min<int64_t>(t < v.nh ? (int64_t)v.halo_cap - rt0 : (int64_t)v.succ_cap - (rt0 - rsNh), 0x7fffffff);
+			if (d < coopMin) {
+				hd = *(const int4 *)(ctab + s);
+				const uint32_t kept = (uint32_t)hd.w & 0xffffu;
+				if (kept != CT_NONE) {
+					bool ok = true;
+					if (kept > 3) { // the kept blocks from the fourth on: the end of the record's own part of the interval arena
+						int64_t abase = 0; int32_t an = 0;
+						if (g.minInt > 0) arena_slice(g.minInt, rs0, d, abase, an);
+						ok = g.minInt > 0 && abase >= 0 && abase + an <= arenaCap && (int32_t)kept - 3 <= 4 * (an - 1);
+						ovfEnd = (const int32_t *)(arena + abase + (an - 1));
+					}
+					if (ok) { have = true; break; }
+				}
+			}
+			if (VEC) copy_node_v<DEF>(g, v.lo + s, d, dref, row, src, err);
+			else copy_node<DEF>(g, v.lo + s, d, (int64_t)dref, row, src, err);
+		} while (false);
+		if (BV_TIMING(g, 0x20000)) continue; // (timing experiments only: the rows' metadata and nothing else)
+		copy_rows_tab(have, d, dref, row, src, limE, limS, ovfEnd, hd);
+	}
+}
+
 // One wave per row of fewer than COPY_BIG_MIN successors with a reference.  The block list is walked once (by
 // every lane: it is short) into two LDS tables -- for the j-th copied block, the number of ids copied up to its
 // end and the offset between an id's index in the referent's row and its index among the copied ids.  Then the
@@ -718,13 +774,29 @@ __global__ void __launch_bounds__(64 * COPY_MID_WAVES) k_copy_mid(GraphDev g, Ra
 		for (int32_t e = lane; e < nExtra; e += 64) vals[nc + e] = row[nc + e];
 		wave_sync();
 		// final positions
+		bool dup = false;
 		for (int32_t t = lane; t < d; t += 64) {
 			const int32_t val = vals[t];
 			int32_t lo, hi;
 			if (t < nc) { lo = nc; hi = d; } // copied id: count the extras below it
 			else { lo = 0; hi = nc; }        // extra: count the copied ids below it
 			while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (vals[mid] < val) lo = mid + 1; else hi = mid; }
+			if (t >= nc && lo < nc && vals[lo] == val) dup = true;
 			row[t - nc + lo] = val;
+		}
+		// an extra that equals a copied id (never in a valid file: the two land on one position and leave a hole): MergedIntIterator.java:69-72 emits equal heads once and
+		// BVG:1210 pads with -1 -- one lane merges the two sets again, from LDS, the way copy_node does
+		if (__any(dup)) {
+			if (lane == 0) {
+				int32_t i = 0, j = nc, k = 0;
+				while (i < nc || j < d) {
+					int32_t val;
+					if (j >= d || (i < nc && vals[i] <= vals[j])) { val = vals[i]; if (j < d && vals[j] == val) j++; i++; }
+					else val = vals[j++];
+					row[k++] = val;
+				}
+				while (k < d) row[k++] = -1;
+			}
 		}
 		wave_sync(); // the tables are reused by the next row
 	}
@@ -1808,6 +1880,89 @@ __device__ __forceinline__ void copy_node_tab(int32_t d, int32_t dref, int32_t *
 	else if (on == 1) row[k - 1] = o3;
 }
 
+// copy_node_tab for all 64 rows of a wave at once (k_copy_list_w).  `have`: this lane has a row with a table; limE / limS: ints readable from the start of the row / of its
+// referent's row (>= d / dref: how far a 16-byte load may reach).  Per pass three windows of four ids each are loaded side by side -- A: the referent's ids from index i on
+// (the current kept block), B: the first ids of the NEXT kept block (only when A ends inside this pass), E: the row's next extras (they sit at row[copied ..), where the parse
+// kernel left them) -- and four trips follow, each emitting min(head of A, head of E) (unsigned; 0xffffffff = nothing left on that side: a row that lost a duplicate -- never in a
+// valid file -- pads itself with -1).  A lane that crosses a second block boundary within a pass (or whose windows were single ids at the end of the buffer) sits out the rest of the
+// pass.  The merged ids leave 16 bytes at a time at row + k - 4 (in place: k <= copied + the extras consumed, and every extra of the window is in a register by then).
+// Memory safety does not depend on the table: i < end <= dref, k < d, and the extras are read below d.
+__device__ __forceinline__ void copy_rows_tab(bool have, int32_t d, int32_t dref, int32_t *__restrict__ row, const int32_t *__restrict__ src, int32_t limE, int32_t limS, const int32_t *__restrict__ tabEnd, int4 hd) {
+	constexpr uint32_t SENT = 0xffffffffu;
+	const int32_t kept = (int32_t)((uint32_t)hd.w & 0xffffu), copied = (int32_t)((uint32_t)hd.w >> 16);
+	bool done = !have || kept == 0 || copied == 0 || copied > d; // (copied == 0: the extras are the row)
+	// kept blocks 3 .. 6 of the table: one 16-byte load below the end of the record's own part of the arena (entry j at tabEnd[2 - j]; at least one IvEntry there when kept > 3)
+	i32x4_u t4 = i32x4_u{ 0, 0, 0, 0 };
+	if (!done && kept > 3) t4 = *(const i32x4_u *)(tabEnd - 4);
+	auto entry = [&](int32_t j) -> uint32_t {
+		if (j >= 7) return (uint32_t)tabEnd[2 - j];
+		int32_t e = hd.z;
+		e = j == 1 ? hd.y : e; e = j == 2 ? hd.x : e; e = j == 3 ? t4.w : e; e = j == 4 ? t4.z : e; e = j == 5 ? t4.y : e; e = j == 6 ? t4.x : e;
+		return (uint32_t)e;
+	};
+	int32_t b = 0, i = 0, end = 0, k = 0, ec = 0; // kept block, index in the referent's row and the block's end there, ids emitted, extras consumed
+	if (!done) { const uint32_t e0 = (uint32_t)hd.z; i = (int32_t)(e0 >> 16); end = min(i + (int32_t)(e0 & 0xffffu), dref); }
+	uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0;
+	uint32_t E0 = SENT, E1 = SENT, E2 = SENT, E3 = SENT; // the window of extras lives across the passes: a row has few of them (2.8 on cnr-2000), and every load of this kernel is a cache line of its own
+	int32_t en = 0;
+	while (wave_any(!done)) {
+		uint32_t A0 = SENT, A1 = SENT, A2 = SENT, A3 = SENT, B0 = SENT, B1 = SENT, B2 = SENT, B3 = SENT;
+		int32_t An = 0, Bn = 0, nI = 0, nEnd = 0;
+		bool stall = false;
+		if (!done) {
+			if (i >= end && b + 1 < kept) { b++; const uint32_t e = entry(b); i = (int32_t)(e >> 16); end = min(i + (int32_t)(e & 0xffffu), dref); } // a crossing left over from the last pass
+			An = max(0, min(4, end - i));
+			if (An > 0) {
+				if (i + 4 <= limS) { const i32x4_u q = *(const i32x4_u *)(src + i); A0 = (uint32_t)q.x; A1 = (uint32_t)q.y; A2 = (uint32_t)q.z; A3 = (uint32_t)q.w; }
+				else { A0 = (uint32_t)src[i]; An = 1; }
+			}
+			if (An < 4 && b + 1 < kept) {
+				const uint32_t e = entry(b + 1);
+				nI = (int32_t)(e >> 16); nEnd = min(nI + (int32_t)(e & 0xffffu), dref);
+				Bn = max(0, min(4, nEnd - nI));
+				if (Bn > 0) {
+					if (nI + 4 <= limS) { const i32x4_u q = *(const i32x4_u *)(src + nI); B0 = (uint32_t)q.x; B1 = (uint32_t)q.y; B2 = (uint32_t)q.z; B3 = (uint32_t)q.w; }
+					else { B0 = (uint32_t)src[nI]; Bn = 1; }
+				}
+			}
+			const int32_t pe = copied + ec;
+			if (en < 2 && pe + en < d) { // (re)load the window from its head on
+				en = min(4, d - pe);
+				if (pe + 4 <= limE) { const i32x4_u q = *(const i32x4_u *)(row + pe); E0 = (uint32_t)q.x; E1 = (uint32_t)q.y; E2 = (uint32_t)q.z; E3 = (uint32_t)q.w; }
+				else { E0 = (uint32_t)row[pe]; en = 1; }
+			}
+		}
+#pragma unroll
+		for (int tr = 0; tr < 4; tr++) {
+			const bool act = !done && !stall;
+			const uint32_t cv = An > 0 ? A0 : SENT, ev = en > 0 ? E0 : SENT;
+			const uint32_t val = min(cv, ev);
+			const bool takeC = act && An > 0 && cv <= ev, takeE = act && en > 0 && ev <= cv; // (equal heads: emitted once)
+			if (act) {
+				o0 = o1; o1 = o2; o2 = o3; o3 = val; k++;
+				if ((k & 3) == 0) *(i32x4_u *)(row + k - 4) = i32x4_u{ (int32_t)o0, (int32_t)o1, (int32_t)o2, (int32_t)o3 };
+			}
+			if (takeE) { E0 = E1; E1 = E2; E2 = E3; en--; ec++; if (en == 0 && copied + ec < d) stall = true; } // (more extras, none in a register: a single-id window, or the pass's last trip)
+			if (takeC) {
+				A0 = A1; A1 = A2; A2 = A3; An--; i++;
+				if (An == 0) {
+					if (i >= end && Bn > 0) { A0 = B0; A1 = B1; A2 = B2; A3 = B3; An = Bn; Bn = 0; b++; i = nI; end = nEnd; }
+					else if (i < end || b + 1 < kept) stall = true; // more copied ids, none of them in a register
+				}
+			}
+			// the row is full, or no copied id is left and the remaining extras are where they belong
+			if (act && (k >= d || (An == 0 && !stall && k == copied + ec))) done = true;
+		}
+	}
+	if (have) {
+		const int32_t on = k & 3; // the ids still in the ring: one store over the last four ids (the ring holds them) when there are four
+		if (on != 0 && k >= 4) *(i32x4_u *)(row + k - 4) = i32x4_u{ (int32_t)o0, (int32_t)o1, (int32_t)o2, (int32_t)o3 };
+		else if (on == 3) { row[k - 3] = (int32_t)o1; row[k - 2] = (int32_t)o2; row[k - 1] = (int32_t)o3; }
+		else if (on == 2) { row[k - 2] = (int32_t)o2; row[k - 1] = (int32_t)o3; }
+		else if (on == 1) row[k - 1] = (int32_t)o3;
+	}
+}
+
 template <int DEF>
 __device__ __forceinline__ void read_header(const GraphDev &g, int32_t x, int32_t &d, int32_t &r, int &e) {
 	BitReader br;
@@ -2410,8 +2565,9 @@ void launch_copy_prewalk(const GraphDev &g, int def, const RangeView &v, const i
 }
 void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int32_t *depth, const int32_t *list, const int32_t *keyBase, int32_t level, int blocks,
                        int32_t midMinKnob, bool bigGroups, const int32_t *bigQ, int32_t bigCap, const int32_t *midQ, int32_t midCap, int32_t *ctl, int32_t *tmp, uint32_t tmpCap, int *err,
-                       hipStream_t st, hipStream_t stMid, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evMid, hipEvent_t evBig, const void *preDesc, bool preMid, bool vecList,
+                       hipStream_t st, hipStream_t stMid, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evMid, hipEvent_t evBig, const void *preDesc, bool preMid, int listMode,
                        const void *tabArena, int64_t tabArenaCap, const void *copyTab) {
+	const bool vecList = (listMode & 1) != 0; // listMode: 1 = 16-byte loads and stores in the lane class's merges, 2 = the table merges as a loop of the whole wave (k_copy_list_w)
 	if (v.cnt <= 0) return;
 #ifdef BV_EXP_NOCOPY // (ablation builds: the scan without its copy pass, or without one of its three row classes)
 	return;
@@ -2452,7 +2608,8 @@ void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int
 		else hipLaunchKernelGGL(k_copy_mid<0>, dim3(1024), dim3(64 * COPY_MID_WAVES), 0, stMid, g, v, depth, midQ, ctl + 6, midCap, level, err, pre && preMid && midQ == bigQ + bigCap ? pre + bigCap : nullptr);
 	}
 	if (stMid != st) (void)hipEventRecord(evMid, stMid);
-#define COPY_LIST(D, V) do { if (copyTab && D != 0) hipLaunchKernelGGL((k_copy_list<D, V, false, (D != 0)>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err, (const IvEntry *)tabArena, tabArenaCap, (const CopyTab *)copyTab); \
+#define COPY_LIST(D, V) do { if (copyTab && D != 0 && (listMode & 2)) hipLaunchKernelGGL((k_copy_list_w<(D != 0 ? D : 1), V>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err, (const IvEntry *)tabArena, tabArenaCap, (const CopyTab *)copyTab); \
+	else if (copyTab && D != 0) hipLaunchKernelGGL((k_copy_list<D, V, false, (D != 0)>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err, (const IvEntry *)tabArena, tabArenaCap, (const CopyTab *)copyTab); \
 	else hipLaunchKernelGGL((k_copy_list<D, V>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err, (const IvEntry *)nullptr, (int64_t)0, (const CopyTab *)nullptr); } while (0)
 	if (v.hx && def == 1) hipLaunchKernelGGL((k_copy_list<1, false, true>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err, (const IvEntry *)nullptr, (int64_t)0, (const CopyTab *)nullptr); // (the hash fold: ids added as they are merged)
 	else if (v.hx && def == 2) hipLaunchKernelGGL((k_copy_list<2, false, true>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err, (const IvEntry *)nullptr, (int64_t)0, (const CopyTab *)nullptr);

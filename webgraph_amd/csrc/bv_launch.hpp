@@ -107,7 +107,7 @@ void launch_build_lists(const GraphDev &g, const RangeView &v, uint64_t giantBit
                         int32_t *bigQ = nullptr, int32_t bigCap = 0, int32_t *midQ = nullptr, int32_t midCap = 0, int32_t midMinKnob = 0, bool bigGroups = false);
 void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int32_t *depth, const int32_t *list, const int32_t *keyBase, int32_t level, int blocks,
                        int32_t midMinKnob, bool bigGroups, const int32_t *bigQ, int32_t bigCap, const int32_t *midQ, int32_t midCap, int32_t *ctl, int32_t *tmp, uint32_t tmpCap, int *err,
-                       hipStream_t st, hipStream_t stMid, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evMid, hipEvent_t evBig, const void *preDesc = nullptr, bool preMid = false, bool vecList = false,
+                       hipStream_t st, hipStream_t stMid, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evMid, hipEvent_t evBig, const void *preDesc = nullptr, bool preMid = false, int listMode = false,
                        const void *tabArena = nullptr, int64_t tabArenaCap = 0, const void *copyTab = nullptr); // copyTab: 16 bytes per slot, the copy blocks of the rows that the one-lane parse decoded (parse_node_lwc / parse_node_tile; bv_lanewin.hpp), blocks from the fourth on in tabArena = the interval arena; null: the lane class walks the stream // vecList: the lane class merges with 16-byte loads and stores (copy_node_v) // preDesc: launch_copy_prewalk's descriptors
 void launch_copy_prewalk(const GraphDev &g, int def, const RangeView &v, const int32_t *bigQ, int32_t bigCap, const int32_t *ctl, void *desc, int blocks, hipStream_t st, int32_t midCap, hipStream_t stLong, bool longKernel, hipStream_t stWalk); // stWalk: the stream of k_copy_prewalk (as stLong) // stLong: the stream of the long lists' kernel (ordered behind the queues by the caller; may be st); // midCap > 0: also the wave class's rows (queue at bigQ + bigCap, descriptors at desc + bigCap)
 void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, void *arena, int64_t arenaCap, int32_t keyLo = 0, int32_t keyHi = NKEYS, bool lwc = true, void *copyTab = nullptr); // lwc: round 6's loop (parse_node_lwc), which leaves the tables in copyTab; false: round 4's // the list's keys [keyLo, keyHi); v.hx (default codings only): hash fold

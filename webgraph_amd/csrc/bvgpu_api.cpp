@@ -172,6 +172,8 @@ struct bvg_graph {
 	int giants_after_list = 1; // BVGPU_GIANTS_AFTER_LIST=0: the giants' kernel does not wait for the parse list
 	int keys_in_headers = 1; // BVGPU_KEYS_IN_HEADERS=0: the parse list's keys by k_depth_keys, not by k_headers
 	bool keys_ready = false; // (per job) k_headers wrote them
+	int level_bins = 1;  // BVGPU_LEVEL_BINS=0: the level lists in node order (round 5), not sorted by the records' work bins inside a level: the wave loop of k_copy_list_w runs as long as its longest row
+	int copy_loop = 1;   // BVGPU_COPY_LOOP=0: the lane class of the copy pass merges lane by lane (copy_node_tab), not as a loop of the wave (k_copy_list_w)
 	int lane_loop = 1;   // BVGPU_LANE_LOOP=0: round 4's one-lane loop (parse_node_lwb) instead of round 6's (parse_node_lwc)
 	int copy_tables = 1; // BVGPU_COPY_TABLES=0: the lane class of the copy pass walks the block lists in the stream although the parse left them as tables
 	int prewalk_long = 1; // BVGPU_PREWALK_LONG=0: no kernel of their own for the lists of >= 2048 codes; 2: on the lists' stream instead of side B
@@ -274,6 +276,8 @@ int apply_option(bvg_graph *g, const std::string &name, const char *value) {
 	else if (name == "walk_tables") g->walk_tables = iv;
 	else if (name == "copy_vec") g->copy_vec = iv;
 	else if (name == "lane_loop") g->lane_loop = iv;
+	else if (name == "copy_loop") g->copy_loop = iv;
+	else if (name == "level_bins") g->level_bins = iv;
 	else if (name == "keys_in_headers") g->keys_in_headers = iv;
 	else if (name == "giants_after_list") g->giants_after_list = iv;
 	else if (name == "copy_tables") g->copy_tables = iv;
@@ -298,7 +302,7 @@ int apply_option(bvg_graph *g, const std::string &name, const char *value) {
 	return BVG_OK;
 }
 const char *const OPTION_NAMES[] = { "coop_min", "giant_min", "coop_waves", "giant_groups", "level_blocks", "copy_big", "parse_windows", "tile", "seg", "seg_hub_min", "seg_blocks", "lists_on_b", "skip_empty_giants", "level_lists_early",
-	"walk_tables", "copy_vec", "lane_loop", "copy_tables", "giants_after_list", "keys_in_headers", "prewalk", "prewalk_long", "prewalk_blocks", "copy_mid_min", "overlap", "halo_min", "batch_dense", "scan_top_tiled_min", "wait_giants", "hash_materialise",
+	"walk_tables", "copy_vec", "lane_loop", "copy_loop", "level_bins", "copy_tables", "giants_after_list", "keys_in_headers", "prewalk", "prewalk_long", "prewalk_blocks", "copy_mid_min", "overlap", "halo_min", "batch_dense", "scan_top_tiled_min", "wait_giants", "hash_materialise",
 	"ef_hash_materialise", "scan_piece", "dbg", "stats", "trace_retry", "trace_err", "trace_host" };
 void options_from_env(bvg_graph *g) {
 	for (const char *n : OPTION_NAMES) {
@@ -499,7 +503,7 @@ int finish_pending(bvg_graph *g, uint64_t *arcs_out) {
 					const bool ov2 = g->overlap && !g->profile;
 					bv::launch_copy_level(gd, s.def, g->pend.view, g->depth.as<int32_t>(), g->lvlist.as<int32_t>(), keyBase, l, g->level_blocks, g->copy_mid_min, g->copy_big != 0,
 					                      g->copyq.as<int32_t>(), g->pend.bigCap, g->copyq.as<int32_t>() + g->pend.bigCap, g->pend.midCap, g->coopctl.as<int32_t>(), g->bigtmp.as<int32_t>(), g->pend.tmpCap, derr,
-					                      g->stream, ov2 ? side_b(g) : g->stream, ov2 ? g->sideA : g->stream, g->evFork, g->evB, g->evA, g->pend.preDesc, g->prewalk < 2 && g->pend.midCap > 0, copy_vec(g),
+					                      g->stream, ov2 ? side_b(g) : g->stream, ov2 ? g->sideA : g->stream, g->evFork, g->evB, g->evA, g->pend.preDesc, g->prewalk < 2 && g->pend.midCap > 0, (copy_vec(g) ? 1 : 0) | (g->copy_loop ? 2 : 0),
 					                      g->pend.tabArena, g->pend.tabArenaCap, g->pend.copyTab);
 				}
 			}
@@ -665,7 +669,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		}
 		// chain depths + per-level lists + copy queues, then the pre-walks of the wave and group classes' block lists: on stL; alone: everything on that one stream
 		auto build_levels = [&](hipStream_t stLists, bool alone) -> int {
-			if (W > 0) bv::launch_build_lists(gd, v, ~0ull, 1, g->depth.as<int32_t>(), g->key16.as<uint16_t>(), hist, keyBase, cursor, g->lvlist.as<int32_t>(),
+			if (W > 0) bv::launch_build_lists(gd, v, ~0ull, g->level_bins ? 0 : 1, g->depth.as<int32_t>(), g->key16.as<uint16_t>(), hist, keyBase, cursor, g->lvlist.as<int32_t>(),
 			                                  g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->maxdepth, stLists,
 			                                  g->copyq.as<int32_t>(), bigCap, g->copyq.as<int32_t>() + bigCap, midCap, g->copy_mid_min, g->copy_big != 0);
 			// the block lists of the group class's rows, walked beside the parse kernels (k_copy_prewalk)
@@ -802,7 +806,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			for (int32_t l = 1; l <= levels; l++) {
 				bv::launch_copy_level(gd, s.def, v, g->depth.as<int32_t>(), g->lvlist.as<int32_t>(), keyBase, l, g->level_blocks, g->copy_mid_min, g->copy_big != 0,
 				                                          g->copyq.as<int32_t>(), bigCap, g->copyq.as<int32_t>() + bigCap, midCap, ctl, g->bigtmp.as<int32_t>(), g->pend.tmpCap, derr,
-				                                          g->stream, ovl ? side_b(g) : g->stream, ovl ? g->sideA : g->stream, g->evFork, g->evB, g->evA, g->pend.preDesc, g->prewalk < 2 && g->pend.midCap > 0, copy_vec(g),
+				                                          g->stream, ovl ? side_b(g) : g->stream, ovl ? g->sideA : g->stream, g->evFork, g->evB, g->evA, g->pend.preDesc, g->prewalk < 2 && g->pend.midCap > 0, (copy_vec(g) ? 1 : 0) | (g->copy_loop ? 2 : 0),
 				                                          g->pend.tabArena, g->pend.tabArenaCap, g->pend.copyTab);
 			}
 		}
