@@ -545,8 +545,10 @@ __global__ void __launch_bounds__(TPB) k_key_hist(int32_t cnt, const uint16_t *_
 	for (int k = threadIdx.x; k < NKEYS; k += TPB) { const int32_t c = s_hist[k]; if (c) atomicAdd(&hist[k], c); }
 }
 
+// packRef: the list's entries carry min(ref, LIST_REF_ESC) in bits 28 .. 31 (the parse list of a job of fewer than 2^28 slots: k_parse_list)
+constexpr int32_t LIST_SLOT_MASK = 0x0fffffff, LIST_REF_ESC = 15;
 __global__ void __launch_bounds__(TPB) k_scatter_keys(int32_t cnt, const uint16_t *__restrict__ key16, int32_t *__restrict__ cursor, int32_t *__restrict__ list,
-                                                      int32_t *__restrict__ giantlist, int32_t giantCap, int32_t *__restrict__ ctl) {
+                                                      int32_t *__restrict__ giantlist, int32_t giantCap, int32_t *__restrict__ ctl, const uint16_t *__restrict__ packRef = nullptr) {
 	__shared__ int32_t s_cnt[NKEYS + 1], s_base[NKEYS + 1];
 	for (int k = threadIdx.x; k <= NKEYS; k += TPB) s_cnt[k] = 0;
 	__syncthreads();
@@ -565,7 +567,7 @@ __global__ void __launch_bounds__(TPB) k_scatter_keys(int32_t cnt, const uint16_
 	for (int it = 0; it < LIST_ITEMS; it++) {
 		const int32_t s = item_of(blockIdx.x * LIST_TILE + it * TPB + threadIdx.x);
 		if (keys[it] == KEY_GIANT) { const int32_t k = s_base[NKEYS] + local[it]; if (k < giantCap) giantlist[k] = s; }
-		else if (keys[it] != KEY_NONE) list[s_base[keys[it]] + local[it]] = s;
+		else if (keys[it] != KEY_NONE) list[s_base[keys[it]] + local[it]] = packRef ? (int32_t)((uint32_t)s | ((uint32_t)min((int32_t)packRef[s], LIST_REF_ESC) << 28)) : s;
 	}
 }
 
@@ -1384,7 +1386,7 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 // ahead, so a sweep waits for the last trip only.  Default codings: parse_node_lwb (bv_lanewin.hpp); others: the generic reader.
 template <int DEF, bool HASH = false, bool LWC = true> // LWC: the round-6 loop (parse_node_lwc: leaves the copy blocks as tables); false: round 4's (parse_node_lwb; knob lane_loop = 0)
 __global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, const int32_t *__restrict__ list, const int32_t *__restrict__ keyBase, int32_t binLo, int32_t binHi,
-                                                    IvEntry *__restrict__ arena, int64_t arenaCap, int *__restrict__ err, CopyTab *__restrict__ ctab = nullptr) {
+                                                    IvEntry *__restrict__ arena, int64_t arenaCap, int *__restrict__ err, CopyTab *__restrict__ ctab = nullptr, int packed = 0) {
 	static_assert(!HASH || DEF != 0, "the hash fold rides on the default codings' loop");
 	__shared__ uint32_t lw[DEF ? (LW_MAIN + 2 * LW_RING) * LW_STRIDE : 1]; // per lane: a window of the stream and a ring of intervals (default codings)
 	const int32_t lo = keyBase[binLo], hi = keyBase[binHi], coopMin = v.coopmin();
@@ -1401,18 +1403,23 @@ __global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, con
 	int32_t d = 0, r = 0; int64_t ra = 0, rb = 0; uint64_t oa = 0, ob = 0;
 	// (rowstart[s], rowstart[s + 1] and offsets[x], offsets[x + 1] by ONE 16-byte load each: every load of this kernel goes to a line of its own and costs its CU as much
 	// whatever it carries -- scripts/ubench_lines.hip)
-	auto fetch_meta = [&](int32_t sc) {
-		d = v.outd[sc]; r = v.ref[sc];
+	// The outdegree is the difference of the row starts, and the reference rides in the list entry (packed: bits 28 .. 31 of an entry hold min(ref, 15), LIST_REF_ESC = look it
+	// up; a job of 2^28 slots and more has plain entries): two lines less per record -- the counters put this kernel at the rate at which its CU takes scattered lines
+	// (172 M line accesses per scan of C2 for 10 M records, 12 per record of 20 ids: 5 stores and 7 of these loads).
+	auto fetch_meta = [&](int32_t ec) { // ec: the list entry (!= -1)
+		const int32_t sc = packed ? (ec & LIST_SLOT_MASK) : ec, code = (int32_t)((uint32_t)ec >> 28);
+		r = packed && code != LIST_REF_ESC ? code : (int32_t)v.ref[sc];
 		const i64x2_a8 rr = *(const i64x2_a8 *)(v.rowstart + sc), oo = *(const i64x2_a8 *)(g.offsets + (v.lo + sc));
 		ra = rr.x; rb = rr.y; oa = (uint64_t)oo.x; ob = (uint64_t)oo.y;
+		d = (int32_t)(rb - ra);
 	};
-	if (sCur >= 0) fetch_meta(sCur);
+	if (sCur != -1) fetch_meta(sCur);
 	for (int64_t sweep = 0; sweep * G < N; sweep++) {
-		const int32_t s = sCur, dC = d, rC = r; const int64_t raC = ra, rbC = rb; const uint64_t oaC = oa, obC = ob;
+		const int32_t s = sCur == -1 ? -1 : packed ? (sCur & LIST_SLOT_MASK) : sCur, dC = d, rC = r; const int64_t raC = ra, rbC = rb; const uint64_t oaC = oa, obC = ob;
 		const int32_t drefC = s >= 0 && rC > 0 ? v.outd[s - rC] : 0;
 		sCur = sNext; sNext = entry(sweep + 2);
 		d = 0;
-		if (sCur >= 0) fetch_meta(sCur);
+		if (sCur != -1) fetch_meta(sCur);
 		if (s < 0 || dC >= coopMin || dC == 0) continue; // decoded by whole waves (k_parse_big) / nothing to decode
 		const bool fits = s >= v.nh ? (uint64_t)(rbC - rs0) <= v.succ_cap : (uint64_t)rbC <= v.halo_cap; // (RangeView::fits)
 		if (!fits) { atomicOr(err, s >= v.nh ? E_CAP : E_HALO); continue; }
@@ -2275,12 +2282,12 @@ void launch_headers(const GraphDev &g, int def, int32_t lo, int32_t cnt, int32_t
 	else hipLaunchKernelGGL(k_headers<0>, dim3(nblk(cnt, TPB)), dim3(TPB), 0, st, g, lo, cnt, outd, ref, err, part, mark, pkey16, phist, pwindows ? 1 : 0);
 }
 // the parse list from keys and a histogram that k_headers left (launch_headers with pkey16): the two kernels that remain of launch_build_lists
-void launch_scatter_lists(int32_t cnt, const uint16_t *key16, const int32_t *hist, int32_t *keyBase, int32_t *cursor, int32_t *list, int32_t *giantlist, int32_t *ctl, int32_t *maxdepth, hipStream_t st) {
+void launch_scatter_lists(int32_t cnt, const uint16_t *key16, const int32_t *hist, int32_t *keyBase, int32_t *cursor, int32_t *list, int32_t *giantlist, int32_t *ctl, int32_t *maxdepth, hipStream_t st, const uint16_t *packRef) {
 	if (cnt <= 0) return;
 	(void)hipMemsetAsync((void *)hist, 0, sizeof(int32_t) * NKEYS, st);
 	hipLaunchKernelGGL(k_key_hist, dim3(nblk(cnt, LIST_TILE)), dim3(TPB), 0, st, cnt, key16, (int32_t *)hist);
 	hipLaunchKernelGGL(k_key_offsets, dim3(1), dim3(TPB), 0, st, hist, keyBase, cursor, maxdepth);
-	hipLaunchKernelGGL(k_scatter_keys, dim3(nblk(cnt, LIST_TILE)), dim3(TPB), 0, st, cnt, key16, cursor, list, giantlist, 0, ctl);
+	hipLaunchKernelGGL(k_scatter_keys, dim3(nblk(cnt, LIST_TILE)), dim3(TPB), 0, st, cnt, key16, cursor, list, giantlist, 0, ctl, packRef);
 }
 __global__ void __launch_bounds__(HASH_ACC_SLOTS) k_hash_sum(const HashCtx *__restrict__ hx, int32_t *__restrict__ out) {
 	__shared__ uint32_t s_part[HASH_ACC_SLOTS / 64];
@@ -2516,7 +2523,7 @@ void launch_bparse_big(const GraphDev &g, int def, const BatchView &v, int32_t c
 
 void launch_build_lists(const GraphDev &g, const RangeView &v, uint64_t giantBits, int32_t noBin, int32_t *depth, uint16_t *key16, int32_t *hist, int32_t *keyBase, int32_t *cursor,
                         int32_t *list, int32_t *giantlist, int32_t giantCap, int32_t *ctl, int32_t *maxdepth, hipStream_t st,
-                        int32_t *bigQ, int32_t bigCap, int32_t *midQ, int32_t midCap, int32_t midMinKnob, bool bigGroups) {
+                        int32_t *bigQ, int32_t bigCap, int32_t *midQ, int32_t midCap, int32_t midMinKnob, bool bigGroups, const uint16_t *packRef) {
 	if (v.cnt <= 0) return;
 	(void)hipMemsetAsync(hist, 0, sizeof(int32_t) * NKEYS, st);
 	int32_t midMin, bigMin;
@@ -2524,7 +2531,7 @@ void launch_build_lists(const GraphDev &g, const RangeView &v, uint64_t giantBit
 	hipLaunchKernelGGL(k_depth_keys, dim3(nblk(v.cnt, LIST_TILE)), dim3(TPB), 0, st, g, v.lo, v.cnt, v.outd, v.ref, giantBits, noBin, depth, key16, hist, ctl, maxdepth,
 	                   bigQ, bigCap, midQ, midCap, midMin, bigMin);
 	hipLaunchKernelGGL(k_key_offsets, dim3(1), dim3(TPB), 0, st, hist, keyBase, cursor, maxdepth);
-	hipLaunchKernelGGL(k_scatter_keys, dim3(nblk(v.cnt, LIST_TILE)), dim3(TPB), 0, st, v.cnt, key16, cursor, list, giantlist, giantCap, ctl);
+	hipLaunchKernelGGL(k_scatter_keys, dim3(nblk(v.cnt, LIST_TILE)), dim3(TPB), 0, st, v.cnt, key16, cursor, list, giantlist, giantCap, ctl, packRef);
 }
 
 void launch_parse_giants(const GraphDev &g, int def, const RangeView &v, const int32_t *giantlist, int32_t *ctl, void *arena, int64_t arenaCap, int giantGroups, int *err, hipStream_t st) {
@@ -2647,23 +2654,24 @@ void launch_parse_listed(const GraphDev &g, int def, const RangeView &v, const i
 	else hipLaunchKernelGGL((k_parse_big<0, 1, RangeView>), dim3(waves), dim3(64), 0, st, g, v, list, ctl, which, (IvEntry *)arena, arenaCap, err);
 }
 
-void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, void *arena, int64_t arenaCap, int32_t keyLo, int32_t keyHi, bool lwc, void *copyTab) {
+void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, void *arena, int64_t arenaCap, int32_t keyLo, int32_t keyHi, bool lwc, void *copyTab, bool packedList) {
 	CopyTab *ct = (CopyTab *)copyTab;
+	const int packed = packedList ? 1 : 0;
 	if (v.cnt <= 0) return;
 	blocks = (int)std::min<int64_t>(blocks, nblk(v.cnt, TPB)); // (a thread per record at most)
 	IvEntry *a = (IvEntry *)arena;
 	if (!lwc && def != 0) { // round 4's loop (knob lane_loop = 0): no tables for the copy pass
-		if (def == 1 && v.hx) hipLaunchKernelGGL((k_parse_list<1, true, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, keyLo, keyHi, a, arenaCap, err, (CopyTab *)nullptr);
-		else if (def == 2 && v.hx) hipLaunchKernelGGL((k_parse_list<2, true, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, keyLo, keyHi, a, arenaCap, err, (CopyTab *)nullptr);
-		else if (def == 1) hipLaunchKernelGGL((k_parse_list<1, false, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, keyLo, keyHi, a, arenaCap, err, (CopyTab *)nullptr);
-		else hipLaunchKernelGGL((k_parse_list<2, false, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, keyLo, keyHi, a, arenaCap, err, (CopyTab *)nullptr);
+		if (def == 1 && v.hx) hipLaunchKernelGGL((k_parse_list<1, true, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, keyLo, keyHi, a, arenaCap, err, (CopyTab *)nullptr, packed);
+		else if (def == 2 && v.hx) hipLaunchKernelGGL((k_parse_list<2, true, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, keyLo, keyHi, a, arenaCap, err, (CopyTab *)nullptr, packed);
+		else if (def == 1) hipLaunchKernelGGL((k_parse_list<1, false, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, keyLo, keyHi, a, arenaCap, err, (CopyTab *)nullptr, packed);
+		else hipLaunchKernelGGL((k_parse_list<2, false, false>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, keyLo, keyHi, a, arenaCap, err, (CopyTab *)nullptr, packed);
 		return;
 	}
-	if (def == 1 && v.hx) hipLaunchKernelGGL((k_parse_list<1, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, keyLo, keyHi, a, arenaCap, err, ct);
-	else if (def == 2 && v.hx) hipLaunchKernelGGL((k_parse_list<2, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, keyLo, keyHi, a, arenaCap, err, ct);
-	else if (def == 1) hipLaunchKernelGGL(k_parse_list<1>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, keyLo, keyHi, a, arenaCap, err, ct);
-	else if (def == 2) hipLaunchKernelGGL(k_parse_list<2>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, keyLo, keyHi, a, arenaCap, err, ct);
-	else hipLaunchKernelGGL(k_parse_list<0>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, keyLo, keyHi, a, arenaCap, err, ct);
+	if (def == 1 && v.hx) hipLaunchKernelGGL((k_parse_list<1, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, keyLo, keyHi, a, arenaCap, err, ct, packed);
+	else if (def == 2 && v.hx) hipLaunchKernelGGL((k_parse_list<2, true>), dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, keyLo, keyHi, a, arenaCap, err, ct, packed);
+	else if (def == 1) hipLaunchKernelGGL(k_parse_list<1>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, keyLo, keyHi, a, arenaCap, err, ct, packed);
+	else if (def == 2) hipLaunchKernelGGL(k_parse_list<2>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, keyLo, keyHi, a, arenaCap, err, ct, packed);
+	else hipLaunchKernelGGL(k_parse_list<0>, dim3(blocks), dim3(TPB), 0, st, g, v, list, keyBase, keyLo, keyHi, a, arenaCap, err, ct, packed);
 }
 
 } // namespace bv

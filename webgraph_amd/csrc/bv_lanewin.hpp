@@ -487,6 +487,7 @@ __device__ __forceinline__ void parse_node_lwc(const GraphDev &g, int32_t x, int
 		if (HASH) { *hacc += k < extra ? val * hw : 0u; hw *= 31u; }
 		return (int32_t)val;
 	};
+	int32_t p1 = 0, p2 = 0, p3 = 0; // the last pass's last three ids
 	for (int32_t k0 = 0; wave_any(k0 < extra); k0 += 4) {
 		// four codes of <= 32 bits behind the cursor, four entries of the ring: or ALL lanes move their windows / top their rings up
 		const bool low = spillLane && ivLoaded <= nIv && ivLoaded - ivIdx < 4;
@@ -512,8 +513,14 @@ __device__ __forceinline__ void parse_node_lwc(const GraphDev &g, int32_t x, int
 		if ((!HASH || hstore) && !BV_TIMING(g, 0x10000)) { // (0x10000: timing experiments only)
 			const int32_t left = extra - k0;
 			if (left >= 4) *(i32x4_a4 *)(out + k0) = i32x4_a4{ v0, v1, v2, v3 };
-			else if (left > 0) { out[k0] = v0; if (left > 1) out[k0 + 1] = v1; if (left > 2) out[k0 + 2] = v2; }
+			else if (left > 0) {
+				// the last one to three ids: ONE 16-byte store over the row's last four ids (the first of them are the last pass's, still at hand) when the row has four --
+				// a store instruction of this kernel costs its CU a line per lane whatever it carries, and three 4-byte stores were three of them
+				if (k0 > 0) *(i32x4_a4 *)(out + extra - 4) = left == 1 ? i32x4_a4{ p1, p2, p3, v0 } : left == 2 ? i32x4_a4{ p2, p3, v0, v1 } : i32x4_a4{ p3, v0, v1, v2 };
+				else { out[k0] = v0; if (left > 1) out[k0 + 1] = v1; if (left > 2) out[k0 + 2] = v2; }
+			}
 		}
+		p1 = v1; p2 = v2; p3 = v3;
 	}
 	if (e) atomicOr(err, e);
 }

@@ -79,7 +79,7 @@ struct BatchView {
 
 void launch_headers(const GraphDev &g, int def, int32_t lo, int32_t cnt, int32_t *outd, uint16_t *ref, int *err, hipStream_t st, int32_t *part = nullptr, uint8_t *mark = nullptr, // mark[cnt] (zeroed): set for every referent
                     uint16_t *pkey16 = nullptr, int32_t *phist = nullptr, bool pwindows = true); // pkey16 / phist: the parse list's keys and their histogram (zeroed here), as k_depth_keys with noBin = 6 (pwindows) / 2 writes them
-void launch_scatter_lists(int32_t cnt, const uint16_t *key16, const int32_t *hist, int32_t *keyBase, int32_t *cursor, int32_t *list, int32_t *giantlist, int32_t *ctl, int32_t *maxdepth, hipStream_t st);
+void launch_scatter_lists(int32_t cnt, const uint16_t *key16, const int32_t *hist, int32_t *keyBase, int32_t *cursor, int32_t *list, int32_t *giantlist, int32_t *ctl, int32_t *maxdepth, hipStream_t st, const uint16_t *packRef = nullptr); // packRef: bvg ref[] -> entries carry min(ref, 15) in bits 28 .. 31 (k_parse_list's list, fewer than 2^28 slots)
 int64_t headers_blocks(int32_t cnt); // part: 5 counts per block of k_headers, [5][headers_blocks(cnt)] (input of k_pick_coop)
 void launch_mark_halo(int32_t nh, int32_t cnt, int32_t W, int32_t *outd, uint16_t *ref, uint8_t *need, int *err, hipStream_t st);
 void launch_scan(const int32_t *in, int64_t n, int64_t *out, int64_t *sums, hipStream_t st, const HashCtx *hx = nullptr, int32_t lo = 0, int32_t nh = 0, long long topTiledMin = -1); // topTiledMin: block sums from which the top level runs tiled (-1: default) // hx: the node numbers of slots >= nh are added to the hash (HashCtx)
@@ -104,13 +104,13 @@ void launch_parse_big(const GraphDev &g, int def, const RangeView &v, const int3
 constexpr int ARENA_ENTRY_BYTES = 16;
 void launch_build_lists(const GraphDev &g, const RangeView &v, uint64_t giantBits, int32_t noBin, int32_t *depth, uint16_t *key16, int32_t *hist, int32_t *keyBase, int32_t *cursor,
                         int32_t *list, int32_t *giantlist, int32_t giantCap, int32_t *ctl, int32_t *maxdepth, hipStream_t st,
-                        int32_t *bigQ = nullptr, int32_t bigCap = 0, int32_t *midQ = nullptr, int32_t midCap = 0, int32_t midMinKnob = 0, bool bigGroups = false);
+                        int32_t *bigQ = nullptr, int32_t bigCap = 0, int32_t *midQ = nullptr, int32_t midCap = 0, int32_t midMinKnob = 0, bool bigGroups = false, const uint16_t *packRef = nullptr);
 void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int32_t *depth, const int32_t *list, const int32_t *keyBase, int32_t level, int blocks,
                        int32_t midMinKnob, bool bigGroups, const int32_t *bigQ, int32_t bigCap, const int32_t *midQ, int32_t midCap, int32_t *ctl, int32_t *tmp, uint32_t tmpCap, int *err,
                        hipStream_t st, hipStream_t stMid, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evMid, hipEvent_t evBig, const void *preDesc = nullptr, bool preMid = false, int listMode = false,
                        const void *tabArena = nullptr, int64_t tabArenaCap = 0, const void *copyTab = nullptr); // copyTab: 16 bytes per slot, the copy blocks of the rows that the one-lane parse decoded (parse_node_lwc / parse_node_tile; bv_lanewin.hpp), blocks from the fourth on in tabArena = the interval arena; null: the lane class walks the stream // vecList: the lane class merges with 16-byte loads and stores (copy_node_v) // preDesc: launch_copy_prewalk's descriptors
 void launch_copy_prewalk(const GraphDev &g, int def, const RangeView &v, const int32_t *bigQ, int32_t bigCap, const int32_t *ctl, void *desc, int blocks, hipStream_t st, int32_t midCap, hipStream_t stLong, bool longKernel, hipStream_t stWalk); // stWalk: the stream of k_copy_prewalk (as stLong) // stLong: the stream of the long lists' kernel (ordered behind the queues by the caller; may be st); // midCap > 0: also the wave class's rows (queue at bigQ + bigCap, descriptors at desc + bigCap)
-void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, void *arena, int64_t arenaCap, int32_t keyLo = 0, int32_t keyHi = NKEYS, bool lwc = true, void *copyTab = nullptr); // lwc: round 6's loop (parse_node_lwc), which leaves the tables in copyTab; false: round 4's // the list's keys [keyLo, keyHi); v.hx (default codings only): hash fold
+void launch_parse_list(const GraphDev &g, int def, const RangeView &v, const int32_t *list, const int32_t *keyBase, int blocks, int *err, hipStream_t st, void *arena, int64_t arenaCap, int32_t keyLo = 0, int32_t keyHi = NKEYS, bool lwc = true, void *copyTab = nullptr, bool packed = false); // lwc: round 6's loop (parse_node_lwc), which leaves the tables in copyTab; false: round 4's // the list's keys [keyLo, keyHi); v.hx (default codings only): hash fold
 // what the decoding kernels did not add to v.hx->acc, from memory: what bit 2 = the node numbers, bit 0 = every row without a reference that the one-lane parse did not
 // hash (a pass over all nodes: only when the rows are not in a list), bit 1 = the same for the rows with a reference and the lane class of the copy pass; qA / qB: work
 // lists whose rows are hashed (those with a reference if wantRef, those without otherwise); inParse / inCopy: the one-lane parse / the lane class of the copy pass

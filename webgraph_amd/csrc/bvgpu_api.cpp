@@ -173,6 +173,7 @@ struct bvg_graph {
 	int keys_in_headers = 1; // BVGPU_KEYS_IN_HEADERS=0: the parse list's keys by k_depth_keys, not by k_headers
 	bool keys_ready = false; // (per job) k_headers wrote them
 	int level_bins = 1;  // BVGPU_LEVEL_BINS=0: the level lists in node order (round 5), not sorted by the records' work bins inside a level: the wave loop of k_copy_list_w runs as long as its longest row
+	int list_refs = 1;   // BVGPU_LIST_REFS=0: plain slot numbers in the parse list (k_parse_list looks the reference up)
 	int copy_loop = 1;   // BVGPU_COPY_LOOP=0: the lane class of the copy pass merges lane by lane (copy_node_tab), not as a loop of the wave (k_copy_list_w)
 	int lane_loop = 1;   // BVGPU_LANE_LOOP=0: round 4's one-lane loop (parse_node_lwb) instead of round 6's (parse_node_lwc)
 	int copy_tables = 1; // BVGPU_COPY_TABLES=0: the lane class of the copy pass walks the block lists in the stream although the parse left them as tables
@@ -277,6 +278,7 @@ int apply_option(bvg_graph *g, const std::string &name, const char *value) {
 	else if (name == "copy_vec") g->copy_vec = iv;
 	else if (name == "lane_loop") g->lane_loop = iv;
 	else if (name == "copy_loop") g->copy_loop = iv;
+	else if (name == "list_refs") g->list_refs = iv;
 	else if (name == "level_bins") g->level_bins = iv;
 	else if (name == "keys_in_headers") g->keys_in_headers = iv;
 	else if (name == "giants_after_list") g->giants_after_list = iv;
@@ -302,7 +304,7 @@ int apply_option(bvg_graph *g, const std::string &name, const char *value) {
 	return BVG_OK;
 }
 const char *const OPTION_NAMES[] = { "coop_min", "giant_min", "coop_waves", "giant_groups", "level_blocks", "copy_big", "parse_windows", "tile", "seg", "seg_hub_min", "seg_blocks", "lists_on_b", "skip_empty_giants", "level_lists_early",
-	"walk_tables", "copy_vec", "lane_loop", "copy_loop", "level_bins", "copy_tables", "giants_after_list", "keys_in_headers", "prewalk", "prewalk_long", "prewalk_blocks", "copy_mid_min", "overlap", "halo_min", "batch_dense", "scan_top_tiled_min", "wait_giants", "hash_materialise",
+	"walk_tables", "copy_vec", "lane_loop", "copy_loop", "list_refs", "level_bins", "copy_tables", "giants_after_list", "keys_in_headers", "prewalk", "prewalk_long", "prewalk_blocks", "copy_mid_min", "overlap", "halo_min", "batch_dense", "scan_top_tiled_min", "wait_giants", "hash_materialise",
 	"ef_hash_materialise", "scan_piece", "dbg", "stats", "trace_retry", "trace_err", "trace_host" };
 void options_from_env(bvg_graph *g) {
 	for (const char *n : OPTION_NAMES) {
@@ -663,6 +665,8 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		const bool noGiants = g->skip_empty_giants && s.max_outdegree >= 0 && s.max_outdegree < (int64_t)giantMin;
 		const bool listsOnB = (g->lists_on_b == 1 || (g->lists_on_b == 0 && noGiants && ovl && coop && !(tiles && g->level_lists_early))) && !segReady; // (with the hand-over side B carries the segment pipeline's chain)
 		const bool listsOnC = g->lists_on_b == 2 && ovl;
+		// the parse list's entries carry the records' references (two lines less per record in k_parse_list: bv_kernels.hip) when a slot fits in 28 bits
+		const uint16_t *packRef = g->list_refs && !tiles && v.cnt < (1 << 28) ? v.ref : nullptr;
 		if (!tiles) {
 			if (!g->plist.need(sizeof(int32_t) * (size_t)v.cnt) || !g->pkeys.need(3 * (bv::NKEYS + 1) * sizeof(int32_t)) || !g->pkey16.need(sizeof(uint16_t) * (size_t)v.cnt)) return fail(g, BVG_ENOMEM, "device scratch allocation failed");
 			pKeyBase = g->pkeys.as<int32_t>() + (bv::NKEYS + 1);
@@ -705,13 +709,13 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		if (earlyList && keysReady) { // k_headers left the keys: three small kernels to the list
 			HIPCHK(g, hipStreamWaitEvent(g->sideA, g->evHdr, 0));
 			bv::launch_scatter_lists(v.cnt, g->pkey16.as<uint16_t>(), g->pkeys.as<int32_t>(), pKeyBase, pKeyBase + (bv::NKEYS + 1), g->plist.as<int32_t>(), g->giantlist.as<int32_t>(), ctl,
-			                         &g->small.as<Small>()->pad, g->sideA);
+			                         &g->small.as<Small>()->pad, g->sideA, packRef);
 			HIPCHK(g, hipEventRecord(g->evP, g->sideA));
 		}
 		else if (earlyList) {
 			HIPCHK(g, hipStreamWaitEvent(g->sideA, g->evHdr, 0));
 			bv::launch_build_lists(gd, v, ~0ull, g->parse_windows ? 6 : 2, nullptr, g->pkey16.as<uint16_t>(), g->pkeys.as<int32_t>(), pKeyBase, pKeyBase + (bv::NKEYS + 1), g->plist.as<int32_t>(),
-			                       g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->pad, g->sideA);
+			                       g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->pad, g->sideA, nullptr, 0, nullptr, 0, 0, false, packRef);
 			HIPCHK(g, hipEventRecord(g->evP, g->sideA));
 		}
 		if (ovl) {
@@ -768,7 +772,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		if (ovl && coop && listsOnB) HIPCHK(g, hipEventRecord(g->evB, side_b(g))); // (the lists sit behind the giants: side B is done when they are)
 		if (!tiles && !earlyList)
 			bv::launch_build_lists(gd, v, ~0ull, g->parse_windows ? 6 : 2, nullptr, g->pkey16.as<uint16_t>(), g->pkeys.as<int32_t>(), pKeyBase, pKeyBase + (bv::NKEYS + 1), g->plist.as<int32_t>(),
-			                       g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->pad, g->stream);
+			                       g->giantlist.as<int32_t>(), 0, ctl, &g->small.as<Small>()->pad, g->stream, nullptr, 0, nullptr, 0, 0, false, packRef);
 		if (earlyList || (tiles && ovl && hdrEvent)) HIPCHK(g, hipStreamWaitEvent(g->stream, g->evP, 0));
 		if (coop && !ovl) bv::launch_classify(v.cnt, v.outd, v.coop_ptr, coopMin, giantMin, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), giantCap, ctl, g->stream);
 		mark(g, 3);
@@ -789,7 +793,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 				if (ovl) HIPCHK(g, hipEventRecord(g->evB, stChain));
 			}
 			if (ovl && coop) { HIPCHK(g, hipStreamWaitEvent(g->stream, g->evC, 0)); if (g->wait_giants && !noGiants) bv::launch_wait_giants(ctl, g->giant_groups, g->stream); } // (the giants first: k_wait_giants)
-			bv::launch_parse_list(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, g->level_blocks, derr, g->stream, g->arena.p, arenaCap, 0, bv::NKEYS, g->lane_loop != 0, copyTab);
+			bv::launch_parse_list(gd, s.def, v, g->plist.as<int32_t>(), pKeyBase, g->level_blocks, derr, g->stream, g->arena.p, arenaCap, 0, bv::NKEYS, g->lane_loop != 0, copyTab, packRef != nullptr);
 		}
 		if (ovl) {
 			HIPCHK(g, hipStreamWaitEvent(g->stream, g->evA, 0));
