@@ -173,6 +173,7 @@ struct bvg_graph {
 	int keys_in_headers = 1; // BVGPU_KEYS_IN_HEADERS=0: the parse list's keys by k_depth_keys, not by k_headers
 	bool keys_ready = false; // (per job) k_headers wrote them
 	int level_bins = 1;  // BVGPU_LEVEL_BINS=0: the level lists in node order (round 5), not sorted by the records' work bins inside a level: the wave loop of k_copy_list_w runs as long as its longest row
+	int pick_aside = 1;  // BVGPU_PICK_ASIDE=0: k_pick_coop in front of the scan of the outdegrees, not beside it
 	int list_refs = 1;   // BVGPU_LIST_REFS=0: plain slot numbers in the parse list (k_parse_list looks the reference up)
 	int copy_loop = 1;   // BVGPU_COPY_LOOP=0: the lane class of the copy pass merges lane by lane (copy_node_tab), not as a loop of the wave (k_copy_list_w)
 	int lane_loop = 1;   // BVGPU_LANE_LOOP=0: round 4's one-lane loop (parse_node_lwb) instead of round 6's (parse_node_lwc)
@@ -187,7 +188,7 @@ struct bvg_graph {
 	hipStream_t sideA = nullptr, sideB = nullptr; // (more streams than this share hardware queues with each other: they would serialise)
 	bool ctl_clean = false;                       // ctl[4..16) were zeroed by this job's k_pick_coop
 	bool host_mode = false;                       // host_scan: sideB carries the PCIe copies, its kernels go to sideA
-	hipEvent_t evFork = nullptr, evA = nullptr, evB = nullptr, evC = nullptr, evHdr = nullptr, evP = nullptr, evM = nullptr, evH = nullptr, evL = nullptr;
+	hipEvent_t evFork = nullptr, evA = nullptr, evB = nullptr, evC = nullptr, evHdr = nullptr, evHdr0 = nullptr, evP = nullptr, evM = nullptr, evH = nullptr, evL = nullptr;
 	bool overlap = true;
 	size_t halo_min = (size_t)16 << 20; // bytes of halo scratch an optimistic sub-range decode starts with (BVGPU_HALO_MIN)
 	bool force_halo_sync = false;   // (retry of an optimistic sub-range decode: size the halo with a host round trip)
@@ -221,6 +222,7 @@ namespace {
 
 bv::GraphDev graph_dev0(const Staged &s);
 bool copy_vec(const bvg_graph *g);
+inline hipStream_t side_b(const bvg_graph *g);
 bv::GraphDev graph_dev_h(const bvg_graph *g, const Staged &s) { bv::GraphDev d = graph_dev0(s); d.stats = (unsigned long long *)g->stats.p; d.dbg = g->dbg; return d; }
 
 int fail(const bvg_graph *g, int code, const std::string &msg) { if (g) g->err = msg; return code; }
@@ -279,6 +281,7 @@ int apply_option(bvg_graph *g, const std::string &name, const char *value) {
 	else if (name == "lane_loop") g->lane_loop = iv;
 	else if (name == "copy_loop") g->copy_loop = iv;
 	else if (name == "list_refs") g->list_refs = iv;
+	else if (name == "pick_aside") g->pick_aside = iv;
 	else if (name == "level_bins") g->level_bins = iv;
 	else if (name == "keys_in_headers") g->keys_in_headers = iv;
 	else if (name == "giants_after_list") g->giants_after_list = iv;
@@ -304,7 +307,7 @@ int apply_option(bvg_graph *g, const std::string &name, const char *value) {
 	return BVG_OK;
 }
 const char *const OPTION_NAMES[] = { "coop_min", "giant_min", "coop_waves", "giant_groups", "level_blocks", "copy_big", "parse_windows", "tile", "seg", "seg_hub_min", "seg_blocks", "lists_on_b", "skip_empty_giants", "level_lists_early",
-	"walk_tables", "copy_vec", "lane_loop", "copy_loop", "list_refs", "level_bins", "copy_tables", "giants_after_list", "keys_in_headers", "prewalk", "prewalk_long", "prewalk_blocks", "copy_mid_min", "overlap", "halo_min", "batch_dense", "scan_top_tiled_min", "wait_giants", "hash_materialise",
+	"walk_tables", "copy_vec", "lane_loop", "copy_loop", "list_refs", "pick_aside", "level_bins", "copy_tables", "giants_after_list", "keys_in_headers", "prewalk", "prewalk_long", "prewalk_blocks", "copy_mid_min", "overlap", "halo_min", "batch_dense", "scan_top_tiled_min", "wait_giants", "hash_materialise",
 	"ef_hash_materialise", "scan_piece", "dbg", "stats", "trace_retry", "trace_err", "trace_host" };
 void options_from_env(bvg_graph *g) {
 	for (const char *n : OPTION_NAMES) {
@@ -338,6 +341,7 @@ int init_handle(bvg_graph *g) {
 	HIPCHK(g, hipEventCreateWithFlags(&g->evB, hipEventDisableTiming));
 	HIPCHK(g, hipEventCreateWithFlags(&g->evC, hipEventDisableTiming));
 	HIPCHK(g, hipEventCreateWithFlags(&g->evHdr, hipEventDisableTiming));
+	HIPCHK(g, hipEventCreateWithFlags(&g->evHdr0, hipEventDisableTiming));
 	HIPCHK(g, hipEventCreateWithFlags(&g->evP, hipEventDisableTiming));
 	HIPCHK(g, hipEventCreateWithFlags(&g->evM, hipEventDisableTiming));
 	HIPCHK(g, hipEventCreateWithFlags(&g->evH, hipEventDisableTiming));
@@ -424,14 +428,25 @@ int enqueue_structure(bvg_graph *g, int32_t from, int32_t to, int32_t nh, bv::Ra
 	bv::launch_headers(gd, s.def, lo, cnt, v.outd, v.ref, derr, g->stream, pick ? g->pickpart.as<int32_t>() : nullptr, g->hash_job ? g->hashmark.as<uint8_t>() : nullptr,
 	                   pk16, pk16 ? g->pkeys.as<int32_t>() : nullptr, g->parse_windows != 0);
 	if (nh) bv::launch_mark_halo(nh, cnt, s.info.window_size, v.outd, v.ref, g->need.as<uint8_t>(), derr, g->stream);
+	// k_pick_coop is ONE block that adds up 7 counts per block of k_headers (21 us on C2, 124 us at 50 M nodes) and the scan of the outdegrees does not need it: on side B,
+	// beside the scan (pick_aside = 0: in front of it, as until round 6).  evHdr then says "headers final, threshold picked, counters clean"; the job's stream joins it behind the scan.
+	const bool pickAside = pick && g->pick_aside && g->overlap && !g->profile;
 	if (pick) { // (also zeroes ctl[4..16), the counters of the lists and of the copy levels: a memset behind the scan kernels sat 22 us on the critical path)
-		bv::launch_pick_coop(g->pickpart.as<int32_t>(), (int32_t)hb, COOP_BUDGET, g->coopctl.as<int32_t>(), g->stream);
+		hipStream_t stPick = g->stream;
+		if (pickAside) {
+			stPick = side_b(g);
+			HIPCHK(g, hipEventRecord(g->evHdr0, g->stream));
+			HIPCHK(g, hipStreamWaitEvent(stPick, g->evHdr0, 0));
+		}
+		bv::launch_pick_coop(g->pickpart.as<int32_t>(), (int32_t)hb, COOP_BUDGET, g->coopctl.as<int32_t>(), stPick);
 		v.coop_ptr = g->coopctl.as<int32_t>() + bv::CTL_COOP;
 		g->ctl_clean = true;
+		if (pickAside) HIPCHK(g, hipEventRecord(g->evHdr, stPick));
 	}
-	HIPCHK(g, hipEventRecord(g->evHdr, g->stream)); // outdegrees and references are final: the parse list can be built while the scan runs
+	if (!pickAside) HIPCHK(g, hipEventRecord(g->evHdr, g->stream)); // outdegrees and references are final: the parse list can be built while the scan runs
 	mark(g, 1);
 	bv::launch_scan(v.outd, cnt, v.rowstart, g->sums.as<int64_t>(), g->stream, g->hash_job ? g->hashctx.as<bv::HashCtx>() : nullptr, lo, nh, g->scan_top_tiled_min);
+	if (pickAside) HIPCHK(g, hipStreamWaitEvent(g->stream, g->evHdr, 0));
 	mark(g, 2);
 	return BVG_OK;
 }
@@ -1360,7 +1375,7 @@ extern "C" int bvg_close(bvg_t *g) {
 		for (hipEvent_t e : { g->evChunk[0], g->evChunk[1], g->evCopied[0], g->evCopied[1] }) if (e) (void)hipEventDestroy(e);
 		if (g->h_small) (void)hipHostFree(g->h_small);
 		for (auto &e : g->ev) if (e) (void)hipEventDestroy(e);
-		for (hipEvent_t e : { g->evFork, g->evA, g->evB, g->evC, g->evHdr, g->evP, g->evM, g->evH, g->evL, g->evIn, g->evOut }) if (e) (void)hipEventDestroy(e);
+		for (hipEvent_t e : { g->evFork, g->evA, g->evB, g->evC, g->evHdr, g->evHdr0, g->evP, g->evM, g->evH, g->evL, g->evIn, g->evOut }) if (e) (void)hipEventDestroy(e);
 		for (hipStream_t st : { g->sideA, g->sideB, g->sideC }) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
 	}
 	delete g;
