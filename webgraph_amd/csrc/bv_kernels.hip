@@ -667,8 +667,9 @@ __global__ void __launch_bounds__(TPB) k_copy_list_w(GraphDev g, RangeView v, co
 			row = s < v.nh ? v.halo + rs0 : v.succ + (rs0 - rsNh);
 			src = t < v.nh ? v.halo + rt0 : v.succ + (rt0 - rsNh);
 			// ints that may be READ from the row's start on (a 16-byte load at the end of a row reads into its neighbours, never past the buffer)
-			limE = (int32_t)min<int64_t>(s < v.nh ? (int64_t)v.halo_cap - rs0 : (int64_t)v.succ_cap - (rs0 - rsNh), 0x7fffffff);
-			limS = (int32_t)min<int64_t>(t < v.nh ? (int64_t)v.halo_cap - rt0 : (int64_t)v.succ_cap - (rt0 - rsNh), 0x7fffffff);
+			// (unsigned: the rows fit, so the differences are >= d / dref)
+			limE = (int32_t)min<uint64_t>(s < v.nh ? v.halo_cap - (uint64_t)rs0 : v.succ_cap - (uint64_t)(rs0 - rsNh), 0x7fffffffull);
+			limS = (int32_t)min<uint64_t>(t < v.nh ? v.halo_cap - (uint64_t)rt0 : v.succ_cap - (uint64_t)(rt0 - rsNh), 0x7fffffffull);
 			if (d < coopMin) {
 				hd = *(const int4 *)(ctab + s);
 				const uint32_t kept = (uint32_t)hd.w & 0xffffu;

@@ -1034,6 +1034,7 @@ int decode_range_device(bvg_graph *g, int32_t from, int32_t to, int64_t *rowptr_
 		break;
 	}
 	v.succ = succ_dev; v.halo = g->halo.as<int32_t>(); v.succ_cap = succ_cap;
+	if (nh > 0) v.halo_cap = g->halo.cap / sizeof(int32_t); // (the real size in every case: the copy pass's 16-byte windows may read up to three ids past a row, never past the buffer)
 	int32_t levels = 0;
 	int32_t giantCap = 0;
 	g->early_rowptr = succ_dev && g->overlap && !g->profile ? rowptr_dev : nullptr;
@@ -1821,6 +1822,7 @@ extern "C" int bvg_successors_batch(bvg_t *g, const int32_t *nodes, size_t q, in
 		}
 		if (!g->halo.need(sizeof(int32_t) * (size_t)std::max<int64_t>(g->h_small->halo_total, 1))) return fail(g, BVG_ENOMEM, "arena allocation failed");
 		v.succ = nullptr; v.halo = g->halo.as<int32_t>(); v.succ_cap = 0;
+		v.halo_cap = g->halo.cap / sizeof(int32_t); // (the arena's real size: the copy pass's 16-byte windows may read up to three ids past a row, never past the buffer)
 		int32_t levels = 0, giantCap = 0;
 		// (the headers' event: outdegrees and references have been final since the round trip above -- with it the parse list is built and the long records are classified
 		// side by side BEFORE the cooperative kernels start, as in a range job; without it the list's three kernels ran beside the giants and the wave class, starved: 0.8 of C4's 4.3 ms)
