@@ -1386,7 +1386,10 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 // outdegree and the stream words) in front of ~5 us of decoding; the entry is fetched two sweeps ahead and what hangs on it one sweep
 // ahead, so a sweep waits for the last trip only.  Default codings: parse_node_lwb (bv_lanewin.hpp); others: the generic reader.
 template <int DEF, bool HASH = false, bool LWC = true> // LWC: the round-6 loop (parse_node_lwc: leaves the copy blocks as tables); false: round 4's (parse_node_lwb; knob lane_loop = 0)
-__global__ void __launch_bounds__(TPB) k_parse_list(GraphDev g, RangeView v, const int32_t *__restrict__ list, const int32_t *__restrict__ keyBase, int32_t binLo, int32_t binHi,
+#ifndef PARSE_LIST_MINWAVES // (tuning builds: blocks per CU the compiler is asked to leave registers for)
+#define PARSE_LIST_MINWAVES 1
+#endif
+__global__ void __launch_bounds__(TPB, PARSE_LIST_MINWAVES) k_parse_list(GraphDev g, RangeView v, const int32_t *__restrict__ list, const int32_t *__restrict__ keyBase, int32_t binLo, int32_t binHi,
                                                     IvEntry *__restrict__ arena, int64_t arenaCap, int *__restrict__ err, CopyTab *__restrict__ ctab = nullptr, int packed = 0) {
 	static_assert(!HASH || DEF != 0, "the hash fold rides on the default codings' loop");
 	__shared__ uint32_t lw[DEF ? (LW_MAIN + 2 * LW_RING) * LW_STRIDE : 1]; // per lane: a window of the stream and a ring of intervals (default codings)
