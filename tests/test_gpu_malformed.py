@@ -265,7 +265,7 @@ def test_extras_that_equal_copied_ids_are_emitted_once(tmp_path, monkeypatch, kn
     """The same one level up: a residual (or an id of an interval) that equals an id COPIED from the referent.  MergedIntIterator.java:69-72 emits the equal heads once, the
     list is shorter than its outdegree and the array ends in -1 (BVGraph.java:1210).  The copy pass's merges -- the wave's loop (k_copy_list_w), the lane-by-lane merges, the
     wave class's ranks (k_copy_mid: rows of 128 .. 1023 ids by default, here from 4 on) -- must agree with the oracle; the rows that copy from such a row (its -1 included) too.
-    (The group class -- rows of 1024 ids and more -- ranks its two sets against each other and would leave a hole behind such a pair: DESIGN.md, open list.)"""
+    (The group class -- rows of 1 024 ids and more: test_group_class_emits_equal_heads_once below.)"""
     from bitio import write_graph, int2nat
     from webgraph_amd.bvgraph import BVGraph
     from oracle import oracle as O
@@ -322,4 +322,70 @@ def test_extras_that_equal_copied_ids_are_emitted_once(tmp_path, monkeypatch, kn
     assert np.array_equal(rp, rp0) and np.array_equal(sc, sc0)
     rp, sc = g.decode_range(101, 303)
     assert np.array_equal(sc, sc0[rp0[101]:rp0[303]])
+    g.close()
+
+
+@pytest.mark.parametrize("shape", ["lds", "chunks", "stream"])
+@pytest.mark.parametrize("knobs", [{}, {"BVGPU_PREWALK": "0"}, {"BVGPU_COOP_MIN": "2147483647"}])
+def test_group_class_emits_equal_heads_once(tmp_path, monkeypatch, shape, knobs):
+    """The same for the rows the GROUP class of the copy pass merges (1 024 ids and more, k_copy_big), through its three merges: both sets in LDS ("lds": a referent of 3 000 ids,
+    2 000 extras), the extras moved in place chunk by chunk ("chunks": 9 000 extras), tables and copied ids in global scratch with the output cut into tiles ("stream": a referent of
+    10 000 ids; one equal pair sits astride the first cut at 8 192, one is the last copied id).  The merges are stable and the group closes the gaps afterwards (dedupe_row)."""
+    from bitio import write_graph, int2nat
+    from webgraph_amd.bvgraph import BVGraph
+    from oracle import oracle as O
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(23)
+
+    def row(x, ref, blocks, res, d):
+        def rec(w):
+            w.gamma(d)
+            if d == 0:
+                return
+            w.unary(ref)
+            if ref:
+                w.gamma(len(blocks))
+                for i, b in enumerate(blocks):
+                    w.gamma(b if i == 0 else b - 1)
+            if res:
+                w.gamma(0)  # no intervals
+            pv = None
+            for r in res:
+                w.zeta(int2nat(r - x) if pv is None else r - pv - 1)
+                pv = r
+        return rec
+
+    nref, nextra = {"lds": (3000, 2000), "chunks": (3000, 9000), "stream": (10000, 3000)}[shape]
+    recs, arcs = [], 0
+    for fam in range(3):
+        x = 4 * fam
+        proto = [2 * t for t in range(nref)]  # the referent: even numbers
+        recs.append(row(x, 0, [], proto, nref)); arcs += nref
+        if fam == 0:  # copies everything; an equal pair at merged positions (8 191, 8 192) when the referent is long enough, the last copied id, a few more
+            dups = [proto[min(8191, nref - 7)], proto[-1], proto[5], proto[nref // 2]]
+            blocks, kept = [], proto
+        elif fam == 1:  # copies every second stretch of 50
+            blocks = [50] * (nref // 50 - 1)
+            kept = [v for i, v in enumerate(proto) if (i // 50) % 2 == 0]
+            dups = [kept[0], kept[-1], kept[len(kept) // 3]] + [kept[int(i)] for i in rng.integers(0, len(kept), size=20)]
+        else:  # skips the first 10, copies the rest
+            blocks = [0, 10]
+            kept = proto[10:]
+            dups = [kept[int(i)] for i in rng.integers(0, len(kept), size=200)]
+        odd = sorted(set(int(v) for v in rng.integers(2 * min(8192, nref - 6), 2 * nref + 60000, size=3 * nextra) if v % 2 == 1))[:nextra]
+        res = sorted(set(dups + odd))
+        d1 = len(kept) + len(res)
+        recs.append(row(x + 1, 1, blocks, res, d1)); arcs += d1
+        recs.append(row(x + 2, 1, [], [], d1)); arcs += d1  # copies the row that ends in -1, whole
+        recs.append(row(x + 3, 0, [], [], 0))
+    base = str(tmp_path / ("groupdup_" + shape))
+    write_graph(base, recs, min_interval=2, arcs=arcs)
+    rp0, sc0, _ = O.OracleGraph.load(base).scan()
+    assert (sc0 == -1).sum() >= 3 * 2 * 3
+    g = BVGraph.load(base)
+    rp, sc = g.decode_range()
+    assert np.array_equal(rp, rp0)
+    for x in range(len(recs)):
+        assert np.array_equal(sc[rp0[x]:rp0[x + 1]], sc0[rp0[x]:rp0[x + 1]]), (shape, x)
     g.close()

@@ -1035,6 +1035,7 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 	__shared__ __attribute__((aligned(16))) uint32_t cwin[OWN_WALK ? CoopLds<1>::WORDS : 4]; // tile of the cooperative walk of a long block list
 	__shared__ int64_t s_copied, s_tmp, s_kmax, s_desc;
 	__shared__ int32_t s_kept, s_bad;
+	__shared__ int32_t s_dup, s_wsum[COPY_BIG_THREADS / 64]; // an extra that equals a copied id was seen in this row (never in a valid file): dedupe_row below
 	// The queue holds the long rows of ALL levels; a group takes the next entry that is of this level and of this pass from a
 	// shared head (rows differ by 200x in length: fixed shares left most groups idle while a few worked through several
 	// giant rows).  Two passes, the rows of >= COPY_BIG_FIRST ids first, so that the longest merges start at once.
@@ -1121,11 +1122,36 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 			}
 			__syncthreads();
 		};
+		// An extra that equals a copied id (no writer produces one): MergedIntIterator.java:69-72 emits equal heads once and the row ends in -1 (BVG:1210).  The merges below
+		// are STABLE -- a copied id goes to t + #(extras smaller), an extra to e + #(copied ids smaller OR EQUAL): the pair lands side by side, nothing is left unwritten -- and
+		// raise s_dup where they see such a pair; the group then closes the gaps in place, a chunk of the row at a time (an id moves left only), and pads the row.
+		auto dedupe_row = [&]() {
+			__syncthreads(); // the row is complete, s_dup is final
+			if (!s_dup) return; // (uniform)
+			int32_t carry = 0;
+			for (int32_t base = 0; base < d; base += COPY_BIG_THREADS) {
+				const int32_t i = base + (int32_t)threadIdx.x;
+				const int32_t x = i < d ? row[i] : 0;
+				const bool gone = i > 0 && i < d && x == row[i - 1]; // (row[base - 1] still holds what the merge put there: ids of earlier chunks moved LEFT of it, or not at all)
+				const unsigned long long m = __ballot(gone);
+				__syncthreads(); // every id of this chunk has been read; the last chunk's sums too
+				if ((threadIdx.x & 63) == 0) s_wsum[threadIdx.x >> 6] = __popcll(m);
+				__syncthreads();
+				int32_t before = 0, total = 0;
+				for (int k = 0; k < COPY_BIG_THREADS / 64; k++) { const int32_t c = s_wsum[k]; if (k < (int)(threadIdx.x >> 6)) before += c; total += c; }
+				const int32_t shift = carry + before + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+				if (i < d && !gone && shift > 0) row[i - shift] = x;
+				carry += total;
+			}
+			__syncthreads();
+			for (int32_t i = d - carry + (int32_t)threadIdx.x; i < d; i += COPY_BIG_THREADS) row[i] = -1;
+		};
 		// The merge proper, on tables that live in LDS (the usual case) or in global scratch (rows copying more ids
 		// than the LDS tables hold): gather the copied ids, rank them among the extras (still at row[nc..d)), move the
 		// extras left chunk by chunk, drop the copied ids into the gaps.  kpos doubles as kend during the gather.
 		auto merge_row = [&](const int32_t *kend, const int32_t *dlt, int32_t *cv_, int32_t *cp_, int32_t nc, int32_t nKept) {
 			const int32_t nExtra = d - nc;
+			if (threadIdx.x == 0) s_dup = 0; // (a barrier follows before anybody raises it)
 			for (int32_t t = threadIdx.x; t < nc; t += COPY_BIG_THREADS) {
 				int32_t lo = 0, hi = nKept; // first copied block with kend > t (a block of length 0 is possible only in first position)
 				while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (kend[mid] <= t) lo = mid + 1; else hi = mid; }
@@ -1146,11 +1172,13 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 				CT(2);
 				for (int32_t e = threadIdx.x; e < nExtra; e += COPY_BIG_THREADS) {
 					const int32_t ev = s_ext[e];
-					int32_t lo = 0, hi = nc; // copied ids smaller than this extra
-					while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (cv_[mid] < ev) lo = mid + 1; else hi = mid; }
+					int32_t lo = 0, hi = nc; // copied ids not larger than this extra
+					while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (cv_[mid] <= ev) lo = mid + 1; else hi = mid; }
+					if (lo > 0 && cv_[lo - 1] == ev) s_dup = 1;
 					if (lo < nc) row[e + lo] = ev; // (the extras behind the last copied id stay where they are)
 				}
 				CT(3);
+				dedupe_row();
 				return;
 			}
 			__syncthreads();
@@ -1165,6 +1193,7 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 			CT(2);
 			// extras up to the one following the last copied id move; the rest stay where they are
 			const int32_t nMove = cp_[nc - 1] - (nc - 1);
+			if (threadIdx.x == 0 && nMove < nExtra && row[nc + nMove] == cv_[nc - 1]) s_dup = 1; // (the first extra that stays equals the last copied id)
 			constexpr int32_t CHUNK = COPY_BIG_THREADS * COPY_BIG_ITEMS;
 			int32_t cur[COPY_BIG_ITEMS], nxt[COPY_BIG_ITEMS];
 #pragma unroll
@@ -1179,8 +1208,9 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 				for (int u = 0; u < COPY_BIG_ITEMS; u++) {
 					const int32_t e = e0 + u * COPY_BIG_THREADS + (int32_t)threadIdx.x;
 					if (e < nMove) {
-						int32_t lo = 0, hi = nc; // copied ids smaller than this extra
-						while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (cv_[mid] < cur[u]) lo = mid + 1; else hi = mid; }
+						int32_t lo = 0, hi = nc; // copied ids not larger than this extra
+						while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (cv_[mid] <= cur[u]) lo = mid + 1; else hi = mid; }
+						if (lo > 0 && cv_[lo - 1] == cur[u]) s_dup = 1;
 						if (lo < nc) row[e + lo] = cur[u];
 					}
 				}
@@ -1189,6 +1219,7 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 			CT(3);
 			for (int32_t t = threadIdx.x; t < nc; t += COPY_BIG_THREADS) row[cp_[t]] = cv_[t];
 			CT(4);
+			dedupe_row();
 		};
 		// The same merge for a row whose tables (kend, dlt) and copied ids (cv_) live in global scratch.  Nothing here searches
 		// global memory element by element (a row of 300 000 ids spent 4 ms in such searches): the copied ids are gathered
@@ -1200,6 +1231,7 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 			constexpr int32_t TS = COPY_BIG_THREADS * 8, GT = TS, ITEMS = TS / COPY_BIG_THREADS; // (a round of the gather is a chain of latencies -- table, search, id, store, barriers --: as many ids per round as the LDS tables allow)
 			static_assert(2 * (GT + 1) <= 3 * COPY_BIG_CAP + 2 && TS + COPY_BIG_THREADS + 1 <= 3 * COPY_BIG_CAP + 2, "the tiles of the streaming merge live in the LDS tables");
 			const int32_t nExtra = d - nc;
+			if (threadIdx.x == 0) s_dup = 0; // (barriers follow before anybody raises it)
 			int32_t *bufK = tabs, *bufD = tabs + GT + 1;
 			// b0 = the block that holds id t0.  Blocks after the first are non-empty, so the blocks of the GT ids of a tile are among
 			// the GT + 1 table entries from b0 on: they are loaded as they lie, and the next tile's b0 is found in LDS.
@@ -1253,7 +1285,8 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 					const int32_t p = (int32_t)min<int64_t>(d, (int64_t)base + (int64_t)k * TS);
 					// copied ids among the first p of the merge; extras below index base - iBase are gone: i(p) <= iBase + (p - base)
 					int32_t lo = max(max(0, p - nExtra), iBase), hi = min(min(p, nc), iBase + (p - base));
-					while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (cv_[mid] < row[nc + (p - 1 - mid)]) lo = mid + 1; else hi = mid; }
+					while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (cv_[mid] <= row[nc + (p - 1 - mid)]) lo = mid + 1; else hi = mid; } // (<=: of equal heads the copied id comes first)
+					if (lo > 0 && p - lo < nExtra && cv_[lo - 1] == row[nc + (p - lo)]) s_dup = 1; // an equal pair astride this cut: no tile sees both
 					splits[k] = lo;
 				}
 				__syncthreads();
@@ -1283,15 +1316,19 @@ __global__ void __launch_bounds__(COPY_BIG_THREADS) k_copy_big(GraphDev g, Range
 						const int32_t t = u * COPY_BIG_THREADS + (int32_t)threadIdx.x;
 						if (t >= tot) continue;
 						int32_t lo, hi, self;
-						if (t < ni) { lo = ni; hi = tot; self = t - ni; }
-						else { lo = 0; hi = ni; self = t - ni; }
-						while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (buf[mid] < y[u]) lo = mid + 1; else hi = mid; }
+						if (t < ni) { lo = ni; hi = tot; self = t - ni; while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (buf[mid] < y[u]) lo = mid + 1; else hi = mid; } } // copied id: the extras smaller
+						else { // extra: the copied ids not larger
+							lo = 0; hi = ni; self = t - ni;
+							while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (buf[mid] <= y[u]) lo = mid + 1; else hi = mid; }
+							if (lo > 0 && buf[lo - 1] == y[u]) s_dup = 1;
+						}
 						row[p0 + self + lo] = y[u];
 					}
 				}
 				iBase = splits[ntl];
 				CT(7);
 			}
+			dedupe_row();
 		};
 		// Where the tables live is decided BEFORE the walk (a long block list is the serial part of the row: it is walked once):
 		// at most bc / 2 + 1 blocks are copied and at most min(dref, d) ids, so a referent of up to COPY_BIG_CAP ids with a
