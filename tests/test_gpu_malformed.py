@@ -323,6 +323,14 @@ def test_extras_that_equal_copied_ids_are_emitted_once(tmp_path, monkeypatch, kn
     rp, sc = g.decode_range(101, 303)
     assert np.array_equal(sc, sc0[rp0[101]:rp0[303]])
     g.close()
+    for dense in ("0", "1"):  # the batch entry point: chains decoded per query (k_bcopy_coop / the lane merges) or a masked scan
+        monkeypatch.setenv("BVGPU_BATCH_DENSE", dense)
+        g = BVGraph.load(base)
+        q = np.arange(len(recs) - 1, -1, -1, dtype=np.int32)
+        rpb, scb = g.successors_batch(q)
+        for i, x in enumerate(q):
+            assert np.array_equal(scb[rpb[i]:rpb[i + 1]], sc0[rp0[x]:rp0[x + 1]]), (dense, x)
+        g.close()
 
 
 @pytest.mark.parametrize("shape", ["lds", "chunks", "stream"])
@@ -389,3 +397,11 @@ def test_group_class_emits_equal_heads_once(tmp_path, monkeypatch, shape, knobs)
     for x in range(len(recs)):
         assert np.array_equal(sc[rp0[x]:rp0[x + 1]], sc0[rp0[x]:rp0[x + 1]]), (shape, x)
     g.close()
+    for dense in ("0", "1"):
+        monkeypatch.setenv("BVGPU_BATCH_DENSE", dense)
+        g = BVGraph.load(base)
+        q = np.array([1, 2, 5, 6, 9, 10, 0], dtype=np.int32)
+        rpb, scb = g.successors_batch(q)
+        for i, x in enumerate(q):
+            assert np.array_equal(scb[rpb[i]:rpb[i + 1]], sc0[rp0[x]:rp0[x + 1]]), (shape, dense, x)
+        g.close()
