@@ -433,10 +433,11 @@ __device__ __forceinline__ void parse_node(const GraphDev &g, int32_t x, int32_t
 	if (br.err | bi.err) atomicOr(err, br.err | bi.err);
 }
 
-__device__ __forceinline__ int32_t record_bin(uint64_t bitsLen) { // half-octave steps from 16 bits up: the lanes of a wave differ by < 1.5x
+__device__ __forceinline__ int32_t record_bin(uint64_t bitsLen) { // half-octave steps (BIN_SUB = 1) from 16 bits up: the lanes of a wave differ by < 1.5x
 	const int lg = 63 - __clzll((long long)(bitsLen | 1));
-	const int h = 2 * lg + (lg > 0 ? (int)((bitsLen >> (lg - 1)) & 1) : 0);
-	return h < 8 ? 0 : h - 8 >= NBIN ? NBIN - 1 : h - 8;
+	const int h = (lg << BIN_SUB) + (lg >= BIN_SUB ? (int)((bitsLen >> (lg - BIN_SUB)) & ((1u << BIN_SUB) - 1u)) : 0);
+	constexpr int BASE = 4 << BIN_SUB; // (16 bits: lg = 4)
+	return h < BASE ? 0 : h - BASE >= NBIN ? NBIN - 1 : h - BASE;
 }
 
 // A row that copies from a very long referent can have a block list of thousands of codes, whatever its own length:

@@ -18,7 +18,10 @@ inline const char *bv_env(const char *name) {
 namespace bv {
 
 // work-list keys (bv_kernels.hip, "work lists")
-constexpr int NBIN = 24, MAXLVL = 64, NKEYS = NBIN * MAXLVL;
+#ifndef BIN_SUB_ // (tuning builds) bits of a work bin below the octave: 1 = half-octave steps (the lanes of a wave differ by < 1.41x), 2 = quarter-octave steps (< 1.19x)
+#define BIN_SUB_ 1
+#endif
+constexpr int BIN_SUB = BIN_SUB_, NBIN = 12 << BIN_SUB, MAXLVL = 64, NKEYS = NBIN * MAXLVL;
 constexpr uint16_t KEY_NONE = 0xffff, KEY_GIANT = 0xfffe;
 
 // A scan that folds ImmutableGraph.hashCode() (ImmutableGraph.java:757-770) instead of handing the rows to anybody (bvg_scan_checksum).  The hash of the
@@ -121,7 +124,7 @@ void launch_hash_rest(const RangeView &v, int what, bool inParse, bool inCopy, i
 // one wave per record of `list` (ctl[which] entries, queue head ctl[which + 2]): k_parse_big<1>
 void launch_wait_giants(const int32_t *ctl, int giantGroups, hipStream_t st); // holds st until the giants' groups are on their CUs (or 30 us have passed)
 void launch_parse_listed(const GraphDev &g, int def, const RangeView &v, const int32_t *list, int32_t *ctl, int which, void *arena, int64_t arenaCap, int waves, int *err, hipStream_t st);
-constexpr int PARSE_LONG_BIN = 14; // work bins from here up (>= 2048 bits of work) are not windowed (k_depth_keys)
+constexpr int PARSE_LONG_BIN = 7 << BIN_SUB; // work bins from here up (>= 2048 bits of work) are not windowed (k_depth_keys)
 // bv_seg.hip: the segment pipeline -- the residual sections of the hubs (giant records with >= minD successors), handed over by k_parse_big
 size_t seg_scratch_bytes(int32_t Rtot, int32_t Scap, int zetaK);
 void launch_seg_sizing(const int64_t *offsets, int32_t lo, int32_t n, const int32_t *outd, const uint16_t *ref, unsigned long long *out5, hipStream_t st); // out5 (zeroed by the caller): records and bits of the long bins, longest record, rows and ids of the copy pass's lane class
