@@ -173,6 +173,7 @@ struct bvg_graph {
 	int keys_in_headers = 1; // BVGPU_KEYS_IN_HEADERS=0: the parse list's keys by k_depth_keys, not by k_headers
 	bool keys_ready = false; // (per job) k_headers wrote them
 	int level_bins = 1;  // BVGPU_LEVEL_BINS=0: the level lists in node order (round 5), not sorted by the records' work bins inside a level: the wave loop of k_copy_list_w runs as long as its longest row
+	int waves_on_b = 1;  // BVGPU_WAVES_ON_B=0: the wave class of a tile job without giants behind the pre-walks on side A (round 5), not on side B
 	int pick_aside = 1;  // BVGPU_PICK_ASIDE=0: k_pick_coop in front of the scan of the outdegrees, not beside it
 	int list_refs = 1;   // BVGPU_LIST_REFS=0: plain slot numbers in the parse list (k_parse_list looks the reference up)
 	int copy_loop = 1;   // BVGPU_COPY_LOOP=0: the lane class of the copy pass merges lane by lane (copy_node_tab), not as a loop of the wave (k_copy_list_w)
@@ -282,6 +283,7 @@ int apply_option(bvg_graph *g, const std::string &name, const char *value) {
 	else if (name == "copy_loop") g->copy_loop = iv;
 	else if (name == "list_refs") g->list_refs = iv;
 	else if (name == "pick_aside") g->pick_aside = iv;
+	else if (name == "waves_on_b") g->waves_on_b = iv;
 	else if (name == "level_bins") g->level_bins = iv;
 	else if (name == "keys_in_headers") g->keys_in_headers = iv;
 	else if (name == "giants_after_list") g->giants_after_list = iv;
@@ -307,7 +309,7 @@ int apply_option(bvg_graph *g, const std::string &name, const char *value) {
 	return BVG_OK;
 }
 const char *const OPTION_NAMES[] = { "coop_min", "giant_min", "coop_waves", "giant_groups", "level_blocks", "copy_big", "parse_windows", "tile", "seg", "seg_hub_min", "seg_blocks", "lists_on_b", "skip_empty_giants", "level_lists_early",
-	"walk_tables", "copy_vec", "lane_loop", "copy_loop", "list_refs", "pick_aside", "level_bins", "copy_tables", "giants_after_list", "keys_in_headers", "prewalk", "prewalk_long", "prewalk_blocks", "copy_mid_min", "overlap", "halo_min", "batch_dense", "scan_top_tiled_min", "wait_giants", "hash_materialise",
+	"walk_tables", "copy_vec", "lane_loop", "copy_loop", "list_refs", "pick_aside", "waves_on_b", "level_bins", "copy_tables", "giants_after_list", "keys_in_headers", "prewalk", "prewalk_long", "prewalk_blocks", "copy_mid_min", "overlap", "halo_min", "batch_dense", "scan_top_tiled_min", "wait_giants", "hash_materialise",
 	"ef_hash_materialise", "scan_piece", "dbg", "stats", "trace_retry", "trace_err", "trace_host" };
 void options_from_env(bvg_graph *g) {
 	for (const char *n : OPTION_NAMES) {
@@ -760,7 +762,10 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			// the giants' groups take a CU each: started while the parse list is still being scattered they starve k_scatter_keys of its blocks (profiles/r4_experiments.txt section 9:
 			// 48 -> 402 us) -- until round 5 the order rested on the scan of the outdegrees being the slower of the two chains; now the giants WAIT for the list (giants_after_list = 0: as before)
 			if (earlyList && g->giants_after_list && !noGiants) HIPCHK(g, hipStreamWaitEvent(side_b(g), g->evP, 0));
-			bv::launch_parse_big(gd, s.def, v, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, noGiants ? 0 : g->giant_groups, derr, side_b(g), g->sideA, g->wait_giants); // (giants, big)
+			// (a tile job without giants whose level lists and pre-walks went to side A during the set-up: the wave class on side B, which is idle, beside the tile kernel --
+			// behind the pre-walks it started when the tile kernel ended and ran 0.2 ms alone on cnr-2000 x 30)
+			const bool wavesOnB = g->waves_on_b && noGiants && earlyLevels;
+			bv::launch_parse_big(gd, s.def, v, g->biglist.as<int32_t>(), g->giantlist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, noGiants ? 0 : g->giant_groups, derr, side_b(g), wavesOnB ? side_b(g) : g->sideA, g->wait_giants); // (giants, big)
 			if (!segReady) HIPCHK(g, hipEventRecord(g->evB, side_b(g))); // (else: behind the segment pipeline's chain, below)
 		}
 		// ... then, behind the wave class, the chain depth of every record + per-level lists (node order inside a level) +
