@@ -14,9 +14,10 @@
 //   k_parse_big<8>   eight waves per record}
 //                    every parse kernel writes the record's "extra" successors (intervals + residuals, merged) to
 //                    the TAIL of its CSR row                                            (BVG:1058-1100, :939-991)
-//   k_copy_list,     for l = 1..maxdepth: rows whose chain depth is l merge the masked copy of their referent's
+//   k_copy_list_w,   for l = 1..maxdepth: rows whose chain depth is l merge the masked copy of their referent's
 //   k_copy_mid,      (already final) row with their extras, in place: one lane / one wave / one 1024-thread group
 //   k_copy_big       per row                                                 (MaskedIntIterator / MergedIntIterator)
+//                    (k_copy_list_w: the 64 rows of a wave merged as ONE loop from the tables the parse left; k_copy_list: lane by lane)
 //   k_chain_*, k_bparse, k_bcopy   the same for batches of random-access queries (slots of reference chains)
 //   k_hash_*         ImmutableGraph.hashCode of a decoded CSR
 // Older single-purpose variants kept as fallbacks behind knobs: k_parse, k_copy (node-order sweeps).  Tile kernels behind
