@@ -642,8 +642,11 @@ __global__ void __launch_bounds__(TPB) k_copy_list(GraphDev g, RangeView v, cons
 // wave waits for memory at nearly every id of its longest row -- a level of cnr-2000 x 30 lasted 215 us for rows of 12 ids, whatever the class bound.  Here a pass is: every lane
 // loads its next four copied ids, the first four of its next kept block and its next four extras (three loads in flight at once, ONE wait), then four trips that emit min(copied
 // head, extra head) each.  Rows without a table (CT_NONE, or an overflow that does not fit) take the old merges, lane by lane, before the wave's loop.
+#ifndef COPY_W_MINWAVES // (tuning builds)
+#define COPY_W_MINWAVES 1
+#endif
 template <int DEF, bool VEC>
-__global__ void __launch_bounds__(TPB) k_copy_list_w(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ list,
+__global__ void __launch_bounds__(TPB, COPY_W_MINWAVES) k_copy_list_w(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ list,
                                                      const int32_t *__restrict__ keyBase, int32_t level, int32_t midMin, int32_t bigMin, int *__restrict__ err,
                                                      const IvEntry *__restrict__ arena, int64_t arenaCap, const CopyTab *__restrict__ ctab) {
 	const int32_t bucket = min(level, MAXLVL - 1);
