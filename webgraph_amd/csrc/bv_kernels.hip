@@ -1956,20 +1956,28 @@ __device__ __forceinline__ void copy_rows_tab(bool have, int32_t d, int32_t dref
 	int32_t b = 0, i = 0, end = 0, k = 0, ec = 0; // kept block, index in the referent's row and the block's end there, ids emitted, extras consumed
 	if (!done) { const uint32_t e0 = (uint32_t)hd.z; i = (int32_t)(e0 >> 16); end = min(i + (int32_t)(e0 & 0xffffu), dref); }
 	uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0;
-	uint32_t E0 = SENT, E1 = SENT, E2 = SENT, E3 = SENT; // the window of extras lives across the passes: a row has few of them (2.8 on cnr-2000), and every load of this kernel is a cache line of its own
+#ifndef COPY_W_WIDE // 1: windows of eight ids (two 16-byte loads side by side) and eight trips per pass -- half the round trips of a row; 0: four and four (tuning builds)
+#define COPY_W_WIDE 1
+#endif
+	constexpr int WN = COPY_W_WIDE ? 8 : 4; // ids per window = trips per pass
+	uint32_t E0 = SENT, E1 = SENT, E2 = SENT, E3 = SENT, E4 = SENT, E5 = SENT, E6 = SENT, E7 = SENT; // the window of extras lives across the passes: a row has few of them (2.8 on cnr-2000), and every load of this kernel is a cache line of its own
 	int32_t en = 0;
 	while (wave_any(!done)) {
-		uint32_t A0 = SENT, A1 = SENT, A2 = SENT, A3 = SENT, B0 = SENT, B1 = SENT, B2 = SENT, B3 = SENT;
+		uint32_t A0 = SENT, A1 = SENT, A2 = SENT, A3 = SENT, A4 = SENT, A5 = SENT, A6 = SENT, A7 = SENT, B0 = SENT, B1 = SENT, B2 = SENT, B3 = SENT;
 		int32_t An = 0, Bn = 0, nI = 0, nEnd = 0;
 		bool stall = false;
 		if (!done) {
 			if (i >= end && b + 1 < kept) { b++; const uint32_t e = entry(b); i = (int32_t)(e >> 16); end = min(i + (int32_t)(e & 0xffffu), dref); } // a crossing left over from the last pass
-			An = max(0, min(4, end - i));
+			An = max(0, min(WN, end - i));
 			if (An > 0) {
 				if (i + 4 <= limS) { const i32x4_u q = *(const i32x4_u *)(src + i); A0 = (uint32_t)q.x; A1 = (uint32_t)q.y; A2 = (uint32_t)q.z; A3 = (uint32_t)q.w; }
 				else { A0 = (uint32_t)src[i]; An = 1; }
+				if (WN == 8 && An > 4) {
+					if (i + 8 <= limS) { const i32x4_u q = *(const i32x4_u *)(src + i + 4); A4 = (uint32_t)q.x; A5 = (uint32_t)q.y; A6 = (uint32_t)q.z; A7 = (uint32_t)q.w; }
+					else An = 4;
+				}
 			}
-			if (An < 4 && b + 1 < kept) {
+			if (An < WN && b + 1 < kept) {
 				const uint32_t e = entry(b + 1);
 				nI = (int32_t)(e >> 16); nEnd = min(nI + (int32_t)(e & 0xffffu), dref);
 				Bn = max(0, min(4, nEnd - nI));
@@ -1980,13 +1988,17 @@ __device__ __forceinline__ void copy_rows_tab(bool have, int32_t d, int32_t dref
 			}
 			const int32_t pe = copied + ec;
 			if (en < 2 && pe + en < d) { // (re)load the window from its head on
-				en = min(4, d - pe);
+				en = min(WN, d - pe);
 				if (pe + 4 <= limE) { const i32x4_u q = *(const i32x4_u *)(row + pe); E0 = (uint32_t)q.x; E1 = (uint32_t)q.y; E2 = (uint32_t)q.z; E3 = (uint32_t)q.w; }
 				else { E0 = (uint32_t)row[pe]; en = 1; }
+				if (WN == 8 && en > 4) {
+					if (pe + 8 <= limE) { const i32x4_u q = *(const i32x4_u *)(row + pe + 4); E4 = (uint32_t)q.x; E5 = (uint32_t)q.y; E6 = (uint32_t)q.z; E7 = (uint32_t)q.w; }
+					else en = 4;
+				}
 			}
 		}
 #pragma unroll
-		for (int tr = 0; tr < 4; tr++) {
+		for (int tr = 0; tr < WN; tr++) {
 			const bool act = !done && !stall;
 			const uint32_t cv = An > 0 ? A0 : SENT, ev = en > 0 ? E0 : SENT;
 			const uint32_t val = min(cv, ev);
@@ -1995,9 +2007,9 @@ __device__ __forceinline__ void copy_rows_tab(bool have, int32_t d, int32_t dref
 				o0 = o1; o1 = o2; o2 = o3; o3 = val; k++;
 				if ((k & 3) == 0) *(i32x4_u *)(row + k - 4) = i32x4_u{ (int32_t)o0, (int32_t)o1, (int32_t)o2, (int32_t)o3 };
 			}
-			if (takeE) { E0 = E1; E1 = E2; E2 = E3; en--; ec++; if (en == 0 && copied + ec < d) stall = true; } // (more extras, none in a register: a single-id window, or the pass's last trip)
+			if (takeE) { E0 = E1; E1 = E2; E2 = E3; if (WN == 8) { E3 = E4; E4 = E5; E5 = E6; E6 = E7; } en--; ec++; if (en == 0 && copied + ec < d) stall = true; } // (more extras, none in a register: a single-id window, or the pass's last trip)
 			if (takeC) {
-				A0 = A1; A1 = A2; A2 = A3; An--; i++;
+				A0 = A1; A1 = A2; A2 = A3; if (WN == 8) { A3 = A4; A4 = A5; A5 = A6; A6 = A7; } An--; i++;
 				if (An == 0) {
 					if (i >= end && Bn > 0) { A0 = B0; A1 = B1; A2 = B2; A3 = B3; An = Bn; Bn = 0; b++; i = nI; end = nEnd; }
 					else if (i < end || b + 1 < kept) stall = true; // more copied ids, none of them in a register
