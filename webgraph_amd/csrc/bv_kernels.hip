@@ -1479,13 +1479,26 @@ __global__ void __launch_bounds__(TPB, PARSE_LIST_MINWAVES) k_parse_list(GraphDe
 			if (LWC) {
 				CopyTab *const ct = ctab ? ctab + s : nullptr; // the slot's table of copy blocks, for the copy pass
 				const int32_t own = g.minInt > 0 ? aslice - 1 : 0;
+				uint32_t *const ring = lw + LW_MAIN * LW_STRIDE + threadIdx.x; // the lane's ring of intervals, behind the stream windows
+				auto open_window = [&](LaneWin<LW_MAIN> &br, uint64_t off0, uint64_t off1, int32_t d_, int32_t r_) { // the lane's window of the stream, from the record's block count on
+					br.col = lw + threadIdx.x;
+					br.vlast = min(((off1 >> 5) + 2) & ~(uint64_t)3, (g.nwords + 4) & ~(uint64_t)3);
+					const uint64_t at = record_body(g, off0, d_, r_);
+					br.seek_short(g, at, off1 > at ? off1 - at : 0);
+				};
 				if (HASH) {
 					const bool mine = s >= v.nh && rC == 0;
 					const uint32_t hw = mine ? hash_upow(hx.ptab, (uint64_t)(1 + rbC + (int64_t)s)) : 0u;
 					const bool keep = !mine || hx.mark[s] != 0;
-					parse_node_lwc<DEF == 1 ? 3 : 0, true>(g, v.lo + s, dC, rC, drefC, row, lw, (int2 *)(arena + abase), own, ct, err, oaC, obC, &hacc, hw, keep);
+					LaneWin<LW_MAIN> br;
+					open_window(br, oaC, obC, dC, rC);
+					parse_node_lwc<DEF == 1 ? 3 : 0, true>(g, br, ring, v.lo + s, dC, rC, drefC, row, (int2 *)(arena + abase), own, ct, err, &hacc, hw, keep);
 				}
-				else parse_node_lwc<DEF == 1 ? 3 : 0>(g, v.lo + s, dC, rC, drefC, row, lw, (int2 *)(arena + abase), own, ct, err, oaC, obC);
+				else {
+					LaneWin<LW_MAIN> br;
+					open_window(br, oaC, obC, dC, rC);
+					parse_node_lwc<DEF == 1 ? 3 : 0>(g, br, ring, v.lo + s, dC, rC, drefC, row, (int2 *)(arena + abase), own, ct, err);
+				}
 			}
 			else if (HASH) {
 				const bool mine = s >= v.nh && rC == 0; // hashed here; the others (rows with a reference, halo rows) are written as ever
@@ -2699,10 +2712,10 @@ void launch_tile_bounds(const GraphDev &g, int32_t lo, int32_t cnt, int32_t ntil
 }
 void launch_parse_tile(const GraphDev &g, int def, const RangeView &v, const int32_t *tb, int32_t ntiles, int variant, int *err, hipStream_t st, void *tabArena, int64_t tabArenaCap, void *copyTab) {
 	if (v.cnt <= 0 || ntiles <= 0) return;
-	(void)variant; // one lane per record (bv_tile.hpp)
+	const int waveLoop = (variant & 0x100) ? 1 : 0; // one lane per record (bv_tile.hpp), through the wave's loop (parse_node_lwc) or the tile's own reader
 	IvEntry *a = g.minInt > 0 ? (IvEntry *)tabArena : nullptr;
-	if (def == 1) hipLaunchKernelGGL(k_parse_tile<1>, dim3(ntiles), dim3(TILE_T), 0, st, g, v, tb, err, a, tabArenaCap, (CopyTab *)copyTab);
-	else hipLaunchKernelGGL(k_parse_tile<2>, dim3(ntiles), dim3(TILE_T), 0, st, g, v, tb, err, a, tabArenaCap, (CopyTab *)copyTab);
+	if (def == 1) hipLaunchKernelGGL(k_parse_tile<1>, dim3(ntiles), dim3(TILE_T), 0, st, g, v, tb, err, a, tabArenaCap, (CopyTab *)copyTab, waveLoop);
+	else hipLaunchKernelGGL(k_parse_tile<2>, dim3(ntiles), dim3(TILE_T), 0, st, g, v, tb, err, a, tabArenaCap, (CopyTab *)copyTab, waveLoop);
 }
 
 void launch_parse_listed(const GraphDev &g, int def, const RangeView &v, const int32_t *list, int32_t *ctl, int which, void *arena, int64_t arenaCap, int waves, int *err, hipStream_t st) {

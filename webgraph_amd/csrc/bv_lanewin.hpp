@@ -86,6 +86,9 @@ template <int NWORDS> struct LaneWin {
 		}
 	}
 	__device__ __forceinline__ uint64_t pos() const { return (w0 << 5) + q; }
+	// (what parse_node_lwc asks of a reader -- the tile kernel's is TileRd, bv_tile.hpp)
+	__device__ __forceinline__ uint32_t word(uint32_t j) const { return col[j * LW_STRIDE]; } // word j of the window
+	__device__ __forceinline__ bool low(uint32_t margin) const { return (q >> 5) + margin >= (uint32_t)NWORDS; } // fewer than `margin` words left behind the cursor
 	// Called where the wave is converged: if ANY lane is about to run out of window, ALL lanes move theirs up to
 	// their cursor.  Left to themselves the lanes would each stall the whole wave for a memory round trip at a
 	// different iteration (64 lanes, one refill every ~40 codes each: a stall in almost every iteration).
@@ -352,10 +355,10 @@ __device__ __forceinline__ bool lane_zeta3_add(uint32_t W, uint32_t &add, uint32
 	return W >= (1u << 25);
 }
 // As code_w, 32 bits wide: values past 2^32 - 1 (a malformed stream) saturate, which every caller rejects.
-template <int KIND, int ZK = 3> __device__ __forceinline__ uint32_t code_w32(LaneWin<LW_MAIN> &br, const GraphDev &g, bool want, int &err) {
+template <int KIND, int ZK = 3, class RD> __device__ __forceinline__ uint32_t code_w32(RD &br, const GraphDev &g, bool want, int &err) {
 	br.template wave_refill<3>(g);
 	const uint32_t j = br.q >> 5, sh = br.q & 31u;
-	const uint64_t ab = ((uint64_t)br.col[j * LW_STRIDE] << 32) | br.col[(j + 1) * LW_STRIDE];
+	const uint64_t ab = ((uint64_t)br.word(j) << 32) | br.word(j + 1);
 	uint32_t v, len;
 	const bool ok = lane_fast_code<KIND, ZK>((uint32_t)((ab << sh) >> 32), v, len, (uint32_t)g.zetaK);
 	if (wave_any(want && !ok)) {
@@ -367,18 +370,16 @@ template <int KIND, int ZK = 3> __device__ __forceinline__ uint32_t code_w32(Lan
 
 // off0 / off1: the record's first bit and the next record's; r: its reference (0: none), dref: the referent's outdegree; iv: the record's slice of the interval arena
 // (ivOwn 16-byte entries of it are the record's alone); ctab: the slot's table (null: none).  HASH: as parse_node_lwb.
-template <int ZK, bool HASH = false>
-__device__ __forceinline__ void parse_node_lwc(const GraphDev &g, int32_t x, int32_t d, int32_t r, int32_t dref, int32_t *__restrict__ row, uint32_t *lds, int2 *__restrict__ iv, int32_t ivOwn,
-                                               CopyTab *__restrict__ ctab, int *__restrict__ err, uint64_t off0, uint64_t off1, uint32_t *hacc = nullptr, uint32_t hw = 0, bool hstore = true) {
-	LaneWin<LW_MAIN> br;
-	br.col = lds + threadIdx.x;
-	uint32_t *const ring = lds + LW_MAIN * LW_STRIDE + threadIdx.x; // entry j of the ring: ring[2 j * LW_STRIDE] = left, ring[(2 j + 1) * LW_STRIDE] = length
-	br.vlast = min(((off1 >> 5) + 2) & ~(uint64_t)3, (g.nwords + 4) & ~(uint64_t)3);
+// where the record's block count starts: behind the outdegree (gamma: 2 floor(log2(d + 1)) + 1 bits) and the reference (unary: r + 1 bits) that k_headers read (BVG:1048-1054)
+__device__ __forceinline__ uint64_t record_body(const GraphDev &g, uint64_t off0, int32_t d, int32_t r) {
+	return off0 + (2u * (31u - (uint32_t)__clz((int)((uint32_t)d + 1u))) + 1u) + (g.W > 0 ? (uint32_t)r + 1u : 0u);
+}
+// br: the reader, positioned at record_body() (LaneWin: the lane's own window of the stream; TileRd: the tile's shared image); ring: the lane's ring of RING intervals in LDS (a power
+// of two), entry j = ring[2 j * LW_STRIDE] (left), ring[(2 j + 1) * LW_STRIDE] (length)
+template <int ZK, bool HASH = false, int RING = LW_RING, class RD>
+__device__ __forceinline__ void parse_node_lwc(const GraphDev &g, RD &br, uint32_t *ring, int32_t x, int32_t d, int32_t r, int32_t dref, int32_t *__restrict__ row, int2 *__restrict__ iv, int32_t ivOwn,
+                                               CopyTab *__restrict__ ctab, int *__restrict__ err, uint32_t *hacc = nullptr, uint32_t hw = 0, bool hstore = true) {
 	const bool hasRef = r > 0;
-	{
-		const uint64_t at = off0 + (2u * (31u - (uint32_t)__clz((int)((uint32_t)d + 1u))) + 1u) + (g.W > 0 ? (uint32_t)r + 1u : 0u); // behind the outdegree and the reference (BVG:1048-1054; k_headers read them)
-		br.seek_short(g, at, off1 > at ? off1 - at : 0);
-	}
 	int e = 0;
 	int32_t copied = 0;
 	const bool tab = hasRef && ctab != nullptr;
@@ -420,7 +421,7 @@ __device__ __forceinline__ void parse_node_lwc(const GraphDev &g, int32_t x, int
 		const uint32_t ni = code_w32<1>(br, g, true, e);
 		if ((uint64_t)ni * (uint32_t)g.minInt > (uint64_t)(uint32_t)extra) { leave_table(false); atomicOr(err, E_FORMAT); return; } // (an interval holds >= minInt ids; the arena slice has d / minInt + 1 entries)
 		nIv = (int32_t)ni;
-		const bool spill = nIv >= LW_RING; // with the sentinel the list does not fit the ring: all of it goes to the arena too
+		const bool spill = nIv >= RING; // with the sentinel the list does not fit the ring: all of it goes to the arena too
 		int32_t prevEnd = 0;
 		for (int32_t i = 0; wave_any(i < nIv && !e); i++) {
 			const bool w = i < nIv && !e;
@@ -433,12 +434,12 @@ __device__ __forceinline__ void parse_node_lwc(const GraphDev &g, int32_t x, int
 					ivArcs += n;
 					const int32_t left = i == 0 ? (int32_t)((int64_t)x + nat2int(a)) : prevEnd + (int32_t)a + 1; // BVG:1084-1093, in Java ints
 					prevEnd = left + n;
-					if (i < LW_RING) { ring[(2 * i) * LW_STRIDE] = (uint32_t)left; ring[(2 * i + 1) * LW_STRIDE] = (uint32_t)n; }
+					if (i < RING) { ring[(2 * i) * LW_STRIDE] = (uint32_t)left; ring[(2 * i + 1) * LW_STRIDE] = (uint32_t)n; }
 					if (spill) iv[i] = int2{ left, n };
 				}
 			}
 		}
-		if (nIv < LW_RING) { ring[(2 * nIv) * LW_STRIDE] = SENT; ring[(2 * nIv + 1) * LW_STRIDE] = 1u; }
+		if (nIv < RING) { ring[(2 * nIv) * LW_STRIDE] = SENT; ring[(2 * nIv + 1) * LW_STRIDE] = 1u; }
 		else iv[nIv] = int2{ -1, 1 };
 		if (spill && tabOk && kept > 3 && 8 * ((int64_t)nIv + 2) + 4 * ((int64_t)kept - 3) > 16 * (int64_t)ivOwn) tabOk = false; // (the list reached into the table's end of the record's part)
 	} else { ring[0] = SENT; ring[LW_STRIDE] = 1u; }
@@ -450,8 +451,8 @@ __device__ __forceinline__ void parse_node_lwc(const GraphDev &g, int32_t x, int
 	int32_t *const out = row + copied;
 	uint32_t ivLeft = ring[0], ivRem = ring[LW_STRIDE]; // the first interval (or the sentinel)
 	int32_t ivIdx = min(1, nIv);                          // the next entry to take: never past the sentinel's
-	int32_t ivLoaded = LW_RING;                           // (lists in the arena) entries [ivLoaded - LW_RING, ivLoaded) are in the ring; even
-	const bool spillLane = nIv >= LW_RING;
+	int32_t ivLoaded = RING;                           // (lists in the arena) entries [ivLoaded - RING, ivLoaded) are in the ring; even
+	const bool spillLane = nIv >= RING;
 	const bool anySpill = wave_any(spillLane);
 	uint32_t resVal = SENT;
 	int32_t resLeft = 0; // codes of the residual section not read yet
@@ -461,10 +462,10 @@ __device__ __forceinline__ void parse_node_lwc(const GraphDev &g, int32_t x, int
 	}
 	auto trip = [&](int32_t k) -> int32_t {
 		// the ring's next entry and the stream's next gap, read by every lane whether it will use them or not
-		const int jr = ivIdx & (LW_RING - 1);
+		const int jr = ivIdx & (RING - 1);
 		const uint32_t rl = ring[(2 * jr) * LW_STRIDE], rn = ring[(2 * jr + 1) * LW_STRIDE];
 		const uint32_t jw = br.q >> 5, sh = br.q & 31u;
-		const uint64_t ab = ((uint64_t)br.col[jw * LW_STRIDE] << 32) | br.col[(jw + 1) * LW_STRIDE];
+		const uint64_t ab = ((uint64_t)br.word(jw) << 32) | br.word(jw + 1);
 		const uint32_t W = (uint32_t)((ab << sh) >> 32);
 		uint32_t add, len;
 		bool ok;
@@ -491,17 +492,17 @@ __device__ __forceinline__ void parse_node_lwc(const GraphDev &g, int32_t x, int
 	for (int32_t k0 = 0; wave_any(k0 < extra); k0 += 4) {
 		// four codes of <= 32 bits behind the cursor, four entries of the ring: or ALL lanes move their windows / top their rings up
 		const bool low = spillLane && ivLoaded <= nIv && ivLoaded - ivIdx < 4;
-		if (wave_any(low | ((br.q >> 5) + 5 >= (uint32_t)LW_MAIN))) {
+		if (wave_any(low | br.low(5))) {
 			br.template wave_refill<5>(g);
 			if (anySpill && wave_any(low)) {
-				// entries [ivLoaded, upto) replace consumed ones (index - LW_RING < ivIdx), two per 16-byte load (ivLoaded is even; one entry past the sentinel may be read: the slice has the room)
-				const int32_t upto = spillLane ? min((ivIdx + LW_RING) & ~1, (nIv + 2) & ~1) : 0;
+				// entries [ivLoaded, upto) replace consumed ones (index - RING < ivIdx), two per 16-byte load (ivLoaded is even; one entry past the sentinel may be read: the slice has the room)
+				const int32_t upto = spillLane ? min((ivIdx + RING) & ~1, (nIv + 2) & ~1) : 0;
 #pragma unroll
-				for (int p = 0; p < LW_RING / 2; p++) {
+				for (int p = 0; p < RING / 2; p++) {
 					const int32_t i0 = ivLoaded + 2 * p;
 					if (i0 < upto) {
 						const int4 t = *(const int4 *)(iv + i0);
-						const int j0 = i0 & (LW_RING - 1);
+						const int j0 = i0 & (RING - 1);
 						ring[(2 * j0) * LW_STRIDE] = (uint32_t)t.x; ring[(2 * j0 + 1) * LW_STRIDE] = (uint32_t)t.y;
 						ring[(2 * j0 + 2) * LW_STRIDE] = (uint32_t)t.z; ring[(2 * j0 + 3) * LW_STRIDE] = (uint32_t)t.w;
 					}

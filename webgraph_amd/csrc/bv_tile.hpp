@@ -112,6 +112,24 @@ struct TFast {
 	}
 };
 
+// The tile's image as a reader of parse_node_lwc (bv_lanewin.hpp; round 6: the wave's loop -- sentinels, four trips per pass, one store per pass -- for the tile kernel too):
+// q counts from the first staged word, a word is one LDS read, nothing is ever refilled; a code the 32-bit decoders cannot take goes through TCur (checked words, all tiers).
+// Only for records whose bits AND the decoders' look-ahead are staged (k_parse_tile checks once per record); the others keep parse_node_tile.
+struct TileRd {
+	const TWin *tw;
+	uint32_t q;
+	__device__ __forceinline__ uint32_t word(uint32_t j) const { return tw->win[j]; }
+	__device__ __forceinline__ bool low(uint32_t) const { return false; }
+	template <int MARGIN> __device__ __forceinline__ void wave_refill(const GraphDev &) {}
+	template <int KIND, int ZK = 3> __device__ __forceinline__ uint64_t code(const GraphDev &g, int &err) {
+		TCur c;
+		c.k0 = 0; c.q = q;
+		const uint64_t v = c.template code<KIND, ZK>(*tw, ZK == 3 ? 3u : (uint32_t)g.zetaK, err);
+		q = c.q;
+		return v;
+	}
+};
+
 // Same contract as parse_node_lw, reading the record from the tile's window.
 // ctab: the slot's table (null: none) -- a record with a reference leaves its copy blocks there for the lane class of the copy pass, as parse_node_lwc does
 // (bv_lanewin.hpp: the format); this reader never touches the arena otherwise.
@@ -222,11 +240,23 @@ __global__ void __launch_bounds__(256) k_tile_bounds(const int64_t *__restrict__
 	tb[t] = a;
 }
 
+#ifndef TILE_WAVE_LOOP // 1: the records of a tile through parse_node_lwc (0: tuning builds without its rings)
+#define TILE_WAVE_LOOP 1
+#endif
+#ifndef TILE_RING_ // intervals a lane's ring holds (a power of two; the lane kernel's is LW_RING = 8: 16 KB per block -- a web-shaped record has two or three)
+#define TILE_RING_ 4
+#endif
+constexpr int TILE_RING = TILE_RING_;
+#ifndef TILE_MINWAVES // blocks per CU the compiler is asked to leave registers for
+#define TILE_MINWAVES 6
+#endif
 template <int DEF>
-__global__ void __launch_bounds__(TILE_T) k_parse_tile(GraphDev g, RangeView v, const int32_t *__restrict__ tb, int *__restrict__ err, IvEntry *__restrict__ arena, int64_t arenaCap, CopyTab *__restrict__ ctab) { // ctab (null: none), arena: the copy blocks' tables for the copy pass
+__global__ void __launch_bounds__(TILE_T, TILE_MINWAVES) k_parse_tile(GraphDev g, RangeView v, const int32_t *__restrict__ tb, int *__restrict__ err, IvEntry *__restrict__ arena, int64_t arenaCap, CopyTab *__restrict__ ctab, int waveLoop) { // ctab (null: none), arena: the copy blocks' tables for the copy pass; waveLoop: parse_node_lwc (knob tile_loop)
 	__shared__ __attribute__((aligned(16))) uint32_t s_win[TILE_WIN_WORDS];
 	__shared__ uint16_t s_list[TILE_NODES];
 	__shared__ int32_t s_hist[TILE_NBIN], s_n;
+	__shared__ uint32_t s_ring[TILE_WAVE_LOOP ? 2 * TILE_RING * TILE_T : 1]; // the lanes' rings of intervals (parse_node_lwc), [word][lane]
+	static_assert(TILE_T == LW_STRIDE, "the ring's layout is the lane kernel's");
 	const int tid = threadIdx.x;
 	const int32_t a = tb[blockIdx.x], b = tb[blockIdx.x + 1];
 	if (a >= b) return;
@@ -299,6 +329,20 @@ __global__ void __launch_bounds__(TILE_T) k_parse_tile(GraphDev g, RangeView v, 
 			int64_t abase; int32_t an;
 			arena_slice(g.minInt, v.rowstart[s], d, abase, an);
 			if (abase >= 0 && abase + an <= arenaCap) { ovfEnd = (int32_t *)(arena + abase + (an - 1)); ovfCap = 4 * (an - 1); }
+		}
+		if (TILE_WAVE_LOOP && waveLoop) {
+			// the wave's loop where the record and the decoders' look-ahead (a trip reads two words at its cursor whether it uses them or not: the cursor never passes the
+			// record's end by more than a code) are staged, and the record has its slice of the arena (interval lists of TILE_RING entries and more go through it)
+			const uint64_t off0 = (uint64_t)g.offsets[v.lo + s], off1 = (uint64_t)g.offsets[v.lo + s + 1];
+			int64_t abase = 0; int32_t an = 0;
+			bool okA = true;
+			if (g.minInt > 0) { arena_slice(g.minInt, v.rowstart[s], d, abase, an); okA = arena != nullptr && abase >= 0 && abase + an <= arenaCap; }
+			const bool staged = ((off1 + 31) >> 5) - w0 + 4 <= (uint64_t)nw;
+			if (staged && okA) {
+				TileRd br{ &tw, (uint32_t)(record_body(g, off0, d, r) - (w0 << 5)) };
+				parse_node_lwc<DEF == 1 ? 3 : 0, false, TILE_RING>(g, br, s_ring + tid, v.lo + s, d, r, r > 0 ? v.outd[s - r] : 0, v.row(s), (int2 *)(arena + abase), g.minInt > 0 ? an - 1 : 0, ctab ? ctab + s : nullptr, err);
+				continue;
+			}
 		}
 		if (BV_TIMING(g, 0x80000)) { if (((int64_t)v.outd[r > 0 ? s - r : s] + (int64_t)(uintptr_t)v.row(s) + g.offsets[v.lo + s] + (int64_t)(uintptr_t)ovfEnd) == 0x123456789ll) atomicOr(err, 1); continue; }
 		parse_node_tile<DEF == 1 ? 3 : 0>(g, tw, v.lo + s, d, r > 0, r > 0 ? (int64_t)v.outd[s - r] : 0, v.row(s), err, ctab ? ctab + s : nullptr, ovfEnd, ovfCap);

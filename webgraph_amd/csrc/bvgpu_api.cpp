@@ -176,6 +176,7 @@ struct bvg_graph {
 	int waves_on_b = 1;  // BVGPU_WAVES_ON_B=0: the wave class of a tile job without giants behind the pre-walks on side A (round 5), not on side B
 	int pick_aside = 1;  // BVGPU_PICK_ASIDE=0: k_pick_coop in front of the scan of the outdegrees, not beside it
 	int list_refs = 1;   // BVGPU_LIST_REFS=0: plain slot numbers in the parse list (k_parse_list looks the reference up)
+	int tile_loop = 1;   // BVGPU_TILE_LOOP=0: the tile kernel decodes with its own reader (parse_node_tile), not with the wave's loop of the lane kernel (parse_node_lwc)
 	int copy_loop = 1;   // BVGPU_COPY_LOOP=0: the lane class of the copy pass merges lane by lane (copy_node_tab), not as a loop of the wave (k_copy_list_w)
 	int lane_loop = 1;   // BVGPU_LANE_LOOP=0: round 4's one-lane loop (parse_node_lwb) instead of round 6's (parse_node_lwc)
 	int copy_tables = 1; // BVGPU_COPY_TABLES=0: the lane class of the copy pass walks the block lists in the stream although the parse left them as tables
@@ -281,6 +282,7 @@ int apply_option(bvg_graph *g, const std::string &name, const char *value) {
 	else if (name == "copy_vec") g->copy_vec = iv;
 	else if (name == "lane_loop") g->lane_loop = iv;
 	else if (name == "copy_loop") g->copy_loop = iv;
+	else if (name == "tile_loop") g->tile_loop = iv;
 	else if (name == "list_refs") g->list_refs = iv;
 	else if (name == "pick_aside") g->pick_aside = iv;
 	else if (name == "waves_on_b") g->waves_on_b = iv;
@@ -309,7 +311,7 @@ int apply_option(bvg_graph *g, const std::string &name, const char *value) {
 	return BVG_OK;
 }
 const char *const OPTION_NAMES[] = { "coop_min", "giant_min", "coop_waves", "giant_groups", "level_blocks", "copy_big", "parse_windows", "tile", "seg", "seg_hub_min", "seg_blocks", "lists_on_b", "skip_empty_giants", "level_lists_early",
-	"walk_tables", "copy_vec", "lane_loop", "copy_loop", "list_refs", "pick_aside", "waves_on_b", "level_bins", "copy_tables", "giants_after_list", "keys_in_headers", "prewalk", "prewalk_long", "prewalk_blocks", "copy_mid_min", "overlap", "halo_min", "batch_dense", "scan_top_tiled_min", "wait_giants", "hash_materialise",
+	"walk_tables", "copy_vec", "lane_loop", "copy_loop", "tile_loop", "list_refs", "pick_aside", "waves_on_b", "level_bins", "copy_tables", "giants_after_list", "keys_in_headers", "prewalk", "prewalk_long", "prewalk_blocks", "copy_mid_min", "overlap", "halo_min", "batch_dense", "scan_top_tiled_min", "wait_giants", "hash_materialise",
 	"ef_hash_materialise", "scan_piece", "dbg", "stats", "trace_retry", "trace_err", "trace_host" };
 void options_from_env(bvg_graph *g) {
 	for (const char *n : OPTION_NAMES) {
@@ -800,7 +802,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 		mark(g, 4);
 		if (coop && !ovl) bv::launch_parse_waves(gd, s.def, v, g->biglist.as<int32_t>(), ctl, g->arena.p, arenaCap, g->coop_waves, derr, g->stream);
 		mark(g, 5);
-		if (tiles) bv::launch_parse_tile(gd, s.def, v, g->tilebounds.as<int32_t>(), ntiles, tileVariant, derr, g->stream, g->arena.p, arenaCap, copyTab);
+		if (tiles) bv::launch_parse_tile(gd, s.def, v, g->tilebounds.as<int32_t>(), ntiles, tileVariant | (g->tile_loop && g->lane_loop ? 0x100 : 0), derr, g->stream, g->arena.p, arenaCap, copyTab);
 		else {
 			if (segReady) { // on side B, behind the giants: the pieces of the records that handed their residual sections over
 				hipStream_t stChain = g->stream;
