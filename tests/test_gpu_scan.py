@@ -268,6 +268,7 @@ KNOBS = [
     # round 6: round 4's one-lane loop instead of the sentinel loop (no copy tables then), the lane class of the copy pass walking the stream although the tables exist,
     # tables with the tile kernel and with the vector merge, the parse list's keys by k_depth_keys, the giants not waiting for the parse list
     {"BVGPU_TILE": "1", "BVGPU_TILE_LOOP": "0"}, {"BVGPU_TILE": "1", "BVGPU_TILE_LOOP": "1", "BVGPU_COOP_MIN": "2147483647"},  # the tile kernel's own reader / the lane kernel's loop over the tile's image
+    {"BVGPU_MID_TABLES": "0"}, {"BVGPU_MID_TABLES": "1", "BVGPU_COPY_MID_MIN": "16", "BVGPU_PREWALK": "0"}, {"BVGPU_MID_TABLES": "1", "BVGPU_COPY_MID_MIN": "8", "BVGPU_TILE": "1", "BVGPU_PREWALK": "0"},  # k_copy_mid: the parse's tables instead of a walk
     {"BVGPU_COPY_LOOP": "0"}, {"BVGPU_LEVEL_BINS": "0"}, {"BVGPU_COPY_LOOP": "0", "BVGPU_LEVEL_BINS": "0", "BVGPU_TILE": "0"}, {"BVGPU_COPY_LOOP": "1", "BVGPU_TILE": "1", "BVGPU_COPY_MID_MIN": "1024"},
     {"BVGPU_LANE_LOOP": "0", "BVGPU_TILE": "0"}, {"BVGPU_COPY_TABLES": "0", "BVGPU_TILE": "0"}, {"BVGPU_TILE": "0", "BVGPU_COPY_VEC": "1"}, {"BVGPU_TILE": "1", "BVGPU_COPY_VEC": "0"},
     {"BVGPU_TILE": "0", "BVGPU_COPY_MID_MIN": "1024", "BVGPU_COOP_MIN": "2147483647"}, {"BVGPU_TILE": "0", "BVGPU_COPY_MID_MIN": "1000", "BVGPU_COOP_MIN": "64", "BVGPU_GIANT_MIN": "4000"},

@@ -706,8 +706,10 @@ __global__ void __launch_bounds__(TPB, COPY_W_MINWAVES) k_copy_list_w(GraphDev g
 constexpr int COPY_MID_WAVES = 4;
 template <int DEF>
 __global__ void __launch_bounds__(64 * COPY_MID_WAVES) k_copy_mid(GraphDev g, RangeView v, const int32_t *__restrict__ depth, const int32_t *__restrict__ queue,
-                                                                  const int32_t *__restrict__ count, int32_t cap, int32_t level, int *__restrict__ err, const int4 *__restrict__ pre) {
+                                                                  const int32_t *__restrict__ count, int32_t cap, int32_t level, int *__restrict__ err, const int4 *__restrict__ pre,
+                                                                  const IvEntry *__restrict__ arena = nullptr, int64_t arenaCap = 0, const CopyTab *__restrict__ ctab = nullptr) { // ctab / arena: the tables the one-lane parse left (null: none)
 	__shared__ int32_t s_vals[COPY_MID_WAVES][COPY_BIG_MIN], s_kend[COPY_MID_WAVES][COPY_BIG_MIN + 1], s_delta[COPY_MID_WAVES][COPY_BIG_MIN + 1];
+	const int32_t coopMinTab = ctab ? v.coopmin() : 0;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	int32_t *vals = s_vals[wave], *kend = s_kend[wave], *delta = s_delta[wave];
 	auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); };
@@ -746,7 +748,46 @@ __global__ void __launch_bounds__(64 * COPY_MID_WAVES) k_copy_mid(GraphDev g, Ra
 		BitReader br;
 		br.init(g.bits, g.nwords);
 		uint64_t bc = 0;
-		if (pw.x >= 0) { // walked already: the tables are in GraphDev::walktab
+		bool fromTab = false;
+		if (pw.x < 0 && d < coopMinTab) {
+			// Not walked by the pre-walk (a list of COPY_COOP_WALK_MIN codes and more), but decoded by the one-lane parse, which left the row's kept blocks as a table (CopyTab:
+			// first index in the referent's row << 16 | length; three in the slot, the others at the end of the record's own part of the arena): the wave turns it into kend /
+			// delta by a prefix sum -- a microsecond instead of the walk of up to a thousand codes by all 64 lanes side by side, 150 cycles each, which WAS this kernel's tail
+			// (C2, level 1: its waves worked 4 us on average and the kernel lasted 330).  The table is read as data: every entry is checked against the two rows.
+			const int4 hd = *(const int4 *)(ctab + s); // (uniform)
+			const uint32_t keptT = (uint32_t)hd.w & 0xffffu;
+			if (keptT != CT_NONE && keptT <= (uint32_t)COPY_BIG_MIN) {
+				const int32_t *tabEnd = nullptr;
+				bool ok = true;
+				if (keptT > 3) {
+					int64_t abase = 0; int32_t an = 0;
+					if (g.minInt > 0) arena_slice(g.minInt, rs0, d, abase, an);
+					ok = arena != nullptr && g.minInt > 0 && abase >= 0 && abase + an <= arenaCap && (int32_t)keptT - 3 <= 4 * (an - 1);
+					tabEnd = (const int32_t *)(arena + abase + (an - 1));
+				}
+				if (ok) {
+					int32_t carry = 0;
+					bool okE = true;
+					for (int32_t j0 = 0; j0 < (int32_t)keptT; j0 += 64) { // (uniform)
+						const int32_t j = j0 + lane;
+						uint32_t ent = 0;
+						if (j < (int32_t)keptT) ent = (uint32_t)(j == 0 ? hd.z : j == 1 ? hd.y : j == 2 ? hd.x : tabEnd[2 - j]);
+						const int32_t len = (int32_t)(ent & 0xffffu), start = (int32_t)(ent >> 16);
+						int32_t inc = len;
+#pragma unroll
+						for (int o = 1; o < 64; o <<= 1) { const int32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+						if (j < (int32_t)keptT) {
+							if (len == 0 || (int64_t)start + len > dref || (int64_t)carry + inc > d) okE = false;
+							kend[j] = carry + inc; delta[j] = start - (carry + inc - len);
+						}
+						carry += __shfl(inc, 63, 64);
+					}
+					if (!__any(!okE) && carry == (int32_t)((uint32_t)hd.w >> 16)) { fromTab = true; nKept = (int32_t)keptT; copied = carry; }
+				}
+			}
+		}
+		if (fromTab) {}
+		else if (pw.x >= 0) { // walked already: the tables are in GraphDev::walktab
 			const int32_t kM = (pw.w >> 1) + 1;
 			nKept = pw.y; copied = pw.z;
 			for (int32_t k = lane; k < nKept; k += 64) { kend[k] = g.walktab[pw.x + k]; delta[k] = g.walktab[pw.x + kM + k]; }
@@ -757,7 +798,7 @@ __global__ void __launch_bounds__(64 * COPY_MID_WAVES) k_copy_mid(GraphDev g, Ra
 			bc = Fields<DEF>::block_count(br, g);
 			if (bc > (uint64_t)dref + 1) continue; // flagged by the parse kernel
 		}
-		for (uint64_t b = 0; pw.x < 0 && b <= bc; b++) {
+		for (uint64_t b = 0; !fromTab && pw.x < 0 && b <= bc; b++) {
 			int64_t len;
 			if (b < bc) len = (int64_t)Fields<DEF>::block(br, g) + (b ? 1 : 0);
 			else len = dref - total; // implicit last block (copied when the block count is even)
@@ -2645,7 +2686,7 @@ void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int
                        int32_t midMinKnob, bool bigGroups, const int32_t *bigQ, int32_t bigCap, const int32_t *midQ, int32_t midCap, int32_t *ctl, int32_t *tmp, uint32_t tmpCap, int *err,
                        hipStream_t st, hipStream_t stMid, hipStream_t stBig, hipEvent_t evFork, hipEvent_t evMid, hipEvent_t evBig, const void *preDesc, bool preMid, int listMode,
                        const void *tabArena, int64_t tabArenaCap, const void *copyTab) {
-	const bool vecList = (listMode & 1) != 0; // listMode: 1 = 16-byte loads and stores in the lane class's merges, 2 = the table merges as a loop of the whole wave (k_copy_list_w)
+	const bool vecList = (listMode & 1) != 0; // listMode: 1 = 16-byte loads and stores in the lane class's merges, 2 = the table merges as a loop of the whole wave (k_copy_list_w), 16 = k_copy_mid takes the parse's tables for the rows the pre-walk left
 	if (v.cnt <= 0) return;
 #ifdef BV_EXP_NOCOPY // (ablation builds: the scan without its copy pass, or without one of its three row classes)
 	return;
@@ -2681,9 +2722,9 @@ void launch_copy_level(const GraphDev &g, int def, const RangeView &v, const int
 #else
 	if (midMin < bigMin) {
 #endif
-		if (def == 1) hipLaunchKernelGGL(k_copy_mid<1>, dim3(1024), dim3(64 * COPY_MID_WAVES), 0, stMid, g, v, depth, midQ, ctl + 6, midCap, level, err, pre && preMid && midQ == bigQ + bigCap ? pre + bigCap : nullptr);
-		else if (def == 2) hipLaunchKernelGGL(k_copy_mid<2>, dim3(1024), dim3(64 * COPY_MID_WAVES), 0, stMid, g, v, depth, midQ, ctl + 6, midCap, level, err, pre && preMid && midQ == bigQ + bigCap ? pre + bigCap : nullptr);
-		else hipLaunchKernelGGL(k_copy_mid<0>, dim3(1024), dim3(64 * COPY_MID_WAVES), 0, stMid, g, v, depth, midQ, ctl + 6, midCap, level, err, pre && preMid && midQ == bigQ + bigCap ? pre + bigCap : nullptr);
+		if (def == 1) hipLaunchKernelGGL(k_copy_mid<1>, dim3(1024), dim3(64 * COPY_MID_WAVES), 0, stMid, g, v, depth, midQ, ctl + 6, midCap, level, err, pre && preMid && midQ == bigQ + bigCap ? pre + bigCap : nullptr, (listMode & 16) ? (const IvEntry *)tabArena : nullptr, tabArenaCap, (listMode & 16) ? (const CopyTab *)copyTab : nullptr);
+		else if (def == 2) hipLaunchKernelGGL(k_copy_mid<2>, dim3(1024), dim3(64 * COPY_MID_WAVES), 0, stMid, g, v, depth, midQ, ctl + 6, midCap, level, err, pre && preMid && midQ == bigQ + bigCap ? pre + bigCap : nullptr, (listMode & 16) ? (const IvEntry *)tabArena : nullptr, tabArenaCap, (listMode & 16) ? (const CopyTab *)copyTab : nullptr);
+		else hipLaunchKernelGGL(k_copy_mid<0>, dim3(1024), dim3(64 * COPY_MID_WAVES), 0, stMid, g, v, depth, midQ, ctl + 6, midCap, level, err, pre && preMid && midQ == bigQ + bigCap ? pre + bigCap : nullptr, (listMode & 16) ? (const IvEntry *)tabArena : nullptr, tabArenaCap, (listMode & 16) ? (const CopyTab *)copyTab : nullptr);
 	}
 	if (stMid != st) (void)hipEventRecord(evMid, stMid);
 #define COPY_LIST(D, V) do { if (copyTab && D != 0 && (listMode & 2)) hipLaunchKernelGGL((k_copy_list_w<(D != 0 ? D : 1), V>), dim3(blocks), dim3(TPB), 0, stList, g, v, depth, list, keyBase, level, midMin, bigMin, err, (const IvEntry *)tabArena, tabArenaCap, (const CopyTab *)copyTab); \

@@ -177,6 +177,7 @@ struct bvg_graph {
 	int pick_aside = 1;  // BVGPU_PICK_ASIDE=0: k_pick_coop in front of the scan of the outdegrees, not beside it
 	int list_refs = 1;   // BVGPU_LIST_REFS=0: plain slot numbers in the parse list (k_parse_list looks the reference up)
 	int tile_loop = 1;   // BVGPU_TILE_LOOP=0: the tile kernel decodes with its own reader (parse_node_tile), not with the wave's loop of the lane kernel (parse_node_lwc)
+	int mid_tables = 1;  // BVGPU_MID_TABLES=0: k_copy_mid walks the block lists that the pre-walk left (192 codes and more) although the one-lane parse left them as tables
 	int copy_loop = 1;   // BVGPU_COPY_LOOP=0: the lane class of the copy pass merges lane by lane (copy_node_tab), not as a loop of the wave (k_copy_list_w)
 	int lane_loop = 1;   // BVGPU_LANE_LOOP=0: round 4's one-lane loop (parse_node_lwb) instead of round 6's (parse_node_lwc)
 	int copy_tables = 1; // BVGPU_COPY_TABLES=0: the lane class of the copy pass walks the block lists in the stream although the parse left them as tables
@@ -282,6 +283,7 @@ int apply_option(bvg_graph *g, const std::string &name, const char *value) {
 	else if (name == "copy_vec") g->copy_vec = iv;
 	else if (name == "lane_loop") g->lane_loop = iv;
 	else if (name == "copy_loop") g->copy_loop = iv;
+	else if (name == "mid_tables") g->mid_tables = iv;
 	else if (name == "tile_loop") g->tile_loop = iv;
 	else if (name == "list_refs") g->list_refs = iv;
 	else if (name == "pick_aside") g->pick_aside = iv;
@@ -311,7 +313,7 @@ int apply_option(bvg_graph *g, const std::string &name, const char *value) {
 	return BVG_OK;
 }
 const char *const OPTION_NAMES[] = { "coop_min", "giant_min", "coop_waves", "giant_groups", "level_blocks", "copy_big", "parse_windows", "tile", "seg", "seg_hub_min", "seg_blocks", "lists_on_b", "skip_empty_giants", "level_lists_early",
-	"walk_tables", "copy_vec", "lane_loop", "copy_loop", "tile_loop", "list_refs", "pick_aside", "waves_on_b", "level_bins", "copy_tables", "giants_after_list", "keys_in_headers", "prewalk", "prewalk_long", "prewalk_blocks", "copy_mid_min", "overlap", "halo_min", "batch_dense", "scan_top_tiled_min", "wait_giants", "hash_materialise",
+	"walk_tables", "copy_vec", "lane_loop", "copy_loop", "mid_tables", "tile_loop", "list_refs", "pick_aside", "waves_on_b", "level_bins", "copy_tables", "giants_after_list", "keys_in_headers", "prewalk", "prewalk_long", "prewalk_blocks", "copy_mid_min", "overlap", "halo_min", "batch_dense", "scan_top_tiled_min", "wait_giants", "hash_materialise",
 	"ef_hash_materialise", "scan_piece", "dbg", "stats", "trace_retry", "trace_err", "trace_host" };
 void options_from_env(bvg_graph *g) {
 	for (const char *n : OPTION_NAMES) {
@@ -524,7 +526,7 @@ int finish_pending(bvg_graph *g, uint64_t *arcs_out) {
 					const bool ov2 = g->overlap && !g->profile;
 					bv::launch_copy_level(gd, s.def, g->pend.view, g->depth.as<int32_t>(), g->lvlist.as<int32_t>(), keyBase, l, g->level_blocks, g->copy_mid_min, g->copy_big != 0,
 					                      g->copyq.as<int32_t>(), g->pend.bigCap, g->copyq.as<int32_t>() + g->pend.bigCap, g->pend.midCap, g->coopctl.as<int32_t>(), g->bigtmp.as<int32_t>(), g->pend.tmpCap, derr,
-					                      g->stream, ov2 ? side_b(g) : g->stream, ov2 ? g->sideA : g->stream, g->evFork, g->evB, g->evA, g->pend.preDesc, g->prewalk < 2 && g->pend.midCap > 0, (copy_vec(g) ? 1 : 0) | (g->copy_loop ? 2 : 0),
+					                      g->stream, ov2 ? side_b(g) : g->stream, ov2 ? g->sideA : g->stream, g->evFork, g->evB, g->evA, g->pend.preDesc, g->prewalk < 2 && g->pend.midCap > 0, (copy_vec(g) ? 1 : 0) | (g->copy_loop ? 2 : 0) | (g->mid_tables ? 16 : 0),
 					                      g->pend.tabArena, g->pend.tabArenaCap, g->pend.copyTab);
 				}
 			}
@@ -832,7 +834,7 @@ int enqueue_decode(bvg_graph *g, bv::RangeView &v, int64_t estArcs, int32_t &lev
 			for (int32_t l = 1; l <= levels; l++) {
 				bv::launch_copy_level(gd, s.def, v, g->depth.as<int32_t>(), g->lvlist.as<int32_t>(), keyBase, l, g->level_blocks, g->copy_mid_min, g->copy_big != 0,
 				                                          g->copyq.as<int32_t>(), bigCap, g->copyq.as<int32_t>() + bigCap, midCap, ctl, g->bigtmp.as<int32_t>(), g->pend.tmpCap, derr,
-				                                          g->stream, ovl ? side_b(g) : g->stream, ovl ? g->sideA : g->stream, g->evFork, g->evB, g->evA, g->pend.preDesc, g->prewalk < 2 && g->pend.midCap > 0, (copy_vec(g) ? 1 : 0) | (g->copy_loop ? 2 : 0),
+				                                          g->stream, ovl ? side_b(g) : g->stream, ovl ? g->sideA : g->stream, g->evFork, g->evB, g->evA, g->pend.preDesc, g->prewalk < 2 && g->pend.midCap > 0, (copy_vec(g) ? 1 : 0) | (g->copy_loop ? 2 : 0) | (g->mid_tables ? 16 : 0),
 				                                          g->pend.tabArena, g->pend.tabArenaCap, g->pend.copyTab);
 			}
 		}
