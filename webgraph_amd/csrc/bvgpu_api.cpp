@@ -177,6 +177,7 @@ struct bvg_graph {
 	int pick_aside = 1;  // BVGPU_PICK_ASIDE=0: k_pick_coop in front of the scan of the outdegrees, not beside it
 	int list_refs = 1;   // BVGPU_LIST_REFS=0: plain slot numbers in the parse list (k_parse_list looks the reference up)
 	int tile_loop = 1;   // BVGPU_TILE_LOOP=0: the tile kernel decodes with its own reader (parse_node_tile), not with the wave's loop of the lane kernel (parse_node_lwc)
+	int stream_prio = 1; // BVGPU_STREAM_PRIO (environment only: read when the handle's streams are created): bit 0 = side B (the giants of the parse phase, the wave class of the copy pass) above the other streams, bit 1 = side A below them; 0: all alike
 	int mid_tables = 1;  // BVGPU_MID_TABLES=0: k_copy_mid walks the block lists that the pre-walk left (192 codes and more) although the one-lane parse left them as tables
 	int copy_loop = 1;   // BVGPU_COPY_LOOP=0: the lane class of the copy pass merges lane by lane (copy_node_tab), not as a loop of the wave (k_copy_list_w)
 	int lane_loop = 1;   // BVGPU_LANE_LOOP=0: round 4's one-lane loop (parse_node_lwb) instead of round 6's (parse_node_lwc)
@@ -284,6 +285,7 @@ int apply_option(bvg_graph *g, const std::string &name, const char *value) {
 	else if (name == "lane_loop") g->lane_loop = iv;
 	else if (name == "copy_loop") g->copy_loop = iv;
 	else if (name == "mid_tables") g->mid_tables = iv;
+	else if (name == "stream_prio") g->stream_prio = iv;
 	else if (name == "tile_loop") g->tile_loop = iv;
 	else if (name == "list_refs") g->list_refs = iv;
 	else if (name == "pick_aside") g->pick_aside = iv;
@@ -313,7 +315,7 @@ int apply_option(bvg_graph *g, const std::string &name, const char *value) {
 	return BVG_OK;
 }
 const char *const OPTION_NAMES[] = { "coop_min", "giant_min", "coop_waves", "giant_groups", "level_blocks", "copy_big", "parse_windows", "tile", "seg", "seg_hub_min", "seg_blocks", "lists_on_b", "skip_empty_giants", "level_lists_early",
-	"walk_tables", "copy_vec", "lane_loop", "copy_loop", "mid_tables", "tile_loop", "list_refs", "pick_aside", "waves_on_b", "level_bins", "copy_tables", "giants_after_list", "keys_in_headers", "prewalk", "prewalk_long", "prewalk_blocks", "copy_mid_min", "overlap", "halo_min", "batch_dense", "scan_top_tiled_min", "wait_giants", "hash_materialise",
+	"walk_tables", "copy_vec", "lane_loop", "copy_loop", "mid_tables", "stream_prio", "tile_loop", "list_refs", "pick_aside", "waves_on_b", "level_bins", "copy_tables", "giants_after_list", "keys_in_headers", "prewalk", "prewalk_long", "prewalk_blocks", "copy_mid_min", "overlap", "halo_min", "batch_dense", "scan_top_tiled_min", "wait_giants", "hash_materialise",
 	"ef_hash_materialise", "scan_piece", "dbg", "stats", "trace_retry", "trace_err", "trace_host" };
 void options_from_env(bvg_graph *g) {
 	for (const char *n : OPTION_NAMES) {
@@ -334,8 +336,15 @@ int init_handle(bvg_graph *g) {
 	if (!g->coopctl.need(bv::CTL_TOTAL_INTS * sizeof(int32_t)) || !g->keys.need(3 * (bv::NKEYS + 1) * sizeof(int32_t))) return fail(g, BVG_ENOMEM, "device allocation failed");
 	HIPCHK(g, hipMemset(g->coopctl.p, 0, bv::CTL_TOTAL_INTS * sizeof(int32_t))); // (k_pick_coop leaves its counters zeroed for the next job)
 	options_from_env(g); // every tuning / debug knob of a handle: read here ONCE (and never per launch), or set later through bvg_set_option
-	HIPCHK(g, hipStreamCreateWithFlags(&g->sideA, hipStreamNonBlocking));
-	HIPCHK(g, hipStreamCreateWithFlags(&g->sideB, hipStreamNonBlocking));
+	if (g->stream_prio) { // side B above the others: what it carries are few, long-lived blocks (the giants' groups; k_copy_mid's waves) that the many short ones of the list kernels would otherwise keep out of the CUs -- C5 shard 4.76 -> 4.65 ms, C2 and cnr-2000 x 30 even (profiles/r6_experiments.txt section 24)
+		int least = 0, greatest = 0;
+		HIPCHK(g, hipDeviceGetStreamPriorityRange(&least, &greatest));
+		HIPCHK(g, hipStreamCreateWithPriority(&g->sideA, hipStreamNonBlocking, (g->stream_prio & 2) ? least : (least + greatest) / 2));
+		HIPCHK(g, hipStreamCreateWithPriority(&g->sideB, hipStreamNonBlocking, (g->stream_prio & 1) ? greatest : (least + greatest) / 2));
+	} else {
+		HIPCHK(g, hipStreamCreateWithFlags(&g->sideA, hipStreamNonBlocking));
+		HIPCHK(g, hipStreamCreateWithFlags(&g->sideB, hipStreamNonBlocking));
+	}
 	HIPCHK(g, hipStreamCreateWithFlags(&g->sideC, hipStreamNonBlocking));
 	g->copyStream = g->sideB; // a fourth stream would share a hardware queue with one of the other three (GPU_MAX_HW_QUEUES = 4, one is the null stream's):
 	                          // its copies then hold back the kernels queued behind them -- measured: every chunk of a host scan took decode + copy, 25 ms instead of 17
